@@ -1,0 +1,214 @@
+/*
+ * havoc_mi355x.h -- C ABI of libhavoc_mi355x.so, the MI355X (gfx950) implementation of the `havoc`
+ * primitive layer of the Turing HEVC encoder.
+ *
+ * Each batch entry point evaluates MANY independent calls of one reference primitive in one kernel launch.
+ * A "job" carries what the reference passes per call as pointers (here: sample offsets into planes that
+ * already live in HBM) and block geometry; strides and bit depth are per launch.  Results are bit-identical
+ * to the reference function cited next to each entry point.
+ *
+ * Conventions
+ *   - every `d_*` pointer is DEVICE memory (hipMalloc / torch.cuda); nothing is copied to or from the host
+ *     unless the name says so (`*_h2d`, `*_d2h`, and the classic per-block API in havoc_classic.hpp);
+ *   - `S` = bytes per sample: 1 (uint8_t, 8-bit) or 2 (uint16_t, 9/10-bit), the reference's `Sample` type;
+ *   - offsets and strides are in SAMPLES (int16 elements for coefficient buffers), exactly like the
+ *     reference's pointer arithmetic (havoc/sad.h:58 etc.); offsets are relative to the plane base pointer
+ *     passed to the call and may address the 96-sample picture padding (turing/StatePictures.h:155-156);
+ *   - launches are asynchronous on the context's HIP stream; call havoc_mi355x_sync() before reading results
+ *     on the host.  Every function returns 0 on success or a negative hipError_t / HAVOC_MI355X_E* code;
+ *     havoc_mi355x_last_error() gives the text.  The reference has no error channel: a
+ *     failure here means the launch did not happen, never that a CPU path was taken.
+ */
+#ifndef HAVOC_MI355X_H
+#define HAVOC_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HAVOC_MI355X_EINVAL (-10001) /* bad argument (S, taps, bit depth, size) */
+#define HAVOC_MI355X_ENODEV (-10002) /* no gfx950 device / HIP runtime unavailable */
+
+typedef struct havoc_mi355x_ctx havoc_mi355x_ctx;
+
+/* ---- context: replaces havoc_new_code / havoc_delete_code (havoc/havoc.h:138-147, havoc.cpp:144-155).
+ * `stream` is a hipStream_t (NULL = the device's default stream; pass torch's current stream to order
+ * launches with torch ops).  Fails with ENODEV when there is no GPU: there is no CPU fallback. */
+int havoc_mi355x_create(havoc_mi355x_ctx **ctx, int device, void *stream);
+void havoc_mi355x_destroy(havoc_mi355x_ctx *ctx);
+int havoc_mi355x_set_stream(havoc_mi355x_ctx *ctx, void *stream);
+int havoc_mi355x_sync(havoc_mi355x_ctx *ctx);
+const char *havoc_mi355x_last_error(void);
+const char *havoc_mi355x_version(void);
+/* device properties for roofline accounting: [0]=CUs [1]=clock kHz [2]=memory clock kHz [3]=bus width bits
+ * [4]=L2 bytes [5]=wavefront size [6]=LDS bytes per workgroup [7]=total global memory MiB */
+int havoc_mi355x_device_info(havoc_mi355x_ctx *ctx, int64_t info[8]);
+
+/* plain device-memory helpers so that a C/C++ host (the encoder) needs no HIP headers */
+int havoc_mi355x_malloc(havoc_mi355x_ctx *ctx, void **d_ptr, size_t bytes);
+int havoc_mi355x_free(havoc_mi355x_ctx *ctx, void *d_ptr);
+int havoc_mi355x_h2d(havoc_mi355x_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int havoc_mi355x_d2h(havoc_mi355x_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+/* timing on the context's stream with HIP events (used by bench.py for per-kernel durations) */
+int havoc_mi355x_timer_start(havoc_mi355x_ctx *ctx);
+int havoc_mi355x_timer_stop_ms(havoc_mi355x_ctx *ctx, float *ms); /* records, synchronises, returns elapsed */
+
+/* ------------------------------------------------------------------------------------------------------- */
+/* job descriptors (plain 32-bit little-endian fields, no padding surprises: sizes asserted in the .cpp)    */
+/* ------------------------------------------------------------------------------------------------------- */
+
+/* two blocks of w x h samples: SAD(src, ref), SSD(a, b), SATD(a, b), residual(src, pred) */
+typedef struct {
+    int32_t a_off;   /* src / srcA */
+    int32_t b_off;   /* ref / srcB */
+    int32_t w, h;
+} havoc_mi355x_pair_job; /* 16 bytes */
+
+/* one source block against four candidate reference positions (havoc/sad.h:100) */
+typedef struct {
+    int32_t src_off;
+    int32_t ref_off[4];
+    int32_t w, h;
+    int32_t reserved;
+} havoc_mi355x_sad4_job; /* 32 bytes */
+
+/* fractional-sample interpolation of one prediction block (havoc/pred_inter.h:35) */
+typedef struct {
+    int32_t dst_off;
+    int32_t ref_off;  /* integer-sample position of the block inside the padded reference plane */
+    int32_t w, h;
+    int32_t xFrac, yFrac; /* quarter (8-tap luma) or eighth (4-tap chroma) sample phase */
+    int32_t reserved[2];
+} havoc_mi355x_pred_uni_job; /* 32 bytes */
+
+/* bi-prediction from two positions of planes sharing one stride (havoc/pred_inter.h:63) */
+typedef struct {
+    int32_t dst_off;
+    int32_t ref0_off, ref1_off;
+    int32_t w, h;
+    int32_t xFrac0, yFrac0, xFrac1, yFrac1;
+    int32_t reserved[3];
+} havoc_mi355x_pred_bi_job; /* 48 bytes */
+
+/* dst = clip(2*src - pred) (havoc/pred_inter.h:87) */
+typedef struct {
+    int32_t dst_off, pred_off, src_off;
+    int32_t w, h;
+    int32_t reserved[3];
+} havoc_mi355x_subtract_bi_job; /* 32 bytes */
+
+/* one intra prediction block (havoc/pred_intra.h:32-52).  nb_off addresses neighbours[0] = p(0,-1):
+ * neighbours[-1] is the corner, [-2 .. -1-2n] the left column top->bottom, [0 .. 2n-1] the top row
+ * (havoc/pred_intra.cpp:43-51).  `edge` = (cIdx == 0): the DC / mode-10 / mode-26 edge filters are applied
+ * when edge && log2 < 5, as Table::lookup does. */
+typedef struct {
+    int32_t dst_off;
+    int32_t nb_off;
+    int32_t log2;    /* 2..5 */
+    int32_t mode;    /* 0 planar, 1 DC, 2..34 angular */
+    int32_t edge;
+    int32_t reserved[3];
+} havoc_mi355x_intra_job; /* 32 bytes */
+
+/* one transform unit.  Used by forward transform (coef <- src residual), inverse transform (+add) and the
+ * quantisers; unused fields are ignored by each entry point. */
+typedef struct {
+    int32_t coef_off;  /* n*n contiguous int16 coefficients (index into the coefficient buffer) */
+    int32_t res_off;   /* int16 residual block (forward input), row stride = stride_res argument */
+    int32_t pred_off;  /* prediction samples (inverse+add input) */
+    int32_t dst_off;   /* reconstructed samples (inverse+add output); may equal pred_off on the same plane */
+    int32_t log2;      /* 2..5 */
+    int32_t trType;    /* 1 = 4x4 DST-VII (log2 must be 2), 0 = DCT-II */
+    int32_t reserved[2];
+} havoc_mi355x_tu_job; /* 32 bytes */
+
+/* one (de)quantisation call over n contiguous int16 values (havoc/quantize.h:42,63) */
+typedef struct {
+    int32_t dst_off, src_off;
+    int32_t n;        /* multiple of 16, as the reference requires */
+    int32_t scale, shift, offset; /* offset ignored by the inverse quantiser */
+    int32_t reserved[2];
+} havoc_mi355x_quant_job; /* 32 bytes */
+
+/* ------------------------------------------------------------------------------------------------------- */
+/* distortion metrics                                                                                        */
+/* ------------------------------------------------------------------------------------------------------- */
+
+/* havoc_sad<Sample> (havoc/sad.h:58, C reference havoc/sad.cpp:432-449): d_out[i] = SAD, 16-bit >> 2 */
+int havoc_mi355x_sad(havoc_mi355x_ctx *ctx, int S, const void *d_src, intptr_t stride_src, const void *d_ref,
+                     intptr_t stride_ref, const havoc_mi355x_pair_job *d_jobs, int njobs, int32_t *d_out);
+/* havoc_sad_multiref<Sample>, ways = 4 (havoc/sad.h:100, havoc/sad.cpp:513-542): d_out[4*i + k] */
+int havoc_mi355x_sad4(havoc_mi355x_ctx *ctx, int S, const void *d_src, intptr_t stride_src, const void *d_ref,
+                      intptr_t stride_ref, const havoc_mi355x_sad4_job *d_jobs, int njobs, int32_t *d_out);
+/* havoc_ssd<Sample> (havoc/ssd.h:33, havoc/ssd.cpp:28-43): uint32 accumulate, 16-bit >> 4 */
+int havoc_mi355x_ssd(havoc_mi355x_ctx *ctx, int S, const void *d_a, intptr_t stride_a, const void *d_b,
+                     intptr_t stride_b, const havoc_mi355x_pair_job *d_jobs, int njobs, uint32_t *d_out);
+/* havoc_hadamard_satd<Sample> tiled over a w x h block exactly as measureSatd does (turing/Measure.h:97-135;
+ * one 2x2 / 4x4 / 8x8 Hadamard = havoc/hadamard.cpp:58-98 when w == h == n) */
+int havoc_mi355x_satd(havoc_mi355x_ctx *ctx, int S, const void *d_a, intptr_t stride_a, const void *d_b,
+                      intptr_t stride_b, const havoc_mi355x_pair_job *d_jobs, int njobs, int32_t *d_out);
+/* havoc_ssd_linear (havoc/diff.h:35, havoc/diff.cpp:29-39): one linear 8-bit run, *d_out = int32 sum */
+int havoc_mi355x_ssd_linear(havoc_mi355x_ctx *ctx, const uint8_t *d_a, const uint8_t *d_b, int size, int32_t *d_out);
+
+/* ------------------------------------------------------------------------------------------------------- */
+/* inter prediction                                                                                          */
+/* ------------------------------------------------------------------------------------------------------- */
+
+/* HavocPredUni<Sample> (havoc/pred_inter.h:35, C reference havoc/pred_inter.cpp:76-202); taps = 8 | 4.
+ * Writes exactly w x h samples per job (the JIT's licence to over-write to the right is not used). */
+int havoc_mi355x_pred_uni(havoc_mi355x_ctx *ctx, int S, int taps, int bitDepth, void *d_dst, intptr_t stride_dst,
+                          const void *d_ref, intptr_t stride_ref, const havoc_mi355x_pred_uni_job *d_jobs, int njobs);
+/* HavocPredBi<Sample> (havoc/pred_inter.h:63, havoc/pred_inter.cpp:1207-1252) */
+int havoc_mi355x_pred_bi(havoc_mi355x_ctx *ctx, int S, int taps, int bitDepth, void *d_dst, intptr_t stride_dst,
+                         const void *d_ref, intptr_t stride_ref, const havoc_mi355x_pred_bi_job *d_jobs, int njobs);
+/* havoc::SubtractBi<Sample> (havoc/pred_inter.h:87, havoc/pred_inter.cpp:2063-2080) */
+int havoc_mi355x_subtract_bi(havoc_mi355x_ctx *ctx, int S, int bitDepth, void *d_dst, intptr_t stride_dst,
+                             const void *d_pred, intptr_t stride_pred, const void *d_src, intptr_t stride_src,
+                             const havoc_mi355x_subtract_bi_job *d_jobs, int njobs);
+
+/* ------------------------------------------------------------------------------------------------------- */
+/* intra prediction                                                                                          */
+/* ------------------------------------------------------------------------------------------------------- */
+
+/* havoc::intra::Function<Sample> via Table::lookup (havoc/pred_intra.h:32-52, pred_intra.cpp:20282-20401) */
+int havoc_mi355x_intra(havoc_mi355x_ctx *ctx, int S, int bitDepth, void *d_dst, intptr_t stride_dst,
+                       const void *d_neighbours, const havoc_mi355x_intra_job *d_jobs, int njobs);
+
+/* ------------------------------------------------------------------------------------------------------- */
+/* residual, transforms, quantisation                                                                        */
+/* ------------------------------------------------------------------------------------------------------- */
+
+/* res = src - pred, int16 (turing/Reconstruct.cpp:258-260, 1274-1286).  job: a = src, b = pred;
+ * the residual of job i is written at d_res + res_off[i] with row stride stride_res. */
+int havoc_mi355x_residual(havoc_mi355x_ctx *ctx, int S, int16_t *d_res, intptr_t stride_res, const int32_t *d_res_off,
+                          const void *d_src, intptr_t stride_src, const void *d_pred, intptr_t stride_pred,
+                          const havoc_mi355x_pair_job *d_jobs, int njobs);
+/* havoc::Transform via get_transform<bitDepth> (havoc/transform.h:117-140, transform.cpp:3087-3397) */
+int havoc_mi355x_transform(havoc_mi355x_ctx *ctx, int bitDepth, int16_t *d_coeffs, const int16_t *d_res,
+                           intptr_t stride_res, const havoc_mi355x_tu_job *d_jobs, int njobs);
+/* havoc::inverse_transform (havoc/transform.h:33-57, transform.cpp:339-355): d_res n*n contiguous at res_off */
+int havoc_mi355x_inverse_transform(havoc_mi355x_ctx *ctx, int bitDepth, int16_t *d_res, const int16_t *d_coeffs,
+                                   const havoc_mi355x_tu_job *d_jobs, int njobs);
+/* havoc::inverse_transform_add<Sample> (havoc/transform.h:61-84, transform.cpp:358-401); d_pred may be d_dst */
+int havoc_mi355x_inverse_transform_add(havoc_mi355x_ctx *ctx, int S, int bitDepth, void *d_dst, intptr_t stride_dst,
+                                       const void *d_pred, intptr_t stride_pred, const int16_t *d_coeffs,
+                                       const havoc_mi355x_tu_job *d_jobs, int njobs);
+/* havoc_quantize (havoc/quantize.h:63, quantize.cpp:278-304): d_cbf[i] = OR of the job's outputs */
+int havoc_mi355x_quantize(havoc_mi355x_ctx *ctx, int16_t *d_dst, const int16_t *d_src,
+                          const havoc_mi355x_quant_job *d_jobs, int njobs, int32_t *d_cbf);
+/* havoc_quantize_inverse (havoc/quantize.h:42, quantize.cpp:37-46) */
+int havoc_mi355x_quantize_inverse(havoc_mi355x_ctx *ctx, int16_t *d_dst, const int16_t *d_src,
+                                  const havoc_mi355x_quant_job *d_jobs, int njobs);
+/* havoc_quantize_reconstruct (havoc/quantize.h:84, quantize.cpp:538-549), 8-bit only:
+ * rec = clip8(pred + res); job: dst_off = rec, pred_off, res_off (n*n contiguous), log2 */
+int havoc_mi355x_quantize_reconstruct(havoc_mi355x_ctx *ctx, uint8_t *d_rec, intptr_t stride_rec, const uint8_t *d_pred,
+                                      intptr_t stride_pred, const int16_t *d_res, const havoc_mi355x_tu_job *d_jobs,
+                                      int njobs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

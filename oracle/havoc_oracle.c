@@ -1,0 +1,435 @@
+/*
+ * TEST INFRASTRUCTURE ONLY -- see havoc_oracle.h.  Plain-C99 restatement of the havoc primitives, written
+ * from the HEVC definitions and the behaviour of the reference C functions cited per function.  Scalar,
+ * single-threaded, deliberately simple: it is the checker, never the thing shipped or optimised.
+ * Parity status: pinned against oracle/_ref (the reference's own sources compiled here) and tests/golden/.
+ */
+#include "havoc_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+static inline int px(const void *p, intptr_t i, int S)
+{
+    return S == 1 ? (int)((const uint8_t *)p)[i] : (int)((const uint16_t *)p)[i];
+}
+
+static inline void put(void *p, intptr_t i, int v, int S)
+{
+    if (S == 1) ((uint8_t *)p)[i] = (uint8_t)v;
+    else ((uint16_t *)p)[i] = (uint16_t)v;
+}
+
+static inline int clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* ------------------------------------------------------------------------------------------------ */
+/* distortion metrics                                                                               */
+/* ------------------------------------------------------------------------------------------------ */
+
+/* havoc/sad.cpp:432-449 */
+int oracle_sad(const void *src, intptr_t ss, const void *ref, intptr_t rs, int w, int h, int S)
+{
+    int sad = 0;
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x)
+            sad += abs(px(src, x + y * ss, S) - px(ref, x + y * rs, S));
+    return S == 2 ? sad >> 2 : sad;
+}
+
+/* havoc/sad.cpp:513-542 */
+void oracle_sad4(const void *src, intptr_t ss, const void *const ref[4], intptr_t rs, int sad[4], int w, int h, int S)
+{
+    for (int k = 0; k < 4; ++k)
+        sad[k] = oracle_sad(src, ss, ref[k], rs, w, h, S);
+}
+
+/* havoc/ssd.cpp:28-43: accumulates in uint32_t (wraps mod 2^32), 16-bit path >>4 */
+uint32_t oracle_ssd(const void *a, intptr_t sa, const void *b, intptr_t sb, int w, int h, int S)
+{
+    uint32_t ssd = 0;
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x)
+        {
+            const int d = px(a, x + y * sa, S) - px(b, x + y * sb, S);
+            ssd += (uint32_t)(d * d);
+        }
+    return S == 2 ? ssd >> 4 : ssd;
+}
+
+/* havoc/diff.cpp:29-39 */
+int oracle_ssd_linear(const uint8_t *a, const uint8_t *b, int n)
+{
+    int sum = 0;
+    for (int i = 0; i < n; ++i)
+    {
+        const int d = (int)a[i] - (int)b[i];
+        sum += d * d;
+    }
+    return sum;
+}
+
+/* in-place length-n Walsh-Hadamard butterfly network over a strided vector (unnormalised).  The output
+ * ordering differs from the reference's recursion (havoc/hadamard.cpp:31-56) but SATD only sums |coeff|. */
+static void wht(int *v, int n, int stride)
+{
+    for (int len = 1; len < n; len <<= 1)
+        for (int i = 0; i < n; i += len << 1)
+            for (int j = i; j < i + len; ++j)
+            {
+                const int a = v[j * stride], b = v[(j + len) * stride];
+                v[j * stride] = a + b;
+                v[(j + len) * stride] = a - b;
+            }
+}
+
+/* havoc/hadamard.cpp:58-98 */
+int oracle_satd(const void *a, intptr_t sa, const void *b, intptr_t sb, int n, int S)
+{
+    int m[8 * 8];
+    for (int y = 0; y < n; ++y)
+        for (int x = 0; x < n; ++x)
+            m[y * n + x] = px(a, x + y * sa, S) - px(b, x + y * sb, S);
+    for (int y = 0; y < n; ++y) wht(m + y * n, n, 1);
+    for (int x = 0; x < n; ++x) wht(m + x, n, n);
+    int sum = n / 4;
+    for (int i = 0; i < n * n; ++i) sum += abs(m[i]);
+    sum /= n / 2;
+    return S == 2 ? sum >> 2 : sum;
+}
+
+/* turing/Measure.h:97-135 */
+int oracle_pu_satd(const void *a, intptr_t sa, const void *b, intptr_t sb, int w, int h, int S)
+{
+    const int n = ((w | h) & 3) ? 2 : (((w | h) & 7) ? 4 : 8);
+    int satd = 0;
+    for (int y = 0; y < h; y += n)
+        for (int x = 0; x < w; x += n)
+            satd += oracle_satd((const char *)a + (x + y * sa) * S, sa, (const char *)b + (x + y * sb) * S, sb, n, S);
+    return satd;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* inter prediction                                                                                 */
+/* ------------------------------------------------------------------------------------------------ */
+
+/* HEVC interpolation filter taps, havoc/pred_inter.cpp:39-69 */
+static const int lumaTaps[4][8] = {
+    { 0, 0, 0, 64, 0, 0, 0, 0 },
+    { -1, 4, -10, 58, 17, -5, 1, 0 },
+    { -1, 4, -11, 40, 40, -11, 4, -1 },
+    { 0, 1, -5, 17, 58, -10, 4, -1 },
+};
+static const int chromaTaps[8][4] = {
+    { 0, 64, 0, 0 }, { -2, 58, 10, -2 }, { -4, 54, 16, -2 }, { -6, 46, 28, -4 },
+    { -4, 36, 36, -4 }, { -4, 28, 46, -6 }, { -2, 16, 54, -4 }, { -2, 10, 58, -2 },
+};
+
+static inline int tap(int taps, int frac, int k) { return taps == 8 ? lumaTaps[frac][k] : chromaTaps[frac][k]; }
+
+/* horizontal pass to an int plane of (h + taps - 1) rows, first row = taps/2-1 rows above the block:
+ * havoc/pred_inter.cpp:146-163 (uni HV) and :1238-1248 (bi): t = sum(c*x) >> shift1, no rounding */
+static void hpass(int *tmp, const void *ref, intptr_t rs, int w, int h, int frac, int taps, int shift1, int S)
+{
+    const int above = taps / 2 - 1;
+    for (int y = 0; y < h + taps - 1; ++y)
+        for (int x = 0; x < w; ++x)
+        {
+            int a = 0;
+            for (int k = 0; k < taps; ++k)
+                a += tap(taps, frac, k) * px(ref, (x + k - above) + (intptr_t)(y - above) * rs, S);
+            tmp[y * 64 + x] = a >> shift1;
+        }
+}
+
+/* havoc/pred_inter.cpp:113-202 */
+void oracle_pred_uni(void *dst, intptr_t sd, const void *ref, intptr_t rs, int w, int h, int xFrac, int yFrac, int bitDepth, int taps, int S)
+{
+    const int max = (1 << bitDepth) - 1;
+    const int above = taps / 2 - 1;
+    if (!xFrac && !yFrac)
+    {
+        for (int y = 0; y < h; ++y)
+            memcpy((char *)dst + y * sd * S, (const char *)ref + y * rs * S, (size_t)w * S);
+        return;
+    }
+    if (!yFrac || !xFrac)
+    {
+        const intptr_t step = xFrac ? 1 : rs;
+        const int frac = xFrac ? xFrac : yFrac;
+        for (int y = 0; y < h; ++y)
+            for (int x = 0; x < w; ++x)
+            {
+                int a = 32;
+                for (int k = 0; k < taps; ++k)
+                    a += tap(taps, frac, k) * px(ref, x + y * rs + (k - above) * step, S);
+                put(dst, x + y * sd, clip3(0, max, a >> 6), S);
+            }
+        return;
+    }
+    int shift1 = bitDepth - 8;
+    if (shift1 > 4) shift1 = 4;
+    int shift3 = 14 - bitDepth;
+    if (shift3 < 2) shift3 = 2;
+    const int shift = 6 + shift3;
+    int *tmp = (int *)malloc(sizeof(int) * 64 * (64 + 7));
+    hpass(tmp, ref, rs, w, h, xFrac, taps, shift1, S);
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x)
+        {
+            int a = 1 << (shift - 1);
+            for (int k = 0; k < taps; ++k)
+                a += tap(taps, yFrac, k) * tmp[(y + k) * 64 + x];
+            put(dst, x + y * sd, clip3(0, max, a >> shift), S);
+        }
+    free(tmp);
+}
+
+/* havoc/pred_inter.cpp:1207-1252 */
+void oracle_pred_bi(void *dst, intptr_t sd, const void *ref0, const void *ref1, intptr_t rs, int w, int h, int xFrac0, int yFrac0, int xFrac1, int yFrac1, int bitDepth, int taps, int S)
+{
+    const int max = (1 << bitDepth) - 1;
+    int shift1 = bitDepth - 8;
+    if (shift1 > 4) shift1 = 4;
+    int shift3 = 14 - bitDepth;
+    if (shift3 < 2) shift3 = 2;
+    int *tmp = (int *)malloc(sizeof(int) * 64 * (64 + 7));
+    int *inter = (int *)malloc(sizeof(int) * 2 * 64 * 64);
+    const void *refs[2] = { ref0, ref1 };
+    const int xf[2] = { xFrac0, xFrac1 }, yf[2] = { yFrac0, yFrac1 };
+    for (int r = 0; r < 2; ++r)
+    {
+        hpass(tmp, refs[r], rs, w, h, xf[r], taps, shift1, S);
+        for (int y = 0; y < h; ++y)
+            for (int x = 0; x < w; ++x)
+            {
+                int a = 0;
+                for (int k = 0; k < taps; ++k)
+                    a += tap(taps, yf[r], k) * tmp[(y + k) * 64 + x];
+                inter[r * 4096 + y * 64 + x] = a >> 6;
+            }
+    }
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x)
+        {
+            const int v = (inter[y * 64 + x] + inter[4096 + y * 64 + x] + (1 << shift3)) >> (shift3 + 1);
+            put(dst, x + y * sd, clip3(0, max, v), S);
+        }
+    free(inter);
+    free(tmp);
+}
+
+/* havoc/pred_inter.cpp:2063-2080 */
+void oracle_subtract_bi(void *dst, intptr_t sd, const void *pred, intptr_t sp, const void *src, intptr_t ss, int w, int h, int bitDepth, int S)
+{
+    const int max = (1 << bitDepth) - 1;
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x)
+            put(dst, x + y * sd, clip3(0, max, 2 * px(src, x + y * ss, S) - px(pred, x + y * sp, S)), S);
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* intra prediction                                                                                 */
+/* ------------------------------------------------------------------------------------------------ */
+
+/* havoc/pred_intra.cpp:76-98 */
+static const int intraPredAngle[35] = { 0, 0, 32, 26, 21, 17, 13, 9, 5, 2, 0, -2, -5, -9, -13, -17, -21, -26, -32,
+                                        -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9, 13, 17, 21, 26, 32 };
+static const int invAngle[26] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, -4096, -1638, -910, -630, -482, -390, -315, -256,
+                                  -315, -390, -482, -630, -910, -1638, -4096 };
+
+/* p(x, y) with the reference's neighbour layout, havoc/pred_intra.cpp:43-51 */
+#define P(x, y) px(nb, (x) - (y) - 1, S)
+
+/* havoc/pred_intra.cpp:20282-20401 */
+void oracle_intra(void *dst, intptr_t sd, const void *nb, int log2, int mode, int edge, int bitDepth, int S)
+{
+    const int n = 1 << log2;
+    const int max = (1 << bitDepth) - 1;
+    if (mode == 0)
+    {
+        for (int y = 0; y < n; ++y)
+            for (int x = 0; x < n; ++x)
+                put(dst, x + y * sd, ((n - 1 - x) * P(-1, y) + (x + 1) * P(n, -1) + (n - 1 - y) * P(x, -1) + (y + 1) * P(-1, n) + n) >> (log2 + 1), S);
+        return;
+    }
+    if (mode == 1)
+    {
+        int dc = n;
+        for (int i = 0; i < n; ++i) dc += P(i, -1) + P(-1, i);
+        dc >>= log2 + 1;
+        for (int y = 0; y < n; ++y)
+            for (int x = 0; x < n; ++x)
+                put(dst, x + y * sd, dc, S);
+        if (edge)
+        {
+            put(dst, 0, (P(-1, 0) + 2 * dc + P(0, -1) + 2) >> 2, S);
+            for (int x = 1; x < n; ++x) put(dst, x, (P(x, -1) + 3 * dc + 2) >> 2, S);
+            for (int y = 1; y < n; ++y) put(dst, y * sd, (P(-1, y) + 3 * dc + 2) >> 2, S);
+        }
+        return;
+    }
+    /* angular: build the 1-D reference array, index range [-n .. 2n] stored at offset 64 */
+    int refbuf[64 + 2 * 32 + 1 + 64];
+    int *ref = refbuf + 64;
+    const int angle = intraPredAngle[mode];
+    const int vertical = mode >= 18;
+    for (int i = 0; i <= n; ++i) ref[i] = vertical ? P(-1 + i, -1) : P(-1, -1 + i);
+    if (angle < 0)
+    {
+        const int last = (n * angle) >> 5;
+        if (last < -1)
+            for (int i = -1; i >= last; --i)
+            {
+                const int j = -1 + ((i * invAngle[mode] + 128) >> 8);
+                ref[i] = vertical ? P(-1, j) : P(j, -1);
+            }
+    }
+    else
+        for (int i = n + 1; i <= 2 * n; ++i) ref[i] = vertical ? P(-1 + i, -1) : P(-1, -1 + i);
+
+    for (int y = 0; y < n; ++y)
+        for (int x = 0; x < n; ++x)
+        {
+            const int major = vertical ? y : x, minor = vertical ? x : y;
+            const int idx = ((major + 1) * angle) >> 5;
+            const int fact = ((major + 1) * angle) & 31;
+            int v;
+            if (fact == 0) v = ref[minor + idx + 1];
+            else v = ((32 - fact) * ref[minor + idx + 1] + fact * ref[minor + idx + 2] + 16) >> 5;
+            put(dst, x + y * sd, v, S);
+        }
+    if (edge && mode == 26)
+        for (int y = 0; y < n; ++y)
+            put(dst, y * sd, clip3(0, max, P(0, -1) + ((P(-1, y) - P(-1, -1)) >> 1)), S);
+    if (edge && mode == 10)
+        for (int x = 0; x < n; ++x)
+            put(dst, x, clip3(0, max, P(-1, 0) + ((P(x, -1) - P(-1, -1)) >> 1)), S);
+}
+#undef P
+
+/* ------------------------------------------------------------------------------------------------ */
+/* transforms                                                                                       */
+/* ------------------------------------------------------------------------------------------------ */
+
+/* HEVC core transform basis.  Magnitudes by angle index j (units of pi/64); row k, column n of the 32-point
+ * matrix is cos-like in k*(2n+1).  Values equal the tables at havoc/transform.cpp:85-91,119-129,170-188,
+ * 243-277 (checked against the reference build by tests/test_oracle_vs_reference.py). */
+static const int mag[33] = { 64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67, 64,
+                             61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9, 4, 0 };
+
+static int basis(int n, int k, int c) /* coefficient (k, c) of the n-point DCT matrix */
+{
+    const int kk = k * (32 / n);
+    if (kk == 0) return 64;
+    const int j = (kk * (2 * c + 1)) & 127;
+    if (j <= 32) return mag[j];
+    if (j <= 64) return -mag[64 - j];
+    if (j <= 96) return -mag[j - 64];
+    return mag[128 - j];
+}
+
+/* DST-VII 4x4, havoc/transform.cpp:59-67 (factorised there) */
+static const int dst7[4][4] = { { 29, 55, 74, 84 }, { 74, 74, 0, -74 }, { 84, -29, -74, 55 }, { 55, -84, 74, -29 } };
+
+static inline int coef(int n, int trType, int k, int c) { return trType ? dst7[k][c] : basis(n, k, c); }
+
+/* forward: out[k][i] = (short)((sum_j M[k][j] * in[i][j] + add) >> shift)  -- WRAPS to int16
+ * (havoc/transform.cpp:3071-3084 shiftRight truncates through `short` before its clamp) */
+static void fwd_pass(int16_t *out, const int16_t *in, intptr_t stride, int n, int trType, int shift)
+{
+    const int add = 1 << (shift - 1);
+    for (int i = 0; i < n; ++i)
+        for (int k = 0; k < n; ++k)
+        {
+            int a = add;
+            for (int j = 0; j < n; ++j) a += coef(n, trType, k, j) * in[i * stride + j];
+            out[k * n + i] = (int16_t)(uint16_t)((uint32_t)(a >> shift) & 0xffff);
+        }
+}
+
+/* havoc/transform.cpp:3355-3397 */
+void oracle_transform(int16_t *coeffs, const int16_t *src, intptr_t stride, int log2, int trType, int bitDepth)
+{
+    const int n = 1 << log2;
+    int16_t tmp[32 * 32];
+    fwd_pass(tmp, src, stride, n, trType, log2 - 1 + bitDepth - 8);
+    fwd_pass(coeffs, tmp, n, n, trType, log2 + 6);
+}
+
+/* inverse: out[j][k] = clip16((sum_i M[i][k] * in[i][j] + add) >> shift)  (havoc/transform.cpp:50-336) */
+static void inv_pass(int16_t *out, const int16_t *in, int n, int trType, int shift)
+{
+    const int add = 1 << (shift - 1);
+    for (int j = 0; j < n; ++j)
+        for (int k = 0; k < n; ++k)
+        {
+            int a = add;
+            for (int i = 0; i < n; ++i) a += coef(n, trType, i, k) * in[i * n + j];
+            out[j * n + k] = (int16_t)clip3(-32768, 32767, a >> shift);
+        }
+}
+
+/* havoc/transform.cpp:339-355 */
+void oracle_inverse_transform(int16_t *dst, const int16_t *coeffs, int log2, int trType, int bitDepth)
+{
+    const int n = 1 << log2;
+    int16_t tmp[32 * 32];
+    inv_pass(tmp, coeffs, n, trType, 7);
+    inv_pass(dst, tmp, n, trType, 20 - bitDepth);
+}
+
+/* havoc/transform.cpp:358-401, transform.h:95-114 */
+void oracle_inverse_transform_add(void *dst, intptr_t sd, const void *pred, intptr_t sp, const int16_t *coeffs, int log2, int trType, int bitDepth, int S)
+{
+    const int n = 1 << log2;
+    const int max = (1 << bitDepth) - 1;
+    int16_t res[32 * 32];
+    oracle_inverse_transform(res, coeffs, log2, trType, bitDepth);
+    for (int y = 0; y < n; ++y)
+        for (int x = 0; x < n; ++x)
+            put(dst, x + y * sd, clip3(0, max, px(pred, x + y * sp, S) + res[y * n + x]), S);
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* quantisation                                                                                     */
+/* ------------------------------------------------------------------------------------------------ */
+
+/* havoc/quantize.cpp:37-46 */
+void oracle_quantize_inverse(int16_t *dst, const int16_t *src, int scale, int shift, int n)
+{
+    for (int i = 0; i < n; ++i)
+        dst[i] = (int16_t)clip3(-32768, 32767, (src[i] * scale + (1 << (shift - 1))) >> shift);
+}
+
+/* havoc/quantize.cpp:278-304 */
+int oracle_quantize(int16_t *dst, const int16_t *src, int scale, int shift, int offset, int n)
+{
+    int cbf = 0;
+    offset <<= shift - 16;
+    for (int i = 0; i < n; ++i)
+    {
+        int x = src[i];
+        const int sign = x < 0 ? -1 : 1;
+        x = ((abs(x) * scale + offset) >> shift) * sign;
+        x = clip3(-32768, 32767, x);
+        cbf |= x;
+        dst[i] = (int16_t)x;
+    }
+    return cbf;
+}
+
+/* havoc/quantize.cpp:538-549 */
+void oracle_quantize_reconstruct(uint8_t *rec, intptr_t sr, const uint8_t *pred, intptr_t sp, const int16_t *res, int n)
+{
+    for (int y = 0; y < n; ++y)
+        for (int x = 0; x < n; ++x)
+            rec[x + y * sr] = (uint8_t)clip3(0, 255, pred[x + y * sp] + res[x + y * n]);
+}
+
+/* turing/Reconstruct.cpp:258-260 */
+void oracle_residual(int16_t *res, intptr_t sres, const void *src, intptr_t ss, const void *pred, intptr_t sp, int w, int h, int S)
+{
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x)
+            res[x + y * sres] = (int16_t)(px(src, x + y * ss, S) - px(pred, x + y * sp, S));
+}

@@ -1,0 +1,69 @@
+/*
+ * TEST INFRASTRUCTURE ONLY.  CPU restatement ("oracle") of the havoc primitive layer of bbc/turingcodec.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load the library built from
+ * this file; the product (libhavoc_mi355x.so, turingcodec_amd/) never includes, links or calls it.
+ *
+ * Parity status: PINNED.  Every function below is checked (tests/test_oracle_vs_reference.py) against the
+ * reference's own C functions compiled from /root/reference/havoc into oracle/_ref/libhavoc_ref.so, and
+ * against the committed golden vectors in tests/golden/ (generated from that build by
+ * tests/golden/make_golden.py).
+ *
+ * All sample pointers are `const void*` + `S` = bytes per sample (1 = uint8_t, 2 = uint16_t); strides are
+ * in samples, exactly as in the reference's function types.
+ */
+#ifndef HAVOC_ORACLE_H
+#define HAVOC_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* havoc/sad.cpp:432-449 (havoc_sad_c_ref); 16-bit result >>2 */
+int oracle_sad(const void *src, intptr_t stride_src, const void *ref, intptr_t stride_ref, int w, int h, int S);
+/* havoc/sad.cpp:513-542 (havoc_sad_multiref_4_c_ref) */
+void oracle_sad4(const void *src, intptr_t stride_src, const void *const ref[4], intptr_t stride_ref, int sad[4], int w, int h, int S);
+/* havoc/ssd.cpp:28-43 (havoc_ssd_c_ref); uint32 accumulate, 16-bit result >>4 */
+uint32_t oracle_ssd(const void *a, intptr_t stride_a, const void *b, intptr_t stride_b, int w, int h, int S);
+/* havoc/hadamard.cpp:58-98 (compute_satd_c_ref<n>), n = 2, 4, 8; 16-bit result >>2 */
+int oracle_satd(const void *a, intptr_t stride_a, const void *b, intptr_t stride_b, int n, int S);
+/* havoc/diff.cpp:29-39 (havoc_ssd_linear_c_ref) */
+int oracle_ssd_linear(const uint8_t *a, const uint8_t *b, int n);
+
+/* havoc/pred_inter.cpp:76-202 (copy / 8tap_h / 8tap_v / 8tap_hv and the 4-tap forms); taps = 8 or 4 */
+void oracle_pred_uni(void *dst, intptr_t stride_dst, const void *ref, intptr_t stride_ref, int w, int h, int xFrac, int yFrac, int bitDepth, int taps, int S);
+/* havoc/pred_inter.cpp:1207-1252 (havocPredBi_c_ref + havoc_pred_bi_mean_c_ref) */
+void oracle_pred_bi(void *dst, intptr_t stride_dst, const void *ref0, const void *ref1, intptr_t stride_ref, int w, int h, int xFrac0, int yFrac0, int xFrac1, int yFrac1, int bitDepth, int taps, int S);
+/* havoc/pred_inter.cpp:2063-2080 (subtractBi_c_ref) */
+void oracle_subtract_bi(void *dst, intptr_t stride_dst, const void *pred, intptr_t stride_pred, const void *src, intptr_t stride_src, int w, int h, int bitDepth, int S);
+
+/* havoc/pred_intra.cpp:20282-20401 (predictPlanar / predictDC / predictAngular); neighbours layout
+ * pred_intra.cpp:43-51: p(x,y) = neighbours[x - y - 1].  edge = (cIdx == 0 && log2 < 5), pred_intra.h:41-48. */
+void oracle_intra(void *dst, intptr_t stride_dst, const void *neighbours, int log2, int mode, int edge, int bitDepth, int S);
+
+/* havoc/transform.cpp:3071-3397 (forward, wraps to int16); trType 1 = DST 4x4 */
+void oracle_transform(int16_t *coeffs, const int16_t *src, intptr_t stride_src, int log2, int trType, int bitDepth);
+/* havoc/transform.cpp:50-355 (inverse, saturating) */
+void oracle_inverse_transform(int16_t *dst, const int16_t *coeffs, int log2, int trType, int bitDepth);
+/* havoc/transform.cpp:358-401 + transform.h:95-114 (inverse + add + clip); pred may alias dst */
+void oracle_inverse_transform_add(void *dst, intptr_t stride_dst, const void *pred, intptr_t stride_pred, const int16_t *coeffs, int log2, int trType, int bitDepth, int S);
+
+/* havoc/quantize.cpp:37-46 */
+void oracle_quantize_inverse(int16_t *dst, const int16_t *src, int scale, int shift, int n);
+/* havoc/quantize.cpp:278-304; returns OR of all outputs */
+int oracle_quantize(int16_t *dst, const int16_t *src, int scale, int shift, int offset, int n);
+/* havoc/quantize.cpp:538-549 (8-bit only) */
+void oracle_quantize_reconstruct(uint8_t *rec, intptr_t stride_rec, const uint8_t *pred, intptr_t stride_pred, const int16_t *res, int n);
+
+/* turing/Reconstruct.cpp:258-260, 1274-1286: res = src - pred (the "residual diff" of the north star) */
+void oracle_residual(int16_t *res, intptr_t stride_res, const void *src, intptr_t stride_src, const void *pred, intptr_t stride_pred, int w, int h, int S);
+
+/* turing/Measure.h:97-135 (measureSatd): PU SATD tiled in 8x8 / 4x4 / 2x2 Hadamards */
+int oracle_pu_satd(const void *a, intptr_t stride_a, const void *b, intptr_t stride_b, int w, int h, int S);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,244 @@
+"""ctypes bindings for the two CHECKERS (test infrastructure, never the product):
+
+  * ``Oracle``    -> oracle/liboracle.so       (our plain-C restatement, oracle/havoc_oracle.c)
+  * ``Reference`` -> oracle/_ref/libhavoc_ref.so (the reference's own havoc sources compiled by oracle/Makefile,
+                    behind oracle/ref_shim.cpp).  ``handle`` 0 = C_REF|C_OPT tables, 1 = x86 JIT tables.
+
+Both take numpy arrays; a "view" is (array, offset) so that negative tap offsets stay inside the buffer.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_SO = os.path.join(ROOT, "oracle", "liboracle.so")
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libhavoc_ref.so")
+
+_ip = C.c_ssize_t
+_vp = C.c_void_p
+
+
+def build_oracle():
+    """(Re)build oracle/liboracle.so with gcc -- seconds."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "oracle"])
+
+
+def _addr(a, off=0):
+    """device-agnostic pointer to element `off` of numpy array a"""
+    return a.ctypes.data + int(off) * a.itemsize
+
+
+def _S(a):
+    assert a.dtype in (np.uint8, np.uint16), a.dtype
+    return a.itemsize
+
+
+class Oracle:
+    def __init__(self):
+        if not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(
+                os.path.join(ROOT, "oracle", "havoc_oracle.c")):
+            build_oracle()
+        L = self.L = C.CDLL(ORACLE_SO)
+        L.oracle_sad.restype = C.c_int
+        L.oracle_sad.argtypes = [_vp, _ip, _vp, _ip, C.c_int, C.c_int, C.c_int]
+        L.oracle_sad4.restype = None
+        L.oracle_sad4.argtypes = [_vp, _ip, C.POINTER(_vp), _ip, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int]
+        L.oracle_ssd.restype = C.c_uint32
+        L.oracle_ssd.argtypes = [_vp, _ip, _vp, _ip, C.c_int, C.c_int, C.c_int]
+        L.oracle_satd.restype = C.c_int
+        L.oracle_satd.argtypes = [_vp, _ip, _vp, _ip, C.c_int, C.c_int]
+        L.oracle_pu_satd.restype = C.c_int
+        L.oracle_pu_satd.argtypes = [_vp, _ip, _vp, _ip, C.c_int, C.c_int, C.c_int]
+        L.oracle_ssd_linear.restype = C.c_int
+        L.oracle_ssd_linear.argtypes = [_vp, _vp, C.c_int]
+        L.oracle_pred_uni.restype = None
+        L.oracle_pred_uni.argtypes = [_vp, _ip, _vp, _ip] + [C.c_int] * 7
+        L.oracle_pred_bi.restype = None
+        L.oracle_pred_bi.argtypes = [_vp, _ip, _vp, _vp, _ip] + [C.c_int] * 9
+        L.oracle_subtract_bi.restype = None
+        L.oracle_subtract_bi.argtypes = [_vp, _ip, _vp, _ip, _vp, _ip] + [C.c_int] * 4
+        L.oracle_intra.restype = None
+        L.oracle_intra.argtypes = [_vp, _ip, _vp] + [C.c_int] * 5
+        L.oracle_transform.restype = None
+        L.oracle_transform.argtypes = [_vp, _vp, _ip, C.c_int, C.c_int, C.c_int]
+        L.oracle_inverse_transform.restype = None
+        L.oracle_inverse_transform.argtypes = [_vp, _vp, C.c_int, C.c_int, C.c_int]
+        L.oracle_inverse_transform_add.restype = None
+        L.oracle_inverse_transform_add.argtypes = [_vp, _ip, _vp, _ip, _vp] + [C.c_int] * 4
+        L.oracle_quantize_inverse.restype = None
+        L.oracle_quantize_inverse.argtypes = [_vp, _vp, C.c_int, C.c_int, C.c_int]
+        L.oracle_quantize.restype = C.c_int
+        L.oracle_quantize.argtypes = [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.oracle_quantize_reconstruct.restype = None
+        L.oracle_quantize_reconstruct.argtypes = [_vp, _ip, _vp, _ip, _vp, C.c_int]
+        L.oracle_residual.restype = None
+        L.oracle_residual.argtypes = [_vp, _ip, _vp, _ip, _vp, _ip, C.c_int, C.c_int, C.c_int]
+
+    # every method: arrays are flat (or 2-D C-contiguous) numpy arrays, offsets/strides in samples
+    def sad(self, src, so, ss, ref, ro, rs, w, h):
+        return self.L.oracle_sad(_addr(src, so), ss, _addr(ref, ro), rs, w, h, _S(src))
+
+    def sad4(self, src, so, ss, ref, ros, rs, w, h):
+        refs = (_vp * 4)(*[_addr(ref, r) for r in ros])
+        out = (C.c_int * 4)()
+        self.L.oracle_sad4(_addr(src, so), ss, refs, rs, out, w, h, _S(src))
+        return list(out)
+
+    def ssd(self, a, ao, sa, b, bo, sb, w, h):
+        return self.L.oracle_ssd(_addr(a, ao), sa, _addr(b, bo), sb, w, h, _S(a))
+
+    def satd(self, a, ao, sa, b, bo, sb, n):
+        return self.L.oracle_satd(_addr(a, ao), sa, _addr(b, bo), sb, n, _S(a))
+
+    def pu_satd(self, a, ao, sa, b, bo, sb, w, h):
+        return self.L.oracle_pu_satd(_addr(a, ao), sa, _addr(b, bo), sb, w, h, _S(a))
+
+    def ssd_linear(self, a, b, n):
+        return self.L.oracle_ssd_linear(_addr(a), _addr(b), n)
+
+    def pred_uni(self, dst, do, sd, ref, ro, sr, w, h, xf, yf, bd, taps):
+        self.L.oracle_pred_uni(_addr(dst, do), sd, _addr(ref, ro), sr, w, h, xf, yf, bd, taps, _S(ref))
+
+    def pred_bi(self, dst, do, sd, ref, r0, r1, sr, w, h, xf0, yf0, xf1, yf1, bd, taps):
+        self.L.oracle_pred_bi(_addr(dst, do), sd, _addr(ref, r0), _addr(ref, r1), sr, w, h, xf0, yf0, xf1, yf1, bd,
+                              taps, _S(ref))
+
+    def subtract_bi(self, dst, do, sd, pred, po, sp, src, so, ss, w, h, bd):
+        self.L.oracle_subtract_bi(_addr(dst, do), sd, _addr(pred, po), sp, _addr(src, so), ss, w, h, bd, _S(src))
+
+    def intra(self, dst, do, sd, nb, no, log2, mode, edge, bd):
+        self.L.oracle_intra(_addr(dst, do), sd, _addr(nb, no), log2, mode, edge, bd, _S(nb))
+
+    def transform(self, coeffs, co, src, so, stride, log2, tr, bd):
+        self.L.oracle_transform(_addr(coeffs, co), _addr(src, so), stride, log2, tr, bd)
+
+    def inverse_transform(self, dst, do, coeffs, co, log2, tr, bd):
+        self.L.oracle_inverse_transform(_addr(dst, do), _addr(coeffs, co), log2, tr, bd)
+
+    def inverse_transform_add(self, dst, do, sd, pred, po, sp, coeffs, co, log2, tr, bd):
+        self.L.oracle_inverse_transform_add(_addr(dst, do), sd, _addr(pred, po), sp, _addr(coeffs, co), log2, tr, bd,
+                                            _S(pred))
+
+    def quantize_inverse(self, dst, do, src, so, scale, shift, n):
+        self.L.oracle_quantize_inverse(_addr(dst, do), _addr(src, so), scale, shift, n)
+
+    def quantize(self, dst, do, src, so, scale, shift, offset, n):
+        return self.L.oracle_quantize(_addr(dst, do), _addr(src, so), scale, shift, offset, n)
+
+    def quantize_reconstruct(self, rec, ro, sr, pred, po, sp, res, so, n):
+        self.L.oracle_quantize_reconstruct(_addr(rec, ro), sr, _addr(pred, po), sp, _addr(res, so), n)
+
+    def residual(self, res, ro, sres, src, so, ss, pred, po, sp, w, h):
+        self.L.oracle_residual(_addr(res, ro), sres, _addr(src, so), ss, _addr(pred, po), sp, w, h, _S(src))
+
+
+def have_reference():
+    return os.path.exists(REF_SO)
+
+
+class Reference:
+    """The reference's own havoc functions (C tables: handle 0; x86 JIT tables: handle 1)."""
+
+    def __init__(self, handle=0):
+        self.h = handle
+        L = self.L = C.CDLL(REF_SO)
+        for sfx in ("u8", "u16"):
+            getattr(L, "ref_sad_" + sfx).restype = C.c_int
+            getattr(L, "ref_sad_" + sfx).argtypes = [C.c_int, _vp, _ip, _vp, _ip, C.c_int, C.c_int]
+            getattr(L, "ref_sad4_" + sfx).restype = C.c_int
+            getattr(L, "ref_sad4_" + sfx).argtypes = [C.c_int, _vp, _ip, _vp, _vp, _vp, _vp, _ip,
+                                                      C.POINTER(C.c_int), C.c_int, C.c_int]
+            getattr(L, "ref_ssd_" + sfx).restype = C.c_longlong
+            getattr(L, "ref_ssd_" + sfx).argtypes = [C.c_int, _vp, _ip, _vp, _ip, C.c_int]
+            getattr(L, "ref_satd_" + sfx).restype = C.c_int
+            getattr(L, "ref_satd_" + sfx).argtypes = [C.c_int, _vp, _ip, _vp, _ip, C.c_int]
+            getattr(L, "ref_pred_uni_" + sfx).restype = C.c_int
+            getattr(L, "ref_pred_uni_" + sfx).argtypes = [C.c_int, _vp, _ip, _vp, _ip] + [C.c_int] * 6
+            getattr(L, "ref_pred_bi_" + sfx).restype = C.c_int
+            getattr(L, "ref_pred_bi_" + sfx).argtypes = [C.c_int, _vp, _ip, _vp, _vp, _ip] + [C.c_int] * 8
+            getattr(L, "ref_subtract_bi_" + sfx).restype = C.c_int
+            getattr(L, "ref_subtract_bi_" + sfx).argtypes = [C.c_int, _vp, _ip, _vp, _ip, _vp, _ip] + [C.c_int] * 3
+            getattr(L, "ref_intra_" + sfx).restype = C.c_int
+            getattr(L, "ref_intra_" + sfx).argtypes = [C.c_int, _vp, _ip, _vp] + [C.c_int] * 4
+            getattr(L, "ref_inverse_transform_add_" + sfx).restype = C.c_int
+            getattr(L, "ref_inverse_transform_add_" + sfx).argtypes = [C.c_int, _vp, _ip, _vp, _ip, _vp] + [C.c_int] * 3
+        L.ref_inverse_transform.restype = C.c_int
+        L.ref_inverse_transform.argtypes = [C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int]
+        L.ref_transform.restype = C.c_int
+        L.ref_transform.argtypes = [C.c_int, _vp, _vp, _ip, C.c_int, C.c_int, C.c_int]
+        L.ref_quantize_inverse.restype = C.c_int
+        L.ref_quantize_inverse.argtypes = [C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int]
+        L.ref_quantize.restype = C.c_int
+        L.ref_quantize.argtypes = [C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.ref_quantize_reconstruct.restype = C.c_int
+        L.ref_quantize_reconstruct.argtypes = [C.c_int, _vp, _ip, _vp, _ip, _vp, C.c_int]
+        L.ref_ssd_linear.restype = C.c_int
+        L.ref_ssd_linear.argtypes = [C.c_int, _vp, _vp, C.c_int]
+        L.ref_mask.restype = C.c_int
+        L.ref_mask.argtypes = [C.c_int]
+
+    @staticmethod
+    def _sfx(a):
+        return "u8" if a.itemsize == 1 else "u16"
+
+    def _f(self, name, a):
+        return getattr(self.L, name + "_" + self._sfx(a))
+
+    def mask(self):
+        return self.L.ref_mask(self.h)
+
+    def sad(self, src, so, ss, ref, ro, rs, w, h):
+        return self._f("ref_sad", src)(self.h, _addr(src, so), ss, _addr(ref, ro), rs, w, h)
+
+    def sad4(self, src, so, ss, ref, ros, rs, w, h):
+        out = (C.c_int * 4)()
+        r = self._f("ref_sad4", src)(self.h, _addr(src, so), ss, *[_addr(ref, x) for x in ros], rs, out, w, h)
+        assert r == 0
+        return list(out)
+
+    def ssd(self, a, ao, sa, b, bo, sb, w, h):
+        assert w == h
+        return self._f("ref_ssd", a)(self.h, _addr(a, ao), sa, _addr(b, bo), sb, int(w).bit_length() - 1)
+
+    def satd(self, a, ao, sa, b, bo, sb, n):
+        return self._f("ref_satd", a)(self.h, _addr(a, ao), sa, _addr(b, bo), sb, int(n).bit_length() - 1)
+
+    def ssd_linear(self, a, b, n):
+        return self.L.ref_ssd_linear(self.h, _addr(a), _addr(b), n)
+
+    def pred_uni(self, dst, do, sd, ref, ro, sr, w, h, xf, yf, bd, taps):
+        assert self._f("ref_pred_uni", ref)(self.h, _addr(dst, do), sd, _addr(ref, ro), sr, w, h, xf, yf, bd, taps) == 0
+
+    def pred_bi(self, dst, do, sd, ref, r0, r1, sr, w, h, xf0, yf0, xf1, yf1, bd, taps):
+        assert self._f("ref_pred_bi", ref)(self.h, _addr(dst, do), sd, _addr(ref, r0), _addr(ref, r1), sr, w, h,
+                                           xf0, yf0, xf1, yf1, bd, taps) == 0
+
+    def subtract_bi(self, dst, do, sd, pred, po, sp, src, so, ss, w, h, bd):
+        assert self._f("ref_subtract_bi", src)(self.h, _addr(dst, do), sd, _addr(pred, po), sp, _addr(src, so), ss,
+                                               w, h, bd) == 0
+
+    def intra(self, dst, do, sd, nb, no, log2, mode, edge, bd):
+        # edge <=> cIdx == 0 (the table itself applies log2 < 5), havoc/pred_intra.h:41-48
+        assert self._f("ref_intra", nb)(self.h, _addr(dst, do), sd, _addr(nb, no), 0 if edge else 1, bd, log2, mode) == 0
+
+    def transform(self, coeffs, co, src, so, stride, log2, tr, bd):
+        assert self.L.ref_transform(self.h, _addr(coeffs, co), _addr(src, so), stride, bd, tr, log2) == 0
+
+    def inverse_transform(self, dst, do, coeffs, co, log2, tr, bd):
+        assert self.L.ref_inverse_transform(self.h, _addr(dst, do), _addr(coeffs, co), bd, tr, log2) == 0
+
+    def inverse_transform_add(self, dst, do, sd, pred, po, sp, coeffs, co, log2, tr, bd):
+        assert self._f("ref_inverse_transform_add", pred)(self.h, _addr(dst, do), sd, _addr(pred, po), sp,
+                                                          _addr(coeffs, co), bd, tr, log2) == 0
+
+    def quantize_inverse(self, dst, do, src, so, scale, shift, n):
+        assert self.L.ref_quantize_inverse(self.h, _addr(dst, do), _addr(src, so), scale, shift, n) == 0
+
+    def quantize(self, dst, do, src, so, scale, shift, offset, n):
+        return self.L.ref_quantize(self.h, _addr(dst, do), _addr(src, so), scale, shift, offset, n)
+
+    def quantize_reconstruct(self, rec, ro, sr, pred, po, sp, res, so, n):
+        assert self.L.ref_quantize_reconstruct(self.h, _addr(rec, ro), sr, _addr(pred, po), sp, _addr(res, so),
+                                               int(n).bit_length() - 1) == 0
