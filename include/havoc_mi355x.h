@@ -103,7 +103,8 @@ typedef struct {
 /* one intra prediction block (havoc/pred_intra.h:32-52).  nb_off addresses neighbours[0] = p(0,-1):
  * neighbours[-1] is the corner, [-2 .. -1-2n] the left column top->bottom, [0 .. 2n-1] the top row
  * (havoc/pred_intra.cpp:43-51).  `edge` = (cIdx == 0): the DC / mode-10 / mode-26 edge filters are applied
- * when edge && log2 < 5, as Table::lookup does. */
+ * when edge && log2 < 5, as Table::lookup does.  The block size is a launch parameter (the reference's table is
+ * indexed by log2TrafoSize); `log2` here is informational and must equal it. */
 typedef struct {
     int32_t dst_off;
     int32_t nb_off;
@@ -113,17 +114,15 @@ typedef struct {
     int32_t reserved[3];
 } havoc_mi355x_intra_job; /* 32 bytes */
 
-/* one transform unit.  Used by forward transform (coef <- src residual), inverse transform (+add) and the
- * quantisers; unused fields are ignored by each entry point. */
+/* one transform unit; size and type are launch parameters (the reference picks one function per
+ * (trType, log2TrafoSize), havoc/transform.h:72-84, :128-140).  Unused fields are ignored by each entry point. */
 typedef struct {
     int32_t coef_off;  /* n*n contiguous int16 coefficients (index into the coefficient buffer) */
-    int32_t res_off;   /* int16 residual block (forward input), row stride = stride_res argument */
+    int32_t res_off;   /* int16 residual block: forward input (row stride = stride_res argument), or n*n
+                          contiguous output of inverse_transform / input of quantize_reconstruct */
     int32_t pred_off;  /* prediction samples (inverse+add input) */
     int32_t dst_off;   /* reconstructed samples (inverse+add output); may equal pred_off on the same plane */
-    int32_t log2;      /* 2..5 */
-    int32_t trType;    /* 1 = 4x4 DST-VII (log2 must be 2), 0 = DCT-II */
-    int32_t reserved[2];
-} havoc_mi355x_tu_job; /* 32 bytes */
+} havoc_mi355x_tu_job; /* 16 bytes */
 
 /* one (de)quantisation call over n contiguous int16 values (havoc/quantize.h:42,63) */
 typedef struct {
@@ -174,7 +173,7 @@ int havoc_mi355x_subtract_bi(havoc_mi355x_ctx *ctx, int S, int bitDepth, void *d
 /* ------------------------------------------------------------------------------------------------------- */
 
 /* havoc::intra::Function<Sample> via Table::lookup (havoc/pred_intra.h:32-52, pred_intra.cpp:20282-20401) */
-int havoc_mi355x_intra(havoc_mi355x_ctx *ctx, int S, int bitDepth, void *d_dst, intptr_t stride_dst,
+int havoc_mi355x_intra(havoc_mi355x_ctx *ctx, int S, int bitDepth, int log2TrafoSize, void *d_dst, intptr_t stride_dst,
                        const void *d_neighbours, const havoc_mi355x_intra_job *d_jobs, int njobs);
 
 /* ------------------------------------------------------------------------------------------------------- */
@@ -187,15 +186,15 @@ int havoc_mi355x_residual(havoc_mi355x_ctx *ctx, int S, int16_t *d_res, intptr_t
                           const void *d_src, intptr_t stride_src, const void *d_pred, intptr_t stride_pred,
                           const havoc_mi355x_pair_job *d_jobs, int njobs);
 /* havoc::Transform via get_transform<bitDepth> (havoc/transform.h:117-140, transform.cpp:3087-3397) */
-int havoc_mi355x_transform(havoc_mi355x_ctx *ctx, int bitDepth, int16_t *d_coeffs, const int16_t *d_res,
-                           intptr_t stride_res, const havoc_mi355x_tu_job *d_jobs, int njobs);
+int havoc_mi355x_transform(havoc_mi355x_ctx *ctx, int bitDepth, int trType, int log2TrafoSize, int16_t *d_coeffs,
+                           const int16_t *d_res, intptr_t stride_res, const havoc_mi355x_tu_job *d_jobs, int njobs);
 /* havoc::inverse_transform (havoc/transform.h:33-57, transform.cpp:339-355): d_res n*n contiguous at res_off */
-int havoc_mi355x_inverse_transform(havoc_mi355x_ctx *ctx, int bitDepth, int16_t *d_res, const int16_t *d_coeffs,
-                                   const havoc_mi355x_tu_job *d_jobs, int njobs);
+int havoc_mi355x_inverse_transform(havoc_mi355x_ctx *ctx, int bitDepth, int trType, int log2TrafoSize, int16_t *d_res,
+                                   const int16_t *d_coeffs, const havoc_mi355x_tu_job *d_jobs, int njobs);
 /* havoc::inverse_transform_add<Sample> (havoc/transform.h:61-84, transform.cpp:358-401); d_pred may be d_dst */
-int havoc_mi355x_inverse_transform_add(havoc_mi355x_ctx *ctx, int S, int bitDepth, void *d_dst, intptr_t stride_dst,
-                                       const void *d_pred, intptr_t stride_pred, const int16_t *d_coeffs,
-                                       const havoc_mi355x_tu_job *d_jobs, int njobs);
+int havoc_mi355x_inverse_transform_add(havoc_mi355x_ctx *ctx, int S, int bitDepth, int trType, int log2TrafoSize,
+                                       void *d_dst, intptr_t stride_dst, const void *d_pred, intptr_t stride_pred,
+                                       const int16_t *d_coeffs, const havoc_mi355x_tu_job *d_jobs, int njobs);
 /* havoc_quantize (havoc/quantize.h:63, quantize.cpp:278-304): d_cbf[i] = OR of the job's outputs */
 int havoc_mi355x_quantize(havoc_mi355x_ctx *ctx, int16_t *d_dst, const int16_t *d_src,
                           const havoc_mi355x_quant_job *d_jobs, int njobs, int32_t *d_cbf);
@@ -203,10 +202,10 @@ int havoc_mi355x_quantize(havoc_mi355x_ctx *ctx, int16_t *d_dst, const int16_t *
 int havoc_mi355x_quantize_inverse(havoc_mi355x_ctx *ctx, int16_t *d_dst, const int16_t *d_src,
                                   const havoc_mi355x_quant_job *d_jobs, int njobs);
 /* havoc_quantize_reconstruct (havoc/quantize.h:84, quantize.cpp:538-549), 8-bit only:
- * rec = clip8(pred + res); job: dst_off = rec, pred_off, res_off (n*n contiguous), log2 */
-int havoc_mi355x_quantize_reconstruct(havoc_mi355x_ctx *ctx, uint8_t *d_rec, intptr_t stride_rec, const uint8_t *d_pred,
-                                      intptr_t stride_pred, const int16_t *d_res, const havoc_mi355x_tu_job *d_jobs,
-                                      int njobs);
+ * rec = clip8(pred + res); job: dst_off = rec, pred_off, res_off (n*n contiguous) */
+int havoc_mi355x_quantize_reconstruct(havoc_mi355x_ctx *ctx, int log2TrafoSize, uint8_t *d_rec, intptr_t stride_rec,
+                                      const uint8_t *d_pred, intptr_t stride_pred, const int16_t *d_res,
+                                      const havoc_mi355x_tu_job *d_jobs, int njobs);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,72 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library builds, loads, exports every symbol the header
+declares, and refuses to run without a GPU (no fallback)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "havoc_mi355x.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import turingcodec_amd
+    if not os.path.exists(turingcodec_amd.LIB_PATH):
+        subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "turingcodec_amd", "csrc")])
+    return C.CDLL(turingcodec_amd.LIB_PATH)
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(havoc_mi355x_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported(lib):
+    names = declared_symbols()
+    assert len(names) >= 29
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/havoc_mi355x.h but not exported"
+
+
+def test_binding_covers_header():
+    import turingcodec_amd
+    assert set(declared_symbols()) == set(turingcodec_amd.exported_symbols())
+
+
+def test_job_struct_sizes():
+    """the sizes the kernels index jobs with (static_asserts in csrc/api.hip mirror this)"""
+    text = open(HEADER).read()
+    sizes = dict(re.findall(r"\}\s*(havoc_mi355x_[a-z0-9_]+_job);\s*/\*\s*(\d+) bytes", text))
+    assert sizes == {"havoc_mi355x_pair_job": "16", "havoc_mi355x_sad4_job": "32", "havoc_mi355x_pred_uni_job": "32",
+                     "havoc_mi355x_pred_bi_job": "48", "havoc_mi355x_subtract_bi_job": "32",
+                     "havoc_mi355x_intra_job": "32", "havoc_mi355x_tu_job": "16", "havoc_mi355x_quant_job": "32"}
+
+
+def test_no_gpu_fails_loudly(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    lib.havoc_mi355x_last_error.restype = C.c_char_p
+    h = C.c_void_p()
+    rc = lib.havoc_mi355x_create(C.byref(h), 0, None)
+    assert rc != 0 and not h.value
+    assert b"no CPU path" in lib.havoc_mi355x_last_error() or b"HIP" in lib.havoc_mi355x_last_error()
+    import turingcodec_amd
+    with pytest.raises(turingcodec_amd.HavocError):
+        turingcodec_amd.Havoc(0)
+
+
+def test_product_does_not_touch_oracle():
+    """the product sources never include, link or import anything under oracle/"""
+    bad = []
+    for base, _, files in os.walk(os.path.join(ROOT, "turingcodec_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp", "Makefile")):
+                s = open(os.path.join(base, f), errors="ignore").read()
+                if re.search(r"oracle|reflibs|liboracle|libhavoc_ref", s):
+                    bad.append(os.path.join(base, f))
+    assert not bad, bad

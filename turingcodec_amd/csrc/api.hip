@@ -1,0 +1,307 @@
+// C ABI of libhavoc_mi355x.so (include/havoc_mi355x.h): context management, argument validation, launches.
+// There is no CPU path in this library: without a gfx950 device havoc_mi355x_create fails with ENODEV.
+#include "common.h"
+
+#include <cstdio>
+#include <cstring>
+
+namespace havoc_gpu {
+hipError_t launch_sad(hipStream_t, int S, int ways, const void *, long, const void *, long, const void *, int, int32_t *);
+hipError_t launch_ssd(hipStream_t, int S, const void *, long, const void *, long, const void *, int, uint32_t *);
+hipError_t launch_satd(hipStream_t, int S, const void *, long, const void *, long, const void *, int, int32_t *);
+hipError_t launch_ssd_linear(hipStream_t, const uint8_t *, const uint8_t *, int, int32_t *);
+hipError_t launch_pred_uni(hipStream_t, int S, int taps, int bd, void *, long, const void *, long, const void *, int);
+hipError_t launch_pred_bi(hipStream_t, int S, int taps, int bd, void *, long, const void *, long, const void *, int);
+hipError_t launch_subtract_bi(hipStream_t, int S, int bd, void *, long, const void *, long, const void *, long, const void *, int);
+hipError_t launch_intra(hipStream_t, int S, int log2, int bd, void *, long, const void *, const void *, int);
+hipError_t launch_transform(hipStream_t, int bd, int log2, int tr, int16_t *, const int16_t *, long, const void *, int);
+hipError_t launch_inverse_transform(hipStream_t, int mode, int bd, int log2, int tr, void *, long, const void *, long, int16_t *, const int16_t *,
+                                    const void *, int);
+hipError_t launch_quantize(hipStream_t, int16_t *, const int16_t *, const void *, int, int32_t *);
+hipError_t launch_quantize_inverse(hipStream_t, int16_t *, const int16_t *, const void *, int);
+hipError_t launch_quantize_reconstruct(hipStream_t, int log2, uint8_t *, long, const uint8_t *, long, const int16_t *, const void *, int);
+hipError_t launch_residual(hipStream_t, int S, int16_t *, long, const int32_t *, const void *, long, const void *, long, const void *, int);
+} // namespace havoc_gpu
+
+using namespace havoc_gpu;
+
+static_assert(sizeof(havoc_mi355x_pair_job) == 16, "job ABI");
+static_assert(sizeof(havoc_mi355x_sad4_job) == 32, "job ABI");
+static_assert(sizeof(havoc_mi355x_pred_uni_job) == 32, "job ABI");
+static_assert(sizeof(havoc_mi355x_pred_bi_job) == 48, "job ABI");
+static_assert(sizeof(havoc_mi355x_subtract_bi_job) == 32, "job ABI");
+static_assert(sizeof(havoc_mi355x_intra_job) == 32, "job ABI");
+static_assert(sizeof(havoc_mi355x_tu_job) == 16, "job ABI");
+static_assert(sizeof(havoc_mi355x_quant_job) == 32, "job ABI");
+
+struct havoc_mi355x_ctx
+{
+    int device;
+    hipStream_t stream;
+    hipEvent_t ev0, ev1;
+    hipDeviceProp_t prop;
+};
+
+static thread_local char g_err[256] = "";
+
+static int fail(int code, const char *what)
+{
+    snprintf(g_err, sizeof(g_err), "%s", what);
+    return code;
+}
+
+static int check(hipError_t e, const char *where)
+{
+    if (e == hipSuccess) return 0;
+    snprintf(g_err, sizeof(g_err), "%s: %s", where, hipGetErrorString(e));
+    return -(int)e;
+}
+
+#define REQUIRE(cond, what) \
+    do { if (!(cond)) return fail(HAVOC_MI355X_EINVAL, what); } while (0)
+#define REQUIRE_CTX() REQUIRE(ctx != nullptr, "null context")
+#define REQUIRE_S() REQUIRE(S == 1 || S == 2, "S (bytes per sample) must be 1 or 2")
+#define REQUIRE_BD() REQUIRE(bitDepth >= 8 && bitDepth <= (S == 1 ? 8 : 10), "bitDepth must be 8 (S=1) or 8..10 (S=2)")
+
+extern "C" {
+
+const char *havoc_mi355x_last_error(void) { return g_err; }
+const char *havoc_mi355x_version(void) { return "havoc_mi355x 0.1 (gfx950)"; }
+
+int havoc_mi355x_create(havoc_mi355x_ctx **out, int device, void *stream)
+{
+    REQUIRE(out != nullptr, "null out pointer");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) return fail(HAVOC_MI355X_ENODEV, "no HIP device: libhavoc_mi355x has no CPU path");
+    REQUIRE(device >= 0 && device < count, "device index out of range");
+    havoc_mi355x_ctx *c = new havoc_mi355x_ctx();
+    c->device = device;
+    c->stream = (hipStream_t)stream;
+    int rc;
+    if ((rc = check(hipSetDevice(device), "hipSetDevice")) || (rc = check(hipGetDeviceProperties(&c->prop, device), "hipGetDeviceProperties")))
+    {
+        delete c;
+        return rc;
+    }
+    if (strncmp(c->prop.gcnArchName, "gfx950", 6) != 0)
+    {
+        snprintf(g_err, sizeof(g_err), "device %d is %s; this library contains gfx950 code only", device, c->prop.gcnArchName);
+        delete c;
+        return HAVOC_MI355X_ENODEV;
+    }
+    if ((rc = check(hipEventCreate(&c->ev0), "hipEventCreate")) || (rc = check(hipEventCreate(&c->ev1), "hipEventCreate")))
+    {
+        delete c;
+        return rc;
+    }
+    *out = c;
+    return 0;
+}
+
+void havoc_mi355x_destroy(havoc_mi355x_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipEventDestroy(ctx->ev0);
+    (void)hipEventDestroy(ctx->ev1);
+    delete ctx;
+}
+
+int havoc_mi355x_set_stream(havoc_mi355x_ctx *ctx, void *stream)
+{
+    REQUIRE_CTX();
+    ctx->stream = (hipStream_t)stream;
+    return 0;
+}
+
+int havoc_mi355x_sync(havoc_mi355x_ctx *ctx)
+{
+    REQUIRE_CTX();
+    return check(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+}
+
+int havoc_mi355x_device_info(havoc_mi355x_ctx *ctx, int64_t info[8])
+{
+    REQUIRE_CTX();
+    const hipDeviceProp_t &p = ctx->prop;
+    info[0] = p.multiProcessorCount;
+    info[1] = p.clockRate;
+    info[2] = p.memoryClockRate;
+    info[3] = p.memoryBusWidth;
+    info[4] = p.l2CacheSize;
+    info[5] = p.warpSize;
+    info[6] = (int64_t)p.sharedMemPerBlock;
+    info[7] = (int64_t)(p.totalGlobalMem >> 20);
+    return 0;
+}
+
+int havoc_mi355x_malloc(havoc_mi355x_ctx *ctx, void **d_ptr, size_t bytes)
+{
+    REQUIRE_CTX();
+    return check(hipMalloc(d_ptr, bytes), "hipMalloc");
+}
+
+int havoc_mi355x_free(havoc_mi355x_ctx *ctx, void *d_ptr)
+{
+    REQUIRE_CTX();
+    return check(hipFree(d_ptr), "hipFree");
+}
+
+int havoc_mi355x_h2d(havoc_mi355x_ctx *ctx, void *d_dst, const void *h_src, size_t bytes)
+{
+    REQUIRE_CTX();
+    int rc = check(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync h2d");
+    return rc ? rc : check(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+}
+
+int havoc_mi355x_d2h(havoc_mi355x_ctx *ctx, void *h_dst, const void *d_src, size_t bytes)
+{
+    REQUIRE_CTX();
+    int rc = check(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync d2h");
+    return rc ? rc : check(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+}
+
+int havoc_mi355x_timer_start(havoc_mi355x_ctx *ctx)
+{
+    REQUIRE_CTX();
+    return check(hipEventRecord(ctx->ev0, ctx->stream), "hipEventRecord");
+}
+
+int havoc_mi355x_timer_stop_ms(havoc_mi355x_ctx *ctx, float *ms)
+{
+    REQUIRE_CTX();
+    int rc = check(hipEventRecord(ctx->ev1, ctx->stream), "hipEventRecord");
+    if (rc) return rc;
+    if ((rc = check(hipEventSynchronize(ctx->ev1), "hipEventSynchronize"))) return rc;
+    return check(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1), "hipEventElapsedTime");
+}
+
+// ---- distortion metrics -----------------------------------------------------------------------------------
+
+int havoc_mi355x_sad(havoc_mi355x_ctx *ctx, int S, const void *d_src, intptr_t stride_src, const void *d_ref, intptr_t stride_ref,
+                     const havoc_mi355x_pair_job *d_jobs, int njobs, int32_t *d_out)
+{
+    REQUIRE_CTX(); REQUIRE_S(); REQUIRE(njobs >= 0, "njobs < 0");
+    return check(launch_sad(ctx->stream, S, 1, d_src, stride_src, d_ref, stride_ref, d_jobs, njobs, d_out), "sad");
+}
+
+int havoc_mi355x_sad4(havoc_mi355x_ctx *ctx, int S, const void *d_src, intptr_t stride_src, const void *d_ref, intptr_t stride_ref,
+                      const havoc_mi355x_sad4_job *d_jobs, int njobs, int32_t *d_out)
+{
+    REQUIRE_CTX(); REQUIRE_S(); REQUIRE(njobs >= 0, "njobs < 0");
+    return check(launch_sad(ctx->stream, S, 4, d_src, stride_src, d_ref, stride_ref, d_jobs, njobs, d_out), "sad4");
+}
+
+int havoc_mi355x_ssd(havoc_mi355x_ctx *ctx, int S, const void *d_a, intptr_t stride_a, const void *d_b, intptr_t stride_b,
+                     const havoc_mi355x_pair_job *d_jobs, int njobs, uint32_t *d_out)
+{
+    REQUIRE_CTX(); REQUIRE_S(); REQUIRE(njobs >= 0, "njobs < 0");
+    return check(launch_ssd(ctx->stream, S, d_a, stride_a, d_b, stride_b, d_jobs, njobs, d_out), "ssd");
+}
+
+int havoc_mi355x_satd(havoc_mi355x_ctx *ctx, int S, const void *d_a, intptr_t stride_a, const void *d_b, intptr_t stride_b,
+                      const havoc_mi355x_pair_job *d_jobs, int njobs, int32_t *d_out)
+{
+    REQUIRE_CTX(); REQUIRE_S(); REQUIRE(njobs >= 0, "njobs < 0");
+    return check(launch_satd(ctx->stream, S, d_a, stride_a, d_b, stride_b, d_jobs, njobs, d_out), "satd");
+}
+
+int havoc_mi355x_ssd_linear(havoc_mi355x_ctx *ctx, const uint8_t *d_a, const uint8_t *d_b, int size, int32_t *d_out)
+{
+    REQUIRE_CTX(); REQUIRE(size >= 0, "size < 0");
+    return check(launch_ssd_linear(ctx->stream, d_a, d_b, size, d_out), "ssd_linear");
+}
+
+// ---- inter prediction -------------------------------------------------------------------------------------
+
+int havoc_mi355x_pred_uni(havoc_mi355x_ctx *ctx, int S, int taps, int bitDepth, void *d_dst, intptr_t stride_dst, const void *d_ref,
+                          intptr_t stride_ref, const havoc_mi355x_pred_uni_job *d_jobs, int njobs)
+{
+    REQUIRE_CTX(); REQUIRE_S(); REQUIRE_BD(); REQUIRE(taps == 8 || taps == 4, "taps must be 8 or 4"); REQUIRE(njobs >= 0, "njobs < 0");
+    return check(launch_pred_uni(ctx->stream, S, taps, bitDepth, d_dst, stride_dst, d_ref, stride_ref, d_jobs, njobs), "pred_uni");
+}
+
+int havoc_mi355x_pred_bi(havoc_mi355x_ctx *ctx, int S, int taps, int bitDepth, void *d_dst, intptr_t stride_dst, const void *d_ref,
+                         intptr_t stride_ref, const havoc_mi355x_pred_bi_job *d_jobs, int njobs)
+{
+    REQUIRE_CTX(); REQUIRE_S(); REQUIRE_BD(); REQUIRE(taps == 8 || taps == 4, "taps must be 8 or 4"); REQUIRE(njobs >= 0, "njobs < 0");
+    return check(launch_pred_bi(ctx->stream, S, taps, bitDepth, d_dst, stride_dst, d_ref, stride_ref, d_jobs, njobs), "pred_bi");
+}
+
+int havoc_mi355x_subtract_bi(havoc_mi355x_ctx *ctx, int S, int bitDepth, void *d_dst, intptr_t stride_dst, const void *d_pred, intptr_t stride_pred,
+                             const void *d_src, intptr_t stride_src, const havoc_mi355x_subtract_bi_job *d_jobs, int njobs)
+{
+    REQUIRE_CTX(); REQUIRE_S(); REQUIRE_BD(); REQUIRE(njobs >= 0, "njobs < 0");
+    return check(launch_subtract_bi(ctx->stream, S, bitDepth, d_dst, stride_dst, d_pred, stride_pred, d_src, stride_src, d_jobs, njobs), "subtract_bi");
+}
+
+// ---- intra prediction -------------------------------------------------------------------------------------
+
+int havoc_mi355x_intra(havoc_mi355x_ctx *ctx, int S, int bitDepth, int log2TrafoSize, void *d_dst, intptr_t stride_dst, const void *d_neighbours,
+                       const havoc_mi355x_intra_job *d_jobs, int njobs)
+{
+    REQUIRE_CTX(); REQUIRE_S(); REQUIRE_BD(); REQUIRE(log2TrafoSize >= 2 && log2TrafoSize <= 5, "log2TrafoSize must be 2..5");
+    REQUIRE(njobs >= 0, "njobs < 0");
+    return check(launch_intra(ctx->stream, S, log2TrafoSize, bitDepth, d_dst, stride_dst, d_neighbours, d_jobs, njobs), "intra");
+}
+
+// ---- residual, transforms, quantisation -------------------------------------------------------------------
+
+int havoc_mi355x_residual(havoc_mi355x_ctx *ctx, int S, int16_t *d_res, intptr_t stride_res, const int32_t *d_res_off, const void *d_src,
+                          intptr_t stride_src, const void *d_pred, intptr_t stride_pred, const havoc_mi355x_pair_job *d_jobs, int njobs)
+{
+    REQUIRE_CTX(); REQUIRE_S(); REQUIRE(njobs >= 0, "njobs < 0");
+    return check(launch_residual(ctx->stream, S, d_res, stride_res, d_res_off, d_src, stride_src, d_pred, stride_pred, d_jobs, njobs), "residual");
+}
+
+#define REQUIRE_TR() \
+    REQUIRE(log2TrafoSize >= 2 && log2TrafoSize <= 5, "log2TrafoSize must be 2..5"); \
+    REQUIRE(trType == 0 || (trType == 1 && log2TrafoSize == 2), "trType 1 (DST) requires log2TrafoSize 2")
+
+int havoc_mi355x_transform(havoc_mi355x_ctx *ctx, int bitDepth, int trType, int log2TrafoSize, int16_t *d_coeffs, const int16_t *d_res,
+                           intptr_t stride_res, const havoc_mi355x_tu_job *d_jobs, int njobs)
+{
+    REQUIRE_CTX(); REQUIRE_TR(); REQUIRE(bitDepth >= 8 && bitDepth <= 10, "bitDepth must be 8..10"); REQUIRE(njobs >= 0, "njobs < 0");
+    return check(launch_transform(ctx->stream, bitDepth, log2TrafoSize, trType, d_coeffs, d_res, stride_res, d_jobs, njobs), "transform");
+}
+
+int havoc_mi355x_inverse_transform(havoc_mi355x_ctx *ctx, int bitDepth, int trType, int log2TrafoSize, int16_t *d_res, const int16_t *d_coeffs,
+                                   const havoc_mi355x_tu_job *d_jobs, int njobs)
+{
+    REQUIRE_CTX(); REQUIRE_TR(); REQUIRE(bitDepth >= 8 && bitDepth <= 10, "bitDepth must be 8..10"); REQUIRE(njobs >= 0, "njobs < 0");
+    return check(launch_inverse_transform(ctx->stream, 0, bitDepth, log2TrafoSize, trType, nullptr, 0, nullptr, 0, d_res, d_coeffs, d_jobs, njobs),
+                 "inverse_transform");
+}
+
+int havoc_mi355x_inverse_transform_add(havoc_mi355x_ctx *ctx, int S, int bitDepth, int trType, int log2TrafoSize, void *d_dst, intptr_t stride_dst,
+                                       const void *d_pred, intptr_t stride_pred, const int16_t *d_coeffs, const havoc_mi355x_tu_job *d_jobs,
+                                       int njobs)
+{
+    REQUIRE_CTX(); REQUIRE_S(); REQUIRE_BD(); REQUIRE_TR(); REQUIRE(njobs >= 0, "njobs < 0");
+    return check(launch_inverse_transform(ctx->stream, S, bitDepth, log2TrafoSize, trType, d_dst, stride_dst, d_pred, stride_pred, nullptr, d_coeffs,
+                                          d_jobs, njobs),
+                 "inverse_transform_add");
+}
+
+int havoc_mi355x_quantize(havoc_mi355x_ctx *ctx, int16_t *d_dst, const int16_t *d_src, const havoc_mi355x_quant_job *d_jobs, int njobs, int32_t *d_cbf)
+{
+    REQUIRE_CTX(); REQUIRE(njobs >= 0, "njobs < 0");
+    return check(launch_quantize(ctx->stream, d_dst, d_src, d_jobs, njobs, d_cbf), "quantize");
+}
+
+int havoc_mi355x_quantize_inverse(havoc_mi355x_ctx *ctx, int16_t *d_dst, const int16_t *d_src, const havoc_mi355x_quant_job *d_jobs, int njobs)
+{
+    REQUIRE_CTX(); REQUIRE(njobs >= 0, "njobs < 0");
+    return check(launch_quantize_inverse(ctx->stream, d_dst, d_src, d_jobs, njobs), "quantize_inverse");
+}
+
+int havoc_mi355x_quantize_reconstruct(havoc_mi355x_ctx *ctx, int log2TrafoSize, uint8_t *d_rec, intptr_t stride_rec, const uint8_t *d_pred,
+                                      intptr_t stride_pred, const int16_t *d_res, const havoc_mi355x_tu_job *d_jobs, int njobs)
+{
+    REQUIRE_CTX(); REQUIRE(log2TrafoSize >= 2 && log2TrafoSize <= 5, "log2TrafoSize must be 2..5"); REQUIRE(njobs >= 0, "njobs < 0");
+    return check(launch_quantize_reconstruct(ctx->stream, log2TrafoSize, d_rec, stride_rec, d_pred, stride_pred, d_res, d_jobs, njobs),
+                 "quantize_reconstruct");
+}
+
+} // extern "C"

@@ -1,0 +1,74 @@
+// Shared device/host helpers for libhavoc_mi355x.so (gfx950 only; wave64 is hard-coded).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/havoc_mi355x.h"
+
+namespace havoc_gpu {
+
+constexpr int kWave = 64;
+
+// ---- unaligned vector loads/stores: gfx950 global/flat accesses have no alignment requirement, and block
+// positions inside a picture are arbitrary (candidate motion vectors), so every wide access is typed align(1).
+typedef uint32_t __attribute__((aligned(1))) u32u;
+typedef uint32_t __attribute__((ext_vector_type(2), aligned(1))) u32x2u;
+typedef uint32_t __attribute__((ext_vector_type(4), aligned(1))) u32x4u;
+typedef uint32_t __attribute__((ext_vector_type(2))) u32x2;
+typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
+typedef short __attribute__((ext_vector_type(2))) s16x2;
+typedef unsigned short __attribute__((ext_vector_type(2))) u16x2;
+
+__device__ __forceinline__ uint32_t ld4(const void *p) { return *reinterpret_cast<const u32u *>(p); }
+__device__ __forceinline__ u32x2 ld8(const void *p)
+{
+    u32x2u v = *reinterpret_cast<const u32x2u *>(p);
+    return u32x2{v.x, v.y};
+}
+__device__ __forceinline__ u32x4 ld16(const void *p)
+{
+    u32x4u v = *reinterpret_cast<const u32x4u *>(p);
+    return u32x4{v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ void st4(void *p, uint32_t v) { *reinterpret_cast<u32u *>(p) = v; }
+__device__ __forceinline__ void st8(void *p, u32x2 v) { *reinterpret_cast<u32x2u *>(p) = u32x2u{v.x, v.y}; }
+
+// ---- wave64 reductions.  DPP row operations + row broadcasts: no LDS traffic, result valid in lane 63,
+// then read back uniformly with readlane.
+__device__ __forceinline__ int wave_sum(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xe, true);  // row_shr:4  (bank_mask 0xe)
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xc, true);  // row_shr:8  (bank_mask 0xc)
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);  // row_bcast:15 (row_mask 0xa)
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);  // row_bcast:31 (row_mask 0xc)
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+// sum within aligned groups of G consecutive lanes (G = power of two <= 64); every lane of the group gets the sum
+template <int G>
+__device__ __forceinline__ int group_sum(int v)
+{
+#pragma unroll
+    for (int o = 1; o < G; o <<= 1) v += __shfl_xor(v, o, kWave);
+    return v;
+}
+
+__device__ __forceinline__ int clip3(int lo, int hi, int v) { return min(max(v, lo), hi); }
+
+// exact y = i / d for 0 <= i < 2^12.3 (i*d_err < 2^20) and 2 <= d <= 128: one multiply instead of an integer division
+struct FastDiv
+{
+    uint32_t inv;
+    int d;
+    __device__ __forceinline__ explicit FastDiv(int d_) : inv(((1u << 20) + d_ - 1) / d_), d(d_) {}
+    __device__ __forceinline__ int div(int i) const { return d == 1 ? i : (int)(((uint32_t)i * inv) >> 20); }
+};
+
+template <int S> struct Sample;
+template <> struct Sample<1> { typedef uint8_t T; };
+template <> struct Sample<2> { typedef uint16_t T; };
+
+} // namespace havoc_gpu

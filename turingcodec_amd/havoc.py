@@ -1,0 +1,315 @@
+"""Host-side binding of libhavoc_mi355x.so (C ABI: include/havoc_mi355x.h).
+
+PyTorch is used only as plumbing: device buffers (torch.uint8/int16/int32 CUDA tensors) and the current HIP
+stream.  Every compute call goes through the C ABI into the hand-written gfx950 kernels; if the shared library
+is missing or there is no GPU this module raises -- there is no CPU/eager fallback.
+
+Two layers:
+  * ``Havoc.<primitive>_d(...)``  device-level: tensors already in HBM, asynchronous on the context stream
+  * ``Havoc.<primitive>(...)``    numpy-level batch interface used by the parity suite (tests/suite.py): uploads
+                                  inputs, launches once per primitive (per size class where the reference's table
+                                  is indexed by size), downloads the result.
+Names and argument meaning mirror the reference's function types (havoc/sad.h:58, pred_inter.h:35, ...).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhavoc_mi355x.so")
+
+_vp = C.c_void_p
+_ip = C.c_ssize_t
+_i = C.c_int
+
+
+class HavocError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise HavocError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                         "(make -C turingcodec_amd/csrc).  There is no fallback path.")
+    L = C.CDLL(LIB_PATH)
+    L.havoc_mi355x_last_error.restype = C.c_char_p
+    L.havoc_mi355x_version.restype = C.c_char_p
+    sig = {
+        "create": [C.POINTER(_vp), _i, _vp],
+        "destroy": [_vp],
+        "set_stream": [_vp, _vp],
+        "sync": [_vp],
+        "device_info": [_vp, C.POINTER(C.c_int64)],
+        "malloc": [_vp, C.POINTER(_vp), C.c_size_t],
+        "free": [_vp, _vp],
+        "h2d": [_vp, _vp, _vp, C.c_size_t],
+        "d2h": [_vp, _vp, _vp, C.c_size_t],
+        "timer_start": [_vp],
+        "timer_stop_ms": [_vp, C.POINTER(C.c_float)],
+        "sad": [_vp, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
+        "sad4": [_vp, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
+        "ssd": [_vp, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
+        "satd": [_vp, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
+        "ssd_linear": [_vp, _vp, _vp, _i, _vp],
+        "pred_uni": [_vp, _i, _i, _i, _vp, _ip, _vp, _ip, _vp, _i],
+        "pred_bi": [_vp, _i, _i, _i, _vp, _ip, _vp, _ip, _vp, _i],
+        "subtract_bi": [_vp, _i, _i, _vp, _ip, _vp, _ip, _vp, _ip, _vp, _i],
+        "intra": [_vp, _i, _i, _i, _vp, _ip, _vp, _vp, _i],
+        "residual": [_vp, _i, _vp, _ip, _vp, _vp, _ip, _vp, _ip, _vp, _i],
+        "transform": [_vp, _i, _i, _i, _vp, _vp, _ip, _vp, _i],
+        "inverse_transform": [_vp, _i, _i, _i, _vp, _vp, _vp, _i],
+        "inverse_transform_add": [_vp, _i, _i, _i, _i, _vp, _ip, _vp, _ip, _vp, _vp, _i],
+        "quantize": [_vp, _vp, _vp, _vp, _i, _vp],
+        "quantize_inverse": [_vp, _vp, _vp, _vp, _i],
+        "quantize_reconstruct": [_vp, _i, _vp, _ip, _vp, _ip, _vp, _vp, _i],
+    }
+    for name, args in sig.items():
+        f = getattr(L, "havoc_mi355x_" + name)
+        f.argtypes = args
+        f.restype = None if name == "destroy" else _i
+    return L, sorted(sig)
+
+
+def exported_symbols():
+    """names the C ABI must export (checked against include/havoc_mi355x.h by the CPU tests)"""
+    _, names = _load()
+    return ["havoc_mi355x_" + n for n in names] + ["havoc_mi355x_last_error", "havoc_mi355x_version"]
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+class Havoc:
+    """One context per process / GPU (the reference's `havoc_code`, havoc/havoc.h:138-147)."""
+
+    def __init__(self, device=0, stream=None):
+        import torch
+        self.torch = torch
+        self.L, _ = _load()
+        if not torch.cuda.is_available():
+            raise HavocError("no GPU visible: libhavoc_mi355x has no CPU path")
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        s = stream if stream is not None else torch.cuda.current_stream(self.device).cuda_stream
+        h = _vp()
+        self._ck(self.L.havoc_mi355x_create(C.byref(h), device, _vp(s)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.havoc_mi355x_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise HavocError(f"libhavoc_mi355x error {rc}: {self.L.havoc_mi355x_last_error().decode()}")
+
+    # ---------------------------------------------------------------- plumbing
+    def sync(self):
+        self._ck(self.L.havoc_mi355x_sync(self.h))
+
+    def device_info(self):
+        a = (C.c_int64 * 8)()
+        self._ck(self.L.havoc_mi355x_device_info(self.h, a))
+        keys = ["cus", "clock_khz", "mem_clock_khz", "bus_bits", "l2_bytes", "wave", "lds_per_wg", "mem_mib"]
+        return dict(zip(keys, [int(x) for x in a]))
+
+    def timer_start(self):
+        self._ck(self.L.havoc_mi355x_timer_start(self.h))
+
+    def timer_stop_ms(self):
+        ms = C.c_float()
+        self._ck(self.L.havoc_mi355x_timer_stop_ms(self.h, C.byref(ms)))
+        return ms.value
+
+    def up(self, a):
+        """numpy -> device tensor (uint16 travels as int16 bits: torch has no uint16 arithmetic, none is needed)"""
+        a = np.ascontiguousarray(a)
+        if a.dtype == np.uint16:
+            a = a.view(np.int16)
+        if a.dtype == np.uint32:
+            a = a.view(np.int32)
+        return self.torch.from_numpy(a).to(self.device)
+
+    def zeros(self, n, dtype):
+        t = {np.uint8: self.torch.uint8, np.uint16: self.torch.int16, np.int16: self.torch.int16,
+             np.int32: self.torch.int32, np.uint32: self.torch.int32}[np.dtype(dtype).type]
+        return self.torch.zeros(int(n), dtype=t, device=self.device)
+
+    @staticmethod
+    def down(t, dtype):
+        a = t.cpu().numpy()
+        return a.view(dtype) if a.dtype != np.dtype(dtype) else a
+
+    @staticmethod
+    def _S(t):
+        return t.element_size()
+
+    # ---------------------------------------------------------------- device-level API (tensors in HBM)
+    def sad_d(self, src, ss, ref, rs, jobs, out):
+        self._ck(self.L.havoc_mi355x_sad(self.h, self._S(src), _ptr(src), ss, _ptr(ref), rs, _ptr(jobs), jobs.shape[0], _ptr(out)))
+
+    def sad4_d(self, src, ss, ref, rs, jobs, out):
+        self._ck(self.L.havoc_mi355x_sad4(self.h, self._S(src), _ptr(src), ss, _ptr(ref), rs, _ptr(jobs), jobs.shape[0], _ptr(out)))
+
+    def ssd_d(self, a, sa, b, sb, jobs, out):
+        self._ck(self.L.havoc_mi355x_ssd(self.h, self._S(a), _ptr(a), sa, _ptr(b), sb, _ptr(jobs), jobs.shape[0], _ptr(out)))
+
+    def satd_d(self, a, sa, b, sb, jobs, out):
+        self._ck(self.L.havoc_mi355x_satd(self.h, self._S(a), _ptr(a), sa, _ptr(b), sb, _ptr(jobs), jobs.shape[0], _ptr(out)))
+
+    def pred_uni_d(self, taps, bd, dst, sd, ref, sr, jobs):
+        self._ck(self.L.havoc_mi355x_pred_uni(self.h, self._S(ref), taps, bd, _ptr(dst), sd, _ptr(ref), sr, _ptr(jobs), jobs.shape[0]))
+
+    def pred_bi_d(self, taps, bd, dst, sd, ref, sr, jobs):
+        self._ck(self.L.havoc_mi355x_pred_bi(self.h, self._S(ref), taps, bd, _ptr(dst), sd, _ptr(ref), sr, _ptr(jobs), jobs.shape[0]))
+
+    def subtract_bi_d(self, bd, dst, sd, pred, sp, src, ss, jobs):
+        self._ck(self.L.havoc_mi355x_subtract_bi(self.h, self._S(src), bd, _ptr(dst), sd, _ptr(pred), sp, _ptr(src), ss, _ptr(jobs), jobs.shape[0]))
+
+    def intra_d(self, bd, log2, dst, sd, nb, jobs):
+        self._ck(self.L.havoc_mi355x_intra(self.h, self._S(nb), bd, log2, _ptr(dst), sd, _ptr(nb), _ptr(jobs), jobs.shape[0]))
+
+    def residual_d(self, res, sres, res_off, src, ss, pred, sp, jobs):
+        self._ck(self.L.havoc_mi355x_residual(self.h, self._S(src), _ptr(res), sres, _ptr(res_off), _ptr(src), ss, _ptr(pred), sp, _ptr(jobs), jobs.shape[0]))
+
+    def transform_d(self, bd, tr, log2, coeffs, res, sres, jobs):
+        self._ck(self.L.havoc_mi355x_transform(self.h, bd, tr, log2, _ptr(coeffs), _ptr(res), sres, _ptr(jobs), jobs.shape[0]))
+
+    def inverse_transform_d(self, bd, tr, log2, res, coeffs, jobs):
+        self._ck(self.L.havoc_mi355x_inverse_transform(self.h, bd, tr, log2, _ptr(res), _ptr(coeffs), _ptr(jobs), jobs.shape[0]))
+
+    def inverse_transform_add_d(self, bd, tr, log2, dst, sd, pred, sp, coeffs, jobs):
+        self._ck(self.L.havoc_mi355x_inverse_transform_add(self.h, self._S(pred), bd, tr, log2, _ptr(dst), sd, _ptr(pred), sp, _ptr(coeffs), _ptr(jobs), jobs.shape[0]))
+
+    def quantize_d(self, dst, src, jobs, cbf):
+        self._ck(self.L.havoc_mi355x_quantize(self.h, _ptr(dst), _ptr(src), _ptr(jobs), jobs.shape[0], _ptr(cbf)))
+
+    def quantize_inverse_d(self, dst, src, jobs):
+        self._ck(self.L.havoc_mi355x_quantize_inverse(self.h, _ptr(dst), _ptr(src), _ptr(jobs), jobs.shape[0]))
+
+    def quantize_reconstruct_d(self, log2, rec, sr, pred, sp, res, jobs):
+        self._ck(self.L.havoc_mi355x_quantize_reconstruct(self.h, log2, _ptr(rec), sr, _ptr(pred), sp, _ptr(res), _ptr(jobs), jobs.shape[0]))
+
+    def ssd_linear_d(self, a, b, n, out):
+        self._ck(self.L.havoc_mi355x_ssd_linear(self.h, _ptr(a), _ptr(b), n, _ptr(out)))
+
+    # ---------------------------------------------------------------- numpy-level batch interface (tests/suite.py)
+    def _jobs(self, j, ncols):
+        j = np.ascontiguousarray(np.asarray(j, np.int32)[:, :ncols])
+        return self.up(j)
+
+    def sad(self, a, sa, b, sb, jobs):
+        out = self.zeros(len(jobs), np.int32)
+        self.sad_d(self.up(a), sa, self.up(b), sb, self._jobs(jobs, 4), out)
+        return self.down(out, np.int32)
+
+    def sad4(self, a, sa, b, sb, jobs):
+        out = self.zeros(4 * len(jobs), np.int32)
+        self.sad4_d(self.up(a), sa, self.up(b), sb, self._jobs(jobs, 8), out)
+        return self.down(out, np.int32).reshape(-1, 4)
+
+    def ssd(self, a, sa, b, sb, jobs):
+        out = self.zeros(len(jobs), np.uint32)
+        self.ssd_d(self.up(a), sa, self.up(b), sb, self._jobs(jobs, 4), out)
+        return self.down(out, np.uint32)
+
+    def satd(self, a, sa, b, sb, jobs):
+        out = self.zeros(len(jobs), np.int32)
+        self.satd_d(self.up(a), sa, self.up(b), sb, self._jobs(jobs, 4), out)
+        return self.down(out, np.int32)
+
+    def ssd_linear(self, a, b, n):
+        out = self.zeros(1, np.int32)
+        self.ssd_linear_d(self.up(a), self.up(b), n, out)
+        return int(self.down(out, np.int32)[0])
+
+    def pred_uni(self, taps, bd, dst_len, sd, ref, sr, jobs):
+        dst = self.zeros(dst_len, ref.dtype)
+        self.pred_uni_d(taps, bd, dst, sd, self.up(ref), sr, self._jobs(jobs, 8))
+        return self.down(dst, ref.dtype)
+
+    def pred_bi(self, taps, bd, dst_len, sd, ref, sr, jobs):
+        dst = self.zeros(dst_len, ref.dtype)
+        self.pred_bi_d(taps, bd, dst, sd, self.up(ref), sr, self._jobs(jobs, 12))
+        return self.down(dst, ref.dtype)
+
+    def subtract_bi(self, bd, dst_len, sd, pred, sp, src, ss, jobs):
+        dst = self.zeros(dst_len, src.dtype)
+        self.subtract_bi_d(bd, dst, sd, self.up(pred), sp, self.up(src), ss, self._jobs(jobs, 8))
+        return self.down(dst, src.dtype)
+
+    def intra(self, bd, dst_len, sd, nb, jobs):
+        jobs = np.asarray(jobs, np.int32)
+        dst = self.zeros(dst_len, nb.dtype)
+        nbd = self.up(nb)
+        for log2 in (2, 3, 4, 5):   # one launch per block size (the reference's table index)
+            sel = jobs[jobs[:, 2] == log2]
+            if len(sel):
+                self.intra_d(bd, log2, dst, sd, nbd, self._jobs(sel, 8))
+        return self.down(dst, nb.dtype)
+
+    def residual(self, res_len, sres, res_off, src, ss, pred, sp, jobs):
+        res = self.zeros(res_len, np.int16)
+        self.residual_d(res, sres, self.up(np.asarray(res_off, np.int32)), self.up(src), ss, self.up(pred), sp, self._jobs(jobs, 4))
+        return self.down(res, np.int16)
+
+    @staticmethod
+    def _tu_groups(jobs):
+        jobs = np.asarray(jobs, np.int32)
+        for log2, tr in ((2, 1), (2, 0), (3, 0), (4, 0), (5, 0)):
+            sel = jobs[(jobs[:, 4] == log2) & (jobs[:, 5] == tr)]
+            if len(sel):
+                yield log2, tr, sel
+
+    def transform(self, bd, ncoef, res, stride, jobs):
+        co = self.zeros(ncoef, np.int16)
+        r = self.up(res)
+        for log2, tr, sel in self._tu_groups(jobs):
+            self.transform_d(bd, tr, log2, co, r, stride, self._jobs(sel, 4))
+        return self.down(co, np.int16)
+
+    def inverse_transform(self, bd, nres, coeffs, jobs):
+        res = self.zeros(nres, np.int16)
+        c = self.up(coeffs)
+        for log2, tr, sel in self._tu_groups(jobs):
+            self.inverse_transform_d(bd, tr, log2, res, c, self._jobs(sel, 4))
+        return self.down(res, np.int16)
+
+    def inverse_transform_add(self, bd, dst_len, sd, pred, sp, coeffs, jobs):
+        dst = self.zeros(dst_len, pred.dtype)
+        c = self.up(coeffs)
+        p = self.up(pred)
+        for log2, tr, sel in self._tu_groups(jobs):
+            self.inverse_transform_add_d(bd, tr, log2, dst, sd, p, sp, c, self._jobs(sel, 4))
+        return self.down(dst, pred.dtype)
+
+    def quantize(self, nout, src, jobs):
+        dst = self.zeros(nout, np.int16)
+        cbf = self.zeros(len(jobs), np.int32)
+        self.quantize_d(dst, self.up(src), self._jobs(jobs, 8), cbf)
+        return self.down(dst, np.int16), self.down(cbf, np.int32)
+
+    def quantize_inverse(self, nout, src, jobs):
+        dst = self.zeros(nout, np.int16)
+        self.quantize_inverse_d(dst, self.up(src), self._jobs(jobs, 8))
+        return self.down(dst, np.int16)
+
+    def quantize_reconstruct(self, dst_len, sr, pred, sp, res, jobs):
+        jobs = np.asarray(jobs, np.int32)
+        rec = self.zeros(dst_len, np.uint8)
+        p = self.up(pred)
+        r = self.up(res)
+        for log2 in (2, 3, 4, 5):
+            sel = jobs[jobs[:, 4] == log2]
+            if len(sel):
+                self.quantize_reconstruct_d(log2, rec, sr, p, sp, r, self._jobs(sel, 4))
+        return self.down(rec, np.uint8)
