@@ -1,0 +1,397 @@
+#!/usr/bin/env python3
+"""bench.py -- hot-path throughput of the havoc primitive layer on MI355X.
+
+One "step" = one random-access B-frame's worth of havoc primitive calls (turingcodec_amd/workload.py: the call
+counts the reference encoder issues per 1920x1080 B-frame at QP32 speed=medium), evaluated
+by the batch kernels of libhavoc_mi355x.so with every operand already resident in HBM.  value = frames per second.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--res 1920x1080] [--bit-depth 8]
+
+N > 1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL): frames are sharded across
+ranks (each rank works on its own picture: weak scaling) and after every step the ranks holding reference pictures
+broadcast their reconstructed planes to all others (turingcodec_amd/frame_parallel.py), as the frame-parallel
+encoder must.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--res", default="1920x1080")
+    ap.add_argument("--bit-depth", type=int, default=8)
+    ap.add_argument("--seed", type=int, default=11)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
+    ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--kernel-reps", type=int, default=5)
+    return ap.parse_args()
+
+
+# --------------------------------------------------------------------------------------------------------------
+# device side
+# --------------------------------------------------------------------------------------------------------------
+
+class DeviceFrame:
+    """A FrameWorkload uploaded to HBM + the list of launches that make one step."""
+
+    def __init__(self, hv, wl):
+        import torch
+        self.hv, self.wl = hv, wl
+        up = hv.up
+        dt = wl.dtype
+        S = wl.S
+        # picture store: 3 input planes + plane 3 = reconstruction
+        store = np.concatenate([wl.luma, np.zeros(wl.plane_len, dt)])
+        self.luma = up(store)
+        self.chroma = up(wl.chroma)
+        z = lambda n, d: hv.zeros(n, d)
+        self.pred = z(wl.pred_len, dt)
+        self.cpred = z(wl.cpred_len, dt)
+        self.bi = z(wl.bi_len + 4096, dt)
+        self.sbi = z(len(wl.subtract_bi) * 4096, dt)
+        self.j_sad4, self.j_sad = up(wl.sad4), up(wl.sad)
+        self.o_sad4, self.o_sad = z(4 * len(wl.sad4), np.int32), z(len(wl.sad), np.int32)
+        self.j_uni8, self.j_uni4 = up(wl.uni8), up(wl.uni4)
+        self.j_bi8, self.j_bi4 = up(wl.bi8), up(wl.bi4)
+        self.j_sbi = up(wl.subtract_bi)
+        self.j_satd = up(wl.satd_inter)
+        self.o_satd = z(len(wl.satd_inter), np.int32)
+        self.intra = {}
+        for log2, j in wl.intra.items():
+            if len(j):
+                js = wl.intra_satd[log2]
+                self.intra[log2] = dict(jobs=up(j), nb=up(wl.intra_nb[log2]), dst=z(len(j) << (2 * log2), dt),
+                                        jsatd=up(js) if len(js) else None, osatd=z(max(1, len(js)), np.int32))
+        self.tu = {}
+        bd = wl.bit_depth
+        qp = 32
+        for (log2, tr), g in wl.tu.items():
+            m = len(g["jobs"])
+            if not m:
+                continue
+            nn = g["n"]
+            # quantiser parameters exactly as turing/QpState.h:85-94 / Reconstruct.cpp:286,311,315 derive them
+            qscale = [26214, 23302, 20560, 18396, 16384, 14564][qp % 6]
+            qshift = 29 - bd + qp // 6 - log2
+            dscale = [40, 45, 51, 57, 64, 72][qp % 6] << (qp // 6)
+            dshift = log2 - 1 + bd - 8
+            qj = np.zeros((m, 8), np.int32)
+            qj[:, 0] = qj[:, 1] = g["jobs"][:, 0]
+            qj[:, 2] = nn * nn
+            qj[:, 3], qj[:, 4], qj[:, 5] = qscale, qshift, 85 << 7
+            dj = qj.copy()
+            dj[:, 3], dj[:, 4] = dscale, dshift
+            self.tu[(log2, tr)] = dict(jobs=up(g["jobs"]), src=up(g["src"]), res_off=up(g["res_off"]), n=nn,
+                                       res=z(m * nn * nn, np.int16), coef=z(m * nn * nn, np.int16),
+                                       level=z(m * nn * nn, np.int16), deq=z(m * nn * nn, np.int16),
+                                       qjobs=up(qj), djobs=up(dj), cbf=z(m, np.int32))
+        self.j_ssd = up(wl.ssd)
+        self.o_ssd = z(len(wl.ssd), np.uint32)
+        self.launches = self._make_launches()
+        # levels for the timed de-quantiser: run residual -> forward T -> havoc_quantize once, untimed (at medium the
+        # reference quantises with RDOQ on the host; the hot path sees its output levels)
+        for name, fn in self.launches:
+            if name.startswith(("residual", "transform")):
+                fn()
+        for g in self.tu.values():
+            hv.quantize_d(g["level"], g["coef"], g["qjobs"], g["cbf"])
+        hv.sync()
+
+    def _make_launches(self):
+        hv, wl = self.hv, self.wl
+        bd, st, cst = wl.bit_depth, wl.stride, wl.cstride
+        L = []
+        L.append(("sad4", lambda: hv.sad4_d(self.luma, st, self.luma, st, self.j_sad4, self.o_sad4)))
+        L.append(("sad", lambda: hv.sad_d(self.luma, st, self.luma, st, self.j_sad, self.o_sad)))
+        L.append(("pred_uni8", lambda: hv.pred_uni_d(8, bd, self.pred, 64, self.luma, st, self.j_uni8)))
+        L.append(("satd_inter", lambda: hv.satd_d(self.luma, st, self.pred, 64, self.j_satd, self.o_satd)))
+        L.append(("pred_uni4", lambda: hv.pred_uni_d(4, bd, self.cpred, 32, self.chroma, cst, self.j_uni4)))
+        L.append(("pred_bi8", lambda: hv.pred_bi_d(8, bd, self.bi, 64, self.luma, st, self.j_bi8)))
+        L.append(("subtract_bi", lambda: hv.subtract_bi_d(bd, self.sbi, 64, self.bi, 64, self.luma, st, self.j_sbi)))
+        L.append(("pred_bi4", lambda: hv.pred_bi_d(4, bd, self.bi, 32, self.chroma, cst, self.j_bi4)))
+        for log2, g in sorted(self.intra.items()):
+            n = 1 << log2
+            L.append((f"intra", lambda g=g, log2=log2, n=n: hv.intra_d(bd, log2, g["dst"], n, g["nb"], g["jobs"])))
+            if g["jsatd"] is not None:
+                L.append((f"satd_intra", lambda g=g, n=n: hv.satd_d(self.luma, st, g["dst"], n, g["jsatd"], g["osatd"])))
+        for (log2, tr), g in sorted(self.tu.items()):
+            n = g["n"]
+            L.append(("residual", lambda g=g, n=n: hv.residual_d(g["res"], n, g["res_off"], self.luma, st, self.luma, st, g["src"])))
+            L.append(("transform", lambda g=g, n=n, log2=log2, tr=tr: hv.transform_d(bd, tr, log2, g["coef"], g["res"], n, g["jobs"])))
+            L.append(("quantize_inverse", lambda g=g: hv.quantize_inverse_d(g["deq"], g["level"], g["djobs"])))
+            L.append(("inverse_transform_add", lambda g=g, log2=log2, tr=tr: hv.inverse_transform_add_d(
+                bd, tr, log2, self.luma, st, self.luma, st, g["deq"], g["jobs"])))
+        L.append(("ssd", lambda: hv.ssd_d(self.luma, st, self.luma, st, self.j_ssd, self.o_ssd)))
+        return L
+
+    def step(self):
+        for _, fn in self.launches:
+            fn()
+
+    def kernel_times_ms(self, reps):
+        """average duration per launch group, HIP events on the context's stream"""
+        hv = self.hv
+        t = {}
+        cnt = {}
+        for name, fn in self.launches:
+            fn()
+            hv.timer_start()
+            for _ in range(reps):
+                fn()
+            ms = hv.timer_stop_ms() / reps
+            t[name] = t.get(name, 0.0) + ms
+            cnt[name] = cnt.get(name, 0) + 1
+        return t, cnt
+
+    def checksum(self):
+        """a checksum of checksums over every result buffer (size-independent parity property; see tests)"""
+        import torch
+        acc = 0
+        bufs = [self.o_sad4, self.o_sad, self.o_satd, self.o_ssd, self.pred, self.cpred, self.bi, self.sbi, self.luma]
+        for g in self.intra.values():
+            bufs += [g["dst"], g["osatd"]]
+        for g in self.tu.values():
+            bufs += [g["res"], g["coef"], g["deq"]]
+        for b in bufs:
+            acc = (acc * 1000003 + int(b.to(torch.int64).sum().item())) & 0xFFFFFFFFFFFF
+        return acc
+
+
+# --------------------------------------------------------------------------------------------------------------
+# CPU baseline: the reference's own havoc functions (oracle/_ref, x86 JIT tables) on a bounded sample of the same
+# job tables, all host cores.  Runs in a worker process so that a SIMD alignment fault cannot take the bench down.
+# --------------------------------------------------------------------------------------------------------------
+
+def _aligned(a, align=64):
+    a = np.ascontiguousarray(a)
+    raw = np.empty(a.nbytes + align, np.uint8)
+    o = (-raw.ctypes.data) % align
+    out = raw[o:o + a.nbytes].view(a.dtype).reshape(a.shape)
+    out[...] = a
+    return out
+
+
+def cpu_worker(args):
+    """child process: time the reference library on every `stride`-th job; prints a JSON dict"""
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+    from turingcodec_amd.workload import FrameWorkload
+    handle, stride = (int(v) for v in args.cpu_worker.split(","))
+    w, h = (int(v) for v in args.res.split("x"))
+    wl = FrameWorkload(w, h, args.bit_depth, args.seed)
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libhavoc_ref.so"))
+    cores = os.cpu_count() or 1
+    S, bd, st, cst = wl.S, wl.bit_depth, wl.stride, wl.cstride
+    dt = wl.dtype
+    P = lambda a: C.c_void_p(a.ctypes.data)
+    ip = C.c_ssize_t
+    sub = lambda j: _aligned(np.ascontiguousarray(j[::stride]))
+
+    luma = _aligned(np.concatenate([wl.luma, np.zeros(wl.plane_len, dt)]))
+    chroma = _aligned(wl.chroma)
+    pred = _aligned(np.zeros(wl.pred_len + 4096, dt))
+    cpred = _aligned(np.zeros(wl.cpred_len + 1024, dt))
+    bi = _aligned(np.zeros(wl.bi_len + 8192, dt))
+    sbi = _aligned(np.zeros(len(wl.subtract_bi) * 4096 + 4096, dt))
+    tasks = []   # (callable(b, e), njobs)
+
+    def add(fn, n):
+        if n:
+            tasks.append((fn, n))
+
+    j4, js = sub(wl.sad4), sub(wl.sad)
+    o4, os_ = np.zeros(4 * len(j4), np.int32), np.zeros(len(js), np.int32)
+    add(lambda b, e: lib.ref_run_sad4(handle, S, P(luma), ip(st), P(luma), ip(st), P(j4), b, e, P(o4)), len(j4))
+    add(lambda b, e: lib.ref_run_sad(handle, S, P(luma), ip(st), P(luma), ip(st), P(js), b, e, P(os_)), len(js))
+    ju8, ju4, jb8, jb4, jsb, jsa = sub(wl.uni8), sub(wl.uni4), sub(wl.bi8), sub(wl.bi4), sub(wl.subtract_bi), sub(wl.satd_inter)
+    osa = np.zeros(len(jsa), np.int32)
+    add(lambda b, e: lib.ref_run_pred_uni(handle, S, 8, bd, P(pred), ip(64), P(luma), ip(st), P(ju8), b, e), len(ju8))
+    add(lambda b, e: lib.ref_run_satd(handle, S, P(luma), ip(st), P(pred), ip(64), P(jsa), b, e, P(osa)), len(jsa))
+    add(lambda b, e: lib.ref_run_pred_uni(handle, S, 4, bd, P(cpred), ip(32), P(chroma), ip(cst), P(ju4), b, e), len(ju4))
+    add(lambda b, e: lib.ref_run_pred_bi(handle, S, 8, bd, P(bi), ip(64), P(luma), ip(st), P(jb8), b, e), len(jb8))
+    add(lambda b, e: lib.ref_run_subtract_bi(handle, S, bd, P(sbi), ip(64), P(bi), ip(64), P(luma), ip(st), P(jsb), b, e), len(jsb))
+    add(lambda b, e: lib.ref_run_pred_bi(handle, S, 4, bd, P(bi), ip(32), P(chroma), ip(cst), P(jb4), b, e), len(jb4))
+    keep = [j4, js, ju8, ju4, jb8, jb4, jsb, jsa, o4, os_, osa]
+    for log2, j in wl.intra.items():
+        if not len(j):
+            continue
+        n = 1 << log2
+        ji, nb = sub(j), _aligned(wl.intra_nb[log2])
+        dst = _aligned(np.zeros((len(j) << (2 * log2)) + 64, dt))
+        jsat = sub(wl.intra_satd[log2])
+        osat = np.zeros(max(1, len(jsat)), np.int32)
+        keep += [ji, nb, dst, jsat, osat]
+        add(lambda b, e, log2=log2, n=n, ji=ji, nb=nb, dst=dst: lib.ref_run_intra(handle, S, bd, log2, P(dst), ip(n), P(nb), P(ji), b, e), len(ji))
+        add(lambda b, e, n=n, jsat=jsat, dst=dst, osat=osat: lib.ref_run_satd(handle, S, P(luma), ip(st), P(dst), ip(n), P(jsat), b, e, P(osat)), len(jsat))
+    qp = 32
+    for (log2, tr), g in wl.tu.items():
+        m = len(g["jobs"])
+        if not m:
+            continue
+        n = g["n"]
+        jt, jsrc, roff = sub(g["jobs"]), sub(g["src"]), sub(g["res_off"])
+        res = _aligned(np.zeros(m * n * n + 64, np.int16))
+        coef = _aligned(np.zeros(m * n * n + 64, np.int16))
+        deq = _aligned(np.zeros(m * n * n + 64, np.int16))
+        dj = np.zeros((len(jt), 8), np.int32)
+        dj[:, 0] = dj[:, 1] = jt[:, 0]
+        dj[:, 2] = n * n
+        dj[:, 3] = [40, 45, 51, 57, 64, 72][qp % 6] << (qp // 6)
+        dj[:, 4] = log2 - 1 + bd - 8
+        dj = _aligned(dj)
+        keep += [jt, jsrc, roff, res, coef, deq, dj]
+        add(lambda b, e, n=n, res=res, roff=roff, jsrc=jsrc: lib.ref_run_residual(S, P(res), ip(n), P(roff), P(luma), ip(st), P(luma), ip(st), P(jsrc), b, e), len(jt))
+        add(lambda b, e, n=n, log2=log2, tr=tr, coef=coef, res=res, jt=jt: lib.ref_run_transform(handle, bd, tr, log2, P(coef), P(res), ip(n), P(jt), b, e), len(jt))
+        add(lambda b, e, deq=deq, coef=coef, dj=dj: lib.ref_run_quantize_inverse(handle, P(deq), P(coef), P(dj), b, e), len(jt))
+        add(lambda b, e, log2=log2, tr=tr, deq=deq, jt=jt: lib.ref_run_inverse_transform_add(handle, S, bd, tr, log2, P(luma), ip(st), P(luma), ip(st), P(deq), P(jt), b, e), len(jt))
+    jss = sub(wl.ssd)
+    oss = np.zeros(len(jss), np.uint32)
+    keep += [jss, oss]
+    add(lambda b, e: lib.ref_run_ssd(handle, S, P(luma), ip(st), P(luma), ip(st), P(jss), b, e, P(oss)), len(jss))
+
+    def run_all(pool):
+        for fn, n in tasks:
+            chunk = (n + cores - 1) // cores
+            list(pool.map(lambda k: fn(k * chunk, min(n, (k + 1) * chunk)), range(cores)))
+
+    with ThreadPoolExecutor(cores) as pool:
+        run_all(pool)   # warm (JIT assembly, page faults)
+        t0 = time.perf_counter()
+        reps = 0
+        while True:
+            run_all(pool)
+            reps += 1
+            if time.perf_counter() - t0 > 2.0 or reps >= 50:
+                break
+        dt_s = (time.perf_counter() - t0) / reps
+    print(json.dumps({"seconds_per_sample": dt_s, "stride": stride, "cores": cores, "handle": handle,
+                      "jobs": int(sum(n for _, n in tasks))}))
+
+
+def cpu_baseline(args):
+    """frames/s of the reference library on the host: sample = every `stride`-th job of every table"""
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libhavoc_ref.so")):
+        return None
+    stride = 16
+    for handle in (1, 0):   # x86 JIT tables first; plain-C tables if the JIT run fails
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", f"{handle},{stride}", "--res", args.res,
+               "--bit-depth", str(args.bit_depth), "--seed", str(args.seed)]
+        try:
+            out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            if out.returncode == 0:
+                r = json.loads(out.stdout.strip().splitlines()[-1])
+                fps = 1.0 / (r["seconds_per_sample"] * r["stride"])
+                return {"value": round(fps, 3), "unit": "frames/s", "cores": r["cores"], "kind": "reference",
+                        "sample": f"every {stride}th job of each primitive's job table ({r['jobs']} calls) through the "
+                                  f"reference's own havoc {'x86-JIT' if handle else 'C'} function tables (oracle/_ref), "
+                                  f"{r['cores']} host threads, extrapolated x{stride}"}
+        except Exception:
+            pass
+    return None
+
+
+# --------------------------------------------------------------------------------------------------------------
+
+def main():
+    args = parse_args()
+    if args.cpu_worker:
+        return cpu_worker(args)
+    import torch
+    import torch.distributed as dist
+    from turingcodec_amd import Havoc
+    from turingcodec_amd.workload import FrameWorkload
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    hv = Havoc(local)
+    w, h = (int(v) for v in args.res.split("x"))
+    wl = FrameWorkload(w, h, args.bit_depth, args.seed + rank)   # every rank owns a different picture
+    dev = DeviceFrame(hv, wl)
+    exch = None
+    if world > 1:
+        from turingcodec_amd.frame_parallel import ReferenceExchange
+        exch = ReferenceExchange(dist, rank, world, dev.luma[3 * wl.plane_len:4 * wl.plane_len], dev.chroma[:wl.cplane_len])
+
+    def one_step(i):
+        dev.step()
+        if exch is not None:
+            exch.exchange(i)
+
+    for i in range(args.warmup):
+        one_step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ktimes, kcount = dev.kernel_times_ms(args.kernel_reps)
+        kbytes = wl.algorithmic_bytes()
+        dom = max(ktimes, key=ktimes.get)
+        ach = kbytes[dom] / (ktimes[dom] * 1e-3) / 1e9
+        total_bytes = sum(kbytes.values())
+        ms_step = elapsed / args.steps * 1e3
+        out = {
+            "metric": "encoded fps (havoc hot path: one RA B-frame's primitive calls per frame)",
+            "value": round(world * args.steps / elapsed, 3),
+            "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8" if args.bit_depth == 8 else "u16", "data": "synthetic",
+            "config": {"workload": f"{args.res} {args.bit_depth}-bit 4:2:0 random-access QP32 speed=medium B-frame call mix "
+                                   f"(SURVEY A.2 counts x {w * h / (1920 * 1080):.2f}; assumed PU/intra size mix), 1xMI355X per rank",
+                       "calls_per_frame": int(sum(wl.counts.values())), "launches_per_frame": len(dev.launches),
+                       "parallelism": f"frame-parallel x{world}" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                         "launch_ms": round(ktimes[dom] / kcount[dom], 5), "launches_per_step": kcount[dom],
+                         "algorithmic_bytes_per_step": kbytes[dom]},
+            "whole_step": {"algorithmic_bytes": total_bytes, "achieved_gbs": round(total_bytes / (ms_step * 1e-3) / 1e9, 2),
+                           "kernel_ms": {k: round(v, 4) for k, v in sorted(ktimes.items(), key=lambda kv: -kv[1])},
+                           "kernel_gbs": {k: round(kbytes[k] / (v * 1e-3) / 1e9, 1) for k, v in ktimes.items()}},
+            "checksum": dev.checksum(),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

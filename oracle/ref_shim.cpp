@@ -252,3 +252,220 @@ int ref_ssd_linear(int h, const uint8_t *a, const uint8_t *b, int size)
 }
 
 } // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------
+// Batch runners for bench.py's cpu_baseline leg: the same job tables the GPU consumes
+// (include/havoc_mi355x.h layouts, int32 columns), executed call-by-call through the reference's function
+// tables.  Jobs [begin, end) so that host threads can split a table.  `h` selects C (0) or JIT (1) tables.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+template <typename Sample>
+void runSad4(int h, const Sample *src, intptr_t ss, const Sample *ref, intptr_t rs, const int32_t *jobs, int b, int e, int32_t *out)
+{
+    auto &t = st<Sample>(tab(h));
+    for (int i = b; i < e; ++i)
+    {
+        const int32_t *j = jobs + 8 * i;
+        auto f = *havoc_get_sad_multiref<Sample>(&t.sad4, 4, j[5], j[6]);
+        const Sample *r[4] = { ref + j[1], ref + j[2], ref + j[3], ref + j[4] };
+        f(src + j[0], ss, r, rs, out + 4 * i, HAVOC_RECT(j[5], j[6]));
+    }
+}
+
+template <typename Sample>
+void runSad(int h, const Sample *src, intptr_t ss, const Sample *ref, intptr_t rs, const int32_t *jobs, int b, int e, int32_t *out)
+{
+    auto &t = st<Sample>(tab(h));
+    for (int i = b; i < e; ++i)
+    {
+        const int32_t *j = jobs + 4 * i;
+        out[i] = (*havoc_get_sad<Sample>(&t.sad, j[2], j[3]))(src + j[0], ss, ref + j[1], rs, HAVOC_RECT(j[2], j[3]));
+    }
+}
+
+template <typename Sample>
+void runSsd(int h, const Sample *a, intptr_t sa, const Sample *pb, intptr_t sb, const int32_t *jobs, int b, int e, uint32_t *out)
+{
+    auto &t = st<Sample>(tab(h));
+    for (int i = b; i < e; ++i)
+    {
+        const int32_t *j = jobs + 4 * i;
+        int log2 = 0;
+        while ((1 << log2) < j[2]) ++log2;
+        out[i] = (*havoc_get_ssd<Sample>(&t.ssd, log2))(a + j[0], sa, pb + j[1], sb, j[2], j[3]);
+    }
+}
+
+// turing/Measure.h:97-135 tiling, through the reference's satd table
+template <typename Sample>
+void runSatd(int h, const Sample *a, intptr_t sa, const Sample *pb, intptr_t sb, const int32_t *jobs, int b, int e, int32_t *out)
+{
+    auto &t = st<Sample>(tab(h));
+    for (int i = b; i < e; ++i)
+    {
+        const int32_t *j = jobs + 4 * i;
+        const int w = j[2], ht = j[3];
+        const int log2 = ((w | ht) & 3) ? 1 : (((w | ht) & 7) ? 2 : 3);
+        const int n = 1 << log2;
+        auto f = *havoc_get_hadamard_satd<Sample>(&t.satd, log2);
+        int s = 0;
+        for (int y = 0; y < ht; y += n)
+            for (int x = 0; x < w; x += n)
+                s += f(a + j[0] + y * sa + x, sa, pb + j[1] + y * sb + x, sb);
+        out[i] = s;
+    }
+}
+
+template <typename Sample>
+void runPredUni(int h, int taps, int bd, Sample *dst, intptr_t sd, const Sample *ref, intptr_t sr, const int32_t *jobs, int b, int e)
+{
+    auto &t = st<Sample>(tab(h));
+    for (int i = b; i < e; ++i)
+    {
+        const int32_t *j = jobs + 8 * i;
+        (*havocGetPredUni<Sample>(&t.predUni, taps, j[2], j[3], j[4], j[5], bd))(dst + j[0], sd, ref + j[1], sr, j[2], j[3], j[4], j[5], bd);
+    }
+}
+
+template <typename Sample>
+void runPredBi(int h, int taps, int bd, Sample *dst, intptr_t sd, const Sample *ref, intptr_t sr, const int32_t *jobs, int b, int e)
+{
+    auto &t = st<Sample>(tab(h));
+    for (int i = b; i < e; ++i)
+    {
+        const int32_t *j = jobs + 12 * i;
+        (*havocGetPredBi<Sample>(&t.predBi, taps, j[3], j[4], j[5], j[6], j[7], j[8], bd))(dst + j[0], sd, ref + j[1], ref + j[2], sr, j[3], j[4],
+                                                                                           j[5], j[6], j[7], j[8], bd);
+    }
+}
+
+template <typename Sample>
+void runSubtractBi(int h, int bd, Sample *dst, intptr_t sd, const Sample *pred, intptr_t sp, const Sample *src, intptr_t ss, const int32_t *jobs,
+                   int b, int e)
+{
+    auto f = st<Sample>(tab(h)).subtractBi.get();
+    for (int i = b; i < e; ++i)
+    {
+        const int32_t *j = jobs + 8 * i;
+        f(dst + j[0], sd, pred + j[1], sp, src + j[2], ss, j[3], j[4], bd);
+    }
+}
+
+template <typename Sample>
+void runIntra(int h, int bd, int log2, Sample *dst, intptr_t sd, const Sample *nb, const int32_t *jobs, int b, int e)
+{
+    auto &t = st<Sample>(tab(h));
+    for (int i = b; i < e; ++i)
+    {
+        const int32_t *j = jobs + 8 * i;
+        t.intra.lookup(j[4] ? 0 : 1, bd, log2, j[3])(dst + j[0], sd, nb + j[1], j[3]);
+    }
+}
+
+template <typename Sample>
+void runResidual(int16_t *res, intptr_t sres, const int32_t *resOff, const Sample *src, intptr_t ss, const Sample *pred, intptr_t sp,
+                 const int32_t *jobs, int b, int e)
+{
+    for (int i = b; i < e; ++i)   // the reference's inline loop, turing/Reconstruct.cpp:258-260
+    {
+        const int32_t *j = jobs + 4 * i;
+        for (int y = 0; y < j[3]; ++y)
+            for (int x = 0; x < j[2]; ++x)
+                res[resOff[i] + y * sres + x] = src[j[0] + y * ss + x] - pred[j[1] + y * sp + x];
+    }
+}
+
+template <typename Sample>
+void runInvAdd(int h, int bd, int tr, int log2, Sample *dst, intptr_t sd, const Sample *pred, intptr_t sp, const int16_t *coeffs, const int32_t *jobs,
+               int b, int e)
+{
+    auto f = *havoc::get_inverse_transform_add<Sample>(&st<Sample>(tab(h)).invAdd, tr, log2);
+    for (int i = b; i < e; ++i)
+    {
+        const int32_t *j = jobs + 4 * i;
+        f(dst + j[3], sd, pred + j[2], sp, coeffs + j[0], bd);
+    }
+}
+
+} // namespace
+
+#define SAMPLE_DISPATCH(S, call8, call16) do { if ((S) == 1) { call8; } else { call16; } } while (0)
+typedef const uint8_t *cu8;
+typedef const uint16_t *cu16;
+
+extern "C" {
+
+void ref_run_sad4(int h, int S, const void *src, intptr_t ss, const void *ref, intptr_t rs, const int32_t *jobs, int b, int e, int32_t *out)
+{
+    SAMPLE_DISPATCH(S, runSad4<uint8_t>(h, (cu8)src, ss, (cu8)ref, rs, jobs, b, e, out), runSad4<uint16_t>(h, (cu16)src, ss, (cu16)ref, rs, jobs, b, e, out));
+}
+void ref_run_sad(int h, int S, const void *src, intptr_t ss, const void *ref, intptr_t rs, const int32_t *jobs, int b, int e, int32_t *out)
+{
+    SAMPLE_DISPATCH(S, runSad<uint8_t>(h, (cu8)src, ss, (cu8)ref, rs, jobs, b, e, out), runSad<uint16_t>(h, (cu16)src, ss, (cu16)ref, rs, jobs, b, e, out));
+}
+void ref_run_ssd(int h, int S, const void *a, intptr_t sa, const void *pb, intptr_t sb, const int32_t *jobs, int b, int e, uint32_t *out)
+{
+    SAMPLE_DISPATCH(S, runSsd<uint8_t>(h, (cu8)a, sa, (cu8)pb, sb, jobs, b, e, out), runSsd<uint16_t>(h, (cu16)a, sa, (cu16)pb, sb, jobs, b, e, out));
+}
+void ref_run_satd(int h, int S, const void *a, intptr_t sa, const void *pb, intptr_t sb, const int32_t *jobs, int b, int e, int32_t *out)
+{
+    SAMPLE_DISPATCH(S, runSatd<uint8_t>(h, (cu8)a, sa, (cu8)pb, sb, jobs, b, e, out), runSatd<uint16_t>(h, (cu16)a, sa, (cu16)pb, sb, jobs, b, e, out));
+}
+void ref_run_pred_uni(int h, int S, int taps, int bd, void *dst, intptr_t sd, const void *ref, intptr_t sr, const int32_t *jobs, int b, int e)
+{
+    SAMPLE_DISPATCH(S, runPredUni<uint8_t>(h, taps, bd, (uint8_t *)dst, sd, (cu8)ref, sr, jobs, b, e),
+                    runPredUni<uint16_t>(h, taps, bd, (uint16_t *)dst, sd, (cu16)ref, sr, jobs, b, e));
+}
+void ref_run_pred_bi(int h, int S, int taps, int bd, void *dst, intptr_t sd, const void *ref, intptr_t sr, const int32_t *jobs, int b, int e)
+{
+    SAMPLE_DISPATCH(S, runPredBi<uint8_t>(h, taps, bd, (uint8_t *)dst, sd, (cu8)ref, sr, jobs, b, e),
+                    runPredBi<uint16_t>(h, taps, bd, (uint16_t *)dst, sd, (cu16)ref, sr, jobs, b, e));
+}
+void ref_run_subtract_bi(int h, int S, int bd, void *dst, intptr_t sd, const void *pred, intptr_t sp, const void *src, intptr_t ss, const int32_t *jobs,
+                         int b, int e)
+{
+    SAMPLE_DISPATCH(S, runSubtractBi<uint8_t>(h, bd, (uint8_t *)dst, sd, (cu8)pred, sp, (cu8)src, ss, jobs, b, e),
+                    runSubtractBi<uint16_t>(h, bd, (uint16_t *)dst, sd, (cu16)pred, sp, (cu16)src, ss, jobs, b, e));
+}
+void ref_run_intra(int h, int S, int bd, int log2, void *dst, intptr_t sd, const void *nb, const int32_t *jobs, int b, int e)
+{
+    SAMPLE_DISPATCH(S, runIntra<uint8_t>(h, bd, log2, (uint8_t *)dst, sd, (cu8)nb, jobs, b, e),
+                    runIntra<uint16_t>(h, bd, log2, (uint16_t *)dst, sd, (cu16)nb, jobs, b, e));
+}
+void ref_run_residual(int S, int16_t *res, intptr_t sres, const int32_t *resOff, const void *src, intptr_t ss, const void *pred, intptr_t sp,
+                      const int32_t *jobs, int b, int e)
+{
+    SAMPLE_DISPATCH(S, runResidual<uint8_t>(res, sres, resOff, (cu8)src, ss, (cu8)pred, sp, jobs, b, e),
+                    runResidual<uint16_t>(res, sres, resOff, (cu16)src, ss, (cu16)pred, sp, jobs, b, e));
+}
+void ref_run_transform(int h, int bd, int tr, int log2, int16_t *coeffs, const int16_t *res, intptr_t sres, const int32_t *jobs, int b, int e)
+{
+    havoc::Transform *f = bd == 8 ? *havoc::get_transform<8>(&tab(h).fwd8, tr, log2) : *havoc::get_transform<10>(&tab(h).fwd10, tr, log2);
+    for (int i = b; i < e; ++i) f(coeffs + jobs[4 * i], res + jobs[4 * i + 1], sres);
+}
+void ref_run_quantize_inverse(int h, int16_t *dst, const int16_t *src, const int32_t *jobs, int b, int e)
+{
+    for (int i = b; i < e; ++i)
+    {
+        const int32_t *j = jobs + 8 * i;
+        (*havoc_get_quantize_inverse(&tab(h).dequant, j[3], j[4]))(dst + j[0], src + j[1], j[3], j[4], j[2]);
+    }
+}
+void ref_run_quantize(int h, int16_t *dst, const int16_t *src, const int32_t *jobs, int b, int e, int32_t *cbf)
+{
+    auto f = *havoc_get_quantize(&tab(h).quant);
+    for (int i = b; i < e; ++i)
+    {
+        const int32_t *j = jobs + 8 * i;
+        cbf[i] = f(dst + j[0], src + j[1], j[3], j[4], j[5], j[2]);
+    }
+}
+void ref_run_inverse_transform_add(int h, int S, int bd, int tr, int log2, void *dst, intptr_t sd, const void *pred, intptr_t sp, const int16_t *coeffs,
+                                   const int32_t *jobs, int b, int e)
+{
+    SAMPLE_DISPATCH(S, runInvAdd<uint8_t>(h, bd, tr, log2, (uint8_t *)dst, sd, (cu8)pred, sp, coeffs, jobs, b, e),
+                    runInvAdd<uint16_t>(h, bd, tr, log2, (uint16_t *)dst, sd, (cu16)pred, sp, coeffs, jobs, b, e));
+}
+
+} // extern "C"

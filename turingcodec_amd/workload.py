@@ -1,0 +1,284 @@
+"""Synthetic hot-path workload: one random-access B-frame's worth of havoc primitive calls.
+
+What a "frame" is here.  The encoder's control flow (mode decision, CABAC, RDOQ) is outside the hot path
+(SURVEY.md 8a / 2.2); what the path has to sustain per picture is the *stream of primitive calls* the reference
+issues.  SURVEY.md Appendix A.2 measured that stream for 1920x1080 random-access QP32 speed=medium (gprof of the
+reference, --asm 0, identical decisions to --asm 1): the per-B-frame call counts below are those numbers divided by
+the 8 B-frames (inter primitives) or 9 frames (intra / TU primitives).  A workload at another resolution scales the
+counts by the CTU count.  Block-size mixes are not in the survey; the ones used are stated in `PU_MIX` / `TU_MIX` /
+`INTRA_MIX` (TU_MIX *is* from A.2's dct32/16/8/4/dst4 split) and are part of the workload's name.
+
+Everything is generated from a seed with numpy on the host, uploaded once, and stays resident in HBM in the
+reference's padded picture layout (96-sample padding, turing/StatePictures.h:155-156; stride a multiple of 64 B).
+"""
+import numpy as np
+
+PAD = 96
+CTU = 64
+
+# ---- per-B-frame call counts at 1080p (510 CTUs), SURVEY.md Appendix A.2 --------------------------------------
+CALLS_1080P = {
+    "sad4": 1462024 // 8,               # havoc_sad_multiref_4
+    "sad": 107571 // 8,                 # havoc_sad
+    "uni8_hv": 728533 // 8, "uni8_h": 329670 // 8, "uni8_v": 326723 // 8, "uni8_copy": 303832 // 8,
+    "uni4_h": 42744 // 8, "uni4_v": 15102 // 8, "uni4_hv": 12316 // 8,
+    "bi8": 132219 // 8, "bi4": 264438 // 8,
+    "subtract_bi": 36890 // 8,          # one per searchMotionBi
+    "intra_satd": 6738655 // 9,         # PredictIntraLumaBlock: prediction + SATD
+    "intra_rd": (1466163 + 615690) // 9,  # ReconstructIntraBlock luma + chroma: prediction only here
+    "tu": 2452215 // 9,                 # fwd T, de-quant, inverse T + add (RDOQ replaces havoc_quantize at medium)
+    "ssd": (1644543 + 1444224) // 9,
+}
+# every luma interpolation is followed by a PU SATD (costDistortionMv / measurePuCost): measureSatd calls/B-frame
+# = 1689441/8 ~ 211k ~ the luma uni count, so the SATD batch pairs one job with each luma uni prediction.
+
+# (w, h, weight): ASSUMED PU-size mix of the ME / MC calls (not measured by the survey)
+PU_MIX = [(64, 64, 2), (64, 32, 2), (32, 64, 2), (32, 32, 10), (32, 16, 7), (16, 32, 7), (16, 16, 22), (16, 8, 10),
+          (8, 16, 10), (8, 8, 20), (32, 8, 1), (8, 32, 1), (32, 24, 1), (24, 32, 1), (16, 4, 1), (4, 16, 1),
+          (16, 12, 1), (12, 16, 1)]
+# (log2, trType, weight): measured split dct32 / dct16 / dct8 / dct4 / dst4 (A.2)
+TU_MIX = [(5, 0, 94163), (4, 0, 350559), (3, 0, 587269), (2, 0, 334902), (2, 1, 1085322)]
+# (log2, weight): ASSUMED intra partition mix (~42 partitions per CTU: 4 x 32, 16 x 16, 22 x 8; a few 4x4)
+INTRA_MIX = [(5, 9), (4, 36), (3, 50), (2, 5)]
+
+
+def synth_frames(width, height, nframes, seed, bit_depth=8):
+    """SURVEY.md 8(d) generator: low-passed noise translating by (3,2) px/frame blended 60/40 with a moving
+    sinusoid, +-3 uniform noise; smooth chroma ramps.  Returns [(Y, U, V)] unpadded planes."""
+    rng = np.random.default_rng(seed)
+    big = rng.integers(0, 256, size=(height + 2 * 64 + 2 * nframes, width + 3 * nframes + 2 * 64)).astype(np.float32)
+    k = np.ones(9, np.float32) / 9.0
+    for ax in (0, 1):   # separable 9-tap box low-pass
+        big = np.apply_along_axis(lambda v: np.convolve(v, k, mode="same"), ax, big)
+    yy, xx = np.mgrid[0:height, 0:width].astype(np.float32)
+    scale = (1 << bit_depth) / 256.0
+    out = []
+    for f in range(nframes):
+        tex = big[2 * f:2 * f + height, 3 * f:3 * f + width]
+        sin = 128.0 + 100.0 * np.sin((xx + 5 * f) * 0.045) * np.cos((yy - 3 * f) * 0.03)
+        y = 0.6 * tex + 0.4 * sin + rng.integers(-3, 4, size=(height, width))
+        u = 128.0 + 60.0 * (xx[::2, ::2] / width - 0.5) + 8.0 * np.sin(f * 0.3)
+        v = 128.0 + 60.0 * (yy[::2, ::2] / height - 0.5) - 8.0 * np.cos(f * 0.3)
+        dt = np.uint8 if bit_depth == 8 else np.uint16
+        mx = (1 << bit_depth) - 1
+        out.append(tuple(np.clip(np.rint(p * scale), 0, mx).astype(dt) for p in (y, u, v)))
+    return out
+
+
+def pad_plane(p, pad, align_bytes=64):
+    """replicate-pad a plane like turing/Padding.h and round the stride to `align_bytes`"""
+    h, w = p.shape
+    q = np.pad(p, pad, mode="edge")
+    stride = q.shape[1]
+    n = align_bytes // p.itemsize
+    if stride % n:
+        q = np.pad(q, ((0, 0), (0, n - stride % n)), mode="edge")
+    return np.ascontiguousarray(q)
+
+
+def _pick(rng, mix, n):
+    w = np.array([m[-1] for m in mix], np.float64)
+    return rng.choice(len(mix), size=n, p=w / w.sum())
+
+
+class FrameWorkload:
+    """Job tables (numpy int32, columns = the job structs of include/havoc_mi355x.h) + picture store layout."""
+
+    def __init__(self, width=1920, height=1080, bit_depth=8, seed=11, scale=1.0):
+        self.width, self.height, self.bit_depth = width, height, bit_depth
+        self.S = 1 if bit_depth == 8 else 2
+        rng = np.random.default_rng(seed)
+        self.dtype = np.uint8 if self.S == 1 else np.uint16
+        frames = synth_frames(width, height, 3, seed, bit_depth)
+        # picture store: planes 0 = source, 1 = ref L0, 2 = ref L1 (luma); same for chroma (U only: V is identical work)
+        luma = [pad_plane(f[0], PAD) for f in (frames[1], frames[0], frames[2])]
+        chroma = [pad_plane(f[1], PAD // 2) for f in (frames[1], frames[0], frames[2])]
+        self.stride = luma[0].shape[1]
+        self.plane_len = luma[0].size
+        self.cstride = chroma[0].shape[1]
+        self.cplane_len = chroma[0].size
+        self.luma = np.concatenate([p.ravel() for p in luma])       # offsets: plane k at k*plane_len
+        self.chroma = np.concatenate([p.ravel() for p in chroma])
+        ctus = ((width + CTU - 1) // CTU) * ((height + CTU - 1) // CTU)
+        f = scale * ctus / 510.0
+        n = {k: max(1, int(round(v * f))) for k, v in CALLS_1080P.items()}
+        self.counts = n
+        W, H, st, pl = width, height, self.stride, self.plane_len
+
+        def pu(nj):
+            idx = _pick(rng, PU_MIX, nj)
+            w = np.array([m[0] for m in PU_MIX], np.int32)[idx]
+            h = np.array([m[1] for m in PU_MIX], np.int32)[idx]
+            # PU positions are aligned to their own size inside the picture (natural CU alignment)
+            x = (rng.integers(0, 1 << 30, nj) % np.maximum(1, (W - w) // w + 1)) * w
+            y = (rng.integers(0, 1 << 30, nj) % np.maximum(1, (H - h) // h + 1)) * h
+            return w, h, x.astype(np.int32), y.astype(np.int32)
+
+        def loff(x, y, plane):  # luma offset inside the picture store
+            return (plane * pl + (y + PAD) * st + (x + PAD)).astype(np.int32)
+
+        def mv(nj, r=64):
+            return rng.integers(-r, r + 1, nj).astype(np.int32), rng.integers(-r, r + 1, nj).astype(np.int32)
+
+        # ---- integer ME: SAD4 (4 candidates of one diamond/star step around a centre) and single SAD
+        w, h, x, y = pu(n["sad4"])
+        cx, cy = mv(n["sad4"], 60)
+        step = rng.choice([1, 2, 4], n["sad4"]).astype(np.int32)
+        lst = rng.integers(1, 3, n["sad4"]).astype(np.int32)   # reference list 0/1 -> plane 1/2
+        j = np.zeros((n["sad4"], 8), np.int32)
+        j[:, 0] = loff(x, y, 0)
+        for k, (dx, dy) in enumerate(((0, -1), (-1, 0), (1, 0), (0, 1))):
+            j[:, 1 + k] = loff(x + cx + dx * step, y + cy + dy * step, lst)
+        j[:, 5], j[:, 6] = w, h
+        self.sad4 = j
+        w, h, x, y = pu(n["sad"])
+        cx, cy = mv(n["sad"])
+        self.sad = np.stack([loff(x, y, 0), loff(x + cx, y + cy, rng.integers(1, 3, n["sad"])), w, h], 1).astype(np.int32)
+
+        # ---- luma interpolation + the SATD that follows each one (prediction slots: stride 64, 64*h samples each)
+        kinds = [("uni8_hv", 1, 1), ("uni8_h", 1, 0), ("uni8_v", 0, 1), ("uni8_copy", 0, 0)]
+        rows = []
+        for name, fx, fy in kinds:
+            w, h, x, y = pu(n[name])
+            cx, cy = mv(n[name])
+            xf = rng.integers(1, 4, n[name]) * fx
+            yf = rng.integers(1, 4, n[name]) * fy
+            rows.append(np.stack([np.zeros_like(w), loff(x + cx, y + cy, rng.integers(1, 3, n[name])), w, h, xf, yf,
+                                  loff(x, y, 0), np.zeros_like(w)], 1))
+        u = np.concatenate(rows).astype(np.int32)
+        u = u[rng.permutation(len(u))]
+        slot = np.concatenate([[0], np.cumsum(64 * u[:-1, 3].astype(np.int64))])
+        u[:, 0] = slot
+        self.pred_len = int(slot[-1] + 64 * u[-1, 3])
+        self.uni8 = u.copy()
+        self.uni8[:, 6] = 0
+        self.satd_inter = np.stack([u[:, 6], u[:, 0], u[:, 2], u[:, 3]], 1).astype(np.int32)   # a = src PU, b = prediction
+
+        # ---- chroma interpolation (4-tap, eighth-sample phases) on the half-size planes
+        cst, cpl = self.cstride, self.cplane_len
+        rows = []
+        for name, fx, fy in (("uni4_h", 1, 0), ("uni4_v", 0, 1), ("uni4_hv", 1, 1)):
+            w, h, x, y = pu(n[name])
+            cx, cy = mv(n[name], 30)
+            off = (rng.integers(1, 3, n[name]) * cpl + (y // 2 + cy + PAD // 2) * cst + (x // 2 + cx + PAD // 2)).astype(np.int32)
+            rows.append(np.stack([np.zeros_like(w), off, w // 2, h // 2, rng.integers(1, 8, n[name]) * fx,
+                                  rng.integers(1, 8, n[name]) * fy, np.zeros_like(w), np.zeros_like(w)], 1))
+        c = np.concatenate(rows).astype(np.int32)
+        c[:, 0] = np.arange(len(c)) * 32 * 32          # chroma prediction slots: 32 x 32, stride 32
+        self.uni4 = c
+        self.cpred_len = len(c) * 1024
+
+        # ---- bi prediction (luma 8-tap into the luma slots area, chroma 4-tap)
+        w, h, x, y = pu(n["bi8"])
+        c0x, c0y = mv(n["bi8"])
+        c1x, c1y = mv(n["bi8"])
+        fr = rng.integers(0, 4, (n["bi8"], 4)).astype(np.int32)
+        b = np.zeros((n["bi8"], 12), np.int32)
+        b[:, 0] = np.arange(n["bi8"]) * 4096
+        b[:, 1], b[:, 2] = loff(x + c0x, y + c0y, 1), loff(x + c1x, y + c1y, 2)
+        b[:, 3], b[:, 4] = w, h
+        b[:, 5:9] = fr
+        self.bi8 = b
+        w, h, x, y = pu(n["bi4"])
+        c0x, c0y = mv(n["bi4"], 30)
+        c1x, c1y = mv(n["bi4"], 30)
+        b = np.zeros((n["bi4"], 12), np.int32)
+        b[:, 0] = np.arange(n["bi4"]) * 1024
+        b[:, 1] = (1 * cpl + (y // 2 + c0y + PAD // 2) * cst + (x // 2 + c0x + PAD // 2)).astype(np.int32)
+        b[:, 2] = (2 * cpl + (y // 2 + c1y + PAD // 2) * cst + (x // 2 + c1x + PAD // 2)).astype(np.int32)
+        b[:, 3], b[:, 4] = w // 2, h // 2
+        b[:, 5:9] = rng.integers(0, 8, (n["bi4"], 4))
+        self.bi4 = b
+        self.bi_len = max(n["bi8"] * 4096, n["bi4"] * 1024)
+
+        # ---- SubtractBi: dst slot <- clip(2*src - pred), pred = a luma prediction slot region (stride 64)
+        w, h, x, y = pu(n["subtract_bi"])
+        s = np.zeros((n["subtract_bi"], 8), np.int32)
+        s[:, 0] = np.arange(n["subtract_bi"]) * 4096
+        s[:, 1] = np.arange(n["subtract_bi"]) * 4096      # pred: the bi8 slots (already filled)
+        s[:, 2] = loff(x, y, 0)
+        s[:, 3], s[:, 4] = w, h
+        self.subtract_bi = s
+
+        # ---- intra prediction (+ SATD for the 35-mode stage): per size class
+        self.intra = {}
+        self.intra_nb = {}
+        self.intra_satd = {}
+        src = luma[0]
+        ni = n["intra_satd"] + n["intra_rd"]
+        sizes = np.array([m[0] for m in INTRA_MIX])[_pick(rng, INTRA_MIX, ni)]
+        is_satd = np.arange(ni) < n["intra_satd"]
+        for log2 in (2, 3, 4, 5):
+            sel = np.flatnonzero(sizes == log2)
+            m, nn = len(sel), 1 << log2
+            x = (rng.integers(0, (W - nn) // nn + 1, m) * nn).astype(np.int32)
+            y = (rng.integers(0, (H - nn) // nn + 1, m) * nn).astype(np.int32)
+            # neighbours taken from the (padded) source picture around the block: [left col bottom->top, corner, top row]
+            L = 4 * nn + 1
+            k = np.arange(L)
+            dy = np.where(k < 2 * nn, 2 * nn - 1 - k, -1)
+            dx = np.where(k <= 2 * nn, -1, k - 2 * nn - 1)
+            nb = src[(y[:, None] + PAD + dy[None, :]), (x[:, None] + PAD + dx[None, :])]
+            self.intra_nb[log2] = np.ascontiguousarray(nb.ravel())
+            j = np.zeros((m, 8), np.int32)
+            j[:, 0] = np.arange(m) * nn * nn
+            j[:, 1] = np.arange(m) * L + 2 * nn + 1
+            j[:, 2] = log2
+            j[:, 3] = rng.integers(0, 35, m)
+            j[:, 4] = 1
+            self.intra[log2] = j
+            ss = is_satd[sel]
+            self.intra_satd[log2] = np.stack([loff(x, y, 0)[ss], j[ss, 0], np.full(ss.sum(), nn), np.full(ss.sum(), nn)], 1).astype(np.int32)
+
+        # ---- TU chain: residual (src - pred) -> forward T -> [RDOQ on host] -> de-quant -> inverse T + add -> SSD
+        self.tu = {}
+        ti = _pick(rng, TU_MIX, n["tu"])
+        for gi, (log2, tr, _) in enumerate(TU_MIX):
+            m, nn = int((ti == gi).sum()), 1 << log2
+            x = (rng.integers(0, (W - nn) // nn + 1, m) * nn).astype(np.int32)
+            y = (rng.integers(0, (H - nn) // nn + 1, m) * nn).astype(np.int32)
+            dx, dy = mv(m, 2)
+            t = np.zeros((m, 4), np.int32)
+            t[:, 0] = np.arange(m) * nn * nn                # coefficients / levels / residual: n*n contiguous
+            t[:, 1] = np.arange(m) * nn * nn
+            t[:, 2] = loff(x + dx, y + dy, 1)               # prediction: a slightly displaced block of ref L0
+            t[:, 3] = loff(x, y, 3)                         # reconstruction plane = plane 3 of the store
+            self.tu[(log2, tr)] = dict(jobs=t, src=np.stack([loff(x, y, 0), t[:, 2], np.full(m, nn), np.full(m, nn)], 1).astype(np.int32),
+                                       res_off=t[:, 1].copy(), n=nn)
+        # SSD after reconstruction: source block vs reconstructed block, n x n
+        rows = []
+        for (log2, tr), g in self.tu.items():
+            rows.append(np.stack([g["src"][:, 0], g["jobs"][:, 3], g["src"][:, 2], g["src"][:, 3]], 1))
+        allssd = np.concatenate(rows)
+        reps = int(np.ceil(n["ssd"] / len(allssd)))
+        self.ssd = np.concatenate([allssd] * reps)[:n["ssd"]].astype(np.int32)
+
+    # ---- algorithmic bytes (SURVEY.md 8(d) "per primitive call": operands read once + results written once) ----
+    def algorithmic_bytes(self):
+        S = self.S
+        b = {}
+        wh = lambda j, cw, ch: j[:, cw].astype(np.int64) * j[:, ch]
+        b["sad4"] = int((5 * wh(self.sad4, 5, 6) * S + 16).sum())
+        b["sad"] = int((2 * wh(self.sad, 2, 3) * S + 4).sum())
+
+        def uni(j, t):
+            w, h = j[:, 2].astype(np.int64), j[:, 3].astype(np.int64)
+            frac = (j[:, 4] != 0) | (j[:, 5] != 0)
+            return int(np.where(frac, (w + t - 1) * (h + t - 1) * S + w * h * S, 2 * w * h * S).sum())
+        b["pred_uni8"] = uni(self.uni8, 8)
+        b["pred_uni4"] = uni(self.uni4, 4)
+        for nm, j, t in (("pred_bi8", self.bi8, 8), ("pred_bi4", self.bi4, 4)):
+            w, h = j[:, 3].astype(np.int64), j[:, 4].astype(np.int64)
+            b[nm] = int((2 * (w + t - 1) * (h + t - 1) * S + w * h * S).sum())
+        b["subtract_bi"] = int((3 * wh(self.subtract_bi, 3, 4) * S).sum())
+        b["satd_inter"] = int((2 * wh(self.satd_inter, 2, 3) * S + 4).sum())
+        b["intra"] = sum(len(j) * ((4 * (1 << l) + 1) * S + (1 << (2 * l)) * S) for l, j in self.intra.items())
+        b["satd_intra"] = sum(int((2 * wh(j, 2, 3) * S + 4).sum()) for j in self.intra_satd.values())
+        ntu = {k: len(g["jobs"]) * g["n"] ** 2 for k, g in self.tu.items()}
+        tot = sum(ntu.values())
+        b["residual"] = tot * (2 * S + 2)
+        b["transform"] = 4 * tot
+        b["quantize_inverse"] = 4 * tot
+        b["inverse_transform_add"] = tot * (2 + 2 * S)
+        b["ssd"] = int((2 * wh(self.ssd, 2, 3) * S + 4).sum())
+        return b
