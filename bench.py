@@ -186,6 +186,18 @@ def _aligned(a, align=64):
     return out
 
 
+def usable_cores():
+    """host threads we may really use: CPU affinity capped by the cgroup CPU quota"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_worker(args):
     """child process: time the reference library on every `stride`-th job; prints a JSON dict"""
     import ctypes as C
@@ -195,7 +207,7 @@ def cpu_worker(args):
     w, h = (int(v) for v in args.res.split("x"))
     wl = FrameWorkload(w, h, args.bit_depth, args.seed)
     lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libhavoc_ref.so"))
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     S, bd, st, cst = wl.S, wl.bit_depth, wl.stride, wl.cstride
     dt = wl.dtype
     P = lambda a: C.c_void_p(a.ctypes.data)
@@ -213,6 +225,10 @@ def cpu_worker(args):
     def add(fn, n):
         if n:
             tasks.append((fn, n))
+            if os.environ.get("HAVOC_BENCH_TRACE"):
+                sys.stderr.write(f"task {len(tasks)} n={n}\n")
+                sys.stderr.flush()
+                fn(0, n)
 
     j4, js = sub(wl.sad4), sub(wl.sad)
     o4, os_ = np.zeros(4 * len(j4), np.int32), np.zeros(len(js), np.int32)
