@@ -37,6 +37,7 @@ typedef struct havoc_mi355x_ctx havoc_mi355x_ctx;
 /* ---- context: replaces havoc_new_code / havoc_delete_code (havoc/havoc.h:138-147, havoc.cpp:144-155).
  * `stream` is a hipStream_t (NULL = the device's default stream; pass torch's current stream to order
  * launches with torch ops).  Fails with ENODEV when there is no GPU: there is no CPU fallback. */
+#define HAVOC_MI355X_NEW_STREAM ((void *)(intptr_t)-1) /* create(): make and own a private non-blocking stream */
 int havoc_mi355x_create(havoc_mi355x_ctx **ctx, int device, void *stream);
 void havoc_mi355x_destroy(havoc_mi355x_ctx *ctx);
 int havoc_mi355x_set_stream(havoc_mi355x_ctx *ctx, void *stream);

@@ -141,9 +141,11 @@ def have_reference():
 class Reference:
     """The reference's own havoc functions (C tables: handle 0; x86 JIT tables: handle 1)."""
 
-    def __init__(self, handle=0):
+    def __init__(self, handle=0, path=None):
+        """path: another library exporting the same ref_* veneer -- tests/test_classic_api.py compiles
+        oracle/ref_shim.cpp (a client of the reference's table API) against OUR include/havoc headers"""
         self.h = handle
-        L = self.L = C.CDLL(REF_SO)
+        L = self.L = C.CDLL(path or REF_SO)
         for sfx in ("u8", "u16"):
             getattr(L, "ref_sad_" + sfx).restype = C.c_int
             getattr(L, "ref_sad_" + sfx).argtypes = [C.c_int, _vp, _ip, _vp, _ip, C.c_int, C.c_int]

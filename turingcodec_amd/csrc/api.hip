@@ -40,6 +40,7 @@ struct havoc_mi355x_ctx
     hipStream_t stream;
     hipEvent_t ev0, ev1;
     hipDeviceProp_t prop;
+    bool ownsStream;
 };
 
 static thread_local char g_err[256] = "";
@@ -78,7 +79,8 @@ int havoc_mi355x_create(havoc_mi355x_ctx **out, int device, void *stream)
     REQUIRE(device >= 0 && device < count, "device index out of range");
     havoc_mi355x_ctx *c = new havoc_mi355x_ctx();
     c->device = device;
-    c->stream = (hipStream_t)stream;
+    c->ownsStream = stream == HAVOC_MI355X_NEW_STREAM;
+    c->stream = c->ownsStream ? nullptr : (hipStream_t)stream;
     int rc;
     if ((rc = check(hipSetDevice(device), "hipSetDevice")) || (rc = check(hipGetDeviceProperties(&c->prop, device), "hipGetDeviceProperties")))
     {
@@ -96,6 +98,11 @@ int havoc_mi355x_create(havoc_mi355x_ctx **out, int device, void *stream)
         delete c;
         return rc;
     }
+    if (c->ownsStream && (rc = check(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate")))
+    {
+        delete c;
+        return rc;
+    }
     *out = c;
     return 0;
 }
@@ -103,6 +110,7 @@ int havoc_mi355x_create(havoc_mi355x_ctx **out, int device, void *stream)
 void havoc_mi355x_destroy(havoc_mi355x_ctx *ctx)
 {
     if (!ctx) return;
+    if (ctx->ownsStream) (void)hipStreamDestroy(ctx->stream);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
     delete ctx;
@@ -111,6 +119,7 @@ void havoc_mi355x_destroy(havoc_mi355x_ctx *ctx)
 int havoc_mi355x_set_stream(havoc_mi355x_ctx *ctx, void *stream)
 {
     REQUIRE_CTX();
+    REQUIRE(!ctx->ownsStream, "context owns its stream");
     ctx->stream = (hipStream_t)stream;
     return 0;
 }
