@@ -177,6 +177,24 @@ int havoc_mi355x_subtract_bi(havoc_mi355x_ctx *ctx, int S, int bitDepth, void *d
 int havoc_mi355x_intra(havoc_mi355x_ctx *ctx, int S, int bitDepth, int log2TrafoSize, void *d_dst, intptr_t stride_dst,
                        const void *d_neighbours, const havoc_mi355x_intra_job *d_jobs, int njobs);
 
+/* The 35-mode luma SATD stage of one intra partition, fused: for every mode m = 0..34 the prediction
+ * (havoc/pred_intra.cpp:20282-20401, from the filtered neighbour array when bit m of filt_lo/filt_hi is set, else the
+ * unfiltered one -- the caller's filterFlag, turing/Reconstruct.cpp:659) is measured against the source block with
+ * the Hadamard SATD (8x8 tiles; one 4x4 for 4x4 blocks) exactly as PredictIntraLumaBlock does
+ * (turing/Reconstruct.cpp:630-701) inside the mode loop of searchIntraPartition (turing/Search.hpp:113-142).
+ * d_cost[35*i + m] = SATD; no prediction is written to memory. */
+typedef struct {
+    int32_t src_off;   /* top-left of the source block in d_src */
+    int32_t nb_off;    /* unfiltered neighbours[0] (same layout as havoc_mi355x_intra_job) in d_neighbours */
+    int32_t nbf_off;   /* filtered neighbours[0] */
+    uint32_t filt_lo;  /* bit m: mode m (0..31) predicts from the filtered array */
+    uint32_t filt_hi;  /* bits 0..2: modes 32..34 */
+    int32_t edge;      /* cIdx == 0 (edge filters apply when log2TrafoSize < 5) */
+    int32_t reserved[2];
+} havoc_mi355x_intra_search_job; /* 32 bytes */
+int havoc_mi355x_intra_satd35(havoc_mi355x_ctx *ctx, int S, int bitDepth, int log2TrafoSize, const void *d_src, intptr_t stride_src,
+                              const void *d_neighbours, const havoc_mi355x_intra_search_job *d_jobs, int njobs, int32_t *d_cost);
+
 /* ------------------------------------------------------------------------------------------------------- */
 /* residual, transforms, quantisation                                                                        */
 /* ------------------------------------------------------------------------------------------------------- */

@@ -134,6 +134,24 @@ def make_inputs(seed=20260927):
     d["qrec.res"] = np.concatenate(rres)
     d["qrec.jobs"] = np.array(rj, np.int32)
     d["ssd_linear.n"] = np.array([1, 16, 100, 512, 4096, 25600], np.int32)
+    # fused 35-mode intra SATD stage: partitions of every size; source block in plane a, unfiltered + filtered
+    # neighbour arrays (independent random data: the kernel must honour the per-mode filter mask), random masks
+    for S, bd in ((1, 8), (2, 10)):
+        k = "u8" if S == 1 else "u16"
+        jobs, nbs = [], []
+        for log2 in (2, 3, 4, 5):
+            n = 1 << log2
+            for rep in range(7 if log2 < 5 else 3):
+                x, y = cases.rand_pos(rng, n, n)
+                kind = "extremes" if rep == 2 else "uniform"
+                nbu, c = cases.rand_neighbours(rng, S, bd, kind)
+                nbf, _ = cases.rand_neighbours(rng, S, bd, kind)
+                base = sum(len(a) for a in nbs)
+                nbs += [nbu, nbf]
+                mask = int(rng.integers(0, 1 << 35)) if rep else 0
+                jobs.append((cases.off(x, y), base + c, base + len(nbu) + c, mask & 0xffffffff, mask >> 32, rep != 1, log2, 0))
+        d[f"{k}.intra35.nb"] = np.concatenate(nbs)
+        d[f"{k}.intra35.jobs"] = np.array(jobs, np.int64).astype(np.uint32).view(np.int32).reshape(len(jobs), 8)
     return d
 
 
@@ -202,6 +220,10 @@ def run(impl, d, keys=None):
         out["qrec"] = impl.quantize_reconstruct(len(j) * SLOT, 64, d["u8.a"], W, d["qrec.res"], j)
     if want("ssd_linear"):
         out["ssd_linear"] = np.array([impl.ssd_linear(d["u8.a"], d["u8.b"], int(n)) for n in d["ssd_linear.n"]], np.int64)
+    for S, bd in ((1, 8), (2, 10)):
+        k = "u8" if S == 1 else "u16"
+        if want(f"{k}.intra35"):
+            out[f"{k}.intra35"] = impl.intra_satd35(bd, d[f"{k}.a"], W, d[f"{k}.intra35.nb"], d[f"{k}.intra35.jobs"])
     return out
 
 
@@ -277,6 +299,28 @@ class LoopImpl:
             else:
                 self.f.intra(dst, do, sd, nb, no, log2, mode, edge, bd)
         return dst
+
+    def intra_satd35(self, bd, src, ss, nb, jobs):
+        """composition of the two per-call primitives, as PredictIntraLumaBlock does (turing/Reconstruct.cpp:630-701):
+        predict into a 32-stride scratch block, then SATD against the source in 8x8 tiles (one 4x4 for 4x4 blocks)"""
+        out = np.zeros((len(jobs), 35), np.int32)
+        pred = np.zeros(32 * 32, nb.dtype)
+        for i, j in enumerate(np.asarray(jobs, np.int64)):
+            so, no, nfo, lo, hi, edge, log2 = (int(v) for v in j[:7])
+            mask = (lo & 0xffffffff) | ((hi & 0xffffffff) << 32)
+            n = 1 << log2
+            for mode in range(35):
+                sel = nfo if (mask >> mode) & 1 else no
+                one = np.array([[0, sel, log2, mode, 1 if edge else 0, 0, 0, 0]], np.int32)
+                p = self.intra(bd, 32 * 32, 32, nb, one)
+                pred[:] = p
+                t = n if n < 8 else 8
+                c = 0
+                for y in range(0, n, t):
+                    for x in range(0, n, t):
+                        c += self.f.satd(src, so + y * ss + x, ss, pred, y * 32 + x, 32, t)
+                out[i, mode] = c
+        return out
 
     def residual(self, res_len, sres, res_off, src, ss, pred, sp, jobs):
         res = np.zeros(res_len, np.int16)

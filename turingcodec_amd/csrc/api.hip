@@ -14,6 +14,7 @@ hipError_t launch_pred_uni(hipStream_t, int S, int taps, int bd, void *, long, c
 hipError_t launch_pred_bi(hipStream_t, int S, int taps, int bd, void *, long, const void *, long, const void *, int);
 hipError_t launch_subtract_bi(hipStream_t, int S, int bd, void *, long, const void *, long, const void *, long, const void *, int);
 hipError_t launch_intra(hipStream_t, int S, int log2, int bd, void *, long, const void *, const void *, int);
+hipError_t launch_intra_satd35(hipStream_t, int S, int log2, int bd, const void *, long, const void *, const void *, int, int32_t *);
 hipError_t launch_transform(hipStream_t, int bd, int log2, int tr, int16_t *, const int16_t *, long, const void *, int);
 hipError_t launch_inverse_transform(hipStream_t, int mode, int bd, int log2, int tr, void *, long, const void *, long, int16_t *, const int16_t *,
                                     const void *, int);
@@ -32,6 +33,7 @@ static_assert(sizeof(havoc_mi355x_pred_bi_job) == 48, "job ABI");
 static_assert(sizeof(havoc_mi355x_subtract_bi_job) == 32, "job ABI");
 static_assert(sizeof(havoc_mi355x_intra_job) == 32, "job ABI");
 static_assert(sizeof(havoc_mi355x_tu_job) == 16, "job ABI");
+static_assert(sizeof(havoc_mi355x_intra_search_job) == 32, "job ABI");
 static_assert(sizeof(havoc_mi355x_quant_job) == 32, "job ABI");
 
 struct havoc_mi355x_ctx
@@ -253,6 +255,14 @@ int havoc_mi355x_intra(havoc_mi355x_ctx *ctx, int S, int bitDepth, int log2Trafo
     REQUIRE_CTX(); REQUIRE_S(); REQUIRE_BD(); REQUIRE(log2TrafoSize >= 2 && log2TrafoSize <= 5, "log2TrafoSize must be 2..5");
     REQUIRE(njobs >= 0, "njobs < 0");
     return check(launch_intra(ctx->stream, S, log2TrafoSize, bitDepth, d_dst, stride_dst, d_neighbours, d_jobs, njobs), "intra");
+}
+
+int havoc_mi355x_intra_satd35(havoc_mi355x_ctx *ctx, int S, int bitDepth, int log2TrafoSize, const void *d_src, intptr_t stride_src,
+                              const void *d_neighbours, const havoc_mi355x_intra_search_job *d_jobs, int njobs, int32_t *d_cost)
+{
+    REQUIRE_CTX(); REQUIRE_S(); REQUIRE_BD(); REQUIRE(log2TrafoSize >= 2 && log2TrafoSize <= 5, "log2TrafoSize must be 2..5");
+    REQUIRE(njobs >= 0, "njobs < 0");
+    return check(launch_intra_satd35(ctx->stream, S, log2TrafoSize, bitDepth, d_src, stride_src, d_neighbours, d_jobs, njobs, d_cost), "intra_satd35");
 }
 
 // ---- residual, transforms, quantisation -------------------------------------------------------------------

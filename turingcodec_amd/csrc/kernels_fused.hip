@@ -1,0 +1,276 @@
+// Fused search kernels: the batches the encoder's decision loops issue as (predict, measure) PAIRS, evaluated
+// without ever writing the prediction to HBM.
+//
+//   k_intra_satd35 : the 35-mode luma SATD stage of searchIntraPartition (turing/Search.hpp:113-142 calling
+//                    PredictIntraLumaBlock, turing/Reconstruct.cpp:630-701): for one partition, all 35 intra predictions
+//                    (havoc/pred_intra.cpp:20282-20401) each followed by the Hadamard SATD against the source block
+//                    (8x8 tiles, or one 4x4 for 4x4 blocks; havoc/hadamard.cpp:58-98).
+//
+// Mapping: one wavefront owns P partitions of one size; source block, both neighbour arrays (unfiltered / filtered)
+// and the 33 projected angular reference arrays live in LDS.  A work item is (partition, mode, SATD tile): one LANE
+// predicts its tile straight into registers, subtracts the source tile, runs the 2-D Hadamard in registers and adds
+// its tile cost into the partition's 35 LDS accumulators.  Horizontal modes are evaluated in the transposed domain
+// (prediction^T against source^T): SATD is invariant under transposition, and it makes the horizontal and vertical
+// modes one code path.  Items are ordered mode-major so that after the first step every wavefront step is
+// divergence-free angular work.
+#include "common.h"
+
+namespace havoc_gpu {
+
+__constant__ int8_t c_angle35[35] = {0,  0,   32,  26,  21,  17,  13, 9,  5,  2,  0, -2, -5, -9, -13, -17, -21, -26,
+                                     -32, -26, -21, -17, -13, -9, -5, -2, 0,  2,  5, 9,  13, 17,  21,  26,  32};
+__constant__ int16_t c_invAngle35[26] = {0,    0,    0,    0,    0,    0,    0,    0,    0,    0,    0,     -4096, -1638,
+                                         -910, -630, -482, -390, -315, -256, -315, -390, -482, -630, -910, -1638, -4096};
+
+template <int N>
+__device__ __forceinline__ void wht_inplace(int (&v)[N])
+{
+#pragma unroll
+    for (int len = 1; len < N; len <<= 1)
+#pragma unroll
+        for (int i = 0; i < N; i += len << 1)
+#pragma unroll
+            for (int k = i; k < i + len; ++k)
+            {
+                const int a = v[k], b = v[k + len];
+                v[k] = a + b;
+                v[k + len] = a - b;
+            }
+}
+
+// normalised SATD of a TS x TS difference tile held in registers (compute_satd_c_ref<TS>)
+template <int S, int TS>
+__device__ __forceinline__ int satd_regs(int (&d)[TS][TS])
+{
+#pragma unroll
+    for (int y = 0; y < TS; ++y) wht_inplace<TS>(d[y]);
+    int sum = TS / 4;
+#pragma unroll
+    for (int x = 0; x < TS; ++x)
+    {
+        int col[TS];
+#pragma unroll
+        for (int y = 0; y < TS; ++y) col[y] = d[y][x];
+        wht_inplace<TS>(col);
+#pragma unroll
+        for (int y = 0; y < TS; ++y) sum += abs(col[y]);
+    }
+    sum /= TS / 2;
+    return S == 2 ? sum >> 2 : sum;
+}
+
+// job: havoc_mi355x_intra_search_job = { src_off, nb_off, nbf_off, filt_lo, filt_hi, edge, reserved[2] }
+template <int S, int LOG2, int P>
+__global__ __launch_bounds__(64) void k_intra_satd35(const char *__restrict__ src, long stride_src, const char *__restrict__ neighbours,
+                                                     const int32_t *__restrict__ jobs, int njobs, int bitDepth, int32_t *__restrict__ cost)
+{
+    typedef typename Sample<S>::T T;
+    constexpr int N = 1 << LOG2;
+    constexpr int TS = N >= 8 ? 8 : 4;       // SATD tile (Reconstruct.cpp:684-701)
+    constexpr int TPR = N / TS, NT = TPR * TPR;
+    constexpr int NB = 4 * N + 1;
+    constexpr int RL = 3 * N + 2;            // projected reference: indices -N .. 2N (+1 slack)
+    constexpr int PT = P * NT;               // (partition, tile) pairs per workgroup
+
+    __shared__ uint16_t s_src[P][N * N];     // row-major source block
+    __shared__ uint16_t s_srcT[P][N * N];    // transposed source block
+    __shared__ uint16_t s_nb[P][2][NB + 1];  // [0] unfiltered, [1] filtered; index i <-> neighbours[i - 2N - 1]
+    __shared__ uint16_t s_ref[P][33][RL];    // angular modes 2..34; ref[i] at [i + N]
+    __shared__ int s_dc[P][2];
+    __shared__ int s_cost[P][36];
+    __shared__ int s_job[P][8];
+
+    const int lane = threadIdx.x;
+    const int job0 = blockIdx.x * P;
+    const int maxv = (1 << bitDepth) - 1;
+
+    for (int i = lane; i < P * 8; i += kWave)
+    {
+        const int p = i >> 3;
+        s_job[p][i & 7] = jobs[(long)min(job0 + p, njobs - 1) * 8 + (i & 7)];
+    }
+    for (int i = lane; i < P * 36; i += kWave) s_cost[i / 36][i % 36] = 0;
+    __syncthreads();
+
+    // ---- phase 0: source block (both orientations) and the two neighbour arrays into LDS
+    const long ssb = stride_src * S;
+    for (int i = lane; i < P * N * N / 4; i += kWave)
+    {
+        const int p = i / (N * N / 4), r = i - p * (N * N / 4);
+        const int y = r / (N / 4), x = (r - y * (N / 4)) * 4;
+        const char *q = src + (long)s_job[p][0] * S + y * ssb + x * S;
+        uint16_t v[4];
+        if (S == 1)
+        {
+            const uint32_t w = ld4(q);
+            v[0] = w & 0xff; v[1] = (w >> 8) & 0xff; v[2] = (w >> 16) & 0xff; v[3] = w >> 24;
+        }
+        else
+        {
+            const u32x2 w = ld8(q);
+            v[0] = w.x & 0xffff; v[1] = w.x >> 16; v[2] = w.y & 0xffff; v[3] = w.y >> 16;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+        {
+            s_src[p][y * N + x + k] = v[k];
+            s_srcT[p][(x + k) * N + y] = v[k];
+        }
+    }
+    for (int i = lane; i < P * 2 * NB; i += kWave)
+    {
+        const int p = i / (2 * NB), r = i - p * 2 * NB;
+        const int f = r / NB, k = r - f * NB;
+        s_nb[p][f][k] = reinterpret_cast<const T *>(neighbours)[s_job[p][1 + f] + k - 2 * N - 1];
+    }
+    __syncthreads();
+
+    // ---- phase 1: projected reference arrays for the 33 angular modes, DC values
+    for (int i = lane; i < P * 33 * (3 * N + 1); i += kWave)
+    {
+        const int p = i / (33 * (3 * N + 1)), r = i - p * 33 * (3 * N + 1);
+        const int mi = r / (3 * N + 1), idx = r - mi * (3 * N + 1) - N;   // idx in -N .. 2N
+        const int mode = mi + 2;
+        const int angle = c_angle35[mode];
+        const bool vertical = mode >= 18;
+        const uint32_t fbits = mode < 32 ? (uint32_t)s_job[p][3] >> mode : (uint32_t)s_job[p][4] >> (mode - 32);
+        const uint16_t *nb = s_nb[p][fbits & 1];
+        int v = 0;
+        if (idx >= 0)
+        {
+            if (idx <= N || angle >= 0) v = vertical ? nb[2 * N + idx] : nb[2 * N - idx];   // p(-1+idx,-1) / p(-1,-1+idx)
+        }
+        else if (angle < 0)
+        {
+            const int last = (N * angle) >> 5;
+            if (last < -1 && idx >= last)
+            {
+                const int k = -1 + ((idx * (int)c_invAngle35[mode] + 128) >> 8);
+                v = vertical ? nb[2 * N - 1 - k] : nb[2 * N + 1 + k];                      // p(-1,k) / p(k,-1)
+            }
+        }
+        s_ref[p][mi][idx + N] = (uint16_t)v;
+    }
+    if (lane < 2 * P)
+    {
+        const uint16_t *nb = s_nb[lane >> 1][lane & 1];
+        int s = N;
+        for (int k = 0; k < N; ++k) s += nb[2 * N + 1 + k] + nb[2 * N - 1 - k];
+        s_dc[lane >> 1][lane & 1] = s >> (LOG2 + 1);
+    }
+    __syncthreads();
+
+    // ---- phase 2: one (mode, partition, tile) item per lane per step; mode-major ordering
+    for (int it = lane; it < 35 * PT; it += kWave)
+    {
+        const int mode = it / PT, pt = it - mode * PT;
+        const int p = pt / NT, tile = pt - p * NT;
+        const int ty = tile / TPR, tx = tile - ty * TPR;
+        const uint32_t fbits = mode < 32 ? (uint32_t)s_job[p][3] >> mode : (uint32_t)s_job[p][4] >> (mode - 32);
+        const uint16_t *nb = s_nb[p][fbits & 1];
+        const bool edge = s_job[p][5] != 0 && LOG2 < 5;
+        int d[TS][TS];
+        if (mode >= 2)
+        {
+            const int angle = c_angle35[mode];
+            const bool vertical = mode >= 18;
+            const uint16_t *ref = &s_ref[p][mode - 2][N];
+            const uint16_t *sb = vertical ? s_src[p] : s_srcT[p];
+            const int maj0 = (vertical ? ty : tx) * TS, min0 = (vertical ? tx : ty) * TS;
+            const bool efilt = edge && min0 == 0 && (mode == 26 || mode == 10);
+#pragma unroll
+            for (int j = 0; j < TS; ++j)
+            {
+                const int t = (maj0 + j + 1) * angle;
+                const int idx = t >> 5, fact = t & 31;
+                const uint16_t *r = ref + min0 + idx + 1;
+                int rv[TS + 1];
+#pragma unroll
+                for (int i = 0; i <= TS; ++i) rv[i] = r[i];
+#pragma unroll
+                for (int i = 0; i < TS; ++i)
+                {
+                    int v = fact ? ((32 - fact) * rv[i] + fact * rv[i + 1] + 16) >> 5 : rv[i];
+                    if (i == 0 && efilt)
+                    {   // pred_intra.cpp:20355-20360 / :20394-20399: first column (row) of vertical (horizontal) prediction
+                        const int side = vertical ? nb[2 * N - 1 - (maj0 + j)] : nb[2 * N + 1 + (maj0 + j)];
+                        v = clip3(0, maxv, (int)ref[1] + ((side - (int)ref[0]) >> 1));
+                    }
+                    d[j][i] = (int)sb[(maj0 + j) * N + min0 + i] - v;
+                }
+            }
+        }
+        else if (mode == 1)
+        {
+            const int dc = s_dc[p][fbits & 1];
+#pragma unroll
+            for (int j = 0; j < TS; ++j)
+#pragma unroll
+                for (int i = 0; i < TS; ++i)
+                {
+                    const int x = tx * TS + i, y = ty * TS + j;
+                    int v = dc;
+                    if (edge)
+                    {
+                        if (x == 0 && y == 0) v = ((int)nb[2 * N - 1] + 2 * dc + (int)nb[2 * N + 1] + 2) >> 2;
+                        else if (y == 0) v = ((int)nb[2 * N + 1 + x] + 3 * dc + 2) >> 2;
+                        else if (x == 0) v = ((int)nb[2 * N - 1 - y] + 3 * dc + 2) >> 2;
+                    }
+                    d[j][i] = (int)s_src[p][y * N + x] - v;
+                }
+        }
+        else
+        {
+            const int topR = nb[2 * N + 1 + N], botL = nb[2 * N - 1 - N];   // p(N,-1), p(-1,N)
+#pragma unroll
+            for (int j = 0; j < TS; ++j)
+            {
+                const int y = ty * TS + j;
+                const int left = nb[2 * N - 1 - y];
+#pragma unroll
+                for (int i = 0; i < TS; ++i)
+                {
+                    const int x = tx * TS + i;
+                    const int v = ((N - 1 - x) * left + (x + 1) * topR + (N - 1 - y) * (int)nb[2 * N + 1 + x] + (y + 1) * botL + N) >> (LOG2 + 1);
+                    d[j][i] = (int)s_src[p][y * N + x] - v;
+                }
+            }
+        }
+        const int c = satd_regs<S, TS>(d);
+        if (NT == 1) s_cost[p][mode] = c;
+        else atomicAdd(&s_cost[p][mode], c);
+    }
+    __syncthreads();
+    for (int i = lane; i < P * 35; i += kWave)
+    {
+        const int p = i / 35, m = i - p * 35;
+        if (job0 + p < njobs) cost[(long)(job0 + p) * 35 + m] = s_cost[p][m];
+    }
+}
+
+template <int S>
+static hipError_t launch_intra_satd35_s(hipStream_t st, int log2, int bitDepth, const void *src, long ss, const void *nb, const void *jobs, int n,
+                                        int32_t *cost)
+{
+    const char *s = (const char *)src, *q = (const char *)nb;
+    const int32_t *j = (const int32_t *)jobs;
+    switch (log2)
+    {
+    case 2: hipLaunchKernelGGL((k_intra_satd35<S, 2, 9>), dim3((n + 8) / 9), dim3(64), 0, st, s, ss, q, j, n, bitDepth, cost); break;
+    case 3: hipLaunchKernelGGL((k_intra_satd35<S, 3, 9>), dim3((n + 8) / 9), dim3(64), 0, st, s, ss, q, j, n, bitDepth, cost); break;
+    case 4: hipLaunchKernelGGL((k_intra_satd35<S, 4, 5>), dim3((n + 4) / 5), dim3(64), 0, st, s, ss, q, j, n, bitDepth, cost); break;
+    case 5: hipLaunchKernelGGL((k_intra_satd35<S, 5, 1>), dim3(n), dim3(64), 0, st, s, ss, q, j, n, bitDepth, cost); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_intra_satd35(hipStream_t st, int S, int log2, int bitDepth, const void *src, long ss, const void *nb, const void *jobs, int n,
+                               int32_t *cost)
+{
+    if (n <= 0) return hipSuccess;
+    return S == 1 ? launch_intra_satd35_s<1>(st, log2, bitDepth, src, ss, nb, jobs, n, cost)
+                  : launch_intra_satd35_s<2>(st, log2, bitDepth, src, ss, nb, jobs, n, cost);
+}
+
+} // namespace havoc_gpu

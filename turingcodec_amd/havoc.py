@@ -56,6 +56,7 @@ def _load():
         "pred_bi": [_vp, _i, _i, _i, _vp, _ip, _vp, _ip, _vp, _i],
         "subtract_bi": [_vp, _i, _i, _vp, _ip, _vp, _ip, _vp, _ip, _vp, _i],
         "intra": [_vp, _i, _i, _i, _vp, _ip, _vp, _vp, _i],
+        "intra_satd35": [_vp, _i, _i, _i, _vp, _ip, _vp, _vp, _i, _vp],
         "residual": [_vp, _i, _vp, _ip, _vp, _vp, _ip, _vp, _ip, _vp, _i],
         "transform": [_vp, _i, _i, _i, _vp, _vp, _ip, _vp, _i],
         "inverse_transform": [_vp, _i, _i, _i, _vp, _vp, _vp, _i],
@@ -178,6 +179,9 @@ class Havoc:
     def intra_d(self, bd, log2, dst, sd, nb, jobs):
         self._ck(self.L.havoc_mi355x_intra(self.h, self._S(nb), bd, log2, _ptr(dst), sd, _ptr(nb), _ptr(jobs), jobs.shape[0]))
 
+    def intra_satd35_d(self, bd, log2, src, ss, nb, jobs, cost):
+        self._ck(self.L.havoc_mi355x_intra_satd35(self.h, self._S(src), bd, log2, _ptr(src), ss, _ptr(nb), _ptr(jobs), jobs.shape[0], _ptr(cost)))
+
     def residual_d(self, res, sres, res_off, src, ss, pred, sp, jobs):
         self._ck(self.L.havoc_mi355x_residual(self.h, self._S(src), _ptr(res), sres, _ptr(res_off), _ptr(src), ss, _ptr(pred), sp, _ptr(jobs), jobs.shape[0]))
 
@@ -256,6 +260,19 @@ class Havoc:
             if len(sel):
                 self.intra_d(bd, log2, dst, sd, nbd, self._jobs(sel, 8))
         return self.down(dst, nb.dtype)
+
+    def intra_satd35(self, bd, src, ss, nb, jobs):
+        """jobs: int32 [n, 8] = (src_off, nb_off, nbf_off, filt_lo, filt_hi, edge, log2, 0); returns int32 [n, 35]"""
+        jobs = np.asarray(jobs, np.int32)
+        out = np.zeros((len(jobs), 35), np.int32)
+        s, nbd = self.up(src), self.up(nb)
+        for log2 in (2, 3, 4, 5):
+            idx = np.flatnonzero(jobs[:, 6] == log2)
+            if len(idx):
+                cost = self.zeros(35 * len(idx), np.int32)
+                self.intra_satd35_d(bd, log2, s, ss, nbd, self._jobs(jobs[idx], 8), cost)
+                out[idx] = self.down(cost, np.int32).reshape(-1, 35)
+        return out
 
     def residual(self, res_len, sres, res_off, src, ss, pred, sp, jobs):
         res = self.zeros(res_len, np.int16)
