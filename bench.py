@@ -36,6 +36,7 @@ def parse_args():
     ap.add_argument("--bit-depth", type=int, default=8)
     ap.add_argument("--seed", type=int, default=11)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--kernel-reps", type=int, default=5)
@@ -74,9 +75,11 @@ class DeviceFrame:
         self.intra = {}
         for log2, j in wl.intra.items():
             if len(j):
-                js = wl.intra_satd[log2]
-                self.intra[log2] = dict(jobs=up(j), nb=up(wl.intra_nb[log2]), dst=z(len(j) << (2 * log2), dt),
-                                        jsatd=up(js) if len(js) else None, osatd=z(max(1, len(js)), np.int32))
+                self.intra[log2] = dict(jobs=up(j), nb=up(wl.intra_nb[log2]), dst=z(len(j) << (2 * log2), dt))
+        self.isearch = {}
+        for log2, j in wl.intra_search.items():
+            if len(j):
+                self.isearch[log2] = dict(jobs=up(j), nb=up(wl.intra_search_nb[log2]), cost=z(35 * len(j), np.int32))
         self.tu = {}
         bd = wl.bit_depth
         qp = 32
@@ -126,9 +129,9 @@ class DeviceFrame:
         L.append(("pred_bi4", lambda: hv.pred_bi_d(4, bd, self.bi, 32, self.chroma, cst, self.j_bi4)))
         for log2, g in sorted(self.intra.items()):
             n = 1 << log2
-            L.append((f"intra", lambda g=g, log2=log2, n=n: hv.intra_d(bd, log2, g["dst"], n, g["nb"], g["jobs"])))
-            if g["jsatd"] is not None:
-                L.append((f"satd_intra", lambda g=g, n=n: hv.satd_d(self.luma, st, g["dst"], n, g["jsatd"], g["osatd"])))
+            L.append(("intra", lambda g=g, log2=log2, n=n: hv.intra_d(bd, log2, g["dst"], n, g["nb"], g["jobs"])))
+        for log2, g in sorted(self.isearch.items()):
+            L.append(("intra_satd35", lambda g=g, log2=log2: hv.intra_satd35_d(bd, log2, self.luma, st, g["nb"], g["jobs"], g["cost"])))
         for (log2, tr), g in sorted(self.tu.items()):
             n = g["n"]
             L.append(("residual", lambda g=g, n=n: hv.residual_d(g["res"], n, g["res_off"], self.luma, st, self.luma, st, g["src"])))
@@ -164,7 +167,9 @@ class DeviceFrame:
         acc = 0
         bufs = [self.o_sad4, self.o_sad, self.o_satd, self.o_ssd, self.pred, self.cpred, self.bi, self.sbi, self.luma]
         for g in self.intra.values():
-            bufs += [g["dst"], g["osatd"]]
+            bufs += [g["dst"]]
+        for g in self.isearch.values():
+            bufs += [g["cost"]]
         for g in self.tu.values():
             bufs += [g["res"], g["coef"], g["deq"]]
         for b in bufs:
@@ -208,6 +213,7 @@ def cpu_worker(args):
     wl = FrameWorkload(w, h, args.bit_depth, args.seed)
     lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libhavoc_ref.so"))
     cores = usable_cores()
+    lib.ref_mask(handle)   # populate the function tables (JIT assembly) once, before any worker thread touches them
     S, bd, st, cst = wl.S, wl.bit_depth, wl.stride, wl.cstride
     dt = wl.dtype
     P = lambda a: C.c_void_p(a.ctypes.data)
@@ -249,11 +255,15 @@ def cpu_worker(args):
         n = 1 << log2
         ji, nb = sub(j), _aligned(wl.intra_nb[log2])
         dst = _aligned(np.zeros((len(j) << (2 * log2)) + 64, dt))
-        jsat = sub(wl.intra_satd[log2])
-        osat = np.zeros(max(1, len(jsat)), np.int32)
-        keep += [ji, nb, dst, jsat, osat]
+        keep += [ji, nb, dst]
         add(lambda b, e, log2=log2, n=n, ji=ji, nb=nb, dst=dst: lib.ref_run_intra(handle, S, bd, log2, P(dst), ip(n), P(nb), P(ji), b, e), len(ji))
-        add(lambda b, e, n=n, jsat=jsat, dst=dst, osat=osat: lib.ref_run_satd(handle, S, P(luma), ip(st), P(dst), ip(n), P(jsat), b, e, P(osat)), len(jsat))
+    for log2, j in wl.intra_search.items():
+        if not len(j):
+            continue
+        jp, nb = sub(j), _aligned(wl.intra_search_nb[log2])
+        cost = np.zeros(35 * len(jp), np.int32)
+        keep += [jp, nb, cost]
+        add(lambda b, e, log2=log2, jp=jp, nb=nb, cost=cost: lib.ref_run_intra_satd35(handle, S, bd, log2, P(luma), ip(st), P(nb), P(jp), b, e, P(cost)), len(jp))
     qp = 32
     for (log2, tr), g in wl.tu.items():
         m = len(g["jobs"])
@@ -340,7 +350,7 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    hv = Havoc(local)
+    hv = Havoc(local, stream="new")   # private stream: the step is captured into a HIP graph and replayed
     w, h = (int(v) for v in args.res.split("x"))
     wl = FrameWorkload(w, h, args.bit_depth, args.seed + rank)   # every rank owns a different picture
     dev = DeviceFrame(hv, wl)
@@ -349,9 +359,17 @@ def main():
         from turingcodec_amd.frame_parallel import ReferenceExchange
         exch = ReferenceExchange(dist, rank, world, dev.luma[3 * wl.plane_len:4 * wl.plane_len], dev.chroma[:wl.cplane_len])
 
+    dev.step()          # first eager pass (loads the code objects) -- also what the graph must reproduce
+    hv.sync()
+    graph = None if args.no_graph else hv.graph_capture(dev.step)
+
     def one_step(i):
-        dev.step()
+        if graph is not None:
+            hv.graph_launch(graph)
+        else:
+            dev.step()
         if exch is not None:
+            hv.sync()   # reconstruction complete before its owner broadcasts it (torch.distributed runs on torch's stream)
             exch.exchange(i)
 
     for i in range(args.warmup):

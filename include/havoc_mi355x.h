@@ -57,6 +57,16 @@ int havoc_mi355x_d2h(havoc_mi355x_ctx *ctx, void *h_dst, const void *d_src, size
 int havoc_mi355x_timer_start(havoc_mi355x_ctx *ctx);
 int havoc_mi355x_timer_stop_ms(havoc_mi355x_ctx *ctx, float *ms); /* records, synchronises, returns elapsed */
 
+/* HIP-graph capture of a fixed sequence of batch launches (one picture's launches are the same sequence with the same
+ * buffers for every CTU row / picture of a size): begin, issue the launches (they are recorded, not run), end, then
+ * replay with graph_launch.  Needs a context that owns its stream (HAVOC_MI355X_NEW_STREAM) or an explicit
+ * non-default stream: the legacy default stream cannot be captured. */
+typedef struct havoc_mi355x_graph havoc_mi355x_graph;
+int havoc_mi355x_graph_begin(havoc_mi355x_ctx *ctx);
+int havoc_mi355x_graph_end(havoc_mi355x_ctx *ctx, havoc_mi355x_graph **graph);
+int havoc_mi355x_graph_launch(havoc_mi355x_ctx *ctx, havoc_mi355x_graph *graph);
+void havoc_mi355x_graph_destroy(havoc_mi355x_graph *graph);
+
 /* ------------------------------------------------------------------------------------------------------- */
 /* job descriptors (plain 32-bit little-endian fields, no padding surprises: sizes asserted in the .cpp)    */
 /* ------------------------------------------------------------------------------------------------------- */
@@ -168,6 +178,16 @@ int havoc_mi355x_pred_bi(havoc_mi355x_ctx *ctx, int S, int taps, int bitDepth, v
 int havoc_mi355x_subtract_bi(havoc_mi355x_ctx *ctx, int S, int bitDepth, void *d_dst, intptr_t stride_dst,
                              const void *d_pred, intptr_t stride_pred, const void *d_src, intptr_t stride_src,
                              const havoc_mi355x_subtract_bi_job *d_jobs, int njobs);
+
+/* One sub-pel motion candidate, fused: HavocPredUni of the PU at (ref_off, xFrac, yFrac) followed by measureSatd
+ * against the source PU -- costDistortionMv (turing/Search.hpp:1965-1998 -> havoc/pred_inter.cpp:113-202 +
+ * turing/Measure.h:97-135).  Jobs are havoc_mi355x_pred_uni_job with `dst_off` naming the SOURCE block in d_src;
+ * d_cost[i] = the PU SATD (8x8 / 4x4 / 2x2 tiles by PU shape); the prediction is not written.  max_w / max_h are
+ * upper bounds on the PU sizes in this batch (the reference's table is indexed by width class,
+ * havoc/pred_inter.h:47-50); 64, 64 is always valid, tighter bounds pick a kernel with less LDS per PU. */
+int havoc_mi355x_subpel_satd(havoc_mi355x_ctx *ctx, int S, int taps, int bitDepth, int max_w, int max_h, const void *d_src,
+                             intptr_t stride_src, const void *d_ref, intptr_t stride_ref, const havoc_mi355x_pred_uni_job *d_jobs,
+                             int njobs, int32_t *d_cost);
 
 /* ------------------------------------------------------------------------------------------------------- */
 /* intra prediction                                                                                          */

@@ -390,6 +390,33 @@ void runInvAdd(int h, int bd, int tr, int log2, Sample *dst, intptr_t sd, const 
 
 } // namespace
 
+namespace {
+// the 35-mode SATD stage of one partition the way the reference runs it: 35 x (table intra prediction into a
+// 32-stride stack block, then 8x8 / 4x4 Hadamard tiles against the source) -- turing/Reconstruct.cpp:630-701
+template <typename Sample>
+void runIntraSatd35(int h, int bd, int log2, const Sample *src, intptr_t ss, const Sample *nb, const int32_t *jobs, int b, int e, int32_t *cost)
+{
+    auto &t = st<Sample>(tab(h));
+    const int n = 1 << log2;
+    HAVOC_ALIGN(32, Sample, pred[32 * 32]);
+    auto satd = *havoc_get_hadamard_satd<Sample>(&t.satd, log2 == 2 ? 2 : 3);
+    const int ts = log2 == 2 ? 4 : 8;
+    for (int i = b; i < e; ++i)
+    {
+        const int32_t *j = jobs + 8 * i;
+        const uint64_t mask = (uint64_t)(uint32_t)j[3] | ((uint64_t)(uint32_t)j[4] << 32);
+        for (int mode = 0; mode < 35; ++mode)
+        {
+            t.intra.lookup(j[5] ? 0 : 1, bd, log2, mode)(pred, 32, nb + (((mask >> mode) & 1) ? j[2] : j[1]), mode);
+            int c = 0;
+            for (int y = 0; y < n; y += ts)
+                for (int x = 0; x < n; x += ts) c += satd(src + j[0] + y * ss + x, ss, pred + y * 32 + x, 32);
+            cost[35 * i + mode] = c;
+        }
+    }
+}
+} // namespace
+
 #define SAMPLE_DISPATCH(S, call8, call16) do { if ((S) == 1) { call8; } else { call16; } } while (0)
 typedef const uint8_t *cu8;
 typedef const uint16_t *cu16;
@@ -432,6 +459,11 @@ void ref_run_intra(int h, int S, int bd, int log2, void *dst, intptr_t sd, const
 {
     SAMPLE_DISPATCH(S, runIntra<uint8_t>(h, bd, log2, (uint8_t *)dst, sd, (cu8)nb, jobs, b, e),
                     runIntra<uint16_t>(h, bd, log2, (uint16_t *)dst, sd, (cu16)nb, jobs, b, e));
+}
+void ref_run_intra_satd35(int h, int S, int bd, int log2, const void *src, intptr_t ss, const void *nb, const int32_t *jobs, int b, int e, int32_t *cost)
+{
+    SAMPLE_DISPATCH(S, runIntraSatd35<uint8_t>(h, bd, log2, (cu8)src, ss, (cu8)nb, jobs, b, e, cost),
+                    runIntraSatd35<uint16_t>(h, bd, log2, (cu16)src, ss, (cu16)nb, jobs, b, e, cost));
 }
 void ref_run_residual(int S, int16_t *res, intptr_t sres, const int32_t *resOff, const void *src, intptr_t ss, const void *pred, intptr_t sp,
                       const int32_t *jobs, int b, int e)

@@ -152,6 +152,13 @@ def make_inputs(seed=20260927):
                 jobs.append((cases.off(x, y), base + c, base + len(nbu) + c, mask & 0xffffffff, mask >> 32, rep != 1, log2, 0))
         d[f"{k}.intra35.nb"] = np.concatenate(nbs)
         d[f"{k}.intra35.jobs"] = np.array(jobs, np.int64).astype(np.uint32).view(np.int32).reshape(len(jobs), 8)
+    # fused sub-pel candidates: the pred_uni job tables with dst_off replaced by a source-block offset in plane b
+    for S in (1, 2):
+        k = "u8" if S == 1 else "u16"
+        for taps in (8, 4):
+            j = d[f"{k}.pred_uni{taps}.jobs"].copy()
+            j[:, 0] = [cases.off(*cases.rand_pos(rng, int(w), int(h))) for (w, h) in j[:, 2:4]]
+            d[f"{k}.subpel{taps}.jobs"] = j
     return d
 
 
@@ -224,6 +231,10 @@ def run(impl, d, keys=None):
         k = "u8" if S == 1 else "u16"
         if want(f"{k}.intra35"):
             out[f"{k}.intra35"] = impl.intra_satd35(bd, d[f"{k}.a"], W, d[f"{k}.intra35.nb"], d[f"{k}.intra35.jobs"])
+        for taps in (8, 4):
+            if want(f"{k}.subpel"):
+                out[f"{k}.subpel{taps}"] = impl.subpel_satd(taps, bd, d[f"{k}.b"], W, d[f"{k}.a"], W, d[f"{k}.subpel{taps}.jobs"])
+                out[f"{k}.subpel{taps}.x"] = impl.subpel_satd(taps, bd, d[f"{k}.b"], W, d[f"{k}.x"], W, d[f"{k}.subpel{taps}.jobs"])
     return out
 
 
@@ -299,6 +310,16 @@ class LoopImpl:
             else:
                 self.f.intra(dst, do, sd, nb, no, log2, mode, edge, bd)
         return dst
+
+    def subpel_satd(self, taps, bd, src, ss, ref, sr, jobs):
+        """costDistortionMv (turing/Search.hpp:1965-1998): pred_uni into a 64-stride scratch block, then measureSatd"""
+        out = np.zeros(len(jobs), np.int32)
+        for i, j in enumerate(np.asarray(jobs, np.int32)):
+            so, ro, w, h, xf, yf = (int(v) for v in j[:6])
+            one = np.array([[0, ro, w, h, xf, yf, 0, 0]], np.int32)
+            pred = self.pred_uni(taps, bd, SLOT, 64, ref, sr, one)
+            out[i] = self.satd(src, ss, pred, 64, np.array([[so, 0, w, h]], np.int32))[0]
+        return out
 
     def intra_satd35(self, bd, src, ss, nb, jobs):
         """composition of the two per-call primitives, as PredictIntraLumaBlock does (turing/Reconstruct.cpp:630-701):

@@ -15,6 +15,8 @@ hipError_t launch_pred_bi(hipStream_t, int S, int taps, int bd, void *, long, co
 hipError_t launch_subtract_bi(hipStream_t, int S, int bd, void *, long, const void *, long, const void *, long, const void *, int);
 hipError_t launch_intra(hipStream_t, int S, int log2, int bd, void *, long, const void *, const void *, int);
 hipError_t launch_intra_satd35(hipStream_t, int S, int log2, int bd, const void *, long, const void *, const void *, int, int32_t *);
+hipError_t launch_subpel_satd(hipStream_t, int S, int taps, int bd, int maxw, int maxh, const void *, long, const void *, long, const void *, int,
+                              int32_t *);
 hipError_t launch_transform(hipStream_t, int bd, int log2, int tr, int16_t *, const int16_t *, long, const void *, int);
 hipError_t launch_inverse_transform(hipStream_t, int mode, int bd, int log2, int tr, void *, long, const void *, long, int16_t *, const int16_t *,
                                     const void *, int);
@@ -188,6 +190,54 @@ int havoc_mi355x_timer_stop_ms(havoc_mi355x_ctx *ctx, float *ms)
     return check(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1), "hipEventElapsedTime");
 }
 
+// ---- HIP graphs ----------------------------------------------------------------------------------------------
+
+struct havoc_mi355x_graph
+{
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+};
+
+int havoc_mi355x_graph_begin(havoc_mi355x_ctx *ctx)
+{
+    REQUIRE_CTX();
+    REQUIRE(ctx->stream != nullptr, "graph capture needs a non-default stream (create the context with HAVOC_MI355X_NEW_STREAM)");
+    return check(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
+}
+
+int havoc_mi355x_graph_end(havoc_mi355x_ctx *ctx, havoc_mi355x_graph **graph)
+{
+    REQUIRE_CTX();
+    REQUIRE(graph != nullptr, "null graph pointer");
+    *graph = nullptr;
+    hipGraph_t g = nullptr;
+    int rc = check(hipStreamEndCapture(ctx->stream, &g), "hipStreamEndCapture");
+    if (rc) return rc;
+    hipGraphExec_t e = nullptr;
+    if ((rc = check(hipGraphInstantiate(&e, g, nullptr, nullptr, 0), "hipGraphInstantiate")))
+    {
+        (void)hipGraphDestroy(g);
+        return rc;
+    }
+    *graph = new havoc_mi355x_graph{g, e};
+    return 0;
+}
+
+int havoc_mi355x_graph_launch(havoc_mi355x_ctx *ctx, havoc_mi355x_graph *graph)
+{
+    REQUIRE_CTX();
+    REQUIRE(graph != nullptr, "null graph");
+    return check(hipGraphLaunch(graph->exec, ctx->stream), "hipGraphLaunch");
+}
+
+void havoc_mi355x_graph_destroy(havoc_mi355x_graph *graph)
+{
+    if (!graph) return;
+    (void)hipGraphExecDestroy(graph->exec);
+    (void)hipGraphDestroy(graph->graph);
+    delete graph;
+}
+
 // ---- distortion metrics -----------------------------------------------------------------------------------
 
 int havoc_mi355x_sad(havoc_mi355x_ctx *ctx, int S, const void *d_src, intptr_t stride_src, const void *d_ref, intptr_t stride_ref,
@@ -245,6 +295,15 @@ int havoc_mi355x_subtract_bi(havoc_mi355x_ctx *ctx, int S, int bitDepth, void *d
 {
     REQUIRE_CTX(); REQUIRE_S(); REQUIRE_BD(); REQUIRE(njobs >= 0, "njobs < 0");
     return check(launch_subtract_bi(ctx->stream, S, bitDepth, d_dst, stride_dst, d_pred, stride_pred, d_src, stride_src, d_jobs, njobs), "subtract_bi");
+}
+
+int havoc_mi355x_subpel_satd(havoc_mi355x_ctx *ctx, int S, int taps, int bitDepth, int max_w, int max_h, const void *d_src, intptr_t stride_src,
+                             const void *d_ref, intptr_t stride_ref, const havoc_mi355x_pred_uni_job *d_jobs, int njobs, int32_t *d_cost)
+{
+    REQUIRE_CTX(); REQUIRE_S(); REQUIRE_BD(); REQUIRE(taps == 8 || taps == 4, "taps must be 8 or 4"); REQUIRE(njobs >= 0, "njobs < 0");
+    REQUIRE(max_w >= 2 && max_w <= 64 && max_h >= 2 && max_h <= 64, "max_w / max_h must be 2..64");
+    return check(launch_subpel_satd(ctx->stream, S, taps, bitDepth, max_w, max_h, d_src, stride_src, d_ref, stride_ref, d_jobs, njobs, d_cost),
+                 "subpel_satd");
 }
 
 // ---- intra prediction -------------------------------------------------------------------------------------

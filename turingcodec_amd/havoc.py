@@ -47,6 +47,10 @@ def _load():
         "d2h": [_vp, _vp, _vp, C.c_size_t],
         "timer_start": [_vp],
         "timer_stop_ms": [_vp, C.POINTER(C.c_float)],
+        "graph_begin": [_vp],
+        "graph_end": [_vp, C.POINTER(_vp)],
+        "graph_launch": [_vp, _vp],
+        "graph_destroy": [_vp],
         "sad": [_vp, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
         "sad4": [_vp, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
         "ssd": [_vp, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
@@ -57,6 +61,7 @@ def _load():
         "subtract_bi": [_vp, _i, _i, _vp, _ip, _vp, _ip, _vp, _ip, _vp, _i],
         "intra": [_vp, _i, _i, _i, _vp, _ip, _vp, _vp, _i],
         "intra_satd35": [_vp, _i, _i, _i, _vp, _ip, _vp, _vp, _i, _vp],
+        "subpel_satd": [_vp, _i, _i, _i, _i, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
         "residual": [_vp, _i, _vp, _ip, _vp, _vp, _ip, _vp, _ip, _vp, _i],
         "transform": [_vp, _i, _i, _i, _vp, _vp, _ip, _vp, _i],
         "inverse_transform": [_vp, _i, _i, _i, _vp, _vp, _vp, _i],
@@ -68,7 +73,7 @@ def _load():
     for name, args in sig.items():
         f = getattr(L, "havoc_mi355x_" + name)
         f.argtypes = args
-        f.restype = None if name == "destroy" else _i
+        f.restype = None if name in ("destroy", "graph_destroy") else _i
     return L, sorted(sig)
 
 
@@ -93,9 +98,14 @@ class Havoc:
             raise HavocError("no GPU visible: libhavoc_mi355x has no CPU path")
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
-        s = stream if stream is not None else torch.cuda.current_stream(self.device).cuda_stream
+        # stream: None -> torch's current stream; "new" -> the context creates and owns a private stream (needed for
+        # graph capture; the caller then orders torch work against it with sync()); an int -> that hipStream_t
+        if stream == "new":
+            s = _vp(-1)   # HAVOC_MI355X_NEW_STREAM
+        else:
+            s = _vp(stream if stream is not None else torch.cuda.current_stream(self.device).cuda_stream)
         h = _vp()
-        self._ck(self.L.havoc_mi355x_create(C.byref(h), device, _vp(s)))
+        self._ck(self.L.havoc_mi355x_create(C.byref(h), device, s))
         self.h = h
 
     def close(self):
@@ -122,6 +132,23 @@ class Havoc:
         self._ck(self.L.havoc_mi355x_device_info(self.h, a))
         keys = ["cus", "clock_khz", "mem_clock_khz", "bus_bits", "l2_bytes", "wave", "lds_per_wg", "mem_mib"]
         return dict(zip(keys, [int(x) for x in a]))
+
+    def graph_capture(self, fn):
+        """record the launches `fn()` issues into a HIP graph; returns a handle for graph_launch"""
+        self._ck(self.L.havoc_mi355x_graph_begin(self.h))
+        try:
+            fn()
+        finally:
+            g = _vp()
+            rc = self.L.havoc_mi355x_graph_end(self.h, C.byref(g))
+        self._ck(rc)
+        return g
+
+    def graph_launch(self, g):
+        self._ck(self.L.havoc_mi355x_graph_launch(self.h, g))
+
+    def graph_destroy(self, g):
+        self.L.havoc_mi355x_graph_destroy(g)
 
     def timer_start(self):
         self._ck(self.L.havoc_mi355x_timer_start(self.h))
@@ -178,6 +205,24 @@ class Havoc:
 
     def intra_d(self, bd, log2, dst, sd, nb, jobs):
         self._ck(self.L.havoc_mi355x_intra(self.h, self._S(nb), bd, log2, _ptr(dst), sd, _ptr(nb), _ptr(jobs), jobs.shape[0]))
+
+    def subpel_satd_d(self, taps, bd, max_w, max_h, src, ss, ref, sr, jobs, cost):
+        self._ck(self.L.havoc_mi355x_subpel_satd(self.h, self._S(ref), taps, bd, max_w, max_h, _ptr(src), ss, _ptr(ref), sr, _ptr(jobs),
+                                                 jobs.shape[0], _ptr(cost)))
+
+    def subpel_satd(self, taps, bd, src, ss, ref, sr, jobs):
+        """jobs: int32 [n, 8] = (src_off, ref_off, w, h, xFrac, yFrac, 0, 0); one launch per size class"""
+        jobs = np.asarray(jobs, np.int32)
+        out = np.zeros(len(jobs), np.int32)
+        s, r = self.up(src), self.up(ref)
+        big = np.maximum(jobs[:, 2], jobs[:, 3])
+        for lo, hi in ((0, 16), (16, 32), (32, 64)):
+            idx = np.flatnonzero((big > lo) & (big <= hi))
+            if len(idx):
+                cost = self.zeros(len(idx), np.int32)
+                self.subpel_satd_d(taps, bd, hi, hi, s, ss, r, sr, self._jobs(jobs[idx], 8), cost)
+                out[idx] = self.down(cost, np.int32)
+        return out
 
     def intra_satd35_d(self, bd, log2, src, ss, nb, jobs, cost):
         self._ck(self.L.havoc_mi355x_intra_satd35(self.h, self._S(src), bd, log2, _ptr(src), ss, _ptr(nb), _ptr(jobs), jobs.shape[0], _ptr(cost)))

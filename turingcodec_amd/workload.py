@@ -201,25 +201,44 @@ class FrameWorkload:
         self.subtract_bi = s
 
         # ---- intra prediction (+ SATD for the 35-mode stage): per size class
+        # (a) RD stage (ReconstructIntraBlock): single predictions written out, n["intra_rd"] calls
+        # (b) 35-mode SATD stage (searchIntraPartition, Search.hpp:113-142): n["intra_satd"] / 35 partitions, each one
+        #     fused job = 35 (prediction, SATD) pairs sharing the partition's neighbours and source block
         self.intra = {}
         self.intra_nb = {}
-        self.intra_satd = {}
+        self.intra_search = {}
+        self.intra_search_nb = {}
         src = luma[0]
-        ni = n["intra_satd"] + n["intra_rd"]
-        sizes = np.array([m[0] for m in INTRA_MIX])[_pick(rng, INTRA_MIX, ni)]
-        is_satd = np.arange(ni) < n["intra_satd"]
-        for log2 in (2, 3, 4, 5):
-            sel = np.flatnonzero(sizes == log2)
-            m, nn = len(sel), 1 << log2
-            x = (rng.integers(0, (W - nn) // nn + 1, m) * nn).astype(np.int32)
-            y = (rng.integers(0, (H - nn) // nn + 1, m) * nn).astype(np.int32)
-            # neighbours taken from the (padded) source picture around the block: [left col bottom->top, corner, top row]
-            L = 4 * nn + 1
-            k = np.arange(L)
+
+        def neighbours_of(x, y, nn):
+            # taken from the (padded) source picture around the block: [left col bottom->top, corner, top row]
+            k = np.arange(4 * nn + 1)
             dy = np.where(k < 2 * nn, 2 * nn - 1 - k, -1)
             dx = np.where(k <= 2 * nn, -1, k - 2 * nn - 1)
-            nb = src[(y[:, None] + PAD + dy[None, :]), (x[:, None] + PAD + dx[None, :])]
-            self.intra_nb[log2] = np.ascontiguousarray(nb.ravel())
+            return src[(y[:, None] + PAD + dy[None, :]), (x[:, None] + PAD + dx[None, :])]
+
+        def filter_mask(nn):
+            # HEVC 8.4.4.2.3 filterFlag (the caller's decision, turing/Reconstruct.cpp:659): filtered neighbours when
+            # min(|mode-26|, |mode-10|) > thres[nTbS]; planar always for nTbS >= 8; never DC, never 4x4
+            if nn == 4:
+                return 0
+            thres = {8: 7, 16: 1, 32: 0}[nn]
+            mask = 1   # planar
+            for mode in range(2, 35):
+                if min(abs(mode - 26), abs(mode - 10)) > thres:
+                    mask |= 1 << mode
+            return mask
+
+        nrd, npart = n["intra_rd"], max(1, n["intra_satd"] // 35)
+        rd_sizes = np.array([m[0] for m in INTRA_MIX])[_pick(rng, INTRA_MIX, nrd)]
+        sr_sizes = np.array([m[0] for m in INTRA_MIX])[_pick(rng, INTRA_MIX, npart)]
+        for log2 in (2, 3, 4, 5):
+            nn = 1 << log2
+            L = 4 * nn + 1
+            m = int((rd_sizes == log2).sum())
+            x = (rng.integers(0, (W - nn) // nn + 1, m) * nn).astype(np.int32)
+            y = (rng.integers(0, (H - nn) // nn + 1, m) * nn).astype(np.int32)
+            self.intra_nb[log2] = np.ascontiguousarray(neighbours_of(x, y, nn).ravel())
             j = np.zeros((m, 8), np.int32)
             j[:, 0] = np.arange(m) * nn * nn
             j[:, 1] = np.arange(m) * L + 2 * nn + 1
@@ -227,8 +246,21 @@ class FrameWorkload:
             j[:, 3] = rng.integers(0, 35, m)
             j[:, 4] = 1
             self.intra[log2] = j
-            ss = is_satd[sel]
-            self.intra_satd[log2] = np.stack([loff(x, y, 0)[ss], j[ss, 0], np.full(ss.sum(), nn), np.full(ss.sum(), nn)], 1).astype(np.int32)
+            m = int((sr_sizes == log2).sum())
+            x = (rng.integers(0, (W - nn) // nn + 1, m) * nn).astype(np.int32)
+            y = (rng.integers(0, (H - nn) // nn + 1, m) * nn).astype(np.int32)
+            nbu = neighbours_of(x, y, nn).astype(np.int32)
+            nbf = nbu.copy()                                     # [1 2 1] smoothing (IntraReferenceSamples.h:373-421)
+            nbf[:, 1:-1] = (nbu[:, :-2] + 2 * nbu[:, 1:-1] + nbu[:, 2:] + 2) >> 2
+            both = np.concatenate([nbu, nbf], 1).astype(self.dtype)   # per job: unfiltered then filtered
+            self.intra_search_nb[log2] = np.ascontiguousarray(both.ravel())
+            mask = filter_mask(nn)
+            j = np.zeros((m, 8), np.int64)
+            j[:, 0] = loff(x, y, 0)
+            j[:, 1] = np.arange(m) * 2 * L + 2 * nn + 1
+            j[:, 2] = j[:, 1] + L
+            j[:, 3], j[:, 4], j[:, 5] = mask & 0xffffffff, mask >> 32, 1
+            self.intra_search[log2] = j.astype(np.uint32).view(np.int32).reshape(m, 8)
 
         # ---- TU chain: residual (src - pred) -> forward T -> [RDOQ on host] -> de-quant -> inverse T + add -> SSD
         self.tu = {}
@@ -273,7 +305,8 @@ class FrameWorkload:
         b["subtract_bi"] = int((3 * wh(self.subtract_bi, 3, 4) * S).sum())
         b["satd_inter"] = int((2 * wh(self.satd_inter, 2, 3) * S + 4).sum())
         b["intra"] = sum(len(j) * ((4 * (1 << l) + 1) * S + (1 << (2 * l)) * S) for l, j in self.intra.items())
-        b["satd_intra"] = sum(int((2 * wh(j, 2, 3) * S + 4).sum()) for j in self.intra_satd.values())
+        # fused stage: source block + the two neighbour arrays read once, 35 costs written
+        b["intra_satd35"] = sum(len(j) * ((1 << (2 * l)) * S + 2 * (4 * (1 << l) + 1) * S + 35 * 4) for l, j in self.intra_search.items())
         ntu = {k: len(g["jobs"]) * g["n"] ** 2 for k, g in self.tu.items()}
         tot = sum(ntu.values())
         b["residual"] = tot * (2 * S + 2)
