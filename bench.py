@@ -72,6 +72,7 @@ class DeviceFrame:
         self.j_sbi = up(wl.subtract_bi)
         self.j_satd = up(wl.satd_inter)
         self.o_satd = z(len(wl.satd_inter), np.int32)
+        self.subpel = {hi: dict(jobs=up(j), cost=z(len(j), np.int32)) for hi, j in wl.subpel.items() if len(j)}
         self.intra = {}
         for log2, j in wl.intra.items():
             if len(j):
@@ -102,9 +103,8 @@ class DeviceFrame:
             self.tu[(log2, tr)] = dict(jobs=up(g["jobs"]), src=up(g["src"]), res_off=up(g["res_off"]), n=nn,
                                        res=z(m * nn * nn, np.int16), coef=z(m * nn * nn, np.int16),
                                        level=z(m * nn * nn, np.int16), deq=z(m * nn * nn, np.int16),
-                                       qjobs=up(qj), djobs=up(dj), cbf=z(m, np.int32))
-        self.j_ssd = up(wl.ssd)
-        self.o_ssd = z(len(wl.ssd), np.uint32)
+                                       qjobs=up(qj), djobs=up(dj), cbf=z(m, np.int32), rec=z(m * nn * nn, dt),
+                                       jssd=up(g["ssd"]), ossd=z(len(g["ssd"]), np.uint32))
         self.launches = self._make_launches()
         # levels for the timed de-quantiser: run residual -> forward T -> havoc_quantize once, untimed (at medium the
         # reference quantises with RDOQ on the host; the hot path sees its output levels)
@@ -121,6 +121,8 @@ class DeviceFrame:
         L = []
         L.append(("sad4", lambda: hv.sad4_d(self.luma, st, self.luma, st, self.j_sad4, self.o_sad4)))
         L.append(("sad", lambda: hv.sad_d(self.luma, st, self.luma, st, self.j_sad, self.o_sad)))
+        for hi, g in sorted(self.subpel.items()):
+            L.append(("subpel_satd", lambda g=g, hi=hi: hv.subpel_satd_d(8, bd, hi, hi, self.luma, st, self.luma, st, g["jobs"], g["cost"])))
         L.append(("pred_uni8", lambda: hv.pred_uni_d(8, bd, self.pred, 64, self.luma, st, self.j_uni8)))
         L.append(("satd_inter", lambda: hv.satd_d(self.luma, st, self.pred, 64, self.j_satd, self.o_satd)))
         L.append(("pred_uni4", lambda: hv.pred_uni_d(4, bd, self.cpred, 32, self.chroma, cst, self.j_uni4)))
@@ -137,9 +139,9 @@ class DeviceFrame:
             L.append(("residual", lambda g=g, n=n: hv.residual_d(g["res"], n, g["res_off"], self.luma, st, self.luma, st, g["src"])))
             L.append(("transform", lambda g=g, n=n, log2=log2, tr=tr: hv.transform_d(bd, tr, log2, g["coef"], g["res"], n, g["jobs"])))
             L.append(("quantize_inverse", lambda g=g: hv.quantize_inverse_d(g["deq"], g["level"], g["djobs"])))
-            L.append(("inverse_transform_add", lambda g=g, log2=log2, tr=tr: hv.inverse_transform_add_d(
-                bd, tr, log2, self.luma, st, self.luma, st, g["deq"], g["jobs"])))
-        L.append(("ssd", lambda: hv.ssd_d(self.luma, st, self.luma, st, self.j_ssd, self.o_ssd)))
+            L.append(("inverse_transform_add", lambda g=g, log2=log2, tr=tr, n=n: hv.inverse_transform_add_d(
+                bd, tr, log2, g["rec"], n, self.luma, st, g["deq"], g["jobs"])))
+            L.append(("ssd", lambda g=g, n=n: hv.ssd_d(self.luma, st, g["rec"], n, g["jssd"], g["ossd"])))
         return L
 
     def step(self):
@@ -165,13 +167,13 @@ class DeviceFrame:
         """a checksum of checksums over every result buffer (size-independent parity property; see tests)"""
         import torch
         acc = 0
-        bufs = [self.o_sad4, self.o_sad, self.o_satd, self.o_ssd, self.pred, self.cpred, self.bi, self.sbi, self.luma]
+        bufs = [self.o_sad4, self.o_sad, self.o_satd, self.pred, self.cpred, self.bi, self.sbi]
         for g in self.intra.values():
             bufs += [g["dst"]]
-        for g in self.isearch.values():
+        for g in list(self.isearch.values()) + list(self.subpel.values()):
             bufs += [g["cost"]]
         for g in self.tu.values():
-            bufs += [g["res"], g["coef"], g["deq"]]
+            bufs += [g["res"], g["coef"], g["deq"], g["rec"], g["ossd"]]
         for b in bufs:
             acc = (acc * 1000003 + int(b.to(torch.int64).sum().item())) & 0xFFFFFFFFFFFF
         return acc
@@ -249,6 +251,17 @@ def cpu_worker(args):
     add(lambda b, e: lib.ref_run_subtract_bi(handle, S, bd, P(sbi), ip(64), P(bi), ip(64), P(luma), ip(st), P(jsb), b, e), len(jsb))
     add(lambda b, e: lib.ref_run_pred_bi(handle, S, 4, bd, P(bi), ip(32), P(chroma), ip(cst), P(jb4), b, e), len(jb4))
     keep = [j4, js, ju8, ju4, jb8, jb4, jsb, jsa, o4, os_, osa]
+    for hi, j in wl.subpel.items():   # fused on the GPU; on the CPU the reference's two calls: pred_uni, then measureSatd
+        if not len(j):
+            continue
+        jp = sub(j)
+        jsat = _aligned(np.stack([jp[:, 0], np.arange(len(jp), dtype=np.int32) * 4096, jp[:, 2], jp[:, 3]], 1).astype(np.int32))
+        jp[:, 0] = np.arange(len(jp)) * 4096
+        scratch = _aligned(np.zeros(len(jp) * 4096 + 4096, dt))
+        osp = np.zeros(len(jp), np.int32)
+        keep += [jp, jsat, scratch, osp]
+        add(lambda b, e, jp=jp, scratch=scratch: lib.ref_run_pred_uni(handle, S, 8, bd, P(scratch), ip(64), P(luma), ip(st), P(jp), b, e), len(jp))
+        add(lambda b, e, jsat=jsat, scratch=scratch, osp=osp: lib.ref_run_satd(handle, S, P(luma), ip(st), P(scratch), ip(64), P(jsat), b, e, P(osp)), len(jp))
     for log2, j in wl.intra.items():
         if not len(j):
             continue
@@ -284,11 +297,12 @@ def cpu_worker(args):
         add(lambda b, e, n=n, res=res, roff=roff, jsrc=jsrc: lib.ref_run_residual(S, P(res), ip(n), P(roff), P(luma), ip(st), P(luma), ip(st), P(jsrc), b, e), len(jt))
         add(lambda b, e, n=n, log2=log2, tr=tr, coef=coef, res=res, jt=jt: lib.ref_run_transform(handle, bd, tr, log2, P(coef), P(res), ip(n), P(jt), b, e), len(jt))
         add(lambda b, e, deq=deq, coef=coef, dj=dj: lib.ref_run_quantize_inverse(handle, P(deq), P(coef), P(dj), b, e), len(jt))
-        add(lambda b, e, log2=log2, tr=tr, deq=deq, jt=jt: lib.ref_run_inverse_transform_add(handle, S, bd, tr, log2, P(luma), ip(st), P(luma), ip(st), P(deq), P(jt), b, e), len(jt))
-    jss = sub(wl.ssd)
-    oss = np.zeros(len(jss), np.uint32)
-    keep += [jss, oss]
-    add(lambda b, e: lib.ref_run_ssd(handle, S, P(luma), ip(st), P(luma), ip(st), P(jss), b, e, P(oss)), len(jss))
+        rec = _aligned(np.zeros(m * n * n + 64, dt))
+        jss = sub(g["ssd"])
+        oss = np.zeros(len(jss), np.uint32)
+        keep += [rec, jss, oss]
+        add(lambda b, e, log2=log2, tr=tr, deq=deq, jt=jt, rec=rec, n=n: lib.ref_run_inverse_transform_add(handle, S, bd, tr, log2, P(rec), ip(n), P(luma), ip(st), P(deq), P(jt), b, e), len(jt))
+        add(lambda b, e, rec=rec, n=n, jss=jss, oss=oss: lib.ref_run_ssd(handle, S, P(luma), ip(st), P(rec), ip(n), P(jss), b, e, P(oss)), len(jss))
 
     def run_all(pool):
         for fn, n in tasks:

@@ -67,6 +67,63 @@ struct FastDiv
     __device__ __forceinline__ int div(int i) const { return d == 1 ? i : (int)(((uint32_t)i * inv) >> 20); }
 };
 
+// ---- Walsh-Hadamard helpers shared by the SATD kernels -----------------------------------------------------------
+
+// in-register length-N butterfly network (unnormalised; output order is irrelevant to SATD)
+template <int N>
+__device__ __forceinline__ void wht_inplace(int (&v)[N])
+{
+#pragma unroll
+    for (int len = 1; len < N; len <<= 1)
+#pragma unroll
+        for (int i = 0; i < N; i += len << 1)
+#pragma unroll
+            for (int k = i; k < i + len; ++k)
+            {
+                const int a = v[k], b = v[k + len];
+                v[k] = a + b;
+                v[k + len] = a - b;
+            }
+}
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
+
+constexpr int kDppXor1 = 0xB1;        // quad_perm [1,0,3,2]
+constexpr int kDppXor3 = 0x1B;        // quad_perm [3,2,1,0]
+constexpr int kDppHalfMirror = 0x141; // row_half_mirror: lane ^ 7 inside each aligned group of 8 lanes
+
+// SATD of a TS x TS tile distributed over TS consecutive lanes: lane r (0..TS-1) holds one row (or one column: SATD
+// is transposition invariant) of the difference tile in d[].  In-lane transform, then the cross-lane transform with
+// DPP mirror butterflies (lane^7, lane^3, lane^1): a Walsh ordering of the Hadamard coefficients, so sum|coeff| is
+// the reference's (havoc/hadamard.cpp:58-98).  Lane r == 0 returns the normalised tile cost, the others 0.
+template <int S, int TS>
+__device__ __forceinline__ int satd_rows(int (&d)[TS], int r)
+{
+    wht_inplace<TS>(d);
+    if (TS == 8)
+    {
+        const int s4 = (r & 4) ? -1 : 1;
+#pragma unroll
+        for (int k = 0; k < TS; ++k) d[k] = dpp_mov<kDppHalfMirror>(d[k]) + s4 * d[k];
+    }
+    const int s2 = (r & 2) ? -1 : 1, s1 = (r & 1) ? -1 : 1;
+#pragma unroll
+    for (int k = 0; k < TS; ++k) d[k] = dpp_mov<kDppXor3>(d[k]) + s2 * d[k];
+    int sum = 0;
+#pragma unroll
+    for (int k = 0; k < TS; ++k) sum += abs(dpp_mov<kDppXor1>(d[k]) + s1 * d[k]);
+    sum += dpp_mov<kDppXor1>(sum);
+    sum += dpp_mov<kDppXor3>(sum);
+    if (TS == 8) sum += dpp_mov<kDppHalfMirror>(sum);
+    sum = (sum + TS / 4) / (TS / 2);
+    if (S == 2) sum >>= 2;
+    return r == 0 ? sum : 0;
+}
+
 template <int S> struct Sample;
 template <> struct Sample<1> { typedef uint8_t T; };
 template <> struct Sample<2> { typedef uint16_t T; };

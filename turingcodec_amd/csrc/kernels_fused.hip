@@ -22,22 +22,6 @@ __constant__ int8_t c_angle35[35] = {0,  0,   32,  26,  21,  17,  13, 9,  5,  2,
 __constant__ int16_t c_invAngle35[26] = {0,    0,    0,    0,    0,    0,    0,    0,    0,    0,    0,     -4096, -1638,
                                          -910, -630, -482, -390, -315, -256, -315, -390, -482, -630, -910, -1638, -4096};
 
-template <int N>
-__device__ __forceinline__ void wht_inplace(int (&v)[N])
-{
-#pragma unroll
-    for (int len = 1; len < N; len <<= 1)
-#pragma unroll
-        for (int i = 0; i < N; i += len << 1)
-#pragma unroll
-            for (int k = i; k < i + len; ++k)
-            {
-                const int a = v[k], b = v[k + len];
-                v[k] = a + b;
-                v[k + len] = a - b;
-            }
-}
-
 // normalised SATD of a TS x TS difference tile held in registers (compute_satd_c_ref<TS>)
 template <int S, int TS>
 __device__ __forceinline__ int satd_regs(int (&d)[TS][TS])
@@ -246,237 +230,6 @@ __global__ __launch_bounds__(THREADS) void k_intra_satd35(const char *__restrict
         const int p = i / 35, m = i - p * 35;
         if (job0 + p < njobs) cost[(long)(job0 + p) * 35 + m] = s_cost[p][m];
     }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// k_subpel_satd: one sub-pel motion candidate = fractional-sample interpolation of the PU (HavocPredUni,
-// havoc/pred_inter.cpp:113-202) followed by the PU SATD against the source (measureSatd, turing/Measure.h:97-135) --
-// costDistortionMv in the reference (turing/Search.hpp:1965-1998).  The prediction never leaves the CU: window -> LDS,
-// H pass -> LDS, V pass -> (source - prediction) as int16 in LDS, then the Hadamard runs with one tile ROW per lane:
-// the row transform in registers, the column transform across the 8 (or 4) lanes of the tile with DPP mirror
-// butterflies (lane^7, lane^3, lane^1: a Walsh ordering of the same coefficients, so sum|coeff| is unchanged).
-// A launch is uniform in a size class (max PU 16x16 / 32x32 / 64x64 -> 64 / 128 / 256 lanes per PU), the way the
-// reference's table is indexed by width class (havoc/pred_inter.h:47-50).
-// ---------------------------------------------------------------------------------------------------------------
-
-__constant__ int8_t c_luma8[4][8] = {
-    {0, 0, 0, 64, 0, 0, 0, 0}, {-1, 4, -10, 58, 17, -5, 1, 0}, {-1, 4, -11, 40, 40, -11, 4, -1}, {0, 1, -5, 17, 58, -10, 4, -1}};
-__constant__ int8_t c_chroma4[8][4] = {{0, 64, 0, 0},   {-2, 58, 10, -2}, {-4, 54, 16, -2}, {-6, 46, 28, -4},
-                                       {-4, 36, 36, -4}, {-4, 28, 46, -6}, {-2, 16, 54, -4}, {-2, 10, 58, -2}};
-
-template <int CTRL>
-__device__ __forceinline__ int dpp_mov(int v)
-{
-    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
-}
-
-constexpr int kDppXor1 = 0xB1;        // quad_perm [1,0,3,2]
-constexpr int kDppXor3 = 0x1B;        // quad_perm [3,2,1,0]
-constexpr int kDppHalfMirror = 0x141; // row_half_mirror: lane ^ 7 inside each group of 8
-
-// SATD of the TS x TS tile whose row `r` (0..TS-1) this lane holds in d[]; TS lanes cooperate, lane r == 0 gets the
-// normalised tile cost (others return 0).
-template <int S, int TS>
-__device__ __forceinline__ int satd_rows(int (&d)[TS], int r)
-{
-    wht_inplace<TS>(d);
-    if (TS == 8)
-    {
-        const int s4 = (r & 4) ? -1 : 1;
-#pragma unroll
-        for (int k = 0; k < TS; ++k) d[k] = dpp_mov<kDppHalfMirror>(d[k]) + s4 * d[k];
-    }
-    const int s2 = (r & 2) ? -1 : 1, s1 = (r & 1) ? -1 : 1;
-#pragma unroll
-    for (int k = 0; k < TS; ++k) d[k] = dpp_mov<kDppXor3>(d[k]) + s2 * d[k];
-    int sum = 0;
-#pragma unroll
-    for (int k = 0; k < TS; ++k) sum += abs(dpp_mov<kDppXor1>(d[k]) + s1 * d[k]);
-    sum += dpp_mov<kDppXor1>(sum);
-    sum += dpp_mov<kDppXor3>(sum);
-    if (TS == 8) sum += dpp_mov<kDppHalfMirror>(sum);
-    sum = (sum + TS / 4) / (TS / 2);
-    if (S == 2) sum >>= 2;
-    return r == 0 ? sum : 0;
-}
-
-template <int S, int TAPS, int MAXW, int MAXH, int THREADS>
-__global__ __launch_bounds__(THREADS) void k_subpel_satd(const char *__restrict__ src, long stride_src, const char *__restrict__ ref,
-                                                         long stride_ref, const int32_t *__restrict__ jobs, int bitDepth,
-                                                         int32_t *__restrict__ cost)
-{
-    typedef typename Sample<S>::T T;
-    constexpr int AB = TAPS / 2 - 1;
-    constexpr int WH = MAXH + TAPS - 1;
-    constexpr int WS = (MAXW + TAPS - 1 + 3 + 3) & ~3;      // window row stride: room for the 4-sample chunk overshoot
-    __shared__ uint16_t win[WH * WS];
-    __shared__ int16_t tmp[WH * MAXW];
-    __shared__ __attribute__((aligned(16))) int16_t diff[MAXH * MAXW];
-    __shared__ int s_total;
-
-    const int32_t *j = jobs + (long)blockIdx.x * 8;   // havoc_mi355x_pred_uni_job, dst_off field = source block offset
-    const int tid = threadIdx.x;
-    const int w = j[2], h = j[3], xFrac = j[4], yFrac = j[5];
-    const long ssb = stride_src * S, rsb = stride_ref * S;
-    const char *s = src + (long)j[0] * S;
-    const char *r0 = ref + (long)j[1] * S;
-    const int maxv = (1 << bitDepth) - 1;
-    const FastDiv fw(w);
-    if (tid == 0) s_total = 0;
-
-    if (xFrac || yFrac)
-    {
-        const int ww = w + TAPS - 1, wh = h + TAPS - 1;
-        const int cpr = (ww + 3) >> 2;
-        const FastDiv fc(cpr);
-        const char *base = r0 - AB * rsb - AB * S;
-        for (int i = tid; i < cpr * wh; i += THREADS)
-        {
-            const int y = fc.div(i), x = (i - y * cpr) * 4;
-            uint16_t *d = win + y * WS + x;
-            const char *p = base + y * rsb + x * S;
-            if (S == 1)
-            {
-                const uint32_t v = ld4(p);
-                d[0] = v & 0xff; d[1] = (v >> 8) & 0xff; d[2] = (v >> 16) & 0xff; d[3] = v >> 24;
-            }
-            else
-            {
-                const u32x2 v = ld8(p);
-                d[0] = v.x & 0xffff; d[1] = v.x >> 16; d[2] = v.y & 0xffff; d[3] = v.y >> 16;
-            }
-        }
-        __syncthreads();
-        if (xFrac && yFrac)
-        {
-            int c[TAPS];
-#pragma unroll
-            for (int k = 0; k < TAPS; ++k) c[k] = TAPS == 8 ? (int)c_luma8[xFrac][k] : (int)c_chroma4[xFrac][k];
-            const int shift1 = min(4, bitDepth - 8);
-            for (int i = tid; i < w * wh; i += THREADS)
-            {
-                const int y = fw.div(i), x = i - y * w;
-                const uint16_t *p = win + y * WS + x;
-                int a = 0;
-#pragma unroll
-                for (int k = 0; k < TAPS; ++k) a += c[k] * (int)p[k];
-                tmp[y * MAXW + x] = (int16_t)(a >> shift1);
-            }
-            __syncthreads();
-        }
-    }
-    {
-        int c[TAPS];
-        const int f = (xFrac && yFrac) ? yFrac : (xFrac ? xFrac : yFrac);
-#pragma unroll
-        for (int k = 0; k < TAPS; ++k) c[k] = TAPS == 8 ? (int)c_luma8[f][k] : (int)c_chroma4[f][k];
-        const int shift = 6 + max(2, 14 - bitDepth);
-        for (int i = tid; i < w * h; i += THREADS)
-        {
-            const int y = fw.div(i), x = i - y * w;
-            int v;
-            if (xFrac && yFrac)
-            {
-                int a = 1 << (shift - 1);
-#pragma unroll
-                for (int k = 0; k < TAPS; ++k) a += c[k] * (int)tmp[(y + k) * MAXW + x];
-                v = clip3(0, maxv, a >> shift);
-            }
-            else if (xFrac | yFrac)
-            {
-                const uint16_t *p = xFrac ? win + (y + AB) * WS + x : win + y * WS + x + AB;
-                const int step = xFrac ? 1 : WS;
-                int a = 32;
-#pragma unroll
-                for (int k = 0; k < TAPS; ++k) a += c[k] * (int)p[k * step];
-                v = clip3(0, maxv, a >> 6);
-            }
-            else
-                v = reinterpret_cast<const T *>(r0 + y * rsb)[x];
-            diff[y * MAXW + x] = (int16_t)((int)reinterpret_cast<const T *>(s + y * ssb)[x] - v);
-        }
-    }
-    __syncthreads();
-
-    int acc = 0;
-    if (((w | h) & 7) == 0)
-    {
-        const int tw = w >> 3;
-        const FastDiv ft(tw);
-        for (int it = tid; it < (tw * (h >> 3)) * 8; it += THREADS)
-        {
-            const int tile = it >> 3, r = it & 7;
-            const int ty = ft.div(tile), tx = tile - ty * tw;
-            const u32x4 q = *reinterpret_cast<const u32x4 *>(&diff[(ty * 8 + r) * MAXW + tx * 8]);
-            int d[8] = {(int16_t)(q.x & 0xffff), (int16_t)(q.x >> 16), (int16_t)(q.y & 0xffff), (int16_t)(q.y >> 16),
-                        (int16_t)(q.z & 0xffff), (int16_t)(q.z >> 16), (int16_t)(q.w & 0xffff), (int16_t)(q.w >> 16)};
-            acc += satd_rows<S, 8>(d, r);
-        }
-    }
-    else if (((w | h) & 3) == 0)
-    {
-        const int tw = w >> 2;
-        const FastDiv ft(tw);
-        for (int it = tid; it < (tw * (h >> 2)) * 4; it += THREADS)
-        {
-            const int tile = it >> 2, r = it & 3;
-            const int ty = ft.div(tile), tx = tile - ty * tw;
-            const u32x2 q = *reinterpret_cast<const u32x2 *>(&diff[(ty * 4 + r) * MAXW + tx * 4]);
-            int d[4] = {(int16_t)(q.x & 0xffff), (int16_t)(q.x >> 16), (int16_t)(q.y & 0xffff), (int16_t)(q.y >> 16)};
-            acc += satd_rows<S, 4>(d, r);
-        }
-    }
-    else
-    {
-        const int tw = w >> 1;
-        const FastDiv ft(tw);
-        for (int t = tid; t < tw * (h >> 1); t += THREADS)
-        {
-            const int ty = ft.div(t), tx = t - ty * tw;
-            const int a = diff[(2 * ty) * MAXW + 2 * tx], b = diff[(2 * ty) * MAXW + 2 * tx + 1];
-            const int c = diff[(2 * ty + 1) * MAXW + 2 * tx], e = diff[(2 * ty + 1) * MAXW + 2 * tx + 1];
-            int sum = abs(a + b + c + e) + abs(a - b + c - e) + abs(a + b - c - e) + abs(a - b - c + e);
-            if (S == 2) sum >>= 2;
-            acc += sum;
-        }
-    }
-    const int t = wave_sum(acc);
-    if (THREADS == 64)
-    {
-        if (tid == 0) cost[blockIdx.x] = t;
-    }
-    else
-    {
-        if ((tid & 63) == 0) atomicAdd(&s_total, t);
-        __syncthreads();
-        if (tid == 0) cost[blockIdx.x] = s_total;
-    }
-}
-
-template <int S, int TAPS>
-static hipError_t launch_subpel_satd_st(hipStream_t st, int bd, int maxw, int maxh, const char *src, long ss, const char *ref, long rs,
-                                        const int32_t *jobs, int n, int32_t *cost)
-{
-    if (maxw <= 16 && maxh <= 16)
-        hipLaunchKernelGGL((k_subpel_satd<S, TAPS, 16, 16, 64>), dim3(n), dim3(64), 0, st, src, ss, ref, rs, jobs, bd, cost);
-    else if (maxw <= 32 && maxh <= 32)
-        hipLaunchKernelGGL((k_subpel_satd<S, TAPS, 32, 32, 128>), dim3(n), dim3(128), 0, st, src, ss, ref, rs, jobs, bd, cost);
-    else
-        hipLaunchKernelGGL((k_subpel_satd<S, TAPS, 64, 64, 256>), dim3(n), dim3(256), 0, st, src, ss, ref, rs, jobs, bd, cost);
-    return hipGetLastError();
-}
-
-hipError_t launch_subpel_satd(hipStream_t st, int S, int taps, int bd, int maxw, int maxh, const void *src, long ss, const void *ref, long rs,
-                              const void *jobs, int n, int32_t *cost)
-{
-    if (n <= 0) return hipSuccess;
-    const char *s = (const char *)src, *r = (const char *)ref;
-    const int32_t *j = (const int32_t *)jobs;
-    if (S == 1 && taps == 8) return launch_subpel_satd_st<1, 8>(st, bd, maxw, maxh, s, ss, r, rs, j, n, cost);
-    if (S == 1 && taps == 4) return launch_subpel_satd_st<1, 4>(st, bd, maxw, maxh, s, ss, r, rs, j, n, cost);
-    if (S == 2 && taps == 8) return launch_subpel_satd_st<2, 8>(st, bd, maxw, maxh, s, ss, r, rs, j, n, cost);
-    if (S == 2 && taps == 4) return launch_subpel_satd_st<2, 4>(st, bd, maxw, maxh, s, ss, r, rs, j, n, cost);
-    return hipErrorInvalidValue;
 }
 
 template <int S>

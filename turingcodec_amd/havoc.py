@@ -216,7 +216,7 @@ class Havoc:
         out = np.zeros(len(jobs), np.int32)
         s, r = self.up(src), self.up(ref)
         big = np.maximum(jobs[:, 2], jobs[:, 3])
-        for lo, hi in ((0, 16), (16, 32), (32, 64)):
+        for lo, hi in ((0, 8), (8, 16), (16, 32), (32, 64)):
             idx = np.flatnonzero((big > lo) & (big <= hi))
             if len(idx):
                 cost = self.zeros(len(idx), np.int32)

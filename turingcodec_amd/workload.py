@@ -147,6 +147,16 @@ class FrameWorkload:
                                   loff(x, y, 0), np.zeros_like(w)], 1))
         u = np.concatenate(rows).astype(np.int32)
         u = u[rng.permutation(len(u))]
+        # costDistortionMv candidates (1474818/8 per B-frame, A.2) only need the COST: they go through the fused
+        # interpolation+SATD entry point, one launch per PU size class; the rest (measurePuCost: the prediction is
+        # kept) are written to prediction slots and measured by the SATD batch
+        nsearch = min(len(u) - 1, int(round(1474818 / 8 * f)))
+        sp = u[:nsearch].copy()
+        sp[:, 0] = sp[:, 6]          # dst_off field = source PU offset (havoc_mi355x_subpel_satd)
+        sp[:, 6] = 0
+        big = np.maximum(sp[:, 2], sp[:, 3])
+        self.subpel = {hi: np.ascontiguousarray(sp[(big > lo) & (big <= hi)]) for lo, hi in ((0, 8), (8, 16), (16, 32), (32, 64))}
+        u = u[nsearch:]
         slot = np.concatenate([[0], np.cumsum(64 * u[:-1, 3].astype(np.int64))])
         u[:, 0] = slot
         self.pred_len = int(slot[-1] + 64 * u[-1, 3])
@@ -274,16 +284,14 @@ class FrameWorkload:
             t[:, 0] = np.arange(m) * nn * nn                # coefficients / levels / residual: n*n contiguous
             t[:, 1] = np.arange(m) * nn * nn
             t[:, 2] = loff(x + dx, y + dy, 1)               # prediction: a slightly displaced block of ref L0
-            t[:, 3] = loff(x, y, 3)                         # reconstruction plane = plane 3 of the store
-            self.tu[(log2, tr)] = dict(jobs=t, src=np.stack([loff(x, y, 0), t[:, 2], np.full(m, nn), np.full(m, nn)], 1).astype(np.int32),
-                                       res_off=t[:, 1].copy(), n=nn)
-        # SSD after reconstruction: source block vs reconstructed block, n x n
-        rows = []
-        for (log2, tr), g in self.tu.items():
-            rows.append(np.stack([g["src"][:, 0], g["jobs"][:, 3], g["src"][:, 2], g["src"][:, 3]], 1))
-        allssd = np.concatenate(rows)
-        reps = int(np.ceil(n["ssd"] / len(allssd)))
-        self.ssd = np.concatenate([allssd] * reps)[:n["ssd"]].astype(np.int32)
+            t[:, 3] = np.arange(m) * nn * nn                # reconstruction piece of this candidate: n*n, stride n
+            #                                                 (turing/ReconstructionCache.h pieces; candidates never share one)
+            src4 = np.stack([loff(x, y, 0), t[:, 2], np.full(m, nn), np.full(m, nn)], 1).astype(np.int32)
+            # SSD after reconstruction (source block vs reconstructed piece); the reference makes ~1.26 SSD calls per TU
+            ssd = np.stack([src4[:, 0], t[:, 3], src4[:, 2], src4[:, 3]], 1).astype(np.int32)
+            nssd = int(round(m * n["ssd"] / max(1, n["tu"])))
+            ssd = np.concatenate([ssd, ssd])[:nssd]
+            self.tu[(log2, tr)] = dict(jobs=t, src=src4, res_off=t[:, 1].copy(), n=nn, ssd=ssd)
 
     # ---- algorithmic bytes (SURVEY.md 8(d) "per primitive call": operands read once + results written once) ----
     def algorithmic_bytes(self):
@@ -298,6 +306,12 @@ class FrameWorkload:
             frac = (j[:, 4] != 0) | (j[:, 5] != 0)
             return int(np.where(frac, (w + t - 1) * (h + t - 1) * S + w * h * S, 2 * w * h * S).sum())
         b["pred_uni8"] = uni(self.uni8, 8)
+        # fused candidate: reference window + source block read once, one int32 written (no prediction traffic)
+        b["subpel_satd"] = 0
+        for j in self.subpel.values():
+            w, h = j[:, 2].astype(np.int64), j[:, 3].astype(np.int64)
+            frac = (j[:, 4] != 0) | (j[:, 5] != 0)
+            b["subpel_satd"] += int((np.where(frac, (w + 7) * (h + 7), w * h) * S + w * h * S + 4).sum())
         b["pred_uni4"] = uni(self.uni4, 4)
         for nm, j, t in (("pred_bi8", self.bi8, 8), ("pred_bi4", self.bi4, 4)):
             w, h = j[:, 3].astype(np.int64), j[:, 4].astype(np.int64)
@@ -313,5 +327,5 @@ class FrameWorkload:
         b["transform"] = 4 * tot
         b["quantize_inverse"] = 4 * tot
         b["inverse_transform_add"] = tot * (2 + 2 * S)
-        b["ssd"] = int((2 * wh(self.ssd, 2, 3) * S + 4).sum())
+        b["ssd"] = sum(int((2 * wh(g["ssd"], 2, 3) * S + 4).sum()) for g in self.tu.values())
         return b
