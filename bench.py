@@ -40,6 +40,7 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--kernel-reps", type=int, default=5)
+    ap.add_argument("--lanes", type=int, default=8, help="fork/join lanes: independent launch chains overlap on the GPU")
     return ap.parse_args()
 
 
@@ -119,34 +120,53 @@ class DeviceFrame:
         hv, wl = self.hv, self.wl
         bd, st, cst = wl.bit_depth, wl.stride, wl.cstride
         L = []
-        L.append(("sad4", lambda: hv.sad4_d(self.luma, st, self.luma, st, self.j_sad4, self.o_sad4)))
-        L.append(("sad", lambda: hv.sad_d(self.luma, st, self.luma, st, self.j_sad, self.o_sad)))
-        for hi, g in sorted(self.subpel.items()):
-            L.append(("subpel_satd", lambda g=g, hi=hi: hv.subpel_satd_d(8, bd, hi, hi, self.luma, st, self.luma, st, g["jobs"], g["cost"])))
-        L.append(("pred_uni8", lambda: hv.pred_uni_d(8, bd, self.pred, 64, self.luma, st, self.j_uni8)))
-        L.append(("satd_inter", lambda: hv.satd_d(self.luma, st, self.pred, 64, self.j_satd, self.o_satd)))
-        L.append(("pred_uni4", lambda: hv.pred_uni_d(4, bd, self.cpred, 32, self.chroma, cst, self.j_uni4)))
-        L.append(("pred_bi8", lambda: hv.pred_bi_d(8, bd, self.bi, 64, self.luma, st, self.j_bi8)))
-        L.append(("subtract_bi", lambda: hv.subtract_bi_d(bd, self.sbi, 64, self.bi, 64, self.luma, st, self.j_sbi)))
-        L.append(("pred_bi4", lambda: hv.pred_bi_d(4, bd, self.bi, 32, self.chroma, cst, self.j_bi4)))
-        for log2, g in sorted(self.intra.items()):
+        chains = []   # lists of indices into L: launches of one chain depend on each other, chains are independent
+
+        def chain(*items):
+            chains.append(list(range(len(L), len(L) + len(items))))
+            L.extend(items)
+
+        chain(("sad4", lambda: hv.sad4_d(self.luma, st, self.luma, st, self.j_sad4, self.o_sad4)))
+        chain(("sad", lambda: hv.sad_d(self.luma, st, self.luma, st, self.j_sad, self.o_sad)))
+        for hi, g in sorted(self.subpel.items(), reverse=True):
+            chain(("subpel_satd", lambda g=g, hi=hi: hv.subpel_satd_d(8, bd, hi, hi, self.luma, st, self.luma, st, g["jobs"], g["cost"])))
+        chain(("pred_uni8", lambda: hv.pred_uni_d(8, bd, self.pred, 64, self.luma, st, self.j_uni8)),
+              ("satd_inter", lambda: hv.satd_d(self.luma, st, self.pred, 64, self.j_satd, self.o_satd)))
+        chain(("pred_uni4", lambda: hv.pred_uni_d(4, bd, self.cpred, 32, self.chroma, cst, self.j_uni4)))
+        chain(("pred_bi8", lambda: hv.pred_bi_d(8, bd, self.bi, 64, self.luma, st, self.j_bi8)),
+              ("subtract_bi", lambda: hv.subtract_bi_d(bd, self.sbi, 64, self.bi, 64, self.luma, st, self.j_sbi)),
+              ("pred_bi4", lambda: hv.pred_bi_d(4, bd, self.bi, 32, self.chroma, cst, self.j_bi4)))
+        for log2, g in sorted(self.isearch.items(), reverse=True):
+            chain(("intra_satd35", lambda g=g, log2=log2: hv.intra_satd35_d(bd, log2, self.luma, st, g["nb"], g["jobs"], g["cost"])))
+        for log2, g in sorted(self.intra.items(), reverse=True):
             n = 1 << log2
-            L.append(("intra", lambda g=g, log2=log2, n=n: hv.intra_d(bd, log2, g["dst"], n, g["nb"], g["jobs"])))
-        for log2, g in sorted(self.isearch.items()):
-            L.append(("intra_satd35", lambda g=g, log2=log2: hv.intra_satd35_d(bd, log2, self.luma, st, g["nb"], g["jobs"], g["cost"])))
-        for (log2, tr), g in sorted(self.tu.items()):
+            chain(("intra", lambda g=g, log2=log2, n=n: hv.intra_d(bd, log2, g["dst"], n, g["nb"], g["jobs"])))
+        for (log2, tr), g in sorted(self.tu.items(), reverse=True):
             n = g["n"]
-            L.append(("residual", lambda g=g, n=n: hv.residual_d(g["res"], n, g["res_off"], self.luma, st, self.luma, st, g["src"])))
-            L.append(("transform", lambda g=g, n=n, log2=log2, tr=tr: hv.transform_d(bd, tr, log2, g["coef"], g["res"], n, g["jobs"])))
-            L.append(("quantize_inverse", lambda g=g: hv.quantize_inverse_d(g["deq"], g["level"], g["djobs"])))
-            L.append(("inverse_transform_add", lambda g=g, log2=log2, tr=tr, n=n: hv.inverse_transform_add_d(
-                bd, tr, log2, g["rec"], n, self.luma, st, g["deq"], g["jobs"])))
-            L.append(("ssd", lambda g=g, n=n: hv.ssd_d(self.luma, st, g["rec"], n, g["jssd"], g["ossd"])))
+            # forward half and reconstruction half of the TU chain are independent here: the levels between them come
+            # from the host's RDOQ in the reference (pre-computed, untimed, in __init__)
+            chain(("residual", lambda g=g, n=n: hv.residual_d(g["res"], n, g["res_off"], self.luma, st, self.luma, st, g["src"])),
+                  ("transform", lambda g=g, n=n, log2=log2, tr=tr: hv.transform_d(bd, tr, log2, g["coef"], g["res"], n, g["jobs"])))
+            chain(("quantize_inverse", lambda g=g: hv.quantize_inverse_d(g["deq"], g["level"], g["djobs"])),
+                  ("inverse_transform_add", lambda g=g, log2=log2, tr=tr, n=n: hv.inverse_transform_add_d(
+                      bd, tr, log2, g["rec"], n, self.luma, st, g["deq"], g["jobs"])),
+                  ("ssd", lambda g=g, n=n: hv.ssd_d(self.luma, st, g["rec"], n, g["jssd"], g["ossd"])))
+        self.chains = chains
         return L
 
-    def step(self):
-        for _, fn in self.launches:
-            fn()
+    def step(self, nlanes=1):
+        """issue one frame's launches; with nlanes > 1 the independent chains go round-robin onto fork/join lanes"""
+        if nlanes <= 1:
+            for _, fn in self.launches:
+                fn()
+            return
+        hv = self.hv
+        hv.fork(nlanes)
+        for ci, ch in enumerate(self.chains):
+            hv.lane(ci % nlanes)
+            for idx in ch:
+                self.launches[idx][1]()
+        hv.join()
 
     def kernel_times_ms(self, reps):
         """average duration per launch group, HIP events on the context's stream"""
@@ -375,13 +395,13 @@ def main():
 
     dev.step()          # first eager pass (loads the code objects) -- also what the graph must reproduce
     hv.sync()
-    graph = None if args.no_graph else hv.graph_capture(dev.step)
+    graph = None if args.no_graph else hv.graph_capture(lambda: dev.step(args.lanes))
 
     def one_step(i):
         if graph is not None:
             hv.graph_launch(graph)
         else:
-            dev.step()
+            dev.step(args.lanes)
         if exch is not None:
             hv.sync()   # reconstruction complete before its owner broadcasts it (torch.distributed runs on torch's stream)
             exch.exchange(i)

@@ -67,6 +67,16 @@ int havoc_mi355x_graph_end(havoc_mi355x_ctx *ctx, havoc_mi355x_graph **graph);
 int havoc_mi355x_graph_launch(havoc_mi355x_ctx *ctx, havoc_mi355x_graph *graph);
 void havoc_mi355x_graph_destroy(havoc_mi355x_graph *graph);
 
+/* Fork / join: batches that do not depend on each other (integer ME of one list, sub-pel candidates of another PU
+ * class, the intra stage, each transform size ...) are small, latency-bound launches; issued on separate HIP streams
+ * they overlap on the 256 CUs.  fork(n) makes n lanes (lane 0 = the context's stream; lanes 1..n-1 are side streams
+ * that start after everything already queued), lane(k) selects where the following launches go (launches on one
+ * lane stay ordered), join() makes the context's stream wait for every lane.  Works inside graph capture: the graph
+ * then holds the parallel branches. */
+int havoc_mi355x_fork(havoc_mi355x_ctx *ctx, int nlanes); /* 1..8 */
+int havoc_mi355x_lane(havoc_mi355x_ctx *ctx, int lane);
+int havoc_mi355x_join(havoc_mi355x_ctx *ctx);
+
 /* ------------------------------------------------------------------------------------------------------- */
 /* job descriptors (plain 32-bit little-endian fields, no padding surprises: sizes asserted in the .cpp)    */
 /* ------------------------------------------------------------------------------------------------------- */

@@ -45,7 +45,17 @@ struct havoc_mi355x_ctx
     hipEvent_t ev0, ev1;
     hipDeviceProp_t prop;
     bool ownsStream;
+    // fork/join lanes: independent launch chains issued on side streams so that they overlap on the GPU
+    static constexpr int kMaxLanes = 8;
+    hipStream_t lanes[kMaxLanes];
+    hipEvent_t laneEv[kMaxLanes];
+    hipEvent_t forkEv;
+    int nlanes;   // 0 = not forked
+    int cur;      // lane the next launch goes to (0 = the context's main stream)
 };
+
+// the stream the next launch is issued on
+static inline hipStream_t LS(havoc_mi355x_ctx *ctx) { return ctx->cur == 0 ? ctx->stream : ctx->lanes[ctx->cur]; }
 
 static thread_local char g_err[256] = "";
 
@@ -114,6 +124,13 @@ int havoc_mi355x_create(havoc_mi355x_ctx **out, int device, void *stream)
 void havoc_mi355x_destroy(havoc_mi355x_ctx *ctx)
 {
     if (!ctx) return;
+    for (int k = 1; k < havoc_mi355x_ctx::kMaxLanes; ++k)
+        if (ctx->lanes[k])
+        {
+            (void)hipStreamDestroy(ctx->lanes[k]);
+            (void)hipEventDestroy(ctx->laneEv[k]);
+        }
+    if (ctx->forkEv) (void)hipEventDestroy(ctx->forkEv);
     if (ctx->ownsStream) (void)hipStreamDestroy(ctx->stream);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
@@ -202,7 +219,7 @@ int havoc_mi355x_graph_begin(havoc_mi355x_ctx *ctx)
 {
     REQUIRE_CTX();
     REQUIRE(ctx->stream != nullptr, "graph capture needs a non-default stream (create the context with HAVOC_MI355X_NEW_STREAM)");
-    return check(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
+    return check(hipStreamBeginCapture(LS(ctx),hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
 }
 
 int havoc_mi355x_graph_end(havoc_mi355x_ctx *ctx, havoc_mi355x_graph **graph)
@@ -211,7 +228,7 @@ int havoc_mi355x_graph_end(havoc_mi355x_ctx *ctx, havoc_mi355x_graph **graph)
     REQUIRE(graph != nullptr, "null graph pointer");
     *graph = nullptr;
     hipGraph_t g = nullptr;
-    int rc = check(hipStreamEndCapture(ctx->stream, &g), "hipStreamEndCapture");
+    int rc = check(hipStreamEndCapture(LS(ctx),&g), "hipStreamEndCapture");
     if (rc) return rc;
     hipGraphExec_t e = nullptr;
     if ((rc = check(hipGraphInstantiate(&e, g, nullptr, nullptr, 0), "hipGraphInstantiate")))
@@ -238,40 +255,86 @@ void havoc_mi355x_graph_destroy(havoc_mi355x_graph *graph)
     delete graph;
 }
 
+// ---- fork / join: overlap independent launch chains ---------------------------------------------------------
+
+int havoc_mi355x_fork(havoc_mi355x_ctx *ctx, int nlanes)
+{
+    REQUIRE_CTX();
+    REQUIRE(nlanes >= 1 && nlanes <= havoc_mi355x_ctx::kMaxLanes, "nlanes must be 1..8");
+    REQUIRE(ctx->nlanes == 0, "already forked");
+    int rc;
+    if (!ctx->forkEv && (rc = check(hipEventCreateWithFlags(&ctx->forkEv, hipEventDisableTiming), "hipEventCreate"))) return rc;
+    if ((rc = check(hipEventRecord(ctx->forkEv, ctx->stream), "hipEventRecord"))) return rc;
+    for (int k = 1; k < nlanes; ++k)
+    {
+        if (!ctx->lanes[k])
+        {
+            if ((rc = check(hipStreamCreateWithFlags(&ctx->lanes[k], hipStreamNonBlocking), "hipStreamCreate"))) return rc;
+            if ((rc = check(hipEventCreateWithFlags(&ctx->laneEv[k], hipEventDisableTiming), "hipEventCreate"))) return rc;
+        }
+        if ((rc = check(hipStreamWaitEvent(ctx->lanes[k], ctx->forkEv, 0), "hipStreamWaitEvent"))) return rc;
+    }
+    ctx->nlanes = nlanes;
+    ctx->cur = 0;
+    return 0;
+}
+
+int havoc_mi355x_lane(havoc_mi355x_ctx *ctx, int lane)
+{
+    REQUIRE_CTX();
+    REQUIRE(lane >= 0 && lane < (ctx->nlanes ? ctx->nlanes : 1), "lane out of range (fork first)");
+    ctx->cur = lane;
+    return 0;
+}
+
+int havoc_mi355x_join(havoc_mi355x_ctx *ctx)
+{
+    REQUIRE_CTX();
+    int rc;
+    for (int k = 1; k < ctx->nlanes; ++k)
+    {
+        if ((rc = check(hipEventRecord(ctx->laneEv[k], ctx->lanes[k]), "hipEventRecord"))) return rc;
+        if ((rc = check(hipStreamWaitEvent(ctx->stream, ctx->laneEv[k], 0), "hipStreamWaitEvent"))) return rc;
+    }
+    ctx->nlanes = 0;
+    ctx->cur = 0;
+    return 0;
+}
+
 // ---- distortion metrics -----------------------------------------------------------------------------------
 
 int havoc_mi355x_sad(havoc_mi355x_ctx *ctx, int S, const void *d_src, intptr_t stride_src, const void *d_ref, intptr_t stride_ref,
                      const havoc_mi355x_pair_job *d_jobs, int njobs, int32_t *d_out)
 {
     REQUIRE_CTX(); REQUIRE_S(); REQUIRE(njobs >= 0, "njobs < 0");
-    return check(launch_sad(ctx->stream, S, 1, d_src, stride_src, d_ref, stride_ref, d_jobs, njobs, d_out), "sad");
+    return check(launch_sad(LS(ctx),S, 1, d_src, stride_src, d_ref, stride_ref, d_jobs, njobs, d_out), "sad");
 }
 
 int havoc_mi355x_sad4(havoc_mi355x_ctx *ctx, int S, const void *d_src, intptr_t stride_src, const void *d_ref, intptr_t stride_ref,
                       const havoc_mi355x_sad4_job *d_jobs, int njobs, int32_t *d_out)
 {
     REQUIRE_CTX(); REQUIRE_S(); REQUIRE(njobs >= 0, "njobs < 0");
-    return check(launch_sad(ctx->stream, S, 4, d_src, stride_src, d_ref, stride_ref, d_jobs, njobs, d_out), "sad4");
+    return check(launch_sad(LS(ctx),S, 4, d_src, stride_src, d_ref, stride_ref, d_jobs, njobs, d_out), "sad4");
 }
 
 int havoc_mi355x_ssd(havoc_mi355x_ctx *ctx, int S, const void *d_a, intptr_t stride_a, const void *d_b, intptr_t stride_b,
                      const havoc_mi355x_pair_job *d_jobs, int njobs, uint32_t *d_out)
 {
     REQUIRE_CTX(); REQUIRE_S(); REQUIRE(njobs >= 0, "njobs < 0");
-    return check(launch_ssd(ctx->stream, S, d_a, stride_a, d_b, stride_b, d_jobs, njobs, d_out), "ssd");
+    return check(launch_ssd(LS(ctx),S, d_a, stride_a, d_b, stride_b, d_jobs, njobs, d_out), "ssd");
 }
 
 int havoc_mi355x_satd(havoc_mi355x_ctx *ctx, int S, const void *d_a, intptr_t stride_a, const void *d_b, intptr_t stride_b,
                       const havoc_mi355x_pair_job *d_jobs, int njobs, int32_t *d_out)
 {
     REQUIRE_CTX(); REQUIRE_S(); REQUIRE(njobs >= 0, "njobs < 0");
-    return check(launch_satd(ctx->stream, S, d_a, stride_a, d_b, stride_b, d_jobs, njobs, d_out), "satd");
+    return check(launch_satd(LS(ctx),S, d_a, stride_a, d_b, stride_b, d_jobs, njobs, d_out), "satd");
 }
 
 int havoc_mi355x_ssd_linear(havoc_mi355x_ctx *ctx, const uint8_t *d_a, const uint8_t *d_b, int size, int32_t *d_out)
 {
     REQUIRE_CTX(); REQUIRE(size >= 0, "size < 0");
-    return check(launch_ssd_linear(ctx->stream, d_a, d_b, size, d_out), "ssd_linear");
+    return check(launch_ssd_linear(LS(ctx),d_a, d_b, size, d_out), "ssd_linear");
 }
 
 // ---- inter prediction -------------------------------------------------------------------------------------
@@ -280,21 +343,21 @@ int havoc_mi355x_pred_uni(havoc_mi355x_ctx *ctx, int S, int taps, int bitDepth, 
                           intptr_t stride_ref, const havoc_mi355x_pred_uni_job *d_jobs, int njobs)
 {
     REQUIRE_CTX(); REQUIRE_S(); REQUIRE_BD(); REQUIRE(taps == 8 || taps == 4, "taps must be 8 or 4"); REQUIRE(njobs >= 0, "njobs < 0");
-    return check(launch_pred_uni(ctx->stream, S, taps, bitDepth, d_dst, stride_dst, d_ref, stride_ref, d_jobs, njobs), "pred_uni");
+    return check(launch_pred_uni(LS(ctx),S, taps, bitDepth, d_dst, stride_dst, d_ref, stride_ref, d_jobs, njobs), "pred_uni");
 }
 
 int havoc_mi355x_pred_bi(havoc_mi355x_ctx *ctx, int S, int taps, int bitDepth, void *d_dst, intptr_t stride_dst, const void *d_ref,
                          intptr_t stride_ref, const havoc_mi355x_pred_bi_job *d_jobs, int njobs)
 {
     REQUIRE_CTX(); REQUIRE_S(); REQUIRE_BD(); REQUIRE(taps == 8 || taps == 4, "taps must be 8 or 4"); REQUIRE(njobs >= 0, "njobs < 0");
-    return check(launch_pred_bi(ctx->stream, S, taps, bitDepth, d_dst, stride_dst, d_ref, stride_ref, d_jobs, njobs), "pred_bi");
+    return check(launch_pred_bi(LS(ctx),S, taps, bitDepth, d_dst, stride_dst, d_ref, stride_ref, d_jobs, njobs), "pred_bi");
 }
 
 int havoc_mi355x_subtract_bi(havoc_mi355x_ctx *ctx, int S, int bitDepth, void *d_dst, intptr_t stride_dst, const void *d_pred, intptr_t stride_pred,
                              const void *d_src, intptr_t stride_src, const havoc_mi355x_subtract_bi_job *d_jobs, int njobs)
 {
     REQUIRE_CTX(); REQUIRE_S(); REQUIRE_BD(); REQUIRE(njobs >= 0, "njobs < 0");
-    return check(launch_subtract_bi(ctx->stream, S, bitDepth, d_dst, stride_dst, d_pred, stride_pred, d_src, stride_src, d_jobs, njobs), "subtract_bi");
+    return check(launch_subtract_bi(LS(ctx),S, bitDepth, d_dst, stride_dst, d_pred, stride_pred, d_src, stride_src, d_jobs, njobs), "subtract_bi");
 }
 
 int havoc_mi355x_subpel_satd(havoc_mi355x_ctx *ctx, int S, int taps, int bitDepth, int max_w, int max_h, const void *d_src, intptr_t stride_src,
@@ -302,7 +365,7 @@ int havoc_mi355x_subpel_satd(havoc_mi355x_ctx *ctx, int S, int taps, int bitDept
 {
     REQUIRE_CTX(); REQUIRE_S(); REQUIRE_BD(); REQUIRE(taps == 8 || taps == 4, "taps must be 8 or 4"); REQUIRE(njobs >= 0, "njobs < 0");
     REQUIRE(max_w >= 2 && max_w <= 64 && max_h >= 2 && max_h <= 64, "max_w / max_h must be 2..64");
-    return check(launch_subpel_satd(ctx->stream, S, taps, bitDepth, max_w, max_h, d_src, stride_src, d_ref, stride_ref, d_jobs, njobs, d_cost),
+    return check(launch_subpel_satd(LS(ctx),S, taps, bitDepth, max_w, max_h, d_src, stride_src, d_ref, stride_ref, d_jobs, njobs, d_cost),
                  "subpel_satd");
 }
 
@@ -313,7 +376,7 @@ int havoc_mi355x_intra(havoc_mi355x_ctx *ctx, int S, int bitDepth, int log2Trafo
 {
     REQUIRE_CTX(); REQUIRE_S(); REQUIRE_BD(); REQUIRE(log2TrafoSize >= 2 && log2TrafoSize <= 5, "log2TrafoSize must be 2..5");
     REQUIRE(njobs >= 0, "njobs < 0");
-    return check(launch_intra(ctx->stream, S, log2TrafoSize, bitDepth, d_dst, stride_dst, d_neighbours, d_jobs, njobs), "intra");
+    return check(launch_intra(LS(ctx),S, log2TrafoSize, bitDepth, d_dst, stride_dst, d_neighbours, d_jobs, njobs), "intra");
 }
 
 int havoc_mi355x_intra_satd35(havoc_mi355x_ctx *ctx, int S, int bitDepth, int log2TrafoSize, const void *d_src, intptr_t stride_src,
@@ -321,7 +384,7 @@ int havoc_mi355x_intra_satd35(havoc_mi355x_ctx *ctx, int S, int bitDepth, int lo
 {
     REQUIRE_CTX(); REQUIRE_S(); REQUIRE_BD(); REQUIRE(log2TrafoSize >= 2 && log2TrafoSize <= 5, "log2TrafoSize must be 2..5");
     REQUIRE(njobs >= 0, "njobs < 0");
-    return check(launch_intra_satd35(ctx->stream, S, log2TrafoSize, bitDepth, d_src, stride_src, d_neighbours, d_jobs, njobs, d_cost), "intra_satd35");
+    return check(launch_intra_satd35(LS(ctx),S, log2TrafoSize, bitDepth, d_src, stride_src, d_neighbours, d_jobs, njobs, d_cost), "intra_satd35");
 }
 
 // ---- residual, transforms, quantisation -------------------------------------------------------------------
@@ -330,7 +393,7 @@ int havoc_mi355x_residual(havoc_mi355x_ctx *ctx, int S, int16_t *d_res, intptr_t
                           intptr_t stride_src, const void *d_pred, intptr_t stride_pred, const havoc_mi355x_pair_job *d_jobs, int njobs)
 {
     REQUIRE_CTX(); REQUIRE_S(); REQUIRE(njobs >= 0, "njobs < 0");
-    return check(launch_residual(ctx->stream, S, d_res, stride_res, d_res_off, d_src, stride_src, d_pred, stride_pred, d_jobs, njobs), "residual");
+    return check(launch_residual(LS(ctx),S, d_res, stride_res, d_res_off, d_src, stride_src, d_pred, stride_pred, d_jobs, njobs), "residual");
 }
 
 #define REQUIRE_TR() \
@@ -341,14 +404,14 @@ int havoc_mi355x_transform(havoc_mi355x_ctx *ctx, int bitDepth, int trType, int 
                            intptr_t stride_res, const havoc_mi355x_tu_job *d_jobs, int njobs)
 {
     REQUIRE_CTX(); REQUIRE_TR(); REQUIRE(bitDepth >= 8 && bitDepth <= 10, "bitDepth must be 8..10"); REQUIRE(njobs >= 0, "njobs < 0");
-    return check(launch_transform(ctx->stream, bitDepth, log2TrafoSize, trType, d_coeffs, d_res, stride_res, d_jobs, njobs), "transform");
+    return check(launch_transform(LS(ctx),bitDepth, log2TrafoSize, trType, d_coeffs, d_res, stride_res, d_jobs, njobs), "transform");
 }
 
 int havoc_mi355x_inverse_transform(havoc_mi355x_ctx *ctx, int bitDepth, int trType, int log2TrafoSize, int16_t *d_res, const int16_t *d_coeffs,
                                    const havoc_mi355x_tu_job *d_jobs, int njobs)
 {
     REQUIRE_CTX(); REQUIRE_TR(); REQUIRE(bitDepth >= 8 && bitDepth <= 10, "bitDepth must be 8..10"); REQUIRE(njobs >= 0, "njobs < 0");
-    return check(launch_inverse_transform(ctx->stream, 0, bitDepth, log2TrafoSize, trType, nullptr, 0, nullptr, 0, d_res, d_coeffs, d_jobs, njobs),
+    return check(launch_inverse_transform(LS(ctx),0, bitDepth, log2TrafoSize, trType, nullptr, 0, nullptr, 0, d_res, d_coeffs, d_jobs, njobs),
                  "inverse_transform");
 }
 
@@ -357,7 +420,7 @@ int havoc_mi355x_inverse_transform_add(havoc_mi355x_ctx *ctx, int S, int bitDept
                                        int njobs)
 {
     REQUIRE_CTX(); REQUIRE_S(); REQUIRE_BD(); REQUIRE_TR(); REQUIRE(njobs >= 0, "njobs < 0");
-    return check(launch_inverse_transform(ctx->stream, S, bitDepth, log2TrafoSize, trType, d_dst, stride_dst, d_pred, stride_pred, nullptr, d_coeffs,
+    return check(launch_inverse_transform(LS(ctx),S, bitDepth, log2TrafoSize, trType, d_dst, stride_dst, d_pred, stride_pred, nullptr, d_coeffs,
                                           d_jobs, njobs),
                  "inverse_transform_add");
 }
@@ -365,20 +428,20 @@ int havoc_mi355x_inverse_transform_add(havoc_mi355x_ctx *ctx, int S, int bitDept
 int havoc_mi355x_quantize(havoc_mi355x_ctx *ctx, int16_t *d_dst, const int16_t *d_src, const havoc_mi355x_quant_job *d_jobs, int njobs, int32_t *d_cbf)
 {
     REQUIRE_CTX(); REQUIRE(njobs >= 0, "njobs < 0");
-    return check(launch_quantize(ctx->stream, d_dst, d_src, d_jobs, njobs, d_cbf), "quantize");
+    return check(launch_quantize(LS(ctx),d_dst, d_src, d_jobs, njobs, d_cbf), "quantize");
 }
 
 int havoc_mi355x_quantize_inverse(havoc_mi355x_ctx *ctx, int16_t *d_dst, const int16_t *d_src, const havoc_mi355x_quant_job *d_jobs, int njobs)
 {
     REQUIRE_CTX(); REQUIRE(njobs >= 0, "njobs < 0");
-    return check(launch_quantize_inverse(ctx->stream, d_dst, d_src, d_jobs, njobs), "quantize_inverse");
+    return check(launch_quantize_inverse(LS(ctx),d_dst, d_src, d_jobs, njobs), "quantize_inverse");
 }
 
 int havoc_mi355x_quantize_reconstruct(havoc_mi355x_ctx *ctx, int log2TrafoSize, uint8_t *d_rec, intptr_t stride_rec, const uint8_t *d_pred,
                                       intptr_t stride_pred, const int16_t *d_res, const havoc_mi355x_tu_job *d_jobs, int njobs)
 {
     REQUIRE_CTX(); REQUIRE(log2TrafoSize >= 2 && log2TrafoSize <= 5, "log2TrafoSize must be 2..5"); REQUIRE(njobs >= 0, "njobs < 0");
-    return check(launch_quantize_reconstruct(ctx->stream, log2TrafoSize, d_rec, stride_rec, d_pred, stride_pred, d_res, d_jobs, njobs),
+    return check(launch_quantize_reconstruct(LS(ctx),log2TrafoSize, d_rec, stride_rec, d_pred, stride_pred, d_res, d_jobs, njobs),
                  "quantize_reconstruct");
 }
 

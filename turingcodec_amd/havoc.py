@@ -51,6 +51,9 @@ def _load():
         "graph_end": [_vp, C.POINTER(_vp)],
         "graph_launch": [_vp, _vp],
         "graph_destroy": [_vp],
+        "fork": [_vp, _i],
+        "lane": [_vp, _i],
+        "join": [_vp],
         "sad": [_vp, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
         "sad4": [_vp, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
         "ssd": [_vp, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
@@ -132,6 +135,15 @@ class Havoc:
         self._ck(self.L.havoc_mi355x_device_info(self.h, a))
         keys = ["cus", "clock_khz", "mem_clock_khz", "bus_bits", "l2_bytes", "wave", "lds_per_wg", "mem_mib"]
         return dict(zip(keys, [int(x) for x in a]))
+
+    def fork(self, nlanes):
+        self._ck(self.L.havoc_mi355x_fork(self.h, nlanes))
+
+    def lane(self, k):
+        self._ck(self.L.havoc_mi355x_lane(self.h, k))
+
+    def join(self):
+        self._ck(self.L.havoc_mi355x_join(self.h))
 
     def graph_capture(self, fn):
         """record the launches `fn()` issues into a HIP graph; returns a handle for graph_launch"""
