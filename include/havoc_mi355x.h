@@ -167,8 +167,9 @@ int havoc_mi355x_sad4(havoc_mi355x_ctx *ctx, int S, const void *d_src, intptr_t 
 int havoc_mi355x_ssd(havoc_mi355x_ctx *ctx, int S, const void *d_a, intptr_t stride_a, const void *d_b,
                      intptr_t stride_b, const havoc_mi355x_pair_job *d_jobs, int njobs, uint32_t *d_out);
 /* havoc_hadamard_satd<Sample> tiled over a w x h block exactly as measureSatd does (turing/Measure.h:97-135;
- * one 2x2 / 4x4 / 8x8 Hadamard = havoc/hadamard.cpp:58-98 when w == h == n) */
-int havoc_mi355x_satd(havoc_mi355x_ctx *ctx, int S, const void *d_a, intptr_t stride_a, const void *d_b,
+ * one 2x2 / 4x4 / 8x8 Hadamard = havoc/hadamard.cpp:58-98 when w == h == n).  max_w / max_h: upper bounds on the
+ * block sizes of this batch (64, 64 always valid): they choose how many lanes share a job. */
+int havoc_mi355x_satd(havoc_mi355x_ctx *ctx, int S, int max_w, int max_h, const void *d_a, intptr_t stride_a, const void *d_b,
                       intptr_t stride_b, const havoc_mi355x_pair_job *d_jobs, int njobs, int32_t *d_out);
 /* havoc_ssd_linear (havoc/diff.h:35, havoc/diff.cpp:29-39): one linear 8-bit run, *d_out = int32 sum */
 int havoc_mi355x_ssd_linear(havoc_mi355x_ctx *ctx, const uint8_t *d_a, const uint8_t *d_b, int size, int32_t *d_out);
@@ -188,6 +189,15 @@ int havoc_mi355x_pred_bi(havoc_mi355x_ctx *ctx, int S, int taps, int bitDepth, v
 int havoc_mi355x_subtract_bi(havoc_mi355x_ctx *ctx, int S, int bitDepth, void *d_dst, intptr_t stride_dst,
                              const void *d_pred, intptr_t stride_pred, const void *d_src, intptr_t stride_src,
                              const havoc_mi355x_subtract_bi_job *d_jobs, int njobs);
+
+/* The 15 fractional-sample luma planes of a reference picture, computed once per picture: for every (xFrac, yFrac)
+ * in 0..3 x 0..3 except (0,0) and every sample (x, y) of the rectangle [x0, x0+width) x [y0, y0+height) of the
+ * padded picture,   d_planes[(4*yFrac + xFrac) * plane_elems + y*stride + x] = the sample HavocPredUni (8-tap,
+ * havoc/pred_inter.cpp:113-202) produces at (x, y) for that phase.  A sub-pel candidate's prediction block is then a
+ * block of one plane and its cost a plain havoc_mi355x_satd job against it (plane 0 is not written: use d_ref).
+ * The rectangle must leave >= 4 rows and >= 12 samples of the allocation around it (the picture padding does). */
+int havoc_mi355x_interp_planes(havoc_mi355x_ctx *ctx, int S, int bitDepth, void *d_planes, intptr_t plane_elems, const void *d_ref,
+                               intptr_t stride, int x0, int y0, int width, int height);
 
 /* One sub-pel motion candidate, fused: HavocPredUni of the PU at (ref_off, xFrac, yFrac) followed by measureSatd
  * against the source PU -- costDistortionMv (turing/Search.hpp:1965-1998 -> havoc/pred_inter.cpp:113-202 +

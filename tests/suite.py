@@ -231,6 +231,10 @@ def run(impl, d, keys=None):
         k = "u8" if S == 1 else "u16"
         if want(f"{k}.intra35"):
             out[f"{k}.intra35"] = impl.intra_satd35(bd, d[f"{k}.a"], W, d[f"{k}.intra35.nb"], d[f"{k}.intra35.jobs"])
+        if want(f"{k}.planes"):
+            # a rectangle that is not a multiple of the 64x16 kernel tile, inside the 160x160 plane with the required margin
+            out[f"{k}.planes"] = impl.interp_planes(bd, d[f"{k}.a"], W, 5, 6, 139, 141)
+            out[f"{k}.planes.x"] = impl.interp_planes(bd, d[f"{k}.x"], W, 16, 16, 64, 16)
         for taps in (8, 4):
             if want(f"{k}.subpel"):
                 out[f"{k}.subpel{taps}"] = impl.subpel_satd(taps, bd, d[f"{k}.b"], W, d[f"{k}.a"], W, d[f"{k}.subpel{taps}.jobs"])
@@ -310,6 +314,20 @@ class LoopImpl:
             else:
                 self.f.intra(dst, do, sd, nb, no, log2, mode, edge, bd)
         return dst
+
+    def interp_planes(self, bd, ref, stride, x0, y0, width, height):
+        """every sample of plane (xf, yf) = what pred_uni writes there when the sample is part of any block: evaluate
+        pred_uni on <= 64x64 blocks tiling the rectangle"""
+        planes = np.zeros((16, len(ref)), ref.dtype)
+        for yf in range(4):
+            for xf in range(4):
+                if xf == 0 and yf == 0:
+                    continue
+                for by in range(y0, y0 + height, 64):
+                    for bx in range(x0, x0 + width, 64):
+                        w, h = min(64, x0 + width - bx), min(64, y0 + height - by)
+                        self.f.pred_uni(planes[4 * yf + xf], by * stride + bx, stride, ref, by * stride + bx, stride, w, h, xf, yf, bd, 8)
+        return planes
 
     def subpel_satd(self, taps, bd, src, ss, ref, sr, jobs):
         """costDistortionMv (turing/Search.hpp:1965-1998): pred_uni into a 64-stride scratch block, then measureSatd"""

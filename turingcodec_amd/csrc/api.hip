@@ -8,13 +8,14 @@
 namespace havoc_gpu {
 hipError_t launch_sad(hipStream_t, int S, int ways, const void *, long, const void *, long, const void *, int, int32_t *);
 hipError_t launch_ssd(hipStream_t, int S, const void *, long, const void *, long, const void *, int, uint32_t *);
-hipError_t launch_satd(hipStream_t, int S, const void *, long, const void *, long, const void *, int, int32_t *);
+hipError_t launch_satd(hipStream_t, int S, int maxw, int maxh, const void *, long, const void *, long, const void *, int, int32_t *);
 hipError_t launch_ssd_linear(hipStream_t, const uint8_t *, const uint8_t *, int, int32_t *);
 hipError_t launch_pred_uni(hipStream_t, int S, int taps, int bd, void *, long, const void *, long, const void *, int);
 hipError_t launch_pred_bi(hipStream_t, int S, int taps, int bd, void *, long, const void *, long, const void *, int);
 hipError_t launch_subtract_bi(hipStream_t, int S, int bd, void *, long, const void *, long, const void *, long, const void *, int);
 hipError_t launch_intra(hipStream_t, int S, int log2, int bd, void *, long, const void *, const void *, int);
 hipError_t launch_intra_satd35(hipStream_t, int S, int log2, int bd, const void *, long, const void *, const void *, int, int32_t *);
+hipError_t launch_interp_planes(hipStream_t, int S, int bd, void *, long, const void *, long, int, int, int, int);
 hipError_t launch_subpel_satd(hipStream_t, int S, int taps, int bd, int maxw, int maxh, const void *, long, const void *, long, const void *, int,
                               int32_t *);
 hipError_t launch_transform(hipStream_t, int bd, int log2, int tr, int16_t *, const int16_t *, long, const void *, int);
@@ -324,11 +325,12 @@ int havoc_mi355x_ssd(havoc_mi355x_ctx *ctx, int S, const void *d_a, intptr_t str
     return check(launch_ssd(LS(ctx),S, d_a, stride_a, d_b, stride_b, d_jobs, njobs, d_out), "ssd");
 }
 
-int havoc_mi355x_satd(havoc_mi355x_ctx *ctx, int S, const void *d_a, intptr_t stride_a, const void *d_b, intptr_t stride_b,
+int havoc_mi355x_satd(havoc_mi355x_ctx *ctx, int S, int max_w, int max_h, const void *d_a, intptr_t stride_a, const void *d_b, intptr_t stride_b,
                       const havoc_mi355x_pair_job *d_jobs, int njobs, int32_t *d_out)
 {
     REQUIRE_CTX(); REQUIRE_S(); REQUIRE(njobs >= 0, "njobs < 0");
-    return check(launch_satd(LS(ctx),S, d_a, stride_a, d_b, stride_b, d_jobs, njobs, d_out), "satd");
+    REQUIRE(max_w >= 2 && max_w <= 64 && max_h >= 2 && max_h <= 64, "max_w / max_h must be 2..64");
+    return check(launch_satd(LS(ctx),S, max_w, max_h, d_a, stride_a, d_b, stride_b, d_jobs, njobs, d_out), "satd");
 }
 
 int havoc_mi355x_ssd_linear(havoc_mi355x_ctx *ctx, const uint8_t *d_a, const uint8_t *d_b, int size, int32_t *d_out)
@@ -358,6 +360,14 @@ int havoc_mi355x_subtract_bi(havoc_mi355x_ctx *ctx, int S, int bitDepth, void *d
 {
     REQUIRE_CTX(); REQUIRE_S(); REQUIRE_BD(); REQUIRE(njobs >= 0, "njobs < 0");
     return check(launch_subtract_bi(LS(ctx),S, bitDepth, d_dst, stride_dst, d_pred, stride_pred, d_src, stride_src, d_jobs, njobs), "subtract_bi");
+}
+
+int havoc_mi355x_interp_planes(havoc_mi355x_ctx *ctx, int S, int bitDepth, void *d_planes, intptr_t plane_elems, const void *d_ref, intptr_t stride,
+                               int x0, int y0, int width, int height)
+{
+    REQUIRE_CTX(); REQUIRE_S(); REQUIRE_BD(); REQUIRE(x0 >= 3 && y0 >= 3 && width >= 0 && height >= 0, "rectangle must start >= 3 samples in");
+    REQUIRE(x0 + width + 12 <= stride, "rectangle must end >= 12 samples before the row end");
+    return check(launch_interp_planes(LS(ctx), S, bitDepth, d_planes, plane_elems, d_ref, stride, x0, y0, width, height), "interp_planes");
 }
 
 int havoc_mi355x_subpel_satd(havoc_mi355x_ctx *ctx, int S, int taps, int bitDepth, int max_w, int max_h, const void *d_src, intptr_t stride_src,

@@ -163,7 +163,7 @@ int satd(const Sample *pa, intptr_t sa, const Sample *pb, intptr_t sb)
     const size_t a = s.pack(pa, sa, N, N, N), b = s.pack(pb, sb, N, N, N);
     *s.job<havoc_mi355x_pair_job>(j) = {0, 0, N, N};
     s.upload();
-    CK(havoc_mi355x_satd(s.ctx, sizeof(Sample), s.d + a, N, s.d + b, N, s.djob<havoc_mi355x_pair_job>(j), 1, (int32_t *)(s.d + o)));
+    CK(havoc_mi355x_satd(s.ctx, sizeof(Sample), N, N, s.d + a, N, s.d + b, N, s.djob<havoc_mi355x_pair_job>(j), 1, (int32_t *)(s.d + o)));
     s.download(o, 4);
     return *reinterpret_cast<int32_t *>(&s.h[o]);
 }

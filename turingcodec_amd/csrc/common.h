@@ -47,6 +47,16 @@ __device__ __forceinline__ int wave_sum(int v)
     return __builtin_amdgcn_readlane(v, 63);
 }
 
+// sum over each aligned row of 16 lanes; valid in lane 15 of the row (first four steps of wave_sum)
+__device__ __forceinline__ int row16_sum(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xe, true);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xc, true);  // row_shr:8
+    return v;
+}
+
 // sum within aligned groups of G consecutive lanes (G = power of two <= 64); every lane of the group gets the sum
 template <int G>
 __device__ __forceinline__ int group_sum(int v)

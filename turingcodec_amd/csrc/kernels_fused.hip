@@ -56,8 +56,12 @@ __global__ __launch_bounds__(THREADS) void k_intra_satd35(const char *__restrict
     constexpr int RL = 3 * N + 2;            // projected reference: indices -N .. 2N (+1 slack)
     constexpr int PT = P * NT;               // (partition, tile) pairs per workgroup
 
-    __shared__ uint16_t s_src[P][N * N];     // row-major source block
-    __shared__ uint16_t s_srcT[P][N * N];    // transposed source block
+    // row stride N+2 and a per-partition skew keep tiles of different rows / partitions on different LDS banks
+    // (with dense N*N blocks every partition and every 8-row band started on bank 0: 10-way conflicts on 16x16)
+    constexpr int NS = N + 2;
+    constexpr int SB = N * NS + 6;
+    __shared__ uint16_t s_src[P][SB];        // row-major source block
+    __shared__ uint16_t s_srcT[P][SB];       // transposed source block
     __shared__ uint16_t s_nb[P][2][NB + 1];  // [0] unfiltered, [1] filtered; index i <-> neighbours[i - 2N - 1]
     __shared__ uint16_t s_ref[P][33][RL];    // angular modes 2..34; ref[i] at [i + N]
     __shared__ int s_dc[P][2];
@@ -97,8 +101,8 @@ __global__ __launch_bounds__(THREADS) void k_intra_satd35(const char *__restrict
 #pragma unroll
         for (int k = 0; k < 4; ++k)
         {
-            s_src[p][y * N + x + k] = v[k];
-            s_srcT[p][(x + k) * N + y] = v[k];
+            s_src[p][y * NS + x + k] = v[k];
+            s_srcT[p][(x + k) * NS + y] = v[k];
         }
     }
     for (int i = lane; i < P * 2 * NB; i += THREADS)
@@ -180,7 +184,7 @@ __global__ __launch_bounds__(THREADS) void k_intra_satd35(const char *__restrict
                         const int side = vertical ? nb[2 * N - 1 - (maj0 + j)] : nb[2 * N + 1 + (maj0 + j)];
                         v = clip3(0, maxv, (int)ref[1] + ((side - (int)ref[0]) >> 1));
                     }
-                    d[j][i] = (int)sb[(maj0 + j) * N + min0 + i] - v;
+                    d[j][i] = (int)sb[(maj0 + j) * NS + min0 + i] - v;
                 }
             }
         }
@@ -200,7 +204,7 @@ __global__ __launch_bounds__(THREADS) void k_intra_satd35(const char *__restrict
                         else if (y == 0) v = ((int)nb[2 * N + 1 + x] + 3 * dc + 2) >> 2;
                         else if (x == 0) v = ((int)nb[2 * N - 1 - y] + 3 * dc + 2) >> 2;
                     }
-                    d[j][i] = (int)s_src[p][y * N + x] - v;
+                    d[j][i] = (int)s_src[p][y * NS + x] - v;
                 }
         }
         else
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(THREADS) void k_intra_satd35(const char *__restrict
                 {
                     const int x = tx * TS + i;
                     const int v = ((N - 1 - x) * left + (x + 1) * topR + (N - 1 - y) * (int)nb[2 * N + 1 + x] + (y + 1) * botL + N) >> (LOG2 + 1);
-                    d[j][i] = (int)s_src[p][y * N + x] - v;
+                    d[j][i] = (int)s_src[p][y * NS + x] - v;
                 }
             }
         }

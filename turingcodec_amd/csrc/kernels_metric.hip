@@ -21,15 +21,20 @@ __device__ __forceinline__ uint32_t sad_dword(uint32_t a, uint32_t b, uint32_t a
 }
 
 // accumulate |src - ref_k| over a w x h block.  CB = bytes per lane chunk (4, 8, 16); rowBytes % CB == 0.
+// 16 lanes (one DPP row) per job, four jobs per wavefront: a 16x16 8-bit block is exactly one 16-byte chunk per lane,
+// 8x8 uses half a row, 64x64 takes 16 steps; the per-job cost (job fetch, address set-up, reduction) is shared four ways
+constexpr int kSadLanes = 16;
+
 template <int S, int WAYS, int CB>
 __device__ __forceinline__ void sad_block(const char *src, long ssb, const char *const (&ref)[WAYS], long rsb, int rowBytes, int h,
                                           int lane, uint32_t (&acc)[WAYS])
 {
     const int cpr = rowBytes / CB;      // chunks per row: 1, 2, 3, 4, 6 or 8
-    const int rpi = kWave / cpr;        // rows per iteration
+    const int rpi = kSadLanes / cpr;    // rows per iteration
     const int y0 = lane / cpr;
     const int xb = (lane - y0 * cpr) * CB;
     if (y0 >= rpi) return;              // lanes beyond rpi*cpr idle (cpr = 3, 6)
+#pragma unroll 4                        // several rows' loads in flight: the loop is latency-, not issue-bound
     for (int y = y0; y < h; y += rpi)
     {
         const char *s = src + y * ssb + xb;
@@ -71,23 +76,23 @@ __global__ __launch_bounds__(256) void k_sad(const char *__restrict__ src, long 
                                              const int32_t *__restrict__ jobs, int njobs, int32_t *__restrict__ out)
 {
     typedef typename Sample<S>::T T;
-    const int job = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (job >= njobs) return;
+    const int job = (blockIdx.x * 256 + threadIdx.x) / kSadLanes;
+    const int lane = threadIdx.x & (kSadLanes - 1);
+    const bool live = job < njobs;
     int so, w, h;
     int ro[WAYS];
     if (WAYS == 1)
     {
-        const int32_t *j = jobs + job * 4;   // havoc_mi355x_pair_job
-        so = j[0]; ro[0] = j[1]; w = j[2]; h = j[3];
+        const int32_t *j = jobs + (long)(live ? job : 0) * 4;   // havoc_mi355x_pair_job
+        so = j[0]; ro[0] = j[1]; w = j[2]; h = live ? j[3] : 0;
     }
     else
     {
-        const int32_t *j = jobs + job * 8;   // havoc_mi355x_sad4_job
+        const int32_t *j = jobs + (long)(live ? job : 0) * 8;   // havoc_mi355x_sad4_job
         so = j[0];
 #pragma unroll
         for (int k = 0; k < WAYS; ++k) ro[k] = j[1 + k];
-        w = j[5]; h = j[6];
+        w = j[5]; h = live ? j[6] : 0;
     }
     const long ssb = stride_src * S, rsb = stride_ref * S;
     const char *s = src + (long)so * S;
@@ -106,7 +111,7 @@ __global__ __launch_bounds__(256) void k_sad(const char *__restrict__ src, long 
     {
         // generic widths (the reference's sadGeneric entry): one sample per lane per step
         const FastDiv fd(w);
-        for (int i = lane; i < w * h; i += kWave)
+        for (int i = lane; i < w * h; i += kSadLanes)
         {
             const int y = fd.div(i), x = i - y * w;
             const int a = reinterpret_cast<const T *>(s + y * ssb)[x];
@@ -117,9 +122,9 @@ __global__ __launch_bounds__(256) void k_sad(const char *__restrict__ src, long 
 #pragma unroll
     for (int k = 0; k < WAYS; ++k)
     {
-        int t = wave_sum((int)acc[k]);
+        int t = row16_sum((int)acc[k]);   // lane 15 of each 16-lane row holds its job's total
         if (S == 2) t >>= 2;
-        if (lane == 0) out[job * WAYS + k] = t;
+        if (live && lane == kSadLanes - 1) out[job * WAYS + k] = t;
     }
 }
 
@@ -187,25 +192,11 @@ __global__ __launch_bounds__(256) void k_ssd(const char *__restrict__ pa, long s
 
 // ---------------------------------------------------------------------------------------------------------
 // Hadamard SATD  (reference: havoc/hadamard.cpp:58-98; PU tiling: turing/Measure.h:97-135)
-// One lane owns one n x n tile: it loads the tile's rows of both operands, takes differences, runs the 2-D
-// butterfly network in registers and sums |coefficients|.  A wave covers up to 64 tiles of its job per step.
+// One tile ROW per lane: the lane loads its 8 (4) samples of both operands with one unaligned vector load each,
+// takes the differences, transforms them in registers, and the 8 (4) lanes of a tile finish the transform with DPP
+// mirror butterflies (common.h, satd_rows).  G = 8 / 16 / 32 / 64 lanes work on one job (chosen from the batch's
+// max block size), so a wavefront carries 8 jobs of 8x8 or one job of 64x64 with every lane busy.
 // ---------------------------------------------------------------------------------------------------------
-
-template <int N>
-__device__ __forceinline__ void wht(int (&v)[N])
-{
-#pragma unroll
-    for (int len = 1; len < N; len <<= 1)
-#pragma unroll
-        for (int i = 0; i < N; i += len << 1)
-#pragma unroll
-            for (int k = i; k < i + len; ++k)
-            {
-                const int a = v[k], b = v[k + len];
-                v[k] = a + b;
-                v[k + len] = a - b;
-            }
-}
 
 template <int S, int N>
 __device__ __forceinline__ void load_diff_row(const char *a, const char *b, int (&d)[N])
@@ -222,16 +213,11 @@ __device__ __forceinline__ void load_diff_row(const char *a, const char *b, int 
                 d[x + 4] = (int)((va.y >> (8 * x)) & 0xff) - (int)((vb.y >> (8 * x)) & 0xff);
             }
         }
-        else if (N == 4)
+        else
         {
             const uint32_t va = ld4(a), vb = ld4(b);
 #pragma unroll
             for (int x = 0; x < 4; ++x) d[x] = (int)((va >> (8 * x)) & 0xff) - (int)((vb >> (8 * x)) & 0xff);
-        }
-        else
-        {
-#pragma unroll
-            for (int x = 0; x < N; ++x) d[x] = (int)(uint8_t)a[x] - (int)(uint8_t)b[x];
         }
     }
     else
@@ -247,7 +233,7 @@ __device__ __forceinline__ void load_diff_row(const char *a, const char *b, int 
                 d[2 * x + 1] = (int)(wa[x] >> 16) - (int)(wb[x] >> 16);
             }
         }
-        else if (N == 4)
+        else
         {
             const u32x2 va = ld8(a), vb = ld8(b);
             d[0] = (int)(va.x & 0xffff) - (int)(vb.x & 0xffff);
@@ -255,73 +241,67 @@ __device__ __forceinline__ void load_diff_row(const char *a, const char *b, int 
             d[2] = (int)(va.y & 0xffff) - (int)(vb.y & 0xffff);
             d[3] = (int)(va.y >> 16) - (int)(vb.y >> 16);
         }
-        else
-        {
-            const uint32_t va = ld4(a), vb = ld4(b);
-            d[0] = (int)(va & 0xffff) - (int)(vb & 0xffff);
-            d[1] = (int)(va >> 16) - (int)(vb >> 16);
-        }
     }
 }
 
-// SATD of one N x N tile, normalised and scaled exactly like compute_satd_c_ref<N>
-template <int S, int N>
-__device__ __forceinline__ int satd_tile(const char *a, long sab, const char *b, long sbb)
-{
-    int m[N][N];
-#pragma unroll
-    for (int y = 0; y < N; ++y)
-    {
-        load_diff_row<S, N>(a + y * sab, b + y * sbb, m[y]);
-        wht<N>(m[y]);
-    }
-    int sum = N / 4;
-#pragma unroll
-    for (int x = 0; x < N; ++x)
-    {
-        int col[N];
-#pragma unroll
-        for (int y = 0; y < N; ++y) col[y] = m[y][x];
-        wht<N>(col);
-#pragma unroll
-        for (int y = 0; y < N; ++y) sum += abs(col[y]);
-    }
-    sum /= N / 2;       // sum >= 0: a shift
-    return S == 2 ? sum >> 2 : sum;
-}
-
-template <int S, int N>
-__device__ __forceinline__ int satd_tiles(const char *a, long sab, const char *b, long sbb, int w, int h, int lane)
-{
-    const int tw = w / N, th = h / N;
-    const FastDiv fd(tw);
-    int acc = 0;
-    for (int t = lane; t < tw * th; t += kWave)
-    {
-        const int ty = fd.div(t), tx = t - ty * tw;
-        acc += satd_tile<S, N>(a + (long)ty * N * sab + tx * N * S, sab, b + (long)ty * N * sbb + tx * N * S, sbb);
-    }
-    return acc;
-}
-
-template <int S>
+template <int S, int G>
 __global__ __launch_bounds__(256) void k_satd(const char *__restrict__ pa, long stride_a, const char *__restrict__ pb, long stride_b,
                                               const int32_t *__restrict__ jobs, int njobs, int32_t *__restrict__ out)
 {
-    const int job = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (job >= njobs) return;
-    const int32_t *j = jobs + job * 4;
-    const int w = j[2], h = j[3];
+    typedef typename Sample<S>::T T;
+    const int job = (blockIdx.x * 256 + threadIdx.x) / G;
+    const int l = threadIdx.x & (G - 1);
+    const bool live = job < njobs;
+    const int32_t *j = jobs + (long)(live ? job : 0) * 4;
+    const int w = j[2], h = live ? j[3] : 0;
     const long sab = stride_a * S, sbb = stride_b * S;
     const char *a = pa + (long)j[0] * S;
     const char *b = pb + (long)j[1] * S;
-    int acc;
-    if ((w | h) & 3) acc = satd_tiles<S, 2>(a, sab, b, sbb, w, h, lane);        // turing/Measure.h:100-111
-    else if ((w | h) & 7) acc = satd_tiles<S, 4>(a, sab, b, sbb, w, h, lane);   // :112-122
-    else acc = satd_tiles<S, 8>(a, sab, b, sbb, w, h, lane);                    // :123-133
-    const int t = wave_sum(acc);
-    if (lane == 0) out[job] = t;
+    int acc = 0;
+    if (((w | h) & 7) == 0)
+    {   // 8x8 tiles (turing/Measure.h:123-133)
+        const int tw = w >> 3;
+        const FastDiv fd(tw);
+        for (int it = l; it < tw * (h >> 3) * 8; it += G)
+        {
+            const int tile = it >> 3, r = it & 7;
+            const int ty = fd.div(tile), tx = tile - ty * tw;
+            int d[8];
+            load_diff_row<S, 8>(a + (long)(ty * 8 + r) * sab + tx * 8 * S, b + (long)(ty * 8 + r) * sbb + tx * 8 * S, d);
+            acc += satd_rows<S, 8>(d, r);
+        }
+    }
+    else if (((w | h) & 3) == 0)
+    {   // 4x4 tiles (:112-122)
+        const int tw = w >> 2;
+        const FastDiv fd(tw);
+        for (int it = l; it < tw * (h >> 2) * 4; it += G)
+        {
+            const int tile = it >> 2, r = it & 3;
+            const int ty = fd.div(tile), tx = tile - ty * tw;
+            int d[4];
+            load_diff_row<S, 4>(a + (long)(ty * 4 + r) * sab + tx * 4 * S, b + (long)(ty * 4 + r) * sbb + tx * 4 * S, d);
+            acc += satd_rows<S, 4>(d, r);
+        }
+    }
+    else
+    {   // 2x2 tiles (:100-111): one tile per lane, no normalisation
+        const int tw = w >> 1;
+        const FastDiv fd(tw);
+        for (int t = l; t < tw * (h >> 1); t += G)
+        {
+            const int ty = fd.div(t), tx = t - ty * tw;
+            const T *p = reinterpret_cast<const T *>(a + (long)(2 * ty) * sab) + 2 * tx;
+            const T *q = reinterpret_cast<const T *>(b + (long)(2 * ty) * sbb) + 2 * tx;
+            const int d0 = (int)p[0] - (int)q[0], d1 = (int)p[1] - (int)q[1];
+            const int d2 = (int)p[stride_a] - (int)q[stride_b], d3 = (int)p[stride_a + 1] - (int)q[stride_b + 1];
+            int sum = abs(d0 + d1 + d2 + d3) + abs(d0 - d1 + d2 - d3) + abs(d0 + d1 - d2 - d3) + abs(d0 - d1 - d2 + d3);
+            if (S == 2) sum >>= 2;
+            acc += sum;
+        }
+    }
+    const int t = G == 64 ? wave_sum(acc) : group_sum<G>(acc);
+    if (live && l == 0) out[job] = t;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -356,10 +336,11 @@ hipError_t launch_sad(hipStream_t st, int S, int ways, const void *src, long ss,
     if (n <= 0) return hipSuccess;
     const char *s = (const char *)src, *r = (const char *)ref;
     const int32_t *j = (const int32_t *)jobs;
-    if (S == 1 && ways == 1) LAUNCH4((k_sad<1, 1>), n, st, s, ss, r, rs, j, n, out);
-    else if (S == 2 && ways == 1) LAUNCH4((k_sad<2, 1>), n, st, s, ss, r, rs, j, n, out);
-    else if (S == 1 && ways == 4) LAUNCH4((k_sad<1, 4>), n, st, s, ss, r, rs, j, n, out);
-    else if (S == 2 && ways == 4) LAUNCH4((k_sad<2, 4>), n, st, s, ss, r, rs, j, n, out);
+    const dim3 g((n + 256 / kSadLanes - 1) / (256 / kSadLanes)), b(256);
+    if (S == 1 && ways == 1) hipLaunchKernelGGL((k_sad<1, 1>), g, b, 0, st, s, ss, r, rs, j, n, out);
+    else if (S == 2 && ways == 1) hipLaunchKernelGGL((k_sad<2, 1>), g, b, 0, st, s, ss, r, rs, j, n, out);
+    else if (S == 1 && ways == 4) hipLaunchKernelGGL((k_sad<1, 4>), g, b, 0, st, s, ss, r, rs, j, n, out);
+    else if (S == 2 && ways == 4) hipLaunchKernelGGL((k_sad<2, 4>), g, b, 0, st, s, ss, r, rs, j, n, out);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
@@ -372,11 +353,20 @@ hipError_t launch_ssd(hipStream_t st, int S, const void *a, long sa, const void 
     return hipGetLastError();
 }
 
-hipError_t launch_satd(hipStream_t st, int S, const void *a, long sa, const void *b, long sb, const void *jobs, int n, int32_t *out)
+hipError_t launch_satd(hipStream_t st, int S, int maxw, int maxh, const void *a, long sa, const void *b, long sb, const void *jobs, int n,
+                       int32_t *out)
 {
     if (n <= 0) return hipSuccess;
-    if (S == 1) LAUNCH4((k_satd<1>), n, st, (const char *)a, sa, (const char *)b, sb, (const int32_t *)jobs, n, out);
-    else LAUNCH4((k_satd<2>), n, st, (const char *)a, sa, (const char *)b, sb, (const int32_t *)jobs, n, out);
+    const char *x = (const char *)a, *y = (const char *)b;
+    const int32_t *j = (const int32_t *)jobs;
+    // lanes per job: one per 8-sample row of the largest block in the batch (8x8 -> 8 ... 64x64 -> 64, looping 8 times)
+    const int rows = ((maxw + 7) / 8) * maxh;
+    const int G = rows <= 8 ? 8 : rows <= 16 ? 16 : rows <= 32 ? 32 : 64;
+    const dim3 g((n + 256 / G - 1) / (256 / G)), b256(256);
+#define SATD_GO(SS, GG) hipLaunchKernelGGL((k_satd<SS, GG>), g, b256, 0, st, x, sa, y, sb, j, n, out)
+    if (S == 1) { if (G == 8) SATD_GO(1, 8); else if (G == 16) SATD_GO(1, 16); else if (G == 32) SATD_GO(1, 32); else SATD_GO(1, 64); }
+    else { if (G == 8) SATD_GO(2, 8); else if (G == 16) SATD_GO(2, 16); else if (G == 32) SATD_GO(2, 32); else SATD_GO(2, 64); }
+#undef SATD_GO
     return hipGetLastError();
 }
 

@@ -57,7 +57,7 @@ def _load():
         "sad": [_vp, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
         "sad4": [_vp, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
         "ssd": [_vp, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
-        "satd": [_vp, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
+        "satd": [_vp, _i, _i, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
         "ssd_linear": [_vp, _vp, _vp, _i, _vp],
         "pred_uni": [_vp, _i, _i, _i, _vp, _ip, _vp, _ip, _vp, _i],
         "pred_bi": [_vp, _i, _i, _i, _vp, _ip, _vp, _ip, _vp, _i],
@@ -65,6 +65,7 @@ def _load():
         "intra": [_vp, _i, _i, _i, _vp, _ip, _vp, _vp, _i],
         "intra_satd35": [_vp, _i, _i, _i, _vp, _ip, _vp, _vp, _i, _vp],
         "subpel_satd": [_vp, _i, _i, _i, _i, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
+        "interp_planes": [_vp, _i, _i, _vp, _ip, _vp, _ip, _i, _i, _i, _i],
         "residual": [_vp, _i, _vp, _ip, _vp, _vp, _ip, _vp, _ip, _vp, _i],
         "transform": [_vp, _i, _i, _i, _vp, _vp, _ip, _vp, _i],
         "inverse_transform": [_vp, _i, _i, _i, _vp, _vp, _vp, _i],
@@ -203,8 +204,8 @@ class Havoc:
     def ssd_d(self, a, sa, b, sb, jobs, out):
         self._ck(self.L.havoc_mi355x_ssd(self.h, self._S(a), _ptr(a), sa, _ptr(b), sb, _ptr(jobs), jobs.shape[0], _ptr(out)))
 
-    def satd_d(self, a, sa, b, sb, jobs, out):
-        self._ck(self.L.havoc_mi355x_satd(self.h, self._S(a), _ptr(a), sa, _ptr(b), sb, _ptr(jobs), jobs.shape[0], _ptr(out)))
+    def satd_d(self, a, sa, b, sb, jobs, out, max_w=64, max_h=64):
+        self._ck(self.L.havoc_mi355x_satd(self.h, self._S(a), max_w, max_h, _ptr(a), sa, _ptr(b), sb, _ptr(jobs), jobs.shape[0], _ptr(out)))
 
     def pred_uni_d(self, taps, bd, dst, sd, ref, sr, jobs):
         self._ck(self.L.havoc_mi355x_pred_uni(self.h, self._S(ref), taps, bd, _ptr(dst), sd, _ptr(ref), sr, _ptr(jobs), jobs.shape[0]))
@@ -217,6 +218,15 @@ class Havoc:
 
     def intra_d(self, bd, log2, dst, sd, nb, jobs):
         self._ck(self.L.havoc_mi355x_intra(self.h, self._S(nb), bd, log2, _ptr(dst), sd, _ptr(nb), _ptr(jobs), jobs.shape[0]))
+
+    def interp_planes_d(self, bd, planes, plane_elems, ref, stride, x0, y0, width, height):
+        self._ck(self.L.havoc_mi355x_interp_planes(self.h, self._S(ref), bd, _ptr(planes), plane_elems, _ptr(ref), stride, x0, y0, width, height))
+
+    def interp_planes(self, bd, ref, stride, x0, y0, width, height):
+        """numpy level: returns the 16 planes as an array [16, len(ref)] (plane 0 and everything outside the rectangle 0)"""
+        planes = self.zeros(16 * len(ref), ref.dtype)
+        self.interp_planes_d(bd, planes, len(ref), self.up(ref), stride, x0, y0, width, height)
+        return self.down(planes, ref.dtype).reshape(16, -1)
 
     def subpel_satd_d(self, taps, bd, max_w, max_h, src, ss, ref, sr, jobs, cost):
         self._ck(self.L.havoc_mi355x_subpel_satd(self.h, self._S(ref), taps, bd, max_w, max_h, _ptr(src), ss, _ptr(ref), sr, _ptr(jobs),
@@ -284,9 +294,18 @@ class Havoc:
         return self.down(out, np.uint32)
 
     def satd(self, a, sa, b, sb, jobs):
-        out = self.zeros(len(jobs), np.int32)
-        self.satd_d(self.up(a), sa, self.up(b), sb, self._jobs(jobs, 4), out)
-        return self.down(out, np.int32)
+        """one launch per lane-group class so that every group size (8 / 16 / 32 / 64 lanes per job) is exercised"""
+        jobs = np.asarray(jobs, np.int32)
+        out = np.zeros(len(jobs), np.int32)
+        ad, bdv = self.up(a), self.up(b)
+        rows = ((jobs[:, 2] + 7) // 8) * jobs[:, 3]
+        for lo, hi, mw, mh in ((0, 8, 8, 8), (8, 16, 16, 8), (16, 32, 16, 16), (32, 1 << 30, 64, 64)):
+            idx = np.flatnonzero((rows > lo) & (rows <= hi))
+            if len(idx):
+                o = self.zeros(len(idx), np.int32)
+                self.satd_d(ad, sa, bdv, sb, self._jobs(jobs[idx], 4), o, mw, mh)
+                out[idx] = self.down(o, np.int32)
+        return out
 
     def ssd_linear(self, a, b, n):
         out = self.zeros(1, np.int32)
