@@ -41,6 +41,8 @@ def parse_args():
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--kernel-reps", type=int, default=5)
     ap.add_argument("--lanes", type=int, default=8, help="fork/join lanes: independent launch chains overlap on the GPU")
+    ap.add_argument("--subpel", choices=["planes", "fused"], default="planes",
+                    help="sub-pel candidates: SATD against per-picture phase planes (default) or the fused per-candidate kernel")
     return ap.parse_args()
 
 
@@ -51,9 +53,9 @@ def parse_args():
 class DeviceFrame:
     """A FrameWorkload uploaded to HBM + the list of launches that make one step."""
 
-    def __init__(self, hv, wl):
+    def __init__(self, hv, wl, use_planes=True):
         import torch
-        self.hv, self.wl = hv, wl
+        self.hv, self.wl, self.use_planes = hv, wl, use_planes
         up = hv.up
         dt = wl.dtype
         S = wl.S
@@ -74,6 +76,12 @@ class DeviceFrame:
         self.j_satd = up(wl.satd_inter)
         self.o_satd = z(len(wl.satd_inter), np.int32)
         self.subpel = {hi: dict(jobs=up(j), cost=z(len(j), np.int32)) for hi, j in wl.subpel.items() if len(j)}
+        if self.use_planes:
+            pl = wl.plane_len
+            self.planes = z(32 * pl, dt)                       # [ref L0 | ref L1] x 16 phase planes
+            self.planes[0:pl].copy_(self.luma[pl:2 * pl])      # slot 0 of each reference = the picture itself
+            self.planes[16 * pl:17 * pl].copy_(self.luma[2 * pl:3 * pl])
+            self.subpel_planes = {c: dict(jobs=up(j), cost=z(len(j), np.int32)) for c, j in wl.subpel_planes.items() if len(j)}
         self.intra = {}
         for log2, j in wl.intra.items():
             if len(j):
@@ -128,8 +136,19 @@ class DeviceFrame:
 
         chain(("sad4", lambda: hv.sad4_d(self.luma, st, self.luma, st, self.j_sad4, self.o_sad4)))
         chain(("sad", lambda: hv.sad_d(self.luma, st, self.luma, st, self.j_sad, self.o_sad)))
-        for hi, g in sorted(self.subpel.items(), reverse=True):
-            chain(("subpel_satd", lambda g=g, hi=hi: hv.subpel_satd_d(8, bd, hi, hi, self.luma, st, self.luma, st, g["jobs"], g["cost"])))
+        if self.use_planes:
+            # sub-pel candidates against phase planes: interpolate each reference picture once (streaming, HBM-bound),
+            # then every candidate is one SATD job between the source PU and a block of the right plane
+            pl, m = wl.plane_len, wl.plane_margin
+            x0, y0, rw, rh = 96 - m, 96 - m, wl.width + 2 * m, wl.height + 2 * m
+            items = [("interp_planes", lambda r=r: hv.interp_planes_d(bd, self.planes[16 * r * pl:], pl, self.luma[(1 + r) * pl:], st, x0, y0, rw, rh))
+                     for r in (0, 1)]
+            for (mw, mh), g in sorted(self.subpel_planes.items(), reverse=True):
+                items.append(("satd_planes", lambda g=g, mw=mw, mh=mh: hv.satd_d(self.luma, st, self.planes, st, g["jobs"], g["cost"], mw, mh)))
+            chain(*items)
+        else:
+            for hi, g in sorted(self.subpel.items(), reverse=True):
+                chain(("subpel_satd", lambda g=g, hi=hi: hv.subpel_satd_d(8, bd, hi, hi, self.luma, st, self.luma, st, g["jobs"], g["cost"])))
         chain(("pred_uni8", lambda: hv.pred_uni_d(8, bd, self.pred, 64, self.luma, st, self.j_uni8)),
               ("satd_inter", lambda: hv.satd_d(self.luma, st, self.pred, 64, self.j_satd, self.o_satd)))
         chain(("pred_uni4", lambda: hv.pred_uni_d(4, bd, self.cpred, 32, self.chroma, cst, self.j_uni4)))
@@ -190,7 +209,7 @@ class DeviceFrame:
         bufs = [self.o_sad4, self.o_sad, self.o_satd, self.pred, self.cpred, self.bi, self.sbi]
         for g in self.intra.values():
             bufs += [g["dst"]]
-        for g in list(self.isearch.values()) + list(self.subpel.values()):
+        for g in list(self.isearch.values()) + list(self.subpel_planes.values() if self.use_planes else self.subpel.values()):
             bufs += [g["cost"]]
         for g in self.tu.values():
             bufs += [g["res"], g["coef"], g["deq"], g["rec"], g["ossd"]]
@@ -387,7 +406,7 @@ def main():
     hv = Havoc(local, stream="new")   # private stream: the step is captured into a HIP graph and replayed
     w, h = (int(v) for v in args.res.split("x"))
     wl = FrameWorkload(w, h, args.bit_depth, args.seed + rank)   # every rank owns a different picture
-    dev = DeviceFrame(hv, wl)
+    dev = DeviceFrame(hv, wl, use_planes=(args.subpel == "planes"))
     exch = None
     if world > 1:
         from turingcodec_amd.frame_parallel import ReferenceExchange

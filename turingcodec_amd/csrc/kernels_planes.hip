@@ -19,12 +19,15 @@
 
 namespace havoc_gpu {
 
+constexpr int kPlaneTileW = 64;   // output tile width (64 or 128)
+
 template <int S>
 __global__ __launch_bounds__(256) void k_interp_planes(char *__restrict__ planes, long plane_elems, const char *__restrict__ ref, long stride,
                                                        int x0, int y0, int x1, int y1, int bitDepth)
 {
     typedef typename Sample<S>::T T;
-    constexpr int TW = 64, THT = 16, COL = 24;   // column of intermediates: THT + 7 = 23 -> 24 (16-byte multiple)
+    constexpr int TW = kPlaneTileW, THT = 16, COL = 24;   // column of intermediates: THT + 7 = 23 -> 24 (16-byte multiple)
+    constexpr int CPL = TW / 64;                          // columns per lane (measured: 1 -> 24.5 us, 2 -> 31 us per 1080p plane set)
     __shared__ __attribute__((aligned(16))) int16_t s_t[4][TW * COL];
 
     const int xf = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -37,9 +40,9 @@ __global__ __launch_bounds__(256) void k_interp_planes(char *__restrict__ planes
     {
         int cx[8];
         taps_of<8>(xf, cx);
-        for (int i = lane; i < 23 * 16; i += kWave)
+        for (int i = lane; i < 23 * (TW / 4); i += kWave)
         {
-            const int r = i >> 4, q = i & 15;
+            const int r = i / (TW / 4), q = i % (TW / 4);
             if (tx + 4 * q >= x1 || ty - 3 + r >= y1 + 4) continue;   // nothing in the region needs this quad
             int a[4];
             hfilter4<S, 8>(ref + (long)(ty - 3 + r) * rsb + (long)(tx + 4 * q - 3) * S, cx, a);
@@ -49,15 +52,21 @@ __global__ __launch_bounds__(256) void k_interp_planes(char *__restrict__ planes
     }
     __syncthreads();
 
-    const int x = tx + lane;
+    const int x = tx + CPL * lane;
     if (x >= x1) return;
-    const int16_t *col = &s_t[xf][lane * COL];
-    const u32x4 q0 = *reinterpret_cast<const u32x4 *>(col), q1 = *reinterpret_cast<const u32x4 *>(col + 8),
-                q2 = *reinterpret_cast<const u32x4 *>(col + 16);
-    const uint32_t e[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};   // (t[2k], t[2k+1])
-    uint32_t od[11];                                                                                    // (t[2k+1], t[2k+2])
+    uint32_t e[CPL][12], od[CPL][11];   // (t[2k], t[2k+1]) and (t[2k+1], t[2k+2]) of each of the lane's columns
 #pragma unroll
-    for (int k = 0; k < 11; ++k) od[k] = __builtin_amdgcn_alignbit(e[k + 1], e[k], 16);
+    for (int c = 0; c < CPL; ++c)
+    {
+        const int16_t *col = &s_t[xf][(CPL * lane + c) * COL];
+        const u32x4 q0 = *reinterpret_cast<const u32x4 *>(col), q1 = *reinterpret_cast<const u32x4 *>(col + 8),
+                    q2 = *reinterpret_cast<const u32x4 *>(col + 16);
+        e[c][0] = q0.x; e[c][1] = q0.y; e[c][2] = q0.z; e[c][3] = q0.w; e[c][4] = q1.x; e[c][5] = q1.y;
+        e[c][6] = q1.z; e[c][7] = q1.w; e[c][8] = q2.x; e[c][9] = q2.y; e[c][10] = q2.z; e[c][11] = q2.w;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) od[c][k] = __builtin_amdgcn_alignbit(e[c][k + 1], e[c][k], 16);
+    }
+    const bool pair = x + 1 < x1;
     const int rnd = 1 << (shift - 1);
 #pragma unroll 1
     for (int yf = 0; yf < 4; ++yf)
@@ -72,10 +81,26 @@ __global__ __launch_bounds__(256) void k_interp_planes(char *__restrict__ planes
 #pragma unroll
         for (int j = 0; j < THT; ++j)
         {
-            int a = rnd;
+            int v[CPL];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) a = sdot2((j & 1) ? od[(j >> 1) + k] : e[(j >> 1) + k], cp[k], a);
-            if (ty + j < y1) out[(long)j * stride] = (T)clip3(0, maxv, a >> shift);
+            for (int c = 0; c < CPL; ++c)
+            {
+                int a = rnd;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) a = sdot2((j & 1) ? od[c][(j >> 1) + k] : e[c][(j >> 1) + k], cp[k], a);
+                v[c] = clip3(0, maxv, a >> shift);
+            }
+            if (ty + j < y1)
+            {
+                T *o = out + (long)j * stride;
+                if (CPL == 2 && pair)
+                {   // one 2-sample store per lane: 64 lanes cover 128 contiguous samples of the row
+                    if (S == 1) *reinterpret_cast<uint16_t __attribute__((aligned(1))) *>(o) = (uint16_t)(v[0] | (v[1] << 8));
+                    else st4(o, (uint32_t)v[0] | ((uint32_t)v[1] << 16));
+                }
+                else
+                    o[0] = (T)v[0];
+            }
         }
     }
 }
@@ -84,7 +109,7 @@ hipError_t launch_interp_planes(hipStream_t st, int S, int bitDepth, void *plane
                                 int width, int height)
 {
     if (width <= 0 || height <= 0) return hipSuccess;
-    const dim3 g((width + 63) / 64, (height + 15) / 16), b(256);
+    const dim3 g((width + kPlaneTileW - 1) / kPlaneTileW, (height + 15) / 16), b(256);
     if (S == 1)
         hipLaunchKernelGGL((k_interp_planes<1>), g, b, 0, st, (char *)planes, plane_elems, (const char *)ref, stride, x0, y0, x0 + width, y0 + height,
                            bitDepth);

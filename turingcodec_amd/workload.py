@@ -156,6 +156,20 @@ class FrameWorkload:
         sp[:, 6] = 0
         big = np.maximum(sp[:, 2], sp[:, 3])
         self.subpel = {hi: np.ascontiguousarray(sp[(big > lo) & (big <= hi)]) for lo, hi in ((0, 8), (8, 16), (16, 32), (32, 64))}
+        self.subpel_idx = {hi: np.flatnonzero((big > lo) & (big <= hi)) for lo, hi in ((0, 8), (8, 16), (16, 32), (32, 64))}
+        # the same candidates against the fractional-phase planes (havoc_mi355x_interp_planes): plane buffer = for each
+        # reference r in {L0, L1}: 16 planes of plane_len samples, plane 4*yFrac+xFrac (slot 0 = the picture itself).
+        # One SATD job per candidate, bucketed by the lane-group class of havoc_mi355x_satd (rows of 8 samples).
+        refi = sp[:, 1] // pl - 1
+        pos = sp[:, 1] % pl
+        pj = np.stack([sp[:, 0], ((refi * 16 + 4 * sp[:, 5] + sp[:, 4]).astype(np.int64) * pl + pos).astype(np.int32), sp[:, 2], sp[:, 3]],
+                      1).astype(np.int32)
+        rows = ((pj[:, 2] + 7) // 8) * pj[:, 3]
+        self.subpel_planes = {(mw, mh): np.ascontiguousarray(pj[(rows > lo) & (rows <= hi)])
+                              for lo, hi, mw, mh in ((0, 8, 8, 8), (8, 16, 16, 8), (16, 32, 16, 16), (32, 1 << 30, 64, 64))}
+        self.subpel_planes_idx = {(mw, mh): np.flatnonzero((rows > lo) & (rows <= hi))
+                                  for lo, hi, mw, mh in ((0, 8, 8, 8), (8, 16, 16, 8), (16, 32, 16, 16), (32, 1 << 30, 64, 64))}
+        self.plane_margin = 72     # planes are computed over the picture plus the motion range (64) plus a block edge (8)
         u = u[nsearch:]
         slot = np.concatenate([[0], np.cumsum(64 * u[:-1, 3].astype(np.int64))])
         u[:, 0] = slot
@@ -189,6 +203,7 @@ class FrameWorkload:
         b[:, 3], b[:, 4] = w, h
         b[:, 5:9] = fr
         self.bi8 = b
+        bi8_geom = (w, h, x, y)
         w, h, x, y = pu(n["bi4"])
         c0x, c0y = mv(n["bi4"], 30)
         c1x, c1y = mv(n["bi4"], 30)
@@ -202,10 +217,11 @@ class FrameWorkload:
         self.bi_len = max(n["bi8"] * 4096, n["bi4"] * 1024)
 
         # ---- SubtractBi: dst slot <- clip(2*src - pred), pred = a luma prediction slot region (stride 64)
-        w, h, x, y = pu(n["subtract_bi"])
-        s = np.zeros((n["subtract_bi"], 8), np.int32)
-        s[:, 0] = np.arange(n["subtract_bi"]) * 4096
-        s[:, 1] = np.arange(n["subtract_bi"]) * 4096      # pred: the bi8 slots (already filled)
+        nsb = min(n["subtract_bi"], n["bi8"])
+        w, h, x, y = (v[:nsb] for v in bi8_geom)           # same PU as the bi prediction whose slot it reads
+        s = np.zeros((nsb, 8), np.int32)
+        s[:, 0] = np.arange(nsb) * 4096
+        s[:, 1] = np.arange(nsb) * 4096                    # pred: the bi8 slot of the same PU (written earlier in the chain)
         s[:, 2] = loff(x, y, 0)
         s[:, 3], s[:, 4] = w, h
         self.subtract_bi = s
@@ -312,6 +328,10 @@ class FrameWorkload:
             w, h = j[:, 2].astype(np.int64), j[:, 3].astype(np.int64)
             frac = (j[:, 4] != 0) | (j[:, 5] != 0)
             b["subpel_satd"] += int((np.where(frac, (w + 7) * (h + 7), w * h) * S + w * h * S + 4).sum())
+        # phase planes: per reference picture the rectangle is read once and 15 planes are written; then one SATD per candidate
+        area = (self.width + 2 * self.plane_margin) * (self.height + 2 * self.plane_margin)
+        b["interp_planes"] = 2 * 16 * area * S
+        b["satd_planes"] = sum(int((2 * wh(j, 2, 3) * S + 4).sum()) for j in self.subpel_planes.values())
         b["pred_uni4"] = uni(self.uni4, 4)
         for nm, j, t in (("pred_bi8", self.bi8, 8), ("pred_bi4", self.bi4, 4)):
             w, h = j[:, 3].astype(np.int64), j[:, 4].astype(np.int64)
