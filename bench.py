@@ -70,8 +70,6 @@ class DeviceFrame:
         self.sbi = z(len(wl.subtract_bi) * 4096, dt)
         self.j_sad4, self.j_sad = up(wl.sad4), up(wl.sad)
         self.o_sad4, self.o_sad = z(4 * len(wl.sad4), np.int32), z(len(wl.sad), np.int32)
-        self.j_uni8, self.j_uni4 = up(wl.uni8), up(wl.uni4)
-        self.j_bi8, self.j_bi4 = up(wl.bi8), up(wl.bi4)
         self.j_sbi = up(wl.subtract_bi)
         self.j_satd = up(wl.satd_inter)
         self.o_satd = z(len(wl.satd_inter), np.int32)
@@ -149,12 +147,18 @@ class DeviceFrame:
         else:
             for hi, g in sorted(self.subpel.items(), reverse=True):
                 chain(("subpel_satd", lambda g=g, hi=hi: hv.subpel_satd_d(8, bd, hi, hi, self.luma, st, self.luma, st, g["jobs"], g["cost"])))
-        chain(("pred_uni8", lambda: hv.pred_uni_d(8, bd, self.pred, 64, self.luma, st, self.j_uni8)),
+        def classes(name, jobs, wcol, fn):
+            """one launch per block-size class (the reference's table is indexed by width class)"""
+            jobs_np = np.asarray(jobs)
+            return [(name, lambda j=hv.up(np.ascontiguousarray(jobs_np[idx])), mw=mw, mh=mh: fn(j, mw, mh))
+                    for idx, mw, mh in hv.size_classes(jobs_np[:, wcol], jobs_np[:, wcol + 1])]
+
+        chain(*classes("pred_uni8", wl.uni8, 2, lambda j, mw, mh: hv.pred_uni_d(8, bd, self.pred, 64, self.luma, st, j, mw, mh)),
               ("satd_inter", lambda: hv.satd_d(self.luma, st, self.pred, 64, self.j_satd, self.o_satd)))
-        chain(("pred_uni4", lambda: hv.pred_uni_d(4, bd, self.cpred, 32, self.chroma, cst, self.j_uni4)))
-        chain(("pred_bi8", lambda: hv.pred_bi_d(8, bd, self.bi, 64, self.luma, st, self.j_bi8)),
+        chain(*classes("pred_uni4", wl.uni4, 2, lambda j, mw, mh: hv.pred_uni_d(4, bd, self.cpred, 32, self.chroma, cst, j, mw, mh)))
+        chain(*classes("pred_bi8", wl.bi8, 3, lambda j, mw, mh: hv.pred_bi_d(8, bd, self.bi, 64, self.luma, st, j, mw, mh)),
               ("subtract_bi", lambda: hv.subtract_bi_d(bd, self.sbi, 64, self.bi, 64, self.luma, st, self.j_sbi)),
-              ("pred_bi4", lambda: hv.pred_bi_d(4, bd, self.bi, 32, self.chroma, cst, self.j_bi4)))
+              *classes("pred_bi4", wl.bi4, 3, lambda j, mw, mh: hv.pred_bi_d(4, bd, self.bi, 32, self.chroma, cst, j, mw, mh)))
         for log2, g in sorted(self.isearch.items(), reverse=True):
             chain(("intra_satd35", lambda g=g, log2=log2: hv.intra_satd35_d(bd, log2, self.luma, st, g["nb"], g["jobs"], g["cost"])))
         for log2, g in sorted(self.intra.items(), reverse=True):

@@ -179,11 +179,14 @@ int havoc_mi355x_ssd_linear(havoc_mi355x_ctx *ctx, const uint8_t *d_a, const uin
 /* ------------------------------------------------------------------------------------------------------- */
 
 /* HavocPredUni<Sample> (havoc/pred_inter.h:35, C reference havoc/pred_inter.cpp:76-202); taps = 8 | 4.
- * Writes exactly w x h samples per job (the JIT's licence to over-write to the right is not used). */
-int havoc_mi355x_pred_uni(havoc_mi355x_ctx *ctx, int S, int taps, int bitDepth, void *d_dst, intptr_t stride_dst,
+ * Writes exactly w x h samples per job (the JIT's licence to over-write to the right is not used).  max_w / max_h:
+ * upper bounds on the block sizes of this batch -- the reference's table is indexed by width class
+ * (havoc/pred_inter.h:47-50); 64, 64 is always valid.  Every job reads the full (w+taps-1) x (h+taps-1) window
+ * around its block whatever the phase (the zero phase is evaluated with the {..,64,..} filter). */
+int havoc_mi355x_pred_uni(havoc_mi355x_ctx *ctx, int S, int taps, int bitDepth, int max_w, int max_h, void *d_dst, intptr_t stride_dst,
                           const void *d_ref, intptr_t stride_ref, const havoc_mi355x_pred_uni_job *d_jobs, int njobs);
 /* HavocPredBi<Sample> (havoc/pred_inter.h:63, havoc/pred_inter.cpp:1207-1252) */
-int havoc_mi355x_pred_bi(havoc_mi355x_ctx *ctx, int S, int taps, int bitDepth, void *d_dst, intptr_t stride_dst,
+int havoc_mi355x_pred_bi(havoc_mi355x_ctx *ctx, int S, int taps, int bitDepth, int max_w, int max_h, void *d_dst, intptr_t stride_dst,
                          const void *d_ref, intptr_t stride_ref, const havoc_mi355x_pred_bi_job *d_jobs, int njobs);
 /* havoc::SubtractBi<Sample> (havoc/pred_inter.h:87, havoc/pred_inter.cpp:2063-2080) */
 int havoc_mi355x_subtract_bi(havoc_mi355x_ctx *ctx, int S, int bitDepth, void *d_dst, intptr_t stride_dst,

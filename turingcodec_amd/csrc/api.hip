@@ -10,8 +10,8 @@ hipError_t launch_sad(hipStream_t, int S, int ways, const void *, long, const vo
 hipError_t launch_ssd(hipStream_t, int S, const void *, long, const void *, long, const void *, int, uint32_t *);
 hipError_t launch_satd(hipStream_t, int S, int maxw, int maxh, const void *, long, const void *, long, const void *, int, int32_t *);
 hipError_t launch_ssd_linear(hipStream_t, const uint8_t *, const uint8_t *, int, int32_t *);
-hipError_t launch_pred_uni(hipStream_t, int S, int taps, int bd, void *, long, const void *, long, const void *, int);
-hipError_t launch_pred_bi(hipStream_t, int S, int taps, int bd, void *, long, const void *, long, const void *, int);
+hipError_t launch_pred_uni(hipStream_t, int S, int taps, int bd, int maxw, int maxh, void *, long, const void *, long, const void *, int);
+hipError_t launch_pred_bi(hipStream_t, int S, int taps, int bd, int maxw, int maxh, void *, long, const void *, long, const void *, int);
 hipError_t launch_subtract_bi(hipStream_t, int S, int bd, void *, long, const void *, long, const void *, long, const void *, int);
 hipError_t launch_intra(hipStream_t, int S, int log2, int bd, void *, long, const void *, const void *, int);
 hipError_t launch_intra_satd35(hipStream_t, int S, int log2, int bd, const void *, long, const void *, const void *, int, int32_t *);
@@ -341,18 +341,22 @@ int havoc_mi355x_ssd_linear(havoc_mi355x_ctx *ctx, const uint8_t *d_a, const uin
 
 // ---- inter prediction -------------------------------------------------------------------------------------
 
-int havoc_mi355x_pred_uni(havoc_mi355x_ctx *ctx, int S, int taps, int bitDepth, void *d_dst, intptr_t stride_dst, const void *d_ref,
-                          intptr_t stride_ref, const havoc_mi355x_pred_uni_job *d_jobs, int njobs)
+#define REQUIRE_MAXWH() REQUIRE(max_w >= 2 && max_w <= 64 && max_h >= 2 && max_h <= 64, "max_w / max_h must be 2..64")
+
+int havoc_mi355x_pred_uni(havoc_mi355x_ctx *ctx, int S, int taps, int bitDepth, int max_w, int max_h, void *d_dst, intptr_t stride_dst,
+                          const void *d_ref, intptr_t stride_ref, const havoc_mi355x_pred_uni_job *d_jobs, int njobs)
 {
     REQUIRE_CTX(); REQUIRE_S(); REQUIRE_BD(); REQUIRE(taps == 8 || taps == 4, "taps must be 8 or 4"); REQUIRE(njobs >= 0, "njobs < 0");
-    return check(launch_pred_uni(LS(ctx),S, taps, bitDepth, d_dst, stride_dst, d_ref, stride_ref, d_jobs, njobs), "pred_uni");
+    REQUIRE_MAXWH();
+    return check(launch_pred_uni(LS(ctx),S, taps, bitDepth, max_w, max_h, d_dst, stride_dst, d_ref, stride_ref, d_jobs, njobs), "pred_uni");
 }
 
-int havoc_mi355x_pred_bi(havoc_mi355x_ctx *ctx, int S, int taps, int bitDepth, void *d_dst, intptr_t stride_dst, const void *d_ref,
-                         intptr_t stride_ref, const havoc_mi355x_pred_bi_job *d_jobs, int njobs)
+int havoc_mi355x_pred_bi(havoc_mi355x_ctx *ctx, int S, int taps, int bitDepth, int max_w, int max_h, void *d_dst, intptr_t stride_dst,
+                         const void *d_ref, intptr_t stride_ref, const havoc_mi355x_pred_bi_job *d_jobs, int njobs)
 {
     REQUIRE_CTX(); REQUIRE_S(); REQUIRE_BD(); REQUIRE(taps == 8 || taps == 4, "taps must be 8 or 4"); REQUIRE(njobs >= 0, "njobs < 0");
-    return check(launch_pred_bi(LS(ctx),S, taps, bitDepth, d_dst, stride_dst, d_ref, stride_ref, d_jobs, njobs), "pred_bi");
+    REQUIRE_MAXWH();
+    return check(launch_pred_bi(LS(ctx),S, taps, bitDepth, max_w, max_h, d_dst, stride_dst, d_ref, stride_ref, d_jobs, njobs), "pred_bi");
 }
 
 int havoc_mi355x_subtract_bi(havoc_mi355x_ctx *ctx, int S, int bitDepth, void *d_dst, intptr_t stride_dst, const void *d_pred, intptr_t stride_pred,

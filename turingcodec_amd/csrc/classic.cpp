@@ -181,17 +181,12 @@ int ssdLinear(const uint8_t *a, const uint8_t *b, int size)
 
 // ---- inter prediction -----------------------------------------------------------------------------------------
 
-// packs the block (copy case) or the (w+taps-1) x (h+taps-1) window around it (+3 columns the kernel's vector loads
-// may touch); returns the byte offset and sets *origin to the sample offset of the block's integer position
+// packs the (w+taps-1) x (h+taps-1) window around the block (+3 columns the kernel's vector loads may touch; the
+// kernel reads the window for every phase, the zero phase included); returns the byte offset and sets *origin to the
+// sample offset of the block's integer position
 template <typename Sample>
-size_t packWindow(Stage &s, const Sample *ref, intptr_t sr, int w, int h, int taps, bool frac, int *pitch, int *origin)
+size_t packWindow(Stage &s, const Sample *ref, intptr_t sr, int w, int h, int taps, int *pitch, int *origin)
 {
-    if (!frac)
-    {
-        *pitch = w;
-        *origin = 0;
-        return s.pack(ref, sr, w, h, w);
-    }
     const int above = taps / 2 - 1, ww = w + taps - 1, wh = h + taps - 1;
     *pitch = ww + 3;
     *origin = above * *pitch + above;
@@ -204,11 +199,11 @@ void predUni(Sample *dst, intptr_t sd, const Sample *ref, intptr_t sr, int w, in
     Stage &s = stage();
     const size_t j = s.reserve(sizeof(havoc_mi355x_pred_uni_job));
     int pitch, origin;
-    const size_t win = packWindow(s, ref, sr, w, h, TAPS, xFrac || yFrac, &pitch, &origin);
+    const size_t win = packWindow(s, ref, sr, w, h, TAPS, &pitch, &origin);
     const size_t out = s.reserve(sizeof(Sample) * size_t(w) * h);
     *s.job<havoc_mi355x_pred_uni_job>(j) = {0, origin, w, h, xFrac, yFrac, {0, 0}};
     s.upload();
-    CK(havoc_mi355x_pred_uni(s.ctx, sizeof(Sample), TAPS, bitDepth, s.d + out, w, s.d + win, pitch, s.djob<havoc_mi355x_pred_uni_job>(j), 1));
+    CK(havoc_mi355x_pred_uni(s.ctx, sizeof(Sample), TAPS, bitDepth, w, h, s.d + out, w, s.d + win, pitch, s.djob<havoc_mi355x_pred_uni_job>(j), 1));
     s.unpack(dst, sd, w, h, w, out);
 }
 
@@ -219,13 +214,13 @@ void predBi(Sample *dst, intptr_t sd, const Sample *ref0, const Sample *ref1, in
     Stage &s = stage();
     const size_t j = s.reserve(sizeof(havoc_mi355x_pred_bi_job));
     int pitch, origin;
-    const size_t w0 = packWindow(s, ref0, sr, w, h, TAPS, true, &pitch, &origin);
-    const size_t w1 = packWindow(s, ref1, sr, w, h, TAPS, true, &pitch, &origin);
+    const size_t w0 = packWindow(s, ref0, sr, w, h, TAPS, &pitch, &origin);
+    const size_t w1 = packWindow(s, ref1, sr, w, h, TAPS, &pitch, &origin);
     const size_t out = s.reserve(sizeof(Sample) * size_t(w) * h);
     havoc_mi355x_pred_bi_job job = {0, origin, int32_t((w1 - w0) / sizeof(Sample)) + origin, w, h, xFrac0, yFrac0, xFrac1, yFrac1, {0, 0, 0}};
     *s.job<havoc_mi355x_pred_bi_job>(j) = job;
     s.upload();
-    CK(havoc_mi355x_pred_bi(s.ctx, sizeof(Sample), TAPS, bitDepth, s.d + out, w, s.d + w0, pitch, s.djob<havoc_mi355x_pred_bi_job>(j), 1));
+    CK(havoc_mi355x_pred_bi(s.ctx, sizeof(Sample), TAPS, bitDepth, w, h, s.d + out, w, s.d + w0, pitch, s.djob<havoc_mi355x_pred_bi_job>(j), 1));
     s.unpack(dst, sd, w, h, w, out);
 }
 

@@ -1,192 +1,134 @@
-// Inter prediction: HEVC 8-tap (luma) / 4-tap (chroma) fractional-sample interpolation, uni and bi, and the
-// bi-search helper SubtractBi.
+// Inter prediction written to memory: HEVC 8-tap (luma) / 4-tap (chroma) fractional-sample interpolation, uni and bi
+// (havoc/pred_inter.h:35,63; C reference havoc/pred_inter.cpp:76-202, 1207-1252), and the bi-search helper SubtractBi.
 //
-// Work mapping: one 64-lane workgroup per prediction block.  The (w+taps-1) x (h+taps-1) reference window is staged
-// from HBM into LDS with 4-sample unaligned vector loads (rows are contiguous in the padded plane), the horizontal
-// pass writes 16-bit intermediates back to LDS, the vertical pass reads them column-wise and writes the block with
-// packed stores.  All arithmetic is int32 on int16/uint16 operands, exactly as the reference's generic C function
-// (havoc/pred_inter.cpp:76-110), whose intermediates provably fit 16 bits for bit depths 8..10.
+// Same two-phase structure as the sub-pel candidate kernel (kernels_subpel.hip):
+//   1. horizontal pass straight from HBM/L2 with dot4 / dot2 (interp.h, hfilter4), transposed into LDS (tmp[x][y]);
+//      bi-prediction does it for both references;
+//   2. one column of 8 outputs per lane: two ds_read_b128 fetch the column's intermediates, the vertical filter is
+//      four v_dot2_i32_i16 per output; uni: round, shift, clip; bi: the two 14-bit intermediates are averaged with
+//      rounding and clipped (havoc_pred_bi_mean_c_ref).  The column goes to an LDS output tile;
+//   3. the output tile is written row-wise, 4 samples per lane (coalesced, exactly w x h samples: the reference JIT's
+//      licence to write to the right of the block, havoc/pred_inter.h:27, is not used).
+// All phase combinations take the two-pass route (zero phase = the {..,64,..} filter), bit-identical to the
+// reference's copy / one-pass forms for bit depths 8..10.  A launch is uniform in a size class (max_w x max_h), as
+// the reference's table is indexed by width class: G = 8 / 32 / 128 / 256 lanes per block, 256 / G blocks per
+// workgroup.
 #include "common.h"
+#include "interp.h"
 
 namespace havoc_gpu {
 
-__constant__ int8_t c_luma[4][8] = {
-    {0, 0, 0, 64, 0, 0, 0, 0}, {-1, 4, -10, 58, 17, -5, 1, 0}, {-1, 4, -11, 40, 40, -11, 4, -1}, {0, 1, -5, 17, 58, -10, 4, -1}};
-__constant__ int8_t c_chroma[8][4] = {{0, 64, 0, 0},   {-2, 58, 10, -2}, {-4, 54, 16, -2}, {-6, 46, 28, -4},
-                                      {-4, 36, 36, -4}, {-4, 28, 46, -6}, {-2, 16, 54, -4}, {-2, 10, 58, -2}};
-
-template <int TAPS>
-__device__ __forceinline__ void load_taps(int frac, int (&c)[TAPS])
+template <int S, int TAPS, int MAXW, int MAXH, int G, bool BI>
+__global__ __launch_bounds__(256) void k_pred(char *__restrict__ dst, long stride_dst, const char *__restrict__ ref, long stride_ref,
+                                              const int32_t *__restrict__ jobs, int njobs, int bitDepth)
 {
-#pragma unroll
-    for (int k = 0; k < TAPS; ++k) c[k] = TAPS == 8 ? (int)c_luma[frac][k] : (int)c_chroma[frac][k];
-}
+    typedef typename Sample<S>::T T;
+    constexpr int JPW = 256 / G;
+    constexpr int NREF = BI ? 2 : 1;
+    constexpr int AB = TAPS / 2 - 1;
+    constexpr int TH = MAXH + 8;     // intermediate column: h + TAPS - 1 <= MAXH + 7, rounded up to 8
+    constexpr int OS = MAXW + 2;     // output tile row stride (samples), skewed against bank conflicts
+    __shared__ __attribute__((aligned(16))) int16_t s_tmp[JPW][NREF][MAXW * TH + 8];
+    __shared__ __attribute__((aligned(16))) uint16_t s_out[JPW][MAXH * OS + 2];
 
-template <int TAPS> struct Geo
-{
-    static constexpr int kAbove = TAPS / 2 - 1;          // rows above / columns left of the block
-    static constexpr int kMaxWin = 64 + TAPS - 1;        // window rows / columns for a 64 x 64 block
-    static constexpr int kWinStride = 64 + TAPS;         // LDS row stride of the window (elements), even
-};
-
-// Stage the window of block (w x h) at `ref` into LDS as uint16.  4 samples per lane per step.
-template <int S, int TAPS>
-__device__ __forceinline__ void stage_window(uint16_t *win, const char *ref, long rsb, int w, int h, int lane)
-{
-    typedef Geo<TAPS> G;
-    const int ww = w + TAPS - 1, wh = h + TAPS - 1;
-    const int cpr = (ww + 3) >> 2;  // 4-sample chunks per row (the last chunk may read <= 3 samples past the window)
-    const FastDiv fd(cpr);
-    const char *base = ref - G::kAbove * rsb - G::kAbove * S;
-    for (int i = lane; i < cpr * wh; i += kWave)
-    {
-        const int y = fd.div(i), x = (i - y * cpr) * 4;
-        uint16_t *d = win + y * G::kWinStride + x;
-        const char *p = base + y * rsb + x * S;
-        if (S == 1)
-        {
-            const uint32_t v = ld4(p);
-            d[0] = v & 0xff; d[1] = (v >> 8) & 0xff; d[2] = (v >> 16) & 0xff; d[3] = v >> 24;
-        }
-        else
-        {
-            const u32x2 v = ld8(p);
-            d[0] = v.x & 0xffff; d[1] = v.x >> 16; d[2] = v.y & 0xffff; d[3] = v.y >> 16;
-        }
-    }
-}
-
-// horizontal pass over all window rows: tmp[y][x] = (sum_k c[k] * win[y][x + k]) >> shift1   (no rounding)
-template <int TAPS>
-__device__ __forceinline__ void hpass(int16_t *tmp, const uint16_t *win, int w, int h, int xFrac, int shift1, int lane)
-{
-    typedef Geo<TAPS> G;
-    int c[TAPS];
-    load_taps<TAPS>(xFrac, c);
-    const int wh = h + TAPS - 1;
-    const FastDiv fd(w);
-    for (int i = lane; i < w * wh; i += kWave)
-    {
-        const int y = fd.div(i), x = i - y * w;
-        const uint16_t *p = win + y * G::kWinStride + x;
-        int a = 0;
-#pragma unroll
-        for (int k = 0; k < TAPS; ++k) a += c[k] * (int)p[k];
-        tmp[y * 64 + x] = (int16_t)(a >> shift1);
-    }
-}
-
-template <int S>
-__device__ __forceinline__ void put(char *dst, long dsb, int x, int y, int v)
-{
-    if (S == 1) reinterpret_cast<uint8_t *>(dst + y * dsb)[x] = (uint8_t)v;
-    else reinterpret_cast<uint16_t *>(dst + y * dsb)[x] = (uint16_t)v;
-}
-
-// HavocPredUni (havoc/pred_inter.h:35; C reference havoc/pred_inter.cpp:113-202)
-template <int S, int TAPS>
-__global__ __launch_bounds__(64) void k_pred_uni(char *__restrict__ dst, long stride_dst, const char *__restrict__ ref, long stride_ref,
-                                                 const int32_t *__restrict__ jobs, int bitDepth)
-{
-    typedef Geo<TAPS> G;
-    __shared__ uint16_t win[G::kMaxWin * G::kWinStride];
-    __shared__ int16_t tmp[G::kMaxWin * 64];
-    const int32_t *j = jobs + blockIdx.x * 8;   // havoc_mi355x_pred_uni_job
-    const int lane = threadIdx.x;
-    const int w = j[2], h = j[3], xFrac = j[4], yFrac = j[5];
+    const int sub = threadIdx.x / G, l = threadIdx.x - sub * G;
+    const int job = blockIdx.x * JPW + sub;
+    const bool live = job < njobs;
+    // havoc_mi355x_pred_uni_job: dst, ref, w, h, xFrac, yFrac | havoc_mi355x_pred_bi_job: dst, ref0, ref1, w, h, 4 fracs
+    const int32_t *j = jobs + (long)(live ? job : 0) * (BI ? 12 : 8);
+    const int w = BI ? j[3] : j[2], h = BI ? j[4] : j[3];
     const long dsb = stride_dst * S, rsb = stride_ref * S;
-    char *d = dst + (long)j[0] * S;
-    const char *r = ref + (long)j[1] * S;
-    const int maxv = (1 << bitDepth) - 1;
-    const FastDiv fd(w);
-
-    if (!xFrac && !yFrac)
-    {   // havoc_pred_uni_copy_block (pred_inter.cpp:113-124)
-        for (int i = lane; i < w * h; i += kWave)
-        {
-            const int y = fd.div(i), x = i - y * w;
-            if (S == 1) reinterpret_cast<uint8_t *>(d + y * dsb)[x] = reinterpret_cast<const uint8_t *>(r + y * rsb)[x];
-            else reinterpret_cast<uint16_t *>(d + y * dsb)[x] = reinterpret_cast<const uint16_t *>(r + y * rsb)[x];
-        }
-        return;
-    }
-    stage_window<S, TAPS>(win, r, rsb, w, h, lane);
-    __syncthreads();
-    if (xFrac && yFrac)
-    {   // *_hv (pred_inter.cpp:146-163, :185-202)
-        const int shift1 = min(4, bitDepth - 8);
-        const int shift = 6 + max(2, 14 - bitDepth);
-        hpass<TAPS>(tmp, win, w, h, xFrac, shift1, lane);
-        __syncthreads();
-        int c[TAPS];
-        load_taps<TAPS>(yFrac, c);
-        for (int i = lane; i < w * h; i += kWave)
-        {
-            const int y = fd.div(i), x = i - y * w;
-            int a = 1 << (shift - 1);
-#pragma unroll
-            for (int k = 0; k < TAPS; ++k) a += c[k] * (int)tmp[(y + k) * 64 + x];
-            put<S>(d, dsb, x, y, clip3(0, maxv, a >> shift));
-        }
-        return;
-    }
-    // *_h / *_v (pred_inter.cpp:127-143, :166-182): one pass, rounding 32, shift 6
-    int c[TAPS];
-    load_taps<TAPS>(xFrac ? xFrac : yFrac, c);
-    const int step = xFrac ? 1 : G::kWinStride;
-    const int origin = xFrac ? G::kAbove * G::kWinStride : G::kAbove;   // skip the unused rows / columns
-    for (int i = lane; i < w * h; i += kWave)
-    {
-        const int y = fd.div(i), x = i - y * w;
-        const uint16_t *p = win + origin + y * G::kWinStride + x;
-        int a = 32;
-#pragma unroll
-        for (int k = 0; k < TAPS; ++k) a += c[k] * (int)p[k * step];
-        put<S>(d, dsb, x, y, clip3(0, maxv, a >> 6));
-    }
-}
-
-// HavocPredBi (havoc/pred_inter.h:63; C reference havoc/pred_inter.cpp:1207-1252): both references always take the
-// two-pass route (frac 0 is the {..,64,..} filter), 14-bit intermediates, rounded mean, clip.
-template <int S, int TAPS>
-__global__ __launch_bounds__(64) void k_pred_bi(char *__restrict__ dst, long stride_dst, const char *__restrict__ ref, long stride_ref,
-                                                const int32_t *__restrict__ jobs, int bitDepth)
-{
-    typedef Geo<TAPS> G;
-    __shared__ uint16_t win[G::kMaxWin * G::kWinStride];
-    __shared__ int16_t tmp[G::kMaxWin * 64];
-    __shared__ int16_t first[64 * 64];
-    const int32_t *j = jobs + blockIdx.x * 12;   // havoc_mi355x_pred_bi_job
-    const int lane = threadIdx.x;
-    const int w = j[3], h = j[4];
-    const long dsb = stride_dst * S, rsb = stride_ref * S;
-    char *d = dst + (long)j[0] * S;
     const int maxv = (1 << bitDepth) - 1;
     const int shift1 = min(4, bitDepth - 8);
     const int shift3 = max(2, 14 - bitDepth);
-    const FastDiv fd(w);
-#pragma unroll 1
-    for (int r = 0; r < 2; ++r)
-    {
-        const char *p = ref + (long)j[1 + r] * S;
-        const int xFrac = j[5 + 2 * r], yFrac = j[6 + 2 * r];
-        __syncthreads();
-        stage_window<S, TAPS>(win, p, rsb, w, h, lane);
-        __syncthreads();
-        hpass<TAPS>(tmp, win, w, h, xFrac, shift1, lane);
-        __syncthreads();
-        int c[TAPS];
-        load_taps<TAPS>(yFrac, c);
-        for (int i = lane; i < w * h; i += kWave)
-        {
-            const int y = fd.div(i), x = i - y * w;
-            int a = 0;
+    const int qpr = (w + 3) >> 2, wh = h + TAPS - 1;
+    const FastDiv fq(qpr);
+
+    // ---- phase 1: horizontal pass(es)
 #pragma unroll
-            for (int k = 0; k < TAPS; ++k) a += c[k] * (int)tmp[(y + k) * 64 + x];
-            a >>= 6;
-            if (r == 0) first[y * 64 + x] = (int16_t)a;
-            else put<S>(d, dsb, x, y, clip3(0, maxv, ((int)first[y * 64 + x] + a + (1 << shift3)) >> (shift3 + 1)));
+    for (int r = 0; r < NREF; ++r)
+    {
+        const char *r0 = ref + (long)j[1 + r] * S;
+        int cx[TAPS];
+        taps_of<TAPS>(BI ? j[5 + 2 * r] : j[4], cx);
+        int16_t *tmp = s_tmp[sub][r];
+        for (int i = l; i < wh * qpr; i += G)
+        {
+            const int y = fq.div(i), x0 = (i - y * qpr) * 4;
+            int a[4];
+            hfilter4<S, TAPS>(r0 + (y - AB) * rsb + (x0 - AB) * S, cx, a);
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+                if (x0 + o < w) tmp[(x0 + o) * TH + y] = (int16_t)(a[o] >> shift1);
         }
+    }
+    __syncthreads();
+
+    // ---- phase 2: vertical pass, one column of 8 rows per lane
+    {
+        uint32_t cp[NREF][TAPS / 2];
+#pragma unroll
+        for (int r = 0; r < NREF; ++r)
+        {
+            int cy[TAPS];
+            taps_of<TAPS>(BI ? j[6 + 2 * r] : j[5], cy);
+#pragma unroll
+            for (int k = 0; k < TAPS / 2; ++k) cp[r][k] = pack_i16(cy[2 * k], cy[2 * k + 1]);
+        }
+        const int groups = (h + 7) >> 3;
+        const FastDiv fw(w);
+        uint16_t *ot = s_out[sub];
+        for (int it = l; it < (live ? w * groups : 0); it += G)
+        {
+            const int gy = fw.div(it), x = it - gy * w;
+            const int y0 = gy * 8;
+            int acc[8];
+#pragma unroll
+            for (int r = 0; r < NREF; ++r)
+            {
+                const int16_t *col = &s_tmp[sub][r][x * TH + y0];
+                const u32x4 q0 = *reinterpret_cast<const u32x4 *>(col), q1 = *reinterpret_cast<const u32x4 *>(col + 8);
+                const uint32_t e[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+                uint32_t od[7];
+#pragma unroll
+                for (int k = 0; k < 7; ++k) od[k] = __builtin_amdgcn_alignbit(e[k + 1], e[k], 16);
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj)
+                {
+                    int a = 0;
+#pragma unroll
+                    for (int k = 0; k < TAPS / 2; ++k) a = sdot2((jj & 1) ? od[(jj >> 1) + k] : e[(jj >> 1) + k], cp[r][k], a);
+                    if (!BI) acc[jj] = a;
+                    else if (r == 0) acc[jj] = a >> 6;
+                    else acc[jj] += a >> 6;
+                }
+            }
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj)
+            {
+                const int v = BI ? (acc[jj] + (1 << shift3)) >> (shift3 + 1) : (acc[jj] + (1 << (5 + shift3))) >> (6 + shift3);
+                if (y0 + jj < h) ot[(y0 + jj) * OS + x] = (uint16_t)clip3(0, maxv, v);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 3: coalesced row-wise write of exactly w x h samples
+    if (!live) return;
+    char *d = dst + (long)j[0] * S;
+    const uint16_t *ot = s_out[sub];
+    for (int i = l; i < h * qpr; i += G)
+    {
+        const int y = fq.div(i), x0 = (i - y * qpr) * 4;
+        const uint16_t *p = ot + y * OS + x0;
+        char *q = d + y * dsb + x0 * S;
+        if (x0 + 4 <= w)
+        {
+            if (S == 1) st4(q, (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24));
+            else st8(q, u32x2{(uint32_t)p[0] | ((uint32_t)p[1] << 16), (uint32_t)p[2] | ((uint32_t)p[3] << 16)});
+        }
+        else
+            for (int o = 0; x0 + o < w; ++o) reinterpret_cast<T *>(q)[o] = (T)p[o];
     }
 }
 
@@ -214,32 +156,46 @@ __global__ __launch_bounds__(256) void k_subtract_bi(char *__restrict__ dst, lon
     }
 }
 
-hipError_t launch_pred_uni(hipStream_t st, int S, int taps, int bitDepth, void *dst, long sd, const void *ref, long sr, const void *jobs, int n)
+template <int S, int TAPS, bool BI>
+static hipError_t launch_pred_st(hipStream_t st, int bd, int maxw, int maxh, char *dst, long sd, const char *ref, long sr, const int32_t *jobs, int n)
 {
-    if (n <= 0) return hipSuccess;
-    const int32_t *j = (const int32_t *)jobs;
-    char *d = (char *)dst;
-    const char *r = (const char *)ref;
-    if (S == 1 && taps == 8) hipLaunchKernelGGL((k_pred_uni<1, 8>), dim3(n), dim3(64), 0, st, d, sd, r, sr, j, bitDepth);
-    else if (S == 1 && taps == 4) hipLaunchKernelGGL((k_pred_uni<1, 4>), dim3(n), dim3(64), 0, st, d, sd, r, sr, j, bitDepth);
-    else if (S == 2 && taps == 8) hipLaunchKernelGGL((k_pred_uni<2, 8>), dim3(n), dim3(64), 0, st, d, sd, r, sr, j, bitDepth);
-    else if (S == 2 && taps == 4) hipLaunchKernelGGL((k_pred_uni<2, 4>), dim3(n), dim3(64), 0, st, d, sd, r, sr, j, bitDepth);
-    else return hipErrorInvalidValue;
+    const dim3 b(256);
+    if (maxw <= 8 && maxh <= 8)
+        hipLaunchKernelGGL((k_pred<S, TAPS, 8, 8, 8, BI>), dim3((n + 31) / 32), b, 0, st, dst, sd, ref, sr, jobs, n, bd);
+    else if (maxw <= 16 && maxh <= 16)
+        hipLaunchKernelGGL((k_pred<S, TAPS, 16, 16, 32, BI>), dim3((n + 7) / 8), b, 0, st, dst, sd, ref, sr, jobs, n, bd);
+    else if (maxw <= 32 && maxh <= 32)
+        hipLaunchKernelGGL((k_pred<S, TAPS, 32, 32, 128, BI>), dim3((n + 1) / 2), b, 0, st, dst, sd, ref, sr, jobs, n, bd);
+    else
+        hipLaunchKernelGGL((k_pred<S, TAPS, 64, 64, 256, BI>), dim3(n), b, 0, st, dst, sd, ref, sr, jobs, n, bd);
     return hipGetLastError();
 }
 
-hipError_t launch_pred_bi(hipStream_t st, int S, int taps, int bitDepth, void *dst, long sd, const void *ref, long sr, const void *jobs, int n)
+template <bool BI>
+static hipError_t launch_pred(hipStream_t st, int S, int taps, int bd, int maxw, int maxh, void *dst, long sd, const void *ref, long sr,
+                              const void *jobs, int n)
 {
     if (n <= 0) return hipSuccess;
-    const int32_t *j = (const int32_t *)jobs;
     char *d = (char *)dst;
     const char *r = (const char *)ref;
-    if (S == 1 && taps == 8) hipLaunchKernelGGL((k_pred_bi<1, 8>), dim3(n), dim3(64), 0, st, d, sd, r, sr, j, bitDepth);
-    else if (S == 1 && taps == 4) hipLaunchKernelGGL((k_pred_bi<1, 4>), dim3(n), dim3(64), 0, st, d, sd, r, sr, j, bitDepth);
-    else if (S == 2 && taps == 8) hipLaunchKernelGGL((k_pred_bi<2, 8>), dim3(n), dim3(64), 0, st, d, sd, r, sr, j, bitDepth);
-    else if (S == 2 && taps == 4) hipLaunchKernelGGL((k_pred_bi<2, 4>), dim3(n), dim3(64), 0, st, d, sd, r, sr, j, bitDepth);
-    else return hipErrorInvalidValue;
-    return hipGetLastError();
+    const int32_t *j = (const int32_t *)jobs;
+    if (S == 1 && taps == 8) return launch_pred_st<1, 8, BI>(st, bd, maxw, maxh, d, sd, r, sr, j, n);
+    if (S == 1 && taps == 4) return launch_pred_st<1, 4, BI>(st, bd, maxw, maxh, d, sd, r, sr, j, n);
+    if (S == 2 && taps == 8) return launch_pred_st<2, 8, BI>(st, bd, maxw, maxh, d, sd, r, sr, j, n);
+    if (S == 2 && taps == 4) return launch_pred_st<2, 4, BI>(st, bd, maxw, maxh, d, sd, r, sr, j, n);
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_pred_uni(hipStream_t st, int S, int taps, int bd, int maxw, int maxh, void *dst, long sd, const void *ref, long sr,
+                           const void *jobs, int n)
+{
+    return launch_pred<false>(st, S, taps, bd, maxw, maxh, dst, sd, ref, sr, jobs, n);
+}
+
+hipError_t launch_pred_bi(hipStream_t st, int S, int taps, int bd, int maxw, int maxh, void *dst, long sd, const void *ref, long sr, const void *jobs,
+                          int n)
+{
+    return launch_pred<true>(st, S, taps, bd, maxw, maxh, dst, sd, ref, sr, jobs, n);
 }
 
 hipError_t launch_subtract_bi(hipStream_t st, int S, int bitDepth, void *dst, long sd, const void *pred, long sp, const void *src, long ss,

@@ -59,8 +59,8 @@ def _load():
         "ssd": [_vp, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
         "satd": [_vp, _i, _i, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
         "ssd_linear": [_vp, _vp, _vp, _i, _vp],
-        "pred_uni": [_vp, _i, _i, _i, _vp, _ip, _vp, _ip, _vp, _i],
-        "pred_bi": [_vp, _i, _i, _i, _vp, _ip, _vp, _ip, _vp, _i],
+        "pred_uni": [_vp, _i, _i, _i, _i, _i, _vp, _ip, _vp, _ip, _vp, _i],
+        "pred_bi": [_vp, _i, _i, _i, _i, _i, _vp, _ip, _vp, _ip, _vp, _i],
         "subtract_bi": [_vp, _i, _i, _vp, _ip, _vp, _ip, _vp, _ip, _vp, _i],
         "intra": [_vp, _i, _i, _i, _vp, _ip, _vp, _vp, _i],
         "intra_satd35": [_vp, _i, _i, _i, _vp, _ip, _vp, _vp, _i, _vp],
@@ -207,11 +207,22 @@ class Havoc:
     def satd_d(self, a, sa, b, sb, jobs, out, max_w=64, max_h=64):
         self._ck(self.L.havoc_mi355x_satd(self.h, self._S(a), max_w, max_h, _ptr(a), sa, _ptr(b), sb, _ptr(jobs), jobs.shape[0], _ptr(out)))
 
-    def pred_uni_d(self, taps, bd, dst, sd, ref, sr, jobs):
-        self._ck(self.L.havoc_mi355x_pred_uni(self.h, self._S(ref), taps, bd, _ptr(dst), sd, _ptr(ref), sr, _ptr(jobs), jobs.shape[0]))
+    def pred_uni_d(self, taps, bd, dst, sd, ref, sr, jobs, max_w=64, max_h=64):
+        self._ck(self.L.havoc_mi355x_pred_uni(self.h, self._S(ref), taps, bd, max_w, max_h, _ptr(dst), sd, _ptr(ref), sr, _ptr(jobs), jobs.shape[0]))
 
-    def pred_bi_d(self, taps, bd, dst, sd, ref, sr, jobs):
-        self._ck(self.L.havoc_mi355x_pred_bi(self.h, self._S(ref), taps, bd, _ptr(dst), sd, _ptr(ref), sr, _ptr(jobs), jobs.shape[0]))
+    def pred_bi_d(self, taps, bd, dst, sd, ref, sr, jobs, max_w=64, max_h=64):
+        self._ck(self.L.havoc_mi355x_pred_bi(self.h, self._S(ref), taps, bd, max_w, max_h, _ptr(dst), sd, _ptr(ref), sr, _ptr(jobs), jobs.shape[0]))
+
+    @staticmethod
+    def size_classes(w, h):
+        """[(index array, max_w, max_h)]: the four block-size classes the interpolation kernels are instantiated for"""
+        big = np.maximum(np.asarray(w), np.asarray(h))
+        out = []
+        for lo, hi in ((0, 8), (8, 16), (16, 32), (32, 64)):
+            idx = np.flatnonzero((big > lo) & (big <= hi))
+            if len(idx):
+                out.append((idx, hi, hi))
+        return out
 
     def subtract_bi_d(self, bd, dst, sd, pred, sp, src, ss, jobs):
         self._ck(self.L.havoc_mi355x_subtract_bi(self.h, self._S(src), bd, _ptr(dst), sd, _ptr(pred), sp, _ptr(src), ss, _ptr(jobs), jobs.shape[0]))
@@ -313,13 +324,19 @@ class Havoc:
         return int(self.down(out, np.int32)[0])
 
     def pred_uni(self, taps, bd, dst_len, sd, ref, sr, jobs):
+        jobs = np.asarray(jobs, np.int32)
         dst = self.zeros(dst_len, ref.dtype)
-        self.pred_uni_d(taps, bd, dst, sd, self.up(ref), sr, self._jobs(jobs, 8))
+        r = self.up(ref)
+        for idx, mw, mh in self.size_classes(jobs[:, 2], jobs[:, 3]):
+            self.pred_uni_d(taps, bd, dst, sd, r, sr, self._jobs(jobs[idx], 8), mw, mh)
         return self.down(dst, ref.dtype)
 
     def pred_bi(self, taps, bd, dst_len, sd, ref, sr, jobs):
+        jobs = np.asarray(jobs, np.int32)
         dst = self.zeros(dst_len, ref.dtype)
-        self.pred_bi_d(taps, bd, dst, sd, self.up(ref), sr, self._jobs(jobs, 12))
+        r = self.up(ref)
+        for idx, mw, mh in self.size_classes(jobs[:, 3], jobs[:, 4]):
+            self.pred_bi_d(taps, bd, dst, sd, r, sr, self._jobs(jobs[idx], 12), mw, mh)
         return self.down(dst, ref.dtype)
 
     def subtract_bi(self, bd, dst_len, sd, pred, sp, src, ss, jobs):
