@@ -390,6 +390,33 @@ def cpu_baseline(args):
 
 # --------------------------------------------------------------------------------------------------------------
 
+def hbm_traffic_from_profiles(group, S):
+    """HBM bytes per launch of a launch group, from the committed PMC passes (profiles/rNN_hbm_traffic.csv: rocprofv3
+    --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this bench, FETCH_SIZE x2 per the gfx950 note of
+    MI355X_MICROARCH.md; written by profiles/summarize.py).  None when there is no profile for the group's kernel or
+    the kernel is shared with another group (k_satd)."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.csv")))
+    if not files:
+        return None
+    prefix = {"sad4": f"k_sad<{S}, 4>", "sad": f"k_sad<{S}, 1>", "interp_planes": "k_interp_planes<", "intra_satd35": "k_intra_satd35<",
+              "intra": "k_intra<", "residual": "k_residual<", "transform": "k_transform<", "quantize_inverse": "k_quantize_inverse",
+              "inverse_transform_add": "k_inverse_transform<", "ssd": "k_ssd<", "subtract_bi": "k_subtract_bi<",
+              "subpel_satd": "k_subpel_satd<"}.get(group)
+    if prefix is None:
+        return None
+    total, n = 0.0, 0
+    for row in csv.DictReader(open(files[-1])):
+        if row["Kernel"].startswith(prefix):
+            try:
+                total += float(row.get("FETCH_SIZE_bytes_per_launch") or 0) + float(row.get("WRITE_SIZE_bytes_per_launch") or 0)
+                n += 1
+            except ValueError:
+                pass
+    return round(total / n) if n else None
+
+
 def main():
     args = parse_args()
     if args.cpu_worker:
@@ -453,7 +480,8 @@ def main():
         kbytes = wl.algorithmic_bytes()
         dom = max(ktimes, key=ktimes.get)
         ach = kbytes[dom] / (ktimes[dom] * 1e-3) / 1e9
-        total_bytes = sum(kbytes.values())
+        total_bytes = sum(kbytes[k] for k in ktimes)
+        traffic = hbm_traffic_from_profiles(dom, wl.S)
         ms_step = elapsed / args.steps * 1e3
         out = {
             "metric": "encoded fps (havoc hot path: one RA B-frame's primitive calls per frame)",
@@ -468,7 +496,7 @@ def main():
                        "calls_per_frame": int(sum(wl.counts.values())), "launches_per_frame": len(dev.launches),
                        "parallelism": f"frame-parallel x{world}" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "launch_ms": round(ktimes[dom] / kcount[dom], 5), "launches_per_step": kcount[dom],
                          "algorithmic_bytes_per_step": kbytes[dom]},
             "whole_step": {"algorithmic_bytes": total_bytes, "achieved_gbs": round(total_bytes / (ms_step * 1e-3) / 1e9, 2),
