@@ -134,6 +134,68 @@ __device__ __forceinline__ int satd_rows(int (&d)[TS], int r)
     return r == 0 ? sum : 0;
 }
 
+// ---- the same on packed 16-bit pairs, for 8-bit samples (|coefficient| <= 64*255 fits int16) ------------------------
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, a) + __builtin_bit_cast(s16x2, b));
+}
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, a) - __builtin_bit_cast(s16x2, b));
+}
+__device__ __forceinline__ uint32_t pk_bfly(uint32_t v)   // (a, b) -> (a + b, a - b)
+{
+    const s16x2 t = __builtin_bit_cast(s16x2, __builtin_amdgcn_alignbit(v, v, 16));   // (b, a)
+    const s16x2 sgn = {1, -1};
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, v) * sgn + t);
+}
+__device__ __forceinline__ uint32_t pk_abs_acc(uint32_t v, uint32_t acc)   // acc + |v.lo| + |v.hi|
+{
+    return __builtin_amdgcn_sad_u16(v ^ 0x80008000u, 0x80008000u, acc);
+}
+
+// satd_rows on packed pairs: p[] holds the lane's TS differences two per register IN ANY ORDER that is a permutation of
+// the index bits (the Walsh-Hadamard coefficient set is invariant under such permutations)
+template <int TS>
+__device__ __forceinline__ int satd_rows_pk(uint32_t (&p)[TS / 2], int r)
+{
+#pragma unroll
+    for (int k = 0; k < TS / 2; ++k) p[k] = pk_bfly(p[k]);
+#pragma unroll
+    for (int len = 1; len < TS / 2; len <<= 1)
+#pragma unroll
+        for (int i = 0; i < TS / 2; i += len << 1)
+#pragma unroll
+            for (int k = i; k < i + len; ++k)
+            {
+                const uint32_t a = p[k], b = p[k + len];
+                p[k] = pk_add(a, b);
+                p[k + len] = pk_sub(a, b);
+            }
+    const s16x2 one = {1, 1}, neg = {-1, -1};
+    if (TS == 8)
+    {
+        const s16x2 s4 = (r & 4) ? neg : one;
+#pragma unroll
+        for (int k = 0; k < TS / 2; ++k)
+            p[k] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, p[k]) * s4 + __builtin_bit_cast(s16x2, (uint32_t)dpp_mov<kDppHalfMirror>((int)p[k])));
+    }
+    const s16x2 s2 = (r & 2) ? neg : one, s1 = (r & 1) ? neg : one;
+#pragma unroll
+    for (int k = 0; k < TS / 2; ++k)
+        p[k] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, p[k]) * s2 + __builtin_bit_cast(s16x2, (uint32_t)dpp_mov<kDppXor3>((int)p[k])));
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < TS / 2; ++k)
+        sum = pk_abs_acc(__builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, p[k]) * s1 + __builtin_bit_cast(s16x2, (uint32_t)dpp_mov<kDppXor1>((int)p[k]))), sum);
+    int t = (int)sum;
+    t += dpp_mov<kDppXor1>(t);
+    t += dpp_mov<kDppXor3>(t);
+    if (TS == 8) t += dpp_mov<kDppHalfMirror>(t);
+    t = (t + TS / 4) / (TS / 2);
+    return r == 0 ? t : 0;
+}
+
 template <int S> struct Sample;
 template <> struct Sample<1> { typedef uint8_t T; };
 template <> struct Sample<2> { typedef uint16_t T; };

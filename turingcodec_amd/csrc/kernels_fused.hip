@@ -43,6 +43,78 @@ __device__ __forceinline__ int satd_regs(int (&d)[TS][TS])
     return S == 2 ? sum >> 2 : sum;
 }
 
+// 8-bit content: the same transform on packed 16-bit pairs (|coefficient| <= 64*255 fits int16): v_pk_add/sub_i16 for
+// the butterflies between registers, rotate + v_pk_mad for the butterfly inside a register, v_sad_u16 against a bias
+// for the sum of absolute values.  Roughly half the instructions of the 32-bit version.
+template <int TS>
+__device__ __forceinline__ int satd_regs_pk(uint32_t (&p)[TS][TS / 2])
+{
+#pragma unroll
+    for (int y = 0; y < TS; ++y)
+    {
+#pragma unroll
+        for (int k = 0; k < TS / 2; ++k) p[y][k] = pk_bfly(p[y][k]);          // x pairs (0,1), (2,3), ...
+#pragma unroll
+        for (int len = 1; len < TS / 2; len <<= 1)                            // between registers of the row
+#pragma unroll
+            for (int i = 0; i < TS / 2; i += len << 1)
+#pragma unroll
+                for (int k = i; k < i + len; ++k)
+                {
+                    const uint32_t a = p[y][k], b = p[y][k + len];
+                    p[y][k] = pk_add(a, b);
+                    p[y][k + len] = pk_sub(a, b);
+                }
+    }
+#pragma unroll
+    for (int len = 1; len < TS; len <<= 1)                                    // between rows
+#pragma unroll
+        for (int i = 0; i < TS; i += len << 1)
+#pragma unroll
+            for (int y = i; y < i + len; ++y)
+#pragma unroll
+                for (int k = 0; k < TS / 2; ++k)
+                {
+                    const uint32_t a = p[y][k], b = p[y + len][k];
+                    p[y][k] = pk_add(a, b);
+                    p[y + len][k] = pk_sub(a, b);
+                }
+    uint32_t sum = TS / 4;
+#pragma unroll
+    for (int y = 0; y < TS; ++y)
+#pragma unroll
+        for (int k = 0; k < TS / 2; ++k) sum = pk_abs_acc(p[y][k], sum);
+    return (int)(sum / (TS / 2));
+}
+
+// the difference tile of one work item: packed pairs for 8-bit samples, 32-bit for 16-bit samples
+template <int S, int TS>
+struct TileDiff
+{
+    int d[S == 1 ? 1 : TS][S == 1 ? 1 : TS];
+    uint32_t p[S == 1 ? TS : 1][S == 1 ? TS / 2 : 1];
+    // row j = source row (TS samples at `src`, 4-byte aligned) minus prediction v[]
+    __device__ __forceinline__ void set_row(int j, const uint16_t *src, const int (&v)[TS])
+    {
+        if constexpr (S == 1)
+        {
+#pragma unroll
+            for (int k = 0; k < TS / 2; ++k)
+                p[j][k] = pk_sub(*reinterpret_cast<const uint32_t *>(src + 2 * k), (uint32_t)v[2 * k] | ((uint32_t)v[2 * k + 1] << 16));
+        }
+        else
+        {
+#pragma unroll
+            for (int i = 0; i < TS; ++i) d[j][i] = (int)src[i] - v[i];
+        }
+    }
+    __device__ __forceinline__ int satd()
+    {
+        if constexpr (S == 1) return satd_regs_pk<TS>(p);
+        else return satd_regs<S, TS>(d);
+    }
+};
+
 // job: havoc_mi355x_intra_search_job = { src_off, nb_off, nbf_off, filt_lo, filt_hi, edge, reserved[2] }
 template <int S, int LOG2, int P, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_intra_satd35(const char *__restrict__ src, long stride_src, const char *__restrict__ neighbours,
@@ -157,7 +229,7 @@ __global__ __launch_bounds__(THREADS) void k_intra_satd35(const char *__restrict
         const uint32_t fbits = mode < 32 ? (uint32_t)s_job[p][3] >> mode : (uint32_t)s_job[p][4] >> (mode - 32);
         const uint16_t *nb = s_nb[p][fbits & 1];
         const bool edge = s_job[p][5] != 0 && LOG2 < 5;
-        int d[TS][TS];
+        TileDiff<S, TS> td;
         if (mode >= 2)
         {
             const int angle = c_angle35[mode];
@@ -172,20 +244,17 @@ __global__ __launch_bounds__(THREADS) void k_intra_satd35(const char *__restrict
                 const int t = (maj0 + j + 1) * angle;
                 const int idx = t >> 5, fact = t & 31;
                 const uint16_t *r = ref + min0 + idx + 1;
-                int rv[TS + 1];
+                int rv[TS + 1], v[TS];
 #pragma unroll
                 for (int i = 0; i <= TS; ++i) rv[i] = r[i];
 #pragma unroll
-                for (int i = 0; i < TS; ++i)
-                {
-                    int v = fact ? ((32 - fact) * rv[i] + fact * rv[i + 1] + 16) >> 5 : rv[i];
-                    if (i == 0 && efilt)
-                    {   // pred_intra.cpp:20355-20360 / :20394-20399: first column (row) of vertical (horizontal) prediction
-                        const int side = vertical ? nb[2 * N - 1 - (maj0 + j)] : nb[2 * N + 1 + (maj0 + j)];
-                        v = clip3(0, maxv, (int)ref[1] + ((side - (int)ref[0]) >> 1));
-                    }
-                    d[j][i] = (int)sb[(maj0 + j) * NS + min0 + i] - v;
+                for (int i = 0; i < TS; ++i) v[i] = fact ? ((32 - fact) * rv[i] + fact * rv[i + 1] + 16) >> 5 : rv[i];
+                if (efilt)
+                {   // pred_intra.cpp:20355-20360 / :20394-20399: first column (row) of vertical (horizontal) prediction
+                    const int side = vertical ? nb[2 * N - 1 - (maj0 + j)] : nb[2 * N + 1 + (maj0 + j)];
+                    v[0] = clip3(0, maxv, (int)ref[1] + ((side - (int)ref[0]) >> 1));
                 }
+                td.set_row(j, sb + (maj0 + j) * NS + min0, v);
             }
         }
         else if (mode == 1)
@@ -193,19 +262,23 @@ __global__ __launch_bounds__(THREADS) void k_intra_satd35(const char *__restrict
             const int dc = s_dc[p][fbits & 1];
 #pragma unroll
             for (int j = 0; j < TS; ++j)
+            {
+                const int y = ty * TS + j;
+                int v[TS];
 #pragma unroll
                 for (int i = 0; i < TS; ++i)
                 {
-                    const int x = tx * TS + i, y = ty * TS + j;
-                    int v = dc;
+                    const int x = tx * TS + i;
+                    v[i] = dc;
                     if (edge)
                     {
-                        if (x == 0 && y == 0) v = ((int)nb[2 * N - 1] + 2 * dc + (int)nb[2 * N + 1] + 2) >> 2;
-                        else if (y == 0) v = ((int)nb[2 * N + 1 + x] + 3 * dc + 2) >> 2;
-                        else if (x == 0) v = ((int)nb[2 * N - 1 - y] + 3 * dc + 2) >> 2;
+                        if (x == 0 && y == 0) v[i] = ((int)nb[2 * N - 1] + 2 * dc + (int)nb[2 * N + 1] + 2) >> 2;
+                        else if (y == 0) v[i] = ((int)nb[2 * N + 1 + x] + 3 * dc + 2) >> 2;
+                        else if (x == 0) v[i] = ((int)nb[2 * N - 1 - y] + 3 * dc + 2) >> 2;
                     }
-                    d[j][i] = (int)s_src[p][y * NS + x] - v;
                 }
+                td.set_row(j, s_src[p] + y * NS + tx * TS, v);
+            }
         }
         else
         {
@@ -215,16 +288,17 @@ __global__ __launch_bounds__(THREADS) void k_intra_satd35(const char *__restrict
             {
                 const int y = ty * TS + j;
                 const int left = nb[2 * N - 1 - y];
+                int v[TS];
 #pragma unroll
                 for (int i = 0; i < TS; ++i)
                 {
                     const int x = tx * TS + i;
-                    const int v = ((N - 1 - x) * left + (x + 1) * topR + (N - 1 - y) * (int)nb[2 * N + 1 + x] + (y + 1) * botL + N) >> (LOG2 + 1);
-                    d[j][i] = (int)s_src[p][y * NS + x] - v;
+                    v[i] = ((N - 1 - x) * left + (x + 1) * topR + (N - 1 - y) * (int)nb[2 * N + 1 + x] + (y + 1) * botL + N) >> (LOG2 + 1);
                 }
+                td.set_row(j, s_src[p] + y * NS + tx * TS, v);
             }
         }
-        const int c = satd_regs<S, TS>(d);
+        const int c = td.satd();
         if (NT == 1) s_cost[p][mode] = c;
         else atomicAdd(&s_cost[p][mode], c);
     }

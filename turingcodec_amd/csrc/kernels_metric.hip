@@ -266,9 +266,21 @@ __global__ __launch_bounds__(256) void k_satd(const char *__restrict__ pa, long 
         {
             const int tile = it >> 3, r = it & 7;
             const int ty = fd.div(tile), tx = tile - ty * tw;
-            int d[8];
-            load_diff_row<S, 8>(a + (long)(ty * 8 + r) * sab + tx * 8 * S, b + (long)(ty * 8 + r) * sbb + tx * 8 * S, d);
-            acc += satd_rows<S, 8>(d, r);
+            const char *pa8 = a + (long)(ty * 8 + r) * sab + tx * 8 * S, *pb8 = b + (long)(ty * 8 + r) * sbb + tx * 8 * S;
+            if (S == 1)
+            {   // bytes (0,2) / (1,3) of each dword become 16-bit pairs: an index-bit permutation, fine for the Hadamard
+                const u32x2 va = ld8(pa8), vb = ld8(pb8);
+                const uint32_t m = 0x00ff00ffu;
+                uint32_t p[4] = {pk_sub(va.x & m, vb.x & m), pk_sub((va.x >> 8) & m, (vb.x >> 8) & m),
+                                 pk_sub(va.y & m, vb.y & m), pk_sub((va.y >> 8) & m, (vb.y >> 8) & m)};
+                acc += satd_rows_pk<8>(p, r);
+            }
+            else
+            {
+                int d[8];
+                load_diff_row<S, 8>(pa8, pb8, d);
+                acc += satd_rows<S, 8>(d, r);
+            }
         }
     }
     else if (((w | h) & 3) == 0)
@@ -279,9 +291,19 @@ __global__ __launch_bounds__(256) void k_satd(const char *__restrict__ pa, long 
         {
             const int tile = it >> 2, r = it & 3;
             const int ty = fd.div(tile), tx = tile - ty * tw;
-            int d[4];
-            load_diff_row<S, 4>(a + (long)(ty * 4 + r) * sab + tx * 4 * S, b + (long)(ty * 4 + r) * sbb + tx * 4 * S, d);
-            acc += satd_rows<S, 4>(d, r);
+            const char *pa4 = a + (long)(ty * 4 + r) * sab + tx * 4 * S, *pb4 = b + (long)(ty * 4 + r) * sbb + tx * 4 * S;
+            if (S == 1)
+            {
+                const uint32_t va = ld4(pa4), vb = ld4(pb4), m = 0x00ff00ffu;
+                uint32_t p[2] = {pk_sub(va & m, vb & m), pk_sub((va >> 8) & m, (vb >> 8) & m)};
+                acc += satd_rows_pk<4>(p, r);
+            }
+            else
+            {
+                int d[4];
+                load_diff_row<S, 4>(pa4, pb4, d);
+                acc += satd_rows<S, 4>(d, r);
+            }
         }
     }
     else

@@ -126,7 +126,13 @@ __global__ __launch_bounds__(256) void k_subpel_satd(const char *__restrict__ sr
                 const int sj = (jj & 1) ? (int)(sv[jj >> 1] >> 16) : (int)(sv[jj >> 1] & 0xffff);
                 d[jj] = sj - v;
             }
-            acc += satd_rows<S, 8>(d, c);
+            if (S == 1)
+            {
+                uint32_t pk[4] = {pack_i16(d[0], d[1]), pack_i16(d[2], d[3]), pack_i16(d[4], d[5]), pack_i16(d[6], d[7])};
+                acc += satd_rows_pk<8>(pk, c);
+            }
+            else
+                acc += satd_rows<S, 8>(d, c);
         }
     }
     const bool other = live && !tiles8;

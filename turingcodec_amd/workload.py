@@ -112,7 +112,18 @@ class FrameWorkload:
             # PU positions are aligned to their own size inside the picture (natural CU alignment)
             x = (rng.integers(0, 1 << 30, nj) % np.maximum(1, (W - w) // w + 1)) * w
             y = (rng.integers(0, 1 << 30, nj) % np.maximum(1, (H - h) // h + 1)) * h
-            return w, h, x.astype(np.int32), y.astype(np.int32)
+            o = ctu_order(x, y)   # the encoder queues jobs CTU by CTU (raster / WPP order): keep that locality
+            return w[o], h[o], x[o].astype(np.int32), y[o].astype(np.int32)
+
+        def ctu_order(x, y):
+            return np.argsort((np.asarray(y) // CTU) * 4096 + np.asarray(x) // CTU, kind="stable")
+
+        def grid_pos(nn, m):
+            """m block positions aligned to nn, in CTU order"""
+            x = (rng.integers(0, (W - nn) // nn + 1, m) * nn).astype(np.int32)
+            y = (rng.integers(0, (H - nn) // nn + 1, m) * nn).astype(np.int32)
+            o = ctu_order(x, y)
+            return x[o], y[o]
 
         def loff(x, y, plane):  # luma offset inside the picture store
             return (plane * pl + (y + PAD) * st + (x + PAD)).astype(np.int32)
@@ -146,7 +157,9 @@ class FrameWorkload:
             rows.append(np.stack([np.zeros_like(w), loff(x + cx, y + cy, rng.integers(1, 3, n[name])), w, h, xf, yf,
                                   loff(x, y, 0), np.zeros_like(w)], 1))
         u = np.concatenate(rows).astype(np.int32)
-        u = u[rng.permutation(len(u))]
+        # interleave the four kinds the way a CTU-by-CTU search meets them: sort by the CTU of the source PU
+        upos = u[:, 6] % pl
+        u = u[ctu_order(upos % st - PAD, upos // st - PAD)]
         # costDistortionMv candidates (1474818/8 per B-frame, A.2) only need the COST: they go through the fused
         # interpolation+SATD entry point, one launch per PU size class; the rest (measurePuCost: the prediction is
         # kept) are written to prediction slots and measured by the SATD batch
@@ -262,8 +275,7 @@ class FrameWorkload:
             nn = 1 << log2
             L = 4 * nn + 1
             m = int((rd_sizes == log2).sum())
-            x = (rng.integers(0, (W - nn) // nn + 1, m) * nn).astype(np.int32)
-            y = (rng.integers(0, (H - nn) // nn + 1, m) * nn).astype(np.int32)
+            x, y = grid_pos(nn, m)
             self.intra_nb[log2] = np.ascontiguousarray(neighbours_of(x, y, nn).ravel())
             j = np.zeros((m, 8), np.int32)
             j[:, 0] = np.arange(m) * nn * nn
@@ -273,8 +285,7 @@ class FrameWorkload:
             j[:, 4] = 1
             self.intra[log2] = j
             m = int((sr_sizes == log2).sum())
-            x = (rng.integers(0, (W - nn) // nn + 1, m) * nn).astype(np.int32)
-            y = (rng.integers(0, (H - nn) // nn + 1, m) * nn).astype(np.int32)
+            x, y = grid_pos(nn, m)
             nbu = neighbours_of(x, y, nn).astype(np.int32)
             nbf = nbu.copy()                                     # [1 2 1] smoothing (IntraReferenceSamples.h:373-421)
             nbf[:, 1:-1] = (nbu[:, :-2] + 2 * nbu[:, 1:-1] + nbu[:, 2:] + 2) >> 2
@@ -293,8 +304,7 @@ class FrameWorkload:
         ti = _pick(rng, TU_MIX, n["tu"])
         for gi, (log2, tr, _) in enumerate(TU_MIX):
             m, nn = int((ti == gi).sum()), 1 << log2
-            x = (rng.integers(0, (W - nn) // nn + 1, m) * nn).astype(np.int32)
-            y = (rng.integers(0, (H - nn) // nn + 1, m) * nn).astype(np.int32)
+            x, y = grid_pos(nn, m)
             dx, dy = mv(m, 2)
             t = np.zeros((m, 4), np.int32)
             t[:, 0] = np.arange(m) * nn * nn                # coefficients / levels / residual: n*n contiguous
