@@ -257,6 +257,24 @@ int havoc_mi355x_inverse_transform(havoc_mi355x_ctx *ctx, int bitDepth, int trTy
 int havoc_mi355x_inverse_transform_add(havoc_mi355x_ctx *ctx, int S, int bitDepth, int trType, int log2TrafoSize,
                                        void *d_dst, intptr_t stride_dst, const void *d_pred, intptr_t stride_pred,
                                        const int16_t *d_coeffs, const havoc_mi355x_tu_job *d_jobs, int njobs);
+/* The TU chain of the reference's reconstruction, fused on either side of the host's quantiser decision (at
+ * speed=medium RDOQ, which is not havoc, runs between the two; turing/Reconstruct.cpp:258-353 and :766-856):
+ *   tu_forward     : residual = src - pred (Reconstruct.cpp:258-260), then havoc::Transform -> d_coeffs[coef_off ..]
+ *   tu_reconstruct : havoc_quantize_inverse(levels, scale, shift), then havoc::inverse_transform_add onto the
+ *                    prediction -> d_rec[rec_off ..] (row stride stride_rec), then havoc_ssd(src, rec) -> d_ssd[i].
+ * Residual and de-quantised coefficients are never written.  Bit-identical to calling the separate entry points. */
+typedef struct {
+    int32_t coef_off;  /* n*n contiguous int16: coefficients (forward) / levels (reconstruct) */
+    int32_t src_off;   /* source block in d_src */
+    int32_t pred_off;  /* prediction block in d_pred */
+    int32_t rec_off;   /* reconstructed block in d_rec (may be the prediction's own location) */
+} havoc_mi355x_tu_fused_job; /* 16 bytes */
+int havoc_mi355x_tu_forward(havoc_mi355x_ctx *ctx, int S, int bitDepth, int trType, int log2TrafoSize, int16_t *d_coeffs, const void *d_src,
+                            intptr_t stride_src, const void *d_pred, intptr_t stride_pred, const havoc_mi355x_tu_fused_job *d_jobs, int njobs);
+int havoc_mi355x_tu_reconstruct(havoc_mi355x_ctx *ctx, int S, int bitDepth, int trType, int log2TrafoSize, int scale, int shift, void *d_rec,
+                                intptr_t stride_rec, const void *d_pred, intptr_t stride_pred, const void *d_src, intptr_t stride_src,
+                                const int16_t *d_levels, const havoc_mi355x_tu_fused_job *d_jobs, int njobs, uint32_t *d_ssd);
+
 /* havoc_quantize (havoc/quantize.h:63, quantize.cpp:278-304): d_cbf[i] = OR of the job's outputs */
 int havoc_mi355x_quantize(havoc_mi355x_ctx *ctx, int16_t *d_dst, const int16_t *d_src,
                           const havoc_mi355x_quant_job *d_jobs, int njobs, int32_t *d_cbf);

@@ -152,6 +152,19 @@ def make_inputs(seed=20260927):
                 jobs.append((cases.off(x, y), base + c, base + len(nbu) + c, mask & 0xffffffff, mask >> 32, rep != 1, log2, 0))
         d[f"{k}.intra35.nb"] = np.concatenate(nbs)
         d[f"{k}.intra35.jobs"] = np.array(jobs, np.int64).astype(np.uint32).view(np.int32).reshape(len(jobs), 8)
+    # fused TU chain: source in plane a, prediction in plane b, reconstruction slots (stride 64), small random levels
+    for S in (1, 2):
+        k = "u8" if S == 1 else "u16"
+        tj, co = [], 0
+        for (log2, tr) in cases.TRANSFORMS:
+            n = 1 << log2
+            for rep in range(5):
+                sx, sy = cases.rand_pos(rng, n, n)
+                px, py = cases.rand_pos(rng, n, n)
+                tj.append((co, cases.off(sx, sy), cases.off(px, py), len(tj) * SLOT, log2, tr, 0, 0))
+                co += n * n
+        d[f"{k}.tuf.jobs"] = np.array(tj, np.int32)
+        d[f"{k}.tuf.levels"] = rng.integers(-48, 49, co).astype(np.int16)
     # fused sub-pel candidates: the pred_uni job tables with dst_off replaced by a source-block offset in plane b
     for S in (1, 2):
         k = "u8" if S == 1 else "u16"
@@ -231,6 +244,11 @@ def run(impl, d, keys=None):
         k = "u8" if S == 1 else "u16"
         if want(f"{k}.intra35"):
             out[f"{k}.intra35"] = impl.intra_satd35(bd, d[f"{k}.a"], W, d[f"{k}.intra35.nb"], d[f"{k}.intra35.jobs"])
+        if want(f"{k}.tuf"):
+            j = d[f"{k}.tuf.jobs"]
+            out[f"{k}.tuf.coef"] = impl.tu_forward(bd, len(d[f"{k}.tuf.levels"]), d[f"{k}.a"], W, d[f"{k}.b"], W, j)
+            rec, ssd = impl.tu_reconstruct(bd, 32, len(j) * SLOT, 64, d[f"{k}.b"], W, d[f"{k}.a"], W, d[f"{k}.tuf.levels"], j)
+            out[f"{k}.tuf.rec"], out[f"{k}.tuf.ssd"] = rec, np.asarray(ssd, np.uint32)
         if want(f"{k}.planes"):
             # a rectangle that is not a multiple of the 64x16 kernel tile, inside the 160x160 plane with the required margin
             out[f"{k}.planes"] = impl.interp_planes(bd, d[f"{k}.a"], W, 5, 6, 139, 141)
@@ -314,6 +332,30 @@ class LoopImpl:
             else:
                 self.f.intra(dst, do, sd, nb, no, log2, mode, edge, bd)
         return dst
+
+    def tu_forward(self, bd, ncoef, src, ss, pred, sp, jobs):
+        """residual loop (turing/Reconstruct.cpp:258-260) then the forward transform, per TU"""
+        co = np.zeros(ncoef, np.int16)
+        for j in np.asarray(jobs, np.int32):
+            c, so, po, _, log2, tr = (int(v) for v in j[:6])
+            n = 1 << log2
+            res = self.residual(n * n, n, [0], src, ss, pred, sp, np.array([[so, po, n, n]], np.int32))
+            self.f.transform(co, c, res, 0, n, log2, tr, bd)
+        return co
+
+    def tu_reconstruct(self, bd, qp, rec_len, sr, pred, sp, src, ss, levels, jobs):
+        """havoc_quantize_inverse -> inverse_transform_add -> havoc_ssd(src, rec), per TU (Reconstruct.cpp:315-353)"""
+        rec = np.zeros(rec_len, src.dtype)
+        ssd = []
+        for j in np.asarray(jobs, np.int32):
+            c, so, po, ro, log2, tr = (int(v) for v in j[:6])
+            n = 1 << log2
+            scale, shift = cases.dequant_params(qp, log2, bd)
+            dq = np.zeros(n * n, np.int16)
+            self.f.quantize_inverse(dq, 0, levels, c, scale, shift, n * n)
+            self.f.inverse_transform_add(rec, ro, sr, pred, po, sp, dq, 0, log2, tr, bd)
+            ssd.append(self.f.ssd(src, so, ss, rec, ro, sr, n, n))
+        return rec, np.array(ssd, np.uint32)
 
     def interp_planes(self, bd, ref, stride, x0, y0, width, height):
         """every sample of plane (xf, yf) = what pred_uni writes there when the sample is part of any block: evaluate

@@ -22,7 +22,7 @@ def golden():
 
 GROUPS = ["u8.sad", "u16.sad", "u8.ssd", "u16.ssd", "u8.satd", "u16.satd", "u8.pred_uni", "u16.pred_uni", "u8.pred_bi",
           "u16.pred_bi", "subtract_bi", "u8.intra", "u16.intra", "residual", "u8.itx", "u16.itx", "fwd8", "fwd10",
-          "quant", "qrec", "ssd_linear", "u8.intra35", "u16.intra35", "u8.subpel", "u16.subpel", "u8.planes", "u16.planes"]
+          "quant", "qrec", "ssd_linear", "u8.intra35", "u16.intra35", "u8.subpel", "u16.subpel", "u8.planes", "u16.planes", "u8.tuf", "u16.tuf"]
 
 
 @pytest.mark.parametrize("group", GROUPS)

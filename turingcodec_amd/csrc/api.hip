@@ -21,6 +21,9 @@ hipError_t launch_subpel_satd(hipStream_t, int S, int taps, int bd, int maxw, in
 hipError_t launch_transform(hipStream_t, int bd, int log2, int tr, int16_t *, const int16_t *, long, const void *, int);
 hipError_t launch_inverse_transform(hipStream_t, int mode, int bd, int log2, int tr, void *, long, const void *, long, int16_t *, const int16_t *,
                                     const void *, int);
+hipError_t launch_tu_forward(hipStream_t, int S, int bd, int log2, int tr, int16_t *, const void *, long, const void *, long, const void *, int);
+hipError_t launch_tu_reconstruct(hipStream_t, int S, int bd, int log2, int tr, int scale, int shift, void *, long, const void *, long, const void *,
+                                 long, const int16_t *, const void *, int, uint32_t *);
 hipError_t launch_quantize(hipStream_t, int16_t *, const int16_t *, const void *, int, int32_t *);
 hipError_t launch_quantize_inverse(hipStream_t, int16_t *, const int16_t *, const void *, int);
 hipError_t launch_quantize_reconstruct(hipStream_t, int log2, uint8_t *, long, const uint8_t *, long, const int16_t *, const void *, int);
@@ -37,6 +40,7 @@ static_assert(sizeof(havoc_mi355x_subtract_bi_job) == 32, "job ABI");
 static_assert(sizeof(havoc_mi355x_intra_job) == 32, "job ABI");
 static_assert(sizeof(havoc_mi355x_tu_job) == 16, "job ABI");
 static_assert(sizeof(havoc_mi355x_intra_search_job) == 32, "job ABI");
+static_assert(sizeof(havoc_mi355x_tu_fused_job) == 16, "job ABI");
 static_assert(sizeof(havoc_mi355x_quant_job) == 32, "job ABI");
 
 struct havoc_mi355x_ctx
@@ -437,6 +441,25 @@ int havoc_mi355x_inverse_transform_add(havoc_mi355x_ctx *ctx, int S, int bitDept
     return check(launch_inverse_transform(LS(ctx),S, bitDepth, log2TrafoSize, trType, d_dst, stride_dst, d_pred, stride_pred, nullptr, d_coeffs,
                                           d_jobs, njobs),
                  "inverse_transform_add");
+}
+
+int havoc_mi355x_tu_forward(havoc_mi355x_ctx *ctx, int S, int bitDepth, int trType, int log2TrafoSize, int16_t *d_coeffs, const void *d_src,
+                            intptr_t stride_src, const void *d_pred, intptr_t stride_pred, const havoc_mi355x_tu_fused_job *d_jobs, int njobs)
+{
+    REQUIRE_CTX(); REQUIRE_S(); REQUIRE_BD(); REQUIRE_TR(); REQUIRE(njobs >= 0, "njobs < 0");
+    return check(launch_tu_forward(LS(ctx), S, bitDepth, log2TrafoSize, trType, d_coeffs, d_src, stride_src, d_pred, stride_pred, d_jobs, njobs),
+                 "tu_forward");
+}
+
+int havoc_mi355x_tu_reconstruct(havoc_mi355x_ctx *ctx, int S, int bitDepth, int trType, int log2TrafoSize, int scale, int shift, void *d_rec,
+                                intptr_t stride_rec, const void *d_pred, intptr_t stride_pred, const void *d_src, intptr_t stride_src,
+                                const int16_t *d_levels, const havoc_mi355x_tu_fused_job *d_jobs, int njobs, uint32_t *d_ssd)
+{
+    REQUIRE_CTX(); REQUIRE_S(); REQUIRE_BD(); REQUIRE_TR(); REQUIRE(njobs >= 0, "njobs < 0");
+    REQUIRE(shift >= 1 && shift <= 30 && scale > 0, "scale / shift out of range");
+    return check(launch_tu_reconstruct(LS(ctx), S, bitDepth, log2TrafoSize, trType, scale, shift, d_rec, stride_rec, d_pred, stride_pred, d_src,
+                                       stride_src, d_levels, d_jobs, njobs, d_ssd),
+                 "tu_reconstruct");
 }
 
 int havoc_mi355x_quantize(havoc_mi355x_ctx *ctx, int16_t *d_dst, const int16_t *d_src, const havoc_mi355x_quant_job *d_jobs, int njobs, int32_t *d_cbf)

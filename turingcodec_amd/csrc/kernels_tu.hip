@@ -10,103 +10,9 @@
 // bank-conflict free.  Integer arithmetic throughout; the wrap (forward) / saturate (inverse) quirks of the reference
 // are reproduced exactly.
 #include "common.h"
+#include "transform_basis.h"
 
 namespace havoc_gpu {
-
-// ---- HEVC core transform basis, generated at compile time.  kMag[j] ~ 64*sqrt(2)*cos(j*pi/64); row k of the N-point
-// DCT is row k*(32/N) of the 32-point matrix (values as in havoc/transform.cpp:85-91,119-129,170-188,243-277).
-constexpr int kMag[33] = {64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67, 64,
-                          61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9,  4,  0};
-constexpr int kDst7[4][4] = {{29, 55, 74, 84}, {74, 74, 0, -74}, {84, -29, -74, 55}, {55, -84, 74, -29}};
-
-constexpr int basis(int n, int tr, int k, int c)
-{
-    if (tr) return kDst7[k][c];
-    const int kk = k * (32 / n);
-    if (kk == 0) return 64;
-    const int j = (kk * (2 * c + 1)) & 127;
-    return j <= 32 ? kMag[j] : (j <= 64 ? -kMag[64 - j] : (j <= 96 ? -kMag[j - 64] : kMag[128 - j]));
-}
-
-// v[k][p] packs (M[k][2p], M[k][2p+1]) for the forward transform, (M[2p][k], M[2p+1][k]) for the inverse
-template <int N> struct PackedBasis { uint32_t v[N][N / 2]; };
-
-template <int N, int TR, bool INV>
-constexpr PackedBasis<N> make_basis()
-{
-    PackedBasis<N> m{};
-    for (int k = 0; k < N; ++k)
-        for (int p = 0; p < N / 2; ++p)
-        {
-            const int lo = INV ? basis(N, TR, 2 * p, k) : basis(N, TR, k, 2 * p);
-            const int hi = INV ? basis(N, TR, 2 * p + 1, k) : basis(N, TR, k, 2 * p + 1);
-            m.v[k][p] = ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16);
-        }
-    return m;
-}
-
-__constant__ PackedBasis<4> c_fwd_dst4 = make_basis<4, 1, false>();
-__constant__ PackedBasis<4> c_fwd_dct4 = make_basis<4, 0, false>();
-__constant__ PackedBasis<8> c_fwd_dct8 = make_basis<8, 0, false>();
-__constant__ PackedBasis<16> c_fwd_dct16 = make_basis<16, 0, false>();
-__constant__ PackedBasis<32> c_fwd_dct32 = make_basis<32, 0, false>();
-__constant__ PackedBasis<4> c_inv_dst4 = make_basis<4, 1, true>();
-__constant__ PackedBasis<4> c_inv_dct4 = make_basis<4, 0, true>();
-__constant__ PackedBasis<8> c_inv_dct8 = make_basis<8, 0, true>();
-__constant__ PackedBasis<16> c_inv_dct16 = make_basis<16, 0, true>();
-__constant__ PackedBasis<32> c_inv_dct32 = make_basis<32, 0, true>();
-
-template <int N, int TR, bool INV> __device__ __forceinline__ const PackedBasis<N> &basis_table();
-template <> __device__ __forceinline__ const PackedBasis<4> &basis_table<4, 1, false>() { return c_fwd_dst4; }
-template <> __device__ __forceinline__ const PackedBasis<4> &basis_table<4, 0, false>() { return c_fwd_dct4; }
-template <> __device__ __forceinline__ const PackedBasis<8> &basis_table<8, 0, false>() { return c_fwd_dct8; }
-template <> __device__ __forceinline__ const PackedBasis<16> &basis_table<16, 0, false>() { return c_fwd_dct16; }
-template <> __device__ __forceinline__ const PackedBasis<32> &basis_table<32, 0, false>() { return c_fwd_dct32; }
-template <> __device__ __forceinline__ const PackedBasis<4> &basis_table<4, 1, true>() { return c_inv_dst4; }
-template <> __device__ __forceinline__ const PackedBasis<4> &basis_table<4, 0, true>() { return c_inv_dct4; }
-template <> __device__ __forceinline__ const PackedBasis<8> &basis_table<8, 0, true>() { return c_inv_dct8; }
-template <> __device__ __forceinline__ const PackedBasis<16> &basis_table<16, 0, true>() { return c_inv_dct16; }
-template <> __device__ __forceinline__ const PackedBasis<32> &basis_table<32, 0, true>() { return c_inv_dct32; }
-
-__device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int c)
-{
-    return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b), c, false);
-}
-
-// out[k] = sum_j M[k][j] * row[j] + add, for all k, M uniform across lanes (scalar operands)
-template <int N, int TR, bool INV>
-__device__ __forceinline__ void basis_times_row(const uint32_t (&row)[N / 2], int add, int (&out)[N])
-{
-    const PackedBasis<N> &m = basis_table<N, TR, INV>();
-#pragma unroll
-    for (int k = 0; k < N; ++k)
-    {
-        int a = add;
-#pragma unroll
-        for (int p = 0; p < N / 2; ++p) a = dot2(row[p], m.v[k][p], a);
-        out[k] = a;
-    }
-}
-
-// load N contiguous int16 (N/2 dwords) from global memory with the widest loads the size allows
-template <int N>
-__device__ __forceinline__ void load_row16(const int16_t *p, uint32_t (&row)[N / 2])
-{
-    if (N == 4)
-    {
-        const u32x2 v = ld8(p);
-        row[0] = v.x; row[1] = v.y;
-    }
-    else
-    {
-#pragma unroll
-        for (int q = 0; q < N / 8; ++q)
-        {
-            const u32x4 v = ld16(p + 8 * q);
-            row[4 * q] = v.x; row[4 * q + 1] = v.y; row[4 * q + 2] = v.z; row[4 * q + 3] = v.w;
-        }
-    }
-}
 
 // havoc::Transform (havoc/transform.h:117; C reference havoc/transform.cpp:3087-3397)
 template <int LOG2, int TR>

@@ -1,0 +1,245 @@
+// The transform-unit chain of the reference's reconstruction (turing/Reconstruct.cpp:258-353 intra, :766-856 inter),
+// fused on either side of the host's quantiser decision (RDOQ sits between the two halves):
+//
+//   k_tu_forward     : residual = source - prediction  (Reconstruct.cpp:258-260)  ->  forward DCT/DST
+//                      (havoc/transform.cpp:3087-3397).  The residual is formed in registers from the two sample rows.
+//   k_tu_reconstruct : de-quantise the levels (havoc/quantize.cpp:37-46)  ->  inverse DCT/DST + add prediction + clip
+//                      (havoc/transform.cpp:50-401, transform.h:104-114)  ->  SSD of the reconstruction against the
+//                      source (havoc/ssd.cpp:28-43).  De-quantised coefficients and the residual never leave the CU.
+//
+// Same mapping as kernels_tu.hip: one lane per TU row, 64/N TUs per wavefront, basis pairs through SGPRs into
+// v_dot2c_i32_i16, padded LDS transpose between the passes.  Results are bit-identical to running the separate
+// kernels (tests: tu_fused groups).
+#include "common.h"
+#include "transform_basis.h"
+
+namespace havoc_gpu {
+
+// N samples of one row as N/2 packed 16-bit pairs (x, x+1)
+template <int S, int N>
+__device__ __forceinline__ void load_sample_row(const char *p, uint32_t (&row)[N / 2])
+{
+    if (S == 1)
+    {
+        uint32_t b[N / 4];
+        if (N == 4) b[0] = ld4(p);
+        else if (N == 8)
+        {
+            const u32x2 v = ld8(p);
+            b[0] = v.x; b[1] = v.y;
+        }
+        else
+        {
+#pragma unroll
+            for (int q = 0; q < N / 16; ++q)
+            {
+                const u32x4 v = ld16(p + 16 * q);
+                b[4 * q] = v.x; b[4 * q + 1] = v.y; b[4 * q + 2] = v.z; b[4 * q + 3] = v.w;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < N / 4; ++q)
+        {
+            row[2 * q] = __builtin_amdgcn_perm(0u, b[q], 0x0c010c00u);       // (byte0, byte1) zero-extended
+            row[2 * q + 1] = __builtin_amdgcn_perm(0u, b[q], 0x0c030c02u);   // (byte2, byte3)
+        }
+    }
+    else
+    {
+        if (N == 4)
+        {
+            const u32x2 v = ld8(p);
+            row[0] = v.x; row[1] = v.y;
+        }
+        else
+        {
+#pragma unroll
+            for (int q = 0; q < N / 8; ++q)
+            {
+                const u32x4 v = ld16(p + 16 * q);
+                row[4 * q] = v.x; row[4 * q + 1] = v.y; row[4 * q + 2] = v.z; row[4 * q + 3] = v.w;
+            }
+        }
+    }
+}
+
+// job: havoc_mi355x_tu_fused_job { coef_off, src_off, pred_off, rec_off }
+template <int S, int LOG2, int TR>
+__global__ __launch_bounds__(64) void k_tu_forward(int16_t *__restrict__ coeffs, const char *__restrict__ src, long stride_src,
+                                                   const char *__restrict__ pred, long stride_pred, const int32_t *__restrict__ jobs, int njobs,
+                                                   int bitDepth)
+{
+    constexpr int N = 1 << LOG2, TPW = 64 / N, LS = N + 2;
+    __shared__ int16_t lds[TPW][N * LS];
+    const int t = threadIdx.x / N, r = threadIdx.x % N;
+    const int job = blockIdx.x * TPW + t;
+    const bool live = job < njobs;
+    const int32_t *j = jobs + (long)(live ? job : 0) * 4;
+    const int shift1 = LOG2 - 1 + bitDepth - 8, shift2 = LOG2 + 6;
+
+    uint32_t row[N / 2], prow[N / 2];
+    load_sample_row<S, N>(src + ((long)j[1] + (long)r * stride_src) * S, row);
+    load_sample_row<S, N>(pred + ((long)j[2] + (long)r * stride_pred) * S, prow);
+#pragma unroll
+    for (int p = 0; p < N / 2; ++p) row[p] = pk_sub(row[p], prow[p]);   // residual (|.| <= 1023: no 16-bit overflow)
+    int o[N];
+    basis_times_row<N, TR, false>(row, 1 << (shift1 - 1), o);
+#pragma unroll
+    for (int k = 0; k < N; ++k) lds[t][k * LS + r] = (int16_t)(o[k] >> shift1);
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < N / 2; ++p) row[p] = *reinterpret_cast<const uint32_t *>(&lds[t][r * LS + 2 * p]);
+    basis_times_row<N, TR, false>(row, 1 << (shift2 - 1), o);
+    if (!live) return;
+    int16_t *c = coeffs + j[0] + r;
+#pragma unroll
+    for (int k = 0; k < N; ++k) c[k * N] = (int16_t)(o[k] >> shift2);
+}
+
+template <int S, int LOG2, int TR>
+__global__ __launch_bounds__(64) void k_tu_reconstruct(char *rec, long stride_rec, const char *pred, long stride_pred, const char *__restrict__ src,
+                                                       long stride_src, const int16_t *__restrict__ levels, const int32_t *__restrict__ jobs,
+                                                       int njobs, int bitDepth, int scale, int shift, uint32_t *__restrict__ ssd)
+{
+    typedef typename Sample<S>::T T;
+    constexpr int N = 1 << LOG2, TPW = 64 / N, LS = N + 2;
+    __shared__ int16_t lds[TPW][N * LS];
+    const int t = threadIdx.x / N, r = threadIdx.x % N;
+    const int job = blockIdx.x * TPW + t;
+    const bool live = job < njobs;
+    const int32_t *j = jobs + (long)(live ? job : 0) * 4;
+    const int shift2 = 20 - bitDepth;
+    const int dqadd = 1 << (shift - 1);
+
+    // column r of the level block, de-quantised on the fly, packed in row pairs
+    const int16_t *c = levels + j[0] + r;
+    uint32_t col[N / 2];
+#pragma unroll
+    for (int p = 0; p < N / 2; ++p)
+    {
+        const int lo = clip3(-32768, 32767, ((int)c[(2 * p) * N] * scale + dqadd) >> shift);
+        const int hi = clip3(-32768, 32767, ((int)c[(2 * p + 1) * N] * scale + dqadd) >> shift);
+        col[p] = ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16);
+    }
+    int o[N];
+    basis_times_row<N, TR, true>(col, 1 << 6, o);
+#pragma unroll
+    for (int k = 0; k < N; ++k) lds[t][k * LS + r] = (int16_t)clip3(-32768, 32767, o[k] >> 7);
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < N / 2; ++p) col[p] = *reinterpret_cast<const uint32_t *>(&lds[t][r * LS + 2 * p]);
+    basis_times_row<N, TR, true>(col, 1 << (shift2 - 1), o);
+
+    const int maxv = (1 << bitDepth) - 1;
+    uint32_t prow[N / 2], srow[N / 2];
+    load_sample_row<S, N>(pred + ((long)j[2] + (long)r * stride_pred) * S, prow);   // whole row read before any write: pred may alias rec
+    load_sample_row<S, N>(src + ((long)j[1] + (long)r * stride_src) * S, srow);
+    uint32_t acc = 0;
+    int v[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+    {
+        const int res = clip3(-32768, 32767, o[k] >> shift2);
+        const int pk = (k & 1) ? (int)(prow[k >> 1] >> 16) : (int)(prow[k >> 1] & 0xffff);
+        const int sk = (k & 1) ? (int)(srow[k >> 1] >> 16) : (int)(srow[k >> 1] & 0xffff);
+        v[k] = clip3(0, maxv, pk + res);
+        const int d = sk - v[k];
+        acc += (uint32_t)(d * d);
+    }
+    if (live)
+    {
+        T *q = reinterpret_cast<T *>(rec) + j[3] + (long)r * stride_rec;
+        if (S == 1)
+        {
+#pragma unroll
+            for (int k = 0; k < N; k += 4) st4(q + k, (uint32_t)v[k] | ((uint32_t)v[k + 1] << 8) | ((uint32_t)v[k + 2] << 16) | ((uint32_t)v[k + 3] << 24));
+        }
+        else
+        {
+#pragma unroll
+            for (int k = 0; k < N; k += 2) st4(q + k, (uint32_t)v[k] | ((uint32_t)v[k + 1] << 16));
+        }
+    }
+    // SSD of the TU: sum over its N lanes (uint32 accumulation as havoc_ssd_c_ref; 16-bit result >> 4)
+    uint32_t tot = (uint32_t)group_sum<N>((int)acc);
+    if (S == 2) tot >>= 4;
+    if (live && r == 0) ssd[job] = tot;
+}
+
+template <int S, int LOG2, int TR>
+static void go_fwd(hipStream_t st, int16_t *co, const char *src, long ss, const char *pred, long sp, const int32_t *j, int n, int bd)
+{
+    constexpr int TPW = 64 >> LOG2;
+    hipLaunchKernelGGL((k_tu_forward<S, LOG2, TR>), dim3((n + TPW - 1) / TPW), dim3(64), 0, st, co, src, ss, pred, sp, j, n, bd);
+}
+
+template <int S>
+static hipError_t launch_fwd_s(hipStream_t st, int bd, int log2, int tr, int16_t *co, const char *src, long ss, const char *pred, long sp,
+                               const int32_t *j, int n)
+{
+    if (tr)
+    {
+        if (log2 != 2) return hipErrorInvalidValue;
+        go_fwd<S, 2, 1>(st, co, src, ss, pred, sp, j, n, bd);
+    }
+    else
+        switch (log2)
+        {
+        case 2: go_fwd<S, 2, 0>(st, co, src, ss, pred, sp, j, n, bd); break;
+        case 3: go_fwd<S, 3, 0>(st, co, src, ss, pred, sp, j, n, bd); break;
+        case 4: go_fwd<S, 4, 0>(st, co, src, ss, pred, sp, j, n, bd); break;
+        case 5: go_fwd<S, 5, 0>(st, co, src, ss, pred, sp, j, n, bd); break;
+        default: return hipErrorInvalidValue;
+        }
+    return hipGetLastError();
+}
+
+hipError_t launch_tu_forward(hipStream_t st, int S, int bd, int log2, int tr, int16_t *coeffs, const void *src, long ss, const void *pred, long sp,
+                             const void *jobs, int n)
+{
+    if (n <= 0) return hipSuccess;
+    return S == 1 ? launch_fwd_s<1>(st, bd, log2, tr, coeffs, (const char *)src, ss, (const char *)pred, sp, (const int32_t *)jobs, n)
+                  : launch_fwd_s<2>(st, bd, log2, tr, coeffs, (const char *)src, ss, (const char *)pred, sp, (const int32_t *)jobs, n);
+}
+
+template <int S, int LOG2, int TR>
+static void go_rec(hipStream_t st, char *rec, long sr, const char *pred, long sp, const char *src, long ss, const int16_t *lv, const int32_t *j, int n,
+                   int bd, int scale, int shift, uint32_t *ssd)
+{
+    constexpr int TPW = 64 >> LOG2;
+    hipLaunchKernelGGL((k_tu_reconstruct<S, LOG2, TR>), dim3((n + TPW - 1) / TPW), dim3(64), 0, st, rec, sr, pred, sp, src, ss, lv, j, n, bd, scale,
+                       shift, ssd);
+}
+
+template <int S>
+static hipError_t launch_rec_s(hipStream_t st, int bd, int log2, int tr, int scale, int shift, char *rec, long sr, const char *pred, long sp,
+                               const char *src, long ss, const int16_t *lv, const int32_t *j, int n, uint32_t *ssd)
+{
+    if (tr)
+    {
+        if (log2 != 2) return hipErrorInvalidValue;
+        go_rec<S, 2, 1>(st, rec, sr, pred, sp, src, ss, lv, j, n, bd, scale, shift, ssd);
+    }
+    else
+        switch (log2)
+        {
+        case 2: go_rec<S, 2, 0>(st, rec, sr, pred, sp, src, ss, lv, j, n, bd, scale, shift, ssd); break;
+        case 3: go_rec<S, 3, 0>(st, rec, sr, pred, sp, src, ss, lv, j, n, bd, scale, shift, ssd); break;
+        case 4: go_rec<S, 4, 0>(st, rec, sr, pred, sp, src, ss, lv, j, n, bd, scale, shift, ssd); break;
+        case 5: go_rec<S, 5, 0>(st, rec, sr, pred, sp, src, ss, lv, j, n, bd, scale, shift, ssd); break;
+        default: return hipErrorInvalidValue;
+        }
+    return hipGetLastError();
+}
+
+hipError_t launch_tu_reconstruct(hipStream_t st, int S, int bd, int log2, int tr, int scale, int shift, void *rec, long sr, const void *pred, long sp,
+                                 const void *src, long ss, const int16_t *levels, const void *jobs, int n, uint32_t *ssd)
+{
+    if (n <= 0) return hipSuccess;
+    return S == 1 ? launch_rec_s<1>(st, bd, log2, tr, scale, shift, (char *)rec, sr, (const char *)pred, sp, (const char *)src, ss, levels,
+                                    (const int32_t *)jobs, n, ssd)
+                  : launch_rec_s<2>(st, bd, log2, tr, scale, shift, (char *)rec, sr, (const char *)pred, sp, (const char *)src, ss, levels,
+                                    (const int32_t *)jobs, n, ssd);
+}
+
+} // namespace havoc_gpu

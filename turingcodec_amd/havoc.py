@@ -70,6 +70,8 @@ def _load():
         "transform": [_vp, _i, _i, _i, _vp, _vp, _ip, _vp, _i],
         "inverse_transform": [_vp, _i, _i, _i, _vp, _vp, _vp, _i],
         "inverse_transform_add": [_vp, _i, _i, _i, _i, _vp, _ip, _vp, _ip, _vp, _vp, _i],
+        "tu_forward": [_vp, _i, _i, _i, _i, _vp, _vp, _ip, _vp, _ip, _vp, _i],
+        "tu_reconstruct": [_vp, _i, _i, _i, _i, _i, _i, _vp, _ip, _vp, _ip, _vp, _ip, _vp, _vp, _i, _vp],
         "quantize": [_vp, _vp, _vp, _vp, _i, _vp],
         "quantize_inverse": [_vp, _vp, _vp, _vp, _i],
         "quantize_reconstruct": [_vp, _i, _vp, _ip, _vp, _ip, _vp, _vp, _i],
@@ -271,6 +273,36 @@ class Havoc:
 
     def inverse_transform_add_d(self, bd, tr, log2, dst, sd, pred, sp, coeffs, jobs):
         self._ck(self.L.havoc_mi355x_inverse_transform_add(self.h, self._S(pred), bd, tr, log2, _ptr(dst), sd, _ptr(pred), sp, _ptr(coeffs), _ptr(jobs), jobs.shape[0]))
+
+    def tu_forward_d(self, bd, tr, log2, coeffs, src, ss, pred, sp, jobs):
+        self._ck(self.L.havoc_mi355x_tu_forward(self.h, self._S(src), bd, tr, log2, _ptr(coeffs), _ptr(src), ss, _ptr(pred), sp, _ptr(jobs), jobs.shape[0]))
+
+    def tu_reconstruct_d(self, bd, tr, log2, scale, shift, rec, sr, pred, sp, src, ss, levels, jobs, ssd):
+        self._ck(self.L.havoc_mi355x_tu_reconstruct(self.h, self._S(src), bd, tr, log2, scale, shift, _ptr(rec), sr, _ptr(pred), sp, _ptr(src), ss,
+                                                    _ptr(levels), _ptr(jobs), jobs.shape[0], _ptr(ssd)))
+
+    def tu_forward(self, bd, ncoef, src, ss, pred, sp, jobs):
+        """jobs: int32 [n, 8] = (coef_off, src_off, pred_off, rec_off, log2, trType, 0, 0)"""
+        co = self.zeros(ncoef, np.int16)
+        s, p = self.up(src), self.up(pred)
+        for log2, tr, sel in self._tu_groups(jobs):
+            self.tu_forward_d(bd, tr, log2, co, s, ss, p, sp, self._jobs(sel, 4))
+        return self.down(co, np.int16)
+
+    def tu_reconstruct(self, bd, qp, rec_len, sr, pred, sp, src, ss, levels, jobs):
+        """de-quantiser parameters from qp as turing/QpState.h:85-86 / Reconstruct.cpp:315; returns (rec, ssd)"""
+        jobs = np.asarray(jobs, np.int32)
+        rec = self.zeros(rec_len, src.dtype)
+        ssd = np.zeros(len(jobs), np.uint32)
+        s, p, lv = self.up(src), self.up(pred), self.up(levels)
+        for log2, tr in ((2, 1), (2, 0), (3, 0), (4, 0), (5, 0)):
+            idx = np.flatnonzero((jobs[:, 4] == log2) & (jobs[:, 5] == tr))
+            if len(idx):
+                scale, shift = [40, 45, 51, 57, 64, 72][qp % 6] << (qp // 6), log2 - 1 + bd - 8
+                o = self.zeros(len(idx), np.uint32)
+                self.tu_reconstruct_d(bd, tr, log2, scale, shift, rec, sr, p, sp, s, ss, lv, self._jobs(jobs[idx], 4), o)
+                ssd[idx] = self.down(o, np.uint32)
+        return self.down(rec, src.dtype), ssd
 
     def quantize_d(self, dst, src, jobs, cbf):
         self._ck(self.L.havoc_mi355x_quantize(self.h, _ptr(dst), _ptr(src), _ptr(jobs), jobs.shape[0], _ptr(cbf)))
