@@ -41,6 +41,8 @@ def parse_args():
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--kernel-reps", type=int, default=5)
     ap.add_argument("--lanes", type=int, default=8, help="fork/join lanes: independent launch chains overlap on the GPU")
+    ap.add_argument("--tu", choices=["fused", "split"], default="fused",
+                    help="TU chain: two fused kernels around the host quantiser (default) or the five separate primitives")
     ap.add_argument("--subpel", choices=["planes", "fused"], default="planes",
                     help="sub-pel candidates: SATD against per-picture phase planes (default) or the fused per-candidate kernel")
     return ap.parse_args()
@@ -53,9 +55,9 @@ def parse_args():
 class DeviceFrame:
     """A FrameWorkload uploaded to HBM + the list of launches that make one step."""
 
-    def __init__(self, hv, wl, use_planes=True):
+    def __init__(self, hv, wl, use_planes=True, fused_tu=True):
         import torch
-        self.hv, self.wl, self.use_planes = hv, wl, use_planes
+        self.hv, self.wl, self.use_planes, self.fused_tu = hv, wl, use_planes, fused_tu
         up = hv.up
         dt = wl.dtype
         S = wl.S
@@ -111,12 +113,16 @@ class DeviceFrame:
                                        res=z(m * nn * nn, np.int16), coef=z(m * nn * nn, np.int16),
                                        level=z(m * nn * nn, np.int16), deq=z(m * nn * nn, np.int16),
                                        qjobs=up(qj), djobs=up(dj), cbf=z(m, np.int32), rec=z(m * nn * nn, dt),
-                                       jssd=up(g["ssd"]), ossd=z(len(g["ssd"]), np.uint32))
+                                       jssd=up(g["ssd"]), ossd=z(len(g["ssd"]), np.uint32), dscale=dscale, dshift=dshift)
+            fj = g["jobs"].copy()
+            fj[:, 1] = g["src"][:, 0]          # havoc_mi355x_tu_fused_job: coef_off, src_off, pred_off, rec_off
+            extra = g["ssd"][m:]
+            self.tu[(log2, tr)].update(fjobs=up(fj), jssd_x=up(extra) if len(extra) else None, ossd_x=z(max(1, len(extra)), np.uint32))
         self.launches = self._make_launches()
         # levels for the timed de-quantiser: run residual -> forward T -> havoc_quantize once, untimed (at medium the
         # reference quantises with RDOQ on the host; the hot path sees its output levels)
         for name, fn in self.launches:
-            if name.startswith(("residual", "transform")):
+            if name.startswith(("residual", "transform", "tu_forward")):
                 fn()
         for g in self.tu.values():
             hv.quantize_d(g["level"], g["coef"], g["qjobs"], g["cbf"])
@@ -168,6 +174,15 @@ class DeviceFrame:
             n = g["n"]
             # forward half and reconstruction half of the TU chain are independent here: the levels between them come
             # from the host's RDOQ in the reference (pre-computed, untimed, in __init__)
+            if self.fused_tu:
+                # residual + forward transform in one kernel; de-quant + inverse transform + add + SSD in another
+                chain(("tu_forward", lambda g=g, log2=log2, tr=tr: hv.tu_forward_d(bd, tr, log2, g["coef"], self.luma, st, self.luma, st, g["fjobs"])))
+                items = [("tu_reconstruct", lambda g=g, log2=log2, tr=tr, n=n: hv.tu_reconstruct_d(
+                    bd, tr, log2, g["dscale"], g["dshift"], g["rec"], n, self.luma, st, self.luma, st, g["level"], g["fjobs"], g["ossd"]))]
+                if g["jssd_x"] is not None:   # the reference makes ~1.26 SSD calls per TU: the rest as plain SSD jobs
+                    items.append(("ssd", lambda g=g, n=n: hv.ssd_d(self.luma, st, g["rec"], n, g["jssd_x"], g["ossd_x"])))
+                chain(*items)
+                continue
             chain(("residual", lambda g=g, n=n: hv.residual_d(g["res"], n, g["res_off"], self.luma, st, self.luma, st, g["src"])),
                   ("transform", lambda g=g, n=n, log2=log2, tr=tr: hv.transform_d(bd, tr, log2, g["coef"], g["res"], n, g["jobs"])))
             chain(("quantize_inverse", lambda g=g: hv.quantize_inverse_d(g["deq"], g["level"], g["djobs"])),
@@ -437,7 +452,7 @@ def main():
     hv = Havoc(local, stream="new")   # private stream: the step is captured into a HIP graph and replayed
     w, h = (int(v) for v in args.res.split("x"))
     wl = FrameWorkload(w, h, args.bit_depth, args.seed + rank)   # every rank owns a different picture
-    dev = DeviceFrame(hv, wl, use_planes=(args.subpel == "planes"))
+    dev = DeviceFrame(hv, wl, use_planes=(args.subpel == "planes"), fused_tu=(args.tu == "fused"))
     exch = None
     if world > 1:
         from turingcodec_amd.frame_parallel import ReferenceExchange

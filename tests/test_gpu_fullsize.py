@@ -56,6 +56,25 @@ def test_step_is_deterministic_across_eager_graph_and_lanes(hv):
     hv.graph_destroy(g)
 
 
+def test_fused_tu_chain_equals_separate_primitives(hv):
+    """272 k transform units at 1080p: tu_forward / tu_reconstruct give the same coefficients, reconstruction and SSD
+    as residual -> transform and quantize_inverse -> inverse_transform_add -> ssd"""
+    import bench
+    from turingcodec_amd.workload import FrameWorkload
+    wl = FrameWorkload(1920, 1080, 8, 9)
+    a = bench.DeviceFrame(hv, wl, fused_tu=True)
+    b = bench.DeviceFrame(hv, wl, fused_tu=False)
+    a.step()
+    b.step()
+    hv.sync()
+    for key in a.tu:
+        ga, gb = a.tu[key], b.tu[key]
+        m = ga["fjobs"].shape[0]
+        assert np.array_equal(hv.down(ga["coef"], np.int16), hv.down(gb["coef"], np.int16)), key
+        assert np.array_equal(hv.down(ga["rec"], np.uint8), hv.down(gb["rec"], np.uint8)), key
+        assert np.array_equal(hv.down(ga["ossd"], np.uint32)[:m], hv.down(gb["ossd"], np.uint32)[:m]), key
+
+
 def test_tu_chain_roundtrip_property(hv):
     """forward transform -> quantise -> de-quantise -> inverse transform + add reconstructs the source block to within
     the quantiser step (QP 32) for every transform unit of the 1080p workload: SSD(source, recon) stays small and is

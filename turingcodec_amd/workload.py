@@ -353,6 +353,8 @@ class FrameWorkload:
         b["intra_satd35"] = sum(len(j) * ((1 << (2 * l)) * S + 2 * (4 * (1 << l) + 1) * S + 35 * 4) for l, j in self.intra_search.items())
         ntu = {k: len(g["jobs"]) * g["n"] ** 2 for k, g in self.tu.items()}
         tot = sum(ntu.values())
+        b["tu_forward"] = tot * (2 * S + 2)          # source + prediction rows in, coefficients out
+        b["tu_reconstruct"] = tot * (2 + 3 * S)      # levels + prediction + source in, reconstruction out (+4 per TU, ignored)
         b["residual"] = tot * (2 * S + 2)
         b["transform"] = 4 * tot
         b["quantize_inverse"] = 4 * tot
