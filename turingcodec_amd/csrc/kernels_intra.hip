@@ -2,7 +2,7 @@
 // (reference: havoc/pred_intra.cpp:20282-20401; neighbour layout havoc/pred_intra.cpp:43-51).
 //
 // Work mapping: a launch is uniform in block size (as the reference's table is indexed by log2TrafoSize,
-// havoc/pred_intra.h:39-52); each job is owned by a group of LANES = min(64, n*n) lanes, so 4x4 blocks run four to a
+// havoc/pred_intra.h:39-52); each job is owned by a group of LANES = min(64, n*n/4) lanes (4 samples each), so 4x4 blocks run 16 to a
 // wavefront and 32x32 blocks give each lane 16 samples.  The 4n+1 neighbour samples and the projected angular
 // reference array live in LDS; every predicted sample is a two-tap blend read from there.
 #include "common.h"
@@ -20,7 +20,7 @@ __global__ __launch_bounds__(64) void k_intra(char *__restrict__ dst, long strid
 {
     typedef typename Sample<S>::T T;
     constexpr int N = 1 << LOG2;
-    constexpr int LANES = N * N < 64 ? N * N : 64;   // lanes per job
+    constexpr int LANES = N * N / 4 < 64 ? N * N / 4 : 64;   // lanes per job: each lane produces 4 adjacent samples
     constexpr int JPW = 64 / LANES;                  // jobs per wavefront
     constexpr int NBLEN = 4 * N + 1;
     // per job: nb[0 .. 4N]: index i <-> neighbours[i - 2N - 1]  (so nb[2N] = corner, nb[2N+1+x] = p(x,-1),
@@ -76,36 +76,45 @@ __global__ __launch_bounds__(64) void k_intra(char *__restrict__ dst, long strid
     __syncthreads();
     if (!live) return;
 
-    for (int i = l; i < N * N; i += LANES)
+    for (int q = l; q < N * N / 4; q += LANES)
     {
-        const int y = i >> LOG2, x = i & (N - 1);
-        int v;
-        if (mode == 0)
-            v = ((N - 1 - x) * P_LEFT(y) + (x + 1) * P_TOP(N) + (N - 1 - y) * P_TOP(x) + (y + 1) * P_LEFT(N) + N) >> (LOG2 + 1);
-        else if (mode == 1)
+        const int y = (4 * q) >> LOG2, x0 = (4 * q) & (N - 1);
+        int v4[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
         {
-            v = dc;
-            if (edge)
+            const int x = x0 + o;
+            int v;
+            if (mode == 0)
+                v = ((N - 1 - x) * P_LEFT(y) + (x + 1) * P_TOP(N) + (N - 1 - y) * P_TOP(x) + (y + 1) * P_LEFT(N) + N) >> (LOG2 + 1);
+            else if (mode == 1)
             {
-                if (x == 0 && y == 0) v = (P_LEFT(0) + 2 * dc + P_TOP(0) + 2) >> 2;
-                else if (y == 0) v = (P_TOP(x) + 3 * dc + 2) >> 2;
-                else if (x == 0) v = (P_LEFT(y) + 3 * dc + 2) >> 2;
+                v = dc;
+                if (edge)
+                {
+                    if (x == 0 && y == 0) v = (P_LEFT(0) + 2 * dc + P_TOP(0) + 2) >> 2;
+                    else if (y == 0) v = (P_TOP(x) + 3 * dc + 2) >> 2;
+                    else if (x == 0) v = (P_LEFT(y) + 3 * dc + 2) >> 2;
+                }
             }
+            else
+            {
+                const int angle = c_intraAngle[mode];
+                const bool vertical = mode >= 18;
+                const int major = vertical ? y : x, minor = vertical ? x : y;
+                const int t = (major + 1) * angle;
+                const int idx = t >> 5, fact = t & 31;
+                const int r0 = ref[minor + idx + 1];
+                if (fact == 0) v = r0;
+                else v = ((32 - fact) * r0 + fact * (int)ref[minor + idx + 2] + 16) >> 5;
+                if (edge && mode == 26 && x == 0) v = clip3(0, maxv, P_TOP(0) + ((P_LEFT(y) - P_TOP(-1)) >> 1));
+                if (edge && mode == 10 && y == 0) v = clip3(0, maxv, P_LEFT(0) + ((P_TOP(x) - P_TOP(-1)) >> 1));
+            }
+            v4[o] = v;
         }
-        else
-        {
-            const int angle = c_intraAngle[mode];
-            const bool vertical = mode >= 18;
-            const int major = vertical ? y : x, minor = vertical ? x : y;
-            const int t = (major + 1) * angle;
-            const int idx = t >> 5, fact = t & 31;
-            const int r0 = ref[minor + idx + 1];
-            if (fact == 0) v = r0;
-            else v = ((32 - fact) * r0 + fact * (int)ref[minor + idx + 2] + 16) >> 5;
-            if (edge && mode == 26 && x == 0) v = clip3(0, maxv, P_TOP(0) + ((P_LEFT(y) - P_TOP(-1)) >> 1));
-            if (edge && mode == 10 && y == 0) v = clip3(0, maxv, P_LEFT(0) + ((P_TOP(x) - P_TOP(-1)) >> 1));
-        }
-        d[y * stride_dst + x] = (T)v;
+        T *o4 = d + y * stride_dst + x0;
+        if (S == 1) st4(o4, (uint32_t)v4[0] | ((uint32_t)v4[1] << 8) | ((uint32_t)v4[2] << 16) | ((uint32_t)v4[3] << 24));
+        else st8(o4, u32x2{(uint32_t)v4[0] | ((uint32_t)v4[1] << 16), (uint32_t)v4[2] | ((uint32_t)v4[3] << 16)});
     }
 #undef P_TOP
 #undef P_LEFT
@@ -119,8 +128,8 @@ static hipError_t launch_intra_s(hipStream_t st, int log2, int bitDepth, void *d
     const int32_t *j = (const int32_t *)jobs;
     switch (log2)
     {
-    case 2: hipLaunchKernelGGL((k_intra<S, 2>), dim3((n + 3) / 4), dim3(64), 0, st, d, sd, p, j, n, bitDepth); break;
-    case 3: hipLaunchKernelGGL((k_intra<S, 3>), dim3(n), dim3(64), 0, st, d, sd, p, j, n, bitDepth); break;
+    case 2: hipLaunchKernelGGL((k_intra<S, 2>), dim3((n + 15) / 16), dim3(64), 0, st, d, sd, p, j, n, bitDepth); break;
+    case 3: hipLaunchKernelGGL((k_intra<S, 3>), dim3((n + 3) / 4), dim3(64), 0, st, d, sd, p, j, n, bitDepth); break;
     case 4: hipLaunchKernelGGL((k_intra<S, 4>), dim3(n), dim3(64), 0, st, d, sd, p, j, n, bitDepth); break;
     case 5: hipLaunchKernelGGL((k_intra<S, 5>), dim3(n), dim3(64), 0, st, d, sd, p, j, n, bitDepth); break;
     default: return hipErrorInvalidValue;
