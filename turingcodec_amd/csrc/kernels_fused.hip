@@ -186,28 +186,26 @@ __global__ __launch_bounds__(THREADS) void k_intra_satd35(const char *__restrict
     __syncthreads();
 
     // ---- phase 1: projected reference arrays for the 33 angular modes, DC values
-    for (int i = lane; i < P * 33 * (3 * N + 1); i += THREADS)
+    // only the entries a mode can read are produced: indices 0 .. 2N for the non-negative angles, last .. N for the
+    // negative ones (last = (N * angle) >> 5 >= -N): at most 2N + 1 per mode
+    for (int i = lane; i < P * 33 * (2 * N + 1); i += THREADS)
     {
-        const int p = i / (33 * (3 * N + 1)), r = i - p * 33 * (3 * N + 1);
-        const int mi = r / (3 * N + 1), idx = r - mi * (3 * N + 1) - N;   // idx in -N .. 2N
+        const int p = i / (33 * (2 * N + 1)), r = i - p * 33 * (2 * N + 1);
+        const int mi = r / (2 * N + 1), e = r - mi * (2 * N + 1);
         const int mode = mi + 2;
         const int angle = c_angle35[mode];
         const bool vertical = mode >= 18;
+        const int last = angle < 0 ? (N * angle) >> 5 : 0;
+        const int idx = (last < -1 ? last : 0) + e;
+        if (idx > (angle < 0 ? N : 2 * N)) continue;
         const uint32_t fbits = mode < 32 ? (uint32_t)s_job[p][3] >> mode : (uint32_t)s_job[p][4] >> (mode - 32);
         const uint16_t *nb = s_nb[p][fbits & 1];
-        int v = 0;
-        if (idx >= 0)
+        int v;
+        if (idx >= 0) v = vertical ? nb[2 * N + idx] : nb[2 * N - idx];   // p(-1+idx,-1) / p(-1,-1+idx)
+        else
         {
-            if (idx <= N || angle >= 0) v = vertical ? nb[2 * N + idx] : nb[2 * N - idx];   // p(-1+idx,-1) / p(-1,-1+idx)
-        }
-        else if (angle < 0)
-        {
-            const int last = (N * angle) >> 5;
-            if (last < -1 && idx >= last)
-            {
-                const int k = -1 + ((idx * (int)c_invAngle35[mode] + 128) >> 8);
-                v = vertical ? nb[2 * N - 1 - k] : nb[2 * N + 1 + k];                      // p(-1,k) / p(k,-1)
-            }
+            const int k = -1 + ((idx * (int)c_invAngle35[mode] + 128) >> 8);
+            v = vertical ? nb[2 * N - 1 - k] : nb[2 * N + 1 + k];          // p(-1,k) / p(k,-1)
         }
         s_ref[p][mi][idx + N] = (uint16_t)v;
     }
