@@ -378,7 +378,7 @@ def cpu_worker(args):
                 break
         dt_s = (time.perf_counter() - t0) / reps
     print(json.dumps({"seconds_per_sample": dt_s, "stride": stride, "cores": cores, "handle": handle,
-                      "jobs": int(sum(n for _, n in tasks))}))
+                      "jobs": int(sum(n for _, n in tasks)), "reps": reps}))
 
 
 def cpu_baseline(args):
@@ -397,7 +397,8 @@ def cpu_baseline(args):
                 return {"value": round(fps, 3), "unit": "frames/s", "cores": r["cores"], "kind": "reference",
                         "sample": f"every {stride}th job of each primitive's job table ({r['jobs']} calls) through the "
                                   f"reference's own havoc {'x86-JIT' if handle else 'C'} function tables (oracle/_ref), "
-                                  f"{r['cores']} host threads, extrapolated x{stride}"}
+                                  f"{r['cores']} host threads, the sample repeated {r['reps']}x (~2 s wall, "
+                                  f"~{2 * r['cores']} core-seconds), extrapolated x{stride}"}
         except Exception:
             pass
     return None

@@ -1,0 +1,28 @@
+#!/bin/bash
+# Collect the round's profiles on the GPU box (run through gpurun from the repo root):
+#
+#   gpurun --timeout 1500 -- 'bash profiles/collect.sh r01'
+#   python profiles/summarize.py r01 gpurun_out/r01_serial gpurun_out/r01_fetch gpurun_out/r01_write
+#
+# Pass 1: rocprofv3 --kernel-trace --stats with one lane and no graph, so each kernel's duration is its isolated one
+#         (the figure bench.py's roofline.achieved is built from).  Pass 2: the same with the default 8 lanes + graph
+#         (durations overlap; kept to show the overlap, not for the roofline).  Passes 3/4: PMC counters, one counter
+#         per pass and no trace domains beside them.  Pass 5: the plain bench line with the CPU baseline.
+tag=${1:-r01}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+B="python $R/bench.py --no-cpu-baseline"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_serial -- $B --steps 10 --warmup 2 --lanes 1 --no-graph > $O/${tag}_serial_bench.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_overlap8 -- $B --steps 10 --warmup 2 > $O/${tag}_overlap8_bench.log 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${tag}_fetch -- $B --steps 2 --warmup 1 --kernel-reps 1 > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${tag}_write -- $B --steps 2 --warmup 1 --kernel-reps 1 > /dev/null 2>&1
+cd $R
+# the traffic table must exist before the final bench line so that roofline.traffic is filled from it
+python profiles/summarize.py $tag $O/${tag}_serial $O/${tag}_fetch $O/${tag}_write > $O/${tag}_summary.txt 2>&1
+cp profiles/${tag}_kernel_stats.csv profiles/${tag}_hbm_traffic.csv $O/ 2>/dev/null
+timeout 400 python bench.py 2> $O/${tag}_bench.err | tail -1 > $O/${tag}_bench.json
+tail -1 $O/${tag}_serial_bench.log | cut -c1-400
+tail -1 $O/${tag}_overlap8_bench.log | cut -c1-400
+cat $O/${tag}_bench.json
