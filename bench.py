@@ -40,6 +40,8 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--kernel-reps", type=int, default=5)
+    ap.add_argument("--exchange", action="store_true",
+                    help="run the reference-picture exchange (process group + RCCL broadcasts) even with one rank")
     ap.add_argument("--lanes", type=int, default=8, help="fork/join lanes: independent launch chains overlap on the GPU")
     ap.add_argument("--tu", choices=["fused", "split"], default="fused",
                     help="TU chain: two fused kernels around the host quantiser (default) or the five separate primitives")
@@ -445,19 +447,31 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    grouped = world > 1 or args.exchange
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = os.environ.get("HAVOC_BENCH_BACKEND", "nccl")   # "gloo": rehearsal of the N>1 path on a 1-GPU box
+        local %= torch.cuda.device_count()
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    hv = Havoc(local, stream="new")   # private stream: the step is captured into a HIP graph and replayed
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    # the compute stream is private (the step is captured into a HIP graph and replayed on it); it is created through
+    # torch only so that torch events can order it against the exchange stream
+    compute = torch.cuda.Stream(device=local)
+    hv = Havoc(local, stream=compute.cuda_stream)
     w, h = (int(v) for v in args.res.split("x"))
     wl = FrameWorkload(w, h, args.bit_depth, args.seed + rank)   # every rank owns a different picture
     dev = DeviceFrame(hv, wl, use_planes=(args.subpel == "planes"), fused_tu=(args.tu == "fused"))
     exch = None
-    if world > 1:
+    if grouped:
         from turingcodec_amd.frame_parallel import ReferenceExchange
-        exch = ReferenceExchange(dist, rank, world, dev.luma[3 * wl.plane_len:4 * wl.plane_len], dev.chroma[:wl.cplane_len])
+        exch = ReferenceExchange(dist, rank, world, dev.luma[3 * wl.plane_len:4 * wl.plane_len], dev.chroma[:wl.cplane_len],
+                                 single_rank_broadcast=args.exchange)
+        comm = torch.cuda.current_stream(local)   # torch.distributed enqueues behind this stream
 
     dev.step()          # first eager pass (loads the code objects) -- also what the graph must reproduce
     hv.sync()
@@ -469,9 +483,21 @@ def main():
         else:
             dev.step(args.lanes)
         if exch is not None:
-            hv.sync()   # reconstruction complete before its owner broadcasts it (torch.distributed runs on torch's stream)
-            exch.exchange(i)
+            # compute stream: [picture i] [owner copies its reconstruction into the DPB mirror] [picture i+1] ...
+            # exchange stream:                          [wait staged_i] [broadcasts of picture i] ...
+            # -> the compute stream never waits for a broadcast of the current picture, only (for DPB slot re-use) for
+            #    the broadcasts of the previous one, which ran underneath this picture's kernels
+            if i > 0:
+                compute.wait_event(sent[(i - 1) & 1])
+            with torch.cuda.stream(compute):
+                exch.stage(i)
+            staged[i & 1].record(compute)
+            comm.wait_event(staged[i & 1])
+            exch.send(i)
+            sent[i & 1].record(comm)
 
+    staged = [torch.cuda.Event(), torch.cuda.Event()]
+    sent = [torch.cuda.Event(), torch.cuda.Event()]
     for i in range(args.warmup):
         one_step(i)
     torch.cuda.synchronize()
@@ -510,7 +536,9 @@ def main():
             "config": {"workload": f"{args.res} {args.bit_depth}-bit 4:2:0 random-access QP32 speed=medium B-frame call mix "
                                    f"(SURVEY A.2 counts x {w * h / (1920 * 1080):.2f}; assumed PU/intra size mix), 1xMI355X per rank",
                        "calls_per_frame": int(sum(wl.counts.values())), "launches_per_frame": len(dev.launches),
-                       "parallelism": f"frame-parallel x{world}" if world > 1 else "single GPU"},
+                       "parallelism": (f"frame-parallel x{world}: one picture per rank per step, reference pictures broadcast "
+                                       f"over RCCL ({exch.sent_bytes // max(1, args.steps + args.warmup)} B sent per step by rank 0), "
+                                       f"overlapped with the next picture") if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "launch_ms": round(ktimes[dom] / kcount[dom], 5), "launches_per_step": kcount[dom],
@@ -523,7 +551,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out))
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

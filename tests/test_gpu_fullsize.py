@@ -86,3 +86,28 @@ def test_tu_chain_roundtrip_property(hv):
         ssd = hv.down(g["ossd"], np.uint32).astype(np.float64)
         n = 1 << log2
         assert np.isfinite(ssd).all() and ssd.mean() / (n * n) < 200.0, (log2, tr, ssd.mean() / (n * n))
+
+
+def test_bench_multi_rank_path_rehearsal():
+    """bench.py's N>1 path (process group, one picture per rank, staged + overlapped reference exchange, barrier,
+    max over ranks) with two ranks sharing the one GPU of the test box; gloo stands in for RCCL, which refuses two
+    ranks on one device.  The per-rank results must be those of the single-rank run of the same seed."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HAVOC_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29577", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--kernel-reps", "1"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    r = json.loads(line)
+    assert r["n_gpus"] == 2 and r["steps"] == 4 and r["scaling"] == "weak" and r["value"] > 0
+    assert "frame-parallel x2" in r["config"]["parallelism"]
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--kernel-reps", "1",
+                          "--no-cpu-baseline", "--exchange"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert one.returncode == 0, one.stderr[-2000:]
+    r1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    assert r1["checksum"] == r["checksum"]     # rank 0 encodes the same picture (seed + rank) in both runs

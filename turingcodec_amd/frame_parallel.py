@@ -70,32 +70,56 @@ def dependency_ready_step(pics: List[Picture], world: int) -> List[int]:
 class ReferenceExchange:
     """Mirror of the decoded-picture buffer on every rank + the broadcast step.
 
-    `recon_luma` / `recon_chroma` are this rank's reconstruction planes (1-D tensors in the padded picture layout);
-    `exchange(step)` is called by every rank after it finished step `step`: for each rank whose picture of this step
-    is a reference picture, that rank's planes are broadcast into slot (poc % slots) of every rank's mirror."""
+    `recon_luma` / `recon_chroma` are this rank's reconstruction planes (1-D tensors in the padded picture layout).
+    Every DPB slot is ONE flat buffer (luma then chroma), so a reference picture costs one broadcast, not one per
+    plane.  After every rank finished step `step`:
 
-    def __init__(self, dist, rank: int, world: int, recon_luma, recon_chroma, slots: int = 6, n_sops: int = 64):
+      stage(step)  the owner of a reference picture copies its planes into slot (poc/2 % slots) of its own mirror --
+                   from then on the reconstruction planes may be overwritten by the next picture;
+      send(step)   one broadcast per reference picture of the step, owner -> every rank's mirror.
+
+    `exchange(step)` = stage + send.  On the GPU both are enqueued on the caller's current stream (the broadcasts on
+    RCCL's own stream behind it), so a caller that orders its compute stream only after `stage` overlaps the
+    broadcasts of picture i with the computation of picture i+1 (bench.py)."""
+
+    def __init__(self, dist, rank: int, world: int, recon_luma, recon_chroma, slots: int = 6, n_sops: int = 64,
+                 single_rank_broadcast: bool = False):
         self.dist, self.rank, self.world = dist, rank, world
+        self.single_rank_broadcast = single_rank_broadcast   # exercise the collective even when world == 1
         self.recon_luma, self.recon_chroma = recon_luma, recon_chroma
         self.pics = coding_order(n_sops)
         self.slots = slots
-        self.dpb_luma = [recon_luma.new_zeros(recon_luma.numel()) for _ in range(slots)]
-        self.dpb_chroma = [recon_chroma.new_zeros(recon_chroma.numel()) for _ in range(slots)]
+        nl, nc = recon_luma.numel(), recon_chroma.numel()
+        self.dpb = [recon_luma.new_zeros(nl + nc) for _ in range(slots)]
+        self.dpb_luma = [b[:nl] for b in self.dpb]          # views
+        self.dpb_chroma = [b[nl:] for b in self.dpb]
         self.sent_bytes = 0
 
     def picture_of(self, step: int, rank: int) -> Picture:
         return self.pics[(step * self.world + rank) % len(self.pics)]
 
-    def exchange(self, step: int):
+    @staticmethod
+    def slot_of(pic: Picture, slots: int) -> int:
+        return (pic.poc // 2) % slots   # reference pictures have even POC inside a SOP (8 4 2 6) or are the IDR
+
+    def stage(self, step: int):
+        pic = self.picture_of(step, self.rank)
+        if pic.is_reference:
+            slot = self.slot_of(pic, self.slots)
+            self.dpb_luma[slot].copy_(self.recon_luma)
+            self.dpb_chroma[slot].copy_(self.recon_chroma)
+
+    def send(self, step: int):
         for src in range(self.world):
             pic = self.picture_of(step, src)
             if not pic.is_reference:
                 continue
-            slot = (pic.poc // 2) % self.slots   # reference pictures have even POC inside a SOP (8 4 2 6) or are the IDR
-            yl, ch = self.dpb_luma[slot], self.dpb_chroma[slot]
+            buf = self.dpb[self.slot_of(pic, self.slots)]
             if src == self.rank:
-                yl.copy_(self.recon_luma)
-                ch.copy_(self.recon_chroma)
-                self.sent_bytes += (yl.numel() * yl.element_size() + ch.numel() * ch.element_size()) * (self.world - 1)
-            self.dist.broadcast(yl, src=src)
-            self.dist.broadcast(ch, src=src)
+                self.sent_bytes += buf.numel() * buf.element_size() * (self.world - 1)
+            if self.world > 1 or self.single_rank_broadcast:
+                self.dist.broadcast(buf, src=src)
+
+    def exchange(self, step: int):
+        self.stage(step)
+        self.send(step)
