@@ -288,11 +288,11 @@ def cpu_worker(args):
     cpred = _aligned(np.zeros(wl.cpred_len + 1024, dt))
     bi = _aligned(np.zeros(wl.bi_len + 8192, dt))
     sbi = _aligned(np.zeros(len(wl.subtract_bi) * 4096 + 4096, dt))
-    tasks = []   # (callable(b, e), njobs)
+    tasks = []   # (callable(b, e), njobs, group the GPU bench times it under)
 
-    def add(fn, n):
+    def add(group, fn, n):
         if n:
-            tasks.append((fn, n))
+            tasks.append((fn, n, group))
             if os.environ.get("HAVOC_BENCH_TRACE"):
                 sys.stderr.write(f"task {len(tasks)} n={n}\n")
                 sys.stderr.flush()
@@ -300,16 +300,16 @@ def cpu_worker(args):
 
     j4, js = sub(wl.sad4), sub(wl.sad)
     o4, os_ = np.zeros(4 * len(j4), np.int32), np.zeros(len(js), np.int32)
-    add(lambda b, e: lib.ref_run_sad4(handle, S, P(luma), ip(st), P(luma), ip(st), P(j4), b, e, P(o4)), len(j4))
-    add(lambda b, e: lib.ref_run_sad(handle, S, P(luma), ip(st), P(luma), ip(st), P(js), b, e, P(os_)), len(js))
+    add("sad4", lambda b, e: lib.ref_run_sad4(handle, S, P(luma), ip(st), P(luma), ip(st), P(j4), b, e, P(o4)), len(j4))
+    add("sad", lambda b, e: lib.ref_run_sad(handle, S, P(luma), ip(st), P(luma), ip(st), P(js), b, e, P(os_)), len(js))
     ju8, ju4, jb8, jb4, jsb, jsa = sub(wl.uni8), sub(wl.uni4), sub(wl.bi8), sub(wl.bi4), sub(wl.subtract_bi), sub(wl.satd_inter)
     osa = np.zeros(len(jsa), np.int32)
-    add(lambda b, e: lib.ref_run_pred_uni(handle, S, 8, bd, P(pred), ip(64), P(luma), ip(st), P(ju8), b, e), len(ju8))
-    add(lambda b, e: lib.ref_run_satd(handle, S, P(luma), ip(st), P(pred), ip(64), P(jsa), b, e, P(osa)), len(jsa))
-    add(lambda b, e: lib.ref_run_pred_uni(handle, S, 4, bd, P(cpred), ip(32), P(chroma), ip(cst), P(ju4), b, e), len(ju4))
-    add(lambda b, e: lib.ref_run_pred_bi(handle, S, 8, bd, P(bi), ip(64), P(luma), ip(st), P(jb8), b, e), len(jb8))
-    add(lambda b, e: lib.ref_run_subtract_bi(handle, S, bd, P(sbi), ip(64), P(bi), ip(64), P(luma), ip(st), P(jsb), b, e), len(jsb))
-    add(lambda b, e: lib.ref_run_pred_bi(handle, S, 4, bd, P(bi), ip(32), P(chroma), ip(cst), P(jb4), b, e), len(jb4))
+    add("pred_uni8", lambda b, e: lib.ref_run_pred_uni(handle, S, 8, bd, P(pred), ip(64), P(luma), ip(st), P(ju8), b, e), len(ju8))
+    add("satd_inter", lambda b, e: lib.ref_run_satd(handle, S, P(luma), ip(st), P(pred), ip(64), P(jsa), b, e, P(osa)), len(jsa))
+    add("pred_uni4", lambda b, e: lib.ref_run_pred_uni(handle, S, 4, bd, P(cpred), ip(32), P(chroma), ip(cst), P(ju4), b, e), len(ju4))
+    add("pred_bi8", lambda b, e: lib.ref_run_pred_bi(handle, S, 8, bd, P(bi), ip(64), P(luma), ip(st), P(jb8), b, e), len(jb8))
+    add("subtract_bi", lambda b, e: lib.ref_run_subtract_bi(handle, S, bd, P(sbi), ip(64), P(bi), ip(64), P(luma), ip(st), P(jsb), b, e), len(jsb))
+    add("pred_bi4", lambda b, e: lib.ref_run_pred_bi(handle, S, 4, bd, P(bi), ip(32), P(chroma), ip(cst), P(jb4), b, e), len(jb4))
     keep = [j4, js, ju8, ju4, jb8, jb4, jsb, jsa, o4, os_, osa]
     for hi, j in wl.subpel.items():   # fused on the GPU; on the CPU the reference's two calls: pred_uni, then measureSatd
         if not len(j):
@@ -320,8 +320,8 @@ def cpu_worker(args):
         scratch = _aligned(np.zeros(len(jp) * 4096 + 4096, dt))
         osp = np.zeros(len(jp), np.int32)
         keep += [jp, jsat, scratch, osp]
-        add(lambda b, e, jp=jp, scratch=scratch: lib.ref_run_pred_uni(handle, S, 8, bd, P(scratch), ip(64), P(luma), ip(st), P(jp), b, e), len(jp))
-        add(lambda b, e, jsat=jsat, scratch=scratch, osp=osp: lib.ref_run_satd(handle, S, P(luma), ip(st), P(scratch), ip(64), P(jsat), b, e, P(osp)), len(jp))
+        add("subpel(interp+satd)", lambda b, e, jp=jp, scratch=scratch: lib.ref_run_pred_uni(handle, S, 8, bd, P(scratch), ip(64), P(luma), ip(st), P(jp), b, e), len(jp))
+        add("subpel(interp+satd)", lambda b, e, jsat=jsat, scratch=scratch, osp=osp: lib.ref_run_satd(handle, S, P(luma), ip(st), P(scratch), ip(64), P(jsat), b, e, P(osp)), len(jp))
     for log2, j in wl.intra.items():
         if not len(j):
             continue
@@ -329,14 +329,14 @@ def cpu_worker(args):
         ji, nb = sub(j), _aligned(wl.intra_nb[log2])
         dst = _aligned(np.zeros((len(j) << (2 * log2)) + 64, dt))
         keep += [ji, nb, dst]
-        add(lambda b, e, log2=log2, n=n, ji=ji, nb=nb, dst=dst: lib.ref_run_intra(handle, S, bd, log2, P(dst), ip(n), P(nb), P(ji), b, e), len(ji))
+        add("intra", lambda b, e, log2=log2, n=n, ji=ji, nb=nb, dst=dst: lib.ref_run_intra(handle, S, bd, log2, P(dst), ip(n), P(nb), P(ji), b, e), len(ji))
     for log2, j in wl.intra_search.items():
         if not len(j):
             continue
         jp, nb = sub(j), _aligned(wl.intra_search_nb[log2])
         cost = np.zeros(35 * len(jp), np.int32)
         keep += [jp, nb, cost]
-        add(lambda b, e, log2=log2, jp=jp, nb=nb, cost=cost: lib.ref_run_intra_satd35(handle, S, bd, log2, P(luma), ip(st), P(nb), P(jp), b, e, P(cost)), len(jp))
+        add("intra_satd35", lambda b, e, log2=log2, jp=jp, nb=nb, cost=cost: lib.ref_run_intra_satd35(handle, S, bd, log2, P(luma), ip(st), P(nb), P(jp), b, e, P(cost)), len(jp))
     qp = 32
     for (log2, tr), g in wl.tu.items():
         m = len(g["jobs"])
@@ -354,40 +354,54 @@ def cpu_worker(args):
         dj[:, 4] = log2 - 1 + bd - 8
         dj = _aligned(dj)
         keep += [jt, jsrc, roff, res, coef, deq, dj]
-        add(lambda b, e, n=n, res=res, roff=roff, jsrc=jsrc: lib.ref_run_residual(S, P(res), ip(n), P(roff), P(luma), ip(st), P(luma), ip(st), P(jsrc), b, e), len(jt))
-        add(lambda b, e, n=n, log2=log2, tr=tr, coef=coef, res=res, jt=jt: lib.ref_run_transform(handle, bd, tr, log2, P(coef), P(res), ip(n), P(jt), b, e), len(jt))
-        add(lambda b, e, deq=deq, coef=coef, dj=dj: lib.ref_run_quantize_inverse(handle, P(deq), P(coef), P(dj), b, e), len(jt))
+        add("tu_forward", lambda b, e, n=n, res=res, roff=roff, jsrc=jsrc: lib.ref_run_residual(S, P(res), ip(n), P(roff), P(luma), ip(st), P(luma), ip(st), P(jsrc), b, e), len(jt))
+        add("tu_forward", lambda b, e, n=n, log2=log2, tr=tr, coef=coef, res=res, jt=jt: lib.ref_run_transform(handle, bd, tr, log2, P(coef), P(res), ip(n), P(jt), b, e), len(jt))
+        add("tu_reconstruct", lambda b, e, deq=deq, coef=coef, dj=dj: lib.ref_run_quantize_inverse(handle, P(deq), P(coef), P(dj), b, e), len(jt))
         rec = _aligned(np.zeros(m * n * n + 64, dt))
         jss = sub(g["ssd"])
         oss = np.zeros(len(jss), np.uint32)
         keep += [rec, jss, oss]
-        add(lambda b, e, log2=log2, tr=tr, deq=deq, jt=jt, rec=rec, n=n: lib.ref_run_inverse_transform_add(handle, S, bd, tr, log2, P(rec), ip(n), P(luma), ip(st), P(deq), P(jt), b, e), len(jt))
-        add(lambda b, e, rec=rec, n=n, jss=jss, oss=oss: lib.ref_run_ssd(handle, S, P(luma), ip(st), P(rec), ip(n), P(jss), b, e, P(oss)), len(jss))
+        add("tu_reconstruct", lambda b, e, log2=log2, tr=tr, deq=deq, jt=jt, rec=rec, n=n: lib.ref_run_inverse_transform_add(handle, S, bd, tr, log2, P(rec), ip(n), P(luma), ip(st), P(deq), P(jt), b, e), len(jt))
+        add("tu_reconstruct", lambda b, e, rec=rec, n=n, jss=jss, oss=oss: lib.ref_run_ssd(handle, S, P(luma), ip(st), P(rec), ip(n), P(jss), b, e, P(oss)), len(jss))
 
-    def run_all(pool):
-        for fn, n in tasks:
+    group_s = {}
+    acc = [dict() for _ in range(cores)]
+
+    def run_slice(k, record):
+        """thread k runs its contiguous slice of EVERY task in order: a chain's later primitives read what the same
+        thread's earlier ones wrote, so no barrier between tasks is needed (and none is timed)"""
+        for fn, n, group in tasks:
             chunk = (n + cores - 1) // cores
-            list(pool.map(lambda k: fn(k * chunk, min(n, (k + 1) * chunk)), range(cores)))
+            b, e = k * chunk, min(n, (k + 1) * chunk)
+            if b < e:
+                t = time.perf_counter()
+                fn(b, e)
+                if record:
+                    acc[k][group] = acc[k].get(group, 0.0) + time.perf_counter() - t
+
+    def run_all(pool, record=False):
+        list(pool.map(lambda k: run_slice(k, record), range(cores)))
 
     with ThreadPoolExecutor(cores) as pool:
         run_all(pool)   # warm (JIT assembly, page faults)
         t0 = time.perf_counter()
         reps = 0
         while True:
-            run_all(pool)
+            run_all(pool, True)
             reps += 1
             if time.perf_counter() - t0 > 2.0 or reps >= 50:
                 break
         dt_s = (time.perf_counter() - t0) / reps
     print(json.dumps({"seconds_per_sample": dt_s, "stride": stride, "cores": cores, "handle": handle,
-                      "jobs": int(sum(n for _, n in tasks)), "reps": reps}))
+                      "jobs": int(sum(n for _, n, _ in tasks)), "reps": reps,
+                      "group_seconds_per_sample": {g: sum(a.get(g, 0.0) for a in acc) / cores / reps for g in acc[0]}}))
 
 
 def cpu_baseline(args):
     """frames/s of the reference library on the host: sample = every `stride`-th job of every table"""
     if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libhavoc_ref.so")):
         return None
-    stride = 16
+    stride = 4
     for handle in (1, 0):   # x86 JIT tables first; plain-C tables if the JIT run fails
         cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", f"{handle},{stride}", "--res", args.res,
                "--bit-depth", str(args.bit_depth), "--seed", str(args.seed)]
@@ -397,6 +411,7 @@ def cpu_baseline(args):
                 r = json.loads(out.stdout.strip().splitlines()[-1])
                 fps = 1.0 / (r["seconds_per_sample"] * r["stride"])
                 return {"value": round(fps, 3), "unit": "frames/s", "cores": r["cores"], "kind": "reference",
+                        "ms_per_frame_by_group": {g: round(v * r["stride"] * 1e3, 3) for g, v in r["group_seconds_per_sample"].items()},
                         "sample": f"every {stride}th job of each primitive's job table ({r['jobs']} calls) through the "
                                   f"reference's own havoc {'x86-JIT' if handle else 'C'} function tables (oracle/_ref), "
                                   f"{r['cores']} host threads, the sample repeated {r['reps']}x (~2 s wall, "
