@@ -215,10 +215,13 @@ class DeviceFrame:
         cnt = {}
         for name, fn in self.launches:
             fn()
-            hv.timer_start()
-            for _ in range(reps):
-                fn()
-            ms = hv.timer_stop_ms() / reps
+            ms = None
+            for _ in range(3):   # best of three averages: the first group after an idle gap can see a clock ramp
+                hv.timer_start()
+                for _ in range(reps):
+                    fn()
+                m = hv.timer_stop_ms() / reps
+                ms = m if ms is None else min(ms, m)
             t[name] = t.get(name, 0.0) + ms
             cnt[name] = cnt.get(name, 0) + 1
         return t, cnt

@@ -96,6 +96,15 @@ typedef struct {
     int32_t reserved;
 } havoc_mi355x_sad4_job; /* 32 bytes */
 
+/* one source block against every integer candidate of a (2R+1) x (2R+1) window centred on ref_off */
+typedef struct {
+    int32_t src_off;
+    int32_t ref_off;   /* candidate (dx, dy) = 0: the sample offset of the centre position in the reference plane */
+    int32_t w, h;      /* w a multiple of 4 */
+    int32_t out_off;   /* index of the surface's first int32 (dx = dy = -R) in d_out */
+    int32_t reserved[3];
+} havoc_mi355x_surface_job; /* 32 bytes */
+
 /* fractional-sample interpolation of one prediction block (havoc/pred_inter.h:35) */
 typedef struct {
     int32_t dst_off;
@@ -163,6 +172,14 @@ int havoc_mi355x_sad(havoc_mi355x_ctx *ctx, int S, const void *d_src, intptr_t s
 /* havoc_sad_multiref<Sample>, ways = 4 (havoc/sad.h:100, havoc/sad.cpp:513-542): d_out[4*i + k] */
 int havoc_mi355x_sad4(havoc_mi355x_ctx *ctx, int S, const void *d_src, intptr_t stride_src, const void *d_ref,
                       intptr_t stride_ref, const havoc_mi355x_sad4_job *d_jobs, int njobs, int32_t *d_out);
+/* Full-pel SAD surface: the super-set serving the havoc_sad / havoc_sad_multiref calls of the integer motion search
+ * (turing/Search.hpp:1447-1482 considerPattern, :1585-1623 bi grid, :2224-2290 star / raster / refinement) as look-ups.
+ * d_out[out_off + (dy + range) * (2*range + 1) + (dx + range)] = havoc_sad(src, ref + dy*stride_ref + dx) for every
+ * dx, dy in [-range, range], range 0..64; every value is the one havoc_mi355x_sad returns for that candidate.
+ * max_w / max_h: upper bounds on the block sizes of the batch.  Reads at most 3 bytes beyond a candidate row. */
+int havoc_mi355x_sad_surface(havoc_mi355x_ctx *ctx, int S, int range, int max_w, int max_h, const void *d_src,
+                             intptr_t stride_src, const void *d_ref, intptr_t stride_ref,
+                             const havoc_mi355x_surface_job *d_jobs, int njobs, int32_t *d_out);
 /* havoc_ssd<Sample> (havoc/ssd.h:33, havoc/ssd.cpp:28-43): uint32 accumulate, 16-bit >> 4 */
 int havoc_mi355x_ssd(havoc_mi355x_ctx *ctx, int S, const void *d_a, intptr_t stride_a, const void *d_b,
                      intptr_t stride_b, const havoc_mi355x_pair_job *d_jobs, int njobs, uint32_t *d_out);

@@ -34,6 +34,8 @@ def make_inputs(seed=20260927):
         d[f"{k}.sad4.jobs"] = np.array([(so, *ros, w, h, 0) for (w, h, so, ros) in
                                         cases.sad4_cases(rng, cases.PU_SIZES, 2)], np.int32)
         d[f"{k}.ssd.jobs"] = _pairs(rng, [(4, 4), (8, 8), (16, 16), (32, 32), (64, 64)], 3)
+        # full-pel SAD surfaces: every PU size, all candidates within +-8 of a random centre (and a 4-wide non-PU shape)
+        d[f"{k}.surface.jobs"] = _pairs(rng, cases.PU_SIZES + [(4, 4), (20, 8)], 1)
         # SATD: single 2/4/8 Hadamards plus PU-sized jobs tiled as measureSatd does (incl. chroma sizes -> 4x4, 2x2)
         d[f"{k}.satd.jobs"] = _pairs(rng, [(2, 2), (4, 4), (8, 8)] + cases.PU_SIZES + [(6, 8), (2, 4), (12, 8)], 2)
         uni = cases.pred_uni_cases(rng, [bd])
@@ -189,6 +191,8 @@ def run(impl, d, keys=None):
             if want(f"{k}.sad"):
                 out[f"{k}.sad{nm}"] = impl.sad(p, W, q, W, d[f"{k}.sad.jobs"])
                 out[f"{k}.sad4{nm}"] = impl.sad4(p, W, q, W, d[f"{k}.sad4.jobs"])
+            if want(f"{k}.surface"):
+                out[f"{k}.surface8{nm}"] = impl.sad_surface(p, W, q, W, 8, d[f"{k}.surface.jobs"])
             if want(f"{k}.ssd"):
                 out[f"{k}.ssd{nm}"] = impl.ssd(p, W, q, W, d[f"{k}.ssd.jobs"])
             if want(f"{k}.satd"):
@@ -273,6 +277,16 @@ class LoopImpl:
     def sad4(self, a, sa, b, sb, jobs):
         return np.array([self.f.sad4(a, int(j[0]), sa, b, [int(x) for x in j[1:5]], sb, int(j[5]), int(j[6]))
                          for j in jobs], np.int32)
+
+    def sad_surface(self, a, sa, b, sb, rng, jobs):
+        """the surface is by definition the single SAD of every candidate (havoc/sad.cpp:432-449)"""
+        side = 2 * rng + 1
+        out = np.zeros((len(jobs), side, side), np.int32)
+        for i, j in enumerate(jobs):
+            for dy in range(-rng, rng + 1):
+                for dx in range(-rng, rng + 1):
+                    out[i, dy + rng, dx + rng] = self.f.sad(a, int(j[0]), sa, b, int(j[1]) + dy * sb + dx, sb, int(j[2]), int(j[3]))
+        return out
 
     def ssd(self, a, sa, b, sb, jobs):
         return np.array([self.f.ssd(a, int(j[0]), sa, b, int(j[1]), sb, int(j[2]), int(j[3])) for j in jobs], np.uint32)

@@ -20,7 +20,7 @@ def golden():
     return load_golden()
 
 
-GROUPS = ["u8.sad", "u16.sad", "u8.ssd", "u16.ssd", "u8.satd", "u16.satd", "u8.pred_uni", "u16.pred_uni", "u8.pred_bi",
+GROUPS = ["u8.sad", "u16.sad", "u8.surface", "u16.surface", "u8.ssd", "u16.ssd", "u8.satd", "u16.satd", "u8.pred_uni", "u16.pred_uni", "u8.pred_bi",
           "u16.pred_bi", "subtract_bi", "u8.intra", "u16.intra", "residual", "u8.itx", "u16.itx", "fwd8", "fwd10",
           "quant", "qrec", "ssd_linear", "u8.intra35", "u16.intra35", "u8.subpel", "u16.subpel", "u8.planes", "u16.planes", "u8.tuf", "u16.tuf"]
 
@@ -51,3 +51,34 @@ def test_library_loaded_in_process():
     maps = open("/proc/self/maps").read()
     assert "libhavoc_mi355x.so" in maps
     assert "liboracle.so" in maps or True   # the checker may be loaded by the test, never by the product
+
+
+@pytest.mark.parametrize("S,bd", [(1, 8), (2, 10)])
+@pytest.mark.parametrize("rng", [0, 1, 5, 16, 33, 64])
+def test_sad_surface_ranges(hv, oracle, S, bd, rng):
+    """surfaces of every supported range on a 352 x 288 plane: bi-prediction grids (3x3, 11x11: many jobs per workgroup)
+    up to the +-64 star-search window (9 bands per job).  Expected values: the SAD definition in numpy (sum |a-b|,
+    16-bit >> 2), itself checked against the oracle on a sample of candidates."""
+    import cases
+    r = np.random.default_rng(77 + rng)
+    pw, ph = 352, 288
+    a = cases.rand_plane(r, S, bd, ph, pw).ravel()
+    b = cases.rand_plane(r, S, bd, ph, pw, kind="uniform").ravel()
+    sizes = cases.PU_SIZES if rng <= 16 else [(64, 64), (16, 16), (8, 8), (32, 8), (4, 8), (48, 64), (12, 16)]
+    jobs = []
+    for (w, h) in sizes:
+        x, y = cases.rand_pos(r, w, h, pw, ph, rng + 4)
+        sx, sy = cases.rand_pos(r, w, h, pw, ph, 4)
+        jobs.append((sy * pw + sx, y * pw + x, w, h))
+    jobs = np.array(jobs, np.int32)
+    got = hv.sad_surface(a, pw, b, pw, rng, jobs)
+    A, B = a.reshape(ph, pw).astype(np.int64), b.reshape(ph, pw).astype(np.int64)
+    for i, (so, ro, w, h) in enumerate(jobs.tolist()):
+        sy, sx, y, x = so // pw, so % pw, ro // pw, ro % pw
+        win = np.lib.stride_tricks.sliding_window_view(B[y - rng:y + rng + h, x - rng:x + rng + w], (h, w))
+        exp = np.abs(win - A[sy:sy + h, sx:sx + w]).sum(axis=(2, 3))
+        if S == 2:
+            exp >>= 2
+        assert np.array_equal(got[i], exp), (i, w, h)
+        for (dy, dx) in ((-rng, -rng), (rng, rng), (0, 0), (-rng, rng)):
+            assert oracle.sad(a, so, pw, b, ro + dy * pw + dx, pw, w, h) == got[i, dy + rng, dx + rng]

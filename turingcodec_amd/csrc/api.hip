@@ -7,6 +7,7 @@
 
 namespace havoc_gpu {
 hipError_t launch_sad(hipStream_t, int S, int ways, const void *, long, const void *, long, const void *, int, int32_t *);
+hipError_t launch_sad_surface(hipStream_t, int S, int range, int maxw, int maxh, const void *, long, const void *, long, const void *, int, int32_t *);
 hipError_t launch_ssd(hipStream_t, int S, const void *, long, const void *, long, const void *, int, uint32_t *);
 hipError_t launch_satd(hipStream_t, int S, int maxw, int maxh, const void *, long, const void *, long, const void *, int, int32_t *);
 hipError_t launch_ssd_linear(hipStream_t, const uint8_t *, const uint8_t *, int, int32_t *);
@@ -34,6 +35,7 @@ using namespace havoc_gpu;
 
 static_assert(sizeof(havoc_mi355x_pair_job) == 16, "job ABI");
 static_assert(sizeof(havoc_mi355x_sad4_job) == 32, "job ABI");
+static_assert(sizeof(havoc_mi355x_surface_job) == 32, "job ABI");
 static_assert(sizeof(havoc_mi355x_pred_uni_job) == 32, "job ABI");
 static_assert(sizeof(havoc_mi355x_pred_bi_job) == 48, "job ABI");
 static_assert(sizeof(havoc_mi355x_subtract_bi_job) == 32, "job ABI");
@@ -320,6 +322,15 @@ int havoc_mi355x_sad4(havoc_mi355x_ctx *ctx, int S, const void *d_src, intptr_t 
 {
     REQUIRE_CTX(); REQUIRE_S(); REQUIRE(njobs >= 0, "njobs < 0");
     return check(launch_sad(LS(ctx),S, 4, d_src, stride_src, d_ref, stride_ref, d_jobs, njobs, d_out), "sad4");
+}
+
+int havoc_mi355x_sad_surface(havoc_mi355x_ctx *ctx, int S, int range, int max_w, int max_h, const void *d_src, intptr_t stride_src,
+                             const void *d_ref, intptr_t stride_ref, const havoc_mi355x_surface_job *d_jobs, int njobs, int32_t *d_out)
+{
+    REQUIRE_CTX(); REQUIRE_S(); REQUIRE(njobs >= 0, "njobs < 0");
+    REQUIRE(range >= 0 && range <= 64, "range must be 0..64");
+    REQUIRE(max_w >= 4 && max_w <= 64 && (max_w & 3) == 0 && max_h >= 1 && max_h <= 64, "max_w must be 4..64 and a multiple of 4, max_h 1..64");
+    return check(launch_sad_surface(LS(ctx), S, range, max_w, max_h, d_src, stride_src, d_ref, stride_ref, d_jobs, njobs, d_out), "sad_surface");
 }
 
 int havoc_mi355x_ssd(havoc_mi355x_ctx *ctx, int S, const void *d_a, intptr_t stride_a, const void *d_b, intptr_t stride_b,

@@ -56,6 +56,7 @@ def _load():
         "join": [_vp],
         "sad": [_vp, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
         "sad4": [_vp, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
+        "sad_surface": [_vp, _i, _i, _i, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
         "ssd": [_vp, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
         "satd": [_vp, _i, _i, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
         "ssd_linear": [_vp, _vp, _vp, _i, _vp],
@@ -200,6 +201,10 @@ class Havoc:
     def sad_d(self, src, ss, ref, rs, jobs, out):
         self._ck(self.L.havoc_mi355x_sad(self.h, self._S(src), _ptr(src), ss, _ptr(ref), rs, _ptr(jobs), jobs.shape[0], _ptr(out)))
 
+    def sad_surface_d(self, src, ss, ref, rs, rng, max_w, max_h, jobs, out):
+        self._ck(self.L.havoc_mi355x_sad_surface(self.h, self._S(src), rng, max_w, max_h, _ptr(src), ss, _ptr(ref), rs, _ptr(jobs),
+                                                 jobs.shape[0], _ptr(out)))
+
     def sad4_d(self, src, ss, ref, rs, jobs, out):
         self._ck(self.L.havoc_mi355x_sad4(self.h, self._S(src), _ptr(src), ss, _ptr(ref), rs, _ptr(jobs), jobs.shape[0], _ptr(out)))
 
@@ -330,6 +335,19 @@ class Havoc:
         out = self.zeros(4 * len(jobs), np.int32)
         self.sad4_d(self.up(a), sa, self.up(b), sb, self._jobs(jobs, 8), out)
         return self.down(out, np.int32).reshape(-1, 4)
+
+    def sad_surface(self, a, sa, b, sb, rng, jobs):
+        """jobs rows: src_off, ref_off, w, h; returns [njobs, 2R+1, 2R+1] (dy, dx)"""
+        jobs = np.asarray(jobs, np.int32)
+        side = 2 * rng + 1
+        j = np.zeros((len(jobs), 8), np.int32)
+        j[:, :4] = jobs[:, :4]
+        j[:, 4] = np.arange(len(jobs)) * side * side
+        out = self.zeros(len(jobs) * side * side, np.int32)
+        if len(jobs):
+            mw = (int(j[:, 2].max()) + 3) & ~3
+            self.sad_surface_d(self.up(a), sa, self.up(b), sb, rng, mw, int(j[:, 3].max()), self.up(j), out)
+        return self.down(out, np.int32).reshape(-1, side, side)
 
     def ssd(self, a, sa, b, sb, jobs):
         out = self.zeros(len(jobs), np.uint32)

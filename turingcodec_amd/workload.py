@@ -112,11 +112,16 @@ class FrameWorkload:
             # PU positions are aligned to their own size inside the picture (natural CU alignment)
             x = (rng.integers(0, 1 << 30, nj) % np.maximum(1, (W - w) // w + 1)) * w
             y = (rng.integers(0, 1 << 30, nj) % np.maximum(1, (H - h) // h + 1)) * h
-            o = ctu_order(x, y)   # the encoder queues jobs CTU by CTU (raster / WPP order): keep that locality
+            o = ctu_order(x, y, w * h)   # the encoder queues jobs CTU by CTU (raster / WPP order): keep that locality
             return w[o], h[o], x[o].astype(np.int32), y[o].astype(np.int32)
 
-        def ctu_order(x, y):
-            return np.argsort((np.asarray(y) // CTU) * 4096 + np.asarray(x) // CTU, kind="stable")
+        def ctu_order(x, y, area=None):
+            """CTU raster order; inside a CTU by decreasing block size, as the quadtree search descends depth by depth
+            (so neighbouring jobs of a table mostly have the same shape)"""
+            ctu = (np.asarray(y) // CTU) * 4096 + np.asarray(x) // CTU
+            if area is None:
+                return np.argsort(ctu, kind="stable")
+            return np.lexsort((-np.asarray(area), ctu))
 
         def grid_pos(nn, m):
             """m block positions aligned to nn, in CTU order"""
@@ -159,7 +164,7 @@ class FrameWorkload:
         u = np.concatenate(rows).astype(np.int32)
         # interleave the four kinds the way a CTU-by-CTU search meets them: sort by the CTU of the source PU
         upos = u[:, 6] % pl
-        u = u[ctu_order(upos % st - PAD, upos // st - PAD)]
+        u = u[ctu_order(upos % st - PAD, upos // st - PAD, u[:, 2] * u[:, 3])]
         # costDistortionMv candidates (1474818/8 per B-frame, A.2) only need the COST: they go through the fused
         # interpolation+SATD entry point, one launch per PU size class; the rest (measurePuCost: the prediction is
         # kept) are written to prediction slots and measured by the SATD batch
