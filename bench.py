@@ -40,6 +40,9 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--kernel-reps", type=int, default=5)
+    ap.add_argument("--ime", choices=["sad4", "surface"], default="sad4",
+                    help="integer ME as per-pattern SAD4 jobs (the reference's call mix) or as one SAD surface per search")
+    ap.add_argument("--ime-range", type=int, default=16, help="surface half-width R: (2R+1)^2 candidates per search")
     ap.add_argument("--exchange", action="store_true",
                     help="run the reference-picture exchange (process group + RCCL broadcasts) even with one rank")
     ap.add_argument("--lanes", type=int, default=8, help="fork/join lanes: independent launch chains overlap on the GPU")
@@ -57,9 +60,9 @@ def parse_args():
 class DeviceFrame:
     """A FrameWorkload uploaded to HBM + the list of launches that make one step."""
 
-    def __init__(self, hv, wl, use_planes=True, fused_tu=True):
+    def __init__(self, hv, wl, use_planes=True, fused_tu=True, ime_range=None):
         import torch
-        self.hv, self.wl, self.use_planes, self.fused_tu = hv, wl, use_planes, fused_tu
+        self.hv, self.wl, self.use_planes, self.fused_tu, self.ime_range = hv, wl, use_planes, fused_tu, ime_range
         up = hv.up
         dt = wl.dtype
         S = wl.S
@@ -74,6 +77,12 @@ class DeviceFrame:
         self.sbi = z(len(wl.subtract_bi) * 4096, dt)
         self.j_sad4, self.j_sad = up(wl.sad4), up(wl.sad)
         self.o_sad4, self.o_sad = z(4 * len(wl.sad4), np.int32), z(len(wl.sad), np.int32)
+        if ime_range is not None:   # integer ME from SAD surfaces: one (2R+1)^2 surface per search instead of SAD4 jobs
+            side = 2 * ime_range + 1
+            sj = np.zeros((len(wl.me_search), 8), np.int32)
+            sj[:, :4] = wl.me_search
+            sj[:, 4] = np.arange(len(sj)) * side * side
+            self.j_surf, self.o_surf = up(sj), z(len(sj) * side * side, np.int32)
         self.j_sbi = up(wl.subtract_bi)
         self.j_satd = up(wl.satd_inter)
         self.o_satd = z(len(wl.satd_inter), np.int32)
@@ -140,7 +149,10 @@ class DeviceFrame:
             chains.append(list(range(len(L), len(L) + len(items))))
             L.extend(items)
 
-        chain(("sad4", lambda: hv.sad4_d(self.luma, st, self.luma, st, self.j_sad4, self.o_sad4)))
+        if self.ime_range is None:
+            chain(("sad4", lambda: hv.sad4_d(self.luma, st, self.luma, st, self.j_sad4, self.o_sad4)))
+        else:
+            chain(("sad_surface", lambda: hv.sad_surface_d(self.luma, st, self.luma, st, self.ime_range, 64, 64, self.j_surf, self.o_surf)))
         chain(("sad", lambda: hv.sad_d(self.luma, st, self.luma, st, self.j_sad, self.o_sad)))
         if self.use_planes:
             # sub-pel candidates against phase planes: interpolate each reference picture once (streaming, HBM-bound),
@@ -230,7 +242,7 @@ class DeviceFrame:
         """a checksum of checksums over every result buffer (size-independent parity property; see tests)"""
         import torch
         acc = 0
-        bufs = [self.o_sad4, self.o_sad, self.o_satd, self.pred, self.cpred, self.bi, self.sbi]
+        bufs = [self.o_sad4 if self.ime_range is None else self.o_surf, self.o_sad, self.o_satd, self.pred, self.cpred, self.bi, self.sbi]
         for g in self.intra.values():
             bufs += [g["dst"]]
         for g in list(self.isearch.values()) + list(self.subpel_planes.values() if self.use_planes else self.subpel.values()):
@@ -483,7 +495,8 @@ def main():
     hv = Havoc(local, stream=compute.cuda_stream)
     w, h = (int(v) for v in args.res.split("x"))
     wl = FrameWorkload(w, h, args.bit_depth, args.seed + rank)   # every rank owns a different picture
-    dev = DeviceFrame(hv, wl, use_planes=(args.subpel == "planes"), fused_tu=(args.tu == "fused"))
+    dev = DeviceFrame(hv, wl, use_planes=(args.subpel == "planes"), fused_tu=(args.tu == "fused"),
+                      ime_range=args.ime_range if args.ime == "surface" else None)
     exch = None
     if grouped:
         from turingcodec_amd.frame_parallel import ReferenceExchange
@@ -538,6 +551,7 @@ def main():
     if rank == 0:
         ktimes, kcount = dev.kernel_times_ms(args.kernel_reps)
         kbytes = wl.algorithmic_bytes()
+        kbytes["sad_surface"] = kbytes["sad_surface"](args.ime_range)
         dom = max(ktimes, key=ktimes.get)
         ach = kbytes[dom] / (ktimes[dom] * 1e-3) / 1e9
         total_bytes = sum(kbytes[k] for k in ktimes)
@@ -554,6 +568,9 @@ def main():
             "config": {"workload": f"{args.res} {args.bit_depth}-bit 4:2:0 random-access QP32 speed=medium B-frame call mix "
                                    f"(SURVEY A.2 counts x {w * h / (1920 * 1080):.2f}; assumed PU/intra size mix), 1xMI355X per rank",
                        "calls_per_frame": int(sum(wl.counts.values())), "launches_per_frame": len(dev.launches),
+                       "integer_me": ("sad4 jobs (the reference's per-pattern calls)" if args.ime == "sad4" else
+                                      f"{len(wl.me_search)} SAD surfaces of (2*{args.ime_range}+1)^2 candidates instead of "
+                                      f"{len(wl.sad4)} SAD4 calls"),
                        "parallelism": (f"frame-parallel x{world}: one picture per rank per step, reference pictures broadcast "
                                        f"over RCCL ({exch.sent_bytes // max(1, args.steps + args.warmup)} B sent per step by rank 0), "
                                        f"overlapped with the next picture") if world > 1 else "single GPU"},

@@ -324,6 +324,14 @@ class FrameWorkload:
             ssd = np.concatenate([ssd, ssd])[:nssd]
             self.tu[(log2, tr)] = dict(jobs=t, src=src4, res_off=t[:, 1].copy(), n=nn, ssd=ssd)
 
+        # ---- integer ME served from SAD surfaces (havoc_mi355x_sad_surface) instead of per-pattern SAD4 jobs: one
+        # surface per uni-directional search.  A.1: ~31 SAD4 calls (124 candidates) per search on average, so the
+        # frame's 183 k SAD4 calls are ~5.9 k searches.  (drawn last: the tables above do not depend on this one)
+        ns = max(1, n["sad4"] // 31)
+        w, h, x, y = pu(ns)
+        cx, cy = mv(ns, 28)          # predictor; +-64 around it stays inside the 96-sample padding
+        self.me_search = np.stack([loff(x, y, 0), loff(x + cx, y + cy, rng.integers(1, 3, ns)), w, h], 1).astype(np.int32)
+
     # ---- algorithmic bytes (SURVEY.md 8(d) "per primitive call": operands read once + results written once) ----
     def algorithmic_bytes(self):
         S = self.S
@@ -331,6 +339,8 @@ class FrameWorkload:
         wh = lambda j, cw, ch: j[:, cw].astype(np.int64) * j[:, ch]
         b["sad4"] = int((5 * wh(self.sad4, 5, 6) * S + 16).sum())
         b["sad"] = int((2 * wh(self.sad, 2, 3) * S + 4).sum())
+        b["sad_surface"] = lambda R: int(((self.me_search[:, 2].astype(np.int64) + 2 * R) * (self.me_search[:, 3] + 2 * R) * S
+                                          + wh(self.me_search, 2, 3) * S + 4 * (2 * R + 1) ** 2).sum())   # window + block in, surface out
 
         def uni(j, t):
             w, h = j[:, 2].astype(np.int64), j[:, 3].astype(np.int64)
