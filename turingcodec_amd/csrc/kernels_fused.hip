@@ -6,13 +6,15 @@
 //                    (havoc/pred_intra.cpp:20282-20401) each followed by the Hadamard SATD against the source block
 //                    (8x8 tiles, or one 4x4 for 4x4 blocks; havoc/hadamard.cpp:58-98).
 //
-// Mapping: one wavefront owns P partitions of one size; source block, both neighbour arrays (unfiltered / filtered)
-// and the 33 projected angular reference arrays live in LDS.  A work item is (partition, mode, SATD tile): one LANE
-// predicts its tile straight into registers, subtracts the source tile, runs the 2-D Hadamard in registers and adds
-// its tile cost into the partition's 35 LDS accumulators.  Horizontal modes are evaluated in the transposed domain
-// (prediction^T against source^T): SATD is invariant under transposition, and it makes the horizontal and vertical
-// modes one code path.  Items are ordered mode-major so that after the first step every wavefront step is
-// divergence-free angular work.
+// Mapping: one workgroup owns P partitions of one size; source block (both orientations), both neighbour arrays
+// (unfiltered / filtered, plus the left column reversed) and the projected reference arrays of the 15 negative-angle
+// modes live in LDS.  A work item is (group of 5 modes, partition, SATD tile): one LANE keeps its source tile in
+// registers, and per mode predicts the tile into registers two samples per instruction (packed 16-bit lerp), subtracts,
+// runs the 2-D Hadamard in registers and adds the tile cost into the partition's 35 LDS accumulators.  Horizontal
+// modes are evaluated in the transposed domain (prediction^T against source^T): SATD is invariant under
+// transposition, and it makes the horizontal and vertical modes one code path.  The kernel is bound by LDS accesses
+// (scattered 16-bit reference reads conflict on banks) more than by VALU, hence the register-resident source tile,
+// the one-vector reference read per row and the rotation instead of a second read.
 #include "common.h"
 
 namespace havoc_gpu {
@@ -87,25 +89,54 @@ __device__ __forceinline__ int satd_regs_pk(uint32_t (&p)[TS][TS / 2])
     return (int)(sum / (TS / 2));
 }
 
+// TS consecutive 16-bit LDS entries as TS/2 packed pairs; the address is only 2-byte aligned (gfx950 DS instructions
+// take unaligned addresses: one ds_read_b128 / b64 instead of TS ds_read_u16)
+typedef uint32_t __attribute__((ext_vector_type(4), aligned(2))) u32x4h;
+typedef uint32_t __attribute__((ext_vector_type(2), aligned(2))) u32x2h;
+
+template <int TS>
+__device__ __forceinline__ void ld_pairs(const uint16_t *q, uint32_t (&o)[TS / 2])
+{
+    if constexpr (TS == 8)
+    {
+        const u32x4h v = *reinterpret_cast<const u32x4h *>(q);
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    }
+    else
+    {
+        const u32x2h v = *reinterpret_cast<const u32x2h *>(q);
+        o[0] = v.x; o[1] = v.y;
+    }
+}
+
+// two angular samples at once: ((32 - f) * a + f * b + 16) >> 5 per 16-bit half.  Exact in 16 bits for samples < 2^11:
+// (32 - f) * a + f * b + 16 <= 32 * 2047 + 16 < 65536; f == 0 gives a (no special case).  w0 = (32-f, 32-f), w1 = (f, f)
+__device__ __forceinline__ uint32_t pk_lerp(uint32_t a, uint32_t b, uint32_t w0, uint32_t w1)
+{
+    const u16x2 r = {16, 16}, five = {5, 5};
+    u16x2 t = __builtin_bit_cast(u16x2, a) * __builtin_bit_cast(u16x2, w0) + r;
+    t = __builtin_bit_cast(u16x2, b) * __builtin_bit_cast(u16x2, w1) + t;
+    return __builtin_bit_cast(uint32_t, t >> five);
+}
+
 // the difference tile of one work item: packed pairs for 8-bit samples, 32-bit for 16-bit samples
 template <int S, int TS>
 struct TileDiff
 {
     int d[S == 1 ? 1 : TS][S == 1 ? 1 : TS];
     uint32_t p[S == 1 ? TS : 1][S == 1 ? TS / 2 : 1];
-    // row j = source row (TS samples at `src`, 4-byte aligned) minus prediction v[]
-    __device__ __forceinline__ void set_row(int j, const uint16_t *src, const int (&v)[TS])
+    // row j = source row s2 (packed pairs, held in registers across the item's modes) minus prediction row v2
+    __device__ __forceinline__ void set_row_pk(int j, const uint32_t (&s2)[TS / 2], const uint32_t (&v2)[TS / 2])
     {
-        if constexpr (S == 1)
-        {
 #pragma unroll
-            for (int k = 0; k < TS / 2; ++k)
-                p[j][k] = pk_sub(*reinterpret_cast<const uint32_t *>(src + 2 * k), (uint32_t)v[2 * k] | ((uint32_t)v[2 * k + 1] << 16));
-        }
-        else
+        for (int k = 0; k < TS / 2; ++k)
         {
-#pragma unroll
-            for (int i = 0; i < TS; ++i) d[j][i] = (int)src[i] - v[i];
+            if constexpr (S == 1) p[j][k] = pk_sub(s2[k], v2[k]);
+            else
+            {
+                d[j][2 * k] = (int)(s2[k] & 0xffffu) - (int)(v2[k] & 0xffffu);
+                d[j][2 * k + 1] = (int)(s2[k] >> 16) - (int)(v2[k] >> 16);
+            }
         }
     }
     __device__ __forceinline__ int satd()
@@ -115,8 +146,13 @@ struct TileDiff
     }
 };
 
+// a lane evaluates MPI (modes per item: 5, or 1 for the single-tile sizes) consecutive entries of this list for one tile: planar, DC and the vertical family
+// (source tile as stored), then the horizontal family (transposed source tile) -- one orientation switch in the list
+__constant__ int8_t c_modeOrder[35] = {0,  1,  18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33,
+                                       34, 2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 16, 17};
+
 // job: havoc_mi355x_intra_search_job = { src_off, nb_off, nbf_off, filt_lo, filt_hi, edge, reserved[2] }
-template <int S, int LOG2, int P, int THREADS>
+template <int S, int LOG2, int P, int THREADS, int MPI>
 __global__ __launch_bounds__(THREADS) void k_intra_satd35(const char *__restrict__ src, long stride_src, const char *__restrict__ neighbours,
                                                      const int32_t *__restrict__ jobs, int njobs, int bitDepth, int32_t *__restrict__ cost)
 {
@@ -125,8 +161,11 @@ __global__ __launch_bounds__(THREADS) void k_intra_satd35(const char *__restrict
     constexpr int TS = N >= 8 ? 8 : 4;       // SATD tile (Reconstruct.cpp:684-701)
     constexpr int TPR = N / TS, NT = TPR * TPR;
     constexpr int NB = 4 * N + 1;
-    constexpr int RL = 3 * N + 2;            // projected reference: indices -N .. 2N (+1 slack)
+    constexpr int NL = 2 * N + 2;            // top / left run: corner + 2N samples (+1 slack)
+    constexpr int RL = 2 * N + 2;            // projected reference of a negative-angle mode: indices -N .. N (+1 slack)
     constexpr int PT = P * NT;               // (partition, tile) pairs per workgroup
+    constexpr int kModeGroups = 35 / MPI;
+    static_assert(kModeGroups * MPI == 35 && kModeGroups * PT <= THREADS, "one item per thread");
 
     // row stride N+2 and a per-partition skew keep tiles of different rows / partitions on different LDS banks
     // (with dense N*N blocks every partition and every 8-row band started on bank 0: 10-way conflicts on 16x16)
@@ -135,7 +174,8 @@ __global__ __launch_bounds__(THREADS) void k_intra_satd35(const char *__restrict
     __shared__ uint16_t s_src[P][SB];        // row-major source block
     __shared__ uint16_t s_srcT[P][SB];       // transposed source block
     __shared__ uint16_t s_nb[P][2][NB + 1];  // [0] unfiltered, [1] filtered; index i <-> neighbours[i - 2N - 1]
-    __shared__ uint16_t s_ref[P][33][RL];    // angular modes 2..34; ref[i] at [i + N]
+    __shared__ uint16_t s_left[P][2][NL];    // the left column read downwards: [i] = p(-1, -1+i) = nb[2N - i]
+    __shared__ uint16_t s_ref[P][15][RL];    // negative-angle modes 11..25; ref[i] at [i + N]
     __shared__ int s_dc[P][2];
     __shared__ int s_cost[P][36];
     __shared__ int s_job[P][8];
@@ -181,24 +221,23 @@ __global__ __launch_bounds__(THREADS) void k_intra_satd35(const char *__restrict
     {
         const int p = i / (2 * NB), r = i - p * 2 * NB;
         const int f = r / NB, k = r - f * NB;
-        s_nb[p][f][k] = reinterpret_cast<const T *>(neighbours)[s_job[p][1 + f] + k - 2 * N - 1];
+        const uint16_t v = reinterpret_cast<const T *>(neighbours)[s_job[p][1 + f] + k - 2 * N - 1];
+        s_nb[p][f][k] = v;
+        if (k <= 2 * N) s_left[p][f][2 * N - k] = v;
     }
     __syncthreads();
 
-    // ---- phase 1: projected reference arrays for the 33 angular modes, DC values
-    // only the entries a mode can read are produced: indices 0 .. 2N for the non-negative angles, last .. N for the
-    // negative ones (last = (N * angle) >> 5 >= -N): at most 2N + 1 per mode
-    for (int i = lane; i < P * 33 * (2 * N + 1); i += THREADS)
+    // ---- phase 1: projected reference arrays of the 15 negative-angle modes (the others read the top row / the left
+    // column as they are), DC values.  Entries last .. N with last = (N * angle) >> 5 >= -N are all a mode can read.
+    for (int i = lane; i < P * 15 * (2 * N + 1); i += THREADS)
     {
-        const int p = i / (33 * (2 * N + 1)), r = i - p * 33 * (2 * N + 1);
-        const int mi = r / (2 * N + 1), e = r - mi * (2 * N + 1);
-        const int mode = mi + 2;
+        const int p = i / (15 * (2 * N + 1)), r = i - p * 15 * (2 * N + 1);
+        const int mi = r / (2 * N + 1), idx = r - mi * (2 * N + 1) - N;
+        const int mode = mi + 11;
         const int angle = c_angle35[mode];
         const bool vertical = mode >= 18;
-        const int last = angle < 0 ? (N * angle) >> 5 : 0;
-        const int idx = (last < -1 ? last : 0) + e;
-        if (idx > (angle < 0 ? N : 2 * N)) continue;
-        const uint32_t fbits = mode < 32 ? (uint32_t)s_job[p][3] >> mode : (uint32_t)s_job[p][4] >> (mode - 32);
+        if (idx < ((N * angle) >> 5)) continue;
+        const uint32_t fbits = (uint32_t)s_job[p][3] >> mode;
         const uint16_t *nb = s_nb[p][fbits & 1];
         int v;
         if (idx >= 0) v = vertical ? nb[2 * N + idx] : nb[2 * N - idx];   // p(-1+idx,-1) / p(-1,-1+idx)
@@ -218,87 +257,118 @@ __global__ __launch_bounds__(THREADS) void k_intra_satd35(const char *__restrict
     }
     __syncthreads();
 
-    // ---- phase 2: one (mode, partition, tile) item per lane per step; mode-major ordering
-    for (int it = lane; it < 35 * PT; it += THREADS)
+    // ---- phase 2: one item per lane = (mode group, partition, tile); the source tile stays in registers across the
+    // group's modes.  Group-major ordering: the lanes of a wavefront mostly run the same modes.
+    if (lane < kModeGroups * PT)
     {
-        const int mode = it / PT, pt = it - mode * PT;
+        const int grp = lane / PT, pt = lane - grp * PT;
         const int p = pt / NT, tile = pt - p * NT;
         const int ty = tile / TPR, tx = tile - ty * TPR;
-        const uint32_t fbits = mode < 32 ? (uint32_t)s_job[p][3] >> mode : (uint32_t)s_job[p][4] >> (mode - 32);
-        const uint16_t *nb = s_nb[p][fbits & 1];
         const bool edge = s_job[p][5] != 0 && LOG2 < 5;
-        TileDiff<S, TS> td;
-        if (mode >= 2)
+        uint32_t sp[TS][TS / 2];
+        int have = -1;   // orientation of the tile in sp: 0 as stored, 1 transposed
+#pragma unroll 1
+        for (int m = 0; m < MPI; ++m)
         {
-            const int angle = c_angle35[mode];
+            const int mode = c_modeOrder[grp * MPI + m];
             const bool vertical = mode >= 18;
-            const uint16_t *ref = &s_ref[p][mode - 2][N];
-            const uint16_t *sb = vertical ? s_src[p] : s_srcT[p];
-            const int maj0 = (vertical ? ty : tx) * TS, min0 = (vertical ? tx : ty) * TS;
-            const bool efilt = edge && min0 == 0 && (mode == 26 || mode == 10);
-#pragma unroll
-            for (int j = 0; j < TS; ++j)
+            const int orient = (mode >= 2 && !vertical) ? 1 : 0;
+            const int maj0 = (orient ? tx : ty) * TS, min0 = (orient ? ty : tx) * TS;
+            if (orient != have)
             {
-                const int t = (maj0 + j + 1) * angle;
-                const int idx = t >> 5, fact = t & 31;
-                const uint16_t *r = ref + min0 + idx + 1;
-                int rv[TS + 1], v[TS];
+                const uint16_t *sb = (orient ? s_srcT[p] : s_src[p]) + maj0 * NS + min0;
 #pragma unroll
-                for (int i = 0; i <= TS; ++i) rv[i] = r[i];
-#pragma unroll
-                for (int i = 0; i < TS; ++i) v[i] = fact ? ((32 - fact) * rv[i] + fact * rv[i + 1] + 16) >> 5 : rv[i];
-                if (efilt)
-                {   // pred_intra.cpp:20355-20360 / :20394-20399: first column (row) of vertical (horizontal) prediction
-                    const int side = vertical ? nb[2 * N - 1 - (maj0 + j)] : nb[2 * N + 1 + (maj0 + j)];
-                    v[0] = clip3(0, maxv, (int)ref[1] + ((side - (int)ref[0]) >> 1));
-                }
-                td.set_row(j, sb + (maj0 + j) * NS + min0, v);
+                for (int j = 0; j < TS; ++j) ld_pairs<TS>(sb + j * NS, sp[j]);
+                have = orient;
             }
-        }
-        else if (mode == 1)
-        {
-            const int dc = s_dc[p][fbits & 1];
-#pragma unroll
-            for (int j = 0; j < TS; ++j)
+            const uint32_t fbits = mode < 32 ? (uint32_t)s_job[p][3] >> mode : (uint32_t)s_job[p][4] >> (mode - 32);
+            const int f = fbits & 1;
+            const uint16_t *nb = s_nb[p][f];
+            TileDiff<S, TS> td;
+            if (mode >= 2)
             {
-                const int y = ty * TS + j;
-                int v[TS];
+                const int angle = c_angle35[mode];
+                // ref[i], i >= 0: p(-1+i,-1) (vertical) or p(-1,-1+i) (horizontal); negative-angle modes add projected entries
+                const uint16_t *ref = angle < 0 ? &s_ref[p][mode - 11][N] : (vertical ? nb + 2 * N : s_left[p][f]);
+                const bool efilt = edge && min0 == 0 && angle == 0;
 #pragma unroll
-                for (int i = 0; i < TS; ++i)
+                for (int j = 0; j < TS; ++j)
                 {
-                    const int x = tx * TS + i;
-                    v[i] = dc;
-                    if (edge)
-                    {
-                        if (x == 0 && y == 0) v[i] = ((int)nb[2 * N - 1] + 2 * dc + (int)nb[2 * N + 1] + 2) >> 2;
-                        else if (y == 0) v[i] = ((int)nb[2 * N + 1 + x] + 3 * dc + 2) >> 2;
-                        else if (x == 0) v[i] = ((int)nb[2 * N - 1 - y] + 3 * dc + 2) >> 2;
+                    const int t = (maj0 + j + 1) * angle;
+                    const int idx = t >> 5, fact = t & 31;
+                    const uint16_t *r = ref + min0 + idx + 1;
+                    uint32_t ra[TS / 2], rb[TS / 2], v2[TS / 2];
+                    ld_pairs<TS>(r, ra);          // (ref[i], ref[i+1]) pairs; the pairs one entry further by rotation, not re-read
+                    const uint32_t rl = r[TS];
+#pragma unroll
+                    for (int k = 0; k < TS / 2; ++k) rb[k] = __builtin_amdgcn_alignbit(k + 1 < TS / 2 ? ra[k + 1] : rl, ra[k], 16);
+                    const uint32_t w1 = (uint32_t)fact * 0x00010001u, w0 = 0x00200020u - w1;
+#pragma unroll
+                    for (int k = 0; k < TS / 2; ++k) v2[k] = pk_lerp(ra[k], rb[k], w0, w1);
+                    if (efilt)
+                    {   // pred_intra.cpp:20355-20360 / :20394-20399: first column (row) of vertical (horizontal) prediction
+                        const int side = vertical ? nb[2 * N - 1 - (maj0 + j)] : nb[2 * N + 1 + (maj0 + j)];
+                        v2[0] = (v2[0] & 0xffff0000u) | (uint32_t)clip3(0, maxv, (int)ref[1] + ((side - (int)ref[0]) >> 1));
                     }
+                    td.set_row_pk(j, sp[j], v2);
                 }
-                td.set_row(j, s_src[p] + y * NS + tx * TS, v);
             }
-        }
-        else
-        {
-            const int topR = nb[2 * N + 1 + N], botL = nb[2 * N - 1 - N];   // p(N,-1), p(-1,N)
-#pragma unroll
-            for (int j = 0; j < TS; ++j)
+            else if (mode == 1)
             {
-                const int y = ty * TS + j;
-                const int left = nb[2 * N - 1 - y];
-                int v[TS];
+                const int dc = s_dc[p][f];
 #pragma unroll
-                for (int i = 0; i < TS; ++i)
+                for (int j = 0; j < TS; ++j)
                 {
-                    const int x = tx * TS + i;
-                    v[i] = ((N - 1 - x) * left + (x + 1) * topR + (N - 1 - y) * (int)nb[2 * N + 1 + x] + (y + 1) * botL + N) >> (LOG2 + 1);
+                    const int y = ty * TS + j;
+                    uint32_t v2[TS / 2];
+#pragma unroll
+                    for (int k = 0; k < TS / 2; ++k) v2[k] = (uint32_t)dc * 0x00010001u;
+                    if (edge && (y == 0 || tx == 0))
+                    {
+                        int v[TS];
+#pragma unroll
+                        for (int i = 0; i < TS; ++i)
+                        {
+                            const int x = tx * TS + i;
+                            v[i] = dc;
+                            if (x == 0 && y == 0) v[i] = ((int)nb[2 * N - 1] + 2 * dc + (int)nb[2 * N + 1] + 2) >> 2;
+                            else if (y == 0) v[i] = ((int)nb[2 * N + 1 + x] + 3 * dc + 2) >> 2;
+                            else if (x == 0) v[i] = ((int)nb[2 * N - 1 - y] + 3 * dc + 2) >> 2;
+                        }
+#pragma unroll
+                        for (int k = 0; k < TS / 2; ++k) v2[k] = (uint32_t)v[2 * k] | ((uint32_t)v[2 * k + 1] << 16);
+                    }
+                    td.set_row_pk(j, sp[j], v2);
                 }
-                td.set_row(j, s_src[p] + y * NS + tx * TS, v);
             }
+            else
+            {
+                const int topR = nb[2 * N + 1 + N], botL = nb[2 * N - 1 - N];   // p(N,-1), p(-1,N)
+#pragma unroll
+                for (int j = 0; j < TS; ++j)
+                {
+                    const int y = ty * TS + j;
+                    const int left = nb[2 * N - 1 - y];
+                    uint32_t v2[TS / 2];
+#pragma unroll
+                    for (int k = 0; k < TS / 2; ++k)
+                    {
+                        int v[2];
+#pragma unroll
+                        for (int e = 0; e < 2; ++e)
+                        {
+                            const int x = tx * TS + 2 * k + e;
+                            v[e] = ((N - 1 - x) * left + (x + 1) * topR + (N - 1 - y) * (int)nb[2 * N + 1 + x] + (y + 1) * botL + N) >> (LOG2 + 1);
+                        }
+                        v2[k] = (uint32_t)v[0] | ((uint32_t)v[1] << 16);
+                    }
+                    td.set_row_pk(j, sp[j], v2);
+                }
+            }
+            const int c = td.satd();
+            if (NT == 1) s_cost[p][mode] = c;
+            else atomicAdd(&s_cost[p][mode], c);
         }
-        const int c = td.satd();
-        if (NT == 1) s_cost[p][mode] = c;
-        else atomicAdd(&s_cost[p][mode], c);
     }
     __syncthreads();
     for (int i = lane; i < P * 35; i += THREADS)
@@ -316,11 +386,13 @@ static hipError_t launch_intra_satd35_s(hipStream_t st, int log2, int bitDepth, 
     const int32_t *j = (const int32_t *)jobs;
     switch (log2)
     {
-    // (partitions per workgroup, threads): items = 35 * P * tiles -> 245 / 245 / 700 / 560: 1, 1, 3, 3 full steps
-    case 2: hipLaunchKernelGGL((k_intra_satd35<S, 2, 7, 256>), dim3((n + 6) / 7), dim3(256), 0, st, s, ss, q, j, n, bitDepth, cost); break;
-    case 3: hipLaunchKernelGGL((k_intra_satd35<S, 3, 7, 256>), dim3((n + 6) / 7), dim3(256), 0, st, s, ss, q, j, n, bitDepth, cost); break;
-    case 4: hipLaunchKernelGGL((k_intra_satd35<S, 4, 5, 256>), dim3((n + 4) / 5), dim3(256), 0, st, s, ss, q, j, n, bitDepth, cost); break;
-    case 5: hipLaunchKernelGGL((k_intra_satd35<S, 5, 1, 192>), dim3(n), dim3(192), 0, st, s, ss, q, j, n, bitDepth, cost); break;
+    // (partitions per workgroup, threads, modes per item).  8x8 / 4x4 partitions are one tile: their set-up phases weigh as
+    // much as the 35 predictions, so they keep 35 lanes per partition (245 items of 256 lanes); the multi-tile sizes run 5
+    // modes per lane on a register-resident source tile (252 / 224 items of 256 lanes)
+    case 2: hipLaunchKernelGGL((k_intra_satd35<S, 2, 7, 256, 1>), dim3((n + 6) / 7), dim3(256), 0, st, s, ss, q, j, n, bitDepth, cost); break;
+    case 3: hipLaunchKernelGGL((k_intra_satd35<S, 3, 7, 256, 1>), dim3((n + 6) / 7), dim3(256), 0, st, s, ss, q, j, n, bitDepth, cost); break;
+    case 4: hipLaunchKernelGGL((k_intra_satd35<S, 4, 9, 256, 5>), dim3((n + 8) / 9), dim3(256), 0, st, s, ss, q, j, n, bitDepth, cost); break;
+    case 5: hipLaunchKernelGGL((k_intra_satd35<S, 5, 2, 256, 5>), dim3((n + 1) / 2), dim3(256), 0, st, s, ss, q, j, n, bitDepth, cost); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
