@@ -19,10 +19,46 @@
 
 namespace havoc_gpu {
 
-__constant__ int8_t c_angle35[35] = {0,  0,   32,  26,  21,  17,  13, 9,  5,  2,  0, -2, -5, -9, -13, -17, -21, -26,
-                                     -32, -26, -21, -17, -13, -9, -5, -2, 0,  2,  5, 9,  13, 17,  21,  26,  32};
-__constant__ int16_t c_invAngle35[26] = {0,    0,    0,    0,    0,    0,    0,    0,    0,    0,    0,     -4096, -1638,
-                                         -910, -630, -482, -390, -315, -256, -315, -390, -482, -630, -910, -1638, -4096};
+// intraPredAngle (havoc/pred_intra.cpp angle table) without a memory look-up: |angle| depends on the distance from the
+// pure horizontal (10) / vertical (26) mode, nine 6-bit entries packed in one constant
+__host__ __device__ constexpr int angle_of(int mode)
+{
+    const int d = mode < 18 ? mode - 10 : mode - 26;
+    const int mag = (int)((0x2069544d245080ull >> (6 * (d < 0 ? -d : d))) & 63);   // 0 2 5 9 13 17 21 26 32
+    return (mode < 18) == (d < 0) ? mag : -mag;
+}
+__host__ __device__ constexpr int inv_angle_of(int mode)   // modes 11..25: round(8192 / angle), negative
+{
+    const int d = mode < 18 ? mode - 10 : 26 - mode;       // 1..8
+    constexpr int t[9] = {0, 4096, 1638, 910, 630, 482, 390, 315, 256};
+    return -t[d];
+}
+
+// the projected (index < 0) entries of the negative-angle modes' reference arrays (pred_intra.cpp:20330-20345, 20370-20384):
+// entry = { mode - 11, index + N, k + 1 } with ref[index] = p(-1, k) (vertical modes) or p(k, -1) (horizontal modes)
+template <int N>
+struct ProjTable
+{
+    int n;
+    uint16_t e[15 * N];
+    constexpr ProjTable() : n(0), e{}
+    {
+        for (int mode = 11; mode <= 25; ++mode)
+        {
+            const int angle = angle_of(mode), inv = inv_angle_of(mode);
+            int last = (N * angle) / 32;
+            if (last * 32 > N * angle) --last;   // arithmetic shift: floor
+            if (last >= -1) continue;
+            for (int idx = last; idx <= -1; ++idx)
+            {
+                int q = idx * inv + 128;         // > 0
+                const int k = -1 + q / 256;
+                e[n++] = (uint16_t)((mode - 11) | ((idx + N) << 4) | ((k + 1) << 10));
+            }
+        }
+    }
+};
+template <int N> __constant__ ProjTable<N> c_proj = ProjTable<N>();
 
 // normalised SATD of a TS x TS difference tile held in registers (compute_satd_c_ref<TS>)
 template <int S, int TS>
@@ -148,9 +184,6 @@ struct TileDiff
 
 // a lane evaluates MPI (modes per item: 5, or 1 for the single-tile sizes) consecutive entries of this list for one tile: planar, DC and the vertical family
 // (source tile as stored), then the horizontal family (transposed source tile) -- one orientation switch in the list
-__constant__ int8_t c_modeOrder[35] = {0,  1,  18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33,
-                                       34, 2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 16, 17};
-
 // job: havoc_mi355x_intra_search_job = { src_off, nb_off, nbf_off, filt_lo, filt_hi, edge, reserved[2] }
 template <int S, int LOG2, int P, int THREADS, int MPI>
 __global__ __launch_bounds__(THREADS) void k_intra_satd35(const char *__restrict__ src, long stride_src, const char *__restrict__ neighbours,
@@ -171,11 +204,11 @@ __global__ __launch_bounds__(THREADS) void k_intra_satd35(const char *__restrict
     // (with dense N*N blocks every partition and every 8-row band started on bank 0: 10-way conflicts on 16x16)
     constexpr int NS = N + 2;
     constexpr int SB = N * NS + 6;
-    __shared__ uint16_t s_src[P][SB];        // row-major source block
-    __shared__ uint16_t s_srcT[P][SB];       // transposed source block
-    __shared__ uint16_t s_nb[P][2][NB + 1];  // [0] unfiltered, [1] filtered; index i <-> neighbours[i - 2N - 1]
-    __shared__ uint16_t s_left[P][2][NL];    // the left column read downwards: [i] = p(-1, -1+i) = nb[2N - i]
-    __shared__ uint16_t s_ref[P][15][RL];    // negative-angle modes 11..25; ref[i] at [i + N]
+    __shared__ __attribute__((aligned(16))) uint16_t s_src[P][SB];        // row-major source block
+    __shared__ __attribute__((aligned(16))) uint16_t s_srcT[P][SB];       // transposed source block
+    __shared__ __attribute__((aligned(16))) uint16_t s_nb[P][2][NB + 1];  // [0] unfiltered, [1] filtered; index i <-> neighbours[i - 2N - 1]
+    __shared__ __attribute__((aligned(16))) uint16_t s_left[P][2][NL];    // the left column read downwards: [i] = p(-1, -1+i) = nb[2N - i]
+    __shared__ __attribute__((aligned(16))) uint16_t s_ref[P][15][RL];    // negative-angle modes 11..25; ref[i] at [i + N]
     __shared__ int s_dc[P][2];
     __shared__ int s_cost[P][36];
     __shared__ int s_job[P][8];
@@ -227,26 +260,26 @@ __global__ __launch_bounds__(THREADS) void k_intra_satd35(const char *__restrict
     }
     __syncthreads();
 
-    // ---- phase 1: projected reference arrays of the 15 negative-angle modes (the others read the top row / the left
-    // column as they are), DC values.  Entries last .. N with last = (N * angle) >> 5 >= -N are all a mode can read.
-    for (int i = lane; i < P * 15 * (2 * N + 1); i += THREADS)
+    // ---- phase 1: reference arrays of the 15 negative-angle modes (the others read the top row / the left column as
+    // they are): entries 0 .. N are a dword copy of the top row / left column, the negative ones come from the table
+    constexpr int CD = N / 2 + 1;            // dwords holding entries 0 .. N (+1)
+    for (int i = lane; i < P * 15 * CD; i += THREADS)
     {
-        const int p = i / (15 * (2 * N + 1)), r = i - p * 15 * (2 * N + 1);
-        const int mi = r / (2 * N + 1), idx = r - mi * (2 * N + 1) - N;
+        const int p = i / (15 * CD), r = i - p * 15 * CD;
+        const int mi = r / CD, c = r - mi * CD;
         const int mode = mi + 11;
-        const int angle = c_angle35[mode];
-        const bool vertical = mode >= 18;
-        if (idx < ((N * angle) >> 5)) continue;
-        const uint32_t fbits = (uint32_t)s_job[p][3] >> mode;
-        const uint16_t *nb = s_nb[p][fbits & 1];
-        int v;
-        if (idx >= 0) v = vertical ? nb[2 * N + idx] : nb[2 * N - idx];   // p(-1+idx,-1) / p(-1,-1+idx)
-        else
-        {
-            const int k = -1 + ((idx * (int)c_invAngle35[mode] + 128) >> 8);
-            v = vertical ? nb[2 * N - 1 - k] : nb[2 * N + 1 + k];          // p(-1,k) / p(k,-1)
-        }
-        s_ref[p][mi][idx + N] = (uint16_t)v;
+        const int f = ((uint32_t)s_job[p][3] >> mode) & 1;
+        const uint32_t *from = reinterpret_cast<const uint32_t *>(mode >= 18 ? &s_nb[p][f][2 * N] : &s_left[p][f][0]);
+        reinterpret_cast<uint32_t *>(&s_ref[p][mi][N])[c] = from[c];
+    }
+    for (int i = lane; i < P * c_proj<N>.n; i += THREADS)
+    {
+        const int p = i / c_proj<N>.n, r = i - p * c_proj<N>.n;
+        const int e = c_proj<N>.e[r];
+        const int mi = e & 15, at = (e >> 4) & 63, k = (e >> 10) - 1;
+        const int mode = mi + 11;
+        const uint16_t *nb = s_nb[p][((uint32_t)s_job[p][3] >> mode) & 1];
+        s_ref[p][mi][at] = mode >= 18 ? nb[2 * N - 1 - k] : nb[2 * N + 1 + k];   // p(-1,k) / p(k,-1)
     }
     if (lane < 2 * P)
     {
@@ -270,7 +303,8 @@ __global__ __launch_bounds__(THREADS) void k_intra_satd35(const char *__restrict
 #pragma unroll 1
         for (int m = 0; m < MPI; ++m)
         {
-            const int mode = c_modeOrder[grp * MPI + m];
+            const int o = grp * MPI + m;
+            const int mode = o < 2 ? o : (o < 19 ? o + 16 : o - 17);   // planar, DC, 18..34, 2..17
             const bool vertical = mode >= 18;
             const int orient = (mode >= 2 && !vertical) ? 1 : 0;
             const int maj0 = (orient ? tx : ty) * TS, min0 = (orient ? ty : tx) * TS;
@@ -287,7 +321,7 @@ __global__ __launch_bounds__(THREADS) void k_intra_satd35(const char *__restrict
             TileDiff<S, TS> td;
             if (mode >= 2)
             {
-                const int angle = c_angle35[mode];
+                const int angle = angle_of(mode);
                 // ref[i], i >= 0: p(-1+i,-1) (vertical) or p(-1,-1+i) (horizontal); negative-angle modes add projected entries
                 const uint16_t *ref = angle < 0 ? &s_ref[p][mode - 11][N] : (vertical ? nb + 2 * N : s_left[p][f]);
                 const bool efilt = edge && min0 == 0 && angle == 0;
