@@ -196,6 +196,24 @@ __device__ __forceinline__ int satd_rows_pk(uint32_t (&p)[TS / 2], int r)
     return r == 0 ? t : 0;
 }
 
+// ---- intra prediction angles ----------------------------------------------------------------------------------
+
+// intraPredAngle (havoc/pred_intra.cpp angle table) without a memory look-up: |angle| depends on the distance from the
+// pure horizontal (10) / vertical (26) mode, nine 6-bit entries packed in one constant
+__host__ __device__ constexpr int angle_of(int mode)
+{
+    const int d = mode < 18 ? mode - 10 : mode - 26;
+    const int mag = (int)((0x2069544d245080ull >> (6 * (d < 0 ? -d : d))) & 63);   // 0 2 5 9 13 17 21 26 32
+    return (mode < 18) == (d < 0) ? mag : -mag;
+}
+__host__ __device__ constexpr int inv_angle_of(int mode)   // modes 11..25: -round(8192 / |angle|); eight 13-bit entries
+{
+    const int i = (mode < 18 ? mode - 10 : 26 - mode) - 1;                      // 0..7 -> 4096 1638 910 630 482 390 315 256
+    const unsigned long long lo = 4096ull | (1638ull << 13) | (910ull << 26) | (630ull << 39);
+    const unsigned long long hi = 482ull | (390ull << 13) | (315ull << 26) | (256ull << 39);
+    return -(int)(((i < 4 ? lo : hi) >> (13 * (i & 3))) & 0x1fff);
+}
+
 template <int S> struct Sample;
 template <> struct Sample<1> { typedef uint8_t T; };
 template <> struct Sample<2> { typedef uint16_t T; };

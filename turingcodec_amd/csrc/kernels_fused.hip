@@ -19,21 +19,6 @@
 
 namespace havoc_gpu {
 
-// intraPredAngle (havoc/pred_intra.cpp angle table) without a memory look-up: |angle| depends on the distance from the
-// pure horizontal (10) / vertical (26) mode, nine 6-bit entries packed in one constant
-__host__ __device__ constexpr int angle_of(int mode)
-{
-    const int d = mode < 18 ? mode - 10 : mode - 26;
-    const int mag = (int)((0x2069544d245080ull >> (6 * (d < 0 ? -d : d))) & 63);   // 0 2 5 9 13 17 21 26 32
-    return (mode < 18) == (d < 0) ? mag : -mag;
-}
-__host__ __device__ constexpr int inv_angle_of(int mode)   // modes 11..25: round(8192 / angle), negative
-{
-    const int d = mode < 18 ? mode - 10 : 26 - mode;       // 1..8
-    constexpr int t[9] = {0, 4096, 1638, 910, 630, 482, 390, 315, 256};
-    return -t[d];
-}
-
 // the projected (index < 0) entries of the negative-angle modes' reference arrays (pred_intra.cpp:20330-20345, 20370-20384):
 // entry = { mode - 11, index + N, k + 1 } with ref[index] = p(-1, k) (vertical modes) or p(k, -1) (horizontal modes)
 template <int N>

@@ -9,18 +9,15 @@
 
 namespace havoc_gpu {
 
-__constant__ int8_t c_intraAngle[35] = {0,  0,   32,  26,  21,  17,  13, 9,  5,  2,  0, -2, -5, -9, -13, -17, -21, -26,
-                                        -32, -26, -21, -17, -13, -9, -5, -2, 0,  2,  5, 9,  13, 17,  21,  26,  32};
-__constant__ int16_t c_invAngle[26] = {0,    0,    0,    0,    0,    0,    0,    0,    0,    0,    0,     -4096, -1638,
-                                       -910, -630, -482, -390, -315, -256, -315, -390, -482, -630, -910, -1638, -4096};
-
-template <int S, int LOG2>
+// SPL = samples per lane: more samples per lane = more jobs per wavefront; the kernel is bound by the per-wavefront
+// latency chain (job -> neighbours -> LDS -> reference -> stores), not by arithmetic
+template <int S, int LOG2, int SPL>
 __global__ __launch_bounds__(64) void k_intra(char *__restrict__ dst, long stride_dst, const char *__restrict__ neighbours,
                                               const int32_t *__restrict__ jobs, int njobs, int bitDepth)
 {
     typedef typename Sample<S>::T T;
     constexpr int N = 1 << LOG2;
-    constexpr int LANES = N * N / 4 < 64 ? N * N / 4 : 64;   // lanes per job: each lane produces 4 adjacent samples
+    constexpr int LANES = N * N / SPL < 1 ? 1 : (N * N / SPL < 64 ? N * N / SPL : 64);   // lanes per job
     constexpr int JPW = 64 / LANES;                  // jobs per wavefront
     constexpr int NBLEN = 4 * N + 1;
     // per job: nb[0 .. 4N]: index i <-> neighbours[i - 2N - 1]  (so nb[2N] = corner, nb[2N+1+x] = p(x,-1),
@@ -48,7 +45,7 @@ __global__ __launch_bounds__(64) void k_intra(char *__restrict__ dst, long strid
 
     if (mode >= 2)
     {
-        const int angle = c_intraAngle[mode];
+        const int angle = angle_of(mode);
         const bool vertical = mode >= 18;
         // main reference: ref[i] = p(-1+i, -1) (vertical modes) or p(-1, -1+i) (horizontal modes), i = 0..N
         for (int i = l; i <= 2 * N; i += LANES)
@@ -56,7 +53,7 @@ __global__ __launch_bounds__(64) void k_intra(char *__restrict__ dst, long strid
         if (angle < 0)
         {
             const int last = (N * angle) >> 5;
-            const int inv = c_invAngle[mode];
+            const int inv = inv_angle_of(mode);
             for (int i = -1 - l; i >= last; i -= LANES)
                 if (last < -1)
                 {
@@ -99,7 +96,7 @@ __global__ __launch_bounds__(64) void k_intra(char *__restrict__ dst, long strid
             }
             else
             {
-                const int angle = c_intraAngle[mode];
+                const int angle = angle_of(mode);
                 const bool vertical = mode >= 18;
                 const int major = vertical ? y : x, minor = vertical ? x : y;
                 const int t = (major + 1) * angle;
@@ -128,10 +125,12 @@ static hipError_t launch_intra_s(hipStream_t st, int log2, int bitDepth, void *d
     const int32_t *j = (const int32_t *)jobs;
     switch (log2)
     {
-    case 2: hipLaunchKernelGGL((k_intra<S, 2>), dim3((n + 15) / 16), dim3(64), 0, st, d, sd, p, j, n, bitDepth); break;
-    case 3: hipLaunchKernelGGL((k_intra<S, 3>), dim3((n + 3) / 4), dim3(64), 0, st, d, sd, p, j, n, bitDepth); break;
-    case 4: hipLaunchKernelGGL((k_intra<S, 4>), dim3(n), dim3(64), 0, st, d, sd, p, j, n, bitDepth); break;
-    case 5: hipLaunchKernelGGL((k_intra<S, 5>), dim3(n), dim3(64), 0, st, d, sd, p, j, n, bitDepth); break;
+#define LAUNCH(l2, spl) hipLaunchKernelGGL((k_intra<S, l2, spl>), dim3((n + 64 / ((1 << (2 * l2)) / spl) - 1) / (64 / ((1 << (2 * l2)) / spl))), dim3(64), 0, st, d, sd, p, j, n, bitDepth)
+    case 2: LAUNCH(2, 4); break;     // 16 jobs per wavefront
+    case 3: LAUNCH(3, 8); break;     // 8
+    case 4: LAUNCH(4, 16); break;    // 4
+    case 5: LAUNCH(5, 16); break;    // 1
+#undef LAUNCH
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
