@@ -404,7 +404,7 @@ def cpu_worker(args):
         while True:
             run_all(pool, True)
             reps += 1
-            if time.perf_counter() - t0 > 2.0 or reps >= 50:
+            if time.perf_counter() - t0 > 2.0 or reps >= 5000:
                 break
         dt_s = (time.perf_counter() - t0) / reps
     print(json.dumps({"seconds_per_sample": dt_s, "stride": stride, "cores": cores, "handle": handle,
@@ -429,8 +429,9 @@ def cpu_baseline(args):
                         "ms_per_frame_by_group": {g: round(v * r["stride"] * 1e3, 3) for g, v in r["group_seconds_per_sample"].items()},
                         "sample": f"every {stride}th job of each primitive's job table ({r['jobs']} calls) through the "
                                   f"reference's own havoc {'x86-JIT' if handle else 'C'} function tables (oracle/_ref), "
-                                  f"{r['cores']} host threads, the sample repeated {r['reps']}x (~2 s wall, "
-                                  f"~{2 * r['cores']} core-seconds), extrapolated x{stride}"}
+                                  f"{r['cores']} host threads, the sample repeated {r['reps']}x "
+                                  f"({r['reps'] * r['seconds_per_sample']:.1f} s wall, "
+                                  f"{r['reps'] * r['seconds_per_sample'] * r['cores']:.0f} core-seconds), extrapolated x{stride}"}
         except Exception:
             pass
     return None
