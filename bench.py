@@ -43,6 +43,9 @@ def parse_args():
     ap.add_argument("--ime", choices=["sad4", "surface"], default="sad4",
                     help="integer ME as per-pattern SAD4 jobs (the reference's call mix) or as one SAD surface per search")
     ap.add_argument("--ime-range", type=int, default=16, help="surface half-width R: (2R+1)^2 candidates per search")
+    ap.add_argument("--tune", type=int, default=16, help="lane assignments tried by the set-up planner (0: round-robin)")
+    ap.add_argument("--skip", default="", help="diagnostic: comma-separated launch groups to leave out (the result is then "
+                                               "NOT the metric; the JSON line says so)")
     ap.add_argument("--exchange", action="store_true",
                     help="run the reference-picture exchange (process group + RCCL broadcasts) even with one rank")
     ap.add_argument("--lanes", type=int, default=8, help="fork/join lanes: independent launch chains overlap on the GPU")
@@ -60,8 +63,9 @@ def parse_args():
 class DeviceFrame:
     """A FrameWorkload uploaded to HBM + the list of launches that make one step."""
 
-    def __init__(self, hv, wl, use_planes=True, fused_tu=True, ime_range=None):
+    def __init__(self, hv, wl, use_planes=True, fused_tu=True, ime_range=None, skip=()):
         import torch
+        self.skip = set(skip)   # diagnostic only: launch groups left out of the step (marginal-cost measurements)
         self.hv, self.wl, self.use_planes, self.fused_tu, self.ime_range = hv, wl, use_planes, fused_tu, ime_range
         up = hv.up
         dt = wl.dtype
@@ -146,8 +150,10 @@ class DeviceFrame:
         chains = []   # lists of indices into L: launches of one chain depend on each other, chains are independent
 
         def chain(*items):
-            chains.append(list(range(len(L), len(L) + len(items))))
-            L.extend(items)
+            items = [it for it in items if it[0] not in self.skip]
+            if items:
+                chains.append(list(range(len(L), len(L) + len(items))))
+                L.extend(items)
 
         if self.ime_range is None:
             chain(("sad4", lambda: hv.sad4_d(self.luma, st, self.luma, st, self.j_sad4, self.o_sad4)))
@@ -207,18 +213,73 @@ class DeviceFrame:
         return L
 
     def step(self, nlanes=1):
-        """issue one frame's launches; with nlanes > 1 the independent chains go round-robin onto fork/join lanes"""
+        """issue one frame's launches; with nlanes > 1 the independent chains go onto fork/join lanes: round-robin, or as
+        `self.assign` (list of chain-index lists, one per lane; see plan_lanes) says"""
         if nlanes <= 1:
             for _, fn in self.launches:
                 fn()
             return
         hv = self.hv
+        assign = getattr(self, "assign", None) or [list(range(k, len(self.chains), nlanes)) for k in range(nlanes)]
         hv.fork(nlanes)
-        for ci, ch in enumerate(self.chains):
-            hv.lane(ci % nlanes)
-            for idx in ch:
-                self.launches[idx][1]()
+        for k, lane in enumerate(assign):
+            hv.lane(k)
+            for ci in lane:
+                for idx in self.chains[ci]:
+                    self.launches[idx][1]()
         hv.join()
+
+    def chain_times_ms(self):
+        """isolated duration of every chain (sum of its launches), for the lane planner"""
+        hv, out = self.hv, []
+        for ch in self.chains:
+            run = lambda: [self.launches[i][1]() for i in ch]
+            run()
+            hv.timer_start()
+            for _ in range(3):
+                run()
+            out.append(hv.timer_stop_ms() / 3)
+        return out
+
+    def plan_lanes(self, nlanes, ntry, seed=1):
+        """Host-side scheduling of the step: which independent chain goes to which lane, in which order.  Candidates:
+        round-robin, longest-chain-first onto the least loaded lane (LPT), and seeded perturbations of LPT; each is
+        captured into a HIP graph and timed, the fastest is kept (returns the graph).  Set-up work, outside any timed
+        region -- like planning an FFT."""
+        import random
+        hv = self.hv
+        cost = self.chain_times_ms()
+        rnd = random.Random(seed)
+
+        def lpt(noise):
+            order = sorted(range(len(cost)), key=lambda c: -cost[c] * (1.0 + noise * rnd.uniform(-1, 1)))
+            lanes, load = [[] for _ in range(nlanes)], [0.0] * nlanes
+            for c in order:
+                k = load.index(min(load))
+                lanes[k].append(c)
+                load[k] += cost[c]
+            return lanes
+
+        cands = [None, lpt(0.0)] + [lpt(0.5) for _ in range(max(0, ntry - 2))]
+        best = (None, None, 1e30)
+        for cand in cands[:max(1, ntry)]:
+            self.assign = cand
+            g = hv.graph_capture(lambda: self.step(nlanes))
+            for _ in range(2):
+                hv.graph_launch(g)
+            hv.sync()
+            hv.timer_start()
+            for _ in range(8):
+                hv.graph_launch(g)
+            ms = hv.timer_stop_ms() / 8
+            if ms < best[2]:
+                if best[1] is not None:
+                    hv.graph_destroy(best[1])
+                best = (cand, g, ms)
+            else:
+                hv.graph_destroy(g)
+        self.assign = best[0]
+        return best[1], best[2]
 
     def kernel_times_ms(self, reps):
         """average duration per launch group, HIP events on the context's stream"""
@@ -497,7 +558,7 @@ def main():
     w, h = (int(v) for v in args.res.split("x"))
     wl = FrameWorkload(w, h, args.bit_depth, args.seed + rank)   # every rank owns a different picture
     dev = DeviceFrame(hv, wl, use_planes=(args.subpel == "planes"), fused_tu=(args.tu == "fused"),
-                      ime_range=args.ime_range if args.ime == "surface" else None)
+                      ime_range=args.ime_range if args.ime == "surface" else None, skip=[k for k in args.skip.split(",") if k])
     exch = None
     if grouped:
         from turingcodec_amd.frame_parallel import ReferenceExchange
@@ -507,7 +568,12 @@ def main():
 
     dev.step()          # first eager pass (loads the code objects) -- also what the graph must reproduce
     hv.sync()
-    graph = None if args.no_graph else hv.graph_capture(lambda: dev.step(args.lanes))
+    if args.no_graph:
+        graph = None
+    elif args.lanes > 1 and args.tune > 0:
+        graph, _ = dev.plan_lanes(args.lanes, args.tune)     # lane assignment chosen by measurement (set-up, untimed)
+    else:
+        graph = hv.graph_capture(lambda: dev.step(args.lanes))
 
     def one_step(i):
         if graph is not None:
@@ -584,6 +650,8 @@ def main():
                            "kernel_gbs": {k: round(kbytes[k] / (v * 1e-3) / 1e9, 1) for k, v in ktimes.items()}},
             "checksum": dev.checksum(),
         }
+        if args.skip:
+            out["metric"] = "DIAGNOSTIC (launch groups skipped: " + args.skip + ") -- not the benchmark metric"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out))
