@@ -96,7 +96,7 @@ class DeviceFrame:
             self.planes = z(32 * pl, dt)                       # [ref L0 | ref L1] x 16 phase planes
             self.planes[0:pl].copy_(self.luma[pl:2 * pl])      # slot 0 of each reference = the picture itself
             self.planes[16 * pl:17 * pl].copy_(self.luma[2 * pl:3 * pl])
-            self.subpel_planes = {c: dict(jobs=up(j), cost=z(len(j), np.int32)) for c, j in wl.subpel_planes.items() if len(j)}
+            self.subpel_planes = {c: dict(jobs=up(j), cost=z(16 * len(j), np.int32)) for c, j in wl.subpel_planes.items() if len(j)}
         self.intra = {}
         for log2, j in wl.intra.items():
             if len(j):
@@ -162,13 +162,13 @@ class DeviceFrame:
         chain(("sad", lambda: hv.sad_d(self.luma, st, self.luma, st, self.j_sad, self.o_sad)))
         if self.use_planes:
             # sub-pel candidates against phase planes: interpolate each reference picture once (streaming, HBM-bound),
-            # then every candidate is one SATD job between the source PU and a block of the right plane
+            # then every group of 16 candidates is one SATD job between the source PU and 16 blocks of the right planes
             pl, m = wl.plane_len, wl.plane_margin
             x0, y0, rw, rh = 96 - m, 96 - m, wl.width + 2 * m, wl.height + 2 * m
             items = [("interp_planes", lambda r=r: hv.interp_planes_d(bd, self.planes[16 * r * pl:], pl, self.luma[(1 + r) * pl:], st, x0, y0, rw, rh))
                      for r in (0, 1)]
             for (mw, mh), g in sorted(self.subpel_planes.items(), reverse=True):
-                items.append(("satd_planes", lambda g=g, mw=mw, mh=mh: hv.satd_d(self.luma, st, self.planes, st, g["jobs"], g["cost"], mw, mh)))
+                items.append(("satd_planes", lambda g=g, mw=mw, mh=mh: hv.satd_multi_d(self.luma, st, self.planes, st, g["jobs"], g["cost"], mw, mh)))
             chain(*items)
         else:
             for hi, g in sorted(self.subpel.items(), reverse=True):

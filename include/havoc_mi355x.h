@@ -105,6 +105,14 @@ typedef struct {
     int32_t reserved[3];
 } havoc_mi355x_surface_job; /* 32 bytes */
 
+/* one block against up to 16 candidate blocks (the 8 half- + 8 quarter-sample candidates of a PU and list) */
+typedef struct {
+    int32_t a_off;
+    int32_t w, h;
+    int32_t count;       /* 1..16 candidates used */
+    int32_t b_off[16];
+} havoc_mi355x_satd_multi_job; /* 80 bytes */
+
 /* fractional-sample interpolation of one prediction block (havoc/pred_inter.h:35) */
 typedef struct {
     int32_t dst_off;
@@ -188,6 +196,11 @@ int havoc_mi355x_ssd(havoc_mi355x_ctx *ctx, int S, const void *d_a, intptr_t str
  * block sizes of this batch (64, 64 always valid): they choose how many lanes share a job. */
 int havoc_mi355x_satd(havoc_mi355x_ctx *ctx, int S, int max_w, int max_h, const void *d_a, intptr_t stride_a, const void *d_b,
                       intptr_t stride_b, const havoc_mi355x_pair_job *d_jobs, int njobs, int32_t *d_out);
+/* The same measure for one block `a` against `count` candidate blocks `b` (costDistortionMv's candidates of one PU,
+ * turing/Search.hpp:1965-1998): d_out[16*i + k], k < count, each equal to what havoc_mi355x_satd returns for that pair. */
+int havoc_mi355x_satd_multi(havoc_mi355x_ctx *ctx, int S, int max_w, int max_h, const void *d_a, intptr_t stride_a,
+                            const void *d_b, intptr_t stride_b, const havoc_mi355x_satd_multi_job *d_jobs, int njobs,
+                            int32_t *d_out);
 /* havoc_ssd_linear (havoc/diff.h:35, havoc/diff.cpp:29-39): one linear 8-bit run, *d_out = int32 sum */
 int havoc_mi355x_ssd_linear(havoc_mi355x_ctx *ctx, const uint8_t *d_a, const uint8_t *d_b, int size, int32_t *d_out);
 

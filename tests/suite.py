@@ -38,6 +38,14 @@ def make_inputs(seed=20260927):
         d[f"{k}.surface.jobs"] = _pairs(rng, cases.PU_SIZES + [(4, 4), (20, 8)], 1)
         # SATD: single 2/4/8 Hadamards plus PU-sized jobs tiled as measureSatd does (incl. chroma sizes -> 4x4, 2x2)
         d[f"{k}.satd.jobs"] = _pairs(rng, [(2, 2), (4, 4), (8, 8)] + cases.PU_SIZES + [(6, 8), (2, 4), (12, 8)], 2)
+        # one block against 1..16 candidate blocks (the sub-pel stage's candidates of one PU)
+        mj = []
+        for i, (w, h) in enumerate([(2, 2), (4, 4), (8, 8)] + cases.PU_SIZES + [(6, 8), (2, 4)]):
+            cnt = 16 if i % 3 else 1 + (5 * i) % 16
+            ao = cases.off(*cases.rand_pos(rng, w, h))
+            bo = [cases.off(*cases.rand_pos(rng, w, h)) for _ in range(cnt)] + [0] * (16 - cnt)
+            mj.append([ao, w, h, cnt] + bo)
+        d[f"{k}.satdm.jobs"] = np.array(mj, np.int32)
         uni = cases.pred_uni_cases(rng, [bd])
         for taps in (8, 4):
             d[f"{k}.pred_uni{taps}.jobs"] = np.array(
@@ -197,6 +205,7 @@ def run(impl, d, keys=None):
                 out[f"{k}.ssd{nm}"] = impl.ssd(p, W, q, W, d[f"{k}.ssd.jobs"])
             if want(f"{k}.satd"):
                 out[f"{k}.satd{nm}"] = impl.satd(p, W, q, W, d[f"{k}.satd.jobs"])
+                out[f"{k}.satdm{nm}"] = impl.satd_multi(p, W, q, W, d[f"{k}.satdm.jobs"])
         for taps in (8, 4):
             if want(f"{k}.pred_uni"):
                 j = d[f"{k}.pred_uni{taps}.jobs"]
@@ -290,6 +299,14 @@ class LoopImpl:
 
     def ssd(self, a, sa, b, sb, jobs):
         return np.array([self.f.ssd(a, int(j[0]), sa, b, int(j[1]), sb, int(j[2]), int(j[3])) for j in jobs], np.uint32)
+
+    def satd_multi(self, a, sa, b, sb, jobs):
+        """by definition the PU SATD of every (a, b_k) pair"""
+        out = np.zeros((len(jobs), 16), np.int32)
+        for i, j in enumerate(jobs):
+            pairs = np.array([(j[0], j[4 + k], j[1], j[2]) for k in range(int(j[3]))], np.int32)
+            out[i, :int(j[3])] = self.satd(a, sa, b, sb, pairs)
+        return out
 
     def satd(self, a, sa, b, sb, jobs):
         res = []

@@ -10,6 +10,7 @@ hipError_t launch_sad(hipStream_t, int S, int ways, const void *, long, const vo
 hipError_t launch_sad_surface(hipStream_t, int S, int range, int maxw, int maxh, const void *, long, const void *, long, const void *, int, int32_t *);
 hipError_t launch_ssd(hipStream_t, int S, const void *, long, const void *, long, const void *, int, uint32_t *);
 hipError_t launch_satd(hipStream_t, int S, int maxw, int maxh, const void *, long, const void *, long, const void *, int, int32_t *);
+hipError_t launch_satd_multi(hipStream_t, int S, int maxw, int maxh, const void *, long, const void *, long, const void *, int, int32_t *);
 hipError_t launch_ssd_linear(hipStream_t, const uint8_t *, const uint8_t *, int, int32_t *);
 hipError_t launch_pred_uni(hipStream_t, int S, int taps, int bd, int maxw, int maxh, void *, long, const void *, long, const void *, int);
 hipError_t launch_pred_bi(hipStream_t, int S, int taps, int bd, int maxw, int maxh, void *, long, const void *, long, const void *, int);
@@ -36,6 +37,7 @@ using namespace havoc_gpu;
 static_assert(sizeof(havoc_mi355x_pair_job) == 16, "job ABI");
 static_assert(sizeof(havoc_mi355x_sad4_job) == 32, "job ABI");
 static_assert(sizeof(havoc_mi355x_surface_job) == 32, "job ABI");
+static_assert(sizeof(havoc_mi355x_satd_multi_job) == 80, "job ABI");
 static_assert(sizeof(havoc_mi355x_pred_uni_job) == 32, "job ABI");
 static_assert(sizeof(havoc_mi355x_pred_bi_job) == 48, "job ABI");
 static_assert(sizeof(havoc_mi355x_subtract_bi_job) == 32, "job ABI");
@@ -346,6 +348,14 @@ int havoc_mi355x_satd(havoc_mi355x_ctx *ctx, int S, int max_w, int max_h, const 
     REQUIRE_CTX(); REQUIRE_S(); REQUIRE(njobs >= 0, "njobs < 0");
     REQUIRE(max_w >= 2 && max_w <= 64 && max_h >= 2 && max_h <= 64, "max_w / max_h must be 2..64");
     return check(launch_satd(LS(ctx),S, max_w, max_h, d_a, stride_a, d_b, stride_b, d_jobs, njobs, d_out), "satd");
+}
+
+int havoc_mi355x_satd_multi(havoc_mi355x_ctx *ctx, int S, int max_w, int max_h, const void *d_a, intptr_t stride_a, const void *d_b,
+                            intptr_t stride_b, const havoc_mi355x_satd_multi_job *d_jobs, int njobs, int32_t *d_out)
+{
+    REQUIRE_CTX(); REQUIRE_S(); REQUIRE(njobs >= 0, "njobs < 0");
+    REQUIRE(max_w >= 2 && max_w <= 64 && max_h >= 2 && max_h <= 64, "max_w / max_h must be 2..64");
+    return check(launch_satd_multi(LS(ctx), S, max_w, max_h, d_a, stride_a, d_b, stride_b, d_jobs, njobs, d_out), "satd_multi");
 }
 
 int havoc_mi355x_ssd_linear(havoc_mi355x_ctx *ctx, const uint8_t *d_a, const uint8_t *d_b, int size, int32_t *d_out)

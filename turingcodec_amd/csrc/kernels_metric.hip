@@ -326,6 +326,137 @@ __global__ __launch_bounds__(256) void k_satd(const char *__restrict__ pa, long 
     if (live && l == 0) out[job] = t;
 }
 
+// One block `a` against up to 16 candidate blocks `b` (the sub-pel stage evaluates 8 half- and 8 quarter-sample
+// candidates per PU and list, turing/Search.hpp:1965-1998): the rows of `a` are fetched and unpacked once and stay in
+// registers while the candidates stream through -- half the row fetches of 16 separate jobs.
+// job: havoc_mi355x_satd_multi_job { a_off, w, h, count, b_off[16] }
+constexpr int kSatdMulti = 16;
+
+// CPS = candidates per lane group: a job's 16 candidates are split over 16 / CPS lane groups (more wavefronts in
+// flight; the source rows are then fetched 16 / CPS times instead of once)
+template <int S, int G, int CPS>
+__global__ __launch_bounds__(256) void k_satd_multi(const char *__restrict__ pa, long stride_a, const char *__restrict__ pb, long stride_b,
+                                                    const int32_t *__restrict__ jobs, int njobs, int32_t *__restrict__ out)
+{
+    typedef typename Sample<S>::T T;
+    constexpr int SL = kSatdMulti / CPS;             // slices per job
+    const int grp = (blockIdx.x * 256 + threadIdx.x) / G;
+    const int job = grp / SL, k0 = (grp - job * SL) * CPS;
+    const int l = threadIdx.x & (G - 1);
+    const bool live = job < njobs;
+    const int32_t *j = jobs + (long)(live ? job : 0) * (4 + kSatdMulti);
+    const int w = j[1], cnt = j[3], h = (live && k0 < cnt) ? j[2] : 0;
+    const long sab = stride_a * S, sbb = stride_b * S;
+    const char *a = pa + (long)j[0] * S;
+    const char *b[CPS];
+#pragma unroll
+    for (int k = 0; k < CPS; ++k) b[k] = pb + (long)j[4 + min(k0 + k, cnt - 1)] * S;   // slots beyond count repeat the last one
+    int acc[CPS];
+#pragma unroll
+    for (int k = 0; k < CPS; ++k) acc[k] = 0;
+    if (((w | h) & 7) == 0)
+    {
+        const int tw = w >> 3;
+        const FastDiv fd(tw);
+        for (int it = l; it < tw * (h >> 3) * 8; it += G)
+        {
+            const int tile = it >> 3, r = it & 7;
+            const int ty = fd.div(tile), tx = tile - ty * tw;
+            const char *pa8 = a + (long)(ty * 8 + r) * sab + tx * 8 * S;
+            const long ob = (long)(ty * 8 + r) * sbb + tx * 8 * S;
+            if (S == 1)
+            {
+                const u32x2 va = ld8(pa8);
+                u32x2 vb[CPS];
+#pragma unroll
+                for (int k = 0; k < CPS; ++k) vb[k] = ld8(b[k] + ob);
+                const uint32_t m = 0x00ff00ffu;
+                const uint32_t ap[4] = {va.x & m, (va.x >> 8) & m, va.y & m, (va.y >> 8) & m};
+#pragma unroll
+                for (int k = 0; k < CPS; ++k)
+                {
+                    uint32_t p[4] = {pk_sub(ap[0], vb[k].x & m), pk_sub(ap[1], (vb[k].x >> 8) & m), pk_sub(ap[2], vb[k].y & m),
+                                     pk_sub(ap[3], (vb[k].y >> 8) & m)};
+                    acc[k] += satd_rows_pk<8>(p, r);
+                }
+            }
+            else
+            {
+                const u32x4 va = ld16(pa8);
+                const uint32_t wa[4] = {va.x, va.y, va.z, va.w};
+#pragma unroll
+                for (int k = 0; k < CPS; ++k)
+                {
+                    const u32x4 vb = ld16(b[k] + ob);
+                    const uint32_t wb[4] = {vb.x, vb.y, vb.z, vb.w};
+                    int d[8];
+#pragma unroll
+                    for (int x = 0; x < 4; ++x)
+                    {
+                        d[2 * x] = (int)(wa[x] & 0xffff) - (int)(wb[x] & 0xffff);
+                        d[2 * x + 1] = (int)(wa[x] >> 16) - (int)(wb[x] >> 16);
+                    }
+                    acc[k] += satd_rows<S, 8>(d, r);
+                }
+            }
+        }
+    }
+    else if (((w | h) & 3) == 0)
+    {
+        const int tw = w >> 2;
+        const FastDiv fd(tw);
+        for (int it = l; it < tw * (h >> 2) * 4; it += G)
+        {
+            const int tile = it >> 2, r = it & 3;
+            const int ty = fd.div(tile), tx = tile - ty * tw;
+            const char *pa4 = a + (long)(ty * 4 + r) * sab + tx * 4 * S;
+            const long ob = (long)(ty * 4 + r) * sbb + tx * 4 * S;
+#pragma unroll
+            for (int k = 0; k < CPS; ++k)
+            {
+                if (S == 1)
+                {
+                    const uint32_t va = ld4(pa4), vb = ld4(b[k] + ob), m = 0x00ff00ffu;
+                    uint32_t p[2] = {pk_sub(va & m, vb & m), pk_sub((va >> 8) & m, (vb >> 8) & m)};
+                    acc[k] += satd_rows_pk<4>(p, r);
+                }
+                else
+                {
+                    int d[4];
+                    load_diff_row<S, 4>(pa4, b[k] + ob, d);
+                    acc[k] += satd_rows<S, 4>(d, r);
+                }
+            }
+        }
+    }
+    else
+    {   // 2x2 tiles: one tile per lane, no normalisation
+        const int tw = w >> 1;
+        const FastDiv fd(tw);
+        for (int t = l; t < tw * (h >> 1); t += G)
+        {
+            const int ty = fd.div(t), tx = t - ty * tw;
+            const T *p = reinterpret_cast<const T *>(a + (long)(2 * ty) * sab) + 2 * tx;
+#pragma unroll
+            for (int k = 0; k < CPS; ++k)
+            {
+                const T *q = reinterpret_cast<const T *>(b[k] + (long)(2 * ty) * sbb) + 2 * tx;
+                const int d0 = (int)p[0] - (int)q[0], d1 = (int)p[1] - (int)q[1];
+                const int d2 = (int)p[stride_a] - (int)q[stride_b], d3 = (int)p[stride_a + 1] - (int)q[stride_b + 1];
+                int sum = abs(d0 + d1 + d2 + d3) + abs(d0 - d1 + d2 - d3) + abs(d0 + d1 - d2 - d3) + abs(d0 - d1 - d2 + d3);
+                if (S == 2) sum >>= 2;
+                acc[k] += sum;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < CPS; ++k)
+    {
+        const int t = G == 64 ? wave_sum(acc[k]) : group_sum<G>(acc[k]);
+        if (h != 0 && l == 0 && k0 + k < cnt) out[(long)job * kSatdMulti + k0 + k] = t;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // linear SSD over an 8-bit run (reference: havoc/diff.cpp:29-39) -- PSNR tool only; grid-stride + one atomic
 // per wave.  *out must be zeroed by the caller (the host entry point does it).
@@ -386,6 +517,26 @@ hipError_t launch_satd(hipStream_t st, int S, int maxw, int maxh, const void *a,
     const int G = rows <= 8 ? 8 : rows <= 16 ? 16 : rows <= 32 ? 32 : 64;
     const dim3 g((n + 256 / G - 1) / (256 / G)), b256(256);
 #define SATD_GO(SS, GG) hipLaunchKernelGGL((k_satd<SS, GG>), g, b256, 0, st, x, sa, y, sb, j, n, out)
+    if (S == 1) { if (G == 8) SATD_GO(1, 8); else if (G == 16) SATD_GO(1, 16); else if (G == 32) SATD_GO(1, 32); else SATD_GO(1, 64); }
+    else { if (G == 8) SATD_GO(2, 8); else if (G == 16) SATD_GO(2, 16); else if (G == 32) SATD_GO(2, 32); else SATD_GO(2, 64); }
+#undef SATD_GO
+    return hipGetLastError();
+}
+
+hipError_t launch_satd_multi(hipStream_t st, int S, int maxw, int maxh, const void *a, long sa, const void *b, long sb, const void *jobs, int n,
+                             int32_t *out)
+{
+    if (n <= 0) return hipSuccess;
+    const char *x = (const char *)a, *y = (const char *)b;
+    const int32_t *j = (const int32_t *)jobs;
+    const int rows = ((maxw + 7) / 8) * maxh;
+    const int G = rows <= 8 ? 8 : rows <= 16 ? 16 : rows <= 32 ? 32 : 64;
+    // measured on MI355X (184 k candidates of a 1080p frame): 2 candidates per lane group 63 us, 1: 69, 4: 70, 8: 83,
+    // all 16: 181 -- wavefronts in flight matter more than fetching the source rows only once
+    constexpr int CPS = 2;
+    const long groups = (long)n * (kSatdMulti / CPS);
+    const dim3 g((unsigned)((groups + 256 / G - 1) / (256 / G))), b256(256);
+#define SATD_GO(SS, GG) hipLaunchKernelGGL((k_satd_multi<SS, GG, CPS>), g, b256, 0, st, x, sa, y, sb, j, n, out)
     if (S == 1) { if (G == 8) SATD_GO(1, 8); else if (G == 16) SATD_GO(1, 16); else if (G == 32) SATD_GO(1, 32); else SATD_GO(1, 64); }
     else { if (G == 8) SATD_GO(2, 8); else if (G == 16) SATD_GO(2, 16); else if (G == 32) SATD_GO(2, 32); else SATD_GO(2, 64); }
 #undef SATD_GO

@@ -59,6 +59,7 @@ def _load():
         "sad_surface": [_vp, _i, _i, _i, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
         "ssd": [_vp, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
         "satd": [_vp, _i, _i, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
+        "satd_multi": [_vp, _i, _i, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
         "ssd_linear": [_vp, _vp, _vp, _i, _vp],
         "pred_uni": [_vp, _i, _i, _i, _i, _i, _vp, _ip, _vp, _ip, _vp, _i],
         "pred_bi": [_vp, _i, _i, _i, _i, _i, _vp, _ip, _vp, _ip, _vp, _i],
@@ -214,6 +215,9 @@ class Havoc:
     def satd_d(self, a, sa, b, sb, jobs, out, max_w=64, max_h=64):
         self._ck(self.L.havoc_mi355x_satd(self.h, self._S(a), max_w, max_h, _ptr(a), sa, _ptr(b), sb, _ptr(jobs), jobs.shape[0], _ptr(out)))
 
+    def satd_multi_d(self, a, sa, b, sb, jobs, out, max_w=64, max_h=64):
+        self._ck(self.L.havoc_mi355x_satd_multi(self.h, self._S(a), max_w, max_h, _ptr(a), sa, _ptr(b), sb, _ptr(jobs), jobs.shape[0], _ptr(out)))
+
     def pred_uni_d(self, taps, bd, dst, sd, ref, sr, jobs, max_w=64, max_h=64):
         self._ck(self.L.havoc_mi355x_pred_uni(self.h, self._S(ref), taps, bd, max_w, max_h, _ptr(dst), sd, _ptr(ref), sr, _ptr(jobs), jobs.shape[0]))
 
@@ -353,6 +357,21 @@ class Havoc:
         out = self.zeros(len(jobs), np.uint32)
         self.ssd_d(self.up(a), sa, self.up(b), sb, self._jobs(jobs, 4), out)
         return self.down(out, np.uint32)
+
+    def satd_multi(self, a, sa, b, sb, jobs):
+        """jobs rows: a_off, w, h, count, b_off[16]; returns [njobs, 16] (entries k >= count are 0); one launch per
+        lane-group class like satd"""
+        jobs = np.asarray(jobs, np.int32)
+        out = np.zeros((len(jobs), 16), np.int32)
+        ad, bdv = self.up(a), self.up(b)
+        rows = ((jobs[:, 1] + 7) // 8) * jobs[:, 2]
+        for lo, hi, mw, mh in ((0, 8, 8, 8), (8, 16, 16, 8), (16, 32, 16, 16), (32, 1 << 30, 64, 64)):
+            idx = np.flatnonzero((rows > lo) & (rows <= hi))
+            if len(idx):
+                o = self.zeros(16 * len(idx), np.int32)
+                self.satd_multi_d(ad, sa, bdv, sb, self._jobs(jobs[idx], 20), o, mw, mh)
+                out[idx] = self.down(o, np.int32).reshape(-1, 16)
+        return out
 
     def satd(self, a, sa, b, sb, jobs):
         """one launch per lane-group class so that every group size (8 / 16 / 32 / 64 lanes per job) is exercised"""

@@ -172,21 +172,38 @@ class FrameWorkload:
         sp = u[:nsearch].copy()
         sp[:, 0] = sp[:, 6]          # dst_off field = source PU offset (havoc_mi355x_subpel_satd)
         sp[:, 6] = 0
+        # the candidates come in groups of 16 per PU and list (8 half-sample positions, then 8 quarter-sample ones,
+        # turing/Search.hpp:1965-1998): same block, same source, integer positions within one sample of each other.
+        # Every row keeps its own phase, so the per-kind counts above stay the measured ones.
+        ng = nsearch // 16
+        g = sp[:ng * 16].reshape(ng, 16, 8)
+        g[:, :, [0, 2, 3]] = g[:, :1, [0, 2, 3]]
+        g[:, :, 1] = g[:, :1, 1] + rng.integers(-1, 1, (ng, 16)) * st + rng.integers(-1, 1, (ng, 16))
+        sp[:ng * 16] = g.reshape(-1, 8)
         big = np.maximum(sp[:, 2], sp[:, 3])
         self.subpel = {hi: np.ascontiguousarray(sp[(big > lo) & (big <= hi)]) for lo, hi in ((0, 8), (8, 16), (16, 32), (32, 64))}
         self.subpel_idx = {hi: np.flatnonzero((big > lo) & (big <= hi)) for lo, hi in ((0, 8), (8, 16), (16, 32), (32, 64))}
         # the same candidates against the fractional-phase planes (havoc_mi355x_interp_planes): plane buffer = for each
         # reference r in {L0, L1}: 16 planes of plane_len samples, plane 4*yFrac+xFrac (slot 0 = the picture itself).
-        # One SATD job per candidate, bucketed by the lane-group class of havoc_mi355x_satd (rows of 8 samples).
+        # One havoc_mi355x_satd_multi job per group (source block + its 16 plane blocks), bucketed by the lane-group
+        # class of the SATD kernels (rows of 8 samples); the nsearch % 16 left-over candidates are jobs of one.
         refi = sp[:, 1] // pl - 1
         pos = sp[:, 1] % pl
-        pj = np.stack([sp[:, 0], ((refi * 16 + 4 * sp[:, 5] + sp[:, 4]).astype(np.int64) * pl + pos).astype(np.int32), sp[:, 2], sp[:, 3]],
-                      1).astype(np.int32)
-        rows = ((pj[:, 2] + 7) // 8) * pj[:, 3]
-        self.subpel_planes = {(mw, mh): np.ascontiguousarray(pj[(rows > lo) & (rows <= hi)])
-                              for lo, hi, mw, mh in ((0, 8, 8, 8), (8, 16, 16, 8), (16, 32, 16, 16), (32, 1 << 30, 64, 64))}
-        self.subpel_planes_idx = {(mw, mh): np.flatnonzero((rows > lo) & (rows <= hi))
-                                  for lo, hi, mw, mh in ((0, 8, 8, 8), (8, 16, 16, 8), (16, 32, 16, 16), (32, 1 << 30, 64, 64))}
+        boff = ((refi * 16 + 4 * sp[:, 5] + sp[:, 4]).astype(np.int64) * pl + pos).astype(np.int32)
+        rem = nsearch - ng * 16
+        mj = np.zeros((ng + rem, 20), np.int32)
+        cand = np.full((ng + rem, 16), -1, np.int64)
+        first = np.arange(ng) * 16
+        mj[:ng, 0], mj[:ng, 1], mj[:ng, 2], mj[:ng, 3] = sp[first, 0], sp[first, 2], sp[first, 3], 16
+        mj[:ng, 4:] = boff[:ng * 16].reshape(ng, 16)
+        cand[:ng] = np.arange(ng * 16).reshape(ng, 16)
+        tail = np.arange(ng * 16, nsearch)
+        mj[ng:, 0], mj[ng:, 1], mj[ng:, 2], mj[ng:, 3], mj[ng:, 4] = sp[tail, 0], sp[tail, 2], sp[tail, 3], 1, boff[tail]
+        cand[ng:, 0] = tail
+        rows = ((mj[:, 1] + 7) // 8) * mj[:, 2]
+        classes = ((0, 8, 8, 8), (8, 16, 16, 8), (16, 32, 16, 16), (32, 1 << 30, 64, 64))
+        self.subpel_planes = {(mw, mh): np.ascontiguousarray(mj[(rows > lo) & (rows <= hi)]) for lo, hi, mw, mh in classes}
+        self.subpel_planes_idx = {(mw, mh): cand[(rows > lo) & (rows <= hi)] for lo, hi, mw, mh in classes}
         self.plane_margin = 72     # planes are computed over the picture plus the motion range (64) plus a block edge (8)
         u = u[nsearch:]
         slot = np.concatenate([[0], np.cumsum(64 * u[:-1, 3].astype(np.int64))])
@@ -356,7 +373,8 @@ class FrameWorkload:
         # phase planes: per reference picture the rectangle is read once and 15 planes are written; then one SATD per candidate
         area = (self.width + 2 * self.plane_margin) * (self.height + 2 * self.plane_margin)
         b["interp_planes"] = 2 * 16 * area * S
-        b["satd_planes"] = sum(int((2 * wh(j, 2, 3) * S + 4).sum()) for j in self.subpel_planes.values())
+        # per group: the source block once, `count` plane blocks, `count` costs
+        b["satd_planes"] = sum(int(((1 + j[:, 3].astype(np.int64)) * wh(j, 1, 2) * S + 4 * j[:, 3]).sum()) for j in self.subpel_planes.values())
         b["pred_uni4"] = uni(self.uni4, 4)
         for nm, j, t in (("pred_bi8", self.bi8, 8), ("pred_bi4", self.bi4, 4)):
             w, h = j[:, 3].astype(np.int64), j[:, 4].astype(np.int64)
