@@ -136,11 +136,19 @@ class FrameWorkload:
         def mv(nj, r=64):
             return rng.integers(-r, r + 1, nj).astype(np.int32), rng.integers(-r, r + 1, nj).astype(np.int32)
 
-        # ---- integer ME: SAD4 (4 candidates of one diamond/star step around a centre) and single SAD
-        w, h, x, y = pu(n["sad4"])
-        cx, cy = mv(n["sad4"], 60)
+        # ---- integer ME: SAD4 (4 candidates of one diamond/star step around a centre) and single SAD.  A search makes
+        # ~31 SAD4 calls (A.1) for the same PU and list around a centre that moves with the best candidate: the jobs
+        # come in runs of 31 sharing block and source, the centre doing a bounded random walk from the predictor
+        RUN = 31
+        nrun = (n["sad4"] + RUN - 1) // RUN
+        w, h, x, y = (np.repeat(v, RUN)[:n["sad4"]] for v in pu(nrun))
+        px, py = mv(nrun, 40)
+        wx = np.cumsum(rng.integers(-3, 4, (nrun, RUN)), axis=1).clip(-20, 20)
+        wy = np.cumsum(rng.integers(-3, 4, (nrun, RUN)), axis=1).clip(-20, 20)
+        cx = (px[:, None] + wx).ravel()[:n["sad4"]].astype(np.int32)
+        cy = (py[:, None] + wy).ravel()[:n["sad4"]].astype(np.int32)
         step = rng.choice([1, 2, 4], n["sad4"]).astype(np.int32)
-        lst = rng.integers(1, 3, n["sad4"]).astype(np.int32)   # reference list 0/1 -> plane 1/2
+        lst = np.repeat(rng.integers(1, 3, nrun), RUN)[:n["sad4"]].astype(np.int32)   # reference list 0/1 -> plane 1/2
         j = np.zeros((n["sad4"], 8), np.int32)
         j[:, 0] = loff(x, y, 0)
         for k, (dx, dy) in enumerate(((0, -1), (-1, 0), (1, 0), (0, 1))):
