@@ -83,7 +83,7 @@ __global__ __launch_bounds__(64) void k_tu_forward(int16_t *__restrict__ coeffs,
 #pragma unroll
     for (int p = 0; p < N / 2; ++p) row[p] = pk_sub(row[p], prow[p]);   // residual (|.| <= 1023: no 16-bit overflow)
     int o[N];
-    basis_times_row<N, TR, false>(row, 1 << (shift1 - 1), o);
+    basis_times_row<N, TR, false, true>(row, 1 << (shift1 - 1), o);   // residual of <= 10-bit samples: the fold is exact
 #pragma unroll
     for (int k = 0; k < N; ++k) lds[t][k * LS + r] = (int16_t)(o[k] >> shift1);
     __syncthreads();

@@ -66,18 +66,94 @@ __device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int c)
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b), c, false);
 }
 
-// out[k] = sum_j M[k][j] * row[j] + add, for all k, M uniform across lanes (scalar operands)
-template <int N, int TR, bool INV>
+// ---- partial butterflies for the DCT sizes where they pay (N >= 16).  DCT-II rows are (anti)symmetric:
+// M[k][N-1-i] = (-1)^k M[k][i] (the structure havoc/transform.cpp's partialButterfly functions use), which halves the
+// multiply-accumulates.  The products summed are exactly those of the full matrix product, in 32 bits, so results are
+// bit-identical.
+
+// inverse: even / odd coefficient pairs down a column: ve[i][q] = (M[4q][i], M[4q+2][i]), vo[i][q] = (M[4q+1][i], M[4q+3][i])
+template <int N> struct PackedBasisEO { uint32_t ve[N / 2][N / 4], vo[N / 2][N / 4]; };
+
+template <int N>
+constexpr PackedBasisEO<N> make_basis_eo()
+{
+    PackedBasisEO<N> m{};
+    for (int i = 0; i < N / 2; ++i)
+        for (int q = 0; q < N / 4; ++q)
+        {
+            m.ve[i][q] = ((uint32_t)basis(N, 0, 4 * q, i) & 0xffffu) | ((uint32_t)basis(N, 0, 4 * q + 2, i) << 16);
+            m.vo[i][q] = ((uint32_t)basis(N, 0, 4 * q + 1, i) & 0xffffu) | ((uint32_t)basis(N, 0, 4 * q + 3, i) << 16);
+        }
+    return m;
+}
+static __constant__ PackedBasisEO<16> c_eo_dct16 = make_basis_eo<16>();
+static __constant__ PackedBasisEO<32> c_eo_dct32 = make_basis_eo<32>();
+template <int N> __device__ __forceinline__ const PackedBasisEO<N> &basis_eo();
+template <> __device__ __forceinline__ const PackedBasisEO<16> &basis_eo<16>() { return c_eo_dct16; }
+template <> __device__ __forceinline__ const PackedBasisEO<32> &basis_eo<32>() { return c_eo_dct32; }
+
+// out[k] = sum_j M[k][j] * row[j] + add, for all k, M uniform across lanes (scalar operands).
+// FOLD (forward only): the caller guarantees |row[j]| <= 2^14 (the residual of samples of <= 10 bits in the first
+// pass), so row[j] +- row[N-1-j] can be formed in packed 16 bits.
+template <int N, int TR, bool INV, bool FOLD = false>
 __device__ __forceinline__ void basis_times_row(const uint32_t (&row)[N / 2], int add, int (&out)[N])
 {
-    const PackedBasis<N> &m = basis_table<N, TR, INV>();
-#pragma unroll
-    for (int k = 0; k < N; ++k)
+    if constexpr (INV && TR == 0 && N >= 16)
     {
-        int a = add;
+        const PackedBasisEO<N> &m = basis_eo<N>();
+        uint32_t ce[N / 4], co[N / 4];
 #pragma unroll
-        for (int p = 0; p < N / 2; ++p) a = dot2(row[p], m.v[k][p], a);
-        out[k] = a;
+        for (int q = 0; q < N / 4; ++q)
+        {
+            ce[q] = __builtin_amdgcn_perm(row[2 * q + 1], row[2 * q], 0x05040100u);   // (c[4q], c[4q+2])
+            co[q] = __builtin_amdgcn_perm(row[2 * q + 1], row[2 * q], 0x07060302u);   // (c[4q+1], c[4q+3])
+        }
+#pragma unroll
+        for (int i = 0; i < N / 2; ++i)
+        {
+            int e = add, o = 0;
+#pragma unroll
+            for (int q = 0; q < N / 4; ++q)
+            {
+                e = dot2(ce[q], m.ve[i][q], e);
+                o = dot2(co[q], m.vo[i][q], o);
+            }
+            out[i] = e + o;
+            out[N - 1 - i] = e - o;
+        }
+    }
+    else if constexpr (!INV && TR == 0 && N >= 16 && FOLD)
+    {
+        const PackedBasis<N> &m = basis_table<N, TR, INV>();
+        uint32_t ev[N / 4], od[N / 4];
+#pragma unroll
+        for (int p = 0; p < N / 4; ++p)
+        {
+            const uint32_t b = row[N / 2 - 1 - p];
+            const uint32_t bs = __builtin_amdgcn_alignbit(b, b, 16);                  // (x[N-1-2p], x[N-2-2p])
+            ev[p] = pk_add(row[p], bs);
+            od[p] = pk_sub(row[p], bs);
+        }
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+        {
+            int a = add;
+#pragma unroll
+            for (int p = 0; p < N / 4; ++p) a = dot2((k & 1) ? od[p] : ev[p], m.v[k][p], a);
+            out[k] = a;
+        }
+    }
+    else
+    {
+        const PackedBasis<N> &m = basis_table<N, TR, INV>();
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+        {
+            int a = add;
+#pragma unroll
+            for (int p = 0; p < N / 2; ++p) a = dot2(row[p], m.v[k][p], a);
+            out[k] = a;
+        }
     }
 }
 
