@@ -1,0 +1,68 @@
+"""CPU checks of the bench workload (turingcodec_amd/workload.py): the call counts are the survey's, and every job
+stays inside the padded picture store (the kernels do no bounds checking, as the reference's primitives)."""
+import numpy as np
+import pytest
+
+from turingcodec_amd.workload import CALLS_1080P, FrameWorkload
+
+
+@pytest.fixture(scope="module")
+def wl():
+    return FrameWorkload(640, 360, 8, 3)
+
+
+def test_counts_scale_with_ctu_count(wl):
+    f = (10 * 6) / 510.0
+    for k, v in CALLS_1080P.items():
+        assert abs(wl.counts[k] - v * f) <= 1, k
+    assert len(wl.sad4) == wl.counts["sad4"] and len(wl.sad) == wl.counts["sad"]
+    assert sum(len(g["jobs"]) for g in wl.tu.values()) == wl.counts["tu"]
+    assert sum(len(j) for j in wl.intra_search.values()) * 35 <= wl.counts["intra_satd"] + 35
+    nsub = sum(len(j) for j in wl.subpel.values())
+    assert nsub == sum(int(j[:, 3].sum()) for j in wl.subpel_planes.values())   # same candidates through both routes
+    assert nsub + len(wl.uni8) == sum(wl.counts[k] for k in ("uni8_hv", "uni8_h", "uni8_v", "uni8_copy"))
+
+
+def _inside(wl, off, w, h, reach, planes, plane_len, stride, rows):
+    off = np.asarray(off, np.int64)
+    p = off // plane_len
+    r = off % plane_len
+    y, x = r // stride, r % stride
+    assert (p >= 0).all() and (p < planes).all()
+    assert (x - reach >= 0).all() and (x + w + reach + 3 <= stride).all()
+    assert (y - reach >= 0).all() and (y + h + reach <= rows).all()
+
+
+def test_luma_jobs_stay_inside_the_padded_planes(wl):
+    pl, st = wl.plane_len, wl.stride
+    rows = pl // st
+    j = wl.sad4
+    for k in range(1, 5):
+        _inside(wl, j[:, k], j[:, 5], j[:, 6], 0, 3, pl, st, rows)
+    _inside(wl, j[:, 0], j[:, 5], j[:, 6], 0, 3, pl, st, rows)
+    _inside(wl, wl.uni8[:, 1], wl.uni8[:, 2], wl.uni8[:, 3], 4, 3, pl, st, rows)          # 8-tap reach -3 .. +4
+    for c in (1, 2):
+        _inside(wl, wl.bi8[:, c], wl.bi8[:, 3], wl.bi8[:, 4], 4, 3, pl, st, rows)
+    for j in wl.subpel.values():
+        _inside(wl, j[:, 1], j[:, 2], j[:, 3], 4, 3, pl, st, rows)
+    m = wl.me_search
+    _inside(wl, m[:, 1], m[:, 2], m[:, 3], 64, 3, pl, st, rows)                           # surfaces up to +-64
+    # candidates against the phase planes: inside the rectangle interp_planes fills (picture + plane_margin)
+    lo, hi_x, hi_y = 96 - wl.plane_margin, 96 + wl.width + wl.plane_margin, 96 + wl.height + wl.plane_margin
+    for j in wl.subpel_planes.values():
+        for k in range(16):
+            use = j[:, 3] > k
+            r = j[use, 4 + k].astype(np.int64) % pl
+            y, x = r // st, r % st
+            assert (x >= lo).all() and (y >= lo).all()
+            assert (x + j[use, 1] <= hi_x).all() and (y + j[use, 2] <= hi_y).all()
+
+
+def test_jobs_are_grouped_as_the_search_issues_them(wl):
+    j = wl.sad4
+    run = 31
+    k = (len(j) // run) * run
+    g = j[:k].reshape(-1, run, 8)
+    assert (g[:, :, 0] == g[:, :1, 0]).all() and (g[:, :, 5] == g[:, :1, 5]).all()       # one PU per run of SAD4 calls
+    for jm in wl.subpel_planes.values():
+        assert ((jm[:, 3] == 16) | (jm[:, 3] == 1)).all()

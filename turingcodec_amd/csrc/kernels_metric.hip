@@ -150,44 +150,71 @@ __device__ __forceinline__ uint32_t ssd_dword(uint32_t a, uint32_t b, uint32_t a
     return acc - 2u * ab;
 }
 
+// 16 lanes (one DPP row) per job, four jobs per wavefront, CB-byte chunks per lane -- the SAD kernel's mapping: most
+// SSD calls are 4x4 / 8x8 transform blocks (16 / 64 bytes), far too little for a wavefront each
+template <int S, int CB>
+__device__ __forceinline__ uint32_t ssd_block(const char *a, long sab, const char *b, long sbb, int rowBytes, int h, int lane)
+{
+    const int cpr = rowBytes / CB;      // chunks per row
+    const int rpi = kSadLanes / cpr;    // rows per iteration (cpr <= 16: rowBytes <= 64 * 2 with CB = 16 -> 8)
+    const int y0 = lane / cpr;
+    const int xb = (lane - y0 * cpr) * CB;
+    uint32_t acc = 0;
+    if (y0 >= rpi) return 0;
+#pragma unroll 2
+    for (int y = y0; y < h; y += rpi)
+    {
+        const char *p = a + y * sab + xb, *q = b + y * sbb + xb;
+        if (CB == 4) acc = ssd_dword<S>(ld4(p), ld4(q), acc);
+        else if (CB == 8)
+        {
+            const u32x2 u = ld8(p), v = ld8(q);
+            acc = ssd_dword<S>(u.x, v.x, acc);
+            acc = ssd_dword<S>(u.y, v.y, acc);
+        }
+        else
+        {
+            const u32x4 u = ld16(p), v = ld16(q);
+            acc = ssd_dword<S>(u.x, v.x, acc);
+            acc = ssd_dword<S>(u.y, v.y, acc);
+            acc = ssd_dword<S>(u.z, v.z, acc);
+            acc = ssd_dword<S>(u.w, v.w, acc);
+        }
+    }
+    return acc;
+}
+
 template <int S>
 __global__ __launch_bounds__(256) void k_ssd(const char *__restrict__ pa, long stride_a, const char *__restrict__ pb, long stride_b,
                                              const int32_t *__restrict__ jobs, int njobs, uint32_t *__restrict__ out)
 {
     typedef typename Sample<S>::T T;
-    const int job = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (job >= njobs) return;
-    const int32_t *j = jobs + job * 4;
-    const int w = j[2], h = j[3];
+    const int job = (blockIdx.x * 256 + threadIdx.x) / kSadLanes;
+    const int lane = threadIdx.x & (kSadLanes - 1);
+    const bool live = job < njobs;
+    const int32_t *j = jobs + (long)(live ? job : 0) * 4;
+    const int w = j[2], h = live ? j[3] : 0;
     const long sab = stride_a * S, sbb = stride_b * S;
     const char *a = pa + (long)j[0] * S;
     const char *b = pb + (long)j[1] * S;
     uint32_t acc = 0;
     const int rowBytes = w * S;
-    if ((rowBytes & 3) == 0)
-    {
-        const int cpr = rowBytes >> 2;          // dwords per row (1..32)
-        const FastDiv fd(cpr);
-        for (int i = lane; i < cpr * h; i += kWave)
-        {
-            const int y = fd.div(i), x = (i - y * cpr) * 4;
-            acc = ssd_dword<S>(ld4(a + y * sab + x), ld4(b + y * sbb + x), acc);
-        }
-    }
+    if ((rowBytes & 15) == 0) acc = ssd_block<S, 16>(a, sab, b, sbb, rowBytes, h, lane);
+    else if ((rowBytes & 7) == 0) acc = ssd_block<S, 8>(a, sab, b, sbb, rowBytes, h, lane);
+    else if ((rowBytes & 3) == 0 && rowBytes <= 64) acc = ssd_block<S, 4>(a, sab, b, sbb, rowBytes, h, lane);
     else
     {
         const FastDiv fd(w);
-        for (int i = lane; i < w * h; i += kWave)
+        for (int i = lane; i < w * h; i += kSadLanes)
         {
             const int y = fd.div(i), x = i - y * w;
             const int d = (int)reinterpret_cast<const T *>(a + y * sab)[x] - (int)reinterpret_cast<const T *>(b + y * sbb)[x];
             acc += (uint32_t)(d * d);
         }
     }
-    uint32_t t = (uint32_t)wave_sum((int)acc);
+    uint32_t t = (uint32_t)row16_sum((int)acc);   // lane 15 of the row holds the job's total
     if (S == 2) t >>= 4;
-    if (lane == 0) out[job] = t;
+    if (live && lane == kSadLanes - 1) out[job] = t;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -345,12 +372,12 @@ __global__ __launch_bounds__(256) void k_satd_multi(const char *__restrict__ pa,
     const int l = threadIdx.x & (G - 1);
     const bool live = job < njobs;
     const int32_t *j = jobs + (long)(live ? job : 0) * (4 + kSatdMulti);
-    const int w = j[1], cnt = j[3], h = (live && k0 < cnt) ? j[2] : 0;
+    const int w = j[1], cnt = min(max(j[3], 0), kSatdMulti), h = (live && k0 < cnt) ? j[2] : 0;   // count outside 1..16 is clamped
     const long sab = stride_a * S, sbb = stride_b * S;
     const char *a = pa + (long)j[0] * S;
     const char *b[CPS];
 #pragma unroll
-    for (int k = 0; k < CPS; ++k) b[k] = pb + (long)j[4 + min(k0 + k, cnt - 1)] * S;   // slots beyond count repeat the last one
+    for (int k = 0; k < CPS; ++k) b[k] = pb + (long)j[4 + max(0, min(k0 + k, cnt - 1))] * S;   // slots beyond count repeat the last one
     int acc[CPS];
 #pragma unroll
     for (int k = 0; k < CPS; ++k) acc[k] = 0;
@@ -481,9 +508,6 @@ __global__ __launch_bounds__(256) void k_ssd_linear(const uint8_t *__restrict__ 
 // launchers (called from api.hip)
 // ---------------------------------------------------------------------------------------------------------
 
-#define LAUNCH4(kernel, njobs, stream, ...) \
-    hipLaunchKernelGGL(kernel, dim3(((njobs) + 3) / 4), dim3(256), 0, stream, __VA_ARGS__)
-
 hipError_t launch_sad(hipStream_t st, int S, int ways, const void *src, long ss, const void *ref, long rs, const void *jobs, int n, int32_t *out)
 {
     if (n <= 0) return hipSuccess;
@@ -501,8 +525,9 @@ hipError_t launch_sad(hipStream_t st, int S, int ways, const void *src, long ss,
 hipError_t launch_ssd(hipStream_t st, int S, const void *a, long sa, const void *b, long sb, const void *jobs, int n, uint32_t *out)
 {
     if (n <= 0) return hipSuccess;
-    if (S == 1) LAUNCH4((k_ssd<1>), n, st, (const char *)a, sa, (const char *)b, sb, (const int32_t *)jobs, n, out);
-    else LAUNCH4((k_ssd<2>), n, st, (const char *)a, sa, (const char *)b, sb, (const int32_t *)jobs, n, out);
+    const dim3 g((n + 256 / kSadLanes - 1) / (256 / kSadLanes)), b256(256);   // 16 lanes per job
+    if (S == 1) hipLaunchKernelGGL((k_ssd<1>), g, b256, 0, st, (const char *)a, sa, (const char *)b, sb, (const int32_t *)jobs, n, out);
+    else hipLaunchKernelGGL((k_ssd<2>), g, b256, 0, st, (const char *)a, sa, (const char *)b, sb, (const int32_t *)jobs, n, out);
     return hipGetLastError();
 }
 
