@@ -39,6 +39,7 @@ def parse_args():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-out", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--kernel-reps", type=int, default=5)
     ap.add_argument("--ime", choices=["sad4", "surface"], default="sad4",
                     help="integer ME as per-pattern SAD4 jobs (the reference's call mix) or as one SAD surface per search")
@@ -365,6 +366,7 @@ def cpu_worker(args):
     bi = _aligned(np.zeros(wl.bi_len + 8192, dt))
     sbi = _aligned(np.zeros(len(wl.subtract_bi) * 4096 + 4096, dt))
     tasks = []   # (callable(b, e), njobs, group the GPU bench times it under)
+    results = {}   # name -> array: what the reference computed for the sampled jobs (full-size parity check in main)
 
     def add(group, fn, n):
         if n:
@@ -387,6 +389,7 @@ def cpu_worker(args):
     add("subtract_bi", lambda b, e: lib.ref_run_subtract_bi(handle, S, bd, P(sbi), ip(64), P(bi), ip(64), P(luma), ip(st), P(jsb), b, e), len(jsb))
     add("pred_bi4", lambda b, e: lib.ref_run_pred_bi(handle, S, 4, bd, P(bi), ip(32), P(chroma), ip(cst), P(jb4), b, e), len(jb4))
     keep = [j4, js, ju8, ju4, jb8, jb4, jsb, jsa, o4, os_, osa]
+    results.update(sad4=o4, sad=os_, satd_inter=osa)
     for hi, j in wl.subpel.items():   # fused on the GPU; on the CPU the reference's two calls: pred_uni, then measureSatd
         if not len(j):
             continue
@@ -405,6 +408,7 @@ def cpu_worker(args):
         ji, nb = sub(j), _aligned(wl.intra_nb[log2])
         dst = _aligned(np.zeros((len(j) << (2 * log2)) + 64, dt))
         keep += [ji, nb, dst]
+        results[f"intra_{log2}"] = (dst, ji[:, 0], n * n)
         add("intra", lambda b, e, log2=log2, n=n, ji=ji, nb=nb, dst=dst: lib.ref_run_intra(handle, S, bd, log2, P(dst), ip(n), P(nb), P(ji), b, e), len(ji))
     for log2, j in wl.intra_search.items():
         if not len(j):
@@ -412,6 +416,7 @@ def cpu_worker(args):
         jp, nb = sub(j), _aligned(wl.intra_search_nb[log2])
         cost = np.zeros(35 * len(jp), np.int32)
         keep += [jp, nb, cost]
+        results[f"intra35_{log2}"] = cost
         add("intra_satd35", lambda b, e, log2=log2, jp=jp, nb=nb, cost=cost: lib.ref_run_intra_satd35(handle, S, bd, log2, P(luma), ip(st), P(nb), P(jp), b, e, P(cost)), len(jp))
     qp = 32
     for (log2, tr), g in wl.tu.items():
@@ -430,6 +435,7 @@ def cpu_worker(args):
         dj[:, 4] = log2 - 1 + bd - 8
         dj = _aligned(dj)
         keep += [jt, jsrc, roff, res, coef, deq, dj]
+        results[f"coef_{log2}_{tr}"] = (coef, jt[:, 0], n * n)
         add("tu_forward", lambda b, e, n=n, res=res, roff=roff, jsrc=jsrc: lib.ref_run_residual(S, P(res), ip(n), P(roff), P(luma), ip(st), P(luma), ip(st), P(jsrc), b, e), len(jt))
         add("tu_forward", lambda b, e, n=n, log2=log2, tr=tr, coef=coef, res=res, jt=jt: lib.ref_run_transform(handle, bd, tr, log2, P(coef), P(res), ip(n), P(jt), b, e), len(jt))
         add("tu_reconstruct", lambda b, e, deq=deq, coef=coef, dj=dj: lib.ref_run_quantize_inverse(handle, P(deq), P(coef), P(dj), b, e), len(jt))
@@ -468,33 +474,87 @@ def cpu_worker(args):
             if time.perf_counter() - t0 > 2.0 or reps >= 5000:
                 break
         dt_s = (time.perf_counter() - t0) / reps
+    if args.cpu_out:
+        flat = {}
+        for name, v in results.items():
+            if isinstance(v, tuple):   # (buffer, block offsets, block length): keep only the sampled blocks
+                buf, offs, ln = v
+                flat[name] = buf[(offs.astype(np.int64)[:, None] + np.arange(ln)[None, :]).ravel()]
+            else:
+                flat[name] = v
+        np.savez(args.cpu_out, **flat)
     print(json.dumps({"seconds_per_sample": dt_s, "stride": stride, "cores": cores, "handle": handle,
                       "jobs": int(sum(n for _, n, _ in tasks)), "reps": reps,
                       "group_seconds_per_sample": {g: sum(a.get(g, 0.0) for a in acc) / cores / reps for g in acc[0]}}))
 
 
-def cpu_baseline(args):
+def parity_vs_reference(dev, path, stride):
+    """full-size parity: what the reference library computed for every `stride`-th job (the cpu_baseline sample) against
+    the GPU's results for the same jobs; returns {"compared": values, "mismatches": values that differ}"""
+    hv, wl = dev.hv, dev.wl
+    ref = np.load(path)
+    compared = mismatches = 0
+    groups = []
+
+    def cmp(name, gpu):
+        nonlocal compared, mismatches
+        a, b = np.asarray(ref[name]).astype(np.int64).ravel(), np.asarray(gpu).astype(np.int64).ravel()
+        assert a.shape == b.shape, (name, a.shape, b.shape)
+        compared += a.size
+        mismatches += int((a != b).sum())
+        groups.append(name)
+
+    def blocks(buf, offs, ln):
+        return buf[(np.asarray(offs, np.int64)[::stride][:, None] + np.arange(ln)[None, :]).ravel()]
+
+    if dev.ime_range is None:
+        cmp("sad4", hv.down(dev.o_sad4, np.int32).reshape(-1, 4)[::stride])
+    cmp("sad", hv.down(dev.o_sad, np.int32)[::stride])
+    cmp("satd_inter", hv.down(dev.o_satd, np.int32)[::stride])
+    for log2, g in dev.intra.items():
+        n = 1 << log2
+        cmp(f"intra_{log2}", blocks(hv.down(g["dst"], wl.dtype), wl.intra[log2][:, 0], n * n))
+    for log2, g in dev.isearch.items():
+        cmp(f"intra35_{log2}", hv.down(g["cost"], np.int32).reshape(-1, 35)[::stride])
+    for (log2, tr), g in dev.tu.items():
+        cmp(f"coef_{log2}_{tr}", blocks(hv.down(g["coef"], np.int16), wl.tu[(log2, tr)]["jobs"][:, 0], g["n"] ** 2))
+    return {"compared": compared, "mismatches": mismatches,
+            "what": "results of the reference library for the cpu_baseline sample vs the GPU results of the same jobs: " + ", ".join(groups)}
+
+
+def cpu_baseline(args, dev=None):
     """frames/s of the reference library on the host: sample = every `stride`-th job of every table"""
     if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libhavoc_ref.so")):
         return None
+    import tempfile
     stride = 4
     for handle in (1, 0):   # x86 JIT tables first; plain-C tables if the JIT run fails
+        tmp = os.path.join(tempfile.gettempdir(), f"havoc_cpu_{os.getpid()}_{handle}.npz")
         cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", f"{handle},{stride}", "--res", args.res,
-               "--bit-depth", str(args.bit_depth), "--seed", str(args.seed)]
+               "--bit-depth", str(args.bit_depth), "--seed", str(args.seed), "--cpu-out", tmp]
         try:
             out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
             if out.returncode == 0:
                 r = json.loads(out.stdout.strip().splitlines()[-1])
                 fps = 1.0 / (r["seconds_per_sample"] * r["stride"])
-                return {"value": round(fps, 3), "unit": "frames/s", "cores": r["cores"], "kind": "reference",
-                        "ms_per_frame_by_group": {g: round(v * r["stride"] * 1e3, 3) for g, v in r["group_seconds_per_sample"].items()},
-                        "sample": f"every {stride}th job of each primitive's job table ({r['jobs']} calls) through the "
-                                  f"reference's own havoc {'x86-JIT' if handle else 'C'} function tables (oracle/_ref), "
-                                  f"{r['cores']} host threads, the sample repeated {r['reps']}x "
-                                  f"({r['reps'] * r['seconds_per_sample']:.1f} s wall, "
-                                  f"{r['reps'] * r['seconds_per_sample'] * r['cores']:.0f} core-seconds), extrapolated x{stride}"}
+                res = {"value": round(fps, 3), "unit": "frames/s", "cores": r["cores"], "kind": "reference",
+                       "ms_per_frame_by_group": {g: round(v * r["stride"] * 1e3, 3) for g, v in r["group_seconds_per_sample"].items()},
+                       "sample": f"every {stride}th job of each primitive's job table ({r['jobs']} calls) through the "
+                                 f"reference's own havoc {'x86-JIT' if handle else 'C'} function tables (oracle/_ref), "
+                                 f"{r['cores']} host threads, the sample repeated {r['reps']}x "
+                                 f"({r['reps'] * r['seconds_per_sample']:.1f} s wall, "
+                                 f"{r['reps'] * r['seconds_per_sample'] * r['cores']:.0f} core-seconds), extrapolated x{stride}"}
+                if dev is not None and os.path.exists(tmp):
+                    try:
+                        res["parity_vs_reference"] = parity_vs_reference(dev, tmp, stride)
+                    except Exception as e:   # the baseline number stands on its own
+                        res["parity_vs_reference"] = {"error": repr(e)}
+                return res
         except Exception:
             pass
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
     return None
 
 
@@ -562,8 +622,9 @@ def main():
     exch = None
     if grouped:
         from turingcodec_amd.frame_parallel import ReferenceExchange
+        # the workload keeps one chroma plane (Cr is identical work); the exchange carries Y, Cb and Cr
         exch = ReferenceExchange(dist, rank, world, dev.luma[3 * wl.plane_len:4 * wl.plane_len], dev.chroma[:wl.cplane_len],
-                                 single_rank_broadcast=args.exchange)
+                                 single_rank_broadcast=args.exchange, recon_chroma2=dev.chroma[:wl.cplane_len])
         comm = torch.cuda.current_stream(local)   # torch.distributed enqueues behind this stream
 
     dev.step()          # first eager pass (loads the code objects) -- also what the graph must reproduce
@@ -653,7 +714,7 @@ def main():
         if args.skip:
             out["metric"] = "DIAGNOSTIC (launch groups skipped: " + args.skip + ") -- not the benchmark metric"
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args)
+            out["cpu_baseline"] = cpu_baseline(args, dev)
         print(json.dumps(out))
     if grouped:
         dist.barrier()

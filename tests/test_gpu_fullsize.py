@@ -112,3 +112,25 @@ def test_bench_multi_rank_path_rehearsal():
     assert one.returncode == 0, one.stderr[-2000:]
     r1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
     assert r1["checksum"] == r["checksum"]     # rank 0 encodes the same picture (seed + rank) in both runs
+
+
+def test_full_size_results_equal_the_reference_library(hv):
+    """every 4th job of the 1080p frame through the reference's own havoc functions (oracle/_ref, built from the
+    reference sources by oracle/Makefile; x86 JIT tables) on the host, against the GPU results of the same jobs:
+    SAD4, SAD, PU SATD, intra predictions, 35-mode intra costs and forward-transform coefficients, ~20 M values"""
+    import argparse
+    import os
+    import bench
+    from turingcodec_amd.workload import FrameWorkload
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, "oracle", "_ref", "libhavoc_ref.so")):
+        pytest.skip("oracle/_ref not built (needs the reference sources at build time)")
+    wl = FrameWorkload(1920, 1080, 8, 11)
+    dev = bench.DeviceFrame(hv, wl)
+    dev.step()
+    hv.sync()
+    r = bench.cpu_baseline(argparse.Namespace(res="1920x1080", bit_depth=8, seed=11), dev)
+    assert r is not None and r["kind"] == "reference"
+    p = r["parity_vs_reference"]
+    assert "error" not in p, p
+    assert p["compared"] > 10_000_000 and p["mismatches"] == 0, p

@@ -23,7 +23,19 @@ __device__ __forceinline__ uint32_t sad_dword(uint32_t a, uint32_t b, uint32_t a
 // accumulate |src - ref_k| over a w x h block.  CB = bytes per lane chunk (4, 8, 16); rowBytes % CB == 0.
 // 16 lanes (one DPP row) per job, four jobs per wavefront: a 16x16 8-bit block is exactly one 16-byte chunk per lane,
 // 8x8 uses half a row, 64x64 takes 16 steps; the per-job cost (job fetch, address set-up, reduction) is shared four ways
-constexpr int kSadLanes = 16;
+#ifndef SADL
+#define SADL 16
+#endif
+constexpr int kSadLanes = SADL;
+// sum over each aligned group of kSadLanes lanes, valid in the group's last lane
+__device__ __forceinline__ int sad_group_sum(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xe, true);  // row_shr:4
+    if (kSadLanes == 16) v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xc, true);  // row_shr:8
+    return v;
+}
 
 template <int S, int WAYS, int CB>
 __device__ __forceinline__ void sad_block(const char *src, long ssb, const char *const (&ref)[WAYS], long rsb, int rowBytes, int h,
@@ -122,7 +134,7 @@ __global__ __launch_bounds__(256) void k_sad(const char *__restrict__ src, long 
 #pragma unroll
     for (int k = 0; k < WAYS; ++k)
     {
-        int t = row16_sum((int)acc[k]);   // lane 15 of each 16-lane row holds its job's total
+        int t = sad_group_sum((int)acc[k]);   // the last lane of each group holds its job's total
         if (S == 2) t >>= 2;
         if (live && lane == kSadLanes - 1) out[job * WAYS + k] = t;
     }
@@ -212,7 +224,7 @@ __global__ __launch_bounds__(256) void k_ssd(const char *__restrict__ pa, long s
             acc += (uint32_t)(d * d);
         }
     }
-    uint32_t t = (uint32_t)row16_sum((int)acc);   // lane 15 of the row holds the job's total
+    uint32_t t = (uint32_t)sad_group_sum((int)acc);   // the last lane of the group holds the job's total
     if (S == 2) t >>= 4;
     if (live && lane == kSadLanes - 1) out[job] = t;
 }

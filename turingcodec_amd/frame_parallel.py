@@ -83,16 +83,19 @@ class ReferenceExchange:
     broadcasts of picture i with the computation of picture i+1 (bench.py)."""
 
     def __init__(self, dist, rank: int, world: int, recon_luma, recon_chroma, slots: int = 6, n_sops: int = 64,
-                 single_rank_broadcast: bool = False):
+                 single_rank_broadcast: bool = False, recon_chroma2=None):
         self.dist, self.rank, self.world = dist, rank, world
         self.single_rank_broadcast = single_rank_broadcast   # exercise the collective even when world == 1
         self.recon_luma, self.recon_chroma = recon_luma, recon_chroma
         self.pics = coding_order(n_sops)
         self.slots = slots
+        self.recon_chroma2 = recon_chroma2                   # second chroma plane (Cr), when the caller keeps one
         nl, nc = recon_luma.numel(), recon_chroma.numel()
-        self.dpb = [recon_luma.new_zeros(nl + nc) for _ in range(slots)]
+        nc2 = recon_chroma2.numel() if recon_chroma2 is not None else 0
+        self.dpb = [recon_luma.new_zeros(nl + nc + nc2) for _ in range(slots)]
         self.dpb_luma = [b[:nl] for b in self.dpb]          # views
-        self.dpb_chroma = [b[nl:] for b in self.dpb]
+        self.dpb_chroma = [b[nl:nl + nc] for b in self.dpb]
+        self.dpb_chroma2 = [b[nl + nc:] for b in self.dpb]
         self.sent_bytes = 0
 
     def picture_of(self, step: int, rank: int) -> Picture:
@@ -108,6 +111,8 @@ class ReferenceExchange:
             slot = self.slot_of(pic, self.slots)
             self.dpb_luma[slot].copy_(self.recon_luma)
             self.dpb_chroma[slot].copy_(self.recon_chroma)
+            if self.recon_chroma2 is not None:
+                self.dpb_chroma2[slot].copy_(self.recon_chroma2)
 
     def send(self, step: int):
         for src in range(self.world):
