@@ -390,6 +390,7 @@ def cpu_worker(args):
     add("pred_bi4", lambda b, e: lib.ref_run_pred_bi(handle, S, 4, bd, P(bi), ip(32), P(chroma), ip(cst), P(jb4), b, e), len(jb4))
     keep = [j4, js, ju8, ju4, jb8, jb4, jsb, jsa, o4, os_, osa]
     results.update(sad4=o4, sad=os_, satd_inter=osa)
+    late = [("pred_uni8", pred, ju8, 0, 2, 64), ("pred_uni4", cpred, ju4, 0, 2, 32)]   # (the bi slots are re-used by the chroma pass)
     for hi, j in wl.subpel.items():   # fused on the GPU; on the CPU the reference's two calls: pred_uni, then measureSatd
         if not len(j):
             continue
@@ -399,6 +400,7 @@ def cpu_worker(args):
         scratch = _aligned(np.zeros(len(jp) * 4096 + 4096, dt))
         osp = np.zeros(len(jp), np.int32)
         keep += [jp, jsat, scratch, osp]
+        results[f"subpel_{hi}"] = osp
         add("subpel(interp+satd)", lambda b, e, jp=jp, scratch=scratch: lib.ref_run_pred_uni(handle, S, 8, bd, P(scratch), ip(64), P(luma), ip(st), P(jp), b, e), len(jp))
         add("subpel(interp+satd)", lambda b, e, jsat=jsat, scratch=scratch, osp=osp: lib.ref_run_satd(handle, S, P(luma), ip(st), P(scratch), ip(64), P(jsat), b, e, P(osp)), len(jp))
     for log2, j in wl.intra.items():
@@ -475,7 +477,7 @@ def cpu_worker(args):
                 break
         dt_s = (time.perf_counter() - t0) / reps
     if args.cpu_out:
-        flat = {}
+        flat = {name: _regions(buf, jobs, oc, wc, sd) for name, buf, jobs, oc, wc, sd in late}
         for name, v in results.items():
             if isinstance(v, tuple):   # (buffer, block offsets, block length): keep only the sampled blocks
                 buf, offs, ln = v
@@ -486,6 +488,16 @@ def cpu_worker(args):
     print(json.dumps({"seconds_per_sample": dt_s, "stride": stride, "cores": cores, "handle": handle,
                       "jobs": int(sum(n for _, n, _ in tasks)), "reps": reps,
                       "group_seconds_per_sample": {g: sum(a.get(g, 0.0) for a in acc) / cores / reps for g in acc[0]}}))
+
+
+def _regions(buf, jobs, ocol, wcol, stride):
+    """concatenated w x h regions (row stride `stride`) at jobs[:, ocol] of a slot buffer"""
+    buf = np.asarray(buf)
+    out = []
+    for j in np.asarray(jobs):
+        o, w, h = int(j[ocol]), int(j[wcol]), int(j[wcol + 1])
+        out.append(buf[o:o + stride * h].reshape(h, stride)[:, :w].ravel())
+    return np.concatenate(out) if out else np.zeros(0, buf.dtype)
 
 
 def parity_vs_reference(dev, path, stride):
@@ -511,6 +523,17 @@ def parity_vs_reference(dev, path, stride):
         cmp("sad4", hv.down(dev.o_sad4, np.int32).reshape(-1, 4)[::stride])
     cmp("sad", hv.down(dev.o_sad, np.int32)[::stride])
     cmp("satd_inter", hv.down(dev.o_satd, np.int32)[::stride])
+    cmp("pred_uni8", _regions(hv.down(dev.pred, wl.dtype), wl.uni8[::stride], 0, 2, 64))
+    cmp("pred_uni4", _regions(hv.down(dev.cpred, wl.dtype), wl.uni4[::stride], 0, 2, 32))
+    if dev.use_planes:
+        n = sum(len(v) for v in wl.subpel_idx.values())
+        ca = np.zeros(n, np.int32)
+        for c, g in dev.subpel_planes.items():
+            idx = wl.subpel_planes_idx[c].ravel()
+            ca[idx[idx >= 0]] = hv.down(g["cost"], np.int32)[idx >= 0]
+        for hi, ids in wl.subpel_idx.items():
+            if len(ids):
+                cmp(f"subpel_{hi}", ca[ids[::stride]])
     for log2, g in dev.intra.items():
         n = 1 << log2
         cmp(f"intra_{log2}", blocks(hv.down(g["dst"], wl.dtype), wl.intra[log2][:, 0], n * n))
