@@ -625,7 +625,11 @@ def main():
     grouped = world > 1 or args.exchange
     if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29541")
+        if "MASTER_PORT" not in os.environ:   # single-rank --exchange run: any free port
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = os.environ.get("HAVOC_BENCH_BACKEND", "nccl")   # "gloo": rehearsal of the N>1 path on a 1-GPU box
         local %= torch.cuda.device_count()
@@ -671,6 +675,11 @@ def main():
             #    the broadcasts of the previous one, which ran underneath this picture's kernels
             if i > 0:
                 compute.wait_event(sent[(i - 1) & 1])
+            if exch.picture_of(i, rank).is_reference:
+                # the owner pads its reconstruction (Padding::padBlock after deblocking, turing/TaskDeblock.cpp:151-159)
+                # before it becomes a reference on every rank
+                hv.pad_block_d(dev.luma, 3 * wl.plane_len + 96 * wl.stride + 96, wl.width, wl.height, wl.stride, 96)
+                hv.pad_block_d(dev.chroma, 48 * wl.cstride + 48, wl.width // 2, wl.height // 2, wl.cstride, 48)
             with torch.cuda.stream(compute):
                 exch.stage(i)
             staged[i & 1].record(compute)

@@ -171,6 +171,17 @@ typedef struct {
 } havoc_mi355x_quant_job; /* 32 bytes */
 
 /* ------------------------------------------------------------------------------------------------------- */
+/* picture-level helper next to the path                                                                     */
+/* ------------------------------------------------------------------------------------------------------- */
+
+/* Padding::padBlock<Sample> (turing/Padding.h:60-97; all four flags set = Padding::padImage :33-57): replicate the edge
+ * samples of the width x height block whose sample (0, 0) sits at d_plane[origin_off] into a border of `pad` samples on
+ * the requested sides, in place.  What TaskDeblock.cpp:151-159 does to a reconstructed picture before it is used
+ * as a reference (and what the owner runs before the frame-parallel broadcast). */
+int havoc_mi355x_pad_block(havoc_mi355x_ctx *ctx, int S, void *d_plane, int64_t origin_off, int width, int height,
+                           intptr_t stride, int pad, int top, int bottom, int left, int right);
+
+/* ------------------------------------------------------------------------------------------------------- */
 /* distortion metrics                                                                                        */
 /* ------------------------------------------------------------------------------------------------------- */
 

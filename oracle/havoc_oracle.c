@@ -433,3 +433,27 @@ void oracle_residual(int16_t *res, intptr_t sres, const void *src, intptr_t ss, 
         for (int x = 0; x < w; ++x)
             res[x + y * sres] = (int16_t)(px(src, x + y * ss, S) - px(pred, x + y * sp, S));
 }
+
+/* turing/Padding.h:60-97 (Padding::padBlock; padImage :33-57 is the all-four-sides case): replicate the edge samples of a
+ * w x h block into a border of `pad` samples on the requested sides.  The vertical pass copies the already
+ * horizontally padded first / last row, so the corners get the corner sample. */
+void oracle_pad_block(void *p, int w, int h, intptr_t stride, int pad, int top, int bottom, int left, int right, int S)
+{
+    unsigned char *b = (unsigned char *)p;
+    intptr_t x0 = 0, wide = w;
+    for (int y = 0; y < h; ++y)
+    {
+        unsigned char *row = b + (intptr_t)y * stride * S;
+        if (left)
+            for (int i = 1; i <= pad; ++i) memcpy(row - (intptr_t)i * S, row, (size_t)S);
+        if (right)
+            for (int i = 0; i < pad; ++i) memcpy(row + (intptr_t)(w + i) * S, row + (intptr_t)(w - 1) * S, (size_t)S);
+    }
+    if (left) { x0 -= pad; wide += pad; }
+    if (right) wide += pad;
+    if (top)
+        for (int i = 1; i <= pad; ++i) memcpy(b + (x0 - (intptr_t)i * stride) * S, b + x0 * S, (size_t)(wide * S));
+    if (bottom)
+        for (int i = 1; i <= pad; ++i)
+            memcpy(b + (x0 + (intptr_t)(h - 1 + i) * stride) * S, b + (x0 + (intptr_t)(h - 1) * stride) * S, (size_t)(wide * S));
+}

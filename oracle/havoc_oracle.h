@@ -58,6 +58,7 @@ int oracle_quantize(int16_t *dst, const int16_t *src, int scale, int shift, int 
 void oracle_quantize_reconstruct(uint8_t *rec, intptr_t stride_rec, const uint8_t *pred, intptr_t stride_pred, const int16_t *res, int n);
 
 /* turing/Reconstruct.cpp:258-260, 1274-1286: res = src - pred (the "residual diff" of the north star) */
+void oracle_pad_block(void *p, int w, int h, intptr_t stride, int pad, int top, int bottom, int left, int right, int S);
 void oracle_residual(int16_t *res, intptr_t stride_res, const void *src, intptr_t stride_src, const void *pred, intptr_t stride_pred, int w, int h, int S);
 
 /* turing/Measure.h:97-135 (measureSatd): PU SATD tiled in 8x8 / 4x4 / 2x2 Hadamards */

@@ -75,6 +75,8 @@ class Oracle:
         L.oracle_quantize_reconstruct.argtypes = [_vp, _ip, _vp, _ip, _vp, C.c_int]
         L.oracle_residual.restype = None
         L.oracle_residual.argtypes = [_vp, _ip, _vp, _ip, _vp, _ip, C.c_int, C.c_int, C.c_int]
+        L.oracle_pad_block.restype = None
+        L.oracle_pad_block.argtypes = [_vp, C.c_int, C.c_int, _ip] + [C.c_int] * 6
 
     # every method: arrays are flat (or 2-D C-contiguous) numpy arrays, offsets/strides in samples
     def sad(self, src, so, ss, ref, ro, rs, w, h):
@@ -130,6 +132,10 @@ class Oracle:
     def quantize_reconstruct(self, rec, ro, sr, pred, po, sp, res, so, n):
         self.L.oracle_quantize_reconstruct(_addr(rec, ro), sr, _addr(pred, po), sp, _addr(res, so), n)
 
+    def pad_block(self, plane, off, w, h, stride, pad, top, bottom, left, right):
+        """in place on `plane` (flat array); off = sample offset of the block's (0, 0)"""
+        self.L.oracle_pad_block(_addr(plane, off), w, h, stride, pad, int(top), int(bottom), int(left), int(right), _S(plane))
+
     def residual(self, res, ro, sres, src, so, ss, pred, po, sp, w, h):
         self.L.oracle_residual(_addr(res, ro), sres, _addr(src, so), ss, _addr(pred, po), sp, w, h, _S(src))
 
@@ -180,6 +186,9 @@ class Reference:
         L.ref_ssd_linear.argtypes = [C.c_int, _vp, _vp, C.c_int]
         L.ref_mask.restype = C.c_int
         L.ref_mask.argtypes = [C.c_int]
+        for sfx in ("u8", "u16"):
+            getattr(L, "ref_pad_block_" + sfx).restype = None
+            getattr(L, "ref_pad_block_" + sfx).argtypes = [_vp, C.c_int, C.c_int, _ip] + [C.c_int] * 5
 
     @staticmethod
     def _sfx(a):
@@ -190,6 +199,9 @@ class Reference:
 
     def mask(self):
         return self.L.ref_mask(self.h)
+
+    def pad_block(self, plane, off, w, h, stride, pad, top, bottom, left, right):
+        self._f("ref_pad_block", plane)(_addr(plane, off), w, h, stride, pad, int(top), int(bottom), int(left), int(right))
 
     def sad(self, src, so, ss, ref, ro, rs, w, h):
         return self._f("ref_sad", src)(self.h, _addr(src, so), ss, _addr(ref, ro), rs, w, h)

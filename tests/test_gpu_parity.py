@@ -82,3 +82,22 @@ def test_sad_surface_ranges(hv, oracle, S, bd, rng):
         assert np.array_equal(got[i], exp), (i, w, h)
         for (dy, dx) in ((-rng, -rng), (rng, rng), (0, 0), (-rng, rng)):
             assert oracle.sad(a, so, pw, b, ro + dy * pw + dx, pw, w, h) == got[i, dy + rng, dx + rng]
+
+
+@pytest.mark.parametrize("S", [1, 2])
+def test_pad_block_matches_oracle(hv, oracle, S):
+    """Padding::padBlock on the GPU, every combination of sides, in place; plus a 1080p plane with the picture store's
+    96-sample border (turing/Picture.cpp:91-125)"""
+    import cases
+    rng = np.random.default_rng(32)
+    dt = cases.sample_dtype(S)
+    for (w, h, pad) in ((37, 23, 8), (64, 40, 16), (5, 3, 4), (1920, 1080, 96)):
+        stride, rows = w + 2 * pad + 5, h + 2 * pad
+        base = rng.integers(0, 1 << (8 if S == 1 else 10), stride * rows).astype(dt)
+        off = pad * stride + pad
+        for flags in (range(16) if w < 1000 else (15, 12)):
+            t, b, l, r = (flags >> 3) & 1, (flags >> 2) & 1, (flags >> 1) & 1, flags & 1
+            exp = base.copy()
+            oracle.pad_block(exp, off, w, h, stride, pad, t, b, l, r)
+            got = hv.pad_block(base, off, w, h, stride, pad, t, b, l, r)
+            assert np.array_equal(got, exp), (w, h, pad, flags)

@@ -213,3 +213,24 @@ def test_quantize(oracle, reference_c, reference_jit):
         reference_c.quantize_reconstruct(e, 0, 64, pred, 0, 64, res, 0, n)
         oracle.quantize_reconstruct(g, 0, 64, pred, 0, 64, res, 0, n)
         assert np.array_equal(e, g)
+
+
+@pytest.mark.parametrize("S", [1, 2])
+def test_pad_block(oracle, reference_c, S):
+    """Padding::padBlock (turing/Padding.h:60-97) for every combination of sides; all four sides = numpy edge padding"""
+    rng = np.random.default_rng(31)
+    dt = cases.sample_dtype(S)
+    for (w, h, pad) in ((37, 23, 8), (64, 40, 16), (5, 3, 4), (160, 90, 40)):
+        stride, rows = w + 2 * pad + 5, h + 2 * pad
+        base = rng.integers(0, 1 << (8 if S == 1 else 10), stride * rows).astype(dt)
+        off = pad * stride + pad
+        for flags in range(16):
+            t, b, l, r = (flags >> 3) & 1, (flags >> 2) & 1, (flags >> 1) & 1, flags & 1
+            a1, a2 = base.copy(), base.copy()
+            oracle.pad_block(a1, off, w, h, stride, pad, t, b, l, r)
+            reference_c.pad_block(a2, off, w, h, stride, pad, t, b, l, r)
+            assert np.array_equal(a1, a2), (w, h, pad, flags)
+            if flags == 15:
+                inner = base.reshape(rows, stride)[pad:pad + h, pad:pad + w]
+                assert np.array_equal(a1.reshape(rows, stride)[:, :w + 2 * pad], np.pad(inner, pad, mode="edge"))
+                assert np.array_equal(a1.reshape(rows, stride)[:, w + 2 * pad:], base.reshape(rows, stride)[:, w + 2 * pad:])

@@ -11,6 +11,7 @@ hipError_t launch_sad_surface(hipStream_t, int S, int range, int maxw, int maxh,
 hipError_t launch_ssd(hipStream_t, int S, const void *, long, const void *, long, const void *, int, uint32_t *);
 hipError_t launch_satd(hipStream_t, int S, int maxw, int maxh, const void *, long, const void *, long, const void *, int, int32_t *);
 hipError_t launch_satd_multi(hipStream_t, int S, int maxw, int maxh, const void *, long, const void *, long, const void *, int, int32_t *);
+hipError_t launch_pad_block(hipStream_t, int S, void *, long, int, int, long, int, int, int, int, int);
 hipError_t launch_ssd_linear(hipStream_t, const uint8_t *, const uint8_t *, int, int32_t *);
 hipError_t launch_pred_uni(hipStream_t, int S, int taps, int bd, int maxw, int maxh, void *, long, const void *, long, const void *, int);
 hipError_t launch_pred_bi(hipStream_t, int S, int taps, int bd, int maxw, int maxh, void *, long, const void *, long, const void *, int);
@@ -356,6 +357,14 @@ int havoc_mi355x_satd_multi(havoc_mi355x_ctx *ctx, int S, int max_w, int max_h, 
     REQUIRE_CTX(); REQUIRE_S(); REQUIRE(njobs >= 0, "njobs < 0");
     REQUIRE(max_w >= 2 && max_w <= 64 && max_h >= 2 && max_h <= 64, "max_w / max_h must be 2..64");
     return check(launch_satd_multi(LS(ctx), S, max_w, max_h, d_a, stride_a, d_b, stride_b, d_jobs, njobs, d_out), "satd_multi");
+}
+
+int havoc_mi355x_pad_block(havoc_mi355x_ctx *ctx, int S, void *d_plane, int64_t origin_off, int width, int height, intptr_t stride, int pad, int top,
+                           int bottom, int left, int right)
+{
+    REQUIRE_CTX(); REQUIRE_S();
+    REQUIRE(width > 0 && height > 0 && pad >= 0, "width / height must be positive, pad >= 0");
+    return check(launch_pad_block(LS(ctx), S, d_plane, (long)origin_off, width, height, stride, pad, top, bottom, left, right), "pad_block");
 }
 
 int havoc_mi355x_ssd_linear(havoc_mi355x_ctx *ctx, const uint8_t *d_a, const uint8_t *d_b, int size, int32_t *d_out)

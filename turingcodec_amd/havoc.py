@@ -56,6 +56,7 @@ def _load():
         "join": [_vp],
         "sad": [_vp, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
         "sad4": [_vp, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
+        "pad_block": [_vp, _i, _vp, C.c_int64, _i, _i, _ip, _i, _i, _i, _i, _i],
         "sad_surface": [_vp, _i, _i, _i, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
         "ssd": [_vp, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
         "satd": [_vp, _i, _i, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
@@ -205,6 +206,15 @@ class Havoc:
     def sad_surface_d(self, src, ss, ref, rs, rng, max_w, max_h, jobs, out):
         self._ck(self.L.havoc_mi355x_sad_surface(self.h, self._S(src), rng, max_w, max_h, _ptr(src), ss, _ptr(ref), rs, _ptr(jobs),
                                                  jobs.shape[0], _ptr(out)))
+
+    def pad_block_d(self, plane, origin, w, h, stride, pad, top=True, bottom=True, left=True, right=True):
+        self._ck(self.L.havoc_mi355x_pad_block(self.h, self._S(plane), _ptr(plane), origin, w, h, stride, pad, int(top), int(bottom), int(left),
+                                               int(right)))
+
+    def pad_block(self, plane, origin, w, h, stride, pad, top=True, bottom=True, left=True, right=True):
+        d = self.up(plane)
+        self.pad_block_d(d, origin, w, h, stride, pad, top, bottom, left, right)
+        return self.down(d, plane.dtype)
 
     def sad4_d(self, src, ss, ref, rs, jobs, out):
         self._ck(self.L.havoc_mi355x_sad4(self.h, self._S(src), _ptr(src), ss, _ptr(ref), rs, _ptr(jobs), jobs.shape[0], _ptr(out)))
