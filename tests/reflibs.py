@@ -186,9 +186,10 @@ class Reference:
         L.ref_ssd_linear.argtypes = [C.c_int, _vp, _vp, C.c_int]
         L.ref_mask.restype = C.c_int
         L.ref_mask.argtypes = [C.c_int]
-        for sfx in ("u8", "u16"):
-            getattr(L, "ref_pad_block_" + sfx).restype = None
-            getattr(L, "ref_pad_block_" + sfx).argtypes = [_vp, C.c_int, C.c_int, _ip] + [C.c_int] * 5
+        for sfx in ("u8", "u16"):   # only in libhavoc_ref.so (ref_shim_turing.cpp), not in the classic-API client
+            if hasattr(L, "ref_pad_block_" + sfx):
+                getattr(L, "ref_pad_block_" + sfx).restype = None
+                getattr(L, "ref_pad_block_" + sfx).argtypes = [_vp, C.c_int, C.c_int, _ip] + [C.c_int] * 5
 
     @staticmethod
     def _sfx(a):
