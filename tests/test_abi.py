@@ -71,3 +71,21 @@ def test_product_does_not_touch_oracle():
                 if re.search(r"oracle|reflibs|liboracle|libhavoc_ref", s):
                     bad.append(os.path.join(base, f))
     assert not bad, bad
+
+
+def test_header_is_plain_c_and_links(lib, tmp_path):
+    """include/havoc_mi355x.h compiles as C99 with -Wall -Wextra -pedantic -Werror (no C++, no HIP, no torch types in
+    the boundary), and a C client that names every declared function links against libhavoc_mi355x.so"""
+    import turingcodec_amd
+    names = declared_symbols()
+    src = tmp_path / "client.c"
+    src.write_text('#include "havoc_mi355x.h"\n#include <stddef.h>\n'
+                   "typedef void (*fn)(void);\n"
+                   "size_t sizes[] = {sizeof(havoc_mi355x_pair_job), sizeof(havoc_mi355x_sad4_job), sizeof(havoc_mi355x_tu_fused_job)};\n"
+                   "fn table[] = {" + ", ".join(f"(fn){n}" for n in names) + "};\n"
+                   "int main(void) { return sizeof table / sizeof table[0] == " + str(len(names)) + " ? 0 : 1; }\n")
+    exe = tmp_path / "client"
+    libdir = os.path.dirname(turingcodec_amd.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           str(src), "-o", str(exe), "-L", libdir, "-lhavoc_mi355x", f"-Wl,-rpath,{libdir}", "-Wl,--allow-shlib-undefined"])
+    assert subprocess.call([str(exe)]) == 0
