@@ -214,6 +214,38 @@ __host__ __device__ constexpr int inv_angle_of(int mode)   // modes 11..25: -rou
     return -(int)(((i < 4 ? lo : hi) >> (13 * (i & 3))) & 0x1fff);
 }
 
+// ---- packed helpers of the intra kernels ------------------------------------------------------------------------
+
+// TS consecutive 16-bit LDS entries as TS/2 packed pairs; the address is only 2-byte aligned (gfx950 DS instructions
+// take unaligned addresses: one ds_read_b128 / b64 instead of TS ds_read_u16)
+typedef uint32_t __attribute__((ext_vector_type(4), aligned(2))) u32x4h;
+typedef uint32_t __attribute__((ext_vector_type(2), aligned(2))) u32x2h;
+
+template <int TS>
+__device__ __forceinline__ void ld_pairs(const uint16_t *q, uint32_t (&o)[TS / 2])
+{
+    if constexpr (TS == 8)
+    {
+        const u32x4h v = *reinterpret_cast<const u32x4h *>(q);
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    }
+    else
+    {
+        const u32x2h v = *reinterpret_cast<const u32x2h *>(q);
+        o[0] = v.x; o[1] = v.y;
+    }
+}
+
+// two angular samples at once: ((32 - f) * a + f * b + 16) >> 5 per 16-bit half.  Exact in 16 bits for samples < 2^11:
+// (32 - f) * a + f * b + 16 <= 32 * 2047 + 16 < 65536; f == 0 gives a (no special case).  w0 = (32-f, 32-f), w1 = (f, f)
+__device__ __forceinline__ uint32_t pk_lerp(uint32_t a, uint32_t b, uint32_t w0, uint32_t w1)
+{
+    const u16x2 r = {16, 16}, five = {5, 5};
+    u16x2 t = __builtin_bit_cast(u16x2, a) * __builtin_bit_cast(u16x2, w0) + r;
+    t = __builtin_bit_cast(u16x2, b) * __builtin_bit_cast(u16x2, w1) + t;
+    return __builtin_bit_cast(uint32_t, t >> five);
+}
+
 template <int S> struct Sample;
 template <> struct Sample<1> { typedef uint8_t T; };
 template <> struct Sample<2> { typedef uint16_t T; };

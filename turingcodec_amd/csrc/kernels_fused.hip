@@ -110,36 +110,6 @@ __device__ __forceinline__ int satd_regs_pk(uint32_t (&p)[TS][TS / 2])
     return (int)(sum / (TS / 2));
 }
 
-// TS consecutive 16-bit LDS entries as TS/2 packed pairs; the address is only 2-byte aligned (gfx950 DS instructions
-// take unaligned addresses: one ds_read_b128 / b64 instead of TS ds_read_u16)
-typedef uint32_t __attribute__((ext_vector_type(4), aligned(2))) u32x4h;
-typedef uint32_t __attribute__((ext_vector_type(2), aligned(2))) u32x2h;
-
-template <int TS>
-__device__ __forceinline__ void ld_pairs(const uint16_t *q, uint32_t (&o)[TS / 2])
-{
-    if constexpr (TS == 8)
-    {
-        const u32x4h v = *reinterpret_cast<const u32x4h *>(q);
-        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
-    }
-    else
-    {
-        const u32x2h v = *reinterpret_cast<const u32x2h *>(q);
-        o[0] = v.x; o[1] = v.y;
-    }
-}
-
-// two angular samples at once: ((32 - f) * a + f * b + 16) >> 5 per 16-bit half.  Exact in 16 bits for samples < 2^11:
-// (32 - f) * a + f * b + 16 <= 32 * 2047 + 16 < 65536; f == 0 gives a (no special case).  w0 = (32-f, 32-f), w1 = (f, f)
-__device__ __forceinline__ uint32_t pk_lerp(uint32_t a, uint32_t b, uint32_t w0, uint32_t w1)
-{
-    const u16x2 r = {16, 16}, five = {5, 5};
-    u16x2 t = __builtin_bit_cast(u16x2, a) * __builtin_bit_cast(u16x2, w0) + r;
-    t = __builtin_bit_cast(u16x2, b) * __builtin_bit_cast(u16x2, w1) + t;
-    return __builtin_bit_cast(uint32_t, t >> five);
-}
-
 // the difference tile of one work item: packed pairs for 8-bit samples, 32-bit for 16-bit samples
 template <int S, int TS>
 struct TileDiff
@@ -235,13 +205,38 @@ __global__ __launch_bounds__(THREADS) void k_intra_satd35(const char *__restrict
             s_srcT[p][(x + k) * NS + y] = v[k];
         }
     }
-    for (int i = lane; i < P * 2 * NB; i += THREADS)
+    // neighbour arrays, four samples per load (NB = 4N+1: N quads + the last sample)
+    constexpr int NQ = N + 1;
+    for (int i = lane; i < P * 2 * NQ; i += THREADS)
     {
-        const int p = i / (2 * NB), r = i - p * 2 * NB;
-        const int f = r / NB, k = r - f * NB;
-        const uint16_t v = reinterpret_cast<const T *>(neighbours)[s_job[p][1 + f] + k - 2 * N - 1];
-        s_nb[p][f][k] = v;
-        if (k <= 2 * N) s_left[p][f][2 * N - k] = v;
+        const int p = i / (2 * NQ), r = i - p * 2 * NQ;
+        const int f = r / NQ, k = (r - f * NQ) * 4;
+        const T *n0 = reinterpret_cast<const T *>(neighbours) + s_job[p][1 + f] - 2 * N - 1;
+        uint16_t v[4];
+        int cnt = 4;
+        if (k + 4 <= NB)
+        {
+            if (S == 1)
+            {
+                const uint32_t w = ld4(n0 + k);
+                v[0] = w & 0xff; v[1] = (w >> 8) & 0xff; v[2] = (w >> 16) & 0xff; v[3] = w >> 24;
+            }
+            else
+            {
+                const u32x2 w = ld8(n0 + k);
+                v[0] = w.x & 0xffff; v[1] = w.x >> 16; v[2] = w.y & 0xffff; v[3] = w.y >> 16;
+            }
+        }
+        else
+        {
+            cnt = NB - k;   // 1
+            v[0] = n0[k]; v[1] = v[2] = v[3] = 0;
+        }
+        for (int q = 0; q < cnt; ++q)
+        {
+            s_nb[p][f][k + q] = v[q];
+            if (k + q <= 2 * N) s_left[p][f][2 * N - k - q] = v[q];
+        }
     }
     __syncthreads();
 

@@ -38,7 +38,28 @@ __global__ __launch_bounds__(64) void k_intra(char *__restrict__ dst, long strid
     uint16_t *ref = s_ref[sub] + N;
     const int maxv = (1 << bitDepth) - 1;
 
-    for (int i = l; i < NBLEN; i += LANES) nb[i] = nbp[i - 2 * N - 1];
+    // 4N+1 neighbour samples, four per load (the array sits at an arbitrary sample offset: unaligned dword / qword loads)
+    {
+        const T *n0 = nbp - 2 * N - 1;
+        for (int i = 4 * l; i < NBLEN; i += 4 * LANES)
+        {
+            if (i + 4 <= NBLEN)
+            {
+                if (S == 1)
+                {
+                    const uint32_t v = ld4(n0 + i);
+                    nb[i] = v & 0xff; nb[i + 1] = (v >> 8) & 0xff; nb[i + 2] = (v >> 16) & 0xff; nb[i + 3] = v >> 24;
+                }
+                else
+                {
+                    const u32x2 v = ld8(n0 + i);
+                    nb[i] = v.x & 0xffff; nb[i + 1] = v.x >> 16; nb[i + 2] = v.y & 0xffff; nb[i + 3] = v.y >> 16;
+                }
+            }
+            else
+                for (int k = i; k < NBLEN; ++k) nb[k] = n0[k];
+        }
+    }
     __syncthreads();
 #define P_TOP(x) ((int)nb[2 * N + 1 + (x)])   /* p(x, -1), x = -1 .. 2N-1 */
 #define P_LEFT(y) ((int)nb[2 * N - 1 - (y)])  /* p(-1, y), y = -1 .. 2N-1 */
@@ -72,6 +93,97 @@ __global__ __launch_bounds__(64) void k_intra(char *__restrict__ dst, long strid
     }
     __syncthreads();
     if (!live) return;
+
+    if constexpr (N >= 8 && SPL == 16)
+    {
+        // one 4x4 sub-block per lane and step.  Angular modes: along the minor axis the samples of one major index are
+        // consecutive reference entries with one weight, so a line of four is two packed 16-bit lerps (pk_lerp) from one
+        // unaligned LDS vector read; horizontal modes are produced as columns and transposed in registers.
+        T *const d0 = d;
+        for (int sb = l; sb < N * N / 16; sb += LANES)
+        {
+            const int by = (sb / (N / 4)) * 4, bx = (sb - (sb / (N / 4)) * (N / 4)) * 4;
+            uint32_t rows[4][2];   // rows[i] = samples (bx .. bx+3, by + i) as two (lo, hi) 16-bit pairs
+            if (mode >= 2)
+            {
+                const int angle = angle_of(mode);
+                const bool vertical = mode >= 18;
+                const int maj0 = vertical ? by : bx, min0 = vertical ? bx : by;
+                const bool efilt = edge && min0 == 0 && angle == 0;
+                uint32_t q[4][2];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                {
+                    const int t = (maj0 + j + 1) * angle;
+                    const int idx = t >> 5, fact = t & 31;
+                    const uint16_t *r = ref + min0 + idx + 1;
+                    uint32_t ra[2], rb[2];
+                    ld_pairs<4>(r, ra);
+                    rb[0] = __builtin_amdgcn_alignbit(ra[1], ra[0], 16);
+                    rb[1] = __builtin_amdgcn_alignbit((uint32_t)r[4], ra[1], 16);
+                    const uint32_t w1 = (uint32_t)fact * 0x00010001u, w0 = 0x00200020u - w1;
+                    q[j][0] = pk_lerp(ra[0], rb[0], w0, w1);
+                    q[j][1] = pk_lerp(ra[1], rb[1], w0, w1);
+                    if (efilt)
+                    {   // pred_intra.cpp:20355-20360 / :20394-20399: first column (row) of the pure vertical (horizontal) mode
+                        const int side = vertical ? P_LEFT(maj0 + j) : P_TOP(maj0 + j);
+                        q[j][0] = (q[j][0] & 0xffff0000u) | (uint32_t)clip3(0, maxv, (int)ref[1] + ((side - (int)ref[0]) >> 1));
+                    }
+                }
+                if (vertical)
+                {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { rows[i][0] = q[i][0]; rows[i][1] = q[i][1]; }
+                }
+                else
+                {   // q[j] is column bx + j: 4x4 transpose of 16-bit values
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                    {
+                        const uint32_t sel = (i & 1) ? 0x07060302u : 0x05040100u;
+                        rows[i][0] = __builtin_amdgcn_perm(q[1][i >> 1], q[0][i >> 1], sel);
+                        rows[i][1] = __builtin_amdgcn_perm(q[3][i >> 1], q[2][i >> 1], sel);
+                    }
+                }
+            }
+            else
+            {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                {
+                    const int y = by + i;
+                    int v[4];
+#pragma unroll
+                    for (int o = 0; o < 4; ++o)
+                    {
+                        const int x = bx + o;
+                        if (mode == 0)
+                            v[o] = ((N - 1 - x) * P_LEFT(y) + (x + 1) * P_TOP(N) + (N - 1 - y) * P_TOP(x) + (y + 1) * P_LEFT(N) + N) >> (LOG2 + 1);
+                        else
+                        {
+                            v[o] = dc;
+                            if (edge)
+                            {
+                                if (x == 0 && y == 0) v[o] = (P_LEFT(0) + 2 * dc + P_TOP(0) + 2) >> 2;
+                                else if (y == 0) v[o] = (P_TOP(x) + 3 * dc + 2) >> 2;
+                                else if (x == 0) v[o] = (P_LEFT(y) + 3 * dc + 2) >> 2;
+                            }
+                        }
+                    }
+                    rows[i][0] = (uint32_t)v[0] | ((uint32_t)v[1] << 16);
+                    rows[i][1] = (uint32_t)v[2] | ((uint32_t)v[3] << 16);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+            {
+                T *o4 = d0 + (by + i) * stride_dst + bx;
+                if (S == 1) st4(o4, __builtin_amdgcn_perm(rows[i][1], rows[i][0], 0x06040200u));   // low byte of each 16-bit sample
+                else st8(o4, u32x2{rows[i][0], rows[i][1]});
+            }
+        }
+        return;
+    }
 
     for (int q = l; q < N * N / 4; q += LANES)
     {
@@ -127,7 +239,7 @@ static hipError_t launch_intra_s(hipStream_t st, int log2, int bitDepth, void *d
     {
 #define LAUNCH(l2, spl) hipLaunchKernelGGL((k_intra<S, l2, spl>), dim3((n + 64 / ((1 << (2 * l2)) / spl) - 1) / (64 / ((1 << (2 * l2)) / spl))), dim3(64), 0, st, d, sd, p, j, n, bitDepth)
     case 2: LAUNCH(2, 4); break;     // 16 jobs per wavefront
-    case 3: LAUNCH(3, 8); break;     // 8
+    case 3: LAUNCH(3, 16); break;    // 16
     case 4: LAUNCH(4, 16); break;    // 4
     case 5: LAUNCH(5, 16); break;    // 1
 #undef LAUNCH
