@@ -18,7 +18,12 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_se
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_overlap8 -- $B --steps 10 --warmup 2 > $O/${tag}_overlap8_bench.log 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${tag}_fetch -- $B --steps 2 --warmup 1 --kernel-reps 1 > /dev/null 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${tag}_write -- $B --steps 2 --warmup 1 --kernel-reps 1 > /dev/null 2>&1
+# SQ counter passes (two sets that fit the hardware's counter slots); summarised into profiles/<tag>_sq_counters.csv
+timeout 300 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/${tag}_sq1 -- $B --steps 2 --warmup 1 --kernel-reps 1 --lanes 1 --no-graph > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_SALU --output-format csv -d $O/${tag}_sq2 -- $B --steps 2 --warmup 1 --kernel-reps 1 --lanes 1 --no-graph > /dev/null 2>&1
 cd $R
+python profiles/summarize.py --sq $tag $O/${tag}_sq1 $O/${tag}_sq2 > $O/${tag}_sq_summary.txt 2>&1
+cp profiles/${tag}_sq_counters.csv $O/ 2>/dev/null
 # the traffic table must exist before the final bench line so that roofline.traffic is filled from it
 python profiles/summarize.py $tag $O/${tag}_serial $O/${tag}_fetch $O/${tag}_write > $O/${tag}_summary.txt 2>&1
 cp profiles/${tag}_kernel_stats.csv profiles/${tag}_hbm_traffic.csv $O/ 2>/dev/null

@@ -24,7 +24,37 @@ def short(name):
     return name.split("(")[0]
 
 
+def sq_summary(tag, dirs):
+    """per kernel: mean SQ counters per launch and the derived occupancy figures the DESIGN.md bound discussion quotes
+    (the SQ counters are summed over all SIMDs/CUs of the device)"""
+    here = os.path.dirname(os.path.abspath(__file__))
+    frames = []
+    for d in dirs:
+        c = pd.read_csv(find(d, "counter_collection.csv"))
+        c = c[c["Kernel_Name"].str.contains("havoc_gpu")].copy()
+        c["Kernel"] = c["Kernel_Name"].map(short)
+        frames.append(c.pivot_table(index="Kernel", columns="Counter_Name", values="Counter_Value", aggfunc="mean"))
+    t = pd.concat(frames, axis=1)
+    # derived figures with rocprof's own formulas (VALUBusy = 100 * SQ_ACTIVE_INST_VALU * 4 / SIMD_NUM / GRBM_GUI_ACTIVE,
+    # LDSBankConflict = 100 * SQ_LDS_BANK_CONFLICT / GRBM_GUI_ACTIVE / CU_NUM); the reported counter values are sums
+    # over the 8 XCDs, so GRBM_GUI_ACTIVE is divided by 8 to get the kernel's busy cycles (checks against the
+    # kernel-trace duration x 2.4 GHz)
+    if {"SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE"} <= set(t.columns):
+        cyc = t["GRBM_GUI_ACTIVE"] / 8.0
+        t["busy_us_at_2.4GHz"] = cyc / 2400.0
+        t["VALUBusy_pct"] = 100.0 * 4 * t["SQ_ACTIVE_INST_VALU"] / 1024.0 / cyc
+        t["LDS_issue_pct"] = 100.0 * 4 * t["SQ_ACTIVE_INST_LDS"] / 1024.0 / cyc
+        t["LDSBankConflict_pct"] = 100.0 * t["SQ_LDS_BANK_CONFLICT"] / cyc / 256.0
+    if {"SQ_INSTS_VALU", "SQ_WAVES"} <= set(t.columns):
+        t["valu_insts_per_wave"] = t["SQ_INSTS_VALU"] / t["SQ_WAVES"].clip(lower=1)
+        t["lds_insts_per_wave"] = t["SQ_INSTS_LDS"] / t["SQ_WAVES"].clip(lower=1)
+    t.round(2).to_csv(os.path.join(here, f"{tag}_sq_counters.csv"))
+    print(t.round(2).to_string())
+
+
 def main():
+    if sys.argv[1] == "--sq":
+        return sq_summary(sys.argv[2], sys.argv[3:])
     tag, stats_dir = sys.argv[1], sys.argv[2]
     here = os.path.dirname(os.path.abspath(__file__))
     st = pd.read_csv(find(stats_dir, "kernel_stats.csv"))
