@@ -95,8 +95,9 @@ __global__ __launch_bounds__(256) void k_interp_planes(char *__restrict__ planes
                 T *o = out + (long)j * stride;
                 if (CPL == 2 && pair)
                 {   // one 2-sample store per lane: 64 lanes cover 128 contiguous samples of the row
-                    if (S == 1) *reinterpret_cast<uint16_t __attribute__((aligned(1))) *>(o) = (uint16_t)(v[0] | (v[1] << 8));
-                    else st4(o, (uint32_t)v[0] | ((uint32_t)v[1] << 16));
+                    const int v1 = v[CPL - 1];
+                    if (S == 1) *reinterpret_cast<uint16_t __attribute__((aligned(1))) *>(o) = (uint16_t)(v[0] | (v1 << 8));
+                    else st4(o, (uint32_t)v[0] | ((uint32_t)v1 << 16));
                 }
                 else
                     o[0] = (T)v[0];
