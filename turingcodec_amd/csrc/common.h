@@ -66,6 +66,17 @@ __device__ __forceinline__ int group_sum(int v)
     return v;
 }
 
+// XCD-aware block index.  Workgroup b is observed to run on XCD b % 8 (MI355X_MICROARCH.md, "Workgroup dispatch": for
+// speed only, nothing depends on it), and every XCD has its own 4 MB L2.  Job tables are in picture (CTU raster)
+// order, so handing XCD x the x-th CONTIGUOUS eighth of the blocks keeps each L2 on one band of the picture instead of
+// all eight L2s holding all of it.  A bijection of [0, nb) for any nb.
+__device__ __forceinline__ int xcd_block(int b, int nb)
+{
+    const int q = nb >> 3, r = nb & 7;
+    const int x = b & 7, i = b >> 3;
+    return x * q + min(x, r) + i;
+}
+
 __device__ __forceinline__ int clip3(int lo, int hi, int v) { return min(max(v, lo), hi); }
 
 // exact y = i / d for 0 <= i < 2^12.3 (i*d_err < 2^20) and 2 <= d <= 128: one multiply instead of an integer division

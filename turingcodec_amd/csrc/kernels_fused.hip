@@ -169,7 +169,7 @@ __global__ __launch_bounds__(THREADS) void k_intra_satd35(const char *__restrict
     __shared__ int s_job[P][8];
 
     const int lane = threadIdx.x;
-    const int job0 = blockIdx.x * P;
+    const int job0 = xcd_block(blockIdx.x, gridDim.x) * P;
     const int maxv = (1 << bitDepth) - 1;
 
     for (int i = lane; i < P * 8; i += THREADS)

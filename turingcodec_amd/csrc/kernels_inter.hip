@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void k_pred(char *__restrict__ dst, long strid
     __shared__ __attribute__((aligned(16))) uint16_t s_out[JPW][MAXH * OS + 2];
 
     const int sub = threadIdx.x / G, l = threadIdx.x - sub * G;
-    const int job = blockIdx.x * JPW + sub;
+    const int job = xcd_block(blockIdx.x, gridDim.x) * JPW + sub;
     const bool live = job < njobs;
     // havoc_mi355x_pred_uni_job: dst, ref, w, h, xFrac, yFrac | havoc_mi355x_pred_bi_job: dst, ref0, ref1, w, h, 4 fracs
     const int32_t *j = jobs + (long)(live ? job : 0) * (BI ? 12 : 8);
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void k_subtract_bi(char *__restrict__ dst, lon
                                                      int bitDepth)
 {
     typedef typename Sample<S>::T T;
-    const int job = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int job = xcd_block(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (job >= njobs) return;
     const int32_t *j = jobs + job * 8;   // havoc_mi355x_subtract_bi_job

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(64) void k_intra(char *__restrict__ dst, long strid
 
     const int sub = threadIdx.x / LANES;
     const int l = threadIdx.x - sub * LANES;
-    const int job = blockIdx.x * JPW + sub;
+    const int job = xcd_block(blockIdx.x, gridDim.x) * JPW + sub;
     const bool live = job < njobs;
     const int32_t *j = jobs + (live ? job : 0) * 8;   // havoc_mi355x_intra_job
     const int mode = j[3];

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void k_sad(const char *__restrict__ src, long 
                                              const int32_t *__restrict__ jobs, int njobs, int32_t *__restrict__ out)
 {
     typedef typename Sample<S>::T T;
-    const int job = (blockIdx.x * 256 + threadIdx.x) / kSadLanes;
+    const int job = (xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x) / kSadLanes;
     const int lane = threadIdx.x & (kSadLanes - 1);
     const bool live = job < njobs;
     int so, w, h;
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void k_ssd(const char *__restrict__ pa, long s
                                              const int32_t *__restrict__ jobs, int njobs, uint32_t *__restrict__ out)
 {
     typedef typename Sample<S>::T T;
-    const int job = (blockIdx.x * 256 + threadIdx.x) / kSadLanes;
+    const int job = (xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x) / kSadLanes;
     const int lane = threadIdx.x & (kSadLanes - 1);
     const bool live = job < njobs;
     const int32_t *j = jobs + (long)(live ? job : 0) * 4;
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void k_satd(const char *__restrict__ pa, long 
                                               const int32_t *__restrict__ jobs, int njobs, int32_t *__restrict__ out)
 {
     typedef typename Sample<S>::T T;
-    const int job = (blockIdx.x * 256 + threadIdx.x) / G;
+    const int job = (xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x) / G;
     const int l = threadIdx.x & (G - 1);
     const bool live = job < njobs;
     const int32_t *j = jobs + (long)(live ? job : 0) * 4;
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) void k_satd_multi(const char *__restrict__ pa,
 {
     typedef typename Sample<S>::T T;
     constexpr int SL = kSatdMulti / CPS;             // slices per job
-    const int grp = (blockIdx.x * 256 + threadIdx.x) / G;
+    const int grp = (xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x) / G;
     const int job = grp / SL, k0 = (grp - job * SL) * CPS;
     const int l = threadIdx.x & (G - 1);
     const bool live = job < njobs;

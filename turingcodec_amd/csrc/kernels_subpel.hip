@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void k_subpel_satd(const char *__restrict__ sr
     __shared__ int s_total[JPW];
 
     const int sub = threadIdx.x / G, l = threadIdx.x - sub * G;
-    const int job = blockIdx.x * JPW + sub;
+    const int job = xcd_block(blockIdx.x, gridDim.x) * JPW + sub;
     const bool live = job < njobs;
     const int32_t *j = jobs + (long)(live ? job : 0) * 8;   // havoc_mi355x_pred_uni_job; dst_off = source block offset
     const int w = j[2], h = j[3], xFrac = j[4], yFrac = j[5];

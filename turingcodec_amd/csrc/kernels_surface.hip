@@ -148,7 +148,7 @@ __global__ __launch_bounds__(kSurfThreads) void k_sad_surface(const char *__rest
     const int tid = threadIdx.x;
     const int dyb = blockIdx.y * g.bd;               // first dy index (0 = -R) of this band
     const int nd = min(g.bd, g.side - dyb);          // candidate rows of this band
-    const int job0 = blockIdx.x * g.jpw;
+    const int job0 = xcd_block(blockIdx.x, gridDim.x) * g.jpw;
     const int nj = min(g.jpw, njobs - job0);
     const long ssb = stride_src * S, rsb = stride_ref * S;
 

@@ -22,7 +22,7 @@ __global__ __launch_bounds__(64) void k_transform(int16_t *__restrict__ coeffs, 
     constexpr int N = 1 << LOG2, TPW = 64 / N, LS = N + 2;
     __shared__ int16_t lds[TPW][N * LS];
     const int t = threadIdx.x / N, r = threadIdx.x % N;
-    const int job = blockIdx.x * TPW + t;
+    const int job = xcd_block(blockIdx.x, gridDim.x) * TPW + t;
     const bool live = job < njobs;
     const int32_t *j = jobs + (live ? job : 0) * 4;   // havoc_mi355x_tu_job
     const int shift1 = LOG2 - 1 + bitDepth - 8, shift2 = LOG2 + 6;
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(64) void k_inverse_transform(char *dst, long stride
     constexpr int N = 1 << LOG2, TPW = 64 / N, LS = N + 2;
     __shared__ int16_t lds[TPW][N * LS];
     const int t = threadIdx.x / N, r = threadIdx.x % N;
-    const int job = blockIdx.x * TPW + t;
+    const int job = xcd_block(blockIdx.x, gridDim.x) * TPW + t;
     const bool live = job < njobs;
     const int32_t *j = jobs + (live ? job : 0) * 4;
     const int shift2 = 20 - bitDepth;
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(64) void k_inverse_transform(char *dst, long stride
 __global__ __launch_bounds__(256) void k_quantize(int16_t *__restrict__ dst, const int16_t *__restrict__ src, const int32_t *__restrict__ jobs,
                                                   int njobs, int32_t *__restrict__ cbf)
 {
-    const int job = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int job = xcd_block(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (job >= njobs) return;
     const int32_t *j = jobs + job * 8;   // havoc_mi355x_quant_job
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void k_quantize(int16_t *__restrict__ dst, con
 __global__ __launch_bounds__(256) void k_quantize_inverse(int16_t *__restrict__ dst, const int16_t *__restrict__ src,
                                                           const int32_t *__restrict__ jobs, int njobs)
 {
-    const int job = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int job = xcd_block(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (job >= njobs) return;
     const int32_t *j = jobs + job * 8;
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void k_quantize_reconstruct(uint8_t *__restric
                                                               long stride_pred, const int16_t *__restrict__ res,
                                                               const int32_t *__restrict__ jobs, int njobs, int log2)
 {
-    const int job = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int job = xcd_block(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (job >= njobs) return;
     const int32_t *j = jobs + job * 4;   // tu_job: [1] res_off, [2] pred_off, [3] dst_off
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void k_residual(int16_t *__restrict__ res, lon
                                                   const int32_t *__restrict__ jobs, int njobs)
 {
     typedef typename Sample<S>::T T;
-    const int job = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int job = xcd_block(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (job >= njobs) return;
     const int32_t *j = jobs + job * 4;

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(64) void k_tu_forward(int16_t *__restrict__ coeffs,
     constexpr int N = 1 << LOG2, TPW = 64 / N, LS = N + 2;
     __shared__ int16_t lds[TPW][N * LS];
     const int t = threadIdx.x / N, r = threadIdx.x % N;
-    const int job = blockIdx.x * TPW + t;
+    const int job = xcd_block(blockIdx.x, gridDim.x) * TPW + t;
     const bool live = job < njobs;
     const int32_t *j = jobs + (long)(live ? job : 0) * 4;
     const int shift1 = LOG2 - 1 + bitDepth - 8, shift2 = LOG2 + 6;
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(64) void k_tu_reconstruct(char *rec, long stride_re
     constexpr int N = 1 << LOG2, TPW = 64 / N, LS = N + 2;
     __shared__ int16_t lds[TPW][N * LS];
     const int t = threadIdx.x / N, r = threadIdx.x % N;
-    const int job = blockIdx.x * TPW + t;
+    const int job = xcd_block(blockIdx.x, gridDim.x) * TPW + t;
     const bool live = job < njobs;
     const int32_t *j = jobs + (long)(live ? job : 0) * 4;
     const int shift2 = 20 - bitDepth;
