@@ -45,6 +45,9 @@ def parse_args():
                     help="integer ME as per-pattern SAD4 jobs (the reference's call mix) or as one SAD surface per search")
     ap.add_argument("--ime-range", type=int, default=16, help="surface half-width R: (2R+1)^2 candidates per search")
     ap.add_argument("--tune", type=int, default=16, help="lane assignments tried by the set-up planner (0: round-robin)")
+    ap.add_argument("--pcie", action="store_true",
+                    help="diagnostic: every step also moves the frame's host traffic over PCIe (source picture, job tables and "
+                         "quantised levels up; costs and coefficients down) -- the PCIe-inclusive rate of DESIGN.md, never the metric")
     ap.add_argument("--skip", default="", help="diagnostic: comma-separated launch groups to leave out (the result is then "
                                                "NOT the metric; the JSON line says so)")
     ap.add_argument("--exchange", action="store_true",
@@ -663,11 +666,36 @@ def main():
     else:
         graph = hv.graph_capture(lambda: dev.step(args.lanes))
 
+    host_io = None
+    if args.pcie:
+        # what a host-side encoder exchanges per picture: up = source planes, every job table, the levels its RDOQ
+        # produced; down = every cost the decision loops read, the coefficients RDOQ needs, the TU SSDs.  Reference
+        # pictures and reconstructions stay on the device.  Pinned staging buffers, async copies on the compute stream.
+        ups = [dev.luma[:wl.plane_len], dev.chroma[:wl.cplane_len], dev.j_sad4, dev.j_sad, dev.j_sbi, dev.j_satd]
+        ups += [g["jobs"] for g in dev.subpel_planes.values()] + [g["jobs"] for g in dev.isearch.values()] + [g["jobs"] for g in dev.intra.values()]
+        ups += [g["nb"] for g in dev.isearch.values()] + [g["nb"] for g in dev.intra.values()]
+        ups += [t for g in dev.tu.values() for t in (g["fjobs"], g["level"])]
+        downs = [dev.o_sad4, dev.o_sad, dev.o_satd] + [g["cost"] for g in dev.subpel_planes.values()] + [g["cost"] for g in dev.isearch.values()]
+        downs += [t for g in dev.tu.values() for t in (g["coef"], g["ossd"])]
+        host_io = ([(t, torch.empty_like(t, device="cpu").pin_memory()) for t in ups],
+                   [(t, torch.empty_like(t, device="cpu").pin_memory()) for t in downs])
+        for t, hb in host_io[0]:
+            hb.copy_(t)
+        pcie_bytes = (sum(t.numel() * t.element_size() for t in ups), sum(t.numel() * t.element_size() for t in downs))
+
     def one_step(i):
+        if host_io is not None:
+            with torch.cuda.stream(compute):
+                for t, hb in host_io[0]:
+                    t.copy_(hb, non_blocking=True)
         if graph is not None:
             hv.graph_launch(graph)
         else:
             dev.step(args.lanes)
+        if host_io is not None:
+            with torch.cuda.stream(compute):
+                for t, hb in host_io[1]:
+                    hb.copy_(t, non_blocking=True)
         if exch is not None:
             # compute stream: [picture i] [owner copies its reconstruction into the DPB mirror] [picture i+1] ...
             # exchange stream:                          [wait staged_i] [broadcasts of picture i] ...
@@ -743,6 +771,9 @@ def main():
                            "kernel_gbs": {k: round(kbytes[k] / (v * 1e-3) / 1e9, 1) for k, v in ktimes.items()}},
             "checksum": dev.checksum(),
         }
+        if args.pcie:
+            out["metric"] = (f"DIAGNOSTIC (PCIe-inclusive: {pcie_bytes[0]} B up, {pcie_bytes[1]} B down per step, serial with the "
+                             "kernels) -- not the benchmark metric")
         if args.skip:
             out["metric"] = "DIAGNOSTIC (launch groups skipped: " + args.skip + ") -- not the benchmark metric"
         if world == 1 and not args.no_cpu_baseline:
