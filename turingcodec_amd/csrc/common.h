@@ -156,9 +156,9 @@ __device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b)
 }
 __device__ __forceinline__ uint32_t pk_bfly(uint32_t v)   // (a, b) -> (a + b, a - b)
 {
-    const s16x2 t = __builtin_bit_cast(s16x2, __builtin_amdgcn_alignbit(v, v, 16));   // (b, a)
-    const s16x2 sgn = {1, -1};
-    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, v) * sgn + t);
+    const u16x2 t = __builtin_bit_cast(u16x2, __builtin_amdgcn_alignbit(v, v, 16));   // (b, a)
+    const u16x2 sgn = {1, 0xffff};   // unsigned form: the low 16 bits are those of the signed product, and it selects v_pk_mad_u16
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, v) * sgn + t);
 }
 __device__ __forceinline__ uint32_t pk_abs_acc(uint32_t v, uint32_t acc)   // acc + |v.lo| + |v.hi|
 {
@@ -249,12 +249,17 @@ __device__ __forceinline__ void ld_pairs(const uint16_t *q, uint32_t (&o)[TS / 2
 
 // two angular samples at once: ((32 - f) * a + f * b + 16) >> 5 per 16-bit half.  Exact in 16 bits for samples < 2^11:
 // (32 - f) * a + f * b + 16 <= 32 * 2047 + 16 < 65536; f == 0 gives a (no special case).  w0 = (32-f, 32-f), w1 = (f, f)
+__device__ __forceinline__ uint32_t pk_mad_u16(uint32_t a, uint32_t b, uint32_t c)   // per 16-bit half: a * b + c (mod 2^16)
+{
+    uint32_t d;
+    asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));   // the compiler splits a*b+c+k into mul, mad, add
+    return d;
+}
 __device__ __forceinline__ uint32_t pk_lerp(uint32_t a, uint32_t b, uint32_t w0, uint32_t w1)
 {
-    const u16x2 r = {16, 16}, five = {5, 5};
-    u16x2 t = __builtin_bit_cast(u16x2, a) * __builtin_bit_cast(u16x2, w0) + r;
-    t = __builtin_bit_cast(u16x2, b) * __builtin_bit_cast(u16x2, w1) + t;
-    return __builtin_bit_cast(uint32_t, t >> five);
+    const u16x2 five = {5, 5};
+    const uint32_t t = pk_mad_u16(b, w1, pk_mad_u16(a, w0, 0x00100010u));
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, t) >> five);
 }
 
 template <int S> struct Sample;
