@@ -84,6 +84,8 @@ class ReferenceExchange:
 
     def __init__(self, dist, rank: int, world: int, recon_luma, recon_chroma, slots: int = 6, n_sops: int = 64,
                  single_rank_broadcast: bool = False, recon_chroma2=None):
+        import torch
+        self._torch = torch
         self.dist, self.rank, self.world = dist, rank, world
         self.single_rank_broadcast = single_rank_broadcast   # exercise the collective even when world == 1
         self.recon_luma, self.recon_chroma = recon_luma, recon_chroma
@@ -109,10 +111,11 @@ class ReferenceExchange:
         pic = self.picture_of(step, self.rank)
         if pic.is_reference:
             slot = self.slot_of(pic, self.slots)
-            self.dpb_luma[slot].copy_(self.recon_luma)
-            self.dpb_chroma[slot].copy_(self.recon_chroma)
+            dst, src = [self.dpb_luma[slot], self.dpb_chroma[slot]], [self.recon_luma, self.recon_chroma]
             if self.recon_chroma2 is not None:
-                self.dpb_chroma2[slot].copy_(self.recon_chroma2)
+                dst.append(self.dpb_chroma2[slot])
+                src.append(self.recon_chroma2)
+            self._torch._foreach_copy_(dst, src)   # one launch for the planes (this sits between two pictures' kernels)
 
     def send(self, step: int):
         for src in range(self.world):
