@@ -2,9 +2,9 @@
 // (reference: havoc/pred_intra.cpp:20282-20401; neighbour layout havoc/pred_intra.cpp:43-51).
 //
 // Work mapping: a launch is uniform in block size (as the reference's table is indexed by log2TrafoSize,
-// havoc/pred_intra.h:39-52); each job is owned by a group of LANES = min(64, n*n/4) lanes (4 samples each), so 4x4 blocks run 16 to a
-// wavefront and 32x32 blocks give each lane 16 samples.  The 4n+1 neighbour samples and the projected angular
-// reference array live in LDS; every predicted sample is a two-tap blend read from there.
+// havoc/pred_intra.h:39-52); a job is owned by n*n/16 lanes (8x8: 4, 16x16: 16, 32x32: 64; 4x4 blocks: 4 lanes of 4
+// samples), each producing 4x4 sub-blocks, so a wavefront carries 16 / 16 / 4 / 1 jobs.  The 4n+1 neighbour samples
+// and the projected angular reference array live in LDS; a line of four angular samples is two packed 16-bit lerps.
 #include "common.h"
 
 namespace havoc_gpu {

@@ -1,10 +1,12 @@
 // Distortion metrics: SAD, 4-way SAD, SSD, Hadamard SATD, linear SSD.
 //
-// Work mapping (all kernels): one wavefront (64 lanes) per job, four jobs per 256-thread workgroup, so a launch
-// of N jobs is N/4 workgroups (>> 256 CUs for any real batch).  Each lane loads 4/8/16-byte row chunks straight
-// from HBM/L2 (rows of a block are contiguous, candidate positions are arbitrary, hence the unaligned vector
-// loads), accumulates with the packed byte/word SAD and dot instructions, and the 64 partial sums are folded
-// with DPP row shifts/broadcasts -- integer arithmetic only, no LDS, no MFMA.
+// Work mapping: a job (one block pair, or one block against 4 / up to 16 candidates) is owned by a GROUP of lanes -- 16
+// lanes (one DPP row) for SAD / SSD, 8..64 lanes (one per 8-sample tile row) for SATD -- so a 256-thread workgroup
+// carries 4..32 jobs and a frame's batch is thousands of workgroups.  Each lane loads 4/8/16-byte row chunks straight
+// from L2/HBM (rows of a block are contiguous, candidate positions are arbitrary, hence the unaligned vector loads),
+// accumulates with the packed byte/word SAD and dot instructions or runs the packed Hadamard, and the group's partial
+// sums are folded with DPP row shifts / mirrors -- integer arithmetic only, no LDS, no MFMA.  Workgroup b takes the
+// b % 8-th contiguous eighth of the job table (xcd_block): one band of the picture per XCD L2.
 #include "common.h"
 
 namespace havoc_gpu {
