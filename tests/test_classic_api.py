@@ -49,7 +49,8 @@ def test_same_mangled_symbols_as_reference_library():
     api = [s for s in ref if ("populate" in s.lower() or s in ("havoc_new_code", "havoc_delete_code", "havoc_get_ssd_linear",
                                                                "havoc_instruction_set_support", "havoc_main",
                                                                "havoc_print_instruction_set_support"))
-           and "test" not in s.lower() and "populateAsm" not in s]   # populateAsm: internal helper of pred_intra.cpp
+           and "test" not in s.lower() and "populateAsm" not in s       # populateAsm: internal helper of pred_intra.cpp
+           and not s.startswith("_ZN5havoc5intra8populateI")]           # havoc::intra::populate<bitDepth, Sample>: ditto (out of line at -O1)
     assert len(api) >= 30
     missing = sorted(s for s in api if s not in ours)
     assert not missing, missing
