@@ -44,6 +44,9 @@ def parse_args():
     ap.add_argument("--ime", choices=["sad4", "surface"], default="sad4",
                     help="integer ME as per-pattern SAD4 jobs (the reference's call mix) or as one SAD surface per search")
     ap.add_argument("--ime-range", type=int, default=16, help="surface half-width R: (2R+1)^2 candidates per search")
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="pictures in flight per GPU: independent pictures (the B pictures of one hierarchy level) alternate on "
+                         "separate streams so that one picture's tail overlaps the next one's head")
     ap.add_argument("--tune", type=int, default=16, help="lane assignments tried by the set-up planner (0: round-robin)")
     ap.add_argument("--pcie", action="store_true",
                     help="diagnostic: every step also moves the frame's host traffic over PCIe (source picture, job tables and "
@@ -641,14 +644,28 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    # the compute stream is private (the step is captured into a HIP graph and replayed on it); it is created through
-    # torch only so that torch events can order it against the exchange stream
-    compute = torch.cuda.Stream(device=local)
-    hv = Havoc(local, stream=compute.cuda_stream)
+    # Each picture in flight has its own context: a private compute stream (the step is captured into a HIP graph and
+    # replayed on it; created through torch only so that torch events can order it against the exchange stream), its
+    # own picture store / job tables / outputs, its own planned graph.  Step i runs picture slot i % inflight.
     w, h = (int(v) for v in args.res.split("x"))
-    wl = FrameWorkload(w, h, args.bit_depth, args.seed + rank)   # every rank owns a different picture
-    dev = DeviceFrame(hv, wl, use_planes=(args.subpel == "planes"), fused_tu=(args.tu == "fused"),
-                      ime_range=args.ime_range if args.ime == "surface" else None, skip=[k for k in args.skip.split(",") if k])
+    inflight = 1 if (args.pcie or args.no_graph) else max(1, args.inflight)
+    slots = []
+    for k in range(inflight):
+        compute_k = torch.cuda.Stream(device=local)
+        hv_k = Havoc(local, stream=compute_k.cuda_stream)
+        wl_k = FrameWorkload(w, h, args.bit_depth, args.seed + rank + 1000 * k)   # every rank / slot owns a different picture
+        dev_k = DeviceFrame(hv_k, wl_k, use_planes=(args.subpel == "planes"), fused_tu=(args.tu == "fused"),
+                            ime_range=args.ime_range if args.ime == "surface" else None, skip=[s for s in args.skip.split(",") if s])
+        dev_k.step()          # first eager pass (loads the code objects) -- also what the graph must reproduce
+        hv_k.sync()
+        if args.no_graph:
+            graph_k = None
+        elif args.lanes > 1 and args.tune > 0:
+            graph_k, _ = dev_k.plan_lanes(args.lanes, args.tune)     # lane assignment chosen by measurement (set-up, untimed)
+        else:
+            graph_k = hv_k.graph_capture(lambda: dev_k.step(args.lanes))
+        slots.append((compute_k, hv_k, wl_k, dev_k, graph_k))
+    compute, hv, wl, dev, graph = slots[0]
     exch = None
     if grouped:
         from turingcodec_amd.frame_parallel import ReferenceExchange
@@ -656,15 +673,6 @@ def main():
         exch = ReferenceExchange(dist, rank, world, dev.luma[3 * wl.plane_len:4 * wl.plane_len], dev.chroma[:wl.cplane_len],
                                  single_rank_broadcast=args.exchange, recon_chroma2=dev.chroma[:wl.cplane_len])
         comm = torch.cuda.current_stream(local)   # torch.distributed enqueues behind this stream
-
-    dev.step()          # first eager pass (loads the code objects) -- also what the graph must reproduce
-    hv.sync()
-    if args.no_graph:
-        graph = None
-    elif args.lanes > 1 and args.tune > 0:
-        graph, _ = dev.plan_lanes(args.lanes, args.tune)     # lane assignment chosen by measurement (set-up, untimed)
-    else:
-        graph = hv.graph_capture(lambda: dev.step(args.lanes))
 
     host_io = None
     if args.pcie:
@@ -684,6 +692,7 @@ def main():
         pcie_bytes = (sum(t.numel() * t.element_size() for t in ups), sum(t.numel() * t.element_size() for t in downs))
 
     def one_step(i):
+        compute, hv, wl, dev, graph = slots[i % inflight]
         if host_io is not None:
             with torch.cuda.stream(compute):
                 for t, hb in host_io[0]:
@@ -697,10 +706,10 @@ def main():
                 for t, hb in host_io[1]:
                     hb.copy_(t, non_blocking=True)
         if exch is not None:
-            # compute stream: [picture i] [owner copies its reconstruction into the DPB mirror] [picture i+1] ...
+            # compute stream: [picture i] [owner copies its reconstruction into the DPB mirror] [next picture of the slot] ...
             # exchange stream:                          [wait staged_i] [broadcasts of picture i] ...
-            # -> the compute stream never waits for a broadcast of the current picture, only (for DPB slot re-use) for
-            #    the broadcasts of the previous one, which ran underneath this picture's kernels
+            # -> a compute stream never waits for a broadcast of the current picture, only (for DPB slot re-use) for
+            #    the broadcasts of the previous step, which ran underneath this picture's kernels
             if i > 0:
                 compute.wait_event(sent[(i - 1) & 1])
             if exch.picture_of(i, rank).is_reference:
@@ -709,7 +718,7 @@ def main():
                 hv.pad_block_d(dev.luma, 3 * wl.plane_len + 96 * wl.stride + 96, wl.width, wl.height, wl.stride, 96)
                 hv.pad_block_d(dev.chroma, 48 * wl.cstride + 48, wl.width // 2, wl.height // 2, wl.cstride, 48)
             with torch.cuda.stream(compute):
-                exch.stage(i)
+                exch.stage(i, (dev.luma[3 * wl.plane_len:4 * wl.plane_len], dev.chroma[:wl.cplane_len], dev.chroma[:wl.cplane_len]))
             staged[i & 1].record(compute)
             comm.wait_event(staged[i & 1])
             exch.send(i)
@@ -755,7 +764,7 @@ def main():
             "dtype": "u8" if args.bit_depth == 8 else "u16", "data": "synthetic",
             "config": {"workload": f"{args.res} {args.bit_depth}-bit 4:2:0 random-access QP32 speed=medium B-frame call mix "
                                    f"(SURVEY A.2 counts x {w * h / (1920 * 1080):.2f}; assumed PU/intra size mix), 1xMI355X per rank",
-                       "calls_per_frame": int(sum(wl.counts.values())), "launches_per_frame": len(dev.launches),
+                       "calls_per_frame": int(sum(wl.counts.values())), "launches_per_frame": len(dev.launches), "pictures_in_flight": inflight,
                        "integer_me": ("sad4 jobs (the reference's per-pattern calls)" if args.ime == "sad4" else
                                       f"{len(wl.me_search)} SAD surfaces of (2*{args.ime_range}+1)^2 candidates instead of "
                                       f"{len(wl.sad4)} SAD4 calls"),

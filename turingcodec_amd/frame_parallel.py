@@ -107,14 +107,17 @@ class ReferenceExchange:
     def slot_of(pic: Picture, slots: int) -> int:
         return (pic.poc // 2) % slots   # reference pictures have even POC inside a SOP (8 4 2 6) or are the IDR
 
-    def stage(self, step: int):
+    def stage(self, step: int, planes=None):
+        """`planes`: (luma, chroma[, chroma2]) of the picture being staged when the caller keeps several pictures in
+        flight; default: the tensors given at construction"""
         pic = self.picture_of(step, self.rank)
         if pic.is_reference:
             slot = self.slot_of(pic, self.slots)
-            dst, src = [self.dpb_luma[slot], self.dpb_chroma[slot]], [self.recon_luma, self.recon_chroma]
-            if self.recon_chroma2 is not None:
+            if planes is None:
+                planes = (self.recon_luma, self.recon_chroma) + ((self.recon_chroma2,) if self.recon_chroma2 is not None else ())
+            dst, src = [self.dpb_luma[slot], self.dpb_chroma[slot]], list(planes)
+            if len(src) > 2:
                 dst.append(self.dpb_chroma2[slot])
-                src.append(self.recon_chroma2)
             self._torch._foreach_copy_(dst, src)   # one launch for the planes (this sits between two pictures' kernels)
 
     def send(self, step: int):
