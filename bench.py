@@ -275,10 +275,12 @@ class DeviceFrame:
             for _ in range(2):
                 hv.graph_launch(g)
             hv.sync()
-            hv.timer_start()
-            for _ in range(8):
-                hv.graph_launch(g)
-            ms = hv.timer_stop_ms() / 8
+            ms = 1e30
+            for _ in range(3):   # best of three batches: one noisy batch must not decide the plan
+                hv.timer_start()
+                for _ in range(8):
+                    hv.graph_launch(g)
+                ms = min(ms, hv.timer_stop_ms() / 8)
             if ms < best[2]:
                 if best[1] is not None:
                     hv.graph_destroy(best[1])
