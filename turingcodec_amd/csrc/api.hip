@@ -260,6 +260,7 @@ int havoc_mi355x_graph_launch(havoc_mi355x_ctx *ctx, havoc_mi355x_graph *graph)
 void havoc_mi355x_graph_destroy(havoc_mi355x_graph *graph)
 {
     if (!graph) return;
+    (void)hipDeviceSynchronize();   // the executable graph must be idle on every internal stream before it goes
     (void)hipGraphExecDestroy(graph->exec);
     (void)hipGraphDestroy(graph->graph);
     delete graph;
