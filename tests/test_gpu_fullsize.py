@@ -134,3 +134,33 @@ def test_full_size_results_equal_the_reference_library(hv):
     p = r["parity_vs_reference"]
     assert "error" not in p, p
     assert p["compared"] > 10_000_000 and p["mismatches"] == 0, p
+
+
+def test_bench_line_contract():
+    """`python bench.py` prints ONE JSON line carrying every field of the driver's contract (plus roofline and
+    cpu_baseline), with the values the contract fixes"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "6", "--warmup", "2", "--tune", "4", "--kernel-reps", "1"],
+                         capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in r, k
+    assert r["n_gpus"] == 1 and r["steps"] == 6 and r["warmup"] == 2 and r["higher_is_better"] is True and r["scaling"] == "weak"
+    assert r["vs_baseline"] is None and r["dtype"] == "u8" and r["data"] == "synthetic" and r["unit"] == "frames/s"
+    assert "workload" in r["config"] and "model" not in r["config"]
+    assert abs(r["value"] - 1e3 / r["ms_per_step"]) / r["value"] < 0.01
+    rf = r["roofline"]
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(rf) and rf["bound"] == "hbm" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4
+    cb = r["cpu_baseline"]
+    if cb is not None:   # None only when oracle/_ref was never built
+        assert set(("value", "unit", "cores", "kind", "sample")) <= set(cb) and cb["kind"] == "reference" and cb["cores"] >= 1
+        assert cb["parity_vs_reference"]["mismatches"] == 0
