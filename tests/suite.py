@@ -182,7 +182,95 @@ def make_inputs(seed=20260927):
             j = d[f"{k}.pred_uni{taps}.jobs"].copy()
             j[:, 0] = [cases.off(*cases.rand_pos(rng, int(w), int(h))) for (w, h) in j[:, 2:4]]
             d[f"{k}.subpel{taps}.jobs"] = j
+    # ---- round-2 additions.  APPENDED: every draw above is unchanged, so the earlier golden arrays stay what they were ----
+    # (1) SAD / SAD4 at widths outside the 23 PU sizes -- the reference's sadGeneric entry (havoc/sad.h:77-89): 16-bit rows
+    #     of 34..62 samples (row bytes % 8 == 4 and > 64), odd widths, a non-PU multiple of 4
+    gen = [(34, 8), (38, 4), (62, 16), (46, 12), (7, 5), (13, 9), (33, 17), (63, 64), (20, 8), (5, 4)]
+    for S in (1, 2):
+        k = "u8" if S == 1 else "u16"
+        d[f"{k}.sadg.jobs"] = _pairs(rng, gen, 2)
+        d[f"{k}.sad4g.jobs"] = np.array([(so, *ros, w, h, 0) for (w, h, so, ros) in cases.sad4_cases(rng, gen, 1)], np.int32)
+    # (2) 9-bit content on the 16-bit path: the reference's tables have a 9-bit row (havoc/pred_inter.h:40, pred_intra.h:37)
+    d["u9.a"] = cases.rand_plane(rng, 2, 9).ravel()
+    d["u9.b"] = cases.rand_plane(rng, 2, 9).ravel()
+    d["u9.x"] = cases.rand_plane(rng, 2, 9, kind="extremes").ravel()
+    uni = cases.pred_uni_cases(rng, [9])
+    for taps in (8, 4):
+        j = np.array([(0, ro, w, h, xf, yf, 0, 0) for (t, w, h, xf, yf, _, ro) in uni if t == taps], np.int32)
+        j[:, 0] = np.arange(len(j)) * SLOT
+        d[f"u9.pred_uni{taps}.jobs"] = j
+        js = j.copy()
+        js[:, 0] = [cases.off(*cases.rand_pos(rng, int(w), int(h))) for (w, h) in j[:, 2:4]]
+        d[f"u9.subpel{taps}.jobs"] = js
+    bi = cases.pred_bi_cases(rng, [9])
+    for taps in (8, 4):
+        j = np.array([(0, r0, r1, w, h, a, b_, c, e, 0, 0, 0) for (t, w, h, a, b_, c, e, _, r0, r1) in bi if t == taps], np.int32)
+        j[:, 0] = np.arange(len(j)) * SLOT
+        d[f"u9.pred_bi{taps}.jobs"] = j
+    ic = [(log2, mode, 1) for log2 in (2, 3, 4, 5) for mode in range(35)] + [(log2, mode, 0) for log2 in (2, 3, 4, 5) for mode in (1, 10, 26)]
+    nbs, jobs = [], []
+    for i, (log2, mode, edge) in enumerate(ic):
+        nb, c = cases.rand_neighbours(rng, 2, 9, "extremes" if i % 5 == 2 else "uniform")
+        nbs.append(nb)
+        jobs.append((i * 1024, i * 160 + c, log2, mode, edge, 0, 0, 0))
+    d["u9.intra.nb"] = np.concatenate(nbs)
+    d["u9.intra.jobs"] = np.array(jobs, np.int32)
+    jobs, nbs = [], []
+    for log2 in (2, 3, 4, 5):
+        n = 1 << log2
+        for rep in range(3):
+            x, y = cases.rand_pos(rng, n, n)
+            nbu, c = cases.rand_neighbours(rng, 2, 9, "extremes" if rep == 2 else "uniform")
+            nbf, _ = cases.rand_neighbours(rng, 2, 9, "uniform")
+            base = sum(len(a) for a in nbs)
+            nbs += [nbu, nbf]
+            mask = int(rng.integers(0, 1 << 35))
+            jobs.append((cases.off(x, y), base + c, base + len(nbu) + c, mask & 0xffffffff, mask >> 32, rep != 1, log2, 0))
+    d["u9.intra35.nb"] = np.concatenate(nbs)
+    d["u9.intra35.jobs"] = np.array(jobs, np.int64).astype(np.uint32).view(np.int32).reshape(len(jobs), 8)
+    tj, coefs, co = [], [], 0
+    for (log2, tr) in cases.TRANSFORMS:
+        n = 1 << log2
+        for (lo, hi, kind) in [(-128, 127, "uniform"), (-511, 511, "uniform"), (-32768, 32767, "extremes")]:
+            x, y = cases.rand_pos(rng, n, n)
+            tj.append((co, 0, cases.off(x, y), len(tj) * SLOT, log2, tr, 0, 0))
+            coefs.append(cases.residual_block(rng, n, lo, hi, kind).ravel())
+            co += n * n
+    d["u9.itx.coeffs"] = np.concatenate(coefs)
+    d["u9.itx.jobs"] = np.array(tj, np.int32)
     return d
+
+
+def run_round2(impl, d, want, out):
+    """the round-2 additions of make_inputs (generic-width SAD, 9-bit on the 16-bit path)"""
+    for S in (1, 2):
+        k = "u8" if S == 1 else "u16"
+        if want(f"{k}.sadg"):
+            out[f"{k}.sadg"] = impl.sad(d[f"{k}.a"], W, d[f"{k}.b"], W, d[f"{k}.sadg.jobs"])
+            out[f"{k}.sadg.x"] = impl.sad(d[f"{k}.x"], W, d[f"{k}.b"], W, d[f"{k}.sadg.jobs"])
+            out[f"{k}.sad4g"] = impl.sad4(d[f"{k}.a"], W, d[f"{k}.b"], W, d[f"{k}.sad4g.jobs"])
+    a, x = d["u9.a"], d["u9.x"]
+    for taps in (8, 4):
+        if want("u9.pred_uni"):
+            j = d[f"u9.pred_uni{taps}.jobs"]
+            out[f"u9.pred_uni{taps}"] = impl.pred_uni(taps, 9, len(j) * SLOT, 64, a, W, j)
+            out[f"u9.pred_uni{taps}.x"] = impl.pred_uni(taps, 9, len(j) * SLOT, 64, x, W, j)
+        if want("u9.pred_bi"):
+            j = d[f"u9.pred_bi{taps}.jobs"]
+            out[f"u9.pred_bi{taps}"] = impl.pred_bi(taps, 9, len(j) * SLOT, 64, a, W, j)
+            out[f"u9.pred_bi{taps}.x"] = impl.pred_bi(taps, 9, len(j) * SLOT, 64, x, W, j)
+        if want("u9.subpel"):
+            out[f"u9.subpel{taps}"] = impl.subpel_satd(taps, 9, d["u9.b"], W, a, W, d[f"u9.subpel{taps}.jobs"])
+    if want("u9.intra"):
+        j = d["u9.intra.jobs"]
+        out["u9.intra"] = impl.intra(9, len(j) * 1024, 32, d["u9.intra.nb"], j)
+    if want("u9.intra35"):
+        out["u9.intra35"] = impl.intra_satd35(9, a, W, d["u9.intra35.nb"], d["u9.intra35.jobs"])
+    if want("u9.itx"):
+        j = d["u9.itx.jobs"]
+        out["u9.itx_add"] = impl.inverse_transform_add(9, len(j) * SLOT, 64, a, W, d["u9.itx.coeffs"], j)
+    if want("u9.planes"):
+        out["u9.planes"] = impl.interp_planes(9, a, W, 5, 6, 139, 141)
 
 
 def run(impl, d, keys=None):
@@ -270,6 +358,8 @@ def run(impl, d, keys=None):
             if want(f"{k}.subpel"):
                 out[f"{k}.subpel{taps}"] = impl.subpel_satd(taps, bd, d[f"{k}.b"], W, d[f"{k}.a"], W, d[f"{k}.subpel{taps}.jobs"])
                 out[f"{k}.subpel{taps}.x"] = impl.subpel_satd(taps, bd, d[f"{k}.b"], W, d[f"{k}.x"], W, d[f"{k}.subpel{taps}.jobs"])
+    if "u9.a" in d:
+        run_round2(impl, d, want, out)
     return out
 
 

@@ -22,7 +22,9 @@ def golden():
 
 GROUPS = ["u8.sad", "u16.sad", "u8.surface", "u16.surface", "u8.ssd", "u16.ssd", "u8.satd", "u16.satd", "u8.pred_uni", "u16.pred_uni", "u8.pred_bi",
           "u16.pred_bi", "subtract_bi", "u8.intra", "u16.intra", "residual", "u8.itx", "u16.itx", "fwd8", "fwd10",
-          "quant", "qrec", "ssd_linear", "u8.intra35", "u16.intra35", "u8.subpel", "u16.subpel", "u8.planes", "u16.planes", "u8.tuf", "u16.tuf"]
+          "quant", "qrec", "ssd_linear", "u8.intra35", "u16.intra35", "u8.subpel", "u16.subpel", "u8.planes", "u16.planes", "u8.tuf", "u16.tuf",
+          # round 2: generic-width SAD (the reference's sadGeneric entry) and the 9-bit rows of the 16-bit tables
+          "u8.sadg", "u16.sadg", "u9.pred_uni", "u9.pred_bi", "u9.subpel", "u9.intra", "u9.itx", "u9.planes"]
 
 
 @pytest.mark.parametrize("group", GROUPS)

@@ -84,7 +84,28 @@ static int check(hipError_t e, const char *where)
 
 #define REQUIRE(cond, what) \
     do { if (!(cond)) return fail(HAVOC_MI355X_EINVAL, what); } while (0)
-#define REQUIRE_CTX() REQUIRE(ctx != nullptr, "null context")
+
+// Every entry point runs with the context's device current on the calling thread and puts the caller's device back on
+// return (a process may hold contexts on several GPUs; hipMalloc, NULL-stream launches and event calls act on whatever
+// device is current).  hipSetDevice is only issued when the current device differs.
+struct DeviceGuard
+{
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int device)
+    {
+        if (hipGetDevice(&prev) == hipSuccess && prev != device) switched = hipSetDevice(device) == hipSuccess;
+    }
+    ~DeviceGuard()
+    {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+#define REQUIRE_CTX() \
+    REQUIRE(ctx != nullptr, "null context"); \
+    DeviceGuard device_guard_(ctx->device)
 #define REQUIRE_S() REQUIRE(S == 1 || S == 2, "S (bytes per sample) must be 1 or 2")
 #define REQUIRE_BD() REQUIRE(bitDepth >= 8 && bitDepth <= (S == 1 ? 8 : 10), "bitDepth must be 8 (S=1) or 8..10 (S=2)")
 
@@ -101,32 +122,27 @@ int havoc_mi355x_create(havoc_mi355x_ctx **out, int device, void *stream)
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0) return fail(HAVOC_MI355X_ENODEV, "no HIP device: libhavoc_mi355x has no CPU path");
     REQUIRE(device >= 0 && device < count, "device index out of range");
+    DeviceGuard device_guard_(device);   // the caller's current device is put back on return
     havoc_mi355x_ctx *c = new havoc_mi355x_ctx();
     c->device = device;
     c->ownsStream = stream == HAVOC_MI355X_NEW_STREAM;
     c->stream = c->ownsStream ? nullptr : (hipStream_t)stream;
-    int rc;
-    if ((rc = check(hipSetDevice(device), "hipSetDevice")) || (rc = check(hipGetDeviceProperties(&c->prop, device), "hipGetDeviceProperties")))
-    {
+    auto bail = [&](int rc) {   // undo whatever was created so far
+        if (c->ev0) (void)hipEventDestroy(c->ev0);
+        if (c->ev1) (void)hipEventDestroy(c->ev1);
+        if (c->ownsStream && c->stream) (void)hipStreamDestroy(c->stream);
         delete c;
         return rc;
-    }
+    };
+    int rc;
+    if ((rc = check(hipGetDeviceProperties(&c->prop, device), "hipGetDeviceProperties"))) return bail(rc);
     if (strncmp(c->prop.gcnArchName, "gfx950", 6) != 0)
     {
         snprintf(g_err, sizeof(g_err), "device %d is %s; this library contains gfx950 code only", device, c->prop.gcnArchName);
-        delete c;
-        return HAVOC_MI355X_ENODEV;
+        return bail(HAVOC_MI355X_ENODEV);
     }
-    if ((rc = check(hipEventCreate(&c->ev0), "hipEventCreate")) || (rc = check(hipEventCreate(&c->ev1), "hipEventCreate")))
-    {
-        delete c;
-        return rc;
-    }
-    if (c->ownsStream && (rc = check(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate")))
-    {
-        delete c;
-        return rc;
-    }
+    if ((rc = check(hipEventCreate(&c->ev0), "hipEventCreate")) || (rc = check(hipEventCreate(&c->ev1), "hipEventCreate"))) return bail(rc);
+    if (c->ownsStream && (rc = check(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate"))) return bail(rc);
     *out = c;
     return 0;
 }
@@ -134,6 +150,7 @@ int havoc_mi355x_create(havoc_mi355x_ctx **out, int device, void *stream)
 void havoc_mi355x_destroy(havoc_mi355x_ctx *ctx)
 {
     if (!ctx) return;
+    DeviceGuard device_guard_(ctx->device);
     for (int k = 1; k < havoc_mi355x_ctx::kMaxLanes; ++k)
         if (ctx->lanes[k])
         {
@@ -158,6 +175,11 @@ int havoc_mi355x_set_stream(havoc_mi355x_ctx *ctx, void *stream)
 int havoc_mi355x_sync(havoc_mi355x_ctx *ctx)
 {
     REQUIRE_CTX();
+    for (int k = 1; k < ctx->nlanes; ++k)   // lanes forked and not yet joined
+    {
+        const int rc = check(hipStreamSynchronize(ctx->lanes[k]), "hipStreamSynchronize(lane)");
+        if (rc) return rc;
+    }
     return check(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
 }
 
@@ -225,10 +247,26 @@ struct havoc_mi355x_graph
     hipGraphExec_t exec;
 };
 
+// side streams + their join events, created on first need and kept for the context's life
+static int ensure_lanes(havoc_mi355x_ctx *ctx, int nlanes)
+{
+    int rc;
+    if (!ctx->forkEv && (rc = check(hipEventCreateWithFlags(&ctx->forkEv, hipEventDisableTiming), "hipEventCreate"))) return rc;
+    for (int k = 1; k < nlanes; ++k)
+        if (!ctx->lanes[k])
+        {
+            if ((rc = check(hipStreamCreateWithFlags(&ctx->lanes[k], hipStreamNonBlocking), "hipStreamCreate"))) return rc;
+            if ((rc = check(hipEventCreateWithFlags(&ctx->laneEv[k], hipEventDisableTiming), "hipEventCreate"))) return rc;
+        }
+    return 0;
+}
+
 int havoc_mi355x_graph_begin(havoc_mi355x_ctx *ctx)
 {
     REQUIRE_CTX();
     REQUIRE(ctx->stream != nullptr, "graph capture needs a non-default stream (create the context with HAVOC_MI355X_NEW_STREAM)");
+    int rc = ensure_lanes(ctx, havoc_mi355x_ctx::kMaxLanes);   // a fork() inside the capture must not create streams / events
+    if (rc) return rc;
     return check(hipStreamBeginCapture(LS(ctx),hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
 }
 
@@ -274,17 +312,10 @@ int havoc_mi355x_fork(havoc_mi355x_ctx *ctx, int nlanes)
     REQUIRE(nlanes >= 1 && nlanes <= havoc_mi355x_ctx::kMaxLanes, "nlanes must be 1..8");
     REQUIRE(ctx->nlanes == 0, "already forked");
     int rc;
-    if (!ctx->forkEv && (rc = check(hipEventCreateWithFlags(&ctx->forkEv, hipEventDisableTiming), "hipEventCreate"))) return rc;
+    if ((rc = ensure_lanes(ctx, nlanes))) return rc;
     if ((rc = check(hipEventRecord(ctx->forkEv, ctx->stream), "hipEventRecord"))) return rc;
     for (int k = 1; k < nlanes; ++k)
-    {
-        if (!ctx->lanes[k])
-        {
-            if ((rc = check(hipStreamCreateWithFlags(&ctx->lanes[k], hipStreamNonBlocking), "hipStreamCreate"))) return rc;
-            if ((rc = check(hipEventCreateWithFlags(&ctx->laneEv[k], hipEventDisableTiming), "hipEventCreate"))) return rc;
-        }
         if ((rc = check(hipStreamWaitEvent(ctx->lanes[k], ctx->forkEv, 0), "hipStreamWaitEvent"))) return rc;
-    }
     ctx->nlanes = nlanes;
     ctx->cur = 0;
     return 0;

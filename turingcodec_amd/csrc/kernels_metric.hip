@@ -118,9 +118,11 @@ __global__ __launch_bounds__(256) void k_sad(const char *__restrict__ src, long 
     for (int k = 0; k < WAYS; ++k) acc[k] = 0;
 
     const int rowBytes = w * S;
-    if ((rowBytes & 15) == 0) sad_block<S, WAYS, 16>(s, ssb, r, rsb, rowBytes, h, lane, acc);
-    else if ((rowBytes & 7) == 0) sad_block<S, WAYS, 8>(s, ssb, r, rsb, rowBytes, h, lane, acc);
-    else if ((rowBytes & 3) == 0) sad_block<S, WAYS, 4>(s, ssb, r, rsb, rowBytes, h, lane, acc);
+    // a chunked path needs its chunks per row to fit the lane group (cpr <= kSadLanes), else rows-per-iteration is 0:
+    // 16-bit widths 34, 38 .. 62 (rowBytes % 8 == 4, > 64) take the generic loop like the odd widths
+    if ((rowBytes & 15) == 0 && rowBytes <= 16 * kSadLanes) sad_block<S, WAYS, 16>(s, ssb, r, rsb, rowBytes, h, lane, acc);
+    else if ((rowBytes & 7) == 0 && rowBytes <= 8 * kSadLanes) sad_block<S, WAYS, 8>(s, ssb, r, rsb, rowBytes, h, lane, acc);
+    else if ((rowBytes & 3) == 0 && rowBytes <= 4 * kSadLanes) sad_block<S, WAYS, 4>(s, ssb, r, rsb, rowBytes, h, lane, acc);
     else
     {
         // generic widths (the reference's sadGeneric entry): one sample per lane per step
@@ -213,9 +215,9 @@ __global__ __launch_bounds__(256) void k_ssd(const char *__restrict__ pa, long s
     const char *b = pb + (long)j[1] * S;
     uint32_t acc = 0;
     const int rowBytes = w * S;
-    if ((rowBytes & 15) == 0) acc = ssd_block<S, 16>(a, sab, b, sbb, rowBytes, h, lane);
-    else if ((rowBytes & 7) == 0) acc = ssd_block<S, 8>(a, sab, b, sbb, rowBytes, h, lane);
-    else if ((rowBytes & 3) == 0 && rowBytes <= 64) acc = ssd_block<S, 4>(a, sab, b, sbb, rowBytes, h, lane);
+    if ((rowBytes & 15) == 0 && rowBytes <= 16 * kSadLanes) acc = ssd_block<S, 16>(a, sab, b, sbb, rowBytes, h, lane);
+    else if ((rowBytes & 7) == 0 && rowBytes <= 8 * kSadLanes) acc = ssd_block<S, 8>(a, sab, b, sbb, rowBytes, h, lane);
+    else if ((rowBytes & 3) == 0 && rowBytes <= 4 * kSadLanes) acc = ssd_block<S, 4>(a, sab, b, sbb, rowBytes, h, lane);
     else
     {
         const FastDiv fd(w);

@@ -107,12 +107,17 @@ class Havoc:
             raise HavocError("no GPU visible: libhavoc_mi355x has no CPU path")
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
-        # stream: None -> torch's current stream; "new" -> the context creates and owns a private stream (needed for
-        # graph capture; the caller then orders torch work against it with sync()); an int -> that hipStream_t
+        # stream: None -> torch's current stream; "new" -> a private non-blocking stream (needed for graph capture), made
+        # through torch so that the numpy-level wrappers below can run their allocations, fills and copies on the SAME
+        # stream as the kernels (`self.tstream`): nothing then depends on incidental synchronisation; an int -> that
+        # hipStream_t (wrapped as an external torch stream for the same reason)
         if stream == "new":
-            s = _vp(-1)   # HAVOC_MI355X_NEW_STREAM
+            self.tstream = torch.cuda.Stream(device=self.device)
+        elif stream is None:
+            self.tstream = torch.cuda.current_stream(self.device)
         else:
-            s = _vp(stream if stream is not None else torch.cuda.current_stream(self.device).cuda_stream)
+            self.tstream = torch.cuda.ExternalStream(int(stream), device=self.device)
+        s = _vp(self.tstream.cuda_stream)
         h = _vp()
         self._ck(self.L.havoc_mi355x_create(C.byref(h), device, s))
         self.h = h
@@ -183,16 +188,18 @@ class Havoc:
             a = a.view(np.int16)
         if a.dtype == np.uint32:
             a = a.view(np.int32)
-        return self.torch.from_numpy(a).to(self.device)
+        with self.torch.cuda.stream(self.tstream):   # ordered with the kernels: same stream
+            return self.torch.from_numpy(a).to(self.device)
 
     def zeros(self, n, dtype):
         t = {np.uint8: self.torch.uint8, np.uint16: self.torch.int16, np.int16: self.torch.int16,
              np.int32: self.torch.int32, np.uint32: self.torch.int32}[np.dtype(dtype).type]
-        return self.torch.zeros(int(n), dtype=t, device=self.device)
+        with self.torch.cuda.stream(self.tstream):
+            return self.torch.zeros(int(n), dtype=t, device=self.device)
 
-    @staticmethod
-    def down(t, dtype):
-        a = t.cpu().numpy()
+    def down(self, t, dtype):
+        with self.torch.cuda.stream(self.tstream):   # the copy queues behind the kernels that produced `t`
+            a = t.cpu().numpy()
         return a.view(dtype) if a.dtype != np.dtype(dtype) else a
 
     @staticmethod
