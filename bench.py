@@ -35,6 +35,15 @@ def parse_args():
     ap.add_argument("--res", default="1920x1080")
     ap.add_argument("--bit-depth", type=int, default=8)
     ap.add_argument("--seed", type=int, default=11)
+    ap.add_argument("--qp", type=int, default=32, help="slice QP: the (de)quantiser scale / shift of the TU chain (turing/QpState.h:85-94)")
+    ap.add_argument("--mix", choices=["ra", "ai"], default="ra",
+                    help="call mix: one random-access B-frame at speed=medium (default) or one all-intra frame at speed=fast "
+                         "(BASELINE.json configs[0]: intra + TU chain with havoc_quantize in it)")
+    ap.add_argument("--min-seconds", type=float, default=0.5,
+                    help="the K-step timed block is repeated until this much time has been measured; the median block is reported")
+    ap.add_argument("--extra-4k", type=int, default=1,
+                    help="also measure the 3840x2160 8-bit QP27 workload (BASELINE.json configs[2]) for a few steps and report it under "
+                         "`extra` (N=1 only; 0 = off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
@@ -53,6 +62,12 @@ def parse_args():
                          "quantised levels up; costs and coefficients down) -- the PCIe-inclusive rate of DESIGN.md, never the metric")
     ap.add_argument("--skip", default="", help="diagnostic: comma-separated launch groups to leave out (the result is then "
                                                "NOT the metric; the JSON line says so)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1: weak = steady state of an endless sequence (one picture per rank per slot); strong = a fixed sequence "
+                         "of --pictures pictures from first to last slot, pipeline fill and drain included")
+    ap.add_argument("--pictures", type=int, default=33, help="--scaling strong: sequence length (IDR + SOPs of 8; SURVEY 8(d): 33)")
+    ap.add_argument("--poc-checksums", action="store_true",
+                    help="frame-parallel verification: synchronise after every picture and report a checksum of its reconstruction per POC")
     ap.add_argument("--exchange", action="store_true",
                     help="run the reference-picture exchange (process group + RCCL broadcasts) even with one rank")
     ap.add_argument("--lanes", type=int, default=8, help="fork/join lanes: independent launch chains overlap on the GPU")
@@ -80,11 +95,12 @@ class DeviceFrame:
         # picture store: 3 input planes + plane 3 = reconstruction
         store = np.concatenate([wl.luma, np.zeros(wl.plane_len, dt)])
         self.luma = up(store)
-        self.chroma = up(wl.chroma)
+        self.chroma = up(np.concatenate([wl.chroma, np.zeros(2 * wl.cplane_len, dt)]))   # + planes 3 / 4: reconstructed Cb / Cr
         z = lambda n, d: hv.zeros(n, d)
         self.pred = z(wl.pred_len, dt)
         self.cpred = z(wl.cpred_len, dt)
         self.bi = z(wl.bi_len + 4096, dt)
+        self.cbi = z(len(wl.bi4) * 1024 + 1024, dt)     # chroma bi predictions: own slots (32 x 32, stride 32)
         self.sbi = z(len(wl.subtract_bi) * 4096, dt)
         self.j_sad4, self.j_sad = up(wl.sad4), up(wl.sad)
         self.o_sad4, self.o_sad = z(4 * len(wl.sad4), np.int32), z(len(wl.sad), np.int32)
@@ -114,21 +130,20 @@ class DeviceFrame:
                 self.isearch[log2] = dict(jobs=up(j), nb=up(wl.intra_search_nb[log2]), cost=z(35 * len(j), np.int32))
         self.tu = {}
         bd = wl.bit_depth
-        qp = 32
+        qp = wl.qp
+        from turingcodec_amd.workload import quant_params, dequant_params
         for (log2, tr), g in wl.tu.items():
             m = len(g["jobs"])
             if not m:
                 continue
             nn = g["n"]
             # quantiser parameters exactly as turing/QpState.h:85-94 / Reconstruct.cpp:286,311,315 derive them
-            qscale = [26214, 23302, 20560, 18396, 16384, 14564][qp % 6]
-            qshift = 29 - bd + qp // 6 - log2
-            dscale = [40, 45, 51, 57, 64, 72][qp % 6] << (qp // 6)
-            dshift = log2 - 1 + bd - 8
+            qscale, qshift, qoffset = quant_params(qp, log2, bd, wl.mix == "ai")
+            dscale, dshift = dequant_params(qp, log2, bd)
             qj = np.zeros((m, 8), np.int32)
             qj[:, 0] = qj[:, 1] = g["jobs"][:, 0]
             qj[:, 2] = nn * nn
-            qj[:, 3], qj[:, 4], qj[:, 5] = qscale, qshift, 85 << 7
+            qj[:, 3], qj[:, 4], qj[:, 5] = qscale, qshift, qoffset
             dj = qj.copy()
             dj[:, 3], dj[:, 4] = dscale, dshift
             self.tu[(log2, tr)] = dict(jobs=up(g["jobs"]), src=up(g["src"]), res_off=up(g["res_off"]), n=nn,
@@ -140,9 +155,21 @@ class DeviceFrame:
             fj[:, 1] = g["src"][:, 0]          # havoc_mi355x_tu_fused_job: coef_off, src_off, pred_off, rec_off
             extra = g["ssd"][m:]
             self.tu[(log2, tr)].update(fjobs=up(fj), jssd_x=up(extra) if len(extra) else None, ossd_x=z(max(1, len(extra)), np.uint32))
+        # final reconstruction pass of the picture (workload.recon): what later pictures predict from
+        self.recon = {}
+        for comp, tabs in wl.recon.items():
+            for log2, g in tabs.items():
+                dscale, dshift = dequant_params(qp, log2, bd)
+                self.recon[(comp, log2)] = dict(jobs=up(g["jobs"]), levels=up(g["levels"]), ssd=z(len(g["jobs"]), np.uint32), n=g["n"],
+                                                dscale=dscale, dshift=dshift)
+        # pristine copy of the synthetic reference planes: what a picture WITHOUT references (the IDR of the frame-parallel
+        # schedule) predicts from, whatever an earlier picture left in the store
+        self.init_refs = (self.luma[wl.plane_len:3 * wl.plane_len].clone(), self.chroma[wl.cplane_len:3 * wl.cplane_len].clone())
         self.launches = self._make_launches()
+        torch.cuda.synchronize()   # every upload / fill above has landed, whatever stream it ran on, before the first launch
         # levels for the timed de-quantiser: run residual -> forward T -> havoc_quantize once, untimed (at medium the
-        # reference quantises with RDOQ on the host; the hot path sees its output levels)
+        # reference quantises with RDOQ on the host; the hot path sees its output levels).  In the all-intra speed=fast
+        # mix havoc_quantize is part of the timed chain instead.
         for name, fn in self.launches:
             if name.startswith(("residual", "transform", "tu_forward")):
                 fn()
@@ -162,12 +189,18 @@ class DeviceFrame:
                 chains.append(list(range(len(L), len(L) + len(items))))
                 L.extend(items)
 
-        if self.ime_range is None:
+        inter = wl.mix == "ra"
+        if not inter:
+            pass
+        elif self.ime_range is None:
             chain(("sad4", lambda: hv.sad4_d(self.luma, st, self.luma, st, self.j_sad4, self.o_sad4)))
         else:
             chain(("sad_surface", lambda: hv.sad_surface_d(self.luma, st, self.luma, st, self.ime_range, 64, 64, self.j_surf, self.o_surf)))
-        chain(("sad", lambda: hv.sad_d(self.luma, st, self.luma, st, self.j_sad, self.o_sad)))
-        if self.use_planes:
+        if inter:
+            chain(("sad", lambda: hv.sad_d(self.luma, st, self.luma, st, self.j_sad, self.o_sad)))
+        if not inter:
+            pass
+        elif self.use_planes:
             # sub-pel candidates against phase planes: interpolate each reference picture once (streaming, HBM-bound),
             # then every group of 16 candidates is one SATD job between the source PU and 16 blocks of the right planes
             pl, m = wl.plane_len, wl.plane_margin
@@ -186,12 +219,13 @@ class DeviceFrame:
             return [(name, lambda j=hv.up(np.ascontiguousarray(jobs_np[idx])), mw=mw, mh=mh: fn(j, mw, mh))
                     for idx, mw, mh in hv.size_classes(jobs_np[:, wcol], jobs_np[:, wcol + 1])]
 
-        chain(*classes("pred_uni8", wl.uni8, 2, lambda j, mw, mh: hv.pred_uni_d(8, bd, self.pred, 64, self.luma, st, j, mw, mh)),
-              ("satd_inter", lambda: hv.satd_d(self.luma, st, self.pred, 64, self.j_satd, self.o_satd)))
-        chain(*classes("pred_uni4", wl.uni4, 2, lambda j, mw, mh: hv.pred_uni_d(4, bd, self.cpred, 32, self.chroma, cst, j, mw, mh)))
-        chain(*classes("pred_bi8", wl.bi8, 3, lambda j, mw, mh: hv.pred_bi_d(8, bd, self.bi, 64, self.luma, st, j, mw, mh)),
-              ("subtract_bi", lambda: hv.subtract_bi_d(bd, self.sbi, 64, self.bi, 64, self.luma, st, self.j_sbi)),
-              *classes("pred_bi4", wl.bi4, 3, lambda j, mw, mh: hv.pred_bi_d(4, bd, self.bi, 32, self.chroma, cst, j, mw, mh)))
+        if inter:
+            chain(*classes("pred_uni8", wl.uni8, 2, lambda j, mw, mh: hv.pred_uni_d(8, bd, self.pred, 64, self.luma, st, j, mw, mh)),
+                  ("satd_inter", lambda: hv.satd_d(self.luma, st, self.pred, 64, self.j_satd, self.o_satd)))
+            chain(*classes("pred_uni4", wl.uni4, 2, lambda j, mw, mh: hv.pred_uni_d(4, bd, self.cpred, 32, self.chroma, cst, j, mw, mh)))
+            chain(*classes("pred_bi8", wl.bi8, 3, lambda j, mw, mh: hv.pred_bi_d(8, bd, self.bi, 64, self.luma, st, j, mw, mh)),
+                  ("subtract_bi", lambda: hv.subtract_bi_d(bd, self.sbi, 64, self.bi, 64, self.luma, st, self.j_sbi)),
+                  *classes("pred_bi4", wl.bi4, 3, lambda j, mw, mh: hv.pred_bi_d(4, bd, self.cbi, 32, self.chroma, cst, j, mw, mh)))
         for log2, g in sorted(self.isearch.items(), reverse=True):
             chain(("intra_satd35", lambda g=g, log2=log2: hv.intra_satd35_d(bd, log2, self.luma, st, g["nb"], g["jobs"], g["cost"])))
         for log2, g in sorted(self.intra.items(), reverse=True):
@@ -203,12 +237,16 @@ class DeviceFrame:
             # from the host's RDOQ in the reference (pre-computed, untimed, in __init__)
             if self.fused_tu:
                 # residual + forward transform in one kernel; de-quant + inverse transform + add + SSD in another
-                chain(("tu_forward", lambda g=g, log2=log2, tr=tr: hv.tu_forward_d(bd, tr, log2, g["coef"], self.luma, st, self.luma, st, g["fjobs"])))
+                fwd = ("tu_forward", lambda g=g, log2=log2, tr=tr: hv.tu_forward_d(bd, tr, log2, g["coef"], self.luma, st, self.luma, st, g["fjobs"]))
                 items = [("tu_reconstruct", lambda g=g, log2=log2, tr=tr, n=n: hv.tu_reconstruct_d(
                     bd, tr, log2, g["dscale"], g["dshift"], g["rec"], n, self.luma, st, self.luma, st, g["level"], g["fjobs"], g["ossd"]))]
                 if g["jssd_x"] is not None:   # the reference makes ~1.26 SSD calls per TU: the rest as plain SSD jobs
                     items.append(("ssd", lambda g=g, n=n: hv.ssd_d(self.luma, st, g["rec"], n, g["jssd_x"], g["ossd_x"])))
-                chain(*items)
+                if inter:
+                    chain(fwd)
+                    chain(*items)
+                else:   # speed=fast: no RDOQ -- havoc_quantize sits between the two halves, one dependent chain on the device
+                    chain(fwd, ("quantize", lambda g=g: hv.quantize_d(g["level"], g["coef"], g["qjobs"], g["cbf"])), *items)
                 continue
             chain(("residual", lambda g=g, n=n: hv.residual_d(g["res"], n, g["res_off"], self.luma, st, self.luma, st, g["src"])),
                   ("transform", lambda g=g, n=n, log2=log2, tr=tr: hv.transform_d(bd, tr, log2, g["coef"], g["res"], n, g["jobs"])))
@@ -216,6 +254,14 @@ class DeviceFrame:
                   ("inverse_transform_add", lambda g=g, log2=log2, tr=tr, n=n: hv.inverse_transform_add_d(
                       bd, tr, log2, g["rec"], n, self.luma, st, g["deq"], g["jobs"])),
                   ("ssd", lambda g=g, n=n: hv.ssd_d(self.luma, st, g["rec"], n, g["jssd"], g["ossd"])))
+        if inter and "recon" not in self.skip:
+            # the chosen modes' reconstruction of the whole picture, every sample once, into the reconstruction planes
+            items = []
+            for (comp, log2), g in sorted(self.recon.items(), key=lambda kv: (-kv[0][1], kv[0][0])):
+                plane, stv = (self.luma, st) if comp == "y" else (self.chroma, cst)
+                items.append(("recon", lambda g=g, log2=log2, plane=plane, stv=stv: hv.tu_reconstruct_d(
+                    bd, 0, log2, g["dscale"], g["dshift"], plane, stv, plane, stv, plane, stv, g["levels"], g["jobs"], g["ssd"])))
+            chain(*items)
         self.chains = chains
         return L
 
@@ -332,15 +378,26 @@ class DeviceFrame:
         """a checksum of checksums over every result buffer (size-independent parity property; see tests)"""
         import torch
         acc = 0
-        bufs = [self.o_sad4 if self.ime_range is None else self.o_surf, self.o_sad, self.o_satd, self.pred, self.cpred, self.bi, self.sbi]
+        bufs = [self.o_sad4 if self.ime_range is None else self.o_surf, self.o_sad, self.o_satd, self.pred, self.cpred, self.bi, self.cbi, self.sbi]
         for g in self.intra.values():
             bufs += [g["dst"]]
         for g in list(self.isearch.values()) + list(self.subpel_planes.values() if self.use_planes else self.subpel.values()):
             bufs += [g["cost"]]
         for g in self.tu.values():
-            bufs += [g["res"], g["coef"], g["deq"], g["rec"], g["ossd"]]
+            bufs += [g["res"], g["coef"], g["level"], g["deq"], g["rec"], g["ossd"], g["ossd_x"]]
+        bufs += [self.luma[3 * self.wl.plane_len:], self.chroma[3 * self.wl.cplane_len:]] + [g["ssd"] for g in self.recon.values()]
         for b in bufs:
             acc = (acc * 1000003 + int(b.to(torch.int64).sum().item())) & 0xFFFFFFFFFFFF
+        return acc
+
+    def recon_checksum(self):
+        """checksum of the reconstructed picture (Y, Cb, Cr planes incl. padding): what a later picture predicts from"""
+        import torch
+        pl, cpl = self.wl.plane_len, self.wl.cplane_len
+        acc = 0
+        for b in (self.luma[3 * pl:4 * pl], self.chroma[3 * cpl:4 * cpl], self.chroma[4 * cpl:5 * cpl]):
+            v = b.to(torch.int64)
+            acc = (acc * 1000003 + int(v.sum().item()) * 31 + int((v[::97] * 7).sum().item())) & 0xFFFFFFFFFFFF
         return acc
 
 
@@ -377,7 +434,8 @@ def cpu_worker(args):
     from turingcodec_amd.workload import FrameWorkload
     handle, stride = (int(v) for v in args.cpu_worker.split(","))
     w, h = (int(v) for v in args.res.split("x"))
-    wl = FrameWorkload(w, h, args.bit_depth, args.seed)
+    wl = FrameWorkload(w, h, args.bit_depth, args.seed, qp=args.qp, mix=args.mix)
+    inter = wl.mix == "ra"
     lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libhavoc_ref.so"))
     cores = usable_cores()
     lib.ref_mask(handle)   # populate the function tables (JIT assembly) once, before any worker thread touches them
@@ -392,12 +450,13 @@ def cpu_worker(args):
     pred = _aligned(np.zeros(wl.pred_len + 4096, dt))
     cpred = _aligned(np.zeros(wl.cpred_len + 1024, dt))
     bi = _aligned(np.zeros(wl.bi_len + 8192, dt))
+    cbi = _aligned(np.zeros(len(wl.bi4) * 1024 + 2048, dt))
     sbi = _aligned(np.zeros(len(wl.subtract_bi) * 4096 + 4096, dt))
     tasks = []   # (callable(b, e), njobs, group the GPU bench times it under)
     results = {}   # name -> array: what the reference computed for the sampled jobs (full-size parity check in main)
 
-    def add(group, fn, n):
-        if n:
+    def add(group, fn, n, always=False):
+        if n and (inter or always):
             tasks.append((fn, n, group))
             if os.environ.get("HAVOC_BENCH_TRACE"):
                 sys.stderr.write(f"task {len(tasks)} n={n}\n")
@@ -415,12 +474,16 @@ def cpu_worker(args):
     add("pred_uni4", lambda b, e: lib.ref_run_pred_uni(handle, S, 4, bd, P(cpred), ip(32), P(chroma), ip(cst), P(ju4), b, e), len(ju4))
     add("pred_bi8", lambda b, e: lib.ref_run_pred_bi(handle, S, 8, bd, P(bi), ip(64), P(luma), ip(st), P(jb8), b, e), len(jb8))
     add("subtract_bi", lambda b, e: lib.ref_run_subtract_bi(handle, S, bd, P(sbi), ip(64), P(bi), ip(64), P(luma), ip(st), P(jsb), b, e), len(jsb))
-    add("pred_bi4", lambda b, e: lib.ref_run_pred_bi(handle, S, 4, bd, P(bi), ip(32), P(chroma), ip(cst), P(jb4), b, e), len(jb4))
+    add("pred_bi4", lambda b, e: lib.ref_run_pred_bi(handle, S, 4, bd, P(cbi), ip(32), P(chroma), ip(cst), P(jb4), b, e), len(jb4))
     keep = [j4, js, ju8, ju4, jb8, jb4, jsb, jsa, o4, os_, osa]
-    results.update(sad4=o4, sad=os_, satd_inter=osa)
-    late = [("pred_uni8", pred, ju8, 0, 2, 64), ("pred_uni4", cpred, ju4, 0, 2, 32)]   # (the bi slots are re-used by the chroma pass)
+    late = []
+    if inter:
+        results.update(sad4=o4, sad=os_, satd_inter=osa)
+        # (name, slot buffer, jobs, column of the slot offset, column of w, slot stride): block regions cut out after the run
+        late = [("pred_uni8", pred, ju8, 0, 2, 64), ("pred_uni4", cpred, ju4, 0, 2, 32), ("pred_bi8", bi, jb8, 0, 3, 64),
+                ("pred_bi4", cbi, jb4, 0, 3, 32), ("subtract_bi", sbi, jsb, 0, 3, 64)]
     for hi, j in wl.subpel.items():   # fused on the GPU; on the CPU the reference's two calls: pred_uni, then measureSatd
-        if not len(j):
+        if not len(j) or not inter:
             continue
         jp = sub(j)
         jsat = _aligned(np.stack([jp[:, 0], np.arange(len(jp), dtype=np.int32) * 4096, jp[:, 2], jp[:, 3]], 1).astype(np.int32))
@@ -439,7 +502,7 @@ def cpu_worker(args):
         dst = _aligned(np.zeros((len(j) << (2 * log2)) + 64, dt))
         keep += [ji, nb, dst]
         results[f"intra_{log2}"] = (dst, ji[:, 0], n * n)
-        add("intra", lambda b, e, log2=log2, n=n, ji=ji, nb=nb, dst=dst: lib.ref_run_intra(handle, S, bd, log2, P(dst), ip(n), P(nb), P(ji), b, e), len(ji))
+        add("intra", lambda b, e, log2=log2, n=n, ji=ji, nb=nb, dst=dst: lib.ref_run_intra(handle, S, bd, log2, P(dst), ip(n), P(nb), P(ji), b, e), len(ji), True)
     for log2, j in wl.intra_search.items():
         if not len(j):
             continue
@@ -447,8 +510,10 @@ def cpu_worker(args):
         cost = np.zeros(35 * len(jp), np.int32)
         keep += [jp, nb, cost]
         results[f"intra35_{log2}"] = cost
-        add("intra_satd35", lambda b, e, log2=log2, jp=jp, nb=nb, cost=cost: lib.ref_run_intra_satd35(handle, S, bd, log2, P(luma), ip(st), P(nb), P(jp), b, e, P(cost)), len(jp))
-    qp = 32
+        add("intra_satd35", lambda b, e, log2=log2, jp=jp, nb=nb, cost=cost: lib.ref_run_intra_satd35(handle, S, bd, log2, P(luma), ip(st), P(nb), P(jp), b, e, P(cost)), len(jp), True)
+    from turingcodec_amd.workload import quant_params, dequant_params
+    qp = wl.qp
+    prepass = []   # untimed: the levels the timed de-quantiser reads (at medium the reference's RDOQ makes them on the host)
     for (log2, tr), g in wl.tu.items():
         m = len(g["jobs"])
         if not m:
@@ -458,23 +523,41 @@ def cpu_worker(args):
         res = _aligned(np.zeros(m * n * n + 64, np.int16))
         coef = _aligned(np.zeros(m * n * n + 64, np.int16))
         deq = _aligned(np.zeros(m * n * n + 64, np.int16))
-        dj = np.zeros((len(jt), 8), np.int32)
-        dj[:, 0] = dj[:, 1] = jt[:, 0]
-        dj[:, 2] = n * n
-        dj[:, 3] = [40, 45, 51, 57, 64, 72][qp % 6] << (qp // 6)
-        dj[:, 4] = log2 - 1 + bd - 8
-        dj = _aligned(dj)
-        keep += [jt, jsrc, roff, res, coef, deq, dj]
+        level = _aligned(np.zeros(m * n * n + 64, np.int16))
+        cbf = np.zeros(len(jt), np.int32)
+        qj = np.zeros((len(jt), 8), np.int32)
+        qj[:, 0] = qj[:, 1] = jt[:, 0]
+        qj[:, 2] = n * n
+        qj[:, 3], qj[:, 4], qj[:, 5] = quant_params(qp, log2, bd, not inter)
+        dj = qj.copy()
+        dj[:, 3], dj[:, 4] = dequant_params(qp, log2, bd)
+        dj[:, 5] = 0
+        qj, dj = _aligned(qj), _aligned(dj)
+        keep += [jt, jsrc, roff, res, coef, deq, level, cbf, qj, dj]
         results[f"coef_{log2}_{tr}"] = (coef, jt[:, 0], n * n)
-        add("tu_forward", lambda b, e, n=n, res=res, roff=roff, jsrc=jsrc: lib.ref_run_residual(S, P(res), ip(n), P(roff), P(luma), ip(st), P(luma), ip(st), P(jsrc), b, e), len(jt))
-        add("tu_forward", lambda b, e, n=n, log2=log2, tr=tr, coef=coef, res=res, jt=jt: lib.ref_run_transform(handle, bd, tr, log2, P(coef), P(res), ip(n), P(jt), b, e), len(jt))
-        add("tu_reconstruct", lambda b, e, deq=deq, coef=coef, dj=dj: lib.ref_run_quantize_inverse(handle, P(deq), P(coef), P(dj), b, e), len(jt))
+        results[f"level_{log2}_{tr}"] = (level, jt[:, 0], n * n)
+        f_res = lambda b, e, n=n, res=res, roff=roff, jsrc=jsrc: lib.ref_run_residual(S, P(res), ip(n), P(roff), P(luma), ip(st), P(luma), ip(st), P(jsrc), b, e)
+        f_fwd = lambda b, e, n=n, log2=log2, tr=tr, coef=coef, res=res, jt=jt: lib.ref_run_transform(handle, bd, tr, log2, P(coef), P(res), ip(n), P(jt), b, e)
+        f_q = lambda b, e, level=level, coef=coef, qj=qj, cbf=cbf: lib.ref_run_quantize(handle, P(level), P(coef), P(qj), b, e, P(cbf))
+        add("tu_forward", f_res, len(jt), True)
+        add("tu_forward", f_fwd, len(jt), True)
+        if inter:
+            prepass.append((len(jt), f_res, f_fwd, f_q))
+        else:   # speed=fast: havoc_quantize is in the timed chain (turing/Reconstruct.cpp:310-311)
+            add("quantize", f_q, len(jt), True)
+        add("tu_reconstruct", lambda b, e, deq=deq, level=level, dj=dj: lib.ref_run_quantize_inverse(handle, P(deq), P(level), P(dj), b, e), len(jt), True)
         rec = _aligned(np.zeros(m * n * n + 64, dt))
         jss = sub(g["ssd"])
         oss = np.zeros(len(jss), np.uint32)
         keep += [rec, jss, oss]
-        add("tu_reconstruct", lambda b, e, log2=log2, tr=tr, deq=deq, jt=jt, rec=rec, n=n: lib.ref_run_inverse_transform_add(handle, S, bd, tr, log2, P(rec), ip(n), P(luma), ip(st), P(deq), P(jt), b, e), len(jt))
-        add("tu_reconstruct", lambda b, e, rec=rec, n=n, jss=jss, oss=oss: lib.ref_run_ssd(handle, S, P(luma), ip(st), P(rec), ip(n), P(jss), b, e, P(oss)), len(jss))
+        results[f"rec_{log2}_{tr}"] = (rec, jt[:, 3], n * n)
+        results[f"ssd_{log2}_{tr}"] = oss
+        add("tu_reconstruct", lambda b, e, log2=log2, tr=tr, deq=deq, jt=jt, rec=rec, n=n: lib.ref_run_inverse_transform_add(handle, S, bd, tr, log2, P(rec), ip(n), P(luma), ip(st), P(deq), P(jt), b, e), len(jt), True)
+        add("tu_reconstruct", lambda b, e, rec=rec, n=n, jss=jss, oss=oss: lib.ref_run_ssd(handle, S, P(luma), ip(st), P(rec), ip(n), P(jss), b, e, P(oss)), len(jss), True)
+    for nj, f_res, f_fwd, f_q in prepass:
+        f_res(0, nj)
+        f_fwd(0, nj)
+        f_q(0, nj)
 
     group_s = {}
     acc = [dict() for _ in range(cores)]
@@ -536,9 +619,12 @@ def parity_vs_reference(dev, path, stride):
     compared = mismatches = 0
     groups = []
 
+    ref_over = {}
+
     def cmp(name, gpu):
         nonlocal compared, mismatches
-        a, b = np.asarray(ref[name]).astype(np.int64).ravel(), np.asarray(gpu).astype(np.int64).ravel()
+        a = np.asarray(ref_over[name] if name in ref_over else ref[name]).astype(np.int64).ravel()
+        b = np.asarray(gpu).astype(np.int64).ravel()
         assert a.shape == b.shape, (name, a.shape, b.shape)
         compared += a.size
         mismatches += int((a != b).sum())
@@ -547,13 +633,18 @@ def parity_vs_reference(dev, path, stride):
     def blocks(buf, offs, ln):
         return buf[(np.asarray(offs, np.int64)[::stride][:, None] + np.arange(ln)[None, :]).ravel()]
 
-    if dev.ime_range is None:
-        cmp("sad4", hv.down(dev.o_sad4, np.int32).reshape(-1, 4)[::stride])
-    cmp("sad", hv.down(dev.o_sad, np.int32)[::stride])
-    cmp("satd_inter", hv.down(dev.o_satd, np.int32)[::stride])
-    cmp("pred_uni8", _regions(hv.down(dev.pred, wl.dtype), wl.uni8[::stride], 0, 2, 64))
-    cmp("pred_uni4", _regions(hv.down(dev.cpred, wl.dtype), wl.uni4[::stride], 0, 2, 32))
-    if dev.use_planes:
+    inter = wl.mix == "ra"
+    if inter:
+        if dev.ime_range is None:
+            cmp("sad4", hv.down(dev.o_sad4, np.int32).reshape(-1, 4)[::stride])
+        cmp("sad", hv.down(dev.o_sad, np.int32)[::stride])
+        cmp("satd_inter", hv.down(dev.o_satd, np.int32)[::stride])
+        cmp("pred_uni8", _regions(hv.down(dev.pred, wl.dtype), wl.uni8[::stride], 0, 2, 64))
+        cmp("pred_uni4", _regions(hv.down(dev.cpred, wl.dtype), wl.uni4[::stride], 0, 2, 32))
+        cmp("pred_bi8", _regions(hv.down(dev.bi, wl.dtype), wl.bi8[::stride], 0, 3, 64))
+        cmp("pred_bi4", _regions(hv.down(dev.cbi, wl.dtype), wl.bi4[::stride], 0, 3, 32))
+        cmp("subtract_bi", _regions(hv.down(dev.sbi, wl.dtype), wl.subtract_bi[::stride], 0, 3, 64))
+    if inter and dev.use_planes:
         n = sum(len(v) for v in wl.subpel_idx.values())
         ca = np.zeros(n, np.int32)
         for c, g in dev.subpel_planes.items():
@@ -568,7 +659,20 @@ def parity_vs_reference(dev, path, stride):
     for log2, g in dev.isearch.items():
         cmp(f"intra35_{log2}", hv.down(g["cost"], np.int32).reshape(-1, 35)[::stride])
     for (log2, tr), g in dev.tu.items():
-        cmp(f"coef_{log2}_{tr}", blocks(hv.down(g["coef"], np.int16), wl.tu[(log2, tr)]["jobs"][:, 0], g["n"] ** 2))
+        t = wl.tu[(log2, tr)]
+        m, nn = len(t["jobs"]), g["n"] ** 2
+        cmp(f"coef_{log2}_{tr}", blocks(hv.down(g["coef"], np.int16), t["jobs"][:, 0], nn))
+        cmp(f"level_{log2}_{tr}", blocks(hv.down(g["level"], np.int16), t["jobs"][:, 0], nn))
+        cmp(f"rec_{log2}_{tr}", blocks(hv.down(g["rec"], wl.dtype), t["jobs"][:, 3], nn))
+        # SSD table = [one job per TU | the reference's extra ~0.26 calls per TU on the first TUs again]: GPU = the value
+        # tu_reconstruct reduced for TU i, then the plain SSD jobs; sampled job i is comparable when the reconstruction
+        # it reads belongs to a sampled TU (the CPU sample only reconstructs those)
+        gpu = np.concatenate([hv.down(g["ossd"], np.uint32), hv.down(g["ossd_x"], np.uint32)[:max(0, len(t["ssd"]) - m)]])
+        i = np.arange(len(t["ssd"]))[::stride]
+        ok = (i < m) | ((i - m) % stride == 0)
+        a = np.asarray(ref[f"ssd_{log2}_{tr}"])[ok]
+        ref_over[f"ssd_{log2}_{tr}"] = a
+        cmp(f"ssd_{log2}_{tr}", gpu[i[ok]])
     return {"compared": compared, "mismatches": mismatches,
             "what": "results of the reference library for the cpu_baseline sample vs the GPU results of the same jobs: " + ", ".join(groups)}
 
@@ -582,7 +686,7 @@ def cpu_baseline(args, dev=None):
     for handle in (1, 0):   # x86 JIT tables first; plain-C tables if the JIT run fails
         tmp = os.path.join(tempfile.gettempdir(), f"havoc_cpu_{os.getpid()}_{handle}.npz")
         cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", f"{handle},{stride}", "--res", args.res,
-               "--bit-depth", str(args.bit_depth), "--seed", str(args.seed), "--cpu-out", tmp]
+               "--bit-depth", str(args.bit_depth), "--seed", str(args.seed), "--qp", str(args.qp), "--mix", args.mix, "--cpu-out", tmp]
         try:
             out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
             if out.returncode == 0:
@@ -590,6 +694,8 @@ def cpu_baseline(args, dev=None):
                 fps = 1.0 / (r["seconds_per_sample"] * r["stride"])
                 res = {"value": round(fps, 3), "unit": "frames/s", "cores": r["cores"], "kind": "reference",
                        "ms_per_frame_by_group": {g: round(v * r["stride"] * 1e3, 3) for g, v in r["group_seconds_per_sample"].items()},
+                       "what": "the reference's havoc primitive tables on the same job tables -- NOT SURVEY 8(d)'s `turing encode` (the full "
+                               "encoder needs a CMake-generated header and is not built here, DESIGN.md 2)",
                        "sample": f"every {stride}th job of each primitive's job table ({r['jobs']} calls) through the "
                                  f"reference's own havoc {'x86-JIT' if handle else 'C'} function tables (oracle/_ref), "
                                  f"{r['cores']} host threads, the sample repeated {r['reps']}x "
@@ -638,6 +744,145 @@ def hbm_traffic_from_profiles(group, S):
     return round(total / n) if n else None
 
 
+def build_contexts(args, torch, Havoc, FrameWorkload, local, res, bit_depth, qp, mix, seed0, count, tune):
+    """`count` picture contexts: each has a private compute stream (the step is captured into a HIP graph and replayed on
+    it; made through torch so that torch events can order it against the exchange stream), its own picture store / job
+    tables / outputs and its own planned graph."""
+    w, h = (int(v) for v in res.split("x"))
+    out = []
+    for k in range(count):
+        compute_k = torch.cuda.Stream(device=local)
+        hv_k = Havoc(local, stream=compute_k.cuda_stream)
+        wl_k = FrameWorkload(w, h, bit_depth, seed0 + 1000 * k, qp=qp, mix=mix)
+        dev_k = DeviceFrame(hv_k, wl_k, use_planes=(args.subpel == "planes"), fused_tu=(args.tu == "fused"),
+                            ime_range=args.ime_range if args.ime == "surface" else None, skip=[s for s in args.skip.split(",") if s])
+        dev_k.step()          # first eager pass (loads the code objects) -- also what the graph must reproduce
+        hv_k.sync()
+        if args.no_graph:
+            graph_k = None
+        elif args.lanes > 1 and tune > 0:
+            graph_k, _ = dev_k.plan_lanes(args.lanes, tune)     # lane assignment chosen by measurement (set-up, untimed)
+        else:
+            graph_k = hv_k.graph_capture(lambda: dev_k.step(args.lanes))
+        out.append((compute_k, hv_k, wl_k, dev_k, graph_k))
+    return out
+
+
+def timed_blocks(torch, dist, world, steps, min_seconds, run_block, max_blocks=64):
+    """Repeat [barrier + synchronize | exactly `steps` steps | synchronize + barrier] until `min_seconds` have been measured
+    (a 20-step block of this path is a few milliseconds: one block alone is mostly noise).  Every block's duration is
+    the MAX over ranks, so all ranks take the same stop decision.  Returns the list of block durations in seconds."""
+    out, total = [], 0.0
+    while True:
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_block(len(out))
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        out.append(dt)
+        total += dt
+        if total >= min_seconds or len(out) >= max_blocks:
+            return out
+
+
+class FramePipeline:
+    """The frame-parallel step loop (N > 1, or --exchange): time slot t of the DagSchedule.
+
+    compute stream k  : [wait arrived(L0), arrived(L1)] [mirror -> picture store copies] [the picture's graph] [pad] [stage]
+    exchange stream   : [wait refs_copied(t), staged(t)] [broadcast of every reference picture of slot t] [record arrived(s)]
+
+    A picture's kernels read their references out of the DPB mirror (copied into the store the captured graph addresses),
+    so its results depend on what the references' owners reconstructed; it starts only after the broadcast events of its
+    references' mirror slots.  A mirror slot is overwritten (owner's stage, or an incoming broadcast) only after every
+    ref copy issued so far on this rank: `refs_copied` events."""
+
+    def __init__(self, torch, dist, exch, contexts, rank, comm, lanes, poc_checksums=False):
+        self.torch, self.dist, self.exch, self.ctx, self.rank, self.comm, self.lanes = torch, dist, exch, contexts, rank, comm, lanes
+        self.count = 0                    # pictures this rank has worked on -> which context the next one uses
+        self.arrived = {}                 # DPB slot -> event recorded after its latest broadcast
+        self.last_copy = [None] * len(contexts)   # per compute stream: event after its latest ref copy
+        self.poc_checksums = {} if poc_checksums else None
+        self.pictures = 0
+
+    def slot(self, t):
+        torch, exch = self.torch, self.exch
+        pic = exch.picture_of(t)
+        staged = None
+        if pic is not None:
+            k = self.count % len(self.ctx)
+            self.count += 1
+            self.pictures += 1
+            compute, hv, wl, dev, graph = self.ctx[k]
+            pl, cpl = wl.plane_len, wl.cplane_len
+            if pic.refs:
+                s0, s1 = exch.refs(pic)
+                for sl in {s0, s1}:
+                    if sl in self.arrived:
+                        compute.wait_event(self.arrived[sl])
+                with torch.cuda.stream(compute):
+                    # references come from the mirror: L0 / L1 luma into store planes 1 / 2 and phase-plane slot 0 of
+                    # each reference, Cb of L0 / L1 into the chroma store (one fused copy launch)
+                    dst = [dev.luma[pl:2 * pl], dev.luma[2 * pl:3 * pl], dev.chroma[cpl:2 * cpl], dev.chroma[2 * cpl:3 * cpl]]
+                    src = [exch.dpb_luma[s0], exch.dpb_luma[s1], exch.dpb_cb[s0], exch.dpb_cb[s1]]
+                    if dev.use_planes:
+                        dst += [dev.planes[0:pl], dev.planes[16 * pl:17 * pl]]
+                        src += [exch.dpb_luma[s0], exch.dpb_luma[s1]]
+                    torch._foreach_copy_(dst, src)
+                ev = torch.cuda.Event()
+                ev.record(compute)
+                self.last_copy[k] = ev
+            else:
+                with torch.cuda.stream(compute):   # no references (IDR): the synthetic ones the context was built with
+                    dst = [dev.luma[pl:3 * pl], dev.chroma[cpl:3 * cpl]]
+                    src = list(dev.init_refs)
+                    if dev.use_planes:
+                        dst += [dev.planes[0:pl], dev.planes[16 * pl:17 * pl]]
+                        src += [dev.init_refs[0][:pl], dev.init_refs[0][pl:]]
+                    torch._foreach_copy_(dst, src)
+            if graph is not None:
+                hv.graph_launch(graph)
+            else:
+                dev.step(self.lanes)
+            if pic.is_reference:
+                # the owner pads its reconstruction (Padding::padBlock after the loop filter, turing/TaskDeblock.cpp:151-159)
+                # before it becomes a reference on every rank
+                hv.pad_block_d(dev.luma, 3 * pl + 96 * wl.stride + 96, wl.width, wl.height, wl.stride, 96)
+                hv.pad_block_d(dev.chroma, 3 * cpl + 48 * wl.cstride + 48, wl.width // 2, wl.height // 2, wl.cstride, 48)
+                hv.pad_block_d(dev.chroma, 4 * cpl + 48 * wl.cstride + 48, wl.width // 2, wl.height // 2, wl.cstride, 48)
+                for j, ev in enumerate(self.last_copy):      # the mirror slot being staged into may still be read by a
+                    if ev is not None and j != k:            # ref copy of the other picture in flight
+                        compute.wait_event(ev)
+                with torch.cuda.stream(compute):
+                    exch.stage(t, (dev.luma[3 * pl:4 * pl], dev.chroma[3 * cpl:4 * cpl], dev.chroma[4 * cpl:5 * cpl]))
+                staged = torch.cuda.Event()
+                staged.record(compute)
+            if self.poc_checksums is not None:
+                hv.sync()
+                self.poc_checksums[pic.poc] = dev.recon_checksum()
+        for ev in self.last_copy:          # incoming broadcasts overwrite mirror slots: behind every ref copy issued so far
+            if ev is not None:
+                self.comm.wait_event(ev)
+        if staged is not None:
+            self.comm.wait_event(staged)
+        exch.send(t)
+        for src in range(exch.world):
+            q = exch.picture_of(t, src)
+            if q is not None and q.is_reference:
+                ev = torch.cuda.Event()
+                ev.record(self.comm)
+                self.arrived[exch.slot_of(q.poc)] = ev
+
+
 def main():
     args = parse_args()
     if args.cpu_worker:
@@ -666,35 +911,21 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    # Each picture in flight has its own context: a private compute stream (the step is captured into a HIP graph and
-    # replayed on it; created through torch only so that torch events can order it against the exchange stream), its
-    # own picture store / job tables / outputs, its own planned graph.  Step i runs picture slot i % inflight.
     w, h = (int(v) for v in args.res.split("x"))
-    inflight = 1 if (args.pcie or args.no_graph) else max(1, args.inflight)
-    slots = []
-    for k in range(inflight):
-        compute_k = torch.cuda.Stream(device=local)
-        hv_k = Havoc(local, stream=compute_k.cuda_stream)
-        wl_k = FrameWorkload(w, h, args.bit_depth, args.seed + rank + 1000 * k)   # every rank / slot owns a different picture
-        dev_k = DeviceFrame(hv_k, wl_k, use_planes=(args.subpel == "planes"), fused_tu=(args.tu == "fused"),
-                            ime_range=args.ime_range if args.ime == "surface" else None, skip=[s for s in args.skip.split(",") if s])
-        dev_k.step()          # first eager pass (loads the code objects) -- also what the graph must reproduce
-        hv_k.sync()
-        if args.no_graph:
-            graph_k = None
-        elif args.lanes > 1 and args.tune > 0:
-            graph_k, _ = dev_k.plan_lanes(args.lanes, args.tune)     # lane assignment chosen by measurement (set-up, untimed)
-        else:
-            graph_k = hv_k.graph_capture(lambda: dev_k.step(args.lanes))
-        slots.append((compute_k, hv_k, wl_k, dev_k, graph_k))
+    inflight = 1 if (args.pcie or args.no_graph or args.poc_checksums) else max(1, args.inflight)
+    # Step i runs picture context i % inflight.  Single GPU: every context owns a different synthetic picture.  Frame-parallel:
+    # the contexts of every rank are built from the same seeds (a picture's result must not depend on who encodes it).
+    slots = build_contexts(args, torch, Havoc, FrameWorkload, local, args.res, args.bit_depth, args.qp, args.mix,
+                           args.seed + (0 if grouped else rank), inflight, args.tune)
     compute, hv, wl, dev, graph = slots[0]
-    exch = None
+    pipe = None
     if grouped:
-        from turingcodec_amd.frame_parallel import ReferenceExchange
-        # the workload keeps one chroma plane (Cr is identical work); the exchange carries Y, Cb and Cr
-        exch = ReferenceExchange(dist, rank, world, dev.luma[3 * wl.plane_len:4 * wl.plane_len], dev.chroma[:wl.cplane_len],
-                                 single_rank_broadcast=args.exchange, recon_chroma2=dev.chroma[:wl.cplane_len])
+        from turingcodec_amd.frame_parallel import DagSchedule, ReferenceExchange
+        strong = args.scaling == "strong"
+        sched = DagSchedule(world, n_sops=(args.pictures - 1) // 8 if strong else None)
+        exch = ReferenceExchange(dist, rank, sched, wl.plane_len, wl.cplane_len, dev.luma, single_rank_broadcast=args.exchange)
         comm = torch.cuda.current_stream(local)   # torch.distributed enqueues behind this stream
+        pipe = FramePipeline(torch, dist, exch, slots, rank, comm, args.lanes, poc_checksums=args.poc_checksums)
 
     host_io = None
     if args.pcie:
@@ -714,6 +945,8 @@ def main():
         pcie_bytes = (sum(t.numel() * t.element_size() for t in ups), sum(t.numel() * t.element_size() for t in downs))
 
     def one_step(i):
+        if pipe is not None:
+            return pipe.slot(i)
         compute, hv, wl, dev, graph = slots[i % inflight]
         if host_io is not None:
             with torch.cuda.stream(compute):
@@ -727,45 +960,45 @@ def main():
             with torch.cuda.stream(compute):
                 for t, hb in host_io[1]:
                     hb.copy_(t, non_blocking=True)
-        if exch is not None:
-            # compute stream: [picture i] [owner copies its reconstruction into the DPB mirror] [next picture of the slot] ...
-            # exchange stream:                          [wait staged_i] [broadcasts of picture i] ...
-            # -> a compute stream never waits for a broadcast of the current picture, only (for DPB slot re-use) for
-            #    the broadcasts of the previous step, which ran underneath this picture's kernels
-            if i > 0:
-                compute.wait_event(sent[(i - 1) & 1])
-            if exch.picture_of(i, rank).is_reference:
-                # the owner pads its reconstruction (Padding::padBlock after deblocking, turing/TaskDeblock.cpp:151-159)
-                # before it becomes a reference on every rank
-                hv.pad_block_d(dev.luma, 3 * wl.plane_len + 96 * wl.stride + 96, wl.width, wl.height, wl.stride, 96)
-                hv.pad_block_d(dev.chroma, 48 * wl.cstride + 48, wl.width // 2, wl.height // 2, wl.cstride, 48)
-            with torch.cuda.stream(compute):
-                exch.stage(i, (dev.luma[3 * wl.plane_len:4 * wl.plane_len], dev.chroma[:wl.cplane_len], dev.chroma[:wl.cplane_len]))
-            staged[i & 1].record(compute)
-            comm.wait_event(staged[i & 1])
-            exch.send(i)
-            sent[i & 1].record(comm)
 
-    staged = [torch.cuda.Event(), torch.cuda.Event()]
-    sent = [torch.cuda.Event(), torch.cuda.Event()]
-    for i in range(args.warmup):
-        one_step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        one_step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    if pipe is not None and args.scaling == "strong":
+        # strong scaling: a FIXED sequence (IDR + SOPs, --pictures) from the first slot to the last, fill and drain of the
+        # pipeline included; a step = one time slot, the timed region = the whole sequence, `steps` is set to its slot count
+        nslots = sched.slots_for_sequence()
+        args.steps, args.warmup = nslots, 0
+
+        def run_block(_b):
+            for i in range(nslots):
+                one_step(i)
+        # one untimed pass over the sequence first (code objects, RCCL channels), on a schedule of its own
+        warm = FramePipeline(torch, dist, ReferenceExchange(dist, rank, DagSchedule(world, n_sops=(args.pictures - 1) // 8), wl.plane_len,
+                                                            wl.cplane_len, dev.luma, single_rank_broadcast=args.exchange), slots, rank, comm, args.lanes)
+        for i in range(nslots):
+            warm.slot(i)
+        blocks = timed_blocks(torch, dist, world, nslots, 0.0, run_block, max_blocks=1)
+        pictures_per_block = args.pictures
+    else:
+        base = [0]
+        for i in range(args.warmup):
+            one_step(i)
+        base[0] = args.warmup
+
+        def run_block(_b):
+            for i in range(args.steps):
+                one_step(base[0] + i)
+            base[0] += args.steps
+        before = pipe.pictures if pipe is not None else 0
+        blocks = timed_blocks(torch, dist, world, args.steps, args.min_seconds, run_block)
+        # frame-parallel steady state: every rank works on one picture per slot (DagSchedule); counted, not assumed
+        if pipe is not None:
+            n = torch.tensor([pipe.pictures - before], device="cuda", dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(n)
+            pictures_per_block = float(n.item()) / len(blocks)
+        else:
+            pictures_per_block = float(world * args.steps)
+    blk = float(np.median(blocks))
+    elapsed = blk
 
     if rank == 0:
         ktimes, kcount = dev.kernel_times_ms(args.kernel_reps)
@@ -776,25 +1009,29 @@ def main():
         total_bytes = sum(kbytes[k] for k in ktimes)
         traffic = hbm_traffic_from_profiles(dom, wl.S)
         ms_step = elapsed / args.steps * 1e3
+        mixname = ("random-access QP%d speed=medium B-frame call mix (SURVEY A.2 counts x %.2f; assumed PU/intra size mix)" % (args.qp, w * h / (1920 * 1080))
+                   if args.mix == "ra" else "all-intra QP%d speed=fast call mix (SURVEY A.1 per-CTU intra / TU counts, havoc_quantize in the chain)" % args.qp)
         out = {
-            "metric": "encoded fps (havoc hot path: one RA B-frame's primitive calls per frame)",
-            "value": round(world * args.steps / elapsed, 3),
+            "metric": "encoded fps (havoc hot path: one picture's primitive calls per frame)",
+            "value": round(pictures_per_block / elapsed, 3),
             "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling if pipe is not None else "weak", "vs_baseline": None,
             "dtype": "u8" if args.bit_depth == 8 else "u16", "data": "synthetic",
-            "config": {"workload": f"{args.res} {args.bit_depth}-bit 4:2:0 random-access QP32 speed=medium B-frame call mix "
-                                   f"(SURVEY A.2 counts x {w * h / (1920 * 1080):.2f}; assumed PU/intra size mix), 1xMI355X per rank",
+            "config": {"workload": f"{args.res} {args.bit_depth}-bit 4:2:0 {mixname}, 1xMI355X per rank",
                        "calls_per_frame": int(sum(wl.counts.values())), "launches_per_frame": len(dev.launches), "pictures_in_flight": inflight,
                        "integer_me": ("sad4 jobs (the reference's per-pattern calls)" if args.ime == "sad4" else
                                       f"{len(wl.me_search)} SAD surfaces of (2*{args.ime_range}+1)^2 candidates instead of "
                                       f"{len(wl.sad4)} SAD4 calls"),
-                       "parallelism": (f"frame-parallel x{world}: one picture per rank per step, reference pictures broadcast "
-                                       f"over RCCL ({exch.sent_bytes // max(1, args.steps + args.warmup)} B sent per step by rank 0), "
-                                       f"overlapped with the next picture") if world > 1 else "single GPU"},
+                       "parallelism": "single GPU"},
+            "timing": {"timed_blocks": len(blocks), "block_seconds_median": round(blk, 6), "block_seconds_min": round(min(blocks), 6),
+                       "block_seconds_max": round(max(blocks), 6), "seconds_measured": round(sum(blocks), 4),
+                       "note": f"each block = exactly {args.steps} steps between barrier + synchronize; ms_per_step and value are the MEDIAN block"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "traffic_source": "profiles/r*_hbm_traffic.csv: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench "
+                                           "(profiles/collect.sh), FETCH_SIZE x2 per the gfx950 note; not re-measured in this run",
                          "launch_ms": round(ktimes[dom] / kcount[dom], 5), "launches_per_step": kcount[dom],
                          "algorithmic_bytes_per_step": kbytes[dom]},
             "whole_step": {"algorithmic_bytes": total_bytes, "achieved_gbs": round(total_bytes / (ms_step * 1e-3) / 1e9, 2),
@@ -802,11 +1039,39 @@ def main():
                            "kernel_gbs": {k: round(kbytes[k] / (v * 1e-3) / 1e9, 1) for k, v in ktimes.items()}},
             "checksum": dev.checksum(),
         }
+        if pipe is not None:
+            out["config"]["parallelism"] = (
+                f"frame-parallel x{world}: hierarchical-B docket (turing/InputQueue.cpp:370-379) list-scheduled on {world} ranks "
+                f"(a picture starts after the broadcasts of its references; references are read from the DPB mirror), "
+                f"{pipe.exch.broadcasts} reference pictures broadcast over {'RCCL' if os.environ.get('HAVOC_BENCH_BACKEND', 'nccl') == 'nccl' else 'gloo'} "
+                f"in the whole run ({pipe.exch.sent_bytes} B sent by rank 0), overlapped with the next slot"
+                + (f"; strong scaling over a fixed {args.pictures}-picture sequence, fill and drain included" if args.scaling == "strong" else
+                   "; weak scaling: steady state of an endless sequence, one picture per rank per slot"))
+            out["config"]["pictures_per_timed_block"] = pictures_per_block
+        if args.poc_checksums and pipe is not None:
+            out["poc_checksums"] = {str(k): v for k, v in sorted(pipe.poc_checksums.items())}
         if args.pcie:
             out["metric"] = (f"DIAGNOSTIC (PCIe-inclusive: {pcie_bytes[0]} B up, {pcie_bytes[1]} B down per step, serial with the "
                              "kernels) -- not the benchmark metric")
         if args.skip:
             out["metric"] = "DIAGNOSTIC (launch groups skipped: " + args.skip + ") -- not the benchmark metric"
+        plain = world == 1 and pipe is None and not (args.pcie or args.skip or args.no_graph)
+        if plain and args.extra_4k and args.res == "1920x1080" and args.mix == "ra":
+            # BASELINE.json configs[2] (the resolution the north star's target is quoted on), same code, fewer steps
+            try:
+                xs = build_contexts(args, torch, Havoc, FrameWorkload, local, "3840x2160", 8, 27, "ra", args.seed + 77, inflight, min(args.tune, 8))
+                ksteps = 20
+
+                def xblock(_b, xs=xs):
+                    for i in range(ksteps):
+                        xs[i % len(xs)][1].graph_launch(xs[i % len(xs)][4])
+                xblock(0)
+                xb = timed_blocks(torch, dist, 1, ksteps, 0.3, xblock)
+                out["extra"] = {"3840x2160 8-bit random-access QP27 speed=medium (BASELINE.json configs[2])": {
+                    "value": round(ksteps / float(np.median(xb)), 3), "unit": "frames/s", "ms_per_step": round(float(np.median(xb)) / ksteps * 1e3, 4),
+                    "steps": ksteps, "timed_blocks": len(xb), "calls_per_frame": int(sum(xs[0][2].counts.values())), "checksum": xs[0][3].checksum()}}
+            except Exception as e:   # the headline line stands on its own
+                out["extra"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, dev)
         print(json.dumps(out))

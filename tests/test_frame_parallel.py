@@ -1,4 +1,5 @@
-"""CPU tests of the N>1 path: GOP plan and the reference-picture exchange over gloo (world_size 2)."""
+"""CPU tests of the N>1 path: the GOP plan, the dependency-aware schedule and the reference-picture exchange over gloo
+(world_size 2 against world_size 1)."""
 import os
 import socket
 
@@ -23,15 +24,61 @@ def test_coding_order_matches_reference_sop():
     for p in pics:
         for q in p.refs:
             assert by[q].is_reference and by[q].index < p.index
+    # searched lists: nearest past picture / nearest future picture (anchors have no future one)
+    assert (by[4].l0, by[4].l1) == (0, 8) and (by[3].l0, by[3].l1) == (2, 4) and (by[8].l0, by[8].l1) == (0, 0)
 
 
-@pytest.mark.parametrize("world", [1, 2, 4, 8])
-def test_lockstep_plan_is_schedulable(world):
-    pics = fp.coding_order(8)
-    ready = fp.dependency_ready_step(pics, world)
-    # a picture never has to wait more than a few steps for its references in steady state
-    late = [r - p.index // world for p, r in zip(pics, ready)]
-    assert max(late) <= 1 + 8 // world
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 8])
+def test_dag_schedule_respects_dependencies(world):
+    n_sops = 12
+    s = fp.DagSchedule(world, n_sops=n_sops)
+    nslots = s.slots_for_sequence()
+    seen = {}
+    live = {}       # DPB slot -> poc currently held
+    for t in range(nslots):
+        row = s.slot(t)
+        assert len(row) == world
+        for p in row:
+            if p is None:
+                continue
+            assert p.poc not in seen
+            for q in p.refs:   # the wait-for-reference rule: every reference finished in an EARLIER slot
+                assert q in seen and seen[q] < t, (p.poc, q)
+            seen[p.poc] = t
+        for p in row:
+            if p is not None and p.is_reference:
+                d = s.dpb_slot[p.poc]
+                if d in live:   # a mirror slot is re-used only when every user of its previous picture ran before slot t
+                    old = live[d]
+                    users = [u for u in s.pics if old in u.refs]
+                    assert all(seen.get(u.poc, 1 << 30) < t for u in users), (p.poc, old)
+                live[d] = p.poc
+    assert len(seen) == 1 + 8 * n_sops
+    # a picture's references are still in the mirror when it runs: the slot was not handed to a later picture before
+    by_slot_owner = {}
+    for t in range(nslots):
+        for p in s.slot(t):
+            if p is not None and p.is_reference:
+                by_slot_owner.setdefault(s.dpb_slot[p.poc], []).append((t, p.poc))
+    for p in s.pics:
+        for q in p.refs:
+            hist = by_slot_owner[s.dpb_slot[q]]
+            holder = max((tt, poc) for tt, poc in hist if tt < seen[p.poc])
+            assert holder[1] == q, (p.poc, q, holder)
+
+
+def test_eight_ranks_reach_the_level_skewed_pipeline():
+    s = fp.DagSchedule(8)
+    # steady state: per slot POCs 1,3,5,7 of SOP k, 2,6 of SOP k+1, 4 of SOP k+2 and the anchor of SOP k+3
+    for t in range(6, 40):
+        pocs = sorted(p.poc for p in s.slot(t))
+        k = pocs[0] // 8
+        assert pocs == [8 * k + 1, 8 * k + 3, 8 * k + 5, 8 * k + 7, 8 * k + 10, 8 * k + 14, 8 * k + 20, 8 * k + 32]
+    for world in (1, 2, 4, 8):   # no idle rank in steady state at any width
+        s = fp.DagSchedule(world)
+        assert all(p is not None for t in range(10, 80) for p in s.slot(t))
+    assert fp.DagSchedule(8, n_sops=4).slots_for_sequence() == 8      # 33 pictures: fill + drain dominate
+    assert fp.DagSchedule(1, n_sops=4).slots_for_sequence() == 33
 
 
 def _free_port():
@@ -42,47 +89,82 @@ def _free_port():
     return p
 
 
-def _recon_for(pic, n):
-    """deterministic stand-in for a picture's reconstruction (what the hot path writes)"""
-    rng = np.random.default_rng(1000 + pic.poc)
-    return torch.from_numpy(rng.integers(0, 256, n).astype(np.uint8))
+NL, NC = 4096, 1024
 
 
-def _worker(rank, world, port, steps, out):
+def _source(poc):
+    rng = np.random.default_rng(1000 + poc)
+    return torch.from_numpy(rng.integers(0, 256, NL + 2 * NC).astype(np.uint8))
+
+
+def _encode(poc, ref0, ref1):
+    """deterministic stand-in for the hot path: the reconstruction is a function of the source and of BOTH references'
+    reconstructions, so a picture that started before a reference arrived produces a different result"""
+    out = _source(poc).to(torch.int32)
+    if ref0 is not None:
+        out = out + 3 * ref0.to(torch.int32) + 5 * ref1.to(torch.int32).roll(1)
+    return (out % 251).to(torch.uint8)
+
+
+def _expected(n_sops):
+    """per-POC reconstructions computed sequentially in coding order (no scheduling involved)"""
+    rec = {}
+    for p in fp.coding_order(n_sops):
+        rec[p.poc] = _encode(p.poc, rec[p.l0] if p.refs else None, rec[p.l1] if p.refs else None)
+    return rec
+
+
+def _worker(rank, world, port, n_sops, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    nl, nc = 4096, 1024
-    luma, chroma = torch.zeros(nl, dtype=torch.uint8), torch.zeros(nc, dtype=torch.uint8)
-    ex = fp.ReferenceExchange(dist, rank, world, luma, chroma, slots=6, n_sops=4)
-    for s in range(steps):
-        pic = ex.picture_of(s, rank)
-        luma.copy_(_recon_for(pic, nl))            # "encode" my picture of this step
-        chroma.copy_(_recon_for(pic, nl)[:nc])
-        ex.exchange(s)
-    out[rank] = (torch.stack(ex.dpb_luma).numpy().copy(), torch.stack(ex.dpb_chroma).numpy().copy(), ex.sent_bytes)
+    sched = fp.DagSchedule(world, n_sops=n_sops)
+    ex = fp.ReferenceExchange(dist, rank, sched, NL, NC, torch.zeros(1, dtype=torch.uint8))
+    want = _expected(n_sops)
+    sums = {}
+    early = []
+    t = 0
+    while not sched.finished(t):
+        pic = ex.picture_of(t)
+        rec = None
+        if pic is not None:
+            if pic.refs:
+                s0, s1 = ex.refs(pic)
+                r0, r1 = ex.dpb[s0].clone(), ex.dpb[s1].clone()      # read from the MIRROR, whoever encoded them
+                if not (torch.equal(r0, want[pic.l0]) and torch.equal(r1, want[pic.l1])):
+                    early.append(pic.poc)                             # a reference had not arrived (or was overwritten)
+                rec = _encode(pic.poc, r0, r1)
+            else:
+                rec = _encode(pic.poc, None, None)
+            sums[pic.poc] = int(rec.to(torch.int64).sum()) * 1000003 + int(rec[::7].to(torch.int64).sum())
+            ex.stage(t, (rec[:NL], rec[NL:NL + NC], rec[NL + NC:]))
+        ex.send(t)
+        t += 1
+    out[rank] = (sums, early, ex.sent_bytes, ex.broadcasts, t)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _run(world, steps):
+def _run(world, n_sops):
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), steps, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), n_sops, out), nprocs=world, join=True)
     return dict(out)
 
 
-def test_reference_exchange_gloo_world2_matches_single_process():
-    steps2, steps1 = 8, 16            # the same 16 pictures: 2 ranks x 8 steps vs 1 rank x 16 steps
-    two = _run(2, steps2)
-    one = _run(1, steps1)
-    # every rank's DPB mirror is identical, and equals the single-process store
-    assert np.array_equal(two[0][0], two[1][0]) and np.array_equal(two[0][1], two[1][1])
-    assert np.array_equal(two[0][0], one[0][0]) and np.array_equal(two[0][1], one[0][1])
-    # the store holds real reconstructions: slot of POC 8 ((8//2) % 6 = 4)
-    pics = fp.coding_order(4)
-    p8 = next(p for p in pics if p.poc == 8)
-    assert np.array_equal(two[0][0][4], _recon_for(p8, 4096).numpy())
-    # only reference pictures were sent (coding order 0 8 4 2 1 3 6 5 7 8+8 ...: count refs among the first 16)
-    nref = sum(p.is_reference for p in pics[:16])
-    assert two[0][2] + two[1][2] == nref * (4096 + 1024) * 1
+def test_frame_parallel_gloo_world2_equals_single_rank_per_poc():
+    n_sops = 3
+    two, one = _run(2, n_sops), _run(1, n_sops)
+    want = {poc: int(r.to(torch.int64).sum()) * 1000003 + int(r[::7].to(torch.int64).sum()) for poc, r in _expected(n_sops).items()}
+    # no picture started before its references had arrived in the local mirror
+    assert two[0][1] == [] and two[1][1] == [] and one[0][1] == []
+    # every picture was encoded exactly once across the ranks, and its result does not depend on the number of ranks
+    merged = dict(two[0][0])
+    assert not (set(merged) & set(two[1][0]))
+    merged.update(two[1][0])
+    assert merged == one[0][0] == want
+    # only reference pictures were broadcast: the IDR + 4 per SOP, each once
+    nref = 1 + 4 * n_sops
+    assert two[0][3] == two[1][3] == nref
+    assert two[0][2] + two[1][2] == nref * (NL + 2 * NC)
+    assert two[0][4] == fp.DagSchedule(2, n_sops=n_sops).slots_for_sequence() and one[0][4] == 1 + 8 * n_sops

@@ -12,11 +12,11 @@ def hv():
     return Havoc(0, stream="new")
 
 
-def _frames(hv, res, bit_depth, seed):
+def _frames(hv, res, bit_depth, seed, qp=32):
     import bench
     from turingcodec_amd.workload import FrameWorkload
     w, h = res
-    wl = FrameWorkload(w, h, bit_depth, seed)
+    wl = FrameWorkload(w, h, bit_depth, seed, qp=qp)
     return wl, bench.DeviceFrame(hv, wl, use_planes=True), bench.DeviceFrame(hv, wl, use_planes=False)
 
 
@@ -89,35 +89,56 @@ def test_tu_chain_roundtrip_property(hv):
         assert np.isfinite(ssd).all() and ssd.mean() / (n * n) < 200.0, (log2, tr, ssd.mean() / (n * n))
 
 
-def test_bench_multi_rank_path_rehearsal():
-    """bench.py's N>1 path (process group, one picture per rank, staged + overlapped reference exchange, barrier,
-    max over ranks) with two ranks sharing the one GPU of the test box; gloo stands in for RCCL, which refuses two
-    ranks on one device.  The per-rank results must be those of the single-rank run of the same seed."""
+def _bench_json(cmd, env, root, timeout=900):
     import json
-    import os
     import subprocess
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_bench_frame_parallel_rehearsal_equals_single_rank_per_poc():
+    """bench.py's N>1 path (process group, dependency-aware schedule, references read from the DPB mirror, staged +
+    overlapped broadcasts, barrier, max over ranks) with two ranks sharing the one GPU of the test box; gloo stands in
+    for RCCL, which refuses two ranks on one device.  A fixed 17-picture sequence (IDR + 2 SOPs): the reconstruction
+    checksum of every POC must be the one the single-rank run produces -- i.e. no picture started before its references
+    had arrived, and who encodes a picture does not matter."""
+    import os
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HAVOC_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29577", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--kernel-reps", "1"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
-    assert out.returncode == 0, out.stderr[-2000:]
-    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
-    r = json.loads(line)
-    assert r["n_gpus"] == 2 and r["steps"] == 4 and r["scaling"] == "weak" and r["value"] > 0
-    assert "frame-parallel x2" in r["config"]["parallelism"]
-    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--kernel-reps", "1",
-                          "--no-cpu-baseline", "--exchange"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
-    assert one.returncode == 0, one.stderr[-2000:]
-    r1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
-    assert r1["checksum"] == r["checksum"]     # rank 0 encodes the same picture (seed + rank) in both runs
+    common = ["--kernel-reps", "1", "--tune", "0", "--scaling", "strong", "--pictures", "17", "--poc-checksums", "--no-cpu-baseline",
+              "--res", "640x360"]
+    r2 = _bench_json([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                      "--master-port", "29577", os.path.join(root, "bench.py"), "--gpus", "2"] + common, env, root)
+    assert r2["n_gpus"] == 2 and r2["scaling"] == "strong" and r2["value"] > 0
+    assert "frame-parallel x2" in r2["config"]["parallelism"]
+    r1 = _bench_json([sys.executable, os.path.join(root, "bench.py"), "--exchange"] + common, env, root)
+    assert r1["n_gpus"] == 1 and len(r1["poc_checksums"]) == 17
+    # rank 0 of the 2-rank run saw about half of the pictures; each of them must agree with the single-rank run
+    assert 6 <= len(r2["poc_checksums"]) <= 11
+    for poc, c in r2["poc_checksums"].items():
+        assert r1["poc_checksums"][poc] == c, poc
+    # the dependency is real: pictures of one hierarchy level have different reconstructions
+    assert len(set(r1["poc_checksums"].values())) == 17
+    from turingcodec_amd.frame_parallel import DagSchedule
+    assert r2["steps"] == DagSchedule(2, n_sops=2).slots_for_sequence() and r1["steps"] == 17
 
 
-def test_full_size_results_equal_the_reference_library(hv):
-    """every 4th job of the 1080p frame through the reference's own havoc functions (oracle/_ref, built from the
-    reference sources by oracle/Makefile; x86 JIT tables) on the host, against the GPU results of the same jobs:
-    SAD4, SAD, PU SATD, intra predictions, 35-mode intra costs and forward-transform coefficients, ~20 M values"""
+def test_bench_weak_scaling_rehearsal_two_ranks():
+    """the driver's N>1 invocation (weak scaling: steady state, one picture per rank per slot) with two gloo ranks on one GPU"""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HAVOC_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = _bench_json([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                     "--master-port", "29578", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "6", "--kernel-reps", "1",
+                     "--tune", "0", "--min-seconds", "0.05", "--res", "640x360"], env, root)
+    assert r["n_gpus"] == 2 and r["steps"] == 6 and r["scaling"] == "weak" and r["value"] > 0
+    assert r["config"]["pictures_per_timed_block"] == 12.0     # both ranks busy in every timed slot
+
+
+def _parity_vs_reference(hv, res, bit_depth, qp, mix="ra", seed=11, min_values=10_000_000):
     import argparse
     import os
     import bench
@@ -125,15 +146,69 @@ def test_full_size_results_equal_the_reference_library(hv):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     if not os.path.exists(os.path.join(root, "oracle", "_ref", "libhavoc_ref.so")):
         pytest.skip("oracle/_ref not built (needs the reference sources at build time)")
-    wl = FrameWorkload(1920, 1080, 8, 11)
+    wl = FrameWorkload(res[0], res[1], bit_depth, seed, qp=qp, mix=mix)
     dev = bench.DeviceFrame(hv, wl)
     dev.step()
     hv.sync()
-    r = bench.cpu_baseline(argparse.Namespace(res="1920x1080", bit_depth=8, seed=11), dev)
+    r = bench.cpu_baseline(argparse.Namespace(res=f"{res[0]}x{res[1]}", bit_depth=bit_depth, seed=seed, qp=qp, mix=mix), dev)
     assert r is not None and r["kind"] == "reference"
     p = r["parity_vs_reference"]
     assert "error" not in p, p
-    assert p["compared"] > 10_000_000 and p["mismatches"] == 0, p
+    assert p["compared"] > min_values and p["mismatches"] == 0, p
+    return p
+
+
+def test_full_size_results_equal_the_reference_library(hv):
+    """every 4th job of the 1080p frame (BASELINE.json configs[1]: 8-bit QP32) through the reference's own havoc functions
+    (oracle/_ref, built from the reference sources by oracle/Makefile; x86 JIT tables) on the host, against the GPU results
+    of the same jobs: SAD4, SAD, PU SATD, uni / bi interpolations (luma + chroma), SubtractBi, sub-pel candidate costs, intra
+    predictions, 35-mode intra costs, forward coefficients, quantised levels, reconstructions and their SSDs"""
+    p = _parity_vs_reference(hv, (1920, 1080), 8, 32)
+    for name in ("pred_bi8", "pred_bi4", "subtract_bi", "rec_3_0", "ssd_3_0", "level_2_1"):
+        assert name in p["what"], name
+
+
+@pytest.mark.parametrize("bit_depth", [8, 10])
+def test_4k_qp27_results_equal_the_reference_library(hv, bit_depth):
+    """BASELINE.json configs[2] and [3]: 3840x2160 random-access QP27, 8-bit and 10-bit (16-bit sample kernels)"""
+    _parity_vs_reference(hv, (3840, 2160), bit_depth, 27, min_values=40_000_000)
+
+
+def test_all_intra_fast_mix_equals_the_reference_library(hv):
+    """BASELINE.json configs[0]: 640x360 all-intra QP32 speed=fast -- intra + TU chain with havoc_quantize IN the timed
+    chain (no RDOQ at fast, turing/Reconstruct.cpp:310-311)"""
+    p = _parity_vs_reference(hv, (640, 360), 8, 32, mix="ai", seed=7, min_values=1_000_000)
+    assert "level_3_0" in p["what"] and "sad4" not in p["what"]
+
+
+def test_8k_frame_properties(hv):
+    """BASELINE.json configs[4] resolution (7680x4320 8-bit QP32) on one GPU, through size-independent properties: the two
+    independent sub-pel routes agree for every candidate, the fused TU chain's reconstruction error stays within the
+    quantiser step, the final reconstruction pass covers every sample of the picture exactly once and serial == 8-lane
+    execution"""
+    wl, a, b = _frames(hv, (7680, 4320), 8, 19)
+    a.step()
+    b.step()
+    hv.sync()
+    n = sum(len(v) for v in wl.subpel_idx.values())
+    ca, cb = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    for c, g in a.subpel_planes.items():
+        idx = wl.subpel_planes_idx[c].ravel()
+        ca[idx[idx >= 0]] = hv.down(g["cost"], np.int32)[idx >= 0]
+    for c, g in b.subpel.items():
+        cb[wl.subpel_idx[c]] = hv.down(g["cost"], np.int32)
+    assert n > 2_000_000 and np.array_equal(ca, cb)
+    for (log2, tr), g in a.tu.items():
+        ssd = hv.down(g["ossd"], np.uint32).astype(np.float64)
+        assert ssd.mean() / (1 << (2 * log2)) < 200.0, (log2, tr)
+    pl, st = wl.plane_len, wl.stride
+    rec = hv.down(a.luma[3 * pl:4 * pl], np.uint8).reshape(-1, st)[96:96 + 4320, 96:96 + 7680]
+    src = wl.luma[:pl].reshape(-1, st)[96:96 + 4320, 96:96 + 7680]
+    assert np.abs(rec.astype(np.int32) - src).mean() < 40 and (rec != 0).mean() > 0.95   # every block was reconstructed
+    ref = a.checksum()
+    a.step(8)
+    hv.sync()
+    assert a.checksum() == ref
 
 
 def test_bench_line_contract():

@@ -66,3 +66,39 @@ def test_jobs_are_grouped_as_the_search_issues_them(wl):
     assert (g[:, :, 0] == g[:, :1, 0]).all() and (g[:, :, 5] == g[:, :1, 5]).all()       # one PU per run of SAD4 calls
     for jm in wl.subpel_planes.values():
         assert ((jm[:, 3] == 16) | (jm[:, 3] == 1)).all()
+
+
+@pytest.mark.parametrize("res", [(640, 360), (1920, 1080)])
+def test_final_reconstruction_pass_tiles_the_picture_once(res):
+    """workload.recon: every luma / chroma sample of the picture belongs to exactly one transform unit of the final pass"""
+    w, h = res
+    wl = FrameWorkload(w, h, 8, 5)
+    for comp, (pw, ph, stride, plane_len, pad, plane) in {"y": (w, h, wl.stride, wl.plane_len, 96, 3), "cb": (w // 2, h // 2, wl.cstride, wl.cplane_len, 48, 3),
+                                                          "cr": (w // 2, h // 2, wl.cstride, wl.cplane_len, 48, 4)}.items():
+        cover = np.zeros((ph, pw), np.int32)
+        for log2, g in wl.recon[comp].items():
+            n = g["n"]
+            assert n == 1 << log2 and len(g["levels"]) == len(g["jobs"]) * n * n
+            o = g["jobs"][:, 3].astype(np.int64) - plane * plane_len
+            y, x = o // stride - pad, o % stride - pad
+            for xi, yi in zip(x, y):
+                cover[yi:yi + n, xi:xi + n] += 1
+            _inside(wl, g["jobs"][:, 2], np.full(len(o), n), np.full(len(o), n), 0, 5, plane_len, stride, plane_len // stride)
+        assert cover.min() == 1 and cover.max() == 1, comp
+
+
+def test_all_intra_mix_has_no_inter_calls_and_the_survey_counts():
+    from turingcodec_amd.workload import CALLS_AI_PER_CTU
+    wl = FrameWorkload(640, 360, 8, 7, mix="ai")
+    assert set(wl.counts) == set(CALLS_AI_PER_CTU)
+    for k, v in CALLS_AI_PER_CTU.items():
+        assert abs(wl.counts[k] - v * 60) <= 1, k
+    assert sum(len(g["jobs"]) for g in wl.tu.values()) == wl.counts["tu"]
+
+
+def test_quantiser_parameters_follow_qpstate():
+    """turing/QpState.h:85-94 / Reconstruct.cpp:286,311,315 at the QPs of BASELINE.json's configs"""
+    from turingcodec_amd.workload import dequant_params, quant_params
+    assert quant_params(32, 3, 8, False) == (20560, 29 - 8 + 5 - 3, 85 << 7)
+    assert quant_params(27, 5, 10, True) == (18396, 29 - 10 + 4 - 5, 171 << 7)
+    assert dequant_params(32, 3, 8) == (51 << 5, 2) and dequant_params(27, 2, 10) == (57 << 4, 3)

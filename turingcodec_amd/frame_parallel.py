@@ -1,17 +1,24 @@
 """Frame-parallel sharding of the hot path over the GPUs of one node.
 
 The primitive layer itself has no cross-block dependency; what ties pictures together is that inter prediction reads
-RECONSTRUCTED reference pictures.  The unit of sharding is therefore the picture: one process per GPU, pictures dealt
-to ranks in coding order, and ONE exchange step per reference picture -- the owner broadcasts its padded
-reconstruction (Y, Cb, Cr planes) to every rank's mirror of the decoded-picture buffer with an RCCL broadcast over
-xGMI (backend "nccl" on ROCm; the CPU tests run the same code over gloo).  Non-reference pictures (the RASL_N /
-TRAIL_N leaves of the hierarchy) are never sent.  No reduction collective exists on this path.
+RECONSTRUCTED reference pictures.  The unit of sharding is therefore the picture: one process per GPU, and ONE exchange
+step per reference picture -- the owner broadcasts its padded reconstruction (Y, Cb, Cr planes) to every rank's mirror
+of the decoded-picture buffer with an RCCL broadcast over xGMI (backend "nccl" on ROCm; the CPU tests run the same code
+over gloo).  Non-reference pictures (the RASL_N / TRAIL_N leaves of the hierarchy) are never sent.  No reduction
+collective exists on this path.
 
-The structure-of-pictures below restates the reference's 8-picture hierarchical-B docket
-(turing/InputQueue.cpp:370-379: coding order 8 4 2 1 3 6 5 7; reference flags nutR/nutN; reference deltas).
+Who may start when follows the reference: the structure-of-pictures below restates its 8-picture hierarchical-B docket
+(turing/InputQueue.cpp:370-379: coding order 8 4 2 1 3 6 5 7; reference flags nutR/nutN; reference deltas), and a picture
+starts only when every picture it predicts from is complete and has arrived in the local DPB mirror -- the picture-level
+form of the reference's wait-for-reference rule (turing/TaskEncodeSubstream.cpp:71-95 blocks a CTU until the reference
+picture is reconstructed 4 CTUs to the right / 3 rows below; across GPUs the granule is the whole picture).
+`DagSchedule` is the resulting list schedule: per time slot at most one picture per rank, earliest coding-order
+picture first among the ready ones.  With 8 ranks it settles into the level-skewed pipeline -- per slot the anchor of SOP
+k+3, POC 4 of SOP k+2, POCs 2 and 6 of SOP k+1 and POCs 1, 3, 5, 7 of SOP k -- i.e. eight pictures in flight, which is
+what ">= 6x at 8 GPUs" needs.
 """
 from dataclasses import dataclass
-from typing import List, Tuple
+from typing import Dict, List, Optional, Tuple
 
 # (poc offset inside the SOP, is_reference, reference deltas)   -- turing/InputQueue.cpp:325-379
 SOP8: List[Tuple[int, bool, Tuple[int, ...]]] = [
@@ -33,6 +40,18 @@ class Picture:
     is_reference: bool
     refs: Tuple[int, ...]   # POCs of the pictures it predicts from
 
+    @property
+    def l0(self) -> Optional[int]:
+        """POC searched as list 0: the nearest earlier picture of the reference set (refIdx 0, turing/Search.hpp:1883)"""
+        past = [q for q in self.refs if q < self.poc]
+        return max(past) if past else (min(self.refs) if self.refs else None)
+
+    @property
+    def l1(self) -> Optional[int]:
+        """POC searched as list 1: the nearest later picture; a picture without one (the SOP anchors) uses L0 again"""
+        fut = [q for q in self.refs if q > self.poc]
+        return min(fut) if fut else self.l0
+
 
 def coding_order(n_sops: int) -> List[Picture]:
     """IDR (POC 0) followed by n_sops hierarchical-B SOPs of 8 pictures, in coding order"""
@@ -47,90 +66,170 @@ def coding_order(n_sops: int) -> List[Picture]:
     return pics
 
 
+class DagSchedule:
+    """List schedule of a hierarchical-B sequence on `world` ranks in lock-step time slots.
+
+    slot(t) -> [Picture or None] * world: the picture each rank works on in slot t.  A picture is READY in slot t when
+    every picture it references was scheduled in a slot < t (its reconstruction is broadcast at the end of its slot) and,
+    for a reference picture, a DPB mirror slot is free.  Among ready pictures the earliest in coding order goes first;
+    run-ahead is bounded by `window` pictures beyond the oldest unscheduled one (DPB capacity).  Deterministic: every
+    rank computes the same plan.  dpb_slot[poc] = mirror slot a reference picture lives in until its last user is done.
+
+    n_sops = None: an endless sequence (the steady state of the weak-scaling bench); an int: IDR + n_sops SOPs, after
+    which slot() returns all-None (the strong-scaling run over a fixed sequence)."""
+
+    def __init__(self, world: int, dpb_slots: int = 24, n_sops: Optional[int] = None, window: int = 32):
+        assert world >= 1 and dpb_slots >= 6
+        self.world, self.n_slots_dpb, self.n_sops, self.window = world, dpb_slots, n_sops, window
+        self.pics: List[Picture] = [Picture(0, 0, True, ())]
+        self._sops = 0
+        self.by_poc: Dict[int, Picture] = {0: self.pics[0]}
+        self.done_slot: Dict[int, int] = {}          # poc -> slot it was scheduled in
+        self.dpb_slot: Dict[int, int] = {}           # poc -> DPB mirror slot (reference pictures)
+        self._free = list(range(dpb_slots))
+        self._held: Dict[int, int] = {}              # poc -> mirror slot still held
+        self._next = 0                               # oldest unscheduled coding-order index
+        self._scheduled = set()
+        self._plan: List[List[Optional[Picture]]] = []
+
+    # ---- sequence generation ---------------------------------------------------------------------------------------
+    def _grow(self, upto_index: int):
+        while len(self.pics) <= upto_index and (self.n_sops is None or self._sops < self.n_sops):
+            base = 8 * self._sops
+            last = None if self.n_sops is None else 8 * self.n_sops
+            for off, is_ref, deltas in SOP8:
+                poc = base + off
+                refs = tuple(sorted({poc + d for d in deltas if poc + d >= 0 and (last is None or poc + d <= last)}))
+                p = Picture(len(self.pics), poc, is_ref, refs)
+                self.pics.append(p)
+                self.by_poc[poc] = p
+            self._sops += 1
+
+    def _users_done(self, poc: int) -> bool:
+        """every picture that references `poc` has been scheduled (users live in the SOP of poc and the next one)"""
+        sop = (poc - 1) // 8 if poc > 0 else -1
+        self._grow(1 + 8 * (sop + 2))                # SOPs sop and sop + 1 exist (or the sequence ends before)
+        lo, hi = max(0, 1 + 8 * sop), min(len(self.pics), 1 + 8 * (sop + 2))
+        return all(p.index in self._scheduled for p in self.pics[lo:hi] if poc in p.refs)
+
+    def total_pictures(self) -> Optional[int]:
+        return None if self.n_sops is None else 1 + 8 * self.n_sops
+
+    # ---- the schedule ----------------------------------------------------------------------------------------------
+    def slot(self, t: int) -> List[Optional[Picture]]:
+        while len(self._plan) <= t:
+            self._plan.append(self._make_slot(len(self._plan)))
+        return self._plan[t]
+
+    def _make_slot(self, t: int) -> List[Optional[Picture]]:
+        # release the mirror slots whose picture has no unscheduled user left (users ran in slots < t)
+        for poc in [q for q in self._held if self._users_done(q)]:
+            # the sequence's last pictures keep their slots (nothing else needs them)
+            if self.n_sops is None or poc < 8 * self.n_sops:
+                self._free.append(self._held.pop(poc))
+        self._free.sort()
+        self._grow(self._next + self.window)
+        chosen: List[Picture] = []
+        i = self._next
+        while len(chosen) < self.world and i < len(self.pics) and i < self._next + self.window:
+            p = self.pics[i]
+            i += 1
+            if p.index in self._scheduled:
+                continue
+            if not all(self.done_slot.get(q, t) < t for q in p.refs):
+                continue
+            if p.is_reference:
+                if not self._free:
+                    continue
+                s = self._free.pop(0)
+                self.dpb_slot[p.poc] = s
+                self._held[p.poc] = s
+            chosen.append(p)
+        for p in chosen:
+            self._scheduled.add(p.index)
+            self.done_slot[p.poc] = t
+        while self._next < len(self.pics) and self._next in self._scheduled:
+            self._next += 1
+        # ranks take the slot's pictures in coding order; a rank without one idles this slot
+        return [chosen[r] if r < len(chosen) else None for r in range(self.world)]
+
+    def finished(self, t: int) -> bool:
+        """True when the (finite) sequence is completely scheduled in slots < t"""
+        if self.n_sops is None:
+            return False
+        self.slot(t)
+        return self._next >= 1 + 8 * self.n_sops and all(p is None for p in self._plan[t])
+
+    def slots_for_sequence(self) -> int:
+        """number of slots the finite sequence takes on `world` ranks"""
+        assert self.n_sops is not None
+        t = 0
+        while not self.finished(t):
+            t += 1
+        return t
+
+
 def owner(pic_index: int, world: int) -> int:
-    """pictures are dealt round-robin in coding order: picture i is encoded by rank i % world"""
+    """round-robin dealing in coding order (the round-1 plan; kept for comparison in tests -- it ignores dependencies)"""
     return pic_index % world
 
 
-def dependency_ready_step(pics: List[Picture], world: int) -> List[int]:
-    """earliest lock-step `step` at which each picture may start: one after the step of its latest reference.
-    With world ranks in lock step, step s encodes pictures [s*world, (s+1)*world); a picture whose reference sits in
-    the same step waits for the reference's rows as the reference encoder does (turing/TaskEncodeSubstream.cpp:71-95),
-    which the lock-step model approximates by the next step.  Used by tests to check the plan is a valid schedule."""
-    by_poc = {p.poc: p for p in pics}
-    ready = []
-    for p in pics:
-        r = 0
-        for q in p.refs:
-            r = max(r, by_poc[q].index // world + 1)
-        ready.append(r)
-    return ready
-
-
 class ReferenceExchange:
-    """Mirror of the decoded-picture buffer on every rank + the broadcast step.
+    """Mirror of the decoded-picture buffer on every rank + the broadcast step of a DagSchedule.
 
-    `recon_luma` / `recon_chroma` are this rank's reconstruction planes (1-D tensors in the padded picture layout).
-    Every DPB slot is ONE flat buffer (luma then chroma), so a reference picture costs one broadcast, not one per
-    plane.  After every rank finished step `step`:
+    Every DPB mirror slot is ONE flat buffer (luma, Cb, Cr in the padded picture layout), so a reference picture costs
+    one broadcast, not one per plane.  Per time slot t:
 
-      stage(step)  the owner of a reference picture copies its planes into slot (poc/2 % slots) of its own mirror --
-                   from then on the reconstruction planes may be overwritten by the next picture;
-      send(step)   one broadcast per reference picture of the step, owner -> every rank's mirror.
+      stage(t, planes)  the rank that encoded a reference picture in slot t copies its reconstruction into the picture's
+                        mirror slot (schedule.dpb_slot[poc]) -- from then on the reconstruction planes may be reused;
+      send(t)           one broadcast per reference picture of the slot, owner -> every rank's mirror, issued by all
+                        ranks in rank order.
 
-    `exchange(step)` = stage + send.  On the GPU both are enqueued on the caller's current stream (the broadcasts on
-    RCCL's own stream behind it), so a caller that orders its compute stream only after `stage` overlaps the
-    broadcasts of picture i with the computation of picture i+1 (bench.py)."""
+    On the GPU both are enqueued on the caller's current stream (the broadcasts on RCCL's own stream behind it), so a
+    caller that orders its compute stream only after `stage` overlaps the broadcasts of slot t with the computation of
+    slot t + 1 (bench.py).  `refs(pic)` returns the mirror buffers a picture predicts from: a picture's kernels read
+    their references FROM THE MIRROR, whoever encoded them."""
 
-    def __init__(self, dist, rank: int, world: int, recon_luma, recon_chroma, slots: int = 6, n_sops: int = 64,
-                 single_rank_broadcast: bool = False, recon_chroma2=None):
+    def __init__(self, dist, rank: int, schedule: DagSchedule, n_luma: int, n_chroma: int, like, single_rank_broadcast: bool = False):
         import torch
         self._torch = torch
-        self.dist, self.rank, self.world = dist, rank, world
+        self.dist, self.rank, self.world, self.schedule = dist, rank, schedule.world, schedule
         self.single_rank_broadcast = single_rank_broadcast   # exercise the collective even when world == 1
-        self.recon_luma, self.recon_chroma = recon_luma, recon_chroma
-        self.pics = coding_order(n_sops)
-        self.slots = slots
-        self.recon_chroma2 = recon_chroma2                   # second chroma plane (Cr), when the caller keeps one
-        nl, nc = recon_luma.numel(), recon_chroma.numel()
-        nc2 = recon_chroma2.numel() if recon_chroma2 is not None else 0
-        self.dpb = [recon_luma.new_zeros(nl + nc + nc2) for _ in range(slots)]
-        self.dpb_luma = [b[:nl] for b in self.dpb]          # views
-        self.dpb_chroma = [b[nl:nl + nc] for b in self.dpb]
-        self.dpb_chroma2 = [b[nl + nc:] for b in self.dpb]
+        self.nl, self.nc = n_luma, n_chroma
+        self.dpb = [like.new_zeros(n_luma + 2 * n_chroma) for _ in range(schedule.n_slots_dpb)]
+        self.dpb_luma = [b[:n_luma] for b in self.dpb]          # views
+        self.dpb_cb = [b[n_luma:n_luma + n_chroma] for b in self.dpb]
+        self.dpb_cr = [b[n_luma + n_chroma:] for b in self.dpb]
         self.sent_bytes = 0
+        self.broadcasts = 0
 
-    def picture_of(self, step: int, rank: int) -> Picture:
-        return self.pics[(step * self.world + rank) % len(self.pics)]
+    def picture_of(self, t: int, rank: Optional[int] = None) -> Optional[Picture]:
+        return self.schedule.slot(t)[self.rank if rank is None else rank]
 
-    @staticmethod
-    def slot_of(pic: Picture, slots: int) -> int:
-        return (pic.poc // 2) % slots   # reference pictures have even POC inside a SOP (8 4 2 6) or are the IDR
+    def slot_of(self, poc: int) -> int:
+        return self.schedule.dpb_slot[poc]
 
-    def stage(self, step: int, planes=None):
-        """`planes`: (luma, chroma[, chroma2]) of the picture being staged when the caller keeps several pictures in
-        flight; default: the tensors given at construction"""
-        pic = self.picture_of(step, self.rank)
-        if pic.is_reference:
-            slot = self.slot_of(pic, self.slots)
-            if planes is None:
-                planes = (self.recon_luma, self.recon_chroma) + ((self.recon_chroma2,) if self.recon_chroma2 is not None else ())
-            dst, src = [self.dpb_luma[slot], self.dpb_chroma[slot]], list(planes)
-            if len(src) > 2:
-                dst.append(self.dpb_chroma2[slot])
-            self._torch._foreach_copy_(dst, src)   # one launch for the planes (this sits between two pictures' kernels)
+    def refs(self, pic: Picture):
+        """(L0 mirror buffer index, L1 mirror buffer index) of a picture, None for the IDR"""
+        if not pic.refs:
+            return None
+        return self.slot_of(pic.l0), self.slot_of(pic.l1)
 
-    def send(self, step: int):
+    def stage(self, t: int, planes):
+        """planes = (luma, cb, cr) reconstruction of this rank's picture of slot t"""
+        pic = self.picture_of(t)
+        if pic is not None and pic.is_reference:
+            s = self.slot_of(pic.poc)
+            self._torch._foreach_copy_([self.dpb_luma[s], self.dpb_cb[s], self.dpb_cr[s]], list(planes))   # one launch
+
+    def send(self, t: int):
         for src in range(self.world):
-            pic = self.picture_of(step, src)
-            if not pic.is_reference:
+            pic = self.picture_of(t, src)
+            if pic is None or not pic.is_reference:
                 continue
-            buf = self.dpb[self.slot_of(pic, self.slots)]
+            buf = self.dpb[self.slot_of(pic.poc)]
             if src == self.rank:
                 self.sent_bytes += buf.numel() * buf.element_size() * (self.world - 1)
             if self.world > 1 or self.single_rank_broadcast:
                 self.dist.broadcast(buf, src=src)
-
-    def exchange(self, step: int):
-        self.stage(step)
-        self.send(step)
+                self.broadcasts += 1

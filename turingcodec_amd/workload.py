@@ -29,6 +29,13 @@ CALLS_1080P = {
     "tu": 2452215 // 9,                 # fwd T, de-quant, inverse T + add (RDOQ replaces havoc_quantize at medium)
     "ssd": (1644543 + 1444224) // 9,
 }
+# all-intra speed=fast (BASELINE.json configs[0]: 640x360 all-intra QP32 fast): per-CTU counts of the intra / TU primitives
+# from SURVEY.md Appendix A.1 (1020 CTUs: intra SATD stage 1 101 590, RD luma + chroma 232 125 + 114 900, 481 905 TUs,
+# 421 389 + 265 788 SSDs); no inter primitive is called, and with RDOQ off at speed=fast (turing/Speed.h:127-130) the TU
+# chain goes through havoc_quantize (turing/Reconstruct.cpp:310-311), which is therefore IN this mix.
+CALLS_AI_PER_CTU = {
+    "intra_satd": 1101590 / 1020, "intra_rd": (232125 + 114900) / 1020, "tu": 481905 / 1020, "ssd": (421389 + 265788) / 1020,
+}
 # every luma interpolation is followed by a PU SATD (costDistortionMv / measurePuCost): measureSatd calls/B-frame
 # = 1689441/8 ~ 211k ~ the luma uni count, so the SATD batch pairs one job with each luma uni prediction.
 
@@ -76,6 +83,21 @@ def pad_plane(p, pad, align_bytes=64):
     return np.ascontiguousarray(q)
 
 
+# turing/QpState.h:85-94
+QUANT_SCALE = [26214, 23302, 20560, 18396, 16384, 14564]
+DEQUANT_SCALE = [40, 45, 51, 57, 64, 72]
+
+
+def quant_params(qp, log2, bit_depth, intra_slice):
+    """(scale, shift, offset) as turing/Reconstruct.cpp:286,311 (intra) / :785,817 (inter) hand them to havoc_quantize"""
+    return QUANT_SCALE[qp % 6], 29 - bit_depth + qp // 6 - log2, (171 if intra_slice else 85) << 7
+
+
+def dequant_params(qp, log2, bit_depth):
+    """(scale, shift) of turing/QpState.h:85-86 / Reconstruct.cpp:315"""
+    return DEQUANT_SCALE[qp % 6] << (qp // 6), log2 - 1 + bit_depth - 8
+
+
 def _pick(rng, mix, n):
     w = np.array([m[-1] for m in mix], np.float64)
     return rng.choice(len(mix), size=n, p=w / w.sum())
@@ -84,7 +106,12 @@ def _pick(rng, mix, n):
 class FrameWorkload:
     """Job tables (numpy int32, columns = the job structs of include/havoc_mi355x.h) + picture store layout."""
 
-    def __init__(self, width=1920, height=1080, bit_depth=8, seed=11, scale=1.0):
+    def __init__(self, width=1920, height=1080, bit_depth=8, seed=11, scale=1.0, qp=32, mix="ra"):
+        """mix: "ra" = one random-access B-frame at speed=medium (Appendix A.2 counts); "ai" = one all-intra frame at
+        speed=fast (Appendix A.1 per-CTU intra / TU counts, havoc_quantize in the TU chain).  qp: the slice QP the
+        (de)quantiser parameters are derived from (BASELINE.json: 32 for configs 0, 1, 4; 27 for configs 2, 3)."""
+        assert mix in ("ra", "ai")
+        self.qp, self.mix = qp, mix
         self.width, self.height, self.bit_depth = width, height, bit_depth
         self.S = 1 if bit_depth == 8 else 2
         rng = np.random.default_rng(seed)
@@ -102,7 +129,10 @@ class FrameWorkload:
         ctus = ((width + CTU - 1) // CTU) * ((height + CTU - 1) // CTU)
         f = scale * ctus / 510.0
         n = {k: max(1, int(round(v * f))) for k, v in CALLS_1080P.items()}
-        self.counts = n
+        if mix == "ai":   # no inter primitive at all; a minimal stub of each inter table keeps the layout code below uniform
+            n = {k: 16 if k != "sad4" else 31 for k in n}
+            n.update({k: max(1, int(round(v * scale * ctus))) for k, v in CALLS_AI_PER_CTU.items()})
+        self.counts = n if mix == "ra" else {k: n[k] for k in CALLS_AI_PER_CTU}
         W, H, st, pl = width, height, self.stride, self.plane_len
 
         def pu(nj):
@@ -176,7 +206,7 @@ class FrameWorkload:
         # costDistortionMv candidates (1474818/8 per B-frame, A.2) only need the COST: they go through the fused
         # interpolation+SATD entry point, one launch per PU size class; the rest (measurePuCost: the prediction is
         # kept) are written to prediction slots and measured by the SATD batch
-        nsearch = min(len(u) - 1, int(round(1474818 / 8 * f)))
+        nsearch = min(len(u) - 1, int(round(1474818 / 8 * f))) if mix == "ra" else 32
         sp = u[:nsearch].copy()
         sp[:, 0] = sp[:, 6]          # dst_off field = source PU offset (havoc_mi355x_subpel_satd)
         sp[:, 6] = 0
@@ -357,6 +387,43 @@ class FrameWorkload:
         cx, cy = mv(ns, 28)          # predictor; +-64 around it stays inside the 96-sample padding
         self.me_search = np.stack([loff(x, y, 0), loff(x + cx, y + cy, rng.integers(1, 3, ns)), w, h], 1).astype(np.int32)
 
+        # ---- final reconstruction of the picture: every sample reconstructed ONCE into the reconstruction planes (plane 3
+        # of the luma store, planes 3 / 4 = Cb / Cr of the chroma store) -- the pass that produces what later pictures
+        # predict from.  Tiling: 32x32 luma (16x16 chroma) TUs over the area that is a multiple of 32 (16), 8x8 (4x4)
+        # TUs over the remaining right / bottom strips.  Prediction = the L0 reference displaced by a small vector (Cr:
+        # L1), levels = sparse small values.  Job rows = havoc_mi355x_tu_fused_job (coef_off, src_off, pred_off, rec_off).
+        def tiling(Wp, Hp, big, small, stride_, plane_len_, pad_, pred_plane, rec_plane):
+            out = {}
+            Wb, Hb = Wp // big * big, Hp // big * big
+            for nn_, xs, ys in ((big, np.arange(0, Wb, big), np.arange(0, Hb, big)),):
+                gx, gy = np.meshgrid(xs, ys)
+                out[nn_] = (gx.ravel(), gy.ravel())
+            sx, sy = [], []
+            if Wp > Wb:   # right strip (full height)
+                gx, gy = np.meshgrid(np.arange(Wb, Wp, small), np.arange(0, Hp, small))
+                sx.append(gx.ravel()); sy.append(gy.ravel())
+            if Hp > Hb:   # bottom strip (left of the right strip)
+                gx, gy = np.meshgrid(np.arange(0, Wb, small), np.arange(Hb, Hp, small))
+                sx.append(gx.ravel()); sy.append(gy.ravel())
+            if sx:
+                out[small] = (np.concatenate(sx), np.concatenate(sy))
+            tabs = {}
+            for nn_, (x_, y_) in out.items():
+                m_ = len(x_)
+                dx_ = rng.integers(-2, 3, m_)
+                dy_ = rng.integers(-2, 3, m_)
+                t_ = np.zeros((m_, 4), np.int32)
+                t_[:, 0] = np.arange(m_) * nn_ * nn_
+                t_[:, 1] = (y_ + pad_) * stride_ + x_ + pad_
+                t_[:, 2] = pred_plane * plane_len_ + (y_ + dy_ + pad_) * stride_ + x_ + dx_ + pad_
+                t_[:, 3] = rec_plane * plane_len_ + (y_ + pad_) * stride_ + x_ + pad_
+                lv = np.where(rng.random(m_ * nn_ * nn_) < 0.06, rng.integers(-6, 7, m_ * nn_ * nn_), 0).astype(np.int16)
+                tabs[int(np.log2(nn_))] = dict(jobs=t_, levels=lv, n=nn_)
+            return tabs
+        self.recon = {"y": tiling(W, H, 32, 8, st, pl, PAD, 1, 3),
+                      "cb": tiling(W // 2, H // 2, 16, 4, self.cstride, self.cplane_len, PAD // 2, 1, 3),
+                      "cr": tiling(W // 2, H // 2, 16, 4, self.cstride, self.cplane_len, PAD // 2, 2, 4)}
+
     # ---- algorithmic bytes (SURVEY.md 8(d) "per primitive call": operands read once + results written once) ----
     def algorithmic_bytes(self):
         S = self.S
@@ -401,4 +468,6 @@ class FrameWorkload:
         b["quantize_inverse"] = 4 * tot
         b["inverse_transform_add"] = tot * (2 + 2 * S)
         b["ssd"] = sum(int((2 * wh(g["ssd"], 2, 3) * S + 4).sum()) for g in self.tu.values())
+        b["recon"] = sum(len(g["jobs"]) * g["n"] ** 2 for t in self.recon.values() for g in t.values()) * (2 + 3 * S)
+        b["quantize"] = 4 * tot
         return b
