@@ -1,0 +1,51 @@
+/*
+ * havoc_classic_ext.h -- what libhavoc_classic.so offers BESIDE the reference's table API (the headers under include/havoc): the one hook
+ * a host encoder adds to make the per-block table calls fast (SURVEY.md 7.1-A "precompute and serve").
+ *
+ * The reference's table entries take raw host pointers and return per block (havoc/sad.h:58, pred_inter.h:35,
+ * hadamard.h:32).  Once the encoder has told the library which host planes are PICTURES -- the input picture when it
+ * arrives (turing/TaskEncodeInput.cpp:134-250), a reconstructed picture when it is complete and padded
+ * (turing/TaskDeblock.cpp:151-167) -- a pointer identifies (picture, x, y), and the library answers
+ *   havoc_sad / havoc_sad_multiref   from a full-pel SAD surface of the (PU, reference) pair: ONE launch on the first
+ *                                    call of a search, look-ups afterwards (turing/Search.hpp:1447-1482, 2060-2336);
+ *   HavocPredUni (8-tap)             as a strided copy out of the reference's 16 fractional-sample planes, interpolated
+ *                                    once at registration and mirrored in pinned host memory (Search.hpp:1976-1979);
+ *   havoc_hadamard_satd              from the tile SATDs of all 49 quarter-sample positions around the vector being
+ *                                    refined: ONE launch per (PU, list) (Search.hpp:1963-2061, Measure.h:97-135).
+ * Every served value is what the batch kernel computed on the GPU, bit-identical to the per-call value.  A call the
+ * precomputed data cannot answer (unregistered planes, other primitives) takes the one-job launch path -- never a CPU
+ * path.  Registered planes must not change until they are unregistered (the encoder's input pictures and completed
+ * reference pictures do not).
+ */
+#ifndef HAVOC_CLASSIC_EXT_H
+#define HAVOC_CLASSIC_EXT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "havoc/havoc.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HAVOC_PICTURE_SOURCE 0     /* an input picture: the `src` operand of SAD / SATD calls */
+#define HAVOC_PICTURE_REFERENCE 1  /* a reconstructed, padded picture: the `ref` operand; its phase planes are made now */
+
+/* origin = host pointer of luma sample (0, 0); stride in samples; pad = samples of border around the picture that belong
+ * to the plane (0 for the reference's input pictures, 96 for its reconstructed pictures, turing/StatePictures.h:155-156);
+ * S = bytes per sample.  Uploads the plane (and for a reference interpolates and mirrors its phase planes): call it from
+ * the thread that completed the picture.  Returns 0, or a negative havoc_mi355x error code. */
+int havoc_classic_register_picture(havoc_code code, const void *origin, intptr_t stride, int width, int height, int pad, int S, int bit_depth,
+                                   int role);
+int havoc_classic_unregister_picture(havoc_code code, const void *origin);
+
+/* counters since havoc_new_code: [0] table calls answered from precomputed data, [1] table calls that took the one-job
+ * launch path, [2] kernel launches issued for table calls (both kinds), [3] SAD surfaces launched, [4] tile-SATD batches
+ * launched, [5] pictures registered, [6] bytes uploaded at registration, [7] bytes mirrored back at registration */
+void havoc_classic_stats(havoc_code code, int64_t out[8]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -57,6 +57,15 @@ int havoc_mi355x_d2h(havoc_mi355x_ctx *ctx, void *h_dst, const void *d_src, size
 int havoc_mi355x_timer_start(havoc_mi355x_ctx *ctx);
 int havoc_mi355x_timer_stop_ms(havoc_mi355x_ctx *ctx, float *ms); /* records, synchronises, returns elapsed */
 
+/* pinned host memory the device can address: *h_ptr for the host, *d_ptr for kernels (results a host loop reads right after
+ * havoc_mi355x_sync() without a copy); asynchronous and pitched copies on the context's stream */
+int havoc_mi355x_host_alloc(havoc_mi355x_ctx *ctx, size_t bytes, void **h_ptr, void **d_ptr);
+int havoc_mi355x_host_free(havoc_mi355x_ctx *ctx, void *h_ptr);
+int havoc_mi355x_h2d_async(havoc_mi355x_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int havoc_mi355x_d2h_async(havoc_mi355x_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+int havoc_mi355x_copy_2d(havoc_mi355x_ctx *ctx, void *dst, size_t dst_pitch, const void *src, size_t src_pitch, size_t row_bytes, size_t rows,
+                         int to_device);
+
 /* HIP-graph capture of a fixed sequence of batch launches (one picture's launches are the same sequence with the same
  * buffers for every CTU row / picture of a size): begin, issue the launches (they are recorded, not run), end, then
  * replay with graph_launch.  Needs a context that owns its stream (HAVOC_MI355X_NEW_STREAM) or an explicit
@@ -180,6 +189,34 @@ typedef struct {
  * as a reference (and what the owner runs before the frame-parallel broadcast). */
 int havoc_mi355x_pad_block(havoc_mi355x_ctx *ctx, int S, void *d_plane, int64_t origin_off, int width, int height,
                            intptr_t stride, int pad, int top, int bottom, int left, int right);
+
+/* Device-side picture store + input upload.  A picture = the three planes of Picture<Sample>
+ * (turing/Picture.cpp:91-125) in ONE HBM allocation: per plane `pad` samples of border (chroma: pad / 2), row stride rounded
+ * up to `alignment` bytes (the reference: pad 96, alignment 32, turing/StatePictures.h:155-156; this library's kernels are
+ * indifferent, 64 keeps rows on 64-byte boundaries).  4:2:0 only, as every configuration of BASELINE.json. */
+typedef struct havoc_mi355x_picture havoc_mi355x_picture;
+int havoc_mi355x_picture_create(havoc_mi355x_ctx *ctx, int S, int bit_depth, int width, int height, int pad, int alignment,
+                                havoc_mi355x_picture **pic);
+void havoc_mi355x_picture_destroy(havoc_mi355x_ctx *ctx, havoc_mi355x_picture *pic);
+/* plane geometry: *d_base = the picture's allocation (one for the three planes), *origin_off = sample offset of sample (0, 0)
+ * of plane cIdx from d_base (what a job's offsets are relative to), *stride in samples; any out pointer may be NULL */
+int havoc_mi355x_picture_plane(havoc_mi355x_picture *pic, int cIdx, void **d_base, int64_t *origin_off, intptr_t *stride, int *width, int *height,
+                               int *pad);
+/* one input frame as the reference reads it (turing/encode.cpp:600-640): planar Y, U, V, tightly packed, src_S bytes per sample
+ * (16-bit: little-endian words); stored << shift (encode.cpp:397: 8-bit input on the 16-bit path, shift 2); pad_after != 0
+ * replicates the borders afterwards (Padding::padImage, turing/Padding.h:33-57) */
+int havoc_mi355x_picture_upload_yuv(havoc_mi355x_ctx *ctx, havoc_mi355x_picture *pic, const void *h_yuv, int src_S, int shift, int pad_after);
+/* one plane from / to a host Picture plane: h_origin = its sample (0, 0), h_stride in samples; with_padding != 0 moves the
+ * `pad` border as well (the host plane must have one at least as wide).  download synchronises. */
+int havoc_mi355x_picture_upload_plane(havoc_mi355x_ctx *ctx, havoc_mi355x_picture *pic, int cIdx, const void *h_origin, intptr_t h_stride,
+                                      int with_padding);
+int havoc_mi355x_picture_download_plane(havoc_mi355x_ctx *ctx, havoc_mi355x_picture *pic, int cIdx, void *h_origin, intptr_t h_stride,
+                                        int with_padding);
+int havoc_mi355x_picture_pad(havoc_mi355x_ctx *ctx, havoc_mi355x_picture *pic);
+/* the 16 fractional-sample luma planes of the picture (havoc_mi355x_interp_planes; slot 0 = the luma plane), made on first
+ * request after the picture changed and kept with it.  Phase k, sample (x, y):
+ *   d_planes[k * plane_elems + (luma origin_off - *luma_first) + y * stride + x]   (luma plane's origin_off / stride). */
+int havoc_mi355x_picture_phase_planes(havoc_mi355x_ctx *ctx, havoc_mi355x_picture *pic, void **d_planes, intptr_t *plane_elems, int64_t *luma_first);
 
 /* ------------------------------------------------------------------------------------------------------- */
 /* distortion metrics                                                                                        */

@@ -1,0 +1,140 @@
+/*
+ * TEST INFRASTRUCTURE ONLY -- a stand-in for libhavoc_mi355x.so on machines WITHOUT a GPU, so that the HOST LOGIC layered on
+ * the C ABI (libhavoc_classic.so's precompute-and-serve layer, libhavoc_search.so's batch client) can be exercised by the
+ * CPU test suite (-m "not gpu").  "Device memory" is host memory and every "kernel" is a loop over the CPU oracle
+ * (oracle/havoc_oracle.c).  It is built by tests/test_search.py into tests/_build/ with the soname of the real library and
+ * loaded, in a SUBPROCESS of the test only, before the host library under test.  The product never builds, links or loads
+ * it; on a GPU box the same tests run against the real library (-m gpu).  Only the entry points those two host libraries
+ * use are implemented; anything else is absent on purpose (an unresolved symbol is a test failure, not a silent CPU path).
+ */
+#include "../include/havoc_mi355x.h"
+#include "../oracle/havoc_oracle.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+struct havoc_mi355x_ctx { int device; long launches; };
+
+static long g_launches = 0;
+long mock_launches(void) { return g_launches; }
+
+const char *havoc_mi355x_last_error(void) { return "mock device"; }
+const char *havoc_mi355x_version(void) { return "MOCK (tests only)"; }
+
+int havoc_mi355x_create(havoc_mi355x_ctx **ctx, int device, void *stream)
+{
+    (void)stream;
+    *ctx = (havoc_mi355x_ctx *)calloc(1, sizeof(**ctx));
+    (*ctx)->device = device;
+    return 0;
+}
+void havoc_mi355x_destroy(havoc_mi355x_ctx *ctx) { free(ctx); }
+int havoc_mi355x_sync(havoc_mi355x_ctx *ctx) { (void)ctx; return 0; }
+int havoc_mi355x_malloc(havoc_mi355x_ctx *ctx, void **p, size_t n) { (void)ctx; *p = calloc(1, n + 64); return *p ? 0 : -1; }
+int havoc_mi355x_free(havoc_mi355x_ctx *ctx, void *p) { (void)ctx; free(p); return 0; }
+int havoc_mi355x_h2d(havoc_mi355x_ctx *ctx, void *d, const void *h, size_t n) { (void)ctx; memcpy(d, h, n); return 0; }
+int havoc_mi355x_d2h(havoc_mi355x_ctx *ctx, void *h, const void *d, size_t n) { (void)ctx; memcpy(h, d, n); return 0; }
+int havoc_mi355x_h2d_async(havoc_mi355x_ctx *ctx, void *d, const void *h, size_t n) { (void)ctx; memcpy(d, h, n); return 0; }
+int havoc_mi355x_d2h_async(havoc_mi355x_ctx *ctx, void *h, const void *d, size_t n) { (void)ctx; memcpy(h, d, n); return 0; }
+int havoc_mi355x_host_alloc(havoc_mi355x_ctx *ctx, size_t n, void **h, void **d)
+{
+    (void)ctx;
+    *h = calloc(1, n + 64);
+    *d = *h;   /* the device view of pinned memory is the same address here */
+    return *h ? 0 : -1;
+}
+int havoc_mi355x_host_free(havoc_mi355x_ctx *ctx, void *h) { (void)ctx; free(h); return 0; }
+
+#define AT(base, off, S) ((const char *)(base) + (long)(off) * (S))
+
+int havoc_mi355x_sad(havoc_mi355x_ctx *ctx, int S, const void *src, intptr_t ss, const void *ref, intptr_t rs, const havoc_mi355x_pair_job *j, int n, int32_t *out)
+{
+    (void)ctx; ++g_launches;
+    for (int i = 0; i < n; ++i) out[i] = oracle_sad(AT(src, j[i].a_off, S), ss, AT(ref, j[i].b_off, S), rs, j[i].w, j[i].h, S);
+    return 0;
+}
+
+int havoc_mi355x_sad4(havoc_mi355x_ctx *ctx, int S, const void *src, intptr_t ss, const void *ref, intptr_t rs, const havoc_mi355x_sad4_job *j, int n, int32_t *out)
+{
+    (void)ctx; ++g_launches;
+    for (int i = 0; i < n; ++i)
+    {
+        const void *r[4];
+        int v[4];
+        for (int k = 0; k < 4; ++k) r[k] = AT(ref, j[i].ref_off[k], S);
+        oracle_sad4(AT(src, j[i].src_off, S), ss, r, rs, v, j[i].w, j[i].h, S);
+        for (int k = 0; k < 4; ++k) out[4 * i + k] = v[k];
+    }
+    return 0;
+}
+
+int havoc_mi355x_sad_surface(havoc_mi355x_ctx *ctx, int S, int range, int max_w, int max_h, const void *src, intptr_t ss, const void *ref, intptr_t rs,
+                             const havoc_mi355x_surface_job *j, int n, int32_t *out)
+{
+    (void)ctx; (void)max_w; (void)max_h; ++g_launches;
+    const int side = 2 * range + 1;
+    for (int i = 0; i < n; ++i)
+        for (int dy = -range; dy <= range; ++dy)
+            for (int dx = -range; dx <= range; ++dx)
+                out[j[i].out_off + (dy + range) * side + dx + range] =
+                    oracle_sad(AT(src, j[i].src_off, S), ss, AT(ref, j[i].ref_off + (long)dy * rs + dx, S), rs, j[i].w, j[i].h, S);
+    return 0;
+}
+
+int havoc_mi355x_satd(havoc_mi355x_ctx *ctx, int S, int max_w, int max_h, const void *a, intptr_t sa, const void *b, intptr_t sb,
+                      const havoc_mi355x_pair_job *j, int n, int32_t *out)
+{
+    (void)ctx; (void)max_w; (void)max_h; ++g_launches;
+    for (int i = 0; i < n; ++i) out[i] = oracle_pu_satd(AT(a, j[i].a_off, S), sa, AT(b, j[i].b_off, S), sb, j[i].w, j[i].h, S);
+    return 0;
+}
+
+int havoc_mi355x_satd_multi(havoc_mi355x_ctx *ctx, int S, int max_w, int max_h, const void *a, intptr_t sa, const void *b, intptr_t sb,
+                            const havoc_mi355x_satd_multi_job *j, int n, int32_t *out)
+{
+    (void)ctx; (void)max_w; (void)max_h; ++g_launches;
+    for (int i = 0; i < n; ++i)
+        for (int k = 0; k < 16; ++k)
+            out[16 * i + k] = k < j[i].count ? oracle_pu_satd(AT(a, j[i].a_off, S), sa, AT(b, j[i].b_off[k], S), sb, j[i].w, j[i].h, S) : 0;
+    return 0;
+}
+
+int havoc_mi355x_pred_uni(havoc_mi355x_ctx *ctx, int S, int taps, int bitDepth, int max_w, int max_h, void *dst, intptr_t sd, const void *ref, intptr_t sr,
+                          const havoc_mi355x_pred_uni_job *j, int n)
+{
+    (void)ctx; (void)max_w; (void)max_h; ++g_launches;
+    for (int i = 0; i < n; ++i)
+        oracle_pred_uni((char *)dst + (long)j[i].dst_off * S, sd, AT(ref, j[i].ref_off, S), sr, j[i].w, j[i].h, j[i].xFrac, j[i].yFrac, bitDepth, taps, S);
+    return 0;
+}
+
+int havoc_mi355x_subtract_bi(havoc_mi355x_ctx *ctx, int S, int bitDepth, void *dst, intptr_t sd, const void *pred, intptr_t sp, const void *src, intptr_t ss,
+                             const havoc_mi355x_subtract_bi_job *j, int n)
+{
+    (void)ctx; ++g_launches;
+    for (int i = 0; i < n; ++i)
+        oracle_subtract_bi((char *)dst + (long)j[i].dst_off * S, sd, AT(pred, j[i].pred_off, S), sp, AT(src, j[i].src_off, S), ss, j[i].w, j[i].h, bitDepth, S);
+    return 0;
+}
+
+/* plane[4*yFrac + xFrac][y][x] = HavocPredUni sample at (x, y): by 64 x 64 blocks, as tests/suite.py's LoopImpl does */
+int havoc_mi355x_interp_planes(havoc_mi355x_ctx *ctx, int S, int bitDepth, void *planes, intptr_t plane_elems, const void *ref, intptr_t stride, int x0, int y0,
+                               int width, int height)
+{
+    (void)ctx; ++g_launches;
+    for (int yf = 0; yf < 4; ++yf)
+        for (int xf = 0; xf < 4; ++xf)
+        {
+            if (!xf && !yf) continue;
+            char *pl = (char *)planes + (long)(4 * yf + xf) * plane_elems * S;
+            for (int by = y0; by < y0 + height; by += 64)
+                for (int bx = x0; bx < x0 + width; bx += 64)
+                {
+                    const int w = x0 + width - bx < 64 ? x0 + width - bx : 64, h = y0 + height - by < 64 ? y0 + height - by : 64;
+                    oracle_pred_uni(pl + ((long)by * stride + bx) * S, stride, AT(ref, (long)by * stride + bx, S), stride, w, h, xf, yf, bitDepth, 8, S);
+                }
+        }
+    return 0;
+}
+

@@ -1,0 +1,242 @@
+// TEST CLIENT of the decision loops (turingcodec_amd/search/decision.hpp) over the reference's per-block TABLE API.
+// Compiled by tests/test_search.py against OUR include/havoc headers and linked
+//   * against oracle/_ref/libhavoc_ref.so (the reference's own havoc library)  -> expected decisions
+//   * against turingcodec_amd/libhavoc_classic.so (the MI355X implementation)  -> decisions under test (-DHAVOC_CLASSIC_EXT)
+// One source, two libraries: the table layouts, accessor functions and populate symbols are the same ABI.
+//   * with -DSEARCH_ORACLE: no table API at all, the calls go to the CPU oracle (oracle/liboracle.so) -- the variant the CPU
+//     tests use to check the restated loops themselves against the reference's tables.
+#include "search_abi.h"
+
+#include <cstring>
+
+#ifndef SEARCH_ORACLE
+#include "table_view.hpp"
+#else
+#include "decision.hpp"
+#include "../oracle/havoc_oracle.h"
+#define HAVOC_ALIGN(n, T, v) T v __attribute__((aligned(n)))
+typedef struct { void *implementation; } havoc_code;
+static havoc_code havoc_new_code(int, int) { return havoc_code{nullptr}; }
+static void havoc_delete_code(havoc_code) {}
+static int havoc_instruction_set_support() { return 3; }
+typedef int havoc_instruction_set;
+namespace havoc_search {
+template <typename Sample> struct MotionTables { void populate(havoc_code) {} };
+template <typename Sample> struct Plane
+{
+    const Sample *origin;
+    intptr_t stride;
+    const Sample *at(int x, int y) const { return origin + intptr_t(y) * stride + x; }
+};
+// the same View interface, every call evaluated by the oracle's plain-C functions
+template <typename Sample> struct TableView
+{
+    const Sample *src;
+    intptr_t srcStride;
+    Plane<Sample> ref;
+    int x0, y0, w, h, bitDepth;
+    TableView(MotionTables<Sample> &, const Sample *src_, intptr_t ss, Plane<Sample> ref_, int x0_, int y0_, int w_, int h_, int bd)
+        : src(src_), srcStride(ss), ref(ref_), x0(x0_), y0(y0_), w(w_), h(h_), bitDepth(bd) {}
+    int sad(int dx, int dy) { return oracle_sad(src, srcStride, ref.at(x0 + dx, y0 + dy), ref.stride, w, h, sizeof(Sample)); }
+    void sad4(const Mv d[4], int32_t out[4])
+    {
+        const void *refs[4];
+        for (int i = 0; i < 4; ++i) refs[i] = ref.at(x0 + d[i].x, y0 + d[i].y);
+        int sads[4];
+        oracle_sad4(src, srcStride, refs, ref.stride, sads, w, h, sizeof(Sample));
+        for (int i = 0; i < 4; ++i) out[i] = sads[i];
+    }
+    int satdQpel(Mv mv)
+    {
+        Sample buffer[64 * 64];
+        oracle_pred_uni(buffer, 64, ref.at(x0 + (mv.x >> 2), y0 + (mv.y >> 2)), ref.stride, w, h, mv.x & 3, mv.y & 3, bitDepth, 8, sizeof(Sample));
+        return oracle_pu_satd(src, srcStride, buffer, 64, w, h, sizeof(Sample));
+    }
+};
+template <typename Sample>
+void makeIdealPredictor(MotionTables<Sample> &, Sample *ideal, const Sample *input, intptr_t inputStride, Plane<Sample> refOther, Mv mvOther,
+                        const LimitFullPelMv &limit, int x0, int y0, int w, int h, int bitDepthY)
+{
+    Sample other[64 * 64];
+    Mv full = shr2(mvOther);
+    limit(full);
+    oracle_pred_uni(other, 64, refOther.at(x0 + full.x, y0 + full.y), refOther.stride, w, h, mvOther.x & 3, mvOther.y & 3, bitDepthY, 8, sizeof(Sample));
+    oracle_subtract_bi(ideal, 64, other, 64, input, inputStride, w, h, 6 + 2 * sizeof(Sample), sizeof(Sample));
+}
+} // namespace havoc_search
+#endif
+
+#ifdef HAVOC_CLASSIC_EXT
+#include "havoc_classic_ext.h"
+#endif
+
+using namespace havoc_search;
+
+namespace {
+
+havoc_code g_code;
+bool g_open = false;
+MotionTables<uint8_t> g_t8;
+MotionTables<uint16_t> g_t16;
+
+template <typename Sample> MotionTables<Sample> &tables();
+template <> MotionTables<uint8_t> &tables<uint8_t>() { return g_t8; }
+template <> MotionTables<uint16_t> &tables<uint16_t>() { return g_t16; }
+
+SearchParams paramsOf(const havoc_search_params &p)
+{
+    SearchParams sp;
+    sp.picWidth = p.pic_width;
+    sp.picHeight = p.pic_height;
+    sp.ctbSize = p.ctb_size;
+    sp.concurrentFrames = p.concurrent_frames;
+    sp.met = p.met != 0;
+    sp.smallSearchWindow = p.small_search_window != 0;
+    sp.biSmallSearchWindow = p.bi_small_search_window != 0;
+    sp.halfPel = p.half_pel != 0;
+    sp.quarterPel = p.quarter_pel != 0;
+    sp.reciprocalSqrtLambda = p.reciprocal_sqrt_lambda;
+    sp.bitDepth = p.bit_depth;
+    return sp;
+}
+
+PuContext puOf(const havoc_search_pu &q)
+{
+    PuContext pu;
+    pu.x0 = q.x0; pu.y0 = q.y0; pu.w = q.w; pu.h = q.h;
+    pu.cuLog2Size = q.cu_log2_size;
+    pu.cqtDepth = q.cqt_depth;
+    pu.part2Nx2N = q.part_2Nx2N != 0;
+    pu.xCtb = q.x_ctb; pu.yCtb = q.y_ctb;
+    for (int k = 0; k < 2; ++k)
+    {
+        pu.mvp[k] = Mv(q.mvp[k][0], q.mvp[k][1]);
+        pu.mvpRate[k] = q.mvp_rate[k];
+    }
+    pu.mvPrevious2Nx2N = Mv(q.mv_previous_2Nx2N[0], q.mv_previous_2Nx2N[1]);
+    return pu;
+}
+
+template <typename Sample>
+void runUni(const Sample *src, intptr_t ss, const Sample *ref, intptr_t rs, const havoc_search_params &p, const havoc_search_pu *pus, int b, int e,
+            havoc_search_result *out)
+{
+    const SearchParams sp = paramsOf(p);
+    for (int i = b; i < e; ++i)
+    {
+        const PuContext pu = puOf(pus[i]);
+        TableView<Sample> view(tables<Sample>(), src + intptr_t(pu.y0) * ss + pu.x0, ss, Plane<Sample>{ref, rs}, pu.x0, pu.y0, pu.w, pu.h, sp.bitDepth);
+        MotionSearch<TableView<Sample>> search(sp, pu, view);
+        const UniResult r = search.run();
+        havoc_search_result &o = out[i];
+        std::memset(&o, 0, sizeof(o));
+        o.mv[0] = r.mv.x; o.mv[1] = r.mv.y;
+        o.mvd[0] = r.mvd.x; o.mvd[1] = r.mvd.y;
+        o.mv_integer[0] = r.mvInteger.x; o.mv_integer[1] = r.mvInteger.y;
+        o.mvp_flag = int16_t(r.mvpFlag);
+        o.wrote_2Nx2N = r.wrote2Nx2N;
+        o.calls = r.calls;
+        o.cost_integer = r.costInteger;
+        o.cost_subpel = r.costSubPel;
+        o.cost_mvd_zero[0] = r.costMvdZero[0];
+        o.cost_mvd_zero[1] = r.costMvdZero[1];
+    }
+}
+
+template <typename Sample>
+void runBi(const Sample *src, intptr_t ss, const Sample *ref, const Sample *refOther, intptr_t rs, const havoc_search_params &p, const havoc_search_pu *pus,
+           const int16_t *start, int b, int e, havoc_search_result *out)
+{
+    const SearchParams sp = paramsOf(p);
+    for (int i = b; i < e; ++i)
+    {
+        const PuContext pu = puOf(pus[i]);
+        HAVOC_ALIGN(32, Sample, ideal[64 * 64]);
+        const LimitFullPelMv limit(pu, sp);
+        makeIdealPredictor<Sample>(tables<Sample>(), ideal, src + intptr_t(pu.y0) * ss + pu.x0, ss, Plane<Sample>{refOther, rs},
+                                   Mv(pus[i].mv_other[0], pus[i].mv_other[1]), limit, pu.x0, pu.y0, pu.w, pu.h, sp.bitDepth);
+        TableView<Sample> view(tables<Sample>(), ideal, 64, Plane<Sample>{ref, rs}, pu.x0, pu.y0, pu.w, pu.h, sp.bitDepth);
+        const BiResult r = searchMotionBi(sp, pu, view, Mv(start[2 * i], start[2 * i + 1]));
+        havoc_search_result &o = out[i];
+        std::memset(&o, 0, sizeof(o));
+        o.mv[0] = r.mv.x; o.mv[1] = r.mv.y;
+        o.mvd[0] = r.mvd.x; o.mvd[1] = r.mvd.y;
+        o.mvp_flag = int16_t(r.mvpFlag);
+        o.calls = r.calls;
+        o.cost_subpel = r.cost;
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+// mask: the reference library honours it (HAVOC_C_REF | HAVOC_C_OPT = 3: plain C tables; -1: everything the CPU supports = JIT)
+int client_open(int mask)
+{
+    if (!g_open)
+    {
+        g_code = havoc_new_code(mask < 0 ? havoc_instruction_set_support() : (havoc_instruction_set)mask, 16 << 20);
+        g_t8.populate(g_code);
+        g_t16.populate(g_code);
+        g_open = true;
+    }
+    return 0;
+}
+
+void client_close(void)
+{
+    if (g_open) havoc_delete_code(g_code);
+    g_open = false;
+}
+
+// origins: pointer to sample (0, 0) of the padded host planes; strides in samples; jobs [b, e)
+int client_uni(int S, const void *src, intptr_t ss, const void *ref, intptr_t rs, const havoc_search_params *p, const havoc_search_pu *pus, int b, int e,
+               havoc_search_result *out)
+{
+    if (!g_open) return -1;
+    if (S == 1) runUni<uint8_t>((const uint8_t *)src, ss, (const uint8_t *)ref, rs, *p, pus, b, e, out);
+    else runUni<uint16_t>((const uint16_t *)src, ss, (const uint16_t *)ref, rs, *p, pus, b, e, out);
+    return 0;
+}
+
+int client_bi(int S, const void *src, intptr_t ss, const void *ref, const void *refOther, intptr_t rs, const havoc_search_params *p,
+              const havoc_search_pu *pus, const int16_t *start, int b, int e, havoc_search_result *out)
+{
+    if (!g_open) return -1;
+    if (S == 1) runBi<uint8_t>((const uint8_t *)src, ss, (const uint8_t *)ref, (const uint8_t *)refOther, rs, *p, pus, start, b, e, out);
+    else runBi<uint16_t>((const uint16_t *)src, ss, (const uint16_t *)ref, (const uint16_t *)refOther, rs, *p, pus, start, b, e, out);
+    return 0;
+}
+
+// the 35-mode intra stage: costs and refinement order from the per-mode SATDs (Search.hpp:40-190)
+int client_intra_order(const havoc_search_intra_ctx *ctx, double reciprocal_sqrt_lambda, const int32_t *satd35, int n, havoc_search_intra_result *out)
+{
+    for (int i = 0; i < n; ++i)
+    {
+        IntraContext ic;
+        for (int k = 0; k < 3; ++k) ic.candModeList[k] = ctx[i].cand_mode_list[k];
+        ic.neighbourModes = ctx[i].neighbour_modes;
+        ic.maxRefine = ctx[i].max_refine;
+        ic.rateAminusC = ctx[i].rate_a_minus_c;
+        ic.rateBminusC = ctx[i].rate_b_minus_c;
+        const IntraResult r = intraModeOrder(ic, reciprocal_sqrt_lambda, satd35 + 35 * i);
+        std::memset(&out[i], 0, sizeof(out[i]));
+        for (int m = 0; m < 35; ++m) out[i].costs[m] = r.costs[m];
+        for (int m = 0; m < r.count; ++m) out[i].order[m] = r.order[m];
+        out[i].count = r.count;
+    }
+    return 0;
+}
+
+#ifdef HAVOC_CLASSIC_EXT
+// the MI355X library's extension beside the reference API: tell it which host planes are pictures
+int client_register(const void *origin, intptr_t stride, int width, int height, int pad, int S, int bit_depth, int role)
+{
+    return havoc_classic_register_picture(g_code, origin, stride, width, height, pad, S, bit_depth, role);
+}
+int client_unregister(const void *origin) { return havoc_classic_unregister_picture(g_code, origin); }
+void client_stats(int64_t out[8]) { havoc_classic_stats(g_code, out); }
+#endif
+
+} // extern "C"

@@ -1,0 +1,184 @@
+"""Test-side tooling for the decision-loop clients (turingcodec_amd/search): builds tests/search_client.cpp against the
+three back ends, generates a seeded list of (prediction unit, list) searches with predictors on the synthetic clip of
+SURVEY.md 8(d), and runs the clients through ctypes.
+
+    ref      tests/_build/libsearch_ref.so      the reference's own havoc library (oracle/_ref) behind the table API
+    oracle   tests/_build/libsearch_oracle.so   the CPU oracle (no table API)
+    classic  tests/_build/libsearch_classic.so  libhavoc_classic.so = the MI355X implementation behind the table API
+"""
+import ctypes as C
+import math
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BUILD = os.path.join(ROOT, "tests", "_build")
+SRC = os.path.join(ROOT, "tests", "search_client.cpp")
+INC = ["-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "turingcodec_amd", "search")]
+
+PU_DT = np.dtype([("x0", "i4"), ("y0", "i4"), ("w", "i4"), ("h", "i4"), ("cu_log2_size", "i4"), ("cqt_depth", "i4"), ("part_2Nx2N", "i4"),
+                  ("ref_list", "i4"), ("x_ctb", "i4"), ("y_ctb", "i4"), ("mvp", "i2", (2, 2)), ("mv_previous_2Nx2N", "i2", (2,)),
+                  ("mv_other", "i2", (2,)), ("mvp_rate", "i8", (2,))])
+RESULT_DT = np.dtype([("mv", "i2", (2,)), ("mvd", "i2", (2,)), ("mv_integer", "i2", (2,)), ("mvp_flag", "i2"), ("wrote_2Nx2N", "i2"),
+                      ("calls", "i4"), ("replays", "i4"), ("cost_integer", "i8"), ("cost_subpel", "i8"), ("cost_mvd_zero", "i8", (2,))])
+INTRA_CTX_DT = np.dtype([("cand_mode_list", "i4", (3,)), ("neighbour_modes", "i4"), ("max_refine", "i4"), ("reserved", "i4"),
+                         ("rate_a_minus_c", "i8"), ("rate_b_minus_c", "i8")])
+INTRA_RESULT_DT = np.dtype([("costs", "i8", (35,)), ("order", "i4", (35,)), ("count", "i4")])
+assert PU_DT.itemsize == 72 and RESULT_DT.itemsize == 56 and INTRA_CTX_DT.itemsize == 40 and INTRA_RESULT_DT.itemsize == 424
+
+
+class Params(C.Structure):
+    _fields_ = [("pic_width", C.c_int32), ("pic_height", C.c_int32), ("ctb_size", C.c_int32), ("concurrent_frames", C.c_int32),
+                ("met", C.c_int32), ("small_search_window", C.c_int32), ("bi_small_search_window", C.c_int32), ("half_pel", C.c_int32),
+                ("quarter_pel", C.c_int32), ("bit_depth", C.c_int32), ("reciprocal_sqrt_lambda", C.c_double)]
+
+
+def reciprocal_sqrt_lambda(qp, qp_factor=0.68, non_reference=True):
+    """computeLambda, turing/Measure.h:58-78 (B picture of the hierarchy), then 1 / sqrt"""
+    lam = qp_factor * 2.0 ** ((qp - 12.0) / 3.0)
+    if non_reference:
+        lam *= min(4.0, max(2.0, (qp - 12.0) / 6.0))
+    return 1.0 / math.sqrt(lam)
+
+
+def medium_params(width, height, bit_depth=8, qp=32, concurrent_frames=4):
+    return Params(width, height, 64, concurrent_frames, 1, 0, 0, 1, 1, bit_depth, reciprocal_sqrt_lambda(qp))
+
+
+def _newer(target, *deps):
+    return os.path.exists(target) and all(os.path.getmtime(target) >= os.path.getmtime(d) for d in deps)
+
+
+def build(kind):
+    """compile the client for one back end; returns the library path (None when the back end's library is not there)"""
+    os.makedirs(BUILD, exist_ok=True)
+    out = os.path.join(BUILD, f"libsearch_{kind}.so")
+    hdrs = [os.path.join(ROOT, "turingcodec_amd", "search", f) for f in ("decision.hpp", "table_view.hpp", "search_abi.h")]
+    base = ["g++", "-O2", "-std=c++14", "-fPIC", "-shared", "-Wall"] + INC + [SRC, "-o", out]
+    if kind == "ref":
+        lib = os.path.join(ROOT, "oracle", "_ref", "libhavoc_ref.so")
+        if not os.path.exists(lib):
+            return out if os.path.exists(out) else None
+        if not _newer(out, SRC, lib, *hdrs):
+            subprocess.check_call(base + ["-L" + os.path.dirname(lib), "-lhavoc_ref", "-Wl,-rpath,$ORIGIN/../../oracle/_ref"])
+    elif kind == "oracle":
+        lib = os.path.join(ROOT, "oracle", "liboracle.so")
+        if not _newer(out, SRC, lib, *hdrs):
+            subprocess.check_call(base + ["-DSEARCH_ORACLE", "-L" + os.path.dirname(lib), "-loracle", "-Wl,-rpath,$ORIGIN/../../oracle"])
+    elif kind == "classic":
+        lib = os.path.join(ROOT, "turingcodec_amd", "libhavoc_classic.so")
+        if not os.path.exists(lib):
+            return None
+        if not _newer(out, SRC, lib, *hdrs, os.path.join(ROOT, "include", "havoc_classic_ext.h")):
+            subprocess.check_call(base + ["-DHAVOC_CLASSIC_EXT", "-L" + os.path.dirname(lib), "-lhavoc_classic", "-lhavoc_mi355x",
+                                          "-Wl,-rpath,$ORIGIN/../../turingcodec_amd"])
+    else:
+        raise ValueError(kind)
+    return out
+
+
+class Client:
+    def __init__(self, kind, mask=3):
+        path = build(kind)
+        if path is None:
+            raise FileNotFoundError(kind)
+        self.kind = kind
+        L = self.L = C.CDLL(path)
+        vp, ip, i = C.c_void_p, C.c_ssize_t, C.c_int
+        L.client_open.argtypes = [i]
+        L.client_uni.argtypes = [i, vp, ip, vp, ip, C.POINTER(Params), vp, i, i, vp]
+        L.client_bi.argtypes = [i, vp, ip, vp, vp, ip, C.POINTER(Params), vp, vp, i, i, vp]
+        L.client_intra_order.argtypes = [vp, C.c_double, vp, i, vp]
+        if kind == "classic":
+            L.client_register.argtypes = [vp, ip, i, i, i, i, i, i]
+            L.client_unregister.argtypes = [vp]
+            L.client_stats.argtypes = [vp]
+        assert L.client_open(mask) == 0
+
+    @staticmethod
+    def _origin(plane, stride, pad):
+        return plane.ctypes.data + (pad * stride + pad) * plane.itemsize
+
+    def uni(self, params, src, ref, stride, pad, pus, b=0, e=None):
+        """src / ref: padded planes (flat numpy arrays, `stride` samples per row, `pad` samples of border)"""
+        e = len(pus) if e is None else e
+        out = np.zeros(len(pus), RESULT_DT)
+        rc = self.L.client_uni(src.itemsize, self._origin(src, stride, pad), stride, self._origin(ref, stride, pad), stride, C.byref(params),
+                               pus.ctypes.data, b, e, out.ctypes.data)
+        assert rc == 0
+        return out
+
+    def bi(self, params, src, ref, ref_other, stride, pad, pus, start):
+        out = np.zeros(len(pus), RESULT_DT)
+        start = np.ascontiguousarray(start, np.int16)
+        rc = self.L.client_bi(src.itemsize, self._origin(src, stride, pad), stride, self._origin(ref, stride, pad), self._origin(ref_other, stride, pad),
+                              stride, C.byref(params), pus.ctypes.data, start.ctypes.data, 0, len(pus), out.ctypes.data)
+        assert rc == 0
+        return out
+
+    def intra_order(self, ctx, rsl, satd35):
+        satd35 = np.ascontiguousarray(satd35, np.int32)
+        out = np.zeros(len(ctx), INTRA_RESULT_DT)
+        assert self.L.client_intra_order(ctx.ctypes.data, rsl, satd35.ctypes.data, len(ctx), out.ctypes.data) == 0
+        return out
+
+    # classic only
+    def register(self, plane, stride, pad, width, height, bit_depth, role):
+        return self.L.client_register(self._origin(plane, stride, pad), stride, width, height, pad, plane.itemsize, bit_depth, role)
+
+    def unregister(self, plane, stride, pad):
+        return self.L.client_unregister(self._origin(plane, stride, pad))
+
+    def stats(self):
+        a = (C.c_int64 * 8)()
+        self.L.client_stats(a)
+        return [int(v) for v in a]
+
+
+# (PartMode name, [(dx, dy, w, h) in units of the CU size / 4]) -- the part modes of turing/Search.hpp's inter loop
+PART_MODES = [("2Nx2N", [(0, 0, 4, 4)]), ("2NxN", [(0, 0, 4, 2), (0, 2, 4, 2)]), ("Nx2N", [(0, 0, 2, 4), (2, 0, 2, 4)]),
+              ("2NxnU", [(0, 0, 4, 1), (0, 1, 4, 3)]), ("2NxnD", [(0, 0, 4, 3), (0, 3, 4, 1)]), ("nLx2N", [(0, 0, 1, 4), (1, 0, 3, 4)]),
+              ("nRx2N", [(0, 0, 3, 4), (3, 0, 1, 4)])]
+
+
+def make_searches(width, height, n, seed, hard_fraction=0.15):
+    """n (PU, list) searches on the clip of workload.synth_frames: coding units of 8..64 at aligned positions, every part
+    mode the inter loop tries, predictors = the clip's true motion ((3,2) samples per frame towards list 0) plus noise;
+    `hard_fraction` of them get predictors far off (long star / raster searches) or sit on the picture border (limits)."""
+    rng = np.random.default_rng(seed)
+    pus = np.zeros(n, PU_DT)
+    for i in range(n):
+        log2 = int(rng.choice([3, 4, 5, 6], p=[0.35, 0.35, 0.2, 0.1]))
+        size = 1 << log2
+        modes = PART_MODES[:3] if log2 == 3 else PART_MODES      # no AMP on 8x8 coding units
+        name, parts = modes[int(rng.integers(0, len(modes)))]
+        dx, dy, w4, h4 = parts[int(rng.integers(0, len(parts)))]
+        q = size // 4
+        edge = rng.random() < hard_fraction / 2
+        cx = (int(rng.integers(0, (width - size) // size + 1)) * size) if not edge else int(rng.choice([0, (width - size) // size * size]))
+        cy = (int(rng.integers(0, (height - size) // size + 1)) * size) if not edge else int(rng.choice([0, (height - size) // size * size]))
+        p = pus[i]
+        p["x0"], p["y0"], p["w"], p["h"] = cx + dx * q, cy + dy * q, w4 * q, h4 * q
+        p["cu_log2_size"], p["cqt_depth"], p["part_2Nx2N"] = log2, 6 - log2, int(name == "2Nx2N")
+        p["ref_list"] = int(rng.integers(0, 2))
+        p["x_ctb"], p["y_ctb"] = cx & ~63, cy & ~63
+        true = np.array([12, 8]) * (1 if p["ref_list"] == 0 else -1)
+        far = rng.random() < hard_fraction
+        spread = 160 if far else 6
+        p["mvp"][0] = true + rng.integers(-spread, spread + 1, 2)
+        p["mvp"][1] = true + rng.integers(-3 * spread, 3 * spread + 1, 2)
+        p["mv_previous_2Nx2N"] = ((true + rng.integers(-8, 9, 2)) // 4) * 4
+        p["mv_other"] = -true + rng.integers(-5, 6, 2)
+        p["mvp_rate"] = rng.integers(30000, 140000, 2)
+    return pus
+
+
+def clip_planes(width, height, seed, bit_depth=8, pad=96):
+    """(src, ref L0, ref L1, stride): padded luma planes of three consecutive frames of the synthetic clip"""
+    from turingcodec_amd.workload import pad_plane, synth_frames
+    frames = synth_frames(width, height, 3, seed, bit_depth)
+    planes = [pad_plane(f[0], pad) for f in (frames[1], frames[0], frames[2])]
+    stride = planes[0].shape[1]
+    return [np.ascontiguousarray(p.ravel()) for p in planes], stride

@@ -48,64 +48,11 @@ static_assert(sizeof(havoc_mi355x_intra_search_job) == 32, "job ABI");
 static_assert(sizeof(havoc_mi355x_tu_fused_job) == 16, "job ABI");
 static_assert(sizeof(havoc_mi355x_quant_job) == 32, "job ABI");
 
-struct havoc_mi355x_ctx
-{
-    int device;
-    hipStream_t stream;
-    hipEvent_t ev0, ev1;
-    hipDeviceProp_t prop;
-    bool ownsStream;
-    // fork/join lanes: independent launch chains issued on side streams so that they overlap on the GPU
-    static constexpr int kMaxLanes = 8;
-    hipStream_t lanes[kMaxLanes];
-    hipEvent_t laneEv[kMaxLanes];
-    hipEvent_t forkEv;
-    int nlanes;   // 0 = not forked
-    int cur;      // lane the next launch goes to (0 = the context's main stream)
-};
+#include "ctx.h"
 
-// the stream the next launch is issued on
-static inline hipStream_t LS(havoc_mi355x_ctx *ctx) { return ctx->cur == 0 ? ctx->stream : ctx->lanes[ctx->cur]; }
+static thread_local char g_err_storage[256] = "";
+char *havoc_err_buf() { return g_err_storage; }
 
-static thread_local char g_err[256] = "";
-
-static int fail(int code, const char *what)
-{
-    snprintf(g_err, sizeof(g_err), "%s", what);
-    return code;
-}
-
-static int check(hipError_t e, const char *where)
-{
-    if (e == hipSuccess) return 0;
-    snprintf(g_err, sizeof(g_err), "%s: %s", where, hipGetErrorString(e));
-    return -(int)e;
-}
-
-#define REQUIRE(cond, what) \
-    do { if (!(cond)) return fail(HAVOC_MI355X_EINVAL, what); } while (0)
-
-// Every entry point runs with the context's device current on the calling thread and puts the caller's device back on
-// return (a process may hold contexts on several GPUs; hipMalloc, NULL-stream launches and event calls act on whatever
-// device is current).  hipSetDevice is only issued when the current device differs.
-struct DeviceGuard
-{
-    int prev = -1;
-    bool switched = false;
-    explicit DeviceGuard(int device)
-    {
-        if (hipGetDevice(&prev) == hipSuccess && prev != device) switched = hipSetDevice(device) == hipSuccess;
-    }
-    ~DeviceGuard()
-    {
-        if (switched) (void)hipSetDevice(prev);
-    }
-    DeviceGuard(const DeviceGuard &) = delete;
-    DeviceGuard &operator=(const DeviceGuard &) = delete;
-};
-#define REQUIRE_CTX() \
-    REQUIRE(ctx != nullptr, "null context"); \
-    DeviceGuard device_guard_(ctx->device)
 #define REQUIRE_S() REQUIRE(S == 1 || S == 2, "S (bytes per sample) must be 1 or 2")
 #define REQUIRE_BD() REQUIRE(bitDepth >= 8 && bitDepth <= (S == 1 ? 8 : 10), "bitDepth must be 8 (S=1) or 8..10 (S=2)")
 
@@ -138,7 +85,7 @@ int havoc_mi355x_create(havoc_mi355x_ctx **out, int device, void *stream)
     if ((rc = check(hipGetDeviceProperties(&c->prop, device), "hipGetDeviceProperties"))) return bail(rc);
     if (strncmp(c->prop.gcnArchName, "gfx950", 6) != 0)
     {
-        snprintf(g_err, sizeof(g_err), "device %d is %s; this library contains gfx950 code only", device, c->prop.gcnArchName);
+        snprintf(g_err, 256, "device %d is %s; this library contains gfx950 code only", device, c->prop.gcnArchName);
         return bail(HAVOC_MI355X_ENODEV);
     }
     if ((rc = check(hipEventCreate(&c->ev0), "hipEventCreate")) || (rc = check(hipEventCreate(&c->ev1), "hipEventCreate"))) return bail(rc);

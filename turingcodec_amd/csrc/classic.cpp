@@ -10,21 +10,17 @@
 // integration that wants throughput batches through include/havoc_mi355x.h.
 // No CPU implementation is linked: without a gfx950 device havoc_new_code aborts.
 #include "../../include/havoc/havoc_tables.hpp"
+#include "../../include/havoc_classic_ext.h"
 #include "../../include/havoc_mi355x.h"
 
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <vector>
 
 namespace {
-
-struct Binding
-{
-    int device;
-};
-
-std::atomic<Binding *> g_binding{nullptr};
 
 [[noreturn]] void die(const char *what, int rc)
 {
@@ -33,6 +29,81 @@ std::atomic<Binding *> g_binding{nullptr};
 }
 
 #define CK(call) do { const int rc_ = (call); if (rc_) die(#call, rc_); } while (0)
+
+// ---- registered pictures (havoc_classic_ext.h) -------------------------------------------------------------------------
+struct Pic
+{
+    int id;
+    const char *lo, *hi;        // host byte range of the padded plane
+    const char *origin;         // host pointer of sample (0, 0)
+    intptr_t stride;            // samples
+    int w, h, pad, S, bd, role;
+    char *d_plane;              // device copy of [lo, hi)
+    char *d_phase;              // reference: 16 planes of `pe` samples each (slot 0 = copy of the plane), device
+    char *h_phase;              // reference: pinned host mirror of the 16 planes
+    long pe;                    // samples per phase plane
+    // rectangle of the padded plane the phase planes are valid in (plane coordinates: x in [-pad, w + pad))
+    int vx0, vy0, vx1, vy1;
+    long first() const { return -((long)pad * stride + pad); }   // sample index of `lo` relative to the origin
+};
+typedef std::vector<std::shared_ptr<Pic>> PicList;
+
+// The process-wide binding behind every havoc_code of this library: reference-counted (havoc_new_code / havoc_delete_code may
+// be called any number of times, from any thread; table entries stay callable while at least one code is alive).
+struct Binding
+{
+    int device = 0;
+    int refs = 0;
+    std::mutex mu;                                   // registration / new / delete
+    std::atomic<const PicList *> pics{nullptr};      // immutable snapshots: table calls read without a lock
+    std::vector<const PicList *> retired;            // old snapshots, freed with the binding
+    havoc_mi355x_ctx *ctx = nullptr;                 // registration work (uploads, interpolation)
+    int nextId = 1;
+    std::atomic<int64_t> stat[8];
+    Binding() { for (auto &c : stat) c = 0; }
+};
+
+Binding *g_binding = nullptr;                        // guarded by g_mu for creation / destruction
+std::mutex g_mu;
+std::atomic<Binding *> g_live{nullptr};              // what table entries see
+
+inline void bump(int k, int64_t n = 1)
+{
+    if (Binding *b = g_live.load(std::memory_order_relaxed)) b->stat[k].fetch_add(n, std::memory_order_relaxed);
+}
+
+// picture containing host pointer p (any byte of the padded plane), or null
+inline const Pic *findPic(const void *p)
+{
+    Binding *b = g_live.load(std::memory_order_acquire);
+    if (!b) return nullptr;
+    const PicList *l = b->pics.load(std::memory_order_acquire);
+    if (!l) return nullptr;
+    static thread_local const Pic *last[2] = {nullptr, nullptr};
+    static thread_local const PicList *lastList = nullptr;
+    const char *c = static_cast<const char *>(p);
+    if (lastList == l)
+        for (const Pic *q : last)
+            if (q && c >= q->lo && c < q->hi) return q;
+    lastList = l;
+    for (const auto &q : *l)
+        if (c >= q->lo && c < q->hi)
+        {
+            last[1] = last[0];
+            last[0] = q.get();
+            return q.get();
+        }
+    return nullptr;
+}
+
+// (x, y) of host pointer p in picture coordinates
+inline void locate(const Pic *q, const void *p, int *x, int *y)
+{
+    const long off = (static_cast<const char *>(p) - q->lo) / q->S;
+    const long row = off / q->stride;
+    *y = int(row) - q->pad;
+    *x = int(off - row * q->stride) - q->pad;
+}
 
 // per-thread device context + staging memory (never torn down explicitly: process exit reclaims it, which avoids
 // calling into the HIP runtime from thread_local destructors during shutdown)
@@ -48,7 +119,7 @@ struct Stage
     {
         if (!ctx)
         {
-            Binding *b = g_binding.load();
+            Binding *b = g_live.load();
             if (!b)
             {
                 fprintf(stderr, "libhavoc_classic: table function called without a live havoc_code\n");
@@ -57,6 +128,20 @@ struct Stage
             CK(havoc_mi355x_create(&ctx, b->device, HAVOC_MI355X_NEW_STREAM));
         }
         used = 0;
+    }
+
+    // pinned, device-visible scratch of this thread (job tables the kernels read and results they write: no copies)
+    char *hp = nullptr, *dp = nullptr;
+    size_t pcap = 0;
+    void pinned(size_t bytes)
+    {
+        if (pcap >= bytes) return;
+        if (hp) CK(havoc_mi355x_host_free(ctx, hp));
+        void *h_ = nullptr, *d_ = nullptr;
+        pcap = bytes;
+        CK(havoc_mi355x_host_alloc(ctx, pcap, &h_, &d_));
+        hp = static_cast<char *>(h_);
+        dp = static_cast<char *>(d_);
     }
 
     size_t reserve(size_t bytes)
@@ -108,13 +193,330 @@ Stage &stage()
     return *s;
 }
 
+// ---- precompute and serve (havoc_classic_ext.h) -------------------------------------------------------
+//
+// Per THREAD (the reference calls the tables from every worker thread, each working on its own PU): a few SAD surfaces, the
+// memo of the last prediction this thread copied out of the phase planes, and a few tile-SATD sets.  All results live in
+// pinned host memory the kernels write directly; a served call is a pointer look-up plus a few comparisons.
+
+constexpr int kSurfR = 64;                              // surface half-width: the star search's window (Search.hpp:2100)
+constexpr int kSurfSide = 2 * kSurfR + 1;
+constexpr int kSurfaces = 4, kSatdSets = 2;
+constexpr int kSubPel = 3, kSubPelSide = 2 * kSubPel + 1, kSubPelCands = kSubPelSide * kSubPelSide;   // quarter-sample positions
+
+struct SrcKey                                           // the source block of a search
+{
+    const Pic *pic = nullptr;                           // registered input picture (used while the key is being built) ...
+    int picId = 0;                                      // ... compared by its never-reused id
+    int x = 0, y = 0;                                   // ... and the block's position in it
+    const void *ptr = nullptr;                          // or an unregistered block (bi search: the ideal second predictor)
+    intptr_t stride = 0;
+    bool same(const SrcKey &o) const { return picId == o.picId && x == o.x && y == o.y && ptr == o.ptr && stride == o.stride; }
+};
+
+struct Surface
+{
+    bool valid = false;
+    SrcKey src;
+    int refId = 0;                                      // Pic::id of the reference (ids are never reused; pointers may be)
+    int w = 0, h = 0, cx = 0, cy = 0;                   // candidates (cx + dx, cy + dy), |dx|, |dy| <= kSurfR
+    uint64_t stamp = 0;
+    int32_t *res = nullptr;                             // pinned: kSurfSide^2 values
+    char *blockCopy = nullptr;                          // pinned copy of an unregistered source block (the kernel's operand
+                                                        // and the reference for "is this still the same block")
+};
+
+struct PredMemo                                         // what this thread last copied out of a reference's phase planes
+{
+    bool valid = false;
+    const void *dst = nullptr;
+    intptr_t sd = 0;
+    const Pic *ref = nullptr;
+    int x = 0, y = 0, xf = 0, yf = 0, w = 0, h = 0;     // block = plane[4*yf+xf] at (x, y)
+};
+
+struct SatdSet
+{
+    bool valid = false;
+    SrcKey src;                                         // the PU's source block (origin of the PU)
+    int refId = 0;
+    int w = 0, h = 0, n = 0;                            // PU size, tile size
+    int cqx = 0, cqy = 0;                               // centre of the 7 x 7 quarter-sample positions (absolute: 4 * x + xFrac)
+    uint64_t stamp = 0;
+    int32_t *res = nullptr;                             // pinned: [cand][tile]; -1 = position outside the phase planes
+    char *blockCopy = nullptr;
+};
+
+struct Serve
+{
+    bool ready = false;
+    Surface surf[kSurfaces];
+    SatdSet sets[kSatdSets];
+    PredMemo memo;
+    uint64_t clock = 0;
+    char *jobsH = nullptr, *jobsD = nullptr;            // pinned job tables
+    int32_t *denseH = nullptr;                          // pinned: results of a tile-SATD batch in job order
+    char *baseH = nullptr, *baseD = nullptr;            // the one pinned arena (host / device view)
+    static constexpr size_t kSurfBytes = size_t(kSurfSide) * kSurfSide * 4;
+    static constexpr size_t kBlockBytes = 64 * 64 * 2;
+    static constexpr size_t kSetBytes = size_t(kSubPelCands) * 256 * 4;            // <= 256 tiles of 4x4 in a 64x64 PU
+    static constexpr size_t kJobBytes = size_t(kSubPelCands) * 256 * 16 + 64;
+    void init(Stage &s)
+    {
+        if (ready) return;
+        const size_t total = kSurfaces * (kSurfBytes + kBlockBytes) + kSatdSets * (kSetBytes + kBlockBytes) + kJobBytes + kSetBytes + 8192;
+        void *h_ = nullptr, *d_ = nullptr;
+        CK(havoc_mi355x_host_alloc(s.ctx, total, &h_, &d_));
+        baseH = static_cast<char *>(h_);
+        baseD = static_cast<char *>(d_);
+        size_t at = 0;
+        auto take = [&](size_t n) { char *p = baseH + at; at += (n + 255) & ~size_t(255); return p; };
+        for (auto &f : surf) { f.res = reinterpret_cast<int32_t *>(take(kSurfBytes)); f.blockCopy = take(kBlockBytes); }
+        for (auto &f : sets) { f.res = reinterpret_cast<int32_t *>(take(kSetBytes)); f.blockCopy = take(kBlockBytes); }
+        jobsH = take(kJobBytes);
+        jobsD = dev(jobsH);
+        denseH = reinterpret_cast<int32_t *>(take(kSetBytes));
+        ready = true;
+    }
+    char *dev(const void *hostPtr) const { return baseD + (static_cast<const char *>(hostPtr) - baseH); }
+};
+
+Serve &serve(Stage &s)
+{
+    static thread_local Serve *v = new Serve();
+    v->init(s);
+    return *v;
+}
+
+template <typename Sample>
+bool sameBlock(const Sample *p, intptr_t stride, const char *copy, int w, int h)
+{
+    for (int y = 0; y < h; ++y)
+        if (memcmp(p + y * stride, copy + sizeof(Sample) * size_t(y) * w, sizeof(Sample) * w)) return false;
+    return true;
+}
+
+template <typename Sample>
+SrcKey keyOf(const Sample *src, intptr_t ss)
+{
+    SrcKey k;
+    const Pic *q = findPic(src);
+    if (q && q->S == int(sizeof(Sample)) && q->stride == ss)
+    {
+        k.pic = q;
+        k.picId = q->id;
+        locate(q, src, &k.x, &k.y);
+    }
+    else
+    {
+        k.ptr = src;
+        k.stride = ss;
+    }
+    return k;
+}
+
+// ---- SAD: one full-pel surface per (source block, reference) -- Search.hpp:1447-1482, 2060-2336
+template <typename Sample>
+Surface *surfaceFor(Stage &s, Serve &v, const SrcKey &key, const Sample *src, intptr_t ss, const Pic *ref, int rx, int ry, int w, int h)
+{
+    for (auto &f : v.surf)
+        if (f.valid && f.refId == ref->id && f.w == w && f.h == h && f.src.same(key) && abs(rx - f.cx) <= kSurfR && abs(ry - f.cy) <= kSurfR)
+        {
+            if (key.ptr && !sameBlock(src, ss, f.blockCopy, w, h)) { f.valid = false; continue; }   // the buffer was rewritten
+            f.stamp = ++v.clock;
+            return &f;
+        }
+    // miss: a new surface centred on this candidate, moved inwards where the window would leave the padded plane
+    const int margin = 4;   // the kernel reads <= 3 bytes past a candidate row
+    const int loX = -ref->pad + kSurfR, hiX = ref->w + ref->pad - w - kSurfR - margin;
+    const int loY = -ref->pad + kSurfR, hiY = ref->h + ref->pad - h - kSurfR;
+    if (loX > hiX || loY > hiY) return nullptr;         // plane too small for a surface of this size
+    const int cx = rx < loX ? loX : (rx > hiX ? hiX : rx), cy = ry < loY ? loY : (ry > hiY ? hiY : ry);
+    if (abs(rx - cx) > kSurfR || abs(ry - cy) > kSurfR) return nullptr;
+    Surface *f = &v.surf[0];
+    for (auto &g : v.surf)
+        if (!g.valid) { f = &g; break; }
+        else if (g.stamp < f->stamp) f = &g;
+    f->valid = false;
+    const void *dSrc;
+    intptr_t dStride;
+    int32_t srcOff;
+    if (key.pic)
+    {
+        dSrc = key.pic->d_plane;
+        dStride = key.pic->stride;
+        srcOff = int32_t((long)(key.y + key.pic->pad) * key.pic->stride + key.x + key.pic->pad);
+    }
+    else
+    {
+        for (int y = 0; y < h; ++y) memcpy(f->blockCopy + sizeof(Sample) * size_t(y) * w, src + y * ss, sizeof(Sample) * w);
+        dSrc = v.dev(f->blockCopy);
+        dStride = w;
+        srcOff = 0;
+    }
+    havoc_mi355x_surface_job *job = reinterpret_cast<havoc_mi355x_surface_job *>(v.jobsH);
+    *job = {srcOff, int32_t((long)(cy + ref->pad) * ref->stride + cx + ref->pad), w, h, 0, {0, 0, 0}};
+    CK(havoc_mi355x_sad_surface(s.ctx, sizeof(Sample), kSurfR, (w + 3) & ~3, h, dSrc, dStride, ref->d_plane, ref->stride,
+                                reinterpret_cast<const havoc_mi355x_surface_job *>(v.jobsD), 1, reinterpret_cast<int32_t *>(v.dev(f->res))));
+    CK(havoc_mi355x_sync(s.ctx));
+    bump(2);
+    bump(3);
+    f->valid = true;
+    f->src = key;
+    f->refId = ref->id;
+    f->w = w; f->h = h; f->cx = cx; f->cy = cy;
+    f->stamp = ++v.clock;
+    return f;
+}
+
+// true and *out set when the call can be answered from a surface
+template <typename Sample>
+bool serveSad(const Sample *src, intptr_t ss, const Sample *const *refs, int nrefs, intptr_t rs, int w, int h, int *out)
+{
+    if ((w & 3) || w > 64 || h > 64) return false;
+    const Pic *ref = findPic(refs[0]);
+    if (!ref || ref->role != HAVOC_PICTURE_REFERENCE || ref->S != int(sizeof(Sample)) || ref->stride != rs) return false;
+    Stage &s = stage();
+    Serve &v = serve(s);
+    const SrcKey key = keyOf(src, ss);
+    for (int i = 0; i < nrefs; ++i)
+    {
+        if (i && findPic(refs[i]) != ref) return false;
+        int rx, ry;
+        locate(ref, refs[i], &rx, &ry);
+        Surface *f = surfaceFor(s, v, key, src, ss, ref, rx, ry, w, h);
+        if (!f) return false;
+        out[i] = f->res[(ry - f->cy + kSurfR) * kSurfSide + (rx - f->cx + kSurfR)];
+    }
+    bump(0);
+    return true;
+}
+
+// ---- HavocPredUni: a strided copy out of the mirrored phase planes -- Search.hpp:1976-1979
+template <typename Sample>
+bool servePredUni(Sample *dst, intptr_t sd, const Sample *refp, intptr_t sr, int w, int h, int xFrac, int yFrac, int bitDepth)
+{
+    Stage &s = stage();
+    Serve &v = serve(s);
+    v.memo.valid = false;
+    const Pic *ref = findPic(refp);
+    if (!ref || ref->role != HAVOC_PICTURE_REFERENCE || !ref->h_phase || ref->S != int(sizeof(Sample)) || ref->stride != sr || ref->bd != bitDepth)
+        return false;
+    int x, y;
+    locate(ref, refp, &x, &y);
+    if (x < ref->vx0 || y < ref->vy0 || x + w > ref->vx1 || y + h > ref->vy1) return false;
+    const Sample *from = reinterpret_cast<const Sample *>(ref->h_phase) + (long)(4 * yFrac + xFrac) * ref->pe + (long)(y + ref->pad) * ref->stride + x + ref->pad;
+    for (int r = 0; r < h; ++r) memcpy(dst + r * sd, from + r * ref->stride, sizeof(Sample) * w);
+    v.memo = PredMemo{true, dst, sd, ref, x, y, xFrac, yFrac, w, h};
+    bump(0);
+    return true;
+}
+
+// ---- havoc_hadamard_satd of (source tile, tile of the prediction this thread just made): the tile SATDs of all 49
+// quarter-sample positions around the vector, one launch per (PU, list) -- Search.hpp:1963-2061, Measure.h:97-135
+template <typename Sample, int N>
+bool serveSatd(const Sample *a, intptr_t sa, const Sample *b, intptr_t sb, int *out)
+{
+    Stage &s = stage();
+    Serve &v = serve(s);
+    const PredMemo &m = v.memo;
+    if (!m.valid || sb != m.sd) return false;
+    const long off = b - static_cast<const Sample *>(m.dst);
+    if (off < 0) return false;
+    const int ty = int(off / m.sd), tx = int(off - (long)ty * m.sd);
+    if (tx >= m.w || ty >= m.h || (tx % N) || (ty % N) || (m.w % N) || (m.h % N)) return false;
+    const Pic *ref = m.ref;
+    // the prediction tile must still be what was copied (the caller owns that buffer)
+    const Sample *plane = reinterpret_cast<const Sample *>(ref->h_phase) + (long)(4 * m.yf + m.xf) * ref->pe;
+    for (int r = 0; r < N; ++r)
+        if (memcmp(b + r * sb, plane + (long)(m.y + ty + r + ref->pad) * ref->stride + m.x + tx + ref->pad, sizeof(Sample) * N)) return false;
+    // the PU's source block: a is its tile (tx, ty)
+    SrcKey key = keyOf(a - (long)ty * sa - tx, sa);
+    const int tilesX = m.w / N, ntiles = tilesX * (m.h / N), tile = (ty / N) * tilesX + tx / N;
+    const int qx = 4 * m.x + m.xf, qy = 4 * m.y + m.yf;
+    SatdSet *f = nullptr;
+    for (auto &g : v.sets)
+        if (g.valid && g.refId == ref->id && g.w == m.w && g.h == m.h && g.n == N && g.src.same(key) && abs(qx - g.cqx) <= kSubPel && abs(qy - g.cqy) <= kSubPel)
+        {
+            if (key.ptr && !sameBlock(static_cast<const Sample *>(key.ptr), sa, g.blockCopy, m.w, m.h)) { g.valid = false; continue; }
+            f = &g;
+            break;
+        }
+    if (!f)
+    {
+        if (size_t(ntiles) > 256) return false;
+        f = &v.sets[0];
+        for (auto &g : v.sets)
+            if (!g.valid) { f = &g; break; }
+            else if (g.stamp < f->stamp) f = &g;
+        f->valid = false;
+        const void *dA;
+        intptr_t dStrideA;
+        long aOrigin;
+        if (key.pic)
+        {
+            dA = key.pic->d_plane;
+            dStrideA = key.pic->stride;
+            aOrigin = (long)(key.y + key.pic->pad) * key.pic->stride + key.x + key.pic->pad;
+        }
+        else
+        {
+            const Sample *blk = static_cast<const Sample *>(key.ptr);
+            for (int y = 0; y < m.h; ++y) memcpy(f->blockCopy + sizeof(Sample) * size_t(y) * m.w, blk + y * sa, sizeof(Sample) * m.w);
+            dA = v.dev(f->blockCopy);
+            dStrideA = m.w;
+            aOrigin = 0;
+        }
+        havoc_mi355x_pair_job *jobs = reinterpret_cast<havoc_mi355x_pair_job *>(v.jobsH);
+        int nj = 0;
+        for (int c = 0; c < kSubPelCands; ++c)
+        {
+            const int cq_x = qx + c % kSubPelSide - kSubPel, cq_y = qy + c / kSubPelSide - kSubPel;
+            const int X = cq_x >> 2, Y = cq_y >> 2, xf = cq_x & 3, yf = cq_y & 3;
+            const bool ok = X >= ref->vx0 && Y >= ref->vy0 && X + m.w <= ref->vx1 && Y + m.h <= ref->vy1;
+            for (int t = 0; t < ntiles; ++t)
+            {
+                f->res[c * ntiles + t] = -1;
+                if (!ok) continue;
+                const int px = (t % tilesX) * N, py = (t / tilesX) * N;
+                jobs[nj] = {int32_t(aOrigin + (long)py * dStrideA + px),
+                            int32_t((long)(4 * yf + xf) * ref->pe + (long)(Y + py + ref->pad) * ref->stride + X + px + ref->pad), N, N};
+                f->res[c * ntiles + t] = -2 - nj;   // job nj's result: moved into place after the launch
+                ++nj;
+            }
+        }
+        CK(havoc_mi355x_satd(s.ctx, sizeof(Sample), N, N, dA, dStrideA, ref->d_phase, ref->stride,
+                             reinterpret_cast<const havoc_mi355x_pair_job *>(v.jobsD), nj, reinterpret_cast<int32_t *>(v.dev(v.denseH))));
+        CK(havoc_mi355x_sync(s.ctx));
+        bump(2);
+        bump(4);
+        for (int i = 0; i < kSubPelCands * ntiles; ++i)
+            if (f->res[i] <= -2) f->res[i] = v.denseH[-2 - f->res[i]];
+        f->valid = true;
+        f->src = key;
+        f->refId = ref->id;
+        f->w = m.w; f->h = m.h; f->n = N; f->cqx = qx; f->cqy = qy;
+    }
+    f->stamp = ++v.clock;
+    const int c = (qy - f->cqy + kSubPel) * kSubPelSide + (qx - f->cqx + kSubPel);
+    const int32_t val = f->res[c * ntiles + tile];
+    if (val < 0) return false;
+    *out = val;
+    bump(0);
+    return true;
+}
+
 // ---- distortion metrics ---------------------------------------------------------------------------------------
 
 template <typename Sample>
 int sad(const Sample *src, intptr_t ss, const Sample *ref, intptr_t rs, uint32_t rect)
 {
     const int w = rect >> 8, h = rect & 0xff;
+    int served;
+    if (serveSad<Sample>(src, ss, &ref, 1, rs, w, h, &served)) return served;
     Stage &s = stage();
+    bump(1);
+    bump(2);
     const size_t j = s.reserve(sizeof(havoc_mi355x_pair_job)), o = s.reserve(4);
     const size_t a = s.pack(src, ss, w, h, w), b = s.pack(ref, rs, w, h, w);
     *s.job<havoc_mi355x_pair_job>(j) = {0, 0, w, h};
@@ -128,7 +530,10 @@ template <typename Sample>
 void sad4(const Sample *src, intptr_t ss, const Sample *ref[], intptr_t rs, int out[], uint32_t rect)
 {
     const int w = rect >> 8, h = rect & 0xff;
+    if (serveSad<Sample>(src, ss, ref, 4, rs, w, h, out)) return;
     Stage &s = stage();
+    bump(1);
+    bump(2);
     const size_t j = s.reserve(sizeof(havoc_mi355x_sad4_job)), o = s.reserve(16);
     const size_t a = s.pack(src, ss, w, h, w);
     size_t b[4];
@@ -146,6 +551,8 @@ template <typename Sample>
 uint32_t ssd(const Sample *pa, intptr_t sa, const Sample *pb, intptr_t sb, int w, int h)
 {
     Stage &s = stage();
+    bump(1);
+    bump(2);
     const size_t j = s.reserve(sizeof(havoc_mi355x_pair_job)), o = s.reserve(4);
     const size_t a = s.pack(pa, sa, w, h, w), b = s.pack(pb, sb, w, h, w);
     *s.job<havoc_mi355x_pair_job>(j) = {0, 0, w, h};
@@ -158,7 +565,11 @@ uint32_t ssd(const Sample *pa, intptr_t sa, const Sample *pb, intptr_t sb, int w
 template <typename Sample, int N>
 int satd(const Sample *pa, intptr_t sa, const Sample *pb, intptr_t sb)
 {
+    int served;
+    if (serveSatd<Sample, N>(pa, sa, pb, sb, &served)) return served;
     Stage &s = stage();
+    bump(1);
+    bump(2);
     const size_t j = s.reserve(sizeof(havoc_mi355x_pair_job)), o = s.reserve(4);
     const size_t a = s.pack(pa, sa, N, N, N), b = s.pack(pb, sb, N, N, N);
     *s.job<havoc_mi355x_pair_job>(j) = {0, 0, N, N};
@@ -181,25 +592,36 @@ int ssdLinear(const uint8_t *a, const uint8_t *b, int size)
 
 // ---- inter prediction -----------------------------------------------------------------------------------------
 
-// packs the (w+taps-1) x (h+taps-1) window around the block (+3 columns the kernel's vector loads may touch; the
-// kernel reads the window for every phase, the zero phase included); returns the byte offset and sets *origin to the
-// sample offset of the block's integer position
+// Stages the (w+taps-1) x (h+taps-1) window the kernel addresses (+3 columns its vector loads may touch), but READS from
+// the caller only what the reference reads for this phase (havoc/pred_inter.cpp:113-202): no rows above / below the block
+// when yFrac == 0, no columns left / right of it when xFrac == 0 -- a caller's buffer may be exactly that tight.  The
+// rest of the window is zero (the kernel multiplies it by the zero taps of the {.., 64, ..} filter).  Returns the byte
+// offset and sets *origin to the sample offset of the block's integer position.
 template <typename Sample>
-size_t packWindow(Stage &s, const Sample *ref, intptr_t sr, int w, int h, int taps, int *pitch, int *origin)
+size_t packWindow(Stage &s, const Sample *ref, intptr_t sr, int w, int h, int taps, int xFrac, int yFrac, int *pitch, int *origin)
 {
     const int above = taps / 2 - 1, ww = w + taps - 1, wh = h + taps - 1;
     *pitch = ww + 3;
     *origin = above * *pitch + above;
-    return s.pack(ref - above * sr - above, sr, ww, wh, *pitch);
+    const size_t o = s.reserve(sizeof(Sample) * size_t(*pitch) * wh + 16);
+    memset(&s.h[o], 0, sizeof(Sample) * size_t(*pitch) * wh + 16);
+    const int r0 = yFrac ? 0 : above, r1 = yFrac ? wh : above + h;     // rows of the window the reference touches
+    const int c0 = xFrac ? 0 : above, c1 = xFrac ? ww : above + w;
+    for (int r = r0; r < r1; ++r)
+        memcpy(&s.h[o + sizeof(Sample) * (size_t(r) * *pitch + c0)], ref + (r - above) * sr + (c0 - above), sizeof(Sample) * (c1 - c0));
+    return o;
 }
 
 template <typename Sample, int TAPS>
 void predUni(Sample *dst, intptr_t sd, const Sample *ref, intptr_t sr, int w, int h, int xFrac, int yFrac, int bitDepth)
 {
+    if (TAPS == 8 && servePredUni<Sample>(dst, sd, ref, sr, w, h, xFrac, yFrac, bitDepth)) return;
     Stage &s = stage();
+    bump(1);
+    bump(2);
     const size_t j = s.reserve(sizeof(havoc_mi355x_pred_uni_job));
     int pitch, origin;
-    const size_t win = packWindow(s, ref, sr, w, h, TAPS, &pitch, &origin);
+    const size_t win = packWindow(s, ref, sr, w, h, TAPS, xFrac, yFrac, &pitch, &origin);
     const size_t out = s.reserve(sizeof(Sample) * size_t(w) * h);
     *s.job<havoc_mi355x_pred_uni_job>(j) = {0, origin, w, h, xFrac, yFrac, {0, 0}};
     s.upload();
@@ -214,8 +636,8 @@ void predBi(Sample *dst, intptr_t sd, const Sample *ref0, const Sample *ref1, in
     Stage &s = stage();
     const size_t j = s.reserve(sizeof(havoc_mi355x_pred_bi_job));
     int pitch, origin;
-    const size_t w0 = packWindow(s, ref0, sr, w, h, TAPS, &pitch, &origin);
-    const size_t w1 = packWindow(s, ref1, sr, w, h, TAPS, &pitch, &origin);
+    const size_t w0 = packWindow(s, ref0, sr, w, h, TAPS, xFrac0, yFrac0, &pitch, &origin);
+    const size_t w1 = packWindow(s, ref1, sr, w, h, TAPS, xFrac1, yFrac1, &pitch, &origin);
     const size_t out = s.reserve(sizeof(Sample) * size_t(w) * h);
     havoc_mi355x_pred_bi_job job = {0, origin, int32_t((w1 - w0) / sizeof(Sample)) + origin, w, h, xFrac0, yFrac0, xFrac1, yFrac1, {0, 0, 0}};
     *s.job<havoc_mi355x_pred_bi_job>(j) = job;
@@ -376,28 +798,135 @@ void havoc_print_instruction_set_support(FILE *f, havoc_instruction_set mask)
             (mask & HAVOC_GFX950) ? 'x' : ' ', (unsigned)mask);
 }
 
+static void releasePic(Binding *b, Pic *q)
+{
+    if (q->d_plane) (void)havoc_mi355x_free(b->ctx, q->d_plane);
+    if (q->d_phase) (void)havoc_mi355x_free(b->ctx, q->d_phase);
+    if (q->h_phase) (void)havoc_mi355x_host_free(b->ctx, q->h_phase);
+    q->d_plane = q->d_phase = q->h_phase = nullptr;
+}
+
 havoc_code havoc_new_code(havoc_instruction_set mask, int size)
 {
     (void)mask;
     (void)size;
-    Binding *b = new Binding{0};
-    if (const char *e = getenv("HAVOC_MI355X_DEVICE")) b->device = atoi(e);
-    havoc_mi355x_ctx *probe = nullptr;
-    const int rc = havoc_mi355x_create(&probe, b->device, nullptr);
-    if (rc) die("havoc_new_code: havoc_mi355x_create", rc);
-    havoc_mi355x_destroy(probe);
-    g_binding.store(b);
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (!g_binding)
+    {
+        Binding *b = new Binding();
+        if (const char *e = getenv("HAVOC_MI355X_DEVICE")) b->device = atoi(e);
+        const int rc = havoc_mi355x_create(&b->ctx, b->device, HAVOC_MI355X_NEW_STREAM);
+        if (rc) die("havoc_new_code: havoc_mi355x_create", rc);
+        g_binding = b;
+        g_live.store(b, std::memory_order_release);
+    }
+    ++g_binding->refs;
     havoc_code code;
-    code.implementation = b;
+    code.implementation = g_binding;
     return code;
 }
 
+// The binding lives as long as any havoc_code does.  Table entries populated from a deleted code must not be called any
+// more (as with the reference, whose JIT buffer goes away); entries of OTHER live codes keep working.
 void havoc_delete_code(havoc_code code)
 {
+    std::lock_guard<std::mutex> lock(g_mu);
     Binding *b = static_cast<Binding *>(code.implementation);
-    Binding *cur = b;
-    g_binding.compare_exchange_strong(cur, nullptr);
+    if (!b || b != g_binding || b->refs <= 0) return;
+    if (--b->refs > 0) return;
+    g_live.store(nullptr, std::memory_order_release);
+    // device memory of the pictures still registered; per-thread contexts are left to process exit (see Stage)
+    if (const PicList *l = b->pics.load())
+        for (const auto &q : *l) releasePic(b, q.get());
+    for (const PicList *l : b->retired) delete l;
+    delete b->pics.load();
+    havoc_mi355x_destroy(b->ctx);
     delete b;
+    g_binding = nullptr;
+}
+
+int havoc_classic_register_picture(havoc_code code, const void *origin, intptr_t stride, int width, int height, int pad, int S, int bit_depth, int role)
+{
+    Binding *b = static_cast<Binding *>(code.implementation);
+    if (!b || !origin || (S != 1 && S != 2) || width <= 0 || height <= 0 || pad < 0 || stride < width + 2 * pad) return HAVOC_MI355X_EINVAL;
+    if (bit_depth < 8 || bit_depth > (S == 1 ? 8 : 10)) return HAVOC_MI355X_EINVAL;
+    std::lock_guard<std::mutex> lock(b->mu);
+    auto q = std::make_shared<Pic>();
+    q->id = b->nextId++;
+    q->origin = static_cast<const char *>(origin);
+    q->stride = stride;
+    q->w = width; q->h = height; q->pad = pad; q->S = S; q->bd = bit_depth; q->role = role;
+    q->lo = q->origin + q->first() * S;
+    const size_t elems = size_t(stride) * (height + 2 * pad);
+    // the last row of a plane need not own its alignment tail: copy up to the last sample of the padded plane
+    const size_t used = elems - size_t(stride - (width + 2 * pad));
+    q->hi = q->lo + used * S;
+    q->d_plane = q->d_phase = q->h_phase = nullptr;
+    q->pe = 0;
+    q->vx0 = q->vy0 = q->vx1 = q->vy1 = 0;
+    havoc_mi355x_ctx *ctx = b->ctx;
+    int rc;
+    void *dp = nullptr;
+    if ((rc = havoc_mi355x_malloc(ctx, &dp, elems * S + 256))) return rc;
+    q->d_plane = static_cast<char *>(dp);
+    if ((rc = havoc_mi355x_h2d(ctx, q->d_plane, q->lo, used * S))) return rc;
+    b->stat[6] += int64_t(used * S);
+    if (role == HAVOC_PICTURE_REFERENCE && pad >= 16)
+    {
+        // the 16 fractional-sample planes, valid where the 8-tap window and the kernels' vector loads stay inside the plane
+        q->pe = long((elems + 63) & ~size_t(63));
+        void *ph = nullptr, *hh = nullptr, *hd = nullptr;
+        if ((rc = havoc_mi355x_malloc(ctx, &ph, size_t(q->pe) * 16 * S + 256))) return rc;
+        q->d_phase = static_cast<char *>(ph);
+        if ((rc = havoc_mi355x_h2d(ctx, q->d_phase, q->lo, used * S))) return rc;          // slot 0 = the picture itself
+        const int x0 = 12, y0 = 4, wdt = width + 2 * pad - 24, hgt = height + 2 * pad - 8;
+        if ((rc = havoc_mi355x_interp_planes(ctx, S, bit_depth, q->d_phase, q->pe, q->d_plane, stride, x0, y0, wdt, hgt))) return rc;
+        if ((rc = havoc_mi355x_host_alloc(ctx, size_t(q->pe) * 16 * S, &hh, &hd))) return rc;
+        q->h_phase = static_cast<char *>(hh);
+        if ((rc = havoc_mi355x_d2h(ctx, q->h_phase, q->d_phase, size_t(q->pe) * 16 * S))) return rc;
+        b->stat[7] += int64_t(size_t(q->pe) * 16 * S);
+        q->vx0 = x0 - pad; q->vy0 = y0 - pad; q->vx1 = x0 - pad + wdt; q->vy1 = y0 - pad + hgt;
+    }
+    else if ((rc = havoc_mi355x_sync(ctx)))
+        return rc;
+    const PicList *old = b->pics.load();
+    PicList *next = old ? new PicList(*old) : new PicList();
+    next->push_back(q);
+    b->pics.store(next, std::memory_order_release);
+    if (old) b->retired.push_back(old);
+    b->stat[5] += 1;
+    return 0;
+}
+
+int havoc_classic_unregister_picture(havoc_code code, const void *origin)
+{
+    Binding *b = static_cast<Binding *>(code.implementation);
+    if (!b || !origin) return HAVOC_MI355X_EINVAL;
+    std::lock_guard<std::mutex> lock(b->mu);
+    const PicList *old = b->pics.load();
+    if (!old) return HAVOC_MI355X_EINVAL;
+    PicList *next = new PicList();
+    std::shared_ptr<Pic> gone;
+    for (const auto &q : *old)
+        if (q->origin == origin && !gone) gone = q;
+        else next->push_back(q);
+    if (!gone)
+    {
+        delete next;
+        return HAVOC_MI355X_EINVAL;
+    }
+    b->pics.store(next, std::memory_order_release);
+    b->retired.push_back(old);   // the snapshot object itself (a reader on another thread may be walking it): freed with the binding
+    // Contract (as for the reference's own picture buffers): unregister a plane only when no table call can still name it.
+    // Its device and pinned memory go now; per-thread caches match pictures by id, and ids are never reused.
+    releasePic(b, gone.get());
+    return 0;
+}
+
+void havoc_classic_stats(havoc_code code, int64_t out[8])
+{
+    Binding *b = static_cast<Binding *>(code.implementation);
+    for (int k = 0; k < 8; ++k) out[k] = b ? b->stat[k].load() : 0;
 }
 
 void havoc_populate_quantize_inverse(havoc_table_quantize_inverse *table, havoc_code)

@@ -45,6 +45,19 @@ def _load():
         "free": [_vp, _vp],
         "h2d": [_vp, _vp, _vp, C.c_size_t],
         "d2h": [_vp, _vp, _vp, C.c_size_t],
+        "host_alloc": [_vp, C.c_size_t, C.POINTER(_vp), C.POINTER(_vp)],
+        "host_free": [_vp, _vp],
+        "h2d_async": [_vp, _vp, _vp, C.c_size_t],
+        "d2h_async": [_vp, _vp, _vp, C.c_size_t],
+        "copy_2d": [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_size_t, C.c_size_t, _i],
+        "picture_create": [_vp, _i, _i, _i, _i, _i, _i, C.POINTER(_vp)],
+        "picture_destroy": [_vp, _vp],
+        "picture_plane": [_vp, _i, C.POINTER(_vp), C.POINTER(C.c_int64), C.POINTER(_ip), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)],
+        "picture_upload_yuv": [_vp, _vp, _vp, _i, _i, _i],
+        "picture_upload_plane": [_vp, _vp, _i, _vp, _ip, _i],
+        "picture_download_plane": [_vp, _vp, _i, _vp, _ip, _i],
+        "picture_pad": [_vp, _vp],
+        "picture_phase_planes": [_vp, _vp, C.POINTER(_vp), C.POINTER(_ip), C.POINTER(C.c_int64)],
         "timer_start": [_vp],
         "timer_stop_ms": [_vp, C.POINTER(C.c_float)],
         "graph_begin": [_vp],
@@ -82,7 +95,7 @@ def _load():
     for name, args in sig.items():
         f = getattr(L, "havoc_mi355x_" + name)
         f.argtypes = args
-        f.restype = None if name in ("destroy", "graph_destroy") else _i
+        f.restype = None if name in ("destroy", "graph_destroy", "picture_destroy") else _i
     return L, sorted(sig)
 
 

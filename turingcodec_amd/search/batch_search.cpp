@@ -1,0 +1,399 @@
+// libhavoc_search.so -- the decision loops of decision.hpp as a BATCH CLIENT of libhavoc_mi355x.so.
+//
+// The reference's motion search asks for one block at a time and decides before it asks again (turing/Search.hpp:1447-1482,
+// 2060-2336): through a per-call interface that is a launch per question.  Here a whole picture's searches run together:
+//
+//   round 0   one SAD-surface launch: for every (PU, list) the SADs of all integer positions within +-16 of the co-located
+//             block (havoc_mi355x_sad_surface) -- a super-set of what most searches will ask;
+//   replay    the loops of decision.hpp run on the host, every sad / sad4 question answered by a look-up.  A question
+//             outside the data at hand (a far predictor, the raster stage, the sub-sample stage) stops that search with
+//             a note of what it needs;
+//   round k   one launch per kind for everything asked: +-64 surfaces centred on the missed position, and for searches that
+//             reached the sub-sample stage the PU SATDs of all 49 quarter-sample positions around their integer vector
+//             against the reference's phase planes (havoc_mi355x_satd_multi);  then the stopped searches are replayed
+//             from the start (they are deterministic and cheap), until none stops.
+//
+// Results are the reference's by construction: the same loop code as the per-call clients, fed values the GPU kernels
+// computed for exactly the positions asked (tests/test_search.py compares with the reference library's tables).  Plain
+// C++ on include/havoc_mi355x.h only.
+#include "../../include/havoc_mi355x.h"
+#include "decision.hpp"
+#include "search_abi.h"
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+using namespace havoc_search;
+
+extern "C" {
+typedef struct
+{
+    int32_t rounds, launches, surfaces_small, surfaces_large, satd_jobs, replays;
+    int64_t bytes_down;
+    double seconds_gpu, seconds_host, seconds_total;
+} havoc_search_stats;
+}
+
+namespace {
+
+constexpr int kR0 = 16, kR1 = 64;
+constexpr int kSub = 3, kSubSide = 7, kSubCands = 49;
+
+struct Miss
+{
+    int kind;       // 1: integer position (x, y) needed; 2: sub-sample centre (quarter units) needed
+    int x, y;
+};
+
+struct SurfaceRef
+{
+    int cx, cy, R;
+    const int32_t *data;    // (2R+1)^2, row = dy
+};
+
+struct SearchState
+{
+    std::vector<SurfaceRef> surfaces;
+    bool haveSub = false;
+    int subCx = 0, subCy = 0;       // quarter units, relative to the PU position
+    const int32_t *sub = nullptr;   // 49 PU SATDs (-1: outside the phase planes)
+    bool done = false;
+    int replays = 0;
+    Miss miss{0, 0, 0};
+};
+
+// the View of decision.hpp over precomputed data
+struct BatchView
+{
+    SearchState &st;
+    explicit BatchView(SearchState &s) : st(s) {}
+    bool lookup(int dx, int dy, int32_t *v) const
+    {
+        for (const SurfaceRef &f : st.surfaces)
+            if (std::abs(dx - f.cx) <= f.R && std::abs(dy - f.cy) <= f.R)
+            {
+                *v = f.data[(dy - f.cy + f.R) * (2 * f.R + 1) + (dx - f.cx + f.R)];
+                return true;
+            }
+        return false;
+    }
+    int sad(int dx, int dy)
+    {
+        int32_t v;
+        if (!lookup(dx, dy, &v)) throw Miss{1, dx, dy};
+        return v;
+    }
+    void sad4(const Mv d[4], int32_t out[4])
+    {
+        for (int i = 0; i < 4; ++i)
+            if (!lookup(d[i].x, d[i].y, &out[i])) throw Miss{1, d[i].x, d[i].y};
+    }
+    int satdQpel(Mv mv)
+    {
+        if (!st.haveSub || std::abs(mv.x - st.subCx) > kSub || std::abs(mv.y - st.subCy) > kSub) throw Miss{2, mv.x, mv.y};
+        const int32_t v = st.sub[(mv.y - st.subCy + kSub) * kSubSide + (mv.x - st.subCx + kSub)];
+        if (v < 0) throw Miss{3, mv.x, mv.y};   // the position's window leaves the phase planes: cannot be served
+        return v;
+    }
+};
+
+SearchParams paramsOf(const havoc_search_params &p)
+{
+    SearchParams sp;
+    sp.picWidth = p.pic_width;
+    sp.picHeight = p.pic_height;
+    sp.ctbSize = p.ctb_size;
+    sp.concurrentFrames = p.concurrent_frames;
+    sp.met = p.met != 0;
+    sp.smallSearchWindow = p.small_search_window != 0;
+    sp.biSmallSearchWindow = p.bi_small_search_window != 0;
+    sp.halfPel = p.half_pel != 0;
+    sp.quarterPel = p.quarter_pel != 0;
+    sp.reciprocalSqrtLambda = p.reciprocal_sqrt_lambda;
+    sp.bitDepth = p.bit_depth;
+    return sp;
+}
+
+PuContext puOf(const havoc_search_pu &q)
+{
+    PuContext pu;
+    pu.x0 = q.x0; pu.y0 = q.y0; pu.w = q.w; pu.h = q.h;
+    pu.cuLog2Size = q.cu_log2_size;
+    pu.cqtDepth = q.cqt_depth;
+    pu.part2Nx2N = q.part_2Nx2N != 0;
+    pu.xCtb = q.x_ctb; pu.yCtb = q.y_ctb;
+    for (int k = 0; k < 2; ++k)
+    {
+        pu.mvp[k] = Mv(q.mvp[k][0], q.mvp[k][1]);
+        pu.mvpRate[k] = q.mvp_rate[k];
+    }
+    pu.mvPrevious2Nx2N = Mv(q.mv_previous_2Nx2N[0], q.mv_previous_2Nx2N[1]);
+    return pu;
+}
+
+double now()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+struct Arena   // device buffer + host mirror that only grow; results of all rounds stay valid until the call returns
+{
+    havoc_mi355x_ctx *ctx;
+    std::vector<void *> dev, host;
+    explicit Arena(havoc_mi355x_ctx *c) : ctx(c) {}
+    int get(size_t bytes, void **d, void **h)
+    {
+        void *dp = nullptr, *hp = nullptr, *hd = nullptr;
+        int rc = havoc_mi355x_malloc(ctx, &dp, bytes + 256);
+        if (rc) return rc;
+        dev.push_back(dp);
+        if ((rc = havoc_mi355x_host_alloc(ctx, bytes + 256, &hp, &hd))) return rc;
+        host.push_back(hp);
+        *d = dp;
+        *h = hp;
+        return 0;
+    }
+    ~Arena()
+    {
+        for (void *p : dev) (void)havoc_mi355x_free(ctx, p);
+        for (void *p : host) (void)havoc_mi355x_host_free(ctx, p);
+    }
+};
+
+#define RC(call) do { const int rc_ = (call); if (rc_) return rc_; } while (0)
+
+} // namespace
+
+extern "C" {
+
+// Uni-directional motion search (searchMotionUni, turing/Search.hpp:1317-1355) of n (PU, list) pairs of ONE picture against
+// ONE reference picture.  Planes are device memory: *_origin = sample offset of picture sample (0, 0) from the base pointer,
+// strides in samples; the reference plane has `ref_pad` samples of replicated border; d_phase = its 16 fractional-sample
+// planes (havoc_mi355x_interp_planes / havoc_mi355x_picture_phase_planes), phase k sample (x, y) at
+// d_phase[k * plane_elems + phase_origin + y * ref_stride + x].  out[i] = what the per-call loop decides for pus[i].
+int havoc_search_motion_uni(havoc_mi355x_ctx *ctx, int S, const havoc_search_params *params, const void *d_src, int64_t src_origin, intptr_t src_stride,
+                            const void *d_ref, int64_t ref_origin, intptr_t ref_stride, int ref_pad, const void *d_phase, intptr_t plane_elems,
+                            int64_t phase_origin, const havoc_search_pu *pus, int n, havoc_search_result *out, int threads,
+                            havoc_search_stats *stats)
+{
+    if (!ctx || !params || !pus || !out || n < 0 || (S != 1 && S != 2)) return HAVOC_MI355X_EINVAL;
+    const double tStart = now();
+    const SearchParams sp = paramsOf(*params);
+    havoc_search_stats stt;
+    std::memset(&stt, 0, sizeof(stt));
+    std::vector<SearchState> state(n);
+    Arena arena(ctx);
+    if (threads < 1) threads = 1;
+    const int W = sp.picWidth, H = sp.picHeight;
+
+    // where a surface of half-width R for PU i may be centred so that its window stays inside the padded plane
+    auto clampCentre = [&](const havoc_search_pu &q, int R, int *cx, int *cy) {
+        const int loX = -ref_pad + R - q.x0, hiX = W + ref_pad - q.w - R - 4 - q.x0;
+        const int loY = -ref_pad + R - q.y0, hiY = H + ref_pad - q.h - R - q.y0;
+        if (loX > hiX || loY > hiY) return false;
+        *cx = std::min(std::max(*cx, loX), hiX);
+        *cy = std::min(std::max(*cy, loY), hiY);
+        return true;
+    };
+
+    struct Want { int i, cx, cy; };
+    std::vector<Want> wantSurf[2];          // [0] small (round 0), [1] large
+    std::vector<Want> wantSub;
+    for (int i = 0; i < n; ++i)
+    {
+        const havoc_search_pu &q = pus[i];
+        if (q.w < 4 || q.h < 4 || q.w > 64 || q.h > 64 || (q.w & 3) || q.x0 < 0 || q.y0 < 0 || q.x0 + q.w > W || q.y0 + q.h > H) return HAVOC_MI355X_EINVAL;
+        int cx = 0, cy = 0;
+        if (!clampCentre(q, kR0, &cx, &cy)) return HAVOC_MI355X_EINVAL;   // picture (with its padding) smaller than a search window
+        wantSurf[0].push_back({i, cx, cy});
+    }
+
+    std::vector<int> pending(n);
+    for (int i = 0; i < n; ++i) pending[i] = i;
+
+    while (!pending.empty())
+    {
+        ++stt.rounds;
+        if (stt.rounds > 64) return HAVOC_MI355X_EINVAL;   // cannot happen: every round serves what stopped a search
+        const double tGpu = now();
+        // ---- launches of this round ----
+        for (int big = 0; big < 2; ++big)
+        {
+            std::vector<Want> &w = wantSurf[big];
+            if (w.empty()) continue;
+            // a surface whose clamped centre cannot reach the wanted position is dropped to radius 0 at the exact position
+            const int R = big ? kR1 : kR0, side = 2 * R + 1;
+            void *dJobs, *hJobs, *dOut, *hOut;
+            RC(arena.get(w.size() * sizeof(havoc_mi355x_surface_job), &dJobs, &hJobs));
+            RC(arena.get(w.size() * size_t(side) * side * 4, &dOut, &hOut));
+            havoc_mi355x_surface_job *jobs = static_cast<havoc_mi355x_surface_job *>(hJobs);
+            for (size_t k = 0; k < w.size(); ++k)
+            {
+                const havoc_search_pu &q = pus[w[k].i];
+                jobs[k] = {int32_t(src_origin + int64_t(q.y0) * src_stride + q.x0),
+                           int32_t(ref_origin + int64_t(q.y0 + w[k].cy) * ref_stride + q.x0 + w[k].cx), q.w, q.h, int32_t(k * size_t(side) * side), {0, 0, 0}};
+                state[w[k].i].surfaces.push_back({w[k].cx, w[k].cy, R, static_cast<const int32_t *>(hOut) + k * size_t(side) * side});
+            }
+            RC(havoc_mi355x_h2d_async(ctx, dJobs, hJobs, w.size() * sizeof(havoc_mi355x_surface_job)));
+            RC(havoc_mi355x_sad_surface(ctx, S, R, 64, 64, d_src, src_stride, d_ref, ref_stride, static_cast<const havoc_mi355x_surface_job *>(dJobs),
+                                        int(w.size()), static_cast<int32_t *>(dOut)));
+            RC(havoc_mi355x_d2h_async(ctx, hOut, dOut, w.size() * size_t(side) * side * 4));
+            ++stt.launches;
+            (big ? stt.surfaces_large : stt.surfaces_small) += int32_t(w.size());
+            stt.bytes_down += int64_t(w.size() * size_t(side) * side * 4);
+            w.clear();
+        }
+        if (!wantSub.empty())
+        {
+            // 49 quarter-sample positions per search = 4 jobs of <= 16 candidates; one launch per lane-group class of the
+            // SATD kernel (rows of 8 samples per PU), as the reference's table is indexed by size
+            struct Cls { int lo, hi, mw, mh; };
+            static const Cls classes[4] = {{0, 8, 8, 8}, {8, 16, 16, 8}, {16, 32, 16, 16}, {32, 1 << 30, 64, 64}};
+            for (const Cls &c : classes)
+            {
+                std::vector<int> sel;
+                for (size_t k = 0; k < wantSub.size(); ++k)
+                {
+                    const havoc_search_pu &q = pus[wantSub[k].i];
+                    const int rows = ((q.w + 7) / 8) * q.h;
+                    if (rows > c.lo && rows <= c.hi) sel.push_back(int(k));
+                }
+                if (sel.empty()) continue;
+                void *dJobs, *hJobs, *dOut, *hOut;
+                RC(arena.get(sel.size() * 4 * sizeof(havoc_mi355x_satd_multi_job), &dJobs, &hJobs));
+                RC(arena.get(sel.size() * 64 * 4, &dOut, &hOut));
+                havoc_mi355x_satd_multi_job *jobs = static_cast<havoc_mi355x_satd_multi_job *>(hJobs);
+                int32_t *res = static_cast<int32_t *>(hOut);
+                for (size_t k = 0; k < sel.size(); ++k)
+                {
+                    const Want &wn = wantSub[sel[k]];
+                    const havoc_search_pu &q = pus[wn.i];
+                    SearchState &st = state[wn.i];
+                    st.haveSub = true;
+                    st.subCx = wn.cx;
+                    st.subCy = wn.cy;
+                    st.sub = res + k * 64;      // slot c of 49 at [c / 16 * 16 + c % 16]: dense since jobs are consecutive
+                    for (int j = 0; j < 4; ++j)
+                    {
+                        havoc_mi355x_satd_multi_job &mj = jobs[4 * k + j];
+                        std::memset(&mj, 0, sizeof(mj));
+                        mj.a_off = int32_t(src_origin + int64_t(q.y0) * src_stride + q.x0);
+                        mj.w = q.w;
+                        mj.h = q.h;
+                        mj.count = j < 3 ? 16 : 1;
+                        for (int e = 0; e < mj.count; ++e)
+                        {
+                            const int c2 = 16 * j + e;
+                            const int qx = wn.cx + c2 % kSubSide - kSub, qy = wn.cy + c2 / kSubSide - kSub;
+                            const int X = q.x0 + (qx >> 2), Y = q.y0 + (qy >> 2);
+                            // positions whose 8-tap window leaves the padded plane are not in the phase planes: point at the
+                            // integer position instead; the value is flagged unusable after the launch
+                            const bool ok = X >= -ref_pad + 12 && Y >= -ref_pad + 4 && X + q.w <= W + ref_pad - 12 && Y + q.h <= H + ref_pad - 4;
+                            mj.b_off[e] = ok ? int32_t(int64_t(4 * (qy & 3) + (qx & 3)) * plane_elems + phase_origin + int64_t(Y) * ref_stride + X)
+                                             : int32_t(phase_origin + int64_t(q.y0) * ref_stride + q.x0);
+                        }
+                    }
+                }
+                RC(havoc_mi355x_h2d_async(ctx, dJobs, hJobs, sel.size() * 4 * sizeof(havoc_mi355x_satd_multi_job)));
+                RC(havoc_mi355x_satd_multi(ctx, S, c.mw, c.mh, d_src, src_stride, d_phase, ref_stride, static_cast<const havoc_mi355x_satd_multi_job *>(dJobs),
+                                           int(sel.size() * 4), static_cast<int32_t *>(dOut)));
+                RC(havoc_mi355x_d2h_async(ctx, hOut, dOut, sel.size() * 64 * 4));
+                RC(havoc_mi355x_sync(ctx));
+                for (size_t k = 0; k < sel.size(); ++k)   // re-flag the positions outside the phase planes
+                {
+                    const Want &wn = wantSub[sel[k]];
+                    const havoc_search_pu &q = pus[wn.i];
+                    for (int c2 = 0; c2 < kSubCands; ++c2)
+                    {
+                        const int qx = wn.cx + c2 % kSubSide - kSub, qy = wn.cy + c2 / kSubSide - kSub;
+                        const int X = q.x0 + (qx >> 2), Y = q.y0 + (qy >> 2);
+                        if (!(X >= -ref_pad + 12 && Y >= -ref_pad + 4 && X + q.w <= W + ref_pad - 12 && Y + q.h <= H + ref_pad - 4)) res[k * 64 + c2] = -1;
+                    }
+                }
+                ++stt.launches;
+                stt.satd_jobs += int32_t(sel.size() * 4);
+                stt.bytes_down += int64_t(sel.size() * 64 * 4);
+            }
+            wantSub.clear();
+        }
+        RC(havoc_mi355x_sync(ctx));
+        stt.seconds_gpu += now() - tGpu;
+
+        // ---- replay the stopped searches on the host ----
+        const double tHost = now();
+        std::atomic<int> next{0};
+        auto worker = [&]() {
+            for (;;)
+            {
+                const int k = next.fetch_add(1);
+                if (k >= int(pending.size())) return;
+                const int i = pending[k];
+                SearchState &st = state[i];
+                const PuContext pu = puOf(pus[i]);
+                BatchView view(st);
+                try
+                {
+                    MotionSearch<BatchView> search(sp, pu, view);
+                    const UniResult r = search.run();
+                    havoc_search_result &o = out[i];
+                    std::memset(&o, 0, sizeof(o));
+                    o.mv[0] = r.mv.x; o.mv[1] = r.mv.y;
+                    o.mvd[0] = r.mvd.x; o.mvd[1] = r.mvd.y;
+                    o.mv_integer[0] = r.mvInteger.x; o.mv_integer[1] = r.mvInteger.y;
+                    o.mvp_flag = int16_t(r.mvpFlag);
+                    o.wrote_2Nx2N = r.wrote2Nx2N;
+                    o.calls = r.calls;
+                    o.replays = st.replays;
+                    o.cost_integer = r.costInteger;
+                    o.cost_subpel = r.costSubPel;
+                    o.cost_mvd_zero[0] = r.costMvdZero[0];
+                    o.cost_mvd_zero[1] = r.costMvdZero[1];
+                    st.done = true;
+                }
+                catch (const Miss &m)
+                {
+                    st.miss = m;
+                    ++st.replays;
+                }
+            }
+        };
+        const int nt = std::min<int>(threads, int(pending.size()));
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; ++t) pool.emplace_back(worker);
+        worker();
+        for (auto &th : pool) th.join();
+        stt.seconds_host += now() - tHost;
+
+        std::vector<int> still;
+        for (int i : pending)
+        {
+            SearchState &st = state[i];
+            if (st.done) continue;
+            ++stt.replays;
+            if (st.miss.kind == 1)
+            {
+                int cx = st.miss.x, cy = st.miss.y;
+                // LimitFullPelMv keeps every candidate within reach of a +-64 window that stays inside the 96-sample padding
+                if (!clampCentre(pus[i], kR1, &cx, &cy) || std::abs(cx - st.miss.x) > kR1 || std::abs(cy - st.miss.y) > kR1) return HAVOC_MI355X_EINVAL;
+                wantSurf[1].push_back({i, cx, cy});
+            }
+            else if (st.miss.kind == 2)
+                wantSub.push_back({i, st.miss.x, st.miss.y});
+            else
+                return HAVOC_MI355X_EINVAL;   // a sub-sample position outside the phase planes: the caller's planes are too small
+            still.push_back(i);
+        }
+        pending.swap(still);
+    }
+    stt.seconds_total = now() - tStart;
+    if (stats) *stats = stt;
+    return 0;
+}
+
+const char *havoc_search_version(void) { return "havoc_search 0.1 (batch client of havoc_mi355x)"; }
+
+} // extern "C"

@@ -1,0 +1,519 @@
+// decision.hpp -- the encoder's decision loops that CALL the havoc hot path, restated once over a small per-call
+// interface so that the same code can be driven by
+//   (a) a per-block implementation of the primitives (the reference's own table API; the tests also plug in their CPU checker) and
+//   (b) the MI355X batch API, which serves the calls from super-set batches (SAD surfaces, phase planes) and replays
+//       the loop on the host (batch_search.cpp).
+// Identical decisions (motion vectors, costs, mode lists) from (a) and (b) is what makes the batched hot path a
+// drop-in for these callers: SURVEY.md 8(f)-1.
+//
+// Restated from the reference (file:line under /root/reference/turing):
+//   Cost / Lambda fixed point            Cost.h:33-34, FixedPoint.h:32-81
+//   rateOf(mvd)                          Measure.h:177-220
+//   MvCandidate (predictor choice, <)    Search.hpp:1252-1314
+//   LimitFullPelMv                       Search.hpp:1366-1407
+//   StateMeFullPel::considerPattern      Search.hpp:1447-1482
+//   fullPelMotionEstimation              Search.hpp:2060-2336
+//   costDistortionMv / costMv            Search.hpp:1963-2006
+//   patternSearch / subPelRefinement     Search.hpp:2010-2061, 2340-2358
+//   searchMotionUni                      Search.hpp:1317-1355
+//   searchMotionBi                       Search.hpp:1498-1657
+//   searchIntraPartition (SATD stage and candidate order)  Search.hpp:40-190
+// Everything outside the primitives is integer arithmetic on 16-bit vector components and Q16 costs; the order of
+// evaluation and the strict `<` comparisons are kept, because ties are decided by them.
+#pragma once
+
+#include <cstdint>
+#include <cstdlib>
+#include <limits>
+
+namespace havoc_search {
+
+typedef int64_t Cost;                       // FixedPoint<int64_t, 16>
+constexpr Cost kCostMax = std::numeric_limits<int64_t>::max();
+
+struct Lambda                               // FixedPoint<int32_t, 16>
+{
+    int32_t value = 0;
+    void set(double d) { value = static_cast<int32_t>(d * (1 << 16) + 0.5); }   // FixedPoint::set(double)
+    Cost operator*(int32_t y) const { return int64_t(value) * int64_t(y); }
+};
+
+struct Mv                                   // MotionVector: 16-bit components, quarter-sample units unless said otherwise
+{
+    int16_t x = 0, y = 0;
+    Mv() {}
+    Mv(int x_, int y_) : x(int16_t(x_)), y(int16_t(y_)) {}
+    bool operator==(const Mv &o) const { return x == o.x && y == o.y; }
+    bool operator!=(const Mv &o) const { return !(*this == o); }
+};
+inline Mv operator+(Mv a, Mv b) { return Mv(int16_t(a.x + b.x), int16_t(a.y + b.y)); }
+inline Mv operator-(Mv a, Mv b) { return Mv(int16_t(a.x - b.x), int16_t(a.y - b.y)); }
+inline Mv shr2(Mv a) { return Mv(int16_t(a.x >> 2), int16_t(a.y >> 2)); }
+inline Mv shl2(Mv a) { return Mv(int16_t(a.x << 2), int16_t(a.y << 2)); }
+
+// Measure.h:177-212 (the portable branch: position of the highest set bit, 0 for 0)
+inline unsigned rateOfMvdComponent(int d)
+{
+    unsigned u = unsigned(std::abs(d)), rate = 0;
+    for (int i = 0; i < 32; ++i)
+        if (u & (1u << i)) rate = unsigned(i) + 1;
+    return rate;
+}
+// Measure.h:214-220: Cost::make(r0 + r1 + 1, -1) = (r0 + r1 + 1) << 17
+inline Cost rateOf(Mv mvd) { return Cost(rateOfMvdComponent(mvd.x) + rateOfMvdComponent(mvd.y) + 1) << 17; }
+
+struct MvCandidate                          // Search.hpp:1252-1314
+{
+    Mv mv, mvd;
+    Cost cost = kCostMax;
+    int mvpFlag = 0;
+    MvCandidate() {}
+    // best of the two predictors for this vector; mvpRate[k] = rate of mvp_lX_flag == k in the current CABAC state
+    MvCandidate(Mv mv_, const Mv predictors[2], const Cost mvpRate[2])
+    {
+        mvpFlag = 0;
+        mvd = mv_ - predictors[0];
+        cost = rateOf(mvd) + mvpRate[0];
+        MvCandidate temp;
+        temp.mvpFlag = 1;
+        temp.mvd = mv_ - predictors[1];
+        temp.cost = rateOf(temp.mvd) + mvpRate[1];
+        consider(temp);
+        mv = mv_;
+    }
+    bool consider(const MvCandidate &other)
+    {
+        const bool better = other.cost < cost;
+        if (better) *this = other;
+        return better;
+    }
+};
+
+// what the loops read from encoder state
+struct SearchParams
+{
+    int picWidth = 0, picHeight = 0;        // pic_width / height_in_luma_samples
+    int ctbSize = 64;                       // CtbSizeY
+    int concurrentFrames = 4;               // StateEncode::concurrentFrames (--concurrent-frames default, encode.cpp:151)
+    bool met = true;                        // Speed::useMet(): medium and faster
+    bool smallSearchWindow = false;         // Speed::useSmallSearchWindow(): fast and faster
+    bool biSmallSearchWindow = false;       // Speed::useBiSmallSearchWindow()
+    bool halfPel = true, quarterPel = true; // Speed::doHalfPelRefinement / doQuarterPelRefinement (medium: both)
+    double reciprocalSqrtLambda = 0.0;      // StateEncodePicture::reciprocalSqrtLambda
+    int bitDepth = 8;
+};
+
+// one prediction unit and the per-PU state the search reads
+struct PuContext
+{
+    int x0 = 0, y0 = 0, w = 0, h = 0;       // prediction_unit
+    int cuLog2Size = 0;                     // log2CbSize of the coding unit
+    int cqtDepth = 0;
+    bool part2Nx2N = true;
+    int xCtb = 0, yCtb = 0;                 // CTU origin (LimitFullPelMv with concurrent frames)
+    Mv mvp[2];                              // predictors->mvp[0][refList][0..1]
+    Cost mvpRate[2] = {0, 0};               // EstimateRateBin<mvp_lX_flag>::rate(0 / 1)
+    Mv mvPrevious2Nx2N;                     // stateEncodeSubstream->mvPreviousInteger2Nx2N[refList] (multiple of 4)
+};
+
+struct LimitFullPelMv                       // Search.hpp:1366-1407; full-sample units
+{
+    Mv lo, hi;
+    LimitFullPelMv(const PuContext &pu, const SearchParams &sp)
+    {
+        lo = Mv(-sp.ctbSize - pu.x0, -sp.ctbSize - pu.y0);
+        hi = Mv(sp.picWidth + sp.ctbSize - pu.x0 - pu.w, sp.picHeight + sp.ctbSize - pu.y0 - pu.h);
+        if (sp.concurrentFrames > 1)
+        {
+            const int howCloseDoYouDare = 15;
+            const int16_t wx = int16_t(pu.xCtb + 3 * sp.ctbSize - pu.x0 - pu.w - howCloseDoYouDare);
+            const int16_t wy = int16_t(pu.yCtb + 2 * sp.ctbSize - pu.y0 - pu.h - howCloseDoYouDare);
+            if (wx < hi.x) hi.x = wx;
+            if (wy < hi.y) hi.y = wy;
+        }
+    }
+    void operator()(Mv &mv) const
+    {
+        if (mv.x < lo.x) mv.x = lo.x;
+        if (mv.y < lo.y) mv.y = lo.y;
+        if (mv.x > hi.x) mv.x = hi.x;
+        if (mv.y > hi.y) mv.y = hi.y;
+    }
+};
+
+struct UniResult
+{
+    Mv mv, mvd;                             // after sub-sample refinement
+    int mvpFlag = 0;
+    Mv mvInteger;                           // best vector of the integer search (quarter units, multiple of 4)
+    Cost costInteger = kCostMax;            // MvCandidate::cost of that vector
+    Cost costSubPel = kCostMax;             // patternSearch's bestCost
+    Cost costMvdZero[2] = {kCostMax, kCostMax};
+    bool wrote2Nx2N = false;                // mvPreviousInteger2Nx2N was updated (to mvInteger)
+    int calls = 0;                          // primitive calls the loop made (SAD, SAD4, interpolate + SATD)
+};
+
+// View = the per-call interface of ONE (PU, reference list) pair:
+//     int  sad(int dx, int dy)                         havoc_sad of the source block against ref(x0 + dx, y0 + dy)
+//     void sad4(const Mv d[4], int32_t out[4])         havoc_sad_multiref, four full-sample displacements
+//     int  satdQpel(Mv mv)                             HavocPredUni at the quarter-sample vector + measureSatd
+// (b)-type views may throw to ask for a replay once the missing data has been computed; the loops hold no state
+// outside their arguments, so a replay is just a second call.
+template <class View>
+struct MotionSearch
+{
+    const SearchParams &sp;
+    const PuContext &pu;
+    View &view;
+    LimitFullPelMv limit;
+    Lambda lambda;
+    MvCandidate best;
+    int calls = 0;
+
+    MotionSearch(const SearchParams &sp_, const PuContext &pu_, View &view_) : sp(sp_), pu(pu_), view(view_), limit(pu_, sp_)
+    {
+        lambda.set(sp.reciprocalSqrtLambda);
+    }
+
+    // Search.hpp:1447-1482.  origin in quarter units; pattern entries are multiplied by dist and divided by 4
+    bool considerPattern(Mv origin, const Mv *pattern, int n, int step, int dist)
+    {
+        bool improved = false;
+        for (int j = 0; j < n; j += 4 * step)
+        {
+            Mv mv[4];
+            for (int i = 0; i < 4; ++i, pattern += step)
+            {
+                mv[i].x = int16_t((origin.x + dist * pattern->x) / 4);
+                mv[i].y = int16_t((origin.y + dist * pattern->y) / 4);
+                limit(mv[i]);
+            }
+            int32_t sads[4];
+            view.sad4(mv, sads);
+            ++calls;
+            for (int i = 0; i < 4; ++i)
+            {
+                MvCandidate candidate(shl2(mv[i]), pu.mvp, pu.mvpRate);
+                candidate.cost += lambda * sads[i];
+                improved |= best.consider(candidate);
+            }
+        }
+        return improved;
+    }
+
+    // the early-termination probe after an improving start point (Search.hpp:2112-2124 and twice more)
+    bool metTriggered()
+    {
+        static const Mv diamond[4] = {{-4, 0}, {0, 4}, {4, 0}, {0, -4}};
+        bool triggerMet = !considerPattern(best.mv, diamond, 4, 1, 1);
+        if (triggerMet && pu.cuLog2Size >= 5)
+        {
+            static const Mv hexagon[8] = {{0, -8}, {8, -4}, {8, 4}, {0, 8}, {-8, 4}, {-8, -4}, {-8, 4}, {-8, -4}};
+            triggerMet = !considerPattern(best.mv, hexagon, 8, 1, 1);
+        }
+        return triggerMet;
+    }
+
+    int sadAt(Mv full)
+    {
+        ++calls;
+        return view.sad(full.x, full.y);
+    }
+
+    // Search.hpp:2060-2336.  Returns true when mvPreviousInteger2Nx2N is to be updated with best.mv
+    bool fullPel(Cost costMvdZero[2])
+    {
+        const int searchWindow = sp.smallSearchWindow ? 32 : 64;
+        const int maxCounter = sp.smallSearchWindow ? 2 : 3;
+        const int rasterSearch = sp.smallSearchWindow ? 120 : 240;
+        {
+            // zero vector as a starting point (the position is NOT limited)
+            MvCandidate candidate(Mv(0, 0), pu.mvp, pu.mvpRate);
+            candidate.cost += lambda * sadAt(Mv(0, 0));
+            const bool better = best.consider(candidate);
+            if (better && sp.met && metTriggered()) return false;
+        }
+        MvCandidate candidate;
+        for (candidate.mvpFlag = 0; candidate.mvpFlag < 2; ++candidate.mvpFlag)
+        {
+            const Mv predicted = pu.mvp[candidate.mvpFlag];
+            candidate.mv = shr2(Mv(int16_t(predicted.x + 1), int16_t(predicted.y + 1)));
+            limit(candidate.mv);
+            candidate.mv = shl2(candidate.mv);
+            candidate.mvd = candidate.mv - predicted;
+            candidate.cost = rateOf(candidate.mvd);
+            candidate.cost += pu.mvpRate[candidate.mvpFlag];
+            candidate.cost += lambda * sadAt(shr2(candidate.mv));
+            costMvdZero[candidate.mvpFlag] = candidate.cost;
+            const bool better = best.consider(candidate);
+            if (better && sp.met && metTriggered()) return false;
+        }
+        if (!pu.part2Nx2N || pu.cqtDepth != 0)
+        {
+            Mv mv = shr2(pu.mvPrevious2Nx2N);
+            limit(mv);
+            mv = shl2(mv);
+            MvCandidate c(mv, pu.mvp, pu.mvpRate);
+            c.cost += lambda * sadAt(shr2(c.mv));
+            const bool better = best.consider(c);
+            if (better && sp.met && metTriggered()) return false;
+        }
+
+        // HM style "star" search
+        Mv mvStart = best.mv;
+        int distBest = 0, counter = 0, step = 4;
+        static const Mv diamond[16] = {{0, -4}, {1, -3}, {2, -2}, {3, -1}, {4, 0}, {3, 1}, {2, 2}, {1, 3},
+                                       {0, 4}, {-1, 3}, {-2, 2}, {-3, 1}, {-4, 0}, {-3, -1}, {-2, -2}, {-1, -3}};
+        static const Mv square4[4] = {{-4, -4}, {-4, 4}, {4, 4}, {4, -4}};
+        for (int dist = 1; dist <= searchWindow && counter < maxCounter; dist <<= 1)
+        {
+            if (dist == 2 || dist == 8) step >>= 1;
+            if (considerPattern(mvStart, diamond, 16, step, dist))
+            {
+                distBest = dist;
+                counter = 0;
+            }
+            else
+                ++counter;
+        }
+        if (distBest == 1)
+        {
+            distBest = 0;
+            considerPattern(best.mv, square4, 4, 1, 1);
+        }
+        if (distBest > 5)
+        {   // raster refinement: absolute positions, every 5th full sample
+            static const Mv line[4] = {{0, 0}, {1, 0}, {2, 0}, {3, 0}};
+            for (int my = -rasterSearch; my <= rasterSearch; my += 20)
+                for (int mx = -rasterSearch; mx <= rasterSearch; mx += 80) considerPattern(Mv(mx, my), line, 4, 1, 20);
+            distBest = 5;
+        }
+        while (distBest > 0)
+        {   // star refinement
+            mvStart = best.mv;
+            distBest = 0;
+            step = 4;
+            for (int dist = 1; dist <= searchWindow; dist <<= 1)
+            {
+                if (dist == 2 || dist == 8) step >>= 1;
+                if (considerPattern(mvStart, diamond, 16, step, dist)) distBest = dist;
+            }
+            if (distBest == 1)
+            {
+                considerPattern(mvStart, square4, 4, 1, 1);
+                distBest = 0;
+            }
+        }
+        if (!sp.smallSearchWindow)
+        {
+            int j;
+            do
+            {
+                static const Mv diamond4[4] = {{0, -1}, {-1, 0}, {0, 1}, {1, 0}};
+                Mv mv[4];
+                for (int i = 0; i < 4; ++i)
+                {
+                    mv[i] = Mv(int16_t(best.mv.x / 4), int16_t(best.mv.y / 4)) + diamond4[i];
+                    limit(mv[i]);
+                }
+                int32_t sads[4];
+                view.sad4(mv, sads);
+                ++calls;
+                j = -1;
+                for (int i = 0; i < 4; ++i)
+                {
+                    MvCandidate temp(shl2(mv[i]), pu.mvp, pu.mvpRate);
+                    temp.cost += lambda * sads[i];
+                    if (best.consider(temp)) j = i;
+                }
+            } while (j >= 0);
+        }
+        return pu.part2Nx2N;
+    }
+
+    // costMv, Search.hpp:2001-2006 (no mvp-flag rate here)
+    Cost costMv(Mv mv, Mv mvd)
+    {
+        ++calls;
+        return rateOf(mvd) + lambda * view.satdQpel(mv);
+    }
+
+    // Search.hpp:2010-2061 with maxIterations = 1, the only way subPelRefinement calls it
+    void patternSearchOnce(const Mv (&pattern)[8], bool tryOrigin, Mv &mv, Mv &mvd, Cost &bestCost)
+    {
+        if (tryOrigin) bestCost = costMv(mv, mvd);
+        int bestI = -1;
+        for (int i = 0; i < 8; ++i)
+        {
+            const Cost cost = costMv(mv + pattern[i], mvd + pattern[i]);
+            if (cost < bestCost)
+            {
+                bestI = i;
+                bestCost = cost;
+            }
+        }
+        if (bestI >= 0)
+        {
+            mvd = mvd + pattern[bestI];
+            mv = mv + pattern[bestI];
+        }
+    }
+
+    // searchMotionUni, Search.hpp:1317-1355
+    UniResult run()
+    {
+        UniResult r;
+        r.wrote2Nx2N = fullPel(r.costMvdZero);
+        r.mvInteger = best.mv;
+        r.costInteger = best.cost;
+        r.mvpFlag = best.mvpFlag;
+        Mv mv = best.mv, mvd = best.mvd;
+        if (sp.halfPel)
+        {
+            static const Mv half[8] = {{-2, -2}, {0, -2}, {2, -2}, {-2, 0}, {2, 0}, {-2, 2}, {0, 2}, {2, 2}};
+            patternSearchOnce(half, true, mv, mvd, r.costSubPel);
+            if (sp.quarterPel)
+            {
+                static const Mv quarter[8] = {{-1, -1}, {0, -1}, {1, -1}, {-1, 0}, {1, 0}, {-1, 1}, {0, 1}, {1, 1}};
+                patternSearchOnce(quarter, false, mv, mvd, r.costSubPel);
+            }
+        }
+        r.mv = mv;
+        r.mvd = mvd;
+        r.calls = calls;
+        return r;
+    }
+};
+
+// ---- bi-directional refinement of one list against the other list's prediction (searchMotionBi, Search.hpp:1498-1657)
+// BiView = the view of (PU, list being refined) whose source block is the "ideal" second predictor
+// clip(2 * source - prediction from the other list) (havoc::SubtractBi); it is built by the caller from the other
+// list's vector (limited like Search.hpp:1527-1530) and offers the same sad4 / satdQpel calls.
+struct BiResult
+{
+    Mv mv, mvd;
+    int mvpFlag = 0;
+    Cost cost = kCostMax;
+    int calls = 0;
+};
+
+template <class BiView>
+BiResult searchMotionBi(const SearchParams &sp, const PuContext &pu, BiView &view, Mv startingMv)
+{
+    BiResult r;
+    LimitFullPelMv limit(pu, sp);
+    MvCandidate best;
+    best.mv = shr2(Mv(int16_t(startingMv.x + 1), int16_t(startingMv.y + 1)));
+    limit(best.mv);
+    Mv mv1 = best.mv, mv2 = best.mv, mv3 = best.mv;
+    best.mv = shl2(best.mv);
+    best.cost = kCostMax;
+    const Mv origin = best.mv;
+    Lambda lambda;
+    lambda.set(sp.reciprocalSqrtLambda * 0.5);
+    const int range = sp.biSmallSearchWindow ? 1 : 5;
+    for (int y = -range; y <= range; ++y)
+    {
+        int32_t sads[4] = {0, 0, 0, 0};
+        for (int x = -range; x <= range; ++x)
+        {
+            Mv mv = shr2(Mv(int16_t(origin.x + 4 * x), int16_t(origin.y + 4 * y)));
+            limit(mv);
+            const int i = (x + range) % 4;
+            if (i == 0)
+            {
+                mv1 = Mv(int16_t(mv.x + 1), mv.y);
+                limit(mv1);
+                mv2 = Mv(int16_t(mv.x + 2), mv.y);
+                limit(mv2);
+                mv3 = Mv(int16_t(mv.x + 3), mv.y);
+                limit(mv3);
+                const Mv four[4] = {mv, mv1, mv2, mv3};
+                view.sad4(four, sads);
+                ++r.calls;
+            }
+            MvCandidate candidate(shl2(mv), pu.mvp, pu.mvpRate);
+            candidate.cost += lambda * sads[i];
+            best.consider(candidate);
+        }
+    }
+    if (sp.halfPel)
+    {
+        const int refinement = sp.quarterPel ? 1 : 2;
+        for (int step = 2; step; step -= refinement)
+        {
+            const Mv org = best.mv;
+            best.cost = kCostMax;
+            for (int y = -step; y <= step; y += step)
+                for (int x = -step; x <= step; x += step)
+                {
+                    const Mv mv(int16_t(org.x + x), int16_t(org.y + y));
+                    MvCandidate candidate(mv, pu.mvp, pu.mvpRate);
+                    candidate.cost += lambda * view.satdQpel(mv);   // costDistortionMv(..., k = 0.5)
+                    ++r.calls;
+                    best.consider(candidate);
+                }
+        }
+    }
+    r.mv = best.mv;
+    r.mvd = best.mvd;
+    r.mvpFlag = best.mvpFlag;
+    r.cost = best.cost;
+    return r;
+}
+
+// ---- intra: the 35-mode SATD stage and the order in which modes go forward to RD refinement (Search.hpp:40-190)
+struct IntraContext
+{
+    int candModeList[3] = {0, 1, 26};       // CandModeList (most probable modes)
+    int neighbourModes = 3;                 // candModeList.neighbourModes
+    Cost rateBminusC = 0;                   // rateB - rateC of the current CABAC state (rateA - rateC = -rateC)
+    Cost rateAminusC = 0;
+    int maxRefine = 3;                      // Speed::nCandidatesIntraRefinement(log2 partition size)
+};
+
+struct IntraResult
+{
+    Cost costs[35];                         // after the SATD stage
+    int order[35];                          // modes in the order they would be RD-refined
+    int count = 0;
+};
+
+// satd35[m] = the distortion predictIntraLuma returns for mode m (prediction + Hadamard SATD against the source)
+inline IntraResult intraModeOrder(const IntraContext &ic, double reciprocalSqrtLambda, const int32_t satd35[35])
+{
+    IntraResult r;
+    Lambda lambda;
+    lambda.set(reciprocalSqrtLambda);
+    Cost costs[35];
+    for (int n = 0; n < 35; ++n) costs[n] = 0;
+    costs[ic.candModeList[0]] = ic.rateAminusC;
+    costs[ic.candModeList[1]] = ic.rateBminusC;
+    costs[ic.candModeList[2]] = ic.rateBminusC;
+    for (int n = 0; n < 35; ++n) costs[n] += lambda * satd35[n];
+    for (int n = 0; n < 35; ++n) r.costs[n] = costs[n];
+    int nMpm = 0;
+    for (int j = 0; j < ic.maxRefine + nMpm; ++j)
+    {
+        int mode = 0;
+        Cost costBest = costs[0];
+        for (int i = 1; i < 35; ++i)
+            if (costs[i] < costBest)
+            {
+                costBest = costs[i];
+                mode = i;
+            }
+        costs[mode] = kCostMax;
+        if (j == ic.maxRefine - 1)
+            for (int i = 0; i < ic.neighbourModes; ++i)
+                if (costs[ic.candModeList[i]] != kCostMax)
+                {
+                    costs[ic.candModeList[i]] = 0;
+                    ++nMpm;
+                }
+        r.order[r.count++] = mode;
+    }
+    return r;
+}
+
+} // namespace havoc_search
