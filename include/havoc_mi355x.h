@@ -190,6 +190,17 @@ typedef struct {
 int havoc_mi355x_pad_block(havoc_mi355x_ctx *ctx, int S, void *d_plane, int64_t origin_off, int width, int height,
                            intptr_t stride, int pad, int top, int bottom, int left, int right);
 
+/* In-loop deblocking of a whole 4:2:0 picture, in place: LoopFilter::Picture::deblock<EDGE_VER> then
+ * <EDGE_HOR> (turing/LoopFilter.h:229-400, 739-777) over every 8x8 region, which is what the reference's CTU-by-CTU order
+ * (turing/TaskDeblock.cpp:105-127) amounts to.  d_luma / d_cb / d_cr point at sample (0, 0) of each plane.  The boundary
+ * strengths and QPs -- the encoder's decisions (LoopFilter.h:480-737) -- come as the two arrays of LoopFilter::Block on its
+ * grid of ((width + 63) / 64 * 8 + 1) x ((height + 63) / 64 * 8 + 1) regions: d_block_data[i] = (QpY << 1) | filter-disabled,
+ * d_block_bs[i] = 2-bit strengths, bits 0-1 / 2-3 = the region's left edge rows 0-3 / 4-7, bits 4-5 / 6-7 = its top edge
+ * columns 0-3 / 4-7 (chroma uses the first of each pair, as the reference does).  One slice: the offsets are per picture. */
+int havoc_mi355x_deblock(havoc_mi355x_ctx *ctx, int S, int bitDepth, void *d_luma, intptr_t stride_luma, void *d_cb, void *d_cr, intptr_t stride_chroma,
+                         int width, int height, const int8_t *d_block_data, const uint8_t *d_block_bs, int tc_offset_div2, int beta_offset_div2,
+                         int cb_qp_offset, int cr_qp_offset);
+
 /* Device-side picture store + input upload.  A picture = the three planes of Picture<Sample>
  * (turing/Picture.cpp:91-125) in ONE HBM allocation: per plane `pad` samples of border (chroma: pad / 2), row stride rounded
  * up to `alignment` bytes (the reference: pad 96, alignment 32, turing/StatePictures.h:155-156; this library's kernels are

@@ -457,3 +457,148 @@ void oracle_pad_block(void *p, int w, int h, intptr_t stride, int pad, int top, 
         for (int i = 1; i <= pad; ++i)
             memcpy(b + (x0 + (intptr_t)(h - 1 + i) * stride) * S, b + (x0 + (intptr_t)(h - 1) * stride) * S, (size_t)(wide * S));
 }
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Deblocking filter.  Follows turing/LoopFilter.h: Block (:52-91, packed QP / disable bit and the
+ * four 2-bit boundary strengths of an 8x8 luma region), betaTable / tCTable (:217-227), LumaBlockEdge (:229-357),
+ * ChromaBlockEdge (:359-400), Picture::deblock (:739-777).  The reference filters CTU by CTU (vertical edges of a region
+ * shifted by 8, then horizontal edges: turing/TaskDeblock.cpp:105-127); no edge of one direction touches samples
+ * another edge of that direction reads, so that order is equivalent to the two picture passes done here: every vertical
+ * edge, then every horizontal edge.  blocks: grid of (W64/8 + 1) x (H64/8 + 1) entries, W64 / H64 = the picture size
+ * rounded up to 64 (LoopFilter::Picture's constructor, :435-441).  4:2:0, one slice (offsets are per picture).
+ * --------------------------------------------------------------------------------------------------------- */
+static const int kBetaTable[52] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 20, 22, 24, 26, 28,
+                                   30, 32, 34, 36, 38, 40, 42, 44, 46, 48, 50, 52, 54, 56, 58, 60, 62, 64};
+static const int kTcTable[54] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 5, 5,
+                                 6, 6, 7, 8, 9, 10, 11, 13, 14, 16, 18, 20, 22, 24};
+
+static int dbk_clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
+static int dbk_get(const void *p, long i, int S) { return S == 1 ? ((const uint8_t *)p)[i] : ((const uint16_t *)p)[i]; }
+static void dbk_put(void *p, long i, int v, int S)
+{
+    if (S == 1) ((uint8_t *)p)[i] = (uint8_t)v;
+    else ((uint16_t *)p)[i] = (uint16_t)v;
+}
+static int dbk_qpc(int qPi)   /* turing/Global.h:1417-1423 */
+{
+    static const int lookup[13] = {29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37};
+    if (qPi < 30) return qPi;
+    if (qPi > 42) return qPi - 6;
+    return lookup[qPi - 30];
+}
+static int dbk_dsam(int p0, int p3, int q0, int q3, int dpq, int beta, int tC)
+{
+    return dpq < (beta >> 2) && abs(p3 - p0) + abs(q0 - q3) < (beta >> 3) && abs(p0 - q0) < ((5 * tC + 1) >> 1);
+}
+
+/* one 4-sample luma edge segment: s = sample q(0,0); across = step from p to q side, along = step to the next line */
+static void dbk_luma_segment(void *pl, long s, long across, long along, int bS, int qpP, int qpQ, int enP, int enQ, int tc2, int beta2, int bd, int S)
+{
+    if (!bS) return;
+#define P(i, k) dbk_get(pl, s - ((i) + 1) * across + (k) * along, S)
+#define Q(i, k) dbk_get(pl, s + (i) * across + (k) * along, S)
+    const int qPL = (qpQ + qpP + 1) >> 1;
+    const int beta = kBetaTable[dbk_clip3(0, 51, qPL + (beta2 << 1))] * (1 << (bd - 8));
+    const int tC = kTcTable[dbk_clip3(0, 53, qPL + 2 * (bS - 1) + (tc2 << 1))] * (1 << (bd - 8));
+    const int dp0 = abs(P(2, 0) - 2 * P(1, 0) + P(0, 0)), dp3 = abs(P(2, 3) - 2 * P(1, 3) + P(0, 3));
+    const int dq0 = abs(Q(2, 0) - 2 * Q(1, 0) + Q(0, 0)), dq3 = abs(Q(2, 3) - 2 * Q(1, 3) + Q(0, 3));
+    const int dpq0 = dp0 + dq0, dpq3 = dp3 + dq3, dp = dp0 + dp3, dq = dq0 + dq3, d = dpq0 + dpq3;
+    int dE = 0, dEp = 0, dEq = 0;
+    if (d < beta)
+    {
+        const int s0 = dbk_dsam(P(0, 0), P(3, 0), Q(0, 0), Q(3, 0), 2 * dpq0, beta, tC);
+        const int s3 = dbk_dsam(P(0, 3), P(3, 3), Q(0, 3), Q(3, 3), 2 * dpq3, beta, tC);
+        dE = (s0 && s3) ? 2 : 1;
+        if (dp < ((beta + (beta >> 1)) >> 3)) dEp = 1;
+        if (dq < ((beta + (beta >> 1)) >> 3)) dEq = 1;
+    }
+    const int maxv = (1 << bd) - 1;
+    for (int k = 0; k < 4 && dE; ++k)
+    {
+        const int p0 = P(0, k), p1 = P(1, k), p2 = P(2, k), p3 = P(3, k), q0 = Q(0, k), q1 = Q(1, k), q2 = Q(2, k), q3 = Q(3, k);
+#define SETP(i, v) dbk_put(pl, s - ((i) + 1) * across + k * along, (v), S)
+#define SETQ(i, v) dbk_put(pl, s + (i) * across + k * along, (v), S)
+        if (dE == 2)
+        {
+            if (enP)
+            {
+                SETP(0, dbk_clip3(p0 - 2 * tC, p0 + 2 * tC, (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3));
+                SETP(1, dbk_clip3(p1 - 2 * tC, p1 + 2 * tC, (p2 + p1 + p0 + q0 + 2) >> 2));
+                SETP(2, dbk_clip3(p2 - 2 * tC, p2 + 2 * tC, (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3));
+            }
+            if (enQ)
+            {
+                SETQ(0, dbk_clip3(q0 - 2 * tC, q0 + 2 * tC, (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3));
+                SETQ(1, dbk_clip3(q1 - 2 * tC, q1 + 2 * tC, (p0 + q0 + q1 + q2 + 2) >> 2));
+                SETQ(2, dbk_clip3(q2 - 2 * tC, q2 + 2 * tC, (p0 + q0 + q1 + 3 * q2 + 2 * q3 + 4) >> 3));
+            }
+        }
+        else
+        {
+            int delta = (9 * (q0 - p0) - 3 * (q1 - p1) + 8) >> 4;
+            if (abs(delta) < tC * 10)
+            {
+                delta = dbk_clip3(-tC, tC, delta);
+                if (enP) SETP(0, dbk_clip3(0, maxv, p0 + delta));
+                if (enQ) SETQ(0, dbk_clip3(0, maxv, q0 - delta));
+                if (dEp && enP) SETP(1, dbk_clip3(0, maxv, p1 + dbk_clip3(-(tC >> 1), tC >> 1, (((p2 + p0 + 1) >> 1) - p1 + delta) >> 1)));
+                if (dEq && enQ) SETQ(1, dbk_clip3(0, maxv, q1 + dbk_clip3(-(tC >> 1), tC >> 1, (((q2 + q0 + 1) >> 1) - q1 - delta) >> 1)));
+            }
+        }
+    }
+#undef P
+#undef Q
+#undef SETP
+#undef SETQ
+}
+
+static void dbk_chroma_segment(void *pl, long s, long across, long along, int bS, int qpP, int qpQ, int enP, int enQ, int tc2, int offset, int bd, int S)
+{
+    if (bS != 2) return;
+    const int qPi = ((qpQ + qpP + 1) >> 1) + offset;
+    const int tC = kTcTable[dbk_clip3(0, 53, dbk_qpc(qPi) + 2 + (tc2 << 1))] * (1 << (bd - 8));
+    const int maxv = (1 << bd) - 1;
+    for (int k = 0; k < 4; ++k)
+    {
+        const int p0 = dbk_get(pl, s - across + k * along, S), p1 = dbk_get(pl, s - 2 * across + k * along, S);
+        const int q0 = dbk_get(pl, s + k * along, S), q1 = dbk_get(pl, s + across + k * along, S);
+        const int delta = dbk_clip3(-tC, tC, ((((q0 - p0) << 2) + p1 - q1 + 4) >> 3));
+        if (enP) dbk_put(pl, s - across + k * along, dbk_clip3(0, maxv, p0 + delta), S);
+        if (enQ) dbk_put(pl, s + k * along, dbk_clip3(0, maxv, q0 - delta), S);
+    }
+}
+
+void oracle_deblock(void *luma, intptr_t stride_y, void *cb, void *cr, intptr_t stride_c, int width, int height, int bitDepth,
+                    const int8_t *block_data, const uint8_t *block_bs, int tc_offset_div2, int beta_offset_div2, int cb_qp_offset,
+                    int cr_qp_offset, int S)
+{
+    const int bstride = ((width + 63) / 64) * 8 + 1;
+    for (int edge = 0; edge < 2; ++edge)   /* 0 = EDGE_VER, 1 = EDGE_HOR */
+        for (int y = 0; y < height / 8; ++y)
+            for (int x = 0; x < width / 8; ++x)
+            {
+                const long q = (long)bstride * y + x, p = edge ? q - bstride : q - 1;
+                const int bsAll = block_bs[q];
+                const int enQ = !(block_data[q] & 1), qpQ = block_data[q] >> 1;
+                for (int pos = 0; pos < 2; ++pos)
+                {
+                    const int bS = 3 & (bsAll >> (4 * edge + 2 * pos));
+                    if (!bS) continue;   /* block P is only looked at behind a non-zero strength (LoopFilter.h:242-247) */
+                    const long s = edge ? (long)(8 * y) * stride_y + 8 * x + 4 * pos : (long)(8 * y + 4 * pos) * stride_y + 8 * x;
+                    dbk_luma_segment(luma, s, edge ? stride_y : 1, edge ? 1 : stride_y, bS, block_data[p] >> 1, qpQ, !(block_data[p] & 1), enQ,
+                                     tc_offset_div2, beta_offset_div2, bitDepth, S);
+                }
+                if (edge ? (y % 2 == 0) : (x % 2 == 0))
+                {
+                    const int bS = 3 & (bsAll >> (4 * edge));   /* position 0's strength for the whole chroma segment (:366, :385) */
+                    if (bS == 2)
+                    {
+                        const long s = (long)(4 * y) * stride_c + 4 * x;
+                        dbk_chroma_segment(cb, s, edge ? stride_c : 1, edge ? 1 : stride_c, bS, block_data[p] >> 1, qpQ, !(block_data[p] & 1), enQ,
+                                           tc_offset_div2, cb_qp_offset, bitDepth, S);
+                        dbk_chroma_segment(cr, s, edge ? stride_c : 1, edge ? 1 : stride_c, bS, block_data[p] >> 1, qpQ, !(block_data[p] & 1), enQ,
+                                           tc_offset_div2, cr_qp_offset, bitDepth, S);
+                    }
+                }
+            }
+}

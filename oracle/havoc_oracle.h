@@ -61,6 +61,13 @@ void oracle_quantize_reconstruct(uint8_t *rec, intptr_t stride_rec, const uint8_
 void oracle_pad_block(void *p, int w, int h, intptr_t stride, int pad, int top, int bottom, int left, int right, int S);
 void oracle_residual(int16_t *res, intptr_t stride_res, const void *src, intptr_t stride_src, const void *pred, intptr_t stride_pred, int w, int h, int S);
 
+/* turing/LoopFilter.h:229-400, 739-777 + TaskDeblock.cpp:105-127: in-place deblocking of a 4:2:0 picture.  luma / cb / cr point at
+ * sample (0, 0); block_data[i] = (QpY << 1) | filter-disabled, block_bs[i] = 2-bit strengths (vertical pos 0, 1, horizontal pos
+ * 0, 1) on the ((width+63)/64*8 + 1)-wide grid of 8x8 luma regions */
+void oracle_deblock(void *luma, intptr_t stride_y, void *cb, void *cr, intptr_t stride_c, int width, int height, int bitDepth,
+                    const int8_t *block_data, const uint8_t *block_bs, int tc_offset_div2, int beta_offset_div2, int cb_qp_offset,
+                    int cr_qp_offset, int S);
+
 /* turing/Measure.h:97-135 (measureSatd): PU SATD tiled in 8x8 / 4x4 / 2x2 Hadamards */
 int oracle_pu_satd(const void *a, intptr_t stride_a, const void *b, intptr_t stride_b, int w, int h, int S);
 

@@ -78,6 +78,13 @@ class Oracle:
         L.oracle_pad_block.restype = None
         L.oracle_pad_block.argtypes = [_vp, C.c_int, C.c_int, _ip] + [C.c_int] * 6
 
+        L.oracle_deblock.restype = None
+        L.oracle_deblock.argtypes = [_vp, _ip, _vp, _vp, _ip, C.c_int, C.c_int, C.c_int, _vp, _vp] + [C.c_int] * 5
+
+    def deblock(self, luma, sy, cb, cr, sc, width, height, bd, data, bs, tc2=0, beta2=0, cb_qp=0, cr_qp=0):
+        """in place on the three planes (numpy arrays whose element 0 is sample (0, 0))"""
+        self.L.oracle_deblock(_addr(luma), sy, _addr(cb), _addr(cr), sc, width, height, bd, _addr(data), _addr(bs), tc2, beta2, cb_qp, cr_qp, _S(luma))
+
     # every method: arrays are flat (or 2-D C-contiguous) numpy arrays, offsets/strides in samples
     def sad(self, src, so, ss, ref, ro, rs, w, h):
         return self.L.oracle_sad(_addr(src, so), ss, _addr(ref, ro), rs, w, h, _S(src))
@@ -194,6 +201,13 @@ class Reference:
     @staticmethod
     def _sfx(a):
         return "u8" if a.itemsize == 1 else "u16"
+
+    def deblock(self, luma, sy, cb, cr, sc, width, height, bd, data, bs, tc2=0, beta2=0, cb_qp=0, cr_qp=0):
+        """the reference's own LoopFilter::Picture::deblock templates in its CTU order (oracle/ref_shim_deblock.cpp); in place"""
+        f = self._f("ref_deblock", luma)
+        f.restype = None
+        f.argtypes = [_vp, _ip, _vp, _vp, _ip, C.c_int, C.c_int, C.c_int, _vp, _vp] + [C.c_int] * 4
+        f(_addr(luma), sy, _addr(cb), _addr(cr), sc, width, height, bd, _addr(data), _addr(bs), tc2, beta2, cb_qp, cr_qp)
 
     def _f(self, name, a):
         return getattr(self.L, name + "_" + self._sfx(a))

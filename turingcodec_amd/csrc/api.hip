@@ -13,6 +13,7 @@ hipError_t launch_satd(hipStream_t, int S, int maxw, int maxh, const void *, lon
 hipError_t launch_satd_multi(hipStream_t, int S, int maxw, int maxh, const void *, long, const void *, long, const void *, int, int32_t *);
 hipError_t launch_pad_block(hipStream_t, int S, void *, long, int, int, long, int, int, int, int, int);
 hipError_t launch_ssd_linear(hipStream_t, const uint8_t *, const uint8_t *, int, int32_t *);
+hipError_t launch_deblock(hipStream_t, int S, int bd, void *, long, void *, void *, long, int, int, const int8_t *, const uint8_t *, int, int, int, int);
 hipError_t launch_pred_uni(hipStream_t, int S, int taps, int bd, int maxw, int maxh, void *, long, const void *, long, const void *, int);
 hipError_t launch_pred_bi(hipStream_t, int S, int taps, int bd, int maxw, int maxh, void *, long, const void *, long, const void *, int);
 hipError_t launch_subtract_bi(hipStream_t, int S, int bd, void *, long, const void *, long, const void *, long, const void *, int);
@@ -344,6 +345,19 @@ int havoc_mi355x_pad_block(havoc_mi355x_ctx *ctx, int S, void *d_plane, int64_t 
     REQUIRE_CTX(); REQUIRE_S();
     REQUIRE(width > 0 && height > 0 && pad >= 0, "width / height must be positive, pad >= 0");
     return check(launch_pad_block(LS(ctx), S, d_plane, (long)origin_off, width, height, stride, pad, top, bottom, left, right), "pad_block");
+}
+
+int havoc_mi355x_deblock(havoc_mi355x_ctx *ctx, int S, int bitDepth, void *d_luma, intptr_t stride_luma, void *d_cb, void *d_cr, intptr_t stride_chroma,
+                         int width, int height, const int8_t *d_block_data, const uint8_t *d_block_bs, int tc_offset_div2, int beta_offset_div2,
+                         int cb_qp_offset, int cr_qp_offset)
+{
+    REQUIRE_CTX(); REQUIRE_S(); REQUIRE_BD();
+    REQUIRE(width >= 8 && height >= 8 && (width & 7) == 0 && (height & 7) == 0, "width / height must be multiples of 8 (minimum coding block)");
+    REQUIRE(d_luma && d_cb && d_cr && d_block_data && d_block_bs, "null plane / block map");
+    REQUIRE(tc_offset_div2 >= -6 && tc_offset_div2 <= 6 && beta_offset_div2 >= -6 && beta_offset_div2 <= 6, "slice offsets must be -6..6");
+    return check(launch_deblock(LS(ctx), S, bitDepth, d_luma, stride_luma, d_cb, d_cr, stride_chroma, width, height, d_block_data, d_block_bs,
+                                tc_offset_div2, beta_offset_div2, cb_qp_offset, cr_qp_offset),
+                 "deblock");
 }
 
 int havoc_mi355x_ssd_linear(havoc_mi355x_ctx *ctx, const uint8_t *d_a, const uint8_t *d_b, int size, int32_t *d_out)

@@ -71,6 +71,7 @@ def _load():
         "sad4": [_vp, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
         "pad_block": [_vp, _i, _vp, C.c_int64, _i, _i, _ip, _i, _i, _i, _i, _i],
         "sad_surface": [_vp, _i, _i, _i, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
+        "deblock": [_vp, _i, _i, _vp, _ip, _vp, _vp, _ip, _i, _i, _vp, _vp, _i, _i, _i, _i],
         "ssd": [_vp, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
         "satd": [_vp, _i, _i, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
         "satd_multi": [_vp, _i, _i, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
@@ -235,6 +236,22 @@ class Havoc:
         d = self.up(plane)
         self.pad_block_d(d, origin, w, h, stride, pad, top, bottom, left, right)
         return self.down(d, plane.dtype)
+
+    def deblock_d(self, bd, luma, luma_off, sy, chroma, cb_off, cr_off, sc, width, height, data, bs, tc2=0, beta2=0, cb_qp=0, cr_qp=0):
+        """in place; luma / chroma = device tensors, *_off = element offset of sample (0, 0) of each plane"""
+        S = self._S(luma)
+        self._ck(self.L.havoc_mi355x_deblock(self.h, S, bd, luma.data_ptr() + luma_off * S, sy, chroma.data_ptr() + cb_off * S,
+                                             chroma.data_ptr() + cr_off * S, sc, width, height, _ptr(data), _ptr(bs), tc2, beta2, cb_qp, cr_qp))
+
+    def deblock(self, bd, luma, sy, cb, cr, sc, width, height, data, bs, tc2=0, beta2=0, cb_qp=0, cr_qp=0):
+        """numpy level: planes WITHOUT padding (stride = row length); returns the three filtered planes"""
+        y = self.up(luma)
+        c = self.up(np.concatenate([cb.ravel(), cr.ravel()]))
+        d = self.torch.from_numpy(np.ascontiguousarray(data, np.int8)).to(self.device)
+        b = self.torch.from_numpy(np.ascontiguousarray(bs, np.uint8)).to(self.device)
+        self.deblock_d(bd, y, 0, sy, c, 0, cb.size, sc, width, height, d, b, tc2, beta2, cb_qp, cr_qp)
+        o = self.down(c, cb.dtype)
+        return self.down(y, luma.dtype), o[:cb.size].reshape(cb.shape), o[cb.size:].reshape(cr.shape)
 
     def sad4_d(self, src, ss, ref, rs, jobs, out):
         self._ck(self.L.havoc_mi355x_sad4(self.h, self._S(src), _ptr(src), ss, _ptr(ref), rs, _ptr(jobs), jobs.shape[0], _ptr(out)))

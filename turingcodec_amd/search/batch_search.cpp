@@ -3,7 +3,7 @@
 // The reference's motion search asks for one block at a time and decides before it asks again (turing/Search.hpp:1447-1482,
 // 2060-2336): through a per-call interface that is a launch per question.  Here a whole picture's searches run together:
 //
-//   round 0   one SAD-surface launch: for every (PU, list) the SADs of all integer positions within +-16 of the co-located
+//   round 0   one SAD-surface launch: for every (PU, list) the SADs of all integer positions within +-32 of the co-located
 //             block (havoc_mi355x_sad_surface) -- a super-set of what most searches will ask;
 //   replay    the loops of decision.hpp run on the host, every sad / sad4 question answered by a look-up.  A question
 //             outside the data at hand (a far predictor, the raster stage, the sub-sample stage) stops that search with
@@ -24,6 +24,8 @@
 #include <atomic>
 #include <chrono>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -40,7 +42,7 @@ typedef struct
 
 namespace {
 
-constexpr int kR0 = 16, kR1 = 64;
+constexpr int kR0 = 32, kR1 = 64;   // round 0 covers what the star search probes around a good start (dist 1..16, three failures)
 constexpr int kSub = 3, kSubSide = 7, kSubCands = 49;
 
 struct Miss
@@ -140,28 +142,66 @@ double now()
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-struct Arena   // device buffer + host mirror that only grow; results of all rounds stay valid until the call returns
+// Work memory of a context: device chunks with pinned host mirrors, bump-allocated within one call and kept between calls
+// (allocating pinned memory costs milliseconds; a picture's searches need the same amount every time).
+struct Pool
 {
-    havoc_mi355x_ctx *ctx;
-    std::vector<void *> dev, host;
-    explicit Arena(havoc_mi355x_ctx *c) : ctx(c) {}
-    int get(size_t bytes, void **d, void **h)
+    struct Chunk { char *dev, *host; size_t cap, used; };
+    std::vector<Chunk> chunks;
+    void reset() { for (Chunk &c : chunks) c.used = 0; }
+    int get(havoc_mi355x_ctx *ctx, size_t bytes, void **d, void **h)
     {
+        bytes = (bytes + 255) & ~size_t(255);
+        for (Chunk &c : chunks)
+            if (c.cap - c.used >= bytes)
+            {
+                *d = c.dev + c.used;
+                *h = c.host + c.used;
+                c.used += bytes;
+                return 0;
+            }
+        Chunk c{nullptr, nullptr, std::max(bytes, size_t(64) << 20), 0};
         void *dp = nullptr, *hp = nullptr, *hd = nullptr;
-        int rc = havoc_mi355x_malloc(ctx, &dp, bytes + 256);
+        int rc = havoc_mi355x_malloc(ctx, &dp, c.cap);
         if (rc) return rc;
-        dev.push_back(dp);
-        if ((rc = havoc_mi355x_host_alloc(ctx, bytes + 256, &hp, &hd))) return rc;
-        host.push_back(hp);
-        *d = dp;
-        *h = hp;
+        if ((rc = havoc_mi355x_host_alloc(ctx, c.cap, &hp, &hd)))
+        {
+            (void)havoc_mi355x_free(ctx, dp);
+            return rc;
+        }
+        c.dev = static_cast<char *>(dp);
+        c.host = static_cast<char *>(hp);
+        c.used = bytes;
+        chunks.push_back(c);
+        *d = c.dev;
+        *h = c.host;
         return 0;
     }
-    ~Arena()
+    void release(havoc_mi355x_ctx *ctx)
     {
-        for (void *p : dev) (void)havoc_mi355x_free(ctx, p);
-        for (void *p : host) (void)havoc_mi355x_host_free(ctx, p);
+        for (Chunk &c : chunks)
+        {
+            (void)havoc_mi355x_free(ctx, c.dev);
+            (void)havoc_mi355x_host_free(ctx, c.host);
+        }
+        chunks.clear();
     }
+};
+
+std::mutex g_poolMu;
+std::map<havoc_mi355x_ctx *, Pool> g_pools;
+
+struct Arena   // one call's view of its context's pool (a context runs one call at a time: its launches share one stream)
+{
+    havoc_mi355x_ctx *ctx;
+    Pool *pool;
+    explicit Arena(havoc_mi355x_ctx *c) : ctx(c)
+    {
+        std::lock_guard<std::mutex> lock(g_poolMu);
+        pool = &g_pools[c];
+        pool->reset();
+    }
+    int get(size_t bytes, void **d, void **h) { return pool->get(ctx, bytes, d, h); }
 };
 
 #define RC(call) do { const int rc_ = (call); if (rc_) return rc_; } while (0)
@@ -392,6 +432,16 @@ int havoc_search_motion_uni(havoc_mi355x_ctx *ctx, int S, const havoc_search_par
     stt.seconds_total = now() - tStart;
     if (stats) *stats = stt;
     return 0;
+}
+
+// frees the work memory libhavoc_search keeps for a context (call before havoc_mi355x_destroy)
+void havoc_search_release(havoc_mi355x_ctx *ctx)
+{
+    std::lock_guard<std::mutex> lock(g_poolMu);
+    auto it = g_pools.find(ctx);
+    if (it == g_pools.end()) return;
+    it->second.release(ctx);
+    g_pools.erase(it);
 }
 
 const char *havoc_search_version(void) { return "havoc_search 0.1 (batch client of havoc_mi355x)"; }
