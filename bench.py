@@ -162,6 +162,8 @@ class DeviceFrame:
                 dscale, dshift = dequant_params(qp, log2, bd)
                 self.recon[(comp, log2)] = dict(jobs=up(g["jobs"]), levels=up(g["levels"]), ssd=z(len(g["jobs"]), np.uint32), n=g["n"],
                                                 dscale=dscale, dshift=dshift)
+        self.dbk_data = torch.from_numpy(np.ascontiguousarray(wl.deblock_blocks[0])).to(hv.device)
+        self.dbk_bs = torch.from_numpy(np.ascontiguousarray(wl.deblock_blocks[1])).to(hv.device)
         # pristine copy of the synthetic reference planes: what a picture WITHOUT references (the IDR of the frame-parallel
         # schedule) predicts from, whatever an earlier picture left in the store
         self.init_refs = (self.luma[wl.plane_len:3 * wl.plane_len].clone(), self.chroma[wl.cplane_len:3 * wl.cplane_len].clone())
@@ -261,6 +263,12 @@ class DeviceFrame:
                 plane, stv = (self.luma, st) if comp == "y" else (self.chroma, cst)
                 items.append(("recon", lambda g=g, log2=log2, plane=plane, stv=stv: hv.tu_reconstruct_d(
                     bd, 0, log2, g["dscale"], g["dshift"], plane, stv, plane, stv, plane, stv, g["levels"], g["jobs"], g["ssd"])))
+            # then the in-loop deblocking filter over the whole picture (turing/TaskDeblock.cpp:105-127): what a reference
+            # picture looks like when later pictures predict from it
+            pl_, cpl_ = wl.plane_len, wl.cplane_len
+            if "deblock" not in self.skip:
+                items.append(("deblock", lambda: hv.deblock_d(bd, self.luma, 3 * pl_ + 96 * st + 96, st, self.chroma, 3 * cpl_ + 48 * cst + 48,
+                                                               4 * cpl_ + 48 * cst + 48, cst, wl.width, wl.height, self.dbk_data, self.dbk_bs)))
             chain(*items)
         self.chains = chains
         return L

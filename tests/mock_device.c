@@ -138,3 +138,35 @@ int havoc_mi355x_interp_planes(havoc_mi355x_ctx *ctx, int S, int bitDepth, void 
     return 0;
 }
 
+
+/* 35-mode intra SATD stage: prediction then Hadamard tiles, per mode (what the fused kernel computes) */
+int havoc_mi355x_intra_satd35(havoc_mi355x_ctx *ctx, int S, int bitDepth, int log2, const void *src, intptr_t ss, const void *nb,
+                              const havoc_mi355x_intra_search_job *j, int n, int32_t *cost)
+{
+    (void)ctx; ++g_launches;
+    const int N = 1 << log2, ts = log2 == 2 ? 4 : 8;
+    uint16_t pred16[32 * 32];
+    for (int i = 0; i < n; ++i)
+    {
+        const unsigned long long mask = (unsigned long long)j[i].filt_lo | ((unsigned long long)j[i].filt_hi << 32);
+        for (int mode = 0; mode < 35; ++mode)
+        {
+            const long no = ((mask >> mode) & 1) ? j[i].nbf_off : j[i].nb_off;
+            oracle_intra(pred16, 32, AT(nb, no, S), log2, mode, (j[i].edge && log2 < 5) ? 1 : 0, bitDepth, S);
+            int c = 0;
+            for (int y = 0; y < N; y += ts)
+                for (int x = 0; x < N; x += ts)
+                    c += oracle_satd(AT(src, j[i].src_off + (long)y * ss + x, S), ss, (const char *)pred16 + ((long)y * 32 + x) * S, 32, ts, S);
+            cost[35 * i + mode] = c;
+        }
+    }
+    return 0;
+}
+
+int havoc_mi355x_intra(havoc_mi355x_ctx *ctx, int S, int bitDepth, int log2, void *dst, intptr_t sd, const void *nb, const havoc_mi355x_intra_job *j, int n)
+{
+    (void)ctx; ++g_launches;
+    for (int i = 0; i < n; ++i)
+        oracle_intra((char *)dst + (long)j[i].dst_off * S, sd, AT(nb, j[i].nb_off, S), log2, j[i].mode, (j[i].edge && log2 < 5) ? 1 : 0, bitDepth, S);
+    return 0;
+}

@@ -8,7 +8,6 @@
 NOT_IN_MOCK(havoc_mi355x_ssd)
 NOT_IN_MOCK(havoc_mi355x_ssd_linear)
 NOT_IN_MOCK(havoc_mi355x_pred_bi)
-NOT_IN_MOCK(havoc_mi355x_intra)
 NOT_IN_MOCK(havoc_mi355x_transform)
 NOT_IN_MOCK(havoc_mi355x_inverse_transform)
 NOT_IN_MOCK(havoc_mi355x_inverse_transform_add)

@@ -11,6 +11,7 @@
 
 #ifndef SEARCH_ORACLE
 #include "table_view.hpp"
+#include "havoc/pred_intra.h"
 #else
 #include "decision.hpp"
 #include "../oracle/havoc_oracle.h"
@@ -169,6 +170,46 @@ void runBi(const Sample *src, intptr_t ss, const Sample *ref, const Sample *refO
 
 } // namespace
 
+// the 35-mode luma SATD stage of n partitions of one size, one block at a time as PredictIntraLumaBlock does (turing/Reconstruct.cpp:630-701):
+// predict into a 32-stride block, then 8x8 (4x4) Hadamard tiles against the source.  jobs = havoc_mi355x_intra_search_job rows.
+#ifndef SEARCH_ORACLE
+namespace {
+havoc::intra::Table<uint8_t> g_i8;
+havoc::intra::Table<uint16_t> g_i16;
+bool g_intraReady = false;
+template <typename Sample> havoc::intra::Table<Sample> &intraTable();
+template <> havoc::intra::Table<uint8_t> &intraTable<uint8_t>() { return g_i8; }
+template <> havoc::intra::Table<uint16_t> &intraTable<uint16_t>() { return g_i16; }
+}
+#endif
+template <typename Sample>
+static void runIntra35(int bitDepth, int log2, const Sample *src, intptr_t ss, const Sample *nb, const int32_t *jobs, int n, int32_t *satd35)
+{
+    const int N = 1 << log2, ts = log2 == 2 ? 4 : 8;
+    HAVOC_ALIGN(32, Sample, pred[32 * 32]);
+    for (int i = 0; i < n; ++i)
+    {
+        const int32_t *j = jobs + 8 * i;
+        const uint64_t mask = (uint64_t)(uint32_t)j[3] | ((uint64_t)(uint32_t)j[4] << 32);
+        for (int mode = 0; mode < 35; ++mode)
+        {
+            const Sample *neigh = nb + (((mask >> mode) & 1) ? j[2] : j[1]);
+            int c = 0;
+#ifndef SEARCH_ORACLE
+            intraTable<Sample>().lookup(j[5] ? 0 : 1, bitDepth, log2, mode)(pred, 32, neigh, mode);
+            auto satd = *havoc_get_hadamard_satd<Sample>(&tables<Sample>().satd, log2 == 2 ? 2 : 3);
+            for (int y = 0; y < N; y += ts)
+                for (int x = 0; x < N; x += ts) c += satd(src + j[0] + y * ss + x, ss, pred + y * 32 + x, 32);
+#else
+            oracle_intra(pred, 32, neigh, log2, mode, (j[5] && log2 < 5) ? 1 : 0, bitDepth, sizeof(Sample));
+            for (int y = 0; y < N; y += ts)
+                for (int x = 0; x < N; x += ts) c += oracle_satd(src + j[0] + y * ss + x, ss, pred + y * 32 + x, 32, ts, sizeof(Sample));
+#endif
+            satd35[35 * i + mode] = c;
+        }
+    }
+}
+
 extern "C" {
 
 // mask: the reference library honours it (HAVOC_C_REF | HAVOC_C_OPT = 3: plain C tables; -1: everything the CPU supports = JIT)
@@ -206,6 +247,22 @@ int client_bi(int S, const void *src, intptr_t ss, const void *ref, const void *
     if (!g_open) return -1;
     if (S == 1) runBi<uint8_t>((const uint8_t *)src, ss, (const uint8_t *)ref, (const uint8_t *)refOther, rs, *p, pus, start, b, e, out);
     else runBi<uint16_t>((const uint16_t *)src, ss, (const uint16_t *)ref, (const uint16_t *)refOther, rs, *p, pus, start, b, e, out);
+    return 0;
+}
+
+int client_intra35(int S, int bitDepth, int log2, const void *src, intptr_t ss, const void *nb, const int32_t *jobs, int n, int32_t *satd35)
+{
+    if (!g_open) return -1;
+#ifndef SEARCH_ORACLE
+    if (!g_intraReady)
+    {
+        g_i8.populate(g_code);
+        g_i16.populate(g_code);
+        g_intraReady = true;
+    }
+#endif
+    if (S == 1) runIntra35<uint8_t>(bitDepth, log2, (const uint8_t *)src, ss, (const uint8_t *)nb, jobs, n, satd35);
+    else runIntra35<uint16_t>(bitDepth, log2, (const uint16_t *)src, ss, (const uint16_t *)nb, jobs, n, satd35);
     return 0;
 }
 

@@ -66,7 +66,7 @@ def main():
     ap.add_argument("--bi", type=int, default=40)
     ap.add_argument("--seed", type=int, default=3)
     ap.add_argument("--threads", type=int, default=8)
-    ap.add_argument("--skip", default="", help="comma list of: classic, batch")
+    ap.add_argument("--skip", default="", help="comma list of: classic, batch, intra")
     args = ap.parse_args()
     W, H = (int(v) for v in args.res.split("x"))
     S = 1 if args.bit_depth == 8 else 2
@@ -204,6 +204,52 @@ def main():
             "launches_per_search": round(tot("launches") / len(pus), 4), "threads": args.threads,
             "max_replays_of_one_search": int(got["replays"].max()),
         }
+    # ---- 35-mode intra stage (Search.hpp:40-190): per-call through the reference tables vs one fused launch + host ordering
+    if "intra" not in skip:
+        from turingcodec_amd.workload import FrameWorkload
+        wl = FrameWorkload(W, H, args.bit_depth, args.seed + 9)
+        rsl = st.reciprocal_sqrt_lambda(32)
+        src = aligned(wl.luma)
+        intra = {"partitions": 0, "mismatching": [], "seconds_batch": 0.0, "seconds_reference": 0.0}
+        if "batch" not in skip:
+            vp, ip = C.c_void_p, C.c_ssize_t
+            L.havoc_search_intra_modes.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, ip, vp, vp, C.c_int, vp, C.c_double, vp, vp]
+            dsrc = vp()
+            assert dev.havoc_mi355x_malloc(ctx, C.byref(dsrc), src.nbytes + 256) == 0
+            assert dev.havoc_mi355x_h2d(ctx, dsrc, src.ctypes.data, src.nbytes) == 0
+        for log2 in (2, 3, 4, 5):
+            jobs = np.ascontiguousarray(wl.intra_search[log2][:160 if W < 1000 else 4000])
+            nb = aligned(wl.intra_search_nb[log2])
+            n = len(jobs)
+            if not n:
+                continue
+            ictx = st.make_intra_contexts(n, log2, args.seed + log2)
+            t0 = time.perf_counter()
+            satd_ref = ref.intra35(args.bit_depth, log2, src, wl.stride, nb, jobs)
+            exp = ref.intra_order(ictx, rsl, satd_ref)
+            intra["seconds_reference"] += time.perf_counter() - t0
+            intra["partitions"] += n
+            if "batch" not in skip:
+                dnb, djobs = vp(), vp()
+                assert dev.havoc_mi355x_malloc(ctx, C.byref(dnb), nb.nbytes + 256) == 0 and dev.havoc_mi355x_malloc(ctx, C.byref(djobs), jobs.nbytes + 256) == 0
+                assert dev.havoc_mi355x_h2d(ctx, dnb, nb.ctypes.data, nb.nbytes) == 0 and dev.havoc_mi355x_h2d(ctx, djobs, jobs.ctypes.data, jobs.nbytes) == 0
+                out = np.zeros(n, st.INTRA_RESULT_DT)
+                satd = np.zeros((n, 35), np.int32)
+                t0 = time.perf_counter()
+                rc = L.havoc_search_intra_modes(ctx, S, args.bit_depth, log2, dsrc, wl.stride, dnb, djobs, n, ictx.ctypes.data, rsl, out.ctypes.data, satd.ctypes.data)
+                intra["seconds_batch"] += time.perf_counter() - t0
+                assert rc == 0, rc
+                if not (np.array_equal(satd, satd_ref) and out.tobytes() == exp.tobytes()):
+                    intra["mismatching"].append(log2)
+            if "classic" not in skip and log2 == 3:
+                few = 4      # the table API has no batched intra entry: 35 x (1 + tiles) one-job launches per partition
+                got = cl.intra35(args.bit_depth, log2, src, wl.stride, nb, jobs[:few])
+                if not np.array_equal(got, satd_ref[:few]):
+                    intra["mismatching"].append("classic")
+        intra["seconds_batch"] = round(intra["seconds_batch"], 4)
+        intra["seconds_reference"] = round(intra["seconds_reference"], 4)
+        intra["mode_decisions_per_second_batch"] = round(intra["partitions"] / max(1e-9, intra["seconds_batch"]), 1) if "batch" not in skip else None
+        report["intra"] = intra
     print(json.dumps(report))
 
 

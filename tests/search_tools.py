@@ -91,6 +91,7 @@ class Client:
         L.client_uni.argtypes = [i, vp, ip, vp, ip, C.POINTER(Params), vp, i, i, vp]
         L.client_bi.argtypes = [i, vp, ip, vp, vp, ip, C.POINTER(Params), vp, vp, i, i, vp]
         L.client_intra_order.argtypes = [vp, C.c_double, vp, i, vp]
+        L.client_intra35.argtypes = [i, i, i, vp, ip, vp, vp, i, vp]
         if kind == "classic":
             L.client_register.argtypes = [vp, ip, i, i, i, i, i, i]
             L.client_unregister.argtypes = [vp]
@@ -116,6 +117,13 @@ class Client:
         rc = self.L.client_bi(src.itemsize, self._origin(src, stride, pad), stride, self._origin(ref, stride, pad), self._origin(ref_other, stride, pad),
                               stride, C.byref(params), pus.ctypes.data, start.ctypes.data, 0, len(pus), out.ctypes.data)
         assert rc == 0
+        return out
+
+    def intra35(self, bit_depth, log2, src, stride, nb, jobs):
+        """per-call 35-mode SATD stage; src = flat plane array addressed by the jobs' src_off, jobs int32 [n, 8]"""
+        jobs = np.ascontiguousarray(jobs, np.int32)
+        out = np.zeros((len(jobs), 35), np.int32)
+        assert self.L.client_intra35(src.itemsize, bit_depth, log2, src.ctypes.data, stride, nb.ctypes.data, jobs.ctypes.data, len(jobs), out.ctypes.data) == 0
         return out
 
     def intra_order(self, ctx, rsl, satd35):
@@ -182,3 +190,16 @@ def clip_planes(width, height, seed, bit_depth=8, pad=96):
     planes = [pad_plane(f[0], pad) for f in (frames[1], frames[0], frames[2])]
     stride = planes[0].shape[1]
     return [np.ascontiguousarray(p.ravel()) for p in planes], stride
+
+
+def make_intra_contexts(n, log2, seed):
+    """per-partition state of the 35-mode stage: most probable modes, rate offsets (Search.hpp:55-87), refinement count at medium"""
+    rng = np.random.default_rng(seed)
+    ctx = np.zeros(n, INTRA_CTX_DT)
+    for i in range(n):
+        ctx[i]["cand_mode_list"] = rng.choice(35, 3, replace=False)
+        ctx[i]["neighbour_modes"] = 3
+        ctx[i]["max_refine"] = 3 if log2 > 3 else 8      # Speed::nCandidatesIntraRefinement at medium
+        ctx[i]["rate_a_minus_c"] = -int(rng.integers(300000, 420000))
+        ctx[i]["rate_b_minus_c"] = -int(rng.integers(100000, 200000))
+    return ctx

@@ -137,6 +137,8 @@ def _check_report(r, searches):
     assert c["unregistered"]["launches"] == c["unregistered"]["table_calls"] > 0
     # the batch client needs a handful of launches for the whole picture, not per search
     assert b["launches"] <= 8 * b["rounds"] and b["launches_per_search"] < 0.5, b
+    # 35-mode intra stage: same distortions, costs and refinement order as the per-call loop through the reference tables
+    assert r["intra"]["mismatching"] == [] and r["intra"]["partitions"] > 100, r["intra"]
 
 
 @needs_ref

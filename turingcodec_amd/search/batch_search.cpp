@@ -434,6 +434,42 @@ int havoc_search_motion_uni(havoc_mi355x_ctx *ctx, int S, const havoc_search_par
     return 0;
 }
 
+// The 35-mode luma stage of n intra partitions of one size (searchIntraPartition, turing/Search.hpp:40-190): one
+// havoc_mi355x_intra_satd35 launch gives every partition's 35 prediction + SATD costs, then the host applies the rate
+// offsets and takes the modes in the order the reference would refine them.  d_jobs / d_neighbours as for
+// havoc_mi355x_intra_satd35; ictx[i] = the partition's most probable modes and rates.  satd35 (optional, host, n * 35)
+// receives the raw distortions.
+int havoc_search_intra_modes(havoc_mi355x_ctx *ctx, int S, int bitDepth, int log2TrafoSize, const void *d_src, intptr_t stride_src,
+                             const void *d_neighbours, const havoc_mi355x_intra_search_job *d_jobs, int n, const havoc_search_intra_ctx *ictx,
+                             double reciprocal_sqrt_lambda, havoc_search_intra_result *out, int32_t *satd35)
+{
+    if (!ctx || !ictx || !out || n < 0) return HAVOC_MI355X_EINVAL;
+    if (n == 0) return 0;
+    Arena arena(ctx);
+    void *dCost, *hCost;
+    RC(arena.get(size_t(n) * 35 * 4, &dCost, &hCost));
+    RC(havoc_mi355x_intra_satd35(ctx, S, bitDepth, log2TrafoSize, d_src, stride_src, d_neighbours, d_jobs, n, static_cast<int32_t *>(dCost)));
+    RC(havoc_mi355x_d2h_async(ctx, hCost, dCost, size_t(n) * 35 * 4));
+    RC(havoc_mi355x_sync(ctx));
+    const int32_t *cost = static_cast<const int32_t *>(hCost);
+    if (satd35) std::memcpy(satd35, cost, size_t(n) * 35 * 4);
+    for (int i = 0; i < n; ++i)
+    {
+        IntraContext ic;
+        for (int k = 0; k < 3; ++k) ic.candModeList[k] = ictx[i].cand_mode_list[k];
+        ic.neighbourModes = ictx[i].neighbour_modes;
+        ic.maxRefine = ictx[i].max_refine;
+        ic.rateAminusC = ictx[i].rate_a_minus_c;
+        ic.rateBminusC = ictx[i].rate_b_minus_c;
+        const IntraResult r = intraModeOrder(ic, reciprocal_sqrt_lambda, cost + 35 * i);
+        std::memset(&out[i], 0, sizeof(out[i]));
+        for (int m = 0; m < 35; ++m) out[i].costs[m] = r.costs[m];
+        for (int m = 0; m < r.count; ++m) out[i].order[m] = r.order[m];
+        out[i].count = r.count;
+    }
+    return 0;
+}
+
 // frees the work memory libhavoc_search keeps for a context (call before havoc_mi355x_destroy)
 void havoc_search_release(havoc_mi355x_ctx *ctx)
 {

@@ -424,6 +424,20 @@ class FrameWorkload:
                       "cb": tiling(W // 2, H // 2, 16, 4, self.cstride, self.cplane_len, PAD // 2, 1, 3),
                       "cr": tiling(W // 2, H // 2, 16, 4, self.cstride, self.cplane_len, PAD // 2, 2, 4)}
 
+        # ---- deblocking of the reconstructed picture (turing/LoopFilter.h:52-91 Block grid): QpY = the slice QP, boundary
+        # strength 2 on a fifth of the 8x8 edges (intra neighbours), 1 on two fifths (transform edges with coefficients /
+        # different motion), none on the picture boundary; a few filter-disabled regions
+        bw_, bh_ = (W + 63) // 64 * 8 + 1, (H + 63) // 64 * 8 + 1
+        data_ = ((np.full((bh_, bw_), qp, np.int32) << 1) | (rng.random((bh_, bw_)) < 0.01)).astype(np.int8)
+        bs_ = np.zeros((bh_, bw_), np.uint8)
+        for k in range(4):
+            u_ = rng.random((bh_, bw_))
+            v_ = np.where(u_ < 0.2, 2, np.where(u_ < 0.6, 1, 0))
+            bs_ |= (v_ << (2 * k)).astype(np.uint8)
+        bs_[:, 0] &= 0xF0
+        bs_[0, :] &= 0x0F
+        self.deblock_blocks = (data_.ravel(), bs_.ravel())
+
     # ---- algorithmic bytes (SURVEY.md 8(d) "per primitive call": operands read once + results written once) ----
     def algorithmic_bytes(self):
         S = self.S
@@ -470,4 +484,5 @@ class FrameWorkload:
         b["ssd"] = sum(int((2 * wh(g["ssd"], 2, 3) * S + 4).sum()) for g in self.tu.values())
         b["recon"] = sum(len(g["jobs"]) * g["n"] ** 2 for t in self.recon.values() for g in t.values()) * (2 + 3 * S)
         b["quantize"] = 4 * tot
+        b["deblock"] = 2 * int(self.width * self.height * 1.5) * S * 2   # two passes, each reads and writes the picture once
         return b
