@@ -71,6 +71,15 @@ void oracle_deblock(void *luma, intptr_t stride_y, void *cb, void *cr, intptr_t 
 /* turing/Measure.h:97-135 (measureSatd): PU SATD tiled in 8x8 / 4x4 / 2x2 Hadamards */
 int oracle_pu_satd(const void *a, intptr_t stride_a, const void *b, intptr_t stride_b, int w, int h, int S);
 
+/* turing/Rdoq.cpp:37-454 + Rdoq.h:163-187 (oracle/rdoq_oracle.c): rate-distortion optimised quantisation of one transform block.
+ * `states` = 128 bytes of CABAC probability states in the layout of include/havoc_mi355x.h (HAVOC_RDOQ_CTX_*); lambdaQ16 / sdhFactor
+ * from oracle_rdoq_lambda.  Returns the OR of the kept absolute levels. */
+int oracle_rdoq(int16_t *dst, const int16_t *src, int log2Size, int cIdx, int scanIdx, int isIntra, int sdh, int quantScale, int quantShift,
+                int invScale, int bitDepth, int32_t lambdaQ16, int32_t sdhFactor, const uint8_t *states);
+void oracle_rdoq_lambda(double lambda, int invQuantScale, int32_t *lambdaQ16, int32_t *sdhFactor);
+/* turing/ScanOrder.h:212-223 */
+int oracle_scan_order(int log2BlockSize, int scanIdx, int sPos, int sComp);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,8 +37,8 @@ def _S(a):
 
 class Oracle:
     def __init__(self):
-        if not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(
-                os.path.join(ROOT, "oracle", "havoc_oracle.c")):
+        if not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < max(
+                os.path.getmtime(os.path.join(ROOT, "oracle", f)) for f in ("havoc_oracle.c", "rdoq_oracle.c", "havoc_oracle.h")):
             build_oracle()
         L = self.L = C.CDLL(ORACLE_SO)
         L.oracle_sad.restype = C.c_int
@@ -80,6 +80,29 @@ class Oracle:
 
         L.oracle_deblock.restype = None
         L.oracle_deblock.argtypes = [_vp, _ip, _vp, _vp, _ip, C.c_int, C.c_int, C.c_int, _vp, _vp] + [C.c_int] * 5
+
+        L.oracle_rdoq.restype = C.c_int
+        L.oracle_rdoq.argtypes = [_vp, _vp] + [C.c_int] * 11 + [_vp]
+        L.oracle_rdoq_lambda.restype = None
+        L.oracle_rdoq_lambda.argtypes = [C.c_double, C.c_int, _vp, _vp]
+        L.oracle_scan_order.restype = C.c_int
+        L.oracle_scan_order.argtypes = [C.c_int] * 4
+
+    def rdoq_lambda(self, lam, inv_scale):
+        """(lambda in Q16, sign-data-hiding factor) as the reference's Rdoq constructor derives them from the double"""
+        out = np.zeros(2, np.int32)
+        self.L.oracle_rdoq_lambda(lam, inv_scale, _addr(out, 0), _addr(out, 1))
+        return int(out[0]), int(out[1])
+
+    def rdoq(self, src, log2, c_idx, scan_idx, is_intra, sdh, q_scale, q_shift, inv_scale, bd, lam, states):
+        """-> (levels int16[n], OR of kept absolute levels)"""
+        dst = np.zeros(1 << 2 * log2, np.int16)
+        lq, sf = self.rdoq_lambda(lam, inv_scale)
+        r = self.L.oracle_rdoq(_addr(dst), _addr(src), log2, c_idx, scan_idx, int(is_intra), int(sdh), q_scale, q_shift, inv_scale, bd, lq, sf, _addr(states))
+        return dst, r
+
+    def scan_order(self, log2, scan_idx, pos, comp):
+        return self.L.oracle_scan_order(log2, scan_idx, pos, comp)
 
     def deblock(self, luma, sy, cb, cr, sc, width, height, bd, data, bs, tc2=0, beta2=0, cb_qp=0, cr_qp=0):
         """in place on the three planes (numpy arrays whose element 0 is sample (0, 0))"""
@@ -211,6 +234,30 @@ class Reference:
 
     def _f(self, name, a):
         return getattr(self.L, name + "_" + self._sfx(a))
+
+    def rdoq(self, src, log2, c_idx, scan_idx, is_intra, sdh, q_scale, q_shift, inv_scale, bd, lam, states):
+        """the reference's own Rdoq::runQuantisation (oracle/ref_shim_rdoq.cpp) -> (levels int16[n], return value)"""
+        f = self.L.ref_rdoq
+        f.restype = C.c_int
+        f.argtypes = [_vp, _vp] + [C.c_int] * 9 + [C.c_double, _vp]
+        dst = np.zeros(1 << 2 * log2, np.int16)
+        r = f(_addr(dst), _addr(src), log2, c_idx, scan_idx, int(is_intra), int(sdh), q_scale, q_shift, inv_scale, bd, float(lam), _addr(states))
+        return dst, r
+
+    def rdoq_initial_states(self, qp, init_type):
+        """the 128-byte state snapshot a slice of that QP / initType starts from (Contexts::initialize)"""
+        f = self.L.ref_rdoq_initial_states
+        f.restype = None
+        f.argtypes = [C.c_int, C.c_int, _vp]
+        out = np.zeros(128, np.uint8)
+        f(qp, init_type, _addr(out))
+        return out
+
+    def scan_order(self, log2, scan_idx, pos, comp):
+        f = self.L.ref_scan_order
+        f.restype = C.c_int
+        f.argtypes = [C.c_int] * 4
+        return f(log2, scan_idx, pos, comp)
 
     def mask(self):
         return self.L.ref_mask(self.h)
