@@ -376,6 +376,41 @@ int havoc_mi355x_quantize_reconstruct(havoc_mi355x_ctx *ctx, int log2TrafoSize, 
                                       const uint8_t *d_pred, intptr_t stride_pred, const int16_t *d_res,
                                       const havoc_mi355x_tu_job *d_jobs, int njobs);
 
+/* ------------------------------------------------------------------------------------------------------- */
+/* rate-distortion optimised quantisation                                                 */
+/* ------------------------------------------------------------------------------------------------------- */
+/* Rdoq::runQuantisation (turing/Rdoq.cpp:37-454), the quantiser the reference's speed=medium uses between the forward
+ * transform and the reconstruction (turing/Reconstruct.cpp:289-312 intra, :794-812 inter).  One job = one transform block of
+ * the launch's size.  The CABAC probability states are read, never updated, so the entropy coder is a frozen snapshot of
+ * state bytes (ContextModel::state, turing/ContextModel.h:29-31) in this layout, 128 bytes per snapshot: */
+enum {
+    HAVOC_RDOQ_CTX_ROOT_CBF = 0,   /* rqt_root_cbf [1] */
+    HAVOC_RDOQ_CTX_CBF_LUMA = 1,   /* cbf_luma [2] */
+    HAVOC_RDOQ_CTX_CBF_CHROMA = 3, /* cbf_cb / cbf_cr [4] */
+    HAVOC_RDOQ_CTX_LAST_X = 8,     /* last_sig_coeff_x_prefix [18] */
+    HAVOC_RDOQ_CTX_LAST_Y = 26,    /* last_sig_coeff_y_prefix [18] */
+    HAVOC_RDOQ_CTX_CSBF = 44,      /* coded_sub_block_flag [4] */
+    HAVOC_RDOQ_CTX_SIG = 48,       /* sig_coeff_flag [44] */
+    HAVOC_RDOQ_CTX_GREATER1 = 92,  /* coeff_abs_level_greater1_flag [24] */
+    HAVOC_RDOQ_CTX_GREATER2 = 116, /* coeff_abs_level_greater2_flag [6] */
+    HAVOC_RDOQ_CTX_BYTES = 128
+};
+typedef struct {
+    int32_t dst_off, src_off;          /* n*n contiguous int16 levels (out) / coefficients (in) */
+    int32_t quant_scale, quant_shift;  /* runQuantisation's quantiserScale / quantiserShift */
+    int32_t inv_scale;                 /* the constructor's invQuantScale */
+    int32_t lambda_q16, sdh_factor;    /* from havoc_mi355x_rdoq_lambda */
+    int32_t ctx_index;                 /* which 128-byte snapshot of d_states */
+    uint8_t c_idx, scan_idx;           /* rc.cIdx (0..2), scanIdx (0 diagonal, 1 horizontal, 2 vertical) */
+    uint8_t is_intra, sdh;             /* isIntra, isSdhEnabled */
+    int32_t reserved[3];
+} havoc_mi355x_rdoq_job; /* 48 bytes */
+/* the two integers the Rdoq constructor derives from the floating-point lambda (turing/Rdoq.h:163-167); host-side, no device work */
+void havoc_mi355x_rdoq_lambda(double lambda, int inv_scale, int32_t *lambda_q16, int32_t *sdh_factor);
+/* d_cbf[i] = runQuantisation's return value (OR of the kept absolute levels) */
+int havoc_mi355x_rdoq(havoc_mi355x_ctx *ctx, int bitDepth, int log2TrafoSize, int16_t *d_dst, const int16_t *d_src, const uint8_t *d_states,
+                      const havoc_mi355x_rdoq_job *d_jobs, int njobs, int32_t *d_cbf);
+
 #ifdef __cplusplus
 }
 #endif

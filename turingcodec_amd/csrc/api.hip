@@ -29,6 +29,7 @@ hipError_t launch_tu_forward(hipStream_t, int S, int bd, int log2, int tr, int16
 hipError_t launch_tu_reconstruct(hipStream_t, int S, int bd, int log2, int tr, int scale, int shift, void *, long, const void *, long, const void *,
                                  long, const int16_t *, const void *, int, uint32_t *);
 hipError_t launch_quantize(hipStream_t, int16_t *, const int16_t *, const void *, int, int32_t *);
+hipError_t launch_rdoq(hipStream_t, int bd, int log2, int16_t *, const int16_t *, const uint8_t *, const void *, int, int32_t *);
 hipError_t launch_quantize_inverse(hipStream_t, int16_t *, const int16_t *, const void *, int);
 hipError_t launch_quantize_reconstruct(hipStream_t, int log2, uint8_t *, long, const uint8_t *, long, const int16_t *, const void *, int);
 hipError_t launch_residual(hipStream_t, int S, int16_t *, long, const int32_t *, const void *, long, const void *, long, const void *, int);
@@ -503,6 +504,22 @@ int havoc_mi355x_quantize_reconstruct(havoc_mi355x_ctx *ctx, int log2TrafoSize, 
     REQUIRE_CTX(); REQUIRE(log2TrafoSize >= 2 && log2TrafoSize <= 5, "log2TrafoSize must be 2..5"); REQUIRE(njobs >= 0, "njobs < 0");
     return check(launch_quantize_reconstruct(LS(ctx),log2TrafoSize, d_rec, stride_rec, d_pred, stride_pred, d_res, d_jobs, njobs),
                  "quantize_reconstruct");
+}
+
+// the two integers turing/Rdoq.h:163-167 derives from the floating-point lambda: FixedPoint<int32_t, 16>::set(double)
+// (turing/FixedPoint.h:47-50) and m_shdRdFactor
+void havoc_mi355x_rdoq_lambda(double lambda, int inv_scale, int32_t *lambda_q16, int32_t *sdh_factor)
+{
+    if (lambda_q16) *lambda_q16 = static_cast<int32_t>(lambda * (1 << 16) + 0.5);
+    if (sdh_factor) *sdh_factor = (int)(inv_scale * inv_scale / lambda / 16 + 0.5);
+}
+
+int havoc_mi355x_rdoq(havoc_mi355x_ctx *ctx, int bitDepth, int log2TrafoSize, int16_t *d_dst, const int16_t *d_src, const uint8_t *d_states,
+                      const havoc_mi355x_rdoq_job *d_jobs, int njobs, int32_t *d_cbf)
+{
+    REQUIRE_CTX(); REQUIRE(log2TrafoSize >= 2 && log2TrafoSize <= 5, "log2TrafoSize must be 2..5"); REQUIRE(njobs >= 0, "njobs < 0");
+    REQUIRE(bitDepth >= 8 && bitDepth <= 12, "bitDepth must be 8..12");
+    return check(launch_rdoq(LS(ctx), bitDepth, log2TrafoSize, d_dst, d_src, d_states, d_jobs, njobs, d_cbf), "rdoq");
 }
 
 } // extern "C"

@@ -92,7 +92,10 @@ def _load():
         "quantize": [_vp, _vp, _vp, _vp, _i, _vp],
         "quantize_inverse": [_vp, _vp, _vp, _vp, _i],
         "quantize_reconstruct": [_vp, _i, _vp, _ip, _vp, _ip, _vp, _vp, _i],
+        "rdoq": [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp],
     }
+    L.havoc_mi355x_rdoq_lambda.argtypes = [C.c_double, _i, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.havoc_mi355x_rdoq_lambda.restype = None
     for name, args in sig.items():
         f = getattr(L, "havoc_mi355x_" + name)
         f.argtypes = args
@@ -103,7 +106,22 @@ def _load():
 def exported_symbols():
     """names the C ABI must export (checked against include/havoc_mi355x.h by the CPU tests)"""
     _, names = _load()
-    return ["havoc_mi355x_" + n for n in names] + ["havoc_mi355x_last_error", "havoc_mi355x_version"]
+    return ["havoc_mi355x_" + n for n in names] + ["havoc_mi355x_last_error", "havoc_mi355x_version", "havoc_mi355x_rdoq_lambda"]
+
+
+# one havoc_mi355x_rdoq_job (include/havoc_mi355x.h), 48 bytes
+RDOQ_JOB_DT = np.dtype([("dst_off", "<i4"), ("src_off", "<i4"), ("quant_scale", "<i4"), ("quant_shift", "<i4"), ("inv_scale", "<i4"),
+                        ("lambda_q16", "<i4"), ("sdh_factor", "<i4"), ("ctx_index", "<i4"), ("c_idx", "u1"), ("scan_idx", "u1"),
+                        ("is_intra", "u1"), ("sdh", "u1"), ("reserved", "<i4", 3)])
+assert RDOQ_JOB_DT.itemsize == 48
+
+
+def rdoq_lambda(lam, inv_scale):
+    """(lambda_q16, sdh_factor) of a job, as the reference's Rdoq constructor derives them (turing/Rdoq.h:163-167)"""
+    L, _ = _load()
+    a, b = C.c_int32(), C.c_int32()
+    L.havoc_mi355x_rdoq_lambda(float(lam), int(inv_scale), C.byref(a), C.byref(b))
+    return a.value, b.value
 
 
 def _ptr(t):
@@ -368,6 +386,21 @@ class Havoc:
 
     def quantize_reconstruct_d(self, log2, rec, sr, pred, sp, res, jobs):
         self._ck(self.L.havoc_mi355x_quantize_reconstruct(self.h, log2, _ptr(rec), sr, _ptr(pred), sp, _ptr(res), _ptr(jobs), jobs.shape[0]))
+
+    def rdoq_d(self, bd, log2, dst, src, states, jobs, cbf):
+        """jobs: uint8 tensor holding RDOQ_JOB_DT records; states: uint8 tensor of 128-byte snapshots"""
+        self._ck(self.L.havoc_mi355x_rdoq(self.h, bd, log2, _ptr(dst), _ptr(src), _ptr(states), _ptr(jobs), jobs.numel() // RDOQ_JOB_DT.itemsize, _ptr(cbf)))
+
+    def rdoq(self, bd, log2, src, states, jobs):
+        """numpy level: src int16 (all blocks), states uint8 [k, 128], jobs RDOQ_JOB_DT array -> (levels int16 like src, cbf int32[njobs])"""
+        jobs = np.ascontiguousarray(jobs, RDOQ_JOB_DT)
+        dst = self.zeros(len(src), np.int16)
+        cbf = self.zeros(len(jobs), np.int32)
+        with self.torch.cuda.stream(self.tstream):
+            st = self.torch.from_numpy(np.ascontiguousarray(states, np.uint8).reshape(-1)).to(self.device)
+            j = self.torch.from_numpy(jobs.view(np.uint8).reshape(-1)).to(self.device)
+        self.rdoq_d(bd, log2, dst, self.up(src), st, j, cbf)
+        return self.down(dst, np.int16), self.down(cbf, np.int32)
 
     def ssd_linear_d(self, a, b, n, out):
         self._ck(self.L.havoc_mi355x_ssd_linear(self.h, _ptr(a), _ptr(b), n, _ptr(out)))
