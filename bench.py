@@ -35,6 +35,8 @@ def parse_args():
     ap.add_argument("--res", default="1920x1080")
     ap.add_argument("--bit-depth", type=int, default=8)
     ap.add_argument("--seed", type=int, default=11)
+    ap.add_argument("--rdoq", type=int, default=1, help="random-access mix: 1 = Rdoq::runQuantisation on the device between tu_forward and "
+                    "tu_reconstruct (speed=medium has RDOQ on); 0 = round 1's step: levels made once, untimed, by havoc_quantize")
     ap.add_argument("--qp", type=int, default=32, help="slice QP: the (de)quantiser scale / shift of the TU chain (turing/QpState.h:85-94)")
     ap.add_argument("--mix", choices=["ra", "ai"], default="ra",
                     help="call mix: one random-access B-frame at speed=medium (default) or one all-intra frame at speed=fast "
@@ -85,8 +87,10 @@ def parse_args():
 class DeviceFrame:
     """A FrameWorkload uploaded to HBM + the list of launches that make one step."""
 
-    def __init__(self, hv, wl, use_planes=True, fused_tu=True, ime_range=None, skip=()):
+    def __init__(self, hv, wl, use_planes=True, fused_tu=True, ime_range=None, skip=(), rdoq=True):
         import torch
+        from turingcodec_amd import havoc as _havoc
+        self.rdoq = bool(rdoq) and wl.mix == "ra"
         self.skip = set(skip)   # diagnostic only: launch groups left out of the step (marginal-cost measurements)
         self.hv, self.wl, self.use_planes, self.fused_tu, self.ime_range = hv, wl, use_planes, fused_tu, ime_range
         up = hv.up
@@ -155,6 +159,10 @@ class DeviceFrame:
             fj[:, 1] = g["src"][:, 0]          # havoc_mi355x_tu_fused_job: coef_off, src_off, pred_off, rec_off
             extra = g["ssd"][m:]
             self.tu[(log2, tr)].update(fjobs=up(fj), jssd_x=up(extra) if len(extra) else None, ossd_x=z(max(1, len(extra)), np.uint32))
+            if self.rdoq:
+                rj = wl.rdoq_jobs((log2, tr), _havoc.rdoq_lambda(wl.rdoq_lambda, dscale))
+                self.tu[(log2, tr)]["rjobs"] = torch.from_numpy(rj.view(np.uint8).reshape(-1)).to(hv.device)
+        self.rdoq_states = torch.from_numpy(np.ascontiguousarray(wl.rdoq_states).reshape(-1)).to(hv.device)
         # final reconstruction pass of the picture (workload.recon): what later pictures predict from
         self.recon = {}
         for comp, tabs in wl.recon.items():
@@ -169,14 +177,14 @@ class DeviceFrame:
         self.init_refs = (self.luma[wl.plane_len:3 * wl.plane_len].clone(), self.chroma[wl.cplane_len:3 * wl.cplane_len].clone())
         self.launches = self._make_launches()
         torch.cuda.synchronize()   # every upload / fill above has landed, whatever stream it ran on, before the first launch
-        # levels for the timed de-quantiser: run residual -> forward T -> havoc_quantize once, untimed (at medium the
-        # reference quantises with RDOQ on the host; the hot path sees its output levels).  In the all-intra speed=fast
-        # mix havoc_quantize is part of the timed chain instead.
-        for name, fn in self.launches:
-            if name.startswith(("residual", "transform", "tu_forward")):
-                fn()
-        for g in self.tu.values():
-            hv.quantize_d(g["level"], g["coef"], g["qjobs"], g["cbf"])
+        # --rdoq 0 (round 1's step): levels for the timed de-quantiser from residual -> forward T -> havoc_quantize once,
+        # untimed.  Default: Rdoq::runQuantisation is in the timed chain (havoc_quantize in the all-intra speed=fast mix).
+        if not self.rdoq:
+            for name, fn in self.launches:
+                if name.startswith(("residual", "transform", "tu_forward")):
+                    fn()
+            for g in self.tu.values():
+                hv.quantize_d(g["level"], g["coef"], g["qjobs"], g["cbf"])
         hv.sync()
 
     def _make_launches(self):
@@ -235,8 +243,9 @@ class DeviceFrame:
             chain(("intra", lambda g=g, log2=log2, n=n: hv.intra_d(bd, log2, g["dst"], n, g["nb"], g["jobs"])))
         for (log2, tr), g in sorted(self.tu.items(), reverse=True):
             n = g["n"]
-            # forward half and reconstruction half of the TU chain are independent here: the levels between them come
-            # from the host's RDOQ in the reference (pre-computed, untimed, in __init__)
+            # speed=medium: tu_forward -> Rdoq::runQuantisation -> tu_reconstruct, one dependent chain on the device.  With
+            # --rdoq 0 the two halves are independent (levels pre-computed, untimed, in __init__)
+            rdq = ("rdoq", lambda g=g, log2=log2: hv.rdoq_d(bd, log2, g["level"], g["coef"], self.rdoq_states, g["rjobs"], g["cbf"]))
             if self.fused_tu:
                 # residual + forward transform in one kernel; de-quant + inverse transform + add + SSD in another
                 fwd = ("tu_forward", lambda g=g, log2=log2, tr=tr: hv.tu_forward_d(bd, tr, log2, g["coef"], self.luma, st, self.luma, st, g["fjobs"]))
@@ -244,18 +253,25 @@ class DeviceFrame:
                     bd, tr, log2, g["dscale"], g["dshift"], g["rec"], n, self.luma, st, self.luma, st, g["level"], g["fjobs"], g["ossd"]))]
                 if g["jssd_x"] is not None:   # the reference makes ~1.26 SSD calls per TU: the rest as plain SSD jobs
                     items.append(("ssd", lambda g=g, n=n: hv.ssd_d(self.luma, st, g["rec"], n, g["jssd_x"], g["ossd_x"])))
-                if inter:
+                if self.rdoq:
+                    chain(fwd, rdq, *items)
+                elif inter:
                     chain(fwd)
                     chain(*items)
                 else:   # speed=fast: no RDOQ -- havoc_quantize sits between the two halves, one dependent chain on the device
                     chain(fwd, ("quantize", lambda g=g: hv.quantize_d(g["level"], g["coef"], g["qjobs"], g["cbf"])), *items)
                 continue
-            chain(("residual", lambda g=g, n=n: hv.residual_d(g["res"], n, g["res_off"], self.luma, st, self.luma, st, g["src"])),
-                  ("transform", lambda g=g, n=n, log2=log2, tr=tr: hv.transform_d(bd, tr, log2, g["coef"], g["res"], n, g["jobs"])))
-            chain(("quantize_inverse", lambda g=g: hv.quantize_inverse_d(g["deq"], g["level"], g["djobs"])),
-                  ("inverse_transform_add", lambda g=g, log2=log2, tr=tr, n=n: hv.inverse_transform_add_d(
-                      bd, tr, log2, g["rec"], n, self.luma, st, g["deq"], g["jobs"])),
-                  ("ssd", lambda g=g, n=n: hv.ssd_d(self.luma, st, g["rec"], n, g["jssd"], g["ossd"])))
+            front = [("residual", lambda g=g, n=n: hv.residual_d(g["res"], n, g["res_off"], self.luma, st, self.luma, st, g["src"])),
+                     ("transform", lambda g=g, n=n, log2=log2, tr=tr: hv.transform_d(bd, tr, log2, g["coef"], g["res"], n, g["jobs"]))]
+            back = [("quantize_inverse", lambda g=g: hv.quantize_inverse_d(g["deq"], g["level"], g["djobs"])),
+                    ("inverse_transform_add", lambda g=g, log2=log2, tr=tr, n=n: hv.inverse_transform_add_d(
+                        bd, tr, log2, g["rec"], n, self.luma, st, g["deq"], g["jobs"])),
+                    ("ssd", lambda g=g, n=n: hv.ssd_d(self.luma, st, g["rec"], n, g["jssd"], g["ossd"]))]
+            if self.rdoq:
+                chain(*front, rdq, *back)
+            else:
+                chain(*front)
+                chain(*back)
         if inter and "recon" not in self.skip:
             # the chosen modes' reconstruction of the whole picture, every sample once, into the reconstruction planes
             items = []
@@ -553,7 +569,14 @@ def cpu_worker(args):
         f_q = lambda b, e, level=level, coef=coef, qj=qj, cbf=cbf: lib.ref_run_quantize(handle, P(level), P(coef), P(qj), b, e, P(cbf))
         add("tu_forward", f_res, len(jt), True)
         add("tu_forward", f_fwd, len(jt), True)
-        if inter:
+        if inter and args.rdoq:   # speed=medium: the reference's own Rdoq::runQuantisation (turing/Rdoq.cpp, oracle/ref_shim_rdoq.cpp)
+            rj = _aligned(wl.rdoq_jobs((log2, tr))[::stride].copy().view(np.uint8))
+            rstates = _aligned(wl.rdoq_states)
+            keep += [rj, rstates]
+            results[f"cbf_{log2}_{tr}"] = cbf
+            add("rdoq", lambda b, e, log2=log2, level=level, coef=coef, rj=rj, rstates=rstates, cbf=cbf: lib.ref_run_rdoq(
+                bd, log2, P(level), P(coef), P(rstates), P(rj), C.c_double(wl.rdoq_lambda), b, e, P(cbf)), len(jt), True)
+        elif inter:
             prepass.append((len(jt), f_res, f_fwd, f_q))
         else:   # speed=fast: havoc_quantize is in the timed chain (turing/Reconstruct.cpp:310-311)
             add("quantize", f_q, len(jt), True)
@@ -684,6 +707,8 @@ def parity_vs_reference(dev, path, stride):
         m, nn = len(t["jobs"]), g["n"] ** 2
         cmp(f"coef_{log2}_{tr}", blocks(hv.down(g["coef"], np.int16), t["jobs"][:, 0], nn))
         cmp(f"level_{log2}_{tr}", blocks(hv.down(g["level"], np.int16), t["jobs"][:, 0], nn))
+        if dev.rdoq:
+            cmp(f"cbf_{log2}_{tr}", hv.down(g["cbf"], np.int32)[::stride])
         cmp(f"rec_{log2}_{tr}", blocks(hv.down(g["rec"], wl.dtype), t["jobs"][:, 3], nn))
         # the SSD tu_reconstruct reduced for each sampled TU (the extra plain-SSD calls are timed, not compared: see cpu_worker)
         cmp(f"ssd_{log2}_{tr}", hv.down(g["ossd"], np.uint32)[:m][::stride])
@@ -700,7 +725,8 @@ def cpu_baseline(args, dev=None):
     for handle in (1, 0):   # x86 JIT tables first; plain-C tables if the JIT run fails
         tmp = os.path.join(tempfile.gettempdir(), f"havoc_cpu_{os.getpid()}_{handle}.npz")
         cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", f"{handle},{stride}", "--res", args.res,
-               "--bit-depth", str(args.bit_depth), "--seed", str(args.seed), "--qp", str(args.qp), "--mix", args.mix, "--cpu-out", tmp]
+               "--bit-depth", str(args.bit_depth), "--seed", str(args.seed), "--qp", str(args.qp), "--mix", args.mix, "--rdoq", str(args.rdoq),
+               "--cpu-out", tmp]
         try:
             out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
             if out.returncode == 0:
@@ -769,7 +795,8 @@ def build_contexts(args, torch, Havoc, FrameWorkload, local, res, bit_depth, qp,
         hv_k = Havoc(local, stream=compute_k.cuda_stream)
         wl_k = FrameWorkload(w, h, bit_depth, seed0 + 1000 * k, qp=qp, mix=mix)
         dev_k = DeviceFrame(hv_k, wl_k, use_planes=(args.subpel == "planes"), fused_tu=(args.tu == "fused"),
-                            ime_range=args.ime_range if args.ime == "surface" else None, skip=[s for s in args.skip.split(",") if s])
+                            ime_range=args.ime_range if args.ime == "surface" else None, skip=[s for s in args.skip.split(",") if s],
+                            rdoq=args.rdoq)
         dev_k.step()          # first eager pass (loads the code objects) -- also what the graph must reproduce
         hv_k.sync()
         if args.no_graph:

@@ -59,3 +59,21 @@ extern "C" void ref_rdoq_initial_states(int qp, int initType, uint8_t *states)
 }
 
 extern "C" int ref_scan_order(int log2BlockSize, int scanIdx, int sPos, int sComp) { return ScanOrder(log2BlockSize, scanIdx, sPos, sComp); }
+
+// bench.py's cpu_baseline leg: jobs [b, e) of a table of 48-byte records laid out like havoc_mi355x_rdoq_job (the integer lambda
+// fields are ignored: the reference takes the double), one lambda for the picture, `states` = 128-byte snapshots
+struct RunJob
+{
+    int32_t dst_off, src_off, quant_scale, quant_shift, inv_scale, lambda_q16, sdh_factor, ctx_index;
+    uint8_t c_idx, scan_idx, is_intra, sdh;
+    int32_t reserved[3];
+};
+extern "C" void ref_run_rdoq(int bitDepth, int log2Size, int16_t *dst, const int16_t *src, const uint8_t *states, const void *jobs, double lambda,
+                             int b, int e, int32_t *cbf)
+{
+    static_assert(sizeof(RunJob) == 48, "job layout");
+    const RunJob *j = static_cast<const RunJob *>(jobs);
+    for (int i = b; i < e; ++i)
+        cbf[i] = ref_rdoq(dst + j[i].dst_off, src + j[i].src_off, log2Size, j[i].c_idx, j[i].scan_idx, j[i].is_intra, j[i].sdh, j[i].quant_scale,
+                          j[i].quant_shift, j[i].inv_scale, bitDepth, lambda, states + 128 * (long)j[i].ctx_index);
+}

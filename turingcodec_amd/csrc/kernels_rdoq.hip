@@ -24,6 +24,8 @@
 // Integer throughout: Q16 int64 costs, Q16 int32 lambda / distortion scale, Q15 bit counts -- bit-exact by construction as
 // long as every sum adds the same terms.
 #include "common.h"
+#include <cstdlib>
+#include <cstring>
 
 namespace havoc_gpu {
 
@@ -55,9 +57,10 @@ static_assert(sizeof(RdoqJob) == 48 && sizeof(havoc_mi355x_rdoq_job) == 48, "rdo
 // what a lane knows about its transform block
 struct Block
 {
-    const uint8_t *states;    // LDS: this block's 128 state bytes
+    const uint8_t *states;    // LDS: this block's 128 state bytes, `stateStride` apart
     const int32_t *bits;      // LDS: kEntropyBits
-    const int16_t *src;       // LDS: the block's coefficients, raster
+    const int16_t *src;       // LDS: coefficient (x, y) at src[(y & coefMask) * coefRow + (x & coefMask) * coefCol]
+    int stateStride, coefMask, coefRow, coefCol;
     int64_t lambda;
     int32_t distScale;
     int quantScale, quantShift, invScale, invShift, invOffset;
@@ -67,7 +70,8 @@ struct Block
 
 struct LevelState { int ctxSet, c1, nG1, nG2, rice; };   // Rdoq.cpp:44-49
 
-__device__ __forceinline__ int32_t bitsOf(const Block &b, int ctx, int bin) { return b.bits[(b.states[ctx] >> 1) ^ bin]; }
+__device__ __forceinline__ int32_t bitsOf(const Block &b, int ctx, int bin) { return b.bits[(b.states[ctx * b.stateStride] >> 1) ^ bin]; }
+__device__ __forceinline__ int coefAt(const Block &b, int x, int y) { return b.src[(y & b.coefMask) * b.coefRow + (x & b.coefMask) * b.coefCol]; }
 __device__ __forceinline__ int baseLevel(const LevelState &s) { return s.nG1 < 8 ? 2 + (s.nG2 < 1) : 1; }
 __device__ __forceinline__ int clip16(int v) { return min(max(v, -32768), 32767); }
 
@@ -230,7 +234,7 @@ __device__ __forceinline__ GroupResult processGroup(const Block &b, int g, int g
     for (int i = 15; i >= 0; --i)
     {
         const int nib = (int)(b.scan4 >> (4 * i)) & 15, x = (gx << 2) + (nib & 3), y = (gy << 2) + (nib >> 2);
-        const int a = abs((int)b.src[y * size + x]);
+        const int a = abs(coefAt(b, x, y));
         const int64_t dist0 = (int64_t)(a * a) * b.distScale;
         r.dist0 += dist0;
         const int sp = g * 16 + i;
@@ -354,7 +358,7 @@ __device__ __forceinline__ GroupResult processGroup(const Block &b, int g, int g
                     if (keptMask >> i & 1)
                     {
                         const int nib = (int)(b.scan4 >> (4 * i)) & 15, x = (gx << 2) + (nib & 3), y = (gy << 2) + (nib >> 2);
-                        const int a = abs((int)b.src[y * size + x]);
+                        const int a = abs(coefAt(b, x, y));
                         rec->kept[i * kGroups + lane] = 0;
                         rec->costCoded[i * kGroups + lane] = (int64_t)(a * a) * b.distScale;
                         rec->costSig[i * kGroups + lane] = 0;
@@ -424,7 +428,7 @@ __device__ __forceinline__ void hideSigns(Records *rec, int lane, const Block &b
             if (i < first)
             {
                 const int nib = (int)(b.scan4 >> (4 * i)) & 15;
-                if ((b.src[((gy << 2) + (nib >> 2)) * size + (gx << 2) + (nib & 3)] >= 0 ? 0 : 1) != signbit) cost = INT32_MAX;
+                if ((coefAt(b, (gx << 2) + (nib & 3), (gy << 2) + (nib >> 2)) >= 0 ? 0 : 1) != signbit) cost = INT32_MAX;
             }
         }
         if (cost < minCost)
@@ -437,7 +441,7 @@ __device__ __forceinline__ void hideSigns(Records *rec, int lane, const Block &b
     const int k = minIdx * kGroups + lane, v = rec->kept[k];
     if (v == 32767 || v == -32768) finalChange = -1;
     const int nib = (int)(b.scan4 >> (4 * minIdx)) & 15;
-    const bool positive = b.src[((gy << 2) + (nib >> 2)) * size + (gx << 2) + (nib & 3)] >= 0;
+    const bool positive = coefAt(b, (gx << 2) + (nib & 3), (gy << 2) + (nib >> 2)) >= 0;
     rec->kept[k] = (int16_t)(positive ? v + finalChange : v - finalChange);
 }
 
@@ -457,7 +461,7 @@ struct RdoqShared
 // LOG2 = log2 of the transform size; a workgroup holds 64 >> (2 * LOG2 - 4) blocks
 template <int LOG2>
 __global__ __launch_bounds__(kRdoqThreads) void k_rdoq(int16_t *__restrict__ dstAll, const int16_t *__restrict__ srcAll, const uint8_t *__restrict__ statesAll,
-                                                       const RdoqJob *__restrict__ jobs, int njobs, int32_t *__restrict__ cbfOut, int bitDepth)
+                                                       const RdoqJob *__restrict__ jobs, int njobs, int32_t *__restrict__ cbfOut, int bitDepth, int stages)
 {
     constexpr int size = 1 << LOG2, n = size * size, G = n >> 4, T = kGroups / G, log2G = 2 * LOG2 - 4, gw = size >> 2;
     __shared__ RdoqShared sh;
@@ -485,6 +489,10 @@ __global__ __launch_bounds__(kRdoqThreads) void k_rdoq(int16_t *__restrict__ dst
     b.states = sh.states + tl * HAVOC_RDOQ_CTX_BYTES;
     b.bits = sh.bits;
     b.src = sh.src + tl * n;
+    b.stateStride = 1;
+    b.coefMask = ~0;
+    b.coefRow = size;
+    b.coefCol = 1;
     b.lambda = job.lambda_q16;
     {   // Rdoq.h:163-187
         const int transformShift = 15 - bitDepth - LOG2;
@@ -509,7 +517,7 @@ __global__ __launch_bounds__(kRdoqThreads) void k_rdoq(int16_t *__restrict__ dst
         for (int i = 15; i >= 0 && top < 0; --i)
         {
             const int nib = (int)(b.scan4 >> (4 * i)) & 15;
-            const int a = abs((int)b.src[((gy << 2) + (nib >> 2)) * size + (gx << 2) + (nib & 3)]);
+            const int a = abs(coefAt(b, (gx << 2) + (nib & 3), (gy << 2) + (nib >> 2)));
             if (((a * b.quantScale + (1 << (b.quantShift - 1))) >> b.quantShift) > 0) top = g * 16 + i;
         }
         if (top >= 0 && valid) atomicMax(&sh.firstPos[tl], top);
@@ -535,6 +543,7 @@ __global__ __launch_bounds__(kRdoqThreads) void k_rdoq(int16_t *__restrict__ dst
         sh.caseFlags[caseBits][lane] = (uint8_t)(r.coded | r.carry << 1);
     }
     __syncthreads();
+    if (stages == 1) return;
 
     // ---- resolve: follow the three bits through the groups in reverse scan order ----
     if (tid < T)
@@ -558,12 +567,14 @@ __global__ __launch_bounds__(kRdoqThreads) void k_rdoq(int16_t *__restrict__ dst
         for (int k = G - 1; k > fg; --k) sh.chosen[tid * G + k] = 0;
     }
     __syncthreads();
+    if (stages == 2) return;
 
     // ---- pass 2 and the tail, one wavefront: lanes = groups ----
     if (tid < kGroups)
     {
         const GroupResult r = processGroup<LOG2, true>(b, g, gx, gy, firstPos, sh.chosen[lane], &sh.rec, lane);
         const bool inScope = firstPos >= 0 && g <= firstGroup;
+        if (stages == 3) return;
 
         // running-cost delta of this group in the last-position search (Rdoq.cpp:356-399 without the early exit) and the
         // position of its highest level > 1
@@ -580,7 +591,7 @@ __global__ __launch_bounds__(kRdoqThreads) void k_rdoq(int16_t *__restrict__ dst
                     if (sh.rec.kept[k])
                     {
                         const int nib = (int)(b.scan4 >> (4 * i)) & 15;
-                        const int a = abs((int)b.src[((gy << 2) + (nib >> 2)) * size + (gx << 2) + (nib & 3)]);
+                        const int a = abs(coefAt(b, (gx << 2) + (nib & 3), (gy << 2) + (nib >> 2)));
                         delta += (int64_t)(a * a) * b.distScale - sh.rec.costCoded[k];
                         if (sh.rec.kept[k] > 1 && big < 0) big = sp;
                     }
@@ -628,7 +639,7 @@ __global__ __launch_bounds__(kRdoqThreads) void k_rdoq(int16_t *__restrict__ dst
                         best = total;
                         bestPos = sp;
                     }
-                    const int a = abs((int)b.src[y * size + x]);
+                    const int a = abs(coefAt(b, x, y));
                     running += (int64_t)(a * a) * b.distScale - sh.rec.costCoded[k];
                 }
                 else
@@ -659,7 +670,7 @@ __global__ __launch_bounds__(kRdoqThreads) void k_rdoq(int16_t *__restrict__ dst
                 const int nib = (int)(b.scan4 >> (4 * i)) & 15;
                 absSum += level;
                 cbf |= level;
-                if (b.src[((gy << 2) + (nib >> 2)) * size + (gx << 2) + (nib & 3)] < 0) level = -level;
+                if (coefAt(b, (gx << 2) + (nib & 3), (gy << 2) + (nib >> 2)) < 0) level = -level;
             }
             else
                 level = 0;
@@ -687,6 +698,326 @@ __global__ __launch_bounds__(kRdoqThreads) void k_rdoq(int16_t *__restrict__ dst
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_rdoq_walk : the work-efficient form.  Transform coefficients after a QP-32 quantiser are sparse (3-5 % of the levels and
+// ~15 % of the 4x4 groups of a 32x32 block are non-zero), and a group whose rounded levels are all zero does no more than add
+// one flag cost: it keeps no level, leaves the level state alone and is never a candidate for the last position.  So:
+//   * lane = transform block, 64 blocks per wavefront; a lane walks ITS block's groups in reverse scan order, hopping over the
+//     all-zero ones (a handful of instructions each) and doing the full per-coefficient work (processGroup above, the same code
+//     the speculative kernel runs) only on the others.  Nothing is speculated: the neighbours' flags and the carry are known.
+//   * the search for the last significant position (Rdoq.cpp:342-399) is streamed: its running cost differs from the block's
+//     final cost by a sum of per-coefficient deltas, so the best candidate relative to that final cost can be tracked group by
+//     group, committed once the group's keep-or-zero decision is made, and compared with "code nothing" at the very end.
+//   * sign-data hiding is applied to each group as it is finished, as if it were not the group holding the last significant
+//     coefficient; that one group (known only at the end) is redone.
+//   * the per-group record arrays live in LDS, [coefficient][lane]; the pre-pass that finds the non-zero groups (and zero-fills
+//     the output) is cooperative: 64 lanes read one 32x32 block's 64 groups (or four 16x16, ...) per step, coalesced.
+// ---------------------------------------------------------------------------------------------------------------------
+struct WalkShared
+{
+    Records rec;
+    int32_t bits[128];
+    uint8_t states[HAVOC_RDOQ_CTX_BYTES][64];     // [context][lane]
+    int32_t cumOne[2][10][64];                    // sum over i < k of bits(1, ctx(i)) for last_sig_coeff_{x,y}_prefix
+    int32_t zeroBin[2][9][64];                    // bits(0, ctx(k))
+    int16_t coef[16][64];                         // the current group's coefficients, raster order within the group
+    uint8_t rasterOf[3][64];                      // scan index -> raster group position, per scan type
+    uint64_t mask[64];                            // non-zero groups of each block (bit = raster group position)
+    int64_t sumSq[64];                            // sum of squared coefficients of each block
+    int32_t srcOff[64], dstOff[64], qScale[64], qShift[64];
+};
+
+template <int LOG2>
+__global__ __launch_bounds__(64) void k_rdoq_walk(int16_t *__restrict__ dstAll, const int16_t *__restrict__ srcAll, const uint8_t *__restrict__ statesAll,
+                                                  const RdoqJob *__restrict__ jobs, int njobs, int32_t *__restrict__ cbfOut, int bitDepth)
+{
+    constexpr int size = 1 << LOG2, G = (size * size) >> 4, log2G = 2 * LOG2 - 4, gw = size >> 2, perStep = 64 / G;
+    __shared__ WalkShared sh;
+    const int lane = threadIdx.x, blk = blockIdx.x * 64 + lane;
+    const bool valid = blk < njobs;
+    const RdoqJob job = jobs[valid ? blk : njobs - 1];
+
+    // ---- stage in ----
+    sh.bits[lane] = kEntropyBits[lane];
+    sh.bits[64 + lane] = kEntropyBits[64 + lane];
+    {
+        const uint32_t *st = reinterpret_cast<const uint32_t *>(statesAll + (long)job.ctx_index * HAVOC_RDOQ_CTX_BYTES);
+        for (int k = 0; k < HAVOC_RDOQ_CTX_BYTES / 4; ++k)
+        {
+            const uint32_t v = st[k];
+            sh.states[4 * k][lane] = (uint8_t)v;
+            sh.states[4 * k + 1][lane] = (uint8_t)(v >> 8);
+            sh.states[4 * k + 2][lane] = (uint8_t)(v >> 16);
+            sh.states[4 * k + 3][lane] = (uint8_t)(v >> 24);
+        }
+    }
+    sh.srcOff[lane] = job.src_off;
+    sh.dstOff[lane] = job.dst_off;
+    sh.qScale[lane] = job.quant_scale;
+    sh.qShift[lane] = job.quant_shift;
+    if (lane < G)
+        for (int t = 0; t < 3; ++t)
+        {
+            int x = 0, y = 0;
+            if (G > 1) scanXy(gw, t, lane, x, y);
+            sh.rasterOf[t][lane] = (uint8_t)(y * gw + x);
+        }
+    __syncthreads();
+
+    // ---- pre-pass: which groups hold a non-zero rounded level, the blocks' energy, zeros into the output ----
+    {
+        const int sub = lane >> log2G, pos = lane & (G - 1), px = pos & (gw - 1), py = pos / gw;
+        for (int step = 0; step < G; ++step)        // G steps of 64 / G blocks = 64 blocks
+        {
+            const int bl = step * perStep + sub;
+            const bool have = blockIdx.x * 64 + bl < njobs;
+            const int16_t *p = srcAll + (long)sh.srcOff[bl] + (py * 4) * size + px * 4;
+            int16_t *q = dstAll + (long)sh.dstOff[bl] + (py * 4) * size + px * 4;
+            const int qs = sh.qScale[bl], rnd = 1 << (sh.qShift[bl] - 1), qsh = sh.qShift[bl];
+            bool nz = false;
+            uint32_t lo = 0, hi = 0;
+            if (have)
+                for (int r = 0; r < 4; ++r)
+                {
+                    const u32x2 v = ld8(p + r * size);
+                    st8(q + r * size, u32x2{0, 0});
+                    const int c[4] = {(int16_t)v.x, (int16_t)(v.x >> 16), (int16_t)v.y, (int16_t)(v.y >> 16)};
+                    for (int k = 0; k < 4; ++k)
+                    {
+                        const uint32_t a = (uint32_t)abs(c[k]);
+                        nz |= (int)((a * qs + rnd) >> qsh) > 0;
+                        lo += (a * a) & 0xffff;
+                        hi += (a * a) >> 16;
+                    }
+                }
+            const uint64_t m = __ballot(nz);
+            const int slo = group_sum<G>((int)lo), shi = group_sum<G>((int)hi);
+            if (pos == 0)
+            {
+                sh.mask[bl] = G == 64 ? m : (m >> (lane & ~(G - 1))) & ((1ull << (G & 63)) - 1);
+                sh.sumSq[bl] = ((int64_t)shi << 16) + slo;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- per-lane set-up ----
+    Block b;
+    b.states = &sh.states[0][lane];
+    b.stateStride = 64;
+    b.bits = sh.bits;
+    b.src = &sh.coef[0][lane];
+    b.coefMask = 3;
+    b.coefRow = 4 * 64;
+    b.coefCol = 64;
+    b.lambda = job.lambda_q16;
+    const int transformShift = 15 - bitDepth - LOG2, distShift = 15 - 2 * transformShift - 2 * (bitDepth - 8) + 16;   // Rdoq.h:163-187
+    b.distScale = 1 << distShift;
+    b.invShift = 6 - transformShift;
+    b.invOffset = 1 << (b.invShift - 1);
+    b.quantScale = job.quant_scale;
+    b.quantShift = job.quant_shift;
+    b.invScale = job.inv_scale;
+    b.cIdx = job.c_idx;
+    b.scanIdx = job.scan_idx;
+    b.scan4 = job.scan_idx == 0 ? scan4Nibbles(0) : (job.scan_idx == 1 ? scan4Nibbles(1) : scan4Nibbles(2));
+    const uint8_t *rasterOf = sh.rasterOf[job.scan_idx < 3 ? job.scan_idx : 0];
+    const int16_t *src = srcAll + job.src_off;
+    int16_t *dst = dstAll + job.dst_off;
+    for (int axis = 0; axis < 2; ++axis)      // Rdoq.cpp:706-771, as prefix sums over the bins
+    {
+        const int base = axis ? HAVOC_RDOQ_CTX_LAST_Y : HAVOC_RDOQ_CTX_LAST_X;
+        const int offset = b.cIdx ? 15 : 3 * (LOG2 - 2) + ((LOG2 - 1) >> 2), shift = b.cIdx ? LOG2 - 2 : (LOG2 + 1) >> 2;
+        int32_t run = 0;
+        for (int i = 0; i < 10; ++i)
+        {
+            const int ctx = base + min(max((i >> shift) + offset, 0), 17);
+            sh.cumOne[axis][i][lane] = run;
+            if (i < 9)
+            {
+                sh.zeroBin[axis][i][lane] = bitsOf(b, ctx, 0);
+                run += bitsOf(b, ctx, 1);
+            }
+        }
+    }
+    auto lastRate = [&](int axis, int c) -> int32_t {
+        const int len = c < 4 ? c : (c < 8 ? 4 + ((c - 4) >> 1) : (c < 16 ? 6 + ((c - 8) >> 2) : 8 + ((c - 16) >> 3)));
+        return sh.cumOne[axis][len][lane] + (len < 9 ? sh.zeroBin[axis][len][lane] : 0) + (len > 3 ? 32768 * ((len - 2) >> 1) : 0);
+    };
+    auto loadGroup = [&](int gx, int gy) {
+        for (int r = 0; r < 4; ++r)
+        {
+            const u32x2 v = ld8(src + ((gy << 2) + r) * size + (gx << 2));
+            sh.coef[4 * r][lane] = (int16_t)v.x;
+            sh.coef[4 * r + 1][lane] = (int16_t)(v.x >> 16);
+            sh.coef[4 * r + 2][lane] = (int16_t)v.y;
+            sh.coef[4 * r + 3][lane] = (int16_t)(v.y >> 16);
+        }
+    };
+    auto storeGroup = [&](int gx, int gy) {      // rec.kept (scan order, signed) -> the output block
+        for (int i = 0; i < 16; ++i)
+        {
+            const int nib = (int)(b.scan4 >> (4 * i)) & 15;
+            sh.coef[nib][lane] = sh.rec.kept[i * kGroups + lane];      // coef doubles as the raster staging area
+        }
+        for (int r = 0; r < 4; ++r)
+        {
+            u32x2 o;
+            o.x = (uint16_t)sh.coef[4 * r][lane] | (uint32_t)(uint16_t)sh.coef[4 * r + 1][lane] << 16;
+            o.y = (uint16_t)sh.coef[4 * r + 2][lane] | (uint32_t)(uint16_t)sh.coef[4 * r + 3][lane] << 16;
+            st8(dst + ((gy << 2) + r) * size + (gx << 2), o);
+        }
+    };
+    auto caseOf = [&](uint64_t coded, int gx, int gy, int carry) {
+        const int p = gy * gw + gx;
+        const int right = gx < gw - 1 ? (int)(coded >> (p + 1)) & 1 : 0, below = gy < gw - 1 ? (int)(coded >> (p + gw)) & 1 : 0;
+        return right | below << 1 | carry << 2;
+    };
+
+    uint64_t nz = valid ? sh.mask[lane] : 0, coded = 0, carries = 0;
+    int g = G - 1;
+    while (g >= 0 && !((nz >> rasterOf[g]) & 1)) --g;
+    const int firstGroup = g;
+    int firstPos = -1;
+    if (firstGroup >= 0)
+    {
+        const int p = rasterOf[firstGroup], gx = p & (gw - 1), gy = p / gw;
+        loadGroup(gx, gy);
+        for (int i = 15; i >= 0 && firstPos < 0; --i)
+        {
+            const int nib = (int)(b.scan4 >> (4 * i)) & 15;
+            const int a = abs((int)sh.coef[nib][lane]);
+            if (((a * b.quantScale + (1 << (b.quantShift - 1))) >> b.quantShift) > 0) firstPos = firstGroup * 16 + i;
+        }
+        nz |= 1;      // the DC group is always walked in full (it is coded whatever its levels, Rdoq.cpp:291-295)
+    }
+
+    // running state of the walk
+    int64_t costTu = 0, heavyDist0 = 0;     // costTu: everything but the energy of the coefficients outside the walked groups
+    int64_t rel = 0;                        // running cost of the last-position search relative to its start
+    int64_t bestRel = INT64_MAX;
+    int bestPos = -1, orSince = 0, carry = 0;
+    bool stopped = false;
+
+    while (true)
+    {
+        while (g >= 0 && !((nz >> rasterOf[g]) & 1))      // all-zero groups: one flag cost each (Rdoq.cpp:200-210)
+        {
+            const int p = rasterOf[g], gx = p & (gw - 1), gy = p / gw;
+            const int c = caseOf(coded, gx, gy, 0);
+            const int64_t zero = b.lambda * bitsOf(b, HAVOC_RDOQ_CTX_CSBF + (b.cIdx ? 2 : 0) + ((c & 3) ? 1 : 0), 0);
+            costTu += zero;
+            rel -= zero;
+            carry = 0;
+            --g;
+        }
+        if (__ballot(g >= 0) == 0) break;
+        if (g >= 0)
+        {
+            const int p = rasterOf[g], gx = p & (gw - 1), gy = p / gw;
+            const int c = caseOf(coded, gx, gy, carry);
+            loadGroup(gx, gy);
+            const GroupResult r = processGroup<LOG2, true>(b, g, gx, gy, firstPos, c, &sh.rec, lane);
+            costTu += r.cost;
+            heavyDist0 += r.dist0;
+            coded |= (uint64_t)r.coded << p;
+            carries |= (uint64_t)carry << g;
+            carry = r.carry;
+            rel -= r.sigCost;
+            if (r.coded)
+            {
+                // candidates of this group (Rdoq.cpp:356-399), relative to `rel`
+                int64_t q = 0, localBest = INT64_MAX;
+                int localPos = -1, localOr = 0, groupOr = 0;
+                bool localStop = false;
+                for (int i = 15; i >= 0; --i)
+                {
+                    const int sp = g * 16 + i, k = i * kGroups + lane;
+                    if (sp > firstPos) continue;
+                    const int kept = sh.rec.kept[k];
+                    if (kept)
+                    {
+                        const int nib = (int)(b.scan4 >> (4 * i)) & 15, x = (gx << 2) + (nib & 3), y = (gy << 2) + (nib >> 2);
+                        const int32_t rate = b.scanIdx == 2 ? lastRate(0, y) + lastRate(1, x) : lastRate(0, x) + lastRate(1, y);
+                        const int64_t total = q + b.lambda * rate - sh.rec.costSig[k];
+                        groupOr |= kept;
+                        if (!localStop && total < localBest)
+                        {
+                            localBest = total;
+                            localPos = sp;
+                            localOr = 0;
+                        }
+                        localOr |= kept;
+                        if (kept > 1) localStop = true;
+                        const int a = abs(coefAt(b, x, y));
+                        q += (int64_t)(a * a) * b.distScale - sh.rec.costCoded[k];
+                    }
+                    else
+                        q -= sh.rec.costSig[k];
+                }
+                if (!stopped && localPos >= 0 && rel + localBest < bestRel)
+                {
+                    bestRel = rel + localBest;
+                    bestPos = localPos;
+                    orSince = localOr;
+                }
+                else
+                    orSince |= groupOr;
+                stopped |= localStop;
+                rel += q;
+
+                // signs, sign-data hiding as for a group below the last one (Rdoq.cpp:418-441, :887-1023), out
+                for (int i = 0; i < 16; ++i)
+                {
+                    const int nib = (int)(b.scan4 >> (4 * i)) & 15, k = i * kGroups + lane;
+                    if (sh.coef[nib][lane] < 0) sh.rec.kept[k] = (int16_t)-sh.rec.kept[k];
+                }
+                if (job.sdh) hideSigns(&sh.rec, lane, b, gx, gy, size, false, job.sdh_factor);
+                storeGroup(gx, gy);
+            }
+            --g;
+        }
+    }
+
+    // ---- the block's verdict (Rdoq.cpp:307-341, :401-441) ----
+    int cbf = 0;
+    if (firstPos >= 0)
+    {
+        const int cbfCtx = (!job.is_intra && b.cIdx == 0) ? HAVOC_RDOQ_CTX_ROOT_CBF : (b.cIdx == 0 ? HAVOC_RDOQ_CTX_CBF_LUMA + 1 : HAVOC_RDOQ_CTX_CBF_CHROMA);
+        const int64_t dist0Total = sh.sumSq[lane] << distShift;
+        const int64_t bestNone = dist0Total + b.lambda * bitsOf(b, cbfCtx, 0);
+        const int64_t start = (dist0Total - heavyDist0) + costTu + b.lambda * bitsOf(b, cbfCtx, 1);
+        const int lastIdx = (bestPos >= 0 && start + bestRel < bestNone) ? bestPos + 1 : 0;
+        cbf = lastIdx ? orSince : 0;
+        const int lastGroup = (lastIdx - 1) >> 4;      // -1: nothing is coded
+        // groups above the last one were written as if coded: clear them
+        for (int k = firstGroup; k > lastGroup; --k)
+        {
+            const int p = rasterOf[k];
+            if ((coded >> p) & 1)
+                for (int r = 0; r < 4; ++r) st8(dst + (((p / gw) << 2) + r) * size + ((p & (gw - 1)) << 2), u32x2{0, 0});
+        }
+        // the group holding the last significant coefficient: levels again, truncated, hidden with the last-group rules
+        if (lastGroup >= 0 && (lastIdx & 15 || job.sdh))
+        {
+            const int p = rasterOf[lastGroup], gx = p & (gw - 1), gy = p / gw;
+            const int c = caseOf(coded, gx, gy, (int)(carries >> lastGroup) & 1);
+            loadGroup(gx, gy);
+            processGroup<LOG2, true>(b, lastGroup, gx, gy, firstPos, c, &sh.rec, lane);
+            for (int i = 0; i < 16; ++i)
+            {
+                const int nib = (int)(b.scan4 >> (4 * i)) & 15, k = i * kGroups + lane;
+                int v = lastGroup * 16 + i < lastIdx ? sh.rec.kept[k] : 0;
+                if (sh.coef[nib][lane] < 0) v = -v;
+                sh.rec.kept[k] = (int16_t)v;
+            }
+            if (job.sdh) hideSigns(&sh.rec, lane, b, gx, gy, size, true, job.sdh_factor);
+            storeGroup(gx, gy);
+        }
+    }
+    if (valid) cbfOut[blk] = cbf;
+}
 } // namespace
 
 hipError_t launch_rdoq(hipStream_t st, int bitDepth, int log2, int16_t *dst, const int16_t *src, const uint8_t *states, const void *jobs, int njobs, int32_t *cbf)
@@ -694,12 +1025,26 @@ hipError_t launch_rdoq(hipStream_t st, int bitDepth, int log2, int16_t *dst, con
     if (njobs <= 0) return hipSuccess;
     const int perGroup = kGroups >> (2 * log2 - 4), blocks = (njobs + perGroup - 1) / perGroup;
     const RdoqJob *j = static_cast<const RdoqJob *>(jobs);
+    static const int stages = getenv("HAVOC_RDOQ_STAGES") ? atoi(getenv("HAVOC_RDOQ_STAGES")) : 0;   // diagnostic: stop after a stage
+    static const bool speculative = getenv("HAVOC_RDOQ_KERNEL") && !strcmp(getenv("HAVOC_RDOQ_KERNEL"), "groups");
+    if (!speculative)
+    {
+        const int wgs = (njobs + 63) / 64;
+        switch (log2)
+        {
+        case 2: hipLaunchKernelGGL(k_rdoq_walk<2>, dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth); break;
+        case 3: hipLaunchKernelGGL(k_rdoq_walk<3>, dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth); break;
+        case 4: hipLaunchKernelGGL(k_rdoq_walk<4>, dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth); break;
+        default: hipLaunchKernelGGL(k_rdoq_walk<5>, dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth); break;
+        }
+        return hipGetLastError();
+    }
     switch (log2)
     {
-    case 2: hipLaunchKernelGGL(k_rdoq<2>, dim3(blocks), dim3(kRdoqThreads), 0, st, dst, src, states, j, njobs, cbf, bitDepth); break;
-    case 3: hipLaunchKernelGGL(k_rdoq<3>, dim3(blocks), dim3(kRdoqThreads), 0, st, dst, src, states, j, njobs, cbf, bitDepth); break;
-    case 4: hipLaunchKernelGGL(k_rdoq<4>, dim3(blocks), dim3(kRdoqThreads), 0, st, dst, src, states, j, njobs, cbf, bitDepth); break;
-    default: hipLaunchKernelGGL(k_rdoq<5>, dim3(blocks), dim3(kRdoqThreads), 0, st, dst, src, states, j, njobs, cbf, bitDepth); break;
+    case 2: hipLaunchKernelGGL(k_rdoq<2>, dim3(blocks), dim3(kRdoqThreads), 0, st, dst, src, states, j, njobs, cbf, bitDepth, stages); break;
+    case 3: hipLaunchKernelGGL(k_rdoq<3>, dim3(blocks), dim3(kRdoqThreads), 0, st, dst, src, states, j, njobs, cbf, bitDepth, stages); break;
+    case 4: hipLaunchKernelGGL(k_rdoq<4>, dim3(blocks), dim3(kRdoqThreads), 0, st, dst, src, states, j, njobs, cbf, bitDepth, stages); break;
+    default: hipLaunchKernelGGL(k_rdoq<5>, dim3(blocks), dim3(kRdoqThreads), 0, st, dst, src, states, j, njobs, cbf, bitDepth, stages); break;
     }
     return hipGetLastError();
 }

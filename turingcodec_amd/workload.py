@@ -98,6 +98,14 @@ def dequant_params(qp, log2, bit_depth):
     return DEQUANT_SCALE[qp % 6] << (qp // 6), log2 - 1 + bit_depth - 8
 
 
+def picture_lambda(qp, qp_factor=0.68, non_reference=True):
+    """computeLambda (turing/Measure.h:58-78) of a B picture of the hierarchy: the lambda Rdoq is constructed with"""
+    lam = qp_factor * 2.0 ** ((qp - 12.0) / 3.0)
+    if non_reference:
+        lam *= min(4.0, max(2.0, (qp - 12.0) / 6.0))
+    return lam
+
+
 def _pick(rng, mix, n):
     w = np.array([m[-1] for m in mix], np.float64)
     return rng.choice(len(mix), size=n, p=w / w.sum())
@@ -377,7 +385,18 @@ class FrameWorkload:
             ssd = np.stack([src4[:, 0], t[:, 3], src4[:, 2], src4[:, 3]], 1).astype(np.int32)
             nssd = int(round(m * n["ssd"] / max(1, n["tu"])))
             ssd = np.concatenate([ssd, ssd])[:nssd]
-            self.tu[(log2, tr)] = dict(jobs=t, src=src4, res_off=t[:, 1].copy(), n=nn, ssd=ssd)
+            # what Rdoq::runQuantisation is told about the block (turing/Reconstruct.cpp:289-312, :794-812): the probability
+            # states of the CTU it sits in, the scan (mode dependent for intra 4x4, diagonal otherwise), intra / inter
+            ctu_idx = ((y // CTU) * ((W + CTU - 1) // CTU) + x // CTU).astype(np.int32)
+            scan = (np.arange(m) % 3).astype(np.uint8) if tr else np.zeros(m, np.uint8)
+            self.tu[(log2, tr)] = dict(jobs=t, src=src4, res_off=t[:, 1].copy(), n=nn, ssd=ssd, ctx_index=ctu_idx, scan_idx=scan,
+                                       is_intra=np.full(m, 1 if (tr or mix == "ai") else 0, np.uint8))
+        # one snapshot of CABAC probability states per CTU (128 bytes, include/havoc_mi355x.h HAVOC_RDOQ_CTX_*): a slice-wide
+        # draw plus a small per-CTU drift, the way the states of a substream adapt from CTU to CTU
+        srng = np.random.default_rng(seed + 7919)      # own stream: the tables drawn after this point do not move
+        base = srng.integers(4, 100, 128)
+        self.rdoq_states = np.clip(base[None, :] + srng.integers(-6, 7, (ctus, 128)), 0, 125).astype(np.uint8)
+        self.rdoq_lambda = picture_lambda(qp)
 
         # ---- integer ME served from SAD surfaces (havoc_mi355x_sad_surface) instead of per-pattern SAD4 jobs: one
         # surface per uni-directional search.  A.1: ~31 SAD4 calls (124 candidates) per search on average, so the
@@ -439,6 +458,21 @@ class FrameWorkload:
         self.deblock_blocks = (data_.ravel(), bs_.ravel())
 
     # ---- algorithmic bytes (SURVEY.md 8(d) "per primitive call": operands read once + results written once) ----
+    def rdoq_jobs(self, key, lambda_ints=(0, 0), sdh=1):
+        """havoc_mi355x_rdoq_job records (48 bytes each, as a structured array) for the TU group `key` = (log2, trType):
+        coefficients and levels share the offsets of the TU table; lambda_ints = havoc_mi355x_rdoq_lambda(rdoq_lambda, inv_scale)"""
+        from .havoc import RDOQ_JOB_DT
+        g = self.tu[key]
+        log2 = key[0]
+        qscale, qshift, _ = quant_params(self.qp, log2, self.bit_depth, self.mix == "ai")
+        inv, _ = dequant_params(self.qp, log2, self.bit_depth)
+        j = np.zeros(len(g["jobs"]), RDOQ_JOB_DT)
+        j["dst_off"] = j["src_off"] = g["jobs"][:, 0]
+        j["quant_scale"], j["quant_shift"], j["inv_scale"] = qscale, qshift, inv
+        j["lambda_q16"], j["sdh_factor"] = lambda_ints
+        j["ctx_index"], j["scan_idx"], j["is_intra"], j["sdh"] = g["ctx_index"], g["scan_idx"], g["is_intra"], sdh
+        return j
+
     def algorithmic_bytes(self):
         S = self.S
         b = {}
@@ -484,5 +518,6 @@ class FrameWorkload:
         b["ssd"] = sum(int((2 * wh(g["ssd"], 2, 3) * S + 4).sum()) for g in self.tu.values())
         b["recon"] = sum(len(g["jobs"]) * g["n"] ** 2 for t in self.recon.values() for g in t.values()) * (2 + 3 * S)
         b["quantize"] = 4 * tot
+        b["rdoq"] = 4 * tot + sum(len(g["jobs"]) for g in self.tu.values()) * (48 + 4)   # coefficients in, levels out, job + cbf per block
         b["deblock"] = 2 * int(self.width * self.height * 1.5) * S * 2   # two passes, each reads and writes the picture once
         return b
