@@ -1065,6 +1065,8 @@ def main():
                        "integer_me": ("sad4 jobs (the reference's per-pattern calls)" if args.ime == "sad4" else
                                       f"{len(wl.me_search)} SAD surfaces of (2*{args.ime_range}+1)^2 candidates instead of "
                                       f"{len(wl.sad4)} SAD4 calls"),
+                       "quantiser": ("Rdoq::runQuantisation on the device between tu_forward and tu_reconstruct (speed=medium has RDOQ on)" if dev.rdoq else
+                                     "havoc_quantize in the chain (speed=fast)" if args.mix == "ai" else "levels pre-computed once, untimed (--rdoq 0)"),
                        "parallelism": "single GPU"},
             "timing": {"timed_blocks": len(blocks), "block_seconds_median": round(blk, 6), "block_seconds_min": round(min(blocks), 6),
                        "block_seconds_max": round(max(blocks), 6), "seconds_measured": round(sum(blocks), 4),
@@ -1113,6 +1115,25 @@ def main():
                     "steps": ksteps, "timed_blocks": len(xb), "calls_per_frame": int(sum(xs[0][2].counts.values())), "checksum": xs[0][3].checksum()}}
             except Exception as e:   # the headline line stands on its own
                 out["extra"] = {"error": repr(e)}
+            if args.rdoq:
+                # round 1's step for continuity: the same picture with the levels made once, untimed, by havoc_quantize (--rdoq 0)
+                try:
+                    import copy
+                    a0 = copy.copy(args)
+                    a0.rdoq = 0
+                    xs = build_contexts(a0, torch, Havoc, FrameWorkload, local, args.res, args.bit_depth, args.qp, "ra", args.seed, inflight, min(args.tune, 8))
+                    ksteps = 50
+
+                    def yblock(_b, xs=xs):
+                        for i in range(ksteps):
+                            xs[i % len(xs)][1].graph_launch(xs[i % len(xs)][4])
+                    yblock(0)
+                    yb = timed_blocks(torch, dist, 1, ksteps, 0.3, yblock)
+                    out.setdefault("extra", {})["same picture without RDOQ in the timed chain (--rdoq 0: round 1's step)"] = {
+                        "value": round(ksteps / float(np.median(yb)), 3), "unit": "frames/s", "ms_per_step": round(float(np.median(yb)) / ksteps * 1e3, 4),
+                        "steps": ksteps, "timed_blocks": len(yb)}
+                except Exception as e:
+                    out.setdefault("extra", {})["rdoq0_error"] = repr(e)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, dev)
         print(json.dumps(out))

@@ -1,5 +1,5 @@
 """Isolated timing of havoc_mi355x_rdoq on the 1080p workload's TU tables (coefficients made by tu_forward on the device).
-usage: python profiles/rdoq_bench.py [reps]      (HAVOC_RDOQ_STAGES=n stops the kernel after stage n: diagnostic)"""
+usage: python profiles/rdoq_bench.py [reps]"""
 import json
 import os
 import sys
@@ -29,5 +29,4 @@ for name, fn in dev.launches:
     out.setdefault("ms", []).append(round(hv.timer_stop_ms() / reps, 4))
 out["total_ms"] = round(sum(out["ms"]), 4)
 out["groups"] = [f"{k}:{len(g['jobs'])}" for k, g in sorted(dev.tu.items(), reverse=True)]
-out["stages"] = os.environ.get("HAVOC_RDOQ_STAGES", "all")
 print(json.dumps(out))

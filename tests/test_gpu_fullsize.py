@@ -150,7 +150,7 @@ def _parity_vs_reference(hv, res, bit_depth, qp, mix="ra", seed=11, min_values=1
     dev = bench.DeviceFrame(hv, wl)
     dev.step()
     hv.sync()
-    r = bench.cpu_baseline(argparse.Namespace(res=f"{res[0]}x{res[1]}", bit_depth=bit_depth, seed=seed, qp=qp, mix=mix), dev)
+    r = bench.cpu_baseline(argparse.Namespace(res=f"{res[0]}x{res[1]}", bit_depth=bit_depth, seed=seed, qp=qp, mix=mix, rdoq=1), dev)
     assert r is not None and r["kind"] == "reference"
     p = r["parity_vs_reference"]
     assert "error" not in p, p
@@ -162,9 +162,10 @@ def test_full_size_results_equal_the_reference_library(hv):
     """every 4th job of the 1080p frame (BASELINE.json configs[1]: 8-bit QP32) through the reference's own havoc functions
     (oracle/_ref, built from the reference sources by oracle/Makefile; x86 JIT tables) on the host, against the GPU results
     of the same jobs: SAD4, SAD, PU SATD, uni / bi interpolations (luma + chroma), SubtractBi, sub-pel candidate costs, intra
-    predictions, 35-mode intra costs, forward coefficients, quantised levels, reconstructions and their SSDs"""
+    predictions, 35-mode intra costs, forward coefficients, the levels and coded-block flags of Rdoq::runQuantisation (the
+    reference's own Rdoq.cpp), reconstructions and their SSDs"""
     p = _parity_vs_reference(hv, (1920, 1080), 8, 32)
-    for name in ("pred_bi8", "pred_bi4", "subtract_bi", "rec_3_0", "ssd_3_0", "level_2_1"):
+    for name in ("pred_bi8", "pred_bi4", "subtract_bi", "rec_3_0", "ssd_3_0", "level_2_1", "cbf_5_0", "cbf_2_1"):
         assert name in p["what"], name
 
 
