@@ -767,21 +767,46 @@ def hbm_traffic_from_profiles(group, S):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.csv")))
     if not files:
         return None
-    prefix = {"sad4": f"k_sad<{S}, 4>", "sad": f"k_sad<{S}, 1>", "interp_planes": "k_interp_planes<", "intra_satd35": "k_intra_satd35<",
-              "intra": "k_intra<", "residual": "k_residual<", "transform": "k_transform<", "quantize_inverse": "k_quantize_inverse",
-              "inverse_transform_add": "k_inverse_transform<", "ssd": "k_ssd<", "subtract_bi": "k_subtract_bi<",
-              "subpel_satd": "k_subpel_satd<"}.get(group)
+    prefix = _kernel_prefix(group, S)
     if prefix is None:
         return None
     total, n = 0.0, 0
     for row in csv.DictReader(open(files[-1])):
-        if row["Kernel"].startswith(prefix):
+        if prefix in row["Kernel"]:
             try:
                 total += float(row.get("FETCH_SIZE_bytes_per_launch") or 0) + float(row.get("WRITE_SIZE_bytes_per_launch") or 0)
                 n += 1
             except ValueError:
                 pass
     return round(total / n) if n else None
+
+
+def valu_busy_from_profiles(group, S):
+    """VALU busy % of the group's kernel(s) from the newest profiles/r*_sq_counters.csv (rocprofv3 --pmc passes of this bench,
+    profiles/collect.sh: 100 * 4 * SQ_ACTIVE_INST_VALU / 1024 SIMDs / busy cycles), weighted by busy time; None without a profile"""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sq_counters.csv")))
+    prefix = _kernel_prefix(group, S)
+    if not files or prefix is None:
+        return None
+    num = den = 0.0
+    for row in csv.DictReader(open(files[-1])):
+        if prefix in row["Kernel"]:
+            try:
+                t = float(row["busy_us_at_2.4GHz"])
+                num += float(row["VALUBusy_pct"]) * t
+                den += t
+            except (KeyError, ValueError):
+                pass
+    return round(num / den, 2) if den else None
+
+
+def _kernel_prefix(group, S):
+    return {"sad4": f"k_sad<{S}, 4>", "sad": f"k_sad<{S}, 1>", "interp_planes": "k_interp_planes<", "intra_satd35": "k_intra_satd35<",
+              "intra": "k_intra<", "residual": "k_residual<", "transform": "k_transform<", "quantize_inverse": "k_quantize_inverse",
+              "inverse_transform_add": "k_inverse_transform<", "ssd": "k_ssd<", "subtract_bi": "k_subtract_bi<",
+              "subpel_satd": "k_subpel_satd<", "rdoq": "k_rdoq_walk<", "deblock": "k_deblock<"}.get(group)
 
 
 def build_contexts(args, torch, Havoc, FrameWorkload, local, res, bit_depth, qp, mix, seed0, count, tune):
@@ -1076,7 +1101,11 @@ def main():
                          "traffic_source": "profiles/r*_hbm_traffic.csv: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench "
                                            "(profiles/collect.sh), FETCH_SIZE x2 per the gfx950 note; not re-measured in this run",
                          "launch_ms": round(ktimes[dom] / kcount[dom], 5), "launches_per_step": kcount[dom],
-                         "algorithmic_bytes_per_step": kbytes[dom]},
+                         "algorithmic_bytes_per_step": kbytes[dom],
+                         "valu_busy_pct": valu_busy_from_profiles(dom, wl.S),
+                         "note": ("k_rdoq_walk is a chain of dependent integer decisions per transform block (4 bytes of traffic per coefficient): it is "
+                                  "bound by instruction issue and latency, not by HBM -- profiles/r02_sq_counters.csv has its instruction counts; the "
+                                  "HBM-bound kernels of the step are in whole_step.kernel_gbs") if dom == "rdoq" else None},
             "whole_step": {"algorithmic_bytes": total_bytes, "achieved_gbs": round(total_bytes / (ms_step * 1e-3) / 1e9, 2),
                            "kernel_ms": {k: round(v, 4) for k, v in sorted(ktimes.items(), key=lambda kv: -kv[1])},
                            "kernel_gbs": {k: round(kbytes[k] / (v * 1e-3) / 1e9, 1) for k, v in ktimes.items()}},

@@ -20,7 +20,7 @@ def find(d, suffix):
 
 
 def short(name):
-    name = name.replace("void ", "").replace("havoc_gpu::", "")
+    name = name.replace("void ", "").replace("havoc_gpu::", "").replace("(anonymous namespace)::", "")
     return name.split("(")[0]
 
 

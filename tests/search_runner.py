@@ -137,6 +137,23 @@ def main():
         s2 = cl.stats()
         got_bi = run_bi(cl)
         s3 = cl.stats()
+        # the reference calls its tables from one thread per CTU row (wavefront parallel processing): the same searches again,
+        # `--threads` host threads each walking a slice of the list through the SAME table set at the same time
+        from concurrent.futures import ThreadPoolExecutor
+
+        def threaded(sub, lst):
+            n, k = len(sub), max(1, args.threads)
+            cuts = [n * t // k for t in range(k + 1)]
+            out = np.zeros(n, st.RESULT_DT)
+            with ThreadPoolExecutor(k) as pool:
+                parts = list(pool.map(lambda t: cl.uni(par, planes[0], planes[1 + lst], stride, pad, sub, cuts[t], cuts[t + 1]), range(k)))
+            for t in range(k):
+                out[cuts[t]:cuts[t + 1]] = parts[t][cuts[t]:cuts[t + 1]]
+            return out
+        t0 = time.perf_counter()
+        got_mt = by_list(threaded)
+        t_mt = time.perf_counter() - t0
+        s4 = cl.stats()
         calls = int(expected["calls"].sum())
         # every SAD / SAD4 call is one table call; every interpolate + SATD call is 1 + tiles table calls
         table_calls = (s2[0] - s1[0]) + (s2[1] - s1[1])
@@ -150,6 +167,8 @@ def main():
                     "launches_per_search": round((s2[2] - s1[2]) / len(pus), 3), "us_per_table_call": round(t_uni / max(1, table_calls) * 1e6, 3),
                     "us_per_loop_call": round(t_uni / max(1, calls) * 1e6, 3)},
             "bi": {"searches": nbi, "served": s3[0] - s2[0], "one_job_path": s3[1] - s2[1], "launches": s3[2] - s2[2]},
+            "threaded": {"threads": args.threads, "mismatching_searches": same(got_mt, expected), "seconds": round(t_mt, 4),
+                         "served": s4[0] - s3[0], "one_job_path": s4[1] - s3[1], "launches": s4[2] - s3[2]},
         }
 
     if "batch" not in skip:

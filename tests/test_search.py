@@ -133,6 +133,8 @@ def _check_report(r, searches):
     assert c["uni"]["one_job_path"] == 0 and c["uni"]["served"] > 30 * searches
     assert c["uni"]["launches_per_search"] <= 3.0, c["uni"]
     assert c["bi"]["one_job_path"] == 0
+    # the same searches from many host threads at once through one table set (the reference's WPP threads share theirs)
+    assert c["threaded"]["threads"] >= 8 and c["threaded"]["mismatching_searches"] == [] and c["threaded"]["one_job_path"] == 0, c["threaded"]
     # unregistered planes still work: one launch per table call
     assert c["unregistered"]["launches"] == c["unregistered"]["table_calls"] > 0
     # the batch client needs a handful of launches for the whole picture, not per search
@@ -145,7 +147,7 @@ def _check_report(r, searches):
 def test_serve_layer_and_batch_client_host_logic_on_the_mock_device():
     """no GPU: libhavoc_classic.so's serve layer and libhavoc_search.so against tests/mock_device.c -- pointer -> picture
     look-up, surface / tile-SATD caches, unregistered source blocks (bi search), miss and replay rounds"""
-    r = _run("mock", "--searches", "140", "--bi", "24")
+    r = _run("mock", "--searches", "140", "--bi", "24", "--threads", "16")
     assert r["device"] == "mock"
     _check_report(r, 140)
 
@@ -154,7 +156,7 @@ def test_serve_layer_and_batch_client_host_logic_on_the_mock_device():
 @pytest.mark.gpu
 @pytest.mark.parametrize("bit_depth", [8, 10])
 def test_decisions_on_the_gpu_equal_the_reference_640x360(bit_depth):
-    r = _run("real", "--searches", "400", "--bi", "60", "--bit-depth", str(bit_depth))
+    r = _run("real", "--searches", "400", "--bi", "60", "--bit-depth", str(bit_depth), "--threads", "16")
     _check_report(r, 400)
     assert r["classic"]["uni"]["us_per_table_call"] < 20.0, r["classic"]["uni"]   # vs 43 us per call through the one-job path
 
