@@ -46,7 +46,7 @@ struct Block
     const int32_t *bits;      // LDS: kEntropyBits
     int stateStride;
     int64_t lambda;
-    int32_t distScale;
+    int distShift;            // distortion scale = 1 << distShift (Q16)
     int quantScale, quantShift, invScale, invShift, invOffset;
     int cIdx, scanIdx;
     uint64_t scan4;           // the 4x4 scan as 16 nibbles x | y << 2
@@ -92,8 +92,12 @@ __host__ __device__ constexpr uint64_t scan4Nibbles(int scanIdx)
 // Rdoq.cpp:710: number of ones in the prefix of a last-significant coordinate: 0 1 2 3 4 4 5 5 6 6 6 6 7 7 7 7 8 x 8, 9 x 8
 __device__ __forceinline__ int lastPrefixLength(int c) { return c < 4 ? c : (c < 8 ? 4 + ((c - 4) >> 1) : (c < 16 ? 6 + ((c - 8) >> 2) : 8 + ((c - 16) >> 3))); }
 
+// the four context-coded bin costs a level's binarisation can touch: coeff_abs_level_greater1_flag = 0 / 1 in its current
+// context and coeff_abs_level_greater2_flag = 0 / 1; looked up when the contexts change, not per candidate level
+struct FlagBits { int32_t g1zero, g1one, g2zero, g2one; };
+
 // Rdoq.cpp:611-668 getLevelRateCost (without the lambda)
-__device__ __forceinline__ int32_t levelBits(const Block &b, int level, int g1, int g2, const LevelState &s)
+__device__ __forceinline__ int32_t levelBits(int level, const LevelState &s, const FlagBits &f)
 {
     int32_t rate = 32768;
     const int base = baseLevel(s);
@@ -109,21 +113,17 @@ __device__ __forceinline__ int32_t levelBits(const Block &b, int level, int g1, 
             while (symbol >= (1 << length)) symbol -= 1 << length++;
             rate += (3 + length + 1 - s.rice + length) << 15;
         }
-        if (s.nG1 < 8)
-        {
-            rate += bitsOf(b, HAVOC_RDOQ_CTX_GREATER1 + g1, 1);
-            if (s.nG2 < 1) rate += bitsOf(b, HAVOC_RDOQ_CTX_GREATER2 + g2, 1);
-        }
+        if (s.nG1 < 8) rate += f.g1one + (s.nG2 < 1 ? f.g2one : 0);
     }
     else if (level == 1)
-        rate += bitsOf(b, HAVOC_RDOQ_CTX_GREATER1 + g1, 0);
+        rate += f.g1zero;
     else if (level == 2)
-        rate += bitsOf(b, HAVOC_RDOQ_CTX_GREATER1 + g1, 1) + bitsOf(b, HAVOC_RDOQ_CTX_GREATER2 + g2, 0);
+        rate += f.g1one + f.g2zero;
     return rate;
 }
 
 // Rdoq.cpp:819-885 getLevelRate
-__device__ __forceinline__ int levelRate(const Block &b, int level, int g1, int g2, const LevelState &s)
+__device__ __forceinline__ int levelRate(int level, const LevelState &s, const FlagBits &f)
 {
     int rate = 0;
     const int base = baseLevel(s);
@@ -141,16 +141,12 @@ __device__ __forceinline__ int levelRate(const Block &b, int level, int g1, int 
             symbol = maxVlc + 1;
         }
         rate += (min(symbol >> (s.rice + 1), prefixMax) + s.rice) << 15;
-        if (s.nG1 < 8)
-        {
-            rate += bitsOf(b, HAVOC_RDOQ_CTX_GREATER1 + g1, 1);
-            if (s.nG2 < 1) rate += bitsOf(b, HAVOC_RDOQ_CTX_GREATER2 + g2, 1);
-        }
+        if (s.nG1 < 8) rate += f.g1one + (s.nG2 < 1 ? f.g2one : 0);
     }
     else if (level == 1)
-        rate += bitsOf(b, HAVOC_RDOQ_CTX_GREATER1 + g1, 0);
+        rate += f.g1zero;
     else if (level == 2)
-        rate += bitsOf(b, HAVOC_RDOQ_CTX_GREATER1 + g1, 1) + bitsOf(b, HAVOC_RDOQ_CTX_GREATER2 + g2, 0);
+        rate += f.g1one + f.g2zero;
     return rate;
 }
 
@@ -246,12 +242,18 @@ __device__ __forceinline__ WalkResult walkGroup(const Block &b, WalkShared &sh, 
     int nonZeroAbovePos0 = 0;
     int64_t gSig = 0, gSigPos0 = 0, gCoded = 0, gDist0 = 0;
     bool any = false;
+    const int g1base = HAVOC_RDOQ_CTX_GREATER1 + 4 * st.ctxSet + (b.cIdx ? 16 : 0), g2 = HAVOC_RDOQ_CTX_GREATER2 + st.ctxSet + (b.cIdx ? 4 : 0);
+    FlagBits fb;      // the context set is fixed for the group; the greater1 context moves with c1
+    fb.g1zero = bitsOf(b, g1base + st.c1, 0);
+    fb.g1one = bitsOf(b, g1base + st.c1, 1);
+    fb.g2zero = bitsOf(b, g2, 0);
+    fb.g2one = bitsOf(b, g2, 1);
 
     for (int i = 15; i >= 0; --i)
     {
         const int nib = (int)(b.scan4 >> (4 * i)) & 15, x = (gx << 2) + (nib & 3), y = (gy << 2) + (nib >> 2);
         const int a = abs((int)sh.coef[nib][lane]);
-        const int64_t dist0 = (int64_t)(a * a) * b.distScale;
+        const int64_t dist0 = (int64_t)(a * a) << b.distShift;
         r.dist0 += dist0;
         const int sp = g * 16 + i;
         if (sp > firstPos)
@@ -264,7 +266,6 @@ __device__ __forceinline__ WalkResult walkGroup(const Block &b, WalkShared &sh, 
         const int scaled = a * b.quantScale;
         const int level = (scaled + (1 << (b.quantShift - 1))) >> b.quantShift;
         const bool first = sp == firstPos;
-        const int g1 = 4 * st.ctxSet + st.c1 + (b.cIdx ? 16 : 0), g2 = st.ctxSet + (b.cIdx ? 4 : 0);
         const int sc = HAVOC_RDOQ_CTX_SIG + sigCtx<LOG2>(neighbours, b.scanIdx, x, y, b.cIdx);
         const int32_t sigZero = first ? 0 : bitsOf(b, sc, 0), sigOneBits = first ? 0 : bitsOf(b, sc, 1);
 
@@ -284,7 +285,7 @@ __device__ __forceinline__ WalkResult walkGroup(const Block &b, WalkShared &sh, 
             {
                 const int rebuilt = clip16((clip16(l) * b.invScale + b.invOffset) >> b.invShift);
                 const int32_t err = a - rebuilt;
-                const int64_t cost = (int64_t)(int32_t)((uint32_t)err * (uint32_t)err) * b.distScale + b.lambda * levelBits(b, l, g1, g2, st) + sigOne;
+                const int64_t cost = ((int64_t)(int32_t)((uint32_t)err * (uint32_t)err) << b.distShift) + b.lambda * levelBits(l, st, fb) + sigOne;
                 if (cost < costCoded)
                 {
                     kept = l;
@@ -299,12 +300,12 @@ __device__ __forceinline__ WalkResult walkGroup(const Block &b, WalkShared &sh, 
         sh.rec.kept[i][lane] = (int16_t)kept;
         if (kept > 0)
         {
-            const int now = levelRate(b, kept, g1, g2, st);
-            sh.rec.costUp[i][lane] = factor * -du + levelRate(b, kept + 1, g1, g2, st) - now;
-            sh.rec.costDown[i][lane] = factor * du + levelRate(b, kept - 1, g1, g2, st) - now - (kept == 1 ? (1 << 15) + sigDelta : 0);
+            const int now = levelRate(kept, st, fb);
+            sh.rec.costUp[i][lane] = factor * -du + levelRate(kept + 1, st, fb) - now;
+            sh.rec.costDown[i][lane] = factor * du + levelRate(kept - 1, st, fb) - now - (kept == 1 ? (1 << 15) + sigDelta : 0);
         }
         else
-            sh.rec.costUp[i][lane] = factor * -abs(du) + (1 << 15) + bitsOf(b, HAVOC_RDOQ_CTX_GREATER1 + g1, 0) + sigDelta;
+            sh.rec.costUp[i][lane] = factor * -abs(du) + (1 << 15) + fb.g1zero + sigDelta;
         if (kept >= baseLevel(st) && kept > 3 * (1 << st.rice)) st.rice = min(st.rice + 1, 4);      // Rdoq.cpp:773-800
         if (kept >= 1) st.nG1++;
         if (kept > 1)
@@ -314,6 +315,11 @@ __device__ __forceinline__ WalkResult walkGroup(const Block &b, WalkShared &sh, 
         }
         else if (st.c1 < 3 && st.c1 > 0 && kept)
             st.c1++;
+        if (kept)
+        {
+            fb.g1zero = bitsOf(b, g1base + st.c1, 0);
+            fb.g1one = bitsOf(b, g1base + st.c1, 1);
+        }
         gSig += costSig;
         if (i == 0) gSigPos0 = costSig;
         if (stored)
@@ -513,7 +519,7 @@ __global__ __launch_bounds__(64) void k_rdoq_walk(int16_t *__restrict__ dstAll, 
     b.bits = sh.bits;
     b.lambda = job.lambda_q16;
     const int transformShift = 15 - bitDepth - LOG2, distShift = 15 - 2 * transformShift - 2 * (bitDepth - 8) + 16;   // Rdoq.h:163-187
-    b.distScale = 1 << distShift;
+    b.distShift = distShift;
     b.invShift = 6 - transformShift;
     b.invOffset = 1 << (b.invShift - 1);
     b.quantScale = job.quant_scale;
