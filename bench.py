@@ -1001,9 +1001,10 @@ def main():
         ups = [dev.luma[:wl.plane_len], dev.chroma[:wl.cplane_len], dev.j_sad4, dev.j_sad, dev.j_sbi, dev.j_satd]
         ups += [g["jobs"] for g in dev.subpel_planes.values()] + [g["jobs"] for g in dev.isearch.values()] + [g["jobs"] for g in dev.intra.values()]
         ups += [g["nb"] for g in dev.isearch.values()] + [g["nb"] for g in dev.intra.values()]
-        ups += [t for g in dev.tu.values() for t in (g["fjobs"], g["level"])]
+        # (with RDOQ on the device neither the coefficients nor the levels cross the link: only the coded-block flags come down)
+        ups += [t for g in dev.tu.values() for t in ((g["fjobs"],) if dev.rdoq else (g["fjobs"], g["level"]))]
         downs = [dev.o_sad4, dev.o_sad, dev.o_satd] + [g["cost"] for g in dev.subpel_planes.values()] + [g["cost"] for g in dev.isearch.values()]
-        downs += [t for g in dev.tu.values() for t in (g["coef"], g["ossd"])]
+        downs += [t for g in dev.tu.values() for t in ((g["cbf"], g["ossd"]) if dev.rdoq else (g["coef"], g["ossd"]))]
         host_io = ([(t, torch.empty_like(t, device="cpu").pin_memory()) for t in ups],
                    [(t, torch.empty_like(t, device="cpu").pin_memory()) for t in downs])
         for t, hb in host_io[0]:
