@@ -396,7 +396,7 @@ enum {
     HAVOC_RDOQ_CTX_BYTES = 128
 };
 typedef struct {
-    int32_t dst_off, src_off;          /* n*n contiguous int16 levels (out) / coefficients (in) */
+    int32_t dst_off, src_off;          /* n*n contiguous int16 levels (out) / coefficients (in); multiples of 4 (8-byte rows) */
     int32_t quant_scale, quant_shift;  /* runQuantisation's quantiserScale / quantiserShift */
     int32_t inv_scale;                 /* the constructor's invQuantScale */
     int32_t lambda_q16, sdh_factor;    /* from havoc_mi355x_rdoq_lambda */
@@ -407,7 +407,8 @@ typedef struct {
 } havoc_mi355x_rdoq_job; /* 48 bytes */
 /* the two integers the Rdoq constructor derives from the floating-point lambda (turing/Rdoq.h:163-167); host-side, no device work */
 void havoc_mi355x_rdoq_lambda(double lambda, int inv_scale, int32_t *lambda_q16, int32_t *sdh_factor);
-/* d_cbf[i] = runQuantisation's return value (OR of the kept absolute levels) */
+/* d_cbf[i] = runQuantisation's return value (OR of the kept absolute levels).  d_dst and d_src are different buffers, as in the
+ * reference (quantizedCoefficients vs coefficients, Reconstruct.cpp:276-277); every level of a job's block is written. */
 int havoc_mi355x_rdoq(havoc_mi355x_ctx *ctx, int bitDepth, int log2TrafoSize, int16_t *d_dst, const int16_t *d_src, const uint8_t *d_states,
                       const havoc_mi355x_rdoq_job *d_jobs, int njobs, int32_t *d_cbf);
 

@@ -96,58 +96,30 @@ __device__ __forceinline__ int lastPrefixLength(int c) { return c < 4 ? c : (c <
 // context and coeff_abs_level_greater2_flag = 0 / 1; looked up when the contexts change, not per candidate level
 struct FlagBits { int32_t g1zero, g1one, g2zero, g2one; };
 
-// Rdoq.cpp:611-668 getLevelRateCost (without the lambda)
+// Rdoq.cpp:611-668 getLevelRateCost (without the lambda), branch free.  The escape loop `while (symbol >= (1 << length))
+// symbol -= 1 << length++` ends with length = floor(log2(symbol + (1 << rice))).
 __device__ __forceinline__ int32_t levelBits(int level, const LevelState &s, const FlagBits &f)
 {
-    int32_t rate = 32768;
-    const int base = baseLevel(s);
-    if (level >= base)
-    {
-        int symbol = level - base, length;
-        if (symbol < (3 << s.rice))
-            rate += ((symbol >> s.rice) + 1 + s.rice) << 15;
-        else
-        {
-            length = s.rice;
-            symbol -= 3 << s.rice;
-            while (symbol >= (1 << length)) symbol -= 1 << length++;
-            rate += (3 + length + 1 - s.rice + length) << 15;
-        }
-        if (s.nG1 < 8) rate += f.g1one + (s.nG2 < 1 ? f.g2one : 0);
-    }
-    else if (level == 1)
-        rate += f.g1zero;
-    else if (level == 2)
-        rate += f.g1one + f.g2zero;
-    return rate;
+    const int base = baseLevel(s), symbol = level - base, rest = symbol - (3 << s.rice);
+    const int length = 31 - __clz(max(rest, 0) + (1 << s.rice));
+    const int bins = rest < 0 ? (symbol >> s.rice) + 1 + s.rice : 3 + length + 1 - s.rice + length;
+    const int32_t coded = (bins << 15) + (s.nG1 < 8 ? f.g1one + (s.nG2 < 1 ? f.g2one : 0) : 0);
+    const int32_t small = level == 1 ? f.g1zero : (level == 2 ? f.g1one + f.g2zero : 0);
+    return 32768 + (symbol >= 0 ? coded : small);
 }
 
-// Rdoq.cpp:819-885 getLevelRate
+// Rdoq.cpp:819-885 getLevelRate, branch free.  `for (top = 2; rest >= top; top <<= 1) egs += 2` gives 1 + 2 floor(log2(rest)).
 __device__ __forceinline__ int levelRate(int level, const LevelState &s, const FlagBits &f)
 {
-    int rate = 0;
-    const int base = baseLevel(s);
-    if (level >= base)
-    {
-        int symbol = level - base;
-        const int maxVlc = (0x4e2e1a0e07ull >> (8 * s.rice)) & 0xff;           // 7, 14, 26, 46, 78
-        const int prefixMax = 8 - s.rice;                                      // 8, 7, 6, 5, 4
-        if (symbol > maxVlc)
-        {
-            const int rest = symbol - maxVlc;
-            int egs = 1;
-            for (int top = 2; rest >= top; top <<= 1) egs += 2;
-            rate += egs << 15;
-            symbol = maxVlc + 1;
-        }
-        rate += (min(symbol >> (s.rice + 1), prefixMax) + s.rice) << 15;
-        if (s.nG1 < 8) rate += f.g1one + (s.nG2 < 1 ? f.g2one : 0);
-    }
-    else if (level == 1)
-        rate += f.g1zero;
-    else if (level == 2)
-        rate += f.g1one + f.g2zero;
-    return rate;
+    const int base = baseLevel(s), symbol = level - base;
+    const int maxVlc = (0x4e2e1a0e07ull >> (8 * s.rice)) & 0xff;           // 7, 14, 26, 46, 78
+    const int prefixMax = 8 - s.rice;                                      // 8, 7, 6, 5, 4
+    const int rest = symbol - maxVlc;
+    const int escape = rest > 0 ? (1 + 2 * (31 - __clz(max(rest, 1)))) << 15 : 0;
+    const int capped = rest > 0 ? maxVlc + 1 : symbol;
+    const int coded = escape + ((min(capped >> (s.rice + 1), prefixMax) + s.rice) << 15) + (s.nG1 < 8 ? f.g1one + (s.nG2 < 1 ? f.g2one : 0) : 0);
+    const int small = level == 1 ? f.g1zero : (level == 2 ? f.g1one + f.g2zero : 0);
+    return symbol >= 0 ? coded : small;
 }
 
 // Rdoq.cpp:517-603 getCoeffSigCtxInc
@@ -207,6 +179,7 @@ struct WalkShared
     uint8_t states[HAVOC_RDOQ_CTX_BYTES][64];     // [context][lane]
     int32_t lastBits[2][10][64];                  // bits of a last_sig_coeff_{x,y} coordinate whose prefix has k ones (Rdoq.cpp:706-763)
     int16_t coef[16][64];                         // the current group's coefficients, raster order within the group
+    uint32_t pre[16][64];                         // per position: significance context << 25 | flag bits of the zero levels above it
     uint8_t rasterOf[3][64];                      // scan index -> raster group position, per scan type
     uint64_t mask[64];                            // non-zero groups of each block (bit = raster group position)
     int64_t sumSq[64];                            // sum of squared coefficients of each block
@@ -223,10 +196,38 @@ struct WalkResult
     int coded, carry;
 };
 
-// Steps 1 and 2 for one group as processGroup, with the group's share of step 3 (Rdoq.cpp:356-399) and the two cost terms of
-// sign-data hiding (Rdoq.cpp:950-957, :980) folded into the same pass over the 16 coefficients.
+// Rdoq.cpp:517-603 for LOG2 > 2: the position-dependent part of the significance context (0, 1 or 2) for every position of
+// a 4x4 group, two bits per raster position x | y << 2, given which of the right / below groups are coded
+__host__ __device__ constexpr uint32_t sigPattern(int neighbours)
+{
+    uint32_t v = 0;
+    for (int yp = 0; yp < 4; ++yp)
+        for (int xp = 0; xp < 4; ++xp)
+        {
+            const int inc = neighbours == 0 ? (xp + yp == 0 ? 2 : (xp + yp < 3 ? 1 : 0))
+                          : neighbours == 1 ? (yp == 0 ? 2 : (yp == 1 ? 1 : 0))
+                          : neighbours == 2 ? (xp == 0 ? 2 : (xp == 1 ? 1 : 0)) : 2;
+            v |= (uint32_t)inc << (2 * (xp | yp << 2));
+        }
+    return v;
+}
+
+// what sign-data hiding needs beside the records: which positions were inside the coded range, the greater1 context each
+// zero level would have been coded in (c1, two bits per position) and the cost of a greater1 flag = 0 in each of the four
+struct SdhAux { uint32_t active, c1At; int32_t g1zero[4]; };
+__device__ __forceinline__ int32_t pick4(const int32_t (&v)[4], int k) { return k == 0 ? v[0] : (k == 1 ? v[1] : (k == 2 ? v[2] : v[3])); }      // registers, not scratch
+
+// Steps 1 and 2 of runQuantisation for one coefficient group (Rdoq.cpp:83-298), with the group's share of step 3
+// (Rdoq.cpp:356-399) and the cost terms of sign-data hiding (Rdoq.cpp:950-957, :980) folded in.  Two loops instead of the
+// reference's one: a level that rounds to zero never changes the entropy coder's level state, so
+//   loop Z  walks the 16 positions once doing only what a zero level needs (energy, significance context, its flag cost as a
+//           running prefix), and notes which positions hold a non-zero rounded level;
+//   loop B  visits only those, in reverse scan order, with the state machine, the two-candidate level decision, the three
+//           level rates of sign-data hiding and the last-position candidate.
+// A wavefront's trip count of loop B is the largest number of non-zero levels any of its 64 blocks has in the group at hand.
 template <int LOG2>
-__device__ __forceinline__ WalkResult walkGroup(const Block &b, WalkShared &sh, int lane, int g, int gx, int gy, int firstPos, int caseBits, int factor)
+__device__ __forceinline__ WalkResult walkGroup(const Block &b, WalkShared &sh, int lane, int g, int gx, int gy, int firstPos, int caseBits, int factor,
+                                                SdhAux &aux)
 {
     WalkResult r;
     r.cost = r.sigCost = r.dist0 = r.q = 0;
@@ -239,35 +240,82 @@ __device__ __forceinline__ WalkResult walkGroup(const Block &b, WalkShared &sh, 
     st.c1 = 1;
     st.nG1 = st.nG2 = st.rice = 0;
     st.ctxSet = g == firstGroup ? ((firstPos < 16 || b.cIdx) ? 0 : 2) : ((g == 0 || b.cIdx) ? 0 : 2) + (caseBits >> 2);
-    int nonZeroAbovePos0 = 0;
-    int64_t gSig = 0, gSigPos0 = 0, gCoded = 0, gDist0 = 0;
-    bool any = false;
     const int g1base = HAVOC_RDOQ_CTX_GREATER1 + 4 * st.ctxSet + (b.cIdx ? 16 : 0), g2 = HAVOC_RDOQ_CTX_GREATER2 + st.ctxSet + (b.cIdx ? 4 : 0);
-    FlagBits fb;      // the context set is fixed for the group; the greater1 context moves with c1
-    fb.g1zero = bitsOf(b, g1base + st.c1, 0);
-    fb.g1one = bitsOf(b, g1base + st.c1, 1);
+    int32_t g1one[4];      // the context set is fixed for the group; the greater1 context moves with c1
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+    {
+        aux.g1zero[c] = bitsOf(b, g1base + c, 0);
+        g1one[c] = bitsOf(b, g1base + c, 1);
+    }
+    FlagBits fb;
     fb.g2zero = bitsOf(b, g2, 0);
     fb.g2one = bitsOf(b, g2, 1);
+    const uint32_t active = g < firstGroup ? 0xffffu : (2u << (firstPos & 15)) - 1;      // positions at or below the first non-zero level
+    aux.active = active;
 
+    // significance contexts of the group (Rdoq.cpp:517-603)
+    const int sigChroma = b.cIdx ? 27 : 0;
+    const int sigGroup = sigChroma + (b.cIdx == 0 ? ((gx + gy > 0 ? 3 : 0) + (LOG2 == 3 ? (b.scanIdx == 0 ? 9 : 15) : 21)) : (LOG2 == 3 ? 9 : 12));
+    const uint32_t pattern = neighbours == 0 ? sigPattern(0) : neighbours == 1 ? sigPattern(1) : neighbours == 2 ? sigPattern(2) : sigPattern(3);
+
+    // ---- loop Z ----
+    uint32_t nzMask = 0, sumAll = 0, sumAllHi = 0;
+    int32_t zeroBits = 0;      // bits of the significance flags (= 0) of the zero levels met so far
+    const int rnd = 1 << (b.quantShift - 1);
     for (int i = 15; i >= 0; --i)
     {
-        const int nib = (int)(b.scan4 >> (4 * i)) & 15, x = (gx << 2) + (nib & 3), y = (gy << 2) + (nib >> 2);
-        const int a = abs((int)sh.coef[nib][lane]);
-        const int64_t dist0 = (int64_t)(a * a) << b.distShift;
-        r.dist0 += dist0;
-        const int sp = g * 16 + i;
-        if (sp > firstPos)
+        const int nib = (int)(b.scan4 >> (4 * i)) & 15;
+        const uint32_t a = (uint32_t)abs((int)sh.coef[nib][lane]), sq = a * a;
+        sumAll += sq & 0xffff;
+        sumAllHi += sq >> 16;
+        if (!((active >> i) & 1))
         {
-            r.cost += dist0;
             sh.rec.kept[i][lane] = 0;
             sh.rec.costUp[i][lane] = 1 << 15;
             continue;
         }
+        int ctx;
+        if (LOG2 == 2) ctx = sigChroma + (int)((0x8877886654325410ull >> (4 * nib)) & 15);
+        else ctx = (gx + gy + nib == 0) ? sigChroma : sigGroup + (int)((pattern >> (2 * nib)) & 3);
+        ctx += HAVOC_RDOQ_CTX_SIG;
+        sh.pre[i][lane] = (uint32_t)ctx << 25 | (uint32_t)zeroBits;
+        const int scaled = (int)a * b.quantScale;
+        if (((scaled + rnd) >> b.quantShift) > 0)
+            nzMask |= 1u << i;
+        else
+        {
+            const int32_t z = bitsOf(b, ctx, 0);
+            zeroBits += z;
+            sh.rec.kept[i][lane] = 0;
+            sh.rec.costUp[i][lane] = factor * -(scaled >> (b.quantShift - 8)) + (1 << 15) + bitsOf(b, ctx, 1) - z;      // + g1zero[c1] when used
+        }
+    }
+    const int64_t sumSq = ((int64_t)sumAllHi << 16) + sumAll;
+    r.dist0 = sumSq << b.distShift;
+
+    // ---- loop B ----
+    int nonZeroAbovePos0 = 0;
+    int64_t gSig = 0, gSigPos0 = 0, gCoded = 0, gDist0 = 0, costB = 0, distB = 0, qB = 0;
+    bool any = false;
+    uint32_t c1At = 0x55555555u;      // c1 = 1 everywhere
+    for (uint32_t m = nzMask; m;)
+    {
+        const int i = 31 - __clz((int)m);
+        m ^= 1u << i;
+        const int nib = (int)(b.scan4 >> (4 * i)) & 15, x = (gx << 2) + (nib & 3), y = (gy << 2) + (nib >> 2);
+        const int a = abs((int)sh.coef[nib][lane]);
+        const int64_t dist0 = (int64_t)(a * a) << b.distShift;
+        const int sp = g * 16 + i;
         const int scaled = a * b.quantScale;
-        const int level = (scaled + (1 << (b.quantShift - 1))) >> b.quantShift;
+        const int level = (scaled + rnd) >> b.quantShift;
         const bool first = sp == firstPos;
-        const int sc = HAVOC_RDOQ_CTX_SIG + sigCtx<LOG2>(neighbours, b.scanIdx, x, y, b.cIdx);
+        const uint32_t pk = sh.pre[i][lane];
+        const int sc = (int)(pk >> 25);
+        const int64_t zerosAbove = b.lambda * (int32_t)(pk & 0x1ffffff);
         const int32_t sigZero = first ? 0 : bitsOf(b, sc, 0), sigOneBits = first ? 0 : bitsOf(b, sc, 1);
+        fb.g1zero = pick4(aux.g1zero, st.c1);
+        fb.g1one = pick4(g1one, st.c1);
 
         int64_t costCoded, costSig = 0;      // Rdoq.cpp:456-515
         int kept = 0;
@@ -278,23 +326,21 @@ __device__ __forceinline__ WalkResult walkGroup(const Block &b, WalkShared &sh, 
         }
         else
             costCoded = INT64_MAX;
-        if (level > 0)
+        const int64_t sigOne = b.lambda * sigOneBits;
+        for (int l = level, lowest = level > 1 ? level - 1 : 1; l >= lowest; --l)
         {
-            const int64_t sigOne = b.lambda * sigOneBits;
-            for (int l = level, lowest = level > 1 ? level - 1 : 1; l >= lowest; --l)
+            const int rebuilt = clip16((clip16(l) * b.invScale + b.invOffset) >> b.invShift);
+            const int32_t err = a - rebuilt;
+            const int64_t cost = ((int64_t)(int32_t)((uint32_t)err * (uint32_t)err) << b.distShift) + b.lambda * levelBits(l, st, fb) + sigOne;
+            if (cost < costCoded)
             {
-                const int rebuilt = clip16((clip16(l) * b.invScale + b.invOffset) >> b.invShift);
-                const int32_t err = a - rebuilt;
-                const int64_t cost = ((int64_t)(int32_t)((uint32_t)err * (uint32_t)err) << b.distShift) + b.lambda * levelBits(l, st, fb) + sigOne;
-                if (cost < costCoded)
-                {
-                    kept = l;
-                    costCoded = cost;
-                    costSig = sigOne;
-                }
+                kept = l;
+                costCoded = cost;
+                costSig = sigOne;
             }
         }
-        r.cost += costCoded;
+        costB += costCoded;
+        distB += dist0;
         const int du = (scaled - (kept << b.quantShift)) >> (b.quantShift - 8), sigDelta = sigOneBits - sigZero;
         const int stored = (int16_t)kept;
         sh.rec.kept[i][lane] = (int16_t)kept;
@@ -305,7 +351,7 @@ __device__ __forceinline__ WalkResult walkGroup(const Block &b, WalkShared &sh, 
             sh.rec.costDown[i][lane] = factor * du + levelRate(kept - 1, st, fb) - now - (kept == 1 ? (1 << 15) + sigDelta : 0);
         }
         else
-            sh.rec.costUp[i][lane] = factor * -abs(du) + (1 << 15) + fb.g1zero + sigDelta;
+            sh.rec.costUp[i][lane] = factor * -abs(du) + (1 << 15) + sigDelta;      // + g1zero[c1] when used, like the other zero levels
         if (kept >= baseLevel(st) && kept > 3 * (1 << st.rice)) st.rice = min(st.rice + 1, 4);      // Rdoq.cpp:773-800
         if (kept >= 1) st.nG1++;
         if (kept > 1)
@@ -315,10 +361,9 @@ __device__ __forceinline__ WalkResult walkGroup(const Block &b, WalkShared &sh, 
         }
         else if (st.c1 < 3 && st.c1 > 0 && kept)
             st.c1++;
-        if (kept)
         {
-            fb.g1zero = bitsOf(b, g1base + st.c1, 0);
-            fb.g1one = bitsOf(b, g1base + st.c1, 1);
+            const uint32_t below = (1u << (2 * i)) - 1;      // every position still to come sees the new c1
+            c1At = (c1At & ~below) | ((0x55555555u * (uint32_t)st.c1) & below);
         }
         gSig += costSig;
         if (i == 0) gSigPos0 = costSig;
@@ -331,7 +376,7 @@ __device__ __forceinline__ WalkResult walkGroup(const Block &b, WalkShared &sh, 
             // candidate for the last significant position
             const int32_t rate = b.scanIdx == 2 ? sh.lastBits[0][lastPrefixLength(y)][lane] + sh.lastBits[1][lastPrefixLength(x)][lane]
                                                 : sh.lastBits[0][lastPrefixLength(x)][lane] + sh.lastBits[1][lastPrefixLength(y)][lane];
-            const int64_t total = r.q + b.lambda * rate - costSig;
+            const int64_t total = qB - zerosAbove + b.lambda * rate - costSig;
             r.groupOr |= stored;
             if (!r.localStop && total < r.localBest)
             {
@@ -341,11 +386,17 @@ __device__ __forceinline__ WalkResult walkGroup(const Block &b, WalkShared &sh, 
             }
             r.localOr |= stored;
             if (stored > 1) r.localStop = true;
-            r.q += dist0 - costCoded;
+            qB += dist0 - costCoded;
         }
         else
-            r.q -= costSig;
+            qB -= costSig;
     }
+    aux.c1At = c1At;
+    const int64_t zeroCost = b.lambda * zeroBits;
+    r.cost = (r.dist0 - distB) + zeroCost + costB;      // inactive and zero levels: their energy (+ the zero levels' flags); the others: their RD cost
+    r.q = qB - zeroCost;
+    gSig += zeroCost;
+    if (!(nzMask & 1)) gSigPos0 = zeroCost - b.lambda * (int32_t)(sh.pre[0][lane] & 0x1ffffff);      // position 0 is always inside the coded range
     r.carry = st.c1 == 0;
     r.coded = any;
     if (g == 0)
@@ -384,7 +435,7 @@ __device__ __forceinline__ WalkResult walkGroup(const Block &b, WalkShared &sh, 
 }
 
 // Rdoq.cpp:887-1023 for one group whose signed levels are in rec.kept[.][lane]
-__device__ __forceinline__ void hideSignsWalk(WalkShared &sh, int lane, const Block &b, bool lastGroup)
+__device__ __forceinline__ void hideSignsWalk(WalkShared &sh, int lane, const Block &b, bool lastGroup, const SdhAux &aux)
 {
     int first = 16, last = -1, sum = 0;
     for (int i = 0; i < 16; ++i)
@@ -422,7 +473,8 @@ __device__ __forceinline__ void hideSignsWalk(WalkShared &sh, int lane, const Bl
         }
         else
         {
-            cost = sh.rec.costUp[i][lane];
+            const int c1 = (int)(aux.c1At >> (2 * i)) & 3;
+            cost = sh.rec.costUp[i][lane] + (((aux.active >> i) & 1) ? pick4(aux.g1zero, c1) : 0);
             change = 1;
             if (i < first && (sh.coef[(int)(b.scan4 >> (4 * i)) & 15][lane] >= 0 ? 0 : 1) != signbit) cost = INT32_MAX;
         }
@@ -554,6 +606,7 @@ __global__ __launch_bounds__(64) void k_rdoq_walk(int16_t *__restrict__ dstAll, 
         }
     };
     // rec.kept (scan order, magnitudes) -> signs (Rdoq.cpp:418-428), sign-data hiding, the output block
+    SdhAux aux;
     auto finishGroup = [&](int g, int gx, int gy, int lastIdx, bool lastGroup) {
         for (int i = 0; i < 16; ++i)
         {
@@ -561,7 +614,7 @@ __global__ __launch_bounds__(64) void k_rdoq_walk(int16_t *__restrict__ dstAll, 
             if (sh.coef[(int)(b.scan4 >> (4 * i)) & 15][lane] < 0) v = -v;
             sh.rec.kept[i][lane] = (int16_t)v;
         }
-        if (job.sdh) hideSignsWalk(sh, lane, b, lastGroup);
+        if (job.sdh) hideSignsWalk(sh, lane, b, lastGroup, aux);
         for (int i = 0; i < 16; ++i) sh.coef[(int)(b.scan4 >> (4 * i)) & 15][lane] = sh.rec.kept[i][lane];      // coef doubles as the raster staging area
         for (int r = 0; r < 4; ++r)
         {
@@ -618,7 +671,7 @@ __global__ __launch_bounds__(64) void k_rdoq_walk(int16_t *__restrict__ dstAll, 
         {
             const int p = rasterOf[g], gx = p & (gw - 1), gy = p / gw;
             loadGroup(gx, gy);
-            const WalkResult r = walkGroup<LOG2>(b, sh, lane, g, gx, gy, firstPos, caseOf(coded, gx, gy, carry), job.sdh_factor);
+            const WalkResult r = walkGroup<LOG2>(b, sh, lane, g, gx, gy, firstPos, caseOf(coded, gx, gy, carry), job.sdh_factor, aux);
             costTu += r.cost;
             walkedDist0 += r.dist0;
             coded |= (uint64_t)r.coded << p;
@@ -665,7 +718,7 @@ __global__ __launch_bounds__(64) void k_rdoq_walk(int16_t *__restrict__ dstAll, 
         {
             const int p = rasterOf[lastGroup], gx = p & (gw - 1), gy = p / gw;
             loadGroup(gx, gy);
-            walkGroup<LOG2>(b, sh, lane, lastGroup, gx, gy, firstPos, caseOf(coded, gx, gy, (int)(carries >> lastGroup) & 1), job.sdh_factor);
+            walkGroup<LOG2>(b, sh, lane, lastGroup, gx, gy, firstPos, caseOf(coded, gx, gy, (int)(carries >> lastGroup) & 1), job.sdh_factor, aux);
             finishGroup(lastGroup, gx, gy, lastIdx, true);
         }
     }
