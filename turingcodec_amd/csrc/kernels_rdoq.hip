@@ -167,7 +167,7 @@ __device__ __forceinline__ int sigCtx(int neighbours, int scanIdx, int x, int y,
 // what sign-data hiding needs of the current group, [coefficient in scan order][lane]
 struct WalkRecords
 {
-    int16_t kept[16][64];
+    int16_t kept[16][64];       // magnitudes, by RASTER position x | y << 2 inside the group (the order they leave in)
     int32_t costUp[16][64];     // level != 0: factor * -deltaU + rateIncUp;  level == 0: factor * -|deltaU| + (1 << 15) + rateIncUp + sigRateDelta
     int32_t costDown[16][64];   // level != 0: factor * deltaU + rateIncDown - (level == 1 ? (1 << 15) + sigRateDelta : 0)
 };
@@ -214,7 +214,9 @@ __host__ __device__ constexpr uint32_t sigPattern(int neighbours)
 
 // what sign-data hiding needs beside the records: which positions were inside the coded range, the greater1 context each
 // zero level would have been coded in (c1, two bits per position) and the cost of a greater1 flag = 0 in each of the four
-struct SdhAux { uint32_t active, c1At; int32_t g1zero[4]; };
+// ... and where the kept levels are (scan-order bit masks: non-zero, odd) and which coefficients are negative (by scan position and
+// by raster position): the records hold magnitudes, the signs go on when the group is written out
+struct SdhAux { uint32_t active, c1At, keptMask, oddMask, negScan, negRaster; int32_t g1zero[4]; };
 __device__ __forceinline__ int32_t pick4(const int32_t (&v)[4], int k) { return k == 0 ? v[0] : (k == 1 ? v[1] : (k == 2 ? v[2] : v[3])); }      // registers, not scratch
 
 // Steps 1 and 2 of runQuantisation for one coefficient group (Rdoq.cpp:83-298), with the group's share of step 3
@@ -260,18 +262,21 @@ __device__ __forceinline__ WalkResult walkGroup(const Block &b, WalkShared &sh, 
     const uint32_t pattern = neighbours == 0 ? sigPattern(0) : neighbours == 1 ? sigPattern(1) : neighbours == 2 ? sigPattern(2) : sigPattern(3);
 
     // ---- loop Z ----
-    uint32_t nzMask = 0, sumAll = 0, sumAllHi = 0;
+    uint32_t nzMask = 0, sumAll = 0, sumAllHi = 0, negScan = 0, negRaster = 0;
     int32_t zeroBits = 0;      // bits of the significance flags (= 0) of the zero levels met so far
     const int rnd = 1 << (b.quantShift - 1);
     for (int i = 15; i >= 0; --i)
     {
         const int nib = (int)(b.scan4 >> (4 * i)) & 15;
-        const uint32_t a = (uint32_t)abs((int)sh.coef[nib][lane]), sq = a * a;
+        const int c = sh.coef[nib][lane];
+        const uint32_t a = (uint32_t)abs(c), sq = a * a;
+        negScan |= (uint32_t)(c < 0) << i;
+        negRaster |= (uint32_t)(c < 0) << nib;
         sumAll += sq & 0xffff;
         sumAllHi += sq >> 16;
         if (!((active >> i) & 1))
         {
-            sh.rec.kept[i][lane] = 0;
+            sh.rec.kept[nib][lane] = 0;
             sh.rec.costUp[i][lane] = 1 << 15;
             continue;
         }
@@ -287,7 +292,7 @@ __device__ __forceinline__ WalkResult walkGroup(const Block &b, WalkShared &sh, 
         {
             const int32_t z = bitsOf(b, ctx, 0);
             zeroBits += z;
-            sh.rec.kept[i][lane] = 0;
+            sh.rec.kept[nib][lane] = 0;
             sh.rec.costUp[i][lane] = factor * -(scaled >> (b.quantShift - 8)) + (1 << 15) + bitsOf(b, ctx, 1) - z;      // + g1zero[c1] when used
         }
     }
@@ -297,9 +302,9 @@ __device__ __forceinline__ WalkResult walkGroup(const Block &b, WalkShared &sh, 
     // ---- loop B ----
     int nonZeroAbovePos0 = 0;
     int64_t gSig = 0, gSigPos0 = 0, gCoded = 0, gDist0 = 0, costB = 0, distB = 0, qB = 0;
-    bool any = false;
     uint32_t c1At = 0x55555555u;      // c1 = 1 everywhere
-    for (uint32_t m = nzMask; m;)
+    uint32_t keptMask = 0, oddMask = 0;
+    for (uint32_t m = nzMask; m;)      // written with selects, not branches: 64 blocks run this body together
     {
         const int i = 31 - __clz((int)m);
         m ^= 1u << i;
@@ -313,92 +318,82 @@ __device__ __forceinline__ WalkResult walkGroup(const Block &b, WalkShared &sh, 
         const uint32_t pk = sh.pre[i][lane];
         const int sc = (int)(pk >> 25);
         const int64_t zerosAbove = b.lambda * (int32_t)(pk & 0x1ffffff);
-        const int32_t sigZero = first ? 0 : bitsOf(b, sc, 0), sigOneBits = first ? 0 : bitsOf(b, sc, 1);
+        const int32_t z0 = bitsOf(b, sc, 0), z1 = bitsOf(b, sc, 1);
+        const int32_t sigZero = first ? 0 : z0, sigOneBits = first ? 0 : z1;
         fb.g1zero = pick4(aux.g1zero, st.c1);
         fb.g1one = pick4(g1one, st.c1);
 
-        int64_t costCoded, costSig = 0;      // Rdoq.cpp:456-515
+        // Rdoq.cpp:456-515: drop (small levels only), keep, or lower by one
+        const bool droppable = !first && level < 3;
+        const int64_t sigOne = b.lambda * sigOneBits, dropSig = b.lambda * sigZero;
+        const int lower = level - 1;
+        const int32_t err1 = a - clip16((clip16(level) * b.invScale + b.invOffset) >> b.invShift);
+        const int32_t err2 = a - clip16((clip16(lower) * b.invScale + b.invOffset) >> b.invShift);
+        const int64_t cost1 = ((int64_t)(int32_t)((uint32_t)err1 * (uint32_t)err1) << b.distShift) + b.lambda * levelBits(level, st, fb) + sigOne;
+        const int64_t cost2 = lower >= 1 ? ((int64_t)(int32_t)((uint32_t)err2 * (uint32_t)err2) << b.distShift) + b.lambda * levelBits(lower, st, fb) + sigOne : INT64_MAX;
+        int64_t costCoded = droppable ? dist0 + dropSig : INT64_MAX, costSig = droppable ? dropSig : 0;
         int kept = 0;
-        if (!first && level < 3)
-        {
-            costSig = b.lambda * sigZero;
-            costCoded = dist0 + costSig;
-        }
-        else
-            costCoded = INT64_MAX;
-        const int64_t sigOne = b.lambda * sigOneBits;
-        for (int l = level, lowest = level > 1 ? level - 1 : 1; l >= lowest; --l)
-        {
-            const int rebuilt = clip16((clip16(l) * b.invScale + b.invOffset) >> b.invShift);
-            const int32_t err = a - rebuilt;
-            const int64_t cost = ((int64_t)(int32_t)((uint32_t)err * (uint32_t)err) << b.distShift) + b.lambda * levelBits(l, st, fb) + sigOne;
-            if (cost < costCoded)
-            {
-                kept = l;
-                costCoded = cost;
-                costSig = sigOne;
-            }
-        }
+        const bool take1 = cost1 < costCoded;
+        kept = take1 ? level : kept;
+        costSig = take1 ? sigOne : costSig;
+        costCoded = take1 ? cost1 : costCoded;
+        const bool take2 = cost2 < costCoded;
+        kept = take2 ? lower : kept;
+        costSig = take2 ? sigOne : costSig;
+        costCoded = take2 ? cost2 : costCoded;
+
         costB += costCoded;
         distB += dist0;
         const int du = (scaled - (kept << b.quantShift)) >> (b.quantShift - 8), sigDelta = sigOneBits - sigZero;
         const int stored = (int16_t)kept;
-        sh.rec.kept[i][lane] = (int16_t)kept;
-        if (kept > 0)
-        {
-            const int now = levelRate(kept, st, fb);
-            sh.rec.costUp[i][lane] = factor * -du + levelRate(kept + 1, st, fb) - now;
-            sh.rec.costDown[i][lane] = factor * du + levelRate(kept - 1, st, fb) - now - (kept == 1 ? (1 << 15) + sigDelta : 0);
-        }
-        else
-            sh.rec.costUp[i][lane] = factor * -abs(du) + (1 << 15) + sigDelta;      // + g1zero[c1] when used, like the other zero levels
-        if (kept >= baseLevel(st) && kept > 3 * (1 << st.rice)) st.rice = min(st.rice + 1, 4);      // Rdoq.cpp:773-800
-        if (kept >= 1) st.nG1++;
-        if (kept > 1)
-        {
-            st.c1 = 0;
-            st.nG2++;
-        }
-        else if (st.c1 < 3 && st.c1 > 0 && kept)
-            st.c1++;
+        const int now = levelRate(kept, st, fb);
+        const int upKept = factor * -du + levelRate(kept + 1, st, fb) - now;
+        const int upZero = factor * -abs(du) + (1 << 15) + sigDelta;      // + g1zero[c1] when used, like the other zero levels
+        sh.rec.kept[nib][lane] = (int16_t)kept;
+        keptMask |= (uint32_t)(stored != 0) << i;
+        oddMask |= (uint32_t)(stored & 1) << i;
+        sh.rec.costUp[i][lane] = kept > 0 ? upKept : upZero;
+        sh.rec.costDown[i][lane] = factor * du + levelRate(kept - 1, st, fb) - now - (kept == 1 ? (1 << 15) + sigDelta : 0);
+
+        // Rdoq.cpp:773-800
+        const bool grow = kept >= baseLevel(st) && kept > 3 * (1 << st.rice);
+        st.rice = grow ? min(st.rice + 1, 4) : st.rice;
+        st.nG1 += kept >= 1;
+        st.nG2 += kept > 1;
+        st.c1 = kept > 1 ? 0 : ((st.c1 < 3 && st.c1 > 0 && kept) ? st.c1 + 1 : st.c1);
         {
             const uint32_t below = (1u << (2 * i)) - 1;      // every position still to come sees the new c1
             c1At = (c1At & ~below) | ((0x55555555u * (uint32_t)st.c1) & below);
         }
         gSig += costSig;
-        if (i == 0) gSigPos0 = costSig;
-        if (stored)
-        {
-            any = true;
-            gCoded += costCoded - costSig;
-            gDist0 += dist0;
-            if (i) nonZeroAbovePos0++;
-            // candidate for the last significant position
-            const int32_t rate = b.scanIdx == 2 ? sh.lastBits[0][lastPrefixLength(y)][lane] + sh.lastBits[1][lastPrefixLength(x)][lane]
-                                                : sh.lastBits[0][lastPrefixLength(x)][lane] + sh.lastBits[1][lastPrefixLength(y)][lane];
-            const int64_t total = qB - zerosAbove + b.lambda * rate - costSig;
-            r.groupOr |= stored;
-            if (!r.localStop && total < r.localBest)
-            {
-                r.localBest = total;
-                r.localPos = sp;
-                r.localOr = 0;
-            }
-            r.localOr |= stored;
-            if (stored > 1) r.localStop = true;
-            qB += dist0 - costCoded;
-        }
-        else
-            qB -= costSig;
+        gSigPos0 = i == 0 ? costSig : gSigPos0;
+        gCoded += stored ? costCoded - costSig : 0;
+        gDist0 += stored ? dist0 : 0;
+        nonZeroAbovePos0 += (stored != 0) & (i != 0);
+        // candidate for the last significant position (Rdoq.cpp:356-399)
+        const int lx = lastPrefixLength(x), ly = lastPrefixLength(y);
+        const int32_t rate = sh.lastBits[0][b.scanIdx == 2 ? ly : lx][lane] + sh.lastBits[1][b.scanIdx == 2 ? lx : ly][lane];
+        const int64_t total = qB - zerosAbove + b.lambda * rate - costSig;
+        const bool better = stored != 0 && !r.localStop && total < r.localBest;
+        r.localBest = better ? total : r.localBest;
+        r.localPos = better ? sp : r.localPos;
+        r.localOr = (better ? 0 : r.localOr) | stored;
+        r.groupOr |= stored;
+        r.localStop |= stored > 1;
+        qB += stored ? dist0 - costCoded : -costSig;
     }
     aux.c1At = c1At;
+    aux.keptMask = keptMask;
+    aux.oddMask = oddMask;
+    aux.negScan = negScan;
+    aux.negRaster = negRaster;
     const int64_t zeroCost = b.lambda * zeroBits;
     r.cost = (r.dist0 - distB) + zeroCost + costB;      // inactive and zero levels: their energy (+ the zero levels' flags); the others: their RD cost
     r.q = qB - zeroCost;
     gSig += zeroCost;
     if (!(nzMask & 1)) gSigPos0 = zeroCost - b.lambda * (int32_t)(sh.pre[0][lane] & 0x1ffffff);      // position 0 is always inside the coded range
     r.carry = st.c1 == 0;
-    r.coded = any;
+    r.coded = keptMask != 0;
     if (g == 0)
     {
         r.coded = 1;
@@ -434,32 +429,24 @@ __device__ __forceinline__ WalkResult walkGroup(const Block &b, WalkShared &sh, 
     return r;
 }
 
-// Rdoq.cpp:887-1023 for one group whose signed levels are in rec.kept[.][lane]
-__device__ __forceinline__ void hideSignsWalk(WalkShared &sh, int lane, const Block &b, bool lastGroup, const SdhAux &aux)
+// Rdoq.cpp:887-1023 for one group.  Works on the magnitudes in rec.kept: a level's sign is its coefficient's, so "dst += change
+// for a non-negative coefficient, dst -= change otherwise" is magnitude += change; sum & 1 is the parity of the magnitudes.
+__device__ __forceinline__ void hideSignsWalk(WalkShared &sh, int lane, const Block &b, bool lastGroup, const SdhAux &aux, uint32_t keptMask)
 {
-    int first = 16, last = -1, sum = 0;
-    for (int i = 0; i < 16; ++i)
-    {
-        const int v = sh.rec.kept[i][lane];
-        sum += v;
-        if (v)
-        {
-            last = i;
-            if (first == 16) first = i;
-        }
-    }
+    if (!keptMask) return;
+    const int first = __ffs((int)keptMask) - 1, last = 31 - __clz((int)keptMask);
     if (last - first < 4) return;
-    const int signbit = sh.rec.kept[first][lane] > 0 ? 0 : 1;
-    if (signbit == (sum & 1)) return;
+    const int signbit = (int)(aux.negScan >> first) & 1;
+    if (signbit == (__popc(aux.oddMask & keptMask) & 1)) return;
     int minCost = INT32_MAX, cost = INT32_MAX, minIdx = -1, finalChange = 0, change = 0;
     for (int i = lastGroup ? last : 15; i >= 0; --i)
     {
-        const int v = sh.rec.kept[i][lane];
-        if (v != 0)
+        if ((keptMask >> i) & 1)
         {
+            const int mag = (uint16_t)sh.rec.kept[(int)(b.scan4 >> (4 * i)) & 15][lane];
             const int up = sh.rec.costUp[i][lane];
             int down = sh.rec.costDown[i][lane];
-            if (lastGroup && last == i && abs(v) == 1) down -= 4 << 15;
+            if (lastGroup && last == i && mag == 1) down -= 4 << 15;
             if (up < down)
             {
                 cost = up;
@@ -468,15 +455,14 @@ __device__ __forceinline__ void hideSignsWalk(WalkShared &sh, int lane, const Bl
             else
             {
                 change = -1;
-                cost = (i == first && abs(v) == 1) ? INT32_MAX : down;
+                cost = (i == first && mag == 1) ? INT32_MAX : down;
             }
         }
         else
         {
-            const int c1 = (int)(aux.c1At >> (2 * i)) & 3;
-            cost = sh.rec.costUp[i][lane] + (((aux.active >> i) & 1) ? pick4(aux.g1zero, c1) : 0);
+            cost = sh.rec.costUp[i][lane] + (((aux.active >> i) & 1) ? pick4(aux.g1zero, (int)(aux.c1At >> (2 * i)) & 3) : 0);
             change = 1;
-            if (i < first && (sh.coef[(int)(b.scan4 >> (4 * i)) & 15][lane] >= 0 ? 0 : 1) != signbit) cost = INT32_MAX;
+            if (i < first && ((int)(aux.negScan >> i) & 1) != signbit) cost = INT32_MAX;
         }
         if (cost < minCost)
         {
@@ -485,9 +471,10 @@ __device__ __forceinline__ void hideSignsWalk(WalkShared &sh, int lane, const Bl
             minIdx = i;
         }
     }
-    const int v = sh.rec.kept[minIdx][lane];
-    if (v == 32767 || v == -32768) finalChange = -1;
-    sh.rec.kept[minIdx][lane] = (int16_t)(sh.coef[(int)(b.scan4 >> (4 * minIdx)) & 15][lane] >= 0 ? v + finalChange : v - finalChange);
+    const int nib = (int)(b.scan4 >> (4 * minIdx)) & 15;
+    const int mag = (uint16_t)sh.rec.kept[nib][lane], negative = (int)(aux.negScan >> minIdx) & 1;
+    if ((!negative && mag == 32767) || (negative && mag == 32768)) finalChange = -1;
+    sh.rec.kept[nib][lane] = (int16_t)(mag + finalChange);
 }
 
 template <int LOG2>
@@ -605,22 +592,30 @@ __global__ __launch_bounds__(64) void k_rdoq_walk(int16_t *__restrict__ dstAll, 
             sh.coef[4 * r + 3][lane] = (int16_t)(v.y >> 16);
         }
     };
-    // rec.kept (scan order, magnitudes) -> signs (Rdoq.cpp:418-428), sign-data hiding, the output block
     SdhAux aux;
-    auto finishGroup = [&](int g, int gx, int gy, int lastIdx, bool lastGroup) {
-        for (int i = 0; i < 16; ++i)
+    // rec.kept (magnitudes, raster order) -> truncation at lastIdx, sign-data hiding, signs (Rdoq.cpp:418-441), the output block
+    auto finishGroup = [&](int g, int lastIdx, bool lastGroup, int gx, int gy) {
+        uint32_t keptMask = aux.keptMask;
+        if (lastGroup)
         {
-            int v = g * 16 + i < lastIdx ? sh.rec.kept[i][lane] : 0;
-            if (sh.coef[(int)(b.scan4 >> (4 * i)) & 15][lane] < 0) v = -v;
-            sh.rec.kept[i][lane] = (int16_t)v;
+            const int n = lastIdx - g * 16;      // scan positions of this group that stay
+            const uint32_t stay = n >= 16 ? 0xffffu : (1u << n) - 1;
+            for (int i = 0; i < 16; ++i)
+                if (!((stay >> i) & 1)) sh.rec.kept[(int)(b.scan4 >> (4 * i)) & 15][lane] = 0;
+            keptMask &= stay;
         }
-        if (job.sdh) hideSignsWalk(sh, lane, b, lastGroup, aux);
-        for (int i = 0; i < 16; ++i) sh.coef[(int)(b.scan4 >> (4 * i)) & 15][lane] = sh.rec.kept[i][lane];      // coef doubles as the raster staging area
+        if (job.sdh) hideSignsWalk(sh, lane, b, lastGroup, aux, keptMask);
         for (int r = 0; r < 4; ++r)
         {
+            int v[4];
+            for (int k = 0; k < 4; ++k)
+            {
+                const int mag = (uint16_t)sh.rec.kept[4 * r + k][lane];
+                v[k] = ((aux.negRaster >> (4 * r + k)) & 1) ? -mag : mag;
+            }
             u32x2 o;
-            o.x = (uint16_t)sh.coef[4 * r][lane] | (uint32_t)(uint16_t)sh.coef[4 * r + 1][lane] << 16;
-            o.y = (uint16_t)sh.coef[4 * r + 2][lane] | (uint32_t)(uint16_t)sh.coef[4 * r + 3][lane] << 16;
+            o.x = (uint32_t)(uint16_t)v[0] | (uint32_t)(uint16_t)v[1] << 16;
+            o.y = (uint32_t)(uint16_t)v[2] | (uint32_t)(uint16_t)v[3] << 16;
             st8(dst + ((gy << 2) + r) * size + (gx << 2), o);
         }
     };
@@ -690,7 +685,7 @@ __global__ __launch_bounds__(64) void k_rdoq_walk(int16_t *__restrict__ dstAll, 
                     orSince |= r.groupOr;
                 stopped |= r.localStop;
                 rel += r.q;
-                finishGroup(g, gx, gy, 1 << 30, false);      // as a group below the last one; the last one is redone below
+                finishGroup(g, 1 << 30, false, gx, gy);      // as a group below the last one; the last one is redone below
             }
             --g;
         }
@@ -719,7 +714,7 @@ __global__ __launch_bounds__(64) void k_rdoq_walk(int16_t *__restrict__ dstAll, 
             const int p = rasterOf[lastGroup], gx = p & (gw - 1), gy = p / gw;
             loadGroup(gx, gy);
             walkGroup<LOG2>(b, sh, lane, lastGroup, gx, gy, firstPos, caseOf(coded, gx, gy, (int)(carries >> lastGroup) & 1), job.sdh_factor, aux);
-            finishGroup(lastGroup, gx, gy, lastIdx, true);
+            finishGroup(lastGroup, lastIdx, true, gx, gy);
         }
     }
     if (valid) cbfOut[blk] = cbf;
