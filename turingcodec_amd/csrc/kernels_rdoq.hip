@@ -31,6 +31,9 @@ __device__ const int32_t kEntropyBits[128] = {
     0x007c9, 0x24ce6, 0x00763, 0x25663, 0x00710, 0x25e8f, 0x006a0, 0x26a26, 0x00672, 0x26f23, 0x005e8, 0x27ef8, 0x005ba, 0x284b5, 0x0055e, 0x29057,
     0x0050c, 0x29bab, 0x004c1, 0x2a674, 0x004a7, 0x2aa5e, 0x0046f, 0x2b32f, 0x0041f, 0x2c0ad, 0x003e7, 0x2ca8d, 0x003ba, 0x2d323, 0x0010c, 0x3bfbb };
 
+typedef short s16x2v __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2v __attribute__((ext_vector_type(2)));
+
 struct RdoqJob   // == havoc_mi355x_rdoq_job
 {
     int32_t dst_off, src_off, quant_scale, quant_shift, inv_scale, lambda_q16, sdh_factor, ctx_index;
@@ -183,7 +186,7 @@ struct WalkShared
     uint8_t rasterOf[3][64];                      // scan index -> raster group position, per scan type
     uint64_t mask[64];                            // non-zero groups of each block (bit = raster group position)
     int64_t sumSq[64];                            // sum of squared coefficients of each block
-    int32_t srcOff[64], dstOff[64], qScale[64], qShift[64];
+    int32_t srcOff[64], dstOff[64], nzThreshold[64];   // nzThreshold: smallest |coefficient| of the block that rounds to a non-zero level
 };
 
 struct WalkResult
@@ -503,8 +506,10 @@ __global__ __launch_bounds__(64) void k_rdoq_walk(int16_t *__restrict__ dstAll, 
     }
     sh.srcOff[lane] = job.src_off;
     sh.dstOff[lane] = job.dst_off;
-    sh.qScale[lane] = job.quant_scale;
-    sh.qShift[lane] = job.quant_shift;
+    {   // smallest |coefficient| whose rounded level is non-zero (Rdoq.cpp:108): ceil(half / scale)
+        const uint32_t half = 1u << (job.quant_shift - 1), scale = (uint32_t)max(job.quant_scale, 1);
+        sh.nzThreshold[lane] = (int32_t)((half + scale - 1) / scale);
+    }
     if (lane < G)
         for (int t = 0; t < 3; ++t)
         {
@@ -523,23 +528,31 @@ __global__ __launch_bounds__(64) void k_rdoq_walk(int16_t *__restrict__ dstAll, 
             const bool have = blockIdx.x * 64 + bl < njobs;
             const int16_t *p = srcAll + (long)sh.srcOff[bl] + (py * 4) * size + px * 4;
             int16_t *q = dstAll + (long)sh.dstOff[bl] + (py * 4) * size + px * 4;
-            const int qs = sh.qScale[bl], rnd = 1 << (sh.qShift[bl] - 1), qsh = sh.qShift[bl];
+            // a coefficient rounds to a non-zero level iff |c| * scale + half >= 2 * half, i.e. |c| >= ceil(half / scale): one
+            // threshold per block; |c| and c^2 two at a time (packed max against the negation, v_dot2 of a pair with itself)
+            const uint32_t thr = (uint32_t)sh.nzThreshold[bl];
             bool nz = false;
             uint32_t lo = 0, hi = 0;
             if (have)
+            {
+                u16x2v big = {0, 0};
                 for (int r = 0; r < 4; ++r)
                 {
                     const u32x2 v = ld8(p + r * size);
                     st8(q + r * size, u32x2{0, 0});
-                    const int c[4] = {(int16_t)v.x, (int16_t)(v.x >> 16), (int16_t)v.y, (int16_t)(v.y >> 16)};
-                    for (int k = 0; k < 4; ++k)
+                    const uint32_t w[2] = {v.x, v.y};
+                    for (int k = 0; k < 2; ++k)
                     {
-                        const uint32_t a = (uint32_t)abs(c[k]);
-                        nz |= (int)((a * qs + rnd) >> qsh) > 0;
-                        lo += (a * a) & 0xffff;
-                        hi += (a * a) >> 16;
+                        const s16x2v c = __builtin_bit_cast(s16x2v, w[k]);
+                        const s16x2v a = __builtin_elementwise_max(c, (s16x2v){0, 0} - c);      // -32768 stays 0x8000 = 32768 unsigned
+                        big = __builtin_elementwise_max(big, __builtin_bit_cast(u16x2v, a));
+                        const uint32_t sq = (uint32_t)__builtin_amdgcn_sdot2(c, c, 0, false);   // c0^2 + c1^2 (mod 2^32: at most 2^31)
+                        lo += sq & 0xffff;
+                        hi += sq >> 16;
                     }
                 }
+                nz = max((uint32_t)big.x, (uint32_t)big.y) >= thr;
+            }
             const uint64_t m = __ballot(nz);
             const int slo = group_sum<G>((int)lo), shi = group_sum<G>((int)hi);
             if (pos == 0)
