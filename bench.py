@@ -162,6 +162,7 @@ class DeviceFrame:
             if self.rdoq:
                 rj = wl.rdoq_jobs((log2, tr), _havoc.rdoq_lambda(wl.rdoq_lambda, dscale))
                 self.tu[(log2, tr)]["rjobs"] = torch.from_numpy(rj.view(np.uint8).reshape(-1)).to(hv.device)
+                self.tu[(log2, tr)]["rwork"] = hv.rdoq_workspace(len(rj))
         self.rdoq_states = torch.from_numpy(np.ascontiguousarray(wl.rdoq_states).reshape(-1)).to(hv.device)
         # final reconstruction pass of the picture (workload.recon): what later pictures predict from
         self.recon = {}
@@ -245,7 +246,7 @@ class DeviceFrame:
             n = g["n"]
             # speed=medium: tu_forward -> Rdoq::runQuantisation -> tu_reconstruct, one dependent chain on the device.  With
             # --rdoq 0 the two halves are independent (levels pre-computed, untimed, in __init__)
-            rdq = ("rdoq", lambda g=g, log2=log2: hv.rdoq_d(bd, log2, g["level"], g["coef"], self.rdoq_states, g["rjobs"], g["cbf"]))
+            rdq = ("rdoq", lambda g=g, log2=log2: hv.rdoq_d(bd, log2, g["level"], g["coef"], self.rdoq_states, g["rjobs"], g["cbf"], g["rwork"]))
             if self.fused_tu:
                 # residual + forward transform in one kernel; de-quant + inverse transform + add + SSD in another
                 fwd = ("tu_forward", lambda g=g, log2=log2, tr=tr: hv.tu_forward_d(bd, tr, log2, g["coef"], self.luma, st, self.luma, st, g["fjobs"]))

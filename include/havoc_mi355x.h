@@ -409,8 +409,12 @@ typedef struct {
 void havoc_mi355x_rdoq_lambda(double lambda, int inv_scale, int32_t *lambda_q16, int32_t *sdh_factor);
 /* d_cbf[i] = runQuantisation's return value (OR of the kept absolute levels).  d_dst and d_src are different buffers, as in the
  * reference (quantizedCoefficients vs coefficients, Reconstruct.cpp:276-277); every level of a job's block is written. */
+/* d_work: havoc_mi355x_rdoq_workspace(njobs) bytes of device scratch, 16-byte aligned, private to the launch until it completes
+ * (per block: which 4x4 groups are non-zero, the block's energy; the order the blocks are walked in: densest first, so that
+ * the 64 blocks a wavefront walks finish together). */
+size_t havoc_mi355x_rdoq_workspace(int njobs);
 int havoc_mi355x_rdoq(havoc_mi355x_ctx *ctx, int bitDepth, int log2TrafoSize, int16_t *d_dst, const int16_t *d_src, const uint8_t *d_states,
-                      const havoc_mi355x_rdoq_job *d_jobs, int njobs, int32_t *d_cbf);
+                      const havoc_mi355x_rdoq_job *d_jobs, int njobs, int32_t *d_cbf, void *d_work, size_t work_bytes);
 
 #ifdef __cplusplus
 }

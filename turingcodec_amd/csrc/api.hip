@@ -29,7 +29,8 @@ hipError_t launch_tu_forward(hipStream_t, int S, int bd, int log2, int tr, int16
 hipError_t launch_tu_reconstruct(hipStream_t, int S, int bd, int log2, int tr, int scale, int shift, void *, long, const void *, long, const void *,
                                  long, const int16_t *, const void *, int, uint32_t *);
 hipError_t launch_quantize(hipStream_t, int16_t *, const int16_t *, const void *, int, int32_t *);
-hipError_t launch_rdoq(hipStream_t, int bd, int log2, int16_t *, const int16_t *, const uint8_t *, const void *, int, int32_t *);
+hipError_t launch_rdoq(hipStream_t, int bd, int log2, int16_t *, const int16_t *, const uint8_t *, const void *, int, int32_t *, void *);
+size_t rdoq_workspace_bytes(int njobs);
 hipError_t launch_quantize_inverse(hipStream_t, int16_t *, const int16_t *, const void *, int);
 hipError_t launch_quantize_reconstruct(hipStream_t, int log2, uint8_t *, long, const uint8_t *, long, const int16_t *, const void *, int);
 hipError_t launch_residual(hipStream_t, int S, int16_t *, long, const int32_t *, const void *, long, const void *, long, const void *, int);
@@ -514,12 +515,17 @@ void havoc_mi355x_rdoq_lambda(double lambda, int inv_scale, int32_t *lambda_q16,
     if (sdh_factor) *sdh_factor = (int)(inv_scale * inv_scale / lambda / 16 + 0.5);
 }
 
+size_t havoc_mi355x_rdoq_workspace(int njobs) { return rdoq_workspace_bytes(njobs); }
+
 int havoc_mi355x_rdoq(havoc_mi355x_ctx *ctx, int bitDepth, int log2TrafoSize, int16_t *d_dst, const int16_t *d_src, const uint8_t *d_states,
-                      const havoc_mi355x_rdoq_job *d_jobs, int njobs, int32_t *d_cbf)
+                      const havoc_mi355x_rdoq_job *d_jobs, int njobs, int32_t *d_cbf, void *d_work, size_t work_bytes)
 {
     REQUIRE_CTX(); REQUIRE(log2TrafoSize >= 2 && log2TrafoSize <= 5, "log2TrafoSize must be 2..5"); REQUIRE(njobs >= 0, "njobs < 0");
     REQUIRE(bitDepth >= 8 && bitDepth <= 12, "bitDepth must be 8..12");
-    return check(launch_rdoq(LS(ctx), bitDepth, log2TrafoSize, d_dst, d_src, d_states, d_jobs, njobs, d_cbf), "rdoq");
+    REQUIRE(d_dst != d_src, "rdoq: d_dst and d_src must be different buffers");
+    REQUIRE(njobs == 0 || (d_work && work_bytes >= rdoq_workspace_bytes(njobs) && (reinterpret_cast<uintptr_t>(d_work) & 15) == 0),
+            "rdoq: workspace missing, misaligned or smaller than havoc_mi355x_rdoq_workspace(njobs)");
+    return check(launch_rdoq(LS(ctx), bitDepth, log2TrafoSize, d_dst, d_src, d_states, d_jobs, njobs, d_cbf, d_work), "rdoq");
 }
 
 } // extern "C"

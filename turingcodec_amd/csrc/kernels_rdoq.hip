@@ -184,9 +184,6 @@ struct WalkShared
     int16_t coef[16][64];                         // the current group's coefficients, raster order within the group
     uint32_t pre[16][64];                         // per position: significance context << 25 | flag bits of the zero levels above it
     uint8_t rasterOf[3][64];                      // scan index -> raster group position, per scan type
-    uint64_t mask[64];                            // non-zero groups of each block (bit = raster group position)
-    int64_t sumSq[64];                            // sum of squared coefficients of each block
-    int32_t srcOff[64], dstOff[64], nzThreshold[64];   // nzThreshold: smallest |coefficient| of the block that rounds to a non-zero level
 };
 
 struct WalkResult
@@ -480,15 +477,162 @@ __device__ __forceinline__ void hideSignsWalk(WalkShared &sh, int lane, const Bl
     sh.rec.kept[nib][lane] = (int16_t)(mag + finalChange);
 }
 
+// Workspace of one launch (caller-provided, havoc_mi355x_rdoq_workspace bytes): what the scan pass found per block, the
+// histogram of blocks by their number of groups to walk, and the order the walk takes the blocks in.
+struct RdoqInfo { uint64_t mask; int64_t sumSq; };      // non-zero groups (bit = raster group position), sum of squared coefficients
+constexpr int kBins = 66;                               // 0..64 groups to walk (+1 spare)
+struct RdoqWork
+{
+    uint32_t hist[kBins], cursor[kBins];
+    // followed by RdoqInfo info[njobs], then uint32_t order[njobs]
+};
+__host__ __device__ inline size_t rdoqInfoOffset() { return (sizeof(RdoqWork) + 15) & ~size_t(15); }
+__device__ __forceinline__ int groupsToWalk(uint64_t mask) { return mask ? __popcll(mask | 1) : 0; }      // the DC group is always walked
+
+// LDS of the cooperative scan of a workgroup's 64 blocks
+struct ScanShared
+{
+    int32_t srcOff[64], dstOff[64], nzThreshold[64];
+    uint64_t mask[64];      // non-zero groups of each block (bit = raster group position)
+    int64_t sumSq[64];      // sum of squared coefficients of each block
+};
+
+// Cooperative scan: 64 lanes look at one 32x32 block's 64 groups (or four 16x16 blocks, ...) per step, coalesced: which groups hold
+// a non-zero rounded level, the block's energy; zeros into the output.  Results for block k of the workgroup in sc.mask[k], sc.sumSq[k].
 template <int LOG2>
-__global__ __launch_bounds__(64) void k_rdoq_walk(int16_t *__restrict__ dstAll, const int16_t *__restrict__ srcAll, const uint8_t *__restrict__ statesAll,
-                                                  const RdoqJob *__restrict__ jobs, int njobs, int32_t *__restrict__ cbfOut, int bitDepth)
+__device__ __forceinline__ void scanBlocks(ScanShared &sc, int16_t *__restrict__ dstAll, const int16_t *__restrict__ srcAll, const RdoqJob *__restrict__ jobs, int njobs)
 {
     constexpr int size = 1 << LOG2, G = (size * size) >> 4, log2G = 2 * LOG2 - 4, gw = size >> 2, perStep = 64 / G;
-    __shared__ WalkShared sh;
     const int lane = threadIdx.x, blk = blockIdx.x * 64 + lane;
-    const bool valid = blk < njobs;
-    const RdoqJob job = jobs[valid ? blk : njobs - 1];
+    {
+        const RdoqJob &job = jobs[blk < njobs ? blk : njobs - 1];
+        sc.srcOff[lane] = job.src_off;
+        sc.dstOff[lane] = job.dst_off;
+        // smallest |coefficient| whose rounded level is non-zero (Rdoq.cpp:108): |c| * scale + half >= 2 * half  <=>  |c| >= ceil(half / scale)
+        const uint32_t half = 1u << (job.quant_shift - 1), scale = (uint32_t)max(job.quant_scale, 1);
+        sc.nzThreshold[lane] = (int32_t)((half + scale - 1) / scale);
+        sc.mask[lane] = 0;
+        sc.sumSq[lane] = 0;
+    }
+    __syncthreads();
+    const int sub = lane >> log2G, pos = lane & (G - 1), px = pos & (gw - 1), py = pos / gw;
+    for (int step = 0; step < G; ++step)        // G steps of 64 / G blocks = 64 blocks
+    {
+        const int bl = step * perStep + sub;
+        const bool have = blockIdx.x * 64 + bl < njobs;
+        const int16_t *p = srcAll + (long)sc.srcOff[bl] + (py * 4) * size + px * 4;
+        int16_t *q = dstAll + (long)sc.dstOff[bl] + (py * 4) * size + px * 4;
+        const uint32_t thr = (uint32_t)sc.nzThreshold[bl];
+        bool nz = false;
+        uint32_t lo = 0, hi = 0;
+        if (have)
+        {
+            u16x2v big = {0, 0};      // |c| and c^2 two at a time: packed max against the negation, v_dot2 of a pair with itself
+            for (int r = 0; r < 4; ++r)
+            {
+                const u32x2 v = ld8(p + r * size);
+                st8(q + r * size, u32x2{0, 0});
+                const uint32_t w[2] = {v.x, v.y};
+                for (int k = 0; k < 2; ++k)
+                {
+                    const s16x2v c = __builtin_bit_cast(s16x2v, w[k]);
+                    const s16x2v a = __builtin_elementwise_max(c, (s16x2v){0, 0} - c);      // -32768 stays 0x8000 = 32768 unsigned
+                    big = __builtin_elementwise_max(big, __builtin_bit_cast(u16x2v, a));
+                    const uint32_t sq = (uint32_t)__builtin_amdgcn_sdot2(c, c, 0, false);   // c0^2 + c1^2 (mod 2^32: at most 2^31)
+                    lo += sq & 0xffff;
+                    hi += sq >> 16;
+                }
+            }
+            nz = max((uint32_t)big.x, (uint32_t)big.y) >= thr;
+        }
+        const uint64_t m = __ballot(nz);
+        const int slo = group_sum<G>((int)lo), shi = group_sum<G>((int)hi);
+        if (pos == 0 && have)
+        {
+            sc.mask[bl] = G == 64 ? m : (m >> (lane & ~(G - 1))) & ((1ull << (G & 63)) - 1);
+            sc.sumSq[bl] = ((int64_t)shi << 16) + slo;
+        }
+    }
+    __syncthreads();
+}
+
+// Pass 1 of the sorted form (large blocks): the scan, its results to the workspace, histogram of the blocks by groups to walk.
+template <int LOG2>
+__global__ __launch_bounds__(64) void k_rdoq_scan(int16_t *__restrict__ dstAll, const int16_t *__restrict__ srcAll, const RdoqJob *__restrict__ jobs, int njobs,
+                                                  RdoqWork *__restrict__ work)
+{
+    __shared__ ScanShared sc;
+    __shared__ uint32_t hist[kBins];
+    const int lane = threadIdx.x, blk = blockIdx.x * 64 + lane;
+    RdoqInfo *info = reinterpret_cast<RdoqInfo *>(reinterpret_cast<char *>(work) + rdoqInfoOffset());
+    for (int k = lane; k < kBins; k += 64) hist[k] = 0;
+    scanBlocks<LOG2>(sc, dstAll, srcAll, jobs, njobs);
+    if (blk < njobs)
+    {
+        RdoqInfo r;
+        r.mask = sc.mask[lane];
+        r.sumSq = sc.sumSq[lane];
+        info[blk] = r;
+        atomicAdd(&hist[groupsToWalk(r.mask)], 1u);
+    }
+    __syncthreads();
+    for (int k = lane; k < kBins; k += 64)
+        if (hist[k]) atomicAdd(&work->hist[k], hist[k]);
+}
+
+// Pass 2: blocks ordered by decreasing number of groups to walk (counting sort; the order inside a bin is whatever the atomics
+// give -- it decides only which lane walks which block).  The 64 blocks of a wavefront then finish together.
+__global__ __launch_bounds__(256) void k_rdoq_order(int njobs, RdoqWork *__restrict__ work)
+{
+    __shared__ uint32_t count[kBins], base[kBins];
+    const RdoqInfo *info = reinterpret_cast<const RdoqInfo *>(reinterpret_cast<const char *>(work) + rdoqInfoOffset());
+    uint32_t *order = reinterpret_cast<uint32_t *>(const_cast<RdoqInfo *>(info) + njobs);
+    const int t = threadIdx.x, blk = blockIdx.x * 256 + t;
+    if (t < kBins) count[t] = 0;
+    __syncthreads();
+    int bin = 0;
+    uint32_t rank = 0;
+    if (blk < njobs)
+    {
+        bin = groupsToWalk(info[blk].mask);
+        rank = atomicAdd(&count[bin], 1u);
+    }
+    __syncthreads();
+    if (t < kBins && count[t])
+    {
+        uint32_t before = 0;
+        for (int k = t + 1; k < kBins; ++k) before += work->hist[k];      // bins with more groups come first
+        base[t] = before + atomicAdd(&work->cursor[t], count[t]);
+    }
+    __syncthreads();
+    if (blk < njobs) order[base[bin] + rank] = (uint32_t)blk;
+}
+
+// The walk.  SORTED (32x32, 16x16): blocks in the order of pass 2, scan results from the workspace.  Otherwise (8x8, 4x4: many short
+// blocks, where three launches and a permuted access cost more than the balance gains) the scan runs here, blocks in job order.
+template <int LOG2, bool SORTED>
+__global__ __launch_bounds__(64) void k_rdoq_walk(int16_t *__restrict__ dstAll, const int16_t *__restrict__ srcAll, const uint8_t *__restrict__ statesAll,
+                                                  const RdoqJob *__restrict__ jobs, int njobs, int32_t *__restrict__ cbfOut, int bitDepth,
+                                                  const RdoqWork *__restrict__ work)
+{
+    constexpr int size = 1 << LOG2, G = (size * size) >> 4, gw = size >> 2;
+    __shared__ WalkShared sh;
+    const RdoqInfo *infoAll = reinterpret_cast<const RdoqInfo *>(reinterpret_cast<const char *>(work) + rdoqInfoOffset());
+    const uint32_t *order = reinterpret_cast<const uint32_t *>(infoAll + njobs);
+    const int lane = threadIdx.x, slot = blockIdx.x * 64 + lane;
+    const bool valid = slot < njobs;
+    const int blk = valid ? (SORTED ? (int)order[slot] : slot) : 0;
+    const RdoqJob job = jobs[blk];
+    RdoqInfo info;
+    if (SORTED)
+        info = infoAll[blk];
+    else
+    {
+        __shared__ ScanShared sc;
+        scanBlocks<LOG2>(sc, dstAll, srcAll, jobs, njobs);
+        info.mask = sc.mask[lane];
+        info.sumSq = sc.sumSq[lane];
+    }
 
     // ---- stage in ----
     sh.bits[lane] = kEntropyBits[lane];
@@ -504,12 +648,6 @@ __global__ __launch_bounds__(64) void k_rdoq_walk(int16_t *__restrict__ dstAll, 
             sh.states[4 * k + 3][lane] = (uint8_t)(v >> 24);
         }
     }
-    sh.srcOff[lane] = job.src_off;
-    sh.dstOff[lane] = job.dst_off;
-    {   // smallest |coefficient| whose rounded level is non-zero (Rdoq.cpp:108): ceil(half / scale)
-        const uint32_t half = 1u << (job.quant_shift - 1), scale = (uint32_t)max(job.quant_scale, 1);
-        sh.nzThreshold[lane] = (int32_t)((half + scale - 1) / scale);
-    }
     if (lane < G)
         for (int t = 0; t < 3; ++t)
         {
@@ -517,51 +655,6 @@ __global__ __launch_bounds__(64) void k_rdoq_walk(int16_t *__restrict__ dstAll, 
             if (G > 1) scanXy(gw, t, lane, x, y);
             sh.rasterOf[t][lane] = (uint8_t)(y * gw + x);
         }
-    __syncthreads();
-
-    // ---- pre-pass: which groups hold a non-zero rounded level, the blocks' energy, zeros into the output ----
-    {
-        const int sub = lane >> log2G, pos = lane & (G - 1), px = pos & (gw - 1), py = pos / gw;
-        for (int step = 0; step < G; ++step)        // G steps of 64 / G blocks = 64 blocks
-        {
-            const int bl = step * perStep + sub;
-            const bool have = blockIdx.x * 64 + bl < njobs;
-            const int16_t *p = srcAll + (long)sh.srcOff[bl] + (py * 4) * size + px * 4;
-            int16_t *q = dstAll + (long)sh.dstOff[bl] + (py * 4) * size + px * 4;
-            // a coefficient rounds to a non-zero level iff |c| * scale + half >= 2 * half, i.e. |c| >= ceil(half / scale): one
-            // threshold per block; |c| and c^2 two at a time (packed max against the negation, v_dot2 of a pair with itself)
-            const uint32_t thr = (uint32_t)sh.nzThreshold[bl];
-            bool nz = false;
-            uint32_t lo = 0, hi = 0;
-            if (have)
-            {
-                u16x2v big = {0, 0};
-                for (int r = 0; r < 4; ++r)
-                {
-                    const u32x2 v = ld8(p + r * size);
-                    st8(q + r * size, u32x2{0, 0});
-                    const uint32_t w[2] = {v.x, v.y};
-                    for (int k = 0; k < 2; ++k)
-                    {
-                        const s16x2v c = __builtin_bit_cast(s16x2v, w[k]);
-                        const s16x2v a = __builtin_elementwise_max(c, (s16x2v){0, 0} - c);      // -32768 stays 0x8000 = 32768 unsigned
-                        big = __builtin_elementwise_max(big, __builtin_bit_cast(u16x2v, a));
-                        const uint32_t sq = (uint32_t)__builtin_amdgcn_sdot2(c, c, 0, false);   // c0^2 + c1^2 (mod 2^32: at most 2^31)
-                        lo += sq & 0xffff;
-                        hi += sq >> 16;
-                    }
-                }
-                nz = max((uint32_t)big.x, (uint32_t)big.y) >= thr;
-            }
-            const uint64_t m = __ballot(nz);
-            const int slo = group_sum<G>((int)lo), shi = group_sum<G>((int)hi);
-            if (pos == 0)
-            {
-                sh.mask[bl] = G == 64 ? m : (m >> (lane & ~(G - 1))) & ((1ull << (G & 63)) - 1);
-                sh.sumSq[bl] = ((int64_t)shi << 16) + slo;
-            }
-        }
-    }
     __syncthreads();
 
     // ---- per-lane set-up ----
@@ -638,7 +731,7 @@ __global__ __launch_bounds__(64) void k_rdoq_walk(int16_t *__restrict__ dstAll, 
         return right | below << 1 | carry << 2;
     };
 
-    uint64_t nz = valid ? sh.mask[lane] : 0, coded = 0, carries = 0;
+    uint64_t nz = valid ? info.mask : 0, coded = 0, carries = 0;
     int g = G - 1;
     while (g >= 0 && !((nz >> rasterOf[g]) & 1)) --g;
     const int firstGroup = g;
@@ -709,7 +802,7 @@ __global__ __launch_bounds__(64) void k_rdoq_walk(int16_t *__restrict__ dstAll, 
     if (firstPos >= 0)
     {
         const int cbfCtx = (!job.is_intra && b.cIdx == 0) ? HAVOC_RDOQ_CTX_ROOT_CBF : (b.cIdx == 0 ? HAVOC_RDOQ_CTX_CBF_LUMA + 1 : HAVOC_RDOQ_CTX_CBF_CHROMA);
-        const int64_t dist0Total = sh.sumSq[lane] << distShift;
+        const int64_t dist0Total = info.sumSq << distShift;
         const int64_t bestNone = dist0Total + b.lambda * bitsOf(b, cbfCtx, 0);
         const int64_t start = (dist0Total - walkedDist0) + costTu + b.lambda * bitsOf(b, cbfCtx, 1);
         const int lastIdx = (bestPos >= 0 && start + bestRel < bestNone) ? bestPos + 1 : 0;
@@ -734,18 +827,28 @@ __global__ __launch_bounds__(64) void k_rdoq_walk(int16_t *__restrict__ dstAll, 
 }
 } // namespace
 
-hipError_t launch_rdoq(hipStream_t st, int bitDepth, int log2, int16_t *dst, const int16_t *src, const uint8_t *states, const void *jobs, int njobs, int32_t *cbf)
+size_t rdoq_workspace_bytes(int njobs) { return rdoqInfoOffset() + (size_t)max(njobs, 0) * (sizeof(RdoqInfo) + sizeof(uint32_t)) + 64; }
+
+hipError_t launch_rdoq(hipStream_t st, int bitDepth, int log2, int16_t *dst, const int16_t *src, const uint8_t *states, const void *jobs, int njobs, int32_t *cbf,
+                       void *workspace)
 {
     if (njobs <= 0) return hipSuccess;
     const RdoqJob *j = static_cast<const RdoqJob *>(jobs);
+    RdoqWork *work = static_cast<RdoqWork *>(workspace);
     const int wgs = (njobs + 63) / 64;
-    switch (log2)
+    if (log2 <= 3)
     {
-    case 2: hipLaunchKernelGGL(k_rdoq_walk<2>, dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth); break;
-    case 3: hipLaunchKernelGGL(k_rdoq_walk<3>, dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth); break;
-    case 4: hipLaunchKernelGGL(k_rdoq_walk<4>, dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth); break;
-    default: hipLaunchKernelGGL(k_rdoq_walk<5>, dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth); break;
+        if (log2 == 2) hipLaunchKernelGGL((k_rdoq_walk<2, false>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work);
+        else hipLaunchKernelGGL((k_rdoq_walk<3, false>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work);
+        return hipGetLastError();
     }
+    hipError_t e = hipMemsetAsync(work, 0, sizeof(RdoqWork), st);
+    if (e != hipSuccess) return e;
+    if (log2 == 4) hipLaunchKernelGGL(k_rdoq_scan<4>, dim3(wgs), dim3(64), 0, st, dst, src, j, njobs, work);
+    else hipLaunchKernelGGL(k_rdoq_scan<5>, dim3(wgs), dim3(64), 0, st, dst, src, j, njobs, work);
+    hipLaunchKernelGGL(k_rdoq_order, dim3((njobs + 255) / 256), dim3(256), 0, st, njobs, work);
+    if (log2 == 4) hipLaunchKernelGGL((k_rdoq_walk<4, true>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work);
+    else hipLaunchKernelGGL((k_rdoq_walk<5, true>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work);
     return hipGetLastError();
 }
 

@@ -92,10 +92,12 @@ def _load():
         "quantize": [_vp, _vp, _vp, _vp, _i, _vp],
         "quantize_inverse": [_vp, _vp, _vp, _vp, _i],
         "quantize_reconstruct": [_vp, _i, _vp, _ip, _vp, _ip, _vp, _vp, _i],
-        "rdoq": [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp],
+        "rdoq": [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, C.c_size_t],
     }
     L.havoc_mi355x_rdoq_lambda.argtypes = [C.c_double, _i, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.havoc_mi355x_rdoq_lambda.restype = None
+    L.havoc_mi355x_rdoq_workspace.argtypes = [_i]
+    L.havoc_mi355x_rdoq_workspace.restype = C.c_size_t
     for name, args in sig.items():
         f = getattr(L, "havoc_mi355x_" + name)
         f.argtypes = args
@@ -106,7 +108,7 @@ def _load():
 def exported_symbols():
     """names the C ABI must export (checked against include/havoc_mi355x.h by the CPU tests)"""
     _, names = _load()
-    return ["havoc_mi355x_" + n for n in names] + ["havoc_mi355x_last_error", "havoc_mi355x_version", "havoc_mi355x_rdoq_lambda"]
+    return ["havoc_mi355x_" + n for n in names] + ["havoc_mi355x_last_error", "havoc_mi355x_version", "havoc_mi355x_rdoq_lambda", "havoc_mi355x_rdoq_workspace"]
 
 
 # one havoc_mi355x_rdoq_job (include/havoc_mi355x.h), 48 bytes
@@ -387,9 +389,16 @@ class Havoc:
     def quantize_reconstruct_d(self, log2, rec, sr, pred, sp, res, jobs):
         self._ck(self.L.havoc_mi355x_quantize_reconstruct(self.h, log2, _ptr(rec), sr, _ptr(pred), sp, _ptr(res), _ptr(jobs), jobs.shape[0]))
 
-    def rdoq_d(self, bd, log2, dst, src, states, jobs, cbf):
-        """jobs: uint8 tensor holding RDOQ_JOB_DT records; states: uint8 tensor of 128-byte snapshots"""
-        self._ck(self.L.havoc_mi355x_rdoq(self.h, bd, log2, _ptr(dst), _ptr(src), _ptr(states), _ptr(jobs), jobs.numel() // RDOQ_JOB_DT.itemsize, _ptr(cbf)))
+    def rdoq_workspace(self, njobs):
+        """device scratch for one rdoq launch of `njobs` blocks (an int64 tensor: 16-byte aligned)"""
+        n = int(self.L.havoc_mi355x_rdoq_workspace(int(njobs)))
+        with self.torch.cuda.stream(self.tstream):
+            return self.torch.zeros((n + 7) // 8 + 2, dtype=self.torch.int64, device=self.device)
+
+    def rdoq_d(self, bd, log2, dst, src, states, jobs, cbf, work):
+        """jobs: uint8 tensor holding RDOQ_JOB_DT records; states: uint8 tensor of 128-byte snapshots; work: rdoq_workspace(njobs)"""
+        self._ck(self.L.havoc_mi355x_rdoq(self.h, bd, log2, _ptr(dst), _ptr(src), _ptr(states), _ptr(jobs), jobs.numel() // RDOQ_JOB_DT.itemsize, _ptr(cbf),
+                                          _ptr(work), work.numel() * 8))
 
     def rdoq(self, bd, log2, src, states, jobs):
         """numpy level: src int16 (all blocks), states uint8 [k, 128], jobs RDOQ_JOB_DT array -> (levels int16 like src, cbf int32[njobs])"""
@@ -399,7 +408,7 @@ class Havoc:
         with self.torch.cuda.stream(self.tstream):
             st = self.torch.from_numpy(np.ascontiguousarray(states, np.uint8).reshape(-1)).to(self.device)
             j = self.torch.from_numpy(jobs.view(np.uint8).reshape(-1)).to(self.device)
-        self.rdoq_d(bd, log2, dst, self.up(src), st, j, cbf)
+        self.rdoq_d(bd, log2, dst, self.up(src), st, j, cbf, self.rdoq_workspace(len(jobs)))
         return self.down(dst, np.int16), self.down(cbf, np.int32)
 
     def ssd_linear_d(self, a, b, n, out):
