@@ -164,8 +164,11 @@ __device__ __forceinline__ int sigCtx(int neighbours, int scanIdx, int x, int y,
 //     group, committed once the group's keep-or-zero decision is made, and compared with "code nothing" at the very end.
 //   * sign-data hiding is applied to each group as it is finished, as if it were not the group holding the last significant
 //     coefficient; that one group (known only at the end) is redone.
-//   * the per-group record arrays live in LDS, [coefficient][lane]; the pre-pass that finds the non-zero groups (and zero-fills
-//     the output) is cooperative: 64 lanes read one 32x32 block's 64 groups (or four 16x16, ...) per step, coalesced.
+//   * the per-group record arrays live in LDS, [coefficient][lane]; the scan that finds the non-zero groups (and zero-fills the
+//     output) is cooperative: 64 lanes read one 32x32 block's 64 groups (or four 16x16, ...) per step, coalesced.
+//   * a wavefront runs as long as its densest block (32x32 at QP 32: 14 groups to walk against a mean of 10; 16x16: 5.6 against
+//     3.2), so the large sizes are walked densest-first: scan kernel -> counting sort by groups to walk -> walk kernel, through a
+//     caller-provided workspace; 8x8 and 4x4 blocks keep the scan inside the walk kernel and job order.
 // ---------------------------------------------------------------------------------------------------------------------
 // what sign-data hiding needs of the current group, [coefficient in scan order][lane]
 struct WalkRecords
