@@ -1167,10 +1167,14 @@ def main():
                     out.setdefault("extra", {})["rdoq0_error"] = repr(e)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, dev)
-        print(json.dumps(out))
+        line = json.dumps(out)
     if grouped:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        sys.stderr.flush()
+        print(line, flush=True)     # the ONE JSON line, after anything the collective library may still say
 
 
 if __name__ == "__main__":
