@@ -68,6 +68,8 @@ def parse_args():
                     help="N > 1: weak = steady state of an endless sequence (one picture per rank per slot); strong = a fixed sequence "
                          "of --pictures pictures from first to last slot, pipeline fill and drain included")
     ap.add_argument("--pictures", type=int, default=33, help="--scaling strong: sequence length (IDR + SOPs of 8; SURVEY 8(d): 33)")
+    ap.add_argument("--lag", type=int, default=0, help="frame-parallel schedule: slots between a picture and the references it gets from "
+                    "other ranks (0 = DagSchedule's default: 2 for 8+ ranks on an endless sequence, else 1)")
     ap.add_argument("--poc-checksums", action="store_true",
                     help="frame-parallel verification: synchronise after every picture and report a checksum of its reconstruction per POC")
     ap.add_argument("--exchange", action="store_true",
@@ -877,6 +879,7 @@ class FramePipeline:
         self.torch, self.dist, self.exch, self.ctx, self.rank, self.comm, self.lanes = torch, dist, exch, contexts, rank, comm, lanes
         self.count = 0                    # pictures this rank has worked on -> which context the next one uses
         self.arrived = {}                 # DPB slot -> event recorded after its latest broadcast
+        self.staged_at = {}               # DPB slot -> event recorded after THIS rank staged its own reconstruction there
         self.last_copy = [None] * len(contexts)   # per compute stream: event after its latest ref copy
         self.poc_checksums = {} if poc_checksums else None
         self.pictures = 0
@@ -893,9 +896,13 @@ class FramePipeline:
             pl, cpl = wl.plane_len, wl.cplane_len
             if pic.refs:
                 s0, s1 = exch.refs(pic)
-                for sl in {s0, s1}:
-                    if sl in self.arrived:
-                        compute.wait_event(self.arrived[sl])
+                for sl, ref_poc in {(s0, pic.l0), (s1, pic.l1)}:
+                    # a reference this rank encoded itself (the anchor chain) is in the mirror once it is staged; one from
+                    # another rank once its broadcast has landed
+                    local = exch.schedule.rank_of.get(ref_poc) == self.rank and sl in self.staged_at
+                    ev = self.staged_at[sl] if local else self.arrived.get(sl)
+                    if ev is not None:
+                        compute.wait_event(ev)
                 with torch.cuda.stream(compute):
                     # references come from the mirror: L0 / L1 luma into store planes 1 / 2 and phase-plane slot 0 of
                     # each reference, Cb of L0 / L1 into the chroma store (one fused copy launch)
@@ -933,6 +940,7 @@ class FramePipeline:
                     exch.stage(t, (dev.luma[3 * pl:4 * pl], dev.chroma[3 * cpl:4 * cpl], dev.chroma[4 * cpl:5 * cpl]))
                 staged = torch.cuda.Event()
                 staged.record(compute)
+                self.staged_at[exch.slot_of(pic.poc)] = staged
             if self.poc_checksums is not None:
                 hv.sync()
                 self.poc_checksums[pic.poc] = dev.recon_checksum()
@@ -989,7 +997,7 @@ def main():
     if grouped:
         from turingcodec_amd.frame_parallel import DagSchedule, ReferenceExchange
         strong = args.scaling == "strong"
-        sched = DagSchedule(world, n_sops=(args.pictures - 1) // 8 if strong else None)
+        sched = DagSchedule(world, n_sops=(args.pictures - 1) // 8 if strong else None, lag=args.lag or None)
         exch = ReferenceExchange(dist, rank, sched, wl.plane_len, wl.cplane_len, dev.luma, single_rank_broadcast=args.exchange)
         comm = torch.cuda.current_stream(local)   # torch.distributed enqueues behind this stream
         pipe = FramePipeline(torch, dist, exch, slots, rank, comm, args.lanes, poc_checksums=args.poc_checksums)
@@ -1039,7 +1047,7 @@ def main():
             for i in range(nslots):
                 one_step(i)
         # one untimed pass over the sequence first (code objects, RCCL channels), on a schedule of its own
-        warm = FramePipeline(torch, dist, ReferenceExchange(dist, rank, DagSchedule(world, n_sops=(args.pictures - 1) // 8), wl.plane_len,
+        warm = FramePipeline(torch, dist, ReferenceExchange(dist, rank, DagSchedule(world, n_sops=(args.pictures - 1) // 8, lag=args.lag or None), wl.plane_len,
                                                             wl.cplane_len, dev.luma, single_rank_broadcast=args.exchange), slots, rank, comm, args.lanes)
         for i in range(nslots):
             warm.slot(i)
@@ -1067,6 +1075,14 @@ def main():
             pictures_per_block = float(world * args.steps)
     blk = float(np.median(blocks))
     elapsed = blk
+    all_poc = None
+    if args.poc_checksums and pipe is not None:      # every rank's pictures, collected on all ranks (rank 0 reports them)
+        all_poc = dict(pipe.poc_checksums)
+        if world > 1:
+            parts = [None] * world
+            dist.all_gather_object(parts, pipe.poc_checksums)
+            for d in parts:
+                all_poc.update(d)
 
     if rank == 0:
         ktimes, kcount = dev.kernel_times_ms(args.kernel_reps)
@@ -1123,7 +1139,7 @@ def main():
                    "; weak scaling: steady state of an endless sequence, one picture per rank per slot"))
             out["config"]["pictures_per_timed_block"] = pictures_per_block
         if args.poc_checksums and pipe is not None:
-            out["poc_checksums"] = {str(k): v for k, v in sorted(pipe.poc_checksums.items())}
+            out["poc_checksums"] = {str(k): v for k, v in sorted(all_poc.items())}
         if args.pcie:
             out["metric"] = (f"DIAGNOSTIC (PCIe-inclusive: {pcie_bytes[0]} B up, {pcie_bytes[1]} B down per step, serial with the "
                              "kernels) -- not the benchmark metric")

@@ -28,10 +28,11 @@ def test_coding_order_matches_reference_sop():
     assert (by[4].l0, by[4].l1) == (0, 8) and (by[3].l0, by[3].l1) == (2, 4) and (by[8].l0, by[8].l1) == (0, 0)
 
 
-@pytest.mark.parametrize("world", [1, 2, 3, 4, 8])
-def test_dag_schedule_respects_dependencies(world):
+@pytest.mark.parametrize("world,lag", [(1, 1), (2, 1), (3, 1), (4, 1), (8, 1), (8, 2), (4, 2)])
+def test_dag_schedule_respects_dependencies(world, lag):
     n_sops = 12
-    s = fp.DagSchedule(world, n_sops=n_sops)
+    s = fp.DagSchedule(world, n_sops=n_sops, lag=lag)
+    assert s.lag == lag
     nslots = s.slots_for_sequence()
     seen = {}
     live = {}       # DPB slot -> poc currently held
@@ -42,9 +43,15 @@ def test_dag_schedule_respects_dependencies(world):
             if p is None:
                 continue
             assert p.poc not in seen
-            for q in p.refs:   # the wait-for-reference rule: every reference finished in an EARLIER slot
+            for q in p.refs:   # the wait-for-reference rule: every reference finished in an EARLIER slot ...
                 assert q in seen and seen[q] < t, (p.poc, q)
+                # ... and `lag` slots earlier when it comes from another rank: its broadcast has a whole slot to land
+                if s.rank_of[q] != row.index(p):
+                    assert seen[q] + lag <= t, (p.poc, q, seen[q], t)
             seen[p.poc] = t
+            assert s.rank_of[p.poc] == row.index(p)
+            if world > 1 and p.poc % 8 == 0:
+                assert row.index(p) == 0      # the anchor chain stays on rank 0
         for p in row:
             if p is not None and p.is_reference:
                 d = s.dpb_slot[p.poc]
@@ -68,15 +75,23 @@ def test_dag_schedule_respects_dependencies(world):
 
 
 def test_eight_ranks_reach_the_level_skewed_pipeline():
-    s = fp.DagSchedule(8)
+    s = fp.DagSchedule(8, lag=1)
     # steady state: per slot POCs 1,3,5,7 of SOP k, 2,6 of SOP k+1, 4 of SOP k+2 and the anchor of SOP k+3
     for t in range(6, 40):
         pocs = sorted(p.poc for p in s.slot(t))
         k = pocs[0] // 8
         assert pocs == [8 * k + 1, 8 * k + 3, 8 * k + 5, 8 * k + 7, 8 * k + 10, 8 * k + 14, 8 * k + 20, 8 * k + 32]
+    # the default for 8 ranks on an endless sequence gives every broadcast a slot to land (lag 2): twice the skew between
+    # the levels, still one SOP = 8 pictures per slot, within the default window and mirror
+    s = fp.DagSchedule(8)
+    assert s.lag == 2
+    for t in range(14, 60):
+        pocs = sorted(p.poc for p in s.slot(t))
+        k = pocs[0] // 8
+        assert pocs == [8 * k + 1, 8 * k + 3, 8 * k + 5, 8 * k + 7, 8 * k + 18, 8 * k + 22, 8 * k + 36, 8 * k + 56], pocs
     for world in (1, 2, 4, 8):   # no idle rank in steady state at any width
         s = fp.DagSchedule(world)
-        assert all(p is not None for t in range(10, 80) for p in s.slot(t))
+        assert all(p is not None for t in range(20, 90) for p in s.slot(t))
     assert fp.DagSchedule(8, n_sops=4).slots_for_sequence() == 8      # 33 pictures: fill + drain dominate
     assert fp.DagSchedule(1, n_sops=4).slots_for_sequence() == 33
 

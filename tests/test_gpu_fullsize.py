@@ -115,14 +115,33 @@ def test_bench_frame_parallel_rehearsal_equals_single_rank_per_poc():
     assert "frame-parallel x2" in r2["config"]["parallelism"]
     r1 = _bench_json([sys.executable, os.path.join(root, "bench.py"), "--exchange"] + common, env, root)
     assert r1["n_gpus"] == 1 and len(r1["poc_checksums"]) == 17
-    # rank 0 of the 2-rank run saw about half of the pictures; each of them must agree with the single-rank run
-    assert 6 <= len(r2["poc_checksums"]) <= 11
+    # every picture of the 2-rank run (the ranks' checksums are gathered) must agree with the single-rank run
+    assert len(r2["poc_checksums"]) == 17
     for poc, c in r2["poc_checksums"].items():
         assert r1["poc_checksums"][poc] == c, poc
     # the dependency is real: pictures of one hierarchy level have different reconstructions
     assert len(set(r1["poc_checksums"].values())) >= 5
     from turingcodec_amd.frame_parallel import DagSchedule
     assert r2["steps"] == DagSchedule(2, n_sops=2).slots_for_sequence() and r1["steps"] == 17
+
+
+def test_bench_frame_parallel_rehearsal_eight_ranks_lag_two():
+    """the 8-rank schedule the driver's scaling run uses (anchor chain on rank 0, every other reference two slots ahead of its
+    users, 40 mirror slots): eight gloo ranks on the one GPU, a 49-picture sequence, every POC's reconstruction equal to the
+    single-rank run's"""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HAVOC_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = ["--kernel-reps", "1", "--tune", "0", "--scaling", "strong", "--pictures", "49", "--poc-checksums", "--no-cpu-baseline",
+              "--res", "416x240"]
+    r8 = _bench_json([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                      "--master-port", "29579", os.path.join(root, "bench.py"), "--gpus", "8", "--lag", "2"] + common, env, root, timeout=1500)
+    assert r8["n_gpus"] == 8 and len(r8["poc_checksums"]) == 49
+    r1 = _bench_json([sys.executable, os.path.join(root, "bench.py"), "--exchange"] + common, env, root)
+    assert r1["poc_checksums"] == r8["poc_checksums"]
+    from turingcodec_amd.frame_parallel import DagSchedule
+    assert r8["steps"] == DagSchedule(8, n_sops=6, lag=2).slots_for_sequence()
 
 
 def test_bench_weak_scaling_rehearsal_two_ranks():

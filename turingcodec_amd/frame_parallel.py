@@ -15,7 +15,9 @@ picture is reconstructed 4 CTUs to the right / 3 rows below; across GPUs the gra
 `DagSchedule` is the resulting list schedule: per time slot at most one picture per rank, earliest coding-order
 picture first among the ready ones.  With 8 ranks it settles into the level-skewed pipeline -- per slot the anchor of SOP
 k+3, POC 4 of SOP k+2, POCs 2 and 6 of SOP k+1 and POCs 1, 3, 5, 7 of SOP k -- i.e. eight pictures in flight, which is
-what ">= 6x at 8 GPUs" needs.
+what ">= 6x at 8 GPUs" needs.  The anchor chain (POC 8k -> 8k + 8) is kept on rank 0, where it is a local
+dependency, and with 8+ ranks every other reference is scheduled two slots ahead of its users (`lag`), so that no broadcast
+sits on a slot's critical path.
 """
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
@@ -78,14 +80,27 @@ class DagSchedule:
     n_sops = None: an endless sequence (the steady state of the weak-scaling bench); an int: IDR + n_sops SOPs, after
     which slot() returns all-None (the strong-scaling run over a fixed sequence)."""
 
-    def __init__(self, world: int, dpb_slots: int = 24, n_sops: Optional[int] = None, window: int = 32):
-        assert world >= 1 and dpb_slots >= 6
-        self.world, self.n_slots_dpb, self.n_sops, self.window = world, dpb_slots, n_sops, window
+    def __init__(self, world: int, dpb_slots: Optional[int] = None, n_sops: Optional[int] = None, window: Optional[int] = None,
+                 lag: Optional[int] = None):
+        """lag: a picture may start `lag` slots after the last reference it gets FROM ANOTHER RANK was scheduled.  1 = the
+        tightest schedule: that reference's broadcast (end of its slot) sits on the critical path of the next slot.  2 gives
+        every broadcast a whole slot to complete underneath other pictures' kernels, at the price of a deeper pipeline (more
+        pictures in the window, more mirror slots held).  The anchor chain POC 8k -> 8k + 8 always runs on rank 0 with lag 1:
+        that dependency is local.  With 8 ranks lag 2 still schedules 8 pictures per slot (one SOP per slot, seven levels of
+        skew); with 2-4 ranks a SOP spans several slots and the extra latency costs more than it hides, so the default is
+        lag 2 for world >= 8 on an endless sequence and 1 otherwise (a short finite sequence is fill / drain bound)."""
+        if lag is None:
+            lag = 2 if (world >= 8 and n_sops is None) else 1
+        dpb_slots = (24 if lag == 1 else 40) if dpb_slots is None else dpb_slots
+        window = (32 if lag == 1 else 64) if window is None else window
+        assert world >= 1 and dpb_slots >= 6 and lag >= 1
+        self.world, self.n_slots_dpb, self.n_sops, self.window, self.lag = world, dpb_slots, n_sops, window, lag
         self.pics: List[Picture] = [Picture(0, 0, True, ())]
         self._sops = 0
         self.by_poc: Dict[int, Picture] = {0: self.pics[0]}
         self.done_slot: Dict[int, int] = {}          # poc -> slot it was scheduled in
         self.dpb_slot: Dict[int, int] = {}           # poc -> DPB mirror slot (reference pictures)
+        self.rank_of: Dict[int, int] = {}            # poc -> rank that works on it
         self._free = list(range(dpb_slots))
         self._held: Dict[int, int] = {}              # poc -> mirror slot still held
         self._next = 0                               # oldest unscheduled coding-order index
@@ -136,7 +151,9 @@ class DagSchedule:
             i += 1
             if p.index in self._scheduled:
                 continue
-            if not all(self.done_slot.get(q, t) < t for q in p.refs):
+            # the anchor chain (POC 8k -> 8k + 8) stays on rank 0, so that dependency is local: no broadcast to wait for
+            lag = 1 if (p.poc % 8 == 0 and self.world > 1) else self.lag
+            if not all(self.done_slot.get(q, t) + lag <= t for q in p.refs):
                 continue
             if p.is_reference:
                 if not self._free:
@@ -150,7 +167,10 @@ class DagSchedule:
             self.done_slot[p.poc] = t
         while self._next < len(self.pics) and self._next in self._scheduled:
             self._next += 1
-        # ranks take the slot's pictures in coding order; a rank without one idles this slot
+        # rank 0 takes the slot's anchor picture (if any), the other ranks the rest in coding order; a rank without one idles
+        chosen.sort(key=lambda p: (p.poc % 8 != 0, p.index))
+        for r, p in enumerate(chosen):
+            self.rank_of[p.poc] = r
         return [chosen[r] if r < len(chosen) else None for r in range(self.world)]
 
     def finished(self, t: int) -> bool:
