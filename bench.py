@@ -936,6 +936,9 @@ class FramePipeline:
                 for j, ev in enumerate(self.last_copy):      # the mirror slot being staged into may still be read by a
                     if ev is not None and j != k:            # ref copy of the other picture in flight
                         compute.wait_event(ev)
+                prev = self.arrived.get(exch.slot_of(pic.poc))   # the slot's previous picture: its broadcast (which this rank
+                if prev is not None:                             # may have been the root of) must be over before it is overwritten
+                    compute.wait_event(prev)
                 with torch.cuda.stream(compute):
                     exch.stage(t, (dev.luma[3 * pl:4 * pl], dev.chroma[3 * cpl:4 * cpl], dev.chroma[4 * cpl:5 * cpl]))
                 staged = torch.cuda.Event()
