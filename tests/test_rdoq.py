@@ -148,6 +148,18 @@ def test_device_edge_cases(hv, oracle):
     want, want_cbf = rt.run_cpu(oracle, src, states, blocks)
     got, cbf = hv.rdoq(8, 4, src, states, jobs[:1])
     assert np.array_equal(got[:256], want[:256]) and not got[256:].any() and cbf[0] == want_cbf[0]
+    # a workspace smaller than havoc_mi355x_rdoq_workspace(njobs), or levels written over the coefficients, is refused
+    import torch
+    from turingcodec_amd.havoc import HavocError
+    d_src = hv.up(src)
+    d_dst = hv.zeros(len(src), np.int16)
+    d_states = torch.from_numpy(states.reshape(-1)).to(hv.device)
+    d_jobs = torch.from_numpy(jobs.view(np.uint8).reshape(-1)).to(hv.device)
+    d_cbf = hv.zeros(len(jobs), np.int32)
+    with pytest.raises(HavocError):
+        hv.rdoq_d(8, 4, d_dst, d_src, d_states, d_jobs, d_cbf, torch.zeros(4, dtype=torch.int64, device=hv.device))
+    with pytest.raises(HavocError):
+        hv.rdoq_d(8, 4, d_src, d_src, d_states, d_jobs, d_cbf, hv.rdoq_workspace(len(jobs)))
     jobs["dst_off"] = jobs["src_off"][::-1]
     got, cbf = hv.rdoq(8, 4, src, states, jobs)
     for i, b in enumerate(blocks):
