@@ -100,5 +100,6 @@ def test_quantiser_parameters_follow_qpstate():
     """turing/QpState.h:85-94 / Reconstruct.cpp:286,311,315 at the QPs of BASELINE.json's configs"""
     from turingcodec_amd.workload import dequant_params, quant_params
     assert quant_params(32, 3, 8, False) == (20560, 29 - 8 + 5 - 3, 85 << 7)
-    assert quant_params(27, 5, 10, True) == (18396, 29 - 10 + 4 - 5, 171 << 7)
-    assert dequant_params(32, 3, 8) == (51 << 5, 2) and dequant_params(27, 2, 10) == (57 << 4, 3)
+    # 10-bit: QP' = QP + QpBdOffsetY = 27 + 12 = 39 (turing/QpState.h:56, 79-94)
+    assert quant_params(27, 5, 10, True) == (18396, 29 - 10 + 6 - 5, 171 << 7)
+    assert dequant_params(32, 3, 8) == (51 << 5, 2) and dequant_params(27, 2, 10) == (57 << 6, 3)

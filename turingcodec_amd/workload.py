@@ -89,13 +89,16 @@ DEQUANT_SCALE = [40, 45, 51, 57, 64, 72]
 
 
 def quant_params(qp, log2, bit_depth, intra_slice):
-    """(scale, shift, offset) as turing/Reconstruct.cpp:286,311 (intra) / :785,817 (inter) hand them to havoc_quantize"""
-    return QUANT_SCALE[qp % 6], 29 - bit_depth + qp // 6 - log2, (171 if intra_slice else 85) << 7
+    """(scale, shift, offset) as turing/Reconstruct.cpp:286,311 (intra) / :785,817 (inter) hand them to havoc_quantize; qp is the
+    slice QP: the quantiser works with QP' = QP + QpBdOffset = QP + 6 * (bitDepth - 8) (turing/QpState.h:56, 79-94)"""
+    q = qp + 6 * (bit_depth - 8)
+    return QUANT_SCALE[q % 6], 29 - bit_depth + q // 6 - log2, (171 if intra_slice else 85) << 7
 
 
 def dequant_params(qp, log2, bit_depth):
-    """(scale, shift) of turing/QpState.h:85-86 / Reconstruct.cpp:315"""
-    return DEQUANT_SCALE[qp % 6] << (qp // 6), log2 - 1 + bit_depth - 8
+    """(scale, shift) of turing/QpState.h:85-86 / Reconstruct.cpp:315, with QP' as above"""
+    q = qp + 6 * (bit_depth - 8)
+    return DEQUANT_SCALE[q % 6] << (q // 6), log2 - 1 + bit_depth - 8
 
 
 def picture_lambda(qp, qp_factor=0.68, non_reference=True):
