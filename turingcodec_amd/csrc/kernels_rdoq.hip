@@ -503,10 +503,11 @@ struct ScanShared
 // Cooperative scan: 64 lanes look at one 32x32 block's 64 groups (or four 16x16 blocks, ...) per step, coalesced: which groups hold
 // a non-zero rounded level, the block's energy; zeros into the output.  Results for block k of the workgroup in sc.mask[k], sc.sumSq[k].
 template <int LOG2>
-__device__ __forceinline__ void scanBlocks(ScanShared &sc, int16_t *__restrict__ dstAll, const int16_t *__restrict__ srcAll, const RdoqJob *__restrict__ jobs, int njobs)
+__device__ __forceinline__ void scanBlocks(ScanShared &sc, int16_t *__restrict__ dstAll, const int16_t *__restrict__ srcAll, const RdoqJob *__restrict__ jobs, int njobs,
+                                           int firstBlock, int steps)
 {
     constexpr int size = 1 << LOG2, G = (size * size) >> 4, log2G = 2 * LOG2 - 4, gw = size >> 2, perStep = 64 / G;
-    const int lane = threadIdx.x, blk = blockIdx.x * 64 + lane;
+    const int lane = threadIdx.x, blk = firstBlock + lane;
     {
         const RdoqJob &job = jobs[blk < njobs ? blk : njobs - 1];
         sc.srcOff[lane] = job.src_off;
@@ -519,10 +520,10 @@ __device__ __forceinline__ void scanBlocks(ScanShared &sc, int16_t *__restrict__
     }
     __syncthreads();
     const int sub = lane >> log2G, pos = lane & (G - 1), px = pos & (gw - 1), py = pos / gw;
-    for (int step = 0; step < G; ++step)        // G steps of 64 / G blocks = 64 blocks
+    for (int step = 0; step < steps; ++step)    // 64 / G blocks per step
     {
         const int bl = step * perStep + sub;
-        const bool have = blockIdx.x * 64 + bl < njobs;
+        const bool have = firstBlock + bl < njobs;
         const int16_t *p = srcAll + (long)sc.srcOff[bl] + (py * 4) * size + px * 4;
         int16_t *q = dstAll + (long)sc.dstOff[bl] + (py * 4) * size + px * 4;
         const uint32_t thr = (uint32_t)sc.nzThreshold[bl];
@@ -559,18 +560,22 @@ __device__ __forceinline__ void scanBlocks(ScanShared &sc, int16_t *__restrict__
     __syncthreads();
 }
 
-// Pass 1 of the sorted form (large blocks): the scan, its results to the workspace, histogram of the blocks by groups to walk.
+// Pass 1 of the sorted form (large blocks): the scan, kScanSteps steps per workgroup (eight 32x32 blocks, or thirty-two 16x16 blocks,
+// per wavefront: enough wavefronts to fill the machine, few enough histogram atomics), its results to the workspace, histogram of
+// the blocks by groups to walk.
+constexpr int kScanSteps = 8;
 template <int LOG2>
 __global__ __launch_bounds__(64) void k_rdoq_scan(int16_t *__restrict__ dstAll, const int16_t *__restrict__ srcAll, const RdoqJob *__restrict__ jobs, int njobs,
                                                   RdoqWork *__restrict__ work)
 {
+    constexpr int perWg = kScanSteps * (64 / (((1 << LOG2) * (1 << LOG2)) >> 4));      // <= 64
     __shared__ ScanShared sc;
     __shared__ uint32_t hist[kBins];
-    const int lane = threadIdx.x, blk = blockIdx.x * 64 + lane;
+    const int lane = threadIdx.x, first = blockIdx.x * perWg, blk = first + lane;
     RdoqInfo *info = reinterpret_cast<RdoqInfo *>(reinterpret_cast<char *>(work) + rdoqInfoOffset());
     for (int k = lane; k < kBins; k += 64) hist[k] = 0;
-    scanBlocks<LOG2>(sc, dstAll, srcAll, jobs, njobs);
-    if (blk < njobs)
+    scanBlocks<LOG2>(sc, dstAll, srcAll, jobs, njobs, first, kScanSteps);
+    if (lane < perWg && blk < njobs)
     {
         RdoqInfo r;
         r.mask = sc.mask[lane];
@@ -632,7 +637,7 @@ __global__ __launch_bounds__(64) void k_rdoq_walk(int16_t *__restrict__ dstAll, 
     else
     {
         __shared__ ScanShared sc;
-        scanBlocks<LOG2>(sc, dstAll, srcAll, jobs, njobs);
+        scanBlocks<LOG2>(sc, dstAll, srcAll, jobs, njobs, blockIdx.x * 64, G);
         info.mask = sc.mask[lane];
         info.sumSq = sc.sumSq[lane];
     }
@@ -847,8 +852,8 @@ hipError_t launch_rdoq(hipStream_t st, int bitDepth, int log2, int16_t *dst, con
     }
     hipError_t e = hipMemsetAsync(work, 0, sizeof(RdoqWork), st);
     if (e != hipSuccess) return e;
-    if (log2 == 4) hipLaunchKernelGGL(k_rdoq_scan<4>, dim3(wgs), dim3(64), 0, st, dst, src, j, njobs, work);
-    else hipLaunchKernelGGL(k_rdoq_scan<5>, dim3(wgs), dim3(64), 0, st, dst, src, j, njobs, work);
+    if (log2 == 4) hipLaunchKernelGGL(k_rdoq_scan<4>, dim3((njobs + 4 * kScanSteps - 1) / (4 * kScanSteps)), dim3(64), 0, st, dst, src, j, njobs, work);
+    else hipLaunchKernelGGL(k_rdoq_scan<5>, dim3((njobs + kScanSteps - 1) / kScanSteps), dim3(64), 0, st, dst, src, j, njobs, work);
     hipLaunchKernelGGL(k_rdoq_order, dim3((njobs + 255) / 256), dim3(256), 0, st, njobs, work);
     if (log2 == 4) hipLaunchKernelGGL((k_rdoq_walk<4, true>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work);
     else hipLaunchKernelGGL((k_rdoq_walk<5, true>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work);
