@@ -24,7 +24,7 @@ import search_tools as st
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not os.path.exists(reflibs.REF_SO), reason="oracle/_ref not built")]
 
-W, H, PAD, BD, QP, N = 416, 240, 96, 8, 32, 16     # picture, border, bit depth, slice QP, block size
+W, H, PAD, QP, N = 416, 240, 96, 32, 16     # picture, border, slice QP, block size
 
 
 class Stats(C.Structure):
@@ -67,11 +67,11 @@ def _strengths(mv, cbf):
     return data.ravel(), bs.ravel()
 
 
-def _host_picture(R, ref_client, par, src, ref, stride, pus, rq, states):
+def _host_picture(R, ref_client, par, src, ref, stride, pus, rq, states, BD):
     """one picture through the reference's functions; returns decisions and every intermediate"""
     res = ref_client.uni(par, src, ref, stride, PAD, pus)
     n = len(pus)
-    pred = np.zeros(W * H, np.uint8)
+    pred = np.zeros(W * H, src.dtype)
     coef = np.zeros(n * N * N, np.int16)
     level = np.zeros_like(coef)
     deq = np.zeros_like(coef)
@@ -95,7 +95,7 @@ def _host_picture(R, ref_client, par, src, ref, stride, pus, rq, states):
         ssd[i] = R.ssd(src, so, stride, recon, so, stride, N, N)
     before = recon.copy()
     data, bs = _strengths(res["mv"], cbf)
-    cb = np.full((H // 2) * (W // 2), 128, np.uint8)
+    cb = np.full((H // 2) * (W // 2), 128 << (BD - 8), src.dtype)
     cr = cb.copy()
     o = PAD * stride + PAD
     y = recon[o:]          # view whose element 0 is sample (0, 0)
@@ -104,20 +104,21 @@ def _host_picture(R, ref_client, par, src, ref, stride, pus, rq, states):
     return dict(res=res, coef=coef, level=level, cbf=cbf, ssd=ssd, before=before, recon=recon, bs=bs)
 
 
-def _device_picture(hv, L, par, d_src, d_ref, stride, pe, pus, rq, d_states):
+def _device_picture(hv, L, par, d_src, d_ref, stride, pe, pus, rq, d_states, BD):
     """the same picture on the device; d_src / d_ref: padded planes in HBM (uint8 tensors)"""
     import torch
     from turingcodec_amd import havoc as hmod
     n = len(pus)
+    dt = np.uint8 if BD == 8 else np.uint16
     origin = PAD * stride + PAD
-    planes = hv.zeros(16 * pe, np.uint8)
+    planes = hv.zeros(16 * pe, dt)
     hv.interp_planes_d(BD, planes, pe, d_ref, stride, 12, 4, W + 2 * PAD - 24, H + 2 * PAD - 8)
     with torch.cuda.stream(hv.tstream):
         planes[:d_ref.numel()] = d_ref          # phase 0 = the picture itself
     hv.sync()
     out = np.zeros(n, st.RESULT_DT)
     stats = Stats()
-    rc = L.havoc_search_motion_uni(hv.h, 1, C.byref(par), C.c_void_p(d_src.data_ptr()), origin, stride, C.c_void_p(d_ref.data_ptr()), origin, stride, PAD,
+    rc = L.havoc_search_motion_uni(hv.h, np.dtype(dt).itemsize, C.byref(par), C.c_void_p(d_src.data_ptr()), origin, stride, C.c_void_p(d_ref.data_ptr()), origin, stride, PAD,
                                    C.c_void_p(planes.data_ptr()), pe, origin, pus.ctypes.data, n, out.ctypes.data, 8, C.byref(stats))
     assert rc == 0, rc
     mv = out["mv"].astype(np.int32)
@@ -126,7 +127,7 @@ def _device_picture(hv, L, par, d_src, d_ref, stride, pe, pus, rq, d_states):
     pj[:, 0] = y0 * W + x0
     pj[:, 1] = (y0 + (mv[:, 1] >> 2) + PAD) * stride + x0 + (mv[:, 0] >> 2) + PAD
     pj[:, 2], pj[:, 3], pj[:, 4], pj[:, 5] = N, N, mv[:, 0] & 3, mv[:, 1] & 3
-    pred = hv.zeros(W * H, np.uint8)
+    pred = hv.zeros(W * H, dt)
     hv.pred_uni_d(8, BD, pred, W, d_ref, stride, hv.up(pj), 16, 16)
     fj = np.zeros((n, 4), np.int32)
     fj[:, 0] = np.arange(n) * N * N
@@ -135,7 +136,7 @@ def _device_picture(hv, L, par, d_src, d_ref, stride, pe, pus, rq, d_states):
     d_fj = hv.up(fj)
     coef, level = hv.zeros(n * N * N, np.int16), hv.zeros(n * N * N, np.int16)
     cbf, ssd = hv.zeros(n, np.int32), hv.zeros(n, np.uint32)
-    recon = hv.zeros(d_src.numel(), np.uint8)
+    recon = hv.zeros(d_src.numel(), dt)
     hv.tu_forward_d(BD, 0, 4, coef, d_src, stride, pred, W, d_fj)
     jobs = np.zeros(n, hmod.RDOQ_JOB_DT)
     jobs["dst_off"] = jobs["src_off"] = fj[:, 0]
@@ -146,10 +147,10 @@ def _device_picture(hv, L, par, d_src, d_ref, stride, pe, pus, rq, d_states):
         d_jobs = torch.from_numpy(jobs.view(np.uint8).reshape(-1)).to(hv.device)
     hv.rdoq_d(BD, 4, level, coef, d_states, d_jobs, cbf, hv.rdoq_workspace(n))
     hv.tu_reconstruct_d(BD, 0, 4, rq["inv"], rq["dshift"], recon, stride, pred, W, d_src, stride, level, d_fj, ssd)
-    before = hv.down(recon, np.uint8).copy()
+    before = hv.down(recon, dt).copy()
     h_cbf = hv.down(cbf, np.int32)
     data, bs = _strengths(out["mv"], h_cbf)     # the encoder's decisions -> the loop filter's block map (host logic, as in the reference)
-    chroma = hv.up(np.full(2 * (H // 2) * (W // 2), 128, np.uint8))
+    chroma = hv.up(np.full(2 * (H // 2) * (W // 2), 128 << (BD - 8), dt))
     with torch.cuda.stream(hv.tstream):
         d_data = torch.from_numpy(data).to(hv.device)
         d_bs = torch.from_numpy(bs).to(hv.device)
@@ -157,10 +158,11 @@ def _device_picture(hv, L, par, d_src, d_ref, stride, pe, pus, rq, d_states):
     hv.pad_block_d(recon, origin, W, H, stride, PAD)
     hv.sync()
     return dict(res=out, coef=hv.down(coef, np.int16), level=hv.down(level, np.int16), cbf=h_cbf, ssd=hv.down(ssd, np.uint32), before=before,
-                recon=hv.down(recon, np.uint8), d_recon=recon, bs=bs, stats=stats)
+                recon=hv.down(recon, dt), d_recon=recon, bs=bs, stats=stats)
 
 
-def test_two_pictures_through_the_whole_chain_equal_the_reference_functions():
+@pytest.mark.parametrize("BD", [8, 10])
+def test_two_pictures_through_the_whole_chain_equal_the_reference_functions(BD):
     from turingcodec_amd import havoc as hmod
     from turingcodec_amd.havoc import Havoc
     from turingcodec_amd.workload import dequant_params, picture_lambda, quant_params
@@ -185,8 +187,8 @@ def test_two_pictures_through_the_whole_chain_equal_the_reference_functions():
         d_states = torch.from_numpy(states).to(hv.device)
 
     pus1 = _blocks((-12, -8))      # the clip moves (3, 2) samples per frame
-    host1 = _host_picture(R, ref_client, par, src1, ref0, stride, pus1, rq, states)
-    dev1 = _device_picture(hv, L, par, hv.up(src1), hv.up(ref0), stride, pe, pus1, rq, d_states)
+    host1 = _host_picture(R, ref_client, par, src1, ref0, stride, pus1, rq, states, BD)
+    dev1 = _device_picture(hv, L, par, hv.up(src1), hv.up(ref0), stride, pe, pus1, rq, d_states, BD)
     for k in ("mv", "mvd", "mv_integer", "mvp_flag", "cost_integer", "cost_subpel", "calls"):
         assert np.array_equal(host1["res"][k], dev1["res"][k]), k
     for k in ("coef", "level", "cbf", "ssd", "bs", "before", "recon"):
@@ -198,8 +200,8 @@ def test_two_pictures_through_the_whole_chain_equal_the_reference_functions():
 
     # picture 2 predicts from picture 1's RECONSTRUCTION: on the device straight from the reconstruction plane in HBM
     pus2 = _blocks((-12, -8))
-    host2 = _host_picture(R, ref_client, par, src2, host1["recon"], stride, pus2, rq, states)
-    dev2 = _device_picture(hv, L, par, hv.up(src2), dev1["d_recon"], stride, pe, pus2, rq, d_states)
+    host2 = _host_picture(R, ref_client, par, src2, host1["recon"], stride, pus2, rq, states, BD)
+    dev2 = _device_picture(hv, L, par, hv.up(src2), dev1["d_recon"], stride, pe, pus2, rq, d_states, BD)
     for k in ("mv", "mvd", "cost_integer", "cost_subpel"):
         assert np.array_equal(host2["res"][k], dev2["res"][k]), k
     for k in ("level", "cbf", "ssd", "recon"):
