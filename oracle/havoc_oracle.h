@@ -80,6 +80,10 @@ void oracle_rdoq_lambda(double lambda, int invQuantScale, int32_t *lambdaQ16, in
 /* turing/ScanOrder.h:212-223 */
 int oracle_scan_order(int log2BlockSize, int scanIdx, int sPos, int sComp);
 
+/* turing/EncSao.h:62-283 and turing/sao.cpp:33-92 (oracle/sao_oracle.c): the statistics and the two filters of sample-adaptive offset */
+void oracle_sao_stats(const void *src, intptr_t ss, const void *rec, intptr_t rs, int w, int h, int shift, int S, int64_t *out /* [105] */);
+void oracle_sao_filter(void *dst, intptr_t ds, const void *src, intptr_t ss, int w, int h, int type, int eoClass, const int16_t *offsets, int bitDepth, int S);
+
 #ifdef __cplusplus
 }
 #endif

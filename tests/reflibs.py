@@ -38,7 +38,7 @@ def _S(a):
 class Oracle:
     def __init__(self):
         if not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < max(
-                os.path.getmtime(os.path.join(ROOT, "oracle", f)) for f in ("havoc_oracle.c", "rdoq_oracle.c", "havoc_oracle.h")):
+                os.path.getmtime(os.path.join(ROOT, "oracle", f)) for f in ("havoc_oracle.c", "rdoq_oracle.c", "sao_oracle.c", "havoc_oracle.h")):
             build_oracle()
         L = self.L = C.CDLL(ORACLE_SO)
         L.oracle_sad.restype = C.c_int
@@ -87,6 +87,20 @@ class Oracle:
         L.oracle_rdoq_lambda.argtypes = [C.c_double, C.c_int, _vp, _vp]
         L.oracle_scan_order.restype = C.c_int
         L.oracle_scan_order.argtypes = [C.c_int] * 4
+
+    def sao_stats(self, src, so, ss, rec, ro, rs, w, h, bd):
+        """-> int64[105] (oracle/sao_oracle.c); src / rec: flat arrays, offsets and strides in samples"""
+        out = np.zeros(105, np.int64)
+        self.L.oracle_sao_stats.restype = None
+        self.L.oracle_sao_stats.argtypes = [_vp, _ip, _vp, _ip] + [C.c_int] * 4 + [_vp]
+        self.L.oracle_sao_stats(_addr(src, so), ss, _addr(rec, ro), rs, w, h, bd - 8, _S(src), _addr(out))
+        return out
+
+    def sao_filter(self, dst, do, ds, src, so, ss, w, h, kind, eo_class, offsets, bd):
+        offsets = np.ascontiguousarray(offsets, np.int16)
+        self.L.oracle_sao_filter.restype = None
+        self.L.oracle_sao_filter.argtypes = [_vp, _ip, _vp, _ip] + [C.c_int] * 4 + [_vp, C.c_int, C.c_int]
+        self.L.oracle_sao_filter(_addr(dst, do), ds, _addr(src, so), ss, w, h, kind, eo_class, _addr(offsets), bd, _S(src))
 
     def rdoq_lambda(self, lam, inv_scale):
         """(lambda in Q16, sign-data-hiding factor) as the reference's Rdoq constructor derives them from the double"""
@@ -243,6 +257,29 @@ class Reference:
         dst = np.zeros(1 << 2 * log2, np.int16)
         r = f(_addr(dst), _addr(src), log2, c_idx, scan_idx, int(is_intra), int(sdh), q_scale, q_shift, inv_scale, bd, float(lam), _addr(states))
         return dst, r
+
+    def sao_stats(self, src, so, ss, rec, ro, rs, w, h, bd):
+        """the reference's EncSao statistics templates (oracle/ref_shim_sao.cpp) -> int64[105]"""
+        f = self._f("ref_sao_stats", src)
+        f.restype = None
+        f.argtypes = [_vp, _ip, _vp, _ip] + [C.c_int] * 3 + [_vp]
+        out = np.zeros(105, np.int64)
+        f(_addr(src, so), ss, _addr(rec, ro), rs, w, h, bd - 8, _addr(out))
+        return out
+
+    def sao_filter(self, dst, do, ds, src, so, ss, w, h, kind, eo_class, offsets, bd):
+        """turing/sao.cpp: kind 1 = sao_filter_band (32-entry table), 2 = sao_filter_edge (SaoOffsetVal[5])"""
+        offsets = np.ascontiguousarray(offsets, np.int16)
+        if kind == 1:
+            f = self._f("ref_sao_band", src)
+            f.restype = None
+            f.argtypes = [_vp, _ip, _vp, _ip, C.c_int, C.c_int, _vp, C.c_int]
+            f(_addr(dst, do), ds, _addr(src, so), ss, w, h, _addr(offsets), bd)
+        else:
+            f = self._f("ref_sao_edge", src)
+            f.restype = None
+            f.argtypes = [_vp, _ip, _vp, _ip, C.c_int, C.c_int, _vp, C.c_int, C.c_int]
+            f(_addr(dst, do), ds, _addr(src, so), ss, w, h, _addr(offsets), eo_class, bd)
 
     def rdoq_initial_states(self, qp, init_type):
         """the 128-byte state snapshot a slice of that QP / initType starts from (Contexts::initialize)"""
