@@ -31,6 +31,8 @@ hipError_t launch_tu_reconstruct(hipStream_t, int S, int bd, int log2, int tr, i
 hipError_t launch_quantize(hipStream_t, int16_t *, const int16_t *, const void *, int, int32_t *);
 hipError_t launch_rdoq(hipStream_t, int bd, int log2, int16_t *, const int16_t *, const uint8_t *, const void *, int, int32_t *, void *);
 size_t rdoq_workspace_bytes(int njobs);
+hipError_t launch_sao_stats(hipStream_t, int S, int bd, const void *, long, const void *, long, const void *, int, int64_t *);
+hipError_t launch_sao_filter(hipStream_t, int S, int bd, void *, long, const void *, long, const void *, int);
 hipError_t launch_quantize_inverse(hipStream_t, int16_t *, const int16_t *, const void *, int);
 hipError_t launch_quantize_reconstruct(hipStream_t, int log2, uint8_t *, long, const uint8_t *, long, const int16_t *, const void *, int);
 hipError_t launch_residual(hipStream_t, int S, int16_t *, long, const int32_t *, const void *, long, const void *, long, const void *, int);
@@ -513,6 +515,21 @@ void havoc_mi355x_rdoq_lambda(double lambda, int inv_scale, int32_t *lambda_q16,
 {
     if (lambda_q16) *lambda_q16 = static_cast<int32_t>(lambda * (1 << 16) + 0.5);
     if (sdh_factor) *sdh_factor = (int)(inv_scale * inv_scale / lambda / 16 + 0.5);
+}
+
+int havoc_mi355x_sao_stats(havoc_mi355x_ctx *ctx, int S, int bitDepth, const void *d_src, intptr_t stride_src, const void *d_rec, intptr_t stride_rec,
+                           const havoc_mi355x_sao_stats_job *d_jobs, int njobs, int64_t *d_out)
+{
+    REQUIRE_CTX(); REQUIRE(S == 1 || S == 2, "S must be 1 or 2"); REQUIRE_BD(); REQUIRE(njobs >= 0, "njobs < 0");
+    return check(launch_sao_stats(LS(ctx), S, bitDepth, d_src, stride_src, d_rec, stride_rec, d_jobs, njobs, d_out), "sao_stats");
+}
+
+int havoc_mi355x_sao_filter(havoc_mi355x_ctx *ctx, int S, int bitDepth, void *d_dst, intptr_t stride_dst, const void *d_src, intptr_t stride_src,
+                            const havoc_mi355x_sao_job *d_jobs, int njobs)
+{
+    REQUIRE_CTX(); REQUIRE(S == 1 || S == 2, "S must be 1 or 2"); REQUIRE_BD(); REQUIRE(njobs >= 0, "njobs < 0");
+    REQUIRE(d_dst != d_src, "sao_filter: the filtered picture and the deblocked picture must be different buffers");
+    return check(launch_sao_filter(LS(ctx), S, bitDepth, d_dst, stride_dst, d_src, stride_src, d_jobs, njobs), "sao_filter");
 }
 
 size_t havoc_mi355x_rdoq_workspace(int njobs) { return rdoq_workspace_bytes(njobs); }

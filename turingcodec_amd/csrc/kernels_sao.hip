@@ -1,0 +1,138 @@
+// Sample-adaptive offset primitives (the SAO third):
+//
+//   k_sao_stats  : the statistics the encoder's SAO decision is made from, turing/EncSao.h:151-283 (edge_offset_stats_class0..3:
+//                  per category the number of samples and the sum of original - reconstruction) and :111-148
+//                  (band_offset_luma_stats: the same per band of 8 << (bitDepth - 8) values, and the four-band window holding most
+//                  samples), over a block WITHOUT its outermost ring of samples.  The horizontal class counts the first interior
+//                  sample of every row twice, the second time in category 0 (EncSao.h:166-176): reproduced.
+//   k_sao_filter : turing/sao.cpp:33-92 -- sao_filter_band (offset by band) and sao_filter_edge (offset by the sign pattern
+//                  against the two neighbours of the edge class); source and destination are different pictures, so every
+//                  sample is independent.
+// The rate-distortion decision between them (EncSao.h:286-1125, floating point) and the CTU availability rules
+// (LoopFilter.h:886-1008) are encoder control and stay on the host, like the deblocking filter's boundary strengths.
+//
+// One workgroup per job (a CTU of one colour component).  Statistics: a lane takes samples of the interior at stride 256, reads
+// the 3x3 neighbourhood through the cache, and adds into 104 LDS counters (no-return ds_add); the sums fit 32 bits (62 x 62
+// samples x 16-bit differences).  Both kernels are a few microseconds per picture: HBM-bound streaming of two planes.
+#include "common.h"
+
+namespace havoc_gpu {
+
+namespace {
+
+struct SaoStatsJob { int32_t src_off, rec_off, w, h; };
+struct SaoJob { int32_t dst_off, src_off, w, h, type, eo_class; int16_t offsets[32]; int32_t reserved[2]; };
+static_assert(sizeof(SaoStatsJob) == sizeof(havoc_mi355x_sao_stats_job) && sizeof(SaoJob) == sizeof(havoc_mi355x_sao_job) && sizeof(SaoJob) == 96, "sao job layout");
+
+__device__ __forceinline__ int sign3(int v) { return (v > 0) - (v < 0); }
+
+template <int S>
+__global__ __launch_bounds__(256) void k_sao_stats(const char *__restrict__ srcPlane, long strideSrc, const char *__restrict__ recPlane, long strideRec,
+                                                   const SaoStatsJob *__restrict__ jobs, int shift, long long *__restrict__ out)
+{
+    typedef typename Sample<S>::T T;
+    __shared__ int acc[104];
+    const SaoStatsJob job = jobs[blockIdx.x];
+    const T *src = reinterpret_cast<const T *>(srcPlane) + job.src_off, *rec = reinterpret_cast<const T *>(recPlane) + job.rec_off;
+    const int tid = threadIdx.x, iw = job.w - 2, ih = job.h - 2;
+    if (tid < 104) acc[tid] = 0;
+    __syncthreads();
+    for (int k = tid; k < iw * ih; k += 256)
+    {
+        const int y = 1 + k / iw, x = 1 + k - (y - 1) * iw;
+        const T *r = rec + y * strideRec + x;
+        const int c = r[0], diff = (int)src[y * strideSrc + x] - c;
+        const int up = r[-strideRec], down = r[strideRec];
+        const int cat[4] = { 2 + sign3(c - (int)r[-1]) + sign3(c - (int)r[1]), 2 + sign3(c - up) + sign3(c - down),
+                             2 + sign3(c - (int)r[-strideRec - 1]) + sign3(c - (int)r[strideRec + 1]),
+                             2 + sign3(c - (int)r[-strideRec + 1]) + sign3(c - (int)r[strideRec - 1]) };
+#pragma unroll
+        for (int cls = 0; cls < 4; ++cls)
+        {
+            const int category = (0x43021 >> (4 * cat[cls])) & 7;      // 2 + sign + sign -> 1, 2, 0, 3, 4
+            atomicAdd(&acc[10 * cls + category], diff);
+            atomicAdd(&acc[10 * cls + 5 + category], 1);
+        }
+        const int band = c >> (3 + shift);
+        atomicAdd(&acc[40 + band], diff);
+        atomicAdd(&acc[72 + band], 1);
+    }
+    if (iw > 0)
+        for (int y = 1 + tid; y <= ih; y += 256)      // the horizontal class's second look at x = 1
+        {
+            atomicAdd(&acc[0], (int)src[y * strideSrc + 1] - (int)rec[y * strideRec + 1]);
+            atomicAdd(&acc[5], 1);
+        }
+    __syncthreads();
+    long long *o = out + 105L * blockIdx.x;
+    if (tid < 104) o[tid] = acc[tid];
+    if (tid == 0)
+    {
+        int best = 0, start = 0;
+        for (int b = 0; b < 29; ++b)
+        {
+            const int cum = acc[72 + b] + acc[73 + b] + acc[74 + b] + acc[75 + b];
+            if (cum > best)
+            {
+                best = cum;
+                start = b;
+            }
+        }
+        o[104] = max(start + 1, 2);
+    }
+}
+
+template <int S>
+__global__ __launch_bounds__(256) void k_sao_filter(char *__restrict__ dstPlane, long strideDst, const char *__restrict__ srcPlane, long strideSrc,
+                                                    const SaoJob *__restrict__ jobs, int bitDepth)
+{
+    typedef typename Sample<S>::T T;
+    __shared__ SaoJob job;
+    if (threadIdx.x < sizeof(SaoJob) / 4) reinterpret_cast<int *>(&job)[threadIdx.x] = reinterpret_cast<const int *>(jobs + blockIdx.x)[threadIdx.x];
+    __syncthreads();
+    T *dst = reinterpret_cast<T *>(dstPlane) + job.dst_off;
+    const T *src = reinterpret_cast<const T *>(srcPlane) + job.src_off;
+    const int mx = (1 << bitDepth) - 1, w = job.w, n = job.w * job.h;
+    // neighbours of the edge class (sao.cpp:63-73): horizontal, vertical, 135 degrees, 45 degrees
+    const int e = job.eo_class & 3, hx = e == 1 ? 0 : (e == 3 ? 1 : -1), vy = e == 0 ? 0 : -1;
+    const long n0 = vy * strideSrc + hx;
+    for (int k = threadIdx.x; k < n; k += 256)
+    {
+        const int y = k / w, x = k - y * w;
+        const T *p = src + y * strideSrc + x;
+        const int c = p[0];
+        int v = c;
+        if (job.type == 1)
+            v = c + job.offsets[c >> (bitDepth - 5)];
+        else if (job.type == 2)
+        {
+            int idx = 2 + sign3(c - (int)p[n0]) + sign3(c - (int)p[-n0]);
+            idx = idx > 2 ? idx : (idx == 2 ? 0 : idx + 1);
+            v = c + job.offsets[idx];
+        }
+        dst[y * strideDst + x] = (T)min(max(v, 0), mx);
+    }
+}
+
+} // namespace
+
+hipError_t launch_sao_stats(hipStream_t st, int S, int bitDepth, const void *src, long strideSrc, const void *rec, long strideRec, const void *jobs, int njobs,
+                            int64_t *out)
+{
+    if (njobs <= 0) return hipSuccess;
+    const SaoStatsJob *j = static_cast<const SaoStatsJob *>(jobs);
+    if (S == 1) hipLaunchKernelGGL(k_sao_stats<1>, dim3(njobs), dim3(256), 0, st, (const char *)src, strideSrc, (const char *)rec, strideRec, j, bitDepth - 8, (long long *)out);
+    else hipLaunchKernelGGL(k_sao_stats<2>, dim3(njobs), dim3(256), 0, st, (const char *)src, strideSrc, (const char *)rec, strideRec, j, bitDepth - 8, (long long *)out);
+    return hipGetLastError();
+}
+
+hipError_t launch_sao_filter(hipStream_t st, int S, int bitDepth, void *dst, long strideDst, const void *src, long strideSrc, const void *jobs, int njobs)
+{
+    if (njobs <= 0) return hipSuccess;
+    const SaoJob *j = static_cast<const SaoJob *>(jobs);
+    if (S == 1) hipLaunchKernelGGL(k_sao_filter<1>, dim3(njobs), dim3(256), 0, st, (char *)dst, strideDst, (const char *)src, strideSrc, j, bitDepth);
+    else hipLaunchKernelGGL(k_sao_filter<2>, dim3(njobs), dim3(256), 0, st, (char *)dst, strideDst, (const char *)src, strideSrc, j, bitDepth);
+    return hipGetLastError();
+}
+
+} // namespace havoc_gpu

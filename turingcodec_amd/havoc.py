@@ -93,6 +93,8 @@ def _load():
         "quantize_inverse": [_vp, _vp, _vp, _vp, _i],
         "quantize_reconstruct": [_vp, _i, _vp, _ip, _vp, _ip, _vp, _vp, _i],
         "rdoq": [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, C.c_size_t],
+        "sao_stats": [_vp, _i, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
+        "sao_filter": [_vp, _i, _i, _vp, _ip, _vp, _ip, _vp, _i],
     }
     L.havoc_mi355x_rdoq_lambda.argtypes = [C.c_double, _i, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.havoc_mi355x_rdoq_lambda.restype = None
@@ -110,6 +112,11 @@ def exported_symbols():
     _, names = _load()
     return ["havoc_mi355x_" + n for n in names] + ["havoc_mi355x_last_error", "havoc_mi355x_version", "havoc_mi355x_rdoq_lambda", "havoc_mi355x_rdoq_workspace"]
 
+
+# one havoc_mi355x_sao_job (include/havoc_mi355x.h), 96 bytes
+SAO_JOB_DT = np.dtype([("dst_off", "<i4"), ("src_off", "<i4"), ("w", "<i4"), ("h", "<i4"), ("type", "<i4"), ("eo_class", "<i4"), ("offsets", "<i2", 32),
+                       ("reserved", "<i4", 2)])
+assert SAO_JOB_DT.itemsize == 96
 
 # one havoc_mi355x_rdoq_job (include/havoc_mi355x.h), 48 bytes
 RDOQ_JOB_DT = np.dtype([("dst_off", "<i4"), ("src_off", "<i4"), ("quant_scale", "<i4"), ("quant_shift", "<i4"), ("inv_scale", "<i4"),
@@ -388,6 +395,25 @@ class Havoc:
 
     def quantize_reconstruct_d(self, log2, rec, sr, pred, sp, res, jobs):
         self._ck(self.L.havoc_mi355x_quantize_reconstruct(self.h, log2, _ptr(rec), sr, _ptr(pred), sp, _ptr(res), _ptr(jobs), jobs.shape[0]))
+
+    def sao_stats(self, bd, src, ss, rec, rs, jobs):
+        """numpy level: jobs int32 [n, 4] = (src_off, rec_off, w, h) -> int64 [n, 105]"""
+        jobs = np.ascontiguousarray(jobs, np.int32)
+        with self.torch.cuda.stream(self.tstream):
+            out = self.torch.zeros(105 * len(jobs), dtype=self.torch.int64, device=self.device)
+        s, r = self.up(src), self.up(rec)
+        self._ck(self.L.havoc_mi355x_sao_stats(self.h, self._S(s), bd, _ptr(s), ss, _ptr(r), rs, _ptr(self.up(jobs)), len(jobs), _ptr(out)))
+        return self.down(out, np.int64).reshape(-1, 105)
+
+    def sao_filter(self, bd, dst_like, sd, src, ss, jobs):
+        """numpy level: jobs = SAO_JOB_DT array; returns the destination plane (zeros where no job wrote)"""
+        jobs = np.ascontiguousarray(jobs, SAO_JOB_DT)
+        dst = self.zeros(len(dst_like), dst_like.dtype)
+        s = self.up(src)
+        with self.torch.cuda.stream(self.tstream):
+            j = self.torch.from_numpy(jobs.view(np.uint8).reshape(-1)).to(self.device)
+        self._ck(self.L.havoc_mi355x_sao_filter(self.h, self._S(s), bd, _ptr(dst), sd, _ptr(s), ss, _ptr(j), len(jobs)))
+        return self.down(dst, dst_like.dtype)
 
     def rdoq_workspace(self, njobs):
         """device scratch for one rdoq launch of `njobs` blocks (an int64 tensor: 16-byte aligned)"""
