@@ -1058,9 +1058,17 @@ def main():
         pictures_per_block = args.pictures
     else:
         base = [0]
+        prime = 0
+        if pipe is not None and world > 1:
+            # weak scaling measures the steady state of an endless sequence: first run the pipeline's fill (the slots before every
+            # rank has a picture two slots running: 6 with lag 1, 14 with lag 2 on 8 ranks) -- untimed, like the warm-up steps
+            while prime < 64 and not (all(p is not None for p in sched.slot(prime)) and all(p is not None for p in sched.slot(prime + 1))):
+                prime += 1
+            for i in range(prime):
+                one_step(i)
         for i in range(args.warmup):
-            one_step(i)
-        base[0] = args.warmup
+            one_step(prime + i)
+        base[0] = prime + args.warmup
 
         def run_block(_b):
             for i in range(args.steps):
@@ -1139,7 +1147,7 @@ def main():
                 f"{pipe.exch.broadcasts} reference pictures broadcast over {'RCCL' if os.environ.get('HAVOC_BENCH_BACKEND', 'nccl') == 'nccl' else 'gloo'} "
                 f"in the whole run ({pipe.exch.sent_bytes} B sent by rank 0), overlapped with the next slot"
                 + (f"; strong scaling over a fixed {args.pictures}-picture sequence, fill and drain included" if args.scaling == "strong" else
-                   "; weak scaling: steady state of an endless sequence, one picture per rank per slot"))
+                   f"; weak scaling: steady state of an endless sequence, one picture per rank per slot (schedule lag {sched.lag}, {prime} untimed pipeline-fill slots before the warm-up)"))
             out["config"]["pictures_per_timed_block"] = pictures_per_block
         if args.poc_checksums and pipe is not None:
             out["poc_checksums"] = {str(k): v for k, v in sorted(all_poc.items())}

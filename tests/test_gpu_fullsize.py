@@ -157,6 +157,21 @@ def test_bench_weak_scaling_rehearsal_two_ranks():
     assert r["config"]["pictures_per_timed_block"] == 12.0     # both ranks busy in every timed slot
 
 
+def test_bench_weak_scaling_rehearsal_eight_ranks():
+    """eight gloo ranks on one GPU, the default (lag 2) schedule: the untimed pipeline fill puts every timed slot in the steady state --
+    8 pictures per slot although the driver's warm-up is shorter than the fill"""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HAVOC_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = _bench_json([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                     "--master-port", "29580", os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "2", "--kernel-reps", "1",
+                     "--tune", "0", "--min-seconds", "0.0", "--res", "416x240"], env, root, timeout=1500)
+    assert r["n_gpus"] == 8 and r["steps"] == 4 and r["scaling"] == "weak" and r["value"] > 0
+    assert r["config"]["pictures_per_timed_block"] == 32.0
+    assert "lag 2" in r["config"]["parallelism"]
+
+
 def _parity_vs_reference(hv, res, bit_depth, qp, mix="ra", seed=11, min_values=10_000_000):
     import argparse
     import os
