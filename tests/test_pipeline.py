@@ -5,7 +5,8 @@ compiled functions on the host -- a toy inter encoder for two pictures (SURVEY.m
   -> motion search of every 16x16 block, decision loops fed by batch launches (libhavoc_search.so)   [8(f)-1]
   -> HavocPredUni at the chosen vectors -> residual + forward DCT -> Rdoq::runQuantisation           [a5, a9, a13, 8(f)-2]
   -> de-quantise + inverse DCT + add -> SSD                                                          [a11, a12, a3]
-  -> in-loop deblocking (boundary strengths from the vectors and coded-block flags) -> padding       [8(f)-3]
+  -> in-loop deblocking (boundary strengths from the vectors and coded-block flags)
+  -> sample-adaptive offset (statistics per CTU, a choice, band / edge filter) -> padding            [8(f)-3]
   -> the reconstruction becomes the reference the NEXT picture's motion search reads (phase planes interpolated from it).
 
 Host twin: the same steps through oracle/_ref (the reference's havoc tables, Rdoq.cpp, LoopFilter.h, Padding.h) and the
@@ -67,6 +68,33 @@ def _strengths(mv, cbf):
     return data.ravel(), bs.ravel()
 
 
+def _ctus():
+    return [(x, y, min(64, W - x), min(64, H - y)) for y in range(0, H, 64) for x in range(0, W, 64)]
+
+
+def _sao_choice(stats, bd, i):
+    """a stand-in for the encoder's SAO decision (turing/EncSao.h:286-520 is floating point and stays on the host): integer only,
+    from the statistics.  CTU i takes type i % 3 -- off; band offset: the four bands from the position the statistics name, offsets =
+    rounded mean differences clipped to +-7; edge offset: the class whose categories 1..4 carry the largest |sum of differences|,
+    offsets = rounded means clipped to 0..7 with the signs the syntax allows"""
+    offs = np.zeros(32, np.int16)
+    up = bd - min(bd, 10)
+    if i % 3 == 0:
+        return 0, 0, offs
+    if i % 3 == 1:
+        start = int(stats[104])
+        for k in range(4):
+            n, e = int(stats[72 + start + k]), int(stats[40 + start + k])
+            offs[(start + k) & 31] = (int(np.sign(e)) * min(7, (abs(e) + n // 2) // n) if n else 0) << up
+        return 1, 0, offs
+    cls = int(np.argmax([int(np.abs(stats[10 * c + 1:10 * c + 5]).sum()) for c in range(4)]))
+    for cat in range(1, 5):
+        n, e = int(stats[10 * cls + 5 + cat]), int(stats[10 * cls + cat])
+        m = min(7, (abs(e) + n // 2) // n) if n else 0
+        offs[cat] = (m if cat <= 2 else -m) << up
+    return 2, cls, offs
+
+
 def _host_picture(R, ref_client, par, src, ref, stride, pus, rq, states, BD):
     """one picture through the reference's functions; returns decisions and every intermediate"""
     res = ref_client.uni(par, src, ref, stride, PAD, pus)
@@ -100,8 +128,21 @@ def _host_picture(R, ref_client, par, src, ref, stride, pus, rq, states, BD):
     o = PAD * stride + PAD
     y = recon[o:]          # view whose element 0 is sample (0, 0)
     R.deblock(y, stride, cb, cr, W // 2, W, H, BD, data, bs)
-    R.pad_block(recon, o, W, H, stride, PAD, True, True, True, True)
-    return dict(res=res, coef=coef, level=level, cbf=cbf, ssd=ssd, before=before, recon=recon, bs=bs)
+    R.pad_block(recon, o, W, H, stride, PAD, True, True, True, True)      # the edge filter looks one sample beyond a CTU
+    # sample-adaptive offset, CTU by CTU: statistics of (source, deblocked), a choice, the filter into a second picture
+    sao = np.zeros_like(recon)
+    kinds = []
+    for i, (x, y0, w, h) in enumerate(_ctus()):
+        oc = (y0 + PAD) * stride + x + PAD
+        kind, cls, offs = _sao_choice(R.sao_stats(src, oc, stride, recon, oc, stride, w, h, BD), BD, i)
+        kinds.append(kind)
+        if kind:
+            R.sao_filter(sao, oc, stride, recon, oc, stride, w, h, kind, cls, offs if kind == 1 else offs[:5], BD)
+        else:
+            rows = oc + np.arange(h)[:, None] * stride + np.arange(w)
+            sao[rows] = recon[rows]
+    R.pad_block(sao, o, W, H, stride, PAD, True, True, True, True)
+    return dict(res=res, coef=coef, level=level, cbf=cbf, ssd=ssd, before=before, recon=sao, deblocked=recon, bs=bs, kinds=np.array(kinds))
 
 
 def _device_picture(hv, L, par, d_src, d_ref, stride, pe, pus, rq, d_states, BD):
@@ -156,9 +197,28 @@ def _device_picture(hv, L, par, d_src, d_ref, stride, pe, pus, rq, d_states, BD)
         d_bs = torch.from_numpy(bs).to(hv.device)
     hv.deblock_d(BD, recon, origin, stride, chroma, 0, (H // 2) * (W // 2), W // 2, W, H, d_data, d_bs)
     hv.pad_block_d(recon, origin, W, H, stride, PAD)
+    # sample-adaptive offset: one statistics launch for all CTUs, the choice on the host, one filter launch
+    ctus = _ctus()
+    sj = np.array([[(y + PAD) * stride + x + PAD] * 2 + [w, h] for x, y, w, h in ctus], np.int32)
+    with torch.cuda.stream(hv.tstream):
+        d_stats = torch.zeros(105 * len(ctus), dtype=torch.int64, device=hv.device)
+    hv._ck(hv.L.havoc_mi355x_sao_stats(hv.h, np.dtype(dt).itemsize, BD, hmod._ptr(d_src), stride, hmod._ptr(recon), stride, hmod._ptr(hv.up(sj)), len(ctus),
+                                       hmod._ptr(d_stats)))
+    st_all = hv.down(d_stats, np.int64).reshape(-1, 105)
+    fj = np.zeros(len(ctus), hmod.SAO_JOB_DT)
+    kinds = []
+    for i, (x, y, w, h) in enumerate(ctus):
+        kind, cls, offs = _sao_choice(st_all[i], BD, i)
+        kinds.append(kind)
+        fj[i] = (sj[i, 0], sj[i, 0], w, h, kind, cls, offs, (0, 0))
+    sao = hv.zeros(d_src.numel(), dt)
+    with torch.cuda.stream(hv.tstream):
+        d_fj = torch.from_numpy(fj.view(np.uint8).reshape(-1)).to(hv.device)
+    hv._ck(hv.L.havoc_mi355x_sao_filter(hv.h, np.dtype(dt).itemsize, BD, hmod._ptr(sao), stride, hmod._ptr(recon), stride, hmod._ptr(d_fj), len(ctus)))
+    hv.pad_block_d(sao, origin, W, H, stride, PAD)
     hv.sync()
     return dict(res=out, coef=hv.down(coef, np.int16), level=hv.down(level, np.int16), cbf=h_cbf, ssd=hv.down(ssd, np.uint32), before=before,
-                recon=hv.down(recon, dt), d_recon=recon, bs=bs, stats=stats)
+                recon=hv.down(sao, dt), deblocked=hv.down(recon, dt), d_recon=sao, bs=bs, stats=stats, kinds=np.array(kinds))
 
 
 @pytest.mark.parametrize("BD", [8, 10])
@@ -191,8 +251,9 @@ def test_two_pictures_through_the_whole_chain_equal_the_reference_functions(BD):
     dev1 = _device_picture(hv, L, par, hv.up(src1), hv.up(ref0), stride, pe, pus1, rq, d_states, BD)
     for k in ("mv", "mvd", "mv_integer", "mvp_flag", "cost_integer", "cost_subpel", "calls"):
         assert np.array_equal(host1["res"][k], dev1["res"][k]), k
-    for k in ("coef", "level", "cbf", "ssd", "bs", "before", "recon"):
+    for k in ("coef", "level", "cbf", "ssd", "bs", "before", "deblocked", "kinds", "recon"):
         assert np.array_equal(host1[k], dev1[k]), k
+    assert len(set(host1["kinds"])) == 3 and not np.array_equal(host1["deblocked"], host1["recon"])      # off, band and edge CTUs; samples changed
     # the picture exercised something: vectors off the predictor, coded and uncoded blocks, filtered edges, a filled border
     assert (host1["res"]["mv"] != pus1["mvp"][:, 0]).any() and (host1["cbf"] != 0).any() and (host1["cbf"] == 0).any()
     assert not np.array_equal(host1["before"], host1["recon"]) and host1["bs"].any()
