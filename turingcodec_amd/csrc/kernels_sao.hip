@@ -12,8 +12,8 @@
 // (LoopFilter.h:886-1008) are encoder control and stay on the host, like the deblocking filter's boundary strengths.
 //
 // One workgroup per job (a CTU of one colour component).  Statistics: a lane takes samples of the interior at stride 256, reads
-// the 3x3 neighbourhood through the cache, and adds into 104 LDS counters (no-return ds_add); the sums fit 32 bits (62 x 62
-// samples x 16-bit differences).  Both kernels are a few microseconds per picture: HBM-bound streaming of two planes.
+// the 3x3 neighbourhood through the cache; the 4 x 5 edge categories accumulate in registers (select on the category, wave
+// reduction at the end), the 32 bands in per-wavefront LDS counters; the sums fit 32 bits (62 x 62 samples x 16-bit differences).
 #include "common.h"
 
 namespace havoc_gpu {
@@ -31,38 +31,62 @@ __global__ __launch_bounds__(256) void k_sao_stats(const char *__restrict__ srcP
                                                    const SaoStatsJob *__restrict__ jobs, int shift, long long *__restrict__ out)
 {
     typedef typename Sample<S>::T T;
-    __shared__ int acc[104];
+    __shared__ int acc[104];            // the block's totals
+    __shared__ int band[4][64];         // per wavefront: sums [0..31], counts [32..63] (fewer lanes fighting over a counter)
     const SaoStatsJob job = jobs[blockIdx.x];
     const T *src = reinterpret_cast<const T *>(srcPlane) + job.src_off, *rec = reinterpret_cast<const T *>(recPlane) + job.rec_off;
-    const int tid = threadIdx.x, iw = job.w - 2, ih = job.h - 2;
+    const int tid = threadIdx.x, wave = tid >> 6, iw = job.w - 2, ih = job.h - 2;
     if (tid < 104) acc[tid] = 0;
+    band[wave][tid & 63] = 0;
     __syncthreads();
+    // edge classes: 4 classes x 5 categories x (sum, count) in registers, selected by comparison -- no memory traffic per sample
+    int e[4][5], n[4][5];
+#pragma unroll
+    for (int cls = 0; cls < 4; ++cls)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) e[cls][k] = n[cls][k] = 0;
     for (int k = tid; k < iw * ih; k += 256)
     {
         const int y = 1 + k / iw, x = 1 + k - (y - 1) * iw;
         const T *r = rec + y * strideRec + x;
         const int c = r[0], diff = (int)src[y * strideSrc + x] - c;
-        const int up = r[-strideRec], down = r[strideRec];
-        const int cat[4] = { 2 + sign3(c - (int)r[-1]) + sign3(c - (int)r[1]), 2 + sign3(c - up) + sign3(c - down),
+        const int idx[4] = { 2 + sign3(c - (int)r[-1]) + sign3(c - (int)r[1]), 2 + sign3(c - (int)r[-strideRec]) + sign3(c - (int)r[strideRec]),
                              2 + sign3(c - (int)r[-strideRec - 1]) + sign3(c - (int)r[strideRec + 1]),
                              2 + sign3(c - (int)r[-strideRec + 1]) + sign3(c - (int)r[strideRec - 1]) };
 #pragma unroll
         for (int cls = 0; cls < 4; ++cls)
-        {
-            const int category = (0x43021 >> (4 * cat[cls])) & 7;      // 2 + sign + sign -> 1, 2, 0, 3, 4
-            atomicAdd(&acc[10 * cls + category], diff);
-            atomicAdd(&acc[10 * cls + 5 + category], 1);
-        }
-        const int band = c >> (3 + shift);
-        atomicAdd(&acc[40 + band], diff);
-        atomicAdd(&acc[72 + band], 1);
+#pragma unroll
+            for (int q = 0; q < 5; ++q)      // q = 2 + sign + sign; its category is 1, 2, 0, 3, 4 (applied when the registers are flushed)
+            {
+                const bool hit = idx[cls] == q;
+                e[cls][q] += hit ? diff : 0;
+                n[cls][q] += hit;
+            }
+        const int b = c >> (3 + shift);
+        atomicAdd(&band[wave][b], diff);
+        atomicAdd(&band[wave][32 + b], 1);
     }
+#pragma unroll
+    for (int cls = 0; cls < 4; ++cls)
+#pragma unroll
+        for (int q = 0; q < 5; ++q)
+        {
+            const int category = (0x43021 >> (4 * q)) & 7;
+            const int se = wave_sum(e[cls][q]), sn = wave_sum(n[cls][q]);
+            if ((tid & 63) == 0)
+            {
+                atomicAdd(&acc[10 * cls + category], se);
+                atomicAdd(&acc[10 * cls + 5 + category], sn);
+            }
+        }
     if (iw > 0)
         for (int y = 1 + tid; y <= ih; y += 256)      // the horizontal class's second look at x = 1
         {
             atomicAdd(&acc[0], (int)src[y * strideSrc + 1] - (int)rec[y * strideRec + 1]);
             atomicAdd(&acc[5], 1);
         }
+    __syncthreads();
+    if (tid < 64) acc[40 + tid] = band[0][tid] + band[1][tid] + band[2][tid] + band[3][tid];
     __syncthreads();
     long long *o = out + 105L * blockIdx.x;
     if (tid < 104) o[tid] = acc[tid];
