@@ -218,6 +218,25 @@ def main():
             assert rc == 0, (rc, dev.havoc_mi355x_last_error())
             got[sel] = out
         t_batch = time.perf_counter() - t0
+        # bi-directional refinement of the first `--bi` searches through the batch client: ideal predictors built on the device
+        L.havoc_search_motion_bi.argtypes = [vp, C.c_int, C.POINTER(st.Params), vp, i64, ip, vp, i64, ip, C.c_int, vp, ip, i64, vp, i64, vp, vp, C.c_int, vp,
+                                             C.c_int, C.POINTER(Stats)]
+        got_bi_batch = np.zeros(nbi, st.RESULT_DT)
+        bi_stats = [Stats(), Stats()]
+        t0 = time.perf_counter()
+        for lst in (0, 1):
+            sel = np.flatnonzero(bi_pus["ref_list"] == lst)
+            if not len(sel):
+                continue
+            sub = np.ascontiguousarray(bi_pus[sel])
+            stt = np.ascontiguousarray(start[sel], np.int16)
+            out = np.zeros(len(sub), st.RESULT_DT)
+            rc = L.havoc_search_motion_bi(ctx, S, C.byref(par), dplane[0], origin, stride, dplane[1 + lst], origin, stride, pad, dphase[lst], pe, origin,
+                                          dplane[2 - lst], origin, sub.ctypes.data, stt.ctypes.data, len(sub), out.ctypes.data, args.threads,
+                                          C.byref(bi_stats[lst]))
+            assert rc == 0, (rc, dev.havoc_mi355x_last_error())
+            got_bi_batch[sel] = out
+        t_bi = time.perf_counter() - t0
         tot = lambda f: sum(getattr(s_, f) for s_ in stats)
         report["batch"] = {
             "mismatching_searches": same(got, expected), "seconds": round(t_batch, 4), "phase_planes_seconds": round(t_planes, 4),
@@ -227,6 +246,8 @@ def main():
             "searches_per_second": round(len(pus) / t_batch, 1), "loop_calls_per_second": round(int(expected["calls"].sum()) / t_batch, 1),
             "launches_per_search": round(tot("launches") / len(pus), 4), "threads": args.threads,
             "max_replays_of_one_search": int(got["replays"].max()),
+            "bi": {"searches": nbi, "mismatching": same(got_bi_batch, expected_bi, ["mv", "mvd", "mvp_flag", "calls", "cost_subpel"]), "seconds": round(t_bi, 4),
+                   "launches": sum(s_.launches for s_ in bi_stats), "rounds": max(s_.rounds for s_ in bi_stats)},
         }
     # ---- 35-mode intra stage (Search.hpp:40-190): per-call through the reference tables vs one fused launch + host ordering
     if "intra" not in skip:

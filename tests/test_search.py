@@ -139,6 +139,8 @@ def _check_report(r, searches):
     assert c["unregistered"]["launches"] == c["unregistered"]["table_calls"] > 0
     # the batch client needs a handful of launches for the whole picture, not per search
     assert b["launches"] <= 8 * b["rounds"] and b["launches_per_search"] < 0.5, b
+    # bi-directional refinement through the batch client: ideal predictors built on the device, same decisions, a few launches
+    assert b["bi"]["mismatching"] == [] and b["bi"]["searches"] > 0 and b["bi"]["launches"] <= 8 * (2 + b["bi"]["rounds"]), b["bi"]
     # 35-mode intra stage: same distortions, costs and refinement order as the per-call loop through the reference tables
     assert r["intra"]["mismatching"] == [] and r["intra"]["partitions"] > 100, r["intra"]
 

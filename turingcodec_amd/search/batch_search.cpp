@@ -13,6 +13,8 @@
 //             against the reference's phase planes (havoc_mi355x_satd_multi);  then the stopped searches are replayed
 //             from the start (they are deterministic and cheap), until none stops.
 //
+// havoc_search_motion_bi runs searchMotionBi the same way on "ideal second predictors" it builds on the device first.
+//
 // Results are the reference's by construction: the same loop code as the per-call clients, fed values the GPU kernels
 // computed for exactly the positions asked (tests/test_search.py compares with the reference library's tables).  Plain
 // C++ on include/havoc_mi355x.h only.
@@ -24,6 +26,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <thread>
@@ -42,7 +45,7 @@ typedef struct
 
 namespace {
 
-constexpr int kR0 = 32, kR1 = 64;   // round 0 covers what the star search probes around a good start (dist 1..16, three failures)
+constexpr int kR1 = 64;             // half-width of the surfaces launched for a miss
 constexpr int kSub = 3, kSubSide = 7, kSubCands = 49;
 
 struct Miss
@@ -210,19 +213,32 @@ struct Arena   // one call's view of its context's pool (a context runs one call
 
 extern "C" {
 
-// Uni-directional motion search (searchMotionUni, turing/Search.hpp:1317-1355) of n (PU, list) pairs of ONE picture against
-// ONE reference picture.  Planes are device memory: *_origin = sample offset of picture sample (0, 0) from the base pointer,
-// strides in samples; the reference plane has `ref_pad` samples of replicated border; d_phase = its 16 fractional-sample
-// planes (havoc_mi355x_interp_planes / havoc_mi355x_picture_phase_planes), phase k sample (x, y) at
-// d_phase[k * plane_elems + phase_origin + y * ref_stride + x].  out[i] = what the per-call loop decides for pus[i].
-int havoc_search_motion_uni(havoc_mi355x_ctx *ctx, int S, const havoc_search_params *params, const void *d_src, int64_t src_origin, intptr_t src_stride,
-                            const void *d_ref, int64_t ref_origin, intptr_t ref_stride, int ref_pad, const void *d_phase, intptr_t plane_elems,
-                            int64_t phase_origin, const havoc_search_pu *pus, int n, havoc_search_result *out, int threads,
-                            havoc_search_stats *stats)
+} // extern "C"
+
+namespace {
+
+// what differs between the uni-directional search and the bi-directional refinement: where a PU's source block is, where the first
+// SAD surface of a search sits, and which loop of decision.hpp is replayed
+struct Flavour
 {
-    if (!ctx || !params || !pus || !out || n < 0 || (S != 1 && S != 2)) return HAVOC_MI355X_EINVAL;
+    const void *d_a;                    // plane holding every PU's source block
+    intptr_t a_stride;
+    std::vector<int64_t> a_off;         // per PU: sample offset of its block in d_a
+    int r0;                             // half-width of the round-0 surfaces
+    std::vector<Mv> centre0;            // per PU: where the round-0 surface is centred (integer samples, relative to the PU)
+    std::function<void(int, BatchView &, havoc_search_result &)> replay;
+};
+
+int runSearches(havoc_mi355x_ctx *ctx, int S, const havoc_search_params *params, const Flavour &fl,
+                const void *d_ref, int64_t ref_origin, intptr_t ref_stride, int ref_pad, const void *d_phase, intptr_t plane_elems,
+                int64_t phase_origin, const havoc_search_pu *pus, int n, havoc_search_result *out, int threads,
+                havoc_search_stats *stats)
+{
     const double tStart = now();
     const SearchParams sp = paramsOf(*params);
+    const void *d_src = fl.d_a;
+    const intptr_t src_stride = fl.a_stride;
+    const int kR0 = fl.r0;
     havoc_search_stats stt;
     std::memset(&stt, 0, sizeof(stt));
     std::vector<SearchState> state(n);
@@ -247,7 +263,7 @@ int havoc_search_motion_uni(havoc_mi355x_ctx *ctx, int S, const havoc_search_par
     {
         const havoc_search_pu &q = pus[i];
         if (q.w < 4 || q.h < 4 || q.w > 64 || q.h > 64 || (q.w & 3) || q.x0 < 0 || q.y0 < 0 || q.x0 + q.w > W || q.y0 + q.h > H) return HAVOC_MI355X_EINVAL;
-        int cx = 0, cy = 0;
+        int cx = fl.centre0[i].x, cy = fl.centre0[i].y;
         if (!clampCentre(q, kR0, &cx, &cy)) return HAVOC_MI355X_EINVAL;   // picture (with its padding) smaller than a search window
         wantSurf[0].push_back({i, cx, cy});
     }
@@ -274,7 +290,7 @@ int havoc_search_motion_uni(havoc_mi355x_ctx *ctx, int S, const havoc_search_par
             for (size_t k = 0; k < w.size(); ++k)
             {
                 const havoc_search_pu &q = pus[w[k].i];
-                jobs[k] = {int32_t(src_origin + int64_t(q.y0) * src_stride + q.x0),
+                jobs[k] = {int32_t(fl.a_off[w[k].i]),
                            int32_t(ref_origin + int64_t(q.y0 + w[k].cy) * ref_stride + q.x0 + w[k].cx), q.w, q.h, int32_t(k * size_t(side) * side), {0, 0, 0}};
                 state[w[k].i].surfaces.push_back({w[k].cx, w[k].cy, R, static_cast<const int32_t *>(hOut) + k * size_t(side) * side});
             }
@@ -321,7 +337,7 @@ int havoc_search_motion_uni(havoc_mi355x_ctx *ctx, int S, const havoc_search_par
                     {
                         havoc_mi355x_satd_multi_job &mj = jobs[4 * k + j];
                         std::memset(&mj, 0, sizeof(mj));
-                        mj.a_off = int32_t(src_origin + int64_t(q.y0) * src_stride + q.x0);
+                        mj.a_off = int32_t(fl.a_off[wn.i]);
                         mj.w = q.w;
                         mj.h = q.h;
                         mj.count = j < 3 ? 16 : 1;
@@ -373,25 +389,13 @@ int havoc_search_motion_uni(havoc_mi355x_ctx *ctx, int S, const havoc_search_par
                 if (k >= int(pending.size())) return;
                 const int i = pending[k];
                 SearchState &st = state[i];
-                const PuContext pu = puOf(pus[i]);
                 BatchView view(st);
                 try
                 {
-                    MotionSearch<BatchView> search(sp, pu, view);
-                    const UniResult r = search.run();
                     havoc_search_result &o = out[i];
                     std::memset(&o, 0, sizeof(o));
-                    o.mv[0] = r.mv.x; o.mv[1] = r.mv.y;
-                    o.mvd[0] = r.mvd.x; o.mvd[1] = r.mvd.y;
-                    o.mv_integer[0] = r.mvInteger.x; o.mv_integer[1] = r.mvInteger.y;
-                    o.mvp_flag = int16_t(r.mvpFlag);
-                    o.wrote_2Nx2N = r.wrote2Nx2N;
-                    o.calls = r.calls;
+                    fl.replay(i, view, o);
                     o.replays = st.replays;
-                    o.cost_integer = r.costInteger;
-                    o.cost_subpel = r.costSubPel;
-                    o.cost_mvd_zero[0] = r.costMvdZero[0];
-                    o.cost_mvd_zero[1] = r.costMvdZero[1];
                     st.done = true;
                 }
                 catch (const Miss &m)
@@ -422,7 +426,9 @@ int havoc_search_motion_uni(havoc_mi355x_ctx *ctx, int S, const havoc_search_par
                 wantSurf[1].push_back({i, cx, cy});
             }
             else if (st.miss.kind == 2)
-                wantSub.push_back({i, st.miss.x, st.miss.y});
+                // the 49 positions are centred on the full-sample vector being refined: the first sub-sample question is that vector
+                // itself (uni, Search.hpp:2340-2358) or its (-2, -2) half-sample neighbour (bi, Search.hpp:1627-1650)
+                wantSub.push_back({i, ((st.miss.x + 2) >> 2) * 4, ((st.miss.y + 2) >> 2) * 4});
             else
                 return HAVOC_MI355X_EINVAL;   // a sub-sample position outside the phase planes: the caller's planes are too small
             still.push_back(i);
@@ -430,8 +436,149 @@ int havoc_search_motion_uni(havoc_mi355x_ctx *ctx, int S, const havoc_search_par
         pending.swap(still);
     }
     stt.seconds_total = now() - tStart;
-    if (stats) *stats = stt;
+    if (stats)
+    {
+        stats->rounds += stt.rounds;
+        stats->launches += stt.launches;
+        stats->surfaces_small += stt.surfaces_small;
+        stats->surfaces_large += stt.surfaces_large;
+        stats->satd_jobs += stt.satd_jobs;
+        stats->replays += stt.replays;
+        stats->bytes_down += stt.bytes_down;
+        stats->seconds_gpu += stt.seconds_gpu;
+        stats->seconds_host += stt.seconds_host;
+        stats->seconds_total += stt.seconds_total;
+    }
     return 0;
+}
+
+void fillUni(const UniResult &r, havoc_search_result &o)
+{
+    o.mv[0] = r.mv.x; o.mv[1] = r.mv.y;
+    o.mvd[0] = r.mvd.x; o.mvd[1] = r.mvd.y;
+    o.mv_integer[0] = r.mvInteger.x; o.mv_integer[1] = r.mvInteger.y;
+    o.mvp_flag = int16_t(r.mvpFlag);
+    o.wrote_2Nx2N = r.wrote2Nx2N;
+    o.calls = r.calls;
+    o.cost_integer = r.costInteger;
+    o.cost_subpel = r.costSubPel;
+    o.cost_mvd_zero[0] = r.costMvdZero[0];
+    o.cost_mvd_zero[1] = r.costMvdZero[1];
+}
+
+} // namespace
+
+extern "C" {
+
+// Uni-directional motion search (searchMotionUni, turing/Search.hpp:1317-1355) of n (PU, list) pairs of ONE picture against
+// ONE reference picture.  Planes are device memory: *_origin = sample offset of picture sample (0, 0) from the base pointer,
+// strides in samples; the reference plane has `ref_pad` samples of replicated border; d_phase = its 16 fractional-sample
+// planes (havoc_mi355x_interp_planes / havoc_mi355x_picture_phase_planes), phase k sample (x, y) at
+// d_phase[k * plane_elems + phase_origin + y * ref_stride + x].  out[i] = what the per-call loop decides for pus[i].
+int havoc_search_motion_uni(havoc_mi355x_ctx *ctx, int S, const havoc_search_params *params, const void *d_src, int64_t src_origin, intptr_t src_stride,
+                            const void *d_ref, int64_t ref_origin, intptr_t ref_stride, int ref_pad, const void *d_phase, intptr_t plane_elems,
+                            int64_t phase_origin, const havoc_search_pu *pus, int n, havoc_search_result *out, int threads,
+                            havoc_search_stats *stats)
+{
+    if (!ctx || !params || !pus || !out || n < 0 || (S != 1 && S != 2)) return HAVOC_MI355X_EINVAL;
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    const SearchParams sp = paramsOf(*params);
+    Flavour fl;
+    fl.d_a = d_src;
+    fl.a_stride = src_stride;
+    fl.r0 = 32;      // round 0 covers what the star search probes around a good start (dist 1..16, three failures)
+    fl.a_off.resize(n);
+    fl.centre0.assign(n, Mv(0, 0));
+    for (int i = 0; i < n; ++i) fl.a_off[i] = src_origin + int64_t(pus[i].y0) * src_stride + pus[i].x0;
+    fl.replay = [&](int i, BatchView &view, havoc_search_result &o) {
+        const PuContext pu = puOf(pus[i]);
+        MotionSearch<BatchView> search(sp, pu, view);
+        fillUni(search.run(), o);
+    };
+    return runSearches(ctx, S, params, fl, d_ref, ref_origin, ref_stride, ref_pad, d_phase, plane_elems, phase_origin, pus, n, out, threads, stats);
+}
+
+// Bi-directional refinement (searchMotionBi, turing/Search.hpp:1498-1657) of n (PU, list) pairs: list pus[i].ref_list is refined
+// around start[i] (quarter samples) against the prediction the OTHER list's vector pus[i].mv_other gives.  The "ideal second
+// predictor" clip(2 * source - other prediction) of every PU is built on the device (HavocPredUni from d_ref_other, then
+// havoc::SubtractBi; Search.hpp:1512-1546) and takes the place of the source block in the SAD surfaces (+-8 around the start:
+// the 11 x 11 grid and its four-wide calls) and the sub-sample SATDs.  d_ref / d_phase: the picture of the list being refined.
+int havoc_search_motion_bi(havoc_mi355x_ctx *ctx, int S, const havoc_search_params *params, const void *d_src, int64_t src_origin, intptr_t src_stride,
+                           const void *d_ref, int64_t ref_origin, intptr_t ref_stride, int ref_pad, const void *d_phase, intptr_t plane_elems,
+                           int64_t phase_origin, const void *d_ref_other, int64_t ref_other_origin, const havoc_search_pu *pus, const int16_t *start, int n,
+                           havoc_search_result *out, int threads, havoc_search_stats *stats)
+{
+    if (!ctx || !params || !pus || !out || !start || n < 0 || (S != 1 && S != 2)) return HAVOC_MI355X_EINVAL;
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    if (n == 0) return 0;
+    const SearchParams sp = paramsOf(*params);
+    // the ideal predictors: slot i = 64 x 64 samples, stride 64.  Not from the arena: it is reset by the search rounds below.
+    void *dIdeal = nullptr, *dOther = nullptr, *dJobs = nullptr;
+    const size_t slotBytes = size_t(64) * 64 * S;
+    int rc = havoc_mi355x_malloc(ctx, &dIdeal, n * slotBytes + 256);
+    if (!rc) rc = havoc_mi355x_malloc(ctx, &dOther, n * slotBytes + 256);
+    if (!rc) rc = havoc_mi355x_malloc(ctx, &dJobs, size_t(n) * 64 + 256);
+    std::vector<havoc_mi355x_pred_uni_job> pj(n);
+    std::vector<havoc_mi355x_subtract_bi_job> sj(n);
+    for (int i = 0; i < n && !rc; ++i)
+    {
+        const havoc_search_pu &q = pus[i];
+        const PuContext pu = puOf(q);
+        const LimitFullPelMv limit(pu, sp);
+        const Mv other(q.mv_other[0], q.mv_other[1]);
+        Mv full = shr2(other);
+        limit(full);
+        std::memset(&pj[i], 0, sizeof(pj[i]));
+        pj[i].dst_off = i * 4096;
+        pj[i].ref_off = int32_t(ref_other_origin + int64_t(q.y0 + full.y) * ref_stride + q.x0 + full.x);
+        pj[i].w = q.w; pj[i].h = q.h;
+        pj[i].xFrac = other.x & 3; pj[i].yFrac = other.y & 3;
+        std::memset(&sj[i], 0, sizeof(sj[i]));
+        sj[i].dst_off = i * 4096;
+        sj[i].pred_off = i * 4096;
+        sj[i].src_off = int32_t(src_origin + int64_t(q.y0) * src_stride + q.x0);
+        sj[i].w = q.w; sj[i].h = q.h;
+    }
+    if (!rc) rc = havoc_mi355x_h2d(ctx, dJobs, pj.data(), n * sizeof(pj[0]));
+    if (!rc) rc = havoc_mi355x_pred_uni(ctx, S, 8, sp.bitDepth, 64, 64, dOther, 64, d_ref_other, ref_stride, static_cast<const havoc_mi355x_pred_uni_job *>(dJobs), n);
+    if (!rc) rc = havoc_mi355x_sync(ctx);
+    if (!rc) rc = havoc_mi355x_h2d(ctx, dJobs, sj.data(), n * sizeof(sj[0]));
+    // SubtractBi is called with 6 + 2 * sizeof(Sample) as its bit depth (turing/Search.hpp:1542-1546), whatever the picture's
+    if (!rc) rc = havoc_mi355x_subtract_bi(ctx, S, 6 + 2 * S, dIdeal, 64, dOther, 64, d_src, src_stride, static_cast<const havoc_mi355x_subtract_bi_job *>(dJobs), n);
+    if (!rc) rc = havoc_mi355x_sync(ctx);
+    if (!rc)
+    {
+        Flavour fl;
+        fl.d_a = dIdeal;
+        fl.a_stride = 64;
+        fl.r0 = 8;
+        fl.a_off.resize(n);
+        fl.centre0.resize(n);
+        for (int i = 0; i < n; ++i)
+        {
+            fl.a_off[i] = int64_t(i) * 4096;
+            const PuContext pu = puOf(pus[i]);
+            const LimitFullPelMv limit(pu, sp);
+            Mv c = shr2(Mv(int16_t(start[2 * i] + 1), int16_t(start[2 * i + 1] + 1)));      // where searchMotionBi puts its grid
+            limit(c);
+            fl.centre0[i] = c;
+        }
+        fl.replay = [&](int i, BatchView &view, havoc_search_result &o) {
+            const PuContext pu = puOf(pus[i]);
+            const BiResult r = searchMotionBi(sp, pu, view, Mv(start[2 * i], start[2 * i + 1]));
+            o.mv[0] = r.mv.x; o.mv[1] = r.mv.y;
+            o.mvd[0] = r.mvd.x; o.mvd[1] = r.mvd.y;
+            o.mvp_flag = int16_t(r.mvpFlag);
+            o.calls = r.calls;
+            o.cost_subpel = r.cost;
+        };
+        rc = runSearches(ctx, S, params, fl, d_ref, ref_origin, ref_stride, ref_pad, d_phase, plane_elems, phase_origin, pus, n, out, threads, stats);
+        if (stats) stats->launches += 2;
+    }
+    if (dIdeal) (void)havoc_mi355x_free(ctx, dIdeal);
+    if (dOther) (void)havoc_mi355x_free(ctx, dOther);
+    if (dJobs) (void)havoc_mi355x_free(ctx, dJobs);
+    return rc;
 }
 
 // The 35-mode luma stage of n intra partitions of one size (searchIntraPartition, turing/Search.hpp:40-190): one
