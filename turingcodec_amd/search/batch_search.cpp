@@ -69,6 +69,7 @@ struct SearchState
     bool done = false;
     int replays = 0;
     Miss miss{0, 0, 0};
+    MotionSearch<struct BatchView>::IntegerStage integer;   // uni search: kept once the integer stage has run to its end
 };
 
 // the View of decision.hpp over precomputed data
@@ -493,7 +494,7 @@ int havoc_search_motion_uni(havoc_mi355x_ctx *ctx, int S, const havoc_search_par
     fl.replay = [&](int i, BatchView &view, havoc_search_result &o) {
         const PuContext pu = puOf(pus[i]);
         MotionSearch<BatchView> search(sp, pu, view);
-        fillUni(search.run(), o);
+        fillUni(search.run(&view.st.integer), o);
     };
     return runSearches(ctx, S, params, fl, d_ref, ref_origin, ref_stride, ref_pad, d_phase, plane_elems, phase_origin, pus, n, out, threads, stats);
 }

@@ -360,10 +360,40 @@ struct MotionSearch
     }
 
     // searchMotionUni, Search.hpp:1317-1355
-    UniResult run()
+    // what the integer stage leaves behind: a caller that may have to run the sub-sample stage again (a batch client whose
+    // sub-sample data was not there yet) keeps it and does not repeat the integer search
+    struct IntegerStage
+    {
+        bool valid = false, wrote2Nx2N = false;
+        MvCandidate best;
+        int calls = 0;
+        Cost costMvdZero[2] = {kCostMax, kCostMax};
+    };
+
+    UniResult run(IntegerStage *keep = nullptr)
     {
         UniResult r;
-        r.wrote2Nx2N = fullPel(r.costMvdZero);
+        if (keep && keep->valid)
+        {
+            best = keep->best;
+            calls = keep->calls;
+            r.wrote2Nx2N = keep->wrote2Nx2N;
+            r.costMvdZero[0] = keep->costMvdZero[0];
+            r.costMvdZero[1] = keep->costMvdZero[1];
+        }
+        else
+        {
+            r.wrote2Nx2N = fullPel(r.costMvdZero);
+            if (keep)
+            {
+                keep->valid = true;
+                keep->wrote2Nx2N = r.wrote2Nx2N;
+                keep->best = best;
+                keep->calls = calls;
+                keep->costMvdZero[0] = r.costMvdZero[0];
+                keep->costMvdZero[1] = r.costMvdZero[1];
+            }
+        }
         r.mvInteger = best.mv;
         r.costInteger = best.cost;
         r.mvpFlag = best.mvpFlag;
