@@ -119,3 +119,36 @@ def test_plane_upload_pad_and_phase_planes(hv, oracle):
                 assert np.array_equal(got.ravel(), dst), (xf, yf)
     finally:
         hv.L.havoc_mi355x_picture_destroy(hv.h, pic)
+
+
+def test_yuv_file_to_device_pictures(hv, tmp_path):
+    """the on-disk input format (turing/encode.cpp:600-640): a raw planar 4:2:0 file, frame by frame, into device pictures; 8-bit
+    file on an 8-bit and on a 10-bit picture (<< 2), 16-bit little-endian file on a 10-bit picture; a truncated last frame is ignored"""
+    from turingcodec_amd.picture_io import DevicePicture, YuvReader
+    from turingcodec_amd.workload import synth_frames
+    W, H = 208, 120
+    for file_bd, pic_bd in ((8, 8), (8, 10), (10, 10)):
+        frames = synth_frames(W, H, 3, 5, file_bd)
+        path = tmp_path / f"clip_{file_bd}.yuv"
+        with open(path, "wb") as f:
+            for fr in frames:
+                for plane in fr:
+                    f.write(np.ascontiguousarray(plane, np.uint8 if file_bd == 8 else "<u2").tobytes())
+            f.write(b"\x00" * 1000)      # a partial frame at the end
+        rd = YuvReader(str(path), W, H, file_bd)
+        assert len(rd) == 3
+        pic = DevicePicture(hv, W, H, pic_bd)
+        for i, frame in enumerate(rd):
+            pic.upload(frame, src_bit_depth=file_bd)
+            for c in range(3):
+                want = frames[i][c].astype(np.uint16) << (pic_bd - file_bd)
+                got = pic.download(c, with_padding=True)
+                p = (got.shape[0] - want.shape[0]) // 2
+                assert np.array_equal(got[p:-p, p:-p], want), (file_bd, pic_bd, i, c)
+                assert np.array_equal(got, np.pad(want, p, mode="edge")), "border replication"
+                assert np.array_equal(rd.planes(i)[c], frames[i][c])
+        base, elems, org = pic.phase_planes()
+        assert base and elems > 0
+        pic.close()
+    with pytest.raises(ValueError):
+        YuvReader(str(path), 4096, 4096, 10)

@@ -103,3 +103,31 @@ def test_quantiser_parameters_follow_qpstate():
     # 10-bit: QP' = QP + QpBdOffsetY = 27 + 12 = 39 (turing/QpState.h:56, 79-94)
     assert quant_params(27, 5, 10, True) == (18396, 29 - 10 + 6 - 5, 171 << 7)
     assert dequant_params(32, 3, 8) == (51 << 5, 2) and dequant_params(27, 2, 10) == (57 << 6, 3)
+
+
+def test_yuv_reader_frames_and_planes(tmp_path):
+    """raw planar 4:2:0 input (turing/encode.cpp:600-640): frame count, plane views, partial last frame, size errors"""
+    import pytest
+    from turingcodec_amd.picture_io import YuvReader
+    from turingcodec_amd.workload import synth_frames
+    W, H = 64, 48
+    for bd in (8, 10):
+        frames = synth_frames(W, H, 2, 3, bd)
+        path = tmp_path / f"c{bd}.yuv"
+        with open(path, "wb") as f:
+            for fr in frames:
+                for plane in fr:
+                    f.write(np.ascontiguousarray(plane, np.uint8 if bd == 8 else "<u2").tobytes())
+            f.write(b"\x01" * 17)
+        rd = YuvReader(str(path), W, H, bd)
+        assert len(rd) == 2 and rd.frame_bytes == W * H * 3 // 2 * (1 if bd == 8 else 2)
+        for i in range(2):
+            assert len(rd[i]) == rd.frame_bytes
+            for c in range(3):
+                assert np.array_equal(rd.planes(i)[c], frames[i][c])
+        with pytest.raises(IndexError):
+            rd[2]
+    with pytest.raises(ValueError):
+        YuvReader(str(path), 63, 48, 10)
+    with pytest.raises(ValueError):
+        YuvReader(str(path), 1920, 1080, 10)
