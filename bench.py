@@ -35,6 +35,8 @@ def parse_args():
     ap.add_argument("--res", default="1920x1080")
     ap.add_argument("--bit-depth", type=int, default=8)
     ap.add_argument("--seed", type=int, default=11)
+    ap.add_argument("--yuv", default=None, help="raw planar 4:2:0 file of --res / --bit-depth (the reference's input format): its first three "
+                    "frames replace the synthetic clip as L0 reference / current picture / L1 reference (`data` then says so)")
     ap.add_argument("--rdoq", type=int, default=1, help="random-access mix: 1 = Rdoq::runQuantisation on the device between tu_forward and "
                     "tu_reconstruct (speed=medium has RDOQ on); 0 = round 1's step: levels made once, untimed, by havoc_quantize")
     ap.add_argument("--qp", type=int, default=32, help="slice QP: the (de)quantiser scale / shift of the TU chain (turing/QpState.h:85-94)")
@@ -465,7 +467,12 @@ def cpu_worker(args):
     from turingcodec_amd.workload import FrameWorkload
     handle, stride = (int(v) for v in args.cpu_worker.split(","))
     w, h = (int(v) for v in args.res.split("x"))
-    wl = FrameWorkload(w, h, args.bit_depth, args.seed, qp=args.qp, mix=args.mix)
+    frames = None
+    if getattr(args, "yuv", None):
+        from turingcodec_amd.picture_io import YuvReader
+        rd = YuvReader(args.yuv, w, h, args.bit_depth)
+        frames = [rd.planes(i % max(1, len(rd))) for i in range(3)]
+    wl = FrameWorkload(w, h, args.bit_depth, args.seed, qp=args.qp, mix=args.mix, frames=frames)
     inter = wl.mix == "ra"
     lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libhavoc_ref.so"))
     cores = usable_cores()
@@ -728,8 +735,8 @@ def cpu_baseline(args, dev=None):
     for handle in (1, 0):   # x86 JIT tables first; plain-C tables if the JIT run fails
         tmp = os.path.join(tempfile.gettempdir(), f"havoc_cpu_{os.getpid()}_{handle}.npz")
         cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", f"{handle},{stride}", "--res", args.res,
-               "--bit-depth", str(args.bit_depth), "--seed", str(args.seed), "--qp", str(args.qp), "--mix", args.mix, "--rdoq", str(args.rdoq),
-               "--cpu-out", tmp]
+               "--bit-depth", str(args.bit_depth), "--seed", str(args.seed), "--qp", str(args.qp), "--mix", args.mix, "--rdoq", str(getattr(args, "rdoq", 1)),
+               "--cpu-out", tmp] + (["--yuv", args.yuv] if getattr(args, "yuv", None) else [])
         try:
             out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
             if out.returncode == 0:
@@ -821,7 +828,12 @@ def build_contexts(args, torch, Havoc, FrameWorkload, local, res, bit_depth, qp,
     for k in range(count):
         compute_k = torch.cuda.Stream(device=local)
         hv_k = Havoc(local, stream=compute_k.cuda_stream)
-        wl_k = FrameWorkload(w, h, bit_depth, seed0 + 1000 * k, qp=qp, mix=mix)
+        frames = None
+        if getattr(args, "yuv", None) and res == args.res:
+            from turingcodec_amd.picture_io import YuvReader
+            rd = YuvReader(args.yuv, w, h, bit_depth)
+            frames = [rd.planes((3 * k + i) % max(1, len(rd))) for i in range(3)]
+        wl_k = FrameWorkload(w, h, bit_depth, seed0 + 1000 * k, qp=qp, mix=mix, frames=frames)
         dev_k = DeviceFrame(hv_k, wl_k, use_planes=(args.subpel == "planes"), fused_tu=(args.tu == "fused"),
                             ime_range=args.ime_range if args.ime == "surface" else None, skip=[s for s in args.skip.split(",") if s],
                             rdoq=args.rdoq)
@@ -1113,7 +1125,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 4),
             "higher_is_better": True, "scaling": args.scaling if pipe is not None else "weak", "vs_baseline": None,
-            "dtype": "u8" if args.bit_depth == 8 else "u16", "data": "synthetic",
+            "dtype": "u8" if args.bit_depth == 8 else "u16", "data": "synthetic" if not args.yuv else f"file {os.path.basename(args.yuv)} (job tables synthetic)",
             "config": {"workload": f"{args.res} {args.bit_depth}-bit 4:2:0 {mixname}, 1xMI355X per rank",
                        "calls_per_frame": int(sum(wl.counts.values())), "launches_per_frame": len(dev.launches), "pictures_in_flight": inflight,
                        "integer_me": ("sad4 jobs (the reference's per-pattern calls)" if args.ime == "sad4" else

@@ -117,7 +117,7 @@ def _pick(rng, mix, n):
 class FrameWorkload:
     """Job tables (numpy int32, columns = the job structs of include/havoc_mi355x.h) + picture store layout."""
 
-    def __init__(self, width=1920, height=1080, bit_depth=8, seed=11, scale=1.0, qp=32, mix="ra"):
+    def __init__(self, width=1920, height=1080, bit_depth=8, seed=11, scale=1.0, qp=32, mix="ra", frames=None):
         """mix: "ra" = one random-access B-frame at speed=medium (Appendix A.2 counts); "ai" = one all-intra frame at
         speed=fast (Appendix A.1 per-CTU intra / TU counts, havoc_quantize in the TU chain).  qp: the slice QP the
         (de)quantiser parameters are derived from (BASELINE.json: 32 for configs 0, 1, 4; 27 for configs 2, 3)."""
@@ -127,7 +127,11 @@ class FrameWorkload:
         self.S = 1 if bit_depth == 8 else 2
         rng = np.random.default_rng(seed)
         self.dtype = np.uint8 if self.S == 1 else np.uint16
-        frames = synth_frames(width, height, 3, seed, bit_depth)
+        # frames: three consecutive pictures [(Y, U, V)] (L0 reference, current, L1 reference), e.g. from picture_io.YuvReader.planes;
+        # default: the synthetic clip of SURVEY.md 8(d)
+        if frames is None:
+            frames = synth_frames(width, height, 3, seed, bit_depth)
+        assert len(frames) >= 3 and frames[0][0].shape == (height, width)
         # picture store: planes 0 = source, 1 = ref L0, 2 = ref L1 (luma); same for chroma (U only: V is identical work)
         luma = [pad_plane(f[0], PAD) for f in (frames[1], frames[0], frames[2])]
         chroma = [pad_plane(f[1], PAD // 2) for f in (frames[1], frames[0], frames[2])]
