@@ -129,11 +129,11 @@ def _expected(n_sops):
     return rec
 
 
-def _worker(rank, world, port, n_sops, out):
+def _worker(rank, world, port, n_sops, out, lag=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    sched = fp.DagSchedule(world, n_sops=n_sops)
+    sched = fp.DagSchedule(world, n_sops=n_sops, lag=lag)
     ex = fp.ReferenceExchange(dist, rank, sched, NL, NC, torch.zeros(1, dtype=torch.uint8))
     want = _expected(n_sops)
     sums = {}
@@ -160,10 +160,10 @@ def _worker(rank, world, port, n_sops, out):
     dist.destroy_process_group()
 
 
-def _run(world, n_sops):
+def _run(world, n_sops, lag=None):
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), n_sops, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), n_sops, out, lag), nprocs=world, join=True)
     return dict(out)
 
 
@@ -183,3 +183,19 @@ def test_frame_parallel_gloo_world2_equals_single_rank_per_poc():
     assert two[0][3] == two[1][3] == nref
     assert two[0][2] + two[1][2] == nref * (NL + 2 * NC)
     assert two[0][4] == fp.DagSchedule(2, n_sops=n_sops).slots_for_sequence() and one[0][4] == 1 + 8 * n_sops
+
+
+def test_frame_parallel_gloo_world4_lag2_equals_sequential_coding():
+    """the deeper schedule (every reference from another rank two slots ahead of its users, the anchor chain local to rank 0, 40 mirror
+    slots) over gloo with four ranks: every picture's reconstruction equals the one sequential coding gives"""
+    n_sops = 5
+    res = _run(4, n_sops, lag=2)
+    want = {poc: int(r.to(torch.int64).sum()) * 1000003 + int(r[::7].to(torch.int64).sum()) for poc, r in _expected(n_sops).items()}
+    merged = {}
+    for r in range(4):
+        assert res[r][1] == [], (r, res[r][1])
+        assert not (set(merged) & set(res[r][0]))
+        merged.update(res[r][0])
+    assert merged == want
+    assert all(poc % 8 == 0 for poc in res[0][0] if poc % 8 == 0) and set(p for p in want if p % 8 == 0) <= set(res[0][0])      # anchors on rank 0
+    assert res[0][4] == fp.DagSchedule(4, n_sops=n_sops, lag=2).slots_for_sequence()
