@@ -54,6 +54,8 @@ FIELDS = ["mv", "mvd", "mv_integer", "mvp_flag", "wrote_2Nx2N", "calls", "cost_i
 
 
 def same(a, b, fields=FIELDS):
+    if len(a) == 0 and len(b) == 0:
+        return []
     return [int(i) for i in np.flatnonzero(~np.all([np.all(a[f].reshape(len(a), -1) == b[f].reshape(len(b), -1), axis=1) for f in fields], axis=0))]
 
 
