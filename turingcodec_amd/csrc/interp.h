@@ -31,7 +31,7 @@ __device__ __forceinline__ int sdot2(uint32_t a, uint32_t b, int c)
 
 // four adjacent horizontal-filter outputs at p = first sample of the first window (no shift applied)
 template <int S, int TAPS>
-__device__ __forceinline__ void hfilter4(const char *p, const int (&c)[TAPS], int (&out)[4])
+__device__ __forceinline__ void hfilter4(const char *p, const int (&c)[TAPS], int (&out)[4], int bias = 0)
 {
     if (S == 1)
     {
@@ -41,21 +41,21 @@ __device__ __forceinline__ void hfilter4(const char *p, const int (&c)[TAPS], in
         {
             const uint32_t clo = pack_i8(c[0], c[1], c[2], c[3]), chi = pack_i8(c[4], c[5], c[6], c[7]);
             const uint32_t d0 = ld4(p) ^ f, d1 = ld4(p + 4) ^ f, d2 = ld4(p + 8) ^ f;
-            out[0] = __builtin_amdgcn_sdot4(d1, chi, __builtin_amdgcn_sdot4(d0, clo, 8192, false), false);
+            out[0] = __builtin_amdgcn_sdot4(d1, chi, __builtin_amdgcn_sdot4(d0, clo, 8192 + bias, false), false);
 #pragma unroll
             for (int o = 1; o < 4; ++o)
             {
                 const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, o), hi = __builtin_amdgcn_alignbyte(d2, d1, o);
-                out[o] = __builtin_amdgcn_sdot4(hi, chi, __builtin_amdgcn_sdot4(lo, clo, 8192, false), false);
+                out[o] = __builtin_amdgcn_sdot4(hi, chi, __builtin_amdgcn_sdot4(lo, clo, 8192 + bias, false), false);
             }
         }
         else
         {
             const uint32_t cc = pack_i8(c[0], c[1], c[2], c[3]);
             const uint32_t d0 = ld4(p) ^ f, d1 = ld4(p + 4) ^ f;
-            out[0] = __builtin_amdgcn_sdot4(d0, cc, 8192, false);
+            out[0] = __builtin_amdgcn_sdot4(d0, cc, 8192 + bias, false);
 #pragma unroll
-            for (int o = 1; o < 4; ++o) out[o] = __builtin_amdgcn_sdot4(__builtin_amdgcn_alignbyte(d1, d0, o), cc, 8192, false);
+            for (int o = 1; o < 4; ++o) out[o] = __builtin_amdgcn_sdot4(__builtin_amdgcn_alignbyte(d1, d0, o), cc, 8192 + bias, false);
         }
     }
     else
@@ -71,7 +71,7 @@ __device__ __forceinline__ void hfilter4(const char *p, const int (&c)[TAPS], in
 #pragma unroll
         for (int o = 0; o < 4; ++o)
         {
-            int a = 0;
+            int a = bias;
 #pragma unroll
             for (int k = 0; k < TAPS / 2; ++k) a = sdot2((o & 1) ? od[(o >> 1) + k] : e[(o >> 1) + k], cp[k], a);
             out[o] = a;
