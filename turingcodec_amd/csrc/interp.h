@@ -29,9 +29,26 @@ __device__ __forceinline__ int sdot2(uint32_t a, uint32_t b, int c)
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b), c, false);
 }
 
-// four adjacent horizontal-filter outputs at p = first sample of the first window (no shift applied)
+// four adjacent horizontal-filter outputs at p = first sample of the first window (no shift applied), in two halves so
+// that a caller can have the loads of all its rows in flight before it needs the first: the dwords covering samples
+// 0 .. TAPS + 2 ...
 template <int S, int TAPS>
-__device__ __forceinline__ void hfilter4(const char *p, const int (&c)[TAPS], int (&out)[4], int bias = 0)
+struct HRaw
+{
+    static constexpr int ND = S == 1 ? (TAPS == 8 ? 3 : 2) : (TAPS == 8 ? 6 : 4);
+    uint32_t d[ND];
+};
+
+template <int S, int TAPS>
+__device__ __forceinline__ void hfilter4_load(const char *p, HRaw<S, TAPS> &r)
+{
+#pragma unroll
+    for (int k = 0; k < HRaw<S, TAPS>::ND; ++k) r.d[k] = ld4(p + 4 * k);
+}
+
+// ... and the four sums (+ bias)
+template <int S, int TAPS>
+__device__ __forceinline__ void hfilter4_eval(const HRaw<S, TAPS> &r, const int (&c)[TAPS], int (&out)[4], int bias = 0)
 {
     if (S == 1)
     {
@@ -40,7 +57,7 @@ __device__ __forceinline__ void hfilter4(const char *p, const int (&c)[TAPS], in
         if (TAPS == 8)
         {
             const uint32_t clo = pack_i8(c[0], c[1], c[2], c[3]), chi = pack_i8(c[4], c[5], c[6], c[7]);
-            const uint32_t d0 = ld4(p) ^ f, d1 = ld4(p + 4) ^ f, d2 = ld4(p + 8) ^ f;
+            const uint32_t d0 = r.d[0] ^ f, d1 = r.d[1] ^ f, d2 = r.d[HRaw<S, TAPS>::ND - 1] ^ f;
             out[0] = __builtin_amdgcn_sdot4(d1, chi, __builtin_amdgcn_sdot4(d0, clo, 8192 + bias, false), false);
 #pragma unroll
             for (int o = 1; o < 4; ++o)
@@ -52,7 +69,7 @@ __device__ __forceinline__ void hfilter4(const char *p, const int (&c)[TAPS], in
         else
         {
             const uint32_t cc = pack_i8(c[0], c[1], c[2], c[3]);
-            const uint32_t d0 = ld4(p) ^ f, d1 = ld4(p + 4) ^ f;
+            const uint32_t d0 = r.d[0] ^ f, d1 = r.d[1] ^ f;
             out[0] = __builtin_amdgcn_sdot4(d0, cc, 8192 + bias, false);
 #pragma unroll
             for (int o = 1; o < 4; ++o) out[o] = __builtin_amdgcn_sdot4(__builtin_amdgcn_alignbyte(d1, d0, o), cc, 8192 + bias, false);
@@ -60,12 +77,10 @@ __device__ __forceinline__ void hfilter4(const char *p, const int (&c)[TAPS], in
     }
     else
     {
-        constexpr int ND = TAPS == 8 ? 6 : 4;       // dwords covering samples 0 .. TAPS+2
-        uint32_t e[ND], od[ND - 1], cp[TAPS / 2];
+        constexpr int ND = HRaw<S, TAPS>::ND;
+        uint32_t od[ND - 1], cp[TAPS / 2];
 #pragma unroll
-        for (int k = 0; k < ND; ++k) e[k] = ld4(p + 4 * k);
-#pragma unroll
-        for (int k = 0; k < ND - 1; ++k) od[k] = __builtin_amdgcn_alignbit(e[k + 1], e[k], 16);
+        for (int k = 0; k < ND - 1; ++k) od[k] = __builtin_amdgcn_alignbit(r.d[k + 1], r.d[k], 16);
 #pragma unroll
         for (int k = 0; k < TAPS / 2; ++k) cp[k] = pack_i16(c[2 * k], c[2 * k + 1]);
 #pragma unroll
@@ -73,10 +88,18 @@ __device__ __forceinline__ void hfilter4(const char *p, const int (&c)[TAPS], in
         {
             int a = bias;
 #pragma unroll
-            for (int k = 0; k < TAPS / 2; ++k) a = sdot2((o & 1) ? od[(o >> 1) + k] : e[(o >> 1) + k], cp[k], a);
+            for (int k = 0; k < TAPS / 2; ++k) a = sdot2((o & 1) ? od[(o >> 1) + k] : r.d[(o >> 1) + k], cp[k], a);
             out[o] = a;
         }
     }
+}
+
+template <int S, int TAPS>
+__device__ __forceinline__ void hfilter4(const char *p, const int (&c)[TAPS], int (&out)[4], int bias = 0)
+{
+    HRaw<S, TAPS> r;
+    hfilter4_load<S, TAPS>(p, r);
+    hfilter4_eval<S, TAPS>(r, c, out, bias);
 }
 
 } // namespace havoc_gpu

@@ -284,21 +284,24 @@ __global__ __launch_bounds__(256) void k_interp_planes_q(char *__restrict__ plan
         taps_of<8>(xf, cx);
         const int bias = (1 << (shift - 7)) << shift1;   // (a + bias) >> shift1 == (a >> shift1) + rnd / 64
         const bool wanted = xq < x1 && xq + 3 >= x0;
-        const char *p = ref + (long)(ty - 3 + g) * rsb + (long)(xq - 3) * S;
         int16_t *t = &s_t[xf][4 * q * COL + g];
         if (wanted)
         {
+            // all six row loads in flight before the first is used (rows past the last one any output needs are clamped onto
+            // it: their intermediates are written but never read by a stored sample)
+            const int last = y1 + 3 - (ty - 3);
+            HRaw<S, 8> raw[(NR + 3) / 4];
+#pragma unroll
+            for (int it = 0; it < (NR + 3) / 4; ++it)
+                hfilter4_load<S, 8>(ref + (long)(ty - 3 + min(g + 4 * it, last)) * rsb + (long)(xq - 3) * S, raw[it]);
 #pragma unroll
             for (int it = 0; it < (NR + 3) / 4; ++it)
             {
-                const int r = g + 4 * it;
-                if (r < NR && ty - 3 + r < y1 + 4)
-                {
-                    int a[4];
-                    hfilter4<S, 8>(p + (long)(4 * it) * rsb, cx, a, bias);
+                int a[4];
+                hfilter4_eval<S, 8>(raw[it], cx, a, bias);
+                // row 23 (it = 5, g = 3) is no row of the tile: it lands in the column's padding (COL = 26 > 24)
 #pragma unroll
-                    for (int o = 0; o < 4; ++o) t[o * COL + 4 * it] = (int16_t)(a[o] >> shift1);
-                }
+                for (int o = 0; o < 4; ++o) t[o * COL + 4 * it] = (int16_t)(a[o] >> shift1);
             }
         }
     }
