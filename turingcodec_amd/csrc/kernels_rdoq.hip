@@ -16,6 +16,8 @@
 // took 1.9 ms per 1080p picture against 0.93 ms for the form below.  profiles/r02_experiments.md has the numbers.)
 #include "common.h"
 
+#include <cstdlib>
+
 namespace havoc_gpu {
 
 namespace {
@@ -47,6 +49,7 @@ struct Block
 {
     const uint8_t *states;    // LDS: this block's 128 state bytes, `stateStride` apart
     const int32_t *bits;      // LDS: kEntropyBits
+    const int32_t *lastBits;  // LDS: this block's [2][10] bits of a last_sig_coeff_{x,y} coordinate whose prefix has k ones (Rdoq.cpp:706-763), `stateStride` apart
     int stateStride;
     int64_t lambda;
     int distShift;            // distortion scale = 1 << distShift (Q16)
@@ -182,16 +185,22 @@ struct WalkShared
 {
     WalkRecords rec;
     int32_t bits[128];
-    uint8_t states[HAVOC_RDOQ_CTX_BYTES][64];     // [context][lane]
-    int32_t lastBits[2][10][64];                  // bits of a last_sig_coeff_{x,y} coordinate whose prefix has k ones (Rdoq.cpp:706-763)
     int16_t coef[16][64];                         // the current group's coefficients, raster order within the group
     uint32_t pre[16][64];                         // per position: significance context << 25 | flag bits of the zero levels above it
     uint8_t rasterOf[3][64];                      // scan index -> raster group position, per scan type
 };
 
+// what is per transform block rather than per lane: SLOTS blocks per wavefront (64 when a lane is a block)
+template <int SLOTS>
+struct BlockTables
+{
+    uint8_t states[HAVOC_RDOQ_CTX_BYTES][SLOTS];  // [context][block]
+    int32_t lastBits[2][10][SLOTS];
+};
+
 struct WalkResult
 {
-    int64_t cost, sigCost, dist0;      // as GroupResult
+    int64_t cost, sigCost, dist0;      // the group's RD cost; the cost of its coded_sub_block_flag; the energy of its coefficients
     int64_t q;                         // change of the last-position search's running cost across the group, if it stays coded
     int64_t localBest;                 // best candidate of the group relative to the running cost at its start
     int localPos, localOr, groupOr;    // its scan position; OR of the levels from it to the end of the group; OR of all levels
@@ -375,7 +384,7 @@ __device__ __forceinline__ WalkResult walkGroup(const Block &b, WalkShared &sh, 
         nonZeroAbovePos0 += (stored != 0) & (i != 0);
         // candidate for the last significant position (Rdoq.cpp:356-399)
         const int lx = lastPrefixLength(x), ly = lastPrefixLength(y);
-        const int32_t rate = sh.lastBits[0][b.scanIdx == 2 ? ly : lx][lane] + sh.lastBits[1][b.scanIdx == 2 ? lx : ly][lane];
+        const int32_t rate = b.lastBits[(b.scanIdx == 2 ? ly : lx) * b.stateStride] + b.lastBits[(10 + (b.scanIdx == 2 ? lx : ly)) * b.stateStride];
         const int64_t total = qB - zerosAbove + b.lambda * rate - costSig;
         const bool better = stored != 0 && !r.localStop && total < r.localBest;
         r.localBest = better ? total : r.localBest;
@@ -482,11 +491,12 @@ __device__ __forceinline__ void hideSignsWalk(WalkShared &sh, int lane, const Bl
 
 // Workspace of one launch (caller-provided, havoc_mi355x_rdoq_workspace bytes): what the scan pass found per block, the
 // histogram of blocks by their number of groups to walk, and the order the walk takes the blocks in.
-struct RdoqInfo { uint64_t mask; int64_t sumSq; };      // non-zero groups (bit = raster group position), sum of squared coefficients
+struct RdoqInfo { uint64_t mask, mask2, mask3; int64_t sumSq; };      // groups holding a rounded level > 0 / > 1 / > 2 (bit = raster group position), sum of squared coefficients
 constexpr int kBins = 66;                               // 0..64 groups to walk (+1 spare)
 struct RdoqWork
 {
     uint32_t hist[kBins], cursor[kBins];
+    uint32_t otherScans, pad[3];      // blocks of this launch that do not use the diagonal scan (walked by the sequential kernel)
     // followed by RdoqInfo info[njobs], then uint32_t order[njobs]
 };
 __host__ __device__ inline size_t rdoqInfoOffset() { return (sizeof(RdoqWork) + 15) & ~size_t(15); }
@@ -495,8 +505,8 @@ __device__ __forceinline__ int groupsToWalk(uint64_t mask) { return mask ? __pop
 // LDS of the cooperative scan of a workgroup's 64 blocks
 struct ScanShared
 {
-    int32_t srcOff[64], dstOff[64], nzThreshold[64];
-    uint64_t mask[64];      // non-zero groups of each block (bit = raster group position)
+    int32_t srcOff[64], dstOff[64], nzThreshold[64], gt1Threshold[64], gt2Threshold[64];
+    uint64_t mask[64], mask2[64], mask3[64];      // groups of each block with a rounded level > 0 / > 1 / > 2 (bit = raster group position)
     int64_t sumSq[64];      // sum of squared coefficients of each block
 };
 
@@ -515,7 +525,9 @@ __device__ __forceinline__ void scanBlocks(ScanShared &sc, int16_t *__restrict__
         // smallest |coefficient| whose rounded level is non-zero (Rdoq.cpp:108): |c| * scale + half >= 2 * half  <=>  |c| >= ceil(half / scale)
         const uint32_t half = 1u << (job.quant_shift - 1), scale = (uint32_t)max(job.quant_scale, 1);
         sc.nzThreshold[lane] = (int32_t)((half + scale - 1) / scale);
-        sc.mask[lane] = 0;
+        sc.gt1Threshold[lane] = (int32_t)((3 * half + scale - 1) / scale);      // rounded level >= 2  <=>  |c| * scale >= 3 * half
+        sc.gt2Threshold[lane] = (int32_t)((5 * half + scale - 1) / scale);      // rounded level >= 3  <=>  |c| * scale >= 5 * half
+        sc.mask[lane] = sc.mask2[lane] = sc.mask3[lane] = 0;
         sc.sumSq[lane] = 0;
     }
     __syncthreads();
@@ -526,8 +538,8 @@ __device__ __forceinline__ void scanBlocks(ScanShared &sc, int16_t *__restrict__
         const bool have = firstBlock + bl < njobs;
         const int16_t *p = srcAll + (long)sc.srcOff[bl] + (py * 4) * size + px * 4;
         int16_t *q = dstAll + (long)sc.dstOff[bl] + (py * 4) * size + px * 4;
-        const uint32_t thr = (uint32_t)sc.nzThreshold[bl];
-        bool nz = false;
+        const uint32_t thr = (uint32_t)sc.nzThreshold[bl], thr2 = (uint32_t)sc.gt1Threshold[bl], thr3 = (uint32_t)sc.gt2Threshold[bl];
+        bool nz = false, nz2 = false, nz3 = false;
         uint32_t lo = 0, hi = 0;
         if (have)
         {
@@ -548,12 +560,16 @@ __device__ __forceinline__ void scanBlocks(ScanShared &sc, int16_t *__restrict__
                 }
             }
             nz = max((uint32_t)big.x, (uint32_t)big.y) >= thr;
+            nz2 = max((uint32_t)big.x, (uint32_t)big.y) >= thr2;
+            nz3 = max((uint32_t)big.x, (uint32_t)big.y) >= thr3;
         }
-        const uint64_t m = __ballot(nz);
+        const uint64_t m = __ballot(nz), m2 = __ballot(nz2), m3 = __ballot(nz3);
         const int slo = group_sum<G>((int)lo), shi = group_sum<G>((int)hi);
         if (pos == 0 && have)
         {
             sc.mask[bl] = G == 64 ? m : (m >> (lane & ~(G - 1))) & ((1ull << (G & 63)) - 1);
+            sc.mask2[bl] = G == 64 ? m2 : (m2 >> (lane & ~(G - 1))) & ((1ull << (G & 63)) - 1);
+            sc.mask3[bl] = G == 64 ? m3 : (m3 >> (lane & ~(G - 1))) & ((1ull << (G & 63)) - 1);
             sc.sumSq[bl] = ((int64_t)shi << 16) + slo;
         }
     }
@@ -579,13 +595,17 @@ __global__ __launch_bounds__(64) void k_rdoq_scan(int16_t *__restrict__ dstAll, 
     {
         RdoqInfo r;
         r.mask = sc.mask[lane];
+        r.mask2 = sc.mask2[lane];
+        r.mask3 = sc.mask3[lane];
         r.sumSq = sc.sumSq[lane];
         info[blk] = r;
         atomicAdd(&hist[groupsToWalk(r.mask)], 1u);
+        if (jobs[blk].scan_idx != 0) atomicAdd(&hist[kBins - 1], 1u);      // the spare bin (never a number of groups: at most 64) counts them
     }
     __syncthreads();
-    for (int k = lane; k < kBins; k += 64)
+    for (int k = lane; k < kBins - 1; k += 64)
         if (hist[k]) atomicAdd(&work->hist[k], hist[k]);
+    if (lane == 0 && hist[kBins - 1]) atomicAdd(&work->otherScans, hist[kBins - 1]);
 }
 
 // Pass 2: blocks ordered by decreasing number of groups to walk (counting sort; the order inside a bin is whatever the atomics
@@ -616,87 +636,81 @@ __global__ __launch_bounds__(256) void k_rdoq_order(int njobs, RdoqWork *__restr
     if (blk < njobs) order[base[bin] + rank] = (uint32_t)blk;
 }
 
-// The walk.  SORTED (32x32, 16x16): blocks in the order of pass 2, scan results from the workspace.  Otherwise (8x8, 4x4: many short
-// blocks, where three launches and a permuted access cost more than the balance gains) the scan runs here, blocks in job order.
-template <int LOG2, bool SORTED>
-__global__ __launch_bounds__(64) void k_rdoq_walk(int16_t *__restrict__ dstAll, const int16_t *__restrict__ srcAll, const uint8_t *__restrict__ statesAll,
-                                                  const RdoqJob *__restrict__ jobs, int njobs, int32_t *__restrict__ cbfOut, int bitDepth,
-                                                  const RdoqWork *__restrict__ work)
+// ---- what the two walk kernels share: a lane's view of its transform block ----
+template <int LOG2>
+struct LaneBlock
 {
-    constexpr int size = 1 << LOG2, G = (size * size) >> 4, gw = size >> 2;
-    __shared__ WalkShared sh;
-    const RdoqInfo *infoAll = reinterpret_cast<const RdoqInfo *>(reinterpret_cast<const char *>(work) + rdoqInfoOffset());
-    const uint32_t *order = reinterpret_cast<const uint32_t *>(infoAll + njobs);
-    const int lane = threadIdx.x, slot = blockIdx.x * 64 + lane;
-    const bool valid = slot < njobs;
-    const int blk = valid ? (SORTED ? (int)order[slot] : slot) : 0;
-    const RdoqJob job = jobs[blk];
-    RdoqInfo info;
-    if (SORTED)
-        info = infoAll[blk];
-    else
-    {
-        __shared__ ScanShared sc;
-        scanBlocks<LOG2>(sc, dstAll, srcAll, jobs, njobs, blockIdx.x * 64, G);
-        info.mask = sc.mask[lane];
-        info.sumSq = sc.sumSq[lane];
-    }
-
-    // ---- stage in ----
-    sh.bits[lane] = kEntropyBits[lane];
-    sh.bits[64 + lane] = kEntropyBits[64 + lane];
-    {
-        const uint32_t *st = reinterpret_cast<const uint32_t *>(statesAll + (long)job.ctx_index * HAVOC_RDOQ_CTX_BYTES);
-        for (int k = 0; k < HAVOC_RDOQ_CTX_BYTES / 4; ++k)
-        {
-            const uint32_t v = st[k];
-            sh.states[4 * k][lane] = (uint8_t)v;
-            sh.states[4 * k + 1][lane] = (uint8_t)(v >> 8);
-            sh.states[4 * k + 2][lane] = (uint8_t)(v >> 16);
-            sh.states[4 * k + 3][lane] = (uint8_t)(v >> 24);
-        }
-    }
-    if (lane < G)
-        for (int t = 0; t < 3; ++t)
-        {
-            int x = 0, y = 0;
-            if (G > 1) scanXy(gw, t, lane, x, y);
-            sh.rasterOf[t][lane] = (uint8_t)(y * gw + x);
-        }
-    __syncthreads();
-
-    // ---- per-lane set-up ----
+    static constexpr int size = 1 << LOG2, G = (size * size) >> 4, gw = size >> 2;
     Block b;
-    b.states = &sh.states[0][lane];
-    b.stateStride = 64;
-    b.bits = sh.bits;
-    b.lambda = job.lambda_q16;
-    const int transformShift = 15 - bitDepth - LOG2, distShift = 15 - 2 * transformShift - 2 * (bitDepth - 8) + 16;   // Rdoq.h:163-187
-    b.distShift = distShift;
-    b.invShift = 6 - transformShift;
-    b.invOffset = 1 << (b.invShift - 1);
-    b.quantScale = job.quant_scale;
-    b.quantShift = job.quant_shift;
-    b.invScale = job.inv_scale;
-    b.cIdx = job.c_idx;
-    b.scanIdx = job.scan_idx;
-    b.scan4 = job.scan_idx == 0 ? scan4Nibbles(0) : (job.scan_idx == 1 ? scan4Nibbles(1) : scan4Nibbles(2));
-    const uint8_t *rasterOf = sh.rasterOf[job.scan_idx < 3 ? job.scan_idx : 0];
-    const int16_t *src = srcAll + job.src_off;
-    int16_t *dst = dstAll + job.dst_off;
-    for (int axis = 0; axis < 2; ++axis)      // Rdoq.cpp:706-771 per prefix length
+    const uint8_t *rasterOf;      // LDS: scan index of a group -> its raster position
+    const int16_t *src;
+    int16_t *dst;
+    int distShift;
+
+    // tables and the block's context states into LDS, then the per-lane constants (Rdoq.h:163-187, Rdoq.cpp:706-771); all 64 lanes call it.
+    // `slot` = the block's place in the wavefront, shared by `per` lanes of which this one is number `sub`.
+    template <int SLOTS>
+    __device__ __forceinline__ void stageIn(WalkShared &sh, BlockTables<SLOTS> &bt, int lane, int slot, int sub, int per, const RdoqJob &job,
+                                            const uint8_t *__restrict__ statesAll, int bitDepth, const int16_t *__restrict__ srcAll, int16_t *__restrict__ dstAll)
     {
-        const int base = axis ? HAVOC_RDOQ_CTX_LAST_Y : HAVOC_RDOQ_CTX_LAST_X;
-        const int offset = b.cIdx ? 15 : 3 * (LOG2 - 2) + ((LOG2 - 1) >> 2), shift = b.cIdx ? LOG2 - 2 : (LOG2 + 1) >> 2;
-        int32_t ones = 0;
-        for (int len = 0; len < 10; ++len)
+        sh.bits[lane] = kEntropyBits[lane];
+        sh.bits[64 + lane] = kEntropyBits[64 + lane];
         {
-            const int ctx = base + min(max((len >> shift) + offset, 0), 17);
-            sh.lastBits[axis][len][lane] = ones + (len < 9 ? bitsOf(b, ctx, 0) : 0) + (len > 3 ? 32768 * ((len - 2) >> 1) : 0);
-            if (len < 9) ones += bitsOf(b, ctx, 1);
+            const uint32_t *st = reinterpret_cast<const uint32_t *>(statesAll + (long)job.ctx_index * HAVOC_RDOQ_CTX_BYTES);
+            for (int k = sub; k < HAVOC_RDOQ_CTX_BYTES / 4; k += per)
+            {
+                const uint32_t v = st[k];
+                bt.states[4 * k][slot] = (uint8_t)v;
+                bt.states[4 * k + 1][slot] = (uint8_t)(v >> 8);
+                bt.states[4 * k + 2][slot] = (uint8_t)(v >> 16);
+                bt.states[4 * k + 3][slot] = (uint8_t)(v >> 24);
+            }
         }
+        if (lane < G)
+            for (int t = 0; t < 3; ++t)
+            {
+                int x = 0, y = 0;
+                if (G > 1) scanXy(gw, t, lane, x, y);
+                sh.rasterOf[t][lane] = (uint8_t)(y * gw + x);
+            }
+        __syncthreads();
+
+        b.states = &bt.states[0][slot];
+        b.lastBits = &bt.lastBits[0][0][slot];
+        b.stateStride = SLOTS;
+        b.bits = sh.bits;
+        b.lambda = job.lambda_q16;
+        const int transformShift = 15 - bitDepth - LOG2;
+        distShift = 15 - 2 * transformShift - 2 * (bitDepth - 8) + 16;
+        b.distShift = distShift;
+        b.invShift = 6 - transformShift;
+        b.invOffset = 1 << (b.invShift - 1);
+        b.quantScale = job.quant_scale;
+        b.quantShift = job.quant_shift;
+        b.invScale = job.inv_scale;
+        b.cIdx = job.c_idx;
+        b.scanIdx = job.scan_idx;
+        b.scan4 = job.scan_idx == 0 ? scan4Nibbles(0) : (job.scan_idx == 1 ? scan4Nibbles(1) : scan4Nibbles(2));
+        rasterOf = sh.rasterOf[job.scan_idx < 3 ? job.scan_idx : 0];
+        src = srcAll + job.src_off;
+        dst = dstAll + job.dst_off;
+        if (sub == 0)
+            for (int axis = 0; axis < 2; ++axis)      // Rdoq.cpp:706-771 per prefix length
+            {
+                const int base = axis ? HAVOC_RDOQ_CTX_LAST_Y : HAVOC_RDOQ_CTX_LAST_X;
+                const int offset = b.cIdx ? 15 : 3 * (LOG2 - 2) + ((LOG2 - 1) >> 2), shift = b.cIdx ? LOG2 - 2 : (LOG2 + 1) >> 2;
+                int32_t ones = 0;
+                for (int len = 0; len < 10; ++len)
+                {
+                    const int ctx = base + min(max((len >> shift) + offset, 0), 17);
+                    bt.lastBits[axis][len][slot] = ones + (len < 9 ? bitsOf(b, ctx, 0) : 0) + (len > 3 ? 32768 * ((len - 2) >> 1) : 0);
+                    if (len < 9) ones += bitsOf(b, ctx, 1);
+                }
+            }
+        __syncthreads();
     }
-    auto loadGroup = [&](int gx, int gy) {
+    __device__ __forceinline__ void loadGroup(WalkShared &sh, int lane, int gx, int gy) const
+    {
         for (int r = 0; r < 4; ++r)
         {
             const u32x2 v = ld8(src + ((gy << 2) + r) * size + (gx << 2));
@@ -705,10 +719,10 @@ __global__ __launch_bounds__(64) void k_rdoq_walk(int16_t *__restrict__ dstAll, 
             sh.coef[4 * r + 2][lane] = (int16_t)v.y;
             sh.coef[4 * r + 3][lane] = (int16_t)(v.y >> 16);
         }
-    };
-    SdhAux aux;
+    }
     // rec.kept (magnitudes, raster order) -> truncation at lastIdx, sign-data hiding, signs (Rdoq.cpp:418-441), the output block
-    auto finishGroup = [&](int g, int lastIdx, bool lastGroup, int gx, int gy) {
+    __device__ __forceinline__ void finishGroup(WalkShared &sh, int lane, bool sdh, const SdhAux &aux, int g, int lastIdx, bool lastGroup, int gx, int gy) const
+    {
         uint32_t keptMask = aux.keptMask;
         if (lastGroup)
         {
@@ -718,7 +732,7 @@ __global__ __launch_bounds__(64) void k_rdoq_walk(int16_t *__restrict__ dstAll, 
                 if (!((stay >> i) & 1)) sh.rec.kept[(int)(b.scan4 >> (4 * i)) & 15][lane] = 0;
             keptMask &= stay;
         }
-        if (job.sdh) hideSignsWalk(sh, lane, b, lastGroup, aux, keptMask);
+        if (sdh) hideSignsWalk(sh, lane, b, lastGroup, aux, keptMask);
         for (int r = 0; r < 4; ++r)
         {
             int v[4];
@@ -732,14 +746,119 @@ __global__ __launch_bounds__(64) void k_rdoq_walk(int16_t *__restrict__ dstAll, 
             o.y = (uint32_t)(uint16_t)v[2] | (uint32_t)(uint16_t)v[3] << 16;
             st8(dst + ((gy << 2) + r) * size + (gx << 2), o);
         }
-    };
-    auto caseOf = [&](uint64_t coded, int gx, int gy, int carry) {
+    }
+    __device__ __forceinline__ void clearGroup(int p) const
+    {
+        for (int r = 0; r < 4; ++r) st8(dst + (((p / gw) << 2) + r) * size + ((p & (gw - 1)) << 2), u32x2{0, 0});
+    }
+    // right coded | below coded << 1 | carry << 2
+    static __device__ __forceinline__ int caseOf(uint64_t coded, int gx, int gy, int carry)
+    {
         const int p = gy * gw + gx;
         const int right = gx < gw - 1 ? (int)(coded >> (p + 1)) & 1 : 0, below = gy < gw - 1 ? (int)(coded >> (p + gw)) & 1 : 0;
         return right | below << 1 | carry << 2;
-    };
+    }
+    // position of the first non-zero rounded level of the group now in sh.coef (scan order within the group), or -1
+    __device__ __forceinline__ int firstInGroup(const WalkShared &sh, int lane) const
+    {
+        for (int i = 15; i >= 0; --i)
+        {
+            const int a = abs((int)sh.coef[(int)(b.scan4 >> (4 * i)) & 15][lane]);
+            if (((a * b.quantScale + (1 << (b.quantShift - 1))) >> b.quantShift) > 0) return i;
+        }
+        return -1;
+    }
+    __device__ __forceinline__ int64_t zeroGroupCost(uint64_t coded, int p) const      // Rdoq.cpp:200-210
+    {
+        const int c = caseOf(coded, p & (gw - 1), p / gw, 0);
+        return b.lambda * bitsOf(b, HAVOC_RDOQ_CTX_CSBF + (b.cIdx ? 2 : 0) + ((c & 3) ? 1 : 0), 0);
+    }
+    // Rdoq.cpp:307-341: the index one past the last significant position (0: nothing is coded)
+    __device__ __forceinline__ int lastIndex(bool isIntra, int64_t sumSq, int64_t walkedDist0, int64_t costTu, int64_t bestRel, int bestPos) const
+    {
+        const int cbfCtx = (!isIntra && b.cIdx == 0) ? HAVOC_RDOQ_CTX_ROOT_CBF : (b.cIdx == 0 ? HAVOC_RDOQ_CTX_CBF_LUMA + 1 : HAVOC_RDOQ_CTX_CBF_CHROMA);
+        const int64_t dist0Total = sumSq << distShift;
+        const int64_t bestNone = dist0Total + b.lambda * bitsOf(b, cbfCtx, 0);
+        const int64_t start = (dist0Total - walkedDist0) + costTu + b.lambda * bitsOf(b, cbfCtx, 1);
+        return (bestPos >= 0 && start + bestRel < bestNone) ? bestPos + 1 : 0;
+    }
+};
 
-    uint64_t nz = valid ? info.mask : 0, coded = 0, carries = 0;
+// the running state of a block's walk (identical in every lane that follows the block)
+struct WalkState
+{
+    int64_t costTu = 0, walkedDist0 = 0;    // costTu: everything but the energy of the coefficients outside the walked groups
+    int64_t rel = 0;                        // running cost of the last-position search relative to its start
+    int64_t bestRel = INT64_MAX;
+    int bestPos = -1, orSince = 0;
+    bool stopped = false;
+    uint64_t coded = 0, carries = 0;        // by raster position; carry INTO each walked group, by scan index
+
+    __device__ __forceinline__ void zeroGroup(int64_t zero)
+    {
+        costTu += zero;
+        rel -= zero;
+    }
+    __device__ __forceinline__ void walkedGroup(const WalkResult &r, int g, int p, int carryIn)
+    {
+        costTu += r.cost;
+        walkedDist0 += r.dist0;
+        coded |= (uint64_t)r.coded << p;
+        carries |= (uint64_t)carryIn << g;
+        rel -= r.sigCost;
+        if (r.coded)
+        {
+            if (!stopped && r.localPos >= 0 && rel + r.localBest < bestRel)
+            {
+                bestRel = rel + r.localBest;
+                bestPos = r.localPos;
+                orSince = r.localOr;
+            }
+            else
+                orSince |= r.groupOr;
+            stopped |= r.localStop;
+            rel += r.q;
+        }
+    }
+};
+
+// The sequential walk.  SORTED (32x32, 16x16 blocks that do not use the diagonal scan -- k_rdoq_diag takes the others): blocks in the
+// order of pass 2, scan results from the workspace.  Otherwise (8x8, 4x4: many short blocks, where three launches and a permuted
+// access cost more than the balance gains) the scan runs here, blocks in job order.
+template <int LOG2, bool SORTED>
+__global__ __launch_bounds__(64) void k_rdoq_walk(int16_t *__restrict__ dstAll, const int16_t *__restrict__ srcAll, const uint8_t *__restrict__ statesAll,
+                                                  const RdoqJob *__restrict__ jobs, int njobs, int32_t *__restrict__ cbfOut, int bitDepth,
+                                                  const RdoqWork *__restrict__ work, int diagonalElsewhere)
+{
+    typedef LaneBlock<LOG2> LB;
+    constexpr int G = LB::G, gw = LB::gw;
+    __shared__ WalkShared sh;
+    __shared__ BlockTables<64> bt;
+    if (SORTED && diagonalElsewhere && work->otherScans == 0) return;
+    const RdoqInfo *infoAll = reinterpret_cast<const RdoqInfo *>(reinterpret_cast<const char *>(work) + rdoqInfoOffset());
+    const uint32_t *order = reinterpret_cast<const uint32_t *>(infoAll + njobs);
+    const int lane = threadIdx.x, slot = blockIdx.x * 64 + lane;
+    bool valid = slot < njobs;
+    const int blk = valid ? (SORTED ? (int)order[slot] : slot) : 0;
+    const RdoqJob job = jobs[blk];
+    if (SORTED && diagonalElsewhere && job.scan_idx == 0) valid = false;
+    RdoqInfo info;
+    if (SORTED)
+        info = infoAll[blk];
+    else
+    {
+        __shared__ ScanShared sc;
+        scanBlocks<LOG2>(sc, dstAll, srcAll, jobs, njobs, blockIdx.x * 64, G);
+        info.mask = sc.mask[lane];
+        info.sumSq = sc.sumSq[lane];
+    }
+    LB lb;
+    lb.stageIn(sh, bt, lane, lane, 0, 1, job, statesAll, bitDepth, srcAll, dstAll);
+    const Block &b = lb.b;
+    const uint8_t *rasterOf = lb.rasterOf;
+    SdhAux aux;
+
+    uint64_t nz = valid ? info.mask : 0;
     int g = G - 1;
     while (g >= 0 && !((nz >> rasterOf[g]) & 1)) --g;
     const int firstGroup = g;
@@ -747,31 +866,18 @@ __global__ __launch_bounds__(64) void k_rdoq_walk(int16_t *__restrict__ dstAll, 
     if (firstGroup >= 0)
     {
         const int p = rasterOf[firstGroup];
-        loadGroup(p & (gw - 1), p / gw);
-        for (int i = 15; i >= 0 && firstPos < 0; --i)
-        {
-            const int a = abs((int)sh.coef[(int)(b.scan4 >> (4 * i)) & 15][lane]);
-            if (((a * b.quantScale + (1 << (b.quantShift - 1))) >> b.quantShift) > 0) firstPos = firstGroup * 16 + i;
-        }
+        lb.loadGroup(sh, lane, p & (gw - 1), p / gw);
+        firstPos = firstGroup * 16 + lb.firstInGroup(sh, lane);
         nz |= 1;      // the DC group is always walked in full (it is coded whatever its levels, Rdoq.cpp:291-295)
     }
 
-    // running state of the walk
-    int64_t costTu = 0, walkedDist0 = 0;    // costTu: everything but the energy of the coefficients outside the walked groups
-    int64_t rel = 0;                        // running cost of the last-position search relative to its start
-    int64_t bestRel = INT64_MAX;
-    int bestPos = -1, orSince = 0, carry = 0;
-    bool stopped = false;
-
+    WalkState ws;
+    int carry = 0;
     while (true)
     {
-        while (g >= 0 && !((nz >> rasterOf[g]) & 1))      // all-zero groups: one flag cost each (Rdoq.cpp:200-210)
+        while (g >= 0 && !((nz >> rasterOf[g]) & 1))      // all-zero groups: one flag cost each
         {
-            const int p = rasterOf[g];
-            const int c = caseOf(coded, p & (gw - 1), p / gw, 0);
-            const int64_t zero = b.lambda * bitsOf(b, HAVOC_RDOQ_CTX_CSBF + (b.cIdx ? 2 : 0) + ((c & 3) ? 1 : 0), 0);
-            costTu += zero;
-            rel -= zero;
+            ws.zeroGroup(lb.zeroGroupCost(ws.coded, rasterOf[g]));
             carry = 0;
             --g;
         }
@@ -779,28 +885,11 @@ __global__ __launch_bounds__(64) void k_rdoq_walk(int16_t *__restrict__ dstAll, 
         if (g >= 0)
         {
             const int p = rasterOf[g], gx = p & (gw - 1), gy = p / gw;
-            loadGroup(gx, gy);
-            const WalkResult r = walkGroup<LOG2>(b, sh, lane, g, gx, gy, firstPos, caseOf(coded, gx, gy, carry), job.sdh_factor, aux);
-            costTu += r.cost;
-            walkedDist0 += r.dist0;
-            coded |= (uint64_t)r.coded << p;
-            carries |= (uint64_t)carry << g;
+            lb.loadGroup(sh, lane, gx, gy);
+            const WalkResult r = walkGroup<LOG2>(b, sh, lane, g, gx, gy, firstPos, LB::caseOf(ws.coded, gx, gy, carry), job.sdh_factor, aux);
+            ws.walkedGroup(r, g, p, carry);
             carry = r.carry;
-            rel -= r.sigCost;
-            if (r.coded)
-            {
-                if (!stopped && r.localPos >= 0 && rel + r.localBest < bestRel)
-                {
-                    bestRel = rel + r.localBest;
-                    bestPos = r.localPos;
-                    orSince = r.localOr;
-                }
-                else
-                    orSince |= r.groupOr;
-                stopped |= r.localStop;
-                rel += r.q;
-                finishGroup(g, 1 << 30, false, gx, gy);      // as a group below the last one; the last one is redone below
-            }
+            if (r.coded) lb.finishGroup(sh, lane, job.sdh, aux, g, 1 << 30, false, gx, gy);      // as a group below the last one; the last one is redone below
             --g;
         }
     }
@@ -809,29 +898,220 @@ __global__ __launch_bounds__(64) void k_rdoq_walk(int16_t *__restrict__ dstAll, 
     int cbf = 0;
     if (firstPos >= 0)
     {
-        const int cbfCtx = (!job.is_intra && b.cIdx == 0) ? HAVOC_RDOQ_CTX_ROOT_CBF : (b.cIdx == 0 ? HAVOC_RDOQ_CTX_CBF_LUMA + 1 : HAVOC_RDOQ_CTX_CBF_CHROMA);
-        const int64_t dist0Total = info.sumSq << distShift;
-        const int64_t bestNone = dist0Total + b.lambda * bitsOf(b, cbfCtx, 0);
-        const int64_t start = (dist0Total - walkedDist0) + costTu + b.lambda * bitsOf(b, cbfCtx, 1);
-        const int lastIdx = (bestPos >= 0 && start + bestRel < bestNone) ? bestPos + 1 : 0;
-        cbf = lastIdx ? orSince : 0;
+        const int lastIdx = lb.lastIndex(job.is_intra, info.sumSq, ws.walkedDist0, ws.costTu, ws.bestRel, ws.bestPos);
+        cbf = lastIdx ? ws.orSince : 0;
         const int lastGroup = (lastIdx - 1) >> 4;      // -1: nothing is coded
         for (int k = firstGroup; k > lastGroup; --k)   // groups above the last one were written as if coded: clear them
-        {
-            const int p = rasterOf[k];
-            if ((coded >> p) & 1)
-                for (int r = 0; r < 4; ++r) st8(dst + (((p / gw) << 2) + r) * size + ((p & (gw - 1)) << 2), u32x2{0, 0});
-        }
+            if ((ws.coded >> rasterOf[k]) & 1) lb.clearGroup(rasterOf[k]);
         // the group holding the last significant coefficient: levels again, truncated, hidden with the last-group rules
         if (lastGroup >= 0 && (lastIdx & 15 || job.sdh))
         {
             const int p = rasterOf[lastGroup], gx = p & (gw - 1), gy = p / gw;
-            loadGroup(gx, gy);
-            walkGroup<LOG2>(b, sh, lane, lastGroup, gx, gy, firstPos, caseOf(coded, gx, gy, (int)(carries >> lastGroup) & 1), job.sdh_factor, aux);
-            finishGroup(lastGroup, lastIdx, true, gx, gy);
+            lb.loadGroup(sh, lane, gx, gy);
+            walkGroup<LOG2>(b, sh, lane, lastGroup, gx, gy, firstPos, LB::caseOf(ws.coded, gx, gy, (int)(ws.carries >> lastGroup) & 1), job.sdh_factor, aux);
+            lb.finishGroup(sh, lane, job.sdh, aux, lastGroup, lastIdx, true, gx, gy);
         }
     }
     if (valid) cbfOut[blk] = cbf;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The diagonal walk (32x32 and 16x16 blocks with the up-right diagonal scan: all of them in the reference's encoder, which uses
+// the other scans for 4x4 / 8x8 intra blocks only).  A group needs of the rest of the block: whether the groups to its RIGHT and
+// BELOW are coded -- both on the next anti-diagonal of groups -- and the carry of the group before it in scan order, which with
+// this scan is its neighbour on the SAME anti-diagonal (or the end of the next one).  So the groups of an anti-diagonal can be
+// walked side by side once the next anti-diagonal is final, if the carry is known.  The carry a group leaves is "one of its
+// kept levels is > 1", and a kept level is the rounded level, that minus one, or (rounded levels 1 and 2 only) zero: a group
+// without a rounded level > 1 leaves 0, one with a rounded level > 2 leaves 1 -- the scan pass tells which -- and only a group
+// whose largest rounded level is exactly 2 is undecided.  The group after such a one is walked TWICE, on two lanes, once for each
+// carry, and the right lane is picked when the round is over; nothing is ever walked again.
+// A block with 14 groups to walk on the anti-diagonals 0 .. 4 takes 5 rounds instead of 14 steps; the sequential chain is what
+// bounds the launch (the machine is far from full).
+//
+// LPB lanes per block, 64 / LPB blocks per wavefront: in a round the lanes of a block take the next groups to walk of the current
+// anti-diagonal, one or two lanes each.  Every lane of a block keeps the block's running state (it is small, and identical in
+// all of them): after a round the lanes exchange their groups' results through LDS and each replays them in scan order.
+// ---------------------------------------------------------------------------------------------------------------------
+struct DiagExchange
+{
+    int64_t cost[64], sigCost[64], dist0[64], q[64], localBest[64];
+    int32_t localPos[64], localOr[64], groupOr[64];
+    int32_t flags[64];      // localStop | coded << 1 | carry out << 2 | carry in << 3
+};
+
+template <int LOG2, int LPB>
+__global__ __launch_bounds__(64) void k_rdoq_diag(int16_t *__restrict__ dstAll, const int16_t *__restrict__ srcAll, const uint8_t *__restrict__ statesAll,
+                                                  const RdoqJob *__restrict__ jobs, int njobs, int32_t *__restrict__ cbfOut, int bitDepth,
+                                                  const RdoqWork *__restrict__ work)
+{
+    typedef LaneBlock<LOG2> LB;
+    constexpr int G = LB::G, gw = LB::gw, ND = 2 * gw - 1;
+    __shared__ WalkShared sh;
+    __shared__ BlockTables<64 / LPB> bt;
+    __shared__ DiagExchange ex;
+    const RdoqInfo *infoAll = reinterpret_cast<const RdoqInfo *>(reinterpret_cast<const char *>(work) + rdoqInfoOffset());
+    const uint32_t *order = reinterpret_cast<const uint32_t *>(infoAll + njobs);
+    const int lane = threadIdx.x, k = lane & (LPB - 1), lane0 = lane & ~(LPB - 1), slot = blockIdx.x * (64 / LPB) + lane / LPB;
+    bool valid = slot < njobs;
+    const int blk = valid ? (int)order[slot] : 0;
+    const RdoqJob job = jobs[blk];
+    valid = valid && job.scan_idx == 0;
+    const RdoqInfo info = infoAll[blk];
+    LB lb;
+    lb.stageIn(sh, bt, lane, lane / LPB, k, LPB, job, statesAll, bitDepth, srcAll, dstAll);
+    const Block &b = lb.b;
+    const uint8_t *rasterOf = lb.rasterOf;
+    SdhAux aux;
+
+    // by SCAN index: groups to walk; groups that leave carry 1 for sure; groups whose carry is not known before they are walked
+    uint64_t walkScan = 0, sureScan = 0, openScan = 0;
+    if (valid)
+        for (int g = 0; g < G; ++g)
+        {
+            const int p = rasterOf[g];
+            walkScan |= ((info.mask >> p) & 1) << g;
+            sureScan |= ((info.mask3 >> p) & 1) << g;
+            openScan |= ((info.mask2 & ~info.mask3) >> p & 1) << g;
+        }
+    const int firstGroup = walkScan ? 63 - __clzll((long long)walkScan) : -1;
+    int firstPos = -1;
+    if (firstGroup >= 0)
+    {
+        const int p = rasterOf[firstGroup];
+        lb.loadGroup(sh, lane, p & (gw - 1), p / gw);
+        firstPos = firstGroup * 16 + lb.firstInGroup(sh, lane);
+        walkScan |= 1;      // the DC group is always walked in full
+    }
+
+    WalkState ws;
+    uint64_t carryOut = 0;      // carry each walked group left, by scan index
+    int gAcc = firstGroup;      // next group (scan index, going down) the running state has not seen yet
+    auto hopZeros = [&](int lowest) {
+        for (; gAcc >= lowest; --gAcc) ws.zeroGroup(lb.zeroGroupCost(ws.coded, rasterOf[gAcc]));
+    };
+
+    // The wavefront goes down the anti-diagonals together.  (Letting each block go down ITS anti-diagonals saves the rounds a block spends
+    // idle on an anti-diagonal only others use, and measured SLOWER, 0.24 against 0.21 ms: a round costs what its longest group costs,
+    // groups of one anti-diagonal are alike -- dense near DC, one or two levels far from it -- and mixing them makes every round a long one.)
+    for (int d = ND - 1; d >= 0; --d)
+    {
+        const int start = d < gw ? d * (d + 1) / 2 : G - (ND - d) * (ND - d + 1) / 2, len = d < gw ? d + 1 : ND - d;
+        if (__ballot(firstGroup >= start) == 0) continue;      // no block of the wavefront reaches this anti-diagonal
+        uint64_t m = walkScan & (((1ull << len) - 1) << start);      // groups of the anti-diagonal still to walk
+        while (__ballot(m != 0))      // rounds
+        {
+            // the round's picks, highest scan index first: group, first lane, lanes (2 = both carries)
+            int pickG[LPB], pickAt[LPB], pickN[LPB];
+#pragma unroll
+            for (int i = 0; i < LPB; ++i)
+            {
+                pickG[i] = -1;
+                pickAt[i] = pickN[i] = 0;
+            }
+            int used = 0, previous = -2;
+            int myG = -1, carryIn = 0;
+            bool full = false;
+#pragma unroll
+            for (int i = 0; i < LPB; ++i)
+            {
+                if (!m || full) continue;
+                const int g = 63 - __clzll((long long)m);
+                int need = 1, carry = 0;
+                if (g < firstGroup && ((walkScan >> (g + 1)) & 1))
+                {
+                    if (g + 1 != previous) carry = (int)(carryOut >> (g + 1)) & 1;          // walked in an earlier round
+                    else if ((openScan >> (g + 1)) & 1) need = 2;                           // walked in this round and undecided
+                    else carry = (int)(sureScan >> (g + 1)) & 1;
+                }
+                if (used + need > LPB)      // the rest waits for the next round
+                {
+                    full = true;
+                    continue;
+                }
+                pickG[i] = g;
+                pickAt[i] = used;
+                pickN[i] = need;
+                if (k >= used && k < used + need)
+                {
+                    myG = g;
+                    carryIn = need == 2 ? k - used : carry;
+                }
+                used += need;
+                previous = g;
+                m ^= 1ull << g;
+            }
+            const bool mine = myG >= 0;
+            const int p = mine ? rasterOf[myG] : 0, gx = p & (gw - 1), gy = p / gw;
+            WalkResult r;
+            r.coded = 0;
+            if (mine)
+            {
+                lb.loadGroup(sh, lane, gx, gy);
+                r = walkGroup<LOG2>(b, sh, lane, myG, gx, gy, firstPos, LB::caseOf(ws.coded, gx, gy, carryIn), job.sdh_factor, aux);
+                ex.flags[lane] = (int)r.localStop | r.coded << 1 | r.carry << 2 | carryIn << 3;
+                ex.cost[lane] = r.cost;
+                ex.sigCost[lane] = r.sigCost;
+                ex.dist0[lane] = r.dist0;
+                ex.q[lane] = r.q;
+                ex.localBest[lane] = r.localBest;
+                ex.localPos[lane] = r.localPos;
+                ex.localOr[lane] = r.localOr;
+                ex.groupOr[lane] = r.groupOr;
+            }
+            __syncthreads();
+            // every lane of the block replays the round in scan order, taking of a group walked twice the lane whose carry was right
+            int carry = 0;
+            bool chosen = false;
+#pragma unroll
+            for (int i = 0; i < LPB; ++i)
+            {
+                if (pickG[i] < 0) continue;
+                const int from = lane0 + pickAt[i] + (pickN[i] == 2 ? carry : 0), f = ex.flags[from];
+                chosen |= from == lane;
+                hopZeros(pickG[i] + 1);
+                WalkResult o;
+                o.cost = ex.cost[from];
+                o.sigCost = ex.sigCost[from];
+                o.dist0 = ex.dist0[from];
+                o.q = ex.q[from];
+                o.localBest = ex.localBest[from];
+                o.localPos = ex.localPos[from];
+                o.localOr = ex.localOr[from];
+                o.groupOr = ex.groupOr[from];
+                o.localStop = f & 1;
+                o.coded = (f >> 1) & 1;
+                o.carry = carry = (f >> 2) & 1;
+                ws.walkedGroup(o, pickG[i], rasterOf[pickG[i]], (f >> 3) & 1);
+                carryOut |= (uint64_t)o.carry << pickG[i];
+                gAcc = pickG[i] - 1;
+            }
+            if (chosen && r.coded) lb.finishGroup(sh, lane, job.sdh, aux, myG, 1 << 30, false, gx, gy);      // as a group below the last one
+    __syncthreads();      // the exchange arrays are free again
+        }
+        if (firstGroup >= start) hopZeros(start);
+    }
+
+    // ---- the block's verdict, by the block's first lane ----
+    if (valid && k == 0)
+    {
+        int cbf = 0;
+        if (firstPos >= 0)
+        {
+            const int lastIdx = lb.lastIndex(job.is_intra, info.sumSq, ws.walkedDist0, ws.costTu, ws.bestRel, ws.bestPos);
+            cbf = lastIdx ? ws.orSince : 0;
+            const int lastGroup = (lastIdx - 1) >> 4;
+            for (int g = firstGroup; g > lastGroup; --g)
+                if ((ws.coded >> rasterOf[g]) & 1) lb.clearGroup(rasterOf[g]);
+            if (lastGroup >= 0 && (lastIdx & 15 || job.sdh))
+            {
+                const int p = rasterOf[lastGroup], gx = p & (gw - 1), gy = p / gw;
+                lb.loadGroup(sh, lane, gx, gy);
+                walkGroup<LOG2>(b, sh, lane, lastGroup, gx, gy, firstPos, LB::caseOf(ws.coded, gx, gy, (int)(ws.carries >> lastGroup) & 1), job.sdh_factor, aux);
+                lb.finishGroup(sh, lane, job.sdh, aux, lastGroup, lastIdx, true, gx, gy);
+            }
+        }
+        cbfOut[blk] = cbf;
+    }
 }
 } // namespace
 
@@ -846,8 +1126,8 @@ hipError_t launch_rdoq(hipStream_t st, int bitDepth, int log2, int16_t *dst, con
     const int wgs = (njobs + 63) / 64;
     if (log2 <= 3)
     {
-        if (log2 == 2) hipLaunchKernelGGL((k_rdoq_walk<2, false>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work);
-        else hipLaunchKernelGGL((k_rdoq_walk<3, false>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work);
+        if (log2 == 2) hipLaunchKernelGGL((k_rdoq_walk<2, false>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work, 0);
+        else hipLaunchKernelGGL((k_rdoq_walk<3, false>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work, 0);
         return hipGetLastError();
     }
     hipError_t e = hipMemsetAsync(work, 0, sizeof(RdoqWork), st);
@@ -855,8 +1135,22 @@ hipError_t launch_rdoq(hipStream_t st, int bitDepth, int log2, int16_t *dst, con
     if (log2 == 4) hipLaunchKernelGGL(k_rdoq_scan<4>, dim3((njobs + 4 * kScanSteps - 1) / (4 * kScanSteps)), dim3(64), 0, st, dst, src, j, njobs, work);
     else hipLaunchKernelGGL(k_rdoq_scan<5>, dim3((njobs + kScanSteps - 1) / kScanSteps), dim3(64), 0, st, dst, src, j, njobs, work);
     hipLaunchKernelGGL(k_rdoq_order, dim3((njobs + 255) / 256), dim3(256), 0, st, njobs, work);
-    if (log2 == 4) hipLaunchKernelGGL((k_rdoq_walk<4, true>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work);
-    else hipLaunchKernelGGL((k_rdoq_walk<5, true>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work);
+    // diagnostic A/B switch (profiles/): HAVOC_RDOQ_DIAG=0 walks every block with the sequential kernel
+    // 32x32 blocks take the diagonal walk while its wavefronts (16 blocks each) still find a SIMD of their own: it shortens the chain, not the
+    // work -- most of its lanes idle -- so a 4K picture's 41 k blocks are better off 64 to a wavefront in the sequential walk (measured: 4K
+    // step 2.43 -> 2.63 ms with the diagonal walk forced).  16x16 blocks (39 k of them in a 1080p picture, 3 groups to walk on average, 7 at
+    // most) have no chain worth shortening.  Diagnostic A/B switch (profiles/): HAVOC_RDOQ_DIAG = lanes per block, 0 (off), 4 or 8
+    static const int diagEnv = getenv("HAVOC_RDOQ_DIAG") ? atoi(getenv("HAVOC_RDOQ_DIAG")) : 4;
+    const int diag = log2 != 5 || diagEnv == 0 || njobs > 16 * 1024 ? 0 : (diagEnv == 8 ? 8 : 4);
+    if (diag)
+    {
+        const int wgd = (njobs + 64 / diag - 1) / (64 / diag);
+        if (diag == 4) hipLaunchKernelGGL((k_rdoq_diag<5, 4>), dim3(wgd), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work);
+        else hipLaunchKernelGGL((k_rdoq_diag<5, 8>), dim3(wgd), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work);
+    }
+    // blocks with a horizontal / vertical scan (none in the reference's encoder at these sizes): the sequential walk; exits at once when there are none
+    if (log2 == 4) hipLaunchKernelGGL((k_rdoq_walk<4, true>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work, diag);
+    else hipLaunchKernelGGL((k_rdoq_walk<5, true>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work, diag);
     return hipGetLastError();
 }
 
