@@ -1,6 +1,7 @@
 #!/bin/bash
 # GPU call U: workgroup shape of k_intra_satd35 for 16x16 / 32x32 partitions (HAVOC_INTRA35_VARIANT: 0 = 9 / 2 partitions x 256 threads,
-# 1 = 4 / 1 x 128, 2 = 18 / 4 x 512): parity, then the isolated launch time.
+# 1 = 4 / 1 x 128, 2 = 18 / 4 x 512): parity, then the isolated launch time.  (The switch was removed from kernels_fused.hip after this
+# measurement -- no shape was faster; the commit before "experiments: k_intra_satd35 workgroup shapes measured" has it.)
 tag=${1:-r02u}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out

@@ -13,6 +13,10 @@
 //             against the reference's phase planes (havoc_mi355x_satd_multi);  then the stopped searches are replayed
 //             from the start (they are deterministic and cheap), until none stops.
 //
+// A stopped search leaves its loop with longjmp, not with a C++ exception: a throw costs ~20 us and takes a process-wide lock in the
+// unwinder, which made 16 replay threads no faster than one (the loops of decision.hpp hold no state and nothing with a destructor,
+// asserted below, so there is nothing to unwind).
+//
 // havoc_search_motion_bi runs searchMotionBi the same way on "ideal second predictors" it builds on the device first.
 //
 // Results are the reference's by construction: the same loop code as the per-call clients, fed values the GPU kernels
@@ -25,11 +29,14 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <csetjmp>
 #include <cstring>
 #include <functional>
 #include <map>
 #include <mutex>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 using namespace havoc_search;
@@ -72,11 +79,18 @@ struct SearchState
     MotionSearch<struct BatchView>::IntegerStage integer;   // uni search: kept once the integer stage has run to its end
 };
 
-// the View of decision.hpp over precomputed data
+// the View of decision.hpp over precomputed data.  A question it cannot answer ends the replay: the miss is noted in the search's state
+// and control returns to the setjmp in the replay worker.
 struct BatchView
 {
     SearchState &st;
-    explicit BatchView(SearchState &s) : st(s) {}
+    std::jmp_buf *stop;
+    BatchView(SearchState &s, std::jmp_buf *j) : st(s), stop(j) {}
+    [[noreturn]] void miss(int kind, int x, int y)
+    {
+        st.miss = Miss{kind, x, y};
+        std::longjmp(*stop, 1);
+    }
     bool lookup(int dx, int dy, int32_t *v) const
     {
         for (const SurfaceRef &f : st.surfaces)
@@ -90,20 +104,84 @@ struct BatchView
     int sad(int dx, int dy)
     {
         int32_t v;
-        if (!lookup(dx, dy, &v)) throw Miss{1, dx, dy};
+        if (!lookup(dx, dy, &v)) miss(1, dx, dy);
         return v;
     }
     void sad4(const Mv d[4], int32_t out[4])
     {
         for (int i = 0; i < 4; ++i)
-            if (!lookup(d[i].x, d[i].y, &out[i])) throw Miss{1, d[i].x, d[i].y};
+            if (!lookup(d[i].x, d[i].y, &out[i])) miss(1, d[i].x, d[i].y);
     }
     int satdQpel(Mv mv)
     {
-        if (!st.haveSub || std::abs(mv.x - st.subCx) > kSub || std::abs(mv.y - st.subCy) > kSub) throw Miss{2, mv.x, mv.y};
+        if (!st.haveSub || std::abs(mv.x - st.subCx) > kSub || std::abs(mv.y - st.subCy) > kSub) miss(2, mv.x, mv.y);
         const int32_t v = st.sub[(mv.y - st.subCy + kSub) * kSubSide + (mv.x - st.subCx + kSub)];
-        if (v < 0) throw Miss{3, mv.x, mv.y};   // the position's window leaves the phase planes: cannot be served
+        if (v < 0) miss(3, mv.x, mv.y);   // the position's window leaves the phase planes: cannot be served
         return v;
+    }
+};
+// what longjmp passes over on its way out of a replay
+static_assert(std::is_trivially_destructible<MotionSearch<BatchView>>::value && std::is_trivially_destructible<PuContext>::value &&
+                  std::is_trivially_destructible<UniResult>::value && std::is_trivially_destructible<BatchView>::value,
+              "a stopped replay leaves by longjmp: nothing on its stack may need a destructor");
+
+// Replay threads of one runSearches call: started once, handed a round's work through run() (each round is a few thousand replays of a few
+// microseconds: starting 15 threads per round cost as much as the round)
+class ReplayThreads
+{
+    std::vector<std::thread> threads_;
+    std::mutex m_;
+    std::condition_variable wake_, done_;
+    std::function<void()> work_;
+    int generation_ = 0, busy_ = 0;
+    bool quit_ = false;
+    void loop()
+    {
+        int seen = 0;
+        for (;;)
+        {
+            std::function<void()> w;
+            {
+                std::unique_lock<std::mutex> l(m_);
+                wake_.wait(l, [&] { return quit_ || generation_ != seen; });
+                if (quit_) return;
+                seen = generation_;
+                w = work_;
+            }
+            w();
+            {
+                std::lock_guard<std::mutex> l(m_);
+                if (--busy_ == 0) done_.notify_one();
+            }
+        }
+    }
+public:
+    explicit ReplayThreads(int extra)
+    {
+        for (int t = 0; t < extra; ++t) threads_.emplace_back([this] { loop(); });
+    }
+    ~ReplayThreads()
+    {
+        {
+            std::lock_guard<std::mutex> l(m_);
+            quit_ = true;
+        }
+        wake_.notify_all();
+        for (auto &t : threads_) t.join();
+    }
+    // every pool thread and the caller run `w` once; returns when all have
+    void run(const std::function<void()> &w)
+    {
+        {
+            std::lock_guard<std::mutex> l(m_);
+            work_ = w;
+            busy_ = int(threads_.size());
+            ++generation_;
+        }
+        wake_.notify_all();
+        w();
+        std::unique_lock<std::mutex> l(m_);
+        done_.wait(l, [&] { return busy_ == 0; });
     }
 };
 
@@ -271,6 +349,7 @@ int runSearches(havoc_mi355x_ctx *ctx, int S, const havoc_search_params *params,
 
     std::vector<int> pending(n);
     for (int i = 0; i < n; ++i) pending[i] = i;
+    ReplayThreads replayers(n >= 64 ? threads - 1 : 0);
 
     while (!pending.empty())
     {
@@ -384,33 +463,28 @@ int runSearches(havoc_mi355x_ctx *ctx, int S, const havoc_search_params *params,
         const double tHost = now();
         std::atomic<int> next{0};
         auto worker = [&]() {
+            std::jmp_buf stop;
             for (;;)
             {
                 const int k = next.fetch_add(1);
                 if (k >= int(pending.size())) return;
                 const int i = pending[k];
                 SearchState &st = state[i];
-                BatchView view(st);
-                try
+                if (setjmp(stop) == 0)
                 {
+                    BatchView view(st, &stop);
                     havoc_search_result &o = out[i];
                     std::memset(&o, 0, sizeof(o));
                     fl.replay(i, view, o);
                     o.replays = st.replays;
                     st.done = true;
                 }
-                catch (const Miss &m)
-                {
-                    st.miss = m;
+                else      // the view noted what is missing in st.miss
                     ++st.replays;
-                }
             }
         };
-        const int nt = std::min<int>(threads, int(pending.size()));
-        std::vector<std::thread> pool;
-        for (int t = 1; t < nt; ++t) pool.emplace_back(worker);
-        worker();
-        for (auto &th : pool) th.join();
+        if (pending.size() < 64 || threads == 1) worker();
+        else replayers.run(worker);
         stt.seconds_host += now() - tHost;
 
         std::vector<int> still;
