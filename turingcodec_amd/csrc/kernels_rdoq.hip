@@ -889,7 +889,9 @@ __global__ __launch_bounds__(64) void k_rdoq_walk(int16_t *__restrict__ dstAll, 
             const WalkResult r = walkGroup<LOG2>(b, sh, lane, g, gx, gy, firstPos, LB::caseOf(ws.coded, gx, gy, carry), job.sdh_factor, aux);
             ws.walkedGroup(r, g, p, carry);
             carry = r.carry;
-            if (r.coded) lb.finishGroup(sh, lane, job.sdh, aux, g, 1 << 30, false, gx, gy);      // as a group below the last one; the last one is redone below
+            // as a group below the last one (the last one is redone below) -- but for the DC group, the last to be walked: its records are
+            // still there when the verdict is known, so it is finished then, once, as what it turns out to be
+            if (r.coded && g != 0) lb.finishGroup(sh, lane, job.sdh, aux, g, 1 << 30, false, gx, gy);
             --g;
         }
     }
@@ -901,10 +903,11 @@ __global__ __launch_bounds__(64) void k_rdoq_walk(int16_t *__restrict__ dstAll, 
         const int lastIdx = lb.lastIndex(job.is_intra, info.sumSq, ws.walkedDist0, ws.costTu, ws.bestRel, ws.bestPos);
         cbf = lastIdx ? ws.orSince : 0;
         const int lastGroup = (lastIdx - 1) >> 4;      // -1: nothing is coded
-        for (int k = firstGroup; k > lastGroup; --k)   // groups above the last one were written as if coded: clear them
+        for (int k = firstGroup; k > max(lastGroup, 0); --k)   // groups above the last one were written as if coded: clear them
             if ((ws.coded >> rasterOf[k]) & 1) lb.clearGroup(rasterOf[k]);
+        if (lastGroup >= 0) lb.finishGroup(sh, lane, job.sdh, aux, 0, lastGroup == 0 ? lastIdx : 1 << 30, lastGroup == 0, 0, 0);      // the DC group, from the records of its walk
         // the group holding the last significant coefficient: levels again, truncated, hidden with the last-group rules
-        if (lastGroup >= 0 && (lastIdx & 15 || job.sdh))
+        if (lastGroup > 0 && (lastIdx & 15 || job.sdh))
         {
             const int p = rasterOf[lastGroup], gx = p & (gw - 1), gy = p / gw;
             lb.loadGroup(sh, lane, gx, gy);
@@ -1085,7 +1088,7 @@ __global__ __launch_bounds__(64) void k_rdoq_diag(int16_t *__restrict__ dstAll, 
                 carryOut |= (uint64_t)o.carry << pickG[i];
                 gAcc = pickG[i] - 1;
             }
-            if (chosen && r.coded) lb.finishGroup(sh, lane, job.sdh, aux, myG, 1 << 30, false, gx, gy);      // as a group below the last one
+            if (chosen && r.coded && myG != 0) lb.finishGroup(sh, lane, job.sdh, aux, myG, 1 << 30, false, gx, gy);      // as a group below the last one; the DC group waits for the verdict
     __syncthreads();      // the exchange arrays are free again
         }
         if (firstGroup >= start) hopZeros(start);
@@ -1100,9 +1103,10 @@ __global__ __launch_bounds__(64) void k_rdoq_diag(int16_t *__restrict__ dstAll, 
             const int lastIdx = lb.lastIndex(job.is_intra, info.sumSq, ws.walkedDist0, ws.costTu, ws.bestRel, ws.bestPos);
             cbf = lastIdx ? ws.orSince : 0;
             const int lastGroup = (lastIdx - 1) >> 4;
-            for (int g = firstGroup; g > lastGroup; --g)
+            for (int g = firstGroup; g > max(lastGroup, 0); --g)
                 if ((ws.coded >> rasterOf[g]) & 1) lb.clearGroup(rasterOf[g]);
-            if (lastGroup >= 0 && (lastIdx & 15 || job.sdh))
+            if (lastGroup >= 0) lb.finishGroup(sh, lane, job.sdh, aux, 0, lastGroup == 0 ? lastIdx : 1 << 30, lastGroup == 0, 0, 0);      // the DC group: this lane walked it last
+            if (lastGroup > 0 && (lastIdx & 15 || job.sdh))
             {
                 const int p = rasterOf[lastGroup], gx = p & (gw - 1), gy = p / gw;
                 lb.loadGroup(sh, lane, gx, gy);
