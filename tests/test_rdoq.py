@@ -166,3 +166,33 @@ def test_device_edge_cases(hv, oracle):
         o, d = b["src_off"], int(jobs["dst_off"][i])
         assert np.array_equal(got[d:d + 256], want[o:o + 256])
     assert np.array_equal(cbf, want_cbf)
+
+
+_WALK_FORMS_SCRIPT = r"""
+import sys
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import rdoq_tools as rt, reflibs
+from turingcodec_amd import havoc
+hv = havoc.Havoc()
+oracle = reflibs.Oracle()
+for seed, count in ((77, 37), (78, 130)):
+    src, states, blocks = rt.make_blocks(seed, 5, 8, count, n_states=5)
+    want, want_cbf = rt.run_cpu(oracle, src, states, blocks)
+    got, got_cbf = hv.rdoq(8, 5, src, states, rt.device_jobs(blocks, havoc.rdoq_lambda))
+    assert np.array_equal(got, want) and np.array_equal(got_cbf, want_cbf), (seed, int((got != want).sum()))
+print("ok")
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["0", "4", "8"])
+def test_every_walk_form_of_32x32_blocks_matches_the_oracle(form):
+    """HAVOC_RDOQ_DIAG picks how 32x32 blocks are walked -- 0: sequential kernel only, 4 / 8: the diagonal walk with that many lanes per
+    block (4 is the default) -- and is read once per process, so each form runs in its own interpreter; diagonal-scan blocks and
+    the few horizontal / vertical ones of make_blocks (which go to the sequential kernel whatever the form) in one launch"""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, "-c", _WALK_FORMS_SCRIPT, ROOT], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, HAVOC_RDOQ_DIAG=form))
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-1500:]

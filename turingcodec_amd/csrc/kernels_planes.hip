@@ -9,174 +9,22 @@
 // plane, writes fifteen: the kernel is bound by HBM write bandwidth, which is the point.
 //
 // 64 x 16 output tile per 256-thread workgroup; wavefront k owns horizontal phase xFrac = k:
-//   1. horizontal pass of the 23 needed rows straight from HBM/L2 (hfilter4: dot4 / dot2), transposed into LDS;
-//   2. lane = column: three ds_read_b128 fetch the column's 23 intermediates, then for each vertical phase the 16
-//      outputs are four v_dot2_i32_i16 each, clipped and stored (a wavefront writes 64 contiguous samples per row).
+//   1. horizontal pass of the 23 needed rows straight from HBM/L2 (hfilter4: dot4 / dot2), column-major into LDS;
+//   2. vertical pass, every vertical phase from the same intermediates (below).
 // All phases use the two-pass formula with the {..,64,..} filter for a zero phase, which is bit-identical to the
 // reference's one-pass H-only / V-only forms for bit depths 8..10 (havoc/pred_inter.cpp:930-937 does the same).
 #include "common.h"
 #include "interp.h"
 
-#include <cstdlib>
-
 namespace havoc_gpu {
 
 constexpr int kPlaneTileW = 64;   // output tile width in samples; tiles sit on a 64-sample grid of the plane (64 / 128-byte aligned rows)
 
-// MODE: how the 16 x 64 results of one (xFrac, yFrac) plane tile leave the wavefront.  Lane = column, so a lane holds a
-// COLUMN of 16 results and a row of the tile is spread over 64 lanes:
-//   0  one sample per lane per store (16 stores of 64 / 128 bytes per wavefront): the round-1 form, kept for A/B runs;
-//   1  4x4 byte (2x2 word) transposes inside lane quads (DPP quad_perm + v_perm) so that each lane holds 4 adjacent
-//      bytes of ONE row: 4 (8) dword stores per plane tile;
-//   2  the same transposes, then the tile goes through a wavefront-private LDS buffer and leaves as 16-byte stores:
-//      one (two) global_store_dwordx4 per lane per plane tile, each row of the tile written as whole 64 / 128-byte runs.
-template <int S, int MODE>
-__global__ __launch_bounds__(256) void k_interp_planes(char *__restrict__ planes, long plane_elems, const char *__restrict__ ref, long stride,
-                                                       int x0, int y0, int x1, int y1, int bitDepth)
-{
-    typedef typename Sample<S>::T T;
-    constexpr int TW = kPlaneTileW, THT = 16, COL = 24;   // column of intermediates: THT + 7 = 23 -> 24 (16-byte multiple)
-    __shared__ __attribute__((aligned(16))) int16_t s_t[4][TW * COL];
-    __shared__ __attribute__((aligned(16))) uint32_t s_o[MODE == 2 ? 4 : 1][MODE == 2 ? THT * TW * S / 4 : 1];
-
-    const int xf = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tx = (x0 & ~(TW - 1)) + blockIdx.x * TW, ty = y0 + blockIdx.y * THT;
-    const long rsb = stride * S;
-    const int maxv = (1 << bitDepth) - 1;
-    const int shift1 = min(4, bitDepth - 8);
-    const int shift = 6 + max(2, 14 - bitDepth);
-
-    {
-        int cx[8];
-        taps_of<8>(xf, cx);
-        for (int i = lane; i < 23 * (TW / 4); i += kWave)
-        {
-            const int r = i / (TW / 4), q = i % (TW / 4);
-            if (tx + 4 * q >= x1 || tx + 4 * q + 3 < x0 || ty - 3 + r >= y1 + 4) continue;   // nothing in the region needs this quad
-            int a[4];
-            hfilter4<S, 8>(ref + (long)(ty - 3 + r) * rsb + (long)(tx + 4 * q - 3) * S, cx, a);
-#pragma unroll
-            for (int o = 0; o < 4; ++o) s_t[xf][(4 * q + o) * COL + r] = (int16_t)(a[o] >> shift1);
-        }
-    }
-    __syncthreads();
-
-    const int x = tx + lane;
-    const bool live = x >= x0 && x < x1;
-    if (MODE == 0 && !live) return;
-    uint32_t e[12], od[11];   // (t[2k], t[2k+1]) and (t[2k+1], t[2k+2]) of the lane's column
-    {
-        const int16_t *col = &s_t[xf][lane * COL];
-        const u32x4 q0 = *reinterpret_cast<const u32x4 *>(col), q1 = *reinterpret_cast<const u32x4 *>(col + 8),
-                    q2 = *reinterpret_cast<const u32x4 *>(col + 16);
-        e[0] = q0.x; e[1] = q0.y; e[2] = q0.z; e[3] = q0.w; e[4] = q1.x; e[5] = q1.y;
-        e[6] = q1.z; e[7] = q1.w; e[8] = q2.x; e[9] = q2.y; e[10] = q2.z; e[11] = q2.w;
-#pragma unroll
-        for (int k = 0; k < 11; ++k) od[k] = __builtin_amdgcn_alignbit(e[k + 1], e[k], 16);
-    }
-    const int rnd = 1 << (shift - 1);
-    // lanes of a quad (S == 1) / pair (S == 2) after the transposes: lane i holds row (R*g + i) of row group g, R adjacent samples
-    constexpr int R = S == 1 ? 4 : 2;             // rows per packed dword before / samples per dword after the transpose
-    const int ri = lane & (R - 1), xq = x - ri;   // first sample of the lane's dword
-    const bool whole = xq >= x0 && xq + R <= x1;  // the dword lies inside the rectangle: one 4-byte store
-#pragma unroll 1
-    for (int yf = 0; yf < 4; ++yf)
-    {
-        if ((xf | yf) == 0) continue;   // plane 0 is the reference picture itself
-        int cy[8];
-        taps_of<8>(yf, cy);
-        uint32_t cp[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) cp[k] = pack_i16(cy[2 * k], cy[2 * k + 1]);
-        T *base = reinterpret_cast<T *>(planes) + (long)(4 * yf + xf) * plane_elems + (long)ty * stride;
-        int v[THT];
-#pragma unroll
-        for (int j = 0; j < THT; ++j)
-        {
-            int a = rnd;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) a = sdot2((j & 1) ? od[(j >> 1) + k] : e[(j >> 1) + k], cp[k], a);
-            v[j] = clip3(0, maxv, a >> shift);
-        }
-        if (MODE == 0)
-        {
-#pragma unroll
-            for (int j = 0; j < THT; ++j)
-                if (ty + j < y1) base[(long)j * stride + x] = (T)v[j];
-            continue;
-        }
-        // ---- column -> row: d[g] = the lane's dword of row R*g + ri (samples xq .. xq + R - 1)
-        uint32_t d[THT / R];
-        if (S == 1)
-        {
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-            {
-                const uint32_t c = (uint32_t)v[4 * g] | ((uint32_t)v[4 * g + 1] << 8) | ((uint32_t)v[4 * g + 2] << 16) | ((uint32_t)v[4 * g + 3] << 24);
-                const uint32_t t = (uint32_t)dpp_mov<kDppXor1>((int)c);                 // the column of lane ^ 1
-                const uint32_t h = (lane & 1) ? __builtin_amdgcn_perm(t, c, 0x03070105u)  // rows 1, 3 of columns (x-1, x)
-                                              : __builtin_amdgcn_perm(t, c, 0x06020400u); // rows 0, 2 of columns (x, x+1)
-                const uint32_t u = (uint32_t)dpp_mov<0x4E>((int)h);                      // quad_perm [2,3,0,1]: lane ^ 2
-                d[g] = (lane & 2) ? __builtin_amdgcn_perm(u, h, 0x03020706u) : __builtin_amdgcn_perm(u, h, 0x05040100u);
-            }
-        }
-        else
-        {
-#pragma unroll
-            for (int g = 0; g < 8; ++g)
-            {
-                const uint32_t c = (uint32_t)v[2 * g] | ((uint32_t)v[2 * g + 1] << 16);
-                const uint32_t t = (uint32_t)dpp_mov<kDppXor1>((int)c);
-                d[g] = (lane & 1) ? __builtin_amdgcn_perm(t, c, 0x03020706u) : __builtin_amdgcn_perm(t, c, 0x05040100u);
-            }
-        }
-        if (MODE == 1)
-        {
-#pragma unroll
-            for (int g = 0; g < THT / R; ++g)
-            {
-                const int row = R * g + ri;
-                if (ty + row >= y1) continue;
-                T *o = base + (long)row * stride + xq;
-                if (whole) st4(o, d[g]);
-                else
-#pragma unroll
-                    for (int k = 0; k < R; ++k)
-                        if (xq + k >= x0 && xq + k < x1) o[k] = (T)(d[g] >> (8 * S * k));
-            }
-            continue;
-        }
-        // ---- MODE 2: row-major tile in the wavefront's LDS buffer, then 16-byte pieces of rows
-        constexpr int RB = TW * S;   // bytes per tile row
-        char *so = reinterpret_cast<char *>(s_o[MODE == 2 ? xf : 0]);
-#pragma unroll
-        for (int g = 0; g < THT / R; ++g) *reinterpret_cast<uint32_t *>(so + (R * g + ri) * RB + (lane - ri) * S) = d[g];
-#pragma unroll
-        for (int k = 0; k < S; ++k)
-        {
-            const int c = lane + 64 * k;                       // 16-byte piece of the tile
-            const int row = c / (RB / 16), xb = (c % (RB / 16)) * 16;
-            const u32x4 piece = *reinterpret_cast<const u32x4 *>(so + row * RB + xb);
-            const int xs = tx + xb / S;                        // first sample of the piece
-            if (ty + row >= y1) continue;
-            T *o = base + (long)row * stride + xs;
-            if (xs >= x0 && xs + 16 / S <= x1) *reinterpret_cast<u32x4 *>(o) = piece;   // planes, stride and the tile grid are 16-byte aligned
-            else
-            {
-                const uint32_t w[4] = {piece.x, piece.y, piece.z, piece.w};
-#pragma unroll
-                for (int b = 0; b < 16 / S; ++b)
-                    if (xs + b >= x0 && xs + b < x1) o[b] = (T)(w[(b * S) >> 2] >> (8 * ((b * S) & 3)));
-            }
-        }
-    }
-}
-
-// ---- MODE 3 (default): lane = 4 adjacent columns x 4 rows of the tile ------------------------------------------------------
-// The forms above give a lane one COLUMN of 16 results, so a row of the tile is spread over 64 lanes and must be transposed
-// (DPP + v_perm, then LDS) before it can leave in stores wider than a sample: ~11 VALU instructions per output sample, 4 of them
-// the filter.  Here a lane owns columns 4q .. 4q+3 (q = lane & 15) of rows 4g .. 4g+3 (g = lane >> 4): its four results of a
-// row ARE one dword (8-bit) / one 8-byte piece (16-bit) of that row, 16 lanes write 64 contiguous samples, and nothing is
+// ---- the vertical pass: lane = 4 adjacent columns x 4 rows of the tile --------------------------------------------------------
+// (Round 1 gave a lane one COLUMN of 16 results: a row of the tile was then spread over 64 lanes and had to be transposed -- DPP +
+// v_perm, then LDS -- before it could leave in stores wider than a sample: ~11 VALU instructions per output sample, 4 of them the
+// filter, 24 us per 1080p reference against 15 now; profiles/r02_experiments.md.)  A lane owns columns 4q .. 4q+3 (q = lane & 15)
+// of rows 4g .. 4g+3 (g = lane >> 4): its four results of a row ARE one dword (8-bit) / one 8-byte piece (16-bit) of that row, 16 lanes write 64 contiguous samples, and nothing is
 // transposed.  The rest of the per-sample work is folded away:
 //   * rounding: every phase's taps sum to 64, so adding rnd / 64 = 1 << (shift - 7) to each horizontal intermediate adds
 //     exactly rnd to the vertical sum (gfx950 only has the accumulating v_dot2c form, so each output still pays one v_mov 0);
@@ -325,42 +173,14 @@ __global__ __launch_bounds__(256) void k_interp_planes_q(char *__restrict__ plan
     planes_vphase<S, 3>(e, sl, maxv, rowp + 3 * pb, rsb, rowsLeft, xq, x0, x1);
 }
 
-static int planes_store_mode()
-{
-    // diagnostic A/B switch (profiles/): HAVOC_PLANES_STORE=0|1|2|3; default = 3, the 4 x 4 samples per lane form
-    static const int mode = [] {
-        const char *e = getenv("HAVOC_PLANES_STORE");
-        return e && e[0] >= '0' && e[0] <= '3' ? e[0] - '0' : 3;
-    }();
-    return mode;
-}
-
 hipError_t launch_interp_planes(hipStream_t st, int S, int bitDepth, void *planes, long plane_elems, const void *ref, long stride, int x0, int y0,
                                 int width, int height)
 {
     if (width <= 0 || height <= 0) return hipSuccess;
     const int xa = x0 & ~(kPlaneTileW - 1);
     const dim3 g((x0 + width - xa + kPlaneTileW - 1) / kPlaneTileW, (height + 15) / 16), b(256);
-    // 16-byte stores need 16-byte aligned rows: plane base, plane pitch and row stride
-    const bool aligned = ((uintptr_t)planes & 15) == 0 && ((plane_elems * S) & 15) == 0 && ((stride * S) & 15) == 0;
-    const int mode = planes_store_mode() == 2 && !aligned ? 1 : planes_store_mode();
-    if (mode == 3)
-    {
-        if (S == 1) hipLaunchKernelGGL((k_interp_planes_q<1>), g, b, 0, st, (char *)planes, plane_elems, (const char *)ref, stride, x0, y0, x0 + width, y0 + height, bitDepth);
-        else hipLaunchKernelGGL((k_interp_planes_q<2>), g, b, 0, st, (char *)planes, plane_elems, (const char *)ref, stride, x0, y0, x0 + width, y0 + height, bitDepth);
-        return hipGetLastError();
-    }
-#define LAUNCH_PLANES(SS, MM) \
-    hipLaunchKernelGGL((k_interp_planes<SS, MM>), g, b, 0, st, (char *)planes, plane_elems, (const char *)ref, stride, x0, y0, x0 + width, y0 + height, bitDepth)
-    if (S == 1)
-    {
-        if (mode == 0) LAUNCH_PLANES(1, 0); else if (mode == 1) LAUNCH_PLANES(1, 1); else LAUNCH_PLANES(1, 2);
-    }
-    else
-    {
-        if (mode == 0) LAUNCH_PLANES(2, 0); else if (mode == 1) LAUNCH_PLANES(2, 1); else LAUNCH_PLANES(2, 2);
-    }
-#undef LAUNCH_PLANES
+    if (S == 1) hipLaunchKernelGGL((k_interp_planes_q<1>), g, b, 0, st, (char *)planes, plane_elems, (const char *)ref, stride, x0, y0, x0 + width, y0 + height, bitDepth);
+    else hipLaunchKernelGGL((k_interp_planes_q<2>), g, b, 0, st, (char *)planes, plane_elems, (const char *)ref, stride, x0, y0, x0 + width, y0 + height, bitDepth);
     return hipGetLastError();
 }
 
