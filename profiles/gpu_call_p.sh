@@ -1,6 +1,7 @@
 #!/bin/bash
 # GPU call P: k_interp_planes store/lane-mapping A/B (HAVOC_PLANES_STORE = 2: column per lane + LDS-staged rows, 3: 4 x 4 samples per
 # lane), after the whole GPU suite and smoke have passed on the new default.
+# (HAVOC_PLANES_STORE was removed from kernels_planes.hip after this measurement, together with the column-per-lane forms it selected.)
 tag=${1:-r02p}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out

@@ -1,6 +1,7 @@
 #!/bin/bash
 # GPU call Q: k_interp_planes_q with K vertically adjacent tiles per workgroup (HAVOC_PLANES_STRIP = K): parity of the plane
 # tests for each K, then the isolated launch time at 1080p.
+# (HAVOC_PLANES_STRIP existed only in the experiment this script measured -- slower, not kept; profiles/r02_experiments.md.)
 tag=${1:-r02q}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out

@@ -1,6 +1,7 @@
 #!/bin/bash
 # GPU call S: blocks per wavefront of the sorted RDOQ walk (HAVOC_RDOQ_PER_WAVE): a wavefront runs as long as its densest block, and
 # 162 full wavefronts leave most of the 1024 SIMDs idle -- narrower wavefronts cost nothing and shorten the longest chain.
+# (HAVOC_RDOQ_PER_WAVE existed only in the experiment this script measured -- no gain, not kept; profiles/r02_experiments.md.)
 tag=${1:-r02s}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
