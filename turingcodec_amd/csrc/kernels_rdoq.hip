@@ -61,7 +61,14 @@ struct Block
 struct LevelState { int ctxSet, c1, nG1, nG2, rice; };   // Rdoq.cpp:44-49
 
 __device__ __forceinline__ int32_t bitsOf(const Block &b, int ctx, int bin) { return b.bits[(b.states[ctx * b.stateStride] >> 1) ^ bin]; }
-__device__ __forceinline__ int baseLevel(const LevelState &s) { return s.nG1 < 8 ? 2 + (s.nG2 < 1) : 1; }
+// c ? a : b with both arms already evaluated: the compiler then emits a select.  Written as a nested conditional expression with
+// arithmetic in its arms, the same thing becomes a branch per arm -- and a wavefront of 64 blocks takes both sides of every branch,
+// plus the exec-mask bookkeeping: the per-level loop of walkGroup lost a quarter of its instructions when its conditionals were
+// rewritten this way (profiles/r02_experiments.md)
+template <class T>
+__device__ __forceinline__ T pick(bool c, T a, T b) { return c ? a : b; }
+
+__device__ __forceinline__ int baseLevel(const LevelState &s) { return pick(s.nG1 < 8, 2 + (int)(s.nG2 < 1), 1); }
 __device__ __forceinline__ int clip16(int v) { return min(max(v, -32768), 32767); }
 
 // ScanOrder.h:31-53: position `pos` of the up-right diagonal scan of a size x size block
@@ -96,11 +103,24 @@ __host__ __device__ constexpr uint64_t scan4Nibbles(int scanIdx)
 }
 
 // Rdoq.cpp:710: number of ones in the prefix of a last-significant coordinate: 0 1 2 3 4 4 5 5 6 6 6 6 7 7 7 7 8 x 8, 9 x 8
-__device__ __forceinline__ int lastPrefixLength(int c) { return c < 4 ? c : (c < 8 ? 4 + ((c - 4) >> 1) : (c < 16 ? 6 + ((c - 8) >> 2) : 8 + ((c - 16) >> 3))); }
+__device__ __forceinline__ int lastPrefixLength(int c) { return pick(c < 4, c, pick(c < 8, 4 + ((c - 4) >> 1), pick(c < 16, 6 + ((c - 8) >> 2), 8 + ((c - 16) >> 3)))); }
 
 // the four context-coded bin costs a level's binarisation can touch: coeff_abs_level_greater1_flag = 0 / 1 in its current
 // context and coeff_abs_level_greater2_flag = 0 / 1; looked up when the contexts change, not per candidate level
 struct FlagBits { int32_t g1zero, g1one, g2zero, g2one; };
+
+// the context-coded part of a level >= base (greater1 = 1, then greater2 = 1 while those flags are still coded) ...
+__device__ __forceinline__ int32_t flagsOfCoded(const LevelState &s, const FlagBits &f)
+{
+    const int32_t both = f.g1one + pick(s.nG2 < 1, f.g2one, 0);
+    return pick(s.nG1 < 8, both, 0);
+}
+// ... and of a level below it: 1 is greater1 = 0; 2 is greater1 = 1, greater2 = 0
+__device__ __forceinline__ int32_t flagsOfSmall(int level, const FlagBits &f)
+{
+    const int32_t two = f.g1one + f.g2zero;
+    return pick(level == 1, f.g1zero, 0) + pick(level == 2, two, 0);
+}
 
 // Rdoq.cpp:611-668 getLevelRateCost (without the lambda), branch free.  The escape loop `while (symbol >= (1 << length))
 // symbol -= 1 << length++` ends with length = floor(log2(symbol + (1 << rice))).
@@ -108,10 +128,9 @@ __device__ __forceinline__ int32_t levelBits(int level, const LevelState &s, con
 {
     const int base = baseLevel(s), symbol = level - base, rest = symbol - (3 << s.rice);
     const int length = 31 - __clz(max(rest, 0) + (1 << s.rice));
-    const int bins = rest < 0 ? (symbol >> s.rice) + 1 + s.rice : 3 + length + 1 - s.rice + length;
-    const int32_t coded = (bins << 15) + (s.nG1 < 8 ? f.g1one + (s.nG2 < 1 ? f.g2one : 0) : 0);
-    const int32_t small = level == 1 ? f.g1zero : (level == 2 ? f.g1one + f.g2zero : 0);
-    return 32768 + (symbol >= 0 ? coded : small);
+    const int shortBins = (symbol >> s.rice) + 1 + s.rice, longBins = 3 + length + 1 - s.rice + length;
+    const int32_t coded = (pick(rest < 0, shortBins, longBins) << 15) + flagsOfCoded(s, f);
+    return 32768 + pick(symbol >= 0, coded, flagsOfSmall(level, f));
 }
 
 // Rdoq.cpp:819-885 getLevelRate, branch free.  `for (top = 2; rest >= top; top <<= 1) egs += 2` gives 1 + 2 floor(log2(rest)).
@@ -121,11 +140,11 @@ __device__ __forceinline__ int levelRate(int level, const LevelState &s, const F
     const int maxVlc = (0x4e2e1a0e07ull >> (8 * s.rice)) & 0xff;           // 7, 14, 26, 46, 78
     const int prefixMax = 8 - s.rice;                                      // 8, 7, 6, 5, 4
     const int rest = symbol - maxVlc;
-    const int escape = rest > 0 ? (1 + 2 * (31 - __clz(max(rest, 1)))) << 15 : 0;
-    const int capped = rest > 0 ? maxVlc + 1 : symbol;
-    const int coded = escape + ((min(capped >> (s.rice + 1), prefixMax) + s.rice) << 15) + (s.nG1 < 8 ? f.g1one + (s.nG2 < 1 ? f.g2one : 0) : 0);
-    const int small = level == 1 ? f.g1zero : (level == 2 ? f.g1one + f.g2zero : 0);
-    return symbol >= 0 ? coded : small;
+    const int escapeBits = (1 + 2 * (31 - __clz(max(rest, 1)))) << 15;
+    const int escape = pick(rest > 0, escapeBits, 0);
+    const int capped = pick(rest > 0, maxVlc + 1, symbol);
+    const int coded = escape + ((min(capped >> (s.rice + 1), prefixMax) + s.rice) << 15) + flagsOfCoded(s, f);
+    return pick(symbol >= 0, coded, flagsOfSmall(level, f));
 }
 
 // Rdoq.cpp:517-603 getCoeffSigCtxInc
@@ -229,7 +248,7 @@ __host__ __device__ constexpr uint32_t sigPattern(int neighbours)
 // ... and where the kept levels are (scan-order bit masks: non-zero, odd) and which coefficients are negative (by scan position and
 // by raster position): the records hold magnitudes, the signs go on when the group is written out
 struct SdhAux { uint32_t active, c1At, keptMask, oddMask, negScan, negRaster; int32_t g1zero[4]; };
-__device__ __forceinline__ int32_t pick4(const int32_t (&v)[4], int k) { return k == 0 ? v[0] : (k == 1 ? v[1] : (k == 2 ? v[2] : v[3])); }      // registers, not scratch
+__device__ __forceinline__ int32_t pick4(const int32_t (&v)[4], int k) { return pick(k == 0, v[0], pick(k == 1, v[1], pick(k == 2, v[2], v[3]))); }      // registers, not scratch
 
 // Steps 1 and 2 of runQuantisation for one coefficient group (Rdoq.cpp:83-298), with the group's share of step 3
 // (Rdoq.cpp:356-399) and the cost terms of sign-data hiding (Rdoq.cpp:950-957, :980) folded in.  Two loops instead of the
@@ -286,27 +305,21 @@ __device__ __forceinline__ WalkResult walkGroup(const Block &b, WalkShared &sh, 
         negRaster |= (uint32_t)(c < 0) << nib;
         sumAll += sq & 0xffff;
         sumAllHi += sq >> 16;
-        if (!((active >> i) & 1))
-        {
-            sh.rec.kept[nib][lane] = 0;
-            sh.rec.costUp[i][lane] = 1 << 15;
-            continue;
-        }
+        // straight-line: every position writes its records (loop B overwrites those of the non-zero levels), what differs is selected
+        const bool inside = (active >> i) & 1;
         int ctx;
         if (LOG2 == 2) ctx = sigChroma + (int)((0x8877886654325410ull >> (4 * nib)) & 15);
-        else ctx = (gx + gy + nib == 0) ? sigChroma : sigGroup + (int)((pattern >> (2 * nib)) & 3);
+        else ctx = pick(gx + gy + nib == 0, sigChroma, sigGroup + (int)((pattern >> (2 * nib)) & 3));
         ctx += HAVOC_RDOQ_CTX_SIG;
         sh.pre[i][lane] = (uint32_t)ctx << 25 | (uint32_t)zeroBits;
         const int scaled = (int)a * b.quantScale;
-        if (((scaled + rnd) >> b.quantShift) > 0)
-            nzMask |= 1u << i;
-        else
-        {
-            const int32_t z = bitsOf(b, ctx, 0);
-            zeroBits += z;
-            sh.rec.kept[nib][lane] = 0;
-            sh.rec.costUp[i][lane] = factor * -(scaled >> (b.quantShift - 8)) + (1 << 15) + bitsOf(b, ctx, 1) - z;      // + g1zero[c1] when used
-        }
+        const bool nonZero = inside & (((scaled + rnd) >> b.quantShift) > 0);
+        nzMask |= (uint32_t)nonZero << i;
+        const int32_t z = bitsOf(b, ctx, 0), one = bitsOf(b, ctx, 1);
+        zeroBits += pick(inside & !nonZero, z, 0);
+        sh.rec.kept[nib][lane] = 0;
+        const int32_t upZero = (int32_t)((uint32_t)factor * (uint32_t)-(scaled >> (b.quantShift - 8))) + (1 << 15) + one - z;      // + g1zero[c1] when used
+        sh.rec.costUp[i][lane] = pick(inside, upZero, 1 << 15);
     }
     const int64_t sumSq = ((int64_t)sumAllHi << 16) + sumAll;
     r.dist0 = sumSq << b.distShift;
@@ -331,7 +344,7 @@ __device__ __forceinline__ WalkResult walkGroup(const Block &b, WalkShared &sh, 
         const int sc = (int)(pk >> 25);
         const int64_t zerosAbove = b.lambda * (int32_t)(pk & 0x1ffffff);
         const int32_t z0 = bitsOf(b, sc, 0), z1 = bitsOf(b, sc, 1);
-        const int32_t sigZero = first ? 0 : z0, sigOneBits = first ? 0 : z1;
+        const int32_t sigZero = pick(first, 0, z0), sigOneBits = pick(first, 0, z1);
         fb.g1zero = pick4(aux.g1zero, st.c1);
         fb.g1one = pick4(g1one, st.c1);
 
@@ -342,17 +355,19 @@ __device__ __forceinline__ WalkResult walkGroup(const Block &b, WalkShared &sh, 
         const int32_t err1 = a - clip16((clip16(level) * b.invScale + b.invOffset) >> b.invShift);
         const int32_t err2 = a - clip16((clip16(lower) * b.invScale + b.invOffset) >> b.invShift);
         const int64_t cost1 = ((int64_t)(int32_t)((uint32_t)err1 * (uint32_t)err1) << b.distShift) + b.lambda * levelBits(level, st, fb) + sigOne;
-        const int64_t cost2 = lower >= 1 ? ((int64_t)(int32_t)((uint32_t)err2 * (uint32_t)err2) << b.distShift) + b.lambda * levelBits(lower, st, fb) + sigOne : INT64_MAX;
-        int64_t costCoded = droppable ? dist0 + dropSig : INT64_MAX, costSig = droppable ? dropSig : 0;
+        const int64_t cost2If = ((int64_t)(int32_t)((uint32_t)err2 * (uint32_t)err2) << b.distShift) + b.lambda * levelBits(lower, st, fb) + sigOne;
+        const int64_t cost2 = pick(lower >= 1, cost2If, (int64_t)INT64_MAX);
+        const int64_t dropCost = dist0 + dropSig;
+        int64_t costCoded = pick(droppable, dropCost, (int64_t)INT64_MAX), costSig = pick(droppable, dropSig, (int64_t)0);
         int kept = 0;
         const bool take1 = cost1 < costCoded;
-        kept = take1 ? level : kept;
-        costSig = take1 ? sigOne : costSig;
-        costCoded = take1 ? cost1 : costCoded;
+        kept = pick(take1, level, kept);
+        costSig = pick(take1, sigOne, costSig);
+        costCoded = pick(take1, cost1, costCoded);
         const bool take2 = cost2 < costCoded;
-        kept = take2 ? lower : kept;
-        costSig = take2 ? sigOne : costSig;
-        costCoded = take2 ? cost2 : costCoded;
+        kept = pick(take2, lower, kept);
+        costSig = pick(take2, sigOne, costSig);
+        costCoded = pick(take2, cost2, costCoded);
 
         costB += costCoded;
         distB += dist0;
@@ -364,35 +379,39 @@ __device__ __forceinline__ WalkResult walkGroup(const Block &b, WalkShared &sh, 
         sh.rec.kept[nib][lane] = (int16_t)kept;
         keptMask |= (uint32_t)(stored != 0) << i;
         oddMask |= (uint32_t)(stored & 1) << i;
-        sh.rec.costUp[i][lane] = kept > 0 ? upKept : upZero;
-        sh.rec.costDown[i][lane] = factor * du + levelRate(kept - 1, st, fb) - now - (kept == 1 ? (1 << 15) + sigDelta : 0);
+        sh.rec.costUp[i][lane] = pick(kept > 0, upKept, upZero);
+        const int lastOne = (1 << 15) + sigDelta;
+        sh.rec.costDown[i][lane] = factor * du + levelRate(kept - 1, st, fb) - now - pick(kept == 1, lastOne, 0);
 
         // Rdoq.cpp:773-800
-        const bool grow = kept >= baseLevel(st) && kept > 3 * (1 << st.rice);
-        st.rice = grow ? min(st.rice + 1, 4) : st.rice;
+        const bool grow = (kept >= baseLevel(st)) & (kept > 3 * (1 << st.rice));
+        st.rice = pick(grow, min(st.rice + 1, 4), st.rice);
         st.nG1 += kept >= 1;
         st.nG2 += kept > 1;
-        st.c1 = kept > 1 ? 0 : ((st.c1 < 3 && st.c1 > 0 && kept) ? st.c1 + 1 : st.c1);
+        const bool step = (st.c1 < 3) & (st.c1 > 0) & (kept != 0);
+        st.c1 = pick(kept > 1, 0, pick(step, st.c1 + 1, st.c1));
         {
             const uint32_t below = (1u << (2 * i)) - 1;      // every position still to come sees the new c1
             c1At = (c1At & ~below) | ((0x55555555u * (uint32_t)st.c1) & below);
         }
         gSig += costSig;
-        gSigPos0 = i == 0 ? costSig : gSigPos0;
-        gCoded += stored ? costCoded - costSig : 0;
-        gDist0 += stored ? dist0 : 0;
+        gSigPos0 = pick(i == 0, costSig, gSigPos0);
+        const int64_t codedPart = costCoded - costSig;
+        gCoded += pick(stored != 0, codedPart, (int64_t)0);
+        gDist0 += pick(stored != 0, dist0, (int64_t)0);
         nonZeroAbovePos0 += (stored != 0) & (i != 0);
         // candidate for the last significant position (Rdoq.cpp:356-399)
         const int lx = lastPrefixLength(x), ly = lastPrefixLength(y);
         const int32_t rate = b.lastBits[(b.scanIdx == 2 ? ly : lx) * b.stateStride] + b.lastBits[(10 + (b.scanIdx == 2 ? lx : ly)) * b.stateStride];
         const int64_t total = qB - zerosAbove + b.lambda * rate - costSig;
-        const bool better = stored != 0 && !r.localStop && total < r.localBest;
-        r.localBest = better ? total : r.localBest;
-        r.localPos = better ? sp : r.localPos;
-        r.localOr = (better ? 0 : r.localOr) | stored;
+        const bool better = (stored != 0) & !r.localStop & (total < r.localBest);
+        r.localBest = pick(better, total, r.localBest);
+        r.localPos = pick(better, sp, r.localPos);
+        r.localOr = pick(better, 0, r.localOr) | stored;
         r.groupOr |= stored;
         r.localStop |= stored > 1;
-        qB += stored ? dist0 - costCoded : -costSig;
+        const int64_t keptGain = dist0 - costCoded, zeroGain = -costSig;
+        qB += pick(stored != 0, keptGain, zeroGain);
     }
     aux.c1At = c1At;
     aux.keptMask = keptMask;
@@ -405,39 +424,19 @@ __device__ __forceinline__ WalkResult walkGroup(const Block &b, WalkShared &sh, 
     gSig += zeroCost;
     if (!(nzMask & 1)) gSigPos0 = zeroCost - b.lambda * (int32_t)(sh.pre[0][lane] & 0x1ffffff);      // position 0 is always inside the coded range
     r.carry = st.c1 == 0;
-    r.coded = keptMask != 0;
-    if (g == 0)
-    {
-        r.coded = 1;
-        return r;
-    }
-    const int flagCtx = HAVOC_RDOQ_CTX_CSBF + (b.cIdx ? 2 : 0) + (neighbours ? 1 : 0);      // step 2 (Rdoq.cpp:196-297)
-    const int64_t zero = b.lambda * bitsOf(b, flagCtx, 0);
-    if (!r.coded)
-    {
-        r.cost += zero - gSig;
-        r.sigCost = zero;
-    }
-    else if (g < firstGroup)
-    {
-        if (nonZeroAbovePos0 == 0)
-        {
-            r.cost -= gSigPos0;
-            gSig -= gSigPos0;
-        }
-        const int64_t one = b.lambda * bitsOf(b, flagCtx, 1);
-        if (zero + gDist0 - gCoded - gSig < one)
-        {
-            r.coded = 0;
-            r.cost += zero + gDist0 - gCoded - gSig;
-            r.sigCost = zero;
-        }
-        else
-        {
-            r.cost += one;
-            r.sigCost = one;
-        }
-    }
+    // step 2 (Rdoq.cpp:196-297), as selects.  The DC group is coded whatever it holds; a group without a kept level pays the flag = 0 and
+    // gets the significance flags of its zero levels back; a group below the first weighs zeroing all its levels against flag = 1 (a
+    // lone level at position 0 implies its significance flag); the first group is coded and pays no flag.
+    const bool dc = g == 0, any = keptMask != 0, inner = any & !dc & (g < firstGroup);
+    const int flagCtx = HAVOC_RDOQ_CTX_CSBF + (b.cIdx ? 2 : 0) + (neighbours ? 1 : 0);
+    const int64_t zero = b.lambda * bitsOf(b, flagCtx, 0), one = b.lambda * bitsOf(b, flagCtx, 1);
+    const int64_t implied = pick(inner & (nonZeroAbovePos0 == 0), gSigPos0, (int64_t)0);
+    const int64_t sigLeft = gSig - implied, allZero = zero + gDist0 - gCoded - sigLeft;
+    const bool dropped = inner & (allZero < one), empty = !any & !dc;
+    const int64_t innerCost = pick(dropped, allZero, one) - implied, emptyCost = zero - gSig;
+    r.cost += pick(empty, emptyCost, pick(inner, innerCost, (int64_t)0));
+    r.sigCost = pick(empty | dropped, zero, pick(inner, one, (int64_t)0));
+    r.coded = dc | (any & !dropped);
     return r;
 }
 
@@ -445,44 +444,35 @@ __device__ __forceinline__ WalkResult walkGroup(const Block &b, WalkShared &sh, 
 // for a non-negative coefficient, dst -= change otherwise" is magnitude += change; sum & 1 is the parity of the magnitudes.
 __device__ __forceinline__ void hideSignsWalk(WalkShared &sh, int lane, const Block &b, bool lastGroup, const SdhAux &aux, uint32_t keptMask)
 {
-    if (!keptMask) return;
-    const int first = __ffs((int)keptMask) - 1, last = 31 - __clz((int)keptMask);
-    if (last - first < 4) return;
+    // the group needs a change when it holds kept levels at least 4 scan positions apart and the parity of their sum is not the sign
+    // of the first of them (Rdoq.cpp:905-930); the search below is straight-line so that the lanes which need it share one pass
+    const int first = max(__ffs((int)keptMask) - 1, 0), last = keptMask ? 31 - __clz((int)keptMask) : 0;
     const int signbit = (int)(aux.negScan >> first) & 1;
-    if (signbit == (__popc(aux.oddMask & keptMask) & 1)) return;
-    int minCost = INT32_MAX, cost = INT32_MAX, minIdx = -1, finalChange = 0, change = 0;
-    for (int i = lastGroup ? last : 15; i >= 0; --i)
+    const bool needed = (keptMask != 0) & (last - first >= 4) & (signbit != (__popc(aux.oddMask & keptMask) & 1));
+    if (__ballot(needed) == 0) return;
+    const int top = lastGroup ? last : 15;      // positions above the last significant coefficient are not candidates
+    int minCost = INT32_MAX, minIdx = 0, finalChange = 0;
+#pragma unroll
+    for (int i = 15; i >= 0; --i)
     {
-        if ((keptMask >> i) & 1)
-        {
-            const int mag = (uint16_t)sh.rec.kept[(int)(b.scan4 >> (4 * i)) & 15][lane];
-            const int up = sh.rec.costUp[i][lane];
-            int down = sh.rec.costDown[i][lane];
-            if (lastGroup && last == i && mag == 1) down -= 4 << 15;
-            if (up < down)
-            {
-                cost = up;
-                change = 1;
-            }
-            else
-            {
-                change = -1;
-                cost = (i == first && mag == 1) ? INT32_MAX : down;
-            }
-        }
-        else
-        {
-            cost = sh.rec.costUp[i][lane] + (((aux.active >> i) & 1) ? pick4(aux.g1zero, (int)(aux.c1At >> (2 * i)) & 3) : 0);
-            change = 1;
-            if (i < first && ((int)(aux.negScan >> i) & 1) != signbit) cost = INT32_MAX;
-        }
-        if (cost < minCost)
-        {
-            minCost = cost;
-            finalChange = change;
-            minIdx = i;
-        }
+        const bool isKept = (keptMask >> i) & 1;
+        const int mag = (uint16_t)sh.rec.kept[(int)(b.scan4 >> (4 * i)) & 15][lane];
+        const int up = sh.rec.costUp[i][lane];
+        // a kept level: one up or one down, whichever is cheaper (down is no option for a first level of 1: it would vanish)
+        const int downRaw = pick(isKept, sh.rec.costDown[i][lane], 0);      // only the kept positions have this record
+        const int down = downRaw - pick(lastGroup & (last == i) & (mag == 1), 4 << 15, 0);
+        const bool upBetter = up < down;
+        const int costKept = pick(upBetter, up, pick((i == first) & (mag == 1), INT32_MAX, down));
+        // a zero level: up to one, unless it comes before the first kept level with the other sign
+        const int g1 = pick((aux.active >> i) & 1, pick4(aux.g1zero, (int)(aux.c1At >> (2 * i)) & 3), 0);
+        const int costZero = pick((i < first) & (((int)(aux.negScan >> i) & 1) != signbit), INT32_MAX, up + g1);
+        const int cost = pick(isKept, costKept, costZero), change = pick(isKept & !upBetter, -1, 1);
+        const bool better = (i <= top) & (cost < minCost);
+        minCost = pick(better, cost, minCost);
+        finalChange = pick(better, change, finalChange);
+        minIdx = pick(better, i, minIdx);
     }
+    if (!needed) return;
     const int nib = (int)(b.scan4 >> (4 * minIdx)) & 15;
     const int mag = (uint16_t)sh.rec.kept[nib][lane], negative = (int)(aux.negScan >> minIdx) & 1;
     if ((!negative && mag == 32767) || (negative && mag == 32768)) finalChange = -1;
