@@ -296,6 +296,7 @@ __device__ __forceinline__ WalkResult walkGroup(const Block &b, WalkShared &sh, 
     uint32_t nzMask = 0, sumAll = 0, sumAllHi = 0, negScan = 0, negRaster = 0;
     int32_t zeroBits = 0;      // bits of the significance flags (= 0) of the zero levels met so far
     const int rnd = 1 << (b.quantShift - 1);
+#pragma unroll
     for (int i = 15; i >= 0; --i)
     {
         const int nib = (int)(b.scan4 >> (4 * i)) & 15;
