@@ -3,7 +3,7 @@
 // The reference's motion search asks for one block at a time and decides before it asks again (turing/Search.hpp:1447-1482,
 // 2060-2336): through a per-call interface that is a launch per question.  Here a whole picture's searches run together:
 //
-//   round 0   one SAD-surface launch: for every (PU, list) the SADs of all integer positions within +-32 of the co-located
+//   round 0   one SAD-surface launch: for every (PU, list) the SADs of all integer positions within +-16 of the co-located
 //             block (havoc_mi355x_sad_surface) -- a super-set of what most searches will ask;
 //   replay    the loops of decision.hpp run on the host, every sad / sad4 question answered by a look-up.  A question
 //             outside the data at hand (a far predictor, the raster stage, the sub-sample stage) stops that search with
@@ -561,7 +561,9 @@ int havoc_search_motion_uni(havoc_mi355x_ctx *ctx, int S, const havoc_search_par
     Flavour fl;
     fl.d_a = d_src;
     fl.a_stride = src_stride;
-    fl.r0 = 32;      // round 0 covers what the star search probes around a good start (dist 1..16, three failures)
+    fl.r0 = 16;      // round 0: +-16 around the co-located block.  Measured on the 1080p clip geometry: +-8 / 12 / 16 / 20 / 24 / 32 move
+                     // 27.3 / 22.9 / 23.1 / 24.1 / 25.2 / 28.0 MB per 600 searches in the same 9 rounds (a smaller window is cheaper for
+                     // every search but sends more of them to a +-64 surface); +-32 or +-48 for the miss surfaces doubles the rounds
     fl.a_off.resize(n);
     fl.centre0.assign(n, Mv(0, 0));
     for (int i = 0; i < n; ++i) fl.a_off[i] = src_origin + int64_t(pus[i].y0) * src_stride + pus[i].x0;
