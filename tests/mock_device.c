@@ -170,3 +170,75 @@ int havoc_mi355x_intra(havoc_mi355x_ctx *ctx, int S, int bitDepth, int log2, voi
         oracle_intra((char *)dst + (long)j[i].dst_off * S, sd, AT(nb, j[i].nb_off, S), log2, j[i].mode, (j[i].edge && log2 < 5) ? 1 : 0, bitDepth, S);
     return 0;
 }
+
+/* ---- the remaining per-call entry points of libhavoc_classic.so's one-job path: reached when the reference's own encoder is run through
+ * the table API on the stand-in device (tests/test_reference_encoder.py) ---- */
+int havoc_mi355x_ssd(havoc_mi355x_ctx *ctx, int S, const void *a, intptr_t sa, const void *b, intptr_t sb, const havoc_mi355x_pair_job *j, int n, uint32_t *out)
+{
+    (void)ctx; ++g_launches;
+    for (int i = 0; i < n; ++i) out[i] = oracle_ssd(AT(a, j[i].a_off, S), sa, AT(b, j[i].b_off, S), sb, j[i].w, j[i].h, S);
+    return 0;
+}
+
+int havoc_mi355x_ssd_linear(havoc_mi355x_ctx *ctx, const uint8_t *a, const uint8_t *b, int size, int32_t *out)
+{
+    (void)ctx; ++g_launches;
+    *out = oracle_ssd_linear(a, b, size);
+    return 0;
+}
+
+int havoc_mi355x_pred_bi(havoc_mi355x_ctx *ctx, int S, int taps, int bitDepth, int max_w, int max_h, void *dst, intptr_t sd, const void *ref, intptr_t sr,
+                         const havoc_mi355x_pred_bi_job *j, int n)
+{
+    (void)ctx; (void)max_w; (void)max_h; ++g_launches;
+    for (int i = 0; i < n; ++i)
+        oracle_pred_bi((char *)dst + (long)j[i].dst_off * S, sd, AT(ref, j[i].ref0_off, S), AT(ref, j[i].ref1_off, S), sr, j[i].w, j[i].h, j[i].xFrac0,
+                       j[i].yFrac0, j[i].xFrac1, j[i].yFrac1, bitDepth, taps, S);
+    return 0;
+}
+
+int havoc_mi355x_transform(havoc_mi355x_ctx *ctx, int bitDepth, int trType, int log2, int16_t *coeffs, const int16_t *res, intptr_t stride_res,
+                           const havoc_mi355x_tu_job *j, int n)
+{
+    (void)ctx; ++g_launches;
+    for (int i = 0; i < n; ++i) oracle_transform(coeffs + j[i].coef_off, res + j[i].res_off, stride_res, log2, trType, bitDepth);
+    return 0;
+}
+
+int havoc_mi355x_inverse_transform(havoc_mi355x_ctx *ctx, int bitDepth, int trType, int log2, int16_t *res, const int16_t *coeffs, const havoc_mi355x_tu_job *j, int n)
+{
+    (void)ctx; ++g_launches;
+    for (int i = 0; i < n; ++i) oracle_inverse_transform(res + j[i].res_off, coeffs + j[i].coef_off, log2, trType, bitDepth);
+    return 0;
+}
+
+int havoc_mi355x_inverse_transform_add(havoc_mi355x_ctx *ctx, int S, int bitDepth, int trType, int log2, void *dst, intptr_t sd, const void *pred, intptr_t sp,
+                                       const int16_t *coeffs, const havoc_mi355x_tu_job *j, int n)
+{
+    (void)ctx; ++g_launches;
+    for (int i = 0; i < n; ++i)
+        oracle_inverse_transform_add((char *)dst + (long)j[i].dst_off * S, sd, AT(pred, j[i].pred_off, S), sp, coeffs + j[i].coef_off, log2, trType, bitDepth, S);
+    return 0;
+}
+
+int havoc_mi355x_quantize(havoc_mi355x_ctx *ctx, int16_t *dst, const int16_t *src, const havoc_mi355x_quant_job *j, int n, int32_t *cbf)
+{
+    (void)ctx; ++g_launches;
+    for (int i = 0; i < n; ++i) cbf[i] = oracle_quantize(dst + j[i].dst_off, src + j[i].src_off, j[i].scale, j[i].shift, j[i].offset, j[i].n);
+    return 0;
+}
+
+int havoc_mi355x_quantize_inverse(havoc_mi355x_ctx *ctx, int16_t *dst, const int16_t *src, const havoc_mi355x_quant_job *j, int n)
+{
+    (void)ctx; ++g_launches;
+    for (int i = 0; i < n; ++i) oracle_quantize_inverse(dst + j[i].dst_off, src + j[i].src_off, j[i].scale, j[i].shift, j[i].n);
+    return 0;
+}
+
+int havoc_mi355x_quantize_reconstruct(havoc_mi355x_ctx *ctx, int log2, uint8_t *rec, intptr_t sr, const uint8_t *pred, intptr_t sp, const int16_t *res,
+                                      const havoc_mi355x_tu_job *j, int n)
+{
+    (void)ctx; ++g_launches;
+    for (int i = 0; i < n; ++i) oracle_quantize_reconstruct(rec + j[i].dst_off, sr, pred + j[i].pred_off, sp, res + j[i].res_off, 1 << log2);
+    return 0;
+}

@@ -540,7 +540,8 @@ int havoc_mi355x_rdoq(havoc_mi355x_ctx *ctx, int bitDepth, int log2TrafoSize, in
     REQUIRE_CTX(); REQUIRE(log2TrafoSize >= 2 && log2TrafoSize <= 5, "log2TrafoSize must be 2..5"); REQUIRE(njobs >= 0, "njobs < 0");
     REQUIRE(bitDepth >= 8 && bitDepth <= 12, "bitDepth must be 8..12");
     REQUIRE(d_dst != d_src, "rdoq: d_dst and d_src must be different buffers");
-    REQUIRE(njobs == 0 || (d_work && work_bytes >= rdoq_workspace_bytes(njobs) && (reinterpret_cast<uintptr_t>(d_work) & 15) == 0),
+    // 8x8 and 4x4 blocks are walked in job order with the scan inside the walk kernel: no workspace is read or written for them
+    REQUIRE(njobs == 0 || log2TrafoSize <= 3 || (d_work && work_bytes >= rdoq_workspace_bytes(njobs) && (reinterpret_cast<uintptr_t>(d_work) & 15) == 0),
             "rdoq: workspace missing, misaligned or smaller than havoc_mi355x_rdoq_workspace(njobs)");
     return check(launch_rdoq(LS(ctx), bitDepth, log2TrafoSize, d_dst, d_src, d_states, d_jobs, njobs, d_cbf, d_work), "rdoq");
 }

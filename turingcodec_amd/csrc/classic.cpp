@@ -46,7 +46,14 @@ struct Pic
     int vx0, vy0, vx1, vy1;
     long first() const { return -((long)pad * stride + pad); }   // sample index of `lo` relative to the origin
 };
-typedef std::vector<std::shared_ptr<Pic>> PicList;
+// an immutable snapshot of the registered pictures.  `serial` is process-wide and never reused: per-thread caches name a snapshot by it,
+// not by its address (a freed snapshot's address may come back for another encoder instance's list)
+struct PicList : std::vector<std::shared_ptr<Pic>>
+{
+    uint64_t serial = 0;
+};
+std::atomic<int> g_nextPicId{1};                     // picture ids are unique in the process, across bindings (per-thread caches compare them)
+std::atomic<uint64_t> g_nextSerial{1};
 
 // The process-wide binding behind every havoc_code of this library: reference-counted (havoc_new_code / havoc_delete_code may
 // be called any number of times, from any thread; table entries stay callable while at least one code is alive).
@@ -58,7 +65,6 @@ struct Binding
     std::atomic<const PicList *> pics{nullptr};      // immutable snapshots: table calls read without a lock
     std::vector<const PicList *> retired;            // old snapshots, freed with the binding
     havoc_mi355x_ctx *ctx = nullptr;                 // registration work (uploads, interpolation)
-    int nextId = 1;
     std::atomic<int64_t> stat[8];
     Binding() { for (auto &c : stat) c = 0; }
 };
@@ -80,12 +86,13 @@ inline const Pic *findPic(const void *p)
     const PicList *l = b->pics.load(std::memory_order_acquire);
     if (!l) return nullptr;
     static thread_local const Pic *last[2] = {nullptr, nullptr};
-    static thread_local const PicList *lastList = nullptr;
+    static thread_local uint64_t lastSerial = 0;
     const char *c = static_cast<const char *>(p);
-    if (lastList == l)
+    if (lastSerial == l->serial)
         for (const Pic *q : last)
             if (q && c >= q->lo && c < q->hi) return q;
-    lastList = l;
+    if (lastSerial != l->serial) last[0] = last[1] = nullptr;   // pictures of another snapshot may be gone
+    lastSerial = l->serial;
     for (const auto &q : *l)
         if (c >= q->lo && c < q->hi)
         {
@@ -432,6 +439,16 @@ bool serveSatd(const Sample *a, intptr_t sa, const Sample *b, intptr_t sb, int *
         if (memcmp(b + r * sb, plane + (long)(m.y + ty + r + ref->pad) * ref->stride + m.x + tx + ref->pad, sizeof(Sample) * N)) return false;
     // the PU's source block: a is its tile (tx, ty)
     SrcKey key = keyOf(a - (long)ty * sa - tx, sa);
+    if (!key.pic)
+    {
+        // havoc_hadamard_satd only promises N x N readable samples at `a`.  An unregistered source is taken for tile (tx, ty) of a
+        // PU-sized block only when this thread has already been handed that very block as the w x h operand of a SAD call (the
+        // ideal second predictor of searchMotionBi: its SAD grid precedes its sub-sample stage, Search.hpp:1585-1650)
+        bool known = false;
+        for (const auto &g : v.surf)
+            known |= g.valid && g.src.ptr == key.ptr && g.src.stride == sa && g.w == m.w && g.h == m.h;
+        if (!known) return false;
+    }
     const int tilesX = m.w / N, ntiles = tilesX * (m.h / N), tile = (ty / N) * tilesX + tx / N;
     const int qx = 4 * m.x + m.xf, qy = 4 * m.y + m.yf;
     SatdSet *f = nullptr;
@@ -806,6 +823,20 @@ static void releasePic(Binding *b, Pic *q)
     q->d_plane = q->d_phase = q->h_phase = nullptr;
 }
 
+// A replaced snapshot may still be under the eyes of a table call on another thread (findPic walks it without a lock, for a few hundred
+// nanoseconds), so it is not freed at once -- but not kept for the life of the binding either (an encode registers pictures per frame):
+// it goes when kRetired newer snapshots have been retired after it.
+static void retire(Binding *b, const PicList *old)
+{
+    constexpr size_t kRetired = 64;
+    b->retired.push_back(old);
+    while (b->retired.size() > kRetired)
+    {
+        delete b->retired.front();
+        b->retired.erase(b->retired.begin());
+    }
+}
+
 havoc_code havoc_new_code(havoc_instruction_set mask, int size)
 {
     (void)mask;
@@ -834,6 +865,9 @@ void havoc_delete_code(havoc_code code)
     Binding *b = static_cast<Binding *>(code.implementation);
     if (!b || b != g_binding || b->refs <= 0) return;
     if (--b->refs > 0) return;
+    if (getenv("HAVOC_CLASSIC_REPORT"))
+        fprintf(stderr, "libhavoc_classic: table calls served %lld, one-job launches %lld, launches %lld, surfaces %lld, tile-SATD batches %lld, pictures %lld\n",
+                (long long)b->stat[0], (long long)b->stat[1], (long long)b->stat[2], (long long)b->stat[3], (long long)b->stat[4], (long long)b->stat[5]);
     g_live.store(nullptr, std::memory_order_release);
     // device memory of the pictures still registered; per-thread contexts are left to process exit (see Stage)
     if (const PicList *l = b->pics.load())
@@ -852,7 +886,7 @@ int havoc_classic_register_picture(havoc_code code, const void *origin, intptr_t
     if (bit_depth < 8 || bit_depth > (S == 1 ? 8 : 10)) return HAVOC_MI355X_EINVAL;
     std::lock_guard<std::mutex> lock(b->mu);
     auto q = std::make_shared<Pic>();
-    q->id = b->nextId++;
+    q->id = g_nextPicId.fetch_add(1);
     q->origin = static_cast<const char *>(origin);
     q->stride = stride;
     q->w = width; q->h = height; q->pad = pad; q->S = S; q->bd = bit_depth; q->role = role;
@@ -867,6 +901,8 @@ int havoc_classic_register_picture(havoc_code code, const void *origin, intptr_t
     havoc_mi355x_ctx *ctx = b->ctx;
     int rc;
     void *dp = nullptr;
+    // whatever a failed registration has allocated goes back before it returns
+    struct Undo { Binding *b; Pic *q; bool armed = true; ~Undo() { if (armed) releasePic(b, q); } } undo{b, q.get()};
     if ((rc = havoc_mi355x_malloc(ctx, &dp, elems * S + 256))) return rc;
     q->d_plane = static_cast<char *>(dp);
     if ((rc = havoc_mi355x_h2d(ctx, q->d_plane, q->lo, used * S))) return rc;
@@ -889,11 +925,13 @@ int havoc_classic_register_picture(havoc_code code, const void *origin, intptr_t
     }
     else if ((rc = havoc_mi355x_sync(ctx)))
         return rc;
+    undo.armed = false;
     const PicList *old = b->pics.load();
     PicList *next = old ? new PicList(*old) : new PicList();
+    next->serial = g_nextSerial.fetch_add(1);
     next->push_back(q);
     b->pics.store(next, std::memory_order_release);
-    if (old) b->retired.push_back(old);
+    if (old) retire(b, old);
     b->stat[5] += 1;
     return 0;
 }
@@ -906,6 +944,7 @@ int havoc_classic_unregister_picture(havoc_code code, const void *origin)
     const PicList *old = b->pics.load();
     if (!old) return HAVOC_MI355X_EINVAL;
     PicList *next = new PicList();
+    next->serial = g_nextSerial.fetch_add(1);
     std::shared_ptr<Pic> gone;
     for (const auto &q : *old)
         if (q->origin == origin && !gone) gone = q;
@@ -916,7 +955,7 @@ int havoc_classic_unregister_picture(havoc_code code, const void *origin)
         return HAVOC_MI355X_EINVAL;
     }
     b->pics.store(next, std::memory_order_release);
-    b->retired.push_back(old);   // the snapshot object itself (a reader on another thread may be walking it): freed with the binding
+    retire(b, old);   // the snapshot object itself (a reader on another thread may be walking it) is kept for a while
     // Contract (as for the reference's own picture buffers): unregister a plane only when no table call can still name it.
     // Its device and pinned memory go now; per-thread caches match pictures by id, and ids are never reused.
     releasePic(b, gone.get());

@@ -147,13 +147,17 @@ int havoc_mi355x_picture_create(havoc_mi355x_ctx *ctx, int S, int bit_depth, int
     return 0;
 }
 
+// ctx must be the context the picture was created with (its device owns the allocations; a NULL ctx cannot free them and is refused
+// loudly rather than leaking device memory in silence)
 void havoc_mi355x_picture_destroy(havoc_mi355x_ctx *ctx, havoc_mi355x_picture *pic)
 {
     if (!pic) return;
+    if (!ctx) (void)fail(HAVOC_MI355X_EINVAL, "havoc_mi355x_picture_destroy: NULL context, the picture's device memory is NOT freed");
     if (ctx)
     {
         DeviceGuard g(ctx->device);
-        (void)hipStreamSynchronize(ctx->stream);
+        // uploads, pads and phase-plane launches go to the current lane, which may be a forked one: wait for all of them
+        (void)havoc_mi355x_sync(ctx);
         if (pic->d_phase) (void)hipFree(pic->d_phase);
         if (pic->d_stage) (void)hipFree(pic->d_stage);
         (void)hipFree(pic->d_base);

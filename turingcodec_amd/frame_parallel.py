@@ -106,6 +106,7 @@ class DagSchedule:
         self._next = 0                               # oldest unscheduled coding-order index
         self._scheduled = set()
         self._plan: List[List[Optional[Picture]]] = []
+        self._stalled = 0                            # consecutive slots that scheduled nothing while pictures remained
 
     # ---- sequence generation ---------------------------------------------------------------------------------------
     def _grow(self, upto_index: int):
@@ -162,6 +163,15 @@ class DagSchedule:
                 self.dpb_slot[p.poc] = s
                 self._held[p.poc] = s
             chosen.append(p)
+        # a slot that schedules nothing while pictures remain must be waiting for a reference that ran in the previous slot(s)
+        # (`lag`) -- otherwise nothing can ever change again (too few mirror slots for this lag / world): fail, do not spin
+        if not chosen and self._next < len(self.pics):
+            self._stalled += 1
+            if self._stalled > self.lag + 1:
+                raise RuntimeError(f"DagSchedule cannot make progress at slot {t}: {len(self._free)} free of {self.n_slots_dpb} mirror slots, "
+                                   f"{len(self._held)} held (lag {self.lag}, world {self.world}); give it more dpb_slots or a larger window")
+        else:
+            self._stalled = 0
         for p in chosen:
             self._scheduled.add(p.index)
             self.done_slot[p.poc] = t
