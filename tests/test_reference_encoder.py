@@ -1,0 +1,75 @@
+"""The reference's own ENCODER as the checker of the drop-in boundary (north star: "the emitted bitstream is
+bit-exact against the reference CPU encoder at the same preset and QP on the same YUV input").
+
+oracle/_ref/turing_ref_havoc and turing_ref_classic are the same encoder objects -- /root/reference/turing/*.cpp compiled where they
+lie by oracle/Makefile, driven by oracle/ref_encoder_main.cpp -- linked against the reference's havoc library and against
+turingcodec_amd/libhavoc_classic.so.  The only difference between the two programs is who answers the primitive table calls.
+
+  -m "not gpu": the reference encoder is deterministic across --asm 0/1 and thread counts and reproduces the committed stream hashes;
+                the classic-table build over the CPU stand-in device (tests/mock_device.c) writes the same streams -- this checks
+                classic.cpp's marshalling (strides, aliasing, sizes, table indexing) for EVERY call a real encode makes;
+  -m gpu:       the classic-table build over the real MI355X library writes the same streams: every table call of the encode is
+                a HIP launch, and the stream is bit-identical to the CPU reference encoder's.
+"""
+import os
+import sys
+
+import pytest
+
+import encoder_tools as et
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+MOCK_DIR = os.path.join(HERE, "_build", "mock")
+
+needs_encoders = pytest.mark.skipif(not et.have_encoders(), reason="oracle/_ref/turing_ref_* not built (needs /root/reference; `make -C oracle encoder`)")
+
+CPU_CASES = ["ra_medium_qp32", "ra_medium_qp22", "ra_fast_qp32", "ra_slow_qp27", "ai_fast_qp32", "ra_medium_10bit_qp27", "ra_medium_internal10"]
+GPU_CASES = ["gpu_ra_medium_qp32", "gpu_ra_medium_qp22", "gpu_ai_fast_qp32", "gpu_ra_medium_10bit"]
+
+
+@pytest.fixture(scope="module")
+def workdir(tmp_path_factory):
+    return str(tmp_path_factory.mktemp("encoder"))
+
+
+def _check_golden(case, stream, workdir):
+    g = et.golden()[case]
+    if et.md5(os.path.join(workdir, case + ".yuv")) != g["clip_md5"]:
+        pytest.skip("the synthetic clip differs from the one the golden hashes were made for (numpy build?)")   # the A == B checks above still ran
+    assert et.md5(stream) == g["stream_md5"] and len(stream) == g["stream_bytes"], case
+
+
+@needs_encoders
+@pytest.mark.parametrize("case", ["ra_medium_qp32", "ai_fast_qp32", "ra_medium_10bit_qp27"])
+def test_reference_encoder_is_deterministic_and_matches_the_committed_hashes(case, workdir):
+    jit, _ = et.encode(et.HAVOC_EXE, case, workdir, ["--asm", "1"])
+    plain_c, _ = et.encode(et.HAVOC_EXE, case, workdir, ["--asm", "0", "--threads", "1"], tag=".c")
+    assert jit == plain_c, "x86 JIT tables and plain-C tables of the reference give different streams"
+    _check_golden(case, jit, workdir)
+
+
+@needs_encoders
+@pytest.mark.parametrize("case", CPU_CASES)
+def test_reference_encoder_over_classic_tables_writes_the_reference_stream_on_the_mock_device(case, workdir):
+    """no GPU: libhavoc_classic.so in front of tests/mock_device.c (soname libhavoc_mi355x.so, found first through LD_LIBRARY_PATH)"""
+    sys.path.insert(0, HERE)
+    import search_runner
+    search_runner.build_mock()
+    ref, _ = et.encode(et.HAVOC_EXE, case, workdir)
+    got, err = et.encode(et.CLASSIC_EXE, case, workdir, env={"LD_LIBRARY_PATH": MOCK_DIR + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""), "HAVOC_CLASSIC_REPORT": "1"})
+    assert "one-job launches" in err and " one-job launches 0," not in err, err[-400:]     # the calls really went through the table library
+    assert got == ref, f"{case}: stream through libhavoc_classic.so differs from the reference encoder's"
+    _check_golden(case, got, workdir)
+
+
+@needs_encoders
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", GPU_CASES)
+def test_reference_encoder_over_mi355x_tables_writes_the_reference_stream(case, workdir):
+    """MI355X: every primitive table call of a real encode (about a million per case) is served by libhavoc_mi355x.so"""
+    ref, _ = et.encode(et.HAVOC_EXE, case, workdir)
+    got, err = et.encode(et.CLASSIC_EXE, case, workdir, env={"HAVOC_CLASSIC_REPORT": "1"}, timeout=1500)
+    assert "one-job launches" in err, err[-400:]
+    print(case, err.strip().splitlines()[-1])
+    assert got == ref, f"{case}: stream through the MI355X tables differs from the reference encoder's"
+    _check_golden(case, got, workdir)
