@@ -48,6 +48,12 @@ def parse_args():
     ap.add_argument("--extra-4k", type=int, default=1,
                     help="also measure the 3840x2160 8-bit QP27 workload (BASELINE.json configs[2]) for a few steps and report it under "
                          "`extra` (N=1 only; 0 = off)")
+    ap.add_argument("--decisions", type=int, default=1,
+                    help="1 (default): the plain N=1 line also carries, under `extra`, the DECISION-DRIVEN path (turingcodec_amd.decisions."
+                         "DecisionPicture: motion searches in WPP wavefront order with predictors derived from earlier decisions, batch-fed; then the "
+                         "TU chain on the chosen vectors) at 1080p QP32 and 4K QP32, and its ratio to `value`; 2: only that (diagnostic line); 0: off")
+    ap.add_argument("--decision-pictures", type=int, default=4, help="independent pictures in flight on the decision-driven path (the B pictures of "
+                    "one hierarchy level do not depend on each other): one host thread + context each, the replay threads shared out between them")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
@@ -973,8 +979,162 @@ class FramePipeline:
                 self.arrived[exch.slot_of(q.poc)] = ev
 
 
+def cpu_decision_walk(args, keep):
+    """cpu_baseline leg: the SAME decision walk (same pictures, PUs, order, derived predictors) one table call at a time through the
+    reference's x86-JIT havoc tables on one host core (tests/search_client.cpp over oracle/_ref -- the checker, timed here as the
+    baseline), and every decision compared with what the batch client decided on the GPU"""
+    import tempfile
+    if not keep or "solo" not in keep:
+        return None
+    tmp = os.path.join(tempfile.gettempdir(), f"havoc_walk_{os.getpid()}.npz")
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", "decisions", "--res", args.res, "--bit-depth", str(args.bit_depth), "--seed", str(args.seed),
+           "--qp", str(args.qp), "--cpu-out", tmp]
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        if out.returncode != 0:
+            return {"error": out.stderr[-500:]}
+        r = json.loads(out.stdout.strip().splitlines()[-1])
+        ref = np.load(tmp)
+        got, field = keep["res"], keep["field"]
+        names = ("mv", "mvd", "mv_integer", "mvp_flag", "wrote_2Nx2N", "calls", "cost_integer", "cost_subpel", "cost_mvd_zero")
+        bad = sum(int((np.asarray(got[k]) != ref[k]).reshape(len(got), -1).any(axis=1).sum()) for k in names)
+        r["parity_vs_reference"] = {"searches_compared": int(len(got)), "fields_per_search": len(names), "mismatching": bad,
+                                    "motion_field_equal": bool(np.array_equal(field, ref["field"]))}
+        r["what"] = ("the decision walk of extra['decision-driven path ...'] (same picture, PUs, wavefront-compatible order, derived predictors) one table "
+                     "call at a time through the reference's x86-JIT havoc tables, ONE host core; searches only (no TU chain)")
+        return r
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+
+
+def cpu_decision_worker(args):
+    """child process of cpu_decision_walk"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import search_tools as st
+    from turingcodec_amd.decisions import decision_inputs
+    w, h = (int(v) for v in args.res.split("x"))
+    d = decision_inputs(w, h, args.bit_depth, args.qp, args.seed)
+    planes = [_aligned(p) for p in d["planes"]]
+    cl = st.Client("ref", -1)      # -1: everything the CPU supports = the reference's x86 JIT tables
+    best = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        res, field = cl.picture_uni(d["params"], planes[0], planes[1], planes[2], d["stride"], d["pad"], d["pus"], d["ctu_first"], d["cx"], d["cy"], d["mvp_rate"])
+        t = time.perf_counter() - t0
+        best = t if best is None else min(best, t)
+    np.savez(args.cpu_out, field=field, **{k: res[k] for k in res.dtype.names})
+    print(json.dumps({"seconds_per_picture": round(best, 4), "pictures_per_second": round(1.0 / best, 3), "cores": 1, "searches": int(len(res)),
+                      "loop_calls": int(res["calls"].sum())}))
+
+
+def cpu_reference_encoder(args):
+    """cpu_baseline leg: the reference's own ENCODER (oracle/_ref/turing_ref_havoc: turing/*.cpp compiled where they lie + our driver over
+    `Encoder`, x86 JIT havoc) on a synthetic clip of --res -- SURVEY 8(d)'s CPU baseline: whole-encoder frames/s at speed=medium, all host threads"""
+    import tempfile
+    exe = os.path.join(ROOT, "oracle", "_ref", "turing_ref_havoc")
+    if not os.path.exists(exe):
+        return None
+    from turingcodec_amd.workload import synth_frames
+    w, h = (int(v) for v in args.res.split("x"))
+    frames = 9 if w * h <= 1920 * 1080 else 5
+    cores = usable_cores()
+    with tempfile.TemporaryDirectory() as d:
+        clip = os.path.join(d, "clip.yuv")
+        with open(clip, "wb") as f:
+            for planes in synth_frames(w, h, frames, args.seed, args.bit_depth):
+                for pl in planes:
+                    f.write(np.ascontiguousarray(pl).tobytes())
+        cmd = [exe, "--input-res", f"{w}x{h}", "--frames", str(frames), "--frame-rate", "24", "--verbosity", "0", "--no-sao", "--qp", str(args.qp),
+               "--speed", "medium", "--threads", str(cores), "-o", os.path.join(d, "out.bit"), clip] + (["--bit-depth", "10"] if args.bit_depth > 8 else [])
+        t0 = time.perf_counter()
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        t = time.perf_counter() - t0
+        if r.returncode != 0:
+            return {"error": r.stderr[-300:]}
+        size = os.path.getsize(os.path.join(d, "out.bit"))
+    return {"value": round(frames / t, 3), "unit": "frames/s", "frames": frames, "threads": cores, "seconds": round(t, 3), "stream_bytes": size,
+            "what": f"the reference encoder itself (whole encoder: search, RDOQ, CABAC, loop filter; x86 JIT havoc), {w}x{h} random access QP{args.qp} "
+                    f"speed=medium --no-sao, {frames} frames of the synthetic clip, wall clock of the process (start-up included)"}
+
+
+def decision_path(args, Havoc, res, bit_depth, qp, pictures, seconds=1.5, keep=None):
+    """pictures/s of the decision-driven path (turingcodec_amd/decisions.py): `pictures` independent pictures in flight, each on its own
+    context / stream and host thread; plus the latency of ONE picture alone and what its search needed (wavefront steps, rounds, launches)"""
+    import threading
+    from turingcodec_amd.decisions import DecisionPicture
+    w, h = (int(v) for v in res.split("x"))
+    cores = usable_cores()
+    per = max(1, cores // max(1, pictures))
+    ctxs = []
+    for k in range(pictures):
+        hv = Havoc(0, stream="new")
+        ctxs.append(DecisionPicture(hv, w, h, bit_depth, qp, seed=args.seed + 13 * k, threads=per))
+    for dp in ctxs:
+        dp.step()      # allocates the client's pinned work memory, pages code in
+    # one picture alone, all replay threads: the latency a dependency-bound encoder sees
+    solo = ctxs[0]
+    solo.threads = cores
+    lat = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        res0, field0, stats = solo.step()
+        lat.append(time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    solo.phase_planes()
+    solo.hv.sync()
+    t_planes = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    solo.search()
+    t_search = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    solo.tu_chain(field0)
+    solo.hv.sync()
+    t_chain = time.perf_counter() - t0
+    solo.threads = per
+    done = [0] * pictures
+    stop = time.perf_counter() + seconds
+
+    def loop(k):
+        while time.perf_counter() < stop:
+            ctxs[k].step()
+            done[k] += 1
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=loop, args=(k,)) for k in range(pictures)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    el = time.perf_counter() - t0
+    d = stats.as_dict()
+    out = {"value": round(sum(done) / el, 2), "unit": "pictures/s", "pictures_in_flight": pictures, "host_threads": cores, "replay_threads_per_picture": per,
+           "seconds_measured": round(el, 3), "pictures_done": int(sum(done)),
+           "one_picture_alone_ms": round(min(lat) * 1e3, 3),
+           "one_picture_alone_split_ms": {"phase_planes": round(t_planes * 1e3, 3), "searches_in_wavefront_order": round(t_search * 1e3, 3),
+                                          "tu_chain_on_chosen_vectors": round(t_chain * 1e3, 3)},
+           "searches_per_picture": int(2 * len(solo.pus)), "ctus": solo.cx * solo.cy, "tu_blocks": int(sum(g["m"] for g in solo.groups)),
+           "wavefront_steps": d["steps"], "rounds": d["rounds"], "rounds_per_step": round(d["rounds"] / max(1, d["steps"]), 2),
+           "max_rounds_in_step": d["max_rounds_in_step"], "launches": d["launches"], "launches_per_step": round(d["launches"] / max(1, d["steps"]), 2),
+           "surfaces": d["surfaces_small"] + d["surfaces_zero"] + d["surfaces_large"], "satd_jobs": d["satd_jobs"],
+           "searches_run_ahead_on_a_guess": d["speculative_runs"], "searches_rerun": d["reruns"], "bytes_down": d["bytes_down"],
+           "client_seconds": {"gpu_rounds": round(d["seconds_gpu"], 5), "host_replay": round(d["seconds_host"], 5), "total": round(d["seconds_total"], 5)},
+           "what": "per picture: 2 x 15 phase planes; every PU's uni-directional search in both lists, CTUs in WPP wavefront order (CTU (x, y) after "
+                   "(x + 1, y - 1)), predictors of a PU = the vectors decided for its left / upper neighbours, mvPreviousInteger2Nx2N handed along the CTU "
+                   "row (turingcodec_amd/search/picture_order.hpp) -- fed by SAD-surface / tile-SATD batch launches, the reference's loops replayed on "
+                   "host threads; then prediction at the chosen vectors -> residual + DCT -> RDOQ -> IQ + IDCT + add -> SSD for every 16x16 block. "
+                   "Not in it: the mode decision between the searched PUs, bi-prediction, intra, CABAC"}
+    if keep is not None:
+        keep["solo"], keep["res"], keep["field"] = solo, res0, field0
+    else:
+        for dp in ctxs:
+            dp.hv.close()
+    return out
+
+
 def main():
     args = parse_args()
+    if args.cpu_worker == "decisions":
+        return cpu_decision_worker(args)
     if args.cpu_worker:
         return cpu_worker(args)
     import torch
@@ -1119,7 +1279,8 @@ def main():
         mixname = ("random-access QP%d speed=medium B-frame call mix (SURVEY A.2 counts x %.2f; assumed PU/intra size mix)" % (args.qp, w * h / (1920 * 1080))
                    if args.mix == "ra" else "all-intra QP%d speed=fast call mix (SURVEY A.1 per-CTU intra / TU counts, havoc_quantize in the chain)" % args.qp)
         out = {
-            "metric": "encoded fps (havoc hot path: one picture's primitive calls per frame)",
+            "metric": "encoded fps (havoc hot path, primitive-batch throughput: one picture's primitive calls per frame as whole-frame batches; "
+                      "the decision-driven path is in extra)",
             "value": round(pictures_per_block / elapsed, 3),
             "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -1208,8 +1369,35 @@ def main():
                         "steps": ksteps, "timed_blocks": len(yb)}
                 except Exception as e:
                     out.setdefault("extra", {})["rdoq0_error"] = repr(e)
+        if plain and args.decisions and args.mix == "ra":
+            # the decision-driven path: what the batches cost when decisions sit between them
+            decision_keep = {}
+            for dres, dqp, label in ((args.res, args.qp, f"decision-driven path {args.res} {args.bit_depth}-bit QP{args.qp}"),
+                                     ("3840x2160", 32, "decision-driven path 3840x2160 8-bit QP32 (BASELINE.json metric: 4K RA QP32)")):
+                if label.startswith("decision-driven path 3840") and args.res == "3840x2160":
+                    continue
+                try:
+                    keep = decision_keep if dres == args.res else None
+                    r = decision_path(args, Havoc, dres, args.bit_depth if dres == args.res else 8, dqp, max(1, args.decision_pictures), keep=keep)
+                    if dres == args.res:
+                        r["ratio_to_value"] = round(r["value"] / out["value"], 5)
+                        r["ratio_note"] = ("`value` is one picture's primitive calls as ideal whole-frame batches (no decision between launches); this is the "
+                                           "same kernels driven by decisions in an order a bit-exact encoder could issue them")
+                    out.setdefault("extra", {})[label] = r
+                    torch.cuda.empty_cache()
+                except Exception as e:
+                    out.setdefault("extra", {})[label] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, dev)
+            if plain and args.decisions and args.mix == "ra" and out["cpu_baseline"] is not None:
+                try:
+                    out["cpu_baseline"]["decision_walk"] = cpu_decision_walk(args, decision_keep)
+                except Exception as e:
+                    out["cpu_baseline"]["decision_walk"] = {"error": repr(e)}
+                try:
+                    out["cpu_baseline"]["reference_encoder"] = cpu_reference_encoder(args)
+                except Exception as e:
+                    out["cpu_baseline"]["reference_encoder"] = {"error": repr(e)}
         line = json.dumps(out)
     if grouped:
         dist.barrier()

@@ -70,6 +70,7 @@ void makeIdealPredictor(MotionTables<Sample> &, Sample *ideal, const Sample *inp
 #ifdef HAVOC_CLASSIC_EXT
 #include "havoc_classic_ext.h"
 #endif
+#include "picture_order.hpp"
 
 using namespace havoc_search;
 
@@ -263,6 +264,41 @@ int client_intra35(int S, int bitDepth, int log2, const void *src, intptr_t ss, 
 #endif
     if (S == 1) runIntra35<uint8_t>(bitDepth, log2, (const uint8_t *)src, ss, (const uint8_t *)nb, jobs, n, satd35);
     else runIntra35<uint16_t>(bitDepth, log2, (const uint16_t *)src, ss, (const uint16_t *)nb, jobs, n, satd35);
+    return 0;
+}
+
+// a whole picture's uni-directional searches in dependency order (picture_order.hpp), one table call at a time: the expected values of
+// havoc_search_picture_uni.  ref0 / ref1 = sample (0, 0) of the two reference pictures; out[2 * p + list]; field_out as there.
+int client_picture_uni(int S, const void *src, intptr_t ss, const void *ref0, const void *ref1, intptr_t rs, const havoc_search_params *p,
+                       const havoc_picture_pu *pus, const int32_t *ctu_first, int ctus_x, int ctus_y, const int64_t *mvp_rate, havoc_search_result *out,
+                       int16_t *field_out)
+{
+    if (!g_open) return -1;
+    const SearchParams sp = paramsOf(*p);
+    const Cost rate[2] = {mvp_rate[0], mvp_rate[1]};
+    MotionField field;
+    auto run = [&](auto sampleTag) {
+        typedef decltype(sampleTag) Sample;
+        const Sample *refs[2] = {(const Sample *)ref0, (const Sample *)ref1};
+        auto search = [&](int pi, int list, const PuContext &pu) {
+            (void)pi;
+            TableView<Sample> view(tables<Sample>(), (const Sample *)src + intptr_t(pu.y0) * ss + pu.x0, ss, Plane<Sample>{refs[list], rs}, pu.x0, pu.y0, pu.w, pu.h,
+                                   sp.bitDepth);
+            MotionSearch<TableView<Sample>> ms(sp, pu, view);
+            return ms.run();
+        };
+        walkPictureSequential(sp, pus, ctu_first, ctus_x, ctus_y, rate, search, out, field);
+    };
+    if (S == 1) run(uint8_t(0));
+    else run(uint16_t(0));
+    if (field_out)
+        for (int l = 0; l < 2; ++l)
+            for (size_t c = 0; c < size_t(field.cw) * field.ch; ++c)
+            {
+                const Mv v = MotionField::unpack(field.mv[l][c]);
+                field_out[(size_t(l) * field.cw * field.ch + c) * 2 + 0] = field.valid[l][c] ? v.x : 0;
+                field_out[(size_t(l) * field.cw * field.ch + c) * 2 + 1] = field.valid[l][c] ? v.y : 0;
+            }
     return 0;
 }
 

@@ -10,10 +10,13 @@ import ctypes as C
 import math
 import os
 import subprocess
+import sys
 
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 BUILD = os.path.join(ROOT, "tests", "_build")
 SRC = os.path.join(ROOT, "tests", "search_client.cpp")
 INC = ["-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "turingcodec_amd", "search")]
@@ -29,10 +32,7 @@ INTRA_RESULT_DT = np.dtype([("costs", "i8", (35,)), ("order", "i4", (35,)), ("co
 assert PU_DT.itemsize == 72 and RESULT_DT.itemsize == 56 and INTRA_CTX_DT.itemsize == 40 and INTRA_RESULT_DT.itemsize == 424
 
 
-class Params(C.Structure):
-    _fields_ = [("pic_width", C.c_int32), ("pic_height", C.c_int32), ("ctb_size", C.c_int32), ("concurrent_frames", C.c_int32),
-                ("met", C.c_int32), ("small_search_window", C.c_int32), ("bi_small_search_window", C.c_int32), ("half_pel", C.c_int32),
-                ("quarter_pel", C.c_int32), ("bit_depth", C.c_int32), ("reciprocal_sqrt_lambda", C.c_double)]
+from turingcodec_amd.decisions import SearchParams as Params  # noqa: E402  (havoc_search_params; one definition for product binding and tests)
 
 
 def reciprocal_sqrt_lambda(qp, qp_factor=0.68, non_reference=True):
@@ -55,7 +55,7 @@ def build(kind):
     """compile the client for one back end; returns the library path (None when the back end's library is not there)"""
     os.makedirs(BUILD, exist_ok=True)
     out = os.path.join(BUILD, f"libsearch_{kind}.so")
-    hdrs = [os.path.join(ROOT, "turingcodec_amd", "search", f) for f in ("decision.hpp", "table_view.hpp", "search_abi.h")]
+    hdrs = [os.path.join(ROOT, "turingcodec_amd", "search", f) for f in ("decision.hpp", "table_view.hpp", "search_abi.h", "picture_order.hpp")]
     base = ["g++", "-O2", "-std=c++14", "-fPIC", "-shared", "-Wall"] + INC + [SRC, "-o", out]
     if kind == "ref":
         lib = os.path.join(ROOT, "oracle", "_ref", "libhavoc_ref.so")
@@ -92,6 +92,7 @@ class Client:
         L.client_bi.argtypes = [i, vp, ip, vp, vp, ip, C.POINTER(Params), vp, vp, i, i, vp]
         L.client_intra_order.argtypes = [vp, C.c_double, vp, i, vp]
         L.client_intra35.argtypes = [i, i, i, vp, ip, vp, vp, i, vp]
+        L.client_picture_uni.argtypes = [i, vp, ip, vp, vp, ip, C.POINTER(Params), vp, vp, i, i, vp, vp, vp]
         if kind == "classic":
             L.client_register.argtypes = [vp, ip, i, i, i, i, i, i]
             L.client_unregister.argtypes = [vp]
@@ -110,6 +111,19 @@ class Client:
                                pus.ctypes.data, b, e, out.ctypes.data)
         assert rc == 0
         return out
+
+    def picture_uni(self, params, src, ref0, ref1, stride, pad, pus, ctu_first, ctus_x, ctus_y, mvp_rate=(65536, 65536)):
+        """a whole picture's searches in dependency order, one table call at a time (turingcodec_amd/search/picture_order.hpp):
+        (results [2 * len(pus)], field int16 [2, cells_y, cells_x, 2])"""
+        out = np.zeros(2 * len(pus), RESULT_DT)
+        field = np.zeros((2, (params.pic_height + 3) // 4, (params.pic_width + 3) // 4, 2), np.int16)
+        rate = np.asarray(mvp_rate, np.int64)
+        pus = np.ascontiguousarray(pus)
+        ctu_first = np.ascontiguousarray(ctu_first, np.int32)
+        rc = self.L.client_picture_uni(src.itemsize, self._origin(src, stride, pad), stride, self._origin(ref0, stride, pad), self._origin(ref1, stride, pad), stride,
+                                       C.byref(params), pus.ctypes.data, ctu_first.ctypes.data, ctus_x, ctus_y, rate.ctypes.data, out.ctypes.data, field.ctypes.data)
+        assert rc == 0
+        return out, field
 
     def bi(self, params, src, ref, ref_other, stride, pad, pus, start):
         out = np.zeros(len(pus), RESULT_DT)

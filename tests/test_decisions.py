@@ -1,0 +1,73 @@
+"""The decision-driven picture step (turingcodec_amd.decisions.DecisionPicture = what `bench.py --decisions` times): motion searches in
+wavefront order with predictors derived from earlier decisions, then the TU chain on the chosen vectors -- against the same step composed
+from the reference's own compiled functions on the host (oracle/_ref: havoc tables, Rdoq.cpp) and the sequential per-call walk.
+Vectors, costs, the final motion field, coefficients, RDOQ levels, coded-block flags, SSDs and the reconstruction must agree bit for bit."""
+import os
+
+import numpy as np
+import pytest
+
+import reflibs
+import search_tools as st
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not os.path.exists(reflibs.REF_SO), reason="oracle/_ref not built")]
+
+
+def _host_chain(R, dp, field):
+    """the TU chain of DecisionPicture.tu_chain through the reference's functions, block by block"""
+    from turingcodec_amd.workload import dequant_params, picture_lambda, quant_params
+    W, PAD, stride, BD = dp.W, dp.PAD, dp.stride, dp.bd
+    src, ref0 = dp.host_planes[0], dp.host_planes[1]
+    pred = np.zeros(W * dp.H, src.dtype)
+    recon = np.zeros(dp.pe, src.dtype)
+    lam = picture_lambda(dp.qp)
+    out = []
+    for g in dp.groups:
+        log2, N, m = g["log2"], g["nn"], g["m"]
+        qs, qshift, _ = quant_params(dp.qp, log2, BD, False)
+        inv, dshift = dequant_params(dp.qp, log2, BD)
+        coef = np.zeros(m * N * N, np.int16)
+        level, deq = np.zeros_like(coef), np.zeros_like(coef)
+        cbf, ssd = np.zeros(m, np.int32), np.zeros(m, np.uint32)
+        rows = np.arange(N)[:, None]
+        for i in range(m):
+            x0, y0 = int(g["x0"][i]), int(g["y0"][i])
+            qx, qy = (int(v) for v in field[0, y0 >> 2, x0 >> 2])
+            so = (y0 + PAD) * stride + x0 + PAD
+            R.pred_uni(pred, y0 * W + x0, W, ref0, (y0 + (qy >> 2) + PAD) * stride + x0 + (qx >> 2) + PAD, stride, N, N, qx & 3, qy & 3, BD, 8)
+            r16 = src[so + rows * stride + np.arange(N)].astype(np.int16) - pred[y0 * W + x0 + rows * W + np.arange(N)].astype(np.int16)
+            R.transform(coef, i * N * N, np.ascontiguousarray(r16).ravel(), 0, N, log2, 0, BD)
+            ctu = (y0 // 64) * dp.cx + x0 // 64
+            lv, c = R.rdoq(np.ascontiguousarray(coef[i * N * N:(i + 1) * N * N]), log2, 0, 0, 0, 1, qs, qshift, inv, BD, lam, dp.rdoq_states[ctu])
+            level[i * N * N:(i + 1) * N * N] = lv
+            cbf[i] = c
+            R.quantize_inverse(deq, i * N * N, level, i * N * N, inv, dshift, N * N)
+            R.inverse_transform_add(recon, so, stride, pred, y0 * W + x0, W, deq, i * N * N, log2, 0, BD)
+            ssd[i] = R.ssd(src, so, stride, recon, so, stride, N, N)
+        out.append(dict(coef=coef, level=level, cbf=cbf, ssd=ssd))
+    return out, recon
+
+
+@pytest.mark.parametrize("res,BD,qp", [((416, 240), 8, 32), ((640, 360), 10, 27), ((640, 360), 8, 22)])
+def test_decision_step_equals_the_reference_functions(res, BD, qp):
+    from turingcodec_amd.decisions import DecisionPicture
+    from turingcodec_amd.havoc import Havoc
+    hv = Havoc(stream="new")
+    dp = DecisionPicture(hv, res[0], res[1], BD, qp, seed=21, threads=8)
+    got, field, stats = dp.step()
+    ref = st.Client("ref", 3)
+    exp, exp_field = ref.picture_uni(dp.params, dp.host_planes[0], dp.host_planes[1], dp.host_planes[2], dp.stride, dp.PAD, dp.pus, dp.ctu_first, dp.cx, dp.cy,
+                                     dp.mvp_rate)
+    for k in ("mv", "mvd", "mv_integer", "mvp_flag", "wrote_2Nx2N", "calls", "cost_integer", "cost_subpel", "cost_mvd_zero"):
+        assert np.array_equal(got[k], exp[k]), k
+    assert np.array_equal(field, exp_field)
+    assert stats.launches < len(got) and stats.steps == dp.cx + 2 * (dp.cy - 1)
+    dev, dev_recon = dp.results()
+    host, host_recon = _host_chain(reflibs.Reference(), dp, exp_field)
+    for d, h in zip(dev, host):
+        for k in ("coef", "level", "cbf", "ssd"):
+            assert np.array_equal(d[k], h[k]), (d["log2"], k)
+    assert np.array_equal(dev_recon, host_recon)
+    # the step did something: vectors moved off zero, coded and uncoded blocks
+    assert (got["mv"] != 0).any() and any((d["cbf"] != 0).any() for d in dev)
+    hv.close()

@@ -172,3 +172,57 @@ def test_decisions_on_the_gpu_equal_the_reference_1080p_clip():
     out = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out):
         json.dump(r, open(os.path.join(out, "search_report_1080p.json"), "w"), indent=1)
+
+
+# ---- a whole picture in dependency order (turingcodec_amd/search/picture_order.hpp, picture_search.cpp) ------------
+def _run_picture(device, *args, timeout=1800):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "picture_runner.py"), "--device", device] + list(args), capture_output=True, text=True,
+                         timeout=timeout, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def _check_picture(r):
+    """every field of every (PU, list) result and the final motion field equal the sequential walk over the reference's tables, although
+    the batch client ran searches ahead on guesses and in wavefront order; a handful of launches per wavefront step, not per search"""
+    assert r["mismatches"] == 0 and r["field_equal"], r
+    p = r["picture"]
+    assert p["steps"] >= 1 and p["launches"] <= 8 * p["rounds"], p
+    assert p["launches"] < r["searches"], p
+
+
+@needs_ref
+@pytest.mark.parametrize("res,bit_depth", [("416x240", 8), ("640x360", 10)])
+def test_picture_client_host_logic_on_the_mock_device(res, bit_depth):
+    """no GPU: wavefront order, derived predictors, run-ahead on guesses and roll-back, against tests/mock_device.c"""
+    r = _run_picture("mock", "--res", res, "--bit-depth", str(bit_depth), "--threads", "8", "--repeat", "1")
+    assert r["device"] == "mock" and "reference tables" in r["expected_from"]
+    _check_picture(r)
+
+
+def test_picture_walk_over_oracle_equals_walk_over_reference_tables():
+    """the sequential walk itself (the checker's arm): CPU oracle primitives vs the reference's C tables"""
+    if not HAVE_REF:
+        pytest.skip("oracle/_ref not built")
+    from turingcodec_amd import workload
+    W, H = 416, 240
+    planes, stride = st.clip_planes(W, H, 12, 8)
+    planes = [_aligned(p) for p in planes]
+    pus, first, cx, cy = workload.picture_pus(W, H, 5)
+    par = st.medium_params(W, H, 8)
+    a, fa = st.Client("oracle").picture_uni(par, planes[0], planes[1], planes[2], stride, 96, pus, first, cx, cy)
+    b, fb = st.Client("ref", 3).picture_uni(par, planes[0], planes[1], planes[2], stride, 96, pus, first, cx, cy)
+    assert a.tobytes() == b.tobytes() and np.array_equal(fa, fb)
+    # the dependency is real: predictors differ from PU to PU and are mostly non-zero on this clip
+    assert len(np.unique(a["mv"], axis=0)) > 3
+
+
+@needs_ref
+@pytest.mark.gpu
+@pytest.mark.parametrize("res,bit_depth", [("640x360", 8), ("640x360", 10), ("1920x1080", 8)])
+def test_picture_client_on_the_gpu_equals_the_reference_walk(res, bit_depth):
+    r = _run_picture("real", "--res", res, "--bit-depth", str(bit_depth), "--threads", "16")
+    _check_picture(r)
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out) and res == "1920x1080":
+        json.dump(r, open(os.path.join(out, "picture_report_1080p.json"), "w"), indent=1)

@@ -1,0 +1,218 @@
+"""Host-side binding of libhavoc_search.so's PICTURE client (turingcodec_amd/search/picture_search.cpp): a whole picture's
+uni-directional motion searches in wavefront order with predictors derived from earlier decisions (search/picture_order.hpp).
+
+Plain ctypes over raw device pointers and a havoc_mi355x context handle, so that the same binding drives the real library (bench.py,
+-m gpu tests) and the CPU stand-in device of the host-logic tests.  There is no CPU path here: the library it loads launches kernels.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .workload import PICTURE_PU_DT
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SEARCH_LIB = os.path.join(_HERE, "libhavoc_search.so")
+
+RESULT_DT = np.dtype([("mv", "i2", (2,)), ("mvd", "i2", (2,)), ("mv_integer", "i2", (2,)), ("mvp_flag", "i2"), ("wrote_2Nx2N", "i2"),
+                      ("calls", "i4"), ("replays", "i4"), ("cost_integer", "i8"), ("cost_subpel", "i8"), ("cost_mvd_zero", "i8", (2,))])
+assert RESULT_DT.itemsize == 56 and PICTURE_PU_DT.itemsize == 32
+
+
+class SearchParams(C.Structure):
+    """havoc_search_params (search/search_abi.h): what the loops read from encoder state"""
+    _fields_ = [("pic_width", C.c_int32), ("pic_height", C.c_int32), ("ctb_size", C.c_int32), ("concurrent_frames", C.c_int32),
+                ("met", C.c_int32), ("small_search_window", C.c_int32), ("bi_small_search_window", C.c_int32), ("half_pel", C.c_int32),
+                ("quarter_pel", C.c_int32), ("bit_depth", C.c_int32), ("reciprocal_sqrt_lambda", C.c_double)]
+
+
+class PictureStats(C.Structure):
+    """havoc_picture_stats"""
+    _fields_ = [("steps", C.c_int32), ("rounds", C.c_int32), ("max_rounds_in_step", C.c_int32), ("launches", C.c_int32), ("surfaces_small", C.c_int32),
+                ("surfaces_zero", C.c_int32), ("surfaces_large", C.c_int32), ("satd_jobs", C.c_int32), ("speculative_runs", C.c_int32), ("reruns", C.c_int32),
+                ("bytes_down", C.c_int64), ("seconds_gpu", C.c_double), ("seconds_host", C.c_double), ("seconds_total", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+def medium_params(width, height, bit_depth, reciprocal_sqrt_lambda, concurrent_frames=4):
+    """speed=medium: multiple early termination on, full search window, half- and quarter-sample refinement (turing/Speed.h)"""
+    return SearchParams(width, height, 64, concurrent_frames, 1, 0, 0, 1, 1, bit_depth, reciprocal_sqrt_lambda)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SEARCH_LIB):
+            raise RuntimeError(f"{SEARCH_LIB} is missing: build it with `make -C turingcodec_amd/csrc` -- there is no fallback path")
+        L = C.CDLL(SEARCH_LIB)
+        vp, ip, i64 = C.c_void_p, C.c_ssize_t, C.c_int64
+        L.havoc_search_picture_uni.argtypes = [vp, C.c_int, C.POINTER(SearchParams), vp, i64, ip, vp, C.POINTER(i64), ip, C.c_int, vp, ip, C.POINTER(i64),
+                                               vp, vp, C.c_int, C.c_int, C.POINTER(i64), vp, vp, C.c_int, C.POINTER(PictureStats)]
+        L.havoc_search_picture_uni.restype = C.c_int
+        L.havoc_search_release.argtypes = [vp]
+        L.havoc_search_release.restype = None
+        _lib = L
+    return _lib
+
+
+def picture_uni(ctx, S, params, d_src, src_origin, src_stride, d_ref, ref_origin, ref_stride, ref_pad, d_phase, plane_elems, phase_origin, pus, ctu_first,
+                ctus_x, ctus_y, mvp_rate=(65536, 65536), threads=16, want_field=True):
+    """havoc_search_picture_uni.  ctx: havoc_mi355x context handle (int / c_void_p); d_*: device addresses (ints); ref_origin / phase_origin:
+    pairs (list 0, list 1).  Returns (results [2 * len(pus)] RESULT_DT indexed 2 * p + list, field int16 [2, cells_y, cells_x, 2] or None, stats)."""
+    pus = np.ascontiguousarray(pus)
+    assert pus.dtype == PICTURE_PU_DT
+    ctu_first = np.ascontiguousarray(ctu_first, np.int32)
+    out = np.zeros(2 * len(pus), RESULT_DT)
+    cw, ch = (params.pic_width + 3) // 4, (params.pic_height + 3) // 4
+    field = np.zeros((2, ch, cw, 2), np.int16) if want_field else None
+    stats = PictureStats()
+    ro = (C.c_int64 * 2)(*[int(v) for v in ref_origin])
+    po = (C.c_int64 * 2)(*[int(v) for v in phase_origin])
+    mr = (C.c_int64 * 2)(*[int(v) for v in mvp_rate])
+    rc = lib().havoc_search_picture_uni(ctx, S, C.byref(params), d_src, int(src_origin), src_stride, d_ref, ro, ref_stride, ref_pad, d_phase, plane_elems, po,
+                                        pus.ctypes.data, ctu_first.ctypes.data, ctus_x, ctus_y, mr, out.ctypes.data,
+                                        field.ctypes.data if want_field else None, threads, C.byref(stats))
+    if rc != 0:
+        raise RuntimeError(f"havoc_search_picture_uni failed ({rc})")
+    return out, field, stats
+
+
+def decision_inputs(width, height, bit_depth=8, qp=32, seed=11, density=1.0, frames=None):
+    """host side of a DecisionPicture: padded luma planes (source, list 0, list 1), the picture's PUs in decision order, search parameters"""
+    from . import workload
+    pad = 96
+    if frames is None:
+        frames = workload.synth_frames(width, height, 3, seed, bit_depth)
+    planes = [workload.pad_plane(f[0], pad) for f in (frames[1], frames[0], frames[2])]
+    stride = planes[0].shape[1]
+    pus, ctu_first, cx, cy = workload.picture_pus(width, height, seed, density)
+    lam = workload.picture_lambda(qp)
+    return dict(planes=[np.ascontiguousarray(p.ravel()) for p in planes], stride=stride, pad=pad, pus=pus, ctu_first=ctu_first, cx=cx, cy=cy,
+                params=medium_params(width, height, bit_depth, 1.0 / np.sqrt(lam)), mvp_rate=(45000, 98000), lam=lam)
+
+
+class DecisionPicture:
+    """One inter picture through the DECISION-DRIVEN path on the device (bench.py --decisions, tests/test_decisions.py):
+
+      1. the 15 fractional-sample planes of both reference pictures (havoc_mi355x_interp_planes);
+      2. every PU's uni-directional search in both lists, CTUs in wavefront order, predictors derived from the vectors decided before
+         (libhavoc_search.so: havoc_search_picture_uni) -- the searches are fed by batch launches, the loops replay on host threads;
+      3. the TU chain ON THE CHOSEN VECTORS: HavocPredUni of every 16x16 block (8x8 in a last partial row) at the list-0 vector the
+         search left for it -> residual + forward DCT -> Rdoq::runQuantisation -> de-quantise + inverse DCT + add -> SSD
+         (one launch per primitive and block size; job tables are built from the decided motion field, i.e. they cannot exist before 2).
+
+    What is NOT in it (stated, not hidden): the encoder's mode decision between the searched PUs (every PU of workload.picture_pus is
+    searched and the last one covering an area stands), bi-prediction, intra candidates and CABAC.  `step()` is what bench.py times."""
+
+    PAD = 96
+
+    def __init__(self, hv, width, height, bit_depth=8, qp=32, seed=11, threads=16, frames=None, density=1.0):
+        import torch
+        from . import havoc as hmod
+        from . import workload
+        self.hv, self.torch, self.hmod = hv, torch, hmod
+        self.W, self.H, self.bd, self.qp, self.threads = width, height, bit_depth, qp, threads
+        self.S = 1 if bit_depth == 8 else 2
+        self.dt = np.uint8 if self.S == 1 else np.uint16
+        d = decision_inputs(width, height, bit_depth, qp, seed, density, frames)
+        self.stride = d["stride"]
+        self.host_planes = d["planes"]                            # source, list 0, list 1
+        self.n = self.host_planes[0].size
+        self.pe = (self.n + 63) & ~63
+        self.origin = self.PAD * self.stride + self.PAD
+        pic = np.zeros(3 * self.pe, self.dt)
+        for k, p in enumerate(self.host_planes):
+            pic[k * self.pe:k * self.pe + self.n] = p
+        self.d_pic = hv.up(pic)                                   # one allocation: a job names a plane by a 32-bit sample offset
+        self.d_phase = hv.zeros(32 * self.pe, self.dt)            # 2 references x 16 phase planes
+        self.pus, self.ctu_first, self.cx, self.cy = d["pus"], d["ctu_first"], d["cx"], d["cy"]
+        lam = d["lam"]
+        self.params, self.mvp_rate = d["params"], d["mvp_rate"]
+        # ---- TU chain: 16x16 blocks over the rows that hold whole ones, 8x8 blocks over a last partial row
+        self.groups = []
+        h16 = height // 16 * 16
+        for log2, y_lo, y_hi in ((4, 0, h16), (3, h16, height // 8 * 8)):
+            nn = 1 << log2
+            if y_hi <= y_lo:
+                continue
+            xs, ys = np.meshgrid(np.arange(0, width // nn * nn, nn), np.arange(y_lo, y_hi, nn))
+            x0, y0 = xs.ravel().astype(np.int64), ys.ravel().astype(np.int64)
+            m = len(x0)
+            qs, qshift, _ = workload.quant_params(qp, log2, bit_depth, False)
+            inv, dshift = workload.dequant_params(qp, log2, bit_depth)
+            fj = np.zeros((m, 4), np.int32)
+            fj[:, 0] = np.arange(m) * nn * nn
+            fj[:, 1] = fj[:, 3] = (y0 + self.PAD) * self.stride + x0 + self.PAD
+            fj[:, 2] = y0 * width + x0
+            jobs = np.zeros(m, hmod.RDOQ_JOB_DT)
+            jobs["dst_off"] = jobs["src_off"] = fj[:, 0]
+            jobs["quant_scale"], jobs["quant_shift"], jobs["inv_scale"] = qs, qshift, inv
+            jobs["lambda_q16"], jobs["sdh_factor"] = hmod.rdoq_lambda(lam, inv)
+            jobs["sdh"] = 1
+            jobs["ctx_index"] = (y0 // 64) * self.cx + x0 // 64
+            with torch.cuda.stream(hv.tstream):
+                d_rj = torch.from_numpy(jobs.view(np.uint8).reshape(-1)).to(hv.device)
+            self.groups.append(dict(log2=log2, nn=nn, x0=x0, y0=y0, m=m, inv=inv, dshift=dshift, d_fj=hv.up(fj), d_rj=d_rj,
+                                    pj=np.zeros((m, 8), np.int32), d_pj=hv.zeros(m * 8, np.int32), coef=hv.zeros(m * nn * nn, np.int16),
+                                    level=hv.zeros(m * nn * nn, np.int16), cbf=hv.zeros(m, np.int32), ssd=hv.zeros(m, np.uint32),
+                                    work=hv.rdoq_workspace(m)))
+        srng = np.random.default_rng(seed + 7919)
+        base = srng.integers(4, 100, 128)
+        self.rdoq_states = np.clip(base[None, :] + srng.integers(-6, 7, (self.cx * self.cy, 128)), 0, 125).astype(np.uint8)
+        self.d_states = hv.up(self.rdoq_states.reshape(-1))
+        self.pred = hv.zeros(width * height, self.dt)
+        self.recon = hv.zeros(self.pe, self.dt)
+        hv.sync()
+
+    def phase_planes(self):
+        hv, pe, S = self.hv, self.pe, self.S
+        for r in (0, 1):
+            ph = self.d_phase[r * 16 * pe:(r + 1) * 16 * pe]
+            ref = self.d_pic[(1 + r) * pe:(2 + r) * pe]
+            with self.torch.cuda.stream(hv.tstream):
+                ph[:pe] = ref                                   # phase 0 = the picture itself
+            hv.interp_planes_d(self.bd, ph, pe, ref, self.stride, 12, 4, self.W + 2 * self.PAD - 24, self.H + 2 * self.PAD - 8)
+
+    def search(self):
+        hv, pe, o = self.hv, self.pe, self.origin
+        base, ph = self.d_pic.data_ptr(), self.d_phase.data_ptr()
+        return picture_uni(hv.h, self.S, self.params, base, o, self.stride, base, (pe + o, 2 * pe + o), self.stride, self.PAD, ph, pe, (o, 16 * pe + o),
+                           self.pus, self.ctu_first, self.cx, self.cy, self.mvp_rate, self.threads)
+
+    def tu_chain(self, field):
+        """prediction at the decided list-0 vectors, then residual -> T -> RDOQ -> IQ -> IT + add -> SSD; asynchronous"""
+        hv, bd, pe = self.hv, self.bd, self.pe
+        ref0 = self.d_pic[pe:2 * pe]
+        src = self.d_pic[:pe]
+        for g in self.groups:
+            mv = field[0, g["y0"] >> 2, g["x0"] >> 2].astype(np.int64)          # quarter samples, [m, 2]
+            pj = g["pj"]
+            pj[:, 0] = g["y0"] * self.W + g["x0"]
+            pj[:, 1] = (g["y0"] + (mv[:, 1] >> 2) + self.PAD) * self.stride + g["x0"] + (mv[:, 0] >> 2) + self.PAD
+            pj[:, 2] = pj[:, 3] = g["nn"]
+            pj[:, 4], pj[:, 5] = mv[:, 0] & 3, mv[:, 1] & 3
+            with self.torch.cuda.stream(hv.tstream):
+                g["d_pj"].copy_(self.torch.from_numpy(pj.reshape(-1)), non_blocking=True)
+            hv.pred_uni_d(8, bd, self.pred, self.W, ref0, self.stride, g["d_pj"].view(-1, 8), g["nn"], g["nn"])
+            hv.tu_forward_d(bd, 0, g["log2"], g["coef"], src, self.stride, self.pred, self.W, g["d_fj"])
+            hv.rdoq_d(bd, g["log2"], g["level"], g["coef"], self.d_states, g["d_rj"], g["cbf"], g["work"])
+            hv.tu_reconstruct_d(bd, 0, g["log2"], g["inv"], g["dshift"], self.recon, self.stride, self.pred, self.W, src, self.stride, g["level"], g["d_fj"], g["ssd"])
+
+    def step(self):
+        self.phase_planes()
+        res, field, stats = self.search()
+        self.tu_chain(field)
+        self.hv.sync()
+        return res, field, stats
+
+    def results(self):
+        """what the TU chain left on the device, as numpy (per group): coefficients, levels, flags, SSDs; and the reconstruction"""
+        hv = self.hv
+        out = [dict(log2=g["log2"], coef=hv.down(g["coef"], np.int16), level=hv.down(g["level"], np.int16), cbf=hv.down(g["cbf"], np.int32),
+                    ssd=hv.down(g["ssd"], np.uint32)) for g in self.groups]
+        return out, hv.down(self.recon, self.dt)

@@ -42,6 +42,29 @@ typedef struct
     int64_t cost_integer, cost_subpel, cost_mvd_zero[2];
 } havoc_search_result;             /* 56 bytes */
 
+/* ---- a whole picture's uni-directional searches, in an order the encoder could issue them (picture_order.hpp) ----
+ * One prediction unit; the picture's PUs come CTU by CTU (raster order), inside a CTU in the order the quadtree search meets them
+ * (turing/Search.hpp:708-887: a coding unit's part modes, then its four sub-units in z-order).  Each PU is searched in list 0, then list 1
+ * (searchMotionUni(L0, 0), (L1, 0), Search.hpp:1883-1884) with predictors DERIVED from the vectors decided before it. */
+typedef struct
+{
+    int32_t x0, y0, w, h;
+    int32_t cu_log2_size, cqt_depth, part_2Nx2N;
+    int32_t reserved;
+} havoc_picture_pu;                /* 32 bytes */
+
+typedef struct
+{
+    int32_t steps;                 /* wavefront steps (CTU anti-diagonals with the two-CTU lag of WPP) */
+    int32_t rounds;                /* launch + replay rounds over all steps */
+    int32_t max_rounds_in_step;
+    int32_t launches, surfaces_small, surfaces_zero, surfaces_large, satd_jobs;
+    int32_t speculative_runs;      /* searches run ahead on a guessed predecessor */
+    int32_t reruns;                /* searches run again because the guess was wrong or data was missing */
+    int64_t bytes_down;
+    double seconds_gpu, seconds_host, seconds_total;
+} havoc_picture_stats;
+
 /* 35-mode intra stage: per partition */
 typedef struct
 {

@@ -49,6 +49,54 @@ TU_MIX = [(5, 0, 94163), (4, 0, 350559), (3, 0, 587269), (2, 0, 334902), (2, 1, 
 INTRA_MIX = [(5, 9), (4, 36), (3, 50), (2, 5)]
 
 
+# (PartMode, [(dx, dy, w, h) in quarters of the CU size]) -- the part modes of turing/Search.hpp's inter loop
+PART_MODES = [("2Nx2N", [(0, 0, 4, 4)]), ("2NxN", [(0, 0, 4, 2), (0, 2, 4, 2)]), ("Nx2N", [(0, 0, 2, 4), (2, 0, 2, 4)]),
+              ("2NxnU", [(0, 0, 4, 1), (0, 1, 4, 3)]), ("2NxnD", [(0, 0, 4, 3), (0, 3, 4, 1)]), ("nLx2N", [(0, 0, 1, 4), (1, 0, 3, 4)]),
+              ("nRx2N", [(0, 0, 3, 4), (3, 0, 1, 4)])]
+PICTURE_PU_DT = np.dtype([("x0", "i4"), ("y0", "i4"), ("w", "i4"), ("h", "i4"), ("cu_log2_size", "i4"), ("cqt_depth", "i4"), ("part_2Nx2N", "i4"),
+                          ("reserved", "i4")])   # havoc_picture_pu, turingcodec_amd/search/search_abi.h
+
+
+def picture_pus(width, height, seed, density=1.0):
+    """The prediction units of one picture whose motion is searched, CTU by CTU in raster order and inside a CTU in the order the quadtree
+    search meets them (a coding unit's part modes -- 2Nx2N first -- then its four sub-units in z-order, turing/Search.hpp:708-887).
+    Which units are searched is the encoder's (data-dependent) decision; here it is drawn at random so that a 1080p picture has about the
+    5 900 (PU, list) searches SURVEY Appendix A.2 measured (~5.8 PUs per CTU, two lists each).  A coding unit that crosses the picture edge
+    is split (as the encoder must).  Returns (pus [PICTURE_PU_DT], ctu_first int32 [ctus + 1], ctus_x, ctus_y)."""
+    rng = np.random.default_rng(seed)
+    p_2n = {6: 1.0, 5: 0.6, 4: 0.5, 3: 0.5}      # P(2Nx2N of a visited CU is searched)
+    p_rect = {6: 0.25, 5: 0.15, 4: 0.10, 3: 0.0}  # P(one two-PU part mode is searched as well)
+    p_split = {6: 0.5, 5: 0.25, 4: 0.15}          # P(the four sub-units are visited)
+    rows = []
+
+    def cu(x, y, log2):
+        if x >= width or y >= height:
+            return
+        size = 1 << log2
+        whole = x + size <= width and y + size <= height
+        if whole:
+            if rng.random() < min(1.0, p_2n[log2] * density):
+                rows.append((x, y, size, size, log2, 6 - log2, 1, 0))
+            if rng.random() < p_rect[log2] * density:
+                modes = PART_MODES[1:3] if log2 == 3 else PART_MODES[1:]
+                _, parts = modes[int(rng.integers(0, len(modes)))]
+                q = size // 4
+                for dx, dy, w4, h4 in parts:
+                    rows.append((x + dx * q, y + dy * q, w4 * q, h4 * q, log2, 6 - log2, 0, 0))
+        if log2 > 3 and (not whole or rng.random() < p_split[log2] * density):
+            for k in range(4):
+                cu(x + (k & 1) * size // 2, y + (k >> 1) * size // 2, log2 - 1)
+
+    ctus_x, ctus_y = (width + CTU - 1) // CTU, (height + CTU - 1) // CTU
+    first = [0]
+    for cy in range(ctus_y):
+        for cx in range(ctus_x):
+            cu(cx * CTU, cy * CTU, 6)
+            first.append(len(rows))
+    pus = np.array(rows, dtype=np.int32).reshape(-1, 8).view(PICTURE_PU_DT).reshape(-1)
+    return np.ascontiguousarray(pus), np.asarray(first, np.int32), ctus_x, ctus_y
+
+
 def synth_frames(width, height, nframes, seed, bit_depth=8):
     """SURVEY.md 8(d) generator: low-passed noise translating by (3,2) px/frame blended 60/40 with a moving
     sinusoid, +-3 uniform noise; smooth chroma ramps.  Returns [(Y, U, V)] unpadded planes."""
