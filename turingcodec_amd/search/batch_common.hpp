@@ -113,33 +113,38 @@ static_assert(std::is_trivially_destructible<MotionSearch<BatchView>>::value && 
               "a stopped replay leaves by longjmp: nothing on its stack may need a destructor");
 
 // Replay threads of one call: started once, handed a round's work through run() (each round is a few thousand replays of a few
-// microseconds: starting 15 threads per round cost as much as the round)
+// microseconds: starting 15 threads per round cost as much as the round).  Rounds follow each other within tens of microseconds, so an
+// idle worker first spins on the generation counter (no system call on either side in the steady state) and only then sleeps.
 class ReplayThreads
 {
     std::vector<std::thread> threads_;
     std::mutex m_;
-    std::condition_variable wake_, done_;
+    std::condition_variable wake_;
     std::function<void()> work_;
-    int generation_ = 0, busy_ = 0;
-    bool quit_ = false;
+    std::atomic<int> generation_{0}, busy_{0}, sleepers_{0};
+    std::atomic<bool> quit_{false};
+    static void relax() { __builtin_ia32_pause(); }
     void loop()
     {
         int seen = 0;
         for (;;)
         {
-            std::function<void()> w;
+            int spins = 0;
+            while (generation_.load(std::memory_order_acquire) == seen && !quit_.load(std::memory_order_relaxed))
             {
-                std::unique_lock<std::mutex> l(m_);
-                wake_.wait(l, [&] { return quit_ || generation_ != seen; });
-                if (quit_) return;
-                seen = generation_;
-                w = work_;
+                if (++spins < 4000) relax();       // ~40 us
+                else
+                {
+                    std::unique_lock<std::mutex> l(m_);
+                    sleepers_.fetch_add(1);
+                    wake_.wait(l, [&] { return quit_.load() || generation_.load() != seen; });
+                    sleepers_.fetch_sub(1);
+                }
             }
-            w();
-            {
-                std::lock_guard<std::mutex> l(m_);
-                if (--busy_ == 0) done_.notify_one();
-            }
+            if (quit_.load()) return;
+            seen = generation_.load(std::memory_order_acquire);
+            work_();
+            busy_.fetch_sub(1, std::memory_order_release);
         }
     }
 public:
@@ -157,19 +162,19 @@ public:
         for (auto &t : threads_) t.join();
     }
     int extra() const { return int(threads_.size()); }
-    // every pool thread and the caller run `w` once; returns when all have
+    // every pool thread and the caller run `w` once; returns when all have (work_ is only written while no worker runs: busy_ == 0)
     void run(const std::function<void()> &w)
     {
+        work_ = w;
+        busy_.store(int(threads_.size()), std::memory_order_relaxed);
+        generation_.fetch_add(1, std::memory_order_release);
+        if (sleepers_.load() > 0)
         {
             std::lock_guard<std::mutex> l(m_);
-            work_ = w;
-            busy_ = int(threads_.size());
-            ++generation_;
+            wake_.notify_all();
         }
-        wake_.notify_all();
         w();
-        std::unique_lock<std::mutex> l(m_);
-        done_.wait(l, [&] { return busy_ == 0; });
+        while (busy_.load(std::memory_order_acquire) != 0) relax();
     }
 };
 
@@ -230,10 +235,10 @@ inline double now()
 // (allocating pinned memory costs milliseconds; a picture's searches need the same amount every time).
 struct Pool
 {
-    struct Chunk { char *dev, *host; size_t cap, used; };
+    struct Chunk { char *dev, *host, *hostDev; size_t cap, used; };   // hostDev: the device's view of the pinned host chunk
     std::vector<Chunk> chunks;
     void reset() { for (Chunk &c : chunks) c.used = 0; }
-    int get(havoc_mi355x_ctx *ctx, size_t bytes, void **d, void **h)
+    int get(havoc_mi355x_ctx *ctx, size_t bytes, void **d, void **h, void **hd = nullptr)
     {
         bytes = (bytes + 255) & ~size_t(255);
         for (Chunk &c : chunks)
@@ -241,24 +246,27 @@ struct Pool
             {
                 *d = c.dev + c.used;
                 *h = c.host + c.used;
+                if (hd) *hd = c.hostDev + c.used;
                 c.used += bytes;
                 return 0;
             }
-        Chunk c{nullptr, nullptr, std::max(bytes, size_t(64) << 20), 0};
-        void *dp = nullptr, *hp = nullptr, *hd = nullptr;
+        Chunk c{nullptr, nullptr, nullptr, std::max(bytes, size_t(64) << 20), 0};
+        void *dp = nullptr, *hp = nullptr, *hdp = nullptr;
         int rc = havoc_mi355x_malloc(ctx, &dp, c.cap);
         if (rc) return rc;
-        if ((rc = havoc_mi355x_host_alloc(ctx, c.cap, &hp, &hd)))
+        if ((rc = havoc_mi355x_host_alloc(ctx, c.cap, &hp, &hdp)))
         {
             (void)havoc_mi355x_free(ctx, dp);
             return rc;
         }
         c.dev = static_cast<char *>(dp);
         c.host = static_cast<char *>(hp);
+        c.hostDev = static_cast<char *>(hdp);
         c.used = bytes;
         chunks.push_back(c);
         *d = c.dev;
         *h = c.host;
+        if (hd) *hd = c.hostDev;
         return 0;
     }
     void release(havoc_mi355x_ctx *ctx)
@@ -280,7 +288,7 @@ struct Arena   // one call's view of its context's pool (a context runs one call
     havoc_mi355x_ctx *ctx;
     Pool *pool;
     explicit Arena(havoc_mi355x_ctx *c) : ctx(c), pool(poolOf(c)) { pool->reset(); }
-    int get(size_t bytes, void **d, void **h) { return pool->get(ctx, bytes, d, h); }
+    int get(size_t bytes, void **d, void **h, void **hd = nullptr) { return pool->get(ctx, bytes, d, h, hd); }
 };
 
 #define HAVOC_SEARCH_RC(call) do { const int rc_ = (call); if (rc_) return rc_; } while (0)
@@ -312,6 +320,9 @@ struct Launcher
     int W, H;
     Arena *arena;
     havoc_search_stats *stt;
+    // direct: the kernels read their job tables from, and write their results to, the pinned host memory itself (its device view) -- no
+    // staging copies.  What a round costs is then launches + one synchronisation; right for many small rounds (picture_search.cpp).
+    bool direct = false;
 
     // where a surface of half-width R may be centred so that its window stays inside the padded plane
     bool clampCentre(const Geom &q, int R, int *cx, int *cy) const
@@ -329,9 +340,14 @@ struct Launcher
     {
         if (w.empty()) return 0;
         const int side = 2 * R + 1;
-        void *dJobs, *hJobs, *dOut, *hOut;
-        HAVOC_SEARCH_RC(arena->get(w.size() * sizeof(havoc_mi355x_surface_job), &dJobs, &hJobs));
-        HAVOC_SEARCH_RC(arena->get(w.size() * size_t(side) * side * 4, &dOut, &hOut));
+        void *dJobs, *hJobs, *dOut, *hOut, *vJobs, *vOut;
+        HAVOC_SEARCH_RC(arena->get(w.size() * sizeof(havoc_mi355x_surface_job), &dJobs, &hJobs, &vJobs));
+        HAVOC_SEARCH_RC(arena->get(w.size() * size_t(side) * side * 4, &dOut, &hOut, &vOut));
+        if (direct)
+        {
+            dJobs = vJobs;
+            dOut = vOut;
+        }
         havoc_mi355x_surface_job *jobs = static_cast<havoc_mi355x_surface_job *>(hJobs);
         for (size_t k = 0; k < w.size(); ++k)
         {
@@ -340,10 +356,10 @@ struct Launcher
                        int32_t(k * size_t(side) * side), {0, 0, 0}};
             state[w[k].i].surfaces.push_back({w[k].cx, w[k].cy, R, static_cast<const int32_t *>(hOut) + k * size_t(side) * side});
         }
-        HAVOC_SEARCH_RC(havoc_mi355x_h2d_async(ctx, dJobs, hJobs, w.size() * sizeof(havoc_mi355x_surface_job)));
+        if (!direct) HAVOC_SEARCH_RC(havoc_mi355x_h2d_async(ctx, dJobs, hJobs, w.size() * sizeof(havoc_mi355x_surface_job)));
         HAVOC_SEARCH_RC(havoc_mi355x_sad_surface(ctx, S, R, 64, 64, d_src, src_stride, d_ref, ref_stride, static_cast<const havoc_mi355x_surface_job *>(dJobs),
                                                  int(w.size()), static_cast<int32_t *>(dOut)));
-        HAVOC_SEARCH_RC(havoc_mi355x_d2h_async(ctx, hOut, dOut, w.size() * size_t(side) * side * 4));
+        if (!direct) HAVOC_SEARCH_RC(havoc_mi355x_d2h_async(ctx, hOut, dOut, w.size() * size_t(side) * side * 4));
         ++stt->launches;
         (large ? stt->surfaces_large : stt->surfaces_small) += int32_t(w.size());
         stt->bytes_down += int64_t(w.size() * size_t(side) * side * 4);
@@ -377,9 +393,14 @@ struct Launcher
                 if (rows > c.lo && rows <= c.hi) sel.push_back(int(k));
             }
             if (sel.empty()) continue;
-            void *dJobs, *hJobs, *dOut, *hOut;
-            HAVOC_SEARCH_RC(arena->get(sel.size() * 4 * sizeof(havoc_mi355x_satd_multi_job), &dJobs, &hJobs));
-            HAVOC_SEARCH_RC(arena->get(sel.size() * 64 * 4, &dOut, &hOut));
+            void *dJobs, *hJobs, *dOut, *hOut, *vJobs, *vOut;
+            HAVOC_SEARCH_RC(arena->get(sel.size() * 4 * sizeof(havoc_mi355x_satd_multi_job), &dJobs, &hJobs, &vJobs));
+            HAVOC_SEARCH_RC(arena->get(sel.size() * 64 * 4, &dOut, &hOut, &vOut));
+            if (direct)
+            {
+                dJobs = vJobs;
+                dOut = vOut;
+            }
             havoc_mi355x_satd_multi_job *jobs = static_cast<havoc_mi355x_satd_multi_job *>(hJobs);
             int32_t *res = batch[ci].res = static_cast<int32_t *>(hOut);
             for (size_t k = 0; k < sel.size(); ++k)
@@ -412,10 +433,10 @@ struct Launcher
                     }
                 }
             }
-            HAVOC_SEARCH_RC(havoc_mi355x_h2d_async(ctx, dJobs, hJobs, sel.size() * 4 * sizeof(havoc_mi355x_satd_multi_job)));
+            if (!direct) HAVOC_SEARCH_RC(havoc_mi355x_h2d_async(ctx, dJobs, hJobs, sel.size() * 4 * sizeof(havoc_mi355x_satd_multi_job)));
             HAVOC_SEARCH_RC(havoc_mi355x_satd_multi(ctx, S, c.mw, c.mh, d_src, src_stride, d_phase, ref_stride, static_cast<const havoc_mi355x_satd_multi_job *>(dJobs),
                                                     int(sel.size() * 4), static_cast<int32_t *>(dOut)));
-            HAVOC_SEARCH_RC(havoc_mi355x_d2h_async(ctx, hOut, dOut, sel.size() * 64 * 4));
+            if (!direct) HAVOC_SEARCH_RC(havoc_mi355x_d2h_async(ctx, hOut, dOut, sel.size() * 64 * 4));
             ++stt->launches;
             stt->satd_jobs += int32_t(sel.size() * 4);
             stt->bytes_down += int64_t(sel.size() * 64 * 4);

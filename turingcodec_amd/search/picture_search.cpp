@@ -22,6 +22,8 @@
 // (tests/test_search.py::test_picture_*).
 #include "batch_common.hpp"
 #include "picture_order.hpp"
+#include <cstdio>
+#include <cstdlib>
 
 using namespace havoc_search;
 
@@ -79,6 +81,7 @@ int havoc_search_picture_uni(havoc_mi355x_ctx *ctx, int S, const havoc_search_pa
     std::memset(&stt, 0, sizeof(stt));
     Arena arena(ctx);
     Launcher launch{ctx, S, d_src, src_stride, d_ref, ref_stride, ref_pad, d_phase, plane_elems, W, H, &arena, &stt};
+    launch.direct = getenv("HAVOC_PICTURE_STAGED") == nullptr;     // diagnostic switch: staged copies instead of mapped host memory
 
     std::vector<SearchState> state(n);
     std::vector<Geom> geom(n);
@@ -231,6 +234,8 @@ int havoc_search_picture_uni(havoc_mi355x_ctx *ctx, int S, const havoc_search_pa
                             {
                                 // sub-sample data missing: ask for the 49 positions around the integer vector and run ahead on that vector
                                 integerMv = st.integer.best.mv;
+                                if (getenv("HAVOC_PICTURE_DEBUG") && st.haveSub)
+                                    fprintf(stderr, "resub d=%d,%d\n", ((st.miss.x + 2) >> 2) * 4 - st.subCx, ((st.miss.y + 2) >> 2) * 4 - st.subCy);
                                 mySub.push_back({i, ((st.miss.x + 2) >> 2) * 4, ((st.miss.y + 2) >> 2) * 4});
                                 decided = integerMv;
                                 wrote = st.integer.wrote2Nx2N;
@@ -239,9 +244,18 @@ int havoc_search_picture_uni(havoc_mi355x_ctx *ctx, int S, const havoc_search_pa
                             else if (st.miss.kind == 1)
                             {
                                 int cx = st.miss.x, cy = st.miss.y;
-                                if (!launch.clampCentre(geom[i], kR1, &cx, &cy) || std::abs(cx - st.miss.x) > kR1 || std::abs(cy - st.miss.y) > kR1) bad = 1;
-                                else myLarge.push_back({i, cx, cy});
-                                break;      // nothing sensible to guess: the chain waits for the surface
+                                if (!launch.clampCentre(geom[i], kR1, &cx, &cy) || std::abs(cx - st.miss.x) > kR1 || std::abs(cy - st.miss.y) > kR1)
+                                {
+                                    bad = 1;
+                                    break;
+                                }
+                                myLarge.push_back({i, cx, cy});
+                                // the integer stage left its surfaces: guess the first predictor (rounded to full samples) for this search, so that
+                                // the searches after it can still say what they need in this round
+                                decided = shl2(shr2(Mv(int16_t(pu.mvp[0].x + 2), int16_t(pu.mvp[0].y + 2))));
+                                integerMv = decided;
+                                wrote = pu.part2Nx2N;
+                                guessing = true;
                             }
                             else
                             {
