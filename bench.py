@@ -1123,8 +1123,13 @@ def decision_path(args, Havoc, res, bit_depth, qp, pictures, seconds=1.5, keep=N
            "seconds_measured": round(el, 3), "pictures_done": int(sum(done)),
            "one_picture_alone_ms": round(min(lat) * 1e3, 3),
            "one_picture_alone_split_ms": {"phase_planes": round(t_planes * 1e3, 3), "searches_in_wavefront_order": round(t_search * 1e3, 3),
-                                          "tu_chain_on_chosen_vectors": round(t_chain * 1e3, 3)},
-           "searches_per_picture": int(2 * len(solo.pus)), "ctus": solo.cx * solo.cy, "tu_blocks": int(sum(g["m"] for g in solo.groups)),
+                                          "prediction_and_transform_tree_decisions": round(t_chain * 1e3, 3)},
+           "searches_per_picture": int(2 * len(solo.pus)), "ctus": solo.cx * solo.cy,
+           "transform_tree_decisions": {"units": int(len(solo.units)), "candidates": int(solo.rqt_stats.candidates), "launches": int(solo.rqt_stats.launches),
+                                        "launches_per_ctu": round(solo.rqt_stats.launches / (solo.cx * solo.cy), 4),
+                                        "split": int((solo.rqt_results["depth"] == 1).sum()), "unsplit": int(((solo.rqt_results["depth"] == 0) & (solo.rqt_results["tried_zero"] == 1)).sum()),
+                                        "uncoded": int((solo.rqt_results["tried_zero"] == 0).sum()),
+                                        "seconds": {"gpu": round(solo.rqt_stats.seconds_gpu, 5), "host": round(solo.rqt_stats.seconds_host, 5)}},
            "wavefront_steps": d["steps"], "rounds": d["rounds"], "rounds_per_step": round(d["rounds"] / max(1, d["steps"]), 2),
            "max_rounds_in_step": d["max_rounds_in_step"], "launches": d["launches"], "launches_per_step": round(d["launches"] / max(1, d["steps"]), 2),
            "surfaces": d["surfaces_small"] + d["surfaces_zero"] + d["surfaces_large"], "satd_jobs": d["satd_jobs"],
@@ -1133,8 +1138,10 @@ def decision_path(args, Havoc, res, bit_depth, qp, pictures, seconds=1.5, keep=N
            "what": "per picture: 2 x 15 phase planes; every PU's uni-directional search in both lists, CTUs in WPP wavefront order (CTU (x, y) after "
                    "(x + 1, y - 1)), predictors of a PU = the vectors decided for its left / upper neighbours, mvPreviousInteger2Nx2N handed along the CTU "
                    "row (turingcodec_amd/search/picture_order.hpp) -- fed by SAD-surface / tile-SATD batch launches, the reference's loops replayed on "
-                   "host threads; then prediction at the chosen vectors -> residual + DCT -> RDOQ -> IQ + IDCT + add -> SSD for every 16x16 block. "
-                   "Not in it: the mode decision between the searched PUs, bi-prediction, intra, CABAC"}
+                   "host threads; then prediction at the chosen vectors and the residual-quadtree decision of every inter unit (both tree depths of "
+                   "every 32x32 unit through residual + DCT -> RDOQ -> IQ + IDCT + add -> SSD in one chain per transform size, decisions from 16 bytes per "
+                   "candidate, chosen candidates reconstructed into the picture; turingcodec_amd/search/tu_decision.hpp). "
+                   "Not in it: the mode decision between the searched PUs, bi-prediction, intra, CABAC (the rate term of the tree decision is a stand-in)"}
     out.update(more)
     if keep is not None:
         keep["solo"], keep["res"], keep["field"] = solo, res0, field0

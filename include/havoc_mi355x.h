@@ -364,6 +364,12 @@ int havoc_mi355x_tu_reconstruct(havoc_mi355x_ctx *ctx, int S, int bitDepth, int 
                                 intptr_t stride_rec, const void *d_pred, intptr_t stride_pred, const void *d_src, intptr_t stride_src,
                                 const int16_t *d_levels, const havoc_mi355x_tu_fused_job *d_jobs, int njobs, uint32_t *d_ssd);
 
+/* What a rate estimate reads of a block of quantised levels, without the levels crossing the link: d_out[2 * i] = number of non-zero
+ * levels, d_out[2 * i + 1] = sum of |level| of the block d_jobs[2 * i] (int16 offset, multiple of 2) of d_jobs[2 * i + 1] values (multiple
+ * of 2).  Not a reference primitive: the reference's EstimateRate<residual_coding> (turing/EstimateRate.h) walks the levels on the host; a
+ * batch client that chooses between transform-tree candidates (libhavoc_search.so: havoc_search_rqt) reads these instead. */
+int havoc_mi355x_level_stats(havoc_mi355x_ctx *ctx, const int16_t *d_levels, const int32_t *d_jobs, int njobs, int32_t *d_out);
+
 /* havoc_quantize (havoc/quantize.h:63, quantize.cpp:278-304): d_cbf[i] = OR of the job's outputs */
 int havoc_mi355x_quantize(havoc_mi355x_ctx *ctx, int16_t *d_dst, const int16_t *d_src,
                           const havoc_mi355x_quant_job *d_jobs, int njobs, int32_t *d_cbf);

@@ -242,3 +242,64 @@ int havoc_mi355x_quantize_reconstruct(havoc_mi355x_ctx *ctx, int log2, uint8_t *
     for (int i = 0; i < n; ++i) oracle_quantize_reconstruct(rec + j[i].dst_off, sr, pred + j[i].pred_off, sp, res + j[i].res_off, 1 << log2);
     return 0;
 }
+
+int havoc_mi355x_level_stats(havoc_mi355x_ctx *ctx, const int16_t *levels, const int32_t *j, int n, int32_t *out)
+{
+    (void)ctx; ++g_launches;
+    for (int i = 0; i < n; ++i)
+    {
+        int nz = 0, sum = 0;
+        for (int k = 0; k < j[2 * i + 1]; ++k)
+        {
+            const int v = levels[j[2 * i] + k];
+            nz += v != 0;
+            sum += v < 0 ? -v : v;
+        }
+        out[2 * i] = nz;
+        out[2 * i + 1] = sum;
+    }
+    return 0;
+}
+
+/* ---- the TU chain either side of RDOQ and RDOQ itself (libhavoc_search.so: havoc_search_rqt) ---- */
+int havoc_mi355x_tu_forward(havoc_mi355x_ctx *ctx, int S, int bitDepth, int trType, int log2, int16_t *coeffs, const void *src, intptr_t ss, const void *pred,
+                            intptr_t sp, const havoc_mi355x_tu_fused_job *j, int n)
+{
+    (void)ctx; ++g_launches;
+    const int N = 1 << log2;
+    int16_t res[32 * 32];
+    for (int i = 0; i < n; ++i)
+    {
+        oracle_residual(res, N, AT(src, j[i].src_off, S), ss, AT(pred, j[i].pred_off, S), sp, N, N, S);
+        oracle_transform(coeffs + j[i].coef_off, res, N, log2, trType, bitDepth);
+    }
+    return 0;
+}
+
+int havoc_mi355x_tu_reconstruct(havoc_mi355x_ctx *ctx, int S, int bitDepth, int trType, int log2, int scale, int shift, void *rec, intptr_t sr, const void *pred,
+                                intptr_t sp, const void *src, intptr_t ss, const int16_t *levels, const havoc_mi355x_tu_fused_job *j, int n, uint32_t *ssd)
+{
+    (void)ctx; ++g_launches;
+    const int N = 1 << log2;
+    int16_t deq[32 * 32];
+    for (int i = 0; i < n; ++i)
+    {
+        oracle_quantize_inverse(deq, levels + j[i].coef_off, scale, shift, N * N);
+        oracle_inverse_transform_add((char *)rec + (long)j[i].rec_off * S, sr, AT(pred, j[i].pred_off, S), sp, deq, log2, trType, bitDepth, S);
+        ssd[i] = oracle_ssd(AT(src, j[i].src_off, S), ss, AT(rec, j[i].rec_off, S), sr, N, N, S);
+    }
+    return 0;
+}
+
+size_t havoc_mi355x_rdoq_workspace(int njobs) { (void)njobs; return 256; }
+void havoc_mi355x_rdoq_lambda(double lambda, int inv_scale, int32_t *lq, int32_t *sf) { oracle_rdoq_lambda(lambda, inv_scale, lq, sf); }
+
+int havoc_mi355x_rdoq(havoc_mi355x_ctx *ctx, int bitDepth, int log2, int16_t *dst, const int16_t *src, const uint8_t *states, const havoc_mi355x_rdoq_job *j, int n,
+                      int32_t *cbf, void *work, size_t work_bytes)
+{
+    (void)ctx; (void)work; (void)work_bytes; ++g_launches;
+    for (int i = 0; i < n; ++i)
+        cbf[i] = oracle_rdoq(dst + j[i].dst_off, src + j[i].src_off, log2, j[i].c_idx, j[i].scan_idx, j[i].is_intra, j[i].sdh, j[i].quant_scale, j[i].quant_shift,
+                             j[i].inv_scale, bitDepth, j[i].lambda_q16, j[i].sdh_factor, states + 128 * (long)j[i].ctx_index);
+    return 0;
+}

@@ -71,6 +71,12 @@ void makeIdealPredictor(MotionTables<Sample> &, Sample *ideal, const Sample *inp
 #include "havoc_classic_ext.h"
 #endif
 #include "picture_order.hpp"
+#include "tu_decision.hpp"
+#ifndef SEARCH_ORACLE
+#include "havoc/quantize.h"
+#include "havoc/ssd.h"
+#include "havoc/transform.h"
+#endif
 
 using namespace havoc_search;
 
@@ -301,6 +307,155 @@ int client_picture_uni(int S, const void *src, intptr_t ss, const void *ref0, co
             }
     return 0;
 }
+
+} // extern "C"
+
+#if !defined(HAVOC_CLASSIC_EXT)
+// ---- the residual-quadtree decisions (tu_decision.hpp) one block at a time: residual -> forward transform -> Rdoq::runQuantisation ->
+// de-quantise -> inverse transform + add -> SSD, through the reference's tables and its own Rdoq.cpp (oracle/ref_shim_rdoq.cpp), or the
+// CPU oracle with -DSEARCH_ORACLE.  The expected values of havoc_search_rqt.  rec receives the chosen candidates' reconstruction.
+#ifndef SEARCH_ORACLE
+extern "C" int ref_rdoq(int16_t *dst, const int16_t *src, int log2Size, int cIdx, int scanIdx, int isIntra, int sdh, int quantScale, int quantShift, int invScale,
+                        int bitDepth, double lambda, const uint8_t *states);
+namespace {
+struct TuTables
+{
+    havoc::table_transform<8> t8;
+    havoc::table_transform<10> t10;
+    havoc::table_inverse_transform_add<uint8_t> ita8;
+    havoc::table_inverse_transform_add<uint16_t> ita16;
+    havoc_table_quantize_inverse qi;
+    havoc_table_ssd<uint8_t> ssd8;
+    havoc_table_ssd<uint16_t> ssd16;
+    bool ready = false;
+} g_tu;
+}
+#else
+extern "C" {
+int oracle_rdoq(int16_t *dst, const int16_t *src, int log2Size, int cIdx, int scanIdx, int isIntra, int sdh, int quantScale, int quantShift, int invScale,
+                int bitDepth, int32_t lambdaQ16, int32_t sdhFactor, const uint8_t *states);
+void oracle_rdoq_lambda(double lambda, int invQuantScale, int32_t *lambdaQ16, int32_t *sdhFactor);
+}
+#endif
+
+template <typename Sample>
+struct PerCallTuView
+{
+    int bitDepth, sdh;
+    const Sample *src;      // sample (0, 0)
+    intptr_t ss;
+    const Sample *pred;
+    intptr_t ps;
+    Sample *rec;            // sample (0, 0) of the reconstruction picture: written by `commit`
+    intptr_t rs;
+    const uint8_t *states;
+    const havoc_rqt_quant *quant;
+    double lambda;
+    int ctxIndex;
+    // pieces of the candidates of the unit being decided: [depth][k]
+    Sample piece[2][4][32 * 32];
+
+    havoc_tu_outcome evaluate(int x0, int y0, int log2, int depth)
+    {
+        const int n = 1 << log2, k = depth ? kNext++ & 3 : 0;
+        HAVOC_ALIGN(32, int16_t, res[32 * 32]);
+        HAVOC_ALIGN(32, int16_t, coef[32 * 32]);
+        HAVOC_ALIGN(32, int16_t, level[32 * 32]);
+        HAVOC_ALIGN(32, int16_t, deq[32 * 32]);
+        const Sample *s = src + intptr_t(y0) * ss + x0, *p = pred + intptr_t(y0) * ps + x0;
+        for (int y = 0; y < n; ++y)
+            for (int x = 0; x < n; ++x) res[y * n + x] = int16_t(s[y * ss + x] - p[y * ps + x]);      // Reconstruct.cpp:1274-1286
+        const havoc_rqt_quant &q = quant[log2 - 2];
+        havoc_tu_outcome o;
+        Sample *out = piece[depth][k];
+#ifndef SEARCH_ORACLE
+        constexpr int tableDepth = 2 * sizeof(Sample) + 6;
+        havoc::Transform *fwd = sizeof(Sample) == 1 ? *havoc::get_transform<8>(&g_tu.t8, 0, log2) : *havoc::get_transform<10>(&g_tu.t10, 0, log2);
+        (void)tableDepth;
+        fwd(coef, res, n);
+        o.cbf = ref_rdoq(level, coef, log2, 0, 0, 0, sdh, q.quant_scale, q.quant_shift, q.inv_scale, bitDepth, lambda, states + 128 * ctxIndex);
+        (*havoc_get_quantize_inverse(&g_tu.qi, q.inv_scale, q.inv_shift))(deq, level, q.inv_scale, q.inv_shift, n * n);
+        itAdd(out, n, p, ps, deq, log2);
+        o.ssd = uint32_t(ssdOf(s, ss, out, n, log2));
+#else
+        oracle_transform(coef, res, n, log2, 0, bitDepth);
+        int32_t lq, sf;
+        oracle_rdoq_lambda(lambda, q.inv_scale, &lq, &sf);
+        o.cbf = oracle_rdoq(level, coef, log2, 0, 0, 0, sdh, q.quant_scale, q.quant_shift, q.inv_scale, bitDepth, lq, sf, states + 128 * ctxIndex);
+        oracle_quantize_inverse(deq, level, q.inv_scale, q.inv_shift, n * n);
+        oracle_inverse_transform_add(out, n, p, ps, deq, log2, 0, bitDepth, sizeof(Sample));
+        o.ssd = oracle_ssd(s, ss, out, n, n, n, sizeof(Sample));
+#endif
+        o.nonzero = o.sum_abs = 0;
+        for (int i = 0; i < n * n; ++i)
+        {
+            o.nonzero += level[i] != 0;
+            o.sum_abs += level[i] < 0 ? -level[i] : level[i];
+        }
+        return o;
+    }
+#ifndef SEARCH_ORACLE
+    void itAdd(uint8_t *dst, intptr_t sd, const uint8_t *p, intptr_t sp, const int16_t *c, int log2) { (*havoc::get_inverse_transform_add<uint8_t>(&g_tu.ita8, 0, log2))(dst, sd, p, sp, c, bitDepth); }
+    void itAdd(uint16_t *dst, intptr_t sd, const uint16_t *p, intptr_t sp, const int16_t *c, int log2) { (*havoc::get_inverse_transform_add<uint16_t>(&g_tu.ita16, 0, log2))(dst, sd, p, sp, c, bitDepth); }
+    int ssdOf(const uint8_t *a, intptr_t sa, const uint8_t *b, intptr_t sb, int log2) { return (*havoc_get_ssd<uint8_t>(&g_tu.ssd8, log2))(a, sa, b, sb, 1 << log2, 1 << log2); }
+    int ssdOf(const uint16_t *a, intptr_t sa, const uint16_t *b, intptr_t sb, int log2) { return (*havoc_get_ssd<uint16_t>(&g_tu.ssd16, log2))(a, sa, b, sb, 1 << log2, 1 << log2); }
+#endif
+    int kNext = 0;
+
+    void commit(const havoc_rqt_cu &cu, const havoc_rqt_result &r)
+    {
+        const int n = 1 << cu.log2_size, half = n / 2;
+        if (r.depth == 0 && r.tried_zero)
+            for (int y = 0; y < n; ++y) std::memcpy(rec + intptr_t(cu.y0 + y) * rs + cu.x0, piece[0][0] + y * n, n * sizeof(Sample));
+        else      // split, or the uncoded short-cut (whose four pieces equal the prediction)
+            for (int k = 0; k < 4; ++k)
+                for (int y = 0; y < half; ++y)
+                    std::memcpy(rec + intptr_t(cu.y0 + (k >> 1) * half + y) * rs + cu.x0 + (k & 1) * half, piece[1][k] + y * half, half * sizeof(Sample));
+    }
+};
+
+extern "C" int client_rqt(int S, int bitDepth, const void *src, intptr_t ss, const void *pred, intptr_t ps, void *rec, intptr_t rs, const uint8_t *states,
+               const havoc_rqt_quant *quant, double lambda, double reciprocal_lambda, int sdh, const havoc_rqt_cu *cus, int n, havoc_rqt_result *out)
+{
+    if (!g_open) return -1;
+#ifndef SEARCH_ORACLE
+    if (!g_tu.ready)
+    {
+        havoc::populate_transform<8>(&g_tu.t8, g_code);
+        havoc::populate_transform<10>(&g_tu.t10, g_code);
+        havoc::populate_inverse_transform_add<uint8_t>(&g_tu.ita8, g_code, 1);
+        havoc::populate_inverse_transform_add<uint16_t>(&g_tu.ita16, g_code, 1);
+        havoc_populate_quantize_inverse(&g_tu.qi, g_code);
+        havoc_populate_ssd<uint8_t>(&g_tu.ssd8, g_code);
+        havoc_populate_ssd<uint16_t>(&g_tu.ssd16, g_code);
+        g_tu.ready = true;
+    }
+#endif
+    Lambda rl;
+    rl.set(reciprocal_lambda);
+    auto run = [&](auto tag) {
+        typedef decltype(tag) Sample;
+        static PerCallTuView<Sample> view;
+        view.bitDepth = bitDepth; view.sdh = sdh;
+        view.src = (const Sample *)src; view.ss = ss;
+        view.pred = (const Sample *)pred; view.ps = ps;
+        view.rec = (Sample *)rec; view.rs = rs;
+        view.states = states; view.quant = quant; view.lambda = lambda;
+        for (int i = 0; i < n; ++i)
+        {
+            view.ctxIndex = cus[i].ctx_index;
+            view.kNext = 0;
+            out[i] = decideRqt(view, cus[i], rl);
+            view.commit(cus[i], out[i]);
+        }
+    };
+    if (S == 1) run(uint8_t(0));
+    else run(uint16_t(0));
+    return 0;
+}
+#endif
+
+extern "C" {
 
 // the 35-mode intra stage: costs and refinement order from the per-mode SATDs (Search.hpp:40-190)
 int client_intra_order(const havoc_search_intra_ctx *ctx, double reciprocal_sqrt_lambda, const int32_t *satd35, int n, havoc_search_intra_result *out)

@@ -29,7 +29,7 @@ import search_tools as st  # noqa: E402
 
 def build_mock():
     out = os.path.join(st.BUILD, "mock", "libhavoc_mi355x.so")
-    srcs = [os.path.join(HERE, "mock_device.c"), os.path.join(ROOT, "oracle", "havoc_oracle.c")]
+    srcs = [os.path.join(HERE, "mock_device.c"), os.path.join(ROOT, "oracle", "havoc_oracle.c"), os.path.join(ROOT, "oracle", "rdoq_oracle.c")]
     if not (os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(s) for s in srcs)):
         os.makedirs(os.path.dirname(out), exist_ok=True)
         subprocess.check_call(["gcc", "-O2", "-std=gnu99", "-fPIC", "-shared", "-w", "-Wl,-soname,libhavoc_mi355x.so"] + srcs + ["-o", out])

@@ -55,7 +55,7 @@ def build(kind):
     """compile the client for one back end; returns the library path (None when the back end's library is not there)"""
     os.makedirs(BUILD, exist_ok=True)
     out = os.path.join(BUILD, f"libsearch_{kind}.so")
-    hdrs = [os.path.join(ROOT, "turingcodec_amd", "search", f) for f in ("decision.hpp", "table_view.hpp", "search_abi.h", "picture_order.hpp")]
+    hdrs = [os.path.join(ROOT, "turingcodec_amd", "search", f) for f in ("decision.hpp", "table_view.hpp", "search_abi.h", "picture_order.hpp", "tu_decision.hpp")]
     base = ["g++", "-O2", "-std=c++14", "-fPIC", "-shared", "-Wall"] + INC + [SRC, "-o", out]
     if kind == "ref":
         lib = os.path.join(ROOT, "oracle", "_ref", "libhavoc_ref.so")
@@ -93,6 +93,8 @@ class Client:
         L.client_intra_order.argtypes = [vp, C.c_double, vp, i, vp]
         L.client_intra35.argtypes = [i, i, i, vp, ip, vp, vp, i, vp]
         L.client_picture_uni.argtypes = [i, vp, ip, vp, vp, ip, C.POINTER(Params), vp, vp, i, i, vp, vp, vp]
+        if kind != "classic":
+            L.client_rqt.argtypes = [i, i, vp, ip, vp, ip, vp, ip, vp, vp, C.c_double, C.c_double, i, vp, i, vp]
         if kind == "classic":
             L.client_register.argtypes = [vp, ip, i, i, i, i, i, i]
             L.client_unregister.argtypes = [vp]
@@ -124,6 +126,20 @@ class Client:
                                        C.byref(params), pus.ctypes.data, ctu_first.ctypes.data, ctus_x, ctus_y, rate.ctypes.data, out.ctypes.data, field.ctypes.data)
         assert rc == 0
         return out, field
+
+    def rqt(self, bit_depth, src, stride, pad, pred, pred_stride, states, quant, lam, reciprocal_lambda, cus, sdh=1):
+        """the residual-quadtree decisions one block at a time (turingcodec_amd/search/tu_decision.hpp) through this back end's primitives and
+        Rdoq: (results RQT_RESULT_DT, reconstruction plane like src)"""
+        from turingcodec_amd.decisions import RQT_RESULT_DT
+        out = np.zeros(len(cus), RQT_RESULT_DT)
+        rec = np.zeros_like(src)
+        quant = np.ascontiguousarray(quant, np.int32)
+        states = np.ascontiguousarray(states, np.uint8)
+        cus = np.ascontiguousarray(cus)
+        rc = self.L.client_rqt(src.itemsize, bit_depth, self._origin(src, stride, pad), stride, pred.ctypes.data, pred_stride, self._origin(rec, stride, pad), stride,
+                               states.ctypes.data, quant.ctypes.data, float(lam), float(reciprocal_lambda), int(sdh), cus.ctypes.data, len(cus), out.ctypes.data)
+        assert rc == 0
+        return out, rec
 
     def bi(self, params, src, ref, ref_other, stride, pad, pus, start):
         out = np.zeros(len(pus), RESULT_DT)

@@ -14,7 +14,7 @@ pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not os.path.exists(reflibs.REF
 
 
 def _host_chain(R, dp, field):
-    """the TU chain of DecisionPicture.tu_chain through the reference's functions, block by block"""
+    """the TU chain of DecisionPicture.tu_chain_fixed through the reference's functions, block by block"""
     from turingcodec_amd.workload import dequant_params, picture_lambda, quant_params
     W, PAD, stride, BD = dp.W, dp.PAD, dp.stride, dp.bd
     src, ref0 = dp.host_planes[0], dp.host_planes[1]
@@ -62,6 +62,16 @@ def test_decision_step_equals_the_reference_functions(res, BD, qp):
         assert np.array_equal(got[k], exp[k]), k
     assert np.array_equal(field, exp_field)
     assert stats.launches < len(got) and stats.steps == dp.cx + 2 * (dp.cy - 1)
+    # the residual-quadtree decisions of the step (both depths of every unit in one chain per transform size) against the same decisions
+    # taken one block at a time through the reference's tables + Rdoq.cpp, on the prediction the device made from the decided vectors
+    pred = hv.down(dp.pred, dp.dt).copy()
+    exp_rqt, exp_rec = ref.rqt(BD, dp.host_planes[0], dp.stride, dp.PAD, pred, dp.W, dp.rdoq_states, dp.quant, dp.lam, 1.0 / dp.lam, dp.units)
+    assert dp.rqt_results.tobytes() == exp_rqt.tobytes()
+    assert np.array_equal(hv.down(dp.recon, dp.dt)[:dp.n], exp_rec)
+    assert dp.rqt_stats.launches <= 5 * 4 + 4 and (exp_rqt["depth"] == 1).any() and (exp_rqt["depth"] == 0).any()
+    # the fixed-size chain (16x16 blocks) on the same vectors: every intermediate against the reference's functions
+    dp.tu_chain_fixed(field)
+    hv.sync()
     dev, dev_recon = dp.results()
     host, host_recon = _host_chain(reflibs.Reference(), dp, exp_field)
     for d, h in zip(dev, host):

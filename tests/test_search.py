@@ -226,3 +226,40 @@ def test_picture_client_on_the_gpu_equals_the_reference_walk(res, bit_depth):
     out = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out) and res == "1920x1080":
         json.dump(r, open(os.path.join(out, "picture_report_1080p.json"), "w"), indent=1)
+
+
+# ---- the residual-quadtree decisions as a batch client (turingcodec_amd/search/tu_decision.hpp, tu_search.cpp) --------
+def _run_rqt(device, *args, timeout=1800):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rqt_runner.py"), "--device", device] + list(args), capture_output=True, text=True,
+                         timeout=timeout, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def _check_rqt(r):
+    """split / no-split decisions, coded flags, SSDs, level statistics and Q16 costs of every unit, and the reconstruction of the chosen
+    candidates, identical to the block-at-a-time loop over the reference's tables + Rdoq.cpp; one chain per transform size for the picture"""
+    assert r["mismatching_units"] == 0 and r["reconstruction_equal"], r
+    assert "Rdoq.cpp" in r["expected_from"]
+    assert r["rqt"]["launches"] <= 5 * 4, r["rqt"]          # <= (4 launches + the final reconstruction) per transform size, for the whole picture
+    assert r["rqt"]["candidates"] == 5 * r["units"]
+
+
+@needs_ref
+@pytest.mark.parametrize("res,bit_depth,qp", [("416x240", 8, 32), ("416x240", 8, 45), ("640x360", 10, 40)])
+def test_rqt_client_host_logic_on_the_mock_device(res, bit_depth, qp):
+    r = _run_rqt("mock", "--res", res, "--bit-depth", str(bit_depth), "--qp", str(qp), "--repeat", "1")
+    _check_rqt(r)
+    if qp >= 40:
+        assert r["depth_histogram"]["uncoded"] > 0      # the uncoded short-cut (depth 0 never evaluated) was taken
+
+
+@needs_ref
+@pytest.mark.gpu
+@pytest.mark.parametrize("res,bit_depth,qp", [("416x240", 8, 32), ("640x360", 10, 40), ("1920x1080", 8, 32), ("1920x1080", 8, 22)])
+def test_rqt_client_on_the_gpu_equals_the_reference_loop(res, bit_depth, qp):
+    r = _run_rqt("real", "--res", res, "--bit-depth", str(bit_depth), "--qp", str(qp))
+    _check_rqt(r)
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out) and res == "1920x1080" and qp == 32:
+        json.dump(r, open(os.path.join(out, "rqt_report_1080p.json"), "w"), indent=1)

@@ -29,6 +29,7 @@ hipError_t launch_tu_forward(hipStream_t, int S, int bd, int log2, int tr, int16
 hipError_t launch_tu_reconstruct(hipStream_t, int S, int bd, int log2, int tr, int scale, int shift, void *, long, const void *, long, const void *,
                                  long, const int16_t *, const void *, int, uint32_t *);
 hipError_t launch_quantize(hipStream_t, int16_t *, const int16_t *, const void *, int, int32_t *);
+hipError_t launch_level_stats(hipStream_t, const int16_t *, const void *, int, int32_t *);
 hipError_t launch_rdoq(hipStream_t, int bd, int log2, int16_t *, const int16_t *, const uint8_t *, const void *, int, int32_t *, void *);
 size_t rdoq_workspace_bytes(int njobs);
 hipError_t launch_sao_stats(hipStream_t, int S, int bd, const void *, long, const void *, long, const void *, int, int64_t *);
@@ -487,6 +488,12 @@ int havoc_mi355x_tu_reconstruct(havoc_mi355x_ctx *ctx, int S, int bitDepth, int 
     return check(launch_tu_reconstruct(LS(ctx), S, bitDepth, log2TrafoSize, trType, scale, shift, d_rec, stride_rec, d_pred, stride_pred, d_src,
                                        stride_src, d_levels, d_jobs, njobs, d_ssd),
                  "tu_reconstruct");
+}
+
+int havoc_mi355x_level_stats(havoc_mi355x_ctx *ctx, const int16_t *d_levels, const int32_t *d_jobs, int njobs, int32_t *d_out)
+{
+    REQUIRE_CTX(); REQUIRE(njobs >= 0, "njobs < 0");
+    return check(launch_level_stats(LS(ctx), d_levels, d_jobs, njobs, d_out), "level_stats");
 }
 
 int havoc_mi355x_quantize(havoc_mi355x_ctx *ctx, int16_t *d_dst, const int16_t *d_src, const havoc_mi355x_quant_job *d_jobs, int njobs, int32_t *d_cbf)

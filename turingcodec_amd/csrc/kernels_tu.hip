@@ -147,6 +147,33 @@ __global__ __launch_bounds__(256) void k_quantize(int16_t *__restrict__ dst, con
     if (lane == 0) cbf[job] = any;
 }
 
+// What a rate estimate reads of a block of quantised levels without downloading them: out[2 * job] = number of non-zero levels,
+// out[2 * job + 1] = sum of |level| (the encoder's EstimateRate<residual_coding> walks the levels themselves on the host; a batch client
+// that decides between transform-tree candidates wants these per candidate).  jobs: (offset, n) pairs, n a multiple of 2.
+__global__ __launch_bounds__(256) void k_level_stats(const int16_t *__restrict__ levels, const int32_t *__restrict__ jobs, int njobs, int32_t *__restrict__ out)
+{
+    const int job = xcd_block(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (job >= njobs) return;
+    const int16_t *s = levels + jobs[2 * job];
+    const int n = jobs[2 * job + 1];
+    int nz = 0, sum = 0;
+    for (int i = 2 * lane; i < n; i += 2 * kWave)
+    {
+        const uint32_t v = *reinterpret_cast<const uint32_t *>(s + i);
+        const int a = (int16_t)(v & 0xffff), b = (int16_t)(v >> 16);
+        nz += (a != 0) + (b != 0);
+        sum += abs(a) + abs(b);
+    }
+    nz = wave_sum(nz);
+    sum = wave_sum(sum);
+    if (lane == 0)
+    {
+        out[2 * job] = nz;
+        out[2 * job + 1] = sum;
+    }
+}
+
 // havoc_quantize_inverse (havoc/quantize.h:42; C reference havoc/quantize.cpp:37-46)
 __global__ __launch_bounds__(256) void k_quantize_inverse(int16_t *__restrict__ dst, const int16_t *__restrict__ src,
                                                           const int32_t *__restrict__ jobs, int njobs)
@@ -268,6 +295,13 @@ hipError_t launch_inverse_transform(hipStream_t st, int mode, int bitDepth, int 
         case 5: go_inv<5, 0>(st, mode, d, sd, p, sp, resout, coeffs, j, n, bitDepth); break;
         default: return hipErrorInvalidValue;
         }
+    return hipGetLastError();
+}
+
+hipError_t launch_level_stats(hipStream_t st, const int16_t *levels, const void *jobs, int n, int32_t *out)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_level_stats, dim3((n + 3) / 4), dim3(256), 0, st, levels, (const int32_t *)jobs, n, out);
     return hipGetLastError();
 }
 

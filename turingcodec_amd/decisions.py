@@ -36,6 +36,31 @@ class PictureStats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+RQT_CU_DT = np.dtype([("x0", "i4"), ("y0", "i4"), ("log2_size", "i4"), ("ctx_index", "i4")])                       # havoc_rqt_cu
+TU_OUTCOME_DT = np.dtype([("cbf", "i4"), ("ssd", "u4"), ("nonzero", "i4"), ("sum_abs", "i4")])                    # havoc_tu_outcome
+RQT_RESULT_DT = np.dtype([("depth", "i4"), ("tried_zero", "i4"), ("zero", TU_OUTCOME_DT), ("one", TU_OUTCOME_DT, (4,)), ("cost_zero", "i8"),
+                          ("cost_one", "i8")])                                                                     # havoc_rqt_result
+assert RQT_CU_DT.itemsize == 16 and RQT_RESULT_DT.itemsize == 104
+
+
+class RqtStats(C.Structure):
+    _fields_ = [("launches", C.c_int32), ("candidates", C.c_int32), ("seconds_gpu", C.c_double), ("seconds_host", C.c_double), ("seconds_total", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+def rqt_quant(qp, bit_depth):
+    """havoc_rqt_quant[4] for transform sizes 4..32 of an inter (non-I slice) luma block (turing/QpState.h:85-94, Reconstruct.cpp:774-782)"""
+    from . import workload
+    q = np.zeros((4, 4), np.int32)
+    for log2 in (2, 3, 4, 5):
+        qs, qshift, _ = workload.quant_params(qp, log2, bit_depth, False)
+        inv, dshift = workload.dequant_params(qp, log2, bit_depth)
+        q[log2 - 2] = (qs, qshift, inv, dshift)
+    return q
+
+
 def medium_params(width, height, bit_depth, reciprocal_sqrt_lambda, concurrent_frames=4):
     """speed=medium: multiple early termination on, full search window, half- and quarter-sample refinement (turing/Speed.h)"""
     return SearchParams(width, height, 64, concurrent_frames, 1, 0, 0, 1, 1, bit_depth, reciprocal_sqrt_lambda)
@@ -54,6 +79,9 @@ def lib():
         L.havoc_search_picture_uni.argtypes = [vp, C.c_int, C.POINTER(SearchParams), vp, i64, ip, vp, C.POINTER(i64), ip, C.c_int, vp, ip, C.POINTER(i64),
                                                vp, vp, C.c_int, C.c_int, C.POINTER(i64), vp, vp, C.c_int, C.POINTER(PictureStats)]
         L.havoc_search_picture_uni.restype = C.c_int
+        L.havoc_search_rqt.argtypes = [vp, C.c_int, C.c_int, vp, i64, ip, vp, ip, vp, i64, ip, vp, vp, C.c_double, C.c_double, C.c_int, vp, C.c_int, vp,
+                                       C.POINTER(RqtStats)]
+        L.havoc_search_rqt.restype = C.c_int
         L.havoc_search_release.argtypes = [vp]
         L.havoc_search_release.restype = None
         _lib = L
@@ -96,15 +124,46 @@ def decision_inputs(width, height, bit_depth=8, qp=32, seed=11, density=1.0, fra
                 params=medium_params(width, height, bit_depth, 1.0 / np.sqrt(lam)), mvp_rate=(45000, 98000), lam=lam)
 
 
+def rqt(ctx, S, bit_depth, d_src, src_origin, src_stride, d_pred, pred_stride, d_rec, rec_origin, rec_stride, d_states, quant, lam, reciprocal_lambda, cus, sdh=1):
+    """havoc_search_rqt: the residual-quadtree decision of every inter unit of `cus` (RQT_CU_DT) in one chain per transform size.
+    Returns (results RQT_RESULT_DT, stats)"""
+    cus = np.ascontiguousarray(cus)
+    assert cus.dtype == RQT_CU_DT
+    quant = np.ascontiguousarray(quant, np.int32)
+    out = np.zeros(len(cus), RQT_RESULT_DT)
+    stats = RqtStats()
+    rc = lib().havoc_search_rqt(ctx, S, bit_depth, d_src, int(src_origin), src_stride, d_pred, pred_stride, d_rec, int(rec_origin), rec_stride, d_states,
+                                quant.ctypes.data, float(lam), float(reciprocal_lambda), int(sdh), cus.ctypes.data, len(cus), out.ctypes.data, C.byref(stats))
+    if rc != 0:
+        raise RuntimeError(f"havoc_search_rqt failed ({rc})")
+    return out, stats
+
+
+def rqt_units(width, height, ctus_x):
+    """the inter units whose transform trees are decided: 32x32 units where they fit, 16x16 then 8x8 units along a partial last row / column"""
+    rows = []
+    for size, log2 in ((32, 5), (16, 4), (8, 3)):
+        for y in range(0, height - size + 1, size):
+            for x in range(0, width - size + 1, size):
+                # a unit is emitted at the largest size that fits its position on the grid of that size and lies outside the area covered by larger units
+                big = size * 2
+                covered = size < 32 and x // big * big + big <= width and y // big * big + big <= height
+                if not covered:
+                    rows.append((x, y, log2, (y // 64) * ctus_x + x // 64))
+    return np.array(rows, np.int32).reshape(-1, 4).view(RQT_CU_DT).reshape(-1)
+
+
 class DecisionPicture:
     """One inter picture through the DECISION-DRIVEN path on the device (bench.py --decisions, tests/test_decisions.py):
 
       1. the 15 fractional-sample planes of both reference pictures (havoc_mi355x_interp_planes);
       2. every PU's uni-directional search in both lists, CTUs in wavefront order, predictors derived from the vectors decided before
          (libhavoc_search.so: havoc_search_picture_uni) -- the searches are fed by batch launches, the loops replay on host threads;
-      3. the TU chain ON THE CHOSEN VECTORS: HavocPredUni of every 16x16 block (8x8 in a last partial row) at the list-0 vector the
-         search left for it -> residual + forward DCT -> Rdoq::runQuantisation -> de-quantise + inverse DCT + add -> SSD
-         (one launch per primitive and block size; job tables are built from the decided motion field, i.e. they cannot exist before 2).
+      3. the TU side ON THE CHOSEN VECTORS: HavocPredUni of every 16x16 block (8x8 in a last partial row) at the list-0 vector the
+         search left for it, then the residual-quadtree decision of every inter unit (32x32 units, smaller along partial edges;
+         libhavoc_search.so: havoc_search_rqt): both tree depths of every unit through residual + forward DCT -> Rdoq::runQuantisation ->
+         de-quantise + inverse DCT + add -> SSD in one chain per transform size, the decisions taken from 16 bytes per candidate, the chosen
+         candidates reconstructed into the picture (job tables are built from the decided motion field: they cannot exist before 2).
 
     What is NOT in it (stated, not hidden): the encoder's mode decision between the searched PUs (every PU of workload.picture_pus is
     searched and the last one covering an area stands), bi-prediction, intra candidates and CABAC.  `step()` is what bench.py times."""
@@ -133,7 +192,11 @@ class DecisionPicture:
         self.pus, self.ctu_first, self.cx, self.cy = d["pus"], d["ctu_first"], d["cx"], d["cy"]
         lam = d["lam"]
         self.params, self.mvp_rate = d["params"], d["mvp_rate"]
-        # ---- TU chain: 16x16 blocks over the rows that hold whole ones, 8x8 blocks over a last partial row
+        # ---- prediction: 16x16 blocks over the rows that hold whole ones, 8x8 blocks over a last partial row; the (older) fixed-size TU chain
+        # over the same blocks stays available as tu_chain_fixed()
+        self.units = rqt_units(width, height, self.cx)
+        self.quant = rqt_quant(qp, bit_depth)
+        self.lam = lam
         self.groups = []
         h16 = height // 16 * 16
         for log2, y_lo, y_hi in ((4, 0, h16), (3, h16, height // 8 * 8)):
@@ -184,8 +247,32 @@ class DecisionPicture:
         return picture_uni(hv.h, self.S, self.params, base, o, self.stride, base, (pe + o, 2 * pe + o), self.stride, self.PAD, ph, pe, (o, 16 * pe + o),
                            self.pus, self.ctu_first, self.cx, self.cy, self.mvp_rate, self.threads)
 
+    def predict(self, field):
+        """HavocPredUni of every block at the decided list-0 vector into the prediction plane; asynchronous"""
+        hv, bd, pe = self.hv, self.bd, self.pe
+        ref0 = self.d_pic[pe:2 * pe]
+        for g in self.groups:
+            mv = field[0, g["y0"] >> 2, g["x0"] >> 2].astype(np.int64)          # quarter samples, [m, 2]
+            pj = g["pj"]
+            pj[:, 0] = g["y0"] * self.W + g["x0"]
+            pj[:, 1] = (g["y0"] + (mv[:, 1] >> 2) + self.PAD) * self.stride + g["x0"] + (mv[:, 0] >> 2) + self.PAD
+            pj[:, 2] = pj[:, 3] = g["nn"]
+            pj[:, 4], pj[:, 5] = mv[:, 0] & 3, mv[:, 1] & 3
+            with self.torch.cuda.stream(hv.tstream):
+                g["d_pj"].copy_(self.torch.from_numpy(pj.reshape(-1)), non_blocking=True)
+            hv.pred_uni_d(8, bd, self.pred, self.W, ref0, self.stride, g["d_pj"].view(-1, 8), g["nn"], g["nn"])
+
     def tu_chain(self, field):
-        """prediction at the decided list-0 vectors, then residual -> T -> RDOQ -> IQ -> IT + add -> SSD; asynchronous"""
+        """prediction at the decided vectors, then the residual-quadtree decisions and the reconstruction; returns (decisions, stats)"""
+        self.predict(field)
+        base = self.d_pic.data_ptr()
+        self.rqt_results, st = rqt(self.hv.h, self.S, self.bd, base, self.origin, self.stride, self.pred.data_ptr(), self.W, self.recon.data_ptr(), self.origin,
+                                   self.stride, self.d_states.data_ptr(), self.quant, self.lam, 1.0 / self.lam, self.units)
+        self.rqt_stats = st
+        return self.rqt_results, st
+
+    def tu_chain_fixed(self, field):
+        """prediction at the decided list-0 vectors, then residual -> T -> RDOQ -> IQ -> IT + add -> SSD on fixed 16x16 (8x8) blocks; asynchronous"""
         hv, bd, pe = self.hv, self.bd, self.pe
         ref0 = self.d_pic[pe:2 * pe]
         src = self.d_pic[:pe]

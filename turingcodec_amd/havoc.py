@@ -89,6 +89,7 @@ def _load():
         "inverse_transform_add": [_vp, _i, _i, _i, _i, _vp, _ip, _vp, _ip, _vp, _vp, _i],
         "tu_forward": [_vp, _i, _i, _i, _i, _vp, _vp, _ip, _vp, _ip, _vp, _i],
         "tu_reconstruct": [_vp, _i, _i, _i, _i, _i, _i, _vp, _ip, _vp, _ip, _vp, _ip, _vp, _vp, _i, _vp],
+        "level_stats": [_vp, _vp, _vp, _i, _vp],
         "quantize": [_vp, _vp, _vp, _vp, _i, _vp],
         "quantize_inverse": [_vp, _vp, _vp, _vp, _i],
         "quantize_reconstruct": [_vp, _i, _vp, _ip, _vp, _ip, _vp, _vp, _i],

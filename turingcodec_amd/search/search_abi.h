@@ -65,6 +65,40 @@ typedef struct
     double seconds_gpu, seconds_host, seconds_total;
 } havoc_picture_stats;
 
+/* ---- the residual quadtree decision of inter coding units (tu_decision.hpp; turing/Reconstruct.cpp:1296-1428) ---- */
+typedef struct
+{
+    int32_t x0, y0, log2_size;     /* luma coding unit = root of its transform tree */
+    int32_t ctx_index;             /* which CABAC-state snapshot RDOQ reads (the CTU's) */
+} havoc_rqt_cu;                    /* 16 bytes */
+
+typedef struct                     /* what one transform block candidate came to (Reconstruct.cpp:740-860) */
+{
+    int32_t cbf;                   /* Rdoq::runQuantisation's return value */
+    uint32_t ssd;                  /* source vs reconstruction */
+    int32_t nonzero, sum_abs;      /* of the quantised levels: what the rate estimate reads */
+} havoc_tu_outcome;                /* 16 bytes */
+
+typedef struct
+{
+    int32_t depth;                 /* chosen candidate->rqtdepth: 0 = one transform block, 1 = four */
+    int32_t tried_zero;            /* 0: all four blocks of the split came out uncoded, depth 0 was never evaluated (Reconstruct.cpp:1328, 1419-1423) */
+    havoc_tu_outcome zero, one[4];
+    int64_t cost_zero, cost_one;   /* Q16: rate + ssd * reciprocal lambda */
+} havoc_rqt_result;                /* 104 bytes */
+
+/* quantiser parameters of one transform size (turing/QpState.h:85-94) */
+typedef struct
+{
+    int32_t quant_scale, quant_shift, inv_scale, inv_shift;
+} havoc_rqt_quant;
+
+typedef struct
+{
+    int32_t launches, candidates;
+    double seconds_gpu, seconds_host, seconds_total;
+} havoc_rqt_stats;
+
 /* 35-mode intra stage: per partition */
 typedef struct
 {

@@ -1,0 +1,55 @@
+// tu_decision.hpp -- the residual-quadtree decision of an inter coding unit, restated over a per-block interface the way decision.hpp
+// restates the motion search.  Reference: turing/Reconstruct.cpp
+//   :740-860    ReconstructInterBlock: residual -> forward transform -> Rdoq::runQuantisation -> de-quantise -> inverse transform + add
+//               -> SSD(source, reconstruction)                                   [one transform block candidate = View::evaluate]
+//   :1296-1428  reconstructInter: with one level of RQT allowed the split tree (rqtdepth 1: four blocks in z-order) is evaluated FIRST;
+//               if none of its blocks is coded the unit stays unsplit with no residual and depth 0 is never tried; otherwise depth 0 is
+//               evaluated too and the cheaper of  rate + (ssd0 + 4 ssd1 + 4 ssd2) * reciprocalLambda  wins, depth 0 on `<`.
+// Luma only here (the chroma blocks of the unit follow the luma tree and add 4 x their SSD: the havoc calls are the same).
+//
+// The RATE term is the entropy coder's estimate of the coded tree (EstimateRate<residual_coding>, turing/EstimateRate.h), which is CABAC and
+// out of this repository's scope: `tuRate` below is a STAND-IN with the same inputs' summary (coded flag, number and magnitude of the
+// levels), the same in every arm of the tests.  What is restated -- and checked against the reference's tables + Rdoq.cpp -- is the
+// order of evaluation, the uncoded short-cut, the cost arithmetic (Q16) and the strict comparison.
+#pragma once
+
+#include "decision.hpp"
+#include "search_abi.h"
+
+namespace havoc_search {
+
+// stand-in for EstimateRate<residual_coding>: Q16 bits of one transform block
+inline Cost tuRate(const havoc_tu_outcome &t) { return Cost(1 + (t.cbf ? 2 * t.nonzero + t.sum_abs : 0)) << 16; }
+
+// View: havoc_tu_outcome evaluate(int x0, int y0, int log2, int depth) = the chain of Reconstruct.cpp:740-860 for the block at (x0, y0)
+template <class View>
+havoc_rqt_result decideRqt(View &view, const havoc_rqt_cu &cu, Lambda reciprocalLambda)
+{
+    havoc_rqt_result r;
+    r = havoc_rqt_result();
+    const int half = 1 << (cu.log2_size - 1);
+    int32_t ssdOne = 0;
+    bool coded = false;
+    Cost rateOne = 0;
+    for (int k = 0; k < 4; ++k)      // rqtdepth = 1 first (Reconstruct.cpp:1325-1326), blocks in z-order
+    {
+        r.one[k] = view.evaluate(cu.x0 + (k & 1) * half, cu.y0 + (k >> 1) * half, cu.log2_size - 1, 1);
+        ssdOne += int32_t(r.one[k].ssd);
+        coded |= r.one[k].cbf != 0;
+        rateOne += tuRate(r.one[k]);
+    }
+    r.cost_one = rateOne + reciprocalLambda * ssdOne;
+    if (!coded)                      // cbfZero: the unit is left unsplit and without residual
+    {
+        r.depth = 0;
+        r.tried_zero = 0;
+        return r;
+    }
+    r.tried_zero = 1;
+    r.zero = view.evaluate(cu.x0, cu.y0, cu.log2_size, 0);
+    r.cost_zero = tuRate(r.zero) + reciprocalLambda * int32_t(r.zero.ssd);
+    r.depth = (r.cost_zero < r.cost_one) ? 0 : 1;     // Reconstruct.cpp:1389
+    return r;
+}
+
+} // namespace havoc_search

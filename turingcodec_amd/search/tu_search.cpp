@@ -1,0 +1,210 @@
+// tu_search.cpp (libhavoc_search.so) -- the residual-quadtree decisions of a picture's inter coding units as a BATCH client
+// (tu_decision.hpp; VERDICT r2 next #2: "every TU of a CTU into one launch per primitive").
+//
+// An inter unit's transform-tree candidates depend on nothing but its own prediction and the (frozen) CABAC states RDOQ reads, so the
+// whole picture's candidates -- both depths of every unit, a super-set of what the decision will look at -- go through ONE chain per
+// transform size:   tu_forward -> rdoq -> tu_reconstruct (+ SSD) -> level_stats,   candidates reconstructing into private pieces
+// (as the reference's ReconstructionCache pieces).  The decisions are then taken on the host by tu_decision.hpp from the downloaded
+// flags / SSDs / level statistics (16 bytes per candidate; no coefficient or sample crosses the link), and the chosen candidates'
+// levels are reconstructed once more, into the picture.
+#include "batch_common.hpp"
+#include "tu_decision.hpp"
+
+using namespace havoc_search;
+
+namespace {
+
+#define RC(call) HAVOC_SEARCH_RC(call)
+
+struct Candidate { int cu, depth, k; };      // which unit, which tree depth, which of the four blocks
+
+struct LookupView
+{
+    const havoc_tu_outcome *zero, *one;      // of the unit being decided
+    havoc_tu_outcome evaluate(int, int, int, int depth) { return depth ? one[k++ & 3] : *zero; }
+    int k = 0;
+};
+
+} // namespace
+
+extern "C" {
+
+// d_src: source picture (src_origin = offset of sample (0, 0)); d_pred: the units' prediction, a plane of its own with sample (0, 0) at
+// offset 0; d_rec: the reconstruction picture (rec_origin).  quant[log2 - 2]: parameters per transform size; d_states: CABAC snapshots.
+// A unit of size 8 has 4x4 blocks at depth 1 (MinTbLog2SizeY = 2); sizes 8..64 with MaxTbLog2SizeY = 5 (a 64 unit's depth 0 is not a
+// candidate: the tree is split by inference, Reconstruct.cpp:1296-1300 -- such units are rejected here).  out[i] per unit.
+int havoc_search_rqt(havoc_mi355x_ctx *ctx, int S, int bitDepth, const void *d_src, int64_t src_origin, intptr_t src_stride, const void *d_pred,
+                     intptr_t pred_stride, void *d_rec, int64_t rec_origin, intptr_t rec_stride, const uint8_t *d_states, const havoc_rqt_quant quant[4],
+                     double lambda, double reciprocal_lambda, int sdh, const havoc_rqt_cu *cus, int n, havoc_rqt_result *out, havoc_rqt_stats *stats)
+{
+    if (!ctx || !d_src || !d_pred || !d_rec || !d_states || !quant || !cus || !out || n < 0 || (S != 1 && S != 2)) return HAVOC_MI355X_EINVAL;
+    const double tStart = now();
+    havoc_rqt_stats st;
+    std::memset(&st, 0, sizeof(st));
+    Arena arena(ctx);
+    for (int i = 0; i < n; ++i)
+        if (cus[i].log2_size < 3 || cus[i].log2_size > 5 || cus[i].x0 < 0 || cus[i].y0 < 0) return HAVOC_MI355X_EINVAL;
+
+    // candidates by transform size
+    std::vector<Candidate> bySize[4];
+    for (int i = 0; i < n; ++i)
+    {
+        bySize[cus[i].log2_size - 2].push_back({i, 0, 0});
+        for (int k = 0; k < 4; ++k) bySize[cus[i].log2_size - 3].push_back({i, 1, k});
+    }
+    struct Group
+    {
+        int log2, m;
+        havoc_mi355x_tu_fused_job *hJobs;
+        void *dJobs, *dCoef, *dLevel, *dPiece, *dWork;
+        havoc_tu_outcome *res;              // host view of the results (pinned): filled from three device arrays below
+        int32_t *hCbf, *hStats;
+        uint32_t *hSsd;
+        void *dCbf, *dSsd, *dStats, *dRj, *dSj;
+    } groups[4];
+    const double tGpu = now();
+    for (int s = 0; s < 4; ++s)
+    {
+        Group &g = groups[s];
+        g.log2 = s + 2;
+        g.m = int(bySize[s].size());
+        if (!g.m) continue;
+        const int nn = 1 << g.log2, area = nn * nn;
+        void *h, *hd;
+        RC(arena.get(size_t(g.m) * sizeof(havoc_mi355x_tu_fused_job), &g.dJobs, &h, &hd));
+        g.hJobs = static_cast<havoc_mi355x_tu_fused_job *>(h);
+        void *dJobsDirect = hd;
+        void *hRj, *hRjD, *hSj, *hSjD, *hx, *hxd;
+        RC(arena.get(size_t(g.m) * sizeof(havoc_mi355x_rdoq_job), &g.dRj, &hRj, &hRjD));
+        RC(arena.get(size_t(g.m) * 8, &g.dSj, &hSj, &hSjD));
+        RC(arena.get(size_t(g.m) * area * 2, &g.dCoef, &hx));
+        RC(arena.get(size_t(g.m) * area * 2, &g.dLevel, &hx));
+        RC(arena.get(size_t(g.m) * area * S, &g.dPiece, &hx));
+        RC(arena.get(havoc_mi355x_rdoq_workspace(g.m) + 64, &g.dWork, &hx));
+        void *hc, *hs, *ht;
+        RC(arena.get(size_t(g.m) * 4, &g.dCbf, &hc, &hxd));
+        g.dCbf = hxd;
+        RC(arena.get(size_t(g.m) * 4, &g.dSsd, &hs, &hxd));
+        g.dSsd = hxd;
+        RC(arena.get(size_t(g.m) * 8, &g.dStats, &ht, &hxd));
+        g.dStats = hxd;
+        g.hCbf = static_cast<int32_t *>(hc);
+        g.hSsd = static_cast<uint32_t *>(hs);
+        g.hStats = static_cast<int32_t *>(ht);
+        havoc_mi355x_rdoq_job *rj = static_cast<havoc_mi355x_rdoq_job *>(hRj);
+        int32_t *sj = static_cast<int32_t *>(hSj);
+        int32_t lq, sf;
+        havoc_mi355x_rdoq_lambda(lambda, quant[s].inv_scale, &lq, &sf);
+        for (int j = 0; j < g.m; ++j)
+        {
+            const Candidate &c = bySize[s][j];
+            const havoc_rqt_cu &cu = cus[c.cu];
+            const int x = cu.x0 + (c.depth ? (c.k & 1) * nn : 0), y = cu.y0 + (c.depth ? (c.k >> 1) * nn : 0);
+            g.hJobs[j] = {int32_t(size_t(j) * area), int32_t(src_origin + int64_t(y) * src_stride + x), int32_t(int64_t(y) * pred_stride + x), int32_t(size_t(j) * area)};
+            std::memset(&rj[j], 0, sizeof(rj[j]));
+            rj[j].dst_off = rj[j].src_off = int32_t(size_t(j) * area);
+            rj[j].quant_scale = quant[s].quant_scale;
+            rj[j].quant_shift = quant[s].quant_shift;
+            rj[j].inv_scale = quant[s].inv_scale;
+            rj[j].lambda_q16 = lq;
+            rj[j].sdh_factor = sf;
+            rj[j].ctx_index = cu.ctx_index;
+            rj[j].sdh = uint8_t(sdh != 0);
+            sj[2 * j] = int32_t(size_t(j) * area);
+            sj[2 * j + 1] = area;
+        }
+        // the chain of this size: job tables are read from mapped host memory, the 16 bytes of results per candidate written to it
+        const havoc_mi355x_tu_fused_job *dj = static_cast<const havoc_mi355x_tu_fused_job *>(dJobsDirect);
+        RC(havoc_mi355x_tu_forward(ctx, S, bitDepth, 0, g.log2, static_cast<int16_t *>(g.dCoef), d_src, src_stride, d_pred, pred_stride, dj, g.m));
+        RC(havoc_mi355x_rdoq(ctx, bitDepth, g.log2, static_cast<int16_t *>(g.dLevel), static_cast<const int16_t *>(g.dCoef), d_states,
+                             static_cast<const havoc_mi355x_rdoq_job *>(hRjD), g.m, static_cast<int32_t *>(g.dCbf), g.dWork, havoc_mi355x_rdoq_workspace(g.m)));
+        // candidates reconstruct into private pieces (n x n, stride n): jobs' rec_off = piece offset
+        RC(havoc_mi355x_tu_reconstruct(ctx, S, bitDepth, 0, g.log2, quant[s].inv_scale, quant[s].inv_shift, g.dPiece, nn, d_pred, pred_stride, d_src, src_stride,
+                                       static_cast<const int16_t *>(g.dLevel), dj, g.m, static_cast<uint32_t *>(g.dSsd)));
+        RC(havoc_mi355x_level_stats(ctx, static_cast<const int16_t *>(g.dLevel), static_cast<const int32_t *>(hSjD), g.m, static_cast<int32_t *>(g.dStats)));
+        st.launches += 4;
+        st.candidates += g.m;
+    }
+    RC(havoc_mi355x_sync(ctx));
+    st.seconds_gpu += now() - tGpu;
+
+    // ---- decisions (tu_decision.hpp) from the downloaded outcomes
+    const double tHost = now();
+    std::vector<havoc_tu_outcome> outcome[4];
+    std::vector<int> cursor(4, 0);
+    for (int s = 0; s < 4; ++s)
+    {
+        outcome[s].resize(groups[s].m);
+        for (int j = 0; j < groups[s].m; ++j)
+            outcome[s][j] = {groups[s].hCbf[j], groups[s].hSsd[j], groups[s].hStats[2 * j], groups[s].hStats[2 * j + 1]};
+    }
+    Lambda rl;
+    rl.set(reciprocal_lambda);
+    std::vector<int> zeroAt(n), oneAt(n);
+    for (int i = 0; i < n; ++i)      // candidates were appended unit by unit: depth 0 to its size's list, then four to the next smaller
+    {
+        const int s0 = cus[i].log2_size - 2, s1 = s0 - 1;
+        zeroAt[i] = cursor[s0]++;
+        oneAt[i] = cursor[s1];
+        cursor[s1] += 4;
+    }
+    std::vector<havoc_mi355x_tu_fused_job> finalJobs[4];
+    for (int i = 0; i < n; ++i)
+    {
+        const int s0 = cus[i].log2_size - 2, s1 = s0 - 1;
+        LookupView view{&outcome[s0][zeroAt[i]], &outcome[s1][oneAt[i]]};
+        out[i] = decideRqt(view, cus[i], rl);
+        // the chosen candidates reconstruct into the picture
+        if (out[i].depth == 0)
+        {
+            havoc_mi355x_tu_fused_job j = groups[s0].hJobs[zeroAt[i]];
+            j.rec_off = int32_t(rec_origin + int64_t(cus[i].y0) * rec_stride + cus[i].x0);
+            if (!out[i].tried_zero) j.coef_off = -1;      // no residual: marked, handled below
+            finalJobs[s0].push_back(j);
+        }
+        else
+            for (int k = 0; k < 4; ++k)
+            {
+                havoc_mi355x_tu_fused_job j = groups[s1].hJobs[oneAt[i] + k];
+                const int nn = 1 << (s1 + 2);
+                j.rec_off = int32_t(rec_origin + int64_t(cus[i].y0 + (k >> 1) * nn) * rec_stride + cus[i].x0 + (k & 1) * nn);
+                finalJobs[s1].push_back(j);
+            }
+    }
+    st.seconds_host += now() - tHost;
+    const double tGpu2 = now();
+    // units left without residual: reconstruction = prediction.  Their depth-1 candidates all quantised to zero, so reconstructing those
+    // four (levels all zero) writes exactly the prediction: use them instead of a copy kernel
+    for (int i = 0; i < n; ++i)
+        if (out[i].depth == 0 && !out[i].tried_zero)
+        {
+            const int s1 = cus[i].log2_size - 3, nn = 1 << (s1 + 2);
+            for (int k = 0; k < 4; ++k)
+            {
+                havoc_mi355x_tu_fused_job j = groups[s1].hJobs[oneAt[i] + k];
+                j.rec_off = int32_t(rec_origin + int64_t(cus[i].y0 + (k >> 1) * nn) * rec_stride + cus[i].x0 + (k & 1) * nn);
+                finalJobs[s1].push_back(j);
+            }
+        }
+    for (int s = 0; s < 4; ++s)
+    {
+        std::vector<havoc_mi355x_tu_fused_job> &f = finalJobs[s];
+        f.erase(std::remove_if(f.begin(), f.end(), [](const havoc_mi355x_tu_fused_job &j) { return j.coef_off < 0; }), f.end());
+        if (f.empty()) continue;
+        void *d, *h, *hd, *dSsd, *hx;
+        RC(arena.get(f.size() * sizeof(f[0]), &d, &h, &hd));
+        RC(arena.get(f.size() * 4, &dSsd, &hx));
+        std::memcpy(h, f.data(), f.size() * sizeof(f[0]));
+        RC(havoc_mi355x_tu_reconstruct(ctx, S, bitDepth, 0, s + 2, quant[s].inv_scale, quant[s].inv_shift, d_rec, rec_stride, d_pred, pred_stride, d_src, src_stride,
+                                       static_cast<const int16_t *>(groups[s].dLevel), static_cast<const havoc_mi355x_tu_fused_job *>(hd), int(f.size()),
+                                       static_cast<uint32_t *>(dSsd)));
+        ++st.launches;
+    }
+    RC(havoc_mi355x_sync(ctx));
+    st.seconds_gpu += now() - tGpu2;
+    st.seconds_total = now() - tStart;
+    if (stats) *stats = st;
+    return 0;
+}
+
+} // extern "C"
