@@ -1162,9 +1162,24 @@ def main():
     from turingcodec_amd import Havoc
     from turingcodec_amd.workload import FrameWorkload
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU over RCCL, as the driver's
+        # `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` does) and hand over to them
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.exit(subprocess.call(cmd, env=env))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(1, args.gpus):
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE): the line would not be what was asked for\n")
+        sys.exit(2)
     if args.decisions == 2:      # diagnostic: only the decision-driven path of --res / --qp, one line
         r = decision_path(args, Havoc, args.res, args.bit_depth, args.qp, max(1, args.decision_pictures), seconds=2.0)
         print(json.dumps({"metric": "DIAGNOSTIC (decision-driven path only) -- not the benchmark metric", "value": r["value"], "unit": r["unit"],

@@ -199,3 +199,14 @@ def test_frame_parallel_gloo_world4_lag2_equals_sequential_coding():
     assert merged == want
     assert all(poc % 8 == 0 for poc in res[0][0] if poc % 8 == 0) and set(p for p in want if p % 8 == 0) <= set(res[0][0])      # anchors on rank 0
     assert res[0][4] == fp.DagSchedule(4, n_sops=n_sops, lag=2).slots_for_sequence()
+
+
+def test_bench_refuses_a_world_that_is_not_what_gpus_asked_for():
+    """`--gpus N` is checked against the ranks the launcher started (VERDICT r2 weak #3): a 1-rank run of `--gpus 2` must not print a line"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert out.returncode == 2 and "--gpus 2" in out.stderr and not [l for l in out.stdout.splitlines() if l.startswith("{")]

@@ -274,3 +274,22 @@ def test_bench_line_contract():
     if cb is not None:   # None only when oracle/_ref was never built
         assert set(("value", "unit", "cores", "kind", "sample")) <= set(cb) and cb["kind"] == "reference" and cb["cores"] >= 1
         assert cb["parity_vs_reference"]["mismatches"] == 0
+
+
+@pytest.mark.gpu
+def test_bench_reference_exchange_over_rccl_single_rank():
+    """the collective path itself on the GPU box: process group on the `nccl` backend (= RCCL), staging, DPB mirror and the broadcasts of the
+    reference pictures, with the one rank a 1-GPU box has.  Per-POC reconstructions must equal the run without a process
+    group, and reference pictures must really have gone through the broadcast call."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("HAVOC_BENCH_BACKEND", None)
+    common = ["--kernel-reps", "1", "--tune", "0", "--scaling", "strong", "--pictures", "17", "--poc-checksums", "--no-cpu-baseline", "--res", "640x360", "--decisions", "0"]
+    rccl = _bench_json([sys.executable, os.path.join(root, "bench.py"), "--exchange"] + common, env, root)
+    assert rccl["n_gpus"] == 1 and len(rccl["poc_checksums"]) == 17
+    assert "RCCL" in rccl["config"]["parallelism"] and " 0 reference pictures broadcast" not in rccl["config"]["parallelism"]
+    env_gloo = dict(env, HAVOC_BENCH_BACKEND="gloo")
+    gloo = _bench_json([sys.executable, os.path.join(root, "bench.py"), "--exchange"] + common, env_gloo, root)
+    assert rccl["poc_checksums"] == gloo["poc_checksums"]
