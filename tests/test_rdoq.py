@@ -196,3 +196,32 @@ def test_every_walk_form_of_32x32_blocks_matches_the_oracle(form):
     out = subprocess.run([sys.executable, "-c", _WALK_FORMS_SCRIPT, ROOT], capture_output=True, text=True, timeout=600,
                          env=dict(os.environ, HAVOC_RDOQ_DIAG=form))
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-1500:]
+
+
+_WALK_FORMS_16_SCRIPT = r"""
+import sys
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import rdoq_tools as rt, reflibs
+from turingcodec_amd import havoc
+hv = havoc.Havoc()
+oracle = reflibs.Oracle()
+for bd, seed, count in ((8, 81, 50), (8, 82, 700), (10, 83, 300)):
+    src, states, blocks = rt.make_blocks(seed, 4, bd, count, n_states=5)
+    want, want_cbf = rt.run_cpu(oracle, src, states, blocks)
+    got, got_cbf = hv.rdoq(bd, 4, src, states, rt.device_jobs(blocks, havoc.rdoq_lambda))
+    assert np.array_equal(got, want) and np.array_equal(got_cbf, want_cbf), (seed, int((got != want).sum()))
+print("ok")
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["0", "4", "8"])
+def test_every_walk_form_of_16x16_blocks_matches_the_oracle(form):
+    """HAVOC_RDOQ_DIAG16: how 16x16 blocks are walked -- 0: sequential kernel (a lane per block), 4 (default since round 3) / 8: the
+    anti-diagonal walk with that many lanes per block; each form in its own interpreter (the switch is read once per process)"""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, "-c", _WALK_FORMS_16_SCRIPT, ROOT], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, HAVOC_RDOQ_DIAG16=form))
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-1500:]

@@ -1136,12 +1136,27 @@ hipError_t launch_rdoq(hipStream_t st, int bitDepth, int log2, int16_t *dst, con
     // step 2.43 -> 2.63 ms with the diagonal walk forced).  16x16 blocks (39 k of them in a 1080p picture, 3 groups to walk on average, 7 at
     // most) have no chain worth shortening.  Diagnostic A/B switch (profiles/): HAVOC_RDOQ_DIAG = lanes per block, 0 (off), 4 or 8
     static const int diagEnv = getenv("HAVOC_RDOQ_DIAG") ? atoi(getenv("HAVOC_RDOQ_DIAG")) : 4;
-    const int diag = log2 != 5 || diagEnv == 0 || njobs > 16 * 1024 ? 0 : (diagEnv == 8 ? 8 : 4);
+    // 16x16 blocks (round 3): the anti-diagonal walk is instantiated for them too (HAVOC_RDOQ_DIAG16 = 4 or 8 lanes per
+    // block; parity: tests/test_rdoq.py) and MEASURED SLOWER than a lane per block -- 1080p QP32, 39 k blocks: 0.098 ms sequential, 0.157 ms
+    // with 4 lanes, 0.228 ms with 8; 4K QP27, 156 k blocks: 0.33 -> 0.82 ms; the whole step 0.521 -> 0.583 ms (profiles/r03/rdoq_*_diag16_*.json).
+    // A 16x16 block walks 3.2 groups on average and 7 at most: there is no chain to shorten, and the walk's replay of every round on every lane
+    // of a block is extra instructions.  What bounds the sequential form is latency with too little independent work to hide it (610
+    // wavefronts for 1 024 SIMDs); it overlaps with the step's other chains instead.  Default: 0.
+    static const int diag16Env = getenv("HAVOC_RDOQ_DIAG16") ? atoi(getenv("HAVOC_RDOQ_DIAG16")) : 0;
+    const int diag = log2 == 5 ? (diagEnv == 0 || njobs > 16 * 1024 ? 0 : (diagEnv == 8 ? 8 : 4)) : (diag16Env == 0 ? 0 : (diag16Env == 8 ? 8 : 4));
     if (diag)
     {
         const int wgd = (njobs + 64 / diag - 1) / (64 / diag);
-        if (diag == 4) hipLaunchKernelGGL((k_rdoq_diag<5, 4>), dim3(wgd), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work);
-        else hipLaunchKernelGGL((k_rdoq_diag<5, 8>), dim3(wgd), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work);
+        if (log2 == 5)
+        {
+            if (diag == 4) hipLaunchKernelGGL((k_rdoq_diag<5, 4>), dim3(wgd), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work);
+            else hipLaunchKernelGGL((k_rdoq_diag<5, 8>), dim3(wgd), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work);
+        }
+        else
+        {
+            if (diag == 4) hipLaunchKernelGGL((k_rdoq_diag<4, 4>), dim3(wgd), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work);
+            else hipLaunchKernelGGL((k_rdoq_diag<4, 8>), dim3(wgd), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work);
+        }
     }
     // blocks with a horizontal / vertical scan (none in the reference's encoder at these sizes): the sequential walk; exits at once when there are none
     if (log2 == 4) hipLaunchKernelGGL((k_rdoq_walk<4, true>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work, diag);
