@@ -201,6 +201,32 @@ int havoc_mi355x_deblock(havoc_mi355x_ctx *ctx, int S, int bitDepth, void *d_lum
                          int width, int height, const int8_t *d_block_data, const uint8_t *d_block_bs, int tc_offset_div2, int beta_offset_div2,
                          int cb_qp_offset, int cr_qp_offset);
 
+/* The boundary strengths and QP bytes havoc_mi355x_deblock reads, DERIVED on the device from the picture's block structure
+ * (LoopFilter::Picture::processCu / processPu / processTu / processRc, turing/LoopFilter.h:541-737, and sameMotion, :402-422) -- the
+ * encoder's decisions as a map of 4x4 luma cells, which is what a device-side encoder holds after mode decision:
+ *   a transform block edge on the 8-sample grid gets strength 2 where the block on either side is intra, 1 where either side is an
+ *   inter block with coded luma coefficients; the left / top edge of an inter prediction unit gets 1 where the motion across it differs
+ *   (different pictures, or a vector component 4 or more quarter samples apart, lists matched either way round); the maximum stands.
+ * A cell outside the picture counts as "no motion" (what the reference's unavailable neighbour is).  PCM units are not modelled (the
+ * reference's encoder never emits them).  Writes the whole grid of ((width + 63) / 64 * 8 + 1) x ((height + 63) / 64 * 8 + 1) regions. */
+typedef struct {
+    int16_t mv[2][2];     /* [list][x, y], quarter samples */
+    int8_t dpb_index[2];  /* which decoded picture each list predicts from; -1 = list unused (both -1: intra / no motion) */
+    uint8_t flags;        /* HAVOC_CELL_* */
+    int8_t qp_y;
+    uint8_t tu_log2;      /* log2 size of the luma transform block holding the cell (2..5) */
+    uint8_t reserved[3];
+} havoc_mi355x_cell; /* 16 bytes */
+enum {
+    HAVOC_CELL_INTRA = 1,      /* CuPredMode == MODE_INTRA */
+    HAVOC_CELL_CODED = 2,      /* cbf_luma of its transform block */
+    HAVOC_CELL_NO_FILTER = 4,  /* cu_transquant_bypass_flag (Block::packData's disable bit) */
+    HAVOC_CELL_PU_LEFT = 8,    /* the cell lies on the left edge of its prediction unit */
+    HAVOC_CELL_PU_TOP = 16     /* ... on its top edge */
+};
+int havoc_mi355x_derive_bs(havoc_mi355x_ctx *ctx, const havoc_mi355x_cell *d_cells, intptr_t cells_stride, int width, int height, int8_t *d_block_data,
+                           uint8_t *d_block_bs);
+
 /* Device-side picture store + input upload.  A picture = the three planes of Picture<Sample>
  * (turing/Picture.cpp:91-125) in ONE HBM allocation: per plane `pad` samples of border (chroma: pad / 2), row stride rounded
  * up to `alignment` bytes (the reference: pad 96, alignment 32, turing/StatePictures.h:155-156; this library's kernels are

@@ -602,3 +602,82 @@ void oracle_deblock(void *luma, intptr_t stride_y, void *cb, void *cr, intptr_t 
                 }
             }
 }
+
+
+/* ---- boundary strengths of the deblocking filter from a picture's block structure ------------------------------------------------------
+ * turing/LoopFilter.h: a transform unit of an intra coding unit raises the four edges of its luma block that lie on the 8-sample grid to
+ * 2 (processTu, :645-690), a coded luma transform block of an inter unit raises them to 1 (processRc, :692-737), the left and top edge of a
+ * prediction unit are raised to 1 over every 4-sample segment whose neighbour across the edge has different motion (processPu, :608-643,
+ * sameMotion :402-422); strengths only ever go up (increaseBs, :85-89).  The byte of a region: (QpY << 1) | cu_transquant_bypass
+ * (processCu :585-605, packData :57-64).  Restated per 4x4 cell: an edge segment looks at the cell on either side. */
+typedef struct { int16_t mv[2][2]; int8_t dpb[2]; uint8_t flags; int8_t qp; uint8_t tu_log2; uint8_t pad[3]; } oracle_cell;
+
+static int cell_same1(const oracle_cell *a, int la, const oracle_cell *b, int lb)
+{
+    if (a->dpb[la] != b->dpb[lb]) return 0;
+    if (a->dpb[la] < 0) return 1;
+    if (abs(a->mv[la][0] - b->mv[lb][0]) >= 4) return 0;
+    if (abs(a->mv[la][1] - b->mv[lb][1]) >= 4) return 0;
+    return 1;
+}
+
+static int cell_same(const oracle_cell *a, const oracle_cell *b)
+{
+    if (cell_same1(a, 0, b, 0) && cell_same1(a, 1, b, 1)) return 1;
+    return cell_same1(a, 0, b, 1) && cell_same1(a, 1, b, 0);
+}
+
+static int cell_edge(const oracle_cell *a, const oracle_cell *b, int pos, int pu_edge_flag)
+{
+    static const oracle_cell none = {{{0, 0}, {0, 0}}, {-1, -1}, 0, 0, 0, {0, 0, 0}};
+    int bs = 0, v;
+    if (a && pos % (1 << a->tu_log2) == 0)
+    {
+        v = (a->flags & 1) ? 2 : ((a->flags & 2) ? 1 : 0);
+        if (v > bs) bs = v;
+    }
+    if (b && pos % (1 << b->tu_log2) == 0)
+    {
+        v = (b->flags & 1) ? 2 : ((b->flags & 2) ? 1 : 0);
+        if (v > bs) bs = v;
+    }
+    if (b && (b->flags & pu_edge_flag) && !(b->flags & 1) && !cell_same(a ? a : &none, b) && bs < 1) bs = 1;
+    return bs;
+}
+
+void oracle_derive_bs(const void *cells_, intptr_t cs, int width, int height, int8_t *data, uint8_t *bs)
+{
+    const oracle_cell *cells = (const oracle_cell *)cells_;
+    const int gw = (width + 63) / 64 * 8 + 1, gh = (height + 63) / 64 * 8 + 1, cw = width / 4, ch = height / 4;
+    for (int ry = 0; ry < gh; ++ry)
+        for (int rx = 0; rx < gw; ++rx)
+        {
+            int packed = 0;
+            int8_t d = 0;
+            for (int k = 0; k < 2; ++k)
+            {
+                /* vertical edge at x = 8 rx, rows 8 ry + 4 k */
+                int cy = 2 * ry + k, cx = 2 * rx;
+                if (cy < ch)
+                {
+                    const oracle_cell *a = cx - 1 >= 0 && cx - 1 < cw ? &cells[cy * cs + cx - 1] : 0, *b = cx < cw ? &cells[cy * cs + cx] : 0;
+                    if (a || b) packed |= cell_edge(a, b, 8 * rx, 8) << (2 * k);
+                }
+                /* horizontal edge at y = 8 ry, columns 8 rx + 4 k */
+                cx = 2 * rx + k;
+                cy = 2 * ry;
+                if (cx < cw)
+                {
+                    const oracle_cell *a = cy - 1 >= 0 && cy - 1 < ch ? &cells[(cy - 1) * cs + cx] : 0, *b = cy < ch ? &cells[cy * cs + cx] : 0;
+                    if (a || b) packed |= cell_edge(a, b, 8 * ry, 16) << (4 + 2 * k);
+                }
+            }
+            if (2 * rx < cw && 2 * ry < ch)
+            {
+                const oracle_cell *c = &cells[2 * ry * cs + 2 * rx];
+                d = (int8_t)((c->qp << 1) | ((c->flags & 4) ? 1 : 0));
+            }
+            data[ry * gw + rx] = d;
+            bs[ry * gw + rx] = (uint8_t)packed;
+        }
+}

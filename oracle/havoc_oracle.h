@@ -68,6 +68,11 @@ void oracle_deblock(void *luma, intptr_t stride_y, void *cb, void *cr, intptr_t 
                     const int8_t *block_data, const uint8_t *block_bs, int tc_offset_div2, int beta_offset_div2, int cb_qp_offset,
                     int cr_qp_offset, int S);
 
+/* turing/LoopFilter.h:402-422 (sameMotion) and :541-737 (processCu / processPu / processTu / processRc), restated per 4x4 luma cell:
+ * cells = 16-byte records of include/havoc_mi355x.h (havoc_mi355x_cell), cells_stride per row; outputs the two arrays of LoopFilter::Block
+ * on the grid of ((width + 63) / 64 * 8 + 1) x ((height + 63) / 64 * 8 + 1) regions */
+void oracle_derive_bs(const void *cells, intptr_t cells_stride, int width, int height, int8_t *block_data, uint8_t *block_bs);
+
 /* turing/Measure.h:97-135 (measureSatd): PU SATD tiled in 8x8 / 4x4 / 2x2 Hadamards */
 int oracle_pu_satd(const void *a, intptr_t stride_a, const void *b, intptr_t stride_b, int w, int h, int S);
 

@@ -303,3 +303,10 @@ int havoc_mi355x_rdoq(havoc_mi355x_ctx *ctx, int bitDepth, int log2, int16_t *ds
                              j[i].inv_scale, bitDepth, j[i].lambda_q16, j[i].sdh_factor, states + 128 * (long)j[i].ctx_index);
     return 0;
 }
+
+int havoc_mi355x_derive_bs(havoc_mi355x_ctx *ctx, const havoc_mi355x_cell *cells, intptr_t cs, int width, int height, int8_t *data, uint8_t *bs)
+{
+    (void)ctx; ++g_launches;
+    oracle_derive_bs(cells, cs, width, height, data, bs);
+    return 0;
+}

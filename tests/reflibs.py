@@ -122,6 +122,16 @@ class Oracle:
         """in place on the three planes (numpy arrays whose element 0 is sample (0, 0))"""
         self.L.oracle_deblock(_addr(luma), sy, _addr(cb), _addr(cr), sc, width, height, bd, _addr(data), _addr(bs), tc2, beta2, cb_qp, cr_qp, _S(luma))
 
+    def derive_bs(self, cells, width, height):
+        """cells: CELL_DT-like structured array [height / 4, width / 4] -> (block_data int8, block_bs uint8) of the region grid"""
+        n = ((width + 63) // 64 * 8 + 1) * ((height + 63) // 64 * 8 + 1)
+        data, bs = np.zeros(n, np.int8), np.zeros(n, np.uint8)
+        cells = np.ascontiguousarray(cells)
+        self.L.oracle_derive_bs.restype = None
+        self.L.oracle_derive_bs.argtypes = [_vp, _ip, C.c_int, C.c_int, _vp, _vp]
+        self.L.oracle_derive_bs(cells.ctypes.data, cells.shape[1], width, height, data.ctypes.data, bs.ctypes.data)
+        return data, bs
+
     # every method: arrays are flat (or 2-D C-contiguous) numpy arrays, offsets/strides in samples
     def sad(self, src, so, ss, ref, ro, rs, w, h):
         return self.L.oracle_sad(_addr(src, so), ss, _addr(ref, ro), rs, w, h, _S(src))
@@ -245,6 +255,18 @@ class Reference:
         f.restype = None
         f.argtypes = [_vp, _ip, _vp, _vp, _ip, C.c_int, C.c_int, C.c_int, _vp, _vp] + [C.c_int] * 4
         f(_addr(luma), sy, _addr(cb), _addr(cr), sc, width, height, bd, _addr(data), _addr(bs), tc2, beta2, cb_qp, cr_qp)
+
+    def derive_bs(self, width, height, cus, pus, tus):
+        """the reference's own LoopFilter::Picture::processCu / Tu / Rc and sameMotion over lists of units (oracle/ref_shim_deblock.cpp):
+        cus int32 [n, 6], pus int32 [n, 10], tus int32 [n, 5] -> (block_data int8, block_bs uint8)"""
+        n = ((width + 63) // 64 * 8 + 1) * ((height + 63) // 64 * 8 + 1)
+        data, bs = np.zeros(n, np.int8), np.zeros(n, np.uint8)
+        cus, pus, tus = (np.ascontiguousarray(a, np.int32) for a in (cus, pus, tus))
+        f = self.L.ref_derive_bs
+        f.restype = None
+        f.argtypes = [C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp]
+        f(width, height, cus.ctypes.data, len(cus), pus.ctypes.data, len(pus), tus.ctypes.data, len(tus), data.ctypes.data, bs.ctypes.data)
+        return data, bs
 
     def _f(self, name, a):
         return getattr(self.L, name + "_" + self._sfx(a))

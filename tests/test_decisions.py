@@ -67,8 +67,31 @@ def test_decision_step_equals_the_reference_functions(res, BD, qp):
     pred = hv.down(dp.pred, dp.dt).copy()
     exp_rqt, exp_rec = ref.rqt(BD, dp.host_planes[0], dp.stride, dp.PAD, pred, dp.W, dp.rdoq_states, dp.quant, dp.lam, 1.0 / dp.lam, dp.units)
     assert dp.rqt_results.tobytes() == exp_rqt.tobytes()
-    assert np.array_equal(hv.down(dp.recon, dp.dt)[:dp.n], exp_rec)
     assert dp.rqt_stats.launches <= 5 * 4 + 4 and (exp_rqt["depth"] == 1).any() and (exp_rqt["depth"] == 0).any()
+    # ... the loop filter that follows in the step: strengths derived on the device from the decided block structure == the reference's own
+    # derivation (LoopFilter.h processCu / Tu / Rc + sameMotion over the same units), then its deblocking templates and padding
+    R = reflibs.Reference()
+    u = dp.units
+    size = 1 << u["log2_size"]
+    mv0 = exp_field[0, u["y0"] >> 2, u["x0"] >> 2]
+    cus = np.stack([u["x0"], u["y0"], u["log2_size"], np.zeros_like(size), np.full_like(size, qp), np.zeros_like(size)], 1)
+    pus = np.stack([u["x0"], u["y0"], size, size, mv0[:, 0], mv0[:, 1], np.zeros_like(size), np.zeros_like(size), np.zeros_like(size), np.full_like(size, -1)], 1)
+    tus = []
+    for i in range(len(u)):
+        if exp_rqt["depth"][i] == 1:
+            h = int(size[i]) // 2
+            tus += [(int(u["x0"][i]) + (k & 1) * h, int(u["y0"][i]) + (k >> 1) * h, int(u["log2_size"][i]) - 1, int(exp_rqt["one"]["cbf"][i, k] != 0), 0) for k in range(4)]
+        else:
+            tus.append((int(u["x0"][i]), int(u["y0"][i]), int(u["log2_size"][i]), int(exp_rqt["tried_zero"][i] == 1 and exp_rqt["zero"]["cbf"][i] != 0), 0))
+    want_data, want_bs = R.derive_bs(dp.W, dp.H, cus, pus, np.array(tus, np.int32))
+    assert np.array_equal(hv.down(dp.d_data, np.int8), want_data) and np.array_equal(hv.down(dp.d_bs, np.uint8), want_bs)
+    assert (want_bs != 0).any()
+    cb = np.full((dp.H // 2) * (dp.W // 2), 128 << (BD - 8), dp.dt)
+    cr = cb.copy()
+    o = dp.PAD * dp.stride + dp.PAD
+    R.deblock(exp_rec[o:], dp.stride, cb, cr, dp.W // 2, dp.W, dp.H, BD, want_data, want_bs)
+    R.pad_block(exp_rec, o, dp.W, dp.H, dp.stride, dp.PAD, True, True, True, True)
+    assert np.array_equal(hv.down(dp.recon, dp.dt)[:dp.n], exp_rec)
     # the fixed-size chain (16x16 blocks) on the same vectors: every intermediate against the reference's functions
     dp.tu_chain_fixed(field)
     hv.sync()

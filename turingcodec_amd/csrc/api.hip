@@ -13,6 +13,7 @@ hipError_t launch_satd(hipStream_t, int S, int maxw, int maxh, const void *, lon
 hipError_t launch_satd_multi(hipStream_t, int S, int maxw, int maxh, const void *, long, const void *, long, const void *, int, int32_t *);
 hipError_t launch_pad_block(hipStream_t, int S, void *, long, int, int, long, int, int, int, int, int);
 hipError_t launch_ssd_linear(hipStream_t, const uint8_t *, const uint8_t *, int, int32_t *);
+hipError_t launch_derive_bs(hipStream_t, const void *, long, int, int, int8_t *, uint8_t *);
 hipError_t launch_deblock(hipStream_t, int S, int bd, void *, long, void *, void *, long, int, int, const int8_t *, const uint8_t *, int, int, int, int);
 hipError_t launch_pred_uni(hipStream_t, int S, int taps, int bd, int maxw, int maxh, void *, long, const void *, long, const void *, int);
 hipError_t launch_pred_bi(hipStream_t, int S, int taps, int bd, int maxw, int maxh, void *, long, const void *, long, const void *, int);
@@ -350,6 +351,15 @@ int havoc_mi355x_pad_block(havoc_mi355x_ctx *ctx, int S, void *d_plane, int64_t 
     REQUIRE_CTX(); REQUIRE_S();
     REQUIRE(width > 0 && height > 0 && pad >= 0, "width / height must be positive, pad >= 0");
     return check(launch_pad_block(LS(ctx), S, d_plane, (long)origin_off, width, height, stride, pad, top, bottom, left, right), "pad_block");
+}
+
+int havoc_mi355x_derive_bs(havoc_mi355x_ctx *ctx, const havoc_mi355x_cell *d_cells, intptr_t cells_stride, int width, int height, int8_t *d_block_data,
+                           uint8_t *d_block_bs)
+{
+    REQUIRE_CTX();
+    REQUIRE(d_cells && d_block_data && d_block_bs, "null pointer");
+    REQUIRE(width > 0 && height > 0 && (width & 7) == 0 && (height & 7) == 0 && cells_stride >= width / 4, "picture size must be a multiple of 8 (minimum coding unit)");
+    return check(launch_derive_bs(LS(ctx), d_cells, (long)cells_stride, width, height, d_block_data, d_block_bs), "derive_bs");
 }
 
 int havoc_mi355x_deblock(havoc_mi355x_ctx *ctx, int S, int bitDepth, void *d_luma, intptr_t stride_luma, void *d_cb, void *d_cr, intptr_t stride_chroma,

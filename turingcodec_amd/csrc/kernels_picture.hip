@@ -215,6 +215,79 @@ __global__ __launch_bounds__(256) void k_deblock(DeblockArgs a)
     }
 }
 
+// ---- boundary strengths from the block structure (LoopFilter::Picture::processCu / Pu / Tu / Rc, turing/LoopFilter.h:541-737) ----
+struct Cell { int16_t mv[2][2]; int8_t dpb[2]; uint8_t flags; int8_t qp; uint8_t tuLog2; uint8_t pad[3]; };
+static_assert(sizeof(Cell) == 16, "havoc_mi355x_cell");
+
+// LoopFilter.h:402-409
+__device__ __forceinline__ bool sameMotion1(const Cell &a, int la, const Cell &b, int lb)
+{
+    if (a.dpb[la] != b.dpb[lb]) return false;
+    if (a.dpb[la] < 0) return true;
+    return abs(a.mv[la][0] - b.mv[lb][0]) < 4 && abs(a.mv[la][1] - b.mv[lb][1]) < 4;
+}
+// LoopFilter.h:411-422
+__device__ __forceinline__ bool sameMotion(const Cell &a, const Cell &b)
+{
+    if (sameMotion1(a, 0, b, 0) && sameMotion1(a, 1, b, 1)) return true;
+    return sameMotion1(a, 0, b, 1) && sameMotion1(a, 1, b, 0);
+}
+
+// strength of the 4-sample edge segment between cell a (left / above; null outside the picture) and cell b (right / below; null outside),
+// `pos` = the edge's coordinate across it (a multiple of 8), puEdge = b lies on that edge of its prediction unit
+__device__ __forceinline__ int edgeStrength(const Cell *a, const Cell *b, int pos, bool puEdge)
+{
+    int bs = 0;
+    if (a && (pos & ((1 << a->tuLog2) - 1)) == 0)      // the right / bottom edge of a's transform block
+        bs = max(bs, (a->flags & HAVOC_CELL_INTRA) ? 2 : ((a->flags & HAVOC_CELL_CODED) ? 1 : 0));
+    if (b && (pos & ((1 << b->tuLog2) - 1)) == 0)      // the left / top edge of b's
+        bs = max(bs, (b->flags & HAVOC_CELL_INTRA) ? 2 : ((b->flags & HAVOC_CELL_CODED) ? 1 : 0));
+    if (b && puEdge && !(b->flags & HAVOC_CELL_INTRA))
+    {
+        Cell none;
+        none.dpb[0] = none.dpb[1] = -1;
+        none.mv[0][0] = none.mv[0][1] = none.mv[1][0] = none.mv[1][1] = 0;
+        if (!sameMotion(a ? *a : none, *b)) bs = max(bs, 1);
+    }
+    return bs;
+}
+
+// one thread per 8x8 region of the grid (incl. the extra column / row and the part of the last CTUs beyond the picture)
+__global__ __launch_bounds__(256) void k_derive_bs(const Cell *__restrict__ cells, long cstride, int width, int height, int gridW, int gridH,
+                                                   int8_t *__restrict__ data, uint8_t *__restrict__ bsOut)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= gridW * gridH) return;
+    const int rx = i % gridW, ry = i / gridW, x = rx * 8, y = ry * 8;
+    const int cw = width >> 2, ch = height >> 2;
+    auto at = [&](int cx, int cy) -> const Cell * { return (cx >= 0 && cy >= 0 && cx < cw && cy < ch) ? cells + (long)cy * cstride + cx : nullptr; };
+    int packed = 0;
+    int8_t d = 0;
+    if (x <= width && y <= height)
+    {
+        for (int k = 0; k < 2; ++k)
+        {
+            // vertical edge at x, rows y + 4k .. +3
+            const Cell *a = at(rx * 2 - 1, ry * 2 + k), *b = at(rx * 2, ry * 2 + k);
+            if (a || b) packed |= edgeStrength(a, b, x, b && (b->flags & HAVOC_CELL_PU_LEFT)) << (2 * k);
+            // horizontal edge at y, columns x + 4k .. +3
+            a = at(rx * 2 + k, ry * 2 - 1);
+            b = at(rx * 2 + k, ry * 2);
+            if (a || b) packed |= edgeStrength(a, b, y, b && (b->flags & HAVOC_CELL_PU_TOP)) << (4 + 2 * k);
+        }
+        if (const Cell *c = at(rx * 2, ry * 2)) d = (int8_t)((c->qp << 1) | ((c->flags & HAVOC_CELL_NO_FILTER) ? 1 : 0));
+    }
+    data[i] = d;
+    bsOut[i] = (uint8_t)packed;
+}
+
+hipError_t launch_derive_bs(hipStream_t st, const void *cells, long cstride, int width, int height, int8_t *data, uint8_t *bs)
+{
+    const int gridW = (width + 63) / 64 * 8 + 1, gridH = (height + 63) / 64 * 8 + 1;
+    hipLaunchKernelGGL(k_derive_bs, dim3((gridW * gridH + 255) / 256), dim3(256), 0, st, (const Cell *)cells, cstride, width, height, gridW, gridH, data, bs);
+    return hipGetLastError();
+}
+
 hipError_t launch_deblock(hipStream_t st, int S, int bitDepth, void *luma, long strideY, void *cb, void *cr, long strideC, int width, int height,
                           const int8_t *data, const uint8_t *bs, int tcOffsetDiv2, int betaOffsetDiv2, int cbQpOffset, int crQpOffset)
 {

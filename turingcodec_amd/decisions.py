@@ -82,6 +82,8 @@ def lib():
         L.havoc_search_rqt.argtypes = [vp, C.c_int, C.c_int, vp, i64, ip, vp, ip, vp, i64, ip, vp, vp, C.c_double, C.c_double, C.c_int, vp, C.c_int, vp,
                                        C.POINTER(RqtStats)]
         L.havoc_search_rqt.restype = C.c_int
+        L.havoc_search_block_cells.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp]
+        L.havoc_search_block_cells.restype = C.c_int
         L.havoc_search_release.argtypes = [vp]
         L.havoc_search_release.restype = None
         _lib = L
@@ -248,10 +250,18 @@ class DecisionPicture:
                            self.pus, self.ctu_first, self.cx, self.cy, self.mvp_rate, self.threads)
 
     def predict(self, field):
-        """HavocPredUni of every block at the decided list-0 vector into the prediction plane; asynchronous"""
+        """HavocPredUni of every inter unit (a 2Nx2N prediction unit per unit of rqt_units) at the list-0 vector decided at its origin, into the
+        prediction plane; asynchronous"""
         hv, bd, pe = self.hv, self.bd, self.pe
         ref0 = self.d_pic[pe:2 * pe]
-        for g in self.groups:
+        if not hasattr(self, "pgroups"):
+            self.pgroups = []
+            for log2 in (5, 4, 3):
+                sel = np.flatnonzero(self.units["log2_size"] == log2)
+                if len(sel):
+                    self.pgroups.append(dict(nn=1 << log2, x0=self.units["x0"][sel].astype(np.int64), y0=self.units["y0"][sel].astype(np.int64),
+                                             pj=np.zeros((len(sel), 8), np.int32), d_pj=hv.zeros(len(sel) * 8, np.int32)))
+        for g in self.pgroups:
             mv = field[0, g["y0"] >> 2, g["x0"] >> 2].astype(np.int64)          # quarter samples, [m, 2]
             pj = g["pj"]
             pj[:, 0] = g["y0"] * self.W + g["x0"]
@@ -270,6 +280,36 @@ class DecisionPicture:
                                    self.stride, self.d_states.data_ptr(), self.quant, self.lam, 1.0 / self.lam, self.units)
         self.rqt_stats = st
         return self.rqt_results, st
+
+    def block_cells(self, field, decisions):
+        """the picture's block structure after the decisions, as the 4x4 cells havoc_mi355x_derive_bs reads: every unit one inter 2Nx2N
+        prediction unit from list 0 at the vector decided at its origin, its transform tree as decided (coded flags per block)"""
+        from .havoc import CELL_DT
+        cells = np.zeros((self.H // 4, self.W // 4), CELL_DT)
+        field = np.ascontiguousarray(field)
+        decisions = np.ascontiguousarray(decisions)
+        rc = lib().havoc_search_block_cells(self.W, self.H, self.qp, 0, field.ctypes.data, self.units.ctypes.data, decisions.ctypes.data, len(self.units),
+                                            cells.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(f"havoc_search_block_cells failed ({rc})")
+        return cells
+
+    def loop_filter(self, cells):
+        """boundary strengths derived on the device from the block structure, in-loop deblocking of the reconstruction (luma; flat chroma planes
+        stand in), padding: the reconstruction is then a reference picture.  Asynchronous."""
+        hv, torch = self.hv, self.torch
+        n = ((self.W + 63) // 64 * 8 + 1) * ((self.H + 63) // 64 * 8 + 1)
+        if not hasattr(self, "d_bs"):
+            with torch.cuda.stream(hv.tstream):
+                self.d_data = torch.zeros(n, dtype=torch.int8, device=hv.device)
+                self.d_bs = torch.zeros(n, dtype=torch.uint8, device=hv.device)
+                self.d_cells = torch.zeros(cells.size * 16, dtype=torch.uint8, device=hv.device)
+            self.d_chroma = hv.up(np.full(2 * (self.H // 2) * (self.W // 2), 128 << (self.bd - 8), self.dt))
+        with torch.cuda.stream(hv.tstream):
+            self.d_cells.copy_(torch.from_numpy(cells.view(np.uint8).reshape(-1)), non_blocking=True)
+        hv.derive_bs_d(self.d_cells, cells.shape[1], self.W, self.H, self.d_data, self.d_bs)
+        hv.deblock_d(self.bd, self.recon, self.origin, self.stride, self.d_chroma, 0, (self.H // 2) * (self.W // 2), self.W // 2, self.W, self.H, self.d_data, self.d_bs)
+        hv.pad_block_d(self.recon, self.origin, self.W, self.H, self.stride, self.PAD)
 
     def tu_chain_fixed(self, field):
         """prediction at the decided list-0 vectors, then residual -> T -> RDOQ -> IQ -> IT + add -> SSD on fixed 16x16 (8x8) blocks; asynchronous"""
@@ -293,7 +333,9 @@ class DecisionPicture:
     def step(self):
         self.phase_planes()
         res, field, stats = self.search()
-        self.tu_chain(field)
+        decisions, _ = self.tu_chain(field)
+        self.cells = self.block_cells(field, decisions)
+        self.loop_filter(self.cells)
         self.hv.sync()
         return res, field, stats
 

@@ -72,6 +72,7 @@ def _load():
         "pad_block": [_vp, _i, _vp, C.c_int64, _i, _i, _ip, _i, _i, _i, _i, _i],
         "sad_surface": [_vp, _i, _i, _i, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
         "deblock": [_vp, _i, _i, _vp, _ip, _vp, _vp, _ip, _i, _i, _vp, _vp, _i, _i, _i, _i],
+        "derive_bs": [_vp, _vp, _ip, _i, _i, _vp, _vp],
         "ssd": [_vp, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
         "satd": [_vp, _i, _i, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
         "satd_multi": [_vp, _i, _i, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
@@ -113,6 +114,11 @@ def exported_symbols():
     _, names = _load()
     return ["havoc_mi355x_" + n for n in names] + ["havoc_mi355x_last_error", "havoc_mi355x_version", "havoc_mi355x_rdoq_lambda", "havoc_mi355x_rdoq_workspace"]
 
+
+# one havoc_mi355x_cell (include/havoc_mi355x.h), 16 bytes: a 4x4 luma cell of a picture's block structure
+CELL_DT = np.dtype([("mv", "<i2", (2, 2)), ("dpb_index", "i1", (2,)), ("flags", "u1"), ("qp_y", "i1"), ("tu_log2", "u1"), ("reserved", "u1", (3,))])
+assert CELL_DT.itemsize == 16
+CELL_INTRA, CELL_CODED, CELL_NO_FILTER, CELL_PU_LEFT, CELL_PU_TOP = 1, 2, 4, 8, 16
 
 # one havoc_mi355x_sao_job (include/havoc_mi355x.h), 96 bytes
 SAO_JOB_DT = np.dtype([("dst_off", "<i4"), ("src_off", "<i4"), ("w", "<i4"), ("h", "<i4"), ("type", "<i4"), ("eo_class", "<i4"), ("offsets", "<i2", 32),
@@ -280,6 +286,23 @@ class Havoc:
         self.deblock_d(bd, y, 0, sy, c, 0, cb.size, sc, width, height, d, b, tc2, beta2, cb_qp, cr_qp)
         o = self.down(c, cb.dtype)
         return self.down(y, luma.dtype), o[:cb.size].reshape(cb.shape), o[cb.size:].reshape(cr.shape)
+
+    def derive_bs_d(self, cells, cells_stride, width, height, data, bs):
+        """cells: uint8 tensor holding CELL_DT records (cells_stride cells per row); data int8 / bs uint8 tensors of the region grid"""
+        self._ck(self.L.havoc_mi355x_derive_bs(self.h, _ptr(cells), cells_stride, width, height, _ptr(data), _ptr(bs)))
+
+    def derive_bs(self, cells, width, height):
+        """numpy level: cells CELL_DT [height / 4, width / 4] -> (block_data int8, block_bs uint8) flat arrays of the region grid"""
+        import torch
+        cells = np.ascontiguousarray(cells)
+        n = ((width + 63) // 64 * 8 + 1) * ((height + 63) // 64 * 8 + 1)
+        with torch.cuda.stream(self.tstream):
+            d_cells = torch.from_numpy(cells.view(np.uint8).reshape(-1)).to(self.device)
+            data = torch.zeros(n, dtype=torch.int8, device=self.device)
+            bs = torch.zeros(n, dtype=torch.uint8, device=self.device)
+        self.derive_bs_d(d_cells, cells.shape[1], width, height, data, bs)
+        with torch.cuda.stream(self.tstream):
+            return data.cpu().numpy(), bs.cpu().numpy()
 
     def sad4_d(self, src, ss, ref, rs, jobs, out):
         self._ck(self.L.havoc_mi355x_sad4(self.h, self._S(src), _ptr(src), ss, _ptr(ref), rs, _ptr(jobs), jobs.shape[0], _ptr(out)))

@@ -207,4 +207,41 @@ int havoc_search_rqt(havoc_mi355x_ctx *ctx, int S, int bitDepth, const void *d_s
     return 0;
 }
 
+// The picture's block structure after the decisions, as the 4x4 cells havoc_mi355x_derive_bs reads (host work, no launch): every unit one
+// inter 2Nx2N prediction unit from list 0 (decoded picture `dpb_index0`) at the vector the motion field holds at its origin, its transform
+// tree as decided by havoc_search_rqt (coded flag per block).  field: int16 [2 lists][height / 4][width / 4][x, y] (havoc_search_picture_uni);
+// cells: [height / 4][width / 4], written completely.
+int havoc_search_block_cells(int width, int height, int qp, int dpb_index0, const int16_t *field, const havoc_rqt_cu *cus, const havoc_rqt_result *dec, int n,
+                             havoc_mi355x_cell *cells)
+{
+    if (!field || !cus || !dec || !cells || width <= 0 || height <= 0 || (width & 3) || (height & 3)) return HAVOC_MI355X_EINVAL;
+    const int cw = width >> 2, ch = height >> 2;
+    havoc_mi355x_cell blank;
+    std::memset(&blank, 0, sizeof(blank));
+    blank.dpb_index[0] = int8_t(dpb_index0);
+    blank.dpb_index[1] = -1;
+    blank.qp_y = int8_t(qp);
+    blank.tu_log2 = 2;
+    for (int i = 0; i < cw * ch; ++i) cells[i] = blank;
+    for (int i = 0; i < n; ++i)
+    {
+        const havoc_rqt_cu &u = cus[i];
+        const int x4 = u.x0 >> 2, y4 = u.y0 >> 2, n4 = (1 << u.log2_size) >> 2, half = n4 / 2;
+        if (x4 < 0 || y4 < 0 || x4 + n4 > cw || y4 + n4 > ch) return HAVOC_MI355X_EINVAL;
+        const int16_t *mv = field + (size_t(y4) * cw + x4) * 2;
+        const bool split = dec[i].depth == 1, coded0 = dec[i].tried_zero == 1 && dec[i].zero.cbf != 0;
+        for (int y = 0; y < n4; ++y)
+            for (int x = 0; x < n4; ++x)
+            {
+                havoc_mi355x_cell &c = cells[size_t(y4 + y) * cw + x4 + x];
+                c.mv[0][0] = mv[0];
+                c.mv[0][1] = mv[1];
+                const bool coded = split ? dec[i].one[(y >= half) * 2 + (x >= half)].cbf != 0 : coded0;
+                c.flags = uint8_t((coded ? HAVOC_CELL_CODED : 0) | (x == 0 ? HAVOC_CELL_PU_LEFT : 0) | (y == 0 ? HAVOC_CELL_PU_TOP : 0));
+                c.tu_log2 = uint8_t(u.log2_size - (split ? 1 : 0));
+            }
+    }
+    return 0;
+}
+
 } // extern "C"
