@@ -207,7 +207,8 @@ int havoc_mi355x_deblock(havoc_mi355x_ctx *ctx, int S, int bitDepth, void *d_lum
  *   a transform block edge on the 8-sample grid gets strength 2 where the block on either side is intra, 1 where either side is an
  *   inter block with coded luma coefficients; the left / top edge of an inter prediction unit gets 1 where the motion across it differs
  *   (different pictures, or a vector component 4 or more quarter samples apart, lists matched either way round); the maximum stands.
- * A cell outside the picture counts as "no motion" (what the reference's unavailable neighbour is).  PCM units are not modelled (the
+ * A cell outside the picture counts as "no motion" (what the reference's unavailable neighbour is); edges on the picture's left and top
+ * boundary end with strength 0 (processCtu, LoopFilter.h:484-510, runs after the CTU's units; one slice per picture).  PCM units are not modelled (the
  * reference's encoder never emits them).  Writes the whole grid of ((width + 63) / 64 * 8 + 1) x ((height + 63) / 64 * 8 + 1) regions. */
 typedef struct {
     int16_t mv[2][2];     /* [list][x, y], quarter samples */

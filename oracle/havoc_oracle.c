@@ -672,6 +672,9 @@ void oracle_derive_bs(const void *cells_, intptr_t cs, int width, int height, in
                     if (a || b) packed |= cell_edge(a, b, 8 * ry, 16) << (4 + 2 * k);
                 }
             }
+            /* processCtu (LoopFilter.h:484-510) comes after the CTU's units (Decode.h:281-286) and clears the edges on the picture boundary */
+            if (rx == 0) packed &= 0xF0;
+            if (ry == 0) packed &= 0x0F;
             if (2 * rx < cw && 2 * ry < ch)
             {
                 const oracle_cell *c = &cells[2 * ry * cs + 2 * rx];

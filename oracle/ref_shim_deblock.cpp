@@ -138,5 +138,10 @@ extern "C" void ref_derive_bs(int W, int H, const int32_t *cus, int ncu, const i
         pic.processTu(h, transform_unit(t[0], t[1], t[0], t[1], t[2], 0, 0));
         if (t[3]) pic.processRc(h, residual_coding(t[0], t[1], t[2], 0));
     }
+    // processCtu (LoopFilter.h:473-537) is the LAST event of a CTU (turing/Decode.h:281-286: after Read<coding_tree_unit>) and needs the slice /
+    // tile address tags of the real handler; what it does to the strengths with one slice per picture -- setBs(.., 0) along the edges whose
+    // neighbouring CTU does not exist -- through the reference's own Block::setBs:
+    for (int y = 0; y < h.heightCtbs * 8; ++y) { pic.blockAt(0, y).setBs(EDGE_VER, 0, 0); pic.blockAt(0, y).setBs(EDGE_VER, 1, 0); }
+    for (int x = 0; x < h.widthCtbs * 8; ++x) { pic.blockAt(x, 0).setBs(EDGE_HOR, 0, 0); pic.blockAt(x, 0).setBs(EDGE_HOR, 1, 0); }
     for (size_t i = 0; i < pic.blocks.size(); ++i) { data[i] = pic.blocks[i].data; bs[i] = pic.blocks[i].packedBs; }
 }

@@ -275,6 +275,10 @@ __global__ __launch_bounds__(256) void k_derive_bs(const Cell *__restrict__ cell
             b = at(rx * 2 + k, ry * 2);
             if (a || b) packed |= edgeStrength(a, b, y, b && (b->flags & HAVOC_CELL_PU_TOP)) << (4 + 2 * k);
         }
+        // processCtu runs AFTER a CTU's units (turing/Decode.h:281-286) and clears the strengths of edges whose neighbouring CTU is not
+        // available (LoopFilter.h:484-510): with one slice, the picture's left column and top row
+        if (rx == 0) packed &= 0xF0;
+        if (ry == 0) packed &= 0x0F;
         if (const Cell *c = at(rx * 2, ry * 2)) d = (int8_t)((c->qp << 1) | ((c->flags & HAVOC_CELL_NO_FILTER) ? 1 : 0));
     }
     data[i] = d;
