@@ -93,6 +93,9 @@ def test_decision_step_equals_the_reference_functions(res, BD, qp):
     R.pad_block(exp_rec, o, dp.W, dp.H, dp.stride, dp.PAD, True, True, True, True)
     assert np.array_equal(hv.down(dp.recon, dp.dt)[:dp.n], exp_rec)
     # the fixed-size chain (16x16 blocks) on the same vectors: every intermediate against the reference's functions
+    import torch
+    with torch.cuda.stream(hv.tstream):
+        dp.recon.zero_()      # the loop filter above left a filtered, padded picture there
     dp.tu_chain_fixed(field)
     hv.sync()
     dev, dev_recon = dp.results()
