@@ -413,7 +413,7 @@ int havoc_mi355x_quantize_reconstruct(havoc_mi355x_ctx *ctx, int log2TrafoSize, 
 /* sample-adaptive offset primitives                                                      */
 /* ------------------------------------------------------------------------------------------------------- */
 /* The statistics the encoder's SAO decision reads (turing/EncSao.h:111-283: edge_offset_stats_class0..3, band_offset_luma_stats)
- * over one block (a CTU of one colour component; chroma band statistics of Cb and Cr are added by the caller, EncSao.h:62-109).
+ * over one block (a CTU of one colour component; the joint band statistics of Cb and Cr, EncSao.h:62-109: havoc_mi355x_sao_band_chroma).
  * d_out: 105 int64 per job -- for edge class c = 0..3 the sums of (original - reconstruction) per category at [10c .. 10c+4] and the
  * sample counts at [10c+5 .. 10c+9]; the sums per band at [40..71], the counts per band at [72..103]; [104] = the band position the
  * reference's function returns.  The block's outermost ring of samples is not counted, as in the reference (w, h >= 3). */
@@ -423,6 +423,17 @@ typedef struct {
 } havoc_mi355x_sao_stats_job; /* 16 bytes */
 int havoc_mi355x_sao_stats(havoc_mi355x_ctx *ctx, int S, int bitDepth, const void *d_src, intptr_t stride_src, const void *d_rec, intptr_t stride_rec,
                            const havoc_mi355x_sao_stats_job *d_jobs, int njobs, int64_t *d_out);
+/* band_offset_chroma_stats (turing/EncSao.h:62-109): the band statistics of the Cb and the Cr block of a CTU TOGETHER -- one histogram over
+ * both interiors -- as the encoder's chroma SAO decision reads them.  d_src / d_rec: the planes holding both chroma components (offsets in
+ * samples; one stride each).  d_out[65 * i]: E[32], count[32], the band position the reference's function returns. */
+typedef struct {
+    int32_t src_u, src_v;   /* the CTU's Cb / Cr block in the source chroma */
+    int32_t rec_u, rec_v;   /* ... in the deblocked reconstruction */
+    int32_t w, h;
+    int32_t reserved[2];
+} havoc_mi355x_sao_chroma_job; /* 32 bytes */
+int havoc_mi355x_sao_band_chroma(havoc_mi355x_ctx *ctx, int S, int bitDepth, const void *d_src, intptr_t stride_src, const void *d_rec, intptr_t stride_rec,
+                                 const havoc_mi355x_sao_chroma_job *d_jobs, int njobs, int64_t *d_out);
 /* sao_filter_band / sao_filter_edge (turing/sao.h, sao.cpp:33-92) on one block: d_dst and d_src are different pictures; the edge
  * filter reads one sample beyond the block on every side.  type 0 copies (SAO off for the block), 1 = band offset with
  * offsets[] = the 32-entry table LoopFilter.h:994-1004 builds, 2 = edge offset with offsets[0..4] = SaoOffsetVal. */

@@ -87,6 +87,8 @@ int oracle_scan_order(int log2BlockSize, int scanIdx, int sPos, int sComp);
 
 /* turing/EncSao.h:62-283 and turing/sao.cpp:33-92 (oracle/sao_oracle.c): the statistics and the two filters of sample-adaptive offset */
 void oracle_sao_stats(const void *src, intptr_t ss, const void *rec, intptr_t rs, int w, int h, int shift, int S, int64_t *out /* [105] */);
+void oracle_sao_band_chroma(const void *src_u, const void *src_v, intptr_t ss, const void *rec_u, const void *rec_v, intptr_t rs, int w, int h, int shift, int S,
+                            int64_t *out /* [65] */);
 void oracle_sao_filter(void *dst, intptr_t ds, const void *src, intptr_t ss, int w, int h, int type, int eoClass, const int16_t *offsets, int bitDepth, int S);
 
 #ifdef __cplusplus

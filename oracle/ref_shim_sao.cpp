@@ -30,6 +30,10 @@ extern "C" int ref_sao_band_chroma_u8(const uint8_t *su, const uint8_t *sv, intp
                                       int64_t *E, int64_t *num)
 { return EncSao::band_offset_chroma_stats<uint8_t>(su, sv, ss, ru, rv, rs, E, num, h, w, shift); }
 
+extern "C" int ref_sao_band_chroma_u16(const uint16_t *su, const uint16_t *sv, intptr_t ss, const uint16_t *ru, const uint16_t *rv, intptr_t rs, int w, int h, int shift,
+                                       int64_t *E, int64_t *num)
+{ return EncSao::band_offset_chroma_stats<uint16_t>(su, sv, ss, ru, rv, rs, E, num, h, w, shift); }
+
 extern "C" void ref_sao_band_u8(uint8_t *dst, intptr_t ds, const uint8_t *src, intptr_t ss, int w, int h, const int16_t *table, int bd)
 { sao_filter_band<uint8_t>(dst, ds, src, ss, w, h, table, bd); }
 extern "C" void ref_sao_band_u16(uint16_t *dst, intptr_t ds, const uint16_t *src, intptr_t ss, int w, int h, const int16_t *table, int bd)

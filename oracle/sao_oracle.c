@@ -78,3 +78,32 @@ void oracle_sao_filter(void *dst, intptr_t ds, const void *src, intptr_t ss, int
             else ((uint16_t *)dst)[y * ds + x] = (uint16_t)v;
         }
 }
+
+
+/* band_offset_chroma_stats, turing/EncSao.h:62-109: one band histogram over the interiors of the Cb and Cr blocks; out[0..31] E, out[32..63]
+ * count, out[64] the band position returned */
+void oracle_sao_band_chroma(const void *src_u, const void *src_v, intptr_t ss, const void *rec_u, const void *rec_v, intptr_t rs, int w, int h, int shift, int S,
+                            int64_t *out)
+{
+    for (int k = 0; k < 65; ++k) out[k] = 0;
+    for (int y = 1; y < h - 1; ++y)
+        for (int x = 1; x < w - 1; ++x)
+            for (int p = 0; p < 2; ++p)
+            {
+                const int c = sao_get(p ? rec_v : rec_u, y * rs + x, S);
+                out[c >> (3 + shift)] += sao_get(p ? src_v : src_u, y * ss + x, S) - c;
+                out[32 + (c >> (3 + shift))]++;
+            }
+    int64_t best = 0;
+    int start = 0;
+    for (int b = 0; b < 29; ++b)
+    {
+        const int64_t cum = out[32 + b] + out[33 + b] + out[34 + b] + out[35 + b];
+        if (cum > best)
+        {
+            best = cum;
+            start = b;
+        }
+    }
+    out[64] = start + 1 < 2 ? 2 : start + 1;
+}

@@ -96,6 +96,14 @@ class Oracle:
         self.L.oracle_sao_stats(_addr(src, so), ss, _addr(rec, ro), rs, w, h, bd - 8, _S(src), _addr(out))
         return out
 
+    def sao_band_chroma(self, src_u, src_v, so, ss, rec_u, rec_v, ro, rs, w, h, bd):
+        """-> int64[65]: E[32], count[32], band position (oracle/sao_oracle.c)"""
+        out = np.zeros(65, np.int64)
+        self.L.oracle_sao_band_chroma.restype = None
+        self.L.oracle_sao_band_chroma.argtypes = [_vp, _vp, _ip, _vp, _vp, _ip] + [C.c_int] * 4 + [_vp]
+        self.L.oracle_sao_band_chroma(_addr(src_u, so), _addr(src_v, so), ss, _addr(rec_u, ro), _addr(rec_v, ro), rs, w, h, bd - 8, _S(src_u), _addr(out))
+        return out
+
     def sao_filter(self, dst, do, ds, src, so, ss, w, h, kind, eo_class, offsets, bd):
         offsets = np.ascontiguousarray(offsets, np.int16)
         self.L.oracle_sao_filter.restype = None
@@ -287,6 +295,15 @@ class Reference:
         f.argtypes = [_vp, _ip, _vp, _ip] + [C.c_int] * 3 + [_vp]
         out = np.zeros(105, np.int64)
         f(_addr(src, so), ss, _addr(rec, ro), rs, w, h, bd - 8, _addr(out))
+        return out
+
+    def sao_band_chroma(self, src_u, src_v, so, ss, rec_u, rec_v, ro, rs, w, h, bd):
+        """the reference's EncSao::band_offset_chroma_stats (EncSao.h:62-109) -> int64[65]: E[32], count[32], returned band position"""
+        f = self._f("ref_sao_band_chroma", src_u)
+        f.restype = C.c_int
+        f.argtypes = [_vp, _vp, _ip, _vp, _vp, _ip, C.c_int, C.c_int, C.c_int, _vp, _vp]
+        out = np.zeros(65, np.int64)
+        out[64] = f(_addr(src_u, so), _addr(src_v, so), ss, _addr(rec_u, ro), _addr(rec_v, ro), rs, w, h, bd - 8, _addr(out), _addr(out, 32))
         return out
 
     def sao_filter(self, dst, do, ds, src, so, ss, w, h, kind, eo_class, offsets, bd):

@@ -44,7 +44,7 @@ def test_job_struct_sizes():
     assert sizes == {"havoc_mi355x_pair_job": "16", "havoc_mi355x_sad4_job": "32", "havoc_mi355x_surface_job": "32", "havoc_mi355x_satd_multi_job": "80", "havoc_mi355x_pred_uni_job": "32",
                      "havoc_mi355x_pred_bi_job": "48", "havoc_mi355x_subtract_bi_job": "32",
                      "havoc_mi355x_intra_job": "32", "havoc_mi355x_tu_job": "16", "havoc_mi355x_quant_job": "32",
-                     "havoc_mi355x_intra_search_job": "32", "havoc_mi355x_tu_fused_job": "16", "havoc_mi355x_rdoq_job": "48", "havoc_mi355x_sao_stats_job": "16", "havoc_mi355x_sao_job": "96"}
+                     "havoc_mi355x_intra_search_job": "32", "havoc_mi355x_tu_fused_job": "16", "havoc_mi355x_rdoq_job": "48", "havoc_mi355x_sao_stats_job": "16", "havoc_mi355x_sao_chroma_job": "32", "havoc_mi355x_sao_job": "96"}
 
 
 def test_no_gpu_fails_loudly(lib):

@@ -107,3 +107,38 @@ def test_device_whole_picture_one_job_per_ctu(hv, oracle, bd):
             oracle.sao_filter(want, o, stride, rec, o, stride, w, h, kind, eo, offs, bd)
         got = hv.sao_filter(bd, rec, stride, rec, stride, fj)
         assert np.array_equal(got, want)
+
+
+# ---- the joint Cb + Cr band statistics of the chroma SAO decision (EncSao.h:62-109) ------------------------------------
+def _chroma_case(seed):
+    a, b = sao_tools.make_case(seed), sao_tools.make_case(seed)
+    rng = np.random.default_rng(1000 + seed)
+    mx = (1 << a["bd"]) - 1
+    v_rec = np.clip(a["rec"].astype(np.int64) + rng.integers(-40, 41, a["rec"].shape), 0, mx).astype(a["rec"].dtype)
+    v_src = np.clip(v_rec.astype(np.int64) + rng.integers(-6, 7, v_rec.shape), 0, mx).astype(a["rec"].dtype)
+    return a, v_src, v_rec
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_oracle_chroma_band_statistics_equal_the_reference_function(seed, oracle, reference_c):
+    a, v_src, v_rec = _chroma_case(seed)
+    want = reference_c.sao_band_chroma(a["src"], v_src, a["origin"], a["stride"], a["rec"], v_rec, a["origin"], a["stride"], a["w"], a["h"], a["bd"])
+    got = oracle.sao_band_chroma(a["src"], v_src, a["origin"], a["stride"], a["rec"], v_rec, a["origin"], a["stride"], a["w"], a["h"], a["bd"])
+    assert np.array_equal(got, want)
+    if a["w"] > 2 and a["h"] > 2:
+        assert want[32:64].sum() == 2 * (a["w"] - 2) * (a["h"] - 2)
+
+
+@pytest.mark.gpu
+def test_device_chroma_band_statistics_equal_the_oracle(oracle):
+    from turingcodec_amd.havoc import Havoc
+    hv = Havoc()
+    for seed in range(12):
+        a, v_src, v_rec = _chroma_case(seed)
+        n = a["src"].size
+        src = np.concatenate([a["src"], v_src])
+        rec = np.concatenate([a["rec"], v_rec])
+        jobs = np.array([[a["origin"], n + a["origin"], a["origin"], n + a["origin"], a["w"], a["h"], 0, 0]], np.int32)
+        got = hv.sao_band_chroma(a["bd"], src, a["stride"], rec, a["stride"], jobs)[0]
+        want = oracle.sao_band_chroma(a["src"], v_src, a["origin"], a["stride"], a["rec"], v_rec, a["origin"], a["stride"], a["w"], a["h"], a["bd"])
+        assert np.array_equal(got, want), seed

@@ -34,6 +34,7 @@ hipError_t launch_level_stats(hipStream_t, const int16_t *, const void *, int, i
 hipError_t launch_rdoq(hipStream_t, int bd, int log2, int16_t *, const int16_t *, const uint8_t *, const void *, int, int32_t *, void *);
 size_t rdoq_workspace_bytes(int njobs);
 hipError_t launch_sao_stats(hipStream_t, int S, int bd, const void *, long, const void *, long, const void *, int, int64_t *);
+hipError_t launch_sao_band_chroma(hipStream_t, int S, int bd, const void *, long, const void *, long, const void *, int, int64_t *);
 hipError_t launch_sao_filter(hipStream_t, int S, int bd, void *, long, const void *, long, const void *, int);
 hipError_t launch_quantize_inverse(hipStream_t, int16_t *, const int16_t *, const void *, int);
 hipError_t launch_quantize_reconstruct(hipStream_t, int log2, uint8_t *, long, const uint8_t *, long, const int16_t *, const void *, int);
@@ -539,6 +540,13 @@ int havoc_mi355x_sao_stats(havoc_mi355x_ctx *ctx, int S, int bitDepth, const voi
 {
     REQUIRE_CTX(); REQUIRE(S == 1 || S == 2, "S must be 1 or 2"); REQUIRE_BD(); REQUIRE(njobs >= 0, "njobs < 0");
     return check(launch_sao_stats(LS(ctx), S, bitDepth, d_src, stride_src, d_rec, stride_rec, d_jobs, njobs, d_out), "sao_stats");
+}
+
+int havoc_mi355x_sao_band_chroma(havoc_mi355x_ctx *ctx, int S, int bitDepth, const void *d_src, intptr_t stride_src, const void *d_rec, intptr_t stride_rec,
+                                 const havoc_mi355x_sao_chroma_job *d_jobs, int njobs, int64_t *d_out)
+{
+    REQUIRE_CTX(); REQUIRE(S == 1 || S == 2, "S must be 1 or 2"); REQUIRE_BD(); REQUIRE(njobs >= 0, "njobs < 0");
+    return check(launch_sao_band_chroma(LS(ctx), S, bitDepth, d_src, stride_src, d_rec, stride_rec, d_jobs, njobs, d_out), "sao_band_chroma");
 }
 
 int havoc_mi355x_sao_filter(havoc_mi355x_ctx *ctx, int S, int bitDepth, void *d_dst, intptr_t stride_dst, const void *d_src, intptr_t stride_src,

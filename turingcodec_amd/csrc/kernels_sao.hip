@@ -106,6 +106,56 @@ __global__ __launch_bounds__(256) void k_sao_stats(const char *__restrict__ srcP
     }
 }
 
+// band_offset_chroma_stats (turing/EncSao.h:62-109): ONE band histogram over the interiors of the Cb and the Cr block of a CTU -- per band
+// the number of samples and the sum of original - reconstruction of both planes -- and the four-band window holding most samples.
+// job = offsets of the Cb / Cr blocks in the source and reconstruction chroma planes; out[65 * job]: E[32], count[32], band position.
+struct SaoChromaJob { int32_t src_u, src_v, rec_u, rec_v, w, h, reserved[2]; };
+static_assert(sizeof(SaoChromaJob) == sizeof(havoc_mi355x_sao_chroma_job), "sao chroma job layout");
+
+template <int S>
+__global__ __launch_bounds__(256) void k_sao_band_chroma(const char *__restrict__ srcPlane, long strideSrc, const char *__restrict__ recPlane, long strideRec,
+                                                         const SaoChromaJob *__restrict__ jobs, int shift, long long *__restrict__ out)
+{
+    typedef typename Sample<S>::T T;
+    __shared__ int band[4][64];         // per wavefront: sums [0..31], counts [32..63]
+    __shared__ int total[64];
+    const SaoChromaJob job = jobs[blockIdx.x];
+    const int tid = threadIdx.x, wave = tid >> 6, iw = job.w - 2, ih = job.h - 2;
+    band[wave][tid & 63] = 0;
+    __syncthreads();
+    for (int plane = 0; plane < 2; ++plane)
+    {
+        const T *src = reinterpret_cast<const T *>(srcPlane) + (plane ? job.src_v : job.src_u);
+        const T *rec = reinterpret_cast<const T *>(recPlane) + (plane ? job.rec_v : job.rec_u);
+        for (int k = tid; k < iw * ih; k += 256)
+        {
+            const int y = 1 + k / iw, x = 1 + k - (y - 1) * iw;
+            const int c = rec[y * strideRec + x], b = c >> (3 + shift);
+            atomicAdd(&band[wave][b], (int)src[y * strideSrc + x] - c);
+            atomicAdd(&band[wave][32 + b], 1);
+        }
+    }
+    __syncthreads();
+    if (tid < 64) total[tid] = band[0][tid] + band[1][tid] + band[2][tid] + band[3][tid];
+    __syncthreads();
+    long long *o = out + 65L * blockIdx.x;
+    if (tid < 64) o[tid] = total[tid];
+    if (tid == 0)
+    {
+        int best = 0, start = 0;
+        for (int b = 0; b < 29; ++b)
+        {
+            const int cum = total[32 + b] + total[33 + b] + total[34 + b] + total[35 + b];
+            if (cum > best)
+            {
+                best = cum;
+                start = b;
+            }
+        }
+        o[64] = max(start + 1, 2);
+    }
+}
+
 template <int S>
 __global__ __launch_bounds__(256) void k_sao_filter(char *__restrict__ dstPlane, long strideDst, const char *__restrict__ srcPlane, long strideSrc,
                                                     const SaoJob *__restrict__ jobs, int bitDepth)
@@ -147,6 +197,16 @@ hipError_t launch_sao_stats(hipStream_t st, int S, int bitDepth, const void *src
     const SaoStatsJob *j = static_cast<const SaoStatsJob *>(jobs);
     if (S == 1) hipLaunchKernelGGL(k_sao_stats<1>, dim3(njobs), dim3(256), 0, st, (const char *)src, strideSrc, (const char *)rec, strideRec, j, bitDepth - 8, (long long *)out);
     else hipLaunchKernelGGL(k_sao_stats<2>, dim3(njobs), dim3(256), 0, st, (const char *)src, strideSrc, (const char *)rec, strideRec, j, bitDepth - 8, (long long *)out);
+    return hipGetLastError();
+}
+
+hipError_t launch_sao_band_chroma(hipStream_t st, int S, int bitDepth, const void *src, long strideSrc, const void *rec, long strideRec, const void *jobs, int njobs,
+                                  int64_t *out)
+{
+    if (njobs <= 0) return hipSuccess;
+    const SaoChromaJob *j = static_cast<const SaoChromaJob *>(jobs);
+    if (S == 1) hipLaunchKernelGGL(k_sao_band_chroma<1>, dim3(njobs), dim3(256), 0, st, (const char *)src, strideSrc, (const char *)rec, strideRec, j, bitDepth - 8, (long long *)out);
+    else hipLaunchKernelGGL(k_sao_band_chroma<2>, dim3(njobs), dim3(256), 0, st, (const char *)src, strideSrc, (const char *)rec, strideRec, j, bitDepth - 8, (long long *)out);
     return hipGetLastError();
 }
 

@@ -97,6 +97,7 @@ def _load():
         "rdoq": [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, C.c_size_t],
         "sao_stats": [_vp, _i, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
         "sao_filter": [_vp, _i, _i, _vp, _ip, _vp, _ip, _vp, _i],
+        "sao_band_chroma": [_vp, _i, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
     }
     L.havoc_mi355x_rdoq_lambda.argtypes = [C.c_double, _i, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.havoc_mi355x_rdoq_lambda.restype = None
@@ -428,6 +429,17 @@ class Havoc:
         s, r = self.up(src), self.up(rec)
         self._ck(self.L.havoc_mi355x_sao_stats(self.h, self._S(s), bd, _ptr(s), ss, _ptr(r), rs, _ptr(self.up(jobs)), len(jobs), _ptr(out)))
         return self.down(out, np.int64).reshape(-1, 105)
+
+    def sao_band_chroma(self, bd, src, ss, rec, rs, jobs):
+        """jobs int32 [n, 8] (src_u, src_v, rec_u, rec_v, w, h, 0, 0) -> int64 [n, 65]: E[32], count[32], band position (EncSao.h:62-109)"""
+        torch = self.torch
+        jobs = np.ascontiguousarray(jobs, np.int32)
+        d_src, d_rec, d_jobs = self.up(src), self.up(rec), self.up(jobs)
+        with torch.cuda.stream(self.tstream):
+            out = torch.zeros(65 * len(jobs), dtype=torch.int64, device=self.device)
+        self._ck(self.L.havoc_mi355x_sao_band_chroma(self.h, self._S(d_src), bd, _ptr(d_src), ss, _ptr(d_rec), rs, _ptr(d_jobs), len(jobs), _ptr(out)))
+        with torch.cuda.stream(self.tstream):
+            return out.cpu().numpy().reshape(-1, 65)
 
     def sao_filter(self, bd, dst_like, sd, src, ss, jobs):
         """numpy level: jobs = SAO_JOB_DT array; returns the destination plane (zeros where no job wrote)"""
