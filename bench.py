@@ -1372,10 +1372,11 @@ def main():
         plain = world == 1 and pipe is None and not (args.pcie or args.skip or args.no_graph)
         if plain and args.extra_4k and args.res == "1920x1080" and args.mix == "ra":
             # BASELINE.json configs[2] and [3] (the resolution the north star's target is quoted on, 8- and 10-bit), same code, fewer steps
-            for xbd, label in ((8, "3840x2160 8-bit random-access QP27 speed=medium (BASELINE.json configs[2])"),
-                               (10, "3840x2160 10-bit Main10 random-access QP27 speed=medium (BASELINE.json configs[3])")):
+            for xbd, xqp, label in ((8, 27, "3840x2160 8-bit random-access QP27 speed=medium (BASELINE.json configs[2])"),
+                                    (10, 27, "3840x2160 10-bit Main10 random-access QP27 speed=medium (BASELINE.json configs[3])"),
+                                    (8, 32, "3840x2160 8-bit random-access QP32 speed=medium (BASELINE.json metric: 4K RA QP32)")):
                 try:
-                    xs = build_contexts(args, torch, Havoc, FrameWorkload, local, "3840x2160", xbd, 27, "ra", args.seed + 77, inflight, min(args.tune, 8))
+                    xs = build_contexts(args, torch, Havoc, FrameWorkload, local, "3840x2160", xbd, xqp, "ra", args.seed + 77, inflight, min(args.tune, 8))
                     ksteps = 20
 
                     def xblock(_b, xs=xs):

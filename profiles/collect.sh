@@ -8,12 +8,12 @@
 #         (the figure bench.py's roofline.achieved is built from).  Pass 2: the same with the default 8 lanes + graph
 #         (durations overlap; kept to show the overlap, not for the roofline).  Passes 3/4: PMC counters, one counter
 #         per pass and no trace domains beside them.  Pass 5: the plain bench line with the CPU baseline.
-tag=${1:-r02}
+tag=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --no-cpu-baseline --extra-4k 0 --min-seconds 0"   # profiled runs: one timed block, no side measurements
+B="python $R/bench.py --no-cpu-baseline --extra-4k 0 --decisions 0 --min-seconds 0"   # profiled runs: one timed block, no side measurements
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_serial -- $B --steps 10 --warmup 2 --lanes 1 --no-graph > $O/${tag}_serial_bench.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_overlap8 -- $B --steps 10 --warmup 2 > $O/${tag}_overlap8_bench.log 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${tag}_fetch -- $B --steps 2 --warmup 1 --kernel-reps 1 > /dev/null 2>&1
