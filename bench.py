@@ -86,6 +86,8 @@ def parse_args():
     ap.add_argument("--lanes", type=int, default=8, help="fork/join lanes: independent launch chains overlap on the GPU")
     ap.add_argument("--tu", choices=["fused", "split"], default="fused",
                     help="TU chain: two fused kernels around the host quantiser (default) or the five separate primitives")
+    ap.add_argument("--pred", choices=["merged", "classes"], default="merged",
+                    help="prediction launches: all size classes of a table in one launch (default) or one launch per width class")
     ap.add_argument("--subpel", choices=["planes", "fused"], default="planes",
                     help="sub-pel candidates: SATD against per-picture phase planes (default) or the fused per-candidate kernel")
     return ap.parse_args()
@@ -98,7 +100,7 @@ def parse_args():
 class DeviceFrame:
     """A FrameWorkload uploaded to HBM + the list of launches that make one step."""
 
-    def __init__(self, hv, wl, use_planes=True, fused_tu=True, ime_range=None, skip=(), rdoq=True):
+    def __init__(self, hv, wl, use_planes=True, fused_tu=True, ime_range=None, skip=(), rdoq=True, pred_launches="merged"):
         import torch
         from turingcodec_amd import havoc as _havoc
         self.rdoq = bool(rdoq) and wl.mix == "ra"
@@ -241,7 +243,18 @@ class DeviceFrame:
             return [(name, lambda j=hv.up(np.ascontiguousarray(jobs_np[idx])), mw=mw, mh=mh: fn(j, mw, mh))
                     for idx, mw, mh in hv.size_classes(jobs_np[:, wcol], jobs_np[:, wcol + 1])]
 
-        if inter:
+        if inter and pred_launches == "merged":
+            # all four size classes of a table in ONE launch (havoc_mi355x_pred_*_classes): 4 prediction launches per picture instead of 16
+            def merged(name, jobs, wcol, bi, taps, dst, sd, ref, sr):
+                srt, counts, _ = hv.sort_by_class(np.asarray(jobs), np.asarray(jobs)[:, wcol], np.asarray(jobs)[:, wcol + 1])
+                return (name, lambda j=hv.up(srt), c=counts: hv.pred_classes_d(bi, taps, bd, dst, sd, ref, sr, j, c))
+            chain(merged("pred_uni8", wl.uni8, 2, False, 8, self.pred, 64, self.luma, st),
+                  ("satd_inter", lambda: hv.satd_d(self.luma, st, self.pred, 64, self.j_satd, self.o_satd)))
+            chain(merged("pred_uni4", wl.uni4, 2, False, 4, self.cpred, 32, self.chroma, cst))
+            chain(merged("pred_bi8", wl.bi8, 3, True, 8, self.bi, 64, self.luma, st),
+                  ("subtract_bi", lambda: hv.subtract_bi_d(bd, self.sbi, 64, self.bi, 64, self.luma, st, self.j_sbi)),
+                  merged("pred_bi4", wl.bi4, 3, True, 4, self.cbi, 32, self.chroma, cst))
+        elif inter:
             chain(*classes("pred_uni8", wl.uni8, 2, lambda j, mw, mh: hv.pred_uni_d(8, bd, self.pred, 64, self.luma, st, j, mw, mh)),
                   ("satd_inter", lambda: hv.satd_d(self.luma, st, self.pred, 64, self.j_satd, self.o_satd)))
             chain(*classes("pred_uni4", wl.uni4, 2, lambda j, mw, mh: hv.pred_uni_d(4, bd, self.cpred, 32, self.chroma, cst, j, mw, mh)))
@@ -843,7 +856,7 @@ def build_contexts(args, torch, Havoc, FrameWorkload, local, res, bit_depth, qp,
         wl_k = FrameWorkload(w, h, bit_depth, seed0 + 1000 * k, qp=qp, mix=mix, frames=frames)
         dev_k = DeviceFrame(hv_k, wl_k, use_planes=(args.subpel == "planes"), fused_tu=(args.tu == "fused"),
                             ime_range=args.ime_range if args.ime == "surface" else None, skip=[s for s in args.skip.split(",") if s],
-                            rdoq=args.rdoq)
+                            rdoq=args.rdoq, pred_launches=getattr(args, "pred", "merged"))
         dev_k.step()          # first eager pass (loads the code objects) -- also what the graph must reproduce
         hv_k.sync()
         if args.no_graph:

@@ -304,6 +304,13 @@ int havoc_mi355x_pred_uni(havoc_mi355x_ctx *ctx, int S, int taps, int bitDepth, 
 /* HavocPredBi<Sample> (havoc/pred_inter.h:63, havoc/pred_inter.cpp:1207-1252) */
 int havoc_mi355x_pred_bi(havoc_mi355x_ctx *ctx, int S, int taps, int bitDepth, int max_w, int max_h, void *d_dst, intptr_t stride_dst,
                          const void *d_ref, intptr_t stride_ref, const havoc_mi355x_pred_bi_job *d_jobs, int njobs);
+/* The same two primitives for a job table that holds ALL size classes, in ONE launch: the table is sorted by class -- count[0] jobs whose
+ * larger side is <= 8, then count[1] jobs <= 16, count[2] <= 32, count[3] <= 64 -- the width class being a property of the job, as the
+ * reference's havocGetPredUni / havocGetPredBi index it (havoc/pred_inter.h:47-50, 72-76).  Results identical to the per-class launches. */
+int havoc_mi355x_pred_uni_classes(havoc_mi355x_ctx *ctx, int S, int taps, int bitDepth, void *d_dst, intptr_t stride_dst, const void *d_ref,
+                                  intptr_t stride_ref, const havoc_mi355x_pred_uni_job *d_jobs, const int32_t count[4]);
+int havoc_mi355x_pred_bi_classes(havoc_mi355x_ctx *ctx, int S, int taps, int bitDepth, void *d_dst, intptr_t stride_dst, const void *d_ref,
+                                 intptr_t stride_ref, const havoc_mi355x_pred_bi_job *d_jobs, const int32_t count[4]);
 /* havoc::SubtractBi<Sample> (havoc/pred_inter.h:87, havoc/pred_inter.cpp:2063-2080) */
 int havoc_mi355x_subtract_bi(havoc_mi355x_ctx *ctx, int S, int bitDepth, void *d_dst, intptr_t stride_dst,
                              const void *d_pred, intptr_t stride_pred, const void *d_src, intptr_t stride_src,

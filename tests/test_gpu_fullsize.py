@@ -246,6 +246,23 @@ def test_8k_frame_properties(hv):
     assert a.checksum() == ref
 
 
+def test_merged_prediction_launches_equal_the_per_class_launches(hv):
+    """havoc_mi355x_pred_uni_classes / pred_bi_classes (all four size classes of a job table in one launch) against one launch per width
+    class, on the 1080p picture's luma and chroma, uni and bi tables: identical output buffers"""
+    import bench
+    from turingcodec_amd.workload import FrameWorkload
+    wl = FrameWorkload(1920, 1080, 8, 11)
+    a = bench.DeviceFrame(hv, wl, pred_launches="merged")
+    b = bench.DeviceFrame(hv, wl, pred_launches="classes")
+    a.step()
+    b.step()
+    hv.sync()
+    assert len(a.launches) == len(b.launches) - 12
+    for name in ("pred", "cpred", "bi", "cbi", "sbi"):
+        assert np.array_equal(hv.down(getattr(a, name), wl.dtype), hv.down(getattr(b, name), wl.dtype)), name
+    assert a.checksum() == b.checksum()
+
+
 def test_bench_line_contract():
     """`python bench.py` prints ONE JSON line carrying every field of the driver's contract (plus roofline and
     cpu_baseline), with the values the contract fixes"""

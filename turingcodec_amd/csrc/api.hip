@@ -18,6 +18,7 @@ hipError_t launch_deblock(hipStream_t, int S, int bd, void *, long, void *, void
 hipError_t launch_pred_uni(hipStream_t, int S, int taps, int bd, int maxw, int maxh, void *, long, const void *, long, const void *, int);
 hipError_t launch_pred_bi(hipStream_t, int S, int taps, int bd, int maxw, int maxh, void *, long, const void *, long, const void *, int);
 hipError_t launch_subtract_bi(hipStream_t, int S, int bd, void *, long, const void *, long, const void *, long, const void *, int);
+hipError_t launch_pred_classes(hipStream_t, int bi, int S, int taps, int bd, void *, long, const void *, long, const void *, const int count[4]);
 hipError_t launch_intra(hipStream_t, int S, int log2, int bd, void *, long, const void *, const void *, int);
 hipError_t launch_intra_satd35(hipStream_t, int S, int log2, int bd, const void *, long, const void *, const void *, int, int32_t *);
 hipError_t launch_interp_planes(hipStream_t, int S, int bd, void *, long, const void *, long, int, int, int, int);
@@ -400,6 +401,22 @@ int havoc_mi355x_pred_bi(havoc_mi355x_ctx *ctx, int S, int taps, int bitDepth, i
     REQUIRE_CTX(); REQUIRE_S(); REQUIRE_BD(); REQUIRE(taps == 8 || taps == 4, "taps must be 8 or 4"); REQUIRE(njobs >= 0, "njobs < 0");
     REQUIRE_MAXWH();
     return check(launch_pred_bi(LS(ctx),S, taps, bitDepth, max_w, max_h, d_dst, stride_dst, d_ref, stride_ref, d_jobs, njobs), "pred_bi");
+}
+
+int havoc_mi355x_pred_uni_classes(havoc_mi355x_ctx *ctx, int S, int taps, int bitDepth, void *d_dst, intptr_t stride_dst, const void *d_ref, intptr_t stride_ref,
+                                  const havoc_mi355x_pred_uni_job *d_jobs, const int32_t count[4])
+{
+    REQUIRE_CTX(); REQUIRE_S(); REQUIRE_BD(); REQUIRE(taps == 8 || taps == 4, "taps must be 8 or 4"); REQUIRE(count != nullptr, "null count");
+    const int c[4] = {count[0], count[1], count[2], count[3]};
+    return check(launch_pred_classes(LS(ctx), 0, S, taps, bitDepth, d_dst, stride_dst, d_ref, stride_ref, d_jobs, c), "pred_uni_classes");
+}
+
+int havoc_mi355x_pred_bi_classes(havoc_mi355x_ctx *ctx, int S, int taps, int bitDepth, void *d_dst, intptr_t stride_dst, const void *d_ref, intptr_t stride_ref,
+                                 const havoc_mi355x_pred_bi_job *d_jobs, const int32_t count[4])
+{
+    REQUIRE_CTX(); REQUIRE_S(); REQUIRE_BD(); REQUIRE(taps == 8 || taps == 4, "taps must be 8 or 4"); REQUIRE(count != nullptr, "null count");
+    const int c[4] = {count[0], count[1], count[2], count[3]};
+    return check(launch_pred_classes(LS(ctx), 1, S, taps, bitDepth, d_dst, stride_dst, d_ref, stride_ref, d_jobs, c), "pred_bi_classes");
 }
 
 int havoc_mi355x_subtract_bi(havoc_mi355x_ctx *ctx, int S, int bitDepth, void *d_dst, intptr_t stride_dst, const void *d_pred, intptr_t stride_pred,

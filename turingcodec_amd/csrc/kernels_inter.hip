@@ -18,21 +18,33 @@
 
 namespace havoc_gpu {
 
+// LDS of one workgroup of a size class: intermediates [JPW][NREF][MAXW * TH + 8] int16, then the output tiles [JPW][MAXH * OS + 2] uint16
+template <int MAXW, int MAXH, int G, bool BI>
+struct PredLds
+{
+    static constexpr int JPW = 256 / G, NREF = BI ? 2 : 1, TH = MAXH + 8, OS = MAXW + 2;
+    static constexpr int tmpElems = MAXW * TH + 8, outElems = MAXH * OS + 2;
+    static constexpr int tmpBytes = ((JPW * NREF * tmpElems * 2) + 15) & ~15;
+    static constexpr int bytes = tmpBytes + ((JPW * outElems * 2 + 15) & ~15);
+};
+
+// one workgroup's share of a size class: workgroup `wg` of `wgs`, job table of `njobs` jobs of that class
 template <int S, int TAPS, int MAXW, int MAXH, int G, bool BI>
-__global__ __launch_bounds__(256) void k_pred(char *__restrict__ dst, long stride_dst, const char *__restrict__ ref, long stride_ref,
-                                              const int32_t *__restrict__ jobs, int njobs, int bitDepth)
+__device__ __forceinline__ void pred_workgroup(char *lds, char *__restrict__ dst, long stride_dst, const char *__restrict__ ref, long stride_ref,
+                                               const int32_t *__restrict__ jobs, int njobs, int bitDepth, int wg, int wgs)
 {
     typedef typename Sample<S>::T T;
+    typedef PredLds<MAXW, MAXH, G, BI> L;
     constexpr int JPW = 256 / G;
     constexpr int NREF = BI ? 2 : 1;
     constexpr int AB = TAPS / 2 - 1;
     constexpr int TH = MAXH + 8;     // intermediate column: h + TAPS - 1 <= MAXH + 7, rounded up to 8
     constexpr int OS = MAXW + 2;     // output tile row stride (samples), skewed against bank conflicts
-    __shared__ __attribute__((aligned(16))) int16_t s_tmp[JPW][NREF][MAXW * TH + 8];
-    __shared__ __attribute__((aligned(16))) uint16_t s_out[JPW][MAXH * OS + 2];
+    int16_t (*s_tmp)[NREF][L::tmpElems] = reinterpret_cast<int16_t (*)[NREF][L::tmpElems]>(lds);
+    uint16_t (*s_out)[L::outElems] = reinterpret_cast<uint16_t (*)[L::outElems]>(lds + L::tmpBytes);
 
     const int sub = threadIdx.x / G, l = threadIdx.x - sub * G;
-    const int job = xcd_block(blockIdx.x, gridDim.x) * JPW + sub;
+    const int job = xcd_block(wg, wgs) * JPW + sub;
     const bool live = job < njobs;
     // havoc_mi355x_pred_uni_job: dst, ref, w, h, xFrac, yFrac | havoc_mi355x_pred_bi_job: dst, ref0, ref1, w, h, 4 fracs
     const int32_t *j = jobs + (long)(live ? job : 0) * (BI ? 12 : 8);
@@ -132,6 +144,39 @@ __global__ __launch_bounds__(256) void k_pred(char *__restrict__ dst, long strid
     }
 }
 
+template <int S, int TAPS, int MAXW, int MAXH, int G, bool BI>
+__global__ __launch_bounds__(256) void k_pred(char *__restrict__ dst, long stride_dst, const char *__restrict__ ref, long stride_ref,
+                                              const int32_t *__restrict__ jobs, int njobs, int bitDepth)
+{
+    __shared__ __attribute__((aligned(16))) char lds[PredLds<MAXW, MAXH, G, BI>::bytes];
+    pred_workgroup<S, TAPS, MAXW, MAXH, G, BI>(lds, dst, stride_dst, ref, stride_ref, jobs, njobs, bitDepth, blockIdx.x, gridDim.x);
+}
+
+// ALL FOUR size classes of a job table in one launch (the width class stays a property of the job, the launch no longer is):
+// the table is sorted by class -- count[c] jobs whose larger side is <= 8, 16, 32, 64 -- and a workgroup finds its class from the prefix of
+// workgroups per class.  LDS is the largest class's (27 KB for bi-prediction), which still leaves 5 workgroups per CU.
+struct PredClasses { int count[4], firstWg[5]; };
+
+template <int S, int TAPS, bool BI>
+__global__ __launch_bounds__(256) void k_pred_classes(char *__restrict__ dst, long stride_dst, const char *__restrict__ ref, long stride_ref,
+                                                      const int32_t *__restrict__ jobs, PredClasses pc, int bitDepth)
+{
+    __shared__ __attribute__((aligned(16))) char lds[PredLds<64, 64, 256, BI>::bytes];
+    constexpr int words = BI ? 12 : 8;
+    const int wg = blockIdx.x;
+    if (wg < pc.firstWg[1])
+        pred_workgroup<S, TAPS, 8, 8, 8, BI>(lds, dst, stride_dst, ref, stride_ref, jobs, pc.count[0], bitDepth, wg, pc.firstWg[1]);
+    else if (wg < pc.firstWg[2])
+        pred_workgroup<S, TAPS, 16, 16, 32, BI>(lds, dst, stride_dst, ref, stride_ref, jobs + (long)pc.count[0] * words, pc.count[1], bitDepth, wg - pc.firstWg[1],
+                                                pc.firstWg[2] - pc.firstWg[1]);
+    else if (wg < pc.firstWg[3])
+        pred_workgroup<S, TAPS, 32, 32, 128, BI>(lds, dst, stride_dst, ref, stride_ref, jobs + (long)(pc.count[0] + pc.count[1]) * words, pc.count[2], bitDepth,
+                                                 wg - pc.firstWg[2], pc.firstWg[3] - pc.firstWg[2]);
+    else
+        pred_workgroup<S, TAPS, 64, 64, 256, BI>(lds, dst, stride_dst, ref, stride_ref, jobs + (long)(pc.count[0] + pc.count[1] + pc.count[2]) * words, pc.count[3],
+                                                 bitDepth, wg - pc.firstWg[3], pc.firstWg[4] - pc.firstWg[3]);
+}
+
 // havoc::SubtractBi (havoc/pred_inter.h:87; havoc/pred_inter.cpp:2063-2080): dst = clip(2*src - pred)
 template <int S>
 __global__ __launch_bounds__(256) void k_subtract_bi(char *__restrict__ dst, long stride_dst, const char *__restrict__ pred, long stride_pred,
@@ -196,6 +241,36 @@ hipError_t launch_pred_bi(hipStream_t st, int S, int taps, int bd, int maxw, int
                           int n)
 {
     return launch_pred<true>(st, S, taps, bd, maxw, maxh, dst, sd, ref, sr, jobs, n);
+}
+
+template <bool BI>
+static hipError_t launch_pred_classes_t(hipStream_t st, int S, int taps, int bd, void *dst, long sd, const void *ref, long sr, const void *jobs, const int count[4])
+{
+    PredClasses pc;
+    static const int jpw[4] = {32, 8, 2, 1};
+    pc.firstWg[0] = 0;
+    for (int c = 0; c < 4; ++c)
+    {
+        if (count[c] < 0) return hipErrorInvalidValue;
+        pc.count[c] = count[c];
+        pc.firstWg[c + 1] = pc.firstWg[c] + (count[c] + jpw[c] - 1) / jpw[c];
+    }
+    if (pc.firstWg[4] == 0) return hipSuccess;
+    char *d = (char *)dst;
+    const char *r = (const char *)ref;
+    const int32_t *j = (const int32_t *)jobs;
+    const dim3 g(pc.firstWg[4]), b(256);
+    if (S == 1 && taps == 8) hipLaunchKernelGGL((k_pred_classes<1, 8, BI>), g, b, 0, st, d, sd, r, sr, j, pc, bd);
+    else if (S == 1 && taps == 4) hipLaunchKernelGGL((k_pred_classes<1, 4, BI>), g, b, 0, st, d, sd, r, sr, j, pc, bd);
+    else if (S == 2 && taps == 8) hipLaunchKernelGGL((k_pred_classes<2, 8, BI>), g, b, 0, st, d, sd, r, sr, j, pc, bd);
+    else if (S == 2 && taps == 4) hipLaunchKernelGGL((k_pred_classes<2, 4, BI>), g, b, 0, st, d, sd, r, sr, j, pc, bd);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_pred_classes(hipStream_t st, int bi, int S, int taps, int bd, void *dst, long sd, const void *ref, long sr, const void *jobs, const int count[4])
+{
+    return bi ? launch_pred_classes_t<true>(st, S, taps, bd, dst, sd, ref, sr, jobs, count) : launch_pred_classes_t<false>(st, S, taps, bd, dst, sd, ref, sr, jobs, count);
 }
 
 hipError_t launch_subtract_bi(hipStream_t st, int S, int bitDepth, void *dst, long sd, const void *pred, long sp, const void *src, long ss,

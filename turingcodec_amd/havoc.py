@@ -80,6 +80,8 @@ def _load():
         "pred_uni": [_vp, _i, _i, _i, _i, _i, _vp, _ip, _vp, _ip, _vp, _i],
         "pred_bi": [_vp, _i, _i, _i, _i, _i, _vp, _ip, _vp, _ip, _vp, _i],
         "subtract_bi": [_vp, _i, _i, _vp, _ip, _vp, _ip, _vp, _ip, _vp, _i],
+        "pred_uni_classes": [_vp, _i, _i, _i, _vp, _ip, _vp, _ip, _vp, C.POINTER(C.c_int32)],
+        "pred_bi_classes": [_vp, _i, _i, _i, _vp, _ip, _vp, _ip, _vp, C.POINTER(C.c_int32)],
         "intra": [_vp, _i, _i, _i, _vp, _ip, _vp, _vp, _i],
         "intra_satd35": [_vp, _i, _i, _i, _vp, _ip, _vp, _vp, _i, _vp],
         "subpel_satd": [_vp, _i, _i, _i, _i, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
@@ -322,6 +324,21 @@ class Havoc:
 
     def pred_bi_d(self, taps, bd, dst, sd, ref, sr, jobs, max_w=64, max_h=64):
         self._ck(self.L.havoc_mi355x_pred_bi(self.h, self._S(ref), taps, bd, max_w, max_h, _ptr(dst), sd, _ptr(ref), sr, _ptr(jobs), jobs.shape[0]))
+
+    @staticmethod
+    def sort_by_class(jobs, w, h):
+        """(jobs reordered so that the four size classes <= 8, 16, 32, 64 follow each other, counts[4], the permutation applied)"""
+        big = np.maximum(np.asarray(w), np.asarray(h))
+        cls = np.searchsorted([8, 16, 32], big, side="left")
+        order = np.argsort(cls, kind="stable")
+        counts = np.bincount(cls, minlength=4).astype(np.int32)
+        return np.ascontiguousarray(np.asarray(jobs)[order]), counts, order
+
+    def pred_classes_d(self, bi, taps, bd, dst, sd, ref, sr, jobs, counts):
+        """all size classes of a (class-sorted) job table in one launch; counts: int32[4]"""
+        c = (C.c_int32 * 4)(*[int(v) for v in counts])
+        f = self.L.havoc_mi355x_pred_bi_classes if bi else self.L.havoc_mi355x_pred_uni_classes
+        self._ck(f(self.h, self._S(ref), taps, bd, _ptr(dst), sd, _ptr(ref), sr, _ptr(jobs), c))
 
     @staticmethod
     def size_classes(w, h):
