@@ -57,9 +57,12 @@ struct BatchView;
 struct SearchState
 {
     std::vector<SurfaceRef> surfaces;
-    bool haveSub = false;
-    int subCx = 0, subCy = 0;       // quarter units, relative to the PU position
-    const int32_t *sub = nullptr;   // 49 PU SATDs (-1: outside the phase planes)
+    // sub-sample data: PU SATDs of the (2K + 1)^2 quarter-sample positions around (cx, cy) (quarter units, relative to the PU position),
+    // -1 where the position's window leaves the phase planes.  The newest set is looked at first; a search keeps a few.
+    struct SubSet { int cx, cy, K; const int32_t *data; };
+    std::vector<SubSet> subs;
+    bool haveSub() const { return !subs.empty(); }
+    bool askedAlternatives = false;
     bool done = false;
     int replays = 0;
     Miss miss{0, 0, 0};
@@ -101,10 +104,15 @@ struct BatchView
     }
     int satdQpel(Mv mv)
     {
-        if (!st.haveSub || std::abs(mv.x - st.subCx) > kSub || std::abs(mv.y - st.subCy) > kSub) miss(2, mv.x, mv.y);
-        const int32_t v = st.sub[(mv.y - st.subCy + kSub) * kSubSide + (mv.x - st.subCx + kSub)];
-        if (v < 0) miss(3, mv.x, mv.y);   // the position's window leaves the phase planes: cannot be served
-        return v;
+        for (size_t k = st.subs.size(); k-- > 0;)
+        {
+            const SearchState::SubSet &u = st.subs[k];
+            if (std::abs(mv.x - u.cx) > u.K || std::abs(mv.y - u.cy) > u.K) continue;
+            const int32_t v = u.data[(mv.y - u.cy + u.K) * (2 * u.K + 1) + (mv.x - u.cx + u.K)];
+            if (v < 0) miss(3, mv.x, mv.y);   // the position's window leaves the phase planes: cannot be served
+            return v;
+        }
+        miss(2, mv.x, mv.y);
     }
 };
 // what longjmp passes over on its way out of a replay
@@ -302,7 +310,7 @@ struct Geom
     int64_t phase_origin;   // sample offset of its phase plane 0, sample (0, 0), from d_phase
 };
 
-struct Want { int i, cx, cy; };
+struct Want { int i, cx, cy, K; };     // K: half-width of a sub-sample set in quarter samples (surfaces ignore it)
 
 // The launches of a round.  Planes: d_src (stride src_stride) holds every source block; d_ref the reference picture(s) (stride ref_stride,
 // `ref_pad` samples of border, picture W x H); d_phase their 16 fractional-sample planes of plane_elems samples each.
@@ -372,30 +380,38 @@ struct Launcher
         return X >= -ref_pad + 12 && Y >= -ref_pad + 4 && X + q.w <= W + ref_pad - 12 && Y + q.h <= H + ref_pad - 4;
     }
 
-    // the PU SATDs of the 49 quarter-sample positions around (cx, cy) for every entry of w: 4 jobs of <= 16 candidates per search, one
-    // launch per lane-group class of the SATD kernel (rows of 8 samples per PU), as the reference's table is indexed by size.
+    // the PU SATDs of the (2K + 1)^2 quarter-sample positions around (cx, cy) for every entry of w (K = 3: the 49 positions one sub-sample
+    // refinement can touch; K = 7 also covers the integer vector moving by a sample): jobs of <= 16 candidates, one launch per lane-group class
+    // of the SATD kernel (rows of 8 samples per PU), as the reference's table is indexed by size.
     // Synchronises the context (the positions outside the phase planes are re-flagged on the host).
     int subSets(const std::vector<Want> &wantSub, const Geom *geom, SearchState *state)
     {
         if (wantSub.empty()) return 0;
         struct Cls { int lo, hi, mw, mh; };
         static const Cls classes[4] = {{0, 8, 8, 8}, {8, 16, 16, 8}, {16, 32, 16, 16}, {32, 1 << 30, 64, 64}};
-        struct Batch { std::vector<int> sel; int32_t *res; };
+        struct Batch { std::vector<int> sel; std::vector<int> first; int32_t *res; };
         Batch batch[4];
         for (int ci = 0; ci < 4; ++ci)
         {
             const Cls &c = classes[ci];
             std::vector<int> &sel = batch[ci].sel;
+            int njobs = 0;
             for (size_t k = 0; k < wantSub.size(); ++k)
             {
                 const Geom &q = geom[wantSub[k].i];
                 const int rows = ((q.w + 7) / 8) * q.h;
-                if (rows > c.lo && rows <= c.hi) sel.push_back(int(k));
+                if (rows > c.lo && rows <= c.hi)
+                {
+                    sel.push_back(int(k));
+                    batch[ci].first.push_back(njobs);
+                    const int side = 2 * wantSub[k].K + 1;
+                    njobs += (side * side + 15) / 16;
+                }
             }
             if (sel.empty()) continue;
             void *dJobs, *hJobs, *dOut, *hOut, *vJobs, *vOut;
-            HAVOC_SEARCH_RC(arena->get(sel.size() * 4 * sizeof(havoc_mi355x_satd_multi_job), &dJobs, &hJobs, &vJobs));
-            HAVOC_SEARCH_RC(arena->get(sel.size() * 64 * 4, &dOut, &hOut, &vOut));
+            HAVOC_SEARCH_RC(arena->get(size_t(njobs) * sizeof(havoc_mi355x_satd_multi_job), &dJobs, &hJobs, &vJobs));
+            HAVOC_SEARCH_RC(arena->get(size_t(njobs) * 16 * 4, &dOut, &hOut, &vOut));
             if (direct)
             {
                 dJobs = vJobs;
@@ -408,22 +424,21 @@ struct Launcher
                 const Want &wn = wantSub[sel[k]];
                 const Geom &q = geom[wn.i];
                 SearchState &st = state[wn.i];
-                st.haveSub = true;
-                st.subCx = wn.cx;
-                st.subCy = wn.cy;
-                st.sub = res + k * 64;      // slot c of 49 at [c / 16 * 16 + c % 16]: dense since jobs are consecutive
-                for (int j = 0; j < 4; ++j)
+                const int side = 2 * wn.K + 1, ncand = side * side, j0 = batch[ci].first[k];
+                if (st.subs.size() >= 6) st.subs.erase(st.subs.begin());
+                st.subs.push_back({wn.cx, wn.cy, wn.K, res + size_t(j0) * 16});      // candidate c at [c]: dense since the jobs are consecutive
+                for (int j = 0; j * 16 < ncand; ++j)
                 {
-                    havoc_mi355x_satd_multi_job &mj = jobs[4 * k + j];
+                    havoc_mi355x_satd_multi_job &mj = jobs[j0 + j];
                     std::memset(&mj, 0, sizeof(mj));
                     mj.a_off = int32_t(q.a_off);
                     mj.w = q.w;
                     mj.h = q.h;
-                    mj.count = j < 3 ? 16 : 1;
+                    mj.count = std::min(16, ncand - 16 * j);
                     for (int e = 0; e < mj.count; ++e)
                     {
                         const int c2 = 16 * j + e;
-                        const int qx = wn.cx + c2 % kSubSide - kSub, qy = wn.cy + c2 / kSubSide - kSub;
+                        const int qx = wn.cx + c2 % side - wn.K, qy = wn.cy + c2 / side - wn.K;
                         const int X = q.x0 + (qx >> 2), Y = q.y0 + (qy >> 2);
                         // positions whose 8-tap window leaves the padded plane are not in the phase planes: point at the
                         // integer position instead; the value is flagged unusable after the launch
@@ -433,13 +448,13 @@ struct Launcher
                     }
                 }
             }
-            if (!direct) HAVOC_SEARCH_RC(havoc_mi355x_h2d_async(ctx, dJobs, hJobs, sel.size() * 4 * sizeof(havoc_mi355x_satd_multi_job)));
+            if (!direct) HAVOC_SEARCH_RC(havoc_mi355x_h2d_async(ctx, dJobs, hJobs, size_t(njobs) * sizeof(havoc_mi355x_satd_multi_job)));
             HAVOC_SEARCH_RC(havoc_mi355x_satd_multi(ctx, S, c.mw, c.mh, d_src, src_stride, d_phase, ref_stride, static_cast<const havoc_mi355x_satd_multi_job *>(dJobs),
-                                                    int(sel.size() * 4), static_cast<int32_t *>(dOut)));
-            if (!direct) HAVOC_SEARCH_RC(havoc_mi355x_d2h_async(ctx, hOut, dOut, sel.size() * 64 * 4));
+                                                    njobs, static_cast<int32_t *>(dOut)));
+            if (!direct) HAVOC_SEARCH_RC(havoc_mi355x_d2h_async(ctx, hOut, dOut, size_t(njobs) * 16 * 4));
             ++stt->launches;
-            stt->satd_jobs += int32_t(sel.size() * 4);
-            stt->bytes_down += int64_t(sel.size() * 64 * 4);
+            stt->satd_jobs += njobs;
+            stt->bytes_down += int64_t(njobs) * 16 * 4;
         }
         HAVOC_SEARCH_RC(havoc_mi355x_sync(ctx));
         for (int ci = 0; ci < 4; ++ci)      // re-flag the positions outside the phase planes
@@ -447,8 +462,9 @@ struct Launcher
             {
                 const Want &wn = wantSub[batch[ci].sel[k]];
                 const Geom &q = geom[wn.i];
-                for (int c2 = 0; c2 < kSubCands; ++c2)
-                    if (!insidePhasePlanes(q, wn.cx + c2 % kSubSide - kSub, wn.cy + c2 / kSubSide - kSub)) batch[ci].res[k * 64 + c2] = -1;
+                const int side = 2 * wn.K + 1;
+                for (int c2 = 0; c2 < side * side; ++c2)
+                    if (!insidePhasePlanes(q, wn.cx + c2 % side - wn.K, wn.cy + c2 / side - wn.K)) batch[ci].res[size_t(batch[ci].first[k]) * 16 + c2] = -1;
             }
         return 0;
     }

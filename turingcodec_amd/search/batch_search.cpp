@@ -81,7 +81,7 @@ int runSearches(havoc_mi355x_ctx *ctx, int S, const havoc_search_params *params,
         geom[i] = Geom{q.x0, q.y0, q.w, q.h, fl.a_off[i], ref_origin, phase_origin};
         int cx = fl.centre0[i].x, cy = fl.centre0[i].y;
         if (!launch.clampCentre(geom[i], kR0, &cx, &cy)) return HAVOC_MI355X_EINVAL;   // picture (with its padding) smaller than a search window
-        wantSurf[0].push_back({i, cx, cy});
+        wantSurf[0].push_back({i, cx, cy, 0});
     }
 
     std::vector<int> pending(n);
@@ -142,12 +142,12 @@ int runSearches(havoc_mi355x_ctx *ctx, int S, const havoc_search_params *params,
                 int cx = st.miss.x, cy = st.miss.y;
                 // LimitFullPelMv keeps every candidate within reach of a +-64 window that stays inside the 96-sample padding
                 if (!launch.clampCentre(geom[i], kR1, &cx, &cy) || std::abs(cx - st.miss.x) > kR1 || std::abs(cy - st.miss.y) > kR1) return HAVOC_MI355X_EINVAL;
-                wantSurf[1].push_back({i, cx, cy});
+                wantSurf[1].push_back({i, cx, cy, 0});
             }
             else if (st.miss.kind == 2)
                 // the 49 positions are centred on the full-sample vector being refined: the first sub-sample question is that vector
                 // itself (uni, Search.hpp:2340-2358) or its (-2, -2) half-sample neighbour (bi, Search.hpp:1627-1650)
-                wantSub.push_back({i, ((st.miss.x + 2) >> 2) * 4, ((st.miss.y + 2) >> 2) * 4});
+                wantSub.push_back({i, ((st.miss.x + 2) >> 2) * 4, ((st.miss.y + 2) >> 2) * 4, kSub});
             else
                 return HAVOC_MI355X_EINVAL;   // a sub-sample position outside the phase planes: the caller's planes are too small
             still.push_back(i);

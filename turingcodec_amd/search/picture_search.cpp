@@ -31,7 +31,8 @@ namespace {
 
 #define RC(call) HAVOC_SEARCH_RC(call)
 
-constexpr int kR0 = 16;     // round-0 surface around the predicted vector
+constexpr int kR0Default = 16;     // round-0 surface around the predicted vector
+constexpr int kRL = 72;     // half-width of a miss surface: the star search's +-64 around a start that may sit a few samples off the surface's centre
 constexpr int kRz = 4;      // round-0 surface around the zero vector (MET probe: diamond +-1, hexagon +-2, Search.hpp:2112-2124)
 
 // the integer stage kept for a search is only good for the predictors it was computed with
@@ -82,6 +83,11 @@ int havoc_search_picture_uni(havoc_mi355x_ctx *ctx, int S, const havoc_search_pa
     Arena arena(ctx);
     Launcher launch{ctx, S, d_src, src_stride, d_ref, ref_stride, ref_pad, d_phase, plane_elems, W, H, &arena, &stt};
     launch.direct = getenv("HAVOC_PICTURE_STAGED") == nullptr;     // diagnostic switch: staged copies instead of mapped host memory
+    // diagnostic switches (profiles/): half-width of the sub-sample sets (3 = the 49 positions of one refinement, 7 = +- a sample), alternatives off
+    const int subK = getenv("HAVOC_PICTURE_SUBK") ? std::max(3, std::min(11, atoi(getenv("HAVOC_PICTURE_SUBK")))) : 7;
+    const bool alternatives = !(getenv("HAVOC_PICTURE_ALT") && atoi(getenv("HAVOC_PICTURE_ALT")) == 0);
+    const bool debug = getenv("HAVOC_PICTURE_DEBUG") != nullptr;
+    const int kR0 = getenv("HAVOC_PICTURE_R0") ? std::max(8, std::min(48, atoi(getenv("HAVOC_PICTURE_R0")))) : kR0Default;
 
     std::vector<SearchState> state(n);
     std::vector<Geom> geom(n);
@@ -144,11 +150,18 @@ int havoc_search_picture_uni(havoc_mi355x_ctx *ctx, int S, const havoc_search_pa
                     const int i = 2 * p + l;
                     int cx = full.x, cy = full.y;
                     if (!launch.clampCentre(geom[i], kR0, &cx, &cy)) return HAVOC_MI355X_EINVAL;
-                    wantR0.push_back({i, cx, cy});
+                    wantR0.push_back({i, cx, cy, 0});
+                    if (alternatives)
+                    {
+                        // ... and already the sub-sample positions around that vector (+- a sample) and around zero: where the search ends on the
+                        // vector its neighbourhood moves with -- the common case -- its chain needs no second round
+                        wantSub.push_back({i, 4 * cx, 4 * cy, subK});
+                        if (std::abs(4 * cx) + kSub > subK || std::abs(4 * cy) + kSub > subK) wantSub.push_back({i, 0, 0, kSub});
+                    }
                     if (std::abs(cx) > kR0 - kRz || std::abs(cy) > kR0 - kRz)
                     {
                         int zx = 0, zy = 0;
-                        if (launch.clampCentre(geom[i], kRz, &zx, &zy) && zx == 0 && zy == 0) wantZero.push_back({i, 0, 0});
+                        if (launch.clampCentre(geom[i], kRz, &zx, &zy) && zx == 0 && zy == 0) wantZero.push_back({i, 0, 0, 0});
                     }
                 }
             }
@@ -164,7 +177,7 @@ int havoc_search_picture_uni(havoc_mi355x_ctx *ctx, int S, const havoc_search_pa
             RC(launch.surfaces(wantR0, kR0, geom.data(), state.data(), false));
             pst.surfaces_zero += int32_t(wantZero.size());
             RC(launch.surfaces(wantZero, kRz, geom.data(), state.data(), false));
-            RC(launch.surfaces(wantLarge, kR1, geom.data(), state.data(), true));
+            RC(launch.surfaces(wantLarge, kRL, geom.data(), state.data(), true));
             RC(launch.subSets(wantSub, geom.data(), state.data()));
             wantR0.clear();
             wantZero.clear();
@@ -230,26 +243,79 @@ int havoc_search_picture_uni(havoc_mi355x_ctx *ctx, int S, const havoc_search_pa
                         else
                         {
                             ++st.replays;
+                            if (debug && !guessing)
+                                fprintf(stderr, "stop step=%d round=%d kind=%d hadsub=%d surfaces=%d miss=%d,%d pu=%d,%d %dx%d last=%d,%d R%d\n", step, roundsInStep, st.miss.kind, int(st.haveSub()), int(st.surfaces.size()), st.miss.x, st.miss.y, q.x0, q.y0, q.w, q.h, st.surfaces.back().cx, st.surfaces.back().cy, st.surfaces.back().R);
                             if (st.miss.kind == 2 && st.integer.valid)
                             {
                                 // sub-sample data missing: ask for the 49 positions around the integer vector and run ahead on that vector
                                 integerMv = st.integer.best.mv;
-                                if (getenv("HAVOC_PICTURE_DEBUG") && st.haveSub)
-                                    fprintf(stderr, "resub d=%d,%d\n", ((st.miss.x + 2) >> 2) * 4 - st.subCx, ((st.miss.y + 2) >> 2) * 4 - st.subCy);
-                                mySub.push_back({i, ((st.miss.x + 2) >> 2) * 4, ((st.miss.y + 2) >> 2) * 4});
+                                const int cxq = ((st.miss.x + 2) >> 2) * 4, cyq = ((st.miss.y + 2) >> 2) * 4;
+                                if (debug && st.haveSub())
+                                {
+                                    fprintf(stderr, "resub want=%d,%d (miss %d,%d) mvp0=%d,%d have:", cxq, cyq, st.miss.x, st.miss.y, pu.mvp[0].x, pu.mvp[0].y);
+                                    for (const auto &u : st.subs) fprintf(stderr, " (%d,%d K%d)", u.cx, u.cy, u.K);
+                                    fprintf(stderr, "\n");
+                                }
+                                // The set is wider than one refinement needs (K = 7: the integer vector may still move by a sample when the
+                                // searches before this one become final), and the first time a search asks it also gets the 49 positions
+                                // around the two other vectors it most often ends on then: zero and its first predictor.  Tile SATDs are the
+                                // cheapest thing the device does; a wrong guess costs a round trip for the whole chain.
+                                const bool first = st.subs.size() <= 2 && !st.askedAlternatives;
+                                mySub.push_back({i, cxq, cyq, subK});
+                                st.askedAlternatives = true;
+                                if (first && alternatives)
+                                {
+                                    // ... zero, its first predictor, and the vector decided next to its CTU (where its round-0 surface sits)
+                                    const Mv p0 = shl2(shr2(Mv(int16_t(pu.mvp[0].x + 2), int16_t(pu.mvp[0].y + 2))));
+                                    const int ax[3] = {0, p0.x, 4 * st.surfaces[0].cx}, ay[3] = {0, p0.y, 4 * st.surfaces[0].cy};
+                                    for (int a = 0; a < 3; ++a)
+                                    {
+                                        bool covered = std::abs(ax[a] - cxq) + kSub <= subK && std::abs(ay[a] - cyq) + kSub <= subK;
+                                        for (int b = 0; b < a; ++b) covered |= ax[b] == ax[a] && ay[b] == ay[a];
+                                        for (const auto &u : st.subs) covered |= std::abs(ax[a] - u.cx) + kSub <= u.K && std::abs(ay[a] - u.cy) + kSub <= u.K;
+                                        if (!covered) mySub.push_back({i, ax[a], ay[a], kSub});
+                                    }
+                                }
                                 decided = integerMv;
                                 wrote = st.integer.wrote2Nx2N;
                                 guessing = true;
                             }
                             else if (st.miss.kind == 1)
                             {
+                                // Where to centre the +-64 surface.  What asks far from the round-0 window is the star search at its large distances
+                                // (+-64 around its START, which is almost always the first predictor rounded, Search.hpp:2196-2215) and the raster
+                                // refinement (absolute positions +-60 around zero, :2253-2267): a surface centred on the missed position serves half
+                                // of either.  So: the first predictor, else zero, else the position itself -- the first whose window holds the
+                                // position and that this search does not have yet.
+                                const Mv p0 = shr2(Mv(int16_t(pu.mvp[0].x + 2), int16_t(pu.mvp[0].y + 2)));
+                                const int tryX[3] = {p0.x, 0, st.miss.x}, tryY[3] = {p0.y, 0, st.miss.y};
                                 int cx = st.miss.x, cy = st.miss.y;
-                                if (!launch.clampCentre(geom[i], kR1, &cx, &cy) || std::abs(cx - st.miss.x) > kR1 || std::abs(cy - st.miss.y) > kR1)
+                                for (int t = 0; t < 3; ++t)
+                                {
+                                    int tx = tryX[t], ty = tryY[t];
+                                    if (!launch.clampCentre(geom[i], kRL, &tx, &ty) || std::abs(tx - st.miss.x) > kRL || std::abs(ty - st.miss.y) > kRL) continue;
+                                    bool have = false;
+                                    for (const SurfaceRef &f : st.surfaces) have |= f.R == kRL && f.cx == tx && f.cy == ty;
+                                    if (have) continue;
+                                    cx = tx;
+                                    cy = ty;
+                                    break;
+                                }
+                                if (!launch.clampCentre(geom[i], kRL, &cx, &cy) || std::abs(cx - st.miss.x) > kRL || std::abs(cy - st.miss.y) > kRL)
                                 {
                                     bad = 1;
                                     break;
                                 }
-                                myLarge.push_back({i, cx, cy});
+                                myLarge.push_back({i, cx, cy, 0});
+                                if (!st.askedAlternatives && alternatives)
+                                {
+                                    st.askedAlternatives = true;
+                                    // ... and, for the sub-sample stage that will follow the integer stage next round, the positions around the two
+                                    // vectors it will most likely end on: the first predictor and zero
+                                    const Mv g = shl2(p0);
+                                    mySub.push_back({i, g.x, g.y, subK});
+                                    if (std::abs(g.x) + kSub > subK || std::abs(g.y) + kSub > subK) mySub.push_back({i, 0, 0, kSub});
+                                }
                                 // the integer stage left its surfaces: guess the first predictor (rounded to full samples) for this search, so that
                                 // the searches after it can still say what they need in this round
                                 decided = shl2(shr2(Mv(int16_t(pu.mvp[0].x + 2), int16_t(pu.mvp[0].y + 2))));
