@@ -269,7 +269,7 @@ int havoc_mi355x_sad4(havoc_mi355x_ctx *ctx, int S, const void *d_src, intptr_t 
 /* Full-pel SAD surface: the super-set serving the havoc_sad / havoc_sad_multiref calls of the integer motion search
  * (turing/Search.hpp:1447-1482 considerPattern, :1585-1623 bi grid, :2224-2290 star / raster / refinement) as look-ups.
  * d_out[out_off + (dy + range) * (2*range + 1) + (dx + range)] = havoc_sad(src, ref + dy*stride_ref + dx) for every
- * dx, dy in [-range, range], range 0..64; every value is the one havoc_mi355x_sad returns for that candidate.
+ * dx, dy in [-range, range], range 0..96 (the reference pads its pictures by 96 samples); every value is the one havoc_mi355x_sad returns for that candidate.
  * max_w / max_h: upper bounds on the block sizes of the batch.  Reads at most 3 bytes beyond a candidate row. */
 int havoc_mi355x_sad_surface(havoc_mi355x_ctx *ctx, int S, int range, int max_w, int max_h, const void *d_src,
                              intptr_t stride_src, const void *d_ref, intptr_t stride_ref,

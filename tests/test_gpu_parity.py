@@ -56,7 +56,7 @@ def test_library_loaded_in_process():
 
 
 @pytest.mark.parametrize("S,bd", [(1, 8), (2, 10)])
-@pytest.mark.parametrize("rng", [0, 1, 5, 16, 33, 64])
+@pytest.mark.parametrize("rng", [0, 1, 5, 16, 33, 64, 72, 96])
 def test_sad_surface_ranges(hv, oracle, S, bd, rng):
     """surfaces of every supported range on a 352 x 288 plane: bi-prediction grids (3x3, 11x11: many jobs per workgroup)
     up to the +-64 star-search window (9 bands per job).  Expected values: the SAD definition in numpy (sum |a-b|,

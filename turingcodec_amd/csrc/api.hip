@@ -319,7 +319,7 @@ int havoc_mi355x_sad_surface(havoc_mi355x_ctx *ctx, int S, int range, int max_w,
                              const void *d_ref, intptr_t stride_ref, const havoc_mi355x_surface_job *d_jobs, int njobs, int32_t *d_out)
 {
     REQUIRE_CTX(); REQUIRE_S(); REQUIRE(njobs >= 0, "njobs < 0");
-    REQUIRE(range >= 0 && range <= 64, "range must be 0..64");
+    REQUIRE(range >= 0 && range <= 96, "range must be 0..96");
     REQUIRE(max_w >= 4 && max_w <= 64 && (max_w & 3) == 0 && max_h >= 1 && max_h <= 64, "max_w must be 4..64 and a multiple of 4, max_h 1..64");
     return check(launch_sad_surface(LS(ctx), S, range, max_w, max_h, d_src, stride_src, d_ref, stride_ref, d_jobs, njobs, d_out), "sad_surface");
 }
