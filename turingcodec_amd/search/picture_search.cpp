@@ -84,7 +84,9 @@ int havoc_search_picture_uni(havoc_mi355x_ctx *ctx, int S, const havoc_search_pa
     Launcher launch{ctx, S, d_src, src_stride, d_ref, ref_stride, ref_pad, d_phase, plane_elems, W, H, &arena, &stt};
     launch.direct = getenv("HAVOC_PICTURE_STAGED") == nullptr;     // diagnostic switch: staged copies instead of mapped host memory
     // diagnostic switches (profiles/): half-width of the sub-sample sets (3 = the 49 positions of one refinement, 7 = +- a sample), alternatives off
-    const int subK = getenv("HAVOC_PICTURE_SUBK") ? std::max(3, std::min(11, atoi(getenv("HAVOC_PICTURE_SUBK")))) : 7;
+    // measured on the 1080p clip (profiles/r03/picture_1080p_k*_a*_t*.json), one picture alone: K = 3 with alternatives 21.6 ms in 243 rounds;
+    // K = 7: 203 rounds but 28 ms (4.6 x the tile SATDs per set); K = 3 without alternatives 23.5 ms in 269 rounds; before any of it 24.9 ms in 359
+    const int subK = getenv("HAVOC_PICTURE_SUBK") ? std::max(3, std::min(11, atoi(getenv("HAVOC_PICTURE_SUBK")))) : 3;
     const bool alternatives = !(getenv("HAVOC_PICTURE_ALT") && atoi(getenv("HAVOC_PICTURE_ALT")) == 0);
     const bool debug = getenv("HAVOC_PICTURE_DEBUG") != nullptr;
     const int kR0 = getenv("HAVOC_PICTURE_R0") ? std::max(8, std::min(48, atoi(getenv("HAVOC_PICTURE_R0")))) : kR0Default;
@@ -256,10 +258,10 @@ int havoc_search_picture_uni(havoc_mi355x_ctx *ctx, int S, const havoc_search_pa
                                     for (const auto &u : st.subs) fprintf(stderr, " (%d,%d K%d)", u.cx, u.cy, u.K);
                                     fprintf(stderr, "\n");
                                 }
-                                // The set is wider than one refinement needs (K = 7: the integer vector may still move by a sample when the
-                                // searches before this one become final), and the first time a search asks it also gets the 49 positions
-                                // around the two other vectors it most often ends on then: zero and its first predictor.  Tile SATDs are the
-                                // cheapest thing the device does; a wrong guess costs a round trip for the whole chain.
+                                // The first time a search asks it also gets the 49 positions around the other vectors it most often ends on when
+                                // the searches before it become final: zero, its first predictor, the vector decided next to its CTU.  (A set may
+                                // be wider than one refinement needs -- HAVOC_PICTURE_SUBK = 7 also covers the integer vector moving by a sample:
+                                // fewer rounds, more tile SATDs per round; measured slower, see above.)
                                 const bool first = st.subs.size() <= 2 && !st.askedAlternatives;
                                 mySub.push_back({i, cxq, cyq, subK});
                                 st.askedAlternatives = true;
