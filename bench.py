@@ -88,6 +88,7 @@ def parse_args():
                     help="TU chain: two fused kernels around the host quantiser (default) or the five separate primitives")
     ap.add_argument("--pred", choices=["merged", "classes"], default="merged",
                     help="prediction launches: all size classes of a table in one launch (default) or one launch per width class")
+    ap.add_argument("--separate-scan", action="store_true", help="diagnostic: RDOQ's scan pass as its own kernel (round 2) instead of inside tu_forward")
     ap.add_argument("--subpel", choices=["planes", "fused"], default="planes",
                     help="sub-pel candidates: SATD against per-picture phase planes (default) or the fused per-candidate kernel")
     return ap.parse_args()
@@ -100,7 +101,7 @@ def parse_args():
 class DeviceFrame:
     """A FrameWorkload uploaded to HBM + the list of launches that make one step."""
 
-    def __init__(self, hv, wl, use_planes=True, fused_tu=True, ime_range=None, skip=(), rdoq=True, pred_launches="merged"):
+    def __init__(self, hv, wl, use_planes=True, fused_tu=True, ime_range=None, skip=(), rdoq=True, pred_launches="merged", scan_in_forward=True):
         import torch
         from turingcodec_amd import havoc as _havoc
         self.rdoq = bool(rdoq) and wl.mix == "ra"
@@ -278,7 +279,13 @@ class DeviceFrame:
                     bd, tr, log2, g["dscale"], g["dshift"], g["rec"], n, self.luma, st, self.luma, st, g["level"], g["fjobs"], g["ossd"]))]
                 if g["jssd_x"] is not None:   # the reference makes ~1.26 SSD calls per TU: the rest as plain SSD jobs
                     items.append(("ssd", lambda g=g, n=n: hv.ssd_d(self.luma, st, g["rec"], n, g["jssd_x"], g["ossd_x"])))
-                if self.rdoq:
+                if self.rdoq and scan_in_forward and log2 >= 4 and tr == 0:
+                    # 16x16 / 32x32: the scan pass of the device RDOQ runs inside tu_forward (the coefficients are in registers there)
+                    chain(("tu_forward", lambda g=g, log2=log2: hv.tu_forward_scan_d(bd, log2, g["coef"], self.luma, st, self.luma, st, g["fjobs"], g["rjobs"],
+                                                                                      g["level"], g["rwork"])),
+                          ("rdoq", lambda g=g, log2=log2: hv.rdoq_prescanned_d(bd, log2, g["level"], g["coef"], self.rdoq_states, g["rjobs"], g["cbf"], g["rwork"])),
+                          *items)
+                elif self.rdoq:
                     chain(fwd, rdq, *items)
                 elif inter:
                     chain(fwd)
@@ -856,7 +863,7 @@ def build_contexts(args, torch, Havoc, FrameWorkload, local, res, bit_depth, qp,
         wl_k = FrameWorkload(w, h, bit_depth, seed0 + 1000 * k, qp=qp, mix=mix, frames=frames)
         dev_k = DeviceFrame(hv_k, wl_k, use_planes=(args.subpel == "planes"), fused_tu=(args.tu == "fused"),
                             ime_range=args.ime_range if args.ime == "surface" else None, skip=[s for s in args.skip.split(",") if s],
-                            rdoq=args.rdoq, pred_launches=getattr(args, "pred", "merged"))
+                            rdoq=args.rdoq, pred_launches=getattr(args, "pred", "merged"), scan_in_forward=not getattr(args, "separate_scan", False))
         dev_k.step()          # first eager pass (loads the code objects) -- also what the graph must reproduce
         hv_k.sync()
         if args.no_graph:

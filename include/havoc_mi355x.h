@@ -493,6 +493,18 @@ size_t havoc_mi355x_rdoq_workspace(int njobs);
 int havoc_mi355x_rdoq(havoc_mi355x_ctx *ctx, int bitDepth, int log2TrafoSize, int16_t *d_dst, const int16_t *d_src, const uint8_t *d_states,
                       const havoc_mi355x_rdoq_job *d_jobs, int njobs, int32_t *d_cbf, void *d_work, size_t work_bytes);
 
+/* The same two steps with the scan of the coefficients done where they are produced (16x16 / 32x32 blocks; round 3):
+ *   tu_forward_scan  = tu_forward + the first pass of the device RDOQ (which 4x4 groups hold a rounded level, the block's energy -> d_work;
+ *                      the level block of d_rdoq_jobs[i].dst_off zeroed).  d_rdoq_jobs[i] describes the same block as d_jobs[i]
+ *                      (src_off = the job's coef_off).
+ *   rdoq_prescanned  = the rest of havoc_mi355x_rdoq on that workspace: levels and flags identical to havoc_mi355x_rdoq on the coefficients.
+ * Saves a kernel that re-reads every coefficient per block size (2 x 47 MB and 47 us of launches per 1080p picture). */
+int havoc_mi355x_tu_forward_scan(havoc_mi355x_ctx *ctx, int S, int bitDepth, int log2TrafoSize, int16_t *d_coeffs, const void *d_src, intptr_t stride_src,
+                                 const void *d_pred, intptr_t stride_pred, const havoc_mi355x_tu_fused_job *d_jobs, int njobs,
+                                 const havoc_mi355x_rdoq_job *d_rdoq_jobs, int16_t *d_levels, void *d_work, size_t work_bytes);
+int havoc_mi355x_rdoq_prescanned(havoc_mi355x_ctx *ctx, int bitDepth, int log2TrafoSize, int16_t *d_dst, const int16_t *d_src, const uint8_t *d_states,
+                                 const havoc_mi355x_rdoq_job *d_jobs, int njobs, int32_t *d_cbf, void *d_work, size_t work_bytes);
+
 #ifdef __cplusplus
 }
 #endif

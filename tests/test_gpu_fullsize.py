@@ -246,6 +246,25 @@ def test_8k_frame_properties(hv):
     assert a.checksum() == ref
 
 
+def test_scan_inside_tu_forward_equals_the_separate_scan(hv):
+    """havoc_mi355x_tu_forward_scan + havoc_mi355x_rdoq_prescanned against tu_forward + havoc_mi355x_rdoq on the 1080p picture's 16x16 and 32x32
+    transform blocks: coefficients, levels, coded-block flags, reconstructions and SSDs identical (8- and 10-bit)"""
+    import bench
+    from turingcodec_amd.workload import FrameWorkload
+    for bd, qp in ((8, 32), (10, 27)):
+        wl = FrameWorkload(1920, 1080, bd, 11, qp=qp)
+        a = bench.DeviceFrame(hv, wl, scan_in_forward=True)
+        b = bench.DeviceFrame(hv, wl, scan_in_forward=False)
+        a.step()
+        b.step()
+        hv.sync()
+        assert len(a.launches) == len(b.launches)
+        for key in a.tu:
+            for name, dt in (("coef", np.int16), ("level", np.int16), ("cbf", np.int32), ("rec", wl.dtype), ("ossd", np.uint32)):
+                assert np.array_equal(hv.down(a.tu[key][name], dt), hv.down(b.tu[key][name], dt)), (bd, key, name)
+        assert a.checksum() == b.checksum()
+
+
 def test_merged_prediction_launches_equal_the_per_class_launches(hv):
     """havoc_mi355x_pred_uni_classes / pred_bi_classes (all four size classes of a job table in one launch) against one launch per width
     class, on the 1080p picture's luma and chroma, uni and bi tables: identical output buffers"""

@@ -28,6 +28,9 @@ hipError_t launch_transform(hipStream_t, int bd, int log2, int tr, int16_t *, co
 hipError_t launch_inverse_transform(hipStream_t, int mode, int bd, int log2, int tr, void *, long, const void *, long, int16_t *, const int16_t *,
                                     const void *, int);
 hipError_t launch_tu_forward(hipStream_t, int S, int bd, int log2, int tr, int16_t *, const void *, long, const void *, long, const void *, int);
+hipError_t launch_tu_forward_scan(hipStream_t, int S, int bd, int log2, int16_t *, const void *, long, const void *, long, const void *, int, const void *, int16_t *,
+                                  void *);
+hipError_t launch_rdoq_prescanned(hipStream_t, int bitDepth, int log2, int16_t *, const int16_t *, const uint8_t *, const void *, int, int32_t *, void *);
 hipError_t launch_tu_reconstruct(hipStream_t, int S, int bd, int log2, int tr, int scale, int shift, void *, long, const void *, long, const void *,
                                  long, const int16_t *, const void *, int, uint32_t *);
 hipError_t launch_quantize(hipStream_t, int16_t *, const int16_t *, const void *, int, int32_t *);
@@ -572,6 +575,29 @@ int havoc_mi355x_sao_filter(havoc_mi355x_ctx *ctx, int S, int bitDepth, void *d_
     REQUIRE_CTX(); REQUIRE(S == 1 || S == 2, "S must be 1 or 2"); REQUIRE_BD(); REQUIRE(njobs >= 0, "njobs < 0");
     REQUIRE(d_dst != d_src, "sao_filter: the filtered picture and the deblocked picture must be different buffers");
     return check(launch_sao_filter(LS(ctx), S, bitDepth, d_dst, stride_dst, d_src, stride_src, d_jobs, njobs), "sao_filter");
+}
+
+int havoc_mi355x_tu_forward_scan(havoc_mi355x_ctx *ctx, int S, int bitDepth, int log2TrafoSize, int16_t *d_coeffs, const void *d_src, intptr_t stride_src,
+                                 const void *d_pred, intptr_t stride_pred, const havoc_mi355x_tu_fused_job *d_jobs, int njobs, const havoc_mi355x_rdoq_job *d_rdoq_jobs,
+                                 int16_t *d_levels, void *d_work, size_t work_bytes)
+{
+    REQUIRE_CTX(); REQUIRE_S(); REQUIRE_BD(); REQUIRE(njobs >= 0, "njobs < 0");
+    REQUIRE(log2TrafoSize == 4 || log2TrafoSize == 5, "tu_forward_scan: 16x16 and 32x32 blocks (smaller ones are scanned inside the RDOQ walk)");
+    REQUIRE(njobs == 0 || (d_rdoq_jobs && d_levels && d_work && work_bytes >= rdoq_workspace_bytes(njobs) && (reinterpret_cast<uintptr_t>(d_work) & 15) == 0),
+            "tu_forward_scan: rdoq jobs / level buffer / workspace missing, misaligned or smaller than havoc_mi355x_rdoq_workspace(njobs)");
+    return check(launch_tu_forward_scan(LS(ctx), S, bitDepth, log2TrafoSize, d_coeffs, d_src, stride_src, d_pred, stride_pred, d_jobs, njobs, d_rdoq_jobs, d_levels, d_work),
+                 "tu_forward_scan");
+}
+
+int havoc_mi355x_rdoq_prescanned(havoc_mi355x_ctx *ctx, int bitDepth, int log2TrafoSize, int16_t *d_dst, const int16_t *d_src, const uint8_t *d_states,
+                                 const havoc_mi355x_rdoq_job *d_jobs, int njobs, int32_t *d_cbf, void *d_work, size_t work_bytes)
+{
+    REQUIRE_CTX(); REQUIRE(log2TrafoSize == 4 || log2TrafoSize == 5, "rdoq_prescanned: 16x16 and 32x32 blocks"); REQUIRE(njobs >= 0, "njobs < 0");
+    REQUIRE(bitDepth >= 8 && bitDepth <= 12, "bitDepth must be 8..12");
+    REQUIRE(d_dst != d_src, "rdoq: d_dst and d_src must be different buffers");
+    REQUIRE(njobs == 0 || (d_work && work_bytes >= rdoq_workspace_bytes(njobs) && (reinterpret_cast<uintptr_t>(d_work) & 15) == 0),
+            "rdoq: workspace missing, misaligned or smaller than havoc_mi355x_rdoq_workspace(njobs)");
+    return check(launch_rdoq_prescanned(LS(ctx), bitDepth, log2TrafoSize, d_dst, d_src, d_states, d_jobs, njobs, d_cbf, d_work), "rdoq_prescanned");
 }
 
 size_t havoc_mi355x_rdoq_workspace(int njobs) { return rdoq_workspace_bytes(njobs); }

@@ -15,6 +15,7 @@
 // chain afterwards: bit exact, but 8x the arithmetic on 85 % zero groups and an LDS footprint that left 3 workgroups per CU; it
 // took 1.9 ms per 1080p picture against 0.93 ms for the form below.  profiles/r02_experiments.md has the numbers.)
 #include "common.h"
+#include "rdoq_work.h"
 
 #include <cstdlib>
 
@@ -36,13 +37,7 @@ __device__ const int32_t kEntropyBits[128] = {
 typedef short s16x2v __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2v __attribute__((ext_vector_type(2)));
 
-struct RdoqJob   // == havoc_mi355x_rdoq_job
-{
-    int32_t dst_off, src_off, quant_scale, quant_shift, inv_scale, lambda_q16, sdh_factor, ctx_index;
-    uint8_t c_idx, scan_idx, is_intra, sdh;
-    int32_t reserved[3];
-};
-static_assert(sizeof(RdoqJob) == 48 && sizeof(havoc_mi355x_rdoq_job) == 48, "rdoq job layout");
+static_assert(sizeof(havoc_mi355x_rdoq_job) == sizeof(RdoqJob), "rdoq job layout");
 
 // what a lane knows about its transform block
 struct Block
@@ -482,17 +477,6 @@ __device__ __forceinline__ void hideSignsWalk(WalkShared &sh, int lane, const Bl
 
 // Workspace of one launch (caller-provided, havoc_mi355x_rdoq_workspace bytes): what the scan pass found per block, the
 // histogram of blocks by their number of groups to walk, and the order the walk takes the blocks in.
-struct RdoqInfo { uint64_t mask, mask2, mask3; int64_t sumSq; };      // groups holding a rounded level > 0 / > 1 / > 2 (bit = raster group position), sum of squared coefficients
-constexpr int kBins = 66;                               // 0..64 groups to walk (+1 spare)
-struct RdoqWork
-{
-    uint32_t hist[kBins], cursor[kBins];
-    uint32_t otherScans, pad[3];      // blocks of this launch that do not use the diagonal scan (walked by the sequential kernel)
-    // followed by RdoqInfo info[njobs], then uint32_t order[njobs]
-};
-__host__ __device__ inline size_t rdoqInfoOffset() { return (sizeof(RdoqWork) + 15) & ~size_t(15); }
-__device__ __forceinline__ int groupsToWalk(uint64_t mask) { return mask ? __popcll(mask | 1) : 0; }      // the DC group is always walked
-
 // LDS of the cooperative scan of a workgroup's 64 blocks
 struct ScanShared
 {
@@ -597,6 +581,25 @@ __global__ __launch_bounds__(64) void k_rdoq_scan(int16_t *__restrict__ dstAll, 
     for (int k = lane; k < kBins - 1; k += 64)
         if (hist[k]) atomicAdd(&work->hist[k], hist[k]);
     if (lane == 0 && hist[kBins - 1]) atomicAdd(&work->otherScans, hist[kBins - 1]);
+}
+
+// The histogram alone, for blocks whose scan was done elsewhere (k_tu_forward<..., SCAN> left RdoqInfo per block in the workspace and zeroed the
+// level blocks): reads 32 bytes per block instead of the block.
+__global__ __launch_bounds__(256) void k_rdoq_hist(const RdoqJob *__restrict__ jobs, int njobs, RdoqWork *__restrict__ work)
+{
+    __shared__ uint32_t hist[kBins];
+    const RdoqInfo *info = reinterpret_cast<const RdoqInfo *>(reinterpret_cast<const char *>(work) + rdoqInfoOffset());
+    const int t = threadIdx.x, blk = blockIdx.x * 256 + t;
+    if (t < kBins) hist[t] = 0;
+    __syncthreads();
+    if (blk < njobs)
+    {
+        atomicAdd(&hist[groupsToWalk(info[blk].mask)], 1u);
+        if (jobs[blk].scan_idx != 0) atomicAdd(&hist[kBins - 1], 1u);
+    }
+    __syncthreads();
+    if (t < kBins - 1 && hist[t]) atomicAdd(&work->hist[t], hist[t]);
+    if (t == kBins - 1 && hist[t]) atomicAdd(&work->otherScans, hist[t]);
 }
 
 // Pass 2: blocks ordered by decreasing number of groups to walk (counting sort; the order inside a bin is whatever the atomics
@@ -1112,29 +1115,16 @@ __global__ __launch_bounds__(64) void k_rdoq_diag(int16_t *__restrict__ dstAll, 
 
 size_t rdoq_workspace_bytes(int njobs) { return rdoqInfoOffset() + (size_t)max(njobs, 0) * (sizeof(RdoqInfo) + sizeof(uint32_t)) + 64; }
 
-hipError_t launch_rdoq(hipStream_t st, int bitDepth, int log2, int16_t *dst, const int16_t *src, const uint8_t *states, const void *jobs, int njobs, int32_t *cbf,
-                       void *workspace)
+// the passes after the scan: order, then the walk(s)
+static hipError_t rdoq_order_and_walk(hipStream_t st, int bitDepth, int log2, int16_t *dst, const int16_t *src, const uint8_t *states, const RdoqJob *j, int njobs,
+                                      int32_t *cbf, RdoqWork *work)
 {
-    if (njobs <= 0) return hipSuccess;
-    const RdoqJob *j = static_cast<const RdoqJob *>(jobs);
-    RdoqWork *work = static_cast<RdoqWork *>(workspace);
     const int wgs = (njobs + 63) / 64;
-    if (log2 <= 3)
-    {
-        if (log2 == 2) hipLaunchKernelGGL((k_rdoq_walk<2, false>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work, 0);
-        else hipLaunchKernelGGL((k_rdoq_walk<3, false>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work, 0);
-        return hipGetLastError();
-    }
-    hipError_t e = hipMemsetAsync(work, 0, sizeof(RdoqWork), st);
-    if (e != hipSuccess) return e;
-    if (log2 == 4) hipLaunchKernelGGL(k_rdoq_scan<4>, dim3((njobs + 4 * kScanSteps - 1) / (4 * kScanSteps)), dim3(64), 0, st, dst, src, j, njobs, work);
-    else hipLaunchKernelGGL(k_rdoq_scan<5>, dim3((njobs + kScanSteps - 1) / kScanSteps), dim3(64), 0, st, dst, src, j, njobs, work);
     hipLaunchKernelGGL(k_rdoq_order, dim3((njobs + 255) / 256), dim3(256), 0, st, njobs, work);
     // diagnostic A/B switch (profiles/): HAVOC_RDOQ_DIAG=0 walks every block with the sequential kernel
     // 32x32 blocks take the diagonal walk while its wavefronts (16 blocks each) still find a SIMD of their own: it shortens the chain, not the
     // work -- most of its lanes idle -- so a 4K picture's 41 k blocks are better off 64 to a wavefront in the sequential walk (measured: 4K
-    // step 2.43 -> 2.63 ms with the diagonal walk forced).  16x16 blocks (39 k of them in a 1080p picture, 3 groups to walk on average, 7 at
-    // most) have no chain worth shortening.  Diagnostic A/B switch (profiles/): HAVOC_RDOQ_DIAG = lanes per block, 0 (off), 4 or 8
+    // step 2.43 -> 2.63 ms with the diagonal walk forced).  Diagnostic A/B switch (profiles/): HAVOC_RDOQ_DIAG = lanes per block, 0 (off), 4 or 8
     static const int diagEnv = getenv("HAVOC_RDOQ_DIAG") ? atoi(getenv("HAVOC_RDOQ_DIAG")) : 4;
     // 16x16 blocks (round 3): the anti-diagonal walk is instantiated for them too (HAVOC_RDOQ_DIAG16 = 4 or 8 lanes per
     // block; parity: tests/test_rdoq.py) and MEASURED SLOWER than a lane per block -- 1080p QP32, 39 k blocks: 0.098 ms sequential, 0.157 ms
@@ -1162,6 +1152,41 @@ hipError_t launch_rdoq(hipStream_t st, int bitDepth, int log2, int16_t *dst, con
     if (log2 == 4) hipLaunchKernelGGL((k_rdoq_walk<4, true>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work, diag);
     else hipLaunchKernelGGL((k_rdoq_walk<5, true>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work, diag);
     return hipGetLastError();
+}
+
+hipError_t launch_rdoq(hipStream_t st, int bitDepth, int log2, int16_t *dst, const int16_t *src, const uint8_t *states, const void *jobs, int njobs, int32_t *cbf,
+                       void *workspace)
+{
+    if (njobs <= 0) return hipSuccess;
+    const RdoqJob *j = static_cast<const RdoqJob *>(jobs);
+    RdoqWork *work = static_cast<RdoqWork *>(workspace);
+    const int wgs = (njobs + 63) / 64;
+    if (log2 <= 3)
+    {
+        if (log2 == 2) hipLaunchKernelGGL((k_rdoq_walk<2, false>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work, 0);
+        else hipLaunchKernelGGL((k_rdoq_walk<3, false>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work, 0);
+        return hipGetLastError();
+    }
+    hipError_t e = hipMemsetAsync(work, 0, sizeof(RdoqWork), st);
+    if (e != hipSuccess) return e;
+    if (log2 == 4) hipLaunchKernelGGL(k_rdoq_scan<4>, dim3((njobs + 4 * kScanSteps - 1) / (4 * kScanSteps)), dim3(64), 0, st, dst, src, j, njobs, work);
+    else hipLaunchKernelGGL(k_rdoq_scan<5>, dim3((njobs + kScanSteps - 1) / kScanSteps), dim3(64), 0, st, dst, src, j, njobs, work);
+    return rdoq_order_and_walk(st, bitDepth, log2, dst, src, states, j, njobs, cbf, work);
+}
+
+// Rdoq::runQuantisation for 16x16 / 32x32 blocks whose scan was done by havoc_mi355x_tu_forward_scan (RdoqInfo per block in the workspace, level
+// blocks zeroed): histogram from the 32-byte records, order, walk
+hipError_t launch_rdoq_prescanned(hipStream_t st, int bitDepth, int log2, int16_t *dst, const int16_t *src, const uint8_t *states, const void *jobs, int njobs,
+                                  int32_t *cbf, void *workspace)
+{
+    if (njobs <= 0) return hipSuccess;
+    if (log2 != 4 && log2 != 5) return hipErrorInvalidValue;
+    const RdoqJob *j = static_cast<const RdoqJob *>(jobs);
+    RdoqWork *work = static_cast<RdoqWork *>(workspace);
+    hipError_t e = hipMemsetAsync(work, 0, sizeof(RdoqWork), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_rdoq_hist, dim3((njobs + 255) / 256), dim3(256), 0, st, j, njobs, work);
+    return rdoq_order_and_walk(st, bitDepth, log2, dst, src, states, j, njobs, cbf, work);
 }
 
 } // namespace havoc_gpu

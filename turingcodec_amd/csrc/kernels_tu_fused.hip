@@ -12,6 +12,7 @@
 // kernels (tests: tu_fused groups).
 #include "common.h"
 #include "transform_basis.h"
+#include "rdoq_work.h"
 
 namespace havoc_gpu {
 
@@ -64,10 +65,15 @@ __device__ __forceinline__ void load_sample_row(const char *p, uint32_t (&row)[N
 }
 
 // job: havoc_mi355x_tu_fused_job { coef_off, src_off, pred_off, rec_off }
-template <int S, int LOG2, int TR>
+// SCAN (16x16 / 32x32 DCT): the first pass of Rdoq::runQuantisation's device form is done HERE, where the coefficients are in registers --
+// which 4x4 groups hold a rounded level > 0 / > 1 / > 2 and the block's energy go to the RDOQ workspace (RdoqInfo of block `job`), and the
+// level block RDOQ will write is zeroed -- instead of a separate kernel reading the coefficients back (k_rdoq_scan: 2 x 47 MB and 47 us
+// per 1080p picture).  rjobs[job] = the havoc_mi355x_rdoq_job of the same block.
+template <int S, int LOG2, int TR, bool SCAN = false>
 __global__ __launch_bounds__(64) void k_tu_forward(int16_t *__restrict__ coeffs, const char *__restrict__ src, long stride_src,
                                                    const char *__restrict__ pred, long stride_pred, const int32_t *__restrict__ jobs, int njobs,
-                                                   int bitDepth)
+                                                   int bitDepth, const RdoqJob *__restrict__ rjobs = nullptr, int16_t *__restrict__ levels = nullptr,
+                                                   RdoqWork *__restrict__ work = nullptr)
 {
     constexpr int N = 1 << LOG2, TPW = 64 / N, LS = N + 2;
     __shared__ int16_t lds[TPW][N * LS];
@@ -90,6 +96,61 @@ __global__ __launch_bounds__(64) void k_tu_forward(int16_t *__restrict__ coeffs,
 #pragma unroll
     for (int p = 0; p < N / 2; ++p) row[p] = *reinterpret_cast<const uint32_t *>(&lds[t][r * LS + 2 * p]);
     basis_times_row<N, TR, false>(row, 1 << (shift2 - 1), o);
+    if (SCAN)
+    {
+        // lane r holds column r of the block: o[k] >> shift2 = coefficient (row k, column r).  Group (gx = r / 4, gy): the largest magnitude of
+        // its 16 coefficients = max over this lane's rows 4 gy .. 4 gy + 3, then over the four lanes of the quad
+        constexpr int GW = N / 4;
+        const RdoqJob rj = rjobs[live ? job : 0];
+        uint32_t thr[3];
+        rdoqThresholds(rj.quant_scale, rj.quant_shift, thr);
+        uint32_t lo = 0, hi = 0;
+        uint64_t mask[3] = {0, 0, 0};
+#pragma unroll
+        for (int gy = 0; gy < GW; ++gy)
+        {
+            uint32_t big = 0;
+#pragma unroll
+            for (int k = 4 * gy; k < 4 * gy + 4; ++k)
+            {
+                const int c = (int16_t)(o[k] >> shift2);
+                big = max(big, (uint32_t)abs(c));        // -32768 -> 32768
+                const uint32_t sq = (uint32_t)(c * c);    // <= 2^30
+                lo += sq & 0xffffu;
+                hi += sq >> 16;
+            }
+            big = max(big, (uint32_t)__shfl_xor((int)big, 1, kWave));
+            big = max(big, (uint32_t)__shfl_xor((int)big, 2, kWave));
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+            {
+                // one bit per quad (its first lane), the block's N lanes are a field of the ballot: compress bits 4 gx -> gx
+                const uint64_t b = __ballot(live && (r & 3) == 0 && big >= thr[m]) >> (t * N);
+                uint32_t f = 0;
+#pragma unroll
+                for (int gx = 0; gx < GW; ++gx) f |= (uint32_t)((b >> (4 * gx)) & 1) << gx;
+                mask[m] |= (uint64_t)f << (gy * GW);
+            }
+        }
+        const int slo = group_sum<N>((int)lo), shi = group_sum<N>((int)hi);
+        if (live)
+        {
+            // the level block, zeroed row by row (RDOQ writes only the levels it keeps)
+            int16_t *z = levels + rj.dst_off + r * N;      // offsets are multiples of 4 levels: 8-byte stores
+#pragma unroll
+            for (int q = 0; q < N / 4; ++q) st8(z + 4 * q, u32x2{0, 0});
+            if (r == 0)
+            {
+                RdoqInfo *info = reinterpret_cast<RdoqInfo *>(reinterpret_cast<char *>(work) + rdoqInfoOffset());
+                RdoqInfo v;
+                v.mask = mask[0];
+                v.mask2 = mask[1];
+                v.mask3 = mask[2];
+                v.sumSq = ((int64_t)shi << 16) + slo;
+                info[job] = v;
+            }
+        }
+    }
     if (!live) return;
     int16_t *c = coeffs + j[0] + r;
 #pragma unroll
@@ -191,6 +252,25 @@ static hipError_t launch_fwd_s(hipStream_t st, int bd, int log2, int tr, int16_t
         case 5: go_fwd<S, 5, 0>(st, co, src, ss, pred, sp, j, n, bd); break;
         default: return hipErrorInvalidValue;
         }
+    return hipGetLastError();
+}
+
+// tu_forward with the RDOQ scan folded in (16x16 / 32x32 DCT blocks)
+hipError_t launch_tu_forward_scan(hipStream_t st, int S, int bd, int log2, int16_t *coeffs, const void *src, long ss, const void *pred, long sp, const void *jobs,
+                                  int n, const void *rdoq_jobs, int16_t *levels, void *workspace)
+{
+    if (n <= 0) return hipSuccess;
+    if (log2 != 4 && log2 != 5) return hipErrorInvalidValue;
+    const char *s8 = (const char *)src, *p8 = (const char *)pred;
+    const int32_t *j = (const int32_t *)jobs;
+    const RdoqJob *rj = (const RdoqJob *)rdoq_jobs;
+    RdoqWork *w = (RdoqWork *)workspace;
+    const int tpw = 64 >> log2;
+    const dim3 g((n + tpw - 1) / tpw), b(64);
+    if (S == 1 && log2 == 4) hipLaunchKernelGGL((k_tu_forward<1, 4, 0, true>), g, b, 0, st, coeffs, s8, ss, p8, sp, j, n, bd, rj, levels, w);
+    else if (S == 1) hipLaunchKernelGGL((k_tu_forward<1, 5, 0, true>), g, b, 0, st, coeffs, s8, ss, p8, sp, j, n, bd, rj, levels, w);
+    else if (log2 == 4) hipLaunchKernelGGL((k_tu_forward<2, 4, 0, true>), g, b, 0, st, coeffs, s8, ss, p8, sp, j, n, bd, rj, levels, w);
+    else hipLaunchKernelGGL((k_tu_forward<2, 5, 0, true>), g, b, 0, st, coeffs, s8, ss, p8, sp, j, n, bd, rj, levels, w);
     return hipGetLastError();
 }
 

@@ -97,6 +97,8 @@ def _load():
         "quantize_inverse": [_vp, _vp, _vp, _vp, _i],
         "quantize_reconstruct": [_vp, _i, _vp, _ip, _vp, _ip, _vp, _vp, _i],
         "rdoq": [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, C.c_size_t],
+        "tu_forward_scan": [_vp, _i, _i, _i, _vp, _vp, _ip, _vp, _ip, _vp, _i, _vp, _vp, _vp, C.c_size_t],
+        "rdoq_prescanned": [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, C.c_size_t],
         "sao_stats": [_vp, _i, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
         "sao_filter": [_vp, _i, _i, _vp, _ip, _vp, _ip, _vp, _i],
         "sao_band_chroma": [_vp, _i, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
@@ -478,6 +480,15 @@ class Havoc:
         """jobs: uint8 tensor holding RDOQ_JOB_DT records; states: uint8 tensor of 128-byte snapshots; work: rdoq_workspace(njobs)"""
         self._ck(self.L.havoc_mi355x_rdoq(self.h, bd, log2, _ptr(dst), _ptr(src), _ptr(states), _ptr(jobs), jobs.numel() // RDOQ_JOB_DT.itemsize, _ptr(cbf),
                                           _ptr(work), work.numel() * 8))
+
+    def tu_forward_scan_d(self, bd, log2, coeffs, src, ss, pred, sp, jobs, rdoq_jobs, levels, work):
+        """tu_forward with the RDOQ scan folded in (16x16 / 32x32): coefficients + RdoqInfo per block in `work`, level blocks zeroed"""
+        self._ck(self.L.havoc_mi355x_tu_forward_scan(self.h, self._S(src), bd, log2, _ptr(coeffs), _ptr(src), ss, _ptr(pred), sp, _ptr(jobs), jobs.shape[0],
+                                                     _ptr(rdoq_jobs), _ptr(levels), _ptr(work), work.numel() * 8))
+
+    def rdoq_prescanned_d(self, bd, log2, dst, src, states, jobs, cbf, work):
+        self._ck(self.L.havoc_mi355x_rdoq_prescanned(self.h, bd, log2, _ptr(dst), _ptr(src), _ptr(states), _ptr(jobs), jobs.numel() // RDOQ_JOB_DT.itemsize,
+                                                     _ptr(cbf), _ptr(work), work.numel() * 8))
 
     def rdoq(self, bd, log2, src, states, jobs):
         """numpy level: src int16 (all blocks), states uint8 [k, 128], jobs RDOQ_JOB_DT array -> (levels int16 like src, cbf int32[njobs])"""
