@@ -107,6 +107,7 @@ class DeviceFrame:
         self.rdoq = bool(rdoq) and wl.mix == "ra"
         self.skip = set(skip)   # diagnostic only: launch groups left out of the step (marginal-cost measurements)
         self.hv, self.wl, self.use_planes, self.fused_tu, self.ime_range = hv, wl, use_planes, fused_tu, ime_range
+        self.pred_launches, self.scan_in_forward = pred_launches, scan_in_forward
         up = hv.up
         dt = wl.dtype
         S = wl.S
@@ -244,7 +245,7 @@ class DeviceFrame:
             return [(name, lambda j=hv.up(np.ascontiguousarray(jobs_np[idx])), mw=mw, mh=mh: fn(j, mw, mh))
                     for idx, mw, mh in hv.size_classes(jobs_np[:, wcol], jobs_np[:, wcol + 1])]
 
-        if inter and pred_launches == "merged":
+        if inter and self.pred_launches == "merged":
             # all four size classes of a table in ONE launch (havoc_mi355x_pred_*_classes): 4 prediction launches per picture instead of 16
             def merged(name, jobs, wcol, bi, taps, dst, sd, ref, sr):
                 srt, counts, _ = hv.sort_by_class(np.asarray(jobs), np.asarray(jobs)[:, wcol], np.asarray(jobs)[:, wcol + 1])
@@ -279,7 +280,7 @@ class DeviceFrame:
                     bd, tr, log2, g["dscale"], g["dshift"], g["rec"], n, self.luma, st, self.luma, st, g["level"], g["fjobs"], g["ossd"]))]
                 if g["jssd_x"] is not None:   # the reference makes ~1.26 SSD calls per TU: the rest as plain SSD jobs
                     items.append(("ssd", lambda g=g, n=n: hv.ssd_d(self.luma, st, g["rec"], n, g["jssd_x"], g["ossd_x"])))
-                if self.rdoq and scan_in_forward and log2 >= 4 and tr == 0:
+                if self.rdoq and self.scan_in_forward and log2 >= 4 and tr == 0:
                     # 16x16 / 32x32: the scan pass of the device RDOQ runs inside tu_forward (the coefficients are in registers there)
                     chain(("tu_forward", lambda g=g, log2=log2: hv.tu_forward_scan_d(bd, log2, g["coef"], self.luma, st, self.luma, st, g["fjobs"], g["rjobs"],
                                                                                       g["level"], g["rwork"])),
