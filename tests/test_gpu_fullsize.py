@@ -276,7 +276,7 @@ def test_merged_prediction_launches_equal_the_per_class_launches(hv):
     a.step()
     b.step()
     hv.sync()
-    assert len(a.launches) == len(b.launches) - 12
+    assert sum(name.startswith("pred_") for name, _ in a.launches) == 4 < sum(name.startswith("pred_") for name, _ in b.launches)
     for name in ("pred", "cpred", "bi", "cbi", "sbi"):
         assert np.array_equal(hv.down(getattr(a, name), wl.dtype), hv.down(getattr(b, name), wl.dtype)), name
     assert a.checksum() == b.checksum()
