@@ -64,7 +64,7 @@ def test_argument_errors_return_nonzero_with_message(hv, data):
         L.havoc_mi355x_pred_uni(h, 1, 6, 8, 64, 64, p(a), 64, p(a), W, p(jobs), 1),           # taps
         L.havoc_mi355x_pred_uni(h, 1, 8, 13, 64, 64, p(a), 64, p(a), W, p(jobs), 1),          # bit depth
         L.havoc_mi355x_satd(h, 1, 65, 64, p(a), W, p(a), W, p(jobs), 1, p(out)),              # max_w
-        L.havoc_mi355x_sad_surface(h, 1, 65, 64, 64, p(a), W, p(a), W, p(jobs), 1, p(out)),   # range
+        L.havoc_mi355x_sad_surface(h, 1, 97, 64, 64, p(a), W, p(a), W, p(jobs), 1, p(out)),   # range
         L.havoc_mi355x_intra(h, 1, 8, 6, p(a), 8, p(a), p(jobs), 1),                          # log2TrafoSize
         L.havoc_mi355x_transform(h, 8, 1, 3, p(a), p(a), 8, p(jobs), 1),                      # DST exists for 4x4 only
         L.havoc_mi355x_sad(None, 1, p(a), W, p(a), W, p(jobs), 1, p(out)),                    # no context
