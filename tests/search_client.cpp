@@ -414,6 +414,126 @@ struct PerCallTuView
     }
 };
 
+// ---- the RD refinement of intra partitions (tu_decision.hpp: decideIntraRd) one candidate at a time through this back end's intra table, TU
+// tables and Rdoq: the expected values of havoc_search_intra_rd.  jobs = havoc_mi355x_intra_search_job rows (8 int32); src / nb flat planes.
+template <typename Sample>
+struct PerCallIntraView
+{
+    int bitDepth, log2, sdh, ctxIndex;
+    const Sample *src;      // the partition's source block
+    intptr_t ss;
+    const Sample *nbU, *nbF;
+    uint64_t filt;
+    int edge;
+    const uint8_t *states;
+    const havoc_rqt_quant *quant;
+    double lambda;
+    Sample rec[36][32 * 32];      // per candidate index
+
+    havoc_tu_outcome evaluate(int mode, int index)
+    {
+        const int n = 1 << log2, tr = log2 == 2 ? 1 : 0;
+        HAVOC_ALIGN(32, Sample, pred[32 * 32]);
+        HAVOC_ALIGN(32, int16_t, res[32 * 32]);
+        HAVOC_ALIGN(32, int16_t, coef[32 * 32]);
+        HAVOC_ALIGN(32, int16_t, level[32 * 32]);
+        HAVOC_ALIGN(32, int16_t, deq[32 * 32]);
+        const Sample *nb = ((filt >> mode) & 1) ? nbF : nbU;
+        const int scan = intraScanIdx(log2, mode);
+        havoc_tu_outcome o;
+        Sample *out = rec[index];
+#ifndef SEARCH_ORACLE
+        intraTable<Sample>().lookup(edge ? 0 : 1, bitDepth, log2, mode)(pred, n, nb, mode);
+#else
+        oracle_intra(pred, n, nb, log2, mode, (edge && log2 < 5) ? 1 : 0, bitDepth, sizeof(Sample));
+#endif
+        for (int y = 0; y < n; ++y)
+            for (int x = 0; x < n; ++x) res[y * n + x] = int16_t(src[y * ss + x] - pred[y * n + x]);      // Reconstruct.cpp:258-260
+#ifndef SEARCH_ORACLE
+        havoc::Transform *fwd = sizeof(Sample) == 1 ? *havoc::get_transform<8>(&g_tu.t8, tr, log2) : *havoc::get_transform<10>(&g_tu.t10, tr, log2);
+        fwd(coef, res, n);
+        o.cbf = ref_rdoq(level, coef, log2, 0, scan, 1, sdh, quant->quant_scale, quant->quant_shift, quant->inv_scale, bitDepth, lambda, states + 128 * ctxIndex);
+        (*havoc_get_quantize_inverse(&g_tu.qi, quant->inv_scale, quant->inv_shift))(deq, level, quant->inv_scale, quant->inv_shift, n * n);
+        itAdd(out, n, pred, n, deq, tr);
+        o.ssd = uint32_t(ssdOf(src, ss, out, n));
+#else
+        oracle_transform(coef, res, n, log2, tr, bitDepth);
+        int32_t lq, sf;
+        oracle_rdoq_lambda(lambda, quant->inv_scale, &lq, &sf);
+        o.cbf = oracle_rdoq(level, coef, log2, 0, scan, 1, sdh, quant->quant_scale, quant->quant_shift, quant->inv_scale, bitDepth, lq, sf, states + 128 * ctxIndex);
+        oracle_quantize_inverse(deq, level, quant->inv_scale, quant->inv_shift, n * n);
+        oracle_inverse_transform_add(out, n, pred, n, deq, log2, tr, bitDepth, sizeof(Sample));
+        o.ssd = oracle_ssd(src, ss, out, n, n, n, sizeof(Sample));
+#endif
+        o.nonzero = o.sum_abs = 0;
+        for (int i = 0; i < n * n; ++i)
+        {
+            o.nonzero += level[i] != 0;
+            o.sum_abs += level[i] < 0 ? -level[i] : level[i];
+        }
+        return o;
+    }
+#ifndef SEARCH_ORACLE
+    void itAdd(uint8_t *dst, intptr_t sd, const uint8_t *p, intptr_t sp, const int16_t *c, int tr) { (*havoc::get_inverse_transform_add<uint8_t>(&g_tu.ita8, tr, log2))(dst, sd, p, sp, c, bitDepth); }
+    void itAdd(uint16_t *dst, intptr_t sd, const uint16_t *p, intptr_t sp, const int16_t *c, int tr) { (*havoc::get_inverse_transform_add<uint16_t>(&g_tu.ita16, tr, log2))(dst, sd, p, sp, c, bitDepth); }
+    int ssdOf(const uint8_t *a, intptr_t sa, const uint8_t *b, intptr_t sb) { return (*havoc_get_ssd<uint8_t>(&g_tu.ssd8, log2))(a, sa, b, sb, 1 << log2, 1 << log2); }
+    int ssdOf(const uint16_t *a, intptr_t sa, const uint16_t *b, intptr_t sb) { return (*havoc_get_ssd<uint16_t>(&g_tu.ssd16, log2))(a, sa, b, sb, 1 << log2, 1 << log2); }
+#endif
+};
+
+static void readyTuTables()
+{
+#ifndef SEARCH_ORACLE
+    if (!g_tu.ready)
+    {
+        havoc::populate_transform<8>(&g_tu.t8, g_code);
+        havoc::populate_transform<10>(&g_tu.t10, g_code);
+        havoc::populate_inverse_transform_add<uint8_t>(&g_tu.ita8, g_code, 1);
+        havoc::populate_inverse_transform_add<uint16_t>(&g_tu.ita16, g_code, 1);
+        havoc_populate_quantize_inverse(&g_tu.qi, g_code);
+        havoc_populate_ssd<uint8_t>(&g_tu.ssd8, g_code);
+        havoc_populate_ssd<uint16_t>(&g_tu.ssd16, g_code);
+        g_tu.ready = true;
+    }
+    if (!g_intraReady)
+    {
+        g_i8.populate(g_code);
+        g_i16.populate(g_code);
+        g_intraReady = true;
+    }
+#endif
+}
+
+extern "C" int client_intra_rd(int S, int bitDepth, int log2, const void *src, intptr_t ss, const void *nb, const int32_t *jobs, int n,
+                               const havoc_search_intra_result *order, const havoc_search_intra_ctx *ictx, const int32_t *ctx_index, const uint8_t *states,
+                               const havoc_rqt_quant *quant, double lambda, double reciprocal_lambda, int sdh, void *rec, havoc_intra_rd_result *out)
+{
+    if (!g_open) return -1;
+    readyTuTables();
+    Lambda rl;
+    rl.set(reciprocal_lambda);
+    auto run = [&](auto tag) {
+        typedef decltype(tag) Sample;
+        static PerCallIntraView<Sample> view;
+        const int area = 1 << 2 * log2;
+        for (int i = 0; i < n; ++i)
+        {
+            const int32_t *j = jobs + 8 * i;
+            view.bitDepth = bitDepth; view.log2 = log2; view.sdh = sdh; view.ctxIndex = ctx_index[i];
+            view.src = (const Sample *)src + j[0]; view.ss = ss;
+            view.nbU = (const Sample *)nb + j[1]; view.nbF = (const Sample *)nb + j[2];
+            view.filt = (uint64_t)(uint32_t)j[3] | ((uint64_t)(uint32_t)j[4] << 32);
+            view.edge = j[5];
+            view.states = states; view.quant = quant; view.lambda = lambda;
+            out[i] = decideIntraRd(view, order[i], ictx[i], rl);
+            std::memcpy((Sample *)rec + size_t(i) * area, view.rec[out[i].index < 0 ? 0 : out[i].index], area * sizeof(Sample));
+        }
+    };
+    if (S == 1) run(uint8_t(0));
+    else run(uint16_t(0));
+    return 0;
+}
+
 extern "C" int client_rqt(int S, int bitDepth, const void *src, intptr_t ss, const void *pred, intptr_t ps, void *rec, intptr_t rs, const uint8_t *states,
                const havoc_rqt_quant *quant, double lambda, double reciprocal_lambda, int sdh, const havoc_rqt_cu *cus, int n, havoc_rqt_result *out)
 {

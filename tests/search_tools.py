@@ -95,6 +95,7 @@ class Client:
         L.client_picture_uni.argtypes = [i, vp, ip, vp, vp, ip, C.POINTER(Params), vp, vp, i, i, vp, vp, vp]
         if kind != "classic":
             L.client_rqt.argtypes = [i, i, vp, ip, vp, ip, vp, ip, vp, vp, C.c_double, C.c_double, i, vp, i, vp]
+            L.client_intra_rd.argtypes = [i, i, i, vp, ip, vp, vp, i, vp, vp, vp, vp, vp, C.c_double, C.c_double, i, vp, vp]
         if kind == "classic":
             L.client_register.argtypes = [vp, ip, i, i, i, i, i, i]
             L.client_unregister.argtypes = [vp]
@@ -138,6 +139,23 @@ class Client:
         cus = np.ascontiguousarray(cus)
         rc = self.L.client_rqt(src.itemsize, bit_depth, self._origin(src, stride, pad), stride, pred.ctypes.data, pred_stride, self._origin(rec, stride, pad), stride,
                                states.ctypes.data, quant.ctypes.data, float(lam), float(reciprocal_lambda), int(sdh), cus.ctypes.data, len(cus), out.ctypes.data)
+        assert rc == 0
+        return out, rec
+
+    def intra_rd(self, bit_depth, log2, src, stride, nb, jobs, order, ictx, ctx_index, states, quant_row, lam, reciprocal_lambda, sdh=1):
+        """the RD refinement of intra partitions one candidate at a time (tu_decision.hpp: decideIntraRd): (INTRA_RD_RESULT_DT[n], reconstructions [n, N*N])"""
+        from turingcodec_amd.decisions import INTRA_RD_RESULT_DT
+        jobs = np.ascontiguousarray(jobs, np.int32)
+        n, area = len(jobs), 1 << 2 * log2
+        out = np.zeros(n, INTRA_RD_RESULT_DT)
+        rec = np.zeros((n, area), src.dtype)
+        order, ictx = np.ascontiguousarray(order), np.ascontiguousarray(ictx)
+        ctx_index = np.ascontiguousarray(ctx_index, np.int32)
+        states = np.ascontiguousarray(states, np.uint8)
+        quant_row = np.ascontiguousarray(quant_row, np.int32)
+        rc = self.L.client_intra_rd(src.itemsize, bit_depth, log2, src.ctypes.data, stride, nb.ctypes.data, jobs.ctypes.data, n, order.ctypes.data, ictx.ctypes.data,
+                                    ctx_index.ctypes.data, states.ctypes.data, quant_row.ctypes.data, float(lam), float(reciprocal_lambda), int(sdh),
+                                    rec.ctypes.data, out.ctypes.data)
         assert rc == 0
         return out, rec
 

@@ -263,3 +263,39 @@ def test_rqt_client_on_the_gpu_equals_the_reference_loop(res, bit_depth, qp):
     out = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out) and res == "1920x1080" and qp == 32:
         json.dump(r, open(os.path.join(out, "rqt_report_1080p.json"), "w"), indent=1)
+
+
+# ---- the RD refinement of intra partitions as a batch client (tu_decision.hpp: decideIntraRd, tu_search.cpp: havoc_search_intra_rd) --------------
+def _run_intra_rd(device, *args, timeout=1800):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "intra_rd_runner.py"), "--device", device] + list(args), capture_output=True, text=True,
+                         timeout=timeout, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def _check_intra_rd(r):
+    """the champion mode, its place in the order, its cost (Q16) and transform-block outcome for every partition, and the champions'
+    reconstructions, identical to the candidate-at-a-time loop over the reference's intra table, transform tables and Rdoq.cpp (intra
+    flag, 4x4 DST, mode-dependent scans); one chain of 6 launches per partition size whatever the number of partitions"""
+    assert r["mismatches"] == 0 and "Rdoq.cpp" in r["expected_from"], r
+    assert set(r["sizes"]) == {"4", "8", "16", "32"}
+    for s in r["sizes"].values():
+        assert s["mismatching"] == 0 and s["reconstructions_equal"] and s["launches"] == 6 and s["candidates"] > 3 * s["partitions"], s
+    assert any(s["champion_is_first_candidate"] < 1.0 for s in r["sizes"].values())      # the refinement changes decisions
+
+
+@needs_ref
+@pytest.mark.parametrize("bit_depth,qp", [(8, 32), (10, 27)])
+def test_intra_rd_client_host_logic_on_the_mock_device(bit_depth, qp):
+    _check_intra_rd(_run_intra_rd("mock", "--res", "416x240", "--limit", "48", "--bit-depth", str(bit_depth), "--qp", str(qp)))
+
+
+@needs_ref
+@pytest.mark.gpu
+@pytest.mark.parametrize("res,bit_depth,qp,limit", [("416x240", 8, 32, 0), ("640x360", 10, 27, 0), ("1920x1080", 8, 32, 3000)])
+def test_intra_rd_client_on_the_gpu_equals_the_reference_loop(res, bit_depth, qp, limit):
+    r = _run_intra_rd("real", "--res", res, "--bit-depth", str(bit_depth), "--qp", str(qp), "--limit", str(limit))
+    _check_intra_rd(r)
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out) and res == "1920x1080":
+        json.dump(r, open(os.path.join(out, "intra_rd_report_1080p.json"), "w"), indent=1)

@@ -43,6 +43,13 @@ RQT_RESULT_DT = np.dtype([("depth", "i4"), ("tried_zero", "i4"), ("zero", TU_OUT
 assert RQT_CU_DT.itemsize == 16 and RQT_RESULT_DT.itemsize == 104
 
 
+INTRA_CTX_DT = np.dtype([("cand_mode_list", "i4", (3,)), ("neighbour_modes", "i4"), ("max_refine", "i4"), ("reserved", "i4"), ("rate_a_minus_c", "i8"),
+                         ("rate_b_minus_c", "i8")])                                                               # havoc_search_intra_ctx
+INTRA_RESULT_DT = np.dtype([("costs", "i8", (35,)), ("order", "i4", (35,)), ("count", "i4")])                       # havoc_search_intra_result
+INTRA_RD_RESULT_DT = np.dtype([("mode", "i4"), ("index", "i4"), ("evaluated", "i4"), ("reserved", "i4"), ("cost", "i8"), ("outcome", TU_OUTCOME_DT)])
+assert INTRA_CTX_DT.itemsize == 40 and INTRA_RESULT_DT.itemsize == 424 and INTRA_RD_RESULT_DT.itemsize == 40
+
+
 class RqtStats(C.Structure):
     _fields_ = [("launches", C.c_int32), ("candidates", C.c_int32), ("seconds_gpu", C.c_double), ("seconds_host", C.c_double), ("seconds_total", C.c_double)]
 
@@ -82,6 +89,9 @@ def lib():
         L.havoc_search_rqt.argtypes = [vp, C.c_int, C.c_int, vp, i64, ip, vp, ip, vp, i64, ip, vp, vp, C.c_double, C.c_double, C.c_int, vp, C.c_int, vp,
                                        C.POINTER(RqtStats)]
         L.havoc_search_rqt.restype = C.c_int
+        L.havoc_search_intra_rd.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, ip, vp, vp, C.c_int, vp, vp, vp, vp, vp, C.c_double, C.c_double, C.c_int, vp, vp,
+                                            C.POINTER(RqtStats)]
+        L.havoc_search_intra_rd.restype = C.c_int
         L.havoc_search_block_cells.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp]
         L.havoc_search_block_cells.restype = C.c_int
         L.havoc_search_release.argtypes = [vp]
@@ -138,6 +148,24 @@ def rqt(ctx, S, bit_depth, d_src, src_origin, src_stride, d_pred, pred_stride, d
                                 quant.ctypes.data, float(lam), float(reciprocal_lambda), int(sdh), cus.ctypes.data, len(cus), out.ctypes.data, C.byref(stats))
     if rc != 0:
         raise RuntimeError(f"havoc_search_rqt failed ({rc})")
+    return out, stats
+
+
+def intra_rd(ctx, S, bit_depth, log2, d_src, src_stride, d_neighbours, jobs, order, ictx, ctx_index, d_states, quant_row, lam, reciprocal_lambda, d_rec, sdh=1):
+    """havoc_search_intra_rd: the RD refinement of n intra partitions of one size (jobs: int32 [n, 8] havoc_mi355x_intra_search_job rows on the
+    HOST; order: INTRA_RESULT_DT from the 35-mode stage; quant_row: int32[4] of rqt_quant for this size).  Returns (INTRA_RD_RESULT_DT[n], stats)"""
+    jobs = np.ascontiguousarray(jobs, np.int32)
+    order = np.ascontiguousarray(order)
+    ictx = np.ascontiguousarray(ictx)
+    ctx_index = np.ascontiguousarray(ctx_index, np.int32)
+    quant_row = np.ascontiguousarray(quant_row, np.int32)
+    out = np.zeros(len(jobs), INTRA_RD_RESULT_DT)
+    stats = RqtStats()
+    rc = lib().havoc_search_intra_rd(ctx, S, bit_depth, log2, d_src, src_stride, d_neighbours, jobs.ctypes.data, len(jobs), order.ctypes.data, ictx.ctypes.data,
+                                     ctx_index.ctypes.data, d_states, quant_row.ctypes.data, float(lam), float(reciprocal_lambda), int(sdh), d_rec, out.ctypes.data,
+                                     C.byref(stats))
+    if rc != 0:
+        raise RuntimeError(f"havoc_search_intra_rd failed ({rc})")
     return out, stats
 
 

@@ -87,6 +87,17 @@ typedef struct
     int64_t cost_zero, cost_one;   /* Q16: rate + ssd * reciprocal lambda */
 } havoc_rqt_result;                /* 104 bytes */
 
+/* the RD refinement of an intra partition (tu_decision.hpp: decideIntraRd; turing/Search.hpp:143-255): which of the candidate modes won */
+typedef struct
+{
+    int32_t mode;                  /* IntraPredModeY of the champion */
+    int32_t index;                 /* its place in the refinement order */
+    int32_t evaluated;             /* candidates reconstructed */
+    int32_t reserved;
+    int64_t cost;                  /* Q16: mode rate + residual rate + ssd * reciprocal lambda */
+    havoc_tu_outcome outcome;      /* of the champion's transform block */
+} havoc_intra_rd_result;           /* 40 bytes */
+
 /* quantiser parameters of one transform size (turing/QpState.h:85-94) */
 typedef struct
 {

@@ -52,4 +52,43 @@ havoc_rqt_result decideRqt(View &view, const havoc_rqt_cu &cu, Lambda reciprocal
     return r;
 }
 
+// ---- intra: the RD refinement of a partition's candidate modes (searchIntraPartition's second stage, turing/Search.hpp:143-255) ----
+// The first stage (35 predictions + SATD, decision.hpp: intraModeOrder) leaves the modes in the order they are to be refined; each is then
+// RECONSTRUCTED -- predict, residual, DST (4x4 luma) / DCT, Rdoq::runQuantisation with the mode's scan (Global.h:1212-1227), de-quantise,
+// inverse transform + add, SSD (reconstructIntraLuma -> Reconstruct.cpp:230-353) -- and the champion is the first candidate with the smallest
+// rate + ssd * reciprocalLambda (`challenger->cost2() < champion->cost2()`, strict; the reference adds a challenger's mode rate only when it is
+// already ahead on distortion, which cannot change who wins).  Rates: the mode's (relative to a non-MPM mode, as the first stage has them)
+// and the stand-in `tuRate` for the residual.
+// View: havoc_tu_outcome evaluate(int mode, int index).
+inline int intraScanIdx(int log2TrafoSize, int mode)      // Global.h:1212-1227, luma
+{
+    if (log2TrafoSize != 2 && log2TrafoSize != 3) return 0;
+    return (mode >= 6 && mode <= 14) ? 2 : ((mode >= 22 && mode <= 30) ? 1 : 0);
+}
+
+template <class View>
+havoc_intra_rd_result decideIntraRd(View &view, const havoc_search_intra_result &order, const havoc_search_intra_ctx &ic, Lambda reciprocalLambda)
+{
+    havoc_intra_rd_result r;
+    r = havoc_intra_rd_result();
+    r.mode = -1;
+    r.cost = kCostMax;
+    for (int j = 0; j < order.count; ++j)
+    {
+        const int mode = order.order[j];
+        const havoc_tu_outcome o = view.evaluate(mode, j);
+        const Cost modeRate = mode == ic.cand_mode_list[0] ? ic.rate_a_minus_c : ((mode == ic.cand_mode_list[1] || mode == ic.cand_mode_list[2]) ? ic.rate_b_minus_c : 0);
+        const Cost cost = modeRate + tuRate(o) + reciprocalLambda * int32_t(o.ssd);
+        ++r.evaluated;
+        if (cost < r.cost)
+        {
+            r.mode = mode;
+            r.index = j;
+            r.cost = cost;
+            r.outcome = o;
+        }
+    }
+    return r;
+}
+
 } // namespace havoc_search

@@ -244,4 +244,133 @@ int havoc_search_block_cells(int width, int height, int qp, int dpb_index0, cons
     return 0;
 }
 
+// The RD refinement of n intra partitions of ONE size (tu_decision.hpp: decideIntraRd): every candidate mode of every partition -- the
+// refinement orders havoc_search_intra_modes returned -- through   intra prediction -> tu_forward -> rdoq -> tu_reconstruct (+ SSD) ->
+// level_stats   in one chain, the champions picked on the host from 16 bytes per candidate, their reconstructions written to d_rec
+// (block i = n x n samples at i * n * n, stride n).  jobs (HOST memory) / d_neighbours as for havoc_mi355x_intra_satd35: the partitions' source
+// blocks and neighbour arrays; independent partitions -- the caller provides the neighbours (in the encoder they are the previous
+// partition's reconstruction, Reconstruct.cpp:609-615: partitions that depend on each other go in successive calls).
+int havoc_search_intra_rd(havoc_mi355x_ctx *ctx, int S, int bitDepth, int log2TrafoSize, const void *d_src, intptr_t src_stride, const void *d_neighbours,
+                          const havoc_mi355x_intra_search_job *jobs, int n, const havoc_search_intra_result *order, const havoc_search_intra_ctx *ictx,
+                          const int32_t *ctx_index, const uint8_t *d_states, const havoc_rqt_quant *quant, double lambda, double reciprocal_lambda, int sdh, void *d_rec,
+                          havoc_intra_rd_result *out, havoc_rqt_stats *stats)
+{
+    if (!ctx || !d_src || !d_neighbours || !jobs || !order || !ictx || !ctx_index || !d_states || !quant || !d_rec || !out || n < 0 || (S != 1 && S != 2) ||
+        log2TrafoSize < 2 || log2TrafoSize > 5)
+        return HAVOC_MI355X_EINVAL;
+    const double tStart = now();
+    havoc_rqt_stats st;
+    std::memset(&st, 0, sizeof(st));
+    if (n == 0)
+    {
+        if (stats) *stats = st;
+        return 0;
+    }
+    Arena arena(ctx);
+    const int nn = 1 << log2TrafoSize, area = nn * nn, tr = log2TrafoSize == 2 ? 1 : 0;
+    std::vector<int> first(n + 1, 0);
+    for (int i = 0; i < n; ++i)
+    {
+        if (order[i].count < 0 || order[i].count > 35) return HAVOC_MI355X_EINVAL;
+        first[i + 1] = first[i] + order[i].count;
+    }
+    const int m = first[n];
+    void *dIj, *hIj, *vIj, *dTj, *hTj, *vTj, *dRj, *hRj, *vRj, *dSj, *hSj, *vSj, *dPred, *dPiece, *dCoef, *dLevel, *dWork, *hx, *dCbf, *hCbf, *vCbf, *dSsd, *hSsd, *vSsd,
+        *dStats, *hStats, *vStats;
+    RC(arena.get(size_t(m) * sizeof(havoc_mi355x_intra_job), &dIj, &hIj, &vIj));
+    RC(arena.get(size_t(m) * sizeof(havoc_mi355x_tu_fused_job), &dTj, &hTj, &vTj));
+    RC(arena.get(size_t(m) * sizeof(havoc_mi355x_rdoq_job), &dRj, &hRj, &vRj));
+    RC(arena.get(size_t(m) * 8, &dSj, &hSj, &vSj));
+    RC(arena.get(size_t(m) * area * S, &dPred, &hx));
+    RC(arena.get(size_t(m) * area * S, &dPiece, &hx));
+    RC(arena.get(size_t(m) * area * 2, &dCoef, &hx));
+    RC(arena.get(size_t(m) * area * 2, &dLevel, &hx));
+    RC(arena.get(havoc_mi355x_rdoq_workspace(m) + 64, &dWork, &hx));
+    RC(arena.get(size_t(m) * 4, &dCbf, &hCbf, &vCbf));
+    RC(arena.get(size_t(m) * 4, &dSsd, &hSsd, &vSsd));
+    RC(arena.get(size_t(m) * 8, &dStats, &hStats, &vStats));
+    havoc_mi355x_intra_job *ij = static_cast<havoc_mi355x_intra_job *>(hIj);
+    havoc_mi355x_tu_fused_job *tj = static_cast<havoc_mi355x_tu_fused_job *>(hTj);
+    havoc_mi355x_rdoq_job *rj = static_cast<havoc_mi355x_rdoq_job *>(hRj);
+    int32_t *sj = static_cast<int32_t *>(hSj);
+    int32_t lq, sf;
+    havoc_mi355x_rdoq_lambda(lambda, quant->inv_scale, &lq, &sf);
+    for (int i = 0; i < n; ++i)
+        for (int k = 0; k < order[i].count; ++k)
+        {
+            const int c = first[i] + k, mode = order[i].order[k];
+            const uint64_t mask = uint64_t(jobs[i].filt_lo) | (uint64_t(jobs[i].filt_hi) << 32);
+            std::memset(&ij[c], 0, sizeof(ij[c]));
+            ij[c].dst_off = c * area;
+            ij[c].nb_off = ((mask >> mode) & 1) ? jobs[i].nbf_off : jobs[i].nb_off;
+            ij[c].log2 = log2TrafoSize;
+            ij[c].mode = mode;
+            ij[c].edge = jobs[i].edge;
+            tj[c] = {c * area, jobs[i].src_off, c * area, c * area};
+            std::memset(&rj[c], 0, sizeof(rj[c]));
+            rj[c].dst_off = rj[c].src_off = c * area;
+            rj[c].quant_scale = quant->quant_scale;
+            rj[c].quant_shift = quant->quant_shift;
+            rj[c].inv_scale = quant->inv_scale;
+            rj[c].lambda_q16 = lq;
+            rj[c].sdh_factor = sf;
+            rj[c].ctx_index = ctx_index[i];
+            rj[c].scan_idx = uint8_t(intraScanIdx(log2TrafoSize, mode));
+            rj[c].is_intra = 1;
+            rj[c].sdh = uint8_t(sdh != 0);
+            sj[2 * c] = c * area;
+            sj[2 * c + 1] = area;
+        }
+    const double tGpu = now();
+    const havoc_mi355x_tu_fused_job *dj = static_cast<const havoc_mi355x_tu_fused_job *>(vTj);
+    RC(havoc_mi355x_intra(ctx, S, bitDepth, log2TrafoSize, dPred, nn, d_neighbours, static_cast<const havoc_mi355x_intra_job *>(vIj), m));
+    RC(havoc_mi355x_tu_forward(ctx, S, bitDepth, tr, log2TrafoSize, static_cast<int16_t *>(dCoef), d_src, src_stride, dPred, nn, dj, m));
+    RC(havoc_mi355x_rdoq(ctx, bitDepth, log2TrafoSize, static_cast<int16_t *>(dLevel), static_cast<const int16_t *>(dCoef), d_states,
+                         static_cast<const havoc_mi355x_rdoq_job *>(vRj), m, static_cast<int32_t *>(vCbf), dWork, havoc_mi355x_rdoq_workspace(m)));
+    RC(havoc_mi355x_tu_reconstruct(ctx, S, bitDepth, tr, log2TrafoSize, quant->inv_scale, quant->inv_shift, dPiece, nn, dPred, nn, d_src, src_stride,
+                                   static_cast<const int16_t *>(dLevel), dj, m, static_cast<uint32_t *>(vSsd)));
+    RC(havoc_mi355x_level_stats(ctx, static_cast<const int16_t *>(dLevel), static_cast<const int32_t *>(vSj), m, static_cast<int32_t *>(vStats)));
+    RC(havoc_mi355x_sync(ctx));
+    st.launches += 5;
+    st.candidates = m;
+    st.seconds_gpu += now() - tGpu;
+
+    const double tHost = now();
+    const int32_t *cbf = static_cast<const int32_t *>(hCbf), *stats32 = static_cast<const int32_t *>(hStats);
+    const uint32_t *ssd = static_cast<const uint32_t *>(hSsd);
+    Lambda rl;
+    rl.set(reciprocal_lambda);
+    struct Lookup
+    {
+        const int32_t *cbf, *stats;
+        const uint32_t *ssd;
+        int base;
+        havoc_tu_outcome evaluate(int, int index) { const int c = base + index; return {cbf[c], ssd[c], stats[2 * c], stats[2 * c + 1]}; }
+    };
+    std::vector<havoc_mi355x_tu_fused_job> fin(n);
+    for (int i = 0; i < n; ++i)
+    {
+        Lookup view{cbf, stats32, ssd, first[i]};
+        out[i] = decideIntraRd(view, order[i], ictx[i], rl);
+        const int c = first[i] + std::max(0, out[i].index);
+        fin[i] = tj[c];
+        fin[i].rec_off = i * area;
+    }
+    st.seconds_host += now() - tHost;
+    // the champions' reconstructions (their levels are still on the device) into d_rec
+    const double tGpu2 = now();
+    void *dF, *hF, *vF, *dS2, *hS2;
+    RC(arena.get(size_t(n) * sizeof(fin[0]), &dF, &hF, &vF));
+    RC(arena.get(size_t(n) * 4, &dS2, &hS2));
+    std::memcpy(hF, fin.data(), size_t(n) * sizeof(fin[0]));
+    RC(havoc_mi355x_tu_reconstruct(ctx, S, bitDepth, tr, log2TrafoSize, quant->inv_scale, quant->inv_shift, d_rec, nn, dPred, nn, d_src, src_stride,
+                                   static_cast<const int16_t *>(dLevel), static_cast<const havoc_mi355x_tu_fused_job *>(vF), n, static_cast<uint32_t *>(dS2)));
+    RC(havoc_mi355x_sync(ctx));
+    ++st.launches;
+    st.seconds_gpu += now() - tGpu2;
+    st.seconds_total = now() - tStart;
+    if (stats) *stats = st;
+    return 0;
+}
+
 } // extern "C"
