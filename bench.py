@@ -1113,6 +1113,9 @@ def decision_path(args, Havoc, res, bit_depth, qp, pictures, seconds=1.5, keep=N
     solo.tu_chain(field0)
     solo.hv.sync()
     t_chain = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    solo.intra_decisions()
+    t_intra = time.perf_counter() - t0
     def throughput(count, secs):
         for dp in ctxs[:count]:
             dp.threads = max(1, cores // count)
@@ -1144,13 +1147,18 @@ def decision_path(args, Havoc, res, bit_depth, qp, pictures, seconds=1.5, keep=N
            "seconds_measured": round(el, 3), "pictures_done": int(sum(done)),
            "one_picture_alone_ms": round(min(lat) * 1e3, 3),
            "one_picture_alone_split_ms": {"phase_planes": round(t_planes * 1e3, 3), "searches_in_wavefront_order": round(t_search * 1e3, 3),
-                                          "prediction_and_transform_tree_decisions": round(t_chain * 1e3, 3)},
+                                          "prediction_and_transform_tree_decisions": round(t_chain * 1e3, 3),
+                                          "intra_35_mode_stage_and_rd_refinement": round(t_intra * 1e3, 3)},
            "searches_per_picture": int(2 * len(solo.pus)), "ctus": solo.cx * solo.cy,
            "transform_tree_decisions": {"units": int(len(solo.units)), "candidates": int(solo.rqt_stats.candidates), "launches": int(solo.rqt_stats.launches),
                                         "launches_per_ctu": round(solo.rqt_stats.launches / (solo.cx * solo.cy), 4),
                                         "split": int((solo.rqt_results["depth"] == 1).sum()), "unsplit": int(((solo.rqt_results["depth"] == 0) & (solo.rqt_results["tried_zero"] == 1)).sum()),
                                         "uncoded": int((solo.rqt_results["tried_zero"] == 0).sum()),
                                         "seconds": {"gpu": round(solo.rqt_stats.seconds_gpu, 5), "host": round(solo.rqt_stats.seconds_host, 5)}},
+           "intra": {"partitions": int(sum(len(g["jobs"]) for g in solo.intra_parts.values())),
+                     "candidates_reconstructed": int(sum(st.candidates for _, _, st in solo.intra_results.values())),
+                     "launches": int(sum(st.launches + 1 for _, _, st in solo.intra_results.values())),
+                     "champion_is_not_the_satd_winner": round(float(np.mean(np.concatenate([b["index"] != 0 for _, b, _ in solo.intra_results.values()]))), 3)},
            "wavefront_steps": d["steps"], "rounds": d["rounds"], "rounds_per_step": round(d["rounds"] / max(1, d["steps"]), 2),
            "max_rounds_in_step": d["max_rounds_in_step"], "launches": d["launches"], "launches_per_step": round(d["launches"] / max(1, d["steps"]), 2),
            "surfaces": d["surfaces_small"] + d["surfaces_zero"] + d["surfaces_large"], "satd_jobs": d["satd_jobs"],
@@ -1161,8 +1169,11 @@ def decision_path(args, Havoc, res, bit_depth, qp, pictures, seconds=1.5, keep=N
                    "row (turingcodec_amd/search/picture_order.hpp) -- fed by SAD-surface / tile-SATD batch launches, the reference's loops replayed on "
                    "host threads; then prediction at the chosen vectors and the residual-quadtree decision of every inter unit (both tree depths of "
                    "every 32x32 unit through residual + DCT -> RDOQ -> IQ + IDCT + add -> SSD in one chain per transform size, decisions from 16 bytes per "
-                   "candidate, chosen candidates reconstructed into the picture; turingcodec_amd/search/tu_decision.hpp). "
-                   "Not in it: the mode decision between the searched PUs, bi-prediction, intra, CABAC (the rate term of the tree decision is a stand-in)"}
+                   "candidate, chosen candidates reconstructed into the picture; turingcodec_amd/search/tu_decision.hpp), boundary strengths derived on "
+                   "the device, deblocking, padding; and the picture's intra candidates (42 partitions per CTU: 35-mode SATD stage, then every candidate "
+                   "mode of the refinement order reconstructed through T -> RDOQ -> IT and the champion picked; neighbours from the source picture, not "
+                   "from the preceding partition's reconstruction). Not in it: the mode decision between the searched PUs and between inter and intra, "
+                   "bi-prediction, CABAC (the rate terms of the tree / intra decisions are stand-ins)"}
     out.update(more)
     if keep is not None:
         keep["solo"], keep["res"], keep["field"] = solo, res0, field0

@@ -92,6 +92,8 @@ def lib():
         L.havoc_search_intra_rd.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, ip, vp, vp, C.c_int, vp, vp, vp, vp, vp, C.c_double, C.c_double, C.c_int, vp, vp,
                                             C.POINTER(RqtStats)]
         L.havoc_search_intra_rd.restype = C.c_int
+        L.havoc_search_intra_modes.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, ip, vp, vp, C.c_int, vp, C.c_double, vp, vp]
+        L.havoc_search_intra_modes.restype = C.c_int
         L.havoc_search_block_cells.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp]
         L.havoc_search_block_cells.restype = C.c_int
         L.havoc_search_release.argtypes = [vp]
@@ -169,6 +171,18 @@ def intra_rd(ctx, S, bit_depth, log2, d_src, src_stride, d_neighbours, jobs, ord
     return out, stats
 
 
+def intra_modes(ctx, S, bit_depth, log2, d_src, src_stride, d_neighbours, d_jobs, n, ictx, reciprocal_sqrt_lambda):
+    """havoc_search_intra_modes: the 35-mode SATD stage of n partitions of one size + the order their modes are refined in (Search.hpp:40-190).
+    d_jobs: device copy of the int32 [n, 8] job rows.  Returns INTRA_RESULT_DT[n]"""
+    ictx = np.ascontiguousarray(ictx)
+    out = np.zeros(n, INTRA_RESULT_DT)
+    rc = lib().havoc_search_intra_modes(ctx, S, bit_depth, log2, d_src, src_stride, d_neighbours, d_jobs, n, ictx.ctypes.data, float(reciprocal_sqrt_lambda),
+                                        out.ctypes.data, None)
+    if rc != 0:
+        raise RuntimeError(f"havoc_search_intra_modes failed ({rc})")
+    return out
+
+
 def rqt_units(width, height, ctus_x):
     """the inter units whose transform trees are decided: 32x32 units where they fit, 16x16 then 8x8 units along a partial last row / column"""
     rows = []
@@ -195,12 +209,17 @@ class DecisionPicture:
          de-quantise + inverse DCT + add -> SSD in one chain per transform size, the decisions taken from 16 bytes per candidate, the chosen
          candidates reconstructed into the picture (job tables are built from the decided motion field: they cannot exist before 2).
 
+      4. the intra candidates an inter picture evaluates (21.4 k partitions per 1080p frame): per partition size the 35-mode
+         prediction + SATD stage and its refinement order (havoc_search_intra_modes), then every candidate mode reconstructed and the champion
+         picked (havoc_search_intra_rd) -- with neighbours from the SOURCE picture, i.e. without the chain through the previous partition's
+         reconstruction that the encoder has (stated; that chain needs a device-side loop).
+
     What is NOT in it (stated, not hidden): the encoder's mode decision between the searched PUs (every PU of workload.picture_pus is
-    searched and the last one covering an area stands), bi-prediction, intra candidates and CABAC.  `step()` is what bench.py times."""
+    searched and the last one covering an area stands) and between inter and intra, bi-prediction, CABAC.  `step()` is what bench.py times."""
 
     PAD = 96
 
-    def __init__(self, hv, width, height, bit_depth=8, qp=32, seed=11, threads=16, frames=None, density=1.0):
+    def __init__(self, hv, width, height, bit_depth=8, qp=32, seed=11, threads=16, frames=None, density=1.0, intra=True):
         import torch
         from . import havoc as hmod
         from . import workload
@@ -260,6 +279,14 @@ class DecisionPicture:
         self.d_states = hv.up(self.rdoq_states.reshape(-1))
         self.pred = hv.zeros(width * height, self.dt)
         self.recon = hv.zeros(self.pe, self.dt)
+        # ---- the intra candidates of the picture (an inter picture evaluates them per coding unit): partitions with neighbours from the source
+        self.intra_parts = {}
+        self.rsl = float(self.params.reciprocal_sqrt_lambda)
+        if intra:
+            src2d = self.host_planes[0].reshape(-1, self.stride)
+            for log2, (jobs, nb, ictx, ctu) in workload.intra_partitions(src2d, width, height, self.PAD, seed + 31).items():
+                self.intra_parts[log2] = dict(jobs=jobs, nb=nb, ictx=ictx, ctu=ctu, d_jobs=hv.up(jobs), d_nb=hv.up(nb),
+                                              d_rec=hv.zeros(len(jobs) << (2 * log2), self.dt))
         hv.sync()
 
     def phase_planes(self):
@@ -358,9 +385,25 @@ class DecisionPicture:
             hv.rdoq_d(bd, g["log2"], g["level"], g["coef"], self.d_states, g["d_rj"], g["cbf"], g["work"])
             hv.tu_reconstruct_d(bd, 0, g["log2"], g["inv"], g["dshift"], self.recon, self.stride, self.pred, self.W, src, self.stride, g["level"], g["d_fj"], g["ssd"])
 
+    def intra_decisions(self):
+        """the intra side of the picture: per partition size the 35-mode SATD stage (one launch) and its refinement order, then the RD refinement
+        of every candidate mode (havoc_search_intra_rd: one chain); returns {log2: (modes stage, RD champions)}"""
+        hv = self.hv
+        base = self.d_pic.data_ptr()
+        out = {}
+        for log2, g in sorted(self.intra_parts.items(), reverse=True):
+            order = intra_modes(hv.h, self.S, self.bd, log2, base, self.stride, g["d_nb"].data_ptr(), g["d_jobs"].data_ptr(), len(g["jobs"]), g["ictx"], self.rsl)
+            best, st = intra_rd(hv.h, self.S, self.bd, log2, base, self.stride, g["d_nb"].data_ptr(), g["jobs"], order, g["ictx"], g["ctu"], self.d_states.data_ptr(),
+                                self.quant[log2 - 2], self.lam, 1.0 / self.lam, g["d_rec"].data_ptr())
+            out[log2] = (order, best, st)
+        self.intra_results = out
+        return out
+
     def step(self):
         self.phase_planes()
         res, field, stats = self.search()
+        if self.intra_parts:
+            self.intra_decisions()
         decisions, _ = self.tu_chain(field)
         self.cells = self.block_cells(field, decisions)
         self.loop_filter(self.cells)

@@ -97,6 +97,65 @@ def picture_pus(width, height, seed, density=1.0):
     return np.ascontiguousarray(pus), np.asarray(first, np.int32), ctus_x, ctus_y
 
 
+def intra_filter_mask(nn):
+    """HEVC 8.4.4.2.3 filterFlag per mode as a bit mask (the caller's decision, turing/Reconstruct.cpp:659): filtered neighbours when
+    min(|mode - 26|, |mode - 10|) > thres[nTbS]; planar always for nTbS >= 8; never DC, never 4x4"""
+    if nn == 4:
+        return 0
+    thres = {8: 7, 16: 1, 32: 0}[nn]
+    mask = 1
+    for mode in range(2, 35):
+        if min(abs(mode - 26), abs(mode - 10)) > thres:
+            mask |= 1 << mode
+    return mask
+
+
+def intra_partitions(src2d, width, height, pad, seed, per_ctu=42.0):
+    """The intra partitions of one picture whose 35 modes are evaluated (21.4 k partitions per 1080p B-frame = ~42 per CTU; sizes by
+    INTRA_MIX), at random aligned positions in CTU order, with their neighbour arrays taken from the (padded) SOURCE picture -- so the partitions
+    are independent of each other (in the encoder the neighbours are the reconstruction of what precedes them, Reconstruct.cpp:609-615).
+    src2d: padded plane [rows, stride].  Returns {log2: (jobs int32 [m, 8] = havoc_mi355x_intra_search_job rows with src_off relative to the
+    plane's first sample, neighbours flat array (per job: unfiltered then filtered), ctx = INTRA_CTX-like structured rates)}."""
+    rng = np.random.default_rng(seed)
+    stride = src2d.shape[1]
+    ctus = ((width + CTU - 1) // CTU) * ((height + CTU - 1) // CTU)
+    total = max(4, int(round(per_ctu * ctus)))
+    sizes = np.array([m[0] for m in INTRA_MIX])[_pick(rng, INTRA_MIX, total)]
+    out = {}
+    for log2 in (2, 3, 4, 5):
+        nn = 1 << log2
+        m = int((sizes == log2).sum())
+        if not m:
+            continue
+        x = (rng.integers(0, (width - nn) // nn + 1, m) * nn).astype(np.int64)
+        y = (rng.integers(0, (height - nn) // nn + 1, m) * nn).astype(np.int64)
+        o = np.argsort((y // CTU) * 4096 + x // CTU, kind="stable")
+        x, y = x[o], y[o]
+        k = np.arange(4 * nn + 1)
+        dy = np.where(k < 2 * nn, 2 * nn - 1 - k, -1)
+        dx = np.where(k <= 2 * nn, -1, k - 2 * nn - 1)
+        nbu = src2d[(y[:, None] + pad + dy[None, :]), (x[:, None] + pad + dx[None, :])].astype(np.int32)
+        nbf = nbu.copy()                                     # [1 2 1] smoothing (IntraReferenceSamples.h:373-421)
+        nbf[:, 1:-1] = (nbu[:, :-2] + 2 * nbu[:, 1:-1] + nbu[:, 2:] + 2) >> 2
+        L = 4 * nn + 1
+        mask = intra_filter_mask(nn)
+        j = np.zeros((m, 8), np.int64)
+        j[:, 0] = (y + pad) * stride + x + pad
+        j[:, 1] = np.arange(m) * 2 * L + 2 * nn + 1
+        j[:, 2] = j[:, 1] + L
+        j[:, 3], j[:, 4], j[:, 5] = mask & 0xffffffff, mask >> 32, 1
+        ctx = np.zeros(m, np.dtype([("cand_mode_list", "i4", (3,)), ("neighbour_modes", "i4"), ("max_refine", "i4"), ("reserved", "i4"),
+                                    ("rate_a_minus_c", "i8"), ("rate_b_minus_c", "i8")]))
+        ctx["cand_mode_list"] = np.argsort(rng.random((m, 35)), axis=1)[:, :3]      # three distinct most probable modes
+        ctx["neighbour_modes"] = 3
+        ctx["max_refine"] = 3 if log2 > 3 else 8            # Speed::nCandidatesIntraRefinement at medium
+        ctx["rate_a_minus_c"] = -rng.integers(300000, 420000, m)
+        ctx["rate_b_minus_c"] = -rng.integers(100000, 200000, m)
+        out[log2] = (j.astype(np.uint32).view(np.int32).reshape(m, 8), np.ascontiguousarray(np.concatenate([nbu, nbf], 1).astype(src2d.dtype).ravel()), ctx,
+                     ((y // CTU) * ((width + CTU - 1) // CTU) + x // CTU).astype(np.int32))
+    return out
+
+
 def synth_frames(width, height, nframes, seed, bit_depth=8):
     """SURVEY.md 8(d) generator: low-passed noise translating by (3,2) px/frame blended 60/40 with a moving
     sinusoid, +-3 uniform noise; smooth chroma ramps.  Returns [(Y, U, V)] unpadded planes."""
