@@ -1156,9 +1156,10 @@ def decision_path(args, Havoc, res, bit_depth, qp, pictures, seconds=1.5, keep=N
                                         "uncoded": int((solo.rqt_results["tried_zero"] == 0).sum()),
                                         "seconds": {"gpu": round(solo.rqt_stats.seconds_gpu, 5), "host": round(solo.rqt_stats.seconds_host, 5)}},
            "intra": {"partitions": int(sum(len(g["jobs"]) for g in solo.intra_parts.values())),
-                     "candidates_reconstructed": int(sum(st.candidates for _, _, st in solo.intra_results.values())),
-                     "launches": int(sum(st.launches + 1 for _, _, st in solo.intra_results.values())),
-                     "champion_is_not_the_satd_winner": round(float(np.mean(np.concatenate([b["index"] != 0 for _, b, _ in solo.intra_results.values()]))), 3)},
+                     "candidates_reconstructed": int(sum(st.candidates for st in solo.intra_stats)),
+                     "launches": int(sum(st.launches for st in solo.intra_stats)),
+                     "decisions": "on the device (order of refinement, candidates' job records, champions): 40 bytes per partition come back",
+                     "champion_is_not_the_satd_winner": round(float(np.mean(np.concatenate([b["index"] != 0 for _, b in solo.intra_results.values()]))), 3)},
            "wavefront_steps": d["steps"], "rounds": d["rounds"], "rounds_per_step": round(d["rounds"] / max(1, d["steps"]), 2),
            "max_rounds_in_step": d["max_rounds_in_step"], "launches": d["launches"], "launches_per_step": round(d["launches"] / max(1, d["steps"]), 2),
            "surfaces": d["surfaces_small"] + d["surfaces_zero"] + d["surfaces_large"], "satd_jobs": d["satd_jobs"],

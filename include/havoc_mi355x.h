@@ -505,6 +505,45 @@ int havoc_mi355x_tu_forward_scan(havoc_mi355x_ctx *ctx, int S, int bitDepth, int
 int havoc_mi355x_rdoq_prescanned(havoc_mi355x_ctx *ctx, int bitDepth, int log2TrafoSize, int16_t *d_dst, const int16_t *d_src, const uint8_t *d_states,
                                  const havoc_mi355x_rdoq_job *d_jobs, int njobs, int32_t *d_cbf, void *d_work, size_t work_bytes);
 
+/* ---- the intra decisions that are data-parallel (one lane per partition), taken on the device between the launches they separate ----
+ * Not reference primitives: the reference takes them inline in searchIntraPartition (turing/Search.hpp:40-255).  A batch client that
+ * refines a picture's intra partitions (libhavoc_search.so: havoc_search_intra_device) chains
+ *     intra_satd35 -> intra_order -> intra_expand -> intra -> tu_forward -> rdoq -> tu_reconstruct -> level_stats -> intra_decide -> tu_reconstruct
+ * so that neither the 35 costs per partition nor the job records per candidate cross the link. */
+#define HAVOC_MI355X_INTRA_MAX_ORDER 12
+typedef struct
+{
+    int32_t cand_mode_list[3];     /* candModeList (Search.hpp:55-98) */
+    int32_t neighbour_modes;       /* how many of them are forced into the refinement if not selected (Search.hpp:170-180) */
+    int32_t max_refine;            /* selections before that happens; max_refine + neighbour_modes <= HAVOC_MI355X_INTRA_MAX_ORDER */
+    int32_t reserved;
+    int64_t rate_a_minus_c, rate_b_minus_c;   /* Q16 rate offsets of candModeList[0] / [1], [2] relative to a mode outside the list */
+} havoc_mi355x_intra_mpm;          /* 40 bytes; = havoc_search_intra_ctx */
+typedef struct
+{
+    int32_t mode, index, evaluated, reserved;
+    int64_t cost;                  /* Q16: mode rate + residual rate + ssd * reciprocal lambda */
+    int32_t cbf;
+    uint32_t ssd;
+    int32_t nonzero, sum_abs;
+} havoc_mi355x_intra_choice;       /* 40 bytes; = havoc_intra_rd_result */
+/* Search.hpp:55-98, 143-190: costs = rate offsets + lambda_q16 * d_satd35[35 * i + mode] (64-bit), then the order the modes are refined in:
+ * d_order[HAVOC_MI355X_INTRA_MAX_ORDER * i + k], k < d_count[i]; d_slot[i] = the partition's first candidate slot;
+ * d_total[0] = slots handed out, d_total[1] != 0 if some partition wanted more than HAVOC_MI355X_INTRA_MAX_ORDER (its order is cut). */
+int havoc_mi355x_intra_order(havoc_mi355x_ctx *ctx, const int32_t *d_satd35, const havoc_mi355x_intra_mpm *d_mpm, int n, int32_t lambda_q16, int32_t *d_order,
+                             int32_t *d_count, int32_t *d_slot, int32_t *d_total);
+/* the job records of every candidate c = d_slot[i] + k: prediction into piece c (n x n, stride n) from the filtered / unfiltered neighbours as
+ * the partition's mask says, residual + forward transform, Rdoq (intra, scan by mode: Global.h:1212-1227), level statistics; d_owner[c] = i */
+int havoc_mi355x_intra_expand(havoc_mi355x_ctx *ctx, const havoc_mi355x_intra_search_job *d_parts, const int32_t *d_order, const int32_t *d_count, const int32_t *d_slot,
+                              const int32_t *d_ctx_index, int n, int log2TrafoSize, int quant_scale, int quant_shift, int inv_scale, int lambda_q16, int sdh_factor, int sdh,
+                              havoc_mi355x_intra_job *d_intra_jobs, havoc_mi355x_tu_fused_job *d_tu_jobs, havoc_mi355x_rdoq_job *d_rdoq_jobs, int32_t *d_stat_jobs,
+                              int32_t *d_owner);
+/* Search.hpp:143-255: the first candidate with the smallest   mode rate + (1 + (cbf ? 2 * nonzero + sum_abs : 0) << 16) + reciprocal_lambda_q16 * ssd;
+ * d_final[i] = the champion's tu job with rec_off = i << (2 * log2TrafoSize) (the block it reconstructs into) */
+int havoc_mi355x_intra_decide(havoc_mi355x_ctx *ctx, const havoc_mi355x_intra_mpm *d_mpm, const int32_t *d_order, const int32_t *d_count, const int32_t *d_slot,
+                              const int32_t *d_cbf, const uint32_t *d_ssd, const int32_t *d_stats, const havoc_mi355x_tu_fused_job *d_tu_jobs, int n, int log2TrafoSize,
+                              int32_t reciprocal_lambda_q16, havoc_mi355x_intra_choice *d_out, havoc_mi355x_tu_fused_job *d_final);
+
 #ifdef __cplusplus
 }
 #endif

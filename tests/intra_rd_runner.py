@@ -68,6 +68,7 @@ def main():
         return d
     d_src, d_states = up(src), up(np.ascontiguousarray(states))
     total_bad = 0
+    groups, expected = [], {}
     for log2 in (2, 3, 4, 5):
         jobs = np.ascontiguousarray(wl.intra_search[log2])
         if args.limit:
@@ -94,10 +95,27 @@ def main():
         assert dev.havoc_mi355x_d2h(ctx, rec.ctypes.data, d_rec, rec.nbytes) == 0
         bad = int(sum(got[i].tobytes() != exp[i].tobytes() for i in range(n)))
         total_bad += bad + (0 if np.array_equal(rec, exp_rec) else 1)
+        rec2 = np.zeros_like(rec)
+        groups.append(dict(log2=log2, n=n, d_nb=d_nb, d_jobs=up(jobs), d_ictx=up(np.ascontiguousarray(ictx)), d_ctu=up(np.ascontiguousarray(ctu, np.int32)), d_rec=up(rec2)))
+        expected[log2] = (exp, exp_rec)
         report["sizes"][str(1 << log2)] = {"partitions": n, "candidates": int(stats.candidates), "launches": int(stats.launches), "mismatching": bad,
                                            "reconstructions_equal": bool(np.array_equal(rec, exp_rec)), "seconds_batch": round(t_dev, 5),
                                            "seconds_per_call_one_core": round(t_ref, 4), "champion_is_first_candidate": float(np.mean(exp["index"] == 0)),
                                            "coded": float(np.mean(exp["outcome"]["cbf"] != 0))}
+    # both stages with the decisions taken on the device (havoc_search_intra_device): all sizes in one call, the same champions
+    for attempt in range(2):
+        t0 = time.perf_counter()
+        got, stats = decisions.intra_device(ctx, S, BD, d_src, wl.stride, groups, d_states, quant, rsl, lam, 1.0 / lam)
+        t_dev = time.perf_counter() - t0
+    bad = 0
+    for g in groups:
+        exp, exp_rec = expected[g["log2"]]
+        rec = np.zeros_like(exp_rec)
+        assert dev.havoc_mi355x_d2h(ctx, rec.ctypes.data, g["d_rec"], rec.nbytes) == 0
+        bad += int(sum(got[g["log2"]][i].tobytes() != exp[i].tobytes() for i in range(g["n"]))) + (0 if np.array_equal(rec, exp_rec) else 1)
+    report["device_decisions"] = {"mismatching": bad, "launches": int(stats.launches), "candidates": int(stats.candidates), "seconds": round(t_dev, 5),
+                                  "candidates_per_call_arm": int(sum(v["candidates"] for v in report["sizes"].values()))}
+    total_bad += bad
     report["mismatches"] = total_bad
     print(json.dumps(report))
 

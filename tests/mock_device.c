@@ -291,6 +291,108 @@ int havoc_mi355x_tu_reconstruct(havoc_mi355x_ctx *ctx, int S, int bitDepth, int 
     return 0;
 }
 
+/* the device-side intra decisions (csrc/kernels_decide.hip), one partition after the other: the same rules as search/decision.hpp: intraModeOrder and
+ * search/tu_decision.hpp: decideIntraRd, which tests/test_search.py compares them with */
+int havoc_mi355x_intra_order(havoc_mi355x_ctx *ctx, const int32_t *satd35, const havoc_mi355x_intra_mpm *mpm, int n, int32_t lambda_q16, int32_t *order, int32_t *count,
+                             int32_t *slot, int32_t *total)
+{
+    (void)ctx; ++g_launches;
+    total[0] = total[1] = 0;
+    for (int i = 0; i < n; ++i)
+    {
+        const havoc_mi355x_intra_mpm *c = &mpm[i];
+        int64_t costs[35];
+        for (int m = 0; m < 35; ++m) costs[m] = 0;
+        costs[c->cand_mode_list[0]] = c->rate_a_minus_c;
+        costs[c->cand_mode_list[1]] = c->rate_b_minus_c;
+        costs[c->cand_mode_list[2]] = c->rate_b_minus_c;
+        for (int m = 0; m < 35; ++m) costs[m] += (int64_t)lambda_q16 * satd35[35 * i + m];
+        int cnt = 0, forced = 0;
+        for (int j = 0; j < c->max_refine + forced; ++j)
+        {
+            if (cnt == HAVOC_MI355X_INTRA_MAX_ORDER) { total[1] = 1; break; }
+            int mode = 0;
+            for (int m = 1; m < 35; ++m) if (costs[m] < costs[mode]) mode = m;
+            costs[mode] = INT64_MAX;
+            if (j == c->max_refine - 1)
+                for (int k = 0; k < c->neighbour_modes; ++k)
+                    if (costs[c->cand_mode_list[k]] != INT64_MAX) { costs[c->cand_mode_list[k]] = 0; ++forced; }
+            order[HAVOC_MI355X_INTRA_MAX_ORDER * i + cnt++] = mode;
+        }
+        count[i] = cnt;
+        slot[i] = total[0];
+        total[0] += cnt;
+    }
+    return 0;
+}
+
+int havoc_mi355x_intra_expand(havoc_mi355x_ctx *ctx, const havoc_mi355x_intra_search_job *parts, const int32_t *order, const int32_t *count, const int32_t *slot,
+                              const int32_t *ctx_index, int n, int log2, int quant_scale, int quant_shift, int inv_scale, int lambda_q16, int sdh_factor, int sdh,
+                              havoc_mi355x_intra_job *ij, havoc_mi355x_tu_fused_job *tj, havoc_mi355x_rdoq_job *rj, int32_t *sj, int32_t *owner)
+{
+    (void)ctx; ++g_launches;
+    const int area = 1 << (2 * log2);
+    for (int i = 0; i < n; ++i)
+        for (int k = 0; k < count[i]; ++k)
+        {
+            const int c = slot[i] + k, mode = order[HAVOC_MI355X_INTRA_MAX_ORDER * i + k];
+            const uint64_t mask = (uint64_t)parts[i].filt_lo | ((uint64_t)parts[i].filt_hi << 32);
+            memset(&ij[c], 0, sizeof(ij[c]));
+            ij[c].dst_off = c * area;
+            ij[c].nb_off = ((mask >> mode) & 1) ? parts[i].nbf_off : parts[i].nb_off;
+            ij[c].log2 = log2;
+            ij[c].mode = mode;
+            ij[c].edge = parts[i].edge;
+            tj[c].coef_off = tj[c].pred_off = tj[c].rec_off = c * area;
+            tj[c].src_off = parts[i].src_off;
+            memset(&rj[c], 0, sizeof(rj[c]));
+            rj[c].dst_off = rj[c].src_off = c * area;
+            rj[c].quant_scale = quant_scale;
+            rj[c].quant_shift = quant_shift;
+            rj[c].inv_scale = inv_scale;
+            rj[c].lambda_q16 = lambda_q16;
+            rj[c].sdh_factor = sdh_factor;
+            rj[c].ctx_index = ctx_index[i];
+            rj[c].scan_idx = (uint8_t)((log2 == 2 || log2 == 3) ? ((mode >= 6 && mode <= 14) ? 2 : ((mode >= 22 && mode <= 30) ? 1 : 0)) : 0);
+            rj[c].is_intra = 1;
+            rj[c].sdh = (uint8_t)(sdh != 0);
+            sj[2 * c] = c * area;
+            sj[2 * c + 1] = area;
+            owner[c] = i;
+        }
+    return 0;
+}
+
+int havoc_mi355x_intra_decide(havoc_mi355x_ctx *ctx, const havoc_mi355x_intra_mpm *mpm, const int32_t *order, const int32_t *count, const int32_t *slot, const int32_t *cbf,
+                              const uint32_t *ssd, const int32_t *stats, const havoc_mi355x_tu_fused_job *tj, int n, int log2, int32_t reciprocal_lambda_q16,
+                              havoc_mi355x_intra_choice *out, havoc_mi355x_tu_fused_job *fin)
+{
+    (void)ctx; ++g_launches;
+    for (int i = 0; i < n; ++i)
+    {
+        const havoc_mi355x_intra_mpm *c = &mpm[i];
+        havoc_mi355x_intra_choice r;
+        memset(&r, 0, sizeof(r));
+        r.mode = -1;
+        r.cost = INT64_MAX;
+        for (int j = 0; j < count[i]; ++j)
+        {
+            const int s = slot[i] + j, mode = order[HAVOC_MI355X_INTRA_MAX_ORDER * i + j];
+            const int64_t mode_rate = mode == c->cand_mode_list[0] ? c->rate_a_minus_c : ((mode == c->cand_mode_list[1] || mode == c->cand_mode_list[2]) ? c->rate_b_minus_c : 0);
+            const int64_t cost = mode_rate + ((int64_t)(1 + (cbf[s] ? 2 * stats[2 * s] + stats[2 * s + 1] : 0)) << 16) + (int64_t)reciprocal_lambda_q16 * (int32_t)ssd[s];
+            ++r.evaluated;
+            if (cost < r.cost)
+            {
+                r.mode = mode; r.index = j; r.cost = cost; r.cbf = cbf[s]; r.ssd = ssd[s]; r.nonzero = stats[2 * s]; r.sum_abs = stats[2 * s + 1];
+            }
+        }
+        out[i] = r;
+        fin[i] = tj[slot[i] + (r.index > 0 ? r.index : 0)];
+        fin[i].rec_off = i << (2 * log2);
+    }
+    return 0;
+}
+
 size_t havoc_mi355x_rdoq_workspace(int njobs) { (void)njobs; return 256; }
 void havoc_mi355x_rdoq_lambda(double lambda, int inv_scale, int32_t *lq, int32_t *sf) { oracle_rdoq_lambda(lambda, inv_scale, lq, sf); }
 

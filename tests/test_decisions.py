@@ -95,14 +95,19 @@ def test_decision_step_equals_the_reference_functions(res, BD, qp):
     # ... the intra side of the step: 35-mode stage + refinement order, then the RD refinement of every candidate, against the per-call loops
     # through the reference's intra table, transform tables and Rdoq.cpp
     assert set(dp.intra_results) == set(dp.intra_parts) and len(dp.intra_parts) == 4
-    for log2, (order, best, _) in dp.intra_results.items():
+    on_device = dict(dp.intra_results)                      # what the step left: decisions taken by kernels between the launches
+    on_device_rec = {log2: hv.down(g["d_rec"], dp.dt) for log2, g in dp.intra_parts.items()}
+    on_host = dp.intra_decisions(on_device=False)           # the two-call route: decisions on the host
+    for log2, (order, best) in on_host.items():
         g = dp.intra_parts[log2]
         exp_order = ref.intra_order(g["ictx"], dp.rsl, ref.intra35(BD, log2, dp.host_planes[0], dp.stride, g["nb"], g["jobs"]))
         assert order.tobytes() == exp_order.tobytes(), log2
         exp_best, exp_irec = ref.intra_rd(BD, log2, dp.host_planes[0], dp.stride, g["nb"], g["jobs"], exp_order, g["ictx"], g["ctu"], dp.rdoq_states, dp.quant[log2 - 2],
                                           dp.lam, 1.0 / dp.lam)
         assert best.tobytes() == exp_best.tobytes(), log2
+        assert on_device[log2][1].tobytes() == exp_best.tobytes(), log2
         assert np.array_equal(hv.down(g["d_rec"], dp.dt).reshape(exp_irec.shape), exp_irec), log2
+        assert np.array_equal(on_device_rec[log2].reshape(exp_irec.shape), exp_irec), log2
     # the fixed-size chain (16x16 blocks) on the same vectors: every intermediate against the reference's functions
     import torch
     with torch.cuda.stream(hv.tstream):

@@ -282,6 +282,9 @@ def _check_intra_rd(r):
     for s in r["sizes"].values():
         assert s["mismatching"] == 0 and s["reconstructions_equal"] and s["launches"] == 6 and s["candidates"] > 3 * s["partitions"], s
     assert any(s["champion_is_first_candidate"] < 1.0 for s in r["sizes"].values())      # the refinement changes decisions
+    # the same with the order, the candidates' job records and the champions decided on the device: 10 launches per size, one wait in between
+    d = r["device_decisions"]
+    assert d["mismatching"] == 0 and d["launches"] == 10 * len(r["sizes"]) and d["candidates"] == d["candidates_per_call_arm"], d
 
 
 @needs_ref

@@ -35,6 +35,11 @@ hipError_t launch_tu_reconstruct(hipStream_t, int S, int bd, int log2, int tr, i
                                  long, const int16_t *, const void *, int, uint32_t *);
 hipError_t launch_quantize(hipStream_t, int16_t *, const int16_t *, const void *, int, int32_t *);
 hipError_t launch_level_stats(hipStream_t, const int16_t *, const void *, int, int32_t *);
+hipError_t launch_intra_order(hipStream_t, const int32_t *, const void *, int, int32_t, int32_t *, int32_t *, int32_t *, int32_t *);
+hipError_t launch_intra_expand(hipStream_t, const void *, const int32_t *, const int32_t *, const int32_t *, const int32_t *, int, int, int, int, int, int, int, int, void *, void *,
+                               void *, int32_t *, int32_t *);
+hipError_t launch_intra_decide(hipStream_t, const void *, const int32_t *, const int32_t *, const int32_t *, const int32_t *, const uint32_t *, const int32_t *, const void *, int,
+                               int, int32_t, void *, void *);
 hipError_t launch_rdoq(hipStream_t, int bd, int log2, int16_t *, const int16_t *, const uint8_t *, const void *, int, int32_t *, void *);
 size_t rdoq_workspace_bytes(int njobs);
 hipError_t launch_sao_stats(hipStream_t, int S, int bd, const void *, long, const void *, long, const void *, int, int64_t *);
@@ -59,6 +64,7 @@ static_assert(sizeof(havoc_mi355x_tu_job) == 16, "job ABI");
 static_assert(sizeof(havoc_mi355x_intra_search_job) == 32, "job ABI");
 static_assert(sizeof(havoc_mi355x_tu_fused_job) == 16, "job ABI");
 static_assert(sizeof(havoc_mi355x_quant_job) == 32, "job ABI");
+static_assert(sizeof(havoc_mi355x_intra_mpm) == 40 && sizeof(havoc_mi355x_intra_choice) == 40, "job ABI");
 
 #include "ctx.h"
 
@@ -525,6 +531,33 @@ int havoc_mi355x_level_stats(havoc_mi355x_ctx *ctx, const int16_t *d_levels, con
 {
     REQUIRE_CTX(); REQUIRE(njobs >= 0, "njobs < 0");
     return check(launch_level_stats(LS(ctx), d_levels, d_jobs, njobs, d_out), "level_stats");
+}
+
+int havoc_mi355x_intra_order(havoc_mi355x_ctx *ctx, const int32_t *d_satd35, const havoc_mi355x_intra_mpm *d_mpm, int n, int32_t lambda_q16, int32_t *d_order,
+                             int32_t *d_count, int32_t *d_slot, int32_t *d_total)
+{
+    REQUIRE_CTX(); REQUIRE(n >= 0, "n < 0");
+    return check(launch_intra_order(LS(ctx), d_satd35, d_mpm, n, lambda_q16, d_order, d_count, d_slot, d_total), "intra_order");
+}
+
+int havoc_mi355x_intra_expand(havoc_mi355x_ctx *ctx, const havoc_mi355x_intra_search_job *d_parts, const int32_t *d_order, const int32_t *d_count, const int32_t *d_slot,
+                              const int32_t *d_ctx_index, int n, int log2TrafoSize, int quant_scale, int quant_shift, int inv_scale, int lambda_q16, int sdh_factor, int sdh,
+                              havoc_mi355x_intra_job *d_intra_jobs, havoc_mi355x_tu_fused_job *d_tu_jobs, havoc_mi355x_rdoq_job *d_rdoq_jobs, int32_t *d_stat_jobs,
+                              int32_t *d_owner)
+{
+    REQUIRE_CTX(); REQUIRE(n >= 0, "n < 0"); REQUIRE(log2TrafoSize >= 2 && log2TrafoSize <= 5, "log2TrafoSize must be 2..5");
+    return check(launch_intra_expand(LS(ctx), d_parts, d_order, d_count, d_slot, d_ctx_index, n, log2TrafoSize, quant_scale, quant_shift, inv_scale, lambda_q16, sdh_factor, sdh,
+                                     d_intra_jobs, d_tu_jobs, d_rdoq_jobs, d_stat_jobs, d_owner),
+                 "intra_expand");
+}
+
+int havoc_mi355x_intra_decide(havoc_mi355x_ctx *ctx, const havoc_mi355x_intra_mpm *d_mpm, const int32_t *d_order, const int32_t *d_count, const int32_t *d_slot,
+                              const int32_t *d_cbf, const uint32_t *d_ssd, const int32_t *d_stats, const havoc_mi355x_tu_fused_job *d_tu_jobs, int n, int log2TrafoSize,
+                              int32_t reciprocal_lambda_q16, havoc_mi355x_intra_choice *d_out, havoc_mi355x_tu_fused_job *d_final)
+{
+    REQUIRE_CTX(); REQUIRE(n >= 0, "n < 0"); REQUIRE(log2TrafoSize >= 2 && log2TrafoSize <= 5, "log2TrafoSize must be 2..5");
+    return check(launch_intra_decide(LS(ctx), d_mpm, d_order, d_count, d_slot, d_cbf, d_ssd, d_stats, d_tu_jobs, n, log2TrafoSize, reciprocal_lambda_q16, d_out, d_final),
+                 "intra_decide");
 }
 
 int havoc_mi355x_quantize(havoc_mi355x_ctx *ctx, int16_t *d_dst, const int16_t *d_src, const havoc_mi355x_quant_job *d_jobs, int njobs, int32_t *d_cbf)

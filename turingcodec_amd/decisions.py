@@ -92,6 +92,8 @@ def lib():
         L.havoc_search_intra_rd.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, ip, vp, vp, C.c_int, vp, vp, vp, vp, vp, C.c_double, C.c_double, C.c_int, vp, vp,
                                             C.POINTER(RqtStats)]
         L.havoc_search_intra_rd.restype = C.c_int
+        L.havoc_search_intra_device.argtypes = [vp, C.c_int, C.c_int, vp, ip, vp, C.c_int, vp, vp, C.c_double, C.c_double, C.c_double, C.c_int, C.POINTER(RqtStats)]
+        L.havoc_search_intra_device.restype = C.c_int
         L.havoc_search_intra_modes.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, ip, vp, vp, C.c_int, vp, C.c_double, vp, vp]
         L.havoc_search_intra_modes.restype = C.c_int
         L.havoc_search_block_cells.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp]
@@ -169,6 +171,37 @@ def intra_rd(ctx, S, bit_depth, log2, d_src, src_stride, d_neighbours, jobs, ord
     if rc != 0:
         raise RuntimeError(f"havoc_search_intra_rd failed ({rc})")
     return out, stats
+
+
+INTRA_GROUP_DT = np.dtype([("log2", "i4"), ("n", "i4"), ("d_neighbours", "u8"), ("d_jobs", "u8"), ("d_ictx", "u8"), ("d_ctx_index", "u8"), ("d_rec", "u8"),
+                           ("out", "u8")])                                                                       # havoc_intra_group
+assert INTRA_GROUP_DT.itemsize == 56
+
+
+def _address(p):
+    return int(p.value or 0) if isinstance(p, C.c_void_p) else int(p)
+
+
+def intra_device(ctx, S, bit_depth, d_src, src_stride, groups, d_states, quant, reciprocal_sqrt_lambda, lam, reciprocal_lambda, sdh=1):
+    """havoc_search_intra_device: both stages of the intra partitions of all sizes, the decisions between the launches taken on the device.
+    groups: dicts(log2, n, d_nb, d_jobs, d_ictx, d_ctu, d_rec) of device addresses; quant: int32 [4, 4] (rqt_quant).
+    Returns ({log2: INTRA_RD_RESULT_DT[n]}, stats)"""
+    table = np.zeros(len(groups), INTRA_GROUP_DT)
+    outs = {}
+    for row, g in zip(table, groups):
+        out = np.zeros(g["n"], INTRA_RD_RESULT_DT)
+        outs[g["log2"]] = out
+        row["log2"], row["n"] = g["log2"], g["n"]
+        for k, name in (("d_nb", "d_neighbours"), ("d_jobs", "d_jobs"), ("d_ictx", "d_ictx"), ("d_ctu", "d_ctx_index"), ("d_rec", "d_rec")):
+            row[name] = _address(g[k])
+        row["out"] = out.ctypes.data
+    quant = np.ascontiguousarray(quant, np.int32)
+    stats = RqtStats()
+    rc = lib().havoc_search_intra_device(ctx, S, bit_depth, d_src, src_stride, table.ctypes.data, len(table), d_states, quant.ctypes.data, float(reciprocal_sqrt_lambda),
+                                         float(lam), float(reciprocal_lambda), int(sdh), C.byref(stats))
+    if rc != 0:
+        raise RuntimeError(f"havoc_search_intra_device failed ({rc})")
+    return outs, stats
 
 
 def intra_modes(ctx, S, bit_depth, log2, d_src, src_stride, d_neighbours, d_jobs, n, ictx, reciprocal_sqrt_lambda):
@@ -286,6 +319,7 @@ class DecisionPicture:
             src2d = self.host_planes[0].reshape(-1, self.stride)
             for log2, (jobs, nb, ictx, ctu) in workload.intra_partitions(src2d, width, height, self.PAD, seed + 31).items():
                 self.intra_parts[log2] = dict(jobs=jobs, nb=nb, ictx=ictx, ctu=ctu, d_jobs=hv.up(jobs), d_nb=hv.up(nb),
+                                              d_ictx=hv.up(np.ascontiguousarray(ictx).view(np.int32)), d_ctu=hv.up(np.ascontiguousarray(ctu, np.int32)),
                                               d_rec=hv.zeros(len(jobs) << (2 * log2), self.dt))
         hv.sync()
 
@@ -385,17 +419,29 @@ class DecisionPicture:
             hv.rdoq_d(bd, g["log2"], g["level"], g["coef"], self.d_states, g["d_rj"], g["cbf"], g["work"])
             hv.tu_reconstruct_d(bd, 0, g["log2"], g["inv"], g["dshift"], self.recon, self.stride, self.pred, self.W, src, self.stride, g["level"], g["d_fj"], g["ssd"])
 
-    def intra_decisions(self):
-        """the intra side of the picture: per partition size the 35-mode SATD stage (one launch) and its refinement order, then the RD refinement
-        of every candidate mode (havoc_search_intra_rd: one chain); returns {log2: (modes stage, RD champions)}"""
+    def intra_decisions(self, on_device=True):
+        """the intra side of the picture: per partition size the 35-mode SATD stage and its refinement order, then the RD refinement of every
+        candidate mode and the champions.  on_device: the order, the candidates' job records and the champions are decided by kernels between the
+        launches (havoc_search_intra_device: one call for all sizes, 40 bytes per partition come back); otherwise the two-call route with the
+        decisions on the host (havoc_search_intra_modes + havoc_search_intra_rd; the tests' link to the per-call loops).
+        Leaves {log2: (order or None, RD champions)} in self.intra_results and the calls' statistics in self.intra_stats"""
         hv = self.hv
         base = self.d_pic.data_ptr()
-        out = {}
-        for log2, g in sorted(self.intra_parts.items(), reverse=True):
-            order = intra_modes(hv.h, self.S, self.bd, log2, base, self.stride, g["d_nb"].data_ptr(), g["d_jobs"].data_ptr(), len(g["jobs"]), g["ictx"], self.rsl)
-            best, st = intra_rd(hv.h, self.S, self.bd, log2, base, self.stride, g["d_nb"].data_ptr(), g["jobs"], order, g["ictx"], g["ctu"], self.d_states.data_ptr(),
-                                self.quant[log2 - 2], self.lam, 1.0 / self.lam, g["d_rec"].data_ptr())
-            out[log2] = (order, best, st)
+        out, self.intra_stats = {}, []
+        if on_device:
+            groups = [dict(log2=log2, n=len(g["jobs"]), d_nb=g["d_nb"].data_ptr(), d_jobs=g["d_jobs"].data_ptr(), d_ictx=g["d_ictx"].data_ptr(), d_ctu=g["d_ctu"].data_ptr(),
+                           d_rec=g["d_rec"].data_ptr()) for log2, g in sorted(self.intra_parts.items(), reverse=True)]
+            best, st = intra_device(hv.h, self.S, self.bd, base, self.stride, groups, self.d_states.data_ptr(), self.quant, self.rsl, self.lam, 1.0 / self.lam)
+            out = {log2: (None, b) for log2, b in best.items()}
+            self.intra_stats.append(st)
+        else:
+            for log2, g in sorted(self.intra_parts.items(), reverse=True):
+                order = intra_modes(hv.h, self.S, self.bd, log2, base, self.stride, g["d_nb"].data_ptr(), g["d_jobs"].data_ptr(), len(g["jobs"]), g["ictx"], self.rsl)
+                best, st = intra_rd(hv.h, self.S, self.bd, log2, base, self.stride, g["d_nb"].data_ptr(), g["jobs"], order, g["ictx"], g["ctu"], self.d_states.data_ptr(),
+                                    self.quant[log2 - 2], self.lam, 1.0 / self.lam, g["d_rec"].data_ptr())
+                st.launches += 1      # the 35-mode stage
+                out[log2] = (order, best)
+                self.intra_stats.append(st)
         self.intra_results = out
         return out
 

@@ -93,6 +93,9 @@ def _load():
         "tu_forward": [_vp, _i, _i, _i, _i, _vp, _vp, _ip, _vp, _ip, _vp, _i],
         "tu_reconstruct": [_vp, _i, _i, _i, _i, _i, _i, _vp, _ip, _vp, _ip, _vp, _ip, _vp, _vp, _i, _vp],
         "level_stats": [_vp, _vp, _vp, _i, _vp],
+        "intra_order": [_vp, _vp, _vp, _i, C.c_int32, _vp, _vp, _vp, _vp],
+        "intra_expand": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+        "intra_decide": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, C.c_int32, _vp, _vp],
         "quantize": [_vp, _vp, _vp, _vp, _i, _vp],
         "quantize_inverse": [_vp, _vp, _vp, _vp, _i],
         "quantize_reconstruct": [_vp, _i, _vp, _ip, _vp, _ip, _vp, _vp, _i],

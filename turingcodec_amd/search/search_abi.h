@@ -124,6 +124,18 @@ typedef struct
     int32_t count;
 } havoc_search_intra_result;       /* 424 bytes */
 
+/* the intra partitions of ONE size of a picture, everything but `out` in device memory (havoc_search_intra_device) */
+typedef struct
+{
+    int32_t log2, n;
+    const void *d_neighbours;                       /* as for havoc_mi355x_intra_satd35 */
+    const void *d_jobs;                             /* havoc_mi355x_intra_search_job[n]: source block, neighbour arrays, filter mask */
+    const havoc_search_intra_ctx *d_ictx;           /* n: most probable modes and their rates */
+    const int32_t *d_ctx_index;                     /* n: which CABAC snapshot Rdoq reads */
+    void *d_rec;                                    /* champions' reconstructions: block i = n x n samples at i * n * n */
+    havoc_intra_rd_result *out;                     /* HOST, n */
+} havoc_intra_group;               /* 56 bytes */
+
 #ifdef __cplusplus
 }
 #endif

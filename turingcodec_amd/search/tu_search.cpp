@@ -373,4 +373,103 @@ int havoc_search_intra_rd(havoc_mi355x_ctx *ctx, int S, int bitDepth, int log2Tr
     return 0;
 }
 
+// Both stages of a picture's intra partitions (all sizes) with the decisions between the launches taken ON THE DEVICE
+// (havoc_mi355x_intra_order / _expand / _decide: csrc/kernels_decide.hip restates intraModeOrder and decideIntraRd lane per partition):
+//   per size:  intra_satd35 -> intra_order                                      | one wait: how many candidates each size has (8 bytes per size)
+//   per size:  intra_expand -> intra -> tu_forward -> rdoq -> tu_reconstruct -> level_stats -> intra_decide -> tu_reconstruct (champions)
+// What crosses the link: the group descriptions down, 40 bytes per partition (the decision) up.  The same results as
+// havoc_search_intra_modes + havoc_search_intra_rd, which take the decisions on the host and are what the tests compare this with.
+int havoc_search_intra_device(havoc_mi355x_ctx *ctx, int S, int bitDepth, const void *d_src, intptr_t src_stride, const havoc_intra_group *groups, int ngroups,
+                              const uint8_t *d_states, const havoc_rqt_quant quant[4], double reciprocal_sqrt_lambda, double lambda, double reciprocal_lambda, int sdh,
+                              havoc_rqt_stats *stats)
+{
+    if (!ctx || !d_src || !groups || ngroups < 0 || ngroups > 16 || !d_states || !quant || (S != 1 && S != 2)) return HAVOC_MI355X_EINVAL;
+    const double tStart = now();
+    havoc_rqt_stats st;
+    std::memset(&st, 0, sizeof(st));
+    Arena arena(ctx);
+    Lambda lsq, rl;
+    lsq.set(reciprocal_sqrt_lambda);
+    rl.set(reciprocal_lambda);
+    struct Work { void *dCost, *dOrder, *dCount, *dSlot, *dTotal, *hTotal; } work[16];
+    void *hx;
+    for (int g = 0; g < ngroups; ++g)
+    {
+        const havoc_intra_group &G = groups[g];
+        if (G.log2 < 2 || G.log2 > 5 || G.n < 0 || (G.n && (!G.d_neighbours || !G.d_jobs || !G.d_ictx || !G.d_ctx_index || !G.d_rec || !G.out))) return HAVOC_MI355X_EINVAL;
+        if (!G.n) continue;
+        Work &w = work[g];
+        RC(arena.get(size_t(G.n) * 35 * 4, &w.dCost, &hx));
+        RC(arena.get(size_t(G.n) * HAVOC_MI355X_INTRA_MAX_ORDER * 4, &w.dOrder, &hx));
+        RC(arena.get(size_t(G.n) * 4, &w.dCount, &hx));
+        RC(arena.get(size_t(G.n) * 4, &w.dSlot, &hx));
+        RC(arena.get(8, &w.dTotal, &w.hTotal));
+        RC(havoc_mi355x_intra_satd35(ctx, S, bitDepth, G.log2, d_src, src_stride, G.d_neighbours, static_cast<const havoc_mi355x_intra_search_job *>(G.d_jobs), G.n, static_cast<int32_t *>(w.dCost)));
+        RC(havoc_mi355x_intra_order(ctx, static_cast<const int32_t *>(w.dCost), reinterpret_cast<const havoc_mi355x_intra_mpm *>(G.d_ictx), G.n, lsq.value,
+                                    static_cast<int32_t *>(w.dOrder), static_cast<int32_t *>(w.dCount), static_cast<int32_t *>(w.dSlot), static_cast<int32_t *>(w.dTotal)));
+        RC(havoc_mi355x_d2h_async(ctx, w.hTotal, w.dTotal, 8));
+        st.launches += 2;
+    }
+    RC(havoc_mi355x_sync(ctx));
+    void *hOut[16] = {nullptr};
+    for (int g = 0; g < ngroups; ++g)
+    {
+        const havoc_intra_group &G = groups[g];
+        if (!G.n) continue;
+        const Work &w = work[g];
+        const int32_t *total = static_cast<const int32_t *>(w.hTotal);
+        if (total[1] || total[0] < 0 || total[0] > G.n * HAVOC_MI355X_INTRA_MAX_ORDER) return HAVOC_MI355X_EINVAL;      // max_refine + neighbour_modes beyond the slots
+        const int m = total[0], nn = 1 << G.log2, area = nn * nn, tr = G.log2 == 2 ? 1 : 0;
+        const havoc_rqt_quant &q = quant[G.log2 - 2];
+        int32_t lq, sf;
+        havoc_mi355x_rdoq_lambda(lambda, q.inv_scale, &lq, &sf);
+        void *dIj, *dTj, *dRj, *dSj, *dOwner, *dPred, *dPiece, *dCoef, *dLevel, *dWork, *dCbf, *dSsd, *dStats, *dFin, *dSsd2, *dOut, *vOut;
+        RC(arena.get(size_t(m) * sizeof(havoc_mi355x_intra_job), &dIj, &hx));
+        RC(arena.get(size_t(m) * sizeof(havoc_mi355x_tu_fused_job), &dTj, &hx));
+        RC(arena.get(size_t(m) * sizeof(havoc_mi355x_rdoq_job), &dRj, &hx));
+        RC(arena.get(size_t(m) * 8, &dSj, &hx));
+        RC(arena.get(size_t(m) * 4, &dOwner, &hx));
+        RC(arena.get(size_t(m) * area * S, &dPred, &hx));
+        RC(arena.get(size_t(m) * area * S, &dPiece, &hx));
+        RC(arena.get(size_t(m) * area * 2, &dCoef, &hx));
+        RC(arena.get(size_t(m) * area * 2, &dLevel, &hx));
+        RC(arena.get(havoc_mi355x_rdoq_workspace(m) + 64, &dWork, &hx));
+        RC(arena.get(size_t(m) * 4, &dCbf, &hx));
+        RC(arena.get(size_t(m) * 4, &dSsd, &hx));
+        RC(arena.get(size_t(m) * 8, &dStats, &hx));
+        RC(arena.get(size_t(G.n) * sizeof(havoc_mi355x_tu_fused_job), &dFin, &hx));
+        RC(arena.get(size_t(G.n) * 4, &dSsd2, &hx));
+        RC(arena.get(size_t(G.n) * sizeof(havoc_intra_rd_result), &dOut, &hOut[g], &vOut));
+        const havoc_mi355x_tu_fused_job *tj = static_cast<const havoc_mi355x_tu_fused_job *>(dTj);
+        RC(havoc_mi355x_intra_expand(ctx, static_cast<const havoc_mi355x_intra_search_job *>(G.d_jobs), static_cast<const int32_t *>(w.dOrder), static_cast<const int32_t *>(w.dCount), static_cast<const int32_t *>(w.dSlot),
+                                     G.d_ctx_index, G.n, G.log2, q.quant_scale, q.quant_shift, q.inv_scale, lq, sf, sdh, static_cast<havoc_mi355x_intra_job *>(dIj),
+                                     static_cast<havoc_mi355x_tu_fused_job *>(dTj), static_cast<havoc_mi355x_rdoq_job *>(dRj), static_cast<int32_t *>(dSj),
+                                     static_cast<int32_t *>(dOwner)));
+        RC(havoc_mi355x_intra(ctx, S, bitDepth, G.log2, dPred, nn, G.d_neighbours, static_cast<const havoc_mi355x_intra_job *>(dIj), m));
+        RC(havoc_mi355x_tu_forward(ctx, S, bitDepth, tr, G.log2, static_cast<int16_t *>(dCoef), d_src, src_stride, dPred, nn, tj, m));
+        RC(havoc_mi355x_rdoq(ctx, bitDepth, G.log2, static_cast<int16_t *>(dLevel), static_cast<const int16_t *>(dCoef), d_states, static_cast<const havoc_mi355x_rdoq_job *>(dRj),
+                             m, static_cast<int32_t *>(dCbf), dWork, havoc_mi355x_rdoq_workspace(m)));
+        RC(havoc_mi355x_tu_reconstruct(ctx, S, bitDepth, tr, G.log2, q.inv_scale, q.inv_shift, dPiece, nn, dPred, nn, d_src, src_stride, static_cast<const int16_t *>(dLevel), tj,
+                                       m, static_cast<uint32_t *>(dSsd)));
+        RC(havoc_mi355x_level_stats(ctx, static_cast<const int16_t *>(dLevel), static_cast<const int32_t *>(dSj), m, static_cast<int32_t *>(dStats)));
+        RC(havoc_mi355x_intra_decide(ctx, reinterpret_cast<const havoc_mi355x_intra_mpm *>(G.d_ictx), static_cast<const int32_t *>(w.dOrder),
+                                     static_cast<const int32_t *>(w.dCount), static_cast<const int32_t *>(w.dSlot), static_cast<const int32_t *>(dCbf),
+                                     static_cast<const uint32_t *>(dSsd), static_cast<const int32_t *>(dStats), tj, G.n, G.log2, rl.value,
+                                     static_cast<havoc_mi355x_intra_choice *>(vOut), static_cast<havoc_mi355x_tu_fused_job *>(dFin)));
+        RC(havoc_mi355x_tu_reconstruct(ctx, S, bitDepth, tr, G.log2, q.inv_scale, q.inv_shift, G.d_rec, nn, dPred, nn, d_src, src_stride, static_cast<const int16_t *>(dLevel),
+                                       static_cast<const havoc_mi355x_tu_fused_job *>(dFin), G.n, static_cast<uint32_t *>(dSsd2)));
+        st.launches += 8;
+        st.candidates += m;
+    }
+    RC(havoc_mi355x_sync(ctx));
+    st.seconds_gpu = now() - tStart;
+    const double tHost = now();
+    for (int g = 0; g < ngroups; ++g)
+        if (groups[g].n) std::memcpy(groups[g].out, hOut[g], size_t(groups[g].n) * sizeof(havoc_intra_rd_result));
+    st.seconds_host = now() - tHost;
+    st.seconds_total = now() - tStart;
+    if (stats) *stats = st;
+    return 0;
+}
+
 } // extern "C"
