@@ -31,6 +31,7 @@ extern "C" {
 
 #define HAVOC_MI355X_EINVAL (-10001) /* bad argument (S, taps, bit depth, size) */
 #define HAVOC_MI355X_ENODEV (-10002) /* no gfx950 device / HIP runtime unavailable */
+#define HAVOC_MI355X_EDEVICE (-10003) /* a kernel reported that it could not finish (havoc_mi355x_search_picture_uni: a wait gave up) */
 
 typedef struct havoc_mi355x_ctx havoc_mi355x_ctx;
 
@@ -543,6 +544,32 @@ int havoc_mi355x_intra_expand(havoc_mi355x_ctx *ctx, const havoc_mi355x_intra_se
 int havoc_mi355x_intra_decide(havoc_mi355x_ctx *ctx, const havoc_mi355x_intra_mpm *d_mpm, const int32_t *d_order, const int32_t *d_count, const int32_t *d_slot,
                               const int32_t *d_cbf, const uint32_t *d_ssd, const int32_t *d_stats, const havoc_mi355x_tu_fused_job *d_tu_jobs, int n, int log2TrafoSize,
                               int32_t reciprocal_lambda_q16, havoc_mi355x_intra_choice *d_out, havoc_mi355x_tu_fused_job *d_final);
+
+/* ---- a picture's uni-directional motion searches with the decision loops ON THE DEVICE (csrc/kernels_search.hip) ----
+ * The reference runs searchMotionUni (turing/Search.hpp:1317-1355: integer search :2060-2336, sub-sample refinement :2010-2061, 2340-2358) per
+ * prediction unit and list through the havoc_sad / havoc_sad_multiref / HavocPredUni / hadamard_satd tables.  Here the same loops (restated in
+ * turingcodec_amd/search/decision.hpp, compiled for gfx950) run inside the kernel with those primitives computed by the workgroup's lanes; the
+ * picture's PUs are walked in the encoder's order with the dependencies of turingcodec_amd/search/picture_order.hpp (derived predictors,
+ * mvPreviousInteger2Nx2N along the CTU row, CTU (x, y) after (x + 1, y - 1): TaskEncodeSubstream.cpp:71-95), one launch per wavefront step.
+ * The records are those of turingcodec_amd/search/search_abi.h: d_pus = havoc_picture_pu[] (CTU by CTU), d_ctu_first[ctus + 1],
+ * d_out = havoc_search_result[2 * n] (index 2 * pu + list), d_field = int16 [2][height / 4][width / 4][x, y] (the decided vectors),
+ * d_work = havoc_mi355x_search_workspace(width, height) bytes.  step_launches = 0: ONE launch, a workgroup per (CTU row, list) that waits in
+ * the kernel for the row above to be two CTUs ahead; a wait that does not end gives up (nothing hangs) and leaves a non-zero int32 in the last
+ * 4 bytes of d_work: the results are then invalid.  step_launches = 1: one launch per wavefront step (no waiting inside a kernel).  d_phase: the 16 fractional-sample planes of each reference picture
+ * (havoc_mi355x_interp_planes; plane 0 = the picture), which must reach ctb_size + 20 samples beyond the picture on every side; origins are the
+ * sample offsets of sample (0, 0).  Everything stays on the device: nothing is uploaded or downloaded by this call. */
+typedef struct
+{
+    int32_t pic_width, pic_height, ctb_size, concurrent_frames;
+    int32_t met, small_search_window, bi_small_search_window, half_pel, quarter_pel;
+    int32_t bit_depth;
+    double reciprocal_sqrt_lambda;
+} havoc_mi355x_search_params;      /* 48 bytes; = havoc_search_params */
+size_t havoc_mi355x_search_workspace(int width, int height);
+int havoc_mi355x_search_picture_uni(havoc_mi355x_ctx *ctx, int S, const havoc_mi355x_search_params *params, const int64_t mvp_rate[2], const void *d_src,
+                                    int64_t src_origin, intptr_t src_stride, const void *d_ref, const int64_t ref_origin[2], intptr_t ref_stride, const void *d_phase,
+                                    intptr_t plane_elems, const int64_t phase_origin[2], const void *d_pus, const int32_t *d_ctu_first, int ctus_x, int ctus_y,
+                                    void *d_out, int16_t *d_field, void *d_work, int step_launches);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,13 @@
+#!/bin/bash
+# round 3, GPU call N: where a device-resident search spends its time (wall-clock ticks written into the results by -DHAVOC_SEARCH_TIMING builds)
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/r03n
+mkdir -p $O
+cd $R
+cp turingcodec_amd/libhavoc_mi355x.so /tmp/keep.so
+for t in 1 3 4; do
+  cp turingcodec_amd/libhavoc_timing$t.so turingcodec_amd/libhavoc_mi355x.so
+  echo "timing variant $t (1 total, 2 staging, 3 integer stage, 4 sub-sample stage)"
+  timeout 300 python profiles/r03/search_timing_run.py 2>&1 | tail -1 | tee $O/timing_$t.json
+done
+cp /tmp/keep.so turingcodec_amd/libhavoc_mi355x.so

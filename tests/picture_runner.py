@@ -107,6 +107,27 @@ def main():
     for k in ("seconds_gpu", "seconds_host", "seconds_total"):
         d[k] = round(d[k], 5)
     report["picture"] = d
+    if args.device == "real":
+        # the same picture with the decision loops inside the kernel (havoc_search_picture_uni_device): no rounds, one launch per wavefront step
+        for form in ("steps", "rows"):      # one launch per wavefront step / one launch, rows waiting for each other inside the kernel (the default)
+            os.environ["HAVOC_SEARCH_STEP_LAUNCHES"] = "1" if form == "steps" else "0"
+            for attempt in range(args.repeat):
+                t0 = time.perf_counter()
+                got_d, field_d, stats_d = decisions.picture_uni(ctx, S, par, dpic.value, origin, stride, dpic.value, (pe + origin, 2 * pe + origin), stride, pad,
+                                                                dphase.value, pe, (origin, 16 * pe + origin), pus, first, cx, cy, rate, on_device=True)
+                t = time.perf_counter() - t0
+            if form == "steps":
+                report["on_device_step_launches"] = {"seconds": round(t, 5), "launches": int(stats_d.launches),
+                                                     "mismatches_vs_batch_client": len(same(got_d, got)), "field_equal_batch_client": bool(np.array_equal(field_d, field))}
+        report["on_device"] = {"seconds": round(t, 5), "pictures_per_second": round(1.0 / t, 2), "searches_per_second": round(2 * len(pus) / t, 1),
+                               "launches": int(stats_d.launches), "bytes_down": int(stats_d.bytes_down)}
+        fields = [k for k in got.dtype.names if k != "replays"]
+        report["on_device"]["mismatches_vs_batch_client"] = int(sum(any(not np.array_equal(got_d[k][i], got[k][i]) for k in fields) for i in range(len(got))))
+        report["on_device"]["field_equal_batch_client"] = bool(np.array_equal(field_d, field))
+        if expected is not None:
+            report["on_device"]["mismatches"] = len(same(got_d, expected))
+            report["on_device"]["mismatching_searches"] = same(got_d, expected)[:10]
+            report["on_device"]["field_equal"] = bool(np.array_equal(field_d, expected_field))
     if expected is not None:
         report["mismatching_searches"] = same(got, expected)[:20]
         report["mismatches"] = len(same(got, expected))

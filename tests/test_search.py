@@ -223,6 +223,14 @@ def test_picture_walk_over_oracle_equals_walk_over_reference_tables():
 def test_picture_client_on_the_gpu_equals_the_reference_walk(res, bit_depth):
     r = _run_picture("real", "--res", res, "--bit-depth", str(bit_depth), "--threads", "16")
     _check_picture(r)
+    # the same picture with the decision loops inside the kernel (csrc/kernels_search.hip): every field of every result and the motion field
+    # equal the walk over the reference's tables; one launch per wavefront step, only the results come back
+    d = r["on_device"]
+    assert d["mismatches"] == 0 and d["field_equal"] and d["mismatches_vs_batch_client"] == 0 and d["field_equal_batch_client"], d
+    assert d["launches"] == 1 and d["bytes_down"] < 100 * r["searches"], d
+    # ... and with one launch per wavefront step instead of rows waiting for each other inside one kernel
+    d = r["on_device_step_launches"]
+    assert d["mismatches_vs_batch_client"] == 0 and d["field_equal_batch_client"] and d["launches"] == r["picture"]["steps"], d
     out = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out) and res == "1920x1080":
         json.dump(r, open(os.path.join(out, "picture_report_1080p.json"), "w"), indent=1)

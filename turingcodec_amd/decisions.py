@@ -86,6 +86,9 @@ def lib():
         L.havoc_search_picture_uni.argtypes = [vp, C.c_int, C.POINTER(SearchParams), vp, i64, ip, vp, C.POINTER(i64), ip, C.c_int, vp, ip, C.POINTER(i64),
                                                vp, vp, C.c_int, C.c_int, C.POINTER(i64), vp, vp, C.c_int, C.POINTER(PictureStats)]
         L.havoc_search_picture_uni.restype = C.c_int
+        L.havoc_search_picture_uni_device.argtypes = [vp, C.c_int, C.POINTER(SearchParams), vp, i64, ip, vp, C.POINTER(i64), ip, C.c_int, vp, ip, C.POINTER(i64),
+                                                      vp, vp, C.c_int, C.c_int, C.POINTER(i64), vp, vp, vp, C.POINTER(PictureStats)]
+        L.havoc_search_picture_uni_device.restype = C.c_int
         L.havoc_search_rqt.argtypes = [vp, C.c_int, C.c_int, vp, i64, ip, vp, ip, vp, i64, ip, vp, vp, C.c_double, C.c_double, C.c_int, vp, C.c_int, vp,
                                        C.POINTER(RqtStats)]
         L.havoc_search_rqt.restype = C.c_int
@@ -105,8 +108,9 @@ def lib():
 
 
 def picture_uni(ctx, S, params, d_src, src_origin, src_stride, d_ref, ref_origin, ref_stride, ref_pad, d_phase, plane_elems, phase_origin, pus, ctu_first,
-                ctus_x, ctus_y, mvp_rate=(65536, 65536), threads=16, want_field=True):
-    """havoc_search_picture_uni.  ctx: havoc_mi355x context handle (int / c_void_p); d_*: device addresses (ints); ref_origin / phase_origin:
+                ctus_x, ctus_y, mvp_rate=(65536, 65536), threads=16, want_field=True, on_device=False, d_field_keep=None):
+    """havoc_search_picture_uni (launch + host replay rounds) or, on_device, havoc_search_picture_uni_device (the decision loops inside the kernel).
+    ctx: havoc_mi355x context handle (int / c_void_p); d_*: device addresses (ints); ref_origin / phase_origin:
     pairs (list 0, list 1).  Returns (results [2 * len(pus)] RESULT_DT indexed 2 * p + list, field int16 [2, cells_y, cells_x, 2] or None, stats)."""
     pus = np.ascontiguousarray(pus)
     assert pus.dtype == PICTURE_PU_DT
@@ -118,11 +122,16 @@ def picture_uni(ctx, S, params, d_src, src_origin, src_stride, d_ref, ref_origin
     ro = (C.c_int64 * 2)(*[int(v) for v in ref_origin])
     po = (C.c_int64 * 2)(*[int(v) for v in phase_origin])
     mr = (C.c_int64 * 2)(*[int(v) for v in mvp_rate])
-    rc = lib().havoc_search_picture_uni(ctx, S, C.byref(params), d_src, int(src_origin), src_stride, d_ref, ro, ref_stride, ref_pad, d_phase, plane_elems, po,
-                                        pus.ctypes.data, ctu_first.ctypes.data, ctus_x, ctus_y, mr, out.ctypes.data,
-                                        field.ctypes.data if want_field else None, threads, C.byref(stats))
+    if on_device:
+        rc = lib().havoc_search_picture_uni_device(ctx, S, C.byref(params), d_src, int(src_origin), src_stride, d_ref, ro, ref_stride, ref_pad, d_phase, plane_elems, po,
+                                                   pus.ctypes.data, ctu_first.ctypes.data, ctus_x, ctus_y, mr, out.ctypes.data,
+                                                   field.ctypes.data if want_field else None, d_field_keep, C.byref(stats))
+    else:
+        rc = lib().havoc_search_picture_uni(ctx, S, C.byref(params), d_src, int(src_origin), src_stride, d_ref, ro, ref_stride, ref_pad, d_phase, plane_elems, po,
+                                            pus.ctypes.data, ctu_first.ctypes.data, ctus_x, ctus_y, mr, out.ctypes.data,
+                                            field.ctypes.data if want_field else None, threads, C.byref(stats))
     if rc != 0:
-        raise RuntimeError(f"havoc_search_picture_uni failed ({rc})")
+        raise RuntimeError(f"havoc_search_picture_uni{'_device' if on_device else ''} failed ({rc})")
     return out, field, stats
 
 

@@ -93,6 +93,7 @@ def _load():
         "tu_forward": [_vp, _i, _i, _i, _i, _vp, _vp, _ip, _vp, _ip, _vp, _i],
         "tu_reconstruct": [_vp, _i, _i, _i, _i, _i, _i, _vp, _ip, _vp, _ip, _vp, _ip, _vp, _vp, _i, _vp],
         "level_stats": [_vp, _vp, _vp, _i, _vp],
+        "search_picture_uni": [_vp, _i, _vp, _vp, _vp, C.c_int64, _ip, _vp, _vp, _ip, _vp, _ip, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i],
         "intra_order": [_vp, _vp, _vp, _i, C.c_int32, _vp, _vp, _vp, _vp],
         "intra_expand": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
         "intra_decide": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, C.c_int32, _vp, _vp],
@@ -110,6 +111,8 @@ def _load():
     L.havoc_mi355x_rdoq_lambda.restype = None
     L.havoc_mi355x_rdoq_workspace.argtypes = [_i]
     L.havoc_mi355x_rdoq_workspace.restype = C.c_size_t
+    L.havoc_mi355x_search_workspace.argtypes = [_i, _i]
+    L.havoc_mi355x_search_workspace.restype = C.c_size_t
     for name, args in sig.items():
         f = getattr(L, "havoc_mi355x_" + name)
         f.argtypes = args
@@ -120,7 +123,8 @@ def _load():
 def exported_symbols():
     """names the C ABI must export (checked against include/havoc_mi355x.h by the CPU tests)"""
     _, names = _load()
-    return ["havoc_mi355x_" + n for n in names] + ["havoc_mi355x_last_error", "havoc_mi355x_version", "havoc_mi355x_rdoq_lambda", "havoc_mi355x_rdoq_workspace"]
+    return ["havoc_mi355x_" + n for n in names] + ["havoc_mi355x_last_error", "havoc_mi355x_version", "havoc_mi355x_rdoq_lambda", "havoc_mi355x_rdoq_workspace",
+                                                "havoc_mi355x_search_workspace"]
 
 
 # one havoc_mi355x_cell (include/havoc_mi355x.h), 16 bytes: a 4x4 luma cell of a picture's block structure

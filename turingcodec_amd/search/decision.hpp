@@ -20,7 +20,18 @@
 //   searchIntraPartition (SATD stage and candidate order)  Search.hpp:40-190
 // Everything outside the primitives is integer arithmetic on 16-bit vector components and Q16 costs; the order of
 // evaluation and the strict `<` comparisons are kept, because ties are decided by them.
+//
+// Since round 3 the same text is ALSO compiled for the device (csrc/kernels_search.hip: a workgroup per chain of searches runs these loops
+// with the primitives computed by its own lanes), hence the HAVOC_HD marks and the constexpr tables.
 #pragma once
+
+#if defined(__HIPCC__)
+#define HAVOC_HD __host__ __device__ __attribute__((always_inline))
+#define HAVOC_UNROLL _Pragma("unroll")      // device: the four candidates of a pattern step live in registers, not in an indexed array
+#else
+#define HAVOC_HD
+#define HAVOC_UNROLL
+#endif
 
 #include <cstdint>
 #include <cstdlib>
@@ -29,46 +40,46 @@
 namespace havoc_search {
 
 typedef int64_t Cost;                       // FixedPoint<int64_t, 16>
-constexpr Cost kCostMax = std::numeric_limits<int64_t>::max();
+constexpr Cost kCostMax = 0x7fffffffffffffffll;
 
 struct Lambda                               // FixedPoint<int32_t, 16>
 {
     int32_t value = 0;
-    void set(double d) { value = static_cast<int32_t>(d * (1 << 16) + 0.5); }   // FixedPoint::set(double)
-    Cost operator*(int32_t y) const { return int64_t(value) * int64_t(y); }
+    HAVOC_HD void set(double d) { value = static_cast<int32_t>(d * (1 << 16) + 0.5); }   // FixedPoint::set(double)
+    HAVOC_HD Cost operator*(int32_t y) const { return int64_t(value) * int64_t(y); }
 };
 
 struct Mv                                   // MotionVector: 16-bit components, quarter-sample units unless said otherwise
 {
     int16_t x = 0, y = 0;
-    Mv() {}
-    Mv(int x_, int y_) : x(int16_t(x_)), y(int16_t(y_)) {}
-    bool operator==(const Mv &o) const { return x == o.x && y == o.y; }
-    bool operator!=(const Mv &o) const { return !(*this == o); }
+    HAVOC_HD constexpr Mv() {}
+    HAVOC_HD constexpr Mv(int x_, int y_) : x(int16_t(x_)), y(int16_t(y_)) {}
+    HAVOC_HD bool operator==(const Mv &o) const { return x == o.x && y == o.y; }
+    HAVOC_HD bool operator!=(const Mv &o) const { return !(*this == o); }
 };
-inline Mv operator+(Mv a, Mv b) { return Mv(int16_t(a.x + b.x), int16_t(a.y + b.y)); }
-inline Mv operator-(Mv a, Mv b) { return Mv(int16_t(a.x - b.x), int16_t(a.y - b.y)); }
-inline Mv shr2(Mv a) { return Mv(int16_t(a.x >> 2), int16_t(a.y >> 2)); }
-inline Mv shl2(Mv a) { return Mv(int16_t(a.x << 2), int16_t(a.y << 2)); }
+HAVOC_HD inline Mv operator+(Mv a, Mv b) { return Mv(int16_t(a.x + b.x), int16_t(a.y + b.y)); }
+HAVOC_HD inline Mv operator-(Mv a, Mv b) { return Mv(int16_t(a.x - b.x), int16_t(a.y - b.y)); }
+HAVOC_HD inline Mv shr2(Mv a) { return Mv(int16_t(a.x >> 2), int16_t(a.y >> 2)); }
+HAVOC_HD inline Mv shl2(Mv a) { return Mv(int16_t(a.x << 2), int16_t(a.y << 2)); }
 
 // Measure.h:177-212: position of the highest set bit of |d|, 0 for 0 (both of the reference's branches -- the 32-step loop and
 // 32 - lzcnt -- compute this; a count-leading-zeros with the zero case spelt out is the cheap form: this runs four times per candidate)
-inline unsigned rateOfMvdComponent(int d)
+HAVOC_HD inline unsigned rateOfMvdComponent(int d)
 {
-    const unsigned u = unsigned(std::abs(d));
+    const unsigned u = unsigned(d < 0 ? -d : d);
     return u ? 32u - unsigned(__builtin_clz(u)) : 0u;
 }
 // Measure.h:214-220: Cost::make(r0 + r1 + 1, -1) = (r0 + r1 + 1) << 17
-inline Cost rateOf(Mv mvd) { return Cost(rateOfMvdComponent(mvd.x) + rateOfMvdComponent(mvd.y) + 1) << 17; }
+HAVOC_HD inline Cost rateOf(Mv mvd) { return Cost(rateOfMvdComponent(mvd.x) + rateOfMvdComponent(mvd.y) + 1) << 17; }
 
 struct MvCandidate                          // Search.hpp:1252-1314
 {
     Mv mv, mvd;
     Cost cost = kCostMax;
     int mvpFlag = 0;
-    MvCandidate() {}
+    HAVOC_HD MvCandidate() {}
     // best of the two predictors for this vector; mvpRate[k] = rate of mvp_lX_flag == k in the current CABAC state
-    MvCandidate(Mv mv_, const Mv predictors[2], const Cost mvpRate[2])
+    HAVOC_HD MvCandidate(Mv mv_, const Mv predictors[2], const Cost mvpRate[2])
     {
         mvpFlag = 0;
         mvd = mv_ - predictors[0];
@@ -80,7 +91,7 @@ struct MvCandidate                          // Search.hpp:1252-1314
         consider(temp);
         mv = mv_;
     }
-    bool consider(const MvCandidate &other)
+    HAVOC_HD bool consider(const MvCandidate &other)
     {
         const bool better = other.cost < cost;
         if (better) *this = other;
@@ -118,7 +129,7 @@ struct PuContext
 struct LimitFullPelMv                       // Search.hpp:1366-1407; full-sample units
 {
     Mv lo, hi;
-    LimitFullPelMv(const PuContext &pu, const SearchParams &sp)
+    HAVOC_HD LimitFullPelMv(const PuContext &pu, const SearchParams &sp)
     {
         lo = Mv(-sp.ctbSize - pu.x0, -sp.ctbSize - pu.y0);
         hi = Mv(sp.picWidth + sp.ctbSize - pu.x0 - pu.w, sp.picHeight + sp.ctbSize - pu.y0 - pu.h);
@@ -131,7 +142,7 @@ struct LimitFullPelMv                       // Search.hpp:1366-1407; full-sample
             if (wy < hi.y) hi.y = wy;
         }
     }
-    void operator()(Mv &mv) const
+    HAVOC_HD void operator()(Mv &mv) const
     {
         if (mv.x < lo.x) mv.x = lo.x;
         if (mv.y < lo.y) mv.y = lo.y;
@@ -158,6 +169,13 @@ struct UniResult
 //     int  satdQpel(Mv mv)                             HavocPredUni at the quarter-sample vector + measureSatd
 // (b)-type views may throw to ask for a replay once the missing data has been computed; the loops hold no state
 // outside their arguments, so a replay is just a second call.
+// a view that can evaluate several sub-sample positions at once (the device view: one wavefront per position) is told which ones the next
+// costMv calls will ask for; other views ignore it
+template <class View>
+HAVOC_HD inline auto hintSatd(View &v, const Mv *positions, int n, int) -> decltype(v.hintSatd(positions, n), void()) { v.hintSatd(positions, n); }
+template <class View>
+HAVOC_HD inline void hintSatd(View &, const Mv *, int, long) {}
+
 template <class View>
 struct MotionSearch
 {
@@ -169,18 +187,19 @@ struct MotionSearch
     MvCandidate best;
     int calls = 0;
 
-    MotionSearch(const SearchParams &sp_, const PuContext &pu_, View &view_) : sp(sp_), pu(pu_), view(view_), limit(pu_, sp_)
+    HAVOC_HD MotionSearch(const SearchParams &sp_, const PuContext &pu_, View &view_) : sp(sp_), pu(pu_), view(view_), limit(pu_, sp_)
     {
         lambda.set(sp.reciprocalSqrtLambda);
     }
 
     // Search.hpp:1447-1482.  origin in quarter units; pattern entries are multiplied by dist and divided by 4
-    bool considerPattern(Mv origin, const Mv *pattern, int n, int step, int dist)
+    HAVOC_HD bool considerPattern(Mv origin, const Mv *pattern, int n, int step, int dist)
     {
         bool improved = false;
         for (int j = 0; j < n; j += 4 * step)
         {
             Mv mv[4];
+            HAVOC_UNROLL
             for (int i = 0; i < 4; ++i, pattern += step)
             {
                 mv[i].x = int16_t((origin.x + dist * pattern->x) / 4);
@@ -190,6 +209,7 @@ struct MotionSearch
             int32_t sads[4];
             view.sad4(mv, sads);
             ++calls;
+            HAVOC_UNROLL
             for (int i = 0; i < 4; ++i)
             {
                 MvCandidate candidate(shl2(mv[i]), pu.mvp, pu.mvpRate);
@@ -201,26 +221,26 @@ struct MotionSearch
     }
 
     // the early-termination probe after an improving start point (Search.hpp:2112-2124 and twice more)
-    bool metTriggered()
+    HAVOC_HD bool metTriggered()
     {
-        static const Mv diamond[4] = {{-4, 0}, {0, 4}, {4, 0}, {0, -4}};
+        static constexpr Mv diamond[4] = {{-4, 0}, {0, 4}, {4, 0}, {0, -4}};
         bool triggerMet = !considerPattern(best.mv, diamond, 4, 1, 1);
         if (triggerMet && pu.cuLog2Size >= 5)
         {
-            static const Mv hexagon[8] = {{0, -8}, {8, -4}, {8, 4}, {0, 8}, {-8, 4}, {-8, -4}, {-8, 4}, {-8, -4}};
+            static constexpr Mv hexagon[8] = {{0, -8}, {8, -4}, {8, 4}, {0, 8}, {-8, 4}, {-8, -4}, {-8, 4}, {-8, -4}};
             triggerMet = !considerPattern(best.mv, hexagon, 8, 1, 1);
         }
         return triggerMet;
     }
 
-    int sadAt(Mv full)
+    HAVOC_HD int sadAt(Mv full)
     {
         ++calls;
         return view.sad(full.x, full.y);
     }
 
     // Search.hpp:2060-2336.  Returns true when mvPreviousInteger2Nx2N is to be updated with best.mv
-    bool fullPel(Cost costMvdZero[2])
+    HAVOC_HD bool fullPel(Cost costMvdZero[2])
     {
         const int searchWindow = sp.smallSearchWindow ? 32 : 64;
         const int maxCounter = sp.smallSearchWindow ? 2 : 3;
@@ -233,6 +253,7 @@ struct MotionSearch
             if (better && sp.met && metTriggered()) return false;
         }
         MvCandidate candidate;
+        HAVOC_UNROLL
         for (candidate.mvpFlag = 0; candidate.mvpFlag < 2; ++candidate.mvpFlag)
         {
             const Mv predicted = pu.mvp[candidate.mvpFlag];
@@ -261,9 +282,9 @@ struct MotionSearch
         // HM style "star" search
         Mv mvStart = best.mv;
         int distBest = 0, counter = 0, step = 4;
-        static const Mv diamond[16] = {{0, -4}, {1, -3}, {2, -2}, {3, -1}, {4, 0}, {3, 1}, {2, 2}, {1, 3},
+        static constexpr Mv diamond[16] = {{0, -4}, {1, -3}, {2, -2}, {3, -1}, {4, 0}, {3, 1}, {2, 2}, {1, 3},
                                        {0, 4}, {-1, 3}, {-2, 2}, {-3, 1}, {-4, 0}, {-3, -1}, {-2, -2}, {-1, -3}};
-        static const Mv square4[4] = {{-4, -4}, {-4, 4}, {4, 4}, {4, -4}};
+        static constexpr Mv square4[4] = {{-4, -4}, {-4, 4}, {4, 4}, {4, -4}};
         for (int dist = 1; dist <= searchWindow && counter < maxCounter; dist <<= 1)
         {
             if (dist == 2 || dist == 8) step >>= 1;
@@ -282,7 +303,7 @@ struct MotionSearch
         }
         if (distBest > 5)
         {   // raster refinement: absolute positions, every 5th full sample
-            static const Mv line[4] = {{0, 0}, {1, 0}, {2, 0}, {3, 0}};
+            static constexpr Mv line[4] = {{0, 0}, {1, 0}, {2, 0}, {3, 0}};
             for (int my = -rasterSearch; my <= rasterSearch; my += 20)
                 for (int mx = -rasterSearch; mx <= rasterSearch; mx += 80) considerPattern(Mv(mx, my), line, 4, 1, 20);
             distBest = 5;
@@ -308,8 +329,9 @@ struct MotionSearch
             int j;
             do
             {
-                static const Mv diamond4[4] = {{0, -1}, {-1, 0}, {0, 1}, {1, 0}};
+                static constexpr Mv diamond4[4] = {{0, -1}, {-1, 0}, {0, 1}, {1, 0}};
                 Mv mv[4];
+                HAVOC_UNROLL
                 for (int i = 0; i < 4; ++i)
                 {
                     mv[i] = Mv(int16_t(best.mv.x / 4), int16_t(best.mv.y / 4)) + diamond4[i];
@@ -319,6 +341,7 @@ struct MotionSearch
                 view.sad4(mv, sads);
                 ++calls;
                 j = -1;
+                HAVOC_UNROLL
                 for (int i = 0; i < 4; ++i)
                 {
                     MvCandidate temp(shl2(mv[i]), pu.mvp, pu.mvpRate);
@@ -331,15 +354,22 @@ struct MotionSearch
     }
 
     // costMv, Search.hpp:2001-2006 (no mvp-flag rate here)
-    Cost costMv(Mv mv, Mv mvd)
+    HAVOC_HD Cost costMv(Mv mv, Mv mvd)
     {
         ++calls;
         return rateOf(mvd) + lambda * view.satdQpel(mv);
     }
 
     // Search.hpp:2010-2061 with maxIterations = 1, the only way subPelRefinement calls it
-    void patternSearchOnce(const Mv (&pattern)[8], bool tryOrigin, Mv &mv, Mv &mvd, Cost &bestCost)
+    HAVOC_HD void patternSearchOnce(const Mv (&pattern)[8], bool tryOrigin, Mv &mv, Mv &mvd, Cost &bestCost)
     {
+        {
+            Mv ask[9];
+            HAVOC_UNROLL
+            for (int i = 0; i < 8; ++i) ask[i] = mv + pattern[i];
+            ask[8] = mv;
+            hintSatd(view, ask, tryOrigin ? 9 : 8, 0);
+        }
         if (tryOrigin) bestCost = costMv(mv, mvd);
         int bestI = -1;
         for (int i = 0; i < 8; ++i)
@@ -369,7 +399,7 @@ struct MotionSearch
         Cost costMvdZero[2] = {kCostMax, kCostMax};
     };
 
-    UniResult run(IntegerStage *keep = nullptr)
+    HAVOC_HD UniResult run(IntegerStage *keep = nullptr)
     {
         UniResult r;
         if (keep && keep->valid)
@@ -399,11 +429,11 @@ struct MotionSearch
         Mv mv = best.mv, mvd = best.mvd;
         if (sp.halfPel)
         {
-            static const Mv half[8] = {{-2, -2}, {0, -2}, {2, -2}, {-2, 0}, {2, 0}, {-2, 2}, {0, 2}, {2, 2}};
+            static constexpr Mv half[8] = {{-2, -2}, {0, -2}, {2, -2}, {-2, 0}, {2, 0}, {-2, 2}, {0, 2}, {2, 2}};
             patternSearchOnce(half, true, mv, mvd, r.costSubPel);
             if (sp.quarterPel)
             {
-                static const Mv quarter[8] = {{-1, -1}, {0, -1}, {1, -1}, {-1, 0}, {1, 0}, {-1, 1}, {0, 1}, {1, 1}};
+                static constexpr Mv quarter[8] = {{-1, -1}, {0, -1}, {1, -1}, {-1, 0}, {1, 0}, {-1, 1}, {0, 1}, {1, 1}};
                 patternSearchOnce(quarter, false, mv, mvd, r.costSubPel);
             }
         }
@@ -427,7 +457,7 @@ struct BiResult
 };
 
 template <class BiView>
-BiResult searchMotionBi(const SearchParams &sp, const PuContext &pu, BiView &view, Mv startingMv)
+HAVOC_HD BiResult searchMotionBi(const SearchParams &sp, const PuContext &pu, BiView &view, Mv startingMv)
 {
     BiResult r;
     LimitFullPelMv limit(pu, sp);
@@ -509,7 +539,7 @@ struct IntraResult
 };
 
 // satd35[m] = the distortion predictIntraLuma returns for mode m (prediction + Hadamard SATD against the source)
-inline IntraResult intraModeOrder(const IntraContext &ic, double reciprocalSqrtLambda, const int32_t satd35[35])
+HAVOC_HD inline IntraResult intraModeOrder(const IntraContext &ic, double reciprocalSqrtLambda, const int32_t satd35[35])
 {
     IntraResult r;
     Lambda lambda;

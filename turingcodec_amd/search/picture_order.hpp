@@ -39,8 +39,8 @@ struct MotionField
             valid[l].assign(size_t(cw) * ch, 0);
         }
     }
-    static int32_t pack(Mv v) { return int32_t(uint16_t(v.x)) | (int32_t(uint16_t(v.y)) << 16); }
-    static Mv unpack(int32_t p) { return Mv(int16_t(p & 0xffff), int16_t(uint32_t(p) >> 16)); }
+    HAVOC_HD static int32_t pack(Mv v) { return int32_t(uint16_t(v.x)) | (int32_t(uint16_t(v.y)) << 16); }
+    HAVOC_HD static Mv unpack(int32_t p) { return Mv(int16_t(p & 0xffff), int16_t(uint32_t(p) >> 16)); }
     bool inside(int x, int y) const { return x >= 0 && y >= 0 && (x >> 2) < cw && (y >> 2) < ch; }
     bool get(int list, int x, int y, Mv *v) const
     {
@@ -105,7 +105,7 @@ struct LocalField
 
 // the two predictors of PU q in `list`, read through `get(list, x, y, &mv)` (false = unavailable)
 template <class Get>
-inline void derivePredictors(const havoc_picture_pu &q, int list, int picW, int picH, Get get, Mv mvp[2])
+HAVOC_HD inline void derivePredictors(const havoc_picture_pu &q, int list, int picW, int picH, Get get, Mv mvp[2])
 {
     Mv a, b;
     const int ax = q.x0 - 1, ay = q.y0 + q.h - 1, bx = q.x0 + q.w - 1, by = q.y0 - 1;
@@ -115,7 +115,7 @@ inline void derivePredictors(const havoc_picture_pu &q, int list, int picW, int 
     mvp[1] = (haveA && haveB && a != b) ? b : Mv(0, 0);
 }
 
-inline PuContext contextOf(const havoc_picture_pu &q, int ctb, const Mv mvp[2], const Cost mvpRate[2], Mv mvPrevious2Nx2N)
+HAVOC_HD inline PuContext contextOf(const havoc_picture_pu &q, int ctb, const Mv mvp[2], const Cost mvpRate[2], Mv mvPrevious2Nx2N)
 {
     PuContext pu;
     pu.x0 = q.x0; pu.y0 = q.y0; pu.w = q.w; pu.h = q.h;

@@ -373,4 +373,66 @@ int havoc_search_picture_uni(havoc_mi355x_ctx *ctx, int S, const havoc_search_pa
     return 0;
 }
 
+// The same picture with the decision loops ON THE DEVICE (havoc_mi355x_search_picture_uni, csrc/kernels_search.hip: decision.hpp compiled for
+// gfx950, one workgroup per chain of dependent searches, one launch per wavefront step): the PU list goes down, the results come back, nothing in
+// between -- no surfaces, no rounds, no replay threads.  Arguments as havoc_search_picture_uni; the phase planes must reach 84 samples beyond the
+// picture (ref_pad >= 96 with the planes of havoc_mi355x_interp_planes(12, 4, ...)).  Results identical to havoc_search_picture_uni's except
+// `replays` (0 here).  d_field_keep (optional, device): where the decided field stays for later launches (int16 [2][cells][2]).
+int havoc_search_picture_uni_device(havoc_mi355x_ctx *ctx, int S, const havoc_search_params *params, const void *d_src, int64_t src_origin, intptr_t src_stride,
+                                    const void *d_ref, const int64_t ref_origin[2], intptr_t ref_stride, int ref_pad, const void *d_phase, intptr_t plane_elems,
+                                    const int64_t phase_origin[2], const havoc_picture_pu *pus, const int32_t *ctu_first, int ctus_x, int ctus_y,
+                                    const int64_t mvp_rate[2], havoc_search_result *out, int16_t *field_out, int16_t *d_field_keep, havoc_picture_stats *stats)
+{
+    if (!ctx || !params || !pus || !ctu_first || !out || !ref_origin || !phase_origin || !mvp_rate || (S != 1 && S != 2) || ctus_x < 1 || ctus_y < 1 || ref_pad < 96)
+        return HAVOC_MI355X_EINVAL;
+    const double tStart = now();
+    const int W = params->pic_width, H = params->pic_height;
+    if (params->ctb_size != 64 || ctus_x != (W + 63) / 64 || ctus_y != (H + 63) / 64) return HAVOC_MI355X_EINVAL;
+    const int nCtus = ctus_x * ctus_y, nPus = ctu_first[nCtus];
+    for (int c = 0; c < nCtus; ++c)
+        for (int p = ctu_first[c]; p < ctu_first[c + 1]; ++p)
+        {
+            const havoc_picture_pu &q = pus[p];
+            if (q.w < 4 || q.h < 4 || q.w > 64 || q.h > 64 || (q.w & 3) || (q.h & 3) || q.x0 < 0 || q.y0 < 0 || q.x0 + q.w > W || q.y0 + q.h > H ||
+                q.x0 / 64 != c % ctus_x || q.y0 / 64 != c / ctus_x || (q.x0 + q.w - 1) / 64 != c % ctus_x || (q.y0 + q.h - 1) / 64 != c / ctus_x)
+                return HAVOC_MI355X_EINVAL;
+        }
+    havoc_picture_stats pst;
+    std::memset(&pst, 0, sizeof(pst));
+    Arena arena(ctx);
+    const int stepLaunches = getenv("HAVOC_SEARCH_STEP_LAUNCHES") && atoi(getenv("HAVOC_SEARCH_STEP_LAUNCHES")) ? 1 : 0;      // diagnostic switch (profiles/)
+    const size_t cells = size_t((W + 3) / 4) * ((H + 3) / 4);
+    void *dPus, *hPus, *vPus, *dFirst, *hFirst, *vFirst, *dOut, *hOut, *dField, *hField, *dWork, *hx;
+    HAVOC_SEARCH_RC(arena.get(size_t(std::max(1, nPus)) * sizeof(havoc_picture_pu), &dPus, &hPus, &vPus));
+    HAVOC_SEARCH_RC(arena.get(size_t(nCtus + 1) * 4, &dFirst, &hFirst, &vFirst));
+    HAVOC_SEARCH_RC(arena.get(size_t(std::max(1, 2 * nPus)) * sizeof(havoc_search_result), &dOut, &hOut));
+    HAVOC_SEARCH_RC(arena.get(2 * cells * 4, &dField, &hField));
+    HAVOC_SEARCH_RC(arena.get(havoc_mi355x_search_workspace(W, H), &dWork, &hx));
+    std::memcpy(hPus, pus, size_t(nPus) * sizeof(havoc_picture_pu));
+    std::memcpy(hFirst, ctu_first, size_t(nCtus + 1) * 4);
+    HAVOC_SEARCH_RC(havoc_mi355x_h2d_async(ctx, dPus, hPus, size_t(nPus) * sizeof(havoc_picture_pu)));
+    HAVOC_SEARCH_RC(havoc_mi355x_h2d_async(ctx, dFirst, hFirst, size_t(nCtus + 1) * 4));
+    int16_t *field = d_field_keep ? d_field_keep : static_cast<int16_t *>(dField);
+    havoc_mi355x_search_params dp;
+    static_assert(sizeof(dp) == sizeof(*params), "search ABI");
+    std::memcpy(&dp, params, sizeof(dp));
+    HAVOC_SEARCH_RC(havoc_mi355x_search_picture_uni(ctx, S, &dp, mvp_rate, d_src, src_origin, src_stride, d_ref, ref_origin, ref_stride, d_phase, plane_elems, phase_origin,
+                                                    dPus, static_cast<const int32_t *>(dFirst), ctus_x, ctus_y, dOut, field, dWork, stepLaunches));
+    void *dFlag, *hFlag;
+    HAVOC_SEARCH_RC(arena.get(4, &dFlag, &hFlag));
+    HAVOC_SEARCH_RC(havoc_mi355x_d2h_async(ctx, hFlag, static_cast<char *>(dWork) + havoc_mi355x_search_workspace(W, H) - 4, 4));
+    HAVOC_SEARCH_RC(havoc_mi355x_d2h_async(ctx, hOut, dOut, size_t(2 * nPus) * sizeof(havoc_search_result)));
+    if (field_out) HAVOC_SEARCH_RC(havoc_mi355x_d2h_async(ctx, hField, field, 2 * cells * 4));
+    HAVOC_SEARCH_RC(havoc_mi355x_sync(ctx));
+    if (*static_cast<const int32_t *>(hFlag)) return HAVOC_MI355X_EDEVICE;      // a row's wait gave up
+    std::memcpy(out, hOut, size_t(2 * nPus) * sizeof(havoc_search_result));
+    if (field_out) std::memcpy(field_out, hField, 2 * cells * 4);
+    pst.steps = ctus_x + 2 * (ctus_y - 1);
+    pst.launches = stepLaunches ? pst.steps : 1;
+    pst.bytes_down = int64_t(2 * nPus) * sizeof(havoc_search_result) + (field_out ? int64_t(2 * cells * 4) : 0);
+    pst.seconds_gpu = pst.seconds_total = now() - tStart;
+    if (stats) *stats = pst;
+    return 0;
+}
+
 } // extern "C"
