@@ -52,9 +52,12 @@ def parse_args():
                     help="1 (default): the plain N=1 line also carries, under `extra`, the DECISION-DRIVEN path (turingcodec_amd.decisions."
                          "DecisionPicture: motion searches in WPP wavefront order with predictors derived from earlier decisions, batch-fed; then the "
                          "TU chain on the chosen vectors) at 1080p QP32 and 4K QP32, and its ratio to `value`; 2: only that (diagnostic line); 0: off")
-    ap.add_argument("--decision-pictures", type=int, default=8, help="contexts built for the decision-driven path: `value` is measured with 4 independent pictures in flight (the "
-                    "leaf B pictures of one SOP), and again with all of them (8 = what the pipelined hierarchy has in flight); one host thread + context "
-                    "each, the replay threads shared out between them")
+    ap.add_argument("--decision-pictures", type=int, default=16, help="contexts built for the decision-driven path: `value` is measured with 4 independent pictures in flight (the "
+                    "leaf B pictures of one SOP), and again with 8 (what the pipelined hierarchy has in flight) and with all of them; one host thread + "
+                    "context each")
+    ap.add_argument("--search-client", choices=["device", "batch"], default="device",
+                    help="the motion searches of the decision-driven path: `device` = the decision loops inside the kernel (csrc/kernels_search.hip, one launch "
+                         "per picture); `batch` = SAD-surface / tile-SATD launches + the loops replayed on host threads (search/picture_search.cpp)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
@@ -1091,7 +1094,7 @@ def decision_path(args, Havoc, res, bit_depth, qp, pictures, seconds=1.5, keep=N
     ctxs = []
     for k in range(pictures):
         hv = Havoc(0, stream="new")
-        ctxs.append(DecisionPicture(hv, w, h, bit_depth, qp, seed=args.seed + 13 * k, threads=per))
+        ctxs.append(DecisionPicture(hv, w, h, bit_depth, qp, seed=args.seed + 13 * k, threads=per, search_on_device=args.search_client == "device"))
     for dp in ctxs:
         dp.step()      # allocates the client's pinned work memory, pages code in
     # one picture alone, all replay threads: the latency a dependency-bound encoder sees
@@ -1137,10 +1140,21 @@ def decision_path(args, Havoc, res, bit_depth, qp, pictures, seconds=1.5, keep=N
     ndone, el = throughput(first, seconds)
     done = [ndone]
     more = {}
-    if pictures > first:
-        n2, e2 = throughput(pictures, seconds)
-        more = {"pictures_in_flight_%d" % pictures: {"value": round(n2 / e2, 2), "unit": "pictures/s", "replay_threads_per_picture": max(1, cores // pictures),
-                                                      "note": "as many independent pictures as the hierarchical-B pipeline has in flight across SOPs (SURVEY 8(e))"}}
+    for count in sorted({c for c in (8, pictures) if first < c <= pictures}):
+        n2, e2 = throughput(count, seconds)
+        more["pictures_in_flight_%d" % count] = {"value": round(n2 / e2, 2), "unit": "pictures/s", "host_threads_per_picture": max(1, cores // count),
+                                                 "note": "8 = as many independent pictures as the hierarchical-B pipeline has in flight across SOPs (SURVEY 8(e)); "
+                                                         "more = several such pipelines (streams) on one device"}
+    if args.search_client == "device" and args.decisions == 2:
+        # the same picture alone through the launch + host replay client, for comparison
+        solo.search_on_device = False
+        solo.threads = cores
+        solo.search()
+        t0 = time.perf_counter()
+        _, _, bstats = solo.search()
+        more["searches_by_the_batch_client_alone_ms"] = {"value": round((time.perf_counter() - t0) * 1e3, 3), "rounds": int(bstats.rounds), "launches": int(bstats.launches),
+                                                         "bytes_down": int(bstats.bytes_down), "replay_threads": cores}
+        solo.search_on_device = True
     per, pictures = max(1, cores // first), first
     d = stats.as_dict()
     out = {"value": round(sum(done) / el, 2), "unit": "pictures/s", "pictures_in_flight": pictures, "host_threads": cores, "replay_threads_per_picture": per,
@@ -1165,10 +1179,12 @@ def decision_path(args, Havoc, res, bit_depth, qp, pictures, seconds=1.5, keep=N
            "surfaces": d["surfaces_small"] + d["surfaces_zero"] + d["surfaces_large"], "satd_jobs": d["satd_jobs"],
            "searches_run_ahead_on_a_guess": d["speculative_runs"], "searches_rerun": d["reruns"], "bytes_down": d["bytes_down"],
            "client_seconds": {"gpu_rounds": round(d["seconds_gpu"], 5), "host_replay": round(d["seconds_host"], 5), "total": round(d["seconds_total"], 5)},
+           "search_client": ("decision loops inside the kernel (csrc/kernels_search.hip: search/decision.hpp compiled for gfx950; a workgroup per (CTU row, list) "
+                             "waits for the row above inside ONE launch; window, source block and neighbour vectors in LDS); only the results come back"
+                             if args.search_client == "device" else "SAD-surface / tile-SATD batch launches, the reference's loops replayed on host threads"),
            "what": "per picture: 2 x 15 phase planes; every PU's uni-directional search in both lists, CTUs in WPP wavefront order (CTU (x, y) after "
                    "(x + 1, y - 1)), predictors of a PU = the vectors decided for its left / upper neighbours, mvPreviousInteger2Nx2N handed along the CTU "
-                   "row (turingcodec_amd/search/picture_order.hpp) -- fed by SAD-surface / tile-SATD batch launches, the reference's loops replayed on "
-                   "host threads; then prediction at the chosen vectors and the residual-quadtree decision of every inter unit (both tree depths of "
+                   "row (turingcodec_amd/search/picture_order.hpp); then prediction at the chosen vectors and the residual-quadtree decision of every inter unit (both tree depths of "
                    "every 32x32 unit through residual + DCT -> RDOQ -> IQ + IDCT + add -> SSD in one chain per transform size, decisions from 16 bytes per "
                    "candidate, chosen candidates reconstructed into the picture; turingcodec_amd/search/tu_decision.hpp), boundary strengths derived on "
                    "the device, deblocking, padding; and the picture's intra candidates (42 partitions per CTU: 35-mode SATD stage, then every candidate "

@@ -227,7 +227,8 @@ def test_picture_client_on_the_gpu_equals_the_reference_walk(res, bit_depth):
     # equal the walk over the reference's tables; one launch per wavefront step, only the results come back
     d = r["on_device"]
     assert d["mismatches"] == 0 and d["field_equal"] and d["mismatches_vs_batch_client"] == 0 and d["field_equal_batch_client"], d
-    assert d["launches"] == 1 and d["bytes_down"] < 100 * r["searches"], d
+    w, h = (int(v) for v in res.split("x"))
+    assert d["launches"] == 1 and d["bytes_down"] == 56 * r["searches"] + 8 * (w // 4) * (h // 4), d      # the results and the motion field
     # ... and with one launch per wavefront step instead of rows waiting for each other inside one kernel
     d = r["on_device_step_launches"]
     assert d["mismatches_vs_batch_client"] == 0 and d["field_equal_batch_client"] and d["launches"] == r["picture"]["steps"], d

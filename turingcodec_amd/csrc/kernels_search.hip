@@ -228,7 +228,10 @@ struct DeviceView
     int bx0, by0, bx1, by1, wsB;      // displacements [bx0, bx1] x [by0, by1] are answered from the staged window (row pitch wsB bytes)
     int sadTurn = 0, satdTurn = 0, satdCount = 0;
 #ifdef HAVOC_SEARCH_TIMING
-    long tHint = 0;
+    long tHint = 0, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define TICK(k, expr) { const long t_ = clock64(); expr; acc[k] += clock64() - t_; }
+#else
+#define TICK(k, expr) { expr; }
 #endif
 
     __device__ __forceinline__ int sadOne(int dx, int dy) const
@@ -238,17 +241,32 @@ struct DeviceView
         return wave_sad<S>(ldsPtr(x->src), w * S, ref + dy * sbb + (long)dx * S, sbb, w, h, lane);
     }
 
-    __device__ __forceinline__ int sad(int dx, int dy) { return sadOne(dx, dy); }
+    __device__ __forceinline__ int sad(int dx, int dy)
+    {
+        int v;
+        TICK(0, v = sadOne(dx, dy));
+        return v;
+    }
 
     __device__ __forceinline__ void sad4(const Mv d[4], int32_t out[4])
     {
-        const Mv m = wave == 0 ? d[0] : (wave == 1 ? d[1] : (wave == 2 ? d[2] : d[3]));
-        const int v = sadOne(m.x, m.y);
+        // this wavefront's position, picked with masks: a choice between d[0..3] by address would keep the caller's array in (per-lane) private
+        // memory, and whatever is read from there counts as divergent -- the whole decision state would leave the scalar registers
+        const int s0 = -(wave == 0), s1 = -(wave == 1), s2 = -(wave == 2), s3 = -(wave == 3);
+        const int mx = (d[0].x & s0) | (d[1].x & s1) | (d[2].x & s2) | (d[3].x & s3), my = (d[0].y & s0) | (d[1].y & s1) | (d[2].y & s2) | (d[3].y & s3);
+        int v;
+        TICK(0, v = sadOne(mx, my));
         sadTurn ^= 1;
+#ifdef HAVOC_SEARCH_TIMING
+        const long c0 = clock64();
+#endif
         if (lane == 0) x->sad[sadTurn][wave] = v;
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 4; ++i) out[i] = __builtin_amdgcn_readfirstlane(x->sad[sadTurn][i]);
+#ifdef HAVOC_SEARCH_TIMING
+        acc[1] += clock64() - c0;
+#endif
     }
 
     __device__ __forceinline__ const char *predAt(Mv mv) const
@@ -261,6 +279,7 @@ struct DeviceView
     {
 #ifdef HAVOC_SEARCH_TIMING
         if (!tHint) tHint = wall_clock64();
+        const long c0 = clock64();
 #endif
         satdTurn ^= 1;
         satdCount = n;
@@ -271,6 +290,9 @@ struct DeviceView
         for (int i = 0; i < 9; ++i)
             if (i < n && tid == i) x->key[satdTurn][i] = havoc_search::MotionField::pack(positions[i]);
         __syncthreads();
+#ifdef HAVOC_SEARCH_TIMING
+        const long c1 = clock64();
+#endif
         if (rows > 32)
         {
             for (int i = wave; i < n; i += 4)
@@ -355,14 +377,31 @@ struct DeviceView
                 if (j < n && l == 0) x->satd[satdTurn][j] = v;
             }
         }
+#ifdef HAVOC_SEARCH_TIMING
+        const long c2 = clock64();
+#endif
         __syncthreads();
+#ifdef HAVOC_SEARCH_TIMING
+        const long c3 = clock64();
+        acc[2] += c1 - c0; acc[3] += c2 - c1; acc[4] += c3 - c2;
+#endif
     }
 
     __device__ __forceinline__ int satdQpel(Mv mv)
     {
         const int32_t k = havoc_search::MotionField::pack(mv);
+#ifdef HAVOC_SEARCH_TIMING
+        const long c0 = clock64();
+#endif
         for (int i = 0; i < satdCount; ++i)
-            if (__builtin_amdgcn_readfirstlane(x->key[satdTurn][i]) == k) return __builtin_amdgcn_readfirstlane(x->satd[satdTurn][i]);
+            if (__builtin_amdgcn_readfirstlane(x->key[satdTurn][i]) == k)
+            {
+                const int v = __builtin_amdgcn_readfirstlane(x->satd[satdTurn][i]);
+#ifdef HAVOC_SEARCH_TIMING
+                acc[5] += clock64() - c0;
+#endif
+                return v;
+            }
         return wave_satd<S>(ldsPtr(x->src), w * S, predAt(mv), sbb, w, h, lane);      // not announced: every wavefront computes it
     }
 };
@@ -392,7 +431,7 @@ __device__ __forceinline__ void search_ctu(const SearchArgs &a, Lds<S> &x, const
     for (int p = first; p < last; ++p)
     {
 #ifdef HAVOC_SEARCH_TIMING
-        const long tTop = wall_clock64();
+        const long tTop = wall_clock64(), cTop = clock64();
 #endif
         const havoc_picture_pu q = a.pus[p];
         Mv mvp[2];
@@ -457,7 +496,7 @@ __device__ __forceinline__ void search_ctu(const SearchArgs &a, Lds<S> &x, const
         havoc_search::MotionSearch<DeviceView<S>> search(a.sp, pu, view);
         const havoc_search::UniResult r = search.run();
 #ifdef HAVOC_SEARCH_TIMING
-        const long tEnd = wall_clock64();
+        const long tEnd = wall_clock64(), cEnd = clock64();
 #endif
         if (tid == 0)
         {
@@ -471,6 +510,8 @@ __device__ __forceinline__ void search_ctu(const SearchArgs &a, Lds<S> &x, const
             o.replays = 0;
 #ifdef HAVOC_SEARCH_TIMING
             o.replays = HAVOC_SEARCH_TIMING == 1 ? int(tEnd - tTop) : (HAVOC_SEARCH_TIMING == 2 ? int(tStaged - tTop) : (HAVOC_SEARCH_TIMING == 3 ? int(view.tHint - tStaged) : int(tEnd - view.tHint)));
+            if (HAVOC_SEARCH_TIMING >= 5 && HAVOC_SEARCH_TIMING <= 10) o.replays = int(view.acc[HAVOC_SEARCH_TIMING - 5]);
+            if (HAVOC_SEARCH_TIMING == 11) o.replays = int(cEnd - cTop);
 #endif
             o.cost_integer = r.costInteger;
             o.cost_subpel = r.costSubPel;

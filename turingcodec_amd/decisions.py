@@ -261,12 +261,13 @@ class DecisionPicture:
 
     PAD = 96
 
-    def __init__(self, hv, width, height, bit_depth=8, qp=32, seed=11, threads=16, frames=None, density=1.0, intra=True):
+    def __init__(self, hv, width, height, bit_depth=8, qp=32, seed=11, threads=16, frames=None, density=1.0, intra=True, search_on_device=True):
         import torch
         from . import havoc as hmod
         from . import workload
         self.hv, self.torch, self.hmod = hv, torch, hmod
         self.W, self.H, self.bd, self.qp, self.threads = width, height, bit_depth, qp, threads
+        self.search_on_device = search_on_device      # the decision loops inside the kernel (kernels_search.hip) / launch + host replay rounds
         self.S = 1 if bit_depth == 8 else 2
         self.dt = np.uint8 if self.S == 1 else np.uint16
         d = decision_inputs(width, height, bit_depth, qp, seed, density, frames)
@@ -345,7 +346,7 @@ class DecisionPicture:
         hv, pe, o = self.hv, self.pe, self.origin
         base, ph = self.d_pic.data_ptr(), self.d_phase.data_ptr()
         return picture_uni(hv.h, self.S, self.params, base, o, self.stride, base, (pe + o, 2 * pe + o), self.stride, self.PAD, ph, pe, (o, 16 * pe + o),
-                           self.pus, self.ctu_first, self.cx, self.cy, self.mvp_rate, self.threads)
+                           self.pus, self.ctu_first, self.cx, self.cy, self.mvp_rate, self.threads, on_device=self.search_on_device)
 
     def predict(self, field):
         """HavocPredUni of every inter unit (a 2Nx2N prediction unit per unit of rqt_units) at the list-0 vector decided at its origin, into the

@@ -42,6 +42,20 @@ namespace havoc_search {
 typedef int64_t Cost;                       // FixedPoint<int64_t, 16>
 constexpr Cost kCostMax = 0x7fffffffffffffffll;
 
+// a < b for the costs of the MOTION search, which are never negative (rates, lambda * distortion, kCostMax): on the device the 64-bit signed
+// comparison has no scalar instruction and would drag the whole (wave-uniform) decision state into vector registers; the sign of the wrapped
+// difference is the same answer for non-negative operands and stays scalar
+HAVOC_HD inline bool costLess(Cost a, Cost b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t sign;      // through an opaque scalar shift: the compiler would fold any C++ spelling of "top bit set" back into the 64-bit comparison
+    asm("s_lshr_b32 %0, %1, 31" : "=s"(sign) : "s"(__builtin_amdgcn_readfirstlane(uint32_t((uint64_t(a) - uint64_t(b)) >> 32))) : "scc");
+    return sign != 0;
+#else
+    return a < b;
+#endif
+}
+
 struct Lambda                               // FixedPoint<int32_t, 16>
 {
     int32_t value = 0;
@@ -93,7 +107,7 @@ struct MvCandidate                          // Search.hpp:1252-1314
     }
     HAVOC_HD bool consider(const MvCandidate &other)
     {
-        const bool better = other.cost < cost;
+        const bool better = costLess(other.cost, cost);
         if (better) *this = other;
         return better;
     }
@@ -375,7 +389,7 @@ struct MotionSearch
         for (int i = 0; i < 8; ++i)
         {
             const Cost cost = costMv(mv + pattern[i], mvd + pattern[i]);
-            if (cost < bestCost)
+            if (costLess(cost, bestCost))
             {
                 bestI = i;
                 bestCost = cost;
