@@ -5,9 +5,9 @@ O=$R/gpurun_out/r03n
 mkdir -p $O
 cd $R
 cp turingcodec_amd/libhavoc_mi355x.so /tmp/keep.so
-for t in 5 6 7 8 9 10 11; do
+for t in 1 10 12 13; do
   cp turingcodec_amd/libhavoc_timing$t.so turingcodec_amd/libhavoc_mi355x.so
-  echo "timing variant $t (cycles: 5 sad compute, 6 sad4 exchange, 7 hint keys+barrier, 8 hint compute, 9 hint final barrier, 10 lookups, 11 total)"
+  echo "variant $t"
   timeout 300 python profiles/r03/search_timing_run.py 2>&1 | tail -1 | tee $O/timing_$t.json
 done
 cp /tmp/keep.so turingcodec_amd/libhavoc_mi355x.so

@@ -227,11 +227,16 @@ struct DeviceView
     Lds<S> *x;
     int bx0, by0, bx1, by1, wsB;      // displacements [bx0, bx1] x [by0, by1] are answered from the staged window (row pitch wsB bytes)
     int sadTurn = 0, satdTurn = 0, satdCount = 0;
+    int32_t satdKey[9], satdValue[9];      // the announced positions and their SATDs, read back once (scalar registers)
 #ifdef HAVOC_SEARCH_TIMING
-    long tHint = 0, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long tHint = 0, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tExit = 0;
+#define GAP_IN() { if (tExit) { acc[6] += clock64() - tExit; acc[7] += 1; } }
+#define GAP_OUT() { tExit = clock64(); }
 #define TICK(k, expr) { const long t_ = clock64(); expr; acc[k] += clock64() - t_; }
 #else
 #define TICK(k, expr) { expr; }
+#define GAP_IN()
+#define GAP_OUT()
 #endif
 
     __device__ __forceinline__ int sadOne(int dx, int dy) const
@@ -244,7 +249,9 @@ struct DeviceView
     __device__ __forceinline__ int sad(int dx, int dy)
     {
         int v;
+        GAP_IN();
         TICK(0, v = sadOne(dx, dy));
+        GAP_OUT();
         return v;
     }
 
@@ -252,6 +259,7 @@ struct DeviceView
     {
         // this wavefront's position, picked with masks: a choice between d[0..3] by address would keep the caller's array in (per-lane) private
         // memory, and whatever is read from there counts as divergent -- the whole decision state would leave the scalar registers
+        GAP_IN();
         const int s0 = -(wave == 0), s1 = -(wave == 1), s2 = -(wave == 2), s3 = -(wave == 3);
         const int mx = (d[0].x & s0) | (d[1].x & s1) | (d[2].x & s2) | (d[3].x & s3), my = (d[0].y & s0) | (d[1].y & s1) | (d[2].y & s2) | (d[3].y & s3);
         int v;
@@ -267,6 +275,7 @@ struct DeviceView
 #ifdef HAVOC_SEARCH_TIMING
         acc[1] += clock64() - c0;
 #endif
+        GAP_OUT();
     }
 
     __device__ __forceinline__ const char *predAt(Mv mv) const
@@ -277,6 +286,7 @@ struct DeviceView
     // the positions the next costMv calls will ask for: small blocks several per wavefront (a position takes as many lanes as it has tile rows)
     __device__ __forceinline__ void hintSatd(const Mv *positions, int n)
     {
+        GAP_IN();
 #ifdef HAVOC_SEARCH_TIMING
         if (!tHint) tHint = wall_clock64();
         const long c0 = clock64();
@@ -381,27 +391,35 @@ struct DeviceView
         const long c2 = clock64();
 #endif
         __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 9; ++i)
+        {
+            satdKey[i] = __builtin_amdgcn_readfirstlane(x->key[satdTurn][i]);
+            satdValue[i] = __builtin_amdgcn_readfirstlane(x->satd[satdTurn][i]);
+        }
 #ifdef HAVOC_SEARCH_TIMING
         const long c3 = clock64();
         acc[2] += c1 - c0; acc[3] += c2 - c1; acc[4] += c3 - c2;
 #endif
+        GAP_OUT();
     }
 
     __device__ __forceinline__ int satdQpel(Mv mv)
     {
+        GAP_IN();
         const int32_t k = havoc_search::MotionField::pack(mv);
 #ifdef HAVOC_SEARCH_TIMING
         const long c0 = clock64();
 #endif
-        for (int i = 0; i < satdCount; ++i)
-            if (__builtin_amdgcn_readfirstlane(x->key[satdTurn][i]) == k)
-            {
-                const int v = __builtin_amdgcn_readfirstlane(x->satd[satdTurn][i]);
+        int v = -1;
+#pragma unroll
+        for (int i = 8; i >= 0; --i)
+            if (i < satdCount && satdKey[i] == k) v = satdValue[i];
 #ifdef HAVOC_SEARCH_TIMING
-                acc[5] += clock64() - c0;
+        acc[5] += clock64() - c0;
 #endif
-                return v;
-            }
+        GAP_OUT();
+        if (v >= 0) return v;
         return wave_satd<S>(ldsPtr(x->src), w * S, predAt(mv), sbb, w, h, lane);      // not announced: every wavefront computes it
     }
 };
@@ -511,6 +529,8 @@ __device__ __forceinline__ void search_ctu(const SearchArgs &a, Lds<S> &x, const
 #ifdef HAVOC_SEARCH_TIMING
             o.replays = HAVOC_SEARCH_TIMING == 1 ? int(tEnd - tTop) : (HAVOC_SEARCH_TIMING == 2 ? int(tStaged - tTop) : (HAVOC_SEARCH_TIMING == 3 ? int(view.tHint - tStaged) : int(tEnd - view.tHint)));
             if (HAVOC_SEARCH_TIMING >= 5 && HAVOC_SEARCH_TIMING <= 10) o.replays = int(view.acc[HAVOC_SEARCH_TIMING - 5]);
+            if (HAVOC_SEARCH_TIMING == 12) o.replays = int(view.acc[6]);
+            if (HAVOC_SEARCH_TIMING == 13) o.replays = int(view.acc[7]) * 100;
             if (HAVOC_SEARCH_TIMING == 11) o.replays = int(cEnd - cTop);
 #endif
             o.cost_integer = r.costInteger;
