@@ -24,6 +24,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# HIP maps streams onto 4 hardware queues unless told otherwise: with more independent pictures in flight than queues, their kernels (the
+# one-launch-per-picture search above all) queue up behind each other.  Must be in the environment before the runtime starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6300 GB/s achievable
 
 
@@ -1158,6 +1162,7 @@ def decision_path(args, Havoc, res, bit_depth, qp, pictures, seconds=1.5, keep=N
     per, pictures = max(1, cores // first), first
     d = stats.as_dict()
     out = {"value": round(sum(done) / el, 2), "unit": "pictures/s", "pictures_in_flight": pictures, "host_threads": cores, "replay_threads_per_picture": per,
+           "hardware_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
            "seconds_measured": round(el, 3), "pictures_done": int(sum(done)),
            "one_picture_alone_ms": round(min(lat) * 1e3, 3),
            "one_picture_alone_split_ms": {"phase_planes": round(t_planes * 1e3, 3), "searches_in_wavefront_order": round(t_search * 1e3, 3),

@@ -67,15 +67,18 @@ __device__ __forceinline__ u32x4 ld16(LdsPtr p)
 template <class T>
 __device__ __forceinline__ LdsPtr ldsPtr(T *p) { return (LdsPtr)p; }
 
+// the wavefront's share `part` of `parts` of the block's row segments; the sum is NOT yet the table's value for 16-bit samples (sadShift)
 template <int S, class PA, class PB>
-__device__ __forceinline__ int wave_sad(PA a, long sab, PB b, long sbb, int w, int h, int lane)
+__device__ __forceinline__ int wave_sad(PA a, long sab, PB b, long sbb, int w, int h, int lane, int part = 0, int parts = 1)
 {
     uint32_t acc = 0;
+    lane += kWave * part;
+    const int stride = kWave * parts;
     if ((w & 7) == 0)
     {   // 8 samples per lane and row segment
         const int tw = w >> 3;
         const FastDiv fd(tw);
-        for (int it = lane; it < tw * h; it += kWave)
+        for (int it = lane; it < tw * h; it += stride)
         {
             const int y = fd.div(it), x = it - y * tw;
             const PA pa = a + y * sab + x * 8 * S;
@@ -100,7 +103,7 @@ __device__ __forceinline__ int wave_sad(PA a, long sab, PB b, long sbb, int w, i
     {   // 4 samples
         const int tw = w >> 2;
         const FastDiv fd(tw);
-        for (int it = lane; it < tw * h; it += kWave)
+        for (int it = lane; it < tw * h; it += stride)
         {
             const int y = fd.div(it), x = it - y * tw;
             const PA pa = a + y * sab + x * 4 * S;
@@ -115,20 +118,22 @@ __device__ __forceinline__ int wave_sad(PA a, long sab, PB b, long sbb, int w, i
             }
         }
     }
-    const int t = wave_sum((int)acc);
-    return S == 2 ? t >> 2 : t;      // havoc/sad.cpp: the 16-bit tables return sad >> 2
+    return wave_sum((int)acc);
 }
+template <int S>
+__device__ __forceinline__ int sadShift(int t) { return S == 2 ? t >> 2 : t; }      // havoc/sad.cpp: the 16-bit tables return sad >> 2
 
 // measureSatd of a w x h block (w, h multiples of 4), one tile row per lane as k_satd (kernels_metric.hip) with a whole wavefront on the block
+// passFirst / passCount: which 64-row passes (all by default)
 template <int S, class PA, class PB>
-__device__ __forceinline__ int wave_satd(PA a, long sab, PB b, long sbb, int w, int h, int lane)
+__device__ __forceinline__ int wave_satd(PA a, long sab, PB b, long sbb, int w, int h, int lane, int passFirst = 0, int passCount = 64)
 {
     int acc = 0;
     if (((w | h) & 7) == 0)
     {
-        const int tw = w >> 3, n = tw * (h >> 3) * 8;
+        const int tw = w >> 3, n0 = tw * (h >> 3) * 8, n = min(n0, (passFirst + passCount) * kWave);
         const FastDiv fd(tw);
-        for (int base = 0; base < n; base += kWave)      // every lane goes through satd_rows (its DPP steps read the neighbours' registers)
+        for (int base = passFirst * kWave; base < n; base += kWave)      // every lane goes through satd_rows (its DPP steps read the neighbours' registers)
         {
             const int it = base + lane, r = it & 7;
             const bool on = it < n;
@@ -168,9 +173,9 @@ __device__ __forceinline__ int wave_satd(PA a, long sab, PB b, long sbb, int w, 
     }
     else
     {
-        const int tw = w >> 2, n = tw * (h >> 2) * 4;
+        const int tw = w >> 2, n0 = tw * (h >> 2) * 4, n = min(n0, (passFirst + passCount) * kWave);
         const FastDiv fd(tw);
-        for (int base = 0; base < n; base += kWave)
+        for (int base = passFirst * kWave; base < n; base += kWave)
         {
             const int it = base + lane, r = it & 3;
             const bool on = it < n;
@@ -205,11 +210,21 @@ __device__ __forceinline__ int wave_satd(PA a, long sab, PB b, long sbb, int w, 
 constexpr int kWinBytes = 20 * 1024;      // per byte of sample size: the staged reference window of a search
 constexpr int kWinMargin = 8;             // full samples around the start candidates: the probes after an improving start (+-2), star distances 1..8
 
+// wavefronts of a workgroup: 4, 8 or 16 (a multiple of the four positions of a sad4; with more than 4, several wavefronts share a position's rows and a
+// big block's (position, pass) SATD items spread wider).  Measured on the 1080p clip, one picture alone (profiles/r03/gpu_call_s.sh): 4 -> 14.4 ms,
+// 8 -> 17.1 ms, 16 -> 26.7 ms: the barriers and the replicated scalar code cost more than the wider arithmetic saves, so 4.
+#ifndef HAVOC_SEARCH_WAVES
+#define HAVOC_SEARCH_WAVES 4
+#endif
+constexpr int kWaves = HAVOC_SEARCH_WAVES;
+constexpr int kThreads = kWave * kWaves;
+static_assert(kWaves % 4 == 0 && kWaves >= 4 && kWaves <= 16, "wavefronts per workgroup");
+
 template <int S>
 struct Lds      // of a workgroup
 {
-    int32_t sad[2][4];
-    int32_t satd[2][12];
+    int32_t sad[2][kWaves];
+    int32_t satd[2][9 * 8];      // per announced position and 64-row pass
     int32_t key[2][12];
     int32_t mv[256 + 32];        // the CTU's own 16 x 16 cells, the 16 cells left of it, the 16 cells above it
     uint8_t valid[256 + 32];
@@ -239,31 +254,32 @@ struct DeviceView
 #define GAP_OUT()
 #endif
 
-    __device__ __forceinline__ int sadOne(int dx, int dy) const
+    __device__ __forceinline__ int sadOne(int dx, int dy, int part, int parts) const
     {
         if (dx >= bx0 && dx <= bx1 && dy >= by0 && dy <= by1)
-            return wave_sad<S>(ldsPtr(x->src), w * S, ldsPtr(x->win) + (dy - by0) * wsB + (dx - bx0) * S, wsB, w, h, lane);
-        return wave_sad<S>(ldsPtr(x->src), w * S, ref + dy * sbb + (long)dx * S, sbb, w, h, lane);
+            return wave_sad<S>(ldsPtr(x->src), w * S, ldsPtr(x->win) + (dy - by0) * wsB + (dx - bx0) * S, wsB, w, h, lane, part, parts);
+        return wave_sad<S>(ldsPtr(x->src), w * S, ref + dy * sbb + (long)dx * S, sbb, w, h, lane, part, parts);
     }
 
     __device__ __forceinline__ int sad(int dx, int dy)
     {
         int v;
         GAP_IN();
-        TICK(0, v = sadOne(dx, dy));
+        TICK(0, v = sadShift<S>(sadOne(dx, dy, 0, 1)));      // every wavefront, whole block: nothing to exchange
         GAP_OUT();
         return v;
     }
 
     __device__ __forceinline__ void sad4(const Mv d[4], int32_t out[4])
     {
+        GAP_IN();
         // this wavefront's position, picked with masks: a choice between d[0..3] by address would keep the caller's array in (per-lane) private
         // memory, and whatever is read from there counts as divergent -- the whole decision state would leave the scalar registers
-        GAP_IN();
-        const int s0 = -(wave == 0), s1 = -(wave == 1), s2 = -(wave == 2), s3 = -(wave == 3);
+        const int k = wave & 3;
+        const int s0 = -(k == 0), s1 = -(k == 1), s2 = -(k == 2), s3 = -(k == 3);
         const int mx = (d[0].x & s0) | (d[1].x & s1) | (d[2].x & s2) | (d[3].x & s3), my = (d[0].y & s0) | (d[1].y & s1) | (d[2].y & s2) | (d[3].y & s3);
         int v;
-        TICK(0, v = sadOne(mx, my));
+        TICK(0, v = sadOne(mx, my, wave >> 2, kWaves / 4));      // kWaves / 4 wavefronts share a position's row segments
         sadTurn ^= 1;
 #ifdef HAVOC_SEARCH_TIMING
         const long c0 = clock64();
@@ -271,7 +287,13 @@ struct DeviceView
         if (lane == 0) x->sad[sadTurn][wave] = v;
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 4; ++i) out[i] = __builtin_amdgcn_readfirstlane(x->sad[sadTurn][i]);
+        for (int i = 0; i < 4; ++i)
+        {
+            int t = 0;
+#pragma unroll
+            for (int p = 0; p < kWaves / 4; ++p) t += __builtin_amdgcn_readfirstlane(x->sad[sadTurn][i + 4 * p]);
+            out[i] = sadShift<S>(t);
+        }
 #ifdef HAVOC_SEARCH_TIMING
         acc[1] += clock64() - c0;
 #endif
@@ -303,12 +325,14 @@ struct DeviceView
 #ifdef HAVOC_SEARCH_TIMING
         const long c1 = clock64();
 #endif
+        const int passes = rows > 32 ? (rows + kWave - 1) / kWave : 1;
         if (rows > 32)
-        {
-            for (int i = wave; i < n; i += 4)
+        {   // (position, pass) items dealt round the wavefronts; a position's passes are added up when the values are read back
+            for (int e = wave; e < n * passes; e += kWaves)
             {
-                const int v = wave_satd<S>(src, w * S, predAt(havoc_search::MotionField::unpack(x->key[satdTurn][i])), sbb, w, h, lane);
-                if (lane == 0) x->satd[satdTurn][i] = v;
+                const int i = e / passes, p = e - i * passes;
+                const int v = wave_satd<S>(src, w * S, predAt(havoc_search::MotionField::unpack(x->key[satdTurn][i])), sbb, w, h, lane, p, 1);
+                if (lane == 0) x->satd[satdTurn][e] = v;
             }
         }
         else
@@ -316,7 +340,7 @@ struct DeviceView
             const int L = rows <= 4 ? 4 : (rows <= 8 ? 8 : (rows <= 16 ? 16 : 32)), G = kWave / L;
             const int l = lane & (L - 1), g = lane / L;
             const FastDiv fd(tw);
-            for (int base = 0; base < n; base += 4 * G)
+            for (int base = 0; base < n; base += kWaves * G)
             {
                 const int j = base + wave * G + g;
                 const bool on = j < n && l < rows;
@@ -391,11 +415,17 @@ struct DeviceView
         const long c2 = clock64();
 #endif
         __syncthreads();
+        {   // lane i collects position i (its passes' sums), then the nine values move to scalar registers
+            const int i = lane < 9 ? lane : 0;
+            int v = 0;
+            for (int p = 0; p < passes; ++p) v += x->satd[satdTurn][i * passes + p];
+            const int key = x->key[satdTurn][i];
 #pragma unroll
-        for (int i = 0; i < 9; ++i)
-        {
-            satdKey[i] = __builtin_amdgcn_readfirstlane(x->key[satdTurn][i]);
-            satdValue[i] = __builtin_amdgcn_readfirstlane(x->satd[satdTurn][i]);
+            for (int j = 0; j < 9; ++j)
+            {
+                satdKey[j] = __builtin_amdgcn_readlane(key, j);
+                satdValue[j] = __builtin_amdgcn_readlane(v, j);
+            }
         }
 #ifdef HAVOC_SEARCH_TIMING
         const long c3 = clock64();
@@ -492,7 +522,7 @@ __device__ __forceinline__ void search_ctu(const SearchArgs &a, Lds<S> &x, const
             const FastDiv fd(rowDw);
             const char *g = view.ref + view.by0 * sbb + (long)view.bx0 * S;
             uint32_t *win = reinterpret_cast<uint32_t *>(x.win);
-            for (int i = tid; i < rowDw * nRows; i += 256)      // the last dword of a row may read up to 3 bytes past it: still inside the padded row
+            for (int i = tid; i < rowDw * nRows; i += kThreads)      // the last dword of a row may read up to 3 bytes past it: still inside the padded row
             {
                 const int y = rowDw <= 128 ? fd.div(i) : i / rowDw, k = i - y * rowDw;
                 win[i] = ld4(g + y * sbb + 4 * k);
@@ -501,7 +531,7 @@ __device__ __forceinline__ void search_ctu(const SearchArgs &a, Lds<S> &x, const
             const FastDiv fs(srcDw);
             const char *gs = a.src + ((long)q.y0 * a.srcStride + q.x0) * S;
             uint32_t *src = reinterpret_cast<uint32_t *>(x.src);
-            for (int i = tid; i < srcDw * q.h; i += 256)
+            for (int i = tid; i < srcDw * q.h; i += kThreads)
             {
                 const int y = fs.div(i), k = i - y * srcDw;
                 src[i] = ld4(gs + y * a.srcStride * S + 4 * k);
@@ -579,12 +609,15 @@ __device__ __forceinline__ void load_neighbours(const SearchArgs &a, Lds<S> &x, 
 
 // (a) one launch per wavefront step: the CTUs with cx + 2 cy == step
 template <int S>
-__global__ __launch_bounds__(256) void k_search_step(const SearchArgs a, const int step, const int yLo)
+__global__ __launch_bounds__(kThreads) void k_search_step(const SearchArgs a, const int step, const int yLo)
 {
     __shared__ Lds<S> x;
     const int list = blockIdx.x & 1, cy = yLo + (blockIdx.x >> 1), cx = step - 2 * cy, tid = threadIdx.x;
-    x.mv[tid] = 0;
-    x.valid[tid] = 0;
+    if (tid < 256)
+    {
+        x.mv[tid] = 0;
+        x.valid[tid] = 0;
+    }
     load_neighbours<S>(a, x, list, cx, cy, true, true);
     __syncthreads();
     Mv mvPrev = cx ? havoc_search::MotionField::unpack(a.rowPrev[2 * cy + list]) : Mv(0, 0);
@@ -599,7 +632,7 @@ __global__ __launch_bounds__(256) void k_search_step(const SearchArgs a, const i
 constexpr int kSpinLimit = 1 << 22;
 
 template <int S>
-__global__ __launch_bounds__(256) void k_search_rows(const SearchArgs a)
+__global__ __launch_bounds__(kThreads) void k_search_rows(const SearchArgs a)
 {
     __shared__ Lds<S> x;
     __shared__ int shared;
@@ -611,8 +644,11 @@ __global__ __launch_bounds__(256) void k_search_rows(const SearchArgs a)
     int *progress = a.progress + 2 * cy + list;
     const int *above = a.progress + 2 * (cy - 1) + list;
     Mv mvPrev(0, 0);
-    x.mv[tid] = 0;
-    x.valid[tid] = 0;
+    if (tid < 256)
+    {
+        x.mv[tid] = 0;
+        x.valid[tid] = 0;
+    }
     if (tid < 32)
     {
         x.mv[256 + tid] = 0;
@@ -656,8 +692,11 @@ __global__ __launch_bounds__(256) void k_search_rows(const SearchArgs a)
         const int32_t keepMv = tid < 16 ? x.mv[tid * 16 + 15] : 0;
         const uint8_t keepValid = tid < 16 ? x.valid[tid * 16 + 15] : 0;
         __syncthreads();
-        x.mv[tid] = 0;
-        x.valid[tid] = 0;
+        if (tid < 256)
+        {
+            x.mv[tid] = 0;
+            x.valid[tid] = 0;
+        }
         if (tid < 16)
         {
             x.mv[256 + tid] = keepMv;
@@ -728,9 +767,9 @@ hipError_t launch_search_picture_uni(hipStream_t st, int S, const havoc_mi355x_s
     if (!stepLaunches)
     {
         if (S == 1)
-            hipLaunchKernelGGL(k_search_rows<1>, dim3(2 * ctusY), dim3(256), 0, st, a);
+            hipLaunchKernelGGL(k_search_rows<1>, dim3(2 * ctusY), dim3(kThreads), 0, st, a);
         else
-            hipLaunchKernelGGL(k_search_rows<2>, dim3(2 * ctusY), dim3(256), 0, st, a);
+            hipLaunchKernelGGL(k_search_rows<2>, dim3(2 * ctusY), dim3(kThreads), 0, st, a);
         return hipGetLastError();
     }
     for (int step = 0; step <= ctusX - 1 + 2 * (ctusY - 1); ++step)
@@ -739,9 +778,9 @@ hipError_t launch_search_picture_uni(hipStream_t st, int S, const havoc_mi355x_s
         if (yHi < yLo) continue;
         const dim3 grid(2 * (yHi - yLo + 1));
         if (S == 1)
-            hipLaunchKernelGGL(k_search_step<1>, grid, dim3(256), 0, st, a, step, yLo);
+            hipLaunchKernelGGL(k_search_step<1>, grid, dim3(kThreads), 0, st, a, step, yLo);
         else
-            hipLaunchKernelGGL(k_search_step<2>, grid, dim3(256), 0, st, a, step, yLo);
+            hipLaunchKernelGGL(k_search_step<2>, grid, dim3(kThreads), 0, st, a, step, yLo);
     }
     return hipGetLastError();
 }
