@@ -25,8 +25,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # HIP maps streams onto 4 hardware queues unless told otherwise: with more independent pictures in flight than queues, their kernels (the
-# one-launch-per-picture search above all) queue up behind each other.  Must be in the environment before the runtime starts.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# one-launch-per-picture search above all) queue up behind each other.  Must be in the environment before the runtime starts, so the
+# decision-driven path is measured in a process of its own (`--decisions 2`, started by the plain run) with 16 queues; the primitive-batch
+# step keeps the runtime's default (its 8 lanes are branches of one HIP graph; measured slower with 16 queues: 0.62 against 0.49 ms).
+if "--decisions" in sys.argv[:-1] and sys.argv[sys.argv.index("--decisions") + 1] == "2":
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6300 GB/s achievable
 
@@ -59,6 +62,8 @@ def parse_args():
     ap.add_argument("--decision-pictures", type=int, default=16, help="contexts built for the decision-driven path: `value` is measured with 4 independent pictures in flight (the "
                     "leaf B pictures of one SOP), and again with 8 (what the pipelined hierarchy has in flight) and with all of them; one host thread + "
                     "context each")
+    ap.add_argument("--decision-walk", type=int, default=0, help="with --decisions 2: also time the same walk through the reference's tables on one host core "
+                    "and compare every decision (the cpu_baseline leg of the plain run)")
     ap.add_argument("--search-client", choices=["device", "batch"], default="device",
                     help="the motion searches of the decision-driven path: `device` = the decision loops inside the kernel (csrc/kernels_search.hip, one launch "
                          "per picture); `batch` = SAD-surface / tile-SATD launches + the loops replayed on host threads (search/picture_search.cpp)")
@@ -1205,12 +1210,41 @@ def decision_path(args, Havoc, res, bit_depth, qp, pictures, seconds=1.5, keep=N
     return out
 
 
+def decision_children(args):
+    """the decision-driven path of --res / --qp and of 4K QP32, each in a process of its own (16 hardware queues: see the top of this file), run BEFORE
+    this process touches the device so that nothing else holds queues or memory while they are measured"""
+    paths, walk = {}, None
+    for dres, dqp, label in ((args.res, args.qp, f"decision-driven path {args.res} {args.bit_depth}-bit QP{args.qp}"),
+                             ("3840x2160", 32, "decision-driven path 3840x2160 8-bit QP32 (BASELINE.json metric: 4K RA QP32)")):
+        if label.startswith("decision-driven path 3840") and args.res == "3840x2160":
+            continue
+        try:
+            want_walk = dres == args.res and not args.no_cpu_baseline
+            cmd = [sys.executable, os.path.abspath(__file__), "--decisions", "2", "--res", dres, "--bit-depth", str(args.bit_depth if dres == args.res else 8),
+                   "--qp", str(dqp), "--seed", str(args.seed), "--decision-pictures", str(max(1, args.decision_pictures)), "--search-client", args.search_client,
+                   "--decision-walk", "1" if want_walk else "0"]
+            child = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+            if child.returncode != 0:
+                raise RuntimeError(child.stderr[-600:])
+            got = json.loads([l for l in child.stdout.splitlines() if l.startswith("{")][-1])
+            paths[label] = got["decision_driven_path"]
+            if want_walk:
+                walk = got.get("decision_walk")
+        except Exception as e:
+            paths[label] = {"error": repr(e)}
+    return {"paths": paths, "walk": walk}
+
+
 def main():
     args = parse_args()
     if args.cpu_worker == "decisions":
         return cpu_decision_worker(args)
     if args.cpu_worker:
         return cpu_worker(args)
+    early = {}
+    if (args.decisions == 1 and args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.mix == "ra"
+            and not (args.pcie or args.skip or args.no_graph)):
+        early = decision_children(args)
     import torch
     import torch.distributed as dist
     from turingcodec_amd import Havoc
@@ -1234,10 +1268,17 @@ def main():
     if world != max(1, args.gpus):
         sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE): the line would not be what was asked for\n")
         sys.exit(2)
-    if args.decisions == 2:      # diagnostic: only the decision-driven path of --res / --qp, one line
-        r = decision_path(args, Havoc, args.res, args.bit_depth, args.qp, max(1, args.decision_pictures), seconds=2.0)
-        print(json.dumps({"metric": "DIAGNOSTIC (decision-driven path only) -- not the benchmark metric", "value": r["value"], "unit": r["unit"],
-                          "config": {"workload": f"{args.res} {args.bit_depth}-bit QP{args.qp}"}, "decision_driven_path": r}), flush=True)
+    if args.decisions == 2:      # only the decision-driven path of --res / --qp, one line (also how the plain run measures it: see the top of this file)
+        keep = {} if args.decision_walk else None
+        r = decision_path(args, Havoc, args.res, args.bit_depth, args.qp, max(1, args.decision_pictures), seconds=2.0 if not args.decision_walk else 1.5, keep=keep)
+        line = {"metric": "DIAGNOSTIC (decision-driven path only) -- not the benchmark metric", "value": r["value"], "unit": r["unit"],
+                "config": {"workload": f"{args.res} {args.bit_depth}-bit QP{args.qp}"}, "decision_driven_path": r}
+        if args.decision_walk:
+            try:
+                line["decision_walk"] = cpu_decision_walk(args, keep)
+            except Exception as e:
+                line["decision_walk"] = {"error": repr(e)}
+        print(json.dumps(line), flush=True)
         return
     grouped = world > 1 or args.exchange
     if grouped:
@@ -1466,29 +1507,17 @@ def main():
                     out.setdefault("extra", {})["rdoq0_error"] = repr(e)
         if plain and args.decisions and args.mix == "ra":
             # the decision-driven path: what the batches cost when decisions sit between them
-            decision_keep = {}
-            for dres, dqp, label in ((args.res, args.qp, f"decision-driven path {args.res} {args.bit_depth}-bit QP{args.qp}"),
-                                     ("3840x2160", 32, "decision-driven path 3840x2160 8-bit QP32 (BASELINE.json metric: 4K RA QP32)")):
-                if label.startswith("decision-driven path 3840") and args.res == "3840x2160":
-                    continue
-                try:
-                    keep = decision_keep if dres == args.res else None
-                    r = decision_path(args, Havoc, dres, args.bit_depth if dres == args.res else 8, dqp, max(1, args.decision_pictures), keep=keep)
-                    if dres == args.res:
-                        r["ratio_to_value"] = round(r["value"] / out["value"], 5)
-                        r["ratio_note"] = ("`value` is one picture's primitive calls as ideal whole-frame batches (no decision between launches); this is the "
-                                           "same kernels driven by decisions in an order a bit-exact encoder could issue them")
-                    out.setdefault("extra", {})[label] = r
-                    torch.cuda.empty_cache()
-                except Exception as e:
-                    out.setdefault("extra", {})[label] = {"error": repr(e)}
+            decision_walk = early.get("walk")
+            for label, r in early.get("paths", {}).items():
+                if "error" not in r and label.startswith(f"decision-driven path {args.res} "):
+                    r["ratio_to_value"] = round(r["value"] / out["value"], 5)
+                    r["ratio_note"] = ("`value` is one picture's primitive calls as ideal whole-frame batches (no decision between launches); this is the "
+                                       "same kernels driven by decisions in an order a bit-exact encoder could issue them")
+                out.setdefault("extra", {})[label] = r
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, dev)
             if plain and args.decisions and args.mix == "ra" and out["cpu_baseline"] is not None:
-                try:
-                    out["cpu_baseline"]["decision_walk"] = cpu_decision_walk(args, decision_keep)
-                except Exception as e:
-                    out["cpu_baseline"]["decision_walk"] = {"error": repr(e)}
+                out["cpu_baseline"]["decision_walk"] = decision_walk
                 try:
                     out["cpu_baseline"]["reference_encoder"] = cpu_reference_encoder(args)
                 except Exception as e:

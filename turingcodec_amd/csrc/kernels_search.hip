@@ -124,16 +124,15 @@ template <int S>
 __device__ __forceinline__ int sadShift(int t) { return S == 2 ? t >> 2 : t; }      // havoc/sad.cpp: the 16-bit tables return sad >> 2
 
 // measureSatd of a w x h block (w, h multiples of 4), one tile row per lane as k_satd (kernels_metric.hip) with a whole wavefront on the block
-// passFirst / passCount: which 64-row passes (all by default)
 template <int S, class PA, class PB>
-__device__ __forceinline__ int wave_satd(PA a, long sab, PB b, long sbb, int w, int h, int lane, int passFirst = 0, int passCount = 64)
+__device__ __forceinline__ int wave_satd(PA a, long sab, PB b, long sbb, int w, int h, int lane)
 {
     int acc = 0;
     if (((w | h) & 7) == 0)
     {
-        const int tw = w >> 3, n0 = tw * (h >> 3) * 8, n = min(n0, (passFirst + passCount) * kWave);
+        const int tw = w >> 3, n = tw * (h >> 3) * 8;
         const FastDiv fd(tw);
-        for (int base = passFirst * kWave; base < n; base += kWave)      // every lane goes through satd_rows (its DPP steps read the neighbours' registers)
+        for (int base = 0; base < n; base += kWave)      // every lane goes through satd_rows (its DPP steps read the neighbours' registers)
         {
             const int it = base + lane, r = it & 7;
             const bool on = it < n;
@@ -173,9 +172,9 @@ __device__ __forceinline__ int wave_satd(PA a, long sab, PB b, long sbb, int w, 
     }
     else
     {
-        const int tw = w >> 2, n0 = tw * (h >> 2) * 4, n = min(n0, (passFirst + passCount) * kWave);
+        const int tw = w >> 2, n = tw * (h >> 2) * 4;
         const FastDiv fd(tw);
-        for (int base = passFirst * kWave; base < n; base += kWave)
+        for (int base = 0; base < n; base += kWave)
         {
             const int it = base + lane, r = it & 3;
             const bool on = it < n;
@@ -224,7 +223,7 @@ template <int S>
 struct Lds      // of a workgroup
 {
     int32_t sad[2][kWaves];
-    int32_t satd[2][9 * 8];      // per announced position and 64-row pass
+    int32_t satd[2][12];
     int32_t key[2][12];
     int32_t mv[256 + 32];        // the CTU's own 16 x 16 cells, the 16 cells left of it, the 16 cells above it
     uint8_t valid[256 + 32];
@@ -325,14 +324,13 @@ struct DeviceView
 #ifdef HAVOC_SEARCH_TIMING
         const long c1 = clock64();
 #endif
-        const int passes = rows > 32 ? (rows + kWave - 1) / kWave : 1;
         if (rows > 32)
-        {   // (position, pass) items dealt round the wavefronts; a position's passes are added up when the values are read back
-            for (int e = wave; e < n * passes; e += kWaves)
+        {   // a whole position per wavefront.  (Dealing its 64-row passes round the wavefronts was measured: the same latency for one picture
+            // alone, but a third less throughput with 8 - 16 pictures in flight -- a reduction and an exchange per pass instead of per position)
+            for (int i = wave; i < n; i += kWaves)
             {
-                const int i = e / passes, p = e - i * passes;
-                const int v = wave_satd<S>(src, w * S, predAt(havoc_search::MotionField::unpack(x->key[satdTurn][i])), sbb, w, h, lane, p, 1);
-                if (lane == 0) x->satd[satdTurn][e] = v;
+                const int v = wave_satd<S>(src, w * S, predAt(havoc_search::MotionField::unpack(x->key[satdTurn][i])), sbb, w, h, lane);
+                if (lane == 0) x->satd[satdTurn][i] = v;
             }
         }
         else
@@ -415,11 +413,9 @@ struct DeviceView
         const long c2 = clock64();
 #endif
         __syncthreads();
-        {   // lane i collects position i (its passes' sums), then the nine values move to scalar registers
+        {   // lane i reads position i, then the nine values move to scalar registers
             const int i = lane < 9 ? lane : 0;
-            int v = 0;
-            for (int p = 0; p < passes; ++p) v += x->satd[satdTurn][i * passes + p];
-            const int key = x->key[satdTurn][i];
+            const int v = x->satd[satdTurn][i], key = x->key[satdTurn][i];
 #pragma unroll
             for (int j = 0; j < 9; ++j)
             {
