@@ -209,6 +209,12 @@ def test_4k_qp27_results_equal_the_reference_library(hv, bit_depth):
     _parity_vs_reference(hv, (3840, 2160), bit_depth, 27, min_values=40_000_000)
 
 
+def test_8k_qp32_results_equal_the_reference_library(hv):
+    """BASELINE.json configs[4]: 7680x4320 8-bit random-access QP32 (the resolution of the 8-GPU configuration) on one GPU against the
+    reference's compiled sources, the same comparison as at 1080p and 4K"""
+    _parity_vs_reference(hv, (7680, 4320), 8, 32, seed=19, min_values=40_000_000)
+
+
 def test_all_intra_fast_mix_equals_the_reference_library(hv):
     """BASELINE.json configs[0]: 640x360 all-intra QP32 speed=fast -- intra + TU chain with havoc_quantize IN the timed
     chain (no RDOQ at fast, turing/Reconstruct.cpp:310-311)"""
