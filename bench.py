@@ -62,6 +62,8 @@ def parse_args():
     ap.add_argument("--decision-pictures", type=int, default=16, help="contexts built for the decision-driven path: `value` is measured with 4 independent pictures in flight (the "
                     "leaf B pictures of one SOP), and again with 8 (what the pipelined hierarchy has in flight) and with all of them; one host thread + "
                     "context each")
+    ap.add_argument("--traffic", type=int, default=1, help="1 (default): the plain N=1 run measures roofline.traffic itself with two rocprofv3 --pmc passes "
+                    "of a two-step run (when rocprofv3 is on PATH); 0: take it from the committed profiles/r*_hbm_traffic.csv")
     ap.add_argument("--decision-walk", type=int, default=0, help="with --decisions 2: also time the same walk through the reference's tables on one host core "
                     "and compare every decision (the cpu_baseline leg of the plain run)")
     ap.add_argument("--search-client", choices=["device", "batch"], default="device",
@@ -831,6 +833,43 @@ def hbm_traffic_from_profiles(group, S):
     return round(total / n) if n else None
 
 
+def hbm_traffic_in_run(args, group, S):
+    """HBM bytes per launch of the group's kernels measured NOW: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; one counter per pass and no
+    trace domain beside it, as MI355X_MICROARCH.md prescribes) over a two-step run of this bench with the same workload; FETCH_SIZE x2 (gfx950
+    note), counters in KiB.  None when rocprofv3 is not on PATH, the passes fail, or --traffic 0"""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    prefix = _kernel_prefix(group, S)
+    if not exe or prefix is None or not args.traffic:
+        return None
+    base = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--extra-4k", "0", "--decisions", "0", "--traffic", "0", "--min-seconds", "0",
+            "--steps", "2", "--warmup", "1", "--kernel-reps", "1", "--res", args.res, "--bit-depth", str(args.bit_depth), "--qp", str(args.qp),
+            "--seed", str(args.seed), "--mix", args.mix, "--rdoq", str(args.rdoq)]
+    per_kernel = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for counter, mult in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+        d = tempfile.mkdtemp(prefix="havoc_pmc_", dir="/tmp")
+        try:
+            subprocess.run([exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + base, capture_output=True, text=True, timeout=400, cwd="/tmp", env=env)
+            vals = {}
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if prefix in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                        vals.setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
+            if not vals:
+                return None
+            for k, v in vals.items():
+                per_kernel[k] = per_kernel.get(k, 0.0) + sum(v) / len(v) * 1024.0 * mult
+        except (subprocess.TimeoutExpired, OSError, KeyError, ValueError):
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return round(sum(per_kernel.values()) / len(per_kernel)) if per_kernel else None
+
+
 def valu_busy_from_profiles(group, S):
     """VALU busy % of the group's kernel(s) from the newest profiles/r*_sq_counters.csv (rocprofv3 --pmc passes of this bench,
     profiles/collect.sh: 100 * 4 * SQ_ACTIVE_INST_VALU / 1024 SIMDs / busy cycles), weighted by busy time; None without a profile"""
@@ -1409,7 +1448,15 @@ def main():
         dom = max(ktimes, key=ktimes.get)
         ach = kbytes[dom] / (ktimes[dom] * 1e-3) / 1e9
         total_bytes = sum(kbytes[k] for k in ktimes)
-        traffic = hbm_traffic_from_profiles(dom, wl.S)
+        traffic, traffic_source = None, None
+        if world == 1 and not (args.pcie or args.skip or args.no_graph) and args.min_seconds > 0:
+            traffic = hbm_traffic_in_run(args, dom, wl.S)
+            traffic_source = ("measured in this run: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, one counter per pass, no trace domain) over a "
+                              "two-step run of the same workload; FETCH_SIZE x2 per the gfx950 note; mean over the kernel's launches")
+        if traffic is None:
+            traffic = hbm_traffic_from_profiles(dom, wl.S)
+            traffic_source = ("profiles/r*_hbm_traffic.csv: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench (profiles/collect.sh), "
+                              "FETCH_SIZE x2 per the gfx950 note; not re-measured in this run (rocprofv3 not on PATH, --traffic 0, or a diagnostic run)")
         ms_step = elapsed / args.steps * 1e3
         mixname = ("random-access QP%d speed=medium B-frame call mix (SURVEY A.2 counts x %.2f; assumed PU/intra size mix)" % (args.qp, w * h / (1920 * 1080))
                    if args.mix == "ra" else "all-intra QP%d speed=fast call mix (SURVEY A.1 per-CTU intra / TU counts, havoc_quantize in the chain)" % args.qp)
@@ -1435,8 +1482,7 @@ def main():
                        "note": f"each block = exactly {args.steps} steps between barrier + synchronize; ms_per_step and value are the MEDIAN block"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "traffic_source": "profiles/r*_hbm_traffic.csv: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench "
-                                           "(profiles/collect.sh), FETCH_SIZE x2 per the gfx950 note; not re-measured in this run",
+                         "traffic_source": traffic_source,
                          "launch_ms": round(ktimes[dom] / kcount[dom], 5), "launches_per_step": kcount[dom],
                          "algorithmic_bytes_per_step": kbytes[dom],
                          "valu_busy_pct": valu_busy_from_profiles(dom, wl.S),
