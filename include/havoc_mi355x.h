@@ -555,7 +555,12 @@ int havoc_mi355x_intra_decide(havoc_mi355x_ctx *ctx, const havoc_mi355x_intra_mp
  * d_out = havoc_search_result[2 * n] (index 2 * pu + list), d_field = int16 [2][height / 4][width / 4][x, y] (the decided vectors),
  * d_work = havoc_mi355x_search_workspace(width, height) bytes.  step_launches = 0: ONE launch, a workgroup per (CTU row, list) that waits in
  * the kernel for the row above to be two CTUs ahead; a wait that does not end gives up (nothing hangs) and leaves a non-zero int32 in the last
- * 4 bytes of d_work: the results are then invalid.  step_launches = 1: one launch per wavefront step (no waiting inside a kernel).  d_phase: the 16 fractional-sample planes of each reference picture
+ * 4 bytes of d_work: the results are then invalid.  step_launches = 1: one launch per wavefront step (no waiting inside a kernel).
+ * d_out_bi (optional, havoc_search_result[2 * n_pus]): the bi-directional refinement of searchBi (Search.hpp:1796-1827) after a PU's two
+ * uni-directional searches, unless nPbW + nPbH == 12: list 0 against the prediction from list 1's vector, then list 1 against the prediction
+ * from list 0's refined vector (searchMotionBi, Search.hpp:1498-1657: the ideal second predictor clip(2 * source - other prediction) built in LDS,
+ * an 11 x 11 integer grid, two sub-sample steps); mv, mvd, mvp_flag, calls and cost_subpel (= the cost) are filled.  The two lists' workgroups of
+ * a CTU row meet per PU on the records' `replays` word (1 = record complete), so this needs step_launches = 0.  d_phase: the 16 fractional-sample planes of each reference picture
  * (havoc_mi355x_interp_planes; plane 0 = the picture), which must reach ctb_size + 20 samples beyond the picture on every side; origins are the
  * sample offsets of sample (0, 0).  Everything stays on the device: nothing is uploaded or downloaded by this call. */
 typedef struct
@@ -569,7 +574,7 @@ size_t havoc_mi355x_search_workspace(int width, int height);
 int havoc_mi355x_search_picture_uni(havoc_mi355x_ctx *ctx, int S, const havoc_mi355x_search_params *params, const int64_t mvp_rate[2], const void *d_src,
                                     int64_t src_origin, intptr_t src_stride, const void *d_ref, const int64_t ref_origin[2], intptr_t ref_stride, const void *d_phase,
                                     intptr_t plane_elems, const int64_t phase_origin[2], const void *d_pus, const int32_t *d_ctu_first, int ctus_x, int ctus_y,
-                                    void *d_out, int16_t *d_field, void *d_work, int step_launches);
+                                    int n_pus, void *d_out, void *d_out_bi, int16_t *d_field, void *d_work, int step_launches);
 
 #ifdef __cplusplus
 }

@@ -13,7 +13,7 @@ for cfg in "640x360 8" "640x360 10" "1920x1080 8"; do
 import json
 try:
     r = json.load(open('$O/picture_$1_$2.json'))
-    print({k: r.get(k) for k in ('searches', 'mismatches', 'field_equal', 'expected_seconds')}, 'batch client', r['picture']['seconds'], r['on_device'], r['on_device_step_launches'])
+    print({k: r.get(k) for k in ('searches', 'mismatches', 'field_equal', 'expected_seconds')}, 'batch client', r['picture']['seconds'], r['on_device'], r['on_device_step_launches'], r.get('on_device_with_bi'))
 except Exception as e:
     print('no report', e); print(open('$O/picture_$1_$2.err').read()[-2000:])
 PY

@@ -397,9 +397,9 @@ int havoc_mi355x_intra_decide(havoc_mi355x_ctx *ctx, const havoc_mi355x_intra_mp
 size_t havoc_mi355x_search_workspace(int width, int height) { (void)width; (void)height; return 256; }
 int havoc_mi355x_search_picture_uni(havoc_mi355x_ctx *ctx, int S, const havoc_mi355x_search_params *params, const int64_t mvp_rate[2], const void *src, int64_t so,
                                     intptr_t ss, const void *ref, const int64_t ro[2], intptr_t rs, const void *phase, intptr_t pe, const int64_t po[2], const void *pus,
-                                    const int32_t *first, int cx, int cy, void *out, int16_t *field, void *work, int steps)
+                                    const int32_t *first, int cx, int cy, int n, void *out, void *out_bi, int16_t *field, void *work, int steps)
 {
-    (void)steps;
+    (void)steps; (void)n; (void)out_bi;
     (void)ctx; (void)S; (void)params; (void)mvp_rate; (void)src; (void)so; (void)ss; (void)ref; (void)ro; (void)rs; (void)phase; (void)pe; (void)po; (void)pus;
     (void)first; (void)cx; (void)cy; (void)out; (void)field; (void)work;
     return HAVOC_MI355X_EINVAL;

@@ -60,7 +60,8 @@ def main():
             ref = st.Client("oracle")
             report["expected_from"] = "CPU oracle"
         t0 = time.perf_counter()
-        expected, expected_field = ref.picture_uni(par, planes[0], planes[1], planes[2], stride, pad, pus, first, cx, cy, rate)
+        expected, expected_field, expected_bi = ref.picture_uni(par, planes[0], planes[1], planes[2], stride, pad, pus, first, cx, cy, rate, bi=True)
+        report["bi_loop_calls"] = int(expected_bi["calls"].sum())
         report["expected_seconds"] = round(time.perf_counter() - t0, 4)
         report["loop_calls"] = int(expected["calls"].sum())
 
@@ -121,6 +122,18 @@ def main():
                                                      "mismatches_vs_batch_client": len(same(got_d, got)), "field_equal_batch_client": bool(np.array_equal(field_d, field))}
         report["on_device"] = {"seconds": round(t, 5), "pictures_per_second": round(1.0 / t, 2), "searches_per_second": round(2 * len(pus) / t, 1),
                                "launches": int(stats_d.launches), "bytes_down": int(stats_d.bytes_down)}
+        # ... and with the bi-directional refinement of every PU after its two searches (searchBi), the two lists' workgroups meeting per PU
+        for attempt in range(args.repeat):
+            t0 = time.perf_counter()
+            got_b, field_b, stats_b, bi_b = decisions.picture_uni(ctx, S, par, dpic.value, origin, stride, dpic.value, (pe + origin, 2 * pe + origin), stride, pad,
+                                                                  dphase.value, pe, (origin, 16 * pe + origin), pus, first, cx, cy, rate, on_device=True, bi=True)
+            t = time.perf_counter() - t0
+        report["on_device_with_bi"] = {"seconds": round(t, 5), "pictures_per_second": round(1.0 / t, 2), "refinements": int((bi_b["calls"] > 0).sum()),
+                                       "uni_mismatches_vs_without_bi": len(same(got_b, got_d)), "field_equal": bool(np.array_equal(field_b, field_d))}
+        if expected is not None:
+            bi_fields = ["mv", "mvd", "mvp_flag", "calls", "cost_subpel"]
+            report["on_device_with_bi"]["mismatches"] = len(same(bi_b, expected_bi, bi_fields))
+            report["on_device_with_bi"]["mismatching"] = same(bi_b, expected_bi, bi_fields)[:10]
         fields = [k for k in got.dtype.names if k != "replays"]
         report["on_device"]["mismatches_vs_batch_client"] = int(sum(any(not np.array_equal(got_d[k][i], got[k][i]) for k in fields) for i in range(len(got))))
         report["on_device"]["field_equal_batch_client"] = bool(np.array_equal(field_d, field))

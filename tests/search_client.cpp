@@ -277,7 +277,7 @@ int client_intra35(int S, int bitDepth, int log2, const void *src, intptr_t ss, 
 // havoc_search_picture_uni.  ref0 / ref1 = sample (0, 0) of the two reference pictures; out[2 * p + list]; field_out as there.
 int client_picture_uni(int S, const void *src, intptr_t ss, const void *ref0, const void *ref1, intptr_t rs, const havoc_search_params *p,
                        const havoc_picture_pu *pus, const int32_t *ctu_first, int ctus_x, int ctus_y, const int64_t *mvp_rate, havoc_search_result *out,
-                       int16_t *field_out)
+                       int16_t *field_out, havoc_search_result *out_bi)
 {
     if (!g_open) return -1;
     const SearchParams sp = paramsOf(*p);
@@ -293,7 +293,17 @@ int client_picture_uni(int S, const void *src, intptr_t ss, const void *ref0, co
             MotionSearch<TableView<Sample>> ms(sp, pu, view);
             return ms.run();
         };
-        walkPictureSequential(sp, pus, ctu_first, ctus_x, ctus_y, rate, search, out, field);
+        // the bi-directional refinement one table call at a time (as runBi above): ideal predictor from the other list's vector, then searchMotionBi
+        auto bi = [&](int pi, int list, const PuContext &pu, Mv other, Mv start) {
+            (void)pi;
+            HAVOC_ALIGN(32, Sample, ideal[64 * 64]);
+            const LimitFullPelMv limit(pu, sp);
+            makeIdealPredictor<Sample>(tables<Sample>(), ideal, (const Sample *)src + intptr_t(pu.y0) * ss + pu.x0, ss, Plane<Sample>{refs[1 - list], rs}, other, limit,
+                                       pu.x0, pu.y0, pu.w, pu.h, sp.bitDepth);
+            TableView<Sample> view(tables<Sample>(), ideal, 64, Plane<Sample>{refs[list], rs}, pu.x0, pu.y0, pu.w, pu.h, sp.bitDepth);
+            return searchMotionBi(sp, pu, view, start);
+        };
+        walkPictureSequential(sp, pus, ctu_first, ctus_x, ctus_y, rate, search, out, field, bi, out_bi);
     };
     if (S == 1) run(uint8_t(0));
     else run(uint16_t(0));

@@ -92,7 +92,7 @@ class Client:
         L.client_bi.argtypes = [i, vp, ip, vp, vp, ip, C.POINTER(Params), vp, vp, i, i, vp]
         L.client_intra_order.argtypes = [vp, C.c_double, vp, i, vp]
         L.client_intra35.argtypes = [i, i, i, vp, ip, vp, vp, i, vp]
-        L.client_picture_uni.argtypes = [i, vp, ip, vp, vp, ip, C.POINTER(Params), vp, vp, i, i, vp, vp, vp]
+        L.client_picture_uni.argtypes = [i, vp, ip, vp, vp, ip, C.POINTER(Params), vp, vp, i, i, vp, vp, vp, vp]
         if kind != "classic":
             L.client_rqt.argtypes = [i, i, vp, ip, vp, ip, vp, ip, vp, vp, C.c_double, C.c_double, i, vp, i, vp]
             L.client_intra_rd.argtypes = [i, i, i, vp, ip, vp, vp, i, vp, vp, vp, vp, vp, C.c_double, C.c_double, i, vp, vp]
@@ -115,18 +115,20 @@ class Client:
         assert rc == 0
         return out
 
-    def picture_uni(self, params, src, ref0, ref1, stride, pad, pus, ctu_first, ctus_x, ctus_y, mvp_rate=(65536, 65536)):
+    def picture_uni(self, params, src, ref0, ref1, stride, pad, pus, ctu_first, ctus_x, ctus_y, mvp_rate=(65536, 65536), bi=False):
         """a whole picture's searches in dependency order, one table call at a time (turingcodec_amd/search/picture_order.hpp):
-        (results [2 * len(pus)], field int16 [2, cells_y, cells_x, 2])"""
+        (results [2 * len(pus)], field int16 [2, cells_y, cells_x, 2]); with bi also the bi-directional refinements [2 * len(pus)] as a third value"""
         out = np.zeros(2 * len(pus), RESULT_DT)
+        out_bi = np.zeros(2 * len(pus), RESULT_DT) if bi else None
         field = np.zeros((2, (params.pic_height + 3) // 4, (params.pic_width + 3) // 4, 2), np.int16)
         rate = np.asarray(mvp_rate, np.int64)
         pus = np.ascontiguousarray(pus)
         ctu_first = np.ascontiguousarray(ctu_first, np.int32)
         rc = self.L.client_picture_uni(src.itemsize, self._origin(src, stride, pad), stride, self._origin(ref0, stride, pad), self._origin(ref1, stride, pad), stride,
-                                       C.byref(params), pus.ctypes.data, ctu_first.ctypes.data, ctus_x, ctus_y, rate.ctypes.data, out.ctypes.data, field.ctypes.data)
+                                       C.byref(params), pus.ctypes.data, ctu_first.ctypes.data, ctus_x, ctus_y, rate.ctypes.data, out.ctypes.data, field.ctypes.data,
+                                       out_bi.ctypes.data if bi else None)
         assert rc == 0
-        return out, field
+        return (out, field, out_bi) if bi else (out, field)
 
     def rqt(self, bit_depth, src, stride, pad, pred, pred_stride, states, quant, lam, reciprocal_lambda, cus, sdh=1):
         """the residual-quadtree decisions one block at a time (turingcodec_amd/search/tu_decision.hpp) through this back end's primitives and

@@ -42,7 +42,7 @@ hipError_t launch_intra_decide(hipStream_t, const void *, const int32_t *, const
                                int, int32_t, void *, void *);
 size_t search_workspace_bytes(int width, int height);
 hipError_t launch_search_picture_uni(hipStream_t, int S, const havoc_mi355x_search_params *, const int64_t *, const void *, long, long, const void *, const long *, long,
-                                     const void *, long, const long *, const void *, const int32_t *, int, int, void *, int16_t *, void *, int);
+                                     const void *, long, const long *, const void *, const int32_t *, int, int, int, void *, void *, int16_t *, void *, int);
 hipError_t launch_rdoq(hipStream_t, int bd, int log2, int16_t *, const int16_t *, const uint8_t *, const void *, int, int32_t *, void *);
 size_t rdoq_workspace_bytes(int njobs);
 hipError_t launch_sao_stats(hipStream_t, int S, int bd, const void *, long, const void *, long, const void *, int, int64_t *);
@@ -541,9 +541,11 @@ size_t havoc_mi355x_search_workspace(int width, int height) { return width > 0 &
 int havoc_mi355x_search_picture_uni(havoc_mi355x_ctx *ctx, int S, const havoc_mi355x_search_params *params, const int64_t mvp_rate[2], const void *d_src,
                                     int64_t src_origin, intptr_t src_stride, const void *d_ref, const int64_t ref_origin[2], intptr_t ref_stride, const void *d_phase,
                                     intptr_t plane_elems, const int64_t phase_origin[2], const void *d_pus, const int32_t *d_ctu_first, int ctus_x, int ctus_y,
-                                    void *d_out, int16_t *d_field, void *d_work, int step_launches)
+                                    int n_pus, void *d_out, void *d_out_bi, int16_t *d_field, void *d_work, int step_launches)
 {
     REQUIRE_CTX(); REQUIRE_S();
+    REQUIRE(n_pus >= 0, "n_pus < 0");
+    REQUIRE(!(d_out_bi && step_launches), "the bi-directional refinement needs the one-launch form (the two lists' workgroups wait for each other)");
     REQUIRE(params && mvp_rate && ref_origin && phase_origin, "null argument");
     REQUIRE(params->ctb_size == 64, "ctb_size must be 64");
     REQUIRE(params->pic_width > 0 && params->pic_height > 0 && params->pic_width % 8 == 0 && params->pic_height % 8 == 0, "picture size must be a positive multiple of 8");
@@ -551,7 +553,7 @@ int havoc_mi355x_search_picture_uni(havoc_mi355x_ctx *ctx, int S, const havoc_mi
     REQUIRE(params->bit_depth >= 8 && params->bit_depth <= (S == 1 ? 8 : 10), "bit_depth must be 8 (S=1) or 8..10 (S=2)");
     const long ro[2] = {(long)ref_origin[0], (long)ref_origin[1]}, po[2] = {(long)phase_origin[0], (long)phase_origin[1]};
     return check(launch_search_picture_uni(LS(ctx), S, params, mvp_rate, d_src, (long)src_origin, src_stride, d_ref, ro, ref_stride, d_phase, plane_elems, po, d_pus,
-                                           d_ctu_first, ctus_x, ctus_y, d_out, d_field, d_work, step_launches),
+                                           d_ctu_first, ctus_x, ctus_y, n_pus, d_out, d_out_bi, d_field, d_work, step_launches),
                  "search_picture_uni");
 }
 

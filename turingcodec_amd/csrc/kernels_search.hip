@@ -38,6 +38,8 @@ struct SearchArgs
     const int32_t *ctuFirst;
     int ctusX, ctusY, cw, ch;
     havoc_search_result *out;
+    havoc_search_result *outBi;               // bi-directional refinements (nullptr: none).  `replays` of out / outBi = "record complete", the word
+                                              // the two lists' workgroups of a row meet on
     int32_t *field;                           // [2][ch][cw]: x | y << 16
     uint8_t *valid;                           // [2][ch][cw]
     int32_t *rowPrev;                         // [ctusY][2]: mvPreviousInteger2Nx2N at the end of the row's last finished CTU
@@ -225,6 +227,8 @@ struct Lds      // of a workgroup
     int32_t sad[2][kWaves];
     int32_t satd[2][12];
     int32_t key[2][12];
+    int32_t mail[2];             // what one thread read for all (a partner's vector, whether a wait ended)
+    int32_t table[16 * 12];      // SADs of a rectangle of full-sample displacements (the grid of a bi-directional refinement)
     int32_t mv[256 + 32];        // the CTU's own 16 x 16 cells, the 16 cells left of it, the 16 cells above it
     uint8_t valid[256 + 32];
     alignas(16) uint8_t src[64 * 64 * S];
@@ -241,6 +245,7 @@ struct DeviceView
     Lds<S> *x;
     int bx0, by0, bx1, by1, wsB;      // displacements [bx0, bx1] x [by0, by1] are answered from the staged window (row pitch wsB bytes)
     int sadTurn = 0, satdTurn = 0, satdCount = 0;
+    int tx0 = 0, ty0 = 0, tw = 0, th = 0;      // displacements [tx0, tx0 + tw) x [ty0, ty0 + th) are in x->table (tw = 0: nothing is)
     int32_t satdKey[9], satdValue[9];      // the announced positions and their SATDs, read back once (scalar registers)
 #ifdef HAVOC_SEARCH_TIMING
     long tHint = 0, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tExit = 0;
@@ -272,6 +277,19 @@ struct DeviceView
     __device__ __forceinline__ void sad4(const Mv d[4], int32_t out[4])
     {
         GAP_IN();
+        if (tw)
+        {   // announced (hintSadRect): four look-ups, no exchange
+            bool all = true;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) all &= d[i].x >= tx0 && d[i].x < tx0 + tw && d[i].y >= ty0 && d[i].y < ty0 + th;
+            if (all)
+            {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) out[i] = __builtin_amdgcn_readfirstlane(x->table[(d[i].y - ty0) * tw + d[i].x - tx0]);
+                GAP_OUT();
+                return;
+            }
+        }
         // this wavefront's position, picked with masks: a choice between d[0..3] by address would keep the caller's array in (per-lane) private
         // memory, and whatever is read from there counts as divergent -- the whole decision state would leave the scalar registers
         const int k = wave & 3;
@@ -297,6 +315,80 @@ struct DeviceView
         acc[1] += clock64() - c0;
 #endif
         GAP_OUT();
+    }
+
+    // the SADs of every full-sample displacement of a rectangle (inside the staged window), a displacement per lane group (small blocks: up to
+    // 16 per wavefront) or per wavefront; sad4 then answers from the table
+    __device__ __forceinline__ void hintSadRect(int x0, int y0, int x1, int y1)
+    {
+        x0 = max(x0, bx0); y0 = max(y0, by0); x1 = min(x1, bx1); y1 = min(y1, by1);
+        tw = 0;
+        const int gw = x1 - x0 + 1, gh = y1 - y0 + 1, count = gw * gh;
+        if (gw <= 0 || gh <= 0 || count > 16 * 12) return;
+        const LdsPtr src = ldsPtr(x->src), win = ldsPtr(x->win);
+        const int seg = (w & 7) ? 4 : 8, segs = w / seg, rows = segs * h;      // row segments of seg samples per displacement
+        const FastDiv fg(gw);
+        if (rows > 32)
+        {
+            for (int j = wave; j < count; j += kWaves)
+            {
+                const int gy = fg.div(j), gx = j - gy * gw;
+                const int v = wave_sad<S>(src, w * S, win + (y0 + gy - by0) * wsB + (x0 + gx - bx0) * S, wsB, w, h, lane);
+                if (lane == 0) x->table[j] = sadShift<S>(v);
+            }
+        }
+        else
+        {
+            const int L = rows <= 4 ? 4 : (rows <= 8 ? 8 : (rows <= 16 ? 16 : 32)), G = kWave / L;
+            const int l = lane & (L - 1), g = lane / L;
+            const FastDiv fs(segs);
+            const int row = fs.div(l), col = l - row * segs;
+            for (int base = 0; base < count; base += kWaves * G)
+            {
+                const int j = base + wave * G + g;
+                const bool on = j < count && l < rows;
+                const int jj = j < count ? j : 0;
+                const int gy = fg.div(jj), gx = jj - gy * gw;
+                const LdsPtr pa = src + (on ? row * w * S + col * seg * S : 0);
+                const LdsPtr pb = win + (y0 + gy - by0 + (on ? row : 0)) * wsB + (x0 + gx - bx0) * S + (on ? col * seg * S : 0);
+                uint32_t acc = 0;
+                if (seg == 8)
+                {
+                    if (S == 1)
+                    {
+                        const u32x2 va = ld8(pa), vb = ld8(pb);
+                        acc = __builtin_amdgcn_sad_u8(va.x, vb.x, acc);
+                        acc = __builtin_amdgcn_sad_u8(va.y, vb.y, acc);
+                    }
+                    else
+                    {
+                        const u32x4 va = ld16(pa), vb = ld16(pb);
+                        acc = __builtin_amdgcn_sad_u16(va.x, vb.x, acc);
+                        acc = __builtin_amdgcn_sad_u16(va.y, vb.y, acc);
+                        acc = __builtin_amdgcn_sad_u16(va.z, vb.z, acc);
+                        acc = __builtin_amdgcn_sad_u16(va.w, vb.w, acc);
+                    }
+                }
+                else if (S == 1)
+                    acc = __builtin_amdgcn_sad_u8(ld4(pa), ld4(pb), acc);
+                else
+                {
+                    const u32x2 va = ld8(pa), vb = ld8(pb);
+                    acc = __builtin_amdgcn_sad_u16(va.x, vb.x, acc);
+                    acc = __builtin_amdgcn_sad_u16(va.y, vb.y, acc);
+                }
+                int v = on ? (int)acc : 0;
+                // sum over the group's lanes with row operations: after k steps the last lane of every aligned group of 2^k lanes holds its sum
+                v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);                    // row_shr:1
+                v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);                    // row_shr:2
+                if (L >= 8) v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xe, true);        // row_shr:4
+                if (L >= 16) v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xc, true);       // row_shr:8
+                if (L >= 32) v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);       // row_bcast:15 into rows 1 and 3
+                if (j < count && l == L - 1) x->table[j] = sadShift<S>(v);
+            }
+        }
+        __syncthreads();
+        tx0 = x0; ty0 = y0; tw = gw; th = gh;
     }
 
     __device__ __forceinline__ const char *predAt(Mv mv) const
@@ -451,8 +543,43 @@ struct DeviceView
 };
 
 // one CTU's searches in one list.  x.mv / x.valid [256 ..]: the cells left of and above the CTU, put there by the caller
+// thread 0 polls `flag` (written with release by another workgroup) until it is set, then reads the record's vector; everybody gets the
+// outcome through LDS.  false: gave up (a.gaveUp is raised)
 template <int S>
-__device__ __forceinline__ void search_ctu(const SearchArgs &a, Lds<S> &x, const int list, const int cx, const int cy, Mv &mvPrev)
+__device__ __forceinline__ bool await_record(const SearchArgs &a, Lds<S> &x, havoc_search_result *rec, Mv *mv)
+{
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        int spins = 0, ok = 1;
+        while (!__hip_atomic_load(&rec->replays, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT))
+        {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1 << 24) || __hip_atomic_load(a.gaveUp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            {
+                ok = 0;
+                atomicOr(a.gaveUp, 1);
+                break;
+            }
+        }
+        x.mail[0] = ok;
+        x.mail[1] = ok ? (int32_t)(uint16_t)rec->mv[0] | ((int32_t)(uint16_t)rec->mv[1] << 16) : 0;
+    }
+    __syncthreads();
+    *mv = havoc_search::MotionField::unpack(__builtin_amdgcn_readfirstlane(x.mail[1]));
+    return __builtin_amdgcn_readfirstlane(x.mail[0]) != 0;
+}
+
+template <int S>
+__device__ __forceinline__ void publish_record(havoc_search_result *rec, const havoc_search_result &o)
+{
+    *rec = o;      // replays = 0 in o
+    __threadfence();
+    __hip_atomic_store(&rec->replays, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int S>
+__device__ __forceinline__ bool search_ctu(const SearchArgs &a, Lds<S> &x, const int list, const int cx, const int cy, Mv &mvPrev)
 {
     const int c = cy * a.ctusX + cx, tid = threadIdx.x;
     const int ctb = a.sp.ctbSize, xCtb = cx * ctb, yCtb = cy * ctb;
@@ -563,7 +690,75 @@ __device__ __forceinline__ void search_ctu(const SearchArgs &a, Lds<S> &x, const
             o.cost_subpel = r.costSubPel;
             o.cost_mvd_zero[0] = r.costMvdZero[0];
             o.cost_mvd_zero[1] = r.costMvdZero[1];
-            a.out[2 * p + list] = o;
+            if (a.outBi)
+                publish_record<S>(&a.out[2 * p + list], o);
+            else
+                a.out[2 * p + list] = o;
+        }
+        if (a.outBi && havoc_search::biRefined(q))
+        {   // searchBi (Search.hpp:1796-1827): list 0 against list 1's uni-directional vector, then list 1 against list 0's refined one
+            Mv other;
+            if (!await_record<S>(a, x, list == 0 ? &a.out[2 * p + 1] : &a.outBi[2 * p], &other)) return false;
+            const havoc_search::LimitFullPelMv limit(pu, a.sp);
+            {   // the "ideal" second predictor clip(2 * source - prediction from the other list) takes the source block's place (Search.hpp:1519-1546)
+                Mv full = havoc_search::shr2(other);
+                limit(full);
+                const char *pred = a.phase[1 - list] + (long)(4 * (other.y & 3) + (other.x & 3)) * a.planeElems * S
+                                   + (((long)q.y0 + full.y) * a.refStride + q.x0 + full.x) * S;
+                const char *gs = a.src + ((long)q.y0 * a.srcStride + q.x0) * S;
+                const int srcDw = q.w * S / 4;
+                const FastDiv fs(srcDw);
+                uint32_t *ideal = reinterpret_cast<uint32_t *>(x.src);
+                for (int i = tid; i < srcDw * q.h; i += kThreads)
+                {
+                    const int y = fs.div(i), k = i - y * srcDw;
+                    const uint32_t sv = ld4(gs + y * a.srcStride * S + 4 * k), pv = ld4(pred + y * sbb + 4 * k);
+                    uint32_t o;
+                    if (S == 1)
+                    {   // SubtractBi with bitDepth = 6 + 2 * sizeof(Sample) = 8
+                        o = 0;
+#pragma unroll
+                        for (int b = 0; b < 4; ++b)
+                        {
+                            const int v = 2 * (int)((sv >> (8 * b)) & 0xff) - (int)((pv >> (8 * b)) & 0xff);
+                            o |= (uint32_t)clip3(0, 255, v) << (8 * b);
+                        }
+                    }
+                    else
+                    {   // bitDepth = 10 whatever the picture's
+                        const int v0 = 2 * (int)(sv & 0xffff) - (int)(pv & 0xffff), v1 = 2 * (int)(sv >> 16) - (int)(pv >> 16);
+                        o = (uint32_t)clip3(0, 1023, v0) | ((uint32_t)clip3(0, 1023, v1) << 16);
+                    }
+                    ideal[i] = o;
+                }
+                // the window: the 11 x 11 grid around the rounded start vector (and the three positions right of each, Search.hpp:1583-1603)
+                Mv o0 = havoc_search::shr2(Mv(int16_t(r.mv.x + 1), int16_t(r.mv.y + 1)));
+                limit(o0);
+                view.bx0 = o0.x - kWinMargin; view.bx1 = o0.x + kWinMargin;
+                view.by0 = o0.y - kWinMargin; view.by1 = o0.y + kWinMargin;
+                const int rowB = (view.bx1 - view.bx0 + q.w) * S, rowDw = (rowB + 3) / 4, nRows = view.by1 - view.by0 + q.h;
+                view.wsB = rowDw * 4;
+                const FastDiv fd(rowDw);
+                const char *g = view.ref + view.by0 * sbb + (long)view.bx0 * S;
+                uint32_t *win = reinterpret_cast<uint32_t *>(x.win);
+                for (int i = tid; i < rowDw * nRows; i += kThreads)
+                {
+                    const int y = rowDw <= 128 ? fd.div(i) : i / rowDw, k = i - y * rowDw;
+                    win[i] = ld4(g + y * sbb + 4 * k);
+                }
+            }
+            __syncthreads();
+            const havoc_search::BiResult b = havoc_search::searchMotionBi(a.sp, pu, view, r.mv);
+            if (tid == 0)
+            {
+                havoc_search_result o = havoc_search_result();
+                o.mv[0] = b.mv.x; o.mv[1] = b.mv.y;
+                o.mvd[0] = b.mvd.x; o.mvd[1] = b.mvd.y;
+                o.mvp_flag = (int16_t)b.mvpFlag;
+                o.calls = b.calls;
+                o.cost_subpel = b.cost;
+                publish_record<S>(&a.outBi[2 * p + list], o);
+            }
         }
         // "last decision covers the area": the PU's cells, in LDS for this CTU's later PUs and in the picture's field for other CTUs' (later launches)
         const int cw4 = q.w >> 2, cells = cw4 * (q.h >> 2);
@@ -585,6 +780,7 @@ __device__ __forceinline__ void search_ctu(const SearchArgs &a, Lds<S> &x, const
         if (r.wrote2Nx2N) mvPrev = r.mvInteger;
     }
     __syncthreads();
+    return true;
 }
 
 // the cells left of and above CTU (cx, cy) from the picture's field (decided by earlier launches / by workgroups whose progress was awaited)
@@ -617,7 +813,7 @@ __global__ __launch_bounds__(kThreads) void k_search_step(const SearchArgs a, co
     load_neighbours<S>(a, x, list, cx, cy, true, true);
     __syncthreads();
     Mv mvPrev = cx ? havoc_search::MotionField::unpack(a.rowPrev[2 * cy + list]) : Mv(0, 0);
-    search_ctu<S>(a, x, list, cx, cy, mvPrev);
+    (void)search_ctu<S>(a, x, list, cx, cy, mvPrev);      // a.outBi is null here: nothing to wait for
     if (tid == 0) a.rowPrev[2 * cy + list] = havoc_search::MotionField::pack(mvPrev);
 }
 
@@ -683,7 +879,11 @@ __global__ __launch_bounds__(kThreads) void k_search_rows(const SearchArgs a)
         }
         load_neighbours<S>(a, x, list, cx, cy, false, true);      // the cells above, now final; the cells to the left were kept below
         __syncthreads();
-        search_ctu<S>(a, x, list, cx, cy, mvPrev);
+        if (!search_ctu<S>(a, x, list, cx, cy, mvPrev))
+        {   // a wait for the other list's workgroup gave up: leave, let the rows below through
+            if (tid == 0) __hip_atomic_store(progress, a.ctusX, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
         // this CTU's right column becomes the next one's left neighbours; its own cells start undecided
         const int32_t keepMv = tid < 16 ? x.mv[tid * 16 + 15] : 0;
         const uint8_t keepValid = tid < 16 ? x.valid[tid * 16 + 15] : 0;
@@ -718,7 +918,7 @@ static_assert(sizeof(havoc_mi355x_search_params) == sizeof(havoc_search_params) 
 
 hipError_t launch_search_picture_uni(hipStream_t st, int S, const havoc_mi355x_search_params *sp, const int64_t mvpRate[2], const void *src, long srcOrigin, long srcStride,
                                      const void *ref, const long refOrigin[2], long refStride, const void *phase, long planeElems, const long phaseOrigin[2], const void *pus,
-                                     const int32_t *ctuFirst, int ctusX, int ctusY, void *out, int16_t *field, void *work, int stepLaunches)
+                                     const int32_t *ctuFirst, int ctusX, int ctusY, int nPus, void *out, void *outBi, int16_t *field, void *work, int stepLaunches)
 {
     SearchArgs a;
     a.sp.picWidth = sp->pic_width;
@@ -750,6 +950,7 @@ hipError_t launch_search_picture_uni(hipStream_t st, int S, const havoc_mi355x_s
     a.cw = (sp->pic_width + 3) / 4;
     a.ch = (sp->pic_height + 3) / 4;
     a.out = static_cast<havoc_search_result *>(out);
+    a.outBi = static_cast<havoc_search_result *>(outBi);
     a.field = reinterpret_cast<int32_t *>(field);
     const size_t cells = (size_t)a.cw * a.ch;
     a.valid = static_cast<uint8_t *>(work);
@@ -760,6 +961,11 @@ hipError_t launch_search_picture_uni(hipStream_t st, int S, const havoc_mi355x_s
     hipError_t e = hipMemsetAsync(work, 0, search_workspace_bytes(sp->pic_width, sp->pic_height), st);
     if (e != hipSuccess) return e;
     if ((e = hipMemsetAsync(field, 0, 2 * cells * 4, st)) != hipSuccess) return e;
+    if (outBi)
+    {   // the records' `replays` words are what the two lists' workgroups wait on
+        if ((e = hipMemsetAsync(out, 0, (size_t)2 * nPus * sizeof(havoc_search_result), st)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(outBi, 0, (size_t)2 * nPus * sizeof(havoc_search_result), st)) != hipSuccess) return e;
+    }
     if (!stepLaunches)
     {
         if (S == 1)

@@ -87,7 +87,7 @@ def lib():
                                                vp, vp, C.c_int, C.c_int, C.POINTER(i64), vp, vp, C.c_int, C.POINTER(PictureStats)]
         L.havoc_search_picture_uni.restype = C.c_int
         L.havoc_search_picture_uni_device.argtypes = [vp, C.c_int, C.POINTER(SearchParams), vp, i64, ip, vp, C.POINTER(i64), ip, C.c_int, vp, ip, C.POINTER(i64),
-                                                      vp, vp, C.c_int, C.c_int, C.POINTER(i64), vp, vp, vp, C.POINTER(PictureStats)]
+                                                      vp, vp, C.c_int, C.c_int, C.POINTER(i64), vp, vp, vp, vp, C.POINTER(PictureStats)]
         L.havoc_search_picture_uni_device.restype = C.c_int
         L.havoc_search_rqt.argtypes = [vp, C.c_int, C.c_int, vp, i64, ip, vp, ip, vp, i64, ip, vp, vp, C.c_double, C.c_double, C.c_int, vp, C.c_int, vp,
                                        C.POINTER(RqtStats)]
@@ -108,10 +108,11 @@ def lib():
 
 
 def picture_uni(ctx, S, params, d_src, src_origin, src_stride, d_ref, ref_origin, ref_stride, ref_pad, d_phase, plane_elems, phase_origin, pus, ctu_first,
-                ctus_x, ctus_y, mvp_rate=(65536, 65536), threads=16, want_field=True, on_device=False, d_field_keep=None):
+                ctus_x, ctus_y, mvp_rate=(65536, 65536), threads=16, want_field=True, on_device=False, d_field_keep=None, bi=False):
     """havoc_search_picture_uni (launch + host replay rounds) or, on_device, havoc_search_picture_uni_device (the decision loops inside the kernel).
     ctx: havoc_mi355x context handle (int / c_void_p); d_*: device addresses (ints); ref_origin / phase_origin:
-    pairs (list 0, list 1).  Returns (results [2 * len(pus)] RESULT_DT indexed 2 * p + list, field int16 [2, cells_y, cells_x, 2] or None, stats)."""
+    pairs (list 0, list 1).  Returns (results [2 * len(pus)] RESULT_DT indexed 2 * p + list, field int16 [2, cells_y, cells_x, 2] or None, stats);
+    with bi (device search only) the bi-directional refinements [2 * len(pus)] as a fourth value."""
     pus = np.ascontiguousarray(pus)
     assert pus.dtype == PICTURE_PU_DT
     ctu_first = np.ascontiguousarray(ctu_first, np.int32)
@@ -122,17 +123,20 @@ def picture_uni(ctx, S, params, d_src, src_origin, src_stride, d_ref, ref_origin
     ro = (C.c_int64 * 2)(*[int(v) for v in ref_origin])
     po = (C.c_int64 * 2)(*[int(v) for v in phase_origin])
     mr = (C.c_int64 * 2)(*[int(v) for v in mvp_rate])
+    out_bi = np.zeros(2 * len(pus), RESULT_DT) if bi else None
+    if bi and not on_device:
+        raise ValueError("the bi-directional refinement inside the picture walk exists in the device search only")
     if on_device:
         rc = lib().havoc_search_picture_uni_device(ctx, S, C.byref(params), d_src, int(src_origin), src_stride, d_ref, ro, ref_stride, ref_pad, d_phase, plane_elems, po,
                                                    pus.ctypes.data, ctu_first.ctypes.data, ctus_x, ctus_y, mr, out.ctypes.data,
-                                                   field.ctypes.data if want_field else None, d_field_keep, C.byref(stats))
+                                                   field.ctypes.data if want_field else None, d_field_keep, out_bi.ctypes.data if bi else None, C.byref(stats))
     else:
         rc = lib().havoc_search_picture_uni(ctx, S, C.byref(params), d_src, int(src_origin), src_stride, d_ref, ro, ref_stride, ref_pad, d_phase, plane_elems, po,
                                             pus.ctypes.data, ctu_first.ctypes.data, ctus_x, ctus_y, mr, out.ctypes.data,
                                             field.ctypes.data if want_field else None, threads, C.byref(stats))
     if rc != 0:
         raise RuntimeError(f"havoc_search_picture_uni{'_device' if on_device else ''} failed ({rc})")
-    return out, field, stats
+    return (out, field, stats, out_bi) if bi else (out, field, stats)
 
 
 def decision_inputs(width, height, bit_depth=8, qp=32, seed=11, density=1.0, frames=None):

@@ -190,6 +190,12 @@ HAVOC_HD inline auto hintSatd(View &v, const Mv *positions, int n, int) -> declt
 template <class View>
 HAVOC_HD inline void hintSatd(View &, const Mv *, int, long) {}
 
+// the same for the full-sample positions of a rectangle of displacements (searchMotionBi's exhaustive grid)
+template <class View>
+HAVOC_HD inline auto hintSadRect(View &v, int x0, int y0, int x1, int y1, int) -> decltype(v.hintSadRect(x0, y0, x1, y1), void()) { v.hintSadRect(x0, y0, x1, y1); }
+template <class View>
+HAVOC_HD inline void hintSadRect(View &, int, int, int, int, long) {}
+
 template <class View>
 struct MotionSearch
 {
@@ -485,31 +491,41 @@ HAVOC_HD BiResult searchMotionBi(const SearchParams &sp, const PuContext &pu, Bi
     Lambda lambda;
     lambda.set(sp.reciprocalSqrtLambda * 0.5);
     const int range = sp.biSmallSearchWindow ? 1 : 5;
-    for (int y = -range; y <= range; ++y)
-    {
-        int32_t sads[4] = {0, 0, 0, 0};
-        for (int x = -range; x <= range; ++x)
-        {
-            Mv mv = shr2(Mv(int16_t(origin.x + 4 * x), int16_t(origin.y + 4 * y)));
-            limit(mv);
-            const int i = (x + range) % 4;
-            if (i == 0)
-            {
-                mv1 = Mv(int16_t(mv.x + 1), mv.y);
-                limit(mv1);
-                mv2 = Mv(int16_t(mv.x + 2), mv.y);
-                limit(mv2);
-                mv3 = Mv(int16_t(mv.x + 3), mv.y);
-                limit(mv3);
-                const Mv four[4] = {mv, mv1, mv2, mv3};
-                view.sad4(four, sads);
-                ++r.calls;
-            }
-            MvCandidate candidate(shl2(mv), pu.mvp, pu.mvpRate);
-            candidate.cost += lambda * sads[i];
-            best.consider(candidate);
-        }
+    {   // every full-sample position the grid below can ask for: a view that can evaluate them all at once is told (others ignore it)
+        const Mv o = shr2(origin);
+        hintSadRect(view, o.x - range, o.y - range, o.x + range + 3, o.y + range, 0);
     }
+    for (int y = -range; y <= range; ++y)
+        for (int xb = -range; xb <= range; xb += 4)      // the reference's x loop, four columns at a time: (x + range) % 4 == 0 exactly at x = xb
+        {
+            Mv mv = shr2(Mv(int16_t(origin.x + 4 * xb), int16_t(origin.y + 4 * y)));
+            limit(mv);
+            mv1 = Mv(int16_t(mv.x + 1), mv.y);
+            limit(mv1);
+            mv2 = Mv(int16_t(mv.x + 2), mv.y);
+            limit(mv2);
+            mv3 = Mv(int16_t(mv.x + 3), mv.y);
+            limit(mv3);
+            const Mv four[4] = {mv, mv1, mv2, mv3};
+            int32_t sads[4];
+            view.sad4(four, sads);
+            ++r.calls;
+            HAVOC_UNROLL
+            for (int i = 0; i < 4; ++i)
+            {
+                const int x = xb + i;
+                if (x > range) continue;
+                if (i)
+                {   // the candidate is the limited position of ITS column, the SAD the one taken i samples right of the group's first (the
+                    // reference pairs them like this: they differ only where the limit moved the group's first position)
+                    mv = shr2(Mv(int16_t(origin.x + 4 * x), int16_t(origin.y + 4 * y)));
+                    limit(mv);
+                }
+                MvCandidate candidate(shl2(mv), pu.mvp, pu.mvpRate);
+                candidate.cost += lambda * sads[i];
+                best.consider(candidate);
+            }
+        }
     if (sp.halfPel)
     {
         const int refinement = sp.quarterPel ? 1 : 2;
@@ -517,6 +533,12 @@ HAVOC_HD BiResult searchMotionBi(const SearchParams &sp, const PuContext &pu, Bi
         {
             const Mv org = best.mv;
             best.cost = kCostMax;
+            {
+                Mv ask[9];
+                HAVOC_UNROLL
+                for (int k = 0; k < 9; ++k) ask[k] = Mv(int16_t(org.x + (k % 3 - 1) * step), int16_t(org.y + (k / 3 - 1) * step));
+                hintSatd(view, ask, 9, 0);
+            }
             for (int y = -step; y <= step; y += step)
                 for (int x = -step; x <= step; x += step)
                 {

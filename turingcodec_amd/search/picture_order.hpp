@@ -136,9 +136,21 @@ HAVOC_HD inline PuContext contextOf(const havoc_picture_pu &q, int ctb, const Mv
 // depends on comes before it).  search(p, list, puContext) -> UniResult.  out[2 * p + list].
 // mvPreviousInteger2Nx2N belongs to the substream (turing/StateEncode.h: StateEncodeSubstream), i.e. with WPP to the CTU row: it starts
 // at (0, 0) with the row and is handed from CTU to CTU along it.
-template <class Search>
+// With `bi` (searchBi, turing/Search.hpp:1796-1827, the branch without mvd_l1_zero_flag): after a PU's two uni-directional searches -- unless
+// nPbW + nPbH == 12 (Search.hpp:1886) -- list 0 is refined against the prediction from list 1's vector starting at its own uni-directional
+// vector, then list 1 against the prediction from list 0's REFINED vector.  bi(p, list, puContext, otherMv, startMv) -> BiResult;
+// outBi[2 * p + list] (mv, mvd, mvp_flag, calls, cost_subpel = cost; zero where no refinement runs).  The refined vectors do not enter the motion
+// field: which of uni / bi / merge a PU ends up with is the mode decision's (not restated), the field keeps the uni-directional vectors.
+HAVOC_HD inline bool biRefined(const havoc_picture_pu &q) { return q.w + q.h != 12; }
+
+struct NoBi
+{
+    BiResult operator()(int, int, const PuContext &, Mv, Mv) const { return BiResult(); }
+};
+
+template <class Search, class Bi = NoBi>
 void walkPictureSequential(const SearchParams &sp, const havoc_picture_pu *pus, const int32_t *ctuFirst, int ctusX, int ctusY, const Cost mvpRate[2],
-                           Search search, havoc_search_result *out, MotionField &field)
+                           Search search, havoc_search_result *out, MotionField &field, Bi bi = Bi(), havoc_search_result *outBi = nullptr)
 {
     field.init(sp.picWidth, sp.picHeight);
     auto get = [&](int list, int x, int y, Mv *v) { return field.get(list, x, y, v); };
@@ -147,12 +159,17 @@ void walkPictureSequential(const SearchParams &sp, const havoc_picture_pu *pus, 
     {
         if (c % ctusX == 0) mvPrev[0] = mvPrev[1] = Mv(0, 0);
         for (int p = ctuFirst[c]; p < ctuFirst[c + 1]; ++p)
+        {
+            PuContext ctx[2];
+            Mv uni[2];
             for (int list = 0; list < 2; ++list)
             {
                 Mv mvp[2];
                 derivePredictors(pus[p], list, sp.picWidth, sp.picHeight, get, mvp);
                 const PuContext pu = contextOf(pus[p], sp.ctbSize, mvp, mvpRate, mvPrev[list]);
                 const UniResult r = search(p, list, pu);
+                ctx[list] = pu;
+                uni[list] = r.mv;
                 havoc_search_result &o = out[2 * p + list];
                 o.mv[0] = r.mv.x; o.mv[1] = r.mv.y;
                 o.mvd[0] = r.mvd.x; o.mvd[1] = r.mvd.y;
@@ -168,6 +185,24 @@ void walkPictureSequential(const SearchParams &sp, const havoc_picture_pu *pus, 
                 field.set(list, pus[p].x0, pus[p].y0, pus[p].w, pus[p].h, r.mv);
                 if (r.wrote2Nx2N) mvPrev[list] = r.mvInteger;
             }
+            if (outBi)
+            {
+                Mv other = uni[1];
+                for (int list = 0; list < 2; ++list)
+                {
+                    havoc_search_result &o = outBi[2 * p + list];
+                    o = havoc_search_result();
+                    if (!biRefined(pus[p])) continue;
+                    const BiResult r = bi(p, list, ctx[list], other, uni[list]);
+                    o.mv[0] = r.mv.x; o.mv[1] = r.mv.y;
+                    o.mvd[0] = r.mvd.x; o.mvd[1] = r.mvd.y;
+                    o.mvp_flag = int16_t(r.mvpFlag);
+                    o.calls = r.calls;
+                    o.cost_subpel = r.cost;
+                    other = r.mv;
+                }
+            }
+        }
     }
 }
 

@@ -377,11 +377,13 @@ int havoc_search_picture_uni(havoc_mi355x_ctx *ctx, int S, const havoc_search_pa
 // gfx950, one workgroup per chain of dependent searches, one launch per wavefront step): the PU list goes down, the results come back, nothing in
 // between -- no surfaces, no rounds, no replay threads.  Arguments as havoc_search_picture_uni; the phase planes must reach 84 samples beyond the
 // picture (ref_pad >= 96 with the planes of havoc_mi355x_interp_planes(12, 4, ...)).  Results identical to havoc_search_picture_uni's except
-// `replays` (0 here).  d_field_keep (optional, device): where the decided field stays for later launches (int16 [2][cells][2]).
+// `replays`.  d_field_keep (optional, device): where the decided field stays for later launches (int16 [2][cells][2]).  out_bi (optional, host,
+// [2 * n]): the bi-directional refinements of searchBi after each PU's two searches (include/havoc_mi355x.h: havoc_mi355x_search_picture_uni).
 int havoc_search_picture_uni_device(havoc_mi355x_ctx *ctx, int S, const havoc_search_params *params, const void *d_src, int64_t src_origin, intptr_t src_stride,
                                     const void *d_ref, const int64_t ref_origin[2], intptr_t ref_stride, int ref_pad, const void *d_phase, intptr_t plane_elems,
                                     const int64_t phase_origin[2], const havoc_picture_pu *pus, const int32_t *ctu_first, int ctus_x, int ctus_y,
-                                    const int64_t mvp_rate[2], havoc_search_result *out, int16_t *field_out, int16_t *d_field_keep, havoc_picture_stats *stats)
+                                    const int64_t mvp_rate[2], havoc_search_result *out, int16_t *field_out, int16_t *d_field_keep, havoc_search_result *out_bi,
+                                    havoc_picture_stats *stats)
 {
     if (!ctx || !params || !pus || !ctu_first || !out || !ref_origin || !phase_origin || !mvp_rate || (S != 1 && S != 2) || ctus_x < 1 || ctus_y < 1 || ref_pad < 96)
         return HAVOC_MI355X_EINVAL;
@@ -408,6 +410,8 @@ int havoc_search_picture_uni_device(havoc_mi355x_ctx *ctx, int S, const havoc_se
     HAVOC_SEARCH_RC(arena.get(size_t(std::max(1, 2 * nPus)) * sizeof(havoc_search_result), &dOut, &hOut));
     HAVOC_SEARCH_RC(arena.get(2 * cells * 4, &dField, &hField));
     HAVOC_SEARCH_RC(arena.get(havoc_mi355x_search_workspace(W, H), &dWork, &hx));
+    void *dBi = nullptr, *hBi = nullptr;
+    if (out_bi) HAVOC_SEARCH_RC(arena.get(size_t(std::max(1, 2 * nPus)) * sizeof(havoc_search_result), &dBi, &hBi));
     std::memcpy(hPus, pus, size_t(nPus) * sizeof(havoc_picture_pu));
     std::memcpy(hFirst, ctu_first, size_t(nCtus + 1) * 4);
     HAVOC_SEARCH_RC(havoc_mi355x_h2d_async(ctx, dPus, hPus, size_t(nPus) * sizeof(havoc_picture_pu)));
@@ -417,7 +421,8 @@ int havoc_search_picture_uni_device(havoc_mi355x_ctx *ctx, int S, const havoc_se
     static_assert(sizeof(dp) == sizeof(*params), "search ABI");
     std::memcpy(&dp, params, sizeof(dp));
     HAVOC_SEARCH_RC(havoc_mi355x_search_picture_uni(ctx, S, &dp, mvp_rate, d_src, src_origin, src_stride, d_ref, ref_origin, ref_stride, d_phase, plane_elems, phase_origin,
-                                                    dPus, static_cast<const int32_t *>(dFirst), ctus_x, ctus_y, dOut, field, dWork, stepLaunches));
+                                                    dPus, static_cast<const int32_t *>(dFirst), ctus_x, ctus_y, nPus, dOut, dBi, field, dWork, stepLaunches));
+    if (out_bi) HAVOC_SEARCH_RC(havoc_mi355x_d2h_async(ctx, hBi, dBi, size_t(2 * nPus) * sizeof(havoc_search_result)));
     void *dFlag, *hFlag;
     HAVOC_SEARCH_RC(arena.get(4, &dFlag, &hFlag));
     HAVOC_SEARCH_RC(havoc_mi355x_d2h_async(ctx, hFlag, static_cast<char *>(dWork) + havoc_mi355x_search_workspace(W, H) - 4, 4));
@@ -426,10 +431,11 @@ int havoc_search_picture_uni_device(havoc_mi355x_ctx *ctx, int S, const havoc_se
     HAVOC_SEARCH_RC(havoc_mi355x_sync(ctx));
     if (*static_cast<const int32_t *>(hFlag)) return HAVOC_MI355X_EDEVICE;      // a row's wait gave up
     std::memcpy(out, hOut, size_t(2 * nPus) * sizeof(havoc_search_result));
+    if (out_bi) std::memcpy(out_bi, hBi, size_t(2 * nPus) * sizeof(havoc_search_result));
     if (field_out) std::memcpy(field_out, hField, 2 * cells * 4);
     pst.steps = ctus_x + 2 * (ctus_y - 1);
     pst.launches = stepLaunches ? pst.steps : 1;
-    pst.bytes_down = int64_t(2 * nPus) * sizeof(havoc_search_result) + (field_out ? int64_t(2 * cells * 4) : 0);
+    pst.bytes_down = int64_t(2 * nPus) * sizeof(havoc_search_result) * (out_bi ? 2 : 1) + (field_out ? int64_t(2 * cells * 4) : 0);
     pst.seconds_gpu = pst.seconds_total = now() - tStart;
     if (stats) *stats = pst;
     return 0;
