@@ -559,8 +559,8 @@ int havoc_mi355x_intra_decide(havoc_mi355x_ctx *ctx, const havoc_mi355x_intra_mp
  * d_out_bi (optional, havoc_search_result[2 * n_pus]): the bi-directional refinement of searchBi (Search.hpp:1796-1827) after a PU's two
  * uni-directional searches, unless nPbW + nPbH == 12: list 0 against the prediction from list 1's vector, then list 1 against the prediction
  * from list 0's refined vector (searchMotionBi, Search.hpp:1498-1657: the ideal second predictor clip(2 * source - other prediction) built in LDS,
- * an 11 x 11 integer grid, two sub-sample steps); mv, mvd, mvp_flag, calls and cost_subpel (= the cost) are filled.  The two lists' workgroups of
- * a CTU row meet per PU on the records' `replays` word (1 = record complete), so this needs step_launches = 0.  d_phase: the 16 fractional-sample planes of each reference picture
+ * an 11 x 11 integer grid, two sub-sample steps); mv, mvd, mvp_flag, calls and cost_subpel (= the cost) are filled.  Nothing of the refinement
+ * feeds the walk (the motion field keeps the uni-directional vectors), so it is two more launches after it -- a workgroup per PU, list 0 then list 1.  d_phase: the 16 fractional-sample planes of each reference picture
  * (havoc_mi355x_interp_planes; plane 0 = the picture), which must reach ctb_size + 20 samples beyond the picture on every side; origins are the
  * sample offsets of sample (0, 0).  Everything stays on the device: nothing is uploaded or downloaded by this call. */
 typedef struct

@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--density", type=float, default=1.0)
     ap.add_argument("--repeat", type=int, default=2)
     ap.add_argument("--expected", choices=["ref", "oracle", "none"], default="ref")
+    ap.add_argument("--stress", type=int, default=0, help="run the device search (with the bi-directional refinement) this many more times and count the "
+                    "runs whose results differ from the expected ones (workgroups of a picture wait for each other: a race would show as a run that differs)")
     args = ap.parse_args()
     W, H = (int(v) for v in args.res.split("x"))
     S = 1 if args.bit_depth == 8 else 2
@@ -134,6 +136,14 @@ def main():
             bi_fields = ["mv", "mvd", "mvp_flag", "calls", "cost_subpel"]
             report["on_device_with_bi"]["mismatches"] = len(same(bi_b, expected_bi, bi_fields))
             report["on_device_with_bi"]["mismatching"] = same(bi_b, expected_bi, bi_fields)[:10]
+        if args.stress and expected is not None:
+            bad_runs = 0
+            for _ in range(args.stress):
+                g2, f2, _, b2 = decisions.picture_uni(ctx, S, par, dpic.value, origin, stride, dpic.value, (pe + origin, 2 * pe + origin), stride, pad, dphase.value, pe,
+                                                      (origin, 16 * pe + origin), pus, first, cx, cy, rate, on_device=True, bi=True)
+                bad_runs += int(bool(same(g2, expected)) or bool(same(b2, expected_bi, ["mv", "mvd", "mvp_flag", "calls", "cost_subpel"]))
+                                or not np.array_equal(f2, expected_field))
+            report["stress"] = {"runs": args.stress, "runs_that_differ": bad_runs}
         fields = [k for k in got.dtype.names if k != "replays"]
         report["on_device"]["mismatches_vs_batch_client"] = int(sum(any(not np.array_equal(got_d[k][i], got[k][i]) for k in fields) for i in range(len(got))))
         report["on_device"]["field_equal_batch_client"] = bool(np.array_equal(field_d, field))

@@ -232,6 +232,19 @@ def test_picture_client_on_the_gpu_equals_the_reference_walk(res, bit_depth):
     # ... and with one launch per wavefront step instead of rows waiting for each other inside one kernel
     d = r["on_device_step_launches"]
     assert d["mismatches_vs_batch_client"] == 0 and d["field_equal_batch_client"] and d["launches"] == r["picture"]["steps"], d
+    # ... and with the bi-directional refinement of every PU (searchBi) as two more launches: the refinements equal searchMotionBi over the
+    # reference's tables on the ideal predictors the reference builds, the uni-directional results are untouched
+    d = r["on_device_with_bi"]
+    assert d["mismatches"] == 0 and d["uni_mismatches_vs_without_bi"] == 0 and d["field_equal"] and d["refinements"] > 0.9 * r["searches"], d
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_device_search_gives_the_same_results_every_time():
+    """the rows of a picture wait for each other inside the kernel and the wavefronts of a workgroup share the decided vectors through LDS: a
+    missing barrier or fence shows as a run that differs (one did, before the barrier after a PU's cells are written was there)"""
+    r = _run_picture("real", "--res", "1920x1080", "--bit-depth", "8", "--threads", "16", "--repeat", "1", "--stress", "25")
+    assert r["stress"] == {"runs": 25, "runs_that_differ": 0}, r["stress"]
     out = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out) and res == "1920x1080":
         json.dump(r, open(os.path.join(out, "picture_report_1080p.json"), "w"), indent=1)

@@ -545,7 +545,6 @@ int havoc_mi355x_search_picture_uni(havoc_mi355x_ctx *ctx, int S, const havoc_mi
 {
     REQUIRE_CTX(); REQUIRE_S();
     REQUIRE(n_pus >= 0, "n_pus < 0");
-    REQUIRE(!(d_out_bi && step_launches), "the bi-directional refinement needs the one-launch form (the two lists' workgroups wait for each other)");
     REQUIRE(params && mvp_rate && ref_origin && phase_origin, "null argument");
     REQUIRE(params->ctb_size == 64, "ctb_size must be 64");
     REQUIRE(params->pic_width > 0 && params->pic_height > 0 && params->pic_width % 8 == 0 && params->pic_height % 8 == 0, "picture size must be a positive multiple of 8");

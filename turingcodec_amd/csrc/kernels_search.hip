@@ -38,8 +38,7 @@ struct SearchArgs
     const int32_t *ctuFirst;
     int ctusX, ctusY, cw, ch;
     havoc_search_result *out;
-    havoc_search_result *outBi;               // bi-directional refinements (nullptr: none).  `replays` of out / outBi = "record complete", the word
-                                              // the two lists' workgroups of a row meet on
+    havoc_search_result *outBi;               // bi-directional refinements (nullptr: none); until k_search_bi runs, the predictors of the searches
     int32_t *field;                           // [2][ch][cw]: x | y << 16
     uint8_t *valid;                           // [2][ch][cw]
     int32_t *rowPrev;                         // [ctusY][2]: mvPreviousInteger2Nx2N at the end of the row's last finished CTU
@@ -227,7 +226,6 @@ struct Lds      // of a workgroup
     int32_t sad[2][kWaves];
     int32_t satd[2][12];
     int32_t key[2][12];
-    int32_t mail[2];             // what one thread read for all (a partner's vector, whether a wait ended)
     int32_t table[16 * 12];      // SADs of a rectangle of full-sample displacements (the grid of a bi-directional refinement)
     int32_t mv[256 + 32];        // the CTU's own 16 x 16 cells, the 16 cells left of it, the 16 cells above it
     uint8_t valid[256 + 32];
@@ -543,43 +541,8 @@ struct DeviceView
 };
 
 // one CTU's searches in one list.  x.mv / x.valid [256 ..]: the cells left of and above the CTU, put there by the caller
-// thread 0 polls `flag` (written with release by another workgroup) until it is set, then reads the record's vector; everybody gets the
-// outcome through LDS.  false: gave up (a.gaveUp is raised)
 template <int S>
-__device__ __forceinline__ bool await_record(const SearchArgs &a, Lds<S> &x, havoc_search_result *rec, Mv *mv)
-{
-    __syncthreads();
-    if (threadIdx.x == 0)
-    {
-        int spins = 0, ok = 1;
-        while (!__hip_atomic_load(&rec->replays, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT))
-        {
-            __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1 << 24) || __hip_atomic_load(a.gaveUp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            {
-                ok = 0;
-                atomicOr(a.gaveUp, 1);
-                break;
-            }
-        }
-        x.mail[0] = ok;
-        x.mail[1] = ok ? (int32_t)(uint16_t)rec->mv[0] | ((int32_t)(uint16_t)rec->mv[1] << 16) : 0;
-    }
-    __syncthreads();
-    *mv = havoc_search::MotionField::unpack(__builtin_amdgcn_readfirstlane(x.mail[1]));
-    return __builtin_amdgcn_readfirstlane(x.mail[0]) != 0;
-}
-
-template <int S>
-__device__ __forceinline__ void publish_record(havoc_search_result *rec, const havoc_search_result &o)
-{
-    *rec = o;      // replays = 0 in o
-    __threadfence();
-    __hip_atomic_store(&rec->replays, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-template <int S>
-__device__ __forceinline__ bool search_ctu(const SearchArgs &a, Lds<S> &x, const int list, const int cx, const int cy, Mv &mvPrev)
+__device__ __forceinline__ void search_ctu(const SearchArgs &a, Lds<S> &x, const int list, const int cx, const int cy, Mv &mvPrev)
 {
     const int c = cy * a.ctusX + cx, tid = threadIdx.x;
     const int ctb = a.sp.ctbSize, xCtb = cx * ctb, yCtb = cy * ctb;
@@ -690,74 +653,13 @@ __device__ __forceinline__ bool search_ctu(const SearchArgs &a, Lds<S> &x, const
             o.cost_subpel = r.costSubPel;
             o.cost_mvd_zero[0] = r.costMvdZero[0];
             o.cost_mvd_zero[1] = r.costMvdZero[1];
+            a.out[2 * p + list] = o;
             if (a.outBi)
-                publish_record<S>(&a.out[2 * p + list], o);
-            else
-                a.out[2 * p + list] = o;
-        }
-        if (a.outBi && havoc_search::biRefined(q))
-        {   // searchBi (Search.hpp:1796-1827): list 0 against list 1's uni-directional vector, then list 1 against list 0's refined one
-            Mv other;
-            if (!await_record<S>(a, x, list == 0 ? &a.out[2 * p + 1] : &a.outBi[2 * p], &other)) return false;
-            const havoc_search::LimitFullPelMv limit(pu, a.sp);
-            {   // the "ideal" second predictor clip(2 * source - prediction from the other list) takes the source block's place (Search.hpp:1519-1546)
-                Mv full = havoc_search::shr2(other);
-                limit(full);
-                const char *pred = a.phase[1 - list] + (long)(4 * (other.y & 3) + (other.x & 3)) * a.planeElems * S
-                                   + (((long)q.y0 + full.y) * a.refStride + q.x0 + full.x) * S;
-                const char *gs = a.src + ((long)q.y0 * a.srcStride + q.x0) * S;
-                const int srcDw = q.w * S / 4;
-                const FastDiv fs(srcDw);
-                uint32_t *ideal = reinterpret_cast<uint32_t *>(x.src);
-                for (int i = tid; i < srcDw * q.h; i += kThreads)
-                {
-                    const int y = fs.div(i), k = i - y * srcDw;
-                    const uint32_t sv = ld4(gs + y * a.srcStride * S + 4 * k), pv = ld4(pred + y * sbb + 4 * k);
-                    uint32_t o;
-                    if (S == 1)
-                    {   // SubtractBi with bitDepth = 6 + 2 * sizeof(Sample) = 8
-                        o = 0;
-#pragma unroll
-                        for (int b = 0; b < 4; ++b)
-                        {
-                            const int v = 2 * (int)((sv >> (8 * b)) & 0xff) - (int)((pv >> (8 * b)) & 0xff);
-                            o |= (uint32_t)clip3(0, 255, v) << (8 * b);
-                        }
-                    }
-                    else
-                    {   // bitDepth = 10 whatever the picture's
-                        const int v0 = 2 * (int)(sv & 0xffff) - (int)(pv & 0xffff), v1 = 2 * (int)(sv >> 16) - (int)(pv >> 16);
-                        o = (uint32_t)clip3(0, 1023, v0) | ((uint32_t)clip3(0, 1023, v1) << 16);
-                    }
-                    ideal[i] = o;
-                }
-                // the window: the 11 x 11 grid around the rounded start vector (and the three positions right of each, Search.hpp:1583-1603)
-                Mv o0 = havoc_search::shr2(Mv(int16_t(r.mv.x + 1), int16_t(r.mv.y + 1)));
-                limit(o0);
-                view.bx0 = o0.x - kWinMargin; view.bx1 = o0.x + kWinMargin;
-                view.by0 = o0.y - kWinMargin; view.by1 = o0.y + kWinMargin;
-                const int rowB = (view.bx1 - view.bx0 + q.w) * S, rowDw = (rowB + 3) / 4, nRows = view.by1 - view.by0 + q.h;
-                view.wsB = rowDw * 4;
-                const FastDiv fd(rowDw);
-                const char *g = view.ref + view.by0 * sbb + (long)view.bx0 * S;
-                uint32_t *win = reinterpret_cast<uint32_t *>(x.win);
-                for (int i = tid; i < rowDw * nRows; i += kThreads)
-                {
-                    const int y = rowDw <= 128 ? fd.div(i) : i / rowDw, k = i - y * rowDw;
-                    win[i] = ld4(g + y * sbb + 4 * k);
-                }
-            }
-            __syncthreads();
-            const havoc_search::BiResult b = havoc_search::searchMotionBi(a.sp, pu, view, r.mv);
-            if (tid == 0)
-            {
-                havoc_search_result o = havoc_search_result();
-                o.mv[0] = b.mv.x; o.mv[1] = b.mv.y;
-                o.mvd[0] = b.mvd.x; o.mvd[1] = b.mvd.y;
-                o.mvp_flag = (int16_t)b.mvpFlag;
-                o.calls = b.calls;
-                o.cost_subpel = b.cost;
-                publish_record<S>(&a.outBi[2 * p + list], o);
+            {   // the predictors this search ran with, for the refinement launched after the walk (k_search_bi overwrites the record with its result)
+                havoc_search_result stash = havoc_search_result();
+                stash.mv[0] = mvp[0].x; stash.mv[1] = mvp[0].y;
+                stash.mvd[0] = mvp[1].x; stash.mvd[1] = mvp[1].y;
+                a.outBi[2 * p + list] = stash;
             }
         }
         // "last decision covers the area": the PU's cells, in LDS for this CTU's later PUs and in the picture's field for other CTUs' (later launches)
@@ -777,10 +679,103 @@ __device__ __forceinline__ bool search_ctu(const SearchArgs &a, Lds<S> &x, const
                 valid[(long)gy * a.cw + gx] = 1;
             }
         }
+        __syncthreads();      // ... and the next PU's predictors are read from these cells by every wavefront
         if (r.wrote2Nx2N) mvPrev = r.mvInteger;
     }
     __syncthreads();
-    return true;
+}
+
+// The bi-directional refinement of every PU in `list` (searchBi, turing/Search.hpp:1796-1827, the branch without mvd_l1_zero_flag): nothing of it
+// feeds the walk above (the motion field keeps the uni-directional vectors), so it is not a chain: ONE launch per list after the walk, a
+// workgroup per PU -- list 0 against the prediction from list 1's vector, then (next launch) list 1 against list 0's refined vector.
+template <int S>
+__global__ __launch_bounds__(kThreads) void k_search_bi(const SearchArgs a, const int list)
+{
+    __shared__ Lds<S> x;
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const havoc_picture_pu q = a.pus[p];
+    if (!havoc_search::biRefined(q))
+    {
+        if (tid == 0) a.outBi[2 * p + list] = havoc_search_result();
+        return;
+    }
+    const havoc_search_result uni = a.out[2 * p + list], stash = a.outBi[2 * p + list];
+    const havoc_search_result from = list == 0 ? a.out[2 * p + 1] : a.outBi[2 * p];
+    const Mv mvp[2] = {Mv(stash.mv[0], stash.mv[1]), Mv(stash.mvd[0], stash.mvd[1])};
+    const Mv other(from.mv[0], from.mv[1]), start(uni.mv[0], uni.mv[1]);
+    const havoc_search::PuContext pu = havoc_search::contextOf(q, a.sp.ctbSize, mvp, a.mvpRate, Mv(0, 0));
+    const long sbb = a.refStride * S;
+    DeviceView<S> view;
+    const long at = (long)q.y0 * a.refStride + q.x0;
+    view.ref = a.ref[list] + at * S;
+    view.phase = a.phase[list] + at * S;
+    view.sbb = sbb;
+    view.planeBytes = a.planeElems * S;
+    view.w = q.w;
+    view.h = q.h;
+    view.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    view.lane = tid & 63;
+    view.tid = tid;
+    view.x = &x;
+    const havoc_search::LimitFullPelMv limit(pu, a.sp);
+    {   // the "ideal" second predictor clip(2 * source - prediction from the other list) takes the source block's place (Search.hpp:1519-1546)
+        Mv full = havoc_search::shr2(other);
+        limit(full);
+        const char *pred = a.phase[1 - list] + (long)(4 * (other.y & 3) + (other.x & 3)) * a.planeElems * S + (((long)q.y0 + full.y) * a.refStride + q.x0 + full.x) * S;
+        const char *gs = a.src + ((long)q.y0 * a.srcStride + q.x0) * S;
+        const int srcDw = q.w * S / 4;
+        const FastDiv fs(srcDw);
+        uint32_t *ideal = reinterpret_cast<uint32_t *>(x.src);
+        for (int i = tid; i < srcDw * q.h; i += kThreads)
+        {
+            const int y = fs.div(i), k = i - y * srcDw;
+            const uint32_t sv = ld4(gs + y * a.srcStride * S + 4 * k), pv = ld4(pred + y * sbb + 4 * k);
+            uint32_t o;
+            if (S == 1)
+            {   // SubtractBi with bitDepth = 6 + 2 * sizeof(Sample) = 8
+                o = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                {
+                    const int v = 2 * (int)((sv >> (8 * b)) & 0xff) - (int)((pv >> (8 * b)) & 0xff);
+                    o |= (uint32_t)clip3(0, 255, v) << (8 * b);
+                }
+            }
+            else
+            {   // bitDepth = 10 whatever the picture's
+                const int v0 = 2 * (int)(sv & 0xffff) - (int)(pv & 0xffff), v1 = 2 * (int)(sv >> 16) - (int)(pv >> 16);
+                o = (uint32_t)clip3(0, 1023, v0) | ((uint32_t)clip3(0, 1023, v1) << 16);
+            }
+            ideal[i] = o;
+        }
+        // the window: the 11 x 11 grid around the rounded start vector (and the three positions right of each, Search.hpp:1583-1603)
+        Mv o0 = havoc_search::shr2(Mv(int16_t(start.x + 1), int16_t(start.y + 1)));
+        limit(o0);
+        view.bx0 = o0.x - kWinMargin; view.bx1 = o0.x + kWinMargin;
+        view.by0 = o0.y - kWinMargin; view.by1 = o0.y + kWinMargin;
+        const int rowB = (view.bx1 - view.bx0 + q.w) * S, rowDw = (rowB + 3) / 4, nRows = view.by1 - view.by0 + q.h;
+        view.wsB = rowDw * 4;
+        const FastDiv fd(rowDw);
+        const char *g = view.ref + view.by0 * sbb + (long)view.bx0 * S;
+        uint32_t *win = reinterpret_cast<uint32_t *>(x.win);
+        for (int i = tid; i < rowDw * nRows; i += kThreads)
+        {
+            const int y = rowDw <= 128 ? fd.div(i) : i / rowDw, k = i - y * rowDw;
+            win[i] = ld4(g + y * sbb + 4 * k);
+        }
+    }
+    __syncthreads();
+    const havoc_search::BiResult b = havoc_search::searchMotionBi(a.sp, pu, view, start);
+    if (tid == 0)
+    {
+        havoc_search_result o = havoc_search_result();
+        o.mv[0] = b.mv.x; o.mv[1] = b.mv.y;
+        o.mvd[0] = b.mvd.x; o.mvd[1] = b.mvd.y;
+        o.mvp_flag = (int16_t)b.mvpFlag;
+        o.calls = b.calls;
+        o.cost_subpel = b.cost;
+        a.outBi[2 * p + list] = o;
+    }
 }
 
 // the cells left of and above CTU (cx, cy) from the picture's field (decided by earlier launches / by workgroups whose progress was awaited)
@@ -813,7 +808,7 @@ __global__ __launch_bounds__(kThreads) void k_search_step(const SearchArgs a, co
     load_neighbours<S>(a, x, list, cx, cy, true, true);
     __syncthreads();
     Mv mvPrev = cx ? havoc_search::MotionField::unpack(a.rowPrev[2 * cy + list]) : Mv(0, 0);
-    (void)search_ctu<S>(a, x, list, cx, cy, mvPrev);      // a.outBi is null here: nothing to wait for
+    search_ctu<S>(a, x, list, cx, cy, mvPrev);
     if (tid == 0) a.rowPrev[2 * cy + list] = havoc_search::MotionField::pack(mvPrev);
 }
 
@@ -879,11 +874,7 @@ __global__ __launch_bounds__(kThreads) void k_search_rows(const SearchArgs a)
         }
         load_neighbours<S>(a, x, list, cx, cy, false, true);      // the cells above, now final; the cells to the left were kept below
         __syncthreads();
-        if (!search_ctu<S>(a, x, list, cx, cy, mvPrev))
-        {   // a wait for the other list's workgroup gave up: leave, let the rows below through
-            if (tid == 0) __hip_atomic_store(progress, a.ctusX, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            return;
-        }
+        search_ctu<S>(a, x, list, cx, cy, mvPrev);
         // this CTU's right column becomes the next one's left neighbours; its own cells start undecided
         const int32_t keepMv = tid < 16 ? x.mv[tid * 16 + 15] : 0;
         const uint8_t keepValid = tid < 16 ? x.valid[tid * 16 + 15] : 0;
@@ -911,6 +902,19 @@ size_t search_workspace_bytes(int width, int height)
     const size_t cells = (size_t)((width + 3) / 4) * ((height + 3) / 4);
     // validity of the two lists' cells | the rows' mvPreviousInteger2Nx2N, their progress | ticket, "a wait gave up" (the last 8 bytes)
     return ((2 * cells + 255) & ~(size_t)255) + 16 * (size_t)((height + 63) / 64) + 16;
+}
+
+static hipError_t launch_bi(hipStream_t st, int S, const SearchArgs &a, int nPus)
+{
+    if (a.outBi && nPus > 0)
+        for (int list = 0; list < 2; ++list)
+        {
+            if (S == 1)
+                hipLaunchKernelGGL(k_search_bi<1>, dim3(nPus), dim3(kThreads), 0, st, a, list);
+            else
+                hipLaunchKernelGGL(k_search_bi<2>, dim3(nPus), dim3(kThreads), 0, st, a, list);
+        }
+    return hipGetLastError();
 }
 
 // the whole picture: one launch (rows wait for each other in the kernel), or -- stepLaunches -- ctusX + 2 * (ctusY - 1) launches on the stream
@@ -961,18 +965,13 @@ hipError_t launch_search_picture_uni(hipStream_t st, int S, const havoc_mi355x_s
     hipError_t e = hipMemsetAsync(work, 0, search_workspace_bytes(sp->pic_width, sp->pic_height), st);
     if (e != hipSuccess) return e;
     if ((e = hipMemsetAsync(field, 0, 2 * cells * 4, st)) != hipSuccess) return e;
-    if (outBi)
-    {   // the records' `replays` words are what the two lists' workgroups wait on
-        if ((e = hipMemsetAsync(out, 0, (size_t)2 * nPus * sizeof(havoc_search_result), st)) != hipSuccess) return e;
-        if ((e = hipMemsetAsync(outBi, 0, (size_t)2 * nPus * sizeof(havoc_search_result), st)) != hipSuccess) return e;
-    }
     if (!stepLaunches)
     {
         if (S == 1)
             hipLaunchKernelGGL(k_search_rows<1>, dim3(2 * ctusY), dim3(kThreads), 0, st, a);
         else
             hipLaunchKernelGGL(k_search_rows<2>, dim3(2 * ctusY), dim3(kThreads), 0, st, a);
-        return hipGetLastError();
+        return launch_bi(st, S, a, nPus);
     }
     for (int step = 0; step <= ctusX - 1 + 2 * (ctusY - 1); ++step)
     {
@@ -984,7 +983,7 @@ hipError_t launch_search_picture_uni(hipStream_t st, int S, const havoc_mi355x_s
         else
             hipLaunchKernelGGL(k_search_step<2>, grid, dim3(kThreads), 0, st, a, step, yLo);
     }
-    return hipGetLastError();
+    return launch_bi(st, S, a, nPus);
 }
 
 } // namespace havoc_gpu
