@@ -1153,6 +1153,7 @@ def decision_path(args, Havoc, res, bit_depth, qp, pictures, seconds=1.5, keep=N
         t0 = time.perf_counter()
         res0, field0, stats = solo.step()
         lat.append(time.perf_counter() - t0)
+    bi_count = int((solo.bi_results["calls"] > 0).sum()) if solo.bi_results is not None else 0
     t0 = time.perf_counter()
     solo.phase_planes()
     solo.hv.sync()
@@ -1213,6 +1214,7 @@ def decision_path(args, Havoc, res, bit_depth, qp, pictures, seconds=1.5, keep=N
                                           "prediction_and_transform_tree_decisions": round(t_chain * 1e3, 3),
                                           "intra_35_mode_stage_and_rd_refinement": round(t_intra * 1e3, 3)},
            "searches_per_picture": int(2 * len(solo.pus)), "ctus": solo.cx * solo.cy,
+           "bi_directional_refinements_per_picture": bi_count,
            "transform_tree_decisions": {"units": int(len(solo.units)), "candidates": int(solo.rqt_stats.candidates), "launches": int(solo.rqt_stats.launches),
                                         "launches_per_ctu": round(solo.rqt_stats.launches / (solo.cx * solo.cy), 4),
                                         "split": int((solo.rqt_results["depth"] == 1).sum()), "unsplit": int(((solo.rqt_results["depth"] == 0) & (solo.rqt_results["tried_zero"] == 1)).sum()),
@@ -1233,13 +1235,14 @@ def decision_path(args, Havoc, res, bit_depth, qp, pictures, seconds=1.5, keep=N
                              if args.search_client == "device" else "SAD-surface / tile-SATD batch launches, the reference's loops replayed on host threads"),
            "what": "per picture: 2 x 15 phase planes; every PU's uni-directional search in both lists, CTUs in WPP wavefront order (CTU (x, y) after "
                    "(x + 1, y - 1)), predictors of a PU = the vectors decided for its left / upper neighbours, mvPreviousInteger2Nx2N handed along the CTU "
-                   "row (turingcodec_amd/search/picture_order.hpp); then prediction at the chosen vectors and the residual-quadtree decision of every inter unit (both tree depths of "
+                   "row (turingcodec_amd/search/picture_order.hpp), then the bi-directional refinement of every PU (searchBi: list 0 against list 1's "
+                   "vector, list 1 against list 0's refined one; device search only); then prediction at the chosen vectors and the residual-quadtree decision of every inter unit (both tree depths of "
                    "every 32x32 unit through residual + DCT -> RDOQ -> IQ + IDCT + add -> SSD in one chain per transform size, decisions from 16 bytes per "
                    "candidate, chosen candidates reconstructed into the picture; turingcodec_amd/search/tu_decision.hpp), boundary strengths derived on "
                    "the device, deblocking, padding; and the picture's intra candidates (42 partitions per CTU: 35-mode SATD stage, then every candidate "
                    "mode of the refinement order reconstructed through T -> RDOQ -> IT and the champion picked; neighbours from the source picture, not "
-                   "from the preceding partition's reconstruction). Not in it: the mode decision between the searched PUs and between inter and intra, "
-                   "bi-prediction, CABAC (the rate terms of the tree / intra decisions are stand-ins)"}
+                   "from the preceding partition's reconstruction). Not in it: the mode decision between the searched PUs (uni / bi / merge) and between "
+                   "inter and intra, CABAC (the rate terms of the tree / intra decisions are stand-ins)"}
     out.update(more)
     if keep is not None:
         keep["solo"], keep["res"], keep["field"] = solo, res0, field0

@@ -56,11 +56,14 @@ def test_decision_step_equals_the_reference_functions(res, BD, qp):
     dp = DecisionPicture(hv, res[0], res[1], BD, qp, seed=21, threads=8)
     got, field, stats = dp.step()
     ref = st.Client("ref", 3)
-    exp, exp_field = ref.picture_uni(dp.params, dp.host_planes[0], dp.host_planes[1], dp.host_planes[2], dp.stride, dp.PAD, dp.pus, dp.ctu_first, dp.cx, dp.cy,
-                                     dp.mvp_rate)
+    exp, exp_field, exp_bi = ref.picture_uni(dp.params, dp.host_planes[0], dp.host_planes[1], dp.host_planes[2], dp.stride, dp.PAD, dp.pus, dp.ctu_first, dp.cx, dp.cy,
+                                             dp.mvp_rate, bi=True)
     for k in ("mv", "mvd", "mv_integer", "mvp_flag", "wrote_2Nx2N", "calls", "cost_integer", "cost_subpel", "cost_mvd_zero"):
         assert np.array_equal(got[k], exp[k]), k
     assert np.array_equal(field, exp_field)
+    for k in ("mv", "mvd", "mvp_flag", "calls", "cost_subpel"):      # the bi-directional refinements (searchBi) of the step
+        assert np.array_equal(dp.bi_results[k], exp_bi[k]), k
+    assert (dp.bi_results["calls"] > 0).mean() > 0.9
     assert stats.launches < len(got) and stats.steps == dp.cx + 2 * (dp.cy - 1)
     # the residual-quadtree decisions of the step (both depths of every unit in one chain per transform size) against the same decisions
     # taken one block at a time through the reference's tables + Rdoq.cpp, on the prediction the device made from the decided vectors

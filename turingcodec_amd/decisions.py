@@ -247,8 +247,9 @@ class DecisionPicture:
     """One inter picture through the DECISION-DRIVEN path on the device (bench.py --decisions, tests/test_decisions.py):
 
       1. the 15 fractional-sample planes of both reference pictures (havoc_mi355x_interp_planes);
-      2. every PU's uni-directional search in both lists, CTUs in wavefront order, predictors derived from the vectors decided before
-         (libhavoc_search.so: havoc_search_picture_uni) -- the searches are fed by batch launches, the loops replay on host threads;
+      2. every PU's uni-directional search in both lists, CTUs in wavefront order, predictors derived from the vectors decided before, then the
+         bi-directional refinement of every PU (searchBi) -- the decision loops run inside the kernel (libhavoc_search.so:
+         havoc_search_picture_uni_device -> csrc/kernels_search.hip; search_on_device=False: launch + host replay rounds, no bi refinement);
       3. the TU side ON THE CHOSEN VECTORS: HavocPredUni of every 16x16 block (8x8 in a last partial row) at the list-0 vector the
          search left for it, then the residual-quadtree decision of every inter unit (32x32 units, smaller along partial edges;
          libhavoc_search.so: havoc_search_rqt): both tree depths of every unit through residual + forward DCT -> Rdoq::runQuantisation ->
@@ -349,8 +350,10 @@ class DecisionPicture:
     def search(self):
         hv, pe, o = self.hv, self.pe, self.origin
         base, ph = self.d_pic.data_ptr(), self.d_phase.data_ptr()
-        return picture_uni(hv.h, self.S, self.params, base, o, self.stride, base, (pe + o, 2 * pe + o), self.stride, self.PAD, ph, pe, (o, 16 * pe + o),
-                           self.pus, self.ctu_first, self.cx, self.cy, self.mvp_rate, self.threads, on_device=self.search_on_device)
+        r = picture_uni(hv.h, self.S, self.params, base, o, self.stride, base, (pe + o, 2 * pe + o), self.stride, self.PAD, ph, pe, (o, 16 * pe + o),
+                        self.pus, self.ctu_first, self.cx, self.cy, self.mvp_rate, self.threads, on_device=self.search_on_device, bi=self.search_on_device)
+        self.bi_results = r[3] if self.search_on_device else None      # the bi-directional refinements (device search only)
+        return r[:3]
 
     def predict(self, field):
         """HavocPredUni of every inter unit (a 2Nx2N prediction unit per unit of rqt_units) at the list-0 vector decided at its origin, into the
