@@ -37,6 +37,9 @@ def main():
     ap.add_argument("--density", type=float, default=1.0)
     ap.add_argument("--repeat", type=int, default=2)
     ap.add_argument("--expected", choices=["ref", "oracle", "none"], default="ref")
+    ap.add_argument("--speed", choices=["slow", "medium", "fast"], default="medium", help="turing/Speed.h: medium = early termination (MET), +-64 window, half + "
+                    "quarter refinement; fast = also the small windows and no quarter-sample step; slow = no early termination (every search runs the star "
+                    "and, where it travels, the raster refinement)")
     ap.add_argument("--stress", type=int, default=0, help="run the device search (with the bi-directional refinement) this many more times and count the "
                     "runs whose results differ from the expected ones (workgroups of a picture wait for each other: a race would show as a run that differs)")
     args = ap.parse_args()
@@ -50,8 +53,12 @@ def main():
     pad = 96
     pus, first, cx, cy = workload.picture_pus(W, H, args.seed, args.density)
     par = st.medium_params(W, H, args.bit_depth, args.qp)
+    if args.speed == "fast":
+        par.small_search_window, par.bi_small_search_window, par.quarter_pel = 1, 1, 0
+    elif args.speed == "slow":
+        par.met = 0
     rate = (45000, 98000)      # rate of mvp_lX_flag = 0 / 1 in some CABAC state (Q16 bits)
-    report = {"device": args.device, "res": args.res, "bit_depth": args.bit_depth, "pus": int(len(pus)), "searches": int(2 * len(pus)), "ctus": cx * cy}
+    report = {"device": args.device, "res": args.res, "bit_depth": args.bit_depth, "speed": args.speed, "pus": int(len(pus)), "searches": int(2 * len(pus)), "ctus": cx * cy}
 
     expected = None
     if args.expected != "none":

@@ -243,6 +243,23 @@ def test_picture_client_on_the_gpu_equals_the_reference_walk(res, bit_depth):
 
 @needs_ref
 @pytest.mark.gpu
+@pytest.mark.parametrize("speed,bit_depth", [("fast", 8), ("slow", 8), ("slow", 10)])
+def test_device_search_at_other_speed_settings(speed, bit_depth):
+    """the branches speed=medium rarely or never takes: no early termination (every search runs the star search, the raster refinement where the
+    vector travels, the final one-sample diamond), the small windows and no quarter-sample step of speed=fast -- uni-directional results, motion
+    field and bi-directional refinements against the walk over the reference's tables"""
+    r = _run_picture("real", "--res", "640x360", "--bit-depth", str(bit_depth), "--threads", "16", "--speed", speed)
+    assert r["speed"] == speed and r["mismatches"] == 0 and r["field_equal"], r
+    d = r["on_device"]
+    assert d["mismatches"] == 0 and d["field_equal"], d
+    d = r["on_device_with_bi"]
+    assert d["mismatches"] == 0 and d["uni_mismatches_vs_without_bi"] == 0 and d["field_equal"], d
+    if speed == "slow":
+        assert r["loop_calls"] > 29 * r["searches"]      # every search ran the star search (26 calls per search with early termination)
+
+
+@needs_ref
+@pytest.mark.gpu
 def test_device_search_gives_the_same_results_every_time():
     """the rows of a picture wait for each other inside the kernel and the wavefronts of a workgroup share the decided vectors through LDS: a
     missing barrier or fence shows as a run that differs (one did, before the barrier after a PU's cells are written was there)"""
