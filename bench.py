@@ -1554,6 +1554,23 @@ def main():
                         "steps": ksteps, "timed_blocks": len(yb)}
                 except Exception as e:
                     out.setdefault("extra", {})["rdoq0_error"] = repr(e)
+        if plain and args.mix == "ra":
+            # the same step with ONE picture in flight, a synchronisation after every picture: the latency a caller sees that needs a picture's
+            # results before it can issue the next one
+            try:
+                hv1, g1 = slots[0][1], slots[0][4]
+                lat = []
+                for _ in range(40):
+                    t0 = time.perf_counter()
+                    hv1.graph_launch(g1)
+                    hv1.sync()
+                    lat.append(time.perf_counter() - t0)
+                lat = sorted(lat)[:30]
+                out.setdefault("extra", {})["same step, one picture in flight and a synchronisation per picture (latency)"] = {
+                    "ms_per_picture": round(float(np.median(lat)) * 1e3, 4), "value": round(1.0 / float(np.median(lat)), 2), "unit": "frames/s",
+                    "launches_per_picture": len(dev.launches)}
+            except Exception as e:
+                out.setdefault("extra", {})["one_in_flight_error"] = repr(e)
         if plain and args.decisions and args.mix == "ra":
             # the decision-driven path: what the batches cost when decisions sit between them
             decision_walk = early.get("walk")
