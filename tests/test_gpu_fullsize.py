@@ -296,7 +296,8 @@ def test_bench_line_contract():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "6", "--warmup", "2", "--tune", "4", "--kernel-reps", "1"],
+    # --decisions 0: the decision-driven path (two more processes, ~40 s) has its own tests (test_decisions.py, test_search.py)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "6", "--warmup", "2", "--tune", "4", "--kernel-reps", "1", "--decisions", "0"],
                          capture_output=True, text=True, timeout=900, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
