@@ -896,7 +896,11 @@ __global__ __launch_bounds__(kThreads) void k_search_rows(const SearchArgs a)
             x.mv[256 + tid] = keepMv;
             x.valid[256 + tid] = keepValid;
         }
-        __threadfence();      // the field cells this workgroup wrote, before the progress that lets the row below read them
+#if HAVOC_SEARCH_FENCE_ALL
+        __threadfence();
+#endif
+        // the field cells every wavefront wrote are ordered before the barrier (a workgroup-scope release / acquire), and the one agent-scope
+        // release below is cumulative over them: one write-back of the L2 per CTU instead of one per wavefront
         __syncthreads();
         if (tid == 0) __hip_atomic_store(progress, cx + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
