@@ -857,7 +857,9 @@ __global__ __launch_bounds__(kThreads) void k_search_rows(const SearchArgs a)
             {
                 const int need = cx + 2 < a.ctusX ? cx + 2 : a.ctusX;
                 int spins = 0, ok = 1;
-                while (__hip_atomic_load(above, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need)
+                // polled relaxed (an acquire per poll would invalidate this XCD's caches every quarter microsecond for as long as the row waits --
+                // and rows wait most of the time); ONE acquire fence once the row above is far enough
+                while (__hip_atomic_load(above, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need)
                 {
                     __builtin_amdgcn_s_sleep(8);
                     if (++spins > kSpinLimit || __hip_atomic_load(a.gaveUp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
@@ -866,6 +868,7 @@ __global__ __launch_bounds__(kThreads) void k_search_rows(const SearchArgs a)
                         break;
                     }
                 }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 shared = ok;
             }
             __syncthreads();
