@@ -861,7 +861,7 @@ __global__ __launch_bounds__(kThreads) void k_search_rows(const SearchArgs a)
                 // and rows wait most of the time); ONE acquire fence once the row above is far enough
                 while (__hip_atomic_load(above, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need)
                 {
-                    __builtin_amdgcn_s_sleep(8);
+                    __builtin_amdgcn_s_sleep(32);
                     if (++spins > kSpinLimit || __hip_atomic_load(a.gaveUp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
                     {
                         ok = 0;
