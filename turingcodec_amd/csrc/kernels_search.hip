@@ -214,7 +214,7 @@ __device__ __forceinline__ int wave_satd(PA a, long sab, PB b, long sbb, int w, 
     return wave_sum(acc);
 }
 
-constexpr int kWinBytes = 20 * 1024;      // per byte of sample size: the staged reference window of a search
+constexpr int kWinBytes = 12 * 1024;      // per byte of sample size: the staged reference window of a search
 constexpr int kWinMargin = 8;             // full samples around the start candidates: the probes after an improving start (+-2), star distances 1..8
 
 // wavefronts of a workgroup: 4, 8 or 16 (a multiple of the four positions of a sad4; with more than 4, several wavefronts share a position's rows and a
