@@ -69,6 +69,25 @@ def test_argument_errors_return_nonzero_with_message(hv, data):
         L.havoc_mi355x_transform(h, 8, 1, 3, p(a), p(a), 8, p(jobs), 1),                      # DST exists for 4x4 only
         L.havoc_mi355x_sad(None, 1, p(a), W, p(a), W, p(jobs), 1, p(out)),                    # no context
     ]
+    # the round-3 entry points: the device-resident search and the intra decisions
+    import ctypes as C2
+    from turingcodec_amd.decisions import SearchParams
+    i64x2 = (C2.c_int64 * 2)
+    def sp(w, h, ctb=64, bd=8):
+        return SearchParams(w, h, ctb, 4, 1, 0, 0, 1, 1, bd, 0.1)
+    def search(S, par, cx, cy, n=0):
+        return L.havoc_mi355x_search_picture_uni(h, S, C2.byref(par), i64x2(1, 1), p(a), 0, W, p(a), i64x2(0, 0), W, p(a), 64, i64x2(0, 0), p(jobs), p(jobs), cx, cy, n,
+                                                 p(out), None, p(out), p(out), 0)
+    bad += [
+        search(3, sp(64, 64), 1, 1),                      # S
+        search(1, sp(64, 60), 1, 1),                      # picture height not a multiple of 8
+        search(1, sp(128, 64), 1, 1),                     # ctus_x does not match the picture
+        search(1, sp(64, 64, ctb=32), 1, 1),              # CTU size
+        search(1, sp(64, 64, bd=10), 1, 1),               # bit depth 10 needs S = 2
+        search(1, sp(64, 64), 1, 1, n=-1),                # n_pus < 0
+        L.havoc_mi355x_intra_expand(h, p(jobs), p(out), p(out), p(out), p(out), 1, 6, 1, 1, 1, 1, 1, 1, p(jobs), p(jobs), p(jobs), p(out), p(out)),   # log2TrafoSize
+        L.havoc_mi355x_intra_order(h, p(out), p(jobs), -1, 1, p(out), p(out), p(out), p(out)),                                                     # n < 0
+    ]
     assert all(rc != 0 for rc in bad), bad
     assert len(L.havoc_mi355x_last_error()) > 0
     # the context stays usable after errors
