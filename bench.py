@@ -1073,6 +1073,12 @@ def cpu_decision_walk(args, keep):
         bad = sum(int((np.asarray(got[k]) != ref[k]).reshape(len(got), -1).any(axis=1).sum()) for k in names)
         r["parity_vs_reference"] = {"searches_compared": int(len(got)), "fields_per_search": len(names), "mismatching": bad,
                                     "motion_field_equal": bool(np.array_equal(field, ref["field"]))}
+        if keep.get("bi") is not None:
+            bi = keep["bi"]
+            bi_names = ("mv", "mvd", "mvp_flag", "calls", "cost_subpel")
+            r["parity_vs_reference"]["bi_directional_refinements_compared"] = int((bi["calls"] > 0).sum())
+            r["parity_vs_reference"]["bi_directional_mismatching"] = sum(int((np.asarray(bi[k]) != ref["bi_" + k]).reshape(len(bi), -1).any(axis=1).sum()) for k in bi_names)
+            r["seconds_per_picture_with_bi_refinements"] = round(float(ref["seconds_with_bi"]), 4)
         r["what"] = ("the decision walk of extra['decision-driven path ...'] (same picture, PUs, wavefront-compatible order, derived predictors) one table "
                      "call at a time through the reference's x86-JIT havoc tables, ONE host core; searches only (no TU chain)")
         return r
@@ -1096,7 +1102,11 @@ def cpu_decision_worker(args):
         res, field = cl.picture_uni(d["params"], planes[0], planes[1], planes[2], d["stride"], d["pad"], d["pus"], d["ctu_first"], d["cx"], d["cy"], d["mvp_rate"])
         t = time.perf_counter() - t0
         best = t if best is None else min(best, t)
-    np.savez(args.cpu_out, field=field, **{k: res[k] for k in res.dtype.names})
+    # the same walk with the bi-directional refinements (searchBi), for the comparison with the device's; timed separately
+    t0 = time.perf_counter()
+    _, _, bi = cl.picture_uni(d["params"], planes[0], planes[1], planes[2], d["stride"], d["pad"], d["pus"], d["ctu_first"], d["cx"], d["cy"], d["mvp_rate"], bi=True)
+    t_bi = time.perf_counter() - t0
+    np.savez(args.cpu_out, field=field, seconds_with_bi=t_bi, **{k: res[k] for k in res.dtype.names}, **{"bi_" + k: bi[k] for k in ("mv", "mvd", "mvp_flag", "calls", "cost_subpel")})
     print(json.dumps({"seconds_per_picture": round(best, 4), "pictures_per_second": round(1.0 / best, 3), "cores": 1, "searches": int(len(res)),
                       "loop_calls": int(res["calls"].sum())}))
 
@@ -1154,6 +1164,7 @@ def decision_path(args, Havoc, res, bit_depth, qp, pictures, seconds=1.5, keep=N
         res0, field0, stats = solo.step()
         lat.append(time.perf_counter() - t0)
     bi_count = int((solo.bi_results["calls"] > 0).sum()) if solo.bi_results is not None else 0
+    bi0 = solo.bi_results.copy() if solo.bi_results is not None else None
     t0 = time.perf_counter()
     solo.phase_planes()
     solo.hv.sync()
@@ -1245,7 +1256,7 @@ def decision_path(args, Havoc, res, bit_depth, qp, pictures, seconds=1.5, keep=N
                    "inter and intra, CABAC (the rate terms of the tree / intra decisions are stand-ins)"}
     out.update(more)
     if keep is not None:
-        keep["solo"], keep["res"], keep["field"] = solo, res0, field0
+        keep["solo"], keep["res"], keep["field"], keep["bi"] = solo, res0, field0, bi0
     else:
         for dp in ctxs:
             dp.hv.close()

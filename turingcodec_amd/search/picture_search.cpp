@@ -434,7 +434,7 @@ int havoc_search_picture_uni_device(havoc_mi355x_ctx *ctx, int S, const havoc_se
     if (out_bi) std::memcpy(out_bi, hBi, size_t(2 * nPus) * sizeof(havoc_search_result));
     if (field_out) std::memcpy(field_out, hField, 2 * cells * 4);
     pst.steps = ctus_x + 2 * (ctus_y - 1);
-    pst.launches = stepLaunches ? pst.steps : 1;
+    pst.launches = (stepLaunches ? pst.steps : 1) + (out_bi ? 2 : 0);
     pst.bytes_down = int64_t(2 * nPus) * sizeof(havoc_search_result) * (out_bi ? 2 : 1) + (field_out ? int64_t(2 * cells * 4) : 0);
     pst.seconds_gpu = pst.seconds_total = now() - tStart;
     if (stats) *stats = pst;
