@@ -570,6 +570,12 @@ typedef struct
     int32_t bit_depth;
     double reciprocal_sqrt_lambda;
 } havoc_mi355x_search_params;      /* 48 bytes; = havoc_search_params */
+/* n INDEPENDENT searches (searchMotionUni per record) in ONE launch, a workgroup per search: d_pus = havoc_search_pu[n] (search_abi.h: geometry, the two
+ * predictors and their rates, the previous 2Nx2N vector -- inputs here, not derived), one reference picture (d_ref / d_phase), d_out =
+ * havoc_search_result[n].  The PUs must lie inside the picture with w, h multiples of 4 in 4..64 and the planes must reach ctb_size + 20 samples beyond it. */
+int havoc_mi355x_search_motion_uni(havoc_mi355x_ctx *ctx, int S, const havoc_mi355x_search_params *params, const void *d_src, int64_t src_origin, intptr_t src_stride,
+                                   const void *d_ref, int64_t ref_origin, intptr_t ref_stride, const void *d_phase, intptr_t plane_elems, int64_t phase_origin,
+                                   const void *d_pus, int n, void *d_out);
 size_t havoc_mi355x_search_workspace(int width, int height);
 int havoc_mi355x_search_picture_uni(havoc_mi355x_ctx *ctx, int S, const havoc_mi355x_search_params *params, const int64_t mvp_rate[2], const void *d_src,
                                     int64_t src_origin, intptr_t src_stride, const void *d_ref, const int64_t ref_origin[2], intptr_t ref_stride, const void *d_phase,

@@ -224,6 +224,26 @@ def main():
             if attempt == 0:
                 t_first = time.perf_counter() - t0
         t_batch = time.perf_counter() - t0
+        # the same searches with the loops inside the kernel: ONE launch per list, a workgroup per search (the real device only)
+        device = None
+        if args.device == "real":
+            L.havoc_search_motion_uni_device.argtypes = [vp, C.c_int, C.POINTER(st.Params), vp, i64, ip, vp, i64, ip, C.c_int, vp, ip, i64, vp, C.c_int, vp,
+                                                         C.POINTER(Stats)]
+            for attempt in (0, 1):
+                dstats = [Stats(), Stats()]
+                got_dev = np.zeros(len(pus), st.RESULT_DT)
+                t0 = time.perf_counter()
+                for lst in (0, 1):
+                    sel = np.flatnonzero(pus["ref_list"] == lst)
+                    sub = np.ascontiguousarray(pus[sel])
+                    out = np.zeros(len(sub), st.RESULT_DT)
+                    rc = L.havoc_search_motion_uni_device(ctx, S, C.byref(par), dplane[0], origin, stride, dplane[1 + lst], origin, stride, pad, dphase[lst], pe, origin,
+                                                          sub.ctypes.data, len(sub), out.ctypes.data, C.byref(dstats[lst]))
+                    assert rc == 0, (rc, dev.havoc_mi355x_last_error())
+                    got_dev[sel] = out
+                t_dev = time.perf_counter() - t0
+            device = {"mismatching_searches": same(got_dev, expected), "seconds": round(t_dev, 5), "searches_per_second": round(len(pus) / t_dev, 1),
+                      "launches": sum(s_.launches for s_ in dstats), "bytes_down": sum(s_.bytes_down for s_ in dstats)}
         # bi-directional refinement of the first `--bi` searches through the batch client: ideal predictors built on the device
         L.havoc_search_motion_bi.argtypes = [vp, C.c_int, C.POINTER(st.Params), vp, i64, ip, vp, i64, ip, C.c_int, vp, ip, i64, vp, i64, vp, vp, C.c_int, vp,
                                              C.c_int, C.POINTER(Stats)]
@@ -253,6 +273,7 @@ def main():
             "searches_per_second": round(len(pus) / t_batch, 1), "loop_calls_per_second": round(int(expected["calls"].sum()) / t_batch, 1),
             "launches_per_search": round(tot("launches") / len(pus), 4), "threads": args.threads,
             "max_replays_of_one_search": int(got["replays"].max()),
+            "loops_inside_the_kernel": device,
             "bi": {"searches": nbi, "mismatching": same(got_bi_batch, expected_bi, ["mv", "mvd", "mvp_flag", "calls", "cost_subpel"]), "seconds": round(t_bi, 4),
                    "launches": sum(s_.launches for s_ in bi_stats), "rounds": max(s_.rounds for s_ in bi_stats)},
         }

@@ -139,6 +139,10 @@ def _check_report(r, searches):
     assert c["unregistered"]["launches"] == c["unregistered"]["table_calls"] > 0
     # the batch client needs a handful of launches for the whole picture, not per search
     assert b["launches"] <= 8 * b["rounds"] and b["launches_per_search"] < 0.5, b
+    # the same independent searches with the loops inside the kernel (the real device): one launch per list, only the results come back
+    if b.get("loops_inside_the_kernel") is not None:
+        d = b["loops_inside_the_kernel"]
+        assert d["mismatching_searches"] == [] and d["launches"] == 2 and d["bytes_down"] == 56 * searches, d
     # bi-directional refinement through the batch client: ideal predictors built on the device, same decisions, a few launches
     assert b["bi"]["mismatching"] == [] and b["bi"]["searches"] > 0 and b["bi"]["launches"] <= 8 * (2 + b["bi"]["rounds"]), b["bi"]
     # 35-mode intra stage: same distortions, costs and refinement order as the per-call loop through the reference tables

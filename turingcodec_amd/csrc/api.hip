@@ -41,6 +41,8 @@ hipError_t launch_intra_expand(hipStream_t, const void *, const int32_t *, const
 hipError_t launch_intra_decide(hipStream_t, const void *, const int32_t *, const int32_t *, const int32_t *, const int32_t *, const uint32_t *, const int32_t *, const void *, int,
                                int, int32_t, void *, void *);
 size_t search_workspace_bytes(int width, int height);
+hipError_t launch_search_list(hipStream_t, int S, const havoc_mi355x_search_params *, const void *, long, long, const void *, long, long, const void *, long, long, const void *,
+                              int, void *);
 hipError_t launch_search_picture_uni(hipStream_t, int S, const havoc_mi355x_search_params *, const int64_t *, const void *, long, long, const void *, const long *, long,
                                      const void *, long, const long *, const void *, const int32_t *, int, int, int, void *, void *, int16_t *, void *, int);
 hipError_t launch_rdoq(hipStream_t, int bd, int log2, int16_t *, const int16_t *, const uint8_t *, const void *, int, int32_t *, void *);
@@ -534,6 +536,18 @@ int havoc_mi355x_level_stats(havoc_mi355x_ctx *ctx, const int16_t *d_levels, con
 {
     REQUIRE_CTX(); REQUIRE(njobs >= 0, "njobs < 0");
     return check(launch_level_stats(LS(ctx), d_levels, d_jobs, njobs, d_out), "level_stats");
+}
+
+int havoc_mi355x_search_motion_uni(havoc_mi355x_ctx *ctx, int S, const havoc_mi355x_search_params *params, const void *d_src, int64_t src_origin, intptr_t src_stride,
+                                   const void *d_ref, int64_t ref_origin, intptr_t ref_stride, const void *d_phase, intptr_t plane_elems, int64_t phase_origin,
+                                   const void *d_pus, int n, void *d_out)
+{
+    REQUIRE_CTX(); REQUIRE_S();
+    REQUIRE(params, "null argument"); REQUIRE(n >= 0, "n < 0");
+    REQUIRE(params->bit_depth >= 8 && params->bit_depth <= (S == 1 ? 8 : 10), "bit_depth must be 8 (S=1) or 8..10 (S=2)");
+    return check(launch_search_list(LS(ctx), S, params, d_src, (long)src_origin, src_stride, d_ref, (long)ref_origin, ref_stride, d_phase, plane_elems, (long)phase_origin,
+                                    d_pus, n, d_out),
+                 "search_motion_uni");
 }
 
 size_t havoc_mi355x_search_workspace(int width, int height) { return width > 0 && height > 0 ? search_workspace_bytes(width, height) : 0; }

@@ -547,6 +547,66 @@ struct DeviceView
     }
 };
 
+// what a uni-directional search needs before its loops run: the view of (PU, list), the source block and a window of the reference picture
+// around the start candidates of fullPel in LDS.  The caller's barrier follows.
+template <int S>
+__device__ __forceinline__ void stage_uni(const SearchArgs &a, Lds<S> &x, DeviceView<S> &view, const havoc_search::PuContext &pu, const int list)
+{
+    const int tid = threadIdx.x;
+    const long sbb = a.refStride * S;
+    const long at = (long)pu.y0 * a.refStride + pu.x0;
+    view.ref = a.ref[list] + at * S;
+    view.phase = a.phase[list] + at * S;
+    view.sbb = sbb;
+    view.planeBytes = a.planeElems * S;
+    view.w = pu.w;
+    view.h = pu.h;
+    view.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    view.lane = tid & 63;
+    view.tid = tid;
+    view.x = &x;
+    {   // the window: the start candidates of fullPel (zero, the two predictors, the previous 2Nx2N vector) and a margin around them
+        const havoc_search::LimitFullPelMv limit(pu, a.sp);
+        int x0 = 0, x1 = 0, y0 = 0, y1 = 0;
+        Mv first0;
+        for (int k = 0; k < 3; ++k)
+        {
+            if (k == 2 && pu.part2Nx2N && pu.cqtDepth == 0) break;
+            Mv m = k < 2 ? havoc_search::shr2(Mv(int16_t(pu.mvp[k].x + 1), int16_t(pu.mvp[k].y + 1))) : havoc_search::shr2(pu.mvPrevious2Nx2N);
+            limit(m);
+            if (k == 0) first0 = m;
+            x0 = min(x0, (int)m.x); x1 = max(x1, (int)m.x);
+            y0 = min(y0, (int)m.y); y1 = max(y1, (int)m.y);
+        }
+        if (((x1 - x0 + 2 * kWinMargin + pu.w) * S + 3) / 4 * 4 * (y1 - y0 + 2 * kWinMargin + pu.h) > kWinBytes * S)
+        {   // too far apart: the first predictor's surroundings
+            x0 = x1 = first0.x;
+            y0 = y1 = first0.y;
+        }
+        view.bx0 = x0 - kWinMargin; view.bx1 = x1 + kWinMargin;
+        view.by0 = y0 - kWinMargin; view.by1 = y1 + kWinMargin;
+        const int rowB = (view.bx1 - view.bx0 + pu.w) * S, rowDw = (rowB + 3) / 4, nRows = view.by1 - view.by0 + pu.h;
+        view.wsB = rowDw * 4;
+        const FastDiv fd(rowDw);
+        const char *g = view.ref + view.by0 * sbb + (long)view.bx0 * S;
+        uint32_t *win = reinterpret_cast<uint32_t *>(x.win);
+        for (int i = tid; i < rowDw * nRows; i += kThreads)      // the last dword of a row may read up to 3 bytes past it: still inside the padded row
+        {
+            const int y = rowDw <= 128 ? fd.div(i) : i / rowDw, k = i - y * rowDw;
+            win[i] = ld4(g + y * sbb + 4 * k);
+        }
+        const int srcDw = pu.w * S / 4;
+        const FastDiv fs(srcDw);
+        const char *gs = a.src + ((long)pu.y0 * a.srcStride + pu.x0) * S;
+        uint32_t *src = reinterpret_cast<uint32_t *>(x.src);
+        for (int i = tid; i < srcDw * pu.h; i += kThreads)
+        {
+            const int y = fs.div(i), k = i - y * srcDw;
+            src[i] = ld4(gs + y * a.srcStride * S + 4 * k);
+        }
+    }
+}
+
 // one CTU's searches in one list.  x.mv / x.valid [256 ..]: the cells left of and above the CTU, put there by the caller
 template <int S>
 __device__ __forceinline__ void search_ctu(const SearchArgs &a, Lds<S> &x, const int list, const int cx, const int cy, Mv &mvPrev)
@@ -568,7 +628,6 @@ __device__ __forceinline__ void search_ctu(const SearchArgs &a, Lds<S> &x, const
         return true;
     };
     const int first = a.ctuFirst[c], last = a.ctuFirst[c + 1];
-    const long sbb = a.refStride * S;
     for (int p = first; p < last; ++p)
     {
 #ifdef HAVOC_SEARCH_TIMING
@@ -579,57 +638,7 @@ __device__ __forceinline__ void search_ctu(const SearchArgs &a, Lds<S> &x, const
         havoc_search::derivePredictors(q, list, a.sp.picWidth, a.sp.picHeight, get, mvp);
         const havoc_search::PuContext pu = havoc_search::contextOf(q, ctb, mvp, a.mvpRate, mvPrev);
         DeviceView<S> view;
-        const long at = (long)q.y0 * a.refStride + q.x0;
-        view.ref = a.ref[list] + at * S;
-        view.phase = a.phase[list] + at * S;
-        view.sbb = sbb;
-        view.planeBytes = a.planeElems * S;
-        view.w = q.w;
-        view.h = q.h;
-        view.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-        view.lane = tid & 63;
-        view.tid = tid;
-        view.x = &x;
-        {   // the window: the start candidates of fullPel (zero, the two predictors, the previous 2Nx2N vector) and a margin around them
-            const havoc_search::LimitFullPelMv limit(pu, a.sp);
-            int x0 = 0, x1 = 0, y0 = 0, y1 = 0;
-            Mv first0;
-            for (int k = 0; k < 3; ++k)
-            {
-                if (k == 2 && pu.part2Nx2N && pu.cqtDepth == 0) break;
-                Mv m = k < 2 ? havoc_search::shr2(Mv(int16_t(mvp[k].x + 1), int16_t(mvp[k].y + 1))) : havoc_search::shr2(mvPrev);
-                limit(m);
-                if (k == 0) first0 = m;
-                x0 = min(x0, (int)m.x); x1 = max(x1, (int)m.x);
-                y0 = min(y0, (int)m.y); y1 = max(y1, (int)m.y);
-            }
-            if (((x1 - x0 + 2 * kWinMargin + q.w) * S + 3) / 4 * 4 * (y1 - y0 + 2 * kWinMargin + q.h) > kWinBytes * S)
-            {   // too far apart: the first predictor's surroundings
-                x0 = x1 = first0.x;
-                y0 = y1 = first0.y;
-            }
-            view.bx0 = x0 - kWinMargin; view.bx1 = x1 + kWinMargin;
-            view.by0 = y0 - kWinMargin; view.by1 = y1 + kWinMargin;
-            const int rowB = (view.bx1 - view.bx0 + q.w) * S, rowDw = (rowB + 3) / 4, nRows = view.by1 - view.by0 + q.h;
-            view.wsB = rowDw * 4;
-            const FastDiv fd(rowDw);
-            const char *g = view.ref + view.by0 * sbb + (long)view.bx0 * S;
-            uint32_t *win = reinterpret_cast<uint32_t *>(x.win);
-            for (int i = tid; i < rowDw * nRows; i += kThreads)      // the last dword of a row may read up to 3 bytes past it: still inside the padded row
-            {
-                const int y = rowDw <= 128 ? fd.div(i) : i / rowDw, k = i - y * rowDw;
-                win[i] = ld4(g + y * sbb + 4 * k);
-            }
-            const int srcDw = q.w * S / 4;
-            const FastDiv fs(srcDw);
-            const char *gs = a.src + ((long)q.y0 * a.srcStride + q.x0) * S;
-            uint32_t *src = reinterpret_cast<uint32_t *>(x.src);
-            for (int i = tid; i < srcDw * q.h; i += kThreads)
-            {
-                const int y = fs.div(i), k = i - y * srcDw;
-                src[i] = ld4(gs + y * a.srcStride * S + 4 * k);
-            }
-        }
+        stage_uni<S>(a, x, view, pu, list);
         __syncthreads();
 #ifdef HAVOC_SEARCH_TIMING
         const long tStaged = wall_clock64();
@@ -690,6 +699,49 @@ __device__ __forceinline__ void search_ctu(const SearchArgs &a, Lds<S> &x, const
         if (r.wrote2Nx2N) mvPrev = r.mvInteger;
     }
     __syncthreads();
+}
+
+// n INDEPENDENT (PU, list) searches whose predictors, rates and previous vector are inputs (havoc_search_pu, search_abi.h): no chain, a workgroup
+// per search, one launch -- what the launch + replay client havoc_search_motion_uni does in rounds.  One reference picture:
+// a.ref[0] / a.phase[0].
+template <int S>
+__global__ __launch_bounds__(kThreads) void k_search_list(const SearchArgs a, const havoc_search_pu *__restrict__ pus)
+{
+    __shared__ Lds<S> x;
+    const int i = blockIdx.x, tid = threadIdx.x;
+    const havoc_search_pu q = pus[i];
+    havoc_search::PuContext pu;
+    pu.x0 = q.x0; pu.y0 = q.y0; pu.w = q.w; pu.h = q.h;
+    pu.cuLog2Size = q.cu_log2_size;
+    pu.cqtDepth = q.cqt_depth;
+    pu.part2Nx2N = q.part_2Nx2N != 0;
+    pu.xCtb = q.x_ctb; pu.yCtb = q.y_ctb;
+    for (int k = 0; k < 2; ++k)
+    {
+        pu.mvp[k] = Mv(q.mvp[k][0], q.mvp[k][1]);
+        pu.mvpRate[k] = q.mvp_rate[k];
+    }
+    pu.mvPrevious2Nx2N = Mv(q.mv_previous_2Nx2N[0], q.mv_previous_2Nx2N[1]);
+    DeviceView<S> view;
+    stage_uni<S>(a, x, view, pu, 0);
+    __syncthreads();
+    havoc_search::MotionSearch<DeviceView<S>> search(a.sp, pu, view);
+    const havoc_search::UniResult r = search.run();
+    if (tid == 0)
+    {
+        havoc_search_result o = havoc_search_result();
+        o.mv[0] = r.mv.x; o.mv[1] = r.mv.y;
+        o.mvd[0] = r.mvd.x; o.mvd[1] = r.mvd.y;
+        o.mv_integer[0] = r.mvInteger.x; o.mv_integer[1] = r.mvInteger.y;
+        o.mvp_flag = (int16_t)r.mvpFlag;
+        o.wrote_2Nx2N = r.wrote2Nx2N;
+        o.calls = r.calls;
+        o.cost_integer = r.costInteger;
+        o.cost_subpel = r.costSubPel;
+        o.cost_mvd_zero[0] = r.costMvdZero[0];
+        o.cost_mvd_zero[1] = r.costMvdZero[1];
+        a.out[i] = o;
+    }
 }
 
 // The bi-directional refinement of every PU in `list` (searchBi, turing/Search.hpp:1796-1827, the branch without mvd_l1_zero_flag): nothing of it
@@ -910,6 +962,36 @@ __global__ __launch_bounds__(kThreads) void k_search_rows(const SearchArgs a)
 }
 
 } // namespace
+
+hipError_t launch_search_list(hipStream_t st, int S, const havoc_mi355x_search_params *sp, const void *src, long srcOrigin, long srcStride, const void *ref, long refOrigin,
+                              long refStride, const void *phase, long planeElems, long phaseOrigin, const void *pus, int n, void *out)
+{
+    if (n <= 0) return hipSuccess;
+    SearchArgs a = SearchArgs();
+    a.sp.picWidth = sp->pic_width;
+    a.sp.picHeight = sp->pic_height;
+    a.sp.ctbSize = sp->ctb_size;
+    a.sp.concurrentFrames = sp->concurrent_frames;
+    a.sp.met = sp->met != 0;
+    a.sp.smallSearchWindow = sp->small_search_window != 0;
+    a.sp.biSmallSearchWindow = sp->bi_small_search_window != 0;
+    a.sp.halfPel = sp->half_pel != 0;
+    a.sp.quarterPel = sp->quarter_pel != 0;
+    a.sp.reciprocalSqrtLambda = sp->reciprocal_sqrt_lambda;
+    a.sp.bitDepth = sp->bit_depth;
+    a.src = static_cast<const char *>(src) + srcOrigin * S;
+    a.ref[0] = a.ref[1] = static_cast<const char *>(ref) + refOrigin * S;
+    a.phase[0] = a.phase[1] = static_cast<const char *>(phase) + phaseOrigin * S;
+    a.srcStride = srcStride;
+    a.refStride = refStride;
+    a.planeElems = planeElems;
+    a.out = static_cast<havoc_search_result *>(out);
+    if (S == 1)
+        hipLaunchKernelGGL(k_search_list<1>, dim3(n), dim3(kThreads), 0, st, a, static_cast<const havoc_search_pu *>(pus));
+    else
+        hipLaunchKernelGGL(k_search_list<2>, dim3(n), dim3(kThreads), 0, st, a, static_cast<const havoc_search_pu *>(pus));
+    return hipGetLastError();
+}
 
 size_t search_workspace_bytes(int width, int height)
 {

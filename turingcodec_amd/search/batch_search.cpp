@@ -205,6 +205,46 @@ int havoc_search_motion_uni(havoc_mi355x_ctx *ctx, int S, const havoc_search_par
     return runSearches(ctx, S, params, fl, d_ref, ref_origin, ref_stride, ref_pad, d_phase, plane_elems, phase_origin, pus, n, out, threads, stats);
 }
 
+// The same n searches with the loops inside the kernel (havoc_mi355x_search_motion_uni, csrc/kernels_search.hip: a workgroup per search, ONE
+// launch, no rounds): the records go down (72 B each), the results come back (56 B each).  Arguments as havoc_search_motion_uni; the planes must
+// reach 84 samples beyond the picture (ref_pad >= 96).  Results identical except `replays` (0).
+int havoc_search_motion_uni_device(havoc_mi355x_ctx *ctx, int S, const havoc_search_params *params, const void *d_src, int64_t src_origin, intptr_t src_stride,
+                                   const void *d_ref, int64_t ref_origin, intptr_t ref_stride, int ref_pad, const void *d_phase, intptr_t plane_elems,
+                                   int64_t phase_origin, const havoc_search_pu *pus, int n, havoc_search_result *out, havoc_search_stats *stats)
+{
+    if (!ctx || !params || !pus || !out || n < 0 || (S != 1 && S != 2) || ref_pad < 96) return HAVOC_MI355X_EINVAL;
+    const double tStart = now();
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    if (n == 0) return 0;
+    const int W = params->pic_width, H = params->pic_height;
+    for (int i = 0; i < n; ++i)
+    {
+        const havoc_search_pu &q = pus[i];
+        if (q.w < 4 || q.h < 4 || q.w > 64 || q.h > 64 || (q.w & 3) || (q.h & 3) || q.x0 < 0 || q.y0 < 0 || q.x0 + q.w > W || q.y0 + q.h > H) return HAVOC_MI355X_EINVAL;
+    }
+    Arena arena(ctx);
+    void *dPus, *hPus, *dOut, *hOut;
+    RC(arena.get(size_t(n) * sizeof(havoc_search_pu), &dPus, &hPus));
+    RC(arena.get(size_t(n) * sizeof(havoc_search_result), &dOut, &hOut));
+    std::memcpy(hPus, pus, size_t(n) * sizeof(havoc_search_pu));
+    RC(havoc_mi355x_h2d_async(ctx, dPus, hPus, size_t(n) * sizeof(havoc_search_pu)));
+    havoc_mi355x_search_params dp;
+    static_assert(sizeof(dp) == sizeof(*params), "search ABI");
+    std::memcpy(&dp, params, sizeof(dp));
+    RC(havoc_mi355x_search_motion_uni(ctx, S, &dp, d_src, src_origin, src_stride, d_ref, ref_origin, ref_stride, d_phase, plane_elems, phase_origin, dPus, n, dOut));
+    RC(havoc_mi355x_d2h_async(ctx, hOut, dOut, size_t(n) * sizeof(havoc_search_result)));
+    RC(havoc_mi355x_sync(ctx));
+    std::memcpy(out, hOut, size_t(n) * sizeof(havoc_search_result));
+    if (stats)
+    {
+        stats->launches = 1;
+        stats->rounds = 1;
+        stats->bytes_down = int64_t(n) * sizeof(havoc_search_result);
+        stats->seconds_total = stats->seconds_gpu = now() - tStart;
+    }
+    return 0;
+}
+
 // Bi-directional refinement (searchMotionBi, turing/Search.hpp:1498-1657) of n (PU, list) pairs: list pus[i].ref_list is refined
 // around start[i] (quarter samples) against the prediction the OTHER list's vector pus[i].mv_other gives.  The "ideal second
 // predictor" clip(2 * source - other prediction) of every PU is built on the device (HavocPredUni from d_ref_other, then
