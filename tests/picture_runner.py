@@ -117,6 +117,25 @@ def main():
     for k in ("seconds_gpu", "seconds_host", "seconds_total"):
         d[k] = round(d[k], 5)
     report["picture"] = d
+    if args.device == "mock":
+        # the device-resident search is a kernel: the mock has nothing behind it.  What can be checked without a GPU is the host wrapper in front
+        # of it -- validation of the PU list, staging, the call -- ending in the stub's refusal; and the wrapper's own refusals
+        try:
+            decisions.picture_uni(ctx, S, par, dpic.value, origin, stride, dpic.value, (pe + origin, 2 * pe + origin), stride, pad, dphase.value, pe,
+                                  (origin, 16 * pe + origin), pus, first, cx, cy, rate, on_device=True, bi=True)
+            report["device_wrapper_on_mock"] = "returned"
+        except RuntimeError as e:
+            report["device_wrapper_on_mock"] = str(e)
+        refused = []
+        bad = pus.copy()
+        bad["x0"][0] = W      # outside the picture
+        for label, kw, p_ in (("pu_outside", {}, bad), ("short_border", {"ref_pad": 64}, pus)):
+            try:
+                decisions.picture_uni(ctx, S, par, dpic.value, origin, stride, dpic.value, (pe + origin, 2 * pe + origin), stride, kw.get("ref_pad", pad), dphase.value, pe,
+                                      (origin, 16 * pe + origin), p_, first, cx, cy, rate, on_device=True)
+            except RuntimeError as e:
+                refused.append(label + ": " + str(e))
+        report["device_wrapper_refusals"] = refused
     if args.device == "real":
         # the same picture with the decision loops inside the kernel (havoc_search_picture_uni_device): no rounds, one launch per wavefront step
         for form in ("steps", "rows"):      # one launch per wavefront step / one launch, rows waiting for each other inside the kernel (the default)

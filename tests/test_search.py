@@ -202,6 +202,10 @@ def test_picture_client_host_logic_on_the_mock_device(res, bit_depth):
     r = _run_picture("mock", "--res", res, "--bit-depth", str(bit_depth), "--threads", "8", "--repeat", "1")
     assert r["device"] == "mock" and "reference tables" in r["expected_from"]
     _check_picture(r)
+    # the wrapper of the device-resident search: argument marshalling and validation run, the mock's kernel stub refuses (-10001) and the
+    # wrapper's own checks refuse a PU outside the picture and planes whose border is too short for the search range
+    assert "-10001" in r["device_wrapper_on_mock"], r["device_wrapper_on_mock"]
+    assert len(r["device_wrapper_refusals"]) == 2 and all("-10001" in x for x in r["device_wrapper_refusals"]), r["device_wrapper_refusals"]
 
 
 def test_picture_walk_over_oracle_equals_walk_over_reference_tables():
