@@ -218,9 +218,14 @@ def test_picture_walk_over_oracle_equals_walk_over_reference_tables():
     planes = [_aligned(p) for p in planes]
     pus, first, cx, cy = workload.picture_pus(W, H, 5)
     par = st.medium_params(W, H, 8)
-    a, fa = st.Client("oracle").picture_uni(par, planes[0], planes[1], planes[2], stride, 96, pus, first, cx, cy)
-    b, fb = st.Client("ref", 3).picture_uni(par, planes[0], planes[1], planes[2], stride, 96, pus, first, cx, cy)
+    a, fa, ba = st.Client("oracle").picture_uni(par, planes[0], planes[1], planes[2], stride, 96, pus, first, cx, cy, bi=True)
+    b, fb, bb = st.Client("ref", 3).picture_uni(par, planes[0], planes[1], planes[2], stride, 96, pus, first, cx, cy, bi=True)
     assert a.tobytes() == b.tobytes() and np.array_equal(fa, fb)
+    # the bi-directional refinements of the walk (searchBi: list 0 against list 1's vector, list 1 against list 0's refined one)
+    assert ba.tobytes() == bb.tobytes() and (ba["calls"] > 0).all() and (ba["mv"] != a["mv"]).any()
+    # without them the uni-directional walk is the same
+    a2, fa2 = st.Client("oracle").picture_uni(par, planes[0], planes[1], planes[2], stride, 96, pus, first, cx, cy)
+    assert a2.tobytes() == a.tobytes() and np.array_equal(fa2, fa)
     # the dependency is real: predictors differ from PU to PU and are mostly non-zero on this clip
     assert len(np.unique(a["mv"], axis=0)) > 3
 
