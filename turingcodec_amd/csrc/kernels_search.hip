@@ -232,7 +232,6 @@ struct Lds      // of a workgroup
 {
     int32_t sad[2][kWaves];
     int32_t satd[2][12];
-    int32_t key[2][12];
     int32_t table[16 * 12];      // SADs of a rectangle of full-sample displacements (the grid of a bi-directional refinement)
     int32_t mv[256 + 32];        // the CTU's own 16 x 16 cells, the 16 cells left of it, the 16 cells above it
     uint8_t valid[256 + 32];
@@ -414,10 +413,17 @@ struct DeviceView
         const LdsPtr src = ldsPtr(x->src);
         const int ts = ((w | h) & 7) ? 4 : 8, tw = w / ts;
         const int rows = tw * (h / ts) * ts;
+        // the positions stay in registers: position `j` of a lane (group) or wavefront is picked with compares, not by address (an indexed array
+        // would live in private memory), and nothing goes through LDS before the SATDs do
+        int32_t packed[9];
 #pragma unroll
-        for (int i = 0; i < 9; ++i)
-            if (i < n && tid == i) x->key[satdTurn][i] = havoc_search::MotionField::pack(positions[i]);
-        __syncthreads();
+        for (int i = 0; i < 9; ++i) packed[i] = havoc_search::MotionField::pack(positions[i < n ? i : 0]);
+        auto pick = [&](int j) {
+            int32_t k = packed[0];
+#pragma unroll
+            for (int i = 1; i < 9; ++i) k = j == i ? packed[i] : k;
+            return havoc_search::MotionField::unpack(k);
+        };
 #ifdef HAVOC_SEARCH_TIMING
         const long c1 = clock64();
 #endif
@@ -426,7 +432,7 @@ struct DeviceView
             // alone, but a third less throughput with 8 - 16 pictures in flight -- a reduction and an exchange per pass instead of per position)
             for (int i = wave; i < n; i += kWaves)
             {
-                const int v = wave_satd<S>(src, w * S, predAt(havoc_search::MotionField::unpack(x->key[satdTurn][i])), sbb, w, h, lane);
+                const int v = wave_satd<S>(src, w * S, predAt(pick(i)), sbb, w, h, lane);
                 if (lane == 0) x->satd[satdTurn][i] = v;
             }
         }
@@ -439,7 +445,7 @@ struct DeviceView
             {
                 const int j = base + wave * G + g;
                 const bool on = j < n && l < rows;
-                const char *pred = predAt(havoc_search::MotionField::unpack(x->key[satdTurn][j < n ? j : 0]));
+                const char *pred = predAt(pick(j < n ? j : 0));
                 int v;
                 if (ts == 8)
                 {
@@ -511,12 +517,11 @@ struct DeviceView
 #endif
         __syncthreads();
         {   // lane i reads position i, then the nine values move to scalar registers
-            const int i = lane < 9 ? lane : 0;
-            const int v = x->satd[satdTurn][i], key = x->key[satdTurn][i];
+            const int v = x->satd[satdTurn][lane < 9 ? lane : 0];
 #pragma unroll
             for (int j = 0; j < 9; ++j)
             {
-                satdKey[j] = __builtin_amdgcn_readlane(key, j);
+                satdKey[j] = packed[j];
                 satdValue[j] = __builtin_amdgcn_readlane(v, j);
             }
         }
