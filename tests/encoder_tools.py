@@ -39,6 +39,9 @@ CASES = {
     "gpu_ra_medium_qp22": (256, 144, 3, 9, 8, ["--qp", "22", "--speed", "medium"]),
     "gpu_ai_fast_qp32": (256, 144, 1, 9, 8, ["--qp", "32", "--speed", "fast", "--max-gop-n", "1", "--max-gop-m", "1"]),
     "gpu_ra_medium_10bit": (256, 144, 3, 21, 10, ["--qp", "27", "--speed", "medium", "--bit-depth", "10"]),
+    # not a stream test: the bench's picture size and clip generator, for profiles/measure_call_mix.py (the reference's call mix by block size)
+    "mix_1080p_qp32": (1920, 1080, 9, 11, 8, ["--qp", "32", "--speed", "medium"]),
+    "mix_4k_qp32": (3840, 2160, 9, 11, 8, ["--qp", "32", "--speed", "medium"]),
 }
 
 

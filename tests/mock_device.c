@@ -19,6 +19,32 @@ struct havoc_mi355x_ctx { int device; long launches; };
 static long g_launches = 0;
 long mock_launches(void) { return g_launches; }
 
+/* HAVOC_MOCK_HISTOGRAM=<file>: the jobs of every call by entry point and block size, written when the context is destroyed -- how
+ * profiles/measure_call_mix.py reads the call mix of the reference's own encoder (run over libhavoc_classic.so + this stand-in) */
+enum { H_SAD, H_SAD4, H_SATD, H_PRED_UNI8, H_PRED_UNI4, H_PRED_BI8, H_PRED_BI4, H_SUBTRACT_BI, H_INTRA, H_TRANSFORM, H_INVERSE, H_SSD, H_QUANTIZE, H_RDOQ, H_COUNT };
+static const char *const g_hname[H_COUNT] = {"sad", "sad4", "satd", "pred_uni8", "pred_uni4", "pred_bi8", "pred_bi4", "subtract_bi", "intra", "transform",
+                                             "inverse_transform", "ssd", "quantize", "rdoq"};
+static long g_hist[H_COUNT][65][65];
+static void tally(int fn, int w, int h) { if (w >= 0 && w <= 64 && h >= 0 && h <= 64) ++g_hist[fn][w][h]; }
+static void write_histogram(void)
+{
+    const char *path = getenv("HAVOC_MOCK_HISTOGRAM");
+    if (!path) return;
+    FILE *f = fopen(path, "w");
+    if (!f) return;
+    fprintf(f, "{");
+    for (int fn = 0, first = 1; fn < H_COUNT; ++fn)
+        for (int w = 0; w <= 64; ++w)
+            for (int h = 0; h <= 64; ++h)
+                if (g_hist[fn][w][h])
+                {
+                    fprintf(f, "%s\"%s %dx%d\": %ld", first ? "" : ", ", g_hname[fn], w, h, g_hist[fn][w][h]);
+                    first = 0;
+                }
+    fprintf(f, "}\n");
+    fclose(f);
+}
+
 const char *havoc_mi355x_last_error(void) { return "mock device"; }
 const char *havoc_mi355x_version(void) { return "MOCK (tests only)"; }
 
@@ -29,7 +55,7 @@ int havoc_mi355x_create(havoc_mi355x_ctx **ctx, int device, void *stream)
     (*ctx)->device = device;
     return 0;
 }
-void havoc_mi355x_destroy(havoc_mi355x_ctx *ctx) { free(ctx); }
+void havoc_mi355x_destroy(havoc_mi355x_ctx *ctx) { write_histogram(); free(ctx); }
 int havoc_mi355x_sync(havoc_mi355x_ctx *ctx) { (void)ctx; return 0; }
 int havoc_mi355x_malloc(havoc_mi355x_ctx *ctx, void **p, size_t n) { (void)ctx; *p = calloc(1, n + 64); return *p ? 0 : -1; }
 int havoc_mi355x_free(havoc_mi355x_ctx *ctx, void *p) { (void)ctx; free(p); return 0; }
@@ -51,6 +77,7 @@ int havoc_mi355x_host_free(havoc_mi355x_ctx *ctx, void *h) { (void)ctx; free(h);
 int havoc_mi355x_sad(havoc_mi355x_ctx *ctx, int S, const void *src, intptr_t ss, const void *ref, intptr_t rs, const havoc_mi355x_pair_job *j, int n, int32_t *out)
 {
     (void)ctx; ++g_launches;
+    for (int i = 0; i < n; ++i) tally(H_SAD, j[i].w, j[i].h);
     for (int i = 0; i < n; ++i) out[i] = oracle_sad(AT(src, j[i].a_off, S), ss, AT(ref, j[i].b_off, S), rs, j[i].w, j[i].h, S);
     return 0;
 }
@@ -62,6 +89,7 @@ int havoc_mi355x_sad4(havoc_mi355x_ctx *ctx, int S, const void *src, intptr_t ss
     {
         const void *r[4];
         int v[4];
+        tally(H_SAD4, j[i].w, j[i].h);
         for (int k = 0; k < 4; ++k) r[k] = AT(ref, j[i].ref_off[k], S);
         oracle_sad4(AT(src, j[i].src_off, S), ss, r, rs, v, j[i].w, j[i].h, S);
         for (int k = 0; k < 4; ++k) out[4 * i + k] = v[k];
@@ -86,6 +114,7 @@ int havoc_mi355x_satd(havoc_mi355x_ctx *ctx, int S, int max_w, int max_h, const 
                       const havoc_mi355x_pair_job *j, int n, int32_t *out)
 {
     (void)ctx; (void)max_w; (void)max_h; ++g_launches;
+    for (int i = 0; i < n; ++i) tally(H_SATD, j[i].w, j[i].h);
     for (int i = 0; i < n; ++i) out[i] = oracle_pu_satd(AT(a, j[i].a_off, S), sa, AT(b, j[i].b_off, S), sb, j[i].w, j[i].h, S);
     return 0;
 }
@@ -104,6 +133,7 @@ int havoc_mi355x_pred_uni(havoc_mi355x_ctx *ctx, int S, int taps, int bitDepth, 
                           const havoc_mi355x_pred_uni_job *j, int n)
 {
     (void)ctx; (void)max_w; (void)max_h; ++g_launches;
+    for (int i = 0; i < n; ++i) tally(taps == 8 ? H_PRED_UNI8 : H_PRED_UNI4, j[i].w, j[i].h);
     for (int i = 0; i < n; ++i)
         oracle_pred_uni((char *)dst + (long)j[i].dst_off * S, sd, AT(ref, j[i].ref_off, S), sr, j[i].w, j[i].h, j[i].xFrac, j[i].yFrac, bitDepth, taps, S);
     return 0;
@@ -113,6 +143,7 @@ int havoc_mi355x_subtract_bi(havoc_mi355x_ctx *ctx, int S, int bitDepth, void *d
                              const havoc_mi355x_subtract_bi_job *j, int n)
 {
     (void)ctx; ++g_launches;
+    for (int i = 0; i < n; ++i) tally(H_SUBTRACT_BI, j[i].w, j[i].h);
     for (int i = 0; i < n; ++i)
         oracle_subtract_bi((char *)dst + (long)j[i].dst_off * S, sd, AT(pred, j[i].pred_off, S), sp, AT(src, j[i].src_off, S), ss, j[i].w, j[i].h, bitDepth, S);
     return 0;
@@ -166,6 +197,7 @@ int havoc_mi355x_intra_satd35(havoc_mi355x_ctx *ctx, int S, int bitDepth, int lo
 int havoc_mi355x_intra(havoc_mi355x_ctx *ctx, int S, int bitDepth, int log2, void *dst, intptr_t sd, const void *nb, const havoc_mi355x_intra_job *j, int n)
 {
     (void)ctx; ++g_launches;
+    for (int i = 0; i < n; ++i) tally(H_INTRA, 1 << log2, 1 << log2);
     for (int i = 0; i < n; ++i)
         oracle_intra((char *)dst + (long)j[i].dst_off * S, sd, AT(nb, j[i].nb_off, S), log2, j[i].mode, (j[i].edge && log2 < 5) ? 1 : 0, bitDepth, S);
     return 0;
@@ -176,6 +208,7 @@ int havoc_mi355x_intra(havoc_mi355x_ctx *ctx, int S, int bitDepth, int log2, voi
 int havoc_mi355x_ssd(havoc_mi355x_ctx *ctx, int S, const void *a, intptr_t sa, const void *b, intptr_t sb, const havoc_mi355x_pair_job *j, int n, uint32_t *out)
 {
     (void)ctx; ++g_launches;
+    for (int i = 0; i < n; ++i) tally(H_SSD, j[i].w, j[i].h);
     for (int i = 0; i < n; ++i) out[i] = oracle_ssd(AT(a, j[i].a_off, S), sa, AT(b, j[i].b_off, S), sb, j[i].w, j[i].h, S);
     return 0;
 }
@@ -191,6 +224,7 @@ int havoc_mi355x_pred_bi(havoc_mi355x_ctx *ctx, int S, int taps, int bitDepth, i
                          const havoc_mi355x_pred_bi_job *j, int n)
 {
     (void)ctx; (void)max_w; (void)max_h; ++g_launches;
+    for (int i = 0; i < n; ++i) tally(taps == 8 ? H_PRED_BI8 : H_PRED_BI4, j[i].w, j[i].h);
     for (int i = 0; i < n; ++i)
         oracle_pred_bi((char *)dst + (long)j[i].dst_off * S, sd, AT(ref, j[i].ref0_off, S), AT(ref, j[i].ref1_off, S), sr, j[i].w, j[i].h, j[i].xFrac0,
                        j[i].yFrac0, j[i].xFrac1, j[i].yFrac1, bitDepth, taps, S);
@@ -201,6 +235,7 @@ int havoc_mi355x_transform(havoc_mi355x_ctx *ctx, int bitDepth, int trType, int 
                            const havoc_mi355x_tu_job *j, int n)
 {
     (void)ctx; ++g_launches;
+    for (int i = 0; i < n; ++i) tally(H_TRANSFORM, 1 << log2, 1 << log2);
     for (int i = 0; i < n; ++i) oracle_transform(coeffs + j[i].coef_off, res + j[i].res_off, stride_res, log2, trType, bitDepth);
     return 0;
 }
@@ -216,6 +251,7 @@ int havoc_mi355x_inverse_transform_add(havoc_mi355x_ctx *ctx, int S, int bitDept
                                        const int16_t *coeffs, const havoc_mi355x_tu_job *j, int n)
 {
     (void)ctx; ++g_launches;
+    for (int i = 0; i < n; ++i) tally(H_INVERSE, 1 << log2, 1 << log2);
     for (int i = 0; i < n; ++i)
         oracle_inverse_transform_add((char *)dst + (long)j[i].dst_off * S, sd, AT(pred, j[i].pred_off, S), sp, coeffs + j[i].coef_off, log2, trType, bitDepth, S);
     return 0;
@@ -224,6 +260,7 @@ int havoc_mi355x_inverse_transform_add(havoc_mi355x_ctx *ctx, int S, int bitDept
 int havoc_mi355x_quantize(havoc_mi355x_ctx *ctx, int16_t *dst, const int16_t *src, const havoc_mi355x_quant_job *j, int n, int32_t *cbf)
 {
     (void)ctx; ++g_launches;
+    for (int i = 0; i < n; ++i) tally(H_QUANTIZE, j[i].n > 64 ? 64 : j[i].n, 0);
     for (int i = 0; i < n; ++i) cbf[i] = oracle_quantize(dst + j[i].dst_off, src + j[i].src_off, j[i].scale, j[i].shift, j[i].offset, j[i].n);
     return 0;
 }
