@@ -64,6 +64,8 @@ def parse_args():
                     "context each")
     ap.add_argument("--traffic", type=int, default=1, help="1 (default): the plain N=1 run measures roofline.traffic itself with two rocprofv3 --pmc passes "
                     "of a two-step run (when rocprofv3 is on PATH); 0: take it from the committed profiles/r*_hbm_traffic.csv")
+    ap.add_argument("--decision-distance", type=int, default=1, help="with --decisions 2: temporal distance of the decision-driven picture's two references "
+                    "(1 = a leaf B picture of the hierarchy; 2, 4, 8 = its upper layers: longer vectors, 2.5 - 3 x the calls per search)")
     ap.add_argument("--decision-walk", type=int, default=0, help="with --decisions 2: also time the same walk through the reference's tables on one host core "
                     "and compare every decision (the cpu_baseline leg of the plain run)")
     ap.add_argument("--search-client", choices=["device", "batch"], default="device",
@@ -1061,7 +1063,7 @@ def cpu_decision_walk(args, keep):
         return None
     tmp = os.path.join(tempfile.gettempdir(), f"havoc_walk_{os.getpid()}.npz")
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", "decisions", "--res", args.res, "--bit-depth", str(args.bit_depth), "--seed", str(args.seed),
-           "--qp", str(args.qp), "--cpu-out", tmp]
+           "--qp", str(args.qp), "--cpu-out", tmp, "--decision-distance", str(max(1, args.decision_distance))]
     try:
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
         if out.returncode != 0:
@@ -1093,7 +1095,7 @@ def cpu_decision_worker(args):
     import search_tools as st
     from turingcodec_amd.decisions import decision_inputs
     w, h = (int(v) for v in args.res.split("x"))
-    d = decision_inputs(w, h, args.bit_depth, args.qp, args.seed)
+    d = decision_inputs(w, h, args.bit_depth, args.qp, args.seed, distance=max(1, args.decision_distance))
     planes = [_aligned(p) for p in d["planes"]]
     cl = st.Client("ref", -1)      # -1: everything the CPU supports = the reference's x86 JIT tables
     best = None
@@ -1152,7 +1154,8 @@ def decision_path(args, Havoc, res, bit_depth, qp, pictures, seconds=1.5, keep=N
     ctxs = []
     for k in range(pictures):
         hv = Havoc(0, stream="new")
-        ctxs.append(DecisionPicture(hv, w, h, bit_depth, qp, seed=args.seed + 13 * k, threads=per, search_on_device=args.search_client == "device"))
+        ctxs.append(DecisionPicture(hv, w, h, bit_depth, qp, seed=args.seed + 13 * k, threads=per, search_on_device=args.search_client == "device",
+                                    distance=max(1, args.decision_distance)))
     for dp in ctxs:
         dp.step()      # allocates the client's pinned work memory, pages code in
     # one picture alone, all replay threads: the latency a dependency-bound encoder sees
@@ -1225,6 +1228,7 @@ def decision_path(args, Havoc, res, bit_depth, qp, pictures, seconds=1.5, keep=N
                                           "prediction_and_transform_tree_decisions": round(t_chain * 1e3, 3),
                                           "intra_35_mode_stage_and_rd_refinement": round(t_intra * 1e3, 3)},
            "searches_per_picture": int(2 * len(solo.pus)), "ctus": solo.cx * solo.cy,
+           "reference_distance": max(1, args.decision_distance), "loop_calls_per_search": round(float(res0["calls"].mean()), 1),
            "bi_directional_refinements_per_picture": bi_count,
            "transform_tree_decisions": {"units": int(len(solo.units)), "candidates": int(solo.rqt_stats.candidates), "launches": int(solo.rqt_stats.launches),
                                         "launches_per_ctu": round(solo.rqt_stats.launches / (solo.cx * solo.cy), 4),
@@ -1244,7 +1248,8 @@ def decision_path(args, Havoc, res, bit_depth, qp, pictures, seconds=1.5, keep=N
            "search_client": ("decision loops inside the kernel (csrc/kernels_search.hip: search/decision.hpp compiled for gfx950; a workgroup per (CTU row, list) "
                              "waits for the row above inside ONE launch; window, source block and neighbour vectors in LDS); only the results come back"
                              if args.search_client == "device" else "SAD-surface / tile-SATD batch launches, the reference's loops replayed on host threads"),
-           "what": "per picture: 2 x 15 phase planes; every PU's uni-directional search in both lists, CTUs in WPP wavefront order (CTU (x, y) after "
+           "what": ("per picture (its two references at temporal distance %d -- 1 = the leaf B pictures, half of a SOP of 8; the upper layers' searches are "
+                   "2.5 - 3 x longer: see the distance-4 entry): 2 x 15 phase planes; every PU's uni-directional search in both lists, CTUs in WPP wavefront order (CTU (x, y) after "
                    "(x + 1, y - 1)), predictors of a PU = the vectors decided for its left / upper neighbours, mvPreviousInteger2Nx2N handed along the CTU "
                    "row (turingcodec_amd/search/picture_order.hpp), then the bi-directional refinement of every PU (searchBi: list 0 against list 1's "
                    "vector, list 1 against list 0's refined one; device search only); then prediction at the chosen vectors and the residual-quadtree decision of every inter unit (both tree depths of "
@@ -1253,7 +1258,7 @@ def decision_path(args, Havoc, res, bit_depth, qp, pictures, seconds=1.5, keep=N
                    "the device, deblocking, padding; and the picture's intra candidates (42 partitions per CTU: 35-mode SATD stage, then every candidate "
                    "mode of the refinement order reconstructed through T -> RDOQ -> IT and the champion picked; neighbours from the source picture, not "
                    "from the preceding partition's reconstruction). Not in it: the mode decision between the searched PUs (uni / bi / merge) and between "
-                   "inter and intra, CABAC (the rate terms of the tree / intra decisions are stand-ins)"}
+                   "inter and intra, CABAC (the rate terms of the tree / intra decisions are stand-ins)") % max(1, args.decision_distance)}
     out.update(more)
     if keep is not None:
         keep["solo"], keep["res"], keep["field"], keep["bi"] = solo, res0, field0, bi0
@@ -1267,15 +1272,17 @@ def decision_children(args):
     """the decision-driven path of --res / --qp and of 4K QP32, each in a process of its own (16 hardware queues: see the top of this file), run BEFORE
     this process touches the device so that nothing else holds queues or memory while they are measured"""
     paths, walk = {}, None
-    for dres, dqp, label in ((args.res, args.qp, f"decision-driven path {args.res} {args.bit_depth}-bit QP{args.qp}"),
-                             ("3840x2160", 32, "decision-driven path 3840x2160 8-bit QP32 (BASELINE.json metric: 4K RA QP32)")):
+    for dres, dqp, dist_, label in ((args.res, args.qp, 1, f"decision-driven path {args.res} {args.bit_depth}-bit QP{args.qp}"),
+                                    (args.res, args.qp, 4, f"decision-driven path {args.res} {args.bit_depth}-bit QP{args.qp}, references at temporal distance 4 "
+                                                          "(an upper layer of the hierarchy: longer vectors, three times the calls per search)"),
+                                    ("3840x2160", 32, 1, "decision-driven path 3840x2160 8-bit QP32 (BASELINE.json metric: 4K RA QP32)")):
         if label.startswith("decision-driven path 3840") and args.res == "3840x2160":
             continue
         try:
-            want_walk = dres == args.res and not args.no_cpu_baseline
+            want_walk = dres == args.res and dist_ == 1 and not args.no_cpu_baseline
             cmd = [sys.executable, os.path.abspath(__file__), "--decisions", "2", "--res", dres, "--bit-depth", str(args.bit_depth if dres == args.res else 8),
-                   "--qp", str(dqp), "--seed", str(args.seed), "--decision-pictures", str(max(1, args.decision_pictures)), "--search-client", args.search_client,
-                   "--decision-walk", "1" if want_walk else "0"]
+                   "--qp", str(dqp), "--seed", str(args.seed), "--decision-pictures", str(max(1, args.decision_pictures) if dist_ == 1 else 8),
+                   "--search-client", args.search_client, "--decision-distance", str(dist_), "--decision-walk", "1" if want_walk else "0"]
             child = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
             if child.returncode != 0:
                 raise RuntimeError(child.stderr[-600:])
@@ -1586,7 +1593,7 @@ def main():
             # the decision-driven path: what the batches cost when decisions sit between them
             decision_walk = early.get("walk")
             for label, r in early.get("paths", {}).items():
-                if "error" not in r and label.startswith(f"decision-driven path {args.res} "):
+                if "error" not in r and label == f"decision-driven path {args.res} {args.bit_depth}-bit QP{args.qp}":
                     r["ratio_to_value"] = round(r["value"] / out["value"], 5)
                     r["ratio_note"] = ("`value` is one picture's primitive calls as ideal whole-frame batches (no decision between launches); this is the "
                                        "same kernels driven by decisions in an order a bit-exact encoder could issue them")

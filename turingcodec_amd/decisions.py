@@ -139,12 +139,15 @@ def picture_uni(ctx, S, params, d_src, src_origin, src_stride, d_ref, ref_origin
     return (out, field, stats, out_bi) if bi else (out, field, stats)
 
 
-def decision_inputs(width, height, bit_depth=8, qp=32, seed=11, density=1.0, frames=None):
-    """host side of a DecisionPicture: padded luma planes (source, list 0, list 1), the picture's PUs in decision order, search parameters"""
+def decision_inputs(width, height, bit_depth=8, qp=32, seed=11, density=1.0, frames=None, distance=1):
+    """host side of a DecisionPicture: padded luma planes (source, list 0, list 1), the picture's PUs in decision order, search parameters.
+    distance: temporal distance of the two reference pictures (1 = the leaf B pictures of the hierarchy, half of a SOP of 8; 2, 4, 8 = its upper
+    layers, whose vectors are longer and whose searches run the star / raster refinement far more often)"""
     from . import workload
     pad = 96
     if frames is None:
-        frames = workload.synth_frames(width, height, 3, seed, bit_depth)
+        frames = workload.synth_frames(width, height, 2 * distance + 1, seed, bit_depth)
+        frames = [frames[0], frames[distance], frames[2 * distance]]
     planes = [workload.pad_plane(f[0], pad) for f in (frames[1], frames[0], frames[2])]
     stride = planes[0].shape[1]
     pus, ctu_first, cx, cy = workload.picture_pus(width, height, seed, density)
@@ -266,7 +269,7 @@ class DecisionPicture:
 
     PAD = 96
 
-    def __init__(self, hv, width, height, bit_depth=8, qp=32, seed=11, threads=16, frames=None, density=1.0, intra=True, search_on_device=True):
+    def __init__(self, hv, width, height, bit_depth=8, qp=32, seed=11, threads=16, frames=None, density=1.0, intra=True, search_on_device=True, distance=1):
         import torch
         from . import havoc as hmod
         from . import workload
@@ -275,7 +278,7 @@ class DecisionPicture:
         self.search_on_device = search_on_device      # the decision loops inside the kernel (kernels_search.hip) / launch + host replay rounds
         self.S = 1 if bit_depth == 8 else 2
         self.dt = np.uint8 if self.S == 1 else np.uint16
-        d = decision_inputs(width, height, bit_depth, qp, seed, density, frames)
+        d = decision_inputs(width, height, bit_depth, qp, seed, density, frames, distance)
         self.stride = d["stride"]
         self.host_planes = d["planes"]                            # source, list 0, list 1
         self.n = self.host_planes[0].size
