@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--density", type=float, default=1.0)
     ap.add_argument("--repeat", type=int, default=2)
     ap.add_argument("--expected", choices=["ref", "oracle", "none"], default="ref")
+    ap.add_argument("--distance", type=int, default=1, help="temporal distance of the two reference pictures")
     ap.add_argument("--speed", choices=["slow", "medium", "fast"], default="medium", help="turing/Speed.h: medium = early termination (MET), +-64 window, half + "
                     "quarter refinement; fast = also the small windows and no quarter-sample step; slow = no early termination (every search runs the star "
                     "and, where it travels, the raster refinement)")
@@ -48,7 +49,7 @@ def main():
     if args.device == "mock":
         C.CDLL(build_mock(), mode=C.RTLD_GLOBAL)   # takes the place of libhavoc_mi355x.so for everything loaded after it
     from turingcodec_amd import decisions, workload
-    planes, stride = st.clip_planes(W, H, args.seed + 4, args.bit_depth)
+    planes, stride = st.clip_planes(W, H, args.seed + 4, args.bit_depth, distance=args.distance)
     planes = [aligned(p) for p in planes]
     pad = 96
     pus, first, cx, cy = workload.picture_pus(W, H, args.seed, args.density)
@@ -58,7 +59,7 @@ def main():
     elif args.speed == "slow":
         par.met = 0
     rate = (45000, 98000)      # rate of mvp_lX_flag = 0 / 1 in some CABAC state (Q16 bits)
-    report = {"device": args.device, "res": args.res, "bit_depth": args.bit_depth, "speed": args.speed, "pus": int(len(pus)), "searches": int(2 * len(pus)), "ctus": cx * cy}
+    report = {"device": args.device, "res": args.res, "bit_depth": args.bit_depth, "speed": args.speed, "distance": args.distance, "pus": int(len(pus)), "searches": int(2 * len(pus)), "ctus": cx * cy}
 
     expected = None
     if args.expected != "none":

@@ -233,11 +233,12 @@ def make_searches(width, height, n, seed, hard_fraction=0.15):
     return pus
 
 
-def clip_planes(width, height, seed, bit_depth=8, pad=96):
-    """(src, ref L0, ref L1, stride): padded luma planes of three consecutive frames of the synthetic clip"""
+def clip_planes(width, height, seed, bit_depth=8, pad=96, distance=1):
+    """(src, ref L0, ref L1, stride): padded luma planes of three frames of the synthetic clip, the references `distance` frames before and after
+    the source (1: consecutive frames; 4, 8: the long vectors of the hierarchy's upper layers -- star search and raster refinement)"""
     from turingcodec_amd.workload import pad_plane, synth_frames
-    frames = synth_frames(width, height, 3, seed, bit_depth)
-    planes = [pad_plane(f[0], pad) for f in (frames[1], frames[0], frames[2])]
+    frames = synth_frames(width, height, 2 * distance + 1, seed, bit_depth)
+    planes = [pad_plane(f[0], pad) for f in (frames[distance], frames[0], frames[2 * distance])]
     stride = planes[0].shape[1]
     return [np.ascontiguousarray(p.ravel()) for p in planes], stride
 

@@ -273,6 +273,19 @@ def test_device_search_at_other_speed_settings(speed, bit_depth):
 
 @needs_ref
 @pytest.mark.gpu
+def test_device_search_with_references_four_pictures_away():
+    """the hierarchy's upper layers: long vectors, the star search and its raster refinement run (three times the calls per search of the
+    neighbouring-picture case) -- every result, the motion field and the bi-directional refinements against the walk over the reference's tables"""
+    r = _run_picture("real", "--res", "1920x1080", "--bit-depth", "8", "--threads", "16", "--distance", "4", "--repeat", "1")
+    assert r["distance"] == 4 and r["mismatches"] == 0 and r["field_equal"] and r["loop_calls"] > 60 * r["searches"], r
+    d = r["on_device"]
+    assert d["mismatches"] == 0 and d["field_equal"], d
+    d = r["on_device_with_bi"]
+    assert d["mismatches"] == 0 and d["uni_mismatches_vs_without_bi"] == 0 and d["field_equal"], d
+
+
+@needs_ref
+@pytest.mark.gpu
 def test_device_search_gives_the_same_results_every_time():
     """the rows of a picture wait for each other inside the kernel and the wavefronts of a workgroup share the decided vectors through LDS: a
     missing barrier or fence shows as a run that differs (one did, before the barrier after a PU's cells are written was there)"""
