@@ -73,3 +73,21 @@ def test_reference_encoder_over_mi355x_tables_writes_the_reference_stream(case, 
     print(case, err.strip().splitlines()[-1])
     assert got == ref, f"{case}: stream through the MI355X tables differs from the reference encoder's"
     _check_golden(case, got, workdir)
+
+
+@needs_encoders
+def test_call_mix_of_the_reference_encoder_can_be_measured(tmp_path):
+    """profiles/measure_call_mix.py: the reference encoder over the classic tables + the stand-in device, which tallies its jobs by entry point and
+    block size -- what DESIGN.md holds against the workload's assumed mixes"""
+    import json
+    import subprocess
+    import sys
+    out = tmp_path / "mix.json"
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "profiles", "measure_call_mix.py"), "ra_medium_qp32", str(out)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    m = json.load(open(out))
+    calls = m["calls_by_entry_point"]
+    assert calls["sad4"] > 10 * calls["sad"] > 0 and calls["intra"] > 0 and calls["transform"] == calls["inverse_transform"]
+    mix = m["searched_pu_size_mix_from_single_sad_calls"]
+    assert abs(sum(mix.values()) - 1.0) < 1e-3 and max(mix, key=mix.get) == "max side 16"
+    assert abs(sum(m["forward_transform_calls_by_size"].values()) - 1.0) < 1e-3
