@@ -25,7 +25,7 @@ enum { H_SAD, H_SAD4, H_SATD, H_PRED_UNI8, H_PRED_UNI4, H_PRED_BI8, H_PRED_BI4, 
 static const char *const g_hname[H_COUNT] = {"sad", "sad4", "satd", "pred_uni8", "pred_uni4", "pred_bi8", "pred_bi4", "subtract_bi", "intra", "transform",
                                              "inverse_transform", "ssd", "quantize", "rdoq"};
 static long g_hist[H_COUNT][65][65];
-static void tally(int fn, int w, int h) { if (w >= 0 && w <= 64 && h >= 0 && h <= 64) ++g_hist[fn][w][h]; }
+static void tally(int fn, int w, int h) { if (w >= 0 && w <= 64 && h >= 0 && h <= 64) __sync_fetch_and_add(&g_hist[fn][w][h], 1); }   /* the encoder calls from several threads */
 static void write_histogram(void)
 {
     const char *path = getenv("HAVOC_MOCK_HISTOGRAM");

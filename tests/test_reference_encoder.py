@@ -87,7 +87,7 @@ def test_call_mix_of_the_reference_encoder_can_be_measured(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     m = json.load(open(out))
     calls = m["calls_by_entry_point"]
-    assert calls["sad4"] > 10 * calls["sad"] > 0 and calls["intra"] > 0 and calls["transform"] == calls["inverse_transform"]
+    assert calls["sad4"] > 10 * calls["sad"] > 0 and calls["intra"] > 0 and abs(calls["transform"] - calls["inverse_transform"]) < 0.01 * calls["transform"]
     mix = m["searched_pu_size_mix_from_single_sad_calls"]
     assert abs(sum(mix.values()) - 1.0) < 1e-3 and max(mix, key=mix.get) == "max side 16"
     assert abs(sum(m["forward_transform_calls_by_size"].values()) - 1.0) < 1e-3
