@@ -576,6 +576,13 @@ typedef struct
 int havoc_mi355x_search_motion_uni(havoc_mi355x_ctx *ctx, int S, const havoc_mi355x_search_params *params, const void *d_src, int64_t src_origin, intptr_t src_stride,
                                    const void *d_ref, int64_t ref_origin, intptr_t ref_stride, const void *d_phase, intptr_t plane_elems, int64_t phase_origin,
                                    const void *d_pus, int n, void *d_out);
+/* n INDEPENDENT bi-directional refinements (searchMotionBi, turing/Search.hpp:1498-1657) in ONE launch, a workgroup per refinement: list
+ * d_pus[i].ref_list's vector is refined around d_start[2 * i .. 2 * i + 1] (quarter samples) against the prediction the OTHER list's vector d_pus[i].mv_other
+ * gives (read from d_phase_other, the other reference picture's 16 phase planes); d_ref / d_phase = the refined list's picture.  d_out[i]: mv, mvd, mvp_flag,
+ * calls, cost_subpel (= the cost).  The list form of the refinement launches of havoc_mi355x_search_picture_uni; mvp_rate[] >= 0. */
+int havoc_mi355x_search_motion_bi(havoc_mi355x_ctx *ctx, int S, const havoc_mi355x_search_params *params, const void *d_src, int64_t src_origin, intptr_t src_stride,
+                                  const void *d_ref, int64_t ref_origin, intptr_t ref_stride, const void *d_phase, intptr_t plane_elems, int64_t phase_origin,
+                                  const void *d_phase_other, int64_t phase_other_origin, const void *d_pus, const int16_t *d_start, int n, void *d_out);
 size_t havoc_mi355x_search_workspace(int width, int height);
 int havoc_mi355x_search_picture_uni(havoc_mi355x_ctx *ctx, int S, const havoc_mi355x_search_params *params, const int64_t mvp_rate[2], const void *d_src,
                                     int64_t src_origin, intptr_t src_stride, const void *d_ref, const int64_t ref_origin[2], intptr_t ref_stride, const void *d_phase,

@@ -437,6 +437,14 @@ int havoc_mi355x_search_motion_uni(havoc_mi355x_ctx *ctx, int S, const havoc_mi3
     (void)ctx; (void)S; (void)params; (void)src; (void)so; (void)ss; (void)ref; (void)ro; (void)rs; (void)phase; (void)pe; (void)po; (void)pus; (void)n; (void)out;
     return HAVOC_MI355X_EINVAL;      /* a kernel: nothing behind it in the mock */
 }
+int havoc_mi355x_search_motion_bi(havoc_mi355x_ctx *ctx, int S, const havoc_mi355x_search_params *params, const void *src, int64_t so, intptr_t ss, const void *ref,
+                                  int64_t ro, intptr_t rs, const void *phase, intptr_t pe, int64_t po, const void *phase_other, int64_t poo, const void *pus,
+                                  const int16_t *start, int n, void *out)
+{
+    (void)ctx; (void)S; (void)params; (void)src; (void)so; (void)ss; (void)ref; (void)ro; (void)rs; (void)phase; (void)pe; (void)po; (void)phase_other; (void)poo;
+    (void)pus; (void)start; (void)n; (void)out;
+    return HAVOC_MI355X_EINVAL;      /* a kernel: nothing behind it in the mock */
+}
 size_t havoc_mi355x_search_workspace(int width, int height) { (void)width; (void)height; return 256; }
 int havoc_mi355x_search_picture_uni(havoc_mi355x_ctx *ctx, int S, const havoc_mi355x_search_params *params, const int64_t mvp_rate[2], const void *src, int64_t so,
                                     intptr_t ss, const void *ref, const int64_t ro[2], intptr_t rs, const void *phase, intptr_t pe, const int64_t po[2], const void *pus,

@@ -125,17 +125,76 @@ PuContext puOf(const havoc_search_pu &q)
     return pu;
 }
 
+// every call a loop makes through its View, in order: what tests/trace_tools.py holds against the call sequence the reference encoder's own
+// loops made (oracle/trace_hooks.h).  A row = {kind (3 sad, 4 sad4, 5 satd as the trace numbers them), x0, y0, .. x3, y3, value0..3}
+struct CallLog
+{
+    int32_t *rows;
+    int64_t capacity, count;
+    int32_t *push(int kind)
+    {
+        static int32_t overflow[13];
+        int32_t *r = count < capacity ? rows + 13 * count : overflow;
+        ++count;
+        std::memset(r, 0, 13 * sizeof(int32_t));
+        r[0] = kind;
+        return r;
+    }
+};
+
+template <class Inner>
+struct LoggedView
+{
+    Inner &inner;
+    CallLog &log;
+    int sad(int dx, int dy)
+    {
+        const int v = inner.sad(dx, dy);
+        int32_t *r = log.push(3);
+        r[1] = dx; r[2] = dy; r[9] = v;
+        return v;
+    }
+    void sad4(const Mv d[4], int32_t out[4])
+    {
+        inner.sad4(d, out);
+        int32_t *r = log.push(4);
+        for (int i = 0; i < 4; ++i)
+        {
+            r[1 + 2 * i] = d[i].x; r[2 + 2 * i] = d[i].y; r[9 + i] = out[i];
+        }
+    }
+    int satdQpel(Mv mv)
+    {
+        const int v = inner.satdQpel(mv);
+        int32_t *r = log.push(5);
+        r[1] = mv.x; r[2] = mv.y; r[9] = v;
+        return v;
+    }
+};
+
 template <typename Sample>
 void runUni(const Sample *src, intptr_t ss, const Sample *ref, intptr_t rs, const havoc_search_params &p, const havoc_search_pu *pus, int b, int e,
-            havoc_search_result *out)
+            havoc_search_result *out, CallLog *log = nullptr, int64_t *logFirst = nullptr)
 {
     const SearchParams sp = paramsOf(p);
     for (int i = b; i < e; ++i)
     {
         const PuContext pu = puOf(pus[i]);
         TableView<Sample> view(tables<Sample>(), src + intptr_t(pu.y0) * ss + pu.x0, ss, Plane<Sample>{ref, rs}, pu.x0, pu.y0, pu.w, pu.h, sp.bitDepth);
-        MotionSearch<TableView<Sample>> search(sp, pu, view);
-        const UniResult r = search.run();
+        UniResult r;
+        if (log)
+        {
+            logFirst[i - b] = log->count;
+            LoggedView<TableView<Sample>> logged{view, *log};
+            MotionSearch<LoggedView<TableView<Sample>>> search(sp, pu, logged);
+            r = search.run();
+            logFirst[i - b + 1] = log->count;
+        }
+        else
+        {
+            MotionSearch<TableView<Sample>> search(sp, pu, view);
+            r = search.run();
+        }
         havoc_search_result &o = out[i];
         std::memset(&o, 0, sizeof(o));
         o.mv[0] = r.mv.x; o.mv[1] = r.mv.y;
@@ -153,7 +212,7 @@ void runUni(const Sample *src, intptr_t ss, const Sample *ref, intptr_t rs, cons
 
 template <typename Sample>
 void runBi(const Sample *src, intptr_t ss, const Sample *ref, const Sample *refOther, intptr_t rs, const havoc_search_params &p, const havoc_search_pu *pus,
-           const int16_t *start, int b, int e, havoc_search_result *out)
+           const int16_t *start, int b, int e, havoc_search_result *out, CallLog *log = nullptr, int64_t *logFirst = nullptr)
 {
     const SearchParams sp = paramsOf(p);
     for (int i = b; i < e; ++i)
@@ -164,7 +223,16 @@ void runBi(const Sample *src, intptr_t ss, const Sample *ref, const Sample *refO
         makeIdealPredictor<Sample>(tables<Sample>(), ideal, src + intptr_t(pu.y0) * ss + pu.x0, ss, Plane<Sample>{refOther, rs},
                                    Mv(pus[i].mv_other[0], pus[i].mv_other[1]), limit, pu.x0, pu.y0, pu.w, pu.h, sp.bitDepth);
         TableView<Sample> view(tables<Sample>(), ideal, 64, Plane<Sample>{ref, rs}, pu.x0, pu.y0, pu.w, pu.h, sp.bitDepth);
-        const BiResult r = searchMotionBi(sp, pu, view, Mv(start[2 * i], start[2 * i + 1]));
+        BiResult r;
+        if (log)
+        {
+            logFirst[i - b] = log->count;
+            LoggedView<TableView<Sample>> logged{view, *log};
+            r = searchMotionBi(sp, pu, logged, Mv(start[2 * i], start[2 * i + 1]));
+            logFirst[i - b + 1] = log->count;
+        }
+        else
+            r = searchMotionBi(sp, pu, view, Mv(start[2 * i], start[2 * i + 1]));
         havoc_search_result &o = out[i];
         std::memset(&o, 0, sizeof(o));
         o.mv[0] = r.mv.x; o.mv[1] = r.mv.y;
@@ -255,6 +323,28 @@ int client_bi(int S, const void *src, intptr_t ss, const void *ref, const void *
     if (S == 1) runBi<uint8_t>((const uint8_t *)src, ss, (const uint8_t *)ref, (const uint8_t *)refOther, rs, *p, pus, start, b, e, out);
     else runBi<uint16_t>((const uint16_t *)src, ss, (const uint16_t *)ref, (const uint16_t *)refOther, rs, *p, pus, start, b, e, out);
     return 0;
+}
+
+// the same, with every View call logged: rows = int32 [capacity][13], first = int64 [e - b + 1] (search i's rows are [first[i - b], first[i - b + 1]));
+// returns the number of rows the searches made (more than capacity: the log is incomplete)
+int64_t client_uni_logged(int S, const void *src, intptr_t ss, const void *ref, intptr_t rs, const havoc_search_params *p, const havoc_search_pu *pus, int b, int e,
+                          havoc_search_result *out, int32_t *rows, int64_t capacity, int64_t *first)
+{
+    if (!g_open) return -1;
+    CallLog log{rows, capacity, 0};
+    if (S == 1) runUni<uint8_t>((const uint8_t *)src, ss, (const uint8_t *)ref, rs, *p, pus, b, e, out, &log, first);
+    else runUni<uint16_t>((const uint16_t *)src, ss, (const uint16_t *)ref, rs, *p, pus, b, e, out, &log, first);
+    return log.count;
+}
+
+int64_t client_bi_logged(int S, const void *src, intptr_t ss, const void *ref, const void *refOther, intptr_t rs, const havoc_search_params *p,
+                         const havoc_search_pu *pus, const int16_t *start, int b, int e, havoc_search_result *out, int32_t *rows, int64_t capacity, int64_t *first)
+{
+    if (!g_open) return -1;
+    CallLog log{rows, capacity, 0};
+    if (S == 1) runBi<uint8_t>((const uint8_t *)src, ss, (const uint8_t *)ref, (const uint8_t *)refOther, rs, *p, pus, start, b, e, out, &log, first);
+    else runBi<uint16_t>((const uint16_t *)src, ss, (const uint16_t *)ref, (const uint16_t *)refOther, rs, *p, pus, start, b, e, out, &log, first);
+    return log.count;
 }
 
 int client_intra35(int S, int bitDepth, int log2, const void *src, intptr_t ss, const void *nb, const int32_t *jobs, int n, int32_t *satd35)

@@ -90,6 +90,10 @@ class Client:
         L.client_open.argtypes = [i]
         L.client_uni.argtypes = [i, vp, ip, vp, ip, C.POINTER(Params), vp, i, i, vp]
         L.client_bi.argtypes = [i, vp, ip, vp, vp, ip, C.POINTER(Params), vp, vp, i, i, vp]
+        L.client_uni_logged.argtypes = [i, vp, ip, vp, ip, C.POINTER(Params), vp, i, i, vp, vp, C.c_int64, vp]
+        L.client_uni_logged.restype = C.c_int64
+        L.client_bi_logged.argtypes = [i, vp, ip, vp, vp, ip, C.POINTER(Params), vp, vp, i, i, vp, vp, C.c_int64, vp]
+        L.client_bi_logged.restype = C.c_int64
         L.client_intra_order.argtypes = [vp, C.c_double, vp, i, vp]
         L.client_intra35.argtypes = [i, i, i, vp, ip, vp, vp, i, vp]
         L.client_picture_uni.argtypes = [i, vp, ip, vp, vp, ip, C.POINTER(Params), vp, vp, i, i, vp, vp, vp, vp]
@@ -114,6 +118,27 @@ class Client:
                                pus.ctypes.data, b, e, out.ctypes.data)
         assert rc == 0
         return out
+
+    def uni_logged(self, params, src, ref, stride, pad, pus, capacity):
+        """uni() + the log of every View call the loops made: (results, rows int32 [calls, 13], first int64 [len(pus) + 1])"""
+        out = np.zeros(len(pus), RESULT_DT)
+        rows = np.zeros((capacity, 13), np.int32)
+        first = np.zeros(len(pus) + 1, np.int64)
+        n = self.L.client_uni_logged(src.itemsize, self._origin(src, stride, pad), stride, self._origin(ref, stride, pad), stride, C.byref(params),
+                                     pus.ctypes.data, 0, len(pus), out.ctypes.data, rows.ctypes.data, capacity, first.ctypes.data)
+        assert 0 <= n <= capacity, (n, capacity)
+        return out, rows[:n], first
+
+    def bi_logged(self, params, src, ref, ref_other, stride, pad, pus, start, capacity):
+        out = np.zeros(len(pus), RESULT_DT)
+        rows = np.zeros((capacity, 13), np.int32)
+        first = np.zeros(len(pus) + 1, np.int64)
+        start = np.ascontiguousarray(start, np.int16)
+        n = self.L.client_bi_logged(src.itemsize, self._origin(src, stride, pad), stride, self._origin(ref, stride, pad), self._origin(ref_other, stride, pad),
+                                    stride, C.byref(params), pus.ctypes.data, start.ctypes.data, 0, len(pus), out.ctypes.data, rows.ctypes.data, capacity,
+                                    first.ctypes.data)
+        assert 0 <= n <= capacity, (n, capacity)
+        return out, rows[:n], first
 
     def picture_uni(self, params, src, ref0, ref1, stride, pad, pus, ctu_first, ctus_x, ctus_y, mvp_rate=(65536, 65536), bi=False):
         """a whole picture's searches in dependency order, one table call at a time (turingcodec_amd/search/picture_order.hpp):

@@ -1,0 +1,74 @@
+"""decision.hpp PINNED against the reference encoder's own loops.
+
+oracle/_ref/turing_ref_trace = the reference encoder with trace points in turing/Search.hpp (oracle/trace_hooks.h, inserted into a temporary copy at
+build time): every searchMotionUni (Search.hpp:1315-1355, 2060-2358), searchMotionBi (:1498-1657) and searchIntraPartition (:38-190) of a real encode
+writes its inputs (prediction unit, predictors, CABAC rates of mvp_lX_flag, mvPreviousInteger2Nx2N, lambda, most probable modes, rate offsets), every
+primitive call it makes with the returned value, and what it decided.  tests/trace_runner.py runs turingcodec_amd/search/decision.hpp -- the text that
+is compiled into the product's search kernels -- on those inputs and the encoder's own pictures:
+
+  -m "not gpu"  per call over the reference's havoc tables: the same CALL SEQUENCE (positions and values) and the same decisions, for every search of
+                the encode, medium / fast / slow, 8- and 10-bit, 1 and 4 encoder threads; + the launch-and-replay batch clients over the stand-in device;
+  -m gpu        on the MI355X: the batch clients, and the loops inside the kernels (k_search_list, k_search_bi_list, k_intra_order).
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+import trace_tools as tt
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+needs_trace = pytest.mark.skipif(not tt.have_trace_encoder(), reason="oracle/_ref/turing_ref_trace not built (needs /root/reference; `make -C oracle trace`)")
+
+
+def run(case, *extra, timeout=900):
+    r = subprocess.run([sys.executable, os.path.join(HERE, "trace_runner.py"), case] + list(extra), capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def check_cpu(rep, min_searches):
+    assert rep["stream_is_the_committed_reference_stream"], "the trace points changed the encode"
+    u, b, i = rep["uni_cpu"], rep["bi_cpu"], rep["intra_cpu"]
+    assert u["searches"] >= min_searches and u["calls"] > 20 * u["searches"]
+    assert u["mismatching_searches"] == 0 and u["mismatching_call_rows"] == 0, u
+    assert u["previous_2Nx2N_handovers_checked"] > u["searches"] // 2 and u["previous_2Nx2N_handovers_wrong"] == 0, u
+    assert b["searches"] >= min_searches // 4 and b["mismatching_searches"] == 0 and b["mismatching_call_rows"] == 0, b
+    assert i["partitions"] >= min_searches // 2 and i["mismatching"] == 0, i
+
+
+@needs_trace
+@pytest.mark.parametrize("case,min_searches", [("ra_medium_qp32", 3000), ("ra_fast_qp32", 3000), ("ra_medium_10bit_qp27", 2000), ("ra_slow_qp27", 10000),
+                                               ("ra_medium_internal10", 1000), ("ra_medium_qp22", 2000)])
+def test_restated_loops_make_the_reference_encoders_calls_and_decisions(case, min_searches):
+    check_cpu(run(case), min_searches)
+
+
+@needs_trace
+def test_the_same_with_four_encoder_threads(tmp_path):
+    """CTU rows on different threads: the trace is followed per thread, the 2Nx2N hand-over in the order the encoder ran the searches"""
+    check_cpu(run("ra_medium_qp32", "--threads", "4"), 3000)
+
+
+@needs_trace
+def test_batch_clients_over_the_stand_in_device_decide_what_the_reference_encoder_decided():
+    rep = run("ra_medium_qp32", "--device", "mock", "--limit", "500")
+    assert rep["uni_device"]["searches"] >= 400 and rep["uni_device"]["mismatching_launch_and_replay"] == 0, rep["uni_device"]
+    assert rep["bi_device"]["searches"] >= 400 and rep["bi_device"]["mismatching_launch_and_replay"] == 0, rep["bi_device"]
+    assert rep["intra_device"]["partitions"] >= 400 and rep["intra_device"]["mismatching"] == 0, rep["intra_device"]
+
+
+@needs_trace
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,min_searches", [("ra_medium_qp32", 3000), ("ra_fast_qp32", 3000), ("ra_medium_10bit_qp27", 2000)])
+def test_search_kernels_decide_what_the_reference_encoder_decided(case, min_searches):
+    """every motion search / refinement / mode order of a real encode through the MI355X: launch + replay clients AND the loops inside the kernels"""
+    rep = run(case, "--device", "real", timeout=1500)
+    check_cpu(rep, min_searches)
+    u, b, i = rep["uni_device"], rep["bi_device"], rep["intra_device"]
+    print(case, json.dumps({"uni": u, "bi": b, "intra": i}))
+    assert u["searches"] == rep["uni_cpu"]["searches"] and u["mismatching_launch_and_replay"] == 0 and u["mismatching_loops_in_kernel"] == 0, u
+    assert b["searches"] == rep["bi_cpu"]["searches"] and b["mismatching_launch_and_replay"] == 0 and b["mismatching_loops_in_kernel"] == 0, b
+    assert i["partitions"] > 0 and i["mismatching"] == 0, i

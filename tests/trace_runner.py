@@ -1,0 +1,310 @@
+#!/usr/bin/env python3
+"""Replays the reference encoder's own motion searches, bi-directional refinements and intra mode orders (tests/trace_tools.py: the traced
+reference encoder oracle/_ref/turing_ref_trace) through turingcodec_amd/search/decision.hpp in ONE fresh process and prints a JSON report
+(tests/test_trace_pin.py asserts on it; profiles/ keeps the GPU box's report).
+
+  cpu            decision.hpp per call over the reference's havoc tables (tests/search_client.cpp, logged): the CALL SEQUENCE (every sad / sad4 /
+                 interpolate + satd position and value) and every decision must be the reference's
+  --device mock  + the batch clients of libhavoc_search.so (launch + host replay) over the CPU stand-in device (tests/mock_device.c)
+  --device real  + the same on the MI355X, and the searches with the loops INSIDE the kernels: havoc_search_motion_uni_device (k_search_list),
+                 havoc_search_motion_bi_device (k_search_bi_list), havoc_mi355x_intra_order (k_intra_order)
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import encoder_tools as et  # noqa: E402
+import search_tools as st  # noqa: E402
+import trace_tools as tt  # noqa: E402
+
+UNI_FIELDS = ["mv", "mvd", "mv_integer", "mvp_flag", "cost_integer", "calls"]
+BI_FIELDS = ["mv", "mvd", "mvp_flag", "cost_subpel", "calls"]
+
+
+def differing(got, exp, fields):
+    if not len(got):
+        return np.zeros(0, np.int64)
+    return np.flatnonzero(~np.all([np.all(got[f].reshape(len(got), -1) == exp[f].reshape(len(exp), -1), axis=1) for f in fields], axis=0))
+
+
+def gather_rows(trace, sel):
+    if not len(sel):
+        return np.zeros((0, 13), np.int32)
+    return np.concatenate([trace.rows[trace.first[i]:trace.first[i + 1]] for i in sel])
+
+
+class Stats(C.Structure):
+    _fields_ = [("rounds", C.c_int32), ("launches", C.c_int32), ("surfaces_small", C.c_int32), ("surfaces_large", C.c_int32),
+                ("satd_jobs", C.c_int32), ("replays", C.c_int32), ("bytes_down", C.c_int64), ("seconds_gpu", C.c_double),
+                ("seconds_host", C.c_double), ("seconds_total", C.c_double)]
+
+
+class Device:
+    """libhavoc_mi355x.so (or the stand-in) + libhavoc_search.so, planes uploaded once per picture"""
+
+    def __init__(self, kind):
+        import search_runner
+        self.kind = kind
+        path = search_runner.build_mock() if kind == "mock" else os.path.join(ROOT, "turingcodec_amd", "libhavoc_mi355x.so")
+        dev = self.dev = C.CDLL(path, mode=C.RTLD_GLOBAL)
+        L = self.L = C.CDLL(os.path.join(ROOT, "turingcodec_amd", "libhavoc_search.so"))
+        vp, ip, i64, i = C.c_void_p, C.c_ssize_t, C.c_int64, C.c_int
+        dev.havoc_mi355x_create.argtypes = [C.POINTER(vp), i, vp]
+        dev.havoc_mi355x_malloc.argtypes = [vp, C.POINTER(vp), C.c_size_t]
+        dev.havoc_mi355x_h2d.argtypes = [vp, vp, vp, C.c_size_t]
+        dev.havoc_mi355x_d2h.argtypes = [vp, vp, vp, C.c_size_t]
+        dev.havoc_mi355x_interp_planes.argtypes = [vp, i, i, vp, ip, vp, ip, i, i, i, i]
+        dev.havoc_mi355x_sync.argtypes = [vp]
+        dev.havoc_mi355x_last_error.restype = C.c_char_p
+        dev.havoc_mi355x_intra_order.argtypes = [vp, vp, vp, i, C.c_int32, vp, vp, vp, vp]
+        P = C.POINTER(st.Params)
+        L.havoc_search_motion_uni.argtypes = [vp, i, P, vp, i64, ip, vp, i64, ip, i, vp, ip, i64, vp, i, vp, i, C.POINTER(Stats)]
+        L.havoc_search_motion_uni_device.argtypes = [vp, i, P, vp, i64, ip, vp, i64, ip, i, vp, ip, i64, vp, i, vp, C.POINTER(Stats)]
+        L.havoc_search_motion_bi.argtypes = [vp, i, P, vp, i64, ip, vp, i64, ip, i, vp, ip, i64, vp, i64, vp, vp, i, vp, i, C.POINTER(Stats)]
+        L.havoc_search_motion_bi_device.argtypes = [vp, i, P, vp, i64, ip, vp, i64, ip, i, vp, ip, i64, vp, i64, vp, vp, i, vp, C.POINTER(Stats)]
+        self.ctx = vp()
+        rc = dev.havoc_mi355x_create(C.byref(self.ctx), 0, vp(-1 & 0xFFFFFFFFFFFFFFFF))
+        assert rc == 0, dev.havoc_mi355x_last_error()
+        self.planes = {}     # (what, poc) -> (device pointer, host array)
+
+    def _alloc(self, nbytes):
+        d = C.c_void_p()
+        assert self.dev.havoc_mi355x_malloc(self.ctx, C.byref(d), nbytes + 256) == 0
+        return d
+
+    def plane(self, what, poc, host):
+        key = (what, poc)
+        if key not in self.planes:
+            d = self._alloc(host.nbytes)
+            assert self.dev.havoc_mi355x_h2d(self.ctx, d, host.ctypes.data, host.nbytes) == 0
+            self.planes[key] = d
+        return self.planes[key]
+
+    def phase(self, poc, host, stride, width, height, bit_depth):
+        """the 16 fractional-sample planes of a reference picture (plane 0 = the picture): (device pointer, plane_elems)"""
+        key = ("phase", poc)
+        S = host.itemsize
+        pe = (host.size + 63) & ~63
+        if key not in self.planes:
+            d = self._alloc(16 * pe * S)
+            assert self.dev.havoc_mi355x_h2d(self.ctx, d, host.ctypes.data, host.nbytes) == 0
+            assert self.dev.havoc_mi355x_interp_planes(self.ctx, S, bit_depth, d, pe, self.plane("ref", poc, host), stride, 12, 4, width + 2 * tt.PAD - 24,
+                                                       height + 2 * tt.PAD - 8) == 0
+            self.dev.havoc_mi355x_sync(self.ctx)
+            self.planes[key] = d
+        return self.planes[key], pe
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("case")
+    ap.add_argument("--device", choices=["none", "mock", "real"], default="none")
+    ap.add_argument("--threads", type=int, default=1, help="encoder threads of the traced run")
+    ap.add_argument("--limit", type=int, default=0, help="device legs: at most this many searches per kind (0: all)")
+    args = ap.parse_args()
+    w, h, nframes, seed, bd, opts = et.CASES[args.case]
+    report = {"case": args.case, "device": args.device, "encoder_threads": args.threads}
+    with tempfile.TemporaryDirectory() as work:
+        t0 = time.perf_counter()
+        stream, records, recon, internal = tt.run(args.case, work, args.threads)
+        report["encode_seconds"] = round(time.perf_counter() - t0, 2)
+    g = et.golden().get(args.case)
+    report["stream_is_the_committed_reference_stream"] = bool(g and et.md5(stream) == g["stream_md5"] and len(stream) == g["stream_bytes"])
+    report["trace_records"] = int(len(records))
+    src = tt.source_frames(args.case, internal)
+    uni, bi, intra = tt.MotionTrace(records), tt.MotionTrace(records, bi=True), tt.IntraTrace(records)
+    del records
+    ref_of = {}          # (poc, list) -> reference picture's poc, from the uni searches (a bi refinement follows the two uni searches of its PU)
+    for poc, lst, rp in zip(uni.meta["poc"], uni.pus["ref_list"], uni.meta["ref_poc"]):
+        ref_of[(int(poc), int(lst))] = int(rp)
+    padded_src, padded_rec = {}, {}
+
+    def P(cache, frames, poc):
+        if poc not in cache:
+            cache[poc] = tt.padded(frames[poc][0])
+        return cache[poc]
+
+    try:
+        cpu = st.Client("ref", 3)
+        report["cpu_tables"] = "the reference's havoc tables (oracle/_ref)"
+    except (FileNotFoundError, OSError):
+        cpu = st.Client("oracle")
+        report["cpu_tables"] = "CPU oracle"
+
+    # ---- CPU: decision.hpp per call, logged
+    t0 = time.perf_counter()
+    r = {"searches": int(len(uni)), "calls": int(len(uni.rows)), "mismatching_searches": 0, "mismatching_call_rows": 0, "groups": 0}
+    expected_uni = {}
+    for key, idx in uni.groups().items():
+        par = uni.params(key, w, h)
+        (s, stride), (rf, _) = P(padded_src, src, key[0]), P(padded_rec, recon, key[1])
+        pus = np.ascontiguousarray(uni.pus[idx])
+        out, rows, first = cpu.uni_logged(par, s, rf, stride, tt.PAD, pus, int(uni.results["calls"][idx].sum()) + 4096)
+        r["mismatching_searches"] += int(len(differing(out, uni.results[idx], UNI_FIELDS)))
+        exp_rows = gather_rows(uni, idx)
+        r["mismatching_call_rows"] += int(abs(len(rows) - len(exp_rows)) + np.count_nonzero(np.any(rows[:len(exp_rows)] != exp_rows[:len(rows)], axis=1)))
+        r["groups"] += 1
+        expected_uni[key] = (idx, out)
+    # mvPreviousInteger2Nx2N: a search that reports wrote_2Nx2N must be what the NEXT search of the same CTU row and list starts from (Search.hpp:2170-2176, 2332-2335)
+    chain_checked = chain_bad = 0
+    state = {}
+    order = np.argsort(uni.meta["seq"], kind="stable")      # the order the encoder ran them in, whatever thread a CTU ran on
+    wrote = np.zeros(len(uni), np.int16)
+    for key, (idx, out) in expected_uni.items():
+        wrote[idx] = out["wrote_2Nx2N"]
+    for i in order:
+        k = (int(uni.meta["poc"][i]), int(uni.pus["y_ctb"][i]), int(uni.pus["ref_list"][i]))
+        prev = tuple(int(v) for v in uni.pus["mv_previous_2Nx2N"][i])
+        if k in state:
+            chain_checked += 1
+            chain_bad += prev != state[k]
+        state[k] = tuple(int(v) for v in uni.results["mv_integer"][i]) if wrote[i] else prev
+    r["previous_2Nx2N_handovers_checked"], r["previous_2Nx2N_handovers_wrong"] = chain_checked, int(chain_bad)
+    r["seconds"] = round(time.perf_counter() - t0, 2)
+    report["uni_cpu"] = r
+
+    t0 = time.perf_counter()
+    r = {"searches": int(len(bi)), "calls": int(len(bi.rows)), "mismatching_searches": 0, "mismatching_call_rows": 0}
+    bi_jobs = []
+    for key, idx in bi.groups().items():
+        par = bi.params(key, w, h)
+        for lst in (0, 1):
+            sel = idx[bi.pus["ref_list"][idx] == lst]
+            if not len(sel):
+                continue
+            other = ref_of[(key[0], 1 - lst)]
+            (s, stride), (rf, _), (ro, _) = P(padded_src, src, key[0]), P(padded_rec, recon, key[1]), P(padded_rec, recon, other)
+            pus = np.ascontiguousarray(bi.pus[sel])
+            start = np.ascontiguousarray(bi.meta["start"][sel])
+            out, rows, first = cpu.bi_logged(par, s, rf, ro, stride, tt.PAD, pus, start, int(bi.results["calls"][sel].sum()) + 4096)
+            r["mismatching_searches"] += int(len(differing(out, bi.results[sel], BI_FIELDS)))
+            exp_rows = gather_rows(bi, sel)
+            r["mismatching_call_rows"] += int(abs(len(rows) - len(exp_rows)) + np.count_nonzero(np.any(rows[:len(exp_rows)] != exp_rows[:len(rows)], axis=1)))
+            bi_jobs.append((key, par, lst, other, sel, pus, start))
+    r["seconds"] = round(time.perf_counter() - t0, 2)
+    report["bi_cpu"] = r
+
+    r = {"partitions": int(len(intra)), "mismatching": 0, "by_log2_size": {int(k): int(v) for k, v in zip(*np.unique(intra.where[:, 3], return_counts=True))} if len(intra) else {}}
+    live = np.arange(35)[None, :]
+    for rsl in np.unique(intra.rsl):
+        sel = np.flatnonzero(intra.rsl == rsl)
+        out = cpu.intra_order(np.ascontiguousarray(intra.ctx[sel]), float(rsl), intra.satd[sel])
+        bad = (out["count"] != intra.count[sel]) | np.any((out["order"] != intra.order[sel]) & (live < intra.count[sel][:, None]), axis=1) | \
+            np.any(out["costs"] != intra.costs[sel], axis=1)
+        r["mismatching"] += int(bad.sum())
+    report["intra_cpu"] = r
+
+    # ---- the product: batch clients (and, on the MI355X, the kernels that hold the loops) on the same inputs
+    if args.device != "none":
+        dev = Device(args.device)
+        origin = lambda stride: tt.PAD * stride + tt.PAD
+        lim = args.limit or 1 << 30
+        r = {"searches": 0, "mismatching_launch_and_replay": 0, "launches": 0, "rounds": 0}
+        if args.device == "real":
+            r["mismatching_loops_in_kernel"] = 0
+        t0 = time.perf_counter()
+        budget = lim
+        for key, idx in uni.groups().items():
+            idx = idx[:budget]
+            budget -= len(idx)
+            if not len(idx):
+                break
+            par = uni.params(key, w, h)
+            (s, stride), (rf, _) = P(padded_src, src, key[0]), P(padded_rec, recon, key[1])
+            S = s.itemsize
+            d_src, d_ref = dev.plane("src", key[0], s), dev.plane("ref", key[1], rf)
+            d_phase, pe = dev.phase(key[1], rf, stride, w, h, key[4])
+            for lst in (0, 1):      # the batch client takes one list's searches per call (one reference picture)
+                sel = idx[uni.pus["ref_list"][idx] == lst]
+                if not len(sel):
+                    continue
+                pus = np.ascontiguousarray(uni.pus[sel])
+                exp = uni.results[sel]
+                out = np.zeros(len(sel), st.RESULT_DT)
+                stats = Stats()
+                rc = dev.L.havoc_search_motion_uni(dev.ctx, S, C.byref(par), d_src, origin(stride), stride, d_ref, origin(stride), stride, tt.PAD, d_phase, pe,
+                                                   origin(stride), pus.ctypes.data, len(pus), out.ctypes.data, 8, C.byref(stats))
+                assert rc == 0, (rc, dev.dev.havoc_mi355x_last_error())
+                r["mismatching_launch_and_replay"] += int(len(differing(out, exp, UNI_FIELDS)))
+                r["launches"] += stats.launches
+                r["rounds"] = max(r["rounds"], stats.rounds)
+                if args.device == "real":
+                    out = np.zeros(len(sel), st.RESULT_DT)
+                    rc = dev.L.havoc_search_motion_uni_device(dev.ctx, S, C.byref(par), d_src, origin(stride), stride, d_ref, origin(stride), stride, tt.PAD, d_phase,
+                                                              pe, origin(stride), pus.ctypes.data, len(pus), out.ctypes.data, C.byref(stats))
+                    assert rc == 0, (rc, dev.dev.havoc_mi355x_last_error())
+                    r["mismatching_loops_in_kernel"] += int(len(differing(out, exp, UNI_FIELDS)))
+                r["searches"] += len(sel)
+        r["seconds"] = round(time.perf_counter() - t0, 2)
+        report["uni_device"] = r
+
+        r = {"searches": 0, "mismatching_launch_and_replay": 0}
+        if args.device == "real":
+            r["mismatching_loops_in_kernel"] = 0
+        t0 = time.perf_counter()
+        budget = lim
+        for key, par, lst, other, sel, pus, start in bi_jobs:
+            sel, pus, start = sel[:budget], np.ascontiguousarray(pus[:budget]), np.ascontiguousarray(start[:budget])
+            budget -= len(sel)
+            if not len(sel):
+                break
+            (s, stride), (rf, _), (ro, _) = P(padded_src, src, key[0]), P(padded_rec, recon, key[1]), P(padded_rec, recon, other)
+            S = s.itemsize
+            d_src, d_ref, d_other = dev.plane("src", key[0], s), dev.plane("ref", key[1], rf), dev.plane("ref", other, ro)
+            d_phase, pe = dev.phase(key[1], rf, stride, w, h, key[4])
+            exp = bi.results[sel]
+            out = np.zeros(len(sel), st.RESULT_DT)
+            stats = Stats()
+            rc = dev.L.havoc_search_motion_bi(dev.ctx, S, C.byref(par), d_src, origin(stride), stride, d_ref, origin(stride), stride, tt.PAD, d_phase, pe, origin(stride),
+                                              d_other, origin(stride), pus.ctypes.data, start.ctypes.data, len(pus), out.ctypes.data, 8, C.byref(stats))
+            assert rc == 0, (rc, dev.dev.havoc_mi355x_last_error())
+            r["mismatching_launch_and_replay"] += int(len(differing(out, exp, BI_FIELDS)))
+            if args.device == "real":
+                d_phase_other, _ = dev.phase(other, ro, stride, w, h, key[4])
+                out = np.zeros(len(sel), st.RESULT_DT)
+                rc = dev.L.havoc_search_motion_bi_device(dev.ctx, S, C.byref(par), d_src, origin(stride), stride, d_ref, origin(stride), stride, tt.PAD, d_phase, pe,
+                                                         origin(stride), d_phase_other, origin(stride), pus.ctypes.data, start.ctypes.data, len(pus), out.ctypes.data,
+                                                         C.byref(stats))
+                assert rc == 0, (rc, dev.dev.havoc_mi355x_last_error())
+                r["mismatching_loops_in_kernel"] += int(len(differing(out, exp, BI_FIELDS)))
+            r["searches"] += len(sel)
+        r["seconds"] = round(time.perf_counter() - t0, 2)
+        report["bi_device"] = r
+
+        # the mode order taken on the device (k_intra_order; the stand-in has its own plain-C version of the kernel)
+        r = {"partitions": 0, "mismatching": 0}
+        MAXO = 12
+        for rsl in np.unique(intra.rsl):
+            sel = np.flatnonzero((intra.rsl == rsl) & (intra.ctx["max_refine"] + intra.ctx["neighbour_modes"] <= MAXO))[:lim]
+            n = len(sel)
+            if not n:
+                continue
+            lam = np.zeros(1, np.int32)
+            lam[0] = int(rsl * 65536 + 0.5)
+            satd, mpm = np.ascontiguousarray(intra.satd[sel]), np.ascontiguousarray(intra.ctx[sel])
+            d_satd, d_mpm = dev._alloc(satd.nbytes), dev._alloc(mpm.nbytes)
+            d_order, d_count, d_slot, d_total = dev._alloc(4 * MAXO * n), dev._alloc(4 * n), dev._alloc(4 * n), dev._alloc(16)
+            assert dev.dev.havoc_mi355x_h2d(dev.ctx, d_satd, satd.ctypes.data, satd.nbytes) == 0 and dev.dev.havoc_mi355x_h2d(dev.ctx, d_mpm, mpm.ctypes.data, mpm.nbytes) == 0
+            assert dev.dev.havoc_mi355x_intra_order(dev.ctx, d_satd, d_mpm, n, int(lam[0]), d_order, d_count, d_slot, d_total) == 0, dev.dev.havoc_mi355x_last_error()
+            order, count = np.zeros((n, MAXO), np.int32), np.zeros(n, np.int32)
+            assert dev.dev.havoc_mi355x_d2h(dev.ctx, order.ctypes.data, d_order, order.nbytes) == 0 and dev.dev.havoc_mi355x_d2h(dev.ctx, count.ctypes.data, d_count, count.nbytes) == 0
+            bad = (count != intra.count[sel]) | np.any((order != intra.order[sel][:, :MAXO]) & (np.arange(MAXO)[None, :] < intra.count[sel][:, None]), axis=1)
+            r["mismatching"] += int(bad.sum())
+            r["partitions"] += n
+        report["intra_device"] = r
+    print(json.dumps(report))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,233 @@
+"""TEST INFRASTRUCTURE: the reference encoder's own decision loops as the checker of turingcodec_amd/search/decision.hpp.
+
+oracle/_ref/turing_ref_trace is the reference encoder (the same objects as turing_ref_havoc) whose Search.hpp carries the trace points of
+oracle/trace_hooks.h: for every searchMotionUni / searchMotionBi / searchIntraPartition of an encode it writes the inputs as the reference's code
+holds them, every primitive call the loop makes (positions and returned values) and what it decided.  This module
+
+  * runs that encoder on a seeded clip (stream checked against the committed hash by the caller: the trace points change nothing),
+  * parses the trace into the records of turingcodec_amd/search/search_abi.h (havoc_search_pu inputs, havoc_search_result decisions) plus the
+    call sequence of every search,
+  * rebuilds the pictures the searches ran on: the source frames of the clip and the encoder's own reconstructed pictures (--dump-pictures),
+    padded by replication as turing/Padding.h pads them,
+
+so that tests/test_trace_pin.py can run decision.hpp -- on the CPU through the reference's tables, and on the MI355X inside the search kernel --
+on the reference's inputs and require the reference's call sequence and decisions.
+"""
+import os
+
+import numpy as np
+
+import encoder_tools as et
+import search_tools as st
+
+TRACE_EXE = os.path.join(et.REFDIR, "turing_ref_trace")
+REC_DT = np.dtype([("thread", "u4"), ("kind", "u2"), ("n", "u2"), ("v", "i4", (14,))])
+assert REC_DT.itemsize == 64
+(UNI_BEGIN, BEGIN2, SAD, SAD4, SATD, UNI_INTEGER, UNI_SUBPEL, UNI_END, BI_BEGIN, BI_MV, BI_END, INTRA_BEGIN, INTRA_SATD, INTRA_MAX, INTRA_PICK, INTRA_SSD,
+ INTRA_END) = range(1, 18)
+PAD = 96
+
+
+def have_trace_encoder():
+    return os.path.exists(TRACE_EXE)
+
+
+def i64(lo, hi):
+    return (lo.astype(np.int64) & 0xFFFFFFFF) | (hi.astype(np.int64) << 32)
+
+
+def f64(lo, hi):
+    return i64(lo, hi).view(np.float64)
+
+
+def run(case, workdir, threads=1):
+    """encode `case` (encoder_tools.CASES) with the traced encoder: (stream bytes, trace records in call order, reconstructed pictures [frames][3 planes])"""
+    w, h, n, seed, bd, opts = et.CASES[case]
+    trace = os.path.join(workdir, case + ".trace")
+    rec = os.path.join(workdir, case + ".rec.yuv")
+    stream, _ = et.encode(TRACE_EXE, case, workdir, ["--threads", str(threads), "--dump-pictures", rec], env={"HAVOC_TRACE_FILE": trace}, tag=".trace")
+    records = np.fromfile(trace, REC_DT)
+    internal = bd
+    if "--internal-bit-depth" in opts:
+        internal = int(opts[opts.index("--internal-bit-depth") + 1])
+    dt = np.uint8 if internal == 8 else np.uint16
+    raw = np.fromfile(rec, dt)
+    per = w * h * 3 // 2
+    assert raw.size == per * n, (raw.size, per, n)
+    frames = []
+    for k in range(n):
+        f = raw[k * per:(k + 1) * per]
+        frames.append((f[:w * h].reshape(h, w), f[w * h:w * h * 5 // 4].reshape(h // 2, w // 2), f[w * h * 5 // 4:].reshape(h // 2, w // 2)))
+    os.remove(trace)
+    return stream, records, frames, internal
+
+
+def source_frames(case, internal):
+    """the clip's frames as the encoder holds them (8-bit input widened by << (internal - 8) when the encoder runs 16-bit samples, turing/encode.cpp:341-449)"""
+    from turingcodec_amd import workload
+    w, h, n, seed, bd, _ = et.CASES[case]
+    out = []
+    for planes in workload.synth_frames(w, h, n, seed, bit_depth=bd):
+        if internal > bd:
+            planes = [p.astype(np.uint16) << (internal - bd) for p in planes]
+        out.append(planes)
+    return out
+
+
+def padded(plane, pad=PAD):
+    """a picture plane with `pad` replicated samples around it (turing/Padding.h), flat, 64-byte aligned; (array, stride)"""
+    p = np.pad(plane, pad, mode="edge")
+    raw = np.empty(p.size * p.itemsize + 64, np.uint8)
+    o = (-raw.ctypes.data) % 64
+    out = raw[o:o + p.size * p.itemsize].view(p.dtype)
+    out[...] = p.ravel()
+    return out, p.shape[1]
+
+
+def _segments(kind, begin, end):
+    """indices of the begin / end records of the non-nested segments of one thread's record stream"""
+    b, e = np.flatnonzero(kind == begin), np.flatnonzero(kind == end)
+    assert len(b) == len(e) and np.all(b < e) and np.all(b[1:] > e[:-1]), "trace segments are not properly paired"
+    return b, e
+
+
+def _call_rows(rec):
+    """the sad / sad4 / satd records as rows of the call log tests/search_client.cpp writes: kind, x0, y0 .. x3, y3, value0..3"""
+    rows = np.zeros((len(rec), 13), np.int32)
+    k = rec["kind"]
+    rows[:, 0] = k
+    one = (k == SAD) | (k == SATD)
+    rows[one, 1:3] = rec["v"][one, 0:2]
+    rows[one, 9] = rec["v"][one, 2]
+    four = k == SAD4
+    rows[four, 1:13] = rec["v"][four, 0:12]
+    return rows
+
+
+class MotionTrace:
+    """every searchMotionUni (bi=False) or searchMotionBi (bi=True) of the encode, in the order the encoder ran them"""
+
+    def __init__(self, records, bi=False):
+        begin, end = (BI_BEGIN, BI_END) if bi else (UNI_BEGIN, UNI_END)
+        pus, meta, results, rows, first = [], [], [], [], [0]
+        for t in np.unique(records["thread"]):
+            mine = np.flatnonzero(records["thread"] == t)
+            rec = records[mine]
+            kind = rec["kind"].astype(np.int32)
+            b, e = _segments(kind, begin, end)
+            if not len(b):
+                continue
+            v = rec["v"]
+            a, a2 = v[b], v[b + 1]
+            assert np.all(kind[b + 1] == BEGIN2)
+            pu = np.zeros(len(b), st.PU_DT)
+            pu["x0"], pu["y0"], pu["w"], pu["h"] = a[:, 3], a[:, 4], a[:, 5], a[:, 6]
+            pu["cu_log2_size"], pu["cqt_depth"], pu["part_2Nx2N"], pu["ref_list"] = a[:, 7], a[:, 8], a[:, 9], a[:, 2]
+            pu["x_ctb"], pu["y_ctb"] = a[:, 10], a[:, 11]
+            pu["mvp"] = a2[:, 0:4].reshape(-1, 2, 2)
+            pu["mv_previous_2Nx2N"] = a2[:, 4:6]
+            pu["mvp_rate"][:, 0], pu["mvp_rate"][:, 1] = i64(a2[:, 6], a2[:, 7]), i64(a2[:, 8], a2[:, 9])
+            m = np.zeros(len(b), [("poc", "i4"), ("ref_poc", "i4"), ("concurrent_frames", "i4"), ("flags", "i4"), ("rsl", "f8"), ("bit_depth", "i4"),
+                                  ("ctb", "i4"), ("thread", "i4"), ("seq", "i8"), ("start", "i2", (2,))])
+            m["seq"] = mine[b]                                             # position in the trace file = the order the encoder ran the searches in
+            m["poc"], m["ref_poc"], m["concurrent_frames"], m["flags"] = a[:, 0], a[:, 1], a[:, 12], a[:, 13]
+            m["rsl"], m["bit_depth"], m["ctb"], m["thread"] = f64(a2[:, 10], a2[:, 11]), a2[:, 12], a2[:, 13], t
+            res = np.zeros(len(b), st.RESULT_DT)
+            r_end = v[e]
+            if bi:
+                assert np.all(kind[b + 2] == BI_MV)
+                mv = v[b + 2][:, 0:4].reshape(-1, 2, 2)                     # [search][list][x, y]
+                lst = pu["ref_list"]
+                idx = np.arange(len(b))
+                m["start"] = mv[idx, lst]
+                pu["mv_other"] = mv[idx, 1 - lst]
+                res["mv"], res["mvd"], res["mvp_flag"] = r_end[:, 0:2], r_end[:, 2:4], r_end[:, 4]
+                res["cost_subpel"] = i64(r_end[:, 5], r_end[:, 6])
+            else:
+                # UNI_INTEGER is the record after the last integer call; UNI_SUBPEL (if the speed refines) the one before UNI_END
+                is_int = np.flatnonzero(kind == UNI_INTEGER)
+                assert len(is_int) == len(b) and np.all((is_int > b) & (is_int < e))
+                ri = v[is_int]
+                res["mv_integer"], res["mvp_flag"], res["cost_integer"] = ri[:, 0:2], ri[:, 4], i64(ri[:, 5], ri[:, 6])
+                res["mv"], res["mvd"] = ri[:, 0:2], ri[:, 2:4]
+                sub = kind[e - 1] == UNI_SUBPEL
+                res["mv"][sub], res["mvd"][sub] = v[e - 1][sub, 0:2], v[e - 1][sub, 2:4]
+                assert np.array_equal(res["mvd"], r_end[:, 0:2]) and np.array_equal(res["mvp_flag"], r_end[:, 2])
+            call = (kind == SAD) | (kind == SAD4) | (kind == SATD)
+            inside = (np.cumsum(kind == begin) - np.cumsum(kind == end)) > 0
+            csum = np.concatenate([[0], np.cumsum(call & inside)])
+            counts = csum[e] - csum[b]
+            res["calls"] = counts
+            rows.append(_call_rows(rec[call & inside]))
+            first.extend((first[-1] + np.cumsum(counts)).tolist())
+            pus.append(pu)
+            meta.append(m)
+            results.append(res)
+        cat = lambda parts, dt: np.concatenate(parts) if parts else np.zeros(0, dt)
+        self.pus, self.meta, self.results = cat(pus, st.PU_DT), cat(meta, np.dtype([("poc", "i4")])), cat(results, st.RESULT_DT)
+        self.rows = np.concatenate(rows) if rows else np.zeros((0, 13), np.int32)
+        self.first = np.asarray(first, np.int64)
+        self.bi = bi
+
+    def __len__(self):
+        return len(self.pus)
+
+    def groups(self):
+        """searches that share pictures and encoder settings: {(poc, ref_poc, other_poc or -1 ...): indices}; one client call each"""
+        m = self.meta
+        keys = np.stack([m["poc"], m["ref_poc"], m["concurrent_frames"], m["flags"], m["bit_depth"], m["ctb"], m["rsl"].view(np.int64) & 0xFFFFFFFF,
+                         m["rsl"].view(np.int64) >> 32], axis=1)
+        out = {}
+        uniq, inv = np.unique(keys, axis=0, return_inverse=True)
+        for g in range(len(uniq)):
+            out[tuple(int(x) for x in uniq[g])] = np.flatnonzero(inv.ravel() == g)
+        return out
+
+    def params(self, key, width, height):
+        poc, ref_poc, cf, flags, bd, ctb = key[:6]
+        rsl = float(np.array([key[6] | (key[7] << 32)], np.int64).view(np.float64)[0])
+        return st.Params(width, height, ctb, cf, flags & 1, (flags >> 1) & 1, (flags >> 2) & 1, (flags >> 3) & 1, (flags >> 4) & 1, bd, rsl)
+
+
+class IntraTrace:
+    """every searchIntraPartition: the 35 distortions predictIntraLuma returned, the rate offsets, and the order the modes went to RD refinement in"""
+
+    def __init__(self, records):
+        ctx, satd, costs, order, count, rsl, where, champion = [], [], [], [], [], [], [], []
+        for t in np.unique(records["thread"]):
+            rec = records[records["thread"] == t]
+            kind = rec["kind"].astype(np.int32)
+            b, e = _segments(kind, INTRA_BEGIN, INTRA_END)
+            v = rec["v"]
+            for k in range(len(b)):
+                seg_kind, seg = kind[b[k]:e[k] + 1], v[b[k]:e[k] + 1]
+                a = seg[0]
+                s = seg[seg_kind == INTRA_SATD]
+                assert len(s) == 35 and np.array_equal(s[:, 0], np.arange(35))
+                c = np.zeros(1, st.INTRA_CTX_DT)[0]
+                c["cand_mode_list"], c["neighbour_modes"] = a[4:7], a[7]
+                c["max_refine"] = seg[seg_kind == INTRA_MAX][0][0]
+                c["rate_a_minus_c"], c["rate_b_minus_c"] = i64(a[8:9], a[9:10])[0], i64(a[10:11], a[11:12])[0]
+                picks = seg[seg_kind == INTRA_PICK]
+                assert np.array_equal(picks[:, 0], np.arange(len(picks)))
+                o = np.full(35, -1, np.int32)
+                o[:len(picks)] = picks[:, 1]
+                ctx.append(c)
+                satd.append(s[:, 1])
+                costs.append(i64(s[:, 2], s[:, 3]))
+                order.append(o)
+                count.append(len(picks))
+                rsl.append(f64(a[12:13], a[13:14])[0])
+                where.append(a[0:4])
+                champion.append(seg[-1][0])
+        self.ctx = np.array(ctx, st.INTRA_CTX_DT) if ctx else np.zeros(0, st.INTRA_CTX_DT)
+        self.satd = np.array(satd, np.int32).reshape(-1, 35)
+        self.costs = np.array(costs, np.int64).reshape(-1, 35)
+        self.order = np.array(order, np.int32).reshape(-1, 35)
+        self.count = np.array(count, np.int32)
+        self.rsl = np.array(rsl, np.float64)
+        self.where = np.array(where, np.int32).reshape(-1, 4)      # poc, x, y, log2 partition size
+        self.champion = np.array(champion, np.int32)
+
+    def __len__(self):
+        return len(self.ctx)

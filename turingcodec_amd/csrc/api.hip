@@ -43,6 +43,8 @@ hipError_t launch_intra_decide(hipStream_t, const void *, const int32_t *, const
 size_t search_workspace_bytes(int width, int height);
 hipError_t launch_search_list(hipStream_t, int S, const havoc_mi355x_search_params *, const void *, long, long, const void *, long, long, const void *, long, long, const void *,
                               int, void *);
+hipError_t launch_search_bi_list(hipStream_t, int S, const havoc_mi355x_search_params *, const void *, long, long, const void *, long, long, const void *, long, long, const void *,
+                                 long, const void *, const int16_t *, int, void *);
 hipError_t launch_search_picture_uni(hipStream_t, int S, const havoc_mi355x_search_params *, const int64_t *, const void *, long, long, const void *, const long *, long,
                                      const void *, long, const long *, const void *, const int32_t *, int, int, int, void *, void *, int16_t *, void *, int);
 hipError_t launch_rdoq(hipStream_t, int bd, int log2, int16_t *, const int16_t *, const uint8_t *, const void *, int, int32_t *, void *);
@@ -544,10 +546,24 @@ int havoc_mi355x_search_motion_uni(havoc_mi355x_ctx *ctx, int S, const havoc_mi3
 {
     REQUIRE_CTX(); REQUIRE_S();
     REQUIRE(params, "null argument"); REQUIRE(n >= 0, "n < 0");
+    REQUIRE(n == 0 || (d_src && d_ref && d_phase && d_pus && d_out), "null device pointer");
     REQUIRE(params->bit_depth >= 8 && params->bit_depth <= (S == 1 ? 8 : 10), "bit_depth must be 8 (S=1) or 8..10 (S=2)");
     return check(launch_search_list(LS(ctx), S, params, d_src, (long)src_origin, src_stride, d_ref, (long)ref_origin, ref_stride, d_phase, plane_elems, (long)phase_origin,
                                     d_pus, n, d_out),
                  "search_motion_uni");
+}
+
+int havoc_mi355x_search_motion_bi(havoc_mi355x_ctx *ctx, int S, const havoc_mi355x_search_params *params, const void *d_src, int64_t src_origin, intptr_t src_stride,
+                                  const void *d_ref, int64_t ref_origin, intptr_t ref_stride, const void *d_phase, intptr_t plane_elems, int64_t phase_origin,
+                                  const void *d_phase_other, int64_t phase_other_origin, const void *d_pus, const int16_t *d_start, int n, void *d_out)
+{
+    REQUIRE_CTX(); REQUIRE_S();
+    REQUIRE(params, "null argument"); REQUIRE(n >= 0, "n < 0");
+    REQUIRE(n == 0 || (d_src && d_ref && d_phase && d_phase_other && d_pus && d_start && d_out), "null device pointer");
+    REQUIRE(params->bit_depth >= 8 && params->bit_depth <= (S == 1 ? 8 : 10), "bit_depth must be 8 (S=1) or 8..10 (S=2)");
+    return check(launch_search_bi_list(LS(ctx), S, params, d_src, (long)src_origin, src_stride, d_ref, (long)ref_origin, ref_stride, d_phase, plane_elems, (long)phase_origin,
+                                       d_phase_other, (long)phase_other_origin, d_pus, d_start, n, d_out),
+                 "search_motion_bi");
 }
 
 size_t havoc_mi355x_search_workspace(int width, int height) { return width > 0 && height > 0 ? search_workspace_bytes(width, height) : 0; }
@@ -560,6 +576,9 @@ int havoc_mi355x_search_picture_uni(havoc_mi355x_ctx *ctx, int S, const havoc_mi
     REQUIRE_CTX(); REQUIRE_S();
     REQUIRE(n_pus >= 0, "n_pus < 0");
     REQUIRE(params && mvp_rate && ref_origin && phase_origin, "null argument");
+    REQUIRE(d_src && d_ref && d_phase && d_pus && d_ctu_first && d_out && d_field && d_work, "null device pointer");
+    REQUIRE(((uintptr_t)d_field & 3) == 0 && ((uintptr_t)d_work & 15) == 0, "d_field must be 4-byte aligned, d_work 16-byte aligned");
+    REQUIRE(mvp_rate[0] >= 0 && mvp_rate[1] >= 0, "mvp_rate must not be negative (the device compares costs as non-negative numbers)");
     REQUIRE(params->ctb_size == 64, "ctb_size must be 64");
     REQUIRE(params->pic_width > 0 && params->pic_height > 0 && params->pic_width % 8 == 0 && params->pic_height % 8 == 0, "picture size must be a positive multiple of 8");
     REQUIRE(ctus_x == (params->pic_width + 63) / 64 && ctus_y == (params->pic_height + 63) / 64, "ctus_x / ctus_y do not match the picture size");

@@ -752,31 +752,22 @@ __global__ __launch_bounds__(kThreads) void k_search_list(const SearchArgs a, co
 // The bi-directional refinement of every PU in `list` (searchBi, turing/Search.hpp:1796-1827, the branch without mvd_l1_zero_flag): nothing of it
 // feeds the walk above (the motion field keeps the uni-directional vectors), so it is not a chain: ONE launch per list after the walk, a
 // workgroup per PU -- list 0 against the prediction from list 1's vector, then (next launch) list 1 against list 0's refined vector.
+// one refinement: the workgroup builds the "ideal" block and the window in LDS and runs searchMotionBi; q = the PU, pu = its context (predictors, rates),
+// `other` = the other list's vector (the prediction is read from a.phase[1 - list]), `start` = the refined list's vector
 template <int S>
-__global__ __launch_bounds__(kThreads) void k_search_bi(const SearchArgs a, const int list)
+__device__ __forceinline__ havoc_search::BiResult bi_refine(const SearchArgs &a, Lds<S> &x, const int list, const int x0, const int y0, const int w, const int h,
+                                                            const havoc_search::PuContext &pu, const Mv other, const Mv start)
 {
-    __shared__ Lds<S> x;
-    const int p = blockIdx.x, tid = threadIdx.x;
-    const havoc_picture_pu q = a.pus[p];
-    if (!havoc_search::biRefined(q))
-    {
-        if (tid == 0) a.outBi[2 * p + list] = havoc_search_result();
-        return;
-    }
-    const havoc_search_result uni = a.out[2 * p + list], stash = a.outBi[2 * p + list];
-    const havoc_search_result from = list == 0 ? a.out[2 * p + 1] : a.outBi[2 * p];
-    const Mv mvp[2] = {Mv(stash.mv[0], stash.mv[1]), Mv(stash.mvd[0], stash.mvd[1])};
-    const Mv other(from.mv[0], from.mv[1]), start(uni.mv[0], uni.mv[1]);
-    const havoc_search::PuContext pu = havoc_search::contextOf(q, a.sp.ctbSize, mvp, a.mvpRate, Mv(0, 0));
+    const int tid = threadIdx.x;
     const long sbb = a.refStride * S;
     DeviceView<S> view;
-    const long at = (long)q.y0 * a.refStride + q.x0;
+    const long at = (long)y0 * a.refStride + x0;
     view.ref = a.ref[list] + at * S;
     view.phase = a.phase[list] + at * S;
     view.sbb = sbb;
     view.planeBytes = a.planeElems * S;
-    view.w = q.w;
-    view.h = q.h;
+    view.w = w;
+    view.h = h;
     view.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     view.lane = tid & 63;
     view.tid = tid;
@@ -785,12 +776,12 @@ __global__ __launch_bounds__(kThreads) void k_search_bi(const SearchArgs a, cons
     {   // the "ideal" second predictor clip(2 * source - prediction from the other list) takes the source block's place (Search.hpp:1519-1546)
         Mv full = havoc_search::shr2(other);
         limit(full);
-        const char *pred = a.phase[1 - list] + (long)(4 * (other.y & 3) + (other.x & 3)) * a.planeElems * S + (((long)q.y0 + full.y) * a.refStride + q.x0 + full.x) * S;
-        const char *gs = a.src + ((long)q.y0 * a.srcStride + q.x0) * S;
-        const int srcDw = q.w * S / 4;
+        const char *pred = a.phase[1 - list] + (long)(4 * (other.y & 3) + (other.x & 3)) * a.planeElems * S + (((long)y0 + full.y) * a.refStride + x0 + full.x) * S;
+        const char *gs = a.src + ((long)y0 * a.srcStride + x0) * S;
+        const int srcDw = w * S / 4;
         const FastDiv fs(srcDw);
         uint32_t *ideal = reinterpret_cast<uint32_t *>(x.src);
-        for (int i = tid; i < srcDw * q.h; i += kThreads)
+        for (int i = tid; i < srcDw * h; i += kThreads)
         {
             const int y = fs.div(i), k = i - y * srcDw;
             const uint32_t sv = ld4(gs + y * a.srcStride * S + 4 * k), pv = ld4(pred + y * sbb + 4 * k);
@@ -817,7 +808,7 @@ __global__ __launch_bounds__(kThreads) void k_search_bi(const SearchArgs a, cons
         limit(o0);
         view.bx0 = o0.x - kWinMargin; view.bx1 = o0.x + kWinMargin;
         view.by0 = o0.y - kWinMargin; view.by1 = o0.y + kWinMargin;
-        const int rowB = (view.bx1 - view.bx0 + q.w) * S, rowDw = (rowB + 3) / 4, nRows = view.by1 - view.by0 + q.h;
+        const int rowB = (view.bx1 - view.bx0 + w) * S, rowDw = (rowB + 3) / 4, nRows = view.by1 - view.by0 + h;
         view.wsB = rowDw * 4;
         const FastDiv fd(rowDw);
         const char *g = view.ref + view.by0 * sbb + (long)view.bx0 * S;
@@ -829,17 +820,61 @@ __global__ __launch_bounds__(kThreads) void k_search_bi(const SearchArgs a, cons
         }
     }
     __syncthreads();
-    const havoc_search::BiResult b = havoc_search::searchMotionBi(a.sp, pu, view, start);
-    if (tid == 0)
+    return havoc_search::searchMotionBi(a.sp, pu, view, start);
+}
+
+__device__ __forceinline__ havoc_search_result biRecord(const havoc_search::BiResult &b)
+{
+    havoc_search_result o = havoc_search_result();
+    o.mv[0] = b.mv.x; o.mv[1] = b.mv.y;
+    o.mvd[0] = b.mvd.x; o.mvd[1] = b.mvd.y;
+    o.mvp_flag = (int16_t)b.mvpFlag;
+    o.calls = b.calls;
+    o.cost_subpel = b.cost;
+    return o;
+}
+
+template <int S>
+__global__ __launch_bounds__(kThreads) void k_search_bi(const SearchArgs a, const int list)
+{
+    __shared__ Lds<S> x;
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const havoc_picture_pu q = a.pus[p];
+    if (!havoc_search::biRefined(q))
     {
-        havoc_search_result o = havoc_search_result();
-        o.mv[0] = b.mv.x; o.mv[1] = b.mv.y;
-        o.mvd[0] = b.mvd.x; o.mvd[1] = b.mvd.y;
-        o.mvp_flag = (int16_t)b.mvpFlag;
-        o.calls = b.calls;
-        o.cost_subpel = b.cost;
-        a.outBi[2 * p + list] = o;
+        if (tid == 0) a.outBi[2 * p + list] = havoc_search_result();
+        return;
     }
+    const havoc_search_result uni = a.out[2 * p + list], stash = a.outBi[2 * p + list];
+    const havoc_search_result from = list == 0 ? a.out[2 * p + 1] : a.outBi[2 * p];
+    const Mv mvp[2] = {Mv(stash.mv[0], stash.mv[1]), Mv(stash.mvd[0], stash.mvd[1])};
+    const Mv other(from.mv[0], from.mv[1]), start(uni.mv[0], uni.mv[1]);
+    const havoc_search::PuContext pu = havoc_search::contextOf(q, a.sp.ctbSize, mvp, a.mvpRate, Mv(0, 0));
+    const havoc_search::BiResult b = bi_refine<S>(a, x, list, q.x0, q.y0, q.w, q.h, pu, other, start);
+    if (tid == 0) a.outBi[2 * p + list] = biRecord(b);
+}
+
+// n INDEPENDENT refinements whose predictors, rates, other-list vector (havoc_search_pu::mv_other) and start vector are inputs: the list form of
+// k_search_bi, as k_search_list is of the walk.  a.ref[0] / a.phase[0] = the refined list's picture, a.phase[1] = the other list's phase planes.
+template <int S>
+__global__ __launch_bounds__(kThreads) void k_search_bi_list(const SearchArgs a, const havoc_search_pu *__restrict__ pus, const int16_t *__restrict__ start)
+{
+    __shared__ Lds<S> x;
+    const int i = blockIdx.x, tid = threadIdx.x;
+    const havoc_search_pu q = pus[i];
+    havoc_search::PuContext pu;
+    pu.x0 = q.x0; pu.y0 = q.y0; pu.w = q.w; pu.h = q.h;
+    pu.cuLog2Size = q.cu_log2_size;
+    pu.cqtDepth = q.cqt_depth;
+    pu.part2Nx2N = q.part_2Nx2N != 0;
+    pu.xCtb = q.x_ctb; pu.yCtb = q.y_ctb;
+    for (int k = 0; k < 2; ++k)
+    {
+        pu.mvp[k] = Mv(q.mvp[k][0], q.mvp[k][1]);
+        pu.mvpRate[k] = q.mvp_rate[k];
+    }
+    const havoc_search::BiResult b = bi_refine<S>(a, x, 0, q.x0, q.y0, q.w, q.h, pu, Mv(q.mv_other[0], q.mv_other[1]), Mv(start[2 * i], start[2 * i + 1]));
+    if (tid == 0) a.out[i] = biRecord(b);
 }
 
 // the cells left of and above CTU (cx, cy) from the picture's field (decided by earlier launches / by workgroups whose progress was awaited)
@@ -995,6 +1030,38 @@ hipError_t launch_search_list(hipStream_t st, int S, const havoc_mi355x_search_p
         hipLaunchKernelGGL(k_search_list<1>, dim3(n), dim3(kThreads), 0, st, a, static_cast<const havoc_search_pu *>(pus));
     else
         hipLaunchKernelGGL(k_search_list<2>, dim3(n), dim3(kThreads), 0, st, a, static_cast<const havoc_search_pu *>(pus));
+    return hipGetLastError();
+}
+
+hipError_t launch_search_bi_list(hipStream_t st, int S, const havoc_mi355x_search_params *sp, const void *src, long srcOrigin, long srcStride, const void *ref,
+                                 long refOrigin, long refStride, const void *phase, long planeElems, long phaseOrigin, const void *phaseOther, long phaseOtherOrigin,
+                                 const void *pus, const int16_t *start, int n, void *out)
+{
+    if (n <= 0) return hipSuccess;
+    SearchArgs a = SearchArgs();
+    a.sp.picWidth = sp->pic_width;
+    a.sp.picHeight = sp->pic_height;
+    a.sp.ctbSize = sp->ctb_size;
+    a.sp.concurrentFrames = sp->concurrent_frames;
+    a.sp.met = sp->met != 0;
+    a.sp.smallSearchWindow = sp->small_search_window != 0;
+    a.sp.biSmallSearchWindow = sp->bi_small_search_window != 0;
+    a.sp.halfPel = sp->half_pel != 0;
+    a.sp.quarterPel = sp->quarter_pel != 0;
+    a.sp.reciprocalSqrtLambda = sp->reciprocal_sqrt_lambda;
+    a.sp.bitDepth = sp->bit_depth;
+    a.src = static_cast<const char *>(src) + srcOrigin * S;
+    a.ref[0] = a.ref[1] = static_cast<const char *>(ref) + refOrigin * S;
+    a.phase[0] = static_cast<const char *>(phase) + phaseOrigin * S;
+    a.phase[1] = static_cast<const char *>(phaseOther) + phaseOtherOrigin * S;
+    a.srcStride = srcStride;
+    a.refStride = refStride;
+    a.planeElems = planeElems;
+    a.out = static_cast<havoc_search_result *>(out);
+    if (S == 1)
+        hipLaunchKernelGGL(k_search_bi_list<1>, dim3(n), dim3(kThreads), 0, st, a, static_cast<const havoc_search_pu *>(pus), start);
+    else
+        hipLaunchKernelGGL(k_search_bi_list<2>, dim3(n), dim3(kThreads), 0, st, a, static_cast<const havoc_search_pu *>(pus), start);
     return hipGetLastError();
 }
 

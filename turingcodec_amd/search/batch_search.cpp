@@ -221,6 +221,7 @@ int havoc_search_motion_uni_device(havoc_mi355x_ctx *ctx, int S, const havoc_sea
     {
         const havoc_search_pu &q = pus[i];
         if (q.w < 4 || q.h < 4 || q.w > 64 || q.h > 64 || (q.w & 3) || (q.h & 3) || q.x0 < 0 || q.y0 < 0 || q.x0 + q.w > W || q.y0 + q.h > H) return HAVOC_MI355X_EINVAL;
+        if (q.mvp_rate[0] < 0 || q.mvp_rate[1] < 0) return HAVOC_MI355X_EINVAL;      // the device compares costs as non-negative numbers (decision.hpp: costLess)
     }
     Arena arena(ctx);
     void *dPus, *hPus, *dOut, *hOut;
@@ -360,6 +361,51 @@ int havoc_search_intra_modes(havoc_mi355x_ctx *ctx, int S, int bitDepth, int log
         for (int m = 0; m < 35; ++m) out[i].costs[m] = r.costs[m];
         for (int m = 0; m < r.count; ++m) out[i].order[m] = r.order[m];
         out[i].count = r.count;
+    }
+    return 0;
+}
+
+// The bi-directional refinements with the loop inside the kernel (havoc_mi355x_search_motion_bi, csrc/kernels_search.hip: a workgroup per refinement,
+// ONE launch): the list form of the refinement launches of havoc_search_picture_uni_device.  d_phase_other = the OTHER list's 16 phase planes (the
+// prediction the ideal block is built against is read from them).  Results identical to havoc_search_motion_bi except `replays` (0).
+int havoc_search_motion_bi_device(havoc_mi355x_ctx *ctx, int S, const havoc_search_params *params, const void *d_src, int64_t src_origin, intptr_t src_stride,
+                                  const void *d_ref, int64_t ref_origin, intptr_t ref_stride, int ref_pad, const void *d_phase, intptr_t plane_elems,
+                                  int64_t phase_origin, const void *d_phase_other, int64_t phase_other_origin, const havoc_search_pu *pus, const int16_t *start, int n,
+                                  havoc_search_result *out, havoc_search_stats *stats)
+{
+    if (!ctx || !params || !pus || !out || !start || n < 0 || (S != 1 && S != 2) || ref_pad < 96) return HAVOC_MI355X_EINVAL;
+    const double tStart = now();
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    if (n == 0) return 0;
+    const int W = params->pic_width, H = params->pic_height;
+    for (int i = 0; i < n; ++i)
+    {
+        const havoc_search_pu &q = pus[i];
+        if (q.w < 4 || q.h < 4 || q.w > 64 || q.h > 64 || (q.w & 3) || (q.h & 3) || q.x0 < 0 || q.y0 < 0 || q.x0 + q.w > W || q.y0 + q.h > H) return HAVOC_MI355X_EINVAL;
+        if (q.mvp_rate[0] < 0 || q.mvp_rate[1] < 0) return HAVOC_MI355X_EINVAL;
+    }
+    Arena arena(ctx);
+    void *dPus, *hPus, *dStart, *hStart, *dOut, *hOut;
+    RC(arena.get(size_t(n) * sizeof(havoc_search_pu), &dPus, &hPus));
+    RC(arena.get(size_t(n) * 4, &dStart, &hStart));
+    RC(arena.get(size_t(n) * sizeof(havoc_search_result), &dOut, &hOut));
+    std::memcpy(hPus, pus, size_t(n) * sizeof(havoc_search_pu));
+    std::memcpy(hStart, start, size_t(n) * 4);
+    RC(havoc_mi355x_h2d_async(ctx, dPus, hPus, size_t(n) * sizeof(havoc_search_pu)));
+    RC(havoc_mi355x_h2d_async(ctx, dStart, hStart, size_t(n) * 4));
+    havoc_mi355x_search_params dp;
+    std::memcpy(&dp, params, sizeof(dp));
+    RC(havoc_mi355x_search_motion_bi(ctx, S, &dp, d_src, src_origin, src_stride, d_ref, ref_origin, ref_stride, d_phase, plane_elems, phase_origin, d_phase_other,
+                                     phase_other_origin, dPus, static_cast<const int16_t *>(dStart), n, dOut));
+    RC(havoc_mi355x_d2h_async(ctx, hOut, dOut, size_t(n) * sizeof(havoc_search_result)));
+    RC(havoc_mi355x_sync(ctx));
+    std::memcpy(out, hOut, size_t(n) * sizeof(havoc_search_result));
+    if (stats)
+    {
+        stats->launches = 1;
+        stats->rounds = 1;
+        stats->bytes_down = int64_t(n) * sizeof(havoc_search_result);
+        stats->seconds_total = stats->seconds_gpu = now() - tStart;
     }
     return 0;
 }
