@@ -31,6 +31,13 @@ def main():
         hist = os.path.join(work, "hist.json")
         et.encode(et.CLASSIC_EXE, case, work, env={"LD_LIBRARY_PATH": mock_dir + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""), "HAVOC_MOCK_HISTOGRAM": hist})
         raw = json.load(open(hist))
+        # the searches themselves, counted by the reference encoder with trace points in its decision loops (oracle/trace_hooks.h; summary mode: counts only)
+        searches = None
+        trace_exe = os.path.join(et.REFDIR, "turing_ref_trace")
+        if os.path.exists(trace_exe):
+            summ = os.path.join(work, "summary.json")
+            et.encode(trace_exe, case, work, env={"HAVOC_TRACE_SUMMARY": summ}, tag=".trace")
+            searches = json.load(open(summ))
     by_fn = collections.defaultdict(dict)
     for k, v in raw.items():
         fn, size = k.split(" ")
@@ -58,6 +65,14 @@ def main():
         rep["intra_prediction_calls_by_size"] = share_by_area(by_fn["intra"])
     if "transform" in by_fn:
         rep["forward_transform_calls_by_size"] = share_by_area(by_fn["transform"])
+    if searches:
+        k = {int(a): b for a, b in searches["records_by_kind"].items()}
+        rep["searches"] = {"what": "counted inside the reference encoder's own loops (oracle/_ref/turing_ref_trace, summary mode)",
+                           "searchMotionUni": k.get(1, 0), "searchMotionBi": k.get(9, 0), "havoc_sad calls": k.get(3, 0), "havoc_sad_multiref calls": k.get(4, 0),
+                           "costDistortionMv calls (interpolate + SATD)": k.get(5, 0), "searchIntraPartition": k.get(12, 0),
+                           "predictIntraLuma calls of the 35-mode stage": k.get(13, 0), "intra RD candidates (reconstructIntraLuma)": k.get(15, 0),
+                           "uni_searches_by_size": searches["uni_searches_by_size"], "bi_searches_by_size": searches["bi_searches_by_size"],
+                           "intra_partitions_by_log2_size": searches["intra_partitions_by_log2_size"]}
     from turingcodec_amd import workload
     tot = sum(n for _, _, n in workload.PU_MIX)
     rep["workload_assumes"] = {"pu_mix (w x h: share)": {f"{w}x{h}": round(n / tot, 4) for w, h, n in workload.PU_MIX},

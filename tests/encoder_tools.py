@@ -19,6 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REFDIR = os.path.join(ROOT, "oracle", "_ref")
 HAVOC_EXE = os.path.join(REFDIR, "turing_ref_havoc")
 CLASSIC_EXE = os.path.join(REFDIR, "turing_ref_classic")
+HOOKED_EXE = os.path.join(REFDIR, "turing_ref_hooked")      # turing_ref_classic + the two havoc_classic_register_picture calls (oracle/register_hooks.h)
 GOLDEN = os.path.join(ROOT, "tests", "golden", "encoder_streams.json")
 
 # name: (width, height, frames, clip seed, bit depth, encoder options).  --no-sao everywhere: with SAO the reference is not

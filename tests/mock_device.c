@@ -21,9 +21,11 @@ long mock_launches(void) { return g_launches; }
 
 /* HAVOC_MOCK_HISTOGRAM=<file>: the jobs of every call by entry point and block size, written when the context is destroyed -- how
  * profiles/measure_call_mix.py reads the call mix of the reference's own encoder (run over libhavoc_classic.so + this stand-in) */
-enum { H_SAD, H_SAD4, H_SATD, H_PRED_UNI8, H_PRED_UNI4, H_PRED_BI8, H_PRED_BI4, H_SUBTRACT_BI, H_INTRA, H_TRANSFORM, H_INVERSE, H_SSD, H_QUANTIZE, H_RDOQ, H_COUNT };
+enum { H_SAD, H_SAD4, H_SATD, H_PRED_UNI8, H_PRED_UNI4, H_PRED_BI8, H_PRED_BI4, H_SUBTRACT_BI, H_INTRA, H_TRANSFORM, H_INVERSE, H_SSD, H_QUANTIZE, H_RDOQ,
+       H_UNI8_COPY, H_UNI8_H, H_UNI8_V, H_UNI8_HV, H_UNI4_COPY, H_UNI4_H, H_UNI4_V, H_UNI4_HV, H_TRANSFORM_DST, H_COUNT };   /* sub-tallies: interpolation by phase class, DST-VII transforms */
 static const char *const g_hname[H_COUNT] = {"sad", "sad4", "satd", "pred_uni8", "pred_uni4", "pred_bi8", "pred_bi4", "subtract_bi", "intra", "transform",
-                                             "inverse_transform", "ssd", "quantize", "rdoq"};
+                                             "inverse_transform", "ssd", "quantize", "rdoq", "uni8_copy", "uni8_h", "uni8_v", "uni8_hv", "uni4_copy",
+                                             "uni4_h", "uni4_v", "uni4_hv", "transform_dst"};
 static long g_hist[H_COUNT][65][65];
 static void tally(int fn, int w, int h) { if (w >= 0 && w <= 64 && h >= 0 && h <= 64) __sync_fetch_and_add(&g_hist[fn][w][h], 1); }   /* the encoder calls from several threads */
 static void write_histogram(void)
@@ -134,6 +136,7 @@ int havoc_mi355x_pred_uni(havoc_mi355x_ctx *ctx, int S, int taps, int bitDepth, 
 {
     (void)ctx; (void)max_w; (void)max_h; ++g_launches;
     for (int i = 0; i < n; ++i) tally(taps == 8 ? H_PRED_UNI8 : H_PRED_UNI4, j[i].w, j[i].h);
+    for (int i = 0; i < n; ++i) tally((taps == 8 ? H_UNI8_COPY : H_UNI4_COPY) + (j[i].xFrac != 0) + 2 * (j[i].yFrac != 0), j[i].w, j[i].h);
     for (int i = 0; i < n; ++i)
         oracle_pred_uni((char *)dst + (long)j[i].dst_off * S, sd, AT(ref, j[i].ref_off, S), sr, j[i].w, j[i].h, j[i].xFrac, j[i].yFrac, bitDepth, taps, S);
     return 0;
@@ -236,6 +239,7 @@ int havoc_mi355x_transform(havoc_mi355x_ctx *ctx, int bitDepth, int trType, int 
 {
     (void)ctx; ++g_launches;
     for (int i = 0; i < n; ++i) tally(H_TRANSFORM, 1 << log2, 1 << log2);
+    if (trType) for (int i = 0; i < n; ++i) tally(H_TRANSFORM_DST, 1 << log2, 1 << log2);
     for (int i = 0; i < n; ++i) oracle_transform(coeffs + j[i].coef_off, res + j[i].res_off, stride_res, log2, trType, bitDepth);
     return 0;
 }

@@ -75,6 +75,58 @@ def test_reference_encoder_over_mi355x_tables_writes_the_reference_stream(case, 
     _check_golden(case, got, workdir)
 
 
+needs_hooked = pytest.mark.skipif(not (et.have_encoders() and os.path.exists(et.HOOKED_EXE)), reason="oracle/_ref/turing_ref_hooked not built (`make -C oracle hooked`)")
+
+
+def _served(err):
+    """'libhavoc_classic: table calls served N, one-job launches M, launches L, surfaces S, tile-SATD batches T, pictures P' -> dict"""
+    import re
+    line = [l for l in err.strip().splitlines() if "table calls served" in l][-1]
+    n = [int(v) for v in re.findall(r"\d+", line)]
+    return dict(zip(["served", "one_job", "launches", "surfaces", "satd_batches", "pictures"], n))
+
+
+@needs_hooked
+@pytest.mark.parametrize("case,concurrent", [("ra_medium_qp22", 1), ("ra_medium_qp32", 4), ("ra_medium_10bit_qp27", 4), ("ra_slow_qp27", 4)])
+def test_hooked_reference_encoder_is_served_from_registered_pictures_and_writes_the_reference_stream_on_the_mock_device(case, concurrent, workdir):
+    """the reference encoder with the two calls of include/havoc_classic_ext.h added (input picture when it starts, reconstructed
+    picture when it is complete and padded; oracle/register_hooks.h, inserted into temporary copies of TaskEncodeInput.cpp / TaskSao.cpp at build time).
+    The precompute-and-serve layer of libhavoc_classic.so now meets the REAL encoder's call patterns -- merge candidates, chroma, bi-prediction,
+    searches into pictures still being reconstructed (--concurrent-frames 4: those planes are not registered yet and take the one-job path),
+    picture buffers freed and reused -- and the stream must still be the reference's."""
+    sys.path.insert(0, HERE)
+    import search_runner
+    search_runner.build_mock()
+    extra = ["--concurrent-frames", str(concurrent)]
+    ref, _ = et.encode(et.HAVOC_EXE, case, workdir, extra, tag=f".cf{concurrent}")
+    got, err = et.encode(et.HOOKED_EXE, case, workdir, extra, env={"LD_LIBRARY_PATH": MOCK_DIR + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""), "HAVOC_CLASSIC_REPORT": "1"},
+                         tag=f".hooked{concurrent}")
+    s = _served(err)
+    print(case, concurrent, s)
+    assert got == ref, f"{case}: the hooked encoder's stream differs from the reference encoder's"
+    assert s["pictures"] >= 4 and s["served"] > 0.4 * (s["served"] + s["one_job"]) and s["one_job"] > 0 and s["surfaces"] > 0 and s["satd_batches"] > 0, s
+    if concurrent == 4:
+        _check_golden(case, got, workdir)          # --concurrent-frames 4 is the default the committed hashes were made with
+
+
+@needs_hooked
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["gpu_ra_medium_qp32", "gpu_ra_medium_10bit"])
+def test_hooked_reference_encoder_on_the_mi355x(case, workdir):
+    """the same on the real device: stream identical, most table calls answered from SAD surfaces / phase planes / tile-SATD sets computed on the GPU"""
+    import time
+    ref, _ = et.encode(et.HAVOC_EXE, case, workdir)
+    t0 = time.perf_counter()
+    got, err = et.encode(et.HOOKED_EXE, case, workdir, env={"HAVOC_CLASSIC_REPORT": "1"}, timeout=1500, tag=".hooked")
+    dt = time.perf_counter() - t0
+    s = _served(err)
+    calls = s["served"] + s["one_job"]
+    print(case, s, f"{dt:.1f} s, {dt / calls * 1e6:.2f} us per table call, {s['launches'] / et.CASES[case][2]:.0f} launches per frame")
+    assert got == ref, f"{case}: the hooked encoder's stream on the MI355X differs from the reference encoder's"
+    assert s["served"] > s["one_job"] > 0, s
+    _check_golden(case, got, workdir)
+
+
 @needs_encoders
 def test_call_mix_of_the_reference_encoder_can_be_measured(tmp_path):
     """profiles/measure_call_mix.py: the reference encoder over the classic tables + the stand-in device, which tallies its jobs by entry point and

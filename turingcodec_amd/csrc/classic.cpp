@@ -927,11 +927,23 @@ int havoc_classic_register_picture(havoc_code code, const void *origin, intptr_t
         return rc;
     undo.armed = false;
     const PicList *old = b->pics.load();
-    PicList *next = old ? new PicList(*old) : new PicList();
+    PicList *next = new PicList();
     next->serial = g_nextSerial.fetch_add(1);
+    // a plane that overlaps this one in host memory cannot still be a picture (its buffer was freed and reused, or the same picture is registered
+    // again with new contents): it goes, so that no pointer can name two pictures
+    std::vector<std::shared_ptr<Pic>> evicted;
+    if (old)
+    {
+        for (const auto &o : *old)
+        {
+            if (o->lo < q->hi && q->lo < o->hi) evicted.push_back(o);
+            else next->push_back(o);
+        }
+    }
     next->push_back(q);
     b->pics.store(next, std::memory_order_release);
     if (old) retire(b, old);
+    for (const auto &o : evicted) releasePic(b, o.get());
     b->stat[5] += 1;
     return 0;
 }
