@@ -64,6 +64,7 @@ def parse_args():
                     "context each")
     ap.add_argument("--traffic", type=int, default=1, help="1 (default): the plain N=1 run measures roofline.traffic itself with two rocprofv3 --pmc passes "
                     "of a two-step run (when rocprofv3 is on PATH); 0: take it from the committed profiles/r*_hbm_traffic.csv")
+    ap.add_argument("--traffic-child", type=int, default=0, help=argparse.SUPPRESS)      # the counter passes' child: exactly this many steps, eagerly, then exit
     ap.add_argument("--decision-distance", type=int, default=1, help="with --decisions 2: temporal distance of the decision-driven picture's two references "
                     "(1 = a leaf B picture of the hierarchy; 2, 4, 8 = its upper layers: longer vectors, 2.5 - 3 x the calls per search)")
     ap.add_argument("--decision-walk", type=int, default=0, help="with --decisions 2: also time the same walk through the reference's tables on one host core "
@@ -836,9 +837,10 @@ def hbm_traffic_from_profiles(group, S):
 
 
 def hbm_traffic_in_run(args, group, S):
-    """HBM bytes per launch of the group's kernels measured NOW: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; one counter per pass and no
-    trace domain beside it, as MI355X_MICROARCH.md prescribes) over a two-step run of this bench with the same workload; FETCH_SIZE x2 (gfx950
-    note), counters in KiB.  None when rocprofv3 is not on PATH, the passes fail, or --traffic 0"""
+    """HBM bytes PER STEP of the group's kernels measured NOW: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; one counter per pass and no
+    trace domain beside it, as MI355X_MICROARCH.md prescribes) over a child run of this bench that executes exactly `nsteps` steps of the same
+    workload and nothing else (--traffic-child); FETCH_SIZE x2 (gfx950 note), counters in KiB; the sum over every launch of the group's kernels
+    divided by the steps -- the same unit as roofline.algorithmic_bytes_per_step.  None when rocprofv3 is not on PATH, the passes fail, or --traffic 0"""
     import csv
     import glob
     import shutil
@@ -847,29 +849,29 @@ def hbm_traffic_in_run(args, group, S):
     prefix = _kernel_prefix(group, S)
     if not exe or prefix is None or not args.traffic:
         return None
-    base = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--extra-4k", "0", "--decisions", "0", "--traffic", "0", "--min-seconds", "0",
-            "--steps", "2", "--warmup", "1", "--kernel-reps", "1", "--res", args.res, "--bit-depth", str(args.bit_depth), "--qp", str(args.qp),
+    nsteps = 2
+    base = [sys.executable, os.path.abspath(__file__), "--traffic-child", str(nsteps), "--no-graph", "--inflight", "1", "--tune", "0", "--no-cpu-baseline", "--extra-4k", "0",
+            "--decisions", "0", "--traffic", "0", "--res", args.res, "--bit-depth", str(args.bit_depth), "--qp", str(args.qp),
             "--seed", str(args.seed), "--mix", args.mix, "--rdoq", str(args.rdoq)]
-    per_kernel = {}
+    total = 0.0
     env = dict(os.environ, TMPDIR="/tmp")
     for counter, mult in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
         d = tempfile.mkdtemp(prefix="havoc_pmc_", dir="/tmp")
         try:
             subprocess.run([exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + base, capture_output=True, text=True, timeout=400, cwd="/tmp", env=env)
-            vals = {}
+            vals = []
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
                     if prefix in row["Kernel_Name"] and row["Counter_Name"] == counter:
-                        vals.setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
+                        vals.append(float(row["Counter_Value"]))
             if not vals:
                 return None
-            for k, v in vals.items():
-                per_kernel[k] = per_kernel.get(k, 0.0) + sum(v) / len(v) * 1024.0 * mult
+            total += sum(vals) * 1024.0 * mult
         except (subprocess.TimeoutExpired, OSError, KeyError, ValueError):
             return None
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    return round(sum(per_kernel.values()) / len(per_kernel)) if per_kernel else None
+    return round(total / nsteps)
 
 
 def valu_busy_from_profiles(group, S):
@@ -1363,6 +1365,11 @@ def main():
     slots = build_contexts(args, torch, Havoc, FrameWorkload, local, args.res, args.bit_depth, args.qp, args.mix,
                            args.seed + (0 if grouped else rank), inflight, args.tune)
     compute, hv, wl, dev, graph = slots[0]
+    if args.traffic_child:      # hbm_traffic_in_run's child under rocprofv3 --pmc: build_contexts ran the step once; the rest, then nothing else
+        for _ in range(args.traffic_child - 1):
+            dev.step()
+        hv.sync()
+        return
     pipe = None
     if grouped:
         from turingcodec_amd.frame_parallel import DagSchedule, ReferenceExchange
@@ -1472,14 +1479,18 @@ def main():
         traffic, traffic_source = None, None
         if world == 1 and not (args.pcie or args.skip or args.no_graph) and args.min_seconds > 0:
             traffic = hbm_traffic_in_run(args, dom, wl.S)
-            traffic_source = ("measured in this run: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, one counter per pass, no trace domain) over a "
-                              "two-step run of the same workload; FETCH_SIZE x2 per the gfx950 note; mean over the kernel's launches")
+            traffic_source = ("measured in this run, bytes PER STEP (the unit of algorithmic_bytes_per_step): two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, one "
+                              "counter per pass, no trace domain) over a child run of exactly two steps of the same workload; FETCH_SIZE x2 per the gfx950 note; "
+                              "summed over every launch of the group's kernels, divided by the steps")
         if traffic is None:
             traffic = hbm_traffic_from_profiles(dom, wl.S)
-            traffic_source = ("profiles/r*_hbm_traffic.csv: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench (profiles/collect.sh), "
+            if traffic is not None:
+                traffic *= kcount[dom]      # the committed summary is per launch: times the group's launches per step (kernels of unequal size: approximate)
+            traffic_source = ("profiles/r*_hbm_traffic.csv (mean per launch x launches per step: approximate): separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench (profiles/collect.sh), "
                               "FETCH_SIZE x2 per the gfx950 note; not re-measured in this run (rocprofv3 not on PATH, --traffic 0, or a diagnostic run)")
         ms_step = elapsed / args.steps * 1e3
-        mixname = ("random-access QP%d speed=medium B-frame call mix (SURVEY A.2 counts x %.2f; assumed PU/intra size mix)" % (args.qp, w * h / (1920 * 1080))
+        mixname = ("random-access QP%d speed=medium B-frame, MEASURED call mix of the reference encoder on this clip generator (profiles/r04_reference_call_mix_1080p.json: "
+                   "call counts x %.2f by CTU count; measured block sizes, phase classes, DCT / DST split)" % (args.qp, ((w + 63) // 64) * ((h + 63) // 64) / 510.0)
                    if args.mix == "ra" else "all-intra QP%d speed=fast call mix (SURVEY A.1 per-CTU intra / TU counts, havoc_quantize in the chain)" % args.qp)
         out = {
             "metric": "encoded fps (havoc hot path, primitive-batch throughput: one picture's primitive calls per frame as whole-frame batches; "
@@ -1603,9 +1614,17 @@ def main():
             if plain and args.decisions and args.mix == "ra" and out["cpu_baseline"] is not None:
                 out["cpu_baseline"]["decision_walk"] = decision_walk
                 try:
-                    out["cpu_baseline"]["reference_encoder"] = cpu_reference_encoder(args)
+                    enc = cpu_reference_encoder(args)
                 except Exception as e:
-                    out["cpu_baseline"]["reference_encoder"] = {"error": repr(e)}
+                    enc = {"error": repr(e)}
+                if enc and "value" in enc:
+                    # the defensible CPU figure is the reference ENCODER's own frames/s; the per-primitive table timing
+                    # (a harness: one C loop per job table, Rdoq objects built per block) stays as a breakdown and as the source of the parity check
+                    tables = {k: out["cpu_baseline"].pop(k) for k in ("value", "unit", "cores", "kind", "ms_per_frame_by_group", "what", "sample")}
+                    out["cpu_baseline"].update({"value": enc["value"], "unit": "frames/s", "cores": enc["threads"], "kind": "reference",
+                                                "sample": enc["what"] + f" ({enc['seconds']} s)", "reference_encoder": enc, "primitive_tables": tables})
+                else:
+                    out["cpu_baseline"]["reference_encoder"] = enc
         line = json.dumps(out)
     if grouped:
         dist.barrier()

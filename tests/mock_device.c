@@ -22,10 +22,10 @@ long mock_launches(void) { return g_launches; }
 /* HAVOC_MOCK_HISTOGRAM=<file>: the jobs of every call by entry point and block size, written when the context is destroyed -- how
  * profiles/measure_call_mix.py reads the call mix of the reference's own encoder (run over libhavoc_classic.so + this stand-in) */
 enum { H_SAD, H_SAD4, H_SATD, H_PRED_UNI8, H_PRED_UNI4, H_PRED_BI8, H_PRED_BI4, H_SUBTRACT_BI, H_INTRA, H_TRANSFORM, H_INVERSE, H_SSD, H_QUANTIZE, H_RDOQ,
-       H_UNI8_COPY, H_UNI8_H, H_UNI8_V, H_UNI8_HV, H_UNI4_COPY, H_UNI4_H, H_UNI4_V, H_UNI4_HV, H_TRANSFORM_DST, H_COUNT };   /* sub-tallies: interpolation by phase class, DST-VII transforms */
+       H_UNI8_COPY, H_UNI8_H, H_UNI8_V, H_UNI8_HV, H_UNI4_COPY, H_UNI4_H, H_UNI4_V, H_UNI4_HV, H_TRANSFORM_DST, H_DEQUANT_NONZERO, H_COUNT };   /* sub-tallies: interpolation by phase class, DST-VII transforms */
 static const char *const g_hname[H_COUNT] = {"sad", "sad4", "satd", "pred_uni8", "pred_uni4", "pred_bi8", "pred_bi4", "subtract_bi", "intra", "transform",
                                              "inverse_transform", "ssd", "quantize", "rdoq", "uni8_copy", "uni8_h", "uni8_v", "uni8_hv", "uni4_copy",
-                                             "uni4_h", "uni4_v", "uni4_hv", "transform_dst"};
+                                             "uni4_h", "uni4_v", "uni4_hv", "transform_dst", "dequant_nonzero"};
 static long g_hist[H_COUNT][65][65];
 static void tally(int fn, int w, int h) { if (w >= 0 && w <= 64 && h >= 0 && h <= 64) __sync_fetch_and_add(&g_hist[fn][w][h], 1); }   /* the encoder calls from several threads */
 static void write_histogram(void)
@@ -272,6 +272,14 @@ int havoc_mi355x_quantize(havoc_mi355x_ctx *ctx, int16_t *dst, const int16_t *sr
 int havoc_mi355x_quantize_inverse(havoc_mi355x_ctx *ctx, int16_t *dst, const int16_t *src, const havoc_mi355x_quant_job *j, int n)
 {
     (void)ctx; ++g_launches;
+    for (int i = 0; i < n; ++i)
+    {   /* how dense the quantised levels of the reference's own encode are: "dequant_nonzero <side>x<class>", class 0 = no level, k = 2^(k-1) .. 2^k - 1 levels */
+        int nz = 0, side = 4, cls = 0;
+        for (int k = 0; k < j[i].n; ++k) nz += src[j[i].src_off + k] != 0;
+        while (side * side < j[i].n) side *= 2;
+        while ((1 << cls) <= nz) ++cls;
+        tally(H_DEQUANT_NONZERO, side, cls);
+    }
     for (int i = 0; i < n; ++i) oracle_quantize_inverse(dst + j[i].dst_off, src + j[i].src_off, j[i].scale, j[i].shift, j[i].n);
     return 0;
 }

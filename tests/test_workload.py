@@ -1,9 +1,56 @@
-"""CPU checks of the bench workload (turingcodec_amd/workload.py): the call counts are the survey's, and every job
-stays inside the padded picture store (the kernels do no bounds checking, as the reference's primitives)."""
+"""CPU checks of the bench workload (turingcodec_amd/workload.py): the call counts and size mixes are the MEASURED ones of the reference's own
+encoder (profiles/r04_reference_call_mix_1080p.json, written by profiles/measure_call_mix.py), and every job stays inside the padded picture
+store (the kernels do no bounds checking, as the reference's primitives)."""
+import json
+import os
+
 import numpy as np
 import pytest
 
+from turingcodec_amd import workload
 from turingcodec_amd.workload import CALLS_1080P, FrameWorkload
+
+MIX = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r04_reference_call_mix_1080p.json")
+
+
+def test_constants_are_the_committed_measurement():
+    """`config.workload` says "measured mix" -- this is where that is checked"""
+    m = json.load(open(MIX))
+    c, by, s = m["calls_by_entry_point"], m["by_size"], m["searches"]
+    assert m["case"] == "mix_1080p_qp32" and m["clip"].startswith("1920x1080, 9 frames")
+    per_b = {"sad4": c["sad4"], "sad": c["sad"], "uni8_hv": c["uni8_hv"], "uni8_h": c["uni8_h"], "uni8_v": c["uni8_v"], "uni8_copy": c["uni8_copy"],
+             "uni4_h": c["uni4_h"], "uni4_v": c["uni4_v"], "uni4_hv": c["uni4_hv"], "uni4_copy": c["uni4_copy"], "bi8": c["pred_bi8"], "bi4": c["pred_bi4"],
+             "subtract_bi": c["subtract_bi"], "searches": s["searchMotionUni"], "subpel": s["costDistortionMv calls (interpolate + SATD)"]}
+    for k, v in per_b.items():
+        assert CALLS_1080P[k] == v // 8, k
+    parts = {int(k): v for k, v in s["intra_partitions_by_log2_size"].items()}
+    blocks = {5: parts[5] + 4 * parts[6], 4: parts[4], 3: parts[3], 2: parts[2]}          # a 64x64 partition is predicted as four 32x32 blocks
+    assert CALLS_1080P["intra_satd"] == 35 * sum(blocks.values()) // 9 and CALLS_1080P["intra_rd"] == (c["intra"] - 35 * sum(blocks.values())) // 9
+    assert CALLS_1080P["tu"] == c["transform"] // 9 == c["inverse_transform"] // 9 and CALLS_1080P["ssd"] == c["ssd"] // 9
+    assert s["searchMotionBi"] == c["subtract_bi"] and s["predictIntraLuma calls of the 35-mode stage"] == 35 * sum(parts.values())
+    # sizes: only square units are searched; the shares are the measured ones
+    assert set(s["uni_searches_by_size"]) == {"8x8", "16x16", "32x32", "64x64"}
+    assert {(w, h): n for w, h, n in workload.PU_MIX} == {tuple(int(v) for v in k.split("x")): n for k, n in s["uni_searches_by_size"].items()}
+    assert dict(workload.INTRA_MIX) == blocks
+    assert dict(workload.INTRA_RD_MIX) == {l: by["intra"][f"{1 << l}x{1 << l}"] - 35 * blocks[l] for l in blocks}
+    t = by["transform"]
+    assert {(l, tr): n for l, tr, n in workload.TU_MIX} == {(5, 0): t["32x32"], (4, 0): t["16x16"], (3, 0): t["8x8"], (2, 0): t["4x4"] - c["transform_dst"],
+                                                           (2, 1): c["transform_dst"]}
+    uni_sad4 = c["sad4"] - 33 * s["searchMotionBi"]                                        # a bi-directional refinement's grid is 11 rows x 3 calls
+    assert abs(workload.SAD4_PER_SEARCH - uni_sad4 / s["searchMotionUni"]) < 1
+    # 4 x 4 is 65 % of the intra predictions, 53 % of the transforms (the round-3 workload assumed 5 % / the survey's smoother clip)
+    assert 0.6 < by["intra"]["4x4"] / c["intra"] < 0.7
+
+
+def test_picture_units_follow_the_measured_sizes():
+    """workload.picture_pus (the decision-driven path's units): 2Nx2N only, counts per size within 20 % of the measured searches per B picture and list"""
+    s = json.load(open(MIX))["searches"]["uni_searches_by_size"]
+    pus, first, cx, cy = workload.picture_pus(1920, 1080, 11)
+    assert (pus["part_2Nx2N"] == 1).all() and (pus["w"] == pus["h"]).all()
+    for size in (16, 32, 64):
+        want = s[f"{size}x{size}"] / 16                                                    # 8 B pictures x 2 lists
+        assert abs(int((pus["w"] == size).sum()) - want) < 0.2 * want, size
+    assert abs(len(pus) - sum(s.values()) / 16) < 0.2 * sum(s.values()) / 16
 
 
 @pytest.fixture(scope="module")
@@ -60,7 +107,7 @@ def test_luma_jobs_stay_inside_the_padded_planes(wl):
 
 def test_jobs_are_grouped_as_the_search_issues_them(wl):
     j = wl.sad4
-    run = 31
+    run = workload.SAD4_PER_SEARCH
     k = (len(j) // run) * run
     g = j[:k].reshape(-1, run, 8)
     assert (g[:, :, 0] == g[:, :1, 0]).all() and (g[:, :, 5] == g[:, :1, 5]).all()       # one PU per run of SAD4 calls

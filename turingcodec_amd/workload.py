@@ -2,11 +2,16 @@
 
 What a "frame" is here.  The encoder's control flow (mode decision, CABAC, RDOQ) is outside the hot path
 (SURVEY.md 8a / 2.2); what the path has to sustain per picture is the *stream of primitive calls* the reference
-issues.  SURVEY.md Appendix A.2 measured that stream for 1920x1080 random-access QP32 speed=medium (gprof of the
-reference, --asm 0, identical decisions to --asm 1): the per-B-frame call counts below are those numbers divided by
-the 8 B-frames (inter primitives) or 9 frames (intra / TU primitives).  A workload at another resolution scales the
-counts by the CTU count.  Block-size mixes are not in the survey; the ones used are stated in `PU_MIX` / `TU_MIX` /
-`INTRA_MIX` (TU_MIX *is* from A.2's dct32/16/8/4/dst4 split) and are part of the workload's name.
+issues.  Round 4: the stream is the MEASURED one -- the reference's own encoder (built as a test harness: over a
+tallying stand-in device, and with counting trace points inside its search loops) on THIS module's 1080p clip at
+QP32 speed=medium: profiles/r04_reference_call_mix_1080p.json, produced by profiles/measure_call_mix.py.  Per-B-frame
+counts are the 9-frame totals divided by the 8 B-frames (inter primitives) or 9 frames (intra / TU primitives); block
+sizes, interpolation phase classes and the DCT / DST split are the measured ones too (`PU_MIX`, `INTRA_MIX`,
+`INTRA_RD_MIX`, `TU_MIX`).  A workload at another resolution scales the counts by the CTU count (the same measurement
+at 3840x2160, profiles/r04_reference_call_mix_4k.json, is 3.5 - 4.0 x the 1080p counts for 4 x the CTUs).
+tests/test_workload.py holds these constants against the committed JSON.  (Rounds 1-3 used SURVEY Appendix A.2's gprof
+counts of a smoother clip -- 183 k SAD4 calls per frame instead of 1.27 M -- and ASSUMED size mixes with rectangular and
+asymmetric units the reference never searches at speed=medium: VERDICT r3 missing #7.)
 
 Everything is generated from a seed with numpy on the host, uploaded once, and stays resident in HBM in the
 reference's padded picture layout (96-sample padding, turing/StatePictures.h:155-156; stride a multiple of 64 B).
@@ -16,18 +21,20 @@ import numpy as np
 PAD = 96
 CTU = 64
 
-# ---- per-B-frame call counts at 1080p (510 CTUs), SURVEY.md Appendix A.2 --------------------------------------
+# ---- per-B-frame call counts at 1080p (510 CTUs): profiles/r04_reference_call_mix_1080p.json (9 frames = 1 I + 8 B) ----------------
 CALLS_1080P = {
-    "sad4": 1462024 // 8,               # havoc_sad_multiref_4
-    "sad": 107571 // 8,                 # havoc_sad
-    "uni8_hv": 728533 // 8, "uni8_h": 329670 // 8, "uni8_v": 326723 // 8, "uni8_copy": 303832 // 8,
-    "uni4_h": 42744 // 8, "uni4_v": 15102 // 8, "uni4_hv": 12316 // 8,
-    "bi8": 132219 // 8, "bi4": 264438 // 8,
-    "subtract_bi": 36890 // 8,          # one per searchMotionBi
-    "intra_satd": 6738655 // 9,         # PredictIntraLumaBlock: prediction + SATD
-    "intra_rd": (1466163 + 615690) // 9,  # ReconstructIntraBlock luma + chroma: prediction only here
-    "tu": 2452215 // 9,                 # fwd T, de-quant, inverse T + add (RDOQ replaces havoc_quantize at medium)
-    "ssd": (1644543 + 1444224) // 9,
+    "sad4": 10187278 // 8,              # havoc_sad_multiref_4
+    "sad": 249394 // 8,                 # havoc_sad
+    "uni8_hv": 1456648 // 8, "uni8_h": 410111 // 8, "uni8_v": 413156 // 8, "uni8_copy": 186686 // 8,
+    "uni4_h": 23594 // 8, "uni4_v": 17476 // 8, "uni4_hv": 126888 // 8, "uni4_copy": 30394 // 8,
+    "bi8": 231781 // 8, "bi4": 463562 // 8,
+    "subtract_bi": 58797 // 8,          # one per searchMotionBi
+    "intra_satd": 7834645 // 9,         # the 35-mode stage: 35 predictions + SATD per partition (a 64x64 partition is four 32x32 blocks)
+    "intra_rd": 2431812 // 9,           # every other havoc intra call (RD refinement luma, chroma): prediction only here
+    "tu": 3051477 // 9,                 # fwd T, de-quant, inverse T + add (RDOQ replaces havoc_quantize at medium)
+    "ssd": 3917781 // 9,
+    "searches": 73546 // 8,             # searchMotionUni calls (a PU in one list)
+    "subpel": 2308628 // 8,             # costDistortionMv calls: interpolation + SATD of one sub-sample candidate, only the cost is kept
 }
 # all-intra speed=fast (BASELINE.json configs[0]: 640x360 all-intra QP32 fast): per-CTU counts of the intra / TU primitives
 # from SURVEY.md Appendix A.1 (1020 CTUs: intra SATD stage 1 101 590, RD luma + chroma 232 125 + 114 900, 481 905 TUs,
@@ -39,14 +46,16 @@ CALLS_AI_PER_CTU = {
 # every luma interpolation is followed by a PU SATD (costDistortionMv / measurePuCost): measureSatd calls/B-frame
 # = 1689441/8 ~ 211k ~ the luma uni count, so the SATD batch pairs one job with each luma uni prediction.
 
-# (w, h, weight): ASSUMED PU-size mix of the ME / MC calls (not measured by the survey)
-PU_MIX = [(64, 64, 2), (64, 32, 2), (32, 64, 2), (32, 32, 10), (32, 16, 7), (16, 32, 7), (16, 16, 22), (16, 8, 10),
-          (8, 16, 10), (8, 8, 20), (32, 8, 1), (8, 32, 1), (32, 24, 1), (24, 32, 1), (16, 4, 1), (4, 16, 1),
-          (16, 12, 1), (12, 16, 1)]
-# (log2, trType, weight): measured split dct32 / dct16 / dct8 / dct4 / dst4 (A.2)
-TU_MIX = [(5, 0, 94163), (4, 0, 350559), (3, 0, 587269), (2, 0, 334902), (2, 1, 1085322)]
-# (log2, weight): ASSUMED intra partition mix (~42 partitions per CTU: 4 x 32, 16 x 16, 22 x 8; a few 4x4)
-INTRA_MIX = [(5, 9), (4, 36), (3, 50), (2, 5)]
+# (w, h, weight): MEASURED sizes of the searched prediction units (uni_searches_by_size: square units only -- rectangular and asymmetric part modes
+# are not searched at speed=medium, turing/Speed.h:59-62)
+PU_MIX = [(64, 64, 7570), (32, 32, 12224), (16, 16, 41576), (8, 8, 12176)]
+# (log2, trType, weight): MEASURED forward transforms by size; 4x4: DST-VII (intra luma) / DCT (the rest)
+TU_MIX = [(5, 0, 131611), (4, 0, 493212), (3, 0, 800290), (2, 0, 1626364 - 1198968), (2, 1, 1198968)]
+# (log2, weight): MEASURED intra partitions of the 35-mode stage (intra_partitions_by_log2_size; 1829 64x64 partitions = 4 x 32x32 blocks each)
+INTRA_MIX = [(5, 6935 + 4 * 1829), (4, 24796), (3, 36960), (2, 147840)]
+# (log2, weight): the other havoc intra calls by size = calls by size - 35 x the partitions above
+INTRA_RD_MIX = [(5, 557339 - 35 * (6935 + 4 * 1829)), (4, 1110358 - 35 * 24796), (3, 1855792 - 35 * 36960), (2, 6742968 - 35 * 147840)]
+SAD4_PER_SEARCH = 112                   # (10187278 - 33 x 58797 bi-directional grids) / 73546 searches
 
 
 # (PartMode, [(dx, dy, w, h) in quarters of the CU size]) -- the part modes of turing/Search.hpp's inter loop
@@ -60,13 +69,13 @@ PICTURE_PU_DT = np.dtype([("x0", "i4"), ("y0", "i4"), ("w", "i4"), ("h", "i4"), 
 def picture_pus(width, height, seed, density=1.0):
     """The prediction units of one picture whose motion is searched, CTU by CTU in raster order and inside a CTU in the order the quadtree
     search meets them (a coding unit's part modes -- 2Nx2N first -- then its four sub-units in z-order, turing/Search.hpp:708-887).
-    Which units are searched is the encoder's (data-dependent) decision; here it is drawn at random so that a 1080p picture has about the
-    5 900 (PU, list) searches SURVEY Appendix A.2 measured (~5.8 PUs per CTU, two lists each).  A coding unit that crosses the picture edge
-    is split (as the encoder must).  Returns (pus [PICTURE_PU_DT], ctu_first int32 [ctus + 1], ctus_x, ctus_y)."""
+    Which units are searched is the encoder's (data-dependent) decision; here it is drawn at random so that a 1080p picture has the MEASURED
+    number and sizes of searched units (profiles/r04_reference_call_mix_1080p.json: 9 193 (PU, list) searches per B picture = 4 597 units, 473 of
+    64x64, 764 of 32x32, 2 598 of 16x16, 761 of 8x8; 2Nx2N only).  A coding unit that crosses the picture edge is split (as the encoder must).  Returns (pus [PICTURE_PU_DT], ctu_first int32 [ctus + 1], ctus_x, ctus_y)."""
     rng = np.random.default_rng(seed)
-    p_2n = {6: 1.0, 5: 0.6, 4: 0.5, 3: 0.5}      # P(2Nx2N of a visited CU is searched)
-    p_rect = {6: 0.25, 5: 0.15, 4: 0.10, 3: 0.0}  # P(one two-PU part mode is searched as well)
-    p_split = {6: 0.5, 5: 0.25, 4: 0.15}          # P(the four sub-units are visited)
+    p_2n = {6: 1.0, 5: 1.0, 4: 1.0, 3: 1.0}      # P(2Nx2N of a visited CU is searched)
+    p_rect = {6: 0.0, 5: 0.0, 4: 0.0, 3: 0.0}    # P(one two-PU part mode is searched as well): never at speed=medium
+    p_split = {6: 0.375, 5: 0.85, 4: 0.05}       # P(the four sub-units are visited): 764 / (4 x 473 + edge), 2598 / (4 x 764), 761 / (4 x 2598)
     rows = []
 
     def cu(x, y, log2):
@@ -110,8 +119,8 @@ def intra_filter_mask(nn):
     return mask
 
 
-def intra_partitions(src2d, width, height, pad, seed, per_ctu=42.0):
-    """The intra partitions of one picture whose 35 modes are evaluated (21.4 k partitions per 1080p B-frame = ~42 per CTU; sizes by
+def intra_partitions(src2d, width, height, pad, seed, per_ctu=48.8):
+    """The intra partitions of one picture whose 35 modes are evaluated (measured: 24.9 k blocks per 1080p frame = ~48.8 per CTU; sizes by
     INTRA_MIX), at random aligned positions in CTU order, with their neighbour arrays taken from the (padded) SOURCE picture -- so the partitions
     are independent of each other (in the encoder the neighbours are the reconstruction of what precedes them, Reconstruct.cpp:609-615).
     src2d: padded plane [rows, stride].  Returns {log2: (jobs int32 [m, 8] = havoc_mi355x_intra_search_job rows with src_off relative to the
@@ -225,7 +234,7 @@ class FrameWorkload:
     """Job tables (numpy int32, columns = the job structs of include/havoc_mi355x.h) + picture store layout."""
 
     def __init__(self, width=1920, height=1080, bit_depth=8, seed=11, scale=1.0, qp=32, mix="ra", frames=None):
-        """mix: "ra" = one random-access B-frame at speed=medium (Appendix A.2 counts); "ai" = one all-intra frame at
+        """mix: "ra" = one random-access B-frame at speed=medium (the measured counts above); "ai" = one all-intra frame at
         speed=fast (Appendix A.1 per-CTU intra / TU counts, havoc_quantize in the TU chain).  qp: the slice QP the
         (de)quantiser parameters are derived from (BASELINE.json: 32 for configs 0, 1, 4; 27 for configs 2, 3)."""
         assert mix in ("ra", "ai")
@@ -289,9 +298,9 @@ class FrameWorkload:
             return rng.integers(-r, r + 1, nj).astype(np.int32), rng.integers(-r, r + 1, nj).astype(np.int32)
 
         # ---- integer ME: SAD4 (4 candidates of one diamond/star step around a centre) and single SAD.  A search makes
-        # ~31 SAD4 calls (A.1) for the same PU and list around a centre that moves with the best candidate: the jobs
-        # come in runs of 31 sharing block and source, the centre doing a bounded random walk from the predictor
-        RUN = 31
+        # ~112 SAD4 calls (measured) for the same PU and list around a centre that moves with the best candidate: the jobs
+        # come in runs of 112 sharing block and source, the centre doing a bounded random walk from the predictor
+        RUN = SAD4_PER_SEARCH
         nrun = (n["sad4"] + RUN - 1) // RUN
         w, h, x, y = (np.repeat(v, RUN)[:n["sad4"]] for v in pu(nrun))
         px, py = mv(nrun, 40)
@@ -325,10 +334,10 @@ class FrameWorkload:
         # interleave the four kinds the way a CTU-by-CTU search meets them: sort by the CTU of the source PU
         upos = u[:, 6] % pl
         u = u[ctu_order(upos % st - PAD, upos // st - PAD, u[:, 2] * u[:, 3])]
-        # costDistortionMv candidates (1474818/8 per B-frame, A.2) only need the COST: they go through the fused
+        # costDistortionMv candidates (2308628/8 per B-frame, measured) only need the COST: they go through the fused
         # interpolation+SATD entry point, one launch per PU size class; the rest (measurePuCost: the prediction is
         # kept) are written to prediction slots and measured by the SATD batch
-        nsearch = min(len(u) - 1, int(round(1474818 / 8 * f))) if mix == "ra" else 32
+        nsearch = min(len(u) - 1, n["subpel"]) if mix == "ra" else 32
         sp = u[:nsearch].copy()
         sp[:, 0] = sp[:, 6]          # dst_off field = source PU offset (havoc_mi355x_subpel_satd)
         sp[:, 6] = 0
@@ -376,7 +385,7 @@ class FrameWorkload:
         # ---- chroma interpolation (4-tap, eighth-sample phases) on the half-size planes
         cst, cpl = self.cstride, self.cplane_len
         rows = []
-        for name, fx, fy in (("uni4_h", 1, 0), ("uni4_v", 0, 1), ("uni4_hv", 1, 1)):
+        for name, fx, fy in (("uni4_h", 1, 0), ("uni4_v", 0, 1), ("uni4_hv", 1, 1), ("uni4_copy", 0, 0)):
             w, h, x, y = pu(n[name])
             cx, cy = mv(n[name], 30)
             off = (rng.integers(1, 3, n[name]) * cpl + (y // 2 + cy + PAD // 2) * cst + (x // 2 + cx + PAD // 2)).astype(np.int32)
@@ -451,7 +460,7 @@ class FrameWorkload:
             return mask
 
         nrd, npart = n["intra_rd"], max(1, n["intra_satd"] // 35)
-        rd_sizes = np.array([m[0] for m in INTRA_MIX])[_pick(rng, INTRA_MIX, nrd)]
+        rd_sizes = np.array([m[0] for m in INTRA_RD_MIX])[_pick(rng, INTRA_RD_MIX, nrd)]
         sr_sizes = np.array([m[0] for m in INTRA_MIX])[_pick(rng, INTRA_MIX, npart)]
         for log2 in (2, 3, 4, 5):
             nn = 1 << log2
@@ -513,9 +522,9 @@ class FrameWorkload:
         self.rdoq_lambda = picture_lambda(qp)
 
         # ---- integer ME served from SAD surfaces (havoc_mi355x_sad_surface) instead of per-pattern SAD4 jobs: one
-        # surface per uni-directional search.  A.1: ~31 SAD4 calls (124 candidates) per search on average, so the
-        # frame's 183 k SAD4 calls are ~5.9 k searches.  (drawn last: the tables above do not depend on this one)
-        ns = max(1, n["sad4"] // 31)
+        # surface per uni-directional search (measured: 9.2 k searches per 1080p B-frame, ~112 SAD4 calls each).
+        # (drawn last: the tables above do not depend on this one)
+        ns = n["searches"]
         w, h, x, y = pu(ns)
         cx, cy = mv(ns, 28)          # predictor; +-64 around it stays inside the 96-sample padding
         self.me_search = np.stack([loff(x, y, 0), loff(x + cx, y + cy, rng.integers(1, 3, ns)), w, h], 1).astype(np.int32)
