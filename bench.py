@@ -1274,26 +1274,47 @@ def decision_children(args):
     """the decision-driven path of --res / --qp and of 4K QP32, each in a process of its own (16 hardware queues: see the top of this file), run BEFORE
     this process touches the device so that nothing else holds queues or memory while they are measured"""
     paths, walk = {}, None
-    for dres, dqp, dist_, label in ((args.res, args.qp, 1, f"decision-driven path {args.res} {args.bit_depth}-bit QP{args.qp}"),
-                                    (args.res, args.qp, 4, f"decision-driven path {args.res} {args.bit_depth}-bit QP{args.qp}, references at temporal distance 4 "
-                                                          "(an upper layer of the hierarchy: longer vectors, three times the calls per search)"),
-                                    ("3840x2160", 32, 1, "decision-driven path 3840x2160 8-bit QP32 (BASELINE.json metric: 4K RA QP32)")):
-        if label.startswith("decision-driven path 3840") and args.res == "3840x2160":
-            continue
+    main_label = f"decision-driven path {args.res} {args.bit_depth}-bit QP{args.qp}"
+    jobs = [(args.res, args.qp, 1, main_label)]
+    jobs += [(args.res, args.qp, d, f"{main_label}, references at temporal distance {d} (an upper layer of the hierarchy: longer vectors, more calls per search)") for d in (2, 4, 8)]
+    if args.res != "3840x2160":
+        k4 = "decision-driven path 3840x2160 8-bit QP32 (BASELINE.json metric: 4K RA QP32)"
+        jobs += [("3840x2160", 32, 1, k4)] + [("3840x2160", 32, d, f"{k4}, references at temporal distance {d}") for d in (2, 4, 8)]
+    for dres, dqp, dist_, label in jobs:
         try:
-            want_walk = dres == args.res and dist_ == 1 and not args.no_cpu_baseline
+            # every timed decision-path figure carries its own comparison with the walk over the reference's tables (VERDICT r3 next #2): the whole
+            # picture, every search, through the x86-JIT tables on one core (a second or two even at 4K)
+            want_walk = not args.no_cpu_baseline
+            primary = dist_ == 1 and dres == args.res
             cmd = [sys.executable, os.path.abspath(__file__), "--decisions", "2", "--res", dres, "--bit-depth", str(args.bit_depth if dres == args.res else 8),
-                   "--qp", str(dqp), "--seed", str(args.seed), "--decision-pictures", str(max(1, args.decision_pictures) if dist_ == 1 else 8),
+                   "--qp", str(dqp), "--seed", str(args.seed), "--decision-pictures", str(max(1, args.decision_pictures) if primary else 8),
                    "--search-client", args.search_client, "--decision-distance", str(dist_), "--decision-walk", "1" if want_walk else "0"]
             child = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
             if child.returncode != 0:
                 raise RuntimeError(child.stderr[-600:])
             got = json.loads([l for l in child.stdout.splitlines() if l.startswith("{")][-1])
             paths[label] = got["decision_driven_path"]
-            if want_walk:
-                walk = got.get("decision_walk")
+            w_ = got.get("decision_walk")
+            if want_walk and w_:
+                paths[label]["parity_vs_reference"] = w_.get("parity_vs_reference", w_)
+                paths[label]["one_cpu_core_through_the_reference_tables_pictures_per_second"] = w_.get("pictures_per_second")
+                if primary:
+                    walk = w_
         except Exception as e:
             paths[label] = {"error": repr(e)}
+    # the 8-picture SOP of the hierarchy: four pictures at distance 1, two at 2, one at 4, one at 8 (turing/InputQueue.cpp:370-379) -- measured rates, 8 in flight
+    for res_key, base in ((args.res, main_label), ("3840x2160", "decision-driven path 3840x2160 8-bit QP32 (BASELINE.json metric: 4K RA QP32)")):
+        try:
+            def rate(d):
+                key = base if d == 1 else [k for k in paths if k.startswith(base + ",") and k.split("distance ")[1].split(" ")[0] == str(d)][0]
+                r = paths[key]
+                return r.get("pictures_in_flight_8", {}).get("value") or r["value"]
+            rates = {d: rate(d) for d in (1, 2, 4, 8)}
+            paths[base]["sop_weighted"] = {"value": round(8.0 / (4 / rates[1] + 2 / rates[2] + 1 / rates[4] + 1 / rates[8]), 2), "unit": "pictures/s",
+                                           "rates_by_reference_distance": rates,
+                                           "what": "harmonic mean over one SOP of 8 (4 x distance 1, 2 x distance 2, distance 4, distance 8), each rate measured with 8 pictures in flight"}
+        except Exception:
+            pass
     return {"paths": paths, "walk": walk}
 
 
@@ -1332,7 +1353,7 @@ def main():
         sys.exit(2)
     if args.decisions == 2:      # only the decision-driven path of --res / --qp, one line (also how the plain run measures it: see the top of this file)
         keep = {} if args.decision_walk else None
-        r = decision_path(args, Havoc, args.res, args.bit_depth, args.qp, max(1, args.decision_pictures), seconds=2.0 if not args.decision_walk else 1.5, keep=keep)
+        r = decision_path(args, Havoc, args.res, args.bit_depth, args.qp, max(1, args.decision_pictures), seconds=(1.0 if args.decision_pictures <= 8 else 1.5), keep=keep)
         line = {"metric": "DIAGNOSTIC (decision-driven path only) -- not the benchmark metric", "value": r["value"], "unit": r["unit"],
                 "config": {"workload": f"{args.res} {args.bit_depth}-bit QP{args.qp}"}, "decision_driven_path": r}
         if args.decision_walk:

@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--density", type=float, default=1.0)
     ap.add_argument("--repeat", type=int, default=2)
     ap.add_argument("--expected", choices=["ref", "oracle", "none"], default="ref")
+    ap.add_argument("--ref-mask", type=int, default=3, help="instruction sets of the reference's tables the expected walk runs through: 3 = its plain-C functions, "
+                    "-1 = everything the host supports (the x86 JIT code: same results, several times faster -- for the 4K / 8K pictures)")
     ap.add_argument("--distance", type=int, default=1, help="temporal distance of the two reference pictures")
     ap.add_argument("--speed", choices=["slow", "medium", "fast"], default="medium", help="turing/Speed.h: medium = early termination (MET), +-64 window, half + "
                     "quarter refinement; fast = also the small windows and no quarter-sample step; slow = no early termination (every search runs the star "
@@ -64,7 +66,7 @@ def main():
     expected = None
     if args.expected != "none":
         try:
-            ref = st.Client("ref", 3) if args.expected == "ref" else st.Client("oracle")
+            ref = st.Client("ref", args.ref_mask) if args.expected == "ref" else st.Client("oracle")
             report["expected_from"] = "reference tables (oracle/_ref)" if args.expected == "ref" else "CPU oracle"
         except (FileNotFoundError, OSError):
             ref = st.Client("oracle")

@@ -256,6 +256,25 @@ def test_picture_client_on_the_gpu_equals_the_reference_walk(res, bit_depth):
 
 @needs_ref
 @pytest.mark.gpu
+@pytest.mark.parametrize("res,bit_depth,qp", [("3840x2160", 8, 32), ("3840x2160", 10, 27), ("7680x4320", 8, 32)])
+def test_device_search_at_the_picture_sizes_of_the_baseline_configs(res, bit_depth, qp):
+    """the decision-driven path where BASELINE's numbers live -- 4K 8-bit QP32 (the metric), 4K Main10 QP27 (configs[3]), 8K
+    (configs[4]): every field of every uni-directional search, the motion field and every bi-directional refinement of the whole picture against the
+    one-call-at-a-time walk over the reference's tables (the whole picture, not a sample: the walk takes a second or two on one core)"""
+    r = _run_picture("real", "--res", res, "--bit-depth", str(bit_depth), "--qp", str(qp), "--threads", "16", "--repeat", "1", "--ref-mask", "-1", timeout=2400)
+    w, h = (int(v) for v in res.split("x"))
+    assert r["searches"] > 8 * (w // 64) * (h // 64) and "reference tables" in r["expected_from"]
+    _check_picture(r)
+    d = r["on_device"]
+    assert d["mismatches"] == 0 and d["field_equal"] and d["mismatches_vs_batch_client"] == 0 and d["launches"] == 1, d
+    d = r["on_device_with_bi"]
+    assert d["mismatches"] == 0 and d["uni_mismatches_vs_without_bi"] == 0 and d["field_equal"] and d["refinements"] > 0.9 * r["searches"], d
+    print(res, bit_depth, {"searches": r["searches"], "loop_calls": r["loop_calls"], "walk_seconds_one_core": r["expected_seconds"], "device_seconds": r["on_device"]["seconds"],
+                           "with_bi_seconds": r["on_device_with_bi"]["seconds"]})
+
+
+@needs_ref
+@pytest.mark.gpu
 @pytest.mark.parametrize("speed,bit_depth", [("fast", 8), ("slow", 8), ("slow", 10)])
 def test_device_search_at_other_speed_settings(speed, bit_depth):
     """the branches speed=medium rarely or never takes: no early termination (every search runs the star search, the raster refinement where the
