@@ -1,59 +1,8 @@
-// TEST INFRASTRUCTURE ONLY (see oracle/README.md).  Nothing under turingcodec_amd/ or include/ knows this file exists.
-//
-// Trace points for the reference encoder's own decision loops (VERDICT r3 "next" #1): oracle/Makefile target `trace` makes a TEMPORARY copy of
-// /root/reference/turing/Search.hpp (+ the two translation units that include it), inserts the one-line macro calls below at the places
-// oracle/trace_points.txt names (line number + a token that must be on that line: a changed reference fails the build, it never mis-inserts),
-// compiles the copy with `-include oracle/trace_hooks.h` and deletes it.  No reference text is stored in this repository; the macros only READ
-// encoder state, and tests/test_trace_pin.py first checks that the traced encoder still writes the committed reference stream.
-//
-// What is recorded, in call order per thread: for every searchMotionUni / searchMotionBi / searchIntraPartition of the encode
-//   * its inputs as the reference's code holds them (prediction unit, list, the two predictors, the rates of mvp_lX_flag in the CABAC state of
-//     that moment, mvPreviousInteger2Nx2N, lambda, picture order counts of the picture and of the reference picture),
-//   * every primitive call it makes (havoc_sad / havoc_sad_multiref positions and values, costDistortionMv positions and SATD values, the 35
-//     predictIntraLuma distortions),
-//   * what it decided (integer vector, refined vector, mvd, mvp flag, cost; the order in which intra modes go to RD refinement).
-// tests/trace_tools.py replays turingcodec_amd/search/decision.hpp on the same inputs and requires the same call sequence and decisions; the
-// `-m gpu` half runs the same searches through the device kernel.
+// TEST INFRASTRUCTURE ONLY: the trace points of turing/Search.hpp (see trace_common.h for what the trace is and how it is made).
 #pragma once
-#include <stdint.h>
-#include <string.h>
-
-extern "C" void havoc_trace_emit(int kind, int n, const int32_t *values);       // oracle/trace_sink.cpp: 64-byte records, one file, mutex
-
-enum
-{
-    HAVOC_TR_UNI_BEGIN = 1,    // poc, refPoc, refList, x0, y0, w, h, log2CbSize, cqtDepth, part2Nx2N, xCtb, yCtb, concurrentFrames, flags
-    HAVOC_TR_BEGIN2 = 2,       // mvp0.x, mvp0.y, mvp1.x, mvp1.y, prev.x, prev.y, rate0 lo, hi, rate1 lo, hi, reciprocalSqrtLambda (double bits) lo, hi, bitDepth, ctbSize
-    HAVOC_TR_SAD = 3,          // x, y (full-sample displacement), value
-    HAVOC_TR_SAD4 = 4,         // x0, y0, x1, y1, x2, y2, x3, y3, value0..3
-    HAVOC_TR_SATD = 5,         // mv.x, mv.y (quarter-sample), value
-    HAVOC_TR_UNI_INTEGER = 6,  // best.mv x, y, best.mvd x, y, mvpFlag, cost lo, hi
-    HAVOC_TR_UNI_SUBPEL = 7,   // mv x, y, mvd x, y   (after subPelRefinement)
-    HAVOC_TR_UNI_END = 8,      // mvd x, y, mvpFlag
-    HAVOC_TR_BI_BEGIN = 9,     // as UNI_BEGIN
-    HAVOC_TR_BI_MV = 10,       // mv(L0) x, y, mv(L1) x, y  (setPuDataMvpPredFlags: the two vectors the refinement starts from / predicts from)
-    HAVOC_TR_BI_END = 11,      // best.mv x, y, best.mvd x, y, mvpFlag, cost lo, hi
-    HAVOC_TR_INTRA_BEGIN = 12, // poc, x, y, log2PartitionSize, cand0, cand1, cand2, neighbourModes, (rateA - rateC) lo, hi, (rateB - rateC) lo, hi, lambda bits lo, hi
-    HAVOC_TR_INTRA_SATD = 13,  // mode, distortion, cost lo, hi
-    HAVOC_TR_INTRA_MAX = 14,   // nCandidatesIntraRefinement
-    HAVOC_TR_INTRA_PICK = 15,  // j, IntraPredModeY
-    HAVOC_TR_INTRA_SSD = 16,   // ssd of the candidate just reconstructed
-    HAVOC_TR_INTRA_END = 17,   // champion's IntraPredModeY
-};
+#include "trace_common.h"
 
 namespace havoc_trace {
-
-static inline void lohi(int32_t *out, int64_t v)
-{
-    out[0] = int32_t(uint32_t(uint64_t(v)));
-    out[1] = int32_t(uint32_t(uint64_t(v) >> 32));
-}
-static inline void dbl(int32_t *out, double d)
-{
-    int64_t bits;
-    memcpy(&bits, &d, 8);
-    lohi(out, bits);
-}
 
 // the inputs of one (prediction unit, list) motion search, read where searchMotionUni / searchMotionBi read them
 template <class H, class Mvdc>
@@ -174,8 +123,19 @@ static inline void candidate(int kind, const Candidate &c)
     } while (0)
 #define HAVOC_TRACE_INTRA_SSD()                                        \
     do {                                                               \
-        int32_t a_[1] = {int32_t(ssd)};                                \
-        havoc_trace_emit(HAVOC_TR_INTRA_SSD, 1, a_);                   \
+        int32_t a_[2] = {int32_t(ssd), int32_t(lambda.value)};         \
+        havoc_trace_emit(HAVOC_TR_INTRA_SSD, 2, a_);                   \
+    } while (0)
+#define HAVOC_TRACE_INTRA_RATE()                                                                     \
+    do {                                                                                             \
+        int32_t a_[2];                                                                               \
+        havoc_trace::lohi(a_, challenger->rate.value - originalCandidate->rate.value);               \
+        havoc_trace_emit(HAVOC_TR_INTRA_RATE, 2, a_);                                                \
+    } while (0)
+#define HAVOC_TRACE_INTRA_SWAP()                                       \
+    do {                                                               \
+        int32_t a_[1] = {int32_t(j)};                                  \
+        havoc_trace_emit(HAVOC_TR_INTRA_SWAP, 1, a_);                  \
     } while (0)
 #define HAVOC_TRACE_INTRA_END()                                                                      \
     do {                                                                                             \

@@ -347,6 +347,86 @@ int64_t client_bi_logged(int S, const void *src, intptr_t ss, const void *ref, c
     return log.count;
 }
 
+// ---- tu_decision.hpp on RECORDED numbers (tests/test_trace_pin.py): the reference encoder's own distortions and rates of the two transform-tree
+// candidates of an inter unit / of the refinement candidates of an intra partition go in, the decision must be the encoder's.
+// rqt rows (int64 [n][6]): root cbf of the split tree, its weighted ssd (ssd0 + 4 ssd1 + 4 ssd2), its rate (Q16), the unsplit block's weighted ssd,
+// its rate, reciprocalLambda (Q16).  out (int32 [n][2]): depth, tried_zero
+int client_rqt_decide(const int64_t *rows, int n, int32_t *out)
+{
+    struct View
+    {
+        const int64_t *r;
+        havoc_tu_outcome evaluate(int x0, int y0, int, int depth)
+        {
+            havoc_tu_outcome o = havoc_tu_outcome();
+            if (depth == 1 && x0 == 0 && y0 == 0)
+            {   // the first block of the split tree carries the tree's totals (decideRqt sums the four)
+                o.cbf = int32_t(r[0]);
+                o.ssd = uint32_t(r[1]);
+            }
+            else if (depth == 0)
+            {
+                o.cbf = 1;
+                o.ssd = uint32_t(r[3]);
+            }
+            return o;
+        }
+    };
+    struct Rate
+    {
+        const int64_t *r;
+        Cost operator()(int depth, const havoc_tu_outcome *, int) const { return depth ? r[2] : r[4]; }
+    };
+    for (int i = 0; i < n; ++i)
+    {
+        const int64_t *r = rows + 6 * i;
+        View view{r};
+        havoc_rqt_cu cu = {0, 0, 5, 0};
+        Lambda rl;
+        rl.value = int32_t(r[5]);
+        const havoc_rqt_result res = decideRqt(view, cu, rl, Rate{r});
+        out[2 * i] = res.depth;
+        out[2 * i + 1] = res.tried_zero;
+    }
+    return 0;
+}
+
+// intra: per partition `count[i]` candidates in refinement order; cand rows (int64 [total][3]): mode, ssd, rate (Q16; -1 = the encoder did not measure it);
+// rl[i] = reciprocalLambda (Q16).  out (int32 [n][2]): champion's mode, its index in the order
+int client_intra_rd_decide(const int64_t *cand, const int32_t *count, const int32_t *rl, int n, int32_t *out)
+{
+    struct View
+    {
+        const int64_t *c;
+        havoc_tu_outcome evaluate(int, int j)
+        {
+            havoc_tu_outcome o = havoc_tu_outcome();
+            o.ssd = uint32_t(c[3 * j + 1]);
+            return o;
+        }
+    };
+    struct Rate
+    {
+        const int64_t *c;
+        Cost operator()(int, int j, const havoc_tu_outcome &) const { return c[3 * j + 2] < 0 ? kCostMax : Cost(c[3 * j + 2]); }
+    };
+    int64_t at = 0;
+    for (int i = 0; i < n; ++i)
+    {
+        havoc_search_intra_result order = havoc_search_intra_result();
+        order.count = count[i];
+        for (int j = 0; j < count[i]; ++j) order.order[j] = int32_t(cand[3 * (at + j)]);
+        View view{cand + 3 * at};
+        Lambda l;
+        l.value = rl[i];
+        const havoc_intra_rd_result r = decideIntraRd(view, order, l, Rate{cand + 3 * at});
+        out[2 * i] = r.mode;
+        out[2 * i + 1] = r.index;
+        at += count[i];
+    }
+    return 0;
+}
+
 int client_intra35(int S, int bitDepth, int log2, const void *src, intptr_t ss, const void *nb, const int32_t *jobs, int n, int32_t *satd35)
 {
     if (!g_open) return -1;

@@ -94,6 +94,8 @@ class Client:
         L.client_uni_logged.restype = C.c_int64
         L.client_bi_logged.argtypes = [i, vp, ip, vp, vp, ip, C.POINTER(Params), vp, vp, i, i, vp, vp, C.c_int64, vp]
         L.client_bi_logged.restype = C.c_int64
+        L.client_rqt_decide.argtypes = [vp, i, vp]
+        L.client_intra_rd_decide.argtypes = [vp, vp, vp, i, vp]
         L.client_intra_order.argtypes = [vp, C.c_double, vp, i, vp]
         L.client_intra35.argtypes = [i, i, i, vp, ip, vp, vp, i, vp]
         L.client_picture_uni.argtypes = [i, vp, ip, vp, vp, ip, C.POINTER(Params), vp, vp, i, i, vp, vp, vp, vp]
@@ -139,6 +141,20 @@ class Client:
                                     first.ctypes.data)
         assert 0 <= n <= capacity, (n, capacity)
         return out, rows[:n], first
+
+    def rqt_decide(self, rows):
+        """tu_decision.hpp: decideRqt on recorded (cbf, weighted ssd, rate) of the split tree and (ssd, rate) of the unsplit block: int32 [n, 2] = depth, tried_zero"""
+        rows = np.ascontiguousarray(rows, np.int64)
+        out = np.zeros((len(rows), 2), np.int32)
+        assert self.L.client_rqt_decide(rows.ctypes.data, len(rows), out.ctypes.data) == 0
+        return out
+
+    def intra_rd_decide(self, cand, count, rl):
+        """tu_decision.hpp: decideIntraRd on recorded (mode, ssd, rate or -1) per candidate: int32 [n, 2] = champion's mode, its index"""
+        cand, count, rl = np.ascontiguousarray(cand, np.int64), np.ascontiguousarray(count, np.int32), np.ascontiguousarray(rl, np.int32)
+        out = np.zeros((len(count), 2), np.int32)
+        assert self.L.client_intra_rd_decide(cand.ctypes.data, count.ctypes.data, rl.ctypes.data, len(count), out.ctypes.data) == 0
+        return out
 
     def picture_uni(self, params, src, ref0, ref1, stride, pad, pus, ctu_first, ctus_x, ctus_y, mvp_rate=(65536, 65536), bi=False):
         """a whole picture's searches in dependency order, one table call at a time (turingcodec_amd/search/picture_order.hpp):

@@ -123,7 +123,7 @@ def test_hooked_reference_encoder_on_the_mi355x(case, workdir):
     calls = s["served"] + s["one_job"]
     print(case, s, f"{dt:.1f} s, {dt / calls * 1e6:.2f} us per table call, {s['launches'] / et.CASES[case][2]:.0f} launches per frame")
     assert got == ref, f"{case}: the hooked encoder's stream on the MI355X differs from the reference encoder's"
-    assert s["served"] > s["one_job"] > 0, s
+    assert s["served"] > 0.3 * calls and s["one_job"] > 0 and s["surfaces"] > 0 and s["satd_batches"] > 0, s      # 1 I + 2 B pictures: intra / TU calls (not served) dominate
     _check_golden(case, got, workdir)
 
 

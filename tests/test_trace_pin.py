@@ -6,6 +6,8 @@ writes its inputs (prediction unit, predictors, CABAC rates of mvp_lX_flag, mvPr
 primitive call it makes with the returned value, and what it decided.  tests/trace_runner.py runs turingcodec_amd/search/decision.hpp -- the text that
 is compiled into the product's search kernels -- on those inputs and the encoder's own pictures:
 
+  (also: tu_decision.hpp's decideRqt / decideIntraRd on the encoder's own recorded distortions and RATES -- trace points in Reconstruct.cpp:1296-1428 and
+  Search.hpp:143-255 -- must choose the depth / the champion the encoder chose)
   -m "not gpu"  per call over the reference's havoc tables: the same CALL SEQUENCE (positions and values) and the same decisions, for every search of
                 the encode, medium / fast / slow, 8- and 10-bit, 1 and 4 encoder threads; + the launch-and-replay batch clients over the stand-in device;
   -m gpu        on the MI355X: the batch clients, and the loops inside the kernels (k_search_list, k_search_bi_list, k_intra_order).
@@ -37,6 +39,13 @@ def check_cpu(rep, min_searches):
     assert u["previous_2Nx2N_handovers_checked"] > u["searches"] // 2 and u["previous_2Nx2N_handovers_wrong"] == 0, u
     assert b["searches"] >= min_searches // 4 and b["mismatching_searches"] == 0 and b["mismatching_call_rows"] == 0, b
     assert i["partitions"] >= min_searches // 2 and i["mismatching"] == 0, i
+    # tu_decision.hpp on the encoder's own rates and distortions: the champion of every intra partition's RD refinement, every transform-tree decision
+    rd, q = rep["intra_rd_cpu"], rep["rqt_cpu"]
+    assert rd["partitions"] == i["partitions"] and rd["rates_measured_by_the_encoder"] > rd["partitions"] and rd["mismatching_champions"] == 0, rd
+    assert rd["champion_is_not_the_first_candidate"] > rd["partitions"] // 10, rd      # the decision is not trivial
+    assert q["mismatching"] == 0, q
+    if rep["case"] == "ra_slow_qp27":      # the residual quadtree is a speed=slow tool (turing/Speed.h: useRqt)
+        assert q["decisions_with_a_choice"] > 5000 and 0 < q["chose_split"] < q["decisions_with_a_choice"], q
 
 
 @needs_trace

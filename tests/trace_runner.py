@@ -124,6 +124,7 @@ def main():
     report["trace_records"] = int(len(records))
     src = tt.source_frames(args.case, internal)
     uni, bi, intra = tt.MotionTrace(records), tt.MotionTrace(records, bi=True), tt.IntraTrace(records)
+    rqt = tt.RqtTrace(records)
     del records
     ref_of = {}          # (poc, list) -> reference picture's poc, from the uni searches (a bi refinement follows the two uni searches of its PU)
     for poc, lst, rp in zip(uni.meta["poc"], uni.pus["ref_list"], uni.meta["ref_poc"]):
@@ -204,6 +205,16 @@ def main():
             np.any(out["costs"] != intra.costs[sel], axis=1)
         r["mismatching"] += int(bad.sum())
     report["intra_cpu"] = r
+
+    # ---- tu_decision.hpp on the encoder's own numbers (rates from its entropy estimator, distortions of three planes): the transform-tree decision
+    # (Reconstruct.cpp:1296-1428) and the champion of an intra partition's RD refinement (Search.hpp:143-255)
+    got = cpu.rqt_decide(rqt.rows) if len(rqt) else np.zeros((0, 2), np.int32)
+    report["rqt_cpu"] = {"decisions_with_a_choice": int(len(rqt)), "units_left_uncoded_without_one": int(rqt.uncoded), "mismatching": int((got[:, 0] != rqt.chosen).sum()),
+                         "chose_split": int((rqt.chosen == 1).sum())}
+    champ = cpu.intra_rd_decide(intra.candidates, intra.count, intra.reciprocal_lambda) if len(intra) else np.zeros((0, 2), np.int32)
+    report["intra_rd_cpu"] = {"partitions": int(len(intra)), "candidates": int(len(intra.candidates)), "rates_measured_by_the_encoder": int((intra.candidates[:, 2] >= 0).sum()),
+                              "mismatching_champions": int((champ[:, 0] != intra.champion).sum()),
+                              "champion_is_not_the_first_candidate": int((champ[:, 1] != 0).sum())}
 
     # ---- the product: batch clients (and, on the MI355X, the kernels that hold the loops) on the same inputs
     if args.device != "none":

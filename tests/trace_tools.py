@@ -24,7 +24,7 @@ TRACE_EXE = os.path.join(et.REFDIR, "turing_ref_trace")
 REC_DT = np.dtype([("thread", "u4"), ("kind", "u2"), ("n", "u2"), ("v", "i4", (14,))])
 assert REC_DT.itemsize == 64
 (UNI_BEGIN, BEGIN2, SAD, SAD4, SATD, UNI_INTEGER, UNI_SUBPEL, UNI_END, BI_BEGIN, BI_MV, BI_END, INTRA_BEGIN, INTRA_SATD, INTRA_MAX, INTRA_PICK, INTRA_SSD,
- INTRA_END) = range(1, 18)
+ INTRA_END, INTRA_RATE, INTRA_SWAP, RQT_ONE, RQT_ZERO, RQT_END) = range(1, 23)
 PAD = 96
 
 
@@ -194,6 +194,7 @@ class IntraTrace:
 
     def __init__(self, records):
         ctx, satd, costs, order, count, rsl, where, champion = [], [], [], [], [], [], [], []
+        cand, rl = [], []          # RD refinement: per candidate (mode, ssd, rate or -1 when the encoder did not measure it); reciprocalLambda (Q16) per partition
         for t in np.unique(records["thread"]):
             rec = records[records["thread"] == t]
             kind = rec["kind"].astype(np.int32)
@@ -220,6 +221,22 @@ class IntraTrace:
                 rsl.append(f64(a[12:13], a[13:14])[0])
                 where.append(a[0:4])
                 champion.append(seg[-1][0])
+                # the refinement loop's records per candidate: PICK, [nested searches of reconstructIntraLuma: none], SSD, [RATE], [SWAP]
+                pk = np.flatnonzero(seg_kind == INTRA_PICK)
+                rows = np.full((len(pk), 3), -1, np.int64)
+                lam = 0
+                for n_, at in enumerate(pk):
+                    end = pk[n_ + 1] if n_ + 1 < len(pk) else len(seg_kind) - 1
+                    kinds = seg_kind[at:end]
+                    rows[n_, 0] = seg[at][1]
+                    ss = np.flatnonzero(kinds == INTRA_SSD)
+                    assert len(ss) == 1
+                    rows[n_, 1], lam = seg[at + ss[0]][0], seg[at + ss[0]][1]
+                    rr = np.flatnonzero(kinds == INTRA_RATE)
+                    if len(rr):
+                        rows[n_, 2] = i64(seg[at + rr[0]][0:1], seg[at + rr[0]][1:2])[0]
+                cand.append(rows)
+                rl.append(lam)
         self.ctx = np.array(ctx, st.INTRA_CTX_DT) if ctx else np.zeros(0, st.INTRA_CTX_DT)
         self.satd = np.array(satd, np.int32).reshape(-1, 35)
         self.costs = np.array(costs, np.int64).reshape(-1, 35)
@@ -228,6 +245,46 @@ class IntraTrace:
         self.rsl = np.array(rsl, np.float64)
         self.where = np.array(where, np.int32).reshape(-1, 4)      # poc, x, y, log2 partition size
         self.champion = np.array(champion, np.int32)
+        self.candidates = np.concatenate(cand) if cand else np.zeros((0, 3), np.int64)
+        self.reciprocal_lambda = np.array(rl, np.int32)
 
     def __len__(self):
         return len(self.ctx)
+
+
+class RqtTrace:
+    """every residual-quadtree decision of reconstructInter (turing/Reconstruct.cpp:1296-1428) that had a choice: the two candidates' distortions (three planes)
+    and RATES as the encoder's entropy estimator gave them, and the depth it chose"""
+
+    def __init__(self, records):
+        rows, chosen, uncoded = [], [], 0
+        for t in np.unique(records["thread"]):
+            rec = records[records["thread"] == t]
+            kind = rec["kind"].astype(np.int32)
+            v = rec["v"]
+            end = np.flatnonzero(kind == RQT_END)
+            one = np.flatnonzero(kind == RQT_ONE)
+            # a decision = [RQT_ONE .. RQT_ZERO ..] RQT_END; the ONE / ZERO records of a decision directly precede its END (nothing of another
+            # decision in between: reconstructInter does not recurse into itself); units whose split tree was uncoded have only the END
+            last_one = {}
+            for i in one:
+                j = end[np.searchsorted(end, i)]
+                last_one[j] = i
+            for j in end:
+                depth, cbf_zero = int(v[j][0]), int(v[j][1])
+                if cbf_zero:
+                    assert j not in last_one
+                    uncoded += 1
+                    continue
+                i = last_one[j]
+                z = i + np.flatnonzero(kind[i:j] == RQT_ZERO)
+                assert len(z) == 1 and np.array_equal(v[i][0:3], v[j][2:5])
+                a, b = v[i], v[z[0]]
+                rows.append([a[9], int(a[3]) + 4 * int(a[4]) + 4 * int(a[5]), i64(a[6:7], a[7:8])[0], int(b[0]) + 4 * int(b[1]) + 4 * int(b[2]), i64(b[3:4], b[4:5])[0], a[8]])
+                chosen.append(depth)
+        self.rows = np.array(rows, np.int64).reshape(-1, 6)
+        self.chosen = np.array(chosen, np.int32)
+        self.uncoded = uncoded
+
+    def __len__(self):
+        return len(self.rows)

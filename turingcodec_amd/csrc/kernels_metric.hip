@@ -39,7 +39,7 @@ __device__ __forceinline__ int sad_group_sum(int v)
     return v;
 }
 
-template <int S, int WAYS, int CB>
+template <int S, int WAYS, int CB, int U = 4>
 __device__ __forceinline__ void sad_block(const char *src, long ssb, const char *const (&ref)[WAYS], long rsb, int rowBytes, int h,
                                           int lane, uint32_t (&acc)[WAYS])
 {
@@ -48,7 +48,7 @@ __device__ __forceinline__ void sad_block(const char *src, long ssb, const char 
     const int y0 = lane / cpr;
     const int xb = (lane - y0 * cpr) * CB;
     if (y0 >= rpi) return;              // lanes beyond rpi*cpr idle (cpr = 3, 6)
-#pragma unroll 4                        // several rows' loads in flight: the loop is latency-, not issue-bound
+#pragma unroll(U)                       // several rows' loads in flight: the loop is latency-, not issue-bound
     for (int y = y0; y < h; y += rpi)
     {
         const char *s = src + y * ssb + xb;
@@ -141,6 +141,173 @@ __global__ __launch_bounds__(256) void k_sad(const char *__restrict__ src, long 
         int t = sad_group_sum((int)acc[k]);   // the last lane of each group holds its job's total
         if (S == 2) t >>= 2;
         if (live && lane == kSadLanes - 1) out[job * WAYS + k] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// 4-way SAD with the candidates' COMMON WINDOW staged in LDS (round 4).  The four reference blocks of a havoc_sad_multiref call are the
+// positions of one pattern step (turing/Search.hpp:1447-1482: a diamond / star ring / raster line around one origin), so they overlap: for a
+// one-sample diamond the union of four 16x16 blocks is 18x18 samples.  k_sad<S, 4> reads each block with unaligned 16-byte loads, a row per
+// lane -- 4 x 2 cache-line accesses per row, and the measured call mix (1.27 M calls per 1080p picture) made it the step's longest kernel,
+// bound by the vector-memory address path (SQ counters: 23 % VALU busy, 18 loads per wavefront, no LDS).  Here a job's lane group (16 lanes,
+// as before) copies the bounding box of the four blocks into LDS ONCE, with 16-byte ALIGNED loads in strips of block rows, and the four
+// SADs read their (unaligned) rows from LDS.  A box that does not fit (far rings of the star: positions 16+ samples apart) takes the direct path.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kSadWinBytes = 1536;      // LDS per lane group and per byte of sample size: 24 KB (8-bit) / 48 KB (16-bit) per workgroup
+
+template <int S, int CB>
+__device__ __forceinline__ void sad4_window_strips(const char *src, long ssb, const char *a0, long rsb, const __attribute__((address_space(3))) char *buf_r,
+                                                   __attribute__((address_space(3))) char *buf_w, int pitch, int lead, const int (&ox)[4], const int (&oy)[4], int spready, int rowBytes, int h, int hs,
+                                                   int lane, uint32_t (&acc)[4])
+{
+    typedef const __attribute__((address_space(3))) u32x4u *LP16;
+    typedef const __attribute__((address_space(3))) u32x2u *LP8;
+    typedef const __attribute__((address_space(3))) u32u *LP4;
+    const int cprw = pitch >> 4;          // 16-byte chunks per window row (1 .. 16)
+    const int cpr = rowBytes / CB;        // chunks per block row
+    const int rpi = kSadLanes / cpr;      // block rows per iteration of the lane group
+    const int y0 = lane / cpr;
+    const int xb = (lane - y0 * cpr) * CB;
+    const FastDiv fw(cprw < 2 ? 2 : cprw);
+    for (int ys = 0; ys < h; ys += hs)
+    {
+        const int he = min(hs, h - ys), total = (he + spready) * cprw;
+        for (int idx = lane; idx < total; idx += kSadLanes)
+        {
+            const int r = cprw < 2 ? idx : fw.div(idx), c = idx - r * cprw;
+            const u32x4 v = ld16(a0 + (long)(ys + r) * rsb + c * 16);      // 16-byte aligned whenever the row stride is a multiple of 16 bytes (our planes: 64)
+            *reinterpret_cast<__attribute__((address_space(3))) u32x4 *>(buf_w + r * pitch + c * 16) = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (y0 < rpi)
+        {
+#pragma unroll 2
+            for (int y = y0; y < he; y += rpi)
+            {
+                const char *sp = src + (long)(ys + y) * ssb + xb;
+                if (CB == 16)
+                {
+                    const u32x4 a = ld16(sp);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                    {
+                        const u32x4u b = *reinterpret_cast<LP16>(buf_r + (y + oy[k]) * pitch + lead + ox[k] + xb);
+                        acc[k] = sad_dword<S>(a.x, b.x, acc[k]);
+                        acc[k] = sad_dword<S>(a.y, b.y, acc[k]);
+                        acc[k] = sad_dword<S>(a.z, b.z, acc[k]);
+                        acc[k] = sad_dword<S>(a.w, b.w, acc[k]);
+                    }
+                }
+                else if (CB == 8)
+                {
+                    const u32x2 a = ld8(sp);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                    {
+                        const u32x2u b = *reinterpret_cast<LP8>(buf_r + (y + oy[k]) * pitch + lead + ox[k] + xb);
+                        acc[k] = sad_dword<S>(a.x, b.x, acc[k]);
+                        acc[k] = sad_dword<S>(a.y, b.y, acc[k]);
+                    }
+                }
+                else
+                {
+                    const uint32_t a = ld4(sp);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[k] = sad_dword<S>(a, *reinterpret_cast<LP4>(buf_r + (y + oy[k]) * pitch + lead + ox[k] + xb), acc[k]);
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();      // the strip's reads are issued before the next strip's writes (one wavefront: LDS runs them in order)
+    }
+}
+
+template <int S>
+__global__ __launch_bounds__(256) void k_sad4w(const char *__restrict__ src, long stride_src, const char *__restrict__ ref, long stride_ref, float inv_stride_ref,
+                                               const int32_t *__restrict__ jobs, int njobs, int32_t *__restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) char lds[256 / kSadLanes][kSadWinBytes * S];
+    const int group = threadIdx.x / kSadLanes, lane = threadIdx.x & (kSadLanes - 1);
+    const int job = xcd_block(blockIdx.x, gridDim.x) * (256 / kSadLanes) + group;
+    const bool live = job < njobs;
+    const int32_t *j = jobs + (long)(live ? job : 0) * 8;   // havoc_mi355x_sad4_job
+    const int so = j[0], w = j[5], h = live ? j[6] : 0;
+    int ro[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ro[k] = j[1 + k];
+    const long ssb = stride_src * S, rsb = stride_ref * S;
+    const char *s = src + (long)so * S;
+    uint32_t acc[4] = {0, 0, 0, 0};
+    const int rowBytes = w * S;
+
+    // the candidates as displacements (dx, dy) from the first one: |dx| < stride / 2, so the split of a linear offset is unique
+    int dx[4] = {0, 0, 0, 0}, dy[4] = {0, 0, 0, 0};
+    const int st = (int)stride_ref, half = st >> 1;
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+    {
+        const int delta = ro[k] - ro[0];
+        int q = (int)floorf(((float)delta + (float)half) * inv_stride_ref);
+        int r = delta - q * st;
+        if (r < -half) { --q; r += st; }
+        if (r >= st - half) { ++q; r -= st; }
+        dx[k] = r; dy[k] = q;
+    }
+    const int mindx = min(min(dx[0], dx[1]), min(dx[2], dx[3])), maxdx = max(max(dx[0], dx[1]), max(dx[2], dx[3]));
+    const int mindy = min(min(dy[0], dy[1]), min(dy[2], dy[3])), maxdy = max(max(dy[0], dy[1]), max(dy[2], dy[3]));
+    const int spready = maxdy - mindy;
+    const long minoff = ((long)ro[0] + (long)mindy * st + mindx) * S;      // bytes from `ref` to the window's first sample
+    const int lead = (int)(reinterpret_cast<uintptr_t>(ref + minoff) & 15);
+    const int pitch = (lead + rowBytes + (maxdx - mindx) * S + 15) & ~15;
+    const int fit = pitch > 0 ? (kSadWinBytes * S) / pitch - spready : 0;      // block rows per strip
+    const bool chunked = (rowBytes & 3) == 0 && rowBytes <= 16 * kSadLanes;
+    const bool window = live && chunked && pitch <= 16 * kSadLanes && minoff >= 16 && fit >= min(h, 4) && fit >= 1;
+    if (window)
+    {
+        int ox[4], oy[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+        {
+            ox[k] = (dx[k] - mindx) * S;
+            oy[k] = dy[k] - mindy;
+        }
+        const char *a0 = ref + (minoff - lead);
+        const auto buf_r = (const __attribute__((address_space(3))) char *)(&lds[group][0]);
+        const auto buf_w = (__attribute__((address_space(3))) char *)(&lds[group][0]);
+        const int hs = min(fit, h);
+        if ((rowBytes & 15) == 0) sad4_window_strips<S, 16>(s, ssb, a0, rsb, buf_r, buf_w, pitch, lead, ox, oy, spready, rowBytes, h, hs, lane, acc);
+        else if ((rowBytes & 7) == 0) sad4_window_strips<S, 8>(s, ssb, a0, rsb, buf_r, buf_w, pitch, lead, ox, oy, spready, rowBytes, h, hs, lane, acc);
+        else sad4_window_strips<S, 4>(s, ssb, a0, rsb, buf_r, buf_w, pitch, lead, ox, oy, spready, rowBytes, h, hs, lane, acc);
+    }
+    else
+    {   // the direct path of k_sad<S, 4>: far-apart candidates, generic widths, a window at the very start of the buffer
+        typedef typename Sample<S>::T T;
+        const char *r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = ref + (long)ro[k] * S;
+        if ((rowBytes & 15) == 0 && rowBytes <= 16 * kSadLanes) sad_block<S, 4, 16, 1>(s, ssb, r, rsb, rowBytes, h, lane, acc);
+        else if ((rowBytes & 7) == 0 && rowBytes <= 8 * kSadLanes) sad_block<S, 4, 8, 1>(s, ssb, r, rsb, rowBytes, h, lane, acc);
+        else if ((rowBytes & 3) == 0 && rowBytes <= 4 * kSadLanes) sad_block<S, 4, 4, 1>(s, ssb, r, rsb, rowBytes, h, lane, acc);
+        else
+        {
+            const FastDiv fd(w);
+            for (int i = lane; i < w * h; i += kSadLanes)
+            {
+                const int y = fd.div(i), x = i - y * w;
+                const int a = reinterpret_cast<const T *>(s + y * ssb)[x];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[k] += abs(a - (int)reinterpret_cast<const T *>(r[k] + y * rsb)[x]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+    {
+        int t = sad_group_sum((int)acc[k]);
+        if (S == 2) t >>= 2;
+        if (live && lane == kSadLanes - 1) out[job * 4 + k] = t;
     }
 }
 
@@ -524,6 +691,12 @@ __global__ __launch_bounds__(256) void k_ssd_linear(const uint8_t *__restrict__ 
 // launchers (called from api.hip)
 // ---------------------------------------------------------------------------------------------------------
 
+static bool sad4_direct()
+{
+    static const bool v = [] { const char *e = getenv("HAVOC_SAD4_DIRECT"); return e && *e == '1'; }();
+    return v;
+}
+
 hipError_t launch_sad(hipStream_t st, int S, int ways, const void *src, long ss, const void *ref, long rs, const void *jobs, int n, int32_t *out)
 {
     if (n <= 0) return hipSuccess;
@@ -532,6 +705,13 @@ hipError_t launch_sad(hipStream_t st, int S, int ways, const void *src, long ss,
     const dim3 g((n + 256 / kSadLanes - 1) / (256 / kSadLanes)), b(256);
     if (S == 1 && ways == 1) hipLaunchKernelGGL((k_sad<1, 1>), g, b, 0, st, s, ss, r, rs, j, n, out);
     else if (S == 2 && ways == 1) hipLaunchKernelGGL((k_sad<2, 1>), g, b, 0, st, s, ss, r, rs, j, n, out);
+    else if (ways == 4 && rs >= 64 && rs < (1 << 22) && !sad4_direct())
+    {   // the candidates' common window through LDS (k_sad4w); HAVOC_SAD4_DIRECT=1 keeps round 1's kernel (both are parity-tested)
+        const float inv = 1.0f / (float)rs;
+        if (S == 1) hipLaunchKernelGGL((k_sad4w<1>), g, b, 0, st, s, ss, r, rs, inv, j, n, out);
+        else if (S == 2) hipLaunchKernelGGL((k_sad4w<2>), g, b, 0, st, s, ss, r, rs, inv, j, n, out);
+        else return hipErrorInvalidValue;
+    }
     else if (S == 1 && ways == 4) hipLaunchKernelGGL((k_sad<1, 4>), g, b, 0, st, s, ss, r, rs, j, n, out);
     else if (S == 2 && ways == 4) hipLaunchKernelGGL((k_sad<2, 4>), g, b, 0, st, s, ss, r, rs, j, n, out);
     else return hipErrorInvalidValue;

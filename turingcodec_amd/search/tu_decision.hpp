@@ -21,24 +21,34 @@ namespace havoc_search {
 // stand-in for EstimateRate<residual_coding>: Q16 bits of one transform block
 inline Cost tuRate(const havoc_tu_outcome &t) { return Cost(1 + (t.cbf ? 2 * t.nonzero + t.sum_abs : 0)) << 16; }
 
+// the rate of a candidate tree (Q16 bits) from its blocks' outcomes.  The product's is the stand-in; the trace-pin test (tests/test_trace_pin.py) puts the
+// reference encoder's OWN recorded rates here, so that the order, the short-cut, the Q16 arithmetic and the comparison below are exercised on real numbers
+struct StandInTreeRate
+{
+    Cost operator()(int /*depth*/, const havoc_tu_outcome *blocks, int n) const
+    {
+        Cost r = 0;
+        for (int i = 0; i < n; ++i) r += tuRate(blocks[i]);
+        return r;
+    }
+};
+
 // View: havoc_tu_outcome evaluate(int x0, int y0, int log2, int depth) = the chain of Reconstruct.cpp:740-860 for the block at (x0, y0)
-template <class View>
-havoc_rqt_result decideRqt(View &view, const havoc_rqt_cu &cu, Lambda reciprocalLambda)
+template <class View, class Rate = StandInTreeRate>
+havoc_rqt_result decideRqt(View &view, const havoc_rqt_cu &cu, Lambda reciprocalLambda, Rate rate = Rate())
 {
     havoc_rqt_result r;
     r = havoc_rqt_result();
     const int half = 1 << (cu.log2_size - 1);
     int32_t ssdOne = 0;
     bool coded = false;
-    Cost rateOne = 0;
     for (int k = 0; k < 4; ++k)      // rqtdepth = 1 first (Reconstruct.cpp:1325-1326), blocks in z-order
     {
         r.one[k] = view.evaluate(cu.x0 + (k & 1) * half, cu.y0 + (k >> 1) * half, cu.log2_size - 1, 1);
         ssdOne += int32_t(r.one[k].ssd);
         coded |= r.one[k].cbf != 0;
-        rateOne += tuRate(r.one[k]);
     }
-    r.cost_one = rateOne + reciprocalLambda * ssdOne;
+    r.cost_one = rate(1, r.one, 4) + reciprocalLambda * ssdOne;
     if (!coded)                      // cbfZero: the unit is left unsplit and without residual
     {
         r.depth = 0;
@@ -47,7 +57,7 @@ havoc_rqt_result decideRqt(View &view, const havoc_rqt_cu &cu, Lambda reciprocal
     }
     r.tried_zero = 1;
     r.zero = view.evaluate(cu.x0, cu.y0, cu.log2_size, 0);
-    r.cost_zero = tuRate(r.zero) + reciprocalLambda * int32_t(r.zero.ssd);
+    r.cost_zero = rate(0, &r.zero, 1) + reciprocalLambda * int32_t(r.zero.ssd);
     r.depth = (r.cost_zero < r.cost_one) ? 0 : 1;     // Reconstruct.cpp:1389
     return r;
 }
@@ -66,8 +76,20 @@ inline int intraScanIdx(int log2TrafoSize, int mode)      // Global.h:1212-1227,
     return (mode >= 6 && mode <= 14) ? 2 : ((mode >= 22 && mode <= 30) ? 1 : 0);
 }
 
-template <class View>
-havoc_intra_rd_result decideIntraRd(View &view, const havoc_search_intra_result &order, const havoc_search_intra_ctx &ic, Lambda reciprocalLambda)
+// the rate of a candidate (mode + residual, Q16 bits): the product's stand-in; kCostMax = "not measured" (the reference measures a challenger's rate only
+// when its distortion alone is below the champion's cost, Search.hpp:242-246: one that is not cannot win)
+struct StandInIntraRate
+{
+    const havoc_search_intra_ctx &ic;
+    Cost operator()(int mode, int /*j*/, const havoc_tu_outcome &o) const
+    {
+        const Cost modeRate = mode == ic.cand_mode_list[0] ? ic.rate_a_minus_c : ((mode == ic.cand_mode_list[1] || mode == ic.cand_mode_list[2]) ? ic.rate_b_minus_c : 0);
+        return modeRate + tuRate(o);
+    }
+};
+
+template <class View, class Rate>
+havoc_intra_rd_result decideIntraRd(View &view, const havoc_search_intra_result &order, Lambda reciprocalLambda, Rate rate)
 {
     havoc_intra_rd_result r;
     r = havoc_intra_rd_result();
@@ -77,8 +99,8 @@ havoc_intra_rd_result decideIntraRd(View &view, const havoc_search_intra_result 
     {
         const int mode = order.order[j];
         const havoc_tu_outcome o = view.evaluate(mode, j);
-        const Cost modeRate = mode == ic.cand_mode_list[0] ? ic.rate_a_minus_c : ((mode == ic.cand_mode_list[1] || mode == ic.cand_mode_list[2]) ? ic.rate_b_minus_c : 0);
-        const Cost cost = modeRate + tuRate(o) + reciprocalLambda * int32_t(o.ssd);
+        const Cost bits = rate(mode, j, o);
+        const Cost cost = bits == kCostMax ? kCostMax : bits + reciprocalLambda * int32_t(o.ssd);
         ++r.evaluated;
         if (cost < r.cost)
         {
@@ -89,6 +111,12 @@ havoc_intra_rd_result decideIntraRd(View &view, const havoc_search_intra_result 
         }
     }
     return r;
+}
+
+template <class View>
+havoc_intra_rd_result decideIntraRd(View &view, const havoc_search_intra_result &order, const havoc_search_intra_ctx &ic, Lambda reciprocalLambda)
+{
+    return decideIntraRd(view, order, reciprocalLambda, StandInIntraRate{ic});
 }
 
 } // namespace havoc_search
