@@ -85,8 +85,8 @@ __device__ __forceinline__ void sad_block(const char *src, long ssb, const char 
     }
 }
 
-template <int S, int WAYS>
-__global__ __launch_bounds__(256) void k_sad(const char *__restrict__ src, long stride_src, const char *__restrict__ ref, long stride_ref,
+template <int S, int WAYS, int U = 4, int MINW = 1>
+__global__ __launch_bounds__(256, MINW) void k_sad(const char *__restrict__ src, long stride_src, const char *__restrict__ ref, long stride_ref,
                                              const int32_t *__restrict__ jobs, int njobs, int32_t *__restrict__ out)
 {
     typedef typename Sample<S>::T T;
@@ -120,9 +120,9 @@ __global__ __launch_bounds__(256) void k_sad(const char *__restrict__ src, long 
     const int rowBytes = w * S;
     // a chunked path needs its chunks per row to fit the lane group (cpr <= kSadLanes), else rows-per-iteration is 0:
     // 16-bit widths 34, 38 .. 62 (rowBytes % 8 == 4, > 64) take the generic loop like the odd widths
-    if ((rowBytes & 15) == 0 && rowBytes <= 16 * kSadLanes) sad_block<S, WAYS, 16>(s, ssb, r, rsb, rowBytes, h, lane, acc);
-    else if ((rowBytes & 7) == 0 && rowBytes <= 8 * kSadLanes) sad_block<S, WAYS, 8>(s, ssb, r, rsb, rowBytes, h, lane, acc);
-    else if ((rowBytes & 3) == 0 && rowBytes <= 4 * kSadLanes) sad_block<S, WAYS, 4>(s, ssb, r, rsb, rowBytes, h, lane, acc);
+    if ((rowBytes & 15) == 0 && rowBytes <= 16 * kSadLanes) sad_block<S, WAYS, 16, U>(s, ssb, r, rsb, rowBytes, h, lane, acc);
+    else if ((rowBytes & 7) == 0 && rowBytes <= 8 * kSadLanes) sad_block<S, WAYS, 8, U>(s, ssb, r, rsb, rowBytes, h, lane, acc);
+    else if ((rowBytes & 3) == 0 && rowBytes <= 4 * kSadLanes) sad_block<S, WAYS, 4, U>(s, ssb, r, rsb, rowBytes, h, lane, acc);
     else
     {
         // generic widths (the reference's sadGeneric entry): one sample per lane per step
@@ -152,6 +152,11 @@ __global__ __launch_bounds__(256) void k_sad(const char *__restrict__ src, long 
 // bound by the vector-memory address path (SQ counters: 23 % VALU busy, 18 loads per wavefront, no LDS).  Here a job's lane group (16 lanes,
 // as before) copies the bounding box of the four blocks into LDS ONCE, with 16-byte ALIGNED loads in strips of block rows, and the four
 // SADs read their (unaligned) rows from LDS.  A box that does not fit (far rings of the star: positions 16+ samples apart) takes the direct path.
+// MEASURED (profiles/r04/sad4_counters.txt): the direct kernel is bound by the L1's access rate -- 474 M cache accesses per launch, texture addresser
+// busy 82 % of the launch -- and this form cuts the accesses to 112 M and the addresser's busy time by 45 %, but it is NOT faster (0.572 against 0.561 ms):
+// the byte-unaligned 16-byte LDS reads stall the LDS pipeline (SQ_LDS_UNALIGNED_STALL 218 M, a third of all wavefront cycles waiting on LDS) and it
+// issues 2.2 x the VALU instructions.  Kept behind HAVOC_SAD4_WINDOW=1 with its parity tests; what would make it pay is reads aligned to 4 bytes with the
+// candidates' byte shifts done by v_mqsad_u32_u8 as k_sad_surface does (next round).
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kSadWinBytes = 1536;      // LDS per lane group and per byte of sample size: 24 KB (8-bit) / 48 KB (16-bit) per workgroup
 
@@ -163,37 +168,51 @@ __device__ __forceinline__ void sad4_window_strips(const char *src, long ssb, co
     typedef const __attribute__((address_space(3))) u32x4u *LP16;
     typedef const __attribute__((address_space(3))) u32x2u *LP8;
     typedef const __attribute__((address_space(3))) u32u *LP4;
+    // the copy: a lane keeps its 16-byte column and walks down the rows (instruction count matters here: the first form of this kernel cut the
+    // vector-memory accesses 4x and was no faster, with 2.5x the VALU instructions of the direct kernel -- profiles/r04/sad4_counters.txt)
     const int cprw = pitch >> 4;          // 16-byte chunks per window row (1 .. 16)
+    const int wstep = kSadLanes / cprw;   // window rows per copy iteration
+    const int wr0 = lane / cprw, wc = (lane - wr0 * cprw) * 16;
+    const bool copies = wr0 < wstep;
+    // the SADs: a lane keeps its chunk column of the block and walks down the rows; the four candidates' LDS addresses advance together
     const int cpr = rowBytes / CB;        // chunks per block row
     const int rpi = kSadLanes / cpr;      // block rows per iteration of the lane group
     const int y0 = lane / cpr;
     const int xb = (lane - y0 * cpr) * CB;
-    const FastDiv fw(cprw < 2 ? 2 : cprw);
+    const bool sums = y0 < rpi;
+    int lo[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) lo[k] = (y0 + oy[k]) * pitch + lead + ox[k] + xb;
+    const int lstep = rpi * pitch;
+    const long gstep = (long)wstep * rsb, sstep = (long)rpi * ssb;
+    const int wlstep = wstep * pitch;
     for (int ys = 0; ys < h; ys += hs)
     {
-        const int he = min(hs, h - ys), total = (he + spready) * cprw;
-        for (int idx = lane; idx < total; idx += kSadLanes)
+        const int he = min(hs, h - ys), nrows = he + spready;
+        if (copies)
         {
-            const int r = cprw < 2 ? idx : fw.div(idx), c = idx - r * cprw;
-            const u32x4 v = ld16(a0 + (long)(ys + r) * rsb + c * 16);      // 16-byte aligned whenever the row stride is a multiple of 16 bytes (our planes: 64)
-            *reinterpret_cast<__attribute__((address_space(3))) u32x4 *>(buf_w + r * pitch + c * 16) = v;
+            const char *g = a0 + (long)(ys + wr0) * rsb + wc;
+            int l = wr0 * pitch + wc;
+            for (int r = wr0; r < nrows; r += wstep, g += gstep, l += wlstep)
+                *reinterpret_cast<__attribute__((address_space(3))) u32x4 *>(buf_w + l) = ld16(g);      // 16-byte aligned when the row stride is a multiple of 16 bytes (our planes: 64)
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (y0 < rpi)
+        if (sums)
         {
+            const char *sp = src + (long)(ys + y0) * ssb + xb;
+            int l = 0;
 #pragma unroll 2
-            for (int y = y0; y < he; y += rpi)
+            for (int y = y0; y < he; y += rpi, sp += sstep, l += lstep)
             {
-                const char *sp = src + (long)(ys + y) * ssb + xb;
                 if (CB == 16)
                 {
                     const u32x4 a = ld16(sp);
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
                     {
-                        const u32x4u b = *reinterpret_cast<LP16>(buf_r + (y + oy[k]) * pitch + lead + ox[k] + xb);
+                        const u32x4u b = *reinterpret_cast<LP16>(buf_r + lo[k] + l);
                         acc[k] = sad_dword<S>(a.x, b.x, acc[k]);
                         acc[k] = sad_dword<S>(a.y, b.y, acc[k]);
                         acc[k] = sad_dword<S>(a.z, b.z, acc[k]);
@@ -206,7 +225,7 @@ __device__ __forceinline__ void sad4_window_strips(const char *src, long ssb, co
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
                     {
-                        const u32x2u b = *reinterpret_cast<LP8>(buf_r + (y + oy[k]) * pitch + lead + ox[k] + xb);
+                        const u32x2u b = *reinterpret_cast<LP8>(buf_r + lo[k] + l);
                         acc[k] = sad_dword<S>(a.x, b.x, acc[k]);
                         acc[k] = sad_dword<S>(a.y, b.y, acc[k]);
                     }
@@ -215,7 +234,7 @@ __device__ __forceinline__ void sad4_window_strips(const char *src, long ssb, co
                 {
                     const uint32_t a = ld4(sp);
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) acc[k] = sad_dword<S>(a, *reinterpret_cast<LP4>(buf_r + (y + oy[k]) * pitch + lead + ox[k] + xb), acc[k]);
+                    for (int k = 0; k < 4; ++k) acc[k] = sad_dword<S>(a, *reinterpret_cast<LP4>(buf_r + lo[k] + l), acc[k]);
                 }
             }
         }
@@ -691,9 +710,15 @@ __global__ __launch_bounds__(256) void k_ssd_linear(const uint8_t *__restrict__ 
 // launchers (called from api.hip)
 // ---------------------------------------------------------------------------------------------------------
 
-static bool sad4_direct()
+// which 4-way kernel (read once per process):  default = k_sad<S, 4> with two rows in flight per lane and 61 registers (8 wavefronts per SIMD: measured
+// 0.537 ms for the 1.27 M calls of a 1080p picture against 0.561 ms for round 1's four rows / 89 registers);  HAVOC_SAD4_DIRECT=1 = round 1's form;
+// HAVOC_SAD4_WINDOW=1 = k_sad4w, the candidates' common window through LDS (0.572 ms: kept as a measured experiment, parity-tested)
+static int sad4_form()
 {
-    static const bool v = [] { const char *e = getenv("HAVOC_SAD4_DIRECT"); return e && *e == '1'; }();
+    static const int v = [] {
+        const char *w = getenv("HAVOC_SAD4_WINDOW"), *d = getenv("HAVOC_SAD4_DIRECT");
+        return (w && *w == '1') ? 2 : ((d && *d == '1') ? 1 : 0);
+    }();
     return v;
 }
 
@@ -705,13 +730,14 @@ hipError_t launch_sad(hipStream_t st, int S, int ways, const void *src, long ss,
     const dim3 g((n + 256 / kSadLanes - 1) / (256 / kSadLanes)), b(256);
     if (S == 1 && ways == 1) hipLaunchKernelGGL((k_sad<1, 1>), g, b, 0, st, s, ss, r, rs, j, n, out);
     else if (S == 2 && ways == 1) hipLaunchKernelGGL((k_sad<2, 1>), g, b, 0, st, s, ss, r, rs, j, n, out);
-    else if (ways == 4 && rs >= 64 && rs < (1 << 22) && !sad4_direct())
-    {   // the candidates' common window through LDS (k_sad4w); HAVOC_SAD4_DIRECT=1 keeps round 1's kernel (both are parity-tested)
+    else if (ways == 4 && rs >= 64 && rs < (1 << 22) && sad4_form() == 2)
+    {
         const float inv = 1.0f / (float)rs;
         if (S == 1) hipLaunchKernelGGL((k_sad4w<1>), g, b, 0, st, s, ss, r, rs, inv, j, n, out);
         else if (S == 2) hipLaunchKernelGGL((k_sad4w<2>), g, b, 0, st, s, ss, r, rs, inv, j, n, out);
         else return hipErrorInvalidValue;
     }
+    else if (S == 1 && ways == 4 && sad4_form() == 0) hipLaunchKernelGGL((k_sad<1, 4, 2, 6>), g, b, 0, st, s, ss, r, rs, j, n, out);
     else if (S == 1 && ways == 4) hipLaunchKernelGGL((k_sad<1, 4>), g, b, 0, st, s, ss, r, rs, j, n, out);
     else if (S == 2 && ways == 4) hipLaunchKernelGGL((k_sad<2, 4>), g, b, 0, st, s, ss, r, rs, j, n, out);
     else return hipErrorInvalidValue;
