@@ -172,9 +172,72 @@ struct LoggedView
     }
 };
 
+// The step hooks of decision.hpp (foldPatternStep / foldSubpelStep) as the device view implements them -- a candidate per lane, the winner = the smallest
+// of the keys (cost << 2 | index) -- emulated lane by lane on the host, so that the FORMULATION (not the DPP plumbing) is held against the generic loops and the
+// reference encoder's traces without a GPU (client_uni_lanes; tests/test_trace_pin.py)
+template <class Inner>
+struct LaneEmuView
+{
+    Inner &inner;
+    int sad(int dx, int dy) { return inner.sad(dx, dy); }
+    void sad4(const Mv d[4], int32_t out[4]) { inner.sad4(d, out); }
+    int satdQpel(Mv mv) { return inner.satdQpel(mv); }
+    bool patternStep(Mv d0, Mv d1, Mv d2, Mv d3, const PuContext &pu, Lambda lambda, MvCandidate &best)
+    {
+        const Mv d[4] = {d0, d1, d2, d3};
+        int32_t sads[4];
+        inner.sad4(d, sads);
+        uint64_t key = ~0ull;
+        Mv mvds[4];
+        int flags[4];
+        for (int i = 0; i < 4; ++i)
+        {
+            const Mv mv = shl2(d[i]);
+            const Mv m0 = mv - pu.mvp[0], m1 = mv - pu.mvp[1];
+            const Cost c0 = rateOf(m0) + pu.mvpRate[0], c1 = rateOf(m1) + pu.mvpRate[1];
+            const bool second = c1 < c0;
+            const Cost c = (second ? c1 : c0) + lambda * sads[i];
+            mvds[i] = second ? m1 : m0;
+            flags[i] = second;
+            const uint64_t k = (uint64_t(c) << 2) | uint32_t(i);
+            if (k < key) key = k;
+        }
+        const int w = int(key & 3);
+        const Cost cw = Cost(key >> 2);
+        if (!(cw < best.cost)) return false;
+        best.cost = cw;
+        best.mv = shl2(d[w]);
+        best.mvd = mvds[w];
+        best.mvpFlag = flags[w];
+        return true;
+    }
+    int subpelStep(Mv mv, Mv mvd, int scale, bool tryOrigin, Lambda lambda, Cost &bestCost)
+    {
+        Cost start = bestCost;
+        if (tryOrigin) start = rateOf(mvd) + lambda * inner.satdQpel(mv);
+        uint64_t key = ~0ull;
+        for (int j = 0; j < 8; ++j)
+        {
+            const int g = j < 4 ? j : j + 1;
+            const Mv off(int16_t((g % 3 - 1) * scale), int16_t((g / 3 - 1) * scale));
+            const Cost c = rateOf(mvd + off) + lambda * inner.satdQpel(mv + off);
+            const uint64_t k = (uint64_t(c) << 4) | uint32_t(j);
+            if (k < key) key = k;
+        }
+        int bestI = -1;
+        if (Cost(key >> 4) < start)
+        {
+            start = Cost(key >> 4);
+            bestI = int(key & 15);
+        }
+        bestCost = start;
+        return bestI;
+    }
+};
+
 template <typename Sample>
 void runUni(const Sample *src, intptr_t ss, const Sample *ref, intptr_t rs, const havoc_search_params &p, const havoc_search_pu *pus, int b, int e,
-            havoc_search_result *out, CallLog *log = nullptr, int64_t *logFirst = nullptr)
+            havoc_search_result *out, CallLog *log = nullptr, int64_t *logFirst = nullptr, bool lanes = false)
 {
     const SearchParams sp = paramsOf(p);
     for (int i = b; i < e; ++i)
@@ -189,6 +252,12 @@ void runUni(const Sample *src, intptr_t ss, const Sample *ref, intptr_t rs, cons
             MotionSearch<LoggedView<TableView<Sample>>> search(sp, pu, logged);
             r = search.run();
             logFirst[i - b + 1] = log->count;
+        }
+        else if (lanes)
+        {
+            LaneEmuView<TableView<Sample>> emu{view};
+            MotionSearch<LaneEmuView<TableView<Sample>>> search(sp, pu, emu);
+            r = search.run();
         }
         else
         {
@@ -313,6 +382,16 @@ int client_uni(int S, const void *src, intptr_t ss, const void *ref, intptr_t rs
     if (!g_open) return -1;
     if (S == 1) runUni<uint8_t>((const uint8_t *)src, ss, (const uint8_t *)ref, rs, *p, pus, b, e, out);
     else runUni<uint16_t>((const uint16_t *)src, ss, (const uint16_t *)ref, rs, *p, pus, b, e, out);
+    return 0;
+}
+
+// the searches through the step hooks in their lane formulation (LaneEmuView)
+int client_uni_lanes(int S, const void *src, intptr_t ss, const void *ref, intptr_t rs, const havoc_search_params *p, const havoc_search_pu *pus, int b, int e,
+                     havoc_search_result *out)
+{
+    if (!g_open) return -1;
+    if (S == 1) runUni<uint8_t>((const uint8_t *)src, ss, (const uint8_t *)ref, rs, *p, pus, b, e, out, nullptr, nullptr, true);
+    else runUni<uint16_t>((const uint16_t *)src, ss, (const uint16_t *)ref, rs, *p, pus, b, e, out, nullptr, nullptr, true);
     return 0;
 }
 

@@ -90,6 +90,7 @@ class Client:
         L.client_open.argtypes = [i]
         L.client_uni.argtypes = [i, vp, ip, vp, ip, C.POINTER(Params), vp, i, i, vp]
         L.client_bi.argtypes = [i, vp, ip, vp, vp, ip, C.POINTER(Params), vp, vp, i, i, vp]
+        L.client_uni_lanes.argtypes = [i, vp, ip, vp, ip, C.POINTER(Params), vp, i, i, vp]
         L.client_uni_logged.argtypes = [i, vp, ip, vp, ip, C.POINTER(Params), vp, i, i, vp, vp, C.c_int64, vp]
         L.client_uni_logged.restype = C.c_int64
         L.client_bi_logged.argtypes = [i, vp, ip, vp, vp, ip, C.POINTER(Params), vp, vp, i, i, vp, vp, C.c_int64, vp]
@@ -119,6 +120,13 @@ class Client:
         rc = self.L.client_uni(src.itemsize, self._origin(src, stride, pad), stride, self._origin(ref, stride, pad), stride, C.byref(params),
                                pus.ctypes.data, b, e, out.ctypes.data)
         assert rc == 0
+        return out
+
+    def uni_lanes(self, params, src, ref, stride, pad, pus):
+        """uni() through decision.hpp's step hooks in the device view's formulation (a candidate per lane, smallest key wins), emulated on the host"""
+        out = np.zeros(len(pus), RESULT_DT)
+        assert self.L.client_uni_lanes(src.itemsize, self._origin(src, stride, pad), stride, self._origin(ref, stride, pad), stride, C.byref(params),
+                                       pus.ctypes.data, 0, len(pus), out.ctypes.data) == 0
         return out
 
     def uni_logged(self, params, src, ref, stride, pad, pus, capacity):

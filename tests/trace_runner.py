@@ -153,6 +153,7 @@ def main():
         pus = np.ascontiguousarray(uni.pus[idx])
         out, rows, first = cpu.uni_logged(par, s, rf, stride, tt.PAD, pus, int(uni.results["calls"][idx].sum()) + 4096)
         r["mismatching_searches"] += int(len(differing(out, uni.results[idx], UNI_FIELDS)))
+        r["mismatching_in_the_lane_formulation"] = r.get("mismatching_in_the_lane_formulation", 0) + int(len(differing(cpu.uni_lanes(par, s, rf, stride, tt.PAD, pus), uni.results[idx], UNI_FIELDS)))
         exp_rows = gather_rows(uni, idx)
         r["mismatching_call_rows"] += int(abs(len(rows) - len(exp_rows)) + np.count_nonzero(np.any(rows[:len(exp_rows)] != exp_rows[:len(rows)], axis=1)))
         r["groups"] += 1
@@ -255,7 +256,12 @@ def main():
                     rc = dev.L.havoc_search_motion_uni_device(dev.ctx, S, C.byref(par), d_src, origin(stride), stride, d_ref, origin(stride), stride, tt.PAD, d_phase,
                                                               pe, origin(stride), pus.ctypes.data, len(pus), out.ctypes.data, C.byref(stats))
                     assert rc == 0, (rc, dev.dev.havoc_mi355x_last_error())
-                    r["mismatching_loops_in_kernel"] += int(len(differing(out, exp, UNI_FIELDS)))
+                    bad = differing(out, exp, UNI_FIELDS)
+                    r["mismatching_loops_in_kernel"] += int(len(bad))
+                    if len(bad) and "examples" not in r:
+                        r["examples"] = [{"pu": [int(v) for v in (pus[k]["x0"], pus[k]["y0"], pus[k]["w"], pus[k]["h"])], "mvp": pus[k]["mvp"].tolist(),
+                                          "got": {f: np.asarray(out[k][f]).tolist() for f in UNI_FIELDS + ["cost_subpel"]}, "want": {f: np.asarray(exp[k][f]).tolist() for f in UNI_FIELDS},
+                                          "cpu_cost_subpel": int(expected_uni[key][1][np.flatnonzero(expected_uni[key][0] == sel[k])[0]]["cost_subpel"])} for k in bad[:6]]
                 r["searches"] += len(sel)
         r["seconds"] = round(time.perf_counter() - t0, 2)
         report["uni_device"] = r

@@ -404,18 +404,34 @@ struct DeviceView
     __device__ __forceinline__ void hintSatd(const Mv *positions, int n)
     {
         GAP_IN();
+        int32_t packed[9];
+        satdTurn ^= 1;
+        satdCount = n;
+        computeSatds(positions, n, packed);
+        {   // lane i reads position i, then the nine values move to scalar registers
+            const int v = x->satd[satdTurn][lane < 9 ? lane : 0];
+#pragma unroll
+            for (int j = 0; j < 9; ++j)
+            {
+                satdKey[j] = packed[j];
+                satdValue[j] = __builtin_amdgcn_readlane(v, j);
+            }
+        }
+        GAP_OUT();
+    }
+
+    // the SATDs of n <= 9 sub-sample positions into x->satd[satdTurn][0 .. n), a position per lane group (small blocks) or per wavefront; ends with the barrier
+    __device__ __forceinline__ void computeSatds(const Mv *positions, int n, int32_t (&packed)[9])
+    {
 #ifdef HAVOC_SEARCH_TIMING
         if (!tHint) tHint = wall_clock64();
         const long c0 = clock64();
 #endif
-        satdTurn ^= 1;
-        satdCount = n;
         const LdsPtr src = ldsPtr(x->src);
         const int ts = ((w | h) & 7) ? 4 : 8, tw = w / ts;
         const int rows = tw * (h / ts) * ts;
         // the positions stay in registers: position `j` of a lane (group) or wavefront is picked with compares, not by address (an indexed array
         // would live in private memory), and nothing goes through LDS before the SATDs do
-        int32_t packed[9];
 #pragma unroll
         for (int i = 0; i < 9; ++i) packed[i] = havoc_search::MotionField::pack(positions[i < n ? i : 0]);
         auto pick = [&](int j) {
@@ -516,21 +532,129 @@ struct DeviceView
         const long c2 = clock64();
 #endif
         __syncthreads();
-        {   // lane i reads position i, then the nine values move to scalar registers
-            const int v = x->satd[satdTurn][lane < 9 ? lane : 0];
-#pragma unroll
-            for (int j = 0; j < 9; ++j)
-            {
-                satdKey[j] = packed[j];
-                satdValue[j] = __builtin_amdgcn_readlane(v, j);
-            }
-        }
 #ifdef HAVOC_SEARCH_TIMING
         const long c3 = clock64();
         acc[2] += c1 - c0; acc[3] += c2 - c1; acc[4] += c3 - c2;
 #endif
-        GAP_OUT();
     }
+
+    // ---- whole steps of decision.hpp's loops with a candidate per LANE (decision.hpp: foldPatternStep / foldSubpelStep) ----
+    __device__ __forceinline__ static uint64_t quadMin(uint64_t key)
+    {   // the smallest key of each aligned group of four lanes, in all four (two quad permutations: lane ^ 1, lane ^ 2)
+        {
+            const int lo = (int)(uint32_t)key, hi = (int)(uint32_t)(key >> 32);
+            const uint32_t olo = (uint32_t)__builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xf, 0xf, false), ohi = (uint32_t)__builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xf, 0xf, false);
+            const uint64_t other = ((uint64_t)ohi << 32) | olo;
+            key = other < key ? other : key;
+        }
+        {
+            const int lo = (int)(uint32_t)key, hi = (int)(uint32_t)(key >> 32);
+            const uint32_t olo = (uint32_t)__builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xf, 0xf, false), ohi = (uint32_t)__builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xf, 0xf, false);
+            const uint64_t other = ((uint64_t)ohi << 32) | olo;
+            key = other < key ? other : key;
+        }
+        return key;
+    }
+
+#ifndef HAVOC_NO_PATTERN_LANES
+    // sad4 + the four best.consider() of StateMeFullPel::considerPattern (Search.hpp:1447-1482): lane i of every quad costs candidate i; the winner is the
+    // first of the cheapest (what considering them in order leaves in `best`), taken if it beats `best` strictly
+    __device__ __forceinline__ bool patternStep(const Mv d0, const Mv d1, const Mv d2, const Mv d3, const havoc_search::PuContext &pu, const havoc_search::Lambda lambda,
+                                                havoc_search::MvCandidate &best)
+    {
+        GAP_IN();
+        const int i = lane & 3;
+        const int px = i == 0 ? d0.x : (i == 1 ? d1.x : (i == 2 ? d2.x : d3.x));
+        const int py = i == 0 ? d0.y : (i == 1 ? d1.y : (i == 2 ? d2.y : d3.y));
+        auto inTable = [&](Mv m) { return m.x >= tx0 && m.x < tx0 + tw && m.y >= ty0 && m.y < ty0 + th; };
+        const bool all = tw != 0 && inTable(d0) && inTable(d1) && inTable(d2) && inTable(d3);
+        int sadv;
+        if (all)
+            sadv = x->table[(py - ty0) * tw + px - tx0];      // announced (hintSadRect): a look-up per lane
+        else
+        {
+            const int k = wave & 3;
+            const int s0 = -(k == 0), s1 = -(k == 1), s2 = -(k == 2), s3 = -(k == 3);
+            const int mx = (d0.x & s0) | (d1.x & s1) | (d2.x & s2) | (d3.x & s3), my = (d0.y & s0) | (d1.y & s1) | (d2.y & s2) | (d3.y & s3);
+            int v;
+            TICK(0, v = sadOne(mx, my, wave >> 2, kWaves / 4));
+            sadTurn ^= 1;
+            if (lane == 0) x->sad[sadTurn][wave] = v;
+            __syncthreads();
+            int t = 0;
+#pragma unroll
+            for (int p = 0; p < kWaves / 4; ++p) t += x->sad[sadTurn][i + 4 * p];
+            sadv = sadShift<S>(t);
+        }
+        const Mv mv(int16_t(px << 2), int16_t(py << 2));
+        const Mv m0 = mv - pu.mvp[0], m1 = mv - pu.mvp[1];
+        const Cost c0 = havoc_search::rateOf(m0) + pu.mvpRate[0], c1 = havoc_search::rateOf(m1) + pu.mvpRate[1];
+        const bool second = c1 < c0;      // MvCandidate's constructor: the second predictor replaces the first on strictly smaller cost
+        const Cost c = (second ? c1 : c0) + lambda * sadv;
+        const int32_t mvdPacked = havoc_search::MotionField::pack(second ? m1 : m0);
+        const uint64_t key = quadMin(((uint64_t)c << 2) | (uint32_t)i);
+        const uint32_t klo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)key), khi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(key >> 32));
+        const int w = klo & 3;
+        const Cost cw = (Cost)((((uint64_t)khi << 32) | klo) >> 2);
+        const bool improved = havoc_search::costLess(cw, best.cost);
+        if (improved)
+        {
+            const int s0 = -(w == 0), s1 = -(w == 1), s2 = -(w == 2), s3 = -(w == 3);
+            best.cost = cw;
+            best.mv = havoc_search::shl2(Mv(int16_t((d0.x & s0) | (d1.x & s1) | (d2.x & s2) | (d3.x & s3)), int16_t((d0.y & s0) | (d1.y & s1) | (d2.y & s2) | (d3.y & s3))));
+            best.mvd = havoc_search::MotionField::unpack(__builtin_amdgcn_readlane(mvdPacked, w));
+            best.mvpFlag = __builtin_amdgcn_readlane((int)second, w);
+        }
+        GAP_OUT();
+        return improved;
+    }
+
+#endif
+#ifndef HAVOC_NO_SUBPEL_LANES
+    // patternSearchOnce's costMv calls (Search.hpp:2001-2061, one iteration): the eight neighbours of `mv` at `scale` quarter samples in raster order (and `mv`
+    // itself first when tryOrigin), a position per lane; returns the first of the cheapest neighbours if it beats the cost so far strictly, else -1
+    __device__ __forceinline__ int subpelStep(Mv mv, Mv mvd, int scale, bool tryOrigin, const havoc_search::Lambda lambda, Cost &bestCost)
+    {
+        GAP_IN();
+        Mv ask[9];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+        {
+            const int g = j < 4 ? j : j + 1;
+            ask[j] = Mv(int16_t(mv.x + (g % 3 - 1) * scale), int16_t(mv.y + (g / 3 - 1) * scale));
+        }
+        ask[8] = mv;
+        satdTurn ^= 1;
+        satdCount = 0;      // nothing is kept for satdQpel: the values are consumed here
+        int32_t packed[9];
+        computeSatds(ask, tryOrigin ? 9 : 8, packed);
+        const int j = lane & 15, g = j < 4 ? j : j + 1;
+        const Mv off = j < 8 ? Mv(int16_t((g % 3 - 1) * scale), int16_t((g / 3 - 1) * scale)) : Mv(0, 0);
+        const int satdv = x->satd[satdTurn][j < 9 ? j : 0];
+        const Cost cj = havoc_search::rateOf(mvd + off) + lambda * satdv;
+        Cost start = bestCost;
+        if (tryOrigin)
+        {
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)cj, 8), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)cj >> 32), 8);
+            start = (Cost)(((uint64_t)hi << 32) | lo);
+        }
+        const uint64_t key = quadMin(j < 8 ? (((uint64_t)cj << 4) | (uint32_t)j) : ~0ull);
+        // (the built-in returns int: without the casts a low word of 2^31 or more -- costs of 64x64 blocks -- would sign-extend over the high word)
+        const uint64_t k0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), 0) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, 0);
+        const uint64_t k1 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), 4) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, 4);
+        const uint64_t k = havoc_search::costLess((Cost)k1, (Cost)k0) ? k1 : k0;      // keys are non-negative and never equal (the index is part of them)
+        const Cost cmin = (Cost)(k >> 4);
+        int bestI = -1;
+        if (havoc_search::costLess(cmin, start))
+        {
+            start = cmin;
+            bestI = (int)(k & 15);
+        }
+        bestCost = start;
+        GAP_OUT();
+        return bestI;
+    }
+#endif
 
     __device__ __forceinline__ int satdQpel(Mv mv)
     {

@@ -196,6 +196,41 @@ HAVOC_HD inline auto hintSadRect(View &v, int x0, int y0, int x1, int y1, int) -
 template <class View>
 HAVOC_HD inline void hintSadRect(View &, int, int, int, int, long) {}
 
+// A view whose lanes can do more than answer calls takes over whole steps of the loops (the device view, csrc/kernels_search.hip: the four candidates of a
+// pattern step / the eight or nine of a sub-sample step are costed one per LANE with the arithmetic below, where this text costs them one after the other in
+// scalar registers -- measured: 28 k scalar instructions per search, the kernel's bound).  Same candidates, same order of preference (the first of equal
+// costs), same results: the trace-pin tests hold both forms against the reference encoder's own decisions.
+//   bool patternStep(Mv, Mv, Mv, Mv, const PuContext &, Lambda, MvCandidate &best)             = sad4 + the four best.consider() of considerPattern
+//   int  subpelStep(Mv mv, Mv mvd, int scale, bool tryOrigin, Lambda, Cost &bestCost)           = patternSearchOnce's costMv calls; returns bestI or -1
+template <class View, class Search>
+HAVOC_HD inline auto foldPatternStep(View &v, const Mv (&mv)[4], Search &s, int) -> decltype(v.patternStep(mv[0], mv[1], mv[2], mv[3], s.pu, s.lambda, s.best), bool())
+{
+    ++s.calls;
+    return v.patternStep(mv[0], mv[1], mv[2], mv[3], s.pu, s.lambda, s.best);      // by value: an array handed down by reference ends up in (per-lane) memory
+}
+template <class View, class Search>
+HAVOC_HD inline bool foldPatternStep(View &v, const Mv (&mv)[4], Search &s, long)
+{
+    int32_t sads[4];
+    v.sad4(mv, sads);
+    ++s.calls;
+    bool improved = false;
+    HAVOC_UNROLL
+    for (int i = 0; i < 4; ++i)
+    {
+        MvCandidate candidate(shl2(mv[i]), s.pu.mvp, s.pu.mvpRate);
+        candidate.cost += s.lambda * sads[i];
+        improved |= s.best.consider(candidate);
+    }
+    return improved;
+}
+template <class View, class Search>
+HAVOC_HD inline auto foldSubpelStep(View &v, Search &s, int scale, bool tryOrigin, Mv mv, Mv mvd, Cost &bestCost, int) -> decltype(v.subpelStep(mv, mvd, scale, tryOrigin, s.lambda, bestCost), int())
+{
+    s.calls += tryOrigin ? 9 : 8;
+    return v.subpelStep(mv, mvd, scale, tryOrigin, s.lambda, bestCost);
+}
+
 template <class View>
 struct MotionSearch
 {
@@ -226,16 +261,7 @@ struct MotionSearch
                 mv[i].y = int16_t((origin.y + dist * pattern->y) / 4);
                 limit(mv[i]);
             }
-            int32_t sads[4];
-            view.sad4(mv, sads);
-            ++calls;
-            HAVOC_UNROLL
-            for (int i = 0; i < 4; ++i)
-            {
-                MvCandidate candidate(shl2(mv[i]), pu.mvp, pu.mvpRate);
-                candidate.cost += lambda * sads[i];
-                improved |= best.consider(candidate);
-            }
+            improved |= foldPatternStep(view, mv, *this, 0);
         }
         return improved;
     }
@@ -357,17 +383,7 @@ struct MotionSearch
                     mv[i] = Mv(int16_t(best.mv.x / 4), int16_t(best.mv.y / 4)) + diamond4[i];
                     limit(mv[i]);
                 }
-                int32_t sads[4];
-                view.sad4(mv, sads);
-                ++calls;
-                j = -1;
-                HAVOC_UNROLL
-                for (int i = 0; i < 4; ++i)
-                {
-                    MvCandidate temp(shl2(mv[i]), pu.mvp, pu.mvpRate);
-                    temp.cost += lambda * sads[i];
-                    if (best.consider(temp)) j = i;
-                }
+                j = foldPatternStep(view, mv, *this, 0) ? 0 : -1;      // the reference keeps the index of the last improving position; only "any" is used
             } while (j >= 0);
         }
         return pu.part2Nx2N;
@@ -380,9 +396,19 @@ struct MotionSearch
         return rateOf(mvd) + lambda * view.satdQpel(mv);
     }
 
-    // Search.hpp:2010-2061 with maxIterations = 1, the only way subPelRefinement calls it
-    HAVOC_HD void patternSearchOnce(const Mv (&pattern)[8], bool tryOrigin, Mv &mv, Mv &mvd, Cost &bestCost)
+    // Search.hpp:2010-2061 with maxIterations = 1, the only way subPelRefinement calls it.  pattern[i] = scale * the i-th of the eight neighbours in raster order
+    HAVOC_HD void patternSearchOnce(const Mv (&pattern)[8], int scale, bool tryOrigin, Mv &mv, Mv &mvd, Cost &bestCost)
     {
+        const int bestLanes = subpelDispatch(pattern, scale, tryOrigin, mv, mvd, bestCost, 0);
+        if (bestLanes >= -1)
+        {
+            if (bestLanes >= 0)
+            {
+                mvd = mvd + pattern[bestLanes];
+                mv = mv + pattern[bestLanes];
+            }
+            return;
+        }
         {
             Mv ask[9];
             HAVOC_UNROLL
@@ -407,6 +433,14 @@ struct MotionSearch
             mv = mv + pattern[bestI];
         }
     }
+
+    // -2: the view has no lane form (the loop above runs); otherwise the index of the winning neighbour or -1
+    template <class V = View>
+    HAVOC_HD auto subpelDispatch(const Mv (&)[8], int scale, bool tryOrigin, Mv mv, Mv mvd, Cost &bestCost, int) -> decltype(foldSubpelStep(*(V *)nullptr, *this, scale, tryOrigin, mv, mvd, bestCost, 0))
+    {
+        return foldSubpelStep(view, *this, scale, tryOrigin, mv, mvd, bestCost, 0);
+    }
+    HAVOC_HD int subpelDispatch(const Mv (&)[8], int, bool, Mv, Mv, Cost &, long) { return -2; }
 
     // searchMotionUni, Search.hpp:1317-1355
     // what the integer stage leaves behind: a caller that may have to run the sub-sample stage again (a batch client whose
@@ -450,11 +484,11 @@ struct MotionSearch
         if (sp.halfPel)
         {
             static constexpr Mv half[8] = {{-2, -2}, {0, -2}, {2, -2}, {-2, 0}, {2, 0}, {-2, 2}, {0, 2}, {2, 2}};
-            patternSearchOnce(half, true, mv, mvd, r.costSubPel);
+            patternSearchOnce(half, 2, true, mv, mvd, r.costSubPel);
             if (sp.quarterPel)
             {
                 static constexpr Mv quarter[8] = {{-1, -1}, {0, -1}, {1, -1}, {-1, 0}, {1, 0}, {-1, 1}, {0, 1}, {1, 1}};
-                patternSearchOnce(quarter, false, mv, mvd, r.costSubPel);
+                patternSearchOnce(quarter, 1, false, mv, mvd, r.costSubPel);
             }
         }
         r.mv = mv;
