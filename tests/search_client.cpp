@@ -211,6 +211,67 @@ struct LaneEmuView
         best.mvpFlag = flags[w];
         return true;
     }
+    // a candidate's cost as a lane computes it; `flag` and `mvd` of the cheaper predictor
+    static Cost laneCost(Mv full, const PuContext &pu, Lambda lambda, int sad, Mv &mvd, int &flag)
+    {
+        const Mv mv = shl2(full);
+        const Mv m0 = mv - pu.mvp[0], m1 = mv - pu.mvp[1];
+        const Cost c0 = rateOf(m0) + pu.mvpRate[0], c1 = rateOf(m1) + pu.mvpRate[1];
+        flag = c1 < c0;
+        mvd = flag ? m1 : m0;
+        return (flag ? c1 : c0) + lambda * sad;
+    }
+    int sadAtFull(Mv p) { return inner.sad(p.x, p.y); }
+    int patternRing(Mv origin, const Mv *pattern, int n, int step, int dist, const LimitFullPelMv &limit, const PuContext &pu, Lambda lambda, MvCandidate &best)
+    {
+        const int count = n / step;
+        uint64_t key = ~0ull;
+        Mv pos[16], mvds[16];
+        int flags[16];
+        for (int c = 0; c < count; ++c)
+        {
+            const Mv p = pattern[c * step];
+            pos[c] = Mv(int16_t((origin.x + dist * p.x) / 4), int16_t((origin.y + dist * p.y) / 4));
+            limit(pos[c]);
+            const Cost cost = laneCost(pos[c], pu, lambda, sadAtFull(pos[c]), mvds[c], flags[c]);
+            const uint64_t k = (uint64_t(cost) << 4) | uint32_t(c);
+            if (k < key) key = k;
+        }
+        const int w = int(key & 15);
+        if (!(Cost(key >> 4) < best.cost)) return 0;
+        best.cost = Cost(key >> 4);
+        best.mv = shl2(pos[w]);
+        best.mvd = mvds[w];
+        best.mvpFlag = flags[w];
+        return 1;
+    }
+    void rasterSweep(int rasterSearch, const LimitFullPelMv &limit, const PuContext &pu, Lambda lambda, MvCandidate &best)
+    {
+        const int rows = 2 * rasterSearch / 20 + 1, perRow = 4 * (2 * rasterSearch / 80 + 1);
+        uint64_t key = ~0ull;
+        for (int idx = 0; idx < rows * perRow; ++idx)
+        {
+            const int r = idx / perRow, k = idx - r * perRow;
+            Mv p(int16_t(-rasterSearch / 4 + 5 * k), int16_t(-rasterSearch / 4 + 5 * r));
+            limit(p);
+            Mv mvd;
+            int flag;
+            const Cost cost = laneCost(p, pu, lambda, sadAtFull(p), mvd, flag);
+            const uint64_t kk = (uint64_t(cost) << 10) | uint32_t(idx);
+            if (kk < key) key = kk;
+        }
+        if (!(Cost(key >> 10) < best.cost)) return;
+        const int idx = int(key & 1023), r = idx / perRow, k = idx - r * perRow;
+        Mv p(int16_t(-rasterSearch / 4 + 5 * k), int16_t(-rasterSearch / 4 + 5 * r));
+        limit(p);
+        Mv mvd;
+        int flag;
+        laneCost(p, pu, lambda, 0, mvd, flag);
+        best.cost = Cost(key >> 10);
+        best.mv = shl2(p);
+        best.mvd = mvd;
+        best.mvpFlag = flag;
+    }
     int subpelStep(Mv mv, Mv mvd, int scale, bool tryOrigin, Lambda lambda, Cost &bestCost)
     {
         Cost start = bestCost;

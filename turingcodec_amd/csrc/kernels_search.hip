@@ -231,6 +231,8 @@ template <int S>
 struct Lds      // of a workgroup
 {
     int32_t sad[2][kWaves];
+    int32_t ring[2][16];         // the SADs of a whole pattern call (4, 8 or 16 candidates)
+    int32_t raster[704];         // ... of the raster refinement's 700 (208) positions
     int32_t satd[2][12];
     int32_t table[16 * 12];      // SADs of a rectangle of full-sample displacements (the grid of a bi-directional refinement)
     int32_t mv[256 + 32];        // the CTU's own 16 x 16 cells, the 16 cells left of it, the 16 cells above it
@@ -610,6 +612,112 @@ struct DeviceView
     }
 
 #endif
+    // a candidate's cost in its lane: the cheaper predictor (the second on strictly smaller cost, as MvCandidate's constructor), rate + lambda * sad
+    __device__ __forceinline__ static Cost laneCost(int px, int py, const havoc_search::PuContext &pu, const havoc_search::Lambda lambda, int sadv, int32_t &mvdPacked, int &second)
+    {
+        const Mv mv(int16_t(px << 2), int16_t(py << 2));
+        const Mv m0 = mv - pu.mvp[0], m1 = mv - pu.mvp[1];
+        const Cost c0 = havoc_search::rateOf(m0) + pu.mvpRate[0], c1 = havoc_search::rateOf(m1) + pu.mvpRate[1];
+        second = c1 < c0;
+        mvdPacked = havoc_search::MotionField::pack(second ? m1 : m0);
+        return (second ? c1 : c0) + lambda * sadv;
+    }
+    __device__ __forceinline__ static uint64_t read64(uint64_t v, int l)
+    {
+        return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+    }
+    __device__ __forceinline__ static uint64_t scalarMin(uint64_t a, uint64_t b) { return havoc_search::costLess((Cost)b, (Cost)a) ? b : a; }      // non-negative keys
+
+    // A WHOLE considerPattern call (Search.hpp:1447-1482): its 4, 8 or 16 candidates one per lane, their SADs dealt round the wavefronts, ONE exchange.  The
+    // reference folds the candidates into `best` four at a time in order; the first of the cheapest, taken on strictly smaller cost, is what that leaves.
+    __device__ __forceinline__ int patternRing(Mv origin, const Mv *pattern, int n, int step, int dist, const havoc_search::LimitFullPelMv &limit, const havoc_search::PuContext &pu,
+                                               const havoc_search::Lambda lambda, havoc_search::MvCandidate &best)
+    {
+        static_assert(kWaves == 4, "a candidate group per wavefront");
+        GAP_IN();
+        const int count = n / step, c = lane & 15;
+        const Mv p = pattern[(c < count ? c : 0) * step];
+        int px = (origin.x + dist * p.x) / 4, py = (origin.y + dist * p.y) / 4;
+        px = min(max(px, (int)limit.lo.x), (int)limit.hi.x);
+        py = min(max(py, (int)limit.lo.y), (int)limit.hi.y);
+        sadTurn ^= 1;
+        for (int q = 0; 4 * q < count; ++q)
+        {
+            const int cc = (wave & 3) + 4 * q;
+            const int mx = __builtin_amdgcn_readlane(px, cc), my = __builtin_amdgcn_readlane(py, cc);
+            int v;
+            TICK(0, v = sadOne(mx, my, 0, 1));
+            if (lane == 0) x->ring[sadTurn][cc] = v;
+        }
+        __syncthreads();
+        const int sadv = sadShift<S>(x->ring[sadTurn][c < count ? c : 0]);
+        int32_t mvdPacked;
+        int second;
+        const Cost cost = laneCost(px, py, pu, lambda, sadv, mvdPacked, second);
+        const uint64_t key = quadMin(c < count ? (((uint64_t)cost << 4) | (uint32_t)c) : ~0ull);
+        uint64_t k = read64(key, 0);
+        if (count > 4) k = scalarMin(k, read64(key, 4));
+        if (count > 8) k = scalarMin(scalarMin(k, read64(key, 8)), read64(key, 12));
+        const int w = (int)(k & 15);
+        const Cost cw = (Cost)(k >> 4);
+        const bool improved = havoc_search::costLess(cw, best.cost);
+        if (improved)
+        {
+            best.cost = cw;
+            best.mv = havoc_search::shl2(Mv(int16_t(__builtin_amdgcn_readlane(px, w)), int16_t(__builtin_amdgcn_readlane(py, w))));
+            best.mvd = havoc_search::MotionField::unpack(__builtin_amdgcn_readlane(mvdPacked, w));
+            best.mvpFlag = __builtin_amdgcn_readlane(second, w);
+        }
+        GAP_OUT();
+        return improved ? 1 : 0;
+    }
+
+    // The raster refinement (Search.hpp:2268-2283): 25 x 28 (13 x 16 with the small window) positions five samples apart, all known before the first is
+    // measured.  Every wavefront takes a quarter of the SADs, ONE exchange, then the candidates are costed 64 at a time and the first of the cheapest wins.
+    __device__ __forceinline__ void rasterSweep(int rasterSearch, const havoc_search::LimitFullPelMv &limit, const havoc_search::PuContext &pu, const havoc_search::Lambda lambda,
+                                                havoc_search::MvCandidate &best)
+    {
+        GAP_IN();
+        const int rows = 2 * rasterSearch / 20 + 1, perRow = 4 * (2 * rasterSearch / 80 + 1), total = rows * perRow, first = -rasterSearch / 4;
+        const FastDiv fr(perRow);
+        for (int idx = wave; idx < total; idx += kWaves)
+        {
+            const int r = fr.div(idx), k = idx - r * perRow;
+            const int mx = min(max(first + 5 * k, (int)limit.lo.x), (int)limit.hi.x), my = min(max(first + 5 * r, (int)limit.lo.y), (int)limit.hi.y);
+            const int v = sadOne(mx, my, 0, 1);
+            if (lane == 0) x->raster[idx] = v;
+        }
+        __syncthreads();
+        uint64_t key = ~0ull;
+        for (int idx = lane; idx < total; idx += kWave)
+        {
+            const int r = fr.div(idx), k = idx - r * perRow;
+            const int px = min(max(first + 5 * k, (int)limit.lo.x), (int)limit.hi.x), py = min(max(first + 5 * r, (int)limit.lo.y), (int)limit.hi.y);
+            int32_t mvdPacked;
+            int second;
+            const Cost cost = laneCost(px, py, pu, lambda, sadShift<S>(x->raster[idx]), mvdPacked, second);
+            const uint64_t kk = ((uint64_t)cost << 10) | (uint32_t)idx;
+            key = kk < key ? kk : key;
+        }
+        key = quadMin(key);
+        uint64_t k = read64(key, 0);
+#pragma unroll
+        for (int l = 4; l < kWave; l += 4) k = scalarMin(k, read64(key, l));
+        const Cost cw = (Cost)(k >> 10);
+        if (havoc_search::costLess(cw, best.cost))
+        {   // the winner's vector, predictor and difference again, in scalar registers (once)
+            const int idx = (int)(k & 1023), r = fr.div(idx), kx = idx - r * perRow;
+            Mv full(int16_t(first + 5 * kx), int16_t(first + 5 * r));
+            limit(full);
+            const havoc_search::MvCandidate again(havoc_search::shl2(full), pu.mvp, pu.mvpRate);
+            best.cost = cw;
+            best.mv = again.mv;
+            best.mvd = again.mvd;
+            best.mvpFlag = again.mvpFlag;
+        }
+        __syncthreads();      // x->raster is free again before anyone writes it (the next raster sweep is a whole search away, but the barrier is cheap here)
+        GAP_OUT();
+    }
 #ifndef HAVOC_NO_SUBPEL_LANES
     // patternSearchOnce's costMv calls (Search.hpp:2001-2061, one iteration): the eight neighbours of `mv` at `scale` quarter samples in raster order (and `mv`
     // itself first when tryOrigin), a position per lane; returns the first of the cheapest neighbours if it beats the cost so far strictly, else -1

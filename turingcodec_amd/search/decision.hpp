@@ -224,6 +224,28 @@ HAVOC_HD inline bool foldPatternStep(View &v, const Mv (&mv)[4], Search &s, long
     }
     return improved;
 }
+//   int  patternRing(Mv origin, const Mv *pattern, int n, int step, int dist, limit, pu, lambda, best)  = a whole considerPattern (4, 8 or 16 candidates): 0 / 1
+//   void rasterSweep(int rasterSearch, limit, pu, lambda, best)                                         = the raster refinement's 175 (52) considerPattern calls
+template <class View, class Search>
+HAVOC_HD inline auto foldPatternRing(View &v, Mv origin, const Mv *pattern, int n, int step, int dist, Search &s, int)
+    -> decltype(v.patternRing(origin, pattern, n, step, dist, s.limit, s.pu, s.lambda, s.best), int())
+{
+    s.calls += n / (4 * step);
+    return v.patternRing(origin, pattern, n, step, dist, s.limit, s.pu, s.lambda, s.best);
+}
+template <class View, class Search>
+HAVOC_HD inline int foldPatternRing(View &, Mv, const Mv *, int, int, int, Search &, long) { return -1; }
+template <class View, class Search>
+HAVOC_HD inline auto foldRasterSweep(View &v, int rasterSearch, Search &s, int) -> decltype(v.rasterSweep(rasterSearch, s.limit, s.pu, s.lambda, s.best), bool())
+{
+    const int rows = 2 * rasterSearch / 20 + 1, groups = 2 * rasterSearch / 80 + 1;
+    s.calls += rows * groups;
+    v.rasterSweep(rasterSearch, s.limit, s.pu, s.lambda, s.best);
+    return true;
+}
+template <class View, class Search>
+HAVOC_HD inline bool foldRasterSweep(View &, int, Search &, long) { return false; }
+
 template <class View, class Search>
 HAVOC_HD inline auto foldSubpelStep(View &v, Search &s, int scale, bool tryOrigin, Mv mv, Mv mvd, Cost &bestCost, int) -> decltype(v.subpelStep(mv, mvd, scale, tryOrigin, s.lambda, bestCost), int())
 {
@@ -250,6 +272,8 @@ struct MotionSearch
     // Search.hpp:1447-1482.  origin in quarter units; pattern entries are multiplied by dist and divided by 4
     HAVOC_HD bool considerPattern(Mv origin, const Mv *pattern, int n, int step, int dist)
     {
+        const int whole = foldPatternRing(view, origin, pattern, n, step, dist, *this, 0);
+        if (whole >= 0) return whole != 0;
         bool improved = false;
         for (int j = 0; j < n; j += 4 * step)
         {
@@ -350,8 +374,9 @@ struct MotionSearch
         if (distBest > 5)
         {   // raster refinement: absolute positions, every 5th full sample
             static constexpr Mv line[4] = {{0, 0}, {1, 0}, {2, 0}, {3, 0}};
-            for (int my = -rasterSearch; my <= rasterSearch; my += 20)
-                for (int mx = -rasterSearch; mx <= rasterSearch; mx += 80) considerPattern(Mv(mx, my), line, 4, 1, 20);
+            if (!foldRasterSweep(view, rasterSearch, *this, 0))
+                for (int my = -rasterSearch; my <= rasterSearch; my += 20)
+                    for (int mx = -rasterSearch; mx <= rasterSearch; mx += 80) considerPattern(Mv(mx, my), line, 4, 1, 20);
             distBest = 5;
         }
         while (distBest > 0)
