@@ -245,6 +245,41 @@ struct LaneEmuView
         best.mvpFlag = flags[w];
         return 1;
     }
+    int startProbe(Mv mvQ, int forcedFlag, bool met, bool hexagon, const LimitFullPelMv &limit, const PuContext &pu, Lambda lambda, MvCandidate &best, Cost *costOut, int &calls)
+    {
+        static const Mv probe[13] = {{0, 0}, {-4, 0}, {0, 4}, {4, 0}, {0, -4}, {0, -8}, {8, -4}, {8, 4}, {0, 8}, {-8, 4}, {-8, -4}, {-8, 4}, {-8, -4}};
+        const int count = met ? (hexagon ? 13 : 5) : 1;
+        Mv pos[13], mvds[13];
+        int flags[13];
+        Cost cost[13];
+        for (int c = 0; c < count; ++c)
+        {   // everything is measured before anything is decided (the device: one exchange)
+            pos[c] = Mv(int16_t((mvQ.x + probe[c].x) / 4), int16_t((mvQ.y + probe[c].y) / 4));
+            if (c) limit(pos[c]);
+            cost[c] = laneCost(pos[c], pu, lambda, sadAtFull(pos[c]), mvds[c], flags[c]);
+        }
+        if (forcedFlag >= 0)
+        {
+            flags[0] = forcedFlag;
+            mvds[0] = mvQ - pu.mvp[forcedFlag];
+            cost[0] = rateOf(mvds[0]) + pu.mvpRate[forcedFlag] + lambda * sadAtFull(pos[0]);
+        }
+        ++calls;
+        if (costOut) *costOut = cost[0];
+        if (!(cost[0] < best.cost)) return 0;
+        auto take = [&](int w) { best.cost = cost[w]; best.mv = shl2(pos[w]); best.mvd = mvds[w]; best.mvpFlag = flags[w]; };
+        take(0);
+        if (!met) return 0;
+        auto firstMin = [&](int b, int e) { int w = b; for (int c = b + 1; c < e; ++c) if (cost[c] < cost[w]) w = c; return w; };
+        ++calls;
+        int w = firstMin(1, 5);
+        if (cost[w] < best.cost) { take(w); return 0; }
+        if (!hexagon) return 1;
+        calls += 2;
+        w = firstMin(5, 13);
+        if (cost[w] < best.cost) { take(w); return 0; }
+        return 1;
+    }
     void rasterSweep(int rasterSearch, const LimitFullPelMv &limit, const PuContext &pu, Lambda lambda, MvCandidate &best)
     {
         const int rows = 2 * rasterSearch / 20 + 1, perRow = 4 * (2 * rasterSearch / 80 + 1);

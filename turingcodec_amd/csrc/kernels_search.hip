@@ -672,6 +672,85 @@ struct DeviceView
         return improved ? 1 : 0;
     }
 
+#ifdef HAVOC_SEARCH_START_PROBE      // measured, no gain (1080p picture alone 16.9 ms either way; with the hexagon's eight measured speculatively as well: 17.2 ms): off
+    // A start candidate of fullPelMotionEstimation AND the early-termination probe around it (Search.hpp:2100-2196, the diamond and hexagon of :2112-2124): the
+    // candidate's SAD, the diamond's four and (coding units of 32 and more) the hexagon's eight measured TOGETHER -- the probe's positions depend only on the
+    // candidate's -- in one exchange, then decided in the reference's order: the candidate against `best`; if it wins and early termination is on, the diamond
+    // (any improvement: no termination), then the hexagon.  A typical search at reference distance 1 is this step and the two sub-sample steps.
+    __device__ __forceinline__ int startProbe(Mv mvQ, int forcedFlag, bool met, bool hexagon, const havoc_search::LimitFullPelMv &limit, const havoc_search::PuContext &pu,
+                                              const havoc_search::Lambda lambda, havoc_search::MvCandidate &best, Cost *costOut, int &calls)
+    {
+        static_assert(kWaves == 4, "a candidate group per wavefront");
+        static constexpr Mv probe[16] = {{0, 0}, {-4, 0}, {0, 4}, {4, 0}, {0, -4}, {0, -8}, {8, -4}, {8, 4}, {0, 8}, {-8, 4}, {-8, -4}, {-8, 4}, {-8, -4}, {0, 0}, {0, 0}, {0, 0}};
+        GAP_IN();
+        const int count = met ? 5 : 1, c = lane & 15;      // (the hexagon's eight measured here as well was tried: slower -- 3-4 SADs per wavefront before the exchange)
+        const Mv p = probe[c];
+        int px = (mvQ.x + p.x) / 4, py = (mvQ.y + p.y) / 4;
+        if (c)
+        {   // the candidate itself is not limited here (the zero vector never is; the others were by the caller)
+            px = min(max(px, (int)limit.lo.x), (int)limit.hi.x);
+            py = min(max(py, (int)limit.lo.y), (int)limit.hi.y);
+        }
+        sadTurn ^= 1;
+        for (int q = 0; 4 * q < count; ++q)
+        {
+            const int cc = (wave & 3) + 4 * q;
+            if (cc < count)
+            {
+                const int mx = __builtin_amdgcn_readlane(px, cc), my = __builtin_amdgcn_readlane(py, cc);
+                int v;
+                TICK(0, v = sadOne(mx, my, 0, 1));
+                if (lane == 0) x->ring[sadTurn][cc] = v;
+            }
+        }
+        __syncthreads();
+        const int sadv = sadShift<S>(x->ring[sadTurn][c < count ? c : 0]);
+        int32_t mvdPacked;
+        int second;
+        Cost cost = laneCost(px, py, pu, lambda, sadv, mvdPacked, second);
+        if (forcedFlag >= 0 && c == 0)
+        {   // a predictor's own start candidate: costed with THAT predictor
+            const Mv mvd = mvQ - pu.mvp[forcedFlag];
+            cost = havoc_search::rateOf(mvd) + pu.mvpRate[forcedFlag] + lambda * sadv;
+            mvdPacked = havoc_search::MotionField::pack(mvd);
+            second = forcedFlag;
+        }
+        auto take = [&](int w, Cost cw) {
+            best.cost = cw;
+            best.mv = havoc_search::shl2(Mv(int16_t(__builtin_amdgcn_readlane(px, w)), int16_t(__builtin_amdgcn_readlane(py, w))));
+            best.mvd = havoc_search::MotionField::unpack(__builtin_amdgcn_readlane(mvdPacked, w));
+            best.mvpFlag = __builtin_amdgcn_readlane(second, w);
+        };
+        ++calls;
+        const Cost c0 = (Cost)read64((uint64_t)cost, 0);
+        if (costOut) *costOut = c0;
+        int ends = 0;
+        if (havoc_search::costLess(c0, best.cost))
+        {
+            take(0, c0);
+            best.mv = mvQ;
+            if (met)
+            {
+                ++calls;
+                const uint64_t kd = quadMin(c >= 1 && c <= 4 ? (((uint64_t)cost << 4) | (uint32_t)c) : ~0ull);
+                const uint64_t d = scalarMin(read64(kd, 0), read64(kd, 4));
+                if (havoc_search::costLess((Cost)(d >> 4), best.cost))
+                    take((int)(d & 15), (Cost)(d >> 4));
+                else if (!hexagon)
+                    ends = 1;
+                else
+                {   // the hexagon around the candidate as a step of its own (coding units of 32 and more whose diamond found nothing)
+                    static constexpr Mv hexagonPattern[8] = {{0, -8}, {8, -4}, {8, 4}, {0, 8}, {-8, 4}, {-8, -4}, {-8, 4}, {-8, -4}};
+                    calls += 2;
+                    ends = patternRing(best.mv, hexagonPattern, 8, 1, 1, limit, pu, lambda, best) ? 0 : 1;
+                }
+            }
+        }
+        GAP_OUT();
+        return ends;
+    }
+#endif
+
     // The raster refinement (Search.hpp:2268-2283): 25 x 28 (13 x 16 with the small window) positions five samples apart, all known before the first is
     // measured.  Every wavefront takes a quarter of the SADs, ONE exchange, then the candidates are costed 64 at a time and the first of the cheapest wins.
     __device__ __forceinline__ void rasterSweep(int rasterSearch, const havoc_search::LimitFullPelMv &limit, const havoc_search::PuContext &pu, const havoc_search::Lambda lambda,

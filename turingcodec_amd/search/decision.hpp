@@ -246,6 +246,18 @@ HAVOC_HD inline auto foldRasterSweep(View &v, int rasterSearch, Search &s, int) 
 template <class View, class Search>
 HAVOC_HD inline bool foldRasterSweep(View &, int, Search &, long) { return false; }
 
+//   int  startProbe(Mv mvQuarter, int forcedFlag, bool met, bool hexagon, limit, pu, lambda, best, Cost *costOut, int &calls)
+//                                                   = a start candidate of fullPel AND the early-termination probe around it (its SAD, the diamond's four and the
+//                                                     hexagon's eight in one exchange): 1 = the search ends here
+template <class View, class Search>
+HAVOC_HD inline auto foldStartProbe(View &v, Mv mv, int forcedFlag, Cost *costOut, Search &s, int)
+    -> decltype(v.startProbe(mv, forcedFlag, s.sp.met, s.pu.cuLog2Size >= 5, s.limit, s.pu, s.lambda, s.best, costOut, s.calls), int())
+{
+    return v.startProbe(mv, forcedFlag, s.sp.met, s.pu.cuLog2Size >= 5, s.limit, s.pu, s.lambda, s.best, costOut, s.calls);
+}
+template <class View, class Search>
+HAVOC_HD inline int foldStartProbe(View &, Mv, int, Cost *, Search &, long) { return -1; }
+
 template <class View, class Search>
 HAVOC_HD inline auto foldSubpelStep(View &v, Search &s, int scale, bool tryOrigin, Mv mv, Mv mvd, Cost &bestCost, int) -> decltype(v.subpelStep(mv, mvd, scale, tryOrigin, s.lambda, bestCost), int())
 {
@@ -309,44 +321,49 @@ struct MotionSearch
         return view.sad(full.x, full.y);
     }
 
+    // one start candidate of fullPel (Search.hpp:2100-2196: the zero vector, the two predictors, the previous 2Nx2N vector): its cost -- with predictor `forcedFlag`,
+    // or the cheaper of the two when that is -1 --, and if it improves `best` and early termination is on, the probe around it.  true = the search ends here
+    HAVOC_HD bool startCandidate(Mv mv, int forcedFlag, Cost *costOut)
+    {
+        const int whole = foldStartProbe(view, mv, forcedFlag, costOut, *this, 0);
+        if (whole >= 0) return whole != 0;
+        MvCandidate candidate;
+        if (forcedFlag < 0)
+            candidate = MvCandidate(mv, pu.mvp, pu.mvpRate);
+        else
+        {
+            candidate.mvpFlag = forcedFlag;
+            candidate.mv = mv;
+            candidate.mvd = mv - pu.mvp[forcedFlag];
+            candidate.cost = rateOf(candidate.mvd);
+            candidate.cost += pu.mvpRate[forcedFlag];
+        }
+        candidate.cost += lambda * sadAt(shr2(mv));
+        if (costOut) *costOut = candidate.cost;
+        const bool better = best.consider(candidate);
+        return better && sp.met && metTriggered();
+    }
+
     // Search.hpp:2060-2336.  Returns true when mvPreviousInteger2Nx2N is to be updated with best.mv
     HAVOC_HD bool fullPel(Cost costMvdZero[2])
     {
         const int searchWindow = sp.smallSearchWindow ? 32 : 64;
         const int maxCounter = sp.smallSearchWindow ? 2 : 3;
         const int rasterSearch = sp.smallSearchWindow ? 120 : 240;
-        {
-            // zero vector as a starting point (the position is NOT limited)
-            MvCandidate candidate(Mv(0, 0), pu.mvp, pu.mvpRate);
-            candidate.cost += lambda * sadAt(Mv(0, 0));
-            const bool better = best.consider(candidate);
-            if (better && sp.met && metTriggered()) return false;
-        }
-        MvCandidate candidate;
+        // zero vector as a starting point (the position is NOT limited)
+        if (startCandidate(Mv(0, 0), -1, nullptr)) return false;
         HAVOC_UNROLL
-        for (candidate.mvpFlag = 0; candidate.mvpFlag < 2; ++candidate.mvpFlag)
-        {
-            const Mv predicted = pu.mvp[candidate.mvpFlag];
-            candidate.mv = shr2(Mv(int16_t(predicted.x + 1), int16_t(predicted.y + 1)));
-            limit(candidate.mv);
-            candidate.mv = shl2(candidate.mv);
-            candidate.mvd = candidate.mv - predicted;
-            candidate.cost = rateOf(candidate.mvd);
-            candidate.cost += pu.mvpRate[candidate.mvpFlag];
-            candidate.cost += lambda * sadAt(shr2(candidate.mv));
-            costMvdZero[candidate.mvpFlag] = candidate.cost;
-            const bool better = best.consider(candidate);
-            if (better && sp.met && metTriggered()) return false;
+        for (int flag = 0; flag < 2; ++flag)
+        {   // the two predictors, rounded to full samples; costed with THEIR predictor (not the cheaper of the two)
+            Mv mv = shr2(Mv(int16_t(pu.mvp[flag].x + 1), int16_t(pu.mvp[flag].y + 1)));
+            limit(mv);
+            if (startCandidate(shl2(mv), flag, &costMvdZero[flag])) return false;
         }
         if (!pu.part2Nx2N || pu.cqtDepth != 0)
         {
             Mv mv = shr2(pu.mvPrevious2Nx2N);
             limit(mv);
-            mv = shl2(mv);
-            MvCandidate c(mv, pu.mvp, pu.mvpRate);
-            c.cost += lambda * sadAt(shr2(c.mv));
-            const bool better = best.consider(c);
-            if (better && sp.met && metTriggered()) return false;
+            if (startCandidate(shl2(mv), -1, nullptr)) return false;
         }
 
         // HM style "star" search
