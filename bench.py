@@ -896,7 +896,7 @@ def valu_busy_from_profiles(group, S):
 
 
 def _kernel_prefix(group, S):
-    return {"sad4": f"k_sad<{S}, 4>", "sad": f"k_sad<{S}, 1>", "interp_planes": "k_interp_planes", "intra_satd35": "k_intra_satd35<",
+    return {"sad4": f"k_sad<{S}, 4", "sad": f"k_sad<{S}, 1", "interp_planes": "k_interp_planes", "intra_satd35": "k_intra_satd35<",
               "intra": "k_intra<", "residual": "k_residual<", "transform": "k_transform<", "quantize_inverse": "k_quantize_inverse",
               "inverse_transform_add": "k_inverse_transform<", "ssd": "k_ssd<", "subtract_bi": "k_subtract_bi<",
               "subpel_satd": "k_subpel_satd<", "rdoq": "k_rdoq_", "deblock": "k_deblock<"}.get(group)
