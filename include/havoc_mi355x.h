@@ -530,7 +530,9 @@ typedef struct
 } havoc_mi355x_intra_choice;       /* 40 bytes; = havoc_intra_rd_result */
 /* Search.hpp:55-98, 143-190: costs = rate offsets + lambda_q16 * d_satd35[35 * i + mode] (64-bit), then the order the modes are refined in:
  * d_order[HAVOC_MI355X_INTRA_MAX_ORDER * i + k], k < d_count[i]; d_slot[i] = the partition's first candidate slot;
- * d_total[0] = slots handed out, d_total[1] != 0 if some partition wanted more than HAVOC_MI355X_INTRA_MAX_ORDER (its order is cut). */
+ * d_total[0] = slots handed out; d_total[1]: bit 0 = some partition wanted more than HAVOC_MI355X_INTRA_MAX_ORDER (its order is cut), bit 1 = some record was out of
+ * range (a mode outside 0..34, neighbour_modes outside 0..3, max_refine < 1: brought into range, nothing is written outside the partition's slots) -- results are
+ * then not to be used. */
 int havoc_mi355x_intra_order(havoc_mi355x_ctx *ctx, const int32_t *d_satd35, const havoc_mi355x_intra_mpm *d_mpm, int n, int32_t lambda_q16, int32_t *d_order,
                              int32_t *d_count, int32_t *d_slot, int32_t *d_total);
 /* the job records of every candidate c = d_slot[i] + k: prediction into piece c (n x n, stride n) from the filtered / unfiltered neighbours as
@@ -539,7 +541,11 @@ int havoc_mi355x_intra_expand(havoc_mi355x_ctx *ctx, const havoc_mi355x_intra_se
                               const int32_t *d_ctx_index, int n, int log2TrafoSize, int quant_scale, int quant_shift, int inv_scale, int lambda_q16, int sdh_factor, int sdh,
                               havoc_mi355x_intra_job *d_intra_jobs, havoc_mi355x_tu_fused_job *d_tu_jobs, havoc_mi355x_rdoq_job *d_rdoq_jobs, int32_t *d_stat_jobs,
                               int32_t *d_owner);
-/* Search.hpp:143-255: the first candidate with the smallest   mode rate + (1 + (cbf ? 2 * nonzero + sum_abs : 0) << 16) + reciprocal_lambda_q16 * ssd;
+/* Search.hpp:143-255: the first candidate with the smallest   mode rate + (1 + (cbf ? 2 * nonzero + sum_abs : 0) << 16) + reciprocal_lambda_q16 * ssd.
+ * The RATE here is a stand-in, not the reference's: its RD stage charges every mode -- candModeList[0] included -- the bits EstimateRateLuma measures in the CABAC state of
+ * that moment (prev_intra_luma_pred_flag, mpm_idx / rem_intra_luma_pred_mode, the residual), where this uses the first stage's offsets (rate_a_minus_c is 0 rate for
+ * candModeList[0]) and a count of levels.  The order of evaluation, the Q16 arithmetic and the strict comparison are the reference's (pinned with the encoder's own rates:
+ * tests/test_trace_pin.py); a caller with an entropy coder supplies real rates through the host form (search/tu_decision.hpp: decideIntraRd with a rate functor);
  * d_final[i] = the champion's tu job with rec_off = i << (2 * log2TrafoSize) (the block it reconstructs into) */
 int havoc_mi355x_intra_decide(havoc_mi355x_ctx *ctx, const havoc_mi355x_intra_mpm *d_mpm, const int32_t *d_order, const int32_t *d_count, const int32_t *d_slot,
                               const int32_t *d_cbf, const uint32_t *d_ssd, const int32_t *d_stats, const havoc_mi355x_tu_fused_job *d_tu_jobs, int n, int log2TrafoSize,

@@ -41,7 +41,17 @@ __global__ __launch_bounds__(64) void k_intra_order(const int32_t *__restrict__ 
     __shared__ int64_t costs[35][64];      // [mode][lane]
     const int lane = threadIdx.x, i = blockIdx.x * 64 + lane;
     if (i >= n) return;
-    const IntraCtx c = ictx[i];
+    IntraCtx c = ictx[i];
+    // the records come from device memory: a mode outside 0..34 or more than three neighbour modes would index past costs[] / cand[] -- flagged
+    // (total[1] bit 1) and brought into range, so nothing is written outside the partition's own slots
+    const bool bad = (unsigned)c.cand[0] > 34u || (unsigned)c.cand[1] > 34u || (unsigned)c.cand[2] > 34u || (unsigned)c.neighbourModes > 3u || c.maxRefine < 1;
+    if (bad)
+    {
+        atomicOr(total + 1, 2);
+        for (int k = 0; k < 3; ++k) c.cand[k] = min(max(c.cand[k], 0), 34);
+        c.neighbourModes = min(max(c.neighbourModes, 0), 3);
+        c.maxRefine = max(c.maxRefine, 1);
+    }
     for (int m = 0; m < 35; ++m) costs[m][lane] = 0;
     costs[c.cand[0]][lane] = c.rateA;
     costs[c.cand[1]][lane] = c.rateB;
@@ -132,7 +142,9 @@ __global__ __launch_bounds__(256) void k_intra_decide(const IntraCtx *__restrict
         }
     }
     out[i] = r;
-    TuJob f = tj[base + max(0, r.index)];
+    // a partition without candidates (count 0: max_refine < 1, which the host wrapper refuses) has no champion: out[i].mode stays -1 and its final job reads the
+    // first slots of the buffers instead of a slot that belongs to another partition or lies past the allocation
+    TuJob f = count[i] > 0 ? tj[base + max(0, r.index)] : TuJob{0, 0, 0, 0};
     f.rec_off = i << (2 * log2);
     fin[i] = f;
 }

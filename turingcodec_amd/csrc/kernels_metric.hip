@@ -48,7 +48,7 @@ __device__ __forceinline__ void sad_block(const char *src, long ssb, const char 
     const int y0 = lane / cpr;
     const int xb = (lane - y0 * cpr) * CB;
     if (y0 >= rpi) return;              // lanes beyond rpi*cpr idle (cpr = 3, 6)
-#pragma unroll(U)                       // several rows' loads in flight: the loop is latency-, not issue-bound
+#pragma unroll U                         // several rows' loads in flight: the loop is latency-, not issue-bound
     for (int y = y0; y < h; y += rpi)
     {
         const char *s = src + y * ssb + xb;
