@@ -1184,6 +1184,11 @@ def decision_path(args, Havoc, res, bit_depth, qp, pictures, seconds=1.5, keep=N
     t0 = time.perf_counter()
     solo.intra_decisions()
     t_intra = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    solo.merge_candidates(field0)
+    solo.chroma_chain(field0)
+    solo.hv.sync()
+    t_merge = time.perf_counter() - t0
     def throughput(count, secs):
         for dp in ctxs[:count]:
             dp.threads = max(1, cores // count)
@@ -1228,7 +1233,8 @@ def decision_path(args, Havoc, res, bit_depth, qp, pictures, seconds=1.5, keep=N
            "one_picture_alone_ms": round(min(lat) * 1e3, 3),
            "one_picture_alone_split_ms": {"phase_planes": round(t_planes * 1e3, 3), "searches_in_wavefront_order": round(t_search * 1e3, 3),
                                           "prediction_and_transform_tree_decisions": round(t_chain * 1e3, 3),
-                                          "intra_35_mode_stage_and_rd_refinement": round(t_intra * 1e3, 3)},
+                                          "intra_35_mode_stage_and_rd_refinement": round(t_intra * 1e3, 3),
+                                          "merge_candidates_three_planes_and_chroma_tu_chain": round(t_merge * 1e3, 3)},
            "searches_per_picture": int(2 * len(solo.pus)), "ctus": solo.cx * solo.cy,
            "reference_distance": max(1, args.decision_distance), "loop_calls_per_search": round(float(res0["calls"].mean()), 1),
            "bi_directional_refinements_per_picture": bi_count,
@@ -1254,9 +1260,10 @@ def decision_path(args, Havoc, res, bit_depth, qp, pictures, seconds=1.5, keep=N
                    "2.5 - 3 x longer: see the distance-4 entry): 2 x 15 phase planes; every PU's uni-directional search in both lists, CTUs in WPP wavefront order (CTU (x, y) after "
                    "(x + 1, y - 1)), predictors of a PU = the vectors decided for its left / upper neighbours, mvPreviousInteger2Nx2N handed along the CTU "
                    "row (turingcodec_amd/search/picture_order.hpp), then the bi-directional refinement of every PU (searchBi: list 0 against list 1's "
-                   "vector, list 1 against list 0's refined one; device search only); then prediction at the chosen vectors and the residual-quadtree decision of every inter unit (both tree depths of "
+                   "vector, list 1 against list 0's refined one; device search only); the five spatial merge candidates of every unit predicted bi-directionally in three planes and "
+                   "measured (SATD; vectors from the decided field, Mvp.h's derivation out of scope); then prediction at the chosen vectors and the residual-quadtree decision of every inter unit (both tree depths of "
                    "every 32x32 unit through residual + DCT -> RDOQ -> IQ + IDCT + add -> SSD in one chain per transform size, decisions from 16 bytes per "
-                   "candidate, chosen candidates reconstructed into the picture; turingcodec_amd/search/tu_decision.hpp), boundary strengths derived on "
+                   "candidate, chosen candidates reconstructed into the picture; turingcodec_amd/search/tu_decision.hpp), the chroma planes' prediction (4-tap) and TU chain at the same vectors, boundary strengths derived on "
                    "the device, deblocking, padding; and the picture's intra candidates (42 partitions per CTU: 35-mode SATD stage, then every candidate "
                    "mode of the refinement order reconstructed through T -> RDOQ -> IT and the champion picked; neighbours from the source picture, not "
                    "from the preceding partition's reconstruction). Not in it: the mode decision between the searched PUs (uni / bi / merge) and between "

@@ -551,6 +551,32 @@ int havoc_mi355x_intra_decide(havoc_mi355x_ctx *ctx, const havoc_mi355x_intra_mp
                               const int32_t *d_cbf, const uint32_t *d_ssd, const int32_t *d_stats, const havoc_mi355x_tu_fused_job *d_tu_jobs, int n, int log2TrafoSize,
                               int32_t reciprocal_lambda_q16, havoc_mi355x_intra_choice *d_out, havoc_mi355x_tu_fused_job *d_final);
 
+/* ---- job tables made on the device from the decided motion field (round 4; csrc/kernels_decide.hip) ----
+ * Not reference primitives: the reference builds its prediction calls inline from the vectors it has just decided (predictInter, turing/Search.hpp:1659-1706;
+ * searchMergeModes :1754-1768).  A batch client whose searches leave the motion field in device memory (havoc_mi355x_search_picture_uni: d_field) gets the
+ * job tables of the next launches here, so nothing of the field crosses the link.  Pictures: the planes of one component lie at multiples of *_plane_elems in
+ * ONE allocation -- luma: source, list 0, list 1; chroma: Cb source, list 0, list 1, Cr source, list 0, list 1 -- with *_pad samples of border (>= range + 4). */
+typedef struct {
+    int32_t pic_width, pic_height;
+    int32_t range;                 /* vectors are limited so that a block stays within `range` samples of the picture (LimitFullPelMv: CtbSizeY = 64) */
+    int32_t field_cw;              /* cells per row of d_field = (pic_width + 3) / 4 */
+    int32_t luma_stride, luma_pad, luma_plane_elems;
+    int32_t chroma_stride, chroma_pad, chroma_plane_elems;
+    int32_t reserved[2];
+} havoc_mi355x_field_layout;       /* 48 bytes */
+/* the five spatial merge candidates (HEVC 8.5.3.2.3 positions A1, B1, B0, A0, B2; the vectors of both lists decided there, zero outside the picture; Mvp.h's
+ * pruning / temporal candidate are the caller's) of n square units of one size as HavocPredBi jobs in three planes: job 5 * i + k, dst_off = job * size^2
+ * (chroma: (size / 2)^2), d_vectors[job][list] = (x, y). */
+int havoc_mi355x_merge_jobs(havoc_mi355x_ctx *ctx, const havoc_mi355x_field_layout *layout, const int16_t *d_field, const int32_t *d_x0, const int32_t *d_y0, int n, int log2_size,
+                            havoc_mi355x_pred_bi_job *d_luma_jobs, havoc_mi355x_pred_bi_job *d_cb_jobs, havoc_mi355x_pred_bi_job *d_cr_jobs, int16_t *d_vectors);
+/* the merge decision of n units from the SATDs of their 5 candidates in three planes (job 5 * i + k): d_cost[5 * i + k] = (min(k + 1, 4) << 16) + (satdY + satdCb + satdCr)
+ * * reciprocal_sqrt_lambda_q16 (measurePuCost, turing/Search.hpp:1659-1706, with a stand-in for the CABAC rate of the merge index), d_best[i] = the first of the cheapest. */
+int havoc_mi355x_merge_decide(havoc_mi355x_ctx *ctx, const int32_t *d_satd_y, const int32_t *d_satd_cb, const int32_t *d_satd_cr, int n, int64_t reciprocal_sqrt_lambda_q16,
+                              int64_t *d_cost, int32_t *d_best);
+/* HavocPredUni jobs of n square units at the vector decided for `list` at their origin: plane 0 = luma, 1 / 2 = Cb / Cr (half size, eighth-sample phases) */
+int havoc_mi355x_pred_jobs(havoc_mi355x_ctx *ctx, const havoc_mi355x_field_layout *layout, const int16_t *d_field, int list, const int32_t *d_x0, const int32_t *d_y0, int n,
+                           int log2_size, int plane, const int32_t *d_dst_off, havoc_mi355x_pred_uni_job *d_jobs);
+
 /* ---- a picture's uni-directional motion searches with the decision loops ON THE DEVICE (csrc/kernels_search.hip) ----
  * The reference runs searchMotionUni (turing/Search.hpp:1317-1355: integer search :2060-2336, sub-sample refinement :2010-2061, 2340-2358) per
  * prediction unit and list through the havoc_sad / havoc_sad_multiref / HavocPredUni / hadamard_satd tables.  Here the same loops (restated in

@@ -48,6 +48,78 @@ def _host_chain(R, dp, field):
     return out, recon
 
 
+def _pu_satd(R, a, ao, sa, b, bo, sb, w, h):
+    """measureSatd (turing/Measure.h:97-135) through the reference's tile functions: 8x8 tiles where both sides are multiples of 8, else 4x4"""
+    n = 8 if (w | h) % 8 == 0 else 4
+    return sum(R.satd(a, ao + y * sa + x, sa, b, bo + y * sb + x, sb, n) for y in range(0, h, n) for x in range(0, w, n))
+
+
+def _check_merge_and_chroma(R, dp, field):
+    """round 4: the merge candidates' three-plane SATD costs and the chroma TU chain of the step against the reference's own
+    HavocPredBi / HavocPredUni (8- and 4-tap), Hadamard tiles, transform tables and Rdoq.cpp, unit by unit on the host"""
+    from turingcodec_amd.workload import dequant_params, quant_params
+    hv, BD, K, PAD, CP = dp.hv, dp.bd, dp.MERGE_CANDIDATES, dp.PAD, dp.PAD // 2
+    u, mg = dp.units, dp.merge
+    assert np.array_equal(mg["vectors"], dp.merge_vectors(field)) and (mg["vectors"] != 0).any()
+    luma = np.concatenate([np.pad(p, (0, dp.pe - dp.n)) for p in dp.host_planes])
+    chroma = np.concatenate([np.pad(p, (0, dp.cpe - dp.cn)) for p in dp.host_chroma])
+    lam_q16 = int(float(dp.params.reciprocal_sqrt_lambda) * 65536 + 0.5)
+    checked = 0
+    for i in range(0, len(u), max(1, len(u) // 80)):      # a sample of the units, all five candidates, all three planes
+        x0, y0, nn = int(u["x0"][i]), int(u["y0"][i]), 1 << int(u["log2_size"][i])
+        costs = []
+        for k in range(K):
+            (ax, ay), (bx, by) = (int(v) for v in mg["vectors"][i, k, 0]), (int(v) for v in mg["vectors"][i, k, 1])
+            want = []
+            for plane in range(3):
+                c = plane > 0
+                size, stride, pad, pe, buf = (nn // 2, dp.cstride, CP, dp.cpe, chroma) if c else (nn, dp.stride, PAD, dp.pe, luma)
+                px, py, sh, fm, taps = (x0 // 2, y0 // 2, 3, 7, 4) if c else (x0, y0, 2, 3, 8)
+                first = 3 * (plane - 1) if c else 0
+                at = lambda k_, mx, my: (first + k_) * pe + (py + (my >> sh) + pad) * stride + px + (mx >> sh) + pad
+                pred = np.zeros(size * size, buf.dtype)
+                R.pred_bi(pred, 0, size, buf, at(1, ax, ay), at(2, bx, by), stride, size, size, ax & fm, ay & fm, bx & fm, by & fm, BD, taps)
+                want.append(_pu_satd(R, buf, first * pe + (py + pad) * stride + px + pad, stride, pred, 0, size, size, size))
+            assert list(mg["satd"][i, k]) == want, (i, k, list(mg["satd"][i, k]), want)
+            costs.append((min(k + 1, 4) << 16) + sum(want) * lam_q16)
+        assert list(mg["cost"][i]) == costs and int(mg["best"][i]) == int(np.argmin(costs)), i
+        checked += 1
+    assert checked >= 40 and len(np.unique(mg["best"])) > 1
+    # the chroma chain: every unit's Cb and Cr block
+    hw, hh = dp.W // 2, dp.H // 2
+    cpred, crecon = np.zeros(2 * hw * hh, luma.dtype), np.zeros(2 * dp.cpe, luma.dtype)
+    coded = 0
+    for g in dp.cgroups:
+        cl, cn, comp, m = g["log2"], g["cn"], g["comp"], g["m"]
+        qs, qshift, _ = quant_params(dp.qp, cl, BD, False)
+        inv, dshift = dequant_params(dp.qp, cl, BD)
+        coef, level, deq = np.zeros(m * cn * cn, np.int16), np.zeros(m * cn * cn, np.int16), np.zeros(m * cn * cn, np.int16)
+        cbf, ssd = np.zeros(m, np.int32), np.zeros(m, np.uint32)
+        rows = np.arange(cn)[:, None]
+        for j in range(m):
+            ui = g["sel"][j]
+            qx, qy = (int(v) for v in field[0, int(u["y0"][ui]) >> 2, int(u["x0"][ui]) >> 2])
+            x0, y0 = int(u["x0"][ui]) // 2, int(u["y0"][ui]) // 2
+            so = 3 * (comp - 1) * dp.cpe + (y0 + CP) * dp.cstride + x0 + CP
+            po = (comp - 1) * hw * hh + y0 * hw + x0
+            ro = (comp - 1) * dp.cpe + (y0 + CP) * dp.cstride + x0 + CP
+            R.pred_uni(cpred, po, hw, chroma, (3 * (comp - 1) + 1) * dp.cpe + (y0 + (qy >> 3) + CP) * dp.cstride + x0 + (qx >> 3) + CP, dp.cstride, cn, cn, qx & 7, qy & 7, BD, 4)
+            r16 = chroma[so + rows * dp.cstride + np.arange(cn)].astype(np.int16) - cpred[po + rows * hw + np.arange(cn)].astype(np.int16)
+            R.transform(coef, j * cn * cn, np.ascontiguousarray(r16).ravel(), 0, cn, cl, 0, BD)
+            ctu = (int(u["y0"][ui]) // 64) * dp.cx + int(u["x0"][ui]) // 64
+            lv, c = R.rdoq(np.ascontiguousarray(coef[j * cn * cn:(j + 1) * cn * cn]), cl, comp, 0, 0, 1, qs, qshift, inv, BD, dp.lam, dp.rdoq_states[ctu])
+            level[j * cn * cn:(j + 1) * cn * cn] = lv
+            cbf[j] = c
+            R.quantize_inverse(deq, j * cn * cn, level, j * cn * cn, inv, dshift, cn * cn)
+            R.inverse_transform_add(crecon, ro, dp.cstride, cpred, po, hw, deq, j * cn * cn, cl, 0, BD)
+            ssd[j] = R.ssd(chroma, so, dp.cstride, crecon, ro, dp.cstride, cn, cn)
+        for name, want in (("coef", coef), ("level", level), ("cbf", cbf), ("ssd", ssd)):
+            assert np.array_equal(hv.down(g[name], want.dtype), want), (cl, comp, name)
+        coded += int((cbf != 0).sum())
+    assert np.array_equal(hv.down(dp.cpred, luma.dtype), cpred) and np.array_equal(hv.down(dp.crecon, luma.dtype), crecon)
+    return checked, coded
+
+
 @pytest.mark.parametrize("res,BD,qp", [((416, 240), 8, 32), ((640, 360), 10, 27), ((640, 360), 8, 22)])
 def test_decision_step_equals_the_reference_functions(res, BD, qp):
     from turingcodec_amd.decisions import DecisionPicture
@@ -65,6 +137,9 @@ def test_decision_step_equals_the_reference_functions(res, BD, qp):
         assert np.array_equal(dp.bi_results[k], exp_bi[k]), k
     assert (dp.bi_results["calls"] > 0).mean() > 0.9
     assert stats.launches < len(got) and stats.steps == dp.cx + 2 * (dp.cy - 1)
+    # the merge candidates (three planes, bi-predictive) and the chroma TU chain of the step against the reference's functions
+    checked, coded = _check_merge_and_chroma(reflibs.Reference(), dp, exp_field)
+    print(res, BD, qp, "merge units checked", checked, "coded chroma blocks", coded)
     # the residual-quadtree decisions of the step (both depths of every unit in one chain per transform size) against the same decisions
     # taken one block at a time through the reference's tables + Rdoq.cpp, on the prediction the device made from the decided vectors
     pred = hv.down(dp.pred, dp.dt).copy()

@@ -40,6 +40,9 @@ hipError_t launch_intra_expand(hipStream_t, const void *, const int32_t *, const
                                void *, int32_t *, int32_t *);
 hipError_t launch_intra_decide(hipStream_t, const void *, const int32_t *, const int32_t *, const int32_t *, const int32_t *, const uint32_t *, const int32_t *, const void *, int,
                                int, int32_t, void *, void *);
+hipError_t launch_merge_jobs(hipStream_t, const void *, const int16_t *, const int32_t *, const int32_t *, int, int, void *, void *, void *, int16_t *);
+hipError_t launch_pred_jobs(hipStream_t, const void *, const int16_t *, int, const int32_t *, const int32_t *, int, int, int, const int32_t *, void *);
+hipError_t launch_merge_decide(hipStream_t, const int32_t *, const int32_t *, const int32_t *, int, int64_t, int64_t *, int32_t *);
 size_t search_workspace_bytes(int width, int height);
 hipError_t launch_search_list(hipStream_t, int S, const havoc_mi355x_search_params *, const void *, long, long, const void *, long, long, const void *, long, long, const void *,
                               int, void *);
@@ -587,6 +590,42 @@ int havoc_mi355x_search_picture_uni(havoc_mi355x_ctx *ctx, int S, const havoc_mi
     return check(launch_search_picture_uni(LS(ctx), S, params, mvp_rate, d_src, (long)src_origin, src_stride, d_ref, ro, ref_stride, d_phase, plane_elems, po, d_pus,
                                            d_ctu_first, ctus_x, ctus_y, n_pus, d_out, d_out_bi, d_field, d_work, step_launches),
                  "search_picture_uni");
+}
+
+static bool layout_ok(const havoc_mi355x_field_layout *l)
+{
+    return l && l->pic_width > 0 && l->pic_height > 0 && l->range >= 0 && l->field_cw >= (l->pic_width + 3) / 4 && l->luma_stride >= l->pic_width + 2 * l->luma_pad &&
+           l->chroma_stride >= l->pic_width / 2 + 2 * l->chroma_pad && l->luma_pad >= l->range + 4 && 2 * l->chroma_pad >= l->range + 4;
+}
+
+int havoc_mi355x_merge_jobs(havoc_mi355x_ctx *ctx, const havoc_mi355x_field_layout *layout, const int16_t *d_field, const int32_t *d_x0, const int32_t *d_y0, int n, int log2_size,
+                            havoc_mi355x_pred_bi_job *d_luma_jobs, havoc_mi355x_pred_bi_job *d_cb_jobs, havoc_mi355x_pred_bi_job *d_cr_jobs, int16_t *d_vectors)
+{
+    REQUIRE_CTX(); REQUIRE(n >= 0, "n < 0"); REQUIRE(log2_size >= 3 && log2_size <= 6, "log2_size must be 3..6");
+    REQUIRE(layout_ok(layout), "field layout: sizes, strides or borders do not fit");
+    REQUIRE(n == 0 || (d_field && d_x0 && d_y0 && d_luma_jobs && d_cb_jobs && d_cr_jobs && d_vectors), "null device pointer");
+    REQUIRE(((uintptr_t)d_field & 3) == 0 && ((uintptr_t)d_vectors & 3) == 0, "d_field and d_vectors must be 4-byte aligned");
+    return check(launch_merge_jobs(LS(ctx), layout, d_field, d_x0, d_y0, n, log2_size, d_luma_jobs, d_cb_jobs, d_cr_jobs, d_vectors), "merge_jobs");
+}
+
+int havoc_mi355x_merge_decide(havoc_mi355x_ctx *ctx, const int32_t *d_satd_y, const int32_t *d_satd_cb, const int32_t *d_satd_cr, int n, int64_t reciprocal_sqrt_lambda_q16,
+                              int64_t *d_cost, int32_t *d_best)
+{
+    REQUIRE_CTX(); REQUIRE(n >= 0, "n < 0"); REQUIRE(reciprocal_sqrt_lambda_q16 >= 0, "reciprocal_sqrt_lambda_q16 < 0");
+    REQUIRE(n == 0 || (d_satd_y && d_satd_cb && d_satd_cr && d_cost && d_best), "null device pointer");
+    REQUIRE(((uintptr_t)d_cost & 7) == 0, "d_cost must be 8-byte aligned");
+    return check(launch_merge_decide(LS(ctx), d_satd_y, d_satd_cb, d_satd_cr, n, reciprocal_sqrt_lambda_q16, d_cost, d_best), "merge_decide");
+}
+
+int havoc_mi355x_pred_jobs(havoc_mi355x_ctx *ctx, const havoc_mi355x_field_layout *layout, const int16_t *d_field, int list, const int32_t *d_x0, const int32_t *d_y0, int n,
+                           int log2_size, int plane, const int32_t *d_dst_off, havoc_mi355x_pred_uni_job *d_jobs)
+{
+    REQUIRE_CTX(); REQUIRE(n >= 0, "n < 0"); REQUIRE(log2_size >= 3 && log2_size <= 6, "log2_size must be 3..6");
+    REQUIRE(list == 0 || list == 1, "list must be 0 or 1"); REQUIRE(plane >= 0 && plane <= 2, "plane must be 0..2");
+    REQUIRE(layout_ok(layout), "field layout: sizes, strides or borders do not fit");
+    REQUIRE(n == 0 || (d_field && d_x0 && d_y0 && d_dst_off && d_jobs), "null device pointer");
+    REQUIRE(((uintptr_t)d_field & 3) == 0, "d_field must be 4-byte aligned");
+    return check(launch_pred_jobs(LS(ctx), layout, d_field, list, d_x0, d_y0, n, log2_size, plane, d_dst_off, d_jobs), "pred_jobs");
 }
 
 int havoc_mi355x_intra_order(havoc_mi355x_ctx *ctx, const int32_t *d_satd35, const havoc_mi355x_intra_mpm *d_mpm, int n, int32_t lambda_q16, int32_t *d_order,

@@ -149,6 +149,136 @@ __global__ __launch_bounds__(256) void k_intra_decide(const IntraCtx *__restrict
     fin[i] = f;
 }
 
+// ---- job tables made ON THE DEVICE from the decided motion field (round 4): what a host would otherwise build per picture and upload -----------------
+// The prediction jobs of the steps that follow the searches -- every unit at its decided vector (luma 8-tap, chroma 4-tap), every unit's spatial merge
+// candidates bi-directionally in three planes -- depend on the field the search kernel has just left in device memory; building them there keeps the
+// picture's step free of host work between its launches.  Layout of the pictures: planes of one component at multiples of `planeElems` (luma: source, list 0,
+// list 1; chroma: Cb source, list 0, list 1, then Cr source, list 0, list 1), `pad` samples of border, `stride` samples per row.
+struct MergeLayout { int32_t picWidth, picHeight, range, fieldCw, lumaStride, lumaPad, lumaPlaneElems, chromaStride, chromaPad, chromaPlaneElems, reserved[2]; };   // havoc_mi355x_field_layout
+struct PredUniJob { int32_t dst_off, ref_off, w, h, xFrac, yFrac, reserved[2]; };
+struct PredBiJob { int32_t dst_off, ref0_off, ref1_off, w, h, xFrac0, yFrac0, xFrac1, yFrac1, reserved[3]; };
+static_assert(sizeof(MergeLayout) == 48 && sizeof(PredUniJob) == 32 && sizeof(PredBiJob) == 48, "record layouts");
+
+__device__ __forceinline__ void clampVector(const MergeLayout &L, int x0, int y0, int n, int &mx, int &my)
+{   // as LimitFullPelMv (Search.hpp:1366-1407) keeps the searches: the block stays within `range` samples of the picture (quarter-sample units)
+    mx = min(max(mx, (-L.range - x0) * 4), (L.picWidth + L.range - x0 - n) * 4);
+    my = min(max(my, (-L.range - y0) * 4), (L.picHeight + L.range - y0 - n) * 4);
+}
+
+// thread = (unit, candidate k of 5): the vectors of both lists at spatial merge position k (HEVC 8.5.3.2.3: A1, B1, B0, A0, B2; outside the picture: zero)
+__global__ __launch_bounds__(256) void k_merge_jobs(const MergeLayout L, const int32_t *__restrict__ field, const int32_t *__restrict__ ux, const int32_t *__restrict__ uy, int n,
+                                                    int log2, PredBiJob *__restrict__ jl, PredBiJob *__restrict__ jcb, PredBiJob *__restrict__ jcr, int32_t *__restrict__ vectors)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= 5 * n) return;
+    const int i = t / 5, k = t - 5 * i, nn = 1 << log2, x0 = ux[i], y0 = uy[i];
+    const int px = k == 0 || k >= 3 ? x0 - 1 : (k == 1 ? x0 + nn - 1 : x0 + nn);
+    const int py = k == 0 ? y0 + nn - 1 : (k == 3 ? y0 + nn : y0 - 1);
+    const bool inside = px >= 0 && py >= 0 && px < L.picWidth && py < L.picHeight;
+    const int ch = (L.picHeight + 3) >> 2;
+    int mv[2][2];
+    for (int lst = 0; lst < 2; ++lst)
+    {
+        const int32_t packed = inside ? field[((long)lst * ch + (py >> 2)) * L.fieldCw + (px >> 2)] : 0;
+        mv[lst][0] = (int16_t)(packed & 0xffff);
+        mv[lst][1] = (int16_t)(packed >> 16);
+        clampVector(L, x0, y0, nn, mv[lst][0], mv[lst][1]);
+        vectors[2 * t + lst] = (mv[lst][0] & 0xffff) | (mv[lst][1] << 16);
+    }
+    {
+        PredBiJob j = PredBiJob();
+        j.dst_off = t * nn * nn;
+        j.w = j.h = nn;
+        const int here = (y0 + L.lumaPad) * L.lumaStride + x0 + L.lumaPad;
+        j.ref0_off = 1 * L.lumaPlaneElems + here + (mv[0][1] >> 2) * L.lumaStride + (mv[0][0] >> 2);
+        j.ref1_off = 2 * L.lumaPlaneElems + here + (mv[1][1] >> 2) * L.lumaStride + (mv[1][0] >> 2);
+        j.xFrac0 = mv[0][0] & 3; j.yFrac0 = mv[0][1] & 3; j.xFrac1 = mv[1][0] & 3; j.yFrac1 = mv[1][1] & 3;
+        jl[t] = j;
+    }
+    for (int comp = 0; comp < 2; ++comp)
+    {
+        PredBiJob j = PredBiJob();
+        const int cn = nn >> 1;
+        j.dst_off = t * cn * cn;
+        j.w = j.h = cn;
+        const int here = ((y0 >> 1) + L.chromaPad) * L.chromaStride + (x0 >> 1) + L.chromaPad;
+        j.ref0_off = (3 * comp + 1) * L.chromaPlaneElems + here + (mv[0][1] >> 3) * L.chromaStride + (mv[0][0] >> 3);
+        j.ref1_off = (3 * comp + 2) * L.chromaPlaneElems + here + (mv[1][1] >> 3) * L.chromaStride + (mv[1][0] >> 3);
+        j.xFrac0 = mv[0][0] & 7; j.yFrac0 = mv[0][1] & 7; j.xFrac1 = mv[1][0] & 7; j.yFrac1 = mv[1][1] & 7;
+        (comp ? jcr : jcb)[t] = j;
+    }
+}
+
+// thread = unit: its HavocPredUni job at the vector decided for list `list` at its origin; plane 0 = luma (8-tap phases), 1 / 2 = Cb / Cr (eighth-sample phases)
+__global__ __launch_bounds__(256) void k_pred_jobs(const MergeLayout L, const int32_t *__restrict__ field, int list, const int32_t *__restrict__ ux, const int32_t *__restrict__ uy,
+                                                   int n, int log2, int plane, const int32_t *__restrict__ dstOff, PredUniJob *__restrict__ jobs)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int x0 = ux[i], y0 = uy[i], ch = (L.picHeight + 3) >> 2;
+    const int32_t packed = field[((long)list * ch + (y0 >> 2)) * L.fieldCw + (x0 >> 2)];
+    const int mx = (int16_t)(packed & 0xffff), my = (int16_t)(packed >> 16);
+    PredUniJob j = PredUniJob();
+    j.dst_off = dstOff[i];
+    if (plane == 0)
+    {
+        j.w = j.h = 1 << log2;
+        j.ref_off = (1 + list) * L.lumaPlaneElems + (y0 + (my >> 2) + L.lumaPad) * L.lumaStride + x0 + (mx >> 2) + L.lumaPad;
+        j.xFrac = mx & 3; j.yFrac = my & 3;
+    }
+    else
+    {
+        j.w = j.h = 1 << (log2 - 1);
+        j.ref_off = (3 * (plane - 1) + 1 + list) * L.chromaPlaneElems + ((y0 >> 1) + (my >> 3) + L.chromaPad) * L.chromaStride + (x0 >> 1) + (mx >> 3) + L.chromaPad;
+        j.xFrac = mx & 7; j.yFrac = my & 7;
+    }
+    jobs[i] = j;
+}
+
+// thread = unit: cost of its five candidates = stand-in rate of the merge index (k + 1 bits, 4 at most) + (satdY + satdCb + satdCr) * reciprocalSqrtLambda (Q16: measurePuCost,
+// Search.hpp:1659-1706), best = the first of the cheapest (`cost < bestCost`, searchMergeModes :1754-1768)
+__global__ __launch_bounds__(256) void k_merge_decide(const int32_t *__restrict__ sy, const int32_t *__restrict__ scb, const int32_t *__restrict__ scr, int n, int64_t lamQ16,
+                                                      int64_t *__restrict__ cost, int32_t *__restrict__ best)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int64_t bestCost = 0;
+    int b = 0;
+    for (int k = 0; k < 5; ++k)
+    {
+        const int t = 5 * i + k;
+        const int64_t c = ((int64_t)min(k + 1, 4) << 16) + ((int64_t)sy[t] + scb[t] + scr[t]) * lamQ16;
+        cost[t] = c;
+        if (k == 0 || c < bestCost) { bestCost = c; b = k; }
+    }
+    best[i] = b;
+}
+
+hipError_t launch_merge_decide(hipStream_t st, const int32_t *sy, const int32_t *scb, const int32_t *scr, int n, int64_t lamQ16, int64_t *cost, int32_t *best)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_merge_decide, dim3((n + 255) / 256), dim3(256), 0, st, sy, scb, scr, n, lamQ16, cost, best);
+    return hipGetLastError();
+}
+
+hipError_t launch_merge_jobs(hipStream_t st, const void *layout, const int16_t *field, const int32_t *ux, const int32_t *uy, int n, int log2, void *jl, void *jcb, void *jcr,
+                             int16_t *vectors)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_merge_jobs, dim3((5 * n + 255) / 256), dim3(256), 0, st, *static_cast<const MergeLayout *>(layout), reinterpret_cast<const int32_t *>(field), ux, uy, n, log2,
+                       (PredBiJob *)jl, (PredBiJob *)jcb, (PredBiJob *)jcr, reinterpret_cast<int32_t *>(vectors));
+    return hipGetLastError();
+}
+
+hipError_t launch_pred_jobs(hipStream_t st, const void *layout, const int16_t *field, int list, const int32_t *ux, const int32_t *uy, int n, int log2, int plane,
+                            const int32_t *dstOff, void *jobs)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_pred_jobs, dim3((n + 255) / 256), dim3(256), 0, st, *static_cast<const MergeLayout *>(layout), reinterpret_cast<const int32_t *>(field), list, ux, uy, n, log2,
+                       plane, dstOff, (PredUniJob *)jobs);
+    return hipGetLastError();
+}
+
 hipError_t launch_intra_order(hipStream_t st, const int32_t *satd35, const void *ictx, int n, int32_t lambdaQ16, int32_t *order, int32_t *count, int32_t *slot,
                               int32_t *total)
 {

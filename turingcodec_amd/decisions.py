@@ -150,9 +150,12 @@ def decision_inputs(width, height, bit_depth=8, qp=32, seed=11, density=1.0, fra
         frames = [frames[0], frames[distance], frames[2 * distance]]
     planes = [workload.pad_plane(f[0], pad) for f in (frames[1], frames[0], frames[2])]
     stride = planes[0].shape[1]
+    # chroma: Cb of (source, list 0, list 1), then Cr, in the same padded layout at half size (48 samples of border)
+    chroma = [workload.pad_plane(f[c], pad // 2) for c in (1, 2) for f in (frames[1], frames[0], frames[2])]
     pus, ctu_first, cx, cy = workload.picture_pus(width, height, seed, density)
     lam = workload.picture_lambda(qp)
-    return dict(planes=[np.ascontiguousarray(p.ravel()) for p in planes], stride=stride, pad=pad, pus=pus, ctu_first=ctu_first, cx=cx, cy=cy,
+    return dict(chroma=[np.ascontiguousarray(p.ravel()) for p in chroma], cstride=chroma[0].shape[1],
+                planes=[np.ascontiguousarray(p.ravel()) for p in planes], stride=stride, pad=pad, pus=pus, ctu_first=ctu_first, cx=cx, cy=cy,
                 params=medium_params(width, height, bit_depth, 1.0 / np.sqrt(lam)), mvp_rate=(45000, 98000), lam=lam)
 
 
@@ -330,6 +333,20 @@ class DecisionPicture:
         self.d_states = hv.up(self.rdoq_states.reshape(-1))
         self.pred = hv.zeros(width * height, self.dt)
         self.recon = hv.zeros(self.pe, self.dt)
+        # chroma (round 4): Cb / Cr of source, list 0, list 1 in ONE allocation (plane k at k * cpe: 0-2 Cb, 3-5 Cr), their prediction and reconstruction planes
+        self.host_chroma, self.cstride = d["chroma"], d["cstride"]
+        self.cn = self.host_chroma[0].size
+        self.cpe = (self.cn + 63) & ~63
+        self.corigin = (self.PAD // 2) * self.cstride + self.PAD // 2
+        cpic = np.zeros(6 * self.cpe, self.dt)
+        for k, p in enumerate(self.host_chroma):
+            cpic[k * self.cpe:k * self.cpe + self.cn] = p
+        self.d_cpic = hv.up(cpic)
+        self.cpred = hv.zeros(2 * (width // 2) * (height // 2), self.dt)      # Cb then Cr, unpadded, stride width / 2
+        # the decided motion field stays on the device (int16 [2 lists][cells][2]); the job tables of the steps after the searches are made from it THERE
+        self.d_field = hv.zeros(2 * ((width + 3) // 4) * ((height + 3) // 4) * 2, np.int16)
+        self.layout = hv.field_layout(width, height, self.stride, self.PAD, self.pe, self.cstride, self.PAD // 2, self.cpe)
+        self.crecon = hv.zeros(2 * self.cpe, self.dt)
         # ---- the intra candidates of the picture (an inter picture evaluates them per coding unit): partitions with neighbours from the source
         self.intra_parts = {}
         self.rsl = float(self.params.reciprocal_sqrt_lambda)
@@ -354,32 +371,156 @@ class DecisionPicture:
         hv, pe, o = self.hv, self.pe, self.origin
         base, ph = self.d_pic.data_ptr(), self.d_phase.data_ptr()
         r = picture_uni(hv.h, self.S, self.params, base, o, self.stride, base, (pe + o, 2 * pe + o), self.stride, self.PAD, ph, pe, (o, 16 * pe + o),
-                        self.pus, self.ctu_first, self.cx, self.cy, self.mvp_rate, self.threads, on_device=self.search_on_device, bi=self.search_on_device)
+                        self.pus, self.ctu_first, self.cx, self.cy, self.mvp_rate, self.threads, on_device=self.search_on_device, bi=self.search_on_device,
+                        d_field_keep=self.d_field.data_ptr() if self.search_on_device else None)
         self.bi_results = r[3] if self.search_on_device else None      # the bi-directional refinements (device search only)
+        if not self.search_on_device:                                  # the host-replay search decides on the host: its field goes down once
+            with self.torch.cuda.stream(hv.tstream):
+                self.d_field.copy_(self.torch.from_numpy(r[1].reshape(-1)), non_blocking=False)
         return r[:3]
 
     def predict(self, field):
         """HavocPredUni of every inter unit (a 2Nx2N prediction unit per unit of rqt_units) at the list-0 vector decided at its origin, into the
         prediction plane; asynchronous"""
-        hv, bd, pe = self.hv, self.bd, self.pe
-        ref0 = self.d_pic[pe:2 * pe]
+        hv, bd = self.hv, self.bd
         if not hasattr(self, "pgroups"):
             self.pgroups = []
             for log2 in (5, 4, 3):
                 sel = np.flatnonzero(self.units["log2_size"] == log2)
                 if len(sel):
-                    self.pgroups.append(dict(nn=1 << log2, x0=self.units["x0"][sel].astype(np.int64), y0=self.units["y0"][sel].astype(np.int64),
-                                             pj=np.zeros((len(sel), 8), np.int32), d_pj=hv.zeros(len(sel) * 8, np.int32)))
+                    x0, y0 = self.units["x0"][sel].astype(np.int32), self.units["y0"][sel].astype(np.int32)
+                    self.pgroups.append(dict(log2=log2, nn=1 << log2, d_x0=hv.up(x0), d_y0=hv.up(y0), d_dst=hv.up(y0 * self.W + x0), d_pj=hv.zeros(len(sel) * 8, np.int32)))
         for g in self.pgroups:
-            mv = field[0, g["y0"] >> 2, g["x0"] >> 2].astype(np.int64)          # quarter samples, [m, 2]
-            pj = g["pj"]
-            pj[:, 0] = g["y0"] * self.W + g["x0"]
-            pj[:, 1] = (g["y0"] + (mv[:, 1] >> 2) + self.PAD) * self.stride + g["x0"] + (mv[:, 0] >> 2) + self.PAD
-            pj[:, 2] = pj[:, 3] = g["nn"]
-            pj[:, 4], pj[:, 5] = mv[:, 0] & 3, mv[:, 1] & 3
-            with self.torch.cuda.stream(hv.tstream):
-                g["d_pj"].copy_(self.torch.from_numpy(pj.reshape(-1)), non_blocking=True)
-            hv.pred_uni_d(8, bd, self.pred, self.W, ref0, self.stride, g["d_pj"].view(-1, 8), g["nn"], g["nn"])
+            # the job table from the field, on the device (k_pred_jobs): reference offsets count from the start of the luma allocation
+            hv.pred_jobs_d(self.layout, self.d_field, 0, g["d_x0"], g["d_y0"], g["log2"], 0, g["d_dst"], g["d_pj"])
+            hv.pred_uni_d(8, bd, self.pred, self.W, self.d_pic, self.stride, g["d_pj"].view(-1, 8), g["nn"], g["nn"])
+
+    # ---- round 4: the merge candidates of every unit and the chroma planes (VERDICT r3 next #6) -------------------------------------------------
+    MERGE_CANDIDATES = 5
+
+    def merge_vectors(self, field):
+        """the candidate vectors of every unit of self.units: both lists' vectors decided for the cells at the five spatial merge positions (HEVC 8.5.3.2.3:
+        A1 left-bottom, B1 above-right, B0, A0, B2 -- Mvp.h's derivation with its pruning and temporal candidate stays out of scope: the vectors are INPUTS);
+        a position outside the picture gives zero vectors; every vector is limited so that the block and its filter taps stay inside the padded planes
+        (as LimitFullPelMv does for the searches).  int16 [units, 5, 2 lists, 2]"""
+        u = self.units
+        n = 1 << u["log2_size"].astype(np.int64)
+        x0, y0 = u["x0"].astype(np.int64), u["y0"].astype(np.int64)
+        px = np.stack([x0 - 1, x0 + n - 1, x0 + n, x0 - 1, x0 - 1], 1)
+        py = np.stack([y0 + n - 1, y0 - 1, y0 - 1, y0 + n, y0 - 1], 1)
+        inside = (px >= 0) & (py >= 0) & (px < self.W) & (py < self.H)
+        cx, cy = np.clip(px, 0, self.W - 1) >> 2, np.clip(py, 0, self.H - 1) >> 2
+        mv = np.stack([field[0, cy, cx], field[1, cy, cx]], 2).astype(np.int64)      # [units, 5, list, xy]
+        mv *= inside[:, :, None, None]
+        lo_x, hi_x = (-64 - x0) * 4, (self.W + 64 - x0 - n) * 4
+        lo_y, hi_y = (-64 - y0) * 4, (self.H + 64 - y0 - n) * 4
+        mv[..., 0] = np.clip(mv[..., 0], lo_x[:, None, None], hi_x[:, None, None])
+        mv[..., 1] = np.clip(mv[..., 1], lo_y[:, None, None], hi_y[:, None, None])
+        return mv.astype(np.int16)
+
+    def merge_candidates(self, field):
+        """searchMergeModes / measurePuCost (turing/Search.hpp:1659-1706, 1754-1768) as batches: every unit's five candidates predicted bi-directionally in all
+        three planes (HavocPredBi 8-tap luma, 4-tap Cb / Cr) and measured with the Hadamard SATD against the source (Measure.h:97-168: chroma only where the
+        halved unit is a multiple of 4), cost = rate + (satdY + satdCb + satdCr) * reciprocalSqrtLambda with a stand-in rate of the merge index (i + 1 bits,
+        4 at most).  Leaves self.merge = dict(vectors, satd [units, 5, 3], cost [units, 5] Q16, best [units]).  9 launches per unit size."""
+        hv, bd, torch = self.hv, self.bd, self.torch
+        u, K = self.units, self.MERGE_CANDIDATES
+        if not hasattr(self, "mgroups"):
+            # everything that does not depend on the vectors is made once: the units' positions, destination slots, the source blocks' SATD jobs
+            self.mgroups, at = [], 0
+            for log2 in (5, 4, 3):
+                sel = np.flatnonzero(u["log2_size"] == log2)
+                if not len(sel):
+                    continue
+                nn, m = 1 << log2, len(sel) * K
+                x0, y0 = np.repeat(u["x0"][sel].astype(np.int64), K), np.repeat(u["y0"][sel].astype(np.int64), K)
+                g = dict(log2=log2, nn=nn, sel=sel, m=m, planes=[], d_x0=hv.up(u["x0"][sel].astype(np.int32)), d_y0=hv.up(u["y0"][sel].astype(np.int32)),
+                         d_vec=hv.zeros(m * 4, np.int16), d_cost=torch.zeros(m, dtype=torch.int64, device=hv.device), d_best=hv.zeros(len(sel), np.int32))
+                for plane in range(3):
+                    c = plane > 0
+                    size, stride, pad, pe = (nn // 2, self.cstride, self.PAD // 2, self.cpe) if c else (nn, self.stride, self.PAD, self.pe)
+                    bx, by = (x0 // 2, y0 // 2) if c else (x0, y0)
+                    first = (3 * (plane - 1)) if c else 0                # plane index of the source inside the allocation (Cb: 0, Cr: 3; luma: 0)
+                    dst = np.arange(m) * size * size
+                    sj = np.stack([first * pe + (by + pad) * stride + bx + pad, dst, np.full(m, size), np.full(m, size)], 1).astype(np.int32)
+                    g["planes"].append(dict(size=size, stride=stride, taps=4 if c else 8, d_bj=hv.zeros(m * 12, np.int32), d_sj=hv.up(sj),
+                                            d_dst=hv.zeros(m * size * size, self.dt), at=at))
+                    at += m
+                self.mgroups.append(g)
+            self.d_merge_satd = hv.zeros(at, np.int32)      # every SATD of the step in one buffer
+        lam_q16 = int(float(self.params.reciprocal_sqrt_lambda) * 65536 + 0.5)
+        for g in self.mgroups:
+            q = g["planes"]
+            hv.merge_jobs_d(self.layout, self.d_field, g["d_x0"], g["d_y0"], g["log2"], q[0]["d_bj"], q[1]["d_bj"], q[2]["d_bj"], g["d_vec"])
+            for plane, p in enumerate(q):
+                ref = self.d_cpic if plane else self.d_pic
+                hv.pred_bi_d(p["taps"], bd, p["d_dst"], p["size"], ref, p["stride"], p["d_bj"].view(-1, 12), p["size"], p["size"])
+                hv.satd_d(ref, p["stride"], p["d_dst"], p["size"], p["d_sj"], self.d_merge_satd[p["at"]:p["at"] + g["m"]], p["size"], p["size"])
+            sat = [self.d_merge_satd[p["at"]:p["at"] + g["m"]] for p in q]
+            hv.merge_decide_d(sat[0], sat[1], sat[2], len(g["sel"]), lam_q16, g["d_cost"], g["d_best"])
+        self._merge = None
+
+    @property
+    def merge(self):
+        """what merge_candidates() left on the device, as numpy: dict(vectors int16 [units, 5, 2 lists, 2], satd [units, 5, 3 planes], cost [units, 5] (Q16),
+        best [units])"""
+        if getattr(self, "_merge", None) is None:
+            hv, u, K = self.hv, self.units, self.MERGE_CANDIDATES
+            flat = hv.down(self.d_merge_satd, np.int32)
+            vec, satd = np.zeros((len(u), K, 2, 2), np.int16), np.zeros((len(u), K, 3), np.int64)
+            cost, best = np.zeros((len(u), K), np.int64), np.zeros(len(u), np.int32)
+            for g in self.mgroups:
+                for plane, p in enumerate(g["planes"]):
+                    satd[g["sel"], :, plane] = flat[p["at"]:p["at"] + g["m"]].reshape(-1, K)
+                vec[g["sel"]] = hv.down(g["d_vec"], np.int16).reshape(-1, K, 2, 2)
+                with self.torch.cuda.stream(hv.tstream):
+                    cost[g["sel"]] = g["d_cost"].cpu().numpy().reshape(-1, K)
+                best[g["sel"]] = hv.down(g["d_best"], np.int32)
+            self._merge = dict(vectors=vec, satd=satd, cost=cost, best=best)
+        return self._merge
+
+    def chroma_chain(self, field):
+        """the inter residual of the chroma planes at the decided vectors (turing/Reconstruct.cpp:1274-1286 with cIdx 1, 2): HavocPredUni 4-tap of every unit's
+        Cb and Cr block at its list-0 vector (eighth-sample phase = the luma vector's low three bits), then residual + DCT -> Rdoq::runQuantisation (cIdx) ->
+        de-quantise + inverse DCT + add -> SSD, one chain per chroma transform size, into the chroma reconstruction planes.  Asynchronous."""
+        hv, bd, torch, hmod = self.hv, self.bd, self.torch, self.hmod
+        from . import workload
+        u = self.units
+        hw, hh = self.W // 2, self.H // 2
+        if not hasattr(self, "cgroups"):
+            self.cgroups = []
+            for log2 in (5, 4, 3):
+                sel = np.flatnonzero(u["log2_size"] == log2)
+                if not len(sel):
+                    continue
+                cl, cn, m = log2 - 1, 1 << (log2 - 1), len(sel)
+                x0, y0 = u["x0"][sel].astype(np.int64) // 2, u["y0"][sel].astype(np.int64) // 2
+                qs, qshift, _ = workload.quant_params(self.qp, cl, bd, False)
+                inv, dshift = workload.dequant_params(self.qp, cl, bd)
+                lq, sf = hmod.rdoq_lambda(self.lam, inv)
+                for comp in (1, 2):
+                    fj = np.zeros((m, 4), np.int32)
+                    fj[:, 0] = np.arange(m) * cn * cn
+                    fj[:, 1] = 3 * (comp - 1) * self.cpe + (y0 + self.PAD // 2) * self.cstride + x0 + self.PAD // 2          # source block in d_cpic
+                    fj[:, 2] = (comp - 1) * hw * hh + y0 * hw + x0                                                           # prediction block in cpred
+                    fj[:, 3] = (comp - 1) * self.cpe + (y0 + self.PAD // 2) * self.cstride + x0 + self.PAD // 2              # reconstruction in crecon
+                    jobs = np.zeros(m, hmod.RDOQ_JOB_DT)
+                    jobs["dst_off"] = jobs["src_off"] = fj[:, 0]
+                    jobs["quant_scale"], jobs["quant_shift"], jobs["inv_scale"], jobs["lambda_q16"], jobs["sdh_factor"] = qs, qshift, inv, lq, sf
+                    jobs["sdh"], jobs["c_idx"] = 1, comp
+                    jobs["ctx_index"] = (u["y0"][sel] // 64) * self.cx + u["x0"][sel] // 64
+                    with torch.cuda.stream(hv.tstream):
+                        d_rj = torch.from_numpy(jobs.view(np.uint8).reshape(-1)).to(hv.device)
+                    self.cgroups.append(dict(log2=cl, cn=cn, comp=comp, m=m, sel=sel, inv=inv, dshift=dshift, d_fj=hv.up(fj), d_rj=d_rj,
+                                             d_x0=hv.up(u["x0"][sel].astype(np.int32)), d_y0=hv.up(u["y0"][sel].astype(np.int32)), d_dst=hv.up(fj[:, 2]),
+                                             d_pj=hv.zeros(m * 8, np.int32), coef=hv.zeros(m * cn * cn, np.int16),
+                                             level=hv.zeros(m * cn * cn, np.int16), cbf=hv.zeros(m, np.int32), ssd=hv.zeros(m, np.uint32), work=hv.rdoq_workspace(m)))
+        for g in self.cgroups:
+            hv.pred_jobs_d(self.layout, self.d_field, 0, g["d_x0"], g["d_y0"], g["log2"] + 1, g["comp"], g["d_dst"], g["d_pj"])
+            hv.pred_uni_d(4, bd, self.cpred, hw, self.d_cpic, self.cstride, g["d_pj"].view(-1, 8), g["cn"], g["cn"])
+            hv.tu_forward_d(bd, 0, g["log2"], g["coef"], self.d_cpic, self.cstride, self.cpred, hw, g["d_fj"])
+            hv.rdoq_d(bd, g["log2"], g["level"], g["coef"], self.d_states, g["d_rj"], g["cbf"], g["work"])
+            hv.tu_reconstruct_d(bd, 0, g["log2"], g["inv"], g["dshift"], self.crecon, self.cstride, self.cpred, hw, self.d_cpic, self.cstride, g["level"], g["d_fj"], g["ssd"])
 
     def tu_chain(self, field):
         """prediction at the decided vectors, then the residual-quadtree decisions and the reconstruction; returns (decisions, stats)"""
@@ -470,7 +611,9 @@ class DecisionPicture:
         res, field, stats = self.search()
         if self.intra_parts:
             self.intra_decisions()
+        self.merge_candidates(field)
         decisions, _ = self.tu_chain(field)
+        self.chroma_chain(field)
         self.cells = self.block_cells(field, decisions)
         self.loop_filter(self.cells)
         self.hv.sync()

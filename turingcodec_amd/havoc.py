@@ -94,6 +94,9 @@ def _load():
         "tu_reconstruct": [_vp, _i, _i, _i, _i, _i, _i, _vp, _ip, _vp, _ip, _vp, _ip, _vp, _vp, _i, _vp],
         "level_stats": [_vp, _vp, _vp, _i, _vp],
         "search_motion_uni": [_vp, _i, _vp, _vp, C.c_int64, _ip, _vp, C.c_int64, _ip, _vp, _ip, C.c_int64, _vp, _i, _vp],
+        "merge_jobs": [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
+        "merge_decide": [_vp, _vp, _vp, _vp, _i, C.c_int64, _vp, _vp],
+        "pred_jobs": [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp],
         "search_motion_bi": [_vp, _i, _vp, _vp, C.c_int64, _ip, _vp, C.c_int64, _ip, _vp, _ip, C.c_int64, _vp, C.c_int64, _vp, _vp, _i, _vp],
         "search_picture_uni": [_vp, _i, _vp, _vp, _vp, C.c_int64, _ip, _vp, _vp, _ip, _vp, _ip, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i],
         "intra_order": [_vp, _vp, _vp, _i, C.c_int32, _vp, _vp, _vp, _vp],
@@ -335,6 +338,20 @@ class Havoc:
 
     def pred_bi_d(self, taps, bd, dst, sd, ref, sr, jobs, max_w=64, max_h=64):
         self._ck(self.L.havoc_mi355x_pred_bi(self.h, self._S(ref), taps, bd, max_w, max_h, _ptr(dst), sd, _ptr(ref), sr, _ptr(jobs), jobs.shape[0]))
+
+    # ---- job tables made on the device from the decided motion field (kernels_decide.hip: k_merge_jobs, k_pred_jobs, k_merge_decide) ----
+    @staticmethod
+    def field_layout(pic_width, pic_height, luma_stride, luma_pad, luma_plane_elems, chroma_stride, chroma_pad, chroma_plane_elems, search_range=64):
+        return (C.c_int32 * 12)(pic_width, pic_height, search_range, (pic_width + 3) // 4, luma_stride, luma_pad, luma_plane_elems, chroma_stride, chroma_pad, chroma_plane_elems, 0, 0)
+
+    def merge_jobs_d(self, layout, field, x0, y0, log2, luma_jobs, cb_jobs, cr_jobs, vectors):
+        self._ck(self.L.havoc_mi355x_merge_jobs(self.h, layout, _ptr(field), _ptr(x0), _ptr(y0), x0.shape[0], log2, _ptr(luma_jobs), _ptr(cb_jobs), _ptr(cr_jobs), _ptr(vectors)))
+
+    def merge_decide_d(self, satd_y, satd_cb, satd_cr, n, lam_q16, cost, best):
+        self._ck(self.L.havoc_mi355x_merge_decide(self.h, _ptr(satd_y), _ptr(satd_cb), _ptr(satd_cr), n, int(lam_q16), _ptr(cost), _ptr(best)))
+
+    def pred_jobs_d(self, layout, field, lst, x0, y0, log2, plane, dst_off, jobs):
+        self._ck(self.L.havoc_mi355x_pred_jobs(self.h, layout, _ptr(field), lst, _ptr(x0), _ptr(y0), x0.shape[0], log2, plane, _ptr(dst_off), _ptr(jobs)))
 
     @staticmethod
     def sort_by_class(jobs, w, h):
