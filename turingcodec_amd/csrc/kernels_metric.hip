@@ -39,13 +39,17 @@ __device__ __forceinline__ int sad_group_sum(int v)
     return v;
 }
 
+// x / c for 0 <= x <= 1024, 1 <= c <= 128 without the 25-instruction integer division: (x + 0.5) / c is at least 0.5 / c from an integer, far beyond what the
+// reciprocal's and the product's rounding can move it
+__device__ __forceinline__ int smallDiv(int x, int c) { return (int)(((float)x + 0.5f) * __builtin_amdgcn_rcpf((float)c)); }
+
 template <int S, int WAYS, int CB, int U = 4>
 __device__ __forceinline__ void sad_block(const char *src, long ssb, const char *const (&ref)[WAYS], long rsb, int rowBytes, int h,
                                           int lane, uint32_t (&acc)[WAYS])
 {
     const int cpr = rowBytes / CB;      // chunks per row: 1, 2, 3, 4, 6 or 8
-    const int rpi = kSadLanes / cpr;    // rows per iteration
-    const int y0 = lane / cpr;
+    const int rpi = smallDiv(kSadLanes, cpr);    // rows per iteration
+    const int y0 = smallDiv(lane, cpr);
     const int xb = (lane - y0 * cpr) * CB;
     if (y0 >= rpi) return;              // lanes beyond rpi*cpr idle (cpr = 3, 6)
 #pragma unroll U                         // several rows' loads in flight: the loop is latency-, not issue-bound
@@ -161,80 +165,94 @@ __global__ __launch_bounds__(256, MINW) void k_sad(const char *__restrict__ src,
 constexpr int kSadWinBytes = 1536;      // LDS per lane group and per byte of sample size: 24 KB (8-bit) / 48 KB (16-bit) per workgroup
 
 template <int S, int CB>
-__device__ __forceinline__ void sad4_window_strips(const char *src, long ssb, const char *a0, long rsb, const __attribute__((address_space(3))) char *buf_r,
-                                                   __attribute__((address_space(3))) char *buf_w, int pitch, int lead, const int (&ox)[4], const int (&oy)[4], int spready, int rowBytes, int h, int hs,
-                                                   int lane, uint32_t (&acc)[4])
+__device__ __forceinline__ void sad4_window_strips(const char *src, uint32_t s0, uint32_t ssb, const char *ref, uint32_t a0, uint32_t rsb, const __attribute__((address_space(3))) uint32_t *buf_r,
+                                                   __attribute__((address_space(3))) uint32_t *buf_w, int pitchD, int chunks, int lead, const int (&ox)[4], const int (&oy)[4],
+                                                   int spready, int rowBytes, int h, int hs, int lane, uint32_t (&acc)[4])
 {
-    typedef const __attribute__((address_space(3))) u32x4u *LP16;
-    typedef const __attribute__((address_space(3))) u32x2u *LP8;
-    typedef const __attribute__((address_space(3))) u32u *LP4;
-    // the copy: a lane keeps its 16-byte column and walks down the rows (instruction count matters here: the first form of this kernel cut the
-    // vector-memory accesses 4x and was no faster, with 2.5x the VALU instructions of the direct kernel -- profiles/r04/sad4_counters.txt)
-    const int cprw = pitch >> 4;          // 16-byte chunks per window row (1 .. 16)
-    const int wstep = kSadLanes / cprw;   // window rows per copy iteration
-    const int wr0 = lane / cprw, wc = (lane - wr0 * cprw) * 16;
+    // LDS side in DWORDS.  A window row takes `pitchD` dwords, an ODD number: the 16 lanes of a job (a row or a quarter row each) then read 16 different
+    // banks, and the next job's buffer starts 16 banks on.  Every read is a 4-byte-aligned dword; a candidate's byte shift inside its dwords (the same for
+    // all rows of a lane) is undone with v_alignbyte_b32.  (Round 4's first form read byte-unaligned 16-byte vectors: a third of the wavefronts' cycles
+    // went to SQ_LDS_UNALIGNED_STALL.)
+    // the copy: a lane keeps its 16-byte column and walks down the rows
+    const int wstep = smallDiv(kSadLanes, chunks);   // window rows per copy iteration
+    const int wr0 = smallDiv(lane, chunks), wc = lane - wr0 * chunks;
     const bool copies = wr0 < wstep;
     // the SADs: a lane keeps its chunk column of the block and walks down the rows; the four candidates' LDS addresses advance together
     const int cpr = rowBytes / CB;        // chunks per block row
-    const int rpi = kSadLanes / cpr;      // block rows per iteration of the lane group
-    const int y0 = lane / cpr;
+    const int rpi = smallDiv(kSadLanes, cpr);      // block rows per iteration of the lane group
+    const int y0 = smallDiv(lane, cpr);
     const int xb = (lane - y0 * cpr) * CB;
     const bool sums = y0 < rpi;
-    int lo[4];
+    int lo[4], sh[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) lo[k] = (y0 + oy[k]) * pitch + lead + ox[k] + xb;
-    const int lstep = rpi * pitch;
-    const long gstep = (long)wstep * rsb, sstep = (long)rpi * ssb;
-    const int wlstep = wstep * pitch;
+    for (int k = 0; k < 4; ++k)
+    {
+        const int bo = lead + ox[k] + xb;
+        lo[k] = (y0 + oy[k]) * pitchD + (bo >> 2);
+        sh[k] = bo & 3;
+    }
+    // global side in 32-bit byte offsets from the (uniform) base pointers: the loads take the base from scalar registers, no 64-bit vector arithmetic
+    const int lstep = rpi * pitchD;
+    const uint32_t gstep = wstep * rsb, sstep = rpi * ssb;
+    const int wlstep = wstep * pitchD;
     for (int ys = 0; ys < h; ys += hs)
     {
         const int he = min(hs, h - ys), nrows = he + spready;
         if (copies)
         {
-            const char *g = a0 + (long)(ys + wr0) * rsb + wc;
-            int l = wr0 * pitch + wc;
+            uint32_t g = a0 + (uint32_t)(ys + wr0) * rsb + wc * 16;
+            int l = wr0 * pitchD + wc * 4;
             for (int r = wr0; r < nrows; r += wstep, g += gstep, l += wlstep)
-                *reinterpret_cast<__attribute__((address_space(3))) u32x4 *>(buf_w + l) = ld16(g);      // 16-byte aligned when the row stride is a multiple of 16 bytes (our planes: 64)
+            {
+                const u32x4 v = ld16(ref + g);      // 16-byte aligned when the row stride is a multiple of 16 bytes (our planes: 64)
+                buf_w[l] = v.x; buf_w[l + 1] = v.y; buf_w[l + 2] = v.z; buf_w[l + 3] = v.w;
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (sums)
         {
-            const char *sp = src + (long)(ys + y0) * ssb + xb;
+            uint32_t sp = s0 + (uint32_t)(ys + y0) * ssb + xb;
             int l = 0;
 #pragma unroll 2
             for (int y = y0; y < he; y += rpi, sp += sstep, l += lstep)
             {
                 if (CB == 16)
                 {
-                    const u32x4 a = ld16(sp);
+                    const u32x4 a = ld16(src + sp);
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
                     {
-                        const u32x4u b = *reinterpret_cast<LP16>(buf_r + lo[k] + l);
-                        acc[k] = sad_dword<S>(a.x, b.x, acc[k]);
-                        acc[k] = sad_dword<S>(a.y, b.y, acc[k]);
-                        acc[k] = sad_dword<S>(a.z, b.z, acc[k]);
-                        acc[k] = sad_dword<S>(a.w, b.w, acc[k]);
+                        const auto q = buf_r + lo[k] + l;
+                        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
+                        acc[k] = sad_dword<S>(a.x, __builtin_amdgcn_alignbyte(d1, d0, sh[k]), acc[k]);
+                        acc[k] = sad_dword<S>(a.y, __builtin_amdgcn_alignbyte(d2, d1, sh[k]), acc[k]);
+                        acc[k] = sad_dword<S>(a.z, __builtin_amdgcn_alignbyte(d3, d2, sh[k]), acc[k]);
+                        acc[k] = sad_dword<S>(a.w, __builtin_amdgcn_alignbyte(d4, d3, sh[k]), acc[k]);
                     }
                 }
                 else if (CB == 8)
                 {
-                    const u32x2 a = ld8(sp);
+                    const u32x2 a = ld8(src + sp);
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
                     {
-                        const u32x2u b = *reinterpret_cast<LP8>(buf_r + lo[k] + l);
-                        acc[k] = sad_dword<S>(a.x, b.x, acc[k]);
-                        acc[k] = sad_dword<S>(a.y, b.y, acc[k]);
+                        const auto q = buf_r + lo[k] + l;
+                        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+                        acc[k] = sad_dword<S>(a.x, __builtin_amdgcn_alignbyte(d1, d0, sh[k]), acc[k]);
+                        acc[k] = sad_dword<S>(a.y, __builtin_amdgcn_alignbyte(d2, d1, sh[k]), acc[k]);
                     }
                 }
                 else
                 {
-                    const uint32_t a = ld4(sp);
+                    const uint32_t a = ld4(src + sp);
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) acc[k] = sad_dword<S>(a, *reinterpret_cast<LP4>(buf_r + lo[k] + l), acc[k]);
+                    for (int k = 0; k < 4; ++k)
+                    {
+                        const auto q = buf_r + lo[k] + l;
+                        acc[k] = sad_dword<S>(a, __builtin_amdgcn_alignbyte(q[1], q[0], sh[k]), acc[k]);
+                    }
                 }
             }
         }
@@ -247,7 +265,9 @@ template <int S>
 __global__ __launch_bounds__(256) void k_sad4w(const char *__restrict__ src, long stride_src, const char *__restrict__ ref, long stride_ref, float inv_stride_ref,
                                                const int32_t *__restrict__ jobs, int njobs, int32_t *__restrict__ out)
 {
-    __shared__ __attribute__((aligned(16))) char lds[256 / kSadLanes][kSadWinBytes * S];
+    // a job's buffer: kSadWinBytes * S bytes + 16 dwords, so that consecutive jobs' buffers start 16 banks apart, + the dword a shifted read takes beyond the last row
+    constexpr int kBufD = kSadWinBytes * S / 4 + 16;
+    __shared__ uint32_t lds[(256 / kSadLanes) * kBufD + 4];
     const int group = threadIdx.x / kSadLanes, lane = threadIdx.x & (kSadLanes - 1);
     const int job = xcd_block(blockIdx.x, gridDim.x) * (256 / kSadLanes) + group;
     const bool live = job < njobs;
@@ -279,10 +299,13 @@ __global__ __launch_bounds__(256) void k_sad4w(const char *__restrict__ src, lon
     const int spready = maxdy - mindy;
     const long minoff = ((long)ro[0] + (long)mindy * st + mindx) * S;      // bytes from `ref` to the window's first sample
     const int lead = (int)(reinterpret_cast<uintptr_t>(ref + minoff) & 15);
-    const int pitch = (lead + rowBytes + (maxdx - mindx) * S + 15) & ~15;
-    const int fit = pitch > 0 ? (kSadWinBytes * S) / pitch - spready : 0;      // block rows per strip
+    const int chunks = (lead + rowBytes + (maxdx - mindx) * S + 15) >> 4;      // 16-byte pieces of a window row
+    const int pitchD = 4 * chunks + 1;                                          // dwords per window row in LDS: odd (see sad4_window_strips)
+    const int fit = chunks > 0 && chunks <= kSadLanes ? smallDiv(kSadWinBytes * S / 4, pitchD) - spready : 0;      // block rows per strip
     const bool chunked = (rowBytes & 3) == 0 && rowBytes <= 16 * kSadLanes;
-    const bool window = live && chunked && pitch <= 16 * kSadLanes && minoff >= 16 && fit >= min(h, 4) && fit >= 1;
+    // (the strips address both pictures with 32-bit byte offsets from their base pointers: a block that reaches beyond 4 GB takes the direct path)
+    const bool near = minoff + (long)(h + spready) * rsb + 16 * chunks < (1ll << 32) && ((long)so * S + (long)h * ssb + rowBytes) < (1ll << 32) && ssb < (1 << 24);
+    const bool window = live && chunked && chunks <= kSadLanes && minoff >= 16 && fit >= min(h, 4) && fit >= 1 && near;
     if (window)
     {
         int ox[4], oy[4];
@@ -292,13 +315,13 @@ __global__ __launch_bounds__(256) void k_sad4w(const char *__restrict__ src, lon
             ox[k] = (dx[k] - mindx) * S;
             oy[k] = dy[k] - mindy;
         }
-        const char *a0 = ref + (minoff - lead);
-        const auto buf_r = (const __attribute__((address_space(3))) char *)(&lds[group][0]);
-        const auto buf_w = (__attribute__((address_space(3))) char *)(&lds[group][0]);
+        const uint32_t a0 = (uint32_t)(minoff - lead), s0 = (uint32_t)so * S;
+        const auto buf_r = (const __attribute__((address_space(3))) uint32_t *)(&lds[group * kBufD]);
+        const auto buf_w = (__attribute__((address_space(3))) uint32_t *)(&lds[group * kBufD]);
         const int hs = min(fit, h);
-        if ((rowBytes & 15) == 0) sad4_window_strips<S, 16>(s, ssb, a0, rsb, buf_r, buf_w, pitch, lead, ox, oy, spready, rowBytes, h, hs, lane, acc);
-        else if ((rowBytes & 7) == 0) sad4_window_strips<S, 8>(s, ssb, a0, rsb, buf_r, buf_w, pitch, lead, ox, oy, spready, rowBytes, h, hs, lane, acc);
-        else sad4_window_strips<S, 4>(s, ssb, a0, rsb, buf_r, buf_w, pitch, lead, ox, oy, spready, rowBytes, h, hs, lane, acc);
+        if ((rowBytes & 15) == 0) sad4_window_strips<S, 16>(src, s0, (uint32_t)ssb, ref, a0, (uint32_t)rsb, buf_r, buf_w, pitchD, chunks, lead, ox, oy, spready, rowBytes, h, hs, lane, acc);
+        else if ((rowBytes & 7) == 0) sad4_window_strips<S, 8>(src, s0, (uint32_t)ssb, ref, a0, (uint32_t)rsb, buf_r, buf_w, pitchD, chunks, lead, ox, oy, spready, rowBytes, h, hs, lane, acc);
+        else sad4_window_strips<S, 4>(src, s0, (uint32_t)ssb, ref, a0, (uint32_t)rsb, buf_r, buf_w, pitchD, chunks, lead, ox, oy, spready, rowBytes, h, hs, lane, acc);
     }
     else
     {   // the direct path of k_sad<S, 4>: far-apart candidates, generic widths, a window at the very start of the buffer
