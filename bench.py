@@ -1548,7 +1548,11 @@ def main():
                          "valu_busy_pct": valu_busy_from_profiles(dom, wl.S),
                          "note": ("k_rdoq_walk is a chain of dependent integer decisions per transform block (4 bytes of traffic per coefficient): it is "
                                   "bound by instruction issue and latency, not by HBM -- profiles/r02_sq_counters.csv has its instruction counts; the "
-                                  "HBM-bound kernels of the step are in whole_step.kernel_gbs") if dom == "rdoq" else None},
+                                  "HBM-bound kernels of the step are in whole_step.kernel_gbs") if dom == "rdoq" else
+                                 ("achieved counts SURVEY 8(d)'s operand bytes of every call (sad4: 5 w h S + 16): the calls of a search overlap, so each reference "
+                                  "sample is an operand of many calls and most operand bytes are served by L2 and, since round 4, by the LDS window the four candidates of a "
+                                  "call share (k_sad4w) -- frac above 1 says exactly that; what reaches HBM is `traffic`, and what bounds the kernel is VALU issue and LDS "
+                                  "cycles (profiles/r04/sad4_counters.txt)") if dom == "sad4" else None},
             "whole_step": {"algorithmic_bytes": total_bytes, "achieved_gbs": round(total_bytes / (ms_step * 1e-3) / 1e9, 2),
                            "kernel_ms": {k: round(v, 4) for k, v in sorted(ktimes.items(), key=lambda kv: -kv[1])},
                            "kernel_gbs": {k: round(kbytes[k] / (v * 1e-3) / 1e9, 1) for k, v in ktimes.items()}},

@@ -157,10 +157,11 @@ __global__ __launch_bounds__(256, MINW) void k_sad(const char *__restrict__ src,
 // as before) copies the bounding box of the four blocks into LDS ONCE, with 16-byte ALIGNED loads in strips of block rows, and the four
 // SADs read their (unaligned) rows from LDS.  A box that does not fit (far rings of the star: positions 16+ samples apart) takes the direct path.
 // MEASURED (profiles/r04/sad4_counters.txt): the direct kernel is bound by the L1's access rate -- 474 M cache accesses per launch, texture addresser
-// busy 82 % of the launch -- and this form cuts the accesses to 112 M and the addresser's busy time by 45 %, but it is NOT faster (0.572 against 0.561 ms):
-// the byte-unaligned 16-byte LDS reads stall the LDS pipeline (SQ_LDS_UNALIGNED_STALL 218 M, a third of all wavefront cycles waiting on LDS) and it
-// issues 2.2 x the VALU instructions.  Kept behind HAVOC_SAD4_WINDOW=1 with its parity tests; what would make it pay is reads aligned to 4 bytes with the
-// candidates' byte shifts done by v_mqsad_u32_u8 as k_sad_surface does (next round).
+// busy 82 % of the launch; the window cuts the accesses to 112 M.  Its first form (byte-unaligned 16-byte LDS reads) was no faster, 0.572 against 0.561 ms:
+// SQ_LDS_UNALIGNED_STALL took a third of the wavefronts' cycles and it issued 2.2 x the VALU instructions.  This form -- window rows at an odd dword pitch,
+// dword-aligned reads + v_alignbyte_b32, no integer division, 32-bit offsets from scalar base pointers -- runs the same calls in 0.39 ms (the direct kernel:
+// 0.57 ms in the same runs) and is the default; what is left is VALU issue (152 M instructions) and LDS cycles (124 M, a third of them bank conflicts
+// between the two jobs that share a 32-lane access group).
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kSadWinBytes = 1536;      // LDS per lane group and per byte of sample size: 24 KB (8-bit) / 48 KB (16-bit) per workgroup
 
@@ -261,12 +262,12 @@ __device__ __forceinline__ void sad4_window_strips(const char *src, uint32_t s0,
     }
 }
 
-template <int S>
-__global__ __launch_bounds__(256) void k_sad4w(const char *__restrict__ src, long stride_src, const char *__restrict__ ref, long stride_ref, float inv_stride_ref,
+template <int S, int WB = kSadWinBytes, int MINW = 1>
+__global__ __launch_bounds__(256, MINW) void k_sad4w(const char *__restrict__ src, long stride_src, const char *__restrict__ ref, long stride_ref, float inv_stride_ref,
                                                const int32_t *__restrict__ jobs, int njobs, int32_t *__restrict__ out)
 {
     // a job's buffer: kSadWinBytes * S bytes + 16 dwords, so that consecutive jobs' buffers start 16 banks apart, + the dword a shifted read takes beyond the last row
-    constexpr int kBufD = kSadWinBytes * S / 4 + 16;
+    constexpr int kBufD = WB * S / 4 + 16;
     __shared__ uint32_t lds[(256 / kSadLanes) * kBufD + 4];
     const int group = threadIdx.x / kSadLanes, lane = threadIdx.x & (kSadLanes - 1);
     const int job = xcd_block(blockIdx.x, gridDim.x) * (256 / kSadLanes) + group;
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(256) void k_sad4w(const char *__restrict__ src, lon
     const int lead = (int)(reinterpret_cast<uintptr_t>(ref + minoff) & 15);
     const int chunks = (lead + rowBytes + (maxdx - mindx) * S + 15) >> 4;      // 16-byte pieces of a window row
     const int pitchD = 4 * chunks + 1;                                          // dwords per window row in LDS: odd (see sad4_window_strips)
-    const int fit = chunks > 0 && chunks <= kSadLanes ? smallDiv(kSadWinBytes * S / 4, pitchD) - spready : 0;      // block rows per strip
+    const int fit = chunks > 0 && chunks <= kSadLanes ? smallDiv(WB * S / 4, pitchD) - spready : 0;      // block rows per strip
     const bool chunked = (rowBytes & 3) == 0 && rowBytes <= 16 * kSadLanes;
     // (the strips address both pictures with 32-bit byte offsets from their base pointers: a block that reaches beyond 4 GB takes the direct path)
     const bool near = minoff + (long)(h + spready) * rsb + 16 * chunks < (1ll << 32) && ((long)so * S + (long)h * ssb + rowBytes) < (1ll << 32) && ssb < (1 << 24);
@@ -733,14 +734,14 @@ __global__ __launch_bounds__(256) void k_ssd_linear(const uint8_t *__restrict__ 
 // launchers (called from api.hip)
 // ---------------------------------------------------------------------------------------------------------
 
-// which 4-way kernel (read once per process):  default = k_sad<S, 4> with two rows in flight per lane and 61 registers (8 wavefronts per SIMD: measured
-// 0.537 ms for the 1.27 M calls of a 1080p picture against 0.561 ms for round 1's four rows / 89 registers);  HAVOC_SAD4_DIRECT=1 = round 1's form;
-// HAVOC_SAD4_WINDOW=1 = k_sad4w, the candidates' common window through LDS (0.572 ms: kept as a measured experiment, parity-tested)
+// which 4-way kernel (read once per process).  Default = k_sad4w, the candidates' common window through LDS: 0.39 ms for the 1.27 M calls of a 1080p picture
+// (profiles/r04/sad4_counters.txt; 1 536 B of LDS per job and 6 wavefronts per SIMD -- 1 024 B / 8 wavefronts measured the same, 768 B slower).
+// HAVOC_SAD4_WINDOW=0 = k_sad<S, 4> reading the four blocks directly, two rows in flight per lane (0.57 ms); HAVOC_SAD4_DIRECT=1 = round 1's form of it.
 static int sad4_form()
 {
     static const int v = [] {
         const char *w = getenv("HAVOC_SAD4_WINDOW"), *d = getenv("HAVOC_SAD4_DIRECT");
-        return (w && *w == '1') ? 2 : ((d && *d == '1') ? 1 : 0);
+        return (d && *d == '1') ? 1 : ((w && *w == '0') ? 0 : 2);
     }();
     return v;
 }
