@@ -84,7 +84,15 @@ struct FastDiv
 {
     uint32_t inv;
     int d;
-    __device__ __forceinline__ explicit FastDiv(int d_) : inv(((1u << 20) + d_ - 1) / d_), d(d_) {}
+    // inv = ceil(2^20 / d), 1 <= d <= 2^20, WITHOUT an integer division (25 - 30 vector instructions where this is built per call): the float quotient is within
+    // one of the true one, so "floor - 1" is at most 2 below floor(2^20 / d) and the remainder says how many steps are missing
+    __device__ __forceinline__ explicit FastDiv(int d_) : d(d_)
+    {
+        const uint32_t ud = (uint32_t)d_;
+        const uint32_t i0 = (uint32_t)(1048576.0f * __builtin_amdgcn_rcpf((float)d_)) - 1u;
+        const uint32_t r = (1u << 20) - i0 * ud;
+        inv = i0 + (r > 0u) + (r > ud) + (r > 2u * ud);
+    }
     __device__ __forceinline__ int div(int i) const { return d == 1 ? i : (int)(((uint32_t)i * inv) >> 20); }
 };
 

@@ -332,7 +332,7 @@ struct DeviceView
         const int gw = x1 - x0 + 1, gh = y1 - y0 + 1, count = gw * gh;
         if (gw <= 0 || gh <= 0 || count > 16 * 12) return;
         const LdsPtr src = ldsPtr(x->src), win = ldsPtr(x->win);
-        const int seg = (w & 7) ? 4 : 8, segs = w / seg, rows = segs * h;      // row segments of seg samples per displacement
+        const int seg = (w & 7) ? 4 : 8, segs = (w & 7) ? w >> 2 : w >> 3, rows = segs * h;      // row segments of seg samples per displacement
         const FastDiv fg(gw);
         if (rows > 32)
         {
@@ -345,8 +345,8 @@ struct DeviceView
         }
         else
         {
-            const int L = rows <= 4 ? 4 : (rows <= 8 ? 8 : (rows <= 16 ? 16 : 32)), G = kWave / L;
-            const int l = lane & (L - 1), g = lane / L;
+            const int Lsh = rows <= 4 ? 2 : (rows <= 8 ? 3 : (rows <= 16 ? 4 : 5)), L = 1 << Lsh, G = kWave >> Lsh;      // shifts: no division by a variable
+            const int l = lane & (L - 1), g = lane >> Lsh;
             const FastDiv fs(segs);
             const int row = fs.div(l), col = l - row * segs;
             for (int base = 0; base < count; base += kWaves * G)
@@ -430,8 +430,8 @@ struct DeviceView
         const long c0 = clock64();
 #endif
         const LdsPtr src = ldsPtr(x->src);
-        const int ts = ((w | h) & 7) ? 4 : 8, tw = w / ts;
-        const int rows = tw * (h / ts) * ts;
+        const int tsh = ((w | h) & 7) ? 2 : 3, ts = 1 << tsh, tw = w >> tsh;
+        const int rows = tw * (h >> tsh) * ts;
         // the positions stay in registers: position `j` of a lane (group) or wavefront is picked with compares, not by address (an indexed array
         // would live in private memory), and nothing goes through LDS before the SATDs do
 #pragma unroll
@@ -456,8 +456,8 @@ struct DeviceView
         }
         else
         {
-            const int L = rows <= 4 ? 4 : (rows <= 8 ? 8 : (rows <= 16 ? 16 : 32)), G = kWave / L;
-            const int l = lane & (L - 1), g = lane / L;
+            const int Lsh = rows <= 4 ? 2 : (rows <= 8 ? 3 : (rows <= 16 ? 4 : 5)), L = 1 << Lsh, G = kWave >> Lsh;      // shifts: no division by a variable
+            const int l = lane & (L - 1), g = lane >> Lsh;
             const FastDiv fd(tw);
             for (int base = 0; base < n; base += kWaves * G)
             {
@@ -635,7 +635,7 @@ struct DeviceView
     {
         static_assert(kWaves == 4, "a candidate group per wavefront");
         GAP_IN();
-        const int count = n / step, c = lane & 15;
+        const int count = step == 1 ? n : (step == 2 ? n >> 1 : n / step), c = lane & 15;
         const Mv p = pattern[(c < count ? c : 0) * step];
         int px = (origin.x + dist * p.x) / 4, py = (origin.y + dist * p.y) / 4;
         px = min(max(px, (int)limit.lo.x), (int)limit.hi.x);
