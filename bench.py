@@ -1195,9 +1195,15 @@ def decision_path(args, Havoc, res, bit_depth, qp, pictures, seconds=1.5, keep=N
         done = [0] * count
         stop = time.perf_counter() + secs
 
+        only_search = os.environ.get("HAVOC_DECISION_PHASES") == "search"      # diagnostic: what the searches alone would reach (profiles/)
+
         def loop(k):
             while time.perf_counter() < stop:
-                ctxs[k].step()
+                if only_search:
+                    ctxs[k].phase_planes()
+                    ctxs[k].search()
+                else:
+                    ctxs[k].step()
                 done[k] += 1
         t0 = time.perf_counter()
         th = [threading.Thread(target=loop, args=(k,)) for k in range(count)]

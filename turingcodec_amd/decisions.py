@@ -279,6 +279,7 @@ class DecisionPicture:
         self.hv, self.torch, self.hmod = hv, torch, hmod
         self.W, self.H, self.bd, self.qp, self.threads = width, height, bit_depth, qp, threads
         self.search_on_device = search_on_device      # the decision loops inside the kernel (kernels_search.hip) / launch + host replay rounds
+        self.use_graphs, self._graphs = True, {}
         self.S = 1 if bit_depth == 8 else 2
         self.dt = np.uint8 if self.S == 1 else np.uint16
         d = decision_inputs(width, height, bit_depth, qp, seed, density, frames, distance)
@@ -522,9 +523,10 @@ class DecisionPicture:
             hv.rdoq_d(bd, g["log2"], g["level"], g["coef"], self.d_states, g["d_rj"], g["cbf"], g["work"])
             hv.tu_reconstruct_d(bd, 0, g["log2"], g["inv"], g["dshift"], self.crecon, self.cstride, self.cpred, hw, self.d_cpic, self.cstride, g["level"], g["d_fj"], g["ssd"])
 
-    def tu_chain(self, field):
+    def tu_chain(self, field, predicted=False):
         """prediction at the decided vectors, then the residual-quadtree decisions and the reconstruction; returns (decisions, stats)"""
-        self.predict(field)
+        if not predicted:
+            self.predict(field)
         base = self.d_pic.data_ptr()
         self.rqt_results, st = rqt(self.hv.h, self.S, self.bd, base, self.origin, self.stride, self.pred.data_ptr(), self.W, self.recon.data_ptr(), self.origin,
                                    self.stride, self.d_states.data_ptr(), self.quant, self.lam, 1.0 / self.lam, self.units)
@@ -606,14 +608,28 @@ class DecisionPicture:
         self.intra_results = out
         return out
 
+    def _replayed(self, key, fn):
+        """run a FIXED sequence of launches (same kernels, same device buffers every picture: the job tables that depend on the decisions are made on the
+        device) -- the first time as it is (it allocates), the second time recorded into a HIP graph, from then on as one graph launch: a picture's ~70
+        launches after its searches cost their issuing thread ~100 us each with 8 pictures in flight (profiles/r04/inflight8_timeline.txt)"""
+        state = self._graphs.get(key)
+        if not self.use_graphs or state is None:
+            fn()
+            self._graphs[key] = False
+        else:
+            if state is False:
+                state = self._graphs[key] = self.hv.graph_capture(fn)
+            self.hv.graph_launch(state)
+
     def step(self):
         self.phase_planes()
         res, field, stats = self.search()
         if self.intra_parts:
             self.intra_decisions()
-        self.merge_candidates(field)
-        decisions, _ = self.tu_chain(field)
-        self.chroma_chain(field)
+        self._merge = None
+        self._replayed("merge + predict", lambda: (self.merge_candidates(field), self.predict(field)))
+        decisions, _ = self.tu_chain(field, predicted=True)
+        self._replayed("chroma", lambda: self.chroma_chain(field))
         self.cells = self.block_cells(field, decisions)
         self.loop_filter(self.cells)
         self.hv.sync()
