@@ -55,6 +55,8 @@ def parse_args():
     ap.add_argument("--extra-4k", type=int, default=1,
                     help="also measure the 3840x2160 8-bit QP27 workload (BASELINE.json configs[2]) for a few steps and report it under "
                          "`extra` (N=1 only; 0 = off)")
+    ap.add_argument("--bands", type=int, default=0, help="frame-parallel runs: exchange the reference pictures in bands of this many CTU rows (turingcodec_amd/"
+                    "frame_parallel.py: BandPlan; 0 = one broadcast per picture)")
     ap.add_argument("--decisions", type=int, default=1,
                     help="1 (default): the plain N=1 line also carries, under `extra`, the DECISION-DRIVEN path (turingcodec_amd.decisions."
                          "DecisionPicture: motion searches in WPP wavefront order with predictors derived from earlier decisions, batch-fed; then the "
@@ -1047,7 +1049,11 @@ class FramePipeline:
                 self.comm.wait_event(ev)
         if staged is not None:
             self.comm.wait_event(staged)
-        exch.send(t)
+        if exch.plan is not None:          # --bands: the same bytes in CTU-row bands (three broadcasts per band), a band's rows usable as soon as they land
+            for b in range(exch.plan.n_bands):
+                exch.send_band(t, b)
+        else:
+            exch.send(t)
         for src in range(exch.world):
             q = exch.picture_of(t, src)
             if q is not None and q.is_reference:
@@ -1410,6 +1416,9 @@ def main():
         strong = args.scaling == "strong"
         sched = DagSchedule(world, n_sops=(args.pictures - 1) // 8 if strong else None, lag=args.lag or None)
         exch = ReferenceExchange(dist, rank, sched, wl.plane_len, wl.cplane_len, dev.luma, single_rank_broadcast=args.exchange)
+        if args.bands > 0:
+            from turingcodec_amd.frame_parallel import BandPlan
+            exch.set_bands(BandPlan(wl.height, 96, wl.stride, wl.cstride, band_ctu_rows=args.bands))
         comm = torch.cuda.current_stream(local)   # torch.distributed enqueues behind this stream
         pipe = FramePipeline(torch, dist, exch, slots, rank, comm, args.lanes, poc_checksums=args.poc_checksums)
 

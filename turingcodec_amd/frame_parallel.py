@@ -204,6 +204,52 @@ def owner(pic_index: int, world: int) -> int:
     return pic_index % world
 
 
+class BandPlan:
+    """A padded picture cut into bands of whole CTU rows, the granule of the reference's own wait-for-reference rule (turing/TaskEncodeSubstream.cpp:71-95: a CTU
+    starts when the reference picture is reconstructed 4 CTUs to the right / 3 rows below; TaskDeblock.cpp:151-167 publishes the deblocked, padded rows).  Band b
+    holds the picture's CTU rows [b * band_ctu_rows, (b + 1) * band_ctu_rows); the first band also carries the top border, the last one the bottom border, so the
+    bands tile the padded planes exactly.  Chroma rows are the luma rows halved (4:2:0)."""
+
+    def __init__(self, height: int, pad: int, luma_stride: int, chroma_stride: int, band_ctu_rows: int = 4, ctb: int = 64, reach_ctu_rows: int = 3):
+        if height <= 0 or pad < 0 or pad % 2 or band_ctu_rows < 1 or luma_stride <= 0 or chroma_stride <= 0:
+            raise ValueError("band plan: sizes")
+        self.height, self.pad, self.ls, self.cs, self.ctb, self.reach = height, pad, luma_stride, chroma_stride, ctb, reach_ctu_rows
+        self.ctu_rows = (height + ctb - 1) // ctb
+        self.band_ctu_rows = band_ctu_rows
+        self.n_bands = (self.ctu_rows + band_ctu_rows - 1) // band_ctu_rows
+        self.luma_rows_total = height + 2 * pad
+        self.chroma_rows_total = height // 2 + pad
+
+    def luma_rows(self, b: int) -> Tuple[int, int]:
+        """[first, last) rows of band b in the padded luma plane"""
+        lo = 0 if b == 0 else self.pad + b * self.band_ctu_rows * self.ctb
+        hi = self.luma_rows_total if b == self.n_bands - 1 else self.pad + (b + 1) * self.band_ctu_rows * self.ctb
+        return lo, hi
+
+    def chroma_rows(self, b: int) -> Tuple[int, int]:
+        lo, hi = self.luma_rows(b)
+        return lo // 2, (self.chroma_rows_total if b == self.n_bands - 1 else hi // 2)
+
+    def pieces(self, b: int, n_luma: int, n_chroma: int) -> List[Tuple[int, int]]:
+        """band b as [first, last) element ranges of a flat (luma | Cb | Cr) mirror buffer"""
+        (l0, l1), (c0, c1) = self.luma_rows(b), self.chroma_rows(b)
+        return [(l0 * self.ls, l1 * self.ls), (n_luma + c0 * self.cs, n_luma + c1 * self.cs), (n_luma + n_chroma + c0 * self.cs, n_luma + n_chroma + c1 * self.cs)]
+
+    def band_of_ctu_row(self, row: int) -> int:
+        return min(max(row, 0), self.ctu_rows - 1) // self.band_ctu_rows
+
+    def bands_needed(self, ctu_row: int) -> int:
+        """how many bands (0 .. n) of a reference must have arrived before CTU row `ctu_row` of a picture predicting from it may start: the rows down to
+        `reach` CTU rows below it (the reference's rule), i.e. everything up to the band holding that row"""
+        return self.band_of_ctu_row(ctu_row + self.reach) + 1
+
+    def rows_ready(self, bands_arrived: int) -> int:
+        """CTU rows of a dependent picture that may start when the first `bands_arrived` bands of its reference are in the mirror"""
+        if bands_arrived >= self.n_bands:
+            return self.ctu_rows
+        return max(0, bands_arrived * self.band_ctu_rows - self.reach)
+
+
 class ReferenceExchange:
     """Mirror of the decoded-picture buffer on every rank + the broadcast step of a DagSchedule.
 
@@ -232,6 +278,8 @@ class ReferenceExchange:
         self.dpb_cr = [b[n_luma + n_chroma:] for b in self.dpb]
         self.sent_bytes = 0
         self.broadcasts = 0
+        self.plan: Optional[BandPlan] = None
+        self.arrived: Dict[int, int] = {}       # poc -> bands of it in the local mirror (band mode)
 
     def picture_of(self, t: int, rank: Optional[int] = None) -> Optional[Picture]:
         return self.schedule.slot(t)[self.rank if rank is None else rank]
@@ -251,6 +299,46 @@ class ReferenceExchange:
         if pic is not None and pic.is_reference:
             s = self.slot_of(pic.poc)
             self._torch._foreach_copy_([self.dpb_luma[s], self.dpb_cb[s], self.dpb_cr[s]], list(planes))   # one launch
+
+    # ---- the same exchange in CTU-row bands: a band leaves when its rows are deblocked and padded, the rest of the picture still computing ----
+    def set_bands(self, plan: BandPlan):
+        if plan.luma_rows_total * plan.ls > self.nl or plan.chroma_rows_total * plan.cs > self.nc:
+            raise ValueError("band plan does not fit the mirror planes")
+        self.plan = plan
+
+    def stage_band(self, t: int, b: int, planes):
+        """band b of this rank's reconstruction of slot t into the picture's mirror slot; planes = (luma, cb, cr) flat padded planes"""
+        pic = self.picture_of(t)
+        if pic is not None and pic.is_reference:
+            buf = self.dpb[self.slot_of(pic.poc)]
+            bases = (0, self.nl, self.nl + self.nc)
+            for (lo, hi), plane, base in zip(self.plan.pieces(b, self.nl, self.nc), planes, bases):
+                buf[lo:hi].copy_(plane[lo - base:hi - base])
+
+    def send_band(self, t: int, b: int, async_op: bool = False):
+        """band b of every reference picture of slot t, owner -> all; every rank calls it for the same (t, b) in the same order.  Returns the work handles when
+        async_op (the caller waits before the rows that need the band start: rows_ready)."""
+        works = []
+        for src in range(self.world):
+            pic = self.picture_of(t, src)
+            if pic is None or not pic.is_reference:
+                continue
+            buf = self.dpb[self.slot_of(pic.poc)]
+            for lo, hi in self.plan.pieces(b, self.nl, self.nc):
+                piece = buf[lo:hi]
+                if src == self.rank:
+                    self.sent_bytes += piece.numel() * piece.element_size() * (self.world - 1)
+                if self.world > 1 or self.single_rank_broadcast:
+                    w = self.dist.broadcast(piece, src=src, async_op=async_op)
+                    if async_op:
+                        works.append(w)
+                    self.broadcasts += 1
+            self.arrived[pic.poc] = b + 1
+        return works
+
+    def rows_ready(self, poc: int) -> int:
+        """CTU rows of a picture predicting from `poc` that may start now (band mode)"""
+        return self.plan.rows_ready(self.arrived.get(poc, 0))
 
     def send(self, t: int):
         for src in range(self.world):
