@@ -551,6 +551,22 @@ int havoc_mi355x_intra_decide(havoc_mi355x_ctx *ctx, const havoc_mi355x_intra_mp
                               const int32_t *d_cbf, const uint32_t *d_ssd, const int32_t *d_stats, const havoc_mi355x_tu_fused_job *d_tu_jobs, int n, int log2TrafoSize,
                               int32_t reciprocal_lambda_q16, havoc_mi355x_intra_choice *d_out, havoc_mi355x_tu_fused_job *d_final);
 
+/* ---- an intra picture's partitions with their real dependencies (round 4; csrc/kernels_decide.hip) ----
+ * A partition predicts from the reconstruction of what precedes it (turing/Reconstruct.cpp:609-615) and takes candModeList from its neighbours' decided modes
+ * (turing/CandModeList.h:33-95).  A client that runs the batch chain over the partitions level by level (every partition of a level has all its neighbours final)
+ * gets what a level needs from the picture's running state here:
+ *   intra_gather: per partition the 4n + 1 reference samples from the reconstruction picture -- a sample is there when it lies inside the picture and the partition
+ *     owning its 4x4 cell (d_owner, one int32 per cell) precedes this one in coding order (`index`); HEVC 8.4.4.2.2 fills in the others -- written unfiltered and
+ *     [1 2 1]-filtered (turing/IntraReferenceSamples.h:373-421) at the job's nb_off / nbf_off, and cand_mode_list / neighbour_modes of its havoc_mi355x_intra_mpm record
+ *     from d_modes (one byte per cell) left of and above it (above only inside the same CTU row);
+ *   intra_commit: the champions' blocks (block i = n x n samples at i * n * n, as havoc_search_intra_device leaves them) into the picture, their modes into d_modes. */
+typedef struct { int32_t x0, y0, log2, index; } havoc_mi355x_intra_chain_part;        /* 16 bytes */
+typedef struct { int32_t pic_width, pic_height, stride, pad, cells_per_row, bit_depth, ctb_log2, reserved; } havoc_mi355x_intra_chain_layout;      /* 32 bytes */
+int havoc_mi355x_intra_gather(havoc_mi355x_ctx *ctx, int S, const havoc_mi355x_intra_chain_layout *layout, const void *d_rec, const int32_t *d_owner, const uint8_t *d_modes,
+                              const havoc_mi355x_intra_chain_part *d_parts, int n, const havoc_mi355x_intra_search_job *d_jobs, void *d_neighbours, havoc_mi355x_intra_mpm *d_mpm);
+int havoc_mi355x_intra_commit(havoc_mi355x_ctx *ctx, int S, const havoc_mi355x_intra_chain_layout *layout, void *d_rec, uint8_t *d_modes, const havoc_mi355x_intra_chain_part *d_parts,
+                              int n, const void *d_blocks, const int32_t *d_mode);
+
 /* ---- job tables made on the device from the decided motion field (round 4; csrc/kernels_decide.hip) ----
  * Not reference primitives: the reference builds its prediction calls inline from the vectors it has just decided (predictInter, turing/Search.hpp:1659-1706;
  * searchMergeModes :1754-1768).  A batch client whose searches leave the motion field in device memory (havoc_mi355x_search_picture_uni: d_field) gets the

@@ -42,6 +42,8 @@ hipError_t launch_intra_decide(hipStream_t, const void *, const int32_t *, const
                                int, int32_t, void *, void *);
 hipError_t launch_merge_jobs(hipStream_t, const void *, const int16_t *, const int32_t *, const int32_t *, int, int, void *, void *, void *, int16_t *);
 hipError_t launch_pred_jobs(hipStream_t, const void *, const int16_t *, int, const int32_t *, const int32_t *, int, int, int, const int32_t *, void *);
+hipError_t launch_intra_gather(hipStream_t, int, const void *, const void *, const int32_t *, const uint8_t *, const void *, int, const void *, void *, void *);
+hipError_t launch_intra_commit(hipStream_t, int, const void *, void *, uint8_t *, const void *, int, const void *, const void *);
 hipError_t launch_merge_decide(hipStream_t, const int32_t *, const int32_t *, const int32_t *, int, int64_t, int64_t *, int32_t *);
 size_t search_workspace_bytes(int width, int height);
 hipError_t launch_search_list(hipStream_t, int S, const havoc_mi355x_search_params *, const void *, long, long, const void *, long, long, const void *, long, long, const void *,
@@ -606,6 +608,28 @@ int havoc_mi355x_merge_jobs(havoc_mi355x_ctx *ctx, const havoc_mi355x_field_layo
     REQUIRE(n == 0 || (d_field && d_x0 && d_y0 && d_luma_jobs && d_cb_jobs && d_cr_jobs && d_vectors), "null device pointer");
     REQUIRE(((uintptr_t)d_field & 3) == 0 && ((uintptr_t)d_vectors & 3) == 0, "d_field and d_vectors must be 4-byte aligned");
     return check(launch_merge_jobs(LS(ctx), layout, d_field, d_x0, d_y0, n, log2_size, d_luma_jobs, d_cb_jobs, d_cr_jobs, d_vectors), "merge_jobs");
+}
+
+static bool chain_layout_ok(const havoc_mi355x_intra_chain_layout *l)
+{
+    return l && l->pic_width > 0 && l->pic_height > 0 && l->pad >= 1 && l->stride >= l->pic_width + 2 * l->pad && l->cells_per_row >= (l->pic_width + 3) / 4 &&
+           l->bit_depth >= 8 && l->bit_depth <= 16 && l->ctb_log2 >= 4 && l->ctb_log2 <= 6;
+}
+
+int havoc_mi355x_intra_gather(havoc_mi355x_ctx *ctx, int S, const havoc_mi355x_intra_chain_layout *layout, const void *d_rec, const int32_t *d_owner, const uint8_t *d_modes,
+                              const havoc_mi355x_intra_chain_part *d_parts, int n, const havoc_mi355x_intra_search_job *d_jobs, void *d_neighbours, havoc_mi355x_intra_mpm *d_mpm)
+{
+    REQUIRE_CTX(); REQUIRE_S(); REQUIRE(n >= 0, "n < 0"); REQUIRE(chain_layout_ok(layout), "chain layout: sizes, stride or border do not fit");
+    REQUIRE(n == 0 || (d_rec && d_owner && d_modes && d_parts && d_jobs && d_neighbours && d_mpm), "null device pointer");
+    return check(launch_intra_gather(LS(ctx), S, layout, d_rec, d_owner, d_modes, d_parts, n, d_jobs, d_neighbours, d_mpm), "intra_gather");
+}
+
+int havoc_mi355x_intra_commit(havoc_mi355x_ctx *ctx, int S, const havoc_mi355x_intra_chain_layout *layout, void *d_rec, uint8_t *d_modes, const havoc_mi355x_intra_chain_part *d_parts,
+                              int n, const void *d_blocks, const int32_t *d_mode)
+{
+    REQUIRE_CTX(); REQUIRE_S(); REQUIRE(n >= 0, "n < 0"); REQUIRE(chain_layout_ok(layout), "chain layout: sizes, stride or border do not fit");
+    REQUIRE(n == 0 || (d_rec && d_modes && d_parts && d_blocks && d_mode), "null device pointer");
+    return check(launch_intra_commit(LS(ctx), S, layout, d_rec, d_modes, d_parts, n, d_blocks, d_mode), "intra_commit");
 }
 
 int havoc_mi355x_merge_decide(havoc_mi355x_ctx *ctx, const int32_t *d_satd_y, const int32_t *d_satd_cb, const int32_t *d_satd_cr, int n, int64_t reciprocal_sqrt_lambda_q16,

@@ -149,6 +149,126 @@ __global__ __launch_bounds__(256) void k_intra_decide(const IntraCtx *__restrict
     fin[i] = f;
 }
 
+// ---- an intra picture's partitions with their REAL dependencies (round 4; turing/Reconstruct.cpp:609-615, CandModeList.h:33-95) ----------------------------
+// A partition predicts from the RECONSTRUCTION of what precedes it and takes its most probable modes from its neighbours' champions, so the partitions of
+// a picture form a dependency graph; the host cuts it into levels (partitions whose neighbours are all final) and runs the batch chain level by level.
+// What a level needs from the picture's running state is made here, on the device:
+//   k_intra_gather   per partition: the 4n + 1 reference samples from the reconstruction picture with the substitution process of HEVC 8.4.4.2.2 for the
+//                    ones not yet coded / outside the picture (availability = "the 4x4 cell's owner precedes me in coding order"), their [1 2 1]-filtered copy
+//                    (IntraReferenceSamples.h:373-421), and candModeList from the modes decided left of and above it (CandModeList.h)
+//   k_intra_commit   per partition: the champion's reconstruction into the picture, its mode into the mode map
+struct ChainPart { int32_t x0, y0, log2, index; };                                                  // havoc_mi355x_intra_chain_part
+struct ChainLayout { int32_t picWidth, picHeight, stride, pad, cellsPerRow, bitDepth, ctbLog2, reserved; };      // havoc_mi355x_intra_chain_layout
+static_assert(sizeof(ChainPart) == 16 && sizeof(ChainLayout) == 32, "record layouts");
+
+template <int S>
+__global__ __launch_bounds__(64) void k_intra_gather(const ChainLayout L, const char *__restrict__ recv, const int32_t *__restrict__ owner, const uint8_t *__restrict__ modes,
+                                                     const ChainPart *__restrict__ parts, int n, const SearchJob *__restrict__ jobs, char *__restrict__ nbv,
+                                                     IntraCtx *__restrict__ ictx)
+{
+    typedef typename Sample<S>::T T;
+    __shared__ int32_t val[132];
+    __shared__ uint8_t have[132];
+    const int i = blockIdx.x, lane = threadIdx.x;
+    if (i >= n) return;
+    const ChainPart p = parts[i];
+    const SearchJob job = jobs[i];
+    const T *rec = reinterpret_cast<const T *>(recv);
+    T *nb = reinterpret_cast<T *>(nbv);
+    const int nn = 1 << p.log2, len = 4 * nn + 1;
+    auto available = [&](int x, int y) {
+        return x >= 0 && y >= 0 && x < L.picWidth && y < L.picHeight && owner[(y >> 2) * L.cellsPerRow + (x >> 2)] < p.index;
+    };
+    for (int k = lane; k < len; k += 64)
+    {   // k < 2n: the left column from the bottom; 2n: the corner; beyond: the row above
+        const int x = k <= 2 * nn ? p.x0 - 1 : p.x0 + k - 2 * nn - 1;
+        const int y = k < 2 * nn ? p.y0 + 2 * nn - 1 - k : p.y0 - 1;
+        const bool a = available(x, y);
+        have[k] = a;
+        val[k] = a ? (int)rec[(long)(y + L.pad) * L.stride + x + L.pad] : 0;
+    }
+    __syncthreads();
+    if (lane == 0)
+    {   // 8.4.4.2.2: nothing there -> mid grey; else the first sample takes the first one there is, every other missing one its predecessor
+        int first = 0;
+        while (first < len && !have[first]) ++first;
+        if (first == len)
+            for (int k = 0; k < len; ++k) val[k] = 1 << (L.bitDepth - 1);
+        else
+        {
+            if (first) val[0] = val[first];
+            for (int k = 1; k < len; ++k)
+                if (!have[k]) val[k] = val[k - 1];
+        }
+    }
+    __syncthreads();
+    const long base = job.nb_off - (2 * nn + 1), basef = job.nbf_off - (2 * nn + 1);
+    for (int k = lane; k < len; k += 64)
+    {
+        nb[base + k] = (T)val[k];
+        nb[basef + k] = (T)((k == 0 || k == len - 1) ? val[k] : (val[k - 1] + 2 * val[k] + val[k + 1] + 2) >> 2);
+    }
+    if (lane == 0)
+    {   // CandModeList.h:33-95: A = left, B = above (DC when not there, or above in another CTU row)
+        const int a = available(p.x0 - 1, p.y0) ? modes[(p.y0 >> 2) * L.cellsPerRow + ((p.x0 - 1) >> 2)] : 1;
+        const int b = available(p.x0, p.y0 - 1) && (p.y0 - 1) >= ((p.y0 >> L.ctbLog2) << L.ctbLog2) ? modes[((p.y0 - 1) >> 2) * L.cellsPerRow + (p.x0 >> 2)] : 1;
+        IntraCtx c = ictx[i];
+        if (a == b)
+        {
+            c.neighbourModes = 1;
+            if (a < 2) { c.cand[0] = 0; c.cand[1] = 1; c.cand[2] = 26; }
+            else { c.cand[0] = a; c.cand[1] = ((a + 29) % 32) + 2; c.cand[2] = ((a - 1) % 32) + 2; }
+        }
+        else
+        {
+            c.neighbourModes = 2;
+            c.cand[0] = a; c.cand[1] = b;
+            c.cand[2] = (a != 0 && b != 0) ? 0 : ((a != 1 && b != 1) ? 1 : 26);
+        }
+        ictx[i] = c;
+    }
+}
+
+template <int S>
+__global__ __launch_bounds__(256) void k_intra_commit(const ChainLayout L, char *__restrict__ recv, uint8_t *__restrict__ modes, const ChainPart *__restrict__ parts, int n,
+                                                      const char *__restrict__ blocksv, const int32_t *__restrict__ choice)
+{
+    typedef typename Sample<S>::T T;
+    const int i = blockIdx.x;
+    if (i >= n) return;
+    const ChainPart p = parts[i];
+    const int nn = 1 << p.log2, area = nn * nn;
+    const T *blk = reinterpret_cast<const T *>(blocksv) + (long)i * area;
+    T *rec = reinterpret_cast<T *>(recv);
+    for (int t = threadIdx.x; t < area; t += 256)
+    {
+        const int y = t >> p.log2, x = t & (nn - 1);
+        rec[(long)(p.y0 + y + L.pad) * L.stride + p.x0 + x + L.pad] = blk[t];
+    }
+    const int cw = nn >> 2, mode = choice[i];
+    for (int t = threadIdx.x; t < cw * cw; t += 256)
+        modes[((p.y0 >> 2) + t / cw) * L.cellsPerRow + (p.x0 >> 2) + t % cw] = (uint8_t)mode;
+}
+
+hipError_t launch_intra_gather(hipStream_t st, int S, const void *layout, const void *rec, const int32_t *owner, const uint8_t *modes, const void *parts, int n, const void *jobs,
+                               void *nb, void *ictx)
+{
+    if (n <= 0) return hipSuccess;
+    const ChainLayout L = *static_cast<const ChainLayout *>(layout);
+    if (S == 1) hipLaunchKernelGGL((k_intra_gather<1>), dim3(n), dim3(64), 0, st, L, (const char *)rec, owner, modes, (const ChainPart *)parts, n, (const SearchJob *)jobs, (char *)nb, (IntraCtx *)ictx);
+    else hipLaunchKernelGGL((k_intra_gather<2>), dim3(n), dim3(64), 0, st, L, (const char *)rec, owner, modes, (const ChainPart *)parts, n, (const SearchJob *)jobs, (char *)nb, (IntraCtx *)ictx);
+    return hipGetLastError();
+}
+
+hipError_t launch_intra_commit(hipStream_t st, int S, const void *layout, void *rec, uint8_t *modes, const void *parts, int n, const void *blocks, const void *choice)
+{
+    if (n <= 0) return hipSuccess;
+    const ChainLayout L = *static_cast<const ChainLayout *>(layout);
+    if (S == 1) hipLaunchKernelGGL((k_intra_commit<1>), dim3(n), dim3(256), 0, st, L, (char *)rec, modes, (const ChainPart *)parts, n, (const char *)blocks, (const int32_t *)choice);
+    else hipLaunchKernelGGL((k_intra_commit<2>), dim3(n), dim3(256), 0, st, L, (char *)rec, modes, (const ChainPart *)parts, n, (const char *)blocks, (const int32_t *)choice);
+    return hipGetLastError();
+}
+
 // ---- job tables made ON THE DEVICE from the decided motion field (round 4): what a host would otherwise build per picture and upload -----------------
 // The prediction jobs of the steps that follow the searches -- every unit at its decided vector (luma 8-tap, chroma 4-tap), every unit's spatial merge
 // candidates bi-directionally in three planes -- depend on the field the search kernel has just left in device memory; building them there keeps the

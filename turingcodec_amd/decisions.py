@@ -235,6 +235,113 @@ def intra_modes(ctx, S, bit_depth, log2, d_src, src_stride, d_neighbours, d_jobs
     return out
 
 
+class IntraChainPicture:
+    """An INTRA picture with the real dependencies between its partitions (round 4): every partition predicts from the reconstruction
+    of the partitions before it and takes its most probable modes from its neighbours' champions (turing/Reconstruct.cpp:609-615, CandModeList.h:33-95), so
+    the picture is a dependency graph, cut here into LEVELS of mutually independent partitions (workload.intra_picture_partitions).  A level is one pass of the
+    batch chain: reference samples + candModeList gathered on the device from the running reconstruction / mode map (havoc_mi355x_intra_gather), the 35-mode
+    SATD stage, the refinement order, every candidate through prediction -> T -> RDOQ -> IQ -> IT -> SSD, the champion (havoc_search_intra_device: decisions on the
+    device), and the champions' blocks + modes committed to the picture (havoc_mi355x_intra_commit).  Levels are many (a 4x4 partition's chain reaches across the
+    picture: ~600 at 640x360, ~1 900 at 1080p) and each is launch-bound -- the whole picture inside one persistent kernel is the form that would pay; this one is
+    the parity-checked statement of the chain."""
+
+    PAD = 96
+
+    def __init__(self, hv, width, height, bit_depth=8, qp=32, seed=11):
+        import torch
+        from . import havoc as hmod
+        from . import workload
+        self.hv, self.torch = hv, torch
+        self.W, self.H, self.bd, self.qp = width, height, bit_depth, qp
+        self.S = 1 if bit_depth == 8 else 2
+        self.dt = np.uint8 if self.S == 1 else np.uint16
+        src = workload.pad_plane(workload.synth_frames(width, height, 1, seed, bit_depth)[0][0], self.PAD)
+        self.stride = src.shape[1]
+        self.host_src = np.ascontiguousarray(src.ravel())
+        self.n = self.host_src.size
+        self.d_src = hv.up(self.host_src)
+        self.d_rec = hv.zeros(self.n, self.dt)
+        self.parts, self.owner, self.level = workload.intra_picture_partitions(width, height, seed + 3)
+        self.cells_per_row = self.owner.shape[1]
+        self.d_owner = hv.up(np.ascontiguousarray(self.owner.ravel()))
+        self.d_modes = hv.zeros(self.owner.size, np.uint8)
+        self.cx = (width + 63) // 64
+        self.lam = workload.picture_lambda(qp)
+        self.rsl = float(1.0 / np.sqrt(self.lam))
+        self.quant = rqt_quant(qp, bit_depth)
+        rng = np.random.default_rng(seed + 7919)
+        base = rng.integers(4, 100, 128)
+        self.rdoq_states = np.clip(base[None, :] + rng.integers(-6, 7, (self.cx * ((height + 63) // 64), 128)), 0, 125).astype(np.uint8)
+        self.d_states = hv.up(self.rdoq_states.reshape(-1))
+        self.layout = hv.intra_chain_layout(width, height, self.stride, self.PAD, self.cells_per_row, bit_depth)
+        # per size: the partitions of that size ordered by level, their tables, and for every level the slice [first, first + count)
+        self.sizes, self.nlevels = {}, int(self.level.max()) + 1
+        for log2 in (5, 4, 3, 2):
+            sel = np.flatnonzero(self.parts["log2"] == log2)
+            if not len(sel):
+                continue
+            sel = sel[np.argsort(self.level[sel], kind="stable")]
+            m, nn = len(sel), 1 << log2
+            L = 4 * nn + 1
+            x0, y0 = self.parts["x0"][sel].astype(np.int64), self.parts["y0"][sel].astype(np.int64)
+            mask = workload.intra_filter_mask(nn)
+            jobs = np.zeros((m, 8), np.int64)
+            jobs[:, 0] = (y0 + self.PAD) * self.stride + x0 + self.PAD
+            jobs[:, 1] = np.arange(m) * 2 * L + 2 * nn + 1
+            jobs[:, 2] = jobs[:, 1] + L
+            jobs[:, 3], jobs[:, 4], jobs[:, 5] = mask & 0xffffffff, mask >> 32, 1
+            jobs = jobs.astype(np.uint32).view(np.int32).reshape(m, 8)
+            ictx = np.zeros(m, INTRA_CTX_DT)
+            ictx["max_refine"] = 3 if log2 > 3 else 8            # Speed::nCandidatesIntraRefinement at medium
+            ictx["rate_a_minus_c"] = -rng.integers(300000, 420000, m)
+            ictx["rate_b_minus_c"] = -rng.integers(100000, 200000, m)
+            chain = np.zeros((m, 4), np.int32)
+            chain[:, 0], chain[:, 1], chain[:, 2], chain[:, 3] = x0, y0, log2, sel
+            ctu = ((y0 // 64) * self.cx + x0 // 64).astype(np.int32)
+            first = np.searchsorted(self.level[sel], np.arange(self.nlevels + 1)).astype(np.int64)
+            self.sizes[log2] = dict(sel=sel, m=m, nn=nn, jobs=jobs, ictx=ictx, ctu=ctu, first=first, d_jobs=hv.up(jobs), d_nb=hv.zeros(m * 2 * L, self.dt),
+                                    d_ictx=hv.up(np.ascontiguousarray(ictx).view(np.int32)), d_ctu=hv.up(ctu), d_parts=hv.up(chain), d_blocks=hv.zeros(m * nn * nn, self.dt),
+                                    d_mode=hv.zeros(m, np.int32), best=np.zeros(m, INTRA_RD_RESULT_DT))
+        hv.sync()
+
+    def step(self):
+        """the picture, level by level; leaves the champions in self.sizes[log2]["best"] (ordered as ["sel"]), the reconstruction in self.d_rec"""
+        hv, S, torch = self.hv, self.S, self.torch
+        self.launches = 0
+        for lvl in range(self.nlevels):
+            groups, live = [], []
+            for log2, g in self.sizes.items():
+                a, b = int(g["first"][lvl]), int(g["first"][lvl + 1])
+                if b == a:
+                    continue
+                n, area = b - a, g["nn"] * g["nn"]
+                hv.intra_gather_a(S, self.layout, self.d_rec.data_ptr(), self.d_owner.data_ptr(), self.d_modes.data_ptr(), g["d_parts"].data_ptr() + 16 * a, n,
+                                  g["d_jobs"].data_ptr() + 32 * a, g["d_nb"].data_ptr(), g["d_ictx"].data_ptr() + 40 * a)
+                groups.append(dict(log2=log2, n=n, d_nb=g["d_nb"].data_ptr(), d_jobs=g["d_jobs"].data_ptr() + 32 * a, d_ictx=g["d_ictx"].data_ptr() + 40 * a,
+                                   d_ctu=g["d_ctu"].data_ptr() + 4 * a, d_rec=g["d_blocks"].data_ptr() + a * area * S))
+                live.append((log2, g, a, b))
+            best, st = intra_device(hv.h, S, self.bd, self.d_src.data_ptr(), self.stride, groups, self.d_states.data_ptr(), self.quant, self.rsl, self.lam, 1.0 / self.lam)
+            self.launches += st.launches + 2 * len(live)
+            for log2, g, a, b in live:
+                g["best"][a:b] = best[log2]
+                with torch.cuda.stream(hv.tstream):
+                    g["d_mode"][a:b].copy_(torch.from_numpy(np.ascontiguousarray(best[log2]["mode"])), non_blocking=False)
+                hv.intra_commit_a(S, self.layout, self.d_rec.data_ptr(), self.d_modes.data_ptr(), g["d_parts"].data_ptr() + 16 * a, b - a,
+                                  g["d_blocks"].data_ptr() + a * g["nn"] * g["nn"] * S, g["d_mode"].data_ptr() + 4 * a)
+        hv.sync()
+
+    def results(self):
+        """(champions INTRA_RD_RESULT_DT [partitions] in CODING order, candModeList the device derived [partitions, 3], neighbour_modes, reconstruction plane)"""
+        hv = self.hv
+        best = np.zeros(len(self.parts), INTRA_RD_RESULT_DT)
+        cand, nbm = np.zeros((len(self.parts), 3), np.int32), np.zeros(len(self.parts), np.int32)
+        for g in self.sizes.values():
+            best[g["sel"]] = g["best"]
+            ic = hv.down(g["d_ictx"], np.int32).view(INTRA_CTX_DT)
+            cand[g["sel"]], nbm[g["sel"]] = ic["cand_mode_list"], ic["neighbour_modes"]
+        return best, cand, nbm, hv.down(self.d_rec, self.dt)
+
+
 def rqt_units(width, height, ctus_x):
     """the inter units whose transform trees are decided: 32x32 units where they fit, 16x16 then 8x8 units along a partial last row / column"""
     rows = []

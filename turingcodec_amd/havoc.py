@@ -94,6 +94,8 @@ def _load():
         "tu_reconstruct": [_vp, _i, _i, _i, _i, _i, _i, _vp, _ip, _vp, _ip, _vp, _ip, _vp, _vp, _i, _vp],
         "level_stats": [_vp, _vp, _vp, _i, _vp],
         "search_motion_uni": [_vp, _i, _vp, _vp, C.c_int64, _ip, _vp, C.c_int64, _ip, _vp, _ip, C.c_int64, _vp, _i, _vp],
+        "intra_gather": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp],
+        "intra_commit": [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp],
         "merge_jobs": [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
         "merge_decide": [_vp, _vp, _vp, _vp, _i, C.c_int64, _vp, _vp],
         "pred_jobs": [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp],
@@ -343,6 +345,18 @@ class Havoc:
     @staticmethod
     def field_layout(pic_width, pic_height, luma_stride, luma_pad, luma_plane_elems, chroma_stride, chroma_pad, chroma_plane_elems, search_range=64):
         return (C.c_int32 * 12)(pic_width, pic_height, search_range, (pic_width + 3) // 4, luma_stride, luma_pad, luma_plane_elems, chroma_stride, chroma_pad, chroma_plane_elems, 0, 0)
+
+    # ---- an intra picture's running state (kernels_decide.hip: k_intra_gather, k_intra_commit) ----
+    @staticmethod
+    def intra_chain_layout(pic_width, pic_height, stride, pad, cells_per_row, bit_depth, ctb_log2=6):
+        return (C.c_int32 * 8)(pic_width, pic_height, stride, pad, cells_per_row, bit_depth, ctb_log2, 0)
+
+    def intra_gather_a(self, S, layout, rec, owner, modes, parts, n, jobs, neighbours, mpm):
+        """device ADDRESSES (ints): a level's slice of a size's tables"""
+        self._ck(self.L.havoc_mi355x_intra_gather(self.h, S, layout, rec, owner, modes, parts, n, jobs, neighbours, mpm))
+
+    def intra_commit_a(self, S, layout, rec, modes, parts, n, blocks, mode):
+        self._ck(self.L.havoc_mi355x_intra_commit(self.h, S, layout, rec, modes, parts, n, blocks, mode))
 
     def merge_jobs_d(self, layout, field, x0, y0, log2, luma_jobs, cb_jobs, cr_jobs, vectors):
         self._ck(self.L.havoc_mi355x_merge_jobs(self.h, layout, _ptr(field), _ptr(x0), _ptr(y0), x0.shape[0], log2, _ptr(luma_jobs), _ptr(cb_jobs), _ptr(cr_jobs), _ptr(vectors)))

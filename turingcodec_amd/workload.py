@@ -165,6 +165,55 @@ def intra_partitions(src2d, width, height, pad, seed, per_ctu=48.8):
     return out
 
 
+def intra_picture_partitions(width, height, seed):
+    """An intra picture as the reference codes it: every CTU a quadtree of coding units in z-order, each one intra partition (2Nx2N; 64x64 units as four
+    32x32 transform blocks) or, at 8x8, four 4x4 partitions (NxN) -- areas roughly 40 / 30 / 15 / 15 % in 32 / 16 / 8 / 4-sample partitions.  The partitions tile the
+    picture (width, height multiples of 8) and DEPEND on each other: a partition predicts from the reconstruction of the ones before it (Reconstruct.cpp:609-615).
+    Returns (parts [n] of (x0, y0, log2) in coding order, owner int32 [height / 4, width / 4] = the partition holding each 4x4 cell, level int32 [n]: 1 + the
+    highest level among the partitions whose samples its reference samples are taken from -- partitions of one level are independent of each other)."""
+    assert width % 8 == 0 and height % 8 == 0
+    rng = np.random.default_rng(seed)
+    parts = []
+
+    def walk(x, y, size):
+        if x >= width or y >= height:
+            return
+        inside = x + size <= width and y + size <= height
+        if size == 64 or not inside or (size > 8 and rng.random() < (0.6 if size == 32 else 0.5)):
+            h = size // 2
+            for dy, dx in ((0, 0), (0, h), (h, 0), (h, h)):
+                walk(x + dx, y + dy, h)
+        elif size == 8 and rng.random() < 0.5:
+            for dy, dx in ((0, 0), (0, 4), (4, 0), (4, 4)):
+                parts.append((x + dx, y + dy, 2))
+        else:
+            parts.append((x, y, size.bit_length() - 1))
+
+    for cy in range(0, height, CTU):
+        for cx in range(0, width, CTU):
+            walk(cx, cy, CTU)
+    parts = np.array(parts, np.dtype([("x0", "i4"), ("y0", "i4"), ("log2", "i4")]))
+    owner = np.full((height // 4, width // 4), -1, np.int32)
+    for i, q in enumerate(parts):
+        n4 = (1 << q["log2"]) >> 2
+        owner[q["y0"] // 4:q["y0"] // 4 + n4, q["x0"] // 4:q["x0"] // 4 + n4] = i
+    assert (owner >= 0).all()
+    level = np.zeros(len(parts), np.int32)
+    for i, q in enumerate(parts):
+        x4, y4, n4 = q["x0"] // 4, q["y0"] // 4, (1 << q["log2"]) >> 2
+        near = []
+        if x4 > 0:
+            near.append(owner[max(0, y4 - 1):min(owner.shape[0], y4 + 2 * n4), x4 - 1])      # the corner, the left column, below-left
+        if y4 > 0:
+            near.append(owner[y4 - 1, x4:min(owner.shape[1], x4 + 2 * n4)])                  # above, above-right
+        if near:
+            o = np.concatenate(near)
+            o = o[o < i]
+            if len(o):
+                level[i] = level[o].max() + 1
+    return parts, owner, level
+
+
 def synth_frames(width, height, nframes, seed, bit_depth=8):
     """SURVEY.md 8(d) generator: low-passed noise translating by (3,2) px/frame blended 60/40 with a moving
     sinusoid, +-3 uniform noise; smooth chroma ramps.  Returns [(Y, U, V)] unpadded planes."""
