@@ -565,7 +565,12 @@ typedef struct { int32_t pic_width, pic_height, stride, pad, cells_per_row, bit_
 int havoc_mi355x_intra_gather(havoc_mi355x_ctx *ctx, int S, const havoc_mi355x_intra_chain_layout *layout, const void *d_rec, const int32_t *d_owner, const uint8_t *d_modes,
                               const havoc_mi355x_intra_chain_part *d_parts, int n, const havoc_mi355x_intra_search_job *d_jobs, void *d_neighbours, havoc_mi355x_intra_mpm *d_mpm);
 int havoc_mi355x_intra_commit(havoc_mi355x_ctx *ctx, int S, const havoc_mi355x_intra_chain_layout *layout, void *d_rec, uint8_t *d_modes, const havoc_mi355x_intra_chain_part *d_parts,
-                              int n, const void *d_blocks, const int32_t *d_mode);
+                              int n, const void *d_blocks, const int32_t *d_mode, int mode_stride);      /* mode of partition i = d_mode[i * mode_stride]: a plain array (1) or
+                                                                                                            havoc_mi355x_intra_choice records (10) */
+/* after intra_expand: the candidate slots [d_total[0], capacity) that no partition was given become copies of slot 0's records writing into their own slots, so the chain
+ * (intra -> tu_forward -> rdoq -> tu_reconstruct -> level_stats) can run over `capacity` = n * HAVOC_MI355X_INTRA_MAX_ORDER jobs WITHOUT the host waiting for the count */
+int havoc_mi355x_intra_fill_spare(havoc_mi355x_ctx *ctx, const int32_t *d_total, int capacity, int log2TrafoSize, havoc_mi355x_intra_job *d_intra_jobs,
+                                  havoc_mi355x_tu_fused_job *d_tu_jobs, havoc_mi355x_rdoq_job *d_rdoq_jobs, int32_t *d_stat_jobs, int32_t *d_owner);
 
 /* ---- job tables made on the device from the decided motion field (round 4; csrc/kernels_decide.hip) ----
  * Not reference primitives: the reference builds its prediction calls inline from the vectors it has just decided (predictInter, turing/Search.hpp:1659-1706;

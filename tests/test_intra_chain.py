@@ -99,6 +99,25 @@ def _host_chain(ref, ip):
 
 
 @pytest.mark.gpu
+def test_both_forms_of_the_level_loop_agree():
+    """a wait per level (havoc_search_intra_device per level: candidate counts known to the host) == no wait at all (worst-case candidate slots, spare ones filled)"""
+    from turingcodec_amd.decisions import IntraChainPicture
+    from turingcodec_amd.havoc import Havoc
+    hv = Havoc(stream="new")
+    ip = IntraChainPicture(hv, 416, 240, 8, 32, seed=29)
+    ip.step(wait_per_level=True)
+    a = ip.results()
+    import torch
+    with torch.cuda.stream(hv.tstream):
+        ip.d_rec.zero_()
+        ip.d_modes.zero_()
+    ip.step()
+    b = ip.results()
+    for x, y in zip(a, b):
+        assert x.tobytes() == y.tobytes()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("res,BD,qp", [((416, 240), 8, 32), ((640, 360), 10, 27), ((1920, 1080), 8, 32)])
 def test_intra_picture_with_running_reconstruction_equals_the_reference_loop(res, BD, qp):
     import search_tools as st

@@ -43,7 +43,8 @@ hipError_t launch_intra_decide(hipStream_t, const void *, const int32_t *, const
 hipError_t launch_merge_jobs(hipStream_t, const void *, const int16_t *, const int32_t *, const int32_t *, int, int, void *, void *, void *, int16_t *);
 hipError_t launch_pred_jobs(hipStream_t, const void *, const int16_t *, int, const int32_t *, const int32_t *, int, int, int, const int32_t *, void *);
 hipError_t launch_intra_gather(hipStream_t, int, const void *, const void *, const int32_t *, const uint8_t *, const void *, int, const void *, void *, void *);
-hipError_t launch_intra_commit(hipStream_t, int, const void *, void *, uint8_t *, const void *, int, const void *, const void *);
+hipError_t launch_intra_commit(hipStream_t, int, const void *, void *, uint8_t *, const void *, int, const void *, const void *, int);
+hipError_t launch_intra_fill_spare(hipStream_t, const int32_t *, int, int, void *, void *, void *, int32_t *, int32_t *);
 hipError_t launch_merge_decide(hipStream_t, const int32_t *, const int32_t *, const int32_t *, int, int64_t, int64_t *, int32_t *);
 size_t search_workspace_bytes(int width, int height);
 hipError_t launch_search_list(hipStream_t, int S, const havoc_mi355x_search_params *, const void *, long, long, const void *, long, long, const void *, long, long, const void *,
@@ -625,11 +626,19 @@ int havoc_mi355x_intra_gather(havoc_mi355x_ctx *ctx, int S, const havoc_mi355x_i
 }
 
 int havoc_mi355x_intra_commit(havoc_mi355x_ctx *ctx, int S, const havoc_mi355x_intra_chain_layout *layout, void *d_rec, uint8_t *d_modes, const havoc_mi355x_intra_chain_part *d_parts,
-                              int n, const void *d_blocks, const int32_t *d_mode)
+                              int n, const void *d_blocks, const int32_t *d_mode, int mode_stride)
 {
     REQUIRE_CTX(); REQUIRE_S(); REQUIRE(n >= 0, "n < 0"); REQUIRE(chain_layout_ok(layout), "chain layout: sizes, stride or border do not fit");
-    REQUIRE(n == 0 || (d_rec && d_modes && d_parts && d_blocks && d_mode), "null device pointer");
-    return check(launch_intra_commit(LS(ctx), S, layout, d_rec, d_modes, d_parts, n, d_blocks, d_mode), "intra_commit");
+    REQUIRE(n == 0 || (d_rec && d_modes && d_parts && d_blocks && d_mode), "null device pointer"); REQUIRE(mode_stride >= 1, "mode_stride < 1");
+    return check(launch_intra_commit(LS(ctx), S, layout, d_rec, d_modes, d_parts, n, d_blocks, d_mode, mode_stride), "intra_commit");
+}
+
+int havoc_mi355x_intra_fill_spare(havoc_mi355x_ctx *ctx, const int32_t *d_total, int capacity, int log2TrafoSize, havoc_mi355x_intra_job *d_intra_jobs,
+                                  havoc_mi355x_tu_fused_job *d_tu_jobs, havoc_mi355x_rdoq_job *d_rdoq_jobs, int32_t *d_stat_jobs, int32_t *d_owner)
+{
+    REQUIRE_CTX(); REQUIRE(capacity >= 0, "capacity < 0"); REQUIRE(log2TrafoSize >= 2 && log2TrafoSize <= 5, "log2TrafoSize must be 2..5");
+    REQUIRE(capacity == 0 || (d_total && d_intra_jobs && d_tu_jobs && d_rdoq_jobs && d_stat_jobs && d_owner), "null device pointer");
+    return check(launch_intra_fill_spare(LS(ctx), d_total, capacity, log2TrafoSize, d_intra_jobs, d_tu_jobs, d_rdoq_jobs, d_stat_jobs, d_owner), "intra_fill_spare");
 }
 
 int havoc_mi355x_merge_decide(havoc_mi355x_ctx *ctx, const int32_t *d_satd_y, const int32_t *d_satd_cb, const int32_t *d_satd_cr, int n, int64_t reciprocal_sqrt_lambda_q16,

@@ -231,7 +231,7 @@ __global__ __launch_bounds__(64) void k_intra_gather(const ChainLayout L, const 
 
 template <int S>
 __global__ __launch_bounds__(256) void k_intra_commit(const ChainLayout L, char *__restrict__ recv, uint8_t *__restrict__ modes, const ChainPart *__restrict__ parts, int n,
-                                                      const char *__restrict__ blocksv, const int32_t *__restrict__ choice)
+                                                      const char *__restrict__ blocksv, const int32_t *__restrict__ choice, int choiceStride)
 {
     typedef typename Sample<S>::T T;
     const int i = blockIdx.x;
@@ -245,9 +245,37 @@ __global__ __launch_bounds__(256) void k_intra_commit(const ChainLayout L, char 
         const int y = t >> p.log2, x = t & (nn - 1);
         rec[(long)(p.y0 + y + L.pad) * L.stride + p.x0 + x + L.pad] = blk[t];
     }
-    const int cw = nn >> 2, mode = choice[i];
+    const int cw = nn >> 2, mode = choice[(long)i * choiceStride];      // a plain array of modes (stride 1) or the choice records (stride 10: `mode` leads)
     for (int t = threadIdx.x; t < cw * cw; t += 256)
         modes[((p.y0 >> 2) + t / cw) * L.cellsPerRow + (p.x0 >> 2) + t % cw] = (uint8_t)mode;
+}
+
+// the candidate slots [total[0], capacity) nobody was given: copies of slot 0's records that write into their OWN slots, so that the chain can be launched over
+// `capacity` jobs without the host first learning how many candidates there are (an intra picture's levels: thousands of small batches, no wait between them)
+__global__ __launch_bounds__(256) void k_intra_fill_spare(const int32_t *__restrict__ total, int capacity, int log2, IntraJob *__restrict__ ij, TuJob *__restrict__ tj,
+                                                          RdoqJobRec *__restrict__ rj, int32_t *__restrict__ sj, int32_t *__restrict__ owner)
+{
+    const int c = total[0] + blockIdx.x * 256 + threadIdx.x;
+    if (c >= capacity || total[0] <= 0) return;
+    const int area = 1 << (2 * log2);
+    IntraJob a = ij[0];
+    a.dst_off = c * area;
+    ij[c] = a;
+    const TuJob b = {c * area, tj[0].src_off, c * area, c * area};
+    tj[c] = b;
+    RdoqJobRec r = rj[0];
+    r.dst_off = r.src_off = c * area;
+    rj[c] = r;
+    sj[2 * c] = c * area;
+    sj[2 * c + 1] = area;
+    owner[c] = owner[0];
+}
+
+hipError_t launch_intra_fill_spare(hipStream_t st, const int32_t *total, int capacity, int log2, void *ij, void *tj, void *rj, int32_t *sj, int32_t *owner)
+{
+    if (capacity <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_intra_fill_spare, dim3((capacity + 255) / 256), dim3(256), 0, st, total, capacity, log2, (IntraJob *)ij, (TuJob *)tj, (RdoqJobRec *)rj, sj, owner);
+    return hipGetLastError();
 }
 
 hipError_t launch_intra_gather(hipStream_t st, int S, const void *layout, const void *rec, const int32_t *owner, const uint8_t *modes, const void *parts, int n, const void *jobs,
@@ -260,12 +288,12 @@ hipError_t launch_intra_gather(hipStream_t st, int S, const void *layout, const 
     return hipGetLastError();
 }
 
-hipError_t launch_intra_commit(hipStream_t st, int S, const void *layout, void *rec, uint8_t *modes, const void *parts, int n, const void *blocks, const void *choice)
+hipError_t launch_intra_commit(hipStream_t st, int S, const void *layout, void *rec, uint8_t *modes, const void *parts, int n, const void *blocks, const void *choice, int choiceStride)
 {
     if (n <= 0) return hipSuccess;
     const ChainLayout L = *static_cast<const ChainLayout *>(layout);
-    if (S == 1) hipLaunchKernelGGL((k_intra_commit<1>), dim3(n), dim3(256), 0, st, L, (char *)rec, modes, (const ChainPart *)parts, n, (const char *)blocks, (const int32_t *)choice);
-    else hipLaunchKernelGGL((k_intra_commit<2>), dim3(n), dim3(256), 0, st, L, (char *)rec, modes, (const ChainPart *)parts, n, (const char *)blocks, (const int32_t *)choice);
+    if (S == 1) hipLaunchKernelGGL((k_intra_commit<1>), dim3(n), dim3(256), 0, st, L, (char *)rec, modes, (const ChainPart *)parts, n, (const char *)blocks, (const int32_t *)choice, choiceStride);
+    else hipLaunchKernelGGL((k_intra_commit<2>), dim3(n), dim3(256), 0, st, L, (char *)rec, modes, (const ChainPart *)parts, n, (const char *)blocks, (const int32_t *)choice, choiceStride);
     return hipGetLastError();
 }
 

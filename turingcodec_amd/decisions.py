@@ -99,6 +99,8 @@ def lib():
         L.havoc_search_intra_device.restype = C.c_int
         L.havoc_search_intra_modes.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, ip, vp, vp, C.c_int, vp, C.c_double, vp, vp]
         L.havoc_search_intra_modes.restype = C.c_int
+        L.havoc_search_intra_chain.argtypes = [vp, C.c_int, C.c_int, vp, vp, ip, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, C.c_double, C.c_double, C.c_double, C.c_int, vp]
+        L.havoc_search_intra_chain.restype = C.c_int
         L.havoc_search_block_cells.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp]
         L.havoc_search_block_cells.restype = C.c_int
         L.havoc_search_release.argtypes = [vp]
@@ -195,6 +197,11 @@ def intra_rd(ctx, S, bit_depth, log2, d_src, src_stride, d_neighbours, jobs, ord
 INTRA_GROUP_DT = np.dtype([("log2", "i4"), ("n", "i4"), ("d_neighbours", "u8"), ("d_jobs", "u8"), ("d_ictx", "u8"), ("d_ctx_index", "u8"), ("d_rec", "u8"),
                            ("out", "u8")])                                                                       # havoc_intra_group
 assert INTRA_GROUP_DT.itemsize == 56
+
+
+INTRA_CHAIN_SIZE_DT = np.dtype([("log2", "i4"), ("n", "i4"), ("d_neighbours", "u8"), ("d_jobs", "u8"), ("d_ictx", "u8"), ("d_ctx_index", "u8"), ("d_parts", "u8"),
+                                ("d_blocks", "u8"), ("first", "u8"), ("out", "u8")])                                  # havoc_intra_chain_size
+assert INTRA_CHAIN_SIZE_DT.itemsize == 72
 
 
 def _address(p):
@@ -304,10 +311,30 @@ class IntraChainPicture:
                                     d_mode=hv.zeros(m, np.int32), best=np.zeros(m, INTRA_RD_RESULT_DT))
         hv.sync()
 
-    def step(self):
-        """the picture, level by level; leaves the champions in self.sizes[log2]["best"] (ordered as ["sel"]), the reconstruction in self.d_rec"""
+    def step(self, wait_per_level=False):
+        """the picture, level by level; leaves the champions in self.sizes[log2]["best"] (ordered as ["sel"]), the reconstruction in self.d_rec.
+        Default: havoc_search_intra_chain -- every level's launches queued without a wait between the levels (the chain runs over the worst-case number of
+        candidate slots), one wait at the end.  wait_per_level: the first form of this step, a havoc_search_intra_device call (two waits) per level."""
         hv, S, torch = self.hv, self.S, self.torch
         self.launches = 0
+        if not wait_per_level:
+            table = np.zeros(len(self.sizes), INTRA_CHAIN_SIZE_DT)
+            firsts = []
+            for row, (log2, g) in zip(table, self.sizes.items()):
+                f = np.ascontiguousarray(g["first"], np.int32)
+                firsts.append(f)
+                row["log2"], row["n"] = log2, g["m"]
+                row["d_neighbours"], row["d_jobs"], row["d_ictx"], row["d_ctx_index"] = g["d_nb"].data_ptr(), g["d_jobs"].data_ptr(), g["d_ictx"].data_ptr(), g["d_ctu"].data_ptr()
+                row["d_parts"], row["d_blocks"], row["first"], row["out"] = g["d_parts"].data_ptr(), g["d_blocks"].data_ptr(), f.ctypes.data, g["best"].ctypes.data
+            quant = np.ascontiguousarray(self.quant, np.int32)
+            stats = RqtStats()
+            rc = lib().havoc_search_intra_chain(hv.h, S, self.bd, self.layout, self.d_src.data_ptr(), self.stride, self.d_rec.data_ptr(), self.d_owner.data_ptr(),
+                                                self.d_modes.data_ptr(), table.ctypes.data, len(table), self.nlevels, self.d_states.data_ptr(), quant.ctypes.data, self.rsl,
+                                                float(self.lam), 1.0 / self.lam, 1, C.byref(stats))
+            if rc != 0:
+                raise RuntimeError(f"havoc_search_intra_chain failed ({rc})")
+            self.launches, self.chain_stats = stats.launches, stats
+            return
         for lvl in range(self.nlevels):
             groups, live = [], []
             for log2, g in self.sizes.items():

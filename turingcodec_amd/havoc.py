@@ -95,7 +95,8 @@ def _load():
         "level_stats": [_vp, _vp, _vp, _i, _vp],
         "search_motion_uni": [_vp, _i, _vp, _vp, C.c_int64, _ip, _vp, C.c_int64, _ip, _vp, _ip, C.c_int64, _vp, _i, _vp],
         "intra_gather": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp],
-        "intra_commit": [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp],
+        "intra_commit": [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i],
+        "intra_fill_spare": [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp],
         "merge_jobs": [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
         "merge_decide": [_vp, _vp, _vp, _vp, _i, C.c_int64, _vp, _vp],
         "pred_jobs": [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp],
@@ -355,8 +356,8 @@ class Havoc:
         """device ADDRESSES (ints): a level's slice of a size's tables"""
         self._ck(self.L.havoc_mi355x_intra_gather(self.h, S, layout, rec, owner, modes, parts, n, jobs, neighbours, mpm))
 
-    def intra_commit_a(self, S, layout, rec, modes, parts, n, blocks, mode):
-        self._ck(self.L.havoc_mi355x_intra_commit(self.h, S, layout, rec, modes, parts, n, blocks, mode))
+    def intra_commit_a(self, S, layout, rec, modes, parts, n, blocks, mode, mode_stride=1):
+        self._ck(self.L.havoc_mi355x_intra_commit(self.h, S, layout, rec, modes, parts, n, blocks, mode, mode_stride))
 
     def merge_jobs_d(self, layout, field, x0, y0, log2, luma_jobs, cb_jobs, cr_jobs, vectors):
         self._ck(self.L.havoc_mi355x_merge_jobs(self.h, layout, _ptr(field), _ptr(x0), _ptr(y0), x0.shape[0], log2, _ptr(luma_jobs), _ptr(cb_jobs), _ptr(cr_jobs), _ptr(vectors)))

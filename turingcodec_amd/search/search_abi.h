@@ -136,6 +136,21 @@ typedef struct
     havoc_intra_rd_result *out;                     /* HOST, n */
 } havoc_intra_group;               /* 56 bytes */
 
+/* one partition size of an INTRA picture's dependency chain (havoc_search_intra_chain): the size's partitions ordered by level, everything but `first` and `out` in
+ * device memory.  Level l holds the partitions [first[l], first[l + 1]): all their neighbours are final when level l - 1 is. */
+typedef struct
+{
+    int32_t log2, n;
+    void *d_neighbours;                             /* 2 * (4 * size + 1) samples per partition: written by the gather, read through the jobs' nb_off / nbf_off */
+    const void *d_jobs;                             /* havoc_mi355x_intra_search_job[n] */
+    havoc_search_intra_ctx *d_ictx;                 /* n: rates and max_refine given; cand_mode_list / neighbour_modes derived on the device */
+    const int32_t *d_ctx_index;                     /* n: which CABAC snapshot Rdoq reads */
+    const void *d_parts;                            /* havoc_mi355x_intra_chain_part[n]: position, size, index in coding order */
+    void *d_blocks;                                 /* champions' reconstructions: block i = size x size samples at i * size * size */
+    const int32_t *first;                           /* HOST, levels + 1 */
+    havoc_intra_rd_result *out;                     /* HOST, n */
+} havoc_intra_chain_size;          /* 72 bytes */
+
 #ifdef __cplusplus
 }
 #endif

@@ -472,4 +472,124 @@ int havoc_search_intra_device(havoc_mi355x_ctx *ctx, int S, int bitDepth, const 
     return 0;
 }
 
+// An INTRA picture with the real dependencies between its partitions (turing/Reconstruct.cpp:609-615: a partition predicts from the reconstruction of the ones before
+// it; CandModeList.h:33-95: its most probable modes are its neighbours' champions), level by level WITHOUT a wait between the levels: per level and size
+//   intra_gather -> intra_satd35 -> intra_order -> intra_expand -> intra_fill_spare -> intra -> tu_forward -> rdoq -> tu_reconstruct -> level_stats -> intra_decide
+//   -> tu_reconstruct (champions) -> intra_commit
+// -- the chain runs over n * HAVOC_MI355X_INTRA_MAX_ORDER candidate slots (the spare ones recompute slot 0 into their own space), so the host never has to learn a count,
+// and the champions' modes reach intra_commit through the choice records in device memory.  One wait at the end; 40 bytes per partition come back.
+int havoc_search_intra_chain(havoc_mi355x_ctx *ctx, int S, int bitDepth, const havoc_mi355x_intra_chain_layout *layout, const void *d_src, intptr_t src_stride, void *d_rec,
+                             const int32_t *d_owner, uint8_t *d_modes, const havoc_intra_chain_size *sizes, int nsizes, int nlevels, const uint8_t *d_states,
+                             const havoc_rqt_quant quant[4], double reciprocal_sqrt_lambda, double lambda, double reciprocal_lambda, int sdh, havoc_rqt_stats *stats)
+{
+    if (!ctx || !layout || !d_src || !d_rec || !d_owner || !d_modes || !sizes || nsizes < 0 || nsizes > 4 || nlevels < 0 || !d_states || !quant || (S != 1 && S != 2))
+        return HAVOC_MI355X_EINVAL;
+    const double tStart = now();
+    havoc_rqt_stats st;
+    std::memset(&st, 0, sizeof(st));
+    Arena arena(ctx);
+    Lambda lsq, rl;
+    lsq.set(reciprocal_sqrt_lambda);
+    rl.set(reciprocal_lambda);
+    constexpr int K = HAVOC_MI355X_INTRA_MAX_ORDER;
+    struct Work
+    {
+        void *dCost, *dOrder, *dCount, *dSlot, *dTotal, *dIj, *dTj, *dRj, *dSj, *dOwner, *dPred, *dPiece, *dCoef, *dLevel, *dWork, *dCbf, *dSsd, *dStats, *dFin, *dSsd2, *dChoice, *hChoice;
+        int32_t lq, sf;
+        size_t workBytes;
+    } work[4];
+    void *hx;
+    for (int g = 0; g < nsizes; ++g)
+    {
+        const havoc_intra_chain_size &G = sizes[g];
+        if (G.log2 < 2 || G.log2 > 5 || G.n < 0 || (G.n && (!G.d_neighbours || !G.d_jobs || !G.d_ictx || !G.d_ctx_index || !G.d_parts || !G.d_blocks || !G.first || !G.out)))
+            return HAVOC_MI355X_EINVAL;
+        if (!G.n) continue;
+        int most = 0;
+        for (int l = 0; l < nlevels; ++l)
+        {
+            if (G.first[l] < 0 || G.first[l + 1] < G.first[l] || G.first[l + 1] > G.n) return HAVOC_MI355X_EINVAL;
+            most = std::max(most, G.first[l + 1] - G.first[l]);
+        }
+        if (G.first[0] != 0 || G.first[nlevels] != G.n) return HAVOC_MI355X_EINVAL;
+        Work &w = work[g];
+        const size_t cap = size_t(most) * K, area = size_t(1) << (2 * G.log2);
+        RC(arena.get(size_t(most) * 35 * 4, &w.dCost, &hx));
+        RC(arena.get(size_t(most) * K * 4, &w.dOrder, &hx));
+        RC(arena.get(size_t(most) * 4, &w.dCount, &hx));
+        RC(arena.get(size_t(most) * 4, &w.dSlot, &hx));
+        RC(arena.get(8, &w.dTotal, &hx));
+        RC(arena.get(cap * sizeof(havoc_mi355x_intra_job), &w.dIj, &hx));
+        RC(arena.get(cap * sizeof(havoc_mi355x_tu_fused_job), &w.dTj, &hx));
+        RC(arena.get(cap * sizeof(havoc_mi355x_rdoq_job), &w.dRj, &hx));
+        RC(arena.get(cap * 8, &w.dSj, &hx));
+        RC(arena.get(cap * 4, &w.dOwner, &hx));
+        RC(arena.get(cap * area * S, &w.dPred, &hx));
+        RC(arena.get(cap * area * S, &w.dPiece, &hx));
+        RC(arena.get(cap * area * 2, &w.dCoef, &hx));
+        RC(arena.get(cap * area * 2, &w.dLevel, &hx));
+        w.workBytes = havoc_mi355x_rdoq_workspace(int(cap));
+        RC(arena.get(w.workBytes + 64, &w.dWork, &hx));
+        RC(arena.get(cap * 4, &w.dCbf, &hx));
+        RC(arena.get(cap * 4, &w.dSsd, &hx));
+        RC(arena.get(cap * 8, &w.dStats, &hx));
+        RC(arena.get(size_t(most) * sizeof(havoc_mi355x_tu_fused_job), &w.dFin, &hx));
+        RC(arena.get(size_t(most) * 4, &w.dSsd2, &hx));
+        RC(arena.get(size_t(G.n) * sizeof(havoc_intra_rd_result), &w.dChoice, &w.hChoice));
+        havoc_mi355x_rdoq_lambda(lambda, quant[G.log2 - 2].inv_scale, &w.lq, &w.sf);
+    }
+    for (int l = 0; l < nlevels; ++l)
+        for (int g = 0; g < nsizes; ++g)
+        {
+            const havoc_intra_chain_size &G = sizes[g];
+            if (!G.n) continue;
+            const int a = G.first[l], cnt = G.first[l + 1] - a;
+            if (!cnt) continue;
+            const Work &w = work[g];
+            const int nn = 1 << G.log2, area = nn * nn, tr = G.log2 == 2 ? 1 : 0, cap = cnt * K;
+            const havoc_rqt_quant &q = quant[G.log2 - 2];
+            const auto *jobs = static_cast<const havoc_mi355x_intra_search_job *>(G.d_jobs) + a;
+            const auto *parts = static_cast<const havoc_mi355x_intra_chain_part *>(G.d_parts) + a;
+            auto *mpm = reinterpret_cast<havoc_mi355x_intra_mpm *>(G.d_ictx + a);
+            auto *choice = static_cast<havoc_mi355x_intra_choice *>(w.dChoice) + a;
+            void *blocks = static_cast<char *>(G.d_blocks) + size_t(a) * area * S;
+            const havoc_mi355x_tu_fused_job *tj = static_cast<const havoc_mi355x_tu_fused_job *>(w.dTj);
+            RC(havoc_mi355x_intra_gather(ctx, S, layout, d_rec, d_owner, d_modes, parts, cnt, jobs, G.d_neighbours, mpm));
+            RC(havoc_mi355x_intra_satd35(ctx, S, bitDepth, G.log2, d_src, src_stride, G.d_neighbours, jobs, cnt, static_cast<int32_t *>(w.dCost)));
+            RC(havoc_mi355x_intra_order(ctx, static_cast<const int32_t *>(w.dCost), mpm, cnt, lsq.value, static_cast<int32_t *>(w.dOrder), static_cast<int32_t *>(w.dCount),
+                                        static_cast<int32_t *>(w.dSlot), static_cast<int32_t *>(w.dTotal)));
+            RC(havoc_mi355x_intra_expand(ctx, jobs, static_cast<const int32_t *>(w.dOrder), static_cast<const int32_t *>(w.dCount), static_cast<const int32_t *>(w.dSlot), G.d_ctx_index + a,
+                                         cnt, G.log2, q.quant_scale, q.quant_shift, q.inv_scale, w.lq, w.sf, sdh, static_cast<havoc_mi355x_intra_job *>(w.dIj),
+                                         static_cast<havoc_mi355x_tu_fused_job *>(w.dTj), static_cast<havoc_mi355x_rdoq_job *>(w.dRj), static_cast<int32_t *>(w.dSj),
+                                         static_cast<int32_t *>(w.dOwner)));
+            RC(havoc_mi355x_intra_fill_spare(ctx, static_cast<const int32_t *>(w.dTotal), cap, G.log2, static_cast<havoc_mi355x_intra_job *>(w.dIj),
+                                             static_cast<havoc_mi355x_tu_fused_job *>(w.dTj), static_cast<havoc_mi355x_rdoq_job *>(w.dRj), static_cast<int32_t *>(w.dSj),
+                                             static_cast<int32_t *>(w.dOwner)));
+            RC(havoc_mi355x_intra(ctx, S, bitDepth, G.log2, w.dPred, nn, G.d_neighbours, static_cast<const havoc_mi355x_intra_job *>(w.dIj), cap));
+            RC(havoc_mi355x_tu_forward(ctx, S, bitDepth, tr, G.log2, static_cast<int16_t *>(w.dCoef), d_src, src_stride, w.dPred, nn, tj, cap));
+            RC(havoc_mi355x_rdoq(ctx, bitDepth, G.log2, static_cast<int16_t *>(w.dLevel), static_cast<const int16_t *>(w.dCoef), d_states, static_cast<const havoc_mi355x_rdoq_job *>(w.dRj),
+                                 cap, static_cast<int32_t *>(w.dCbf), w.dWork, havoc_mi355x_rdoq_workspace(cap)));
+            RC(havoc_mi355x_tu_reconstruct(ctx, S, bitDepth, tr, G.log2, q.inv_scale, q.inv_shift, w.dPiece, nn, w.dPred, nn, d_src, src_stride, static_cast<const int16_t *>(w.dLevel), tj,
+                                           cap, static_cast<uint32_t *>(w.dSsd)));
+            RC(havoc_mi355x_level_stats(ctx, static_cast<const int16_t *>(w.dLevel), static_cast<const int32_t *>(w.dSj), cap, static_cast<int32_t *>(w.dStats)));
+            RC(havoc_mi355x_intra_decide(ctx, mpm, static_cast<const int32_t *>(w.dOrder), static_cast<const int32_t *>(w.dCount), static_cast<const int32_t *>(w.dSlot),
+                                         static_cast<const int32_t *>(w.dCbf), static_cast<const uint32_t *>(w.dSsd), static_cast<const int32_t *>(w.dStats), tj, cnt, G.log2, rl.value,
+                                         choice, static_cast<havoc_mi355x_tu_fused_job *>(w.dFin)));
+            RC(havoc_mi355x_tu_reconstruct(ctx, S, bitDepth, tr, G.log2, q.inv_scale, q.inv_shift, blocks, nn, w.dPred, nn, d_src, src_stride, static_cast<const int16_t *>(w.dLevel),
+                                           static_cast<const havoc_mi355x_tu_fused_job *>(w.dFin), cnt, static_cast<uint32_t *>(w.dSsd2)));
+            RC(havoc_mi355x_intra_commit(ctx, S, layout, d_rec, d_modes, parts, cnt, blocks, reinterpret_cast<const int32_t *>(choice), int(sizeof(havoc_mi355x_intra_choice) / 4)));
+            st.launches += 13;
+            st.candidates += cap;
+        }
+    for (int g = 0; g < nsizes; ++g)
+        if (sizes[g].n) RC(havoc_mi355x_d2h_async(ctx, work[g].hChoice, work[g].dChoice, size_t(sizes[g].n) * sizeof(havoc_intra_rd_result)));
+    RC(havoc_mi355x_sync(ctx));
+    st.seconds_gpu = now() - tStart;
+    for (int g = 0; g < nsizes; ++g)
+        if (sizes[g].n) std::memcpy(sizes[g].out, work[g].hChoice, size_t(sizes[g].n) * sizeof(havoc_intra_rd_result));
+    st.seconds_total = now() - tStart;
+    if (stats) *stats = st;
+    return 0;
+}
+
 } // extern "C"
