@@ -1062,6 +1062,97 @@ class FramePipeline:
                 self.arrived[exch.slot_of(q.poc)] = ev
 
 
+def decision_frame_parallel(args, torch, dist, Havoc, rank, world, local):
+    """--decisions 3: the frame-parallel pipeline driving the DECISION step: time slot t of the DagSchedule, this rank's picture of
+    the slot = one DecisionPicture.step() (searches in wavefront order, bi-directional refinement, intra candidates, merge candidates, transform-tree decisions,
+    chroma chain, deblocking, padding) predicting from the DPB MIRROR -- luma and both chroma planes of its two references are copied out of the mirror slots the
+    schedule names -- and, for a reference picture, its padded reconstruction staged into the mirror and broadcast (whole, or in CTU-row bands with --bands).
+    A picture's step is host-synchronous (it ends with a wait), so one context per rank.  Reports pictures/s over all ranks and per-POC checksums of the
+    reconstructions (equal for every world size: tests compare world 1 with world 2)."""
+    from turingcodec_amd.decisions import DecisionPicture
+    from turingcodec_amd.frame_parallel import BandPlan, DagSchedule, ReferenceExchange
+    w, h = (int(v) for v in args.res.split("x"))
+    n_sops = max(1, (args.pictures - 1) // 8)
+    sched = DagSchedule(world, n_sops=n_sops, lag=args.lag or None)
+    hv = Havoc(local, stream="new")
+    dp = DecisionPicture(hv, w, h, args.bit_depth, args.qp, seed=args.seed, threads=max(1, usable_cores() // max(1, world)), distance=max(1, args.decision_distance))
+    pe, cpe = dp.pe, dp.cpe
+    exch = ReferenceExchange(dist, rank, sched, pe, cpe, dp.d_pic, single_rank_broadcast=args.exchange)
+    if args.bands > 0:
+        exch.set_bands(BandPlan(h, dp.PAD, dp.stride, dp.cstride, band_ctu_rows=args.bands))
+    comm = torch.cuda.current_stream(local)
+    sums, pictures = {}, 0
+    # every picture of the sequence has its own source (the generator's translating texture, frame = POC): luma, Cb, Cr in the context's padded layout, resident
+    from turingcodec_amd import workload
+    frames = workload.synth_frames(w, h, 8 * n_sops + 1, args.seed, args.bit_depth)
+    sources = []
+    for f in frames:
+        planes = [workload.pad_plane(f[0], dp.PAD), workload.pad_plane(f[1], dp.PAD // 2), workload.pad_plane(f[2], dp.PAD // 2)]
+        assert planes[0].shape[1] == dp.stride and planes[1].shape[1] == dp.cstride
+        sources.append([hv.up(np.ascontiguousarray(p.ravel())) for p in planes])
+    dp.step()      # allocations, code objects
+    dp.step()      # records the fixed launch sequences into HIP graphs
+    hv.sync()
+    nslots = sched.slots_for_sequence()
+    if world > 1 or args.exchange:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(nslots):
+        pic = exch.picture_of(t)
+        if pic is not None:
+            pictures += 1
+            src = sources[pic.poc]
+            with torch.cuda.stream(hv.tstream):
+                torch._foreach_copy_([dp.d_pic[:src[0].numel()], dp.d_cpic[:src[1].numel()], dp.d_cpic[3 * cpe:3 * cpe + src[2].numel()]], src)
+            if pic.refs:
+                s0, s1 = exch.refs(pic)
+                hv.tstream.wait_stream(comm)      # the broadcasts of the earlier slots have landed in the mirror
+                with torch.cuda.stream(hv.tstream):
+                    torch._foreach_copy_([dp.d_pic[pe:2 * pe], dp.d_pic[2 * pe:3 * pe], dp.d_cpic[cpe:2 * cpe], dp.d_cpic[2 * cpe:3 * cpe], dp.d_cpic[4 * cpe:5 * cpe],
+                                          dp.d_cpic[5 * cpe:6 * cpe]],
+                                         [exch.dpb_luma[s0], exch.dpb_luma[s1], exch.dpb_cb[s0], exch.dpb_cb[s1], exch.dpb_cr[s0], exch.dpb_cr[s1]])
+            dp.step()
+            # the chroma planes' borders (the luma plane's are made by the step's loop filter): every picture, so that the checksum below covers whole planes
+            hv.pad_block_d(dp.crecon, dp.corigin, w // 2, h // 2, dp.cstride, dp.PAD // 2)
+            hv.pad_block_d(dp.crecon, cpe + dp.corigin, w // 2, h // 2, dp.cstride, dp.PAD // 2)
+            with torch.cuda.stream(hv.tstream):
+                sums[pic.poc] = int(dp.recon.to(torch.int64).sum().item()) * 1000003 + int(dp.crecon.to(torch.int64).sum().item())
+            if pic.is_reference:
+                hv.tstream.wait_stream(comm)      # the mirror slot's previous picture: its broadcast is over before it is overwritten
+                with torch.cuda.stream(hv.tstream):
+                    exch.stage(t, (dp.recon[:pe], dp.crecon[:cpe], dp.crecon[cpe:2 * cpe]))
+        comm.wait_stream(hv.tstream)
+        if exch.plan is not None:
+            for b in range(exch.plan.n_bands):
+                exch.send_band(t, b)
+        else:
+            exch.send(t)
+    torch.cuda.synchronize()
+    if world > 1 or args.exchange:
+        dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], device="cuda", dtype=torch.float64)
+    n = torch.tensor([pictures], device="cuda", dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(n)
+        parts = [None] * world
+        dist.all_gather_object(parts, sums)
+        for d in parts:
+            sums.update(d)
+    if rank == 0:
+        total = 0
+        for poc in sorted(sums):
+            total = (total * 1000003 + sums[poc]) % (1 << 61)
+        print(json.dumps({"metric": "DIAGNOSTIC (frame-parallel pipeline driving the decision step) -- not the benchmark metric", "value": round(float(n.item()) / float(el.item()), 2),
+                          "unit": "pictures/s", "n_gpus": world, "pictures": int(n.item()), "slots": nslots, "seconds": round(float(el.item()), 4),
+                          "config": {"workload": f"{args.res} {args.bit_depth}-bit QP{args.qp}: IDR + {n_sops} SOPs of 8, hierarchical-B docket, one DecisionPicture.step per picture",
+                                     "exchange": ("CTU-row bands of %d rows (%d bands x 3 planes per reference picture)" % (args.bands, exch.plan.n_bands)) if exch.plan is not None
+                                     else "one broadcast per reference picture", "backend": os.environ.get("HAVOC_BENCH_BACKEND", "nccl") if (world > 1 or args.exchange) else None,
+                                     "broadcasts": exch.broadcasts, "bytes_sent_by_rank0": exch.sent_bytes},
+                          "checksum_of_poc_checksums": total, "poc_checksums": {str(k): v for k, v in sorted(sums.items())}}), flush=True)
+
+
 def cpu_decision_walk(args, keep):
     """cpu_baseline leg: the SAME decision walk (same pictures, PUs, order, derived predictors) one table call at a time through the
     reference's x86-JIT havoc tables on one host core (tests/search_client.cpp over oracle/_ref -- the checker, timed here as the
@@ -1398,6 +1489,12 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    if args.decisions == 3:
+        decision_frame_parallel(args, torch, dist, Havoc, rank, world, local)
+        if grouped:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     w, h = (int(v) for v in args.res.split("x"))
     inflight = 1 if (args.pcie or args.no_graph or args.poc_checksums) else max(1, args.inflight)
     # Step i runs picture context i % inflight.  Single GPU: every context owns a different synthetic picture.  Frame-parallel:

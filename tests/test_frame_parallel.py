@@ -325,3 +325,28 @@ def test_bench_refuses_a_world_that_is_not_what_gpus_asked_for():
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, env=env, cwd=root)
     assert out.returncode == 2 and "--gpus 2" in out.stderr and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.gpu
+def test_decision_pipeline_two_rank_rehearsal_equals_one_rank_with_and_without_bands():
+    """bench.py --decisions 3: the frame-parallel pipeline driving the DECISION step (a DecisionPicture.step per picture, references read from the DPB mirror).
+    One rank with the RCCL exchange (whole pictures, then CTU-row bands) against two ranks sharing the one GPU over gloo: per-POC checksums of the reconstructions
+    (all three planes, borders included) equal -- a picture's result does not depend on who encodes it or on how its references travelled."""
+    import json
+    import subprocess
+    import sys
+    bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+
+    def run(gpus, extra, env=None):
+        out = subprocess.run([sys.executable, bench, "--decisions", "3", "--gpus", str(gpus), "--res", "416x240", "--pictures", "17"] + extra, capture_output=True, text=True,
+                             env=dict(os.environ, **(env or {})), timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    one = run(1, ["--exchange"])
+    one_bands = run(1, ["--exchange", "--bands", "2"])
+    two = run(2, ["--bands", "2"], {"HAVOC_BENCH_BACKEND": "gloo"})
+    assert one["pictures"] == one_bands["pictures"] == two["pictures"] == 17 and len(one["poc_checksums"]) == 17
+    assert one["poc_checksums"] == one_bands["poc_checksums"] == two["poc_checksums"]
+    assert len(set(one["poc_checksums"].values())) == 17                       # every picture of the sequence is its own
+    assert one_bands["config"]["broadcasts"] == 9 * 2 * 3 and one["config"]["broadcasts"] == 9
+    assert two["slots"] < one["slots"]                                          # two ranks: fewer time slots for the same sequence
