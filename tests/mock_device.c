@@ -457,6 +457,25 @@ int havoc_mi355x_search_motion_bi(havoc_mi355x_ctx *ctx, int S, const havoc_mi35
     (void)pus; (void)start; (void)n; (void)out;
     return HAVOC_MI355X_EINVAL;      /* a kernel: nothing behind it in the mock */
 }
+/* the intra chain's device-side steps (round 4): kernels, nothing behind them in the mock (havoc_search_intra_chain is exercised on the GPU: tests/test_intra_chain.py) */
+int havoc_mi355x_intra_gather(havoc_mi355x_ctx *ctx, int S, const havoc_mi355x_intra_chain_layout *layout, const void *rec, const int32_t *owner, const uint8_t *modes,
+                              const havoc_mi355x_intra_chain_part *parts, int n, const havoc_mi355x_intra_search_job *jobs, void *nb, havoc_mi355x_intra_mpm *mpm)
+{
+    (void)ctx; (void)S; (void)layout; (void)rec; (void)owner; (void)modes; (void)parts; (void)n; (void)jobs; (void)nb; (void)mpm;
+    return HAVOC_MI355X_EINVAL;
+}
+int havoc_mi355x_intra_commit(havoc_mi355x_ctx *ctx, int S, const havoc_mi355x_intra_chain_layout *layout, void *rec, uint8_t *modes, const havoc_mi355x_intra_chain_part *parts,
+                              int n, const void *blocks, const int32_t *mode, int mode_stride)
+{
+    (void)ctx; (void)S; (void)layout; (void)rec; (void)modes; (void)parts; (void)n; (void)blocks; (void)mode; (void)mode_stride;
+    return HAVOC_MI355X_EINVAL;
+}
+int havoc_mi355x_intra_fill_spare(havoc_mi355x_ctx *ctx, const int32_t *total, int capacity, int log2, havoc_mi355x_intra_job *ij, havoc_mi355x_tu_fused_job *tj,
+                                  havoc_mi355x_rdoq_job *rj, int32_t *sj, int32_t *owner)
+{
+    (void)ctx; (void)total; (void)capacity; (void)log2; (void)ij; (void)tj; (void)rj; (void)sj; (void)owner;
+    return HAVOC_MI355X_EINVAL;
+}
 size_t havoc_mi355x_search_workspace(int width, int height) { (void)width; (void)height; return 256; }
 int havoc_mi355x_search_picture_uni(havoc_mi355x_ctx *ctx, int S, const havoc_mi355x_search_params *params, const int64_t mvp_rate[2], const void *src, int64_t so,
                                     intptr_t ss, const void *ref, const int64_t ro[2], intptr_t rs, const void *phase, intptr_t pe, const int64_t po[2], const void *pus,
