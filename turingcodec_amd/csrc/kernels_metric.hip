@@ -42,6 +42,9 @@ __device__ __forceinline__ int sad_group_sum(int v)
 // x / c for 0 <= x <= 1024, 1 <= c <= 128 without the 25-instruction integer division: (x + 0.5) / c is at least 0.5 / c from an integer, far beyond what the
 // reciprocal's and the product's rounding can move it
 __device__ __forceinline__ int smallDiv(int x, int c) { return (int)(((float)x + 0.5f) * __builtin_amdgcn_rcpf((float)c)); }
+// products of values below 2^23 on the full-rate 24-bit multiplier (v_mul_lo_u32 runs at a quarter of the rate; k_sad4w's per-job set-up has two dozen of them)
+__device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
+__device__ __forceinline__ uint32_t mulu24(uint32_t a, uint32_t b) { return __umul24(a, b); }
 
 template <int S, int WAYS, int CB, int U = 4>
 __device__ __forceinline__ void sad_block(const char *src, long ssb, const char *const (&ref)[WAYS], long rsb, int rowBytes, int h,
@@ -176,33 +179,33 @@ __device__ __forceinline__ void sad4_window_strips(const char *src, uint32_t s0,
     // went to SQ_LDS_UNALIGNED_STALL.)
     // the copy: a lane keeps its 16-byte column and walks down the rows
     const int wstep = smallDiv(kSadLanes, chunks);   // window rows per copy iteration
-    const int wr0 = smallDiv(lane, chunks), wc = lane - wr0 * chunks;
+    const int wr0 = smallDiv(lane, chunks), wc = lane - mul24(wr0, chunks);
     const bool copies = wr0 < wstep;
     // the SADs: a lane keeps its chunk column of the block and walks down the rows; the four candidates' LDS addresses advance together
     const int cpr = rowBytes / CB;        // chunks per block row
     const int rpi = smallDiv(kSadLanes, cpr);      // block rows per iteration of the lane group
     const int y0 = smallDiv(lane, cpr);
-    const int xb = (lane - y0 * cpr) * CB;
+    const int xb = (lane - mul24(y0, cpr)) * CB;
     const bool sums = y0 < rpi;
     int lo[4], sh[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
     {
         const int bo = lead + ox[k] + xb;
-        lo[k] = (y0 + oy[k]) * pitchD + (bo >> 2);
+        lo[k] = mul24(y0 + oy[k], pitchD) + (bo >> 2);
         sh[k] = bo & 3;
     }
     // global side in 32-bit byte offsets from the (uniform) base pointers: the loads take the base from scalar registers, no 64-bit vector arithmetic
-    const int lstep = rpi * pitchD;
-    const uint32_t gstep = wstep * rsb, sstep = rpi * ssb;
-    const int wlstep = wstep * pitchD;
+    const int lstep = mul24(rpi, pitchD);
+    const uint32_t gstep = mulu24(wstep, rsb), sstep = mulu24(rpi, ssb);
+    const int wlstep = mul24(wstep, pitchD);
     for (int ys = 0; ys < h; ys += hs)
     {
         const int he = min(hs, h - ys), nrows = he + spready;
         if (copies)
         {
-            uint32_t g = a0 + (uint32_t)(ys + wr0) * rsb + wc * 16;
-            int l = wr0 * pitchD + wc * 4;
+            uint32_t g = a0 + mulu24(ys + wr0, rsb) + wc * 16;
+            int l = mul24(wr0, pitchD) + wc * 4;
             for (int r = wr0; r < nrows; r += wstep, g += gstep, l += wlstep)
             {
                 const u32x4 v = ld16(ref + g);      // 16-byte aligned when the row stride is a multiple of 16 bytes (our planes: 64)
@@ -214,7 +217,7 @@ __device__ __forceinline__ void sad4_window_strips(const char *src, uint32_t s0,
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (sums)
         {
-            uint32_t sp = s0 + (uint32_t)(ys + y0) * ssb + xb;
+            uint32_t sp = s0 + mulu24(ys + y0, ssb) + xb;
             int l = 0;
 #pragma unroll 2
             for (int y = y0; y < he; y += rpi, sp += sstep, l += lstep)
@@ -298,14 +301,16 @@ __global__ __launch_bounds__(256, MINW) void k_sad4w(const char *__restrict__ sr
     const int mindx = min(min(dx[0], dx[1]), min(dx[2], dx[3])), maxdx = max(max(dx[0], dx[1]), max(dx[2], dx[3]));
     const int mindy = min(min(dy[0], dy[1]), min(dy[2], dy[3])), maxdy = max(max(dy[0], dy[1]), max(dy[2], dy[3]));
     const int spready = maxdy - mindy;
-    const long minoff = ((long)ro[0] + (long)mindy * st + mindx) * S;      // bytes from `ref` to the window's first sample
+    // (a job whose candidates lie thousands of rows apart makes mul24 wrap: its spready is then far beyond what fits, and `window` below is false whatever minoff is)
+    const long minoff = ((long)ro[0] + mul24(mindy, st) + mindx) * S;      // bytes from `ref` to the window's first sample
     const int lead = (int)(reinterpret_cast<uintptr_t>(ref + minoff) & 15);
     const int chunks = (lead + rowBytes + (maxdx - mindx) * S + 15) >> 4;      // 16-byte pieces of a window row
     const int pitchD = 4 * chunks + 1;                                          // dwords per window row in LDS: odd (see sad4_window_strips)
     const int fit = chunks > 0 && chunks <= kSadLanes ? smallDiv(WB * S / 4, pitchD) - spready : 0;      // block rows per strip
     const bool chunked = (rowBytes & 3) == 0 && rowBytes <= 16 * kSadLanes;
     // (the strips address both pictures with 32-bit byte offsets from their base pointers: a block that reaches beyond 4 GB takes the direct path)
-    const bool near = minoff + (long)(h + spready) * rsb + 16 * chunks < (1ll << 32) && ((long)so * S + (long)h * ssb + rowBytes) < (1ll << 32) && ssb < (1 << 24);
+    const bool rows24 = (unsigned)spready < 1024u && (unsigned)h <= 64u && ssb < (1 << 23);
+    const bool near = rows24 && minoff + (long)mulu24(h + spready, (uint32_t)rsb) + 16 * chunks < (1ll << 32) && ((long)so * S + (long)mulu24(h, (uint32_t)ssb) + rowBytes) < (1ll << 32);
     const bool window = live && chunked && chunks <= kSadLanes && minoff >= 16 && fit >= min(h, 4) && fit >= 1 && near;
     if (window)
     {
