@@ -241,6 +241,21 @@ struct Lds      // of a workgroup
     alignas(16) uint8_t win[kWinBytes * S];
 };
 
+// What a CTU's searches share, staged ONCE per CTU (and list) by the picture kernels instead of once per search (round 4): the CTU's 64 x 64 source block and a
+// window of the reference picture around the CTU, shifted by the first search's first start candidate.  A search whose start candidates (+ margin) lie inside
+// reads both from here and stages nothing (staging was 2.1 of a search's 14.4 us: a dependent global round trip per search); one whose vectors point elsewhere
+// stages its own window as before.  Which of the two serves a position changes no value.
+constexpr int kCtuMargin = 56;
+constexpr int kCtuWinW = 64 + 2 * kCtuMargin;      // 176 samples square: 31 KB (8-bit), 62 KB (16-bit)
+constexpr int kPlaneReach = 84;                     // samples beyond the picture every plane is good for (havoc_search_picture_uni_device: ref_pad >= 96)
+template <int S>
+struct CtuStage
+{
+    alignas(16) uint8_t win[kCtuWinW * S * kCtuWinW];      // row pitch kCtuWinW * S bytes: a multiple of 16
+    alignas(16) uint8_t src[64 * 64 * S];
+};
+struct CtuBox { int X0 = 0, Y0 = 0, X1 = -1, Y1 = -1; bool valid = false; };      // the staged window in picture coordinates (wave-uniform)
+
 // the per-call interface decision.hpp's loops are written against (its `View`), answered by the workgroup itself
 template <int S>
 struct DeviceView
@@ -250,6 +265,8 @@ struct DeviceView
     int w, h, wave, lane, tid;
     Lds<S> *x;
     int bx0, by0, bx1, by1, wsB;      // displacements [bx0, bx1] x [by0, by1] are answered from the staged window (row pitch wsB bytes)
+    LdsPtr winBase, srcBase;          // where displacement (bx0, by0) and the source block start in LDS (the search's own staging, or the CTU's)
+    int srcPitch;                     // bytes per source row there: w * S, or 64 * S inside the CTU's block
     int sadTurn = 0, satdTurn = 0, satdCount = 0;
     int tx0 = 0, ty0 = 0, tw = 0, th = 0;      // displacements [tx0, tx0 + tw) x [ty0, ty0 + th) are in x->table (tw = 0: nothing is)
     int32_t satdKey[9], satdValue[9];      // the announced positions and their SATDs, read back once (scalar registers)
@@ -267,8 +284,8 @@ struct DeviceView
     __device__ __forceinline__ int sadOne(int dx, int dy, int part, int parts) const
     {
         if (dx >= bx0 && dx <= bx1 && dy >= by0 && dy <= by1)
-            return wave_sad<S>(ldsPtr(x->src), w * S, ldsPtr(x->win) + (dy - by0) * wsB + (dx - bx0) * S, wsB, w, h, lane, part, parts);
-        return wave_sad<S>(ldsPtr(x->src), w * S, ref + dy * sbb + (long)dx * S, sbb, w, h, lane, part, parts);
+            return wave_sad<S>(srcBase, srcPitch, winBase + (dy - by0) * wsB + (dx - bx0) * S, wsB, w, h, lane, part, parts);
+        return wave_sad<S>(srcBase, srcPitch, ref + dy * sbb + (long)dx * S, sbb, w, h, lane, part, parts);
     }
 
     __device__ __forceinline__ int sad(int dx, int dy)
@@ -331,7 +348,7 @@ struct DeviceView
         tw = 0;
         const int gw = x1 - x0 + 1, gh = y1 - y0 + 1, count = gw * gh;
         if (gw <= 0 || gh <= 0 || count > 16 * 12) return;
-        const LdsPtr src = ldsPtr(x->src), win = ldsPtr(x->win);
+        const LdsPtr src = srcBase, win = winBase;
         const int seg = (w & 7) ? 4 : 8, segs = (w & 7) ? w >> 2 : w >> 3, rows = segs * h;      // row segments of seg samples per displacement
         const FastDiv fg(gw);
         if (rows > 32)
@@ -339,7 +356,7 @@ struct DeviceView
             for (int j = wave; j < count; j += kWaves)
             {
                 const int gy = fg.div(j), gx = j - gy * gw;
-                const int v = wave_sad<S>(src, w * S, win + (y0 + gy - by0) * wsB + (x0 + gx - bx0) * S, wsB, w, h, lane);
+                const int v = wave_sad<S>(src, srcPitch, win + (y0 + gy - by0) * wsB + (x0 + gx - bx0) * S, wsB, w, h, lane);
                 if (lane == 0) x->table[j] = sadShift<S>(v);
             }
         }
@@ -355,7 +372,7 @@ struct DeviceView
                 const bool on = j < count && l < rows;
                 const int jj = j < count ? j : 0;
                 const int gy = fg.div(jj), gx = jj - gy * gw;
-                const LdsPtr pa = src + (on ? row * w * S + col * seg * S : 0);
+                const LdsPtr pa = src + (on ? row * srcPitch + col * seg * S : 0);
                 const LdsPtr pb = win + (y0 + gy - by0 + (on ? row : 0)) * wsB + (x0 + gx - bx0) * S + (on ? col * seg * S : 0);
                 uint32_t acc = 0;
                 if (seg == 8)
@@ -429,7 +446,7 @@ struct DeviceView
         if (!tHint) tHint = wall_clock64();
         const long c0 = clock64();
 #endif
-        const LdsPtr src = ldsPtr(x->src);
+        const LdsPtr src = srcBase;
         const int tsh = ((w | h) & 7) ? 2 : 3, ts = 1 << tsh, tw = w >> tsh;
         const int rows = tw * (h >> tsh) * ts;
         // the positions stay in registers: position `j` of a lane (group) or wavefront is picked with compares, not by address (an indexed array
@@ -450,7 +467,7 @@ struct DeviceView
             // alone, but a third less throughput with 8 - 16 pictures in flight -- a reduction and an exchange per pass instead of per position)
             for (int i = wave; i < n; i += kWaves)
             {
-                const int v = wave_satd<S>(src, w * S, predAt(pick(i)), sbb, w, h, lane);
+                const int v = wave_satd<S>(src, srcPitch, predAt(pick(i)), sbb, w, h, lane);
                 if (lane == 0) x->satd[satdTurn][i] = v;
             }
         }
@@ -469,7 +486,7 @@ struct DeviceView
                 {
                     const int tile = on ? l >> 3 : 0, r = l & 7;
                     const int ty = fd.div(tile), tx = tile - ty * tw;
-                    const LdsPtr pa = src + (ty * 8 + r) * w * S + tx * 8 * S;
+                    const LdsPtr pa = src + (ty * 8 + r) * srcPitch + tx * 8 * S;
                     const char *pb = pred + (long)(ty * 8 + r) * sbb + tx * 8 * S;
                     if (S == 1)
                     {
@@ -504,7 +521,7 @@ struct DeviceView
                 {
                     const int tile = on ? l >> 2 : 0, r = l & 3;
                     const int ty = fd.div(tile), tx = tile - ty * tw;
-                    const LdsPtr pa = src + (ty * 4 + r) * w * S + tx * 4 * S;
+                    const LdsPtr pa = src + (ty * 4 + r) * srcPitch + tx * 4 * S;
                     const char *pb = pred + (long)(ty * 4 + r) * sbb + tx * 4 * S;
                     if (S == 1)
                     {
@@ -859,14 +876,15 @@ struct DeviceView
 #endif
         GAP_OUT();
         if (v >= 0) return v;
-        return wave_satd<S>(ldsPtr(x->src), w * S, predAt(mv), sbb, w, h, lane);      // not announced: every wavefront computes it
+        return wave_satd<S>(srcBase, srcPitch, predAt(mv), sbb, w, h, lane);      // not announced: every wavefront computes it
     }
 };
 
 // what a uni-directional search needs before its loops run: the view of (PU, list), the source block and a window of the reference picture
 // around the start candidates of fullPel in LDS.  The caller's barrier follows.
 template <int S>
-__device__ __forceinline__ void stage_uni(const SearchArgs &a, Lds<S> &x, DeviceView<S> &view, const havoc_search::PuContext &pu, const int list)
+__device__ __forceinline__ void stage_uni(const SearchArgs &a, Lds<S> &x, DeviceView<S> &view, const havoc_search::PuContext &pu, const int list,
+                                          CtuStage<S> *cs = nullptr, CtuBox *box = nullptr)
 {
     const int tid = threadIdx.x;
     const long sbb = a.refStride * S;
@@ -901,8 +919,44 @@ __device__ __forceinline__ void stage_uni(const SearchArgs &a, Lds<S> &x, Device
         }
         view.bx0 = x0 - kWinMargin; view.bx1 = x1 + kWinMargin;
         view.by0 = y0 - kWinMargin; view.by1 = y1 + kWinMargin;
+        if (cs && box)
+        {   // the picture kernels: the CTU's source block is staged; its window too -- made around the first search's first start candidate
+            view.srcBase = ldsPtr(cs->src) + ((pu.y0 - pu.yCtb) * 64 + (pu.x0 - pu.xCtb)) * S;
+            view.srcPitch = 64 * S;
+            if (!box->valid)
+            {
+                const int W = a.sp.picWidth, H = a.sp.picHeight;
+                int X0 = pu.xCtb + first0.x - kCtuMargin, Y0 = pu.yCtb + first0.y - kCtuMargin;
+                X0 = min(max(X0, -kPlaneReach), W + kPlaneReach - kCtuWinW);      // inside what every plane holds (pictures narrower than the window: see `fits`)
+                Y0 = min(max(Y0, -kPlaneReach), H + kPlaneReach - kCtuWinW);
+                box->X0 = X0; box->Y0 = Y0; box->X1 = X0 + kCtuWinW - 1; box->Y1 = Y0 + kCtuWinW - 1;
+                box->valid = X0 >= -kPlaneReach && Y0 >= -kPlaneReach;
+                if (box->valid)
+                {
+                    constexpr int chunks = kCtuWinW * S / 16;
+                    const char *g = a.ref[list] + ((long)Y0 * a.refStride + X0) * S;
+                    const FastDiv fc(chunks);
+                    for (int i = tid; i < chunks * kCtuWinW; i += kThreads)
+                    {
+                        const int y = fc.div(i), k = i - y * chunks;
+                        *reinterpret_cast<u32x4 *>(&cs->win[y * (kCtuWinW * S) + 16 * k]) = ld16(g + y * sbb + 16 * k);
+                    }
+                }
+            }
+            const bool fits = box->valid && pu.x0 + view.bx0 >= box->X0 && pu.x0 + view.bx1 + pu.w - 1 <= box->X1 && pu.y0 + view.by0 >= box->Y0 &&
+                              pu.y0 + view.by1 + pu.h - 1 <= box->Y1;
+            if (fits)
+            {   // every displacement that keeps the block inside the CTU's window is answered from it
+                view.bx0 = box->X0 - pu.x0; view.bx1 = box->X1 - pu.x0 - pu.w + 1;
+                view.by0 = box->Y0 - pu.y0; view.by1 = box->Y1 - pu.y0 - pu.h + 1;
+                view.wsB = kCtuWinW * S;
+                view.winBase = ldsPtr(cs->win);
+                return;
+            }
+        }
         const int rowB = (view.bx1 - view.bx0 + pu.w) * S, rowDw = (rowB + 3) / 4, nRows = view.by1 - view.by0 + pu.h;
         view.wsB = rowDw * 4;
+        view.winBase = ldsPtr(x.win);
         const FastDiv fd(rowDw);
         const char *g = view.ref + view.by0 * sbb + (long)view.bx0 * S;
         uint32_t *win = reinterpret_cast<uint32_t *>(x.win);
@@ -911,6 +965,9 @@ __device__ __forceinline__ void stage_uni(const SearchArgs &a, Lds<S> &x, Device
             const int y = rowDw <= 128 ? fd.div(i) : i / rowDw, k = i - y * rowDw;
             win[i] = ld4(g + y * sbb + 4 * k);
         }
+        if (cs && box) return;      // the source block is the CTU's
+        view.srcBase = ldsPtr(x.src);
+        view.srcPitch = pu.w * S;
         const int srcDw = pu.w * S / 4;
         const FastDiv fs(srcDw);
         const char *gs = a.src + ((long)pu.y0 * a.srcStride + pu.x0) * S;
@@ -925,10 +982,20 @@ __device__ __forceinline__ void stage_uni(const SearchArgs &a, Lds<S> &x, Device
 
 // one CTU's searches in one list.  x.mv / x.valid [256 ..]: the cells left of and above the CTU, put there by the caller
 template <int S>
-__device__ __forceinline__ void search_ctu(const SearchArgs &a, Lds<S> &x, const int list, const int cx, const int cy, Mv &mvPrev)
+__device__ __forceinline__ void search_ctu(const SearchArgs &a, Lds<S> &x, CtuStage<S> &cs, const int list, const int cx, const int cy, Mv &mvPrev)
 {
     const int c = cy * a.ctusX + cx, tid = threadIdx.x;
     const int ctb = a.sp.ctbSize, xCtb = cx * ctb, yCtb = cy * ctb;
+    CtuBox box;
+    {   // the CTU's source block (rows below / right of the picture's edge come from the plane's border: nothing reads them)
+        constexpr int chunks = 64 * S / 16;
+        const char *gs = a.src + ((long)yCtb * a.srcStride + xCtb) * S;
+        for (int i = tid; i < chunks * 64; i += kThreads)
+        {
+            const int y = i / chunks, k = i - y * chunks;
+            *reinterpret_cast<u32x4 *>(&cs.src[y * (64 * S) + 16 * k]) = ld16(gs + (long)y * a.srcStride * S + 16 * k);
+        }
+    }
     int32_t *field = a.field + (long)list * a.cw * a.ch;
     uint8_t *valid = a.valid + (long)list * a.cw * a.ch;
     auto get = [&](int, int px, int py, Mv *v) {
@@ -954,7 +1021,7 @@ __device__ __forceinline__ void search_ctu(const SearchArgs &a, Lds<S> &x, const
         havoc_search::derivePredictors(q, list, a.sp.picWidth, a.sp.picHeight, get, mvp);
         const havoc_search::PuContext pu = havoc_search::contextOf(q, ctb, mvp, a.mvpRate, mvPrev);
         DeviceView<S> view;
-        stage_uni<S>(a, x, view, pu, list);
+        stage_uni<S>(a, x, view, pu, list, &cs, &box);
         __syncthreads();
 #ifdef HAVOC_SEARCH_TIMING
         const long tStaged = wall_clock64();
@@ -1121,6 +1188,9 @@ __device__ __forceinline__ havoc_search::BiResult bi_refine(const SearchArgs &a,
         view.by0 = o0.y - kWinMargin; view.by1 = o0.y + kWinMargin;
         const int rowB = (view.bx1 - view.bx0 + w) * S, rowDw = (rowB + 3) / 4, nRows = view.by1 - view.by0 + h;
         view.wsB = rowDw * 4;
+        view.winBase = ldsPtr(x.win);
+        view.srcBase = ldsPtr(x.src);
+        view.srcPitch = w * S;
         const FastDiv fd(rowDw);
         const char *g = view.ref + view.by0 * sbb + (long)view.bx0 * S;
         uint32_t *win = reinterpret_cast<uint32_t *>(x.win);
@@ -1209,6 +1279,7 @@ template <int S>
 __global__ __launch_bounds__(kThreads) void k_search_step(const SearchArgs a, const int step, const int yLo)
 {
     __shared__ Lds<S> x;
+    __shared__ CtuStage<S> cs;
     const int list = blockIdx.x & 1, cy = yLo + (blockIdx.x >> 1), cx = step - 2 * cy, tid = threadIdx.x;
     if (tid < 256)
     {
@@ -1218,7 +1289,7 @@ __global__ __launch_bounds__(kThreads) void k_search_step(const SearchArgs a, co
     load_neighbours<S>(a, x, list, cx, cy, true, true);
     __syncthreads();
     Mv mvPrev = cx ? havoc_search::MotionField::unpack(a.rowPrev[2 * cy + list]) : Mv(0, 0);
-    search_ctu<S>(a, x, list, cx, cy, mvPrev);
+    search_ctu<S>(a, x, cs, list, cx, cy, mvPrev);
     if (tid == 0) a.rowPrev[2 * cy + list] = havoc_search::MotionField::pack(mvPrev);
 }
 
@@ -1232,6 +1303,7 @@ template <int S>
 __global__ __launch_bounds__(kThreads) void k_search_rows(const SearchArgs a)
 {
     __shared__ Lds<S> x;
+    __shared__ CtuStage<S> cs;
     __shared__ int shared;
     const int tid = threadIdx.x;
     if (tid == 0) shared = atomicAdd(a.ticket, 1);
@@ -1287,7 +1359,7 @@ __global__ __launch_bounds__(kThreads) void k_search_rows(const SearchArgs a)
         }
         load_neighbours<S>(a, x, list, cx, cy, false, true);      // the cells above, now final; the cells to the left were kept below
         __syncthreads();
-        search_ctu<S>(a, x, list, cx, cy, mvPrev);
+        search_ctu<S>(a, x, cs, list, cx, cy, mvPrev);
         // this CTU's right column becomes the next one's left neighbours; its own cells start undecided
         const int32_t keepMv = tid < 16 ? x.mv[tid * 16 + 15] : 0;
         const uint8_t keepValid = tid < 16 ? x.valid[tid * 16 + 15] : 0;
