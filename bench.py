@@ -829,7 +829,7 @@ def hbm_traffic_from_profiles(group, S):
         return None
     total, n = 0.0, 0
     for row in csv.DictReader(open(files[-1])):
-        if prefix in row["Kernel"]:
+        if _matches(prefix, row["Kernel"]):
             try:
                 total += float(row.get("FETCH_SIZE_bytes_per_launch") or 0) + float(row.get("WRITE_SIZE_bytes_per_launch") or 0)
                 n += 1
@@ -864,7 +864,7 @@ def hbm_traffic_in_run(args, group, S):
             vals = []
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
-                    if prefix in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                    if _matches(prefix, row["Kernel_Name"]) and row["Counter_Name"] == counter:
                         vals.append(float(row["Counter_Value"]))
             if not vals:
                 return None
@@ -887,7 +887,7 @@ def valu_busy_from_profiles(group, S):
         return None
     num = den = 0.0
     for row in csv.DictReader(open(files[-1])):
-        if prefix in row["Kernel"]:
+        if _matches(prefix, row["Kernel"]):
             try:
                 t = float(row["busy_us_at_2.4GHz"])
                 num += float(row["VALUBusy_pct"]) * t
@@ -897,8 +897,12 @@ def valu_busy_from_profiles(group, S):
     return round(num / den, 2) if den else None
 
 
+def _matches(prefix, name):
+    return any(p in name for p in prefix) if isinstance(prefix, tuple) else prefix in name
+
+
 def _kernel_prefix(group, S):
-    return {"sad4": f"k_sad<{S}, 4", "sad": f"k_sad<{S}, 1", "interp_planes": "k_interp_planes", "intra_satd35": "k_intra_satd35<",
+    return {"sad4": (f"k_sad4w<{S}", f"k_sad<{S}, 4"), "sad": f"k_sad<{S}, 1", "interp_planes": "k_interp_planes", "intra_satd35": "k_intra_satd35<",
               "intra": "k_intra<", "residual": "k_residual<", "transform": "k_transform<", "quantize_inverse": "k_quantize_inverse",
               "inverse_transform_add": "k_inverse_transform<", "ssd": "k_ssd<", "subtract_bi": "k_subtract_bi<",
               "subpel_satd": "k_subpel_satd<", "rdoq": "k_rdoq_", "deblock": "k_deblock<"}.get(group)
