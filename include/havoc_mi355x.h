@@ -551,6 +551,25 @@ int havoc_mi355x_intra_decide(havoc_mi355x_ctx *ctx, const havoc_mi355x_intra_mp
                               const int32_t *d_cbf, const uint32_t *d_ssd, const int32_t *d_stats, const havoc_mi355x_tu_fused_job *d_tu_jobs, int n, int log2TrafoSize,
                               int32_t reciprocal_lambda_q16, havoc_mi355x_intra_choice *d_out, havoc_mi355x_tu_fused_job *d_final);
 
+/* ---- the transform-tree decision of inter units and the picture's block structure on the device (round 4; csrc/kernels_decide.hip) ----
+ * reconstructInter's choice between one transform block and four (turing/Reconstruct.cpp:1296-1428; turingcodec_amd/search/tu_decision.hpp: decideRqt) from the outcomes of a
+ * unit's five candidate blocks, evaluated by the caller's chain tu_forward -> rdoq -> tu_reconstruct (into pieces) -> level_stats: the split tree first; none of its blocks
+ * coded -> the unit stays unsplit without residual and depth 0 is never considered; else the cheaper of  rate + ssd * reciprocal_lambda  wins, depth 0 on `<` (rate = the
+ * stand-in of tu_decision.hpp: (1 + (cbf ? 2 * nonzero + sum_abs : 0)) << 16 per block).  Candidate j of size s has its outcome at sizes[s - 2].d_cbf / d_ssd / d_stats [j] and its
+ * job at d_jobs[j]; unit i's depth-0 candidate is d_zero_at[i] of its size, its four depth-1 candidates d_one_at[i] .. + 3 of the next smaller size.  d_final[j] = the job that
+ * reconstructs candidate j again: into the picture (rec_off = rec_origin + y * rec_stride + x) when it belongs to the chosen tree -- a unit without residual through its four
+ * depth-1 blocks -- else at dump_off (any block-sized area of the same allocation nobody reads: the launches after the decision have a fixed size). */
+typedef struct { int32_t x0, y0, log2_size, ctx_index; } havoc_mi355x_rqt_unit;                 /* = havoc_rqt_cu */
+typedef struct { int32_t cbf; uint32_t ssd; int32_t nonzero, sum_abs; } havoc_mi355x_tu_outcome;   /* = havoc_tu_outcome */
+typedef struct { int32_t depth, tried_zero; havoc_mi355x_tu_outcome zero, one[4]; int64_t cost_zero, cost_one; } havoc_mi355x_rqt_choice;      /* 104 bytes; = havoc_rqt_result */
+typedef struct { const int32_t *d_cbf; const uint32_t *d_ssd; const int32_t *d_stats; const havoc_mi355x_tu_fused_job *d_jobs; havoc_mi355x_tu_fused_job *d_final; } havoc_mi355x_rqt_size;
+int havoc_mi355x_rqt_decide(havoc_mi355x_ctx *ctx, const havoc_mi355x_rqt_unit *d_units, int n, const int32_t *d_zero_at, const int32_t *d_one_at, const havoc_mi355x_rqt_size sizes[4],
+                            int64_t rec_origin, intptr_t rec_stride, int32_t dump_off, int32_t reciprocal_lambda_q16, havoc_mi355x_rqt_choice *d_out);
+/* the 4x4 cells havoc_mi355x_derive_bs reads, made from the decisions: every unit one inter 2Nx2N prediction unit from list 0 (decoded picture dpb_index0) at the vector d_field
+ * (int16 [2][height / 4][width / 4][2]) holds at its origin, coded flags and transform sizes as decided; cells outside the units: no motion coded, qp, tu_log2 = 2 */
+int havoc_mi355x_block_cells(havoc_mi355x_ctx *ctx, int width, int height, int qp, int dpb_index0, const int16_t *d_field, const havoc_mi355x_rqt_unit *d_units,
+                             const havoc_mi355x_rqt_choice *d_decisions, int n, havoc_mi355x_cell *d_cells);
+
 /* ---- an intra picture's partitions with their real dependencies (round 4; csrc/kernels_decide.hip) ----
  * A partition predicts from the reconstruction of what precedes it (turing/Reconstruct.cpp:609-615) and takes candModeList from its neighbours' decided modes
  * (turing/CandModeList.h:33-95).  A client that runs the batch chain over the partitions level by level (every partition of a level has all its neighbours final)

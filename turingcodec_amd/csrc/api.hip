@@ -42,6 +42,8 @@ hipError_t launch_intra_decide(hipStream_t, const void *, const int32_t *, const
                                int, int32_t, void *, void *);
 hipError_t launch_merge_jobs(hipStream_t, const void *, const int16_t *, const int32_t *, const int32_t *, int, int, void *, void *, void *, int16_t *);
 hipError_t launch_pred_jobs(hipStream_t, const void *, const int16_t *, int, const int32_t *, const int32_t *, int, int, int, const int32_t *, void *);
+hipError_t launch_rqt_decide(hipStream_t, const void *, int, const int32_t *, const int32_t *, const void *, long, int, int, int32_t, void *);
+hipError_t launch_block_cells(hipStream_t, int, int, int, int, const int16_t *, const void *, const void *, int, void *);
 hipError_t launch_intra_gather(hipStream_t, int, const void *, const void *, const int32_t *, const uint8_t *, const void *, int, const void *, void *, void *);
 hipError_t launch_intra_commit(hipStream_t, int, const void *, void *, uint8_t *, const void *, int, const void *, const void *, int);
 hipError_t launch_intra_fill_spare(hipStream_t, const int32_t *, int, int, void *, void *, void *, int32_t *, int32_t *);
@@ -609,6 +611,23 @@ int havoc_mi355x_merge_jobs(havoc_mi355x_ctx *ctx, const havoc_mi355x_field_layo
     REQUIRE(n == 0 || (d_field && d_x0 && d_y0 && d_luma_jobs && d_cb_jobs && d_cr_jobs && d_vectors), "null device pointer");
     REQUIRE(((uintptr_t)d_field & 3) == 0 && ((uintptr_t)d_vectors & 3) == 0, "d_field and d_vectors must be 4-byte aligned");
     return check(launch_merge_jobs(LS(ctx), layout, d_field, d_x0, d_y0, n, log2_size, d_luma_jobs, d_cb_jobs, d_cr_jobs, d_vectors), "merge_jobs");
+}
+
+int havoc_mi355x_rqt_decide(havoc_mi355x_ctx *ctx, const havoc_mi355x_rqt_unit *d_units, int n, const int32_t *d_zero_at, const int32_t *d_one_at, const havoc_mi355x_rqt_size sizes[4],
+                            int64_t rec_origin, intptr_t rec_stride, int32_t dump_off, int32_t reciprocal_lambda_q16, havoc_mi355x_rqt_choice *d_out)
+{
+    REQUIRE_CTX(); REQUIRE(n >= 0, "n < 0"); REQUIRE(sizes != nullptr, "null sizes"); REQUIRE(rec_stride > 0 && rec_stride < (1 << 24), "rec_stride out of range");
+    REQUIRE(n == 0 || (d_units && d_zero_at && d_one_at && d_out), "null device pointer");
+    REQUIRE(reciprocal_lambda_q16 >= 0, "reciprocal_lambda_q16 < 0"); REQUIRE(dump_off >= 0, "dump_off < 0");
+    return check(launch_rqt_decide(LS(ctx), d_units, n, d_zero_at, d_one_at, sizes, (long)rec_origin, (int)rec_stride, dump_off, reciprocal_lambda_q16, d_out), "rqt_decide");
+}
+
+int havoc_mi355x_block_cells(havoc_mi355x_ctx *ctx, int width, int height, int qp, int dpb_index0, const int16_t *d_field, const havoc_mi355x_rqt_unit *d_units,
+                             const havoc_mi355x_rqt_choice *d_decisions, int n, havoc_mi355x_cell *d_cells)
+{
+    REQUIRE_CTX(); REQUIRE(n >= 0, "n < 0"); REQUIRE(width > 0 && height > 0 && !(width & 3) && !(height & 3), "width / height must be positive multiples of 4");
+    REQUIRE(d_cells && (n == 0 || (d_field && d_units && d_decisions)), "null device pointer"); REQUIRE(((uintptr_t)d_field & 3) == 0, "d_field must be 4-byte aligned");
+    return check(launch_block_cells(LS(ctx), width, height, qp, dpb_index0, d_field, d_units, d_decisions, n, d_cells), "block_cells");
 }
 
 static bool chain_layout_ok(const havoc_mi355x_intra_chain_layout *l)

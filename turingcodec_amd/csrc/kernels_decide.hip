@@ -149,6 +149,121 @@ __global__ __launch_bounds__(256) void k_intra_decide(const IntraCtx *__restrict
     fin[i] = f;
 }
 
+// ---- the transform-tree decision of inter units and the picture's block structure, ON THE DEVICE (round 4) -----------------------------------------------
+// search/tu_decision.hpp's decideRqt (turing/Reconstruct.cpp:1296-1428) restated lane per unit over the outcomes of its five candidate blocks (depth 0: one block,
+// depth 1: four, evaluated by the chain tu_forward -> rdoq -> tu_reconstruct -> level_stats), so that a picture's launches after its searches need no host in
+// between: the decision, the job records that reconstruct EVERY candidate -- the chosen ones into the picture, the others into a dump area (a fixed number of jobs per
+// size: the sequence can be recorded into a HIP graph) -- and the 4x4 cells havoc_mi355x_derive_bs reads.  The host forms stay: tests hold these against them.
+struct RqtUnit { int32_t x0, y0, log2, ctxIndex; };                                                                          // havoc_rqt_cu
+struct TuOutcome { int32_t cbf; uint32_t ssd; int32_t nonzero, sumAbs; };                                                    // havoc_tu_outcome
+struct RqtResult { int32_t depth, triedZero; TuOutcome zero, one[4]; int64_t costZero, costOne; };                            // havoc_rqt_result
+struct RqtSize { const int32_t *cbf; const uint32_t *ssd; const int32_t *stats; const TuJob *jobs; TuJob *fin; };             // one transform size: havoc_mi355x_rqt_size
+struct RqtSizes { RqtSize s[4]; };
+struct Cell { int16_t mv[2][2]; int8_t dpb[2]; uint8_t flags; int8_t qpY; uint8_t tuLog2; uint8_t reserved[3]; };            // havoc_mi355x_cell
+static_assert(sizeof(RqtUnit) == 16 && sizeof(TuOutcome) == 16 && sizeof(RqtResult) == 104 && sizeof(RqtSize) == 40 && sizeof(Cell) == 16, "record layouts");
+
+__device__ __forceinline__ TuOutcome outcomeOf(const RqtSize &z, int j) { return TuOutcome{z.cbf[j], z.ssd[j], z.stats[2 * j], z.stats[2 * j + 1]}; }
+__device__ __forceinline__ int64_t tuRateOf(const TuOutcome &t) { return (int64_t)(1 + (t.cbf ? 2 * t.nonzero + t.sumAbs : 0)) << 16; }      // tu_decision.hpp: tuRate (stand-in)
+
+__global__ __launch_bounds__(256) void k_rqt_decide(const RqtUnit *__restrict__ units, int n, const int32_t *__restrict__ zeroAt, const int32_t *__restrict__ oneAt,
+                                                    const RqtSizes z, long recOrigin, int recStride, int dumpOff, int32_t reciprocalLambdaQ16, RqtResult *__restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const RqtUnit u = units[i];
+    const RqtSize &s0 = z.s[u.log2 - 2], &s1 = z.s[u.log2 - 3];
+    const int j0 = zeroAt[i], j1 = oneAt[i], half = 1 << (u.log2 - 1);
+    RqtResult r = RqtResult();
+    int32_t ssdOne = 0;
+    bool coded = false;
+    int64_t rateOne = 0;
+    for (int k = 0; k < 4; ++k)      // rqtdepth = 1 first (Reconstruct.cpp:1325-1326), blocks in z-order
+    {
+        r.one[k] = outcomeOf(s1, j1 + k);
+        ssdOne += (int32_t)r.one[k].ssd;
+        coded |= r.one[k].cbf != 0;
+        rateOne += tuRateOf(r.one[k]);
+    }
+    r.costOne = rateOne + (int64_t)reciprocalLambdaQ16 * (int64_t)ssdOne;
+    if (coded)
+    {
+        r.triedZero = 1;
+        r.zero = outcomeOf(s0, j0);
+        r.costZero = tuRateOf(r.zero) + (int64_t)reciprocalLambdaQ16 * (int64_t)(int32_t)r.zero.ssd;
+        r.depth = r.costZero < r.costOne ? 0 : 1;      // Reconstruct.cpp:1389
+    }
+    out[i] = r;
+    // every candidate is reconstructed once more: the chosen tree into the picture -- a unit left without residual through its four depth-1 blocks, whose levels are
+    // all zero (= the prediction) -- the rest into the dump area
+    const bool zeroWins = r.depth == 0 && r.triedZero;
+    TuJob f = s0.jobs[j0];
+    f.rec_off = zeroWins ? (int32_t)(recOrigin + (long)u.y0 * recStride + u.x0) : dumpOff;
+    s0.fin[j0] = f;
+    for (int k = 0; k < 4; ++k)
+    {
+        TuJob g = s1.jobs[j1 + k];
+        g.rec_off = zeroWins ? dumpOff : (int32_t)(recOrigin + (long)(u.y0 + (k >> 1) * half) * recStride + u.x0 + (k & 1) * half);
+        s1.fin[j1 + k] = g;
+    }
+}
+
+// havoc_search_block_cells on the device: every unit one inter 2Nx2N prediction unit from list 0 at the vector the field holds at its origin, its transform tree as decided
+__global__ __launch_bounds__(256) void k_block_cells_blank(Cell *__restrict__ cells, int count, int qp, int dpb0)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    Cell c = Cell();
+    c.dpb[0] = (int8_t)dpb0;
+    c.dpb[1] = -1;
+    c.qpY = (int8_t)qp;
+    c.tuLog2 = 2;
+    cells[i] = c;
+}
+
+__global__ __launch_bounds__(64) void k_block_cells(const RqtUnit *__restrict__ units, const RqtResult *__restrict__ dec, int n, const int32_t *__restrict__ field, int cw,
+                                                    int qp, int dpb0, Cell *__restrict__ cells)
+{
+    const int i = blockIdx.x;
+    if (i >= n) return;
+    const RqtUnit u = units[i];
+    const int x4 = u.x0 >> 2, y4 = u.y0 >> 2, n4 = (1 << u.log2) >> 2, half = n4 >> 1;
+    const int32_t packed = field[(long)y4 * cw + x4];
+    const RqtResult &d = dec[i];
+    const bool split = d.depth == 1, coded0 = d.triedZero == 1 && d.zero.cbf != 0;
+    for (int t = threadIdx.x; t < n4 * n4; t += 64)
+    {
+        const int y = t / n4, x = t - y * n4;
+        Cell c = Cell();
+        c.mv[0][0] = (int16_t)(packed & 0xffff);
+        c.mv[0][1] = (int16_t)(packed >> 16);
+        c.dpb[0] = (int8_t)dpb0;
+        c.dpb[1] = -1;
+        c.qpY = (int8_t)qp;
+        const bool coded = split ? d.one[(y >= half) * 2 + (x >= half)].cbf != 0 : coded0;
+        c.flags = (uint8_t)((coded ? 2 : 0) | (x == 0 ? 8 : 0) | (y == 0 ? 16 : 0));      // HAVOC_CELL_CODED, _PU_LEFT, _PU_TOP
+        c.tuLog2 = (uint8_t)(u.log2 - (split ? 1 : 0));
+        cells[(long)(y4 + y) * cw + x4 + x] = c;
+    }
+}
+
+hipError_t launch_rqt_decide(hipStream_t st, const void *units, int n, const int32_t *zeroAt, const int32_t *oneAt, const void *sizes, long recOrigin, int recStride, int dumpOff,
+                             int32_t rlQ16, void *out)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_rqt_decide, dim3((n + 255) / 256), dim3(256), 0, st, (const RqtUnit *)units, n, zeroAt, oneAt, *static_cast<const RqtSizes *>(sizes), recOrigin, recStride,
+                       dumpOff, rlQ16, (RqtResult *)out);
+    return hipGetLastError();
+}
+
+hipError_t launch_block_cells(hipStream_t st, int width, int height, int qp, int dpb0, const int16_t *field, const void *units, const void *dec, int n, void *cells)
+{
+    const int cw = width >> 2, ch = height >> 2;
+    hipLaunchKernelGGL(k_block_cells_blank, dim3((cw * ch + 255) / 256), dim3(256), 0, st, (Cell *)cells, cw * ch, qp, dpb0);
+    if (n > 0)
+        hipLaunchKernelGGL(k_block_cells, dim3(n), dim3(64), 0, st, (const RqtUnit *)units, (const RqtResult *)dec, n, reinterpret_cast<const int32_t *>(field), cw, qp, dpb0, (Cell *)cells);
+    return hipGetLastError();
+}
+
 // ---- an intra picture's partitions with their REAL dependencies (round 4; turing/Reconstruct.cpp:609-615, CandModeList.h:33-95) ----------------------------
 // A partition predicts from the RECONSTRUCTION of what precedes it and takes its most probable modes from its neighbours' champions, so the partitions of
 // a picture form a dependency graph; the host cuts it into levels (partitions whose neighbours are all final) and runs the batch chain level by level.

@@ -662,10 +662,97 @@ class DecisionPicture:
         if not predicted:
             self.predict(field)
         base = self.d_pic.data_ptr()
-        self.rqt_results, st = rqt(self.hv.h, self.S, self.bd, base, self.origin, self.stride, self.pred.data_ptr(), self.W, self.recon.data_ptr(), self.origin,
+        self._rqt, st = rqt(self.hv.h, self.S, self.bd, base, self.origin, self.stride, self.pred.data_ptr(), self.W, self.recon.data_ptr(), self.origin,
                                    self.stride, self.d_states.data_ptr(), self.quant, self.lam, 1.0 / self.lam, self.units)
         self.rqt_stats = st
-        return self.rqt_results, st
+        return self._rqt, st
+
+    # ---- round 4: the transform-tree decision and the block structure on the device -- nothing of the picture's step waits for the host after its searches ----
+    def _rqt_plan(self):
+        """what havoc_search_rqt builds per call, built ONCE (the units of a picture do not move): per transform size the candidates' job records (depth 0 of every unit
+        of that size, then the four depth-1 blocks of every unit of the next larger size, unit by unit), their buffers, and where each unit finds its candidates"""
+        hv, hmod, torch = self.hv, self.hmod, self.torch
+        from . import workload
+        u = self.units
+        lists = {s: [] for s in (2, 3, 4, 5)}
+        zero_at, one_at = np.zeros(len(u), np.int32), np.zeros(len(u), np.int32)
+        for i in range(len(u)):
+            L = int(u["log2_size"][i])
+            zero_at[i] = len(lists[L])
+            lists[L].append((i, 0, 0))
+            one_at[i] = len(lists[L - 1])
+            lists[L - 1] += [(i, 1, k) for k in range(4)]
+        plan = dict(sizes={}, d_units=hv.up(np.ascontiguousarray(u).view(np.int32)), d_zero_at=hv.up(zero_at), d_one_at=hv.up(one_at),
+                    d_out=hv.zeros(len(u) * 26, np.int32), table=np.zeros((4, 5), np.uint64), launches=0)
+        for log2, cand in lists.items():
+            m = len(cand)
+            if not m:
+                continue
+            nn = 1 << log2
+            area = nn * nn
+            c = np.array(cand, np.int64)
+            x = u["x0"][c[:, 0]].astype(np.int64) + np.where(c[:, 1] == 1, (c[:, 2] & 1) * nn, 0)
+            y = u["y0"][c[:, 0]].astype(np.int64) + np.where(c[:, 1] == 1, (c[:, 2] >> 1) * nn, 0)
+            jobs = np.stack([np.arange(m) * area, self.origin + y * self.stride + x, y * self.W + x, np.arange(m) * area], 1).astype(np.int32)
+            qs, qshift, inv, dshift = (int(v) for v in self.quant[log2 - 2])
+            rj = np.zeros(m, hmod.RDOQ_JOB_DT)
+            rj["dst_off"] = rj["src_off"] = jobs[:, 0]
+            rj["quant_scale"], rj["quant_shift"], rj["inv_scale"] = qs, qshift, inv
+            rj["lambda_q16"], rj["sdh_factor"] = hmod.rdoq_lambda(self.lam, inv)
+            rj["sdh"] = 1
+            rj["ctx_index"] = u["ctx_index"][c[:, 0]]
+            with torch.cuda.stream(hv.tstream):
+                d_rj = torch.from_numpy(rj.view(np.uint8).reshape(-1)).to(hv.device)
+            g = dict(log2=log2, nn=nn, m=m, inv=inv, dshift=dshift, d_jobs=hv.up(jobs), d_fin=hv.zeros(m * 4, np.int32), d_rj=d_rj,
+                     d_sj=hv.up(np.stack([jobs[:, 0], np.full(m, area)], 1).astype(np.int32)), coef=hv.zeros(m * area, np.int16), level=hv.zeros(m * area, np.int16),
+                     piece=hv.zeros(m * area, self.dt), work=hv.rdoq_workspace(m), cbf=hv.zeros(m, np.int32), ssd=hv.zeros(m, np.uint32), stats=hv.zeros(2 * m, np.int32),
+                     ssd2=hv.zeros(m, np.uint32))
+            plan["sizes"][log2] = g
+            plan["table"][log2 - 2] = [g["cbf"].data_ptr(), g["ssd"].data_ptr(), g["stats"].data_ptr(), g["d_jobs"].data_ptr(), g["d_fin"].data_ptr()]
+            plan["launches"] += 5
+        plan["launches"] += 1
+        # a block-sized area nobody reads, inside the reconstruction's bottom border (rewritten by the padding that ends the step): where the candidates that lost go
+        plan["dump"] = (self.H + self.PAD + 16) * self.stride + self.PAD
+        plan["rl_q16"] = int((1.0 / self.lam) * 65536 + 0.5)
+        n = ((self.W + 63) // 64 * 8 + 1) * ((self.H + 63) // 64 * 8 + 1)
+        with torch.cuda.stream(hv.tstream):
+            self.d_data = torch.zeros(n, dtype=torch.int8, device=hv.device)
+            self.d_bs = torch.zeros(n, dtype=torch.uint8, device=hv.device)
+            self.d_cells = torch.zeros((self.H // 4) * (self.W // 4) * 16, dtype=torch.uint8, device=hv.device)
+        self.d_chroma = hv.up(np.full(2 * (self.H // 2) * (self.W // 2), 128 << (self.bd - 8), self.dt))
+        return plan
+
+    def tree_and_filter_on_device(self):
+        """the transform-tree decisions of every inter unit (both depths through residual + DCT -> RDOQ -> IQ + IDCT + add -> SSD, the decision by k_rqt_decide, every
+        candidate reconstructed again -- the chosen trees into the picture), the block structure (k_block_cells), boundary strengths, deblocking, padding: launches only"""
+        hv, bd = self.hv, self.bd
+        if not hasattr(self, "rqt_plan"):
+            self.rqt_plan = self._rqt_plan()
+        P = self.rqt_plan
+        src = self.d_pic
+        for g in P["sizes"].values():
+            hv.tu_forward_d(bd, 0, g["log2"], g["coef"], src, self.stride, self.pred, self.W, g["d_jobs"].view(-1, 4))
+            hv.rdoq_d(bd, g["log2"], g["level"], g["coef"], self.d_states, g["d_rj"], g["cbf"], g["work"])
+            hv.tu_reconstruct_d(bd, 0, g["log2"], g["inv"], g["dshift"], g["piece"], g["nn"], self.pred, self.W, src, self.stride, g["level"], g["d_jobs"].view(-1, 4), g["ssd"])
+            hv.level_stats_d(g["level"], g["d_sj"], g["m"], g["stats"])
+        hv.rqt_decide_d(P["d_units"].view(-1, 4), P["d_zero_at"], P["d_one_at"], P["table"], self.origin, self.stride, P["dump"], P["rl_q16"], P["d_out"])
+        for g in P["sizes"].values():
+            hv.tu_reconstruct_d(bd, 0, g["log2"], g["inv"], g["dshift"], self.recon, self.stride, self.pred, self.W, src, self.stride, g["level"], g["d_fin"].view(-1, 4), g["ssd2"])
+        hv.block_cells_d(self.W, self.H, self.qp, 0, self.d_field, P["d_units"].view(-1, 4), P["d_out"], self.d_cells)
+        hv.derive_bs_d(self.d_cells, self.W // 4, self.W, self.H, self.d_data, self.d_bs)
+        hv.deblock_d(bd, self.recon, self.origin, self.stride, self.d_chroma, 0, (self.H // 2) * (self.W // 2), self.W // 2, self.W, self.H, self.d_data, self.d_bs)
+        hv.pad_block_d(self.recon, self.origin, self.W, self.H, self.stride, self.PAD)
+
+    @property
+    def rqt_results(self):
+        """the transform-tree decisions of the last step (RQT_RESULT_DT per unit): downloaded when asked for"""
+        if getattr(self, "_rqt", None) is None:
+            self._rqt = self.hv.down(self.rqt_plan["d_out"], np.int32).view(RQT_RESULT_DT).copy()
+        return self._rqt
+
+    @rqt_results.setter
+    def rqt_results(self, v):
+        self._rqt = v
 
     def block_cells(self, field, decisions):
         """the picture's block structure after the decisions, as the 4x4 cells havoc_mi355x_derive_bs reads: every unit one inter 2Nx2N
@@ -763,11 +850,19 @@ class DecisionPicture:
             # 294 -> 268 / 383 -> 237 pictures/s with 8 / 16 in flight: a second issuing thread per picture costs more than the overlap gives)
             self.intra_decisions()
         self._merge = None
-        self._replayed("merge + predict", lambda: (self.merge_candidates(field), self.predict(field)))
-        decisions, _ = self.tu_chain(field, predicted=True)
-        self._replayed("chroma", lambda: self.chroma_chain(field))
-        self.cells = self.block_cells(field, decisions)
-        self.loop_filter(self.cells)
+        if self.search_on_device:
+            # everything after the searches is a FIXED sequence of launches over device-resident tables (the decided field never leaves the device, the decisions
+            # between the launches are kernels): recorded once into a HIP graph, one launch per picture, one wait at the end
+            self._rqt = None
+            self._replayed("after the searches", lambda: (self.merge_candidates(field), self.predict(field), self.tree_and_filter_on_device(), self.chroma_chain(field)))
+            self.rqt_stats = RqtStats()
+            self.rqt_stats.launches, self.rqt_stats.candidates = self.rqt_plan["launches"], 5 * len(self.units)
+        else:
+            self._replayed("merge + predict", lambda: (self.merge_candidates(field), self.predict(field)))
+            decisions, _ = self.tu_chain(field, predicted=True)
+            self._replayed("chroma", lambda: self.chroma_chain(field))
+            self.cells = self.block_cells(field, decisions)
+            self.loop_filter(self.cells)
         self.hv.sync()
         return res, field, stats
 

@@ -94,6 +94,8 @@ def _load():
         "tu_reconstruct": [_vp, _i, _i, _i, _i, _i, _i, _vp, _ip, _vp, _ip, _vp, _ip, _vp, _vp, _i, _vp],
         "level_stats": [_vp, _vp, _vp, _i, _vp],
         "search_motion_uni": [_vp, _i, _vp, _vp, C.c_int64, _ip, _vp, C.c_int64, _ip, _vp, _ip, C.c_int64, _vp, _i, _vp],
+        "rqt_decide": [_vp, _vp, _i, _vp, _vp, _vp, C.c_int64, C.c_ssize_t, _i, _i, _vp],
+        "block_cells": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp],
         "intra_gather": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp],
         "intra_commit": [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i],
         "intra_fill_spare": [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp],
@@ -347,6 +349,15 @@ class Havoc:
     def field_layout(pic_width, pic_height, luma_stride, luma_pad, luma_plane_elems, chroma_stride, chroma_pad, chroma_plane_elems, search_range=64):
         return (C.c_int32 * 12)(pic_width, pic_height, search_range, (pic_width + 3) // 4, luma_stride, luma_pad, luma_plane_elems, chroma_stride, chroma_pad, chroma_plane_elems, 0, 0)
 
+    # ---- the transform-tree decision and the block structure on the device (kernels_decide.hip: k_rqt_decide, k_block_cells) ----
+    def rqt_decide_d(self, units, zero_at, one_at, sizes, rec_origin, rec_stride, dump_off, rl_q16, out):
+        """sizes: numpy uint64 [4, 5] of device addresses (d_cbf, d_ssd, d_stats, d_jobs, d_final) per transform size 4, 8, 16, 32"""
+        self._ck(self.L.havoc_mi355x_rqt_decide(self.h, _ptr(units), units.shape[0], _ptr(zero_at), _ptr(one_at), sizes.ctypes.data, int(rec_origin), int(rec_stride), int(dump_off),
+                                                int(rl_q16), _ptr(out)))
+
+    def block_cells_d(self, width, height, qp, dpb_index0, field, units, decisions, cells):
+        self._ck(self.L.havoc_mi355x_block_cells(self.h, width, height, qp, dpb_index0, _ptr(field), _ptr(units), _ptr(decisions), units.shape[0], _ptr(cells)))
+
     # ---- an intra picture's running state (kernels_decide.hip: k_intra_gather, k_intra_commit) ----
     @staticmethod
     def intra_chain_layout(pic_width, pic_height, stride, pad, cells_per_row, bit_depth, ctb_log2=6):
@@ -448,6 +459,10 @@ class Havoc:
     def tu_reconstruct_d(self, bd, tr, log2, scale, shift, rec, sr, pred, sp, src, ss, levels, jobs, ssd):
         self._ck(self.L.havoc_mi355x_tu_reconstruct(self.h, self._S(src), bd, tr, log2, scale, shift, _ptr(rec), sr, _ptr(pred), sp, _ptr(src), ss,
                                                     _ptr(levels), _ptr(jobs), jobs.shape[0], _ptr(ssd)))
+
+    def level_stats_d(self, levels, jobs, njobs, out):
+        """jobs: int32 [njobs, 2] (offset, count) into `levels`; out: int32 [2 * njobs] (non-zero levels, sum of magnitudes)"""
+        self._ck(self.L.havoc_mi355x_level_stats(self.h, _ptr(levels), _ptr(jobs), njobs, _ptr(out)))
 
     def tu_forward(self, bd, ncoef, src, ss, pred, sp, jobs):
         """jobs: int32 [n, 8] = (coef_off, src_off, pred_off, rec_off, log2, trType, 0, 0)"""
