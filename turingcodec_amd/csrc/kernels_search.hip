@@ -814,6 +814,65 @@ struct DeviceView
         __syncthreads();      // x->raster is free again before anyone writes it (the next raster sweep is a whole search away, but the barrier is cheap here)
         GAP_OUT();
     }
+    // searchMotionBi's exhaustive grid (Search.hpp:1583-1623): (2 range + 1)^2 candidates in raster order, every SAD already in x->table (hintSadRect).  The reference takes
+    // them four columns at a time: the candidate of column x is the limited position of ITS column, its SAD the one taken (x - first column) samples right of the group's
+    // limited first position.  A candidate per lane (every wavefront the whole grid: nothing to exchange), the first of the cheapest wins on strictly smaller cost.
+    __device__ __forceinline__ bool biGrid(Mv origin, int range, const havoc_search::LimitFullPelMv &limit, const havoc_search::PuContext &pu, const havoc_search::Lambda lambda,
+                                           havoc_search::MvCandidate &best)
+    {
+        if (!tw) return false;
+        GAP_IN();
+        const int side = 2 * range + 1, total = side * side;
+        const FastDiv fs(side);
+        const int ox = origin.x >> 2, oy = origin.y >> 2;
+        const int lox = limit.lo.x, hix = limit.hi.x, loy = limit.lo.y, hiy = limit.hi.y;
+        uint64_t key = 0x7fffffffffffffffull;      // lanes without a candidate (the 3 x 3 grid of the small window): beyond every cost, and non-negative for scalarMin
+        bool ok = true;
+        for (int idx = lane; idx < total; idx += kWave)
+        {
+            const int yy = fs.div(idx), xx = idx - yy * side, i = xx & 3;
+            const int fy = min(max(oy + yy - range, loy), hiy);
+            const int fx = min(max(ox + xx - range - i, lox), hix);                      // the group's first position, limited
+            const int sx = i ? min(max(fx + i, lox), hix) : fx;                         // where this column's SAD is taken
+            const int cx = i ? min(max(ox + xx - range, lox), hix) : fx;                // the candidate itself
+            const bool in = sx >= tx0 && sx < tx0 + tw && fy >= ty0 && fy < ty0 + th;
+            ok &= in;
+            const int sadv = in ? x->table[(fy - ty0) * tw + sx - tx0] : 0;
+            int32_t mvdPacked;
+            int second;
+            const Cost cost = laneCost(cx, fy, pu, lambda, sadv, mvdPacked, second);
+            const uint64_t kk = ((uint64_t)cost << 8) | (uint32_t)idx;
+            key = kk < key ? kk : key;
+        }
+        if (__builtin_amdgcn_ballot_w64(!ok) != 0)
+        {   // a position outside the announced rectangle: the generic loops answer (every wavefront decides the same)
+            GAP_OUT();
+            return false;
+        }
+        key = quadMin(key);
+        uint64_t k = read64(key, 0);
+#pragma unroll
+        for (int l = 4; l < kWave; l += 4) k = scalarMin(k, read64(key, l));
+        const Cost cw = (Cost)(k >> 8);
+        if (havoc_search::costLess(cw, best.cost))
+        {
+            const int idx = (int)(k & 255), yy = fs.div(idx), xx = idx - yy * side, i = xx & 3;
+            Mv full(int16_t(ox + xx - range - i), int16_t(oy + yy - range));
+            limit(full);
+            if (i)
+            {
+                full = Mv(int16_t(ox + xx - range), int16_t(oy + yy - range));
+                limit(full);
+            }
+            const havoc_search::MvCandidate again(havoc_search::shl2(full), pu.mvp, pu.mvpRate);
+            best.cost = cw;
+            best.mv = again.mv;
+            best.mvd = again.mvd;
+            best.mvpFlag = again.mvpFlag;
+        }
+        GAP_OUT();
+        return true;
+    }
 #ifndef HAVOC_NO_SUBPEL_LANES
     // patternSearchOnce's costMv calls (Search.hpp:2001-2061, one iteration): the eight neighbours of `mv` at `scale` quarter samples in raster order (and `mv`
     // itself first when tryOrigin), a position per lane; returns the first of the cheapest neighbours if it beats the cost so far strictly, else -1

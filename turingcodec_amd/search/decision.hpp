@@ -258,6 +258,20 @@ HAVOC_HD inline auto foldStartProbe(View &v, Mv mv, int forcedFlag, Cost *costOu
 template <class View, class Search>
 HAVOC_HD inline int foldStartProbe(View &, Mv, int, Cost *, Search &, long) { return -1; }
 
+//   bool biGrid(Mv originQuarter, int range, limit, pu, lambda, best)
+//                                                   = the whole exhaustive grid of searchMotionBi ((2 range + 1)^2 candidates, their SADs announced with hintSadRect): a
+//                                                     candidate per lane, the first of the cheapest folded into `best`; false = not taken over (the loops below run)
+template <class View>
+HAVOC_HD inline auto foldBiGrid(View &v, Mv origin, int range, const LimitFullPelMv &limit, const PuContext &pu, Lambda lambda, MvCandidate &best, int &calls, int)
+    -> decltype(v.biGrid(origin, range, limit, pu, lambda, best), bool())
+{
+    if (!v.biGrid(origin, range, limit, pu, lambda, best)) return false;
+    calls += (2 * range + 1) * ((2 * range + 1 + 3) / 4);
+    return true;
+}
+template <class View>
+HAVOC_HD inline bool foldBiGrid(View &, Mv, int, const LimitFullPelMv &, const PuContext &, Lambda, MvCandidate &, int &, long) { return false; }
+
 template <class View, class Search>
 HAVOC_HD inline auto foldSubpelStep(View &v, Search &s, int scale, bool tryOrigin, Mv mv, Mv mvd, Cost &bestCost, int) -> decltype(v.subpelStep(mv, mvd, scale, tryOrigin, s.lambda, bestCost), int())
 {
@@ -571,6 +585,7 @@ HAVOC_HD BiResult searchMotionBi(const SearchParams &sp, const PuContext &pu, Bi
         const Mv o = shr2(origin);
         hintSadRect(view, o.x - range, o.y - range, o.x + range + 3, o.y + range, 0);
     }
+    if (!foldBiGrid(view, origin, range, limit, pu, lambda, best, r.calls, 0))
     for (int y = -range; y <= range; ++y)
         for (int xb = -range; xb <= range; xb += 4)      // the reference's x loop, four columns at a time: (x + range) % 4 == 0 exactly at x = xb
         {
