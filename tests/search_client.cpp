@@ -307,6 +307,46 @@ struct LaneEmuView
         best.mvd = mvd;
         best.mvpFlag = flag;
     }
+    // searchMotionBi's exhaustive grid as the device view takes it (csrc/kernels_search.hip: DeviceView::biGrid): every candidate's position, the position its SAD is taken
+    // at (the quirk of the four-column groups) and its cost computed per "lane", the first of the cheapest on a (cost, index) key
+    bool biGrid(Mv origin, int range, const LimitFullPelMv &limit, const PuContext &pu, Lambda lambda, MvCandidate &best)
+    {
+        const int side = 2 * range + 1, ox = origin.x >> 2, oy = origin.y >> 2;
+        uint64_t key = 0x7fffffffffffffffull;
+        auto place = [&](int idx, Mv &cand, Mv &sadAt) {
+            const int yy = idx / side, xx = idx - yy * side, i = xx & 3;
+            Mv first(int16_t(ox + xx - range - i), int16_t(oy + yy - range));
+            limit(first);
+            sadAt = first;
+            cand = first;
+            if (i)
+            {
+                sadAt = Mv(int16_t(first.x + i), first.y);
+                limit(sadAt);
+                cand = Mv(int16_t(ox + xx - range), int16_t(oy + yy - range));
+                limit(cand);
+            }
+        };
+        for (int idx = 0; idx < side * side; ++idx)
+        {
+            Mv cand, sadAt, mvd;
+            int flag;
+            place(idx, cand, sadAt);
+            const Cost cost = laneCost(cand, pu, lambda, sadAtFull(sadAt), mvd, flag);
+            const uint64_t kk = (uint64_t(cost) << 8) | uint32_t(idx);
+            if (kk < key) key = kk;
+        }
+        if (!(Cost(key >> 8) < best.cost)) return true;
+        Mv cand, sadAt, mvd;
+        int flag;
+        place(int(key & 255), cand, sadAt);
+        laneCost(cand, pu, lambda, 0, mvd, flag);
+        best.cost = Cost(key >> 8);
+        best.mv = shl2(cand);
+        best.mvd = mvd;
+        best.mvpFlag = flag;
+        return true;
+    }
     int subpelStep(Mv mv, Mv mvd, int scale, bool tryOrigin, Lambda lambda, Cost &bestCost)
     {
         Cost start = bestCost;
@@ -377,7 +417,7 @@ void runUni(const Sample *src, intptr_t ss, const Sample *ref, intptr_t rs, cons
 
 template <typename Sample>
 void runBi(const Sample *src, intptr_t ss, const Sample *ref, const Sample *refOther, intptr_t rs, const havoc_search_params &p, const havoc_search_pu *pus,
-           const int16_t *start, int b, int e, havoc_search_result *out, CallLog *log = nullptr, int64_t *logFirst = nullptr)
+           const int16_t *start, int b, int e, havoc_search_result *out, CallLog *log = nullptr, int64_t *logFirst = nullptr, bool lanes = false)
 {
     const SearchParams sp = paramsOf(p);
     for (int i = b; i < e; ++i)
@@ -395,6 +435,11 @@ void runBi(const Sample *src, intptr_t ss, const Sample *ref, const Sample *refO
             LoggedView<TableView<Sample>> logged{view, *log};
             r = searchMotionBi(sp, pu, logged, Mv(start[2 * i], start[2 * i + 1]));
             logFirst[i - b + 1] = log->count;
+        }
+        else if (lanes)
+        {
+            LaneEmuView<TableView<Sample>> emu{view};
+            r = searchMotionBi(sp, pu, emu, Mv(start[2 * i], start[2 * i + 1]));
         }
         else
             r = searchMotionBi(sp, pu, view, Mv(start[2 * i], start[2 * i + 1]));
@@ -497,6 +542,16 @@ int client_bi(int S, const void *src, intptr_t ss, const void *ref, const void *
     if (!g_open) return -1;
     if (S == 1) runBi<uint8_t>((const uint8_t *)src, ss, (const uint8_t *)ref, (const uint8_t *)refOther, rs, *p, pus, start, b, e, out);
     else runBi<uint16_t>((const uint16_t *)src, ss, (const uint16_t *)ref, (const uint16_t *)refOther, rs, *p, pus, start, b, e, out);
+    return 0;
+}
+
+// the bi-directional refinements through the grid step in its lane formulation (LaneEmuView::biGrid)
+int client_bi_lanes(int S, const void *src, intptr_t ss, const void *ref, const void *refOther, intptr_t rs, const havoc_search_params *p, const havoc_search_pu *pus,
+                    const int16_t *start, int b, int e, havoc_search_result *out)
+{
+    if (!g_open) return -1;
+    if (S == 1) runBi<uint8_t>((const uint8_t *)src, ss, (const uint8_t *)ref, (const uint8_t *)refOther, rs, *p, pus, start, b, e, out, nullptr, nullptr, true);
+    else runBi<uint16_t>((const uint16_t *)src, ss, (const uint16_t *)ref, (const uint16_t *)refOther, rs, *p, pus, start, b, e, out, nullptr, nullptr, true);
     return 0;
 }
 

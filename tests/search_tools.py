@@ -94,6 +94,7 @@ class Client:
         L.client_uni_logged.argtypes = [i, vp, ip, vp, ip, C.POINTER(Params), vp, i, i, vp, vp, C.c_int64, vp]
         L.client_uni_logged.restype = C.c_int64
         L.client_bi_logged.argtypes = [i, vp, ip, vp, vp, ip, C.POINTER(Params), vp, vp, i, i, vp, vp, C.c_int64, vp]
+        L.client_bi_lanes.argtypes = [i, vp, ip, vp, vp, ip, C.POINTER(Params), vp, vp, i, i, vp]
         L.client_bi_logged.restype = C.c_int64
         L.client_rqt_decide.argtypes = [vp, i, vp]
         L.client_intra_rd_decide.argtypes = [vp, vp, vp, i, vp]
@@ -149,6 +150,14 @@ class Client:
                                     first.ctypes.data)
         assert 0 <= n <= capacity, (n, capacity)
         return out, rows[:n], first
+
+    def bi_lanes(self, params, src, ref, ref_other, stride, pad, pus, start):
+        """bi() with the exhaustive grid in the device view's formulation (a candidate per lane, smallest (cost, index) key), emulated on the host"""
+        out = np.zeros(len(pus), RESULT_DT)
+        start = np.ascontiguousarray(start, np.int16)
+        assert self.L.client_bi_lanes(src.itemsize, self._origin(src, stride, pad), stride, self._origin(ref, stride, pad), self._origin(ref_other, stride, pad),
+                                      stride, C.byref(params), pus.ctypes.data, start.ctypes.data, 0, len(pus), out.ctypes.data) == 0
+        return out
 
     def rqt_decide(self, rows):
         """tu_decision.hpp: decideRqt on recorded (cbf, weighted ssd, rate) of the split tree and (ssd, rate) of the unsplit block: int32 [n, 2] = depth, tried_zero"""

@@ -36,8 +36,10 @@ def check_cpu(rep, min_searches):
     u, b, i = rep["uni_cpu"], rep["bi_cpu"], rep["intra_cpu"]
     assert u["searches"] >= min_searches and u["calls"] > 20 * u["searches"]
     assert u["mismatching_searches"] == 0 and u["mismatching_call_rows"] == 0, u
+    assert u["mismatching_in_the_lane_formulation"] == 0, u      # the pattern / raster / sub-sample steps a candidate per "lane" (what k_search_rows runs), emulated on the host
     assert u["previous_2Nx2N_handovers_checked"] > u["searches"] // 2 and u["previous_2Nx2N_handovers_wrong"] == 0, u
     assert b["searches"] >= min_searches // 4 and b["mismatching_searches"] == 0 and b["mismatching_call_rows"] == 0, b
+    assert b["mismatching_in_the_lane_formulation"] == 0, b      # the exhaustive grid costed a candidate per "lane" (what k_search_bi runs), emulated on the host
     assert i["partitions"] >= min_searches // 2 and i["mismatching"] == 0, i
     # tu_decision.hpp on the encoder's own rates and distortions: the champion of every intra partition's RD refinement, every transform-tree decision
     rd, q = rep["intra_rd_cpu"], rep["rqt_cpu"]

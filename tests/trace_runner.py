@@ -191,6 +191,7 @@ def main():
             start = np.ascontiguousarray(bi.meta["start"][sel])
             out, rows, first = cpu.bi_logged(par, s, rf, ro, stride, tt.PAD, pus, start, int(bi.results["calls"][sel].sum()) + 4096)
             r["mismatching_searches"] += int(len(differing(out, bi.results[sel], BI_FIELDS)))
+            r["mismatching_in_the_lane_formulation"] = r.get("mismatching_in_the_lane_formulation", 0) + int(len(differing(cpu.bi_lanes(par, s, rf, ro, stride, tt.PAD, pus, start), bi.results[sel], BI_FIELDS)))
             exp_rows = gather_rows(bi, sel)
             r["mismatching_call_rows"] += int(abs(len(rows) - len(exp_rows)) + np.count_nonzero(np.any(rows[:len(exp_rows)] != exp_rows[:len(rows)], axis=1)))
             bi_jobs.append((key, par, lst, other, sel, pus, start))
