@@ -51,6 +51,7 @@ struct SearchArgs
     int32_t *rowPrev;                         // [ctusY][2]: mvPreviousInteger2Nx2N at the end of the row's last finished CTU
     int *progress;                            // [ctusY][2]: CTUs of the row done (the one-launch form)
     int *ticket, *gaveUp;                     // rows are handed out in the order workgroups start; a wait that gave up
+    int rowLag;                               // CTUs the row above must be ahead: 2 = the reference's wavefront rule (TaskEncodeSubstream.cpp:71-95); 1 = diagnostic
 };
 
 // LDS operands are named by address-space-3 pointers so that they are read with ds_read (a generic pointer would be a flat load)
@@ -1389,7 +1390,7 @@ __global__ __launch_bounds__(kThreads) void k_search_rows(const SearchArgs a)
         {
             if (tid == 0)
             {
-                const int need = cx + 2 < a.ctusX ? cx + 2 : a.ctusX;
+                const int need = cx + a.rowLag < a.ctusX ? cx + a.rowLag : a.ctusX;
                 int spins = 0, ok = 1;
                 // polled relaxed (an acquire per poll would invalidate this XCD's caches every quarter microsecond for as long as the row waits --
                 // and rows wait most of the time); ONE acquire fence once the row above is far enough
@@ -1572,6 +1573,9 @@ hipError_t launch_search_picture_uni(hipStream_t st, int S, const havoc_mi355x_s
     a.progress = a.rowPrev + 2 * ctusY;
     a.ticket = a.progress + 2 * ctusY + 2;
     a.gaveUp = a.ticket + 1;
+    // HAVOC_SEARCH_ROW_LAG=1 (diagnostic, profiles/): what picture_order.hpp's derivation READS of the row above is the CTU directly above (no above-right candidate), so its
+    // data would allow a lag of one CTU -- same results, 46 instead of 62 steps at 1080p.  The default is the reference's rule: its real AMVP reads above-right.
+    a.rowLag = (getenv("HAVOC_SEARCH_ROW_LAG") && atoi(getenv("HAVOC_SEARCH_ROW_LAG")) == 1) ? 1 : 2;
     hipError_t e = hipMemsetAsync(work, 0, search_workspace_bytes(sp->pic_width, sp->pic_height), st);
     if (e != hipSuccess) return e;
     if ((e = hipMemsetAsync(field, 0, 2 * cells * 4, st)) != hipSuccess) return e;
