@@ -457,24 +457,100 @@ int havoc_mi355x_search_motion_bi(havoc_mi355x_ctx *ctx, int S, const havoc_mi35
     (void)pus; (void)start; (void)n; (void)out;
     return HAVOC_MI355X_EINVAL;      /* a kernel: nothing behind it in the mock */
 }
-/* the intra chain's device-side steps (round 4): kernels, nothing behind them in the mock (havoc_search_intra_chain is exercised on the GPU: tests/test_intra_chain.py) */
-int havoc_mi355x_intra_gather(havoc_mi355x_ctx *ctx, int S, const havoc_mi355x_intra_chain_layout *layout, const void *rec, const int32_t *owner, const uint8_t *modes,
+/* the intra chain's device-side steps (round 4), restated on the host so that libhavoc_search's havoc_search_intra_chain runs over this stand-in (tests/intra_chain_runner.py):
+ * reference samples of a partition from the running reconstruction with the substitution process of HEVC 8.4.4.2.2 (availability: the owner of the sample's 4x4 cell precedes
+ * the partition in coding order), their [1 2 1]-filtered copy, candModeList from the neighbours' modes (turing/CandModeList.h:33-95); the champions back into the picture */
+static int chain_sample(const void *rec, int S, long at) { return S == 1 ? ((const uint8_t *)rec)[at] : ((const uint16_t *)rec)[at]; }
+static void chain_store(void *p, int S, long at, int v) { if (S == 1) ((uint8_t *)p)[at] = (uint8_t)v; else ((uint16_t *)p)[at] = (uint16_t)v; }
+static int chain_available(const havoc_mi355x_intra_chain_layout *L, const int32_t *owner, int index, int x, int y)
+{
+    return x >= 0 && y >= 0 && x < L->pic_width && y < L->pic_height && owner[(y >> 2) * L->cells_per_row + (x >> 2)] < index;
+}
+int havoc_mi355x_intra_gather(havoc_mi355x_ctx *ctx, int S, const havoc_mi355x_intra_chain_layout *L, const void *rec, const int32_t *owner, const uint8_t *modes,
                               const havoc_mi355x_intra_chain_part *parts, int n, const havoc_mi355x_intra_search_job *jobs, void *nb, havoc_mi355x_intra_mpm *mpm)
 {
-    (void)ctx; (void)S; (void)layout; (void)rec; (void)owner; (void)modes; (void)parts; (void)n; (void)jobs; (void)nb; (void)mpm;
-    return HAVOC_MI355X_EINVAL;
+    (void)ctx; ++g_launches;
+    for (int i = 0; i < n; ++i)
+    {
+        const havoc_mi355x_intra_chain_part *p = &parts[i];
+        const int nn = 1 << p->log2, len = 4 * nn + 1;
+        int val[132], have[132], any = 0;
+        for (int k = 0; k < len; ++k)
+        {
+            const int x = k <= 2 * nn ? p->x0 - 1 : p->x0 + k - 2 * nn - 1, y = k < 2 * nn ? p->y0 + 2 * nn - 1 - k : p->y0 - 1;
+            have[k] = chain_available(L, owner, p->index, x, y);
+            val[k] = have[k] ? chain_sample(rec, S, (long)(y + L->pad) * L->stride + x + L->pad) : 0;
+            any |= have[k];
+        }
+        if (!any)
+            for (int k = 0; k < len; ++k) val[k] = 1 << (L->bit_depth - 1);
+        else
+        {
+            int first = 0;
+            while (!have[first]) ++first;
+            val[0] = val[first];
+            for (int k = 1; k < len; ++k)
+                if (!have[k]) val[k] = val[k - 1];
+        }
+        const long base = jobs[i].nb_off - (2 * nn + 1), basef = jobs[i].nbf_off - (2 * nn + 1);
+        for (int k = 0; k < len; ++k)
+        {
+            chain_store(nb, S, base + k, val[k]);
+            chain_store(nb, S, basef + k, (k == 0 || k == len - 1) ? val[k] : (val[k - 1] + 2 * val[k] + val[k + 1] + 2) >> 2);
+        }
+        const int a = chain_available(L, owner, p->index, p->x0 - 1, p->y0) ? modes[(p->y0 >> 2) * L->cells_per_row + ((p->x0 - 1) >> 2)] : 1;
+        const int b = chain_available(L, owner, p->index, p->x0, p->y0 - 1) && (p->y0 - 1) >= ((p->y0 >> L->ctb_log2) << L->ctb_log2)
+                          ? modes[((p->y0 - 1) >> 2) * L->cells_per_row + (p->x0 >> 2)] : 1;
+        havoc_mi355x_intra_mpm *c = &mpm[i];
+        if (a == b)
+        {
+            c->neighbour_modes = 1;
+            if (a < 2) { c->cand_mode_list[0] = 0; c->cand_mode_list[1] = 1; c->cand_mode_list[2] = 26; }
+            else { c->cand_mode_list[0] = a; c->cand_mode_list[1] = ((a + 29) % 32) + 2; c->cand_mode_list[2] = ((a - 1) % 32) + 2; }
+        }
+        else
+        {
+            c->neighbour_modes = 2;
+            c->cand_mode_list[0] = a; c->cand_mode_list[1] = b;
+            c->cand_mode_list[2] = (a != 0 && b != 0) ? 0 : ((a != 1 && b != 1) ? 1 : 26);
+        }
+    }
+    return 0;
 }
-int havoc_mi355x_intra_commit(havoc_mi355x_ctx *ctx, int S, const havoc_mi355x_intra_chain_layout *layout, void *rec, uint8_t *modes, const havoc_mi355x_intra_chain_part *parts,
+int havoc_mi355x_intra_commit(havoc_mi355x_ctx *ctx, int S, const havoc_mi355x_intra_chain_layout *L, void *rec, uint8_t *modes, const havoc_mi355x_intra_chain_part *parts,
                               int n, const void *blocks, const int32_t *mode, int mode_stride)
 {
-    (void)ctx; (void)S; (void)layout; (void)rec; (void)modes; (void)parts; (void)n; (void)blocks; (void)mode; (void)mode_stride;
-    return HAVOC_MI355X_EINVAL;
+    (void)ctx; ++g_launches;
+    for (int i = 0; i < n; ++i)
+    {
+        const havoc_mi355x_intra_chain_part *p = &parts[i];
+        const int nn = 1 << p->log2;
+        for (int y = 0; y < nn; ++y)
+            for (int x = 0; x < nn; ++x)
+                chain_store(rec, S, (long)(p->y0 + y + L->pad) * L->stride + p->x0 + x + L->pad, chain_sample(blocks, S, (long)i * nn * nn + y * nn + x));
+        for (int y = 0; y < nn / 4; ++y)
+            for (int x = 0; x < nn / 4; ++x) modes[((p->y0 >> 2) + y) * L->cells_per_row + (p->x0 >> 2) + x] = (uint8_t)mode[(long)i * mode_stride];
+    }
+    return 0;
 }
 int havoc_mi355x_intra_fill_spare(havoc_mi355x_ctx *ctx, const int32_t *total, int capacity, int log2, havoc_mi355x_intra_job *ij, havoc_mi355x_tu_fused_job *tj,
                                   havoc_mi355x_rdoq_job *rj, int32_t *sj, int32_t *owner)
 {
-    (void)ctx; (void)total; (void)capacity; (void)log2; (void)ij; (void)tj; (void)rj; (void)sj; (void)owner;
-    return HAVOC_MI355X_EINVAL;
+    (void)ctx; ++g_launches;
+    const int area = 1 << (2 * log2);
+    if (total[0] <= 0) return 0;
+    for (int c = total[0]; c < capacity; ++c)
+    {
+        ij[c] = ij[0];
+        ij[c].dst_off = c * area;
+        tj[c].coef_off = c * area; tj[c].src_off = tj[0].src_off; tj[c].pred_off = c * area; tj[c].rec_off = c * area;
+        rj[c] = rj[0];
+        rj[c].dst_off = rj[c].src_off = c * area;
+        sj[2 * c] = c * area;
+        sj[2 * c + 1] = area;
+        owner[c] = owner[0];
+    }
+    return 0;
 }
 size_t havoc_mi355x_search_workspace(int width, int height) { (void)width; (void)height; return 256; }
 int havoc_mi355x_search_picture_uni(havoc_mi355x_ctx *ctx, int S, const havoc_mi355x_search_params *params, const int64_t mvp_rate[2], const void *src, int64_t so,

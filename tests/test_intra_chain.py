@@ -98,6 +98,21 @@ def _host_chain(ref, ip):
     return best, cands, rec
 
 
+@pytest.mark.parametrize("res,BD,qp", [("416x240", 8, 32), ("640x360", 10, 27)])
+def test_chain_client_on_the_cpu_stand_in_device_equals_the_reference_loop(res, BD, qp):
+    """havoc_search_intra_chain (the level loop, the per-size slices, the worst-case candidate slots) over tests/mock_device.c, where the chain's device-side steps --
+    gather with substitution, candModeList, commit, spare slots -- are restated on the host: champions, candModeLists and the reconstruction equal the reference's loop"""
+    import json
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(HERE, "intra_chain_runner.py"), "--device", "mock", "--res", res, "--bit-depth", str(BD), "--qp", str(qp)],
+                         capture_output=True, text=True, timeout=1200, cwd=os.path.dirname(HERE))
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    assert r["partitions"] > 1000 and r["levels"] > 100 and r["launches"] > 13 * r["levels"]
+    assert r["mismatching_champions"] == 0 and r["mismatching_cand_mode_lists"] == 0 and r["reconstruction_equal"], r
+    assert r["distinct_champion_modes"] > 10 and r["coded"] > 0.05, r
+
+
 @pytest.mark.gpu
 def test_both_forms_of_the_level_loop_agree():
     """a wait per level (havoc_search_intra_device per level: candidate counts known to the host) == no wait at all (worst-case candidate slots, spare ones filled)"""

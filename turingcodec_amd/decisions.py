@@ -242,6 +242,47 @@ def intra_modes(ctx, S, bit_depth, log2, d_src, src_stride, d_neighbours, d_jobs
     return out
 
 
+def intra_chain_tables(width, height, bit_depth, qp, seed, stride, pad):
+    """host side of an intra picture's dependency chain (IntraChainPicture; tests/intra_chain_runner.py drives the same tables through the CPU stand-in device): the
+    partitions, their owner map and levels (workload.intra_picture_partitions), and per partition size -- ordered by level -- the job records, the most-probable-mode
+    records (rates and max_refine; the modes are derived from the neighbours' champions as the chain runs), CABAC snapshot indices, chain records and level slices"""
+    from . import workload
+    parts, owner, level = workload.intra_picture_partitions(width, height, seed + 3)
+    cx = (width + 63) // 64
+    lam = workload.picture_lambda(qp)
+    rng = np.random.default_rng(seed + 7919)
+    base = rng.integers(4, 100, 128)
+    rdoq_states = np.clip(base[None, :] + rng.integers(-6, 7, (cx * ((height + 63) // 64), 128)), 0, 125).astype(np.uint8)
+    nlevels = int(level.max()) + 1
+    sizes = {}
+    for log2 in (5, 4, 3, 2):
+        sel = np.flatnonzero(parts["log2"] == log2)
+        if not len(sel):
+            continue
+        sel = sel[np.argsort(level[sel], kind="stable")]
+        m, nn = len(sel), 1 << log2
+        L = 4 * nn + 1
+        x0, y0 = parts["x0"][sel].astype(np.int64), parts["y0"][sel].astype(np.int64)
+        mask = workload.intra_filter_mask(nn)
+        jobs = np.zeros((m, 8), np.int64)
+        jobs[:, 0] = (y0 + pad) * stride + x0 + pad
+        jobs[:, 1] = np.arange(m) * 2 * L + 2 * nn + 1
+        jobs[:, 2] = jobs[:, 1] + L
+        jobs[:, 3], jobs[:, 4], jobs[:, 5] = mask & 0xffffffff, mask >> 32, 1
+        jobs = jobs.astype(np.uint32).view(np.int32).reshape(m, 8)
+        ictx = np.zeros(m, INTRA_CTX_DT)
+        ictx["max_refine"] = 3 if log2 > 3 else 8            # Speed::nCandidatesIntraRefinement at medium
+        ictx["rate_a_minus_c"] = -rng.integers(300000, 420000, m)
+        ictx["rate_b_minus_c"] = -rng.integers(100000, 200000, m)
+        chain = np.zeros((m, 4), np.int32)
+        chain[:, 0], chain[:, 1], chain[:, 2], chain[:, 3] = x0, y0, log2, sel
+        ctu = ((y0 // 64) * cx + x0 // 64).astype(np.int32)
+        first = np.searchsorted(level[sel], np.arange(nlevels + 1)).astype(np.int64)
+        sizes[log2] = dict(sel=sel, m=m, nn=nn, jobs=jobs, ictx=ictx, ctu=ctu, chain=chain, first=first)
+    return dict(parts=parts, owner=owner, level=level, nlevels=nlevels, cx=cx, lam=lam, rsl=float(1.0 / np.sqrt(lam)), quant=rqt_quant(qp, bit_depth), rdoq_states=rdoq_states,
+                sizes=sizes)
+
+
 class IntraChainPicture:
     """An INTRA picture with the real dependencies between its partitions (round 4): every partition predicts from the reconstruction
     of the partitions before it and takes its most probable modes from its neighbours' champions (turing/Reconstruct.cpp:609-615, CandModeList.h:33-95), so
@@ -268,47 +309,20 @@ class IntraChainPicture:
         self.n = self.host_src.size
         self.d_src = hv.up(self.host_src)
         self.d_rec = hv.zeros(self.n, self.dt)
-        self.parts, self.owner, self.level = workload.intra_picture_partitions(width, height, seed + 3)
+        t = intra_chain_tables(width, height, bit_depth, qp, seed, self.stride, self.PAD)
+        self.parts, self.owner, self.level, self.nlevels = t["parts"], t["owner"], t["level"], t["nlevels"]
         self.cells_per_row = self.owner.shape[1]
         self.d_owner = hv.up(np.ascontiguousarray(self.owner.ravel()))
         self.d_modes = hv.zeros(self.owner.size, np.uint8)
-        self.cx = (width + 63) // 64
-        self.lam = workload.picture_lambda(qp)
-        self.rsl = float(1.0 / np.sqrt(self.lam))
-        self.quant = rqt_quant(qp, bit_depth)
-        rng = np.random.default_rng(seed + 7919)
-        base = rng.integers(4, 100, 128)
-        self.rdoq_states = np.clip(base[None, :] + rng.integers(-6, 7, (self.cx * ((height + 63) // 64), 128)), 0, 125).astype(np.uint8)
+        self.cx, self.lam, self.rsl, self.quant, self.rdoq_states = t["cx"], t["lam"], t["rsl"], t["quant"], t["rdoq_states"]
         self.d_states = hv.up(self.rdoq_states.reshape(-1))
         self.layout = hv.intra_chain_layout(width, height, self.stride, self.PAD, self.cells_per_row, bit_depth)
-        # per size: the partitions of that size ordered by level, their tables, and for every level the slice [first, first + count)
-        self.sizes, self.nlevels = {}, int(self.level.max()) + 1
-        for log2 in (5, 4, 3, 2):
-            sel = np.flatnonzero(self.parts["log2"] == log2)
-            if not len(sel):
-                continue
-            sel = sel[np.argsort(self.level[sel], kind="stable")]
-            m, nn = len(sel), 1 << log2
-            L = 4 * nn + 1
-            x0, y0 = self.parts["x0"][sel].astype(np.int64), self.parts["y0"][sel].astype(np.int64)
-            mask = workload.intra_filter_mask(nn)
-            jobs = np.zeros((m, 8), np.int64)
-            jobs[:, 0] = (y0 + self.PAD) * self.stride + x0 + self.PAD
-            jobs[:, 1] = np.arange(m) * 2 * L + 2 * nn + 1
-            jobs[:, 2] = jobs[:, 1] + L
-            jobs[:, 3], jobs[:, 4], jobs[:, 5] = mask & 0xffffffff, mask >> 32, 1
-            jobs = jobs.astype(np.uint32).view(np.int32).reshape(m, 8)
-            ictx = np.zeros(m, INTRA_CTX_DT)
-            ictx["max_refine"] = 3 if log2 > 3 else 8            # Speed::nCandidatesIntraRefinement at medium
-            ictx["rate_a_minus_c"] = -rng.integers(300000, 420000, m)
-            ictx["rate_b_minus_c"] = -rng.integers(100000, 200000, m)
-            chain = np.zeros((m, 4), np.int32)
-            chain[:, 0], chain[:, 1], chain[:, 2], chain[:, 3] = x0, y0, log2, sel
-            ctu = ((y0 // 64) * self.cx + x0 // 64).astype(np.int32)
-            first = np.searchsorted(self.level[sel], np.arange(self.nlevels + 1)).astype(np.int64)
-            self.sizes[log2] = dict(sel=sel, m=m, nn=nn, jobs=jobs, ictx=ictx, ctu=ctu, first=first, d_jobs=hv.up(jobs), d_nb=hv.zeros(m * 2 * L, self.dt),
-                                    d_ictx=hv.up(np.ascontiguousarray(ictx).view(np.int32)), d_ctu=hv.up(ctu), d_parts=hv.up(chain), d_blocks=hv.zeros(m * nn * nn, self.dt),
-                                    d_mode=hv.zeros(m, np.int32), best=np.zeros(m, INTRA_RD_RESULT_DT))
+        self.sizes = {}
+        for log2, g in t["sizes"].items():
+            m, nn = g["m"], g["nn"]
+            self.sizes[log2] = dict(g, d_jobs=hv.up(g["jobs"]), d_nb=hv.zeros(m * 2 * (4 * nn + 1), self.dt), d_ictx=hv.up(np.ascontiguousarray(g["ictx"]).view(np.int32)),
+                                    d_ctu=hv.up(g["ctu"]), d_parts=hv.up(g["chain"]), d_blocks=hv.zeros(m * nn * nn, self.dt), d_mode=hv.zeros(m, np.int32),
+                                    best=np.zeros(m, INTRA_RD_RESULT_DT))
         hv.sync()
 
     def step(self, wait_per_level=False):
