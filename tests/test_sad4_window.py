@@ -114,3 +114,33 @@ def test_round_one_kernel_is_still_there_and_agrees():
     """HAVOC_SAD4_DIRECT=1: same jobs, same results"""
     n, nbad, tail = _in_a_process_with({"HAVOC_SAD4_DIRECT": "1"}, 8, 0, 0, 1)
     assert n > 200 and nbad == 0, tail
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bit_depth", [8, 10])
+def test_generic_widths_with_nearby_candidates(bit_depth):
+    """widths the strips cannot cover with 16 chunks of the size their alignment picks (16-bit 34, 38, 46, 62: row bytes % 8 == 4
+    beyond 64 bytes; 8-bit 68 ... 128) -- with NEARBY candidates, so that the window condition holds but for the width: they must take the direct / generic
+    path, never return the zero sums a zero-rows-per-iteration strip would"""
+    from reflibs import Oracle
+    from turingcodec_amd import Havoc
+    hv, orc = Havoc(0), Oracle()
+    rng = np.random.default_rng(40 + bit_depth)
+    dt = np.uint8 if bit_depth == 8 else np.uint16
+    pad, W, H = 96, 256, 96
+    stride = W + 2 * pad
+    src = rng.integers(0, 1 << bit_depth, (H + 2 * pad) * stride + 64).astype(dt)
+    ref = rng.integers(0, 1 << bit_depth, (H + 2 * pad) * stride + 64).astype(dt)
+    widths = [34, 38, 42, 46, 50, 54, 58, 62, 36, 44, 52, 60, 33, 35, 6, 10, 14, 18, 22, 26, 30, 68, 72, 76, 100, 128]
+    rows = []
+    for w in widths:
+        for h in (1, 3, 8, 17, 32):
+            for pat in (PATTERNS["diamond1"], PATTERNS["ring8a"], PATTERNS["bi_grid"], PATTERNS["same"]):
+                x, y = int(rng.integers(0, W - w + 1)), int(rng.integers(0, H - h + 1))
+                so = (y + pad) * stride + x + pad
+                rows.append([so] + [(y + dy + pad) * stride + x + dx + pad for dx, dy in pat] + [w, h, 0])
+    jobs = np.array(rows, np.int32)
+    got = hv.sad4(src, stride, ref, stride, jobs)
+    bad = [(list(j), list(got[i])) for i, j in enumerate(jobs)
+           if list(got[i]) != orc.sad4(src, int(j[0]), stride, ref, [int(v) for v in j[1:5]], stride, int(j[5]), int(j[6]))]
+    assert not bad, bad[:5]

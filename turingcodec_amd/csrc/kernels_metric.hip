@@ -307,7 +307,9 @@ __global__ __launch_bounds__(256, MINW) void k_sad4w(const char *__restrict__ sr
     const int chunks = (lead + rowBytes + (maxdx - mindx) * S + 15) >> 4;      // 16-byte pieces of a window row
     const int pitchD = 4 * chunks + 1;                                          // dwords per window row in LDS: odd (see sad4_window_strips)
     const int fit = chunks > 0 && chunks <= kSadLanes ? smallDiv(WB * S / 4, pitchD) - spready : 0;      // block rows per strip
-    const bool chunked = (rowBytes & 3) == 0 && rowBytes <= 16 * kSadLanes;
+    // the chunk size the strips pick (16 / 8 / 4 bytes by the row's alignment) must cover a block row with the 16 lanes of a job -- the direct path's own guard;
+    // other widths (16-bit 34, 38, ... 62: rowBytes % 8 == 4 beyond 64 bytes) take the direct / generic path
+    const bool chunked = (rowBytes & 15) == 0 ? rowBytes <= 16 * kSadLanes : (rowBytes & 7) == 0 ? rowBytes <= 8 * kSadLanes : (rowBytes & 3) == 0 && rowBytes <= 4 * kSadLanes;
     // (the strips address both pictures with 32-bit byte offsets from their base pointers: a block that reaches beyond 4 GB takes the direct path)
     const bool rows24 = (unsigned)spready < 1024u && (unsigned)h <= 64u && ssb < (1 << 23);
     const bool near = rows24 && minoff + (long)mulu24(h + spready, (uint32_t)rsb) + 16 * chunks < (1ll << 32) && ((long)so * S + (long)mulu24(h, (uint32_t)ssb) + rowBytes) < (1ll << 32);

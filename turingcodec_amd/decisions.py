@@ -768,6 +768,19 @@ class DecisionPicture:
     def rqt_results(self, v):
         self._rqt = v
 
+    @property
+    def cells(self):
+        """the picture's block structure of the last step (CELL_DT [H / 4, W / 4]): on the device route k_block_cells leaves it in HBM and it is
+        downloaded when asked for; the host route (search_on_device=False) made it on the host"""
+        if getattr(self, "_cells", None) is None:
+            from .havoc import CELL_DT
+            self._cells = self.hv.down(self.d_cells, np.uint8).view(CELL_DT).reshape(self.H // 4, self.W // 4).copy()
+        return self._cells
+
+    @cells.setter
+    def cells(self, v):
+        self._cells = v
+
     def block_cells(self, field, decisions):
         """the picture's block structure after the decisions, as the 4x4 cells havoc_mi355x_derive_bs reads: every unit one inter 2Nx2N
         prediction unit from list 0 at the vector decided at its origin, its transform tree as decided (coded flags per block)"""
@@ -867,7 +880,7 @@ class DecisionPicture:
         if self.search_on_device:
             # everything after the searches is a FIXED sequence of launches over device-resident tables (the decided field never leaves the device, the decisions
             # between the launches are kernels): recorded once into a HIP graph, one launch per picture, one wait at the end
-            self._rqt = None
+            self._rqt = self._cells = None
             self._replayed("after the searches", lambda: (self.merge_candidates(field), self.predict(field), self.tree_and_filter_on_device(), self.chroma_chain(field)))
             self.rqt_stats = RqtStats()
             self.rqt_stats.launches, self.rqt_stats.candidates = self.rqt_plan["launches"], 5 * len(self.units)
