@@ -32,6 +32,9 @@ if "--decisions" in sys.argv[:-1] and sys.argv[sys.argv.index("--decisions") + 1
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6300 GB/s achievable
+# vector-instruction issue peak: 256 CUs x 4 SIMD-32 per CU, a wave64 VALU instruction issues over 2 cycles (MI355X_MICROARCH.md "Each CU has 4 SIMD-32 units ...
+# issues each VALU instruction over 2 cycles"), 2.4 GHz: wavefront-level instructions per second, in G
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 2
 
 
 def parse_args():
@@ -75,11 +78,19 @@ def parse_args():
                     help="the motion searches of the decision-driven path: `device` = the decision loops inside the kernel (csrc/kernels_search.hip, one launch "
                          "per picture); `batch` = SAD-surface / tile-SATD launches + the loops replayed on host threads (search/picture_search.cpp)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--detail-out", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"),
+                    help="the FULL result (every `what` / `note` string, per-distance decision-path detail, per-kernel tables) goes to this file; the ONE JSON "
+                         "line on stdout stays below 8 KB (the driver keeps 8 KB of it: VERDICT r4 next #1c)")
+    ap.add_argument("--parity-dump", default=os.path.join(ROOT, "gpurun_out", "bench_parity_mismatches.json"),
+                    help="where a failed full-size parity check writes which values differed (group, job, sample, both values, lane plan)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-out", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--kernel-reps", type=int, default=5)
+    ap.add_argument("--sad4", choices=["runs", "calls"], default="runs",
+                    help="the 4-way SAD jobs: by runs (default; havoc_mi355x_sad4_runs: the ~112 consecutive calls of a search share one staged window, round 5) "
+                         "or one window per call (havoc_mi355x_sad4, round 4's k_sad4w)")
     ap.add_argument("--ime", choices=["sad4", "surface"], default="sad4",
                     help="integer ME as per-pattern SAD4 jobs (the reference's call mix) or as one SAD surface per search")
     ap.add_argument("--ime-range", type=int, default=16, help="surface half-width R: (2R+1)^2 candidates per search")
@@ -120,8 +131,9 @@ def parse_args():
 class DeviceFrame:
     """A FrameWorkload uploaded to HBM + the list of launches that make one step."""
 
-    def __init__(self, hv, wl, use_planes=True, fused_tu=True, ime_range=None, skip=(), rdoq=True, pred_launches="merged", scan_in_forward=True):
+    def __init__(self, hv, wl, use_planes=True, fused_tu=True, ime_range=None, skip=(), rdoq=True, pred_launches="merged", scan_in_forward=True, sad4_runs=True):
         import torch
+        self.sad4_runs = sad4_runs
         from turingcodec_amd import havoc as _havoc
         self.rdoq = bool(rdoq) and wl.mix == "ra"
         self.skip = set(skip)   # diagnostic only: launch groups left out of the step (marginal-cost measurements)
@@ -141,6 +153,7 @@ class DeviceFrame:
         self.cbi = z(len(wl.bi4) * 1024 + 1024, dt)     # chroma bi predictions: own slots (32 x 32, stride 32)
         self.sbi = z(len(wl.subtract_bi) * 4096, dt)
         self.j_sad4, self.j_sad = up(wl.sad4), up(wl.sad)
+        self.j_runs = up(hv.sad4_make_runs(wl.sad4)) if sad4_runs and len(wl.sad4) else None      # the calls of a search follow each other in the table: one run each
         self.o_sad4, self.o_sad = z(4 * len(wl.sad4), np.int32), z(len(wl.sad), np.int32)
         if ime_range is not None:   # integer ME from SAD surfaces: one (2R+1)^2 surface per search instead of SAD4 jobs
             side = 2 * ime_range + 1
@@ -238,7 +251,10 @@ class DeviceFrame:
         if not inter:
             pass
         elif self.ime_range is None:
-            chain(("sad4", lambda: hv.sad4_d(self.luma, st, self.luma, st, self.j_sad4, self.o_sad4)))
+            if self.j_runs is not None:
+                chain(("sad4", lambda: hv.sad4_runs_d(self.luma, st, self.luma, st, self.j_sad4, self.j_runs, self.o_sad4)))
+            else:
+                chain(("sad4", lambda: hv.sad4_d(self.luma, st, self.luma, st, self.j_sad4, self.o_sad4)))
         else:
             chain(("sad_surface", lambda: hv.sad_surface_d(self.luma, st, self.luma, st, self.ime_range, 64, 64, self.j_surf, self.o_surf)))
         if inter:
@@ -851,8 +867,9 @@ def cpu_baseline(args, dev=None):
                                  f"{r['reps'] * r['seconds_per_sample'] * r['cores']:.0f} core-seconds), extrapolated x{stride}"}
                 if dev is not None and os.path.exists(tmp):
                     try:
-                        res["parity_vs_reference"] = parity_vs_reference(dev, tmp, stride)
-                    except Exception as e:   # the baseline number stands on its own
+                        res["parity_vs_reference"] = parity_vs_reference(dev, tmp, stride, dump_path=getattr(args, "parity_dump", None),
+                                                                         lane_plan=getattr(dev, "assign", None))
+                    except Exception as e:   # a comparison that could not be made is not a green one: main() reports parity "red"
                         res["parity_vs_reference"] = {"error": repr(e)}
                 return res
         except Exception:
@@ -889,11 +906,12 @@ def hbm_traffic_from_profiles(group, S):
     return round(total / n) if n else None
 
 
-def hbm_traffic_in_run(args, group, S):
-    """HBM bytes PER STEP of the group's kernels measured NOW: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; one counter per pass and no
-    trace domain beside it, as MI355X_MICROARCH.md prescribes) over a child run of this bench that executes exactly `nsteps` steps of the same
-    workload and nothing else (--traffic-child); FETCH_SIZE x2 (gfx950 note), counters in KiB; the sum over every launch of the group's kernels
-    divided by the steps -- the same unit as roofline.algorithmic_bytes_per_step.  None when rocprofv3 is not on PATH, the passes fail, or --traffic 0"""
+def counters_in_run(args, group, S, counters=(("FETCH_SIZE", 2.0 * 1024.0), ("WRITE_SIZE", 1024.0), ("SQ_INSTS_VALU", 1.0))):
+    """Per-STEP sums of hardware counters over the group's kernels, measured NOW: one rocprofv3 --pmc pass per counter (one counter per pass and no trace
+    domain beside it, as MI355X_MICROARCH.md prescribes) over a child run of this bench that executes exactly `nsteps` steps of the same workload and nothing
+    else (--traffic-child).  FETCH_SIZE / WRITE_SIZE are in KiB, FETCH_SIZE x2 (gfx950 note): their sum is the HBM traffic in the unit of
+    roofline.algorithmic_bytes_per_step; SQ_INSTS_VALU = wavefront-level vector instructions.  Returns {counter: value per step} (a counter whose pass failed is
+    missing), {} when rocprofv3 is not on PATH or --traffic 0."""
     import csv
     import glob
     import shutil
@@ -901,14 +919,14 @@ def hbm_traffic_in_run(args, group, S):
     exe = shutil.which("rocprofv3")
     prefix = _kernel_prefix(group, S)
     if not exe or prefix is None or not args.traffic:
-        return None
+        return {}
     nsteps = 2
     base = [sys.executable, os.path.abspath(__file__), "--traffic-child", str(nsteps), "--no-graph", "--inflight", "1", "--tune", "0", "--no-cpu-baseline", "--extra-4k", "0",
             "--decisions", "0", "--traffic", "0", "--res", args.res, "--bit-depth", str(args.bit_depth), "--qp", str(args.qp),
-            "--seed", str(args.seed), "--mix", args.mix, "--rdoq", str(args.rdoq)]
-    total = 0.0
+            "--seed", str(args.seed), "--mix", args.mix, "--rdoq", str(args.rdoq), "--sad4", args.sad4]
+    out = {}
     env = dict(os.environ, TMPDIR="/tmp")
-    for counter, mult in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+    for counter, mult in counters:
         d = tempfile.mkdtemp(prefix="havoc_pmc_", dir="/tmp")
         try:
             subprocess.run([exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + base, capture_output=True, text=True, timeout=400, cwd="/tmp", env=env)
@@ -917,14 +935,13 @@ def hbm_traffic_in_run(args, group, S):
                 for row in csv.DictReader(open(f)):
                     if _matches(prefix, row["Kernel_Name"]) and row["Counter_Name"] == counter:
                         vals.append(float(row["Counter_Value"]))
-            if not vals:
-                return None
-            total += sum(vals) * 1024.0 * mult
+            if vals:
+                out[counter] = sum(vals) * mult / nsteps
         except (subprocess.TimeoutExpired, OSError, KeyError, ValueError):
-            return None
+            pass
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    return round(total / nsteps)
+    return out
 
 
 def valu_busy_from_profiles(group, S):
@@ -953,10 +970,119 @@ def _matches(prefix, name):
 
 
 def _kernel_prefix(group, S):
-    return {"sad4": (f"k_sad4w<{S}", f"k_sad<{S}, 4"), "sad": f"k_sad<{S}, 1", "interp_planes": "k_interp_planes", "intra_satd35": "k_intra_satd35<",
+    return {"sad4": (f"k_sad4r<{S}", f"k_sad4w<{S}", f"k_sad<{S}, 4"), "sad": f"k_sad<{S}, 1", "interp_planes": "k_interp_planes", "intra_satd35": "k_intra_satd35<",
               "intra": "k_intra<", "residual": "k_residual<", "transform": "k_transform<", "quantize_inverse": "k_quantize_inverse",
               "inverse_transform_add": "k_inverse_transform<", "ssd": "k_ssd<", "subtract_bi": "k_subtract_bi<",
               "subpel_satd": "k_subpel_satd<", "rdoq": "k_rdoq_", "deblock": "k_deblock<"}.get(group)
+
+
+def parity_problems(out):
+    """every comparison with the reference this run made that did NOT come out equal (or could not be made): [] = green"""
+    bad = []
+    cb = out.get("cpu_baseline")
+    if isinstance(cb, dict):
+        pv = cb.get("parity_vs_reference")
+        if isinstance(pv, dict):
+            if "error" in pv:
+                bad.append("primitive parity could not be checked: " + str(pv["error"])[:200])
+            elif pv.get("mismatches"):
+                bad.append(f"primitives: {pv['mismatches']} of {pv['compared']} values differ from the reference library ({pv.get('mismatches_by_group')})")
+    for label, r in (out.get("extra") or {}).items():
+        pv = r.get("parity_vs_reference") if isinstance(r, dict) else None
+        if isinstance(pv, dict):
+            if "error" in pv:
+                bad.append(f"{label}: decision parity could not be checked: " + str(pv["error"])[:200])
+            elif pv.get("mismatching") or pv.get("bi_directional_mismatching") or pv.get("motion_field_equal") is False:
+                bad.append(f"{label}: {pv.get('mismatching')} searches / {pv.get('bi_directional_mismatching')} refinements differ from the walk through the reference's tables")
+    return bad
+
+
+def short_label(label):
+    """`extra` keys of the ONE line: the long, self-explaining labels stay in the detail file"""
+    import re
+    m = re.match(r"decision-driven path (\d+)x(\d+) (\d+)-bit QP(\d+)", label)
+    if m:
+        d = re.search(r"temporal distance (\d+)", label)
+        return f"decisions_{m.group(2)}p_{m.group(3)}bit_qp{m.group(4)}_d{d.group(1) if d else 1}"
+    m = re.match(r"(\d+)x(\d+) (\d+)-bit.*QP(\d+)", label)
+    if m:
+        return f"primitives_{m.group(2)}p_{m.group(3)}bit_qp{m.group(4)}"
+    if label.startswith("same picture without RDOQ"):
+        return "primitives_without_rdoq"
+    if label.startswith("same step, one picture in flight"):
+        return "primitives_one_in_flight_latency"
+    return re.sub(r"[^a-z0-9]+", "_", label.lower())[:48]
+
+
+def compact_line(out, args):
+    """the ONE JSON line: the contract's keys, `roofline`, `cpu_baseline`, `parity`, and figures only under `extra` -- every explanatory string and every
+    per-kernel / per-distance table is in --detail-out (the driver keeps 8 KB of the line; round 4's 41 KB line went unparsed)"""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "parity")
+    line = {k: out[k] for k in keep if k in out}
+    line["metric"] = out["metric"][:120]
+    cfg = out.get("config", {})
+    line["config"] = {"workload": cfg.get("workload", "")[:160], **{k: cfg[k] for k in ("calls_per_frame", "launches_per_frame", "pictures_in_flight", "pictures_per_timed_block") if k in cfg},
+                      "parallelism": cfg.get("parallelism_short") or cfg.get("parallelism", "")[:100]}
+    t = out.get("timing", {})
+    line["timing"] = {k: t[k] for k in ("timed_blocks", "block_seconds_median", "block_seconds_min", "block_seconds_max") if k in t}
+    rf = dict(out.get("roofline", {}))
+    for k in ("note", "traffic_source"):
+        rf.pop(k, None)
+    line["roofline"] = rf
+    ws = out.get("whole_step", {})
+    if ws:
+        line["whole_step"] = {"algorithmic_bytes": ws.get("algorithmic_bytes"), "achieved_gbs": ws.get("achieved_gbs"),
+                              "kernel_ms": {k: round(v, 3) for k, v in list(ws.get("kernel_ms", {}).items())[:8]}}
+    line["checksum"] = out.get("checksum")
+    cb = out.get("cpu_baseline")
+    if isinstance(cb, dict):
+        c = {k: cb[k] for k in ("value", "unit", "cores", "kind") if k in cb}
+        c["sample"] = str(cb.get("sample", ""))[:200]
+        pv = cb.get("parity_vs_reference")
+        if isinstance(pv, dict):
+            c["parity_vs_reference"] = {k: pv[k] for k in ("compared", "mismatches", "mismatches_by_group", "mismatches_after_eager_rerun", "first_mismatch", "dump", "error") if k in pv}
+            if len(json.dumps(c["parity_vs_reference"])) > 1500:
+                c["parity_vs_reference"].pop("first_mismatch", None)
+        pt = cb.get("primitive_tables")
+        if isinstance(pt, dict):
+            c["primitive_tables"] = {"value": pt.get("value"), "unit": pt.get("unit"), "cores": pt.get("cores")}
+        dw = cb.get("decision_walk")
+        if isinstance(dw, dict):
+            c["decision_walk"] = {k: dw[k] for k in ("pictures_per_second", "cores", "searches") if k in dw}
+            if isinstance(dw.get("parity_vs_reference"), dict):
+                c["decision_walk"]["parity_vs_reference"] = dw["parity_vs_reference"]
+        he = cb.get("hooked_encoder")
+        if isinstance(he, dict):
+            c["hooked_encoder"] = {k: he[k] for k in ("value", "unit", "served_fraction", "us_per_table_call", "stream_identical", "error") if k in he}
+        line["cpu_baseline"] = c
+    elif "cpu_baseline" in out:
+        line["cpu_baseline"] = cb
+    ex = {}
+    for label, r in (out.get("extra") or {}).items():
+        if not isinstance(r, dict):
+            continue
+        e = {k: r[k] for k in ("value", "unit", "ms_per_step", "ms_per_picture", "pictures_in_flight", "one_picture_alone_ms", "ratio_to_value", "error") if k in r}
+        for k, v in r.items():
+            if k.startswith("pictures_in_flight_") and isinstance(v, dict):
+                e[k] = v.get("value")
+        if isinstance(r.get("sop_weighted"), dict):
+            e["sop_weighted"] = r["sop_weighted"].get("value")
+        pv = r.get("parity_vs_reference")
+        if isinstance(pv, dict):
+            e["mismatching"] = (pv.get("mismatching", 0) or 0) + (pv.get("bi_directional_mismatching", 0) or 0) if "error" not in pv else pv["error"][:80]
+            e["searches_compared"] = pv.get("searches_compared")
+        if "error" in e:
+            e["error"] = str(e["error"])[:160]
+        ex[short_label(label)] = e
+    if ex:
+        line["extra"] = ex
+    if out.get("poc_checksums"):
+        line["poc_checksums"] = out["poc_checksums"]
+    if out.get("parity_problems"):
+        line["parity_problems"] = [p[:300] for p in out["parity_problems"][:4]]
+    if args.detail_out:
+        line["detail"] = os.path.relpath(args.detail_out, ROOT)
+    return line
 
 
 def build_contexts(args, torch, Havoc, FrameWorkload, local, res, bit_depth, qp, mix, seed0, count, tune):
@@ -976,7 +1102,8 @@ def build_contexts(args, torch, Havoc, FrameWorkload, local, res, bit_depth, qp,
         wl_k = FrameWorkload(w, h, bit_depth, seed0 + 1000 * k, qp=qp, mix=mix, frames=frames)
         dev_k = DeviceFrame(hv_k, wl_k, use_planes=(args.subpel == "planes"), fused_tu=(args.tu == "fused"),
                             ime_range=args.ime_range if args.ime == "surface" else None, skip=[s for s in args.skip.split(",") if s],
-                            rdoq=args.rdoq, pred_launches=getattr(args, "pred", "merged"), scan_in_forward=not getattr(args, "separate_scan", False))
+                            rdoq=args.rdoq, pred_launches=getattr(args, "pred", "merged"), scan_in_forward=not getattr(args, "separate_scan", False),
+                            sad4_runs=getattr(args, "sad4", "runs") == "runs")
         dev_k.step()          # first eager pass (loads the code objects) -- also what the graph must reproduce
         hv_k.sync()
         if args.no_graph:
@@ -1669,14 +1796,28 @@ def main():
         kbytes = wl.algorithmic_bytes()
         kbytes["sad_surface"] = kbytes["sad_surface"](args.ime_range)
         dom = max(ktimes, key=ktimes.get)
-        ach = kbytes[dom] / (ktimes[dom] * 1e-3) / 1e9
+        # roofline of the dominant launch group.  HBM: `achieved` counts UNIQUE algorithmic bytes -- SURVEY 8(d)'s operands once +
+        # results once per call, except where the calls of one search overlap (sad4: the box of a search's candidates + its source block once per run + 16 B per
+        # call; the per-call figure, which counts every reference sample ~112 times, is kept beside it as `operand_bytes_per_step`), so frac <= 1 by construction
+        # and comparable with `traffic`.  VALU: wavefront-level vector instructions (SQ_INSTS_VALU of a --pmc pass of this run) / duration against the issue peak.
+        unique = dict(kbytes)
+        if dom == "sad4":
+            unique["sad4"] = wl.sad4_unique_bytes()
+        ach = unique[dom] / (ktimes[dom] * 1e-3) / 1e9
         total_bytes = sum(kbytes[k] for k in ktimes)
-        traffic, traffic_source = None, None
+        traffic, traffic_source, valu = None, None, None
         if world == 1 and not (args.pcie or args.skip or args.no_graph) and args.min_seconds > 0:
-            traffic = hbm_traffic_in_run(args, dom, wl.S)
-            traffic_source = ("measured in this run, bytes PER STEP (the unit of algorithmic_bytes_per_step): two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, one "
-                              "counter per pass, no trace domain) over a child run of exactly two steps of the same workload; FETCH_SIZE x2 per the gfx950 note; "
-                              "summed over every launch of the group's kernels, divided by the steps")
+            c = counters_in_run(args, dom, wl.S)
+            if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                traffic = round(c["FETCH_SIZE"] + c["WRITE_SIZE"])
+                traffic_source = ("measured in this run, bytes PER STEP (the unit of algorithmic_bytes_per_step): rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, one "
+                                  "counter per pass, no trace domain) over a child run of exactly two steps of the same workload; FETCH_SIZE x2 per the gfx950 note; "
+                                  "summed over every launch of the group's kernels, divided by the steps")
+            if "SQ_INSTS_VALU" in c:
+                insts = c["SQ_INSTS_VALU"]
+                rate = insts / (ktimes[dom] * 1e-3) / 1e9
+                valu = {"insts_per_step": round(insts), "achieved": round(rate, 2), "peak": VALU_PEAK_GINST, "unit": "G wavefront-instructions/s",
+                        "frac": round(rate / VALU_PEAK_GINST, 5)}
         if traffic is None:
             traffic = hbm_traffic_from_profiles(dom, wl.S)
             if traffic is not None:
@@ -1711,15 +1852,12 @@ def main():
                          "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "traffic_source": traffic_source,
                          "launch_ms": round(ktimes[dom] / kcount[dom], 5), "launches_per_step": kcount[dom],
-                         "algorithmic_bytes_per_step": kbytes[dom],
-                         "valu_busy_pct": valu_busy_from_profiles(dom, wl.S),
-                         "note": ("k_rdoq_walk is a chain of dependent integer decisions per transform block (4 bytes of traffic per coefficient): it is "
-                                  "bound by instruction issue and latency, not by HBM -- profiles/r02_sq_counters.csv has its instruction counts; the "
-                                  "HBM-bound kernels of the step are in whole_step.kernel_gbs") if dom == "rdoq" else
-                                 ("achieved counts SURVEY 8(d)'s operand bytes of every call (sad4: 5 w h S + 16): the calls of a search overlap, so each reference "
-                                  "sample is an operand of many calls and most operand bytes are served by L2 and, since round 4, by the LDS window the four candidates of a "
-                                  "call share (k_sad4w) -- frac above 1 says exactly that; what reaches HBM is `traffic`, and what bounds the kernel is VALU issue and LDS "
-                                  "cycles (profiles/r04/sad4_counters.txt)") if dom == "sad4" else None},
+                         "algorithmic_bytes_per_step": unique[dom], "operand_bytes_per_step": kbytes[dom],
+                         "valu": valu, "valu_busy_pct": valu_busy_from_profiles(dom, wl.S),
+                         "note": ("achieved = unique algorithmic bytes / the group's isolated HIP-event time.  The group is not HBM-bound: its operands are cache- and LDS-resident "
+                                  "and what bounds it is instruction issue along short dependent chains -- `valu` is the instruction roofline (SQ_INSTS_VALU / time against "
+                                  "256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction); `traffic` / `algorithmic_bytes_per_step` says how close the kernel is to "
+                                  "touching every byte once")},
             "whole_step": {"algorithmic_bytes": total_bytes, "achieved_gbs": round(total_bytes / (ms_step * 1e-3) / 1e9, 2),
                            "kernel_ms": {k: round(v, 4) for k, v in sorted(ktimes.items(), key=lambda kv: -kv[1])},
                            "kernel_gbs": {k: round(kbytes[k] / (v * 1e-3) / 1e9, 1) for k, v in ktimes.items()}},
@@ -1734,6 +1872,8 @@ def main():
                 + (f"; strong scaling over a fixed {args.pictures}-picture sequence, fill and drain included" if args.scaling == "strong" else
                    f"; weak scaling: steady state of an endless sequence, one picture per rank per slot (schedule lag {sched.lag}, {prime} untimed pipeline-fill slots before the warm-up)"))
             out["config"]["pictures_per_timed_block"] = pictures_per_block
+            out["config"]["parallelism_short"] = (f"frame-parallel x{world} over {'RCCL' if os.environ.get('HAVOC_BENCH_BACKEND', 'nccl') == 'nccl' else 'gloo'}, "
+                                                  f"{pipe.exch.broadcasts} reference pictures broadcast, {args.scaling} scaling, lag {sched.lag}")
         if args.poc_checksums and pipe is not None:
             out["poc_checksums"] = {str(k): v for k, v in sorted(all_poc.items())}
         if args.pcie:
@@ -1824,7 +1964,19 @@ def main():
                                                 "sample": enc["what"] + f" ({enc['seconds']} s)", "reference_encoder": enc, "primitive_tables": tables})
                 else:
                     out["cpu_baseline"]["reference_encoder"] = enc
-        line = json.dumps(out)
+        red = parity_problems(out)
+        out["parity"] = "red" if red else "green"
+        if red:
+            out["parity_problems"] = red
+        line = json.dumps(compact_line(out, args))
+        assert len(line) < 8000, len(line)
+        if args.detail_out:
+            try:
+                os.makedirs(os.path.dirname(os.path.abspath(args.detail_out)), exist_ok=True)
+                with open(args.detail_out, "w") as f:
+                    json.dump(out, f, indent=1)
+            except OSError as e:
+                sys.stderr.write(f"bench.py: could not write {args.detail_out}: {e}\n")
     if grouped:
         dist.barrier()
         dist.destroy_process_group()
@@ -1832,6 +1984,9 @@ def main():
         sys.stdout.flush()
         sys.stderr.flush()
         print(line, flush=True)     # the ONE JSON line, after anything the collective library may still say
+        if red:                     # a result that differs from the reference's is not a benchmark result (VERDICT r4 next #1a)
+            sys.stderr.write("bench.py: PARITY RED -- " + "; ".join(red)[:2000] + "\n")
+            sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -200,7 +200,7 @@ def test_full_size_results_equal_the_reference_library(hv):
     reference's own Rdoq.cpp), reconstructions and their SSDs"""
     p = _parity_vs_reference(hv, (1920, 1080), 8, 32)
     for name in ("pred_bi8", "pred_bi4", "subtract_bi", "rec_3_0", "ssd_3_0", "level_2_1", "cbf_5_0", "cbf_2_1"):
-        assert name in p["what"], name
+        assert name in p["groups"], name
 
 
 @pytest.mark.parametrize("bit_depth", [8, 10])
@@ -219,7 +219,7 @@ def test_all_intra_fast_mix_equals_the_reference_library(hv):
     """BASELINE.json configs[0]: 640x360 all-intra QP32 speed=fast -- intra + TU chain with havoc_quantize IN the timed
     chain (no RDOQ at fast, turing/Reconstruct.cpp:310-311)"""
     p = _parity_vs_reference(hv, (640, 360), 8, 32, mix="ai", seed=7, min_values=1_000_000)
-    assert "level_3_0" in p["what"] and "sad4" not in p["what"]
+    assert "level_3_0" in p["groups"] and "sad4" not in p["groups"]
 
 
 def test_8k_frame_properties(hv):
@@ -302,7 +302,11 @@ def test_bench_line_contract():
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
+    assert len(lines[0]) < 8000, len(lines[0])      # the driver keeps 8 KB of the line: round 4's 41 KB line went unparsed (VERDICT r4 next #1c)
     r = json.loads(lines[0])
+    assert r["parity"] == "green" and os.path.exists(os.path.join(root, r["detail"]))
+    detail = json.load(open(os.path.join(root, r["detail"])))
+    assert detail["value"] == r["value"] and "note" in detail["roofline"] and "whole_step" in detail
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
               "config", "roofline", "cpu_baseline"):
         assert k in r, k
@@ -312,7 +316,9 @@ def test_bench_line_contract():
     assert abs(r["value"] - 1e3 / r["ms_per_step"]) / r["value"] < 0.01
     rf = r["roofline"]
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(rf) and rf["bound"] == "hbm" and rf["peak"] == 8000.0
-    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4 and rf["frac"] <= 1.0      # unique bytes: a fraction above 1 is not a roofline
+    if rf.get("valu"):
+        assert 0 < rf["valu"]["frac"] <= 1.0 and rf["valu"]["peak"] == 1228.8
     cb = r["cpu_baseline"]
     if cb is not None:   # None only when oracle/_ref was never built
         assert set(("value", "unit", "cores", "kind", "sample")) <= set(cb) and cb["kind"] == "reference" and cb["cores"] >= 1
@@ -332,7 +338,7 @@ def test_bench_reference_exchange_over_rccl_single_rank():
     common = ["--kernel-reps", "1", "--tune", "0", "--scaling", "strong", "--pictures", "17", "--poc-checksums", "--no-cpu-baseline", "--res", "640x360", "--decisions", "0"]
     rccl = _bench_json([sys.executable, os.path.join(root, "bench.py"), "--exchange"] + common, env, root)
     assert rccl["n_gpus"] == 1 and len(rccl["poc_checksums"]) == 17
-    assert "RCCL" in rccl["config"]["parallelism"] and " 0 reference pictures broadcast" not in rccl["config"]["parallelism"]
+    assert "RCCL" in rccl["config"]["parallelism"] and ", 0 reference pictures broadcast" not in rccl["config"]["parallelism"]
     env_gloo = dict(env, HAVOC_BENCH_BACKEND="gloo")
     gloo = _bench_json([sys.executable, os.path.join(root, "bench.py"), "--exchange"] + common, env_gloo, root)
     assert rccl["poc_checksums"] == gloo["poc_checksums"]

@@ -1,0 +1,72 @@
+"""The replayed step under the conditions of the bench (VERDICT r4 next #1a: 17 subtract_bi values differed from the reference library in ONE driver run,
+never again): the captured step -- 8 fork/join lanes, a lane plan chosen by measurement, two pictures in flight, both prediction-launch forms -- replayed
+hundreds of times with the bi-prediction slots and the SubtractBi output ZEROED between replays, so that an ordering hazard between pred_bi8 and
+subtract_bi (the same values are otherwise rewritten every replay and a hazard could not be seen) or a stray write from a concurrent lane shows up as a
+wrong value.  What the replays must reproduce is pinned first: the eager step's pred_bi8 / subtract_bi regions against the reference's own library
+(oracle/_ref, x86 JIT) for a sample of jobs, and SubtractBi's definition (havoc/pred_inter.cpp:2063-2080) for ALL of them."""
+import os
+
+import numpy as np
+import pytest
+
+
+def _ctx(torch, Havoc, bench, FrameWorkload, seed, pred, tune):
+    s = torch.cuda.Stream(device=0)
+    hv = Havoc(0, stream=s.cuda_stream)
+    wl = FrameWorkload(1920, 1080, 8, seed)
+    dev = bench.DeviceFrame(hv, wl, pred_launches=pred)
+    dev.step()
+    hv.sync()
+    want = {k: getattr(dev, k).clone() for k in ("bi", "sbi", "cbi", "pred", "o_satd")}
+    want["o_sad4"] = dev.o_sad4.clone()
+    graph, _ = dev.plan_lanes(8, tune, seed=seed)
+    return s, hv, wl, dev, graph, want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pred", ["merged", "classes"])
+def test_replayed_step_reproduces_the_eager_step_with_bi_slots_zeroed_between_replays(pred, reference_jit):
+    import torch
+    import bench
+    from turingcodec_amd import Havoc
+    from turingcodec_amd.workload import FrameWorkload
+    ctxs = [_ctx(torch, Havoc, bench, FrameWorkload, 11 + 1000 * k, pred, 10) for k in range(2)]
+    # ---- what the replays must reproduce, against the reference
+    s, hv, wl, dev, _, want = ctxs[0]
+    bi, sbi = hv.down(want["bi"], np.uint8), hv.down(want["sbi"], np.uint8)
+    luma = wl.luma
+    rng = np.random.default_rng(3)
+    for i in rng.integers(0, len(wl.subtract_bi), 400):
+        d, p, so, w, h = (int(v) for v in wl.subtract_bi[i][:5])
+        ref_out = np.zeros(64 * 64 + 64, np.uint8)
+        reference_jit.subtract_bi(ref_out, 0, 64, bi, p, 64, luma, so, wl.stride, w, h, 8)
+        assert np.array_equal(ref_out[:64 * h].reshape(h, 64)[:, :w], sbi[d:d + 64 * h].reshape(h, 64)[:, :w]), i
+        b = wl.bi8[i]
+        ref_bi = np.zeros(64 * 64 + 64, np.uint8)
+        reference_jit.pred_bi(ref_bi, 0, 64, luma, int(b[1]), int(b[2]), wl.stride, int(b[3]), int(b[4]), int(b[5]), int(b[6]), int(b[7]), int(b[8]), 8, 8)
+        assert np.array_equal(ref_bi[:64 * h].reshape(h, 64)[:, :w], bi[p:p + 64 * h].reshape(h, 64)[:, :w]), i
+    src = luma.astype(np.int32)
+    for i, (d, p, so, w, h) in enumerate(wl.subtract_bi[:, :5]):      # every job: the definition
+        yy, xx = np.mgrid[0:h, 0:w]
+        exp = np.clip(2 * src[so + yy * wl.stride + xx] - bi[p + yy * 64 + xx].astype(np.int32), 0, 255)
+        assert np.array_equal(exp, sbi[d + yy * 64 + xx]), i
+    # ---- the replays: two pictures in flight, slots zeroed before every replay
+    bad = []
+    for rep in range(250):
+        for s, hv, wl, dev, graph, want in ctxs:
+            with torch.cuda.stream(hv.tstream):
+                dev.bi.zero_()
+                dev.sbi.zero_()
+                if rep % 3 == 0:
+                    dev.cbi.zero_()
+                    dev.o_sad4.zero_()
+            hv.graph_launch(graph)
+        for k, (s, hv, wl, dev, graph, want) in enumerate(ctxs):
+            with torch.cuda.stream(hv.tstream):
+                for name, exp in want.items():
+                    if not torch.equal(getattr(dev, name), exp):
+                        idx = torch.nonzero(getattr(dev, name) != exp).flatten()[:8].tolist()
+                        bad.append((rep, k, name, idx, [int(getattr(dev, name)[i]) for i in idx], [int(exp[i]) for i in idx], dev.assign))
+        if len(bad) > 4:
+            break
+    assert not bad, bad[:3]

@@ -21,6 +21,7 @@ hipError_t launch_subtract_bi(hipStream_t, int S, int bd, void *, long, const vo
 hipError_t launch_pred_classes(hipStream_t, int bi, int S, int taps, int bd, void *, long, const void *, long, const void *, const int count[4]);
 hipError_t launch_intra(hipStream_t, int S, int log2, int bd, void *, long, const void *, const void *, int);
 hipError_t launch_intra_satd35(hipStream_t, int S, int log2, int bd, const void *, long, const void *, const void *, int, int32_t *);
+hipError_t launch_sad4_runs(hipStream_t, int S, const void *, long, const void *, long, const void *, int, const void *, int, int32_t *);
 hipError_t launch_interp_planes(hipStream_t, int S, int bd, void *, long, const void *, long, int, int, int, int);
 hipError_t launch_subpel_satd(hipStream_t, int S, int taps, int bd, int maxw, int maxh, const void *, long, const void *, long, const void *, int,
                               int32_t *);
@@ -337,6 +338,31 @@ int havoc_mi355x_sad4(havoc_mi355x_ctx *ctx, int S, const void *d_src, intptr_t 
 {
     REQUIRE_CTX(); REQUIRE_S(); REQUIRE(njobs >= 0, "njobs < 0");
     return check(launch_sad(LS(ctx),S, 4, d_src, stride_src, d_ref, stride_ref, d_jobs, njobs, d_out), "sad4");
+}
+
+int havoc_mi355x_sad4_runs(havoc_mi355x_ctx *ctx, int S, const void *d_src, intptr_t stride_src, const void *d_ref, intptr_t stride_ref,
+                           const havoc_mi355x_sad4_job *d_jobs, int njobs, const havoc_mi355x_sad4_run *d_runs, int nruns, int32_t *d_out)
+{
+    REQUIRE_CTX(); REQUIRE_S(); REQUIRE(njobs >= 0 && nruns >= 0, "njobs / nruns < 0");
+    REQUIRE(stride_ref >= 64 && stride_ref < (1 << 22), "sad4_runs: reference stride must be 64 .. 2^22 - 1 samples");
+    return check(launch_sad4_runs(LS(ctx), S, d_src, stride_src, d_ref, stride_ref, d_jobs, njobs, d_runs, nruns, d_out), "sad4_runs");
+}
+
+int havoc_mi355x_sad4_make_runs(const havoc_mi355x_sad4_job *jobs, int njobs, int max_run, havoc_mi355x_sad4_run *runs)
+{
+    if (!jobs || !runs || njobs < 0) return -1;
+    if (max_run < 1 || max_run > 128) max_run = 128;
+    int n = 0;
+    for (int i = 0; i < njobs;)
+    {
+        int e = i + 1;
+        while (e < njobs && e - i < max_run && jobs[e].src_off == jobs[i].src_off && jobs[e].w == jobs[i].w && jobs[e].h == jobs[i].h) ++e;
+        runs[n].first_job = i;
+        runs[n].count = e - i;
+        ++n;
+        i = e;
+    }
+    return n;
 }
 
 int havoc_mi355x_sad_surface(havoc_mi355x_ctx *ctx, int S, int range, int max_w, int max_h, const void *d_src, intptr_t stride_src,

@@ -265,17 +265,12 @@ __device__ __forceinline__ void sad4_window_strips(const char *src, uint32_t s0,
     }
 }
 
-template <int S, int WB = kSadWinBytes, int MINW = 1>
-__global__ __launch_bounds__(256, MINW) void k_sad4w(const char *__restrict__ src, long stride_src, const char *__restrict__ ref, long stride_ref, float inv_stride_ref,
-                                               const int32_t *__restrict__ jobs, int njobs, int32_t *__restrict__ out)
+// one havoc_sad_multiref call by the 16 lanes of a group (all four groups of a wavefront go through it together: the strips' barriers are wavefront barriers);
+// `gbuf` = the group's WB * S bytes (+ 16 dwords) of LDS; the job's four totals are left in lane kSadLanes - 1 of the group
+template <int S, int WB>
+__device__ __forceinline__ void sad4_job(const char *__restrict__ src, long stride_src, const char *__restrict__ ref, long stride_ref, float inv_stride_ref,
+                                         const int32_t *__restrict__ j, bool live, uint32_t *gbuf, int lane, int (&total)[4])
 {
-    // a job's buffer: kSadWinBytes * S bytes + 16 dwords, so that consecutive jobs' buffers start 16 banks apart, + the dword a shifted read takes beyond the last row
-    constexpr int kBufD = WB * S / 4 + 16;
-    __shared__ uint32_t lds[(256 / kSadLanes) * kBufD + 4];
-    const int group = threadIdx.x / kSadLanes, lane = threadIdx.x & (kSadLanes - 1);
-    const int job = xcd_block(blockIdx.x, gridDim.x) * (256 / kSadLanes) + group;
-    const bool live = job < njobs;
-    const int32_t *j = jobs + (long)(live ? job : 0) * 8;   // havoc_mi355x_sad4_job
     const int so = j[0], w = j[5], h = live ? j[6] : 0;
     int ro[4];
 #pragma unroll
@@ -324,8 +319,8 @@ __global__ __launch_bounds__(256, MINW) void k_sad4w(const char *__restrict__ sr
             oy[k] = dy[k] - mindy;
         }
         const uint32_t a0 = (uint32_t)(minoff - lead), s0 = (uint32_t)so * S;
-        const auto buf_r = (const __attribute__((address_space(3))) uint32_t *)(&lds[group * kBufD]);
-        const auto buf_w = (__attribute__((address_space(3))) uint32_t *)(&lds[group * kBufD]);
+        const auto buf_r = (const __attribute__((address_space(3))) uint32_t *)(gbuf);
+        const auto buf_w = (__attribute__((address_space(3))) uint32_t *)(gbuf);
         const int hs = min(fit, h);
         if ((rowBytes & 15) == 0) sad4_window_strips<S, 16>(src, s0, (uint32_t)ssb, ref, a0, (uint32_t)rsb, buf_r, buf_w, pitchD, chunks, lead, ox, oy, spready, rowBytes, h, hs, lane, acc);
         else if ((rowBytes & 7) == 0) sad4_window_strips<S, 8>(src, s0, (uint32_t)ssb, ref, a0, (uint32_t)rsb, buf_r, buf_w, pitchD, chunks, lead, ox, oy, spready, rowBytes, h, hs, lane, acc);
@@ -357,7 +352,226 @@ __global__ __launch_bounds__(256, MINW) void k_sad4w(const char *__restrict__ sr
     {
         int t = sad_group_sum((int)acc[k]);
         if (S == 2) t >>= 2;
-        if (live && lane == kSadLanes - 1) out[job * 4 + k] = t;
+        total[k] = t;
+    }
+}
+
+template <int S, int WB = kSadWinBytes, int MINW = 1>
+__global__ __launch_bounds__(256, MINW) void k_sad4w(const char *__restrict__ src, long stride_src, const char *__restrict__ ref, long stride_ref, float inv_stride_ref,
+                                               const int32_t *__restrict__ jobs, int njobs, int32_t *__restrict__ out)
+{
+    // a job's buffer: kSadWinBytes * S bytes + 16 dwords, so that consecutive jobs' buffers start 16 banks apart, + the dword a shifted read takes beyond the last row
+    constexpr int kBufD = WB * S / 4 + 16;
+    __shared__ uint32_t lds[(256 / kSadLanes) * kBufD + 4];
+    const int group = threadIdx.x / kSadLanes, lane = threadIdx.x & (kSadLanes - 1);
+    const int job = xcd_block(blockIdx.x, gridDim.x) * (256 / kSadLanes) + group;
+    const bool live = job < njobs;
+    int total[4];
+    sad4_job<S, WB>(src, stride_src, ref, stride_ref, inv_stride_ref, jobs + (long)(live ? job : 0) * 8, live, &lds[group * kBufD], lane, total);
+    if (live && lane == kSadLanes - 1)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out[job * 4 + k] = total[k];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// 4-way SAD by RUNS (round 5).  The ~112 havoc_sad_multiref calls of one motion search (turing/Search.hpp:2224-2297 -> considerPattern :1447-1482) share
+// their source block and move around one centre: k_sad4w staged a window PER CALL and spent 470 wavefront instructions per four calls on set-up (displacement
+// split, bounding box, copy-in, reduction) against the 32 its absolute differences need for a 16x16 block (profiles/r04_sq_counters.csv: 149.5 M VALU
+// instructions per 1.27 M-call launch).  Here a WORKGROUP takes a run = the consecutive calls of one search (the caller's run table:
+// havoc_mi355x_sad4_run): one pass splits every candidate's offset into (dx, dy) and finds the run's bounding box, the box and the source block are staged in
+// LDS ONCE (16-byte aligned loads, rows at an odd dword pitch as in k_sad4w), then the lane groups (16 lanes each) take the calls in turn: four packed
+// displacements from LDS, four LDS base addresses, the rows' dword reads + v_alignbyte_b32 + v_sad_u8/u16, one DPP-row reduction per candidate.
+// Any split of a candidate's offset into dy * stride + dx addresses the same sample in the staged box, so the float reciprocal only has to be near.  A run whose
+// box does not fit (far raster rings), whose calls differ in source / size, or with an unchunkable width goes call by call through sad4_job above --
+// same results either way; runs are an accelerator, not a contract (jobs outside every run are simply not computed).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kRunMax = 128;        // calls of a run whose displacements are kept in LDS (longer runs: call by call)
+
+template <int S, int CB>
+__device__ __forceinline__ void sad4_run_calls(const __attribute__((address_space(3))) uint32_t *win, const __attribute__((address_space(3))) uint32_t *srcw,
+                                               const __attribute__((address_space(3))) uint32_t *cand, int pitchD, int lead, int mndx, int mndy, int rowBytes, int h,
+                                               int count, int group, int ngroups, int lane, int32_t *__restrict__ out)
+{
+    const int cpr = rowBytes / CB;                  // chunks per block row
+    const int rpi = smallDiv(kSadLanes, cpr);       // block rows per iteration of the lane group
+    const int y0 = smallDiv(lane, cpr);
+    const int xb = (lane - mul24(y0, cpr)) * CB;
+    const bool sums = y0 < rpi;
+    const int lstep = mul24(rpi, pitchD);
+    const int s0 = (mul24(y0, rowBytes) + xb) >> 2, sstep = mul24(rpi, rowBytes) >> 2;      // source block: dense rows, dword index
+    const int base = lead + xb - mndx * S;
+    for (int c = group; c < count; c += ngroups)
+    {
+        int lo[4], sh[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+        {
+            const int v = (int)cand[4 * c + k];
+            const int dx = (int)(short)(v & 0xffff), dy = v >> 16;
+            const int bo = base + dx * S;
+            lo[k] = mul24(y0 + dy - mndy, pitchD) + (bo >> 2);
+            sh[k] = bo & 3;
+        }
+        uint32_t acc[4] = {0, 0, 0, 0};
+        if (sums)
+        {
+            int l = 0, sp = s0;
+#pragma unroll 2
+            for (int y = y0; y < h; y += rpi, sp += sstep, l += lstep)
+            {
+                if (CB == 16)
+                {
+                    const uint32_t a0 = srcw[sp], a1 = srcw[sp + 1], a2 = srcw[sp + 2], a3 = srcw[sp + 3];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                    {
+                        const auto q = win + lo[k] + l;
+                        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
+                        acc[k] = sad_dword<S>(a0, __builtin_amdgcn_alignbyte(d1, d0, sh[k]), acc[k]);
+                        acc[k] = sad_dword<S>(a1, __builtin_amdgcn_alignbyte(d2, d1, sh[k]), acc[k]);
+                        acc[k] = sad_dword<S>(a2, __builtin_amdgcn_alignbyte(d3, d2, sh[k]), acc[k]);
+                        acc[k] = sad_dword<S>(a3, __builtin_amdgcn_alignbyte(d4, d3, sh[k]), acc[k]);
+                    }
+                }
+                else if (CB == 8)
+                {
+                    const uint32_t a0 = srcw[sp], a1 = srcw[sp + 1];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                    {
+                        const auto q = win + lo[k] + l;
+                        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+                        acc[k] = sad_dword<S>(a0, __builtin_amdgcn_alignbyte(d1, d0, sh[k]), acc[k]);
+                        acc[k] = sad_dword<S>(a1, __builtin_amdgcn_alignbyte(d2, d1, sh[k]), acc[k]);
+                    }
+                }
+                else
+                {
+                    const uint32_t a0 = srcw[sp];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                    {
+                        const auto q = win + lo[k] + l;
+                        acc[k] = sad_dword<S>(a0, __builtin_amdgcn_alignbyte(q[1], q[0], sh[k]), acc[k]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+        {
+            int t = sad_group_sum((int)acc[k]);
+            if (S == 2) t >>= 2;
+            if (lane == kSadLanes - 1) out[4 * c + k] = t;
+        }
+    }
+}
+
+template <int S, int NW>
+__global__ __launch_bounds__(64 * NW) void k_sad4r(const char *__restrict__ src, long stride_src, const char *__restrict__ ref, long stride_ref, float inv_stride_ref,
+                                                   const int32_t *__restrict__ jobs, int njobs, const int32_t *__restrict__ runs, int nruns, int32_t *__restrict__ out)
+{
+    constexpr int T = 64 * NW, NG = T / kSadLanes;
+    constexpr int kWinD = (S == 1 ? 16 : 32) * 256;      // the window: 16 KB (8-bit) / 32 KB (16-bit), in dwords
+    constexpr int kSrcD = 64 * 64 * S / 4;                // the source block
+    constexpr int kFallWB = 1024, kFallD = kFallWB * S / 4 + 16;      // the call-by-call path's buffer per lane group
+    static_assert(NG * kFallD + 4 <= kWinD + kSrcD, "the call-by-call path's buffers must fit the run's LDS");
+    __shared__ __attribute__((aligned(16))) uint32_t lds[kWinD + kSrcD + 8];
+    __shared__ __attribute__((aligned(16))) uint32_t s_cand[kRunMax * 4];
+    __shared__ int s_box[6];
+    const int run = xcd_block(blockIdx.x, gridDim.x);
+    const int tid = threadIdx.x, lane = tid & (kSadLanes - 1), group = tid / kSadLanes;
+    int first = runs[2 * run], count = runs[2 * run + 1];
+    if (first < 0 || count <= 0 || (long)first + count > njobs) return;      // (uniform: the whole workgroup leaves)
+    const int32_t *j0 = jobs + (long)first * 8;
+    const int so = j0[0], ro0 = j0[1], w = j0[5], h = j0[6];
+    const int st = (int)stride_ref, half = st >> 1;
+    const int rowBytes = w * S;
+    if (tid < 6) s_box[tid] = tid == 4 ? 1 : 0;      // min dx, max dx, min dy, max dy (candidate 0 of call 0 is (0, 0)), ok, -
+    __syncthreads();
+    // ---- pass 1: every candidate's displacement from the run's first one, the box, and whether the run is one search (same source block and size)
+    int mn_x = 0, mx_x = 0, mn_y = 0, mx_y = 0, ok = count <= kRunMax;
+    for (int p = tid; p < 4 * min(count, kRunMax); p += T)
+    {
+        const int32_t *j = j0 + (p >> 2) * 8;
+        const int delta = j[1 + (p & 3)] - ro0;
+        int q = (int)floorf(((float)delta + (float)half) * inv_stride_ref);
+        long rl = (long)delta - (long)q * st;      // (64-bit: a far candidate's quotient times the stride does not fit 32 bits; such a run goes call by call)
+        if (rl < -half) { --q; rl += st; }
+        if (rl >= st - half) { ++q; rl -= st; }
+        ok &= (j[0] == so) & (j[5] == w) & (j[6] == h) & (q >= -32768) & (q < 32768) & (rl >= -32768) & (rl < 32768);
+        const int r = (int)rl;
+        s_cand[p] = (uint32_t)(r & 0xffff) | ((uint32_t)q << 16);
+        mn_x = min(mn_x, r); mx_x = max(mx_x, r); mn_y = min(mn_y, q); mx_y = max(mx_y, q);
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1)
+    {
+        mn_x = min(mn_x, __shfl_xor(mn_x, o, 64)); mx_x = max(mx_x, __shfl_xor(mx_x, o, 64));
+        mn_y = min(mn_y, __shfl_xor(mn_y, o, 64)); mx_y = max(mx_y, __shfl_xor(mx_y, o, 64));
+        ok &= __shfl_xor(ok, o, 64);
+    }
+    if ((tid & 63) == 0)
+    {
+        atomicMin(&s_box[0], mn_x); atomicMax(&s_box[1], mx_x); atomicMin(&s_box[2], mn_y); atomicMax(&s_box[3], mx_y); atomicAnd(&s_box[4], ok);
+    }
+    __syncthreads();
+    const int mndx = s_box[0], mxdx = s_box[1], mndy = s_box[2], mxdy = s_box[3];
+    ok = s_box[4];
+    const long ssb = stride_src * S, rsb = stride_ref * S;
+    const int spready = mxdy - mndy;
+    const long minoff = ((long)ro0 + (long)mndy * st + mndx) * S;      // bytes from `ref` to the box's first sample
+    const int lead = (int)(reinterpret_cast<uintptr_t>(ref + minoff) & 15);
+    const int chunks = (lead + rowBytes + (mxdx - mndx) * S + 15) >> 4;      // 16-byte pieces of a box row
+    const int pitchD = 4 * chunks + 1, rows = h + spready;
+    const bool chunked = (rowBytes & 15) == 0 ? rowBytes <= 16 * kSadLanes : (rowBytes & 7) == 0 ? rowBytes <= 8 * kSadLanes : (rowBytes & 3) == 0 && rowBytes <= 4 * kSadLanes;
+    const bool near = (unsigned)spready < 1024u && (unsigned)h <= 64u && ssb < (1 << 23) && rsb < (1 << 23) && chunks <= 1024 &&
+                      minoff + (long)rows * rsb + 16l * chunks < (1ll << 32) && ((long)so * S + (long)h * ssb + rowBytes) < (1ll << 32);
+    const bool fits = ok && chunked && near && w <= 64 && minoff >= 16 && (long)pitchD * rows + 4 <= kWinD;
+    if (fits)
+    {
+        const auto win_w = (__attribute__((address_space(3))) uint32_t *)(&lds[0]);
+        const auto src_w = (__attribute__((address_space(3))) uint32_t *)(&lds[kWinD + 4]);
+        // the box: 16-byte pieces, aligned in memory (rows of our planes: multiples of 64 bytes), a piece per thread
+        {
+            const FastDiv fc(chunks);
+            const uint32_t a0 = (uint32_t)(minoff - lead);
+            for (int i = tid; i < rows * chunks; i += T)
+            {
+                const int r = fc.div(i), c = i - r * chunks;
+                const u32x4 v = ld16(ref + a0 + (uint32_t)r * (uint32_t)rsb + c * 16);
+                const int l = r * pitchD + c * 4;
+                win_w[l] = v.x; win_w[l + 1] = v.y; win_w[l + 2] = v.z; win_w[l + 3] = v.w;
+            }
+            // the source block: dense rows of dwords
+            const int dpr = rowBytes >> 2;
+            const FastDiv fdw(dpr);
+            const uint32_t sb0 = (uint32_t)so * S;
+            for (int i = tid; i < h * dpr; i += T)
+            {
+                const int y = fdw.div(i), x = i - y * dpr;
+                src_w[i] = ld4(src + sb0 + (uint32_t)y * (uint32_t)ssb + x * 4);
+            }
+        }
+        __syncthreads();
+        const auto win = (const __attribute__((address_space(3))) uint32_t *)(&lds[0]);
+        const auto srcw = (const __attribute__((address_space(3))) uint32_t *)(&lds[kWinD + 4]);
+        const auto cand = (const __attribute__((address_space(3))) uint32_t *)(&s_cand[0]);
+        int32_t *o = out + (long)first * 4;
+        if ((rowBytes & 15) == 0) sad4_run_calls<S, 16>(win, srcw, cand, pitchD, lead, mndx, mndy, rowBytes, h, count, group, NG, lane, o);
+        else if ((rowBytes & 7) == 0) sad4_run_calls<S, 8>(win, srcw, cand, pitchD, lead, mndx, mndy, rowBytes, h, count, group, NG, lane, o);
+        else sad4_run_calls<S, 4>(win, srcw, cand, pitchD, lead, mndx, mndy, rowBytes, h, count, group, NG, lane, o);
+        return;
+    }
+    // ---- call by call
+    for (int c = group; c < ((count + NG - 1) / NG) * NG; c += NG)
+    {
+        const bool live = c < count;
+        int total[4];
+        sad4_job<S, kFallWB>(src, stride_src, ref, stride_ref, inv_stride_ref, j0 + (long)(live ? c : 0) * 8, live, &lds[group * kFallD], lane, total);
+        if (live && lane == kSadLanes - 1)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) out[((long)first + c) * 4 + k] = total[k];
     }
 }
 
@@ -751,6 +965,33 @@ static int sad4_form()
         return (d && *d == '1') ? 1 : ((w && *w == '0') ? 0 : 2);
     }();
     return v;
+}
+
+// workgroup size of the run kernel (read once per process): HAVOC_SAD4_RUN_WAVES = 1, 2 or 4 wavefronts share a run's window
+static int sad4_run_waves()
+{
+    static const int v = [] {
+        const char *e = getenv("HAVOC_SAD4_RUN_WAVES");
+        const int n = e ? atoi(e) : 4;
+        return n == 1 || n == 2 ? n : 4;
+    }();
+    return v;
+}
+
+hipError_t launch_sad4_runs(hipStream_t st, int S, const void *src, long ss, const void *ref, long rs, const void *jobs, int n, const void *runs, int nruns, int32_t *out)
+{
+    if (n <= 0 || nruns <= 0) return hipSuccess;
+    if (rs < 64 || rs >= (1 << 22) || (S != 1 && S != 2)) return hipErrorInvalidValue;
+    const char *s = (const char *)src, *r = (const char *)ref;
+    const int32_t *j = (const int32_t *)jobs, *rn = (const int32_t *)runs;
+    const float inv = 1.0f / (float)rs;
+    const int nw = sad4_run_waves();
+    const dim3 g(nruns), b(64 * nw);
+#define HAVOC_RUN(SS, NW) hipLaunchKernelGGL((k_sad4r<SS, NW>), g, b, 0, st, s, ss, r, rs, inv, j, n, rn, nruns, out)
+    if (S == 1) { if (nw == 1) HAVOC_RUN(1, 1); else if (nw == 2) HAVOC_RUN(1, 2); else HAVOC_RUN(1, 4); }
+    else { if (nw == 1) HAVOC_RUN(2, 1); else if (nw == 2) HAVOC_RUN(2, 2); else HAVOC_RUN(2, 4); }
+#undef HAVOC_RUN
+    return hipGetLastError();
 }
 
 hipError_t launch_sad(hipStream_t st, int S, int ways, const void *src, long ss, const void *ref, long rs, const void *jobs, int n, int32_t *out)

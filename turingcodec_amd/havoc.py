@@ -69,6 +69,8 @@ def _load():
         "join": [_vp],
         "sad": [_vp, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
         "sad4": [_vp, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
+        "sad4_runs": [_vp, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp, _i, _vp],
+        "sad4_make_runs": [_vp, _i, _i, _vp],
         "pad_block": [_vp, _i, _vp, C.c_int64, _i, _i, _ip, _i, _i, _i, _i, _i],
         "sad_surface": [_vp, _i, _i, _i, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
         "deblock": [_vp, _i, _i, _vp, _ip, _vp, _vp, _ip, _i, _i, _vp, _vp, _i, _i, _i, _i],
@@ -329,6 +331,21 @@ class Havoc:
     def sad4_d(self, src, ss, ref, rs, jobs, out):
         self._ck(self.L.havoc_mi355x_sad4(self.h, self._S(src), _ptr(src), ss, _ptr(ref), rs, _ptr(jobs), jobs.shape[0], _ptr(out)))
 
+    def sad4_runs_d(self, src, ss, ref, rs, jobs, runs, out):
+        """the same calls by runs (include/havoc_mi355x.h: havoc_mi355x_sad4_runs); runs: int32 tensor [nruns, 2] = (first job, count)"""
+        self._ck(self.L.havoc_mi355x_sad4_runs(self.h, self._S(src), _ptr(src), ss, _ptr(ref), rs, _ptr(jobs), jobs.shape[0], _ptr(runs), runs.shape[0], _ptr(out)))
+
+    @staticmethod
+    def sad4_make_runs(jobs, max_run=128):
+        """host: cut a sad4 job table (int32 [n, 8]) into runs of consecutive calls with equal source block and size -> int32 [nruns, 2]"""
+        L, _ = _load()
+        jobs = np.ascontiguousarray(jobs, np.int32)
+        runs = np.zeros((max(1, len(jobs)), 2), np.int32)
+        n = L.havoc_mi355x_sad4_make_runs(jobs.ctypes.data, len(jobs), max_run, runs.ctypes.data)
+        if n < 0:
+            raise HavocError("havoc_mi355x_sad4_make_runs failed")
+        return np.ascontiguousarray(runs[:n])
+
     def ssd_d(self, a, sa, b, sb, jobs, out):
         self._ck(self.L.havoc_mi355x_ssd(self.h, self._S(a), _ptr(a), sa, _ptr(b), sb, _ptr(jobs), jobs.shape[0], _ptr(out)))
 
@@ -573,6 +590,16 @@ class Havoc:
     def sad4(self, a, sa, b, sb, jobs):
         out = self.zeros(4 * len(jobs), np.int32)
         self.sad4_d(self.up(a), sa, self.up(b), sb, self._jobs(jobs, 8), out)
+        return self.down(out, np.int32).reshape(-1, 4)
+
+    def sad4_runs(self, a, sa, b, sb, jobs, runs=None, max_run=128):
+        """havoc_sad_multiref calls by runs (one search's consecutive calls share a staged window); runs None = cut by sad4_make_runs"""
+        jobs = np.ascontiguousarray(jobs, np.int32)
+        if runs is None:
+            runs = self.sad4_make_runs(jobs, max_run)
+        out = self.zeros(4 * len(jobs), np.int32)
+        if len(jobs):
+            self.sad4_runs_d(self.up(a), sa, self.up(b), sb, self._jobs(jobs, 8), self.up(np.ascontiguousarray(runs, np.int32)), out)
         return self.down(out, np.int32).reshape(-1, 4)
 
     def sad_surface(self, a, sa, b, sb, rng, jobs):

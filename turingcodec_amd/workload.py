@@ -645,6 +645,28 @@ class FrameWorkload:
         j["ctx_index"], j["scan_idx"], j["is_intra"], j["sdh"] = g["ctx_index"], g["scan_idx"], g["is_intra"], sdh
         return j
 
+    def sad4_unique_bytes(self, max_run=128):
+        """HBM bytes the 4-way SAD calls need when the calls of one search share their operands: per run of consecutive calls with equal
+        source block and size, the bounding box of every candidate block ONCE + the source block ONCE + 16 bytes of results per call.  SURVEY 8(d)'s per-call
+        figure (5 w h S + 16) counts the same reference samples once per call -- 112 times per search."""
+        j = self.sad4
+        if not len(j):
+            return 0
+        S, st, pl = self.S, self.stride, self.plane_len
+        key = j[:, [0, 5, 6]]
+        cut = np.flatnonzero((key[1:] != key[:-1]).any(axis=1)) + 1
+        starts = np.concatenate([[0], cut])
+        ends = np.concatenate([cut, [len(j)]])
+        total = 0
+        for b, e in zip(starts, ends):
+            for b2 in range(b, e, max_run):
+                r = j[b2:min(e, b2 + max_run)]
+                off = r[:, 1:5].astype(np.int64).ravel() % pl
+                y, x = off // st, off % st
+                w, h = int(r[0, 5]), int(r[0, 6])
+                total += (int(x.max() - x.min()) + w) * (int(y.max() - y.min()) + h) * S + w * h * S + 16 * len(r)
+        return int(total)
+
     def algorithmic_bytes(self):
         S = self.S
         b = {}
