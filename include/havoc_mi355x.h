@@ -594,7 +594,9 @@ int havoc_mi355x_block_cells(havoc_mi355x_ctx *ctx, int width, int height, int q
  *     from d_modes (one byte per cell) left of and above it (above only inside the same CTU row);
  *   intra_commit: the champions' blocks (block i = n x n samples at i * n * n, as havoc_search_intra_device leaves them) into the picture, their modes into d_modes. */
 typedef struct { int32_t x0, y0, log2, index; } havoc_mi355x_intra_chain_part;        /* 16 bytes */
-typedef struct { int32_t pic_width, pic_height, stride, pad, cells_per_row, bit_depth, ctb_log2, reserved; } havoc_mi355x_intra_chain_layout;      /* 32 bytes */
+typedef struct { int32_t pic_width, pic_height, stride, pad, cells_per_row, bit_depth, ctb_log2, strong_intra_smoothing; } havoc_mi355x_intra_chain_layout;      /* 32 bytes;
+ * strong_intra_smoothing = the sequence's strong_intra_smoothing_enabled_flag (turing/Encoder.cpp:688 sets it): flat 32x32 blocks then take the bi-linear filter of
+ * IntraReferenceSamples.h:382-402 */
 int havoc_mi355x_intra_gather(havoc_mi355x_ctx *ctx, int S, const havoc_mi355x_intra_chain_layout *layout, const void *d_rec, const int32_t *d_owner, const uint8_t *d_modes,
                               const havoc_mi355x_intra_chain_part *d_parts, int n, const havoc_mi355x_intra_search_job *d_jobs, void *d_neighbours, havoc_mi355x_intra_mpm *d_mpm);
 int havoc_mi355x_intra_commit(havoc_mi355x_ctx *ctx, int S, const havoc_mi355x_intra_chain_layout *layout, void *d_rec, uint8_t *d_modes, const havoc_mi355x_intra_chain_part *d_parts,

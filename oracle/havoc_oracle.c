@@ -684,3 +684,49 @@ void oracle_derive_bs(const void *cells_, intptr_t cs, int width, int height, in
             bs[ry * gw + rx] = (uint8_t)packed;
         }
 }
+
+/* turing/IntraReferenceSamples.h:373-421 */
+void oracle_intra_filter_neighbours(const int32_t *p, int32_t *pF, int nTbS, int bitDepthY, int strong)
+{
+#define P(x, y) p[(x) - (y)-1]
+#define PF(x, y) pF[(x) - (y)-1]
+    const int last = nTbS * 2 - 1;
+    const int thr = 1 << (bitDepthY - 5);
+    const int biInt = strong == 1 && nTbS == 32 && abs(P(-1, -1) + P(last, -1) - 2 * P(nTbS - 1, -1)) < thr &&
+                      abs(P(-1, -1) + P(-1, last) - 2 * P(-1, nTbS - 1)) < thr;
+    if (biInt)
+    {   /* :384-397 */
+        PF(-1, -1) = P(-1, -1);
+        for (int y = 0; y <= 62; ++y) PF(-1, y) = ((63 - y) * P(-1, -1) + (y + 1) * P(-1, 63) + 32) >> 6;
+        PF(-1, 63) = P(-1, 63);
+        for (int x = 0; x <= 62; ++x) PF(x, -1) = ((63 - x) * P(-1, -1) + (x + 1) * P(63, -1) + 32) >> 6;
+        PF(63, -1) = P(63, -1);
+    }
+    else
+    {   /* :400-412 */
+        PF(-1, -1) = (P(-1, 0) + 2 * P(-1, -1) + P(0, -1) + 2) >> 2;
+        for (int y = 0; y <= last - 1; ++y) PF(-1, y) = (P(-1, y + 1) + 2 * P(-1, y) + P(-1, y - 1) + 2) >> 2;
+        PF(-1, last) = P(-1, last);
+        for (int x = 0; x <= last - 1; ++x) PF(x, -1) = (P(x - 1, -1) + 2 * P(x, -1) + P(x + 1, -1) + 2) >> 2;
+        PF(last, -1) = P(last, -1);
+    }
+#undef P
+#undef PF
+}
+
+/* HEVC 8.4.4.2.2 / turing/IntraReferenceSamples.h:286-346: search from the bottom of the left column for the first available sample; everything before it
+ * takes its value; every later unavailable sample takes its predecessor's; nothing available -> 1 << (bitDepth - 1) */
+void oracle_intra_substitute(int32_t *val, const uint8_t *have, int nTbS, int bitDepthY)
+{
+    const int len = 4 * nTbS + 1;
+    int first = 0;
+    while (first < len && !have[first]) ++first;
+    if (first == len)
+    {
+        for (int k = 0; k < len; ++k) val[k] = 1 << (bitDepthY - 1);
+        return;
+    }
+    for (int k = 0; k < first; ++k) val[k] = val[first];
+    for (int k = first + 1; k < len; ++k)
+        if (!have[k]) val[k] = val[k - 1];
+}

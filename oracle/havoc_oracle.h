@@ -73,6 +73,14 @@ void oracle_deblock(void *luma, intptr_t stride_y, void *cb, void *cr, intptr_t 
  * on the grid of ((width + 63) / 64 * 8 + 1) x ((height + 63) / 64 * 8 + 1) regions */
 void oracle_derive_bs(const void *cells, intptr_t cells_stride, int width, int height, int8_t *block_data, uint8_t *block_bs);
 
+/* turing/IntraReferenceSamples.h:373-421 (IntraReferenceSamples::filter; HEVC 8.4.4.2.3): the filtered copy of a block's 4 * nTbS + 1 reference samples.
+ * p / pF point at the MIDDLE of the linear arrays the intra functions read (havoc/pred_intra.cpp:43-51): p(x, y) = p[x - y - 1], i.e. [-1 - 2n, -2] = left
+ * column from the bottom, [-1] = corner, [0, 2n - 1] = row above.  strong = strong_intra_smoothing_enabled_flag. */
+void oracle_intra_filter_neighbours(const int32_t *p, int32_t *pF, int nTbS, int bitDepthY, int strong);
+/* HEVC 8.4.4.2.2 as IntraReferenceSamples::substitute (turing/IntraReferenceSamples.h:286-346) applies it, on the array index k = 0 .. 4n (k = t + 2n + 1 of
+ * the layout above: from the bottom of the left column to the end of the row above): have[k] != 0 where the sample is available; the others are filled in */
+void oracle_intra_substitute(int32_t *val, const uint8_t *have, int nTbS, int bitDepthY);
+
 /* turing/Measure.h:97-135 (measureSatd): PU SATD tiled in 8x8 / 4x4 / 2x2 Hadamards */
 int oracle_pu_satd(const void *a, intptr_t stride_a, const void *b, intptr_t stride_b, int w, int h, int S);
 

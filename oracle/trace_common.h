@@ -43,6 +43,9 @@ enum
     HAVOC_TR_INTRA_SWAP = 19,  // j: that candidate became the champion
     HAVOC_TR_RQT_ONE = 20,     // x0, y0, log2TrafoSize, ssd[0], ssd[1], ssd[2] of the split tree, its rate lo, hi, reciprocalLambda (Q16), rqt_root_cbf
     HAVOC_TR_RQT_ZERO = 21,    // ssd[0..2] of the unsplit block, its rate lo, hi
+    HAVOC_TR_INTRA_NB = 23,    // (round 5) before INTRA_BEGIN, partitions below 64x64: the 4n + 1 UNFILTERED reference samples of the partition as the encoder's
+                               // substituteFast left them (Search.hpp:57), 14 per record, from the bottom of the left column over the corner to the end of the row above
+    HAVOC_TR_INTRA_NBF = 24,   // the same positions of the FILTERED copy (Search.hpp:59; partitions above 4x4)
     HAVOC_TR_RQT_END = 22,     // chosen rqtdepth, cbfZero (the split tree had no coded block: depth 0 never evaluated)
 };
 

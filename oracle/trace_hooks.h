@@ -57,6 +57,24 @@ static inline void candidate(int kind, const Candidate &c)
     havoc_trace_emit(kind, 7, a);
 }
 
+// a partition's reference samples, 14 per record: index k = 0 .. 4n walks p(-1, 2n - 1) .. p(-1, 0), p(-1, -1), p(0, -1) .. p(2n - 1, -1)
+template <class Samples>
+static inline void neighbours(int kind, Samples &p, int nTbS)
+{
+    int32_t v[14];
+    int n = 0;
+    for (int k = 0; k <= 4 * nTbS; ++k)
+    {
+        const int x = k <= 2 * nTbS ? -1 : k - 2 * nTbS - 1, y = k < 2 * nTbS ? 2 * nTbS - 1 - k : -1;
+        v[n++] = p(x, y);
+        if (n == 14 || k == 4 * nTbS)
+        {
+            havoc_trace_emit(kind, n, v);
+            n = 0;
+        }
+    }
+}
+
 } // namespace havoc_trace
 
 // ---- the macros the inserted lines call (each a statement) ----
@@ -98,6 +116,12 @@ static inline void candidate(int kind, const Candidate &c)
 #define HAVOC_TRACE_BI_END() havoc_trace::candidate(HAVOC_TR_BI_END, best)
 #define HAVOC_TRACE_INTRA_BEGIN()                                                                                            \
     do {                                                                                                                     \
+        if (log2PartitionSize != 6)                                                                                          \
+        {                                                                                                                    \
+            havoc_trace::neighbours(HAVOC_TR_INTRA_NB, stateEncodeSubstream->unfiltered[0], 1 << log2PartitionSize);         \
+            if (log2PartitionSize != 2)                                                                                      \
+                havoc_trace::neighbours(HAVOC_TR_INTRA_NBF, stateEncodeSubstream->filtered, 1 << log2PartitionSize);         \
+        }                                                                                                                    \
         int32_t a_[14] = {h[PicOrderCntVal()], xPositionOf(intraPartition), yPositionOf(intraPartition), log2PartitionSize,  \
                           candModeList[0], candModeList[1], candModeList[2], candModeList.neighbourModes};                   \
         havoc_trace::lohi(a_ + 8, (rateA - rateC).value);                                                                    \

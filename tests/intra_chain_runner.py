@@ -67,7 +67,7 @@ def main():
     d_src, d_rec = up(src), up(np.zeros_like(src))
     d_owner, d_modes = up(t["owner"].ravel()), up(np.zeros(t["owner"].size, np.uint8))
     d_states = up(t["rdoq_states"])
-    layout = (C.c_int32 * 8)(W, H, stride, PAD, t["owner"].shape[1], BD, 6, 0)
+    layout = (C.c_int32 * 8)(W, H, stride, PAD, t["owner"].shape[1], BD, 6, 1)      # strong_intra_smoothing: the reference encoder's default
     table = np.zeros(len(t["sizes"]), decisions.INTRA_CHAIN_SIZE_DT)
     keep = []
     for row, (log2, g) in zip(table, t["sizes"].items()):

@@ -493,10 +493,16 @@ int havoc_mi355x_intra_gather(havoc_mi355x_ctx *ctx, int S, const havoc_mi355x_i
                 if (!have[k]) val[k] = val[k - 1];
         }
         const long base = jobs[i].nb_off - (2 * nn + 1), basef = jobs[i].nbf_off - (2 * nn + 1);
+        /* IntraReferenceSamples.h:382-402: flat edges of a 32x32 block -> bi-linear between the corner and the two ends */
+        const int corner = val[2 * nn], thr = 1 << (L->bit_depth - 5);
+        const int strong = L->strong_intra_smoothing == 1 && nn == 32 && abs(corner + val[4 * nn] - 2 * val[3 * nn]) < thr && abs(corner + val[0] - 2 * val[nn]) < thr;
         for (int k = 0; k < len; ++k)
         {
             chain_store(nb, S, base + k, val[k]);
-            chain_store(nb, S, basef + k, (k == 0 || k == len - 1) ? val[k] : (val[k - 1] + 2 * val[k] + val[k + 1] + 2) >> 2);
+            int f;
+            if (strong) f = k < 64 ? (k * corner + (64 - k) * val[0] + 32) >> 6 : k == 64 ? corner : ((128 - k) * corner + (k - 64) * val[128] + 32) >> 6;
+            else f = (k == 0 || k == len - 1) ? val[k] : (val[k - 1] + 2 * val[k] + val[k + 1] + 2) >> 2;
+            chain_store(nb, S, basef + k, f);
         }
         const int a = chain_available(L, owner, p->index, p->x0 - 1, p->y0) ? modes[(p->y0 >> 2) * L->cells_per_row + ((p->x0 - 1) >> 2)] : 1;
         const int b = chain_available(L, owner, p->index, p->x0, p->y0 - 1) && (p->y0 - 1) >= ((p->y0 >> L->ctb_log2) << L->ctb_log2)

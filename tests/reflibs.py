@@ -130,6 +130,24 @@ class Oracle:
         """in place on the three planes (numpy arrays whose element 0 is sample (0, 0))"""
         self.L.oracle_deblock(_addr(luma), sy, _addr(cb), _addr(cr), sc, width, height, bd, _addr(data), _addr(bs), tc2, beta2, cb_qp, cr_qp, _S(luma))
 
+    def intra_filter_neighbours(self, samples, n, bit_depth, strong):
+        """IntraReferenceSamples::filter on the 4n + 1 samples in array order (left column from the bottom, corner, row above) -> the filtered copy"""
+        a = np.ascontiguousarray(samples, np.int32)
+        out = np.zeros_like(a)
+        mid = (2 * n + 1) * 4
+        self.L.oracle_intra_filter_neighbours.restype = None
+        self.L.oracle_intra_filter_neighbours.argtypes = [_vp, _vp, C.c_int, C.c_int, C.c_int]
+        self.L.oracle_intra_filter_neighbours(a.ctypes.data + mid, out.ctypes.data + mid, n, bit_depth, strong)
+        return out
+
+    def intra_substitute(self, values, have, n, bit_depth):
+        a = np.ascontiguousarray(values, np.int32).copy()
+        h = np.ascontiguousarray(have, np.uint8)
+        self.L.oracle_intra_substitute.restype = None
+        self.L.oracle_intra_substitute.argtypes = [_vp, _vp, C.c_int, C.c_int]
+        self.L.oracle_intra_substitute(a.ctypes.data, h.ctypes.data, n, bit_depth)
+        return a
+
     def derive_bs(self, cells, width, height):
         """cells: CELL_DT-like structured array [height / 4, width / 4] -> (block_data int8, block_bs uint8) of the region grid"""
         n = ((width + 63) // 64 * 8 + 1) * ((height + 63) // 64 * 8 + 1)

@@ -36,7 +36,7 @@ def test_partitions_tile_the_picture_and_levels_respect_every_dependency():
 
 
 def _reference_samples(rec2d, owner, pad, w, h, q, i, bit_depth):
-    """HEVC 8.4.4.2.2 on the running reconstruction: (unfiltered, [1 2 1]-filtered) arrays of 4n + 1 samples, left column from the bottom, corner, row above"""
+    """HEVC 8.4.4.2.2 on the running reconstruction: (unfiltered, filtered) arrays of 4n + 1 samples, left column from the bottom, corner, row above"""
     n = 1 << int(q["log2"])
     k = np.arange(4 * n + 1)
     x = np.where(k <= 2 * n, q["x0"] - 1, q["x0"] + k - 2 * n - 1)
@@ -53,8 +53,15 @@ def _reference_samples(rec2d, owner, pad, w, h, q, i, bit_depth):
         for j in range(1, len(val)):
             if not have[j]:
                 val[j] = val[j - 1]
-    filt = val.copy()
-    filt[1:-1] = (val[:-2] + 2 * val[1:-1] + val[2:] + 2) >> 2
+    # the filtered copy: IntraReferenceSamples::filter as restated in the oracle -- pinned against the arrays the reference ENCODER held (tests/trace_runner.py:
+    # intra_neighbours, 0 of 3 230 differ), strong intra smoothing of flat 32x32 edges included (the encoder's default, Encoder.cpp:688)
+    from reflibs import Oracle
+    global _ORC
+    try:
+        orc = _ORC
+    except NameError:
+        orc = _ORC = Oracle()
+    filt = orc.intra_filter_neighbours(val.astype(np.int32), n, bit_depth, 1).astype(np.int64)
     return val, filt
 
 

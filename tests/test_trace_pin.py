@@ -41,6 +41,12 @@ def check_cpu(rep, min_searches):
     assert b["searches"] >= min_searches // 4 and b["mismatching_searches"] == 0 and b["mismatching_call_rows"] == 0, b
     assert b["mismatching_in_the_lane_formulation"] == 0, b      # the exhaustive grid costed a candidate per "lane" (what k_search_bi runs), emulated on the host
     assert i["partitions"] >= min_searches // 2 and i["mismatching"] == 0, i
+    # the reference samples the encoder held for every intra partition (round 5): filter (strong intra smoothing included) and substitution restated == recorded
+    nb = rep["intra_neighbours_cpu"]
+    assert nb["partitions_with_samples"] >= i["partitions"] * 9 // 10 and nb["filtered_arrays"] > nb["partitions_with_samples"] // 10, nb
+    assert nb["filter_mismatching"] == 0 and nb["substitution_mismatching"] == 0 and nb["partitions_with_substituted_samples"] > 0, nb
+    if rep["case"] == "ra_medium_qp32":
+        assert nb["strong_smoothing_taken"] > 10, nb      # the bi-linear branch is exercised by real content
     # tu_decision.hpp on the encoder's own rates and distortions: the champion of every intra partition's RD refinement, every transform-tree decision
     rd, q = rep["intra_rd_cpu"], rep["rqt_cpu"]
     assert rd["partitions"] == i["partitions"] and rd["rates_measured_by_the_encoder"] > rd["partitions"] and rd["mismatching_champions"] == 0, rd
@@ -69,6 +75,8 @@ def test_batch_clients_over_the_stand_in_device_decide_what_the_reference_encode
     assert rep["uni_device"]["searches"] >= 400 and rep["uni_device"]["mismatching_launch_and_replay"] == 0, rep["uni_device"]
     assert rep["bi_device"]["searches"] >= 400 and rep["bi_device"]["mismatching_launch_and_replay"] == 0, rep["bi_device"]
     assert rep["intra_device"]["partitions"] >= 400 and rep["intra_device"]["mismatching"] == 0, rep["intra_device"]
+    g = rep["intra_neighbours_device"]      # the stand-in's gather on the encoder's own samples: copies and filtered copies (strong smoothing included)
+    assert g["gathered"] > 1000 and g["gather_unfiltered_mismatching"] == 0 and g["gather_filtered_mismatching"] == 0, g
 
 
 @needs_trace
@@ -83,3 +91,5 @@ def test_search_kernels_decide_what_the_reference_encoder_decided(case, min_sear
     assert u["searches"] == rep["uni_cpu"]["searches"] and u["mismatching_launch_and_replay"] == 0 and u["mismatching_loops_in_kernel"] == 0, u
     assert b["searches"] == rep["bi_cpu"]["searches"] and b["mismatching_launch_and_replay"] == 0 and b["mismatching_loops_in_kernel"] == 0, b
     assert i["partitions"] > 0 and i["mismatching"] == 0, i
+    g = rep["intra_neighbours_device"]      # k_intra_gather on the encoder's own reference samples
+    assert g["gathered"] > 500 and g["gather_unfiltered_mismatching"] == 0 and g["gather_filtered_mismatching"] == 0, g

@@ -106,6 +106,94 @@ class Device:
         return self.planes[key], pe
 
 
+def z_order(x4, y4):
+    """Morton index of a 4x4 cell inside its 64x64 CTU"""
+    z = 0
+    for b in range(4):
+        z |= ((x4 >> b) & 1) << (2 * b) | ((y4 >> b) & 1) << (2 * b + 1)
+    return z
+
+
+def intra_neighbours(intra, w, h, bit_depth, dev):
+    """the reference samples the ENCODER held for every intra partition it searched (trace records INTRA_NB / INTRA_NBF: Search.hpp:57-59) against
+      * IntraReferenceSamples::filter restated (oracle_intra_filter_neighbours; strong intra smoothing = the encoder's default, Encoder.cpp:688): filtered == F(unfiltered);
+      * the substitution process (HEVC 8.4.4.2.2) on the availability of HEVC 6.4.1 (inside the picture, earlier in z-scan order): the recorded array rebuilt from its
+        available samples alone must be the recorded array (a sample the encoder had substituted although it is available by 6.4.1 cannot be seen this way, the
+        other direction can);
+      * with a device: havoc_mi355x_intra_gather (k_intra_gather / the stand-in) on a picture tiled with the recorded samples: its unfiltered and filtered arrays."""
+    from reflibs import Oracle
+    orc = Oracle()
+    sel = [i for i in range(len(intra)) if intra.neighbours[i] is not None]
+    r = {"partitions_with_samples": len(sel), "filtered_arrays": 0, "filter_mismatching": 0, "strong_smoothing_taken": 0, "substitution_mismatching": 0,
+         "partitions_with_substituted_samples": 0}
+    ctus_x = (w + 63) // 64
+    for i in sel:
+        poc, x0, y0, log2 = (int(v) for v in intra.where[i])
+        n = 1 << log2
+        unf, fil = intra.neighbours[i], intra.neighbours_filtered[i]
+        if fil is not None:
+            r["filtered_arrays"] += 1
+            want = orc.intra_filter_neighbours(unf, n, bit_depth, 1)
+            r["filter_mismatching"] += int(not np.array_equal(want, fil))
+            r["strong_smoothing_taken"] += int(n == 32 and not np.array_equal(want, orc.intra_filter_neighbours(unf, n, bit_depth, 0)))
+        k = np.arange(4 * n + 1)
+        x = np.where(k <= 2 * n, x0 - 1, x0 + k - 2 * n - 1)
+        y = np.where(k < 2 * n, y0 + 2 * n - 1 - k, y0 - 1)
+        inside = (x >= 0) & (y >= 0) & (x < w) & (y < h)
+        addr = lambda xx, yy: ((yy >> 6) * ctus_x + (xx >> 6)) * 256 + z_order((xx >> 2) & 15, (yy >> 2) & 15)
+        me = addr(x0, y0)
+        have = np.array([bool(inside[j]) and addr(int(x[j]), int(y[j])) < me for j in range(len(k))])
+        r["partitions_with_substituted_samples"] += int(not have.all())
+        rebuilt = orc.intra_substitute(np.where(have, unf, 0), have, n, bit_depth)
+        r["substitution_mismatching"] += int(not np.array_equal(rebuilt, unf))
+    if dev is None or not sel:
+        return r
+    # ---- the device's gather on a picture made of the recorded samples: a 192 x 192 tile per partition, the partition at (64, 64) of its tile
+    sel = [i for i in sel if intra.neighbours_filtered[i] is not None][:4000]
+    S = 1 if bit_depth == 8 else 2
+    dt = np.uint8 if S == 1 else np.uint16
+    T = 192
+    cols = 16
+    rows = (len(sel) + cols - 1) // cols
+    W, H = cols * T, rows * T
+    pic = np.zeros((H, W), dt)
+    parts = np.zeros((len(sel), 4), np.int32)
+    jobs = np.zeros((len(sel), 8), np.int32)
+    for t, i in enumerate(sel):
+        n = 1 << int(intra.where[i][3])
+        ox, oy = (t % cols) * T + 64, (t // cols) * T + 64
+        unf = intra.neighbours[i]
+        pic[oy + 2 * n - 1 - np.arange(2 * n), ox - 1] = unf[:2 * n]
+        pic[oy - 1, ox - 1] = unf[2 * n]
+        pic[oy - 1, ox + np.arange(2 * n)] = unf[2 * n + 1:]
+        parts[t] = (ox, oy, int(intra.where[i][3]), 1)
+        jobs[t, 1], jobs[t, 2] = 264 * (2 * t) + 132, 264 * (2 * t + 1) + 132      # nb_off / nbf_off: the arrays' middles
+    owner = np.zeros((H // 4, W // 4), np.int32)                                      # every cell precedes the partitions (index 1): all samples available
+    modes = np.ones((H // 4, W // 4), np.uint8)
+    layout = (C.c_int32 * 8)(W, H, W, 0, W // 4, bit_depth, 6, 1)
+    nb = np.zeros(264 * 2 * len(sel) + 264, dt)
+    mpm = np.zeros(len(sel), st.INTRA_CTX_DT)
+    d = {}
+    for name, a in (("pic", pic), ("owner", owner), ("modes", modes), ("parts", parts), ("jobs", jobs), ("nb", nb), ("mpm", mpm)):
+        d[name] = dev._alloc(a.nbytes)
+        assert dev.dev.havoc_mi355x_h2d(dev.ctx, d[name], a.ctypes.data, a.nbytes) == 0
+    vp = C.c_void_p
+    dev.dev.havoc_mi355x_intra_gather.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp]
+    rc = dev.dev.havoc_mi355x_intra_gather(dev.ctx, S, layout, d["pic"], d["owner"], d["modes"], d["parts"], len(sel), d["jobs"], d["nb"], d["mpm"])
+    assert rc == 0, dev.dev.havoc_mi355x_last_error()
+    dev.dev.havoc_mi355x_sync(dev.ctx)
+    assert dev.dev.havoc_mi355x_d2h(dev.ctx, nb.ctypes.data, d["nb"], nb.nbytes) == 0
+    r.update({"gathered": len(sel), "gather_unfiltered_mismatching": 0, "gather_filtered_mismatching": 0})
+    for t, i in enumerate(sel):
+        n = 1 << int(intra.where[i][3])
+        lo = 2 * n + 1
+        got_u = nb[264 * (2 * t) + 132 - lo:264 * (2 * t) + 132 - lo + 4 * n + 1].astype(np.int32)
+        got_f = nb[264 * (2 * t + 1) + 132 - lo:264 * (2 * t + 1) + 132 - lo + 4 * n + 1].astype(np.int32)
+        r["gather_unfiltered_mismatching"] += int(not np.array_equal(got_u, intra.neighbours[i]))
+        r["gather_filtered_mismatching"] += int(not np.array_equal(got_f, intra.neighbours_filtered[i]))
+    return r
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("case")
@@ -207,6 +295,8 @@ def main():
             np.any(out["costs"] != intra.costs[sel], axis=1)
         r["mismatching"] += int(bad.sum())
     report["intra_cpu"] = r
+
+    report["intra_neighbours_cpu"] = intra_neighbours(intra, w, h, internal, None)
 
     # ---- tu_decision.hpp on the encoder's own numbers (rates from its entropy estimator, distortions of three planes): the transform-tree decision
     # (Reconstruct.cpp:1296-1428) and the champion of an intra partition's RD refinement (Search.hpp:143-255)
@@ -321,6 +411,7 @@ def main():
             r["mismatching"] += int(bad.sum())
             r["partitions"] += n
         report["intra_device"] = r
+        report["intra_neighbours_device"] = intra_neighbours(intra, w, h, internal, dev)
     print(json.dumps(report))
 
 

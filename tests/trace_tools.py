@@ -25,6 +25,7 @@ REC_DT = np.dtype([("thread", "u4"), ("kind", "u2"), ("n", "u2"), ("v", "i4", (1
 assert REC_DT.itemsize == 64
 (UNI_BEGIN, BEGIN2, SAD, SAD4, SATD, UNI_INTEGER, UNI_SUBPEL, UNI_END, BI_BEGIN, BI_MV, BI_END, INTRA_BEGIN, INTRA_SATD, INTRA_MAX, INTRA_PICK, INTRA_SSD,
  INTRA_END, INTRA_RATE, INTRA_SWAP, RQT_ONE, RQT_ZERO, RQT_END) = range(1, 23)
+INTRA_NB, INTRA_NBF = 23, 24      # (round 5) the partition's reference samples as the encoder held them: unfiltered / filtered, 14 per record, before INTRA_BEGIN
 PAD = 96
 
 
@@ -194,6 +195,7 @@ class IntraTrace:
 
     def __init__(self, records):
         ctx, satd, costs, order, count, rsl, where, champion = [], [], [], [], [], [], [], []
+        nb, nbf = [], []            # per partition: the unfiltered / filtered reference samples (None when the encoder had none: 64x64 / 4x4 filtered)
         cand, rl = [], []          # RD refinement: per candidate (mode, ssd, rate or -1 when the encoder did not measure it); reciprocalLambda (Q16) per partition
         for t in np.unique(records["thread"]):
             rec = records[records["thread"] == t]
@@ -203,6 +205,18 @@ class IntraTrace:
             for k in range(len(b)):
                 seg_kind, seg = kind[b[k]:e[k] + 1], v[b[k]:e[k] + 1]
                 a = seg[0]
+                # the reference samples of the partition: the NB / NBF records that directly precede the BEGIN record
+                at = b[k]
+                while at > 0 and kind[at - 1] in (INTRA_NB, INTRA_NBF):
+                    at -= 1
+                parts = {INTRA_NB: [], INTRA_NBF: []}
+                for q in range(at, b[k]):
+                    parts[int(kind[q])].append(v[q][:int(rec["n"][q])])
+                length = 4 * (1 << int(a[3])) + 1
+                for key_, store in ((INTRA_NB, nb), (INTRA_NBF, nbf)):
+                    arr = np.concatenate(parts[key_]).astype(np.int32) if parts[key_] else None
+                    assert arr is None or len(arr) == length, (len(arr), length)
+                    store.append(arr)
                 s = seg[seg_kind == INTRA_SATD]
                 assert len(s) == 35 and np.array_equal(s[:, 0], np.arange(35))
                 c = np.zeros(1, st.INTRA_CTX_DT)[0]
@@ -247,6 +261,7 @@ class IntraTrace:
         self.champion = np.array(champion, np.int32)
         self.candidates = np.concatenate(cand) if cand else np.zeros((0, 3), np.int64)
         self.reciprocal_lambda = np.array(rl, np.int32)
+        self.neighbours, self.neighbours_filtered = nb, nbf
 
     def __len__(self):
         return len(self.ctx)

@@ -269,11 +269,11 @@ hipError_t launch_block_cells(hipStream_t st, int width, int height, int qp, int
 // a picture form a dependency graph; the host cuts it into levels (partitions whose neighbours are all final) and runs the batch chain level by level.
 // What a level needs from the picture's running state is made here, on the device:
 //   k_intra_gather   per partition: the 4n + 1 reference samples from the reconstruction picture with the substitution process of HEVC 8.4.4.2.2 for the
-//                    ones not yet coded / outside the picture (availability = "the 4x4 cell's owner precedes me in coding order"), their [1 2 1]-filtered copy
-//                    (IntraReferenceSamples.h:373-421), and candModeList from the modes decided left of and above it (CandModeList.h)
+//                    ones not yet coded / outside the picture (availability = "the 4x4 cell's owner precedes me in coding order"), their filtered copy ([1 2 1], or the bi-linear
+//                    strong smoothing of a flat 32x32 block's edges: IntraReferenceSamples.h:373-421), and candModeList from the modes decided left of and above it (CandModeList.h)
 //   k_intra_commit   per partition: the champion's reconstruction into the picture, its mode into the mode map
 struct ChainPart { int32_t x0, y0, log2, index; };                                                  // havoc_mi355x_intra_chain_part
-struct ChainLayout { int32_t picWidth, picHeight, stride, pad, cellsPerRow, bitDepth, ctbLog2, reserved; };      // havoc_mi355x_intra_chain_layout
+struct ChainLayout { int32_t picWidth, picHeight, stride, pad, cellsPerRow, bitDepth, ctbLog2, strongIntraSmoothing; };      // havoc_mi355x_intra_chain_layout
 static_assert(sizeof(ChainPart) == 16 && sizeof(ChainLayout) == 32, "record layouts");
 
 template <int S>
@@ -318,10 +318,19 @@ __global__ __launch_bounds__(64) void k_intra_gather(const ChainLayout L, const 
     }
     __syncthreads();
     const long base = job.nb_off - (2 * nn + 1), basef = job.nbf_off - (2 * nn + 1);
+    // IntraReferenceSamples.h:382-402 (HEVC 8.4.4.2.3): a 32x32 block whose two edges are nearly linear takes the bi-linear interpolation between the corner
+    // and the ends instead of the [1 2 1] filter (strong_intra_smoothing_enabled_flag, on by default: Encoder.cpp:688)
+    const int corner = val[2 * nn], thr = 1 << (L.bitDepth - 5);
+    const bool strong = L.strongIntraSmoothing == 1 && nn == 32 && abs(corner + val[4 * nn] - 2 * val[3 * nn]) < thr && abs(corner + val[0] - 2 * val[nn]) < thr;
     for (int k = lane; k < len; k += 64)
     {
         nb[base + k] = (T)val[k];
-        nb[basef + k] = (T)((k == 0 || k == len - 1) ? val[k] : (val[k - 1] + 2 * val[k] + val[k + 1] + 2) >> 2);
+        int f;
+        if (strong)      // k <= 64: the left column from the bottom (k = 63 - y), corner at 64; beyond: the row above (x = k - 65)
+            f = k < 64 ? (k * corner + (64 - k) * val[0] + 32) >> 6 : k == 64 ? corner : ((128 - k) * corner + (k - 64) * val[128] + 32) >> 6;
+        else
+            f = (k == 0 || k == len - 1) ? val[k] : (val[k - 1] + 2 * val[k] + val[k + 1] + 2) >> 2;
+        nb[basef + k] = (T)f;
     }
     if (lane == 0)
     {   // CandModeList.h:33-95: A = left, B = above (DC when not there, or above in another CTU row)

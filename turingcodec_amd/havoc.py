@@ -377,8 +377,9 @@ class Havoc:
 
     # ---- an intra picture's running state (kernels_decide.hip: k_intra_gather, k_intra_commit) ----
     @staticmethod
-    def intra_chain_layout(pic_width, pic_height, stride, pad, cells_per_row, bit_depth, ctb_log2=6):
-        return (C.c_int32 * 8)(pic_width, pic_height, stride, pad, cells_per_row, bit_depth, ctb_log2, 0)
+    def intra_chain_layout(pic_width, pic_height, stride, pad, cells_per_row, bit_depth, ctb_log2=6, strong_intra_smoothing=1):
+        """strong_intra_smoothing: the reference encoder's default (turing/Encoder.cpp:688)"""
+        return (C.c_int32 * 8)(pic_width, pic_height, stride, pad, cells_per_row, bit_depth, ctb_log2, int(bool(strong_intra_smoothing)))
 
     def intra_gather_a(self, S, layout, rec, owner, modes, parts, n, jobs, neighbours, mpm):
         """device ADDRESSES (ints): a level's slice of a size's tables"""
