@@ -12,6 +12,14 @@
  *                                    once at registration and mirrored in pinned host memory (Search.hpp:1976-1979);
  *   havoc_hadamard_satd              from the tile SATDs of all 49 quarter-sample positions around the vector being
  *                                    refined: ONE launch per (PU, list) (Search.hpp:1963-2061, Measure.h:97-135).
+ * Round 5, keyed on CONTENT (no registration needed beyond the input picture), per calling thread:
+ *   havoc::intra::Function           every mode of a partition from the reference-sample array a call names: ONE launch (35 modes + the edge-filtered forms of
+ *                                    DC / 10 / 26), look-ups while the array's content stays the same (turing/Reconstruct.cpp:244-246, 672-674);
+ *   havoc_hadamard_satd (intra)      every mode's tiles against the source block, and every mode's forward transform, in ONE more launch (Reconstruct.cpp:684-701);
+ *   havoc::Transform                 an intra candidate's: from that launch, when the residual handed in IS source - prediction;
+ *   inverse_transform_add, havoc_ssd an intra candidate's: computed in the wait of its havoc_quantize_inverse call (prediction and source are on the device);
+ *                                    an inter block's two havoc_ssd calls: in the wait of its inverse_transform_add (the source block is residual + prediction);
+ *   every such answer is given only if the operands the call names hold exactly the samples the precomputed value was made from (compared on the host).
  * Every served value is what the batch kernel computed on the GPU, bit-identical to the per-call value.  A call the
  * precomputed data cannot answer (unregistered planes, other primitives) takes the one-job launch path -- never a CPU
  * path.  Registered planes must not change until they are unregistered (the encoder's input pictures and completed

@@ -104,7 +104,12 @@ def test_hooked_reference_encoder_is_served_from_registered_pictures_and_writes_
     s = _served(err)
     print(case, concurrent, s)
     assert got == ref, f"{case}: the hooked encoder's stream differs from the reference encoder's"
-    assert s["pictures"] >= 4 and s["served"] > 0.4 * (s["served"] + s["one_job"]) and s["one_job"] > 0 and s["surfaces"] > 0 and s["satd_batches"] > 0, s
+    # round 5: the intra stage (every mode of a partition from one launch, its SATDs and forward transforms from one more), the intra candidates' chain
+    # (inverse transform + SSD computed with the de-quantiser call) and the inter blocks' two SSDs (with the inverse transform) are served as well:
+    # ~90 % of the table calls at speed=medium (what is left: the de-quantiser and the inter blocks' transform / inverse transform -- operands that come
+    # from the host's RDOQ -- bi-prediction, single-tile chroma SATDs); speed=slow adds residual-quadtree candidates
+    share = s["served"] / (s["served"] + s["one_job"])
+    assert s["pictures"] >= 4 and share > (0.8 if "slow" in case else 0.88) and s["one_job"] > 0 and s["surfaces"] > 0 and s["satd_batches"] > 0, (share, s)
     if concurrent == 4:
         _check_golden(case, got, workdir)          # --concurrent-frames 4 is the default the committed hashes were made with
 
@@ -123,7 +128,7 @@ def test_hooked_reference_encoder_on_the_mi355x(case, workdir):
     calls = s["served"] + s["one_job"]
     print(case, s, f"{dt:.1f} s, {dt / calls * 1e6:.2f} us per table call, {s['launches'] / et.CASES[case][2]:.0f} launches per frame")
     assert got == ref, f"{case}: the hooked encoder's stream on the MI355X differs from the reference encoder's"
-    assert s["served"] > 0.3 * calls and s["one_job"] > 0 and s["surfaces"] > 0 and s["satd_batches"] > 0, s      # 1 I + 2 B pictures: intra / TU calls (not served) dominate
+    assert s["served"] > 0.85 * calls and s["one_job"] > 0 and s["surfaces"] > 0 and s["satd_batches"] > 0, s      # round 5: intra stage and TU chains served too
     _check_golden(case, got, workdir)
 
 

@@ -156,7 +156,9 @@ def intra_neighbours(intra, w, h, bit_depth, dev):
     cols = 16
     rows = (len(sel) + cols - 1) // cols
     W, H = cols * T, rows * T
-    pic = np.zeros((H, W), dt)
+    PADG = 4                                                                          # (the C ABI wants a border of at least one sample)
+    full = np.zeros((H + 2 * PADG, W + 2 * PADG), dt)
+    pic = full[PADG:PADG + H, PADG:PADG + W]
     parts = np.zeros((len(sel), 4), np.int32)
     jobs = np.zeros((len(sel), 8), np.int32)
     for t, i in enumerate(sel):
@@ -170,11 +172,11 @@ def intra_neighbours(intra, w, h, bit_depth, dev):
         jobs[t, 1], jobs[t, 2] = 264 * (2 * t) + 132, 264 * (2 * t + 1) + 132      # nb_off / nbf_off: the arrays' middles
     owner = np.zeros((H // 4, W // 4), np.int32)                                      # every cell precedes the partitions (index 1): all samples available
     modes = np.ones((H // 4, W // 4), np.uint8)
-    layout = (C.c_int32 * 8)(W, H, W, 0, W // 4, bit_depth, 6, 1)
+    layout = (C.c_int32 * 8)(W, H, W + 2 * PADG, PADG, W // 4, bit_depth, 6, 1)
     nb = np.zeros(264 * 2 * len(sel) + 264, dt)
     mpm = np.zeros(len(sel), st.INTRA_CTX_DT)
     d = {}
-    for name, a in (("pic", pic), ("owner", owner), ("modes", modes), ("parts", parts), ("jobs", jobs), ("nb", nb), ("mpm", mpm)):
+    for name, a in (("pic", full), ("owner", owner), ("modes", modes), ("parts", parts), ("jobs", jobs), ("nb", nb), ("mpm", mpm)):
         d[name] = dev._alloc(a.nbytes)
         assert dev.dev.havoc_mi355x_h2d(dev.ctx, d[name], a.ctypes.data, a.nbytes) == 0
     vp = C.c_void_p

@@ -66,7 +66,8 @@ struct Binding
     std::vector<const PicList *> retired;            // old snapshots, freed with the binding
     havoc_mi355x_ctx *ctx = nullptr;                 // registration work (uploads, interpolation)
     std::atomic<int64_t> stat[8];
-    Binding() { for (auto &c : stat) c = 0; }
+    std::atomic<int64_t> oneJob[16];                 // one-job launches by entry point (HAVOC_CLASSIC_REPORT): see kOneJobNames
+    Binding() { for (auto &c : stat) c = 0; for (auto &c : oneJob) c = 0; }
 };
 
 Binding *g_binding = nullptr;                        // guarded by g_mu for creation / destruction
@@ -76,6 +77,19 @@ std::atomic<Binding *> g_live{nullptr};              // what table entries see
 inline void bump(int k, int64_t n = 1)
 {
     if (Binding *b = g_live.load(std::memory_order_relaxed)) b->stat[k].fetch_add(n, std::memory_order_relaxed);
+}
+enum { kSad, kSad4, kSsd, kSatd, kSsdLinear, kPredUni, kPredBi, kSubtractBi, kIntra, kTransform, kInverse, kInverseAdd, kDequant, kQuant, kQuantRec };
+const char *const kOneJobNames[15] = {"sad", "sad4", "ssd", "satd", "ssd_linear", "pred_uni", "pred_bi", "subtract_bi", "intra", "transform", "inverse_transform",
+                                      "inverse_transform_add", "quantize_inverse", "quantize", "quantize_reconstruct"};
+// a table call that took the one-job launch path
+inline void oneJob(int kind)
+{
+    if (Binding *b = g_live.load(std::memory_order_relaxed))
+    {
+        b->stat[1].fetch_add(1, std::memory_order_relaxed);
+        b->stat[2].fetch_add(1, std::memory_order_relaxed);
+        b->oneJob[kind].fetch_add(1, std::memory_order_relaxed);
+    }
 }
 
 // picture containing host pointer p (any byte of the padded plane), or null
@@ -254,12 +268,104 @@ struct SatdSet
     char *blockCopy = nullptr;
 };
 
+// ---- intra (round 5; turing/Search.hpp:113-142 -> Reconstruct.cpp:630-701, and the RD candidates' chain Reconstruct.cpp:230-353) ----
+// A partition's 35 predictIntraLuma calls read the same 4n + 1 reference samples (two arrays: unfiltered / filtered) and measure against the same source
+// block; its RD candidates predict from them again and run transform -> [RDOQ on the host] -> de-quantise -> inverse transform + add -> SSD.  Keyed on the
+// CONTENT of the array a call names: the first call predicts every mode from that array in one launch (35 modes + the edge-filtered forms of DC / 10 / 26);
+// the first SATD call of the partition measures every mode's tiles against the source block AND makes every mode's forward transform in one wait; the
+// de-quantiser call of a candidate also reconstructs it and takes its SSD (prediction and source are known on the device).  Every later call is a look-up
+// VALIDATED by content (the residual the transform is given, the coefficients and prediction the inverse transform is given, the reconstruction the SSD
+// is given): whatever the caller does differently simply misses and takes the one-job path.
+constexpr int kIntraSets = 4, kIntraSlots = 38;
+
+struct IntraSet
+{
+    bool valid = false;
+    int log2 = 0, bd = 0, S = 0, nslots = 0;
+    uint64_t stamp = 0;
+    char *nb = nullptr;                                 // pinned: the 4n + 1 samples the predictions were made from (the key)
+    char *pred = nullptr;                               // pinned: slot k = mode k (k < 35), 35 / 36 / 37 = modes 1 / 10 / 26 with the edge filter; n x n each
+    bool measured = false;                              // the 35-mode stage ran for this source block:
+    const char *srcHost = nullptr;                      // ... its host address and stride (the caller's picture)
+    intptr_t srcStride = 0;
+    int srcPicId = 0;
+    long srcOff = 0;                                    // ... and its sample offset in the picture's device plane
+    const char *srcDev = nullptr;
+    int32_t *satd = nullptr;                            // pinned [slot][tile]
+    int16_t *coef = nullptr;                            // pinned [slot][n * n]: forward transform of (source - prediction)
+};
+
+struct IntraMemo                                        // what this thread last wrote as an intra prediction
+{
+    bool valid = false;
+    const void *dst = nullptr;
+    intptr_t sd = 0;
+    IntraSet *set = nullptr;
+    int slot = 0;
+};
+
+struct ChainMemo                                        // what the de-quantiser call of an intra candidate computed ahead
+{
+    bool valid = false;
+    IntraSet *set = nullptr;
+    int slot = 0, tr = 0;
+    int16_t *deq = nullptr;                             // pinned: the de-quantised coefficients it returned
+    char *rec = nullptr;                                // pinned: prediction + inverse transform of them, n x n
+    uint32_t *ssd = nullptr;                            // pinned: havoc_ssd(source, rec)
+    const void *recDst = nullptr;                       // where inverse_transform_add was asked to put it (then an SSD call may follow)
+    intptr_t recSd = 0;
+};
+
+// the last inter prediction this thread made through a one-job launch (bi-prediction, chroma, unregistered references): its PU-SATD is asked for tile by
+// tile right after (Measure.h:97-135) -- the first tile call measures every tile of the block in one launch
+struct LastPred
+{
+    bool valid = false, measured = false;
+    const void *dst = nullptr;
+    intptr_t sd = 0;
+    int w = 0, h = 0, S = 0, n = 0;
+    const void *srcBlock = nullptr;                     // the source block the tiles were measured against
+    intptr_t srcStride = 0;
+    std::vector<char> copy;                             // the prediction as it was returned
+    std::vector<int32_t> tiles;
+};
+
+// the prediction of the last inverse_transform_add that took the launch path: an inter block's SSD(source, reconstruction) is followed by SSD(source, prediction)
+// (Reconstruct.cpp:849-856) -- both in the first one's launch
+struct SsdPair
+{
+    bool havePred = false, valid = false;
+    int n = 0, S = 0;
+    const void *pa = nullptr;
+    intptr_t sa = 0;
+    uint32_t value = 0;
+    std::vector<char> pred, src;
+};
+
+// An inter block's chain (Reconstruct.cpp:766-856): transform(residual) -> [RDOQ] -> de-quantise -> inverse_transform_add(pred) -> SSD(source, rec) -> SSD(source, pred).
+// The residual the transform was given is source - prediction, so when the inverse transform arrives with the prediction the source block is residual + prediction:
+// both SSDs are measured in the inverse transform's wait, and served when the blocks the SSD calls name hold exactly those samples.
+struct InterAhead
+{
+    bool haveRes = false, valid = false;
+    int resN = 0, n = 0, S = 0;
+    std::vector<int16_t> res;
+    std::vector<char> src, rec, pred;
+    uint32_t ssdRec = 0, ssdPred = 0;
+};
+
 struct Serve
 {
     bool ready = false;
+    LastPred last;
+    SsdPair pair;
+    InterAhead inter;
     Surface surf[kSurfaces];
     SatdSet sets[kSatdSets];
     PredMemo memo;
+    IntraSet intra[kIntraSets];
+    IntraMemo imemo;
+    ChainMemo chain;
     uint64_t clock = 0;
     char *jobsH = nullptr, *jobsD = nullptr;            // pinned job tables
     int32_t *denseH = nullptr;                          // pinned: results of a tile-SATD batch in job order
@@ -271,7 +377,9 @@ struct Serve
     void init(Stage &s)
     {
         if (ready) return;
-        const size_t total = kSurfaces * (kSurfBytes + kBlockBytes) + kSatdSets * (kSetBytes + kBlockBytes) + kJobBytes + kSetBytes + 8192;
+        constexpr size_t kIntraPred = size_t(kIntraSlots) * 32 * 32 * 2, kIntraSatd = size_t(kIntraSlots) * 16 * 4, kIntraNb = 512;
+        const size_t total = kSurfaces * (kSurfBytes + kBlockBytes) + kSatdSets * (kSetBytes + kBlockBytes) + kJobBytes + kSetBytes + 8192 +
+                             kIntraSets * (2 * kIntraPred + kIntraSatd + kIntraNb + 1024) + 3 * 32 * 32 * 2 + 2048;
         void *h_ = nullptr, *d_ = nullptr;
         CK(havoc_mi355x_host_alloc(s.ctx, total, &h_, &d_));
         baseH = static_cast<char *>(h_);
@@ -283,6 +391,16 @@ struct Serve
         jobsH = take(kJobBytes);
         jobsD = dev(jobsH);
         denseH = reinterpret_cast<int32_t *>(take(kSetBytes));
+        for (auto &f : intra)
+        {
+            f.nb = take(kIntraNb);
+            f.pred = take(kIntraPred);
+            f.coef = reinterpret_cast<int16_t *>(take(kIntraPred));
+            f.satd = reinterpret_cast<int32_t *>(take(kIntraSatd));
+        }
+        chain.deq = reinterpret_cast<int16_t *>(take(32 * 32 * 2));
+        chain.rec = take(32 * 32 * 2);
+        chain.ssd = reinterpret_cast<uint32_t *>(take(64));
         ready = true;
     }
     char *dev(const void *hostPtr) const { return baseD + (static_cast<const char *>(hostPtr) - baseH); }
@@ -523,6 +641,259 @@ bool serveSatd(const Sample *a, intptr_t sa, const Sample *b, intptr_t sb, int *
     return true;
 }
 
+// ---- intra prediction: every mode from the array the call names, one launch -- Reconstruct.cpp:244-246, 672-674
+template <typename Sample, int BD, int LOG2, bool EDGE>
+bool serveIntra(Sample *dst, intptr_t sd, const Sample *neighbours, int mode)
+{
+    constexpr int n = 1 << LOG2, len = 4 * n + 1;
+    if (mode < 0 || mode > 34 || (EDGE && mode != 1 && mode != 10 && mode != 26)) return false;
+    Stage &s = stage();
+    Serve &v = serve(s);
+    v.imemo.valid = false;
+    const Sample *arr = neighbours - (2 * n + 1);
+    IntraSet *f = nullptr;
+    for (auto &g : v.intra)
+        if (g.valid && g.log2 == LOG2 && g.bd == BD && g.S == int(sizeof(Sample)) && !memcmp(g.nb, arr, sizeof(Sample) * len)) { f = &g; break; }
+    if (!f)
+    {
+        f = &v.intra[0];
+        for (auto &g : v.intra)
+            if (!g.valid) { f = &g; break; }
+            else if (g.stamp < f->stamp) f = &g;
+        f->valid = false;
+        if (v.chain.set == f) v.chain.valid = false;
+        memcpy(f->nb, arr, sizeof(Sample) * len);
+        havoc_mi355x_intra_job *jobs = reinterpret_cast<havoc_mi355x_intra_job *>(v.jobsH);
+        const int nslots = LOG2 < 5 ? kIntraSlots : 35;      // the edge filters exist below 32x32 only (havoc/pred_intra.h:41-48)
+        static const int edgeMode[3] = {1, 10, 26};
+        for (int k = 0; k < nslots; ++k) jobs[k] = {k * n * n, 2 * n + 1, LOG2, k < 35 ? k : edgeMode[k - 35], k < 35 ? 0 : 1, {0, 0, 0}};
+        CK(havoc_mi355x_intra(s.ctx, sizeof(Sample), BD, LOG2, v.dev(f->pred), n, v.dev(f->nb), reinterpret_cast<const havoc_mi355x_intra_job *>(v.jobsD), nslots));
+        CK(havoc_mi355x_sync(s.ctx));
+        bump(2);
+        f->valid = true;
+        f->log2 = LOG2; f->bd = BD; f->S = sizeof(Sample); f->nslots = nslots;
+        f->measured = false;
+    }
+    f->stamp = ++v.clock;
+    const int slot = EDGE ? (mode == 1 ? 35 : mode == 10 ? 36 : 37) : mode;
+    if (slot >= f->nslots) return false;
+    const Sample *from = reinterpret_cast<const Sample *>(f->pred) + slot * n * n;
+    for (int y = 0; y < n; ++y) memcpy(dst + y * sd, from + y * n, sizeof(Sample) * n);
+    v.imemo = IntraMemo{true, dst, sd, f, slot};
+    bump(0);
+    return true;
+}
+
+// ---- havoc_hadamard_satd of (source tile, tile of the intra prediction this thread just made): every mode's tiles in one launch, and every mode's forward
+// transform with it -- Reconstruct.cpp:684-701, 258-273
+template <typename Sample, int N>
+bool serveIntraSatd(const Sample *a, intptr_t sa, const Sample *b, intptr_t sb, int *out)
+{
+    Stage &s = stage();
+    Serve &v = serve(s);
+    const IntraMemo &m = v.imemo;
+    if (!m.valid || sb != m.sd || m.set->S != int(sizeof(Sample))) return false;
+    IntraSet *f = m.set;
+    const int n = 1 << f->log2;
+    if (N != (f->log2 == 2 ? 4 : 8)) return false;
+    const long off = b - static_cast<const Sample *>(m.dst);
+    if (off < 0) return false;
+    const int ty = int(off / m.sd), tx = int(off - (long)ty * m.sd);
+    if (tx >= n || ty >= n || (tx % N) || (ty % N)) return false;
+    const Sample *pred = reinterpret_cast<const Sample *>(f->pred) + m.slot * n * n;
+    for (int r = 0; r < N; ++r)      // the prediction must still be what was served (the caller owns that buffer)
+        if (memcmp(b + r * sb, pred + (ty + r) * n + tx, sizeof(Sample) * N)) return false;
+    const Sample *block = a - (long)ty * sa - tx;
+    if (!f->measured || f->srcHost != reinterpret_cast<const char *>(block) || f->srcStride != sa)
+    {
+        const Pic *q = findPic(block);
+        if (!q || q->S != int(sizeof(Sample)) || q->stride != sa) return false;
+        int x, y;
+        locate(q, block, &x, &y);
+        if (x < -q->pad || y < -q->pad || x + n > q->w + q->pad || y + n > q->h + q->pad) return false;
+        const long so = (long)(y + q->pad) * q->stride + x + q->pad;
+        const int tiles = (n / N) * (n / N), tilesX = n / N;
+        havoc_mi355x_pair_job *jobs = reinterpret_cast<havoc_mi355x_pair_job *>(v.jobsH);
+        int nj = 0;
+        for (int k = 0; k < f->nslots; ++k)
+            for (int t = 0; t < tiles; ++t)
+            {
+                const int px = (t % tilesX) * N, py = (t / tilesX) * N;
+                jobs[nj++] = {int32_t(so + (long)py * q->stride + px), int32_t(k * n * n + py * n + px), N, N};
+            }
+        CK(havoc_mi355x_satd(s.ctx, sizeof(Sample), N, N, q->d_plane, q->stride, v.dev(f->pred), n, reinterpret_cast<const havoc_mi355x_pair_job *>(v.jobsD), nj,
+                             reinterpret_cast<int32_t *>(v.dev(f->satd))));
+        // every mode's residual + forward transform (luma: DST for 4x4 -- Reconstruct.cpp:263): what the candidates' `transform` calls will ask for
+        constexpr size_t kTuAt = 16384;
+        havoc_mi355x_tu_fused_job *tj = reinterpret_cast<havoc_mi355x_tu_fused_job *>(v.jobsH + kTuAt);
+        for (int k = 0; k < f->nslots; ++k) tj[k] = {k * n * n, int32_t(so), k * n * n, 0};
+        CK(havoc_mi355x_tu_forward(s.ctx, sizeof(Sample), f->bd, f->log2 == 2 ? 1 : 0, f->log2, reinterpret_cast<int16_t *>(v.dev(f->coef)), q->d_plane, q->stride,
+                                   v.dev(f->pred), n, reinterpret_cast<const havoc_mi355x_tu_fused_job *>(v.jobsD + kTuAt), f->nslots));
+        CK(havoc_mi355x_sync(s.ctx));
+        bump(2, 2);
+        f->measured = true;
+        f->srcHost = reinterpret_cast<const char *>(block);
+        f->srcStride = sa;
+        f->srcPicId = q->id;
+        f->srcOff = so;
+        f->srcDev = q->d_plane;
+        if (v.chain.set == f) v.chain.valid = false;
+    }
+    const int tilesX = n / N;
+    *out = f->satd[m.slot * tilesX * tilesX + (ty / N) * tilesX + tx / N];
+    bump(0);
+    return true;
+}
+
+// ---- the forward transform of an intra candidate: made with the 35-mode stage; served when the residual handed in IS source - prediction
+template <int BITDEPTH, int LOG2, int TR>
+bool serveForward(int16_t *coeffs, const int16_t *res, intptr_t stride)
+{
+    constexpr int n = 1 << LOG2;
+    Stage &s = stage();
+    Serve &v = serve(s);
+    const IntraMemo &m = v.imemo;
+    if (!m.valid) return false;
+    const IntraSet *f = m.set;
+    if (!f->measured || f->log2 != LOG2 || f->bd != BITDEPTH || TR != (LOG2 == 2 ? 1 : 0)) return false;
+    for (int y = 0; y < n; ++y)
+        for (int x = 0; x < n; ++x)
+        {
+            const int p = f->S == 1 ? reinterpret_cast<const uint8_t *>(f->pred)[m.slot * n * n + y * n + x] : reinterpret_cast<const uint16_t *>(f->pred)[m.slot * n * n + y * n + x];
+            const int o = f->S == 1 ? reinterpret_cast<const uint8_t *>(f->srcHost)[y * f->srcStride + x] : reinterpret_cast<const uint16_t *>(f->srcHost)[y * f->srcStride + x];
+            if (res[y * stride + x] != int16_t(o - p)) return false;
+        }
+    memcpy(coeffs, f->coef + m.slot * n * n, sizeof(int16_t) * n * n);
+    bump(0);
+    return true;
+}
+
+// ---- de-quantise (always a launch: its input comes from the host's RDOQ) -- and, for an intra candidate whose prediction and source block are on the device,
+// inverse transform + add + SSD in the same wait (Reconstruct.cpp:314-353)
+inline void chainAhead(Stage &s, Serve &v, const char *dLevels, int scale, int shift, int n2)
+{
+    v.chain.valid = false;
+    const IntraMemo &m = v.imemo;
+    if (!m.valid || !m.set->measured) return;
+    IntraSet *f = m.set;
+    const int n = 1 << f->log2;
+    if (n2 != n * n) return;
+    havoc_mi355x_tu_fused_job *tj = reinterpret_cast<havoc_mi355x_tu_fused_job *>(v.jobsH);
+    tj[0] = {0, int32_t(f->srcOff), m.slot * n * n, 0};
+    const int tr = f->log2 == 2 ? 1 : 0;
+    CK(havoc_mi355x_tu_reconstruct(s.ctx, f->S, f->bd, tr, f->log2, scale, shift, v.dev(v.chain.rec), n, v.dev(f->pred), n, f->srcDev, f->srcStride,
+                                   reinterpret_cast<const int16_t *>(dLevels), reinterpret_cast<const havoc_mi355x_tu_fused_job *>(v.jobsD), 1,
+                                   reinterpret_cast<uint32_t *>(v.dev(v.chain.ssd))));
+    bump(2);
+    v.chain.valid = true;
+    v.chain.set = f;
+    v.chain.slot = m.slot;
+    v.chain.tr = tr;
+    v.chain.recDst = nullptr;
+}
+
+template <typename Sample, int LOG2, int TR>
+bool serveInverseAdd(Sample *dst, intptr_t sd, const Sample *pred, intptr_t sp, const int16_t *coeffs, int bitDepth)
+{
+    constexpr int n = 1 << LOG2;
+    Stage &s = stage();
+    Serve &v = serve(s);
+    ChainMemo &c = v.chain;
+    if (!c.valid) return false;
+    const IntraSet *f = c.set;
+    if (!f->valid || f->log2 != LOG2 || f->S != int(sizeof(Sample)) || f->bd != bitDepth || c.tr != TR) return false;
+    if (memcmp(coeffs, c.deq, sizeof(int16_t) * n * n)) return false;
+    const Sample *want = reinterpret_cast<const Sample *>(f->pred) + c.slot * n * n;
+    for (int y = 0; y < n; ++y)
+        if (memcmp(pred + y * sp, want + y * n, sizeof(Sample) * n)) return false;
+    const Sample *rec = reinterpret_cast<const Sample *>(c.rec);
+    for (int y = 0; y < n; ++y) memcpy(dst + y * sd, rec + y * n, sizeof(Sample) * n);      // (pred may alias dst: compared above, before this)
+    c.recDst = dst;
+    c.recSd = sd;
+    bump(0);
+    return true;
+}
+
+template <typename Sample>
+bool serveSsd(const Sample *pa, intptr_t sa, const Sample *pb, intptr_t sb, int w, int h, uint32_t *out)
+{
+    Stage &s = stage();
+    Serve &v = serve(s);
+    const ChainMemo &c = v.chain;
+    if (!c.valid || c.recDst != pb || c.recSd != sb) return false;
+    const IntraSet *f = c.set;
+    const int n = 1 << f->log2;
+    if (w != n || h != n || f->S != int(sizeof(Sample)) || reinterpret_cast<const char *>(pa) != f->srcHost || sa != f->srcStride) return false;
+    const Sample *rec = reinterpret_cast<const Sample *>(c.rec);
+    for (int y = 0; y < n; ++y)
+        if (memcmp(pb + y * sb, rec + y * n, sizeof(Sample) * n)) return false;
+    *out = *c.ssd;
+    bump(0);
+    return true;
+}
+
+template <typename Sample>
+void rememberPrediction(const Sample *dst, intptr_t sd, int w, int h)
+{
+    Serve &v = serve(stage());
+    LastPred &l = v.last;
+    l.valid = true;
+    l.measured = false;
+    l.dst = dst; l.sd = sd; l.w = w; l.h = h; l.S = sizeof(Sample);
+    l.copy.resize(sizeof(Sample) * size_t(w) * h);
+    for (int y = 0; y < h; ++y) memcpy(&l.copy[sizeof(Sample) * size_t(y) * w], dst + y * sd, sizeof(Sample) * w);
+}
+
+// every tile of the PU in the first tile's launch; false = not this pattern (the caller takes the one-job path)
+template <typename Sample, int N>
+bool serveTileSatd(const Sample *a, intptr_t sa, const Sample *b, intptr_t sb, int *out)
+{
+    Stage &s = stage();
+    Serve &v = serve(s);
+    LastPred &l = v.last;
+    if (!l.valid || l.S != int(sizeof(Sample)) || sb != l.sd) return false;
+    const long off = b - static_cast<const Sample *>(l.dst);
+    if (off < 0) return false;
+    const int ty = int(off / l.sd), tx = int(off - (long)ty * l.sd);
+    if (tx >= l.w || ty >= l.h || (tx % N) || (ty % N) || (l.w % N) || (l.h % N)) return false;
+    const Sample *pred = reinterpret_cast<const Sample *>(l.copy.data());
+    for (int r = 0; r < N; ++r)
+        if (memcmp(b + r * sb, pred + (ty + r) * l.w + tx, sizeof(Sample) * N)) return false;
+    const Sample *block = a - (long)ty * sa - tx;
+    const int tilesX = l.w / N, ntiles = tilesX * (l.h / N);
+    if (!l.measured || l.n != N || l.srcBlock != block || l.srcStride != sa)
+    {
+        // the whole source block must be the caller's to read: a registered picture says so
+        const Pic *q = findPic(block);
+        if (!q || q->S != int(sizeof(Sample)) || q->stride != sa || ntiles < 2 || ntiles > 256) return false;
+        int x, y;
+        locate(q, block, &x, &y);
+        if (x < -q->pad || y < -q->pad || x + l.w > q->w + q->pad || y + l.h > q->h + q->pad) return false;
+        const size_t j = s.reserve(sizeof(havoc_mi355x_pair_job) * ntiles), o = s.reserve(4 * size_t(ntiles));
+        const size_t pb = s.pack(pred, l.w, l.w, l.h, l.w);
+        havoc_mi355x_pair_job *jobs = s.job<havoc_mi355x_pair_job>(j);
+        const long so = (long)(y + q->pad) * q->stride + x + q->pad;
+        for (int t = 0; t < ntiles; ++t)
+        {
+            const int px = (t % tilesX) * N, py = (t / tilesX) * N;
+            jobs[t] = {int32_t(so + (long)py * q->stride + px), int32_t(py * l.w + px), N, N};
+        }
+        s.upload();
+        CK(havoc_mi355x_satd(s.ctx, sizeof(Sample), N, N, q->d_plane, q->stride, s.d + pb, l.w, s.djob<havoc_mi355x_pair_job>(j), ntiles, (int32_t *)(s.d + o)));
+        s.download(o, 4 * size_t(ntiles));
+        l.tiles.assign(reinterpret_cast<int32_t *>(&s.h[o]), reinterpret_cast<int32_t *>(&s.h[o]) + ntiles);
+        l.measured = true;
+        l.n = N;
+        l.srcBlock = block;
+        l.srcStride = sa;
+        bump(2);
+        bump(4);
+    }
+    *out = l.tiles[(ty / N) * tilesX + tx / N];
+    bump(0);
+    return true;
+}
+
 // ---- distortion metrics ---------------------------------------------------------------------------------------
 
 template <typename Sample>
@@ -532,8 +903,7 @@ int sad(const Sample *src, intptr_t ss, const Sample *ref, intptr_t rs, uint32_t
     int served;
     if (serveSad<Sample>(src, ss, &ref, 1, rs, w, h, &served)) return served;
     Stage &s = stage();
-    bump(1);
-    bump(2);
+    oneJob(kSad);
     const size_t j = s.reserve(sizeof(havoc_mi355x_pair_job)), o = s.reserve(4);
     const size_t a = s.pack(src, ss, w, h, w), b = s.pack(ref, rs, w, h, w);
     *s.job<havoc_mi355x_pair_job>(j) = {0, 0, w, h};
@@ -549,8 +919,7 @@ void sad4(const Sample *src, intptr_t ss, const Sample *ref[], intptr_t rs, int 
     const int w = rect >> 8, h = rect & 0xff;
     if (serveSad<Sample>(src, ss, ref, 4, rs, w, h, out)) return;
     Stage &s = stage();
-    bump(1);
-    bump(2);
+    oneJob(kSad4);
     const size_t j = s.reserve(sizeof(havoc_mi355x_sad4_job)), o = s.reserve(16);
     const size_t a = s.pack(src, ss, w, h, w);
     size_t b[4];
@@ -567,15 +936,63 @@ void sad4(const Sample *src, intptr_t ss, const Sample *ref[], intptr_t rs, int 
 template <typename Sample>
 uint32_t ssd(const Sample *pa, intptr_t sa, const Sample *pb, intptr_t sb, int w, int h)
 {
+    uint32_t served;
+    if (serveSsd<Sample>(pa, sa, pb, sb, w, h, &served)) return served;
     Stage &s = stage();
-    bump(1);
-    bump(2);
-    const size_t j = s.reserve(sizeof(havoc_mi355x_pair_job)), o = s.reserve(4);
+    {
+        const InterAhead &ia = serve(s).inter;
+        if (ia.valid && w == ia.n && h == ia.n && ia.S == int(sizeof(Sample)))
+        {
+            auto equal = [&](const Sample *q, intptr_t st, const std::vector<char> &want) {
+                for (int y = 0; y < h; ++y)
+                    if (memcmp(q + y * st, &want[sizeof(Sample) * size_t(y) * w], sizeof(Sample) * w)) return false;
+                return true;
+            };
+            if (equal(pa, sa, ia.src))
+            {
+                if (equal(pb, sb, ia.rec)) { bump(0); return ia.ssdRec; }
+                if (equal(pb, sb, ia.pred)) { bump(0); return ia.ssdPred; }
+            }
+        }
+    }
+    SsdPair &pr = serve(s).pair;
+    const size_t bytes = sizeof(Sample) * size_t(w) * h;
+    if (pr.valid && pr.pa == pa && pr.sa == sa && w == pr.n && h == pr.n && pr.S == int(sizeof(Sample)))
+    {   // the second SSD of an inter block: the same source block against the prediction its reconstruction was made from
+        bool same = true;
+        for (int y = 0; y < h && same; ++y)
+            same = !memcmp(pb + y * sb, &pr.pred[sizeof(Sample) * size_t(y) * w], sizeof(Sample) * w) && !memcmp(pa + y * sa, &pr.src[sizeof(Sample) * size_t(y) * w], sizeof(Sample) * w);
+        pr.valid = false;
+        if (same)
+        {
+            bump(0);
+            return pr.value;
+        }
+    }
+    oneJob(kSsd);
+    const bool two = pr.havePred && w == pr.n && h == pr.n && pr.S == int(sizeof(Sample));
+    const size_t j = s.reserve(2 * sizeof(havoc_mi355x_pair_job)), o = s.reserve(8);
     const size_t a = s.pack(pa, sa, w, h, w), b = s.pack(pb, sb, w, h, w);
-    *s.job<havoc_mi355x_pair_job>(j) = {0, 0, w, h};
+    havoc_mi355x_pair_job *jobs = s.job<havoc_mi355x_pair_job>(j);
+    jobs[0] = {0, 0, w, h};
+    if (two)
+    {
+        const size_t c = s.pack(reinterpret_cast<const Sample *>(pr.pred.data()), w, w, h, w);
+        jobs = s.job<havoc_mi355x_pair_job>(j);      // (the staging buffer may have moved)
+        jobs[1] = {0, int32_t((c - b) / sizeof(Sample)), w, h};
+    }
     s.upload();
-    CK(havoc_mi355x_ssd(s.ctx, sizeof(Sample), s.d + a, w, s.d + b, w, s.djob<havoc_mi355x_pair_job>(j), 1, (uint32_t *)(s.d + o)));
-    s.download(o, 4);
+    CK(havoc_mi355x_ssd(s.ctx, sizeof(Sample), s.d + a, w, s.d + b, w, s.djob<havoc_mi355x_pair_job>(j), two ? 2 : 1, (uint32_t *)(s.d + o)));
+    s.download(o, 8);
+    pr.havePred = false;
+    if (two)
+    {
+        pr.valid = true;
+        pr.pa = pa; pr.sa = sa;
+        pr.value = reinterpret_cast<uint32_t *>(&s.h[o])[1];
+        pr.src.resize(bytes);
+        for (int y = 0; y < h; ++y) memcpy(&pr.src[sizeof(Sample) * size_t(y) * w], pa + y * sa, sizeof(Sample) * w);
+    }
     return *reinterpret_cast<uint32_t *>(&s.h[o]);
 }
 
@@ -584,9 +1001,10 @@ int satd(const Sample *pa, intptr_t sa, const Sample *pb, intptr_t sb)
 {
     int served;
     if (serveSatd<Sample, N>(pa, sa, pb, sb, &served)) return served;
+    if (serveIntraSatd<Sample, N>(pa, sa, pb, sb, &served)) return served;
+    if (serveTileSatd<Sample, N>(pa, sa, pb, sb, &served)) return served;
     Stage &s = stage();
-    bump(1);
-    bump(2);
+    oneJob(kSatd);
     const size_t j = s.reserve(sizeof(havoc_mi355x_pair_job)), o = s.reserve(4);
     const size_t a = s.pack(pa, sa, N, N, N), b = s.pack(pb, sb, N, N, N);
     *s.job<havoc_mi355x_pair_job>(j) = {0, 0, N, N};
@@ -599,6 +1017,7 @@ int satd(const Sample *pa, intptr_t sa, const Sample *pb, intptr_t sb)
 int ssdLinear(const uint8_t *a, const uint8_t *b, int size)
 {
     Stage &s = stage();
+    oneJob(kSsdLinear);
     const size_t o = s.reserve(4);
     const size_t pa = s.pack(a, 0, size, 1, size), pb = s.pack(b, 0, size, 1, size);
     s.upload();
@@ -634,8 +1053,7 @@ void predUni(Sample *dst, intptr_t sd, const Sample *ref, intptr_t sr, int w, in
 {
     if (TAPS == 8 && servePredUni<Sample>(dst, sd, ref, sr, w, h, xFrac, yFrac, bitDepth)) return;
     Stage &s = stage();
-    bump(1);
-    bump(2);
+    oneJob(kPredUni);
     const size_t j = s.reserve(sizeof(havoc_mi355x_pred_uni_job));
     int pitch, origin;
     const size_t win = packWindow(s, ref, sr, w, h, TAPS, xFrac, yFrac, &pitch, &origin);
@@ -644,6 +1062,7 @@ void predUni(Sample *dst, intptr_t sd, const Sample *ref, intptr_t sr, int w, in
     s.upload();
     CK(havoc_mi355x_pred_uni(s.ctx, sizeof(Sample), TAPS, bitDepth, w, h, s.d + out, w, s.d + win, pitch, s.djob<havoc_mi355x_pred_uni_job>(j), 1));
     s.unpack(dst, sd, w, h, w, out);
+    rememberPrediction(dst, sd, w, h);
 }
 
 template <typename Sample, int TAPS>
@@ -651,6 +1070,7 @@ void predBi(Sample *dst, intptr_t sd, const Sample *ref0, const Sample *ref1, in
             int bitDepth)
 {
     Stage &s = stage();
+    oneJob(kPredBi);
     const size_t j = s.reserve(sizeof(havoc_mi355x_pred_bi_job));
     int pitch, origin;
     const size_t w0 = packWindow(s, ref0, sr, w, h, TAPS, xFrac0, yFrac0, &pitch, &origin);
@@ -661,12 +1081,14 @@ void predBi(Sample *dst, intptr_t sd, const Sample *ref0, const Sample *ref1, in
     s.upload();
     CK(havoc_mi355x_pred_bi(s.ctx, sizeof(Sample), TAPS, bitDepth, w, h, s.d + out, w, s.d + w0, pitch, s.djob<havoc_mi355x_pred_bi_job>(j), 1));
     s.unpack(dst, sd, w, h, w, out);
+    rememberPrediction(dst, sd, w, h);
 }
 
 template <typename Sample>
 void subtractBi(Sample *dst, intptr_t sd, const Sample *pred, intptr_t sp, const Sample *src, intptr_t ss, int w, int h, int bitDepth)
 {
     Stage &s = stage();
+    oneJob(kSubtractBi);
     const size_t j = s.reserve(sizeof(havoc_mi355x_subtract_bi_job));
     const size_t p = s.pack(pred, sp, w, h, w), q = s.pack(src, ss, w, h, w);
     const size_t out = s.reserve(sizeof(Sample) * size_t(w) * h);
@@ -682,7 +1104,9 @@ template <typename Sample, int BITDEPTH, int LOG2, bool EDGE>
 void intraPredict(Sample *dst, intptr_t sd, const Sample *neighbours, int mode)
 {
     constexpr int n = 1 << LOG2;
+    if (serveIntra<Sample, BITDEPTH, LOG2, EDGE>(dst, sd, neighbours, mode)) return;
     Stage &s = stage();
+    oneJob(kIntra);
     const size_t j = s.reserve(sizeof(havoc_mi355x_intra_job));
     const size_t nb = s.pack(neighbours - 2 * n - 1, 0, 4 * n + 1, 1, 4 * n + 1);
     const size_t out = s.reserve(sizeof(Sample) * n * n);
@@ -698,7 +1122,18 @@ template <int BITDEPTH, int LOG2, int TR>
 void forwardTransform(int16_t *coeffs, const int16_t *src, intptr_t stride)
 {
     constexpr int n = 1 << LOG2;
+    if (serveForward<BITDEPTH, LOG2, TR>(coeffs, src, stride)) return;
     Stage &s = stage();
+    oneJob(kTransform);
+    serve(s).imemo.valid = false;      // not the residual of the intra prediction last served: the de-quantiser call that follows is not that candidate's
+    {
+        InterAhead &ia = serve(s).inter;
+        ia.haveRes = true;
+        ia.valid = false;
+        ia.resN = n;
+        ia.res.resize(n * n);
+        for (int y = 0; y < n; ++y) memcpy(&ia.res[y * n], src + y * stride, sizeof(int16_t) * n);
+    }
     const size_t j = s.reserve(sizeof(havoc_mi355x_tu_job));
     const size_t r = s.pack(src, stride, n, n, n);
     const size_t out = s.reserve(2 * n * n);
@@ -714,6 +1149,7 @@ void inverseTransform(int16_t dst[], int16_t const coeffs[], int bitDepth)
 {
     constexpr int n = 1 << LOG2;
     Stage &s = stage();
+    oneJob(kInverse);
     const size_t j = s.reserve(sizeof(havoc_mi355x_tu_job));
     const size_t c = s.pack(coeffs, 0, n * n, 1, n * n);
     const size_t out = s.reserve(2 * n * n);
@@ -728,34 +1164,93 @@ template <typename Sample, int LOG2, int TR>
 void inverseTransformAdd(Sample *dst, intptr_t sd, Sample const *pred, intptr_t sp, int16_t const coeffs[], int bitDepth)
 {
     constexpr int n = 1 << LOG2;
+    if (serveInverseAdd<Sample, LOG2, TR>(dst, sd, pred, sp, coeffs, bitDepth)) return;
     Stage &s = stage();
-    const size_t j = s.reserve(sizeof(havoc_mi355x_tu_job));
+    oneJob(kInverseAdd);
+    {   // (before dst is written: pred may alias it) the prediction, for the SSD(source, prediction) that follows SSD(source, reconstruction)
+        SsdPair &pr = serve(s).pair;
+        pr.havePred = true;
+        pr.valid = false;
+        pr.n = n; pr.S = sizeof(Sample);
+        pr.pred.resize(sizeof(Sample) * n * n);
+        for (int y = 0; y < n; ++y) memcpy(&pr.pred[sizeof(Sample) * size_t(y) * n], pred + y * sp, sizeof(Sample) * n);
+    }
+    InterAhead &ia = serve(s).inter;
+    ia.valid = false;
+    bool ahead = ia.haveRes && ia.resN == n;
+    if (ahead)
+    {   // the source block this residual was taken against: residual + prediction (no clipping happened if every sum is a sample)
+        ia.src.resize(sizeof(Sample) * n * n);
+        Sample *sp_ = reinterpret_cast<Sample *>(ia.src.data());
+        const int maxv = (1 << bitDepth) - 1;
+        for (int y = 0; y < n && ahead; ++y)
+            for (int x = 0; x < n; ++x)
+            {
+                const int v = int(pred[y * sp + x]) + ia.res[y * n + x];
+                if (v < 0 || v > maxv) { ahead = false; break; }
+                sp_[y * n + x] = Sample(v);
+            }
+    }
+    ia.haveRes = false;
+    const size_t j = s.reserve(sizeof(havoc_mi355x_tu_job)), j2 = s.reserve(2 * sizeof(havoc_mi355x_pair_job)), o2 = s.reserve(8);
     const size_t c = s.pack(coeffs, 0, n * n, 1, n * n);
     const size_t p = s.pack(pred, sp, n, n, n);       // staged before dst is written: pred may alias dst
     const size_t out = s.reserve(sizeof(Sample) * n * n);
+    const size_t so = ahead ? s.pack(reinterpret_cast<const Sample *>(ia.src.data()), n, n, n, n) : 0;
     *s.job<havoc_mi355x_tu_job>(j) = {0, 0, 0, 0};
+    if (ahead)
+    {
+        havoc_mi355x_pair_job *pj = s.job<havoc_mi355x_pair_job>(j2);
+        pj[0] = {0, int32_t((long)(out - p) / (long)sizeof(Sample)), n, n};      // (source', reconstruction): b offsets are relative to the prediction's staging place
+        pj[1] = {0, 0, n, n};                                                     // (source', prediction)
+    }
     s.upload();
     CK(havoc_mi355x_inverse_transform_add(s.ctx, sizeof(Sample), bitDepth, TR, LOG2, s.d + out, n, s.d + p, n, (const int16_t *)(s.d + c),
                                           s.djob<havoc_mi355x_tu_job>(j), 1));
+    if (ahead)
+    {
+        CK(havoc_mi355x_ssd(s.ctx, sizeof(Sample), s.d + so, n, s.d + p, n, s.djob<havoc_mi355x_pair_job>(j2), 2, (uint32_t *)(s.d + o2)));
+        bump(2);
+    }
+    if (ahead)
+    {
+        ia.pred.resize(sizeof(Sample) * n * n);
+        for (int y = 0; y < n; ++y) memcpy(&ia.pred[sizeof(Sample) * size_t(y) * n], pred + y * sp, sizeof(Sample) * n);
+    }
     s.unpack(dst, sd, n, n, n, out);
+    if (ahead)
+    {
+        s.download(o2, 8);
+        ia.ssdRec = reinterpret_cast<uint32_t *>(&s.h[o2])[0];
+        ia.ssdPred = reinterpret_cast<uint32_t *>(&s.h[o2])[1];
+        ia.rec.assign(&s.h[out], &s.h[out] + sizeof(Sample) * n * n);
+        ia.n = n;
+        ia.S = sizeof(Sample);
+        ia.valid = true;
+    }
 }
 
 void quantizeInverse(int16_t *dst, const int16_t *src, int scale, int shift, int n)
 {
     Stage &s = stage();
+    Serve &v = serve(s);
+    oneJob(kDequant);
     const size_t j = s.reserve(sizeof(havoc_mi355x_quant_job));
     const size_t in = s.pack(src, 0, n, 1, n);
     const size_t out = s.reserve(2 * n);
     *s.job<havoc_mi355x_quant_job>(j) = {0, 0, n, scale, shift, 0, {0, 0}};
     s.upload();
     CK(havoc_mi355x_quantize_inverse(s.ctx, (int16_t *)(s.d + out), (const int16_t *)(s.d + in), s.djob<havoc_mi355x_quant_job>(j), 1));
+    chainAhead(s, v, s.d + in, scale, shift, n);      // an intra candidate: its reconstruction and SSD in the same wait
     s.download(out, 2 * n);
     memcpy(dst, &s.h[out], 2 * n);
+    if (v.chain.valid) memcpy(v.chain.deq, &s.h[out], 2 * n);
 }
 
 int quantize(int16_t *dst, const int16_t *src, int scale, int shift, int offset, int n)
 {
     Stage &s = stage();
+    oneJob(kQuant);
     const size_t j = s.reserve(sizeof(havoc_mi355x_quant_job)), cbf = s.reserve(4);
     const size_t in = s.pack(src, 0, n, 1, n);
     const size_t out = s.reserve(2 * n);
@@ -772,6 +1267,7 @@ template <int LOG2>
 void quantizeReconstruct(uint8_t *rec, intptr_t sr, const uint8_t *pred, intptr_t sp, const int16_t *res, int n)
 {
     Stage &s = stage();
+    oneJob(kQuantRec);
     const size_t j = s.reserve(sizeof(havoc_mi355x_tu_job));
     const size_t p = s.pack(pred, sp, n, n, n), r = s.pack(res, 0, n * n, 1, n * n);
     const size_t out = s.reserve(size_t(n) * n);
@@ -868,6 +1364,13 @@ void havoc_delete_code(havoc_code code)
     if (getenv("HAVOC_CLASSIC_REPORT"))
         fprintf(stderr, "libhavoc_classic: table calls served %lld, one-job launches %lld, launches %lld, surfaces %lld, tile-SATD batches %lld, pictures %lld\n",
                 (long long)b->stat[0], (long long)b->stat[1], (long long)b->stat[2], (long long)b->stat[3], (long long)b->stat[4], (long long)b->stat[5]);
+    if (getenv("HAVOC_CLASSIC_REPORT"))
+    {
+        fprintf(stderr, "libhavoc_classic: one-job launches by entry point:");
+        for (int k = 0; k < 15; ++k)
+            if (b->oneJob[k].load()) fprintf(stderr, " %s %lld", kOneJobNames[k], (long long)b->oneJob[k].load());
+        fprintf(stderr, "\n");
+    }
     g_live.store(nullptr, std::memory_order_release);
     // device memory of the pictures still registered; per-thread contexts are left to process exit (see Stage)
     if (const PicList *l = b->pics.load())

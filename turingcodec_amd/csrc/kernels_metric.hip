@@ -421,7 +421,9 @@ __device__ __forceinline__ void sad4_run_calls(const __attribute__((address_spac
             {
                 if (CB == 16)
                 {
-                    const uint32_t a0 = srcw[sp], a1 = srcw[sp + 1], a2 = srcw[sp + 2], a3 = srcw[sp + 3];
+                    // (one ds_read_b128: the source rows are dense and 16-byte aligned; four dword reads at a 16-byte lane pitch would be 4-way bank conflicts)
+                    const u32x4 av = *reinterpret_cast<const __attribute__((address_space(3))) u32x4 *>(srcw + sp);
+                    const uint32_t a0 = av.x, a1 = av.y, a2 = av.z, a3 = av.w;
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
                     {
@@ -435,7 +437,8 @@ __device__ __forceinline__ void sad4_run_calls(const __attribute__((address_spac
                 }
                 else if (CB == 8)
                 {
-                    const uint32_t a0 = srcw[sp], a1 = srcw[sp + 1];
+                    const u32x2 av = *reinterpret_cast<const __attribute__((address_space(3))) u32x2 *>(srcw + sp);
+                    const uint32_t a0 = av.x, a1 = av.y;
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
                     {
