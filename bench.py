@@ -153,7 +153,8 @@ class DeviceFrame:
         self.cbi = z(len(wl.bi4) * 1024 + 1024, dt)     # chroma bi predictions: own slots (32 x 32, stride 32)
         self.sbi = z(len(wl.subtract_bi) * 4096, dt)
         self.j_sad4, self.j_sad = up(wl.sad4), up(wl.sad)
-        self.j_runs = up(hv.sad4_make_runs(wl.sad4)) if sad4_runs and len(wl.sad4) else None      # the calls of a search follow each other in the table: one run each
+        # the calls of a search follow each other in the table: the host cutter makes them runs (boxes of their candidates; lengths by block size)
+        self.j_runs = up(hv.sad4_make_runs(wl.sad4, 0, wl.stride, wl.S)) if sad4_runs and len(wl.sad4) else None
         self.o_sad4, self.o_sad = z(4 * len(wl.sad4), np.int32), z(len(wl.sad), np.int32)
         if ime_range is not None:   # integer ME from SAD surfaces: one (2R+1)^2 surface per search instead of SAD4 jobs
             side = 2 * ime_range + 1
@@ -987,6 +988,9 @@ def parity_problems(out):
                 bad.append("primitive parity could not be checked: " + str(pv["error"])[:200])
             elif pv.get("mismatches"):
                 bad.append(f"primitives: {pv['mismatches']} of {pv['compared']} values differ from the reference library ({pv.get('mismatches_by_group')})")
+        he = cb.get("hooked_encoder")
+        if isinstance(he, dict) and he.get("stream_identical") is False:
+            bad.append("the reference encoder over the drop-in tables wrote a different stream than over its own havoc library")
     for label, r in (out.get("extra") or {}).items():
         pv = r.get("parity_vs_reference") if isinstance(r, dict) else None
         if isinstance(pv, dict):
@@ -1422,6 +1426,48 @@ def cpu_reference_encoder(args):
     return {"value": round(frames / t, 3), "unit": "frames/s", "frames": frames, "threads": cores, "seconds": round(t, 3), "stream_bytes": size,
             "what": f"the reference encoder itself (whole encoder: search, RDOQ, CABAC, loop filter; x86 JIT havoc), {w}x{h} random access QP{args.qp} "
                     f"speed=medium --no-sao, {frames} frames of the synthetic clip, wall clock of the process (start-up included)"}
+
+
+def hooked_reference_encoder(args):
+    """cpu_baseline leg: the reference ENCODER itself running on the drop-in tables -- oracle/_ref/turing_ref_hooked = the reference's own encoder
+    linked against libhavoc_classic.so (every havoc table call answered by the MI355X) with the two picture-registration calls of include/havoc_classic_ext.h -- on a short
+    416x240 clip at speed=medium, next to the same encoder over its own x86-JIT havoc library on the same clip: frames/s of both, the share of table calls answered from
+    precomputed data, microseconds per table call, and whether the two streams are identical (they must be)."""
+    import re
+    import tempfile
+    hooked = os.path.join(ROOT, "oracle", "_ref", "turing_ref_hooked")
+    plain = os.path.join(ROOT, "oracle", "_ref", "turing_ref_havoc")
+    if not (os.path.exists(hooked) and os.path.exists(plain)):
+        return None
+    from turingcodec_amd.workload import synth_frames
+    w, h, frames = 416, 240, 3
+    with tempfile.TemporaryDirectory() as d:
+        clip = os.path.join(d, "clip.yuv")
+        with open(clip, "wb") as f:
+            for planes in synth_frames(w, h, frames, 7, 8):
+                for pl in planes:
+                    f.write(np.ascontiguousarray(pl).tobytes())
+        out = {}
+        for name, exe in (("reference", plain), ("hooked", hooked)):
+            bit = os.path.join(d, name + ".bit")
+            cmd = [exe, "--input-res", f"{w}x{h}", "--frames", str(frames), "--frame-rate", "24", "--verbosity", "0", "--no-sao", "--qp", "32", "--speed", "medium", "-o", bit, clip]
+            t0 = time.perf_counter()
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, HAVOC_CLASSIC_REPORT="1"))
+            t = time.perf_counter() - t0
+            if r.returncode != 0:
+                return {"error": f"{name}: " + r.stderr[-300:]}
+            out[name] = (t, open(bit, "rb").read(), r.stderr)
+    t_ref, s_ref, _ = out["reference"]
+    t_hk, s_hk, err = out["hooked"]
+    line = [l for l in err.splitlines() if "table calls served" in l]
+    n = [int(v) for v in re.findall(r"\d+", line[-1])] if line else [0, 0, 0]
+    calls = max(1, n[0] + n[1])
+    by_entry = [l.split("entry point:")[1].strip() for l in err.splitlines() if "one-job launches by entry point" in l]
+    return {"value": round(frames / t_hk, 3), "unit": "frames/s", "clip": f"{w}x{h}, {frames} frames (1 I + 2 B), QP32 speed=medium --no-sao", "seconds": round(t_hk, 3),
+            "reference_encoder_same_clip_fps": round(frames / t_ref, 3), "stream_identical": bool(s_ref == s_hk), "stream_bytes": len(s_hk),
+            "table_calls": calls, "served_fraction": round(n[0] / calls, 4), "one_job_launches": n[1], "launches": n[2], "us_per_table_call": round(t_hk / calls * 1e6, 3),
+            "one_job_by_entry_point": by_entry[-1] if by_entry else None,
+            "what": "the reference encoder over libhavoc_classic.so (the drop-in table library; the MI355X answers every havoc table call), wall clock of the process"}
 
 
 def decision_path(args, Havoc, res, bit_depth, qp, pictures, seconds=1.5, keep=None):
@@ -1964,6 +2010,10 @@ def main():
                                                 "sample": enc["what"] + f" ({enc['seconds']} s)", "reference_encoder": enc, "primitive_tables": tables})
                 else:
                     out["cpu_baseline"]["reference_encoder"] = enc
+                try:
+                    out["cpu_baseline"]["hooked_encoder"] = hooked_reference_encoder(args)
+                except Exception as e:
+                    out["cpu_baseline"]["hooked_encoder"] = {"error": repr(e)}
         red = parity_problems(out)
         out["parity"] = "red" if red else "green"
         if red:

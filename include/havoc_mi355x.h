@@ -267,20 +267,26 @@ int havoc_mi355x_sad(havoc_mi355x_ctx *ctx, int S, const void *d_src, intptr_t s
 /* havoc_sad_multiref<Sample>, ways = 4 (havoc/sad.h:100, havoc/sad.cpp:513-542): d_out[4*i + k] */
 int havoc_mi355x_sad4(havoc_mi355x_ctx *ctx, int S, const void *d_src, intptr_t stride_src, const void *d_ref,
                       intptr_t stride_ref, const havoc_mi355x_sad4_job *d_jobs, int njobs, int32_t *d_out);
-/* The same calls BY RUNS: a run = the consecutive havoc_sad_multiref calls of one motion search (turing/Search.hpp:2224-2297 -> considerPattern
- * :1447-1482: ~112 calls sharing the source block and moving around one centre).  A workgroup stages the run's source block and the bounding box of all its
- * candidates in LDS once and the calls read them there; d_out as havoc_mi355x_sad4.  d_runs must tile the jobs the caller wants computed (jobs in no run are
- * not computed); a run whose calls differ in source / size or whose box does not fit is computed call by call -- runs change the speed, never a result.
- * havoc_mi355x_sad4_make_runs (host, no device) cuts a host copy of a job table into runs: consecutive jobs with equal src_off, w, h, at most max_run
- * (<= 128) of them; returns the number of runs written to `runs` (capacity njobs). */
+/* The same calls BY RUNS: a run = consecutive havoc_sad_multiref calls of one motion search (turing/Search.hpp:2224-2297 -> considerPattern :1447-1482: ~112 calls
+ * sharing the source block and moving around one centre).  A workgroup stages the run's source block and the bounding box of all its candidates in LDS once and the
+ * calls read them there; d_out as havoc_mi355x_sad4.  d_runs must tile the jobs the caller wants computed (jobs in no run are not computed).  Runs change the speed,
+ * never a result: a run whose calls differ in source / size, whose box does not fit LDS or does not hold every candidate, is computed call by call.
+ *   box_off / box_w / box_h: the rectangle of the reference plane (sample offset of its top-left from d_ref, width in samples, rows) that holds every candidate BLOCK of
+ *   the run -- staged at once, each candidate then checked against it; box_w = 0: the kernel finds the box itself (one more pass over the run's jobs).
+ * havoc_mi355x_sad4_make_runs (host code, no device) cuts a HOST copy of a job table into runs and gives them their boxes: consecutive jobs with equal src_off, w, h whose
+ * box fits the kernel's window (16 KB x S), at most max_run calls (1 .. 128; <= 0: by block size -- 16 calls of a 64x64 block, 48 of a 32x32, 128 below: what keeps a
+ * workgroup's work even, profiles/r05/sad4_run_policy.jsonl); stride_ref = the reference plane's row stride in samples (the boxes are rectangles of that plane).
+ * Returns the number of runs written to `runs` (capacity njobs), or -1. */
 typedef struct {
     int32_t first_job;
     int32_t count;
-} havoc_mi355x_sad4_run; /* 8 bytes */
+    int32_t box_off, box_w, box_h;
+    int32_t reserved[3];
+} havoc_mi355x_sad4_run; /* 32 bytes */
 int havoc_mi355x_sad4_runs(havoc_mi355x_ctx *ctx, int S, const void *d_src, intptr_t stride_src, const void *d_ref,
                            intptr_t stride_ref, const havoc_mi355x_sad4_job *d_jobs, int njobs,
                            const havoc_mi355x_sad4_run *d_runs, int nruns, int32_t *d_out);
-int havoc_mi355x_sad4_make_runs(const havoc_mi355x_sad4_job *jobs, int njobs, int max_run, havoc_mi355x_sad4_run *runs);
+int havoc_mi355x_sad4_make_runs(const havoc_mi355x_sad4_job *jobs, int njobs, int max_run, intptr_t stride_ref, int S, havoc_mi355x_sad4_run *runs);
 /* Full-pel SAD surface: the super-set serving the havoc_sad / havoc_sad_multiref calls of the integer motion search
  * (turing/Search.hpp:1447-1482 considerPattern, :1585-1623 bi grid, :2224-2290 star / raster / refinement) as look-ups.
  * d_out[out_off + (dy + range) * (2*range + 1) + (dx + range)] = havoc_sad(src, ref + dy*stride_ref + dx) for every

@@ -18,7 +18,17 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 hv = Havoc(0, stream="new")
 wl = FrameWorkload(1920, 1080, 8, 11)
 luma, jobs = hv.up(wl.luma), hv.up(wl.sad4)
-runs = Havoc.sad4_make_runs(wl.sad4, int(os.environ.get("HAVOC_SAD4_MAX_RUN", "128")))
+boxed = os.environ.get("HAVOC_SAD4_BOX", "1") == "1"      # 0: runs without a box (the kernel reduces every run's box itself)
+runs = Havoc.sad4_make_runs(wl.sad4, int(os.environ.get("HAVOC_SAD4_MAX_RUN", "0")), wl.stride if boxed else None, wl.S)
+policy = os.environ.get("HAVOC_SAD4_POLICY")      # "64:16,32:32,16:64,8:128": calls per run by block width (experiment: work per workgroup evened out); runs without a box
+if policy:
+    cap = {int(k): int(v) for k, v in (kv.split(":") for kv in policy.split(","))}
+    out_runs = []
+    for first, count in Havoc.sad4_make_runs(wl.sad4, 128)[:, :2]:
+        c = cap.get(int(wl.sad4[first, 5]), 128)
+        for b in range(0, count, c):
+            out_runs.append((first + b, min(c, count - b)))
+    runs = Havoc.as_runs(np.array(out_runs, np.int32))
 d_runs = hv.up(runs)
 out = hv.zeros(4 * len(wl.sad4), np.int32)
 fn = (lambda: hv.sad4_runs_d(luma, wl.stride, luma, wl.stride, jobs, d_runs, out)) if form == "runs" else (lambda: hv.sad4_d(luma, wl.stride, luma, wl.stride, jobs, out))
@@ -33,5 +43,5 @@ for _ in range(3):
 size = {}
 for w in (8, 16, 32, 64):
     size[w] = int((wl.sad4[runs[:, 0], 5] == w).sum())
-print(json.dumps({"form": form, "waves": os.environ.get("HAVOC_SAD4_RUN_WAVES", "4"), "ms": round(best, 4), "calls": int(len(wl.sad4)), "runs": int(len(runs)), "runs_by_width": size,
+print(json.dumps({"form": form, "waves": os.environ.get("HAVOC_SAD4_RUN_WAVES", "4"), "unroll": os.environ.get("HAVOC_SAD4_RUN_UNROLL", "2"), "policy": policy, "max_run": os.environ.get("HAVOC_SAD4_MAX_RUN", "0"), "boxed": bool(boxed and not policy), "ms": round(best, 4), "calls": int(len(wl.sad4)), "runs": int(len(runs)), "runs_by_width": size,
                   "checksum": int(hv.down(out, np.int32).astype(np.int64).sum())}))

@@ -53,12 +53,29 @@ def test_run_cutter_on_the_host():
     j[:, 0] = [5, 5, 5, 9, 9, 9, 9, 5, 5, 5, 5, 5]
     j[:, 5], j[:, 6] = 16, 16
     j[10:, 6] = 8                                                       # same source offset, another height: another search
-    assert Havoc.sad4_make_runs(j).tolist() == [[0, 3], [3, 4], [7, 3], [10, 2]]
-    assert Havoc.sad4_make_runs(j, 2).tolist() == [[0, 2], [2, 1], [3, 2], [5, 2], [7, 2], [9, 1], [10, 2]]
-    assert Havoc.sad4_make_runs(j[:0]).shape == (0, 2)
+    assert Havoc.sad4_make_runs(j, 128)[:, :2].tolist() == [[0, 3], [3, 4], [7, 3], [10, 2]]
+    assert Havoc.sad4_make_runs(j, 2)[:, :2].tolist() == [[0, 2], [2, 1], [3, 2], [5, 2], [7, 2], [9, 1], [10, 2]]
+    assert Havoc.sad4_make_runs(j[:0]).shape == (0, 8)
     big = np.zeros((300, 8), np.int32)
-    assert Havoc.sad4_make_runs(big).tolist() == [[0, 128], [128, 128], [256, 44]]      # at most 128 calls per run, whatever is asked for
-    assert Havoc.sad4_make_runs(big, 1000).tolist() == [[0, 128], [128, 128], [256, 44]]
+    big[:, 5], big[:, 6] = 16, 16
+    assert Havoc.sad4_make_runs(big, 128)[:, :2].tolist() == [[0, 128], [128, 128], [256, 44]]      # at most 128 calls per run, whatever is asked for
+    assert Havoc.sad4_make_runs(big, 1000)[:, :2].tolist() == [[0, 128], [128, 128], [256, 44]]
+    assert not Havoc.sad4_make_runs(big, 128)[:, 2:].any()                                             # no stride given: runs without a box
+    # with the plane's stride every run carries the box of its candidate blocks, and is cut where the box would outgrow the kernel's window or by block size
+    st = 512
+    k = np.zeros((40, 8), np.int32)
+    k[:, 0], k[:, 5], k[:, 6] = 7, 64, 64
+    for i in range(40):
+        k[i, 1:5] = [(100 + i) * st + 200 + d for d in (0, 1, -1, 2)]
+    r = Havoc.sad4_make_runs(k, 0, st, 1)
+    assert r[:, 1].sum() == 40 and r[:, 1].max() <= 16                                                  # 64x64 blocks: 16 calls per run
+    for first, count, off, bw, bh in r[:, :5]:
+        cand = k[first:first + count, 1:5].ravel()
+        assert off == cand.min() - 0 - ((cand.min() % st) - (cand % st).min()) and bw == (cand % st).max() - (cand % st).min() + 64 and bh == cand.max() // st - cand.min() // st + 64
+    far = k.copy()
+    far[5, 1] += 300 * st                                                                              # one candidate 300 rows away: the box would not fit -> the run is cut there
+    rf = Havoc.sad4_make_runs(far, 0, st, 1)
+    assert [5, 1] in rf[:, :2].tolist() and rf[rf[:, 0] == 5][0, 3] == 0                                # ... and that call's own run has no box (it cannot have one that fits)
 
 
 @pytest.mark.gpu
@@ -72,12 +89,28 @@ def test_runs_of_a_search_equal_the_oracle(bit_depth, stride_extra, base_shift):
     if base_shift:
         ref = ref[base_shift:]
     jobs = search_like_jobs(rng, 192, 160, stride, pad, SIZES + [(16, 16)] * 6 + [(8, 8)] * 6, 37)
-    runs = Havoc.sad4_make_runs(jobs)
+    runs = Havoc.sad4_make_runs(jobs, 128)                               # runs without a box: the kernel finds each run's box itself
     assert len(runs) >= len(SIZES) and runs[:, 1].max() <= 128
     assert not (bad := check(hv, orc, src, ref, stride, jobs, runs)), bad[:4]
-    # the same calls in runs of 112 (the measured calls per search) and cut at odd places, in runs of 1: same values
-    assert not (bad := check(hv, orc, src, ref, stride, jobs, Havoc.sad4_make_runs(jobs, 5))), bad[:4]
-    assert not (bad := check(hv, orc, src, ref, stride, jobs, Havoc.sad4_make_runs(jobs, 1))), bad[:4]
+    S = src.itemsize
+    boxed = Havoc.sad4_make_runs(jobs, 0, stride, S)                    # the cutter's runs: boxes given, lengths by block size
+    assert boxed[:, 3].min() > 0 and boxed[:, 1].sum() == len(jobs)
+    assert not (bad := check(hv, orc, src, ref, stride, jobs, boxed)), bad[:4]
+    # the same calls cut at odd places, in runs of 1 (boxed and not): same values
+    for mr in (5, 1):
+        assert not (bad := check(hv, orc, src, ref, stride, jobs, Havoc.sad4_make_runs(jobs, mr))), bad[:4]
+        assert not (bad := check(hv, orc, src, ref, stride, jobs, Havoc.sad4_make_runs(jobs, mr, stride, S))), bad[:4]
+    # boxes that LIE (too small, shifted, huge): every candidate is checked against the box it was given, a run whose box does not hold goes call by call
+    for lie in ("small", "shifted", "huge"):
+        wrong = boxed.copy()
+        if lie == "small":
+            wrong[:, 3] = np.maximum(1, wrong[:, 3] - 3)
+            wrong[:, 4] = np.maximum(1, wrong[:, 4] - 2)
+        elif lie == "shifted":
+            wrong[:, 2] += 2 * stride + 3
+        else:
+            wrong[:, 3], wrong[:, 4] = stride - 1, 900
+        assert not (bad := check(hv, orc, src, ref, stride, jobs, wrong)), (lie, bad[:4])
 
 
 @pytest.mark.gpu
@@ -142,8 +175,8 @@ def test_runs_equal_calls_on_a_picture_of_the_bench(tmp_path):
     hv, orc = Havoc(0), Oracle()
     wl = FrameWorkload(1920, 1080, 8, 11)
     luma, jobs = hv.up(wl.luma), hv.up(wl.sad4)
-    runs = Havoc.sad4_make_runs(wl.sad4)
-    assert 100 < len(wl.sad4) / len(runs) <= 128
+    runs = Havoc.sad4_make_runs(wl.sad4, 0, wl.stride, wl.S)
+    assert 30 < len(wl.sad4) / len(runs) <= 128 and (runs[:, 3] > 0).mean() > 0.99
     a, b = hv.zeros(4 * len(wl.sad4), np.int32), hv.zeros(4 * len(wl.sad4), np.int32)
     hv.sad4_d(luma, wl.stride, luma, wl.stride, jobs, a)
     hv.sad4_runs_d(luma, wl.stride, luma, wl.stride, jobs, hv.up(runs), b)

@@ -348,18 +348,56 @@ int havoc_mi355x_sad4_runs(havoc_mi355x_ctx *ctx, int S, const void *d_src, intp
     return check(launch_sad4_runs(LS(ctx), S, d_src, stride_src, d_ref, stride_ref, d_jobs, njobs, d_runs, nruns, d_out), "sad4_runs");
 }
 
-int havoc_mi355x_sad4_make_runs(const havoc_mi355x_sad4_job *jobs, int njobs, int max_run, havoc_mi355x_sad4_run *runs)
+int havoc_mi355x_sad4_make_runs(const havoc_mi355x_sad4_job *jobs, int njobs, int max_run, intptr_t stride_ref, int S, havoc_mi355x_sad4_run *runs)
 {
-    if (!jobs || !runs || njobs < 0) return -1;
-    if (max_run < 1 || max_run > 128) max_run = 128;
+    if (!jobs || !runs || njobs < 0 || (S != 1 && S != 2)) return -1;
+    const long st = (long)stride_ref, half = st >> 1;
+    const long budget = (S == 1 ? 16 : 32) * 1024 - 64;      // the kernel's window in bytes (csrc/kernels_metric.hip: k_sad4r), less the dwords it keeps spare
     int n = 0;
     for (int i = 0; i < njobs;)
     {
-        int e = i + 1;
-        while (e < njobs && e - i < max_run && jobs[e].src_off == jobs[i].src_off && jobs[e].w == jobs[i].w && jobs[e].h == jobs[i].h) ++e;
-        runs[n].first_job = i;
-        runs[n].count = e - i;
-        ++n;
+        const havoc_mi355x_sad4_job &a = jobs[i];
+        const long area = (long)a.w * a.h;
+        const int cap = max_run >= 1 ? (max_run > 128 ? 128 : max_run) : (area >= 4096 ? 16 : area >= 1024 ? 48 : 128);
+        // the box grows call by call, in displacements (dx, dy) from the run's first candidate: |dx| <= stride / 2 makes the split of an offset unique
+        long mnx = 0, mxx = 0, mny = 0, mxy = 0;
+        bool boxed = st >= 64 && a.w > 0 && a.h > 0 && a.w <= 64 && a.h <= 64;
+        int e = i;
+        while (e < njobs && e - i < cap && jobs[e].src_off == a.src_off && jobs[e].w == a.w && jobs[e].h == a.h)
+        {
+            long nx0 = mnx, nx1 = mxx, ny0 = mny, ny1 = mxy;
+            if (boxed)
+                for (int k = 0; k < 4; ++k)
+                {
+                    const long delta = (long)jobs[e].ref_off[k] - a.ref_off[0];
+                    long q = (delta + half >= 0 ? (delta + half) / st : -((-(delta + half) + st - 1) / st)), r = delta - q * st;
+                    nx0 = r < nx0 ? r : nx0; nx1 = r > nx1 ? r : nx1; ny0 = q < ny0 ? q : ny0; ny1 = q > ny1 ? q : ny1;
+                }
+            // bytes of the staged box: rows at a 16-byte granularity (+ up to 15 bytes of alignment lead + the odd dword of the LDS pitch)
+            const long pitch = ((15 + (nx1 - nx0 + a.w) * S + 15) / 16) * 16 + 4, bytes = pitch * (ny1 - ny0 + a.h);
+            const bool holds = boxed && nx1 - nx0 + a.w < st && bytes <= budget;
+            if (boxed && !holds && e > i) break;      // this call would burst the box: it opens the next run
+            if (!holds && st >= 64)                   // a single call whose own four candidates do not fit: a run of one, without a box (the kernel takes it call by call)
+            {
+                boxed = false;
+                ++e;
+                break;
+            }
+            if (!holds) boxed = false;                // (no stride given: runs without boxes, cut by source block and length only)
+            mnx = nx0; mxx = nx1; mny = ny0; mxy = ny1;
+            ++e;
+        }
+        const long off = (long)a.ref_off[0] + mny * st + mnx;
+        havoc_mi355x_sad4_run &r = runs[n++];
+        r = havoc_mi355x_sad4_run();
+        r.first_job = i;
+        r.count = e - i;
+        if (boxed && off >= 0 && off < (1l << 31))
+        {
+            r.box_off = (int32_t)off;
+            r.box_w = (int32_t)(mxx - mnx + a.w);
+            r.box_h = (int32_t)(mxy - mny + a.h);
+        }
         i = e;
     }
     return n;
@@ -645,6 +683,13 @@ int havoc_mi355x_rqt_decide(havoc_mi355x_ctx *ctx, const havoc_mi355x_rqt_unit *
     REQUIRE_CTX(); REQUIRE(n >= 0, "n < 0"); REQUIRE(sizes != nullptr, "null sizes"); REQUIRE(rec_stride > 0 && rec_stride < (1 << 24), "rec_stride out of range");
     REQUIRE(n == 0 || (d_units && d_zero_at && d_one_at && d_out), "null device pointer");
     REQUIRE(reciprocal_lambda_q16 >= 0, "reciprocal_lambda_q16 < 0"); REQUIRE(dump_off >= 0, "dump_off < 0");
+    if (n > 0)      // units of 8x8 .. 32x32 read the tables of their own size and of half of it: sizes 4 .. 32 = sizes[0 .. 3]; a table nobody can need may be null,
+        for (int k = 0; k < 4; ++k)      // a partly filled one is a caller's mistake
+        {
+            const havoc_mi355x_rqt_size &z = sizes[k];
+            const bool all = z.d_cbf && z.d_ssd && z.d_stats && z.d_jobs && z.d_final, none = !z.d_cbf && !z.d_ssd && !z.d_stats && !z.d_jobs && !z.d_final;
+            REQUIRE(all || none, "rqt_decide: a size table with some null pointers");
+        }
     return check(launch_rqt_decide(LS(ctx), d_units, n, d_zero_at, d_one_at, sizes, (long)rec_origin, (int)rec_stride, dump_off, reciprocal_lambda_q16, d_out), "rqt_decide");
 }
 

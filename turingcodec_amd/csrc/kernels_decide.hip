@@ -171,10 +171,17 @@ __global__ __launch_bounds__(256) void k_rqt_decide(const RqtUnit *__restrict__ 
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const RqtUnit u = units[i];
+    if (u.log2 < 3 || u.log2 > 5)      // a unit has a depth-0 block of 8 .. 32 and four depth-1 blocks of half that: anything else has no size table
+    {
+        RqtResult bad = RqtResult();
+        bad.depth = -1;
+        out[i] = bad;
+        return;
+    }
     const RqtSize &s0 = z.s[u.log2 - 2], &s1 = z.s[u.log2 - 3];
     const int j0 = zeroAt[i], j1 = oneAt[i], half = 1 << (u.log2 - 1);
     RqtResult r = RqtResult();
-    int32_t ssdOne = 0;
+    int32_t ssdOne = 0;      // (int32 as the reference's StateEncodeSubstream::ssd: four 16x16 blocks of <= 255^2 * 256 each, or 10-bit SSDs >> 4, stay far below 2^31)
     bool coded = false;
     int64_t rateOne = 0;
     for (int k = 0; k < 4; ++k)      // rqtdepth = 1 first (Reconstruct.cpp:1325-1326), blocks in z-order

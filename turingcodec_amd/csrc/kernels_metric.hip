@@ -387,11 +387,14 @@ __global__ __launch_bounds__(256, MINW) void k_sad4w(const char *__restrict__ sr
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kRunMax = 128;        // calls of a run whose displacements are kept in LDS (longer runs: call by call)
 
-template <int S, int CB>
+template <int S, int CB, int U>
 __device__ __forceinline__ void sad4_run_calls(const __attribute__((address_space(3))) uint32_t *win, const __attribute__((address_space(3))) uint32_t *srcw,
                                                const __attribute__((address_space(3))) uint32_t *cand, int pitchD, int lead, int mndx, int mndy, int rowBytes, int h,
                                                int count, int group, int ngroups, int lane, int32_t *__restrict__ out)
 {
+    // U calls per pass of a lane group: their 4 U candidates read the same source chunk and their LDS reads are in flight together -- the kernel is bound by the
+    // latency of a pass (LDS round trip -> 16 packed SADs -> a 4-step DPP reduction -> store), not by issue (profiles/r05/sad4r_counters.csv: 29 % of a wavefront's
+    // cycles issue, 40 % wait)
     const int cpr = rowBytes / CB;                  // chunks per block row
     const int rpi = smallDiv(kSadLanes, cpr);       // block rows per iteration of the lane group
     const int y0 = smallDiv(lane, cpr);
@@ -400,19 +403,31 @@ __device__ __forceinline__ void sad4_run_calls(const __attribute__((address_spac
     const int lstep = mul24(rpi, pitchD);
     const int s0 = (mul24(y0, rowBytes) + xb) >> 2, sstep = mul24(rpi, rowBytes) >> 2;      // source block: dense rows, dword index
     const int base = lead + xb - mndx * S;
-    for (int c = group; c < count; c += ngroups)
+    for (int c0 = group; c0 < count; c0 += ngroups * U)
     {
-        int lo[4], sh[4];
+        int lo[4 * U], sh[4 * U];
+        uint32_t acc[4 * U];
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+        for (int u = 0; u < U; ++u)
         {
-            const int v = (int)cand[4 * c + k];
-            const int dx = (int)(short)(v & 0xffff), dy = v >> 16;
-            const int bo = base + dx * S;
-            lo[k] = mul24(y0 + dy - mndy, pitchD) + (bo >> 2);
-            sh[k] = bo & 3;
+            const int c = min(c0 + u * ngroups, count - 1);      // (a pass beyond the run's end repeats its last call; nothing is stored for it)
+            uint32_t v4[4];
+            if (true)
+            {
+                const u32x4 cv = *reinterpret_cast<const __attribute__((address_space(3))) u32x4 *>(cand + 4 * c);
+                v4[0] = cv.x; v4[1] = cv.y; v4[2] = cv.z; v4[3] = cv.w;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+            {
+                const int v = (int)v4[k];
+                const int dx = (int)(short)(v & 0xffff), dy = v >> 16;
+                const int bo = base + dx * S;
+                lo[4 * u + k] = mul24(y0 + dy - mndy, pitchD) + (bo >> 2);
+                sh[4 * u + k] = bo & 3;
+                acc[4 * u + k] = 0;
+            }
         }
-        uint32_t acc[4] = {0, 0, 0, 0};
         if (sums)
         {
             int l = 0, sp = s0;
@@ -423,36 +438,34 @@ __device__ __forceinline__ void sad4_run_calls(const __attribute__((address_spac
                 {
                     // (one ds_read_b128: the source rows are dense and 16-byte aligned; four dword reads at a 16-byte lane pitch would be 4-way bank conflicts)
                     const u32x4 av = *reinterpret_cast<const __attribute__((address_space(3))) u32x4 *>(srcw + sp);
-                    const uint32_t a0 = av.x, a1 = av.y, a2 = av.z, a3 = av.w;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k)
+                    for (int k = 0; k < 4 * U; ++k)
                     {
                         const auto q = win + lo[k] + l;
                         const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
-                        acc[k] = sad_dword<S>(a0, __builtin_amdgcn_alignbyte(d1, d0, sh[k]), acc[k]);
-                        acc[k] = sad_dword<S>(a1, __builtin_amdgcn_alignbyte(d2, d1, sh[k]), acc[k]);
-                        acc[k] = sad_dword<S>(a2, __builtin_amdgcn_alignbyte(d3, d2, sh[k]), acc[k]);
-                        acc[k] = sad_dword<S>(a3, __builtin_amdgcn_alignbyte(d4, d3, sh[k]), acc[k]);
+                        acc[k] = sad_dword<S>(av.x, __builtin_amdgcn_alignbyte(d1, d0, sh[k]), acc[k]);
+                        acc[k] = sad_dword<S>(av.y, __builtin_amdgcn_alignbyte(d2, d1, sh[k]), acc[k]);
+                        acc[k] = sad_dword<S>(av.z, __builtin_amdgcn_alignbyte(d3, d2, sh[k]), acc[k]);
+                        acc[k] = sad_dword<S>(av.w, __builtin_amdgcn_alignbyte(d4, d3, sh[k]), acc[k]);
                     }
                 }
                 else if (CB == 8)
                 {
                     const u32x2 av = *reinterpret_cast<const __attribute__((address_space(3))) u32x2 *>(srcw + sp);
-                    const uint32_t a0 = av.x, a1 = av.y;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k)
+                    for (int k = 0; k < 4 * U; ++k)
                     {
                         const auto q = win + lo[k] + l;
                         const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
-                        acc[k] = sad_dword<S>(a0, __builtin_amdgcn_alignbyte(d1, d0, sh[k]), acc[k]);
-                        acc[k] = sad_dword<S>(a1, __builtin_amdgcn_alignbyte(d2, d1, sh[k]), acc[k]);
+                        acc[k] = sad_dword<S>(av.x, __builtin_amdgcn_alignbyte(d1, d0, sh[k]), acc[k]);
+                        acc[k] = sad_dword<S>(av.y, __builtin_amdgcn_alignbyte(d2, d1, sh[k]), acc[k]);
                     }
                 }
                 else
                 {
                     const uint32_t a0 = srcw[sp];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k)
+                    for (int k = 0; k < 4 * U; ++k)
                     {
                         const auto q = win + lo[k] + l;
                         acc[k] = sad_dword<S>(a0, __builtin_amdgcn_alignbyte(q[1], q[0], sh[k]), acc[k]);
@@ -461,16 +474,21 @@ __device__ __forceinline__ void sad4_run_calls(const __attribute__((address_spac
             }
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+        for (int u = 0; u < U; ++u)
         {
-            int t = sad_group_sum((int)acc[k]);
-            if (S == 2) t >>= 2;
-            if (lane == kSadLanes - 1) out[4 * c + k] = t;
+            const int c = c0 + u * ngroups;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+            {
+                int t = sad_group_sum((int)acc[4 * u + k]);
+                if (S == 2) t >>= 2;
+                if (lane == kSadLanes - 1 && c < count) out[4 * c + k] = t;
+            }
         }
     }
 }
 
-template <int S, int NW>
+template <int S, int NW, int U>
 __global__ __launch_bounds__(64 * NW) void k_sad4r(const char *__restrict__ src, long stride_src, const char *__restrict__ ref, long stride_ref, float inv_stride_ref,
                                                    const int32_t *__restrict__ jobs, int njobs, const int32_t *__restrict__ runs, int nruns, int32_t *__restrict__ out)
 {
@@ -484,53 +502,69 @@ __global__ __launch_bounds__(64 * NW) void k_sad4r(const char *__restrict__ src,
     __shared__ int s_box[6];
     const int run = xcd_block(blockIdx.x, gridDim.x);
     const int tid = threadIdx.x, lane = tid & (kSadLanes - 1), group = tid / kSadLanes;
-    int first = runs[2 * run], count = runs[2 * run + 1];
+    const int32_t *rr = runs + (long)run * 8;      // havoc_mi355x_sad4_run
+    const int first = rr[0], count = rr[1], boxOff = rr[2], boxW = rr[3], boxH = rr[4];
     if (first < 0 || count <= 0 || (long)first + count > njobs) return;      // (uniform: the whole workgroup leaves)
     const int32_t *j0 = jobs + (long)first * 8;
     const int so = j0[0], ro0 = j0[1], w = j0[5], h = j0[6];
     const int st = (int)stride_ref, half = st >> 1;
     const int rowBytes = w * S;
-    if (tid < 6) s_box[tid] = tid == 4 ? 1 : 0;      // min dx, max dx, min dy, max dy (candidate 0 of call 0 is (0, 0)), ok, -
-    __syncthreads();
-    // ---- pass 1: every candidate's displacement from the run's first one, the box, and whether the run is one search (same source block and size)
-    int mn_x = 0, mx_x = 0, mn_y = 0, mx_y = 0, ok = count <= kRunMax;
-    for (int p = tid; p < 4 * min(count, kRunMax); p += T)
-    {
-        const int32_t *j = j0 + (p >> 2) * 8;
-        const int delta = j[1 + (p & 3)] - ro0;
-        int q = (int)floorf(((float)delta + (float)half) * inv_stride_ref);
-        long rl = (long)delta - (long)q * st;      // (64-bit: a far candidate's quotient times the stride does not fit 32 bits; such a run goes call by call)
-        if (rl < -half) { --q; rl += st; }
-        if (rl >= st - half) { ++q; rl -= st; }
-        ok &= (j[0] == so) & (j[5] == w) & (j[6] == h) & (q >= -32768) & (q < 32768) & (rl >= -32768) & (rl < 32768);
-        const int r = (int)rl;
-        s_cand[p] = (uint32_t)(r & 0xffff) | ((uint32_t)q << 16);
-        mn_x = min(mn_x, r); mx_x = max(mx_x, r); mn_y = min(mn_y, q); mx_y = max(mx_y, q);
-    }
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1)
-    {
-        mn_x = min(mn_x, __shfl_xor(mn_x, o, 64)); mx_x = max(mx_x, __shfl_xor(mx_x, o, 64));
-        mn_y = min(mn_y, __shfl_xor(mn_y, o, 64)); mx_y = max(mx_y, __shfl_xor(mx_y, o, 64));
-        ok &= __shfl_xor(ok, o, 64);
-    }
-    if ((tid & 63) == 0)
-    {
-        atomicMin(&s_box[0], mn_x); atomicMax(&s_box[1], mx_x); atomicMin(&s_box[2], mn_y); atomicMax(&s_box[3], mx_y); atomicAnd(&s_box[4], ok);
-    }
-    __syncthreads();
-    const int mndx = s_box[0], mxdx = s_box[1], mndy = s_box[2], mxdy = s_box[3];
-    ok = s_box[4];
     const long ssb = stride_src * S, rsb = stride_ref * S;
-    const int spready = mxdy - mndy;
-    const long minoff = ((long)ro0 + (long)mndy * st + mndx) * S;      // bytes from `ref` to the box's first sample
-    const int lead = (int)(reinterpret_cast<uintptr_t>(ref + minoff) & 15);
-    const int chunks = (lead + rowBytes + (mxdx - mndx) * S + 15) >> 4;      // 16-byte pieces of a box row
-    const int pitchD = 4 * chunks + 1, rows = h + spready;
     const bool chunked = (rowBytes & 15) == 0 ? rowBytes <= 16 * kSadLanes : (rowBytes & 7) == 0 ? rowBytes <= 8 * kSadLanes : (rowBytes & 3) == 0 && rowBytes <= 4 * kSadLanes;
-    const bool near = (unsigned)spready < 1024u && (unsigned)h <= 64u && ssb < (1 << 23) && rsb < (1 << 23) && chunks <= 1024 &&
+    const bool given = boxW > 0 && boxH > 0 && boxW < st;      // the cutter's box (havoc_mi355x_sad4_make_runs): staged at once, every candidate then checked against it
+    int mndx = 0, mndy = 0, spanx, spready, ok = count <= kRunMax;
+    long minoff;
+    if (given)
+    {
+        spanx = boxW - w;
+        spready = boxH - h;
+        minoff = (long)boxOff * S;
+        ok &= spanx >= 0 && spready >= 0 && boxOff >= 0;
+    }
+    else
+    {
+        // ---- the box by reduction: every candidate's displacement from the run's first one (any split of an offset into dy * stride + dx names the same sample)
+        if (tid < 6) s_box[tid] = tid == 4 ? 1 : 0;      // min dx, max dx, min dy, max dy (candidate 0 of call 0 is (0, 0)), ok, -
+        __syncthreads();
+        int mn_x = 0, mx_x = 0, mn_y = 0, mx_y = 0;
+        for (int p = tid; p < 4 * min(count, kRunMax); p += T)
+        {
+            const int32_t *j = j0 + (p >> 2) * 8;
+            const int delta = j[1 + (p & 3)] - ro0;
+            int q = (int)floorf(((float)delta + (float)half) * inv_stride_ref);
+            long rl = (long)delta - (long)q * st;      // (64-bit: a far candidate's quotient times the stride does not fit 32 bits; such a run goes call by call)
+            if (rl < -half) { --q; rl += st; }
+            if (rl >= st - half) { ++q; rl -= st; }
+            ok &= (j[0] == so) & (j[5] == w) & (j[6] == h) & (q >= -32768) & (q < 32768) & (rl >= -32768) & (rl < 32768);
+            const int r = (int)rl;
+            s_cand[p] = (uint32_t)(r & 0xffff) | ((uint32_t)q << 16);
+            mn_x = min(mn_x, r); mx_x = max(mx_x, r); mn_y = min(mn_y, q); mx_y = max(mx_y, q);
+        }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1)
+        {
+            mn_x = min(mn_x, __shfl_xor(mn_x, o, 64)); mx_x = max(mx_x, __shfl_xor(mx_x, o, 64));
+            mn_y = min(mn_y, __shfl_xor(mn_y, o, 64)); mx_y = max(mx_y, __shfl_xor(mx_y, o, 64));
+            ok &= __shfl_xor(ok, o, 64);
+        }
+        if ((tid & 63) == 0)
+        {
+            atomicMin(&s_box[0], mn_x); atomicMax(&s_box[1], mx_x); atomicMin(&s_box[2], mn_y); atomicMax(&s_box[3], mx_y); atomicAnd(&s_box[4], ok);
+        }
+        __syncthreads();
+        mndx = s_box[0];
+        mndy = s_box[2];
+        spanx = s_box[1] - mndx;
+        spready = s_box[3] - mndy;
+        ok = s_box[4];
+        minoff = ((long)ro0 + (long)mndy * st + mndx) * S;      // bytes from `ref` to the box's first sample
+    }
+    const int lead = (int)(reinterpret_cast<uintptr_t>(ref + minoff) & 15);
+    const int chunks = (lead + rowBytes + spanx * S + 15) >> 4;      // 16-byte pieces of a box row
+    const int pitchD = 4 * chunks + 1, rows = h + spready;
+    const bool near = (unsigned)spready < 1024u && (unsigned)h <= 64u && ssb < (1 << 23) && rsb < (1 << 23) && chunks <= 1024 && spanx >= 0 &&
                       minoff + (long)rows * rsb + 16l * chunks < (1ll << 32) && ((long)so * S + (long)h * ssb + rowBytes) < (1ll << 32);
-    const bool fits = ok && chunked && near && w <= 64 && minoff >= 16 && (long)pitchD * rows + 4 <= kWinD;
+    bool fits = ok && chunked && near && w <= 64 && minoff >= 16 && (long)pitchD * rows + 4 <= kWinD;
     if (fits)
     {
         const auto win_w = (__attribute__((address_space(3))) uint32_t *)(&lds[0]);
@@ -556,16 +590,37 @@ __global__ __launch_bounds__(64 * NW) void k_sad4r(const char *__restrict__ src,
                 src_w[i] = ld4(src + sb0 + (uint32_t)y * (uint32_t)ssb + x * 4);
             }
         }
-        __syncthreads();
+        if (given)
+        {   // every candidate against the cutter's box, as (column, row) inside it; the run must be one search (same source block and size)
+            int in = 1;
+            for (int p = tid; p < 4 * count; p += T)
+            {
+                const int32_t *j = j0 + (p >> 2) * 8;
+                const int delta = j[1 + (p & 3)] - boxOff;
+                int q = (int)(((float)delta + 0.5f) * inv_stride_ref);
+                int r = delta - q * st;      // (|delta| beyond the box makes this wrap or leave the box either way: the checks below catch both)
+                if (r < 0) { --q; r += st; }
+                if (r >= st) { ++q; r -= st; }
+                in &= (j[0] == so) & (j[5] == w) & (j[6] == h) & (delta >= 0) & (q >= 0) & (q <= spready) & (r >= 0) & (r <= spanx);
+                s_cand[p] = (uint32_t)(r & 0xffff) | ((uint32_t)q << 16);
+            }
+            fits = __syncthreads_and(in) != 0;      // (also the barrier between the staging above and the reads below)
+        }
+        else
+            __syncthreads();
+    }
+    if (fits)
+    {
         const auto win = (const __attribute__((address_space(3))) uint32_t *)(&lds[0]);
         const auto srcw = (const __attribute__((address_space(3))) uint32_t *)(&lds[kWinD + 4]);
         const auto cand = (const __attribute__((address_space(3))) uint32_t *)(&s_cand[0]);
         int32_t *o = out + (long)first * 4;
-        if ((rowBytes & 15) == 0) sad4_run_calls<S, 16>(win, srcw, cand, pitchD, lead, mndx, mndy, rowBytes, h, count, group, NG, lane, o);
-        else if ((rowBytes & 7) == 0) sad4_run_calls<S, 8>(win, srcw, cand, pitchD, lead, mndx, mndy, rowBytes, h, count, group, NG, lane, o);
-        else sad4_run_calls<S, 4>(win, srcw, cand, pitchD, lead, mndx, mndy, rowBytes, h, count, group, NG, lane, o);
+        if ((rowBytes & 15) == 0) sad4_run_calls<S, 16, U>(win, srcw, cand, pitchD, lead, mndx, mndy, rowBytes, h, count, group, NG, lane, o);
+        else if ((rowBytes & 7) == 0) sad4_run_calls<S, 8, U>(win, srcw, cand, pitchD, lead, mndx, mndy, rowBytes, h, count, group, NG, lane, o);
+        else sad4_run_calls<S, 4, U>(win, srcw, cand, pitchD, lead, mndx, mndy, rowBytes, h, count, group, NG, lane, o);
         return;
     }
+    __syncthreads();      // (a run whose box did not hold: the staged window is dropped, its LDS becomes the call-by-call path's buffers)
     // ---- call by call
     for (int c = group; c < ((count + NG - 1) / NG) * NG; c += NG)
     {
@@ -975,8 +1030,8 @@ static int sad4_run_waves()
 {
     static const int v = [] {
         const char *e = getenv("HAVOC_SAD4_RUN_WAVES");
-        const int n = e ? atoi(e) : 4;
-        return n == 1 || n == 2 ? n : 4;
+        const int n = e ? atoi(e) : 2;      // two wavefronts per run with the cutter's run lengths: profiles/r05/sad4_run_policy.jsonl
+        return n == 1 || n == 4 ? n : 2;
     }();
     return v;
 }
@@ -990,7 +1045,9 @@ hipError_t launch_sad4_runs(hipStream_t st, int S, const void *src, long ss, con
     const float inv = 1.0f / (float)rs;
     const int nw = sad4_run_waves();
     const dim3 g(nruns), b(64 * nw);
-#define HAVOC_RUN(SS, NW) hipLaunchKernelGGL((k_sad4r<SS, NW>), g, b, 0, st, s, ss, r, rs, inv, j, n, rn, nruns, out)
+    static const int unroll = [] { const char *e = getenv("HAVOC_SAD4_RUN_UNROLL"); return e && *e == '1' ? 1 : 2; }();      // calls per pass of a lane group
+#define HAVOC_RUN(SS, NW) do { if (unroll == 1) hipLaunchKernelGGL((k_sad4r<SS, NW, 1>), g, b, 0, st, s, ss, r, rs, inv, j, n, rn, nruns, out); \
+                               else hipLaunchKernelGGL((k_sad4r<SS, NW, 2>), g, b, 0, st, s, ss, r, rs, inv, j, n, rn, nruns, out); } while (0)
     if (S == 1) { if (nw == 1) HAVOC_RUN(1, 1); else if (nw == 2) HAVOC_RUN(1, 2); else HAVOC_RUN(1, 4); }
     else { if (nw == 1) HAVOC_RUN(2, 1); else if (nw == 2) HAVOC_RUN(2, 2); else HAVOC_RUN(2, 4); }
 #undef HAVOC_RUN

@@ -70,7 +70,7 @@ def _load():
         "sad": [_vp, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
         "sad4": [_vp, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
         "sad4_runs": [_vp, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp, _i, _vp],
-        "sad4_make_runs": [_vp, _i, _i, _vp],
+        "sad4_make_runs": [_vp, _i, _i, _ip, _i, _vp],
         "pad_block": [_vp, _i, _vp, C.c_int64, _i, _i, _ip, _i, _i, _i, _i, _i],
         "sad_surface": [_vp, _i, _i, _i, _i, _vp, _ip, _vp, _ip, _vp, _i, _vp],
         "deblock": [_vp, _i, _i, _vp, _ip, _vp, _vp, _ip, _i, _i, _vp, _vp, _i, _i, _i, _i],
@@ -332,16 +332,27 @@ class Havoc:
         self._ck(self.L.havoc_mi355x_sad4(self.h, self._S(src), _ptr(src), ss, _ptr(ref), rs, _ptr(jobs), jobs.shape[0], _ptr(out)))
 
     def sad4_runs_d(self, src, ss, ref, rs, jobs, runs, out):
-        """the same calls by runs (include/havoc_mi355x.h: havoc_mi355x_sad4_runs); runs: int32 tensor [nruns, 2] = (first job, count)"""
+        """the same calls by runs (include/havoc_mi355x.h: havoc_mi355x_sad4_runs); runs: int32 tensor [nruns, 8] = havoc_mi355x_sad4_run records"""
+        assert runs.shape[1] == 8, "runs: [n, 8] havoc_mi355x_sad4_run records (sad4_make_runs makes them; as_runs widens [n, 2] = (first job, count) pairs)"
         self._ck(self.L.havoc_mi355x_sad4_runs(self.h, self._S(src), _ptr(src), ss, _ptr(ref), rs, _ptr(jobs), jobs.shape[0], _ptr(runs), runs.shape[0], _ptr(out)))
 
     @staticmethod
-    def sad4_make_runs(jobs, max_run=128):
-        """host: cut a sad4 job table (int32 [n, 8]) into runs of consecutive calls with equal source block and size -> int32 [nruns, 2]"""
+    def as_runs(pairs):
+        """(first job, count) pairs -> havoc_mi355x_sad4_run records without a box (the kernel then finds each run's box itself)"""
+        pairs = np.asarray(pairs, np.int32).reshape(-1, 2)
+        runs = np.zeros((len(pairs), 8), np.int32)
+        runs[:, :2] = pairs
+        return runs
+
+    @staticmethod
+    def sad4_make_runs(jobs, max_run=0, stride=None, S=1):
+        """host: cut a sad4 job table (int32 [n, 8]) into runs of consecutive calls with equal source block and size -> int32 [nruns, 8] (first job, count, box offset,
+        box width, box rows, 0, 0, 0).  stride = the reference plane's row stride in samples: with it every run gets the box of its candidates (and is cut where the box
+        would outgrow the kernel's window); without it the runs have no box.  max_run 0 = by block size."""
         L, _ = _load()
         jobs = np.ascontiguousarray(jobs, np.int32)
-        runs = np.zeros((max(1, len(jobs)), 2), np.int32)
-        n = L.havoc_mi355x_sad4_make_runs(jobs.ctypes.data, len(jobs), max_run, runs.ctypes.data)
+        runs = np.zeros((max(1, len(jobs)), 8), np.int32)
+        n = L.havoc_mi355x_sad4_make_runs(jobs.ctypes.data, len(jobs), max_run, stride if stride is not None else 0, S, runs.ctypes.data)
         if n < 0:
             raise HavocError("havoc_mi355x_sad4_make_runs failed")
         return np.ascontiguousarray(runs[:n])
@@ -593,14 +604,17 @@ class Havoc:
         self.sad4_d(self.up(a), sa, self.up(b), sb, self._jobs(jobs, 8), out)
         return self.down(out, np.int32).reshape(-1, 4)
 
-    def sad4_runs(self, a, sa, b, sb, jobs, runs=None, max_run=128):
+    def sad4_runs(self, a, sa, b, sb, jobs, runs=None, max_run=0):
         """havoc_sad_multiref calls by runs (one search's consecutive calls share a staged window); runs None = cut by sad4_make_runs"""
         jobs = np.ascontiguousarray(jobs, np.int32)
         if runs is None:
-            runs = self.sad4_make_runs(jobs, max_run)
+            runs = self.sad4_make_runs(jobs, max_run, sb, np.asarray(b).itemsize)
+        runs = np.ascontiguousarray(runs, np.int32)
+        if runs.ndim == 2 and runs.shape[1] == 2:
+            runs = self.as_runs(runs)
         out = self.zeros(4 * len(jobs), np.int32)
-        if len(jobs):
-            self.sad4_runs_d(self.up(a), sa, self.up(b), sb, self._jobs(jobs, 8), self.up(np.ascontiguousarray(runs, np.int32)), out)
+        if len(jobs) and len(runs):
+            self.sad4_runs_d(self.up(a), sa, self.up(b), sb, self._jobs(jobs, 8), self.up(runs), out)
         return self.down(out, np.int32).reshape(-1, 4)
 
     def sad_surface(self, a, sa, b, sb, rng, jobs):

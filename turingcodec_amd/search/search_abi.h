@@ -110,6 +110,10 @@ typedef struct
     double seconds_gpu, seconds_host, seconds_total;
 } havoc_rqt_stats;
 
+/* havoc_search_intra_chain: a level's mode-order step raised a flag (havoc_mi355x_intra_order's d_total[1]): returns HAVOC_SEARCH_EORDER - flags, i.e. -101 = an order
+ * was cut at HAVOC_MI355X_INTRA_MAX_ORDER, -102 = a record was out of range, -103 = both; no result is written */
+#define HAVOC_SEARCH_EORDER (-100)
+
 /* 35-mode intra stage: per partition */
 typedef struct
 {

@@ -494,7 +494,7 @@ int havoc_search_intra_chain(havoc_mi355x_ctx *ctx, int S, int bitDepth, const h
     constexpr int K = HAVOC_MI355X_INTRA_MAX_ORDER;
     struct Work
     {
-        void *dCost, *dOrder, *dCount, *dSlot, *dTotal, *dIj, *dTj, *dRj, *dSj, *dOwner, *dPred, *dPiece, *dCoef, *dLevel, *dWork, *dCbf, *dSsd, *dStats, *dFin, *dSsd2, *dChoice, *hChoice;
+        void *dCost, *dOrder, *dCount, *dSlot, *dTotal, *hTotal, *dIj, *dTj, *dRj, *dSj, *dOwner, *dPred, *dPiece, *dCoef, *dLevel, *dWork, *dCbf, *dSsd, *dStats, *dFin, *dSsd2, *dChoice, *hChoice;
         int32_t lq, sf;
         size_t workBytes;
     } work[4];
@@ -518,7 +518,7 @@ int havoc_search_intra_chain(havoc_mi355x_ctx *ctx, int S, int bitDepth, const h
         RC(arena.get(size_t(most) * K * 4, &w.dOrder, &hx));
         RC(arena.get(size_t(most) * 4, &w.dCount, &hx));
         RC(arena.get(size_t(most) * 4, &w.dSlot, &hx));
-        RC(arena.get(8, &w.dTotal, &hx));
+        RC(arena.get(size_t(nlevels) * 8, &w.dTotal, &w.hTotal));      // a (slots handed out, flags) pair PER LEVEL: the flags of every level are looked at after the wait
         RC(arena.get(cap * sizeof(havoc_mi355x_intra_job), &w.dIj, &hx));
         RC(arena.get(cap * sizeof(havoc_mi355x_tu_fused_job), &w.dTj, &hx));
         RC(arena.get(cap * sizeof(havoc_mi355x_rdoq_job), &w.dRj, &hx));
@@ -556,13 +556,14 @@ int havoc_search_intra_chain(havoc_mi355x_ctx *ctx, int S, int bitDepth, const h
             const havoc_mi355x_tu_fused_job *tj = static_cast<const havoc_mi355x_tu_fused_job *>(w.dTj);
             RC(havoc_mi355x_intra_gather(ctx, S, layout, d_rec, d_owner, d_modes, parts, cnt, jobs, G.d_neighbours, mpm));
             RC(havoc_mi355x_intra_satd35(ctx, S, bitDepth, G.log2, d_src, src_stride, G.d_neighbours, jobs, cnt, static_cast<int32_t *>(w.dCost)));
+            int32_t *total = static_cast<int32_t *>(w.dTotal) + 2 * l;
             RC(havoc_mi355x_intra_order(ctx, static_cast<const int32_t *>(w.dCost), mpm, cnt, lsq.value, static_cast<int32_t *>(w.dOrder), static_cast<int32_t *>(w.dCount),
-                                        static_cast<int32_t *>(w.dSlot), static_cast<int32_t *>(w.dTotal)));
+                                        static_cast<int32_t *>(w.dSlot), total));
             RC(havoc_mi355x_intra_expand(ctx, jobs, static_cast<const int32_t *>(w.dOrder), static_cast<const int32_t *>(w.dCount), static_cast<const int32_t *>(w.dSlot), G.d_ctx_index + a,
                                          cnt, G.log2, q.quant_scale, q.quant_shift, q.inv_scale, w.lq, w.sf, sdh, static_cast<havoc_mi355x_intra_job *>(w.dIj),
                                          static_cast<havoc_mi355x_tu_fused_job *>(w.dTj), static_cast<havoc_mi355x_rdoq_job *>(w.dRj), static_cast<int32_t *>(w.dSj),
                                          static_cast<int32_t *>(w.dOwner)));
-            RC(havoc_mi355x_intra_fill_spare(ctx, static_cast<const int32_t *>(w.dTotal), cap, G.log2, static_cast<havoc_mi355x_intra_job *>(w.dIj),
+            RC(havoc_mi355x_intra_fill_spare(ctx, total, cap, G.log2, static_cast<havoc_mi355x_intra_job *>(w.dIj),
                                              static_cast<havoc_mi355x_tu_fused_job *>(w.dTj), static_cast<havoc_mi355x_rdoq_job *>(w.dRj), static_cast<int32_t *>(w.dSj),
                                              static_cast<int32_t *>(w.dOwner)));
             RC(havoc_mi355x_intra(ctx, S, bitDepth, G.log2, w.dPred, nn, G.d_neighbours, static_cast<const havoc_mi355x_intra_job *>(w.dIj), cap));
@@ -582,8 +583,20 @@ int havoc_search_intra_chain(havoc_mi355x_ctx *ctx, int S, int bitDepth, const h
             st.candidates += cap;
         }
     for (int g = 0; g < nsizes; ++g)
-        if (sizes[g].n) RC(havoc_mi355x_d2h_async(ctx, work[g].hChoice, work[g].dChoice, size_t(sizes[g].n) * sizeof(havoc_intra_rd_result)));
+        if (sizes[g].n)
+        {
+            RC(havoc_mi355x_d2h_async(ctx, work[g].hChoice, work[g].dChoice, size_t(sizes[g].n) * sizeof(havoc_intra_rd_result)));
+            RC(havoc_mi355x_d2h_async(ctx, work[g].hTotal, work[g].dTotal, size_t(nlevels) * 8));
+        }
     RC(havoc_mi355x_sync(ctx));
+    // havoc_mi355x_intra_order's flags of every level: bit 0 = a partition's refinement order was cut at HAVOC_MI355X_INTRA_MAX_ORDER, bit 1 = a record was
+    // out of range -- the champions are then not the reference's: no result is returned
+    int flags = 0;
+    for (int g = 0; g < nsizes; ++g)
+        if (sizes[g].n)
+            for (int l = 0; l < nlevels; ++l)
+                if (sizes[g].first[l + 1] > sizes[g].first[l]) flags |= static_cast<const int32_t *>(work[g].hTotal)[2 * l + 1];
+    if (flags & 3) return HAVOC_SEARCH_EORDER - (flags & 3);
     st.seconds_gpu = now() - tStart;
     for (int g = 0; g < nsizes; ++g)
         if (sizes[g].n) std::memcpy(sizes[g].out, work[g].hChoice, size_t(sizes[g].n) * sizeof(havoc_intra_rd_result));
