@@ -43,5 +43,5 @@ for _ in range(3):
 size = {}
 for w in (8, 16, 32, 64):
     size[w] = int((wl.sad4[runs[:, 0], 5] == w).sum())
-print(json.dumps({"form": form, "waves": os.environ.get("HAVOC_SAD4_RUN_WAVES", "4"), "unroll": os.environ.get("HAVOC_SAD4_RUN_UNROLL", "2"), "policy": policy, "max_run": os.environ.get("HAVOC_SAD4_MAX_RUN", "0"), "boxed": bool(boxed and not policy), "ms": round(best, 4), "calls": int(len(wl.sad4)), "runs": int(len(runs)), "runs_by_width": size,
+print(json.dumps({"form": form, "waves": os.environ.get("HAVOC_SAD4_RUN_WAVES", "4"), "unroll": os.environ.get("HAVOC_SAD4_RUN_UNROLL", "1"), "caps": os.environ.get("HAVOC_SAD4_CAPS", "16,48,128"), "policy": policy, "max_run": os.environ.get("HAVOC_SAD4_MAX_RUN", "0"), "boxed": bool(boxed and not policy), "ms": round(best, 4), "calls": int(len(wl.sad4)), "runs": int(len(runs)), "runs_by_width": size,
                   "checksum": int(hv.down(out, np.int32).astype(np.int64).sum())}))

@@ -358,7 +358,10 @@ int havoc_mi355x_sad4_make_runs(const havoc_mi355x_sad4_job *jobs, int njobs, in
     {
         const havoc_mi355x_sad4_job &a = jobs[i];
         const long area = (long)a.w * a.h;
-        const int cap = max_run >= 1 ? (max_run > 128 ? 128 : max_run) : (area >= 4096 ? 16 : area >= 1024 ? 48 : 128);
+        // calls per run by block size (what keeps the workgroups' work even: a 64x64 call is sixteen 16x16 calls' worth); HAVOC_SAD4_CAPS="big,middle,small" overrides (experiments)
+        static const struct Caps { int big = 16, mid = 48, small = 128; Caps() { if (const char *e = getenv("HAVOC_SAD4_CAPS")) sscanf(e, "%d,%d,%d", &big, &mid, &small); } } caps;
+        const int byArea = area >= 4096 ? caps.big : area >= 1024 ? caps.mid : caps.small;
+        const int cap = max_run >= 1 ? (max_run > 128 ? 128 : max_run) : (byArea < 1 ? 1 : byArea > 128 ? 128 : byArea);
         // the box grows call by call, in displacements (dx, dy) from the run's first candidate: |dx| <= stride / 2 makes the split of an offset unique
         long mnx = 0, mxx = 0, mny = 0, mxy = 0;
         bool boxed = st >= 64 && a.w > 0 && a.h > 0 && a.w <= 64 && a.h <= 64;

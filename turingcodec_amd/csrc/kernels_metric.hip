@@ -1030,8 +1030,8 @@ static int sad4_run_waves()
 {
     static const int v = [] {
         const char *e = getenv("HAVOC_SAD4_RUN_WAVES");
-        const int n = e ? atoi(e) : 2;      // two wavefronts per run with the cutter's run lengths: profiles/r05/sad4_run_policy.jsonl
-        return n == 1 || n == 4 ? n : 2;
+        const int n = e ? atoi(e) : 4;      // four wavefronts per run: 0.155 ms against 0.172 with two, 1.27 M calls (profiles/r05/sad4_run_policy.txt)
+        return n == 1 || n == 2 ? n : 4;
     }();
     return v;
 }
@@ -1045,7 +1045,7 @@ hipError_t launch_sad4_runs(hipStream_t st, int S, const void *src, long ss, con
     const float inv = 1.0f / (float)rs;
     const int nw = sad4_run_waves();
     const dim3 g(nruns), b(64 * nw);
-    static const int unroll = [] { const char *e = getenv("HAVOC_SAD4_RUN_UNROLL"); return e && *e == '1' ? 1 : 2; }();      // calls per pass of a lane group
+    static const int unroll = [] { const char *e = getenv("HAVOC_SAD4_RUN_UNROLL"); return e && *e == '2' ? 2 : 1; }();      // calls per pass of a lane group (2: no gain once the cutter keeps big blocks' runs short)
 #define HAVOC_RUN(SS, NW) do { if (unroll == 1) hipLaunchKernelGGL((k_sad4r<SS, NW, 1>), g, b, 0, st, s, ss, r, rs, inv, j, n, rn, nruns, out); \
                                else hipLaunchKernelGGL((k_sad4r<SS, NW, 2>), g, b, 0, st, s, ss, r, rs, inv, j, n, rn, nruns, out); } while (0)
     if (S == 1) { if (nw == 1) HAVOC_RUN(1, 1); else if (nw == 2) HAVOC_RUN(1, 2); else HAVOC_RUN(1, 4); }
