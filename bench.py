@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 # one-launch-per-picture search above all) queue up behind each other.  Must be in the environment before the runtime starts, so the
 # decision-driven path is measured in a process of its own (`--decisions 2`, started by the plain run) with 16 queues; the primitive-batch
 # step keeps the runtime's default (its 8 lanes are branches of one HIP graph; measured slower with 16 queues: 0.62 against 0.49 ms).
-if "--decisions" in sys.argv[:-1] and sys.argv[sys.argv.index("--decisions") + 1] == "2":
+if "--decisions" in sys.argv[:-1] and sys.argv[sys.argv.index("--decisions") + 1] in ("2", "4"):
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6300 GB/s achievable
@@ -64,6 +64,7 @@ def parse_args():
                     help="1 (default): the plain N=1 line also carries, under `extra`, the DECISION-DRIVEN path (turingcodec_amd.decisions."
                          "DecisionPicture: motion searches in WPP wavefront order with predictors derived from earlier decisions, batch-fed; then the "
                          "TU chain on the chosen vectors) at 1080p QP32 and 4K QP32, and its ratio to `value`; 2: only that (diagnostic line); 0: off")
+    ap.add_argument("--virtual-ranks", type=int, default=8, help="--decisions 4: contexts / host threads that execute the frame-parallel schedule on ONE GPU")
     ap.add_argument("--decision-pictures", type=int, default=16, help="contexts built for the decision-driven path: `value` is measured with 4 independent pictures in flight (the "
                     "leaf B pictures of one SOP), and again with 8 (what the pipelined hierarchy has in flight) and with all of them; one host thread + "
                     "context each")
@@ -557,9 +558,10 @@ def cpu_worker(args):
     tasks = []   # (callable(b, e), njobs, group the GPU bench times it under)
     results = {}   # name -> array: what the reference computed for the sampled jobs (full-size parity check in main)
 
-    def add(group, fn, n, always=False):
+    def add(group, fn, n, always=False, like=None):
+        """`like`: cut this task's jobs into the thread slices of a table of that length -- for a task whose job i reads what job i of an earlier task wrote"""
         if n and (inter or always):
-            tasks.append((fn, n, group))
+            tasks.append((fn, n, group, like or n))
             if os.environ.get("HAVOC_BENCH_TRACE"):
                 sys.stderr.write(f"task {len(tasks)} n={n}\n")
                 sys.stderr.flush()
@@ -575,7 +577,11 @@ def cpu_worker(args):
     add("satd_inter", lambda b, e: lib.ref_run_satd(handle, S, P(luma), ip(st), P(pred), ip(64), P(jsa), b, e, P(osa)), len(jsa))
     add("pred_uni4", lambda b, e: lib.ref_run_pred_uni(handle, S, 4, bd, P(cpred), ip(32), P(chroma), ip(cst), P(ju4), b, e), len(ju4))
     add("pred_bi8", lambda b, e: lib.ref_run_pred_bi(handle, S, 8, bd, P(bi), ip(64), P(luma), ip(st), P(jb8), b, e), len(jb8))
-    add("subtract_bi", lambda b, e: lib.ref_run_subtract_bi(handle, S, bd, P(sbi), ip(64), P(bi), ip(64), P(luma), ip(st), P(jsb), b, e), len(jsb))
+    # SubtractBi job i reads the bi-prediction slot job i of pred_bi8 wrote, and that table is longer: sliced like IT, so that a thread reads only slots it has itself
+    # finished.  (Sliced by its own length -- rounds 1-4 -- another thread could be REWRITING the slot meanwhile: the reference's JIT stores 16 bytes per 8 samples it
+    # computes (PRED_BI_V_8NxH: packuswb m3, m3; movdqu [dst], m3 -- havoc/pred_inter.cpp:880-882), so columns x + 8 .. x + 15 of a row briefly hold a copy of columns
+    # x .. x + 7 -- the "17 subtract_bi values" of round 4's driver run, caught again and located in round 5: NOTEBOOK.md.)
+    add("subtract_bi", lambda b, e: lib.ref_run_subtract_bi(handle, S, bd, P(sbi), ip(64), P(bi), ip(64), P(luma), ip(st), P(jsb), b, e), len(jsb), like=len(jb8))
     add("pred_bi4", lambda b, e: lib.ref_run_pred_bi(handle, S, 4, bd, P(cbi), ip(32), P(chroma), ip(cst), P(jb4), b, e), len(jb4))
     keep = [j4, js, ju8, ju4, jb8, jb4, jsb, jsa, o4, os_, osa]
     late = []
@@ -679,9 +685,9 @@ def cpu_worker(args):
     def run_slice(k, record):
         """thread k runs its contiguous slice of EVERY task in order: a chain's later primitives read what the same
         thread's earlier ones wrote, so no barrier between tasks is needed (and none is timed)"""
-        for fn, n, group in tasks:
-            chunk = (n + cores - 1) // cores
-            b, e = k * chunk, min(n, (k + 1) * chunk)
+        for fn, n, group, like in tasks:
+            chunk = (like + cores - 1) // cores
+            b, e = min(n, k * chunk), min(n, (k + 1) * chunk)
             if b < e:
                 t = time.perf_counter()
                 fn(b, e)
@@ -711,7 +717,7 @@ def cpu_worker(args):
                 flat[name] = v
         np.savez(args.cpu_out, **flat)
     print(json.dumps({"seconds_per_sample": dt_s, "stride": stride, "cores": cores, "handle": handle,
-                      "jobs": int(sum(n for _, n, _ in tasks)), "reps": reps,
+                      "jobs": int(sum(t[1] for t in tasks)), "reps": reps,
                       "group_seconds_per_sample": {g: sum(a.get(g, 0.0) for a in acc) / cores / reps for g in acc[0]}}))
 
 
@@ -1339,6 +1345,100 @@ def decision_frame_parallel(args, torch, dist, Havoc, rank, world, local):
                           "checksum_of_poc_checksums": total, "poc_checksums": {str(k): v for k, v in sorted(sums.items())}}), flush=True)
 
 
+def decision_virtual_ranks(args, torch, Havoc):
+    """--decisions 4: ONE sequence through the decision step with its real picture dependencies on ONE GPU (the single-device half): the frame-parallel
+    schedule of K = --virtual-ranks ranks (DagSchedule: the hierarchical-B docket, a picture starts after the slots of its references) executed by K host threads, each with
+    its own DecisionPicture context and stream, sharing one DPB mirror in device memory -- what K GPUs would do with the broadcasts replaced by the shared mirror.  Slots are
+    separated by a barrier of the threads (a picture's references are complete when its slot starts; a mirror slot is reused as the schedule says).  Reports pictures/s of the
+    whole sequence and a checksum per POC: equal to --decisions 3 on one rank (tests), whatever K.  The bound of ONE sequence is its anchor chain -- POC 8 -> 16 -> 24 are
+    serial, each a picture at reference distance 8 -- so at most 8 pictures per latency of such a picture, however many contexts run."""
+    import threading
+    from turingcodec_amd import workload
+    from turingcodec_amd.decisions import DecisionPicture
+    from turingcodec_amd.frame_parallel import DagSchedule, ReferenceExchange
+    K = max(1, args.virtual_ranks)
+    w, h = (int(v) for v in args.res.split("x"))
+    n_sops = max(1, (args.pictures - 1) // 8)
+    sched = DagSchedule(K, n_sops=n_sops, lag=args.lag or None)
+    cores = usable_cores()
+    ctxs = []
+    for r in range(K):
+        hv = Havoc(0, stream="new")
+        ctxs.append(DecisionPicture(hv, w, h, args.bit_depth, args.qp, seed=args.seed, threads=max(1, cores // K), distance=max(1, args.decision_distance)))
+    dp0 = ctxs[0]
+    pe, cpe = dp0.pe, dp0.cpe
+    exch = [ReferenceExchange(None, r, sched, pe, cpe, dp0.d_pic) for r in range(K)]
+    for e in exch[1:]:      # ONE mirror: what a broadcast would have delivered is simply there
+        e.dpb, e.dpb_luma, e.dpb_cb, e.dpb_cr = exch[0].dpb, exch[0].dpb_luma, exch[0].dpb_cb, exch[0].dpb_cr
+    frames = workload.synth_frames(w, h, 8 * n_sops + 1, args.seed, args.bit_depth)
+    sources = []
+    for f in frames:
+        planes = [workload.pad_plane(f[0], dp0.PAD), workload.pad_plane(f[1], dp0.PAD // 2), workload.pad_plane(f[2], dp0.PAD // 2)]
+        sources.append([dp0.hv.up(np.ascontiguousarray(p.ravel())) for p in planes])
+    for dp in ctxs:
+        dp.step()
+        dp.step()      # records the fixed launch sequences into HIP graphs
+        dp.hv.sync()
+    torch.cuda.synchronize()
+    nslots = sched.slots_for_sequence()
+    barrier = threading.Barrier(K)
+    sums, busy, errors = {}, [0.0] * K, []
+
+    def worker(r):
+        dp, hv, ex = ctxs[r], ctxs[r].hv, exch[r]
+        try:
+            for t in range(nslots):
+                pic = ex.picture_of(t)
+                if pic is not None:
+                    t0 = time.perf_counter()
+                    src = sources[pic.poc]
+                    with torch.cuda.stream(hv.tstream):
+                        torch._foreach_copy_([dp.d_pic[:src[0].numel()], dp.d_cpic[:src[1].numel()], dp.d_cpic[3 * cpe:3 * cpe + src[2].numel()]], src)
+                        if pic.refs:
+                            s0, s1 = ex.refs(pic)
+                            torch._foreach_copy_([dp.d_pic[pe:2 * pe], dp.d_pic[2 * pe:3 * pe], dp.d_cpic[cpe:2 * cpe], dp.d_cpic[2 * cpe:3 * cpe], dp.d_cpic[4 * cpe:5 * cpe],
+                                                  dp.d_cpic[5 * cpe:6 * cpe]],
+                                                 [ex.dpb_luma[s0], ex.dpb_luma[s1], ex.dpb_cb[s0], ex.dpb_cb[s1], ex.dpb_cr[s0], ex.dpb_cr[s1]])
+                    dp.step()
+                    hv.pad_block_d(dp.crecon, dp.corigin, w // 2, h // 2, dp.cstride, dp.PAD // 2)
+                    hv.pad_block_d(dp.crecon, cpe + dp.corigin, w // 2, h // 2, dp.cstride, dp.PAD // 2)
+                    with torch.cuda.stream(hv.tstream):
+                        if args.poc_checksums:
+                            sums[pic.poc] = int(dp.recon.to(torch.int64).sum().item()) * 1000003 + int(dp.crecon.to(torch.int64).sum().item())
+                        if pic.is_reference:
+                            ex.stage(t, (dp.recon[:pe], dp.crecon[:cpe], dp.crecon[cpe:2 * cpe]))
+                    hv.sync()
+                    busy[r] += time.perf_counter() - t0
+                barrier.wait()
+        except Exception as e:      # a thread that dies must not leave the others at the barrier
+            errors.append(repr(e))
+            barrier.abort()
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(K)]
+    t0 = time.perf_counter()
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if errors:
+        raise RuntimeError("; ".join(errors))
+    pictures = 8 * n_sops + 1
+    total = 0
+    for poc in sorted(sums):
+        total = (total * 1000003 + sums[poc]) % (1 << 61)
+    line = {"metric": "DIAGNOSTIC (one sequence through the decision step with its picture dependencies, K virtual ranks on one GPU) -- not the benchmark metric",
+            "value": round(pictures / el, 2), "unit": "pictures/s", "n_gpus": 1, "virtual_ranks": K, "pictures": pictures, "slots": nslots, "seconds": round(el, 4),
+            "busy_fraction_of_the_contexts": round(sum(busy) / (K * el), 3),
+            "config": {"workload": f"{args.res} {args.bit_depth}-bit QP{args.qp}: IDR + {n_sops} SOPs of 8, hierarchical-B docket, one DecisionPicture.step per picture, "
+                                   f"schedule of {K} ranks (lag {sched.lag}) run by {K} host threads / contexts sharing one DPB mirror"},
+            "checksum_of_poc_checksums": total if sums else None}
+    if args.poc_checksums:
+        line["poc_checksums"] = {str(k): v for k, v in sorted(sums.items())}
+    print(json.dumps(line), flush=True)
+
+
 def cpu_decision_walk(args, keep):
     """cpu_baseline leg: the SAME decision walk (same pictures, PUs, order, derived predictors) one table call at a time through the
     reference's x86-JIT havoc tables on one host core (tests/search_client.cpp over oracle/_ref -- the checker, timed here as the
@@ -1689,6 +1789,8 @@ def main():
     if world != max(1, args.gpus):
         sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE): the line would not be what was asked for\n")
         sys.exit(2)
+    if args.decisions == 4:      # one sequence with its picture dependencies, K virtual ranks on this GPU
+        return decision_virtual_ranks(args, torch, Havoc)
     if args.decisions == 2:      # only the decision-driven path of --res / --qp, one line (also how the plain run measures it: see the top of this file)
         keep = {} if args.decision_walk else None
         r = decision_path(args, Havoc, args.res, args.bit_depth, args.qp, max(1, args.decision_pictures), seconds=(1.0 if args.decision_pictures <= 8 else 1.5), keep=keep)
@@ -1841,7 +1943,9 @@ def main():
         ktimes, kcount = dev.kernel_times_ms(args.kernel_reps)
         kbytes = wl.algorithmic_bytes()
         kbytes["sad_surface"] = kbytes["sad_surface"](args.ime_range)
-        dom = max(ktimes, key=ktimes.get)
+        # the dominant KERNEL: the launch group whose single launch takes longest (a group's time / its launches per step).  Round 4 picked the group with the largest TOTAL,
+        # which since the run form of sad4 would be `rdoq` -- four to five launches of different kernels per step, none of them the step's longest
+        dom = max(ktimes, key=lambda k: ktimes[k] / kcount[k])
         # roofline of the dominant launch group.  HBM: `achieved` counts UNIQUE algorithmic bytes -- SURVEY 8(d)'s operands once +
         # results once per call, except where the calls of one search overlap (sad4: the box of a search's candidates + its source block once per run + 16 B per
         # call; the per-call figure, which counts every reference sample ~112 times, is kept beside it as `operand_bytes_per_step`), so frac <= 1 by construction
@@ -2018,8 +2122,13 @@ def main():
         out["parity"] = "red" if red else "green"
         if red:
             out["parity_problems"] = red
-        line = json.dumps(compact_line(out, args))
-        assert len(line) < 8000, len(line)
+        short = compact_line(out, args)
+        line = json.dumps(short)
+        for drop in ("poc_checksums", "whole_step", "extra", "timing"):      # the line must stay parseable by the driver whatever a run adds to it: shed the least needed first
+            if len(line) < 7800:
+                break
+            short.pop(drop, None)
+            line = json.dumps(short)
         if args.detail_out:
             try:
                 os.makedirs(os.path.dirname(os.path.abspath(args.detail_out)), exist_ok=True)

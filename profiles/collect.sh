@@ -8,7 +8,7 @@
 #         (the figure bench.py's roofline.achieved is built from).  Pass 2: the same with the default 8 lanes + graph
 #         (durations overlap; kept to show the overlap, not for the roofline).  Passes 3/4: PMC counters, one counter
 #         per pass and no trace domains beside them.  Pass 5: the plain bench line with the CPU baseline.
-tag=${1:-r04}
+tag=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 mkdir -p $O

@@ -350,3 +350,25 @@ def test_decision_pipeline_two_rank_rehearsal_equals_one_rank_with_and_without_b
     assert len(set(one["poc_checksums"].values())) == 17                       # every picture of the sequence is its own
     assert one_bands["config"]["broadcasts"] == 9 * 2 * 3 and one["config"]["broadcasts"] == 9
     assert two["slots"] < one["slots"]                                          # two ranks: fewer time slots for the same sequence
+
+
+@pytest.mark.gpu
+def test_one_sequence_with_its_dependencies_on_virtual_ranks_equals_the_one_rank_pipeline():
+    """bench.py --decisions 4: the frame-parallel schedule of K ranks executed by K host threads / contexts on ONE GPU, sharing one DPB mirror (round 5): per-POC
+    checksums equal to the one-rank pipeline of --decisions 3, for 2 and 8 virtual ranks -- pictures really predict from the pictures other contexts reconstructed,
+    and nothing depends on who ran what when"""
+    import json
+    import subprocess
+    import sys
+    bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+
+    def run(extra):
+        out = subprocess.run([sys.executable, bench, "--res", "416x240", "--pictures", "17", "--poc-checksums"] + extra, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    one = run(["--decisions", "3", "--gpus", "1"])
+    two = run(["--decisions", "4", "--virtual-ranks", "2"])
+    eight = run(["--decisions", "4", "--virtual-ranks", "8"])
+    assert one["pictures"] == two["pictures"] == eight["pictures"] == 17 and len(two["poc_checksums"]) == 17
+    assert one["poc_checksums"] == two["poc_checksums"] == eight["poc_checksums"]
+    assert eight["slots"] < two["slots"] < one["slots"]

@@ -70,3 +70,22 @@ def test_replayed_step_reproduces_the_eager_step_with_bi_slots_zeroed_between_re
         if len(bad) > 4:
             break
     assert not bad, bad[:3]
+
+
+def test_the_references_jit_bi_prediction_stores_sixteen_bytes_per_eight_samples(reference_jit):
+    """ROOT CAUSE of the "17 subtract_bi values" of round 4's driver run (and of the one value gpu call r05h caught and located: reference 168, GPU 177 before AND after an
+    eager re-run, job 1616, x = 27): not the GPU.  The reference's JIT bi-prediction computes 8 samples per step and stores 16 bytes (`packuswb m3, m3; movdqu [dst], m3`,
+    havoc/pred_inter.cpp:880-882), so columns x + 8 .. x + 15 of a row hold a COPY of columns x .. x + 7 until the next step overwrites them -- harmless in one thread (it is the
+    licence of havoc/pred_inter.h:27 to write to the right of the block), but bench.py's CPU worker cut `subtract_bi` into thread slices of its OWN table length while its job i
+    reads the slot job i of the longer `pred_bi8` table writes: another thread could be REWRITING the slot it read.  Fixed by slicing like the table it depends on
+    (bench.py: add(..., like=len(jb8))).  What stays visible after a call is the last step's spill to the right of the block: that is what this test shows."""
+    rng = np.random.default_rng(2)
+    stride = 128
+    ref = rng.integers(0, 256, 96 * stride).astype(np.uint8)
+    for w in (8, 16, 24, 32):
+        dst = np.full(64 * 64 + 64, 0xAA, np.uint8)
+        reference_jit.pred_bi(dst, 0, 64, ref, 20 * stride + 30, 22 * stride + 41, stride, w, 8, 1, 2, 3, 1, 8, 8)
+        rows = dst[:8 * 64].reshape(8, 64)
+        cw = (w + 15) // 16 * 16                                                 # the table entry's width class: columns computed
+        assert np.array_equal(rows[:, cw:cw + 8], rows[:, cw - 8:cw]), w        # the spill: a copy of the last eight computed columns (x = 27 of a 32-wide block is such a
+        assert (rows[:, cw + 8:cw + 16] == 0xAA).all(), w                        # column while the row's third step has run and its fourth has not) ... and nothing beyond it

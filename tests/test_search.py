@@ -132,7 +132,9 @@ def _check_report(r, searches):
     # with at most ~3 launches per search (one surface, sometimes a second, one tile-SATD batch)
     assert c["uni"]["one_job_path"] == 0 and c["uni"]["served"] > 30 * searches
     assert c["uni"]["launches_per_search"] <= 3.0, c["uni"]
-    assert c["bi"]["one_job_path"] == 0
+    # a bi-directional refinement: SubtractBi and the bi-prediction of its outcome are operands-from-the-host calls (one launch each: Search.hpp:1542, Dsp.h:832-864;
+    # round 5 counts EVERY table call, these two were not counted before); its SAD grid, interpolations and SATDs are answered from precomputed data
+    assert c["bi"]["one_job_path"] <= 2 * c["bi"]["searches"] and c["bi"]["served"] > 20 * c["bi"]["searches"], c["bi"]
     # the same searches from many host threads at once through one table set (the reference's WPP threads share theirs)
     assert c["threaded"]["threads"] >= 8 and c["threaded"]["mismatching_searches"] == [] and c["threaded"]["one_job_path"] == 0, c["threaded"]
     # unregistered planes still work: one launch per table call
