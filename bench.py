@@ -64,6 +64,7 @@ def parse_args():
                     help="1 (default): the plain N=1 line also carries, under `extra`, the DECISION-DRIVEN path (turingcodec_amd.decisions."
                          "DecisionPicture: motion searches in WPP wavefront order with predictors derived from earlier decisions, batch-fed; then the "
                          "TU chain on the chosen vectors) at 1080p QP32 and 4K QP32, and its ratio to `value`; 2: only that (diagnostic line); 0: off")
+    ap.add_argument("--vr-dataflow", type=int, default=1, help="--decisions 4: 1 = a picture starts when its references are in the mirror (default); 0 = a barrier between the slots")
     ap.add_argument("--virtual-ranks", type=int, default=8, help="--decisions 4: contexts / host threads that execute the frame-parallel schedule on ONE GPU")
     ap.add_argument("--decision-pictures", type=int, default=16, help="contexts built for the decision-driven path: `value` is measured with 4 independent pictures in flight (the "
                     "leaf B pictures of one SOP), and again with 8 (what the pipelined hierarchy has in flight) and with all of them; one host thread + "
@@ -1383,6 +1384,21 @@ def decision_virtual_ranks(args, torch, Havoc):
     nslots = sched.slots_for_sequence()
     barrier = threading.Barrier(K)
     sums, busy, errors = {}, [0.0] * K, []
+    # --vr-dataflow 1 (default): no barrier between the slots -- a picture starts when the pictures it predicts from are in the mirror, and stages its reconstruction when every
+    # picture that predicts from the mirror slot's previous occupant has taken its copy (each context still works through its own pictures in slot order, so nothing can wait
+    # for something scheduled after it)
+    dataflow = bool(args.vr_dataflow)
+    done = {}                  # poc -> Event: the picture's reconstruction is in the mirror
+    readers_left = {}          # poc -> pictures that still have to copy it out of the mirror
+    occupant = {}              # mirror slot -> poc staged there last
+    lock = threading.Condition()
+    for t in range(nslots):
+        for q in sched.slot(t):
+            if q is not None:
+                done[q.poc] = threading.Event()
+                if q.refs:
+                    for ref_poc in {q.l0, q.l1}:
+                        readers_left[ref_poc] = readers_left.get(ref_poc, 0) + 1
 
     def worker(r):
         dp, hv, ex = ctxs[r], ctxs[r].hv, exch[r]
@@ -1390,6 +1406,10 @@ def decision_virtual_ranks(args, torch, Havoc):
             for t in range(nslots):
                 pic = ex.picture_of(t)
                 if pic is not None:
+                    if dataflow and pic.refs:
+                        for ref_poc in {pic.l0, pic.l1}:
+                            if not done[ref_poc].wait(timeout=120):
+                                raise RuntimeError(f"POC {pic.poc}: reference {ref_poc} never arrived")
                     t0 = time.perf_counter()
                     src = sources[pic.poc]
                     with torch.cuda.stream(hv.tstream):
@@ -1402,14 +1422,28 @@ def decision_virtual_ranks(args, torch, Havoc):
                     dp.step()
                     hv.pad_block_d(dp.crecon, dp.corigin, w // 2, h // 2, dp.cstride, dp.PAD // 2)
                     hv.pad_block_d(dp.crecon, cpe + dp.corigin, w // 2, h // 2, dp.cstride, dp.PAD // 2)
+                    if dataflow:
+                        hv.sync()      # (the step ended with a wait; the copies out of the mirror were queued before it: they are done)
+                        with lock:
+                            if pic.refs:
+                                for ref_poc in {pic.l0, pic.l1}:
+                                    readers_left[ref_poc] -= 1
+                            lock.notify_all()
+                            if pic.is_reference:      # the mirror slot's previous picture must have been read by everyone who predicts from it
+                                prev = occupant.get(ex.slot_of(pic.poc))
+                                if prev is not None and not lock.wait_for(lambda: readers_left.get(prev, 0) <= 0, timeout=120):
+                                    raise RuntimeError(f"POC {pic.poc}: the mirror slot of POC {prev} was never released")
+                                occupant[ex.slot_of(pic.poc)] = pic.poc
                     with torch.cuda.stream(hv.tstream):
                         if args.poc_checksums:
                             sums[pic.poc] = int(dp.recon.to(torch.int64).sum().item()) * 1000003 + int(dp.crecon.to(torch.int64).sum().item())
                         if pic.is_reference:
                             ex.stage(t, (dp.recon[:pe], dp.crecon[:cpe], dp.crecon[cpe:2 * cpe]))
                     hv.sync()
+                    done[pic.poc].set()
                     busy[r] += time.perf_counter() - t0
-                barrier.wait()
+                if not dataflow:
+                    barrier.wait()
         except Exception as e:      # a thread that dies must not leave the others at the barrier
             errors.append(repr(e))
             barrier.abort()
@@ -1430,7 +1464,7 @@ def decision_virtual_ranks(args, torch, Havoc):
         total = (total * 1000003 + sums[poc]) % (1 << 61)
     line = {"metric": "DIAGNOSTIC (one sequence through the decision step with its picture dependencies, K virtual ranks on one GPU) -- not the benchmark metric",
             "value": round(pictures / el, 2), "unit": "pictures/s", "n_gpus": 1, "virtual_ranks": K, "pictures": pictures, "slots": nslots, "seconds": round(el, 4),
-            "busy_fraction_of_the_contexts": round(sum(busy) / (K * el), 3),
+            "busy_fraction_of_the_contexts": round(sum(busy) / (K * el), 3), "between_slots": "dependencies only (dataflow)" if dataflow else "barrier",
             "config": {"workload": f"{args.res} {args.bit_depth}-bit QP{args.qp}: IDR + {n_sops} SOPs of 8, hierarchical-B docket, one DecisionPicture.step per picture, "
                                    f"schedule of {K} ranks (lag {sched.lag}) run by {K} host threads / contexts sharing one DPB mirror"},
             "checksum_of_poc_checksums": total if sums else None}

@@ -656,7 +656,10 @@ int havoc_mi355x_pred_jobs(havoc_mi355x_ctx *ctx, const havoc_mi355x_field_layou
  * an 11 x 11 integer grid, two sub-sample steps); mv, mvd, mvp_flag, calls and cost_subpel (= the cost) are filled.  Nothing of the refinement
  * feeds the walk (the motion field keeps the uni-directional vectors), so it is two more launches after it -- a workgroup per PU, list 0 then list 1.  d_phase: the 16 fractional-sample planes of each reference picture
  * (havoc_mi355x_interp_planes; plane 0 = the picture), which must reach ctb_size + 20 samples beyond the picture on every side; origins are the
- * sample offsets of sample (0, 0).  Everything stays on the device: nothing is uploaded or downloaded by this call. */
+ * sample offsets of sample (0, 0).  Everything stays on the device: nothing is uploaded or downloaded by this call.
+ * The SOURCE plane d_src is read in whole CTUs (the kernel stages a CTU's ctb_size x ctb_size source block with 16-byte loads): when the picture's width / height are
+ * not multiples of ctb_size it must be READABLE up to the next multiple -- i.e. own a border of at least ctb_size - 8 samples to the right and below (the picture store's
+ * planes have 96; the values there reach no result: only samples inside a prediction unit are measured). */
 typedef struct
 {
     int32_t pic_width, pic_height, ctb_size, concurrent_frames;

@@ -376,7 +376,8 @@ int havoc_search_picture_uni(havoc_mi355x_ctx *ctx, int S, const havoc_search_pa
 // The same picture with the decision loops ON THE DEVICE (havoc_mi355x_search_picture_uni, csrc/kernels_search.hip: decision.hpp compiled for
 // gfx950, one workgroup per chain of dependent searches, one launch per wavefront step): the PU list goes down, the results come back, nothing in
 // between -- no surfaces, no rounds, no replay threads.  Arguments as havoc_search_picture_uni; the phase planes must reach 84 samples beyond the
-// picture (ref_pad >= 96 with the planes of havoc_mi355x_interp_planes(12, 4, ...)).  Results identical to havoc_search_picture_uni's except
+// picture (ref_pad >= 96 with the planes of havoc_mi355x_interp_planes(12, 4, ...)); the SOURCE plane is read in whole CTUs, so it must be readable up to the
+// next multiple of the CTU size to the right of and below the picture (a border of ctb_size - 8 samples; include/havoc_mi355x.h).  Results identical to havoc_search_picture_uni's except
 // `replays`.  d_field_keep (optional, device): where the decided field stays for later launches (int16 [2][cells][2]).  out_bi (optional, host,
 // [2 * n]): the bi-directional refinements of searchBi after each PU's two searches (include/havoc_mi355x.h: havoc_mi355x_search_picture_uni).
 int havoc_search_picture_uni_device(havoc_mi355x_ctx *ctx, int S, const havoc_search_params *params, const void *d_src, int64_t src_origin, intptr_t src_stride,
