@@ -1,0 +1,105 @@
+// amvp.hpp -- the reference's derivation of a prediction unit's two motion vector predictors (HEVC 8.5.3.2.6 / 8.5.3.2.7 as turing/Mvp.h:195-436 applies it),
+// restated as DATA-ONLY code: what it reads of the encoder's state is handed in as five neighbour records and the temporal candidate.
+//
+// Why it is here: picture_order.hpp's derivePredictors is a two-candidate stand-in (the cell left of the bottom-left sample, the cell above the
+// top-right sample) and every decision-path number depends on it.  This file is the real rule, PINNED: the traced reference encoder records, for every searchUni call,
+// the five neighbours as its neighbourPuData() returned them, the temporal candidate and the two predictors it derived (oracle/trace_hooks.h: HAVOC_TRACE_AMVP, inserted
+// after Search.hpp:1779); tests/test_trace_pin.py requires deriveAmvp() to give the same two predictors for every record of six encodes.  It is NOT yet what the decision
+// path's walk uses: that needs the neighbours' prediction lists and reference pictures in the motion field (today: one vector per list and cell), and the above-right
+// neighbour B0 makes the wavefront's two-CTU lag a real requirement (HAVOC_SEARCH_ROW_LAG=1 is only legal for the stand-in).
+#pragma once
+
+#include "decision.hpp"
+
+namespace havoc_search {
+
+struct AmvpNeighbour
+{
+    bool available = false;      // neighbourPuData(...).isAvailable(): inside the picture / slice, already coded, not intra (turing/StateSpatial.h:208-260)
+    bool predFlag[2] = {false, false};
+    int refPoc[2] = {0, 0};      // picture order count of the reference picture the neighbour's list-l vector points into
+    Mv mv[2];
+};
+
+// 8.5.3.2.7 (turing/Mvp.h: distScale): the vector of a candidate that points into another reference picture, scaled by the ratio of the picture distances
+HAVOC_HD inline int amvpClip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
+HAVOC_HD inline Mv amvpDistScale(Mv mv, int tD, int tB)
+{
+    const int td = amvpClip3(-128, 127, tD), tb = amvpClip3(-128, 127, tB);
+    const int tx = (16384 + (td < 0 ? -td : td) / 2) / td;
+    const int f = amvpClip3(-4096, 4095, (tb * tx + 32) >> 6);
+    auto one = [f](int c) {
+        const int p = f * c;
+        const int a = ((p < 0 ? -p : p) + 127) >> 8;
+        return amvpClip3(-32768, 32767, p < 0 ? -a : a);
+    };
+    return Mv(int16_t(one(mv.x)), int16_t(one(mv.y)));
+}
+
+// nb[0..4] = A0 (below-left), A1 (left), B0 (above-right), B1 (above), B2 (above-left); X = the list being predicted, curPoc / targetPoc = the picture order counts of
+// the current picture and of RefPicList(X)[refIdxLX]; every reference picture is a short-term one (the reference encoder uses no long-term pictures);
+// colAvailable / col = the temporal candidate (Mvp.h:141-181), consulted only where the rule consults it.  out[0..1] = mvpListLX[0..1].
+HAVOC_HD inline void deriveAmvp(int X, int curPoc, int targetPoc, const AmvpNeighbour nb[5], bool colAvailable, Mv col, Mv out[2])
+{
+    const int Y = 1 - X;
+    bool availableA = false, availableB = false;
+    Mv mvA, mvB;
+    const bool isScaled = nb[0].available || nb[1].available;
+    // A: the first of A0, A1 with a vector into the target picture (own list first) ...
+    for (int k = 0; k < 2 && !availableA; ++k)
+        if (nb[k].available)
+        {
+            if (nb[k].predFlag[X] && nb[k].refPoc[X] == targetPoc) { availableA = true; mvA = nb[k].mv[X]; }
+            else if (nb[k].predFlag[Y] && nb[k].refPoc[Y] == targetPoc) { availableA = true; mvA = nb[k].mv[Y]; }
+        }
+    // ... else the first with any vector, scaled to the target picture's distance (step 7)
+    for (int k = 0; k < 2 && !availableA; ++k)
+        if (nb[k].available)
+        {
+            int poc = 0;
+            if (nb[k].predFlag[X]) { availableA = true; mvA = nb[k].mv[X]; poc = nb[k].refPoc[X]; }
+            else if (nb[k].predFlag[Y]) { availableA = true; mvA = nb[k].mv[Y]; poc = nb[k].refPoc[Y]; }
+            if (availableA && poc != targetPoc) mvA = amvpDistScale(mvA, curPoc - poc, curPoc - targetPoc);
+        }
+    // B: the first of B0, B1, B2 with a vector into the target picture
+    for (int k = 2; k < 5 && !availableB; ++k)
+        if (nb[k].available)
+        {
+            if (nb[k].predFlag[X] && nb[k].refPoc[X] == targetPoc) { availableB = true; mvB = nb[k].mv[X]; }
+            else if (nb[k].predFlag[Y] && nb[k].refPoc[Y] == targetPoc) { availableB = true; mvB = nb[k].mv[Y]; }
+        }
+    // steps 4 / 5: with neither A0 nor A1 there, B's unscaled candidate becomes A and B is looked for again, this time allowing a scaled one
+    if (!isScaled && availableB)
+    {
+        availableA = true;
+        mvA = mvB;
+    }
+    if (!isScaled)
+    {
+        availableB = false;
+        for (int k = 2; k < 5 && !availableB; ++k)
+            if (nb[k].available)
+            {
+                int poc = 0;
+                if (nb[k].predFlag[X]) { availableB = true; mvB = nb[k].mv[X]; poc = nb[k].refPoc[X]; }
+                else if (nb[k].predFlag[Y]) { availableB = true; mvB = nb[k].mv[Y]; poc = nb[k].refPoc[Y]; }
+                if (availableB && poc != targetPoc) mvB = amvpDistScale(mvB, curPoc - poc, curPoc - targetPoc);
+            }
+    }
+    // the temporal candidate only when A and B do not already give two different predictors
+    const bool useCol = !(availableA && availableB && mvA != mvB) && colAvailable;
+    Mv list[3];
+    int n = 0;
+    if (availableA) list[n++] = mvA;
+    if (availableB)
+    {
+        list[n++] = mvB;
+        if (n == 2 && list[0] == list[1]) n = 1;
+    }
+    if (useCol) list[n++] = col;
+    while (n < 2) list[n++] = Mv(0, 0);
+    out[0] = list[0];
+    out[1] = list[1];
+}
+
+} // namespace havoc_search
