@@ -46,6 +46,11 @@ enum
     HAVOC_TR_INTRA_NB = 23,    // (round 5) before INTRA_BEGIN, partitions below 64x64: the 4n + 1 UNFILTERED reference samples of the partition as the encoder's
                                // substituteFast left them (Search.hpp:57), 14 per record, from the bottom of the left column over the corner to the end of the row above
     HAVOC_TR_INTRA_NBF = 24,   // the same positions of the FILTERED copy (Search.hpp:59; partitions above 4x4)
+    HAVOC_TR_AMVP = 25,        // (round 5) after predictMvp in searchUni (Search.hpp:1779): poc, refList X, refIdx, xPb, yPb, nPbW, nPbH, POC of RefPicList(X)[refIdx],
+                               // temporal candidate available (deriveTemporalLumaMotionVectorPredictors; 0 when slice_temporal_mvp_enabled_flag is off), its x, y,
+                               // mvp[0] x, y packed (x & 0xffff | y << 16), mvp[1] packed, 0
+    HAVOC_TR_AMVP_NB = 26,     // five of them after an AMVP record, k = 0 .. 4 = A0, A1, B0, B1, B2 as neighbourPuData() returned them: k, available, predFlag L0, predFlag L1,
+                               // POC of its L0 reference, POC of its L1 reference, mv L0 x, y, mv L1 x, y
     HAVOC_TR_RQT_END = 22,     // chosen rqtdepth, cbfZero (the split tree had no coded block: depth 0 never evaluated)
 };
 

@@ -75,9 +75,54 @@ static inline void neighbours(int kind, Samples &p, int nTbS)
     }
 }
 
+// what predictMvp (turing/Mvp.h:195-436) read and what it derived, for the pin of turingcodec_amd/search/amvp.hpp: the five spatial neighbours through the encoder's own
+// neighbourPuData(), the temporal candidate through its own deriveTemporalLumaMotionVectorPredictors() (called once more: it only reads), the two predictors it stored
+template <class H>
+static inline void amvp(H &h, int refList, int refIdx)
+{
+    prediction_unit const &pu = *static_cast<prediction_unit *>(h);
+    Mvp::Predictors *predictors = h;
+    int32_t a[14] = {0};
+    a[0] = h[PicOrderCntVal()];
+    a[1] = refList;
+    a[2] = refIdx;
+    a[3] = pu.x0;
+    a[4] = pu.y0;
+    a[5] = pu.nPbW;
+    a[6] = pu.nPbH;
+    a[7] = (*h[RefPicList(refList)][refIdx].dp)[PicOrderCntVal()];
+    if (h[slice_temporal_mvp_enabled_flag()])
+    {
+        PuData col = PuData();
+        a[8] = deriveTemporalLumaMotionVectorPredictors(h, col, pu, refList, refIdx) ? 1 : 0;
+        a[9] = col.mv(refList)[0];
+        a[10] = col.mv(refList)[1];
+    }
+    const auto &mvp = predictors->mvp[refIdx][refList];
+    a[11] = int32_t(uint32_t(uint16_t(mvp[0][0])) | (uint32_t(uint16_t(mvp[0][1])) << 16));
+    a[12] = int32_t(uint32_t(uint16_t(mvp[1][0])) | (uint32_t(uint16_t(mvp[1][1])) << 16));
+    havoc_trace_emit(HAVOC_TR_AMVP, 14, a);
+    const int xN[5] = {pu.x0 - 1, pu.x0 - 1, pu.x0 + pu.nPbW, pu.x0 + pu.nPbW - 1, pu.x0 - 1};
+    const int yN[5] = {pu.y0 + pu.nPbH, pu.y0 + pu.nPbH - 1, pu.y0 - 1, pu.y0 - 1, pu.y0 - 1};
+    for (int k = 0; k < 5; ++k)
+    {
+        const PuData nb = neighbourPuData(h, xN[k], yN[k]);
+        int32_t b[10] = {k, nb.isAvailable() ? 1 : 0, nb.predFlag(0) ? 1 : 0, nb.predFlag(1) ? 1 : 0, 0, 0, 0, 0, 0, 0};
+        for (int l = 0; l < 2; ++l)
+            if (nb.isAvailable() && nb.predFlag(l))
+            {
+                b[4 + l] = (*h[RefPicList(l)][nb.refIdx(l)].dp)[PicOrderCntVal()];
+                b[6 + 2 * l] = nb.mv(l)[0];
+                b[7 + 2 * l] = nb.mv(l)[1];
+            }
+        havoc_trace_emit(HAVOC_TR_AMVP_NB, 10, b);
+    }
+}
+
 } // namespace havoc_trace
 
 // ---- the macros the inserted lines call (each a statement) ----
+#define HAVOC_TRACE_AMVP() havoc_trace::amvp(h, refList, refIdx)
 #define HAVOC_TRACE_UNI_BEGIN() havoc_trace::searchBegin(HAVOC_TR_UNI_BEGIN, h, mvdc)
 #define HAVOC_TRACE_UNI_INTEGER() havoc_trace::candidate(HAVOC_TR_UNI_INTEGER, best)
 #define HAVOC_TRACE_UNI_SUBPEL()                                       \

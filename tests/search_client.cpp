@@ -71,6 +71,7 @@ void makeIdealPredictor(MotionTables<Sample> &, Sample *ideal, const Sample *inp
 #include "havoc_classic_ext.h"
 #endif
 #include "picture_order.hpp"
+#include "amvp.hpp"
 #include "tu_decision.hpp"
 #ifndef SEARCH_ORACLE
 #include "havoc/quantize.h"
@@ -617,6 +618,32 @@ int client_rqt_decide(const int64_t *rows, int n, int32_t *out)
         const havoc_rqt_result res = decideRqt(view, cu, rl, Rate{r});
         out[2 * i] = res.depth;
         out[2 * i + 1] = res.tried_zero;
+    }
+    return 0;
+}
+
+// amvp.hpp on recorded inputs: rows (int32 [n][4 + 5 * 9 + 3]): X, current POC, target POC, 0 | per neighbour A0, A1, B0, B1, B2: available, predFlag0, predFlag1, poc0,
+// poc1, mv0.x, mv0.y, mv1.x, mv1.y | temporal candidate available, x, y.  out (int32 [n][4]): mvp[0].x, .y, mvp[1].x, .y
+int client_amvp(const int32_t *rows, int n, int32_t *out)
+{
+    for (int i = 0; i < n; ++i)
+    {
+        const int32_t *r = rows + 52 * i;
+        AmvpNeighbour nb[5];
+        for (int k = 0; k < 5; ++k)
+        {
+            const int32_t *q = r + 4 + 9 * k;
+            nb[k].available = q[0] != 0;
+            nb[k].predFlag[0] = q[1] != 0;
+            nb[k].predFlag[1] = q[2] != 0;
+            nb[k].refPoc[0] = q[3];
+            nb[k].refPoc[1] = q[4];
+            nb[k].mv[0] = Mv(int16_t(q[5]), int16_t(q[6]));
+            nb[k].mv[1] = Mv(int16_t(q[7]), int16_t(q[8]));
+        }
+        Mv mvp[2];
+        deriveAmvp(r[0], r[1], r[2], nb, r[49] != 0, Mv(int16_t(r[50]), int16_t(r[51])), mvp);
+        out[4 * i] = mvp[0].x; out[4 * i + 1] = mvp[0].y; out[4 * i + 2] = mvp[1].x; out[4 * i + 3] = mvp[1].y;
     }
     return 0;
 }

@@ -97,6 +97,7 @@ class Client:
         L.client_bi_lanes.argtypes = [i, vp, ip, vp, vp, ip, C.POINTER(Params), vp, vp, i, i, vp]
         L.client_bi_logged.restype = C.c_int64
         L.client_rqt_decide.argtypes = [vp, i, vp]
+        L.client_amvp.argtypes = [vp, i, vp]
         L.client_intra_rd_decide.argtypes = [vp, vp, vp, i, vp]
         L.client_intra_order.argtypes = [vp, C.c_double, vp, i, vp]
         L.client_intra35.argtypes = [i, i, i, vp, ip, vp, vp, i, vp]
@@ -164,6 +165,13 @@ class Client:
         rows = np.ascontiguousarray(rows, np.int64)
         out = np.zeros((len(rows), 2), np.int32)
         assert self.L.client_rqt_decide(rows.ctypes.data, len(rows), out.ctypes.data) == 0
+        return out
+
+    def amvp(self, rows):
+        """turingcodec_amd/search/amvp.hpp: deriveAmvp on recorded inputs (int32 [n, 52]) -> int32 [n, 4] = mvp[0].x, .y, mvp[1].x, .y"""
+        rows = np.ascontiguousarray(rows, np.int32)
+        out = np.zeros((len(rows), 4), np.int32)
+        assert self.L.client_amvp(rows.ctypes.data, len(rows), out.ctypes.data) == 0
         return out
 
     def intra_rd_decide(self, cand, count, rl):

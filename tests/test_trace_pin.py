@@ -47,6 +47,11 @@ def check_cpu(rep, min_searches):
     assert nb["filter_mismatching"] == 0 and nb["substitution_mismatching"] == 0 and nb["partitions_with_substituted_samples"] > 0, nb
     if rep["case"] == "ra_medium_qp32":
         assert nb["strong_smoothing_taken"] > 10, nb      # the bi-linear branch is exercised by real content
+    # search/amvp.hpp -- the reference's derivation of the two predictors (Mvp.h:195-436) as data-only code -- on the neighbours the encoder's own neighbourPuData() returned
+    # and its temporal candidate, for every searchUni call: the predictors the encoder derived
+    a = rep["amvp_cpu"]
+    assert a["derivations"] == u["searches"] and a["mismatching"] == 0, a
+    assert a["with_a_scaled_candidate"] > 0 and a["second_predictor_is_not_zero"] > 0, a      # the scaling and the two-candidate list are exercised
     # tu_decision.hpp on the encoder's own rates and distortions: the champion of every intra partition's RD refinement, every transform-tree decision
     rd, q = rep["intra_rd_cpu"], rep["rqt_cpu"]
     assert rd["partitions"] == i["partitions"] and rd["rates_measured_by_the_encoder"] > rd["partitions"] and rd["mismatching_champions"] == 0, rd

@@ -215,6 +215,7 @@ def main():
     src = tt.source_frames(args.case, internal)
     uni, bi, intra = tt.MotionTrace(records), tt.MotionTrace(records, bi=True), tt.IntraTrace(records)
     rqt = tt.RqtTrace(records)
+    amvp = tt.AmvpTrace(records)
     del records
     ref_of = {}          # (poc, list) -> reference picture's poc, from the uni searches (a bi refinement follows the two uni searches of its PU)
     for poc, lst, rp in zip(uni.meta["poc"], uni.pus["ref_list"], uni.meta["ref_poc"]):
@@ -299,6 +300,32 @@ def main():
     report["intra_cpu"] = r
 
     report["intra_neighbours_cpu"] = intra_neighbours(intra, w, h, internal, None)
+
+    # ---- amvp.hpp (the reference's two-predictor derivation restated as data-only code) on the encoder's own neighbours: the predictors it derived
+    if len(amvp):
+        got = cpu.amvp(amvp.rows)
+        bad = np.flatnonzero(np.any(got != amvp.mvp, axis=1))
+        nbr = amvp.rows[:, 4:49].reshape(-1, 5, 9)
+        target = amvp.rows[:, 2][:, None]
+        own = amvp.rows[:, 0]
+        into_target = ((nbr[:, :, 1] != 0) & (nbr[:, :, 3] == target)) | ((nbr[:, :, 2] != 0) & (nbr[:, :, 4] == target))
+        # how far picture_order.hpp's two-candidate stand-in (A1's and B1's vector of the same list, duplicate pruned, zero-filled) is from the real rule on the same neighbours
+        X = amvp.rows[:, 0]
+        pick = lambda k: (np.where(X == 0, nbr[:, k, 1], nbr[:, k, 2]) != 0) & (nbr[:, k, 0] != 0)
+        vec = lambda k: np.where((X == 0)[:, None], nbr[:, k, 5:7], nbr[:, k, 7:9])
+        ha, hb, va, vb = pick(1), pick(3), vec(1), vec(3)
+        s0 = np.where(ha[:, None], va, np.where(hb[:, None], vb, 0))
+        s1 = np.where((ha & hb & np.any(va != vb, axis=1))[:, None], vb, 0)
+        stand_in = np.concatenate([s0, s1], axis=1)
+        report["amvp_cpu"] = {"derivations": int(len(amvp)), "mismatching": int(len(bad)),
+                              "two_candidate_stand_in_of_picture_order_hpp_agrees": int(np.sum(np.all(stand_in == amvp.mvp, axis=1))),
+                              "with_a_scaled_candidate": int(np.sum(np.any((nbr[:, :, 0] != 0) & ~into_target, axis=1))),
+                              "with_the_temporal_candidate_available": int((amvp.rows[:, 49] != 0).sum()),
+                              "with_no_neighbour_at_all": int(np.sum(~np.any(nbr[:, :, 0] != 0, axis=1))),
+                              "second_predictor_is_not_zero": int(np.sum(np.any(amvp.mvp[:, 2:] != 0, axis=1))),
+                              "examples": [{"where": amvp.where[i].tolist(), "row": amvp.rows[i].tolist(), "got": got[i].tolist(), "want": amvp.mvp[i].tolist()} for i in bad[:3]]}
+    else:
+        report["amvp_cpu"] = {"derivations": 0, "mismatching": 0}
 
     # ---- tu_decision.hpp on the encoder's own numbers (rates from its entropy estimator, distortions of three planes): the transform-tree decision
     # (Reconstruct.cpp:1296-1428) and the champion of an intra partition's RD refinement (Search.hpp:143-255)

@@ -25,6 +25,7 @@ REC_DT = np.dtype([("thread", "u4"), ("kind", "u2"), ("n", "u2"), ("v", "i4", (1
 assert REC_DT.itemsize == 64
 (UNI_BEGIN, BEGIN2, SAD, SAD4, SATD, UNI_INTEGER, UNI_SUBPEL, UNI_END, BI_BEGIN, BI_MV, BI_END, INTRA_BEGIN, INTRA_SATD, INTRA_MAX, INTRA_PICK, INTRA_SSD,
  INTRA_END, INTRA_RATE, INTRA_SWAP, RQT_ONE, RQT_ZERO, RQT_END) = range(1, 23)
+AMVP, AMVP_NB = 25, 26         # (round 5) predictMvp's inputs and outputs per searchUni call
 INTRA_NB, INTRA_NBF = 23, 24      # (round 5) the partition's reference samples as the encoder held them: unfiltered / filtered, 14 per record, before INTRA_BEGIN
 PAD = 96
 
@@ -265,6 +266,37 @@ class IntraTrace:
 
     def __len__(self):
         return len(self.ctx)
+
+
+class AmvpTrace:
+    """every predictMvp of searchUni (turing/Search.hpp:1779 -> Mvp.h:195-436): the five spatial neighbours as neighbourPuData() returned them, the temporal candidate,
+    the two predictors the encoder derived.  rows = the inputs in the layout of tests/search_client.cpp: client_amvp; mvp = int32 [n, 4]"""
+
+    def __init__(self, records):
+        rows, mvp, where = [], [], []
+        for t in np.unique(records["thread"]):
+            rec = records[records["thread"] == t]
+            kind = rec["kind"].astype(np.int32)
+            v = rec["v"]
+            for i in np.flatnonzero(kind == AMVP):
+                assert np.all(kind[i + 1:i + 6] == AMVP_NB) and np.array_equal(v[i + 1:i + 6, 0], np.arange(5)), "an AMVP record is followed by its five neighbours"
+                a = v[i]
+                r = np.zeros(52, np.int32)
+                r[0], r[1], r[2] = a[1], a[0], a[7]
+                for k in range(5):
+                    r[4 + 9 * k:13 + 9 * k] = v[i + 1 + k][1:10]
+                r[49], r[50], r[51] = a[8], a[9], a[10]
+                rows.append(r)
+                s16 = lambda u: u - 65536 if u >= 32768 else u
+                unpack = lambda p: (s16(p & 0xFFFF), s16((p >> 16) & 0xFFFF))
+                mvp.append(unpack(int(a[11]) & 0xFFFFFFFF) + unpack(int(a[12]) & 0xFFFFFFFF))
+                where.append(a[0:7])
+        self.rows = np.array(rows, np.int32).reshape(-1, 52)
+        self.mvp = np.array(mvp, np.int32).reshape(-1, 4)
+        self.where = np.array(where, np.int32).reshape(-1, 7)
+
+    def __len__(self):
+        return len(self.rows)
 
 
 class RqtTrace:
