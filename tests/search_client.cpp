@@ -622,6 +622,86 @@ int client_rqt_decide(const int64_t *rows, int n, int32_t *out)
     return 0;
 }
 
+// The neighbour cells k_search_rows keeps in LDS (csrc/kernels_search.hip: Lds::mv / valid, load_neighbours, search_ctu's `get`) restated on the host and held against the
+// picture-wide field: every PU's predictors derived through both must be the same (fake decided vectors: a hash of (PU, list)).  Returns the number of derivations that differ;
+// example[0..7] = p, list, the two predictors through the field, the two through the emulated LDS (packed)
+int client_check_lds_neighbours(const havoc_picture_pu *pus, const int32_t *ctu_first, int ctus_x, int ctus_y, int pic_w, int pic_h, int ctb, int32_t *example)
+{
+    MotionField field;
+    field.init(pic_w, pic_h);
+    int bad = 0;
+    for (int cy = 0; cy < ctus_y; ++cy)
+        for (int cx = 0; cx < ctus_x; ++cx)
+        {
+            const int c = cy * ctus_x + cx, xCtb = cx * ctb, yCtb = cy * ctb;
+            for (int list = 0; list < 2; ++list)
+            {
+                int32_t mv[256 + 36];
+                uint8_t valid[256 + 36];
+                std::memset(mv, 0, sizeof(mv));
+                std::memset(valid, 0, sizeof(valid));
+                for (int t = 0; t < 34; ++t)      // load_neighbours(left = true, top = true): the row walk keeps the left column instead, the same values
+                {
+                    const int gx = t < 16 ? cx * 16 - 1 : (t < 32 ? cx * 16 + t - 16 : (t == 32 ? cx * 16 - 1 : cx * 16 + 16));
+                    const int gy = t < 16 ? cy * 16 + t : cy * 16 - 1;
+                    const bool in = gx >= 0 && gy >= 0 && gx < field.cw && gy < field.ch;
+                    mv[256 + t] = in ? field.mv[list][size_t(gy) * field.cw + gx] : 0;
+                    valid[256 + t] = in ? field.valid[list][size_t(gy) * field.cw + gx] : 0;
+                }
+                auto getLds = [&](int, int px, int py, Mv *v) {
+                    const int rx = px - xCtb, ry = py - yCtb;
+                    int i;
+                    if (rx >= 0 && ry >= 0 && rx < 64 && ry < 64) i = (ry >> 2) * 16 + (rx >> 2);
+                    else if (rx >= -4 && rx < 0 && ry >= 0 && ry < 64) i = 256 + (ry >> 2);
+                    else if (ry >= -4 && ry < 0 && rx >= 0 && rx < 64) i = 272 + (rx >> 2);
+                    else if (ry >= -4 && ry < 0 && rx >= -4 && rx < 0) i = 288;
+                    else if (ry >= -4 && ry < 0 && rx >= 64 && rx < 68) i = 289;
+                    else
+                        return false;
+                    if (!valid[i]) return false;
+                    *v = MotionField::unpack(mv[i]);
+                    return true;
+                };
+                // the field as it is while THIS list's walk of the CTU runs: a private copy that receives this CTU's decisions
+                MotionField f2 = field;
+                auto getField = [&](int l, int x, int y, Mv *v) { return f2.get(l, x, y, v); };
+                for (int p = ctu_first[c]; p < ctu_first[c + 1]; ++p)
+                {
+                    Mv a[2], b[2];
+                    derivePredictors(pus[p], list, ctb, pic_w, pic_h, getField, a);
+                    derivePredictors(pus[p], list, ctb, pic_w, pic_h, getLds, b);
+                    if (a[0] != b[0] || a[1] != b[1])
+                    {
+                        if (!bad && example)
+                        {
+                            example[0] = p; example[1] = list;
+                            example[2] = MotionField::pack(a[0]); example[3] = MotionField::pack(a[1]);
+                            example[4] = MotionField::pack(b[0]); example[5] = MotionField::pack(b[1]);
+                        }
+                        ++bad;
+                    }
+                    const uint32_t hsh = uint32_t(p) * 2654435761u + uint32_t(list) * 40503u;
+                    const Mv v(int16_t((hsh >> 8) % 61) - 30, int16_t((hsh >> 16) % 41) - 20);
+                    f2.set(list, pus[p].x0, pus[p].y0, pus[p].w, pus[p].h, v);
+                    const int cw4 = pus[p].w >> 2;
+                    for (int t = 0; t < cw4 * (pus[p].h >> 2); ++t)
+                    {
+                        const int gx = (pus[p].x0 >> 2) + t % cw4, gy = (pus[p].y0 >> 2) + t / cw4;
+                        const int li = (gy - (yCtb >> 2)) * 16 + gx - (xCtb >> 2);
+                        mv[li] = MotionField::pack(v);
+                        valid[li] = 1;
+                    }
+                }
+                for (int p = ctu_first[c]; p < ctu_first[c + 1]; ++p)
+                {
+                    const uint32_t hsh = uint32_t(p) * 2654435761u + uint32_t(list) * 40503u;
+                    field.set(list, pus[p].x0, pus[p].y0, pus[p].w, pus[p].h, Mv(int16_t((hsh >> 8) % 61) - 30, int16_t((hsh >> 16) % 41) - 20));
+                }
+            }
+        }
+    return bad;
+}
+
 // amvp.hpp on recorded inputs: rows (int32 [n][4 + 5 * 9 + 3]): X, current POC, target POC, 0 | per neighbour A0, A1, B0, B1, B2: available, predFlag0, predFlag1, poc0,
 // poc1, mv0.x, mv0.y, mv1.x, mv1.y | temporal candidate available, x, y.  out (int32 [n][4]): mvp[0].x, .y, mvp[1].x, .y
 int client_amvp(const int32_t *rows, int n, int32_t *out)

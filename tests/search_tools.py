@@ -55,7 +55,7 @@ def build(kind):
     """compile the client for one back end; returns the library path (None when the back end's library is not there)"""
     os.makedirs(BUILD, exist_ok=True)
     out = os.path.join(BUILD, f"libsearch_{kind}.so")
-    hdrs = [os.path.join(ROOT, "turingcodec_amd", "search", f) for f in ("decision.hpp", "table_view.hpp", "search_abi.h", "picture_order.hpp", "tu_decision.hpp")]
+    hdrs = [os.path.join(ROOT, "turingcodec_amd", "search", f) for f in ("decision.hpp", "table_view.hpp", "search_abi.h", "picture_order.hpp", "amvp.hpp", "tu_decision.hpp")]
     base = ["g++", "-O2", "-std=c++14", "-fPIC", "-shared", "-Wall"] + INC + [SRC, "-o", out]
     if kind == "ref":
         lib = os.path.join(ROOT, "oracle", "_ref", "libhavoc_ref.so")
@@ -98,6 +98,7 @@ class Client:
         L.client_bi_logged.restype = C.c_int64
         L.client_rqt_decide.argtypes = [vp, i, vp]
         L.client_amvp.argtypes = [vp, i, vp]
+        L.client_check_lds_neighbours.argtypes = [vp, vp, i, i, i, i, i, vp]
         L.client_intra_rd_decide.argtypes = [vp, vp, vp, i, vp]
         L.client_intra_order.argtypes = [vp, C.c_double, vp, i, vp]
         L.client_intra35.argtypes = [i, i, i, vp, ip, vp, vp, i, vp]
@@ -173,6 +174,13 @@ class Client:
         out = np.zeros((len(rows), 4), np.int32)
         assert self.L.client_amvp(rows.ctypes.data, len(rows), out.ctypes.data) == 0
         return out
+
+    def check_lds_neighbours(self, pus, ctu_first, ctus_x, ctus_y, pic_w, pic_h, ctb=64):
+        """the device walk's view of a CTU's neighbours (csrc/kernels_search.hip: 256 cells of the CTU + 16 left + 16 above + the two corners, load_neighbours' addressing,
+        restated on the host) against the whole motion field: how many derivations differ, and the first one (pu, list, field's two predictors, view's two)"""
+        pus, ctu_first = np.ascontiguousarray(pus), np.ascontiguousarray(ctu_first, np.int32)
+        example = np.zeros(6, np.int32)
+        return self.L.client_check_lds_neighbours(pus.ctypes.data, ctu_first.ctypes.data, ctus_x, ctus_y, pic_w, pic_h, ctb, example.ctypes.data), example
 
     def intra_rd_decide(self, cand, count, rl):
         """tu_decision.hpp: decideIntraRd on recorded (mode, ssd, rate or -1) per candidate: int32 [n, 2] = champion's mode, its index"""

@@ -210,6 +210,18 @@ def test_picture_client_host_logic_on_the_mock_device(res, bit_depth):
     assert len(r["device_wrapper_refusals"]) == 2 and all("-10001" in x for x in r["device_wrapper_refusals"]), r["device_wrapper_refusals"]
 
 
+@pytest.mark.parametrize("size", [(416, 240), (1920, 1080), (1000, 600)])
+def test_the_device_walks_view_of_a_ctus_neighbours_gives_the_fields_predictors(size):
+    """k_search_rows / k_search_step keep, per CTU, its own 256 cells plus 34 cells around it (16 left, 16 above, above-left, above-right) in LDS; derivePredictors
+    reads its five positions (A0, A1, B0, B1, B2 under the encoder's availability rule) through that view.  The view's addressing, restated on the host, must give the
+    predictors the whole motion field gives, for every PU of pictures whose last CTU row / column is cut by the edge."""
+    from turingcodec_amd import workload
+    W, H = size
+    pus, first, cx, cy = workload.picture_pus(W, H, 9)
+    bad, example = st.Client("oracle").check_lds_neighbours(pus, first, cx, cy, W, H)
+    assert bad == 0, (bad, example.tolist())
+
+
 def test_picture_walk_over_oracle_equals_walk_over_reference_tables():
     """the sequential walk itself (the checker's arm): CPU oracle primitives vs the reference's C tables"""
     if not HAVE_REF:

@@ -236,8 +236,8 @@ struct Lds      // of a workgroup
     int32_t raster[704];         // ... of the raster refinement's 700 (208) positions
     int32_t satd[2][12];
     int32_t table[16 * 12];      // SADs of a rectangle of full-sample displacements (the grid of a bi-directional refinement)
-    int32_t mv[256 + 32];        // the CTU's own 16 x 16 cells, the 16 cells left of it, the 16 cells above it
-    uint8_t valid[256 + 32];
+    int32_t mv[256 + 36];        // the CTU's own 16 x 16 cells, the 16 cells left of it, the 16 cells above it, the cell above-left (288) and the cell above-right (289):
+    uint8_t valid[256 + 36];     // where the five spatial candidates of a PU of this CTU can lie (search/picture_order.hpp: derivePredictors)
     alignas(16) uint8_t src[64 * 64 * S];
     alignas(16) uint8_t win[kWinBytes * S];
 };
@@ -1064,6 +1064,8 @@ __device__ __forceinline__ void search_ctu(const SearchArgs &a, Lds<S> &x, CtuSt
         if (rx >= 0 && ry >= 0 && rx < 64 && ry < 64) i = (ry >> 2) * 16 + (rx >> 2);
         else if (rx >= -4 && rx < 0 && ry >= 0 && ry < 64) i = 256 + (ry >> 2);
         else if (ry >= -4 && ry < 0 && rx >= 0 && rx < 64) i = 272 + (rx >> 2);
+        else if (ry >= -4 && ry < 0 && rx >= -4 && rx < 0) i = 288;      // B2 of a PU in the CTU's top-left corner
+        else if (ry >= -4 && ry < 0 && rx >= 64 && rx < 68) i = 289;     // B0 of a PU at the CTU's top-right corner: the CTU above-right (done: the wavefront's lag)
         else
             return false;      // not a position a predictor of this CTU is read from
         if (!__builtin_amdgcn_readfirstlane((int)x.valid[i])) return false;
@@ -1078,7 +1080,7 @@ __device__ __forceinline__ void search_ctu(const SearchArgs &a, Lds<S> &x, CtuSt
 #endif
         const havoc_picture_pu q = a.pus[p];
         Mv mvp[2];
-        havoc_search::derivePredictors(q, list, a.sp.picWidth, a.sp.picHeight, get, mvp);
+        havoc_search::derivePredictors(q, list, ctb, a.sp.picWidth, a.sp.picHeight, get, mvp);
         const havoc_search::PuContext pu = havoc_search::contextOf(q, ctb, mvp, a.mvpRate, mvPrev);
         DeviceView<S> view;
         stage_uni<S>(a, x, view, pu, list, &cs, &box);
@@ -1325,12 +1327,17 @@ __device__ __forceinline__ void load_neighbours(const SearchArgs &a, Lds<S> &x, 
     const int tid = threadIdx.x;
     const int32_t *field = a.field + (long)list * a.cw * a.ch;
     const uint8_t *valid = a.valid + (long)list * a.cw * a.ch;
-    if (tid < 32 && (tid < 16 ? left : top))
-    {
-        const int gx = tid < 16 ? cx * 16 - 1 : cx * 16 + tid - 16, gy = tid < 16 ? cy * 16 + tid : cy * 16 - 1;
+    if (tid < 34)
+    {   // 0 .. 15: left of the CTU; 16 .. 31: above it; 32: above-left; 33: above-right (all of the row above are final: the CTU above-right is done before this one starts)
+        const int gx = tid < 16 ? cx * 16 - 1 : (tid < 32 ? cx * 16 + tid - 16 : (tid == 32 ? cx * 16 - 1 : cx * 16 + 16));
+        const int gy = tid < 16 ? cy * 16 + tid : cy * 16 - 1;
+        const bool want = tid < 16 ? left : top;      // (the cell above-left belongs to the row above: loaded with it, whether or not the left column is kept in LDS)
         const bool in = gx >= 0 && gy >= 0 && gx < a.cw && gy < a.ch;
-        x.mv[256 + tid] = in ? field[(long)gy * a.cw + gx] : 0;
-        x.valid[256 + tid] = in ? valid[(long)gy * a.cw + gx] : 0;
+        if (want)      // (cells not asked for keep what they hold: the row walk hands a CTU's right column on as the next one's left neighbours)
+        {
+            x.mv[256 + tid] = in ? field[(long)gy * a.cw + gx] : 0;
+            x.valid[256 + tid] = in ? valid[(long)gy * a.cw + gx] : 0;
+        }
     }
 }
 
@@ -1378,7 +1385,7 @@ __global__ __launch_bounds__(kThreads) void k_search_rows(const SearchArgs a)
         x.mv[tid] = 0;
         x.valid[tid] = 0;
     }
-    if (tid < 32)
+    if (tid < 36)
     {
         x.mv[256 + tid] = 0;
         x.valid[256 + tid] = 0;
@@ -1573,9 +1580,10 @@ hipError_t launch_search_picture_uni(hipStream_t st, int S, const havoc_mi355x_s
     a.progress = a.rowPrev + 2 * ctusY;
     a.ticket = a.progress + 2 * ctusY + 2;
     a.gaveUp = a.ticket + 1;
-    // HAVOC_SEARCH_ROW_LAG=1 (diagnostic, profiles/): what picture_order.hpp's derivation READS of the row above is the CTU directly above (no above-right candidate), so its
-    // data would allow a lag of one CTU -- same results, 46 instead of 62 steps at 1080p.  The default is the reference's rule: its real AMVP reads above-right.
-    a.rowLag = (getenv("HAVOC_SEARCH_ROW_LAG") && atoi(getenv("HAVOC_SEARCH_ROW_LAG")) == 1) ? 1 : 2;
+    // The reference's wavefront rule (TaskEncodeSubstream.cpp:71-95): since round 5 a REQUIREMENT of the data, not only of the rule -- the derivation of the predictors
+    // (picture_order.hpp: the reference's five spatial candidates) reads the cell above-right of a CTU (B0).  (Round 4's derivation had no above-right candidate and
+    // HAVOC_SEARCH_ROW_LAG=1 was a legal diagnostic: 13.5 -> 10.6 ms per 1080p picture, profiles/r04/row_lag_diagnostic.json; it no longer is and is ignored.)
+    a.rowLag = 2;
     hipError_t e = hipMemsetAsync(work, 0, search_workspace_bytes(sp->pic_width, sp->pic_height), st);
     if (e != hipSuccess) return e;
     if ((e = hipMemsetAsync(field, 0, 2 * cells * 4, st)) != hipSuccess) return e;

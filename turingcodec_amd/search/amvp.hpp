@@ -1,12 +1,12 @@
 // amvp.hpp -- the reference's derivation of a prediction unit's two motion vector predictors (HEVC 8.5.3.2.6 / 8.5.3.2.7 as turing/Mvp.h:195-436 applies it),
 // restated as DATA-ONLY code: what it reads of the encoder's state is handed in as five neighbour records and the temporal candidate.
 //
-// Why it is here: picture_order.hpp's derivePredictors is a two-candidate stand-in (the cell left of the bottom-left sample, the cell above the
-// top-right sample) and every decision-path number depends on it.  This file is the real rule, PINNED: the traced reference encoder records, for every searchUni call,
-// the five neighbours as its neighbourPuData() returned them, the temporal candidate and the two predictors it derived (oracle/trace_hooks.h: HAVOC_TRACE_AMVP, inserted
-// after Search.hpp:1779); tests/test_trace_pin.py requires deriveAmvp() to give the same two predictors for every record of six encodes.  It is NOT yet what the decision
-// path's walk uses: that needs the neighbours' prediction lists and reference pictures in the motion field (today: one vector per list and cell), and the above-right
-// neighbour B0 makes the wavefront's two-CTU lag a real requirement (HAVOC_SEARCH_ROW_LAG=1 is only legal for the stand-in).
+// Why it is here: until round 5 picture_order.hpp's derivePredictors was a two-candidate stand-in (the cell left of the bottom-left sample, the cell
+// above the top-right sample; it gives the encoder's predictors for 75 % of the recorded derivations) and every decision-path number depends on it.  This file is the real
+// rule, PINNED: the traced reference encoder records, for every searchUni call, the five neighbours as its neighbourPuData() returned them, the temporal candidate and the
+// two predictors it derived (the HAVOC_TRACE_AMVP trace point, inserted after Search.hpp:1779); tests/test_trace_pin.py requires deriveAmvp() to give the same two
+// predictors for every record of six encodes (0 differ).  picture_order.hpp's walk -- on the host and inside k_search_rows -- derives its predictors with it, from the five
+// positions under the encoder's availability rules; the walk's neighbours are vectors of the same list into the same reference picture (no scaling, no temporal candidate).
 #pragma once
 
 #include "decision.hpp"
@@ -45,16 +45,20 @@ HAVOC_HD inline void deriveAmvp(int X, int curPoc, int targetPoc, const AmvpNeig
     bool availableA = false, availableB = false;
     Mv mvA, mvB;
     const bool isScaled = nb[0].available || nb[1].available;
+    // (every loop has a constant trip count and is unrolled on the device: the five records then live in registers -- indexed, they went to scratch memory and cost the
+    // walk 2.6 ms per 1080p picture)
     // A: the first of A0, A1 with a vector into the target picture (own list first) ...
-    for (int k = 0; k < 2 && !availableA; ++k)
-        if (nb[k].available)
+    HAVOC_UNROLL
+    for (int k = 0; k < 2; ++k)
+        if (!availableA && nb[k].available)
         {
             if (nb[k].predFlag[X] && nb[k].refPoc[X] == targetPoc) { availableA = true; mvA = nb[k].mv[X]; }
             else if (nb[k].predFlag[Y] && nb[k].refPoc[Y] == targetPoc) { availableA = true; mvA = nb[k].mv[Y]; }
         }
     // ... else the first with any vector, scaled to the target picture's distance (step 7)
-    for (int k = 0; k < 2 && !availableA; ++k)
-        if (nb[k].available)
+    HAVOC_UNROLL
+    for (int k = 0; k < 2; ++k)
+        if (!availableA && nb[k].available)
         {
             int poc = 0;
             if (nb[k].predFlag[X]) { availableA = true; mvA = nb[k].mv[X]; poc = nb[k].refPoc[X]; }
@@ -62,8 +66,9 @@ HAVOC_HD inline void deriveAmvp(int X, int curPoc, int targetPoc, const AmvpNeig
             if (availableA && poc != targetPoc) mvA = amvpDistScale(mvA, curPoc - poc, curPoc - targetPoc);
         }
     // B: the first of B0, B1, B2 with a vector into the target picture
-    for (int k = 2; k < 5 && !availableB; ++k)
-        if (nb[k].available)
+    HAVOC_UNROLL
+    for (int k = 2; k < 5; ++k)
+        if (!availableB && nb[k].available)
         {
             if (nb[k].predFlag[X] && nb[k].refPoc[X] == targetPoc) { availableB = true; mvB = nb[k].mv[X]; }
             else if (nb[k].predFlag[Y] && nb[k].refPoc[Y] == targetPoc) { availableB = true; mvB = nb[k].mv[Y]; }
@@ -77,8 +82,9 @@ HAVOC_HD inline void deriveAmvp(int X, int curPoc, int targetPoc, const AmvpNeig
     if (!isScaled)
     {
         availableB = false;
-        for (int k = 2; k < 5 && !availableB; ++k)
-            if (nb[k].available)
+        HAVOC_UNROLL
+        for (int k = 2; k < 5; ++k)
+            if (!availableB && nb[k].available)
             {
                 int poc = 0;
                 if (nb[k].predFlag[X]) { availableB = true; mvB = nb[k].mv[X]; poc = nb[k].refPoc[X]; }
@@ -88,18 +94,22 @@ HAVOC_HD inline void deriveAmvp(int X, int curPoc, int targetPoc, const AmvpNeig
     }
     // the temporal candidate only when A and B do not already give two different predictors
     const bool useCol = !(availableA && availableB && mvA != mvB) && colAvailable;
-    Mv list[3];
+    // mvpListLX: A, then B unless it repeats A, then the temporal candidate, zero-filled to two (the list's third entry is never used)
+    Mv first(0, 0), second(0, 0);
     int n = 0;
-    if (availableA) list[n++] = mvA;
-    if (availableB)
+    if (availableA) { first = mvA; n = 1; }
+    if (availableB && !(n == 1 && mvB == first))
     {
-        list[n++] = mvB;
-        if (n == 2 && list[0] == list[1]) n = 1;
+        if (n == 0) first = mvB; else second = mvB;
+        ++n;
     }
-    if (useCol) list[n++] = col;
-    while (n < 2) list[n++] = Mv(0, 0);
-    out[0] = list[0];
-    out[1] = list[1];
+    if (useCol && n < 2)
+    {
+        if (n == 0) first = col; else second = col;
+        ++n;
+    }
+    out[0] = first;
+    out[1] = second;
 }
 
 } // namespace havoc_search

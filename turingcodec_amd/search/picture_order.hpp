@@ -7,14 +7,16 @@
 //   * mvPreviousInteger2Nx2N is what the last 2Nx2N search of the list left behind (Search.hpp:2170-2176 reads, :2332-2335 writes);
 //   * CTUs start in wavefront order: CTU (x, y) may start when (x + 1, y - 1) is done (turing/TaskEncodeSubstream.cpp:71-95).
 // This file restates that skeleton -- not the encoder's mode decision: every PU of the caller's list is searched, in list order, and its
-// vector becomes the neighbourhood of the PUs after it ("last decision covers the area").  The predictor derivation is the two spatial
-// candidates of HEVC's AMVP in their simplest form:
-//   A = vector (same list) of the 4x4 cell left of the PU's bottom-left sample, B = of the cell above its top-right sample;
-//   an unavailable candidate (outside the picture, or nothing decided there yet) is the zero vector; when both are available and equal the
-//   second becomes the zero vector (the duplicate is pruned and the list is filled with zero, as 8.5.3.2.6 does).
+// vector becomes the neighbourhood of the PUs after it ("last decision covers the area").  Round 5: the predictor derivation IS the reference's
+// (amvp.hpp: the five spatial candidates A0, A1, B0, B1, B2 of turing/Mvp.h:195-436, pinned against the encoder's own derivations), read at the positions
+// and under the availability rules of the encoder's neighbourPuData (turing/StateSpatial.h:208-246, Global.h:285-370: inside the picture, not in the next CTU
+// row, earlier than the PU in z-order).  What the walk still simplifies: a neighbour is a vector of the SAME list into the SAME reference picture (every PU is
+// searched in both lists with reference index 0, and the two lists' walks read nothing of each other: Search.hpp:1883-1884), so no candidate is scaled; there
+// is no temporal candidate.  The above-right neighbour B0 makes the wavefront's two-CTU lag a requirement (TaskEncodeSubstream.cpp:71-95).
 // What matters for the batch client is that the dependency is REAL: a PU's search cannot be replayed before its neighbours' vectors exist.
 #pragma once
 
+#include "amvp.hpp"
 #include "decision.hpp"
 #include "search_abi.h"
 
@@ -103,16 +105,55 @@ struct LocalField
     }
 };
 
-// the two predictors of PU q in `list`, read through `get(list, x, y, &mv)` (false = unavailable)
-template <class Get>
-HAVOC_HD inline void derivePredictors(const havoc_picture_pu &q, int list, int picW, int picH, Get get, Mv mvp[2])
+// loop-free comparison of z-order positions (turing/Global.h:285-298): true if (xN, yN) precedes (xC, yC)
+HAVOC_HD inline bool precedesInZ(int xC, int yC, int xN, int yN)
 {
-    Mv a, b;
-    const int ax = q.x0 - 1, ay = q.y0 + q.h - 1, bx = q.x0 + q.w - 1, by = q.y0 - 1;
-    const bool haveA = ax >= 0 && ay < picH && get(list, ax, ay, &a);
-    const bool haveB = by >= 0 && bx < picW && get(list, bx, by, &b);
-    mvp[0] = haveA ? a : (haveB ? b : Mv(0, 0));
-    mvp[1] = (haveA && haveB && a != b) ? b : Mv(0, 0);
+    const int xNot = ~xN, yNot = ~yN;
+    const int yXor = yC ^ yNot, yAnd = yC & yNot;
+    const int p = yAnd | (xC & yXor);
+    const int q = ~(yAnd | (xNot & yXor));
+    return p > q;
+}
+
+// may prediction unit q read its neighbour at (xN, yN)?  neighbourPuData (turing/StateSpatial.h:208-246) with AvailabilityCtu::available (Global.h:317-370) for a
+// picture of one slice and one tile: not in the next CTU row, inside the picture, in a CTU that exists and precedes this one, earlier than the PU's last sample in z-order
+HAVOC_HD inline bool neighbourPositionAvailable(const havoc_picture_pu &q, int ctb, int picW, int picH, int xN, int yN)
+{
+    const int maskHigh = ~(ctb - 1), log2 = ctb == 64 ? 6 : (ctb == 32 ? 5 : 4);
+    const int yCtbCurr = q.y0 & maskHigh;
+    if ((yN & maskHigh) > yCtbCurr) return false;
+    const int xCurr = q.x0 + q.w - 1, yCurr = q.y0 + q.h - 1;
+    if (xN >= picW || yN >= picH) return false;
+    const int dx = (xN >> log2) - (xCurr >> log2), dy = (yN >> log2) - (yCurr >> log2);      // (arithmetic shifts: -1 for a position left of / above the picture)
+    if (dy == 0)
+    {
+        if (dx == 0) { if (!precedesInZ(xCurr, yCurr, xN, yN)) return false; }
+        else if (dx > 0 || xN < 0) return false;
+    }
+    else if (dy > 0 || yN < 0 || xN < 0)
+        return false;
+    return precedesInZ(xCurr, yCurr - yCtbCurr, xN, yN - yCtbCurr);
+}
+
+// the two predictors of PU q in `list`, read through `get(list, x, y, &mv)` (false = nothing decided there)
+template <class Get>
+HAVOC_HD inline void derivePredictors(const havoc_picture_pu &q, int list, int ctb, int picW, int picH, Get get, Mv mvp[2])
+{
+    const int xN[5] = {q.x0 - 1, q.x0 - 1, q.x0 + q.w, q.x0 + q.w - 1, q.x0 - 1};                 // A0, A1, B0, B1, B2 (Mvp.h:219-222, 286-287)
+    const int yN[5] = {q.y0 + q.h, q.y0 + q.h - 1, q.y0 - 1, q.y0 - 1, q.y0 - 1};
+    AmvpNeighbour nb[5];
+    HAVOC_UNROLL
+    for (int k = 0; k < 5; ++k)
+    {
+        Mv v;
+        if (neighbourPositionAvailable(q, ctb, picW, picH, xN[k], yN[k]) && get(list, xN[k], yN[k], &v))
+        {
+            nb[k].available = true;
+            nb[k].predFlag[0] = true;         // the same list into the same reference picture: refPoc == the target's (0 == 0), nothing to scale; with one list in play its
+            nb[k].mv[0] = v;                  // name does not enter the rule, so the records are filed under list 0 -- a constant index: indexed by `list` they went to scratch
+        }                                     // memory on the device (112 bytes per lane, +2.6 ms per 1080p picture)
+    }
+    deriveAmvp(0, 0, 0, nb, false, Mv(0, 0), mvp);
 }
 
 HAVOC_HD inline PuContext contextOf(const havoc_picture_pu &q, int ctb, const Mv mvp[2], const Cost mvpRate[2], Mv mvPrevious2Nx2N)
@@ -165,7 +206,7 @@ void walkPictureSequential(const SearchParams &sp, const havoc_picture_pu *pus, 
             for (int list = 0; list < 2; ++list)
             {
                 Mv mvp[2];
-                derivePredictors(pus[p], list, sp.picWidth, sp.picHeight, get, mvp);
+                derivePredictors(pus[p], list, sp.ctbSize, sp.picWidth, sp.picHeight, get, mvp);
                 const PuContext pu = contextOf(pus[p], sp.ctbSize, mvp, mvpRate, mvPrev[list]);
                 const UniResult r = search(p, list, pu);
                 ctx[list] = pu;

@@ -210,7 +210,7 @@ int havoc_search_picture_uni(havoc_mi355x_ctx *ctx, int S, const havoc_search_pa
                         const int p = ch.first + s / 2, list = s & 1, i = 2 * p + list;
                         const havoc_picture_pu &q = pus[p];
                         Mv mvp[2];
-                        derivePredictors(q, list, W, H, get, mvp);
+                        derivePredictors(q, list, ctb, W, H, get, mvp);
                         const PuContext pu = contextOf(q, ctb, mvp, mvpRate, prev[list]);
                         SearchState &st = state[i];
                         if (st.integer.valid && !kept[i].same(pu)) st.integer.valid = false;
