@@ -488,19 +488,200 @@ __device__ __forceinline__ void sad4_run_calls(const __attribute__((address_spac
     }
 }
 
-template <int S, int NW, int U>
-__global__ __launch_bounds__(64 * NW) void k_sad4r(const char *__restrict__ src, long stride_src, const char *__restrict__ ref, long stride_ref, float inv_stride_ref,
-                                                   const int32_t *__restrict__ jobs, int njobs, const int32_t *__restrict__ runs, int nruns, int32_t *__restrict__ out)
+// The same run with a LANE per CANDIDATE (round 5, second form; U = 0 of k_sad4r).  In the form above 16 lanes share a call and every pass pays the call's set-up and
+// four DPP reductions -- for a 16x16 block 32 of ~100 wavefront instructions are absolute differences, and the launch issues 77 M vector instructions against the
+// ~31 M its sample pairs need (one v_alignbyte_b32 + one v_sad_u8 per four).  Here a lane owns one candidate: it walks the candidate's rows in the staged box (dword reads
+// at its own displacement, the carry dword of v_alignbyte kept from one read to the next), the source rows are the same for every lane (one broadcast ds_read_b128 per 16
+// bytes), there is NO reduction, and 64 results leave in one coalesced store.  Runs of few candidates (big blocks: the cutter keeps them to 16 calls) are cut into row
+// slices so that all the workgroup's wavefronts have work; the slices' partial sums meet in LDS (ds_add_u32).
+typedef u32x4 __attribute__((aligned(4))) u32x4_dw;      // four dwords at a dword-aligned address (what a scalar load needs)
+typedef u32x2 __attribute__((aligned(4))) u32x2_dw;
+
+// SG: the source rows come from global memory at a wave-uniform address -- scalar loads (s_load_dwordx4: the operand of v_sad_u8 is then an SGPR and the LDS carries
+// only the box) -- instead of the broadcast reads of the block staged in LDS
+template <int S, int ND, bool SG>
+__device__ __forceinline__ uint32_t sad_lane_rows(const __attribute__((address_space(3))) uint32_t *q, const __attribute__((address_space(3))) uint32_t *s, int pitchD,
+                                                  int nd, int rows, int sh, const uint32_t *__restrict__ gs, int gpitch)
+{
+    uint32_t acc = 0;
+    if (SG)
+    {
+        if (ND >= 4)
+        {
+            // (four accumulators rather than one chain of 16 dependent v_sad_u8 per row: measured, no difference at six wavefronts per SIMD)
+            uint32_t a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll 2
+            for (int y = 0; y < rows; ++y, q += pitchD, gs += gpitch)
+            {
+                uint32_t prev = q[0];
+#pragma unroll
+                for (int i = 0; i < ND; i += 4)
+                {
+                    const u32x4 a = *reinterpret_cast<const u32x4_dw *>(gs + i);
+                    const uint32_t d1 = q[i + 1], d2 = q[i + 2], d3 = q[i + 3], d4 = q[i + 4];
+                    acc = sad_dword<S>(a.x, __builtin_amdgcn_alignbyte(d1, prev, sh), acc);
+                    a1 = sad_dword<S>(a.y, __builtin_amdgcn_alignbyte(d2, d1, sh), a1);
+                    a2 = sad_dword<S>(a.z, __builtin_amdgcn_alignbyte(d3, d2, sh), a2);
+                    a3 = sad_dword<S>(a.w, __builtin_amdgcn_alignbyte(d4, d3, sh), a3);
+                    prev = d4;
+                }
+            }
+            acc += a1 + a2 + a3;
+        }
+        else if (ND == 2)
+        {
+#pragma unroll 4
+            for (int y = 0; y < rows; ++y, q += pitchD, gs += gpitch)
+            {
+                const u32x2 a = *reinterpret_cast<const u32x2_dw *>(gs);
+                const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+                acc = sad_dword<S>(a.x, __builtin_amdgcn_alignbyte(d1, d0, sh), acc);
+                acc = sad_dword<S>(a.y, __builtin_amdgcn_alignbyte(d2, d1, sh), acc);
+            }
+        }
+        else
+        {
+            for (int y = 0; y < rows; ++y, q += pitchD, gs += gpitch)
+            {
+                uint32_t prev = q[0];
+                for (int i = 0; i < nd; ++i)
+                {
+                    const uint32_t d = q[i + 1];
+                    acc = sad_dword<S>(gs[i], __builtin_amdgcn_alignbyte(d, prev, sh), acc);
+                    prev = d;
+                }
+            }
+        }
+        return acc;
+    }
+    if (ND >= 4)
+    {
+#pragma unroll 2
+        for (int y = 0; y < rows; ++y, q += pitchD, s += ND)
+        {
+            uint32_t prev = q[0];
+#pragma unroll
+            for (int i = 0; i < ND; i += 4)
+            {
+                const u32x4 a = *reinterpret_cast<const __attribute__((address_space(3))) u32x4 *>(s + i);
+                const uint32_t d1 = q[i + 1], d2 = q[i + 2], d3 = q[i + 3], d4 = q[i + 4];
+                acc = sad_dword<S>(a.x, __builtin_amdgcn_alignbyte(d1, prev, sh), acc);
+                acc = sad_dword<S>(a.y, __builtin_amdgcn_alignbyte(d2, d1, sh), acc);
+                acc = sad_dword<S>(a.z, __builtin_amdgcn_alignbyte(d3, d2, sh), acc);
+                acc = sad_dword<S>(a.w, __builtin_amdgcn_alignbyte(d4, d3, sh), acc);
+                prev = d4;
+            }
+        }
+    }
+    else if (ND == 2)
+    {
+#pragma unroll 4
+        for (int y = 0; y < rows; ++y, q += pitchD, s += 2)
+        {
+            const u32x2 a = *reinterpret_cast<const __attribute__((address_space(3))) u32x2 *>(s);
+            const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+            acc = sad_dword<S>(a.x, __builtin_amdgcn_alignbyte(d1, d0, sh), acc);
+            acc = sad_dword<S>(a.y, __builtin_amdgcn_alignbyte(d2, d1, sh), acc);
+        }
+    }
+    else
+    {   // any number of dwords per row (widths 4, 12, 24, 48 ...; 64 samples of 16 bits): the loop's control is scalar, the row is walked a dword at a time
+        for (int y = 0; y < rows; ++y, q += pitchD, s += nd)
+        {
+            uint32_t prev = q[0];
+            for (int i = 0; i < nd; ++i)
+            {
+                const uint32_t d = q[i + 1];
+                acc = sad_dword<S>(s[i], __builtin_amdgcn_alignbyte(d, prev, sh), acc);
+                prev = d;
+            }
+        }
+    }
+    return acc;
+}
+
+// (Measured and dropped, profiles/r05/sad4_lane_forms.txt: the box rows through ds_read_b64 -- the lanes sorted by the parity of their first box dword, a wavefront of one
+// parity reading aligned pairs -- took 0.49 ms against 0.14: an 8-byte read whose 64 addresses are scattered costs ~25 LDS cycles, not the 2 of a regular stride.)
+// Also measured and dropped: the lanes taking the candidates in the order of their box row (counting sort in LDS): bank conflicts 30.9 M -> 21.9 M cycles, but the sort's
+// three barriers cost more than that (0.152 against 0.144 ms); and a lane per block ROW for 64x64 blocks (source row and box row in registers, the box read once per distinct
+// row by ds_read_b128, a wavefront reduction per candidate): LDS cycles 66.8 M -> 43.3 M, time 0.156 against 0.143 ms.  What the launch waits for is not the LDS: a
+// workgroup's chain run record -> first job -> box -> barrier -> a scalar load per source row is memory latency, with six workgroups per CU to cover it.  PERSISTENT
+// workgroups that fetch their next run's box and jobs into registers while they compute (the run record carrying the source offset and size): 0.20 ms -- the registers
+// that costs leave four workgroups per CU, and ONE workgroup alone on a CU still takes ~15 k cycles per run (the per-row scalar loads miss the scalar cache).
+// profiles/r05/sad4_lane_forms.txt has every number.
+template <int S, int NW, bool SG>
+__device__ __forceinline__ void sad4_run_lanes(const __attribute__((address_space(3))) uint32_t *win, const __attribute__((address_space(3))) uint32_t *srcw,
+                                               const __attribute__((address_space(3))) uint32_t *cand, uint32_t *s_acc, int pitchD, int lead, int mndx,
+                                               int mndy, int rowBytes, int h, int count, int tid, int32_t *__restrict__ out, const uint32_t *__restrict__ gsrc, int gpitch)
+{
+    const int P = 4 * count, nd = rowBytes >> 2, chunks = (P + 63) >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    // row slices only where wavefronts would idle (a run of few candidates: the big blocks), and of at least eight rows
+    int ns = 1;
+    while (ns < 8 && chunks * ns < NW && h >= 16 * ns) ns *= 2;
+    const int rps = (h + ns - 1) / ns;
+    if (ns > 1)
+    {   // (the partial sums meet in s_acc: cleared here)
+        for (int i = tid; i < P; i += 64 * NW) s_acc[i] = 0;
+        __syncthreads();
+    }
+    for (int t = wave; t < chunks * ns; t += NW)
+    {
+        const int chunk = ns == 1 ? t : t / ns, slice = t - chunk * ns;
+        const int pos = chunk * 64 + lane;
+        const int p = pos;
+        const int v = (int)cand[min(p, P - 1)];
+        const int col = (int)(short)(v & 0xffff) - mndx, row = (v >> 16) - mndy;
+        const int bo = lead + col * S, sh = bo & 3;
+        const int yBeg = slice * rps, rows = min(h, yBeg + rps) - yBeg;
+        const auto q = win + mul24(row + yBeg, pitchD) + (bo >> 2);
+        const auto sp = srcw + yBeg * nd;
+        const uint32_t *gs = gsrc + (long)yBeg * gpitch;
+        uint32_t acc;
+        if (nd == 16) acc = sad_lane_rows<S, 16, SG>(q, sp, pitchD, nd, rows, sh, gs, gpitch);
+        else if (nd == 8) acc = sad_lane_rows<S, 8, SG>(q, sp, pitchD, nd, rows, sh, gs, gpitch);
+        else if (nd == 4) acc = sad_lane_rows<S, 4, SG>(q, sp, pitchD, nd, rows, sh, gs, gpitch);
+        else if (nd == 2) acc = sad_lane_rows<S, 2, SG>(q, sp, pitchD, nd, rows, sh, gs, gpitch);
+        else acc = sad_lane_rows<S, 0, SG>(q, sp, pitchD, nd, rows, sh, gs, gpitch);
+        if (p < P)
+        {
+            if (ns == 1) out[p] = (int32_t)(S == 2 ? acc >> 2 : acc);
+            else atomicAdd(&s_acc[p], acc);
+        }
+    }
+    if (ns > 1)
+    {
+        __syncthreads();
+        for (int p = tid; p < P; p += 64 * NW) out[p] = (int32_t)(S == 2 ? s_acc[p] >> 2 : s_acc[p]);
+    }
+}
+
+// the LDS of a run's workgroup
+template <int S>
+struct RunLds
+{
+    static constexpr int kWinD = (S == 1 ? 16 : 32) * 256;      // the window: 16 KB (8-bit) / 32 KB (16-bit), in dwords
+    static constexpr int kSrcD = 64 * 64 * S / 4;                // the source block
+    __attribute__((aligned(16))) uint32_t lds[kWinD + kSrcD + 8];
+    __attribute__((aligned(16))) uint32_t cand[kRunMax * 4];     // the candidates' (column, row) in the box
+    uint32_t acc[kRunMax * 4];                                    // lane-per-candidate form: where the row slices' partial sums meet
+    int box[6];
+};
+
+// one run, start to finish (every thread of the workgroup; returns at uniform points, LDS may be in any state afterwards)
+template <int S, int NW, int U, bool SRCG>
+__device__ __forceinline__ void sad4_run_general(RunLds<S> &sh, const char *__restrict__ src, long stride_src, const char *__restrict__ ref, long stride_ref,
+                                                 float inv_stride_ref, const int32_t *__restrict__ jobs, int njobs, const int32_t *__restrict__ runs, int run,
+                                                 int32_t *__restrict__ out)
 {
     constexpr int T = 64 * NW, NG = T / kSadLanes;
-    constexpr int kWinD = (S == 1 ? 16 : 32) * 256;      // the window: 16 KB (8-bit) / 32 KB (16-bit), in dwords
-    constexpr int kSrcD = 64 * 64 * S / 4;                // the source block
+    constexpr int kWinD = RunLds<S>::kWinD, kSrcD = RunLds<S>::kSrcD;
     constexpr int kFallWB = 1024, kFallD = kFallWB * S / 4 + 16;      // the call-by-call path's buffer per lane group
     static_assert(NG * kFallD + 4 <= kWinD + kSrcD, "the call-by-call path's buffers must fit the run's LDS");
-    __shared__ __attribute__((aligned(16))) uint32_t lds[kWinD + kSrcD + 8];
-    __shared__ __attribute__((aligned(16))) uint32_t s_cand[kRunMax * 4];
-    __shared__ int s_box[6];
-    const int run = xcd_block(blockIdx.x, gridDim.x);
+    uint32_t (&lds)[kWinD + kSrcD + 8] = sh.lds;
+    uint32_t (&s_cand)[kRunMax * 4] = sh.cand;
+    uint32_t (&s_acc)[kRunMax * 4] = sh.acc;
+    int (&s_box)[6] = sh.box;
     const int tid = threadIdx.x, lane = tid & (kSadLanes - 1), group = tid / kSadLanes;
     const int32_t *rr = runs + (long)run * 8;      // havoc_mi355x_sad4_run
     const int first = rr[0], count = rr[1], boxOff = rr[2], boxW = rr[3], boxH = rr[4];
@@ -615,9 +796,17 @@ __global__ __launch_bounds__(64 * NW) void k_sad4r(const char *__restrict__ src,
         const auto srcw = (const __attribute__((address_space(3))) uint32_t *)(&lds[kWinD + 4]);
         const auto cand = (const __attribute__((address_space(3))) uint32_t *)(&s_cand[0]);
         int32_t *o = out + (long)first * 4;
-        if ((rowBytes & 15) == 0) sad4_run_calls<S, 16, U>(win, srcw, cand, pitchD, lead, mndx, mndy, rowBytes, h, count, group, NG, lane, o);
-        else if ((rowBytes & 7) == 0) sad4_run_calls<S, 8, U>(win, srcw, cand, pitchD, lead, mndx, mndy, rowBytes, h, count, group, NG, lane, o);
-        else sad4_run_calls<S, 4, U>(win, srcw, cand, pitchD, lead, mndx, mndy, rowBytes, h, count, group, NG, lane, o);
+        if (U == 0)
+        {
+            const long sbyte = (long)so * S;
+            if (SRCG && ((sbyte | ssb) & 3) == 0)
+                sad4_run_lanes<S, NW, true>(win, srcw, cand, s_acc, pitchD, lead, mndx, mndy, rowBytes, h, count, tid, o, reinterpret_cast<const uint32_t *>(src + sbyte), (int)(ssb >> 2));
+            else
+                sad4_run_lanes<S, NW, false>(win, srcw, cand, s_acc, pitchD, lead, mndx, mndy, rowBytes, h, count, tid, o, nullptr, 0);
+        }
+        else if ((rowBytes & 15) == 0) sad4_run_calls<S, 16, (U ? U : 1)>(win, srcw, cand, pitchD, lead, mndx, mndy, rowBytes, h, count, group, NG, lane, o);
+        else if ((rowBytes & 7) == 0) sad4_run_calls<S, 8, (U ? U : 1)>(win, srcw, cand, pitchD, lead, mndx, mndy, rowBytes, h, count, group, NG, lane, o);
+        else sad4_run_calls<S, 4, (U ? U : 1)>(win, srcw, cand, pitchD, lead, mndx, mndy, rowBytes, h, count, group, NG, lane, o);
         return;
     }
     __syncthreads();      // (a run whose box did not hold: the staged window is dropped, its LDS becomes the call-by-call path's buffers)
@@ -631,6 +820,14 @@ __global__ __launch_bounds__(64 * NW) void k_sad4r(const char *__restrict__ src,
 #pragma unroll
             for (int k = 0; k < 4; ++k) out[((long)first + c) * 4 + k] = total[k];
     }
+}
+
+template <int S, int NW, int U, bool SRCG = true>
+__global__ __launch_bounds__(64 * NW) void k_sad4r(const char *__restrict__ src, long stride_src, const char *__restrict__ ref, long stride_ref, float inv_stride_ref,
+                                                   const int32_t *__restrict__ jobs, int njobs, const int32_t *__restrict__ runs, int nruns, int32_t *__restrict__ out)
+{
+    __shared__ RunLds<S> sh;
+    sad4_run_general<S, NW, U, SRCG>(sh, src, stride_src, ref, stride_ref, inv_stride_ref, jobs, njobs, runs, xcd_block(blockIdx.x, gridDim.x), out);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1045,9 +1242,13 @@ hipError_t launch_sad4_runs(hipStream_t st, int S, const void *src, long ss, con
     const float inv = 1.0f / (float)rs;
     const int nw = sad4_run_waves();
     const dim3 g(nruns), b(64 * nw);
-    static const int unroll = [] { const char *e = getenv("HAVOC_SAD4_RUN_UNROLL"); return e && *e == '2' ? 2 : 1; }();      // calls per pass of a lane group (2: no gain once the cutter keeps big blocks' runs short)
-#define HAVOC_RUN(SS, NW) do { if (unroll == 1) hipLaunchKernelGGL((k_sad4r<SS, NW, 1>), g, b, 0, st, s, ss, r, rs, inv, j, n, rn, nruns, out); \
-                               else hipLaunchKernelGGL((k_sad4r<SS, NW, 2>), g, b, 0, st, s, ss, r, rs, inv, j, n, rn, nruns, out); } while (0)
+    // 0 (default): a lane per candidate; 1 / 2: a lane group of 16 per call, that many calls per pass (the round's first form, kept for comparison: HAVOC_SAD4_RUN_UNROLL)
+    static const int unroll = [] { const char *e = getenv("HAVOC_SAD4_RUN_UNROLL"); return e && *e == '2' ? 2 : (e && *e == '1' ? 1 : 0); }();
+    static const bool srcl = [] { const char *e = getenv("HAVOC_SAD4_RUN_SRC"); return e && *e == 'l'; }();      // l: the source block by broadcast reads of its LDS copy (default: scalar loads)
+#define HAVOC_RUN(SS, NW) do { if (unroll == 0 && !srcl) hipLaunchKernelGGL((k_sad4r<SS, NW, 0, true>), g, b, 0, st, s, ss, r, rs, inv, j, n, rn, nruns, out); \
+                               else if (unroll == 0) hipLaunchKernelGGL((k_sad4r<SS, NW, 0, false>), g, b, 0, st, s, ss, r, rs, inv, j, n, rn, nruns, out); \
+                               else if (unroll == 1) hipLaunchKernelGGL((k_sad4r<SS, NW, 1, false>), g, b, 0, st, s, ss, r, rs, inv, j, n, rn, nruns, out); \
+                               else hipLaunchKernelGGL((k_sad4r<SS, NW, 2, false>), g, b, 0, st, s, ss, r, rs, inv, j, n, rn, nruns, out); } while (0)
     if (S == 1) { if (nw == 1) HAVOC_RUN(1, 1); else if (nw == 2) HAVOC_RUN(1, 2); else HAVOC_RUN(1, 4); }
     else { if (nw == 1) HAVOC_RUN(2, 1); else if (nw == 2) HAVOC_RUN(2, 2); else HAVOC_RUN(2, 4); }
 #undef HAVOC_RUN
