@@ -692,6 +692,7 @@ __device__ __forceinline__ void sad4_run_general(RunLds<S> &sh, const char *__re
     const int rowBytes = w * S;
     const long ssb = stride_src * S, rsb = stride_ref * S;
     const bool chunked = (rowBytes & 15) == 0 ? rowBytes <= 16 * kSadLanes : (rowBytes & 7) == 0 ? rowBytes <= 8 * kSadLanes : (rowBytes & 3) == 0 && rowBytes <= 4 * kSadLanes;
+    const bool srcScalar = U == 0 && SRCG && ((((long)so * S) | ssb) & 3) == 0;      // the source block's rows at dword-aligned addresses: scalar loads
     const bool given = boxW > 0 && boxH > 0 && boxW < st;      // the cutter's box (havoc_mi355x_sad4_make_runs): staged at once, every candidate then checked against it
     int mndx = 0, mndy = 0, spanx, spready, ok = count <= kRunMax;
     long minoff;
@@ -761,14 +762,17 @@ __device__ __forceinline__ void sad4_run_general(RunLds<S> &sh, const char *__re
                 const int l = r * pitchD + c * 4;
                 win_w[l] = v.x; win_w[l + 1] = v.y; win_w[l + 2] = v.z; win_w[l + 3] = v.w;
             }
-            // the source block: dense rows of dwords
-            const int dpr = rowBytes >> 2;
-            const FastDiv fdw(dpr);
-            const uint32_t sb0 = (uint32_t)so * S;
-            for (int i = tid; i < h * dpr; i += T)
+            // the source block: dense rows of dwords (not needed where the lanes read it through scalar loads)
+            if (!srcScalar)
             {
-                const int y = fdw.div(i), x = i - y * dpr;
-                src_w[i] = ld4(src + sb0 + (uint32_t)y * (uint32_t)ssb + x * 4);
+                const int dpr = rowBytes >> 2;
+                const FastDiv fdw(dpr);
+                const uint32_t sb0 = (uint32_t)so * S;
+                for (int i = tid; i < h * dpr; i += T)
+                {
+                    const int y = fdw.div(i), x = i - y * dpr;
+                    src_w[i] = ld4(src + sb0 + (uint32_t)y * (uint32_t)ssb + x * 4);
+                }
             }
         }
         if (given)
@@ -799,7 +803,7 @@ __device__ __forceinline__ void sad4_run_general(RunLds<S> &sh, const char *__re
         if (U == 0)
         {
             const long sbyte = (long)so * S;
-            if (SRCG && ((sbyte | ssb) & 3) == 0)
+            if (srcScalar)
                 sad4_run_lanes<S, NW, true>(win, srcw, cand, s_acc, pitchD, lead, mndx, mndy, rowBytes, h, count, tid, o, reinterpret_cast<const uint32_t *>(src + sbyte), (int)(ssb >> 2));
             else
                 sad4_run_lanes<S, NW, false>(win, srcw, cand, s_acc, pitchD, lead, mndx, mndy, rowBytes, h, count, tid, o, nullptr, 0);
