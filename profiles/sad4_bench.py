@@ -16,7 +16,8 @@ from turingcodec_amd.workload import FrameWorkload  # noqa: E402
 form = sys.argv[1] if len(sys.argv) > 1 else "runs"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 hv = Havoc(0, stream="new")
-wl = FrameWorkload(1920, 1080, 8, 11)
+res = os.environ.get("HAVOC_SAD4_RES", "1920x1080x8").split("x")      # width x height x bit depth
+wl = FrameWorkload(int(res[0]), int(res[1]), int(res[2]), 11)
 luma, jobs = hv.up(wl.luma), hv.up(wl.sad4)
 boxed = os.environ.get("HAVOC_SAD4_BOX", "1") == "1"      # 0: runs without a box (the kernel reduces every run's box itself)
 runs = Havoc.sad4_make_runs(wl.sad4, int(os.environ.get("HAVOC_SAD4_MAX_RUN", "0")), wl.stride if boxed else None, wl.S)
@@ -43,5 +44,5 @@ for _ in range(3):
 size = {}
 for w in (8, 16, 32, 64):
     size[w] = int((wl.sad4[runs[:, 0], 5] == w).sum())
-print(json.dumps({"form": form, "waves": os.environ.get("HAVOC_SAD4_RUN_WAVES", "4"), "unroll": os.environ.get("HAVOC_SAD4_RUN_UNROLL", "1"), "caps": os.environ.get("HAVOC_SAD4_CAPS", "16,48,128"), "policy": policy, "max_run": os.environ.get("HAVOC_SAD4_MAX_RUN", "0"), "boxed": bool(boxed and not policy), "ms": round(best, 4), "calls": int(len(wl.sad4)), "runs": int(len(runs)), "runs_by_width": size,
+print(json.dumps({"form": form, "picture": "x".join(res), "waves": os.environ.get("HAVOC_SAD4_RUN_WAVES", "4"), "unroll": os.environ.get("HAVOC_SAD4_RUN_UNROLL", "1"), "caps": os.environ.get("HAVOC_SAD4_CAPS", "16,48,128"), "policy": policy, "max_run": os.environ.get("HAVOC_SAD4_MAX_RUN", "0"), "boxed": bool(boxed and not policy), "ms": round(best, 4), "calls": int(len(wl.sad4)), "runs": int(len(runs)), "runs_by_width": size,
                   "checksum": int(hv.down(out, np.int32).astype(np.int64).sum())}))

@@ -638,7 +638,8 @@ __device__ __forceinline__ void sad4_run_lanes(const __attribute__((address_spac
         const auto sp = srcw + yBeg * nd;
         const uint32_t *gs = gsrc + (long)yBeg * gpitch;
         uint32_t acc;
-        if (nd == 16) acc = sad_lane_rows<S, 16, SG>(q, sp, pitchD, nd, rows, sh, gs, gpitch);
+        if (S == 2 && nd == 32) acc = sad_lane_rows<S, 32, SG>(q, sp, pitchD, nd, rows, sh, gs, gpitch);      // 64 samples of 16 bits
+        else if (nd == 16) acc = sad_lane_rows<S, 16, SG>(q, sp, pitchD, nd, rows, sh, gs, gpitch);
         else if (nd == 8) acc = sad_lane_rows<S, 8, SG>(q, sp, pitchD, nd, rows, sh, gs, gpitch);
         else if (nd == 4) acc = sad_lane_rows<S, 4, SG>(q, sp, pitchD, nd, rows, sh, gs, gpitch);
         else if (nd == 2) acc = sad_lane_rows<S, 2, SG>(q, sp, pitchD, nd, rows, sh, gs, gpitch);
