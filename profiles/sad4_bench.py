@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """The 4-way SAD calls of one 1080p picture (1.27 M calls, the bench's workload) timed alone: `calls` = havoc_mi355x_sad4 (a window per call, k_sad4w),
-`runs` = havoc_mi355x_sad4_runs (a window per search, k_sad4r; HAVOC_SAD4_RUN_WAVES picks the workgroup size, read once per process).
+`runs` = havoc_mi355x_sad4_runs (a window per search, k_sad4r; HAVOC_SAD4_RUN_WAVES picks the workgroup size, HAVOC_SAD4_RUN_UNROLL=1|2 the round's first form (16 lanes per
+call) instead of a lane per candidate, HAVOC_SAD4_RUN_SRC=l the source block from its LDS copy instead of scalar loads; each read once per process).
+HAVOC_SAD4_RES=WxHxBITS picks the picture (default 1920x1080x8).
     python profiles/sad4_bench.py runs|calls [reps]
 Prints one JSON line; run under rocprofv3 for the counters (profiles/gpu_call_r05b.sh)."""
 import json
@@ -44,5 +46,5 @@ for _ in range(3):
 size = {}
 for w in (8, 16, 32, 64):
     size[w] = int((wl.sad4[runs[:, 0], 5] == w).sum())
-print(json.dumps({"form": form, "picture": "x".join(res), "waves": os.environ.get("HAVOC_SAD4_RUN_WAVES", "4"), "unroll": os.environ.get("HAVOC_SAD4_RUN_UNROLL", "1"), "caps": os.environ.get("HAVOC_SAD4_CAPS", "16,48,128"), "policy": policy, "max_run": os.environ.get("HAVOC_SAD4_MAX_RUN", "0"), "boxed": bool(boxed and not policy), "ms": round(best, 4), "calls": int(len(wl.sad4)), "runs": int(len(runs)), "runs_by_width": size,
+print(json.dumps({"form": form, "picture": "x".join(res), "waves": os.environ.get("HAVOC_SAD4_RUN_WAVES", "4"), "unroll": os.environ.get("HAVOC_SAD4_RUN_UNROLL", "0"), "src": os.environ.get("HAVOC_SAD4_RUN_SRC", "scalar"), "caps": os.environ.get("HAVOC_SAD4_CAPS", "16,48,128"), "policy": policy, "max_run": os.environ.get("HAVOC_SAD4_MAX_RUN", "0"), "boxed": bool(boxed and not policy), "ms": round(best, 4), "calls": int(len(wl.sad4)), "runs": int(len(runs)), "runs_by_width": size,
                   "checksum": int(hv.down(out, np.int32).astype(np.int64).sum())}))

@@ -167,13 +167,15 @@ def test_generic_widths_and_a_window_at_the_start_of_the_buffer(bit_depth):
 
 
 @pytest.mark.gpu
-def test_runs_equal_calls_on_a_picture_of_the_bench(tmp_path):
-    """size-independent property at full size: the 1.27 M calls of a 1080p picture by runs == the same calls one by one (k_sad4w), both against the oracle on a sample"""
+@pytest.mark.parametrize("bit_depth", [8, 10])
+def test_runs_equal_calls_on_a_picture_of_the_bench(bit_depth):
+    """size-independent property at full size: the 1.27 M calls of a 1080p picture by runs == the same calls one by one (k_sad4w), both against the oracle on a sample
+    (16-bit samples: a 64-wide block's rows are the 32-dword case of the lane-per-candidate form)"""
     from reflibs import Oracle
     from turingcodec_amd import Havoc
     from turingcodec_amd.workload import FrameWorkload
     hv, orc = Havoc(0), Oracle()
-    wl = FrameWorkload(1920, 1080, 8, 11)
+    wl = FrameWorkload(1920, 1080, bit_depth, 11)
     luma, jobs = hv.up(wl.luma), hv.up(wl.sad4)
     runs = Havoc.sad4_make_runs(wl.sad4, 0, wl.stride, wl.S)
     assert 30 < len(wl.sad4) / len(runs) <= 128 and (runs[:, 3] > 0).mean() > 0.99
