@@ -685,6 +685,17 @@ int havoc_mi355x_search_picture_uni(havoc_mi355x_ctx *ctx, int S, const havoc_mi
                                     int64_t src_origin, intptr_t src_stride, const void *d_ref, const int64_t ref_origin[2], intptr_t ref_stride, const void *d_phase,
                                     intptr_t plane_elems, const int64_t phase_origin[2], const void *d_pus, const int32_t *d_ctu_first, int ctus_x, int ctus_y,
                                     int n_pus, void *d_out, void *d_out_bi, int16_t *d_field, void *d_work, int step_launches);
+/* Searching into reference pictures that are STILL ARRIVING (the reference: turing/TaskEncodeSubstream.cpp:71-95 -- a CTU starts when its reference picture is
+ * reconstructed three CTU rows below it; TaskDeblock.cpp:151-167 publishes the deblocked, padded rows).  d_rows_ready = two device int32: entry l = how many luma rows
+ * of reference list l, counted from picture row 0, are final in d_ref AND in all 16 planes of d_phase -- raised (never lowered) by whatever delivers the picture, on
+ * ANOTHER stream, while the search kernel runs; the last band raises it to at least pic_height + ctb_size + 8 (bottom border included).  The havoc_mi355x_search_picture_uni
+ * launches of this context that follow make CTU row r of list l wait until d_rows_ready[l] >= min((r + 2) * ctb_size, pic_height + ctb_size + 8): with
+ * concurrent_frames > 1 (required) the search limits a CTU row's vectors to blocks that end above row (r + 2) * ctb_size - 15 (the reference's LimitFullPelMv), so
+ * nothing below is read for a result.  Results are those of the ungated call.  A wait that outlasts ~4 s gives up (HAVOC_MI355X_EDEVICE from the next sync of the
+ * caller).  d_rows_ready = NULL removes the gate.  The delivering stream must make its writes visible before it raises the counter (a kernel boundary does), and it
+ * must be able to RUN while the search kernel waits: give it another priority than the searching stream (hipStreamCreateWithPriority) -- HIP multiplexes the streams of
+ * one priority onto a few hardware queues, and a waiting kernel blocks what is queued behind it. */
+int havoc_mi355x_search_gate(havoc_mi355x_ctx *ctx, const int32_t *d_rows_ready);
 
 #ifdef __cplusplus
 }

@@ -55,7 +55,7 @@ hipError_t launch_search_list(hipStream_t, int S, const havoc_mi355x_search_para
 hipError_t launch_search_bi_list(hipStream_t, int S, const havoc_mi355x_search_params *, const void *, long, long, const void *, long, long, const void *, long, long, const void *,
                                  long, const void *, const int16_t *, int, void *);
 hipError_t launch_search_picture_uni(hipStream_t, int S, const havoc_mi355x_search_params *, const int64_t *, const void *, long, long, const void *, const long *, long,
-                                     const void *, long, const long *, const void *, const int32_t *, int, int, int, void *, void *, int16_t *, void *, int);
+                                     const void *, long, const long *, const void *, const int32_t *, int, int, int, void *, void *, int16_t *, void *, int, const int32_t *);
 hipError_t launch_rdoq(hipStream_t, int bd, int log2, int16_t *, const int16_t *, const uint8_t *, const void *, int, int32_t *, void *);
 size_t rdoq_workspace_bytes(int njobs);
 hipError_t launch_sao_stats(hipStream_t, int S, int bd, const void *, long, const void *, long, const void *, int, int64_t *);
@@ -658,10 +658,20 @@ int havoc_mi355x_search_picture_uni(havoc_mi355x_ctx *ctx, int S, const havoc_mi
     REQUIRE(params->pic_width > 0 && params->pic_height > 0 && params->pic_width % 8 == 0 && params->pic_height % 8 == 0, "picture size must be a positive multiple of 8");
     REQUIRE(ctus_x == (params->pic_width + 63) / 64 && ctus_y == (params->pic_height + 63) / 64, "ctus_x / ctus_y do not match the picture size");
     REQUIRE(params->bit_depth >= 8 && params->bit_depth <= (S == 1 ? 8 : 10), "bit_depth must be 8 (S=1) or 8..10 (S=2)");
+    REQUIRE(!ctx->searchGate || (params->concurrent_frames > 1 && !step_launches),
+            "search gate: needs concurrent_frames > 1 (only then are the vectors of a CTU row limited to rows the gate can promise) and the one-launch form");
     const long ro[2] = {(long)ref_origin[0], (long)ref_origin[1]}, po[2] = {(long)phase_origin[0], (long)phase_origin[1]};
     return check(launch_search_picture_uni(LS(ctx), S, params, mvp_rate, d_src, (long)src_origin, src_stride, d_ref, ro, ref_stride, d_phase, plane_elems, po, d_pus,
-                                           d_ctu_first, ctus_x, ctus_y, n_pus, d_out, d_out_bi, d_field, d_work, step_launches),
+                                           d_ctu_first, ctus_x, ctus_y, n_pus, d_out, d_out_bi, d_field, d_work, step_launches, ctx->searchGate),
                  "search_picture_uni");
+}
+
+int havoc_mi355x_search_gate(havoc_mi355x_ctx *ctx, const int32_t *d_rows_ready)
+{
+    REQUIRE_CTX();
+    REQUIRE(((uintptr_t)d_rows_ready & 3) == 0, "d_rows_ready must be 4-byte aligned");
+    ctx->searchGate = d_rows_ready;
+    return 0;
 }
 
 static bool layout_ok(const havoc_mi355x_field_layout *l)

@@ -21,6 +21,7 @@ struct havoc_mi355x_ctx
     hipEvent_t forkEv;
     int nlanes;   // 0 = not forked
     int cur;      // lane the next launch goes to (0 = the context's main stream)
+    const int32_t *searchGate = nullptr;      // havoc_mi355x_search_gate: rows of the reference pictures that have arrived, [2] device ints (nullptr: references complete)
 };
 
 // the stream the next launch is issued on

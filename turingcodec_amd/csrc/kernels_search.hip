@@ -52,6 +52,8 @@ struct SearchArgs
     int *progress;                            // [ctusY][2]: CTUs of the row done (the one-launch form)
     int *ticket, *gaveUp;                     // rows are handed out in the order workgroups start; a wait that gave up
     int rowLag;                               // CTUs the row above must be ahead: 2 = the reference's wavefront rule (TaskEncodeSubstream.cpp:71-95); 1 = diagnostic
+    const int *rowsReady;                     // [2] or nullptr: luma rows (from picture row 0) of reference list l that are final in ref[l] AND in all of phase[l], raised
+                                              // by another stream while this kernel runs (havoc_mi355x_search_gate): a CTU row waits for what its vectors can reach
 };
 
 // LDS operands are named by address-space-3 pointers so that they are read with ds_read (a generic pointer would be a flat load)
@@ -1379,6 +1381,39 @@ __global__ __launch_bounds__(kThreads) void k_search_rows(const SearchArgs a)
     if (cy >= a.ctusY) return;
     int *progress = a.progress + 2 * cy + list;
     const int *above = a.progress + 2 * (cy - 1) + list;
+    if (a.rowsReady)
+    {   // The reference picture is still arriving (TaskEncodeSubstream.cpp:71-95: a CTU waits until its reference is reconstructed 3 rows below).  With frames encoded
+        // concurrently the vectors of this CTU row are limited to blocks that end above row yCtb + 2 * ctb - 15 (decision.hpp: LimitFullPelMv, the reference's
+        // howCloseDoYouDare), so rows [0, (cy + 2) * ctb) of the picture and of its 15 fractional planes are all this row reads; the last rows reach the bottom border.
+        __syncthreads();      // (every thread has read its ticket from `shared`)
+        if (tid == 0)
+        {
+            const int ctb = a.sp.ctbSize, need = min((cy + 2) * ctb, a.sp.picHeight + ctb + 8);
+            int spins = 0, ok = 1;
+            while (__hip_atomic_load(a.rowsReady + list, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need)
+            {
+                __builtin_amdgcn_s_sleep(64);
+                if (++spins > kSpinLimit || __hip_atomic_load(a.gaveUp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                {
+                    ok = 0;
+                    break;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            shared = ok;
+        }
+        __syncthreads();
+        if (!shared)
+        {
+            if (tid == 0)
+            {
+                atomicOr(a.gaveUp, 1);
+                __hip_atomic_store(progress, a.ctusX, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
+        __syncthreads();
+    }
     Mv mvPrev(0, 0);
     if (tid < 256)
     {
@@ -1540,9 +1575,11 @@ static_assert(sizeof(havoc_mi355x_search_params) == sizeof(havoc_search_params) 
 
 hipError_t launch_search_picture_uni(hipStream_t st, int S, const havoc_mi355x_search_params *sp, const int64_t mvpRate[2], const void *src, long srcOrigin, long srcStride,
                                      const void *ref, const long refOrigin[2], long refStride, const void *phase, long planeElems, const long phaseOrigin[2], const void *pus,
-                                     const int32_t *ctuFirst, int ctusX, int ctusY, int nPus, void *out, void *outBi, int16_t *field, void *work, int stepLaunches)
+                                     const int32_t *ctuFirst, int ctusX, int ctusY, int nPus, void *out, void *outBi, int16_t *field, void *work, int stepLaunches,
+                                     const int32_t *rowsReady)
 {
     SearchArgs a;
+    a.rowsReady = rowsReady;
     a.sp.picWidth = sp->pic_width;
     a.sp.picHeight = sp->pic_height;
     a.sp.ctbSize = sp->ctb_size;

@@ -106,6 +106,7 @@ def _load():
         "pred_jobs": [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp],
         "search_motion_bi": [_vp, _i, _vp, _vp, C.c_int64, _ip, _vp, C.c_int64, _ip, _vp, _ip, C.c_int64, _vp, C.c_int64, _vp, _vp, _i, _vp],
         "search_picture_uni": [_vp, _i, _vp, _vp, _vp, C.c_int64, _ip, _vp, _vp, _ip, _vp, _ip, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i],
+        "search_gate": [_vp, _vp],
         "intra_order": [_vp, _vp, _vp, _i, C.c_int32, _vp, _vp, _vp, _vp],
         "intra_expand": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
         "intra_decide": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, C.c_int32, _vp, _vp],
@@ -439,6 +440,12 @@ class Havoc:
 
     def intra_d(self, bd, log2, dst, sd, nb, jobs):
         self._ck(self.L.havoc_mi355x_intra(self.h, self._S(nb), bd, log2, _ptr(dst), sd, _ptr(nb), _ptr(jobs), jobs.shape[0]))
+
+    def search_gate(self, rows_ready=None):
+        """havoc_mi355x_search_gate: the picture searches this context launches from now on wait, CTU row by CTU row, for their reference pictures -- rows_ready = an int32
+        device tensor of 2 (rows of list 0 / list 1 that are final in the picture and its 16 phase planes, raised on another stream); None removes the gate"""
+        self._gate = rows_ready      # (kept alive)
+        self._ck(self.L.havoc_mi355x_search_gate(self.h, _ptr(rows_ready) if rows_ready is not None else None))
 
     def interp_planes_d(self, bd, planes, plane_elems, ref, stride, x0, y0, width, height):
         self._ck(self.L.havoc_mi355x_interp_planes(self.h, self._S(ref), bd, _ptr(planes), plane_elems, _ptr(ref), stride, x0, y0, width, height))
