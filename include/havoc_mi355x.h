@@ -589,6 +589,9 @@ int havoc_mi355x_rqt_decide(havoc_mi355x_ctx *ctx, const havoc_mi355x_rqt_unit *
  * (int16 [2][height / 4][width / 4][2]) holds at its origin, coded flags and transform sizes as decided; cells outside the units: no motion coded, qp, tu_log2 = 2 */
 int havoc_mi355x_block_cells(havoc_mi355x_ctx *ctx, int width, int height, int qp, int dpb_index0, const int16_t *d_field, const havoc_mi355x_rqt_unit *d_units,
                              const havoc_mi355x_rqt_choice *d_decisions, int n, havoc_mi355x_cell *d_cells);
+/* ... the cells of n more units into cells that hold other units' already (a picture decided band by band: havoc_mi355x_block_cells with n = 0 blanks them once) */
+int havoc_mi355x_block_cells_add(havoc_mi355x_ctx *ctx, int width, int height, int qp, int dpb_index0, const int16_t *d_field, const havoc_mi355x_rqt_unit *d_units,
+                                 const havoc_mi355x_rqt_choice *d_decisions, int n, havoc_mi355x_cell *d_cells);
 
 /* ---- an intra picture's partitions with their real dependencies (round 4; csrc/kernels_decide.hip) ----
  * A partition predicts from the reconstruction of what precedes it (turing/Reconstruct.cpp:609-615) and takes candModeList from its neighbours' decided modes
@@ -696,6 +699,12 @@ int havoc_mi355x_search_picture_uni(havoc_mi355x_ctx *ctx, int S, const havoc_mi
  * must be able to RUN while the search kernel waits: give it another priority than the searching stream (hipStreamCreateWithPriority) -- HIP multiplexes the streams of
  * one priority onto a few hardware queues, and a waiting kernel blocks what is queued behind it. */
 int havoc_mi355x_search_gate(havoc_mi355x_ctx *ctx, const int32_t *d_rows_ready);
+/* The PRODUCER's side of the same rule (turing/TaskDeblock.cpp:151-167 deblocks and publishes a picture's rows while the rows below are still being encoded): a launch on
+ * THIS context's stream that ends when CTU rows 0 .. ctu_row of both lists of the havoc_mi355x_search_picture_uni running over d_work (its workspace; one-launch form) on
+ * ANOTHER stream are done -- whatever is queued behind it (the band's predictions, transform trees, deblocking, padding, the counter a dependent picture's search_gate
+ * polls) runs while the rows below are searched.  The two streams must not share a hardware queue (give them different priorities).  The workspace must have been zeroed
+ * since the previous picture before anything waits on it.  A wait that outlasts ~8 s, or a search that gave up, sets *d_gave_up and lets the stream through. */
+int havoc_mi355x_search_wait_rows(havoc_mi355x_ctx *ctx, const void *d_work, int pic_width, int pic_height, int ctu_row, int32_t *d_gave_up);
 
 #ifdef __cplusplus
 }

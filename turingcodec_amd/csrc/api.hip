@@ -44,7 +44,8 @@ hipError_t launch_intra_decide(hipStream_t, const void *, const int32_t *, const
 hipError_t launch_merge_jobs(hipStream_t, const void *, const int16_t *, const int32_t *, const int32_t *, int, int, void *, void *, void *, int16_t *);
 hipError_t launch_pred_jobs(hipStream_t, const void *, const int16_t *, int, const int32_t *, const int32_t *, int, int, int, const int32_t *, void *);
 hipError_t launch_rqt_decide(hipStream_t, const void *, int, const int32_t *, const int32_t *, const void *, long, int, int, int32_t, void *);
-hipError_t launch_block_cells(hipStream_t, int, int, int, int, const int16_t *, const void *, const void *, int, void *);
+hipError_t launch_block_cells(hipStream_t, int, int, int, int, const int16_t *, const void *, const void *, int, void *, bool);
+hipError_t launch_search_wait_rows(hipStream_t, const void *, int, int, int, int *);
 hipError_t launch_intra_gather(hipStream_t, int, const void *, const void *, const int32_t *, const uint8_t *, const void *, int, const void *, void *, void *);
 hipError_t launch_intra_commit(hipStream_t, int, const void *, void *, uint8_t *, const void *, int, const void *, const void *, int);
 hipError_t launch_intra_fill_spare(hipStream_t, const int32_t *, int, int, void *, void *, void *, int32_t *, int32_t *);
@@ -711,7 +712,23 @@ int havoc_mi355x_block_cells(havoc_mi355x_ctx *ctx, int width, int height, int q
 {
     REQUIRE_CTX(); REQUIRE(n >= 0, "n < 0"); REQUIRE(width > 0 && height > 0 && !(width & 3) && !(height & 3), "width / height must be positive multiples of 4");
     REQUIRE(d_cells && (n == 0 || (d_field && d_units && d_decisions)), "null device pointer"); REQUIRE(((uintptr_t)d_field & 3) == 0, "d_field must be 4-byte aligned");
-    return check(launch_block_cells(LS(ctx), width, height, qp, dpb_index0, d_field, d_units, d_decisions, n, d_cells), "block_cells");
+    return check(launch_block_cells(LS(ctx), width, height, qp, dpb_index0, d_field, d_units, d_decisions, n, d_cells, true), "block_cells");
+}
+
+int havoc_mi355x_block_cells_add(havoc_mi355x_ctx *ctx, int width, int height, int qp, int dpb_index0, const int16_t *d_field, const havoc_mi355x_rqt_unit *d_units,
+                                 const havoc_mi355x_rqt_choice *d_decisions, int n, havoc_mi355x_cell *d_cells)
+{
+    REQUIRE_CTX(); REQUIRE(n >= 0, "n < 0"); REQUIRE(width > 0 && height > 0 && !(width & 3) && !(height & 3), "width / height must be positive multiples of 4");
+    REQUIRE(d_cells && (n == 0 || (d_field && d_units && d_decisions)), "null device pointer"); REQUIRE(((uintptr_t)d_field & 3) == 0, "d_field must be 4-byte aligned");
+    return check(launch_block_cells(LS(ctx), width, height, qp, dpb_index0, d_field, d_units, d_decisions, n, d_cells, false), "block_cells_add");
+}
+
+int havoc_mi355x_search_wait_rows(havoc_mi355x_ctx *ctx, const void *d_work, int pic_width, int pic_height, int ctu_row, int32_t *d_gave_up)
+{
+    REQUIRE_CTX();
+    REQUIRE(d_work && d_gave_up && ((uintptr_t)d_work & 15) == 0 && ((uintptr_t)d_gave_up & 3) == 0, "search_wait_rows: null or misaligned device pointer");
+    REQUIRE(pic_width > 0 && pic_height > 0 && ctu_row >= 0, "search_wait_rows: sizes");
+    return check(launch_search_wait_rows(LS(ctx), d_work, pic_width, pic_height, ctu_row, d_gave_up), "search_wait_rows");
 }
 
 static bool chain_layout_ok(const havoc_mi355x_intra_chain_layout *l)

@@ -262,10 +262,11 @@ hipError_t launch_rqt_decide(hipStream_t st, const void *units, int n, const int
     return hipGetLastError();
 }
 
-hipError_t launch_block_cells(hipStream_t st, int width, int height, int qp, int dpb0, const int16_t *field, const void *units, const void *dec, int n, void *cells)
+hipError_t launch_block_cells(hipStream_t st, int width, int height, int qp, int dpb0, const int16_t *field, const void *units, const void *dec, int n, void *cells, bool blank)
 {
     const int cw = width >> 2, ch = height >> 2;
-    hipLaunchKernelGGL(k_block_cells_blank, dim3((cw * ch + 255) / 256), dim3(256), 0, st, (Cell *)cells, cw * ch, qp, dpb0);
+    if (blank)
+        hipLaunchKernelGGL(k_block_cells_blank, dim3((cw * ch + 255) / 256), dim3(256), 0, st, (Cell *)cells, cw * ch, qp, dpb0);
     if (n > 0)
         hipLaunchKernelGGL(k_block_cells, dim3(n), dim3(64), 0, st, (const RqtUnit *)units, (const RqtResult *)dec, n, reinterpret_cast<const int32_t *>(field), cw, qp, dpb0, (Cell *)cells);
     return hipGetLastError();

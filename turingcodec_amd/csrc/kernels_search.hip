@@ -1557,6 +1557,37 @@ size_t search_workspace_bytes(int width, int height)
     return ((2 * cells + 255) & ~(size_t)255) + 16 * (size_t)((height + 63) / 64) + 16;
 }
 
+// ---- a launch that ends when CTU rows 0 .. rowHi of BOTH lists of the picture search in `work` are done (k_search_rows' progress counters): what is queued behind it on
+// its stream -- the band's merge candidates, predictions, transform trees, deblocking (decisions.py: step_banded) -- then runs while the rows below are still searched.
+// The stream must not be the search's, nor share its hardware queue (another priority).
+__global__ __launch_bounds__(64) void k_wait_rows(const int *progress, int rowHi, int ctusX, const int *searchGaveUp, int *gaveUp)
+{
+    if (threadIdx.x != 0) return;
+    int spins = 0;
+    for (int r = 0; r <= rowHi; ++r)
+        for (int l = 0; l < 2; ++l)
+            while (__hip_atomic_load(progress + 2 * r + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ctusX)
+            {
+                __builtin_amdgcn_s_sleep(64);
+                if (++spins > kSpinLimit || __hip_atomic_load(searchGaveUp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                {
+                    atomicOr(gaveUp, 1);
+                    return;
+                }
+            }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+hipError_t launch_search_wait_rows(hipStream_t st, const void *work, int width, int height, int rowHi, int *gaveUp)
+{
+    const size_t cells = (size_t)((width + 3) / 4) * ((height + 3) / 4);
+    const int ctusX = (width + 63) / 64, ctusY = (height + 63) / 64;
+    const int32_t *rowPrev = reinterpret_cast<const int32_t *>(static_cast<const char *>(work) + ((2 * cells + 255) & ~(size_t)255));      // (launch_search_picture_uni's layout)
+    const int *progress = rowPrev + 2 * ctusY, *ticket = progress + 2 * ctusY + 2;
+    hipLaunchKernelGGL(k_wait_rows, dim3(1), dim3(64), 0, st, progress, rowHi < ctusY - 1 ? rowHi : ctusY - 1, ctusX, ticket + 1, gaveUp);
+    return hipGetLastError();
+}
+
 static hipError_t launch_bi(hipStream_t st, int S, const SearchArgs &a, int nPus)
 {
     if (a.outBi && nPus > 0)

@@ -24,6 +24,13 @@ _ip = C.c_ssize_t
 _i = C.c_int
 
 
+
+def search_workspace(width, height):
+    """bytes of the device workspace a picture search of this size needs (havoc_mi355x_search_workspace)"""
+    L, _ = _load()
+    return int(L.havoc_mi355x_search_workspace(width, height))
+
+
 class HavocError(RuntimeError):
     pass
 
@@ -107,6 +114,8 @@ def _load():
         "search_motion_bi": [_vp, _i, _vp, _vp, C.c_int64, _ip, _vp, C.c_int64, _ip, _vp, _ip, C.c_int64, _vp, C.c_int64, _vp, _vp, _i, _vp],
         "search_picture_uni": [_vp, _i, _vp, _vp, _vp, C.c_int64, _ip, _vp, _vp, _ip, _vp, _ip, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i],
         "search_gate": [_vp, _vp],
+        "search_wait_rows": [_vp, _vp, _i, _i, _i, _vp],
+        "block_cells_add": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp],
         "intra_order": [_vp, _vp, _vp, _i, C.c_int32, _vp, _vp, _vp, _vp],
         "intra_expand": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
         "intra_decide": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, C.c_int32, _vp, _vp],
@@ -384,6 +393,10 @@ class Havoc:
         self._ck(self.L.havoc_mi355x_rqt_decide(self.h, _ptr(units), units.shape[0], _ptr(zero_at), _ptr(one_at), sizes.ctypes.data, int(rec_origin), int(rec_stride), int(dump_off),
                                                 int(rl_q16), _ptr(out)))
 
+    def block_cells_add_d(self, width, height, qp, dpb_index0, field, units, decisions, cells):
+        """the cells of `units` into cells that keep what they hold elsewhere (havoc_mi355x_block_cells_add)"""
+        self._ck(self.L.havoc_mi355x_block_cells_add(self.h, width, height, qp, dpb_index0, _ptr(field), _ptr(units), _ptr(decisions), units.shape[0], _ptr(cells)))
+
     def block_cells_d(self, width, height, qp, dpb_index0, field, units, decisions, cells):
         self._ck(self.L.havoc_mi355x_block_cells(self.h, width, height, qp, dpb_index0, _ptr(field), _ptr(units), _ptr(decisions), units.shape[0], _ptr(cells)))
 
@@ -446,6 +459,19 @@ class Havoc:
         device tensor of 2 (rows of list 0 / list 1 that are final in the picture and its 16 phase planes, raised on another stream); None removes the gate"""
         self._gate = rows_ready      # (kept alive)
         self._ck(self.L.havoc_mi355x_search_gate(self.h, _ptr(rows_ready) if rows_ready is not None else None))
+
+    def search_wait_rows(self, work, width, height, ctu_row, gave_up):
+        """havoc_mi355x_search_wait_rows: a launch on THIS context's stream that ends when CTU rows 0 .. ctu_row (both lists) of the picture search running over the workspace
+        `work` on another stream are done"""
+        self._ck(self.L.havoc_mi355x_search_wait_rows(self.h, _ptr(work), width, height, ctu_row, _ptr(gave_up)))
+
+    def search_picture_uni_d(self, S, params, mvp_rate, src, src_origin, src_stride, ref, ref_origin, ref_stride, phase, plane_elems, phase_origin, pus, ctu_first, ctus_x, ctus_y,
+                             n_pus, out, out_bi, field, work):
+        """havoc_mi355x_search_picture_uni with everything on the device and NOTHING downloaded: asynchronous (d_* = device tensors, params = the ctypes parameter record)"""
+        ro, po, mr = (C.c_int64 * 2)(*[int(v) for v in ref_origin]), (C.c_int64 * 2)(*[int(v) for v in phase_origin]), (C.c_int64 * 2)(*[int(v) for v in mvp_rate])
+        self._ck(self.L.havoc_mi355x_search_picture_uni(self.h, S, C.byref(params), mr, _ptr(src), int(src_origin), src_stride, _ptr(ref), ro, ref_stride, _ptr(phase), plane_elems, po,
+                                                        _ptr(pus), _ptr(ctu_first), ctus_x, ctus_y, n_pus, _ptr(out), _ptr(out_bi) if out_bi is not None else None, _ptr(field),
+                                                        _ptr(work), 0))
 
     def interp_planes_d(self, bd, planes, plane_elems, ref, stride, x0, y0, width, height):
         self._ck(self.L.havoc_mi355x_interp_planes(self.h, self._S(ref), bd, _ptr(planes), plane_elems, _ptr(ref), stride, x0, y0, width, height))
