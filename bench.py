@@ -64,6 +64,8 @@ def parse_args():
                     help="1 (default): the plain N=1 line also carries, under `extra`, the DECISION-DRIVEN path (turingcodec_amd.decisions."
                          "DecisionPicture: motion searches in WPP wavefront order with predictors derived from earlier decisions, batch-fed; then the "
                          "TU chain on the chosen vectors) at 1080p QP32 and 4K QP32, and its ratio to `value`; 2: only that (diagnostic line); 0: off")
+    ap.add_argument("--vr-bands", type=int, default=0, help="--decisions 4: CTU rows per band -- a picture's reconstruction enters the mirror band by band while its lower rows "
+                    "are still searched (DecisionPicture.step_banded) and the pictures predicting from it follow it down the picture (havoc_mi355x_search_gate); 0 = whole pictures")
     ap.add_argument("--vr-dataflow", type=int, default=1, help="--decisions 4: 1 = a picture starts when its references are in the mirror (default); 0 = a barrier between the slots")
     ap.add_argument("--virtual-ranks", type=int, default=8, help="--decisions 4: contexts / host threads that execute the frame-parallel schedule on ONE GPU")
     ap.add_argument("--decision-pictures", type=int, default=16, help="contexts built for the decision-driven path: `value` is measured with 4 independent pictures in flight (the "
@@ -1376,9 +1378,20 @@ def decision_virtual_ranks(args, torch, Havoc):
     for f in frames:
         planes = [workload.pad_plane(f[0], dp0.PAD), workload.pad_plane(f[1], dp0.PAD // 2), workload.pad_plane(f[2], dp0.PAD // 2)]
         sources.append([dp0.hv.up(np.ascontiguousarray(p.ravel())) for p in planes])
-    for dp in ctxs:
-        dp.step()
-        dp.step()      # records the fixed launch sequences into HIP graphs
+    bands = max(0, args.vr_bands)
+    sides = []
+    if bands:
+        # a second context per picture context, on a stream of ANOTHER PRIORITY (= a hardware queue of its own: what waits on it must not sit behind what it waits for)
+        for dp in ctxs:
+            st = torch.cuda.Stream(device=0, priority=-1)
+            sides.append((Havoc(0, stream=st.cuda_stream), st))
+    for r, dp in enumerate(ctxs):
+        if bands:
+            dp.step_banded(sides[r][0], bands)
+            dp.step_banded(sides[r][0], bands)
+        else:
+            dp.step()
+            dp.step()      # records the fixed launch sequences into HIP graphs
         dp.hv.sync()
     torch.cuda.synchronize()
     nslots = sched.slots_for_sequence()
@@ -1400,7 +1413,124 @@ def decision_virtual_ranks(args, torch, Havoc):
                     for ref_poc in {q.l0, q.l1}:
                         readers_left[ref_poc] = readers_left.get(ref_poc, 0) + 1
 
+    # ---- --vr-bands: a picture's rows enter the mirror as they become final, and its dependants follow it down the picture -------------------------------------------
+    queued = {q.poc: threading.Event() for t in range(nslots) for q in sched.slot(t) if q is not None}      # everything of the picture is queued: its band events exist
+    band_events = {}           # poc -> [torch event per band]: the band's rows (Y, Cb, Cr, padded) are in the mirror
+    PAD = dp0.PAD
+    rows_total, crows_total = h + 2 * PAD, h // 2 + PAD
+    bl = dp0.band_rows(bands) if bands else []
+
+    def final_rows(b):          # luma rows of a picture that are final once band b is deblocked (the next band's top edge still changes three rows above it)
+        return h + PAD if b == len(bl) - 1 else bl[b][1] - 4
+
+    def banded_worker(r):
+        dp, hv, ex, (side, side_stream) = ctxs[r], ctxs[r].hv, exch[r], sides[r]
+        stride, cstride = dp.stride, dp.cstride
+        gate = hv.zeros(2, np.int32)
+        try:
+            for t in range(nslots):
+                pic = ex.picture_of(t)
+                if pic is None:
+                    continue
+                t0 = time.perf_counter()
+                refs = sorted({pic.l0, pic.l1}) if pic.refs else []
+                for ref_poc in refs:
+                    if not queued[ref_poc].wait(timeout=120):
+                        raise RuntimeError(f"POC {pic.poc}: reference {ref_poc} was never queued")
+                if pic.is_reference:      # the mirror slot's previous picture must have been read by everyone who predicts from it before the first band goes in
+                    with lock:
+                        prev = occupant.get(ex.slot_of(pic.poc))
+                        if prev is not None and not lock.wait_for(lambda: readers_left.get(prev, 0) <= 0, timeout=120):
+                            raise RuntimeError(f"POC {pic.poc}: the mirror slot of POC {prev} was never released")
+                        occupant[ex.slot_of(pic.poc)] = pic.poc
+                src = sources[pic.poc]
+                with torch.cuda.stream(hv.tstream):
+                    torch._foreach_copy_([dp.d_pic[:src[0].numel()], dp.d_cpic[:src[1].numel()], dp.d_cpic[3 * cpe:3 * cpe + src[2].numel()]], src)
+                    gate.zero_() if pic.refs else gate.fill_(1 << 20)
+                hv.sync()
+                hv.search_gate(gate)
+                state = {"rows": 0, "planes": 4, "next": 0, "staged": 0}
+                if pic.refs:
+                    s0, s1 = ex.refs(pic)
+                    mine = [(dp.d_pic[pe:2 * pe], ex.dpb_luma[s0], stride, 1), (dp.d_pic[2 * pe:3 * pe], ex.dpb_luma[s1], stride, 1),
+                            (dp.d_cpic[cpe:2 * cpe], ex.dpb_cb[s0], cstride, 2), (dp.d_cpic[2 * cpe:3 * cpe], ex.dpb_cb[s1], cstride, 2),
+                            (dp.d_cpic[4 * cpe:5 * cpe], ex.dpb_cr[s0], cstride, 2), (dp.d_cpic[5 * cpe:6 * cpe], ex.dpb_cr[s1], cstride, 2)]
+
+                def follow(k):      # band k of BOTH references out of the mirror: the rows, the fractional planes of those whose filter taps are there, the gate
+                    for ref_poc in refs:
+                        side_stream.wait_event(band_events[ref_poc][k])
+                    upto = rows_total if k == len(bl) - 1 else PAD + final_rows(k)
+                    lo, end = state["rows"], (rows_total - 4 if upto == rows_total else upto - 4)
+                    with torch.cuda.stream(side_stream):
+                        for own, mirror, st_, div in mine:      # (div 2: a chroma plane, half the rows)
+                            a = (lo // div) * st_
+                            z = (upto if div == 1 else (crows_total if upto == rows_total else upto // 2)) * st_
+                            own[a:z] = mirror[a:z]
+                        for q in (0, 1):
+                            dp.d_phase[q * 16 * pe + lo * stride:q * 16 * pe + upto * stride] = dp.d_pic[(1 + q) * pe + lo * stride:(1 + q) * pe + upto * stride]
+                    for q in (0, 1):
+                        side.interp_planes_d(dp.bd, dp.d_phase[q * 16 * pe:(q + 1) * 16 * pe], pe, dp.d_pic[(1 + q) * pe:(2 + q) * pe], stride, 12, state["planes"],
+                                             w + 2 * PAD - 24, end - state["planes"])
+                    with torch.cuda.stream(side_stream):
+                        gate.fill_(end - PAD)
+                    state["rows"], state["planes"] = upto, end
+
+                def before_band(b):      # what band b reads of its references: down to two CTU rows below its last one (+ the filter taps), i.e. the references' bands up to ...
+                    if not pic.refs:
+                        return
+                    need = min(len(bl) - 1, ((bl[b][1] - 1) // 64 + 3) // bands)
+                    while state["next"] <= need:
+                        follow(state["next"])
+                        state["next"] += 1
+
+                events = []
+
+                def on_band(b, final):      # the band into the mirror: chroma borders first (luma's are made by the step), then the rows of the three planes
+                    if pic.is_reference:
+                        s = ex.slot_of(pic.poc)
+                        last = b == len(bl) - 1
+                        cy0, cy1 = bl[b][0] // 2, bl[b][1] // 2
+                        for comp in (0, 1):
+                            side.pad_block_d(dp.crecon, comp * cpe + dp.corigin + cy0 * cstride, w // 2, cy1 - cy0, cstride, PAD // 2, top=b == 0, bottom=last)
+                        upto = rows_total if last else PAD + final
+                        lo = state["staged"]
+                        with torch.cuda.stream(side_stream):
+                            ex.dpb_luma[s][lo * stride:upto * stride] = dp.recon[lo * stride:upto * stride]
+                            c0, c1 = (lo // 2) * cstride, (crows_total if last else upto // 2) * cstride
+                            ex.dpb_cb[s][c0:c1] = dp.crecon[c0:c1]
+                            ex.dpb_cr[s][c0:c1] = dp.crecon[cpe + c0:cpe + c1]
+                        state["staged"] = upto
+                    ev = torch.cuda.Event()
+                    ev.record(side_stream)
+                    events.append(ev)
+
+                def on_queued():
+                    band_events[pic.poc] = events
+                    queued[pic.poc].set()
+
+                dp.step_banded(side, bands, on_band=on_band, before_band=before_band, on_queued=on_queued)
+                hv.search_gate(None)
+                if not pic.is_reference:      # (a leaf's chroma borders: made per band above only where the planes go into the mirror)
+                    hv.pad_block_d(dp.crecon, dp.corigin, w // 2, h // 2, dp.cstride, PAD // 2)
+                    hv.pad_block_d(dp.crecon, cpe + dp.corigin, w // 2, h // 2, dp.cstride, PAD // 2)
+                with torch.cuda.stream(hv.tstream):
+                    if args.poc_checksums:
+                        sums[pic.poc] = int(dp.recon.to(torch.int64).sum().item()) * 1000003 + int(dp.crecon.to(torch.int64).sum().item())
+                hv.sync()
+                with lock:
+                    for ref_poc in refs:
+                        readers_left[ref_poc] -= 1
+                    lock.notify_all()
+                done[pic.poc].set()
+                busy[r] += time.perf_counter() - t0
+        except Exception as e:
+            errors.append(repr(e))
+            for ev in queued.values():      # nobody must wait for a picture that will not come
+                ev.set()
+
     def worker(r):
+        if bands:
+            return banded_worker(r)
         dp, hv, ex = ctxs[r], ctxs[r].hv, exch[r]
         try:
             for t in range(nslots):
@@ -1464,7 +1594,7 @@ def decision_virtual_ranks(args, torch, Havoc):
         total = (total * 1000003 + sums[poc]) % (1 << 61)
     line = {"metric": "DIAGNOSTIC (one sequence through the decision step with its picture dependencies, K virtual ranks on one GPU) -- not the benchmark metric",
             "value": round(pictures / el, 2), "unit": "pictures/s", "n_gpus": 1, "virtual_ranks": K, "pictures": pictures, "slots": nslots, "seconds": round(el, 4),
-            "busy_fraction_of_the_contexts": round(sum(busy) / (K * el), 3), "between_slots": "dependencies only (dataflow)" if dataflow else "barrier",
+            "busy_fraction_of_the_contexts": round(sum(busy) / (K * el), 3), "between_slots": (f"bands of {bands} CTU rows (a picture follows its references down the picture)" if bands else "dependencies only (dataflow)" if dataflow else "barrier"),
             "config": {"workload": f"{args.res} {args.bit_depth}-bit QP{args.qp}: IDR + {n_sops} SOPs of 8, hierarchical-B docket, one DecisionPicture.step per picture, "
                                    f"schedule of {K} ranks (lag {sched.lag}) run by {K} host threads / contexts sharing one DPB mirror"},
             "checksum_of_poc_checksums": total if sums else None}

@@ -372,3 +372,8 @@ def test_one_sequence_with_its_dependencies_on_virtual_ranks_equals_the_one_rank
     assert one["pictures"] == two["pictures"] == eight["pictures"] == 17 and len(two["poc_checksums"]) == 17
     assert one["poc_checksums"] == two["poc_checksums"] == eight["poc_checksums"]
     assert eight["slots"] < two["slots"] < one["slots"]
+    # ... and with the reconstructions entering the mirror BAND BY BAND while their lower rows are still searched, the pictures predicting from them following them down
+    # the picture (DecisionPicture.step_banded + havoc_mi355x_search_gate): the same pictures, sample for sample
+    for ranks, rows in ((2, 1), (4, 2), (8, 1)):
+        banded = run(["--decisions", "4", "--virtual-ranks", str(ranks), "--vr-bands", str(rows)])
+        assert banded["poc_checksums"] == one["poc_checksums"], (ranks, rows)

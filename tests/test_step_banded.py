@@ -48,7 +48,7 @@ def test_the_banded_step_leaves_what_the_whole_step_leaves(res, bit_depth, rows)
         mv = v.merge
         idx = np.array([at[(int(u["x0"]), int(u["y0"]))] for u in v.units])
         for k in ("vectors", "satd", "cost", "best"):
-            assert np.array_equal(mv[k], m[k][idx]), (k, v.band_rows)
+            assert np.array_equal(mv[k], m[k][idx]), (k, v.band_span)
 
 
 @pytest.mark.gpu
