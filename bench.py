@@ -29,7 +29,8 @@ sys.path.insert(0, ROOT)
 # decision-driven path is measured in a process of its own (`--decisions 2`, started by the plain run) with 16 queues; the primitive-batch
 # step keeps the runtime's default (its 8 lanes are branches of one HIP graph; measured slower with 16 queues: 0.62 against 0.49 ms).
 if "--decisions" in sys.argv[:-1] and sys.argv[sys.argv.index("--decisions") + 1] in ("2", "4"):
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    # (--vr-bands: three streams per picture context, and what WAITS on a stream must never sit in a hardware queue in front of what it waits for)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "32" if "--vr-bands" in sys.argv else "16")
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6300 GB/s achievable
 # vector-instruction issue peak: 256 CUs x 4 SIMD-32 per CU, a wave64 VALU instruction issues over 2 cycles (MI355X_MICROARCH.md "Each CU has 4 SIMD-32 units ...
@@ -1383,12 +1384,12 @@ def decision_virtual_ranks(args, torch, Havoc):
     if bands:
         # a second context per picture context, on a stream of ANOTHER PRIORITY (= a hardware queue of its own: what waits on it must not sit behind what it waits for)
         for dp in ctxs:
-            st = torch.cuda.Stream(device=0, priority=-1)
-            sides.append((Havoc(0, stream=st.cuda_stream), st))
+            st, fs = torch.cuda.Stream(device=0, priority=-1), torch.cuda.Stream(device=0, priority=-1)
+            sides.append((Havoc(0, stream=st.cuda_stream), st, Havoc(0, stream=fs.cuda_stream), fs))
     for r, dp in enumerate(ctxs):
         if bands:
-            dp.step_banded(sides[r][0], bands)
-            dp.step_banded(sides[r][0], bands)
+            for _ in range(3):      # (allocations, then the bands' launch sequences recorded into graphs, then replayed)
+                dp.step_banded(sides[r][0], bands)
         else:
             dp.step()
             dp.step()      # records the fixed launch sequences into HIP graphs
@@ -1424,7 +1425,7 @@ def decision_virtual_ranks(args, torch, Havoc):
         return h + PAD if b == len(bl) - 1 else bl[b][1] - 4
 
     def banded_worker(r):
-        dp, hv, ex, (side, side_stream) = ctxs[r], ctxs[r].hv, exch[r], sides[r]
+        dp, hv, ex, (side, side_stream, fol, fol_stream) = ctxs[r], ctxs[r].hv, exch[r], sides[r]
         stride, cstride = dp.stride, dp.cstride
         gate = hv.zeros(2, np.int32)
         try:
@@ -1437,51 +1438,68 @@ def decision_virtual_ranks(args, torch, Havoc):
                 for ref_poc in refs:
                     if not queued[ref_poc].wait(timeout=120):
                         raise RuntimeError(f"POC {pic.poc}: reference {ref_poc} was never queued")
+                t1 = time.perf_counter()
                 if pic.is_reference:      # the mirror slot's previous picture must have been read by everyone who predicts from it before the first band goes in
                     with lock:
                         prev = occupant.get(ex.slot_of(pic.poc))
                         if prev is not None and not lock.wait_for(lambda: readers_left.get(prev, 0) <= 0, timeout=120):
                             raise RuntimeError(f"POC {pic.poc}: the mirror slot of POC {prev} was never released")
                         occupant[ex.slot_of(pic.poc)] = pic.poc
+                t2 = time.perf_counter()
                 src = sources[pic.poc]
                 with torch.cuda.stream(hv.tstream):
                     torch._foreach_copy_([dp.d_pic[:src[0].numel()], dp.d_cpic[:src[1].numel()], dp.d_cpic[3 * cpe:3 * cpe + src[2].numel()]], src)
                     gate.zero_() if pic.refs else gate.fill_(1 << 20)
-                hv.sync()
+                    ready = torch.cuda.Event()
+                    ready.record(hv.tstream)
+                fol_stream.wait_event(ready)      # (what this picture's follower stream does to the reference planes and the gate comes after the source copy and the gate's reset)
                 hv.search_gate(gate)
-                state = {"rows": 0, "planes": 4, "next": 0, "staged": 0}
+                state = {"rows": 0, "planes": 4, "staged": 0}
+                followed = []      # per band of the references: the event "its rows are in this picture's planes
                 if pic.refs:
                     s0, s1 = ex.refs(pic)
                     mine = [(dp.d_pic[pe:2 * pe], ex.dpb_luma[s0], stride, 1), (dp.d_pic[2 * pe:3 * pe], ex.dpb_luma[s1], stride, 1),
                             (dp.d_cpic[cpe:2 * cpe], ex.dpb_cb[s0], cstride, 2), (dp.d_cpic[2 * cpe:3 * cpe], ex.dpb_cb[s1], cstride, 2),
                             (dp.d_cpic[4 * cpe:5 * cpe], ex.dpb_cr[s0], cstride, 2), (dp.d_cpic[5 * cpe:6 * cpe], ex.dpb_cr[s1], cstride, 2)]
 
-                def follow(k):      # band k of BOTH references out of the mirror: the rows, the fractional planes of those whose filter taps are there, the gate
+                def follow(k):      # band k of BOTH references out of the mirror: the rows, the fractional planes of those whose filter taps are there, the gate -- on a
+                    # stream of its own: the gate must rise as fast as the references allow, whatever this picture's own bands are doing (queued behind them on the side
+                    # stream the follow steps made search and after-search take turns: a picture alone took 50-105 ms instead of 16-46)
                     for ref_poc in refs:
-                        side_stream.wait_event(band_events[ref_poc][k])
+                        fol_stream.wait_event(band_events[ref_poc][k])
                     upto = rows_total if k == len(bl) - 1 else PAD + final_rows(k)
                     lo, end = state["rows"], (rows_total - 4 if upto == rows_total else upto - 4)
-                    with torch.cuda.stream(side_stream):
+                    with torch.cuda.stream(fol_stream):
+                        dst, srcs = [], []
                         for own, mirror, st_, div in mine:      # (div 2: a chroma plane, half the rows)
                             a = (lo // div) * st_
                             z = (upto if div == 1 else (crows_total if upto == rows_total else upto // 2)) * st_
-                            own[a:z] = mirror[a:z]
-                        for q in (0, 1):
-                            dp.d_phase[q * 16 * pe + lo * stride:q * 16 * pe + upto * stride] = dp.d_pic[(1 + q) * pe + lo * stride:(1 + q) * pe + upto * stride]
+                            dst.append(own[a:z])
+                            srcs.append(mirror[a:z])
+                        for q in (0, 1):      # phase 0 = the picture itself
+                            dst.append(dp.d_phase[q * 16 * pe + lo * stride:q * 16 * pe + upto * stride])
+                            srcs.append(mine[q][1][lo * stride:upto * stride])
+                        # (one copy per plane: torch._foreach_copy_ over these eight gave pictures that differed from run to run with four and more threads issuing --
+                        # gpu call r05z; the three-plane one of on_band below and the whole-picture worker's do not)
+                        for d_, s_ in zip(dst, srcs):
+                            d_.copy_(s_)
                     for q in (0, 1):
-                        side.interp_planes_d(dp.bd, dp.d_phase[q * 16 * pe:(q + 1) * 16 * pe], pe, dp.d_pic[(1 + q) * pe:(2 + q) * pe], stride, 12, state["planes"],
-                                             w + 2 * PAD - 24, end - state["planes"])
-                    with torch.cuda.stream(side_stream):
+                        fol.interp_planes_d(dp.bd, dp.d_phase[q * 16 * pe:(q + 1) * 16 * pe], pe, dp.d_pic[(1 + q) * pe:(2 + q) * pe], stride, 12, state["planes"],
+                                            w + 2 * PAD - 24, end - state["planes"])
+                    with torch.cuda.stream(fol_stream):
                         gate.fill_(end - PAD)
+                        ev = torch.cuda.Event()
+                        ev.record(fol_stream)
+                    followed.append(ev)
                     state["rows"], state["planes"] = upto, end
 
-                def before_band(b):      # what band b reads of its references: down to two CTU rows below its last one (+ the filter taps), i.e. the references' bands up to ...
-                    if not pic.refs:
-                        return
-                    need = min(len(bl) - 1, ((bl[b][1] - 1) // 64 + 3) // bands)
-                    while state["next"] <= need:
-                        follow(state["next"])
-                        state["next"] += 1
+                if pic.refs:
+                    for k in range(len(bl)):
+                        follow(k)
+
+                def before_band(b):      # what band b's predictions read of the references: down to two CTU rows below its last one (+ the filter taps), i.e. their bands up to ...
+                    if pic.refs:
+                        side_stream.wait_event(followed[min(len(bl) - 1, ((bl[b][1] - 1) // 64 + 3) // bands)])
 
                 events = []
 
@@ -1495,10 +1513,10 @@ def decision_virtual_ranks(args, torch, Havoc):
                         upto = rows_total if last else PAD + final
                         lo = state["staged"]
                         with torch.cuda.stream(side_stream):
-                            ex.dpb_luma[s][lo * stride:upto * stride] = dp.recon[lo * stride:upto * stride]
                             c0, c1 = (lo // 2) * cstride, (crows_total if last else upto // 2) * cstride
-                            ex.dpb_cb[s][c0:c1] = dp.crecon[c0:c1]
-                            ex.dpb_cr[s][c0:c1] = dp.crecon[cpe + c0:cpe + c1]
+                            dst = [ex.dpb_luma[s][lo * stride:upto * stride], ex.dpb_cb[s][c0:c1], ex.dpb_cr[s][c0:c1]]
+                            srcs = [dp.recon[lo * stride:upto * stride], dp.crecon[c0:c1], dp.crecon[cpe + c0:cpe + c1]]
+                            torch._foreach_copy_(dst, srcs)
                         state["staged"] = upto
                     ev = torch.cuda.Event()
                     ev.record(side_stream)
@@ -1507,8 +1525,14 @@ def decision_virtual_ranks(args, torch, Havoc):
                 def on_queued():
                     band_events[pic.poc] = events
                     queued[pic.poc].set()
+                    phases["queued"] = time.perf_counter()
 
+                phases = {}
                 dp.step_banded(side, bands, on_band=on_band, before_band=before_band, on_queued=on_queued)
+                t3 = time.perf_counter()
+                if os.environ.get("HAVOC_VR_TRACE"):
+                    print(f"rank {r} POC {pic.poc:3d} refs {refs}: start {1e3 * (t0 - t_begin[0]):7.1f} ms, waited for its references' queues {1e3 * (t1 - t0):6.1f}, for its mirror slot "
+                          f"{1e3 * (t2 - t1):6.1f}, queued after {1e3 * (phases.get('queued', t3) - t2):6.1f}, done after {1e3 * (t3 - t2):6.1f}", file=sys.stderr, flush=True)
                 hv.search_gate(None)
                 if not pic.is_reference:      # (a leaf's chroma borders: made per band above only where the planes go into the mirror)
                     hv.pad_block_d(dp.crecon, dp.corigin, w // 2, h // 2, dp.cstride, PAD // 2)
@@ -1579,6 +1603,7 @@ def decision_virtual_ranks(args, torch, Havoc):
             barrier.abort()
 
     threads = [threading.Thread(target=worker, args=(r,)) for r in range(K)]
+    t_begin = [time.perf_counter()]
     t0 = time.perf_counter()
     for th in threads:
         th.start()

@@ -921,7 +921,7 @@ class DecisionPicture:
                 v = copy.copy(self)
                 for name in ("mgroups", "pgroups", "cgroups", "rqt_plan", "d_merge_satd", "_merge", "_rqt", "_cells", "_views", "_views_key", "_graphs"):
                     v.__dict__.pop(name, None)
-                v.hv, v._graphs, v.use_graphs = side, {}, False
+                v.hv, v._graphs, v.use_graphs = side, {}, True
                 v.units = self.units[(self.units["y0"] >= y0) & (self.units["y0"] < y0 + rows)]
                 v.band_span = (y0, min(self.H, y0 + rows))
                 views.append(v)
@@ -975,17 +975,23 @@ class DecisionPicture:
             last = b == len(views) - 1
             if before_band is not None:
                 before_band(b)
-            side.search_wait_rows(D["work"], W, H, min(self.cy - 1, (y1 - 1) // 64 + 1), D["gave_up"])
-            v.merge_candidates(None)
-            v.predict(None)
-            P = v.tree_decisions()
-            v.chroma_chain(None)
-            side.block_cells_add_d(W, H, self.qp, 0, self.d_field, P["d_units"].view(-1, 4), P["d_out"], self.d_cells)
-            side.derive_bs_d(self.d_cells, W // 4, W, H, self.d_data, self.d_bs)
-            side.deblock_d(self.bd, self.recon, self.origin + y0 * self.stride, self.stride, self.d_chroma, (y0 // 2) * (W // 2), half + (y0 // 2) * (W // 2), W // 2, W, y1 - y0,
-                           self.d_data[(y0 // 8) * bstride:], self.d_bs[(y0 // 8) * bstride:])
-            lo = max(0, y0 - 8)
-            side.pad_block_d(self.recon, self.origin + lo * self.stride, W, y1 - lo, self.stride, self.PAD, top=b == 0, bottom=last)
+
+            def band(v=v, b=b, y0=y0, y1=y1, last=last):
+                side.search_wait_rows(D["work"], W, H, min(self.cy - 1, (y1 - 1) // 64 + 1), D["gave_up"])
+                v.merge_candidates(None)
+                v.predict(None)
+                P = v.tree_decisions()
+                v.chroma_chain(None)
+                side.block_cells_add_d(W, H, self.qp, 0, self.d_field, P["d_units"].view(-1, 4), P["d_out"], self.d_cells)
+                side.derive_bs_d(self.d_cells, W // 4, W, H, self.d_data, self.d_bs)
+                side.deblock_d(self.bd, self.recon, self.origin + y0 * self.stride, self.stride, self.d_chroma, (y0 // 2) * (W // 2), half + (y0 // 2) * (W // 2), W // 2, W, y1 - y0,
+                               self.d_data[(y0 // 8) * bstride:], self.d_bs[(y0 // 8) * bstride:])
+                lo = max(0, y0 - 8)
+                side.pad_block_d(self.recon, self.origin + lo * self.stride, W, y1 - lo, self.stride, self.PAD, top=b == 0, bottom=last)
+
+            # a band's ~170 launches are the same every picture (its job tables are made on the device): one graph launch from the third picture on -- with eight pictures
+            # in flight a launch costs its issuing thread ~100 us (the plain form ran one 1080p sequence at 45 pictures/s instead of 108)
+            v._replayed("band", band)
             final = H + self.PAD if last else y1 - 4
             if rows_final is not None:
                 with torch.cuda.stream(side.tstream):
