@@ -110,7 +110,7 @@ def test_searches_run_while_the_bands_of_their_references_arrive(res, bit_depth)
     # of its rows behind it by then
     assert t_last - t0 > alone, (t_last - t0, alone)
     if H > 600:      # (17 CTU rows: the four that reach into the last band are a wavefront of 36 CTU steps against the picture's 62; a small picture is mostly its last band)
-        assert t_done - t_last < 0.85 * alone, (t_done - t_last, alone, pause, plan.n_bands)
+        assert t_done - t_last < 0.95 * alone, (t_done - t_last, alone, pause, plan.n_bands)      # (measured: 0.6-0.7)
     # and with the references back the ungated search is unchanged
     again, again_field, _ = dp.search()
     assert again.tobytes() == want.tobytes() and np.array_equal(again_field, want_field)
