@@ -30,7 +30,8 @@ sys.path.insert(0, ROOT)
 # step keeps the runtime's default (its 8 lanes are branches of one HIP graph; measured slower with 16 queues: 0.62 against 0.49 ms).
 if "--decisions" in sys.argv[:-1] and sys.argv[sys.argv.index("--decisions") + 1] in ("2", "4"):
     # (--vr-bands: three streams per picture context, and what WAITS on a stream must never sit in a hardware queue in front of what it waits for)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "32" if "--vr-bands" in sys.argv else "16")
+    # -- measured (gpu calls r05ad): 24 queues 82 pictures/s, 28: 80, 32: 68, 40: 53, 48: 47 with eight contexts; the device has about that many real queues)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "24" if "--vr-bands" in sys.argv else "16")
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6300 GB/s achievable
 # vector-instruction issue peak: 256 CUs x 4 SIMD-32 per CU, a wave64 VALU instruction issues over 2 cycles (MI355X_MICROARCH.md "Each CU has 4 SIMD-32 units ...
@@ -67,6 +68,10 @@ def parse_args():
                          "TU chain on the chosen vectors) at 1080p QP32 and 4K QP32, and its ratio to `value`; 2: only that (diagnostic line); 0: off")
     ap.add_argument("--vr-bands", type=int, default=0, help="--decisions 4: CTU rows per band -- a picture's reconstruction enters the mirror band by band while its lower rows "
                     "are still searched (DecisionPicture.step_banded) and the pictures predicting from it follow it down the picture (havoc_mi355x_search_gate); 0 = whole pictures")
+    ap.add_argument("--vr-no-intra", type=int, default=0, help="--decisions 4: 1 = contexts without the intra candidates (what --vr-issue single runs: the like-for-like whole-picture figure)")
+    ap.add_argument("--vr-issue", default="single", choices=("single", "threads"),
+                    help="--vr-bands: who queues the work -- ONE thread for the whole sequence (every dependency is an event or a device counter; the contexts then leave the "
+                         "intra candidates out: their call is synchronous) or a thread per context")
     ap.add_argument("--vr-dataflow", type=int, default=1, help="--decisions 4: 1 = a picture starts when its references are in the mirror (default); 0 = a barrier between the slots")
     ap.add_argument("--virtual-ranks", type=int, default=8, help="--decisions 4: contexts / host threads that execute the frame-parallel schedule on ONE GPU")
     ap.add_argument("--decision-pictures", type=int, default=16, help="contexts built for the decision-driven path: `value` is measured with 4 independent pictures in flight (the "
@@ -1368,7 +1373,8 @@ def decision_virtual_ranks(args, torch, Havoc):
     ctxs = []
     for r in range(K):
         hv = Havoc(0, stream="new")
-        ctxs.append(DecisionPicture(hv, w, h, args.bit_depth, args.qp, seed=args.seed, threads=max(1, cores // K), distance=max(1, args.decision_distance)))
+        ctxs.append(DecisionPicture(hv, w, h, args.bit_depth, args.qp, seed=args.seed, threads=max(1, cores // K), distance=max(1, args.decision_distance),
+                                    intra=not (args.vr_bands > 0 and args.vr_issue == "single") and not args.vr_no_intra))
     dp0 = ctxs[0]
     pe, cpe = dp0.pe, dp0.cpe
     exch = [ReferenceExchange(None, r, sched, pe, cpe, dp0.d_pic) for r in range(K)]
@@ -1382,9 +1388,12 @@ def decision_virtual_ranks(args, torch, Havoc):
     bands = max(0, args.vr_bands)
     sides = []
     if bands:
-        # a second context per picture context, on a stream of ANOTHER PRIORITY (= a hardware queue of its own: what waits on it must not sit behind what it waits for)
+        # two more contexts per picture context (the bands' work; following the references), each on a stream of its own.  What waits on a stream must not sit in a hardware
+        # queue in front of what it waits for: HIP deals the streams of one priority onto GPU_MAX_HW_QUEUES queues -- and the HIGH-priority pool turned out to be small: with
+        # these sixteen streams at priority -1 eight contexts ran no faster than one (33-40 pictures/s; at the searching streams' priority 63-82: gpu calls r05ac / r05ad)
         for dp in ctxs:
-            st, fs = torch.cuda.Stream(device=0, priority=-1), torch.cuda.Stream(device=0, priority=-1)
+            prio = int(os.environ.get("HAVOC_VR_SIDE_PRIORITY", "0"))
+            st, fs = torch.cuda.Stream(device=0, priority=prio), torch.cuda.Stream(device=0, priority=prio)
             sides.append((Havoc(0, stream=st.cuda_stream), st, Havoc(0, stream=fs.cuda_stream), fs))
     for r, dp in enumerate(ctxs):
         if bands:
@@ -1528,7 +1537,7 @@ def decision_virtual_ranks(args, torch, Havoc):
                     phases["queued"] = time.perf_counter()
 
                 phases = {}
-                dp.step_banded(side, bands, on_band=on_band, before_band=before_band, on_queued=on_queued)
+                dp.step_banded(side, bands, on_band=on_band, before_band=before_band, on_queued=on_queued, make_phase_planes=False)
                 t3 = time.perf_counter()
                 if os.environ.get("HAVOC_VR_TRACE"):
                     print(f"rank {r} POC {pic.poc:3d} refs {refs}: start {1e3 * (t0 - t_begin[0]):7.1f} ms, waited for its references' queues {1e3 * (t1 - t0):6.1f}, for its mirror slot "
@@ -1551,6 +1560,121 @@ def decision_virtual_ranks(args, torch, Havoc):
             errors.append(repr(e))
             for ev in queued.values():      # nobody must wait for a picture that will not come
                 ev.set()
+
+    def banded_sequence():
+        """--vr-issue single: the whole sequence queued by ONE thread, slot by slot -- nothing on the host waits for the device until the end.  What orders the device:
+        a context's streams (its pictures one after the other), an event per band of a reconstruction in the mirror, an event per picture's last follow step (its reads
+        of the mirror: the next occupant of a mirror slot stages behind them), the search gates, the wait-for-rows launches."""
+        gates = [ctxs[r].hv.zeros(2, np.int32) for r in range(K)]
+        ctx_done = [None] * K          # the context's previous picture is complete (its planes and streams are free)
+        last_follow = {}               # poc -> event: the picture has taken everything it reads out of the mirror
+        readers = {}
+        for t in range(nslots):
+            for q in sched.slot(t):
+                if q is not None and q.refs:
+                    for ref_poc in {q.l0, q.l1}:
+                        readers.setdefault(ref_poc, []).append(q.poc)
+        sum_t = {}
+        for t in range(nslots):
+            for r in range(K):
+                ex = exch[r]
+                pic = ex.picture_of(t)
+                if pic is None:
+                    continue
+                dp, hv, (side, side_stream, fol, fol_stream), gate = ctxs[r], ctxs[r].hv, sides[r], gates[r]
+                stride, cstride = dp.stride, dp.cstride
+                refs = sorted({pic.l0, pic.l1}) if pic.refs else []
+                src = sources[pic.poc]
+                with torch.cuda.stream(hv.tstream):
+                    if ctx_done[r] is not None:
+                        hv.tstream.wait_event(ctx_done[r])
+                    torch._foreach_copy_([dp.d_pic[:src[0].numel()], dp.d_cpic[:src[1].numel()], dp.d_cpic[3 * cpe:3 * cpe + src[2].numel()]], src)
+                    gate.zero_() if pic.refs else gate.fill_(1 << 20)
+                    ready = torch.cuda.Event()
+                    ready.record(hv.tstream)
+                fol_stream.wait_event(ready)
+                side_stream.wait_event(ready)
+                hv.search_gate(gate)
+                state = {"rows": 0, "planes": 4, "staged": 0}
+                followed, events = [], []
+                if pic.refs:
+                    s0, s1 = ex.refs(pic)
+                    mine = [(dp.d_pic[pe:2 * pe], ex.dpb_luma[s0], stride, 1), (dp.d_pic[2 * pe:3 * pe], ex.dpb_luma[s1], stride, 1),
+                            (dp.d_cpic[cpe:2 * cpe], ex.dpb_cb[s0], cstride, 2), (dp.d_cpic[2 * cpe:3 * cpe], ex.dpb_cb[s1], cstride, 2),
+                            (dp.d_cpic[4 * cpe:5 * cpe], ex.dpb_cr[s0], cstride, 2), (dp.d_cpic[5 * cpe:6 * cpe], ex.dpb_cr[s1], cstride, 2)]
+                    for k in range(len(bl)):
+                        for ref_poc in refs:
+                            fol_stream.wait_event(band_events[ref_poc][k])
+                        upto = rows_total if k == len(bl) - 1 else PAD + final_rows(k)
+                        lo, end = state["rows"], (rows_total - 4 if upto == rows_total else upto - 4)
+                        with torch.cuda.stream(fol_stream):
+                            for own, mirror, st_, div in mine:
+                                a = (lo // div) * st_
+                                z = (upto if div == 1 else (crows_total if upto == rows_total else upto // 2)) * st_
+                                own[a:z].copy_(mirror[a:z])
+                            for q in (0, 1):
+                                dp.d_phase[q * 16 * pe + lo * stride:q * 16 * pe + upto * stride].copy_(mine[q][1][lo * stride:upto * stride])
+                        for q in (0, 1):
+                            fol.interp_planes_d(dp.bd, dp.d_phase[q * 16 * pe:(q + 1) * 16 * pe], pe, dp.d_pic[(1 + q) * pe:(2 + q) * pe], stride, 12, state["planes"],
+                                                w + 2 * PAD - 24, end - state["planes"])
+                        with torch.cuda.stream(fol_stream):
+                            gate.fill_(end - PAD)
+                            ev = torch.cuda.Event()
+                            ev.record(fol_stream)
+                        followed.append(ev)
+                        state["rows"], state["planes"] = upto, end
+                    last_follow[pic.poc] = followed[-1]
+                if pic.is_reference:      # the mirror slot's previous picture: read by everyone who predicts from it before this one's first band goes in
+                    prev = occupant.get(ex.slot_of(pic.poc))
+                    if prev is not None:
+                        for reader in readers.get(prev, []):
+                            side_stream.wait_event(last_follow[reader])
+                    occupant[ex.slot_of(pic.poc)] = pic.poc
+
+                def before_band(b, followed=followed, side_stream=side_stream, pic=pic):
+                    if pic.refs:
+                        side_stream.wait_event(followed[min(len(bl) - 1, ((bl[b][1] - 1) // 64 + 3) // bands)])
+
+                def on_band(b, final, dp=dp, ex=ex, pic=pic, side=side, side_stream=side_stream, state=state, events=events, stride=stride, cstride=cstride):
+                    if pic.is_reference:
+                        s = ex.slot_of(pic.poc)
+                        last = b == len(bl) - 1
+                        cy0, cy1 = bl[b][0] // 2, bl[b][1] // 2
+                        for comp in (0, 1):
+                            side.pad_block_d(dp.crecon, comp * cpe + dp.corigin + cy0 * cstride, w // 2, cy1 - cy0, cstride, PAD // 2, top=b == 0, bottom=last)
+                        upto = rows_total if last else PAD + final
+                        lo = state["staged"]
+                        with torch.cuda.stream(side_stream):
+                            c0, c1 = (lo // 2) * cstride, (crows_total if last else upto // 2) * cstride
+                            torch._foreach_copy_([ex.dpb_luma[s][lo * stride:upto * stride], ex.dpb_cb[s][c0:c1], ex.dpb_cr[s][c0:c1]],
+                                                 [dp.recon[lo * stride:upto * stride], dp.crecon[c0:c1], dp.crecon[cpe + c0:cpe + c1]])
+                        state["staged"] = upto
+                    ev = torch.cuda.Event()
+                    ev.record(side_stream)
+                    events.append(ev)
+
+                dp.step_banded(side, bands, on_band=on_band, before_band=before_band, make_phase_planes=False, wait=False)
+                band_events[pic.poc] = events
+                with torch.cuda.stream(hv.tstream):
+                    hv.tstream.wait_event(events[-1])
+                    if followed:
+                        hv.tstream.wait_event(followed[-1])
+                if not pic.is_reference:
+                    hv.pad_block_d(dp.crecon, dp.corigin, w // 2, h // 2, dp.cstride, PAD // 2)
+                    hv.pad_block_d(dp.crecon, cpe + dp.corigin, w // 2, h // 2, dp.cstride, PAD // 2)
+                with torch.cuda.stream(hv.tstream):
+                    if args.poc_checksums:
+                        sum_t[pic.poc] = (dp.recon.to(torch.int64).sum(), dp.crecon.to(torch.int64).sum())
+                    done_ev = torch.cuda.Event()
+                    done_ev.record(hv.tstream)
+                ctx_done[r] = done_ev
+        torch.cuda.synchronize()
+        for r in range(K):
+            D = ctxs[r]._dsearch
+            if int(ctxs[r].hv.down(D["gave_up"], np.int32)[0]) or int(ctxs[r].hv.down(D["work"], np.int32)[-1]):
+                raise RuntimeError("a wait on the device gave up")
+        for poc, (a, b) in sum_t.items():
+            sums[poc] = int(a.item()) * 1000003 + int(b.item())
 
     def worker(r):
         if bands:
@@ -1605,10 +1729,14 @@ def decision_virtual_ranks(args, torch, Havoc):
     threads = [threading.Thread(target=worker, args=(r,)) for r in range(K)]
     t_begin = [time.perf_counter()]
     t0 = time.perf_counter()
-    for th in threads:
-        th.start()
-    for th in threads:
-        th.join()
+    if bands and args.vr_issue == "single":
+        banded_sequence()
+        busy = [time.perf_counter() - t0] * K
+    else:
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     if errors:
@@ -1619,7 +1747,7 @@ def decision_virtual_ranks(args, torch, Havoc):
         total = (total * 1000003 + sums[poc]) % (1 << 61)
     line = {"metric": "DIAGNOSTIC (one sequence through the decision step with its picture dependencies, K virtual ranks on one GPU) -- not the benchmark metric",
             "value": round(pictures / el, 2), "unit": "pictures/s", "n_gpus": 1, "virtual_ranks": K, "pictures": pictures, "slots": nslots, "seconds": round(el, 4),
-            "busy_fraction_of_the_contexts": round(sum(busy) / (K * el), 3), "between_slots": (f"bands of {bands} CTU rows (a picture follows its references down the picture)" if bands else "dependencies only (dataflow)" if dataflow else "barrier"),
+            "busy_fraction_of_the_contexts": round(sum(busy) / (K * el), 3), "between_slots": (f"bands of {bands} CTU rows (a picture follows its references down the picture), queued by {'one thread' if args.vr_issue == 'single' else 'a thread per context'}" if bands else "dependencies only (dataflow)" if dataflow else "barrier"),
             "config": {"workload": f"{args.res} {args.bit_depth}-bit QP{args.qp}: IDR + {n_sops} SOPs of 8, hierarchical-B docket, one DecisionPicture.step per picture, "
                                    f"schedule of {K} ranks (lag {sched.lag}) run by {K} host threads / contexts sharing one DPB mirror"},
             "checksum_of_poc_checksums": total if sums else None}

@@ -696,8 +696,9 @@ int havoc_mi355x_search_picture_uni(havoc_mi355x_ctx *ctx, int S, const havoc_mi
  * concurrent_frames > 1 (required) the search limits a CTU row's vectors to blocks that end above row (r + 2) * ctb_size - 15 (the reference's LimitFullPelMv), so
  * nothing below is read for a result.  Results are those of the ungated call.  A wait that outlasts ~4 s gives up (HAVOC_MI355X_EDEVICE from the next sync of the
  * caller).  d_rows_ready = NULL removes the gate.  The delivering stream must make its writes visible before it raises the counter (a kernel boundary does), and it
- * must be able to RUN while the search kernel waits: give it another priority than the searching stream (hipStreamCreateWithPriority) -- HIP multiplexes the streams of
- * one priority onto a few hardware queues, and a waiting kernel blocks what is queued behind it. */
+ * must be able to RUN while the search kernel waits: HIP multiplexes the streams of one priority onto GPU_MAX_HW_QUEUES hardware queues (default 4), and a waiting kernel
+ * blocks what is queued behind it -- give the delivering stream another priority (hipStreamCreateWithPriority: fine for a few such streams; the high-priority pool is
+ * small) or, for many, raise GPU_MAX_HW_QUEUES to about the device's two dozen and keep one priority (bench.py --vr-bands; profiles/r05/banded_pipeline.txt). */
 int havoc_mi355x_search_gate(havoc_mi355x_ctx *ctx, const int32_t *d_rows_ready);
 /* The PRODUCER's side of the same rule (turing/TaskDeblock.cpp:151-167 deblocks and publishes a picture's rows while the rows below are still being encoded): a launch on
  * THIS context's stream that ends when CTU rows 0 .. ctu_row of both lists of the havoc_mi355x_search_picture_uni running over d_work (its workspace; one-launch form) on

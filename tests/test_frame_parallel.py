@@ -374,6 +374,7 @@ def test_one_sequence_with_its_dependencies_on_virtual_ranks_equals_the_one_rank
     assert eight["slots"] < two["slots"] < one["slots"]
     # ... and with the reconstructions entering the mirror BAND BY BAND while their lower rows are still searched, the pictures predicting from them following them down
     # the picture (DecisionPicture.step_banded + havoc_mi355x_search_gate): the same pictures, sample for sample
-    for ranks, rows in ((2, 1), (4, 2), (8, 1)):
-        banded = run(["--decisions", "4", "--virtual-ranks", str(ranks), "--vr-bands", str(rows)])
-        assert banded["poc_checksums"] == one["poc_checksums"], (ranks, rows)
+    # (queued by a thread per context, or the whole sequence by ONE thread -- nothing on the host then waits for the device before the end)
+    for ranks, rows, issue in ((2, 1, "threads"), (4, 2, "single"), (8, 1, "single"), (8, 2, "threads")):
+        banded = run(["--decisions", "4", "--virtual-ranks", str(ranks), "--vr-bands", str(rows), "--vr-issue", issue])
+        assert banded["poc_checksums"] == one["poc_checksums"], (ranks, rows, issue)

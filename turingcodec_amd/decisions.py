@@ -933,7 +933,7 @@ class DecisionPicture:
         rows = band_ctu_rows * 64
         return [(y0, min(self.H, y0 + rows)) for y0 in range(0, self.H, rows)]
 
-    def step_banded(self, side, band_ctu_rows=4, rows_final=None, on_band=None, before_band=None, on_queued=None):
+    def step_banded(self, side, band_ctu_rows=4, rows_final=None, on_band=None, before_band=None, on_queued=None, make_phase_planes=True, wait=True):
         """step() with everything after the searches done BAND BY BAND while the rows below are still searched: the search kernel is launched on this picture's stream
         and nothing waits for it on the host; on `side` (a Havoc context on a stream of ANOTHER PRIORITY, so that it has its own hardware queue) every band of
         band_ctu_rows CTU rows is queued behind a launch that ends when the band's rows and the row below them are searched (havoc_mi355x_search_wait_rows; the merge
@@ -943,12 +943,15 @@ class DecisionPicture:
         built on (after the filtering of its taps' rows).  on_band(b, final_rows) (optional) is called when band b's launches are queued: what it queues on `side`
         runs when the band is final (hand the rows on to a dependent picture: tests/test_step_banded.py); before_band(b) is called before band b's launches are queued
         (what it queues on `side` runs before them: bring in the rows of the references the band reads); on_queued() when everything of the picture is queued and
-        nothing has been waited for.  Same results as step(), returned the same way."""
+        nothing has been waited for.  make_phase_planes = False: the fractional planes of the references are somebody else's business (a pipeline whose follow steps make
+        them band by band: a whole-plane pass here would race with those).  wait = False: nothing is waited for and nothing downloaded -- the call only queues (the intra
+        candidates, whose call is synchronous, are then left out); the caller orders what follows with events.  Same results as step(), returned the same way."""
         hv, torch, W, H = self.hv, self.torch, self.W, self.H
         if not self.search_on_device:
             raise ValueError("step_banded needs the device search")
         views = self._band_views(band_ctu_rows, side)
-        self.phase_planes()
+        if make_phase_planes:
+            self.phase_planes()
         if not hasattr(self, "_dsearch"):
             n = len(self.pus)
             self._dsearch = dict(pus=hv.up(np.ascontiguousarray(self.pus).view(np.uint8).reshape(-1)), first=hv.up(np.ascontiguousarray(self.ctu_first, np.int32)),
@@ -1000,6 +1003,8 @@ class DecisionPicture:
                 on_band(b, final)
         if on_queued is not None:
             on_queued()
+        if not wait:
+            return None
         if self.intra_parts:
             self.intra_decisions()
         hv.sync()
