@@ -51,6 +51,14 @@ enum
                                // mvp[0] x, y packed (x & 0xffff | y << 16), mvp[1] packed, 0
     HAVOC_TR_AMVP_NB = 26,     // five of them after an AMVP record, k = 0 .. 4 = A0, A1, B0, B1, B2 as neighbourPuData() returned them: k, available, predFlag L0, predFlag L1,
                                // POC of its L0 reference, POC of its L1 reference, mv L0 x, y, mv L1 x, y
+    HAVOC_TR_MERGE = 27,       // (round 5) after populateMergeCandidates in searchMergeModes (Search.hpp:1763 -> Mvp.h:486-697): poc, xPb, yPb, nPbW, nPbH (after the
+                               // parallel-merge-level adjustment), partIdx, slice is B, active references of L0, of L1, MaxNumMergeCand, temporal candidates enabled, the
+                               // temporal candidate available, Log2ParMrgLevel
+    HAVOC_TR_MERGE_NB = 28,    // five after a MERGE record, k = 0 .. 4 = A1, B1, B0, A0, B2 as PuMergeNeighbour<>::get returned them: k, available, predFlag L0, L1, refIdx L0, L1,
+                               // mv L0 x, y, mv L1 x, y
+    HAVOC_TR_MERGE_COL = 29,   // the temporal candidate (deriveTemporalLumaMotionVectorPredictors for L0, then L1 in a B slice; refIdx 0): predFlag L0, L1, mv L0 x, y, mv L1 x, y
+    HAVOC_TR_MERGE_POC = 30,   // picture order counts of RefPicList(L0)[0 .. 3], RefPicList(L1)[0 .. 3] (0 beyond the active entries)
+    HAVOC_TR_MERGE_OUT = 31,   // MaxNumMergeCand of them: i, predFlag L0, L1, refIdx L0, L1, mv L0 x, y, mv L1 x, y of predictors->merge[i]
     HAVOC_TR_RQT_END = 22,     // chosen rqtdepth, cbfZero (the split tree had no coded block: depth 0 never evaluated)
 };
 

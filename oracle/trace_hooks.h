@@ -119,9 +119,77 @@ static inline void amvp(H &h, int refList, int refIdx)
     }
 }
 
+// what populateMergeCandidates (turing/Mvp.h:486-697) read and what it left, for the pin of turingcodec_amd/search/merge.hpp: the five spatial neighbours through the
+// encoder's own PuMergeNeighbour<>::get, the temporal candidate through its own deriveTemporalLumaMotionVectorPredictors (called once more: it only reads), the list
+template <class H>
+static inline void mergePack(int kind, int k, const PuData &d, bool withIndex)
+{
+    int32_t b[10] = {k, d.isAvailable() ? 1 : 0, d.predFlag(0) ? 1 : 0, d.predFlag(1) ? 1 : 0, d.predFlag(0) ? d.refIdx(0) : 0, d.predFlag(1) ? d.refIdx(1) : 0,
+                     d.predFlag(0) ? d.mv(0)[0] : 0, d.predFlag(0) ? d.mv(0)[1] : 0, d.predFlag(1) ? d.mv(1)[0] : 0, d.predFlag(1) ? d.mv(1)[1] : 0};
+    (void)withIndex;
+    havoc_trace_emit(kind, 10, b);
+}
+
+template <class H>
+static inline void merge(H &h, const prediction_unit &puOrig)
+{
+    StateSubstream *stateSubstream = h;
+    coding_quadtree const *cqt = h;
+    Mvp::Predictors *predictors = h;
+    prediction_unit pu = puOrig;
+    int partIdx = stateSubstream->partIdx;
+    const int nCbS = 1 << cqt->log2CbSize;
+    if (h[Log2ParMrgLevel()] > 2 && nCbS == 8)
+    {
+        pu.x0 = cqt->x0;
+        pu.y0 = cqt->y0;
+        pu.nPbW = pu.nPbH = nCbS;
+        partIdx = 0;
+    }
+    const bool isB = h[slice_type()] == B;
+    const int n0 = h[num_ref_idx_l0_active_minus1()] + 1, n1 = isB ? h[num_ref_idx_l1_active_minus1()] + 1 : 0, maxCand = h[MaxNumMergeCand()];
+    PuData col;
+    col.reset();
+    bool colAvailable = false;
+    if (h[slice_temporal_mvp_enabled_flag()])
+    {
+        colAvailable = deriveTemporalLumaMotionVectorPredictors(h, col, pu, L0, 0);
+        if (isB) colAvailable |= deriveTemporalLumaMotionVectorPredictors(h, col, pu, L1, 0);
+    }
+    int32_t a[14] = {h[PicOrderCntVal()], pu.x0, pu.y0, pu.nPbW, pu.nPbH, partIdx, isB ? 1 : 0, n0, n1, maxCand, h[slice_temporal_mvp_enabled_flag()] ? 1 : 0,
+                     colAvailable ? 1 : 0, h[Log2ParMrgLevel()], 0};
+    havoc_trace_emit(HAVOC_TR_MERGE, 14, a);
+    PuData nb;
+    nb.reset();
+    PuMergeNeighbour<-1, 0>::get(h, nb, pu.x0 - 1, pu.y0 + pu.nPbH - 1, pu.x0, pu.y0);
+    mergePack<H>(HAVOC_TR_MERGE_NB, 0, nb, true);
+    nb.reset();
+    PuMergeNeighbour<0, -1>::get(h, nb, pu.x0 + pu.nPbW - 1, pu.y0 - 1, pu.x0, pu.y0);
+    mergePack<H>(HAVOC_TR_MERGE_NB, 1, nb, true);
+    nb.reset();
+    PuMergeNeighbour<0, -1>::get(h, nb, pu.x0 + pu.nPbW, pu.y0 - 1, pu.x0, pu.y0);
+    mergePack<H>(HAVOC_TR_MERGE_NB, 2, nb, true);
+    nb.reset();
+    PuMergeNeighbour<-1, 0>::get(h, nb, pu.x0 - 1, pu.y0 + pu.nPbH, pu.x0, pu.y0);
+    mergePack<H>(HAVOC_TR_MERGE_NB, 3, nb, true);
+    nb.reset();
+    PuMergeNeighbour<-1, -1>::get(h, nb, pu.x0 - 1, pu.y0 - 1, pu.x0, pu.y0);
+    mergePack<H>(HAVOC_TR_MERGE_NB, 4, nb, true);
+    mergePack<H>(HAVOC_TR_MERGE_COL, 0, col, false);
+    int32_t p[8] = {0};
+    for (int i = 0; i < 4; ++i)
+    {
+        if (i < n0) p[i] = (*h[RefPicList(L0)][i].dp)[PicOrderCntVal()];
+        if (i < n1) p[4 + i] = (*h[RefPicList(L1)][i].dp)[PicOrderCntVal()];
+    }
+    havoc_trace_emit(HAVOC_TR_MERGE_POC, 8, p);
+    for (int i = 0; i < maxCand && i < 5; ++i) mergePack<H>(HAVOC_TR_MERGE_OUT, i, predictors->merge[i], true);
+}
+
 } // namespace havoc_trace
 
 // ---- the macros the inserted lines call (each a statement) ----
+#define HAVOC_TRACE_MERGE() havoc_trace::merge(h, pu)
 #define HAVOC_TRACE_AMVP() havoc_trace::amvp(h, refList, refIdx)
 #define HAVOC_TRACE_UNI_BEGIN() havoc_trace::searchBegin(HAVOC_TR_UNI_BEGIN, h, mvdc)
 #define HAVOC_TRACE_UNI_INTEGER() havoc_trace::candidate(HAVOC_TR_UNI_INTEGER, best)

@@ -72,6 +72,7 @@ void makeIdealPredictor(MotionTables<Sample> &, Sample *ideal, const Sample *inp
 #endif
 #include "picture_order.hpp"
 #include "amvp.hpp"
+#include "merge.hpp"
 #include "tu_decision.hpp"
 #ifndef SEARCH_ORACLE
 #include "havoc/quantize.h"
@@ -700,6 +701,40 @@ int client_check_lds_neighbours(const havoc_picture_pu *pus, const int32_t *ctu_
             }
         }
     return bad;
+}
+
+// merge.hpp on recorded inputs: rows (int32 [n][64]): partIdx, nPbW, nPbH, slice is B, active references of L0, of L1, MaxNumMergeCand, temporal candidate available |
+// per neighbour A1, B1, B0, A0, B2: predFlag0, predFlag1, refIdx0, refIdx1, mv0.x, mv0.y, mv1.x, mv1.y | the temporal candidate likewise | POC of L0[0..3], L1[0..3].
+// out (int32 [n][40]): five candidates in the same eight-value form (beyond MaxNumMergeCand: zeros)
+int client_merge(const int32_t *rows, int n, int32_t *out)
+{
+    auto unpack = [](const int32_t *q) {
+        MergeCandidate c;
+        c.predFlag[0] = q[0] != 0; c.predFlag[1] = q[1] != 0;
+        c.refIdx[0] = q[2]; c.refIdx[1] = q[3];
+        c.mv[0] = Mv(int16_t(q[4]), int16_t(q[5])); c.mv[1] = Mv(int16_t(q[6]), int16_t(q[7]));
+        return c;
+    };
+    for (int i = 0; i < n; ++i)
+    {
+        const int32_t *r = rows + 64 * i;
+        MergeCandidate nb[5], list[5];
+        for (int k = 0; k < 5; ++k) nb[k] = unpack(r + 8 + 8 * k);
+        const MergeCandidate col = unpack(r + 48);
+        const int maxCand = r[6] < 5 ? r[6] : 5;
+        deriveMergeCandidates(nb, r[0], r[1], r[2], r[1], r[2], r[7] != 0, col, r[3] != 0, r[4], r[5], r + 56, r + 60, maxCand, list);      // (Log2ParMrgLevel = 2 in every trace: the unit is its own)
+        int32_t *o = out + 40 * i;
+        std::memset(o, 0, 40 * sizeof(int32_t));
+        for (int k = 0; k < maxCand; ++k)
+        {
+            const MergeCandidate &c = list[k];
+            int32_t *q = o + 8 * k;
+            q[0] = c.predFlag[0]; q[1] = c.predFlag[1];
+            q[2] = c.predFlag[0] ? c.refIdx[0] : 0; q[3] = c.predFlag[1] ? c.refIdx[1] : 0;
+            q[4] = c.predFlag[0] ? c.mv[0].x : 0; q[5] = c.predFlag[0] ? c.mv[0].y : 0; q[6] = c.predFlag[1] ? c.mv[1].x : 0; q[7] = c.predFlag[1] ? c.mv[1].y : 0;
+        }
+    }
+    return 0;
 }
 
 // amvp.hpp on recorded inputs: rows (int32 [n][4 + 5 * 9 + 3]): X, current POC, target POC, 0 | per neighbour A0, A1, B0, B1, B2: available, predFlag0, predFlag1, poc0,

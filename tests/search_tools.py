@@ -55,7 +55,7 @@ def build(kind):
     """compile the client for one back end; returns the library path (None when the back end's library is not there)"""
     os.makedirs(BUILD, exist_ok=True)
     out = os.path.join(BUILD, f"libsearch_{kind}.so")
-    hdrs = [os.path.join(ROOT, "turingcodec_amd", "search", f) for f in ("decision.hpp", "table_view.hpp", "search_abi.h", "picture_order.hpp", "amvp.hpp", "tu_decision.hpp")]
+    hdrs = [os.path.join(ROOT, "turingcodec_amd", "search", f) for f in ("decision.hpp", "table_view.hpp", "search_abi.h", "picture_order.hpp", "amvp.hpp", "merge.hpp", "tu_decision.hpp")]
     base = ["g++", "-O2", "-std=c++14", "-fPIC", "-shared", "-Wall"] + INC + [SRC, "-o", out]
     if kind == "ref":
         lib = os.path.join(ROOT, "oracle", "_ref", "libhavoc_ref.so")
@@ -98,6 +98,7 @@ class Client:
         L.client_bi_logged.restype = C.c_int64
         L.client_rqt_decide.argtypes = [vp, i, vp]
         L.client_amvp.argtypes = [vp, i, vp]
+        L.client_merge.argtypes = [vp, i, vp]
         L.client_check_lds_neighbours.argtypes = [vp, vp, i, i, i, i, i, vp]
         L.client_intra_rd_decide.argtypes = [vp, vp, vp, i, vp]
         L.client_intra_order.argtypes = [vp, C.c_double, vp, i, vp]
@@ -166,6 +167,14 @@ class Client:
         rows = np.ascontiguousarray(rows, np.int64)
         out = np.zeros((len(rows), 2), np.int32)
         assert self.L.client_rqt_decide(rows.ctypes.data, len(rows), out.ctypes.data) == 0
+        return out
+
+    def merge(self, rows):
+        """turingcodec_amd/search/merge.hpp: deriveMergeCandidates on recorded inputs (int32 [n, 64]) -> int32 [n, 5, 8] = per candidate predFlag0, predFlag1, refIdx0,
+        refIdx1, mv0.x, mv0.y, mv1.x, mv1.y"""
+        rows = np.ascontiguousarray(rows, np.int32)
+        out = np.zeros((len(rows), 5, 8), np.int32)
+        assert self.L.client_merge(rows.ctypes.data, len(rows), out.ctypes.data) == 0
         return out
 
     def amvp(self, rows):

@@ -52,6 +52,11 @@ def check_cpu(rep, min_searches):
     a = rep["amvp_cpu"]
     assert a["derivations"] == u["searches"] and a["mismatching"] == 0, a
     assert a["with_a_scaled_candidate"] > 0 and a["second_predictor_is_not_zero"] > 0, a      # the scaling and the two-candidate list are exercised
+    # search/merge.hpp -- the reference's merge candidate list (Mvp.h:486-697: spatial candidates with their pruning, the temporal candidate, combined bi-predictive and zero
+    # candidates) as data-only code -- on the neighbours the encoder's own PuMergeNeighbour<>::get returned, for every searchMergeModes call: the list the encoder left
+    m = rep["merge_cpu"]
+    assert m["derivations"] > u["searches"] // 8 and m["mismatching"] == 0, m
+    assert m["with_a_pruned_neighbour"] > 0 and m["lists_with_a_bi_predictive_candidate"] > 0, m      # pruning and the combined candidates are exercised
     # tu_decision.hpp on the encoder's own rates and distortions: the champion of every intra partition's RD refinement, every transform-tree decision
     rd, q = rep["intra_rd_cpu"], rep["rqt_cpu"]
     assert rd["partitions"] == i["partitions"] and rd["rates_measured_by_the_encoder"] > rd["partitions"] and rd["mismatching_champions"] == 0, rd

@@ -216,6 +216,7 @@ def main():
     uni, bi, intra = tt.MotionTrace(records), tt.MotionTrace(records, bi=True), tt.IntraTrace(records)
     rqt = tt.RqtTrace(records)
     amvp = tt.AmvpTrace(records)
+    merge = tt.MergeTrace(records)
     del records
     ref_of = {}          # (poc, list) -> reference picture's poc, from the uni searches (a bi refinement follows the two uni searches of its PU)
     for poc, lst, rp in zip(uni.meta["poc"], uni.pus["ref_list"], uni.meta["ref_poc"]):
@@ -326,6 +327,21 @@ def main():
                               "examples": [{"where": amvp.where[i].tolist(), "row": amvp.rows[i].tolist(), "got": got[i].tolist(), "want": amvp.mvp[i].tolist()} for i in bad[:3]]}
     else:
         report["amvp_cpu"] = {"derivations": 0, "mismatching": 0}
+    # ---- merge.hpp (the reference's merge candidate list restated as data-only code) on the encoder's own neighbours: the list populateMergeCandidates left
+    if len(merge):
+        got = cpu.merge(merge.rows)
+        bad = np.flatnonzero(np.any(got.reshape(len(got), -1) != merge.out.reshape(len(got), -1), axis=1))
+        nb = merge.rows[:, 8:48].reshape(-1, 5, 8)
+        avail = (nb[:, :, 0] != 0) | (nb[:, :, 1] != 0)
+        bipred = (merge.out[:, :, 0] != 0) & (merge.out[:, :, 1] != 0)
+        report["merge_cpu"] = {"derivations": int(len(merge)), "mismatching": int(len(bad)),
+                               "with_the_temporal_candidate": int((merge.rows[:, 7] != 0).sum()),
+                               "with_a_pruned_neighbour": int(np.sum(avail.sum(axis=1) > np.minimum(5, [len({tuple(x) for x, a in zip(n, av) if a}) for n, av in zip(nb, avail)]))),
+                               "lists_with_a_bi_predictive_candidate": int(bipred.any(axis=1).sum()),
+                               "second_units_of_a_split": int((merge.rows[:, 0] != 0).sum()),
+                               "examples": [{"where": merge.where[i].tolist(), "row": merge.rows[i].tolist(), "got": got[i].tolist(), "want": merge.out[i].tolist()} for i in bad[:3]]}
+    else:
+        report["merge_cpu"] = {"derivations": 0, "mismatching": 0}
 
     # ---- tu_decision.hpp on the encoder's own numbers (rates from its entropy estimator, distortions of three planes): the transform-tree decision
     # (Reconstruct.cpp:1296-1428) and the champion of an intra partition's RD refinement (Search.hpp:143-255)

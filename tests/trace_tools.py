@@ -26,6 +26,7 @@ assert REC_DT.itemsize == 64
 (UNI_BEGIN, BEGIN2, SAD, SAD4, SATD, UNI_INTEGER, UNI_SUBPEL, UNI_END, BI_BEGIN, BI_MV, BI_END, INTRA_BEGIN, INTRA_SATD, INTRA_MAX, INTRA_PICK, INTRA_SSD,
  INTRA_END, INTRA_RATE, INTRA_SWAP, RQT_ONE, RQT_ZERO, RQT_END) = range(1, 23)
 AMVP, AMVP_NB = 25, 26         # (round 5) predictMvp's inputs and outputs per searchUni call
+MERGE, MERGE_NB, MERGE_COL, MERGE_POC, MERGE_OUT = 27, 28, 29, 30, 31      # populateMergeCandidates' inputs and the list it left, per searchMergeModes call
 INTRA_NB, INTRA_NBF = 23, 24      # (round 5) the partition's reference samples as the encoder held them: unfiltered / filtered, 14 per record, before INTRA_BEGIN
 PAD = 96
 
@@ -294,6 +295,42 @@ class AmvpTrace:
         self.rows = np.array(rows, np.int32).reshape(-1, 52)
         self.mvp = np.array(mvp, np.int32).reshape(-1, 4)
         self.where = np.array(where, np.int32).reshape(-1, 7)
+
+    def __len__(self):
+        return len(self.rows)
+
+
+class MergeTrace:
+    """every populateMergeCandidates of searchMergeModes (turing/Search.hpp:1763 -> Mvp.h:486-697): the five spatial neighbours as PuMergeNeighbour<>::get returned them,
+    the temporal candidate, the reference lists' picture order counts, and the list the encoder left.  rows = the inputs in the layout of tests/search_client.cpp:
+    client_merge (int32 [n, 64]); out = int32 [n, 5, 8]; where = poc, xPb, yPb, nPbW, nPbH"""
+
+    def __init__(self, records):
+        rows, outs, where = [], [], []
+        for t in np.unique(records["thread"]):
+            rec = records[records["thread"] == t]
+            kind = rec["kind"].astype(np.int32)
+            v = rec["v"]
+            for i in np.flatnonzero(kind == MERGE):
+                a = v[i]
+                ncand = min(int(a[9]), 5)
+                assert np.all(kind[i + 1:i + 6] == MERGE_NB) and np.array_equal(v[i + 1:i + 6, 0], np.arange(5)) and kind[i + 6] == MERGE_COL and kind[i + 7] == MERGE_POC
+                assert np.all(kind[i + 8:i + 8 + ncand] == MERGE_OUT) and np.array_equal(v[i + 8:i + 8 + ncand, 0], np.arange(ncand)), "a MERGE record is followed by its list"
+                r = np.zeros(64, np.int32)
+                r[0:8] = [a[5], a[3], a[4], a[6], a[7], a[8], a[9], a[11]]
+                for k in range(5):
+                    r[8 + 8 * k:16 + 8 * k] = v[i + 1 + k][2:10]
+                r[48:56] = v[i + 6][2:10]
+                r[56:64] = v[i + 7][0:8]
+                o = np.zeros((5, 8), np.int32)
+                for k in range(ncand):
+                    o[k] = v[i + 8 + k][2:10]
+                rows.append(r)
+                outs.append(o)
+                where.append(a[0:5])
+        self.rows = np.array(rows, np.int32).reshape(-1, 64)
+        self.out = np.array(outs, np.int32).reshape(-1, 5, 8)
+        self.where = np.array(where, np.int32).reshape(-1, 5)
 
     def __len__(self):
         return len(self.rows)
