@@ -59,6 +59,11 @@ enum
     HAVOC_TR_MERGE_COL = 29,   // the temporal candidate (deriveTemporalLumaMotionVectorPredictors for L0, then L1 in a B slice; refIdx 0): predFlag L0, L1, mv L0 x, y, mv L1 x, y
     HAVOC_TR_MERGE_POC = 30,   // picture order counts of RefPicList(L0)[0 .. 3], RefPicList(L1)[0 .. 3] (0 beyond the active entries)
     HAVOC_TR_MERGE_OUT = 31,   // MaxNumMergeCand of them: i, predFlag L0, L1, refIdx L0, L1, mv L0 x, y, mv L1 x, y of predictors->merge[i]
+    HAVOC_TR_COL = 32,         // (round 5) after an AMVP group and after a MERGE group, when temporal candidates are enabled and the collocated picture has a motion field: xPb, yPb,
+                               // nPbW, nPbH (what deriveTemporalLumaMotionVectorPredictors was given), POC of the collocated picture, StatePicture::allBackwards,
+                               // collocated_from_l0_flag, picture width, height, CtbLog2SizeY, POC of the current picture
+    HAVOC_TR_COL_PU = 33,      // two after a COL record: the collocated picture's 16x16 cell at 0 = the bottom-right position (zeros where the rule does not look there: another CTU
+                               // row, outside the picture), 1 = the centre: position, predFlag L0, L1, mv L0 x, y, mv L1 x, y, POC of its L0 / L1 reference, those are long-term
     HAVOC_TR_RQT_END = 22,     // chosen rqtdepth, cbfZero (the split tree had no coded block: depth 0 never evaluated)
 };
 

@@ -75,6 +75,41 @@ static inline void neighbours(int kind, Samples &p, int nTbS)
     }
 }
 
+// what deriveTemporalLumaMotionVectorPredictors (turing/Mvp.h:44-181) can read of the collocated picture for this prediction unit: for the pin of amvp.hpp's
+// deriveTemporalCandidate.  Only reads.
+template <class H>
+static inline void colocated(H &h, const prediction_unit &pu)
+{
+    if (!h[slice_temporal_mvp_enabled_flag()]) return;
+    const StatePicture *colPic = getColPic(h);
+    StateCollocatedMotion *motion = colPic ? colPic->motion.get() : 0;
+    if (!motion) return;
+    const int picW = h[pic_width_in_luma_samples()], picH = h[pic_height_in_luma_samples()], ctbLog2 = h[CtbLog2SizeY()];
+    int32_t a[11] = {pu.x0, pu.y0, pu.nPbW, pu.nPbH, int32_t(motion->poc), static_cast<StatePicture *>(h)->allBackwards ? 1 : 0, h[collocated_from_l0_flag()] ? 1 : 0, picW, picH,
+                     ctbLog2, h[PicOrderCntVal()]};
+    havoc_trace_emit(HAVOC_TR_COL, 11, a);
+    const int xs[2] = {pu.x0 + pu.nPbW, pu.x0 + (pu.nPbW >> 1)}, ys[2] = {pu.y0 + pu.nPbH, pu.y0 + (pu.nPbH >> 1)};
+    for (int k = 0; k < 2; ++k)
+    {
+        int32_t b[11] = {k, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const bool looks = k == 1 || ((pu.y0 >> ctbLog2) == (ys[0] >> ctbLog2) && ys[0] < picH && xs[0] < picW);
+        if (looks)
+        {
+            const PuData &c = (*motion)((xs[k] >> 4) << 4, (ys[k] >> 4) << 4);
+            for (int l = 0; l < 2; ++l)
+                if (c.isAvailable() && c.predFlag(l))
+                {
+                    b[1 + l] = 1;
+                    b[3 + 2 * l] = c.mv(l)[0];
+                    b[4 + 2 * l] = c.mv(l)[1];
+                    b[7 + l] = motion->getPoc(c, l);
+                    b[9 + l] = motion->getReference(c, l) == LONG_TERM ? 1 : 0;
+                }
+        }
+        havoc_trace_emit(HAVOC_TR_COL_PU, 11, b);
+    }
+}
+
 // what predictMvp (turing/Mvp.h:195-436) read and what it derived, for the pin of turingcodec_amd/search/amvp.hpp: the five spatial neighbours through the encoder's own
 // neighbourPuData(), the temporal candidate through its own deriveTemporalLumaMotionVectorPredictors() (called once more: it only reads), the two predictors it stored
 template <class H>
@@ -117,6 +152,7 @@ static inline void amvp(H &h, int refList, int refIdx)
             }
         havoc_trace_emit(HAVOC_TR_AMVP_NB, 10, b);
     }
+    colocated(h, pu);
 }
 
 // what populateMergeCandidates (turing/Mvp.h:486-697) read and what it left, for the pin of turingcodec_amd/search/merge.hpp: the five spatial neighbours through the
@@ -184,6 +220,7 @@ static inline void merge(H &h, const prediction_unit &puOrig)
     }
     havoc_trace_emit(HAVOC_TR_MERGE_POC, 8, p);
     for (int i = 0; i < maxCand && i < 5; ++i) mergePack<H>(HAVOC_TR_MERGE_OUT, i, predictors->merge[i], true);
+    colocated(h, pu);
 }
 
 } // namespace havoc_trace

@@ -703,6 +703,29 @@ int client_check_lds_neighbours(const havoc_picture_pu *pus, const int32_t *ctu_
     return bad;
 }
 
+// amvp.hpp: deriveTemporalCandidate on recorded inputs: rows (int32 [n][36]): X, current POC, target POC, POC of the collocated picture, allBackwards, collocated_from_l0 |
+// xPb, yPb, nPbW, nPbH, picture width, height, CtbLog2SizeY, 0 | the bottom-right cell, the centre cell: predFlag0, predFlag1, mv0.x, mv0.y, mv1.x, mv1.y, refPoc0, refPoc1,
+// longTerm0, longTerm1.  out (int32 [n][3]): available, x, y
+int client_temporal(const int32_t *rows, int n, int32_t *out)
+{
+    auto unpack = [](const int32_t *q) {
+        ColocatedCell c;
+        c.predFlag[0] = q[0] != 0; c.predFlag[1] = q[1] != 0;
+        c.mv[0] = Mv(int16_t(q[2]), int16_t(q[3])); c.mv[1] = Mv(int16_t(q[4]), int16_t(q[5]));
+        c.refPoc[0] = q[6]; c.refPoc[1] = q[7];
+        c.longTerm[0] = q[8] != 0; c.longTerm[1] = q[9] != 0;
+        return c;
+    };
+    for (int i = 0; i < n; ++i)
+    {
+        const int32_t *r = rows + 36 * i;
+        Mv v;
+        const bool ok = deriveTemporalCandidate(r[6], r[7], r[8], r[9], r[10], r[11], r[12], unpack(r + 14), unpack(r + 24), r[0], r[3], r[1], r[2], r[4] != 0, r[5] != 0, &v);
+        out[3 * i] = ok; out[3 * i + 1] = v.x; out[3 * i + 2] = v.y;
+    }
+    return 0;
+}
+
 // merge.hpp on recorded inputs: rows (int32 [n][64]): partIdx, nPbW, nPbH, slice is B, active references of L0, of L1, MaxNumMergeCand, temporal candidate available |
 // per neighbour A1, B1, B0, A0, B2: predFlag0, predFlag1, refIdx0, refIdx1, mv0.x, mv0.y, mv1.x, mv1.y | the temporal candidate likewise | POC of L0[0..3], L1[0..3].
 // out (int32 [n][40]): five candidates in the same eight-value form (beyond MaxNumMergeCand: zeros)

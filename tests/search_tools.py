@@ -99,6 +99,7 @@ class Client:
         L.client_rqt_decide.argtypes = [vp, i, vp]
         L.client_amvp.argtypes = [vp, i, vp]
         L.client_merge.argtypes = [vp, i, vp]
+        L.client_temporal.argtypes = [vp, i, vp]
         L.client_check_lds_neighbours.argtypes = [vp, vp, i, i, i, i, i, vp]
         L.client_intra_rd_decide.argtypes = [vp, vp, vp, i, vp]
         L.client_intra_order.argtypes = [vp, C.c_double, vp, i, vp]
@@ -167,6 +168,13 @@ class Client:
         rows = np.ascontiguousarray(rows, np.int64)
         out = np.zeros((len(rows), 2), np.int32)
         assert self.L.client_rqt_decide(rows.ctypes.data, len(rows), out.ctypes.data) == 0
+        return out
+
+    def temporal(self, rows):
+        """turingcodec_amd/search/amvp.hpp: deriveTemporalCandidate on recorded inputs (int32 [n, 36]) -> int32 [n, 3] = available, x, y"""
+        rows = np.ascontiguousarray(rows, np.int32)
+        out = np.zeros((len(rows), 3), np.int32)
+        assert self.L.client_temporal(rows.ctypes.data, len(rows), out.ctypes.data) == 0
         return out
 
     def merge(self, rows):

@@ -57,6 +57,10 @@ def check_cpu(rep, min_searches):
     m = rep["merge_cpu"]
     assert m["derivations"] > u["searches"] // 8 and m["mismatching"] == 0, m
     assert m["with_a_pruned_neighbour"] > 0 and m["lists_with_a_bi_predictive_candidate"] > 0, m      # pruning and the combined candidates are exercised
+    # ... and the TEMPORAL candidate both lists start from (amvp.hpp: deriveTemporalCandidate, Mvp.h:44-181) on the two cells of the collocated picture the encoder could read:
+    # the candidate it derived for every predictor pair and, per list, for every merge list -- the derivations above no longer take anything but motion data as given
+    tc = rep["temporal_cpu"]
+    assert tc["derivations"] >= a["derivations"] and tc["mismatching"] == 0 and tc["available"] > 0, tc
     # tu_decision.hpp on the encoder's own rates and distortions: the champion of every intra partition's RD refinement, every transform-tree decision
     rd, q = rep["intra_rd_cpu"], rep["rqt_cpu"]
     assert rd["partitions"] == i["partitions"] and rd["rates_measured_by_the_encoder"] > rd["partitions"] and rd["mismatching_champions"] == 0, rd

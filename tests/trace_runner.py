@@ -342,6 +342,18 @@ def main():
                                "examples": [{"where": merge.where[i].tolist(), "row": merge.rows[i].tolist(), "got": got[i].tolist(), "want": merge.out[i].tolist()} for i in bad[:3]]}
     else:
         report["merge_cpu"] = {"derivations": 0, "mismatching": 0}
+    # ---- amvp.hpp: deriveTemporalCandidate on the collocated picture's cells the encoder could read: the temporal candidates it derived (for its predictors and its merge lists)
+    trows = np.concatenate([amvp.temporal, merge.temporal]) if len(amvp) or len(merge) else np.zeros((0, 36), np.int32)
+    twant = np.concatenate([amvp.temporal_want, merge.temporal_want]) if len(trows) else np.zeros((0, 3), np.int32)
+    if len(trows):
+        got = cpu.temporal(trows)
+        bad = np.flatnonzero(np.any(got != twant, axis=1))
+        cells = trows[:, 14:34].reshape(-1, 2, 10)
+        report["temporal_cpu"] = {"derivations": int(len(trows)), "for_predictors": int(len(amvp.temporal)), "for_merge_lists": int(len(merge.temporal)), "mismatching": int(len(bad)),
+                                  "available": int((twant[:, 0] != 0).sum()), "from_a_cell_with_two_vectors": int(((cells[:, :, 0] != 0) & (cells[:, :, 1] != 0)).any(axis=1).sum()),
+                                  "examples": [{"row": trows[i].tolist(), "got": got[i].tolist(), "want": twant[i].tolist()} for i in bad[:3]]}
+    else:
+        report["temporal_cpu"] = {"derivations": 0, "mismatching": 0}
 
     # ---- tu_decision.hpp on the encoder's own numbers (rates from its entropy estimator, distortions of three planes): the transform-tree decision
     # (Reconstruct.cpp:1296-1428) and the champion of an intra partition's RD refinement (Search.hpp:143-255)

@@ -26,6 +26,7 @@ assert REC_DT.itemsize == 64
 (UNI_BEGIN, BEGIN2, SAD, SAD4, SATD, UNI_INTEGER, UNI_SUBPEL, UNI_END, BI_BEGIN, BI_MV, BI_END, INTRA_BEGIN, INTRA_SATD, INTRA_MAX, INTRA_PICK, INTRA_SSD,
  INTRA_END, INTRA_RATE, INTRA_SWAP, RQT_ONE, RQT_ZERO, RQT_END) = range(1, 23)
 AMVP, AMVP_NB = 25, 26         # (round 5) predictMvp's inputs and outputs per searchUni call
+COL, COL_PU = 32, 33          # the collocated picture's two cells a temporal candidate can come from, after an AMVP / MERGE group
 MERGE, MERGE_NB, MERGE_COL, MERGE_POC, MERGE_OUT = 27, 28, 29, 30, 31      # populateMergeCandidates' inputs and the list it left, per searchMergeModes call
 INTRA_NB, INTRA_NBF = 23, 24      # (round 5) the partition's reference samples as the encoder held them: unfiltered / filtered, 14 per record, before INTRA_BEGIN
 PAD = 96
@@ -274,7 +275,7 @@ class AmvpTrace:
     the two predictors the encoder derived.  rows = the inputs in the layout of tests/search_client.cpp: client_amvp; mvp = int32 [n, 4]"""
 
     def __init__(self, records):
-        rows, mvp, where = [], [], []
+        rows, mvp, where, temporal, temporal_want = [], [], [], [], []
         for t in np.unique(records["thread"]):
             rec = records[records["thread"] == t]
             kind = rec["kind"].astype(np.int32)
@@ -292,9 +293,19 @@ class AmvpTrace:
                 unpack = lambda p: (s16(p & 0xFFFF), s16((p >> 16) & 0xFFFF))
                 mvp.append(unpack(int(a[11]) & 0xFFFFFFFF) + unpack(int(a[12]) & 0xFFFFFFFF))
                 where.append(a[0:7])
+                if i + 8 < len(kind) and kind[i + 6] == COL:      # the collocated picture's cells: the temporal candidate of (list a[1], target POC a[7]) must come out of them
+                    c = v[i + 6]
+                    t = np.zeros(36, np.int32)
+                    t[0:6] = [a[1], c[10], a[7], c[4], c[5], c[6]]
+                    t[6:13] = [c[0], c[1], c[2], c[3], c[7], c[8], c[9]]
+                    t[14:24], t[24:34] = v[i + 7][1:11], v[i + 8][1:11]
+                    temporal.append(t)
+                    temporal_want.append([a[8], a[9] if a[8] else 0, a[10] if a[8] else 0])
         self.rows = np.array(rows, np.int32).reshape(-1, 52)
         self.mvp = np.array(mvp, np.int32).reshape(-1, 4)
         self.where = np.array(where, np.int32).reshape(-1, 7)
+        self.temporal = np.array(temporal, np.int32).reshape(-1, 36)            # inputs of client_temporal
+        self.temporal_want = np.array(temporal_want, np.int32).reshape(-1, 3)   # available, x, y as the encoder derived them
 
     def __len__(self):
         return len(self.rows)
@@ -306,7 +317,7 @@ class MergeTrace:
     client_merge (int32 [n, 64]); out = int32 [n, 5, 8]; where = poc, xPb, yPb, nPbW, nPbH"""
 
     def __init__(self, records):
-        rows, outs, where = [], [], []
+        rows, outs, where, temporal, temporal_want = [], [], [], [], []
         for t in np.unique(records["thread"]):
             rec = records[records["thread"] == t]
             kind = rec["kind"].astype(np.int32)
@@ -328,6 +339,19 @@ class MergeTrace:
                 rows.append(r)
                 outs.append(o)
                 where.append(a[0:5])
+                j = i + 8 + ncand
+                if a[10] and j + 2 < len(kind) and kind[j] == COL:      # temporal candidates enabled: for list 0 and, in a B slice, list 1, towards reference index 0
+                    c = v[j]
+                    for X in range(2 if a[6] else 1):
+                        t = np.zeros(36, np.int32)
+                        t[0:6] = [X, c[10], r[56 + 4 * X], c[4], c[5], c[6]]
+                        t[6:13] = [c[0], c[1], c[2], c[3], c[7], c[8], c[9]]
+                        t[14:24], t[24:34] = v[j + 1][1:11], v[j + 2][1:11]
+                        temporal.append(t)
+                        have = int(r[48 + X])
+                        temporal_want.append([have, r[52 + 2 * X] if have else 0, r[53 + 2 * X] if have else 0])
+        self.temporal = np.array(temporal, np.int32).reshape(-1, 36)
+        self.temporal_want = np.array(temporal_want, np.int32).reshape(-1, 3)
         self.rows = np.array(rows, np.int32).reshape(-1, 64)
         self.out = np.array(outs, np.int32).reshape(-1, 5, 8)
         self.where = np.array(where, np.int32).reshape(-1, 5)

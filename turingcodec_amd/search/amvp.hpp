@@ -5,7 +5,7 @@
 // above the top-right sample; it gives the encoder's predictors for 75 % of the recorded derivations) and every decision-path number depends on it.  This file is the real
 // rule, PINNED: the traced reference encoder records, for every searchUni call, the five neighbours as its neighbourPuData() returned them, the temporal candidate and the
 // two predictors it derived (the HAVOC_TRACE_AMVP trace point, inserted after Search.hpp:1779); tests/test_trace_pin.py requires deriveAmvp() to give the same two
-// predictors for every record of six encodes (0 differ).  picture_order.hpp's walk -- on the host and inside k_search_rows -- derives its predictors with it, from the five
+// predictors for every record of six encodes (0 differ); the temporal candidate is derived below from the collocated picture's cells and pinned likewise.  picture_order.hpp's walk -- on the host and inside k_search_rows -- derives its predictors with it, from the five
 // positions under the encoder's availability rules; the walk's neighbours are vectors of the same list into the same reference picture (no scaling, no temporal candidate).
 #pragma once
 
@@ -34,6 +34,43 @@ HAVOC_HD inline Mv amvpDistScale(Mv mv, int tD, int tB)
         return amvpClip3(-32768, 32767, p < 0 ? -a : a);
     };
     return Mv(int16_t(one(mv.x)), int16_t(one(mv.y)));
+}
+
+// ---- the temporal candidate (8.5.3.2.8 / 8.5.3.2.9 as turing/Mvp.h:44-181 applies it), data-only: what it reads of the collocated picture is handed in as two of that
+// picture's 16x16 motion cells.  PINNED with the rest: the traced encoder records the two cells with every predictMvp and every populateMergeCandidates, and
+// tests/test_trace_pin.py requires the candidate (available or not, vector) the encoder derived -- per list, reference index 0 for merge -- from them.
+struct ColocatedCell
+{
+    bool predFlag[2] = {false, false};      // neither: intra, or not coded
+    Mv mv[2];
+    int refPoc[2] = {0, 0};                 // picture order count of the picture its list-l vector points into
+    bool longTerm[2] = {false, false};
+};
+
+// one cell's contribution for list X towards the picture `targetPoc` (short-term): Mvp.h:44-121
+HAVOC_HD inline bool colocatedVector(const ColocatedCell &c, int X, int colPoc, int curPoc, int targetPoc, bool allBackwards, bool collocatedFromL0, Mv *out)
+{
+    *out = Mv(0, 0);
+    if (!c.predFlag[0] && !c.predFlag[1]) return false;
+    // which of the cell's vectors: its only one; with two, the current list's when every reference picture lies in the past, else the list the collocated picture is NOT taken from
+    const int listCol = !c.predFlag[0] ? 1 : (!c.predFlag[1] ? 0 : (allBackwards ? X : (collocatedFromL0 ? 1 : 0)));
+    if (c.longTerm[listCol]) return false;      // (the target is a short-term picture: the reference encoder has no others)
+    const int colPocDiff = colPoc - c.refPoc[listCol], currPocDiff = curPoc - targetPoc;
+    *out = colPocDiff == currPocDiff ? c.mv[listCol] : amvpDistScale(c.mv[listCol], colPocDiff, currPocDiff);
+    return true;
+}
+
+// the prediction unit's temporal candidate for list X: the cell at its bottom-right corner if that lies in the same CTU row and inside the picture and has motion, else the
+// cell at its centre (Mvp.h:141-181)
+HAVOC_HD inline bool deriveTemporalCandidate(int xPb, int yPb, int nPbW, int nPbH, int picW, int picH, int ctbLog2, const ColocatedCell &bottomRight, const ColocatedCell &centre,
+                                             int X, int colPoc, int curPoc, int targetPoc, bool allBackwards, bool collocatedFromL0, Mv *out)
+{
+    const int xBr = xPb + nPbW, yBr = yPb + nPbH;
+    bool available = false;
+    if ((yPb >> ctbLog2) == (yBr >> ctbLog2) && yBr < picH && xBr < picW)
+        available = colocatedVector(bottomRight, X, colPoc, curPoc, targetPoc, allBackwards, collocatedFromL0, out);
+    if (!available) available = colocatedVector(centre, X, colPoc, curPoc, targetPoc, allBackwards, collocatedFromL0, out);
+    return available;
 }
 
 // nb[0..4] = A0 (below-left), A1 (left), B0 (above-right), B1 (above), B2 (above-left); X = the list being predicted, curPoc / targetPoc = the picture order counts of
