@@ -48,9 +48,9 @@ enum
     HAVOC_TR_INTRA_NBF = 24,   // the same positions of the FILTERED copy (Search.hpp:59; partitions above 4x4)
     HAVOC_TR_AMVP = 25,        // (round 5) after predictMvp in searchUni (Search.hpp:1779): poc, refList X, refIdx, xPb, yPb, nPbW, nPbH, POC of RefPicList(X)[refIdx],
                                // temporal candidate available (deriveTemporalLumaMotionVectorPredictors; 0 when slice_temporal_mvp_enabled_flag is off), its x, y,
-                               // mvp[0] x, y packed (x & 0xffff | y << 16), mvp[1] packed, 0
+                               // mvp[0] x, y packed (x & 0xffff | y << 16), mvp[1] packed, picture width | height << 16
     HAVOC_TR_AMVP_NB = 26,     // five of them after an AMVP record, k = 0 .. 4 = A0, A1, B0, B1, B2 as neighbourPuData() returned them: k, available, predFlag L0, predFlag L1,
-                               // POC of its L0 reference, POC of its L1 reference, mv L0 x, y, mv L1 x, y
+                               // POC of its L0 reference, POC of its L1 reference, mv L0 x, y, mv L1 x, y, the POSITION may be read (neighbourPuData's three tests before it looks at what is stored there)
     HAVOC_TR_MERGE = 27,       // (round 5) after populateMergeCandidates in searchMergeModes (Search.hpp:1763 -> Mvp.h:486-697): poc, xPb, yPb, nPbW, nPbH (after the
                                // parallel-merge-level adjustment), partIdx, slice is B, active references of L0, of L1, MaxNumMergeCand, temporal candidates enabled, the
                                // temporal candidate available, Log2ParMrgLevel

@@ -136,13 +136,19 @@ static inline void amvp(H &h, int refList, int refIdx)
     const auto &mvp = predictors->mvp[refIdx][refList];
     a[11] = int32_t(uint32_t(uint16_t(mvp[0][0])) | (uint32_t(uint16_t(mvp[0][1])) << 16));
     a[12] = int32_t(uint32_t(uint16_t(mvp[1][0])) | (uint32_t(uint16_t(mvp[1][1])) << 16));
+    a[13] = int32_t(uint32_t(h[pic_width_in_luma_samples()]) | (uint32_t(h[pic_height_in_luma_samples()]) << 16));
     havoc_trace_emit(HAVOC_TR_AMVP, 14, a);
     const int xN[5] = {pu.x0 - 1, pu.x0 - 1, pu.x0 + pu.nPbW, pu.x0 + pu.nPbW - 1, pu.x0 - 1};
     const int yN[5] = {pu.y0 + pu.nPbH, pu.y0 + pu.nPbH - 1, pu.y0 - 1, pu.y0 - 1, pu.y0 - 1};
     for (int k = 0; k < 5; ++k)
     {
         const PuData nb = neighbourPuData(h, xN[k], yN[k]);
-        int32_t b[10] = {k, nb.isAvailable() ? 1 : 0, nb.predFlag(0) ? 1 : 0, nb.predFlag(1) ? 1 : 0, 0, 0, 0, 0, 0, 0};
+        // may the unit read that POSITION at all (the three tests of neighbourPuData, turing/StateSpatial.h:208-246, before it looks at what is stored there)?
+        const int maskHigh = ~(h[CtbSizeY()] - 1), yCtbCurr = pu.y0 & maskHigh, xCurr = pu.x0 + pu.nPbW - 1, yCurr = pu.y0 + pu.nPbH - 1;
+        AvailabilityCtu *availabilityCtu = h;
+        const bool position = !((yN[k] & maskHigh) > yCtbCurr) && availabilityCtu->available(xCurr, yCurr, xN[k], yN[k], h[CtbLog2SizeY()]) &&
+                              compareZ(xCurr, yCurr - yCtbCurr, xN[k], yN[k] - yCtbCurr);
+        int32_t b[11] = {k, nb.isAvailable() ? 1 : 0, nb.predFlag(0) ? 1 : 0, nb.predFlag(1) ? 1 : 0, 0, 0, 0, 0, 0, 0, position ? 1 : 0};
         for (int l = 0; l < 2; ++l)
             if (nb.isAvailable() && nb.predFlag(l))
             {
@@ -150,7 +156,7 @@ static inline void amvp(H &h, int refList, int refIdx)
                 b[6 + 2 * l] = nb.mv(l)[0];
                 b[7 + 2 * l] = nb.mv(l)[1];
             }
-        havoc_trace_emit(HAVOC_TR_AMVP_NB, 10, b);
+        havoc_trace_emit(HAVOC_TR_AMVP_NB, 11, b);
     }
     colocated(h, pu);
 }

@@ -703,6 +703,21 @@ int client_check_lds_neighbours(const havoc_picture_pu *pus, const int32_t *ctu_
     return bad;
 }
 
+// picture_order.hpp: neighbourPositionAvailable for the five predictor positions of recorded prediction units: rows (int32 [n][8]): x0, y0, w, h, ctb size, picture width,
+// height, 0.  out (int32 [n][5]): A0, A1, B0, B1, B2 may be read
+int client_positions_available(const int32_t *rows, int n, int32_t *out)
+{
+    for (int i = 0; i < n; ++i)
+    {
+        const int32_t *r = rows + 8 * i;
+        havoc_picture_pu q = havoc_picture_pu();
+        q.x0 = r[0]; q.y0 = r[1]; q.w = r[2]; q.h = r[3];
+        const int xN[5] = {q.x0 - 1, q.x0 - 1, q.x0 + q.w, q.x0 + q.w - 1, q.x0 - 1}, yN[5] = {q.y0 + q.h, q.y0 + q.h - 1, q.y0 - 1, q.y0 - 1, q.y0 - 1};
+        for (int k = 0; k < 5; ++k) out[5 * i + k] = neighbourPositionAvailable(q, r[4], r[5], r[6], xN[k], yN[k]) ? 1 : 0;
+    }
+    return 0;
+}
+
 // amvp.hpp: deriveTemporalCandidate on recorded inputs: rows (int32 [n][36]): X, current POC, target POC, POC of the collocated picture, allBackwards, collocated_from_l0 |
 // xPb, yPb, nPbW, nPbH, picture width, height, CtbLog2SizeY, 0 | the bottom-right cell, the centre cell: predFlag0, predFlag1, mv0.x, mv0.y, mv1.x, mv1.y, refPoc0, refPoc1,
 // longTerm0, longTerm1.  out (int32 [n][3]): available, x, y

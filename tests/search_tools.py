@@ -100,6 +100,7 @@ class Client:
         L.client_amvp.argtypes = [vp, i, vp]
         L.client_merge.argtypes = [vp, i, vp]
         L.client_temporal.argtypes = [vp, i, vp]
+        L.client_positions_available.argtypes = [vp, i, vp]
         L.client_check_lds_neighbours.argtypes = [vp, vp, i, i, i, i, i, vp]
         L.client_intra_rd_decide.argtypes = [vp, vp, vp, i, vp]
         L.client_intra_order.argtypes = [vp, C.c_double, vp, i, vp]
@@ -168,6 +169,13 @@ class Client:
         rows = np.ascontiguousarray(rows, np.int64)
         out = np.zeros((len(rows), 2), np.int32)
         assert self.L.client_rqt_decide(rows.ctypes.data, len(rows), out.ctypes.data) == 0
+        return out
+
+    def positions_available(self, rows):
+        """turingcodec_amd/search/picture_order.hpp: neighbourPositionAvailable for A0, A1, B0, B1, B2 of prediction units (int32 [n, 8]: x0, y0, w, h, ctb, picture width, height, 0)"""
+        rows = np.ascontiguousarray(rows, np.int32)
+        out = np.zeros((len(rows), 5), np.int32)
+        assert self.L.client_positions_available(rows.ctypes.data, len(rows), out.ctypes.data) == 0
         return out
 
     def temporal(self, rows):

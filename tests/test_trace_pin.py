@@ -52,6 +52,10 @@ def check_cpu(rep, min_searches):
     a = rep["amvp_cpu"]
     assert a["derivations"] == u["searches"] and a["mismatching"] == 0, a
     assert a["with_a_scaled_candidate"] > 0 and a["second_predictor_is_not_zero"] > 0, a      # the scaling and the two-candidate list are exercised
+    # picture_order.hpp: neighbourPositionAvailable -- may a prediction unit read a position at all (next CTU row, picture edge, coding order)? -- for the five positions of
+    # every searchUni against the three tests of the encoder's neighbourPuData: what the walk on the host and in k_search_rows decides its reads by
+    av = rep["availability_cpu"]
+    assert av["prediction_units"] == u["searches"] and av["mismatching"] == 0 and min(av["by_position_A0_A1_B0_B1_B2"]) > 0, av
     # search/merge.hpp -- the reference's merge candidate list (Mvp.h:486-697: spatial candidates with their pruning, the temporal candidate, combined bi-predictive and zero
     # candidates) as data-only code -- on the neighbours the encoder's own PuMergeNeighbour<>::get returned, for every searchMergeModes call: the list the encoder left
     m = rep["merge_cpu"]

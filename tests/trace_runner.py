@@ -327,6 +327,15 @@ def main():
                               "examples": [{"where": amvp.where[i].tolist(), "row": amvp.rows[i].tolist(), "got": got[i].tolist(), "want": amvp.mvp[i].tolist()} for i in bad[:3]]}
     else:
         report["amvp_cpu"] = {"derivations": 0, "mismatching": 0}
+    # ---- picture_order.hpp: neighbourPositionAvailable (what the walk on the host and in k_search_rows decides its five reads by) against neighbourPuData's own three tests
+    if len(amvp):
+        got = cpu.positions_available(amvp.geometry)
+        bad = np.flatnonzero(np.any(got != amvp.position, axis=1))
+        report["availability_cpu"] = {"prediction_units": int(len(amvp)), "mismatching": int(len(bad)), "positions_not_available": int((amvp.position == 0).sum()),
+                                      "by_position_A0_A1_B0_B1_B2": (amvp.position == 0).sum(axis=0).tolist(),
+                                      "examples": [{"geometry": amvp.geometry[i].tolist(), "got": got[i].tolist(), "want": amvp.position[i].tolist()} for i in bad[:3]]}
+    else:
+        report["availability_cpu"] = {"prediction_units": 0, "mismatching": 0}
     # ---- merge.hpp (the reference's merge candidate list restated as data-only code) on the encoder's own neighbours: the list populateMergeCandidates left
     if len(merge):
         got = cpu.merge(merge.rows)

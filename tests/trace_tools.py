@@ -275,7 +275,7 @@ class AmvpTrace:
     the two predictors the encoder derived.  rows = the inputs in the layout of tests/search_client.cpp: client_amvp; mvp = int32 [n, 4]"""
 
     def __init__(self, records):
-        rows, mvp, where, temporal, temporal_want = [], [], [], [], []
+        rows, mvp, where, temporal, temporal_want, geometry, position = [], [], [], [], [], [], []
         for t in np.unique(records["thread"]):
             rec = records[records["thread"] == t]
             kind = rec["kind"].astype(np.int32)
@@ -293,6 +293,9 @@ class AmvpTrace:
                 unpack = lambda p: (s16(p & 0xFFFF), s16((p >> 16) & 0xFFFF))
                 mvp.append(unpack(int(a[11]) & 0xFFFFFFFF) + unpack(int(a[12]) & 0xFFFFFFFF))
                 where.append(a[0:7])
+                dims = int(a[13]) & 0xFFFFFFFF
+                geometry.append([a[3], a[4], a[5], a[6], 64, dims & 0xFFFF, dims >> 16, 0])
+                position.append(v[i + 1:i + 6, 10])
                 if i + 8 < len(kind) and kind[i + 6] == COL:      # the collocated picture's cells: the temporal candidate of (list a[1], target POC a[7]) must come out of them
                     c = v[i + 6]
                     t = np.zeros(36, np.int32)
@@ -304,6 +307,8 @@ class AmvpTrace:
         self.rows = np.array(rows, np.int32).reshape(-1, 52)
         self.mvp = np.array(mvp, np.int32).reshape(-1, 4)
         self.where = np.array(where, np.int32).reshape(-1, 7)
+        self.geometry = np.array(geometry, np.int32).reshape(-1, 8)             # inputs of client_positions_available
+        self.position = np.array(position, np.int32).reshape(-1, 5)             # A0, A1, B0, B1, B2: the encoder's neighbourPuData would look at what is stored there
         self.temporal = np.array(temporal, np.int32).reshape(-1, 36)            # inputs of client_temporal
         self.temporal_want = np.array(temporal_want, np.int32).reshape(-1, 3)   # available, x, y as the encoder derived them
 

@@ -115,6 +115,8 @@ HAVOC_HD inline bool precedesInZ(int xC, int yC, int xN, int yN)
     return p > q;
 }
 
+// (PINNED: tests/test_trace_pin.py holds this against the three tests of the encoder's own neighbourPuData for the five predictor positions of every searchUni of six traced
+// encodes: 0 differ)
 // may prediction unit q read its neighbour at (xN, yN)?  neighbourPuData (turing/StateSpatial.h:208-246) with AvailabilityCtu::available (Global.h:317-370) for a
 // picture of one slice and one tile: not in the next CTU row, inside the picture, in a CTU that exists and precedes this one, earlier than the PU's last sample in z-order
 HAVOC_HD inline bool neighbourPositionAvailable(const havoc_picture_pu &q, int ctb, int picW, int picH, int xN, int yN)
