@@ -78,6 +78,35 @@ def test_run_cutter_on_the_host():
     assert [5, 1] in rf[:, :2].tolist() and rf[rf[:, 0] == 5][0, 3] == 0                                # ... and that call's own run has no box (it cannot have one that fits)
 
 
+@pytest.mark.parametrize("bit_depth", [8, 10])
+def test_every_box_the_cutter_gives_fits_the_kernels_window(bit_depth):
+    """host code against kernel arithmetic (no device): k_sad4r stages a run's box at a pitch of 4 * ceil((lead + w S + span_x S) / 16) + 1 dwords per row, lead <= 15 bytes
+    of alignment, and takes the fast path only if pitch * rows + 4 <= its window (16 KB x S); a box the cutter thought would fit and does not would silently go call by
+    call.  For the picture of the bench and for random search-like tables: every boxed run fits whatever the alignment, holds every candidate block, and is one search."""
+    from turingcodec_amd import Havoc
+    from turingcodec_amd.workload import FrameWorkload
+    S = 1 if bit_depth == 8 else 2
+    wl = FrameWorkload(1920, 1080, bit_depth, 11)
+    rng = np.random.default_rng(5 + bit_depth)
+    tables = [(wl.sad4, wl.stride)]
+    src, ref, stride, pad = planes(rng, bit_depth, 320, 256)
+    tables.append((search_like_jobs(rng, 320, 256, stride, pad, SIZES * 3, 90, reach=40, pred=40), stride))
+    for jobs, st in tables:
+        runs = Havoc.sad4_make_runs(jobs, 0, st, S)
+        assert runs[:, 1].sum() == len(jobs) and (runs[:, 0] == np.concatenate([[0], np.cumsum(runs[:, 1])[:-1]])).all()      # the runs tile the table in order
+        boxed = runs[runs[:, 3] > 0]
+        assert len(boxed) > 0.9 * len(runs)
+        for first, count, off, bw, bh in boxed[:, :5]:
+            j = jobs[first:first + count]
+            w, h = int(j[0, 5]), int(j[0, 6])
+            assert (j[:, 0] == j[0, 0]).all() and (j[:, 5] == w).all() and (j[:, 6] == h).all()
+            chunks = (15 + bw * S + 15) // 16                      # the worst alignment of the box's first sample
+            assert (4 * chunks + 1) * bh + 4 <= 4096 * S, (first, count, bw, bh)
+            d = j[:, 1:5].astype(np.int64).ravel() - off
+            q, r = d // st, d % st
+            assert (d >= 0).all() and (q + h <= bh).all() and (r + w <= bw).all(), (first, count)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("bit_depth,stride_extra,base_shift", [(8, 0, 0), (8, 5, 3), (10, 0, 0), (10, 3, 5)])
 def test_runs_of_a_search_equal_the_oracle(bit_depth, stride_extra, base_shift):
