@@ -33,7 +33,7 @@ enum
     HAVOC_TR_BI_BEGIN = 9,     // as UNI_BEGIN
     HAVOC_TR_BI_MV = 10,       // mv(L0) x, y, mv(L1) x, y  (setPuDataMvpPredFlags: the two vectors the refinement starts from / predicts from)
     HAVOC_TR_BI_END = 11,      // best.mv x, y, best.mvd x, y, mvpFlag, cost lo, hi
-    HAVOC_TR_INTRA_BEGIN = 12, // poc, x, y, log2PartitionSize, cand0, cand1, cand2, neighbourModes, (rateA - rateC) lo, hi, (rateB - rateC) lo, hi, lambda bits lo, hi
+    HAVOC_TR_INTRA_BEGIN = 12, // poc, x, y, log2PartitionSize, cand0, cand1, cand2, neighbourModes | candIntraPredModeA << 8 | candIntraPredModeB << 16 (CandModeList::getCandidate), (rateA - rateC) lo, hi, (rateB - rateC) lo, hi, lambda bits lo, hi
     HAVOC_TR_INTRA_SATD = 13,  // mode, distortion, cost lo, hi
     HAVOC_TR_INTRA_MAX = 14,   // nCandidatesIntraRefinement
     HAVOC_TR_INTRA_PICK = 15,  // j, IntraPredModeY

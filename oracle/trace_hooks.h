@@ -279,7 +279,9 @@ static inline void merge(H &h, const prediction_unit &puOrig)
                 havoc_trace::neighbours(HAVOC_TR_INTRA_NBF, stateEncodeSubstream->filtered, 1 << log2PartitionSize);         \
         }                                                                                                                    \
         int32_t a_[14] = {h[PicOrderCntVal()], xPositionOf(intraPartition), yPositionOf(intraPartition), log2PartitionSize,  \
-                          candModeList[0], candModeList[1], candModeList[2], candModeList.neighbourModes};                   \
+                          candModeList[0], candModeList[1], candModeList[2],                                                 \
+                          candModeList.neighbourModes | (CandModeList::getCandidate<Left>(h, xPositionOf(intraPartition), yPositionOf(intraPartition)) << 8) | \
+                              (CandModeList::getCandidate<Up>(h, xPositionOf(intraPartition), yPositionOf(intraPartition)) << 16)};                            \
         havoc_trace::lohi(a_ + 8, (rateA - rateC).value);                                                                    \
         havoc_trace::lohi(a_ + 10, (rateB - rateC).value);                                                                   \
         havoc_trace::dbl(a_ + 12, getReciprocalSqrtLambda(h));                                                               \

@@ -73,6 +73,7 @@ void makeIdealPredictor(MotionTables<Sample> &, Sample *ideal, const Sample *inp
 #include "picture_order.hpp"
 #include "amvp.hpp"
 #include "merge.hpp"
+#include "cand_mode_list.hpp"
 #include "tu_decision.hpp"
 #ifndef SEARCH_ORACLE
 #include "havoc/quantize.h"
@@ -701,6 +702,18 @@ int client_check_lds_neighbours(const havoc_picture_pu *pus, const int32_t *ctu_
             }
         }
     return bad;
+}
+
+// cand_mode_list.hpp on recorded neighbour modes: ab (int32 [n][2]) -> out (int32 [n][4]): candModeList[0..2], neighbourModes
+int client_cand_mode_list(const int32_t *ab, int n, int32_t *out)
+{
+    for (int i = 0; i < n; ++i)
+    {
+        int cand[3];
+        out[4 * i + 3] = candModeListOf(ab[2 * i], ab[2 * i + 1], cand);
+        out[4 * i] = cand[0]; out[4 * i + 1] = cand[1]; out[4 * i + 2] = cand[2];
+    }
+    return 0;
 }
 
 // picture_order.hpp: neighbourPositionAvailable for the five predictor positions of recorded prediction units: rows (int32 [n][8]): x0, y0, w, h, ctb size, picture width,

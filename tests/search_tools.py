@@ -55,7 +55,7 @@ def build(kind):
     """compile the client for one back end; returns the library path (None when the back end's library is not there)"""
     os.makedirs(BUILD, exist_ok=True)
     out = os.path.join(BUILD, f"libsearch_{kind}.so")
-    hdrs = [os.path.join(ROOT, "turingcodec_amd", "search", f) for f in ("decision.hpp", "table_view.hpp", "search_abi.h", "picture_order.hpp", "amvp.hpp", "merge.hpp", "tu_decision.hpp")]
+    hdrs = [os.path.join(ROOT, "turingcodec_amd", "search", f) for f in ("decision.hpp", "table_view.hpp", "search_abi.h", "picture_order.hpp", "amvp.hpp", "merge.hpp", "cand_mode_list.hpp", "tu_decision.hpp")]
     base = ["g++", "-O2", "-std=c++14", "-fPIC", "-shared", "-Wall"] + INC + [SRC, "-o", out]
     if kind == "ref":
         lib = os.path.join(ROOT, "oracle", "_ref", "libhavoc_ref.so")
@@ -100,6 +100,7 @@ class Client:
         L.client_amvp.argtypes = [vp, i, vp]
         L.client_merge.argtypes = [vp, i, vp]
         L.client_temporal.argtypes = [vp, i, vp]
+        L.client_cand_mode_list.argtypes = [vp, i, vp]
         L.client_positions_available.argtypes = [vp, i, vp]
         L.client_check_lds_neighbours.argtypes = [vp, vp, i, i, i, i, i, vp]
         L.client_intra_rd_decide.argtypes = [vp, vp, vp, i, vp]
@@ -169,6 +170,13 @@ class Client:
         rows = np.ascontiguousarray(rows, np.int64)
         out = np.zeros((len(rows), 2), np.int32)
         assert self.L.client_rqt_decide(rows.ctypes.data, len(rows), out.ctypes.data) == 0
+        return out
+
+    def cand_mode_list(self, ab):
+        """turingcodec_amd/search/cand_mode_list.hpp: candModeListOf on recorded (A, B) (int32 [n, 2]) -> int32 [n, 4] = candModeList[0..2], neighbourModes"""
+        ab = np.ascontiguousarray(ab, np.int32)
+        out = np.zeros((len(ab), 4), np.int32)
+        assert self.L.client_cand_mode_list(ab.ctypes.data, len(ab), out.ctypes.data) == 0
         return out
 
     def positions_available(self, rows):

@@ -52,6 +52,11 @@ def check_cpu(rep, min_searches):
     a = rep["amvp_cpu"]
     assert a["derivations"] == u["searches"] and a["mismatching"] == 0, a
     assert a["with_a_scaled_candidate"] > 0 and a["second_predictor_is_not_zero"] > 0, a      # the scaling and the two-candidate list are exercised
+    # search/cand_mode_list.hpp (the function k_intra_gather makes a partition's most probable modes with) on the neighbour modes the encoder's own CandModeList::getCandidate
+    # returned, for every searchIntraPartition: the encoder's list and its number of neighbour modes; and the above neighbour counts as DC at the top of a CTU
+    cm = rep["cand_mode_list_cpu"]
+    assert cm["partitions"] == i["partitions"] and cm["mismatching"] == 0 and cm["neighbours_differ"] > 0 and cm["angular_and_equal"] > 0, cm
+    assert cm["above_is_dc_at_the_top_of_a_ctu"] and cm["partitions_at_the_top_of_a_ctu"] > 0, cm
     # picture_order.hpp: neighbourPositionAvailable -- may a prediction unit read a position at all (next CTU row, picture edge, coding order)? -- for the five positions of
     # every searchUni against the three tests of the encoder's neighbourPuData: what the walk on the host and in k_search_rows decides its reads by
     av = rep["availability_cpu"]

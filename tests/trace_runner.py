@@ -327,6 +327,18 @@ def main():
                               "examples": [{"where": amvp.where[i].tolist(), "row": amvp.rows[i].tolist(), "got": got[i].tolist(), "want": amvp.mvp[i].tolist()} for i in bad[:3]]}
     else:
         report["amvp_cpu"] = {"derivations": 0, "mismatching": 0}
+    # ---- cand_mode_list.hpp (what k_intra_gather makes a partition's most probable modes with) on the neighbour modes the encoder's CandModeList::getCandidate returned
+    if len(intra):
+        got = cpu.cand_mode_list(intra.mode_ab)
+        want = np.concatenate([intra.ctx["cand_mode_list"].reshape(-1, 3), intra.ctx["neighbour_modes"].reshape(-1, 1)], axis=1).astype(np.int32)
+        bad = np.flatnonzero(np.any(got != want, axis=1))
+        top = intra.where[:, 2] % 64 == 0 if intra.where.shape[1] > 2 else np.zeros(len(intra), bool)
+        report["cand_mode_list_cpu"] = {"partitions": int(len(intra)), "mismatching": int(len(bad)), "neighbours_differ": int((intra.mode_ab[:, 0] != intra.mode_ab[:, 1]).sum()),
+                                        "angular_and_equal": int(((intra.mode_ab[:, 0] == intra.mode_ab[:, 1]) & (intra.mode_ab[:, 0] > 1)).sum()),
+                                        "above_is_dc_at_the_top_of_a_ctu": bool((intra.mode_ab[top, 1] == 1).all()), "partitions_at_the_top_of_a_ctu": int(top.sum()),
+                                        "examples": [{"ab": intra.mode_ab[i].tolist(), "got": got[i].tolist(), "want": want[i].tolist()} for i in bad[:3]]}
+    else:
+        report["cand_mode_list_cpu"] = {"partitions": 0, "mismatching": 0}
     # ---- picture_order.hpp: neighbourPositionAvailable (what the walk on the host and in k_search_rows decides its five reads by) against neighbourPuData's own three tests
     if len(amvp):
         got = cpu.positions_available(amvp.geometry)

@@ -198,6 +198,7 @@ class IntraTrace:
 
     def __init__(self, records):
         ctx, satd, costs, order, count, rsl, where, champion = [], [], [], [], [], [], [], []
+        mode_ab = []
         nb, nbf = [], []            # per partition: the unfiltered / filtered reference samples (None when the encoder had none: 64x64 / 4x4 filtered)
         cand, rl = [], []          # RD refinement: per candidate (mode, ssd, rate or -1 when the encoder did not measure it); reciprocalLambda (Q16) per partition
         for t in np.unique(records["thread"]):
@@ -223,7 +224,8 @@ class IntraTrace:
                 s = seg[seg_kind == INTRA_SATD]
                 assert len(s) == 35 and np.array_equal(s[:, 0], np.arange(35))
                 c = np.zeros(1, st.INTRA_CTX_DT)[0]
-                c["cand_mode_list"], c["neighbour_modes"] = a[4:7], a[7]
+                c["cand_mode_list"], c["neighbour_modes"] = a[4:7], int(a[7]) & 0xFF
+                mode_ab.append([(int(a[7]) >> 8) & 0xFF, (int(a[7]) >> 16) & 0xFF])      # candIntraPredModeA (left), B (above) as CandModeList::getCandidate returned them
                 c["max_refine"] = seg[seg_kind == INTRA_MAX][0][0]
                 c["rate_a_minus_c"], c["rate_b_minus_c"] = i64(a[8:9], a[9:10])[0], i64(a[10:11], a[11:12])[0]
                 picks = seg[seg_kind == INTRA_PICK]
@@ -255,6 +257,7 @@ class IntraTrace:
                 cand.append(rows)
                 rl.append(lam)
         self.ctx = np.array(ctx, st.INTRA_CTX_DT) if ctx else np.zeros(0, st.INTRA_CTX_DT)
+        self.mode_ab = np.array(mode_ab, np.int32).reshape(-1, 2)      # the neighbours' modes the candModeList was made from
         self.satd = np.array(satd, np.int32).reshape(-1, 35)
         self.costs = np.array(costs, np.int64).reshape(-1, 35)
         self.order = np.array(order, np.int32).reshape(-1, 35)

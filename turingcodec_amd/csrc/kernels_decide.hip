@@ -14,6 +14,7 @@
 //                   caller's buffer.
 // The host forms of the same rules stay: they are what the per-call arms of the tests run over the reference's tables.
 #include "common.h"
+#include "../search/cand_mode_list.hpp"
 
 namespace havoc_gpu {
 
@@ -345,18 +346,9 @@ __global__ __launch_bounds__(64) void k_intra_gather(const ChainLayout L, const 
         const int a = available(p.x0 - 1, p.y0) ? modes[(p.y0 >> 2) * L.cellsPerRow + ((p.x0 - 1) >> 2)] : 1;
         const int b = available(p.x0, p.y0 - 1) && (p.y0 - 1) >= ((p.y0 >> L.ctbLog2) << L.ctbLog2) ? modes[((p.y0 - 1) >> 2) * L.cellsPerRow + (p.x0 >> 2)] : 1;
         IntraCtx c = ictx[i];
-        if (a == b)
-        {
-            c.neighbourModes = 1;
-            if (a < 2) { c.cand[0] = 0; c.cand[1] = 1; c.cand[2] = 26; }
-            else { c.cand[0] = a; c.cand[1] = ((a + 29) % 32) + 2; c.cand[2] = ((a - 1) % 32) + 2; }
-        }
-        else
-        {
-            c.neighbourModes = 2;
-            c.cand[0] = a; c.cand[1] = b;
-            c.cand[2] = (a != 0 && b != 0) ? 0 : ((a != 1 && b != 1) ? 1 : 26);
-        }
+        int cand[3];
+        c.neighbourModes = havoc_search::candModeListOf(a, b, cand);      // (search/cand_mode_list.hpp: pinned against the encoder's own lists)
+        c.cand[0] = cand[0]; c.cand[1] = cand[1]; c.cand[2] = cand[2];
         ictx[i] = c;
     }
 }
