@@ -684,6 +684,16 @@ bool serveIntra(Sample *dst, intptr_t sd, const Sample *neighbours, int mode)
     return true;
 }
 
+// The source block an IntraSet was measured against lives in a REGISTERED picture: every use of what was made from it (SATDs, coefficients, the device plane a
+// reconstruction reads) first checks that the picture is still the one it was -- same never-reused id, same device plane.  A picture unregistered and another
+// registered at the same host address (a reused buffer) with equal neighbour samples (flat areas; the top-left block, whose neighbours are all 1 << (bd - 1))
+// would otherwise be answered from the old picture's samples, and its device plane is freed memory.
+inline bool sourceStillRegistered(const IntraSet *f)
+{
+    const Pic *q = f->srcHost ? findPic(f->srcHost) : nullptr;
+    return q && q->id == f->srcPicId && q->d_plane == f->srcDev;
+}
+
 // ---- havoc_hadamard_satd of (source tile, tile of the intra prediction this thread just made): every mode's tiles in one launch, and every mode's forward
 // transform with it -- Reconstruct.cpp:684-701, 258-273
 template <typename Sample, int N>
@@ -704,8 +714,9 @@ bool serveIntraSatd(const Sample *a, intptr_t sa, const Sample *b, intptr_t sb, 
     for (int r = 0; r < N; ++r)      // the prediction must still be what was served (the caller owns that buffer)
         if (memcmp(b + r * sb, pred + (ty + r) * n + tx, sizeof(Sample) * N)) return false;
     const Sample *block = a - (long)ty * sa - tx;
-    if (!f->measured || f->srcHost != reinterpret_cast<const char *>(block) || f->srcStride != sa)
+    if (!f->measured || f->srcHost != reinterpret_cast<const char *>(block) || f->srcStride != sa || !sourceStillRegistered(f))
     {
+        f->measured = false;
         const Pic *q = findPic(block);
         if (!q || q->S != int(sizeof(Sample)) || q->stride != sa) return false;
         int x, y;
@@ -756,6 +767,7 @@ bool serveForward(int16_t *coeffs, const int16_t *res, intptr_t stride)
     if (!m.valid) return false;
     const IntraSet *f = m.set;
     if (!f->measured || f->log2 != LOG2 || f->bd != BITDEPTH || TR != (LOG2 == 2 ? 1 : 0)) return false;
+    if (!sourceStillRegistered(f)) return false;      // f->srcHost is read below: only while its picture is the one that was measured
     for (int y = 0; y < n; ++y)
         for (int x = 0; x < n; ++x)
         {
@@ -774,7 +786,7 @@ inline void chainAhead(Stage &s, Serve &v, const char *dLevels, int scale, int s
 {
     v.chain.valid = false;
     const IntraMemo &m = v.imemo;
-    if (!m.valid || !m.set->measured) return;
+    if (!m.valid || !m.set->measured || !sourceStillRegistered(m.set)) return;      // f->srcDev below: freed with its picture
     IntraSet *f = m.set;
     const int n = 1 << f->log2;
     if (n2 != n * n) return;
@@ -823,7 +835,7 @@ bool serveSsd(const Sample *pa, intptr_t sa, const Sample *pb, intptr_t sb, int 
     if (!c.valid || c.recDst != pb || c.recSd != sb) return false;
     const IntraSet *f = c.set;
     const int n = 1 << f->log2;
-    if (w != n || h != n || f->S != int(sizeof(Sample)) || reinterpret_cast<const char *>(pa) != f->srcHost || sa != f->srcStride) return false;
+    if (w != n || h != n || f->S != int(sizeof(Sample)) || reinterpret_cast<const char *>(pa) != f->srcHost || sa != f->srcStride || !sourceStillRegistered(f)) return false;
     const Sample *rec = reinterpret_cast<const Sample *>(c.rec);
     for (int y = 0; y < n; ++y)
         if (memcmp(pb + y * sb, rec + y * n, sizeof(Sample) * n)) return false;

@@ -21,6 +21,39 @@
 
 namespace havoc_gpu {
 
+// Diagnostic build only (-DHAVOC_RDOQ_TIMING; profiles/micro/rdoq_timing.py): shader-clock cycles a wavefront of the walk kernels spends in each section, summed
+// over the wavefronts of every launch since the last reset; read back by havoc_mi355x_debug_rdoq_timing.  The product build has none of this.
+#ifdef HAVOC_RDOQ_TIMING
+__device__ unsigned long long g_rdoqTiming[32];
+struct RdoqTimer
+{
+    unsigned long long acc[16] = {}, last = __builtin_readcyclecounter();
+    __device__ __forceinline__ void mark(int k)
+    {
+        const unsigned long long now = __builtin_readcyclecounter();
+        acc[k] += now - last;
+        last = now;
+    }
+    __device__ __forceinline__ void flush(int lane, int base)
+    {
+        if (lane != 0) return;
+        for (int k = 0; k < 16; ++k)
+            if (acc[k]) atomicAdd(&g_rdoqTiming[base + k], acc[k]);
+    }
+};
+#define RT_DECL RdoqTimer rt
+#define RT_MARK(k) rt.mark(k)
+#define RT_PARAM , RdoqTimer &rt
+#define RT_ARG , rt
+#define RT_FLUSH(lane, base) rt.flush(lane, base)
+#else
+#define RT_DECL
+#define RT_MARK(k)
+#define RT_PARAM
+#define RT_ARG
+#define RT_FLUSH(lane, base)
+#endif
+
 namespace {
 
 // turing/Write.h:413-422: estimated bits (Q15) for the more / less probable symbol from each CABAC state
@@ -42,15 +75,16 @@ static_assert(sizeof(havoc_mi355x_rdoq_job) == sizeof(RdoqJob), "rdoq job layout
 // what a lane knows about its transform block
 struct Block
 {
-    const uint8_t *states;    // LDS: this block's 128 state bytes, `stateStride` apart
+    const uint8_t *states;    // this block's 128 context states, `stateStride` apart: a column of the wavefront's LDS copy, or (stride 1) the CTU's snapshot in global memory
     const int32_t *bits;      // LDS: kEntropyBits
-    const int32_t *lastBits;  // LDS: this block's [2][10] bits of a last_sig_coeff_{x,y} coordinate whose prefix has k ones (Rdoq.cpp:706-763), `stateStride` apart
-    int stateStride;
+    const int32_t *lastBits;  // LDS: this block's [2][NLEN] bits of a last_sig_coeff_{x,y} coordinate whose prefix has k ones (Rdoq.cpp:706-763), `lastStride` apart
+    int stateStride, lastStride, lastLen;
     int64_t lambda;
     int distShift;            // distortion scale = 1 << distShift (Q16)
     int quantScale, quantShift, invScale, invShift, invOffset;
     int cIdx, scanIdx;
     uint64_t scan4;           // the 4x4 scan as 16 nibbles x | y << 2
+    const uint32_t *clsTab;   // LDS: [right / below coded: 4 cases] scan positions of THIS block's scan whose significance context is base + 1 | those at base + 2, << 16
 };
 
 struct LevelState { int ctxSet, c1, nG1, nG2, rice; };   // Rdoq.cpp:44-49
@@ -200,16 +234,22 @@ struct WalkShared
     WalkRecords rec;
     int32_t bits[128];
     int16_t coef[16][64];                         // the current group's coefficients, raster order within the group
-    uint32_t pre[16][64];                         // per position: significance context << 25 | flag bits of the zero levels above it
+    // (4x4 blocks keep, per position, significance context << 25 | flag bits of the zero levels above it IN rec.costDown: a position's record is read by loop B
+    // before that iteration writes the position's costDown, position 0's only when loop B never visits it, and sign-data hiding reads costDown of kept levels only)
     uint8_t rasterOf[3][64];                      // scan index -> raster group position, per scan type
+    uint32_t clsScan[3][4];                       // per scan type and neighbour case: sigPattern() by SCAN position, as two 16-bit masks (value 1 | value 2 << 16)
 };
 
-// what is per transform block rather than per lane: SLOTS blocks per wavefront (64 when a lane is a block)
-template <int SLOTS>
+// what is per transform block rather than per lane: SLOTS blocks per wavefront (64 when a lane is a block).  NLEN = 2 * log2 size: the prefix lengths a coordinate of the
+// block can have.  LDS_STATES false: no copy of the context states -- the lanes read their CTU's snapshot where it lies (round 6: the copy was 8 of a wavefront's 30 KB of
+// LDS, which is what kept the walk kernels at one wavefront per SIMD; blocks in job order share their CTU's 128 bytes, one or two cache lines per access).
+template <int SLOTS, int NLEN, bool LDS_STATES>
 struct BlockTables
 {
-    uint8_t states[HAVOC_RDOQ_CTX_BYTES][SLOTS];  // [context][block]
-    int32_t lastBits[2][10][SLOTS];
+    static constexpr int slots = SLOTS, nlen = NLEN;
+    static constexpr bool ldsStates = LDS_STATES;
+    uint8_t states[LDS_STATES ? HAVOC_RDOQ_CTX_BYTES : 1][SLOTS];  // [context][block]
+    int32_t lastBits[2][NLEN][SLOTS];
 };
 
 struct WalkResult
@@ -255,8 +295,9 @@ __device__ __forceinline__ int32_t pick4(const int32_t (&v)[4], int k) { return 
 // A wavefront's trip count of loop B is the largest number of non-zero levels any of its 64 blocks has in the group at hand.
 template <int LOG2>
 __device__ __forceinline__ WalkResult walkGroup(const Block &b, WalkShared &sh, int lane, int g, int gx, int gy, int firstPos, int caseBits, int factor,
-                                                SdhAux &aux)
+                                                SdhAux &aux RT_PARAM)
 {
+    RT_MARK(3);
     WalkResult r;
     r.cost = r.sigCost = r.dist0 = r.q = 0;
     r.localBest = INT64_MAX;
@@ -285,7 +326,27 @@ __device__ __forceinline__ WalkResult walkGroup(const Block &b, WalkShared &sh, 
     // significance contexts of the group (Rdoq.cpp:517-603)
     const int sigChroma = b.cIdx ? 27 : 0;
     const int sigGroup = sigChroma + (b.cIdx == 0 ? ((gx + gy > 0 ? 3 : 0) + (LOG2 == 3 ? (b.scanIdx == 0 ? 9 : 15) : 21)) : (LOG2 == 3 ? 9 : 12));
-    const uint32_t pattern = neighbours == 0 ? sigPattern(0) : neighbours == 1 ? sigPattern(1) : neighbours == 2 ? sigPattern(2) : sigPattern(3);
+    // Blocks above 4x4 (round 6): a position's context is one of FOUR -- base + 0 / 1 / 2 by where it sits in the group (sigPattern) or, for the block's DC
+    // position, a context of its own -- so the eight bit costs are looked up once per group and every position takes its pair with selects; which scan
+    // positions have which is a table lookup (clsTab: made once per wavefront).  The flag bits of the zero levels above a position -- a running sum the
+    // first form kept per position in LDS -- are then popcounts of (zero positions above) & (positions of a class) times the class's cost, made only for the
+    // positions loop B visits.  Per position loop Z is left with: magnitude, sign, energy, "rounds to non-zero", and the up-cost record of sign-data hiding.
+    const bool dcGroup = gx + gy == 0;
+    uint32_t cls1 = 0, cls2 = 0, clsD = 0, cls0 = 0;
+    int32_t zc0 = 0, zc1 = 0, zc2 = 0, zcD = 0, oc0 = 0, oc1 = 0, oc2 = 0, ocD = 0;
+    if (LOG2 > 2)
+    {
+        const uint32_t w = b.clsTab[neighbours];
+        clsD = dcGroup ? 1u : 0u;
+        cls1 = (w & 0xffff) & ~clsD;
+        cls2 = (w >> 16) & ~clsD;
+        cls0 = 0xffffu & ~(cls1 | cls2 | clsD);
+        const int base = HAVOC_RDOQ_CTX_SIG + sigGroup, dcCtx = HAVOC_RDOQ_CTX_SIG + sigChroma;
+        zc0 = bitsOf(b, base, 0); oc0 = bitsOf(b, base, 1);
+        zc1 = bitsOf(b, base + 1, 0); oc1 = bitsOf(b, base + 1, 1);
+        zc2 = bitsOf(b, base + 2, 0); oc2 = bitsOf(b, base + 2, 1);
+        zcD = bitsOf(b, dcCtx, 0); ocD = bitsOf(b, dcCtx, 1);
+    }
 
     // ---- loop Z ----
     uint32_t nzMask = 0, sumAll = 0, sumAllHi = 0, negScan = 0, negRaster = 0;
@@ -303,24 +364,36 @@ __device__ __forceinline__ WalkResult walkGroup(const Block &b, WalkShared &sh, 
         sumAllHi += sq >> 16;
         // straight-line: every position writes its records (loop B overwrites those of the non-zero levels), what differs is selected
         const bool inside = (active >> i) & 1;
-        int ctx;
-        if (LOG2 == 2) ctx = sigChroma + (int)((0x8877886654325410ull >> (4 * nib)) & 15);
-        else ctx = pick(gx + gy + nib == 0, sigChroma, sigGroup + (int)((pattern >> (2 * nib)) & 3));
-        ctx += HAVOC_RDOQ_CTX_SIG;
-        sh.pre[i][lane] = (uint32_t)ctx << 25 | (uint32_t)zeroBits;
         const int scaled = (int)a * b.quantScale;
         const bool nonZero = inside & (((scaled + rnd) >> b.quantShift) > 0);
         nzMask |= (uint32_t)nonZero << i;
-        const int32_t z = bitsOf(b, ctx, 0), one = bitsOf(b, ctx, 1);
-        zeroBits += pick(inside & !nonZero, z, 0);
+        int32_t z, one;
+        if (LOG2 == 2)
+        {
+            const int ctx = HAVOC_RDOQ_CTX_SIG + sigChroma + (int)((0x8877886654325410ull >> (4 * nib)) & 15);
+            reinterpret_cast<uint32_t (*)[64]>(sh.rec.costDown)[i][lane] = (uint32_t)ctx << 25 | (uint32_t)zeroBits;
+            z = bitsOf(b, ctx, 0);
+            one = bitsOf(b, ctx, 1);
+            zeroBits += pick(inside & !nonZero, z, 0);
+        }
+        else
+        {
+            const bool is1 = (cls1 >> i) & 1, is2 = (cls2 >> i) & 1, isD = i == 0 && dcGroup;
+            z = pick(isD, zcD, pick(is1, zc1, pick(is2, zc2, zc0)));
+            one = pick(isD, ocD, pick(is1, oc1, pick(is2, oc2, oc0)));
+        }
         sh.rec.kept[nib][lane] = 0;
         const int32_t upZero = (int32_t)((uint32_t)factor * (uint32_t)-(scaled >> (b.quantShift - 8))) + (1 << 15) + one - z;      // + g1zero[c1] when used
         sh.rec.costUp[i][lane] = pick(inside, upZero, 1 << 15);
     }
+    const uint32_t zeroMask = active & ~nzMask;      // positions inside the coded range whose level rounds to zero
+    if (LOG2 > 2)
+        zeroBits = zc0 * __popc(zeroMask & cls0) + zc1 * __popc(zeroMask & cls1) + zc2 * __popc(zeroMask & cls2) + zcD * __popc(zeroMask & clsD);
     const int64_t sumSq = ((int64_t)sumAllHi << 16) + sumAll;
     r.dist0 = sumSq << b.distShift;
 
     // ---- loop B ----
+    RT_MARK(4);
     int nonZeroAbovePos0 = 0;
     int64_t gSig = 0, gSigPos0 = 0, gCoded = 0, gDist0 = 0, costB = 0, distB = 0, qB = 0;
     uint32_t c1At = 0x55555555u;      // c1 = 1 everywhere
@@ -336,10 +409,24 @@ __device__ __forceinline__ WalkResult walkGroup(const Block &b, WalkShared &sh, 
         const int scaled = a * b.quantScale;
         const int level = (scaled + rnd) >> b.quantShift;
         const bool first = sp == firstPos;
-        const uint32_t pk = sh.pre[i][lane];
-        const int sc = (int)(pk >> 25);
-        const int64_t zerosAbove = b.lambda * (int32_t)(pk & 0x1ffffff);
-        const int32_t z0 = bitsOf(b, sc, 0), z1 = bitsOf(b, sc, 1);
+        int32_t z0, z1, aboveBits;
+        if (LOG2 == 2)
+        {
+            const uint32_t pk = reinterpret_cast<const uint32_t (*)[64]>(sh.rec.costDown)[i][lane];
+            const int sc = (int)(pk >> 25);
+            aboveBits = (int32_t)(pk & 0x1ffffff);
+            z0 = bitsOf(b, sc, 0);
+            z1 = bitsOf(b, sc, 1);
+        }
+        else
+        {
+            const bool is1 = (cls1 >> i) & 1, is2 = (cls2 >> i) & 1, isD = (clsD >> i) & 1;
+            z0 = pick(isD, zcD, pick(is1, zc1, pick(is2, zc2, zc0)));
+            z1 = pick(isD, ocD, pick(is1, oc1, pick(is2, oc2, oc0)));
+            const uint32_t above = zeroMask & ~((2u << i) - 1);      // the zero levels at higher scan positions (the block's DC position is never one of them)
+            aboveBits = zc0 * __popc(above & cls0) + zc1 * __popc(above & cls1) + zc2 * __popc(above & cls2);
+        }
+        const int64_t zerosAbove = b.lambda * aboveBits;
         const int32_t sigZero = pick(first, 0, z0), sigOneBits = pick(first, 0, z1);
         fb.g1zero = pick4(aux.g1zero, st.c1);
         fb.g1one = pick4(g1one, st.c1);
@@ -398,7 +485,7 @@ __device__ __forceinline__ WalkResult walkGroup(const Block &b, WalkShared &sh, 
         nonZeroAbovePos0 += (stored != 0) & (i != 0);
         // candidate for the last significant position (Rdoq.cpp:356-399)
         const int lx = lastPrefixLength(x), ly = lastPrefixLength(y);
-        const int32_t rate = b.lastBits[(b.scanIdx == 2 ? ly : lx) * b.stateStride] + b.lastBits[(10 + (b.scanIdx == 2 ? lx : ly)) * b.stateStride];
+        const int32_t rate = b.lastBits[(b.scanIdx == 2 ? ly : lx) * b.lastStride] + b.lastBits[(b.lastLen + (b.scanIdx == 2 ? lx : ly)) * b.lastStride];
         const int64_t total = qB - zerosAbove + b.lambda * rate - costSig;
         const bool better = (stored != 0) & !r.localStop & (total < r.localBest);
         r.localBest = pick(better, total, r.localBest);
@@ -409,6 +496,7 @@ __device__ __forceinline__ WalkResult walkGroup(const Block &b, WalkShared &sh, 
         const int64_t keptGain = dist0 - costCoded, zeroGain = -costSig;
         qB += pick(stored != 0, keptGain, zeroGain);
     }
+    RT_MARK(5);
     aux.c1At = c1At;
     aux.keptMask = keptMask;
     aux.oddMask = oddMask;
@@ -418,7 +506,9 @@ __device__ __forceinline__ WalkResult walkGroup(const Block &b, WalkShared &sh, 
     r.cost = (r.dist0 - distB) + zeroCost + costB;      // inactive and zero levels: their energy (+ the zero levels' flags); the others: their RD cost
     r.q = qB - zeroCost;
     gSig += zeroCost;
-    if (!(nzMask & 1)) gSigPos0 = zeroCost - b.lambda * (int32_t)(sh.pre[0][lane] & 0x1ffffff);      // position 0 is always inside the coded range
+    // position 0 is always inside the coded range: when its level rounds to zero, its flag is what the running sum gained last
+    if (!(nzMask & 1))
+        gSigPos0 = LOG2 == 2 ? zeroCost - b.lambda * (int32_t)(reinterpret_cast<const uint32_t (*)[64]>(sh.rec.costDown)[0][lane] & 0x1ffffff) : b.lambda * pick(dcGroup, zcD, pick((bool)(cls1 & 1), zc1, pick((bool)(cls2 & 1), zc2, zc0)));
     r.carry = st.c1 == 0;
     // step 2 (Rdoq.cpp:196-297), as selects.  The DC group is coded whatever it holds; a group without a kept level pays the flag = 0 and
     // gets the significance flags of its zero levels back; a group below the first weighs zeroing all its levels against flag = 1 (a
@@ -433,6 +523,7 @@ __device__ __forceinline__ WalkResult walkGroup(const Block &b, WalkShared &sh, 
     r.cost += pick(empty, emptyCost, pick(inner, innerCost, (int64_t)0));
     r.sigCost = pick(empty | dropped, zero, pick(inner, one, (int64_t)0));
     r.coded = dc | (any & !dropped);
+    RT_MARK(6);
     return r;
 }
 
@@ -643,12 +734,15 @@ struct LaneBlock
 
     // tables and the block's context states into LDS, then the per-lane constants (Rdoq.h:163-187, Rdoq.cpp:706-771); all 64 lanes call it.
     // `slot` = the block's place in the wavefront, shared by `per` lanes of which this one is number `sub`.
-    template <int SLOTS>
-    __device__ __forceinline__ void stageIn(WalkShared &sh, BlockTables<SLOTS> &bt, int lane, int slot, int sub, int per, const RdoqJob &job,
+    template <class BT>
+    __device__ __forceinline__ void stageIn(WalkShared &sh, BT &bt, int lane, int slot, int sub, int per, const RdoqJob &job,
                                             const uint8_t *__restrict__ statesAll, int bitDepth, const int16_t *__restrict__ srcAll, int16_t *__restrict__ dstAll)
     {
+        constexpr int SLOTS = BT::slots;
+        static_assert(BT::nlen == 2 * LOG2, "prefix lengths of a coordinate");
         sh.bits[lane] = kEntropyBits[lane];
         sh.bits[64 + lane] = kEntropyBits[64 + lane];
+        if (BT::ldsStates)
         {
             const uint32_t *st = reinterpret_cast<const uint32_t *>(statesAll + (long)job.ctx_index * HAVOC_RDOQ_CTX_BYTES);
             for (int k = sub; k < HAVOC_RDOQ_CTX_BYTES / 4; k += per)
@@ -667,11 +761,27 @@ struct LaneBlock
                 if (G > 1) scanXy(gw, t, lane, x, y);
                 sh.rasterOf[t][lane] = (uint8_t)(y * gw + x);
             }
+        if (lane < 12)
+        {
+            const int t = lane >> 2, nb = lane & 3;
+            const uint64_t sc = t == 0 ? scan4Nibbles(0) : (t == 1 ? scan4Nibbles(1) : scan4Nibbles(2));
+            const uint32_t pat = nb == 0 ? sigPattern(0) : nb == 1 ? sigPattern(1) : nb == 2 ? sigPattern(2) : sigPattern(3);
+            uint32_t one = 0, two = 0;
+            for (int i = 0; i < 16; ++i)
+            {
+                const uint32_t inc = (pat >> (2 * ((int)(sc >> (4 * i)) & 15))) & 3;
+                one |= (uint32_t)(inc == 1) << i;
+                two |= (uint32_t)(inc == 2) << i;
+            }
+            sh.clsScan[t][nb] = one | two << 16;
+        }
         __syncthreads();
 
-        b.states = &bt.states[0][slot];
+        b.states = BT::ldsStates ? &bt.states[0][slot] : statesAll + (long)job.ctx_index * HAVOC_RDOQ_CTX_BYTES;
+        b.stateStride = BT::ldsStates ? SLOTS : 1;
         b.lastBits = &bt.lastBits[0][0][slot];
-        b.stateStride = SLOTS;
+        b.lastStride = SLOTS;
+        b.lastLen = BT::nlen;
         b.bits = sh.bits;
         b.lambda = job.lambda_q16;
         const int transformShift = 15 - bitDepth - LOG2;
@@ -686,6 +796,7 @@ struct LaneBlock
         b.scanIdx = job.scan_idx;
         b.scan4 = job.scan_idx == 0 ? scan4Nibbles(0) : (job.scan_idx == 1 ? scan4Nibbles(1) : scan4Nibbles(2));
         rasterOf = sh.rasterOf[job.scan_idx < 3 ? job.scan_idx : 0];
+        b.clsTab = sh.clsScan[job.scan_idx < 3 ? job.scan_idx : 0];
         src = srcAll + job.src_off;
         dst = dstAll + job.dst_off;
         if (sub == 0)
@@ -694,7 +805,7 @@ struct LaneBlock
                 const int base = axis ? HAVOC_RDOQ_CTX_LAST_Y : HAVOC_RDOQ_CTX_LAST_X;
                 const int offset = b.cIdx ? 15 : 3 * (LOG2 - 2) + ((LOG2 - 1) >> 2), shift = b.cIdx ? LOG2 - 2 : (LOG2 + 1) >> 2;
                 int32_t ones = 0;
-                for (int len = 0; len < 10; ++len)
+                for (int len = 0; len < BT::nlen; ++len)      // (the longest prefix of a 32x32 block, 9 ones, has no terminating zero)
                 {
                     const int ctx = base + min(max((len >> shift) + offset, 0), 17);
                     bt.lastBits[axis][len][slot] = ones + (len < 9 ? bitsOf(b, ctx, 0) : 0) + (len > 3 ? 32768 * ((len - 2) >> 1) : 0);
@@ -755,12 +866,14 @@ struct LaneBlock
     // position of the first non-zero rounded level of the group now in sh.coef (scan order within the group), or -1
     __device__ __forceinline__ int firstInGroup(const WalkShared &sh, int lane) const
     {
-        for (int i = 15; i >= 0; --i)
+        uint32_t nz = 0;      // straight-line: sixteen independent reads, one wait (a loop that returns at the first hit runs as long as the unluckiest lane, a round trip per position)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
         {
             const int a = abs((int)sh.coef[(int)(b.scan4 >> (4 * i)) & 15][lane]);
-            if (((a * b.quantScale + (1 << (b.quantShift - 1))) >> b.quantShift) > 0) return i;
+            nz |= (uint32_t)(((a * b.quantScale + (1 << (b.quantShift - 1))) >> b.quantShift) > 0) << i;
         }
-        return -1;
+        return nz ? 31 - __clz((int)nz) : -1;
     }
     __device__ __forceinline__ int64_t zeroGroupCost(uint64_t coded, int p) const      // Rdoq.cpp:200-210
     {
@@ -787,6 +900,7 @@ struct WalkState
     int bestPos = -1, orSince = 0;
     bool stopped = false;
     uint64_t coded = 0, carries = 0;        // by raster position; carry INTO each walked group, by scan index
+    uint64_t codedScan = 0;                 // `coded` by scan index: what the verdict clears above the last significant group
 
     __device__ __forceinline__ void zeroGroup(int64_t zero)
     {
@@ -798,6 +912,7 @@ struct WalkState
         costTu += r.cost;
         walkedDist0 += r.dist0;
         coded |= (uint64_t)r.coded << p;
+        codedScan |= (uint64_t)r.coded << g;
         carries |= (uint64_t)carryIn << g;
         rel -= r.sigCost;
         if (r.coded)
@@ -819,15 +934,17 @@ struct WalkState
 // The sequential walk.  SORTED (32x32, 16x16 blocks that do not use the diagonal scan -- k_rdoq_diag takes the others): blocks in the
 // order of pass 2, scan results from the workspace.  Otherwise (8x8, 4x4: many short blocks, where three launches and a permuted
 // access cost more than the balance gains) the scan runs here, blocks in job order.
-template <int LOG2, bool SORTED>
+template <int LOG2, bool SORTED, bool LDS_STATES>
 __global__ __launch_bounds__(64) void k_rdoq_walk(int16_t *__restrict__ dstAll, const int16_t *__restrict__ srcAll, const uint8_t *__restrict__ statesAll,
                                                   const RdoqJob *__restrict__ jobs, int njobs, int32_t *__restrict__ cbfOut, int bitDepth,
                                                   const RdoqWork *__restrict__ work, int diagonalElsewhere)
 {
     typedef LaneBlock<LOG2> LB;
     constexpr int G = LB::G, gw = LB::gw;
-    __shared__ WalkShared sh;
-    __shared__ BlockTables<64> bt;
+    // the cooperative scan's arrays (job-order form) are dead before the walk's first LDS write: they share its memory (a workgroup is ONE wavefront)
+    __shared__ __attribute__((aligned(16))) unsigned char walkMem[sizeof(WalkShared) > sizeof(ScanShared) ? sizeof(WalkShared) : sizeof(ScanShared)];
+    WalkShared &sh = *reinterpret_cast<WalkShared *>(walkMem);
+    __shared__ BlockTables<64, 2 * LOG2, LDS_STATES> bt;
     if (SORTED && diagonalElsewhere && work->otherScans == 0) return;
     const RdoqInfo *infoAll = reinterpret_cast<const RdoqInfo *>(reinterpret_cast<const char *>(work) + rdoqInfoOffset());
     const uint32_t *order = reinterpret_cast<const uint32_t *>(infoAll + njobs);
@@ -841,13 +958,16 @@ __global__ __launch_bounds__(64) void k_rdoq_walk(int16_t *__restrict__ dstAll, 
         info = infoAll[blk];
     else
     {
-        __shared__ ScanShared sc;
+        ScanShared &sc = *reinterpret_cast<ScanShared *>(walkMem);
         scanBlocks<LOG2>(sc, dstAll, srcAll, jobs, njobs, blockIdx.x * 64, G);
         info.mask = sc.mask[lane];
         info.sumSq = sc.sumSq[lane];
+        __syncthreads();
     }
+    RT_DECL;
     LB lb;
     lb.stageIn(sh, bt, lane, lane, 0, 1, job, statesAll, bitDepth, srcAll, dstAll);
+    RT_MARK(0);
     const Block &b = lb.b;
     const uint8_t *rasterOf = lb.rasterOf;
     SdhAux aux;
@@ -879,16 +999,20 @@ __global__ __launch_bounds__(64) void k_rdoq_walk(int16_t *__restrict__ dstAll, 
         if (g >= 0)
         {
             const int p = rasterOf[g], gx = p & (gw - 1), gy = p / gw;
+            RT_MARK(2);
             lb.loadGroup(sh, lane, gx, gy);
-            const WalkResult r = walkGroup<LOG2>(b, sh, lane, g, gx, gy, firstPos, LB::caseOf(ws.coded, gx, gy, carry), job.sdh_factor, aux);
+            const WalkResult r = walkGroup<LOG2>(b, sh, lane, g, gx, gy, firstPos, LB::caseOf(ws.coded, gx, gy, carry), job.sdh_factor, aux RT_ARG);
             ws.walkedGroup(r, g, p, carry);
             carry = r.carry;
             // as a group below the last one (the last one is redone below) -- but for the DC group, the last to be walked: its records are
             // still there when the verdict is known, so it is finished then, once, as what it turns out to be
+            RT_MARK(8);
             if (r.coded && g != 0) lb.finishGroup(sh, lane, job.sdh, aux, g, 1 << 30, false, gx, gy);
+            RT_MARK(9);
             --g;
         }
     }
+    RT_MARK(2);
 
     // ---- the block's verdict (Rdoq.cpp:307-341, :401-441) ----
     int cbf = 0;
@@ -897,19 +1021,28 @@ __global__ __launch_bounds__(64) void k_rdoq_walk(int16_t *__restrict__ dstAll, 
         const int lastIdx = lb.lastIndex(job.is_intra, info.sumSq, ws.walkedDist0, ws.costTu, ws.bestRel, ws.bestPos);
         cbf = lastIdx ? ws.orSince : 0;
         const int lastGroup = (lastIdx - 1) >> 4;      // -1: nothing is coded
-        for (int k = firstGroup; k > max(lastGroup, 0); --k)   // groups above the last one were written as if coded: clear them
-            if ((ws.coded >> rasterOf[k]) & 1) lb.clearGroup(rasterOf[k]);
+        for (uint64_t m = ws.codedScan & ~((2ull << max(lastGroup, 0)) - 1); m;)   // groups above the last one were written as if coded: clear them
+        {
+            const int k = 63 - __clzll((long long)m);
+            m ^= 1ull << k;
+            lb.clearGroup(rasterOf[k]);
+        }
         if (lastGroup >= 0) lb.finishGroup(sh, lane, job.sdh, aux, 0, lastGroup == 0 ? lastIdx : 1 << 30, lastGroup == 0, 0, 0);      // the DC group, from the records of its walk
         // the group holding the last significant coefficient: levels again, truncated, hidden with the last-group rules
         if (lastGroup > 0 && (lastIdx & 15 || job.sdh))
         {
             const int p = rasterOf[lastGroup], gx = p & (gw - 1), gy = p / gw;
             lb.loadGroup(sh, lane, gx, gy);
-            walkGroup<LOG2>(b, sh, lane, lastGroup, gx, gy, firstPos, LB::caseOf(ws.coded, gx, gy, (int)(ws.carries >> lastGroup) & 1), job.sdh_factor, aux);
+            walkGroup<LOG2>(b, sh, lane, lastGroup, gx, gy, firstPos, LB::caseOf(ws.coded, gx, gy, (int)(ws.carries >> lastGroup) & 1), job.sdh_factor, aux RT_ARG);
             lb.finishGroup(sh, lane, job.sdh, aux, lastGroup, lastIdx, true, gx, gy);
         }
     }
     if (valid) cbfOut[blk] = cbf;
+    RT_MARK(11);
+    RT_FLUSH(lane, 0);
+#ifdef HAVOC_RDOQ_TIMING
+    if (lane == 0) atomicAdd(&g_rdoqTiming[15], 1ull);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -937,14 +1070,14 @@ struct DiagExchange
 };
 
 template <int LOG2, int LPB>
-__global__ __launch_bounds__(64) void k_rdoq_diag(int16_t *__restrict__ dstAll, const int16_t *__restrict__ srcAll, const uint8_t *__restrict__ statesAll,
+__global__ __launch_bounds__(64, 2) void k_rdoq_diag(int16_t *__restrict__ dstAll, const int16_t *__restrict__ srcAll, const uint8_t *__restrict__ statesAll,
                                                   const RdoqJob *__restrict__ jobs, int njobs, int32_t *__restrict__ cbfOut, int bitDepth,
                                                   const RdoqWork *__restrict__ work)
 {
     typedef LaneBlock<LOG2> LB;
     constexpr int G = LB::G, gw = LB::gw, ND = 2 * gw - 1;
     __shared__ WalkShared sh;
-    __shared__ BlockTables<64 / LPB> bt;
+    __shared__ BlockTables<64 / LPB, 2 * LOG2, true> bt;
     __shared__ DiagExchange ex;
     const RdoqInfo *infoAll = reinterpret_cast<const RdoqInfo *>(reinterpret_cast<const char *>(work) + rdoqInfoOffset());
     const uint32_t *order = reinterpret_cast<const uint32_t *>(infoAll + njobs);
@@ -954,8 +1087,10 @@ __global__ __launch_bounds__(64) void k_rdoq_diag(int16_t *__restrict__ dstAll, 
     const RdoqJob job = jobs[blk];
     valid = valid && job.scan_idx == 0;
     const RdoqInfo info = infoAll[blk];
+    RT_DECL;
     LB lb;
     lb.stageIn(sh, bt, lane, lane / LPB, k, LPB, job, statesAll, bitDepth, srcAll, dstAll);
+    RT_MARK(0);
     const Block &b = lb.b;
     const uint8_t *rasterOf = lb.rasterOf;
     SdhAux aux;
@@ -990,6 +1125,7 @@ __global__ __launch_bounds__(64) void k_rdoq_diag(int16_t *__restrict__ dstAll, 
     // The wavefront goes down the anti-diagonals together.  (Letting each block go down ITS anti-diagonals saves the rounds a block spends
     // idle on an anti-diagonal only others use, and measured SLOWER, 0.24 against 0.21 ms: a round costs what its longest group costs,
     // groups of one anti-diagonal are alike -- dense near DC, one or two levels far from it -- and mixing them makes every round a long one.)
+    RT_MARK(1);
     for (int d = ND - 1; d >= 0; --d)
     {
         const int start = d < gw ? d * (d + 1) / 2 : G - (ND - d) * (ND - d + 1) / 2, len = d < gw ? d + 1 : ND - d;
@@ -1041,10 +1177,11 @@ __global__ __launch_bounds__(64) void k_rdoq_diag(int16_t *__restrict__ dstAll, 
             const int p = mine ? rasterOf[myG] : 0, gx = p & (gw - 1), gy = p / gw;
             WalkResult r;
             r.coded = 0;
+            RT_MARK(2);
             if (mine)
             {
                 lb.loadGroup(sh, lane, gx, gy);
-                r = walkGroup<LOG2>(b, sh, lane, myG, gx, gy, firstPos, LB::caseOf(ws.coded, gx, gy, carryIn), job.sdh_factor, aux);
+                r = walkGroup<LOG2>(b, sh, lane, myG, gx, gy, firstPos, LB::caseOf(ws.coded, gx, gy, carryIn), job.sdh_factor, aux RT_ARG);
                 ex.flags[lane] = (int)r.localStop | r.coded << 1 | r.carry << 2 | carryIn << 3;
                 ex.cost[lane] = r.cost;
                 ex.sigCost[lane] = r.sigCost;
@@ -1056,6 +1193,7 @@ __global__ __launch_bounds__(64) void k_rdoq_diag(int16_t *__restrict__ dstAll, 
                 ex.groupOr[lane] = r.groupOr;
             }
             __syncthreads();
+            RT_MARK(7);
             // every lane of the block replays the round in scan order, taking of a group walked twice the lane whose carry was right
             int carry = 0;
             bool chosen = false;
@@ -1082,8 +1220,11 @@ __global__ __launch_bounds__(64) void k_rdoq_diag(int16_t *__restrict__ dstAll, 
                 carryOut |= (uint64_t)o.carry << pickG[i];
                 gAcc = pickG[i] - 1;
             }
+            RT_MARK(8);
             if (chosen && r.coded && myG != 0) lb.finishGroup(sh, lane, job.sdh, aux, myG, 1 << 30, false, gx, gy);      // as a group below the last one; the DC group waits for the verdict
+            RT_MARK(9);
     __syncthreads();      // the exchange arrays are free again
+            RT_MARK(10);
         }
         if (firstGroup >= start) hopZeros(start);
     }
@@ -1097,21 +1238,44 @@ __global__ __launch_bounds__(64) void k_rdoq_diag(int16_t *__restrict__ dstAll, 
             const int lastIdx = lb.lastIndex(job.is_intra, info.sumSq, ws.walkedDist0, ws.costTu, ws.bestRel, ws.bestPos);
             cbf = lastIdx ? ws.orSince : 0;
             const int lastGroup = (lastIdx - 1) >> 4;
-            for (int g = firstGroup; g > max(lastGroup, 0); --g)
-                if ((ws.coded >> rasterOf[g]) & 1) lb.clearGroup(rasterOf[g]);
+            for (uint64_t m = ws.codedScan & ~((2ull << max(lastGroup, 0)) - 1); m;)
+            {
+                const int g = 63 - __clzll((long long)m);
+                m ^= 1ull << g;
+                lb.clearGroup(rasterOf[g]);
+            }
             if (lastGroup >= 0) lb.finishGroup(sh, lane, job.sdh, aux, 0, lastGroup == 0 ? lastIdx : 1 << 30, lastGroup == 0, 0, 0);      // the DC group: this lane walked it last
             if (lastGroup > 0 && (lastIdx & 15 || job.sdh))
             {
                 const int p = rasterOf[lastGroup], gx = p & (gw - 1), gy = p / gw;
                 lb.loadGroup(sh, lane, gx, gy);
-                walkGroup<LOG2>(b, sh, lane, lastGroup, gx, gy, firstPos, LB::caseOf(ws.coded, gx, gy, (int)(ws.carries >> lastGroup) & 1), job.sdh_factor, aux);
+                walkGroup<LOG2>(b, sh, lane, lastGroup, gx, gy, firstPos, LB::caseOf(ws.coded, gx, gy, (int)(ws.carries >> lastGroup) & 1), job.sdh_factor, aux RT_ARG);
                 lb.finishGroup(sh, lane, job.sdh, aux, lastGroup, lastIdx, true, gx, gy);
             }
         }
         cbfOut[blk] = cbf;
     }
+    RT_MARK(11);
+    RT_FLUSH(lane, 16);
+#ifdef HAVOC_RDOQ_TIMING
+    if (lane == 0) atomicAdd(&g_rdoqTiming[31], 1ull);
+#endif
 }
 } // namespace
+
+#ifdef HAVOC_RDOQ_TIMING
+extern "C" __attribute__((visibility("default"))) int havoc_mi355x_debug_rdoq_timing(unsigned long long *out, int reset)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rdoqTiming), sizeof(g_rdoqTiming)) != hipSuccess) return -2;
+    if (reset)
+    {
+        unsigned long long z[32] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_rdoqTiming), z, sizeof(z)) != hipSuccess) return -3;
+    }
+    return 0;
+}
+#endif
 
 size_t rdoq_workspace_bytes(int njobs) { return rdoqInfoOffset() + (size_t)max(njobs, 0) * (sizeof(RdoqInfo) + sizeof(uint32_t)) + 64; }
 
@@ -1149,8 +1313,9 @@ static hipError_t rdoq_order_and_walk(hipStream_t st, int bitDepth, int log2, in
         }
     }
     // blocks with a horizontal / vertical scan (none in the reference's encoder at these sizes): the sequential walk; exits at once when there are none
-    if (log2 == 4) hipLaunchKernelGGL((k_rdoq_walk<4, true>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work, diag);
-    else hipLaunchKernelGGL((k_rdoq_walk<5, true>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work, diag);
+    // sorted blocks come from all over the picture: their context states stay a per-wavefront LDS copy (64 different cache lines per access otherwise)
+    if (log2 == 4) hipLaunchKernelGGL((k_rdoq_walk<4, true, true>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work, diag);
+    else hipLaunchKernelGGL((k_rdoq_walk<5, true, true>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work, diag);
     return hipGetLastError();
 }
 
@@ -1163,8 +1328,15 @@ hipError_t launch_rdoq(hipStream_t st, int bitDepth, int log2, int16_t *dst, con
     const int wgs = (njobs + 63) / 64;
     if (log2 <= 3)
     {
-        if (log2 == 2) hipLaunchKernelGGL((k_rdoq_walk<2, false>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work, 0);
-        else hipLaunchKernelGGL((k_rdoq_walk<3, false>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work, 0);
+        // diagnostic A/B switch (profiles/): HAVOC_RDOQ_LDS_STATES=1 gives the job-order walks the per-wavefront LDS copy of the context states back
+        static const bool ldsStates = getenv("HAVOC_RDOQ_LDS_STATES") && atoi(getenv("HAVOC_RDOQ_LDS_STATES")) != 0;
+        if (ldsStates)
+        {
+            if (log2 == 2) hipLaunchKernelGGL((k_rdoq_walk<2, false, true>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work, 0);
+            else hipLaunchKernelGGL((k_rdoq_walk<3, false, true>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work, 0);
+        }
+        else if (log2 == 2) hipLaunchKernelGGL((k_rdoq_walk<2, false, false>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work, 0);
+        else hipLaunchKernelGGL((k_rdoq_walk<3, false, false>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work, 0);
         return hipGetLastError();
     }
     hipError_t e = hipMemsetAsync(work, 0, sizeof(RdoqWork), st);

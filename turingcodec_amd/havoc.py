@@ -17,7 +17,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhavoc_mi355x.so")
+LIB_PATH = os.environ.get("HAVOC_MI355X_LIB") or os.path.join(_HERE, "libhavoc_mi355x.so")      # the override: diagnostic builds of profiles/micro/ (timing variants)
 
 _vp = C.c_void_p
 _ip = C.c_ssize_t
