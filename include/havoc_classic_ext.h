@@ -20,6 +20,22 @@
  *   inverse_transform_add, havoc_ssd an intra candidate's: computed in the wait of its havoc_quantize_inverse call (prediction and source are on the device);
  *                                    an inter block's two havoc_ssd calls: in the wait of its inverse_transform_add (the source block is residual + prediction);
  *   every such answer is given only if the operands the call names hold exactly the samples the precomputed value was made from (compared on the host).
+ * Round 6 (per calling thread, same rule -- the operands a call names must hold what the value was made from):
+ *   havoc_quantize_inverse           from a table of the call's (scale, shift) pair: havoc_mi355x_quantize_inverse of all 65 536 int16 levels, ONE launch the first time a
+ *                                    pair is seen (the de-quantiser is element-wise, havoc/quantize.cpp:37-46); an intra candidate WITH levels keeps its launch (its
+ *                                    inverse transform + add + SSD ride in the same wait), one WITHOUT any is reconstructed already: the 35-mode stage also makes
+ *                                    every mode's reconstruction from a block of zero levels and its SSD (two thirds of the reference encoder's de-quantiser calls at QP 32);
+ *   the 35-mode stage itself         in the wait of the partition's FIRST intra call, against the block this thread's partitions of that size have been walking towards
+ *                                    (coding order; the source picture is on the device, nothing of the caller's is read) -- used if the first SATD call names that block;
+ *   the Cb / Cr candidates of a unit (predict -> residual -> transform, no SATD call: Reconstruct.cpp:244-353) measured at their first `transform` call against
+ *                                    residual + prediction -- the source block, exactly -- every mode's transform and zero-level reconstruction in that one wait;
+ *   havoc::Transform of an inter unit all blocks of the unit (luma, Cb, Cr: the encoder has subtracted the whole unit before it walks the transform tree,
+ *                                    Reconstruct.cpp:1246-1285) in the wait of the first: the library learns which residual blocks followed a first block the last time,
+ *                                    reads them when it comes again, and answers the following calls if their residuals hold exactly what was transformed.  (The one
+ *                                    place it reads memory the current call does not name: blocks that WERE operands of this thread's earlier `transform` calls, in the
+ *                                    encoder's per-thread residual buffer; a host that frees that buffer while encoding must not use this library.)
+ *   a one-job call                   packs its operands into pinned memory the device addresses directly and waits ONCE (before: copy + wait, launch, copy + wait).
+ * It helps to register all three planes of an input picture as HAVOC_PICTURE_SOURCE (chroma tile SATDs are then batched like luma's).
  * Every served value is what the batch kernel computed on the GPU, bit-identical to the per-call value.  A call the
  * precomputed data cannot answer (unregistered planes, other primitives) takes the one-job launch path -- never a CPU
  * path.  Registered planes must not change until they are unregistered (the encoder's input pictures and completed

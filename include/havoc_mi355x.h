@@ -269,13 +269,14 @@ int havoc_mi355x_sad4(havoc_mi355x_ctx *ctx, int S, const void *d_src, intptr_t 
                       intptr_t stride_ref, const havoc_mi355x_sad4_job *d_jobs, int njobs, int32_t *d_out);
 /* The same calls BY RUNS: a run = consecutive havoc_sad_multiref calls of one motion search (turing/Search.hpp:2224-2297 -> considerPattern :1447-1482: ~112 calls
  * sharing the source block and moving around one centre).  A workgroup stages the run's source block and the bounding box of all its candidates in LDS once and the
- * calls read them there; d_out as havoc_mi355x_sad4.  d_runs must tile the jobs the caller wants computed (jobs in no run are not computed).  Runs change the speed,
+ * calls read them there; d_out as havoc_mi355x_sad4.  d_runs must tile the jobs the caller wants computed: the d_out entries of a job in no run are LEFT AS THEY ARE
+ * (clear d_out first if that matters), and runs must not overlap (two workgroups would write the same entries).  havoc_mi355x_sad4_make_runs' output tiles [0, njobs).  Runs change the speed,
  * never a result: a run whose calls differ in source / size, whose box does not fit LDS or does not hold every candidate, is computed call by call.
  *   box_off / box_w / box_h: the rectangle of the reference plane (sample offset of its top-left from d_ref, width in samples, rows) that holds every candidate BLOCK of
  *   the run -- staged at once, each candidate then checked against it; box_w = 0: the kernel finds the box itself (one more pass over the run's jobs).
  * havoc_mi355x_sad4_make_runs (host code, no device) cuts a HOST copy of a job table into runs and gives them their boxes: consecutive jobs with equal src_off, w, h whose
  * box fits the kernel's window (16 KB x S), at most max_run calls (1 .. 128; <= 0: by block size -- 16 calls of a 64x64 block, 48 of a 32x32, 128 below: what keeps a
- * workgroup's work even, profiles/r05/sad4_run_policy.jsonl); stride_ref = the reference plane's row stride in samples (the boxes are rectangles of that plane).
+ * workgroup's work even, profiles/r05/sad4_run_policy.txt); stride_ref = the reference plane's row stride in samples (the boxes are rectangles of that plane).
  * Returns the number of runs written to `runs` (capacity njobs), or -1. */
 typedef struct {
     int32_t first_job;
@@ -415,6 +416,17 @@ typedef struct {
 } havoc_mi355x_tu_fused_job; /* 16 bytes */
 int havoc_mi355x_tu_forward(havoc_mi355x_ctx *ctx, int S, int bitDepth, int trType, int log2TrafoSize, int16_t *d_coeffs, const void *d_src,
                             intptr_t stride_src, const void *d_pred, intptr_t stride_pred, const havoc_mi355x_tu_fused_job *d_jobs, int njobs);
+/* The 35-mode stage of ONE intra partition in one launch (round 6; what libhavoc_classic.so's serve layer precomputes when a partition's first prediction / SATD /
+ * transform call arrives -- turing/Search.hpp:113-142, Reconstruct.cpp:244-353): job i = mode slot i, its prediction block (pred_off, row stride stride_pred) against
+ * the partition's source block (src_off); coef_off / rec_off = where its n*n coefficients / reconstructed samples (n x n, contiguous) go.  Per job, each bit-identical to
+ * the entry point named:
+ *   d_satd[i * tiles + t]    havoc_mi355x_satd of tile t (8x8 tiles in raster order; one 4x4 tile for a 4x4 partition), only if with_satd
+ *   d_coeffs                 havoc_mi355x_tu_forward, DST-VII for 4x4 / DCT above (the luma rule, Reconstruct.cpp:263)
+ *   d_coeffs_dct             4x4 only: havoc_mi355x_tu_forward with trType 0 (a 4x4 chroma block)
+ *   d_rec0, d_ssd0[i]        havoc_mi355x_tu_reconstruct on a block of ZERO levels: the reconstruction (= the clipped prediction) and its SSD against the source */
+int havoc_mi355x_intra_measure(havoc_mi355x_ctx *ctx, int S, int bitDepth, int log2TrafoSize, int16_t *d_coeffs, int16_t *d_coeffs_dct, int32_t *d_satd, void *d_rec0,
+                               uint32_t *d_ssd0, const void *d_src, intptr_t stride_src, const void *d_pred, intptr_t stride_pred, const havoc_mi355x_tu_fused_job *d_jobs,
+                               int njobs, int with_satd);
 int havoc_mi355x_tu_reconstruct(havoc_mi355x_ctx *ctx, int S, int bitDepth, int trType, int log2TrafoSize, int scale, int shift, void *d_rec,
                                 intptr_t stride_rec, const void *d_pred, intptr_t stride_pred, const void *d_src, intptr_t stride_src,
                                 const int16_t *d_levels, const havoc_mi355x_tu_fused_job *d_jobs, int njobs, uint32_t *d_ssd);

@@ -74,7 +74,10 @@ void pictureStarts(H &h, const Docket &docket)
 {
     StateFunctionTables *tables = h;
     auto &input = static_cast<PictureWrap<Sample> &>(*docket->picture);
-    add(tables->code, input[0].p, input[0].stride, input[0].width, input[0].height, 0, int(sizeof(Sample)), h[BitDepthY()], HAVOC_PICTURE_SOURCE, docket->picture);
+    // all three planes of the input picture (round 6: the intra candidates of Cb / Cr are measured against their source blocks like luma's)
+    for (int cIdx = 0; cIdx < 3; ++cIdx)
+        add(tables->code, input[cIdx].p, input[cIdx].stride, input[cIdx].width, input[cIdx].height, 0, int(sizeof(Sample)), cIdx ? h[BitDepthC()] : h[BitDepthY()],
+            HAVOC_PICTURE_SOURCE, docket->picture);
 }
 
 template <typename Sample, class H>

@@ -9,7 +9,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-import bench                                                  # noqa: E402
+from turingcodec_amd import step                              # noqa: E402
 from turingcodec_amd import havoc as H                        # noqa: E402
 from turingcodec_amd.workload import FrameWorkload            # noqa: E402
 
@@ -20,7 +20,7 @@ hv = H.Havoc(stream="new")
 L = C.CDLL(H.LIB_PATH)
 buf = (C.c_ulonglong * 32)()
 wl = FrameWorkload(int(res.split("x")[0]), int(res.split("x")[1]), 8, qp=qp)
-dev = bench.DeviceFrame(hv, wl)
+dev = step.DeviceFrame(hv, wl)
 dev.step()
 hv.sync()
 out = []

@@ -6,7 +6,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-import bench                                                  # noqa: E402
+from turingcodec_amd import step                              # noqa: E402
 from turingcodec_amd.havoc import Havoc                       # noqa: E402
 from turingcodec_amd.workload import FrameWorkload            # noqa: E402
 
@@ -14,7 +14,7 @@ res = sys.argv[1] if len(sys.argv) > 1 else "1920x1080"
 qp = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 hv = Havoc(stream="new")
 wl = FrameWorkload(int(res.split("x")[0]), int(res.split("x")[1]), 8, qp=qp)
-dev = bench.DeviceFrame(hv, wl)
+dev = step.DeviceFrame(hv, wl)
 dev.step()
 hv.sync()
 # the TU chains: lists of launch indices whose first launch is a tu_forward

@@ -8,7 +8,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import bench                                                  # noqa: E402
+from turingcodec_amd import step                              # noqa: E402
 from turingcodec_amd.havoc import Havoc                       # noqa: E402
 from turingcodec_amd.workload import FrameWorkload            # noqa: E402
 
@@ -17,7 +17,7 @@ hv = Havoc(stream="new")
 res = sys.argv[2] if len(sys.argv) > 2 else "1920x1080"
 qp = int(sys.argv[3]) if len(sys.argv) > 3 else 32
 wl = FrameWorkload(int(res.split("x")[0]), int(res.split("x")[1]), 8, qp=qp)
-dev = bench.DeviceFrame(hv, wl)
+dev = step.DeviceFrame(hv, wl)
 dev.step()
 hv.sync()
 out = {}

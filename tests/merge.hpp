@@ -1,3 +1,4 @@
+// TEST INFRASTRUCTURE since round 6 (moved out of turingcodec_amd/search/: nothing in the product derives a merge candidate list -- VERDICT r5 next #4).
 // merge.hpp -- the reference's derivation of a prediction unit's merge candidates (HEVC 8.5.3.2.2 - 8.5.3.2.5 as turing/Mvp.h:486-697 applies it), restated as
 // DATA-ONLY code: what it reads of the encoder's state is handed in -- the five spatial neighbours, the temporal candidate, the picture order counts of the reference
 // lists -- and the candidate list comes out.

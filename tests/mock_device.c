@@ -340,6 +340,29 @@ int havoc_mi355x_tu_reconstruct(havoc_mi355x_ctx *ctx, int S, int bitDepth, int 
     return 0;
 }
 
+/* the 35-mode stage of one partition in one call (csrc/kernels_tu_fused.hip: k_intra_measure): the three entry points it stands for, one after the other */
+int havoc_mi355x_intra_measure(havoc_mi355x_ctx *ctx, int S, int bitDepth, int log2, int16_t *coeffs, int16_t *coeffs_dct, int32_t *satd, void *rec0, uint32_t *ssd0,
+                               const void *src, intptr_t ss, const void *pred, intptr_t sp, const havoc_mi355x_tu_fused_job *j, int n, int with_satd)
+{
+    (void)ctx; ++g_launches;
+    const int N = 1 << log2, TS = N >= 8 ? 8 : 4, TX = N / TS;
+    int16_t res[32 * 32], zero[32 * 32];
+    memset(zero, 0, sizeof(zero));
+    for (int i = 0; i < n; ++i)
+    {
+        const char *a = AT(src, j[i].src_off, S), *b = AT(pred, j[i].pred_off, S);
+        if (with_satd)
+            for (int t = 0; t < TX * TX; ++t)
+                satd[i * TX * TX + t] = oracle_satd(a + ((long)(t / TX) * TS * ss + (t % TX) * TS) * S, ss, b + ((long)(t / TX) * TS * sp + (t % TX) * TS) * S, sp, TS, S);
+        oracle_residual(res, N, a, ss, b, sp, N, N, S);
+        oracle_transform(coeffs + j[i].coef_off, res, N, log2, log2 == 2 ? 1 : 0, bitDepth);
+        if (log2 == 2) oracle_transform(coeffs_dct + j[i].coef_off, res, N, log2, 0, bitDepth);
+        oracle_inverse_transform_add((char *)rec0 + (long)j[i].rec_off * S, N, b, sp, zero, log2, log2 == 2 ? 1 : 0, bitDepth, S);
+        ssd0[i] = oracle_ssd(a, ss, AT(rec0, j[i].rec_off, S), N, N, N, S);
+    }
+    return 0;
+}
+
 /* the device-side intra decisions (csrc/kernels_decide.hip), one partition after the other: the same rules as search/decision.hpp: intraModeOrder and
  * search/tu_decision.hpp: decideIntraRd, which tests/test_search.py compares them with */
 int havoc_mi355x_intra_order(havoc_mi355x_ctx *ctx, const int32_t *satd35, const havoc_mi355x_intra_mpm *mpm, int n, int32_t lambda_q16, int32_t *order, int32_t *count,

@@ -14,10 +14,11 @@ def hv():
 
 def _frames(hv, res, bit_depth, seed, qp=32):
     import bench
+    from turingcodec_amd import step
     from turingcodec_amd.workload import FrameWorkload
     w, h = res
     wl = FrameWorkload(w, h, bit_depth, seed, qp=qp)
-    return wl, bench.DeviceFrame(hv, wl, use_planes=True), bench.DeviceFrame(hv, wl, use_planes=False)
+    return wl, step.DeviceFrame(hv, wl, use_planes=True), step.DeviceFrame(hv, wl, use_planes=False)
 
 
 @pytest.mark.parametrize("res,bit_depth", [((1920, 1080), 8), ((3840, 2160), 8), ((1920, 1080), 10)])
@@ -61,10 +62,11 @@ def test_fused_tu_chain_equals_separate_primitives(hv):
     """272 k transform units at 1080p: tu_forward / tu_reconstruct give the same coefficients, reconstruction and SSD
     as residual -> transform and quantize_inverse -> inverse_transform_add -> ssd"""
     import bench
+    from turingcodec_amd import step
     from turingcodec_amd.workload import FrameWorkload
     wl = FrameWorkload(1920, 1080, 8, 9)
-    a = bench.DeviceFrame(hv, wl, fused_tu=True)
-    b = bench.DeviceFrame(hv, wl, fused_tu=False)
+    a = step.DeviceFrame(hv, wl, fused_tu=True)
+    b = step.DeviceFrame(hv, wl, fused_tu=False)
     a.step()
     b.step()
     hv.sync()
@@ -176,12 +178,13 @@ def _parity_vs_reference(hv, res, bit_depth, qp, mix="ra", seed=11, min_values=1
     import argparse
     import os
     import bench
+    from turingcodec_amd import step
     from turingcodec_amd.workload import FrameWorkload
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     if not os.path.exists(os.path.join(root, "oracle", "_ref", "libhavoc_ref.so")):
         pytest.skip("oracle/_ref not built (needs the reference sources at build time)")
     wl = FrameWorkload(res[0], res[1], bit_depth, seed, qp=qp, mix=mix)
-    dev = bench.DeviceFrame(hv, wl)
+    dev = step.DeviceFrame(hv, wl)
     dev.step()
     hv.sync()
     r = bench.cpu_baseline(argparse.Namespace(res=f"{res[0]}x{res[1]}", bit_depth=bit_depth, seed=seed, qp=qp, mix=mix, rdoq=1), dev)
@@ -256,11 +259,12 @@ def test_scan_inside_tu_forward_equals_the_separate_scan(hv):
     """havoc_mi355x_tu_forward_scan + havoc_mi355x_rdoq_prescanned against tu_forward + havoc_mi355x_rdoq on the 1080p picture's 16x16 and 32x32
     transform blocks: coefficients, levels, coded-block flags, reconstructions and SSDs identical (8- and 10-bit)"""
     import bench
+    from turingcodec_amd import step
     from turingcodec_amd.workload import FrameWorkload
     for bd, qp in ((8, 32), (10, 27)):
         wl = FrameWorkload(1920, 1080, bd, 11, qp=qp)
-        a = bench.DeviceFrame(hv, wl, scan_in_forward=True)
-        b = bench.DeviceFrame(hv, wl, scan_in_forward=False)
+        a = step.DeviceFrame(hv, wl, scan_in_forward=True)
+        b = step.DeviceFrame(hv, wl, scan_in_forward=False)
         a.step()
         b.step()
         hv.sync()
@@ -275,10 +279,11 @@ def test_merged_prediction_launches_equal_the_per_class_launches(hv):
     """havoc_mi355x_pred_uni_classes / pred_bi_classes (all four size classes of a job table in one launch) against one launch per width
     class, on the 1080p picture's luma and chroma, uni and bi tables: identical output buffers"""
     import bench
+    from turingcodec_amd import step
     from turingcodec_amd.workload import FrameWorkload
     wl = FrameWorkload(1920, 1080, 8, 11)
-    a = bench.DeviceFrame(hv, wl, pred_launches="merged")
-    b = bench.DeviceFrame(hv, wl, pred_launches="classes")
+    a = step.DeviceFrame(hv, wl, pred_launches="merged")
+    b = step.DeviceFrame(hv, wl, pred_launches="classes")
     a.step()
     b.step()
     hv.sync()

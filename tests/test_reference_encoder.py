@@ -108,8 +108,11 @@ def test_hooked_reference_encoder_is_served_from_registered_pictures_and_writes_
     # (inverse transform + SSD computed with the de-quantiser call) and the inter blocks' two SSDs (with the inverse transform) are served as well:
     # ~90 % of the table calls at speed=medium (what is left: the de-quantiser and the inter blocks' transform / inverse transform -- operands that come
     # from the host's RDOQ -- bi-prediction, single-tile chroma SATDs); speed=slow adds residual-quadtree candidates
+    # round 6: the de-quantiser from device-made tables, candidates without a level from the 35-mode stage's zero-level reconstructions, the Cb / Cr candidates measured
+    # from their residual, an inter unit's forward transforms read ahead in its first block's wait: > 93 % served at speed=medium (96.5 % at QP 32: one-job launches 11 % -> 3.5 %; QP 22 keeps more levels: 94 %; speed=slow, whose residual-quadtree candidates are not read ahead: 89.9 %)
     share = s["served"] / (s["served"] + s["one_job"])
-    assert s["pictures"] >= 4 and share > (0.8 if "slow" in case else 0.88) and s["one_job"] > 0 and s["surfaces"] > 0 and s["satd_batches"] > 0, (share, s)
+    print(case, concurrent, f"served share {share:.4f}")
+    assert s["pictures"] >= 4 and share > (0.88 if "slow" in case else 0.93) and s["one_job"] > 0 and s["surfaces"] > 0 and s["satd_batches"] > 0, (share, s)
     if concurrent == 4:
         _check_golden(case, got, workdir)          # --concurrent-frames 4 is the default the committed hashes were made with
 
@@ -129,6 +132,9 @@ def test_hooked_reference_encoder_on_the_mi355x(case, workdir):
     print(case, s, f"{dt:.1f} s, {dt / calls * 1e6:.2f} us per table call, {s['launches'] / et.CASES[case][2]:.0f} launches per frame")
     assert got == ref, f"{case}: the hooked encoder's stream on the MI355X differs from the reference encoder's"
     assert s["served"] > 0.85 * calls and s["one_job"] > 0 and s["surfaces"] > 0 and s["satd_batches"] > 0, s      # round 5: intra stage and TU chains served too
+    # round 6: one-job launches 11 % -> < 5 % of the table calls, launches per frame 125 k -> < 90 k, 0.5 -> > 1 frame/s (measured: 3.5 %, 71 k, 1.5)
+    frames = et.CASES[case][2]
+    assert s["one_job"] < 0.05 * calls and s["launches"] / frames < 90e3 and frames / dt > 1.0, (s, dt)
     _check_golden(case, got, workdir)
 
 
@@ -144,7 +150,7 @@ def test_call_mix_of_the_reference_encoder_can_be_measured(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     m = json.load(open(out))
     calls = m["calls_by_entry_point"]
-    assert calls["sad4"] > 10 * calls["sad"] > 0 and calls["intra"] > 0 and abs(calls["transform"] - calls["inverse_transform"]) < 0.01 * calls["transform"]
+    assert calls["sad4"] > 10 * calls["sad"] > 0 and calls["intra"] > 0 and abs(calls["transform"] - calls["inverse_transform"]) < 0.02 * calls["transform"]      # (round 6: the table library transforms an inter unit's blocks ahead; 1.3 % of them are never asked for)
     mix = m["searched_pu_size_mix_from_single_sad_calls"]
     assert abs(sum(mix.values()) - 1.0) < 1e-3 and max(mix, key=mix.get) == "max side 16"
     assert abs(sum(m["forward_transform_calls_by_size"].values()) - 1.0) < 1e-3

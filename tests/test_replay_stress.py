@@ -11,10 +11,11 @@ import pytest
 
 
 def _ctx(torch, Havoc, bench, FrameWorkload, seed, pred, tune):
+    from turingcodec_amd import step
     s = torch.cuda.Stream(device=0)
     hv = Havoc(0, stream=s.cuda_stream)
     wl = FrameWorkload(1920, 1080, 8, seed)
-    dev = bench.DeviceFrame(hv, wl, pred_launches=pred)
+    dev = step.DeviceFrame(hv, wl, pred_launches=pred)
     dev.step()
     hv.sync()
     want = {k: getattr(dev, k).clone() for k in ("bi", "sbi", "cbi", "pred", "o_satd")}
@@ -28,6 +29,7 @@ def _ctx(torch, Havoc, bench, FrameWorkload, seed, pred, tune):
 def test_replayed_step_reproduces_the_eager_step_with_bi_slots_zeroed_between_replays(pred, reference_jit):
     import torch
     import bench
+    from turingcodec_amd import step
     from turingcodec_amd import Havoc
     from turingcodec_amd.workload import FrameWorkload
     ctxs = [_ctx(torch, Havoc, bench, FrameWorkload, 11 + 1000 * k, pred, 10) for k in range(2)]

@@ -61,7 +61,7 @@ def check_cpu(rep, min_searches):
     # every searchUni against the three tests of the encoder's neighbourPuData: what the walk on the host and in k_search_rows decides its reads by
     av = rep["availability_cpu"]
     assert av["prediction_units"] == u["searches"] and av["mismatching"] == 0 and min(av["by_position_A0_A1_B0_B1_B2"]) > 0, av
-    # search/merge.hpp -- the reference's merge candidate list (Mvp.h:486-697: spatial candidates with their pruning, the temporal candidate, combined bi-predictive and zero
+    # tests/merge.hpp -- the reference's merge candidate list (Mvp.h:486-697: spatial candidates with their pruning, the temporal candidate, combined bi-predictive and zero
     # candidates) as data-only code -- on the neighbours the encoder's own PuMergeNeighbour<>::get returned, for every searchMergeModes call: the list the encoder left
     m = rep["merge_cpu"]
     assert m["derivations"] > u["searches"] // 8 and m["mismatching"] == 0, m

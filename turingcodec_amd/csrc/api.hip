@@ -29,6 +29,7 @@ hipError_t launch_transform(hipStream_t, int bd, int log2, int tr, int16_t *, co
 hipError_t launch_inverse_transform(hipStream_t, int mode, int bd, int log2, int tr, void *, long, const void *, long, int16_t *, const int16_t *,
                                     const void *, int);
 hipError_t launch_tu_forward(hipStream_t, int S, int bd, int log2, int tr, int16_t *, const void *, long, const void *, long, const void *, int);
+hipError_t launch_intra_measure(hipStream_t, int S, int bd, int log2, int16_t *, int16_t *, int32_t *, void *, uint32_t *, const void *, long, const void *, long, const void *, int, int);
 hipError_t launch_tu_forward_scan(hipStream_t, int S, int bd, int log2, int16_t *, const void *, long, const void *, long, const void *, int, const void *, int16_t *,
                                   void *);
 hipError_t launch_rdoq_prescanned(hipStream_t, int bitDepth, int log2, int16_t *, const int16_t *, const uint8_t *, const void *, int, int32_t *, void *);
@@ -346,6 +347,7 @@ int havoc_mi355x_sad4_runs(havoc_mi355x_ctx *ctx, int S, const void *d_src, intp
 {
     REQUIRE_CTX(); REQUIRE_S(); REQUIRE(njobs >= 0 && nruns >= 0, "njobs / nruns < 0");
     REQUIRE(stride_ref >= 64 && stride_ref < (1 << 22), "sad4_runs: reference stride must be 64 .. 2^22 - 1 samples");
+    REQUIRE(njobs == 0 || nruns == 0 || (d_src && d_ref && d_jobs && d_runs && d_out), "sad4_runs: null device pointer");
     return check(launch_sad4_runs(LS(ctx), S, d_src, stride_src, d_ref, stride_ref, d_jobs, njobs, d_runs, nruns, d_out), "sad4_runs");
 }
 
@@ -597,6 +599,18 @@ int havoc_mi355x_tu_forward(havoc_mi355x_ctx *ctx, int S, int bitDepth, int trTy
     REQUIRE_CTX(); REQUIRE_S(); REQUIRE_BD(); REQUIRE_TR(); REQUIRE(njobs >= 0, "njobs < 0");
     return check(launch_tu_forward(LS(ctx), S, bitDepth, log2TrafoSize, trType, d_coeffs, d_src, stride_src, d_pred, stride_pred, d_jobs, njobs),
                  "tu_forward");
+}
+
+int havoc_mi355x_intra_measure(havoc_mi355x_ctx *ctx, int S, int bitDepth, int log2TrafoSize, int16_t *d_coeffs, int16_t *d_coeffs_dct, int32_t *d_satd, void *d_rec0,
+                               uint32_t *d_ssd0, const void *d_src, intptr_t stride_src, const void *d_pred, intptr_t stride_pred, const havoc_mi355x_tu_fused_job *d_jobs,
+                               int njobs, int with_satd)
+{
+    REQUIRE_CTX(); REQUIRE_S(); REQUIRE(log2TrafoSize >= 2 && log2TrafoSize <= 5, "log2TrafoSize must be 2..5"); REQUIRE(njobs >= 0, "njobs < 0");
+    REQUIRE(bitDepth >= 8 && bitDepth <= (S == 1 ? 8 : 10), "bit depth");
+    REQUIRE(njobs == 0 || (d_coeffs && d_rec0 && d_ssd0 && d_src && d_pred && d_jobs && (log2TrafoSize != 2 || d_coeffs_dct) && (!with_satd || d_satd)), "intra_measure: null device pointer");
+    return check(launch_intra_measure(LS(ctx), S, bitDepth, log2TrafoSize, d_coeffs, d_coeffs_dct, d_satd, d_rec0, d_ssd0, d_src, stride_src, d_pred, stride_pred, d_jobs, njobs,
+                                      with_satd),
+                 "intra_measure");
 }
 
 int havoc_mi355x_tu_reconstruct(havoc_mi355x_ctx *ctx, int S, int bitDepth, int trType, int log2TrafoSize, int scale, int shift, void *d_rec,

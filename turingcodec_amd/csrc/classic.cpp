@@ -16,6 +16,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <memory>
 #include <mutex>
 #include <vector>
@@ -65,20 +66,39 @@ struct Binding
     std::atomic<const PicList *> pics{nullptr};      // immutable snapshots: table calls read without a lock
     std::vector<const PicList *> retired;            // old snapshots, freed with the binding
     havoc_mi355x_ctx *ctx = nullptr;                 // registration work (uploads, interpolation)
-    std::atomic<int64_t> stat[8];
+    std::atomic<int64_t> stat[12];                   // [0..7]: havoc_classic_stats; [8] / [9]: 35-mode stages measured at a guessed position / guesses that were right;
+                                                     // [10]: waits (a call that launched and waited: what a table call's time is made of), [11]: nanoseconds spent in them (HAVOC_CLASSIC_REPORT only)
     std::atomic<int64_t> oneJob[16];                 // one-job launches by entry point (HAVOC_CLASSIC_REPORT): see kOneJobNames
-    Binding() { for (auto &c : stat) c = 0; for (auto &c : oneJob) c = 0; }
+    std::atomic<int64_t> waitsBy[16], launchesBy[16]; // waits / launches by the entry point the calling thread was in (HAVOC_CLASSIC_REPORT)
+    // havoc_quantize_inverse of EVERY int16 level for a (scale, shift) pair, made on the device the first time the pair is seen (one launch, 65 536 values) and kept in
+    // pinned memory: the de-quantiser is element-wise (havoc/quantize.cpp:37-46), so a call is answered by looking its levels up (round 6; a picture uses a handful of pairs)
+    struct DeqTab { int scale, shift; int16_t *tab; DeqTab *next; };
+    std::atomic<DeqTab *> deq{nullptr};              // append-only list; built under mu, read without a lock
+    int16_t *deqRampH = nullptr, *deqRampD = nullptr;   // the 65 536 levels in index order (pinned), the tables' common input
+    Binding() { for (auto &c : stat) c = 0; for (auto &c : oneJob) c = 0; for (auto &c : waitsBy) c = 0; for (auto &c : launchesBy) c = 0; }
 };
 
 Binding *g_binding = nullptr;                        // guarded by g_mu for creation / destruction
 std::mutex g_mu;
 std::atomic<Binding *> g_live{nullptr};              // what table entries see
 
+enum { kSad, kSad4, kSsd, kSatd, kSsdLinear, kPredUni, kPredBi, kSubtractBi, kIntra, kTransform, kInverse, kInverseAdd, kDequant, kQuant, kQuantRec };
+thread_local int t_site = 15;                        // the table entry point this thread is in (kSad ...; 15 = none): what a wait / launch is tallied under
+struct Site
+{
+    int before;
+    explicit Site(int k) : before(t_site) { t_site = k; }
+    ~Site() { t_site = before; }
+};
 inline void bump(int k, int64_t n = 1)
 {
-    if (Binding *b = g_live.load(std::memory_order_relaxed)) b->stat[k].fetch_add(n, std::memory_order_relaxed);
+    if (Binding *b = g_live.load(std::memory_order_relaxed))
+    {
+        b->stat[k].fetch_add(n, std::memory_order_relaxed);
+        if (k == 2) b->launchesBy[t_site & 15].fetch_add(n, std::memory_order_relaxed);
+        if (k == 10) b->waitsBy[t_site & 15].fetch_add(n, std::memory_order_relaxed);
+    }
 }
-enum { kSad, kSad4, kSsd, kSatd, kSsdLinear, kPredUni, kPredBi, kSubtractBi, kIntra, kTransform, kInverse, kInverseAdd, kDequant, kQuant, kQuantRec };
 const char *const kOneJobNames[15] = {"sad", "sad4", "ssd", "satd", "ssd_linear", "pred_uni", "pred_bi", "subtract_bi", "intra", "transform", "inverse_transform",
                                       "inverse_transform_add", "quantize_inverse", "quantize", "quantize_reconstruct"};
 // a table call that took the one-job launch path
@@ -88,6 +108,7 @@ inline void oneJob(int kind)
     {
         b->stat[1].fetch_add(1, std::memory_order_relaxed);
         b->stat[2].fetch_add(1, std::memory_order_relaxed);
+        b->launchesBy[t_site & 15].fetch_add(1, std::memory_order_relaxed);
         b->oneJob[kind].fetch_add(1, std::memory_order_relaxed);
     }
 }
@@ -126,15 +147,43 @@ inline void locate(const Pic *q, const void *p, int *x, int *y)
     *x = int(off - row * q->stride) - q->pad;
 }
 
+// every wait of a table call for the device goes through here: waits are what a table call's time is made of (HAVOC_CLASSIC_REPORT)
+inline void waitFor(havoc_mi355x_ctx *ctx)
+{
+    static const bool timed = getenv("HAVOC_CLASSIC_REPORT") != nullptr;
+    if (timed)
+    {
+        timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        CK(havoc_mi355x_sync(ctx));
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        bump(11, (t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec));
+    }
+    else
+        CK(havoc_mi355x_sync(ctx));
+    bump(10);
+}
+
 // per-thread device context + staging memory (never torn down explicitly: process exit reclaims it, which avoids
 // calling into the HIP runtime from thread_local destructors during shutdown)
+//
+// Round 6: the staging buffer is PINNED host memory the device addresses directly (havoc_mi355x_host_alloc): a one-job call packs its operands there, launches,
+// and waits ONCE -- the kernel reads the operands and writes its results through the host mapping.  (Before, every such call was a pageable hipMemcpy + wait up, the
+// launch, and a hipMemcpy + wait down: three round trips for a few hundred bytes.)
 struct Stage
 {
     havoc_mi355x_ctx *ctx = nullptr;
-    char *d = nullptr;
-    size_t cap = 0;
-    std::vector<char> h;
+    char *d = nullptr;                 // device view of the staging buffer
+    struct Host                        // host view: what the calls below index as they did the std::vector it replaces
+    {
+        char *p = nullptr;
+        size_t n = 0;
+        char &operator[](size_t i) { return p[i]; }
+        char *data() { return p; }
+        size_t size() const { return n; }
+    } h;
     size_t used = 0;
+    bool inFlight = false;             // a launch of this call has not been waited for yet
 
     void begin()
     {
@@ -165,11 +214,33 @@ struct Stage
         dp = static_cast<char *>(d_);
     }
 
+    void grow(size_t bytes)            // (between calls nothing of this thread is in flight: every call waits for what it launched)
+    {
+        wait();
+        void *h_ = nullptr, *d_ = nullptr;
+        CK(havoc_mi355x_host_alloc(ctx, bytes, &h_, &d_));
+        if (h.p)
+        {
+            memcpy(h_, h.p, used < h.n ? used : h.n);
+            CK(havoc_mi355x_host_free(ctx, h.p));
+        }
+        h.p = static_cast<char *>(h_);
+        h.n = bytes;
+        d = static_cast<char *>(d_);
+    }
+
     size_t reserve(size_t bytes)
     {
         const size_t o = (used + 63) & ~size_t(63);
+        const size_t before = used;
         used = o + bytes;
-        if (h.size() < used + 64) h.resize((used + 64) * 2);
+        if (h.n < used + 64)
+        {
+            const size_t keep = used;
+            used = before;             // what grow() carries over
+            grow((keep + 64) * 2 < (size_t(1) << 18) ? (size_t(1) << 18) : (keep + 64) * 2);
+            used = keep;
+        }
         return o;
     }
 
@@ -181,25 +252,22 @@ struct Stage
         return o;
     }
 
-    void upload()
+    // the operands are where the device reads them: nothing to copy; what follows is a launch this call will wait for
+    void upload() { inFlight = true; }
+
+    void wait()
     {
-        if (cap < used + 64)
-        {
-            if (d) CK(havoc_mi355x_free(ctx, d));
-            cap = (used + 64) * 2;
-            void *p = nullptr;
-            CK(havoc_mi355x_malloc(ctx, &p, cap));
-            d = static_cast<char *>(p);
-        }
-        CK(havoc_mi355x_h2d(ctx, d, h.data(), used));
+        if (!inFlight) return;
+        waitFor(ctx);
+        inFlight = false;
     }
 
-    void download(size_t off, size_t bytes) { CK(havoc_mi355x_d2h(ctx, &h[off], d + off, bytes)); }
+    void download(size_t, size_t) { wait(); }      // the results were written through the host mapping
 
     template <typename T>
     void unpack(T *dst, intptr_t stride, int w, int rows, int pitch, size_t off)
     {
-        download(off, sizeof(T) * size_t(pitch) * rows);
+        wait();
         for (int y = 0; y < rows; ++y) memcpy(dst + y * stride, &h[off + sizeof(T) * size_t(y) * pitch], sizeof(T) * w);
     }
 
@@ -292,7 +360,27 @@ struct IntraSet
     long srcOff = 0;                                    // ... and its sample offset in the picture's device plane
     const char *srcDev = nullptr;
     int32_t *satd = nullptr;                            // pinned [slot][tile]
-    int16_t *coef = nullptr;                            // pinned [slot][n * n]: forward transform of (source - prediction)
+    int16_t *coef = nullptr;                            // pinned [slot][n * n]: forward transform of (source - prediction); 4x4: DST-VII (luma, Reconstruct.cpp:263)
+    int16_t *coefDct = nullptr;                         // pinned [slot][16]: 4x4 sets only -- the DCT of the same residuals (a 4x4 CHROMA block; the set cannot tell)
+    // round 6: what a candidate whose quantised levels are ALL ZERO reconstructs to (two thirds of the reference encoder's de-quantiser calls carry no level at QP 32,
+    // profiles/r04_reference_call_mix_1080p.json): havoc_mi355x_tu_reconstruct of every mode on a zero level block, made with the 35-mode stage
+    char *rec0 = nullptr;                               // pinned [slot][n * n]
+    uint32_t *ssd0 = nullptr;                           // pinned [slot]: havoc_ssd(source, rec0)
+    // round 6: a set whose partition never met a SATD call (the Cb / Cr candidates of a unit, Reconstruct.cpp:244-353: predict -> residual -> transform) is measured at
+    // its first `transform` call against the source block that call implies -- residual + prediction, exact: the encoder subtracted them -- kept here
+    bool ownSource = false;
+    char *srcCopy = nullptr;                            // pinned: n x n
+    const void *nbPtr = nullptr;                        // where the encoder held the reference samples the set was made from (its per-thread arrays: luma's and chroma's differ)
+    bool guessed = false;                               // measured at a GUESSED position (the partition after the last one of this size): valid only if the first SATD call names it
+};
+
+// where this thread's last partition of each size was measured: the next one of that size is looked for at its successor in coding order
+struct LastPartition
+{
+    bool valid = false;
+    int picId = 0, x = 0, y = 0;
+    const void *nbPtr = nullptr;      // the reference-sample array of the set measured there last ...
+    int sets = 0;                     // ... and how many sets have been: a luma partition above 4x4 is predicted from TWO arrays (unfiltered / filtered), each a set of its own
 };
 
 struct IntraMemo                                        // what this thread last wrote as an intra prediction
@@ -302,6 +390,7 @@ struct IntraMemo                                        // what this thread last
     intptr_t sd = 0;
     IntraSet *set = nullptr;
     int slot = 0;
+    int tr = 0;                                         // transform type of the candidate: the luma rule until a `transform` call of the candidate says otherwise
 };
 
 struct ChainMemo                                        // what the de-quantiser call of an intra candidate computed ahead
@@ -312,6 +401,8 @@ struct ChainMemo                                        // what the de-quantiser
     int16_t *deq = nullptr;                             // pinned: the de-quantised coefficients it returned
     char *rec = nullptr;                                // pinned: prediction + inverse transform of them, n x n
     uint32_t *ssd = nullptr;                            // pinned: havoc_ssd(source, rec)
+    const char *recAt = nullptr;                        // what is served: `rec` / `ssd`, or the set's zero-level reconstruction of the slot
+    const uint32_t *ssdAt = nullptr;
     const void *recDst = nullptr;                       // where inverse_transform_add was asked to put it (then an SSD call may follow)
     intptr_t recSd = 0;
 };
@@ -354,10 +445,61 @@ struct InterAhead
     uint32_t ssdRec = 0, ssdPred = 0;
 };
 
+// Round 6 -- the forward transforms of an inter unit in ONE wait.  reconstructInter subtracts the prediction from the whole unit, all three components, BEFORE it walks
+// the transform tree (Reconstruct.cpp:1246-1285), so when the first block's `transform` call arrives the residuals of the blocks that follow (the other luma blocks of a
+// 64 x 64 unit, Cb, Cr) are already in the encoder's residual buffer -- a member of its per-thread state, at the same addresses unit after unit.  The library LEARNS, per
+// calling thread, which blocks followed a first block (same pointer, stride, size, type) the last time, reads those blocks when the first block comes again, transforms
+// them all in the first block's launch, and answers the calls that follow when the residual they name holds EXACTLY the samples that were transformed (compared on the
+// host, like every served answer); anything else takes the one-job path and is learnt for the next unit.  A run ends at the first call that is not part of a unit's
+// transform chain (a prediction, a SAD / SATD: the encoder is at another candidate).  The blocks read ahead were operands of earlier calls of this thread in the same
+// place -- the one assumption made: a residual buffer the encoder passed to `transform` stays readable while it keeps encoding.
+constexpr int kFwdFollowers = 12, kFwdHeads = 8;
+struct FwdKey
+{
+    const int16_t *ptr = nullptr;
+    intptr_t stride = 0;
+    int log2 = 0, tr = 0, bd = 0;
+    bool same(const FwdKey &o) const { return ptr == o.ptr && stride == o.stride && log2 == o.log2 && tr == o.tr && bd == o.bd; }
+};
+struct FwdHead
+{
+    bool valid = false;
+    FwdKey key;
+    int nf = 0;
+    FwdKey f[kFwdFollowers];
+    uint64_t stamp = 0;
+};
+struct FwdSpec
+{
+    bool valid = false;
+    FwdKey key;
+    int16_t *res = nullptr, *coef = nullptr;            // pinned: the residual block as it was read (n x n, contiguous), its coefficients
+};
+struct FwdState
+{
+    bool groupOpen = false;
+    int cur = -1;                                       // the head whose followers are being recorded
+    FwdHead heads[kFwdHeads];
+    FwdSpec spec[kFwdFollowers];
+    int16_t *headRes = nullptr, *headCoef = nullptr;    // pinned: the first block itself
+    char *jobsH = nullptr;                              // pinned: tu jobs of the launches
+};
+
+// where the source block of this thread's last tile-SATD measurement lay: a search measures candidate after candidate of one PU against the same source block, so the
+// prediction launch of the next candidate takes its tiles' SATDs against that block along (one wait instead of two); used only if the first tile call names that block
+struct SourceGuess
+{
+    bool valid = false;
+    const void *block = nullptr;
+    intptr_t stride = 0;
+    int w = 0, h = 0, S = 0;
+};
+
 struct Serve
 {
     bool ready = false;
     LastPred last;
+    SourceGuess guess;
     SsdPair pair;
     InterAhead inter;
     Surface surf[kSurfaces];
@@ -366,6 +508,10 @@ struct Serve
     IntraSet intra[kIntraSets];
     IntraMemo imemo;
     ChainMemo chain;
+    FwdState fwd;
+    LastPartition lastPart[4];                          // by log2 size - 2
+    const void *noGuess[8] = {};                        // reference-sample arrays whose sets ended up measured from a residual (chroma): no position is guessed for them
+    char *zeroLevels = nullptr;                         // pinned: a 32 x 32 block of zero levels
     uint64_t clock = 0;
     char *jobsH = nullptr, *jobsD = nullptr;            // pinned job tables
     int32_t *denseH = nullptr;                          // pinned: results of a tile-SATD batch in job order
@@ -379,7 +525,7 @@ struct Serve
         if (ready) return;
         constexpr size_t kIntraPred = size_t(kIntraSlots) * 32 * 32 * 2, kIntraSatd = size_t(kIntraSlots) * 16 * 4, kIntraNb = 512;
         const size_t total = kSurfaces * (kSurfBytes + kBlockBytes) + kSatdSets * (kSetBytes + kBlockBytes) + kJobBytes + kSetBytes + 8192 +
-                             kIntraSets * (2 * kIntraPred + kIntraSatd + kIntraNb + 1024) + 3 * 32 * 32 * 2 + 2048;
+                             kIntraSets * (3 * kIntraPred + kIntraSatd + kIntraNb + 4096 + 32 * 32 * 2) + 4 * 32 * 32 * 2 + 4096 + (kFwdFollowers + 1) * 2 * (32 * 32 * 2 + 256) + 1024;
         void *h_ = nullptr, *d_ = nullptr;
         CK(havoc_mi355x_host_alloc(s.ctx, total, &h_, &d_));
         baseH = static_cast<char *>(h_);
@@ -397,7 +543,21 @@ struct Serve
             f.pred = take(kIntraPred);
             f.coef = reinterpret_cast<int16_t *>(take(kIntraPred));
             f.satd = reinterpret_cast<int32_t *>(take(kIntraSatd));
+            f.coefDct = reinterpret_cast<int16_t *>(take(kIntraSlots * 16 * 2));
+            f.srcCopy = take(32 * 32 * 2);
+            f.rec0 = take(kIntraPred);
+            f.ssd0 = reinterpret_cast<uint32_t *>(take(kIntraSlots * 4));
         }
+        zeroLevels = take(32 * 32 * 2);
+        memset(zeroLevels, 0, 32 * 32 * 2);
+        for (auto &e : fwd.spec)
+        {
+            e.res = reinterpret_cast<int16_t *>(take(32 * 32 * 2));
+            e.coef = reinterpret_cast<int16_t *>(take(32 * 32 * 2));
+        }
+        fwd.headRes = reinterpret_cast<int16_t *>(take(32 * 32 * 2));
+        fwd.headCoef = reinterpret_cast<int16_t *>(take(32 * 32 * 2));
+        fwd.jobsH = take((kFwdFollowers + 1) * sizeof(havoc_mi355x_tu_job));
         chain.deq = reinterpret_cast<int16_t *>(take(32 * 32 * 2));
         chain.rec = take(32 * 32 * 2);
         chain.ssd = reinterpret_cast<uint32_t *>(take(64));
@@ -483,7 +643,7 @@ Surface *surfaceFor(Stage &s, Serve &v, const SrcKey &key, const Sample *src, in
     *job = {srcOff, int32_t((long)(cy + ref->pad) * ref->stride + cx + ref->pad), w, h, 0, {0, 0, 0}};
     CK(havoc_mi355x_sad_surface(s.ctx, sizeof(Sample), kSurfR, (w + 3) & ~3, h, dSrc, dStride, ref->d_plane, ref->stride,
                                 reinterpret_cast<const havoc_mi355x_surface_job *>(v.jobsD), 1, reinterpret_cast<int32_t *>(v.dev(f->res))));
-    CK(havoc_mi355x_sync(s.ctx));
+    waitFor(s.ctx);
     bump(2);
     bump(3);
     f->valid = true;
@@ -622,7 +782,7 @@ bool serveSatd(const Sample *a, intptr_t sa, const Sample *b, intptr_t sb, int *
         }
         CK(havoc_mi355x_satd(s.ctx, sizeof(Sample), N, N, dA, dStrideA, ref->d_phase, ref->stride,
                              reinterpret_cast<const havoc_mi355x_pair_job *>(v.jobsD), nj, reinterpret_cast<int32_t *>(v.dev(v.denseH))));
-        CK(havoc_mi355x_sync(s.ctx));
+        waitFor(s.ctx);
         bump(2);
         bump(4);
         for (int i = 0; i < kSubPelCands * ntiles; ++i)
@@ -639,6 +799,97 @@ bool serveSatd(const Sample *a, intptr_t sa, const Sample *b, intptr_t sb, int *
     *out = val;
     bump(0);
     return true;
+}
+
+// The 35-mode stage of a partition whose predictions are in f->pred, against the source block at (x, y) of registered picture q: every mode's tile SATDs, every
+// mode's residual + forward transform (luma: DST for 4x4 -- Reconstruct.cpp:263) and every mode's reconstruction from a block of ZERO levels with its SSD -- three
+// launches on the thread's stream, not waited for here.  False: the block does not lie in the padded plane.
+inline void launchIntraMeasureAt(Stage &s, Serve &v, IntraSet *f, const void *dSrc, intptr_t strideSrc, long so, bool withSatd)
+{
+    const int n = 1 << f->log2;
+    constexpr size_t kTuAt = 16384;
+    havoc_mi355x_tu_fused_job *tj = reinterpret_cast<havoc_mi355x_tu_fused_job *>(v.jobsH + kTuAt);
+    for (int k = 0; k < f->nslots; ++k) tj[k] = {k * n * n, int32_t(so), k * n * n, k * n * n};
+    // ONE launch (havoc_mi355x_intra_measure: the tile SATDs, the forward transforms and the zero-level reconstructions of every mode)
+    CK(havoc_mi355x_intra_measure(s.ctx, f->S, f->bd, f->log2, reinterpret_cast<int16_t *>(v.dev(f->coef)), reinterpret_cast<int16_t *>(v.dev(f->coefDct)),
+                                  reinterpret_cast<int32_t *>(v.dev(f->satd)), v.dev(f->rec0), reinterpret_cast<uint32_t *>(v.dev(f->ssd0)), dSrc, strideSrc, v.dev(f->pred), n,
+                                  reinterpret_cast<const havoc_mi355x_tu_fused_job *>(v.jobsD + kTuAt), f->nslots, withSatd ? 1 : 0));
+    bump(2);
+    f->measured = true;
+    f->srcOff = so;
+    f->srcDev = static_cast<const char *>(dSrc);
+    f->srcStride = strideSrc;
+    if (v.chain.set == f) v.chain.valid = false;
+}
+
+inline bool launchIntraMeasure(Stage &s, Serve &v, IntraSet *f, const Pic *q, int x, int y)
+{
+    const int n = 1 << f->log2;
+    if (x < -q->pad || y < -q->pad || x + n > q->w + q->pad || y + n > q->h + q->pad) return false;
+    launchIntraMeasureAt(s, v, f, q->d_plane, q->stride, (long)(y + q->pad) * q->stride + x + q->pad, true);
+    f->ownSource = false;
+    f->srcHost = q->origin + ((long)y * q->stride + x) * q->S;
+    f->srcPicId = q->id;
+    LastPartition &lp = v.lastPart[f->log2 - 2];
+    lp.sets = lp.valid && lp.picId == q->id && lp.x == x && lp.y == y ? lp.sets + 1 : 1;
+    lp.valid = true;
+    lp.picId = q->id;
+    lp.x = x;
+    lp.y = y;
+    lp.nbPtr = f->nbPtr;
+    return true;
+}
+
+// A candidate of an unmeasured set arrives at `transform`: the source block is residual + prediction (false if a sum is not a sample: then it is not that); every mode's
+// forward transform and zero-level reconstruction against it, one wait -- the unit's other candidates from these neighbours are then answered like luma's
+template <int BITDEPTH, int LOG2>
+bool measureFromResidual(Stage &s, Serve &v, const int16_t *res, intptr_t stride)
+{
+    constexpr int n = 1 << LOG2;
+    const IntraMemo &m = v.imemo;
+    if (!m.valid) return false;
+    IntraSet *f = m.set;
+    if (!f->valid || f->log2 != LOG2 || f->bd != BITDEPTH) return false;
+    const int maxv = (1 << BITDEPTH) - 1;
+    for (int y = 0; y < n; ++y)
+        for (int x = 0; x < n; ++x)
+        {
+            const int p = f->S == 1 ? reinterpret_cast<const uint8_t *>(f->pred)[m.slot * n * n + y * n + x] : reinterpret_cast<const uint16_t *>(f->pred)[m.slot * n * n + y * n + x];
+            const int o = p + res[y * stride + x];
+            if (o < 0 || o > maxv) return false;
+            if (f->S == 1) reinterpret_cast<uint8_t *>(f->srcCopy)[y * n + x] = uint8_t(o);
+            else reinterpret_cast<uint16_t *>(f->srcCopy)[y * n + x] = uint16_t(o);
+        }
+    launchIntraMeasureAt(s, v, f, v.dev(f->srcCopy), n, 0, false);
+    waitFor(s.ctx);
+    f->ownSource = true;
+    f->guessed = false;
+    f->srcHost = f->srcCopy;
+    f->srcPicId = 0;
+    {
+        bool known = false;
+        for (const void *p_ : v.noGuess) known |= p_ == f->nbPtr;
+        if (!known)
+        {
+            for (int k = 7; k > 0; --k) v.noGuess[k] = v.noGuess[k - 1];
+            v.noGuess[0] = f->nbPtr;
+        }
+    }
+    return true;
+}
+
+// the partition of size n that follows (x, y) in coding order: z-order inside the 64 x 64 CTU, then the CTU to the right (a thread encodes a CTU row)
+inline void nextPartition(int n, int *x, int *y)
+{
+    const int cx = *x & ~63, cy = *y & ~63, per = 64 / n;
+    int ix = (*x - cx) / n, iy = (*y - cy) / n, m = 0;
+    for (int b = 0; b < 4; ++b) m |= ((ix >> b) & 1) << (2 * b) | ((iy >> b) & 1) << (2 * b + 1);
+    ++m;
+    if (m >= per * per) { *x = cx + 64; *y = cy; return; }
+    ix = iy = 0;
+    for (int b = 0; b < 4; ++b) { ix |= ((m >> (2 * b)) & 1) << b; iy |= ((m >> (2 * b + 1)) & 1) << b; }
+    *x = cx + ix * n;
+    *y = cy + iy * n;
 }
 
 // ---- intra prediction: every mode from the array the call names, one launch -- Reconstruct.cpp:244-246, 672-674
@@ -663,23 +914,49 @@ bool serveIntra(Sample *dst, intptr_t sd, const Sample *neighbours, int mode)
         f->valid = false;
         if (v.chain.set == f) v.chain.valid = false;
         memcpy(f->nb, arr, sizeof(Sample) * len);
-        havoc_mi355x_intra_job *jobs = reinterpret_cast<havoc_mi355x_intra_job *>(v.jobsH);
+        constexpr size_t kIntraAt = 24576;      // (its own place in the job arena: the 35-mode stage queued behind it below fills the arena's head before this launch has run)
+        havoc_mi355x_intra_job *jobs = reinterpret_cast<havoc_mi355x_intra_job *>(v.jobsH + kIntraAt);
         const int nslots = LOG2 < 5 ? kIntraSlots : 35;      // the edge filters exist below 32x32 only (havoc/pred_intra.h:41-48)
         static const int edgeMode[3] = {1, 10, 26};
         for (int k = 0; k < nslots; ++k) jobs[k] = {k * n * n, 2 * n + 1, LOG2, k < 35 ? k : edgeMode[k - 35], k < 35 ? 0 : 1, {0, 0, 0}};
-        CK(havoc_mi355x_intra(s.ctx, sizeof(Sample), BD, LOG2, v.dev(f->pred), n, v.dev(f->nb), reinterpret_cast<const havoc_mi355x_intra_job *>(v.jobsD), nslots));
-        CK(havoc_mi355x_sync(s.ctx));
+        CK(havoc_mi355x_intra(s.ctx, sizeof(Sample), BD, LOG2, v.dev(f->pred), n, v.dev(f->nb), reinterpret_cast<const havoc_mi355x_intra_job *>(v.jobsD + kIntraAt), nslots));
         bump(2);
         f->valid = true;
         f->log2 = LOG2; f->bd = BD; f->S = sizeof(Sample); f->nslots = nslots;
         f->measured = false;
+        f->guessed = false;
+        f->ownSource = false;
+        f->nbPtr = neighbours;
+        bool guessable = true;
+        for (const void *p_ : v.noGuess) guessable &= p_ != neighbours;
+        // round 6: the 35-mode stage in the SAME wait, against the block this thread's partitions of this size have been walking towards (the source picture is on
+        // the device: a wrong guess reads nothing of the caller's and costs three small launches; the first SATD call says whether it was right)
+        const LastPartition &lp = v.lastPart[LOG2 - 2];
+        if (lp.valid && guessable)
+        {
+            int gx = lp.x, gy = lp.y;
+            // the partition's OTHER reference-sample array (its first one was measured there a moment ago), or the next partition
+            if (!(lp.sets == 1 && lp.nbPtr != neighbours)) nextPartition(n, &gx, &gy);
+            Binding *b = g_live.load(std::memory_order_acquire);
+            const PicList *l = b ? b->pics.load(std::memory_order_acquire) : nullptr;
+            const Pic *q = nullptr;
+            if (l)
+                for (const auto &c : *l)
+                    if (c->id == lp.picId) { q = c.get(); break; }
+            if (q && q->S == int(sizeof(Sample)) && q->bd == BD && gx < q->w && gy < q->h && launchIntraMeasure(s, v, f, q, gx, gy))
+            {
+                f->guessed = true;
+                bump(8);
+            }
+        }
+        waitFor(s.ctx);
     }
     f->stamp = ++v.clock;
     const int slot = EDGE ? (mode == 1 ? 35 : mode == 10 ? 36 : 37) : mode;
     if (slot >= f->nslots) return false;
     const Sample *from = reinterpret_cast<const Sample *>(f->pred) + slot * n * n;
     for (int y = 0; y < n; ++y) memcpy(dst + y * sd, from + y * n, sizeof(Sample) * n);
-    v.imemo = IntraMemo{true, dst, sd, f, slot};
+    v.imemo = IntraMemo{true, dst, sd, f, slot, LOG2 == 2 ? 1 : 0};
     bump(0);
     return true;
 }
@@ -690,6 +967,7 @@ bool serveIntra(Sample *dst, intptr_t sd, const Sample *neighbours, int mode)
 // would otherwise be answered from the old picture's samples, and its device plane is freed memory.
 inline bool sourceStillRegistered(const IntraSet *f)
 {
+    if (f->ownSource) return true;      // the source block is the set's own copy
     const Pic *q = f->srcHost ? findPic(f->srcHost) : nullptr;
     return q && q->id == f->srcPicId && q->d_plane == f->srcDev;
 }
@@ -717,38 +995,20 @@ bool serveIntraSatd(const Sample *a, intptr_t sa, const Sample *b, intptr_t sb, 
     if (!f->measured || f->srcHost != reinterpret_cast<const char *>(block) || f->srcStride != sa || !sourceStillRegistered(f))
     {
         f->measured = false;
+        f->guessed = false;
         const Pic *q = findPic(block);
         if (!q || q->S != int(sizeof(Sample)) || q->stride != sa) return false;
         int x, y;
         locate(q, block, &x, &y);
-        if (x < -q->pad || y < -q->pad || x + n > q->w + q->pad || y + n > q->h + q->pad) return false;
-        const long so = (long)(y + q->pad) * q->stride + x + q->pad;
-        const int tiles = (n / N) * (n / N), tilesX = n / N;
-        havoc_mi355x_pair_job *jobs = reinterpret_cast<havoc_mi355x_pair_job *>(v.jobsH);
-        int nj = 0;
-        for (int k = 0; k < f->nslots; ++k)
-            for (int t = 0; t < tiles; ++t)
-            {
-                const int px = (t % tilesX) * N, py = (t / tilesX) * N;
-                jobs[nj++] = {int32_t(so + (long)py * q->stride + px), int32_t(k * n * n + py * n + px), N, N};
-            }
-        CK(havoc_mi355x_satd(s.ctx, sizeof(Sample), N, N, q->d_plane, q->stride, v.dev(f->pred), n, reinterpret_cast<const havoc_mi355x_pair_job *>(v.jobsD), nj,
-                             reinterpret_cast<int32_t *>(v.dev(f->satd))));
-        // every mode's residual + forward transform (luma: DST for 4x4 -- Reconstruct.cpp:263): what the candidates' `transform` calls will ask for
-        constexpr size_t kTuAt = 16384;
-        havoc_mi355x_tu_fused_job *tj = reinterpret_cast<havoc_mi355x_tu_fused_job *>(v.jobsH + kTuAt);
-        for (int k = 0; k < f->nslots; ++k) tj[k] = {k * n * n, int32_t(so), k * n * n, 0};
-        CK(havoc_mi355x_tu_forward(s.ctx, sizeof(Sample), f->bd, f->log2 == 2 ? 1 : 0, f->log2, reinterpret_cast<int16_t *>(v.dev(f->coef)), q->d_plane, q->stride,
-                                   v.dev(f->pred), n, reinterpret_cast<const havoc_mi355x_tu_fused_job *>(v.jobsD + kTuAt), f->nslots));
-        CK(havoc_mi355x_sync(s.ctx));
-        bump(2, 2);
-        f->measured = true;
-        f->srcHost = reinterpret_cast<const char *>(block);
-        f->srcStride = sa;
-        f->srcPicId = q->id;
-        f->srcOff = so;
-        f->srcDev = q->d_plane;
-        if (v.chain.set == f) v.chain.valid = false;
+        if (!launchIntraMeasure(s, v, f, q, x, y)) return false;
+        waitFor(s.ctx);
+        for (auto &p_ : v.noGuess)
+            if (p_ == f->nbPtr) p_ = nullptr;      // a SATD call named its partition: luma after all
+    }
+    else if (f->guessed)
+    {
+        f->guessed = false;      // a right guess: this partition's 35-mode stage cost no wait of its own
+        bump(9);
     }
     const int tilesX = n / N;
     *out = f->satd[m.slot * tilesX * tilesX + (ty / N) * tilesX + tx / N];
@@ -763,10 +1023,10 @@ bool serveForward(int16_t *coeffs, const int16_t *res, intptr_t stride)
     constexpr int n = 1 << LOG2;
     Stage &s = stage();
     Serve &v = serve(s);
-    const IntraMemo &m = v.imemo;
+    IntraMemo &m = v.imemo;
     if (!m.valid) return false;
     const IntraSet *f = m.set;
-    if (!f->measured || f->log2 != LOG2 || f->bd != BITDEPTH || TR != (LOG2 == 2 ? 1 : 0)) return false;
+    if (!f->measured || f->log2 != LOG2 || f->bd != BITDEPTH || (LOG2 != 2 && TR != 0)) return false;
     if (!sourceStillRegistered(f)) return false;      // f->srcHost is read below: only while its picture is the one that was measured
     for (int y = 0; y < n; ++y)
         for (int x = 0; x < n; ++x)
@@ -775,7 +1035,8 @@ bool serveForward(int16_t *coeffs, const int16_t *res, intptr_t stride)
             const int o = f->S == 1 ? reinterpret_cast<const uint8_t *>(f->srcHost)[y * f->srcStride + x] : reinterpret_cast<const uint16_t *>(f->srcHost)[y * f->srcStride + x];
             if (res[y * stride + x] != int16_t(o - p)) return false;
         }
-    memcpy(coeffs, f->coef + m.slot * n * n, sizeof(int16_t) * n * n);
+    memcpy(coeffs, (LOG2 == 2 && TR == 0 ? f->coefDct : f->coef) + m.slot * n * n, sizeof(int16_t) * n * n);
+    m.tr = TR;
     bump(0);
     return true;
 }
@@ -792,7 +1053,7 @@ inline void chainAhead(Stage &s, Serve &v, const char *dLevels, int scale, int s
     if (n2 != n * n) return;
     havoc_mi355x_tu_fused_job *tj = reinterpret_cast<havoc_mi355x_tu_fused_job *>(v.jobsH);
     tj[0] = {0, int32_t(f->srcOff), m.slot * n * n, 0};
-    const int tr = f->log2 == 2 ? 1 : 0;
+    const int tr = m.tr;
     CK(havoc_mi355x_tu_reconstruct(s.ctx, f->S, f->bd, tr, f->log2, scale, shift, v.dev(v.chain.rec), n, v.dev(f->pred), n, f->srcDev, f->srcStride,
                                    reinterpret_cast<const int16_t *>(dLevels), reinterpret_cast<const havoc_mi355x_tu_fused_job *>(v.jobsD), 1,
                                    reinterpret_cast<uint32_t *>(v.dev(v.chain.ssd))));
@@ -802,6 +1063,8 @@ inline void chainAhead(Stage &s, Serve &v, const char *dLevels, int scale, int s
     v.chain.slot = m.slot;
     v.chain.tr = tr;
     v.chain.recDst = nullptr;
+    v.chain.recAt = v.chain.rec;
+    v.chain.ssdAt = v.chain.ssd;
 }
 
 template <typename Sample, int LOG2, int TR>
@@ -818,7 +1081,7 @@ bool serveInverseAdd(Sample *dst, intptr_t sd, const Sample *pred, intptr_t sp, 
     const Sample *want = reinterpret_cast<const Sample *>(f->pred) + c.slot * n * n;
     for (int y = 0; y < n; ++y)
         if (memcmp(pred + y * sp, want + y * n, sizeof(Sample) * n)) return false;
-    const Sample *rec = reinterpret_cast<const Sample *>(c.rec);
+    const Sample *rec = reinterpret_cast<const Sample *>(c.recAt);
     for (int y = 0; y < n; ++y) memcpy(dst + y * sd, rec + y * n, sizeof(Sample) * n);      // (pred may alias dst: compared above, before this)
     c.recDst = dst;
     c.recSd = sd;
@@ -835,11 +1098,17 @@ bool serveSsd(const Sample *pa, intptr_t sa, const Sample *pb, intptr_t sb, int 
     if (!c.valid || c.recDst != pb || c.recSd != sb) return false;
     const IntraSet *f = c.set;
     const int n = 1 << f->log2;
-    if (w != n || h != n || f->S != int(sizeof(Sample)) || reinterpret_cast<const char *>(pa) != f->srcHost || sa != f->srcStride || !sourceStillRegistered(f)) return false;
-    const Sample *rec = reinterpret_cast<const Sample *>(c.rec);
+    if (w != n || h != n || f->S != int(sizeof(Sample))) return false;
+    if (f->ownSource)
+    {
+        if (!sameBlock(pa, sa, f->srcCopy, n, n)) return false;      // the block the call names holds the samples the value was measured against
+    }
+    else if (reinterpret_cast<const char *>(pa) != f->srcHost || sa != f->srcStride || !sourceStillRegistered(f))
+        return false;
+    const Sample *rec = reinterpret_cast<const Sample *>(c.recAt);
     for (int y = 0; y < n; ++y)
         if (memcmp(pb + y * sb, rec + y * n, sizeof(Sample) * n)) return false;
-    *out = *c.ssd;
+    *out = *c.ssdAt;
     bump(0);
     return true;
 }
@@ -877,10 +1146,13 @@ bool serveTileSatd(const Sample *a, intptr_t sa, const Sample *b, intptr_t sb, i
     {
         // the whole source block must be the caller's to read: a registered picture says so
         const Pic *q = findPic(block);
-        if (!q || q->S != int(sizeof(Sample)) || q->stride != sa || ntiles < 2 || ntiles > 256) return false;
+        if (!q || q->S != int(sizeof(Sample)) || q->stride != sa || ntiles > 256) return false;
         int x, y;
         locate(q, block, &x, &y);
         if (x < -q->pad || y < -q->pad || x + l.w > q->w + q->pad || y + l.h > q->h + q->pad) return false;
+        v.guess.valid = true;
+        v.guess.block = block; v.guess.stride = sa; v.guess.w = l.w; v.guess.h = l.h; v.guess.S = int(sizeof(Sample));
+        if (ntiles < 2) return false;      // (a single tile: the one-job call is the same launch)
         const size_t j = s.reserve(sizeof(havoc_mi355x_pair_job) * ntiles), o = s.reserve(4 * size_t(ntiles));
         const size_t pb = s.pack(pred, l.w, l.w, l.h, l.w);
         havoc_mi355x_pair_job *jobs = s.job<havoc_mi355x_pair_job>(j);
@@ -906,11 +1178,78 @@ bool serveTileSatd(const Sample *a, intptr_t sa, const Sample *b, intptr_t sb, i
     return true;
 }
 
+// Round 6: a prediction that takes the launch path (bi-prediction, chroma, references not registered yet) measures its tiles in the same wait -- against the block the
+// last measurement of a prediction of this size was made against (SourceGuess).  planTiles reserves the job table and the results BEFORE the prediction is launched (the
+// staging buffer must not move under a launch); launchTiles queues the SATD kernel behind the prediction kernel; keepTiles files the results once the call has waited.
+struct TilePlan
+{
+    bool on = false;
+    const Pic *q = nullptr;
+    int n = 0, ntiles = 0;
+    size_t jobs = 0, out = 0;
+};
+template <typename Sample>
+inline TilePlan planTiles(Stage &s, Serve &v, int w, int h)
+{
+    TilePlan t;
+    const SourceGuess &g = v.guess;
+    if (!g.valid || g.w != w || g.h != h || g.S != int(sizeof(Sample))) return t;
+    const Pic *q = findPic(g.block);
+    if (!q || q->S != int(sizeof(Sample)) || q->stride != g.stride) return t;
+    int x, y;
+    locate(q, g.block, &x, &y);
+    if (x < -q->pad || y < -q->pad || x + w > q->w + q->pad || y + h > q->h + q->pad) return t;
+    t.n = ((w | h) & 3) ? 2 : ((w | h) & 7) ? 4 : 8;      // Measure.h:97-135
+    t.ntiles = (w / t.n) * (h / t.n);
+    if (t.ntiles < 1 || t.ntiles > 256) return t;
+    t.q = q;
+    t.jobs = s.reserve(sizeof(havoc_mi355x_pair_job) * t.ntiles);
+    t.out = s.reserve(4 * size_t(t.ntiles));
+    const long so = (long)(y + q->pad) * q->stride + x + q->pad;
+    havoc_mi355x_pair_job *jobs = s.job<havoc_mi355x_pair_job>(t.jobs);
+    const int tilesX = w / t.n;
+    for (int k = 0; k < t.ntiles; ++k)
+    {
+        const int px = (k % tilesX) * t.n, py = (k / tilesX) * t.n;
+        jobs[k] = {int32_t(so + (long)py * q->stride + px), int32_t(py * w + px), t.n, t.n};
+    }
+    t.on = true;
+    return t;
+}
+template <typename Sample>
+inline void launchTiles(Stage &s, const TilePlan &t, size_t pred, int w)      // `pred`: where the prediction kernel just launched writes its w-pitch block
+{
+    if (!t.on) return;
+    CK(havoc_mi355x_satd(s.ctx, sizeof(Sample), t.n, t.n, t.q->d_plane, t.q->stride, s.d + pred, w, s.djob<havoc_mi355x_pair_job>(t.jobs), t.ntiles, (int32_t *)(s.d + t.out)));
+    bump(2);
+    bump(4);
+}
+inline void keepTiles(Stage &s, Serve &v, const TilePlan &t)      // after rememberPrediction
+{
+    if (!t.on) return;
+    LastPred &l = v.last;
+    l.tiles.assign(reinterpret_cast<int32_t *>(&s.h[t.out]), reinterpret_cast<int32_t *>(&s.h[t.out]) + t.ntiles);
+    l.measured = true;
+    l.n = t.n;
+    l.srcBlock = v.guess.block;
+    l.srcStride = v.guess.stride;
+}
+
 // ---- distortion metrics ---------------------------------------------------------------------------------------
+
+// a call that is not part of a unit's transform chain: whatever was read ahead for the unit before it is void
+inline void endTransformRun()
+{
+    static thread_local Serve *mine = nullptr;      // (serve() initialises per call: this is on every prediction / SAD / SATD call's path)
+    if (!mine) mine = &serve(stage());
+    mine->fwd.groupOpen = false;
+}
 
 template <typename Sample>
 int sad(const Sample *src, intptr_t ss, const Sample *ref, intptr_t rs, uint32_t rect)
 {
+    Site site_(kSad);
+    endTransformRun();
     const int w = rect >> 8, h = rect & 0xff;
     int served;
     if (serveSad<Sample>(src, ss, &ref, 1, rs, w, h, &served)) return served;
@@ -928,6 +1267,8 @@ int sad(const Sample *src, intptr_t ss, const Sample *ref, intptr_t rs, uint32_t
 template <typename Sample>
 void sad4(const Sample *src, intptr_t ss, const Sample *ref[], intptr_t rs, int out[], uint32_t rect)
 {
+    Site site_(kSad4);
+    endTransformRun();
     const int w = rect >> 8, h = rect & 0xff;
     if (serveSad<Sample>(src, ss, ref, 4, rs, w, h, out)) return;
     Stage &s = stage();
@@ -948,6 +1289,7 @@ void sad4(const Sample *src, intptr_t ss, const Sample *ref[], intptr_t rs, int 
 template <typename Sample>
 uint32_t ssd(const Sample *pa, intptr_t sa, const Sample *pb, intptr_t sb, int w, int h)
 {
+    Site site_(kSsd);
     uint32_t served;
     if (serveSsd<Sample>(pa, sa, pb, sb, w, h, &served)) return served;
     Stage &s = stage();
@@ -1011,6 +1353,8 @@ uint32_t ssd(const Sample *pa, intptr_t sa, const Sample *pb, intptr_t sb, int w
 template <typename Sample, int N>
 int satd(const Sample *pa, intptr_t sa, const Sample *pb, intptr_t sb)
 {
+    Site site_(kSatd);
+    endTransformRun();
     int served;
     if (serveSatd<Sample, N>(pa, sa, pb, sb, &served)) return served;
     if (serveIntraSatd<Sample, N>(pa, sa, pb, sb, &served)) return served;
@@ -1063,6 +1407,8 @@ size_t packWindow(Stage &s, const Sample *ref, intptr_t sr, int w, int h, int ta
 template <typename Sample, int TAPS>
 void predUni(Sample *dst, intptr_t sd, const Sample *ref, intptr_t sr, int w, int h, int xFrac, int yFrac, int bitDepth)
 {
+    Site site_(kPredUni);
+    endTransformRun();
     if (TAPS == 8 && servePredUni<Sample>(dst, sd, ref, sr, w, h, xFrac, yFrac, bitDepth)) return;
     Stage &s = stage();
     oneJob(kPredUni);
@@ -1070,17 +1416,23 @@ void predUni(Sample *dst, intptr_t sd, const Sample *ref, intptr_t sr, int w, in
     int pitch, origin;
     const size_t win = packWindow(s, ref, sr, w, h, TAPS, xFrac, yFrac, &pitch, &origin);
     const size_t out = s.reserve(sizeof(Sample) * size_t(w) * h);
+    Serve &v = serve(s);
+    const TilePlan tiles = TAPS == 8 ? planTiles<Sample>(s, v, w, h) : TilePlan();
     *s.job<havoc_mi355x_pred_uni_job>(j) = {0, origin, w, h, xFrac, yFrac, {0, 0}};
     s.upload();
     CK(havoc_mi355x_pred_uni(s.ctx, sizeof(Sample), TAPS, bitDepth, w, h, s.d + out, w, s.d + win, pitch, s.djob<havoc_mi355x_pred_uni_job>(j), 1));
+    launchTiles<Sample>(s, tiles, out, w);
     s.unpack(dst, sd, w, h, w, out);
     rememberPrediction(dst, sd, w, h);
+    keepTiles(s, v, tiles);
 }
 
 template <typename Sample, int TAPS>
 void predBi(Sample *dst, intptr_t sd, const Sample *ref0, const Sample *ref1, intptr_t sr, int w, int h, int xFrac0, int yFrac0, int xFrac1, int yFrac1,
             int bitDepth)
 {
+    Site site_(kPredBi);
+    endTransformRun();
     Stage &s = stage();
     oneJob(kPredBi);
     const size_t j = s.reserve(sizeof(havoc_mi355x_pred_bi_job));
@@ -1088,17 +1440,22 @@ void predBi(Sample *dst, intptr_t sd, const Sample *ref0, const Sample *ref1, in
     const size_t w0 = packWindow(s, ref0, sr, w, h, TAPS, xFrac0, yFrac0, &pitch, &origin);
     const size_t w1 = packWindow(s, ref1, sr, w, h, TAPS, xFrac1, yFrac1, &pitch, &origin);
     const size_t out = s.reserve(sizeof(Sample) * size_t(w) * h);
+    Serve &v = serve(s);
+    const TilePlan tiles = TAPS == 8 ? planTiles<Sample>(s, v, w, h) : TilePlan();
     havoc_mi355x_pred_bi_job job = {0, origin, int32_t((w1 - w0) / sizeof(Sample)) + origin, w, h, xFrac0, yFrac0, xFrac1, yFrac1, {0, 0, 0}};
     *s.job<havoc_mi355x_pred_bi_job>(j) = job;
     s.upload();
     CK(havoc_mi355x_pred_bi(s.ctx, sizeof(Sample), TAPS, bitDepth, w, h, s.d + out, w, s.d + w0, pitch, s.djob<havoc_mi355x_pred_bi_job>(j), 1));
+    launchTiles<Sample>(s, tiles, out, w);
     s.unpack(dst, sd, w, h, w, out);
     rememberPrediction(dst, sd, w, h);
+    keepTiles(s, v, tiles);
 }
 
 template <typename Sample>
 void subtractBi(Sample *dst, intptr_t sd, const Sample *pred, intptr_t sp, const Sample *src, intptr_t ss, int w, int h, int bitDepth)
 {
+    Site site_(kSubtractBi);
     Stage &s = stage();
     oneJob(kSubtractBi);
     const size_t j = s.reserve(sizeof(havoc_mi355x_subtract_bi_job));
@@ -1115,7 +1472,9 @@ void subtractBi(Sample *dst, intptr_t sd, const Sample *pred, intptr_t sp, const
 template <typename Sample, int BITDEPTH, int LOG2, bool EDGE>
 void intraPredict(Sample *dst, intptr_t sd, const Sample *neighbours, int mode)
 {
+    Site site_(kIntra);
     constexpr int n = 1 << LOG2;
+    endTransformRun();
     if (serveIntra<Sample, BITDEPTH, LOG2, EDGE>(dst, sd, neighbours, mode)) return;
     Stage &s = stage();
     oneJob(kIntra);
@@ -1130,30 +1489,173 @@ void intraPredict(Sample *dst, intptr_t sd, const Sample *neighbours, int mode)
 
 // ---- transforms and quantisation ------------------------------------------------------------------------------
 
+// the de-quantiser's table for (scale, shift): tab[(uint16_t)level] = havoc_quantize_inverse(level), every entry computed by the device kernel
+const int16_t *dequantTable(int scale, int shift)
+{
+    Binding *b = g_live.load(std::memory_order_acquire);
+    if (!b) return nullptr;
+    static thread_local const Binding::DeqTab *last = nullptr;
+    static thread_local const Binding *lastOwner = nullptr;
+    if (lastOwner == b && last && last->scale == scale && last->shift == shift) return last->tab;
+    auto find = [&]() -> const Binding::DeqTab * {
+        for (const Binding::DeqTab *t = b->deq.load(std::memory_order_acquire); t; t = t->next)
+            if (t->scale == scale && t->shift == shift) return t;
+        return nullptr;
+    };
+    const Binding::DeqTab *t = find();
+    if (!t)
+    {
+        std::lock_guard<std::mutex> lock(b->mu);
+        t = find();
+        if (!t)
+        {
+            constexpr int kLevels = 65536, kJobs = 64;
+            if (!b->deqRampH)
+            {
+                void *h_ = nullptr, *d_ = nullptr;
+                CK(havoc_mi355x_host_alloc(b->ctx, sizeof(int16_t) * kLevels, &h_, &d_));
+                b->deqRampH = static_cast<int16_t *>(h_);
+                b->deqRampD = static_cast<int16_t *>(d_);
+                for (int k = 0; k < kLevels; ++k) b->deqRampH[k] = int16_t(uint16_t(k));
+            }
+            void *h_ = nullptr, *d_ = nullptr;
+            CK(havoc_mi355x_host_alloc(b->ctx, sizeof(int16_t) * kLevels + sizeof(havoc_mi355x_quant_job) * kJobs, &h_, &d_));
+            havoc_mi355x_quant_job *jobs = reinterpret_cast<havoc_mi355x_quant_job *>(static_cast<char *>(h_) + sizeof(int16_t) * kLevels);
+            for (int k = 0; k < kJobs; ++k) jobs[k] = {k * (kLevels / kJobs), k * (kLevels / kJobs), kLevels / kJobs, scale, shift, 0, {0, 0}};
+            CK(havoc_mi355x_quantize_inverse(b->ctx, static_cast<int16_t *>(d_), b->deqRampD,
+                                             reinterpret_cast<const havoc_mi355x_quant_job *>(static_cast<char *>(d_) + sizeof(int16_t) * kLevels), kJobs));
+            CK(havoc_mi355x_sync(b->ctx));
+            b->stat[2].fetch_add(1, std::memory_order_relaxed);
+            Binding::DeqTab *n = new Binding::DeqTab{scale, shift, static_cast<int16_t *>(h_), b->deq.load(std::memory_order_relaxed)};
+            b->deq.store(n, std::memory_order_release);
+            t = n;
+        }
+    }
+    last = t;
+    lastOwner = b;
+    return t->tab;
+}
+
+// launches havoc_mi355x_transform for `count` residual blocks of one (size, type) class packed n x n in pinned memory; jobs at v.fwd.jobsH + at
+inline void launchForwardClass(Stage &s, Serve &v, int bd, int tr, int log2, int16_t *const *res, int16_t *const *coef, int count, int at)
+{
+    havoc_mi355x_tu_job *jobs = reinterpret_cast<havoc_mi355x_tu_job *>(v.fwd.jobsH) + at;
+    const int n = 1 << log2;
+    const int16_t *base = reinterpret_cast<const int16_t *>(v.baseH);      // offsets are int16 indices into the thread's pinned arena
+    for (int k = 0; k < count; ++k) jobs[k] = {int32_t(coef[k] - base), int32_t(res[k] - base), 0, 0};
+    CK(havoc_mi355x_transform(s.ctx, bd, tr, log2, reinterpret_cast<int16_t *>(v.baseD), reinterpret_cast<const int16_t *>(v.baseD), n,
+                              reinterpret_cast<const havoc_mi355x_tu_job *>(v.dev(jobs)), count));
+    bump(2);
+}
+
 template <int BITDEPTH, int LOG2, int TR>
 void forwardTransform(int16_t *coeffs, const int16_t *src, intptr_t stride)
 {
+    Site site_(kTransform);
     constexpr int n = 1 << LOG2;
     if (serveForward<BITDEPTH, LOG2, TR>(coeffs, src, stride)) return;
     Stage &s = stage();
-    oneJob(kTransform);
-    serve(s).imemo.valid = false;      // not the residual of the intra prediction last served: the de-quantiser call that follows is not that candidate's
+    Serve &v = serve(s);
+    if (v.imemo.valid && (LOG2 == 2 || TR == 0) && (!v.imemo.set->measured || v.imemo.set->ownSource || v.imemo.set->guessed) && measureFromResidual<BITDEPTH, LOG2>(s, v, src, stride) &&
+        serveForward<BITDEPTH, LOG2, TR>(coeffs, src, stride))
+        return;
+    v.imemo.valid = false;      // not the residual of the intra prediction last served: the de-quantiser call that follows is not that candidate's
     {
-        InterAhead &ia = serve(s).inter;
+        InterAhead &ia = v.inter;
         ia.haveRes = true;
         ia.valid = false;
         ia.resN = n;
         ia.res.resize(n * n);
         for (int y = 0; y < n; ++y) memcpy(&ia.res[y * n], src + y * stride, sizeof(int16_t) * n);
     }
-    const size_t j = s.reserve(sizeof(havoc_mi355x_tu_job));
-    const size_t r = s.pack(src, stride, n, n, n);
-    const size_t out = s.reserve(2 * n * n);
-    *s.job<havoc_mi355x_tu_job>(j) = {0, 0, 0, 0};
-    s.upload();
-    CK(havoc_mi355x_transform(s.ctx, BITDEPTH, TR, LOG2, (int16_t *)(s.d + out), (const int16_t *)(s.d + r), n, s.djob<havoc_mi355x_tu_job>(j), 1));
-    s.download(out, 2 * n * n);
-    memcpy(coeffs, &s.h[out], 2 * n * n);
+    FwdState &fs = v.fwd;
+    FwdKey key;
+    key.ptr = src; key.stride = stride; key.log2 = LOG2; key.tr = TR; key.bd = BITDEPTH;
+    auto record = [&]() {      // this call followed the run's first block: the first block's next occurrence reads it ahead
+        if (fs.cur < 0) return;
+        FwdHead &h = fs.heads[fs.cur];
+        for (int k = 0; k < h.nf; ++k)
+            if (h.f[k].same(key)) return;
+        if (h.nf < kFwdFollowers && !h.key.same(key)) h.f[h.nf++] = key;
+    };
+    if (fs.groupOpen)
+    {
+        for (auto &e : fs.spec)
+            if (e.valid && e.key.same(key))
+            {
+                e.valid = false;
+                bool equal = true;
+                for (int y = 0; y < n && equal; ++y) equal = !memcmp(src + y * stride, e.res + y * n, sizeof(int16_t) * n);
+                if (!equal) break;
+                memcpy(coeffs, e.coef, sizeof(int16_t) * n * n);
+                record();
+                bump(0);
+                return;
+            }
+        record();
+    }
+    oneJob(kTransform);
+    // the blocks to transform in this wait: the one asked for, and -- when it opens a run -- those that followed it the last time
+    int16_t *res[kFwdFollowers + 1], *coef[kFwdFollowers + 1];
+    FwdKey keys[kFwdFollowers + 1];
+    int count = 1;
+    keys[0] = key;
+    res[0] = fs.headRes;
+    coef[0] = fs.headCoef;
+    for (int y = 0; y < n; ++y) memcpy(fs.headRes + y * n, src + y * stride, sizeof(int16_t) * n);
+    if (!fs.groupOpen)
+    {
+        for (auto &e : fs.spec) e.valid = false;
+        int at = -1, lru = 0;
+        for (int k = 0; k < kFwdHeads; ++k)
+            if (fs.heads[k].valid && fs.heads[k].key.same(key)) at = k;
+            else if (!fs.heads[k].valid || (fs.heads[lru].valid && fs.heads[k].stamp < fs.heads[lru].stamp)) lru = k;
+        if (at < 0)
+        {
+            at = lru;
+            fs.heads[at] = FwdHead();
+            fs.heads[at].valid = true;
+            fs.heads[at].key = key;
+        }
+        FwdHead &h = fs.heads[at];
+        h.stamp = ++v.clock;
+        for (int k = 0; k < h.nf; ++k)
+        {
+            FwdSpec &e = fs.spec[k];
+            const int m = 1 << h.f[k].log2;
+            for (int y = 0; y < m; ++y) memcpy(e.res + y * m, h.f[k].ptr + y * h.f[k].stride, sizeof(int16_t) * m);
+            e.key = h.f[k];
+            e.valid = true;
+            keys[count] = h.f[k];
+            res[count] = e.res;
+            coef[count] = e.coef;
+            ++count;
+        }
+        h.nf = 0;      // recorded again by the calls that follow
+        fs.cur = at;
+        fs.groupOpen = true;
+    }
+    // one launch per (size, type) class among them
+    bool done[kFwdFollowers + 1] = {};
+    int at = 0;
+    for (int k = 0; k < count; ++k)
+    {
+        if (done[k]) continue;
+        int16_t *r[kFwdFollowers + 1], *c[kFwdFollowers + 1];
+        int m = 0;
+        for (int q = k; q < count; ++q)
+            if (!done[q] && keys[q].log2 == keys[k].log2 && keys[q].tr == keys[k].tr && keys[q].bd == keys[k].bd)
+            {
+                done[q] = true;
+                r[m] = res[q];
+                c[m] = coef[q];
+                ++m;
+            }
+        launchForwardClass(s, v, keys[k].bd, keys[k].tr, keys[k].log2, r, c, m, at);
+        at += m;
+    }
+    waitFor(s.ctx);
+    memcpy(coeffs, fs.headCoef, sizeof(int16_t) * n * n);
 }
 
 template <int LOG2, int TR>
@@ -1175,6 +1677,7 @@ void inverseTransform(int16_t dst[], int16_t const coeffs[], int bitDepth)
 template <typename Sample, int LOG2, int TR>
 void inverseTransformAdd(Sample *dst, intptr_t sd, Sample const *pred, intptr_t sp, int16_t const coeffs[], int bitDepth)
 {
+    Site site_(kInverseAdd);
     constexpr int n = 1 << LOG2;
     if (serveInverseAdd<Sample, LOG2, TR>(dst, sd, pred, sp, coeffs, bitDepth)) return;
     Stage &s = stage();
@@ -1242,21 +1745,49 @@ void inverseTransformAdd(Sample *dst, intptr_t sd, Sample const *pred, intptr_t 
     }
 }
 
+// Round 6.  The de-quantiser is answered from the device-made table of its (scale, shift) pair -- but for an intra candidate with levels (prediction and source on the
+// device): its call stays a launch, with the candidate's inverse transform + add + SSD in the same wait (Reconstruct.cpp:314-353).  An intra candidate WITHOUT a level is
+// reconstructed already: the 35-mode stage made every mode's zero-level reconstruction and SSD.
 void quantizeInverse(int16_t *dst, const int16_t *src, int scale, int shift, int n)
 {
+    Site site_(kDequant);
     Stage &s = stage();
     Serve &v = serve(s);
-    oneJob(kDequant);
-    const size_t j = s.reserve(sizeof(havoc_mi355x_quant_job));
+    const IntraMemo &m = v.imemo;
+    const bool intraCandidate = m.valid && m.set->measured && n == (1 << (2 * m.set->log2)) && sourceStillRegistered(m.set);
+    bool anyLevel = false;
+    for (int i = 0; i < n && !anyLevel; ++i) anyLevel = src[i] != 0;
+    if (!intraCandidate || !anyLevel)
+    {
+        const int16_t *tab = dequantTable(scale, shift);
+        for (int i = 0; i < n; ++i) dst[i] = tab[uint16_t(src[i])];
+        v.chain.valid = false;
+        if (intraCandidate)
+        {
+            IntraSet *f = m.set;
+            const int nn = 1 << f->log2;
+            v.chain.valid = true;
+            v.chain.set = f;
+            v.chain.slot = m.slot;
+            v.chain.tr = m.tr;
+            v.chain.recDst = nullptr;
+            v.chain.recAt = f->rec0 + size_t(m.slot) * nn * nn * f->S;
+            v.chain.ssdAt = f->ssd0 + m.slot;
+            memcpy(v.chain.deq, dst, 2 * n);
+        }
+        bump(0);
+        return;
+    }
+    // an intra candidate with levels: the values from the table like every other call; what is launched and waited for is the candidate's reconstruction and SSD from
+    // its LEVELS (havoc_mi355x_tu_reconstruct de-quantises them itself), which the inverse_transform_add and ssd calls that follow are answered from
+    const int16_t *tab = dequantTable(scale, shift);
+    for (int i = 0; i < n; ++i) dst[i] = tab[uint16_t(src[i])];
     const size_t in = s.pack(src, 0, n, 1, n);
-    const size_t out = s.reserve(2 * n);
-    *s.job<havoc_mi355x_quant_job>(j) = {0, 0, n, scale, shift, 0, {0, 0}};
     s.upload();
-    CK(havoc_mi355x_quantize_inverse(s.ctx, (int16_t *)(s.d + out), (const int16_t *)(s.d + in), s.djob<havoc_mi355x_quant_job>(j), 1));
-    chainAhead(s, v, s.d + in, scale, shift, n);      // an intra candidate: its reconstruction and SSD in the same wait
-    s.download(out, 2 * n);
-    memcpy(dst, &s.h[out], 2 * n);
-    if (v.chain.valid) memcpy(v.chain.deq, &s.h[out], 2 * n);
+    chainAhead(s, v, s.d + in, scale, shift, n);
+    s.wait();
+    if (v.chain.valid) memcpy(v.chain.deq, dst, 2 * n);
+    bump(0);
 }
 
 int quantize(int16_t *dst, const int16_t *src, int scale, int shift, int offset, int n)
@@ -1377,10 +1908,16 @@ void havoc_delete_code(havoc_code code)
         fprintf(stderr, "libhavoc_classic: table calls served %lld, one-job launches %lld, launches %lld, surfaces %lld, tile-SATD batches %lld, pictures %lld\n",
                 (long long)b->stat[0], (long long)b->stat[1], (long long)b->stat[2], (long long)b->stat[3], (long long)b->stat[4], (long long)b->stat[5]);
     if (getenv("HAVOC_CLASSIC_REPORT"))
+        fprintf(stderr, "libhavoc_classic: waits %lld (%.3f s in them, all threads); 35-mode stages at a guessed position %lld, right %lld\n", (long long)b->stat[10], double(b->stat[11]) * 1e-9, (long long)b->stat[8], (long long)b->stat[9]);
+    if (getenv("HAVOC_CLASSIC_REPORT"))
     {
         fprintf(stderr, "libhavoc_classic: one-job launches by entry point:");
         for (int k = 0; k < 15; ++k)
             if (b->oneJob[k].load()) fprintf(stderr, " %s %lld", kOneJobNames[k], (long long)b->oneJob[k].load());
+        fprintf(stderr, "\n");
+        fprintf(stderr, "libhavoc_classic: waits / launches by entry point:");
+        for (int k = 0; k < 16; ++k)
+            if (b->waitsBy[k].load() || b->launchesBy[k].load()) fprintf(stderr, " %s %lld/%lld", k < 15 ? kOneJobNames[k] : "other", (long long)b->waitsBy[k].load(), (long long)b->launchesBy[k].load());
         fprintf(stderr, "\n");
     }
     g_live.store(nullptr, std::memory_order_release);
@@ -1389,6 +1926,14 @@ void havoc_delete_code(havoc_code code)
         for (const auto &q : *l) releasePic(b, q.get());
     for (const PicList *l : b->retired) delete l;
     delete b->pics.load();
+    for (Binding::DeqTab *t = b->deq.load(); t;)
+    {
+        Binding::DeqTab *next = t->next;
+        (void)havoc_mi355x_host_free(b->ctx, t->tab);
+        delete t;
+        t = next;
+    }
+    if (b->deqRampH) (void)havoc_mi355x_host_free(b->ctx, b->deqRampH);
     havoc_mi355x_destroy(b->ctx);
     delete b;
     g_binding = nullptr;

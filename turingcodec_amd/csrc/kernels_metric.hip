@@ -693,7 +693,8 @@ __device__ __forceinline__ void sad4_run_general(RunLds<S> &sh, const char *__re
     const int rowBytes = w * S;
     const long ssb = stride_src * S, rsb = stride_ref * S;
     const bool chunked = (rowBytes & 15) == 0 ? rowBytes <= 16 * kSadLanes : (rowBytes & 7) == 0 ? rowBytes <= 8 * kSadLanes : (rowBytes & 3) == 0 && rowBytes <= 4 * kSadLanes;
-    const bool srcScalar = U == 0 && SRCG && ((((long)so * S) | ssb) & 3) == 0;      // the source block's rows at dword-aligned addresses: scalar loads
+    // the source block's rows at dword-aligned ADDRESSES (base pointer included: scalar loads ignore the low address bits -- ADVICE r5): scalar loads
+    const bool srcScalar = U == 0 && SRCG && (((reinterpret_cast<uintptr_t>(src) + (long)so * S) | ssb) & 3) == 0;
     const bool given = boxW > 0 && boxH > 0 && boxW < st;      // the cutter's box (havoc_mi355x_sad4_make_runs): staged at once, every candidate then checked against it
     int mndx = 0, mndy = 0, spanx, spready, ok = count <= kRunMax;
     long minoff;

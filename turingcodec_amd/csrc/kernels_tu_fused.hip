@@ -227,6 +227,139 @@ __global__ __launch_bounds__(64) void k_tu_reconstruct(char *rec, long stride_re
     if (live && r == 0) ssd[job] = tot;
 }
 
+// The 35-mode stage of ONE intra partition in one launch (round 6; the per-block table API's serve layer, csrc/classic.cpp): job i = mode slot i of the partition --
+// its prediction block (pred_off, row stride stride_pred) against the partition's source block (src_off) -- and per job
+//   satd[i * tiles + t]   havoc_hadamard_satd of tile t (8x8 tiles; 4x4 for a 4x4 partition), raster order          = havoc_mi355x_satd on those tiles
+//   coeffs[coef_off ..]   forward transform of source - prediction, DST-VII for 4x4 / DCT above (Reconstruct.cpp:263)  = havoc_mi355x_tu_forward
+//   coeffsDct[coef_off ..] 4x4 only: the DCT of the same residual (a chroma block's type)                              = havoc_mi355x_tu_forward, trType 0
+//   rec0[rec_off ..], ssd0[i]  the reconstruction from a block of ZERO levels and its SSD against the source           = havoc_mi355x_tu_reconstruct on zero levels
+// (de-quantised zeros are zeros and their inverse transform rounds to zero, so the reconstruction is the clipped prediction; the SSD as havoc_ssd: 16-bit >> 4).
+// Same mapping as k_tu_forward -- a lane per row, 64 / N blocks per wavefront -- whose residual rows are exactly what the tile SATDs and the SSD need.
+template <int S, int LOG2>
+__global__ __launch_bounds__(64) void k_intra_measure(int16_t *__restrict__ coeffs, int16_t *__restrict__ coeffsDct, int32_t *__restrict__ satd, char *__restrict__ rec0,
+                                                      uint32_t *__restrict__ ssd0, const char *__restrict__ src, long stride_src, const char *__restrict__ pred,
+                                                      long stride_pred, const int32_t *__restrict__ jobs, int njobs, int bitDepth, int withSatd)
+{
+    typedef typename Sample<S>::T T;
+    constexpr int N = 1 << LOG2, TPW = 64 / N, LS = N + 2, TS = N >= 8 ? 8 : 4, TX = N / TS, TILES = TX * TX;
+    __shared__ int16_t lds[TPW][N * LS];
+    const int t = threadIdx.x / N, r = threadIdx.x % N;
+    const int job = blockIdx.x * TPW + t;
+    const bool live = job < njobs;
+    const int32_t *j = jobs + (long)(live ? job : 0) * 4;
+    const int shift1 = LOG2 - 1 + bitDepth - 8, shift2 = LOG2 + 6;
+
+    uint32_t row[N / 2], prow[N / 2];
+    load_sample_row<S, N>(src + ((long)j[1] + (long)r * stride_src) * S, row);
+    load_sample_row<S, N>(pred + ((long)j[2] + (long)r * stride_pred) * S, prow);
+    // zero-level reconstruction = the prediction, clipped like inverse_transform_add's output
+    if (live)
+    {
+        const int maxv = (1 << bitDepth) - 1;
+        T *q = reinterpret_cast<T *>(rec0) + j[3] + (long)r * N;
+#pragma unroll
+        for (int p = 0; p < N / 2; ++p)
+        {
+            q[2 * p] = (T)clip3(0, maxv, (int)(prow[p] & 0xffff));
+            q[2 * p + 1] = (T)clip3(0, maxv, (int)(prow[p] >> 16));
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < N / 2; ++p) row[p] = pk_sub(row[p], prow[p]);   // residual (|.| <= 1023: no 16-bit overflow)
+    // SSD(source, zero-level reconstruction): the prediction is inside the sample range, so the difference is the residual
+    {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int p = 0; p < N / 2; ++p)
+        {
+            const int lo = (int16_t)(row[p] & 0xffff), hi = (int16_t)(row[p] >> 16);
+            acc += (uint32_t)(lo * lo) + (uint32_t)(hi * hi);
+        }
+        uint32_t tot = (uint32_t)group_sum<N>((int)acc);
+        if (S == 2) tot >>= 4;
+        if (live && r == 0) ssd0[job] = tot;
+    }
+    if (withSatd)      // (uniform)
+    {
+#pragma unroll
+        for (int tx = 0; tx < TX; ++tx)
+        {
+            int c;
+            if (S == 1)
+            {
+                uint32_t p[TS / 2];
+#pragma unroll
+                for (int k = 0; k < TS / 2; ++k) p[k] = row[tx * (TS / 2) + k];
+                c = satd_rows_pk<TS>(p, r & (TS - 1));
+            }
+            else
+            {
+                int d[TS];
+#pragma unroll
+                for (int k = 0; k < TS / 2; ++k)
+                {
+                    d[2 * k] = (int16_t)(row[tx * (TS / 2) + k] & 0xffff);
+                    d[2 * k + 1] = (int16_t)(row[tx * (TS / 2) + k] >> 16);
+                }
+                c = satd_rows<S, TS>(d, r & (TS - 1));
+            }
+            if (live && (r & (TS - 1)) == 0) satd[(long)job * TILES + (r / TS) * TX + tx] = c;
+        }
+    }
+    uint32_t keep[N / 2];
+#pragma unroll
+    for (int p = 0; p < N / 2; ++p) keep[p] = row[p];
+    int o[N];
+    constexpr int TR = LOG2 == 2 ? 1 : 0;
+    basis_times_row<N, TR, false, true>(row, 1 << (shift1 - 1), o);
+#pragma unroll
+    for (int k = 0; k < N; ++k) lds[t][k * LS + r] = (int16_t)(o[k] >> shift1);
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < N / 2; ++p) row[p] = *reinterpret_cast<const uint32_t *>(&lds[t][r * LS + 2 * p]);
+    basis_times_row<N, TR, false>(row, 1 << (shift2 - 1), o);
+    if (live)
+    {
+        int16_t *c = coeffs + j[0] + r;
+#pragma unroll
+        for (int k = 0; k < N; ++k) c[k * N] = (int16_t)(o[k] >> shift2);
+    }
+    if (LOG2 == 2)
+    {
+        __syncthreads();
+        basis_times_row<N, 0, false, true>(keep, 1 << (shift1 - 1), o);
+#pragma unroll
+        for (int k = 0; k < N; ++k) lds[t][k * LS + r] = (int16_t)(o[k] >> shift1);
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < N / 2; ++p) row[p] = *reinterpret_cast<const uint32_t *>(&lds[t][r * LS + 2 * p]);
+        basis_times_row<N, 0, false>(row, 1 << (shift2 - 1), o);
+        if (live)
+        {
+            int16_t *c = coeffsDct + j[0] + r;
+#pragma unroll
+            for (int k = 0; k < N; ++k) c[k * N] = (int16_t)(o[k] >> shift2);
+        }
+    }
+}
+
+hipError_t launch_intra_measure(hipStream_t st, int S, int bd, int log2, int16_t *coeffs, int16_t *coeffsDct, int32_t *satd, void *rec0, uint32_t *ssd0, const void *src,
+                                long ss, const void *pred, long sp, const void *jobs, int n, int withSatd)
+{
+    if (n <= 0) return hipSuccess;
+    if (log2 < 2 || log2 > 5) return hipErrorInvalidValue;
+    const int tpw = 64 >> log2;
+    const dim3 g((n + tpw - 1) / tpw), b(64);
+    char *r0 = (char *)rec0;
+    const char *s8 = (const char *)src, *p8 = (const char *)pred;
+    const int32_t *j = (const int32_t *)jobs;
+#define MEASURE_GO(SS, LL) hipLaunchKernelGGL((k_intra_measure<SS, LL>), g, b, 0, st, coeffs, coeffsDct, satd, r0, ssd0, s8, ss, p8, sp, j, n, bd, withSatd)
+    if (S == 1) { if (log2 == 2) MEASURE_GO(1, 2); else if (log2 == 3) MEASURE_GO(1, 3); else if (log2 == 4) MEASURE_GO(1, 4); else MEASURE_GO(1, 5); }
+    else { if (log2 == 2) MEASURE_GO(2, 2); else if (log2 == 3) MEASURE_GO(2, 3); else if (log2 == 4) MEASURE_GO(2, 4); else MEASURE_GO(2, 5); }
+#undef MEASURE_GO
+    return hipGetLastError();
+}
+
 template <int S, int LOG2, int TR>
 static void go_fwd(hipStream_t st, int16_t *co, const char *src, long ss, const char *pred, long sp, const int32_t *j, int n, int bd)
 {

@@ -1004,18 +1004,26 @@ class DecisionPicture:
         if on_queued is not None:
             on_queued()
         if not wait:
-            return None
+            return None      # the caller MUST call check_banded() after its own synchronisation: a wait that gave up leaves a wrong reconstruction and no error
         if self.intra_parts:
             self.intra_decisions()
         hv.sync()
         side.sync()
-        if int(hv.down(D["gave_up"], np.int32)[0]) or int(hv.down(D["work"], np.int32)[-1]):
-            raise RuntimeError("step_banded: a wait on the search's progress gave up")
+        self.check_banded()
         self._merge = self._rqt = self._cells = None
         res = hv.down(D["out"], np.uint8).view(RESULT_DT)
         self.bi_results = hv.down(D["bi"], np.uint8).view(RESULT_DT)
         field = hv.down(self.d_field, np.int16).reshape(2, (H + 3) // 4, (W + 3) // 4, 2)
         return res, field, None
+
+    def check_banded(self):
+        """after step_banded (wait=False: after the caller's own synchronisation of both streams): raises if a device-side wait on the search's progress gave up (a side
+        stream sharing a hardware queue with the search it waits for, ~4-8 s) -- the band's launches then ran on unfinished rows"""
+        D = getattr(self, "_dsearch", None)
+        if D is None:
+            return
+        if int(self.hv.down(D["gave_up"], np.int32)[0]) or int(self.hv.down(D["work"], np.int32)[-1]):
+            raise RuntimeError("step_banded: a wait on the search's progress gave up; the picture's reconstruction is not to be used")
 
     def results(self):
         """what the TU chain left on the device, as numpy (per group): coefficients, levels, flags, SSDs; and the reconstruction"""

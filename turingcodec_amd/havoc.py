@@ -101,6 +101,7 @@ def _load():
         "inverse_transform_add": [_vp, _i, _i, _i, _i, _vp, _ip, _vp, _ip, _vp, _vp, _i],
         "tu_forward": [_vp, _i, _i, _i, _i, _vp, _vp, _ip, _vp, _ip, _vp, _i],
         "tu_reconstruct": [_vp, _i, _i, _i, _i, _i, _i, _vp, _ip, _vp, _ip, _vp, _ip, _vp, _vp, _i, _vp],
+        "intra_measure": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _ip, _vp, _ip, _vp, _i, _i],
         "level_stats": [_vp, _vp, _vp, _i, _vp],
         "search_motion_uni": [_vp, _i, _vp, _vp, C.c_int64, _ip, _vp, C.c_int64, _ip, _vp, _ip, C.c_int64, _vp, _i, _vp],
         "rqt_decide": [_vp, _vp, _i, _vp, _vp, _vp, C.c_int64, C.c_ssize_t, _i, _i, _vp],
@@ -521,6 +522,13 @@ class Havoc:
     def tu_reconstruct_d(self, bd, tr, log2, scale, shift, rec, sr, pred, sp, src, ss, levels, jobs, ssd):
         self._ck(self.L.havoc_mi355x_tu_reconstruct(self.h, self._S(src), bd, tr, log2, scale, shift, _ptr(rec), sr, _ptr(pred), sp, _ptr(src), ss,
                                                     _ptr(levels), _ptr(jobs), jobs.shape[0], _ptr(ssd)))
+
+    def intra_measure_d(self, bd, log2, coeffs, coeffs_dct, satd, rec0, ssd0, src, ss, pred, sp, jobs, with_satd=True):
+        """the 35-mode stage of one intra partition in one launch (csrc/kernels_tu_fused.hip k_intra_measure): per job the tile SATDs, the forward transform
+        (DST-VII for 4x4, plus the 4x4 DCT in coeffs_dct), and the reconstruction from zero levels with its SSD"""
+        self._ck(self.L.havoc_mi355x_intra_measure(self.h, self._S(src), bd, log2, _ptr(coeffs), _ptr(coeffs_dct) if coeffs_dct is not None else None,
+                                                   _ptr(satd) if satd is not None else None, _ptr(rec0), _ptr(ssd0), _ptr(src), ss, _ptr(pred), sp, _ptr(jobs),
+                                                   jobs.shape[0], 1 if with_satd else 0))
 
     def level_stats_d(self, levels, jobs, njobs, out):
         """jobs: int32 [njobs, 2] (offset, count) into `levels`; out: int32 [2 * njobs] (non-zero levels, sum of magnitudes)"""
