@@ -43,6 +43,9 @@ int havoc_mi355x_create(havoc_mi355x_ctx **ctx, int device, void *stream);
 void havoc_mi355x_destroy(havoc_mi355x_ctx *ctx);
 int havoc_mi355x_set_stream(havoc_mi355x_ctx *ctx, void *stream);
 int havoc_mi355x_sync(havoc_mi355x_ctx *ctx);
+/* the same wait for a caller that queued microseconds of work and needs it now (a table call of libhavoc_classic.so): the stream writes a sequence number into pinned
+ * memory behind the queued work and the calling thread POLLS it (bounded: falls back to havoc_mi355x_sync after ~2 ms, and with forked lanes) */
+int havoc_mi355x_sync_spin(havoc_mi355x_ctx *ctx);
 const char *havoc_mi355x_last_error(void);
 const char *havoc_mi355x_version(void);
 /* device properties for roofline accounting: [0]=CUs [1]=clock kHz [2]=memory clock kHz [3]=bus width bits

@@ -141,6 +141,7 @@ void havoc_mi355x_destroy(havoc_mi355x_ctx *ctx)
             (void)hipEventDestroy(ctx->laneEv[k]);
         }
     if (ctx->forkEv) (void)hipEventDestroy(ctx->forkEv);
+    if (ctx->flagH) (void)hipHostFree(const_cast<uint32_t *>(ctx->flagH));
     if (ctx->ownsStream) (void)hipStreamDestroy(ctx->stream);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
@@ -162,6 +163,44 @@ int havoc_mi355x_sync(havoc_mi355x_ctx *ctx)
     {
         const int rc = check(hipStreamSynchronize(ctx->lanes[k]), "hipStreamSynchronize(lane)");
         if (rc) return rc;
+    }
+    return check(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+}
+
+// The wait of a caller that launched a few microseconds of work and needs the result NOW (libhavoc_classic.so's table calls): the stream writes a sequence number
+// into pinned memory behind the work queued so far and the calling thread polls that word -- hipStreamSynchronize costs ~10 us of its own on this stack, a polled
+// word is seen ~1-2 us after the kernel ends.  Bounded: after ~2 ms of polling (or if the write cannot be queued) it falls back to hipStreamSynchronize, which is
+// also what reports a device fault.
+int havoc_mi355x_sync_spin(havoc_mi355x_ctx *ctx)
+{
+    REQUIRE_CTX();
+    if (ctx->nlanes > 1) return havoc_mi355x_sync(ctx);
+    if (!ctx->flagH)
+    {
+        void *h = nullptr, *d = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&d, h, 0) != hipSuccess)
+        {
+            (void)hipGetLastError();
+            return check(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+        }
+        memset(h, 0, 64);
+        ctx->flagH = static_cast<volatile uint32_t *>(h);
+        ctx->flagD = d;
+    }
+    const uint32_t want = ++ctx->flagSeq;
+    if (hipStreamWriteValue32(ctx->stream, ctx->flagD, want, 0) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        return check(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    }
+    for (int spins = 0; spins < (1 << 18); ++spins)
+    {
+        if (*ctx->flagH == want)
+        {
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            return 0;
+        }
+        __builtin_ia32_pause();
     }
     return check(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
 }

@@ -155,12 +155,12 @@ inline void waitFor(havoc_mi355x_ctx *ctx)
     {
         timespec t0, t1;
         clock_gettime(CLOCK_MONOTONIC, &t0);
-        CK(havoc_mi355x_sync(ctx));
+        CK(havoc_mi355x_sync_spin(ctx));
         clock_gettime(CLOCK_MONOTONIC, &t1);
         bump(11, (t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec));
     }
     else
-        CK(havoc_mi355x_sync(ctx));
+        CK(havoc_mi355x_sync_spin(ctx));
     bump(10);
 }
 
@@ -485,21 +485,28 @@ struct FwdState
     char *jobsH = nullptr;                              // pinned: tu jobs of the launches
 };
 
-// where the source block of this thread's last tile-SATD measurement lay: a search measures candidate after candidate of one PU against the same source block, so the
-// prediction launch of the next candidate takes its tiles' SATDs against that block along (one wait instead of two); used only if the first tile call names that block
-struct SourceGuess
+// Round 6.  measurePuCost predicts a PU's luma, Cb and Cr into the reconstructed picture and THEN measures the three SATDs tile by tile against the source picture at the
+// same coordinates (Search.hpp:1656-1683, Measure.h:139-163).  The first measured tile of a plane tells where the reconstructed plane's sample (0, 0) lies relative to
+// the prediction's address, and which registered source plane it is measured against; from then on a prediction that takes the launch path into that plane measures its
+// tiles against the block at the same coordinates in the same wait.  Used only if the first tile call names exactly that source block.
+struct PlaneMap
 {
     bool valid = false;
-    const void *block = nullptr;
-    intptr_t stride = 0;
-    int w = 0, h = 0, S = 0;
+    const char *recOrigin = nullptr;                    // address of the destination plane's sample (0, 0) (arithmetic only: never read)
+    intptr_t sd = 0;
+    const char *srcOrigin = nullptr;                    // the registered source plane's sample (0, 0)
+    intptr_t ss = 0;
+    int S = 0, rows = 0;                                // rows: the source plane's height (a destination address further down belongs to another plane)
+    uint64_t stamp = 0;
 };
+constexpr int kLastPreds = 3, kPlaneMaps = 4;
 
 struct Serve
 {
     bool ready = false;
-    LastPred last;
-    SourceGuess guess;
+    LastPred last[kLastPreds];                          // luma, Cb, Cr of a PU are predicted before any of them is measured
+    int lastAt = 0;
+    PlaneMap maps[kPlaneMaps];
     SsdPair pair;
     InterAhead inter;
     Surface surf[kSurfaces];
@@ -1114,15 +1121,20 @@ bool serveSsd(const Sample *pa, intptr_t sa, const Sample *pb, intptr_t sb, int 
 }
 
 template <typename Sample>
-void rememberPrediction(const Sample *dst, intptr_t sd, int w, int h)
+LastPred &rememberPrediction(const Sample *dst, intptr_t sd, int w, int h)
 {
     Serve &v = serve(stage());
-    LastPred &l = v.last;
+    int at = -1;
+    for (int k = 0; k < kLastPreds; ++k)
+        if (v.last[k].valid && v.last[k].dst == dst && v.last[k].sd == sd) at = k;      // the same place again (the next candidate of a search)
+    if (at < 0) at = v.lastAt = (v.lastAt + 1) % kLastPreds;
+    LastPred &l = v.last[at];
     l.valid = true;
     l.measured = false;
     l.dst = dst; l.sd = sd; l.w = w; l.h = h; l.S = sizeof(Sample);
     l.copy.resize(sizeof(Sample) * size_t(w) * h);
     for (int y = 0; y < h; ++y) memcpy(&l.copy[sizeof(Sample) * size_t(y) * w], dst + y * sd, sizeof(Sample) * w);
+    return l;
 }
 
 // every tile of the PU in the first tile's launch; false = not this pattern (the caller takes the one-job path)
@@ -1131,12 +1143,21 @@ bool serveTileSatd(const Sample *a, intptr_t sa, const Sample *b, intptr_t sb, i
 {
     Stage &s = stage();
     Serve &v = serve(s);
-    LastPred &l = v.last;
-    if (!l.valid || l.S != int(sizeof(Sample)) || sb != l.sd) return false;
-    const long off = b - static_cast<const Sample *>(l.dst);
-    if (off < 0) return false;
-    const int ty = int(off / l.sd), tx = int(off - (long)ty * l.sd);
-    if (tx >= l.w || ty >= l.h || (tx % N) || (ty % N) || (l.w % N) || (l.h % N)) return false;
+    LastPred *hit = nullptr;
+    int tx = 0, ty = 0;
+    for (LastPred &c : v.last)
+    {
+        if (!c.valid || c.S != int(sizeof(Sample)) || sb != c.sd) continue;
+        const long off = b - static_cast<const Sample *>(c.dst);
+        if (off < 0) continue;
+        const int cy = int(off / c.sd), cx = int(off - (long)cy * c.sd);
+        if (cx >= c.w || cy >= c.h || (cx % N) || (cy % N) || (c.w % N) || (c.h % N)) continue;
+        hit = &c;
+        tx = cx; ty = cy;
+        break;
+    }
+    if (!hit) return false;
+    LastPred &l = *hit;
     const Sample *pred = reinterpret_cast<const Sample *>(l.copy.data());
     for (int r = 0; r < N; ++r)
         if (memcmp(b + r * sb, pred + (ty + r) * l.w + tx, sizeof(Sample) * N)) return false;
@@ -1150,8 +1171,22 @@ bool serveTileSatd(const Sample *a, intptr_t sa, const Sample *b, intptr_t sb, i
         int x, y;
         locate(q, block, &x, &y);
         if (x < -q->pad || y < -q->pad || x + l.w > q->w + q->pad || y + l.h > q->h + q->pad) return false;
-        v.guess.valid = true;
-        v.guess.block = block; v.guess.stride = sa; v.guess.w = l.w; v.guess.h = l.h; v.guess.S = int(sizeof(Sample));
+        {   // where this destination plane lies against this source plane (PlaneMap)
+            const char *recOrigin = static_cast<const char *>(l.dst) - ((long)y * l.sd + x) * (long)sizeof(Sample);
+            int at = 0;
+            bool known = false;
+            for (int k = 0; k < kPlaneMaps && !known; ++k)
+                if (v.maps[k].valid && v.maps[k].recOrigin == recOrigin && v.maps[k].sd == l.sd) { at = k; known = true; }
+            if (!known)
+                for (int k = 1; k < kPlaneMaps; ++k)
+                    if (!v.maps[k].valid || (v.maps[at].valid && v.maps[k].stamp < v.maps[at].stamp)) at = k;
+            PlaneMap &m = v.maps[at];
+            m.valid = true;
+            m.recOrigin = recOrigin; m.sd = l.sd;
+            m.srcOrigin = q->lo + ((long)q->pad * q->stride + q->pad) * (long)q->S; m.ss = q->stride;
+            m.S = int(sizeof(Sample)); m.rows = q->h;
+            m.stamp = ++v.clock;
+        }
         if (ntiles < 2) return false;      // (a single tile: the one-job call is the same launch)
         const size_t j = s.reserve(sizeof(havoc_mi355x_pair_job) * ntiles), o = s.reserve(4 * size_t(ntiles));
         const size_t pb = s.pack(pred, l.w, l.w, l.h, l.w);
@@ -1187,33 +1222,42 @@ struct TilePlan
     const Pic *q = nullptr;
     int n = 0, ntiles = 0;
     size_t jobs = 0, out = 0;
+    const void *block = nullptr;      // the source block the tiles are measured against
 };
 template <typename Sample>
-inline TilePlan planTiles(Stage &s, Serve &v, int w, int h)
+inline TilePlan planTiles(Stage &s, Serve &v, const Sample *dst, intptr_t sd, int w, int h)
 {
     TilePlan t;
-    const SourceGuess &g = v.guess;
-    if (!g.valid || g.w != w || g.h != h || g.S != int(sizeof(Sample))) return t;
-    const Pic *q = findPic(g.block);
-    if (!q || q->S != int(sizeof(Sample)) || q->stride != g.stride) return t;
-    int x, y;
-    locate(q, g.block, &x, &y);
-    if (x < -q->pad || y < -q->pad || x + w > q->w + q->pad || y + h > q->h + q->pad) return t;
-    t.n = ((w | h) & 3) ? 2 : ((w | h) & 7) ? 4 : 8;      // Measure.h:97-135
-    t.ntiles = (w / t.n) * (h / t.n);
-    if (t.ntiles < 1 || t.ntiles > 256) return t;
-    t.q = q;
-    t.jobs = s.reserve(sizeof(havoc_mi355x_pair_job) * t.ntiles);
-    t.out = s.reserve(4 * size_t(t.ntiles));
-    const long so = (long)(y + q->pad) * q->stride + x + q->pad;
-    havoc_mi355x_pair_job *jobs = s.job<havoc_mi355x_pair_job>(t.jobs);
-    const int tilesX = w / t.n;
-    for (int k = 0; k < t.ntiles; ++k)
+    for (PlaneMap &m : v.maps)
     {
-        const int px = (k % tilesX) * t.n, py = (k / tilesX) * t.n;
-        jobs[k] = {int32_t(so + (long)py * q->stride + px), int32_t(py * w + px), t.n, t.n};
+        if (!m.valid || m.S != int(sizeof(Sample)) || m.sd != sd) continue;
+        const long off = (reinterpret_cast<const char *>(dst) - m.recOrigin) / (long)sizeof(Sample);
+        if (off < 0) continue;
+        const long y = off / sd, x = off - y * sd;
+        if (y + h > m.rows) continue;
+        const Sample *block = reinterpret_cast<const Sample *>(m.srcOrigin) + y * m.ss + x;
+        const Pic *q = findPic(block);
+        if (!q || q->S != int(sizeof(Sample)) || q->stride != m.ss || q->lo + ((long)q->pad * q->stride + q->pad) * (long)q->S != m.srcOrigin) { m.valid = false; continue; }
+        if (x + w > q->w + q->pad || y + h > q->h + q->pad) continue;
+        t.n = ((w | h) & 3) ? 2 : ((w | h) & 7) ? 4 : 8;      // Measure.h:97-135
+        t.ntiles = (w / t.n) * (h / t.n);
+        if (t.ntiles < 1 || t.ntiles > 256) return t;
+        t.q = q;
+        t.block = block;
+        t.jobs = s.reserve(sizeof(havoc_mi355x_pair_job) * t.ntiles);
+        t.out = s.reserve(4 * size_t(t.ntiles));
+        const long so = (long)(y + q->pad) * q->stride + x + q->pad;
+        havoc_mi355x_pair_job *jobs = s.job<havoc_mi355x_pair_job>(t.jobs);
+        const int tilesX = w / t.n;
+        for (int k = 0; k < t.ntiles; ++k)
+        {
+            const int px = (k % tilesX) * t.n, py = (k / tilesX) * t.n;
+            jobs[k] = {int32_t(so + (long)py * q->stride + px), int32_t(py * w + px), t.n, t.n};
+        }
+        m.stamp = ++v.clock;
+        t.on = true;
+        return t;
     }
-    t.on = true;
     return t;
 }
 template <typename Sample>
@@ -1224,15 +1268,14 @@ inline void launchTiles(Stage &s, const TilePlan &t, size_t pred, int w)      //
     bump(2);
     bump(4);
 }
-inline void keepTiles(Stage &s, Serve &v, const TilePlan &t)      // after rememberPrediction
+inline void keepTiles(Stage &s, LastPred &l, const TilePlan &t)
 {
     if (!t.on) return;
-    LastPred &l = v.last;
     l.tiles.assign(reinterpret_cast<int32_t *>(&s.h[t.out]), reinterpret_cast<int32_t *>(&s.h[t.out]) + t.ntiles);
     l.measured = true;
     l.n = t.n;
-    l.srcBlock = v.guess.block;
-    l.srcStride = v.guess.stride;
+    l.srcBlock = t.block;
+    l.srcStride = t.q->stride;
 }
 
 // ---- distortion metrics ---------------------------------------------------------------------------------------
@@ -1417,14 +1460,13 @@ void predUni(Sample *dst, intptr_t sd, const Sample *ref, intptr_t sr, int w, in
     const size_t win = packWindow(s, ref, sr, w, h, TAPS, xFrac, yFrac, &pitch, &origin);
     const size_t out = s.reserve(sizeof(Sample) * size_t(w) * h);
     Serve &v = serve(s);
-    const TilePlan tiles = TAPS == 8 ? planTiles<Sample>(s, v, w, h) : TilePlan();
+    const TilePlan tiles = planTiles<Sample>(s, v, dst, sd, w, h);
     *s.job<havoc_mi355x_pred_uni_job>(j) = {0, origin, w, h, xFrac, yFrac, {0, 0}};
     s.upload();
     CK(havoc_mi355x_pred_uni(s.ctx, sizeof(Sample), TAPS, bitDepth, w, h, s.d + out, w, s.d + win, pitch, s.djob<havoc_mi355x_pred_uni_job>(j), 1));
     launchTiles<Sample>(s, tiles, out, w);
     s.unpack(dst, sd, w, h, w, out);
-    rememberPrediction(dst, sd, w, h);
-    keepTiles(s, v, tiles);
+    keepTiles(s, rememberPrediction(dst, sd, w, h), tiles);
 }
 
 template <typename Sample, int TAPS>
@@ -1441,15 +1483,14 @@ void predBi(Sample *dst, intptr_t sd, const Sample *ref0, const Sample *ref1, in
     const size_t w1 = packWindow(s, ref1, sr, w, h, TAPS, xFrac1, yFrac1, &pitch, &origin);
     const size_t out = s.reserve(sizeof(Sample) * size_t(w) * h);
     Serve &v = serve(s);
-    const TilePlan tiles = TAPS == 8 ? planTiles<Sample>(s, v, w, h) : TilePlan();
+    const TilePlan tiles = planTiles<Sample>(s, v, dst, sd, w, h);
     havoc_mi355x_pred_bi_job job = {0, origin, int32_t((w1 - w0) / sizeof(Sample)) + origin, w, h, xFrac0, yFrac0, xFrac1, yFrac1, {0, 0, 0}};
     *s.job<havoc_mi355x_pred_bi_job>(j) = job;
     s.upload();
     CK(havoc_mi355x_pred_bi(s.ctx, sizeof(Sample), TAPS, bitDepth, w, h, s.d + out, w, s.d + w0, pitch, s.djob<havoc_mi355x_pred_bi_job>(j), 1));
     launchTiles<Sample>(s, tiles, out, w);
     s.unpack(dst, sd, w, h, w, out);
-    rememberPrediction(dst, sd, w, h);
-    keepTiles(s, v, tiles);
+    keepTiles(s, rememberPrediction(dst, sd, w, h), tiles);
 }
 
 template <typename Sample>

@@ -21,6 +21,10 @@ struct havoc_mi355x_ctx
     hipEvent_t forkEv;
     int nlanes;   // 0 = not forked
     int cur;      // lane the next launch goes to (0 = the context's main stream)
+    // havoc_mi355x_sync_spin: a pinned word the stream writes a sequence number to (hipStreamWriteValue32) and the host polls
+    volatile uint32_t *flagH = nullptr;
+    void *flagD = nullptr;
+    uint32_t flagSeq = 0;
     const int32_t *searchGate = nullptr;      // havoc_mi355x_search_gate: rows of the reference pictures that have arrived, [2] device ints (nullptr: references complete)
 };
 

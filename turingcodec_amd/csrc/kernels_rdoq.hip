@@ -84,6 +84,8 @@ struct Block
     int quantScale, quantShift, invScale, invShift, invOffset;
     int cIdx, scanIdx;
     uint64_t scan4;           // the 4x4 scan as 16 nibbles x | y << 2
+    int64_t csbfZero[2], csbfOne[2];   // lambda * bits of coded_sub_block_flag = 0 / 1 in its two contexts (neighbour coded or not): fixed for the block, asked for per group
+    int64_t cbfZero, cbfOne;           // lambda * bits of the block's coded-block flag
     const uint32_t *clsTab;   // LDS: [right / below coded: 4 cases] scan positions of THIS block's scan whose significance context is base + 1 | those at base + 2, << 16
 };
 
@@ -129,6 +131,39 @@ __host__ __device__ constexpr uint64_t scan4Nibbles(int scanIdx)
     else
         for (; i < 16; ++i) v |= (uint64_t)(scanIdx == 1 ? i : (i >> 2) | (i & 3) << 2) << (4 * i);
     return v;
+}
+
+// The scan pass marks a block's 4x4 groups by RASTER position (a ballot of the lanes that looked at them); the walks go through the groups in SCAN order and ask "the
+// next marked group below this one", "how many unmarked groups in between": bit g of a scan-order mask = group number g of the scan (ScanOrder.h:31-95 applied to the
+// GW x GW groups).  Done once per block (k_rdoq_order for the sorted sizes, after the in-kernel scan for the others).
+template <int GW>
+__device__ __forceinline__ void toScanOrder(int scanIdx, uint64_t &m, uint64_t &m2, uint64_t &m3)
+{
+    if (GW == 1 || scanIdx == 1) return;      // horizontal: raster order
+    uint64_t a = 0, b = 0, c = 0;
+    int x = 0, y = 0;
+    for (int g = 0; g < GW * GW; ++g)
+    {
+        const int p = y * GW + x;
+        a |= ((m >> p) & 1) << g;
+        b |= ((m2 >> p) & 1) << g;
+        c |= ((m3 >> p) & 1) << g;
+        if (scanIdx == 2)      // vertical: x = g / GW, y = g % GW
+        {
+            if (++y == GW) { y = 0; ++x; }
+        }
+        else                   // up-right diagonal: along an anti-diagonal x goes up and y down; the next one starts at its bottom-left end
+        {
+            ++x; --y;
+            if (y < 0 || x >= GW)
+            {
+                const int d = x + y + 1;
+                x = d < GW ? 0 : d - GW + 1;
+                y = d - x;
+            }
+        }
+    }
+    m = a; m2 = b; m3 = c;
 }
 
 // Rdoq.cpp:710: number of ones in the prefix of a last-significant coordinate: 0 1 2 3 4 4 5 5 6 6 6 6 7 7 7 7 8 x 8, 9 x 8
@@ -237,6 +272,7 @@ struct WalkShared
     // (4x4 blocks keep, per position, significance context << 25 | flag bits of the zero levels above it IN rec.costDown: a position's record is read by loop B
     // before that iteration writes the position's costDown, position 0's only when loop B never visits it, and sign-data hiding reads costDown of kept levels only)
     uint8_t rasterOf[3][64];                      // scan index -> raster group position, per scan type
+    uint8_t scanOf[3][64];                        // ... and back
     uint32_t clsScan[3][4];                       // per scan type and neighbour case: sigPattern() by SCAN position, as two 16-bit masks (value 1 | value 2 << 16)
 };
 
@@ -514,8 +550,7 @@ __device__ __forceinline__ WalkResult walkGroup(const Block &b, WalkShared &sh, 
     // gets the significance flags of its zero levels back; a group below the first weighs zeroing all its levels against flag = 1 (a
     // lone level at position 0 implies its significance flag); the first group is coded and pays no flag.
     const bool dc = g == 0, any = keptMask != 0, inner = any & !dc & (g < firstGroup);
-    const int flagCtx = HAVOC_RDOQ_CTX_CSBF + (b.cIdx ? 2 : 0) + (neighbours ? 1 : 0);
-    const int64_t zero = b.lambda * bitsOf(b, flagCtx, 0), one = b.lambda * bitsOf(b, flagCtx, 1);
+    const int64_t zero = pick(neighbours != 0, b.csbfZero[1], b.csbfZero[0]), one = pick(neighbours != 0, b.csbfOne[1], b.csbfOne[0]);
     const int64_t implied = pick(inner & (nonZeroAbovePos0 == 0), gSigPos0, (int64_t)0);
     const int64_t sigLeft = gSig - implied, allZero = zero + gDist0 - gCoded - sigLeft;
     const bool dropped = inner & (allZero < one), empty = !any & !dc;
@@ -648,7 +683,7 @@ __device__ __forceinline__ void scanBlocks(ScanShared &sc, int16_t *__restrict__
 constexpr int kScanSteps = 8;
 template <int LOG2>
 __global__ __launch_bounds__(64) void k_rdoq_scan(int16_t *__restrict__ dstAll, const int16_t *__restrict__ srcAll, const RdoqJob *__restrict__ jobs, int njobs,
-                                                  RdoqWork *__restrict__ work)
+                                                  RdoqWork *__restrict__ work, int withHist)
 {
     constexpr int perWg = kScanSteps * (64 / (((1 << LOG2) * (1 << LOG2)) >> 4));      // <= 64
     __shared__ ScanShared sc;
@@ -669,6 +704,7 @@ __global__ __launch_bounds__(64) void k_rdoq_scan(int16_t *__restrict__ dstAll, 
         if (jobs[blk].scan_idx != 0) atomicAdd(&hist[kBins - 1], 1u);      // the spare bin (never a number of groups: at most 64) counts them
     }
     __syncthreads();
+    if (!withHist) return;      // a launch walked in job order: nothing reads the histogram
     for (int k = lane; k < kBins - 1; k += 64)
         if (hist[k]) atomicAdd(&work->hist[k], hist[k]);
     if (lane == 0 && hist[kBins - 1]) atomicAdd(&work->otherScans, hist[kBins - 1]);
@@ -695,11 +731,12 @@ __global__ __launch_bounds__(256) void k_rdoq_hist(const RdoqJob *__restrict__ j
 
 // Pass 2: blocks ordered by decreasing number of groups to walk (counting sort; the order inside a bin is whatever the atomics
 // give -- it decides only which lane walks which block).  The 64 blocks of a wavefront then finish together.
-__global__ __launch_bounds__(256) void k_rdoq_order(int njobs, RdoqWork *__restrict__ work)
+template <int LOG2>
+__global__ __launch_bounds__(256) void k_rdoq_order(const RdoqJob *__restrict__ jobs, int njobs, RdoqWork *__restrict__ work)
 {
     __shared__ uint32_t count[kBins], base[kBins];
-    const RdoqInfo *info = reinterpret_cast<const RdoqInfo *>(reinterpret_cast<const char *>(work) + rdoqInfoOffset());
-    uint32_t *order = reinterpret_cast<uint32_t *>(const_cast<RdoqInfo *>(info) + njobs);
+    RdoqInfo *info = reinterpret_cast<RdoqInfo *>(reinterpret_cast<char *>(work) + rdoqInfoOffset());
+    uint32_t *order = reinterpret_cast<uint32_t *>(info + njobs);
     const int t = threadIdx.x, blk = blockIdx.x * 256 + t;
     if (t < kBins) count[t] = 0;
     __syncthreads();
@@ -707,14 +744,21 @@ __global__ __launch_bounds__(256) void k_rdoq_order(int njobs, RdoqWork *__restr
     uint32_t rank = 0;
     if (blk < njobs)
     {
-        bin = groupsToWalk(info[blk].mask);
+        RdoqInfo v = info[blk];
+        bin = groupsToWalk(v.mask);
         rank = atomicAdd(&count[bin], 1u);
+        // what the walks read: the masks by scan position (the DC group is number 0 either way: the bin stays what the histogram counted)
+        toScanOrder<(1 << LOG2) / 4>(jobs[blk].scan_idx, v.mask, v.mask2, v.mask3);
+        info[blk] = v;
     }
+    __syncthreads();
+    __shared__ uint32_t histAll[kBins];
+    if (t < kBins) histAll[t] = work->hist[t];      // (one load per lane, then the sums in LDS: 65 dependent global loads per lane made this launch 20-50 us)
     __syncthreads();
     if (t < kBins && count[t])
     {
         uint32_t before = 0;
-        for (int k = t + 1; k < kBins; ++k) before += work->hist[k];      // bins with more groups come first
+        for (int k = t + 1; k < kBins - 1; ++k) before += histAll[k];      // bins with more groups come first
         base[t] = before + atomicAdd(&work->cursor[t], count[t]);
     }
     __syncthreads();
@@ -728,6 +772,7 @@ struct LaneBlock
     static constexpr int size = 1 << LOG2, G = (size * size) >> 4, gw = size >> 2;
     Block b;
     const uint8_t *rasterOf;      // LDS: scan index of a group -> its raster position
+    const uint8_t *scanOf;        // LDS: ... and back
     const int16_t *src;
     int16_t *dst;
     int distShift;
@@ -760,6 +805,7 @@ struct LaneBlock
                 int x = 0, y = 0;
                 if (G > 1) scanXy(gw, t, lane, x, y);
                 sh.rasterOf[t][lane] = (uint8_t)(y * gw + x);
+                sh.scanOf[t][y * gw + x] = (uint8_t)lane;
             }
         if (lane < 12)
         {
@@ -796,9 +842,25 @@ struct LaneBlock
         b.scanIdx = job.scan_idx;
         b.scan4 = job.scan_idx == 0 ? scan4Nibbles(0) : (job.scan_idx == 1 ? scan4Nibbles(1) : scan4Nibbles(2));
         rasterOf = sh.rasterOf[job.scan_idx < 3 ? job.scan_idx : 0];
+        scanOf = sh.scanOf[job.scan_idx < 3 ? job.scan_idx : 0];
         b.clsTab = sh.clsScan[job.scan_idx < 3 ? job.scan_idx : 0];
         src = srcAll + job.src_off;
         dst = dstAll + job.dst_off;
+        if (G > 1)      // (a 4x4 block has no group flag)
+        {
+            const int csbf = HAVOC_RDOQ_CTX_CSBF + (b.cIdx ? 2 : 0);
+            b.csbfZero[0] = b.lambda * bitsOf(b, csbf, 0);
+            b.csbfOne[0] = b.lambda * bitsOf(b, csbf, 1);
+            b.csbfZero[1] = b.lambda * bitsOf(b, csbf + 1, 0);
+            b.csbfOne[1] = b.lambda * bitsOf(b, csbf + 1, 1);
+        }
+        else
+            b.csbfZero[0] = b.csbfZero[1] = b.csbfOne[0] = b.csbfOne[1] = 0;
+        {
+            const int cbfCtx = (!job.is_intra && b.cIdx == 0) ? HAVOC_RDOQ_CTX_ROOT_CBF : (b.cIdx == 0 ? HAVOC_RDOQ_CTX_CBF_LUMA + 1 : HAVOC_RDOQ_CTX_CBF_CHROMA);
+            b.cbfZero = b.lambda * bitsOf(b, cbfCtx, 0);
+            b.cbfOne = b.lambda * bitsOf(b, cbfCtx, 1);
+        }
         if (sub == 0)
             for (int axis = 0; axis < 2; ++axis)      // Rdoq.cpp:706-771 per prefix length
             {
@@ -875,18 +937,12 @@ struct LaneBlock
         }
         return nz ? 31 - __clz((int)nz) : -1;
     }
-    __device__ __forceinline__ int64_t zeroGroupCost(uint64_t coded, int p) const      // Rdoq.cpp:200-210
-    {
-        const int c = caseOf(coded, p & (gw - 1), p / gw, 0);
-        return b.lambda * bitsOf(b, HAVOC_RDOQ_CTX_CSBF + (b.cIdx ? 2 : 0) + ((c & 3) ? 1 : 0), 0);
-    }
     // Rdoq.cpp:307-341: the index one past the last significant position (0: nothing is coded)
     __device__ __forceinline__ int lastIndex(bool isIntra, int64_t sumSq, int64_t walkedDist0, int64_t costTu, int64_t bestRel, int bestPos) const
     {
-        const int cbfCtx = (!isIntra && b.cIdx == 0) ? HAVOC_RDOQ_CTX_ROOT_CBF : (b.cIdx == 0 ? HAVOC_RDOQ_CTX_CBF_LUMA + 1 : HAVOC_RDOQ_CTX_CBF_CHROMA);
         const int64_t dist0Total = sumSq << distShift;
-        const int64_t bestNone = dist0Total + b.lambda * bitsOf(b, cbfCtx, 0);
-        const int64_t start = (dist0Total - walkedDist0) + costTu + b.lambda * bitsOf(b, cbfCtx, 1);
+        const int64_t bestNone = dist0Total + b.cbfZero;
+        const int64_t start = (dist0Total - walkedDist0) + costTu + b.cbfOne;
         return (bestPos >= 0 && start + bestRel < bestNone) ? bestPos + 1 : 0;
     }
 };
@@ -901,18 +957,30 @@ struct WalkState
     bool stopped = false;
     uint64_t coded = 0, carries = 0;        // by raster position; carry INTO each walked group, by scan index
     uint64_t codedScan = 0;                 // `coded` by scan index: what the verdict clears above the last significant group
+    uint64_t nbrScan = 0;                   // by scan index: groups whose right or below neighbour is coded (what picks a coded_sub_block_flag's context)
 
-    __device__ __forceinline__ void zeroGroup(int64_t zero)
+    // the all-zero groups `range` (by scan index) between two walked groups: each pays its flag = 0, in the context its neighbours give it (Rdoq.cpp:200-210) --
+    // a sum of per-group terms, so counted instead of visited
+    __device__ __forceinline__ void zeroGroups(uint64_t range, const Block &b)
     {
+        const int n = __popcll(range), n1 = __popcll(range & nbrScan);
+        const int64_t zero = (int64_t)(n - n1) * b.csbfZero[0] + (int64_t)n1 * b.csbfZero[1];
         costTu += zero;
         rel -= zero;
     }
-    __device__ __forceinline__ void walkedGroup(const WalkResult &r, int g, int p, int carryIn)
+    __device__ __forceinline__ void walkedGroup(const WalkResult &r, int g, int p, int carryIn, const uint8_t *scanOf, int gw)
     {
         costTu += r.cost;
         walkedDist0 += r.dist0;
         coded |= (uint64_t)r.coded << p;
         codedScan |= (uint64_t)r.coded << g;
+        if (gw > 1)
+        {
+            const int gx = p & (gw - 1), gy = p / gw;
+            const bool left = r.coded && gx > 0, above = r.coded && gy > 0;
+            nbrScan |= (uint64_t)left << scanOf[left ? p - 1 : 0];
+            nbrScan |= (uint64_t)above << scanOf[above ? p - gw : 0];
+        }
         carries |= (uint64_t)carryIn << g;
         rel -= r.sigCost;
         if (r.coded)
@@ -931,37 +999,59 @@ struct WalkState
     }
 };
 
-// The sequential walk.  SORTED (32x32, 16x16 blocks that do not use the diagonal scan -- k_rdoq_diag takes the others): blocks in the
-// order of pass 2, scan results from the workspace.  Otherwise (8x8, 4x4: many short blocks, where three launches and a permuted
-// access cost more than the balance gains) the scan runs here, blocks in job order.
-template <int LOG2, bool SORTED, bool LDS_STATES>
-__global__ __launch_bounds__(64) void k_rdoq_walk(int16_t *__restrict__ dstAll, const int16_t *__restrict__ srcAll, const uint8_t *__restrict__ statesAll,
-                                                  const RdoqJob *__restrict__ jobs, int njobs, int32_t *__restrict__ cbfOut, int bitDepth,
-                                                  const RdoqWork *__restrict__ work, int diagonalElsewhere)
+// The sequential walk, a lane per block.  Where the blocks and what the scan found of them come from:
+//   kInKernel  8x8, 4x4: many short blocks -- the scan runs here, blocks in job order;
+//   kSorted    32x32 / 16x16 of a launch with more wavefronts than the machine holds at once: blocks in the order of pass 2 (densest first, so that a wavefront's 64
+//              blocks finish together), scan results from the workspace, masks already by scan position (k_rdoq_order);
+//   kJobOrder  32x32 / 16x16 of a smaller launch (round 6): blocks in job order, scan results from the workspace as the scan left them.  Every wavefront of such a
+//              launch is resident from the start and the launch lasts as long as its longest wavefront whichever blocks share it, so the histogram and the sort --
+//              three dependent launches, 25-60 us of the picture's critical path at 1080p (profiles/r06/rdoq_side_by_side_timeline.txt) -- buy nothing.
+// onlyOther: walk only the blocks that do NOT use the diagonal scan (k_rdoq_diag takes the others).
+enum WalkSource { kInKernel, kSorted, kJobOrder };
+// the sequential walk's LDS
+template <int LOG2, bool LDS_STATES>
+struct WalkLds
 {
+    // the cooperative scan's arrays (job-order form) are dead before the walk's first LDS write: they share its memory (a workgroup is ONE wavefront)
+    __attribute__((aligned(16))) unsigned char walkMem[sizeof(WalkShared) > sizeof(ScanShared) ? sizeof(WalkShared) : sizeof(ScanShared)];
+    BlockTables<64, 2 * LOG2, LDS_STATES> bt;
+};
+template <int LOG2, WalkSource SOURCE, bool LDS_STATES>
+__device__ __forceinline__ void walkBody(WalkLds<LOG2, LDS_STATES> &lds, int wg, int16_t *__restrict__ dstAll, const int16_t *__restrict__ srcAll,
+                                         const uint8_t *__restrict__ statesAll, const RdoqJob *__restrict__ jobs, int njobs, int32_t *__restrict__ cbfOut, int bitDepth,
+                                         const RdoqWork *__restrict__ work, int onlyOther, int masksByScan = 0)
+{
+    constexpr bool SORTED = SOURCE == kSorted;
     typedef LaneBlock<LOG2> LB;
     constexpr int G = LB::G, gw = LB::gw;
-    // the cooperative scan's arrays (job-order form) are dead before the walk's first LDS write: they share its memory (a workgroup is ONE wavefront)
-    __shared__ __attribute__((aligned(16))) unsigned char walkMem[sizeof(WalkShared) > sizeof(ScanShared) ? sizeof(WalkShared) : sizeof(ScanShared)];
+    unsigned char *walkMem = lds.walkMem;
     WalkShared &sh = *reinterpret_cast<WalkShared *>(walkMem);
-    __shared__ BlockTables<64, 2 * LOG2, LDS_STATES> bt;
-    if (SORTED && diagonalElsewhere && work->otherScans == 0) return;
+    BlockTables<64, 2 * LOG2, LDS_STATES> &bt = lds.bt;
+    if (SORTED && onlyOther && work->otherScans == 0) return;
     const RdoqInfo *infoAll = reinterpret_cast<const RdoqInfo *>(reinterpret_cast<const char *>(work) + rdoqInfoOffset());
     const uint32_t *order = reinterpret_cast<const uint32_t *>(infoAll + njobs);
-    const int lane = threadIdx.x, slot = blockIdx.x * 64 + lane;
+    const int lane = threadIdx.x, slot = wg * 64 + lane;
     bool valid = slot < njobs;
     const int blk = valid ? (SORTED ? (int)order[slot] : slot) : 0;
     const RdoqJob job = jobs[blk];
-    if (SORTED && diagonalElsewhere && job.scan_idx == 0) valid = false;
+    if (onlyOther && job.scan_idx == 0) valid = false;
+    if (SOURCE == kJobOrder && onlyOther && __ballot(valid) == 0) return;      // (the usual case: the reference's encoder scans these sizes diagonally)
     RdoqInfo info;
     if (SORTED)
+        info = infoAll[blk];      // (masks by scan position: k_rdoq_order)
+    else if (SOURCE == kJobOrder)
+    {
         info = infoAll[blk];
+        if (!masksByScan) toScanOrder<gw>(job.scan_idx, info.mask, info.mask2, info.mask3);      // (a sorted launch's k_rdoq_order has done it)
+    }
     else
     {
         ScanShared &sc = *reinterpret_cast<ScanShared *>(walkMem);
-        scanBlocks<LOG2>(sc, dstAll, srcAll, jobs, njobs, blockIdx.x * 64, G);
+        scanBlocks<LOG2>(sc, dstAll, srcAll, jobs, njobs, wg * 64, G);
         info.mask = sc.mask[lane];
+        info.mask2 = info.mask3 = 0;
         info.sumSq = sc.sumSq[lane];
+        toScanOrder<gw>(job.scan_idx, info.mask, info.mask2, info.mask3);
         __syncthreads();
     }
     RT_DECL;
@@ -972,9 +1062,8 @@ __global__ __launch_bounds__(64) void k_rdoq_walk(int16_t *__restrict__ dstAll, 
     const uint8_t *rasterOf = lb.rasterOf;
     SdhAux aux;
 
-    uint64_t nz = valid ? info.mask : 0;
-    int g = G - 1;
-    while (g >= 0 && !((nz >> rasterOf[g]) & 1)) --g;
+    uint64_t nz = valid ? info.mask : 0;      // groups to walk, by scan position
+    int g = nz ? 63 - __clzll((long long)nz) : -1;
     const int firstGroup = g;
     int firstPos = -1;
     if (firstGroup >= 0)
@@ -987,29 +1076,26 @@ __global__ __launch_bounds__(64) void k_rdoq_walk(int16_t *__restrict__ dstAll, 
 
     WalkState ws;
     int carry = 0;
-    while (true)
+    while (__ballot(g >= 0) != 0)
     {
-        while (g >= 0 && !((nz >> rasterOf[g]) & 1))      // all-zero groups: one flag cost each
-        {
-            ws.zeroGroup(lb.zeroGroupCost(ws.coded, rasterOf[g]));
-            carry = 0;
-            --g;
-        }
-        if (__ballot(g >= 0) == 0) break;
         if (g >= 0)
         {
             const int p = rasterOf[g], gx = p & (gw - 1), gy = p / gw;
             RT_MARK(2);
             lb.loadGroup(sh, lane, gx, gy);
             const WalkResult r = walkGroup<LOG2>(b, sh, lane, g, gx, gy, firstPos, LB::caseOf(ws.coded, gx, gy, carry), job.sdh_factor, aux RT_ARG);
-            ws.walkedGroup(r, g, p, carry);
-            carry = r.carry;
+            ws.walkedGroup(r, g, p, carry, lb.scanOf, gw);
             // as a group below the last one (the last one is redone below) -- but for the DC group, the last to be walked: its records are
             // still there when the verdict is known, so it is finished then, once, as what it turns out to be
             RT_MARK(8);
             if (r.coded && g != 0) lb.finishGroup(sh, lane, job.sdh, aux, g, 1 << 30, false, gx, gy);
             RT_MARK(9);
-            --g;
+            // the next group to walk, and the all-zero groups on the way to it: one flag cost each, no carry across them
+            const uint64_t below = nz & ((1ull << g) - 1);
+            const int next = below ? 63 - __clzll((long long)below) : -1;
+            if (G > 1) ws.zeroGroups(((1ull << g) - 1) & ~((2ull << max(next, 0)) - 1) & ~below, b);
+            carry = next == g - 1 ? r.carry : 0;
+            g = next;
         }
     }
     RT_MARK(2);
@@ -1045,6 +1131,15 @@ __global__ __launch_bounds__(64) void k_rdoq_walk(int16_t *__restrict__ dstAll, 
 #endif
 }
 
+template <int LOG2, WalkSource SOURCE, bool LDS_STATES>
+__global__ __launch_bounds__(64, 2) void k_rdoq_walk(int16_t *__restrict__ dstAll, const int16_t *__restrict__ srcAll, const uint8_t *__restrict__ statesAll,
+                                                  const RdoqJob *__restrict__ jobs, int njobs, int32_t *__restrict__ cbfOut, int bitDepth,
+                                                  const RdoqWork *__restrict__ work, int onlyOther)
+{
+    __shared__ WalkLds<LOG2, LDS_STATES> lds;
+    walkBody<LOG2, SOURCE, LDS_STATES>(lds, blockIdx.x, dstAll, srcAll, statesAll, jobs, njobs, cbfOut, bitDepth, work, onlyOther);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // The diagonal walk (32x32 and 16x16 blocks with the up-right diagonal scan: all of them in the reference's encoder, which uses
 // the other scans for 4x4 / 8x8 intra blocks only).  A group needs of the rest of the block: whether the groups to its RIGHT and
@@ -1069,24 +1164,40 @@ struct DiagExchange
     int32_t flags[64];      // localStop | coded << 1 | carry out << 2 | carry in << 3
 };
 
+// sorted: blocks in the order of pass 2, masks by scan position (k_rdoq_order); otherwise (round 6: a launch whose wavefronts are all resident at once -- see WalkSource)
+// blocks in job order, masks as the scan left them.  The workgroups past `diagWgs` walk the blocks that do not use the diagonal scan (a lane per block, job
+// order: they look at their 64 jobs and leave when there is none -- the reference's encoder has none at these sizes; round 6: before, a launch of its own behind
+// this one, 12 us of every picture's critical path for nothing).
 template <int LOG2, int LPB>
 __global__ __launch_bounds__(64, 2) void k_rdoq_diag(int16_t *__restrict__ dstAll, const int16_t *__restrict__ srcAll, const uint8_t *__restrict__ statesAll,
                                                   const RdoqJob *__restrict__ jobs, int njobs, int32_t *__restrict__ cbfOut, int bitDepth,
-                                                  const RdoqWork *__restrict__ work)
+                                                  const RdoqWork *__restrict__ work, int sorted, int diagWgs)
 {
+    struct DiagLds
+    {
+        WalkShared sh;
+        BlockTables<64 / LPB, 2 * LOG2, true> bt;
+        DiagExchange ex;
+    };
+    __shared__ union { DiagLds d; WalkLds<LOG2, false> w; } mem;      // (a workgroup is one or the other)
+    if ((int)blockIdx.x >= diagWgs)
+    {
+        walkBody<LOG2, kJobOrder, false>(mem.w, blockIdx.x - diagWgs, dstAll, srcAll, statesAll, jobs, njobs, cbfOut, bitDepth, work, 1, sorted);
+        return;
+    }
     typedef LaneBlock<LOG2> LB;
     constexpr int G = LB::G, gw = LB::gw, ND = 2 * gw - 1;
-    __shared__ WalkShared sh;
-    __shared__ BlockTables<64 / LPB, 2 * LOG2, true> bt;
-    __shared__ DiagExchange ex;
+    WalkShared &sh = mem.d.sh;
+    BlockTables<64 / LPB, 2 * LOG2, true> &bt = mem.d.bt;
+    DiagExchange &ex = mem.d.ex;
     const RdoqInfo *infoAll = reinterpret_cast<const RdoqInfo *>(reinterpret_cast<const char *>(work) + rdoqInfoOffset());
     const uint32_t *order = reinterpret_cast<const uint32_t *>(infoAll + njobs);
     const int lane = threadIdx.x, k = lane & (LPB - 1), lane0 = lane & ~(LPB - 1), slot = blockIdx.x * (64 / LPB) + lane / LPB;
     bool valid = slot < njobs;
-    const int blk = valid ? (int)order[slot] : 0;
+    const int blk = valid ? (sorted ? (int)order[slot] : slot) : 0;
     const RdoqJob job = jobs[blk];
     valid = valid && job.scan_idx == 0;
-    const RdoqInfo info = infoAll[blk];
+    RdoqInfo info = infoAll[blk];
     RT_DECL;
     LB lb;
     lb.stageIn(sh, bt, lane, lane / LPB, k, LPB, job, statesAll, bitDepth, srcAll, dstAll);
@@ -1094,17 +1205,36 @@ __global__ __launch_bounds__(64, 2) void k_rdoq_diag(int16_t *__restrict__ dstAl
     const Block &b = lb.b;
     const uint8_t *rasterOf = lb.rasterOf;
     SdhAux aux;
-
-    // by SCAN index: groups to walk; groups that leave carry 1 for sure; groups whose carry is not known before they are walked
-    uint64_t walkScan = 0, sureScan = 0, openScan = 0;
-    if (valid)
-        for (int g = 0; g < G; ++g)
+    if (!sorted)      // masks by raster position -> by scan position: the block's LPB lanes take every LPB-th group and put their parts together
+    {
+        uint64_t m[3] = {0, 0, 0};
+        for (int g = k; g < G; g += LPB)
         {
             const int p = rasterOf[g];
-            walkScan |= ((info.mask >> p) & 1) << g;
-            sureScan |= ((info.mask3 >> p) & 1) << g;
-            openScan |= ((info.mask2 & ~info.mask3) >> p & 1) << g;
+            m[0] |= ((info.mask >> p) & 1) << g;
+            m[1] |= ((info.mask2 >> p) & 1) << g;
+            m[2] |= ((info.mask3 >> p) & 1) << g;
         }
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+        {
+            uint32_t lo = (uint32_t)m[q], hi = (uint32_t)(m[q] >> 32);
+#pragma unroll
+            for (int d = 1; d < LPB; d <<= 1)
+            {
+                lo |= (uint32_t)__shfl_xor((int)lo, d, kWave);
+                hi |= (uint32_t)__shfl_xor((int)hi, d, kWave);
+            }
+            m[q] = (uint64_t)hi << 32 | lo;
+        }
+        info.mask = m[0];
+        info.mask2 = m[1];
+        info.mask3 = m[2];
+    }
+
+    // by SCAN index: groups to walk; groups that leave carry 1 for sure; groups whose carry is not known before they are walked
+    uint64_t walkScan = valid ? info.mask : 0;      // (the workspace holds the masks by scan position: k_rdoq_order)
+    const uint64_t sureScan = valid ? info.mask3 : 0, openScan = valid ? info.mask2 & ~info.mask3 : 0;
     const int firstGroup = walkScan ? 63 - __clzll((long long)walkScan) : -1;
     int firstPos = -1;
     if (firstGroup >= 0)
@@ -1118,8 +1248,10 @@ __global__ __launch_bounds__(64, 2) void k_rdoq_diag(int16_t *__restrict__ dstAl
     WalkState ws;
     uint64_t carryOut = 0;      // carry each walked group left, by scan index
     int gAcc = firstGroup;      // next group (scan index, going down) the running state has not seen yet
-    auto hopZeros = [&](int lowest) {
-        for (; gAcc >= lowest; --gAcc) ws.zeroGroup(lb.zeroGroupCost(ws.coded, rasterOf[gAcc]));
+    auto hopZeros = [&](int lowest) {      // the groups lowest .. gAcc are all-zero ones
+        if (gAcc < lowest) return;
+        ws.zeroGroups(((2ull << gAcc) - 1) & ~((1ull << lowest) - 1), b);
+        gAcc = lowest - 1;
     };
 
     // The wavefront goes down the anti-diagonals together.  (Letting each block go down ITS anti-diagonals saves the rounds a block spends
@@ -1216,7 +1348,7 @@ __global__ __launch_bounds__(64, 2) void k_rdoq_diag(int16_t *__restrict__ dstAl
                 o.localStop = f & 1;
                 o.coded = (f >> 1) & 1;
                 o.carry = carry = (f >> 2) & 1;
-                ws.walkedGroup(o, pickG[i], rasterOf[pickG[i]], (f >> 3) & 1);
+                ws.walkedGroup(o, pickG[i], rasterOf[pickG[i]], (f >> 3) & 1, lb.scanOf, gw);
                 carryOut |= (uint64_t)o.carry << pickG[i];
                 gAcc = pickG[i] - 1;
             }
@@ -1279,43 +1411,72 @@ extern "C" __attribute__((visibility("default"))) int havoc_mi355x_debug_rdoq_ti
 
 size_t rdoq_workspace_bytes(int njobs) { return rdoqInfoOffset() + (size_t)max(njobs, 0) * (sizeof(RdoqInfo) + sizeof(uint32_t)) + 64; }
 
-// the passes after the scan: order, then the walk(s)
+// diagnostic A/B switches (profiles/): HAVOC_RDOQ_DIAG = lanes per block of the anti-diagonal walk of 32x32 blocks (0: off, 4, 8), HAVOC_RDOQ_DIAG16 the same for 16x16
+// blocks, HAVOC_RDOQ_SORT = 1: histogram + counting sort whatever the launch's size (tests/test_rdoq.py runs its cases both ways)
+static int envInt(const char *name, int otherwise) { const char *v = getenv(name); return v ? atoi(v) : otherwise; }
+
+// 32x32 blocks take the diagonal walk while its wavefronts (16 blocks each) still find a SIMD of their own: it shortens the chain, not the work -- most of its lanes
+// idle -- so a 4K picture's 41 k blocks are better off 64 to a wavefront in the sequential walk (measured: 4K step 2.43 -> 2.63 ms with the diagonal walk forced).
+// 16x16 blocks (round 3): the anti-diagonal walk is instantiated for them too (parity: tests/test_rdoq.py) and MEASURED SLOWER than a lane per
+// block -- 1080p QP32, 39 k blocks: 0.098 ms sequential, 0.157 ms with 4 lanes, 0.228 ms with 8; 4K QP27, 156 k blocks: 0.33 -> 0.82 ms (profiles/r03/rdoq_*_diag16_*.json):
+// a 16x16 block walks 3.2 groups on average and 7 at most, there is no chain to shorten.  Default: 0.
+static int diagLanes(int log2, int njobs)
+{
+    static const int diagEnv = envInt("HAVOC_RDOQ_DIAG", 4), diag16Env = envInt("HAVOC_RDOQ_DIAG16", 0);
+    return log2 == 5 ? (diagEnv == 0 || njobs > 16 * 1024 ? 0 : (diagEnv == 8 ? 8 : 4)) : (diag16Env == 0 ? 0 : (diag16Env == 8 ? 8 : 4));
+}
+// Round 6: is the launch small enough that all its walk wavefronts are resident at once (one per SIMD, 1 024 SIMDs)?  Then it lasts as long as its longest wavefront
+// whichever blocks share one, and the histogram + counting sort (memset, k_rdoq_hist / the scan's histogram, k_rdoq_order: three dependent launches on the picture's
+// critical path) are left out: blocks in job order.
+static bool inJobOrder(int log2, int njobs)
+{
+    // MEASURED (gpu call r06n, 1080p QP32): alone, the 32x32 launch 0.115 -> 0.110 ms and the five sizes side by side 0.248 -> 0.200 ms; but a 16x16 launch in job order
+    // takes 0.078 instead of 0.068 ms (every wavefront now walks as many groups as its densest block), and the STEP -- two pictures in flight, bound by instruction
+    // issue and wavefront slots, not by one chain's latency -- goes 0.687 -> 0.711 ms.  So: sorted by default (HAVOC_RDOQ_SORT: 0 = job order where it applies,
+    // 2 = job order for 32x32 only, 3 = for 16x16 only; tests/test_rdoq.py runs both orders).
+    static const int sortEnv = envInt("HAVOC_RDOQ_SORT", 1);
+    if (sortEnv == 1 || (sortEnv == 2 && log2 == 4) || (sortEnv == 3 && log2 == 5)) return false;
+    const int diag = diagLanes(log2, njobs);
+    const long waves = diag ? ((long)njobs * diag + 63) / 64 : ((long)njobs + 63) / 64;
+    return waves <= 1024;
+}
+
+template <int LOG2>
+static void launchDiag(hipStream_t st, int lpb, int16_t *dst, const int16_t *src, const uint8_t *states, const RdoqJob *j, int njobs, int32_t *cbf, int bitDepth,
+                       RdoqWork *work, int sorted)
+{
+    const int wgd = (njobs + 64 / lpb - 1) / (64 / lpb), tail = (njobs + 63) / 64;
+    if (lpb == 4) hipLaunchKernelGGL((k_rdoq_diag<LOG2, 4>), dim3(wgd + tail), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work, sorted, wgd);
+    else hipLaunchKernelGGL((k_rdoq_diag<LOG2, 8>), dim3(wgd + tail), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work, sorted, wgd);
+}
+
+// the passes after the scan.  Sorted: order, then the walk(s).  In job order: the walk alone
 static hipError_t rdoq_order_and_walk(hipStream_t st, int bitDepth, int log2, int16_t *dst, const int16_t *src, const uint8_t *states, const RdoqJob *j, int njobs,
-                                      int32_t *cbf, RdoqWork *work)
+                                      int32_t *cbf, RdoqWork *work, bool jobOrder)
 {
     const int wgs = (njobs + 63) / 64;
-    hipLaunchKernelGGL(k_rdoq_order, dim3((njobs + 255) / 256), dim3(256), 0, st, njobs, work);
-    // diagnostic A/B switch (profiles/): HAVOC_RDOQ_DIAG=0 walks every block with the sequential kernel
-    // 32x32 blocks take the diagonal walk while its wavefronts (16 blocks each) still find a SIMD of their own: it shortens the chain, not the
-    // work -- most of its lanes idle -- so a 4K picture's 41 k blocks are better off 64 to a wavefront in the sequential walk (measured: 4K
-    // step 2.43 -> 2.63 ms with the diagonal walk forced).  Diagnostic A/B switch (profiles/): HAVOC_RDOQ_DIAG = lanes per block, 0 (off), 4 or 8
-    static const int diagEnv = getenv("HAVOC_RDOQ_DIAG") ? atoi(getenv("HAVOC_RDOQ_DIAG")) : 4;
-    // 16x16 blocks (round 3): the anti-diagonal walk is instantiated for them too (HAVOC_RDOQ_DIAG16 = 4 or 8 lanes per
-    // block; parity: tests/test_rdoq.py) and MEASURED SLOWER than a lane per block -- 1080p QP32, 39 k blocks: 0.098 ms sequential, 0.157 ms
-    // with 4 lanes, 0.228 ms with 8; 4K QP27, 156 k blocks: 0.33 -> 0.82 ms; the whole step 0.521 -> 0.583 ms (profiles/r03/rdoq_*_diag16_*.json).
-    // A 16x16 block walks 3.2 groups on average and 7 at most: there is no chain to shorten, and the walk's replay of every round on every lane
-    // of a block is extra instructions.  What bounds the sequential form is latency with too little independent work to hide it (610
-    // wavefronts for 1 024 SIMDs); it overlaps with the step's other chains instead.  Default: 0.
-    static const int diag16Env = getenv("HAVOC_RDOQ_DIAG16") ? atoi(getenv("HAVOC_RDOQ_DIAG16")) : 0;
-    const int diag = log2 == 5 ? (diagEnv == 0 || njobs > 16 * 1024 ? 0 : (diagEnv == 8 ? 8 : 4)) : (diag16Env == 0 ? 0 : (diag16Env == 8 ? 8 : 4));
-    if (diag)
+    const int diag = diagLanes(log2, njobs);
+    if (jobOrder)
     {
-        const int wgd = (njobs + 64 / diag - 1) / (64 / diag);
-        if (log2 == 5)
+        if (diag)
         {
-            if (diag == 4) hipLaunchKernelGGL((k_rdoq_diag<5, 4>), dim3(wgd), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work);
-            else hipLaunchKernelGGL((k_rdoq_diag<5, 8>), dim3(wgd), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work);
+            if (log2 == 5) launchDiag<5>(st, diag, dst, src, states, j, njobs, cbf, bitDepth, work, 0);
+            else launchDiag<4>(st, diag, dst, src, states, j, njobs, cbf, bitDepth, work, 0);
         }
-        else
-        {
-            if (diag == 4) hipLaunchKernelGGL((k_rdoq_diag<4, 4>), dim3(wgd), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work);
-            else hipLaunchKernelGGL((k_rdoq_diag<4, 8>), dim3(wgd), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work);
-        }
+        else if (log2 == 4) hipLaunchKernelGGL((k_rdoq_walk<4, kJobOrder, false>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work, 0);
+        else hipLaunchKernelGGL((k_rdoq_walk<5, kJobOrder, false>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work, 0);
+        return hipGetLastError();
     }
-    // blocks with a horizontal / vertical scan (none in the reference's encoder at these sizes): the sequential walk; exits at once when there are none
+    if (log2 == 4) hipLaunchKernelGGL(k_rdoq_order<4>, dim3((njobs + 255) / 256), dim3(256), 0, st, j, njobs, work);
+    else hipLaunchKernelGGL(k_rdoq_order<5>, dim3((njobs + 255) / 256), dim3(256), 0, st, j, njobs, work);
+    if (diag)      // (its last workgroups take the blocks of the other scans)
+    {
+        if (log2 == 5) launchDiag<5>(st, diag, dst, src, states, j, njobs, cbf, bitDepth, work, 1);
+        else launchDiag<4>(st, diag, dst, src, states, j, njobs, cbf, bitDepth, work, 1);
+    }
     // sorted blocks come from all over the picture: their context states stay a per-wavefront LDS copy (64 different cache lines per access otherwise)
-    if (log2 == 4) hipLaunchKernelGGL((k_rdoq_walk<4, true, true>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work, diag);
-    else hipLaunchKernelGGL((k_rdoq_walk<5, true, true>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work, diag);
+    else if (log2 == 4) hipLaunchKernelGGL((k_rdoq_walk<4, kSorted, true>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work, 0);
+    else hipLaunchKernelGGL((k_rdoq_walk<5, kSorted, true>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work, 0);
     return hipGetLastError();
 }
 
@@ -1332,18 +1493,22 @@ hipError_t launch_rdoq(hipStream_t st, int bitDepth, int log2, int16_t *dst, con
         static const bool ldsStates = getenv("HAVOC_RDOQ_LDS_STATES") && atoi(getenv("HAVOC_RDOQ_LDS_STATES")) != 0;
         if (ldsStates)
         {
-            if (log2 == 2) hipLaunchKernelGGL((k_rdoq_walk<2, false, true>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work, 0);
-            else hipLaunchKernelGGL((k_rdoq_walk<3, false, true>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work, 0);
+            if (log2 == 2) hipLaunchKernelGGL((k_rdoq_walk<2, kInKernel, true>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work, 0);
+            else hipLaunchKernelGGL((k_rdoq_walk<3, kInKernel, true>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work, 0);
         }
-        else if (log2 == 2) hipLaunchKernelGGL((k_rdoq_walk<2, false, false>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work, 0);
-        else hipLaunchKernelGGL((k_rdoq_walk<3, false, false>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work, 0);
+        else if (log2 == 2) hipLaunchKernelGGL((k_rdoq_walk<2, kInKernel, false>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work, 0);
+        else hipLaunchKernelGGL((k_rdoq_walk<3, kInKernel, false>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work, 0);
         return hipGetLastError();
     }
-    hipError_t e = hipMemsetAsync(work, 0, sizeof(RdoqWork), st);
-    if (e != hipSuccess) return e;
-    if (log2 == 4) hipLaunchKernelGGL(k_rdoq_scan<4>, dim3((njobs + 4 * kScanSteps - 1) / (4 * kScanSteps)), dim3(64), 0, st, dst, src, j, njobs, work);
-    else hipLaunchKernelGGL(k_rdoq_scan<5>, dim3((njobs + kScanSteps - 1) / kScanSteps), dim3(64), 0, st, dst, src, j, njobs, work);
-    return rdoq_order_and_walk(st, bitDepth, log2, dst, src, states, j, njobs, cbf, work);
+    const bool jobOrder = inJobOrder(log2, njobs);
+    if (!jobOrder)
+    {
+        hipError_t e = hipMemsetAsync(work, 0, sizeof(RdoqWork), st);
+        if (e != hipSuccess) return e;
+    }
+    if (log2 == 4) hipLaunchKernelGGL(k_rdoq_scan<4>, dim3((njobs + 4 * kScanSteps - 1) / (4 * kScanSteps)), dim3(64), 0, st, dst, src, j, njobs, work, jobOrder ? 0 : 1);
+    else hipLaunchKernelGGL(k_rdoq_scan<5>, dim3((njobs + kScanSteps - 1) / kScanSteps), dim3(64), 0, st, dst, src, j, njobs, work, jobOrder ? 0 : 1);
+    return rdoq_order_and_walk(st, bitDepth, log2, dst, src, states, j, njobs, cbf, work, jobOrder);
 }
 
 // Rdoq::runQuantisation for 16x16 / 32x32 blocks whose scan was done by havoc_mi355x_tu_forward_scan (RdoqInfo per block in the workspace, level
@@ -1355,10 +1520,11 @@ hipError_t launch_rdoq_prescanned(hipStream_t st, int bitDepth, int log2, int16_
     if (log2 != 4 && log2 != 5) return hipErrorInvalidValue;
     const RdoqJob *j = static_cast<const RdoqJob *>(jobs);
     RdoqWork *work = static_cast<RdoqWork *>(workspace);
+    if (inJobOrder(log2, njobs)) return rdoq_order_and_walk(st, bitDepth, log2, dst, src, states, j, njobs, cbf, work, true);
     hipError_t e = hipMemsetAsync(work, 0, sizeof(RdoqWork), st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_rdoq_hist, dim3((njobs + 255) / 256), dim3(256), 0, st, j, njobs, work);
-    return rdoq_order_and_walk(st, bitDepth, log2, dst, src, states, j, njobs, cbf, work);
+    return rdoq_order_and_walk(st, bitDepth, log2, dst, src, states, j, njobs, cbf, work, false);
 }
 
 } // namespace havoc_gpu

@@ -47,6 +47,7 @@ def _load():
         "destroy": [_vp],
         "set_stream": [_vp, _vp],
         "sync": [_vp],
+        "sync_spin": [_vp],
         "device_info": [_vp, C.POINTER(C.c_int64)],
         "malloc": [_vp, C.POINTER(_vp), C.c_size_t],
         "free": [_vp, _vp],
