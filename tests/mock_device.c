@@ -60,6 +60,10 @@ int havoc_mi355x_create(havoc_mi355x_ctx **ctx, int device, void *stream)
 void havoc_mi355x_destroy(havoc_mi355x_ctx *ctx) { write_histogram(); free(ctx); }
 int havoc_mi355x_sync(havoc_mi355x_ctx *ctx) { (void)ctx; return 0; }
 int havoc_mi355x_sync_spin(havoc_mi355x_ctx *ctx) { (void)ctx; return 0; }
+/* fork / join lanes: the stand-in runs every launch at once, in call order */
+int havoc_mi355x_fork(havoc_mi355x_ctx *ctx, int nlanes) { (void)ctx; return nlanes >= 1 && nlanes <= 8 ? 0 : -1; }
+int havoc_mi355x_lane(havoc_mi355x_ctx *ctx, int lane) { (void)ctx; return lane >= 0 && lane < 8 ? 0 : -1; }
+int havoc_mi355x_join(havoc_mi355x_ctx *ctx) { (void)ctx; return 0; }
 int havoc_mi355x_malloc(havoc_mi355x_ctx *ctx, void **p, size_t n) { (void)ctx; *p = calloc(1, n + 64); return *p ? 0 : -1; }
 int havoc_mi355x_free(havoc_mi355x_ctx *ctx, void *p) { (void)ctx; free(p); return 0; }
 int havoc_mi355x_h2d(havoc_mi355x_ctx *ctx, void *d, const void *h, size_t n) { (void)ctx; memcpy(d, h, n); return 0; }

@@ -191,12 +191,12 @@ print("ok")
 def test_every_walk_form_of_32x32_blocks_matches_the_oracle(form, sort):
     """HAVOC_RDOQ_SORT (round 6; default 1): 0 = a launch this small is walked in job order (no histogram, no counting sort; the diagonal walk's last workgroups take the
     blocks of the other scans), 1 = sorted densest-first as a 4K picture's launch is.  HAVOC_RDOQ_DIAG picks how 32x32 blocks are walked -- 0: sequential kernel only, 4 / 8: the diagonal walk with that many lanes per
-    block (4 is the default) -- and is read once per process, so each form runs in its own interpreter; diagonal-scan blocks and
+    block (0 is the default since round 6: the step is bound by instruction issue and the diagonal walk issues 3.5x the instructions) -- and is read once per process, so each form runs in its own interpreter; diagonal-scan blocks and
     the few horizontal / vertical ones of make_blocks (which go to the sequential kernel whatever the form) in one launch"""
     import subprocess
     import sys
     out = subprocess.run([sys.executable, "-c", _WALK_FORMS_SCRIPT, ROOT], capture_output=True, text=True, timeout=600,
-                         env=dict(os.environ, HAVOC_RDOQ_DIAG=form, HAVOC_RDOQ_SORT=sort))
+                         env=dict(os.environ, HAVOC_RDOQ_DIAG=form, HAVOC_RDOQ_SORT=sort, HAVOC_RDOQ_TINY="0"))      # (TINY 0: launches this small would otherwise be one kernel in job order)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-1500:]
 
 
@@ -221,10 +221,10 @@ print("ok")
 @pytest.mark.parametrize("sort", ["0", "1"])
 @pytest.mark.parametrize("form", ["0", "4", "8"])
 def test_every_walk_form_of_16x16_blocks_matches_the_oracle(form, sort):
-    """(HAVOC_RDOQ_SORT as above.)  HAVOC_RDOQ_DIAG16: how 16x16 blocks are walked -- 0: sequential kernel (a lane per block), 4 (default since round 3) / 8: the
+    """(HAVOC_RDOQ_SORT as above.)  HAVOC_RDOQ_DIAG16: how 16x16 blocks are walked -- 0 (default): sequential kernel (a lane per block), 4 / 8: the
     anti-diagonal walk with that many lanes per block; each form in its own interpreter (the switch is read once per process)"""
     import subprocess
     import sys
     out = subprocess.run([sys.executable, "-c", _WALK_FORMS_16_SCRIPT, ROOT], capture_output=True, text=True, timeout=600,
-                         env=dict(os.environ, HAVOC_RDOQ_DIAG16=form, HAVOC_RDOQ_SORT=sort))
+                         env=dict(os.environ, HAVOC_RDOQ_DIAG16=form, HAVOC_RDOQ_SORT=sort, HAVOC_RDOQ_TINY="0"))
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-1500:]

@@ -119,7 +119,7 @@ def test_hooked_reference_encoder_is_served_from_registered_pictures_and_writes_
 
 @needs_hooked
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["gpu_ra_medium_qp32", "gpu_ra_medium_10bit"])
+@pytest.mark.parametrize("case", ["gpu_ra_medium_qp32", "gpu_ra_medium_10bit", "ra_medium_qp32"])
 def test_hooked_reference_encoder_on_the_mi355x(case, workdir):
     """the same on the real device: stream identical, most table calls answered from SAD surfaces / phase planes / tile-SATD sets computed on the GPU"""
     import time
@@ -132,9 +132,11 @@ def test_hooked_reference_encoder_on_the_mi355x(case, workdir):
     print(case, s, f"{dt:.1f} s, {dt / calls * 1e6:.2f} us per table call, {s['launches'] / et.CASES[case][2]:.0f} launches per frame")
     assert got == ref, f"{case}: the hooked encoder's stream on the MI355X differs from the reference encoder's"
     assert s["served"] > 0.85 * calls and s["one_job"] > 0 and s["surfaces"] > 0 and s["satd_batches"] > 0, s      # round 5: intra stage and TU chains served too
-    # round 6: one-job launches 11 % -> < 5 % of the table calls, launches per frame 125 k -> < 90 k, 0.5 -> > 1 frame/s (measured: 3.5 %, 71 k, 1.5)
+    # round 6: one-job launches 11 % -> < 2 % of the table calls (measured 1.6 %; the 10-bit clip at QP 27 keeps more levels: 1.9 %), launches per frame
+    # 125 k -> < 50 k (45 k: one per wait is the floor, and a frame has ~30 k waits), 0.5 -> 1.9 frames/s on the 3-frame clips -- whose 1.5 s hold ~0.4 s of process and
+    # HIP start-up -- and the rate proper on the 9 frames of ra_medium_qp32
     frames = et.CASES[case][2]
-    assert s["one_job"] < 0.05 * calls and s["launches"] / frames < 90e3 and frames / dt > 1.0, (s, dt)
+    assert s["one_job"] < 0.025 * calls and s["launches"] / frames < 50e3 and frames / dt > (2.0 if frames >= 9 else 1.5), (s, dt)
     _check_golden(case, got, workdir)
 
 

@@ -215,6 +215,41 @@ __device__ __forceinline__ int satd_rows_pk(uint32_t (&p)[TS / 2], int r)
     return r == 0 ? t : 0;
 }
 
+// SATD of an 8 x 8 tile of 8-bit samples held by ONE lane (round 6): d[r][k] = row r's eight differences two per register, in the pairing of the masks
+// (b0, b2), (b1, b3), (b4, b6), (b5, b7) -- any pairing that permutes the index bits leaves the coefficient set alone.  The 64-point transform is six butterfly
+// stages over the index bits: two between a row's registers, three between rows (plain packed adds / subtracts), the sixth inside a register (pk_bfly) right before
+// the magnitudes are summed.  352 instructions per tile where the row-per-lane form (satd_rows_pk<8>: eight lanes, three DPP stages) issues 8 x 75: the step is bound
+// by instruction issue.  Returns the normalised tile cost, (sum + 2) >> 2 (havoc/hadamard.cpp:58-98).
+__device__ __forceinline__ int satd_tile8_pk(uint32_t (&d)[8][4])
+{
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+    {
+        const uint32_t a0 = pk_add(d[r][0], d[r][1]), a1 = pk_sub(d[r][0], d[r][1]), a2 = pk_add(d[r][2], d[r][3]), a3 = pk_sub(d[r][2], d[r][3]);
+        d[r][0] = pk_add(a0, a2); d[r][2] = pk_sub(a0, a2);
+        d[r][1] = pk_add(a1, a3); d[r][3] = pk_sub(a1, a3);
+    }
+#pragma unroll
+    for (int len = 1; len < 8; len <<= 1)
+#pragma unroll
+        for (int i = 0; i < 8; i += len << 1)
+#pragma unroll
+            for (int r = i; r < i + len; ++r)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                {
+                    const uint32_t a = d[r][k], b = d[r + len][k];
+                    d[r][k] = pk_add(a, b);
+                    d[r + len][k] = pk_sub(a, b);
+                }
+    uint32_t sum = 0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sum = pk_abs_acc(pk_bfly(d[r][k]), sum);
+    return (int)((sum + 2) >> 2);
+}
+
 // ---- intra prediction angles ----------------------------------------------------------------------------------
 
 // intraPredAngle (havoc/pred_intra.cpp angle table) without a memory look-up: |angle| depends on the distance from the

@@ -9,6 +9,8 @@
 // b % 8-th contiguous eighth of the job table (xcd_block): one band of the picture per XCD L2.
 #include "common.h"
 
+#include <cstdlib>
+
 namespace havoc_gpu {
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1069,7 +1071,9 @@ constexpr int kSatdMulti = 16;
 
 // CPS = candidates per lane group: a job's 16 candidates are split over 16 / CPS lane groups (more wavefronts in
 // flight; the source rows are then fetched 16 / CPS times instead of once)
-template <int S, int G, int CPS>
+// TILE (round 6; 8-bit samples, blocks of >= four 8 x 8 tiles): a LANE takes a whole 8 x 8 tile instead of one of its rows (common.h: satd_tile8_pk), G = the tiles of
+// the class's largest block.  No cross-lane step but the final sum, 0.59 of the instructions.
+template <int S, int G, int CPS, bool TILE = false>
 __global__ __launch_bounds__(256) void k_satd_multi(const char *__restrict__ pa, long stride_a, const char *__restrict__ pb, long stride_b,
                                                     const int32_t *__restrict__ jobs, int njobs, int32_t *__restrict__ out)
 {
@@ -1089,7 +1093,39 @@ __global__ __launch_bounds__(256) void k_satd_multi(const char *__restrict__ pa,
     int acc[CPS];
 #pragma unroll
     for (int k = 0; k < CPS; ++k) acc[k] = 0;
-    if (((w | h) & 7) == 0)
+    if (TILE && S == 1 && ((w | h) & 7) == 0)
+    {
+        const int tw = w >> 3;
+        const FastDiv fd(tw);
+        const uint32_t m = 0x00ff00ffu;
+        for (int t = l; t < tw * (h >> 3); t += G)
+        {
+            const int ty = fd.div(t), tx = t - ty * tw;
+            const char *pa8 = a + (long)(ty * 8) * sab + tx * 8;
+            const long ob = (long)(ty * 8) * sbb + tx * 8;
+            uint32_t ap[8][4];
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+            {
+                const u32x2 va = ld8(pa8 + r * sab);
+                ap[r][0] = va.x & m; ap[r][1] = (va.x >> 8) & m; ap[r][2] = va.y & m; ap[r][3] = (va.y >> 8) & m;
+            }
+#pragma unroll
+            for (int k = 0; k < CPS; ++k)
+            {
+                uint32_t d[8][4];
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                {
+                    const u32x2 vb = ld8(b[k] + ob + r * sbb);
+                    d[r][0] = pk_sub(ap[r][0], vb.x & m); d[r][1] = pk_sub(ap[r][1], (vb.x >> 8) & m);
+                    d[r][2] = pk_sub(ap[r][2], vb.y & m); d[r][3] = pk_sub(ap[r][3], (vb.y >> 8) & m);
+                }
+                acc[k] += satd_tile8_pk(d);
+            }
+        }
+    }
+    else if (((w | h) & 7) == 0)
     {
         const int tw = w >> 3;
         const FastDiv fd(tw);
@@ -1320,6 +1356,19 @@ hipError_t launch_satd_multi(hipStream_t st, int S, int maxw, int maxh, const vo
     // measured on MI355X (184 k candidates of a 1080p frame): 2 candidates per lane group 63 us, 1: 69, 4: 70, 8: 83,
     // all 16: 181 -- wavefronts in flight matter more than fetching the source rows only once
     constexpr int CPS = 2;
+    // round 6: 8-bit classes whose largest block has at least four 8 x 8 tiles take a tile per lane (G = those tiles, a power of two)
+    const int tiles = ((maxw + 7) / 8) * ((maxh + 7) / 8);
+    static const bool tileOff = getenv("HAVOC_SATD_TILE") && atoi(getenv("HAVOC_SATD_TILE")) == 0;      // diagnostic A/B switch (profiles/)
+    if (S == 1 && tiles >= 4 && !tileOff)
+    {
+        const int GT = tiles <= 4 ? 4 : tiles <= 8 ? 8 : tiles <= 16 ? 16 : tiles <= 32 ? 32 : 64;
+        const long groups = (long)n * (kSatdMulti / CPS);
+        const dim3 g((unsigned)((groups + 256 / GT - 1) / (256 / GT))), b256(256);
+#define SATD_GO_T(GG) hipLaunchKernelGGL((k_satd_multi<1, GG, CPS, true>), g, b256, 0, st, x, sa, y, sb, j, n, out)
+        if (GT == 4) SATD_GO_T(4); else if (GT == 8) SATD_GO_T(8); else if (GT == 16) SATD_GO_T(16); else if (GT == 32) SATD_GO_T(32); else SATD_GO_T(64);
+#undef SATD_GO_T
+        return hipGetLastError();
+    }
     const long groups = (long)n * (kSatdMulti / CPS);
     const dim3 g((unsigned)((groups + 256 / G - 1) / (256 / G))), b256(256);
 #define SATD_GO(SS, GG) hipLaunchKernelGGL((k_satd_multi<SS, GG, CPS>), g, b256, 0, st, x, sa, y, sb, j, n, out)

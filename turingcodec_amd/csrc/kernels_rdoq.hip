@@ -1415,14 +1415,18 @@ size_t rdoq_workspace_bytes(int njobs) { return rdoqInfoOffset() + (size_t)max(n
 // blocks, HAVOC_RDOQ_SORT = 1: histogram + counting sort whatever the launch's size (tests/test_rdoq.py runs its cases both ways)
 static int envInt(const char *name, int otherwise) { const char *v = getenv(name); return v ? atoi(v) : otherwise; }
 
-// 32x32 blocks take the diagonal walk while its wavefronts (16 blocks each) still find a SIMD of their own: it shortens the chain, not the work -- most of its lanes
-// idle -- so a 4K picture's 41 k blocks are better off 64 to a wavefront in the sequential walk (measured: 4K step 2.43 -> 2.63 ms with the diagonal walk forced).
+// The diagonal walk of 32x32 blocks shortens a block's chain, not the work: 16 blocks to a wavefront instead of 64, most lanes idle -- 28 M vector instructions for a
+// 1080p picture's 14.7 k blocks where the sequential sorted walk issues ~8 M.  Alone the launch is shorter (0.110 against 0.135 ms) and rounds 2-5 chose it for that;
+// but the STEP is bound by vector-instruction issue (the kernels' VALU-busy time adds up to ~0.47 of its 0.69 ms), and there the sequential walk wins: same box,
+// alternating, three runs each (gpu call r06s): step 0.697 / 0.699 / 0.696 ms with 4 lanes per block, 0.688 / 0.676 / 0.685 sequential, 0.730-0.741 with 8 lanes; one picture
+// in flight 0.719 -> 0.690 ms.  (At 4K it always lost: 2.43 -> 2.63 ms forced.)  So since round 6 the default is the sequential walk; HAVOC_RDOQ_DIAG = 4 / 8 selects the
+// diagonal walk for a caller that wants one launch's latency (<= 16 k blocks).
 // 16x16 blocks (round 3): the anti-diagonal walk is instantiated for them too (parity: tests/test_rdoq.py) and MEASURED SLOWER than a lane per
 // block -- 1080p QP32, 39 k blocks: 0.098 ms sequential, 0.157 ms with 4 lanes, 0.228 ms with 8; 4K QP27, 156 k blocks: 0.33 -> 0.82 ms (profiles/r03/rdoq_*_diag16_*.json):
 // a 16x16 block walks 3.2 groups on average and 7 at most, there is no chain to shorten.  Default: 0.
 static int diagLanes(int log2, int njobs)
 {
-    static const int diagEnv = envInt("HAVOC_RDOQ_DIAG", 4), diag16Env = envInt("HAVOC_RDOQ_DIAG16", 0);
+    static const int diagEnv = envInt("HAVOC_RDOQ_DIAG", 0), diag16Env = envInt("HAVOC_RDOQ_DIAG16", 0);
     return log2 == 5 ? (diagEnv == 0 || njobs > 16 * 1024 ? 0 : (diagEnv == 8 ? 8 : 4)) : (diag16Env == 0 ? 0 : (diag16Env == 8 ? 8 : 4));
 }
 // Round 6: is the launch small enough that all its walk wavefronts are resident at once (one per SIMD, 1 024 SIMDs)?  Then it lasts as long as its longest wavefront
@@ -1498,6 +1502,15 @@ hipError_t launch_rdoq(hipStream_t st, int bitDepth, int log2, int16_t *dst, con
         }
         else if (log2 == 2) hipLaunchKernelGGL((k_rdoq_walk<2, kInKernel, false>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work, 0);
         else hipLaunchKernelGGL((k_rdoq_walk<3, kInKernel, false>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work, 0);
+        return hipGetLastError();
+    }
+    // Round 6: a launch of a few wavefronts (an intra picture's level, a decision step's candidates of one size: tens to hundreds of blocks) is ONE kernel, the scan
+    // inside it, blocks in job order -- memset + scan + order + walk were four dependent launches for a few microseconds of work
+    static const int tiny = envInt("HAVOC_RDOQ_TINY", 1024);
+    if (njobs <= tiny)
+    {
+        if (log2 == 4) hipLaunchKernelGGL((k_rdoq_walk<4, kInKernel, false>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work, 0);
+        else hipLaunchKernelGGL((k_rdoq_walk<5, kInKernel, false>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work, 0);
         return hipGetLastError();
     }
     const bool jobOrder = inJobOrder(log2, njobs);

@@ -684,7 +684,7 @@ class Havoc:
         out = np.zeros((len(jobs), 16), np.int32)
         ad, bdv = self.up(a), self.up(b)
         rows = ((jobs[:, 1] + 7) // 8) * jobs[:, 2]
-        for lo, hi, mw, mh in ((0, 8, 8, 8), (8, 16, 16, 8), (16, 32, 16, 16), (32, 1 << 30, 64, 64)):
+        for lo, hi, mw, mh in ((0, 8, 8, 8), (8, 16, 16, 8), (16, 32, 16, 16), (32, 128, 32, 32), (128, 1 << 30, 64, 64)):
             idx = np.flatnonzero((rows > lo) & (rows <= hi))
             if len(idx):
                 o = self.zeros(16 * len(idx), np.int32)

@@ -539,12 +539,23 @@ int havoc_search_intra_chain(havoc_mi355x_ctx *ctx, int S, int bitDepth, const h
         havoc_mi355x_rdoq_lambda(lambda, quant[G.log2 - 2].inv_scale, &w.lq, &w.sf);
     }
     for (int l = 0; l < nlevels; ++l)
+    {
+        // Round 6: the partitions of a level are independent of each other WHATEVER their size (that is what a level is), so the sizes' launch chains -- 13 launches each, one
+        // behind the other -- go side by side on the context's fork / join lanes instead of in a row on one stream; the join is the level's end (the next level's gathers
+        // read what every size committed).  A level then lasts as long as its longest chain, not as long as their sum.
+        int active = 0;
+        for (int g = 0; g < nsizes; ++g)
+            if (sizes[g].n && sizes[g].first[l + 1] > sizes[g].first[l]) ++active;
+        const bool forked = active > 1;
+        if (forked) RC(havoc_mi355x_fork(ctx, active));
+        int laneAt = 0;
         for (int g = 0; g < nsizes; ++g)
         {
             const havoc_intra_chain_size &G = sizes[g];
             if (!G.n) continue;
             const int a = G.first[l], cnt = G.first[l + 1] - a;
             if (!cnt) continue;
+            if (forked) RC(havoc_mi355x_lane(ctx, laneAt++));
             const Work &w = work[g];
             const int nn = 1 << G.log2, area = nn * nn, tr = G.log2 == 2 ? 1 : 0, cap = cnt * K;
             const havoc_rqt_quant &q = quant[G.log2 - 2];
@@ -582,6 +593,8 @@ int havoc_search_intra_chain(havoc_mi355x_ctx *ctx, int S, int bitDepth, const h
             st.launches += 13;
             st.candidates += cap;
         }
+        if (forked) RC(havoc_mi355x_join(ctx));
+    }
     for (int g = 0; g < nsizes; ++g)
         if (sizes[g].n)
         {

@@ -419,7 +419,8 @@ class FrameWorkload:
         mj[ng:, 0], mj[ng:, 1], mj[ng:, 2], mj[ng:, 3], mj[ng:, 4] = sp[tail, 0], sp[tail, 2], sp[tail, 3], 1, boff[tail]
         cand[ng:, 0] = tail
         rows = ((mj[:, 1] + 7) // 8) * mj[:, 2]
-        classes = ((0, 8, 8, 8), (8, 16, 16, 8), (16, 32, 16, 16), (32, 1 << 30, 64, 64))
+        # (round 6: 32x32 units apart from 64x64 ones -- the SATD kernel gives a lane an 8x8 TILE and a class as many lanes per job as its largest block has tiles)
+        classes = ((0, 8, 8, 8), (8, 16, 16, 8), (16, 32, 16, 16), (32, 128, 32, 32), (128, 1 << 30, 64, 64))
         self.subpel_planes = {(mw, mh): np.ascontiguousarray(mj[(rows > lo) & (rows <= hi)]) for lo, hi, mw, mh in classes}
         self.subpel_planes_idx = {(mw, mh): cand[(rows > lo) & (rows <= hi)] for lo, hi, mw, mh in classes}
         self.plane_margin = 72     # planes are computed over the picture plus the motion range (64) plus a block edge (8)
