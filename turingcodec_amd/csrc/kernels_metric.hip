@@ -1356,7 +1356,8 @@ hipError_t launch_satd_multi(hipStream_t st, int S, int maxw, int maxh, const vo
     // measured on MI355X (184 k candidates of a 1080p frame): 2 candidates per lane group 63 us, 1: 69, 4: 70, 8: 83,
     // all 16: 181 -- wavefronts in flight matter more than fetching the source rows only once
     constexpr int CPS = 2;
-    // round 6: 8-bit classes whose largest block has at least four 8 x 8 tiles take a tile per lane (G = those tiles, a power of two)
+    // round 6: 8-bit classes whose largest block has at least four 8 x 8 tiles take a tile per lane (G = those tiles, a power of two); 4 candidates per lane group
+    // instead of 2 measured slower there too (group 0.076 -> 0.097 ms, step 0.642 -> 0.652: gpu call r06v)
     const int tiles = ((maxw + 7) / 8) * ((maxh + 7) / 8);
     static const bool tileOff = getenv("HAVOC_SATD_TILE") && atoi(getenv("HAVOC_SATD_TILE")) == 0;      // diagnostic A/B switch (profiles/)
     if (S == 1 && tiles >= 4 && !tileOff)
