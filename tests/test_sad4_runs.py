@@ -216,3 +216,37 @@ def test_runs_equal_calls_on_a_picture_of_the_bench(bit_depth):
     for i in np.random.default_rng(1).integers(0, len(wl.sad4), 300):
         j = wl.sad4[i]
         assert list(b[i]) == orc.sad4(wl.luma, int(j[0]), wl.stride, wl.luma, [int(v) for v in j[1:5]], wl.stride, int(j[5]), int(j[6]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bit_depth", [8, 10])
+def test_repeated_candidates_of_a_run(bit_depth):
+    """a third of the reference encoder's own havoc_sad_multiref candidates repeat an earlier one of the same search (same source block, size, reference position: counted in
+    libhavoc_classic.so over four encodes, NOTEBOOK round 6).  Runs of ONE position asked 512 times, of a handful of positions in every order, of 512 distinct positions, of
+    64x64 blocks (row slices), boxes given / found by the kernel: all equal the oracle's per-call values.  (Written for a form of k_sad4r that measured the distinct positions
+    once -- an LDS hash table per run -- which was exact and SLOWER, 0.154 -> 0.162 ms: the cases stay.)"""
+    from reflibs import Oracle
+    from turingcodec_amd import Havoc
+    hv, orc = Havoc(0), Oracle()
+    S = 1 if bit_depth == 8 else 2
+    rng = np.random.default_rng(400 + bit_depth)
+    src, ref, stride, pad = planes(rng, bit_depth, 256, 192)
+
+    def run_of(w, h, offsets):
+        x, y = 96, 64
+        so = (y + pad) * stride + x + pad
+        o = np.asarray(offsets, np.int64).reshape(-1, 4, 2)
+        j = np.zeros((len(o), 8), np.int32)
+        j[:, 0], j[:, 5], j[:, 6] = so, w, h
+        j[:, 1:5] = (y + pad + o[:, :, 1]) * stride + x + pad + o[:, :, 0]
+        return j
+
+    same = run_of(16, 16, np.tile([[3, -2]], (128 * 4, 1)))
+    few = run_of(16, 16, rng.integers(-2, 3, (128 * 4, 2)))                                             # 25 positions, 512 slots
+    grid = np.stack(np.meshgrid(np.arange(-16, 16), np.arange(-8, 8)), -1).reshape(-1, 2)              # 512 distinct positions
+    distinct = run_of(8, 8, grid[rng.permutation(512)])
+    big = run_of(64, 64, rng.integers(-3, 4, (16 * 4, 2)))
+    mixed = run_of(32, 32, np.concatenate([np.tile([[0, 0]], (40, 1)), rng.integers(-20, 21, (152, 2))]))
+    for name, jobs in (("same", same), ("few", few), ("distinct", distinct), ("big", big), ("mixed", mixed)):
+        for runs in (Havoc.sad4_make_runs(jobs, 128, stride, S), Havoc.sad4_make_runs(jobs, 128)):
+            assert not (bad := check(hv, orc, src, ref, stride, jobs, runs)), (name, bad[:4])
