@@ -387,10 +387,6 @@ __global__ __launch_bounds__(256, MINW) void k_sad4w(const char *__restrict__ sr
 // box does not fit (far raster rings), whose calls differ in source / size, or with an unchunkable width goes call by call through sad4_job above --
 // same results either way; runs are an accelerator, not a contract (jobs outside every run are simply not computed).
 // ---------------------------------------------------------------------------------------------------------
-#ifndef HAVOC_SAD4_DEDUP
-#define HAVOC_SAD4_DEDUP 1
-#endif
-constexpr bool kSadDedup = HAVOC_SAD4_DEDUP != 0;      // (diagnostic builds: -DHAVOC_SAD4_DEDUP=0)
 constexpr int kRunMax = 128;        // calls of a run whose displacements are kept in LDS (longer runs: call by call)
 
 template <int S, int CB, int U>
@@ -615,63 +611,18 @@ __device__ __forceinline__ uint32_t sad_lane_rows(const __attribute__((address_s
 // workgroups that fetch their next run's box and jobs into registers while they compute (the run record carrying the source offset and size): 0.20 ms -- the registers
 // that costs leave four workgroups per CU, and ONE workgroup alone on a CU still takes ~15 k cycles per run (the per-row scalar loads miss the scalar cache).
 // profiles/r05/sad4_lane_forms.txt has every number.
-// Round 6: a search evaluates the same position again and again -- of the reference ENCODER's own havoc_sad_multiref candidates 30-40 % repeat an earlier one of the
-// same search (same source block, size and reference position; counted per calling thread in libhavoc_classic.so over four encodes: NOTEBOOK round 6) -- and a run is
-// a search's calls, so the run's candidates are first reduced to the DISTINCT ones (a 1 024-slot open-addressing table in LDS keyed by the candidate's (column, row),
-// the distinct ones listed densely), only those are measured, and every call slot then copies the value of its position's first occurrence.  `dup` (null: the
-// source block occupies that memory, no reduction) = the table's 1 024 dwords; owner / uniq: kRunMax * 4 entries each.
-struct RunDup
-{
-    uint16_t owner[kRunMax * 4], uniq[kRunMax * 4];
-    int nuniq;
-};
-
 template <int S, int NW, bool SG>
 __device__ __forceinline__ void sad4_run_lanes(const __attribute__((address_space(3))) uint32_t *win, const __attribute__((address_space(3))) uint32_t *srcw,
                                                const __attribute__((address_space(3))) uint32_t *cand, uint32_t *s_acc, int pitchD, int lead, int mndx,
-                                               int mndy, int rowBytes, int h, int count, int tid, int32_t *__restrict__ out, const uint32_t *__restrict__ gsrc, int gpitch,
-                                               uint32_t *dupTable = nullptr, RunDup *dup = nullptr)
+                                               int mndy, int rowBytes, int h, int count, int tid, int32_t *__restrict__ out, const uint32_t *__restrict__ gsrc, int gpitch)
 {
-    const int P = 4 * count, nd = rowBytes >> 2;
+    const int P = 4 * count, nd = rowBytes >> 2, chunks = (P + 63) >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const bool dedup = dupTable != nullptr;
-    int nu = P;
-    if (dedup)
-    {
-        for (int i = tid; i < 1024; i += 64 * NW) dupTable[i] = 0xffffffffu;
-        for (int i = tid; i < P; i += 64 * NW) s_acc[i] = 0;      // (also what the row slices' partial sums need)
-        if (tid == 0) dup->nuniq = 0;
-        __syncthreads();
-        for (int p = tid; p < P; p += 64 * NW)
-        {
-            const uint32_t v = cand[p];
-            uint32_t hs = (v * 0x9E3779B1u) >> 22;
-            while (true)
-            {
-                const uint32_t old = atomicCAS(&dupTable[hs], 0xffffffffu, (uint32_t)p);
-                if (old == 0xffffffffu)
-                {
-                    dup->uniq[atomicAdd(&dup->nuniq, 1)] = (uint16_t)p;
-                    dup->owner[p] = (uint16_t)p;
-                    break;
-                }
-                if (cand[old] == v)
-                {
-                    dup->owner[p] = (uint16_t)old;
-                    break;
-                }
-                hs = (hs + 1) & 1023;
-            }
-        }
-        __syncthreads();
-        nu = dup->nuniq;
-    }
-    const int chunks = (nu + 63) >> 6;
     // row slices only where wavefronts would idle (a run of few candidates: the big blocks), and of at least eight rows
     int ns = 1;
     while (ns < 8 && chunks * ns < NW && h >= 16 * ns) ns *= 2;
     const int rps = (h + ns - 1) / ns;
-    if (ns > 1 && !dedup)
+    if (ns > 1)
     {   // (the partial sums meet in s_acc: cleared here)
         for (int i = tid; i < P; i += 64 * NW) s_acc[i] = 0;
         __syncthreads();
@@ -680,7 +631,7 @@ __device__ __forceinline__ void sad4_run_lanes(const __attribute__((address_spac
     {
         const int chunk = ns == 1 ? t : t / ns, slice = t - chunk * ns;
         const int pos = chunk * 64 + lane;
-        const int p = dedup ? (int)dup->uniq[min(pos, nu - 1)] : pos;
+        const int p = pos;
         const int v = (int)cand[min(p, P - 1)];
         const int col = (int)(short)(v & 0xffff) - mndx, row = (v >> 16) - mndy;
         const int bo = lead + col * S, sh = bo & 3;
@@ -695,21 +646,16 @@ __device__ __forceinline__ void sad4_run_lanes(const __attribute__((address_spac
         else if (nd == 4) acc = sad_lane_rows<S, 4, SG>(q, sp, pitchD, nd, rows, sh, gs, gpitch);
         else if (nd == 2) acc = sad_lane_rows<S, 2, SG>(q, sp, pitchD, nd, rows, sh, gs, gpitch);
         else acc = sad_lane_rows<S, 0, SG>(q, sp, pitchD, nd, rows, sh, gs, gpitch);
-        if (pos < nu)
+        if (p < P)
         {
-            if (ns > 1) atomicAdd(&s_acc[p], acc);
-            else if (dedup) s_acc[p] = acc;
-            else out[p] = (int32_t)(S == 2 ? acc >> 2 : acc);
+            if (ns == 1) out[p] = (int32_t)(S == 2 ? acc >> 2 : acc);
+            else atomicAdd(&s_acc[p], acc);
         }
     }
-    if (ns > 1 || dedup)
+    if (ns > 1)
     {
         __syncthreads();
-        for (int p = tid; p < P; p += 64 * NW)
-        {
-            const uint32_t a = s_acc[dedup ? (int)dup->owner[p] : p];
-            out[p] = (int32_t)(S == 2 ? a >> 2 : a);
-        }
+        for (int p = tid; p < P; p += 64 * NW) out[p] = (int32_t)(S == 2 ? s_acc[p] >> 2 : s_acc[p]);
     }
 }
 
@@ -721,8 +667,7 @@ struct RunLds
     static constexpr int kSrcD = 64 * 64 * S / 4;                // the source block
     __attribute__((aligned(16))) uint32_t lds[kWinD + kSrcD + 8];
     __attribute__((aligned(16))) uint32_t cand[kRunMax * 4];     // the candidates' (column, row) in the box
-    uint32_t acc[kRunMax * 4];                                    // lane-per-candidate form: where the row slices' partial sums (round 6: and the distinct candidates' values) meet
-    RunDup dup;
+    uint32_t acc[kRunMax * 4];                                    // lane-per-candidate form: where the row slices' partial sums meet
     int box[6];
 };
 
@@ -863,12 +808,7 @@ __device__ __forceinline__ void sad4_run_general(RunLds<S> &sh, const char *__re
         {
             const long sbyte = (long)so * S;
             if (srcScalar)
-            {
-                // (the source rows come through scalar loads: the LDS of the source block holds the table of distinct candidates)
-                static_assert(kSrcD >= 1024, "the duplicate table's 1 024 dwords live where the source block would be staged");
-                sad4_run_lanes<S, NW, true>(win, srcw, cand, s_acc, pitchD, lead, mndx, mndy, rowBytes, h, count, tid, o, reinterpret_cast<const uint32_t *>(src + sbyte), (int)(ssb >> 2),
-                                            kSadDedup ? &lds[kWinD + 4] : nullptr, &sh.dup);
-            }
+                sad4_run_lanes<S, NW, true>(win, srcw, cand, s_acc, pitchD, lead, mndx, mndy, rowBytes, h, count, tid, o, reinterpret_cast<const uint32_t *>(src + sbyte), (int)(ssb >> 2));
             else
                 sad4_run_lanes<S, NW, false>(win, srcw, cand, s_acc, pitchD, lead, mndx, mndy, rowBytes, h, count, tid, o, nullptr, 0);
         }
