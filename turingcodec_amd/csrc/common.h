@@ -250,6 +250,48 @@ __device__ __forceinline__ int satd_tile8_pk(uint32_t (&d)[8][4])
     return (int)((sum + 2) >> 2);
 }
 
+// The same for 9 / 10-bit samples (the contract of S = 2, include/havoc_mi355x.h): |difference| <= 1023, so the five stages between registers stay inside 16 bits
+// (1023 * 32 = 32 736) and only the sixth, inside a register, would leave them.  It is not made: |lo + hi| + |lo - hi| = 2 max(|lo|, |hi|) = |lo| + |hi| + ||lo| - |hi||,
+// so X = sum of (|lo| + |hi|) and Y = sum of 2 ||lo| - |hi|| (v_sad_u16 against zero / against the swapped halves) give the tile's sum of magnitudes as X + Y / 2.
+// 352 instructions per tile where the row-per-lane form (32-bit butterflies, satd_rows<2, 8>) issues 8 x ~110.  Returns ((sum + 2) >> 2) >> 2 (hadamard.cpp: the
+// 16-bit tables' extra >> 2).
+__device__ __forceinline__ int satd_tile8_pk16(uint32_t (&d)[8][4])
+{
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+    {
+        const uint32_t a0 = pk_add(d[r][0], d[r][1]), a1 = pk_sub(d[r][0], d[r][1]), a2 = pk_add(d[r][2], d[r][3]), a3 = pk_sub(d[r][2], d[r][3]);
+        d[r][0] = pk_add(a0, a2); d[r][2] = pk_sub(a0, a2);
+        d[r][1] = pk_add(a1, a3); d[r][3] = pk_sub(a1, a3);
+    }
+#pragma unroll
+    for (int len = 1; len < 8; len <<= 1)
+#pragma unroll
+        for (int i = 0; i < 8; i += len << 1)
+#pragma unroll
+            for (int r = i; r < i + len; ++r)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                {
+                    const uint32_t a = d[r][k], b = d[r + len][k];
+                    d[r][k] = pk_add(a, b);
+                    d[r + len][k] = pk_sub(a, b);
+                }
+    uint32_t X = 0, Y = 0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+        {
+            const s16x2 v = __builtin_bit_cast(s16x2, d[r][k]);
+            const uint32_t mag = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(v, (s16x2){0, 0} - v));      // (|lo|, |hi|)
+            X = __builtin_amdgcn_sad_u16(mag, 0u, X);
+            Y = __builtin_amdgcn_sad_u16(mag, __builtin_amdgcn_alignbit(mag, mag, 16), Y);
+        }
+    const uint32_t sum = X + (Y >> 1);
+    return (int)(((sum + 2) >> 2) >> 2);
+}
+
 // ---- intra prediction angles ----------------------------------------------------------------------------------
 
 // intraPredAngle (havoc/pred_intra.cpp angle table) without a memory look-up: |angle| depends on the distance from the

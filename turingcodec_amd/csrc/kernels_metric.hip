@@ -1071,7 +1071,7 @@ constexpr int kSatdMulti = 16;
 
 // CPS = candidates per lane group: a job's 16 candidates are split over 16 / CPS lane groups (more wavefronts in
 // flight; the source rows are then fetched 16 / CPS times instead of once)
-// TILE (round 6; 8-bit samples, blocks of >= four 8 x 8 tiles): a LANE takes a whole 8 x 8 tile instead of one of its rows (common.h: satd_tile8_pk), G = the tiles of
+// TILE (round 6; blocks of >= four 8 x 8 tiles): a LANE takes a whole 8 x 8 tile instead of one of its rows (common.h: satd_tile8_pk / satd_tile8_pk16), G = the tiles of
 // the class's largest block.  No cross-lane step but the final sum, 0.59 of the instructions.
 template <int S, int G, int CPS, bool TILE = false>
 __global__ __launch_bounds__(256) void k_satd_multi(const char *__restrict__ pa, long stride_a, const char *__restrict__ pb, long stride_b,
@@ -1093,7 +1093,37 @@ __global__ __launch_bounds__(256) void k_satd_multi(const char *__restrict__ pa,
     int acc[CPS];
 #pragma unroll
     for (int k = 0; k < CPS; ++k) acc[k] = 0;
-    if (TILE && S == 1 && ((w | h) & 7) == 0)
+    if (TILE && S == 2 && ((w | h) & 7) == 0)
+    {   // 9 / 10-bit samples: a row of eight is four dwords of pairs already
+        const int tw = w >> 3;
+        const FastDiv fd(tw);
+        for (int t = l; t < tw * (h >> 3); t += G)
+        {
+            const int ty = fd.div(t), tx = t - ty * tw;
+            const char *pa8 = a + (long)(ty * 8) * sab + tx * 16;
+            const long ob = (long)(ty * 8) * sbb + tx * 16;
+            uint32_t ap[8][4];
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+            {
+                const u32x4 va = ld16(pa8 + r * sab);
+                ap[r][0] = va.x; ap[r][1] = va.y; ap[r][2] = va.z; ap[r][3] = va.w;
+            }
+#pragma unroll
+            for (int k = 0; k < CPS; ++k)
+            {
+                uint32_t d[8][4];
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                {
+                    const u32x4 vb = ld16(b[k] + ob + r * sbb);
+                    d[r][0] = pk_sub(ap[r][0], vb.x); d[r][1] = pk_sub(ap[r][1], vb.y); d[r][2] = pk_sub(ap[r][2], vb.z); d[r][3] = pk_sub(ap[r][3], vb.w);
+                }
+                acc[k] += satd_tile8_pk16(d);
+            }
+        }
+    }
+    else if (TILE && S == 1 && ((w | h) & 7) == 0)
     {
         const int tw = w >> 3;
         const FastDiv fd(tw);
@@ -1356,17 +1386,18 @@ hipError_t launch_satd_multi(hipStream_t st, int S, int maxw, int maxh, const vo
     // measured on MI355X (184 k candidates of a 1080p frame): 2 candidates per lane group 63 us, 1: 69, 4: 70, 8: 83,
     // all 16: 181 -- wavefronts in flight matter more than fetching the source rows only once
     constexpr int CPS = 2;
-    // round 6: 8-bit classes whose largest block has at least four 8 x 8 tiles take a tile per lane (G = those tiles, a power of two); 4 candidates per lane group
+    // round 6: classes whose largest block has at least four 8 x 8 tiles take a tile per lane (G = those tiles, a power of two); 4 candidates per lane group
     // instead of 2 measured slower there too (group 0.076 -> 0.097 ms, step 0.642 -> 0.652: gpu call r06v)
     const int tiles = ((maxw + 7) / 8) * ((maxh + 7) / 8);
     static const bool tileOff = getenv("HAVOC_SATD_TILE") && atoi(getenv("HAVOC_SATD_TILE")) == 0;      // diagnostic A/B switch (profiles/)
-    if (S == 1 && tiles >= 4 && !tileOff)
+    if (tiles >= 4 && !tileOff)
     {
         const int GT = tiles <= 4 ? 4 : tiles <= 8 ? 8 : tiles <= 16 ? 16 : tiles <= 32 ? 32 : 64;
         const long groups = (long)n * (kSatdMulti / CPS);
         const dim3 g((unsigned)((groups + 256 / GT - 1) / (256 / GT))), b256(256);
-#define SATD_GO_T(GG) hipLaunchKernelGGL((k_satd_multi<1, GG, CPS, true>), g, b256, 0, st, x, sa, y, sb, j, n, out)
-        if (GT == 4) SATD_GO_T(4); else if (GT == 8) SATD_GO_T(8); else if (GT == 16) SATD_GO_T(16); else if (GT == 32) SATD_GO_T(32); else SATD_GO_T(64);
+#define SATD_GO_T(SS, GG) hipLaunchKernelGGL((k_satd_multi<SS, GG, CPS, true>), g, b256, 0, st, x, sa, y, sb, j, n, out)
+        if (S == 1) { if (GT == 4) SATD_GO_T(1, 4); else if (GT == 8) SATD_GO_T(1, 8); else if (GT == 16) SATD_GO_T(1, 16); else if (GT == 32) SATD_GO_T(1, 32); else SATD_GO_T(1, 64); }
+        else { if (GT == 4) SATD_GO_T(2, 4); else if (GT == 8) SATD_GO_T(2, 8); else if (GT == 16) SATD_GO_T(2, 16); else if (GT == 32) SATD_GO_T(2, 32); else SATD_GO_T(2, 64); }
 #undef SATD_GO_T
         return hipGetLastError();
     }
