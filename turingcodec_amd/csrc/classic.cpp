@@ -75,6 +75,7 @@ struct Binding
     struct DeqTab { int scale, shift; int16_t *tab; DeqTab *next; };
     std::atomic<DeqTab *> deq{nullptr};              // append-only list; built under mu, read without a lock
     int16_t *deqRampH = nullptr, *deqRampD = nullptr;   // the 65 536 levels in index order (pinned), the tables' common input
+    uint64_t generation = 0;                         // never reused in the process (a later binding may be allocated where this one was: per-thread caches compare this, not the address)
     Binding() { for (auto &c : stat) c = 0; for (auto &c : oneJob) c = 0; for (auto &c : waitsBy) c = 0; for (auto &c : launchesBy) c = 0; }
 };
 
@@ -1536,8 +1537,8 @@ const int16_t *dequantTable(int scale, int shift)
     Binding *b = g_live.load(std::memory_order_acquire);
     if (!b) return nullptr;
     static thread_local const Binding::DeqTab *last = nullptr;
-    static thread_local const Binding *lastOwner = nullptr;
-    if (lastOwner == b && last && last->scale == scale && last->shift == shift) return last->tab;
+    static thread_local uint64_t lastOwner = 0;
+    if (lastOwner == b->generation && last && last->scale == scale && last->shift == shift) return last->tab;
     auto find = [&]() -> const Binding::DeqTab * {
         for (const Binding::DeqTab *t = b->deq.load(std::memory_order_acquire); t; t = t->next)
             if (t->scale == scale && t->shift == shift) return t;
@@ -1573,7 +1574,7 @@ const int16_t *dequantTable(int scale, int shift)
         }
     }
     last = t;
-    lastOwner = b;
+    lastOwner = b->generation;
     return t->tab;
 }
 
@@ -1925,6 +1926,8 @@ havoc_code havoc_new_code(havoc_instruction_set mask, int size)
     if (!g_binding)
     {
         Binding *b = new Binding();
+        static uint64_t generations = 0;      // (under g_mu)
+        b->generation = ++generations;
         if (const char *e = getenv("HAVOC_MI355X_DEVICE")) b->device = atoi(e);
         const int rc = havoc_mi355x_create(&b->ctx, b->device, HAVOC_MI355X_NEW_STREAM);
         if (rc) die("havoc_new_code: havoc_mi355x_create", rc);
