@@ -1509,7 +1509,16 @@ hipError_t launch_rdoq(hipStream_t st, int bitDepth, int log2, int16_t *dst, con
     static const int tiny = envInt("HAVOC_RDOQ_TINY", 1024);
     if (njobs <= tiny)
     {
-        if (log2 == 4) hipLaunchKernelGGL((k_rdoq_walk<4, kInKernel, false>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work, 0);
+        // ... but for 32x32 blocks, whose walk is up to 64 groups one after the other (~11 us per group for a wavefront alone: 91 us per launch in an intra picture's
+        // levels, profiles/r06/intra_chain_kernel_stats.csv): here one launch's LATENCY is what the caller waits for and the machine is empty, which is what the
+        // diagonal walk is for -- scan + diagonal walk with 8 lanes per block, blocks in job order: an intra picture 0.323 -> 0.305 s (gpu call r06ad)
+        static const int tinyDiag = envInt("HAVOC_RDOQ_TINY_DIAG", 8);
+        if (log2 == 5 && (tinyDiag == 4 || tinyDiag == 8))
+        {
+            hipLaunchKernelGGL(k_rdoq_scan<5>, dim3((njobs + kScanSteps - 1) / kScanSteps), dim3(64), 0, st, dst, src, j, njobs, work, 0);
+            launchDiag<5>(st, tinyDiag, dst, src, states, j, njobs, cbf, bitDepth, work, 0);
+        }
+        else if (log2 == 4) hipLaunchKernelGGL((k_rdoq_walk<4, kInKernel, false>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work, 0);
         else hipLaunchKernelGGL((k_rdoq_walk<5, kInKernel, false>), dim3(wgs), dim3(64), 0, st, dst, src, states, j, njobs, cbf, bitDepth, work, 0);
         return hipGetLastError();
     }
