@@ -11,6 +11,8 @@
 // v_dot2c_i32_i16, padded LDS transpose between the passes.  Results are bit-identical to running the separate
 // kernels (tests: tu_fused groups).
 #include "common.h"
+
+#include <cstdlib>
 #include "transform_basis.h"
 #include "rdoq_work.h"
 
@@ -360,6 +362,162 @@ hipError_t launch_intra_measure(hipStream_t st, int S, int bd, int log2, int16_t
     return hipGetLastError();
 }
 
+
+// ---- The 32x32 forward DCT of 8-bit content on the MATRIX cores (round 6).  The transform is two matrix products with the constant basis M (|M| <= 90: int8):
+//   T = (M * R^T + 8) >> 4 (wrapped to int16),   C = (M * T^T + 1024) >> 11   -- exactly what k_tu_forward<1, 5> computes with 768 v_dot2 per lane.
+// v_mfma_i32_32x32x32_i8 (gfx950) multiplies a 32 x 32 int8 A by a 32 x 32 int8 B in ONE instruction: lane l holds row / column (l & 31) and the 16 K values
+// 16 (l >> 5) .. + 15; D[row][col] lands in register reg of lane l with col = l & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (l >> 5).  The second operand is 16 bits
+// wide (9 in the first pass), so it goes in as TWO byte planes -- v = 256 vh + (vl' + 128) with vh = v >> 8 (the high byte as it stands) and vl' = the low byte with
+// its top bit flipped -- and M v = 256 (M vh) + M vl' + 128 rowsum(M): two MFMAs per pass, the constant in the accumulator's initial value, everything exact in int32.
+// A wavefront per block (lane = row y, half of its 32 samples): ~350 vector instructions per block where the dot2 form issues ~940 (the step is bound by
+// instruction issue).  SCAN as in k_tu_forward.
+typedef int i32x16v __attribute__((ext_vector_type(16)));
+typedef int i32x4v __attribute__((ext_vector_type(4)));
+
+struct Dct32I8 { int8_t m[32][32]; int32_t rowsum128[32]; };
+constexpr Dct32I8 make_dct32_i8()
+{
+    Dct32I8 t{};
+    for (int k = 0; k < 32; ++k)
+    {
+        int sum = 0;
+        for (int c = 0; c < 32; ++c)
+        {
+            t.m[k][c] = (int8_t)basis(32, 0, k, c);
+            sum += basis(32, 0, k, c);
+        }
+        t.rowsum128[k] = 128 * sum;
+    }
+    return t;
+}
+static __constant__ Dct32I8 c_dct32_i8 = make_dct32_i8();
+
+// acc[reg] = sum_j M[row(reg)][j] * v[j][col] + add for the 32 x 32 int16 operand whose column (lane & 31), K values 16 (lane >> 5) .. + 15 this lane holds as eight packed pairs
+__device__ __forceinline__ void mfma_dct32(const i32x4v a, const uint32_t (&v)[8], int add, int half, int (&out)[16])
+{
+    i32x4v bh, bl;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+    {
+        bh[q] = (int)__builtin_amdgcn_perm(v[2 * q + 1], v[2 * q], 0x07050301u);                    // the high bytes of four values
+        bl[q] = (int)(__builtin_amdgcn_perm(v[2 * q + 1], v[2 * q], 0x06040200u) ^ 0x80808080u);    // the low bytes - 128
+    }
+    i32x16v ch, cl;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg)
+    {
+        ch[reg] = 0;
+        cl[reg] = add + c_dct32_i8.rowsum128[(reg & 3) + 8 * (reg >> 2) + 4 * half];
+    }
+    ch = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bh, ch, 0, 0, 0);
+    cl = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bl, cl, 0, 0, 0);
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) out[reg] = (int)(((uint32_t)ch[reg] << 8) + (uint32_t)cl[reg]);
+}
+
+template <bool SCAN>
+__global__ __launch_bounds__(64) void k_tu_forward_mfma32(int16_t *__restrict__ coeffs, const char *__restrict__ src, long stride_src, const char *__restrict__ pred,
+                                                          long stride_pred, const int32_t *__restrict__ jobs, int njobs, const RdoqJob *__restrict__ rjobs = nullptr,
+                                                          int16_t *__restrict__ levels = nullptr, RdoqWork *__restrict__ work = nullptr)
+{
+    constexpr int LS = 40;      // int16 per row of the transposed intermediate: 80 bytes, so that a lane's 32 bytes are 16-byte aligned
+    __shared__ __attribute__((aligned(16))) int16_t lds[32 * LS];
+    const int job = xcd_block(blockIdx.x, gridDim.x);
+    if (job >= njobs) return;      // (uniform: a wavefront is a block)
+    const int32_t *j = jobs + (long)job * 4;
+    const int lane = threadIdx.x, y = lane & 31, half = lane >> 5;
+    // the basis rows this lane feeds as A: row y, K = 16 half .. + 15
+    const i32x4v a = *reinterpret_cast<const i32x4v *>(&c_dct32_i8.m[y][16 * half]);
+    // residual of row y, samples 16 half .. + 15, as packed pairs
+    uint32_t r[8];
+    {
+        const u32x4 s4 = ld16(src + (long)j[1] + (long)y * stride_src + 16 * half), p4 = ld16(pred + (long)j[2] + (long)y * stride_pred + 16 * half);
+        const uint32_t sw[4] = {s4.x, s4.y, s4.z, s4.w}, pw[4] = {p4.x, p4.y, p4.z, p4.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+        {
+            r[2 * q] = pk_sub(__builtin_amdgcn_perm(0u, sw[q], 0x0c010c00u), __builtin_amdgcn_perm(0u, pw[q], 0x0c010c00u));
+            r[2 * q + 1] = pk_sub(__builtin_amdgcn_perm(0u, sw[q], 0x0c030c02u), __builtin_amdgcn_perm(0u, pw[q], 0x0c030c02u));
+        }
+    }
+    int t[16];
+    mfma_dct32(a, r, 8, half, t);      // T[k][y], k = (reg & 3) + 8 (reg >> 2) + 4 half
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) lds[((reg & 3) + 8 * (reg >> 2) + 4 * half) * LS + y] = (int16_t)(t[reg] >> 4);
+    __syncthreads();
+    // second pass: this lane's column r' = y of T^T is row y of T: K = 16 half .. + 15
+    uint32_t v[8];
+    {
+        const u32x4 q0 = *reinterpret_cast<const u32x4 *>(&lds[y * LS + 16 * half]), q1 = *reinterpret_cast<const u32x4 *>(&lds[y * LS + 16 * half + 8]);
+        v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w; v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
+    }
+    int o[16];
+    mfma_dct32(a, v, 1024, half, o);   // C[k][y] << 11
+    int16_t *c = coeffs + j[0] + y;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) c[((reg & 3) + 8 * (reg >> 2) + 4 * half) * 32] = (int16_t)(o[reg] >> 11);
+    if (SCAN)
+    {
+        // the lane holds column y, rows 4 gy .. 4 gy + 3 of group row gy = 2 q + half in registers 4 q .. 4 q + 3: a group's largest magnitude is the maximum over those
+        // four and over the four lanes of the quad
+        const RdoqJob rj = rjobs[job];
+        uint32_t thr[3];
+        rdoqThresholds(rj.quant_scale, rj.quant_shift, thr);
+        uint32_t lo = 0, hi = 0;
+        uint64_t mask[3] = {0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+        {
+            uint32_t big = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+            {
+                const int cf = (int16_t)(o[4 * q + k] >> 11);
+                big = max(big, (uint32_t)abs(cf));
+                const uint32_t sq = (uint32_t)(cf * cf);
+                lo += sq & 0xffffu;
+                hi += sq >> 16;
+            }
+            big = max(big, (uint32_t)__shfl_xor((int)big, 1, kWave));
+            big = max(big, (uint32_t)__shfl_xor((int)big, 2, kWave));
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+            {
+                const uint64_t b = __ballot((y & 3) == 0 && big >= thr[m]);      // bit 4 gx + 32 half: group (gx, 2 q + half)
+                uint32_t f0 = 0, f1 = 0;
+#pragma unroll
+                for (int gx = 0; gx < 8; ++gx)
+                {
+                    f0 |= (uint32_t)((b >> (4 * gx)) & 1) << gx;
+                    f1 |= (uint32_t)((b >> (32 + 4 * gx)) & 1) << gx;
+                }
+                mask[m] |= (uint64_t)f0 << (16 * q) | (uint64_t)f1 << (16 * q + 8);
+            }
+        }
+        const int slo = wave_sum((int)lo), shi = wave_sum((int)hi);
+        // the level block, zeroed (RDOQ writes only the levels it keeps): 2 048 bytes, 32 per lane
+        int16_t *z = levels + rj.dst_off + lane * 16;
+        st8(z, u32x2{0, 0}); st8(z + 4, u32x2{0, 0}); st8(z + 8, u32x2{0, 0}); st8(z + 12, u32x2{0, 0});
+        if (lane == 0)
+        {
+            RdoqInfo *info = reinterpret_cast<RdoqInfo *>(reinterpret_cast<char *>(work) + rdoqInfoOffset());
+            RdoqInfo w;
+            w.mask = mask[0];
+            w.mask2 = mask[1];
+            w.mask3 = mask[2];
+            w.sumSq = ((int64_t)shi << 16) + slo;
+            info[job] = w;
+        }
+    }
+}
+
+// diagnostic A/B switch (profiles/): HAVOC_TU_MFMA=0 keeps the 32x32 forward transform of 8-bit content on the vector units
+static bool mfmaForward()
+{
+    static const bool on = !(getenv("HAVOC_TU_MFMA") && atoi(getenv("HAVOC_TU_MFMA")) == 0);
+    return on;
+}
+
 template <int S, int LOG2, int TR>
 static void go_fwd(hipStream_t st, int16_t *co, const char *src, long ss, const char *pred, long sp, const int32_t *j, int n, int bd)
 {
@@ -382,7 +540,10 @@ static hipError_t launch_fwd_s(hipStream_t st, int bd, int log2, int tr, int16_t
         case 2: go_fwd<S, 2, 0>(st, co, src, ss, pred, sp, j, n, bd); break;
         case 3: go_fwd<S, 3, 0>(st, co, src, ss, pred, sp, j, n, bd); break;
         case 4: go_fwd<S, 4, 0>(st, co, src, ss, pred, sp, j, n, bd); break;
-        case 5: go_fwd<S, 5, 0>(st, co, src, ss, pred, sp, j, n, bd); break;
+        case 5:
+            if (S == 1 && bd == 8 && mfmaForward()) hipLaunchKernelGGL((k_tu_forward_mfma32<false>), dim3(n), dim3(64), 0, st, co, src, ss, pred, sp, j, n);
+            else go_fwd<S, 5, 0>(st, co, src, ss, pred, sp, j, n, bd);
+            break;
         default: return hipErrorInvalidValue;
         }
     return hipGetLastError();
@@ -401,6 +562,7 @@ hipError_t launch_tu_forward_scan(hipStream_t st, int S, int bd, int log2, int16
     const int tpw = 64 >> log2;
     const dim3 g((n + tpw - 1) / tpw), b(64);
     if (S == 1 && log2 == 4) hipLaunchKernelGGL((k_tu_forward<1, 4, 0, true>), g, b, 0, st, coeffs, s8, ss, p8, sp, j, n, bd, rj, levels, w);
+    else if (S == 1 && bd == 8 && mfmaForward()) hipLaunchKernelGGL((k_tu_forward_mfma32<true>), dim3(n), b, 0, st, coeffs, s8, ss, p8, sp, j, n, rj, levels, w);
     else if (S == 1) hipLaunchKernelGGL((k_tu_forward<1, 5, 0, true>), g, b, 0, st, coeffs, s8, ss, p8, sp, j, n, bd, rj, levels, w);
     else if (log2 == 4) hipLaunchKernelGGL((k_tu_forward<2, 4, 0, true>), g, b, 0, st, coeffs, s8, ss, p8, sp, j, n, bd, rj, levels, w);
     else hipLaunchKernelGGL((k_tu_forward<2, 5, 0, true>), g, b, 0, st, coeffs, s8, ss, p8, sp, j, n, bd, rj, levels, w);
