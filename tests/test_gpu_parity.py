@@ -103,3 +103,14 @@ def test_pad_block_matches_oracle(hv, oracle, S):
             oracle.pad_block(exp, off, w, h, stride, pad, t, b, l, r)
             got = hv.pad_block(base, off, w, h, stride, pad, t, b, l, r)
             assert np.array_equal(got, exp), (w, h, pad, flags)
+
+
+def test_both_forms_of_the_32x32_forward_transform_match_the_golden_vectors():
+    """round 6: the 32x32 forward DCT of 8-bit content runs on the matrix cores (k_tu_forward_mfma32) by default; HAVOC_TU_MFMA=0 keeps it on the vector units
+    (k_tu_forward<1, 5>).  The switch is read once per process: the golden groups that hold 32x32 transforms again in an interpreter of their own with the switch off."""
+    import os
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-p", "no:cacheprovider", "-k", "test_matches_golden and (tuf or fwd8 or fwd10)"],
+                         capture_output=True, text=True, timeout=900, env=dict(os.environ, HAVOC_TU_MFMA="0"), cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0 and " passed" in out.stdout and "failed" not in out.stdout, out.stdout[-1500:] + out.stderr[-500:]
